@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X lsp-dsp-units hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload biquad]
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+  biquad    : BASELINE.json configs[1] -- 1024 channels x 4096-sample block through an 8-stage biquad
+              cascade (FilterBank::process), state carried from block to block.  (default)
+With N > 1 (launched by torch.distributed.run, one process per GPU) the channels are sharded: every rank
+owns its own 1024 channels (weak scaling, no data-path collective: channels are independent).
+
+Prints ONE JSON line on rank 0.  `value` is whole-job Msamples/s over the timed region (barrier +
+synchronize on both sides, max over ranks); `roofline` is priced from the kernel's average launch
+duration measured with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a scalar C port
+of the reference algorithm, OpenMP over channels) timed on this host on a bounded sample.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="biquad", choices=["biquad"])
+    ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
+    ap.add_argument("--samples", type=int, default=4096, help="samples per block")
+    ap.add_argument("--ring", type=int, default=16, help="distinct resident blocks cycled through "
+                    "(16 x 32 MiB in+out > the 256 MiB Infinity Cache, so steps stream from HBM)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline_biquad(coef, samples, budget_s=3.0):
+    """CPU oracle ("port" of the reference algorithm) on this host's cores: repeat 1024ch x 4096 blocks
+    until ~budget_s of wall time (x cores of CPU work) has been spent."""
+    import numpy as np
+    import oracle
+    import workloads as wl
+    C = coef.shape[0]
+    x = wl.c2_input(C, samples, blocks=2, seed=12)
+    state = np.zeros((C, coef.shape[1], 2), np.float32)
+    nsec = np.full(C, coef.shape[1], np.uint32)
+    oracle.biquad_bank(x[0], coef, nsec, state)          # warm up threads / pages
+    t0 = time.perf_counter()
+    blocks = 0
+    while time.perf_counter() - t0 < budget_s:
+        oracle.biquad_bank(x[blocks & 1], coef, nsec, state)
+        blocks += 1
+    dt = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return {
+        "value": round(blocks * C * samples / dt / 1e6, 2),
+        "unit": "Msamples/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "%d blocks of %d ch x %d samples, 8-section cascade, scalar C oracle with OpenMP over channels "
+                  "(reference SIMD library lsp-dsp-lib is not available offline)" % (blocks, C, samples),
+    }
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch                                   # torch first: one HIP runtime per process
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group(backend="nccl" if torch.cuda.is_available() else "gloo")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    mi = importlib.import_module("lsp-dsp-units_amd")
+    mi.check(mi.lib.mi_dspu_set_device(local_rank))
+    import workloads as wl
+
+    C, n, ring = args.channels, args.samples, args.ring
+    # per-rank channel shard: rank r owns global channels [r*C, (r+1)*C)
+    coef_all, _ = wl.c2_coefficients(C * world)
+    coef = coef_all[rank * C:(rank + 1) * C]
+    bank = mi.BiquadBank(C, coef.shape[1])
+    bank.set_all_chains(coef)
+
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(2 + rank)
+    xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    yout = torch.empty_like(xin)
+    stream = torch.cuda.current_stream()
+    bank.commit(stream)
+
+    def step(i):
+        k = i % ring
+        bank.process(yout[k], xin[k], n, stream=stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        starts[i].record(stream)
+        step(args.warmup + i)
+        stops[i].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
+    med_kernel_ms = kernel_ms[len(kernel_ms) // 2]
+
+    # sanity: the output of the last step is finite and non-trivial
+    chk = yout[(args.warmup + args.steps - 1) % ring]
+    assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
+
+    if rank == 0:
+        samples_per_step = C * n * world
+        alg_bytes = 8.0 * C * n                     # 4 B in + 4 B out per channel-sample
+        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_biquad_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "Msamples/sec per GPU (biquad-x8 1024ch; Convolver 65536-tap) + HBM roofline %",
+            "value": round(samples_per_step * args.steps / elapsed / 1e6, 1),
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "biquad-x8 cascade (FilterBank::process), %d channels x %d-sample blocks per GPU, "
+                            "FLT_BT_LRX_LOPASS slope 4 per-channel cutoffs, state carried across blocks" % (C, n),
+                "channels_per_gpu": C, "block": n, "sections": int(coef.shape[1]),
+                "resident_ring_blocks": ring, "parallelism": "channel-shard x%d, no collective" % world,
+            },
+            "per_gpu_msamples_s": round(C * n * args.steps / elapsed / 1e6, 1),
+            "roofline": {
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "kernel": "biquad_bank_kernel<32,128>", "kernel_avg_us": round(avg_kernel_ms * 1e3, 3),
+                "kernel_median_us": round(med_kernel_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes,
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline_biquad(coef, n)
+        print(json.dumps(line), flush=True)
+
+    bank.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,145 @@
+/*
+ * mi_dspu.h -- C-ABI of the MI355X (gfx950) implementation of the lsp-dsp-units
+ * block-streaming hot path.
+ *
+ * This is the drop-in boundary: plain C, plain pointers and sizes, no C++ or
+ * torch types.  Every entry point names the reference interface it replaces
+ * (paths relative to the reference tree, lsp-plugins/lsp-dsp-units 1.0.36).
+ *
+ * Conventions
+ *   - every function returns MI_OK (0) or a negative MI_E* code;
+ *     mi_dspu_last_error() returns a thread-local human-readable message;
+ *   - sample buffers are DEVICE pointers to float32, laid out
+ *     [channel][stride] (one reference object == one channel == one row);
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); no
+ *     entry point synchronises the stream unless its name says so;
+ *   - objects are opaque handles created/destroyed by the library; they are
+ *     not thread-safe (same contract as the reference objects).
+ *   - there is NO CPU fallback: without a usable HIP device every compute
+ *     entry point fails with MI_ENODEV.
+ */
+#ifndef MI_DSPU_H_
+#define MI_DSPU_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_DSPU_ABI_VERSION     1
+
+enum
+{
+    MI_OK            =  0,
+    MI_EINVAL        = -1,   /* bad argument (reference: silently clamped or `false`)   */
+    MI_ENOMEM        = -2,   /* allocation failure (reference: init() returns false)     */
+    MI_ENODEV        = -3,   /* no HIP device / kernel image not loadable                 */
+    MI_EHIP          = -4,   /* a HIP runtime call failed; see mi_dspu_last_error()       */
+    MI_ESTATE        = -5    /* object not initialised (reference: STATUS_BAD_STATE)      */
+};
+
+/* ---- library / device plumbing ------------------------------------------------------- */
+
+int         mi_dspu_abi_version(void);
+const char *mi_dspu_last_error(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int         mi_dspu_device_count(void);
+/* Select the device used by the calling thread (hipSetDevice). */
+int         mi_dspu_set_device(int device);
+
+int         mi_dspu_malloc(void **dev_ptr, size_t bytes);
+int         mi_dspu_free(void *dev_ptr);
+int         mi_dspu_memset(void *dev_ptr, int value, size_t bytes, void *stream);
+int         mi_dspu_copy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int         mi_dspu_copy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int         mi_dspu_copy_d2d(void *dev_dst, const void *dev_src, size_t bytes, void *stream);
+int         mi_dspu_stream_create(void **stream);
+int         mi_dspu_stream_destroy(void *stream);
+int         mi_dspu_stream_synchronize(void *stream);
+
+/* Timing helper used by bench.py: runs `fn`-less event pairs on `stream`. */
+int         mi_dspu_event_create(void **event);
+int         mi_dspu_event_destroy(void *event);
+int         mi_dspu_event_record(void *event, void *stream);
+int         mi_dspu_event_synchronize(void *event);
+int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
+
+/* ---- biquad cascade bank -------------------------------------------------------------- */
+/*
+ * One digital section, same field order/size as dsp::biquad_x1_t used by
+ * FilterBank::add_chain() (include/lsp-plug.in/dsp-units/filters/FilterBank.h:86,
+ * fields as written in src/main/filters/Filter.cpp:2254-2265):
+ *      y[n] = b0 x[n] + b1 x[n-1] + b2 x[n-2] + a1 y[n-1] + a2 y[n-2]
+ * (denominator signs pre-negated).  p0..p2 are padding.
+ */
+typedef struct mi_biquad_x1
+{
+    float b0, b1, b2;
+    float a1, a2;
+    float p0, p1, p2;
+} mi_biquad_x1_t;
+
+/*
+ * mi_biquad_bank: `channels` independent lsp::dspu::FilterBank objects
+ * (filters/FilterBank.h:34-139), each holding up to `max_sections` biquads that
+ * run strictly in series (src/main/filters/FilterBank.cpp:256-291).
+ */
+typedef struct mi_biquad_bank mi_biquad_bank_t;
+
+/* FilterBank::init(filters), FilterBank.cpp:62-92, for every channel. */
+int mi_biquad_bank_create(mi_biquad_bank_t **bank, uint32_t channels, uint32_t max_sections);
+/* FilterBank::destroy(), FilterBank.cpp:51-60. */
+int mi_biquad_bank_destroy(mi_biquad_bank_t *bank);
+/*
+ * FilterBank::begin() + add_chain() x count + end(clear) for one channel
+ * (FilterBank.h:78-82, FilterBank.cpp:94-99,106-236).  As in the reference the
+ * delay memory of the channel is cleared when `clear` is non-zero or when the
+ * number of sections changed (FilterBank.cpp:233-235).  count > max_sections
+ * is clamped the way add_chain() clamps (the last slot keeps the last chain).
+ * Host-side only; the device tables are refreshed by the next process()/commit().
+ */
+int mi_biquad_bank_set_chains(mi_biquad_bank_t *bank, uint32_t channel,
+                              const mi_biquad_x1_t *chains, uint32_t count, int clear);
+/* Same for all channels at once: chains is [channels][count]. */
+int mi_biquad_bank_set_all_chains(mi_biquad_bank_t *bank, const mi_biquad_x1_t *chains,
+                                  uint32_t count, int clear);
+/* FilterBank::size() of one channel. */
+int mi_biquad_bank_size(const mi_biquad_bank_t *bank, uint32_t channel, uint32_t *count);
+/* Push pending coefficient tables / state clears to the device (async on stream). */
+int mi_biquad_bank_commit(mi_biquad_bank_t *bank, void *stream);
+/* FilterBank::reset(), FilterBank.cpp:238-254; channel = UINT32_MAX for all. */
+int mi_biquad_bank_reset(mi_biquad_bank_t *bank, uint32_t channel, void *stream);
+/*
+ * FilterBank::process(out, in, samples) for every channel, FilterBank.cpp:256-291.
+ * out/in: device float32 [channels][*_stride]; out may be the same buffer as in
+ * (exact alias only, as in the reference).  A channel with 0 sections copies.
+ */
+int mi_biquad_bank_process(mi_biquad_bank_t *bank, float *out, const float *in,
+                           size_t samples, size_t out_stride, size_t in_stride, void *stream);
+/*
+ * FilterBank::impulse_response(out, samples), FilterBank.cpp:293-330: delay
+ * memory is saved, zeroed, a unit impulse is run and the memory restored.
+ */
+int mi_biquad_bank_impulse_response(mi_biquad_bank_t *bank, float *out, size_t samples,
+                                    size_t out_stride, void *stream);
+/* Delay memory access (biquad_t::d[], FilterBank.cpp:248-252): host arrays of
+ * [channels][max_sections][2] floats {d0,d1}.  Synchronise the stream. */
+int mi_biquad_bank_get_state(mi_biquad_bank_t *bank, float *host_state, void *stream);
+int mi_biquad_bank_set_state(mi_biquad_bank_t *bank, const float *host_state, void *stream);
+
+/*
+ * Host-only introspection of the per-section device table (no GPU needed): the
+ * chunk-parallel form of the TDF-II section used by the kernel.
+ * variant 0 = 32-sample chunks x 128 lanes, 1 = 8-sample chunks x 64 lanes.
+ * geometry[4] receives {chunk, lanes, scan_levels, floats_per_row}; table (may be
+ * NULL) receives one row: {b0 b1 b2 a1 a2 0 0 0 | P^(2^j) j<levels | p[chunk] | q[chunk]}.
+ */
+int mi_biquad_section_tables(const mi_biquad_x1_t *chain, int variant, float *table, uint32_t *geometry);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* MI_DSPU_H_ */

@@ -1,0 +1,71 @@
+"""ctypes declarations for include/mi_dspu.h (one line per exported symbol)."""
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi_dspu.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        "libmi_dspu.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+        "or `make -C lsp-dsp-units_amd`. There is no CPU fallback." % LIB_PATH)
+
+lib = ctypes.CDLL(LIB_PATH)
+
+
+class MiError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("mi_dspu error %d: %s" % (code, message))
+        self.code = code
+
+
+class BiquadX1(ctypes.Structure):
+    """mi_biquad_x1_t == dsp::biquad_x1_t layout."""
+    _fields_ = [(n, c_float) for n in ("b0", "b1", "b2", "a1", "a2", "p0", "p1", "p2")]
+
+
+# name -> (restype, argtypes); every symbol declared in include/mi_dspu.h must be listed here
+# (tests/test_abi.py parses the header and checks both directions).
+PROTOTYPES = {
+    "mi_dspu_abi_version": (c_int, []),
+    "mi_dspu_last_error": (c_char_p, []),
+    "mi_dspu_device_count": (c_int, []),
+    "mi_dspu_set_device": (c_int, [c_int]),
+    "mi_dspu_malloc": (c_int, [POINTER(c_void_p), c_size_t]),
+    "mi_dspu_free": (c_int, [c_void_p]),
+    "mi_dspu_memset": (c_int, [c_void_p, c_int, c_size_t, c_void_p]),
+    "mi_dspu_copy_h2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi_dspu_copy_d2h": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi_dspu_copy_d2d": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi_dspu_stream_create": (c_int, [POINTER(c_void_p)]),
+    "mi_dspu_stream_destroy": (c_int, [c_void_p]),
+    "mi_dspu_stream_synchronize": (c_int, [c_void_p]),
+    "mi_dspu_event_create": (c_int, [POINTER(c_void_p)]),
+    "mi_dspu_event_destroy": (c_int, [c_void_p]),
+    "mi_dspu_event_record": (c_int, [c_void_p, c_void_p]),
+    "mi_dspu_event_synchronize": (c_int, [c_void_p]),
+    "mi_dspu_event_elapsed_ms": (c_int, [POINTER(c_float), c_void_p, c_void_p]),
+    "mi_biquad_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
+    "mi_biquad_bank_destroy": (c_int, [c_void_p]),
+    "mi_biquad_bank_set_chains": (c_int, [c_void_p, c_uint32, POINTER(BiquadX1), c_uint32, c_int]),
+    "mi_biquad_bank_set_all_chains": (c_int, [c_void_p, POINTER(BiquadX1), c_uint32, c_int]),
+    "mi_biquad_bank_size": (c_int, [c_void_p, c_uint32, POINTER(c_uint32)]),
+    "mi_biquad_bank_commit": (c_int, [c_void_p, c_void_p]),
+    "mi_biquad_bank_reset": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "mi_biquad_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_biquad_bank_impulse_response": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "mi_biquad_bank_get_state": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi_biquad_bank_set_state": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi_biquad_section_tables": (c_int, [POINTER(BiquadX1), c_int, POINTER(c_float), POINTER(c_uint32)]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)          # AttributeError here == symbol missing from the .so
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def check(code):
+    if code != 0:
+        raise MiError(code, (lib.mi_dspu_last_error() or b"").decode("utf-8", "replace"))
+    return code

@@ -1,0 +1,150 @@
+// Device/stream/memory plumbing of the C-ABI (include/mi_dspu.h).
+#include "mi_common.h"
+
+namespace mi
+{
+    char *error_buffer()
+    {
+        static thread_local char buf[512] = "";
+        return buf;
+    }
+
+    int fail(int code, const char *fmt, ...)
+    {
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(error_buffer(), 512, fmt, ap);
+        va_end(ap);
+        return code;
+    }
+} // namespace mi
+
+extern "C" {
+
+int mi_dspu_abi_version(void) { return MI_DSPU_ABI_VERSION; }
+
+const char *mi_dspu_last_error(void) { return mi::error_buffer(); }
+
+int mi_dspu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int mi_dspu_set_device(int device)
+{
+    MI_HIP_CHECK(hipSetDevice(device));
+    return MI_OK;
+}
+
+int mi_dspu_malloc(void **dev_ptr, size_t bytes)
+{
+    MI_REQUIRE(dev_ptr != nullptr, MI_EINVAL, "mi_dspu_malloc: NULL result pointer");
+    *dev_ptr = nullptr;
+    if (bytes == 0)
+        return MI_OK;
+    hipError_t e = hipMalloc(dev_ptr, bytes);
+    if (e == hipErrorOutOfMemory)
+        return mi::fail(MI_ENOMEM, "hipMalloc(%zu) out of memory", bytes);
+    MI_HIP_CHECK(e);
+    return MI_OK;
+}
+
+int mi_dspu_free(void *dev_ptr)
+{
+    if (dev_ptr != nullptr)
+        MI_HIP_CHECK(hipFree(dev_ptr));
+    return MI_OK;
+}
+
+int mi_dspu_memset(void *dev_ptr, int value, size_t bytes, void *stream)
+{
+    if (bytes > 0)
+        MI_HIP_CHECK(hipMemsetAsync(dev_ptr, value, bytes, mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_copy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream)
+{
+    if (bytes > 0)
+        MI_HIP_CHECK(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_copy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream)
+{
+    if (bytes > 0)
+        MI_HIP_CHECK(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_copy_d2d(void *dev_dst, const void *dev_src, size_t bytes, void *stream)
+{
+    if (bytes > 0)
+        MI_HIP_CHECK(hipMemcpyAsync(dev_dst, dev_src, bytes, hipMemcpyDeviceToDevice, mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_stream_create(void **stream)
+{
+    MI_REQUIRE(stream != nullptr, MI_EINVAL, "mi_dspu_stream_create: NULL result pointer");
+    hipStream_t s;
+    MI_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = s;
+    return MI_OK;
+}
+
+int mi_dspu_stream_destroy(void *stream)
+{
+    if (stream != nullptr)
+        MI_HIP_CHECK(hipStreamDestroy(mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_stream_synchronize(void *stream)
+{
+    MI_HIP_CHECK(hipStreamSynchronize(mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_event_create(void **event)
+{
+    MI_REQUIRE(event != nullptr, MI_EINVAL, "mi_dspu_event_create: NULL result pointer");
+    hipEvent_t e;
+    MI_HIP_CHECK(hipEventCreate(&e));
+    *event = e;
+    return MI_OK;
+}
+
+int mi_dspu_event_destroy(void *event)
+{
+    if (event != nullptr)
+        MI_HIP_CHECK(hipEventDestroy(reinterpret_cast<hipEvent_t>(event)));
+    return MI_OK;
+}
+
+int mi_dspu_event_record(void *event, void *stream)
+{
+    MI_HIP_CHECK(hipEventRecord(reinterpret_cast<hipEvent_t>(event), mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_event_synchronize(void *event)
+{
+    MI_HIP_CHECK(hipEventSynchronize(reinterpret_cast<hipEvent_t>(event)));
+    return MI_OK;
+}
+
+int mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop)
+{
+    MI_REQUIRE(ms != nullptr, MI_EINVAL, "mi_dspu_event_elapsed_ms: NULL result pointer");
+    MI_HIP_CHECK(hipEventElapsedTime(ms, reinterpret_cast<hipEvent_t>(start), reinterpret_cast<hipEvent_t>(stop)));
+    return MI_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,143 @@
+"""Small object wrappers over the C-ABI handles (no arithmetic here)."""
+import ctypes
+from ctypes import byref, c_float, c_uint32, c_void_p
+
+import numpy as np
+
+from .capi import BiquadX1, check, lib
+
+
+def device_count():
+    return int(lib.mi_dspu_device_count())
+
+
+def _ptr(x):
+    """Device address of a DeviceBuffer, a torch tensor or a raw int."""
+    if isinstance(x, DeviceBuffer):
+        return c_void_p(x.ptr)
+    if hasattr(x, "data_ptr"):
+        return c_void_p(x.data_ptr())
+    return c_void_p(int(x))
+
+
+def _stream(s):
+    if s is None:
+        return c_void_p(0)
+    if hasattr(s, "cuda_stream"):
+        return c_void_p(s.cuda_stream)
+    return c_void_p(int(s))
+
+
+class DeviceBuffer:
+    """float32 device array owned by the library allocator (mi_dspu_malloc)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in (shape if hasattr(shape, "__len__") else (shape,)))
+        self.size = int(np.prod(self.shape)) if self.shape else 1
+        p = c_void_p()
+        check(lib.mi_dspu_malloc(byref(p), self.size * 4))
+        self.ptr = p.value or 0
+
+    @classmethod
+    def from_host(cls, array, stream=None):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        buf = cls(a.shape)
+        buf.upload(a, stream)
+        return buf
+
+    def upload(self, array, stream=None):
+        a = np.ascontiguousarray(array, dtype=np.float32)
+        assert a.size == self.size
+        check(lib.mi_dspu_copy_h2d(c_void_p(self.ptr), a.ctypes.data_as(c_void_p), a.nbytes, _stream(stream)))
+        check(lib.mi_dspu_stream_synchronize(_stream(stream)))
+
+    def download(self, stream=None):
+        out = np.empty(self.shape, dtype=np.float32)
+        check(lib.mi_dspu_copy_d2h(out.ctypes.data_as(c_void_p), c_void_p(self.ptr), out.nbytes, _stream(stream)))
+        check(lib.mi_dspu_stream_synchronize(_stream(stream)))
+        return out
+
+    def zero(self, stream=None):
+        check(lib.mi_dspu_memset(c_void_p(self.ptr), 0, self.size * 4, _stream(stream)))
+
+    def free(self):
+        if self.ptr:
+            lib.mi_dspu_free(c_void_p(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _chains(coefs):
+    """(n,5) float32 {b0,b1,b2,a1,a2} rows -> ctypes array of mi_biquad_x1_t."""
+    c = np.ascontiguousarray(coefs, dtype=np.float32).reshape(-1, 5)
+    full = np.zeros((c.shape[0], 8), dtype=np.float32)
+    full[:, :5] = c
+    arr = (BiquadX1 * max(1, c.shape[0])).from_buffer_copy(full.tobytes() if c.shape[0] else bytes(32))
+    return arr, c.shape[0]
+
+
+class BiquadBank:
+    """`channels` x lsp::dspu::FilterBank on the device (mi_biquad_bank_*)."""
+
+    def __init__(self, channels, max_sections):
+        h = c_void_p()
+        check(lib.mi_biquad_bank_create(byref(h), channels, max_sections))
+        self.handle = h
+        self.channels = channels
+        self.max_sections = max(1, max_sections)
+
+    def set_chains(self, channel, coefs, clear=False):
+        arr, n = _chains(coefs)
+        check(lib.mi_biquad_bank_set_chains(self.handle, channel, arr, n, int(clear)))
+
+    def set_all_chains(self, coefs, clear=False):
+        c = np.ascontiguousarray(coefs, dtype=np.float32)
+        assert c.ndim == 3 and c.shape[0] == self.channels and c.shape[2] == 5
+        arr, _ = _chains(c.reshape(-1, 5))
+        check(lib.mi_biquad_bank_set_all_chains(self.handle, arr, c.shape[1], int(clear)))
+
+    def size(self, channel):
+        n = c_uint32()
+        check(lib.mi_biquad_bank_size(self.handle, channel, byref(n)))
+        return n.value
+
+    def commit(self, stream=None):
+        check(lib.mi_biquad_bank_commit(self.handle, _stream(stream)))
+
+    def reset(self, channel=None, stream=None):
+        check(lib.mi_biquad_bank_reset(self.handle, 0xFFFFFFFF if channel is None else channel, _stream(stream)))
+
+    def process(self, out, inp, samples, out_stride=None, in_stride=None, stream=None):
+        check(lib.mi_biquad_bank_process(self.handle, _ptr(out), _ptr(inp), samples,
+                                         samples if out_stride is None else out_stride,
+                                         samples if in_stride is None else in_stride, _stream(stream)))
+
+    def impulse_response(self, out, samples, out_stride=None, stream=None):
+        check(lib.mi_biquad_bank_impulse_response(self.handle, _ptr(out), samples,
+                                                  samples if out_stride is None else out_stride, _stream(stream)))
+
+    def get_state(self, stream=None):
+        st = np.empty((self.channels, self.max_sections, 2), dtype=np.float32)
+        check(lib.mi_biquad_bank_get_state(self.handle, st.ctypes.data_as(c_void_p), _stream(stream)))
+        return st
+
+    def set_state(self, state, stream=None):
+        st = np.ascontiguousarray(state, dtype=np.float32)
+        assert st.shape == (self.channels, self.max_sections, 2)
+        check(lib.mi_biquad_bank_set_state(self.handle, st.ctypes.data_as(c_void_p), _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_biquad_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

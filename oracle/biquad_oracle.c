@@ -1,0 +1,91 @@
+/*
+ * ORACLE -- test infrastructure only. Nothing under lsp-dsp-units_amd/ may
+ * include, link or call this file; tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py are its only users.
+ *
+ * CPU restatement of the reference's IIR streaming path:
+ *   FilterBank::process      /root/reference/src/main/filters/FilterBank.cpp:256-291
+ *   FilterBank::reset        FilterBank.cpp:238-254
+ *   FilterBank::impulse_response  FilterBank.cpp:293-330
+ * and of the lsp-dsp-lib 1.0.36 primitives it calls, dsp::biquad_process_x1/x2/x4/x8
+ * (un-vendored dependency, modules.mk:29-33).  Their published algorithm is a
+ * transposed direct form II section with pre-negated denominator signs
+ * (Filter.cpp:2261-2262 "Sign negated", Filter.cpp:1628-1634):
+ *
+ *      y    = b0*x + d0
+ *      d0'  = d1 + (b1*x + a1*y)
+ *      d1'  =       b2*x + a2*y
+ *
+ * The x2/x4/x8 variants run 2/4/8 such sections in series on the same sample
+ * stream (software-pipelined over SIMD lanes upstream); the arithmetic seen by
+ * each section is the one above, so the oracle runs sections one after another.
+ *
+ * Parity pin: no reference test asserts IIR output.  The pins
+ * are (1) the sign convention + the BS.1770 table in Filter.cpp:2103-2111
+ * checked through the designer oracle, (2) frequency-response identity of the
+ * impulse response (tests/test_oracle_filters.py).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off so the rounding is the
+ * same on every host).
+ */
+#include <stddef.h>
+#include <string.h>
+
+/* One channel: `ns` sections in series. coef = ns x {b0,b1,b2,a1,a2}; state = ns x {d0,d1}. */
+void orc_biquad_cascade(float *dst, const float *src, size_t n,
+                        const float *coef, float *state, size_t ns)
+{
+    if (ns == 0)                     /* FilterBank.cpp:261-265: empty bank copies */
+    {
+        if (dst != src)
+            memmove(dst, src, n * sizeof(float));
+        return;
+    }
+    for (size_t s = 0; s < ns; ++s)
+    {
+        const float b0 = coef[5*s+0], b1 = coef[5*s+1], b2 = coef[5*s+2];
+        const float a1 = coef[5*s+3], a2 = coef[5*s+4];
+        float d0 = state[2*s+0], d1 = state[2*s+1];
+        const float *in = (s == 0) ? src : dst;     /* later banks run in place, FilterBank.cpp:270 */
+        for (size_t i = 0; i < n; ++i)
+        {
+            const float x  = in[i];
+            const float y  = b0*x + d0;
+            const float p1 = b1*x + a1*y;
+            const float p2 = b2*x + a2*y;
+            d0      = d1 + p1;
+            d1      = p2;
+            dst[i]  = y;
+        }
+        state[2*s+0] = d0;
+        state[2*s+1] = d1;
+    }
+}
+
+/* A bank of independent channels ([channels][stride] layout), optionally threaded. */
+void orc_biquad_bank(float *dst, const float *src, size_t channels, size_t n,
+                     size_t dst_stride, size_t src_stride,
+                     const float *coef, float *state, const unsigned *nsec, size_t max_sections)
+{
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
+    for (long c = 0; c < (long)channels; ++c)
+        orc_biquad_cascade(dst + c*dst_stride, src + c*src_stride, n,
+                           coef + (size_t)c*max_sections*5, state + (size_t)c*max_sections*2, nsec[c]);
+}
+
+/* FilterBank::impulse_response: save state, zero it, run a unit impulse, restore. */
+void orc_biquad_impulse_response(float *out, size_t n, const float *coef, float *state, size_t ns)
+{
+    float backup[2*1024];
+    if (ns > 1024)
+        ns = 1024;
+    memcpy(backup, state, 2*ns*sizeof(float));
+    memset(state, 0, 2*ns*sizeof(float));
+    memset(out, 0, n*sizeof(float));
+    if (n > 0)
+        out[0] = 1.0f;
+    orc_biquad_cascade(out, out, n, coef, state, ns);
+    memcpy(state, backup, 2*ns*sizeof(float));
+}

@@ -1,0 +1,74 @@
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _package():
+    return importlib.import_module("lsp-dsp-units_amd")
+
+
+@pytest.fixture(scope="session")
+def mi():
+    """The product package (ctypes binding over libmi_dspu.so)."""
+    return _package()
+
+
+@pytest.fixture(scope="session")
+def gpu(mi):
+    """The product package on a machine that really has a HIP device.
+
+    GPU tests fail loudly (not skip) when collected with -m gpu on a box without a device,
+    so a silent fallback can never turn them green."""
+    if mi.device_count() <= 0:
+        pytest.fail("test marked gpu but no HIP device is visible; there is no CPU fallback")
+    return mi
+
+
+def parity_report(gpu_out, ref32, ref64):
+    """Relative-to-block-peak errors used by every floating-point parity test.
+
+    ref32 = oracle in the reference's float32 arithmetic, ref64 = the same algorithm in float64.
+    noise = how far the reference's own float32 path is from exact arithmetic on this input."""
+    ref64 = np.asarray(ref64, dtype=np.float64)
+    peak = max(float(np.max(np.abs(ref64))), 1e-30)
+    return {
+        "peak": peak,
+        "gpu_vs_ref32": float(np.max(np.abs(np.asarray(gpu_out, np.float64) - np.asarray(ref32, np.float64)))) / peak,
+        "gpu_vs_exact": float(np.max(np.abs(np.asarray(gpu_out, np.float64) - ref64))) / peak,
+        "noise": float(np.max(np.abs(np.asarray(ref32, np.float64) - ref64))) / peak,
+    }
+
+
+# north_star tolerance: 1e-5 relative (to the block peak, SURVEY.md section 8c "Tolerance note")
+TOL = 1e-5
+# a recursion whose float32 round-off noise is below this is "well conditioned": strict tolerance applies
+NOISE_FLOOR = 3e-6
+
+
+def assert_iir_parity(gpu_out, ref32, ref64, what=""):
+    """IIR parity rule (DESIGN.md "Parity for recursive filters").
+
+    * well-conditioned filter (reference's own float32 noise <= NOISE_FLOOR): |gpu - ref32| <= 1e-5 * peak;
+    * otherwise the float32 recursion itself is only reproducible to `noise`; the GPU result must then be
+      at least as close to exact arithmetic as the reference's float32 path is (factor 2 head-room) and
+      within 3x noise of the reference."""
+    r = parity_report(gpu_out, ref32, ref64)
+    msg = "%s: %s" % (what, r)
+    assert np.all(np.isfinite(gpu_out)), msg
+    if r["noise"] <= NOISE_FLOOR:
+        assert r["gpu_vs_ref32"] <= TOL, msg
+    else:
+        assert r["gpu_vs_exact"] <= max(TOL, 2.0 * r["noise"]), msg
+        assert r["gpu_vs_ref32"] <= max(TOL, 3.0 * r["noise"]), msg
+    return r

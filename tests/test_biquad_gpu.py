@@ -1,0 +1,229 @@
+"""GPU parity of mi_biquad_bank_* (FilterBank::process) against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import filter_design as fd
+from conftest import assert_iir_parity, parity_report
+
+import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bank(gpu, x, coef_list, blocks=1, in_place=False, pad=0, clear=False):
+    """x: [blocks][C][n]; coef_list: per-channel (ns,5) arrays. Returns (y, state)."""
+    nb, C, n = x.shape
+    max_sec = max(1, max(len(c) for c in coef_list))
+    bank = gpu.BiquadBank(C, max_sec)
+    for c in range(C):
+        bank.set_chains(c, coef_list[c], clear)
+    stride = n + pad
+    y = np.empty_like(x)
+    dbuf_in = gpu.DeviceBuffer((C, stride))
+    dbuf_out = dbuf_in if in_place else gpu.DeviceBuffer((C, stride))
+    for b in range(nb):
+        host = np.zeros((C, stride), np.float32)
+        host[:, :n] = x[b]
+        dbuf_in.upload(host)
+        bank.process(dbuf_out, dbuf_in, n, stride, stride)
+        y[b] = dbuf_out.download()[:, :n]
+    st = bank.get_state()
+    bank.close()
+    return y, st
+
+
+def oracle_bank(x, coef_list):
+    nb, C, n = x.shape
+    y32 = np.empty_like(x)
+    y64 = np.empty(x.shape, np.float64)
+    states = []
+    for c in range(C):
+        st = None
+        for b in range(nb):
+            y32[b, c], st = oracle.biquad_cascade(x[b, c], coef_list[c], st)
+        states.append(st)
+        y64[:, c, :] = oracle.biquad_cascade_f64(x[:, c, :].reshape(-1), coef_list[c]).reshape(nb, n)
+    return y32, y64, states
+
+
+def check_all(gpu_y, y32, y64, what):
+    worst = None
+    for c in range(gpu_y.shape[1]):
+        r = assert_iir_parity(gpu_y[:, c], y32[:, c], y64[:, c], "%s ch%d" % (what, c))
+        if worst is None or r["gpu_vs_ref32"] > worst["gpu_vs_ref32"]:
+            worst = r
+    return worst
+
+
+def test_c1_readme_hishelf(gpu):
+    """BASELINE config 0: 1 ch x 48000, FLT_BT_BWC_HISHELF slope 2 @1 kHz +6 dB (README.md:176-191), in place."""
+    gain = float(np.float32(np.exp(np.float32(6.0) * np.float32(np.log(10.0)) * np.float32(0.05))))
+    bq = wl.design(fd.FLT_BT_BWC_HISHELF, 2, 1000.0, 1000.0, gain, 0.0)
+    assert bq.shape == (2, 5)
+    x = (np.random.default_rng(1).standard_normal((1, 1, 48000)) * 0.25).astype(np.float32)
+    y, _ = run_bank(gpu, x, [bq], in_place=True)
+    y32, y64, _ = oracle_bank(x, [bq])
+    r = check_all(y, y32, y64, "C1")
+    assert r["gpu_vs_ref32"] <= 1e-5            # well-conditioned: the strict north-star tolerance holds
+    imp = np.zeros((1, 1, 4096), np.float32)
+    imp[0, 0, 0] = 1.0
+    yi, _ = run_bank(gpu, imp, [bq])
+    np.testing.assert_allclose(yi[0, 0, :8], [1.93714225, -0.114121534, -0.109540939, -0.10430833,
+                                              -0.0985007137, -0.0922033042, -0.0855074227, -0.0785082579],
+                               rtol=0, atol=2e-7)
+
+
+def test_c2_shape_state_carry(gpu):
+    """G2: 8-section LRX lowpass, 4 channels x 4096 x 3 consecutive blocks (state carried between calls)."""
+    coef, _ = wl.c2_coefficients(4)
+    x = wl.c2_input(4, 4096, blocks=3)
+    y, st = run_bank(gpu, x, list(coef))
+    y32, y64, states = oracle_bank(x, list(coef))
+    check_all(y, y32, y64, "C2x4")
+    # delay memory after the last block agrees with the oracle's (same scale as the output)
+    for c in range(4):
+        scale = max(1e-30, np.abs(states[c]).max())
+        assert np.abs(st[c, :8] - states[c]).max() / scale < 5e-3
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 5, 8, 31, 64, 100, 511, 512, 513, 1000, 4095, 4096, 4097, 9001])
+def test_ragged_lengths(gpu, n):
+    rng = np.random.default_rng(100 + n)
+    coefs = [wl.design(fd.FLT_BT_RLC_BELL, 2, 1000.0 * (c + 1), 0, 2.0, 1.0) for c in range(3)]
+    x = (rng.standard_normal((2, 3, n))).astype(np.float32)
+    y, _ = run_bank(gpu, x, coefs, pad=(n % 3))          # odd strides exercise the unaligned path
+    y32, y64, _ = oracle_bank(x, coefs)
+    check_all(y, y32, y64, "n=%d" % n)
+
+
+@pytest.mark.parametrize("ns", [0, 1, 2, 3, 4, 7, 8, 9, 15, 16, 32])
+def test_section_counts(gpu, ns):
+    """x8/x4/x2/x1 packing of FilterBank::end() (FilterBank.cpp:106-236) == ns sections in series."""
+    rng = np.random.default_rng(7 + ns)
+    if ns == 0:
+        coefs = [np.zeros((0, 5), np.float32)] * 2
+    else:
+        one = wl.design(fd.FLT_BT_RLC_BELL, ns, 2500.0, 0, 1.5, 0.7)
+        assert one.shape[0] == ns
+        coefs = [one, one[::-1].copy()]
+    x = rng.standard_normal((2, 2, 2048)).astype(np.float32)
+    y, _ = run_bank(gpu, x, coefs)
+    y32, y64, _ = oracle_bank(x, coefs)
+    check_all(y, y32, y64, "ns=%d" % ns)
+    if ns == 0:
+        np.testing.assert_array_equal(y, x)          # FilterBank.cpp:261-265: empty bank copies
+
+
+def test_mixed_channels_and_in_place(gpu):
+    rng = np.random.default_rng(11)
+    coefs = [wl.design(fd.FLT_BT_LRX_HIPASS, 2, 100.0, 0, 1.0, 0.0),
+             np.zeros((0, 5), np.float32),
+             wl.design(fd.FLT_K_WEIGHTED),
+             wl.design(fd.FLT_BT_BWC_LOPASS, 3, 8000.0, 0, 1.0, 0.2),
+             wl.design(fd.FLT_DR_APO_PEAKING, 1, 3000.0, 0, 0.25, 4.0)]
+    x = rng.standard_normal((3, 5, 1536)).astype(np.float32)
+    y, _ = run_bank(gpu, x, coefs, in_place=True)
+    y32, y64, _ = oracle_bank(x, coefs)
+    check_all(y, y32, y64, "mixed")
+
+
+def test_low_frequency_filters_noise_floor(gpu):
+    """20-200 Hz sections: the float32 recursion is only reproducible to its own round-off noise
+    (reference float32 vs float64 differ by >1e-5 here); the GPU must not be worse than that."""
+    rng = np.random.default_rng(5)
+    coefs = [wl.design(fd.FLT_BT_RLC_BELL, 4, 20.0, 0, 4.0, 2.0),
+             wl.design(fd.FLT_BT_LRX_LOPASS, 4, 200.0, 0, 1.0, 0.75),
+             wl.design(fd.FLT_BT_LRX_HIPASS, 4, 30.0, 0, 1.0, 0.0)]
+    x = (rng.standard_normal((2, 3, 4096)) * 0.25).astype(np.float32)
+    y, _ = run_bank(gpu, x, coefs)
+    y32, y64, _ = oracle_bank(x, coefs)
+    for c in range(3):
+        r = assert_iir_parity(y[:, c], y32[:, c], y64[:, c], "lowfreq ch%d" % c)
+        assert r["gpu_vs_exact"] <= 2.0 * max(r["noise"], 1e-5)
+
+
+def test_clear_and_reset_semantics(gpu):
+    """FilterBank::end(clear) clears delays when asked or when the section count changed (FilterBank.cpp:233-235)."""
+    bq2 = wl.design(fd.FLT_BT_RLC_BELL, 2, 500.0, 0, 2.0, 1.0)
+    bq3 = wl.design(fd.FLT_BT_RLC_BELL, 3, 500.0, 0, 2.0, 1.0)
+    x = np.random.default_rng(3).standard_normal(1024).astype(np.float32)
+    bank = gpu.BiquadBank(1, 8)
+    din = gpu.DeviceBuffer.from_host(x.reshape(1, -1))
+    dout = gpu.DeviceBuffer((1, 1024))
+    bank.set_chains(0, bq2)
+    bank.process(dout, din, 1024)
+    st1 = bank.get_state()
+    assert np.abs(st1[0, :2]).max() > 0
+    bank.set_chains(0, bq2, clear=False)             # same count, no clear: memory kept
+    bank.commit()
+    np.testing.assert_array_equal(bank.get_state(), st1)
+    bank.set_chains(0, bq3, clear=False)             # count changed: memory cleared
+    assert bank.size(0) == 3
+    np.testing.assert_array_equal(bank.get_state(), np.zeros_like(st1))
+    bank.process(dout, din, 1024)
+    bank.set_chains(0, bq3, clear=True)              # explicit clear
+    np.testing.assert_array_equal(bank.get_state(), np.zeros_like(st1))
+    bank.process(dout, din, 1024)
+    y1 = dout.download()
+    bank.reset()
+    np.testing.assert_array_equal(bank.get_state(), np.zeros_like(st1))
+    bank.process(dout, din, 1024)
+    np.testing.assert_array_equal(dout.download(), y1)      # same start state -> bit-identical rerun
+    bank.close()
+
+
+def test_impulse_response_restores_state(gpu):
+    """FilterBank::impulse_response (FilterBank.cpp:293-330)."""
+    bq = wl.design(fd.FLT_BT_LRX_LOPASS, 2, 2000.0, 0, 1.0, 0.0)
+    x = np.random.default_rng(4).standard_normal((2, 2048)).astype(np.float32)
+    bank = gpu.BiquadBank(2, 4)
+    bank.set_chains(0, bq)
+    bank.set_chains(1, bq[:2])
+    din = gpu.DeviceBuffer.from_host(x)
+    dout = gpu.DeviceBuffer((2, 2048))
+    bank.process(dout, din, 2048)
+    st = bank.get_state()
+    ir = gpu.DeviceBuffer((2, 600))
+    bank.impulse_response(ir, 600)
+    np.testing.assert_array_equal(bank.get_state(), st)
+    h = ir.download()
+    for c, q in enumerate([bq, bq[:2]]):
+        ref = oracle.biquad_impulse_response(600, q, np.zeros((len(q), 2), np.float32))
+        assert np.abs(h[c] - ref).max() <= 1e-5 * np.abs(ref).max()
+    bank.close()
+
+
+def test_c2_full_size_all_channels(gpu):
+    """BASELINE config 1 at full size: 1024 ch x 4096, 8 sections, 4 consecutive blocks, every channel
+    checked against the oracle (OpenMP over channels keeps it to seconds)."""
+    C, n, nb = 1024, 4096, 4
+    coef, fc = wl.c2_coefficients(C)
+    x = wl.c2_input(C, n, blocks=nb)
+    y, _ = run_bank(gpu, x, list(coef))
+    state = np.zeros((C, 8, 2), np.float32)
+    nsec = np.full(C, 8, np.uint32)
+    y32 = np.stack([oracle.biquad_bank(x[b], coef, nsec, state) for b in range(nb)])
+    worst_strict, worst_any, n_strict = 0.0, 0.0, 0
+    for c in range(C):
+        y64 = oracle.biquad_cascade_f64(x[:, c, :].reshape(-1), coef[c]).reshape(nb, n)
+        r = assert_iir_parity(y[:, c], y32[:, c], y64, "C2 ch%d fc=%.0f" % (c, fc[c]))
+        worst_any = max(worst_any, r["gpu_vs_ref32"])
+        if r["noise"] <= 3e-6:
+            n_strict += 1
+            worst_strict = max(worst_strict, r["gpu_vs_ref32"])
+    print("C2 full: %d/%d channels under the strict 1e-5 rule (worst %.2e); worst overall %.2e"
+          % (n_strict, C, worst_strict, worst_any))
+    assert n_strict > C // 4
+
+
+def test_linearity_and_determinism_full_size(gpu):
+    """Size-independent properties at full size: same input twice -> identical bits; scaling by 2 is exact."""
+    C, n = 1024, 4096
+    coef, _ = wl.c2_coefficients(C)
+    x = wl.c2_input(C, n, blocks=1)
+    y1, _ = run_bank(gpu, x, list(coef))
+    y2, _ = run_bank(gpu, x, list(coef))
+    np.testing.assert_array_equal(y1, y2)
+    y3, _ = run_bank(gpu, x * np.float32(2.0), list(coef))
+    np.testing.assert_array_equal(y3, y1 * np.float32(2.0))     # power-of-two scaling commutes with rounding
