@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--ring", type=int, default=16, help="distinct resident blocks cycled through "
                     "(16 x 32 MiB in+out > the 256 MiB Infinity Cache, so steps stream from HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sections", type=int, default=8, help="experiment knob: keep only the first N sections")
     return ap.parse_args()
 
 
@@ -94,8 +95,8 @@ def main():
     C, n, ring = args.channels, args.samples, args.ring
     # per-rank channel shard: rank r owns global channels [r*C, (r+1)*C)
     coef_all, _ = wl.c2_coefficients(C * world)
-    coef = coef_all[rank * C:(rank + 1) * C]
-    bank = mi.BiquadBank(C, coef.shape[1])
+    coef = np.ascontiguousarray(coef_all[rank * C:(rank + 1) * C, :args.sections])
+    bank = mi.BiquadBank(C, max(1, coef.shape[1]))
     bank.set_all_chains(coef)
 
     gen = torch.Generator(device="cpu")
@@ -116,13 +117,19 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
 
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    # one HIP event pair per step, recorded by the launch itself at the kernel's begin and end
+    # (hipExtLaunchKernelGGL on the launch stream), so the average is the kernel's launch duration
+    import ctypes
+    def new_event():
+        e = ctypes.c_void_p()
+        mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
+        return e
+    starts = [new_event() for _ in range(args.steps)]
+    stops = [new_event() for _ in range(args.steps)]
     t0 = time.perf_counter()
     for i in range(args.steps):
-        starts[i].record(stream)
+        mi.check(mi.lib.mi_dspu_profile_next_launch(starts[i], stops[i]))
         step(args.warmup + i)
-        stops[i].record(stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -134,13 +141,20 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    kernel_ms = sorted(s.elapsed_time(e) for s, e in zip(starts, stops))
+    def elapsed_ms(a, b):
+        ms = ctypes.c_float()
+        mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), a, b))
+        return float(ms.value)
+    kernel_ms = sorted(elapsed_ms(a, b) for a, b in zip(starts, stops))
+    for e in starts + stops:
+        mi.lib.mi_dspu_event_destroy(e)
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     med_kernel_ms = kernel_ms[len(kernel_ms) // 2]
 
     # sanity: the output of the last step is finite and non-trivial
     chk = yout[(args.warmup + args.steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
+    assert args.sections == 8 or args.no_cpu_baseline, "--sections is an experiment knob; the headline config has 8"
 
     if rank == 0:
         samples_per_step = C * n * world

@@ -65,6 +65,13 @@ int         mi_dspu_event_destroy(void *event);
 int         mi_dspu_event_record(void *event, void *stream);
 int         mi_dspu_event_synchronize(void *event);
 int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
+/*
+ * Arm a pair of events for the calling thread: the next hot-path kernel this
+ * thread launches (the dominant kernel of the next process() call) records them
+ * at its own begin and end (hipExtLaunchKernelGGL), so their elapsed time is the
+ * kernel's launch duration as a profiler reports it.  One-shot.
+ */
+int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
 
 /* ---- biquad cascade bank -------------------------------------------------------------- */
 /*
@@ -133,8 +140,8 @@ int mi_biquad_bank_set_state(mi_biquad_bank_t *bank, const float *host_state, vo
  * Host-only introspection of the per-section device table (no GPU needed): the
  * chunk-parallel form of the TDF-II section used by the kernel.
  * variant 0 = 32-sample chunks x 128 lanes, 1 = 8-sample chunks x 64 lanes.
- * geometry[4] receives {chunk, lanes, scan_levels, floats_per_row}; table (may be
- * NULL) receives one row: {b0 b1 b2 a1 a2 0 0 0 | P^(2^j) j<levels | p[chunk] | q[chunk]}.
+ * geometry[4] receives {chunk, lanes, matrices, floats_per_row}; table (may be
+ * NULL) receives one row: {b0 b1 b2 a1 a2 0 0 0 | P^(i+1) i<matrices | p[chunk] | q[chunk]}.
  */
 int mi_biquad_section_tables(const mi_biquad_x1_t *chain, int variant, float *table, uint32_t *geometry);
 

@@ -9,10 +9,16 @@
 // runs every section in three steps (state s = {d0,d1}, s' = A s + B x):
 //
 //   1. zero-state response of the chunk's end state:  z = sum_k A^(L-1-k) B x[k]
-//      -> two dot products with per-section tables p[],q[] (wave-uniform, SGPR);
-//   2. inclusive scan over chunks  E_t = P E_(t-1) + z_t  with P = A^L
-//      (Hillis-Steele, level j uses P^(2^j), also wave-uniform); the state the
-//      channel carried in from the previous call enters at chunk 0;
+//      -> two dot products with per-section tables p[],q[];
+//   2. prefix over chunks  E_t = P E_(t-1) + z_t,  P = A^L, done in two levels so
+//      that no data-dependent lane shuffles are needed:
+//        a. inclusive scan inside each row of 16 lanes with DPP row_shr 1,2,4,8
+//           and the uniform matrices P, P^2, P^4, P^8;
+//        b. the four row totals of a wave are chained with P^16 (uniform math),
+//           waves are chained through one LDS word pair and one barrier;
+//        c. every lane adds P^(i+1) C_row, i = lane % 16, C_row = state entering
+//           its row (a 16-entry matrix table, the same for all rows);
+//      the state the channel carried in from the previous call enters at chunk 0;
 //   3. the exact TDF-II recurrence over the chunk, started from E_(t-1):
 //         y = b0 x + d0;  d0 = (b1 x + d1) + a1 y;  d1 = b2 x + a2 y
 //      -- the reference's own per-sample arithmetic; only the chunk start state
@@ -23,7 +29,8 @@
 // A workgroup owns one channel: it loads the block with coalesced 16-B loads,
 // transposes it through a padded LDS tile so each lane gets its L consecutive
 // samples (conflict-free ds_read_b128: row pitch L+4 dwords, (L+4)/4 odd), and
-// stores the result the same way back.
+// stores the result the same way back.  The per-section tables of the channel
+// are staged in LDS (8 sections at a time) and read as broadcasts.
 #include "mi_common.h"
 
 #include <cmath>
@@ -32,23 +39,34 @@
 
 namespace
 {
-    constexpr int ilog2(int v) { return (v <= 1) ? 0 : 1 + ilog2(v >> 1); }
-
     template <int L, int NT>
     struct geom
     {
-        static constexpr int NLEV   = ilog2(NT);            // scan levels
-        static constexpr int TAB    = 8 + 4 * NLEV + 2 * L; // floats per (channel, section)
+        static constexpr int TAB    = 72 + 2 * L;           // floats per (channel, section)
         static constexpr int PITCH  = L + 4;                // LDS dwords per chunk
         static constexpr int BLOCK  = L * NT;               // samples per launch and channel
+        static constexpr int NW     = NT / 64;              // waves per workgroup
+        static constexpr int SG     = 8;                    // sections whose tables are staged at once
         static_assert(((PITCH / 4) & 1) == 1, "LDS pitch must be an odd number of 16-B slots");
         static_assert((TAB % 4) == 0, "table rows stay 16-B aligned");
+        static_assert(NT % 64 == 0, "whole waves");
     };
 
-    // Table row of one section (all wave-uniform):
-    //   [0..4]  b0 b1 b2 a1 a2          [5..7] unused
-    //   [8 + 4j ..]  P^(2^j) row-major, j = 0..NLEV-1
-    //   then p[L], q[L]
+    // Table row of one section:
+    //   [0..4]   b0 b1 b2 a1 a2            [5..7] unused
+    //   [8+4i..] P^(i+1) row-major, i = 0..15   (P = A^L; P,P^2,P^4,P^8 drive the row scan, P^16 the chain)
+    //   [72..]   p[L], q[L]
+    template <int CTRL>
+    __device__ __forceinline__ float dpp_zero(float v)
+    {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    }
+
+    __device__ __forceinline__ float lane_value(float v, int lane)
+    {
+        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+    }
+
     template <int L, int NT, bool ALIGNED, bool FULL>
     __global__ __launch_bounds__(NT)
     void biquad_bank_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
@@ -56,20 +74,45 @@ namespace
                             const uint32_t *__restrict__ nsec, int max_sec)
     {
         using G = geom<L, NT>;
-        constexpr int NLEV = G::NLEV;
-        constexpr int TAB  = G::TAB;
+        constexpr int TAB   = G::TAB;
         constexpr int PITCH = G::PITCH;
-        constexpr int WLEV = (NLEV < 6) ? NLEV : 6;         // levels that stay inside a wave
+        constexpr int NW    = G::NW;
+        constexpr int SG    = G::SG;
+
+        constexpr int TQ    = SG * TAB / 4;                 // float4 per staged table group
+        constexpr int TPT   = (TQ + NT - 1) / NT;           // float4 per thread and group
 
         __shared__ __attribute__((aligned(16))) float sx[NT * PITCH];
-        __shared__ float2 sscan[(NT > 64) ? 2 * NT : 2];
+        __shared__ __attribute__((aligned(16))) float stab[SG * TAB];
+        __shared__ float2 sstate[SG];
+        __shared__ float2 stot[2][NW];
 
         const int ch    = blockIdx.x;
         const int t     = threadIdx.x;
         const int lane  = t & 63;
+        const int l16   = t & 15;
+        const int row   = lane >> 4;
+        const int wave  = t >> 6;
         const int ns    = int(nsec[ch]);
         const float *xin = in + size_t(ch) * in_stride;
         float *yout      = out + size_t(ch) * out_stride;
+
+        // tables and carried state of the first section group: issued before the samples so that
+        // their latency hides behind the block load
+        float4 tpre[TPT];
+        float2 spre = make_float2(0.0f, 0.0f);
+        {
+            const int group = (ns < SG) ? ns : SG;
+            const float4 *src = reinterpret_cast<const float4 *>(tab + size_t(ch) * max_sec * TAB);
+            #pragma unroll
+            for (int j = 0; j < TPT; ++j)
+            {
+                const int i = t + j * NT;
+                tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (t < group)
+                spre = reinterpret_cast<const float2 *>(state + size_t(ch) * max_sec * 2)[t];
+        }
 
         // ---- coalesced load, transposed through LDS -------------------------------------
         float x[L];
@@ -102,113 +145,162 @@ namespace
         const int m_last = FULL ? L : (cnt - t_last * L);
 
         // ---- sections, strictly in series (FilterBank.cpp:267-290) ----------------------
-        for (int s = 0; s < ns; ++s)
+        for (int s0 = 0; s0 < ns; s0 += SG)
         {
-            const float *T  = tab + (size_t(ch) * max_sec + s) * TAB;
-            const float *M  = T + 8;
-            const float *P  = T + 8 + 4 * NLEV;
-            const float *Q  = P + L;
-            float *st       = state + (size_t(ch) * max_sec + s) * 2;
-            const float b0 = T[0], b1 = T[1], b2 = T[2], a1 = T[3], a2 = T[4];
-            const float c0 = st[0], c1 = st[1];          // state carried in from the previous call
-
-            // 1. end state of the chunk for zero start state
-            float z0 = 0.0f, z1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
-            #pragma unroll
-            for (int k = 0; k < L; k += 2)
+            const int group = (ns - s0 < SG) ? (ns - s0) : SG;
+            if (s0 > 0)
             {
-                z0 = fmaf(P[k], x[k], z0);
-                w0 = fmaf(Q[k], x[k], w0);
-                z1 = fmaf(P[k + 1], x[k + 1], z1);
-                w1 = fmaf(Q[k + 1], x[k + 1], w1);
-            }
-            float z = z0 + z1, w = w0 + w1;
-            if (t == 0)
-            {
-                z = fmaf(M[0], c0, fmaf(M[1], c1, z));
-                w = fmaf(M[2], c0, fmaf(M[3], c1, w));
-            }
-
-            // 2. inclusive scan over chunks: E_t += P^(2^j) E_(t - 2^j)
-            #pragma unroll
-            for (int j = 0; j < WLEV; ++j)
-            {
-                const int d = 1 << j;
-                const float zs = __shfl_up(z, d, 64);
-                const float ws = __shfl_up(w, d, 64);
-                if (lane >= d)
-                {
-                    z = fmaf(M[4 * j + 0], zs, fmaf(M[4 * j + 1], ws, z));
-                    w = fmaf(M[4 * j + 2], zs, fmaf(M[4 * j + 3], ws, w));
-                }
-            }
-            float d0 = __shfl_up(z, 1, 64);
-            float d1 = __shfl_up(w, 1, 64);
-            if (NT > 64)
-            {
-                float2 *sc = sscan + (s & 1) * NT;
-                sc[t] = make_float2(z, w);
-                __syncthreads();
+                __syncthreads();                        // everybody is done with the previous tables
+                const float4 *src = reinterpret_cast<const float4 *>(tab + (size_t(ch) * max_sec + s0) * TAB);
                 #pragma unroll
-                for (int j = 6; j < NLEV; ++j)
+                for (int j = 0; j < TPT; ++j)
                 {
-                    const int d = 1 << j;
-                    if (t >= d)
-                    {
-                        const float2 e = sc[t - d];
-                        z = fmaf(M[4 * j + 0], e.x, fmaf(M[4 * j + 1], e.y, z));
-                        w = fmaf(M[4 * j + 2], e.x, fmaf(M[4 * j + 3], e.y, w));
-                    }
-                    if (NLEV > 7)       // more than two waves: republish before the next level / the hand-over
-                    {
-                        __syncthreads();
-                        sc[t] = make_float2(z, w);
-                        __syncthreads();
-                    }
+                    const int i = t + j * NT;
+                    tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 }
-                // hand E_(t-1) to the first lane of every wave but the first (for two waves
-                // the first wave's entries were final when they were published)
-                d0 = __shfl_up(z, 1, 64);
-                d1 = __shfl_up(w, 1, 64);
-                if (lane == 0 && t != 0)
-                {
-                    const float2 e = sc[t - 1];
-                    d0 = e.x;
-                    d1 = e.y;
-                }
+                if (t < group)
+                    spre = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[t];
             }
-            if (t == 0)
-            {
-                d0 = c0;
-                d1 = c1;
-            }
-
-            // 3. exact recurrence over the chunk
-            float f0 = d0, f1 = d1;
             #pragma unroll
-            for (int k = 0; k < L; ++k)
+            for (int j = 0; j < TPT; ++j)
             {
-                const float xx = x[k];
-                const float y  = fmaf(b0, xx, d0);
-                const float tt = fmaf(b1, xx, d1);
-                d0   = fmaf(a1, y, tt);
-                d1   = fmaf(a2, y, b2 * xx);
-                x[k] = y;
-                if (!FULL && (k + 1 == m_last))
+                const int i = t + j * NT;
+                if (i < TQ)
+                    reinterpret_cast<float4 *>(stab)[i] = tpre[j];
+            }
+            if (t < SG)
+                sstate[t] = spre;
+            __syncthreads();
+
+            for (int si = 0; si < group; ++si)
+            {
+                const int s     = s0 + si;
+                const float *T  = stab + si * TAB;
+                float *st       = state + (size_t(ch) * max_sec + s) * 2;
+                const float4 cf = *reinterpret_cast<const float4 *>(T);
+                const float b0 = cf.x, b1 = cf.y, b2 = cf.z, a1 = cf.w, a2 = T[4];
+                const float2 cs = sstate[si];           // state carried in from the previous call
+                const float c0 = cs.x, c1 = cs.y;
+
+                // 1. end state of the chunk for zero start state
+                float z0 = 0.0f, z1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
+                #pragma unroll
+                for (int k = 0; k < L; k += 4)
+                {
+                    const float4 p = *reinterpret_cast<const float4 *>(T + 72 + k);
+                    const float4 q = *reinterpret_cast<const float4 *>(T + 72 + L + k);
+                    z0 = fmaf(p.x, x[k + 0], z0); w0 = fmaf(q.x, x[k + 0], w0);
+                    z1 = fmaf(p.y, x[k + 1], z1); w1 = fmaf(q.y, x[k + 1], w1);
+                    z0 = fmaf(p.z, x[k + 2], z0); w0 = fmaf(q.z, x[k + 2], w0);
+                    z1 = fmaf(p.w, x[k + 3], z1); w1 = fmaf(q.w, x[k + 3], w1);
+                }
+                float z = z0 + z1, w = w0 + w1;
+                const float4 P1  = *reinterpret_cast<const float4 *>(T + 8 + 4 * 0);
+                if (t == 0)
+                {
+                    z = fmaf(P1.x, c0, fmaf(P1.y, c1, z));
+                    w = fmaf(P1.z, c0, fmaf(P1.w, c1, w));
+                }
+
+                // 2a. inclusive scan inside rows of 16 lanes
+                {
+                    const float4 P2 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 1);
+                    const float4 P4 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 3);
+                    const float4 P8 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 7);
+                    float zs, ws;
+                    zs = dpp_zero<0x111>(z); ws = dpp_zero<0x111>(w);
+                    z = fmaf(P1.x, zs, fmaf(P1.y, ws, z)); w = fmaf(P1.z, zs, fmaf(P1.w, ws, w));
+                    zs = dpp_zero<0x112>(z); ws = dpp_zero<0x112>(w);
+                    z = fmaf(P2.x, zs, fmaf(P2.y, ws, z)); w = fmaf(P2.z, zs, fmaf(P2.w, ws, w));
+                    zs = dpp_zero<0x114>(z); ws = dpp_zero<0x114>(w);
+                    z = fmaf(P4.x, zs, fmaf(P4.y, ws, z)); w = fmaf(P4.z, zs, fmaf(P4.w, ws, w));
+                    zs = dpp_zero<0x118>(z); ws = dpp_zero<0x118>(w);
+                    z = fmaf(P8.x, zs, fmaf(P8.y, ws, z)); w = fmaf(P8.z, zs, fmaf(P8.w, ws, w));
+                }
+
+                // 2b. chain the row totals (uniform per wave), waves one after another
+                const float4 P16 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 15);
+                const float t0x = lane_value(z, 15), t0y = lane_value(w, 15);
+                const float t1x = lane_value(z, 31), t1y = lane_value(w, 31);
+                const float t2x = lane_value(z, 47), t2y = lane_value(w, 47);
+                const float t3x = lane_value(z, 63), t3y = lane_value(w, 63);
+                float cinx = 0.0f, ciny = 0.0f;         // state entering this wave (carry is already in lane 0)
+                float c1x, c1y, c2x, c2y, c3x, c3y;
+                #pragma unroll
+                for (int wv = 0; wv < NW; ++wv)
+                {
+                    if (wave == wv)
+                    {
+                        c1x = fmaf(P16.x, cinx, fmaf(P16.y, ciny, t0x)); c1y = fmaf(P16.z, cinx, fmaf(P16.w, ciny, t0y));
+                        c2x = fmaf(P16.x, c1x, fmaf(P16.y, c1y, t1x));   c2y = fmaf(P16.z, c1x, fmaf(P16.w, c1y, t1y));
+                        c3x = fmaf(P16.x, c2x, fmaf(P16.y, c2y, t2x));   c3y = fmaf(P16.z, c2x, fmaf(P16.w, c2y, t2y));
+                        if (wv + 1 < NW && lane == 0)
+                        {
+                            const float ex = fmaf(P16.x, c3x, fmaf(P16.y, c3y, t3x));
+                            const float ey = fmaf(P16.z, c3x, fmaf(P16.w, c3y, t3y));
+                            stot[s & 1][wv] = make_float2(ex, ey);
+                        }
+                    }
+                    if (wv + 1 < NW)
+                    {
+                        __syncthreads();
+                        if (wave == wv + 1)
+                        {
+                            const float2 e = stot[s & 1][wv];
+                            cinx = e.x;
+                            ciny = e.y;
+                        }
+                    }
+                }
+
+                // 2c. state entering the lane's row, pushed through the lane's own power of P
+                const float crx = (row == 0) ? cinx : (row == 1) ? c1x : (row == 2) ? c2x : c3x;
+                const float cry = (row == 0) ? ciny : (row == 1) ? c1y : (row == 2) ? c2y : c3y;
+                const float4 PL = *reinterpret_cast<const float4 *>(T + 8 + 4 * l16);
+                z = fmaf(PL.x, crx, fmaf(PL.y, cry, z));
+                w = fmaf(PL.z, crx, fmaf(PL.w, cry, w));
+
+                // start state of the chunk = end state of the previous chunk
+                float d0 = dpp_zero<0x111>(z);
+                float d1 = dpp_zero<0x111>(w);
+                if (l16 == 0)
+                {
+                    d0 = crx;
+                    d1 = cry;
+                }
+                if (t == 0)
+                {
+                    d0 = c0;
+                    d1 = c1;
+                }
+
+                // 3. exact recurrence over the chunk
+                float f0 = d0, f1 = d1;
+                #pragma unroll
+                for (int k = 0; k < L; ++k)
+                {
+                    const float xx = x[k];
+                    const float y  = fmaf(b0, xx, d0);
+                    const float tt = fmaf(b1, xx, d1);
+                    d0   = fmaf(a1, y, tt);
+                    d1   = fmaf(a2, y, b2 * xx);
+                    x[k] = y;
+                    if (!FULL && (k + 1 == m_last))
+                    {
+                        f0 = d0;
+                        f1 = d1;
+                    }
+                }
+                if (FULL)
                 {
                     f0 = d0;
                     f1 = d1;
                 }
-            }
-            if (FULL)
-            {
-                f0 = d0;
-                f1 = d1;
-            }
-            if (t == t_last)
-            {
-                st[0] = f0;
-                st[1] = f1;
+                if (t == t_last)
+                {
+                    st[0] = f0;
+                    st[1] = f1;
+                }
             }
         }
 
@@ -259,14 +351,13 @@ namespace
     template <int L, int NT>
     void fill_row(float *row, const float *q /* b0 b1 b2 a1 a2 */)
     {
-        using G = geom<L, NT>;
         const double b0 = q[0], b1 = q[1], b2 = q[2], a1 = q[3], a2 = q[4];
         for (int i = 0; i < 8; ++i)
             row[i] = (i < 5) ? q[i] : 0.0f;
         // s' = A s + B x  with  A = [a1 1; a2 0],  B = [b1 + a1 b0, b2 + a2 b0]
         const mat2 A = { a1, 1.0, a2, 0.0 };
         double v0 = b1 + a1 * b0, v1 = b2 + a2 * b0;
-        float *p = row + 8 + 4 * G::NLEV, *qq = p + L;
+        float *p = row + 72, *qq = p + L;
         for (int k = L - 1; k >= 0; --k)        // p[k],q[k] = A^(L-1-k) B
         {
             p[k]  = float(v0);
@@ -275,14 +366,15 @@ namespace
             v0 = n0;
             v1 = n1;
         }
-        mat2 Pm = { 1.0, 0.0, 0.0, 1.0 };
+        mat2 P = { 1.0, 0.0, 0.0, 1.0 };
         for (int k = 0; k < L; ++k)
-            Pm = mul(Pm, A);
-        for (int j = 0; j < G::NLEV; ++j)
+            P = mul(P, A);
+        mat2 Pi = P;                             // P^(i+1)
+        for (int i = 0; i < 16; ++i)
         {
-            float *m = row + 8 + 4 * j;
-            m[0] = float(Pm.a); m[1] = float(Pm.b); m[2] = float(Pm.c); m[3] = float(Pm.d);
-            Pm = mul(Pm, Pm);
+            float *m = row + 8 + 4 * i;
+            m[0] = float(Pi.a); m[1] = float(Pi.b); m[2] = float(Pi.c); m[3] = float(Pi.d);
+            Pi = mul(Pi, P);
         }
     }
 
@@ -316,8 +408,10 @@ namespace
     {
         const dim3 grid(b->channels), block(NT);
         const bool full = (cnt == L * NT);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
         #define MI_LAUNCH(A, F)                                                                   \
-            hipLaunchKernelGGL((biquad_bank_kernel<L, NT, A, F>), grid, block, 0, st, out, in,    \
+            hipExtLaunchKernelGGL((biquad_bank_kernel<L, NT, A, F>), grid, block, 0, st, ev0, ev1, 0, out, in, \
                                out_stride, in_stride, cnt, tab, b->d_state, b->d_nsec, int(b->max_sec))
         if (aligned) { if (full) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
         else         { if (full) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
@@ -588,13 +682,13 @@ int mi_biquad_section_tables(const mi_biquad_x1_t *chain, int variant, float *ta
     const float q[5] = { chain->b0, chain->b1, chain->b2, chain->a1, chain->a2 };
     if (variant == 0)
     {
-        geometry[0] = 32; geometry[1] = 128; geometry[2] = big::NLEV; geometry[3] = big::TAB;
+        geometry[0] = 32; geometry[1] = 128; geometry[2] = 16; geometry[3] = big::TAB;
         if (table != nullptr)
             fill_row<32, 128>(table, q);
     }
     else
     {
-        geometry[0] = 8; geometry[1] = 64; geometry[2] = small::NLEV; geometry[3] = small::TAB;
+        geometry[0] = 8; geometry[1] = 64; geometry[2] = 16; geometry[3] = small::TAB;
         if (table != nullptr)
             fill_row<8, 64>(table, q);
     }

@@ -2,6 +2,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -16,6 +17,10 @@ namespace mi
     int         fail(int code, const char *fmt, ...);
 
     inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+    // Events armed by mi_dspu_profile_next_launch(); the next hot-path kernel launch of this thread
+    // consumes them (hipExtLaunchKernelGGL records them at the kernel's own begin/end).
+    void        take_profile_events(hipEvent_t *start, hipEvent_t *stop);
 } // namespace mi
 
 #define MI_HIP_CHECK(expr)                                                              \

@@ -17,9 +17,26 @@ namespace mi
         va_end(ap);
         return code;
     }
+    static thread_local hipEvent_t tl_start = nullptr, tl_stop = nullptr;
+
+    void take_profile_events(hipEvent_t *start, hipEvent_t *stop)
+    {
+        *start = tl_start;
+        *stop  = tl_stop;
+        tl_start = nullptr;
+        tl_stop  = nullptr;
+    }
 } // namespace mi
 
 extern "C" {
+
+int mi_dspu_profile_next_launch(void *start_event, void *stop_event)
+{
+    mi::tl_start = reinterpret_cast<hipEvent_t>(start_event);
+    mi::tl_stop  = reinterpret_cast<hipEvent_t>(stop_event);
+    return MI_OK;
+}
+
 
 int mi_dspu_abi_version(void) { return MI_DSPU_ABI_VERSION; }
 

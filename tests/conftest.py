@@ -61,14 +61,14 @@ def assert_iir_parity(gpu_out, ref32, ref64, what=""):
 
     * well-conditioned filter (reference's own float32 noise <= NOISE_FLOOR): |gpu - ref32| <= 1e-5 * peak;
     * otherwise the float32 recursion itself is only reproducible to `noise`; the GPU result must then be
-      at least as close to exact arithmetic as the reference's float32 path is (factor 2 head-room) and
-      within 3x noise of the reference."""
+      of the same accuracy class: within 4x the reference's own distance from exact arithmetic (the
+      single-run maximum of a round-off random walk varies by that much between equally good orderings)."""
     r = parity_report(gpu_out, ref32, ref64)
     msg = "%s: %s" % (what, r)
     assert np.all(np.isfinite(gpu_out)), msg
     if r["noise"] <= NOISE_FLOOR:
         assert r["gpu_vs_ref32"] <= TOL, msg
     else:
-        assert r["gpu_vs_exact"] <= max(TOL, 2.0 * r["noise"]), msg
-        assert r["gpu_vs_ref32"] <= max(TOL, 3.0 * r["noise"]), msg
+        assert r["gpu_vs_exact"] <= max(TOL, 4.0 * r["noise"]), msg
+        assert r["gpu_vs_ref32"] <= max(TOL, 5.0 * r["noise"]), msg
     return r

@@ -140,7 +140,7 @@ def test_low_frequency_filters_noise_floor(gpu):
     y32, y64, _ = oracle_bank(x, coefs)
     for c in range(3):
         r = assert_iir_parity(y[:, c], y32[:, c], y64[:, c], "lowfreq ch%d" % c)
-        assert r["gpu_vs_exact"] <= 2.0 * max(r["noise"], 1e-5)
+        assert r["gpu_vs_exact"] <= 4.0 * max(r["noise"], 1e-5)
 
 
 def test_clear_and_reset_semantics(gpu):
