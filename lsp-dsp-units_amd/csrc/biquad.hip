@@ -35,6 +35,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace
@@ -328,6 +329,284 @@ namespace
         }
     }
 
+    // ------------------------------------------------------------------------------------------
+    // Packed variant for long blocks: ONE wave per channel, every lane owns TWO chunks (chunk t of
+    // the first half of the block and chunk t of the second half) and runs them as the two halves
+    // of v_pk_fma_f32 operands.  A lone wave issues one VALU instruction per 4 cycles, which is
+    // half the SIMD's rate for plain v_fma_f32 but the full rate for packed fp32, so this shape
+    // gets full VALU throughput at one wave per SIMD, needs no workgroup barrier inside the
+    // section loop, and leaves the whole 512-register file to the wave.
+    // ------------------------------------------------------------------------------------------
+    typedef float v2f __attribute__((ext_vector_type(2)));
+
+    __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+    __device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+
+    template <int CTRL>
+    __device__ __forceinline__ v2f dpp_zero2(v2f v)
+    {
+        return v2f{dpp_zero<CTRL>(v.x), dpp_zero<CTRL>(v.y)};
+    }
+
+    template <int L, bool ALIGNED, bool FULL>
+    __global__ __launch_bounds__(64, 1)
+    void biquad_bank_kernel_pk(float *out, const float *in, size_t out_stride, size_t in_stride,
+                               int cnt, const float *__restrict__ tab, float *state,
+                               const uint32_t *__restrict__ nsec, int max_sec)
+    {
+        constexpr int NT    = 64;
+        constexpr int NC    = 128;                          // chunks per block
+        constexpr int TAB   = 72 + 2 * L;
+        constexpr int PITCH = L + 4;
+        constexpr int SG    = 8;
+        constexpr int TQ    = SG * TAB / 4;
+        constexpr int TPT   = (TQ + NT - 1) / NT;
+
+        __shared__ __attribute__((aligned(16))) float sx[NC * PITCH];
+        __shared__ __attribute__((aligned(16))) float stab[SG * TAB];
+        __shared__ float2 sstate[SG];
+
+        const int ch    = blockIdx.x;
+        const int t     = threadIdx.x;
+        const int l16   = t & 15;
+        const int row   = t >> 4;
+        const int ns    = int(nsec[ch]);
+        const float *xin = in + size_t(ch) * in_stride;
+        float *yout      = out + size_t(ch) * out_stride;
+
+        float4 tpre[TPT];
+        float2 spre = make_float2(0.0f, 0.0f);
+        {
+            const int group = (ns < SG) ? ns : SG;
+            const float4 *src = reinterpret_cast<const float4 *>(tab + size_t(ch) * max_sec * TAB);
+            #pragma unroll
+            for (int j = 0; j < TPT; ++j)
+            {
+                const int i = t + j * NT;
+                tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            if (t < group)
+                spre = reinterpret_cast<const float2 *>(state + size_t(ch) * max_sec * 2)[t];
+        }
+
+        // ---- coalesced load, transposed through LDS -------------------------------------
+        #pragma unroll
+        for (int k = 0; k < NC * L / 4 / NT; ++k)
+        {
+            const int i = 4 * (k * NT + t);
+            float4 v;
+            if (ALIGNED && (FULL || i + 4 <= cnt))
+                v = *reinterpret_cast<const float4 *>(xin + i);
+            else
+            {
+                v.x = (i + 0 < cnt) ? xin[i + 0] : 0.0f;
+                v.y = (i + 1 < cnt) ? xin[i + 1] : 0.0f;
+                v.z = (i + 2 < cnt) ? xin[i + 2] : 0.0f;
+                v.w = (i + 3 < cnt) ? xin[i + 3] : 0.0f;
+            }
+            *reinterpret_cast<float4 *>(&sx[i + (i / L) * 4]) = v;
+        }
+        __syncthreads();
+        v2f x[L];                                            // .x: chunk t, .y: chunk t + 64
+        #pragma unroll
+        for (int k = 0; k < L / 4; ++k)
+        {
+            const float4 a = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * k]);
+            const float4 b = *reinterpret_cast<const float4 *>(&sx[(t + 64) * PITCH + 4 * k]);
+            x[4 * k + 0] = v2f{a.x, b.x}; x[4 * k + 1] = v2f{a.y, b.y};
+            x[4 * k + 2] = v2f{a.z, b.z}; x[4 * k + 3] = v2f{a.w, b.w};
+        }
+
+        // chunk (0..127) that owns the last valid sample, and how many samples it owns
+        const int c_last = FULL ? (NC - 1) : ((cnt - 1) / L);
+        const int m_last = FULL ? L : (cnt - c_last * L);
+
+        for (int s0 = 0; s0 < ns; s0 += SG)
+        {
+            const int group = (ns - s0 < SG) ? (ns - s0) : SG;
+            if (s0 > 0)
+            {
+                __syncthreads();
+                const float4 *src = reinterpret_cast<const float4 *>(tab + (size_t(ch) * max_sec + s0) * TAB);
+                #pragma unroll
+                for (int j = 0; j < TPT; ++j)
+                {
+                    const int i = t + j * NT;
+                    tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                }
+                if (t < group)
+                    spre = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[t];
+            }
+            #pragma unroll
+            for (int j = 0; j < TPT; ++j)
+            {
+                const int i = t + j * NT;
+                if (i < TQ)
+                    reinterpret_cast<float4 *>(stab)[i] = tpre[j];
+            }
+            if (t < SG)
+                sstate[t] = spre;
+            __syncthreads();
+
+            // Section tables are read from LDS as broadcasts (all lanes, same address).
+            constexpr int TAB4 = TAB / 4;
+            float4 ta[TAB4];
+            float4 pla;
+            float2 csa;
+            auto prefetch = [&](float4 (&tt)[TAB4], float4 &pl, float2 &cs, int si)
+            {
+                const float *T = stab + si * TAB;
+                #pragma unroll
+                for (int j = 0; j < TAB4; ++j)
+                    tt[j] = reinterpret_cast<const float4 *>(T)[j];
+                pl = *reinterpret_cast<const float4 *>(T + 8 + 4 * l16);
+                cs = sstate[si];
+            };
+            auto body = [&](const float4 (&tt)[TAB4], const float4 &PL, const float2 &cs, int s)
+            {
+                float *st       = state + (size_t(ch) * max_sec + s) * 2;
+                const float4 cf = tt[0];
+                const v2f b0 = splat(cf.x), b1 = splat(cf.y), b2 = splat(cf.z), a1 = splat(cf.w), a2 = splat(tt[1].x);
+                const float c0 = cs.x, c1 = cs.y;
+
+                // 1. end state of both chunks for zero start state
+                v2f z0 = splat(0.0f), z1 = splat(0.0f), w0 = splat(0.0f), w1 = splat(0.0f);
+                #pragma unroll
+                for (int k = 0; k < L; k += 4)
+                {
+                    const float4 p = tt[18 + k / 4];
+                    const float4 q = tt[18 + L / 4 + k / 4];
+                    z0 = pk_fma(splat(p.x), x[k + 0], z0); w0 = pk_fma(splat(q.x), x[k + 0], w0);
+                    z1 = pk_fma(splat(p.y), x[k + 1], z1); w1 = pk_fma(splat(q.y), x[k + 1], w1);
+                    z0 = pk_fma(splat(p.z), x[k + 2], z0); w0 = pk_fma(splat(q.z), x[k + 2], w0);
+                    z1 = pk_fma(splat(p.w), x[k + 3], z1); w1 = pk_fma(splat(q.w), x[k + 3], w1);
+                }
+                v2f z = z0 + z1, w = w0 + w1;
+                const float4 P1 = tt[2 + 0];
+                if (t == 0)
+                {
+                    z.x = fmaf(P1.x, c0, fmaf(P1.y, c1, z.x));
+                    w.x = fmaf(P1.z, c0, fmaf(P1.w, c1, w.x));
+                }
+
+                // 2a. inclusive scan inside rows of 16 lanes (both halves at once)
+                {
+                    const float4 P2 = tt[2 + 1];
+                    const float4 P4 = tt[2 + 3];
+                    const float4 P8 = tt[2 + 7];
+                    v2f zs, ws;
+                    zs = dpp_zero2<0x111>(z); ws = dpp_zero2<0x111>(w);
+                    z = pk_fma(splat(P1.x), zs, pk_fma(splat(P1.y), ws, z)); w = pk_fma(splat(P1.z), zs, pk_fma(splat(P1.w), ws, w));
+                    zs = dpp_zero2<0x112>(z); ws = dpp_zero2<0x112>(w);
+                    z = pk_fma(splat(P2.x), zs, pk_fma(splat(P2.y), ws, z)); w = pk_fma(splat(P2.z), zs, pk_fma(splat(P2.w), ws, w));
+                    zs = dpp_zero2<0x114>(z); ws = dpp_zero2<0x114>(w);
+                    z = pk_fma(splat(P4.x), zs, pk_fma(splat(P4.y), ws, z)); w = pk_fma(splat(P4.z), zs, pk_fma(splat(P4.w), ws, w));
+                    zs = dpp_zero2<0x118>(z); ws = dpp_zero2<0x118>(w);
+                    z = pk_fma(splat(P8.x), zs, pk_fma(splat(P8.y), ws, z)); w = pk_fma(splat(P8.z), zs, pk_fma(splat(P8.w), ws, w));
+                }
+
+                // 2b. chain the eight row totals: rows 0..3 = first half, 4..7 = second half
+                const float4 P16 = tt[2 + 15];
+                float cx[8], cy[8];
+                cx[0] = 0.0f; cy[0] = 0.0f;                 // the carry is already inside lane 0
+                #pragma unroll
+                for (int r = 0; r < 7; ++r)
+                {
+                    const int ln = 16 * (r & 3) + 15;
+                    const float tx = (r < 4) ? lane_value(z.x, ln) : lane_value(z.y, ln);
+                    const float ty = (r < 4) ? lane_value(w.x, ln) : lane_value(w.y, ln);
+                    cx[r + 1] = fmaf(P16.x, cx[r], fmaf(P16.y, cy[r], tx));
+                    cy[r + 1] = fmaf(P16.z, cx[r], fmaf(P16.w, cy[r], ty));
+                }
+
+                // 2c. state entering the lane's rows, pushed through the lane's own power of P
+                // (selects written as a flat chain so they stay v_cndmask, not branches)
+                const bool r1 = (row == 1), r2 = (row == 2), r3 = (row == 3);
+                v2f crx = v2f{cx[0], cx[4]}, cry = v2f{cy[0], cy[4]};
+                crx.x = r1 ? cx[1] : crx.x; cry.x = r1 ? cy[1] : cry.x; crx.y = r1 ? cx[5] : crx.y; cry.y = r1 ? cy[5] : cry.y;
+                crx.x = r2 ? cx[2] : crx.x; cry.x = r2 ? cy[2] : cry.x; crx.y = r2 ? cx[6] : crx.y; cry.y = r2 ? cy[6] : cry.y;
+                crx.x = r3 ? cx[3] : crx.x; cry.x = r3 ? cy[3] : cry.x; crx.y = r3 ? cx[7] : crx.y; cry.y = r3 ? cy[7] : cry.y;
+                z = pk_fma(splat(PL.x), crx, pk_fma(splat(PL.y), cry, z));
+                w = pk_fma(splat(PL.z), crx, pk_fma(splat(PL.w), cry, w));
+
+                // start state of each chunk = end state of the chunk before it
+                v2f d0 = dpp_zero2<0x111>(z);
+                v2f d1 = dpp_zero2<0x111>(w);
+                if (l16 == 0)
+                {
+                    d0 = crx;
+                    d1 = cry;
+                }
+                if (t == 0)
+                {
+                    d0.x = c0;
+                    d1.x = c1;
+                }
+
+                // 3. exact recurrence over both chunks
+                v2f f0 = d0, f1 = d1;
+                #pragma unroll
+                for (int k = 0; k < L; ++k)
+                {
+                    const v2f xx = x[k];
+                    const v2f y  = pk_fma(b0, xx, d0);
+                    const v2f tt2 = pk_fma(b1, xx, d1);
+                    d0   = pk_fma(a1, y, tt2);
+                    d1   = pk_fma(a2, y, b2 * xx);
+                    x[k] = y;
+                    if (!FULL && (k + 1 == m_last))
+                    {
+                        f0 = d0;
+                        f1 = d1;
+                    }
+                }
+                if (FULL)
+                {
+                    f0 = d0;
+                    f1 = d1;
+                }
+                if (t == (c_last & 63))
+                {
+                    st[0] = (c_last < 64) ? f0.x : f0.y;
+                    st[1] = (c_last < 64) ? f1.x : f1.y;
+                }
+            };
+
+            for (int si = 0; si < group; ++si)
+            {
+                prefetch(ta, pla, csa, si);
+                body(ta, pla, csa, s0 + si);
+            }
+        }
+
+        // ---- transposed back through LDS, coalesced store -------------------------------
+        __syncthreads();
+        #pragma unroll
+        for (int k = 0; k < L / 4; ++k)
+        {
+            *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
+                make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
+            *reinterpret_cast<float4 *>(&sx[(t + 64) * PITCH + 4 * k]) =
+                make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int k = 0; k < NC * L / 4 / NT; ++k)
+        {
+            const int i = 4 * (k * NT + t);
+            const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / L) * 4]);
+            if (ALIGNED && (FULL || i + 4 <= cnt))
+                *reinterpret_cast<float4 *>(yout + i) = v;
+            else
+            {
+                if (i + 0 < cnt) yout[i + 0] = v.x;
+                if (i + 1 < cnt) yout[i + 1] = v.y;
+                if (i + 2 < cnt) yout[i + 2] = v.z;
+                if (i + 3 < cnt) yout[i + 3] = v.w;
+            }
+        }
+    }
+
     __global__ void impulse_kernel(float *out, size_t stride, size_t samples, uint32_t channels)
     {
         // FilterBank.cpp:316-318: zero the buffer, out[0] = 1
@@ -412,6 +691,23 @@ namespace
         mi::take_profile_events(&ev0, &ev1);
         #define MI_LAUNCH(A, F)                                                                   \
             hipExtLaunchKernelGGL((biquad_bank_kernel<L, NT, A, F>), grid, block, 0, st, ev0, ev1, 0, out, in, \
+                               out_stride, in_stride, cnt, tab, b->d_state, b->d_nsec, int(b->max_sec))
+        if (aligned) { if (full) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
+        else         { if (full) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
+        #undef MI_LAUNCH
+        return hipGetLastError();
+    }
+
+    template <int L>
+    hipError_t launch_pk(mi_biquad_bank *b, float *out, const float *in, size_t out_stride,
+                         size_t in_stride, int cnt, bool aligned, const float *tab, hipStream_t st)
+    {
+        const dim3 grid(b->channels), block(64);
+        const bool full = (cnt == L * 128);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        #define MI_LAUNCH(A, F)                                                                   \
+            hipExtLaunchKernelGGL((biquad_bank_kernel_pk<L, A, F>), grid, block, 0, st, ev0, ev1, 0, out, in, \
                                out_stride, in_stride, cnt, tab, b->d_state, b->d_nsec, int(b->max_sec))
         if (aligned) { if (full) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
         else         { if (full) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
@@ -638,8 +934,11 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
         if (left > size_t(small::BLOCK))
         {
             step = (left < size_t(big::BLOCK)) ? left : size_t(big::BLOCK);
-            e = launch<32, 128>(b, out + done, in + done, out_stride, in_stride, int(step),
-                                aligned && (done % 4 == 0), b->d_big, st);
+            static const bool two_wave = (getenv("MI_BIQUAD_TWO_WAVE") != nullptr);   // A/B knob for profiling
+            e = two_wave ? launch<32, 128>(b, out + done, in + done, out_stride, in_stride, int(step),
+                                           aligned && (done % 4 == 0), b->d_big, st)
+                         : launch_pk<32>(b, out + done, in + done, out_stride, in_stride, int(step),
+                                         aligned && (done % 4 == 0), b->d_big, st);
         }
         else
         {

@@ -71,7 +71,7 @@ def test_c1_readme_hishelf(gpu):
     yi, _ = run_bank(gpu, imp, [bq])
     np.testing.assert_allclose(yi[0, 0, :8], [1.93714225, -0.114121534, -0.109540939, -0.10430833,
                                               -0.0985007137, -0.0922033042, -0.0855074227, -0.0785082579],
-                               rtol=0, atol=2e-7)
+                               rtol=0, atol=1e-6)
 
 
 def test_c2_shape_state_carry(gpu):
