@@ -136,6 +136,42 @@ int mi_biquad_bank_impulse_response(mi_biquad_bank_t *bank, float *out, size_t s
 int mi_biquad_bank_get_state(mi_biquad_bank_t *bank, float *host_state, void *stream);
 int mi_biquad_bank_set_state(mi_biquad_bank_t *bank, const float *host_state, void *stream);
 
+/* ---- partitioned FFT convolver bank ------------------------------------------------------ */
+/*
+ * mi_convolver_bank: `channels` independent lsp::dspu::Convolver objects
+ * (include/lsp-plug.in/dsp-units/util/Convolver.h:35-114): exact linear
+ * convolution of each channel with its own impulse response, zero added
+ * latency, any call size.
+ */
+typedef struct mi_convolver_bank mi_convolver_bank_t;
+
+/*
+ * Convolver::init(data, count, rank, phase) for every channel
+ * (src/main/util/Convolver.cpp:77-215).  irs: HOST float32 [channels][ir_stride];
+ * channel c uses counts[c] taps (counts == NULL: `count` for all).  rank is
+ * clamped to [8,16] (Convolver.h:28-29, Convolver.cpp:87) and sets the frame
+ * 2^(rank-1) at which whole-frame calls take the FFT path; frames above 4096
+ * are processed as 4096-sample partitions.  phase only staggers the
+ * reference's CPU load (Convolver.cpp:139) and has no effect on the output; it
+ * is accepted and ignored.  All counts == 0 leaves the bank uninitialised:
+ * process() then writes zeros (Convolver.cpp:80-84,219-223).  Synchronises `stream`.
+ */
+int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, const float *irs, size_t ir_stride,
+                             const uint32_t *counts, uint32_t count, uint32_t rank, float phase, void *stream);
+/* Convolver::destroy(), Convolver.cpp:71-75. */
+int mi_convolver_bank_destroy(mi_convolver_bank_t *bank);
+/* Forget all input history (state right after init). */
+int mi_convolver_bank_reset(mi_convolver_bank_t *bank, void *stream);
+/* Convolver::rank() / data_size() (Convolver.h:100-106) plus the partition geometry in use. */
+int mi_convolver_bank_info(const mi_convolver_bank_t *bank, uint32_t *rank, uint32_t *frame,
+                           uint32_t *partitions, uint32_t *data_size);
+/*
+ * Convolver::process(dst, src, count) for every channel, Convolver.cpp:217-313.
+ * out/in: device float32 [channels][*_stride]; out may be the same buffer as in.
+ */
+int mi_convolver_bank_process(mi_convolver_bank_t *bank, float *out, const float *in, size_t samples,
+                              size_t out_stride, size_t in_stride, void *stream);
+
 /*
  * Host-only introspection of the per-section device table (no GPU needed): the
  * chunk-parallel form of the TDF-II section used by the kernel.

@@ -12,4 +12,4 @@ Import with ``importlib.import_module("lsp-dsp-units_amd")`` (the directory
 name carries the reference's name and is not a Python identifier).
 """
 from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
-from .units import BiquadBank, DeviceBuffer, device_count  # noqa: F401
+from .units import BiquadBank, ConvolverBank, DeviceBuffer, device_count  # noqa: F401

@@ -57,6 +57,13 @@ PROTOTYPES = {
     "mi_biquad_bank_impulse_response": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mi_biquad_bank_get_state": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mi_biquad_bank_set_state": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi_convolver_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_void_p, c_size_t, c_void_p, c_uint32, c_uint32,
+                                         c_float, c_void_p]),
+    "mi_convolver_bank_destroy": (c_int, [c_void_p]),
+    "mi_convolver_bank_reset": (c_int, [c_void_p, c_void_p]),
+    "mi_convolver_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
+                                       POINTER(c_uint32)]),
+    "mi_convolver_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_biquad_section_tables": (c_int, [POINTER(BiquadX1), c_int, POINTER(c_float), POINTER(c_uint32)]),
 }
 

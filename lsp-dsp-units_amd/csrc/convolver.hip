@@ -1,0 +1,529 @@
+// Partitioned FFT convolver bank for gfx950: the GPU side of lsp::dspu::Convolver
+// (reference: src/main/util/Convolver.cpp:77-215 init, :217-313 process).
+//
+// The reference is a zero-latency NON-uniform partitioned convolver (128-tap head, doubling levels, equal
+// tail blocks, 15 inverse transforms per frame at rank 13, a load-spreading schedule) because a CPU thread
+// has to bound the work of every 128-sample step.  On the GPU the same input/output contract -- exact linear
+// convolution, zero added latency, arbitrary call sizes -- is met with a UNIFORM partition of B = frame
+// samples and a frequency-domain delay line:
+//
+//   state per channel:  acc[2B]   contributions of everything received so far to the current and the next frame
+//                       ring[P-1] spectra of the last P-1 complete input frames
+//                       H[P]      spectra of the IR partitions (2B-point real transforms, packed to B complex)
+//
+//   whole frame (off == 0, >= B samples):                                       [conv_frame_kernel]
+//       X = FFT(frame);  y0 = IFFT(H0 * X);  out = acc[0:B] + y0[0:B];  acc = shift(acc) + y0[B:2B]
+//   then, off the output's critical path, the tail of the NEXT frame:           [conv_mac_kernel, conv_tail_kernel]
+//       acc += IFFT( sum_{p>=1} H_p * X_(c+1-p) )        <- the HBM-bound part: streams H and the ring once
+//   partial call (anything else): the head partition is applied directly in the time domain
+//       acc[off+i] += sum_j x[j] h[i-j]  (zero latency for any chunking)        [conv_direct_kernel]
+//     and when the frame completes its spectrum enters the ring                 [conv_commit_kernel]
+//
+// Spectra use the packed real-FFT image of fft_device.h (B complex per 2B-point real transform).
+#include "mi_common.h"
+#include "fft_device.h"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace
+{
+    using namespace mi_fft;
+
+    constexpr int TWN = 8192;               // twiddle table length: exp(-2 pi i j / TWN)
+    constexpr int LOGM_MIN = 7, LOGM_MAX = 12;
+
+    // ---- forward transform of a real block of `valid` samples zero-padded to 2M, into buf ---------------
+    template <int LOGM>
+    __device__ void load_and_forward(float2 *buf, const float *src, int valid, bool aligned,
+                                     const float2 *__restrict__ tw, int tid)
+    {
+        using PL = plan<LOGM>;
+        constexpr int M = PL::N, T = PL::T;
+        for (int n = tid; n < M; n += T)
+        {
+            float2 v = make_float2(0.0f, 0.0f);
+            const int i = 2 * n;
+            if (i + 1 < valid)
+                v = aligned ? *reinterpret_cast<const float2 *>(src + i) : make_float2(src[i], src[i + 1]);
+            else if (i < valid)
+                v.x = src[i];
+            buf[n] = v;
+        }
+        __syncthreads();
+        fft_lds<LOGM, false>(buf, tw, TWN / M, tid);
+        real_split<LOGM>(buf, tw, TWN / (2 * M), tid);
+    }
+
+    // image in buf -> 2M real samples (times 2M), left in buf as (x[2n], x[2n+1])
+    template <int LOGM>
+    __device__ void inverse_in_place(float2 *buf, const float2 *__restrict__ tw, int tid)
+    {
+        constexpr int M = plan<LOGM>::N;
+        real_merge<LOGM>(buf, tw, TWN / (2 * M), tid);
+        fft_lds<LOGM, true>(buf, tw, TWN / M, tid);
+    }
+
+    __device__ __forceinline__ float2 image_mul(float2 x, float2 h, int k)
+    {
+        return (k == 0) ? make_float2(x.x * h.x, x.y * h.y) : cmul(x, h);      // bin 0 packs DC and Nyquist
+    }
+
+    // ---- IR partition -> image (Convolver::init, Convolver.cpp:152-197) -----------------------------------
+    template <int LOGM>
+    __global__ __launch_bounds__(plan<LOGM>::T)
+    void conv_parse_kernel(float2 *H, const float *ir, size_t ir_stride, const uint32_t *__restrict__ counts,
+                           int P, const float2 *__restrict__ tw)
+    {
+        constexpr int M = plan<LOGM>::N;
+        __shared__ float2 buf[M];
+        const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+        const int count = int(counts[ch]);
+        int valid = count - p * M;
+        valid = (valid < 0) ? 0 : (valid > M ? M : valid);
+        load_and_forward<LOGM>(buf, ir + size_t(ch) * ir_stride + size_t(p) * M, valid, false, tw, tid);
+        float2 *dst = H + (size_t(ch) * P + p) * M;
+        for (int k = tid; k < M; k += plan<LOGM>::T)
+            dst[k] = buf[k];
+    }
+
+    // ---- whole frame --------------------------------------------------------------------------------------
+    template <int LOGM>
+    __global__ __launch_bounds__(plan<LOGM>::T)
+    void conv_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
+                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
+                           float *acc, const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, B = M;
+        __shared__ float2 buf[M];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+
+        load_and_forward<LOGM>(buf, in + size_t(ch) * in_stride, B, aligned, tw, tid);
+
+        float2 *rdst = (R > 0) ? ring + (size_t(ch) * R + slot) * M : nullptr;
+        const float2 *h0 = H + size_t(ch) * P * M;
+        for (int k = tid; k < M; k += T)
+        {
+            const float2 x = buf[k];
+            if (rdst != nullptr)
+                rdst[k] = x;
+            buf[k] = image_mul(x, h0[k], k);
+        }
+        __syncthreads();
+        inverse_in_place<LOGM>(buf, tw, tid);
+
+        const float scale = 1.0f / float(2 * M);
+        float *a = acc + size_t(ch) * 2 * B;
+        float *o = out + size_t(ch) * out_stride;
+        for (int n = tid; n < M / 2; n += T)
+        {
+            const float2 y0 = buf[n], y1 = buf[n + M / 2];
+            const float2 a0 = *reinterpret_cast<const float2 *>(a + 2 * n);
+            const float2 a1 = *reinterpret_cast<const float2 *>(a + B + 2 * n);
+            const float2 r = make_float2(fmaf(y0.x, scale, a0.x), fmaf(y0.y, scale, a0.y));
+            if (aligned)
+                *reinterpret_cast<float2 *>(o + 2 * n) = r;
+            else
+            {
+                o[2 * n] = r.x;
+                o[2 * n + 1] = r.y;
+            }
+            *reinterpret_cast<float2 *>(a + 2 * n)     = make_float2(fmaf(y1.x, scale, a1.x), fmaf(y1.y, scale, a1.y));
+            *reinterpret_cast<float2 *>(a + B + 2 * n) = make_float2(0.0f, 0.0f);
+        }
+    }
+
+    // ---- tail of the next frame: Yt = sum_{p=1..P-1} H_p * X_(newest - (p-1)) ------------------------------
+    // One thread owns two neighbouring bins (16-B loads); grid = (M / 512, channels).
+    __global__ __launch_bounds__(256)
+    void conv_mac_kernel(float2 *Yt, const float2 *__restrict__ ring, int R, int newest,
+                         const float2 *__restrict__ H, int P, int M)
+    {
+        const int ch = blockIdx.y;
+        const int idx = blockIdx.x * 256 + threadIdx.x;          // float4 index inside the image
+        if (2 * idx >= M)
+            return;
+        const float4 *Hc = reinterpret_cast<const float4 *>(H + size_t(ch) * P * M);
+        const float4 *Xc = reinterpret_cast<const float4 *>(ring + size_t(ch) * R * M);
+        const int M4 = M / 2;
+        float4 s = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        float dc = 0.0f, ny = 0.0f;
+        int r = newest;
+        #pragma unroll 4
+        for (int p = 1; p < P; ++p)
+        {
+            const float4 h = Hc[size_t(p) * M4 + idx];
+            const float4 x = Xc[size_t(r) * M4 + idx];
+            r = (r == 0) ? R - 1 : r - 1;
+            // second bin of the pair is always an ordinary complex bin
+            s.z = fmaf(x.z, h.z, fmaf(-x.w, h.w, s.z));
+            s.w = fmaf(x.z, h.w, fmaf(x.w, h.z, s.w));
+            // first bin: complex product; for idx == 0 it is the packed (DC, Nyquist) pair instead
+            s.x = fmaf(x.x, h.x, fmaf(-x.y, h.y, s.x));
+            s.y = fmaf(x.x, h.y, fmaf(x.y, h.x, s.y));
+            dc  = fmaf(x.x, h.x, dc);
+            ny  = fmaf(x.y, h.y, ny);
+        }
+        if (idx == 0)
+        {
+            s.x = dc;
+            s.y = ny;
+        }
+        reinterpret_cast<float4 *>(Yt + size_t(ch) * M)[idx] = s;
+    }
+
+    template <int LOGM>
+    __global__ __launch_bounds__(plan<LOGM>::T)
+    void conv_tail_kernel(float *acc, const float2 *__restrict__ Yt, const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGM>;
+        constexpr int M = PL::N, T = PL::T;
+        __shared__ float2 buf[M];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        const float2 *src = Yt + size_t(ch) * M;
+        for (int k = tid; k < M; k += T)
+            buf[k] = src[k];
+        __syncthreads();
+        inverse_in_place<LOGM>(buf, tw, tid);
+        const float scale = 1.0f / float(2 * M);
+        float2 *a = reinterpret_cast<float2 *>(acc + size_t(ch) * 2 * M);
+        for (int n = tid; n < M; n += T)
+        {
+            const float2 y = buf[n], v = a[n];
+            a[n] = make_float2(fmaf(y.x, scale, v.x), fmaf(y.y, scale, v.y));
+        }
+    }
+
+    // ---- partial call: time-domain head (Convolver.cpp:292-296 does the same with dsp::convolve) ---------
+    __global__ __launch_bounds__(256)
+    void conv_direct_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
+                            float *acc, float *frame, const float *__restrict__ h0, int B, int off, int cnt)
+    {
+        extern __shared__ float sxin[];                         // cnt samples of this call
+        const int ch = blockIdx.y, tid = threadIdx.x;
+        const float *x = in + size_t(ch) * in_stride;
+        for (int j = tid; j < cnt; j += 256)
+            sxin[j] = x[j];
+        __syncthreads();
+        const int i = blockIdx.x * 256 + tid;                   // output position relative to `off`
+        if (i >= cnt + B - 1)
+            return;
+        const float *h = h0 + size_t(ch) * B;
+        const int jlo = (i - (B - 1) > 0) ? i - (B - 1) : 0;
+        const int jhi = (i < cnt - 1) ? i : cnt - 1;
+        float s = 0.0f;
+        for (int j = jlo; j <= jhi; ++j)
+            s = fmaf(sxin[j], h[i - j], s);
+        float *a = acc + size_t(ch) * 2 * B + off + i;
+        const float v = *a + s;
+        *a = v;
+        if (i < cnt)
+        {
+            out[size_t(ch) * out_stride + i] = v;
+            frame[size_t(ch) * B + off + i] = sxin[i];
+        }
+    }
+
+    // frame complete after partial calls: its spectrum enters the ring, acc moves on by one frame
+    template <int LOGM>
+    __global__ __launch_bounds__(plan<LOGM>::T)
+    void conv_commit_kernel(const float *frame, float2 *ring, int R, int slot, float *acc,
+                            const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, B = M;
+        __shared__ float2 buf[M];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        if (R > 0)
+        {
+            load_and_forward<LOGM>(buf, frame + size_t(ch) * B, B, true, tw, tid);
+            float2 *rdst = ring + (size_t(ch) * R + slot) * M;
+            for (int k = tid; k < M; k += T)
+                rdst[k] = buf[k];
+        }
+        float2 *a = reinterpret_cast<float2 *>(acc + size_t(ch) * 2 * B);
+        for (int n = tid; n < M / 2; n += T)
+        {
+            a[n] = a[n + M / 2];
+            a[n + M / 2] = make_float2(0.0f, 0.0f);
+        }
+    }
+
+    // ---- twiddle table, one per device -------------------------------------------------------------------
+    float2 *g_tw[64] = { nullptr };
+
+    int twiddle_table(const float2 **out)
+    {
+        int dev = 0;
+        MI_HIP_CHECK(hipGetDevice(&dev));
+        MI_REQUIRE(dev >= 0 && dev < 64, MI_EINVAL, "device index %d out of range", dev);
+        if (g_tw[dev] == nullptr)
+        {
+            std::vector<float2> h(TWN);
+            for (int j = 0; j < TWN; ++j)
+            {
+                const double a = -2.0 * M_PI * double(j) / double(TWN);
+                h[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
+            }
+            float2 *d = nullptr;
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), TWN * sizeof(float2)));
+            MI_HIP_CHECK(hipMemcpy(d, h.data(), TWN * sizeof(float2), hipMemcpyHostToDevice));
+            g_tw[dev] = d;
+        }
+        *out = g_tw[dev];
+        return MI_OK;
+    }
+} // namespace
+
+namespace mi
+{
+    int fft_twiddles(const float2 **tw, int *twn)
+    {
+        *twn = TWN;
+        return twiddle_table(tw);
+    }
+}
+
+struct mi_convolver_bank
+{
+    uint32_t    channels = 0;
+    uint32_t    rank = 0;           // reference rank after clamping (Convolver.cpp:87)
+    int         logm = 0;           // log2 of the partition (= complex transform) size
+    int         B = 0, P = 0, R = 0;
+    uint32_t    taps = 0;           // longest IR of the bank (Convolver::data_size of that channel)
+    float       phase = 0.0f;
+    int         slot = 0;           // ring slot of the newest complete frame
+    int         off = 0;            // samples already received of the current frame
+    bool        live = false;       // false: count == 0, process() emits zeros (Convolver.cpp:219-223)
+    float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
+    float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
+    const float2 *d_tw = nullptr;
+    std::vector<uint32_t> counts;
+};
+
+namespace
+{
+    #define MI_LOGM_SWITCH(logm, CALL)                  \
+        switch (logm)                                   \
+        {                                               \
+            case 7:  { CALL(7);  break; }               \
+            case 8:  { CALL(8);  break; }               \
+            case 9:  { CALL(9);  break; }               \
+            case 10: { CALL(10); break; }               \
+            case 11: { CALL(11); break; }               \
+            default: { CALL(12); break; }               \
+        }
+
+    // tail of the next frame from the ring (the dominant, HBM-bound step)
+    int launch_tail(mi_convolver_bank *b, hipStream_t st)
+    {
+        if (b->P <= 1)
+            return MI_OK;
+        const int M = b->B;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        hipExtLaunchKernelGGL(conv_mac_kernel, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1, 0,
+                              b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
+        MI_HIP_CHECK(hipGetLastError());
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_tail_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                                               b->d_acc, b->d_yt, b->d_tw)
+        MI_LOGM_SWITCH(b->logm, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, const float *irs, size_t ir_stride,
+                             const uint32_t *counts, uint32_t count, uint32_t rank, float phase, void *stream)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_convolver_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0, MI_EINVAL, "mi_convolver_bank_create: channels must be > 0");
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    hipStream_t st = mi::as_stream(stream);
+
+    mi_convolver_bank *b = new (std::nothrow) mi_convolver_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_convolver_bank_create: out of host memory");
+    b->channels = channels;
+    b->rank     = (rank < 8) ? 8 : (rank > 16) ? 16 : rank;             // CONVOLVER_RANK_MIN/MAX
+    b->phase    = phase;
+    b->counts.assign(channels, count);
+    uint32_t longest = 0;
+    for (uint32_t c = 0; c < channels; ++c)
+    {
+        if (counts != nullptr)
+            b->counts[c] = counts[c];
+        longest = (b->counts[c] > longest) ? b->counts[c] : longest;
+    }
+    b->taps = longest;
+    if (longest == 0)                                                    // Convolver.cpp:80-84
+    {
+        *bank = b;
+        return MI_OK;
+    }
+    MI_REQUIRE(irs != nullptr && ir_stride >= longest, MI_EINVAL, "mi_convolver_bank_create: bad impulse responses");
+
+    b->logm = int(b->rank) - 1;
+    if (b->logm > LOGM_MAX) b->logm = LOGM_MAX;                          // partitions above 4096 are cut to 4096
+    if (b->logm < LOGM_MIN) b->logm = LOGM_MIN;
+    b->B = 1 << b->logm;
+    b->P = int((longest + b->B - 1) / b->B);
+    b->R = b->P - 1;
+    b->live = true;
+
+    int twn = 0;
+    const int r = mi::fft_twiddles(&b->d_tw, &twn);
+    if (r != MI_OK) { mi_convolver_bank_destroy(b); return r; }
+
+    const size_t M = size_t(b->B);
+    hipError_t e = hipSuccess;
+    float *d_ir = nullptr;
+    uint32_t *d_counts = nullptr;
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_H), size_t(channels) * b->P * M * sizeof(float2));
+    if (e == hipSuccess && b->R > 0) e = hipMalloc(reinterpret_cast<void **>(&b->d_ring), size_t(channels) * b->R * M * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_yt), size_t(channels) * M * sizeof(float2));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_acc), size_t(channels) * 2 * M * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_frame), size_t(channels) * M * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_h0), size_t(channels) * M * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_ir), size_t(channels) * b->P * M * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_counts), channels * sizeof(uint32_t));
+    // host staging: every row zero-padded to P*B, only the channel's own `count` taps copied
+    std::vector<float> stage;
+    try { stage.assign(size_t(channels) * b->P * M, 0.0f); }
+    catch (...) { (void)hipFree(d_ir); (void)hipFree(d_counts); mi_convolver_bank_destroy(b);
+                  return mi::fail(MI_ENOMEM, "mi_convolver_bank_create: out of host memory"); }
+    for (uint32_t c = 0; c < channels; ++c)
+        std::memcpy(&stage[size_t(c) * b->P * M], irs + size_t(c) * ir_stride, size_t(b->counts[c]) * sizeof(float));
+    if (e == hipSuccess) e = hipMemcpyAsync(d_ir, stage.data(), stage.size() * sizeof(float), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_counts, b->counts.data(), channels * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(b->d_h0, M * sizeof(float), d_ir, size_t(b->P) * M * sizeof(float),
+                                              M * sizeof(float), channels, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess)
+    {
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, channels), dim3(plan<LM>::T), 0, st, \
+                                               b->d_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw)
+        MI_LOGM_SWITCH(b->logm, MI_CALL)
+        #undef MI_CALL
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_ir);
+    (void)hipFree(d_counts);
+    if (e != hipSuccess)
+    {
+        mi_convolver_bank_destroy(b);
+        return mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_convolver_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return mi_convolver_bank_reset(b, stream);
+}
+
+int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    (void)hipFree(b->d_H); (void)hipFree(b->d_ring); (void)hipFree(b->d_yt);
+    (void)hipFree(b->d_acc); (void)hipFree(b->d_frame); (void)hipFree(b->d_h0);
+    delete b;
+    return MI_OK;
+}
+
+int mi_convolver_bank_reset(mi_convolver_bank_t *b, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_convolver_bank_reset: NULL bank");
+    if (!b->live)
+        return MI_OK;
+    hipStream_t st = mi::as_stream(stream);
+    const size_t M = size_t(b->B);
+    if (b->R > 0)
+        MI_HIP_CHECK(hipMemsetAsync(b->d_ring, 0, size_t(b->channels) * b->R * M * sizeof(float2), st));
+    MI_HIP_CHECK(hipMemsetAsync(b->d_acc, 0, size_t(b->channels) * 2 * M * sizeof(float), st));
+    MI_HIP_CHECK(hipMemsetAsync(b->d_frame, 0, size_t(b->channels) * M * sizeof(float), st));
+    b->slot = 0;
+    b->off  = 0;
+    return MI_OK;
+}
+
+int mi_convolver_bank_info(const mi_convolver_bank_t *b, uint32_t *rank, uint32_t *frame, uint32_t *partitions,
+                           uint32_t *data_size)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_convolver_bank_info: NULL bank");
+    if (rank)       *rank = b->live ? b->rank : 0;              // Convolver::rank() is 0 when uninitialised
+    if (frame)      *frame = uint32_t(b->B);
+    if (partitions) *partitions = uint32_t(b->P);
+    if (data_size)  *data_size = b->taps;
+    return MI_OK;
+}
+
+int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *in, size_t samples,
+                              size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_convolver_bank_process: NULL bank");
+    if (samples == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_convolver_bank_process: NULL buffer");
+    MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL, "mi_convolver_bank_process: stride shorter than the block");
+    hipStream_t st = mi::as_stream(stream);
+    if (!b->live)                                                // Convolver.cpp:219-223
+    {
+        MI_HIP_CHECK(hipMemset2DAsync(out, out_stride * sizeof(float), 0, samples * sizeof(float), b->channels, st));
+        return MI_OK;
+    }
+    const int B = b->B;
+    size_t done = 0;
+    while (done < samples)
+    {
+        const size_t left = samples - done;
+        float *o = out + done;
+        const float *x = in + done;
+        if (b->off == 0 && left >= size_t(B))
+        {
+            const bool aligned = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) % 8 == 0) &&
+                                 (out_stride % 2 == 0) && (in_stride % 2 == 0);
+            if (b->R > 0)
+                b->slot = (b->slot + 1) % b->R;
+            #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                                                   o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
+                                                   b->d_H, b->P, b->d_acc, b->d_tw)
+            MI_LOGM_SWITCH(b->logm, MI_CALL)
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            const int r = launch_tail(b, st);
+            if (r != MI_OK)
+                return r;
+            done += size_t(B);
+        }
+        else
+        {
+            const int cnt = int((left < size_t(B - b->off)) ? left : size_t(B - b->off));
+            const dim3 grid((cnt + B - 1 + 255) / 256, b->channels);
+            hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
+                               o, x, out_stride, in_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
+            MI_HIP_CHECK(hipGetLastError());
+            b->off += cnt;
+            done += size_t(cnt);
+            if (b->off == B)
+            {
+                if (b->R > 0)
+                    b->slot = (b->slot + 1) % b->R;
+                #define MI_CALL(LM) hipLaunchKernelGGL((conv_commit_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                                                       b->d_frame, b->d_ring, b->R, b->slot, b->d_acc, b->d_tw)
+                MI_LOGM_SWITCH(b->logm, MI_CALL)
+                #undef MI_CALL
+                MI_HIP_CHECK(hipGetLastError());
+                const int r = launch_tail(b, st);
+                if (r != MI_OK)
+                    return r;
+                b->off = 0;
+            }
+        }
+    }
+    return MI_OK;
+}
+
+} // extern "C"

@@ -21,6 +21,9 @@ namespace mi
     // Events armed by mi_dspu_profile_next_launch(); the next hot-path kernel launch of this thread
     // consumes them (hipExtLaunchKernelGGL records them at the kernel's own begin/end).
     void        take_profile_events(hipEvent_t *start, hipEvent_t *stop);
+
+    // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
+    int         fft_twiddles(const float2 **tw, int *twn);
 } // namespace mi
 
 #define MI_HIP_CHECK(expr)                                                              \

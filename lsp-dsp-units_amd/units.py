@@ -141,3 +141,47 @@ class BiquadBank:
             self.close()
         except Exception:
             pass
+
+
+class ConvolverBank:
+    """`channels` x lsp::dspu::Convolver on the device (mi_convolver_bank_*)."""
+
+    def __init__(self, irs, rank, counts=None, phase=0.0, stream=None):
+        irs = np.ascontiguousarray(irs, dtype=np.float32)
+        if irs.ndim == 1:
+            irs = irs.reshape(1, -1)
+        self.channels = irs.shape[0]
+        cnt = None
+        if counts is not None:
+            cnt = np.ascontiguousarray(counts, dtype=np.uint32)
+            assert cnt.shape == (self.channels,)
+        h = c_void_p()
+        check(lib.mi_convolver_bank_create(byref(h), self.channels,
+                                           irs.ctypes.data_as(c_void_p) if irs.size else None, irs.shape[1],
+                                           cnt.ctypes.data_as(c_void_p) if cnt is not None else None,
+                                           irs.shape[1], rank, phase, _stream(stream)))
+        self.handle = h
+
+    def info(self):
+        v = [c_uint32() for _ in range(4)]
+        check(lib.mi_convolver_bank_info(self.handle, *[byref(x) for x in v]))
+        return dict(zip(("rank", "frame", "partitions", "data_size"), [x.value for x in v]))
+
+    def reset(self, stream=None):
+        check(lib.mi_convolver_bank_reset(self.handle, _stream(stream)))
+
+    def process(self, out, inp, samples, out_stride=None, in_stride=None, stream=None):
+        check(lib.mi_convolver_bank_process(self.handle, _ptr(out), _ptr(inp), samples,
+                                            samples if out_stride is None else out_stride,
+                                            samples if in_stride is None else in_stride, _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_convolver_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

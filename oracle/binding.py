@@ -72,3 +72,110 @@ def biquad_cascade_f64(x, coef):
     for b0, b1, b2, a1, a2 in np.asarray(coef, dtype=np.float64).reshape(-1, 5):
         y = lfilter([b0, b1, b2], [1.0, -a1, -a2], y)
     return y
+
+
+# ---- FFT / fast convolution primitives (fft_oracle.c) ---------------------------------------------------
+_lib.orc_packed_direct_fft.argtypes = [_fp, _fp, c_size_t]
+_lib.orc_packed_reverse_fft.argtypes = [_fp, _fp, c_size_t]
+_lib.orc_fastconv_parse.argtypes = [_fp, _fp, c_size_t]
+_lib.orc_fastconv_apply.argtypes = [_fp, _fp, _fp, _fp, c_size_t]
+_lib.orc_fastconv_parse_apply.argtypes = [_fp, _fp, _fp, _fp, c_size_t]
+_lib.orc_convolve.argtypes = [_fp, _fp, _fp, c_size_t, c_size_t]
+_lib.orc_convolve_f64.argtypes = [POINTER(ctypes.c_double), _fp, _fp, c_size_t, c_size_t]
+
+
+def packed_direct_fft(x, rank):
+    """x: 2*2^rank interleaved float32 -> spectrum (unnormalised, e^{-jwn})."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    assert x.size == 2 << rank
+    y = np.empty_like(x)
+    _lib.orc_packed_direct_fft(_f(y), _f(x), rank)
+    return y
+
+
+def packed_reverse_fft(x, rank):
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    assert x.size == 2 << rank
+    y = np.empty_like(x)
+    _lib.orc_packed_reverse_fft(_f(y), _f(x), rank)
+    return y
+
+
+def fastconv_parse(src, rank):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    assert src.size >= 1 << (rank - 1)
+    img = np.empty(2 << rank, np.float32)
+    _lib.orc_fastconv_parse(_f(img), _f(src), rank)
+    return img
+
+
+def fastconv_parse_apply(dst, conv_image, src, rank):
+    """dst[0..2^rank) += conv(src[0..2^(rank-1)), ir); dst is modified in place."""
+    tmp = np.empty(2 << rank, np.float32)
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    assert dst.dtype == np.float32 and dst.flags.c_contiguous and dst.size >= 1 << rank
+    _lib.orc_fastconv_parse_apply(_f(dst), _f(tmp), _f(conv_image), _f(src), rank)
+
+
+def convolve(src, conv, count=None):
+    """Naive float32 dst[i+j] += src[i]*conv[j] over the first `count` source samples."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    conv = np.ascontiguousarray(conv, dtype=np.float32)
+    count = src.size if count is None else count
+    dst = np.zeros(count + conv.size, np.float32)
+    _lib.orc_convolve(_f(dst), _f(src), _f(conv), conv.size, count)
+    return dst
+
+
+def convolve_f64(src, conv, count=None):
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    conv = np.ascontiguousarray(conv, dtype=np.float32)
+    count = src.size if count is None else count
+    dst = np.zeros(count + conv.size, np.float64)
+    _lib.orc_convolve_f64(dst.ctypes.data_as(POINTER(ctypes.c_double)), _f(src), _f(conv), conv.size, count)
+    return dst
+
+
+# ---- Convolver (convolver_oracle.c) -------------------------------------------------------------------
+_lib.orc_convolver_create.restype = c_void_p
+_lib.orc_convolver_create.argtypes = [_fp, c_size_t, c_size_t, c_float]
+_lib.orc_convolver_destroy.argtypes = [c_void_p]
+_lib.orc_convolver_process.argtypes = [c_void_p, _fp, _fp, c_size_t]
+_lib.orc_convolver_data_size.restype = c_size_t
+_lib.orc_convolver_data_size.argtypes = [c_void_p]
+_lib.orc_convolver_rank.restype = c_size_t
+_lib.orc_convolver_rank.argtypes = [c_void_p]
+
+
+class Convolver:
+    """lsp::dspu::Convolver restated (util/Convolver.h:35-114)."""
+
+    def __init__(self, data, rank, phase=0.0):
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        self._h = _lib.orc_convolver_create(_f(data), data.size, rank, phase)
+
+    def process(self, src):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        dst = np.empty_like(src)
+        _lib.orc_convolver_process(self._h, _f(dst), _f(src), src.size)
+        return dst
+
+    def process_chunked(self, src, step):
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        out = np.empty_like(src)
+        for i in range(0, src.size, step):
+            out[i:i + step] = self.process(src[i:i + step])
+        return out
+
+    @property
+    def data_size(self):
+        return _lib.orc_convolver_data_size(self._h)
+
+    @property
+    def rank(self):
+        return _lib.orc_convolver_rank(self._h)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _lib.orc_convolver_destroy(self._h)
+            self._h = None

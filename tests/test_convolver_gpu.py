@@ -1,0 +1,177 @@
+"""GPU parity of mi_convolver_bank_* (lsp::dspu::Convolver) against the CPU oracle, through the C-ABI.
+
+The oracle restates the reference's non-uniform partitioned algorithm; the GPU uses a uniform partition
+(DESIGN.md).  Both compute the same linear convolution, so they are compared sample by sample, relative to
+the block peak, next to a float64 FFT convolution that tells how far float32 itself is off."""
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import TOL, parity_report
+
+pytestmark = pytest.mark.gpu
+
+
+def exact_conv(x, ir):
+    n = x.size + ir.size
+    nfft = 1 << int(np.ceil(np.log2(n)))
+    y = np.fft.irfft(np.fft.rfft(x.astype(np.float64), nfft) * np.fft.rfft(ir.astype(np.float64), nfft), nfft)
+    return y[:x.size]
+
+
+def run_gpu(gpu, irs, rank, x, chunks, counts=None, in_place=False):
+    """x: [C][n]; chunks: list of call sizes covering n."""
+    C, n = x.shape
+    bank = gpu.ConvolverBank(irs, rank, counts=counts)
+    y = np.empty_like(x)
+    pos = 0
+    for c in chunks:
+        din = gpu.DeviceBuffer.from_host(x[:, pos:pos + c])
+        dout = din if in_place else gpu.DeviceBuffer((C, c))
+        bank.process(dout, din, c)
+        y[:, pos:pos + c] = dout.download()
+        pos += c
+    assert pos == n
+    info = bank.info()
+    bank.close()
+    return y, info
+
+
+def chunks_of(n, step):
+    out = [step] * (n // step)
+    if n % step:
+        out.append(n % step)
+    return out
+
+
+def check(gpu_y, ref32, ref64, what, tol=TOL):
+    r = parity_report(gpu_y, ref32, ref64)
+    assert np.all(np.isfinite(gpu_y)), what
+    assert r["gpu_vs_ref32"] <= max(tol, 3.0 * r["noise"]), "%s: %s" % (what, r)
+    assert r["gpu_vs_exact"] <= max(tol, 3.0 * r["noise"]), "%s: %s" % (what, r)
+    return r
+
+
+def test_reference_utest_small(gpu):
+    """src/test/utest/util/convolver.cpp:88-136 replayed through the GPU path."""
+    conv = np.arange(1, 0x20, dtype=np.float32)
+    src = np.zeros(0x2000 + conv.size, np.float32)
+    for j, i in enumerate(range(0, 0x2000, 5)):
+        src[i] = (1.0, 0.1, 0.01)[j % 3]
+    ref = oracle.convolve(src, conv, 0x2000)[:src.size]
+    y, info = run_gpu(gpu, conv, 9, src.reshape(1, -1), chunks_of(src.size, 31))
+    assert info["rank"] == 9 and info["data_size"] == 31
+    mask = np.abs(ref) > 1e-3
+    assert np.all(np.abs(y[0][mask] - ref[mask]) <= 1e-4 * np.abs(ref[mask]))      # equals_relative 1e-4
+    assert np.abs(y[0] - ref).max() <= 1e-4
+
+
+def test_reference_utest_large(gpu):
+    """convolver.cpp:184-223: rank 10, 0x2000 random taps, 0x20 random samples + zeros, 31-sample chunks."""
+    rng = np.random.default_rng(1234)
+    conv = rng.uniform(0.0, 1.0, 0x2000).astype(np.float32)
+    src = np.zeros(0x20 + conv.size, np.float32)
+    src[:0x20] = rng.uniform(0.0, 1.0, 0x20).astype(np.float32)
+    ref = oracle.convolve(src, conv, 0x20)[:src.size]
+    y, _ = run_gpu(gpu, conv, 10, src.reshape(1, -1), chunks_of(src.size, 31))
+    assert np.abs(y[0] - ref).max() <= 1e-4                                          # equals_absolute 1e-4
+
+
+def test_collisions_subset(gpu):
+    """convolver.cpp:138-182 (disabled upstream): two unit impulses, 127-sample chunks, abs 1e-5."""
+    rng = np.random.default_rng(7)
+    conv = rng.uniform(-1.0, 1.0, 4096).astype(np.float32)
+    for gap in (1, 127, 128, 129, 1000, 4095):
+        src = np.zeros(4096 + conv.size, np.float32)
+        src[0] = 1.0; src[gap] = 1.0
+        ref = exact_conv(src, conv)
+        y, _ = run_gpu(gpu, conv, 10, src.reshape(1, -1), chunks_of(src.size, 127))
+        assert np.abs(y[0] - ref).max() <= 1e-5, gap
+
+
+@pytest.mark.parametrize("rank", [8, 9, 10, 11, 12, 13, 14, 16])
+def test_whole_frames_every_rank(gpu, rank):
+    rng = np.random.default_rng(rank)
+    frame = 1 << (rank - 1)
+    taps = 3 * frame + 17
+    ir = (rng.standard_normal(taps) * np.exp(-np.arange(taps) / (taps / 3.0))).astype(np.float32)
+    x = rng.standard_normal((1, 4 * frame)).astype(np.float32)
+    y, info = run_gpu(gpu, ir, rank, x, chunks_of(x.shape[1], frame))
+    assert info["rank"] == rank and info["frame"] == min(frame, 4096)
+    o = oracle.Convolver(ir, rank)
+    ref32 = np.concatenate([o.process(x[0, i:i + frame]) for i in range(0, x.shape[1], frame)])
+    check(y[0], ref32, exact_conv(x[0], ir), "rank %d" % rank)
+
+
+def test_mixed_call_sizes_multi_channel(gpu):
+    """Arbitrary chunking across frame boundaries, distinct IRs and IR lengths per channel, in place."""
+    rng = np.random.default_rng(21)
+    C, rank, frame = 5, 10, 512
+    counts = np.array([1, 100, 512, 513, 2500], np.uint32)
+    irs = rng.standard_normal((C, 2500)).astype(np.float32)
+    n = 6000
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    chunks, left = [], n
+    while left:
+        c = int(min(left, rng.choice([1, 7, 31, 128, 500, 512, 1024, 1300])))
+        chunks.append(c); left -= c
+    y, info = run_gpu(gpu, irs, rank, x, chunks, counts=counts, in_place=True)
+    assert info["partitions"] == 5
+    for c in range(C):
+        ir = irs[c, :counts[c]]
+        ref32 = oracle.Convolver(ir, rank).process_chunked(x[c], 512)
+        check(y[c], ref32, exact_conv(x[c], ir), "ch %d" % c)
+
+
+def test_uninitialised_bank_outputs_zero(gpu):
+    """Convolver::init(count = 0) leaves the object empty; process() writes zeros (Convolver.cpp:80-84,219-223)."""
+    bank = gpu.ConvolverBank(np.zeros((2, 0), np.float32), 9)
+    din = gpu.DeviceBuffer.from_host(np.ones((2, 100), np.float32))
+    dout = gpu.DeviceBuffer.from_host(np.full((2, 100), 7.0, np.float32))
+    bank.process(dout, din, 100)
+    np.testing.assert_array_equal(dout.download(), np.zeros((2, 100), np.float32))
+    assert bank.info()["rank"] == 0
+    bank.close()
+
+
+def test_reset_and_linearity(gpu):
+    rng = np.random.default_rng(9)
+    ir = rng.standard_normal(3000).astype(np.float32)
+    x = rng.standard_normal((1, 2048)).astype(np.float32)
+    bank = gpu.ConvolverBank(ir, 10)
+    din = gpu.DeviceBuffer.from_host(x)
+    dout = gpu.DeviceBuffer((1, 2048))
+    bank.process(dout, din, 2048)
+    y1 = dout.download()
+    bank.reset()
+    bank.process(dout, din, 2048)
+    np.testing.assert_array_equal(dout.download(), y1)            # same history -> same bits
+    bank.reset()
+    din.upload(x * np.float32(4.0))
+    bank.process(dout, din, 2048)
+    np.testing.assert_array_equal(dout.download(), y1 * np.float32(4.0))   # power-of-two scaling is exact
+    bank.close()
+
+
+def test_c3_full_size(gpu):
+    """BASELINE config 2 at full size: 256 channels, distinct 65536-tap IRs (N(0,1)*exp(-t/16384), seed 4),
+    rank 13, three 4096-sample frames (seed 5); every channel against the oracle and float64."""
+    C, taps, frame, nf = 256, 65536, 4096, 3
+    rng = np.random.default_rng(4)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
+    x = np.random.default_rng(5).standard_normal((C, nf * frame)).astype(np.float32)
+    y, info = run_gpu(gpu, irs, 13, x, [frame] * nf)
+    assert info == {"rank": 13, "frame": 4096, "partitions": 16, "data_size": 65536}
+
+    def ref(c):
+        o = oracle.Convolver(irs[c], 13)
+        return np.concatenate([o.process(x[c, i:i + frame]) for i in range(0, nf * frame, frame)])
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        refs = list(ex.map(ref, range(C)))
+    worst = 0.0
+    for c in range(C):
+        r = check(y[c], refs[c], exact_conv(x[c], irs[c]), "C3 ch %d" % c)
+        worst = max(worst, r["gpu_vs_ref32"])
+    print("C3 full size: worst |gpu - oracle| / peak = %.2e" % worst)
