@@ -34,13 +34,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="biquad", choices=["biquad"])
+    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver"],
+                    help="all = headline biquad line with the convolver result attached under \"convolver\"")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
     ap.add_argument("--ring", type=int, default=16, help="distinct resident blocks cycled through "
                     "(16 x 32 MiB in+out > the 256 MiB Infinity Cache, so steps stream from HBM)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sections", type=int, default=8, help="experiment knob: keep only the first N sections")
+    ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
+    ap.add_argument("--conv-steps", type=int, default=50)
+    ap.add_argument("--conv-warmup", type=int, default=5)
     return ap.parse_args()
 
 
@@ -72,6 +76,132 @@ def cpu_baseline_biquad(coef, samples, budget_s=3.0):
     }
 
 
+def _pmc_traffic(name):
+    """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline_convolver(irs, frame, budget_s=4.0):
+    """Oracle Convolver (restated reference algorithm: non-uniform partitions, scalar C) on this host's cores:
+    one object per channel, whole 4096-sample frames, as many channels as fit in ~budget_s."""
+    import numpy as np
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = min(cores, 64)
+    nch = min(irs.shape[0], workers)
+    x = np.random.default_rng(5).standard_normal((nch, 2 * frame)).astype(np.float32)
+    objs = [oracle.Convolver(irs[c], 13) for c in range(nch)]
+
+    def run(c):
+        objs[c].process(x[c, :frame])
+        objs[c].process(x[c, frame:])
+        return 2 * frame
+    t0 = time.perf_counter()
+    done = 0
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        while time.perf_counter() - t0 < budget_s:
+            done += sum(ex.map(run, range(nch)))
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(done / dt / 1e6, 3), "unit": "Msamples/s", "cores": workers, "kind": "port",
+        "sample": "%d channel-frames of 4096 samples, 65536-tap IR, rank 13, scalar C oracle of the reference's "
+                  "non-uniform partitioned algorithm, one thread per channel" % (done // frame),
+    }
+
+
+def run_convolver(args, mi, torch, dist, rank, world, dev):
+    """BASELINE.json configs[2]: 256 channels per GPU, 65536-tap IR per channel, rank 13 -> 4096-sample frames."""
+    import ctypes
+    import numpy as np
+    C, taps, frame = args.conv_channels, 65536, 4096
+    rng = np.random.default_rng(4 + rank)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
+    bank = mi.ConvolverBank(irs, 13)
+    info = bank.info()
+    P = info["partitions"]
+    ring = 8
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(5 + rank)
+    xin = torch.randn((ring, C, frame), generator=gen, dtype=torch.float32).to(dev)
+    yout = torch.empty_like(xin)
+    stream = torch.cuda.current_stream()
+    steps, warmup = args.conv_steps, args.conv_warmup
+
+    def step(i):
+        k = i % ring
+        bank.process(yout[k], xin[k], frame, stream=stream)
+
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    def new_event():
+        e = ctypes.c_void_p()
+        mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
+        return e
+    starts = [new_event() for _ in range(steps)]
+    stops = [new_event() for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        mi.check(mi.lib.mi_dspu_profile_next_launch(starts[i], stops[i]))
+        step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    def elapsed_ms(a, b):
+        ms = ctypes.c_float()
+        mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), a, b))
+        return float(ms.value)
+    kernel_ms = sorted(elapsed_ms(a, b) for a, b in zip(starts, stops))
+    for e in starts + stops:
+        mi.lib.mi_dspu_event_destroy(e)
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    chk = yout[(warmup + steps - 1) % ring]
+    assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
+    bank.close()
+    if rank != 0:
+        return None
+    # dominant kernel conv_mac_kernel: per channel-frame it reads (P-1) IR images and (P-1) ring images of
+    # 32 KiB each and writes one 32 KiB image
+    img = 8 * frame
+    mac_bytes = float(C) * (2 * (P - 1) + 1) * img
+    # whole step (SURVEY.md 8d): 272 B per channel-sample at P = 16
+    step_bytes = float(C) * frame * 16.0 * (P + 1)
+    achieved = mac_bytes / (avg_ms * 1e-3) / 1e9
+    res = {
+        "value": round(C * frame * world * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
+        "config": {"workload": "Convolver (partitioned FFT overlap-add), %d channels per GPU, 65536-tap IR per "
+                               "channel, rank 13, one 4096-sample frame per step" % C,
+                   "channels_per_gpu": C, "taps": taps, "frame": frame, "partitions": P},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("pmc_convolver_latest.json") if C == 256 else None,
+                     "kernel": "conv_mac_kernel",
+                     "kernel_avg_us": round(avg_ms * 1e3, 3), "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3),
+                     "algorithmic_bytes_per_launch": mac_bytes},
+        "whole_step": {"algorithmic_bytes": step_bytes,
+                       "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / steps) / 1e9, 1),
+                       "frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+    if not args.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline_convolver(irs, frame)
+    return res
+
+
 def main():
     args = parse()
     import numpy as np
@@ -91,6 +221,19 @@ def main():
     mi = importlib.import_module("lsp-dsp-units_amd")
     mi.check(mi.lib.mi_dspu_set_device(local_rank))
     import workloads as wl
+
+    if args.workload == "convolver":
+        res = run_convolver(args, mi, torch, dist, rank, world, dev)
+        if rank == 0:
+            line = {"metric": "Msamples/sec per GPU (biquad-x8 1024ch; Convolver 65536-tap) + HBM roofline %",
+                    "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": "f32", "data": "synthetic"}
+            line.update(res)
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     C, n, ring = args.channels, args.samples, args.ring
     # per-rank channel shard: rank r owns global channels [r*C, (r+1)*C)
@@ -196,9 +339,17 @@ def main():
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_biquad(coef, n)
-        print(json.dumps(line), flush=True)
 
     bank.close()
+    del xin, yout
+    torch.cuda.empty_cache()
+    if args.workload == "all" and args.sections == 8:
+        conv = run_convolver(args, mi, torch, dist, rank, world, dev)
+        if rank == 0:
+            line["convolver"] = conv
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

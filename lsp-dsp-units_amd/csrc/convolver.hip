@@ -11,11 +11,14 @@
 //                       ring[P-1] spectra of the last P-1 complete input frames
 //                       H[P]      spectra of the IR partitions (2B-point real transforms, packed to B complex)
 //
+//                       Yt        pending spectrum: sum_{p>=1} H_p * X_(c+1-p), the tail owed to the next frame
+//
 //   whole frame (off == 0, >= B samples):                                       [conv_frame_kernel]
-//       X = FFT(frame);  y0 = IFFT(H0 * X);  out = acc[0:B] + y0[0:B];  acc = shift(acc) + y0[B:2B]
-//   then, off the output's critical path, the tail of the NEXT frame:           [conv_mac_kernel, conv_tail_kernel]
-//       acc += IFFT( sum_{p>=1} H_p * X_(c+1-p) )        <- the HBM-bound part: streams H and the ring once
-//   partial call (anything else): the head partition is applied directly in the time domain
+//       X = FFT(frame);  y = IFFT(H0 * X + Yt);  out = acc[0:B] + y[0:B];  acc = shift(acc) + y[B:2B]
+//   then, off the output's critical path, the tail owed to the NEXT frame:      [conv_mac_kernel]
+//       Yt = sum_{p>=1} H_p * X_(c+1-p)                  <- the HBM-bound part: streams H and the ring once
+//   partial call (anything else): a pending Yt is first folded into acc         [conv_tail_kernel]
+//     and the head partition is applied directly in the time domain
 //       acc[off+i] += sum_j x[j] h[i-j]  (zero latency for any chunking)        [conv_direct_kernel]
 //     and when the frame completes its spectrum enters the ring                 [conv_commit_kernel]
 //
@@ -93,7 +96,8 @@ namespace
     __global__ __launch_bounds__(plan<LOGM>::T)
     void conv_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                            float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
-                           float *acc, const float2 *__restrict__ tw)
+                           float *acc, const float2 *__restrict__ Yt /* pending tail or NULL */,
+                           const float2 *__restrict__ tw)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
@@ -104,12 +108,16 @@ namespace
 
         float2 *rdst = (R > 0) ? ring + (size_t(ch) * R + slot) * M : nullptr;
         const float2 *h0 = H + size_t(ch) * P * M;
+        const float2 *yt = (Yt != nullptr) ? Yt + size_t(ch) * M : nullptr;
         for (int k = tid; k < M; k += T)
         {
             const float2 x = buf[k];
             if (rdst != nullptr)
                 rdst[k] = x;
-            buf[k] = image_mul(x, h0[k], k);
+            float2 y = image_mul(x, h0[k], k);
+            if (yt != nullptr)
+                y = cadd(y, yt[k]);
+            buf[k] = y;
         }
         __syncthreads();
         inverse_in_place<LOGM>(buf, tw, tid);
@@ -197,13 +205,15 @@ namespace
     }
 
     // ---- partial call: time-domain head (Convolver.cpp:292-296 does the same with dsp::convolve) ---------
+    // The call's samples have already been copied into frame[off..off+cnt) (so `out` may alias the caller's
+    // input: several workgroups of one channel read all of them).
     __global__ __launch_bounds__(256)
-    void conv_direct_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
-                            float *acc, float *frame, const float *__restrict__ h0, int B, int off, int cnt)
+    void conv_direct_kernel(float *out, size_t out_stride, float *acc, const float *frame,
+                            const float *__restrict__ h0, int B, int off, int cnt)
     {
         extern __shared__ float sxin[];                         // cnt samples of this call
         const int ch = blockIdx.y, tid = threadIdx.x;
-        const float *x = in + size_t(ch) * in_stride;
+        const float *x = frame + size_t(ch) * B + off;
         for (int j = tid; j < cnt; j += 256)
             sxin[j] = x[j];
         __syncthreads();
@@ -220,10 +230,7 @@ namespace
         const float v = *a + s;
         *a = v;
         if (i < cnt)
-        {
             out[size_t(ch) * out_stride + i] = v;
-            frame[size_t(ch) * B + off + i] = sxin[i];
-        }
     }
 
     // frame complete after partial calls: its spectrum enters the ring, acc moves on by one frame
@@ -297,6 +304,7 @@ struct mi_convolver_bank
     int         slot = 0;           // ring slot of the newest complete frame
     int         off = 0;            // samples already received of the current frame
     bool        live = false;       // false: count == 0, process() emits zeros (Convolver.cpp:219-223)
+    bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     const float2 *d_tw = nullptr;
@@ -316,8 +324,8 @@ namespace
             default: { CALL(12); break; }               \
         }
 
-    // tail of the next frame from the ring (the dominant, HBM-bound step)
-    int launch_tail(mi_convolver_bank *b, hipStream_t st)
+    // tail owed to the next frame, from the ring (the dominant, HBM-bound step)
+    int launch_mac(mi_convolver_bank *b, hipStream_t st)
     {
         if (b->P <= 1)
             return MI_OK;
@@ -327,11 +335,21 @@ namespace
         hipExtLaunchKernelGGL(conv_mac_kernel, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1, 0,
                               b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
         MI_HIP_CHECK(hipGetLastError());
+        b->yt_pending = true;
+        return MI_OK;
+    }
+
+    // acc += IFFT(Yt): only the partial-call path needs the tail in the time domain
+    int fold_pending(mi_convolver_bank *b, hipStream_t st)
+    {
+        if (!b->yt_pending)
+            return MI_OK;
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_tail_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
                                                b->d_acc, b->d_yt, b->d_tw)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
+        b->yt_pending = false;
         return MI_OK;
     }
 } // namespace
@@ -446,6 +464,7 @@ int mi_convolver_bank_reset(mi_convolver_bank_t *b, void *stream)
     MI_HIP_CHECK(hipMemsetAsync(b->d_frame, 0, size_t(b->channels) * M * sizeof(float), st));
     b->slot = 0;
     b->off  = 0;
+    b->yt_pending = false;
     return MI_OK;
 }
 
@@ -489,21 +508,27 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 b->slot = (b->slot + 1) % b->R;
             #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
                                                    o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
-                                                   b->d_H, b->P, b->d_acc, b->d_tw)
+                                                   b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw)
             MI_LOGM_SWITCH(b->logm, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
-            const int r = launch_tail(b, st);
+            b->yt_pending = false;
+            const int r = launch_mac(b, st);
             if (r != MI_OK)
                 return r;
             done += size_t(B);
         }
         else
         {
+            const int rf = fold_pending(b, st);
+            if (rf != MI_OK)
+                return rf;
             const int cnt = int((left < size_t(B - b->off)) ? left : size_t(B - b->off));
             const dim3 grid((cnt + B - 1 + 255) / 256, b->channels);
+            MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
+                                          size_t(cnt) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
             hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
-                               o, x, out_stride, in_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
+                               o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
             MI_HIP_CHECK(hipGetLastError());
             b->off += cnt;
             done += size_t(cnt);
@@ -516,7 +541,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
-                const int r = launch_tail(b, st);
+                const int r = launch_mac(b, st);
                 if (r != MI_OK)
                     return r;
                 b->off = 0;

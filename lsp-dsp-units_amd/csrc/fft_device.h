@@ -32,7 +32,7 @@ namespace mi_fft
     struct plan
     {
         static constexpr int N   = 1 << LOGN;
-        static constexpr int T   = (N / 16 > 64) ? ((N / 16 > 256) ? 256 : N / 16) : 64;
+        static constexpr int T   = (N / 4 > 64) ? ((N / 4 > 1024) ? 1024 : N / 4) : 64;   // one butterfly per thread
         static constexpr int BPT = (N / 4 + T - 1) / T;         // radix-4 butterflies per thread and pass
     };
 
@@ -75,11 +75,11 @@ namespace mi_fft
                     const float2 jb = INVERSE ? make_float2(-bmd.y, bmd.x) : make_float2(bmd.y, -bmd.x);
                     const int o = q + 4 * s * p;
                     const int ti = p * s * tw_stride;
-                    float2 w1 = tw[ti], w2 = tw[2 * ti], w3 = tw[3 * ti];
+                    // one table read per butterfly; w^2 and w^3 by multiplication (2 roundings, ~1e-7)
+                    float2 w1 = tw[ti];
                     if (INVERSE)
-                    {
-                        w1 = cconj(w1); w2 = cconj(w2); w3 = cconj(w3);
-                    }
+                        w1 = cconj(w1);
+                    const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
                     buf[o]         = cadd(apc, bpd);
                     buf[o + s]     = cmul(w1, cadd(amc, jb));
                     buf[o + 2 * s] = cmul(w2, csub(apc, bpd));
