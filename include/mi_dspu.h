@@ -136,6 +136,132 @@ int mi_biquad_bank_impulse_response(mi_biquad_bank_t *bank, float *out, size_t s
 int mi_biquad_bank_get_state(mi_biquad_bank_t *bank, float *host_state, void *stream);
 int mi_biquad_bank_set_state(mi_biquad_bank_t *bank, const float *host_state, void *stream);
 
+/* ---- filter designer (host side) --------------------------------------------------------- */
+/*
+ * filter_params_t, field for field (include/lsp-plug.in/dsp-units/filters/common.h:137-145).
+ */
+typedef struct mi_filter_params
+{
+    uint32_t    nType;      /* enum mi_filter_type */
+    uint32_t    nSlope;
+    float       fFreq;
+    float       fFreq2;
+    float       fGain;
+    float       fQuality;
+} mi_filter_params_t;
+
+/* filter_type_t with the same enumerator values (filters/common.h:38-135). */
+enum mi_filter_type
+{
+    MI_FLT_NONE = 0,
+    MI_FLT_BT_AMPLIFIER = 1,
+    MI_FLT_MT_AMPLIFIER = 2,
+    MI_FLT_BT_RLC_LOPASS = 3,
+    MI_FLT_MT_RLC_LOPASS = 4,
+    MI_FLT_BT_RLC_HIPASS = 5,
+    MI_FLT_MT_RLC_HIPASS = 6,
+    MI_FLT_BT_RLC_LOSHELF = 7,
+    MI_FLT_MT_RLC_LOSHELF = 8,
+    MI_FLT_BT_RLC_HISHELF = 9,
+    MI_FLT_MT_RLC_HISHELF = 10,
+    MI_FLT_BT_RLC_BELL = 11,
+    MI_FLT_MT_RLC_BELL = 12,
+    MI_FLT_BT_RLC_RESONANCE = 13,
+    MI_FLT_MT_RLC_RESONANCE = 14,
+    MI_FLT_BT_RLC_NOTCH = 15,
+    MI_FLT_MT_RLC_NOTCH = 16,
+    MI_FLT_BT_RLC_ALLPASS = 17,
+    MI_FLT_MT_RLC_ALLPASS = 18,
+    MI_FLT_BT_RLC_ALLPASS2 = 19,
+    MI_FLT_MT_RLC_ALLPASS2 = 20,
+    MI_FLT_BT_RLC_LADDERPASS = 21,
+    MI_FLT_MT_RLC_LADDERPASS = 22,
+    MI_FLT_BT_RLC_LADDERREJ = 23,
+    MI_FLT_MT_RLC_LADDERREJ = 24,
+    MI_FLT_BT_RLC_BANDPASS = 25,
+    MI_FLT_MT_RLC_BANDPASS = 26,
+    MI_FLT_BT_RLC_ENVELOPE = 27,
+    MI_FLT_MT_RLC_ENVELOPE = 28,
+    MI_FLT_BT_BWC_LOPASS = 29,
+    MI_FLT_MT_BWC_LOPASS = 30,
+    MI_FLT_BT_BWC_HIPASS = 31,
+    MI_FLT_MT_BWC_HIPASS = 32,
+    MI_FLT_BT_BWC_LOSHELF = 33,
+    MI_FLT_MT_BWC_LOSHELF = 34,
+    MI_FLT_BT_BWC_HISHELF = 35,
+    MI_FLT_MT_BWC_HISHELF = 36,
+    MI_FLT_BT_BWC_BELL = 37,
+    MI_FLT_MT_BWC_BELL = 38,
+    MI_FLT_BT_BWC_LADDERPASS = 39,
+    MI_FLT_MT_BWC_LADDERPASS = 40,
+    MI_FLT_BT_BWC_LADDERREJ = 41,
+    MI_FLT_MT_BWC_LADDERREJ = 42,
+    MI_FLT_BT_BWC_BANDPASS = 43,
+    MI_FLT_MT_BWC_BANDPASS = 44,
+    MI_FLT_BT_BWC_ALLPASS = 45,
+    MI_FLT_MT_BWC_ALLPASS = 46,
+    MI_FLT_BT_LRX_LOPASS = 47,
+    MI_FLT_MT_LRX_LOPASS = 48,
+    MI_FLT_BT_LRX_HIPASS = 49,
+    MI_FLT_MT_LRX_HIPASS = 50,
+    MI_FLT_BT_LRX_LOSHELF = 51,
+    MI_FLT_MT_LRX_LOSHELF = 52,
+    MI_FLT_BT_LRX_HISHELF = 53,
+    MI_FLT_MT_LRX_HISHELF = 54,
+    MI_FLT_BT_LRX_BELL = 55,
+    MI_FLT_MT_LRX_BELL = 56,
+    MI_FLT_BT_LRX_LADDERPASS = 57,
+    MI_FLT_MT_LRX_LADDERPASS = 58,
+    MI_FLT_BT_LRX_LADDERREJ = 59,
+    MI_FLT_MT_LRX_LADDERREJ = 60,
+    MI_FLT_BT_LRX_BANDPASS = 61,
+    MI_FLT_MT_LRX_BANDPASS = 62,
+    MI_FLT_BT_LRX_ALLPASS = 63,
+    MI_FLT_MT_LRX_ALLPASS = 64,
+    MI_FLT_DR_APO_LOPASS = 65,
+    MI_FLT_DR_APO_HIPASS = 66,
+    MI_FLT_DR_APO_BANDPASS = 67,
+    MI_FLT_DR_APO_NOTCH = 68,
+    MI_FLT_DR_APO_ALLPASS = 69,
+    MI_FLT_DR_APO_ALLPASS2 = 70,
+    MI_FLT_DR_APO_PEAKING = 71,
+    MI_FLT_DR_APO_LOSHELF = 72,
+    MI_FLT_DR_APO_HISHELF = 73,
+    MI_FLT_DR_APO_LADDERPASS = 74,
+    MI_FLT_DR_APO_LADDERREJ = 75,
+    MI_FLT_A_WEIGHTED = 76,
+    MI_FLT_B_WEIGHTED = 77,
+    MI_FLT_C_WEIGHTED = 78,
+    MI_FLT_D_WEIGHTED = 79,
+    MI_FLT_K_WEIGHTED = 80
+};
+
+/* dsp::f_cascade_t: numerator t[] and denominator b[] of one analog (or plot) cascade. */
+typedef struct mi_filter_cascade
+{
+    float t[4];
+    float b[4];
+} mi_filter_cascade_t;
+
+/* Filter::filter_mode_t (filters/Filter.h:41-47). */
+enum { MI_FM_BYPASS = 0, MI_FM_BILINEAR = 1, MI_FM_MATCHED = 2, MI_FM_APO = 3 };
+
+/*
+ * Filter::update() + Filter::rebuild() without a bank (src/main/filters/Filter.cpp:141-167,208-403):
+ * limits the parameters, builds the prototype cascades and transforms them into digital sections
+ * exactly as they would be handed to FilterBank::add_chain().  Host-only, no GPU needed.
+ * chains/cascades may be NULL to query the counts; at most max_* entries are written.
+ */
+int mi_filter_design(const mi_filter_params_t *params, uint32_t sample_rate,
+                     mi_biquad_x1_t *chains, uint32_t max_chains, uint32_t *n_chains,
+                     mi_filter_cascade_t *cascades, uint32_t max_cascades, uint32_t *n_cascades, int *mode);
+/* Filter::limit(), Filter.cpp:161-167. */
+int mi_filter_limit(mi_filter_params_t *params, uint32_t sample_rate);
+/*
+ * Filter::freq_chart(c, f, count), packed-complex form (Filter.cpp:602-696): c[2i], c[2i+1] = H(f[i]).
+ */
+int mi_filter_freq_chart(const mi_filter_params_t *params, uint32_t sample_rate, float *c, const float *f, size_t count);
+
 /* ---- partitioned FFT convolver bank ------------------------------------------------------ */
 /*
  * mi_convolver_bank: `channels` independent lsp::dspu::Convolver objects

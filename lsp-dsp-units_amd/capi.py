@@ -19,6 +19,16 @@ class MiError(RuntimeError):
         self.code = code
 
 
+class FilterParams(ctypes.Structure):
+    """mi_filter_params_t == filter_params_t layout."""
+    _fields_ = [("nType", c_uint32), ("nSlope", c_uint32), ("fFreq", c_float), ("fFreq2", c_float),
+                ("fGain", c_float), ("fQuality", c_float)]
+
+
+class FilterCascade(ctypes.Structure):
+    _fields_ = [("t", c_float * 4), ("b", c_float * 4)]
+
+
 class BiquadX1(ctypes.Structure):
     """mi_biquad_x1_t == dsp::biquad_x1_t layout."""
     _fields_ = [(n, c_float) for n in ("b0", "b1", "b2", "a1", "a2", "p0", "p1", "p2")]
@@ -57,6 +67,10 @@ PROTOTYPES = {
     "mi_biquad_bank_impulse_response": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mi_biquad_bank_get_state": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mi_biquad_bank_set_state": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "mi_filter_design": (c_int, [POINTER(FilterParams), c_uint32, c_void_p, c_uint32, POINTER(c_uint32),
+                                 c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_int)]),
+    "mi_filter_limit": (c_int, [POINTER(FilterParams), c_uint32]),
+    "mi_filter_freq_chart": (c_int, [POINTER(FilterParams), c_uint32, c_void_p, c_void_p, c_size_t]),
     "mi_convolver_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_void_p, c_size_t, c_void_p, c_uint32, c_uint32,
                                          c_float, c_void_p]),
     "mi_convolver_bank_destroy": (c_int, [c_void_p]),

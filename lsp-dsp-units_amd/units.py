@@ -4,7 +4,7 @@ from ctypes import byref, c_float, c_uint32, c_void_p
 
 import numpy as np
 
-from .capi import BiquadX1, check, lib
+from .capi import BiquadX1, FilterCascade, FilterParams, check, lib
 
 
 def device_count():
@@ -185,3 +185,23 @@ class ConvolverBank:
             self.close()
         except Exception:
             pass
+
+
+def design_filter(ftype, slope=1, freq=1000.0, freq2=1000.0, gain=1.0, quality=0.0, sample_rate=48000):
+    """Filter::update + rebuild on the host: returns (mode, cascades[n][2][3], sections[n][5])."""
+    fp = FilterParams(int(ftype), int(slope), float(freq), float(freq2), float(gain), float(quality))
+    chains = (BiquadX1 * 256)()
+    casc = (FilterCascade * 256)()
+    nch, nca, mode = c_uint32(), c_uint32(), ctypes.c_int()
+    check(lib.mi_filter_design(byref(fp), sample_rate, chains, 256, byref(nch), casc, 256, byref(nca), byref(mode)))
+    sec = np.array([[c.b0, c.b1, c.b2, c.a1, c.a2] for c in chains[:nch.value]], dtype=np.float32).reshape(-1, 5)
+    cas = np.array([[list(c.t)[:3], list(c.b)[:3]] for c in casc[:nca.value]], dtype=np.float32).reshape(-1, 2, 3)
+    return mode.value, cas, sec
+
+
+def filter_freq_chart(freqs, ftype, slope=1, freq=1000.0, freq2=1000.0, gain=1.0, quality=0.0, sample_rate=48000):
+    fp = FilterParams(int(ftype), int(slope), float(freq), float(freq2), float(gain), float(quality))
+    f = np.ascontiguousarray(freqs, dtype=np.float32)
+    c = np.empty(2 * f.size, np.float32)
+    check(lib.mi_filter_freq_chart(byref(fp), sample_rate, c.ctypes.data_as(c_void_p), f.ctypes.data_as(c_void_p), f.size))
+    return c[0::2] + 1j * c[1::2]

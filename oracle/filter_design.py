@@ -747,7 +747,7 @@ class _Designer:
                 AI.append((A, I))
             Tt, Bb = PP
             (A0, I0), (A1, I1) = AI
-            AN = D(F(A1 * I0)) / D(F(A0 * I1))
+            AN = D(F(F(A1 * I0) / F(A0 * I1)))            # float division, then widened (Filter.cpp:2395)
             N = 1.0 / D(Bb[0])
             self._chain(D(Tt[0]) * N * AN, D(Tt[1]) * N * AN, D(Tt[2]) * N * AN,
                         -D(Bb[1]) * N, -D(Bb[2]) * N)
