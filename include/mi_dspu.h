@@ -298,6 +298,103 @@ int mi_convolver_bank_info(const mi_convolver_bank_t *bank, uint32_t *rank, uint
 int mi_convolver_bank_process(mi_convolver_bank_t *bank, float *out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream);
 
+/* ---- windows and spectral envelopes (host side) ---------------------------------------- */
+/* windows::window_t with the same enumerator values (include/lsp-plug.in/dsp-units/misc/windows.h:34-62). */
+enum mi_window
+{
+    MI_WINDOW_HANN, MI_WINDOW_HAMMING, MI_WINDOW_BLACKMAN, MI_WINDOW_LANCZOS, MI_WINDOW_GAUSSIAN,
+    MI_WINDOW_POISSON, MI_WINDOW_PARZEN, MI_WINDOW_TUKEY, MI_WINDOW_WELCH, MI_WINDOW_NUTTALL,
+    MI_WINDOW_BLACKMAN_NUTTALL, MI_WINDOW_BLACKMAN_HARRIS, MI_WINDOW_HANN_POISSON, MI_WINDOW_BARTLETT_HANN,
+    MI_WINDOW_BARTLETT_FEJER, MI_WINDOW_TRIANGULAR, MI_WINDOW_RECTANGULAR, MI_WINDOW_FLAT_TOP,
+    MI_WINDOW_COSINE, MI_WINDOW_SQR_COSINE, MI_WINDOW_CUBIC, MI_WINDOW_TOTAL
+};
+/* envelope::envelope_t (include/lsp-plug.in/dsp-units/misc/envelope.h:36-50). */
+enum mi_envelope
+{
+    MI_ENVELOPE_VIOLET_NOISE, MI_ENVELOPE_BLUE_NOISE, MI_ENVELOPE_WHITE_NOISE, MI_ENVELOPE_PINK_NOISE,
+    MI_ENVELOPE_BROWN_NOISE, MI_ENVELOPE_MINUS_4_5_DB, MI_ENVELOPE_PLUS_4_5_DB, MI_ENVELOPE_TOTAL
+};
+/* windows::window(dst, n, type), src/main/misc/windows.cpp:62-98 (host memory). */
+int mi_window(float *dst, size_t n, int type);
+/* envelope::reverse_noise_lin(dst, first, last, center, n, type), src/main/misc/envelope.cpp:95-123 (host memory). */
+int mi_envelope_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
+
+/* ---- spectral processor bank -------------------------------------------------------------- */
+/*
+ * mi_spectral_bank: `channels` lsp::dspu::SpectralProcessor objects sharing rank and phase, equivalently one
+ * lsp::dspu::MultiSpectralProcessor with `channels` channels (util/SpectralProcessor.h:45-175,
+ * util/MultiSpectralProcessor.h:47-247): 50 %-overlap sine-window STFT -> operation -> ISTFT overlap-add,
+ * latency 2^rank samples.
+ */
+typedef struct mi_spectral_bank mi_spectral_bank_t;
+enum { MI_SPECTRAL_OP_NONE = 0, MI_SPECTRAL_OP_MASK = 1, MI_SPECTRAL_OP_CALLBACK = 2 };
+/*
+ * spectral_processor_func_t / multi_spectral_processor_func_t on the device
+ * (util/SpectralProcessor.h:39, util/MultiSpectralProcessor.h:41): `spectrum` is a DEVICE pointer to
+ * [channels][2 * 2^rank] floats (packed complex, all 2^rank bins); the function runs on the host and may enqueue
+ * work on `stream` (including collectives); the inverse transform is ordered after it on the same stream.
+ */
+typedef void (*mi_spectral_func_t)(void *object, void *subject, float *spectrum, size_t rank, size_t channels, void *stream);
+
+/* SpectralProcessor::init(max_rank), SpectralProcessor.cpp:59-75 (ranks 5..12 supported). */
+int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32_t max_rank);
+int mi_spectral_bank_destroy(mi_spectral_bank_t *bank);
+/* set_rank / set_phase, SpectralProcessor.cpp:127-145 (a rank above max_rank is ignored, phase is clamped to 0..1). */
+int mi_spectral_bank_set_rank(mi_spectral_bank_t *bank, uint32_t rank);
+int mi_spectral_bank_set_phase(mi_spectral_bank_t *bank, float phase);
+/* get_rank(), latency(), remaining() (SpectralProcessor.h:128,142, SpectralProcessor.cpp:251-255). */
+int mi_spectral_bank_get(const mi_spectral_bank_t *bank, uint32_t *rank, uint32_t *latency, uint32_t *remaining);
+/* bind(func, object, subject) / unbind(), SpectralProcessor.cpp:91-105. */
+int mi_spectral_bank_bind(mi_spectral_bank_t *bank, mi_spectral_func_t func, void *object, void *subject);
+int mi_spectral_bank_unbind(mi_spectral_bank_t *bank);
+/*
+ * Built-in callback: spectrum[k] *= mask[k], k = 0..2^(rank-1) (real gains, applied to both halves of the
+ * spectrum), fused into the transform kernel.  mask is HOST memory, one row shared by all channels
+ * (mask_stride == 0) or [channels][mask_stride].
+ */
+int mi_spectral_bank_bind_mask(mi_spectral_bank_t *bank, const float *mask, size_t mask_stride, void *stream);
+/* MultiSpectralProcessor::bind_in/bind_out (MultiSpectralProcessor.cpp:160-227): which channels have an input /
+ * an output bound (HOST byte arrays, NULL = unchanged; default all bound). Callback mode only. */
+int mi_spectral_bank_bind_channels(mi_spectral_bank_t *bank, const uint8_t *has_in, const uint8_t *has_out, void *stream);
+/* reset(), SpectralProcessor.cpp:257-266. */
+int mi_spectral_bank_reset(mi_spectral_bank_t *bank, void *stream);
+/* process(dst, src, count) / process(src, count) with out == NULL, SpectralProcessor.cpp:147-249. */
+int mi_spectral_bank_process(mi_spectral_bank_t *bank, float *out, const float *in, size_t count,
+                             size_t out_stride, size_t in_stride, void *stream);
+
+/* ---- spectrum analyzer bank ---------------------------------------------------------------- */
+/*
+ * mi_analyzer_bank: one lsp::dspu::Analyzer with `channels` channels (util/Analyzer.h:53-361): ring-buffer
+ * ingest, windowed FFT magnitude per channel once per refresh period, exponential smoothing, envelope.
+ */
+typedef struct mi_analyzer_bank mi_analyzer_bank_t;
+enum { MI_ANALYZER_SAMPLE_RATE, MI_ANALYZER_RATE, MI_ANALYZER_WINDOW, MI_ANALYZER_ENVELOPE, MI_ANALYZER_SHIFT,
+       MI_ANALYZER_REACTIVITY, MI_ANALYZER_RANK, MI_ANALYZER_ACTIVE };
+enum { MI_ANALYZER_CH_FREEZE, MI_ANALYZER_CH_ENABLE, MI_ANALYZER_CH_DELAY };
+
+/* Analyzer::init(channels, max_rank, max_sr, min_rate, max_delay), Analyzer.cpp:83-152 (ranks 5..13 supported). */
+int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t max_sample_rate,
+                            float min_rate, uint32_t max_delay);
+int mi_analyzer_bank_destroy(mi_analyzer_bank_t *bank);
+/* set_sample_rate/set_rate/set_window/set_envelope/set_shift/set_reactivity/set_rank/set_activity, Analyzer.cpp:154-211. */
+int mi_analyzer_bank_configure(mi_analyzer_bank_t *bank, int what, double value);
+/* freeze_channel/enable_channel/set_channel_delay, Analyzer.cpp:213-249. */
+int mi_analyzer_bank_channel(mi_analyzer_bank_t *bank, uint32_t channel, int what, uint32_t value);
+/*
+ * Analyzer::process(in, samples), Analyzer.cpp:299-409.  in: device [channels][in_stride] or NULL (zeros).
+ * Unlike the reference (which divides by zero, Analyzer.cpp:258-260,315) a refresh rate above
+ * sample_rate / channels is rejected with MI_EINVAL.
+ */
+int mi_analyzer_bank_process(mi_analyzer_bank_t *bank, const float *in, size_t samples, size_t in_stride, void *stream);
+/* Analyzer::get_spectrum for every channel at once, Analyzer.cpp:443-456: out[c][i] = vData[c][idx[i]] * envelope[idx[i]]
+ * (out and idx are DEVICE pointers). */
+int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *bank, float *out, size_t out_stride, const uint32_t *idx,
+                                  uint32_t count, void *stream);
+/* Per-bin sum over this bank's channels of the smoothed magnitudes (2^(rank-1)+1 floats, DEVICE): the local half
+ * of the cross-channel per-bin reduction; the caller all-reduces it across GPUs. */
+int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_envelope, void *stream);
+int mi_analyzer_bank_info(const mi_analyzer_bank_t *bank, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step);
+
 /*
  * Host-only introspection of the per-section device table (no GPU needed): the
  * chunk-parallel form of the TDF-II section used by the kernel.

@@ -78,6 +78,27 @@ PROTOTYPES = {
     "mi_convolver_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                        POINTER(c_uint32)]),
     "mi_convolver_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_window": (c_int, [c_void_p, c_size_t, c_int]),
+    "mi_envelope_reverse_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
+    "mi_spectral_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
+    "mi_spectral_bank_destroy": (c_int, [c_void_p]),
+    "mi_spectral_bank_set_rank": (c_int, [c_void_p, c_uint32]),
+    "mi_spectral_bank_set_phase": (c_int, [c_void_p, c_float]),
+    "mi_spectral_bank_get": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "mi_spectral_bank_bind": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi_spectral_bank_unbind": (c_int, [c_void_p]),
+    "mi_spectral_bank_bind_mask": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "mi_spectral_bank_bind_channels": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi_spectral_bank_reset": (c_int, [c_void_p, c_void_p]),
+    "mi_spectral_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_analyzer_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32, c_float, c_uint32]),
+    "mi_analyzer_bank_destroy": (c_int, [c_void_p]),
+    "mi_analyzer_bank_configure": (c_int, [c_void_p, c_int, ctypes.c_double]),
+    "mi_analyzer_bank_channel": (c_int, [c_void_p, c_uint32, c_int, c_uint32]),
+    "mi_analyzer_bank_process": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "mi_analyzer_bank_get_spectrum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32, c_void_p]),
+    "mi_analyzer_bank_reduce_bins": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
+    "mi_analyzer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "mi_biquad_section_tables": (c_int, [POINTER(BiquadX1), c_int, POINTER(c_float), POINTER(c_uint32)]),
 }
 
@@ -91,3 +112,6 @@ def check(code):
     if code != 0:
         raise MiError(code, (lib.mi_dspu_last_error() or b"").decode("utf-8", "replace"))
     return code
+
+
+SPECTRAL_FUNC = ctypes.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p)

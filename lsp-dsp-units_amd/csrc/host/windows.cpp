@@ -1,0 +1,287 @@
+// Host-side window and spectral-envelope generators (product code).
+// Counterparts of lsp::dspu::windows::* (reference: src/main/misc/windows.cpp:62-401) and
+// lsp::dspu::envelope::reverse_noise_lin (src/main/misc/envelope.cpp:40-123).  They run at reconfigure time
+// only; the tables are uploaded to the device by the units that use them.
+#include <cmath>
+#include <cstddef>
+
+#include "../mi_common.h"
+
+namespace mi
+{
+namespace
+{
+    // a0 - a1 cos(f i) + a2 cos(2 f i) - a3 cos(3 f i) + a4 cos(4 f i), f = 2 pi / (n - 1)
+    void cosine_sum(float *dst, size_t n, const float *a, int terms)
+    {
+        if (n == 0)
+            return;
+        const float f1 = 2.0f * M_PI / (n - 1);
+        float f[5] = { 0.0f, f1, f1 * 2.0f, f1 * 3.0f, f1 * 4.0f };
+        if (terms == 2)                     // Hann / Hamming (windows.cpp:139-160)
+        {
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = a[0] - a[1] * cosf(i * f[1]);
+        }
+        else if (terms == 3)                // Blackman (windows.cpp:162-180): note the double 0.5
+        {
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = a[0] - 0.5 * cosf(i * f[1]) + a[2] * cosf(i * f[2]);
+        }
+        else if (terms == 4)                // Nuttall family (windows.cpp:182-214)
+        {
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = a[0] - a[1] * cosf(i * f[1]) + a[2] * cosf(i * f[2]) - a[3] * cosf(i * f[3]);
+        }
+        else                                // flat top, normalised at the centre (windows.cpp:216-236)
+        {
+            const float norm = 1.0f / (a[0] - a[1] * cosf(n * 0.5 * f[1]) + a[2] * cosf(n * 0.5 * f[2])
+                                       - a[3] * cosf(n * 0.5 * f[3]) + a[4] * cosf(n * 0.5 * f[4]));
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = norm * (a[0] - a[1] * cosf(i * f[1]) + a[2] * cosf(i * f[2]) - a[3] * cosf(i * f[3])
+                                 + a[4] * cosf(i * f[4]));
+        }
+    }
+
+    void triangle(float *dst, size_t n, int dn)         // windows.cpp:100-137
+    {
+        if (n == 0)
+            return;
+        float l = (dn > 0) ? n + 1 : (dn < 0) ? n - 1 : n;
+        if (l == 0.0f)
+        {
+            dst[0] = 0.0f;
+            return;
+        }
+        l = 2.0f / l;
+        const float c = (n - 1) * 0.5;
+        for (size_t i = 0; i < n; ++i)
+            dst[i] = 1.0f - fabs((i - c) * l);
+    }
+} // namespace
+
+void make_window(float *dst, size_t n, int type)
+{
+    switch (type)
+    {
+        case MI_WINDOW_HANN:            { const float a[] = { 0.5f, 0.5f };   cosine_sum(dst, n, a, 2); break; }
+        case MI_WINDOW_HAMMING:         { const float a[] = { 0.54f, 0.46f }; cosine_sum(dst, n, a, 2); break; }
+        case MI_WINDOW_BLACKMAN:
+        {
+            const float alpha = 0.16f, a2 = alpha * 0.5f;
+            const float a[] = { 0.5f - a2, 0.5f, a2 };
+            cosine_sum(dst, n, a, 3);
+            break;
+        }
+        case MI_WINDOW_NUTTALL:          { const float a[] = { 0.355768f, 0.487396f, 0.144232f, 0.012604f };   cosine_sum(dst, n, a, 4); break; }
+        case MI_WINDOW_BLACKMAN_NUTTALL: { const float a[] = { 0.3635819f, 0.4891775f, 0.1365995f, 0.0106411f }; cosine_sum(dst, n, a, 4); break; }
+        case MI_WINDOW_BLACKMAN_HARRIS:  { const float a[] = { 0.35875f, 0.48829f, 0.14128f, 0.01168f };       cosine_sum(dst, n, a, 4); break; }
+        case MI_WINDOW_FLAT_TOP:         { const float a[] = { 1.0f, 1.93f, 1.29f, 0.388f, 0.028f };           cosine_sum(dst, n, a, 5); break; }
+        case MI_WINDOW_RECTANGULAR:
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = 1.0f;
+            break;
+        case MI_WINDOW_TRIANGULAR:      triangle(dst, n, 0); break;
+        case MI_WINDOW_BARTLETT_FEJER:  triangle(dst, n, -1); break;
+        case MI_WINDOW_PARZEN:                              // windows.cpp:139-...: piecewise cubic
+        {
+            if (n == 0)
+                break;
+            const float n_2 = 0.5 * n, n_4 = 0.25 * n, n__2 = 1.0 / n_2;
+            for (size_t i = 0; i < n; ++i)
+            {
+                const float x = fabs(i - n_2), k = x * n__2, p = 1.0f - k;
+                dst[i] = (x <= n_4) ? 1.0f - 6.0f * k * k * p : 2.0f * p * p * p;
+            }
+            break;
+        }
+        case MI_WINDOW_WELCH:
+        {
+            if (n == 0)
+                break;
+            const float c = (n - 1) * 0.5f, mc = 1.0f / c;
+            for (size_t i = 0; i < n; ++i)
+            {
+                const float t = (i - c) * mc;
+                dst[i] = 1.0f - t * t;
+            }
+            break;
+        }
+        case MI_WINDOW_COSINE:                              // sin(pi i / n), windows.cpp:238-246
+        {
+            if (n == 0)
+                break;
+            const float f = M_PI / n;
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = sinf(f * i);
+            break;
+        }
+        case MI_WINDOW_SQR_COSINE:
+        {
+            if (n == 0)
+                break;
+            const float f = M_PI / n;
+            for (size_t i = 0; i < n; ++i)
+            {
+                const float a = sinf(f * i);
+                dst[i] = a * a;
+            }
+            break;
+        }
+        case MI_WINDOW_CUBIC:                               // windows.cpp:261-281 (its n == 1 case writes dst[1]; we write dst[0])
+        {
+            if (n <= 1)
+            {
+                if (n == 1)
+                    dst[0] = 1.0f;
+                break;
+            }
+            size_t middle = n >> 1;
+            const float kx = 1.0f / middle;
+            size_t i = 0;
+            for (; i < middle; ++i)
+            {
+                const float x = i * kx;
+                dst[i] = x * x * (3.0f - 2.0f * x);
+            }
+            middle = n - 1;
+            for (; i < n; ++i)
+                dst[i] = 1.0f - dst[middle - i];
+            break;
+        }
+        case MI_WINDOW_GAUSSIAN:
+        {
+            const float s = 0.4;
+            if (n == 0 || s > 0.5)
+                break;
+            const float c = (n - 1) * 0.5f, sc = 1.0f / (c * s);
+            for (size_t i = 0; i < n; ++i)
+            {
+                const float v = (i - c) * sc;
+                dst[i] = expf(-0.5f * v * v);
+            }
+            break;
+        }
+        case MI_WINDOW_POISSON:
+        {
+            const float c = (n - 1) * 0.5f;
+            const float t = -1.0f / (n * 0.5f);
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = expf(t * fabs(i - c));
+            break;
+        }
+        case MI_WINDOW_BARTLETT_HANN:
+        {
+            if (n == 0)
+                break;
+            const float a0 = 0.62f, a1 = 0.48f, a2 = 0.38f;
+            const float k1 = 1.0f / (n - 1), k2 = 2.0f * M_PI * k1;
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = a0 - a1 * fabs(i * k1 - 0.5f) - a2 * cosf(i * k2);
+            break;
+        }
+        case MI_WINDOW_HANN_POISSON:
+        {
+            if (n == 0)
+                break;
+            const float a = 2.0f;
+            const float f = 2.0f * M_PI / (n - 1);
+            const float k1 = (n - 1) * 0.5, k2 = -a / k1;
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = (0.5 - 0.5 * cosf(i * f)) * expf(k2 * fabs(k1 - i));
+            break;
+        }
+        case MI_WINDOW_LANCZOS:
+        {
+            if (n == 0)
+                break;
+            const float k = 2.0f * M_PI / (n - 1);
+            for (size_t i = 0; i < n; ++i)
+            {
+                const float x = k * i - M_PI;
+                dst[i] = (x == 0.0f) ? 1.0f : sinf(x) / x;
+            }
+            break;
+        }
+        case MI_WINDOW_TUKEY:
+        {
+            if (n == 0)
+                break;
+            const float a = 0.5f;
+            const size_t last = n - 1;
+            const size_t b1 = 0.5 * a * last, b2 = last - b1;
+            const float k = M_PI * 2.0f / (a * last);
+            const float x = M_PI - 2.0f * M_PI / a;
+            for (size_t i = 0; i < n; ++i)
+            {
+                if (i <= b1)      dst[i] = 0.5f + 0.5f * cosf(k * i - M_PI);
+                else if (i > b2)  dst[i] = 0.5f + 0.5f * cosf(k * i + x);
+                else              dst[i] = 1.0f;
+            }
+            break;
+        }
+        default:
+            break;
+    }
+}
+
+// envelope::reverse_noise_lin (envelope.cpp:95-123): the inverse colour of `type` on a linear frequency grid
+void make_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type)
+{
+    constexpr float LOG10_2 = 0.30102999566398119521f;      // M_LOG10_2
+    constexpr float PLUS_4_5 = 4.5f / (20.0f * LOG10_2), MINUS_4_5 = -4.5f / (20.0f * LOG10_2);
+    float k;
+    switch (type)
+    {
+        case MI_ENVELOPE_WHITE_NOISE:
+            for (size_t i = 0; i < n; ++i)
+                dst[i] = 1.0f;
+            return;
+        case MI_ENVELOPE_PINK_NOISE:    k = 0.5f;  break;   // reverse of pink is blue
+        case MI_ENVELOPE_BROWN_NOISE:   k = 1.0f;  break;
+        case MI_ENVELOPE_BLUE_NOISE:    k = -0.5f; break;
+        case MI_ENVELOPE_VIOLET_NOISE:  k = -1.0f; break;
+        case MI_ENVELOPE_PLUS_4_5_DB:   k = MINUS_4_5; break;
+        case MI_ENVELOPE_MINUS_4_5_DB:  k = PLUS_4_5; break;
+        default:
+            return;
+    }
+    if (n <= 1)                                             // envelope.cpp:42-47
+    {
+        if (n > 0)
+            dst[0] = 1.0f;
+        return;
+    }
+    const float kf = 1.0f / center;
+    first *= kf;
+    last  *= kf;
+    const float df = (last - first) / (n - 1);
+    for (size_t i = 0; i < n; ++i)
+        dst[i] = first + df * i;
+    if (dst[0] <= 0.0f)
+        dst[0] = dst[1];
+    for (size_t i = 0; i < n; ++i)                          // dsp::powvc1(dst, k, n)
+        dst[i] = powf(dst[i], k);
+}
+
+} // namespace mi
+
+extern "C" {
+
+int mi_window(float *dst, size_t n, int type)
+{
+    MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_window: NULL destination");
+    MI_REQUIRE(type >= 0 && type < MI_WINDOW_TOTAL, MI_EINVAL, "mi_window: unknown window %d", type);
+    mi::make_window(dst, n, type);
+    return MI_OK;
+}
+
+int mi_envelope_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type)
+{
+    MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_envelope_reverse_noise_lin: NULL destination");
+    MI_REQUIRE(type >= 0 && type < MI_ENVELOPE_TOTAL, MI_EINVAL, "mi_envelope_reverse_noise_lin: unknown envelope %d", type);
+    mi::make_reverse_noise_lin(dst, first, last, center, n, type);
+    return MI_OK;
+}
+
+} // extern "C"

