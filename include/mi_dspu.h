@@ -395,6 +395,57 @@ int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *bank, float *out, size_t o
 int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_envelope, void *stream);
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *bank, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step);
 
+/* ---- delay line and ring buffer banks ----------------------------------------------------- */
+/*
+ * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  All
+ * channels share one write position; the delay is per channel.  Index arithmetic is the reference's
+ * (uint32 head/tail/size, src/main/util/Delay.cpp:76-102,434,569-574): outputs are bit-exact.
+ */
+typedef struct mi_delay_bank mi_delay_bank_t;
+enum { MI_GAIN_NONE = 0, MI_GAIN_SCALAR = 1, MI_GAIN_VECTOR = 2 };
+
+/* Delay::init(max_size), Delay.cpp:51-66: line length = align(max_size + 0x200, 0x200). */
+int mi_delay_bank_create(mi_delay_bank_t **bank, uint32_t channels, size_t max_size);
+int mi_delay_bank_destroy(mi_delay_bank_t *bank);
+/* Delay::set_delay(delay) (delay %= size), Delay.cpp:569-574; channel = UINT32_MAX for all. */
+int mi_delay_bank_set_delay(mi_delay_bank_t *bank, uint32_t channel, size_t delay);
+/* get_delay() and the raw nSize / nHead / nTail of one channel. */
+int mi_delay_bank_get(const mi_delay_bank_t *bank, uint32_t channel, uint32_t *delay, uint32_t *size, uint32_t *head, uint32_t *tail);
+/* Delay::clear(), Delay.cpp:576-582. */
+int mi_delay_bank_clear(mi_delay_bank_t *bank, void *stream);
+/* Delay::append(src, count), Delay.cpp:76-102. */
+int mi_delay_bank_append(mi_delay_bank_t *bank, const float *in, size_t count, size_t in_stride, void *stream);
+/*
+ * Delay::process / process_add and their gain variants (Delay.cpp:104-397): out (+)= gain * delayed(in).
+ * add != 0 selects process_add; gain_mode MI_GAIN_NONE / MI_GAIN_SCALAR (gain) / MI_GAIN_VECTOR
+ * (gain_vec: device [channels][gain_stride]).  out may be the same buffer as in.
+ */
+int mi_delay_bank_process(mi_delay_bank_t *bank, float *out, const float *in, size_t count, size_t out_stride,
+                          size_t in_stride, int add, int gain_mode, float gain, const float *gain_vec,
+                          size_t gain_stride, void *stream);
+/*
+ * Delay::process_ramping(dst, src, [gain,] delay, count), Delay.cpp:399-546: the delay of channel c slides
+ * linearly to new_delays[c] (HOST array) over the block; tail index (old_tail + ssize_t(delta * offset)) % size.
+ */
+int mi_delay_bank_process_ramping(mi_delay_bank_t *bank, float *out, const float *in, const uint32_t *new_delays,
+                                  size_t count, size_t out_stride, size_t in_stride, int gain_mode, float gain,
+                                  const float *gain_vec, size_t gain_stride, void *stream);
+
+/* mi_ring_bank: `channels` x lsp::dspu::RingBuffer (util/RingBuffer.h:35-179, src/main/util/RingBuffer.cpp:48-209). */
+typedef struct mi_ring_bank mi_ring_bank_t;
+/* RingBuffer::init(size, fill), RingBuffer.cpp:48-63. */
+int mi_ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill);
+int mi_ring_bank_destroy(mi_ring_bank_t *bank);
+/* clear() / fill(value), RingBuffer.cpp:108-120 (head returns to 0). */
+int mi_ring_bank_fill(mi_ring_bank_t *bank, float value, void *stream);
+/* append(data, count) -> *appended = min(count, capacity), RingBuffer.cpp:76-106. */
+int mi_ring_bank_append(mi_ring_bank_t *bank, const float *in, size_t count, size_t in_stride, size_t *appended, void *stream);
+/* get(dst, offset, count) -> *read, zero-filled where nothing is stored, RingBuffer.cpp:147-183.
+ * The single-sample get(offset) (RingBuffer.cpp:122-129) is get(dst, offset, 1). */
+int mi_ring_bank_get(mi_ring_bank_t *bank, float *out, size_t offset, size_t count, size_t out_stride, size_t *read, void *stream);
+/* size(), head position and tail_position(offset), RingBuffer.cpp:140-145. */
+int mi_ring_bank_info(const mi_ring_bank_t *bank, size_t offset, uint32_t *capacity, uint32_t *head, uint32_t *tail_position);
+
 /*
  * Host-only introspection of the per-section device table (no GPU needed): the
  * chunk-parallel form of the TDF-II section used by the kernel.

@@ -12,5 +12,5 @@ Import with ``importlib.import_module("lsp-dsp-units_amd")`` (the directory
 name carries the reference's name and is not a Python identifier).
 """
 from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
-from .units import (AnalyzerBank, BiquadBank, ConvolverBank, DeviceBuffer, SpectralBank,  # noqa: F401
+from .units import (AnalyzerBank, BiquadBank, ConvolverBank, DelayBank, DeviceBuffer, RingBank, SpectralBank,  # noqa: F401
                     design_filter, device_count, filter_freq_chart, make_window)

@@ -99,6 +99,22 @@ PROTOTYPES = {
     "mi_analyzer_bank_get_spectrum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32, c_void_p]),
     "mi_analyzer_bank_reduce_bins": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "mi_analyzer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "mi_delay_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t]),
+    "mi_delay_bank_destroy": (c_int, [c_void_p]),
+    "mi_delay_bank_set_delay": (c_int, [c_void_p, c_uint32, c_size_t]),
+    "mi_delay_bank_get": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "mi_delay_bank_clear": (c_int, [c_void_p, c_void_p]),
+    "mi_delay_bank_append": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "mi_delay_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int, c_int, c_float,
+                                      c_void_p, c_size_t, c_void_p]),
+    "mi_delay_bank_process_ramping": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int,
+                                              c_float, c_void_p, c_size_t, c_void_p]),
+    "mi_ring_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t, c_float]),
+    "mi_ring_bank_destroy": (c_int, [c_void_p]),
+    "mi_ring_bank_fill": (c_int, [c_void_p, c_float, c_void_p]),
+    "mi_ring_bank_append": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, POINTER(c_size_t), c_void_p]),
+    "mi_ring_bank_get": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, POINTER(c_size_t), c_void_p]),
+    "mi_ring_bank_info": (c_int, [c_void_p, c_size_t, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "mi_biquad_section_tables": (c_int, [POINTER(BiquadX1), c_int, POINTER(c_float), POINTER(c_uint32)]),
 }
 

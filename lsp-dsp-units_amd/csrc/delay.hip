@@ -1,0 +1,438 @@
+// Delay-line and ring-buffer banks for gfx950:
+//   mi_delay_bank -- `channels` x lsp::dspu::Delay      (reference: src/main/util/Delay.cpp:51-582)
+//   mi_ring_bank  -- `channels` x lsp::dspu::RingBuffer (reference: src/main/util/RingBuffer.cpp:48-209)
+// Pure data movement: every kernel is a gather/scatter whose index arithmetic is the reference's own
+// (unsigned 32-bit head/tail/size, same modulo expressions), so results are bit-exact by construction.
+// All channels of a bank advance together (one head), delays are per channel.
+#include "mi_common.h"
+
+#include <cstdint>
+#include <vector>
+
+namespace
+{
+    constexpr uint32_t DELAY_GAP = 0x200;       // Delay.cpp:26
+
+    // gain modes shared by the process variants (Delay.cpp:104-397)
+    enum { G_NONE = 0, G_SCALAR = 1, G_VECTOR = 2 };
+
+    __device__ __forceinline__ float apply_gain(float v, int mode, float k, const float *gv, size_t i)
+    {
+        return (mode == G_SCALAR) ? v * k : (mode == G_VECTOR) ? v * gv[i] : v;
+    }
+
+    // ring[(head + i) % size] = src[i] for the last min(count, size) samples (Delay::append, Delay.cpp:76-102)
+    __global__ __launch_bounds__(256)
+    void ring_append_kernel(float *ring, uint32_t size, uint32_t head, const float *src, size_t src_stride, size_t count)
+    {
+        const uint32_t ch = blockIdx.y;
+        const size_t first = (count > size) ? count - size : 0;         // older samples would be overwritten anyway
+        for (size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+            ring[size_t(ch) * size + (head + i) % size] = src[size_t(ch) * src_stride + i];
+    }
+
+    // dst[i] (+)= gain * ring[(tail_c + i) % size] -- the "shift data from buffer" half of Delay::process
+    __global__ __launch_bounds__(256)
+    void ring_read_kernel(float *dst, size_t dst_stride, const float *ring, uint32_t size, uint32_t head,
+                          const uint32_t *__restrict__ delay, size_t count, int add, int gmode, float k,
+                          const float *gv, size_t gv_stride)
+    {
+        const uint32_t ch = blockIdx.y;
+        const uint32_t tail = (head + size - delay[ch]) % size;         // Delay.cpp:101
+        for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+        {
+            const float v = apply_gain(ring[size_t(ch) * size + (tail + i) % size], gmode, k, gv + size_t(ch) * gv_stride, i);
+            float *d = dst + size_t(ch) * dst_stride + i;
+            *d = add ? *d + v : v;
+        }
+    }
+
+    // Delay::process_ramping (Delay.cpp:399-546): the read position slides from the old delay to the new one.
+    // Reproduces the reference's chunked write-then-read order in closed form: the sample read at output offset o
+    // is the newest input written to that ring cell by the end of o's chunk, else the cell's old content.
+    __global__ __launch_bounds__(256)
+    void delay_ramp_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, const float *ring,
+                           uint32_t size, uint32_t head, const uint32_t *__restrict__ old_delay,
+                           const uint32_t *__restrict__ new_delay, size_t count, int gmode, float k,
+                           const float *gv, size_t gv_stride)
+    {
+        const uint32_t ch = blockIdx.y;
+        const uint32_t od = old_delay[ch], nd = new_delay[ch];
+        const uint32_t old_tail = (head + size - od) % size;
+        const float *x = src + size_t(ch) * src_stride;
+        const float *rb = ring + size_t(ch) * size;
+        if (od == nd)                                                   // Delay.cpp:402-406: plain process
+        {
+            for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+            {
+                const float v = (i >= od) ? x[i - od] : rb[(old_tail + i) % size];
+                dst[size_t(ch) * dst_stride + i] = apply_gain(v, gmode, k, gv + size_t(ch) * gv_stride, i);
+            }
+            return;
+        }
+        const size_t gap = size - ((nd > od) ? nd : od);               // free_gap
+        const float delta = 1.0f + float(int64_t(od) - int64_t(nd)) / float(count);
+        for (size_t o = size_t(blockIdx.x) * 256 + threadIdx.x; o < count; o += size_t(gridDim.x) * 256)
+        {
+            const size_t chunk_end = ((o / gap + 1) * gap < count) ? (o / gap + 1) * gap : count;
+            const size_t tail = (size_t(old_tail) + size_t(int64_t(delta * float(o)))) % size;    // Delay.cpp:434
+            const size_t i0 = (tail + size - head) % size;              // input index that lands on this cell
+            float v;
+            if (i0 < chunk_end)
+                v = x[i0 + ((chunk_end - 1 - i0) / size) * size];       // newest write so far
+            else
+                v = rb[tail];
+            dst[size_t(ch) * dst_stride + o] = apply_gain(v, gmode, k, gv + size_t(ch) * gv_stride, o);
+        }
+    }
+
+    // RingBuffer::get(dst, offset, count) (RingBuffer.cpp:147-183) for every channel
+    __global__ __launch_bounds__(256)
+    void ring_get_kernel(float *dst, size_t dst_stride, const float *ring, uint32_t cap, uint32_t head,
+                         size_t offset, size_t count)
+    {
+        const uint32_t ch = blockIdx.y;
+        // leading zeros while the requested position is older than the buffer
+        size_t lead = 0;
+        size_t off = offset;
+        if (off >= cap)
+        {
+            lead = (count < off - cap + 1) ? count : off - cap + 1;
+            off -= lead;
+        }
+        const bool empty = (off >= cap);
+        const size_t tail = empty ? 0 : (size_t(head) + cap - off - 1) % cap;
+        const size_t rest = count - lead;
+        const size_t to_read = empty ? 0 : ((rest < off + 1) ? rest : off + 1);
+        for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+        {
+            float v = 0.0f;
+            if (i >= lead && i - lead < to_read)
+                v = ring[size_t(ch) * cap + (tail + (i - lead)) % cap];
+            dst[size_t(ch) * dst_stride + i] = v;
+        }
+    }
+
+    __global__ __launch_bounds__(256)
+    void fill_kernel(float *p, size_t n, float v)
+    {
+        for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < n; i += size_t(gridDim.x) * 256)
+            p[i] = v;
+    }
+
+    inline dim3 grid_for(size_t count, uint32_t channels)
+    {
+        size_t gx = (count + 255) / 256;
+        if (gx > 64) gx = 64;
+        if (gx == 0) gx = 1;
+        return dim3(uint32_t(gx), channels);
+    }
+} // namespace
+
+struct mi_delay_bank
+{
+    uint32_t    channels = 0, size = 0, head = 0;
+    std::vector<uint32_t> delay;
+    float      *d_ring = nullptr, *d_scratch = nullptr;
+    size_t      scratch_floats = 0;
+    uint32_t   *d_delay = nullptr, *d_delay_new = nullptr;
+    bool        delay_dirty = true;
+};
+
+namespace
+{
+    int sync_delays(mi_delay_bank *b, hipStream_t st)
+    {
+        if (!b->delay_dirty)
+            return MI_OK;
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_delay, b->delay.data(), b->channels * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        b->delay_dirty = false;
+        return MI_OK;
+    }
+
+    int append(mi_delay_bank *b, const float *src, size_t stride, size_t count, hipStream_t st)
+    {
+        hipLaunchKernelGGL(ring_append_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+                           b->d_ring, b->size, b->head, src, stride, count);
+        MI_HIP_CHECK(hipGetLastError());
+        b->head = uint32_t((size_t(b->head) + count) % b->size);
+        return MI_OK;
+    }
+
+    // a private copy of the caller's input when dst aliases src
+    int stage_input(mi_delay_bank *b, const float **src, size_t *stride, size_t count, hipStream_t st)
+    {
+        const size_t need = size_t(b->channels) * count;
+        if (need > b->scratch_floats)
+        {
+            (void)hipFree(b->d_scratch);
+            b->d_scratch = nullptr;
+            b->scratch_floats = 0;
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_scratch), need * sizeof(float)));
+            b->scratch_floats = need;
+        }
+        MI_HIP_CHECK(hipMemcpy2DAsync(b->d_scratch, count * sizeof(float), *src, *stride * sizeof(float),
+                                      count * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+        *src = b->d_scratch;
+        *stride = count;
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_delay_bank_create(mi_delay_bank_t **bank, uint32_t channels, size_t max_size)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_delay_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0, MI_EINVAL, "mi_delay_bank_create: channels must be > 0");
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_delay_bank *b = new (std::nothrow) mi_delay_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_delay_bank_create: out of host memory");
+    b->channels = channels;
+    // Delay.cpp:53: size = align_size(max_size + DELAY_GAP, DELAY_GAP)
+    b->size = uint32_t(((max_size + DELAY_GAP + DELAY_GAP - 1) / DELAY_GAP) * DELAY_GAP);
+    b->delay.assign(channels, 0);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_ring), size_t(channels) * b->size * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_delay), channels * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_delay_new), channels * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemset(b->d_ring, 0, size_t(channels) * b->size * sizeof(float));
+    if (e != hipSuccess)
+    {
+        mi_delay_bank_destroy(b);
+        return mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_delay_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_delay_bank_destroy(mi_delay_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_scratch); (void)hipFree(b->d_delay); (void)hipFree(b->d_delay_new);
+    delete b;
+    return MI_OK;
+}
+
+int mi_delay_bank_set_delay(mi_delay_bank_t *b, uint32_t channel, size_t delay)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_delay_bank_set_delay: NULL bank");
+    const uint32_t d = uint32_t(delay % b->size);                      // Delay.cpp:571
+    if (channel == UINT32_MAX)
+        std::fill(b->delay.begin(), b->delay.end(), d);
+    else
+    {
+        MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_delay_bank_set_delay: channel %u out of range", channel);
+        b->delay[channel] = d;
+    }
+    b->delay_dirty = true;
+    return MI_OK;
+}
+
+int mi_delay_bank_get(const mi_delay_bank_t *b, uint32_t channel, uint32_t *delay, uint32_t *size, uint32_t *head, uint32_t *tail)
+{
+    MI_REQUIRE(b != nullptr && channel < b->channels, MI_EINVAL, "mi_delay_bank_get: bad argument");
+    if (delay) *delay = b->delay[channel];
+    if (size)  *size = b->size;
+    if (head)  *head = b->head;
+    if (tail)  *tail = (b->head + b->size - b->delay[channel]) % b->size;
+    return MI_OK;
+}
+
+int mi_delay_bank_clear(mi_delay_bank_t *b, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_delay_bank_clear: NULL bank");
+    MI_HIP_CHECK(hipMemsetAsync(b->d_ring, 0, size_t(b->channels) * b->size * sizeof(float), mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_delay_bank_append(mi_delay_bank_t *b, const float *in, size_t count, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "mi_delay_bank_append: bad argument");
+    if (count == 0)
+        return MI_OK;
+    return append(b, in, in_stride, count, mi::as_stream(stream));
+}
+
+int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_t count, size_t out_stride,
+                          size_t in_stride, int add, int gain_mode, float gain, const float *gain_vec,
+                          size_t gain_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_delay_bank_process: NULL bank");
+    if (count == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_delay_bank_process: NULL buffer");
+    MI_REQUIRE(gain_mode != G_VECTOR || gain_vec != nullptr, MI_EINVAL, "mi_delay_bank_process: NULL gain vector");
+    hipStream_t st = mi::as_stream(stream);
+    int r = sync_delays(b, st);
+    if (r != MI_OK)
+        return r;
+    // The reference alternates "push to_do samples / pull to_do samples" in pieces of at most size - delay
+    // (Delay.cpp:113-142) so that a pull never reads a cell a later push of the same call already overwrote.
+    // Same order here, with the piece bounded by the largest delay of the bank.
+    uint32_t dmax = 0;
+    for (uint32_t d : b->delay)
+        dmax = (d > dmax) ? d : dmax;
+    const size_t gap = b->size - dmax;
+    size_t done = 0;
+    while (done < count)
+    {
+        const size_t n = (count - done < gap) ? count - done : gap;
+        const uint32_t head_before = b->head;
+        r = append(b, in + done, in_stride, n, st);
+        if (r != MI_OK)
+            return r;
+        hipLaunchKernelGGL(ring_read_kernel, grid_for(n, b->channels), dim3(256), 0, st,
+                           out + done, out_stride, b->d_ring, b->size, head_before, b->d_delay, n, add, gain_mode, gain,
+                           gain_vec ? gain_vec + done : nullptr, gain_stride);
+        MI_HIP_CHECK(hipGetLastError());
+        done += n;
+    }
+    return MI_OK;
+}
+
+int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *in, const uint32_t *new_delays,
+                                  size_t count, size_t out_stride, size_t in_stride, int gain_mode, float gain,
+                                  const float *gain_vec, size_t gain_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_delay_bank_process_ramping: NULL bank");
+    MI_REQUIRE(new_delays != nullptr, MI_EINVAL, "mi_delay_bank_process_ramping: NULL delays");
+    if (count == 0)                                                     // Delay.cpp:407-408
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_delay_bank_process_ramping: NULL buffer");
+    hipStream_t st = mi::as_stream(stream);
+    int r = sync_delays(b, st);
+    if (r != MI_OK)
+        return r;
+    std::vector<uint32_t> nd(new_delays, new_delays + b->channels);
+    for (uint32_t c = 0; c < b->channels; ++c)
+        MI_REQUIRE(nd[c] < b->size, MI_EINVAL, "mi_delay_bank_process_ramping: delay %u does not fit the line", nd[c]);
+    MI_HIP_CHECK(hipMemcpyAsync(b->d_delay_new, nd.data(), nd.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    const float *src = in;
+    size_t stride = in_stride;
+    if (static_cast<const void *>(out) == static_cast<const void *>(in))
+    {
+        r = stage_input(b, &src, &stride, count, st);
+        if (r != MI_OK)
+            return r;
+    }
+    hipLaunchKernelGGL(delay_ramp_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+                       out, out_stride, src, stride, b->d_ring, b->size, b->head, b->d_delay, b->d_delay_new,
+                       count, gain_mode, gain, gain_vec, gain_stride);
+    MI_HIP_CHECK(hipGetLastError());
+    r = append(b, src, stride, count, st);
+    if (r != MI_OK)
+        return r;
+    b->delay = nd;                                                      // Delay.cpp:444-445
+    b->delay_dirty = true;
+    return MI_OK;
+}
+
+} // extern "C"
+
+// =============================================================================================================
+struct mi_ring_bank
+{
+    uint32_t    channels = 0, capacity = 0, head = 0;
+    float      *d_ring = nullptr;
+};
+
+extern "C" {
+
+int mi_ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_ring_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0 && size > 0, MI_EINVAL, "mi_ring_bank_create: channels and size must be > 0");
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_ring_bank *b = new (std::nothrow) mi_ring_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_ring_bank_create: out of host memory");
+    b->channels = channels;
+    b->capacity = uint32_t(size);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_ring), size_t(channels) * size * sizeof(float));
+    if (e != hipSuccess)
+    {
+        delete b;
+        return mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_ring_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return mi_ring_bank_fill(b, fill, nullptr);                         // RingBuffer::init fills (RingBuffer.cpp:48-63)
+}
+
+int mi_ring_bank_destroy(mi_ring_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    (void)hipFree(b->d_ring);
+    delete b;
+    return MI_OK;
+}
+
+int mi_ring_bank_fill(mi_ring_bank_t *b, float value, void *stream)    // clear() / fill(), RingBuffer.cpp:108-120
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ring_bank_fill: NULL bank");
+    b->head = 0;
+    const size_t n = size_t(b->channels) * b->capacity;
+    hipLaunchKernelGGL(fill_kernel, dim3(uint32_t((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
+                       mi::as_stream(stream), b->d_ring, n, value);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_ring_bank_append(mi_ring_bank_t *b, const float *in, size_t count, size_t in_stride, size_t *appended, void *stream)
+{
+    MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "mi_ring_bank_append: bad argument");
+    if (appended)
+        *appended = (count > b->capacity) ? b->capacity : count;        // RingBuffer.cpp:78-83,105
+    if (count == 0)
+        return MI_OK;
+    if (count > b->capacity)                                            // keeps the newest `capacity`, head = 0
+    {
+        in += count - b->capacity;
+        count = b->capacity;
+        b->head = 0;
+    }
+    hipLaunchKernelGGL(ring_append_kernel, grid_for(count, b->channels), dim3(256), 0, mi::as_stream(stream),
+                       b->d_ring, b->capacity, b->head, in, in_stride, count);
+    MI_HIP_CHECK(hipGetLastError());
+    b->head = uint32_t((size_t(b->head) + count) % b->capacity);
+    return MI_OK;
+}
+
+int mi_ring_bank_get(mi_ring_bank_t *b, float *out, size_t offset, size_t count, size_t out_stride, size_t *read, void *stream)
+{
+    MI_REQUIRE(b != nullptr && (count == 0 || out != nullptr), MI_EINVAL, "mi_ring_bank_get: bad argument");
+    // return value of RingBuffer::get(dst, offset, count), RingBuffer.cpp:147-183
+    size_t off = offset, cnt = count, got = 0;
+    if (off >= b->capacity)
+    {
+        const size_t lead = (cnt < off - b->capacity + 1) ? cnt : off - b->capacity + 1;
+        off -= lead;
+        cnt -= lead;
+    }
+    if (off < b->capacity)
+        got = (cnt < off + 1) ? cnt : off + 1;
+    if (read)
+        *read = got;
+    if (count == 0)
+        return MI_OK;
+    hipLaunchKernelGGL(ring_get_kernel, grid_for(count, b->channels), dim3(256), 0, mi::as_stream(stream),
+                       out, out_stride, b->d_ring, b->capacity, b->head, offset, count);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_ring_bank_info(const mi_ring_bank_t *b, size_t offset, uint32_t *capacity, uint32_t *head, uint32_t *tail_position)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ring_bank_info: NULL bank");
+    if (capacity) *capacity = b->capacity;
+    if (head)     *head = b->head;
+    if (tail_position)                                                  // RingBuffer.cpp:140-145
+        *tail_position = (offset < b->capacity) ? uint32_t((size_t(b->head) + b->capacity - offset - 1) % b->capacity) : b->head;
+    return MI_OK;
+}
+
+} // extern "C"

@@ -324,3 +324,93 @@ class AnalyzerBank:
             self.close()
         except Exception:
             pass
+
+
+class DelayBank:
+    """`channels` x lsp::dspu::Delay on the device."""
+
+    def __init__(self, channels, max_size):
+        h = c_void_p()
+        check(lib.mi_delay_bank_create(byref(h), channels, max_size))
+        self.handle, self.channels = h, channels
+
+    def set_delay(self, delay, channel=None):
+        check(lib.mi_delay_bank_set_delay(self.handle, 0xFFFFFFFF if channel is None else channel, int(delay)))
+
+    def get(self, channel=0):
+        v = [c_uint32() for _ in range(4)]
+        check(lib.mi_delay_bank_get(self.handle, channel, *[byref(x) for x in v]))
+        return dict(zip(("delay", "size", "head", "tail"), [x.value for x in v]))
+
+    def clear(self, stream=None):
+        check(lib.mi_delay_bank_clear(self.handle, _stream(stream)))
+
+    def append(self, inp, count, in_stride=None, stream=None):
+        check(lib.mi_delay_bank_append(self.handle, _ptr(inp), count, count if in_stride is None else in_stride, _stream(stream)))
+
+    def process(self, out, inp, count, add=False, gain=None, gain_vec=None, out_stride=None, in_stride=None, stream=None):
+        mode = 2 if gain_vec is not None else (1 if gain is not None else 0)
+        check(lib.mi_delay_bank_process(self.handle, _ptr(out), _ptr(inp), count,
+                                        count if out_stride is None else out_stride,
+                                        count if in_stride is None else in_stride, int(add), mode,
+                                        0.0 if gain is None else float(gain),
+                                        _ptr(gain_vec) if gain_vec is not None else None, count, _stream(stream)))
+
+    def process_ramping(self, out, inp, new_delays, count, gain=None, gain_vec=None, stream=None):
+        nd = np.ascontiguousarray(new_delays, dtype=np.uint32)
+        assert nd.shape == (self.channels,)
+        mode = 2 if gain_vec is not None else (1 if gain is not None else 0)
+        check(lib.mi_delay_bank_process_ramping(self.handle, _ptr(out), _ptr(inp), nd.ctypes.data_as(c_void_p), count,
+                                                count, count, mode, 0.0 if gain is None else float(gain),
+                                                _ptr(gain_vec) if gain_vec is not None else None, count, _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_delay_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class RingBank:
+    """`channels` x lsp::dspu::RingBuffer on the device."""
+
+    def __init__(self, channels, size, fill=0.0):
+        h = c_void_p()
+        check(lib.mi_ring_bank_create(byref(h), channels, size, fill))
+        self.handle, self.channels = h, channels
+
+    def fill(self, value=0.0, stream=None):
+        check(lib.mi_ring_bank_fill(self.handle, value, _stream(stream)))
+
+    def append(self, inp, count, in_stride=None, stream=None):
+        n = ctypes.c_size_t()
+        check(lib.mi_ring_bank_append(self.handle, _ptr(inp), count, count if in_stride is None else in_stride,
+                                      byref(n), _stream(stream)))
+        return n.value
+
+    def get(self, out, offset, count, out_stride=None, stream=None):
+        n = ctypes.c_size_t()
+        check(lib.mi_ring_bank_get(self.handle, _ptr(out), offset, count, count if out_stride is None else out_stride,
+                                   byref(n), _stream(stream)))
+        return n.value
+
+    def info(self, offset=0):
+        v = [c_uint32() for _ in range(3)]
+        check(lib.mi_ring_bank_info(self.handle, offset, *[byref(x) for x in v]))
+        return dict(zip(("capacity", "head", "tail_position"), [x.value for x in v]))
+
+    def close(self):
+        if self.handle:
+            lib.mi_ring_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,114 @@
+"""GPU Delay / RingBuffer banks: bit-exact against the oracle (and, for RingBuffer, the reference's own KAT)."""
+import numpy as np
+import pytest
+
+from oracle import delay as od
+from ringbuffer_kat import KAT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_reference_ringbuffer_kat_on_gpu(gpu):
+    """src/test/utest/util/ringbuffer.cpp:30-192, every channel of a 3-channel bank."""
+    C = 3
+    rb = None
+    for op, arg, exp in KAT:
+        if op == "init":
+            rb = gpu.RingBank(C, arg)
+            assert rb.info()["capacity"] == 8
+        elif op in ("append1", "append"):
+            items = [[v] for v in arg] if op == "append1" else [arg]
+            for it in items:
+                d = gpu.DeviceBuffer.from_host(np.tile(np.array(it, np.float32), (C, 1)))
+                n = rb.append(d, len(it))
+                if op == "append":
+                    assert n == exp
+        elif op == "get1":
+            for o, e in zip(arg, exp):
+                out = gpu.DeviceBuffer((C, 1))
+                rb.get(out, o, 1)
+                assert np.all(out.download() == np.float32(e)), (o, e)
+        elif op == "get":
+            out = gpu.DeviceBuffer.from_host(np.full((C, arg[1]), 99.0, np.float32))
+            n = rb.get(out, arg[0], arg[1])
+            assert n == exp[0]
+            np.testing.assert_array_equal(out.download(), np.tile(np.array(exp[1], np.float32), (C, 1)))
+    rb.close()
+
+
+@pytest.mark.parametrize("in_place", [False, True])
+def test_delay_process_variants_bit_exact(gpu, in_place):
+    rng = np.random.default_rng(1)
+    C, maxd = 4, 1000
+    delays = [0, 1, 511, 1000]
+    x = rng.standard_normal((C, 6000)).astype(np.float32)
+    g = rng.uniform(0.5, 2.0, (C, 6000)).astype(np.float32)
+    base = rng.standard_normal((C, 6000)).astype(np.float32)
+    bank = gpu.DelayBank(C, maxd)
+    refs = [od.Delay(maxd) for _ in range(C)]
+    for c, d in enumerate(delays):
+        bank.set_delay(d, c); refs[c].set_delay(d)
+    assert bank.get(3) == {"delay": 1000, "size": 1536, "head": 0, "tail": 536}
+    pos = 0
+    for n, mode in ((700, "plain"), (1536, "scalar"), (64, "vector"), (2000, "add"), (1700, "add_vector")):
+        xs, gs, bs = x[:, pos:pos + n], g[:, pos:pos + n], base[:, pos:pos + n]
+        din = gpu.DeviceBuffer.from_host(xs)
+        dout = din if (in_place and not mode.startswith("add")) else gpu.DeviceBuffer.from_host(bs)
+        dg = gpu.DeviceBuffer.from_host(gs)
+        if mode == "plain":
+            bank.process(dout, din, n); ref = [r.process(xs[c]) for c, r in enumerate(refs)]
+        elif mode == "scalar":
+            bank.process(dout, din, n, gain=0.37); ref = [r.process(xs[c], gain=0.37) for c, r in enumerate(refs)]
+        elif mode == "vector":
+            bank.process(dout, din, n, gain_vec=dg); ref = [r.process(xs[c], gain=gs[c]) for c, r in enumerate(refs)]
+        elif mode == "add":
+            bank.process(dout, din, n, add=True); ref = [r.process(xs[c], add_to=bs[c]) for c, r in enumerate(refs)]
+        else:
+            bank.process(dout, din, n, add=True, gain_vec=dg); ref = [r.process(xs[c], gain=gs[c], add_to=bs[c]) for c, r in enumerate(refs)]
+        np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=mode)
+        pos += n
+    bank.close()
+
+
+@pytest.mark.parametrize("in_place", [False, True])
+def test_delay_ramping_bit_exact(gpu, in_place):
+    """Delay::process_ramping index (old_tail + ssize_t(delta * offset)) % size, incl. pieces and wrap."""
+    rng = np.random.default_rng(2)
+    C, maxd = 5, 2000
+    x = rng.standard_normal((C, 9000)).astype(np.float32)
+    bank = gpu.DelayBank(C, maxd)
+    refs = [od.Delay(maxd) for _ in range(C)]
+    start = [0, 100, 1500, 2000, 700]
+    for c, d in enumerate(start):
+        bank.set_delay(d, c); refs[c].set_delay(d)
+    pos = 0
+    for n, targets in ((1000, [50, 100, 20, 1999, 701]), (3000, [2000, 0, 1999, 3, 700]), (37, [0, 1, 2, 3, 4]),
+                       (4000, [1000, 1000, 1000, 1000, 1000])):
+        xs = x[:, pos:pos + n]
+        din = gpu.DeviceBuffer.from_host(xs)
+        dout = din if in_place else gpu.DeviceBuffer((C, n))
+        bank.process_ramping(dout, din, targets, n, gain=1.25)
+        ref = np.stack([r.process_ramping(xs[c], targets[c], gain=1.25) for c, r in enumerate(refs)])
+        np.testing.assert_array_equal(dout.download(), ref, err_msg=str((n, targets)))
+        pos += n
+    # the line keeps working with plain process afterwards
+    xs = x[:, pos:pos + 500]
+    din = gpu.DeviceBuffer.from_host(xs); dout = gpu.DeviceBuffer((C, 500))
+    bank.process(dout, din, 500)
+    np.testing.assert_array_equal(dout.download(), np.stack([r.process(xs[c]) for c, r in enumerate(refs)]))
+    bank.close()
+
+
+def test_delay_append_and_clear(gpu):
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 5000)).astype(np.float32)
+    bank = gpu.DelayBank(2, 100)          # size 512
+    bank.set_delay(100)
+    bank.append(gpu.DeviceBuffer.from_host(x[:, :3000]), 3000)      # longer than the line
+    din = gpu.DeviceBuffer.from_host(x[:, 3000:3300]); dout = gpu.DeviceBuffer((2, 300))
+    bank.process(dout, din, 300)
+    np.testing.assert_array_equal(dout.download(), x[:, 2900:3200])
+    bank.clear()
+    bank.process(dout, din, 50)
+    np.testing.assert_array_equal(dout.download()[:, :50], np.zeros((2, 50), np.float32))
+    bank.close()
