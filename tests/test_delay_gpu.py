@@ -109,6 +109,6 @@ def test_delay_append_and_clear(gpu):
     bank.process(dout, din, 300)
     np.testing.assert_array_equal(dout.download(), x[:, 2900:3200])
     bank.clear()
-    bank.process(dout, din, 50)
+    bank.process(dout, din, 50, out_stride=300, in_stride=300)
     np.testing.assert_array_equal(dout.download()[:, :50], np.zeros((2, 50), np.float32))
     bank.close()
