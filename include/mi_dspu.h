@@ -284,6 +284,10 @@ typedef struct mi_convolver_bank mi_convolver_bank_t;
  */
 int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, const float *irs, size_t ir_stride,
                              const uint32_t *counts, uint32_t count, uint32_t rank, float phase, void *stream);
+/* Replace every channel's impulse response by `count` taps read from DEVICE memory [channels][ir_stride]
+ * (count within the capacity the bank was created with); input history is kept.  Used by the equalizer bank
+ * when it retunes (the reference re-parses its FIR the same way, Equalizer.cpp:342-345). Synchronises `stream`. */
+int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count, void *stream);
 /* Convolver::destroy(), Convolver.cpp:71-75. */
 int mi_convolver_bank_destroy(mi_convolver_bank_t *bank);
 /* Forget all input history (state right after init). */
@@ -342,6 +346,10 @@ int mi_spectral_bank_destroy(mi_spectral_bank_t *bank);
 /* set_rank / set_phase, SpectralProcessor.cpp:127-145 (a rank above max_rank is ignored, phase is clamped to 0..1). */
 int mi_spectral_bank_set_rank(mi_spectral_bank_t *bank, uint32_t rank);
 int mi_spectral_bank_set_phase(mi_spectral_bank_t *bank, float phase);
+/* Analysis / synthesis windows (enum mi_window, or -1 for none).  The reference processor always uses the sine
+ * window on both sides (SpectralProcessor.cpp:118); the Equalizer's SPM mode uses none / squared cosine
+ * (Equalizer.cpp:352-353,535-540) and is built on this. */
+int mi_spectral_bank_set_windows(mi_spectral_bank_t *bank, int in_window, int out_window);
 /* get_rank(), latency(), remaining() (SpectralProcessor.h:128,142, SpectralProcessor.cpp:251-255). */
 int mi_spectral_bank_get(const mi_spectral_bank_t *bank, uint32_t *rank, uint32_t *latency, uint32_t *remaining);
 /* bind(func, object, subject) / unbind(), SpectralProcessor.cpp:91-105. */
@@ -394,6 +402,36 @@ int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *bank, float *out, size_t o
  * of the cross-channel per-bin reduction; the caller all-reduces it across GPUs. */
 int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_envelope, void *stream);
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *bank, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step);
+
+/* ---- equalizer bank --------------------------------------------------------------------------- */
+/*
+ * mi_equalizer_bank: `channels` x lsp::dspu::Equalizer(filters, fir_rank)
+ * (include/lsp-plug.in/dsp-units/filters/Equalizer.h:47-289).  equalizer_mode_t values as in Equalizer.h:35-42.
+ */
+typedef struct mi_equalizer_bank mi_equalizer_bank_t;
+enum { MI_EQM_BYPASS = 0, MI_EQM_IIR = 1, MI_EQM_FIR = 2, MI_EQM_FFT = 3, MI_EQM_SPM = 4 };
+
+/* Equalizer::init(filters, fir_rank), src/main/filters/Equalizer.cpp:67-160 (fir_rank 0 or 5..13). */
+int mi_equalizer_bank_create(mi_equalizer_bank_t **bank, uint32_t channels, uint32_t filters, uint32_t fir_rank);
+int mi_equalizer_bank_destroy(mi_equalizer_bank_t *bank);
+/* set_params(id, params) of one channel (or UINT32_MAX: all), Equalizer.cpp:210-218; MI_EINVAL for a bad id
+ * where the reference returns false. */
+int mi_equalizer_bank_set_params(mi_equalizer_bank_t *bank, uint32_t channel, uint32_t filter, const mi_filter_params_t *params);
+int mi_equalizer_bank_get_params(const mi_equalizer_bank_t *bank, uint32_t channel, uint32_t filter, mi_filter_params_t *params);
+/* set_mode / set_sample_rate / set_actual_sample_rate, Equalizer.cpp:360-375,188-203. */
+int mi_equalizer_bank_set_mode(mi_equalizer_bank_t *bank, int mode);
+int mi_equalizer_bank_set_sample_rate(mi_equalizer_bank_t *bank, uint32_t sample_rate);
+int mi_equalizer_bank_set_actual_sample_rate(mi_equalizer_bank_t *bank, uint32_t sample_rate);
+/* get_latency() (reconfigures first), Equalizer.cpp:237-241. */
+int mi_equalizer_bank_get_latency(mi_equalizer_bank_t *bank, uint32_t *latency, void *stream);
+/* reset(), Equalizer.cpp:573-597. */
+int mi_equalizer_bank_reset(mi_equalizer_bank_t *bank, void *stream);
+/* process(out, in, samples), Equalizer.cpp:460-571.  The one-off cross-fade of a "smooth" retune
+ * (EF_XFADE, Equalizer.cpp:486-501) is not implemented: a retune switches at the next block. */
+int mi_equalizer_bank_process(mi_equalizer_bank_t *bank, float *out, const float *in, size_t samples,
+                              size_t out_stride, size_t in_stride, void *stream);
+/* filter count, fir_rank(), mode(), ir_size() (Equalizer.cpp:599-616). */
+int mi_equalizer_bank_info(const mi_equalizer_bank_t *bank, uint32_t *filters, uint32_t *fir_rank, int *mode, uint32_t *ir_size);
 
 /* ---- delay line and ring buffer banks ----------------------------------------------------- */
 /*

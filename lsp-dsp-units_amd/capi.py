@@ -99,6 +99,19 @@ PROTOTYPES = {
     "mi_analyzer_bank_get_spectrum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32, c_void_p]),
     "mi_analyzer_bank_reduce_bins": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "mi_analyzer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "mi_convolver_bank_set_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
+    "mi_spectral_bank_set_windows": (c_int, [c_void_p, c_int, c_int]),
+    "mi_equalizer_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32]),
+    "mi_equalizer_bank_destroy": (c_int, [c_void_p]),
+    "mi_equalizer_bank_set_params": (c_int, [c_void_p, c_uint32, c_uint32, POINTER(FilterParams)]),
+    "mi_equalizer_bank_get_params": (c_int, [c_void_p, c_uint32, c_uint32, POINTER(FilterParams)]),
+    "mi_equalizer_bank_set_mode": (c_int, [c_void_p, c_int]),
+    "mi_equalizer_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),
+    "mi_equalizer_bank_set_actual_sample_rate": (c_int, [c_void_p, c_uint32]),
+    "mi_equalizer_bank_get_latency": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
+    "mi_equalizer_bank_reset": (c_int, [c_void_p, c_void_p]),
+    "mi_equalizer_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_equalizer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int), POINTER(c_uint32)]),
     "mi_delay_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t]),
     "mi_delay_bank_destroy": (c_int, [c_void_p]),
     "mi_delay_bank_set_delay": (c_int, [c_void_p, c_uint32, c_size_t]),

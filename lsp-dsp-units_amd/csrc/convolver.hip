@@ -441,6 +441,43 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     return mi_convolver_bank_reset(b, stream);
 }
 
+int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count, void *stream)
+{
+    MI_REQUIRE(b != nullptr && b->live, MI_ESTATE, "mi_convolver_bank_set_irs_device: bank is not initialised");
+    MI_REQUIRE(d_irs != nullptr && count > 0 && ir_stride >= count, MI_EINVAL, "mi_convolver_bank_set_irs_device: bad argument");
+    MI_REQUIRE(count <= uint32_t(b->P) * uint32_t(b->B), MI_EINVAL,
+               "mi_convolver_bank_set_irs_device: %u taps exceed the %d x %d the bank was created for", count, b->P, b->B);
+    hipStream_t st = mi::as_stream(stream);
+    const size_t M = size_t(b->B);
+    // zero-padded staging rows [channels][P*B], then the same parse kernel as init
+    float *d_ir = nullptr;
+    uint32_t *d_counts = nullptr;
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d_ir), size_t(b->channels) * b->P * M * sizeof(float)));
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_counts), b->channels * sizeof(uint32_t));
+    std::vector<uint32_t> cnt(b->channels, count);
+    if (e == hipSuccess) e = hipMemsetAsync(d_ir, 0, size_t(b->channels) * b->P * M * sizeof(float), st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(d_ir, size_t(b->P) * M * sizeof(float), d_irs, ir_stride * sizeof(float),
+                                              size_t(count) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_counts, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpy2DAsync(b->d_h0, M * sizeof(float), d_ir, size_t(b->P) * M * sizeof(float),
+                                              M * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess)
+    {
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, b->channels), dim3(plan<LM>::T), 0, st, \
+                                               b->d_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw)
+        MI_LOGM_SWITCH(b->logm, MI_CALL)
+        #undef MI_CALL
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(d_ir);
+    (void)hipFree(d_counts);
+    MI_HIP_CHECK(e);
+    b->counts.assign(b->channels, count);
+    b->taps = count;
+    return MI_OK;
+}
+
 int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
 {
     if (b == nullptr)

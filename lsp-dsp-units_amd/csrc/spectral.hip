@@ -269,7 +269,8 @@ struct mi_spectral_bank
     int         op = MI_SPECTRAL_OP_NONE;
     mi_spectral_func_t func = nullptr;
     void       *object = nullptr, *subject = nullptr;
-    float      *d_in = nullptr, *d_out = nullptr, *d_wnd = nullptr, *d_mask = nullptr;
+    float      *d_in = nullptr, *d_out = nullptr, *d_wnd = nullptr, *d_wnd_out = nullptr, *d_mask = nullptr;
+    int         wnd_in = MI_WINDOW_COSINE, wnd_out = MI_WINDOW_COSINE;     // < 0: no window
     float2     *d_spec = nullptr;
     uint8_t    *d_active = nullptr, *d_has_out = nullptr;   // MultiSpectralProcessor bindings (NULL: all bound)
     size_t      mask_stride = 0;
@@ -292,13 +293,37 @@ namespace
             default: { CALL(12); break; }               \
         }
 
+    // full complex transforms of N = 2^rank points (callback path): ranks 5..13
+    #define MI_LOGN_SWITCH(ln, CALL)                    \
+        switch (ln)                                     \
+        {                                               \
+            case 5:  { CALL(5);  break; }               \
+            case 6:  { CALL(6);  break; }               \
+            case 7:  { CALL(7);  break; }               \
+            case 8:  { CALL(8);  break; }               \
+            case 9:  { CALL(9);  break; }               \
+            case 10: { CALL(10); break; }               \
+            case 11: { CALL(11); break; }               \
+            case 12: { CALL(12); break; }               \
+            default: { CALL(13); break; }               \
+        }
+
     int spectral_apply_settings(mi_spectral_bank *b, hipStream_t st)
     {
         // SpectralProcessor::update_settings (SpectralProcessor.cpp:107-125)
         const size_t N = size_t(1) << b->rank;
         std::vector<float> w(N);
-        mi::make_window(w.data(), N, MI_WINDOW_COSINE);
-        MI_HIP_CHECK(hipMemcpyAsync(b->d_wnd, w.data(), N * sizeof(float), hipMemcpyHostToDevice, st));
+        if (b->wnd_in >= 0)
+        {
+            mi::make_window(w.data(), N, b->wnd_in);
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_wnd, w.data(), N * sizeof(float), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+        }
+        if (b->wnd_out >= 0)
+            mi::make_window(w.data(), N, b->wnd_out);
+        else
+            std::fill(w.begin(), w.end(), 1.0f);
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_wnd_out, w.data(), N * sizeof(float), hipMemcpyHostToDevice, st));
         MI_HIP_CHECK(hipStreamSynchronize(st));
         MI_HIP_CHECK(hipMemsetAsync(b->d_in, 0, size_t(b->channels) * N * sizeof(float), st));
         MI_HIP_CHECK(hipMemsetAsync(b->d_out, 0, size_t(b->channels) * N * sizeof(float), st));
@@ -317,7 +342,7 @@ namespace
         if (b->op == MI_SPECTRAL_OP_NONE || !bound)
         {
             #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 0>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
-                b->d_in, b->d_out, b->d_wnd, b->d_wnd, (const float *)nullptr, size_t(0), (float2 *)nullptr, \
+                b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), (float2 *)nullptr, \
                 (const uint8_t *)nullptr, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
@@ -325,7 +350,7 @@ namespace
         else if (b->op == MI_SPECTRAL_OP_MASK)
         {
             #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 1>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
-                b->d_in, b->d_out, b->d_wnd, b->d_wnd, b->d_mask, b->mask_stride, (float2 *)nullptr, \
+                b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, b->d_mask, b->mask_stride, (float2 *)nullptr, \
                 (const uint8_t *)nullptr, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
@@ -333,14 +358,14 @@ namespace
         else
         {
             #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
-                b->d_in, b->d_out, b->d_wnd, b->d_wnd, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
+                b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
             b->func(b->object, b->subject, reinterpret_cast<float *>(b->d_spec), b->rank, b->channels, st);
             #define MI_CALL(LN) hipLaunchKernelGGL((stft_inverse_kernel<LN>), grid, dim3(plan<LN>::T), 0, st, \
-                b->d_in, b->d_out, b->d_wnd, b->d_spec, b->d_active, b->d_has_out, b->d_tw)
-            MI_LOGH_SWITCH(int(b->rank), MI_CALL)
+                b->d_in, b->d_out, b->d_wnd_out, b->d_spec, b->d_active, b->d_has_out, b->d_tw)
+            MI_LOGN_SWITCH(int(b->rank), MI_CALL)
             #undef MI_CALL
         }
         MI_HIP_CHECK(hipGetLastError());
@@ -355,8 +380,8 @@ int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_spectral_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0, MI_EINVAL, "mi_spectral_bank_create: channels must be > 0");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 12, MI_EINVAL,
-               "mi_spectral_bank_create: max_rank %u outside the supported 5..12 (frames of 32..4096 samples)", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 13, MI_EINVAL,
+               "mi_spectral_bank_create: max_rank %u outside the supported 5..13 (frames of 32..8192 samples)", max_rank);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_spectral_bank *b = new (std::nothrow) mi_spectral_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_spectral_bank_create: out of host memory");
@@ -371,6 +396,7 @@ int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_in), size_t(channels) * N * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_out), size_t(channels) * N * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), N * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd_out), N * sizeof(float));
         if (e != hipSuccess)
             r = mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_spectral_bank_create: %s", hipGetErrorString(e));
     }
@@ -387,7 +413,7 @@ int mi_spectral_bank_destroy(mi_spectral_bank_t *b)
 {
     if (b == nullptr)
         return MI_OK;
-    (void)hipFree(b->d_in); (void)hipFree(b->d_out); (void)hipFree(b->d_wnd); (void)hipFree(b->d_mask);
+    (void)hipFree(b->d_in); (void)hipFree(b->d_out); (void)hipFree(b->d_wnd); (void)hipFree(b->d_wnd_out); (void)hipFree(b->d_mask);
     (void)hipFree(b->d_spec); (void)hipFree(b->d_active); (void)hipFree(b->d_has_out);
     delete b;
     return MI_OK;
@@ -408,6 +434,16 @@ int mi_spectral_bank_set_phase(mi_spectral_bank_t *b, float phase)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_set_phase: NULL bank");
     b->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
+    b->update = true;
+    return MI_OK;
+}
+
+int mi_spectral_bank_set_windows(mi_spectral_bank_t *b, int in_window, int out_window)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_set_windows: NULL bank");
+    MI_REQUIRE(in_window < MI_WINDOW_TOTAL && out_window < MI_WINDOW_TOTAL, MI_EINVAL, "mi_spectral_bank_set_windows: unknown window");
+    b->wnd_in = in_window;
+    b->wnd_out = out_window;
     b->update = true;
     return MI_OK;
 }

@@ -414,3 +414,47 @@ class RingBank:
             self.close()
         except Exception:
             pass
+
+
+class EqualizerBank:
+    """`channels` x lsp::dspu::Equalizer on the device."""
+    BYPASS, IIR, FIR, FFT, SPM = range(5)
+
+    def __init__(self, channels, filters, fir_rank):
+        h = c_void_p()
+        check(lib.mi_equalizer_bank_create(byref(h), channels, filters, fir_rank))
+        self.handle, self.channels = h, channels
+
+    def set_params(self, filter_id, ftype, slope=1, freq=1000.0, freq2=1000.0, gain=1.0, quality=0.0, channel=None):
+        fp = FilterParams(int(ftype), int(slope), float(freq), float(freq2), float(gain), float(quality))
+        check(lib.mi_equalizer_bank_set_params(self.handle, 0xFFFFFFFF if channel is None else channel, filter_id, byref(fp)))
+
+    def set_mode(self, mode):
+        check(lib.mi_equalizer_bank_set_mode(self.handle, mode))
+
+    def set_sample_rate(self, sr):
+        check(lib.mi_equalizer_bank_set_sample_rate(self.handle, sr))
+
+    def get_latency(self, stream=None):
+        v = c_uint32()
+        check(lib.mi_equalizer_bank_get_latency(self.handle, byref(v), _stream(stream)))
+        return v.value
+
+    def reset(self, stream=None):
+        check(lib.mi_equalizer_bank_reset(self.handle, _stream(stream)))
+
+    def process(self, out, inp, samples, out_stride=None, in_stride=None, stream=None):
+        check(lib.mi_equalizer_bank_process(self.handle, _ptr(out), _ptr(inp), samples,
+                                            samples if out_stride is None else out_stride,
+                                            samples if in_stride is None else in_stride, _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_equalizer_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

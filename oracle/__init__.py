@@ -16,3 +16,4 @@ it follows and is pinned against the reference's own unit-test expectations
 from .binding import *  # noqa: F401,F403
 from . import spectral  # noqa: F401,E402
 from . import delay  # noqa: F401,E402
+from . import equalizer  # noqa: F401,E402

@@ -770,3 +770,45 @@ def freq_response(biquads, freqs, sample_rate):
     for b0, b1, b2, a1, a2 in np.asarray(biquads, dtype=np.float64):
         h = h * (b0 + b1 * z1 + b2 * z2) / (1.0 - a1 * z1 - a2 * z2)
     return h
+
+
+def freq_chart(params, sample_rate, freqs):
+    """Filter::freq_chart(c, f, count) (Filter.cpp:602-696): complex H at the given frequencies, float32 math.
+    The analog cascade response is lsp-dsp-lib's filter_transfer_calc/apply_pc:
+    H = (t0 - t2 w^2 + j t1 w) / (b0 - b2 w^2 + j b1 w) at the normalised frequency w."""
+    d = _Designer(params, sample_rate).run()
+    f = np.asarray(freqs, dtype=np.float32)
+    mode = d.mode if d.cascades else FM_BYPASS
+    sr = F(d.sr)
+    h = np.ones(f.size, np.complex64)
+    if mode in (FM_BILINEAR, FM_MATCHED):
+        if mode == FM_BILINEAR:
+            nf = F(C_PI / sr)
+            kf = F(F(1.0) / tanf(F(d.p.fFreq * nf)))
+            lf = F(F(d.sr) * F(0.499))
+            w = np.array([F(tanf(F(min(x, lf) * nf)) * kf) for x in f], np.float32)
+        else:
+            w = (f * F(F(1.0) / d.p.fFreq)).astype(np.float32)
+        w2 = (w * w).astype(np.float32)
+        for c in d.cascades:
+            t, b = c["t"], c["b"]
+            t_re = (t[0] - t[2] * w2).astype(np.float32); t_im = (t[1] * w).astype(np.float32)
+            b_re = (b[0] - b[2] * w2).astype(np.float32); b_im = (b[1] * w).astype(np.float32)
+            n = (F(1.0) / (b_re * b_re + b_im * b_im)).astype(np.float32)
+            re = ((t_re * b_re + t_im * b_im) * n).astype(np.float32)
+            im = ((t_im * b_re - t_re * b_im) * n).astype(np.float32)
+            h = (h * (re + 1j * im)).astype(np.complex64)
+    elif mode == FM_APO:
+        kf = F(C_PI_MUL_2 / sr); lf = F(F(d.sr) * F(0.5))
+        a = [F(min(x, lf) * kf) for x in f]
+        cw = np.array([cosf(x) for x in a], np.float32); sw = np.array([sinf(x) for x in a], np.float32)
+        c2w = (cw * cw - sw * sw).astype(np.float32); s2w = (F(2.0) * sw * cw).astype(np.float32)
+        for c in d.cascades:
+            t, b = c["t"], c["b"]
+            alpha = (t[0] + t[1] * cw + t[2] * c2w).astype(np.float32); beta = (t[1] * sw + t[2] * s2w).astype(np.float32)
+            gamma = (b[0] + b[1] * cw + b[2] * c2w).astype(np.float32); delta = (b[1] * sw + b[2] * s2w).astype(np.float32)
+            mag = (F(1.0) / (gamma * gamma + delta * delta)).astype(np.float32)
+            re = (mag * (alpha * gamma - beta * delta)).astype(np.float32)
+            im = (mag * (alpha * delta + beta * gamma)).astype(np.float32)
+            h = (h * (re + 1j * im)).astype(np.complex64)
+    return h, mode
