@@ -33,6 +33,8 @@ class Equalizer:
         self.rebuild = self.clear = True
         self.latency = 0
         self.bufsize = 0
+        # hook: how the bank's impulse response is taken (tests swap in a float64 one to measure the float32 noise)
+        self.ir_func = B.biquad_impulse_response
         if self.n:
             self.inb = np.zeros(2 * self.n, np.float32)
             self.outb = np.zeros(2 * self.n, np.float32)
@@ -76,7 +78,7 @@ class Equalizer:
             self.inb[:] = 0; self.outb[:] = 0; self.bufsize = 0
         if self.mode == FIR:
             w2 = sp.window(2 * n, "blackman_nuttall")
-            ir = B.biquad_impulse_response(n, self.coef, self.state)
+            ir = self.ir_func(n, self.coef, self.state)
             tmp = (ir * w2[n:]).astype(np.float32)
             spec = B.packed_direct_fft(_r2c(tmp), self.rank)
             mag = np.sqrt((spec[0::2] * spec[0::2] + spec[1::2] * spec[1::2]).astype(np.float32)).astype(np.float32)

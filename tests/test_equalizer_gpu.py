@@ -62,12 +62,31 @@ def test_c4_shape_32_band_eq(gpu, mode):
         y[:, pos:pos + k] = dout.download()
         pos += k
     assert eq.get_latency() == refs[0].get_latency()
+    import oracle
+    from conftest import assert_iir_parity
     for c in range(C):
         ref = refs[c].process(x[c])
+        if mode == oe.IIR:
+            # 32 sections down to 20 Hz: the float32 recursion's own round-off noise exceeds 1e-5 here, so
+            # the IIR rule of conftest.assert_iir_parity applies (DESIGN.md "Parity for recursive filters")
+            assert_iir_parity(y[c], ref, oracle.biquad_cascade_f64(x[c], refs[c].coef), "EQ IIR ch%d" % c)
+            continue
+        tol = 2 * TOL
+        if mode == oe.FIR:
+            # the FIR is synthesised from that same recursion's impulse response: measure how far the
+            # reference's float32 impulse response moves the output, and allow that much
+            ex = oe.Equalizer(nfilt, rank); ex.set_mode(mode); ex.set_sample_rate(48000)
+            ex.params = [p.copy() for p in refs[c].params]
+
+            def exact_ir(n_, coef, state):
+                imp = np.zeros(n_); imp[0] = 1.0
+                return oracle.biquad_cascade_f64(imp, coef).astype(np.float32)
+            ex.ir_func = exact_ir
+            noise = np.abs(ex.process(x[c]) - ref).max() / np.abs(ref).max()
+            tol = max(tol, 4.0 * noise)
         peak = np.abs(ref).max()
         err = np.abs(y[c] - ref).max() / peak
-        # IIR: 32 low-Q sections down to 20 Hz sit on the float32 noise floor of the recursion
-        assert err <= (2e-4 if mode == oe.IIR else 2 * TOL), (mode, c, err)
+        assert err <= tol, (mode, c, err, tol)
     eq.close()
 
 
