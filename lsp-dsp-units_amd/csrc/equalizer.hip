@@ -118,7 +118,7 @@ namespace
         for (uint32_t f = 0; f < b->filters; ++f)
         {
             mi::design &d = (*designs)[f];
-            d.cascades.reserve(mi::FILTER_CHAINS_MAX + 1);
+            d.cascades.reserve(mi::CHAINS_MAX + 1);
             mi::design_filter(&d, &b->params[size_t(ch) * b->filters + f], b->sample_rate);
             out->insert(out->end(), d.sections.begin(), d.sections.end());
         }
@@ -261,7 +261,7 @@ int mi_equalizer_bank_create(mi_equalizer_bank_t **bank, uint32_t channels, uint
     mi_filter_params_t none = { MI_FLT_NONE, 1, 1000.0f, 1000.0f, 1.0f, 0.0f };        // Filter::init defaults (Filter.cpp:71-78)
     b->params.assign(size_t(channels) * filters, none);
     b->dirty.assign(channels, 1);
-    int r = mi_biquad_bank_create(&b->biquads, channels, filters * mi::FILTER_CHAINS_MAX);   // Equalizer.cpp:79
+    int r = mi_biquad_bank_create(&b->biquads, channels, filters * mi::CHAINS_MAX);   // Equalizer.cpp:79
     if (r == MI_OK && fir_rank > 0)
     {
         const size_t N = b->fir_size;

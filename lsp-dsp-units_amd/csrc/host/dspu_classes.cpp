@@ -1,0 +1,1068 @@
+// lsp::dspu::* compatibility classes (one object == one channel, HOST sample pointers) implemented on the
+// C-ABI banks with channels = 1.  Every process() stages the caller's block through device memory:
+// correct and convenient, but it measures PCIe and launch latency -- anything performance critical should
+// hold many channels in one bank and keep the samples in HBM (mi_*_bank_* in include/mi_dspu.h).
+// Error behaviour follows the reference: init() returns false on failure, process() is void and, on an
+// unusable object, leaves the output as the reference would (zeros or a copy).
+#include <lsp-plug.in/dsp-units/filters/Filter.h>
+#include <lsp-plug.in/dsp-units/filters/FilterBank.h>
+#include <lsp-plug.in/dsp-units/filters/Equalizer.h>
+#include <lsp-plug.in/dsp-units/util/Convolver.h>
+#include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/Delay.h>
+#include <lsp-plug.in/dsp-units/util/RingBuffer.h>
+#include <lsp-plug.in/dsp-units/util/Analyzer.h>
+#include <lsp-plug.in/dsp-units/misc/windows.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "filter_design.h"
+
+namespace lsp
+{
+namespace dspu
+{
+namespace
+{
+    // a pair of device rows that grows on demand
+    struct staging
+    {
+        float  *d_in = nullptr, *d_out = nullptr;
+        size_t  cap = 0;
+
+        bool reserve(size_t n)
+        {
+            if (n <= cap)
+                return true;
+            release();
+            if (mi_dspu_malloc(reinterpret_cast<void **>(&d_in), n * sizeof(float)) != MI_OK) return false;
+            if (mi_dspu_malloc(reinterpret_cast<void **>(&d_out), n * sizeof(float)) != MI_OK) return false;
+            cap = n;
+            return true;
+        }
+        void release()
+        {
+            mi_dspu_free(d_in); mi_dspu_free(d_out);
+            d_in = d_out = nullptr;
+            cap = 0;
+        }
+        bool up(const float *src, size_t n)     { return mi_dspu_copy_h2d(d_in, src, n * sizeof(float), nullptr) == MI_OK; }
+        bool down(float *dst, size_t n)
+        {
+            return mi_dspu_copy_d2h(dst, d_out, n * sizeof(float), nullptr) == MI_OK &&
+                   mi_dspu_stream_synchronize(nullptr) == MI_OK;
+        }
+    };
+} // namespace
+
+// ---- windows ----------------------------------------------------------------------------------------------------
+namespace windows
+{
+    void window(float *dst, size_t n, window_t type)
+    {
+        mi_window(dst, n, int(type));
+    }
+}
+
+// ---- FilterBank -------------------------------------------------------------------------------------------------
+struct FilterBank::impl_t
+{
+    mi_biquad_bank_t               *bank = nullptr;
+    std::vector<dsp::biquad_x1_t>   chains;
+    size_t                          items = 0, max_items = 0;
+    staging                         st;
+};
+
+FilterBank::FilterBank() : pImpl(nullptr) { construct(); }
+FilterBank::~FilterBank() { destroy(); }
+void FilterBank::construct() { pImpl = nullptr; }
+
+bool FilterBank::init(size_t filters)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (mi_biquad_bank_create(&p->bank, 1, uint32_t(filters)) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    p->max_items = (filters > 0) ? filters : 1;
+    p->chains.assign(p->max_items, dsp::biquad_x1_t());
+    pImpl = p;
+    return true;
+}
+
+void FilterBank::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_biquad_bank_destroy(pImpl->bank);
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+void FilterBank::begin()                { if (pImpl) pImpl->items = 0; }
+size_t FilterBank::max_chains() const   { return pImpl ? pImpl->max_items : 0; }
+size_t FilterBank::size() const         { return pImpl ? pImpl->items : 0; }
+
+dsp::biquad_x1_t *FilterBank::add_chain()
+{
+    if (pImpl == nullptr)
+        return nullptr;
+    if (pImpl->items >= pImpl->max_items)
+        return (pImpl->items == 0) ? nullptr : &pImpl->chains[pImpl->items - 1];
+    return &pImpl->chains[pImpl->items++];
+}
+
+dsp::biquad_x1_t *FilterBank::chain(size_t id)
+{
+    return (pImpl != nullptr && id < pImpl->items) ? &pImpl->chains[id] : nullptr;
+}
+
+void FilterBank::end(bool clear)
+{
+    if (pImpl == nullptr)
+        return;
+    static_assert(sizeof(dsp::biquad_x1_t) == sizeof(mi_biquad_x1_t), "section layout");
+    mi_biquad_bank_set_chains(pImpl->bank, 0, reinterpret_cast<const mi_biquad_x1_t *>(pImpl->chains.data()),
+                              uint32_t(pImpl->items), clear ? 1 : 0);
+}
+
+void FilterBank::process(float *out, const float *in, size_t samples)
+{
+    if (samples == 0)
+        return;
+    if (pImpl == nullptr || !pImpl->st.reserve(samples) || !pImpl->st.up(in, samples) ||
+        mi_biquad_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, samples, samples, samples, nullptr) != MI_OK ||
+        !pImpl->st.down(out, samples))
+    {
+        if (out != in)
+            std::memmove(out, in, samples * sizeof(float));
+    }
+}
+
+void FilterBank::impulse_response(float *out, size_t samples)
+{
+    if (samples == 0)
+        return;
+    if (pImpl == nullptr || !pImpl->st.reserve(samples) ||
+        mi_biquad_bank_impulse_response(pImpl->bank, pImpl->st.d_out, samples, samples, nullptr) != MI_OK ||
+        !pImpl->st.down(out, samples))
+        std::memset(out, 0, samples * sizeof(float));
+}
+
+void FilterBank::reset()                { if (pImpl) mi_biquad_bank_reset(pImpl->bank, 0, nullptr); }
+
+void FilterBank::dump(IStateDumper *v) const
+{
+    v->write("nItems", size());
+    v->write("nMaxItems", max_chains());
+}
+
+// ---- Filter ------------------------------------------------------------------------------------------------------
+struct Filter::impl_t
+{
+    FilterBank         *bank = nullptr;
+    bool                own_bank = false;
+    bool                need_rebuild = true, need_clear = true;
+    filter_params_t     params;
+    size_t              sample_rate = 48000;
+    mi::design          d;
+};
+
+Filter::Filter() : pImpl(nullptr) { construct(); }
+Filter::~Filter() { destroy(); }
+void Filter::construct() { pImpl = nullptr; }
+
+bool Filter::init(FilterBank *fb)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (fb != nullptr)
+        p->bank = fb;
+    else
+    {
+        p->bank = new (std::nothrow) FilterBank();
+        p->own_bank = true;
+        if (p->bank == nullptr || !p->bank->init(FILTER_CHAINS_MAX))
+        {
+            delete p->bank;
+            delete p;
+            return false;
+        }
+    }
+    pImpl = p;
+    filter_params_t fp = { FLT_NONE, 1, 1000.0f, 1000.0f, 1.0f, 0.0f };
+    pImpl->params = fp;
+    update(48000, &fp);
+    pImpl->need_rebuild = pImpl->need_clear = true;
+    return true;
+}
+
+void Filter::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    if (pImpl->own_bank)
+    {
+        pImpl->bank->destroy();
+        delete pImpl->bank;
+    }
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+void Filter::update(size_t sr, const filter_params_t *params)
+{
+    if (pImpl == nullptr)
+        return;
+    const uint32_t type = pImpl->params.nType, slope = pImpl->params.nSlope;
+    pImpl->sample_rate = sr;
+    pImpl->params = *params;
+    mi::limit_params(&pImpl->params, uint32_t(sr));
+    pImpl->need_rebuild = true;
+    if (type != pImpl->params.nType || slope != pImpl->params.nSlope)
+        pImpl->need_clear = true;
+}
+
+void Filter::limit(size_t, filter_params_t *fp)
+{
+    if (pImpl != nullptr)                                   // the reference ignores its sr argument too (Filter.cpp:161-163)
+        mi::limit_params(fp, uint32_t(pImpl->sample_rate));
+}
+
+void Filter::set_sample_rate(size_t sr)     { if (pImpl) { filter_params_t p = pImpl->params; update(sr, &p); } }
+void Filter::get_params(filter_params_t *params) { if (pImpl && params) *params = pImpl->params; }
+void Filter::clear()                        { if (pImpl) pImpl->need_clear = true; }
+size_t Filter::latency() const              { return 0; }
+bool Filter::inactive() const               { return pImpl == nullptr || pImpl->d.mode == mi::FM_BYPASS; }
+bool Filter::active() const                 { return !inactive(); }
+
+void Filter::rebuild()
+{
+    if (pImpl == nullptr)
+        return;
+    if (pImpl->own_bank)
+        pImpl->bank->begin();
+    pImpl->d.cascades.reserve(mi::CHAINS_MAX + 1);
+    mi::design_filter(&pImpl->d, &pImpl->params, uint32_t(pImpl->sample_rate));
+    for (const mi_biquad_x1_t &s : pImpl->d.sections)
+    {
+        dsp::biquad_x1_t *c = pImpl->bank->add_chain();
+        if (c == nullptr)
+            break;
+        std::memcpy(c, &s, sizeof(s));
+    }
+    if (pImpl->own_bank)
+        pImpl->bank->end(pImpl->need_clear);
+    pImpl->need_rebuild = pImpl->need_clear = false;
+}
+
+void Filter::process(float *out, const float *in, size_t samples)
+{
+    if (pImpl == nullptr)
+    {
+        if (out != in)
+            std::memmove(out, in, samples * sizeof(float));
+        return;
+    }
+    if (pImpl->need_rebuild || pImpl->need_clear)
+        rebuild();
+    if (pImpl->d.mode == mi::FM_BYPASS)
+    {
+        if (out != in)
+            std::memmove(out, in, samples * sizeof(float));
+        return;
+    }
+    pImpl->bank->process(out, in, samples);
+}
+
+bool Filter::impulse_response(float *out, size_t length)
+{
+    if (pImpl == nullptr || !pImpl->own_bank)
+        return false;
+    if (pImpl->need_rebuild || pImpl->need_clear)
+        rebuild();
+    pImpl->bank->impulse_response(out, length);
+    return true;
+}
+
+void Filter::freq_chart(float *c, const float *f, size_t count)
+{
+    if (pImpl == nullptr)
+        return;
+    if (pImpl->need_rebuild)
+    {
+        pImpl->d.cascades.reserve(mi::CHAINS_MAX + 1);
+        mi::design_filter(&pImpl->d, &pImpl->params, uint32_t(pImpl->sample_rate));
+    }
+    mi::freq_chart(pImpl->d, c, f, count);
+}
+
+void Filter::freq_chart(float *re, float *im, const float *f, size_t count)
+{
+    std::vector<float> c(2 * count);
+    freq_chart(c.data(), f, count);
+    for (size_t i = 0; i < count; ++i)
+    {
+        re[i] = c[2 * i];
+        im[i] = c[2 * i + 1];
+    }
+}
+
+void Filter::dump(IStateDumper *v) const
+{
+    if (pImpl == nullptr)
+        return;
+    v->write("nSampleRate", pImpl->sample_rate);
+    v->write("nMode", size_t(pImpl->d.mode));
+}
+
+// ---- Equalizer ---------------------------------------------------------------------------------------------------
+struct Equalizer::impl_t
+{
+    mi_equalizer_bank_t *bank = nullptr;
+    size_t  filters = 0, fir_rank = 0, sample_rate = 0;
+    bool    smooth = false, changed = true;
+    equalizer_mode_t mode = EQM_BYPASS;
+    staging st;
+};
+
+Equalizer::Equalizer() : pImpl(nullptr) { construct(); }
+Equalizer::~Equalizer() { destroy(); }
+void Equalizer::construct() { pImpl = nullptr; }
+
+bool Equalizer::init(size_t filters, size_t fir_rank)
+{
+    if (pImpl != nullptr && pImpl->filters == filters && pImpl->fir_rank == fir_rank)
+    {
+        reset();
+        return true;
+    }
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (mi_equalizer_bank_create(&p->bank, 1, uint32_t(filters), uint32_t(fir_rank)) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    p->filters = filters;
+    p->fir_rank = fir_rank;
+    pImpl = p;
+    return true;
+}
+
+void Equalizer::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_equalizer_bank_destroy(pImpl->bank);
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+bool Equalizer::configuration_changed() const { return pImpl != nullptr && pImpl->changed; }
+
+bool Equalizer::set_params(size_t id, const filter_params_t *params)
+{
+    if (pImpl == nullptr || id >= pImpl->filters)
+        return false;
+    pImpl->changed = true;
+    return mi_equalizer_bank_set_params(pImpl->bank, 0, uint32_t(id), params) == MI_OK;
+}
+
+bool Equalizer::limit_params(size_t id, filter_params_t *fp)
+{
+    if (pImpl == nullptr || id >= pImpl->filters)
+        return false;
+    return mi_filter_limit(fp, uint32_t(pImpl->sample_rate)) == MI_OK;
+}
+
+bool Equalizer::get_params(size_t id, filter_params_t *params)
+{
+    if (pImpl == nullptr || id >= pImpl->filters)
+        return false;
+    return mi_equalizer_bank_get_params(pImpl->bank, 0, uint32_t(id), params) == MI_OK;
+}
+
+void Equalizer::set_mode(equalizer_mode_t mode)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->mode = mode;
+    pImpl->changed = true;
+    mi_equalizer_bank_set_mode(pImpl->bank, int(mode));
+}
+
+void Equalizer::set_actual_sample_rate(size_t sr) { if (pImpl) mi_equalizer_bank_set_actual_sample_rate(pImpl->bank, uint32_t(sr)); }
+
+void Equalizer::set_sample_rate(size_t sr)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->sample_rate = sr;
+    pImpl->changed = true;
+    mi_equalizer_bank_set_sample_rate(pImpl->bank, uint32_t(sr));
+}
+
+equalizer_mode_t Equalizer::get_mode() const { return pImpl ? pImpl->mode : EQM_BYPASS; }
+equalizer_mode_t Equalizer::mode() const     { return get_mode(); }
+
+size_t Equalizer::get_latency()
+{
+    uint32_t lat = 0;
+    if (pImpl != nullptr)
+    {
+        mi_equalizer_bank_get_latency(pImpl->bank, &lat, nullptr);
+        pImpl->changed = false;
+    }
+    return lat;
+}
+
+size_t Equalizer::max_latency() const
+{
+    const size_t n = (pImpl && pImpl->fir_rank) ? (size_t(1) << pImpl->fir_rank) : 0;
+    return n + (n >> 1);
+}
+
+bool Equalizer::freq_chart(size_t id, float *c, const float *f, size_t count)
+{
+    filter_params_t fp;
+    if (!get_params(id, &fp))
+        return false;
+    return mi_filter_freq_chart(&fp, uint32_t(pImpl->sample_rate), c, f, count) == MI_OK;
+}
+
+void Equalizer::freq_chart(float *c, const float *f, size_t count)
+{
+    for (size_t i = 0; i < count; ++i)
+    {
+        c[2 * i] = 1.0f;
+        c[2 * i + 1] = 0.0f;
+    }
+    if (pImpl == nullptr)
+        return;
+    std::vector<float> t(2 * count);
+    for (size_t id = 0; id < pImpl->filters; ++id)
+    {
+        filter_params_t fp;
+        if (!get_params(id, &fp) || fp.nType == FLT_NONE)
+            continue;
+        if (mi_filter_freq_chart(&fp, uint32_t(pImpl->sample_rate), t.data(), f, count) != MI_OK)
+            continue;
+        for (size_t i = 0; i < count; ++i)
+        {
+            const float re = c[2 * i] * t[2 * i] - c[2 * i + 1] * t[2 * i + 1];
+            const float im = c[2 * i] * t[2 * i + 1] + c[2 * i + 1] * t[2 * i];
+            c[2 * i] = re;
+            c[2 * i + 1] = im;
+        }
+    }
+}
+
+void Equalizer::process(float *out, const float *in, size_t samples)
+{
+    if (samples == 0)
+        return;
+    if (pImpl == nullptr || !pImpl->st.reserve(samples) || !pImpl->st.up(in, samples) ||
+        mi_equalizer_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, samples, samples, samples, nullptr) != MI_OK ||
+        !pImpl->st.down(out, samples))
+    {
+        if (out != in)
+            std::memmove(out, in, samples * sizeof(float));
+        return;
+    }
+    pImpl->changed = false;
+}
+
+void Equalizer::reset()                     { if (pImpl) mi_equalizer_bank_reset(pImpl->bank, nullptr); }
+size_t Equalizer::fir_rank() const          { return pImpl ? pImpl->fir_rank : 0; }
+bool Equalizer::smooth() const              { return pImpl && pImpl->smooth; }
+void Equalizer::set_smooth(bool smooth)     { if (pImpl) pImpl->smooth = smooth; }
+
+size_t Equalizer::ir_size() const
+{
+    uint32_t n = 0;
+    if (pImpl != nullptr)
+        mi_equalizer_bank_info(pImpl->bank, nullptr, nullptr, nullptr, &n);
+    return n;
+}
+
+void Equalizer::dump(IStateDumper *v) const
+{
+    if (pImpl == nullptr)
+        return;
+    v->write("nFilters", pImpl->filters);
+    v->write("nFirRank", pImpl->fir_rank);
+}
+
+// ---- Convolver ---------------------------------------------------------------------------------------------------
+struct Convolver::impl_t
+{
+    mi_convolver_bank_t *bank = nullptr;
+    staging st;
+};
+
+Convolver::Convolver() : pImpl(nullptr) { construct(); }
+Convolver::~Convolver() { destroy(); }
+void Convolver::construct() { pImpl = nullptr; }
+
+void Convolver::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_convolver_bank_destroy(pImpl->bank);
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+bool Convolver::init(const float *data, size_t count, size_t rank, float phase)
+{
+    destroy();
+    if (count == 0)                                     // stays uninitialised, still "success"
+        return true;
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (mi_convolver_bank_create(&p->bank, 1, data, count, nullptr, uint32_t(count), uint32_t(rank), phase, nullptr) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    pImpl = p;
+    return true;
+}
+
+void Convolver::process(float *dst, const float *src, size_t count)
+{
+    if (count == 0)
+        return;
+    if (pImpl == nullptr || !pImpl->st.reserve(count) || !pImpl->st.up(src, count) ||
+        mi_convolver_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, count, count, count, nullptr) != MI_OK ||
+        !pImpl->st.down(dst, count))
+        std::memset(dst, 0, count * sizeof(float));
+}
+
+size_t Convolver::data_size() const
+{
+    uint32_t n = 0;
+    if (pImpl != nullptr)
+        mi_convolver_bank_info(pImpl->bank, nullptr, nullptr, nullptr, &n);
+    return n;
+}
+
+size_t Convolver::rank() const
+{
+    uint32_t r = 0;
+    if (pImpl != nullptr)
+        mi_convolver_bank_info(pImpl->bank, &r, nullptr, nullptr, nullptr);
+    return r;
+}
+
+void Convolver::dump(IStateDumper *v) const
+{
+    v->write("nConvSize", data_size());
+    v->write("nRank", rank());
+}
+
+// ---- SpectralProcessor ------------------------------------------------------------------------------------------
+struct SpectralProcessor::impl_t
+{
+    mi_spectral_bank_t *bank = nullptr;
+    size_t  max_rank = 0, rank = 0;
+    float   phase = 0.0f;
+    bool    update = true;
+    spectral_processor_func_t func = nullptr;
+    void   *object = nullptr, *subject = nullptr;
+    std::vector<float> host_spec;
+    staging st;
+
+    // device-side hook: bring the spectrum to the host, run the user's function, send it back
+    static void trampoline(void *object, void *, float *spectrum, size_t rank, size_t, void *stream)
+    {
+        impl_t *p = static_cast<impl_t *>(object);
+        const size_t floats = size_t(2) << rank;
+        p->host_spec.resize(floats);
+        if (mi_dspu_copy_d2h(p->host_spec.data(), spectrum, floats * sizeof(float), stream) != MI_OK ||
+            mi_dspu_stream_synchronize(stream) != MI_OK)
+            return;
+        p->func(p->object, p->subject, p->host_spec.data(), rank);
+        mi_dspu_copy_h2d(spectrum, p->host_spec.data(), floats * sizeof(float), stream);
+        mi_dspu_stream_synchronize(stream);
+    }
+};
+
+SpectralProcessor::SpectralProcessor() : pImpl(nullptr) { construct(); }
+SpectralProcessor::~SpectralProcessor() { destroy(); }
+void SpectralProcessor::construct() { pImpl = nullptr; }
+
+bool SpectralProcessor::init(size_t max_rank)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    // the library holds frames up to 2^13; larger max_rank values are accepted as long as the rank in use fits
+    const uint32_t cap = uint32_t(std::min<size_t>(std::max<size_t>(max_rank, 5), 13));
+    if (mi_spectral_bank_create(&p->bank, 1, cap) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    p->max_rank = max_rank;
+    p->rank = max_rank;
+    pImpl = p;
+    return true;
+}
+
+void SpectralProcessor::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_spectral_bank_destroy(pImpl->bank);
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+void SpectralProcessor::bind(spectral_processor_func_t func, void *object, void *subject)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->func = func;
+    pImpl->object = object;
+    pImpl->subject = subject;
+    if (func != nullptr)
+        mi_spectral_bank_bind(pImpl->bank, &impl_t::trampoline, pImpl, nullptr);
+    else
+        mi_spectral_bank_unbind(pImpl->bank);
+}
+
+void SpectralProcessor::unbind()            { bind(nullptr, nullptr, nullptr); }
+bool SpectralProcessor::needs_update() const { return pImpl && pImpl->update; }
+void SpectralProcessor::update_settings()   { if (pImpl) pImpl->update = false; }
+size_t SpectralProcessor::get_rank() const  { return pImpl ? pImpl->rank : 0; }
+float SpectralProcessor::phase() const      { return pImpl ? pImpl->phase : 0.0f; }
+size_t SpectralProcessor::latency() const   { return pImpl ? (size_t(1) << pImpl->rank) : 0; }
+
+void SpectralProcessor::set_phase(float phase)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->phase = std::min(std::max(phase, 0.0f), 1.0f);
+    pImpl->update = true;
+    mi_spectral_bank_set_phase(pImpl->bank, pImpl->phase);
+}
+
+void SpectralProcessor::set_rank(size_t rank)
+{
+    if (pImpl == nullptr || rank == pImpl->rank || rank > pImpl->max_rank)
+        return;
+    pImpl->rank = rank;
+    pImpl->update = true;
+    mi_spectral_bank_set_rank(pImpl->bank, uint32_t(rank));
+}
+
+void SpectralProcessor::process(float *dst, const float *src, size_t count)
+{
+    if (count == 0)
+        return;
+    if (pImpl == nullptr || !pImpl->st.reserve(count) || !pImpl->st.up(src, count) ||
+        mi_spectral_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, count, count, count, nullptr) != MI_OK ||
+        !pImpl->st.down(dst, count))
+    {
+        std::memset(dst, 0, count * sizeof(float));
+        return;
+    }
+    pImpl->update = false;
+}
+
+void SpectralProcessor::process(const float *src, size_t count)
+{
+    if (count == 0 || pImpl == nullptr || !pImpl->st.reserve(count) || !pImpl->st.up(src, count))
+        return;
+    mi_spectral_bank_process(pImpl->bank, nullptr, pImpl->st.d_in, count, count, count, nullptr);
+    mi_dspu_stream_synchronize(nullptr);
+    pImpl->update = false;
+}
+
+void SpectralProcessor::reset()             { if (pImpl) mi_spectral_bank_reset(pImpl->bank, nullptr); }
+
+size_t SpectralProcessor::remaining() const
+{
+    uint32_t r = 0;
+    if (pImpl != nullptr)
+        mi_spectral_bank_get(pImpl->bank, nullptr, nullptr, &r);
+    return r;
+}
+
+void SpectralProcessor::dump(IStateDumper *v) const
+{
+    v->write("nRank", get_rank());
+}
+
+// ---- Delay -----------------------------------------------------------------------------------------------------
+struct Delay::impl_t
+{
+    mi_delay_bank_t *bank = nullptr;
+    staging st;
+    float  *d_gain = nullptr;
+    size_t  gain_cap = 0;
+
+    bool gain_up(const float *g, size_t n)
+    {
+        if (n > gain_cap)
+        {
+            mi_dspu_free(d_gain);
+            d_gain = nullptr;
+            gain_cap = 0;
+            if (mi_dspu_malloc(reinterpret_cast<void **>(&d_gain), n * sizeof(float)) != MI_OK)
+                return false;
+            gain_cap = n;
+        }
+        return mi_dspu_copy_h2d(d_gain, g, n * sizeof(float), nullptr) == MI_OK;
+    }
+
+    // common body of process / process_add with the three gain forms
+    void run(float *dst, const float *src, size_t count, int add, int gmode, float gain, const float *gvec)
+    {
+        if (count == 0 || !st.reserve(count) || !st.up(src, count))
+            return;
+        if (add && mi_dspu_copy_h2d(st.d_out, dst, count * sizeof(float), nullptr) != MI_OK)
+            return;
+        if (gmode == MI_GAIN_VECTOR && !gain_up(gvec, count))
+            return;
+        if (mi_delay_bank_process(bank, st.d_out, st.d_in, count, count, count, add, gmode, gain, d_gain, count, nullptr) == MI_OK)
+            st.down(dst, count);
+    }
+
+    void ramp(float *dst, const float *src, size_t delay, size_t count, int gmode, float gain, const float *gvec)
+    {
+        if (count == 0 || !st.reserve(count) || !st.up(src, count))
+            return;
+        if (gmode == MI_GAIN_VECTOR && !gain_up(gvec, count))
+            return;
+        const uint32_t nd = uint32_t(delay);
+        if (mi_delay_bank_process_ramping(bank, st.d_out, st.d_in, &nd, count, count, count, gmode, gain, d_gain, count, nullptr) == MI_OK)
+            st.down(dst, count);
+    }
+};
+
+Delay::Delay() : pImpl(nullptr) { construct(); }
+Delay::~Delay() { destroy(); }
+void Delay::construct() { pImpl = nullptr; }
+
+void Delay::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_delay_bank_destroy(pImpl->bank);
+    mi_dspu_free(pImpl->d_gain);
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+bool Delay::init(size_t max_size)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (mi_delay_bank_create(&p->bank, 1, max_size) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    pImpl = p;
+    return true;
+}
+
+void Delay::append(const float *src, size_t count)
+{
+    if (pImpl && count && pImpl->st.reserve(count) && pImpl->st.up(src, count))
+    {
+        mi_delay_bank_append(pImpl->bank, pImpl->st.d_in, count, count, nullptr);
+        mi_dspu_stream_synchronize(nullptr);
+    }
+}
+
+void Delay::process(float *dst, const float *src, size_t count)                     { if (pImpl) pImpl->run(dst, src, count, 0, MI_GAIN_NONE, 0.0f, nullptr); }
+void Delay::process(float *dst, const float *src, float gain, size_t count)         { if (pImpl) pImpl->run(dst, src, count, 0, MI_GAIN_SCALAR, gain, nullptr); }
+void Delay::process(float *dst, const float *src, const float *gain, size_t count)  { if (pImpl) pImpl->run(dst, src, count, 0, MI_GAIN_VECTOR, 0.0f, gain); }
+void Delay::process_add(float *dst, const float *src, size_t count)                 { if (pImpl) pImpl->run(dst, src, count, 1, MI_GAIN_NONE, 0.0f, nullptr); }
+void Delay::process_add(float *dst, const float *src, float gain, size_t count)     { if (pImpl) pImpl->run(dst, src, count, 1, MI_GAIN_SCALAR, gain, nullptr); }
+void Delay::process_add(float *dst, const float *src, const float *gain, size_t count) { if (pImpl) pImpl->run(dst, src, count, 1, MI_GAIN_VECTOR, 0.0f, gain); }
+void Delay::process_ramping(float *dst, const float *src, size_t delay, size_t count) { if (pImpl) pImpl->ramp(dst, src, delay, count, MI_GAIN_NONE, 0.0f, nullptr); }
+void Delay::process_ramping(float *dst, const float *src, float gain, size_t delay, size_t count) { if (pImpl) pImpl->ramp(dst, src, delay, count, MI_GAIN_SCALAR, gain, nullptr); }
+void Delay::process_ramping(float *dst, const float *src, const float *gain, size_t delay, size_t count) { if (pImpl) pImpl->ramp(dst, src, delay, count, MI_GAIN_VECTOR, 0.0f, gain); }
+
+float Delay::process(float src)
+{
+    float out = 0.0f;
+    process(&out, &src, 1);
+    return out;
+}
+
+float Delay::process(float src, float gain)
+{
+    float out = 0.0f;
+    process(&out, &src, gain, 1);
+    return out;
+}
+
+void Delay::set_delay(size_t delay)         { if (pImpl) mi_delay_bank_set_delay(pImpl->bank, 0, delay); }
+
+size_t Delay::get_delay() const
+{
+    uint32_t d = 0;
+    if (pImpl != nullptr)
+        mi_delay_bank_get(pImpl->bank, 0, &d, nullptr, nullptr, nullptr);
+    return d;
+}
+
+size_t Delay::delay() const                 { return get_delay(); }
+void Delay::clear()                         { if (pImpl) mi_delay_bank_clear(pImpl->bank, nullptr); }
+void Delay::dump(IStateDumper *v) const     { v->write("nDelay", get_delay()); }
+
+// ---- RingBuffer --------------------------------------------------------------------------------------------------
+struct RingBuffer::impl_t
+{
+    mi_ring_bank_t *bank = nullptr;
+    size_t  capacity = 0;
+    staging st;
+};
+
+RingBuffer::RingBuffer() : pImpl(nullptr) { construct(); }
+RingBuffer::~RingBuffer() { destroy(); }
+void RingBuffer::construct() { pImpl = nullptr; }
+
+bool RingBuffer::init(size_t size, float fill)
+{
+    if (pImpl != nullptr && pImpl->capacity == size)
+    {
+        mi_ring_bank_fill(pImpl->bank, fill, nullptr);      // note: the reference keeps nHead here; fill() resets it
+        return true;
+    }
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (mi_ring_bank_create(&p->bank, 1, size, fill) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    p->capacity = size;
+    pImpl = p;
+    return true;
+}
+
+void RingBuffer::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_ring_bank_destroy(pImpl->bank);
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+size_t RingBuffer::append(const float *data, size_t count)
+{
+    size_t n = 0;
+    if (pImpl && count && pImpl->st.reserve(count) && pImpl->st.up(data, count))
+    {
+        mi_ring_bank_append(pImpl->bank, pImpl->st.d_in, count, count, &n, nullptr);
+        mi_dspu_stream_synchronize(nullptr);
+    }
+    return n;
+}
+
+void RingBuffer::append(float data)         { append(&data, 1); }
+void RingBuffer::clear()                    { if (pImpl) mi_ring_bank_fill(pImpl->bank, 0.0f, nullptr); }
+void RingBuffer::fill(float value)          { if (pImpl) mi_ring_bank_fill(pImpl->bank, value, nullptr); }
+size_t RingBuffer::size() const             { return pImpl ? pImpl->capacity : 0; }
+
+size_t RingBuffer::get(float *dst, size_t offset, size_t count) const
+{
+    size_t n = 0;
+    if (pImpl == nullptr || count == 0 || !pImpl->st.reserve(count))
+        return 0;
+    if (mi_ring_bank_get(pImpl->bank, pImpl->st.d_out, offset, count, count, &n, nullptr) != MI_OK || !pImpl->st.down(dst, count))
+        return 0;
+    return n;
+}
+
+float RingBuffer::get(size_t offset) const
+{
+    float v = 0.0f;
+    get(&v, offset, 1);
+    return v;
+}
+
+size_t RingBuffer::head_position() const
+{
+    uint32_t h = 0;
+    if (pImpl != nullptr)
+        mi_ring_bank_info(pImpl->bank, 0, nullptr, &h, nullptr);
+    return h;
+}
+
+size_t RingBuffer::tail_position(size_t offset) const
+{
+    uint32_t t = 0;
+    if (pImpl != nullptr)
+        mi_ring_bank_info(pImpl->bank, offset, nullptr, nullptr, &t);
+    return t;
+}
+
+void RingBuffer::dump(IStateDumper *v) const { v->write("nCapacity", size()); }
+
+// ---- Analyzer ----------------------------------------------------------------------------------------------------
+struct Analyzer::impl_t
+{
+    mi_analyzer_bank_t *bank = nullptr;
+    size_t  channels = 0, rank = 0, sample_rate = 0;
+    float  *d_in = nullptr;
+    size_t  in_cap = 0;
+    float  *d_out = nullptr;
+    uint32_t *d_idx = nullptr;
+    size_t  q_cap = 0;
+};
+
+Analyzer::Analyzer() : pImpl(nullptr) { construct(); }
+Analyzer::~Analyzer() { destroy(); }
+void Analyzer::construct() { pImpl = nullptr; }
+
+void Analyzer::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_analyzer_bank_destroy(pImpl->bank);
+    mi_dspu_free(pImpl->d_in); mi_dspu_free(pImpl->d_out); mi_dspu_free(pImpl->d_idx);
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+bool Analyzer::init(size_t channels, size_t max_rank, size_t max_sr, float min_rate, size_t max_delay)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    if (mi_analyzer_bank_create(&p->bank, uint32_t(channels), uint32_t(max_rank), uint32_t(max_sr), min_rate, uint32_t(max_delay)) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    p->channels = channels;
+    p->rank = max_rank;
+    pImpl = p;
+    return true;
+}
+
+void Analyzer::set_sample_rate(size_t sr)   { if (pImpl) { pImpl->sample_rate = sr; mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SAMPLE_RATE, double(sr)); } }
+void Analyzer::set_rate(float rate)         { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RATE, rate); }
+void Analyzer::set_window(size_t window)    { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_WINDOW, double(window)); }
+void Analyzer::set_envelope(size_t env)     { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ENVELOPE, double(env)); }
+void Analyzer::set_shift(float shift)       { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SHIFT, shift); }
+void Analyzer::set_reactivity(float r)      { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_REACTIVITY, r); }
+void Analyzer::set_activity(bool active)    { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ACTIVE, active ? 1.0 : 0.0); }
+size_t Analyzer::get_rank() const           { return pImpl ? pImpl->rank : 0; }
+
+bool Analyzer::set_rank(size_t rank)
+{
+    if (pImpl == nullptr || mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RANK, double(rank)) != MI_OK)
+        return false;
+    pImpl->rank = rank;
+    return true;
+}
+
+bool Analyzer::freeze_channel(size_t ch, bool freeze)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_FREEZE, freeze) == MI_OK; }
+bool Analyzer::enable_channel(size_t ch, bool enable)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_ENABLE, enable) == MI_OK; }
+bool Analyzer::set_channel_delay(size_t ch, size_t d)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_DELAY, uint32_t(d)) == MI_OK; }
+
+void Analyzer::process(const float * const *in, size_t samples)
+{
+    if (pImpl == nullptr || samples == 0)
+        return;
+    const size_t need = pImpl->channels * samples;
+    if (need > pImpl->in_cap)
+    {
+        mi_dspu_free(pImpl->d_in);
+        pImpl->d_in = nullptr;
+        pImpl->in_cap = 0;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&pImpl->d_in), need * sizeof(float)) != MI_OK)
+            return;
+        pImpl->in_cap = need;
+    }
+    for (size_t c = 0; c < pImpl->channels; ++c)
+    {
+        if (in != nullptr && in[c] != nullptr)
+            mi_dspu_copy_h2d(pImpl->d_in + c * samples, in[c], samples * sizeof(float), nullptr);
+        else
+            mi_dspu_memset(pImpl->d_in + c * samples, 0, samples * sizeof(float), nullptr);
+    }
+    mi_analyzer_bank_process(pImpl->bank, pImpl->d_in, samples, samples, nullptr);
+    mi_dspu_stream_synchronize(nullptr);
+}
+
+bool Analyzer::get_spectrum(size_t channel, float *out, const uint32_t *idx, size_t count)
+{
+    if (pImpl == nullptr || channel >= pImpl->channels || count == 0)
+        return false;
+    if (count > pImpl->q_cap)
+    {
+        mi_dspu_free(pImpl->d_out); mi_dspu_free(pImpl->d_idx);
+        pImpl->d_out = nullptr; pImpl->d_idx = nullptr; pImpl->q_cap = 0;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&pImpl->d_out), pImpl->channels * count * sizeof(float)) != MI_OK ||
+            mi_dspu_malloc(reinterpret_cast<void **>(&pImpl->d_idx), count * sizeof(uint32_t)) != MI_OK)
+            return false;
+        pImpl->q_cap = count;
+    }
+    if (mi_dspu_copy_h2d(pImpl->d_idx, idx, count * sizeof(uint32_t), nullptr) != MI_OK ||
+        mi_analyzer_bank_get_spectrum(pImpl->bank, pImpl->d_out, count, pImpl->d_idx, uint32_t(count), nullptr) != MI_OK ||
+        mi_dspu_copy_d2h(out, pImpl->d_out + channel * count, count * sizeof(float), nullptr) != MI_OK)
+        return false;
+    return mi_dspu_stream_synchronize(nullptr) == MI_OK;
+}
+
+float Analyzer::get_level(size_t channel, const uint32_t idx)
+{
+    float v = 0.0f;
+    return get_spectrum(channel, &v, &idx, 1) ? v : 0.0f;
+}
+
+void Analyzer::get_frequencies(float *frq, uint32_t *idx, float start, float stop, size_t count, bool linear)
+{
+    if (pImpl == nullptr)
+        return;
+    const size_t fft_size = size_t(1) << pImpl->rank, fft_width = fft_size >> 1;
+    const float scale = float(fft_size) / float(pImpl->sample_rate);
+    const float norm = linear ? (stop - start) / (count - 1) : logf(stop / start) / (count - 1);
+    for (size_t i = 0; i < count; ++i)
+    {
+        const float f = linear ? start + i * norm : start * expf(i * norm);
+        frq[i] = f;
+        const float pos = scale * f;
+        idx[i] = uint32_t((pos < float(fft_width)) ? pos : float(fft_width));
+    }
+}
+
+void Analyzer::dump(IStateDumper *v) const  { v->write("nRank", get_rank()); }
+
+} // namespace dspu
+} // namespace lsp

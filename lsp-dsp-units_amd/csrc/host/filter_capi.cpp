@@ -11,7 +11,7 @@ int mi_filter_design(const mi_filter_params_t *params, uint32_t sample_rate,
     MI_REQUIRE(params != nullptr, MI_EINVAL, "mi_filter_design: NULL parameters");
     MI_REQUIRE(sample_rate > 0, MI_EINVAL, "mi_filter_design: sample rate must be > 0");
     mi::design d;
-    d.cascades.reserve(mi::FILTER_CHAINS_MAX + 1);
+    d.cascades.reserve(mi::CHAINS_MAX + 1);
     mi::design_filter(&d, params, sample_rate);
     if (n_chains != nullptr)
         *n_chains = uint32_t(d.sections.size());
@@ -47,7 +47,7 @@ int mi_filter_freq_chart(const mi_filter_params_t *params, uint32_t sample_rate,
                "mi_filter_freq_chart: bad argument");
     MI_REQUIRE(sample_rate > 0, MI_EINVAL, "mi_filter_freq_chart: sample rate must be > 0");
     mi::design d;
-    d.cascades.reserve(mi::FILTER_CHAINS_MAX + 1);
+    d.cascades.reserve(mi::CHAINS_MAX + 1);
     mi::design_filter(&d, params, sample_rate);
     mi::freq_chart(d, c, f, count);
     return MI_OK;

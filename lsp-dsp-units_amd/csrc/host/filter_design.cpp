@@ -31,7 +31,7 @@ namespace
         // Filter::add_cascade (Filter.cpp:177-197): zeroed; past the limit the last slot is recycled
         cascade &next()
         {
-            if (d.cascades.size() >= FILTER_CHAINS_MAX)
+            if (d.cascades.size() >= CHAINS_MAX)
                 d.cascades.pop_back();
             d.cascades.push_back(cascade{ {0, 0, 0, 0}, {0, 0, 0, 0} });
             return d.cascades.back();
@@ -637,7 +637,7 @@ namespace
             const double T0 = c.t[0], T1 = c.t[1] * kf, T2 = c.t[2] * kf2;
             const double B0 = c.b[0], B1 = c.b[1] * kf, B2 = c.b[2] * kf2;
             const double N = 1.0 / (B0 + B1 + B2);
-            if (++emitted > FILTER_CHAINS_MAX)
+            if (++emitted > CHAINS_MAX)
                 break;
             b.d.sections.push_back(mi_biquad_x1_t{
                 float((T0 + T1 + T2) * N), float(2.0 * (T0 - T2) * N), float((T0 - T1 + T2) * N),
@@ -710,7 +710,7 @@ namespace
             }
             const double AN = (A[1] * I[0]) / (A[0] * I[1]);
             const double N  = 1.0 / P[1][0];
-            if (++emitted > FILTER_CHAINS_MAX)
+            if (++emitted > CHAINS_MAX)
                 break;
             b.d.sections.push_back(mi_biquad_x1_t{
                 float(P[0][0] * N * AN), float(P[0][1] * N * AN), float(P[0][2] * N * AN),
@@ -724,7 +724,7 @@ namespace
 void limit_params(mi_filter_params_t *fp, uint32_t sample_rate)
 {
     const float max_freq = 0.49f * sample_rate;
-    fp->nSlope = std::min(std::max(fp->nSlope, 1U), FILTER_CHAINS_MAX);
+    fp->nSlope = std::min(std::max(fp->nSlope, 1U), CHAINS_MAX);
     fp->fFreq  = std::min(std::max(fp->fFreq, 0.0f), max_freq);
     fp->fFreq2 = std::min(std::max(fp->fFreq2, 0.0f), max_freq);
 }

@@ -36,7 +36,7 @@ namespace mi
         std::vector<mi_biquad_x1_t> sections;       // what add_chain() receives
     };
 
-    constexpr uint32_t FILTER_CHAINS_MAX = 0x80;
+    constexpr uint32_t CHAINS_MAX = 0x80;          // FILTER_CHAINS_MAX of filters/common.h
 
     // Filter::limit (Filter.cpp:161-167)
     void limit_params(mi_filter_params_t *fp, uint32_t sample_rate);

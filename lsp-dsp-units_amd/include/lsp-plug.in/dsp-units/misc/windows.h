@@ -1,0 +1,38 @@
+// lsp::dspu::windows: window generators (host memory), enumerators identical to mi_window.
+#ifndef MI_LSP_PLUG_IN_DSP_UNITS_MISC_WINDOWS_H_
+#define MI_LSP_PLUG_IN_DSP_UNITS_MISC_WINDOWS_H_
+
+#include <lsp-plug.in/dsp-units/version.h>
+#include <mi_dspu.h>
+#include <cstddef>
+
+namespace lsp
+{
+    namespace dspu
+    {
+        namespace windows
+        {
+            enum window_t
+            {
+                HANN = MI_WINDOW_HANN, HAMMING, BLACKMAN, LANCZOS, GAUSSIAN, POISSON, PARZEN, TUKEY, WELCH, NUTTALL,
+                BLACKMAN_NUTTALL, BLACKMAN_HARRIS, HANN_POISSON, BARTLETT_HANN, BARTLETT_FEJER, TRIANGULAR,
+                RECTANGULAR, FLAT_TOP, COSINE, SQR_COSINE, CUBIC,
+                TOTAL, FIRST = HANN, LAST = TOTAL - 1
+            };
+
+            LSP_DSP_UNITS_PUBLIC void window(float *dst, size_t n, window_t type);
+
+            #define MI_WND(fn, id) inline void fn(float *dst, size_t n) { window(dst, n, id); }
+            MI_WND(hann, HANN) MI_WND(hamming, HAMMING) MI_WND(blackman, BLACKMAN) MI_WND(lanczos, LANCZOS)
+            MI_WND(gaussian, GAUSSIAN) MI_WND(poisson, POISSON) MI_WND(parzen, PARZEN) MI_WND(tukey, TUKEY)
+            MI_WND(welch, WELCH) MI_WND(nuttall, NUTTALL) MI_WND(blackman_nuttall, BLACKMAN_NUTTALL)
+            MI_WND(blackman_harris, BLACKMAN_HARRIS) MI_WND(hann_poisson, HANN_POISSON)
+            MI_WND(bartlett_hann, BARTLETT_HANN) MI_WND(bartlett_fejer, BARTLETT_FEJER) MI_WND(triangular, TRIANGULAR)
+            MI_WND(rectangular, RECTANGULAR) MI_WND(flat_top, FLAT_TOP) MI_WND(cosine, COSINE)
+            MI_WND(sqr_cosine, SQR_COSINE) MI_WND(cubic, CUBIC)
+            #undef MI_WND
+        }
+    }
+}
+
+#endif

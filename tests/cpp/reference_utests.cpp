@@ -1,0 +1,222 @@
+// The reference's own unit tests for the hot path, replayed against the lsp::dspu::* classes of this library
+// (same class names, same calls, same tolerances):
+//   src/test/utest/util/convolver.cpp      test_small (:88-136), test_large (:184-223)
+//   src/test/utest/filters/equalizer.cpp   test_latency FIR/FFT/SPM (:35-92)
+//   src/test/utest/util/spectral_proc.cpp  test_simple (:37-67)
+//   src/test/utest/util/ringbuffer.cpp     (:30-192)
+//   README.md:145-230                      the Filter demo (C1)
+// Plain C++11, no test framework: exit code 0 == all passed.  Needs a GPU (the classes have no CPU fallback).
+#include <lsp-plug.in/dsp-units/filters/Filter.h>
+#include <lsp-plug.in/dsp-units/filters/Equalizer.h>
+#include <lsp-plug.in/dsp-units/util/Convolver.h>
+#include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/RingBuffer.h>
+#include <lsp-plug.in/dsp-units/util/Delay.h>
+#include <lsp-plug.in/dsp-units/units.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+using namespace lsp;
+
+static int failures = 0;
+#define CHECK(cond, ...) do { if (!(cond)) { ++failures; printf("  FAIL %s:%d: ", __FILE__, __LINE__); printf(__VA_ARGS__); printf("\n"); } } while (0)
+
+static void naive_convolve(std::vector<float> &dst, const std::vector<float> &src, const std::vector<float> &conv, size_t count)
+{
+    for (size_t i = 0; i < count; ++i)
+        for (size_t j = 0; j < conv.size(); ++j)
+            dst[i + j] += src[i] * conv[j];
+}
+
+static void chunked(dspu::Convolver &c, std::vector<float> &dst, const std::vector<float> &src, size_t step)
+{
+    for (size_t i = 0; i < src.size();)
+    {
+        const size_t todo = (src.size() - i > step) ? step : src.size() - i;
+        c.process(&dst[i], &src[i], todo);
+        i += todo;
+    }
+}
+
+static void convolver_small()
+{
+    printf("convolver.test_small\n");
+    dspu::Convolver c;
+    std::vector<float> conv(0x1f), src(0x2000 + 0x1f, 0.0f);
+    for (size_t i = 0; i < conv.size(); ++i) conv[i] = i + 1;
+    for (size_t i = 0, j = 0; i < 0x2000; i += 5, ++j)
+        src[i] = ((j % 3) == 0) ? 1.0f : ((j % 3) == 1) ? 0.1f : 0.01f;
+    std::vector<float> d1(src.size() + conv.size(), 0.0f), d3(src.size(), 0.0f);
+    CHECK(c.init(conv.data(), conv.size(), 9, 0), "init");
+    naive_convolve(d1, src, conv, 0x2000);
+    chunked(c, d3, src, 31);
+    for (size_t i = 0; i < src.size(); ++i)
+    {
+        const float tol = 1e-4f * fmaxf(fabsf(d1[i]), 1.0f);      // equals_relative 1e-4 (values of order 1..500)
+        if (fabsf(d3[i] - d1[i]) > tol) { CHECK(false, "sample %zu: %.6f vs %.6f", i, d1[i], d3[i]); break; }
+    }
+    c.destroy();
+}
+
+static void convolver_large()
+{
+    printf("convolver.test_large\n");
+    dspu::Convolver c;
+    srand(1);
+    std::vector<float> conv(0x2000), src(0x20 + 0x2000, 0.0f);
+    for (float &v : conv) v = float(rand()) / float(RAND_MAX);
+    for (size_t i = 0; i < 0x20; ++i) src[i] = float(rand()) / float(RAND_MAX);
+    std::vector<float> d1(src.size() + conv.size(), 0.0f), d3(src.size(), 0.0f);
+    CHECK(c.init(conv.data(), conv.size(), 10, 0), "init");
+    CHECK(c.data_size() == 0x2000 && c.rank() == 10, "data_size/rank");
+    naive_convolve(d1, src, conv, 0x20);
+    chunked(c, d3, src, 31);
+    for (size_t i = 0; i < src.size(); ++i)
+        if (fabsf(d3[i] - d1[i]) > 1e-4f) { CHECK(false, "sample %zu: %.6f vs %.6f", i, d1[i], d3[i]); break; }   // equals_absolute 1e-4
+    c.destroy();
+}
+
+static void equalizer_latency(const char *label, dspu::equalizer_mode_t mode)
+{
+    printf("equalizer.test_latency %s\n", label);
+    const size_t RANK = 13, BUF = size_t(1) << (RANK + 2);
+    dspu::Equalizer eq;
+    dspu::filter_params_t fp;
+    CHECK(eq.init(1, RANK), "init");
+    eq.set_mode(mode);
+    eq.set_sample_rate(48000);
+    fp.nType = dspu::FLT_BT_LRX_HIPASS; fp.fFreq = 100.0f; fp.fFreq2 = 100.0f; fp.fGain = 1.0f; fp.nSlope = 2; fp.fQuality = 0.0f;
+    eq.set_params(0, &fp);
+    std::vector<float> src(BUF, 0.0f), dst(BUF, 0.0f);
+    src[0] = 1.0f;
+    eq.process(dst.data(), src.data(), BUF);
+    const size_t latency = eq.get_latency();
+    size_t index = 0;
+    for (size_t i = 1; i < BUF; ++i)
+        if (fabsf(dst[i]) > fabsf(dst[index])) index = i;
+    printf("  latency = %zu, maximum = %zu\n", latency, index);
+    CHECK(latency == index, "latency %zu != peak %zu", latency, index);
+    eq.destroy();
+}
+
+static void spectral_proc_simple()
+{
+    printf("spectral_proc.test_simple\n");
+    const size_t SAMPLES = 8192;
+    std::vector<float> in(SAMPLES), out(SAMPLES, 0.0f);
+    const float w = 2 * M_PI * 440.0f / 48000.0f;
+    for (size_t i = 0; i < SAMPLES; ++i) in[i] = sinf(w * i);
+    dspu::SpectralProcessor sp;
+    CHECK(sp.init(14), "init");
+    sp.set_phase(0.0f);
+    sp.set_rank(8);
+    sp.process(out.data(), in.data(), SAMPLES);
+    const size_t latency = sp.latency();
+    CHECK(latency == 256, "latency %zu", latency);
+    for (size_t i = 0; i < SAMPLES - latency; ++i)
+        if (fabsf(in[i] - out[latency + i]) > 1e-5f) { CHECK(false, "sample %zu: %.7f vs %.7f", i, in[i], out[latency + i]); break; }
+}
+
+static void halve(void *, void *, float *spectrum, size_t rank)
+{
+    for (size_t i = 0; i < (size_t(2) << rank); ++i) spectrum[i] *= 0.5f;
+}
+
+static void spectral_proc_callback()
+{
+    printf("spectral_proc host callback (x0.5)\n");
+    const size_t SAMPLES = 4096;
+    std::vector<float> in(SAMPLES), out(SAMPLES, 0.0f);
+    srand(2);
+    for (float &v : in) v = float(rand()) / float(RAND_MAX) - 0.5f;
+    dspu::SpectralProcessor sp;
+    CHECK(sp.init(10), "init");
+    sp.bind(halve, NULL, NULL);
+    sp.process(out.data(), in.data(), SAMPLES);
+    for (size_t i = 0; i + 1024 < SAMPLES; ++i)
+        if (fabsf(0.5f * in[i] - out[1024 + i]) > 1e-5f) { CHECK(false, "sample %zu", i); break; }
+}
+
+static void ringbuffer()
+{
+    printf("ringbuffer\n");
+    dspu::RingBuffer rb;
+    float dst[16];
+    CHECK(rb.init(8), "init");
+    CHECK(rb.size() == 8, "size");
+    rb.append(1.0f); rb.append(2.0f); rb.append(3.0f); rb.append(4.0f);
+    const float e1[9] = { 0, 0, 0, 0, 0, 1, 2, 3, 4 };
+    for (int o = 8; o >= 0; --o) CHECK(rb.get(size_t(o)) == e1[8 - o], "get(%d)", o);
+    static const float buf1[2] = { 5.0f, 6.0f };
+    CHECK(rb.append(buf1, 2) == 2, "append 2");
+    CHECK(rb.get(dst, 9, 10) == 8, "get(dst, 9, 10)");
+    const float e2[10] = { 0, 0, 0, 0, 1, 2, 3, 4, 5, 6 };
+    CHECK(memcmp(dst, e2, sizeof(e2)) == 0, "block 1");
+    static const float buf2[4] = { 7.0f, 8.0f, 9.0f, 10.0f };
+    CHECK(rb.append(buf2, 4) == 4, "append 4");
+    CHECK(rb.get(dst, 7, 10) == 8, "get(dst, 7, 10)");
+    const float e3[10] = { 3, 4, 5, 6, 7, 8, 9, 10, 0, 0 };
+    CHECK(memcmp(dst, e3, sizeof(e3)) == 0, "block 2");
+    static const float buf3[12] = { -1, -2, -3, -4, -5, -6, -7, -8, -9, -10, -11, -12 };
+    CHECK(rb.append(buf3, 12) == 8, "append 12");
+    CHECK(rb.get(dst, 16, 8) == 0, "get(dst, 16, 8)");
+    CHECK(rb.get(dst, 12, 16) == 8, "get(dst, 12, 16)");
+    const float e4[16] = { 0, 0, 0, 0, 0, -5, -6, -7, -8, -9, -10, -11, -12, 0, 0, 0 };
+    CHECK(memcmp(dst, e4, sizeof(e4)) == 0, "block 3");
+    CHECK(rb.get(&dst[0], 8, 2) == 1 && rb.get(&dst[2], 6, 2) == 2 && rb.get(&dst[8], 0, 2) == 1, "short reads");
+    CHECK(dst[0] == 0.0f && dst[1] == -5.0f && dst[2] == -6.0f && dst[3] == -7.0f && dst[8] == -12.0f && dst[9] == 0.0f, "short read values");
+}
+
+static void readme_filter()
+{
+    printf("README filter demo (C1)\n");
+    dspu::Filter f;
+    dspu::filter_params_t fp;
+    fp.nType = dspu::FLT_BT_BWC_HISHELF; fp.fFreq = 1000.0f; fp.fFreq2 = 1000.0f;
+    fp.fGain = dspu::db_to_gain(6.0f); fp.nSlope = 2; fp.fQuality = 0.0f;
+    CHECK(f.init(NULL), "init");
+    f.update(48000, &fp);
+    std::vector<float> c(48000, 0.0f);
+    c[0] = 1.0f;
+    f.clear();
+    f.process(c.data(), c.data(), c.size());                        // in place, as the README does
+    const float head[8] = { 1.93714225f, -0.114121534f, -0.109540939f, -0.10430833f, -0.0985007137f,
+                            -0.0922033042f, -0.0855074227f, -0.0785082579f };
+    for (int i = 0; i < 8; ++i) CHECK(fabsf(c[i] - head[i]) <= 1e-6f, "impulse[%d] = %.8f", i, c[i]);
+    // delay line used as the README-style latency compensation (utest/dynamics/limiter.cpp:58-77 pattern)
+    dspu::Delay d;
+    CHECK(d.init(1000), "delay init");
+    d.set_delay(480);
+    std::vector<float> y(2000);
+    d.process(y.data(), c.data(), 2000);
+    CHECK(y[479] == 0.0f && y[480] == c[0] && y[1999] == c[1519], "delay");
+}
+
+int main(int argc, char **argv)
+{
+    if (argc > 1 && strcmp(argv[1], "--list") == 0)
+    {
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc ringbuffer readme_filter");
+        return 0;
+    }
+    if (mi_dspu_device_count() <= 0)
+    {
+        puts("no HIP device: the lsp::dspu classes of this library have no CPU fallback");
+        return 2;
+    }
+    convolver_small();
+    convolver_large();
+    equalizer_latency("FIR", dspu::EQM_FIR);
+    equalizer_latency("FFT", dspu::EQM_FFT);
+    equalizer_latency("SPM", dspu::EQM_SPM);
+    spectral_proc_simple();
+    spectral_proc_callback();
+    ringbuffer();
+    readme_filter();
+    printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
+    return failures ? 1 : 0;
+}
