@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver"],
+    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral"],
                     help="all = headline biquad line with the convolver result attached under \"convolver\"")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
@@ -43,6 +43,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sections", type=int, default=8, help="experiment knob: keep only the first N sections")
     ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
+    ap.add_argument("--eq-channels", type=int, default=256, help="equalizer channels per GPU (config 3: 2048 over 8 GPUs)")
+    ap.add_argument("--spec-channels", type=int, default=1024, help="analyzer channels per GPU (config 4: 8192 over 8 GPUs)")
     ap.add_argument("--conv-steps", type=int, default=50)
     ap.add_argument("--conv-warmup", type=int, default=5)
     return ap.parse_args()
@@ -202,6 +204,139 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
     return res
 
 
+def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True):
+    """warm up, then time `steps` calls of step(i): returns (elapsed_s_max_over_ranks, sorted kernel ms list)."""
+    import ctypes
+    for i in range(warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    def new_event():
+        e = ctypes.c_void_p()
+        mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
+        return e
+    starts = [new_event() for _ in range(steps)]
+    stops = [new_event() for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        if profile:
+            mi.check(mi.lib.mi_dspu_profile_next_launch(starts[i], stops[i]))
+        step(warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = []
+    if profile:
+        for a, b in zip(starts, stops):
+            ms = ctypes.c_float()
+            mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), a, b))
+            kernel_ms.append(float(ms.value))
+    for e in starts + stops:
+        mi.lib.mi_dspu_event_destroy(e)
+    return elapsed, sorted(kernel_ms)
+
+
+def run_equalizer(args, mi, torch, dist, rank, world, dev):
+    """BASELINE.json configs[3]: 32-band Equalizer (FIR mode, fir_rank 12), 256 channels per GPU, 4096-sample blocks."""
+    import numpy as np
+    C, nfilt, fir_rank, n = args.eq_channels, 32, 12, 4096
+    rng = np.random.default_rng(6 + rank)
+    eq = mi.EqualizerBank(C, nfilt, fir_rank)
+    eq.set_mode(mi.EqualizerBank.FIR)
+    eq.set_sample_rate(48000)
+    freqs = np.exp(np.linspace(np.log(20.0), np.log(20000.0), nfilt))
+    FLT_BT_RLC_BELL = 11
+    for c in range(C):
+        gains = 10.0 ** (rng.uniform(-12.0, 12.0, nfilt) / 20.0)
+        for i in range(nfilt):
+            eq.set_params(i, FLT_BT_RLC_BELL, 1, float(freqs[i]), float(freqs[i]), float(gains[i]), 2.0, channel=c)
+    ring = 8
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(60 + rank)
+    xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    yout = torch.empty_like(xin)
+    stream = torch.cuda.current_stream()
+    eq.get_latency(stream)                                  # reconfigure (designer + FIR synthesis) outside the timing
+
+    def step(i):
+        eq.process(yout[i % ring], xin[i % ring], n, stream=stream)
+    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    assert bool(torch.isfinite(yout[0]).all())
+    eq.close()
+    if rank != 0:
+        return None
+    step_bytes = 24.0 * C * n                               # SURVEY.md 8d C4: 24 B per channel-sample
+    return {
+        "value": round(C * n * world * args.conv_steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+        "ms_per_step": round(elapsed / args.conv_steps * 1e3, 5),
+        "config": {"workload": "Equalizer EQM_FIR, 32 x FLT_BT_RLC_BELL per channel, fir_rank 12, %d channels per GPU, "
+                               "4096-sample blocks" % C, "channels_per_gpu": C},
+        "whole_step": {"algorithmic_bytes": step_bytes,
+                       "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / args.conv_steps) / 1e9, 1),
+                       "frac": round(step_bytes / (elapsed / args.conv_steps) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+
+def run_spectral(args, mi, torch, dist, rank, world, dev):
+    """BASELINE.json configs[4]: 4096-point Hann spectrum of 1024 channels per GPU every 2048 samples, per-bin sum
+    over ALL channels of the job: local reduction on the device + one RCCL all-reduce per batch of frames."""
+    sharding = importlib.import_module("lsp-dsp-units_amd.sharding")
+    C, rank_fft, hop, batch = args.spec_channels, 12, 2048, 8
+    sr = 48000
+    an = mi.AnalyzerBank(C, rank_fft, sr, 1.0, 0)
+    for what, v in ((an.SAMPLE_RATE, sr), (an.RATE, sr / float(hop)), (an.RANK, rank_fft), (an.WINDOW, 0),
+                    (an.REACTIVITY, 0.2), (an.SHIFT, 1.0)):
+        an.configure(what, v)
+    ring = 8
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(7 + rank)
+    xin = torch.randn((ring, C, hop), generator=gen, dtype=torch.float32).to(dev)
+    bins = (1 << (rank_fft - 1)) + 1
+    sums = torch.zeros((batch, bins), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+    an.process(xin[0], hop, stream=stream)
+    info = an.info()
+    assert info["period"] == hop, info
+
+    def step(i):
+        an.process(xin[i % ring], hop, stream=stream)       # one frame: ingest + strobe analysis of every channel
+        an.reduce_bins(sums[i % batch], stream=stream)      # local per-bin sum over this GPU's channels
+        if (i % batch) == batch - 1:
+            sharding.allreduce_bins(sums)                   # one collective per `batch` frames (RCCL over xGMI)
+    steps = args.conv_steps - (args.conv_steps % batch) or batch
+    elapsed, kernel_ms = _timed_steps(mi, torch, dist, world, dev, step, steps, batch)
+    assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
+    an.close()
+    if rank != 0:
+        return None
+    frame_bytes = float(C) * (4096 * 4 + bins * 4)          # SURVEY.md 8d C5: 24 580 B per channel-frame
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    return {
+        "value": round(C * world * steps / elapsed, 1), "unit": "channel-frames/s",
+        "msamples_per_s": round(C * world * hop * steps / elapsed / 1e6, 1),
+        "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "config": {"workload": "Analyzer: 4096-point Hann spectrum per channel every 2048 samples, %d channels per GPU, "
+                               "per-bin sum over all channels (all-reduce of %d x %d floats per %d frames)"
+                               % (C, batch, bins, batch), "channels_per_gpu": C},
+        "roofline": {"bound": "hbm", "achieved": round(frame_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(frame_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "kernel": "analyzer_kernel<11>", "kernel_avg_us": round(avg_ms * 1e3, 3),
+                     "algorithmic_bytes_per_launch": frame_bytes},
+        "whole_step": {"algorithmic_bytes": frame_bytes,
+                       "achieved_GBps_incl_launch_gaps": round(frame_bytes / (elapsed / steps) / 1e9, 1),
+                       "frac": round(frame_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+    }
+
+
 def main():
     args = parse()
     import numpy as np
@@ -222,8 +357,9 @@ def main():
     mi.check(mi.lib.mi_dspu_set_device(local_rank))
     import workloads as wl
 
-    if args.workload == "convolver":
-        res = run_convolver(args, mi, torch, dist, rank, world, dev)
+    if args.workload in ("convolver", "equalizer", "spectral"):
+        runner = {"convolver": run_convolver, "equalizer": run_equalizer, "spectral": run_spectral}[args.workload]
+        res = runner(args, mi, torch, dist, rank, world, dev)
         if rank == 0:
             line = {"metric": "Msamples/sec per GPU (biquad-x8 1024ch; Convolver 65536-tap) + HBM roofline %",
                     "n_gpus": world, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -345,8 +481,12 @@ def main():
     torch.cuda.empty_cache()
     if args.workload == "all" and args.sections == 8:
         conv = run_convolver(args, mi, torch, dist, rank, world, dev)
+        eqr = run_equalizer(args, mi, torch, dist, rank, world, dev)
+        spr = run_spectral(args, mi, torch, dist, rank, world, dev)
         if rank == 0:
             line["convolver"] = conv
+            line["equalizer"] = eqr
+            line["spectral"] = spr
     if rank == 0:
         print(json.dumps(line), flush=True)
 
