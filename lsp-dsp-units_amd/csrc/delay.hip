@@ -47,6 +47,27 @@ namespace
         }
     }
 
+    // Not-aliased fast path of Delay::process: dst[i] (+)= gain * (i >= d ? src[i - d] : ring[(tail + i) % size]).
+    // Same values as the push/pull pieces of the reference (a cell read `d` behind the write position holds
+    // src[i - d] as soon as i >= d), without cutting the block into pieces.
+    __global__ __launch_bounds__(256)
+    void delay_direct_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, const float *ring,
+                             uint32_t size, uint32_t head, const uint32_t *__restrict__ delay, size_t count,
+                             int add, int gmode, float k, const float *gv, size_t gv_stride)
+    {
+        const uint32_t ch = blockIdx.y;
+        const uint32_t d = delay[ch];
+        const uint32_t tail = (head + size - d) % size;
+        const float *x = src + size_t(ch) * src_stride;
+        for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+        {
+            const float raw = (i >= d) ? x[i - d] : ring[size_t(ch) * size + (tail + i) % size];
+            const float v = apply_gain(raw, gmode, k, gv + size_t(ch) * gv_stride, i);
+            float *o = dst + size_t(ch) * dst_stride + i;
+            *o = add ? *o + v : v;
+        }
+    }
+
     // Delay::process_ramping (Delay.cpp:399-546): the read position slides from the old delay to the new one.
     // Reproduces the reference's chunked write-then-read order in closed form: the sample read at output offset o
     // is the newest input written to that ring cell by the end of o's chunk, else the cell's old content.
@@ -272,6 +293,14 @@ int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_
     // The reference alternates "push to_do samples / pull to_do samples" in pieces of at most size - delay
     // (Delay.cpp:113-142) so that a pull never reads a cell a later push of the same call already overwrote.
     // Same order here, with the piece bounded by the largest delay of the bank.
+    if (static_cast<const void *>(out) != static_cast<const void *>(in))
+    {
+        hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+                           out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
+                           gain, gain_vec, gain_stride);
+        MI_HIP_CHECK(hipGetLastError());
+        return append(b, in, in_stride, count, st);
+    }
     uint32_t dmax = 0;
     for (uint32_t d : b->delay)
         dmax = (d > dmax) ? d : dmax;

@@ -270,7 +270,8 @@ int mi_equalizer_bank_create(mi_equalizer_bank_t **bank, uint32_t channels, uint
         std::vector<float> zeros(size_t(channels) * N, 0.0f);
         zeros[0] = 0.0f;
         if (r == MI_OK) r = mi_convolver_bank_create(&b->conv, channels, zeros.data(), N, nullptr, uint32_t(N), fir_rank + 1, 0.0f, nullptr);
-        if (r == MI_OK) r = mi_delay_bank_create(&b->delay, channels, N);
+        // the line is longer than the delay so that a whole block fits the in-place push/pull piece (delay.hip)
+        if (r == MI_OK) r = mi_delay_bank_create(&b->delay, channels, N + ((N > 8192) ? N : 8192));
         if (r == MI_OK) r = mi_delay_bank_set_delay(b->delay, UINT32_MAX, N);
         if (r == MI_OK) r = mi_spectral_bank_create(&b->spm, channels, fir_rank);
         if (r == MI_OK) r = mi_spectral_bank_set_windows(b->spm, -1, MI_WINDOW_SQR_COSINE);

@@ -224,17 +224,35 @@ namespace
         }
     }
 
-    // out[k] = sum over channels of src[c][k] * env[k]   (per-bin reduction used by the C5 callback)
+    // Per-bin reduction over channels (the C5 callback), deterministic two-stage sum:
+    //   stage 1: part[g][k] = sum of src[c][k] over the channels of group g   (grid: bins/256 x groups)
+    //   stage 2: out[k]     = (sum over groups of part[g][k]) * env[k]
+    constexpr uint32_t REDUCE_GROUPS = 64;
+
     __global__ __launch_bounds__(256)
-    void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels,
-                           uint32_t bins, const float *__restrict__ env)
+    void bin_reduce_stage1(float *part, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins)
+    {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
+        if (k >= bins)
+            return;
+        const uint32_t per = (channels + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
+        const uint32_t c0 = g * per, c1 = (c0 + per < channels) ? c0 + per : channels;
+        float s = 0.0f;
+        for (uint32_t c = c0; c < c1; ++c)
+            s += src[size_t(c) * stride + k];
+        part[size_t(g) * stride + k] = s;
+    }
+
+    __global__ __launch_bounds__(256)
+    void bin_reduce_stage2(float *out, const float *__restrict__ part, uint32_t stride, uint32_t bins,
+                           const float *__restrict__ env)
     {
         const uint32_t k = blockIdx.x * 256 + threadIdx.x;
         if (k >= bins)
             return;
         float s = 0.0f;
-        for (uint32_t c = 0; c < channels; ++c)
-            s += src[size_t(c) * stride + k];
+        for (uint32_t g = 0; g < REDUCE_GROUPS; ++g)
+            s += part[size_t(g) * stride + k];
         out[k] = (env != nullptr) ? s * env[k] : s;
     }
 
@@ -587,7 +605,7 @@ struct mi_analyzer_bank
     uint32_t    reconfigure = 0x1f;
     std::vector<uint32_t> user_delay, delay;
     std::vector<uint8_t>  ch_active, ch_freeze;
-    float      *d_ring = nullptr, *d_amp = nullptr, *d_data = nullptr, *d_wnd = nullptr, *d_env = nullptr;
+    float      *d_ring = nullptr, *d_amp = nullptr, *d_data = nullptr, *d_wnd = nullptr, *d_env = nullptr, *d_part = nullptr;
     uint32_t   *d_delay = nullptr;
     uint8_t    *d_flags = nullptr;
     const float2 *d_tw = nullptr;
@@ -739,7 +757,7 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
     if (b == nullptr)
         return MI_OK;
     (void)hipFree(b->d_ring); (void)hipFree(b->d_amp); (void)hipFree(b->d_data); (void)hipFree(b->d_wnd);
-    (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
+    (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags); (void)hipFree(b->d_part);
     delete b;
     return MI_OK;
 }
@@ -874,8 +892,12 @@ int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *b, float *out, int with_env
     MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_reduce_bins: bad argument");
     hipStream_t st = mi::as_stream(stream);
     const uint32_t bins = (1u << (b->rank - 1)) + 1;
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3((bins + 255) / 256), dim3(256), 0, st,
-                       out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr);
+    if (b->d_part == nullptr)
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_part), size_t(REDUCE_GROUPS) * b->bins_stride * sizeof(float)));
+    hipLaunchKernelGGL(bin_reduce_stage1, dim3((bins + 255) / 256, REDUCE_GROUPS), dim3(256), 0, st,
+                       b->d_part, b->d_amp, b->bins_stride, b->channels, bins);
+    hipLaunchKernelGGL(bin_reduce_stage2, dim3((bins + 255) / 256), dim3(256), 0, st,
+                       out, b->d_part, b->bins_stride, bins, with_envelope ? b->d_env : nullptr);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
