@@ -469,7 +469,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "kernel": "biquad_bank_kernel_pk<32>", "kernel_avg_us": round(avg_kernel_ms * 1e3, 3),
+                "kernel": "biquad_bank_kernel<16,2>", "kernel_avg_us": round(avg_kernel_ms * 1e3, 3),
                 "kernel_median_us": round(med_kernel_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes,
             },
         }

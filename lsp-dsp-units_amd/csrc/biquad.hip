@@ -5,32 +5,35 @@
 // Why this is not "one channel per lane, serial in time": a block of N samples
 // through one section is a chain of 2N dependent FMAs; at N = 4096 that chain
 // alone is longer than the whole HBM budget of the block.  The kernel therefore
-// cuts every channel's block into chunks of L samples, one chunk per lane, and
-// runs every section in three steps (state s = {d0,d1}, s' = A s + B x):
+// makes the recurrence parallel in time.  Per section, state s = {d0,d1},
+// s' = A s + B x, and every lane owns a PAIR of adjacent chunks of L samples:
 //
-//   1. zero-state response of the chunk's end state:  z = sum_k A^(L-1-k) B x[k]
-//      -> two dot products with per-section tables p[],q[];
-//   2. prefix over chunks  E_t = P E_(t-1) + z_t,  P = A^L, done in two levels so
-//      that no data-dependent lane shuffles are needed:
+//   1. zero-state end state of each chunk:  z = sum_k A^(L-1-k) B x[k]
+//      -> two dot products with the per-section tables p[],q[];
+//   2. the pair's end state for a zero start:  e = P zA + zB,  P = A^L;
+//      prefix over the 64 pairs of the wave,  E_t = P^2 E_(t-1) + e_t:
 //        a. inclusive scan inside each row of 16 lanes with DPP row_shr 1,2,4,8
-//           and the uniform matrices P, P^2, P^4, P^8;
-//        b. the four row totals of a wave are chained with P^16 (uniform math),
-//           waves are chained through one LDS word pair and one barrier;
-//        c. every lane adds P^(i+1) C_row, i = lane % 16, C_row = state entering
-//           its row (a 16-entry matrix table, the same for all rows);
-//      the state the channel carried in from the previous call enters at chunk 0;
-//   3. the exact TDF-II recurrence over the chunk, started from E_(t-1):
+//           and the uniform matrices P^2, P^4, P^8, P^16;
+//        b. the row totals are chained with P^32 (uniform math via v_readlane);
+//        c. every lane adds (P^2)^(i+1) C_row, i = lane % 16 (16-entry table);
+//      the state carried in from the previous sub-block / call enters at lane 0;
+//   3. start state of the lane's first chunk = E_(t-1), of its second chunk
+//      P S + zA; then the EXACT TDF-II recurrence of the reference over both
+//      chunks at once, as the two halves of v_pk_fma_f32 operands:
 //         y = b0 x + d0;  d0 = (b1 x + d1) + a1 y;  d1 = b2 x + a2 y
-//      -- the reference's own per-sample arithmetic; only the chunk start state
-//      carries the (float32 round-off sized) difference of steps 1-2.
+//      Only the chunk start states carry the (float32 round-off sized)
+//      difference of steps 1-2.
 //
-// All sections of a channel run back to back on samples held in registers, so
-// HBM sees each sample once in and once out (8 B per channel-sample).
-// A workgroup owns one channel: it loads the block with coalesced 16-B loads,
-// transposes it through a padded LDS tile so each lane gets its L consecutive
-// samples (conflict-free ds_read_b128: row pitch L+4 dwords, (L+4)/4 odd), and
-// stores the result the same way back.  The per-section tables of the channel
-// are staged in LDS (8 sections at a time) and read as broadcasts.
+// One WAVE owns one channel.  A lone wave issues one VALU instruction per 4
+// cycles: half rate for v_fma_f32, full rate for packed fp32 -- so one wave per
+// SIMD (1024 channels on 1024 SIMDs) runs at full VALU throughput with no
+// workgroup barrier in the section loop and the whole register file to itself.
+// All sections run back to back on samples held in registers (HBM sees each
+// sample once in, once out).  A call is cut into sub-blocks of 64 x 2L samples;
+// the loads of sub-block k+1 are in flight while sub-block k is computed and the
+// stores of sub-block k (write-through, sc1) drain while k+1 is computed.
+// Loads are coalesced 16-B rows, transposed through a padded LDS tile (pitch
+// 2L+4 dwords, an odd number of 16-B slots: conflict-free ds_read_b128).
 #include "mi_common.h"
 
 #include <cmath>
@@ -40,23 +43,29 @@
 
 namespace
 {
-    template <int L, int NT>
+    template <int L>
     struct geom
     {
-        static constexpr int TAB    = 72 + 2 * L;           // floats per (channel, section)
-        static constexpr int PITCH  = L + 4;                // LDS dwords per chunk
-        static constexpr int BLOCK  = L * NT;               // samples per launch and channel
-        static constexpr int NW     = NT / 64;              // waves per workgroup
+        static constexpr int W      = 2 * L;                // samples per lane and sub-block
+        static constexpr int TAB    = 80 + 2 * L;           // floats per (channel, section)
+        static constexpr int PITCH  = W + 4;                // LDS dwords per lane
+        static constexpr int BLOCK  = 64 * W;               // samples per sub-block
         static constexpr int SG     = 8;                    // sections whose tables are staged at once
         static_assert(((PITCH / 4) & 1) == 1, "LDS pitch must be an odd number of 16-B slots");
         static_assert((TAB % 4) == 0, "table rows stay 16-B aligned");
-        static_assert(NT % 64 == 0, "whole waves");
     };
 
     // Table row of one section:
-    //   [0..4]   b0 b1 b2 a1 a2            [5..7] unused
-    //   [8+4i..] P^(i+1) row-major, i = 0..15   (P = A^L; P,P^2,P^4,P^8 drive the row scan, P^16 the chain)
-    //   [72..]   p[L], q[L]
+    //   [0..4]    b0 b1 b2 a1 a2              [5..7] unused
+    //   [8..11]   P = A^L, row-major
+    //   [12+4i..] (P^2)^(i+1), i = 0..15
+    //   [76..79]  (P^2)^64: one whole sub-block
+    //   [80..]    p[L], q[L]
+    typedef float v2f __attribute__((ext_vector_type(2)));
+
+    __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+    __device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+
     template <int CTRL>
     __device__ __forceinline__ float dpp_zero(float v)
     {
@@ -68,543 +77,420 @@ namespace
         return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
     }
 
-    template <int L, int NT, bool ALIGNED, bool FULL>
-    __global__ __launch_bounds__(NT)
+    // 16-byte write-through store (sc1): the output leaves the XCD's L2 while the kernel is still running
+    // instead of being written back in one burst by the end-of-kernel release (MI355X_MICROARCH.md,
+    // "publish-large": tens of KB per workgroup from a streaming epilogue -> write-through wins).
+    // A buffer store (not inline asm) so that the compiler's vmcnt bookkeeping sees it: the wait for the
+    // prefetched loads of the next sub-block must not also wait for these stores.
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int BUFFER_DWORD3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
+    constexpr int CPOL_SC1 = 16;
+
+    __device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t rsrc, int dword_index, float4 v)
+    {
+        const u32x4 d = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
+        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, dword_index * 4, 0, CPOL_SC1);
+    }
+
+#ifndef MI_ABLATE
+#define MI_ABLATE 0                 // timing experiments only (tests/experiments/biquad_phase_probe.hip): drop one phase
+#endif
+#ifdef MI_BIQUAD_PROBE
+    // phase timestamps of lane 0 (tests/experiments/biquad_phase_probe.hip): [block][slot] = {100 MHz wall clock, shader cycles}
+    __device__ unsigned long long g_probe[4096 * 16 * 2];
+    #define MI_PROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (t == 0 && (slot) < 16) { \
+        const unsigned pw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+        g_probe[(pw_ * 16 + (slot)) * 2] = wall_clock64(); \
+        g_probe[(pw_ * 16 + (slot)) * 2 + 1] = __builtin_readcyclecounter(); } __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+    #define MI_PROBE(slot) do { } while (0)
+#endif
+#ifdef MI_BIQUAD_PROBE
+    // in-section timestamps stay in SGPRs until the section is over (a store per stamp would perturb the section)
+    #define MI_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_readcyclecounter(); \
+                             __builtin_amdgcn_sched_barrier(0); } while (0)
+    #define MI_STAMP_DUMP() do { if (si == 1 && par == 0 && t == 0) { \
+        const unsigned pw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
+        for (int i_ = 0; i_ < 8; ++i_) g_probe[(pw_ * 16 + 8 + i_) * 2 + 1] = ts[i_]; } } while (0)
+#else
+    #define MI_STAMP(i) do { } while (0)
+    #define MI_STAMP_DUMP() do { } while (0)
+#endif
+
+    template <int L, int NW, bool ALIGNED>
+    __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
     void biquad_bank_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
-                            int cnt, const float *__restrict__ tab, float *state,
+                            int n /* multiple of L */, const float *__restrict__ tab, float *state,
                             const uint32_t *__restrict__ nsec, int max_sec)
     {
-        using G = geom<L, NT>;
-        constexpr int TAB   = G::TAB;
-        constexpr int PITCH = G::PITCH;
-        constexpr int NW    = G::NW;
-        constexpr int SG    = G::SG;
+        using G = geom<L>;
+        constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
+        constexpr int LPT = W / 4;                          // float4 per lane and sub-block
+        constexpr int TAB4 = TAB / 4;
+        constexpr int NT = 64 * NW;
+        constexpr int TQ = SG * TAB4, TPT = (TQ + NT - 1) / NT;
+        constexpr int PQ = 20;                              // float4 index of p[] inside a table row
 
-        constexpr int TQ    = SG * TAB / 4;                 // float4 per staged table group
-        constexpr int TPT   = (TQ + NT - 1) / NT;           // float4 per thread and group
-
-        __shared__ __attribute__((aligned(16))) float sx[NT * PITCH];
+        __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
         __shared__ __attribute__((aligned(16))) float stab[SG * TAB];
-        __shared__ float2 sstate[SG];
-        __shared__ float2 stot[2][NW];
+        __shared__ float2 sstate[2][SG];                    // state carried between super-blocks, by parity
+        __shared__ float2 xchg[2][SG][NW];                  // zero-start end state of every wave's sub-block
 
-        const int ch    = blockIdx.x;
-        const int t     = threadIdx.x;
-        const int lane  = t & 63;
-        const int l16   = t & 15;
-        const int row   = lane >> 4;
-        const int wave  = t >> 6;
-        const int ns    = int(nsec[ch]);
-        const float *xin = in + size_t(ch) * in_stride;
-        float *yout      = out + size_t(ch) * out_stride;
+        const int ch   = blockIdx.x;
+        const int tid  = threadIdx.x;
+        const int t    = tid & 63;                          // lane
+        const int wv   = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int l16  = t & 15;
+        const int row  = t >> 4;
+        const int ns   = int(nsec[ch]);
+        float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile
+        const bool r1 = (row == 1), r2 = (row == 2), r3 = (row == 3);
+        // Buffer descriptors over the channel's n samples: reads past the end return 0, writes past the end are
+        // dropped, so the tile rows need no bounds branches and the compiler's vmcnt bookkeeping stays exact.
+        const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(in + size_t(ch) * in_stride), 0, n * 4, BUFFER_DWORD3);
+        const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+            out + size_t(ch) * out_stride, 0, n * 4, BUFFER_DWORD3);
+        MI_PROBE(0);
 
-        // tables and carried state of the first section group: issued before the samples so that
-        // their latency hides behind the block load
-        float4 tpre[TPT];
-        float2 spre = make_float2(0.0f, 0.0f);
+        // ---- helpers ---------------------------------------------------------------------------
+        float4 ld[LPT];
+        auto issue_loads = [&](int base)                    // coalesced rows of the wave's sub-block -> registers
         {
-            const int group = (ns < SG) ? ns : SG;
-            const float4 *src = reinterpret_cast<const float4 *>(tab + size_t(ch) * max_sec * TAB);
+            #pragma unroll
+            for (int k = 0; k < LPT; ++k)
+            {
+                const int o = (base + 4 * (k * 64 + t)) * 4;
+                if (ALIGNED)
+                {
+                    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(irsrc, o, 0, 0);
+                    ld[k] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+                }
+                else
+                    ld[k] = make_float4(__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irsrc, o, 0, 0)),
+                                        __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irsrc, o + 4, 0, 0)),
+                                        __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irsrc, o + 8, 0, 0)),
+                                        __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irsrc, o + 12, 0, 0)));
+            }
+        };
+        auto stage_tables = [&](int s0, int group, int par) // tables + carried state of a section group -> LDS
+        {
+            const float4 *src = reinterpret_cast<const float4 *>(tab + (size_t(ch) * max_sec + s0) * TAB);
             #pragma unroll
             for (int j = 0; j < TPT; ++j)
             {
-                const int i = t + j * NT;
-                tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                const int i = tid + j * NT;
+                if (i < group * TAB4)
+                    reinterpret_cast<float4 *>(stab)[i] = src[i];
             }
-            if (t < group)
-                spre = reinterpret_cast<const float2 *>(state + size_t(ch) * max_sec * 2)[t];
-        }
-
-        // ---- coalesced load, transposed through LDS -------------------------------------
-        float x[L];
-        #pragma unroll
-        for (int k = 0; k < L / 4; ++k)
+            if (tid < group)
+                sstate[par][tid] = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[tid];
+        };
+        auto flush_state = [&](int s0, int group, int par)
         {
-            const int i = 4 * (k * NT + t);
-            float4 v;
-            if (ALIGNED && (FULL || i + 4 <= cnt))
-                v = *reinterpret_cast<const float4 *>(xin + i);
+            if (tid < group)
+                reinterpret_cast<float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[tid] = sstate[par][tid];
+        };
+
+        v2f x[L];                                            // .x: first chunk of the lane, .y: second chunk
+
+        // Registers of one section's table.  The reads of section s+1 are issued right before the recurrence of
+        // section s (which only needs the five coefficients), into the registers section s no longer uses.
+        struct tabregs
+        {
+            float4 p[L / 4], q[L / 4];
+            float4 cf, P, Q1, Q2, Q4, Q8, Q16, Q64, QL;
+            float  a2;
+        };
+        auto load_tab = [&](tabregs &r, const float *T)
+        {
+            const float4 *T4 = reinterpret_cast<const float4 *>(T);
+            #pragma unroll
+            for (int j = 0; j < L / 4; ++j)                 // needed first, read first: LDS returns in order
+            {
+                r.p[j] = T4[PQ + j];
+                r.q[j] = T4[PQ + L / 4 + j];
+            }
+            r.P   = T4[2];
+            r.Q1  = T4[3 + 0];
+            r.Q2  = T4[3 + 1];
+            r.Q4  = T4[3 + 3];
+            r.Q8  = T4[3 + 7];
+            r.Q16 = T4[3 + 15];
+            r.Q64 = T4[19];
+            r.QL  = *reinterpret_cast<const float4 *>(T + 12 + 4 * l16);
+            r.cf  = T4[0];
+            r.a2  = T[4];
+            __builtin_amdgcn_sched_barrier(0);              // all reads in flight before anything else is scheduled
+        };
+
+        // One section over the lane's two chunks.  par: parity of the super-block.  `saver` marks the lane holding
+        // the last sample of the super-block (in its first chunk if !save_hi) -- it saves the state for what follows.
+        // `tb` holds this section's table on entry and the table at `Tnext` on exit.
+        auto section = [&](tabregs &tb, const float *Tnext, int si, int par, bool saver, bool save_hi)
+        {
+#ifdef MI_BIQUAD_PROBE
+            unsigned long long ts[8];
+#endif
+            MI_STAMP(0);
+            const float4 P = tb.P;
+
+            // 1. zero-state end states of both chunks
+            v2f z0 = splat(0.0f), z1 = splat(0.0f), w0 = splat(0.0f), w1 = splat(0.0f);
+            if (MI_ABLATE == 1) { z0 = x[0] * splat(tb.p[0].x); w0 = x[1] * splat(tb.q[0].x); }
+            #pragma unroll
+            for (int k = 0; k < ((MI_ABLATE == 1) ? 0 : L); k += 4)
+            {
+                const float4 p = tb.p[k / 4];
+                const float4 q = tb.q[k / 4];
+                z0 = pk_fma(splat(p.x), x[k + 0], z0); w0 = pk_fma(splat(q.x), x[k + 0], w0);
+                z1 = pk_fma(splat(p.y), x[k + 1], z1); w1 = pk_fma(splat(q.y), x[k + 1], w1);
+                z0 = pk_fma(splat(p.z), x[k + 2], z0); w0 = pk_fma(splat(q.z), x[k + 2], w0);
+                z1 = pk_fma(splat(p.w), x[k + 3], z1); w1 = pk_fma(splat(q.w), x[k + 3], w1);
+            }
+            const v2f z = z0 + z1, w = w0 + w1;
+            MI_STAMP(1);
+
+            // 2. end state of the pair for a zero start
+            float ex = fmaf(P.x, z.x, fmaf(P.y, w.x, z.y));
+            float ey = fmaf(P.z, z.x, fmaf(P.w, w.x, w.y));
+
+            // 2a. inclusive scan over the pairs inside rows of 16 lanes: E += (P^2)^d E(lane - d)
+            if (MI_ABLATE != 2 && MI_ABLATE != 4)
+            {
+                const float4 Q1 = tb.Q1, Q2 = tb.Q2, Q4 = tb.Q4, Q8 = tb.Q8;
+                float sx_, sy_;
+                sx_ = dpp_zero<0x111>(ex); sy_ = dpp_zero<0x111>(ey);
+                ex = fmaf(Q1.x, sx_, fmaf(Q1.y, sy_, ex)); ey = fmaf(Q1.z, sx_, fmaf(Q1.w, sy_, ey));
+                sx_ = dpp_zero<0x112>(ex); sy_ = dpp_zero<0x112>(ey);
+                ex = fmaf(Q2.x, sx_, fmaf(Q2.y, sy_, ex)); ey = fmaf(Q2.z, sx_, fmaf(Q2.w, sy_, ey));
+                sx_ = dpp_zero<0x114>(ex); sy_ = dpp_zero<0x114>(ey);
+                ex = fmaf(Q4.x, sx_, fmaf(Q4.y, sy_, ex)); ey = fmaf(Q4.z, sx_, fmaf(Q4.w, sy_, ey));
+                sx_ = dpp_zero<0x118>(ex); sy_ = dpp_zero<0x118>(ey);
+                ex = fmaf(Q8.x, sx_, fmaf(Q8.y, sy_, ex)); ey = fmaf(Q8.z, sx_, fmaf(Q8.w, sy_, ey));
+            }
+
+            v2f d0, d1;
+            if (MI_ABLATE == 4) { d0 = v2f{ex, z.x}; d1 = v2f{ey, w.x}; }
             else
             {
-                v.x = (i + 0 < cnt) ? xin[i + 0] : 0.0f;
-                v.y = (i + 1 < cnt) ? xin[i + 1] : 0.0f;
-                v.z = (i + 2 < cnt) ? xin[i + 2] : 0.0f;
-                v.w = (i + 3 < cnt) ? xin[i + 3] : 0.0f;
-            }
-            *reinterpret_cast<float4 *>(&sx[i + (i / L) * 4]) = v;
-        }
-        __syncthreads();
-        #pragma unroll
-        for (int k = 0; k < L / 4; ++k)
-        {
-            const float4 v = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * k]);
-            x[4 * k + 0] = v.x; x[4 * k + 1] = v.y; x[4 * k + 2] = v.z; x[4 * k + 3] = v.w;
-        }
+            MI_STAMP(2);
+            // 2b. row totals (wave-uniform from here to 2c)
+            const float4 Q16 = tb.Q16;
+            const float t0x = lane_value(ex, 15), t0y = lane_value(ey, 15);
+            const float t1x = lane_value(ex, 31), t1y = lane_value(ey, 31);
+            const float t2x = lane_value(ex, 47), t2y = lane_value(ey, 47);
 
-        // Lane that owns the last valid sample of the block, and how many it owns.
-        const int t_last = FULL ? (NT - 1) : ((cnt - 1) / L);
-        const int m_last = FULL ? L : (cnt - t_last * L);
-
-        // ---- sections, strictly in series (FilterBank.cpp:267-290) ----------------------
-        for (int s0 = 0; s0 < ns; s0 += SG)
-        {
-            const int group = (ns - s0 < SG) ? (ns - s0) : SG;
-            if (s0 > 0)
+            // state entering this wave's sub-block: carried state pushed through the sub-blocks of the waves before
+            float c0x, c0y;
+            if (NW > 1)
             {
-                __syncthreads();                        // everybody is done with the previous tables
-                const float4 *src = reinterpret_cast<const float4 *>(tab + (size_t(ch) * max_sec + s0) * TAB);
-                #pragma unroll
-                for (int j = 0; j < TPT; ++j)
-                {
-                    const int i = t + j * NT;
-                    tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                if (t < group)
-                    spre = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[t];
-            }
-            #pragma unroll
-            for (int j = 0; j < TPT; ++j)
-            {
-                const int i = t + j * NT;
-                if (i < TQ)
-                    reinterpret_cast<float4 *>(stab)[i] = tpre[j];
-            }
-            if (t < SG)
-                sstate[t] = spre;
-            __syncthreads();
-
-            for (int si = 0; si < group; ++si)
-            {
-                const int s     = s0 + si;
-                const float *T  = stab + si * TAB;
-                float *st       = state + (size_t(ch) * max_sec + s) * 2;
-                const float4 cf = *reinterpret_cast<const float4 *>(T);
-                const float b0 = cf.x, b1 = cf.y, b2 = cf.z, a1 = cf.w, a2 = T[4];
-                const float2 cs = sstate[si];           // state carried in from the previous call
-                const float c0 = cs.x, c1 = cs.y;
-
-                // 1. end state of the chunk for zero start state
-                float z0 = 0.0f, z1 = 0.0f, w0 = 0.0f, w1 = 0.0f;
-                #pragma unroll
-                for (int k = 0; k < L; k += 4)
-                {
-                    const float4 p = *reinterpret_cast<const float4 *>(T + 72 + k);
-                    const float4 q = *reinterpret_cast<const float4 *>(T + 72 + L + k);
-                    z0 = fmaf(p.x, x[k + 0], z0); w0 = fmaf(q.x, x[k + 0], w0);
-                    z1 = fmaf(p.y, x[k + 1], z1); w1 = fmaf(q.y, x[k + 1], w1);
-                    z0 = fmaf(p.z, x[k + 2], z0); w0 = fmaf(q.z, x[k + 2], w0);
-                    z1 = fmaf(p.w, x[k + 3], z1); w1 = fmaf(q.w, x[k + 3], w1);
-                }
-                float z = z0 + z1, w = w0 + w1;
-                const float4 P1  = *reinterpret_cast<const float4 *>(T + 8 + 4 * 0);
+                // zero-start end state of the whole sub-block, published for the waves after this one
+                const float t3x = lane_value(ex, 63), t3y = lane_value(ey, 63);
+                const float u2x = fmaf(Q16.x, t0x, fmaf(Q16.y, t0y, t1x)), u2y = fmaf(Q16.z, t0x, fmaf(Q16.w, t0y, t1y));
+                const float u3x = fmaf(Q16.x, u2x, fmaf(Q16.y, u2y, t2x)), u3y = fmaf(Q16.z, u2x, fmaf(Q16.w, u2y, t2y));
+                const float u4x = fmaf(Q16.x, u3x, fmaf(Q16.y, u3y, t3x)), u4y = fmaf(Q16.z, u3x, fmaf(Q16.w, u3y, t3y));
                 if (t == 0)
-                {
-                    z = fmaf(P1.x, c0, fmaf(P1.y, c1, z));
-                    w = fmaf(P1.z, c0, fmaf(P1.w, c1, w));
-                }
-
-                // 2a. inclusive scan inside rows of 16 lanes
-                {
-                    const float4 P2 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 1);
-                    const float4 P4 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 3);
-                    const float4 P8 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 7);
-                    float zs, ws;
-                    zs = dpp_zero<0x111>(z); ws = dpp_zero<0x111>(w);
-                    z = fmaf(P1.x, zs, fmaf(P1.y, ws, z)); w = fmaf(P1.z, zs, fmaf(P1.w, ws, w));
-                    zs = dpp_zero<0x112>(z); ws = dpp_zero<0x112>(w);
-                    z = fmaf(P2.x, zs, fmaf(P2.y, ws, z)); w = fmaf(P2.z, zs, fmaf(P2.w, ws, w));
-                    zs = dpp_zero<0x114>(z); ws = dpp_zero<0x114>(w);
-                    z = fmaf(P4.x, zs, fmaf(P4.y, ws, z)); w = fmaf(P4.z, zs, fmaf(P4.w, ws, w));
-                    zs = dpp_zero<0x118>(z); ws = dpp_zero<0x118>(w);
-                    z = fmaf(P8.x, zs, fmaf(P8.y, ws, z)); w = fmaf(P8.z, zs, fmaf(P8.w, ws, w));
-                }
-
-                // 2b. chain the row totals (uniform per wave), waves one after another
-                const float4 P16 = *reinterpret_cast<const float4 *>(T + 8 + 4 * 15);
-                const float t0x = lane_value(z, 15), t0y = lane_value(w, 15);
-                const float t1x = lane_value(z, 31), t1y = lane_value(w, 31);
-                const float t2x = lane_value(z, 47), t2y = lane_value(w, 47);
-                const float t3x = lane_value(z, 63), t3y = lane_value(w, 63);
-                float cinx = 0.0f, ciny = 0.0f;         // state entering this wave (carry is already in lane 0)
-                float c1x, c1y, c2x, c2y, c3x, c3y;
-                #pragma unroll
-                for (int wv = 0; wv < NW; ++wv)
-                {
-                    if (wave == wv)
-                    {
-                        c1x = fmaf(P16.x, cinx, fmaf(P16.y, ciny, t0x)); c1y = fmaf(P16.z, cinx, fmaf(P16.w, ciny, t0y));
-                        c2x = fmaf(P16.x, c1x, fmaf(P16.y, c1y, t1x));   c2y = fmaf(P16.z, c1x, fmaf(P16.w, c1y, t1y));
-                        c3x = fmaf(P16.x, c2x, fmaf(P16.y, c2y, t2x));   c3y = fmaf(P16.z, c2x, fmaf(P16.w, c2y, t2y));
-                        if (wv + 1 < NW && lane == 0)
-                        {
-                            const float ex = fmaf(P16.x, c3x, fmaf(P16.y, c3y, t3x));
-                            const float ey = fmaf(P16.z, c3x, fmaf(P16.w, c3y, t3y));
-                            stot[s & 1][wv] = make_float2(ex, ey);
-                        }
-                    }
-                    if (wv + 1 < NW)
-                    {
-                        __syncthreads();
-                        if (wave == wv + 1)
-                        {
-                            const float2 e = stot[s & 1][wv];
-                            cinx = e.x;
-                            ciny = e.y;
-                        }
-                    }
-                }
-
-                // 2c. state entering the lane's row, pushed through the lane's own power of P
-                const float crx = (row == 0) ? cinx : (row == 1) ? c1x : (row == 2) ? c2x : c3x;
-                const float cry = (row == 0) ? ciny : (row == 1) ? c1y : (row == 2) ? c2y : c3y;
-                const float4 PL = *reinterpret_cast<const float4 *>(T + 8 + 4 * l16);
-                z = fmaf(PL.x, crx, fmaf(PL.y, cry, z));
-                w = fmaf(PL.z, crx, fmaf(PL.w, cry, w));
-
-                // start state of the chunk = end state of the previous chunk
-                float d0 = dpp_zero<0x111>(z);
-                float d1 = dpp_zero<0x111>(w);
-                if (l16 == 0)
-                {
-                    d0 = crx;
-                    d1 = cry;
-                }
-                if (t == 0)
-                {
-                    d0 = c0;
-                    d1 = c1;
-                }
-
-                // 3. exact recurrence over the chunk
-                float f0 = d0, f1 = d1;
-                #pragma unroll
-                for (int k = 0; k < L; ++k)
-                {
-                    const float xx = x[k];
-                    const float y  = fmaf(b0, xx, d0);
-                    const float tt = fmaf(b1, xx, d1);
-                    d0   = fmaf(a1, y, tt);
-                    d1   = fmaf(a2, y, b2 * xx);
-                    x[k] = y;
-                    if (!FULL && (k + 1 == m_last))
-                    {
-                        f0 = d0;
-                        f1 = d1;
-                    }
-                }
-                if (FULL)
-                {
-                    f0 = d0;
-                    f1 = d1;
-                }
-                if (t == t_last)
-                {
-                    st[0] = f0;
-                    st[1] = f1;
-                }
-            }
-        }
-
-        // ---- transposed back through LDS, coalesced store -------------------------------
-        __syncthreads();
-        #pragma unroll
-        for (int k = 0; k < L / 4; ++k)
-            *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
-                make_float4(x[4 * k + 0], x[4 * k + 1], x[4 * k + 2], x[4 * k + 3]);
-        __syncthreads();
-        #pragma unroll
-        for (int k = 0; k < L / 4; ++k)
-        {
-            const int i = 4 * (k * NT + t);
-            const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / L) * 4]);
-            if (ALIGNED && (FULL || i + 4 <= cnt))
-                *reinterpret_cast<float4 *>(yout + i) = v;
-            else
-            {
-                if (i + 0 < cnt) yout[i + 0] = v.x;
-                if (i + 1 < cnt) yout[i + 1] = v.y;
-                if (i + 2 < cnt) yout[i + 2] = v.z;
-                if (i + 3 < cnt) yout[i + 3] = v.w;
-            }
-        }
-    }
-
-    // ------------------------------------------------------------------------------------------
-    // Packed variant for long blocks: ONE wave per channel, every lane owns TWO chunks (chunk t of
-    // the first half of the block and chunk t of the second half) and runs them as the two halves
-    // of v_pk_fma_f32 operands.  A lone wave issues one VALU instruction per 4 cycles, which is
-    // half the SIMD's rate for plain v_fma_f32 but the full rate for packed fp32, so this shape
-    // gets full VALU throughput at one wave per SIMD, needs no workgroup barrier inside the
-    // section loop, and leaves the whole 512-register file to the wave.
-    // ------------------------------------------------------------------------------------------
-    typedef float v2f __attribute__((ext_vector_type(2)));
-
-    __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
-    __device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
-
-    template <int CTRL>
-    __device__ __forceinline__ v2f dpp_zero2(v2f v)
-    {
-        return v2f{dpp_zero<CTRL>(v.x), dpp_zero<CTRL>(v.y)};
-    }
-
-    template <int L, bool ALIGNED, bool FULL>
-    __global__ __launch_bounds__(64, 1)
-    void biquad_bank_kernel_pk(float *out, const float *in, size_t out_stride, size_t in_stride,
-                               int cnt, const float *__restrict__ tab, float *state,
-                               const uint32_t *__restrict__ nsec, int max_sec)
-    {
-        constexpr int NT    = 64;
-        constexpr int NC    = 128;                          // chunks per block
-        constexpr int TAB   = 72 + 2 * L;
-        constexpr int PITCH = L + 4;
-        constexpr int SG    = 8;
-        constexpr int TQ    = SG * TAB / 4;
-        constexpr int TPT   = (TQ + NT - 1) / NT;
-
-        __shared__ __attribute__((aligned(16))) float sx[NC * PITCH];
-        __shared__ __attribute__((aligned(16))) float stab[SG * TAB];
-        __shared__ float2 sstate[SG];
-
-        const int ch    = blockIdx.x;
-        const int t     = threadIdx.x;
-        const int l16   = t & 15;
-        const int row   = t >> 4;
-        const int ns    = int(nsec[ch]);
-        const float *xin = in + size_t(ch) * in_stride;
-        float *yout      = out + size_t(ch) * out_stride;
-
-        float4 tpre[TPT];
-        float2 spre = make_float2(0.0f, 0.0f);
-        {
-            const int group = (ns < SG) ? ns : SG;
-            const float4 *src = reinterpret_cast<const float4 *>(tab + size_t(ch) * max_sec * TAB);
-            #pragma unroll
-            for (int j = 0; j < TPT; ++j)
-            {
-                const int i = t + j * NT;
-                tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
-            if (t < group)
-                spre = reinterpret_cast<const float2 *>(state + size_t(ch) * max_sec * 2)[t];
-        }
-
-        // ---- coalesced load, transposed through LDS -------------------------------------
-        #pragma unroll
-        for (int k = 0; k < NC * L / 4 / NT; ++k)
-        {
-            const int i = 4 * (k * NT + t);
-            float4 v;
-            if (ALIGNED && (FULL || i + 4 <= cnt))
-                v = *reinterpret_cast<const float4 *>(xin + i);
-            else
-            {
-                v.x = (i + 0 < cnt) ? xin[i + 0] : 0.0f;
-                v.y = (i + 1 < cnt) ? xin[i + 1] : 0.0f;
-                v.z = (i + 2 < cnt) ? xin[i + 2] : 0.0f;
-                v.w = (i + 3 < cnt) ? xin[i + 3] : 0.0f;
-            }
-            *reinterpret_cast<float4 *>(&sx[i + (i / L) * 4]) = v;
-        }
-        __syncthreads();
-        v2f x[L];                                            // .x: chunk t, .y: chunk t + 64
-        #pragma unroll
-        for (int k = 0; k < L / 4; ++k)
-        {
-            const float4 a = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * k]);
-            const float4 b = *reinterpret_cast<const float4 *>(&sx[(t + 64) * PITCH + 4 * k]);
-            x[4 * k + 0] = v2f{a.x, b.x}; x[4 * k + 1] = v2f{a.y, b.y};
-            x[4 * k + 2] = v2f{a.z, b.z}; x[4 * k + 3] = v2f{a.w, b.w};
-        }
-
-        // chunk (0..127) that owns the last valid sample, and how many samples it owns
-        const int c_last = FULL ? (NC - 1) : ((cnt - 1) / L);
-        const int m_last = FULL ? L : (cnt - c_last * L);
-
-        for (int s0 = 0; s0 < ns; s0 += SG)
-        {
-            const int group = (ns - s0 < SG) ? (ns - s0) : SG;
-            if (s0 > 0)
-            {
+                    xchg[par][si][wv] = make_float2(u4x, u4y);
+                MI_STAMP(3);
                 __syncthreads();
-                const float4 *src = reinterpret_cast<const float4 *>(tab + (size_t(ch) * max_sec + s0) * TAB);
+                MI_STAMP(4);
+                const float2 cs = sstate[par][si];
+                const float4 Q64 = tb.Q64;
+                c0x = cs.x; c0y = cs.y;
                 #pragma unroll
-                for (int j = 0; j < TPT; ++j)
-                {
-                    const int i = t + j * NT;
-                    tpre[j] = (i < group * (TAB / 4)) ? src[i] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-                }
-                if (t < group)
-                    spre = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[t];
-            }
-            #pragma unroll
-            for (int j = 0; j < TPT; ++j)
-            {
-                const int i = t + j * NT;
-                if (i < TQ)
-                    reinterpret_cast<float4 *>(stab)[i] = tpre[j];
-            }
-            if (t < SG)
-                sstate[t] = spre;
-            __syncthreads();
-
-            // Section tables are read from LDS as broadcasts (all lanes, same address).
-            constexpr int TAB4 = TAB / 4;
-            float4 ta[TAB4];
-            float4 pla;
-            float2 csa;
-            auto prefetch = [&](float4 (&tt)[TAB4], float4 &pl, float2 &cs, int si)
-            {
-                const float *T = stab + si * TAB;
-                #pragma unroll
-                for (int j = 0; j < TAB4; ++j)
-                    tt[j] = reinterpret_cast<const float4 *>(T)[j];
-                pl = *reinterpret_cast<const float4 *>(T + 8 + 4 * l16);
-                cs = sstate[si];
-            };
-            auto body = [&](const float4 (&tt)[TAB4], const float4 &PL, const float2 &cs, int s)
-            {
-                float *st       = state + (size_t(ch) * max_sec + s) * 2;
-                const float4 cf = tt[0];
-                const v2f b0 = splat(cf.x), b1 = splat(cf.y), b2 = splat(cf.z), a1 = splat(cf.w), a2 = splat(tt[1].x);
-                const float c0 = cs.x, c1 = cs.y;
-
-                // 1. end state of both chunks for zero start state
-                v2f z0 = splat(0.0f), z1 = splat(0.0f), w0 = splat(0.0f), w1 = splat(0.0f);
-                #pragma unroll
-                for (int k = 0; k < L; k += 4)
-                {
-                    const float4 p = tt[18 + k / 4];
-                    const float4 q = tt[18 + L / 4 + k / 4];
-                    z0 = pk_fma(splat(p.x), x[k + 0], z0); w0 = pk_fma(splat(q.x), x[k + 0], w0);
-                    z1 = pk_fma(splat(p.y), x[k + 1], z1); w1 = pk_fma(splat(q.y), x[k + 1], w1);
-                    z0 = pk_fma(splat(p.z), x[k + 2], z0); w0 = pk_fma(splat(q.z), x[k + 2], w0);
-                    z1 = pk_fma(splat(p.w), x[k + 3], z1); w1 = pk_fma(splat(q.w), x[k + 3], w1);
-                }
-                v2f z = z0 + z1, w = w0 + w1;
-                const float4 P1 = tt[2 + 0];
-                if (t == 0)
-                {
-                    z.x = fmaf(P1.x, c0, fmaf(P1.y, c1, z.x));
-                    w.x = fmaf(P1.z, c0, fmaf(P1.w, c1, w.x));
-                }
-
-                // 2a. inclusive scan inside rows of 16 lanes (both halves at once)
-                {
-                    const float4 P2 = tt[2 + 1];
-                    const float4 P4 = tt[2 + 3];
-                    const float4 P8 = tt[2 + 7];
-                    v2f zs, ws;
-                    zs = dpp_zero2<0x111>(z); ws = dpp_zero2<0x111>(w);
-                    z = pk_fma(splat(P1.x), zs, pk_fma(splat(P1.y), ws, z)); w = pk_fma(splat(P1.z), zs, pk_fma(splat(P1.w), ws, w));
-                    zs = dpp_zero2<0x112>(z); ws = dpp_zero2<0x112>(w);
-                    z = pk_fma(splat(P2.x), zs, pk_fma(splat(P2.y), ws, z)); w = pk_fma(splat(P2.z), zs, pk_fma(splat(P2.w), ws, w));
-                    zs = dpp_zero2<0x114>(z); ws = dpp_zero2<0x114>(w);
-                    z = pk_fma(splat(P4.x), zs, pk_fma(splat(P4.y), ws, z)); w = pk_fma(splat(P4.z), zs, pk_fma(splat(P4.w), ws, w));
-                    zs = dpp_zero2<0x118>(z); ws = dpp_zero2<0x118>(w);
-                    z = pk_fma(splat(P8.x), zs, pk_fma(splat(P8.y), ws, z)); w = pk_fma(splat(P8.z), zs, pk_fma(splat(P8.w), ws, w));
-                }
-
-                // 2b. chain the eight row totals: rows 0..3 = first half, 4..7 = second half
-                const float4 P16 = tt[2 + 15];
-                float cx[8], cy[8];
-                cx[0] = 0.0f; cy[0] = 0.0f;                 // the carry is already inside lane 0
-                #pragma unroll
-                for (int r = 0; r < 7; ++r)
-                {
-                    const int ln = 16 * (r & 3) + 15;
-                    const float tx = (r < 4) ? lane_value(z.x, ln) : lane_value(z.y, ln);
-                    const float ty = (r < 4) ? lane_value(w.x, ln) : lane_value(w.y, ln);
-                    cx[r + 1] = fmaf(P16.x, cx[r], fmaf(P16.y, cy[r], tx));
-                    cy[r + 1] = fmaf(P16.z, cx[r], fmaf(P16.w, cy[r], ty));
-                }
-
-                // 2c. state entering the lane's rows, pushed through the lane's own power of P
-                // (selects written as a flat chain so they stay v_cndmask, not branches)
-                const bool r1 = (row == 1), r2 = (row == 2), r3 = (row == 3);
-                v2f crx = v2f{cx[0], cx[4]}, cry = v2f{cy[0], cy[4]};
-                crx.x = r1 ? cx[1] : crx.x; cry.x = r1 ? cy[1] : cry.x; crx.y = r1 ? cx[5] : crx.y; cry.y = r1 ? cy[5] : cry.y;
-                crx.x = r2 ? cx[2] : crx.x; cry.x = r2 ? cy[2] : cry.x; crx.y = r2 ? cx[6] : crx.y; cry.y = r2 ? cy[6] : cry.y;
-                crx.x = r3 ? cx[3] : crx.x; cry.x = r3 ? cy[3] : cry.x; crx.y = r3 ? cx[7] : crx.y; cry.y = r3 ? cy[7] : cry.y;
-                z = pk_fma(splat(PL.x), crx, pk_fma(splat(PL.y), cry, z));
-                w = pk_fma(splat(PL.z), crx, pk_fma(splat(PL.w), cry, w));
-
-                // start state of each chunk = end state of the chunk before it
-                v2f d0 = dpp_zero2<0x111>(z);
-                v2f d1 = dpp_zero2<0x111>(w);
-                if (l16 == 0)
-                {
-                    d0 = crx;
-                    d1 = cry;
-                }
-                if (t == 0)
-                {
-                    d0.x = c0;
-                    d1.x = c1;
-                }
-
-                // 3. exact recurrence over both chunks
-                v2f f0 = d0, f1 = d1;
-                #pragma unroll
-                for (int k = 0; k < L; ++k)
-                {
-                    const v2f xx = x[k];
-                    const v2f y  = pk_fma(b0, xx, d0);
-                    const v2f tt2 = pk_fma(b1, xx, d1);
-                    d0   = pk_fma(a1, y, tt2);
-                    d1   = pk_fma(a2, y, b2 * xx);
-                    x[k] = y;
-                    if (!FULL && (k + 1 == m_last))
+                for (int v = 0; v < NW - 1; ++v)
+                    if (v < wv)
                     {
-                        f0 = d0;
-                        f1 = d1;
+                        const float2 tv = xchg[par][si][v];
+                        const float nx = fmaf(Q64.x, c0x, fmaf(Q64.y, c0y, tv.x));
+                        const float ny = fmaf(Q64.z, c0x, fmaf(Q64.w, c0y, tv.y));
+                        c0x = nx; c0y = ny;
                     }
-                }
-                if (FULL)
-                {
-                    f0 = d0;
-                    f1 = d1;
-                }
-                if (t == (c_last & 63))
-                {
-                    st[0] = (c_last < 64) ? f0.x : f0.y;
-                    st[1] = (c_last < 64) ? f1.x : f1.y;
-                }
-            };
-
-            for (int si = 0; si < group; ++si)
-            {
-                prefetch(ta, pla, csa, si);
-                body(ta, pla, csa, s0 + si);
             }
-        }
-
-        // ---- transposed back through LDS, coalesced store -------------------------------
-        __syncthreads();
-        #pragma unroll
-        for (int k = 0; k < L / 4; ++k)
-        {
-            *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
-                make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
-            *reinterpret_cast<float4 *>(&sx[(t + 64) * PITCH + 4 * k]) =
-                make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
-        }
-        __syncthreads();
-        #pragma unroll
-        for (int k = 0; k < NC * L / 4 / NT; ++k)
-        {
-            const int i = 4 * (k * NT + t);
-            const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / L) * 4]);
-            if (ALIGNED && (FULL || i + 4 <= cnt))
-                *reinterpret_cast<float4 *>(yout + i) = v;
             else
             {
-                if (i + 0 < cnt) yout[i + 0] = v.x;
-                if (i + 1 < cnt) yout[i + 1] = v.y;
-                if (i + 2 < cnt) yout[i + 2] = v.z;
-                if (i + 3 < cnt) yout[i + 3] = v.w;
+                const float2 cs = sstate[par][si];
+                c0x = cs.x; c0y = cs.y;
             }
+            const float c1x = fmaf(Q16.x, c0x, fmaf(Q16.y, c0y, t0x)), c1y = fmaf(Q16.z, c0x, fmaf(Q16.w, c0y, t0y));
+            const float c2x = fmaf(Q16.x, c1x, fmaf(Q16.y, c1y, t1x)), c2y = fmaf(Q16.z, c1x, fmaf(Q16.w, c1y, t1y));
+            const float c3x = fmaf(Q16.x, c2x, fmaf(Q16.y, c2y, t2x)), c3y = fmaf(Q16.z, c2x, fmaf(Q16.w, c2y, t2y));
+
+            MI_STAMP(5);
+            // 2c. state entering the lane's row, pushed through the lane's own power of P^2
+            const float4 QL = tb.QL;
+            float crx = c0x, cry = c0y;
+            crx = r1 ? c1x : crx; cry = r1 ? c1y : cry;
+            crx = r2 ? c2x : crx; cry = r2 ? c2y : cry;
+            crx = r3 ? c3x : crx; cry = r3 ? c3y : cry;
+            ex = fmaf(QL.x, crx, fmaf(QL.y, cry, ex));
+            ey = fmaf(QL.z, crx, fmaf(QL.w, cry, ey));
+
+            // 3. start states: first chunk = end of the previous pair, second chunk = P S + zA
+            float sx0 = dpp_zero<0x111>(ex), sy0 = dpp_zero<0x111>(ey);
+            if (l16 == 0) { sx0 = crx; sy0 = cry; }
+            d0.x = sx0;
+            d1.x = sy0;
+            d0.y = fmaf(P.x, sx0, fmaf(P.y, sy0, z.x));
+            d1.y = fmaf(P.z, sx0, fmaf(P.w, sy0, w.x));
+
+            }
+            // exact recurrence over both chunks; the next section's table streams in underneath it
+            MI_STAMP(6);
+            const v2f b0 = splat(tb.cf.x), b1 = splat(tb.cf.y), b2 = splat(tb.cf.z), a1 = splat(tb.cf.w), a2 = splat(tb.a2);
+            if (MI_ABLATE != 5)
+                load_tab(tb, Tnext);
+            #pragma unroll
+            for (int k = 0; k < ((MI_ABLATE == 3) ? 1 : L); ++k)
+            {
+                const v2f xx = x[k];
+                const v2f tq = pk_fma(b1, xx, d1);
+                const v2f u  = b2 * xx;
+                const v2f y  = pk_fma(b0, xx, d0);
+                d0   = pk_fma(a1, y, tq);
+                d1   = pk_fma(a2, y, u);
+                x[k] = y;
+            }
+            MI_STAMP(7);
+            MI_STAMP_DUMP();
+            if (saver)                                       // n is a multiple of L: the call ends with a chunk
+                sstate[par ^ 1][si] = save_hi ? make_float2(d0.y, d1.y) : make_float2(d0.x, d1.x);
+        };
+
+        // ---- super-blocks of NW sub-blocks --------------------------------------------------------
+        constexpr int SUPER = NW * SB;
+        const int nsup = (n + SUPER - 1) / SUPER;
+        const int off  = wv * SB;                            // this wave's sub-block inside the super-block
+        if (ns > 0)                                         // tables first: they must not queue behind the samples
+            stage_tables(0, (ns < SG) ? ns : SG, 0);
+        issue_loads(off);
+
+        for (int sp = 0; sp < nsup; ++sp)
+        {
+            const int par  = sp & 1;
+            const int base = sp * SUPER + off;
+            const int left = n - sp * SUPER;                 // samples of the call from this super-block on
+
+            // registers -> own LDS tile (transposed), then immediately start the loads of the next super-block.
+            // The tile is private to the wave and a wave's LDS accesses complete in program order: no barrier.
+            #pragma unroll
+            for (int k = 0; k < LPT; ++k)
+            {
+                const int i = 4 * (k * 64 + t);
+                *reinterpret_cast<float4 *>(&sx[i + (i / W) * 4]) = ld[k];
+            }
+            __builtin_amdgcn_wave_barrier();
+            MI_PROBE(1 + 4 * sp);
+            if (sp + 1 < nsup)
+                issue_loads(base + SUPER);
+            #pragma unroll
+            for (int k = 0; k < L / 4; ++k)
+            {
+                const float4 a = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * k]);
+                const float4 b = *reinterpret_cast<const float4 *>(&sx[t * PITCH + L + 4 * k]);
+                x[4 * k + 0] = v2f{a.x, b.x}; x[4 * k + 1] = v2f{a.y, b.y};
+                x[4 * k + 2] = v2f{a.z, b.z}; x[4 * k + 3] = v2f{a.w, b.w};
+            }
+
+            // the lane that owns the last sample of the super-block
+            const int last   = ((left < SUPER) ? left : SUPER) - 1;
+            const int w_last = last / SB;
+            const int t_last = (last - w_last * SB) / W;
+            const bool save_hi = (last - w_last * SB - t_last * W) >= L;
+            const bool saver   = (wv == w_last) && (t == t_last);
+            for (int s0 = 0; s0 < ns; s0 += SG)
+            {
+                const int group = (ns - s0 < SG) ? (ns - s0) : SG;
+                if (ns > SG)                                 // more sections than fit the staging area: restage
+                {
+                    __syncthreads();
+                    stage_tables(s0, group, par);
+                }
+                if (ns > SG || sp == 0)
+                    __syncthreads();
+                tabregs tb;
+                load_tab(tb, stab);
+                for (int si = 0; si < group; ++si)
+                    section(tb, stab + ((si + 1 < SG) ? si + 1 : 0) * TAB, si, par, saver, save_hi);
+                if (ns > SG)
+                {
+                    __syncthreads();
+                    flush_state(s0, group, par ^ 1);
+                }
+            }
+            MI_PROBE(2 + 4 * sp);
+
+            // transposed back through the wave's tile, coalesced write-through store
+            #pragma unroll
+            for (int k = 0; k < L / 4; ++k)
+            {
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
+                    make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * k]) =
+                    make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int k = 0; k < LPT; ++k)
+            {
+                const int i = 4 * (k * 64 + t);
+                const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / W) * 4]);
+                if (ALIGNED)
+                    store_through(orsrc, base + i, v);
+                else
+                {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), orsrc, (base + i) * 4, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), orsrc, (base + i) * 4 + 4, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), orsrc, (base + i) * 4 + 8, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), orsrc, (base + i) * 4 + 12, 0, CPOL_SC1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            MI_PROBE(3 + 4 * sp);
         }
+        if (ns > 0 && ns <= SG)
+        {
+            __syncthreads();
+            flush_state(0, ns, nsup & 1);
+        }
+        MI_PROBE(15);
+    }
+
+    // The last samples % L samples of a call: one thread per channel walks them through the cascade with the same
+    // recurrence (FilterBank.cpp:256-291 semantics for block sizes that are not a multiple of the chunk length).
+    __global__ void biquad_tail_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
+                                       size_t start, int count /* < 16 */, const float *__restrict__ tab, int tab_row,
+                                       float *state, const uint32_t *__restrict__ nsec, int max_sec, uint32_t channels)
+    {
+        const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
+        if (ch >= channels)
+            return;
+        float xs[16];
+        for (int k = 0; k < 16; ++k)
+            xs[k] = (k < count) ? in[size_t(ch) * in_stride + start + k] : 0.0f;
+        const int ns = int(nsec[ch]);
+        for (int s = 0; s < ns; ++s)
+        {
+            const float *q = tab + (size_t(ch) * max_sec + s) * tab_row;
+            float *st = state + (size_t(ch) * max_sec + s) * 2;
+            const float b0 = q[0], b1 = q[1], b2 = q[2], a1 = q[3], a2 = q[4];
+            float d0 = st[0], d1 = st[1];
+            for (int k = 0; k < count; ++k)
+            {
+                const float xx = xs[k];
+                const float tq = fmaf(b1, xx, d1);
+                const float u  = b2 * xx;
+                const float y  = fmaf(b0, xx, d0);
+                d0 = fmaf(a1, y, tq);
+                d1 = fmaf(a2, y, u);
+                xs[k] = y;
+            }
+            st[0] = d0;
+            st[1] = d1;
+        }
+        for (int k = 0; k < count; ++k)
+            out[size_t(ch) * out_stride + start + k] = xs[k];
     }
 
     __global__ void impulse_kernel(float *out, size_t stride, size_t samples, uint32_t channels)
@@ -627,7 +513,7 @@ namespace
                  x.c * y.a + x.d * y.c, x.c * y.b + x.d * y.d };
     }
 
-    template <int L, int NT>
+    template <int L>
     void fill_row(float *row, const float *q /* b0 b1 b2 a1 a2 */)
     {
         const double b0 = q[0], b1 = q[1], b2 = q[2], a1 = q[3], a2 = q[4];
@@ -636,7 +522,7 @@ namespace
         // s' = A s + B x  with  A = [a1 1; a2 0],  B = [b1 + a1 b0, b2 + a2 b0]
         const mat2 A = { a1, 1.0, a2, 0.0 };
         double v0 = b1 + a1 * b0, v1 = b2 + a2 * b0;
-        float *p = row + 72, *qq = p + L;
+        float *p = row + 80, *qq = p + L;
         for (int k = L - 1; k >= 0; --k)        // p[k],q[k] = A^(L-1-k) B
         {
             p[k]  = float(v0);
@@ -648,17 +534,22 @@ namespace
         mat2 P = { 1.0, 0.0, 0.0, 1.0 };
         for (int k = 0; k < L; ++k)
             P = mul(P, A);
-        mat2 Pi = P;                             // P^(i+1)
+        row[8] = float(P.a); row[9] = float(P.b); row[10] = float(P.c); row[11] = float(P.d);
+        const mat2 P2 = mul(P, P);
+        mat2 Qi = P2;                            // (P^2)^(i+1)
         for (int i = 0; i < 16; ++i)
         {
-            float *m = row + 8 + 4 * i;
-            m[0] = float(Pi.a); m[1] = float(Pi.b); m[2] = float(Pi.c); m[3] = float(Pi.d);
-            Pi = mul(Pi, P);
+            float *m = row + 12 + 4 * i;
+            m[0] = float(Qi.a); m[1] = float(Qi.b); m[2] = float(Qi.c); m[3] = float(Qi.d);
+            if (i < 15)
+                Qi = mul(Qi, P2);
         }
+        const mat2 Q32 = mul(Qi, Qi), Q64 = mul(Q32, Q32);      // Qi = (P^2)^16
+        row[76] = float(Q64.a); row[77] = float(Q64.b); row[78] = float(Q64.c); row[79] = float(Q64.d);
     }
 
-    using big   = geom<32, 128>;    // blocks of up to 4096 samples per launch
-    using small = geom<8, 64>;      // blocks of up to 512 samples per launch
+    using big   = geom<16>;     // sub-blocks of 2048 samples: calls longer than 1024 samples
+    using small = geom<8>;      // sub-blocks of 1024 samples: short calls
 } // namespace
 
 struct mi_biquad_bank
@@ -681,37 +572,19 @@ struct mi_biquad_bank
 
 namespace
 {
-    template <int L, int NT>
+    template <int L, int NW>
     hipError_t launch(mi_biquad_bank *b, float *out, const float *in, size_t out_stride,
-                      size_t in_stride, int cnt, bool aligned, const float *tab, hipStream_t st)
+                      size_t in_stride, int n, bool aligned, const float *tab, hipStream_t st)
     {
-        const dim3 grid(b->channels), block(NT);
-        const bool full = (cnt == L * NT);
+        const dim3 grid(b->channels), block(64 * NW);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
-        #define MI_LAUNCH(A, F)                                                                   \
-            hipExtLaunchKernelGGL((biquad_bank_kernel<L, NT, A, F>), grid, block, 0, st, ev0, ev1, 0, out, in, \
-                               out_stride, in_stride, cnt, tab, b->d_state, b->d_nsec, int(b->max_sec))
-        if (aligned) { if (full) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
-        else         { if (full) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
-        #undef MI_LAUNCH
-        return hipGetLastError();
-    }
-
-    template <int L>
-    hipError_t launch_pk(mi_biquad_bank *b, float *out, const float *in, size_t out_stride,
-                         size_t in_stride, int cnt, bool aligned, const float *tab, hipStream_t st)
-    {
-        const dim3 grid(b->channels), block(64);
-        const bool full = (cnt == L * 128);
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        mi::take_profile_events(&ev0, &ev1);
-        #define MI_LAUNCH(A, F)                                                                   \
-            hipExtLaunchKernelGGL((biquad_bank_kernel_pk<L, A, F>), grid, block, 0, st, ev0, ev1, 0, out, in, \
-                               out_stride, in_stride, cnt, tab, b->d_state, b->d_nsec, int(b->max_sec))
-        if (aligned) { if (full) MI_LAUNCH(true, true); else MI_LAUNCH(true, false); }
-        else         { if (full) MI_LAUNCH(false, true); else MI_LAUNCH(false, false); }
-        #undef MI_LAUNCH
+        if (aligned)
+            hipExtLaunchKernelGGL((biquad_bank_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, 0, out, in,
+                                  out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
+        else
+            hipExtLaunchKernelGGL((biquad_bank_kernel<L, NW, false>), grid, block, 0, st, ev0, ev1, 0, out, in,
+                                  out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
         return hipGetLastError();
     }
 
@@ -729,8 +602,8 @@ namespace
             for (uint32_t s = 0; s < b->nsec[c]; ++s)
             {
                 const float *q = &b->coef[(size_t(c) * b->max_sec + s) * 5];
-                fill_row<32, 128>(&b->h_big[c * row_big + size_t(s) * big::TAB], q);
-                fill_row<8, 64>(&b->h_small[c * row_small + size_t(s) * small::TAB], q);
+                fill_row<16>(&b->h_big[c * row_big + size_t(s) * big::TAB], q);
+                fill_row<8>(&b->h_small[c * row_small + size_t(s) * small::TAB], q);
             }
         }
         if (n_dirty > 0)
@@ -925,29 +798,37 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
 
     const bool aligned = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 16 == 0) &&
                          (out_stride % 4 == 0) && (in_stride % 4 == 0);
+    // One launch walks the whole call.  The variant sets the chunk length and how many waves share a channel:
+    // a wave owns a sub-block of 64 x 2L samples, NW waves cover NW consecutive sub-blocks at once.
+    //   <= 1024 samples: L = 8, one wave;  <= 2048: L = 8, two waves;  longer: L = 16, two waves.
+    static const int force_nw = getenv("MI_BIQUAD_WAVES") ? atoi(getenv("MI_BIQUAD_WAVES")) : 0;    // profiling knob
+    const bool use_small = samples <= 2 * size_t(small::BLOCK);
+    const size_t chunk = use_small ? 8 : 16;
+    const size_t tail  = samples % chunk;                   // < chunk samples, done by biquad_tail_kernel
+    const size_t body  = samples - tail;
     size_t done = 0;
-    while (done < samples)
+    while (done < body)
     {
-        const size_t left = samples - done;
+        const size_t left = body - done;
+        const size_t step = (left < (size_t(1) << 28)) ? left : (size_t(1) << 28);      // multiple of 16
         hipError_t e;
-        size_t step;
-        if (left > size_t(small::BLOCK))
-        {
-            step = (left < size_t(big::BLOCK)) ? left : size_t(big::BLOCK);
-            static const bool two_wave = (getenv("MI_BIQUAD_TWO_WAVE") != nullptr);   // A/B knob for profiling
-            e = two_wave ? launch<32, 128>(b, out + done, in + done, out_stride, in_stride, int(step),
-                                           aligned && (done % 4 == 0), b->d_big, st)
-                         : launch_pk<32>(b, out + done, in + done, out_stride, in_stride, int(step),
-                                         aligned && (done % 4 == 0), b->d_big, st);
-        }
+        if (samples <= size_t(small::BLOCK))
+            e = launch<8, 1>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+        else if (use_small)
+            e = launch<8, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+        else if (force_nw == 1)
+            e = launch<16, 1>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
         else
-        {
-            step = left;
-            e = launch<8, 64>(b, out + done, in + done, out_stride, in_stride, int(step),
-                              aligned && (done % 4 == 0), b->d_small, st);
-        }
+            e = launch<16, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
         MI_HIP_CHECK(e);
         done += step;
+    }
+    if (tail > 0)
+    {
+        hipLaunchKernelGGL(biquad_tail_kernel, dim3((b->channels + 63) / 64), dim3(64), 0, st, out, in, out_stride,
+                           in_stride, body, int(tail), b->d_small, int(small::TAB), b->d_state, b->d_nsec,
+                           int(b->max_sec), b->channels);
+        MI_HIP_CHECK(hipGetLastError());
     }
     return MI_OK;
 }
@@ -981,15 +862,15 @@ int mi_biquad_section_tables(const mi_biquad_x1_t *chain, int variant, float *ta
     const float q[5] = { chain->b0, chain->b1, chain->b2, chain->a1, chain->a2 };
     if (variant == 0)
     {
-        geometry[0] = 32; geometry[1] = 128; geometry[2] = 16; geometry[3] = big::TAB;
+        geometry[0] = 16; geometry[1] = 64; geometry[2] = 16; geometry[3] = big::TAB;
         if (table != nullptr)
-            fill_row<32, 128>(table, q);
+            fill_row<16>(table, q);
     }
     else
     {
         geometry[0] = 8; geometry[1] = 64; geometry[2] = 16; geometry[3] = small::TAB;
         if (table != nullptr)
-            fill_row<8, 64>(table, q);
+            fill_row<8>(table, q);
     }
     return MI_OK;
 }

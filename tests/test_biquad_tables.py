@@ -1,8 +1,8 @@
 """Host logic of the biquad kernel, checked without a GPU.
 
 The kernel evaluates each TDF-II section chunk-parallel: zero-state end state of every
-chunk by two dot products, an inclusive scan over chunks with powers of P = A^L, then the exact
-recurrence from the scanned start state.  This test takes the REAL per-section tables the product
+chunk by two dot products, an inclusive scan over pairs of chunks with powers of P^2 (P = A^L), then the
+exact recurrence from the scanned start states.  This test takes the REAL per-section tables the product
 builds (mi_biquad_section_tables, host C++) and replays the kernel's three steps in numpy float32 with
 the same lane/chunk index math, against the sequential oracle."""
 import ctypes
@@ -29,10 +29,12 @@ def product_tables(mi, q, variant):
     row = np.zeros(TAB, np.float32)
     mi.check(mi.lib.mi_biquad_section_tables(ctypes.byref(chain), variant,
                                              row.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), geo))
-    M = row[8:8 + 4 * NM].reshape(NM, 2, 2)          # M[i] = P^(i+1)
-    p = row[8 + 4 * NM: 8 + 4 * NM + L]
-    qq = row[8 + 4 * NM + L: 8 + 4 * NM + 2 * L]
-    return L, NT, NM, row[:5], M, p, qq
+    P = row[8:12].reshape(2, 2)                      # A^L
+    Q = row[12:12 + 4 * NM].reshape(NM, 2, 2)        # Q[i] = (P^2)^(i+1)
+    Q64 = row[76:80].reshape(2, 2)                   # (P^2)^64
+    p = row[80: 80 + L]
+    qq = row[80 + L: 80 + 2 * L]
+    return L, NT, NM, row[:5], P, Q, Q64, p, qq
 
 
 def _mv(M, vx, vy, ax, ay):
@@ -41,89 +43,132 @@ def _mv(M, vx, vy, ax, ay):
             (M[1, 0] * vx + (M[1, 1] * vy + ay).astype(F)).astype(F))
 
 
-def emulate_block(mi, x, coef, state, variant):
-    """One kernel launch for one channel, lane for lane: x has at most L*NT samples."""
+def _mv1(M, v, a):
+    x, y = _mv(M, np.array([v[0]], F), np.array([v[1]], F), np.array([a[0]], F), np.array([a[1]], F))
+    return np.array([x[0], y[0]], F)
+
+
+def emulate_super_block(mi, x, coef, state, L, NW):
+    """One super-block of one channel, wave for wave and lane for lane: NW waves, each owning a sub-block of
+    64 * 2L samples; every lane owns two adjacent chunks A and B of L samples."""
     cnt = len(x)
-    L, NT = (32, 128) if variant == 0 else (8, 64)
-    assert cnt <= L * NT
-    X = np.zeros(L * NT, F)
+    W = 2 * L
+    SB = 64 * W
+    assert cnt <= NW * SB
+    X = np.zeros(NW * SB, F)
     X[:cnt] = x
-    X = X.reshape(NT, L).copy()
-    t = np.arange(NT)
-    l16, row, wave = t & 15, (t & 63) >> 4, t >> 6
-    t_last = (cnt - 1) // L
-    m_last = cnt - t_last * L
+    X = X.reshape(NW, 64, 2, L).copy()               # [wave][lane][chunk][k]
+    t = np.arange(64)
+    l16, row = t & 15, t >> 4
+    last = cnt - 1
+    w_last = last // SB
+    t_last = (last - w_last * SB) // W
+    m_last = last - w_last * SB - t_last * W + 1
+    variant = 0 if L == 16 else 1
     for s, q in enumerate(coef):
-        L_, NT_, NM, c5, M, p, qq = product_tables(mi, q, variant)
-        assert (L_, NT_, NM) == (L, NT, 16)
+        L_, NT_, NM, c5, P, Q, Q64, p, qq = product_tables(mi, q, variant)
+        assert (L_, NT_, NM) == (L, 64, 16)
         np.testing.assert_array_equal(c5, np.asarray(q, F))
         b0, b1, b2, a1, a2 = [F(v) for v in q]
-        c0, c1 = F(state[s][0]), F(state[s][1])
-        # 1. dot products (two accumulators each, as in the kernel)
-        z0 = np.zeros(NT, F); z1 = np.zeros(NT, F); w0 = np.zeros(NT, F); w1 = np.zeros(NT, F)
-        for k in range(0, L, 4):
-            z0 = (p[k] * X[:, k] + z0).astype(F); w0 = (qq[k] * X[:, k] + w0).astype(F)
-            z1 = (p[k + 1] * X[:, k + 1] + z1).astype(F); w1 = (qq[k + 1] * X[:, k + 1] + w1).astype(F)
-            z0 = (p[k + 2] * X[:, k + 2] + z0).astype(F); w0 = (qq[k + 2] * X[:, k + 2] + w0).astype(F)
-            z1 = (p[k + 3] * X[:, k + 3] + z1).astype(F); w1 = (qq[k + 3] * X[:, k + 3] + w1).astype(F)
-        z = (z0 + z1).astype(F); w = (w0 + w1).astype(F)
-        zc, wc = _mv(M[0], np.array([c0]), np.array([c1]), z[:1], w[:1])
-        z[0], w[0] = zc[0], wc[0]
-        # 2a. row scan with DPP row_shr d (lanes whose source falls out of the 16-lane row read 0)
-        for d, Mi in ((1, M[0]), (2, M[1]), (4, M[3]), (8, M[7])):
-            src = t - d
-            ok = l16 >= d
-            zs = np.where(ok, z[np.maximum(src, 0)], F(0)); ws = np.where(ok, w[np.maximum(src, 0)], F(0))
-            z, w = _mv(Mi, zs, ws, z, w)
-        # 2b. chain of row totals inside each wave, waves in order
-        NW = NT // 64
-        cr = np.zeros((NT, 2), F)
-        cin = np.zeros(2, F)
-        P16 = M[15]
+        Q16 = Q[15]
+        carried = np.array([state[s][0], state[s][1]], F)
+        pre = []
         for wv in range(NW):
-            base = 64 * wv
-            c = [cin.copy()]
-            for r in range(4):
-                tx, ty = z[base + 16 * r + 15], w[base + 16 * r + 15]
-                nx, ny = _mv(P16, np.array([c[-1][0]]), np.array([c[-1][1]]), np.array([tx]), np.array([ty]))
-                c.append(np.array([nx[0], ny[0]], F))
-            for r in range(4):
-                cr[base + 16 * r: base + 16 * r + 16] = c[r]
-            cin = c[4]
-        # 2c. lane power
-        ML = M[l16]                                   # (NT,2,2)
-        zn = (ML[:, 0, 0] * cr[:, 0] + (ML[:, 0, 1] * cr[:, 1] + z).astype(F)).astype(F)
-        wn = (ML[:, 1, 0] * cr[:, 0] + (ML[:, 1, 1] * cr[:, 1] + w).astype(F)).astype(F)
-        z, w = zn, wn
-        d0 = np.where(l16 == 0, cr[:, 0], z[np.maximum(t - 1, 0)]).astype(F)
-        d1 = np.where(l16 == 0, cr[:, 1], w[np.maximum(t - 1, 0)]).astype(F)
-        d0[0], d1[0] = c0, c1
-        f0 = d0.copy(); f1 = d1.copy()
-        for k in range(L):
-            xx = X[:, k]
-            y = (b0 * xx + d0).astype(F)
-            tt = (b1 * xx + d1).astype(F)
-            d0 = (a1 * y + tt).astype(F)
-            d1 = (a2 * y + (b2 * xx).astype(F)).astype(F)
-            X[:, k] = y
-            if k + 1 == m_last:
-                f0 = d0.copy(); f1 = d1.copy()
-        state[s][0] = f0[t_last]; state[s][1] = f1[t_last]
+            Xw = X[wv]
+            # 1. dot products (two accumulators each, both chunks at once as in the packed kernel)
+            z0 = np.zeros((64, 2), F); z1 = np.zeros((64, 2), F); w0 = np.zeros((64, 2), F); w1 = np.zeros((64, 2), F)
+            for k in range(0, L, 4):
+                z0 = (p[k] * Xw[:, :, k] + z0).astype(F); w0 = (qq[k] * Xw[:, :, k] + w0).astype(F)
+                z1 = (p[k + 1] * Xw[:, :, k + 1] + z1).astype(F); w1 = (qq[k + 1] * Xw[:, :, k + 1] + w1).astype(F)
+                z0 = (p[k + 2] * Xw[:, :, k + 2] + z0).astype(F); w0 = (qq[k + 2] * Xw[:, :, k + 2] + w0).astype(F)
+                z1 = (p[k + 3] * Xw[:, :, k + 3] + z1).astype(F); w1 = (qq[k + 3] * Xw[:, :, k + 3] + w1).astype(F)
+            z = (z0 + z1).astype(F); w = (w0 + w1).astype(F)
+            # 2. pair end state for a zero start
+            ex, ey = _mv(P, z[:, 0], w[:, 0], z[:, 1], w[:, 1])
+            # 2a. row scan with DPP row_shr d (lanes whose source falls out of the 16-lane row read 0)
+            for d, Qi in ((1, Q[0]), (2, Q[1]), (4, Q[3]), (8, Q[7])):
+                src = t - d
+                ok = l16 >= d
+                xs = np.where(ok, ex[np.maximum(src, 0)], F(0)); ys = np.where(ok, ey[np.maximum(src, 0)], F(0))
+                ex, ey = _mv(Qi, xs, ys, ex, ey)
+            tot = [np.array([ex[16 * r + 15], ey[16 * r + 15]], F) for r in range(4)]
+            # zero-start end state of the whole sub-block (published to the later waves)
+            u = tot[0]
+            for r in (1, 2, 3):
+                u = _mv1(Q16, u, tot[r])
+            pre.append((z, w, ex, ey, tot, u))
+        for wv in range(NW):
+            z, w, ex, ey, tot, _ = pre[wv]
+            Xw = X[wv]
+            c0 = carried.copy()
+            for v in range(wv):
+                c0 = _mv1(Q64, c0, pre[v][5])
+            c = [c0]
+            for r in range(3):
+                c.append(_mv1(Q16, c[-1], tot[r]))
+            cr = np.array([c[r] for r in row], F)
+            # 2c. lane power
+            QL = Q[l16]
+            exn = (QL[:, 0, 0] * cr[:, 0] + (QL[:, 0, 1] * cr[:, 1] + ex).astype(F)).astype(F)
+            eyn = (QL[:, 1, 0] * cr[:, 0] + (QL[:, 1, 1] * cr[:, 1] + ey).astype(F)).astype(F)
+            # 3. start states
+            sx0 = np.where(l16 == 0, cr[:, 0], exn[np.maximum(t - 1, 0)]).astype(F)
+            sy0 = np.where(l16 == 0, cr[:, 1], eyn[np.maximum(t - 1, 0)]).astype(F)
+            bx, by = _mv(P, sx0, sy0, z[:, 0], w[:, 0])
+            d0 = np.stack([sx0, bx], 1); d1 = np.stack([sy0, by], 1)
+            f0 = d0.copy(); f1 = d1.copy()
+            for k in range(L):
+                xx = Xw[:, :, k]
+                y = (b0 * xx + d0).astype(F)
+                tt = (b1 * xx + d1).astype(F)
+                d0 = (a1 * y + tt).astype(F)
+                d1 = (a2 * y + (b2 * xx).astype(F)).astype(F)
+                Xw[:, :, k] = y
+                if k + 1 == m_last or k + 1 + L == m_last:
+                    f0 = d0.copy(); f1 = d1.copy()
+            if cnt == NW * SB:
+                if wv == NW - 1:
+                    state[s][0] = d0[63, 1]; state[s][1] = d1[63, 1]
+            elif wv == w_last:
+                h = 0 if m_last <= L else 1
+                state[s][0] = f0[t_last, h]; state[s][1] = f1[t_last, h]
     return X.reshape(-1)[:cnt]
 
 
+def emulate_tail(x, coef, state):
+    """biquad_tail_kernel: the samples % L leftover samples, one after the other."""
+    y = x.copy()
+    for s, q in enumerate(coef):
+        b0, b1, b2, a1, a2 = [F(v) for v in q]
+        d0, d1 = F(state[s][0]), F(state[s][1])
+        for k in range(len(y)):
+            xx = y[k]
+            out = F(b0 * xx + d0)
+            tt = F(b1 * xx + d1)
+            d0 = F(a1 * out + tt)
+            d1 = F(a2 * out + F(b2 * xx))
+            y[k] = out
+        state[s][0], state[s][1] = d0, d1
+    return y
+
+
 def emulate(mi, x, coef):
+    """Variant selection of mi_biquad_bank_process, then super-block after super-block, then the tail."""
     st = [[F(0), F(0)] for _ in coef]
     out = np.empty_like(x)
-    done = 0
-    while done < len(x):
-        left = len(x) - done
-        if left > 512:
-            step, variant = min(left, 4096), 0
-        else:
-            step, variant = left, 1
-        out[done:done + step] = emulate_block(mi, x[done:done + step], coef, st, variant)
-        done += step
+    if len(x) <= 1024:
+        L, NW = 8, 1
+    elif len(x) <= 2048:
+        L, NW = 8, 2
+    else:
+        L, NW = 16, 2
+    body = len(x) - len(x) % L
+    sup = NW * 64 * 2 * L
+    for done in range(0, body, sup):
+        step = min(sup, body - done)
+        out[done:done + step] = emulate_super_block(mi, x[done:done + step], coef, st, L, NW)
+    if body < len(x):
+        out[body:] = emulate_tail(x[body:], coef, st)
     return out, np.array(st, F)
 
 
@@ -139,7 +184,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("name,ftype,slope,freq,gain,q", CASES)
-@pytest.mark.parametrize("n", [4096, 5000, 300])
+@pytest.mark.parametrize("n", [4096, 5000, 300, 1030, 2048, 9000, 5, 4111])
 def test_chunked_form_matches_sequential(mi, name, ftype, slope, freq, gain, q, n):
     coef = wl.design(ftype, slope, freq, freq, gain, q)
     x = (np.random.default_rng(42).standard_normal(n) * 0.25).astype(F)
@@ -150,11 +195,13 @@ def test_chunked_form_matches_sequential(mi, name, ftype, slope, freq, gain, q, 
 
 
 def test_table_shapes(mi):
-    L, NT, NM, c5, M, p, q = product_tables(mi, [1, 0, 0, 0.5, 0], 0)
-    assert (L, NT, NM) == (32, 128, 16)
+    L, NT, NM, c5, P, Q, Q64, p, q = product_tables(mi, [1, 0, 0, 0.5, 0], 0)
+    assert (L, NT, NM) == (16, 64, 16)
     # one-pole y = x + 0.5 y[-1]: d0' = 0.5 (x + d0); end-state weight of sample k is 0.5^(L-k)
     np.testing.assert_allclose(p, 0.5 ** (L - np.arange(L)), rtol=1e-6)
-    np.testing.assert_allclose(M[0], [[0.5 ** L, 0.5 ** (L - 1)], [0, 0]], rtol=1e-6)
-    np.testing.assert_allclose(M[1][0, 0], 0.5 ** (2 * L), rtol=1e-6)
+    np.testing.assert_allclose(P, [[0.5 ** L, 0.5 ** (L - 1)], [0, 0]], rtol=1e-6)
+    np.testing.assert_allclose(Q[0][0, 0], 0.5 ** (2 * L), rtol=1e-6)
+    np.testing.assert_allclose(Q[1][0, 0], 0.5 ** (4 * L), rtol=1e-6)
+    np.testing.assert_allclose(Q64[0, 0], 0.5 ** (128 * L), rtol=1e-5, atol=0)
     L, NT, NM, *_ = product_tables(mi, [1, 0, 0, 0.5, 0], 1)
     assert (L, NT, NM) == (8, 64, 16)
