@@ -487,9 +487,11 @@ int mi_ring_bank_info(const mi_ring_bank_t *bank, size_t offset, uint32_t *capac
 /*
  * Host-only introspection of the per-section device table (no GPU needed): the
  * chunk-parallel form of the TDF-II section used by the kernel.
- * variant 0 = 32-sample chunks x 128 lanes, 1 = 8-sample chunks x 64 lanes.
- * geometry[4] receives {chunk, lanes, matrices, floats_per_row}; table (may be
- * NULL) receives one row: {b0 b1 b2 a1 a2 0 0 0 | P^(i+1) i<matrices | p[chunk] | q[chunk]}.
+ * variant 0 = 16-sample chunks (calls longer than 2048 samples), 1 = 8-sample
+ * chunks; a lane owns two adjacent chunks, a wave 64 such pairs.
+ * geometry[4] receives {chunk L, lanes, per-lane matrices, floats_per_row};
+ * table (may be NULL) receives one row, 2x2 matrices column-major (m00 m10 m01 m11):
+ *   {b0 b1 b2 a1 a2 0 0 0 | P P^2 P^4 P^8 P^16 P^32 | (p[k],q[k]) k<L | (P^2)^(i+1) i<16},  P = A^L.
  */
 int mi_biquad_section_tables(const mi_biquad_x1_t *chain, int variant, float *table, uint32_t *geometry);
 

@@ -8,32 +8,35 @@
 // makes the recurrence parallel in time.  Per section, state s = {d0,d1},
 // s' = A s + B x, and every lane owns a PAIR of adjacent chunks of L samples:
 //
-//   1. zero-state end state of each chunk:  z = sum_k A^(L-1-k) B x[k]
-//      -> two dot products with the per-section tables p[],q[];
-//   2. the pair's end state for a zero start:  e = P zA + zB,  P = A^L;
-//      prefix over the 64 pairs of the wave,  E_t = P^2 E_(t-1) + e_t:
-//        a. inclusive scan inside each row of 16 lanes with DPP row_shr 1,2,4,8
-//           and the uniform matrices P^2, P^4, P^8, P^16;
-//        b. the row totals are chained with P^32 (uniform math via v_readlane);
-//        c. every lane adds (P^2)^(i+1) C_row, i = lane % 16 (16-entry table);
-//      the state carried in from the previous sub-block / call enters at lane 0;
-//   3. start state of the lane's first chunk = E_(t-1), of its second chunk
-//      P S + zA; then the EXACT TDF-II recurrence of the reference over both
-//      chunks at once, as the two halves of v_pk_fma_f32 operands:
+//   1. zero-state end state of each chunk:  (z,w) = sum_k A^(L-1-k) B x[k]
+//      -> dot products with the per-section table (p[k],q[k]);
+//   2. the pair's end state for a zero start:  e = P zwA + zwB,  P = A^L;
+//      the state carried in from the samples before the wave enters at lane 0
+//      (e_0 += P^2 c); then an inclusive scan over the 64 pairs of the wave,
+//      E_t = P^2 E_(t-1) + e_t, entirely with DPP:
+//        a. inside each row of 16 lanes: row_shr 1,2,4,8 with P^2, P^4, P^8, P^16;
+//        b. row_bcast:15 into rows 1 and 3 with the lane's own (P^2)^(i+1),
+//           i = lane % 16 (16-entry per-lane table);
+//        c. row_bcast:31 into rows 2 and 3 (row 3 through one more P^32);
+//   3. start state of the lane's first chunk = E_(t-1) (wave_shr:1), of its
+//      second chunk P S + zwA; then the EXACT TDF-II recurrence of the reference
+//      over both chunks at once, as the two halves of v_pk_fma_f32 operands:
 //         y = b0 x + d0;  d0 = (b1 x + d1) + a1 y;  d1 = b2 x + a2 y
 //      Only the chunk start states carry the (float32 round-off sized)
 //      difference of steps 1-2.
 //
-// One WAVE owns one channel.  A lone wave issues one VALU instruction per 4
-// cycles: half rate for v_fma_f32, full rate for packed fp32 -- so one wave per
-// SIMD (1024 channels on 1024 SIMDs) runs at full VALU throughput with no
-// workgroup barrier in the section loop and the whole register file to itself.
+// A wave owns a sub-block of 64 x 2L samples of one channel; NW waves of a
+// workgroup cover NW consecutive sub-blocks (a super-block) and hand the state
+// from wave to wave through LDS, one workgroup barrier per section.  With 1024
+// channels x 4096 samples that is 2 waves on every SIMD of the chip.
 // All sections run back to back on samples held in registers (HBM sees each
-// sample once in, once out).  A call is cut into sub-blocks of 64 x 2L samples;
-// the loads of sub-block k+1 are in flight while sub-block k is computed and the
-// stores of sub-block k (write-through, sc1) drain while k+1 is computed.
-// Loads are coalesced 16-B rows, transposed through a padded LDS tile (pitch
-// 2L+4 dwords, an odd number of 16-B slots: conflict-free ds_read_b128).
+// sample once in, once out).  The uniform part of a section's table lives in
+// SGPRs (s_load, no LDS staging, no VGPRs); the loads of section s+1 are issued
+// while section s is still computing.  Longer calls walk super-block after
+// super-block; the loads of the next one are in flight during the sections and
+// the write-through (sc1) stores drain behind them.  Loads are coalesced 16-B
+// rows, transposed through a padded LDS tile private to the wave (pitch 2L+4
+// dwords, an odd number of 16-B slots: conflict-free ds_read_b128).
 #include "mi_common.h"
 
 #include <cmath>
@@ -47,35 +50,47 @@ namespace
     struct geom
     {
         static constexpr int W      = 2 * L;                // samples per lane and sub-block
-        static constexpr int TAB    = 80 + 2 * L;           // floats per (channel, section)
+        static constexpr int TAB    = 96 + 2 * L;           // floats per (channel, section)
         static constexpr int PITCH  = W + 4;                // LDS dwords per lane
         static constexpr int BLOCK  = 64 * W;               // samples per sub-block
-        static constexpr int SG     = 8;                    // sections whose tables are staged at once
+        static constexpr int SG     = 128;                  // sections whose carried state is kept in LDS at once
         static_assert(((PITCH / 4) & 1) == 1, "LDS pitch must be an odd number of 16-B slots");
-        static_assert((TAB % 4) == 0, "table rows stay 16-B aligned");
+        static_assert((TAB % 16) == 0, "table rows stay 64-B aligned (s_load_dwordx16)");
     };
 
-    // Table row of one section:
-    //   [0..4]    b0 b1 b2 a1 a2              [5..7] unused
-    //   [8..11]   P = A^L, row-major
-    //   [12+4i..] (P^2)^(i+1), i = 0..15
-    //   [76..79]  (P^2)^64: one whole sub-block
-    //   [80..]    p[L], q[L]
-    typedef float v2f __attribute__((ext_vector_type(2)));
+    // Table row of one section (matrices column-major: m00 m10 m01 m11, so that a column is a register pair):
+    //   [0..7]     b0 b1 b2 a1 a2 0 0 0
+    //   [8..15]    P = A^L, P^2
+    //   [16..31]   P^4, P^8, P^16, P^32
+    //   [32..]     (p[k], q[k]) k < L : weights of sample k in the chunk's zero-state end state
+    //   [32+2L..]  (P^2)^(i+1), i = 0..15 (per-lane operand of the scan)
+    constexpr int TAB_PQ = 32;
+    typedef float v2f  __attribute__((ext_vector_type(2)));
+    typedef float v8f  __attribute__((ext_vector_type(8)));
+    typedef float v16f __attribute__((ext_vector_type(16)));
 
     __device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
     __device__ __forceinline__ v2f splat(float a) { return v2f{a, a}; }
+    // a + M v for a column-major 2x2 matrix given as its two columns
+    __device__ __forceinline__ v2f mat_fma(v2f c0, v2f c1, v2f v, v2f a) { return pk_fma(c0, splat(v.x), pk_fma(c1, splat(v.y), a)); }
+
+    template <int CTRL, int ROW_MASK>
+    __device__ __forceinline__ float dpp_or(float old, float v)      // lanes without a source / masked rows keep `old`
+    {
+        return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+    }
+    template <int CTRL, int ROW_MASK>
+    __device__ __forceinline__ v2f dpp_or(v2f old, v2f v) { return v2f{dpp_or<CTRL, ROW_MASK>(old.x, v.x), dpp_or<CTRL, ROW_MASK>(old.y, v.y)}; }
 
     template <int CTRL>
-    __device__ __forceinline__ float dpp_zero(float v)
+    __device__ __forceinline__ v2f dpp_zero(v2f v)                    // lanes without a source read 0 (bound_ctrl)
     {
-        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+        return v2f{__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), CTRL, 0xf, 0xf, true)),
+                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), CTRL, 0xf, 0xf, true))};
     }
 
-    __device__ __forceinline__ float lane_value(float v, int lane)
-    {
-        return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-    }
+    constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
+    constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
     // 16-byte write-through store (sc1): the output leaves the XCD's L2 while the kernel is still running
     // instead of being written back in one burst by the end-of-kernel release (MI355X_MICROARCH.md,
@@ -105,18 +120,6 @@ namespace
 #else
     #define MI_PROBE(slot) do { } while (0)
 #endif
-#ifdef MI_BIQUAD_PROBE
-    // in-section timestamps stay in SGPRs until the section is over (a store per stamp would perturb the section)
-    #define MI_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); ts[i] = __builtin_readcyclecounter(); \
-                             __builtin_amdgcn_sched_barrier(0); } while (0)
-    #define MI_STAMP_DUMP() do { if (si == 1 && par == 0 && t == 0) { \
-        const unsigned pw_ = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); \
-        for (int i_ = 0; i_ < 8; ++i_) g_probe[(pw_ * 16 + 8 + i_) * 2 + 1] = ts[i_]; } } while (0)
-#else
-    #define MI_STAMP(i) do { } while (0)
-    #define MI_STAMP_DUMP() do { } while (0)
-#endif
-
     template <int L, int NW, bool ALIGNED>
     __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
     void biquad_bank_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
@@ -126,25 +129,22 @@ namespace
         using G = geom<L>;
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
         constexpr int LPT = W / 4;                          // float4 per lane and sub-block
-        constexpr int TAB4 = TAB / 4;
         constexpr int NT = 64 * NW;
-        constexpr int TQ = SG * TAB4, TPT = (TQ + NT - 1) / NT;
-        constexpr int PQ = 20;                              // float4 index of p[] inside a table row
+        constexpr int TAB_QL = TAB_PQ + 2 * L;
 
         __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
-        __shared__ __attribute__((aligned(16))) float stab[SG * TAB];
         __shared__ float2 sstate[2][SG];                    // state carried between super-blocks, by parity
-        __shared__ float2 xchg[2][SG][NW];                  // zero-start end state of every wave's sub-block
+        __shared__ float2 xchg[2][SG][NW];                  // end state of every wave's sub-block
 
         const int ch   = blockIdx.x;
         const int tid  = threadIdx.x;
         const int t    = tid & 63;                          // lane
         const int wv   = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int l16  = t & 15;
-        const int row  = t >> 4;
         const int ns   = int(nsec[ch]);
         float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile
-        const bool r1 = (row == 1), r2 = (row == 2), r3 = (row == 3);
+        const bool lane0 = (t == 0), row3 = (t >= 48);
+        const float *ctab = tab + size_t(ch) * max_sec * TAB;             // this channel's table rows (uniform address)
         // Buffer descriptors over the channel's n samples: reads past the end return 0, writes past the end are
         // dropped, so the tile rows need no bounds branches and the compiler's vmcnt bookkeeping stays exact.
         const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -173,176 +173,115 @@ namespace
                                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irsrc, o + 12, 0, 0)));
             }
         };
-        auto stage_tables = [&](int s0, int group, int par) // tables + carried state of a section group -> LDS
+        auto load_state = [&](int s0, int group, int par)   // carried state of a section group -> LDS
         {
-            const float4 *src = reinterpret_cast<const float4 *>(tab + (size_t(ch) * max_sec + s0) * TAB);
-            #pragma unroll
-            for (int j = 0; j < TPT; ++j)
-            {
-                const int i = tid + j * NT;
-                if (i < group * TAB4)
-                    reinterpret_cast<float4 *>(stab)[i] = src[i];
-            }
-            if (tid < group)
-                sstate[par][tid] = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[tid];
+            for (int i = tid; i < group; i += NT)
+                sstate[par][i] = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[i];
         };
         auto flush_state = [&](int s0, int group, int par)
         {
-            if (tid < group)
-                reinterpret_cast<float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[tid] = sstate[par][tid];
+            for (int i = tid; i < group; i += NT)
+                reinterpret_cast<float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[i] = sstate[par][i];
         };
 
         v2f x[L];                                            // .x: first chunk of the lane, .y: second chunk
 
-        // Registers of one section's table.  The reads of section s+1 are issued right before the recurrence of
-        // section s (which only needs the five coefficients), into the registers section s no longer uses.
-        struct tabregs
+        // One section's table.  Everything but `ql` is wave-uniform and sits in SGPRs (scalar loads); `ql` is the lane's
+        // own (P^2)^(lane%16+1).  The three parts are reloaded for the next section as soon as this section is done with
+        // them, so the loads are in flight underneath the rest of the section.
+        struct sectab
         {
-            float4 p[L / 4], q[L / 4];
-            float4 cf, P, Q1, Q2, Q4, Q8, Q16, Q64, QL;
-            float  a2;
+            v16f pq[L / 8];                                  // (p[k], q[k]) pairs
+            v8f  m0;                                         // P, P^2
+            v16f m1;                                         // P^4, P^8, P^16, P^32
+            float4 cf;                                       // b0 b1 b2 a1   (no dead lanes in any scalar load: the
+            float  a2;                                       //  compiler would recycle them and stall on the load)
+            float4 ql;
         };
-        auto load_tab = [&](tabregs &r, const float *T)
+        auto load_pq = [&](sectab &r, const float *T)
         {
-            const float4 *T4 = reinterpret_cast<const float4 *>(T);
             #pragma unroll
-            for (int j = 0; j < L / 4; ++j)                 // needed first, read first: LDS returns in order
-            {
-                r.p[j] = T4[PQ + j];
-                r.q[j] = T4[PQ + L / 4 + j];
-            }
-            r.P   = T4[2];
-            r.Q1  = T4[3 + 0];
-            r.Q2  = T4[3 + 1];
-            r.Q4  = T4[3 + 3];
-            r.Q8  = T4[3 + 7];
-            r.Q16 = T4[3 + 15];
-            r.Q64 = T4[19];
-            r.QL  = *reinterpret_cast<const float4 *>(T + 12 + 4 * l16);
-            r.cf  = T4[0];
-            r.a2  = T[4];
-            __builtin_amdgcn_sched_barrier(0);              // all reads in flight before anything else is scheduled
+            for (int j = 0; j < L / 8; ++j)
+                r.pq[j] = *reinterpret_cast<const v16f *>(T + TAB_PQ + 16 * j);
+        };
+        auto load_mats = [&](sectab &r, const float *T)
+        {
+            r.m0 = *reinterpret_cast<const v8f *>(T + 8);
+            r.m1 = *reinterpret_cast<const v16f *>(T + 16);
+            r.ql = *reinterpret_cast<const float4 *>(T + TAB_QL + 4 * l16);
+        };
+        auto load_coefs = [&](sectab &r, const float *T)
+        {
+            r.cf = *reinterpret_cast<const float4 *>(T);
+            r.a2 = T[4];
         };
 
         // One section over the lane's two chunks.  par: parity of the super-block.  `saver` marks the lane holding
         // the last sample of the super-block (in its first chunk if !save_hi) -- it saves the state for what follows.
         // `tb` holds this section's table on entry and the table at `Tnext` on exit.
-        auto section = [&](tabregs &tb, const float *Tnext, int si, int par, bool saver, bool save_hi)
+        auto section = [&](sectab &tb, const float *Tnext, int si, int par, bool saver, bool save_hi)
         {
-#ifdef MI_BIQUAD_PROBE
-            unsigned long long ts[8];
-#endif
-            MI_STAMP(0);
-            const float4 P = tb.P;
-
-            // 1. zero-state end states of both chunks
-            v2f z0 = splat(0.0f), z1 = splat(0.0f), w0 = splat(0.0f), w1 = splat(0.0f);
-            if (MI_ABLATE == 1) { z0 = x[0] * splat(tb.p[0].x); w0 = x[1] * splat(tb.q[0].x); }
+            // 1. zero-state end states of both chunks: zwA = (z, w) of the first, zwB of the second
+            v2f a0 = splat(0.0f), a1_ = splat(0.0f), b0_ = splat(0.0f), b1_ = splat(0.0f);
             #pragma unroll
-            for (int k = 0; k < ((MI_ABLATE == 1) ? 0 : L); k += 4)
+            for (int k = 0; k < L; k += 2)
             {
-                const float4 p = tb.p[k / 4];
-                const float4 q = tb.q[k / 4];
-                z0 = pk_fma(splat(p.x), x[k + 0], z0); w0 = pk_fma(splat(q.x), x[k + 0], w0);
-                z1 = pk_fma(splat(p.y), x[k + 1], z1); w1 = pk_fma(splat(q.y), x[k + 1], w1);
-                z0 = pk_fma(splat(p.z), x[k + 2], z0); w0 = pk_fma(splat(q.z), x[k + 2], w0);
-                z1 = pk_fma(splat(p.w), x[k + 3], z1); w1 = pk_fma(splat(q.w), x[k + 3], w1);
+                const v16f &r = tb.pq[k / 8];
+                const v2f pq0 = v2f{r[(2 * k) % 16], r[(2 * k + 1) % 16]};
+                const v2f pq1 = v2f{r[(2 * k + 2) % 16], r[(2 * k + 3) % 16]};
+                a0  = pk_fma(pq0, splat(x[k].x), a0);      b0_ = pk_fma(pq0, splat(x[k].y), b0_);
+                a1_ = pk_fma(pq1, splat(x[k + 1].x), a1_); b1_ = pk_fma(pq1, splat(x[k + 1].y), b1_);
             }
-            const v2f z = z0 + z1, w = w0 + w1;
-            MI_STAMP(1);
+            const v2f zwA = a0 + a1_, zwB = b0_ + b1_;
 
             // 2. end state of the pair for a zero start
-            float ex = fmaf(P.x, z.x, fmaf(P.y, w.x, z.y));
-            float ey = fmaf(P.z, z.x, fmaf(P.w, w.x, w.y));
+            const v2f Pc0 = v2f{tb.m0[0], tb.m0[1]}, Pc1 = v2f{tb.m0[2], tb.m0[3]};
+            v2f e = mat_fma(Pc0, Pc1, zwA, zwB);
+
+            // state entering this wave's sub-block: carried over for wave 0, else the end state of the wave before
+            if (NW > 1)
+                for (int v = 0; v < wv; ++v)
+                    __syncthreads();
+            const float2 cs = (NW > 1 && wv > 0) ? xchg[par][si][wv - 1] : sstate[par][si];
+            const v2f cvec = lane0 ? v2f{cs.x, cs.y} : splat(0.0f);
+            e = mat_fma(v2f{tb.m0[4], tb.m0[5]}, v2f{tb.m0[6], tb.m0[7]}, cvec, e);
 
             // 2a. inclusive scan over the pairs inside rows of 16 lanes: E += (P^2)^d E(lane - d)
-            if (MI_ABLATE != 2 && MI_ABLATE != 4)
+            const v2f zero = splat(0.0f);
+            e = mat_fma(v2f{tb.m0[4], tb.m0[5]}, v2f{tb.m0[6], tb.m0[7]}, dpp_zero<DPP_ROW_SHR1>(e), e);
+            e = mat_fma(v2f{tb.m1[0], tb.m1[1]}, v2f{tb.m1[2], tb.m1[3]}, dpp_zero<DPP_ROW_SHR2>(e), e);
+            e = mat_fma(v2f{tb.m1[4], tb.m1[5]}, v2f{tb.m1[6], tb.m1[7]}, dpp_zero<DPP_ROW_SHR4>(e), e);
+            e = mat_fma(v2f{tb.m1[8], tb.m1[9]}, v2f{tb.m1[10], tb.m1[11]}, dpp_zero<DPP_ROW_SHR8>(e), e);
+            // 2b. rows 1 and 3 take in the row before them
+            const v2f QLc0 = v2f{tb.ql.x, tb.ql.y}, QLc1 = v2f{tb.ql.z, tb.ql.w};
+            e = mat_fma(QLc0, QLc1, dpp_or<DPP_ROW_BCAST15, 0xa>(zero, e), e);
+            // 2c. rows 2 and 3 take in rows 0-1 (lane 31), row 3 across one more row of 16 pairs
             {
-                const float4 Q1 = tb.Q1, Q2 = tb.Q2, Q4 = tb.Q4, Q8 = tb.Q8;
-                float sx_, sy_;
-                sx_ = dpp_zero<0x111>(ex); sy_ = dpp_zero<0x111>(ey);
-                ex = fmaf(Q1.x, sx_, fmaf(Q1.y, sy_, ex)); ey = fmaf(Q1.z, sx_, fmaf(Q1.w, sy_, ey));
-                sx_ = dpp_zero<0x112>(ex); sy_ = dpp_zero<0x112>(ey);
-                ex = fmaf(Q2.x, sx_, fmaf(Q2.y, sy_, ex)); ey = fmaf(Q2.z, sx_, fmaf(Q2.w, sy_, ey));
-                sx_ = dpp_zero<0x114>(ex); sy_ = dpp_zero<0x114>(ey);
-                ex = fmaf(Q4.x, sx_, fmaf(Q4.y, sy_, ex)); ey = fmaf(Q4.z, sx_, fmaf(Q4.w, sy_, ey));
-                sx_ = dpp_zero<0x118>(ex); sy_ = dpp_zero<0x118>(ey);
-                ex = fmaf(Q8.x, sx_, fmaf(Q8.y, sy_, ex)); ey = fmaf(Q8.z, sx_, fmaf(Q8.w, sy_, ey));
+                const v2f s  = dpp_or<DPP_ROW_BCAST31, 0xc>(zero, e);
+                const v2f s2 = mat_fma(v2f{tb.m1[12], tb.m1[13]}, v2f{tb.m1[14], tb.m1[15]}, s, zero);
+                e = mat_fma(QLc0, QLc1, row3 ? s2 : s, e);
             }
-
-            v2f d0, d1;
-            if (MI_ABLATE == 4) { d0 = v2f{ex, z.x}; d1 = v2f{ey, w.x}; }
-            else
-            {
-            MI_STAMP(2);
-            // 2b. row totals (wave-uniform from here to 2c)
-            const float4 Q16 = tb.Q16;
-            const float t0x = lane_value(ex, 15), t0y = lane_value(ey, 15);
-            const float t1x = lane_value(ex, 31), t1y = lane_value(ey, 31);
-            const float t2x = lane_value(ex, 47), t2y = lane_value(ey, 47);
-
-            // state entering this wave's sub-block: carried state pushed through the sub-blocks of the waves before
-            float c0x, c0y;
             if (NW > 1)
             {
-                // zero-start end state of the whole sub-block, published for the waves after this one
-                const float t3x = lane_value(ex, 63), t3y = lane_value(ey, 63);
-                const float u2x = fmaf(Q16.x, t0x, fmaf(Q16.y, t0y, t1x)), u2y = fmaf(Q16.z, t0x, fmaf(Q16.w, t0y, t1y));
-                const float u3x = fmaf(Q16.x, u2x, fmaf(Q16.y, u2y, t2x)), u3y = fmaf(Q16.z, u2x, fmaf(Q16.w, u2y, t2y));
-                const float u4x = fmaf(Q16.x, u3x, fmaf(Q16.y, u3y, t3x)), u4y = fmaf(Q16.z, u3x, fmaf(Q16.w, u3y, t3y));
-                if (t == 0)
-                    xchg[par][si][wv] = make_float2(u4x, u4y);
-                MI_STAMP(3);
-                __syncthreads();
-                MI_STAMP(4);
-                const float2 cs = sstate[par][si];
-                const float4 Q64 = tb.Q64;
-                c0x = cs.x; c0y = cs.y;
-                #pragma unroll
-                for (int v = 0; v < NW - 1; ++v)
-                    if (v < wv)
-                    {
-                        const float2 tv = xchg[par][si][v];
-                        const float nx = fmaf(Q64.x, c0x, fmaf(Q64.y, c0y, tv.x));
-                        const float ny = fmaf(Q64.z, c0x, fmaf(Q64.w, c0y, tv.y));
-                        c0x = nx; c0y = ny;
-                    }
+                if (t == 63)
+                    xchg[par][si][wv] = make_float2(e.x, e.y);
+                for (int v = wv; v < NW - 1; ++v)
+                    __syncthreads();
             }
-            else
-            {
-                const float2 cs = sstate[par][si];
-                c0x = cs.x; c0y = cs.y;
-            }
-            const float c1x = fmaf(Q16.x, c0x, fmaf(Q16.y, c0y, t0x)), c1y = fmaf(Q16.z, c0x, fmaf(Q16.w, c0y, t0y));
-            const float c2x = fmaf(Q16.x, c1x, fmaf(Q16.y, c1y, t1x)), c2y = fmaf(Q16.z, c1x, fmaf(Q16.w, c1y, t1y));
-            const float c3x = fmaf(Q16.x, c2x, fmaf(Q16.y, c2y, t2x)), c3y = fmaf(Q16.z, c2x, fmaf(Q16.w, c2y, t2y));
 
-            MI_STAMP(5);
-            // 2c. state entering the lane's row, pushed through the lane's own power of P^2
-            const float4 QL = tb.QL;
-            float crx = c0x, cry = c0y;
-            crx = r1 ? c1x : crx; cry = r1 ? c1y : cry;
-            crx = r2 ? c2x : crx; cry = r2 ? c2y : cry;
-            crx = r3 ? c3x : crx; cry = r3 ? c3y : cry;
-            ex = fmaf(QL.x, crx, fmaf(QL.y, cry, ex));
-            ey = fmaf(QL.z, crx, fmaf(QL.w, cry, ey));
+            // 3. start states: first chunk = end of the previous pair, second chunk = P S + zwA
+            const v2f S  = dpp_or<DPP_WAVE_SHR1, 0xf>(cvec, e);
+            const v2f SB = mat_fma(Pc0, Pc1, S, zwA);
+            v2f d0 = v2f{S.x, SB.x}, d1 = v2f{S.y, SB.y};
+            __builtin_amdgcn_sched_barrier(0);              // the next section's table streams in underneath the recurrence,
+            load_pq(tb, Tnext);                             // into the registers this section no longer needs
+            load_mats(tb, Tnext);
+            __builtin_amdgcn_sched_barrier(0);
 
-            // 3. start states: first chunk = end of the previous pair, second chunk = P S + zA
-            float sx0 = dpp_zero<0x111>(ex), sy0 = dpp_zero<0x111>(ey);
-            if (l16 == 0) { sx0 = crx; sy0 = cry; }
-            d0.x = sx0;
-            d1.x = sy0;
-            d0.y = fmaf(P.x, sx0, fmaf(P.y, sy0, z.x));
-            d1.y = fmaf(P.z, sx0, fmaf(P.w, sy0, w.x));
-
-            }
-            // exact recurrence over both chunks; the next section's table streams in underneath it
-            MI_STAMP(6);
+            // exact recurrence over both chunks
             const v2f b0 = splat(tb.cf.x), b1 = splat(tb.cf.y), b2 = splat(tb.cf.z), a1 = splat(tb.cf.w), a2 = splat(tb.a2);
-            if (MI_ABLATE != 5)
-                load_tab(tb, Tnext);
             #pragma unroll
-            for (int k = 0; k < ((MI_ABLATE == 3) ? 1 : L); ++k)
+            for (int k = 0; k < L; ++k)
             {
                 const v2f xx = x[k];
                 const v2f tq = pk_fma(b1, xx, d1);
@@ -352,8 +291,8 @@ namespace
                 d1   = pk_fma(a2, y, u);
                 x[k] = y;
             }
-            MI_STAMP(7);
-            MI_STAMP_DUMP();
+            __builtin_amdgcn_sched_barrier(0);
+            load_coefs(tb, Tnext);
             if (saver)                                       // n is a multiple of L: the call ends with a chunk
                 sstate[par ^ 1][si] = save_hi ? make_float2(d0.y, d1.y) : make_float2(d0.x, d1.x);
         };
@@ -362,9 +301,18 @@ namespace
         constexpr int SUPER = NW * SB;
         const int nsup = (n + SUPER - 1) / SUPER;
         const int off  = wv * SB;                            // this wave's sub-block inside the super-block
-        if (ns > 0)                                         // tables first: they must not queue behind the samples
-            stage_tables(0, (ns < SG) ? ns : SG, 0);
+        sectab tb;
+        if (ns <= SG)
+            load_state(0, ns, 0);
+        if (ns > 0)                                         // scalar loads: they do not queue behind the samples
+        {
+            load_pq(tb, ctab);
+            load_mats(tb, ctab);
+            load_coefs(tb, ctab);
+        }
         issue_loads(off);
+        if (ns <= SG)
+            __syncthreads();
 
         for (int sp = 0; sp < nsup; ++sp)
         {
@@ -402,17 +350,17 @@ namespace
             for (int s0 = 0; s0 < ns; s0 += SG)
             {
                 const int group = (ns - s0 < SG) ? (ns - s0) : SG;
-                if (ns > SG)                                 // more sections than fit the staging area: restage
+                if (ns > SG)                                 // more sections than state slots: one group at a time
                 {
                     __syncthreads();
-                    stage_tables(s0, group, par);
-                }
-                if (ns > SG || sp == 0)
+                    load_state(s0, group, par);
                     __syncthreads();
-                tabregs tb;
-                load_tab(tb, stab);
+                }
                 for (int si = 0; si < group; ++si)
-                    section(tb, stab + ((si + 1 < SG) ? si + 1 : 0) * TAB, si, par, saver, save_hi);
+                {
+                    const int snext = (s0 + si + 1 < ns) ? s0 + si + 1 : 0;
+                    section(tb, ctab + size_t(snext) * TAB, si, par, saver, save_hi);
+                }
                 if (ns > SG)
                 {
                     __syncthreads();
@@ -447,6 +395,8 @@ namespace
                 }
             }
             __builtin_amdgcn_wave_barrier();
+            if (NW > 1)
+                __syncthreads();                             // the saved state is visible before wave 0 reads it again
             MI_PROBE(3 + 4 * sp);
         }
         if (ns > 0 && ns <= SG)
@@ -522,33 +472,35 @@ namespace
         // s' = A s + B x  with  A = [a1 1; a2 0],  B = [b1 + a1 b0, b2 + a2 b0]
         const mat2 A = { a1, 1.0, a2, 0.0 };
         double v0 = b1 + a1 * b0, v1 = b2 + a2 * b0;
-        float *p = row + 80, *qq = p + L;
-        for (int k = L - 1; k >= 0; --k)        // p[k],q[k] = A^(L-1-k) B
+        float *pq = row + TAB_PQ;
+        for (int k = L - 1; k >= 0; --k)        // (p[k], q[k]) = A^(L-1-k) B
         {
-            p[k]  = float(v0);
-            qq[k] = float(v1);
+            pq[2 * k]     = float(v0);
+            pq[2 * k + 1] = float(v1);
             const double n0 = A.a * v0 + A.b * v1, n1 = A.c * v0 + A.d * v1;
             v0 = n0;
             v1 = n1;
         }
+        const auto put = [](float *m, const mat2 &M) { m[0] = float(M.a); m[1] = float(M.c); m[2] = float(M.b); m[3] = float(M.d); };
         mat2 P = { 1.0, 0.0, 0.0, 1.0 };
         for (int k = 0; k < L; ++k)
             P = mul(P, A);
-        row[8] = float(P.a); row[9] = float(P.b); row[10] = float(P.c); row[11] = float(P.d);
+        mat2 M = P;                              // P, P^2, P^4, P^8, P^16, P^32
+        for (int i = 0; i < 6; ++i)
+        {
+            put(row + 8 + 4 * i, M);
+            M = mul(M, M);
+        }
         const mat2 P2 = mul(P, P);
         mat2 Qi = P2;                            // (P^2)^(i+1)
         for (int i = 0; i < 16; ++i)
         {
-            float *m = row + 12 + 4 * i;
-            m[0] = float(Qi.a); m[1] = float(Qi.b); m[2] = float(Qi.c); m[3] = float(Qi.d);
-            if (i < 15)
-                Qi = mul(Qi, P2);
+            put(row + TAB_PQ + 2 * L + 4 * i, Qi);
+            Qi = mul(Qi, P2);
         }
-        const mat2 Q32 = mul(Qi, Qi), Q64 = mul(Q32, Q32);      // Qi = (P^2)^16
-        row[76] = float(Q64.a); row[77] = float(Q64.b); row[78] = float(Q64.c); row[79] = float(Q64.d);
     }
 
-    using big   = geom<16>;     // sub-blocks of 2048 samples: calls longer than 1024 samples
+    using big   = geom<16>;     // sub-blocks of 2048 samples: calls longer than 2048 samples
     using small = geom<8>;      // sub-blocks of 1024 samples: short calls
 } // namespace
 

@@ -1,7 +1,7 @@
 """Host logic of the biquad kernel, checked without a GPU.
 
 The kernel evaluates each TDF-II section chunk-parallel: zero-state end state of every
-chunk by two dot products, an inclusive scan over pairs of chunks with powers of P^2 (P = A^L), then the
+chunk by two dot products, an inclusive DPP scan over pairs of chunks with powers of P^2 (P = A^L), then the
 exact recurrence from the scanned start states.  This test takes the REAL per-section tables the product
 builds (mi_biquad_section_tables, host C++) and replays the kernel's three steps in numpy float32 with
 the same lane/chunk index math, against the sequential oracle."""
@@ -19,6 +19,11 @@ import workloads as wl
 F = np.float32
 
 
+def _cm(r):
+    """column-major 2x2 (m00 m10 m01 m11) -> row-major array"""
+    return np.array([[r[0], r[2]], [r[1], r[3]]], F)
+
+
 def product_tables(mi, q, variant):
     from importlib import import_module
     capi = import_module("lsp-dsp-units_amd.capi")
@@ -26,15 +31,15 @@ def product_tables(mi, q, variant):
     geo = (ctypes.c_uint32 * 4)()
     mi.check(mi.lib.mi_biquad_section_tables(ctypes.byref(chain), variant, None, geo))
     L, NT, NM, TAB = [int(v) for v in geo]
+    assert TAB == 96 + 2 * L
     row = np.zeros(TAB, np.float32)
     mi.check(mi.lib.mi_biquad_section_tables(ctypes.byref(chain), variant,
                                              row.ctypes.data_as(ctypes.POINTER(ctypes.c_float)), geo))
-    P = row[8:12].reshape(2, 2)                      # A^L
-    Q = row[12:12 + 4 * NM].reshape(NM, 2, 2)        # Q[i] = (P^2)^(i+1)
-    Q64 = row[76:80].reshape(2, 2)                   # (P^2)^64
-    p = row[80: 80 + L]
-    qq = row[80 + L: 80 + 2 * L]
-    return L, NT, NM, row[:5], P, Q, Q64, p, qq
+    # PW[j] = P^(2^j), j = 0..5 : P, P^2, P^4, P^8, P^16, P^32   (P = A^L)
+    PW = [_cm(row[8 + 4 * j: 12 + 4 * j]) for j in range(6)]
+    pq = row[32:32 + 2 * L].reshape(L, 2)
+    QL = np.array([_cm(row[32 + 2 * L + 4 * i: 36 + 2 * L + 4 * i]) for i in range(NM)], F)     # (P^2)^(i+1)
+    return L, NT, NM, row[:5], PW, QL, pq[:, 0].copy(), pq[:, 1].copy()
 
 
 def _mv(M, vx, vy, ax, ay):
@@ -43,18 +48,13 @@ def _mv(M, vx, vy, ax, ay):
             (M[1, 0] * vx + (M[1, 1] * vy + ay).astype(F)).astype(F))
 
 
-def _mv1(M, v, a):
-    x, y = _mv(M, np.array([v[0]], F), np.array([v[1]], F), np.array([a[0]], F), np.array([a[1]], F))
-    return np.array([x[0], y[0]], F)
-
-
 def emulate_super_block(mi, x, coef, state, L, NW):
     """One super-block of one channel, wave for wave and lane for lane: NW waves, each owning a sub-block of
-    64 * 2L samples; every lane owns two adjacent chunks A and B of L samples."""
+    64 * 2L samples; every lane owns two adjacent chunks A and B of L samples.  cnt is a multiple of L."""
     cnt = len(x)
     W = 2 * L
     SB = 64 * W
-    assert cnt <= NW * SB
+    assert cnt <= NW * SB and cnt % L == 0
     X = np.zeros(NW * SB, F)
     X[:cnt] = x
     X = X.reshape(NW, 64, 2, L).copy()               # [wave][lane][chunk][k]
@@ -63,60 +63,55 @@ def emulate_super_block(mi, x, coef, state, L, NW):
     last = cnt - 1
     w_last = last // SB
     t_last = (last - w_last * SB) // W
-    m_last = last - w_last * SB - t_last * W + 1
+    save_hi = (last - w_last * SB - t_last * W) >= L
     variant = 0 if L == 16 else 1
+    zero = np.zeros(64, F)
     for s, q in enumerate(coef):
-        L_, NT_, NM, c5, P, Q, Q64, p, qq = product_tables(mi, q, variant)
+        L_, NT_, NM, c5, PW, QLT, p, qq = product_tables(mi, q, variant)
         assert (L_, NT_, NM) == (L, 64, 16)
         np.testing.assert_array_equal(c5, np.asarray(q, F))
         b0, b1, b2, a1, a2 = [F(v) for v in q]
-        Q16 = Q[15]
-        carried = np.array([state[s][0], state[s][1]], F)
-        pre = []
+        P, P2 = PW[0], PW[1]
+        carry = np.array([state[s][0], state[s][1]], F)
+        new_state = None
         for wv in range(NW):
             Xw = X[wv]
-            # 1. dot products (two accumulators each, both chunks at once as in the packed kernel)
-            z0 = np.zeros((64, 2), F); z1 = np.zeros((64, 2), F); w0 = np.zeros((64, 2), F); w1 = np.zeros((64, 2), F)
-            for k in range(0, L, 4):
-                z0 = (p[k] * Xw[:, :, k] + z0).astype(F); w0 = (qq[k] * Xw[:, :, k] + w0).astype(F)
-                z1 = (p[k + 1] * Xw[:, :, k + 1] + z1).astype(F); w1 = (qq[k + 1] * Xw[:, :, k + 1] + w1).astype(F)
-                z0 = (p[k + 2] * Xw[:, :, k + 2] + z0).astype(F); w0 = (qq[k + 2] * Xw[:, :, k + 2] + w0).astype(F)
-                z1 = (p[k + 3] * Xw[:, :, k + 3] + z1).astype(F); w1 = (qq[k + 3] * Xw[:, :, k + 3] + w1).astype(F)
-            z = (z0 + z1).astype(F); w = (w0 + w1).astype(F)
-            # 2. pair end state for a zero start
-            ex, ey = _mv(P, z[:, 0], w[:, 0], z[:, 1], w[:, 1])
+            # 1. dot products: accumulators for even and odd k, for the first (A) and second (B) chunk
+            acc = np.zeros((2, 2, 64, 2), F)                     # [chunk][parity][lane][z|w]
+            for k in range(L):
+                for c in range(2):
+                    acc[c, k & 1, :, 0] = (p[k] * Xw[:, c, k] + acc[c, k & 1, :, 0]).astype(F)
+                    acc[c, k & 1, :, 1] = (qq[k] * Xw[:, c, k] + acc[c, k & 1, :, 1]).astype(F)
+            zwA = (acc[0, 0] + acc[0, 1]).astype(F); zwB = (acc[1, 0] + acc[1, 1]).astype(F)
+            # 2. pair end state for a zero start; the state entering the wave joins at lane 0
+            ex, ey = _mv(P, zwA[:, 0], zwA[:, 1], zwB[:, 0], zwB[:, 1])
+            cx = np.where(t == 0, carry[0], F(0)).astype(F); cy = np.where(t == 0, carry[1], F(0)).astype(F)
+            ex, ey = _mv(P2, cx, cy, ex, ey)
             # 2a. row scan with DPP row_shr d (lanes whose source falls out of the 16-lane row read 0)
-            for d, Qi in ((1, Q[0]), (2, Q[1]), (4, Q[3]), (8, Q[7])):
-                src = t - d
+            for d, M in ((1, PW[1]), (2, PW[2]), (4, PW[3]), (8, PW[4])):
                 ok = l16 >= d
-                xs = np.where(ok, ex[np.maximum(src, 0)], F(0)); ys = np.where(ok, ey[np.maximum(src, 0)], F(0))
-                ex, ey = _mv(Qi, xs, ys, ex, ey)
-            tot = [np.array([ex[16 * r + 15], ey[16 * r + 15]], F) for r in range(4)]
-            # zero-start end state of the whole sub-block (published to the later waves)
-            u = tot[0]
-            for r in (1, 2, 3):
-                u = _mv1(Q16, u, tot[r])
-            pre.append((z, w, ex, ey, tot, u))
-        for wv in range(NW):
-            z, w, ex, ey, tot, _ = pre[wv]
-            Xw = X[wv]
-            c0 = carried.copy()
-            for v in range(wv):
-                c0 = _mv1(Q64, c0, pre[v][5])
-            c = [c0]
-            for r in range(3):
-                c.append(_mv1(Q16, c[-1], tot[r]))
-            cr = np.array([c[r] for r in row], F)
-            # 2c. lane power
-            QL = Q[l16]
-            exn = (QL[:, 0, 0] * cr[:, 0] + (QL[:, 0, 1] * cr[:, 1] + ex).astype(F)).astype(F)
-            eyn = (QL[:, 1, 0] * cr[:, 0] + (QL[:, 1, 1] * cr[:, 1] + ey).astype(F)).astype(F)
-            # 3. start states
-            sx0 = np.where(l16 == 0, cr[:, 0], exn[np.maximum(t - 1, 0)]).astype(F)
-            sy0 = np.where(l16 == 0, cr[:, 1], eyn[np.maximum(t - 1, 0)]).astype(F)
-            bx, by = _mv(P, sx0, sy0, z[:, 0], w[:, 0])
+                xs = np.where(ok, ex[np.maximum(t - d, 0)], F(0)); ys = np.where(ok, ey[np.maximum(t - d, 0)], F(0))
+                ex, ey = _mv(M, xs, ys, ex, ey)
+            # 2b. row_bcast:15 into rows 1 and 3, with the lane's own (P^2)^(l16+1)
+            odd = (row & 1) == 1
+            xs = np.where(odd, ex[np.maximum(16 * row - 1, 0)], F(0)); ys = np.where(odd, ey[np.maximum(16 * row - 1, 0)], F(0))
+            QL = QLT[l16]
+            exn = (QL[:, 0, 0] * xs + (QL[:, 0, 1] * ys + ex).astype(F)).astype(F)
+            eyn = (QL[:, 1, 0] * xs + (QL[:, 1, 1] * ys + ey).astype(F)).astype(F)
+            ex, ey = exn, eyn
+            # 2c. row_bcast:31 into rows 2 and 3; row 3 through one more P^32
+            hi = row >= 2
+            xs = np.where(hi, ex[31], F(0)); ys = np.where(hi, ey[31], F(0))
+            x2, y2 = _mv(PW[5], xs, ys, zero, zero)
+            xs = np.where(row == 3, x2, xs); ys = np.where(row == 3, y2, ys)
+            exn = (QL[:, 0, 0] * xs + (QL[:, 0, 1] * ys + ex).astype(F)).astype(F)
+            eyn = (QL[:, 1, 0] * xs + (QL[:, 1, 1] * ys + ey).astype(F)).astype(F)
+            ex, ey = exn, eyn
+            # 3. start states (wave_shr:1, lane 0 keeps the carried state)
+            sx0 = np.where(t == 0, carry[0], ex[np.maximum(t - 1, 0)]).astype(F)
+            sy0 = np.where(t == 0, carry[1], ey[np.maximum(t - 1, 0)]).astype(F)
+            bx, by = _mv(P, sx0, sy0, zwA[:, 0], zwA[:, 1])
             d0 = np.stack([sx0, bx], 1); d1 = np.stack([sy0, by], 1)
-            f0 = d0.copy(); f1 = d1.copy()
             for k in range(L):
                 xx = Xw[:, :, k]
                 y = (b0 * xx + d0).astype(F)
@@ -124,14 +119,11 @@ def emulate_super_block(mi, x, coef, state, L, NW):
                 d0 = (a1 * y + tt).astype(F)
                 d1 = (a2 * y + (b2 * xx).astype(F)).astype(F)
                 Xw[:, :, k] = y
-                if k + 1 == m_last or k + 1 + L == m_last:
-                    f0 = d0.copy(); f1 = d1.copy()
-            if cnt == NW * SB:
-                if wv == NW - 1:
-                    state[s][0] = d0[63, 1]; state[s][1] = d1[63, 1]
-            elif wv == w_last:
-                h = 0 if m_last <= L else 1
-                state[s][0] = f0[t_last, h]; state[s][1] = f1[t_last, h]
+            if wv == w_last:
+                h = 1 if save_hi else 0
+                new_state = (d0[t_last, h], d1[t_last, h])
+            carry = np.array([ex[63], ey[63]], F)                # what the next wave starts from
+        state[s][0], state[s][1] = new_state
     return X.reshape(-1)[:cnt]
 
 
@@ -195,13 +187,14 @@ def test_chunked_form_matches_sequential(mi, name, ftype, slope, freq, gain, q, 
 
 
 def test_table_shapes(mi):
-    L, NT, NM, c5, P, Q, Q64, p, q = product_tables(mi, [1, 0, 0, 0.5, 0], 0)
+    L, NT, NM, c5, PW, QL, p, q = product_tables(mi, [1, 0, 0, 0.5, 0], 0)
     assert (L, NT, NM) == (16, 64, 16)
     # one-pole y = x + 0.5 y[-1]: d0' = 0.5 (x + d0); end-state weight of sample k is 0.5^(L-k)
     np.testing.assert_allclose(p, 0.5 ** (L - np.arange(L)), rtol=1e-6)
-    np.testing.assert_allclose(P, [[0.5 ** L, 0.5 ** (L - 1)], [0, 0]], rtol=1e-6)
-    np.testing.assert_allclose(Q[0][0, 0], 0.5 ** (2 * L), rtol=1e-6)
-    np.testing.assert_allclose(Q[1][0, 0], 0.5 ** (4 * L), rtol=1e-6)
-    np.testing.assert_allclose(Q64[0, 0], 0.5 ** (128 * L), rtol=1e-5, atol=0)
+    np.testing.assert_allclose(PW[0], [[0.5 ** L, 0.5 ** (L - 1)], [0, 0]], rtol=1e-6)
+    np.testing.assert_allclose(PW[1][0, 0], 0.5 ** (2 * L), rtol=1e-6)
+    np.testing.assert_allclose(PW[2][0, 0], 0.5 ** (4 * L), rtol=1e-6)
+    np.testing.assert_allclose(QL[0], PW[1], rtol=1e-6)
+    np.testing.assert_allclose(QL[1][0, 0], 0.5 ** (4 * L), rtol=1e-6)
     L, NT, NM, *_ = product_tables(mi, [1, 0, 0, 0.5, 0], 1)
     assert (L, NT, NM) == (8, 64, 16)
