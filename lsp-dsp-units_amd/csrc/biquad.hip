@@ -92,19 +92,12 @@ namespace
     constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118;
     constexpr int DPP_WAVE_SHR1 = 0x138, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
 
-    // 16-byte write-through store (sc1): the output leaves the XCD's L2 while the kernel is still running
-    // instead of being written back in one burst by the end-of-kernel release (MI355X_MICROARCH.md,
-    // "publish-large": tens of KB per workgroup from a streaming epilogue -> write-through wins).
-    // A buffer store (not inline asm) so that the compiler's vmcnt bookkeeping sees it: the wait for the
-    // prefetched loads of the next sub-block must not also wait for these stores.
-    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-    constexpr int BUFFER_DWORD3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
-    constexpr int CPOL_SC1 = 16;
-
+    using mi::BUFFER_DWORD3;
+    using mi::CPOL_SC1;
+    using mi::u32x4;
     __device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t rsrc, int dword_index, float4 v)
     {
-        const u32x4 d = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
-        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, dword_index * 4, 0, CPOL_SC1);
+        mi::wt_store(rsrc, dword_index * 4, v);
     }
 
 #ifndef MI_ABLATE

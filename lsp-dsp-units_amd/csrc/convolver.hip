@@ -37,10 +37,19 @@ namespace
     constexpr int TWN = 8192;               // twiddle table length: exp(-2 pi i j / TWN)
     constexpr int LOGM_MIN = 7, LOGM_MAX = 12;
 
+#ifdef MI_CONV_PROBE
+    // phase timestamps of thread 0 of every workgroup (tests/experiments/conv_frame_probe.hip)
+    __device__ unsigned long long g_conv_probe[1024 * 8];
+    #define MI_CPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) \
+        g_conv_probe[blockIdx.x * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+    #define MI_CPROBE(slot) do { } while (0)
+#endif
+
     // ---- forward transform of a real block of `valid` samples zero-padded to 2M, into buf ---------------
     template <int LOGM>
-    __device__ void load_and_forward(float2 *buf, const float *src, int valid, bool aligned,
-                                     const float2 *__restrict__ tw, int tid)
+    __device__ void load_and_forward(float2 *buf, float2 *scr, const float *src, int valid, bool aligned,
+                                     const real_fft<LOGM> &rf, int tid)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T;
@@ -55,17 +64,7 @@ namespace
             buf[n] = v;
         }
         __syncthreads();
-        fft_lds<LOGM, false>(buf, tw, TWN / M, tid);
-        real_split<LOGM>(buf, tw, TWN / (2 * M), tid);
-    }
-
-    // image in buf -> 2M real samples (times 2M), left in buf as (x[2n], x[2n+1])
-    template <int LOGM>
-    __device__ void inverse_in_place(float2 *buf, const float2 *__restrict__ tw, int tid)
-    {
-        constexpr int M = plan<LOGM>::N;
-        real_merge<LOGM>(buf, tw, TWN / (2 * M), tid);
-        fft_lds<LOGM, true>(buf, tw, TWN / M, tid);
+        rf.forward(buf, scr, tid);
     }
 
     __device__ __forceinline__ float2 image_mul(float2 x, float2 h, int k)
@@ -80,12 +79,15 @@ namespace
                            int P, const float2 *__restrict__ tw)
     {
         constexpr int M = plan<LOGM>::N;
-        __shared__ float2 buf[M];
+        __shared__ float2 buf[M], scr[M];
         const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+        real_fft<LOGM> rf;
+        rf.load(tw, TWN, tid);
+        rf.prepare();
         const int count = int(counts[ch]);
         int valid = count - p * M;
         valid = (valid < 0) ? 0 : (valid > M ? M : valid);
-        load_and_forward<LOGM>(buf, ir + size_t(ch) * ir_stride + size_t(p) * M, valid, false, tw, tid);
+        load_and_forward<LOGM>(buf, scr, ir + size_t(ch) * ir_stride + size_t(p) * M, valid, false, rf, tid);
         float2 *dst = H + (size_t(ch) * P + p) * M;
         for (int k = tid; k < M; k += plan<LOGM>::T)
             dst[k] = buf[k];
@@ -101,46 +103,86 @@ namespace
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
-        __shared__ float2 buf[M];
+        __shared__ float2 buf[M], scr[M];
         const int ch = blockIdx.x, tid = threadIdx.x;
-
-        load_and_forward<LOGM>(buf, in + size_t(ch) * in_stride, B, aligned, tw, tid);
-
-        float2 *rdst = (R > 0) ? ring + (size_t(ch) * R + slot) * M : nullptr;
+        MI_CPROBE(0);
+        // Request order = order of use (vmcnt counts in order): twiddles, the frame, then the operands of the later
+        // phases -- the head partition's image, the pending tail and the overlap-add accumulator wait in registers.
+        // One exposed HBM latency instead of four.
+        real_fft<LOGM> rf;
+        rf.load(tw, TWN, tid);
+        constexpr int KPT = M / T, NPT = (M / 2) / T;
+        const float *x = in + size_t(ch) * in_stride;
+        float2 xin[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int n = tid + i * T;                      // B samples, zero-padded to 2B
+            xin[i] = (n >= B / 2) ? make_float2(0.0f, 0.0f)
+                   : aligned ? *reinterpret_cast<const float2 *>(x + 2 * n) : make_float2(x[2 * n], x[2 * n + 1]);
+        }
         const float2 *h0 = H + size_t(ch) * P * M;
         const float2 *yt = (Yt != nullptr) ? Yt + size_t(ch) * M : nullptr;
-        for (int k = tid; k < M; k += T)
+        float *a = acc + size_t(ch) * 2 * B;
+        float2 hreg[KPT], yreg[KPT], a0[NPT], a1[NPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
         {
-            const float2 x = buf[k];
-            if (rdst != nullptr)
-                rdst[k] = x;
-            float2 y = image_mul(x, h0[k], k);
-            if (yt != nullptr)
-                y = cadd(y, yt[k]);
-            buf[k] = y;
+            hreg[i] = h0[tid + i * T];
+            yreg[i] = (yt != nullptr) ? yt[tid + i * T] : make_float2(0.0f, 0.0f);
+        }
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            a0[i] = *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T));
+            a1[i] = *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
+        }
+        MI_CPROBE(1);
+        rf.prepare();
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            buf[tid + i * T] = xin[i];
+        __syncthreads();
+        rf.forward(buf, scr, tid);
+        MI_CPROBE(2);
+
+        // the frame's image enters the ring; its product with the head partition plus the pending tail goes back
+        const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer((R > 0) ? ring + (size_t(ch) * R + slot) * M : nullptr,
+                                                           (R > 0) ? unsigned(M * sizeof(float2)) : 0u);
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int k = tid + i * T;
+            const float2 xk = buf[k];
+            mi::wt_store(rring, k * int(sizeof(float2)), xk);        // dropped by the bounds check when there is no ring
+            buf[k] = cadd(image_mul(xk, hreg[i], k), yreg[i]);
         }
         __syncthreads();
-        inverse_in_place<LOGM>(buf, tw, tid);
+        MI_CPROBE(3);
+        rf.inverse(buf, scr, tid);
+        MI_CPROBE(4);
 
         const float scale = 1.0f / float(2 * M);
-        float *a = acc + size_t(ch) * 2 * B;
         float *o = out + size_t(ch) * out_stride;
-        for (int n = tid; n < M / 2; n += T)
+        const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(a, unsigned(2 * B * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, unsigned(B * sizeof(float)));
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
         {
+            const int n = tid + i * T;
             const float2 y0 = buf[n], y1 = buf[n + M / 2];
-            const float2 a0 = *reinterpret_cast<const float2 *>(a + 2 * n);
-            const float2 a1 = *reinterpret_cast<const float2 *>(a + B + 2 * n);
-            const float2 r = make_float2(fmaf(y0.x, scale, a0.x), fmaf(y0.y, scale, a0.y));
+            const float2 r = make_float2(fmaf(y0.x, scale, a0[i].x), fmaf(y0.y, scale, a0[i].y));
             if (aligned)
-                *reinterpret_cast<float2 *>(o + 2 * n) = r;
+                mi::wt_store(rout, 8 * n, r);
             else
             {
-                o[2 * n] = r.x;
-                o[2 * n + 1] = r.y;
+                mi::wt_store(rout, 8 * n, r.x);
+                mi::wt_store(rout, 8 * n + 4, r.y);
             }
-            *reinterpret_cast<float2 *>(a + 2 * n)     = make_float2(fmaf(y1.x, scale, a1.x), fmaf(y1.y, scale, a1.y));
-            *reinterpret_cast<float2 *>(a + B + 2 * n) = make_float2(0.0f, 0.0f);
+            mi::wt_store(racc, 8 * n, make_float2(fmaf(y1.x, scale, a1[i].x), fmaf(y1.y, scale, a1[i].y)));
+            mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
         }
+        MI_CPROBE(5);
     }
 
     // ---- tail of the next frame: Yt = sum_{p=1..P-1} H_p * X_(newest - (p-1)) ------------------------------
@@ -188,13 +230,16 @@ namespace
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T;
-        __shared__ float2 buf[M];
+        __shared__ float2 buf[M], scr[M];
         const int ch = blockIdx.x, tid = threadIdx.x;
+        real_fft<LOGM> rf;
+        rf.load(tw, TWN, tid);
         const float2 *src = Yt + size_t(ch) * M;
         for (int k = tid; k < M; k += T)
             buf[k] = src[k];
+        rf.prepare();
         __syncthreads();
-        inverse_in_place<LOGM>(buf, tw, tid);
+        rf.inverse(buf, scr, tid);
         const float scale = 1.0f / float(2 * M);
         float2 *a = reinterpret_cast<float2 *>(acc + size_t(ch) * 2 * M);
         for (int n = tid; n < M; n += T)
@@ -241,11 +286,14 @@ namespace
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
-        __shared__ float2 buf[M];
+        __shared__ float2 buf[M], scr[M];
         const int ch = blockIdx.x, tid = threadIdx.x;
         if (R > 0)
         {
-            load_and_forward<LOGM>(buf, frame + size_t(ch) * B, B, true, tw, tid);
+            real_fft<LOGM> rf;
+            rf.load(tw, TWN, tid);
+            rf.prepare();
+            load_and_forward<LOGM>(buf, scr, frame + size_t(ch) * B, B, true, rf, tid);
             float2 *rdst = ring + (size_t(ch) * R + slot) * M;
             for (int k = tid; k < M; k += T)
                 rdst[k] = buf[k];

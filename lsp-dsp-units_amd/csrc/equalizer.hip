@@ -38,12 +38,15 @@ namespace
     {
         using PL = plan<LOGN>;
         constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N];
+        __shared__ float2 buf[N], scr[N];
         const int ch = blockIdx.x, tid = threadIdx.x;
+        fft_tw<LOGN> ft;
+        load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
+        finish_fft_tw<LOGN>(ft);
         for (int n = tid; n < N; n += T)
             buf[n] = make_float2(ir[size_t(ch) * ir_stride + n] * wnd_tail[n], 0.0f);
         __syncthreads();
-        fft_lds<LOGN, false>(buf, tw, TWN / N, tid);
+        fft_lds<LOGN, false>(buf, scr, ft, tid);
         for (int k = tid; k < N; k += T)
             mag[size_t(ch) * N + k] = sqrtf(buf[k].x * buf[k].x + buf[k].y * buf[k].y);
     }
@@ -56,12 +59,15 @@ namespace
     {
         using PL = plan<LOGN>;
         constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N];
+        __shared__ float2 buf[N], scr[N];
         const int ch = blockIdx.x, tid = threadIdx.x;
+        fft_tw<LOGN> ft;
+        load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
+        finish_fft_tw<LOGN>(ft);
         for (int k = tid; k < N; k += T)
             buf[k] = make_float2(mag[size_t(ch) * N + k], 0.0f);
         __syncthreads();
-        fft_lds<LOGN, true>(buf, tw, TWN / N, tid);
+        fft_lds<LOGN, true>(buf, scr, ft, tid);
         const float scale = 1.0f / float(N);
         for (int i = tid; i < N; i += T)
             taps[size_t(ch) * N + i] = buf[(i + N / 2) & (N - 1)].x * scale * wnd[i];

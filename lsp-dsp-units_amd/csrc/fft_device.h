@@ -2,16 +2,17 @@
 //
 // The transform is the autosort radix-4 decimation-in-frequency Stockham scheme with a final radix-2
 // pass when log2(N) is odd.  A workgroup of T threads owns one N-point complex sequence held in a single
-// LDS buffer: in every pass each thread pulls its butterflies' inputs into registers, the workgroup
-// synchronises, and the outputs are written back permuted (read index j + k*N/4 is conflict free; the write
-// index q + s*(4p + k) is the autosort permutation).  No bit reversal, no second buffer.
+// pair of LDS buffers: in every pass each thread pulls its butterflies' inputs from one buffer and writes the outputs
+// permuted into the other (read index j + k*N/4 is conflict free; the write index q + s*(4p + k) is the autosort
+// permutation, bank-swizzled in the intermediate passes).  No bit reversal, one barrier per pass.
 //
 // Conventions match the reference's dsp::packed_direct_fft / packed_reverse_fft: forward
 // is unnormalised with e^{-jwn}; the inverse here is ALSO unnormalised -- callers fold the 1/N into the
 // pass that follows it (window, overlap-add, ...), which is where the reference's 1/N ends up as well.
 //
 // Twiddles come from a table tw[j] = exp(-2*pi*i*j / TWN), TWN >= N a power of two (built on the host in
-// double precision); W_N^k = tw[k * (TWN / N)].
+// double precision); W_N^k = tw[k * (TWN / N)].  A thread fetches the few values it needs once per kernel, before
+// the samples, and keeps them in registers for every transform of the kernel.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -27,6 +28,37 @@ namespace mi_fft
     __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
     __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 
+    // Packed-fp32 forms for the butterflies: a complex value is one 64-bit register pair, add/sub are one
+    // v_pk_add_f32, a complex product is v_pk_mul_f32 + v_pk_fma_f32 (half swaps and sign flips fold into the
+    // instructions' op_sel / neg modifiers).  The transforms are VALU-issue bound, so instruction count is what matters.
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    // complex a * b (CONJ_A: conj(a) * b).  op_sel picks the half that feeds the low lane, op_sel_hi the high lane:
+    //   t = (a.x b.x, a.x b.y);   r = (t.x -+ a.y b.y, t.y +- a.y b.x)
+    template <bool CONJ_A>
+    __device__ __forceinline__ v2f pmul(v2f a, v2f b)
+    {
+        v2f t, r;
+        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
+        if (CONJ_A)
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_hi:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+        else
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
+        return r;
+    }
+    // a + i b (PLUS_I) or a - i b:  (a.x -+ b.y, a.y +- b.x) in one v_pk_add_f32
+    template <bool PLUS_I>
+    __device__ __forceinline__ v2f padd_i(v2f a, v2f b)
+    {
+        v2f r;
+        if (PLUS_I)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        else
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+    }
+    __device__ __forceinline__ v2f ld2(const float2 *p) { return *reinterpret_cast<const v2f *>(p); }
+    __device__ __forceinline__ void st2(float2 *p, v2f v) { *reinterpret_cast<v2f *>(p) = v; }
+
     // Number of threads that cooperate on one N = 2^LOGN point transform.
     template <int LOGN>
     struct plan
@@ -36,82 +68,146 @@ namespace mi_fft
         static constexpr int BPT = (N / 4 + T - 1) / T;         // radix-4 butterflies per thread and pass
     };
 
-    // buf: N complex points in LDS.  All T threads of the workgroup must call this (it synchronises).
-    // On entry the caller must have synchronised after filling buf; on exit buf is complete and synchronised.
-    template <int LOGN, bool INVERSE>
-    __device__ void fft_lds(float2 *buf, const float2 *__restrict__ tw, int tw_stride /* TWN / N */, int tid)
+    // Bank swizzle of the intermediate passes: the autosort write index q + s*(4p + k) has a stride of 4 (s = 1) or
+    // 16 (s = 4) complex values between neighbouring lanes -- an 8-way LDS bank conflict in the first two passes.
+    // XOR-ing the low four index bits with the next four spreads those writes over all banks; reads of 16 consecutive
+    // values stay a permutation of the same 16 slots.  First read and last write of a transform use natural order.
+    template <int N>
+    __device__ __forceinline__ int swz(int i) { return (N >= 256) ? (i ^ ((i >> 4) & 15)) : i; }
+
+    // Twiddles of every radix-4 pass for the butterflies this thread owns, fetched once (ideally long before the
+    // transform: the table lives in global memory) and reused by the forward and the inverse transform.
+    template <int LOGN>
+    struct fft_tw
+    {
+        v2f w[(LOGN / 2 > 0) ? LOGN / 2 : 1][plan<LOGN>::BPT][3];      // W^(p s), its square and cube
+    };
+
+    // Two steps, so that the table reads can be issued first thing in a kernel and their latency hidden behind the
+    // kernel's other loads: load_fft_tw() only requests W^(p s); finish_fft_tw() derives the square and the cube.
+    template <int LOGN>
+    __device__ __forceinline__ void load_fft_tw(fft_tw<LOGN> &r, const float2 *__restrict__ tw, int tw_stride /* TWN / N */, int tid)
     {
         using P = plan<LOGN>;
-        constexpr int N = P::N, T = P::T, BPT = P::BPT, Q = N / 4;
-
+        constexpr int T = P::T, BPT = P::BPT, Q = P::N / 4;
         int s = 1;
         #pragma unroll
         for (int pass = 0; pass < LOGN / 2; ++pass, s <<= 2)
+            #pragma unroll
+            for (int b = 0; b < BPT; ++b)
+            {
+                const int j = (tid + b * T) & (Q - 1);
+                if (s < Q)                                          // s == Q: p = 0, the twiddles are 1 and unused
+                    r.w[pass][b][0] = ld2(tw + (j & ~(s - 1)) * tw_stride);     // W_N^(p s), p = j / s
+            }
+    }
+
+    template <int LOGN>
+    __device__ __forceinline__ void finish_fft_tw(fft_tw<LOGN> &r)
+    {
+        using P = plan<LOGN>;
+        constexpr int BPT = P::BPT, Q = P::N / 4;
+        int s = 1;
+        #pragma unroll
+        for (int pass = 0; pass < LOGN / 2; ++pass, s <<= 2)
+            #pragma unroll
+            for (int b = 0; b < BPT; ++b)
+                if (s < Q)
+                {
+                    // one table value per butterfly; w^2 and w^3 by multiplication (2 roundings, ~1e-7)
+                    const v2f w1 = r.w[pass][b][0];
+                    const v2f w2 = pmul<false>(w1, w1);
+                    r.w[pass][b][1] = w2;
+                    r.w[pass][b][2] = pmul<false>(w2, w1);
+                }
+    }
+
+    // buf: N complex points in LDS in natural order, scr: N more.  All T threads of the workgroup must call this (it
+    // synchronises).  On entry the caller must have synchronised after filling buf; on exit the transform is in buf,
+    // natural order, synchronised.  One barrier per pass: the passes ping-pong between the two buffers (an odd number of
+    // passes starts with one in-place pass).
+    template <int LOGN, bool INVERSE>
+    __device__ void fft_lds(float2 *buf, float2 *scr, const fft_tw<LOGN> &tws, int tid)
+    {
+        using P = plan<LOGN>;
+        constexpr int N = P::N, T = P::T, BPT = P::BPT, Q = N / 4;
+        constexpr int NP4 = LOGN / 2, NP = NP4 + (LOGN & 1);
+
+        float2 *src = buf;
+        float2 *dst = (NP & 1) ? buf : scr;
+        int s = 1;
+        #pragma unroll
+        for (int pass = 0; pass < NP4; ++pass, s <<= 2)
         {
-            float2 v[BPT][4];
+            const bool first = (pass == 0), last = (pass == NP - 1);
+            v2f v[BPT][4];
             #pragma unroll
             for (int b = 0; b < BPT; ++b)
             {
                 const int j = tid + b * T;
                 if (j < Q)
                 {
-                    v[b][0] = buf[j];
-                    v[b][1] = buf[j + Q];
-                    v[b][2] = buf[j + 2 * Q];
-                    v[b][3] = buf[j + 3 * Q];
+                    #pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        v[b][k] = ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
                 }
             }
-            __syncthreads();
+            if (dst == src)
+                __syncthreads();
             #pragma unroll
             for (int b = 0; b < BPT; ++b)
             {
                 const int j = tid + b * T;
                 if (j < Q)
                 {
-                    const int p = j / s, q = j - p * s;          // s is a power of four: shifts
-                    const float2 a = v[b][0], bb = v[b][1], c = v[b][2], d = v[b][3];
-                    const float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(bb, d), bmd = csub(bb, d);
-                    // forward: -i*(b-d) ; inverse: +i*(b-d)
-                    const float2 jb = INVERSE ? make_float2(-bmd.y, bmd.x) : make_float2(bmd.y, -bmd.x);
-                    const int o = q + 4 * s * p;
-                    const int ti = p * s * tw_stride;
-                    // one table read per butterfly; w^2 and w^3 by multiplication (2 roundings, ~1e-7)
-                    float2 w1 = tw[ti];
-                    if (INVERSE)
-                        w1 = cconj(w1);
-                    const float2 w2 = cmul(w1, w1), w3 = cmul(w2, w1);
-                    buf[o]         = cadd(apc, bpd);
-                    buf[o + s]     = cmul(w1, cadd(amc, jb));
-                    buf[o + 2 * s] = cmul(w2, csub(apc, bpd));
-                    buf[o + 3 * s] = cmul(w3, csub(amc, jb));
+                    const int q = j & (s - 1);                       // s is a power of four
+                    const v2f a = v[b][0], bb = v[b][1], c = v[b][2], d = v[b][3];
+                    const v2f apc = a + c, amc = a - c, bpd = bb + d, bmd = bb - d;
+                    // forward: a-c -+ i (b-d) ; inverse: a-c +- i (b-d)
+                    const int o = q + 4 * (j - q);                   // q + 4 s p
+                    v2f r0 = apc + bpd, r1 = padd_i<INVERSE>(amc, bmd), r2 = apc - bpd, r3 = padd_i<!INVERSE>(amc, bmd);
+                    if (s < Q)                                       // s == Q: p = 0, all twiddles are 1
+                    {
+                        r1 = pmul<INVERSE>(tws.w[pass][b][0], r1);
+                        r2 = pmul<INVERSE>(tws.w[pass][b][1], r2);
+                        r3 = pmul<INVERSE>(tws.w[pass][b][2], r3);
+                    }
+                    st2(dst + (last ? o         : swz<N>(o)),         r0);
+                    st2(dst + (last ? o + s     : swz<N>(o + s)),     r1);
+                    st2(dst + (last ? o + 2 * s : swz<N>(o + 2 * s)), r2);
+                    st2(dst + (last ? o + 3 * s : swz<N>(o + 3 * s)), r3);
                 }
             }
             __syncthreads();
+            src = dst;
+            dst = (src == buf) ? scr : buf;
         }
-        if (LOGN & 1)           // one radix-2 pass left: pairs (j, j + N/2), stride N/2, no twiddle
+        if (LOGN & 1)           // one radix-2 pass left: pairs (j, j + N/2), stride N/2, no twiddle; always the last pass
         {
             constexpr int H = N / 2;
             constexpr int PPT = (H + T - 1) / T;
-            float2 a[PPT], b2[PPT];
+            constexpr bool first = (NP4 == 0);
+            v2f a[PPT], b2[PPT];
             #pragma unroll
             for (int b = 0; b < PPT; ++b)
             {
                 const int j = tid + b * T;
                 if (j < H)
                 {
-                    a[b]  = buf[j];
-                    b2[b] = buf[j + H];
+                    a[b]  = ld2(src + (first ? j : swz<N>(j)));
+                    b2[b] = ld2(src + (first ? j + H : swz<N>(j + H)));
                 }
             }
-            __syncthreads();
+            if (dst == src)
+                __syncthreads();
             #pragma unroll
             for (int b = 0; b < PPT; ++b)
             {
                 const int j = tid + b * T;
                 if (j < H)
                 {
-                    buf[j]     = cadd(a[b], b2[b]);
-                    buf[j + H] = csub(a[b], b2[b]);
+                    st2(dst + j, a[b] + b2[b]);
+                    st2(dst + j + H, a[b] - b2[b]);
                 }
             }
             __syncthreads();
@@ -124,29 +220,48 @@ namespace mi_fft
     //   img[0] = (X[0], X[M])  (both real),  img[k] = X[k], 0 < k < M.
     // rtw[k] = exp(-i*pi*k/M) = tw2m[k] with tw2m the 2M-point table.
 
+    // The split/merge twiddles e^{-i pi k / M} of the pairs (k, M-k) this thread owns, k = tid + i*T < M/2.
+    template <int LOGM>
+    struct real_tw
+    {
+        static constexpr int ITER = (plan<LOGM>::N / 2 + plan<LOGM>::T - 1) / plan<LOGM>::T;
+        float2 w[ITER];
+    };
+
+    template <int LOGM>
+    __device__ __forceinline__ void load_real_tw(real_tw<LOGM> &r, const float2 *__restrict__ tw2m, int tw_stride /* TWN / 2M */, int tid)
+    {
+        constexpr int M = plan<LOGM>::N, T = plan<LOGM>::T;
+        #pragma unroll
+        for (int i = 0; i < real_tw<LOGM>::ITER; ++i)
+            r.w[i] = tw2m[((tid + i * T) & (M / 2 - 1)) * tw_stride];
+    }
+
     // Z (the M-point transform of z[n] = x[2n] + i x[2n+1], in buf) -> image, in place.
     template <int LOGM>
-    __device__ void real_split(float2 *buf, const float2 *__restrict__ tw2m, int tw_stride /* TWN / 2M */, int tid)
+    __device__ void real_split(float2 *buf, const real_tw<LOGM> &rt, int tid)
     {
         using P = plan<LOGM>;
         constexpr int M = P::N, T = P::T;
         // pairs (k, M-k), k = 1 .. M/2 - 1; k = 0 and k = M/2 are their own partners
-        for (int k = tid; k <= M / 2; k += T)
+        #pragma unroll
+        for (int i = 0; i < real_tw<LOGM>::ITER; ++i)
         {
+            const int k = tid + i * T;
+            if (k >= M / 2)
+                continue;
             if (k == 0)
             {
                 const float2 z0 = buf[0];
                 buf[0] = make_float2(z0.x + z0.y, z0.x - z0.y);
+                buf[M / 2] = cconj(buf[M / 2]);
             }
-            else if (k == M / 2)
-                buf[k] = cconj(buf[k]);
             else
             {
                 const float2 zk = buf[k], zm = buf[M - k];
-                const float2 w  = tw2m[k * tw_stride];                    // e^{-i pi k / M}
+                const float2 w  = rt.w[i];                                // e^{-i pi k / M}
                 const float2 e  = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));   // (Zk + conj Zm)/2
                 const float2 o  = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));   // (Zk - conj Zm)/2
-                // X[k]   = e - i w o ;  X[M-k] = conj(e) - i (-conj w) conj(o) = conj(e + i w o) ... written out:
                 const float2 wo = cmul(w, o);
                 buf[k]     = make_float2(e.x + wo.y, e.y - wo.x);         // e - i*wo
                 buf[M - k] = make_float2(e.x - wo.y, -(e.y + wo.x));      // conj(e + i*wo)
@@ -156,29 +271,30 @@ namespace mi_fft
     }
 
     // image (in buf) -> Z such that the UNNORMALISED inverse M-point transform of Z gives
-    // z[n] = M * (x[2n] + i x[2n+1]) * ... : with the factors used here  ifft_unnorm(Z)[n] = 2M * (x[2n] + i x[2n+1])
-    // where x is the real 2M-point sequence whose UNNORMALISED forward transform is the image.
+    // ifft_unnorm(Z)[n] = 2M * (x[2n] + i x[2n+1]) where x is the real 2M-point sequence whose UNNORMALISED forward
+    // transform is the image.
     template <int LOGM>
-    __device__ void real_merge(float2 *buf, const float2 *__restrict__ tw2m, int tw_stride, int tid)
+    __device__ void real_merge(float2 *buf, const real_tw<LOGM> &rt, int tid)
     {
         using P = plan<LOGM>;
         constexpr int M = P::N, T = P::T;
-        for (int k = tid; k <= M / 2; k += T)
+        #pragma unroll
+        for (int i = 0; i < real_tw<LOGM>::ITER; ++i)
         {
+            const int k = tid + i * T;
+            if (k >= M / 2)
+                continue;
             if (k == 0)
             {
                 const float2 y0 = buf[0];                                 // (X0, XM)
                 buf[0] = make_float2(y0.x + y0.y, y0.x - y0.y);
-            }
-            else if (k == M / 2)
-            {
-                const float2 y = buf[k];
-                buf[k] = make_float2(2.0f * y.x, -2.0f * y.y);
+                const float2 y = buf[M / 2];
+                buf[M / 2] = make_float2(2.0f * y.x, -2.0f * y.y);
             }
             else
             {
                 const float2 xk = buf[k], xm = buf[M - k];
-                const float2 w  = cconj(tw2m[k * tw_stride]);             // e^{+i pi k / M}
+                const float2 w  = cconj(rt.w[i]);                         // e^{+i pi k / M}
                 const float2 e  = make_float2(xk.x + xm.x, xk.y - xm.y);  // Xk + conj Xm
                 const float2 o  = make_float2(xk.x - xm.x, xk.y + xm.y);  // Xk - conj Xm
                 const float2 wo = cmul(w, o);
@@ -188,4 +304,33 @@ namespace mi_fft
         }
         __syncthreads();
     }
+
+    // A 2M-point real transform pair through M-point complex transforms: twiddles in registers, two LDS buffers.
+    template <int LOGM>
+    struct real_fft
+    {
+        fft_tw<LOGM>  ft;
+        real_tw<LOGM> rt;
+
+        __device__ __forceinline__ void load(const float2 *__restrict__ tw, int twn, int tid)
+        {
+            constexpr int M = plan<LOGM>::N;
+            load_fft_tw<LOGM>(ft, tw, twn / M, tid);
+            load_real_tw<LOGM>(rt, tw, twn / (2 * M), tid);
+        }
+        // after the kernel's other loads have been issued, before the first transform
+        __device__ __forceinline__ void prepare() { finish_fft_tw<LOGM>(ft); }
+        // packed samples z[n] = x[2n] + i x[2n+1] in buf -> image in buf
+        __device__ __forceinline__ void forward(float2 *buf, float2 *scr, int tid) const
+        {
+            fft_lds<LOGM, false>(buf, scr, ft, tid);
+            real_split<LOGM>(buf, rt, tid);
+        }
+        // image in buf -> 2M real samples (times 2M), left in buf as (x[2n], x[2n+1])
+        __device__ __forceinline__ void inverse(float2 *buf, float2 *scr, int tid) const
+        {
+            real_merge<LOGM>(buf, rt, tid);
+            fft_lds<LOGM, true>(buf, scr, ft, tid);
+        }
+    };
 } // namespace mi_fft

@@ -26,6 +26,38 @@ namespace mi
     int         fft_twiddles(const float2 **tw, int *twn);
 } // namespace mi
 
+#if defined(__HIPCC__)
+namespace mi
+{
+    // Write-through (sc1) stores through a raw buffer descriptor: output that nobody on this device reads again soon
+    // leaves the XCD's L2 while the kernel is still running instead of in one write-back burst when it ends
+    // (MI355X_MICROARCH.md, "publish-large").  Builtins, not inline asm: the compiler's vmcnt bookkeeping sees them.
+    constexpr int BUFFER_DWORD3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
+    constexpr int CPOL_SC1 = 16;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+    __device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_buffer(void *base, unsigned bytes)
+    {
+        return __builtin_amdgcn_make_buffer_rsrc(base, 0, int(bytes), BUFFER_DWORD3);
+    }
+    __device__ __forceinline__ void wt_store(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, float v)
+    {
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, byte_offset, 0, CPOL_SC1);
+    }
+    __device__ __forceinline__ void wt_store(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, float2 v)
+    {
+        const u32x2 d = { __float_as_uint(v.x), __float_as_uint(v.y) };
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, byte_offset, 0, CPOL_SC1);
+    }
+    __device__ __forceinline__ void wt_store(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, float4 v)
+    {
+        const u32x4 d = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
+        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, byte_offset, 0, CPOL_SC1);
+    }
+} // namespace mi
+#endif
+
 #define MI_HIP_CHECK(expr)                                                              \
     do {                                                                                \
         hipError_t mi_err__ = (expr);                                                   \

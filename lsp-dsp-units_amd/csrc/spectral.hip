@@ -38,8 +38,14 @@ namespace
     {
         using PL = plan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 buf[H];
+        __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
+        real_fft<LOGH> rf;
+        if (MODE == 1 || MODE == 2)
+        {
+            rf.load(tw, TWN, tid);
+            rf.prepare();
+        }
         float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * N);
         float2 *o2 = reinterpret_cast<float2 *>(out_buf + size_t(ch) * N);
         const float2 *wi = reinterpret_cast<const float2 *>(wnd_in);
@@ -62,10 +68,7 @@ namespace
             }
             __syncthreads();
             if (MODE != 0 && on)
-            {
-                fft_lds<LOGH, false>(buf, tw, TWN / H, tid);
-                real_split<LOGH>(buf, tw, TWN / N, tid);
-            }
+                rf.forward(buf, scr, tid);
         }
         if (MODE == 1 && on)
         {
@@ -78,8 +81,7 @@ namespace
                 buf[k] = v;
             }
             __syncthreads();
-            real_merge<LOGH>(buf, tw, TWN / N, tid);
-            fft_lds<LOGH, true>(buf, tw, TWN / H, tid);
+            rf.inverse(buf, scr, tid);
         }
         if (MODE == 2)
         {
@@ -143,9 +145,12 @@ namespace
     {
         using PL = plan<LOGN>;
         constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N];
+        __shared__ float2 buf[N], scr[N];
         const int ch = blockIdx.x, tid = threadIdx.x;
         const bool on = ((active == nullptr) || (active[ch] != 0)) && ((has_out == nullptr) || (has_out[ch] != 0));
+        fft_tw<LOGN> ft;
+        load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
+        finish_fft_tw<LOGN>(ft);
         const float2 *sp = spec + size_t(ch) * N;
         float *ob = out_buf + size_t(ch) * N;
         float *ib = in_buf + size_t(ch) * N;
@@ -154,7 +159,7 @@ namespace
             for (int k = tid; k < N; k += T)
                 buf[k] = sp[k];
             __syncthreads();
-            fft_lds<LOGN, true>(buf, tw, TWN / N, tid);
+            fft_lds<LOGN, true>(buf, scr, ft, tid);
         }
         const float scale = 1.0f / float(N);
         const float *sr = reinterpret_cast<const float *>(sp);
@@ -185,7 +190,7 @@ namespace
     {
         using PL = plan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 buf[H];
+        __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
         const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
         float *a = amp + size_t(ch) * amp_stride;
@@ -197,31 +202,57 @@ namespace
                 a[k] = 0.0f;
             return;
         }
+        // request order = order of use: twiddles, the frame, then the spectrum being smoothed (one exposed HBM latency)
+        real_fft<LOGH> rf;
+        rf.load(tw, TWN, tid);
+        constexpr int KPT = (H + T - 1) / T;
         // Analyzer.cpp:339-353: doff = head - (fft_size + delay), wrapped into the ring
         int64_t doff = int64_t(head) - int64_t(N) - int64_t(delay[ch]);
         while (doff < 0)
             doff += buf_size;
         const float *rb = ring + size_t(ch) * buf_size;
-        for (int m = tid; m < H; m += T)
+        const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
+        float2 xin[KPT], win[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
         {
-            uint32_t i0 = uint32_t(doff) + 2 * m, i1 = i0 + 1;
+            const int m = (tid + i * T) & (H - 1);
+            uint32_t i0 = uint32_t(doff) + 2 * m;
             if (i0 >= buf_size) i0 -= buf_size;
-            if (i1 >= buf_size) i1 -= buf_size;
-            buf[m] = make_float2(rb[i0] * wnd[2 * m], rb[i1] * wnd[2 * m + 1]);
+            if (i0 + 1 < buf_size)
+                xin[i] = *reinterpret_cast<const float2 *>(rb + i0);     // 4-byte aligned 8-byte load
+            else
+                xin[i] = make_float2(rb[i0], rb[0]);
+            win[i] = w2[m];
         }
+        float aold[KPT], aold_h = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            aold[i] = (tid + i * T < H) ? a[tid + i * T] : 0.0f;
+        if (tid == 0)
+            aold_h = a[H];
+        rf.prepare();
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            if (tid + i * T < H)
+                buf[tid + i * T] = make_float2(xin[i].x * win[i].x, xin[i].y * win[i].y);
         __syncthreads();
-        fft_lds<LOGH, false>(buf, tw, TWN / H, tid);
-        real_split<LOGH>(buf, tw, TWN / N, tid);
+        rf.forward(buf, scr, tid);
         // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
         const float keep = 1.0f - tau;
-        for (int k = tid; k <= H; k += T)
+        const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(a, unsigned((H + 1) * sizeof(float)));
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
         {
-            float mag;
-            if (k == 0)       mag = fabsf(buf[0].x);
-            else if (k == H)  mag = fabsf(buf[0].y);
-            else              mag = sqrtf(buf[k].x * buf[k].x + buf[k].y * buf[k].y);
-            a[k] = a[k] * keep + mag * tau;
+            const int k = tid + i * T;
+            if (k >= H)
+                break;
+            const float2 v = buf[k];
+            const float mag = (k == 0) ? fabsf(v.x) : sqrtf(v.x * v.x + v.y * v.y);
+            mi::wt_store(ramp, 4 * k, aold[i] * keep + mag * tau);
         }
+        if (tid == 0)
+            mi::wt_store(ramp, 4 * H, aold_h * keep + fabsf(buf[0].y) * tau);
     }
 
     // Per-bin reduction over channels (the C5 callback), deterministic two-stage sum:
