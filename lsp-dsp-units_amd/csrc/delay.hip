@@ -68,6 +68,27 @@ namespace
         }
     }
 
+    // Blocks no longer than the shortest delay of the bank (and than size - longest delay): no cell read in this call
+    // is written in this call, so "push then pull" collapses into one pass, in place or not:
+    //   v = ring[(tail + i) % size];  ring[(head + i) % size] = src[i];  dst[i] (+)= gain * v
+    __global__ __launch_bounds__(256)
+    void delay_exchange_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, float *ring,
+                               uint32_t size, uint32_t head, const uint32_t *__restrict__ delay, size_t count,
+                               int add, int gmode, float k, const float *gv, size_t gv_stride)
+    {
+        const uint32_t ch = blockIdx.y;
+        const uint32_t tail = (head + size - delay[ch]) % size;
+        float *r = ring + size_t(ch) * size;
+        for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+        {
+            const float x = src[size_t(ch) * src_stride + i];
+            const float v = apply_gain(r[(tail + i) % size], gmode, k, gv + size_t(ch) * gv_stride, i);
+            r[(head + i) % size] = x;
+            float *o = dst + size_t(ch) * dst_stride + i;
+            *o = add ? *o + v : v;
+        }
+    }
+
     // Delay::process_ramping (Delay.cpp:399-546): the read position slides from the old delay to the new one.
     // Reproduces the reference's chunked write-then-read order in closed form: the sample read at output offset o
     // is the newest input written to that ring cell by the end of o's chunk, else the cell's old content.
@@ -293,6 +314,21 @@ int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_
     // The reference alternates "push to_do samples / pull to_do samples" in pieces of at most size - delay
     // (Delay.cpp:113-142) so that a pull never reads a cell a later push of the same call already overwrote.
     // Same order here, with the piece bounded by the largest delay of the bank.
+    uint32_t dmin = UINT32_MAX, dmax = 0;
+    for (uint32_t d : b->delay)
+    {
+        dmin = (d < dmin) ? d : dmin;
+        dmax = (d > dmax) ? d : dmax;
+    }
+    if (count <= dmin && count <= size_t(b->size - dmax))
+    {
+        hipLaunchKernelGGL(delay_exchange_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+                           out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
+                           gain, gain_vec, gain_stride);
+        MI_HIP_CHECK(hipGetLastError());
+        b->head = uint32_t((size_t(b->head) + count) % b->size);
+        return MI_OK;
+    }
     if (static_cast<const void *>(out) != static_cast<const void *>(in))
     {
         hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, b->channels), dim3(256), 0, st,
@@ -301,9 +337,6 @@ int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_
         MI_HIP_CHECK(hipGetLastError());
         return append(b, in, in_stride, count, st);
     }
-    uint32_t dmax = 0;
-    for (uint32_t d : b->delay)
-        dmax = (d > dmax) ? d : dmax;
     const size_t gap = b->size - dmax;
     size_t done = 0;
     while (done < count)

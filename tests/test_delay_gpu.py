@@ -71,6 +71,40 @@ def test_delay_process_variants_bit_exact(gpu, in_place):
 
 
 @pytest.mark.parametrize("in_place", [False, True])
+def test_delay_short_blocks_single_pass_bit_exact(gpu, in_place):
+    """Blocks no longer than the shortest delay (and than size - longest delay) take the one-kernel exchange path
+    (delay_exchange_kernel): same samples as the reference's push/pull order, in place or not, with wrap-around."""
+    rng = np.random.default_rng(3)
+    C, maxd = 4, 1000
+    delays = [300, 512, 700, 1000]
+    x = rng.standard_normal((C, 4000)).astype(np.float32)
+    g = rng.uniform(0.5, 2.0, (C, 4000)).astype(np.float32)
+    base = rng.standard_normal((C, 4000)).astype(np.float32)
+    bank = gpu.DelayBank(C, maxd)
+    refs = [od.Delay(maxd) for _ in range(C)]
+    for c, d in enumerate(delays):
+        bank.set_delay(d, c); refs[c].set_delay(d)
+    pos = 0
+    for n, mode in ((300, "plain"), (256, "scalar"), (300, "vector"), (299, "add"), (300, "plain"), (300, "plain"),
+                    (300, "scalar"), (1, "plain"), (300, "add"), (300, "plain")):
+        xs, gs, bs = x[:, pos:pos + n], g[:, pos:pos + n], base[:, pos:pos + n]
+        din = gpu.DeviceBuffer.from_host(xs)
+        dout = din if (in_place and mode != "add") else gpu.DeviceBuffer.from_host(bs)
+        dg = gpu.DeviceBuffer.from_host(gs)
+        if mode == "plain":
+            bank.process(dout, din, n); ref = [r.process(xs[c]) for c, r in enumerate(refs)]
+        elif mode == "scalar":
+            bank.process(dout, din, n, gain=0.37); ref = [r.process(xs[c], gain=0.37) for c, r in enumerate(refs)]
+        elif mode == "vector":
+            bank.process(dout, din, n, gain_vec=dg); ref = [r.process(xs[c], gain=gs[c]) for c, r in enumerate(refs)]
+        else:
+            bank.process(dout, din, n, add=True); ref = [r.process(xs[c], add_to=bs[c]) for c, r in enumerate(refs)]
+        np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg="%s at %d" % (mode, pos))
+        pos += n
+    bank.close()
+
+
+@pytest.mark.parametrize("in_place", [False, True])
 def test_delay_ramping_bit_exact(gpu, in_place):
     """Delay::process_ramping index (old_tail + ssize_t(delta * offset)) % size, incl. pieces and wrap."""
     rng = np.random.default_rng(2)
