@@ -181,25 +181,47 @@ namespace
 
     // ---- analyzer -------------------------------------------------------------------------------------------
     // ring: [channels][buf_size]; the frame of channel c ends `delay[c]` samples before `head`.
+    // amp_old: vAmp as of the strobe (what get_spectrum() shows until the next strobe: the reference copies vAmp to vData
+    // at the strobe, Analyzer.cpp:321-326 -- here the two buffers swap roles instead); amp_new: vAmp after this analysis.
+    // ingest: `ingest_n` new samples per channel go into the ring behind `head` in the same launch (the "fill the
+    // buffer" half of Analyzer::process, Analyzer.cpp:371-398; they lie outside every analysis window of this strobe).
     template <int LOGH>
     __global__ __launch_bounds__(plan<LOGH>::T)
-    void analyzer_kernel(const float *__restrict__ ring, uint32_t buf_size, uint32_t head,
+    void analyzer_kernel(float *ring, uint32_t buf_size, uint32_t head,
                          const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
-                         const float *__restrict__ wnd, float *amp, uint32_t amp_stride, float tau,
-                         const float2 *__restrict__ tw)
+                         const float *__restrict__ wnd, const float *__restrict__ amp_old, float *amp_new,
+                         uint32_t amp_stride, float tau, const float2 *__restrict__ tw,
+                         const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero)
     {
         using PL = plan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
         __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
         const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
-        float *a = amp + size_t(ch) * amp_stride;
-        if (fl & 2)                                         // frozen: keep vAmp (Analyzer.cpp:334)
+        const float *a = amp_old + size_t(ch) * amp_stride;
+        float *an = amp_new + size_t(ch) * amp_stride;
+        float *rbw = ring + size_t(ch) * buf_size;
+        // the new samples are requested now and stored at the very end
+        constexpr int IPT = 4;                              // up to 4*T samples per pass
+        if (ingest_n > 0 && ((fl & 2) || !(fl & 1)))        // channels that skip the analysis still take their samples
+        {
+            for (uint32_t i = tid; i < ingest_n; i += T)
+            {
+                uint32_t w = head + i;
+                if (w >= buf_size) w -= buf_size;
+                rbw[w] = ingest_zero ? 0.0f : ingest[size_t(ch) * ingest_stride + i];
+            }
+        }
+        if (fl & 2)                                         // frozen: vAmp stays (Analyzer.cpp:334)
+        {
+            for (int k = tid; k <= H; k += T)
+                an[k] = a[k];
             return;
+        }
         if (!(fl & 1))                                      // inactive: vAmp = 0 (Analyzer.cpp:363-364)
         {
             for (int k = tid; k <= H; k += T)
-                a[k] = 0.0f;
+                an[k] = 0.0f;
             return;
         }
         // request order = order of use: twiddles, the frame, then the spectrum being smoothed (one exposed HBM latency)
@@ -210,7 +232,7 @@ namespace
         int64_t doff = int64_t(head) - int64_t(N) - int64_t(delay[ch]);
         while (doff < 0)
             doff += buf_size;
-        const float *rb = ring + size_t(ch) * buf_size;
+        const float *rb = rbw;
         const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
         float2 xin[KPT], win[KPT];
         #pragma unroll
@@ -240,7 +262,7 @@ namespace
         rf.forward(buf, scr, tid);
         // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
         const float keep = 1.0f - tau;
-        const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(a, unsigned((H + 1) * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(an, unsigned((H + 1) * sizeof(float)));
         #pragma unroll
         for (int i = 0; i < KPT; ++i)
         {
@@ -253,38 +275,70 @@ namespace
         }
         if (tid == 0)
             mi::wt_store(ramp, 4 * H, aold_h * keep + fabsf(buf[0].y) * tau);
+        // ring ingest: cells head .. head + ingest_n - 1 (mod size), none of them inside a window read above
+        if (ingest_n > 0)
+        {
+            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+            for (uint32_t i0 = 0; i0 < ingest_n; i0 += IPT * T)
+            {
+                float v[IPT];
+                #pragma unroll
+                for (int j = 0; j < IPT; ++j)
+                {
+                    const uint32_t i = i0 + tid + j * T;
+                    v[j] = (i < ingest_n && !ingest_zero) ? ingest[size_t(ch) * ingest_stride + i] : 0.0f;
+                }
+                #pragma unroll
+                for (int j = 0; j < IPT; ++j)
+                {
+                    const uint32_t i = i0 + tid + j * T;
+                    uint32_t w = head + i;
+                    if (w >= buf_size) w -= buf_size;
+                    if (i < ingest_n)
+                        mi::wt_store(rring, int(w * sizeof(float)), v[j]);
+                }
+            }
+        }
     }
 
-    // Per-bin reduction over channels (the C5 callback), deterministic two-stage sum:
-    //   stage 1: part[g][k] = sum of src[c][k] over the channels of group g   (grid: bins/256 x groups)
-    //   stage 2: out[k]     = (sum over groups of part[g][k]) * env[k]
-    constexpr uint32_t REDUCE_GROUPS = 64;
+    // Per-bin reduction over channels (the C5 callback), deterministic: a workgroup owns 64 bins; its 16 waves sum
+    // channels w, w+16, w+32, ... (256-B coalesced rows), then the 16 partial sums are added in wave order.
+    constexpr uint32_t REDUCE_BINS = 64, REDUCE_WAVES = 16;
 
-    __global__ __launch_bounds__(256)
-    void bin_reduce_stage1(float *part, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins)
-    {
-        const uint32_t k = blockIdx.x * 256 + threadIdx.x, g = blockIdx.y;
-        if (k >= bins)
-            return;
-        const uint32_t per = (channels + REDUCE_GROUPS - 1) / REDUCE_GROUPS;
-        const uint32_t c0 = g * per, c1 = (c0 + per < channels) ? c0 + per : channels;
-        float s = 0.0f;
-        for (uint32_t c = c0; c < c1; ++c)
-            s += src[size_t(c) * stride + k];
-        part[size_t(g) * stride + k] = s;
-    }
-
-    __global__ __launch_bounds__(256)
-    void bin_reduce_stage2(float *out, const float *__restrict__ part, uint32_t stride, uint32_t bins,
+    __global__ __launch_bounds__(REDUCE_BINS * REDUCE_WAVES)
+    void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins,
                            const float *__restrict__ env)
     {
-        const uint32_t k = blockIdx.x * 256 + threadIdx.x;
-        if (k >= bins)
-            return;
+        __shared__ float part[REDUCE_WAVES][REDUCE_BINS];
+        const uint32_t lane = threadIdx.x & (REDUCE_BINS - 1), w = threadIdx.x / REDUCE_BINS;
+        const uint32_t k = blockIdx.x * REDUCE_BINS + lane;
         float s = 0.0f;
-        for (uint32_t g = 0; g < REDUCE_GROUPS; ++g)
-            s += part[size_t(g) * stride + k];
-        out[k] = (env != nullptr) ? s * env[k] : s;
+        if (k < bins)
+        {
+            uint32_t c = w;
+            for (; c + 7 * REDUCE_WAVES < channels; c += 8 * REDUCE_WAVES)      // eight rows in flight
+            {
+                float v[8];
+                #pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    v[j] = src[size_t(c + j * REDUCE_WAVES) * stride + k];
+                #pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    s += v[j];
+            }
+            for (; c < channels; c += REDUCE_WAVES)
+                s += src[size_t(c) * stride + k];
+        }
+        part[w][lane] = s;
+        __syncthreads();
+        if (w == 0 && k < bins)
+        {
+            float t = 0.0f;
+            #pragma unroll
+            for (uint32_t g = 0; g < REDUCE_WAVES; ++g)
+                t += part[g][lane];
+            out[k] = (env != nullptr) ? t * env[k] : t;
+        }
     }
 
     // out[c][i] = data[c][idx[i]] * env[idx[i]]   (Analyzer::get_spectrum, Analyzer.cpp:443-456)
@@ -641,6 +695,14 @@ struct mi_analyzer_bank
     uint8_t    *d_flags = nullptr;
     const float2 *d_tw = nullptr;
     bool        meta_dirty = true;
+
+    uint32_t max_user_delay() const
+    {
+        uint32_t m = 0;
+        for (uint32_t d : user_delay)
+            m = (d > m) ? d : m;
+        return m;
+    }
 };
 
 namespace
@@ -694,13 +756,9 @@ namespace
 
     // One analysis pass for all channels at the strobe instant (the reference staggers the
     // channels over the period but every channel reads the window that ends at the strobe).
-    int analyzer_strobe(mi_analyzer_bank *b, hipStream_t st)
+    // One launch per strobe: the analysis of every channel plus the ingest of the `n` samples that follow the strobe.
+    int analyzer_strobe(mi_analyzer_bank *b, hipStream_t st, const float *in, size_t in_stride, uint32_t n, bool zero)
     {
-        const size_t csize = (size_t(1) << (b->rank - 1)) + 1;
-        // Analyzer.cpp:321-326: vData <- vAmp for every channel
-        MI_HIP_CHECK(hipMemcpyAsync(b->d_data, b->d_amp, size_t(b->channels) * b->bins_stride * sizeof(float),
-                                    hipMemcpyDeviceToDevice, st));
-        (void)csize;
         if (b->meta_dirty)
         {
             std::vector<uint32_t> d(b->channels);
@@ -717,10 +775,14 @@ namespace
             MI_HIP_CHECK(hipStreamSynchronize(st));
             b->meta_dirty = false;
         }
+        // Analyzer.cpp:321-326 (vData <- vAmp at the strobe): the buffers swap roles, the kernel reads the old vAmp
+        // (now vData) and writes the new one
+        std::swap(b->d_amp, b->d_data);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         #define MI_CALL(LH) hipExtLaunchKernelGGL((analyzer_kernel<LH>), dim3(b->channels), dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
-            b->d_ring, b->buf_size, b->head, b->d_delay, b->d_flags, b->d_wnd, b->d_amp, b->bins_stride, b->tau, b->d_tw)
+            b->d_ring, b->buf_size, b->head, b->d_delay, b->d_flags, b->d_wnd, b->d_data, b->d_amp, b->bins_stride, b->tau, \
+            b->d_tw, in, in_stride, n, zero ? 1 : 0)
         MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
@@ -872,29 +934,41 @@ int mi_analyzer_bank_process(mi_analyzer_bank_t *b, const float *in, size_t samp
     size_t offset = 0;
     while (offset < samples)                                // Analyzer.cpp:309-408
     {
-        if (b->counter == 0)
-        {
-            r = analyzer_strobe(b, st);
-            if (r != MI_OK)
-                return r;
-        }
         // run to the next strobe (channel analyses inside the period are folded into the strobe pass)
         size_t n = b->period - b->counter;
         n = (samples - offset < n) ? samples - offset : n;
-        size_t left = n, src = offset;
-        while (left > 0)                                    // ring ingest with wrap (Analyzer.cpp:371-398)
+        // the window of a strobe ends `delay` samples before head and is N long: the n cells behind head are free
+        const bool fits = size_t(b->buf_size) >= (size_t(1) << b->rank) + b->max_user_delay() + n;
+        if (b->counter == 0 && fits)
         {
-            const size_t piece = (left < b->buf_size - b->head) ? left : b->buf_size - b->head;
-            if (in != nullptr)
-                MI_HIP_CHECK(hipMemcpy2DAsync(b->d_ring + b->head, size_t(b->buf_size) * sizeof(float), in + src,
-                                              in_stride * sizeof(float), piece * sizeof(float), b->channels,
-                                              hipMemcpyDeviceToDevice, st));
-            else
-                MI_HIP_CHECK(hipMemset2DAsync(b->d_ring + b->head, size_t(b->buf_size) * sizeof(float), 0,
-                                              piece * sizeof(float), b->channels, st));
-            b->head = uint32_t((b->head + piece) % b->buf_size);
-            left -= piece;
-            src += piece;
+            r = analyzer_strobe(b, st, (in != nullptr) ? in + offset : nullptr, in_stride, uint32_t(n), in == nullptr);
+            if (r != MI_OK)
+                return r;
+            b->head = uint32_t((b->head + n) % b->buf_size);
+        }
+        else
+        {
+            if (b->counter == 0)
+            {
+                r = analyzer_strobe(b, st, nullptr, 0, 0, false);
+                if (r != MI_OK)
+                    return r;
+            }
+            size_t left = n, src = offset;
+            while (left > 0)                                // ring ingest with wrap (Analyzer.cpp:371-398)
+            {
+                const size_t piece = (left < b->buf_size - b->head) ? left : b->buf_size - b->head;
+                if (in != nullptr)
+                    MI_HIP_CHECK(hipMemcpy2DAsync(b->d_ring + b->head, size_t(b->buf_size) * sizeof(float), in + src,
+                                                  in_stride * sizeof(float), piece * sizeof(float), b->channels,
+                                                  hipMemcpyDeviceToDevice, st));
+                else
+                    MI_HIP_CHECK(hipMemset2DAsync(b->d_ring + b->head, size_t(b->buf_size) * sizeof(float), 0,
+                                                  piece * sizeof(float), b->channels, st));
+                b->head = uint32_t((b->head + piece) % b->buf_size);
+                left -= piece;
+                src += piece;
+            }
         }
         offset += n;
         b->counter += uint32_t(n);
@@ -923,12 +997,8 @@ int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *b, float *out, int with_env
     MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_reduce_bins: bad argument");
     hipStream_t st = mi::as_stream(stream);
     const uint32_t bins = (1u << (b->rank - 1)) + 1;
-    if (b->d_part == nullptr)
-        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_part), size_t(REDUCE_GROUPS) * b->bins_stride * sizeof(float)));
-    hipLaunchKernelGGL(bin_reduce_stage1, dim3((bins + 255) / 256, REDUCE_GROUPS), dim3(256), 0, st,
-                       b->d_part, b->d_amp, b->bins_stride, b->channels, bins);
-    hipLaunchKernelGGL(bin_reduce_stage2, dim3((bins + 255) / 256), dim3(256), 0, st,
-                       out, b->d_part, b->bins_stride, bins, with_envelope ? b->d_env : nullptr);
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3((bins + REDUCE_BINS - 1) / REDUCE_BINS), dim3(REDUCE_BINS * REDUCE_WAVES), 0, st,
+                       out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
