@@ -9,6 +9,7 @@
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Analyzer.h>
@@ -710,6 +711,234 @@ size_t SpectralProcessor::remaining() const
 
 void SpectralProcessor::dump(IStateDumper *v) const
 {
+    v->write("nRank", get_rank());
+}
+
+// ---- MultiSpectralProcessor -------------------------------------------------------------------------------------
+struct MultiSpectralProcessor::impl_t
+{
+    mi_spectral_bank_t *bank = nullptr;
+    size_t  channels = 0, max_rank = 0, rank = 0;
+    float   phase = 0.0f;
+    bool    update = true;
+    multi_spectral_processor_func_t func = nullptr;
+    void   *object = nullptr, *subject = nullptr;
+    std::vector<const float *> in;          // bound pointers, advanced by process() (MultiSpectralProcessor.cpp:310-320)
+    std::vector<float *>       out;
+    std::vector<uint8_t>       has_in, has_out;
+    std::vector<float>         host_io, host_spec;
+    std::vector<float *>       spec_ptr;
+    float  *d_in = nullptr, *d_out = nullptr;
+    size_t  cap = 0;
+
+    bool reserve(size_t count)
+    {
+        if (count <= cap)
+            return true;
+        mi_dspu_free(d_in); mi_dspu_free(d_out);
+        d_in = d_out = nullptr;
+        cap = 0;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_in), channels * count * sizeof(float)) != MI_OK) return false;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_out), channels * count * sizeof(float)) != MI_OK) return false;
+        cap = count;
+        return true;
+    }
+
+    // device-side hook: bring all spectra to the host, run the user's handler on the per-channel pointers, send them back
+    static void trampoline(void *object, void *, float *spectrum, size_t rank, size_t channels, void *stream)
+    {
+        impl_t *p = static_cast<impl_t *>(object);
+        const size_t floats = size_t(2) << rank;
+        p->host_spec.resize(floats * channels);
+        if (mi_dspu_copy_d2h(p->host_spec.data(), spectrum, floats * channels * sizeof(float), stream) != MI_OK ||
+            mi_dspu_stream_synchronize(stream) != MI_OK)
+            return;
+        p->spec_ptr.resize(channels);
+        for (size_t i = 0; i < channels; ++i)
+            p->spec_ptr[i] = p->has_in[i] ? &p->host_spec[i * floats] : nullptr;    // MultiSpectralProcessor.cpp:338-350
+        p->func(p->object, p->subject, p->spec_ptr.data(), rank);
+        mi_dspu_copy_h2d(spectrum, p->host_spec.data(), floats * channels * sizeof(float), stream);
+        mi_dspu_stream_synchronize(stream);
+    }
+};
+
+MultiSpectralProcessor::MultiSpectralProcessor() : pImpl(nullptr) { construct(); }
+MultiSpectralProcessor::~MultiSpectralProcessor() { destroy(); }
+void MultiSpectralProcessor::construct() { pImpl = nullptr; }
+
+bool MultiSpectralProcessor::init(size_t channels, size_t max_rank)
+{
+    if (channels <= 0)                                      // MultiSpectralProcessor.cpp:62-63
+        return false;
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    const uint32_t cap = uint32_t(std::min<size_t>(std::max<size_t>(max_rank, 5), 13));
+    if (mi_spectral_bank_create(&p->bank, uint32_t(channels), cap) != MI_OK)
+    {
+        delete p;
+        return false;
+    }
+    destroy();
+    p->channels = channels;
+    p->max_rank = max_rank;
+    p->rank = max_rank;
+    p->in.assign(channels, nullptr);
+    p->out.assign(channels, nullptr);
+    p->has_in.assign(channels, 0);
+    p->has_out.assign(channels, 0);
+    pImpl = p;
+    return true;
+}
+
+void MultiSpectralProcessor::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_spectral_bank_destroy(pImpl->bank);
+    mi_dspu_free(pImpl->d_in);
+    mi_dspu_free(pImpl->d_out);
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+void MultiSpectralProcessor::bind_handler(multi_spectral_processor_func_t func, void *object, void *subject)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->func = func;
+    pImpl->object = object;
+    pImpl->subject = subject;
+    if (func != nullptr)
+        mi_spectral_bank_bind(pImpl->bank, &impl_t::trampoline, pImpl, nullptr);
+    else
+        mi_spectral_bank_unbind(pImpl->bank);
+}
+
+void MultiSpectralProcessor::unbind_handler() { bind_handler(nullptr, nullptr, nullptr); }
+
+status_t MultiSpectralProcessor::bind(size_t index, float *out, const float *in)
+{
+    if (pImpl == nullptr)
+        return STATUS_BAD_STATE;
+    if (index >= pImpl->channels)
+        return STATUS_INVALID_VALUE;
+    pImpl->in[index] = in;
+    pImpl->out[index] = out;
+    return STATUS_OK;
+}
+
+status_t MultiSpectralProcessor::bind_in(size_t index, const float *in)
+{
+    if (pImpl == nullptr)
+        return STATUS_BAD_STATE;
+    if (index >= pImpl->channels)
+        return STATUS_INVALID_VALUE;
+    pImpl->in[index] = in;
+    return STATUS_OK;
+}
+
+status_t MultiSpectralProcessor::bind_out(size_t index, float *out)
+{
+    if (pImpl == nullptr)
+        return STATUS_BAD_STATE;
+    if (index >= pImpl->channels)
+        return STATUS_INVALID_VALUE;
+    pImpl->out[index] = out;
+    return STATUS_OK;
+}
+
+status_t MultiSpectralProcessor::unbind(size_t index)     { return bind(index, nullptr, nullptr); }
+status_t MultiSpectralProcessor::unbind_in(size_t index)  { return bind_in(index, nullptr); }
+status_t MultiSpectralProcessor::unbind_out(size_t index) { return bind_out(index, nullptr); }
+
+void MultiSpectralProcessor::unbind_all()
+{
+    if (pImpl == nullptr)
+        return;
+    std::fill(pImpl->in.begin(), pImpl->in.end(), nullptr);
+    std::fill(pImpl->out.begin(), pImpl->out.end(), nullptr);
+}
+
+bool MultiSpectralProcessor::needs_update() const  { return pImpl && pImpl->update; }
+void MultiSpectralProcessor::update_settings()     { if (pImpl) pImpl->update = false; }
+size_t MultiSpectralProcessor::get_rank() const    { return pImpl ? pImpl->rank : 0; }
+float MultiSpectralProcessor::phase() const        { return pImpl ? pImpl->phase : 0.0f; }
+size_t MultiSpectralProcessor::latency() const     { return pImpl ? (size_t(1) << pImpl->rank) : 0; }
+size_t MultiSpectralProcessor::frame_size() const  { return pImpl ? (size_t(1) << (pImpl->rank - 1)) : 0; }
+
+void MultiSpectralProcessor::set_phase(float phase)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->phase = std::min(std::max(phase, 0.0f), 1.0f);
+    pImpl->update = true;
+    mi_spectral_bank_set_phase(pImpl->bank, pImpl->phase);
+}
+
+void MultiSpectralProcessor::set_rank(size_t rank)
+{
+    if (pImpl == nullptr || rank == pImpl->rank || rank > pImpl->max_rank)
+        return;
+    pImpl->rank = rank;
+    pImpl->update = true;
+    mi_spectral_bank_set_rank(pImpl->bank, uint32_t(rank));
+}
+
+void MultiSpectralProcessor::process(size_t count)
+{
+    impl_t *p = pImpl;
+    if (p == nullptr || count == 0)
+        return;
+    const size_t C = p->channels;
+    for (size_t i = 0; i < C; ++i)
+    {
+        p->has_in[i]  = (p->in[i] != nullptr) ? 1 : 0;
+        p->has_out[i] = (p->out[i] != nullptr) ? 1 : 0;
+    }
+    bool ok = p->reserve(count) &&
+              mi_spectral_bank_bind_channels(p->bank, p->has_in.data(), p->has_out.data(), nullptr) == MI_OK;
+    if (ok)
+    {
+        // channels without an input take zeros (MultiSpectralProcessor.cpp:316-317)
+        p->host_io.assign(C * count, 0.0f);
+        for (size_t i = 0; i < C; ++i)
+            if (p->in[i] != nullptr)
+                std::memcpy(&p->host_io[i * count], p->in[i], count * sizeof(float));
+        ok = mi_dspu_copy_h2d(p->d_in, p->host_io.data(), C * count * sizeof(float), nullptr) == MI_OK &&
+             mi_spectral_bank_process(p->bank, p->d_out, p->d_in, count, count, count, nullptr) == MI_OK &&
+             mi_dspu_copy_d2h(p->host_io.data(), p->d_out, C * count * sizeof(float), nullptr) == MI_OK &&
+             mi_dspu_stream_synchronize(nullptr) == MI_OK;
+    }
+    for (size_t i = 0; i < C; ++i)
+    {
+        if (p->out[i] != nullptr)
+        {
+            if (ok)
+                std::memcpy(p->out[i], &p->host_io[i * count], count * sizeof(float));
+            else
+                std::memset(p->out[i], 0, count * sizeof(float));
+            p->out[i] += count;
+        }
+        if (p->in[i] != nullptr)
+            p->in[i] += count;
+    }
+    p->update = false;
+}
+
+void MultiSpectralProcessor::reset()             { if (pImpl) mi_spectral_bank_reset(pImpl->bank, nullptr); }
+
+size_t MultiSpectralProcessor::remaining() const
+{
+    uint32_t r = 0;
+    if (pImpl != nullptr)
+        mi_spectral_bank_get(pImpl->bank, nullptr, nullptr, &r);
+    return r;
+}
+
+void MultiSpectralProcessor::dump(IStateDumper *v) const
+{
+    v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
     v->write("nRank", get_rank());
 }
 

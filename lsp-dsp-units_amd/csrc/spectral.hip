@@ -656,13 +656,6 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
     size_t done = 0;
     while (done < count)                                    // SpectralProcessor.cpp:156-198
     {
-        if (b->offset >= frame)
-        {
-            const int r = spectral_hop(b, st);
-            if (r != MI_OK)
-                return r;
-            b->offset = 0;
-        }
         const size_t n = (count - done < frame - b->offset) ? count - done : frame - b->offset;
         MI_HIP_CHECK(hipMemcpy2DAsync(b->d_in + frame + b->offset, N * sizeof(float), in + done, in_stride * sizeof(float),
                                       n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
@@ -671,6 +664,13 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
                                           n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
         b->offset += uint32_t(n);
         done += n;
+        if (b->offset >= frame)                             // the frame is complete: transform it now, as the reference does
+        {
+            const int r = spectral_hop(b, st);
+            if (r != MI_OK)
+                return r;
+            b->offset = 0;
+        }
     }
     return MI_OK;
 }

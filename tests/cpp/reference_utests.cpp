@@ -10,6 +10,7 @@
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/units.h>
@@ -141,6 +142,45 @@ static void spectral_proc_callback()
         if (fabsf(0.5f * in[i] - out[1024 + i]) > 1e-5f) { CHECK(false, "sample %zu", i); break; }
 }
 
+// MultiSpectralProcessor (no reference utest; semantics of MultiSpectralProcessor.cpp:160-393): three channels --
+// #0 in+out, #1 input only (spectrum visible to the handler, no output), #2 nothing bound (NULL spectrum pointer);
+// the handler writes 0.25 * spectrum[1] into spectrum[0], so out[0] = 0.25 * in[1] delayed by the latency;
+// bound pointers advance with process(count).
+static int multi_calls = 0, multi_null = 0;
+static void multi_mix(void *, void *, float * const *spectrum, size_t rank)
+{
+    ++multi_calls;
+    if (spectrum[2] == NULL) ++multi_null;
+    for (size_t i = 0; i < (size_t(2) << rank); ++i) spectrum[0][i] = 0.25f * spectrum[1][i];
+}
+
+static void multi_spectral_proc()
+{
+    printf("multi_spectral_proc (3 channels, cross-channel handler)\n");
+    const size_t SAMPLES = 4096, RANK = 9, LAT = 512;
+    std::vector<float> in0(SAMPLES), in1(SAMPLES), out0(SAMPLES, -1.0f);
+    srand(3);
+    for (float &v : in0) v = float(rand()) / float(RAND_MAX) - 0.5f;
+    for (float &v : in1) v = float(rand()) / float(RAND_MAX) - 0.5f;
+    dspu::MultiSpectralProcessor mp;
+    CHECK(!mp.init(0, 10), "init(0 channels) must fail");
+    CHECK(mp.bind(0, NULL, NULL) == STATUS_BAD_STATE, "bind before init");
+    CHECK(mp.init(3, 10), "init");
+    mp.set_rank(RANK);
+    CHECK(mp.latency() == LAT && mp.frame_size() == LAT / 2, "latency/frame_size");
+    CHECK(mp.bind(3, NULL, NULL) == STATUS_INVALID_VALUE, "bind out of range");
+    CHECK(mp.bind(0, out0.data(), in0.data()) == STATUS_OK, "bind 0");
+    CHECK(mp.bind_in(1, in1.data()) == STATUS_OK, "bind_in 1");
+    mp.bind_handler(multi_mix, NULL, NULL);
+    for (size_t done = 0; done < SAMPLES; done += 1000)                 // uneven calls: pointers must advance
+        mp.process((SAMPLES - done < 1000) ? SAMPLES - done : 1000);
+    CHECK(multi_calls == int(SAMPLES / (LAT / 2)), "handler calls %d", multi_calls);
+    CHECK(multi_null == multi_calls, "unbound channel must be NULL in the handler");
+    for (size_t i = 0; i + LAT < SAMPLES; ++i)
+        if (fabsf(0.25f * in1[i] - out0[LAT + i]) > 1e-5f) { CHECK(false, "sample %zu: %.7f vs %.7f", i, 0.25f * in1[i], out0[LAT + i]); break; }
+    mp.destroy();
+}
+
 static void ringbuffer()
 {
     printf("ringbuffer\n");
@@ -200,7 +240,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc ringbuffer readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc ringbuffer readme_filter");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -215,6 +255,7 @@ int main(int argc, char **argv)
     equalizer_latency("SPM", dspu::EQM_SPM);
     spectral_proc_simple();
     spectral_proc_callback();
+    multi_spectral_proc();
     ringbuffer();
     readme_filter();
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
