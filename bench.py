@@ -185,10 +185,12 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True)
         e = ctypes.c_void_p()
         mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
         return e
-    # The dominant kernel of every 8th step carries a start/stop event pair (hipExtLaunchKernelGGL): live kernel
-    # durations from inside the timed region without putting an event packet between every two launches.
-    every = 8 if steps >= 16 else 1
-    probes = list(range(0, steps, every)) if profile else []
+    # The dominant kernel of the last `burst` steps of the timed region carries a start/stop event pair
+    # (hipExtLaunchKernelGGL).  An event pair serialises its launch against its neighbours, so a contiguous burst measures
+    # what rocprofv3 measures (one launch at a time) while the steps before it run back to back; the first launch of the
+    # burst still overlaps the un-instrumented launch before it and is dropped from the average.
+    burst = min(32, max(1, steps // 4)) if profile else 0
+    probes = list(range(steps - burst, steps))
     starts = {i: new_event() for i in probes}
     stops = {i: new_event() for i in probes}
     t0 = time.perf_counter()
@@ -206,7 +208,7 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = []
-    for i in probes:
+    for i in (probes[1:] if len(probes) > 1 else probes):
         ms = ctypes.c_float()
         mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), starts[i], stops[i]))
         kernel_ms.append(float(ms.value))
