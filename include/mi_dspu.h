@@ -288,6 +288,14 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
  * (count within the capacity the bank was created with); input history is kept.  Used by the equalizer bank
  * when it retunes (the reference re-parses its FIR the same way, Equalizer.cpp:342-345). Synchronises `stream`. */
 int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count, void *stream);
+/*
+ * Single-partition banks (taps <= frame): the new responses wait for the next frame boundary and are cross-faded in
+ * over that frame -- weight of the new response 0 up to B/2, a linear ramp over the next B output positions of the
+ * frame's 2B-long result, 1 after that (what Equalizer::process does for a "smooth" retune, Equalizer.cpp:486-501).
+ * A second call before the boundary replaces the waiting responses.  mi_convolver_bank_set_irs_device() in the middle
+ * of a frame likewise takes effect at the boundary (without a fade).
+ */
+int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count, void *stream);
 /* Convolver::destroy(), Convolver.cpp:71-75. */
 int mi_convolver_bank_destroy(mi_convolver_bank_t *bank);
 /* Forget all input history (state right after init). */
@@ -426,8 +434,10 @@ int mi_equalizer_bank_set_actual_sample_rate(mi_equalizer_bank_t *bank, uint32_t
 int mi_equalizer_bank_get_latency(mi_equalizer_bank_t *bank, uint32_t *latency, void *stream);
 /* reset(), Equalizer.cpp:573-597. */
 int mi_equalizer_bank_reset(mi_equalizer_bank_t *bank, void *stream);
-/* process(out, in, samples), Equalizer.cpp:460-571.  The one-off cross-fade of a "smooth" retune
- * (EF_XFADE, Equalizer.cpp:486-501) is not implemented: a retune switches at the next block. */
+/* smooth() / set_smooth(), Equalizer.cpp:618-626: in FIR and FFT modes a retune is cross-faded in over the block
+ * that completes next (EF_XFADE, Equalizer.cpp:339-343,486-501) instead of switching at its start. */
+int mi_equalizer_bank_set_smooth(mi_equalizer_bank_t *bank, int smooth);
+/* process(out, in, samples), Equalizer.cpp:460-571. */
 int mi_equalizer_bank_process(mi_equalizer_bank_t *bank, float *out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream);
 /* filter count, fir_rank(), mode(), ir_size() (Equalizer.cpp:599-616). */

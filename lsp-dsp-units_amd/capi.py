@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mi_analyzer_bank_reduce_bins": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "mi_analyzer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "mi_convolver_bank_set_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
+    "mi_convolver_bank_crossfade_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
     "mi_spectral_bank_set_windows": (c_int, [c_void_p, c_int, c_int]),
     "mi_equalizer_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32]),
     "mi_equalizer_bank_destroy": (c_int, [c_void_p]),
@@ -109,6 +110,7 @@ PROTOTYPES = {
     "mi_equalizer_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),
     "mi_equalizer_bank_set_actual_sample_rate": (c_int, [c_void_p, c_uint32]),
     "mi_equalizer_bank_get_latency": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
+    "mi_equalizer_bank_set_smooth": (c_int, [c_void_p, c_int]),
     "mi_equalizer_bank_reset": (c_int, [c_void_p, c_void_p]),
     "mi_equalizer_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_equalizer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int), POINTER(c_uint32)]),

@@ -28,6 +28,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace
@@ -306,6 +307,125 @@ namespace
         }
     }
 
+    // ---- one-frame cross-fade between two impulse responses (Equalizer "smooth" retune, Equalizer.cpp:486-501) ----------
+    // Weight of the NEW response at position n of the frame's 2B-long result: 0 before B/2, a linear ramp i/B over the
+    // next B positions (dsp::lramp1 / lramp_add2 with delta = 1/B), 1 from 3B/2 on; the old response gets 1 - that.
+    __device__ __forceinline__ float xfade_new_weight(int n, int B)
+    {
+        const int i = n - B / 2;
+        return (i <= 0) ? 0.0f : (i >= B) ? 1.0f : float(i) * (1.0f / float(B));
+    }
+
+    // whole frame, single partition (P == 1): y = w_old IFFT(X H_old) + w_new IFFT(X H_new), then the usual overlap-add
+    template <int LOGM>
+    __global__ __launch_bounds__(plan<LOGM>::T)
+    void conv_xfade_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
+                                 const float2 *__restrict__ Hold, const float2 *__restrict__ Hnew, float *acc,
+                                 const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T;
+        __shared__ float2 buf[M], scr[M];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        real_fft<LOGM> rf;
+        rf.load(tw, TWN, tid);
+        rf.prepare();
+        load_and_forward<LOGM>(buf, scr, in + size_t(ch) * in_stride, B, aligned, rf, tid);
+        float2 X[KPT], yo[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int k = tid + i * T;
+            X[i] = buf[k];
+            buf[k] = image_mul(X[i], Hold[size_t(ch) * M + k], k);
+        }
+        __syncthreads();
+        rf.inverse(buf, scr, tid);
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int k = tid + i * T;
+            yo[i] = buf[k];
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int k = tid + i * T;
+            buf[k] = image_mul(X[i], Hnew[size_t(ch) * M + k], k);
+        }
+        __syncthreads();
+        rf.inverse(buf, scr, tid);
+        const float scale = 1.0f / float(2 * M);
+        float *a = acc + size_t(ch) * 2 * B;
+        float *o = out + size_t(ch) * out_stride;
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int m = tid + i * T;                          // samples 2m, 2m+1 of the 2B-long result
+            const float2 yn = buf[m];
+            const float w0 = xfade_new_weight(2 * m, B), w1 = xfade_new_weight(2 * m + 1, B);
+            if (m < M / 2)                                      // first half: out = acc + y, acc <- next half
+            {
+                // the reference ramps its output buffer down, i.e. the old result TOGETHER WITH the overlap tail of the
+                // blocks before it (Equalizer.cpp:496): same here
+                const float2 a0 = *reinterpret_cast<const float2 *>(a + 2 * m);
+                o[2 * m]     = (a0.x + yo[i].x * scale) * (1.0f - w0) + yn.x * scale * w0;
+                o[2 * m + 1] = (a0.y + yo[i].y * scale) * (1.0f - w1) + yn.y * scale * w1;
+            }
+            else
+            {
+                const float y0 = (yo[i].x * (1.0f - w0) + yn.x * w0) * scale;
+                const float y1 = (yo[i].y * (1.0f - w1) + yn.y * w1) * scale;
+                const int n = 2 * m - B;
+                const float2 a1 = *reinterpret_cast<const float2 *>(a + B + n);
+                *reinterpret_cast<float2 *>(a + n)     = make_float2(a1.x + y0, a1.y + y1);
+                *reinterpret_cast<float2 *>(a + B + n) = make_float2(0.0f, 0.0f);
+            }
+        }
+    }
+
+    // start of a cross-fade frame that arrives in pieces: the overlap tail already in acc fades with the old response
+    // (see conv_xfade_frame_kernel), once
+    __global__ __launch_bounds__(256)
+    void conv_xfade_prescale_kernel(float *acc, int B)
+    {
+        const int ch = blockIdx.y, n = B / 2 + blockIdx.x * 256 + threadIdx.x;
+        if (n < B)
+            acc[size_t(ch) * 2 * B + n] *= 1.0f - xfade_new_weight(n, B);
+    }
+
+    // partial call inside the cross-fade frame: both head responses in the time domain, mixed by output position
+    __global__ __launch_bounds__(256)
+    void conv_direct_xfade_kernel(float *out, size_t out_stride, float *acc, const float *frame,
+                                  const float *__restrict__ h0_old, const float *__restrict__ h0_new, int B, int off, int cnt)
+    {
+        extern __shared__ float sxin[];                         // cnt samples of this call
+        const int ch = blockIdx.y, tid = threadIdx.x;
+        const float *x = frame + size_t(ch) * B + off;
+        for (int j = tid; j < cnt; j += 256)
+            sxin[j] = x[j];
+        __syncthreads();
+        const int i = blockIdx.x * 256 + tid;                   // output position relative to `off`
+        if (i >= cnt + B - 1)
+            return;
+        const float *ho = h0_old + size_t(ch) * B, *hn = h0_new + size_t(ch) * B;
+        const int jlo = (i - (B - 1) > 0) ? i - (B - 1) : 0;
+        const int jhi = (i < cnt - 1) ? i : cnt - 1;
+        float so = 0.0f, sn = 0.0f;
+        for (int j = jlo; j <= jhi; ++j)
+        {
+            so = fmaf(sxin[j], ho[i - j], so);
+            sn = fmaf(sxin[j], hn[i - j], sn);
+        }
+        const float w = xfade_new_weight(off + i, B);
+        float *a = acc + size_t(ch) * 2 * B + off + i;
+        const float v = *a + (so * (1.0f - w) + sn * w);
+        *a = v;
+        if (i < cnt)
+            out[size_t(ch) * out_stride + i] = v;
+    }
+
     // ---- twiddle table, one per device -------------------------------------------------------------------
     float2 *g_tw[64] = { nullptr };
 
@@ -355,6 +475,14 @@ struct mi_convolver_bank
     bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
+    // A response that takes over at the next frame boundary: plainly (a replacement that arrived in the middle of a
+    // frame) or cross-faded over that frame (mi_convolver_bank_crossfade_irs_device).  Single-partition banks only.
+    float2     *d_Hx = nullptr, *d_Hy = nullptr;   // x: target of the active cross-fade or the waiting response;
+    float      *d_h0x = nullptr, *d_h0y = nullptr; // y: a response that arrived while x was busy cross-fading
+    bool        pending_in_y = false;
+    enum { PEND_NONE = 0, PEND_REPLACE = 1, PEND_XFADE = 2 };
+    int         pending = PEND_NONE;
+    bool        xfade_active = false;   // the frame being received is the cross-fade frame
     const float2 *d_tw = nullptr;
     std::vector<uint32_t> counts;
 };
@@ -489,13 +617,10 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     return mi_convolver_bank_reset(b, stream);
 }
 
-int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count, void *stream)
+// parse `count` taps per channel (device rows) into partition images at dst_H and the head taps at dst_h0
+static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count, float2 *dst_H,
+                     float *dst_h0, hipStream_t st)
 {
-    MI_REQUIRE(b != nullptr && b->live, MI_ESTATE, "mi_convolver_bank_set_irs_device: bank is not initialised");
-    MI_REQUIRE(d_irs != nullptr && count > 0 && ir_stride >= count, MI_EINVAL, "mi_convolver_bank_set_irs_device: bad argument");
-    MI_REQUIRE(count <= uint32_t(b->P) * uint32_t(b->B), MI_EINVAL,
-               "mi_convolver_bank_set_irs_device: %u taps exceed the %d x %d the bank was created for", count, b->P, b->B);
-    hipStream_t st = mi::as_stream(stream);
     const size_t M = size_t(b->B);
     // zero-padded staging rows [channels][P*B], then the same parse kernel as init
     float *d_ir = nullptr;
@@ -507,12 +632,12 @@ int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs,
     if (e == hipSuccess) e = hipMemcpy2DAsync(d_ir, size_t(b->P) * M * sizeof(float), d_irs, ir_stride * sizeof(float),
                                               size_t(count) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_counts, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpy2DAsync(b->d_h0, M * sizeof(float), d_ir, size_t(b->P) * M * sizeof(float),
+    if (e == hipSuccess) e = hipMemcpy2DAsync(dst_h0, M * sizeof(float), d_ir, size_t(b->P) * M * sizeof(float),
                                               M * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess)
     {
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, b->channels), dim3(plan<LM>::T), 0, st, \
-                                               b->d_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw)
+                                               dst_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         e = hipGetLastError();
@@ -521,8 +646,68 @@ int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs,
     (void)hipFree(d_ir);
     (void)hipFree(d_counts);
     MI_HIP_CHECK(e);
+    return MI_OK;
+}
+
+static int ensure_pending_buffers(mi_convolver_bank_t *b)
+{
+    const size_t M = size_t(b->B);
+    if (b->d_Hx == nullptr)
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_Hx), size_t(b->channels) * b->P * M * sizeof(float2)));
+    if (b->d_h0x == nullptr)
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_h0x), size_t(b->channels) * M * sizeof(float)));
+    if (b->d_Hy == nullptr)
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_Hy), size_t(b->channels) * b->P * M * sizeof(float2)));
+    if (b->d_h0y == nullptr)
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_h0y), size_t(b->channels) * M * sizeof(float)));
+    return MI_OK;
+}
+
+int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count, void *stream)
+{
+    MI_REQUIRE(b != nullptr && b->live, MI_ESTATE, "mi_convolver_bank_set_irs_device: bank is not initialised");
+    MI_REQUIRE(d_irs != nullptr && count > 0 && ir_stride >= count, MI_EINVAL, "mi_convolver_bank_set_irs_device: bad argument");
+    MI_REQUIRE(count <= uint32_t(b->P) * uint32_t(b->B), MI_EINVAL,
+               "mi_convolver_bank_set_irs_device: %u taps exceed the %d x %d the bank was created for", count, b->P, b->B);
+    hipStream_t st = mi::as_stream(stream);
     b->counts.assign(b->channels, count);
     b->taps = count;
+    if (b->P == 1 && (b->off != 0 || b->xfade_active))
+    {
+        // in the middle of a frame: the frame keeps the response it started with, the new one takes over at the boundary
+        // (the reference's Equalizer convolves a block as a whole with the response in force when the block completes)
+        int r = ensure_pending_buffers(b);
+        if (r == MI_OK)
+            r = parse_irs(b, d_irs, ir_stride, count, b->xfade_active ? b->d_Hy : b->d_Hx,
+                          b->xfade_active ? b->d_h0y : b->d_h0x, st);
+        if (r != MI_OK)
+            return r;
+        b->pending_in_y = b->xfade_active;
+        b->pending = mi_convolver_bank::PEND_REPLACE;
+        return MI_OK;
+    }
+    b->pending = mi_convolver_bank::PEND_NONE;
+    return parse_irs(b, d_irs, ir_stride, count, b->d_H, b->d_h0, st);
+}
+
+int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count,
+                                           void *stream)
+{
+    MI_REQUIRE(b != nullptr && b->live, MI_ESTATE, "mi_convolver_bank_crossfade_irs_device: bank is not initialised");
+    MI_REQUIRE(d_irs != nullptr && count > 0 && ir_stride >= count, MI_EINVAL, "mi_convolver_bank_crossfade_irs_device: bad argument");
+    MI_REQUIRE(b->P == 1, MI_EINVAL, "mi_convolver_bank_crossfade_irs_device: only for single-partition banks (taps <= frame)");
+    MI_REQUIRE(count <= uint32_t(b->B), MI_EINVAL, "mi_convolver_bank_crossfade_irs_device: %u taps exceed the frame of %d", count, b->B);
+    hipStream_t st = mi::as_stream(stream);
+    int r = ensure_pending_buffers(b);
+    if (r == MI_OK)                                                             // a later call before the boundary wins
+        r = parse_irs(b, d_irs, ir_stride, count, b->xfade_active ? b->d_Hy : b->d_Hx,
+                      b->xfade_active ? b->d_h0y : b->d_h0x, st);
+    if (r != MI_OK)
+        return r;
+    b->counts.assign(b->channels, count);
+    b->taps = count;
+    b->pending_in_y = b->xfade_active;
+    b->pending = mi_convolver_bank::PEND_XFADE;
     return MI_OK;
 }
 
@@ -532,6 +717,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
         return MI_OK;
     (void)hipFree(b->d_H); (void)hipFree(b->d_ring); (void)hipFree(b->d_yt);
     (void)hipFree(b->d_acc); (void)hipFree(b->d_frame); (void)hipFree(b->d_h0);
+    (void)hipFree(b->d_Hx); (void)hipFree(b->d_h0x); (void)hipFree(b->d_Hy); (void)hipFree(b->d_h0y);
     delete b;
     return MI_OK;
 }
@@ -550,6 +736,12 @@ int mi_convolver_bank_reset(mi_convolver_bank_t *b, void *stream)
     b->slot = 0;
     b->off  = 0;
     b->yt_pending = false;
+    if (b->xfade_active)                                        // reset inside the cross-fade frame: the new response stays
+    {
+        std::swap(b->d_H, b->d_Hx);
+        std::swap(b->d_h0, b->d_h0x);
+        b->xfade_active = false;
+    }
     return MI_OK;
 }
 
@@ -585,7 +777,38 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
         const size_t left = samples - done;
         float *o = out + done;
         const float *x = in + done;
-        if (b->off == 0 && left >= size_t(B))
+        if (b->off == 0 && b->pending != mi_convolver_bank::PEND_NONE)      // frame boundary: a waiting response takes over
+        {
+            if (b->pending_in_y)                                            // (the cross-fade that kept x busy is over)
+            {
+                std::swap(b->d_Hx, b->d_Hy);
+                std::swap(b->d_h0x, b->d_h0y);
+                b->pending_in_y = false;
+            }
+            if (b->pending == mi_convolver_bank::PEND_XFADE)
+                b->xfade_active = true;                                     // ... across this frame
+            else
+            {
+                std::swap(b->d_H, b->d_Hx);
+                std::swap(b->d_h0, b->d_h0x);
+            }
+            b->pending = mi_convolver_bank::PEND_NONE;
+        }
+        if (b->off == 0 && left >= size_t(B) && b->xfade_active)
+        {
+            const bool aligned = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) % 8 == 0) &&
+                                 (out_stride % 2 == 0) && (in_stride % 2 == 0);
+            #define MI_CALL(LM) hipLaunchKernelGGL((conv_xfade_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                                                   o, x, out_stride, in_stride, aligned, b->d_H, b->d_Hx, b->d_acc, b->d_tw)
+            MI_LOGM_SWITCH(b->logm, MI_CALL)
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            std::swap(b->d_H, b->d_Hx);
+            std::swap(b->d_h0, b->d_h0x);
+            b->xfade_active = false;
+            done += size_t(B);
+        }
+        else if (b->off == 0 && left >= size_t(B))
         {
             const bool aligned = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) % 8 == 0) &&
                                  (out_stride % 2 == 0) && (in_stride % 2 == 0);
@@ -612,8 +835,14 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             const dim3 grid((cnt + B - 1 + 255) / 256, b->channels);
             MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
                                           size_t(cnt) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
-            hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
-                               o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
+            if (b->xfade_active && b->off == 0)
+                hipLaunchKernelGGL(conv_xfade_prescale_kernel, dim3((B / 2 + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, B);
+            if (b->xfade_active)
+                hipLaunchKernelGGL(conv_direct_xfade_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
+                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, b->d_h0x, B, b->off, cnt);
+            else
+                hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
+                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
             MI_HIP_CHECK(hipGetLastError());
             b->off += cnt;
             done += size_t(cnt);
@@ -630,6 +859,12 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 if (r != MI_OK)
                     return r;
                 b->off = 0;
+                if (b->xfade_active)                                        // the cross-fade frame is over
+                {
+                    std::swap(b->d_H, b->d_Hx);
+                    std::swap(b->d_h0, b->d_h0x);
+                    b->xfade_active = false;
+                }
             }
         }
     }

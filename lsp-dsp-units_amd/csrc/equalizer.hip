@@ -106,6 +106,8 @@ struct mi_equalizer_bank
     const float2 *d_tw = nullptr;
     std::vector<float> h_mag;                       // [channels][N] host magnitudes (FFT/SPM modes)
     bool        streaming_ready = false;
+    uint32_t    primed = 0;                         // samples pushed into the (cleared) delay line so far, up to N
+    bool        smooth = false;                     // EF_SMOOTH: retunes cross-fade over one block (Equalizer.cpp:339-343)
 };
 
 namespace
@@ -203,6 +205,7 @@ namespace
         {
             if ((r = mi_convolver_bank_reset(b->conv, stream)) != MI_OK) return r;
             if ((r = mi_delay_bank_clear(b->delay, stream)) != MI_OK) return r;
+            b->primed = 0;
             if ((r = mi_spectral_bank_set_rank(b->spm, b->fir_rank)) != MI_OK) return r;
             if ((r = mi_spectral_bank_set_phase(b->spm, 0.0f)) != MI_OK) return r;     // forces the STFT buffers to clear
         }
@@ -229,7 +232,10 @@ namespace
                 MI_LOGN_SWITCH(int(b->fir_rank), MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
-                if ((r = mi_convolver_bank_set_irs_device(b->conv, b->d_taps, N, uint32_t(N), stream)) != MI_OK) return r;
+                // EF_SMOOTH: the new response waits for the next block boundary and is cross-faded in over that block
+                r = b->smooth ? mi_convolver_bank_crossfade_irs_device(b->conv, b->d_taps, N, uint32_t(N), stream)
+                              : mi_convolver_bank_set_irs_device(b->conv, b->d_taps, N, uint32_t(N), stream);
+                if (r != MI_OK) return r;
             }
             else
             {
@@ -397,6 +403,13 @@ int mi_equalizer_bank_get_latency(mi_equalizer_bank_t *b, uint32_t *latency, voi
     return MI_OK;
 }
 
+int mi_equalizer_bank_set_smooth(mi_equalizer_bank_t *b, int smooth)    // Equalizer.cpp:618-626
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_equalizer_bank_set_smooth: NULL bank");
+    b->smooth = (smooth != 0);
+    return MI_OK;
+}
+
 int mi_equalizer_bank_reset(mi_equalizer_bank_t *b, void *stream)       // Equalizer.cpp:573-597
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_equalizer_bank_reset: NULL bank");
@@ -410,6 +423,7 @@ int mi_equalizer_bank_reset(mi_equalizer_bank_t *b, void *stream)       // Equal
         case MI_EQM_FIR: case MI_EQM_FFT:
             if ((r = mi_convolver_bank_reset(b->conv, stream)) == MI_OK)
                 r = mi_delay_bank_clear(b->delay, stream);
+            b->primed = 0;
             break;
         case MI_EQM_SPM:
             r = mi_spectral_bank_reset(b->spm, stream);
@@ -436,9 +450,27 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
         case MI_EQM_IIR:
             return mi_biquad_bank_process(b->biquads, out, in, samples, out_stride, in_stride, stream);
         case MI_EQM_FIR: case MI_EQM_FFT:
-            if ((r = mi_convolver_bank_process(b->conv, out, in, samples, out_stride, in_stride, stream)) != MI_OK)
-                return r;
-            return mi_delay_bank_process(b->delay, out, out, samples, out_stride, out_stride, 0, MI_GAIN_NONE, 0.0f, nullptr, 0, stream);
+            // The reference buffers a block of N samples and then convolves it as a whole with the response in force at
+            // that moment (Equalizer.cpp:477-511): a delay of N in FRONT of the zero-latency convolver -- same samples
+            // out, and a retune (or its cross-fade) lands on the same block as in the reference.
+            // While the first block after a clear is still being buffered the reference convolves nothing (its first
+            // convolution happens when that block is complete): the convolver's frames start with the first real block.
+            {
+                size_t done = 0;
+                if (b->primed < b->fir_size)
+                {
+                    done = (samples < size_t(b->fir_size - b->primed)) ? samples : size_t(b->fir_size - b->primed);
+                    if ((r = mi_delay_bank_process(b->delay, out, in, done, out_stride, in_stride, 0, MI_GAIN_NONE, 0.0f, nullptr, 0, stream)) != MI_OK)
+                        return r;                               // emits the zeros the cleared line holds
+                    b->primed += uint32_t(done);
+                    if (done == samples)
+                        return MI_OK;
+                }
+                const size_t rest = samples - done;
+                if ((r = mi_delay_bank_process(b->delay, out + done, in + done, rest, out_stride, in_stride, 0, MI_GAIN_NONE, 0.0f, nullptr, 0, stream)) != MI_OK)
+                    return r;
+                return mi_convolver_bank_process(b->conv, out + done, out + done, rest, out_stride, out_stride, stream);
+            }
         case MI_EQM_SPM:
             return mi_spectral_bank_process(b->spm, out, in, samples, out_stride, in_stride, stream);
         default:                                                        // EQM_BYPASS (Equalizer.cpp:564-569)

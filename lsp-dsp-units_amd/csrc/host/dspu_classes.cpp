@@ -490,7 +490,13 @@ void Equalizer::process(float *out, const float *in, size_t samples)
 void Equalizer::reset()                     { if (pImpl) mi_equalizer_bank_reset(pImpl->bank, nullptr); }
 size_t Equalizer::fir_rank() const          { return pImpl ? pImpl->fir_rank : 0; }
 bool Equalizer::smooth() const              { return pImpl && pImpl->smooth; }
-void Equalizer::set_smooth(bool smooth)     { if (pImpl) pImpl->smooth = smooth; }
+void Equalizer::set_smooth(bool smooth)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->smooth = smooth;
+    mi_equalizer_bank_set_smooth(pImpl->bank, smooth ? 1 : 0);
+}
 
 size_t Equalizer::ir_size() const
 {

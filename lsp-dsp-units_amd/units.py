@@ -440,6 +440,10 @@ class EqualizerBank:
         check(lib.mi_equalizer_bank_get_latency(self.handle, byref(v), _stream(stream)))
         return v.value
 
+    def set_smooth(self, smooth):
+        """Equalizer::set_smooth: FIR/FFT retunes cross-fade over the block that completes next."""
+        check(lib.mi_equalizer_bank_set_smooth(self.handle, 1 if smooth else 0))
+
     def reset(self, stream=None):
         check(lib.mi_equalizer_bank_reset(self.handle, _stream(stream)))
 

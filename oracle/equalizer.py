@@ -31,6 +31,8 @@ class Equalizer:
         self.sr = 0
         self.mode = BYPASS
         self.rebuild = self.clear = True
+        self.smooth = False                     # EF_SMOOTH (Equalizer.cpp:618-626)
+        self.xfade = False                      # EF_XFADE
         self.latency = 0
         self.bufsize = 0
         # hook: how the bank's impulse response is taken (tests swap in a float64 one to measure the float32 noise)
@@ -38,6 +40,12 @@ class Equalizer:
         if self.n:
             self.inb = np.zeros(2 * self.n, np.float32)
             self.outb = np.zeros(2 * self.n, np.float32)
+            # vConv / vNewConv start zeroed (Equalizer.cpp:112): a smooth first configuration fades in from silence
+            self.conv = B.fastconv_parse(np.zeros(self.n, np.float32), self.rank + 1)
+            self.newconv = self.conv.copy()
+
+    def set_smooth(self, smooth):
+        self.smooth = bool(smooth)
 
     def set_mode(self, mode):
         if mode != self.mode:
@@ -61,7 +69,7 @@ class Equalizer:
         if not (self.rebuild or self.clear):
             return
         if self.mode == BYPASS:
-            self.rebuild = self.clear = False
+            self.rebuild = self.clear = self.xfade = False      # Equalizer.cpp:250
             self.latency = 0
             return
         designs = [fd.design(p, self.sr) for p in self.params]
@@ -70,7 +78,7 @@ class Equalizer:
             self.state = np.zeros((max(coef.shape[0], 1), 2), np.float32)       # FilterBank::end(clear) / count change
         self.coef = coef.astype(np.float32)
         if self.mode == IIR:
-            self.rebuild = self.clear = False
+            self.rebuild = self.clear = self.xfade = False      # Equalizer.cpp:264
             self.latency = 0
             return
         n, half = self.n, self.n >> 1
@@ -104,11 +112,16 @@ class Equalizer:
             h = np.concatenate([re[half:], re[:half]]).astype(np.float32)
             h = (h * sp.window(n, "blackman_nuttall")).astype(np.float32)
             self.fir = h
-            self.conv = B.fastconv_parse(h, self.rank + 1)
+            if self.smooth:                                     # Equalizer.cpp:339-345
+                self.xfade = True
+                self.newconv = B.fastconv_parse(h, self.rank + 1)
+            else:
+                self.conv = B.fastconv_parse(h, self.rank + 1)
             self.latency = n + half
         else:
             self.wnd = sp.window(n, "sqr_cosine")
             self.latency = n
+            self.xfade = False                                  # Equalizer.cpp:356
         self.rebuild = self.clear = False
 
     def process(self, x):
@@ -128,6 +141,20 @@ class Equalizer:
                     self.outb[:n] = self.outb[n:]
                     self.outb[n:] = 0
                     B.fastconv_parse_apply(self.outb, self.conv, self.inb[:n], self.rank + 1)
+                    if self.xfade:                              # Equalizer.cpp:486-501
+                        vfft = np.zeros(2 * n, np.float32)
+                        self.conv = self.newconv.copy()
+                        B.fastconv_parse_apply(vfft, self.conv, self.inb[:n], self.rank + 1)
+                        # lramp1(dst, 1, 0, n): dst[i] *= 1 + (0-1)/n * i ; lramp_add2(dst, src, 0, 1, n): dst[i] += src[i] * (i/n)
+                        # (lsp-dsp-lib generic semantics: value = v1 + (v2 - v1)/count * i; not pinned by a reference test)
+                        i = np.arange(n, dtype=np.float32)
+                        delta = np.float32(1.0) / np.float32(n)
+                        down = (np.float32(1.0) - delta * i).astype(np.float32)
+                        up = (delta * i).astype(np.float32)
+                        seg = slice(half, half + n)
+                        self.outb[seg] = ((self.outb[seg] * down).astype(np.float32) + (vfft[seg] * up).astype(np.float32)).astype(np.float32)
+                        self.outb[n + half:] = vfft[n + half:]
+                        self.xfade = False
                     self.bufsize = 0
                 k = min(left, n - self.bufsize)
                 self.inb[self.bufsize:self.bufsize + k] = x[pos:pos + k]

@@ -110,3 +110,58 @@ def test_retune_mode_switch_and_reset(gpu):
         assert np.abs(dout.download()[0] - ref).max() <= 2 * TOL * np.abs(ref).max(), mode
         assert eq.get_latency() == o.get_latency()
     eq.close()
+
+
+@pytest.mark.parametrize("mode", [oe.FFT, oe.FIR])
+@pytest.mark.parametrize("calls", ["blocks", "ragged"])
+def test_smooth_retune_cross_fades_over_one_block(gpu, mode, calls):
+    """Equalizer::set_smooth(true): a retune is cross-faded in over the block that completes next (EF_XFADE,
+    Equalizer.cpp:339-343,486-501) -- including the very first configuration, which fades in from silence.
+    GPU bank vs the oracle's restatement, retunes at a block boundary and in the middle of a block."""
+    rng = np.random.default_rng(11)
+    C, rank, nfilt = 2, 10, 4
+    N = 1 << rank
+    n = 12 * N
+    x = (rng.standard_normal((C, n)) * 0.25).astype(np.float32)
+    curves = [
+        [(fd.FLT_BT_RLC_BELL, 1, 500.0, 500.0, 2.0, 2.0), (fd.FLT_BT_RLC_HISHELF, 1, 6000.0, 6000.0, 0.5, 0.0)],
+        [(fd.FLT_BT_RLC_BELL, 1, 900.0, 900.0, 0.4, 1.0), (fd.FLT_BT_RLC_LOSHELF, 1, 200.0, 200.0, 1.8, 0.0)],
+        [(fd.FLT_BT_RLC_BELL, 1, 3000.0, 3000.0, 3.0, 4.0), (fd.FLT_BT_RLC_BELL, 1, 120.0, 120.0, 0.7, 1.0)],
+    ]
+    eq = gpu.EqualizerBank(C, nfilt, rank)
+    eq.set_mode(mode); eq.set_sample_rate(48000); eq.set_smooth(True)
+    refs = []
+    for c in range(C):
+        o = oe.Equalizer(nfilt, rank); o.set_mode(mode); o.set_sample_rate(48000); o.set_smooth(True)
+        refs.append(o)
+
+    def retune(k):
+        for c in range(C):
+            for i, p in enumerate(curves[(k + c) % len(curves)]):
+                eq.set_params(i, *p, channel=c)
+                refs[c].set_params(i, fd.Params(*p))
+
+    sizes = [N] * 12 if calls == "blocks" else [N, 300, N - 300, 700, 2 * N, 324, N, 6 * N]
+    assert sum(sizes) == n
+    retune_before_call = {0: 0, 3: 1, 5: 2} if calls == "blocks" else {0: 0, 2: 1, 5: 2}     # ragged: mid-block retunes
+    y = np.empty_like(x)
+    ref = np.empty_like(x)
+    pos = 0
+    for call, k in enumerate(sizes):
+        if call in retune_before_call:
+            retune(retune_before_call[call])
+        din = gpu.DeviceBuffer.from_host(x[:, pos:pos + k]); dout = gpu.DeviceBuffer((C, k))
+        eq.process(dout, din, k)
+        y[:, pos:pos + k] = dout.download()
+        for c in range(C):
+            ref[c, pos:pos + k] = refs[c].process(x[c, pos:pos + k])
+        pos += k
+    for c in range(C):
+        peak = float(np.abs(ref[c]).max())
+        err = float(np.abs(y[c] - ref[c]).max())
+        tol = (2e-5 if mode == oe.FFT else 1e-4) * peak          # FIR: its taps come from a float32 IIR impulse response
+        assert err <= tol, "channel %d: max error %.3e (peak %.3f)" % (c, err, peak)
+    # the fade is really there: right after the first configuration the output ramps up from silence
+    first = np.abs(y[0, N:N + N // 2]).max()
+    assert first < 1e-6 * max(1.0, float(np.abs(y[0]).max())), "before N/2 into the first block's result only the old (zero) response may sound"
+    eq.close()
