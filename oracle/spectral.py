@@ -180,6 +180,9 @@ class Analyzer:
         self.window_name = "hann"; self.env_k = 0.5; self.shift = F(1.0)       # PINK_NOISE -> reversed = blue (0.5)
         self.counter = 0; self.head = 0
         self.reconf = True
+        self.active = True                              # Analyzer::set_activity (Analyzer.h)
+        self.ch_active = [True] * channels              # enable_channel  (Analyzer.cpp:213-249)
+        self.ch_freeze = [False] * channels             # freeze_channel
 
     def configure(self, sample_rate=None, rate=None, rank=None, window_name=None, reactivity=None, shift=None):
         if sample_rate is not None: self.sample_rate = sample_rate
@@ -218,6 +221,10 @@ class Analyzer:
             if o == 0:
                 if self.counter == 0:
                     self.data[:, :self.csize] = self.amp[:, :self.csize]
+                if self.ch_freeze[ch]:                  # Analyzer.cpp:334: a frozen channel keeps vAmp
+                    pass
+                elif not (self.active and self.ch_active[ch]):
+                    self.amp[ch, :self.csize] = 0       # Analyzer.cpp:363-364
                 doff = self.head - (fft_size + self.delay[ch] + self.user_delay[ch])
                 if doff < 0:
                     doff += self.buf_size
@@ -227,7 +234,8 @@ class Analyzer:
                 spec = B.packed_direct_fft(c, self.rank)
                 re, im = spec[0:2 * self.csize:2], spec[1:2 * self.csize:2]
                 mod = np.sqrt((re * re + im * im).astype(np.float32)).astype(np.float32)
-                self.amp[ch, :self.csize] = (self.amp[ch, :self.csize] * F(F(1.0) - self.tau) + mod * self.tau).astype(np.float32)
+                if not self.ch_freeze[ch] and self.active and self.ch_active[ch]:
+                    self.amp[ch, :self.csize] = (self.amp[ch, :self.csize] * F(F(1.0) - self.tau) + mod * self.tau).astype(np.float32)
             todo = min(n - off, self.step - o)
             idx = (self.head + np.arange(todo)) % self.buf_size
             self.buffer[:, idx] = x[:, off:off + todo]

@@ -151,9 +151,62 @@ def test_analyzer_matches_staggered_oracle(gpu):
         peak = max(np.abs(ref).max(), 1e-30)
         assert np.abs(got - ref).max() <= TOL * peak, (pos, np.abs(got - ref).max() / peak)
     assert bank.info() == {"rank": rank, "bins": 513, "period": 2400, "step": 400}
-    # per-bin reduction over channels == sum of the smoothed magnitudes
+    # per-bin reduction over channels == sum of the smoothed magnitudes (vAmp, Analyzer.cpp:361), with / without envelope.
+    # The bank updates every channel's vAmp at the strobe, the reference one channel every nStep samples: the two agree
+    # once the period is complete, so finish it (just short of the next strobe) before comparing.
+    rest = 2400 - (n - 7200) - 1
+    tail = (0.3 * rng.standard_normal((C, rest))).astype(np.float32)
+    o.process(tail)
+    bank.process(gpu.DeviceBuffer.from_host(tail), rest)
     out = gpu.DeviceBuffer((513,))
     bank.reduce_bins(out)
+    ref = o.amp[:, :513].astype(np.float64).sum(axis=0)
+    assert np.abs(out.download() - ref).max() <= TOL * np.abs(ref).max()
+    bank.reduce_bins(out, with_envelope=True)
+    assert np.abs(out.download() - ref * o.envelope[:513]).max() <= TOL * np.abs(ref * o.envelope[:513]).max()
+    bank.close()
+
+
+def test_analyzer_frozen_disabled_and_delayed_channels(gpu):
+    """freeze_channel / enable_channel / set_channel_delay / set_activity (Analyzer.cpp:213-249,330-365), changed at
+    period boundaries: a frozen channel keeps its spectrum, a disabled one reads zero, a delayed one looks further back.
+    Calls are whole periods (one fused analysis + ingest launch each) and odd pieces (separate ingest copies)."""
+    sr, rank, C = 48000, 9, 5
+    rng = np.random.default_rng(9)
+    period = 2400
+    n = 8 * period
+    x = (0.5 * rng.standard_normal((C, n))).astype(np.float32)
+    o = sp.Analyzer(C, rank, sr, 1.0, 600)
+    o.configure(sample_rate=sr, rate=20.0, rank=rank, window_name="hann", reactivity=0.2, shift=1.0)
+    bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 600)
+    for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, 20.0), (bank.RANK, rank), (bank.WINDOW, 0),
+                    (bank.REACTIVITY, 0.2), (bank.SHIFT, 1.0)):
+        bank.configure(what, v)
+    o.user_delay[3] = 500
+    bank.channel(3, bank.CH_DELAY, 500)
+    idx = np.arange(0, 257, dtype=np.uint32)
+    schedule = {2: ("freeze", 1, True), 3: ("enable", 2, False), 5: ("freeze", 1, False), 6: ("activity", None, False)}
+    pos = 0
+    for k in range(8):
+        if k in schedule:
+            what, ch, v = schedule[k]
+            if what == "freeze":
+                o.ch_freeze[ch] = v; bank.channel(ch, bank.CH_FREEZE, int(v))
+            elif what == "enable":
+                o.ch_active[ch] = v; bank.channel(ch, bank.CH_ENABLE, int(v))
+            else:
+                o.active = v; bank.configure(bank.ACTIVE, float(v))
+        pieces = (period,) if k % 2 == 0 else (1000, 1400)
+        for c in pieces:
+            o.process(x[:, pos:pos + c])
+            d = gpu.DeviceBuffer.from_host(x[:, pos:pos + c])
+            bank.process(d, c)
+            pos += c
+        got, ref = bank.get_spectrum(idx), o.get_spectrum(idx)
+        peak = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(got - ref).max() <= TOL * peak, (k, np.abs(got - ref).max() / peak)
+        if k >= 4:
+            assert np.abs(got[2]).max() == 0.0              # disabled channel: vData follows vAmp = 0 one period later
     bank.close()
 
 
