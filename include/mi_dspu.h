@@ -443,6 +443,42 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *bank, float *out, const float
 /* filter count, fir_rank(), mode(), ir_size() (Equalizer.cpp:599-616). */
 int mi_equalizer_bank_info(const mi_equalizer_bank_t *bank, uint32_t *filters, uint32_t *fir_rank, int *mode, uint32_t *ir_size);
 
+/* ---- IIR crossover bank (first caller of the filter path) ----------------------------- */
+/*
+ * mi_crossover_bank: one lsp::dspu::Crossover per channel, all channels sharing the split settings
+ * (util/Crossover.h:97-330, src/main/util/Crossover.cpp): `bands` bands, bands-1 split points; an active split point
+ * low-passes into the band on its left (+ all-pass filters of the split points above it, so that the bands sum to an
+ * all-pass) and high-passes into the chain on its right.  Linkwitz-Riley slopes: 1 = LR2 (12 dB/oct) ... 9 = LR32,
+ * 0 = split point off (enum crossover_slope_t).  Band outputs go to caller-owned device buffers instead of the
+ * reference's per-band callback.
+ */
+typedef struct mi_crossover_bank mi_crossover_bank_t;
+enum { MI_CROSS_MODE_BT = 0, MI_CROSS_MODE_MT = 1 };                /* crossover_mode_t */
+
+/* Crossover::init(bands, buf_size), Crossover.cpp:71-160 (default split frequencies log-spaced over 10 Hz..24 kHz). */
+int mi_crossover_bank_create(mi_crossover_bank_t **bank, uint32_t channels, uint32_t bands);
+int mi_crossover_bank_destroy(mi_crossover_bank_t *bank);
+/* set_sample_rate / set_slope / set_frequency / set_mode / set_gain, Crossover.cpp:185-254,327-341 */
+int mi_crossover_bank_set_sample_rate(mi_crossover_bank_t *bank, uint32_t sample_rate);
+int mi_crossover_bank_set_slope(mi_crossover_bank_t *bank, uint32_t split, uint32_t slope);
+int mi_crossover_bank_set_frequency(mi_crossover_bank_t *bank, uint32_t split, float freq);
+int mi_crossover_bank_set_mode(mi_crossover_bank_t *bank, uint32_t split, int mode);
+int mi_crossover_bank_set_gain(mi_crossover_bank_t *bank, uint32_t band, float gain);
+/* get_slope / get_frequency / get_mode (any pointer may be NULL) */
+int mi_crossover_bank_get_split(const mi_crossover_bank_t *bank, uint32_t split, uint32_t *slope, float *freq, int *mode);
+/* get_gain / get_band_start / get_band_end / band_active after reconfigure(), Crossover.cpp:256-325 */
+int mi_crossover_bank_get_band(mi_crossover_bank_t *bank, uint32_t band, float *gain, float *start, float *end, int *active,
+                               void *stream);
+/*
+ * Crossover::process(in, samples), Crossover.cpp:451-498.  band_out: HOST array of `bands` DEVICE pointers
+ * [channels][out_stride]; NULL = no handler bound to that band (its low-pass is skipped like in the reference).
+ * Inactive bands are not written.  in: [channels][in_stride].
+ */
+int mi_crossover_bank_process(mi_crossover_bank_t *bank, float *const *band_out, const float *in, size_t samples,
+                              size_t out_stride, size_t in_stride, void *stream);
+/* freq_chart(band, c, f, count), packed complex (re, im interleaved), HOST memory, Crossover.cpp:500-590 */
+int mi_crossover_bank_freq_chart(mi_crossover_bank_t *bank, uint32_t band, float *c, const float *f, size_t count, void *stream);
+
 /* ---- delay line and ring buffer banks ----------------------------------------------------- */
 /*
  * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  All

@@ -12,6 +12,7 @@ Import with ``importlib.import_module("lsp-dsp-units_amd")`` (the directory
 name carries the reference's name and is not a Python identifier).
 """
 from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
-from .units import (AnalyzerBank, BiquadBank, ConvolverBank, DelayBank, DeviceBuffer, EqualizerBank, RingBank,  # noqa: F401
+from .units import (AnalyzerBank, BiquadBank, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, EqualizerBank,  # noqa: F401
+                    RingBank,
                     SpectralBank,
                     design_filter, device_count, filter_freq_chart, make_window)

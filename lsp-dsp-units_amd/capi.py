@@ -111,6 +111,17 @@ PROTOTYPES = {
     "mi_equalizer_bank_set_actual_sample_rate": (c_int, [c_void_p, c_uint32]),
     "mi_equalizer_bank_get_latency": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "mi_equalizer_bank_set_smooth": (c_int, [c_void_p, c_int]),
+    "mi_crossover_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
+    "mi_crossover_bank_destroy": (c_int, [c_void_p]),
+    "mi_crossover_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),
+    "mi_crossover_bank_set_slope": (c_int, [c_void_p, c_uint32, c_uint32]),
+    "mi_crossover_bank_set_frequency": (c_int, [c_void_p, c_uint32, c_float]),
+    "mi_crossover_bank_set_mode": (c_int, [c_void_p, c_uint32, c_int]),
+    "mi_crossover_bank_set_gain": (c_int, [c_void_p, c_uint32, c_float]),
+    "mi_crossover_bank_get_split": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_float), POINTER(c_int)]),
+    "mi_crossover_bank_get_band": (c_int, [c_void_p, c_uint32, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int), c_void_p]),
+    "mi_crossover_bank_process": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_crossover_bank_freq_chart": (c_int, [c_void_p, c_uint32, POINTER(c_float), POINTER(c_float), c_size_t, c_void_p]),
     "mi_equalizer_bank_reset": (c_int, [c_void_p, c_void_p]),
     "mi_equalizer_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_equalizer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int), POINTER(c_uint32)]),

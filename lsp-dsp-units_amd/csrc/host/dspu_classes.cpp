@@ -10,6 +10,7 @@
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Analyzer.h>
@@ -946,6 +947,216 @@ void MultiSpectralProcessor::dump(IStateDumper *v) const
 {
     v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
     v->write("nRank", get_rank());
+}
+
+// ---- Crossover --------------------------------------------------------------------------------------------------
+struct Crossover::impl_t
+{
+    mi_crossover_bank_t *bank = nullptr;
+    size_t  bands = 0, buf_size = 0, sample_rate = 48000;
+    struct handler_t { crossover_func_t func = nullptr; void *object = nullptr, *subject = nullptr; };
+    std::vector<handler_t> handlers;
+    std::vector<float *>   d_band;          // one device buffer of buf_size samples per band
+    std::vector<float>     host;
+    float  *d_in = nullptr;
+};
+
+Crossover::Crossover() : pImpl(nullptr) { construct(); }
+Crossover::~Crossover() { destroy(); }
+void Crossover::construct() { pImpl = nullptr; }
+
+void Crossover::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_crossover_bank_destroy(pImpl->bank);
+    for (float *p : pImpl->d_band)
+        mi_dspu_free(p);
+    mi_dspu_free(pImpl->d_in);
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+bool Crossover::init(size_t bands, size_t buf_size)
+{
+    if (bands < 1)                                          // Crossover.cpp:73-74
+        return false;
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return false;
+    bool ok = mi_crossover_bank_create(&p->bank, 1, uint32_t(bands)) == MI_OK;
+    p->bands = bands;
+    p->buf_size = (buf_size > 0) ? buf_size : 1;
+    p->handlers.resize(bands);
+    p->d_band.assign(bands, nullptr);
+    for (size_t i = 0; ok && i < bands; ++i)
+        ok = mi_dspu_malloc(reinterpret_cast<void **>(&p->d_band[i]), p->buf_size * sizeof(float)) == MI_OK;
+    ok = ok && mi_dspu_malloc(reinterpret_cast<void **>(&p->d_in), p->buf_size * sizeof(float)) == MI_OK;
+    if (!ok)
+    {
+        mi_crossover_bank_destroy(p->bank);
+        for (float *q : p->d_band)
+            mi_dspu_free(q);
+        mi_dspu_free(p->d_in);
+        delete p;
+        return false;
+    }
+    destroy();
+    p->buf_size = buf_size;
+    pImpl = p;
+    return true;
+}
+
+size_t Crossover::num_bands() const        { return pImpl ? pImpl->bands : 1; }
+size_t Crossover::num_splits() const       { return pImpl ? pImpl->bands - 1 : 0; }
+size_t Crossover::max_buffer_size() const  { return pImpl ? pImpl->buf_size : 0; }
+
+void Crossover::set_slope(size_t sp, size_t slope)
+{
+    if (pImpl) mi_crossover_bank_set_slope(pImpl->bank, uint32_t(sp), uint32_t(slope));
+}
+
+ssize_t Crossover::get_slope(size_t sp) const
+{
+    uint32_t v = 0;
+    return (pImpl && sp + 1 < pImpl->bands && mi_crossover_bank_get_split(pImpl->bank, uint32_t(sp), &v, nullptr, nullptr) == MI_OK) ? ssize_t(v) : -1;
+}
+
+void Crossover::set_frequency(size_t sp, float freq)
+{
+    if (pImpl) mi_crossover_bank_set_frequency(pImpl->bank, uint32_t(sp), freq);
+}
+
+float Crossover::get_frequency(size_t sp) const
+{
+    float v = -1.0f;
+    return (pImpl && sp + 1 < pImpl->bands && mi_crossover_bank_get_split(pImpl->bank, uint32_t(sp), nullptr, &v, nullptr) == MI_OK) ? v : -1.0f;
+}
+
+void Crossover::set_mode(size_t sp, crossover_mode_t mode)
+{
+    if (pImpl) mi_crossover_bank_set_mode(pImpl->bank, uint32_t(sp), int(mode));
+}
+
+ssize_t Crossover::get_mode(size_t sp) const
+{
+    int v = -1;
+    return (pImpl && sp + 1 < pImpl->bands && mi_crossover_bank_get_split(pImpl->bank, uint32_t(sp), nullptr, nullptr, &v) == MI_OK) ? ssize_t(v) : -1;
+}
+
+void Crossover::set_gain(size_t band, float gain)
+{
+    if (pImpl) mi_crossover_bank_set_gain(pImpl->bank, uint32_t(band), gain);
+}
+
+namespace
+{
+    // one field of a band after reconfigure(); `fallback` for bad indices (Crossover.cpp:256-325)
+    float crossover_band_field(mi_crossover_bank_t *bank, size_t bands, size_t band, int which, float fallback)
+    {
+        float g = 0.0f, s = 0.0f, e = 0.0f;
+        int a = 0;
+        if (bank == nullptr || band >= bands || mi_crossover_bank_get_band(bank, uint32_t(band), &g, &s, &e, &a, nullptr) != MI_OK)
+            return fallback;
+        return (which == 0) ? g : (which == 1) ? s : (which == 2) ? e : float(a);
+    }
+}
+
+float Crossover::get_gain(size_t band) const
+{
+    return pImpl ? crossover_band_field(pImpl->bank, pImpl->bands, band, 0, -1.0f) : -1.0f;
+}
+float Crossover::get_band_start(size_t band)   { return pImpl ? crossover_band_field(pImpl->bank, pImpl->bands, band, 1, -1.0f) : -1.0f; }
+float Crossover::get_band_end(size_t band)     { return pImpl ? crossover_band_field(pImpl->bank, pImpl->bands, band, 2, -1.0f) : -1.0f; }
+bool Crossover::band_active(size_t band)       { return pImpl && crossover_band_field(pImpl->bank, pImpl->bands, band, 3, 0.0f) != 0.0f; }
+
+bool Crossover::set_handler(size_t band, crossover_func_t func, void *object, void *subject)
+{
+    if (pImpl == nullptr || band >= pImpl->bands)
+        return false;
+    pImpl->handlers[band].func = func;
+    pImpl->handlers[band].object = object;
+    pImpl->handlers[band].subject = subject;
+    return true;
+}
+
+bool Crossover::unset_handler(size_t band)     { return set_handler(band, nullptr, nullptr, nullptr); }
+
+void Crossover::set_sample_rate(size_t sr)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->sample_rate = sr;
+    mi_crossover_bank_set_sample_rate(pImpl->bank, uint32_t(sr));
+}
+
+size_t Crossover::get_sample_rate()            { return pImpl ? pImpl->sample_rate : 48000; }
+
+void Crossover::reconfigure()
+{
+    if (pImpl) mi_crossover_bank_get_band(pImpl->bank, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+}
+
+bool Crossover::freq_chart(size_t band, float *c, const float *f, size_t count)
+{
+    if (pImpl == nullptr || band >= pImpl->bands)
+        return false;
+    return mi_crossover_bank_freq_chart(pImpl->bank, uint32_t(band), c, f, count, nullptr) == MI_OK;
+}
+
+bool Crossover::freq_chart(size_t band, float *re, float *im, const float *f, size_t count)
+{
+    if (pImpl == nullptr || band >= pImpl->bands)
+        return false;
+    std::vector<float> c(2 * count);
+    if (mi_crossover_bank_freq_chart(pImpl->bank, uint32_t(band), c.data(), f, count, nullptr) != MI_OK)
+        return false;
+    for (size_t i = 0; i < count; ++i)
+    {
+        re[i] = c[2 * i];
+        im[i] = c[2 * i + 1];
+    }
+    return true;
+}
+
+void Crossover::process(const float *in, size_t samples)   // Crossover.cpp:451-498: chunks of buf_size, handlers per chunk
+{
+    impl_t *p = pImpl;
+    if (p == nullptr)
+        return;
+    std::vector<float *> outs(p->bands);
+    for (size_t sample = 0; sample < samples; )
+    {
+        const size_t to_do = std::min(samples - sample, p->buf_size);
+        for (size_t b = 0; b < p->bands; ++b)
+            outs[b] = (p->handlers[b].func != nullptr) ? p->d_band[b] : nullptr;
+        if (mi_dspu_copy_h2d(p->d_in, in, to_do * sizeof(float), nullptr) != MI_OK ||
+            mi_crossover_bank_process(p->bank, outs.data(), p->d_in, to_do, to_do, to_do, nullptr) != MI_OK)
+            return;
+        p->host.resize(to_do);
+        // handlers fire from the lowest band upwards, the order the reference walks its plan in
+        std::vector<std::pair<float, size_t> > order;
+        for (size_t b = 0; b < p->bands; ++b)
+            if (outs[b] != nullptr && band_active(b))
+                order.push_back(std::make_pair((b == 0) ? -1.0f : get_band_start(b), b));
+        std::sort(order.begin(), order.end());
+        for (size_t k = 0; k < order.size(); ++k)
+        {
+            const size_t b = order[k].second;
+            if (mi_dspu_copy_d2h(p->host.data(), outs[b], to_do * sizeof(float), nullptr) != MI_OK ||
+                mi_dspu_stream_synchronize(nullptr) != MI_OK)
+                return;
+            p->handlers[b].func(p->handlers[b].object, p->handlers[b].subject, b, p->host.data(), sample, to_do);
+        }
+        in += to_do;
+        sample += to_do;
+    }
+}
+
+void Crossover::dump(IStateDumper *v) const
+{
+    v->write("nSplits", num_splits());
+    v->write("nBufSize", max_buffer_size());
 }
 
 // ---- Delay -----------------------------------------------------------------------------------------------------

@@ -1,6 +1,6 @@
 """Small object wrappers over the C-ABI handles (no arithmetic here)."""
 import ctypes
-from ctypes import byref, c_float, c_uint32, c_void_p
+from ctypes import byref, c_float, c_int, c_uint32, c_void_p
 
 import numpy as np
 
@@ -407,6 +407,68 @@ class RingBank:
     def close(self):
         if self.handle:
             lib.mi_ring_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CrossoverBank:
+    """lsp::dspu::Crossover for `channels` channels sharing the split settings (mi_crossover_bank_*)."""
+    MODE_BT, MODE_MT = 0, 1
+
+    def __init__(self, channels, bands):
+        h = c_void_p()
+        check(lib.mi_crossover_bank_create(byref(h), channels, bands))
+        self.handle, self.channels, self.bands = h, channels, bands
+
+    def set_sample_rate(self, sr):
+        check(lib.mi_crossover_bank_set_sample_rate(self.handle, sr))
+
+    def set_slope(self, split, slope):
+        check(lib.mi_crossover_bank_set_slope(self.handle, split, slope))
+
+    def set_frequency(self, split, freq):
+        check(lib.mi_crossover_bank_set_frequency(self.handle, split, float(freq)))
+
+    def set_mode(self, split, mode):
+        check(lib.mi_crossover_bank_set_mode(self.handle, split, mode))
+
+    def set_gain(self, band, gain):
+        check(lib.mi_crossover_bank_set_gain(self.handle, band, float(gain)))
+
+    def get_split(self, split):
+        sl, fr, mo = c_uint32(), c_float(), c_int()
+        check(lib.mi_crossover_bank_get_split(self.handle, split, byref(sl), byref(fr), byref(mo)))
+        return {"slope": sl.value, "freq": fr.value, "mode": mo.value}
+
+    def get_band(self, band, stream=None):
+        g, s0, s1, act = c_float(), c_float(), c_float(), c_int()
+        check(lib.mi_crossover_bank_get_band(self.handle, band, byref(g), byref(s0), byref(s1), byref(act), _stream(stream)))
+        return {"gain": g.value, "start": s0.value, "end": s1.value, "active": bool(act.value)}
+
+    def process(self, band_out, inp, samples, out_stride=None, in_stride=None, stream=None):
+        """band_out: list of `bands` device buffers or None (band without a handler)."""
+        arr = (c_void_p * self.bands)(*[(_ptr(b) if b is not None else None) for b in band_out])
+        check(lib.mi_crossover_bank_process(self.handle, arr, _ptr(inp), samples,
+                                            samples if out_stride is None else out_stride,
+                                            samples if in_stride is None else in_stride, _stream(stream)))
+
+    def freq_chart(self, band, freqs, stream=None):
+        import numpy as np
+        f = np.ascontiguousarray(freqs, dtype=np.float32)
+        c = np.empty(2 * f.size, np.float32)
+        from ctypes import POINTER as _P
+        check(lib.mi_crossover_bank_freq_chart(self.handle, band, c.ctypes.data_as(_P(c_float)),
+                                               f.ctypes.data_as(_P(c_float)), f.size, _stream(stream)))
+        return c[0::2] + 1j * c[1::2]
+
+    def close(self):
+        if self.handle:
+            lib.mi_crossover_bank_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

@@ -11,6 +11,7 @@
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/units.h>
@@ -181,6 +182,48 @@ static void multi_spectral_proc()
     mp.destroy();
 }
 
+// Crossover (no reference utest): three LR4 bands with per-band handlers that add their data into one buffer -- an LR4
+// crossover sums to an all-pass, so the sum keeps the input's energy; handler offsets follow the buf_size chunks.
+struct xover_sum_t { std::vector<float> sum; size_t calls; size_t last_first; };
+static void xover_collect(void *object, void *, size_t band, const float *data, size_t first, size_t count)
+{
+    xover_sum_t *s = static_cast<xover_sum_t *>(object);
+    for (size_t i = 0; i < count; ++i) s->sum[s->last_first + first + i] += data[i];
+    ++s->calls;
+    (void)band;
+}
+
+static void crossover_bands_sum_to_allpass()
+{
+    printf("crossover (3 bands LR4, handlers)\n");
+    const size_t SAMPLES = 16384, BUF = 1000;
+    std::vector<float> in(2 * SAMPLES, 0.0f);
+    srand(4);
+    for (size_t i = 0; i < SAMPLES; ++i) in[i] = float(rand()) / float(RAND_MAX) - 0.5f;
+    dspu::Crossover x;
+    CHECK(!x.init(0, BUF), "init(0 bands) must fail");
+    CHECK(x.init(3, BUF), "init");
+    CHECK(x.num_bands() == 3 && x.num_splits() == 2 && x.max_buffer_size() == BUF, "geometry");
+    x.set_sample_rate(48000);
+    x.set_slope(0, dspu::CROSS_SLOPE_LR4); x.set_frequency(0, 300.0f);
+    x.set_slope(1, dspu::CROSS_SLOPE_LR4); x.set_frequency(1, 3000.0f);
+    CHECK(x.get_slope(1) == dspu::CROSS_SLOPE_LR4 && x.get_frequency(0) == 300.0f && x.get_mode(0) == dspu::CROSS_MODE_BT, "getters");
+    CHECK(x.get_slope(2) == -1 && x.get_gain(3) == -1.0f, "getters out of range");
+    CHECK(x.band_active(0) && x.band_active(1) && x.band_active(2), "bands active");
+    CHECK(x.get_band_end(0) == 300.0f && x.get_band_start(2) == 3000.0f && x.get_band_end(2) == 24000.0f, "band ranges");
+    xover_sum_t acc; acc.sum.assign(2 * SAMPLES, 0.0f); acc.calls = 0; acc.last_first = 0;
+    for (size_t b = 0; b < 3; ++b) CHECK(x.set_handler(b, xover_collect, &acc, NULL), "set_handler");
+    CHECK(!x.set_handler(3, xover_collect, &acc, NULL), "set_handler out of range");
+    x.process(in.data(), 2 * SAMPLES);
+    CHECK(acc.calls == 3 * ((2 * SAMPLES + BUF - 1) / BUF), "handler calls %zu", acc.calls);
+    double ein = 0.0, eout = 0.0;
+    for (size_t i = 0; i < 2 * SAMPLES; ++i) { ein += double(in[i]) * in[i]; eout += double(acc.sum[i]) * acc.sum[i]; }
+    CHECK(fabs(eout / ein - 1.0) < 2e-3, "energy ratio %.5f", eout / ein);
+    float c[4]; const float f[2] = { 30.0f, 10000.0f };
+    CHECK(x.freq_chart(0, c, f, 2) && fabsf(hypotf(c[0], c[1]) - 1.0f) < 1e-2f && hypotf(c[2], c[3]) < 1e-3f, "freq_chart band 0");
+    x.destroy();
+}
+
 static void ringbuffer()
 {
     printf("ringbuffer\n");
@@ -240,7 +283,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc ringbuffer readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover ringbuffer readme_filter");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -256,6 +299,7 @@ int main(int argc, char **argv)
     spectral_proc_simple();
     spectral_proc_callback();
     multi_spectral_proc();
+    crossover_bands_sum_to_allpass();
     ringbuffer();
     readme_filter();
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");

@@ -1,0 +1,136 @@
+"""GPU parity of mi_crossover_bank_* (lsp::dspu::Crossover) against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+import oracle
+from oracle import crossover as oc
+
+pytestmark = pytest.mark.gpu
+
+
+def run_both(gpu, C, bands, script, n_blocks, block, handlers=None, seed=3):
+    """script: {block_index: [(setter, args...), ...]} applied to both before that block."""
+    rng = np.random.default_rng(seed)
+    x = (rng.standard_normal((C, n_blocks * block)) * 0.25).astype(np.float32)
+    bank = gpu.CrossoverBank(C, bands)
+    refs = [oc.Crossover(bands) for _ in range(C)]
+    handlers = list(range(bands)) if handlers is None else handlers
+    got = {b: np.zeros_like(x) for b in handlers}
+    ref = {b: np.zeros_like(x) for b in handlers}
+    wrote = {b: False for b in handlers}
+    for k in range(n_blocks):
+        for name, *args in script.get(k, []):
+            getattr(bank, name)(*args)
+            for r in refs:
+                getattr(r, name)(*args)
+        seg = slice(k * block, (k + 1) * block)
+        din = gpu.DeviceBuffer.from_host(x[:, seg])
+        outs = [gpu.DeviceBuffer.from_host(np.full((C, block), 7.0, np.float32)) if b in handlers else None for b in range(bands)]
+        bank.process(outs, din, block)
+        per_ch = [r.process(x[c, seg], handlers) for c, r in enumerate(refs)]
+        for b in handlers:
+            y = outs[b].download()
+            if b in per_ch[0]:
+                got[b][:, seg] = y
+                wrote[b] = True
+                for c in range(C):
+                    ref[b][c, seg] = per_ch[c][b]
+            else:
+                assert np.all(y == 7.0), "inactive band %d must not be written" % b
+    return bank, refs, x, got, ref, wrote
+
+
+def f64_bands(r, x):
+    """The same chain in float64 from a zero state (no retunes): band -> output."""
+    out, src = {}, np.asarray(x, np.float64)
+    left = 0
+    for pi in r.plan:
+        sp = r.split[pi]
+        out[left] = oracle.biquad_cascade_f64(src, sp["lpf_coef"])
+        src = oracle.biquad_cascade_f64(src, sp["hpf_coef"])
+        left = sp["band"]
+    out[left] = src
+    return out
+
+
+def check_bands(x, got, ref, refs, wrote, what, tol=2e-5, exact=False):
+    """Recursive filters: the float32 round-off of the recursion bounds reproducibility.
+    exact: the configuration never changed -> every band against its own noise floor (conftest.assert_iir_parity,
+    float64 chain as the yardstick).  Otherwise a fixed tolerance relative to the level inside the chain (the
+    input's, not what a narrow band lets through); chained cascades accumulate a little more than a single one."""
+    for b in got:
+        if not wrote[b]:
+            continue
+        for c in range(x.shape[0]):
+            if exact:
+                # conftest.assert_iir_parity's rule, normalised by the level inside the chain (the input's peak) rather
+                # than by what the band lets through
+                ex = f64_bands(refs[c], x[c])[b]
+                P = max(float(np.abs(ref[b][c]).max()), float(np.abs(x[c]).max()))
+                noise = float(np.abs(ref[b][c] - ex).max()) / P
+                e32 = float(np.abs(got[b][c] - ref[b][c]).max()) / P
+                e64 = float(np.abs(got[b][c] - ex).max()) / P
+                msg = "%s band %d ch %d: vs oracle %.2e, vs float64 %.2e, oracle's own noise %.2e" % (what, b, c, e32, e64, noise)
+                if noise <= 3e-6:
+                    assert e32 <= 1e-5, msg
+                else:
+                    assert e64 <= 4 * noise and e32 <= 5 * noise, msg
+                continue
+            peak = max(float(np.abs(ref[b][c]).max()), float(np.abs(x[c]).max()))
+            err = float(np.abs(got[b][c] - ref[b][c]).max())
+            assert err <= tol * peak, "%s band %d ch %d: %.3e of peak %.3f" % (what, b, c, err / peak, peak)
+
+
+def test_four_band_lr4_matches_oracle_with_state_carry(gpu):
+    script = {0: [("set_sample_rate", 48000), ("set_slope", 0, 2), ("set_frequency", 0, 120.0),
+                  ("set_slope", 1, 2), ("set_frequency", 1, 1000.0), ("set_slope", 2, 2), ("set_frequency", 2, 8000.0),
+                  ("set_gain", 1, 1.5), ("set_gain", 3, 0.5)]}
+    bank, refs, x, got, ref, wrote = run_both(gpu, 3, 4, script, 4, 2048)
+    check_bands(x, got, ref, refs, wrote, "LR4", exact=True)
+    for b in range(4):
+        assert bank.get_band(b) == pytest.approx(refs[0].band_info(b))
+    bank.close()
+
+
+def test_retunes_slopes_modes_and_unsorted_split_points(gpu):
+    """slopes LR2..LR16, matched-transform mode, a split point switched off and on, frequencies out of order,
+    gain changes: the plan is rebuilt, filter states survive or clear exactly as in the reference."""
+    script = {
+        0: [("set_sample_rate", 44100), ("set_slope", 0, 3), ("set_frequency", 0, 3000.0), ("set_slope", 2, 1),
+            ("set_frequency", 2, 300.0), ("set_mode", 2, 1)],
+        1: [("set_gain", 0, 0.7), ("set_frequency", 0, 2500.0)],
+        2: [("set_slope", 1, 5), ("set_frequency", 1, 900.0)],
+        3: [("set_slope", 2, 0)],
+        4: [("set_slope", 2, 4), ("set_mode", 0, 1), ("set_gain", 3, 2.0)],
+    }
+    bank, refs, x, got, ref, wrote = run_both(gpu, 2, 4, script, 6, 1500, seed=4)
+    check_bands(x, got, ref, refs, wrote, "retune", tol=5e-5)
+    assert all(wrote.values())
+    bank.close()
+
+
+def test_bands_without_handler_and_single_band(gpu):
+    script = {0: [("set_slope", 0, 2), ("set_frequency", 0, 500.0), ("set_slope", 1, 2), ("set_frequency", 1, 4000.0)]}
+    bank, refs, x, got, ref, wrote = run_both(gpu, 2, 3, script, 3, 1024, handlers=[0, 2])
+    check_bands(x, got, ref, refs, wrote, "handlers 0,2", exact=True)
+    bank.close()
+    # no active split point: band 0 is the input times its gain (Crossover.cpp:486-490)
+    bank, refs, x, got, ref, wrote = run_both(gpu, 2, 3, {0: [("set_gain", 0, 0.25)]}, 1, 777)
+    assert wrote[0] and not wrote[1] and not wrote[2]
+    np.testing.assert_array_equal(got[0], (x * np.float32(0.25)).astype(np.float32))
+    bank.close()
+
+
+def test_freq_charts_match_oracle(gpu):
+    bank = gpu.CrossoverBank(1, 4)
+    ref = oc.Crossover(4)
+    for obj in (bank, ref):
+        obj.set_sample_rate(48000)
+        for i, (sl, fr) in enumerate(((2, 150.0), (4, 1200.0), (1, 7000.0))):
+            obj.set_slope(i, sl); obj.set_frequency(i, fr)
+        obj.set_gain(2, 1.7)
+    f = np.geomspace(10.0, 22000.0, 300).astype(np.float32)
+    for b in range(4):
+        g, r = bank.freq_chart(b, f), ref.freq_chart(b, f)
+        assert np.abs(g - r).max() <= 2e-5 * max(1.0, np.abs(r).max()), b
+    bank.close()
