@@ -45,8 +45,8 @@ def parse():
     ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
     ap.add_argument("--eq-channels", type=int, default=256, help="equalizer channels per GPU (config 3: 2048 over 8 GPUs)")
     ap.add_argument("--spec-channels", type=int, default=1024, help="analyzer channels per GPU (config 4: 8192 over 8 GPUs)")
-    ap.add_argument("--conv-steps", type=int, default=50)
-    ap.add_argument("--conv-warmup", type=int, default=5)
+    ap.add_argument("--conv-steps", type=int, default=200)
+    ap.add_argument("--conv-warmup", type=int, default=10)
     return ap.parse_args()
 
 
@@ -193,16 +193,27 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True)
     probes = list(range(steps - burst, steps))
     starts = {i: new_event() for i in probes}
     stops = {i: new_event() for i in probes}
+    trace = [] if os.environ.get("MI_BENCH_TRACE") else None
+    # no interpreter housekeeping inside the timed region (a generation-2 collection after the set-up's many small
+    # ctypes objects costs more than a thousand of these steps' launch calls)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for i in range(steps):
         if i in starts:
             mi.check(mi.lib.mi_dspu_profile_next_launch(starts[i], stops[i]))
         step(warmup + i)
+        if trace is not None:
+            trace.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
+    if trace is not None:
+        print("host return times (us):", [round(t * 1e6) for t in trace[:16]], "end", round(elapsed * 1e6), file=sys.stderr)
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)

@@ -1,7 +1,7 @@
 // In-LDS Stockham FFT for one workgroup (device code shared by the convolver, equalizer and spectral kernels).
 //
-// The transform is the autosort radix-4 decimation-in-frequency Stockham scheme with a final radix-2
-// pass when log2(N) is odd.  A workgroup of T threads owns one N-point complex sequence held in a single
+// The transform is the autosort decimation-in-frequency Stockham scheme with radix-8 passes followed by up to two
+// radix-4 passes.  A workgroup of T threads owns one N-point complex sequence held in a single
 // pair of LDS buffers: in every pass each thread pulls its butterflies' inputs from one buffer and writes the outputs
 // permuted into the other (read index j + k*N/4 is conflict free; the write index q + s*(4p + k) is the autosort
 // permutation, bank-swizzled in the intermediate passes).  No bit reversal, one barrier per pass.
@@ -59,40 +59,54 @@ namespace mi_fft
     __device__ __forceinline__ v2f ld2(const float2 *p) { return *reinterpret_cast<const v2f *>(p); }
     __device__ __forceinline__ void st2(float2 *p, v2f v) { *reinterpret_cast<v2f *>(p) = v; }
 
-    // Number of threads that cooperate on one N = 2^LOGN point transform.
+    // Pass plan of one N = 2^LOGN point transform: radix-8 passes first, then radix-4 passes (3a + 2b = LOGN with b <= 2:
+    // every LOGN >= 2 except 3 decomposes; LOGN == 3 is a single radix-8 pass).  One radix-8 butterfly per thread.
     template <int LOGN>
     struct plan
     {
         static constexpr int N   = 1 << LOGN;
-        static constexpr int T   = (N / 4 > 64) ? ((N / 4 > 1024) ? 1024 : N / 4) : 64;   // one butterfly per thread
-        static constexpr int BPT = (N / 4 + T - 1) / T;         // radix-4 butterflies per thread and pass
+        static constexpr int N4  = (LOGN % 3 == 0) ? 0 : (LOGN % 3 == 2) ? 1 : (LOGN >= 4 ? 2 : 0);   // radix-4 passes
+        static constexpr int N8  = (LOGN - 2 * N4) / 3;                                               // radix-8 passes
+        static constexpr int NP  = N8 + N4;
+        static constexpr int TB  = (N8 > 0) ? N / 8 : N / 4;                         // butterflies of the widest pass
+        static constexpr int T   = (TB > 64) ? ((TB > 1024) ? 1024 : TB) : 64;
+        static constexpr int BPT8 = (N / 8 + T - 1) / T;        // radix-8 butterflies per thread and pass
+        static constexpr int BPT4 = (N / 4 + T - 1) / T;        // radix-4 butterflies per thread and pass
+        static_assert(LOGN >= 2 && 3 * N8 + 2 * N4 == LOGN, "unsupported transform size");
+        // radix of pass i and the stride (product of the radices before it)
+        static constexpr int radix(int i)  { return (i < N8) ? 8 : 4; }
+        static constexpr int stride(int i) { return (i <= N8) ? (1 << (3 * i)) : (1 << (3 * N8 + 2 * (i - N8))); }
     };
 
-    // Bank swizzle of the intermediate passes: the autosort write index q + s*(4p + k) has a stride of 4 (s = 1) or
-    // 16 (s = 4) complex values between neighbouring lanes -- an 8-way LDS bank conflict in the first two passes.
+    // Bank swizzle of the intermediate passes: the autosort write index q + s*(R p + k) has a stride of R (s = 1) or
+    // R^2 complex values between neighbouring lanes -- a many-way LDS bank conflict in the first passes.
     // XOR-ing the low four index bits with the next four spreads those writes over all banks; reads of 16 consecutive
     // values stay a permutation of the same 16 slots.  First read and last write of a transform use natural order.
     template <int N>
     __device__ __forceinline__ int swz(int i) { return (N >= 256) ? (i ^ ((i >> 4) & 15)) : i; }
 
-    // Twiddles of every radix-4 pass for the butterflies this thread owns, fetched once (ideally long before the
-    // transform: the table lives in global memory) and reused by the forward and the inverse transform.
+    // Twiddles of every pass for the butterflies this thread owns: W^(m p s), m = 1 .. radix-1, fetched (m = 1) once
+    // per kernel -- ideally long before the transform: the table lives in global memory -- and reused by the forward and
+    // the inverse transform.
     template <int LOGN>
     struct fft_tw
     {
-        v2f w[(LOGN / 2 > 0) ? LOGN / 2 : 1][plan<LOGN>::BPT][3];      // W^(p s), its square and cube
+        static constexpr int MAXB = (plan<LOGN>::BPT8 > plan<LOGN>::BPT4) ? plan<LOGN>::BPT8 : plan<LOGN>::BPT4;
+        v2f w[plan<LOGN>::NP][MAXB][7];
     };
 
     // Two steps, so that the table reads can be issued first thing in a kernel and their latency hidden behind the
-    // kernel's other loads: load_fft_tw() only requests W^(p s); finish_fft_tw() derives the square and the cube.
+    // kernel's other loads: load_fft_tw() only requests W^(p s); finish_fft_tw() derives the higher powers.
     template <int LOGN>
     __device__ __forceinline__ void load_fft_tw(fft_tw<LOGN> &r, const float2 *__restrict__ tw, int tw_stride /* TWN / N */, int tid)
     {
         using P = plan<LOGN>;
-        constexpr int T = P::T, BPT = P::BPT, Q = P::N / 4;
-        int s = 1;
+        constexpr int T = P::T, N = P::N;
         #pragma unroll
-        for (int pass = 0; pass < LOGN / 2; ++pass, s <<= 2)
+        for (int pass = 0; pass < P::NP; ++pass)
+        {
+            const int R = P::radix(pass), s = P::stride(pass), Q = N / R;
+            const int BPT = (R == 8) ? P::BPT8 : P::BPT4;
             #pragma unroll
             for (int b = 0; b < BPT; ++b)
             {
@@ -100,26 +114,68 @@ namespace mi_fft
                 if (s < Q)                                          // s == Q: p = 0, the twiddles are 1 and unused
                     r.w[pass][b][0] = ld2(tw + (j & ~(s - 1)) * tw_stride);     // W_N^(p s), p = j / s
             }
+        }
     }
 
     template <int LOGN>
     __device__ __forceinline__ void finish_fft_tw(fft_tw<LOGN> &r)
     {
         using P = plan<LOGN>;
-        constexpr int BPT = P::BPT, Q = P::N / 4;
-        int s = 1;
         #pragma unroll
-        for (int pass = 0; pass < LOGN / 2; ++pass, s <<= 2)
+        for (int pass = 0; pass < P::NP; ++pass)
+        {
+            const int R = P::radix(pass), s = P::stride(pass), Q = P::N / R;
+            const int BPT = (R == 8) ? P::BPT8 : P::BPT4;
             #pragma unroll
             for (int b = 0; b < BPT; ++b)
                 if (s < Q)
                 {
-                    // one table value per butterfly; w^2 and w^3 by multiplication (2 roundings, ~1e-7)
+                    // one table value per butterfly; the higher powers by multiplication (a few roundings, ~1e-7)
                     const v2f w1 = r.w[pass][b][0];
                     const v2f w2 = pmul<false>(w1, w1);
+                    const v2f w3 = pmul<false>(w2, w1);
                     r.w[pass][b][1] = w2;
-                    r.w[pass][b][2] = pmul<false>(w2, w1);
+                    r.w[pass][b][2] = w3;
+                    if (R == 8)
+                    {
+                        const v2f w4 = pmul<false>(w2, w2);
+                        r.w[pass][b][3] = w4;
+                        r.w[pass][b][4] = pmul<false>(w4, w1);
+                        r.w[pass][b][5] = pmul<false>(w3, w3);
+                        r.w[pass][b][6] = pmul<false>(w4, w3);
+                    }
                 }
+        }
+    }
+
+    // 4-point DFT in registers, outputs in natural order (forward: e^{-j}, INVERSE: e^{+j})
+    template <bool INVERSE>
+    __device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
+    {
+        const v2f apc = x0 + x2, amc = x0 - x2, bpd = x1 + x3, bmd = x1 - x3;
+        x0 = apc + bpd;
+        x1 = padd_i<INVERSE>(amc, bmd);          // forward: (a-c) - i (b-d)
+        x2 = apc - bpd;
+        x3 = padd_i<!INVERSE>(amc, bmd);
+    }
+
+    // 8-point DFT in registers, outputs in natural order: even outputs = DFT4 of the sums, odd outputs = DFT4 of the
+    // differences rotated by W8^k
+    template <bool INVERSE>
+    __device__ __forceinline__ void dft8(v2f (&x)[8])
+    {
+        constexpr float H = 0.70710678118654752f;
+        v2f a0 = x[0] + x[4], a1 = x[1] + x[5], a2 = x[2] + x[6], a3 = x[3] + x[7];
+        v2f b0 = x[0] - x[4], b1 = x[1] - x[5], b2 = x[2] - x[6], b3 = x[3] - x[7];
+        // W8^1 = (1 -+ i)/sqrt2, W8^2 = -+i, W8^3 = (-1 -+ i)/sqrt2   (upper sign: forward)
+        b1 = padd_i<INVERSE>(b1, b1) * v2f{H, H};                // b1 (1 -+ i) / sqrt2
+        const v2f t3 = padd_i<!INVERSE>(b3, b3) * v2f{H, H};     // b3 (1 +- i) / sqrt2, negated below
+        b3 = -t3;
+        b2 = INVERSE ? v2f{-b2.y, b2.x} : v2f{b2.y, -b2.x};      // b2 * (-+ i)
+        dft4<INVERSE>(a0, a1, a2, a3);
+        dft4<INVERSE>(b0, b1, b2, b3);
+        x[0] = a0; x[2] = a1; x[4] = a2; x[6] = a3;
+        x[1] = b0; x[3] = b1; x[5] = b2; x[7] = b3;
     }
 
     // buf: N complex points in LDS in natural order, scr: N more.  All T threads of the workgroup must call this (it
@@ -130,87 +186,92 @@ namespace mi_fft
     __device__ void fft_lds(float2 *buf, float2 *scr, const fft_tw<LOGN> &tws, int tid)
     {
         using P = plan<LOGN>;
-        constexpr int N = P::N, T = P::T, BPT = P::BPT, Q = N / 4;
-        constexpr int NP4 = LOGN / 2, NP = NP4 + (LOGN & 1);
+        constexpr int N = P::N, T = P::T, NP = P::NP;
 
         float2 *src = buf;
         float2 *dst = (NP & 1) ? buf : scr;
-        int s = 1;
         #pragma unroll
-        for (int pass = 0; pass < NP4; ++pass, s <<= 2)
+        for (int pass = 0; pass < NP; ++pass)
         {
             const bool first = (pass == 0), last = (pass == NP - 1);
-            v2f v[BPT][4];
-            #pragma unroll
-            for (int b = 0; b < BPT; ++b)
+            const int R = P::radix(pass), s = P::stride(pass), Q = N / R;
+            if (R == 8)
             {
-                const int j = tid + b * T;
-                if (j < Q)
+                constexpr int BPT = P::BPT8;
+                v2f v[BPT][8];
+                #pragma unroll
+                for (int b = 0; b < BPT; ++b)
                 {
-                    #pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        v[b][k] = ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
+                    const int j = tid + b * T;
+                    if (j < Q)
+                    {
+                        #pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            v[b][k] = ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
+                    }
+                }
+                if (dst == src)
+                    __syncthreads();
+                #pragma unroll
+                for (int b = 0; b < BPT; ++b)
+                {
+                    const int j = tid + b * T;
+                    if (j < Q)
+                    {
+                        const int q = j & (s - 1);
+                        const int o = q + 8 * (j - q);                   // q + R s p
+                        dft8<INVERSE>(v[b]);
+                        #pragma unroll
+                        for (int m = 0; m < 8; ++m)
+                        {
+                            v2f r = v[b][m];
+                            if (m > 0 && s < Q)                          // s == Q: p = 0, all twiddles are 1
+                                r = pmul<INVERSE>(tws.w[pass][b][m - 1], r);
+                            st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
+                        }
+                    }
                 }
             }
-            if (dst == src)
-                __syncthreads();
-            #pragma unroll
-            for (int b = 0; b < BPT; ++b)
+            else
             {
-                const int j = tid + b * T;
-                if (j < Q)
+                constexpr int BPT = P::BPT4;
+                v2f v[BPT][4];
+                #pragma unroll
+                for (int b = 0; b < BPT; ++b)
                 {
-                    const int q = j & (s - 1);                       // s is a power of four
-                    const v2f a = v[b][0], bb = v[b][1], c = v[b][2], d = v[b][3];
-                    const v2f apc = a + c, amc = a - c, bpd = bb + d, bmd = bb - d;
-                    // forward: a-c -+ i (b-d) ; inverse: a-c +- i (b-d)
-                    const int o = q + 4 * (j - q);                   // q + 4 s p
-                    v2f r0 = apc + bpd, r1 = padd_i<INVERSE>(amc, bmd), r2 = apc - bpd, r3 = padd_i<!INVERSE>(amc, bmd);
-                    if (s < Q)                                       // s == Q: p = 0, all twiddles are 1
+                    const int j = tid + b * T;
+                    if (j < Q)
                     {
-                        r1 = pmul<INVERSE>(tws.w[pass][b][0], r1);
-                        r2 = pmul<INVERSE>(tws.w[pass][b][1], r2);
-                        r3 = pmul<INVERSE>(tws.w[pass][b][2], r3);
+                        #pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            v[b][k] = ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
                     }
-                    st2(dst + (last ? o         : swz<N>(o)),         r0);
-                    st2(dst + (last ? o + s     : swz<N>(o + s)),     r1);
-                    st2(dst + (last ? o + 2 * s : swz<N>(o + 2 * s)), r2);
-                    st2(dst + (last ? o + 3 * s : swz<N>(o + 3 * s)), r3);
+                }
+                if (dst == src)
+                    __syncthreads();
+                #pragma unroll
+                for (int b = 0; b < BPT; ++b)
+                {
+                    const int j = tid + b * T;
+                    if (j < Q)
+                    {
+                        const int q = j & (s - 1);
+                        const int o = q + 4 * (j - q);
+                        dft4<INVERSE>(v[b][0], v[b][1], v[b][2], v[b][3]);
+                        #pragma unroll
+                        for (int m = 0; m < 4; ++m)
+                        {
+                            v2f r = v[b][m];
+                            if (m > 0 && s < Q)
+                                r = pmul<INVERSE>(tws.w[pass][b][m - 1], r);
+                            st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
+                        }
+                    }
                 }
             }
             __syncthreads();
             src = dst;
             dst = (src == buf) ? scr : buf;
-        }
-        if (LOGN & 1)           // one radix-2 pass left: pairs (j, j + N/2), stride N/2, no twiddle; always the last pass
-        {
-            constexpr int H = N / 2;
-            constexpr int PPT = (H + T - 1) / T;
-            constexpr bool first = (NP4 == 0);
-            v2f a[PPT], b2[PPT];
-            #pragma unroll
-            for (int b = 0; b < PPT; ++b)
-            {
-                const int j = tid + b * T;
-                if (j < H)
-                {
-                    a[b]  = ld2(src + (first ? j : swz<N>(j)));
-                    b2[b] = ld2(src + (first ? j + H : swz<N>(j + H)));
-                }
-            }
-            if (dst == src)
-                __syncthreads();
-            #pragma unroll
-            for (int b = 0; b < PPT; ++b)
-            {
-                const int j = tid + b * T;
-                if (j < H)
-                {
-                    st2(dst + j, a[b] + b2[b]);
-                    st2(dst + j + H, a[b] - b2[b]);
-                }
-            }
-            __syncthreads();
         }
     }
 
