@@ -100,7 +100,8 @@ namespace
     void conv_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                            float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                            float *acc, const float2 *__restrict__ Yt /* pending tail or NULL */,
-                           const float2 *__restrict__ tw)
+                           const float2 *__restrict__ tw,
+                           float *dl_ring /* or NULL */, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
@@ -119,6 +120,24 @@ namespace
         for (int i = 0; i < KPT; ++i)
         {
             const int n = tid + i * T;                      // B samples, zero-padded to 2B
+            if (dl_ring != nullptr)
+            {
+                // Equalizer FIR path: the frame is what a delay line of dl_size cells gives back (cells dl_tail ...,
+                // even offsets, so a pair never straddles the end), and the call's own samples go into the line
+                // at dl_head ... -- the two ranges do not meet (delay.hip, delay_exchange_kernel)
+                float *line = dl_ring + size_t(ch) * dl_size;
+                xin[i] = make_float2(0.0f, 0.0f);
+                if (n < B / 2)
+                {
+                    uint32_t r = dl_tail + 2 * n, w = dl_head + 2 * n;
+                    if (r >= dl_size) r -= dl_size;
+                    if (w >= dl_size) w -= dl_size;
+                    xin[i] = *reinterpret_cast<const float2 *>(line + r);
+                    *reinterpret_cast<float2 *>(line + w) =
+                        aligned ? *reinterpret_cast<const float2 *>(x + 2 * n) : make_float2(x[2 * n], x[2 * n + 1]);
+                }
+                continue;
+            }
             xin[i] = (n >= B / 2) ? make_float2(0.0f, 0.0f)
                    : aligned ? *reinterpret_cast<const float2 *>(x + 2 * n) : make_float2(x[2 * n], x[2 * n + 1]);
         }
@@ -530,6 +549,37 @@ namespace
     }
 } // namespace
 
+namespace mi
+{
+    bool convolver_takes_delayed_frame(const mi_convolver_bank_t *b, size_t samples)
+    {
+        return b != nullptr && b->live && b->off == 0 && samples == size_t(b->B) && !b->xfade_active &&
+               b->pending == mi_convolver_bank::PEND_NONE;
+    }
+
+    int convolver_process_delayed_frame(mi_convolver_bank_t *b, float *out, const float *in, size_t out_stride,
+                                        size_t in_stride, const delay_view &dl, hipStream_t st)
+    {
+        MI_REQUIRE(convolver_takes_delayed_frame(b, size_t(b->B)), MI_ESTATE, "convolver_process_delayed_frame: not at a plain frame boundary");
+        const uint32_t tail = (dl.head + dl.size - dl.delay) % dl.size;
+        MI_REQUIRE((dl.size % 2 == 0) && (tail % 2 == 0) && (dl.head % 2 == 0) && dl.delay >= uint32_t(b->B) &&
+                   size_t(dl.size - dl.delay) >= size_t(b->B), MI_EINVAL, "convolver_process_delayed_frame: delay line geometry");
+        const bool aligned = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 8 == 0) &&
+                             (out_stride % 2 == 0) && (in_stride % 2 == 0);
+        if (b->R > 0)
+            b->slot = (b->slot + 1) % b->R;
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                                               out, in, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
+                                               b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
+                                               dl.ring, dl.size, tail, dl.head)
+        MI_LOGM_SWITCH(b->logm, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        b->yt_pending = false;
+        return launch_mac(b, st);
+    }
+} // namespace mi
+
 extern "C" {
 
 int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, const float *irs, size_t ir_stride,
@@ -816,7 +866,8 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 b->slot = (b->slot + 1) % b->R;
             #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
                                                    o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
-                                                   b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw)
+                                                   b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
+                                                   static_cast<float *>(nullptr), 0u, 0u, 0u)
             MI_LOGM_SWITCH(b->logm, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());

@@ -222,6 +222,27 @@ namespace
     }
 } // namespace
 
+namespace mi
+{
+    int delay_bank_view(mi_delay_bank_t *b, delay_view *v)
+    {
+        MI_REQUIRE(b != nullptr && v != nullptr, MI_ESTATE, "delay_bank_view: NULL bank");
+        v->ring = b->d_ring;
+        v->size = b->size;
+        v->head = b->head;
+        v->delay = b->delay.empty() ? 0 : b->delay[0];
+        for (uint32_t d : b->delay)
+            if (d != v->delay)
+                v->delay = UINT32_MAX;
+        return MI_OK;
+    }
+
+    void delay_bank_advance(mi_delay_bank_t *b, size_t samples)
+    {
+        b->head = uint32_t((size_t(b->head) + samples) % b->size);
+    }
+} // namespace mi
+
 extern "C" {
 
 int mi_delay_bank_create(mi_delay_bank_t **bank, uint32_t channels, size_t max_size)

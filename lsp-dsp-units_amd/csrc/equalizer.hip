@@ -467,6 +467,18 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
                         return MI_OK;
                 }
                 const size_t rest = samples - done;
+                // a whole block at a plain frame boundary: the frame kernel reads its frame out of the delay line and
+                // pushes the new samples into it itself (one launch)
+                mi::delay_view dl;
+                if (mi::convolver_takes_delayed_frame(b->conv, rest) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
+                    dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && (dl.delay % 2 == 0) &&
+                    size_t(dl.size - dl.delay) >= rest)
+                {
+                    r = mi::convolver_process_delayed_frame(b->conv, out + done, in + done, out_stride, in_stride, dl, st);
+                    if (r == MI_OK)
+                        mi::delay_bank_advance(b->delay, rest);
+                    return r;
+                }
                 if ((r = mi_delay_bank_process(b->delay, out + done, in + done, rest, out_stride, in_stride, 0, MI_GAIN_NONE, 0.0f, nullptr, 0, stream)) != MI_OK)
                     return r;
                 return mi_convolver_bank_process(b->conv, out + done, out + done, rest, out_stride, out_stride, stream);

@@ -24,6 +24,22 @@ namespace mi
 
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);
+
+    // Library-internal coupling of a delay line bank and a convolver bank (the Equalizer's FIR path): the convolver's
+    // frame kernel pulls its frame straight out of the delay line and pushes the new samples into it, one launch
+    // instead of two.  delay.hip / convolver.hip.
+    struct delay_view
+    {
+        float      *ring;           // [channels][size]
+        uint32_t    size, head;
+        uint32_t    delay;          // common delay of all channels, UINT32_MAX if they differ
+    };
+    int         delay_bank_view(mi_delay_bank_t *bank, delay_view *view);
+    void        delay_bank_advance(mi_delay_bank_t *bank, size_t samples);
+    // true if the next `samples` of the bank are exactly one whole frame handled by the plain frame kernel
+    bool        convolver_takes_delayed_frame(const mi_convolver_bank_t *bank, size_t samples);
+    int         convolver_process_delayed_frame(mi_convolver_bank_t *bank, float *out, const float *in, size_t out_stride,
+                                                size_t in_stride, const delay_view &dl, hipStream_t st);
 } // namespace mi
 
 #if defined(__HIPCC__)
