@@ -479,6 +479,45 @@ int mi_crossover_bank_process(mi_crossover_bank_t *bank, float *const *band_out,
 /* freq_chart(band, c, f, count), packed complex (re, im interleaved), HOST memory, Crossover.cpp:500-590 */
 int mi_crossover_bank_freq_chart(mi_crossover_bank_t *bank, uint32_t band, float *c, const float *f, size_t count, void *stream);
 
+/* ---- loudness meter bank (SURVEY 8f, K-weighted cascade fused with a mean-square reduction) ------------ */
+/*
+ * mi_loudness_bank: `meters` x lsp::dspu::LoudnessMeter(channels) sharing one configuration
+ * (meters/LoudnessMeter.h:47-330, src/main/meters/LoudnessMeter.cpp): per channel a weighting filter (K by default,
+ * ITU-R BS.1770), a sliding mean square over `period` ms, the channels mixed with their BS.2051 designation weights,
+ * square root.  Rows of the sample buffers: row = meter * channels + channel.
+ */
+typedef struct mi_loudness_bank mi_loudness_bank_t;
+enum { MI_BS_WEIGHT_NONE = 0, MI_BS_WEIGHT_A, MI_BS_WEIGHT_B, MI_BS_WEIGHT_C, MI_BS_WEIGHT_D, MI_BS_WEIGHT_K };   /* bs::weighting_t */
+/* bs::channel_t (misc/broadcast.h:58-94), numeric values as in the reference: 0 NONE, 1 CENTER, 4 LEFT, 5 RIGHT,
+ * 6..11 the +1.5 dB group (FRONT_LEFT .. RIGHT_SURROUND), 32/33 LFE1/LFE2 (excluded from the measurement). */
+enum { MI_BS_CHANNEL_NONE = 0, MI_BS_CHANNEL_CENTER = 1, MI_BS_CHANNEL_LEFT = 4, MI_BS_CHANNEL_RIGHT = 5,
+       MI_BS_CHANNEL_FRONT_LEFT = 6, MI_BS_CHANNEL_RIGHT_SURROUND = 11, MI_BS_CHANNEL_LFE1 = 32, MI_BS_CHANNEL_LFE2 = 33 };
+
+/* LoudnessMeter::init(channels, max_period), LoudnessMeter.cpp:85-185 (mono: CENTER, stereo: LEFT/RIGHT by default). */
+int mi_loudness_bank_create(mi_loudness_bank_t **bank, uint32_t meters, uint32_t channels, float max_period_ms);
+int mi_loudness_bank_destroy(mi_loudness_bank_t *bank);
+/* set_sample_rate (reallocates and clears the mean-square lines), set_period, set_weighting, LoudnessMeter.cpp:203-309 */
+int mi_loudness_bank_set_sample_rate(mi_loudness_bank_t *bank, uint32_t sample_rate, void *stream);
+int mi_loudness_bank_set_period(mi_loudness_bank_t *bank, float period_ms);
+int mi_loudness_bank_set_weighting(mi_loudness_bank_t *bank, int weighting);
+/* per channel index, for every meter: set_designation / set_link / set_active, LoudnessMeter.cpp:213-268 */
+int mi_loudness_bank_set_designation(mi_loudness_bank_t *bank, uint32_t channel, int designation);
+int mi_loudness_bank_set_link(mi_loudness_bank_t *bank, uint32_t channel, float link);
+int mi_loudness_bank_set_active(mi_loudness_bank_t *bank, uint32_t channel, int active, void *stream);
+/* clear(), LoudnessMeter.cpp:280-295; latency() in samples, :323-326 */
+int mi_loudness_bank_clear(mi_loudness_bank_t *bank, void *stream);
+int mi_loudness_bank_latency(const mi_loudness_bank_t *bank, uint32_t *samples);
+/*
+ * process(out, count) / process(out, count, gain), LoudnessMeter.cpp:427-560.  in: [meters*channels][in_stride];
+ * out: [meters][out_stride] or NULL; ch_out: [meters*channels][out_stride] or NULL (the reference's per-channel vOut with
+ * linking: link 0 = the channel's own RMS, 1 = the mixed loudness).  gain multiplies every output (pass 1 for the
+ * first form).  Channels without an input in the reference = set_active(channel, 0) here.
+ */
+int mi_loudness_bank_process(mi_loudness_bank_t *bank, float *out, float *ch_out, const float *in, size_t count,
+                             size_t out_stride, size_t in_stride, float gain, void *stream);
+/* loudness(): the last value of the mixed loudness of every meter (HOST array of `meters` floats; synchronises) */
+int mi_loudness_bank_loudness(mi_loudness_bank_t *bank, float *loudness, void *stream);
+
 /* ---- delay line and ring buffer banks ----------------------------------------------------- */
 /*
  * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  All

@@ -111,6 +111,18 @@ PROTOTYPES = {
     "mi_equalizer_bank_set_actual_sample_rate": (c_int, [c_void_p, c_uint32]),
     "mi_equalizer_bank_get_latency": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "mi_equalizer_bank_set_smooth": (c_int, [c_void_p, c_int]),
+    "mi_loudness_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_float]),
+    "mi_loudness_bank_destroy": (c_int, [c_void_p]),
+    "mi_loudness_bank_set_sample_rate": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "mi_loudness_bank_set_period": (c_int, [c_void_p, c_float]),
+    "mi_loudness_bank_set_weighting": (c_int, [c_void_p, c_int]),
+    "mi_loudness_bank_set_designation": (c_int, [c_void_p, c_uint32, c_int]),
+    "mi_loudness_bank_set_link": (c_int, [c_void_p, c_uint32, c_float]),
+    "mi_loudness_bank_set_active": (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
+    "mi_loudness_bank_clear": (c_int, [c_void_p, c_void_p]),
+    "mi_loudness_bank_latency": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "mi_loudness_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float, c_void_p]),
+    "mi_loudness_bank_loudness": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "mi_crossover_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_crossover_bank_destroy": (c_int, [c_void_p]),
     "mi_crossover_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),

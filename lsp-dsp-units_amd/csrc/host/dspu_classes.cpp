@@ -11,6 +11,7 @@
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
+#include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Analyzer.h>
@@ -1157,6 +1158,225 @@ void Crossover::dump(IStateDumper *v) const
 {
     v->write("nSplits", num_splits());
     v->write("nBufSize", max_buffer_size());
+}
+
+// ---- bs::channel_weighting / LoudnessMeter ---------------------------------------------------------------------
+namespace bs
+{
+    float channel_weighting(channel_t designation)           // src/main/misc/broadcast.cpp:32-55
+    {
+        if (designation >= CHANNEL_FRONT_LEFT && designation <= CHANNEL_RIGHT_SURROUND)
+            return 1.41f;
+        if (designation == CHANNEL_LFE1 || designation == CHANNEL_LFE2)
+            return 0.0f;
+        return 1.0f;
+    }
+}
+
+struct LoudnessMeter::impl_t
+{
+    mi_loudness_bank_t *bank = nullptr;
+    size_t  channels = 0, sample_rate = 0;
+    float   period = 400.0f, max_period = 400.0f, loudness = 0.0f;
+    bs::weighting_t weighting = bs::WEIGHT_K;
+    struct chan_t { const float *in = nullptr; float *out = nullptr; size_t offset = 0; float link = 1.0f;
+                    bs::channel_t designation = bs::CHANNEL_NONE; bool active = true; };
+    std::vector<chan_t> ch;
+    std::vector<float>  host;
+    float  *d_in = nullptr, *d_out = nullptr, *d_ch = nullptr;
+    size_t  cap = 0;
+
+    bool reserve(size_t n)
+    {
+        if (n <= cap)
+            return true;
+        mi_dspu_free(d_in); mi_dspu_free(d_out); mi_dspu_free(d_ch);
+        d_in = d_out = d_ch = nullptr;
+        cap = 0;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_in), channels * n * sizeof(float)) != MI_OK) return false;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_ch), channels * n * sizeof(float)) != MI_OK) return false;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_out), n * sizeof(float)) != MI_OK) return false;
+        cap = n;
+        return true;
+    }
+};
+
+LoudnessMeter::LoudnessMeter() : pImpl(nullptr) { construct(); }
+LoudnessMeter::~LoudnessMeter() { destroy(); }
+void LoudnessMeter::construct() { pImpl = nullptr; }
+
+void LoudnessMeter::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_loudness_bank_destroy(pImpl->bank);
+    mi_dspu_free(pImpl->d_in); mi_dspu_free(pImpl->d_out); mi_dspu_free(pImpl->d_ch);
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+status_t LoudnessMeter::init(size_t channels, float max_period)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return STATUS_NO_MEM;
+    if (channels == 0 || mi_loudness_bank_create(&p->bank, 1, uint32_t(channels), max_period) != MI_OK)
+    {
+        delete p;
+        return STATUS_NO_MEM;
+    }
+    p->channels = channels;
+    p->max_period = max_period;
+    p->period = std::min(max_period, bs::LUFS_MEASURE_PERIOD_MS);
+    p->ch.resize(channels);
+    if (channels == 1)
+        p->ch[0].designation = bs::CHANNEL_CENTER;
+    else if (channels == 2)
+    {
+        p->ch[0].designation = bs::CHANNEL_LEFT;
+        p->ch[1].designation = bs::CHANNEL_RIGHT;
+    }
+    pImpl = p;
+    return STATUS_OK;
+}
+
+status_t LoudnessMeter::bind(size_t id, float *out, const float *in, size_t pos)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].in = in;
+    pImpl->ch[id].out = out;
+    pImpl->ch[id].offset = pos;
+    return STATUS_OK;
+}
+
+status_t LoudnessMeter::unbind(size_t id) { return bind(id, nullptr, nullptr, 0); }
+
+status_t LoudnessMeter::set_designation(size_t id, bs::channel_t designation)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].designation = designation;
+    mi_loudness_bank_set_designation(pImpl->bank, uint32_t(id), int(designation));
+    return STATUS_OK;
+}
+
+bs::channel_t LoudnessMeter::designation(size_t id) const
+{
+    return (pImpl && id < pImpl->channels) ? pImpl->ch[id].designation : bs::CHANNEL_NONE;
+}
+
+status_t LoudnessMeter::set_link(size_t id, float link)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].link = std::min(std::max(link, 0.0f), 1.0f);
+    mi_loudness_bank_set_link(pImpl->bank, uint32_t(id), link);
+    return STATUS_OK;
+}
+
+float LoudnessMeter::link(size_t id) const { return (pImpl && id < pImpl->channels) ? pImpl->ch[id].link : 0.0f; }
+
+status_t LoudnessMeter::set_active(size_t id, bool active)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].active = active;
+    mi_loudness_bank_set_active(pImpl->bank, uint32_t(id), active ? 1 : 0, nullptr);
+    return STATUS_OK;
+}
+
+bool LoudnessMeter::active(size_t id) const { return (pImpl && id < pImpl->channels) ? pImpl->ch[id].active : false; }
+
+void LoudnessMeter::set_weighting(bs::weighting_t weighting)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->weighting = weighting;
+    mi_loudness_bank_set_weighting(pImpl->bank, int(weighting));
+}
+
+bs::weighting_t LoudnessMeter::weighting() const { return pImpl ? pImpl->weighting : bs::WEIGHT_K; }
+
+void LoudnessMeter::set_period(float period)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->period = std::min(std::max(period, 0.0f), pImpl->max_period);
+    mi_loudness_bank_set_period(pImpl->bank, period);
+}
+
+float LoudnessMeter::period() const { return pImpl ? pImpl->period : 0.0f; }
+
+status_t LoudnessMeter::set_sample_rate(size_t sample_rate)
+{
+    if (pImpl == nullptr)
+        return STATUS_BAD_STATE;
+    if (mi_loudness_bank_set_sample_rate(pImpl->bank, uint32_t(sample_rate), nullptr) != MI_OK)
+        return STATUS_NO_MEM;
+    pImpl->sample_rate = sample_rate;
+    return STATUS_OK;
+}
+
+size_t LoudnessMeter::sample_rate() const { return pImpl ? pImpl->sample_rate : 0; }
+
+size_t LoudnessMeter::latency() const
+{
+    uint32_t v = 0;
+    if (pImpl != nullptr)
+        mi_loudness_bank_latency(pImpl->bank, &v);
+    return v;
+}
+
+void LoudnessMeter::process(float *out, size_t count) { process(out, count, 1.0f); }
+
+void LoudnessMeter::process(float *out, size_t count, float gain)
+{
+    impl_t *p = pImpl;
+    if (p == nullptr || count == 0 || !p->reserve(count))
+        return;
+    const size_t K = p->channels;
+    p->host.assign(K * count, 0.0f);                        // a channel without an input is measured as silence
+    bool want_ch = false;
+    for (size_t c = 0; c < K; ++c)
+    {
+        if (p->ch[c].in != nullptr)
+            std::memcpy(&p->host[c * count], p->ch[c].in, count * sizeof(float));      // vIn is read from its start every call (:424)
+        want_ch = want_ch || (p->ch[c].out != nullptr);
+    }
+    bool ok = mi_dspu_copy_h2d(p->d_in, p->host.data(), K * count * sizeof(float), nullptr) == MI_OK &&
+              mi_loudness_bank_process(p->bank, p->d_out, want_ch ? p->d_ch : nullptr, p->d_in, count, count, count, gain, nullptr) == MI_OK;
+    if (ok && out != nullptr)
+        ok = mi_dspu_copy_d2h(out, p->d_out, count * sizeof(float), nullptr) == MI_OK;
+    if (ok && want_ch)
+        ok = mi_dspu_copy_d2h(p->host.data(), p->d_ch, K * count * sizeof(float), nullptr) == MI_OK;
+    ok = ok && mi_dspu_stream_synchronize(nullptr) == MI_OK;
+    for (size_t c = 0; c < K; ++c)
+    {
+        if (ok && p->ch[c].out != nullptr && p->ch[c].active)
+            std::memcpy(p->ch[c].out + p->ch[c].offset, &p->host[c * count], count * sizeof(float));
+        if (p->ch[c].active)
+            p->ch[c].offset += count;                       // LoudnessMeter.cpp:499
+    }
+    if (ok)
+        mi_loudness_bank_loudness(p->bank, &p->loudness, nullptr);
+}
+
+float LoudnessMeter::loudness() const { return pImpl ? pImpl->loudness : 0.0f; }
+
+void LoudnessMeter::clear()
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->loudness = 0.0f;
+    mi_loudness_bank_clear(pImpl->bank, nullptr);
+}
+
+void LoudnessMeter::dump(IStateDumper *v) const
+{
+    v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
+    v->write("fPeriod", period());
 }
 
 // ---- Delay -----------------------------------------------------------------------------------------------------

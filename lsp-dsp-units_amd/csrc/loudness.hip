@@ -1,0 +1,456 @@
+// Loudness meter bank: lsp::dspu::LoudnessMeter for many meters
+// (reference: src/main/meters/LoudnessMeter.cpp:85-185 init, :328-379 update_settings, :381-407 refresh_rms,
+//  :409-466 process_channels, :468-560 process).
+//
+// Per channel: weighting filter (the biquad cascade bank, designer on the host), squares into a power-of-two line,
+// sliding sum over the last nPeriod squares.  The reference updates that sum sample by sample (ms += new - old) and
+// re-sums the window exactly every max(4096, nPeriod/4) samples to stop the float32 drift; here a block is one
+// prefix scan of (new - old) on top of the carried sum, and the exact re-summation runs on the same schedule.
+// One workgroup per meter: it walks the meter's channels, mixes the mean squares with the designation weights,
+// takes the square root and writes the mixed loudness and the (linked) per-channel values.
+#include "mi_common.h"
+#include "host/filter_design.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace
+{
+    constexpr uint32_t BUFFER_SIZE = 0x400;                 // LoudnessMeter.cpp:32
+    constexpr int      LT = 256;                            // threads per meter
+    constexpr uint32_t MAX_BLOCK = 8192;                    // samples per launch (LDS: two float arrays of this size)
+
+    // bs::channel_weighting (src/main/misc/broadcast.cpp:32-55)
+    float channel_weighting(int designation)
+    {
+        if (designation >= 6 && designation <= 11)
+            return 1.41f;                                   // ~ +1.5 dB
+        if (designation == MI_BS_CHANNEL_LFE1 || designation == MI_BS_CHANNEL_LFE2)
+            return 0.0f;
+        return 1.0f;
+    }
+
+    struct chan_cfg
+    {
+        float   weight;
+        float   link;
+        int     enabled;
+        int     pad;
+    };
+
+    // exact window sums (refresh_rms): ms[row] = sum of the last `period` cells behind head
+    __global__ __launch_bounds__(LT)
+    void loudness_refresh_kernel(float *ms, const float *__restrict__ data, uint32_t size, uint32_t head, uint32_t period,
+                                 const chan_cfg *__restrict__ cfg, uint32_t channels)
+    {
+        __shared__ float part[LT];
+        const uint32_t row = blockIdx.x, tid = threadIdx.x;
+        if (!cfg[row % channels].enabled)
+            return;
+        const float *d = data + size_t(row) * size;
+        const uint32_t tail = (head + size - period) & (size - 1);
+        float s = 0.0f;
+        for (uint32_t i = tid; i < period; i += LT)
+            s += d[(tail + i) & (size - 1)];
+        part[tid] = s;
+        __syncthreads();
+        for (int w = LT / 2; w > 0; w >>= 1)
+        {
+            if (int(tid) < w)
+                part[tid] += part[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0)
+            ms[row] = part[0];
+    }
+
+    // one block of `n` samples of one meter
+    __global__ __launch_bounds__(LT)
+    void loudness_block_kernel(float *out, float *ch_out, size_t out_stride, const float *__restrict__ flt, size_t flt_stride,
+                               float *data, uint32_t size, uint32_t head, uint32_t period, float avg, float *ms,
+                               float *msbuf, size_t msbuf_stride, const chan_cfg *__restrict__ cfg, uint32_t channels,
+                               uint32_t n, float gain, float *loud)
+    {
+        __shared__ float sq[MAX_BLOCK];                     // this channel's squares (new values)
+        __shared__ float mix[MAX_BLOCK];                    // weighted sum of the channels' mean squares
+        __shared__ float tot[LT];
+        const uint32_t meter = blockIdx.x, tid = threadIdx.x, mask = size - 1;
+        const uint32_t E = (n + LT - 1) / LT;               // elements per thread (a contiguous run)
+        const uint32_t j0 = tid * E, j1 = (j0 + E < n) ? j0 + E : n;
+        const uint32_t tail = (head + size - period) & mask;
+        for (uint32_t j = tid; j < n; j += LT)
+            mix[j] = 0.0f;
+        uint32_t mixed = 0;
+        for (uint32_t c = 0; c < channels; ++c)
+        {
+            const chan_cfg cc = cfg[c];
+            if (!cc.enabled)
+                continue;
+            const uint32_t row = meter * channels + c;
+            float *line = data + size_t(row) * size;
+            const float *x = flt + size_t(row) * flt_stride;
+            __syncthreads();
+            for (uint32_t j = tid; j < n; j += LT)          // dsp::sqr2 into the line (LoudnessMeter.cpp:428-436)
+            {
+                const float v = x[j] * x[j];
+                sq[j] = v;
+                line[(head + j) & mask] = v;
+            }
+            __syncthreads();
+            // ms_j = ms_(j-1) + (new_j - old_j): local prefix over the thread's run, then the runs are chained
+            float run = 0.0f;
+            for (uint32_t j = j0; j < j1; ++j)
+            {
+                const float old = (j >= period) ? sq[j - period] : line[(tail + j) & mask];
+                run += sq[j] - old;
+            }
+            tot[tid] = run;
+            __syncthreads();
+            float base = ms[row];
+            for (uint32_t k = 0; k < tid; ++k)              // 256 adds per thread: cheap next to the block, exact order
+                base += tot[k];
+            float acc = base;
+            float *mb = msbuf + size_t(row) * msbuf_stride;
+            for (uint32_t j = j0; j < j1; ++j)
+            {
+                const float old = (j >= period) ? sq[j - period] : line[(tail + j) & mask];
+                acc += sq[j] - old;
+                const float m = avg * acc;                  // vMS[j] = fAvgCoeff * ms
+                mb[j] = m;
+                mix[j] = (mixed > 0) ? fmaf(m, cc.weight, mix[j]) : m * cc.weight;         // fmadd_k3 / mul_k3
+            }
+            __syncthreads();
+            if (tid == LT - 1 || j1 == n)
+            {
+                if (j0 < n && j1 == n)
+                    ms[row] = acc;                          // the thread that owns the last sample carries the sum on
+            }
+            ++mixed;
+        }
+        __syncthreads();
+        // ssqrt1: sqrt of the non-negative part; then the outputs
+        for (uint32_t j = tid; j < n; j += LT)
+        {
+            const float l = (mix[j] > 0.0f) ? sqrtf(mix[j]) : 0.0f;
+            mix[j] = l;
+            if (out != nullptr)
+                out[size_t(meter) * out_stride + j] = l * gain;
+        }
+        if (tid == 0 && n > 0)
+            loud[meter] = (mix[n - 1] > 0.0f) ? mix[n - 1] : 0.0f;
+        __syncthreads();
+        if (ch_out == nullptr)
+            return;
+        for (uint32_t c = 0; c < channels; ++c)
+        {
+            const chan_cfg cc = cfg[c];
+            if (!cc.enabled)
+                continue;
+            const uint32_t row = meter * channels + c;
+            const float *mb = msbuf + size_t(row) * msbuf_stride;
+            float *o = ch_out + size_t(row) * out_stride;
+            for (uint32_t j = tid; j < n; j += LT)
+            {
+                const float r = (mb[j] > 0.0f) ? sqrtf(mb[j]) : 0.0f;
+                float v;
+                if (cc.link <= 0.0f)       v = r * gain;
+                else if (cc.link >= 1.0f)  v = mix[j] * gain;
+                else                       v = mix[j] * (cc.link * gain) + r * ((1.0f - cc.link) * gain);     // mix_copy2
+                o[j] = v;
+            }
+        }
+    }
+} // namespace
+
+struct mi_loudness_bank
+{
+    uint32_t    meters = 0, channels = 0, rows = 0;
+    uint32_t    sample_rate = 0, period = 0, ms_refresh = 0, data_size = 0, head = 0;
+    float       period_ms = 400.0f, max_period_ms = 400.0f, avg = 1.0f;
+    int         weighting = MI_BS_WEIGHT_K;
+    bool        upd_filters = true, upd_time = true, cfg_dirty = true;
+    std::vector<chan_cfg> cfg;
+    std::vector<int>      designation;
+    mi_biquad_bank_t *filters = nullptr;
+    float      *d_data = nullptr, *d_ms = nullptr, *d_flt = nullptr, *d_msbuf = nullptr, *d_loud = nullptr;
+    chan_cfg   *d_cfg = nullptr;
+    size_t      cap = 0;
+};
+
+namespace
+{
+    uint32_t round_pow2(uint32_t v)
+    {
+        uint32_t p = 1;
+        while (p < v)
+            p <<= 1;
+        return p;
+    }
+
+    int update_settings(mi_loudness_bank *b, hipStream_t st)           // LoudnessMeter.cpp:328-379
+    {
+        if (b->upd_time)
+        {
+            const uint32_t p = uint32_t((b->period_ms * 0.001f) * float(b->sample_rate));    // millis_to_samples, truncated
+            b->period = (p > 1u) ? p : 1u;
+            b->avg = 1.0f / float(b->period);
+            b->ms_refresh = 0;
+            b->upd_time = false;
+        }
+        if (b->upd_filters)
+        {
+            static const uint32_t types[6] = { MI_FLT_NONE, MI_FLT_A_WEIGHTED, MI_FLT_B_WEIGHTED, MI_FLT_C_WEIGHTED,
+                                               MI_FLT_D_WEIGHTED, MI_FLT_K_WEIGHTED };
+            mi_filter_params_t fp;
+            fp.nType = types[b->weighting]; fp.nSlope = 0; fp.fFreq = 0.0f; fp.fFreq2 = 0.0f; fp.fGain = 1.0f; fp.fQuality = 0.0f;
+            mi::design d;
+            d.cascades.reserve(mi::CHAINS_MAX + 1);
+            mi::design_filter(&d, &fp, b->sample_rate);
+            for (uint32_t r = 0; r < b->rows; ++r)                      // sBank.end(true): state cleared
+            {
+                const int e = mi_biquad_bank_set_chains(b->filters, r, d.sections.data(), uint32_t(d.sections.size()), 1);
+                if (e != MI_OK)
+                    return e;
+            }
+            const int e = mi_biquad_bank_commit(b->filters, st);
+            if (e != MI_OK)
+                return e;
+            b->upd_filters = false;
+        }
+        if (b->cfg_dirty)
+        {
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_cfg, b->cfg.data(), b->channels * sizeof(chan_cfg), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+            b->cfg_dirty = false;
+        }
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_loudness_bank_create(mi_loudness_bank_t **bank, uint32_t meters, uint32_t channels, float max_period_ms)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_loudness_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(meters > 0 && channels > 0, MI_EINVAL, "mi_loudness_bank_create: meters and channels must be > 0");
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_loudness_bank *b = new (std::nothrow) mi_loudness_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_loudness_bank_create: out of host memory");
+    b->meters = meters;
+    b->channels = channels;
+    b->rows = meters * channels;
+    b->max_period_ms = max_period_ms;
+    b->period_ms = (max_period_ms < 400.0f) ? max_period_ms : 400.0f;          // LoudnessMeter.cpp:166
+    b->cfg.assign(channels, chan_cfg{ 0.0f, 1.0f, 1, 0 });
+    b->designation.assign(channels, MI_BS_CHANNEL_NONE);
+    if (channels == 1)
+        b->designation[0] = MI_BS_CHANNEL_CENTER;
+    else if (channels == 2)
+    {
+        b->designation[0] = MI_BS_CHANNEL_LEFT;
+        b->designation[1] = MI_BS_CHANNEL_RIGHT;
+    }
+    for (uint32_t c = 0; c < channels; ++c)                                     // others keep fWeight = 0 (:131)
+        if (b->designation[c] != MI_BS_CHANNEL_NONE)
+            b->cfg[c].weight = channel_weighting(b->designation[c]);
+    int r = mi_biquad_bank_create(&b->filters, b->rows, 4);                     // sBank.init(4)
+    hipError_t e = hipSuccess;
+    if (r == MI_OK)
+    {
+        e = hipMalloc(reinterpret_cast<void **>(&b->d_ms), b->rows * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_loud), meters * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_cfg), channels * sizeof(chan_cfg));
+        if (e == hipSuccess) e = hipMemset(b->d_ms, 0, b->rows * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_loud, 0, meters * sizeof(float));
+    }
+    if (r != MI_OK || e != hipSuccess)
+    {
+        mi_loudness_bank_destroy(b);
+        return (r != MI_OK) ? r : mi::fail(MI_EHIP, "mi_loudness_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_loudness_bank_destroy(mi_loudness_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    mi_biquad_bank_destroy(b->filters);
+    (void)hipFree(b->d_data); (void)hipFree(b->d_ms); (void)hipFree(b->d_flt); (void)hipFree(b->d_msbuf);
+    (void)hipFree(b->d_loud); (void)hipFree(b->d_cfg);
+    delete b;
+    return MI_OK;
+}
+
+int mi_loudness_bank_clear(mi_loudness_bank_t *b, void *stream)                // LoudnessMeter.cpp:280-295
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_clear: NULL bank");
+    hipStream_t st = mi::as_stream(stream);
+    MI_HIP_CHECK(hipMemsetAsync(b->d_loud, 0, b->meters * sizeof(float), st));
+    const int r = mi_biquad_bank_reset(b->filters, UINT32_MAX, stream);
+    if (r != MI_OK)
+        return r;
+    // enabled channels only: rows of channel c are strided, clear them one channel at a time
+    for (uint32_t c = 0; c < b->channels && b->d_data != nullptr; ++c)
+    {
+        if (!b->cfg[c].enabled)
+            continue;
+        MI_HIP_CHECK(hipMemset2DAsync(b->d_data + size_t(c) * b->data_size, size_t(b->channels) * b->data_size * sizeof(float), 0,
+                                      size_t(b->data_size) * sizeof(float), b->meters, st));
+        MI_HIP_CHECK(hipMemset2DAsync(b->d_ms + c, b->channels * sizeof(float), 0, sizeof(float), b->meters, st));
+    }
+    return MI_OK;
+}
+
+int mi_loudness_bank_set_sample_rate(mi_loudness_bank_t *b, uint32_t sample_rate, void *stream)    // LoudnessMeter.cpp:297-321
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_sample_rate: NULL bank");
+    if (b->sample_rate == sample_rate)
+        return MI_OK;
+    const uint32_t len = round_pow2(uint32_t((b->max_period_ms * 0.001f) * float(sample_rate)) + BUFFER_SIZE);
+    (void)hipFree(b->d_data);
+    b->d_data = nullptr;
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_data), size_t(b->rows) * len * sizeof(float)));
+    MI_HIP_CHECK(hipMemsetAsync(b->d_data, 0, size_t(b->rows) * len * sizeof(float), mi::as_stream(stream)));
+    MI_HIP_CHECK(hipMemsetAsync(b->d_ms, 0, b->rows * sizeof(float), mi::as_stream(stream)));
+    b->sample_rate = sample_rate;
+    b->data_size = len;
+    b->head = 0;
+    b->upd_filters = b->upd_time = true;
+    return mi_loudness_bank_clear(b, stream);
+}
+
+int mi_loudness_bank_set_period(mi_loudness_bank_t *b, float period_ms)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_period: NULL bank");
+    period_ms = (period_ms < 0.0f) ? 0.0f : (period_ms > b->max_period_ms) ? b->max_period_ms : period_ms;
+    if (b->period_ms == period_ms)
+        return MI_OK;
+    b->period_ms = period_ms;
+    b->upd_time = true;
+    return MI_OK;
+}
+
+int mi_loudness_bank_set_weighting(mi_loudness_bank_t *b, int weighting)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_weighting: NULL bank");
+    MI_REQUIRE(weighting >= MI_BS_WEIGHT_NONE && weighting <= MI_BS_WEIGHT_K, MI_EINVAL, "mi_loudness_bank_set_weighting: bad weighting %d", weighting);
+    if (weighting == b->weighting)
+        return MI_OK;
+    b->weighting = weighting;
+    b->upd_filters = true;
+    return MI_OK;
+}
+
+int mi_loudness_bank_set_designation(mi_loudness_bank_t *b, uint32_t channel, int designation)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_designation: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_loudness_bank_set_designation: channel %u out of range", channel);   // STATUS_OVERFLOW
+    b->designation[channel] = designation;
+    b->cfg[channel].weight = channel_weighting(designation);
+    b->cfg_dirty = true;
+    return MI_OK;
+}
+
+int mi_loudness_bank_set_link(mi_loudness_bank_t *b, uint32_t channel, float link)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_link: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_loudness_bank_set_link: channel %u out of range", channel);
+    b->cfg[channel].link = (link < 0.0f) ? 0.0f : (link > 1.0f) ? 1.0f : link;
+    b->cfg_dirty = true;
+    return MI_OK;
+}
+
+int mi_loudness_bank_set_active(mi_loudness_bank_t *b, uint32_t channel, int active, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_active: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_loudness_bank_set_active: channel %u out of range", channel);
+    if ((b->cfg[channel].enabled != 0) == (active != 0))
+        return MI_OK;
+    b->cfg[channel].enabled = active ? 1 : 0;
+    b->cfg_dirty = true;
+    if (active && b->d_data != nullptr)                     // re-enabled: the channel starts from silence (:249-253)
+    {
+        hipStream_t st = mi::as_stream(stream);
+        MI_HIP_CHECK(hipMemset2DAsync(b->d_data + size_t(channel) * b->data_size, size_t(b->channels) * b->data_size * sizeof(float), 0,
+                                      size_t(b->data_size) * sizeof(float), b->meters, st));
+        MI_HIP_CHECK(hipMemset2DAsync(b->d_ms + channel, b->channels * sizeof(float), 0, sizeof(float), b->meters, st));
+    }
+    return MI_OK;
+}
+
+int mi_loudness_bank_latency(const mi_loudness_bank_t *b, uint32_t *samples)
+{
+    MI_REQUIRE(b != nullptr && samples != nullptr, MI_EINVAL, "mi_loudness_bank_latency: bad argument");
+    *samples = uint32_t((b->period_ms * 0.001f) * float(b->sample_rate));
+    return MI_OK;
+}
+
+int mi_loudness_bank_process(mi_loudness_bank_t *b, float *out, float *ch_out, const float *in, size_t count,
+                             size_t out_stride, size_t in_stride, float gain, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_process: NULL bank");
+    if (count == 0)
+        return MI_OK;
+    MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_loudness_bank_process: NULL input");
+    MI_REQUIRE(b->sample_rate != 0 && b->d_data != nullptr, MI_ESTATE, "mi_loudness_bank_process: set_sample_rate() first");
+    hipStream_t st = mi::as_stream(stream);
+    int r = update_settings(b, st);
+    if (r != MI_OK)
+        return r;
+    const uint32_t room = b->data_size - b->period;         // cells that may be written before the window's tail is reached
+    size_t offset = 0;
+    while (offset < count)
+    {
+        if (b->ms_refresh == 0)                             // refresh_rms(), LoudnessMeter.cpp:381-407
+        {
+            hipLaunchKernelGGL(loudness_refresh_kernel, dim3(b->rows), dim3(LT), 0, st, b->d_ms, b->d_data, b->data_size, b->head,
+                               b->period, b->d_cfg, b->channels);
+            MI_HIP_CHECK(hipGetLastError());
+            const uint32_t a = BUFFER_SIZE << 2, q = b->period >> 2;
+            b->ms_refresh = (a > q) ? a : q;
+        }
+        size_t n = count - offset;
+        n = std::min<size_t>(n, b->ms_refresh);
+        n = std::min<size_t>(n, MAX_BLOCK);
+        n = std::min<size_t>(n, (room > BUFFER_SIZE) ? room : BUFFER_SIZE);
+        if (n > b->cap)
+        {
+            (void)hipFree(b->d_flt); (void)hipFree(b->d_msbuf);
+            b->d_flt = b->d_msbuf = nullptr;
+            b->cap = 0;
+            const size_t cap = std::min<size_t>(std::max<size_t>(n, 4096), MAX_BLOCK);
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_flt), size_t(b->rows) * cap * sizeof(float)));
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_msbuf), size_t(b->rows) * cap * sizeof(float)));
+            b->cap = cap;
+        }
+        // the weighting filter of every row, then the block kernel (one workgroup per meter)
+        r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
+        if (r != MI_OK)
+            return r;
+        hipLaunchKernelGGL(loudness_block_kernel, dim3(b->meters), dim3(LT), 0, st,
+                           out ? out + offset : nullptr, ch_out ? ch_out + offset : nullptr, out_stride, b->d_flt, b->cap,
+                           b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, b->d_msbuf, b->cap, b->d_cfg,
+                           b->channels, uint32_t(n), gain, b->d_loud);
+        MI_HIP_CHECK(hipGetLastError());
+        b->head = (b->head + uint32_t(n)) & (b->data_size - 1);
+        b->ms_refresh -= uint32_t(n);
+        offset += n;
+    }
+    return MI_OK;
+}
+
+int mi_loudness_bank_loudness(mi_loudness_bank_t *b, float *loudness, void *stream)
+{
+    MI_REQUIRE(b != nullptr && loudness != nullptr, MI_EINVAL, "mi_loudness_bank_loudness: bad argument");
+    hipStream_t st = mi::as_stream(stream);
+    MI_HIP_CHECK(hipMemcpyAsync(loudness, b->d_loud, b->meters * sizeof(float), hipMemcpyDeviceToHost, st));
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
+} // extern "C"

@@ -12,7 +12,7 @@ namespace lsp
 {
     // status codes used by the few hot-path APIs that return one
     typedef int status_t;
-    enum { STATUS_OK = 0, STATUS_NO_MEM = 5, STATUS_BAD_STATE = 12, STATUS_INVALID_VALUE = 27 };
+    enum { STATUS_OK = 0, STATUS_NO_MEM = 5, STATUS_BAD_STATE = 12, STATUS_OVERFLOW = 18, STATUS_INVALID_VALUE = 27 };
 
     namespace dsp
     {

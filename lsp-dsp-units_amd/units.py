@@ -416,6 +416,64 @@ class RingBank:
             pass
 
 
+class LoudnessBank:
+    """`meters` x lsp::dspu::LoudnessMeter(channels) sharing one configuration (mi_loudness_bank_*)."""
+    WEIGHT_NONE, WEIGHT_A, WEIGHT_B, WEIGHT_C, WEIGHT_D, WEIGHT_K = range(6)
+
+    def __init__(self, meters, channels, max_period_ms=400.0):
+        h = c_void_p()
+        check(lib.mi_loudness_bank_create(byref(h), meters, channels, float(max_period_ms)))
+        self.handle, self.meters, self.channels = h, meters, channels
+
+    def set_sample_rate(self, sr, stream=None):
+        check(lib.mi_loudness_bank_set_sample_rate(self.handle, sr, _stream(stream)))
+
+    def set_period(self, ms):
+        check(lib.mi_loudness_bank_set_period(self.handle, float(ms)))
+
+    def set_weighting(self, w):
+        check(lib.mi_loudness_bank_set_weighting(self.handle, int(w)))
+
+    def set_designation(self, channel, designation):
+        check(lib.mi_loudness_bank_set_designation(self.handle, channel, int(designation)))
+
+    def set_link(self, channel, link):
+        check(lib.mi_loudness_bank_set_link(self.handle, channel, float(link)))
+
+    def set_active(self, channel, active=True, stream=None):
+        check(lib.mi_loudness_bank_set_active(self.handle, channel, 1 if active else 0, _stream(stream)))
+
+    def clear(self, stream=None):
+        check(lib.mi_loudness_bank_clear(self.handle, _stream(stream)))
+
+    def latency(self):
+        v = c_uint32()
+        check(lib.mi_loudness_bank_latency(self.handle, byref(v)))
+        return v.value
+
+    def process(self, out, ch_out, inp, count, out_stride=None, in_stride=None, gain=1.0, stream=None):
+        check(lib.mi_loudness_bank_process(self.handle, _ptr(out) if out is not None else None,
+                                           _ptr(ch_out) if ch_out is not None else None, _ptr(inp), count,
+                                           count if out_stride is None else out_stride,
+                                           count if in_stride is None else in_stride, float(gain), _stream(stream)))
+
+    def loudness(self, stream=None):
+        v = (c_float * self.meters)()
+        check(lib.mi_loudness_bank_loudness(self.handle, v, _stream(stream)))
+        return np.array(list(v), np.float32)
+
+    def close(self):
+        if self.handle:
+            lib.mi_loudness_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CrossoverBank:
     """lsp::dspu::Crossover for `channels` channels sharing the split settings (mi_crossover_bank_*)."""
     MODE_BT, MODE_MT = 0, 1

@@ -12,6 +12,7 @@
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
+#include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/units.h>
@@ -224,6 +225,34 @@ static void crossover_bands_sum_to_allpass()
     x.destroy();
 }
 
+// LoudnessMeter (no reference utest): ITU-R BS.1770-4 anchor -- a 0 dBFS 997 Hz sine on one front channel reads
+// -3.01 LKFS -- plus the bookkeeping of bound outputs (offset advances, link 0 = the channel's own RMS).
+static void loudness_meter_bs1770()
+{
+    printf("loudness_meter (BS.1770 sine anchor)\n");
+    const size_t SR = 48000, N = 48000;
+    std::vector<float> l(N), r(N, 0.0f), out(N), lout(2 * N, -1.0f);
+    for (size_t i = 0; i < N; ++i) l[i] = sinf(2.0f * float(M_PI) * 997.0f * float(i) / float(SR));
+    dspu::LoudnessMeter m;
+    CHECK(m.init(2) == STATUS_OK, "init");
+    CHECK(m.designation(0) == dspu::bs::CHANNEL_LEFT && m.designation(1) == dspu::bs::CHANNEL_RIGHT, "default designations");
+    CHECK(m.set_sample_rate(SR) == STATUS_OK, "set_sample_rate");
+    CHECK(m.latency() == 19200, "latency %zu", m.latency());
+    CHECK(m.bind(2, NULL, NULL) == STATUS_OVERFLOW, "bind out of range");
+    CHECK(m.bind(0, lout.data(), l.data(), N / 2) == STATUS_OK && m.bind(1, NULL, r.data()) == STATUS_OK, "bind");
+    CHECK(m.set_link(0, 0.0f) == STATUS_OK, "set_link");
+    m.process(out.data(), N / 2);
+    CHECK(m.bind(0, lout.data(), l.data() + N / 2, N) == STATUS_OK, "rebind");          // second half of the signal
+    m.process(out.data() + N / 2, N / 2);
+    const float lkfs = -0.691f + 20.0f * log10f(out[N - 1]);
+    printf("  loudness %.3f LKFS\n", lkfs);
+    CHECK(fabsf(lkfs + 3.01f) < 0.02f, "LKFS %.3f", lkfs);
+    CHECK(fabsf(m.loudness() - out[N - 1]) < 1e-7f, "loudness()");
+    CHECK(lout[N / 2 - 1] == -1.0f && lout[N / 2] >= 0.0f && lout[3 * N / 2 - 1] > 0.5f && lout[3 * N / 2] == -1.0f, "bound output window");
+    CHECK(fabsf(lout[3 * N / 2 - 1] - out[N - 1]) < 1e-6f, "link 0 of the only sounding channel equals the mix");
+    m.destroy();
+}
+
 static void ringbuffer()
 {
     printf("ringbuffer\n");
@@ -283,7 +312,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover ringbuffer readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ringbuffer readme_filter");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -300,6 +329,7 @@ int main(int argc, char **argv)
     spectral_proc_callback();
     multi_spectral_proc();
     crossover_bands_sum_to_allpass();
+    loudness_meter_bs1770();
     ringbuffer();
     readme_filter();
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");

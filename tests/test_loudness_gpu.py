@@ -1,0 +1,89 @@
+"""GPU parity of mi_loudness_bank_* (lsp::dspu::LoudnessMeter) against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from oracle import loudness as ol
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def test_bs1770_sine_anchor_on_gpu(gpu):
+    """ITU-R BS.1770-4: a 0 dBFS 997 Hz sine reads -3.01 LKFS."""
+    sr = 48000
+    bank = gpu.LoudnessBank(2, 1)
+    bank.set_sample_rate(sr)
+    t = np.arange(sr)
+    x = np.stack([np.sin(2 * np.pi * 997.0 * t / sr), 0.5 * np.sin(2 * np.pi * 997.0 * t / sr)]).astype(np.float32)
+    out = gpu.DeviceBuffer((2, sr))
+    bank.process(out, None, gpu.DeviceBuffer.from_host(x), sr)
+    y = out.download()
+    lkfs = -0.691 + 20.0 * np.log10(y[:, -1])
+    assert abs(lkfs[0] + 3.01) < 0.02 and abs(lkfs[1] + 9.03) < 0.02, lkfs
+    np.testing.assert_allclose(bank.loudness(), y[:, -1], rtol=0, atol=0)
+    assert bank.latency() == 19200
+    bank.close()
+
+
+@pytest.mark.parametrize("calls", [(30000,), (777, 8223, 4096, 16904)])
+def test_three_channel_meters_match_oracle(gpu, calls):
+    """Two independent meters of three channels: designations (incl. the +1.5 dB group and an LFE), links, a short
+    period, a disabled channel, gain -- per-sample loudness and linked per-channel values against the oracle."""
+    sr, M, K = 44100, 2, 4
+    n = sum(calls)
+    rng = np.random.default_rng(12)
+    x = (rng.standard_normal((M * K, n)) * 0.2).astype(np.float32)
+    x[K:] *= 0.5
+    bank = gpu.LoudnessBank(M, K)
+    refs = [ol.LoudnessMeter(K) for _ in range(M)]
+    for obj in [bank] + refs:
+        obj.set_sample_rate(sr)
+        obj.set_designation(0, ol.CHANNEL_LEFT); obj.set_designation(1, 7); obj.set_designation(2, ol.CHANNEL_LFE1)
+        obj.set_designation(3, ol.CHANNEL_RIGHT)
+        obj.set_link(0, 0.0); obj.set_link(1, 0.25)
+        obj.set_period(100.0)
+        obj.set_active(3, False)
+    got = np.zeros((M, n), np.float32); gch = np.zeros((M * K, n), np.float32)
+    ref = np.zeros((M, n), np.float32); rch = np.zeros((M * K, n), np.float32)
+    pos = 0
+    for k in calls:
+        out = gpu.DeviceBuffer((M, k)); ch = gpu.DeviceBuffer.from_host(np.full((M * K, k), -1.0, np.float32))
+        bank.process(out, ch, gpu.DeviceBuffer.from_host(x[:, pos:pos + k]), k, gain=0.5)
+        got[:, pos:pos + k] = out.download(); gch[:, pos:pos + k] = ch.download()
+        for m in range(M):
+            o, c = refs[m].process(x[m * K:(m + 1) * K, pos:pos + k], gain=0.5)
+            ref[m, pos:pos + k] = o; rch[m * K:(m + 1) * K, pos:pos + k] = c
+        pos += k
+    peak = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= TOL * peak, np.abs(got - ref).max() / peak
+    for r in range(M * K):
+        if r % K == 3:
+            assert np.all(gch[r] == -1.0)                    # disabled channel: its output is not touched
+        else:
+            assert np.abs(gch[r] - rch[r]).max() <= TOL * peak, (r, np.abs(gch[r] - rch[r]).max() / peak)
+    np.testing.assert_allclose(bank.loudness(), [float(refs[m].loud) for m in range(M)], rtol=2e-5)
+    bank.close()
+
+
+def test_weightings_clear_and_reenable(gpu):
+    sr, K = 48000, 2
+    rng = np.random.default_rng(13)
+    x = (rng.standard_normal((K, 12000)) * 0.3).astype(np.float32)
+    for w in (ol.WEIGHT_NONE, ol.WEIGHT_A, ol.WEIGHT_C):
+        # A and C weighting have their poles at 20.6 Hz: the float32 recursion's own round-off
+        # leaves a little more than 1e-5 between two correct evaluations
+        tol = TOL if w == ol.WEIGHT_NONE else 3e-5
+        bank = gpu.LoudnessBank(1, K)
+        ref = ol.LoudnessMeter(K)
+        for obj in (bank, ref):
+            obj.set_sample_rate(sr); obj.set_weighting(w); obj.set_period(50.0)
+        out = gpu.DeviceBuffer((1, 6000))
+        bank.process(out, None, gpu.DeviceBuffer.from_host(x[:, :6000]), 6000)
+        r1, _ = ref.process(x[:, :6000])
+        assert np.abs(out.download()[0] - r1).max() <= tol * float(np.abs(r1).max()), w
+        bank.clear(); ref.clear()
+        bank.set_active(1, False); ref.set_active(1, False)
+        bank.process(out, None, gpu.DeviceBuffer.from_host(x[:, 6000:]), 6000)
+        r2, _ = ref.process(x[:, 6000:])
+        assert np.abs(out.download()[0] - r2).max() <= tol * float(np.abs(r2).max()), w
+        bank.close()
