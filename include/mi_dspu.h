@@ -518,6 +518,31 @@ int mi_loudness_bank_process(mi_loudness_bank_t *bank, float *out, float *ch_out
 /* loudness(): the last value of the mixed loudness of every meter (HOST array of `meters` floats; synchronises) */
 int mi_loudness_bank_loudness(mi_loudness_bank_t *bank, float *loudness, void *stream);
 
+/*
+ * mi_ilufs_bank: `meters` x lsp::dspu::ILUFSMeter(channels) sharing one configuration
+ * (meters/ILUFSMeter.h:41-260, src/main/meters/ILUFSMeter.cpp): integrated loudness per ITU-R BS.1770-4 -- weighting
+ * filter, gating blocks of `block_period` ms overlapping by 75 %, absolute (-70 LKFS) and relative (-10 LU) gating over
+ * the integration period (0 = since the last clear()).  The output is the integrated loudness as a gain, held between
+ * block boundaries.  Rows of the input: row = meter * channels + channel.
+ */
+typedef struct mi_ilufs_bank mi_ilufs_bank_t;
+/* ILUFSMeter::init(channels, max_int_time [s], block_period [ms]), ILUFSMeter.cpp:113-211 */
+int mi_ilufs_bank_create(mi_ilufs_bank_t **bank, uint32_t meters, uint32_t channels, float max_int_time, float block_period_ms);
+int mi_ilufs_bank_destroy(mi_ilufs_bank_t *bank);
+/* set_sample_rate / set_integration_period [s] / set_weighting, ILUFSMeter.cpp:258-322 */
+int mi_ilufs_bank_set_sample_rate(mi_ilufs_bank_t *bank, uint32_t sample_rate, void *stream);
+int mi_ilufs_bank_set_integration_period(mi_ilufs_bank_t *bank, float period, void *stream);
+int mi_ilufs_bank_set_weighting(mi_ilufs_bank_t *bank, int weighting);
+/* per channel index, for every meter: set_designation / set_active, ILUFSMeter.cpp:223-256 */
+int mi_ilufs_bank_set_designation(mi_ilufs_bank_t *bank, uint32_t channel, int designation);
+int mi_ilufs_bank_set_active(mi_ilufs_bank_t *bank, uint32_t channel, int active);
+int mi_ilufs_bank_clear(mi_ilufs_bank_t *bank, void *stream);                      /* ILUFSMeter.cpp:547-560 */
+/* process(out, count, gain), ILUFSMeter.cpp:355-470.  in: [meters*channels][in_stride]; out: [meters][out_stride] or NULL. */
+int mi_ilufs_bank_process(mi_ilufs_bank_t *bank, float *out, const float *in, size_t count, size_t out_stride,
+                          size_t in_stride, float gain, void *stream);
+/* loudness() of every meter (HOST array of `meters` floats; synchronises) */
+int mi_ilufs_bank_loudness(mi_ilufs_bank_t *bank, float *loudness, void *stream);
+
 /* ---- delay line and ring buffer banks ----------------------------------------------------- */
 /*
  * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  All

@@ -13,7 +13,7 @@ name carries the reference's name and is not a Python identifier).
 """
 from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
 from .units import (AnalyzerBank, BiquadBank, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, EqualizerBank,  # noqa: F401
-                    LoudnessBank,
+                    ILUFSBank, LoudnessBank,
                     RingBank,
                     SpectralBank,
                     design_filter, device_count, filter_freq_chart, make_window)

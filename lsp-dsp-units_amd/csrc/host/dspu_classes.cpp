@@ -11,6 +11,7 @@
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
+#include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
 #include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
@@ -1377,6 +1378,184 @@ void LoudnessMeter::dump(IStateDumper *v) const
 {
     v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
     v->write("fPeriod", period());
+}
+
+// ---- ILUFSMeter ------------------------------------------------------------------------------------------------
+struct ILUFSMeter::impl_t
+{
+    mi_ilufs_bank_t *bank = nullptr;
+    size_t  channels = 0, sample_rate = 0;
+    float   int_time = 60.0f, max_int_time = 60.0f, block_period = 400.0f, loudness = 0.0f;
+    bs::weighting_t weighting = bs::WEIGHT_K;
+    struct chan_t { const float *in = nullptr; bs::channel_t designation = bs::CHANNEL_NONE; bool active = true, bound = true; };
+    std::vector<chan_t> ch;
+    std::vector<float>  host;
+    float  *d_in = nullptr, *d_out = nullptr;
+    size_t  cap = 0;
+
+    bool reserve(size_t n)
+    {
+        if (n <= cap)
+            return true;
+        mi_dspu_free(d_in); mi_dspu_free(d_out);
+        d_in = d_out = nullptr;
+        cap = 0;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_in), channels * n * sizeof(float)) != MI_OK) return false;
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&d_out), n * sizeof(float)) != MI_OK) return false;
+        cap = n;
+        return true;
+    }
+};
+
+ILUFSMeter::ILUFSMeter() : pImpl(nullptr) { construct(); }
+ILUFSMeter::~ILUFSMeter() { destroy(); }
+void ILUFSMeter::construct() { pImpl = nullptr; }
+
+void ILUFSMeter::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_ilufs_bank_destroy(pImpl->bank);
+    mi_dspu_free(pImpl->d_in); mi_dspu_free(pImpl->d_out);
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+status_t ILUFSMeter::init(size_t channels, float max_int_time, float block_period)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return STATUS_NO_MEM;
+    if (channels == 0 || mi_ilufs_bank_create(&p->bank, 1, uint32_t(channels), max_int_time, block_period) != MI_OK)
+    {
+        delete p;
+        return STATUS_NO_MEM;
+    }
+    p->channels = channels;
+    p->int_time = p->max_int_time = max_int_time;
+    p->block_period = block_period;
+    p->ch.resize(channels);
+    if (channels == 1)
+        p->ch[0].designation = bs::CHANNEL_CENTER;
+    else if (channels == 2)
+    {
+        p->ch[0].designation = bs::CHANNEL_LEFT;
+        p->ch[1].designation = bs::CHANNEL_RIGHT;
+    }
+    pImpl = p;
+    return STATUS_OK;
+}
+
+status_t ILUFSMeter::bind(size_t id, const float *in)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].in = in;
+    return STATUS_OK;
+}
+
+status_t ILUFSMeter::set_designation(size_t id, bs::channel_t designation)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].designation = designation;
+    mi_ilufs_bank_set_designation(pImpl->bank, uint32_t(id), int(designation));
+    return STATUS_OK;
+}
+
+bs::channel_t ILUFSMeter::designation(size_t id) const
+{
+    return (pImpl && id < pImpl->channels) ? pImpl->ch[id].designation : bs::CHANNEL_NONE;
+}
+
+status_t ILUFSMeter::set_active(size_t id, bool active)
+{
+    if (pImpl == nullptr || id >= pImpl->channels)
+        return STATUS_OVERFLOW;
+    pImpl->ch[id].active = active;
+    return STATUS_OK;
+}
+
+bool ILUFSMeter::active(size_t id) const { return (pImpl && id < pImpl->channels) ? pImpl->ch[id].active : false; }
+
+void ILUFSMeter::set_weighting(bs::weighting_t weighting)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->weighting = weighting;
+    mi_ilufs_bank_set_weighting(pImpl->bank, int(weighting));
+}
+
+bs::weighting_t ILUFSMeter::weighting() const { return pImpl ? pImpl->weighting : bs::WEIGHT_K; }
+
+void ILUFSMeter::set_integration_period(float period)
+{
+    if (pImpl == nullptr)
+        return;
+    const float lo = pImpl->block_period * 0.001f;
+    pImpl->int_time = (period < lo) ? lo : (period > pImpl->max_int_time) ? pImpl->max_int_time : period;      // lsp_limit, :266
+    mi_ilufs_bank_set_integration_period(pImpl->bank, period, nullptr);
+}
+
+float ILUFSMeter::integration_period() const { return pImpl ? pImpl->int_time : 0.0f; }
+
+status_t ILUFSMeter::set_sample_rate(size_t sample_rate)
+{
+    if (pImpl == nullptr)
+        return STATUS_BAD_STATE;
+    if (mi_ilufs_bank_set_sample_rate(pImpl->bank, uint32_t(sample_rate), nullptr) != MI_OK)
+        return STATUS_NO_MEM;
+    if (pImpl->sample_rate != sample_rate)
+        pImpl->loudness = 0.0f;
+    pImpl->sample_rate = sample_rate;
+    return STATUS_OK;
+}
+
+size_t ILUFSMeter::sample_rate() const { return pImpl ? pImpl->sample_rate : 0; }
+
+void ILUFSMeter::process(float *out, size_t count, float gain)
+{
+    impl_t *p = pImpl;
+    if (p == nullptr || count == 0 || !p->reserve(count))
+        return;
+    const size_t K = p->channels;
+    p->host.assign(K * count, 0.0f);
+    for (size_t c = 0; c < K; ++c)
+    {
+        // a channel takes part when it is bound AND enabled (ILUFSMeter.cpp:370)
+        const bool on = p->ch[c].active && p->ch[c].in != nullptr;
+        if (on != p->ch[c].bound)
+        {
+            mi_ilufs_bank_set_active(p->bank, uint32_t(c), on ? 1 : 0);
+            p->ch[c].bound = on;
+        }
+        if (on)
+            std::memcpy(&p->host[c * count], p->ch[c].in, count * sizeof(float));
+    }
+    bool ok = mi_dspu_copy_h2d(p->d_in, p->host.data(), K * count * sizeof(float), nullptr) == MI_OK &&
+              mi_ilufs_bank_process(p->bank, (out != nullptr) ? p->d_out : nullptr, p->d_in, count, count, count, gain, nullptr) == MI_OK;
+    if (ok && out != nullptr)
+        ok = mi_dspu_copy_d2h(out, p->d_out, count * sizeof(float), nullptr) == MI_OK;
+    ok = ok && mi_dspu_stream_synchronize(nullptr) == MI_OK;
+    if (ok)
+        mi_ilufs_bank_loudness(p->bank, &p->loudness, nullptr);
+}
+
+float ILUFSMeter::loudness() const { return pImpl ? pImpl->loudness : 0.0f; }
+
+void ILUFSMeter::clear()
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->loudness = 0.0f;
+    mi_ilufs_bank_clear(pImpl->bank, nullptr);
+}
+
+void ILUFSMeter::dump(IStateDumper *v) const
+{
+    v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
+    v->write("fIntTime", integration_period());
 }
 
 // ---- Delay -----------------------------------------------------------------------------------------------------

@@ -454,3 +454,474 @@ int mi_loudness_bank_loudness(mi_loudness_bank_t *b, float *loudness, void *stre
 }
 
 } // extern "C"
+
+// =====================================================================================================================
+// Integrated loudness: lsp::dspu::ILUFSMeter for many meters
+// (reference: src/main/meters/ILUFSMeter.cpp:113-211 init, :291-322 set_sample_rate, :324-353 gated / infinite
+//  loudness, :355-470 process, :472-513 update_settings, :515-560 clear).
+// The weighting filter is the biquad bank; a block quarter's square sums are one reduction per row; at every quarter
+// boundary one workgroup per meter does the reference's gating arithmetic over the meter's history of gating blocks.
+namespace
+{
+    constexpr float GATING_ABS_THRESH = 1.17246530458e-07f;         // ILUFSMeter.cpp:39
+    constexpr uint32_t MIN_GATING_BLOCKS = 64;                      // :55
+
+    struct ilufs_state { uint32_t head, count; float loudness; uint32_t pad; };
+
+    // vBlock[row][part] += sum of squares of the row's filtered samples
+    __global__ __launch_bounds__(LT)
+    void ilufs_sqsum_kernel(float *block, uint32_t part, const float *__restrict__ flt, size_t flt_stride, uint32_t n,
+                            const chan_cfg *__restrict__ cfg, uint32_t channels)
+    {
+        __shared__ float partial[LT];
+        const uint32_t row = blockIdx.x, tid = threadIdx.x;
+        if (!cfg[row % channels].enabled)
+            return;
+        const float *x = flt + size_t(row) * flt_stride;
+        float s = 0.0f;
+        for (uint32_t i = tid; i < n; i += LT)
+            s = fmaf(x[i], x[i], s);
+        partial[tid] = s;
+        __syncthreads();
+        for (int w = LT / 2; w > 0; w >>= 1)
+        {
+            if (int(tid) < w)
+                partial[tid] += partial[tid + w];
+            __syncthreads();
+        }
+        if (tid == 0)
+            block[row * 4 + part] += partial[0];
+    }
+
+    // out[meter][i] = loudness[meter] * gain (the value is held between block boundaries, ILUFSMeter.cpp:386-387)
+    __global__ __launch_bounds__(256)
+    void ilufs_fill_kernel(float *out, size_t out_stride, const ilufs_state *__restrict__ st, float gain, uint32_t n)
+    {
+        const uint32_t meter = blockIdx.y;
+        const float v = st[meter].loudness * gain;
+        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
+            out[size_t(meter) * out_stride + i] = v;
+    }
+
+    // mean of the last `count` history entries above the ABSOLUTE gate (compute_gated_loudness, ILUFSMeter.cpp:324-341:
+    // its `threshold` argument is not used by the reference -- both gating stages compare with GATING_ABS_THRESH, so the
+    // relative stage returns what the absolute stage returned; one pass gives the reference's result for both)
+    __device__ float gated_mean(const float *hist, uint32_t size, uint32_t head, uint32_t count, float *s_sum, uint32_t *s_cnt)
+    {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t tail = (head + size - count) % size;
+        float s = 0.0f;
+        uint32_t c = 0;
+        for (uint32_t j = tid; j < count; j += LT)
+        {
+            const float l = hist[(tail + j) % size];
+            if (l > GATING_ABS_THRESH)
+            {
+                s += l;
+                ++c;
+            }
+        }
+        s_sum[tid] = s;
+        s_cnt[tid] = c;
+        __syncthreads();
+        for (int w = LT / 2; w > 0; w >>= 1)
+        {
+            if (int(tid) < w)
+            {
+                s_sum[tid] += s_sum[tid + w];
+                s_cnt[tid] += s_cnt[tid + w];
+            }
+            __syncthreads();
+        }
+        const float r = (s_cnt[0] > 0) ? s_sum[0] / float(s_cnt[0]) : 0.0f;
+        __syncthreads();
+        return r;
+    }
+
+    // a gating block is complete (ILUFSMeter.cpp:402-458); one workgroup per meter
+    __global__ __launch_bounds__(LT)
+    void ilufs_gate_kernel(ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *__restrict__ block,
+                           const chan_cfg *__restrict__ cfg, uint32_t channels, float avg)
+    {
+        __shared__ float s_sum[LT];
+        __shared__ uint32_t s_cnt[LT];
+        __shared__ float s_val;
+        const uint32_t meter = blockIdx.x, tid = threadIdx.x;
+        float *h = hist + size_t(meter) * size;
+        ilufs_state me = st[meter];
+        if (tid == 0)
+        {
+            float loudness = 0.0f;                          // every channel's block enters, enabled or not (:407-414)
+            for (uint32_t c = 0; c < channels; ++c)
+            {
+                const float *blk = block + (size_t(meter) * channels + c) * 4;
+                loudness += cfg[c].weight * ((blk[0] + blk[1] + blk[2] + blk[3]) * avg);
+            }
+            s_val = loudness;
+        }
+        __syncthreads();
+        float loudness = s_val;
+        __syncthreads();
+        if (ms_int > 0)                                     // finite integration period
+        {
+            me.count = (me.count + 1 < ms_int) ? me.count + 1 : ms_int;
+            if (tid == 0)
+                h[me.head] = loudness;
+            me.head = (me.head + 1) % size;
+            __syncthreads();
+            loudness = gated_mean(h, size, me.head, me.count, s_sum, s_cnt);
+        }
+        else                                                // since the last clear(): running mean of the gated blocks
+        {
+            if (loudness > GATING_ABS_THRESH)
+            {
+                if (me.count >= 0x100)                      // floating-point overflow protection (:440-444)
+                {
+                    for (uint32_t j = tid; j < size; j += LT)
+                        h[j] *= 0.5f;
+                    me.count >>= 1;
+                    __syncthreads();
+                }
+                ++me.count;
+                if (tid == 0)
+                    h[me.head] += loudness;
+                me.head = (me.head + 1) % size;
+                __syncthreads();
+            }
+            if (me.count > 0)                               // compute_infinite_loudness: sum of hist[j] / count
+            {
+                const float mult = 1.0f / float(me.count);
+                float s = 0.0f;
+                for (uint32_t j = tid; j < size; j += LT)
+                    s += mult * h[j];
+                s_sum[tid] = s;
+                __syncthreads();
+                for (int w = LT / 2; w > 0; w >>= 1)
+                {
+                    if (int(tid) < w)
+                        s_sum[tid] += s_sum[tid + w];
+                    __syncthreads();
+                }
+                loudness = s_sum[0];
+            }
+            else
+                loudness = 0.0f;
+        }
+        if (tid == 0)
+        {
+            me.loudness = sqrtf(loudness);
+            st[meter] = me;
+        }
+    }
+
+    __global__ void ilufs_zero_part_kernel(float *block, uint32_t rows, uint32_t part)
+    {
+        const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+        if (r < rows)
+            block[r * 4 + part] = 0.0f;
+    }
+} // namespace
+
+struct mi_ilufs_bank
+{
+    uint32_t    meters = 0, channels = 0, rows = 0;
+    uint32_t    sample_rate = 0, block_size = 0, block_offset = 0, block_part = 0, ms_size = 0, ms_int = 0;
+    float       block_period = 400.0f, int_time = 60.0f, max_int_time = 60.0f, avg = 1.0f;
+    int         weighting = MI_BS_WEIGHT_K;
+    bool        upd_filters = true, upd_time = true, cfg_dirty = true, blk_full = false;
+    std::vector<chan_cfg> cfg;
+    mi_biquad_bank_t *filters = nullptr;
+    float      *d_block = nullptr, *d_hist = nullptr, *d_flt = nullptr;
+    ilufs_state *d_state = nullptr;
+    chan_cfg   *d_cfg = nullptr;
+    size_t      cap = 0;
+};
+
+namespace
+{
+    int ilufs_clear_blocks(mi_ilufs_bank *b, hipStream_t st)           // clear_block_buffers(), ILUFSMeter.cpp:515-526
+    {
+        MI_HIP_CHECK(hipMemsetAsync(b->d_block, 0, size_t(b->rows) * 4 * sizeof(float), st));
+        if (b->d_hist != nullptr)
+            MI_HIP_CHECK(hipMemsetAsync(b->d_hist, 0, size_t(b->meters) * b->ms_size * sizeof(float), st));
+        b->blk_full = false;
+        return MI_OK;
+    }
+
+    int ilufs_update(mi_ilufs_bank *b, hipStream_t st)                 // update_settings(), ILUFSMeter.cpp:472-513
+    {
+        if (b->upd_time)
+        {
+            const float int_time = (b->int_time < b->max_int_time) ? b->int_time : b->max_int_time;
+            const size_t blk = size_t((b->block_period * 0.25f * 0.001f) * float(b->sample_rate));
+            if (int_time > 0)
+            {
+                const size_t total = size_t(int_time * float(b->sample_rate));
+                const long v = (long(total) - long(blk) * 2 - 1) / long(blk ? blk : 1);
+                b->ms_int = uint32_t((v > 1) ? v : 1);
+            }
+            else
+                b->ms_int = 0;
+            // nMSCount = min(nMSCount, nMSInt) for every meter: done on the host side of the state
+            std::vector<ilufs_state> h(b->meters);
+            MI_HIP_CHECK(hipMemcpyAsync(h.data(), b->d_state, h.size() * sizeof(ilufs_state), hipMemcpyDeviceToHost, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+            for (ilufs_state &s : h)
+                s.count = (s.count < b->ms_int) ? s.count : b->ms_int;
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_state, h.data(), h.size() * sizeof(ilufs_state), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+            b->upd_time = false;
+        }
+        if (b->upd_filters)
+        {
+            static const uint32_t types[6] = { MI_FLT_NONE, MI_FLT_A_WEIGHTED, MI_FLT_B_WEIGHTED, MI_FLT_C_WEIGHTED,
+                                               MI_FLT_D_WEIGHTED, MI_FLT_K_WEIGHTED };
+            mi_filter_params_t fp;
+            fp.nType = types[b->weighting]; fp.nSlope = 0; fp.fFreq = 0.0f; fp.fFreq2 = 0.0f; fp.fGain = 1.0f; fp.fQuality = 0.0f;
+            mi::design d;
+            d.cascades.reserve(mi::CHAINS_MAX + 1);
+            mi::design_filter(&d, &fp, b->sample_rate);
+            for (uint32_t r = 0; r < b->rows; ++r)
+            {
+                const int e = mi_biquad_bank_set_chains(b->filters, r, d.sections.data(), uint32_t(d.sections.size()), 1);
+                if (e != MI_OK)
+                    return e;
+            }
+            const int e = mi_biquad_bank_commit(b->filters, st);
+            if (e != MI_OK)
+                return e;
+            b->upd_filters = false;
+        }
+        if (b->cfg_dirty)
+        {
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_cfg, b->cfg.data(), b->channels * sizeof(chan_cfg), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+            b->cfg_dirty = false;
+        }
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_ilufs_bank_create(mi_ilufs_bank_t **bank, uint32_t meters, uint32_t channels, float max_int_time, float block_period_ms)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_ilufs_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(meters > 0 && channels > 0 && block_period_ms > 0.0f, MI_EINVAL, "mi_ilufs_bank_create: bad argument");
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_ilufs_bank *b = new (std::nothrow) mi_ilufs_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_ilufs_bank_create: out of host memory");
+    b->meters = meters;
+    b->channels = channels;
+    b->rows = meters * channels;
+    b->block_period = block_period_ms;
+    b->int_time = b->max_int_time = max_int_time;
+    b->cfg.assign(channels, chan_cfg{ 0.0f, 1.0f, 1, 0 });
+    if (channels == 1)
+        b->cfg[0].weight = channel_weighting(MI_BS_CHANNEL_CENTER);
+    else if (channels == 2)
+        b->cfg[0].weight = b->cfg[1].weight = channel_weighting(MI_BS_CHANNEL_LEFT);
+    int r = mi_biquad_bank_create(&b->filters, b->rows, 4);
+    hipError_t e = hipSuccess;
+    if (r == MI_OK)
+    {
+        e = hipMalloc(reinterpret_cast<void **>(&b->d_block), size_t(b->rows) * 4 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_state), meters * sizeof(ilufs_state));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_cfg), channels * sizeof(chan_cfg));
+        if (e == hipSuccess) e = hipMemset(b->d_block, 0, size_t(b->rows) * 4 * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_state, 0, meters * sizeof(ilufs_state));
+    }
+    if (r != MI_OK || e != hipSuccess)
+    {
+        mi_ilufs_bank_destroy(b);
+        return (r != MI_OK) ? r : mi::fail(MI_EHIP, "mi_ilufs_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_destroy(mi_ilufs_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    mi_biquad_bank_destroy(b->filters);
+    (void)hipFree(b->d_block); (void)hipFree(b->d_hist); (void)hipFree(b->d_flt); (void)hipFree(b->d_state); (void)hipFree(b->d_cfg);
+    delete b;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_clear(mi_ilufs_bank_t *b, void *stream)                      // ILUFSMeter.cpp:547-560
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_clear: NULL bank");
+    hipStream_t st = mi::as_stream(stream);
+    int r = mi_biquad_bank_reset(b->filters, UINT32_MAX, stream);
+    if (r == MI_OK)
+        r = ilufs_clear_blocks(b, st);
+    if (r != MI_OK)
+        return r;
+    MI_HIP_CHECK(hipMemsetAsync(b->d_state, 0, b->meters * sizeof(ilufs_state), st));
+    b->block_offset = 0;
+    b->block_part = 0;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_set_sample_rate(mi_ilufs_bank_t *b, uint32_t sample_rate, void *stream)      // ILUFSMeter.cpp:291-322
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_set_sample_rate: NULL bank");
+    if (b->sample_rate == sample_rate)
+        return MI_OK;
+    const size_t blk = size_t((b->block_period * 0.25f * 0.001f) * float(sample_rate));          // 75 % overlap
+    MI_REQUIRE(blk > 0, MI_EINVAL, "mi_ilufs_bank_set_sample_rate: block period too short for %u Hz", sample_rate);
+    const size_t int_count = (size_t(b->max_int_time * float(sample_rate)) + blk - 1) / blk;
+    size_t blocks = (int_count > MIN_GATING_BLOCKS) ? int_count : MIN_GATING_BLOCKS;
+    blocks = (blocks + 3) & ~size_t(3);                     // align_size(.., DEFAULT_ALIGN = 16 bytes)
+    (void)hipFree(b->d_hist);
+    b->d_hist = nullptr;
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_hist), size_t(b->meters) * blocks * sizeof(float)));
+    b->avg = 0.25f / float(blk);
+    b->sample_rate = sample_rate;
+    b->block_size = uint32_t(blk);
+    b->ms_size = uint32_t(blocks);
+    b->upd_filters = b->upd_time = true;
+    return mi_ilufs_bank_clear(b, stream);
+}
+
+int mi_ilufs_bank_set_integration_period(mi_ilufs_bank_t *b, float period, void *stream)        // ILUFSMeter.cpp:264-289
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_set_integration_period: NULL bank");
+    const float lo = b->block_period * 0.001f;
+    period = (period < lo) ? lo : (period > b->max_int_time) ? b->max_int_time : period;
+    if (b->int_time == period)
+        return MI_OK;
+    hipStream_t st = mi::as_stream(stream);
+    if (b->int_time <= 0)
+    {
+        MI_HIP_CHECK(hipMemsetAsync(b->d_state, 0, b->meters * sizeof(ilufs_state), st));     // nMSCount = 0 (loudness too: next gate rewrites it)
+        const int r = ilufs_clear_blocks(b, st);
+        if (r != MI_OK)
+            return r;
+    }
+    else if (period <= 0.0f)
+    {
+        const int r = ilufs_clear_blocks(b, st);
+        if (r != MI_OK)
+            return r;
+    }
+    b->int_time = period;
+    b->upd_time = true;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_set_weighting(mi_ilufs_bank_t *b, int weighting)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_set_weighting: NULL bank");
+    MI_REQUIRE(weighting >= MI_BS_WEIGHT_NONE && weighting <= MI_BS_WEIGHT_K, MI_EINVAL, "mi_ilufs_bank_set_weighting: bad weighting %d", weighting);
+    if (weighting == b->weighting)
+        return MI_OK;
+    b->weighting = weighting;
+    b->upd_filters = true;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_set_designation(mi_ilufs_bank_t *b, uint32_t channel, int designation)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_set_designation: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_ilufs_bank_set_designation: channel %u out of range", channel);
+    b->cfg[channel].weight = channel_weighting(designation);
+    b->cfg_dirty = true;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_set_active(mi_ilufs_bank_t *b, uint32_t channel, int active)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_set_active: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_ilufs_bank_set_active: channel %u out of range", channel);
+    b->cfg[channel].enabled = active ? 1 : 0;
+    b->cfg_dirty = true;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_t count, size_t out_stride,
+                          size_t in_stride, float gain, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_process: NULL bank");
+    if (count == 0)
+        return MI_OK;
+    MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_ilufs_bank_process: NULL input");
+    MI_REQUIRE(b->sample_rate != 0 && b->d_hist != nullptr, MI_ESTATE, "mi_ilufs_bank_process: set_sample_rate() first");
+    hipStream_t st = mi::as_stream(stream);
+    int r = ilufs_update(b, st);
+    if (r != MI_OK)
+        return r;
+    // update_settings() ends with `nFlags = 0` (ILUFSMeter.cpp:519) and F_BLK_FULL is one of those flags: every process()
+    // call starts with the flag cleared, and gating blocks are evaluated only from the point where the quarter counter
+    // wraps inside the same call.  Reproduced so that a host that switches banks sees the same meter readings.
+    b->blk_full = false;
+    size_t offset = 0;
+    while (offset < count)
+    {
+        size_t n = std::min<size_t>(count - offset, b->block_size - b->block_offset);
+        n = std::min<size_t>(n, 16384);
+        if (n > 0)
+        {
+            if (n > b->cap)
+            {
+                (void)hipFree(b->d_flt);
+                b->d_flt = nullptr;
+                b->cap = 0;
+                const size_t cap = std::min<size_t>(std::max<size_t>(n, 4096), 16384);
+                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_flt), size_t(b->rows) * cap * sizeof(float)));
+                b->cap = cap;
+            }
+            r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
+            if (r != MI_OK)
+                return r;
+            hipLaunchKernelGGL(ilufs_sqsum_kernel, dim3(b->rows), dim3(LT), 0, st, b->d_block, b->block_part, b->d_flt, b->cap,
+                               uint32_t(n), b->d_cfg, b->channels);
+            MI_HIP_CHECK(hipGetLastError());
+            b->block_offset += uint32_t(n);
+            if (out != nullptr)
+            {
+                const unsigned gx = unsigned(std::min<size_t>((n + 255) / 256, 64));
+                hipLaunchKernelGGL(ilufs_fill_kernel, dim3(gx, b->meters), dim3(256), 0, st, out + offset, out_stride, b->d_state,
+                                   gain, uint32_t(n));
+                MI_HIP_CHECK(hipGetLastError());
+            }
+        }
+        if (b->block_offset >= b->block_size)               // a quarter of a gating block is complete
+        {
+            b->block_offset = 0;
+            if (++b->block_part >= 4)
+            {
+                b->block_part = 0;
+                b->blk_full = true;
+            }
+            if (b->blk_full)
+            {
+                hipLaunchKernelGGL(ilufs_gate_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_state, b->d_hist, b->ms_size, b->ms_int,
+                                   b->d_block, b->d_cfg, b->channels, b->avg);
+                MI_HIP_CHECK(hipGetLastError());
+            }
+            hipLaunchKernelGGL(ilufs_zero_part_kernel, dim3((b->rows + 255) / 256), dim3(256), 0, st, b->d_block, b->rows, b->block_part);
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        offset += n;
+    }
+    return MI_OK;
+}
+
+int mi_ilufs_bank_loudness(mi_ilufs_bank_t *b, float *loudness, void *stream)
+{
+    MI_REQUIRE(b != nullptr && loudness != nullptr, MI_EINVAL, "mi_ilufs_bank_loudness: bad argument");
+    hipStream_t st = mi::as_stream(stream);
+    std::vector<ilufs_state> h(b->meters);
+    MI_HIP_CHECK(hipMemcpyAsync(h.data(), b->d_state, h.size() * sizeof(ilufs_state), hipMemcpyDeviceToHost, st));
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    for (uint32_t m = 0; m < b->meters; ++m)
+        loudness[m] = h[m].loudness;
+    return MI_OK;
+}
+
+} // extern "C"
+

@@ -30,6 +30,16 @@ namespace lsp
 
             constexpr float DBFS_TO_LUFS_SHIFT_DB   = -0.691f;
             constexpr float LUFS_TO_DBFS_SHIFT_DB   =  0.691f;
+            constexpr float LUFS_TO_LU_SHIFT_DB     = 23.0f;
+            constexpr float LO_TO_LUFS_SHIFT_DB     = -23.0f;
+            constexpr float DB_TO_LU_SHIFT_DB       = 22.309f;
+            constexpr float LU_TO_DB_SHIFT          = -22.309f;
+            constexpr float DBFS_TO_LUFS_SHIFT_GAIN = 0.923527857225f;      // 10^(-0.691 / 20)
+            constexpr float LUFS_TO_DBFS_SHIFT_GAIN = 1.08280437041f;
+            constexpr float LUFS_TO_LU_SHIFT_GAIN   = 14.1253754462f;       // 10^(23 / 20)
+            constexpr float LO_TO_LUFS_SHIFT_GAIN   = 0.0707945784385f;
+            constexpr float DB_TO_LU_SHIFT_GAIN     = 13.0451777184f;
+            constexpr float LU_TO_DB_SHIFT_GAIN     = 0.0766566789345f;
             constexpr float LUFS_MEASURE_PERIOD_MS  = 400.0f;
             constexpr float LUFS_MOMENTARY_PERIOD   = 400.0f;
             constexpr float LUFS_SHORT_TERM_PERIOD  = 3000.0f;

@@ -474,6 +474,55 @@ class LoudnessBank:
             pass
 
 
+class ILUFSBank:
+    """`meters` x lsp::dspu::ILUFSMeter(channels) sharing one configuration (mi_ilufs_bank_*)."""
+    DBFS_TO_LUFS_SHIFT_GAIN = 0.923527857225
+
+    def __init__(self, meters, channels, max_int_time=60.0, block_period_ms=400.0):
+        h = c_void_p()
+        check(lib.mi_ilufs_bank_create(byref(h), meters, channels, float(max_int_time), float(block_period_ms)))
+        self.handle, self.meters, self.channels = h, meters, channels
+
+    def set_sample_rate(self, sr, stream=None):
+        check(lib.mi_ilufs_bank_set_sample_rate(self.handle, sr, _stream(stream)))
+
+    def set_integration_period(self, seconds, stream=None):
+        check(lib.mi_ilufs_bank_set_integration_period(self.handle, float(seconds), _stream(stream)))
+
+    def set_weighting(self, w):
+        check(lib.mi_ilufs_bank_set_weighting(self.handle, int(w)))
+
+    def set_designation(self, channel, designation):
+        check(lib.mi_ilufs_bank_set_designation(self.handle, channel, int(designation)))
+
+    def set_active(self, channel, active=True):
+        check(lib.mi_ilufs_bank_set_active(self.handle, channel, 1 if active else 0))
+
+    def clear(self, stream=None):
+        check(lib.mi_ilufs_bank_clear(self.handle, _stream(stream)))
+
+    def process(self, out, inp, count, out_stride=None, in_stride=None, gain=DBFS_TO_LUFS_SHIFT_GAIN, stream=None):
+        check(lib.mi_ilufs_bank_process(self.handle, _ptr(out) if out is not None else None, _ptr(inp), count,
+                                        count if out_stride is None else out_stride,
+                                        count if in_stride is None else in_stride, float(gain), _stream(stream)))
+
+    def loudness(self, stream=None):
+        v = (c_float * self.meters)()
+        check(lib.mi_ilufs_bank_loudness(self.handle, v, _stream(stream)))
+        return np.array(list(v), np.float32)
+
+    def close(self):
+        if self.handle:
+            lib.mi_ilufs_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CrossoverBank:
     """lsp::dspu::Crossover for `channels` channels sharing the split settings (mi_crossover_bank_*)."""
     MODE_BT, MODE_MT = 0, 1

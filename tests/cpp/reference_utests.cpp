@@ -12,6 +12,7 @@
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
+#include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
 #include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
@@ -253,6 +254,42 @@ static void loudness_meter_bs1770()
     m.destroy();
 }
 
+// ILUFSMeter, the flow of the reference's manual test (src/test/mtest/meters/ilufs.cpp:44-78: stereo file, integration
+// period = file length, blocks of 0x400) on a synthetic signal with a known answer: a 0 dBFS 997 Hz sine on the left
+// channel integrates to -3.01 LUFS.
+static void ilufs_meter_mtest_flow()
+{
+    printf("ilufs_meter (mtest flow, BS.1770 sine anchor)\n");
+    const size_t SR = 48000, N = 2 * 48000, BUF = 0x400;
+    std::vector<float> l(N), r(N, 0.0f), out(N, -1.0f);
+    for (size_t i = 0; i < N; ++i) l[i] = sinf(2.0f * float(M_PI) * 997.0f * float(i) / float(SR));
+    dspu::ILUFSMeter lm;
+    const float integration_period = float(N) / float(SR);
+    CHECK(lm.init(2, integration_period, dspu::bs::LUFS_MEASURE_PERIOD_MS) == STATUS_OK, "init");
+    CHECK(lm.set_sample_rate(SR) == STATUS_OK, "set_sample_rate");
+    lm.set_integration_period(integration_period);
+    lm.set_weighting(dspu::bs::WEIGHT_K);
+    lm.set_active(0, true);
+    lm.set_active(1, true);
+    CHECK(lm.set_designation(0, dspu::bs::CHANNEL_LEFT) == STATUS_OK && lm.set_designation(1, dspu::bs::CHANNEL_RIGHT) == STATUS_OK, "designation");
+    CHECK(lm.set_designation(2, dspu::bs::CHANNEL_LEFT) == STATUS_OVERFLOW, "designation out of range");
+    for (size_t offset = 0; offset < N; )
+    {
+        const size_t to_process = std::min(N - offset, BUF);
+        lm.bind(0, &l[offset]);
+        lm.bind(1, &r[offset]);
+        lm.process(&out[offset], to_process);
+        offset += to_process;
+    }
+    const float lufs = 20.0f * log10f(lm.loudness() * dspu::bs::DBFS_TO_LUFS_SHIFT_GAIN);
+    printf("  integrated loudness %.3f LUFS\n", lufs);
+    CHECK(fabsf(lufs + 3.01f) < 0.02f, "LUFS %.3f", lufs);
+    CHECK(out[0] == 0.0f && out[19199] == 0.0f && out[N - 1] > 0.6f, "held output");
+    lm.clear();
+    CHECK(lm.loudness() == 0.0f, "clear");
+    lm.destroy();
+}
+
 static void ringbuffer()
 {
     printf("ringbuffer\n");
@@ -312,7 +349,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ringbuffer readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter ringbuffer readme_filter");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -330,6 +367,7 @@ int main(int argc, char **argv)
     multi_spectral_proc();
     crossover_bands_sum_to_allpass();
     loudness_meter_bs1770();
+    ilufs_meter_mtest_flow();
     ringbuffer();
     readme_filter();
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");

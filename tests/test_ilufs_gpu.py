@@ -1,0 +1,122 @@
+"""GPU parity of mi_ilufs_bank_* (lsp::dspu::ILUFSMeter) against the CPU oracle, through the C-ABI."""
+import numpy as np
+import pytest
+
+from oracle import ilufs as oi
+from oracle import loudness as ol
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _run(gpu, bank, refs, x, calls, K, gain=None):
+    M = len(refs)
+    n = sum(calls)
+    got = np.zeros((M, n), np.float32); ref = np.zeros((M, n), np.float32)
+    pos = 0
+    kw = {} if gain is None else {"gain": gain}
+    for k in calls:
+        out = gpu.DeviceBuffer((M, k))
+        bank.process(out, gpu.DeviceBuffer.from_host(x[:, pos:pos + k]), k, **kw)
+        got[:, pos:pos + k] = out.download()
+        for m in range(M):
+            ref[m, pos:pos + k] = refs[m].process(x[m * K:(m + 1) * K, pos:pos + k], **kw)
+        pos += k
+    return got, ref
+
+
+def test_bs1770_sine_anchor_on_gpu(gpu):
+    """ITU-R BS.1770-4: a 0 dBFS 997 Hz sine integrates to -3.01 LKFS (and half the amplitude to -9.03)."""
+    sr = 48000
+    n = 2 * sr
+    t = np.arange(n)
+    x = np.stack([np.sin(2 * np.pi * 997.0 * t / sr), 0.5 * np.sin(2 * np.pi * 997.0 * t / sr)]).astype(np.float32)
+    bank = gpu.ILUFSBank(2, 1, 5.0)
+    bank.set_sample_rate(sr)
+    out = gpu.DeviceBuffer((2, n))
+    bank.process(out, gpu.DeviceBuffer.from_host(x), n)
+    y = out.download()
+    lkfs = 20.0 * np.log10(y[:, -1])
+    assert abs(lkfs[0] + 3.01) < 0.02 and abs(lkfs[1] + 9.03) < 0.02, lkfs
+    assert np.all(y[:, :4 * 4800 - 1] == 0.0)
+    np.testing.assert_allclose(bank.loudness() * np.float32(bank.DBFS_TO_LUFS_SHIFT_GAIN), y[:, -1], rtol=1e-5)   # one more gating block ended with the last sample
+    bank.close()
+
+
+@pytest.mark.parametrize("calls", [(3 * 44100,), (50000, 1024, 1024, 30000, 777, 49475), (1024,) * 100])
+def test_gated_integration_matches_oracle(gpu, calls):
+    """Two meters of three channels (one LFE, one of the +1.5 dB group), a stretch under the absolute gate, an integration
+    window shorter than the signal; single call, ragged calls and plugin-sized calls (where only the call in which the
+    quarter counter wraps evaluates gating blocks, as in the reference)."""
+    sr, M, K = 44100, 2, 3
+    n = sum(calls)
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((M * K, n)) * 0.1).astype(np.float32)
+    x[:, sr:sr + sr // 2] *= 1e-5
+    x[:, 2 * sr:] *= 3.0
+    x[K:] *= 0.25
+    bank = gpu.ILUFSBank(M, K, 1.5)
+    refs = [oi.ILUFSMeter(K, 1.5) for _ in range(M)]
+    for obj in [bank] + refs:
+        obj.set_sample_rate(sr)
+        obj.set_designation(0, ol.CHANNEL_LEFT); obj.set_designation(1, 7); obj.set_designation(2, ol.CHANNEL_LFE1)
+    got, ref = _run(gpu, bank, refs, x, calls, K)
+    peak = float(np.abs(ref).max())
+    assert peak > 0
+    assert np.abs(got - ref).max() <= TOL * peak, np.abs(got - ref).max() / peak
+    np.testing.assert_allclose(bank.loudness(), [float(r.loud) for r in refs], rtol=2e-5)
+    bank.close()
+
+
+def test_infinite_mode_halving_clear_and_disabled_channel(gpu):
+    sr, K = 8000, 2
+    n = 80 * 300
+    rng = np.random.default_rng(22)
+    x = (rng.standard_normal((K, n)) * 0.2).astype(np.float32)
+    bank = gpu.ILUFSBank(1, K, 0.0, 40.0)
+    ref = oi.ILUFSMeter(K, 0.0, 40.0)
+    for obj in (bank, ref):
+        obj.set_sample_rate(sr)
+        obj.set_active(1, False)
+    got, want = _run(gpu, bank, [ref], x, (n // 2, n // 2), K, gain=1.0)
+    assert ref.ms_count < 0x100 and ref.ms_count > 0x80      # the halving did happen
+    peak = float(want.max())
+    assert np.abs(got - want).max() <= TOL * peak, np.abs(got - want).max() / peak
+    for obj in (bank, ref):
+        obj.clear()
+        obj.set_active(1, True)
+    assert bank.loudness()[0] == 0.0
+    got, want = _run(gpu, bank, [ref], x[:, :8000], (8000,), K, gain=1.0)
+    assert np.abs(got - want).max() <= TOL * float(want.max())
+    bank.close()
+
+
+def test_weighting_and_integration_period_change(gpu):
+    sr, K = 48000, 1
+    rng = np.random.default_rng(23)
+    x = (rng.standard_normal((K, 3 * sr)) * 0.2).astype(np.float32)
+    x[:, sr:] *= 0.3
+    bank = gpu.ILUFSBank(1, K, 10.0)
+    ref = oi.ILUFSMeter(K, 10.0)
+    for obj in (bank, ref):
+        obj.set_sample_rate(sr)
+        obj.set_weighting(ol.WEIGHT_NONE)
+    g1, w1 = _run(gpu, bank, [ref], x[:, :2 * sr], (2 * sr,), K)
+    for obj in (bank, ref):
+        obj.set_integration_period(0.8)                       # shrinks the window: older blocks drop out
+    g2, w2 = _run(gpu, bank, [ref], x[:, 2 * sr:], (sr,), K)
+    got = np.concatenate([g1, g2], 1); want = np.concatenate([w1, w2], 1)
+    assert np.abs(got - want).max() <= TOL * float(want.max())
+    assert ref.ms_int == (int(np.float32(0.8) * np.float32(sr)) - 2 * 4800 - 1) // 4800
+    bank.close()
+
+
+def test_argument_errors(gpu):
+    lib = gpu.lib
+    bank = gpu.ILUFSBank(1, 1)
+    x = gpu.DeviceBuffer((1, 64))
+    with pytest.raises(gpu.MiError):
+        bank.process(None, x, 64)                            # no sample rate yet
+    with pytest.raises(gpu.MiError):
+        bank.set_designation(3, 1)
+    bank.close()
