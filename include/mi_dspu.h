@@ -543,6 +543,55 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *bank, float *out, const float *in, si
 /* loudness() of every meter (HOST array of `meters` floats; synchronises) */
 int mi_ilufs_bank_loudness(mi_ilufs_bank_t *bank, float *loudness, void *stream);
 
+/*
+ * mi_splitter_bank: lsp::dspu::SpectralSplitter for `channels` channels sharing the settings
+ * (util/SpectralSplitter.h:62-250, src/main/util/SpectralSplitter.cpp:62-361) -- the engine of lsp::dspu::FFTCrossover.
+ * The last 2^rank samples of every channel are transformed once per 2^(chunk_rank-1) samples; each handler shapes that
+ * spectrum, returns to the time domain and overlap-adds the last 2^chunk_rank samples (sin^2 window) into its output.
+ * A handler is bound as COPY (no spectral function), MASK (2^rank real gains in FFT order: FFTCrossover::spectral_func,
+ * FFTCrossover.cpp:124-140) or CALLBACK; its sink is the device buffer passed to process().
+ */
+typedef struct mi_splitter_bank mi_splitter_bank_t;
+/* spectral_splitter_func_t on the device (util/SpectralSplitter.h:41-46): in/out are DEVICE pointers to
+ * [channels][2 * 2^rank] floats (packed complex); the function runs on the host and may enqueue work on `stream`. */
+typedef void (*mi_splitter_func_t)(void *object, void *subject, float *out, const float *in, size_t rank, size_t channels, void *stream);
+/* init(max_rank, handlers), SpectralSplitter.cpp:62-127 (max_rank 5..13) */
+int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t handlers);
+int mi_splitter_bank_destroy(mi_splitter_bank_t *bank);
+/* set_rank / set_chunk_rank / set_phase, SpectralSplitter.cpp:260-282 */
+int mi_splitter_bank_set_rank(mi_splitter_bank_t *bank, uint32_t rank);
+int mi_splitter_bank_set_chunk_rank(mi_splitter_bank_t *bank, int32_t rank);
+int mi_splitter_bank_set_phase(mi_splitter_bank_t *bank, float phase);
+/* rank(), chunk_rank(), latency() (:284-293) and the samples left until the next transform */
+int mi_splitter_bank_get(const mi_splitter_bank_t *bank, uint32_t *rank, uint32_t *chunk_rank, uint32_t *latency, uint32_t *remaining);
+/* bind(id, object, subject, func, sink) in its three forms, unbind(id) (:143-180).  mask: HOST memory, one row of 2^rank
+ * gains for all channels (mask_stride == 0) or [channels][mask_stride]; binding a mask to a handler that already has
+ * one only replaces the gains. */
+int mi_splitter_bank_bind_copy(mi_splitter_bank_t *bank, uint32_t handler, void *stream);
+int mi_splitter_bank_bind_mask(mi_splitter_bank_t *bank, uint32_t handler, const float *mask, size_t mask_stride, void *stream);
+int mi_splitter_bank_bind_callback(mi_splitter_bank_t *bank, uint32_t handler, mi_splitter_func_t func, void *object, void *subject, void *stream);
+int mi_splitter_bank_unbind(mi_splitter_bank_t *bank, uint32_t handler);
+int mi_splitter_bank_clear(mi_splitter_bank_t *bank, void *stream);                /* SpectralSplitter.cpp:246-258 */
+/* process(src, count), :295-361.  in: [channels][in_stride] or NULL (silence); outs: HOST array of `handlers` device
+ * pointers, each [channels][out_stride] or NULL (no sink). */
+int mi_splitter_bank_process(mi_splitter_bank_t *bank, float *const *outs, const float *in, size_t count, size_t out_stride,
+                             size_t in_stride, void *stream);
+
+/*
+ * crossover::* of misc/fft_crossover.h:47-154 (src/main/misc/fft_crossover.cpp): magnitude of the FFT crossover's high-
+ * and low-pass at single frequencies, on frequency lists and on FFT-ordered bins.  Host functions, host memory.
+ */
+float mi_crossover_hipass(float f, float f0, float slope);
+float mi_crossover_lopass(float f, float f0, float slope);
+void  mi_crossover_hipass_set(float *gain, const float *f, float f0, float slope, size_t count);
+void  mi_crossover_hipass_apply(float *gain, const float *f, float f0, float slope, size_t count);
+void  mi_crossover_lopass_set(float *gain, const float *f, float f0, float slope, size_t count);
+void  mi_crossover_lopass_apply(float *gain, const float *f, float f0, float slope, size_t count);
+void  mi_crossover_hipass_fft_set(float *mag, float f0, float slope, float sample_rate, size_t rank);
+void  mi_crossover_hipass_fft_apply(float *mag, float f0, float slope, float sample_rate, size_t rank);
+void  mi_crossover_lopass_fft_set(float *mag, float f0, float slope, float sample_rate, size_t rank);
+void  mi_crossover_lopass_fft_apply(float *mag, float f0, float slope, float sample_rate, size_t rank);
+
 /* ---- delay line and ring buffer banks ----------------------------------------------------- */
 /*
  * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  All

@@ -15,5 +15,5 @@ from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
 from .units import (AnalyzerBank, BiquadBank, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, EqualizerBank,  # noqa: F401
                     ILUFSBank, LoudnessBank,
                     RingBank,
-                    SpectralBank,
+                    SpectralBank, SplitterBank, crossover_fft_mask,
                     design_filter, device_count, filter_freq_chart, make_window)

@@ -133,6 +133,28 @@ PROTOTYPES = {
     "mi_ilufs_bank_clear": (c_int, [c_void_p, c_void_p]),
     "mi_ilufs_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float, c_void_p]),
     "mi_ilufs_bank_loudness": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
+    "mi_splitter_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32]),
+    "mi_splitter_bank_destroy": (c_int, [c_void_p]),
+    "mi_splitter_bank_set_rank": (c_int, [c_void_p, c_uint32]),
+    "mi_splitter_bank_set_chunk_rank": (c_int, [c_void_p, ctypes.c_int32]),
+    "mi_splitter_bank_set_phase": (c_int, [c_void_p, c_float]),
+    "mi_splitter_bank_get": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "mi_splitter_bank_bind_copy": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "mi_splitter_bank_bind_mask": (c_int, [c_void_p, c_uint32, POINTER(c_float), c_size_t, c_void_p]),
+    "mi_splitter_bank_bind_callback": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "mi_splitter_bank_unbind": (c_int, [c_void_p, c_uint32]),
+    "mi_splitter_bank_clear": (c_int, [c_void_p, c_void_p]),
+    "mi_splitter_bank_process": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_crossover_hipass": (c_float, [c_float, c_float, c_float]),
+    "mi_crossover_lopass": (c_float, [c_float, c_float, c_float]),
+    "mi_crossover_hipass_set": (None, [POINTER(c_float), POINTER(c_float), c_float, c_float, c_size_t]),
+    "mi_crossover_hipass_apply": (None, [POINTER(c_float), POINTER(c_float), c_float, c_float, c_size_t]),
+    "mi_crossover_lopass_set": (None, [POINTER(c_float), POINTER(c_float), c_float, c_float, c_size_t]),
+    "mi_crossover_lopass_apply": (None, [POINTER(c_float), POINTER(c_float), c_float, c_float, c_size_t]),
+    "mi_crossover_hipass_fft_set": (None, [POINTER(c_float), c_float, c_float, c_float, c_size_t]),
+    "mi_crossover_hipass_fft_apply": (None, [POINTER(c_float), c_float, c_float, c_float, c_size_t]),
+    "mi_crossover_lopass_fft_set": (None, [POINTER(c_float), c_float, c_float, c_float, c_size_t]),
+    "mi_crossover_lopass_fft_apply": (None, [POINTER(c_float), c_float, c_float, c_float, c_size_t]),
     "mi_crossover_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_crossover_bank_destroy": (c_int, [c_void_p]),
     "mi_crossover_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),
@@ -179,3 +201,4 @@ def check(code):
 
 
 SPECTRAL_FUNC = ctypes.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p)
+SPLITTER_FUNC = ctypes.CFUNCTYPE(None, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_void_p)

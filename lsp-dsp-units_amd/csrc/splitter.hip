@@ -1,0 +1,632 @@
+// mi_splitter_bank -- lsp::dspu::SpectralSplitter for many channels (reference: src/main/util/SpectralSplitter.cpp:62-361),
+// the engine under lsp::dspu::FFTCrossover (src/main/util/FFTCrossover.cpp).
+//
+// Per channel: the last N = 2^rank input samples form the analysis buffer; every `frame` = 2^(chunk_rank-1) samples it is
+// transformed ONCE, every handler shapes that spectrum its own way, goes back to the time domain, and the last 2*frame
+// samples -- windowed with sin^2 -- are overlap-added into the handler's output line.  One workgroup owns one channel's
+// hop: the half spectrum of the real transform stays in registers while the handlers take turns in LDS, so the input is
+// read once and transformed once however many bands there are ("multiple masks per frame ->
+// multi-band output in one pass").
+//
+// Handler kinds:
+//   COPY      no spectral function: the first 2*frame samples of the analysis buffer go to the output line
+//             (SpectralSplitter.cpp:330);
+//   MASK      spectrum[k] *= gain[k] with N real gains in FFT order (what FFTCrossover::spectral_func does with its vFFT,
+//             FFTCrossover.cpp:124-140), fused in the hop kernel;
+//   CALLBACK  the full complex spectrum is handed to a host function as a device pointer (it may enqueue anything on the
+//             stream); a complex inverse transform brings its result back.  This is the compatibility path of the
+//             lsp::dspu::SpectralSplitter class mirror.
+#include "mi_common.h"
+#include "fft_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+namespace mi
+{
+    void make_window(float *dst, size_t n, int type);                       // host/windows.cpp
+}
+
+namespace
+{
+    using namespace mi_fft;
+    constexpr int TWN = 8192;           // must match convolver.hip (mi::fft_twiddles)
+
+    enum { H_OFF = 0, H_COPY = 1, H_MASK = 2, H_CALLBACK = 3 };
+
+    struct handler_desc
+    {
+        const float *mask;              // H_MASK: [channels or 1][mask_stride] real gains, N per row
+        uint64_t     mask_stride;       // 0: one row for every channel
+        uint32_t     mode;
+        uint32_t     has_sink;          // overlap-add only where somebody listens (SpectralSplitter.cpp:333)
+    };
+
+    // overlap-add of 2*frame windowed samples y (as pairs) into a handler's line: the line moves on by one frame
+    template <typename GET>
+    __device__ __forceinline__ void overlap_add(float2 *line, const float2 *__restrict__ wnd, uint32_t frame, int tid, int T,
+                                                float scale, GET y)
+    {
+        const uint32_t hp = frame >> 1;                                 // a frame of samples is frame/2 pairs
+        for (uint32_t m = tid; m < hp; m += T)
+        {
+            // a thread owns pair m of both frames of the line: the old second frame is read before it is overwritten
+            const float2 y0 = y(m), y1 = y(m + hp), w0 = wnd[m], w1 = wnd[m + hp];
+            const float2 prev = line[m + hp];
+            line[m]      = make_float2(fmaf(y0.x * scale, w0.x, prev.x), fmaf(y0.y * scale, w0.y, prev.y));
+            line[m + hp] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+        }
+    }
+
+    // One hop of one channel.  in_buf: [channels][in_pitch], the analysis buffer in its first N floats; lines:
+    // [handlers][channels][line_pitch]; spec (only when WRITE_SPEC): [channels][N] complex.
+    template <int LOGH, bool WRITE_SPEC>
+    __global__ __launch_bounds__(plan<LOGH>::T)
+    void splitter_hop_kernel(float *in_buf, size_t in_pitch, float *lines, size_t line_pitch, uint32_t channels,
+                             const handler_desc *__restrict__ hd, uint32_t handlers, const float *__restrict__ wnd,
+                             uint32_t frame, float2 *spec, const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H, PER = (H + T - 1) / T;
+        __shared__ float2 buf[H], scr[H];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        real_fft<LOGH> rf;
+        rf.load(tw, TWN, tid);
+        float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * in_pitch);
+        const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
+
+        float2 xr[PER];
+        #pragma unroll
+        for (int i = 0; i < PER; ++i)
+            xr[i] = (tid + i * T < H) ? x2[tid + i * T] : make_float2(0.0f, 0.0f);
+        rf.prepare();
+        #pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (tid + i * T < H)
+                buf[tid + i * T] = xr[i];
+        __syncthreads();
+
+        // handlers without a spectral function see the head of the analysis buffer as it is
+        for (uint32_t h = 0; h < handlers; ++h)
+        {
+            if (hd[h].mode != H_COPY || !hd[h].has_sink)
+                continue;
+            float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
+            overlap_add(line, w2, frame, tid, T, 1.0f, [&](uint32_t m) { return buf[m]; });
+        }
+        // the analysis buffer moves on by one frame (every read of it above has completed: the values went through LDS)
+        #pragma unroll
+        for (int i = 0; i < PER; ++i)
+        {
+            const int m = tid + i * T;
+            if (m >= int(frame >> 1) && m < H)
+                x2[m - (frame >> 1)] = xr[i];
+        }
+        __syncthreads();
+
+        rf.forward(buf, scr, tid);
+        float2 sp[PER];
+        #pragma unroll
+        for (int i = 0; i < PER; ++i)
+            sp[i] = (tid + i * T < H) ? buf[tid + i * T] : make_float2(0.0f, 0.0f);
+
+        if (WRITE_SPEC)
+        {
+            float2 *so = spec + size_t(ch) * N;
+            #pragma unroll
+            for (int i = 0; i < PER; ++i)
+            {
+                const int k = tid + i * T;
+                if (k >= H)
+                    continue;
+                if (k == 0)
+                {
+                    so[0] = make_float2(sp[i].x, 0.0f);
+                    so[H] = make_float2(sp[i].y, 0.0f);
+                }
+                else
+                {
+                    so[k]     = sp[i];
+                    so[N - k] = cconj(sp[i]);
+                }
+            }
+        }
+
+        const float scale = 1.0f / float(N);
+        for (uint32_t h = 0; h < handlers; ++h)
+        {
+            if (hd[h].mode != H_MASK || !hd[h].has_sink)
+                continue;
+            const float *g = hd[h].mask + size_t(ch) * hd[h].mask_stride;
+            __syncthreads();                                            // the previous handler is done with buf
+            #pragma unroll
+            for (int i = 0; i < PER; ++i)
+            {
+                const int k = tid + i * T;
+                if (k >= H)
+                    continue;
+                float2 v = sp[i];
+                if (k == 0)
+                {
+                    v.x *= g[0];
+                    v.y *= g[H];
+                }
+                else
+                {
+                    // only the real part of the inverse is kept (pcomplex_c2r): a real gain acts through its even part
+                    const float gk = 0.5f * (g[k] + g[N - k]);
+                    v.x *= gk;
+                    v.y *= gk;
+                }
+                buf[k] = v;
+            }
+            __syncthreads();
+            rf.inverse(buf, scr, tid);
+            float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
+            const uint32_t first = uint32_t(H) - frame;                // the last 2*frame samples, in pairs
+            overlap_add(line, w2, frame, tid, T, scale, [&](uint32_t m) { return buf[first + m]; });
+        }
+    }
+
+    // CALLBACK handlers: complex N-point inverse of what the function left in `spec`, real part of the last 2*frame samples
+    template <int LOGN>
+    __global__ __launch_bounds__(plan<LOGN>::T)
+    void splitter_inverse_kernel(float *line0, size_t line_pitch, const float2 *__restrict__ spec,
+                                 const float *__restrict__ wnd, uint32_t frame, const float2 *__restrict__ tw)
+    {
+        using PL = plan<LOGN>;
+        constexpr int N = PL::N, T = PL::T;
+        __shared__ float2 buf[N], scr[N];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        fft_tw<LOGN> ft;
+        load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
+        finish_fft_tw<LOGN>(ft);
+        const float2 *sp = spec + size_t(ch) * N;
+        for (int k = tid; k < N; k += T)
+            buf[k] = sp[k];
+        __syncthreads();
+        fft_lds<LOGN, true>(buf, scr, ft, tid);
+        float *line = line0 + size_t(ch) * line_pitch;
+        const float scale = 1.0f / float(N);
+        const uint32_t first = uint32_t(N) - 2 * frame;
+        for (uint32_t n = tid; n < frame; n += T)
+        {
+            const float y0 = buf[first + n].x * scale, y1 = buf[first + n + frame].x * scale;
+            const float prev = line[n + frame];
+            line[n]         = fmaf(y0, wnd[n], prev);
+            line[n + frame] = y1 * wnd[n + frame];
+        }
+    }
+
+    // the streaming side of process(): new samples into the analysis buffers, finished samples out of the lines
+    // grid (pieces of 256, channels, handlers + 1): z == 0 is the input, z - 1 the handler
+    __global__ __launch_bounds__(256)
+    void splitter_io_kernel(float *in_buf, size_t in_pitch, uint32_t in_pos, const float *__restrict__ src, size_t src_stride,
+                            const float *__restrict__ lines, size_t line_pitch, uint32_t line_pos, float *const *__restrict__ outs,
+                            size_t out_stride, size_t out_pos, uint32_t channels, uint32_t n)
+    {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y, z = blockIdx.z;
+        if (i >= n)
+            return;
+        if (z == 0)
+            in_buf[size_t(ch) * in_pitch + in_pos + i] = (src != nullptr) ? src[size_t(ch) * src_stride + i] : 0.0f;
+        else
+        {
+            float *o = outs[z - 1];
+            if (o != nullptr)
+                o[size_t(ch) * out_stride + out_pos + i] = lines[(size_t(z - 1) * channels + ch) * line_pitch + line_pos + i];
+        }
+    }
+} // namespace
+
+struct mi_splitter_bank
+{
+    struct handler_t
+    {
+        int          mode = H_OFF;
+        float       *d_mask = nullptr;      // owned copy of the gains
+        size_t       mask_stride = 0, mask_cap = 0;
+        mi_splitter_func_t func = nullptr;
+        void        *object = nullptr, *subject = nullptr;
+    };
+    uint32_t    channels = 0, handlers = 0, max_rank = 0, rank = 0, chunk_rank = 0;
+    int32_t     user_chunk_rank = 0;
+    float       phase = 0.0f;
+    bool        update = true, desc_dirty = true;
+    uint32_t    fill = 0;                   // nFrameSize
+    uint32_t    bindings = 0;
+    std::vector<handler_t> h;
+    std::vector<uint8_t> has_sink;
+    float      *d_in = nullptr, *d_lines = nullptr, *d_wnd = nullptr;
+    float2     *d_spec = nullptr, *d_tmp = nullptr;
+    handler_desc *d_desc = nullptr;
+    float     **d_outs = nullptr;
+    std::vector<float *> outs_shadow;
+    const float2 *d_tw = nullptr;
+    size_t      pitch = 0;                  // 2^max_rank
+};
+
+namespace
+{
+    uint32_t effective_chunk_rank(const mi_splitter_bank *b, uint32_t rank)
+    {
+        if (b->user_chunk_rank <= 0)
+            return rank;
+        const int32_t r = b->user_chunk_rank;
+        return uint32_t((r < 5) ? 5 : (r > int32_t(rank)) ? int32_t(rank) : r);          // lsp_limit(user, 5, rank)
+    }
+
+    int splitter_clear(mi_splitter_bank *b, hipStream_t st)                              // SpectralSplitter.cpp:246-258
+    {
+        MI_HIP_CHECK(hipMemsetAsync(b->d_in, 0, size_t(b->channels) * b->pitch * sizeof(float), st));
+        // every line: a handler nobody listens to never adds to its line, and bind() clears it anyway
+        MI_HIP_CHECK(hipMemsetAsync(b->d_lines, 0, size_t(b->handlers) * b->channels * b->pitch * sizeof(float), st));
+        return MI_OK;
+    }
+
+    int splitter_apply_settings(mi_splitter_bank *b, hipStream_t st)                     // update_settings(), :224-244
+    {
+        b->rank = std::min(b->rank, b->max_rank);
+        b->chunk_rank = effective_chunk_rank(b, b->rank);
+        const size_t frame = size_t(1) << (b->chunk_rank - 1);
+        std::vector<float> w(frame * 2);
+        mi::make_window(w.data(), frame * 2, MI_WINDOW_SQR_COSINE);
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_wnd, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        const int r = splitter_clear(b, st);
+        if (r != MI_OK)
+            return r;
+        b->fill = uint32_t(float(frame) * (b->phase * 0.5f));
+        b->update = false;
+        return MI_OK;
+    }
+
+    int splitter_upload_desc(mi_splitter_bank *b, hipStream_t st)
+    {
+        std::vector<handler_desc> d(b->handlers);
+        for (uint32_t i = 0; i < b->handlers; ++i)
+        {
+            d[i].mask = b->h[i].d_mask;
+            d[i].mask_stride = b->h[i].mask_stride;
+            d[i].mode = uint32_t(b->h[i].mode);
+            d[i].has_sink = b->has_sink[i];
+        }
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_desc, d.data(), d.size() * sizeof(handler_desc), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        b->desc_dirty = false;
+        return MI_OK;
+    }
+
+    #define MI_LOGH_SWITCH(lh, CALL)                    \
+        switch (lh)                                     \
+        {                                               \
+            case 4:  { CALL(4);  break; }               \
+            case 5:  { CALL(5);  break; }               \
+            case 6:  { CALL(6);  break; }               \
+            case 7:  { CALL(7);  break; }               \
+            case 8:  { CALL(8);  break; }               \
+            case 9:  { CALL(9);  break; }               \
+            case 10: { CALL(10); break; }               \
+            case 11: { CALL(11); break; }               \
+            default: { CALL(12); break; }               \
+        }
+
+    int splitter_hop(mi_splitter_bank *b, hipStream_t st)
+    {
+        const int lh = int(b->rank) - 1;
+        const uint32_t frame = 1u << (b->chunk_rank - 1);
+        const dim3 grid(b->channels);
+        bool callbacks = false;
+        for (uint32_t i = 0; i < b->handlers; ++i)
+            callbacks = callbacks || (b->h[i].mode == H_CALLBACK);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        if (!callbacks)
+        {
+            #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+                b->d_in, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, (float2 *)nullptr, b->d_tw)
+            MI_LOGH_SWITCH(lh, MI_CALL)
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            return MI_OK;
+        }
+        #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, true>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+            b->d_in, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, b->d_spec, b->d_tw)
+        MI_LOGH_SWITCH(lh, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        for (uint32_t i = 0; i < b->handlers; ++i)
+        {
+            mi_splitter_bank::handler_t &h = b->h[i];
+            if (h.mode != H_CALLBACK)
+                continue;
+            h.func(h.object, h.subject, reinterpret_cast<float *>(b->d_tmp), reinterpret_cast<const float *>(b->d_spec), b->rank,
+                   b->channels, st);
+            if (!b->has_sink[i])
+                continue;
+            float *line0 = b->d_lines + size_t(i) * b->channels * b->pitch;
+            #define MI_CALL(LN) hipLaunchKernelGGL((splitter_inverse_kernel<LN>), grid, dim3(plan<LN>::T), 0, st, \
+                line0, b->pitch, b->d_tmp, b->d_wnd, frame, b->d_tw)
+            switch (b->rank)
+            {
+                case 5:  { MI_CALL(5);  break; }
+                case 6:  { MI_CALL(6);  break; }
+                case 7:  { MI_CALL(7);  break; }
+                case 8:  { MI_CALL(8);  break; }
+                case 9:  { MI_CALL(9);  break; }
+                case 10: { MI_CALL(10); break; }
+                case 11: { MI_CALL(11); break; }
+                case 12: { MI_CALL(12); break; }
+                default: { MI_CALL(13); break; }
+            }
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        return MI_OK;
+    }
+
+    int splitter_bind_common(mi_splitter_bank *b, uint32_t handler, int mode, hipStream_t st)
+    {
+        mi_splitter_bank::handler_t &h = b->h[handler];
+        if (h.mode == H_OFF)
+            ++b->bindings;
+        h.mode = mode;
+        b->desc_dirty = true;
+        // bind() clears the handler's output line (SpectralSplitter.cpp:159-160)
+        MI_HIP_CHECK(hipMemsetAsync(b->d_lines + size_t(handler) * b->channels * b->pitch, 0,
+                                    size_t(b->channels) * b->pitch * sizeof(float), st));
+        return MI_OK;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t handlers)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_splitter_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0 && handlers > 0, MI_EINVAL, "mi_splitter_bank_create: no channels or handlers");
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 13, MI_EINVAL, "mi_splitter_bank_create: max_rank %u outside 5..13", max_rank);
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_splitter_bank *b = new (std::nothrow) mi_splitter_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_splitter_bank_create: out of host memory");
+    b->channels = channels;
+    b->handlers = handlers;
+    b->rank = b->max_rank = max_rank;
+    b->pitch = size_t(1) << max_rank;
+    b->h.resize(handlers);
+    b->has_sink.assign(handlers, 1);
+    b->outs_shadow.assign(handlers, nullptr);
+    int twn = 0;
+    int r = mi::fft_twiddles(&b->d_tw, &twn);
+    hipError_t e = hipSuccess;
+    if (r == MI_OK)
+    {
+        const size_t row = size_t(channels) * b->pitch;
+        e = hipMalloc(reinterpret_cast<void **>(&b->d_in), row * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_lines), row * handlers * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), b->pitch * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_desc), handlers * sizeof(handler_desc));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_outs), handlers * sizeof(float *));
+        if (e == hipSuccess) e = hipMemset(b->d_in, 0, row * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_lines, 0, row * handlers * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_outs, 0, handlers * sizeof(float *));
+    }
+    if (r != MI_OK || e != hipSuccess)
+    {
+        mi_splitter_bank_destroy(b);
+        return (r != MI_OK) ? r : mi::fail(MI_EHIP, "mi_splitter_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_splitter_bank_destroy(mi_splitter_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    for (mi_splitter_bank::handler_t &h : b->h)
+        (void)hipFree(h.d_mask);
+    (void)hipFree(b->d_in); (void)hipFree(b->d_lines); (void)hipFree(b->d_wnd); (void)hipFree(b->d_desc);
+    (void)hipFree(b->d_outs); (void)hipFree(b->d_spec); (void)hipFree(b->d_tmp);
+    delete b;
+    return MI_OK;
+}
+
+int mi_splitter_bank_set_rank(mi_splitter_bank_t *b, uint32_t rank)                  // SpectralSplitter.cpp:266-273
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_set_rank: NULL bank");
+    if (rank == b->rank || rank > b->max_rank)
+        return MI_OK;
+    MI_REQUIRE(rank >= 5, MI_EINVAL, "mi_splitter_bank_set_rank: rank %u below 5", rank);
+    b->rank = rank;
+    b->update = true;
+    return MI_OK;
+}
+
+int mi_splitter_bank_set_chunk_rank(mi_splitter_bank_t *b, int32_t rank)             // :275-282
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_set_chunk_rank: NULL bank");
+    if (rank == b->user_chunk_rank)
+        return MI_OK;
+    b->user_chunk_rank = rank;
+    b->update = true;
+    return MI_OK;
+}
+
+int mi_splitter_bank_set_phase(mi_splitter_bank_t *b, float phase)                   // :260-264
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_set_phase: NULL bank");
+    b->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
+    b->update = true;
+    return MI_OK;
+}
+
+int mi_splitter_bank_get(const mi_splitter_bank_t *b, uint32_t *rank, uint32_t *chunk_rank, uint32_t *latency, uint32_t *remaining)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_get: NULL bank");
+    const uint32_t r = std::min(b->rank, b->max_rank);
+    // latency() with settings pending takes the chunk rank from the new settings but falls back to nRank as it is (:284-293)
+    const uint32_t cr = b->update ? ((b->user_chunk_rank > 0) ? effective_chunk_rank(b, r) : b->rank) : b->chunk_rank;
+    if (rank != nullptr) *rank = b->rank;
+    if (chunk_rank != nullptr) *chunk_rank = cr;
+    if (latency != nullptr) *latency = 1u << cr;
+    if (remaining != nullptr)
+    {
+        const uint32_t frame = 1u << (cr - 1);
+        const uint32_t fill = b->update ? uint32_t(float(frame) * (b->phase * 0.5f)) : b->fill;
+        *remaining = (fill >= frame) ? frame : frame - fill;           // a full frame is transformed first, then refilled
+    }
+    return MI_OK;
+}
+
+int mi_splitter_bank_bind_copy(mi_splitter_bank_t *b, uint32_t handler, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_bind_copy: NULL bank");
+    MI_REQUIRE(handler < b->handlers, MI_EINVAL, "mi_splitter_bank_bind_copy: handler %u out of range", handler);
+    return splitter_bind_common(b, handler, H_COPY, mi::as_stream(stream));
+}
+
+int mi_splitter_bank_bind_mask(mi_splitter_bank_t *b, uint32_t handler, const float *mask, size_t mask_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_bind_mask: NULL bank");
+    MI_REQUIRE(handler < b->handlers, MI_EINVAL, "mi_splitter_bank_bind_mask: handler %u out of range", handler);
+    MI_REQUIRE(mask != nullptr, MI_EINVAL, "mi_splitter_bank_bind_mask: NULL mask");
+    const size_t N = size_t(1) << b->rank;
+    MI_REQUIRE(mask_stride == 0 || mask_stride >= N, MI_EINVAL, "mi_splitter_bank_bind_mask: stride %zu below 2^rank", mask_stride);
+    hipStream_t st = mi::as_stream(stream);
+    mi_splitter_bank::handler_t &h = b->h[handler];
+    const size_t rows = (mask_stride == 0) ? 1 : b->channels;
+    const size_t need = rows * N;
+    if (need > h.mask_cap)
+    {
+        MI_HIP_CHECK(hipStreamSynchronize(st));                         // a hop in flight may still read the old gains
+        (void)hipFree(h.d_mask);
+        h.d_mask = nullptr;
+        h.mask_cap = 0;
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&h.d_mask), need * sizeof(float)));
+        h.mask_cap = need;
+        b->desc_dirty = true;
+    }
+    MI_HIP_CHECK(hipMemcpy2DAsync(h.d_mask, N * sizeof(float), mask, ((mask_stride == 0) ? N : mask_stride) * sizeof(float),
+                                  N * sizeof(float), rows, hipMemcpyHostToDevice, st));
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    const size_t new_stride = (mask_stride == 0) ? 0 : N;
+    if (h.mask_stride != new_stride)
+    {
+        h.mask_stride = new_stride;
+        b->desc_dirty = true;
+    }
+    if (h.mode == H_MASK)
+        return MI_OK;                                                   // new gains for a bound handler: the line lives on
+    return splitter_bind_common(b, handler, H_MASK, st);
+}
+
+int mi_splitter_bank_bind_callback(mi_splitter_bank_t *b, uint32_t handler, mi_splitter_func_t func, void *object, void *subject,
+                                   void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_bind_callback: NULL bank");
+    MI_REQUIRE(handler < b->handlers, MI_EINVAL, "mi_splitter_bank_bind_callback: handler %u out of range", handler);
+    MI_REQUIRE(func != nullptr, MI_EINVAL, "mi_splitter_bank_bind_callback: NULL function");
+    if (b->d_spec == nullptr)
+    {
+        const size_t n = size_t(b->channels) * b->pitch;
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_spec), n * sizeof(float2)));
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_tmp), n * sizeof(float2)));
+    }
+    mi_splitter_bank::handler_t &h = b->h[handler];
+    h.func = func;
+    h.object = object;
+    h.subject = subject;
+    return splitter_bind_common(b, handler, H_CALLBACK, mi::as_stream(stream));
+}
+
+int mi_splitter_bank_unbind(mi_splitter_bank_t *b, uint32_t handler)                 // :165-180
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_unbind: NULL bank");
+    MI_REQUIRE(handler < b->handlers, MI_EINVAL, "mi_splitter_bank_unbind: handler %u out of range", handler);
+    mi_splitter_bank::handler_t &h = b->h[handler];
+    if (h.mode == H_OFF)
+        return mi::fail(MI_ESTATE, "mi_splitter_bank_unbind: handler %u is not bound", handler);
+    h.mode = H_OFF;
+    h.func = nullptr;
+    --b->bindings;
+    b->desc_dirty = true;
+    return MI_OK;
+}
+
+int mi_splitter_bank_clear(mi_splitter_bank_t *b, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_clear: NULL bank");
+    return splitter_clear(b, mi::as_stream(stream));
+}
+
+int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const float *in, size_t count, size_t out_stride,
+                             size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_process: NULL bank");
+    hipStream_t st = mi::as_stream(stream);
+    if (b->update)
+    {
+        const int r = splitter_apply_settings(b, st);
+        if (r != MI_OK)
+            return r;
+    }
+    if (b->bindings == 0 || count == 0)                                // SpectralSplitter.cpp:299-300
+        return MI_OK;
+    // who listens: a handler whose output pointer is NULL has no sink
+    bool outs_changed = false;
+    for (uint32_t i = 0; i < b->handlers; ++i)
+    {
+        float *o = (outs != nullptr) ? outs[i] : nullptr;
+        const uint8_t sink = (o != nullptr && b->h[i].mode != H_OFF) ? 1 : 0;
+        if (sink != b->has_sink[i])
+        {
+            b->has_sink[i] = sink;
+            b->desc_dirty = true;
+        }
+        if (b->h[i].mode == H_OFF)
+            o = nullptr;
+        if (o != b->outs_shadow[i])
+        {
+            b->outs_shadow[i] = o;
+            outs_changed = true;
+        }
+    }
+    if (outs_changed)
+    {
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_outs, b->outs_shadow.data(), b->handlers * sizeof(float *), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (b->desc_dirty)
+    {
+        const int r = splitter_upload_desc(b, st);
+        if (r != MI_OK)
+            return r;
+    }
+    const uint32_t N = 1u << b->rank, frame = 1u << (b->chunk_rank - 1), gap = N - frame;
+    size_t done = 0;
+    while (done < count)
+    {
+        if (b->fill >= frame)                                           // a frame is complete: transform (:311-356)
+        {
+            const int r = splitter_hop(b, st);
+            if (r != MI_OK)
+                return r;
+            b->fill = 0;
+        }
+        const uint32_t n = uint32_t(std::min<size_t>(frame - b->fill, count - done));
+        const dim3 grid((n + 255) / 256, b->channels, b->handlers + 1);
+        hipLaunchKernelGGL(splitter_io_kernel, grid, dim3(256), 0, st, b->d_in, b->pitch, gap + b->fill,
+                           (in != nullptr) ? in + done : (const float *)nullptr, in_stride, b->d_lines, b->pitch, b->fill,
+                           b->d_outs, out_stride, done, b->channels, n);
+        MI_HIP_CHECK(hipGetLastError());
+        b->fill += n;
+        done += n;
+    }
+    return MI_OK;
+}
+
+} // extern "C"

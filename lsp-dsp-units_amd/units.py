@@ -523,6 +523,103 @@ class ILUFSBank:
             pass
 
 
+class SplitterBank:
+    """lsp::dspu::SpectralSplitter for `channels` channels sharing the settings (mi_splitter_bank_*)."""
+
+    def __init__(self, channels, max_rank, handlers):
+        h = c_void_p()
+        check(lib.mi_splitter_bank_create(byref(h), channels, max_rank, handlers))
+        self.handle, self.channels, self.handlers = h, channels, handlers
+        self._cbs = {}
+
+    def set_rank(self, rank):
+        check(lib.mi_splitter_bank_set_rank(self.handle, rank))
+
+    def set_chunk_rank(self, rank):
+        check(lib.mi_splitter_bank_set_chunk_rank(self.handle, rank))
+
+    def set_phase(self, phase):
+        check(lib.mi_splitter_bank_set_phase(self.handle, float(phase)))
+
+    def _get(self):
+        v = [c_uint32() for _ in range(4)]
+        check(lib.mi_splitter_bank_get(self.handle, *[byref(x) for x in v]))
+        return [x.value for x in v]
+
+    def rank(self):
+        return self._get()[0]
+
+    def chunk_rank(self):
+        return self._get()[1]
+
+    def latency(self):
+        return self._get()[2]
+
+    def remaining(self):
+        return self._get()[3]
+
+    def bind_copy(self, handler, stream=None):
+        check(lib.mi_splitter_bank_bind_copy(self.handle, handler, _stream(stream)))
+
+    def bind_mask(self, handler, mask, stream=None):
+        """mask: 2^rank gains (shared) or [channels][2^rank], host array."""
+        from ctypes import POINTER as _P
+        m = np.ascontiguousarray(mask, dtype=np.float32)
+        stride = 0 if m.ndim == 1 else m.shape[1]
+        check(lib.mi_splitter_bank_bind_mask(self.handle, handler, m.ctypes.data_as(_P(c_float)), stride, _stream(stream)))
+
+    def bind_callback(self, handler, pyfunc, stream=None):
+        """pyfunc(out_ptr, in_ptr, rank, channels, stream): device addresses of [channels][2 * 2^rank] floats."""
+        from ctypes import cast
+        from .capi import SPLITTER_FUNC
+        cb = SPLITTER_FUNC(lambda obj, subj, out, inp, rank, ch, st: pyfunc(out, inp, rank, ch, st))
+        self._cbs[handler] = cb
+        check(lib.mi_splitter_bank_bind_callback(self.handle, handler, cast(cb, c_void_p), None, None, _stream(stream)))
+
+    def unbind(self, handler):
+        check(lib.mi_splitter_bank_unbind(self.handle, handler))
+        self._cbs.pop(handler, None)
+
+    def clear(self, stream=None):
+        check(lib.mi_splitter_bank_clear(self.handle, _stream(stream)))
+
+    def process(self, outs, inp, count, out_stride=None, in_stride=None, stream=None):
+        """outs: list of `handlers` device buffers or None (handler without a sink); inp None = silence."""
+        arr = (c_void_p * self.handlers)(*[(_ptr(b) if b is not None else None) for b in outs])
+        check(lib.mi_splitter_bank_process(self.handle, arr, _ptr(inp) if inp is not None else None, count,
+                                           count if out_stride is None else out_stride,
+                                           count if in_stride is None else in_stride, _stream(stream)))
+
+    def close(self):
+        if self.handle:
+            lib.mi_splitter_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def crossover_fft_mask(hpf, lpf, flatten, gain, sample_rate, rank):
+    """FFTCrossover::update_band (FFTCrossover.cpp:459-486): hpf / lpf = (freq, slope) or None."""
+    from ctypes import POINTER as _P
+    n = 1 << rank
+    m = np.empty(n, np.float32)
+    p = m.ctypes.data_as(_P(c_float))
+    if hpf is not None:
+        lib.mi_crossover_hipass_fft_set(p, hpf[0], hpf[1], float(sample_rate), rank)
+        if lpf is not None:
+            lib.mi_crossover_lopass_fft_apply(p, lpf[0], lpf[1], float(sample_rate), rank)
+    elif lpf is not None:
+        lib.mi_crossover_lopass_fft_set(p, lpf[0], lpf[1], float(sample_rate), rank)
+    else:
+        m[:] = np.float32(flatten) * np.float32(gain)
+        return m
+    return (np.clip(m, np.float32(0.0), np.float32(flatten)) * np.float32(gain)).astype(np.float32)
+
+
 class CrossoverBank:
     """lsp::dspu::Crossover for `channels` channels sharing the split settings (mi_crossover_bank_*)."""
     MODE_BT, MODE_MT = 0, 1

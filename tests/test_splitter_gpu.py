@@ -1,0 +1,202 @@
+"""GPU parity of mi_splitter_bank_* (lsp::dspu::SpectralSplitter / the engine of FFTCrossover) against the CPU oracle,
+through the C-ABI."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import splitter as osp
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _oracle_run(rank, chunk, phase, handlers, x, calls):
+    """handlers: list of None (unbound) | "copy" | mask array.  Returns [handler][channels][n]."""
+    C, n = x.shape
+    outs = np.zeros((len(handlers), C, n), np.float32)
+    for c in range(C):
+        sp = osp.SpectralSplitter(rank, len(handlers))
+        sp.set_chunk_rank(chunk); sp.set_phase(phase)
+        pos = [0] * len(handlers)
+        for i, h in enumerate(handlers):
+            if h is None:
+                continue
+
+            def sink(s, first, count, i=i, c=c):
+                outs[i, c, pos[i]:pos[i] + count] = s; pos[i] += count
+            if isinstance(h, str):
+                sp.bind(i, None, sink)
+            else:
+                m = np.asarray(h, np.float32)
+                m = m if m.ndim == 1 else m[c]
+
+                def func(spec, r, m=m):
+                    spec[0::2] *= m; spec[1::2] *= m
+                    return spec
+                sp.bind(i, func, sink)
+        p = 0
+        for k in calls:
+            sp.process(x[c, p:p + k], k); p += k
+    return outs
+
+
+def _gpu_run(gpu, rank, chunk, phase, handlers, x, calls, max_rank=None):
+    C, n = x.shape
+    bank = gpu.SplitterBank(C, max_rank or rank, len(handlers))
+    bank.set_rank(rank); bank.set_chunk_rank(chunk); bank.set_phase(phase)
+    for i, h in enumerate(handlers):
+        if h is None:
+            continue
+        if isinstance(h, str):
+            bank.bind_copy(i)
+        else:
+            bank.bind_mask(i, h)
+    got = np.zeros((len(handlers), C, n), np.float32)
+    p = 0
+    for k in calls:
+        bufs = [gpu.DeviceBuffer.from_host(np.full((C, k), -7.0, np.float32)) if h is not None else None for h in handlers]
+        bank.process(bufs, gpu.DeviceBuffer.from_host(x[:, p:p + k]), k)
+        for i, b in enumerate(bufs):
+            if b is not None:
+                got[i, :, p:p + k] = b.download()
+        p += k
+    lat = bank.latency()
+    bank.close()
+    return got, lat
+
+
+@pytest.mark.parametrize("rank,chunk,phase,calls", [
+    (5, 0, 0.0, (300,)), (8, 0, 0.0, (1000, 24)), (9, 7, 0.0, (100, 3, 700, 197)), (10, 8, 0.5, (333, 1667)),
+    (12, 10, 0.0, (8192, 5000)), (13, 0, 0.25, (20000,)), (12, 5, 1.0, (6000,)),
+])
+def test_masks_and_copy_handlers_match_oracle(gpu, rank, chunk, phase, calls):
+    """Several bands in one pass: a shared symmetric mask, per-channel masks, an ASYMMETRIC real mask (only the real part
+    of the inverse is kept, so its even part acts), a handler without a spectral function, and an unbound slot."""
+    C, n = 3, sum(calls)
+    N = 1 << rank
+    rng = np.random.default_rng(rank * 100 + chunk)
+    x = (rng.standard_normal((C, n)) * 0.5).astype(np.float32)
+    sym = osp.hipass_fft_set(2000.0, -24.0, 48000.0, rank)
+    per = np.stack([osp.lopass_fft_set(500.0 * (c + 1), -32.0, 48000.0, rank) for c in range(C)])
+    asym = rng.uniform(0.0, 1.5, N).astype(np.float32)
+    handlers = [sym, None, per, "copy", asym]
+    want = _oracle_run(rank, chunk, phase, handlers, x, calls)
+    got, lat = _gpu_run(gpu, rank, chunk, phase, handlers, x, calls)
+    assert lat == 1 << (min(max(chunk, 5), rank) if chunk > 0 else rank)
+    peak = float(np.abs(x).max())
+    for i, h in enumerate(handlers):
+        if h is None:
+            continue
+        err = float(np.abs(got[i] - want[i]).max())
+        assert err <= TOL * max(peak, float(np.abs(want[i]).max())), (i, err)
+        assert float(np.abs(want[i]).max()) > 0.01
+
+
+def test_rank_below_max_rank_rebind_unbind_clear_and_silence(gpu):
+    C, rank, n = 2, 9, 2048
+    rng = np.random.default_rng(77)
+    x = rng.standard_normal((C, 3 * n)).astype(np.float32)
+    m1 = osp.lopass_fft_set(1000.0, -24.0, 48000.0, rank)
+    m2 = osp.hipass_fft_set(1000.0, -24.0, 48000.0, rank)
+    bank = gpu.SplitterBank(C, 11, 2)
+    bank.set_rank(rank)
+    refs = []
+    for c in range(C):
+        sp = osp.SpectralSplitter(11, 2); sp.set_rank(rank); refs.append(sp)
+    col = {(c, i): [] for c in range(C) for i in range(2)}
+
+    def mk(m):
+        def func(spec, r):
+            spec[0::2] *= m; spec[1::2] *= m
+            return spec
+        return func
+
+    def bind_ref(i, m):
+        for c, sp in enumerate(refs):
+            sp.bind(i, mk(m), lambda s, first, count, c=c, i=i: col[(c, i)].append(s.copy()))
+
+    def step(x_blk, k, listen):
+        bufs = [gpu.DeviceBuffer.from_host(np.zeros((C, k), np.float32)) if listen[i] else None for i in range(2)]
+        bank.process(bufs, gpu.DeviceBuffer.from_host(x_blk) if x_blk is not None else None, k)
+        for c, sp in enumerate(refs):
+            sp.process(x_blk[c] if x_blk is not None else None, k)
+        return [b.download() if b is not None else None for b in bufs]
+
+    bank.bind_mask(0, m1); bind_ref(0, m1)
+    g = step(x[:, :n], n, (True, False))
+    want = np.stack([np.concatenate(col[(c, 0)]) for c in range(C)])
+    assert np.abs(g[0] - want).max() <= TOL * 4.0
+    # second handler joins mid-stream (its line starts from zero), first one gets new gains without losing its line
+    bank.bind_mask(1, m2); bind_ref(1, m2)
+    bank.bind_mask(0, m2)
+    for sp in refs:
+        sp.h[0]["func"] = mk(m2)                             # FFTCrossover::update_band: same binding, new vFFT
+    for k in col:
+        col[k].clear()
+    g = step(x[:, n:2 * n], n, (True, True))
+    for i in range(2):
+        want = np.stack([np.concatenate(col[(c, i)]) for c in range(C)])
+        assert np.abs(g[i] - want).max() <= TOL * 4.0, i
+    # unbind one, feed silence (src == NULL): the other drains its tail
+    bank.unbind(0)
+    for sp in refs:
+        sp.unbind(0)
+    with pytest.raises(gpu.MiError):
+        bank.unbind(0)
+    for k in col:
+        col[k].clear()
+    g = step(None, 1024, (True, True))
+    assert np.all(g[0] == 0.0)                               # an unbound handler's buffer is not written
+    want = np.stack([np.concatenate(col[(c, 1)]) for c in range(C)])
+    assert np.abs(g[1] - want).max() <= TOL * 4.0 and np.abs(want).max() > 0.1
+    bank.clear()
+    for sp in refs:
+        sp.clear()
+    for k in col:
+        col[k].clear()
+    g = step(None, 600, (False, True))
+    assert np.all(g[1] == 0.0)
+    bank.close()
+
+
+def test_callback_handler_gets_the_full_spectrum(gpu):
+    """CALLBACK path: the function sees [channels][2^rank] complex bins on the device and leaves its result in `out`;
+    here it is a device-to-device copy, so the handler must reproduce the input delayed by the latency."""
+    C, rank, chunk, n = 2, 10, 9, 6000
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    bank = gpu.SplitterBank(C, rank, 2)
+    bank.set_chunk_rank(chunk)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    seen = []
+
+    def func(out, inp, r, ch, st):
+        seen.append((r, ch))
+        assert hip.hipMemcpyAsync(out, inp, ch * (2 << r) * 4, 3, st) == 0
+    bank.bind_callback(0, func)
+    bank.bind_mask(1, np.ones(1 << rank, np.float32))
+    o0 = gpu.DeviceBuffer((C, n)); o1 = gpu.DeviceBuffer((C, n))
+    bank.process([o0, o1], gpu.DeviceBuffer.from_host(x), n)
+    y0, y1 = o0.download(), o1.download()
+    lat = bank.latency()
+    assert seen and seen[0] == (rank, C) and len(seen) == (n - 1) // (lat // 2)
+    assert np.abs(y0[:, 2 * lat:] - x[:, lat:n - lat]).max() < 2e-5 * np.abs(x).max()
+    assert np.abs(y0 - y1).max() < 2e-5 * np.abs(x).max()     # same result through the fused mask path
+    bank.close()
+
+
+def test_argument_errors(gpu):
+    with pytest.raises(gpu.MiError):
+        gpu.SplitterBank(1, 4, 1)
+    with pytest.raises(gpu.MiError):
+        gpu.SplitterBank(1, 14, 1)
+    bank = gpu.SplitterBank(1, 8, 2)
+    with pytest.raises(gpu.MiError):
+        bank.bind_copy(2)
+    bank.set_rank(9)                                          # above max_rank: ignored
+    assert bank.rank() == 8 and bank.latency() == 256 and bank.remaining() == 128
+    bank.set_chunk_rank(3)
+    assert bank.chunk_rank() == 5 and bank.latency() == 32
+    bank.close()
