@@ -12,6 +12,9 @@
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
+#include <lsp-plug.in/dsp-units/misc/fft_crossover.h>
+#include <lsp-plug.in/dsp-units/util/FFTCrossover.h>
+#include <lsp-plug.in/dsp-units/util/SpectralSplitter.h>
 #include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
@@ -1159,6 +1162,667 @@ void Crossover::dump(IStateDumper *v) const
 {
     v->write("nSplits", num_splits());
     v->write("nBufSize", max_buffer_size());
+}
+
+// ---- crossover::* / SpectralSplitter / FFTCrossover ------------------------------------------------------------
+namespace crossover
+{
+    float hipass(float f, float f0, float slope) { return mi_crossover_hipass(f, f0, slope); }
+    float lopass(float f, float f0, float slope) { return mi_crossover_lopass(f, f0, slope); }
+    void hipass_set(float *gain, const float *f, float f0, float slope, size_t count)   { mi_crossover_hipass_set(gain, f, f0, slope, count); }
+    void hipass_apply(float *gain, const float *f, float f0, float slope, size_t count) { mi_crossover_hipass_apply(gain, f, f0, slope, count); }
+    void lopass_set(float *gain, const float *f, float f0, float slope, size_t count)   { mi_crossover_lopass_set(gain, f, f0, slope, count); }
+    void lopass_apply(float *gain, const float *f, float f0, float slope, size_t count) { mi_crossover_lopass_apply(gain, f, f0, slope, count); }
+    void hipass_fft_set(float *mag, float f0, float slope, float sample_rate, size_t rank)   { mi_crossover_hipass_fft_set(mag, f0, slope, sample_rate, rank); }
+    void hipass_fft_apply(float *mag, float f0, float slope, float sample_rate, size_t rank) { mi_crossover_hipass_fft_apply(mag, f0, slope, sample_rate, rank); }
+    void lopass_fft_set(float *mag, float f0, float slope, float sample_rate, size_t rank)   { mi_crossover_lopass_fft_set(mag, f0, slope, sample_rate, rank); }
+    void lopass_fft_apply(float *mag, float f0, float slope, float sample_rate, size_t rank) { mi_crossover_lopass_fft_apply(mag, f0, slope, sample_rate, rank); }
+}
+
+namespace
+{
+    // one channel of a splitter bank driven with host buffers: the pieces between two transforms go up, every listening
+    // handler's samples come down, and `emit` hands them on (handlers in index order, as SpectralSplitter.cpp:344-352)
+    struct splitter_stream
+    {
+        mi_splitter_bank_t *bank = nullptr;
+        size_t  handlers = 0, cap = 0;
+        float  *d_in = nullptr;
+        std::vector<float *> d_out;
+        std::vector<float>   host;
+
+        bool init(size_t max_rank, size_t n_handlers)
+        {
+            if (mi_splitter_bank_create(&bank, 1, uint32_t(max_rank), uint32_t(n_handlers)) != MI_OK)
+                return false;
+            handlers = n_handlers;
+            cap = size_t(1) << (max_rank - 1);
+            d_out.assign(n_handlers, nullptr);
+            host.resize(cap);
+            bool ok = mi_dspu_malloc(reinterpret_cast<void **>(&d_in), cap * sizeof(float)) == MI_OK;
+            for (size_t i = 0; ok && i < n_handlers; ++i)
+                ok = mi_dspu_malloc(reinterpret_cast<void **>(&d_out[i]), cap * sizeof(float)) == MI_OK;
+            return ok;
+        }
+        void release()
+        {
+            mi_splitter_bank_destroy(bank);
+            bank = nullptr;
+            mi_dspu_free(d_in);
+            d_in = nullptr;
+            for (float *p : d_out)
+                mi_dspu_free(p);
+            d_out.clear();
+        }
+        template <class LISTENS, class EMIT>
+        void process(const float *src, size_t count, LISTENS listens, EMIT emit)
+        {
+            std::vector<float *> outs(handlers);
+            for (size_t offset = 0; offset < count; )
+            {
+                uint32_t remaining = 0;
+                if (mi_splitter_bank_get(bank, nullptr, nullptr, nullptr, &remaining) != MI_OK || remaining == 0)
+                    return;
+                const size_t n = std::min<size_t>(remaining, count - offset);
+                for (size_t i = 0; i < handlers; ++i)
+                    outs[i] = listens(i) ? d_out[i] : nullptr;
+                if (src != nullptr && mi_dspu_copy_h2d(d_in, src + offset, n * sizeof(float), nullptr) != MI_OK)
+                    return;
+                if (mi_splitter_bank_process(bank, outs.data(), (src != nullptr) ? d_in : nullptr, n, n, n, nullptr) != MI_OK)
+                    return;
+                for (size_t i = 0; i < handlers; ++i)
+                {
+                    if (outs[i] == nullptr)
+                        continue;
+                    if (mi_dspu_copy_d2h(host.data(), outs[i], n * sizeof(float), nullptr) != MI_OK ||
+                        mi_dspu_stream_synchronize(nullptr) != MI_OK)
+                        return;
+                    emit(i, host.data(), offset, n);
+                }
+                offset += n;
+            }
+        }
+    };
+}
+
+struct SpectralSplitter::impl_t
+{
+    splitter_stream st;
+    size_t  max_rank = 0, bindings = 0;
+    ssize_t user_chunk_rank = 0;
+    float   phase = 0.0f;
+    bool    update = true;
+    struct handler_t
+    {
+        void *object = nullptr, *subject = nullptr;
+        spectral_splitter_func_t func = nullptr;
+        spectral_splitter_sink_t sink = nullptr;
+        std::vector<float> *spec_in = nullptr, *spec_out = nullptr;
+    };
+    std::vector<handler_t> h;
+    std::vector<float> spec_in, spec_out;
+
+    // mi_splitter_func_t: the device spectrum comes down, the user's function runs on host memory, its result goes up
+    static void trampoline(void *object, void *, float *out, const float *in, size_t rank, size_t channels, void *stream)
+    {
+        handler_t *h = static_cast<handler_t *>(object);
+        const size_t bytes = channels * (size_t(2) << rank) * sizeof(float);
+        if (mi_dspu_copy_d2h(h->spec_in->data(), in, bytes, stream) != MI_OK || mi_dspu_stream_synchronize(stream) != MI_OK)
+            return;
+        h->func(h->object, h->subject, h->spec_out->data(), h->spec_in->data(), rank);
+        if (mi_dspu_copy_h2d(out, h->spec_out->data(), bytes, stream) == MI_OK)
+            mi_dspu_stream_synchronize(stream);
+    }
+};
+
+SpectralSplitter::SpectralSplitter() : pImpl(nullptr) { construct(); }
+SpectralSplitter::~SpectralSplitter() { destroy(); }
+void SpectralSplitter::construct() { pImpl = nullptr; }
+
+void SpectralSplitter::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+status_t SpectralSplitter::init(size_t max_rank, size_t handlers)
+{
+    if (max_rank < 5)                                       // SpectralSplitter.cpp:64-65
+        return STATUS_INVALID_VALUE;
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return STATUS_NO_MEM;
+    if (handlers == 0 || !p->st.init(max_rank, handlers))
+    {
+        p->st.release();
+        delete p;
+        return STATUS_NO_MEM;
+    }
+    p->max_rank = max_rank;
+    p->h.resize(handlers);
+    p->spec_in.resize(size_t(2) << max_rank);
+    p->spec_out.resize(size_t(2) << max_rank);
+    for (impl_t::handler_t &h : p->h)
+    {
+        h.spec_in = &p->spec_in;
+        h.spec_out = &p->spec_out;
+    }
+    pImpl = p;
+    return STATUS_OK;
+}
+
+status_t SpectralSplitter::bind(size_t id, void *object, void *subject, spectral_splitter_func_t func, spectral_splitter_sink_t sink)
+{
+    if (pImpl == nullptr || id >= pImpl->h.size())
+        return STATUS_OVERFLOW;
+    if (func == nullptr && sink == nullptr)
+        return STATUS_INVALID_VALUE;
+    impl_t::handler_t &h = pImpl->h[id];
+    if (h.func == nullptr && h.sink == nullptr)
+        ++pImpl->bindings;
+    h.object = object;
+    h.subject = subject;
+    h.func = func;
+    h.sink = sink;
+    const int r = (func != nullptr) ?
+        mi_splitter_bank_bind_callback(pImpl->st.bank, uint32_t(id), impl_t::trampoline, &h, nullptr, nullptr) :
+        mi_splitter_bank_bind_copy(pImpl->st.bank, uint32_t(id), nullptr);
+    return (r == MI_OK) ? STATUS_OK : STATUS_NO_MEM;
+}
+
+status_t SpectralSplitter::unbind(size_t id)
+{
+    if (pImpl == nullptr || id >= pImpl->h.size())
+        return STATUS_OVERFLOW;
+    impl_t::handler_t &h = pImpl->h[id];
+    if (h.func == nullptr && h.sink == nullptr)
+        return STATUS_NOT_BOUND;
+    h = impl_t::handler_t();
+    h.spec_in = &pImpl->spec_in;
+    h.spec_out = &pImpl->spec_out;
+    --pImpl->bindings;
+    mi_splitter_bank_unbind(pImpl->st.bank, uint32_t(id));
+    return STATUS_OK;
+}
+
+void SpectralSplitter::unbind_all()
+{
+    if (pImpl == nullptr)
+        return;
+    for (size_t i = 0; i < pImpl->h.size(); ++i)
+        unbind(i);
+}
+
+bool SpectralSplitter::bound(size_t id) const
+{
+    return pImpl != nullptr && id < pImpl->h.size() && (pImpl->h[id].func != nullptr || pImpl->h[id].sink != nullptr);
+}
+
+size_t SpectralSplitter::handlers() const { return pImpl ? pImpl->h.size() : 0; }
+size_t SpectralSplitter::bindings() const { return pImpl ? pImpl->bindings : 0; }
+bool SpectralSplitter::needs_update() const { return pImpl ? pImpl->update : false; }
+
+void SpectralSplitter::update_settings()
+{
+    if (pImpl == nullptr || !pImpl->update)
+        return;
+    mi_splitter_bank_process(pImpl->st.bank, nullptr, nullptr, 0, 0, 0, nullptr);      // applies the pending settings
+    pImpl->update = false;
+}
+
+size_t SpectralSplitter::rank() const
+{
+    uint32_t v = 0;
+    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, &v, nullptr, nullptr, nullptr);
+    return v;
+}
+
+size_t SpectralSplitter::max_rank() const { return pImpl ? pImpl->max_rank : 0; }
+
+ssize_t SpectralSplitter::chunk_rank() const
+{
+    uint32_t v = 0;
+    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, nullptr, &v, nullptr, nullptr);
+    return ssize_t(v);
+}
+
+float SpectralSplitter::phase() const { return pImpl ? pImpl->phase : 0.0f; }
+
+void SpectralSplitter::set_phase(float phase)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
+    pImpl->update = true;
+    mi_splitter_bank_set_phase(pImpl->st.bank, phase);
+}
+
+void SpectralSplitter::set_rank(size_t rank)
+{
+    if (pImpl == nullptr || rank == this->rank() || rank > pImpl->max_rank)
+        return;
+    if (mi_splitter_bank_set_rank(pImpl->st.bank, uint32_t(rank)) == MI_OK)
+        pImpl->update = true;
+}
+
+void SpectralSplitter::set_chunk_rank(ssize_t rank)
+{
+    if (pImpl == nullptr || rank == pImpl->user_chunk_rank)
+        return;
+    pImpl->user_chunk_rank = rank;
+    pImpl->update = true;
+    mi_splitter_bank_set_chunk_rank(pImpl->st.bank, int32_t(rank));
+}
+
+size_t SpectralSplitter::latency() const
+{
+    uint32_t v = 0;
+    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, nullptr, nullptr, &v, nullptr);
+    return v;
+}
+
+void SpectralSplitter::process(const float *src, size_t count)
+{
+    impl_t *p = pImpl;
+    if (p == nullptr)
+        return;
+    update_settings();
+    if (p->bindings == 0)
+        return;
+    p->st.process(src, count,
+        [p](size_t i) { return p->h[i].sink != nullptr; },
+        [p](size_t i, const float *data, size_t first, size_t n) { p->h[i].sink(p->h[i].object, p->h[i].subject, data, first, n); });
+}
+
+void SpectralSplitter::clear()
+{
+    if (pImpl)
+        mi_splitter_bank_clear(pImpl->st.bank, nullptr);
+}
+
+void SpectralSplitter::dump(IStateDumper *v) const
+{
+    v->write("nRank", rank());
+    v->write("nMaxRank", max_rank());
+    v->write("nChunkRank", size_t(chunk_rank()));
+    v->write("fPhase", phase());
+}
+
+struct FFTCrossover::impl_t
+{
+    splitter_stream st;
+    size_t  max_rank = 0, sample_rate = 0;
+    float   phase = 0.0f;
+    struct band_t
+    {
+        float   hpf_freq = 100.0f, lpf_freq = 1000.0f, hpf_slope = -24.0f, lpf_slope = -24.0f, gain = 1.0f, flatten = 1.0f;
+        bool    lpf = false, hpf = false, enabled = false, update = true, bound = false;
+        crossover_func_t func = nullptr;
+        void   *object = nullptr, *subject = nullptr;
+    };
+    std::vector<band_t> b;
+    std::vector<float>  mask;
+
+    size_t rank() const
+    {
+        uint32_t v = 0;
+        mi_splitter_bank_get(st.bank, &v, nullptr, nullptr, nullptr);
+        return v;
+    }
+
+    // FFTCrossover::update_band (FFTCrossover.cpp:459-486); the gains go to the band's handler when it is bound
+    void update_band(size_t i)
+    {
+        band_t &x = b[i];
+        if (!x.update)
+            return;
+        const size_t rk = rank(), bins = size_t(1) << rk;
+        mask.resize(bins);
+        if (x.hpf || x.lpf)
+        {
+            if (x.hpf)
+            {
+                mi_crossover_hipass_fft_set(mask.data(), x.hpf_freq, x.hpf_slope, float(sample_rate), rk);
+                if (x.lpf)
+                    mi_crossover_lopass_fft_apply(mask.data(), x.lpf_freq, x.lpf_slope, float(sample_rate), rk);
+            }
+            else
+                mi_crossover_lopass_fft_set(mask.data(), x.lpf_freq, x.lpf_slope, float(sample_rate), rk);
+            for (float &g : mask)                            // limit1(0, fFlatten), mul_k2(fGain)
+                g = ((g < 0.0f) ? 0.0f : (g > x.flatten) ? x.flatten : g) * x.gain;
+        }
+        else
+            std::fill(mask.begin(), mask.end(), x.flatten * x.gain);
+        if (x.bound)
+            mi_splitter_bank_bind_mask(st.bank, uint32_t(i), mask.data(), 0, nullptr);
+        x.update = false;
+    }
+
+    void sync_binding(size_t i)                              // :355-364
+    {
+        band_t &x = b[i];
+        if (x.enabled && x.func != nullptr)
+        {
+            if (!x.bound)
+            {
+                x.bound = true;
+                x.update = true;                             // the handler needs its gains: same values the reference's
+                update_band(i);                              // spectral_func would find or rebuild at the next transform
+            }
+        }
+        else if (x.bound)
+        {
+            mi_splitter_bank_unbind(st.bank, uint32_t(i));
+            x.bound = false;
+        }
+    }
+};
+
+FFTCrossover::FFTCrossover() : pImpl(nullptr) { construct(); }
+FFTCrossover::~FFTCrossover() { destroy(); }
+void FFTCrossover::construct() { pImpl = nullptr; }
+
+void FFTCrossover::destroy()
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->st.release();
+    delete pImpl;
+    pImpl = nullptr;
+}
+
+status_t FFTCrossover::init(size_t max_rank, size_t bands)
+{
+    if (max_rank < 5)
+        return STATUS_INVALID_VALUE;
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    if (p == nullptr)
+        return STATUS_NO_MEM;
+    if (bands == 0 || !p->st.init(max_rank, bands))
+    {
+        p->st.release();
+        delete p;
+        return STATUS_NO_MEM;
+    }
+    p->max_rank = max_rank;
+    p->b.resize(bands);
+    pImpl = p;
+    return STATUS_OK;
+}
+
+size_t FFTCrossover::bands() const { return pImpl ? pImpl->b.size() : 0; }
+
+#define MI_BAND_OR(ret)                                         \
+    if (pImpl == nullptr || band >= pImpl->b.size())            \
+        return ret;                                             \
+    impl_t::band_t &x = pImpl->b[band];
+
+// the update-flag rules are the reference's, including the asymmetric ones (FFTCrossover.cpp:155-345)
+void FFTCrossover::set_slope(size_t band, float lpf, float hpf)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = (x.lpf && x.lpf_slope != lpf) || (x.hpf && x.hpf_slope != hpf);
+    x.lpf_slope = lpf;
+    x.hpf_slope = hpf;
+}
+
+void FFTCrossover::set_lpf_slope(size_t band, float slope)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = x.lpf && x.lpf_slope != slope;
+    x.lpf_slope = slope;
+}
+
+void FFTCrossover::set_hpf_slope(size_t band, float slope)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = x.hpf && x.hpf_slope != slope;
+    x.hpf_slope = slope;
+}
+
+void FFTCrossover::set_frequency(size_t band, float lpf, float hpf)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = (x.lpf && x.lpf_freq != lpf) || (x.hpf && x.hpf_freq != hpf);
+    x.lpf_freq = lpf;
+    x.hpf_freq = hpf;
+}
+
+void FFTCrossover::set_lpf_frequency(size_t band, float freq)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = x.lpf && x.lpf_freq != freq;
+    x.lpf_freq = freq;
+}
+
+void FFTCrossover::set_hpf_frequency(size_t band, float freq)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = x.hpf && x.hpf_freq != freq;
+    x.hpf_freq = freq;
+}
+
+void FFTCrossover::enable_filters(size_t band, bool lpf, bool hpf)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = (x.lpf != lpf) || (x.hpf != hpf);
+    x.lpf = lpf;
+    x.hpf = hpf;
+}
+
+void FFTCrossover::enable_lpf(size_t band, bool enable)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = x.lpf != enable;
+    x.lpf = enable;
+}
+
+void FFTCrossover::enable_hpf(size_t band, bool enable)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = x.hpf != enable;
+    x.hpf = enable;
+}
+
+void FFTCrossover::set_lpf(size_t band, float freq, float slope, bool enabled)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = enabled && (x.lpf_freq != freq || x.lpf_slope != slope || x.lpf != enabled);
+    x.lpf_freq = freq;
+    x.lpf_slope = slope;
+    x.lpf = enabled;
+}
+
+void FFTCrossover::set_hpf(size_t band, float freq, float slope, bool enabled)
+{
+    MI_BAND_OR()
+    if (!x.update)
+        x.update = enabled && (x.hpf_freq != freq || x.hpf_slope != slope || x.hpf != enabled);
+    x.hpf_freq = freq;
+    x.hpf_slope = slope;
+    x.hpf = enabled;
+}
+
+void FFTCrossover::set_gain(size_t band, float gain)
+{
+    MI_BAND_OR()
+    if (x.gain == gain)
+        return;
+    x.update = true;
+    x.gain = gain;
+}
+
+void FFTCrossover::set_flatten(size_t band, float amount)
+{
+    MI_BAND_OR()
+    if (x.flatten == amount)
+        return;
+    x.update = true;
+    x.flatten = amount;
+}
+
+#undef MI_BAND_OR
+#define MI_BAND_GET(field, fallback) ((pImpl != nullptr && band < pImpl->b.size()) ? pImpl->b[band].field : (fallback))
+float FFTCrossover::lpf_slope(size_t band) const     { return MI_BAND_GET(lpf_slope, -1.0f); }
+float FFTCrossover::hpf_slope(size_t band) const     { return MI_BAND_GET(hpf_slope, -1.0f); }
+float FFTCrossover::lpf_frequency(size_t band) const { return MI_BAND_GET(lpf_freq, -1.0f); }
+float FFTCrossover::hpf_frequency(size_t band) const { return MI_BAND_GET(hpf_freq, -1.0f); }
+bool  FFTCrossover::lpf_enabled(size_t band) const   { return MI_BAND_GET(lpf, false); }
+bool  FFTCrossover::hpf_enabled(size_t band) const   { return MI_BAND_GET(hpf, false); }
+float FFTCrossover::gain(size_t band) const          { return MI_BAND_GET(gain, -1.0f); }
+float FFTCrossover::flatten(size_t band) const       { return MI_BAND_GET(flatten, -1.0f); }
+bool  FFTCrossover::band_enabled(size_t band) const  { return MI_BAND_GET(enabled, false); }
+#undef MI_BAND_GET
+
+void FFTCrossover::enable_band(size_t band, bool enable)
+{
+    if (pImpl == nullptr || band >= pImpl->b.size() || pImpl->b[band].enabled == enable)
+        return;
+    pImpl->b[band].enabled = enable;
+    pImpl->sync_binding(band);
+}
+
+bool FFTCrossover::set_handler(size_t band, crossover_func_t func, void *object, void *subject)
+{
+    if (pImpl == nullptr || band >= pImpl->b.size())
+        return false;
+    impl_t::band_t &x = pImpl->b[band];
+    x.func = func;
+    x.object = object;
+    x.subject = subject;
+    pImpl->sync_binding(band);
+    return true;
+}
+
+bool FFTCrossover::unset_handler(size_t band) { return set_handler(band, nullptr, nullptr, nullptr); }
+
+void FFTCrossover::set_sample_rate(size_t sr)
+{
+    if (pImpl == nullptr || pImpl->sample_rate == sr)
+        return;
+    pImpl->sample_rate = sr;
+    for (impl_t::band_t &x : pImpl->b)
+        x.update = true;
+}
+
+size_t FFTCrossover::sample_rate() const { return pImpl ? pImpl->sample_rate : 0; }
+
+void FFTCrossover::set_rank(size_t rank)
+{
+    if (pImpl == nullptr)
+        return;
+    rank = std::min(rank, pImpl->max_rank);
+    if (pImpl->rank() == rank || mi_splitter_bank_set_rank(pImpl->st.bank, uint32_t(rank)) != MI_OK)
+        return;
+    for (impl_t::band_t &x : pImpl->b)
+        x.update = true;
+}
+
+void FFTCrossover::set_phase(float phase)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
+    mi_splitter_bank_set_phase(pImpl->st.bank, phase);
+}
+
+float  FFTCrossover::phase() const { return pImpl ? pImpl->phase : 0.0f; }
+size_t FFTCrossover::rank() const  { return pImpl ? pImpl->rank() : 0; }
+
+size_t FFTCrossover::latency() const
+{
+    uint32_t v = 0;
+    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, nullptr, nullptr, &v, nullptr);
+    return v;
+}
+
+bool FFTCrossover::needs_update() const
+{
+    if (pImpl == nullptr)
+        return false;
+    for (const impl_t::band_t &x : pImpl->b)
+        if (x.enabled && x.update)
+            return true;
+    return false;
+}
+
+void FFTCrossover::update_settings()
+{
+    if (pImpl == nullptr)
+        return;
+    mi_splitter_bank_process(pImpl->st.bank, nullptr, nullptr, 0, 0, 0, nullptr);
+    for (size_t i = 0; i < pImpl->b.size(); ++i)
+        if (pImpl->b[i].enabled)
+            pImpl->update_band(i);
+}
+
+void FFTCrossover::process(const float *in, size_t samples)
+{
+    impl_t *p = pImpl;
+    if (p == nullptr)
+        return;
+    // the reference refreshes a band's gains inside its spectral function, i.e. before the next transform uses them
+    for (size_t i = 0; i < p->b.size(); ++i)
+        if (p->b[i].bound)
+            p->update_band(i);
+    p->st.process(in, samples,
+        [p](size_t i) { return p->b[i].bound; },
+        [p](size_t i, const float *data, size_t first, size_t n)
+        {
+            if (p->b[i].func != nullptr)
+                p->b[i].func(p->b[i].object, p->b[i].subject, i, data, first, n);
+        });
+}
+
+void FFTCrossover::clear()
+{
+    if (pImpl)
+        mi_splitter_bank_clear(pImpl->st.bank, nullptr);
+}
+
+bool FFTCrossover::freq_chart(size_t band, float *m, const float *f, size_t count)      // :497-521
+{
+    if (pImpl == nullptr || band >= pImpl->b.size())
+        return false;
+    const impl_t::band_t &x = pImpl->b[band];
+    if (x.hpf || x.lpf)
+    {
+        if (x.hpf)
+        {
+            mi_crossover_hipass_set(m, f, x.hpf_freq, x.hpf_slope, count);
+            if (x.lpf)
+                mi_crossover_lopass_apply(m, f, x.lpf_freq, x.lpf_slope, count);
+        }
+        else
+            mi_crossover_lopass_set(m, f, x.lpf_freq, x.lpf_slope, count);
+        for (size_t i = 0; i < count; ++i)
+            m[i] = ((m[i] < 0.0f) ? 0.0f : (m[i] > x.flatten) ? x.flatten : m[i]) * x.gain;
+    }
+    else
+        std::fill(m, m + count, x.flatten * x.gain);
+    return true;
+}
+
+void FFTCrossover::dump(IStateDumper *v) const
+{
+    v->write("nBands", bands());
+    v->write("nSampleRate", sample_rate());
+    v->write("nRank", rank());
 }
 
 // ---- bs::channel_weighting / LoudnessMeter ---------------------------------------------------------------------

@@ -12,7 +12,9 @@ namespace lsp
 {
     // status codes used by the few hot-path APIs that return one
     typedef int status_t;
-    enum { STATUS_OK = 0, STATUS_NO_MEM = 5, STATUS_BAD_STATE = 12, STATUS_OVERFLOW = 18, STATUS_INVALID_VALUE = 27 };
+    // (lsp-common-lib's status.h is not part of the reference tree: callers compare these symbolically)
+    enum { STATUS_OK = 0, STATUS_NO_MEM = 5, STATUS_BAD_STATE = 12, STATUS_OVERFLOW = 18, STATUS_INVALID_VALUE = 27,
+           STATUS_NOT_BOUND = 50 };
 
     namespace dsp
     {

@@ -14,10 +14,14 @@
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
 #include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
+#include <lsp-plug.in/dsp-units/misc/fft_crossover.h>
+#include <lsp-plug.in/dsp-units/util/FFTCrossover.h>
+#include <lsp-plug.in/dsp-units/util/SpectralSplitter.h>
 #include <lsp-plug.in/dsp-units/util/RingBuffer.h>
 #include <lsp-plug.in/dsp-units/util/Delay.h>
 #include <lsp-plug.in/dsp-units/units.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -290,6 +294,138 @@ static void ilufs_meter_mtest_flow()
     lm.destroy();
 }
 
+// SpectralSplitter, the flow of the reference's manual test (src/test/mtest/util/spectral_splitter.cpp:86-150: four
+// brick-wall bands on rank 12 with chunk rank 10, process(src) then process(NULL, 4096)) on seeded noise, with the
+// property the manual test lets one hear: the bands add up to the input delayed by latency().
+struct split_band_t { size_t imin, imax, offset; std::vector<float> s; };
+
+static void split_func(void *, void *subject, float *out, const float *in, size_t rank)
+{
+    split_band_t *band = static_cast<split_band_t *>(subject);
+    const size_t len = size_t(1) << rank, freq = len >> 1;
+    for (size_t i = 0; i < len; ++i)
+    {
+        const size_t idx = (i < freq) ? i : len - i;
+        const bool keep = (idx >= band->imin) && (idx < band->imax);
+        out[2 * i]     = keep ? in[2 * i] : 0.0f;
+        out[2 * i + 1] = keep ? in[2 * i + 1] : 0.0f;
+    }
+}
+
+static void split_sink(void *, void *subject, const float *samples, size_t, size_t count)
+{
+    split_band_t *band = static_cast<split_band_t *>(subject);
+    memcpy(&band->s[band->offset], samples, count * sizeof(float));
+    band->offset += count;
+}
+
+static void spectral_splitter_mtest_flow()
+{
+    printf("spectral_splitter (mtest flow: brick-wall bands add up to the delayed input)\n");
+    const size_t rank = 12, xlength = size_t(1) << rank, N = 20000, SR = 48000;
+    std::vector<float> src(N);
+    uint32_t seed = 12345;
+    for (size_t i = 0; i < N; ++i) { seed = seed * 1664525u + 1013904223u; src[i] = float(int32_t(seed)) * (0.5f / 2147483648.0f); }
+    const float flist[] = { 0.0f, 100.0f, 1000.0f, 10000.0f, SR * 0.5f + 100.0f };
+    split_band_t bands[4];
+    for (size_t i = 0; i < 4; ++i)
+    {
+        bands[i].imin = size_t((flist[i] * xlength) / SR);
+        bands[i].imax = size_t((flist[i + 1] * xlength) / SR);
+        bands[i].offset = 0;
+        bands[i].s.assign(N + xlength, 0.0f);
+    }
+    dspu::SpectralSplitter split;
+    CHECK(split.init(4, 6) == STATUS_INVALID_VALUE, "init with rank 4");
+    CHECK(split.init(rank, 6) == STATUS_OK, "init");
+    split.set_rank(rank);
+    split.set_chunk_rank(rank - 2);
+    split.set_phase(0);
+    CHECK(split.latency() == 1024 && split.needs_update(), "latency %zu", split.latency());
+    CHECK(split.bind(6, NULL, NULL, split_func, split_sink) == STATUS_OVERFLOW, "bind out of range");
+    CHECK(split.bind(0, NULL, NULL, NULL, NULL) == STATUS_INVALID_VALUE, "bind nothing");
+    CHECK(split.unbind(0) == STATUS_NOT_BOUND, "unbind unbound");
+    for (size_t i = 0; i < 4; ++i)
+        CHECK(split.bind(i, NULL, &bands[i], split_func, split_sink) == STATUS_OK, "bind");
+    CHECK(split.bindings() == 4 && split.bound(3) && !split.bound(4), "bindings");
+    split.process(src.data(), N);
+    split.process(NULL, xlength);
+    CHECK(bands[0].offset == N + xlength, "sink sample count %zu", bands[0].offset);
+    const size_t lat = split.latency();
+    float err = 0.0f, peak[4] = { 0, 0, 0, 0 };
+    for (size_t i = 2 * lat; i < N; ++i)
+    {
+        float sum = 0.0f;
+        for (size_t b = 0; b < 4; ++b) { sum += bands[b].s[i]; peak[b] = std::max(peak[b], fabsf(bands[b].s[i])); }
+        err = std::max(err, fabsf(sum - src[i - lat]));
+    }
+    printf("  latency %zu, max |sum of bands - delayed input| = %g\n", lat, err);
+    CHECK(err < 5e-5f, "bands do not add up: %g", err);
+    CHECK(peak[0] > 1e-3f && peak[1] > 1e-2f && peak[2] > 1e-2f && peak[3] > 1e-2f, "a band is silent");
+    split.destroy();
+}
+
+// FFTCrossover, the band plan of the reference's manual test (src/test/mtest/util/fft_crossover.cpp:74-110).  Every band
+// is flattened to -3 dB there; with flatten = 1 (and the same frequencies and slopes) neighbouring bands are exact
+// complements at their crossover point, so the five outputs add up to the delayed input within the steep-slope leakage.
+struct xover_band_t { size_t offset; std::vector<float> s; };
+
+static void xover_func(void *, void *subject, size_t, const float *data, size_t, size_t count)
+{
+    xover_band_t *b = static_cast<xover_band_t *>(subject);
+    memcpy(&b->s[b->offset], data, count * sizeof(float));
+    b->offset += count;
+}
+
+static void fft_crossover_mtest_flow()
+{
+    printf("fft_crossover (mtest flow: five bands add up to the delayed input)\n");
+    const size_t rank = 12, xlength = size_t(1) << rank, N = 20000, SR = 48000;
+    std::vector<float> src(N);
+    uint32_t seed = 777;
+    for (size_t i = 0; i < N; ++i) { seed = seed * 1664525u + 1013904223u; src[i] = float(int32_t(seed)) * (0.5f / 2147483648.0f); }
+    xover_band_t bands[5];
+    for (size_t i = 0; i < 5; ++i) { bands[i].offset = 0; bands[i].s.assign(N + xlength, 0.0f); }
+    dspu::FFTCrossover xo;
+    CHECK(xo.init(rank, 5) == STATUS_OK, "init");
+    xo.set_sample_rate(SR);
+    const float split[] = { 90.0f, 425.0f, 1750.0f, 7300.0f };
+    for (size_t i = 0; i < 5; ++i)
+    {
+        if (i > 0) xo.set_hpf(i, split[i - 1], -32.0f, true);
+        if (i < 4) xo.set_lpf(i, split[i], -32.0f, true);
+        xo.enable_band(i, true);
+        CHECK(xo.set_handler(i, xover_func, NULL, &bands[i]), "set_handler");
+    }
+    CHECK(!xo.set_handler(5, xover_func, NULL, NULL), "set_handler out of range");
+    CHECK(xo.latency() == xlength && xo.bands() == 5 && xo.hpf_enabled(1) && !xo.hpf_enabled(0), "settings");
+    xo.process(src.data(), N);
+    xo.process(NULL, xlength);
+    CHECK(bands[4].offset == N + xlength, "handler sample count %zu", bands[4].offset);
+    const size_t lat = xo.latency();
+    float err = 0.0f;
+    for (size_t i = 2 * lat; i < N; ++i)
+    {
+        float sum = 0.0f;
+        for (size_t b = 0; b < 5; ++b) sum += bands[b].s[i];
+        err = std::max(err, fabsf(sum - src[i - lat]));
+    }
+    printf("  max |sum of bands - delayed input| = %g\n", err);
+    CHECK(err < 5e-4f, "bands do not add up: %g", err);
+    float f[3] = { 425.0f, 1000.0f, 40.0f }, m[3];
+    CHECK(xo.freq_chart(2, m, f, 3) && m[0] == 0.5f * dspu::crossover::lopass(425.0f, 1750.0f, -32.0f) && m[1] > 0.9f && m[2] < 1e-3f,
+          "freq_chart %g %g %g", m[0], m[1], m[2]);
+    // a disabled band stops receiving data; the reference's flag rule: set_lpf(.., false) alone requests no update
+    xo.enable_band(0, false);
+    xo.set_lpf(1, 425.0f, -32.0f, false);
+    CHECK(!xo.needs_update() && !xo.lpf_enabled(1), "update flag rule");
+    const size_t before0 = bands[0].offset, before1 = bands[1].offset;
+    for (size_t i = 0; i < 5; ++i) bands[i].s.resize(bands[i].s.size() + 512);
+    xo.process(src.data(), 512);
+    CHECK(bands[0].offset == before0 && bands[1].offset == before1 + 512, "disabled band");
+    xo.destroy();
+}
+
 static void ringbuffer()
 {
     printf("ringbuffer\n");
@@ -349,7 +485,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter ringbuffer readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer readme_filter");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -368,6 +504,8 @@ int main(int argc, char **argv)
     crossover_bands_sum_to_allpass();
     loudness_meter_bs1770();
     ilufs_meter_mtest_flow();
+    spectral_splitter_mtest_flow();
+    fft_crossover_mtest_flow();
     ringbuffer();
     readme_filter();
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
