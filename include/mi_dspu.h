@@ -114,6 +114,10 @@ int mi_biquad_bank_set_all_chains(mi_biquad_bank_t *bank, const mi_biquad_x1_t *
                                   uint32_t count, int clear);
 /* FilterBank::size() of one channel. */
 int mi_biquad_bank_size(const mi_biquad_bank_t *bank, uint32_t channel, uint32_t *count);
+/* A channel that is switched off is skipped by process(): its delay memory stays as it is and its output row is not
+ * written -- what a caller gets by not calling FilterBank::process() for that object (the meters do this for disabled
+ * channels, LoudnessMeter.cpp:420-422, ILUFSMeter.cpp:370). */
+int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *bank, uint32_t channel, int enabled);
 /* Push pending coefficient tables / state clears to the device (async on stream). */
 int mi_biquad_bank_commit(mi_biquad_bank_t *bank, void *stream);
 /* FilterBank::reset(), FilterBank.cpp:238-254; channel = UINT32_MAX for all. */

@@ -61,6 +61,7 @@ PROTOTYPES = {
     "mi_biquad_bank_set_chains": (c_int, [c_void_p, c_uint32, POINTER(BiquadX1), c_uint32, c_int]),
     "mi_biquad_bank_set_all_chains": (c_int, [c_void_p, POINTER(BiquadX1), c_uint32, c_int]),
     "mi_biquad_bank_size": (c_int, [c_void_p, c_uint32, POINTER(c_uint32)]),
+    "mi_biquad_bank_set_row_enabled": (c_int, [c_void_p, c_uint32, c_int]),
     "mi_biquad_bank_commit": (c_int, [c_void_p, c_void_p]),
     "mi_biquad_bank_reset": (c_int, [c_void_p, c_uint32, c_void_p]),
     "mi_biquad_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),

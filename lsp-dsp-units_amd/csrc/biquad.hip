@@ -135,6 +135,8 @@ namespace
         const int wv   = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int l16  = t & 15;
         const int ns   = int(nsec[ch]);
+        if (ns < 0)                                         // row switched off: state kept, output not written
+            return;
         float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile
         const bool lane0 = (t == 0), row3 = (t >= 48);
         const float *ctab = tab + size_t(ch) * max_sec * TAB;             // this channel's table rows (uniform address)
@@ -409,10 +411,12 @@ namespace
         const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
         if (ch >= channels)
             return;
+        const int ns = int(nsec[ch]);
+        if (ns < 0)
+            return;
         float xs[16];
         for (int k = 0; k < 16; ++k)
             xs[k] = (k < count) ? in[size_t(ch) * in_stride + start + k] : 0.0f;
-        const int ns = int(nsec[ch]);
         for (int s = 0; s < ns; ++s)
         {
             const float *q = tab + (size_t(ch) * max_sec + s) * tab_row;
@@ -506,6 +510,8 @@ struct mi_biquad_bank
     std::vector<float>      coef;           // [channels][max_sec][5]
     std::vector<uint8_t>    dirty;          // tables of the channel need a rebuild
     std::vector<uint8_t>    clear;          // delay memory of the channel must be cleared
+    std::vector<uint8_t>    row_off;        // channel switched off: process() leaves its state and its output alone
+    bool                    nsec_dirty  = false;
     bool                    pending     = false;
     std::vector<float>      h_big, h_small; // host images of the device tables
     float                  *d_big       = nullptr;
@@ -574,8 +580,18 @@ namespace
                                                 hipMemcpyHostToDevice, st));
                 }
             }
-            MI_HIP_CHECK(hipMemcpyAsync(b->d_nsec, b->nsec.data(), b->channels * sizeof(uint32_t),
-                                        hipMemcpyHostToDevice, st));
+            b->nsec_dirty = true;
+        }
+        if (b->nsec_dirty)
+        {
+            // section count per channel; the sign bit marks a channel that is switched off
+            std::vector<uint32_t> v(b->nsec);
+            for (uint32_t c = 0; c < b->channels; ++c)
+                if (b->row_off[c])
+                    v[c] |= 0x80000000u;
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_nsec, v.data(), b->channels * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+            b->nsec_dirty = false;
         }
         // delay memory clears (FilterBank.cpp:233-235)
         uint32_t c = 0;
@@ -615,6 +631,7 @@ int mi_biquad_bank_create(mi_biquad_bank_t **bank, uint32_t channels, uint32_t m
     try
     {
         b->nsec.assign(channels, 0);
+        b->row_off.assign(channels, 0);
         b->last_nsec.assign(channels, -1);
         b->coef.assign(cs * 5, 0.0f);
         b->dirty.assign(channels, 0);
@@ -704,6 +721,19 @@ int mi_biquad_bank_size(const mi_biquad_bank_t *b, uint32_t channel, uint32_t *c
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_size: NULL bank");
     MI_REQUIRE(channel < b->channels && count != nullptr, MI_EINVAL, "mi_biquad_bank_size: bad argument");
     *count = b->nsec[channel];
+    return MI_OK;
+}
+
+int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *b, uint32_t channel, int enabled)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_set_row_enabled: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_biquad_bank_set_row_enabled: channel %u out of range", channel);
+    const uint8_t off = enabled ? 0 : 1;
+    if (b->row_off[channel] == off)
+        return MI_OK;
+    b->row_off[channel] = off;
+    b->nsec_dirty = true;
+    b->pending = true;
     return MI_OK;
 }
 

@@ -373,6 +373,12 @@ int mi_loudness_bank_set_active(mi_loudness_bank_t *b, uint32_t channel, int act
         return MI_OK;
     b->cfg[channel].enabled = active ? 1 : 0;
     b->cfg_dirty = true;
+    for (uint32_t m = 0; m < b->meters; ++m)                // a disabled channel's filter is not run: its memory freezes (:420-422)
+    {
+        const int r = mi_biquad_bank_set_row_enabled(b->filters, m * b->channels + channel, active);
+        if (r != MI_OK)
+            return r;
+    }
     if (active && b->d_data != nullptr)                     // re-enabled: the channel starts from silence (:249-253)
     {
         hipStream_t st = mi::as_stream(stream);
@@ -839,6 +845,12 @@ int mi_ilufs_bank_set_active(mi_ilufs_bank_t *b, uint32_t channel, int active)
     MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_ilufs_bank_set_active: channel %u out of range", channel);
     b->cfg[channel].enabled = active ? 1 : 0;
     b->cfg_dirty = true;
+    for (uint32_t m = 0; m < b->meters; ++m)                // the filter of a disabled channel is not run (ILUFSMeter.cpp:370)
+    {
+        const int r = mi_biquad_bank_set_row_enabled(b->filters, m * b->channels + channel, active);
+        if (r != MI_OK)
+            return r;
+    }
     return MI_OK;
 }
 

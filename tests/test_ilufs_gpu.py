@@ -120,3 +120,25 @@ def test_argument_errors(gpu):
     with pytest.raises(gpu.MiError):
         bank.set_designation(3, 1)
     bank.close()
+
+
+def test_disabled_channel_filter_freezes_until_reenabled(gpu):
+    sr, K, n = 48000, 2, 19200
+    rng = np.random.default_rng(24)
+    x = (rng.standard_normal((K, 3 * n)) * 0.2).astype(np.float32)
+    x[1] += 0.7
+    bank = gpu.ILUFSBank(1, K, 4.0)
+    ref = oi.ILUFSMeter(K, 4.0)
+    for obj in (bank, ref):
+        obj.set_sample_rate(sr)
+    got, want = [], []
+    for blk, active in ((0, True), (1, False), (2, True)):
+        for obj in (bank, ref):
+            obj.set_active(1, active)
+        g, w = _run(gpu, bank, [ref], x[:, blk * n:(blk + 1) * n], (n,), K)
+        got.append(g); want.append(w)
+    got = np.concatenate(got, 1); want = np.concatenate(want, 1)
+    # DC into the K weighting's 38 Hz high-pass: float32 round-off of the recursion itself, see test_loudness_gpu.py
+    assert np.abs(got - want).max() <= 3e-5 * float(want.max())
+    np.testing.assert_allclose(bank.loudness(), [float(ref.loud)], rtol=3e-5)
+    bank.close()

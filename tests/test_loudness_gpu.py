@@ -87,3 +87,42 @@ def test_weightings_clear_and_reenable(gpu):
         r2, _ = ref.process(x[:, 6000:])
         assert np.abs(out.download()[0] - r2).max() <= tol * float(np.abs(r2).max()), w
         bank.close()
+
+
+def test_disabled_channel_filter_freezes_until_reenabled(gpu):
+    """A disabled channel's weighting filter is not run (LoudnessMeter.cpp:420-422): when the channel comes back, its
+    filter continues from the memory it had when it was switched off, not from what the skipped samples would have left."""
+    sr, K, n = 48000, 2, 4000
+    rng = np.random.default_rng(14)
+    x = (rng.standard_normal((K, 3 * n)) * 0.3).astype(np.float32)
+    x[1] += 0.5                                              # DC through the K-weighting high-pass: long filter memory
+    x[1, n:2 * n] -= 1.0                                     # ... and the opposite offset while the channel is off
+    bank = gpu.LoudnessBank(1, K)
+    ref = ol.LoudnessMeter(K)
+    for obj in (bank, ref):
+        obj.set_sample_rate(sr); obj.set_period(20.0); obj.set_link(1, 0.0)
+    got, want, wch = [], [], []
+    gch = []
+    for blk, active in ((0, True), (1, False), (2, True)):
+        for obj in (bank, ref):
+            obj.set_active(1, active)
+        out = gpu.DeviceBuffer((1, n)); ch = gpu.DeviceBuffer.from_host(np.zeros((K, n), np.float32))
+        bank.process(out, ch, gpu.DeviceBuffer.from_host(x[:, blk * n:(blk + 1) * n]), n)
+        got.append(out.download()[0]); gch.append(ch.download()[1])
+        o, c = ref.process(x[:, blk * n:(blk + 1) * n])
+        want.append(o); wch.append(c[1])
+    got, want, gch, wch = map(np.concatenate, (got, want, gch, wch))
+    peak = float(want.max())
+    # DC into the 38 Hz high-pass of the K weighting: as with the A and C curves above, the float32 recursion's own
+    # round-off (DESIGN.md section 4) leaves a little more than 1e-5 between two correct evaluations
+    tol = 3e-5
+    assert np.abs(got - want).max() <= tol * peak
+    assert np.abs(gch - wch).max() <= tol * peak
+    # the property itself: a filter that had kept running would start block 2 from a settled high-pass instead
+    naive = ol.LoudnessMeter(K)
+    naive.set_sample_rate(sr); naive.set_period(20.0); naive.set_link(1, 0.0)
+    naive.process(x[:, :2 * n])
+    naive.set_active(1, False); naive.set_active(1, True)
+    _, c = naive.process(x[:, 2 * n:])
+    assert np.abs(c[1][:200] - wch[2 * n:2 * n + 200]).max() > 0.05 * peak
+    bank.close()
