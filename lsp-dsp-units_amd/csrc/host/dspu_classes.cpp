@@ -340,7 +340,12 @@ struct Equalizer::impl_t
     size_t  filters = 0, fir_rank = 0, sample_rate = 0;
     bool    smooth = false, changed = true;
     equalizer_mode_t mode = EQM_BYPASS;
+    size_t  actual_sample_rate = 0;
+    std::vector<uint8_t> stale;             // filter updated since the last reconfigure(): Filter::update() leaves it in
+                                            // FM_BYPASS until rebuild() (Filter.cpp:150), so it reads as inactive
     staging st;
+
+    void rebuilt() { std::fill(stale.begin(), stale.end(), uint8_t(0)); changed = false; }
 };
 
 Equalizer::Equalizer() : pImpl(nullptr) { construct(); }
@@ -365,6 +370,7 @@ bool Equalizer::init(size_t filters, size_t fir_rank)
     }
     p->filters = filters;
     p->fir_rank = fir_rank;
+    p->stale.assign(filters, 0);
     pImpl = p;
     return true;
 }
@@ -386,6 +392,7 @@ bool Equalizer::set_params(size_t id, const filter_params_t *params)
     if (pImpl == nullptr || id >= pImpl->filters)
         return false;
     pImpl->changed = true;
+    pImpl->stale[id] = 1;
     return mi_equalizer_bank_set_params(pImpl->bank, 0, uint32_t(id), params) == MI_OK;
 }
 
@@ -412,14 +419,47 @@ void Equalizer::set_mode(equalizer_mode_t mode)
     mi_equalizer_bank_set_mode(pImpl->bank, int(mode));
 }
 
-void Equalizer::set_actual_sample_rate(size_t sr) { if (pImpl) mi_equalizer_bank_set_actual_sample_rate(pImpl->bank, uint32_t(sr)); }
-
-void Equalizer::set_sample_rate(size_t sr)
+void Equalizer::set_actual_sample_rate(size_t sr)
 {
     if (pImpl == nullptr)
         return;
+    pImpl->actual_sample_rate = sr;
+    mi_equalizer_bank_set_actual_sample_rate(pImpl->bank, uint32_t(sr));
+}
+
+size_t Equalizer::actual_sample_rate() const
+{
+    return (pImpl == nullptr) ? 0 : (pImpl->actual_sample_rate != 0) ? pImpl->actual_sample_rate : pImpl->sample_rate;
+}
+
+size_t Equalizer::fir_ir_size() const { return pImpl ? (size_t(1) << pImpl->fir_rank) << 1 : 0; }      // nFirSize << 1
+
+bool Equalizer::filter_inactive(size_t id) const
+{
+    if (pImpl == nullptr || id >= pImpl->filters)
+        return false;                                       // both forms answer false for a bad id (Equalizer.h:143-150)
+    if (pImpl->stale[id])
+        return true;
+    filter_params_t fp;
+    if (mi_equalizer_bank_get_params(pImpl->bank, 0, uint32_t(id), &fp) != MI_OK)
+        return true;
+    mi::design d;
+    mi::design_filter(&d, &fp, uint32_t(pImpl->sample_rate));
+    return d.mode == mi::FM_BYPASS;
+}
+
+bool Equalizer::filter_active(size_t id) const
+{
+    return pImpl != nullptr && id < pImpl->filters && !filter_inactive(id);
+}
+
+void Equalizer::set_sample_rate(size_t sr)
+{
+    if (pImpl == nullptr || pImpl->sample_rate == sr)       // Equalizer.cpp:190-191
+        return;
     pImpl->sample_rate = sr;
     pImpl->changed = true;
+    std::fill(pImpl->stale.begin(), pImpl->stale.end(), uint8_t(1));       // every filter is update()d (:196-200)
     mi_equalizer_bank_set_sample_rate(pImpl->bank, uint32_t(sr));
 }
 
@@ -432,7 +472,7 @@ size_t Equalizer::get_latency()
     if (pImpl != nullptr)
     {
         mi_equalizer_bank_get_latency(pImpl->bank, &lat, nullptr);
-        pImpl->changed = false;
+        pImpl->rebuilt();
     }
     return lat;
 }
@@ -490,7 +530,7 @@ void Equalizer::process(float *out, const float *in, size_t samples)
             std::memmove(out, in, samples * sizeof(float));
         return;
     }
-    pImpl->changed = false;
+    pImpl->rebuilt();
 }
 
 void Equalizer::reset()                     { if (pImpl) mi_equalizer_bank_reset(pImpl->bank, nullptr); }
@@ -2422,6 +2462,48 @@ float RingBuffer::get(size_t offset) const
     return v;
 }
 
+float RingBuffer::lerp_get(float offset) const            // RingBuffer.cpp:131-138
+{
+    const ssize_t off = ssize_t(offset);
+    const float s1 = get(size_t(off)), s2 = get(size_t(off + 1));
+    return s1 + (s2 - s1) * (offset - float(off));          // lerp(s1, s2, k) of units.h
+}
+
+// Raw positions: the sample `offset` behind the newest sits at tail_position(offset), so position p is the sample
+// (head - 1 - p) mod size behind the newest.
+float RingBuffer::read(size_t position) const
+{
+    const size_t cap = size();
+    if (position >= cap)
+        return 0.0f;
+    return get((head_position() + cap - 1 - position) % cap);
+}
+
+size_t RingBuffer::read(float *dst, size_t position, size_t count) const
+{
+    const size_t cap = size();
+    if (position >= cap)
+        return 0;
+    // the whole storage, oldest sample first == raw order rotated by head
+    std::vector<float> chrono(cap), raw(cap);
+    if (get(chrono.data(), cap - 1, cap) == 0 && cap > 0)
+        return 0;
+    const size_t head = head_position();
+    for (size_t j = 0; j < cap; ++j)
+        raw[(head + j) % cap] = chrono[j];
+    // the reference's loop as it is, including its never-advancing dst (RingBuffer.cpp:185-205)
+    size_t to_copy = std::min(cap - position, count);
+    std::memcpy(dst, &raw[position], to_copy * sizeof(float));
+    position += to_copy;
+    while (position < count)
+    {
+        to_copy = std::min(cap, count);
+        std::memcpy(dst, raw.data(), to_copy * sizeof(float));
+        position += to_copy;
+    }
+    return count;
+}
+
 size_t RingBuffer::head_position() const
 {
     uint32_t h = 0;
@@ -2444,7 +2526,12 @@ void RingBuffer::dump(IStateDumper *v) const { v->write("nCapacity", size()); }
 struct Analyzer::impl_t
 {
     mi_analyzer_bank_t *bank = nullptr;
-    size_t  channels = 0, rank = 0, sample_rate = 0;
+    size_t  channels = 0, rank = 0, max_rank = 0, sample_rate = 0, max_sample_rate = 0, max_delay = 0;
+    size_t  window = windows::HANN, envelope = 2 /* envelope::PINK_NOISE */;
+    float   shift = 1.0f, rate = 1.0f, min_rate = 1.0f, reactivity = 0.0f;
+    bool    active = true, dirty = true;
+    struct chan_t { bool active = true; size_t delay = 0; };
+    std::vector<chan_t> ch;
     float  *d_in = nullptr;
     size_t  in_cap = 0;
     float  *d_out = nullptr;
@@ -2478,31 +2565,171 @@ bool Analyzer::init(size_t channels, size_t max_rank, size_t max_sr, float min_r
         return false;
     }
     p->channels = channels;
-    p->rank = max_rank;
+    p->rank = p->max_rank = max_rank;
+    p->max_sample_rate = max_sr;
+    p->max_delay = max_delay;
+    p->min_rate = float(uint32_t(min_rate));                // fMinRate = uint32_t(min_rate), Analyzer.cpp:120
+    p->ch.resize(channels);
     pImpl = p;
     return true;
 }
 
-void Analyzer::set_sample_rate(size_t sr)   { if (pImpl) { pImpl->sample_rate = sr; mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SAMPLE_RATE, double(sr)); } }
-void Analyzer::set_rate(float rate)         { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RATE, rate); }
-void Analyzer::set_window(size_t window)    { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_WINDOW, double(window)); }
-void Analyzer::set_envelope(size_t env)     { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ENVELOPE, double(env)); }
-void Analyzer::set_shift(float shift)       { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SHIFT, shift); }
-void Analyzer::set_reactivity(float r)      { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_REACTIVITY, r); }
-void Analyzer::set_activity(bool active)    { if (pImpl) mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ACTIVE, active ? 1.0 : 0.0); }
-size_t Analyzer::get_rank() const           { return pImpl ? pImpl->rank : 0; }
+// The setters keep the values the getters report and the "something changed" flag of needs_reconfiguration(), with the
+// reference's own no-change tests (Analyzer.cpp:154-250); the bank applies them at the next process() / reconfigure().
+void Analyzer::set_sample_rate(size_t sr)
+{
+    if (pImpl == nullptr)
+        return;
+    sr = std::min(sr, pImpl->max_sample_rate);
+    if (pImpl->sample_rate == sr)
+        return;
+    pImpl->sample_rate = sr;
+    pImpl->dirty = true;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SAMPLE_RATE, double(sr));
+}
+
+void Analyzer::set_rate(float rate)
+{
+    if (pImpl == nullptr)
+        return;
+    rate = std::max(pImpl->min_rate, rate);
+    if (pImpl->rate == rate)
+        return;
+    pImpl->rate = rate;
+    pImpl->dirty = true;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RATE, rate);
+}
+
+void Analyzer::set_window(size_t window)
+{
+    if (pImpl == nullptr || pImpl->window == window)
+        return;
+    pImpl->window = window;
+    pImpl->dirty = true;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_WINDOW, double(window));
+}
+
+void Analyzer::set_envelope(size_t env)
+{
+    if (pImpl == nullptr || pImpl->envelope == env)
+        return;
+    pImpl->envelope = env;
+    pImpl->dirty = true;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ENVELOPE, double(env));
+}
+
+void Analyzer::set_shift(float shift)
+{
+    if (pImpl == nullptr || pImpl->shift == shift)
+        return;
+    pImpl->shift = shift;
+    pImpl->dirty = true;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SHIFT, shift);
+}
+
+void Analyzer::set_reactivity(float r)
+{
+    if (pImpl == nullptr || pImpl->reactivity == r)
+        return;
+    pImpl->reactivity = r;
+    pImpl->dirty = true;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_REACTIVITY, r);
+}
+
+void Analyzer::set_activity(bool active)
+{
+    if (pImpl == nullptr)
+        return;
+    pImpl->active = active;
+    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ACTIVE, active ? 1.0 : 0.0);
+}
+
+size_t Analyzer::get_rank() const               { return pImpl ? pImpl->rank : 0; }
+size_t Analyzer::get_channels() const           { return pImpl ? pImpl->channels : 0; }
+size_t Analyzer::get_window() const             { return pImpl ? pImpl->window : size_t(windows::HANN); }
+size_t Analyzer::get_envelope() const           { return pImpl ? pImpl->envelope : 2; }
+float  Analyzer::get_shift() const              { return pImpl ? pImpl->shift : 1.0f; }
+size_t Analyzer::get_sample_rate() const        { return pImpl ? pImpl->sample_rate : 0; }
+size_t Analyzer::get_max_sample_rate() const    { return pImpl ? pImpl->max_sample_rate : 0; }
+float  Analyzer::get_rate() const               { return pImpl ? pImpl->rate : 1.0f; }
+float  Analyzer::get_min_rate() const           { return pImpl ? pImpl->min_rate : 1.0f; }
+float  Analyzer::get_reactivity() const         { return pImpl ? pImpl->reactivity : 0.0f; }
+bool   Analyzer::activity() const               { return pImpl ? pImpl->active : true; }
+bool   Analyzer::channel_active(size_t c) const { return pImpl != nullptr && c < pImpl->channels && pImpl->ch[c].active; }
+size_t Analyzer::channel_delay(size_t c) const  { return (pImpl != nullptr && c < pImpl->channels) ? pImpl->ch[c].delay : 0; }
+bool   Analyzer::needs_reconfiguration() const  { return pImpl != nullptr && pImpl->dirty; }
+void   Analyzer::reset()                        { if (pImpl) pImpl->dirty = true; }    // nReconfigure |= R_ANALYSIS: nothing to redo here
+
+void Analyzer::reconfigure()
+{
+    if (pImpl == nullptr || !pImpl->dirty)
+        return;
+    mi_analyzer_bank_process(pImpl->bank, nullptr, 0, 0, nullptr);      // applies the pending settings, consumes no samples
+    pImpl->dirty = false;
+}
 
 bool Analyzer::set_rank(size_t rank)
 {
-    if (pImpl == nullptr || mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RANK, double(rank)) != MI_OK)
+    if (pImpl == nullptr || rank < 2 || rank > pImpl->max_rank)
+        return false;
+    if (pImpl->rank == rank)
+        return true;
+    if (mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RANK, double(rank)) != MI_OK)
         return false;
     pImpl->rank = rank;
+    pImpl->dirty = true;
     return true;
 }
 
 bool Analyzer::freeze_channel(size_t ch, bool freeze)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_FREEZE, freeze) == MI_OK; }
-bool Analyzer::enable_channel(size_t ch, bool enable)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_ENABLE, enable) == MI_OK; }
-bool Analyzer::set_channel_delay(size_t ch, size_t d)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_DELAY, uint32_t(d)) == MI_OK; }
+
+bool Analyzer::enable_channel(size_t ch, bool enable)
+{
+    if (pImpl == nullptr || ch >= pImpl->channels || pImpl->ch[ch].active == enable)     // no change answers false (:232-235)
+        return false;
+    if (mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_ENABLE, enable) != MI_OK)
+        return false;
+    pImpl->ch[ch].active = enable;
+    pImpl->dirty = true;
+    return true;
+}
+
+bool Analyzer::set_channel_delay(size_t ch, size_t d)
+{
+    if (pImpl == nullptr || ch >= pImpl->channels || d > pImpl->max_delay)
+        return false;
+    if (mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_DELAY, uint32_t(d)) != MI_OK)
+        return false;
+    pImpl->ch[ch].delay = d;
+    return true;
+}
+
+bool Analyzer::read_frequencies(float *frq, float start, float stop, size_t count, size_t flags)     // Analyzer.cpp:411-441
+{
+    if (pImpl == nullptr || count == 0)
+        return false;
+    if (count == 1)
+    {
+        *frq = start;
+        return true;
+    }
+    if (flags == FRQA_SCALE_LOGARITHMIC)
+    {
+        const float norm = logf(stop / start) / (--count);
+        for (size_t i = 0; i < count; ++i)
+            frq[i] = start * expf(i * norm);
+    }
+    else if (flags == FRQA_SCALE_LINEAR)
+    {
+        const float norm = (stop - start) / (--count);
+        for (size_t i = 0; i < count; ++i)
+            frq[i] = start + i * norm;
+    }
+    else
+        return false;
+    frq[count] = stop;
+    return true;
+}
 
 void Analyzer::process(const float * const *in, size_t samples)
 {
@@ -2527,6 +2754,7 @@ void Analyzer::process(const float * const *in, size_t samples)
     }
     mi_analyzer_bank_process(pImpl->bank, pImpl->d_in, samples, samples, nullptr);
     mi_dspu_stream_synchronize(nullptr);
+    pImpl->dirty = false;
 }
 
 bool Analyzer::get_spectrum(size_t channel, float *out, const uint32_t *idx, size_t count)

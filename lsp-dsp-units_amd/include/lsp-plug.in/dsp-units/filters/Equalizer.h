@@ -53,6 +53,10 @@ namespace lsp
                 void                reset();
                 size_t              fir_rank() const;
                 size_t              ir_size() const;
+                size_t              fir_ir_size() const;
+                size_t              actual_sample_rate() const;
+                bool                filter_active(size_t id) const;
+                bool                filter_inactive(size_t id) const;
                 bool                smooth() const;
                 void                set_smooth(bool smooth);
                 void                dump(IStateDumper *v) const;

@@ -33,6 +33,10 @@ namespace lsp
                 void            fill(float value);
                 float           get(size_t offset) const;
                 size_t          get(float *dst, size_t offset, size_t count) const;
+                // raw positions inside the buffer (the storage itself lives on the device: there is no data())
+                size_t          read(float *dst, size_t position, size_t count) const;
+                float           read(size_t position) const;
+                float           lerp_get(float offset) const;
                 size_t          size() const;
                 size_t          head_position() const;
                 size_t          tail_position(size_t offset) const;

@@ -11,6 +11,7 @@
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
+#include <lsp-plug.in/dsp-units/util/Analyzer.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
 #include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
@@ -454,6 +455,62 @@ static void ringbuffer()
     CHECK(memcmp(dst, e4, sizeof(e4)) == 0, "block 3");
     CHECK(rb.get(&dst[0], 8, 2) == 1 && rb.get(&dst[2], 6, 2) == 2 && rb.get(&dst[8], 0, 2) == 1, "short reads");
     CHECK(dst[0] == 0.0f && dst[1] == -5.0f && dst[2] == -6.0f && dst[3] == -7.0f && dst[8] == -12.0f && dst[9] == 0.0f, "short read values");
+    // raw positions: read(tail_position(o)) is get(o); lerp_get interpolates between neighbours (RingBuffer.cpp:122-145)
+    for (size_t o = 0; o < 8; ++o)
+        CHECK(rb.read(rb.tail_position(o)) == rb.get(o), "read(tail_position(%zu))", o);
+    CHECK(rb.read(8) == 0.0f && rb.read(dst, 8, 4) == 0, "read past the end");
+    CHECK(rb.lerp_get(1.5f) == 0.5f * (rb.get(1) + rb.get(2)) && rb.lerp_get(3.0f) == rb.get(3), "lerp_get");
+    const size_t p0 = rb.tail_position(5);                  // three samples up to the end of the storage or fewer
+    const size_t n = std::min<size_t>(3, 8 - p0);
+    CHECK(rb.read(dst, p0, n) == n, "block read");
+    for (size_t i = 0; i < n; ++i)
+        CHECK(dst[i] == rb.read(p0 + i), "block read value %zu", i);
+}
+
+// Getters and state flags that the reference keeps next to the hot path (Analyzer.h:144-354, Equalizer.h:143-261)
+static void accessors()
+{
+    printf("accessors (Analyzer, Equalizer)\n");
+    dspu::Analyzer a;
+    CHECK(a.init(2, 10, 96000, 5.5f, 100), "analyzer init");
+    CHECK(a.get_channels() == 2 && a.get_rank() == 10 && a.get_max_sample_rate() == 96000 && a.get_min_rate() == 5.0f, "init values");
+    CHECK(a.get_window() == size_t(dspu::windows::HANN) && a.get_shift() == 1.0f && a.get_reactivity() == 0.0f && a.activity(), "defaults");
+    CHECK(a.needs_reconfiguration(), "dirty after init");
+    a.set_sample_rate(192000);
+    CHECK(a.get_sample_rate() == 96000, "sample rate clamp %zu", a.get_sample_rate());
+    a.set_rate(1.0f);
+    CHECK(a.get_rate() == 5.0f, "rate clamp %g", a.get_rate());
+    CHECK(!a.set_rank(11) && !a.set_rank(1) && a.set_rank(9) && a.get_rank() == 9, "set_rank range");
+    a.set_window(dspu::windows::BLACKMAN); a.set_envelope(0); a.set_shift(2.0f); a.set_reactivity(0.2f);
+    CHECK(a.get_window() == size_t(dspu::windows::BLACKMAN) && a.get_envelope() == 0 && a.get_shift() == 2.0f && a.get_reactivity() == 0.2f, "setters");
+    a.reconfigure();
+    CHECK(!a.needs_reconfiguration(), "clean after reconfigure");
+    a.set_shift(2.0f);
+    CHECK(!a.needs_reconfiguration(), "same value requests nothing");
+    CHECK(!a.enable_channel(1, true) && a.enable_channel(1, false) && !a.channel_active(1) && a.channel_active(0) && a.needs_reconfiguration(), "enable_channel");
+    CHECK(!a.set_channel_delay(0, 101) && a.set_channel_delay(0, 100) && a.channel_delay(0) == 100 && a.channel_delay(5) == 0, "channel delay");
+    float f[5];
+    CHECK(a.read_frequencies(f, 10.0f, 160.0f, 5) && f[0] == 10.0f && f[4] == 160.0f && fabsf(f[2] - 40.0f) < 1e-3f, "log frequencies %g", f[2]);
+    CHECK(a.read_frequencies(f, 10.0f, 50.0f, 5, dspu::FRQA_SCALE_LINEAR) && f[1] == 20.0f && f[4] == 50.0f, "linear frequencies");
+    CHECK(!a.read_frequencies(f, 10.0f, 50.0f, 5, 7) && !a.read_frequencies(f, 10.0f, 50.0f, 0), "bad frequency requests");
+    a.destroy();
+
+    dspu::Equalizer eq;
+    CHECK(eq.init(2, 8), "equalizer init");
+    eq.set_sample_rate(48000);
+    dspu::filter_params_t fp;
+    fp.nType = dspu::FLT_BT_RLC_BELL; fp.fFreq = 1000.0f; fp.fFreq2 = 1000.0f; fp.fGain = 2.0f; fp.nSlope = 1; fp.fQuality = 1.0f;
+    eq.set_params(0, &fp);
+    eq.set_mode(dspu::EQM_IIR);
+    // Filter::update() parks the filter in FM_BYPASS until the equalizer rebuilds (Filter.cpp:150)
+    CHECK(eq.filter_inactive(0) && !eq.filter_active(0) && eq.configuration_changed(), "stale filter reads inactive");
+    (void)eq.get_latency();
+    CHECK(eq.filter_active(0) && !eq.filter_inactive(0) && eq.filter_inactive(1) && !eq.configuration_changed(), "after reconfigure");
+    CHECK(!eq.filter_active(2) && !eq.filter_inactive(2), "bad id");
+    CHECK(eq.fir_ir_size() == 512 && eq.actual_sample_rate() == 48000, "sizes");
+    eq.set_actual_sample_rate(44100);
+    CHECK(eq.actual_sample_rate() == 44100, "actual sample rate");
+    eq.destroy();
 }
 
 static void readme_filter()
@@ -485,7 +542,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -507,6 +564,7 @@ int main(int argc, char **argv)
     spectral_splitter_mtest_flow();
     fft_crossover_mtest_flow();
     ringbuffer();
+    accessors();
     readme_filter();
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
