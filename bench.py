@@ -32,8 +32,8 @@ HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral"],
                     help="all = headline biquad line with the convolver result attached under \"convolver\"")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
@@ -188,8 +188,10 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True)
     # The dominant kernel of the last `burst` steps of the timed region carries a start/stop event pair
     # (hipExtLaunchKernelGGL).  An event pair serialises its launch against its neighbours, so a contiguous burst measures
     # what rocprofv3 measures (one launch at a time) while the steps before it run back to back; the first launch of the
-    # burst still overlaps the un-instrumented launch before it and is dropped from the average.
-    burst = min(32, max(1, steps // 4)) if profile else 0
+    # burst still overlaps the un-instrumented launch before it and is dropped from the average.  An instrumented launch
+    # costs about two un-instrumented steps of the biquad workload, so the burst is kept short: it is part of the timed
+    # region and of `value`.
+    burst = min(16, max(2, steps // 8)) if profile else 0
     probes = list(range(steps - burst, steps))
     starts = {i: new_event() for i in probes}
     stops = {i: new_event() for i in probes}

@@ -378,9 +378,15 @@ int mi_spectral_bank_bind_mask(mi_spectral_bank_t *bank, const float *mask, size
 int mi_spectral_bank_bind_channels(mi_spectral_bank_t *bank, const uint8_t *has_in, const uint8_t *has_out, void *stream);
 /* reset(), SpectralProcessor.cpp:257-266. */
 int mi_spectral_bank_reset(mi_spectral_bank_t *bank, void *stream);
-/* process(dst, src, count) / process(src, count) with out == NULL, SpectralProcessor.cpp:147-249. */
+/* process(dst, src, count), SpectralProcessor.cpp:147-199.  With out == NULL: process(src, count), :201-249 -- analysis
+ * only: the function is called on every frame, nothing is transformed back and the output buffer is shifted and its
+ * tail zeroed instead of overlap-added (MultiSpectralProcessor timing: out == NULL just skips the copy-out). */
 int mi_spectral_bank_process(mi_spectral_bank_t *bank, float *out, const float *in, size_t count,
                              size_t out_stride, size_t in_stride, void *stream);
+/* When a complete frame is transformed: eager == 0 (default) when the next sample arrives, as SpectralProcessor does
+ * (SpectralProcessor.cpp:159: remaining() can read 0, the function runs at the start of the following call); eager != 0
+ * as soon as the frame is complete, as MultiSpectralProcessor does (MultiSpectralProcessor.cpp:324). */
+int mi_spectral_bank_set_timing(mi_spectral_bank_t *bank, int eager);
 
 /* ---- spectrum analyzer bank ---------------------------------------------------------------- */
 /*

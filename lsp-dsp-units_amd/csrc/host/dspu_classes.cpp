@@ -831,6 +831,7 @@ bool MultiSpectralProcessor::init(size_t channels, size_t max_rank)
         delete p;
         return false;
     }
+    mi_spectral_bank_set_timing(p->bank, 1);                // transform as soon as the frame is complete (:324)
     destroy();
     p->channels = channels;
     p->max_rank = max_rank;

@@ -179,6 +179,20 @@ namespace
         }
     }
 
+    // process(src, count) of the reference -- analysis only (SpectralProcessor.cpp:201-249): no inverse transform and
+    // nothing is added to the output buffer; it is shifted by half a frame and its tail zeroed, the input buffer shifted.
+    __global__ __launch_bounds__(256)
+    void stft_shift_kernel(float *in_buf, float *out_buf, uint32_t frame)
+    {
+        float *ib = in_buf + size_t(blockIdx.y) * 2 * frame, *ob = out_buf + size_t(blockIdx.y) * 2 * frame;
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+        if (i >= frame)
+            return;
+        ob[i] = ob[i + frame];          // every cell is read and written by the same thread or by exactly one other
+        ob[i + frame] = 0.0f;           // one, in this order: thread i reads i + frame before it writes it
+        ib[i] = ib[i + frame];
+    }
+
     // ---- analyzer -------------------------------------------------------------------------------------------
     // ring: [channels][buf_size]; the frame of channel c ends `delay[c]` samples before `head`.
     // amp_old: vAmp as of the strobe (what get_spectrum() shows until the next strobe: the reference copies vAmp to vData
@@ -368,6 +382,7 @@ struct mi_spectral_bank
     uint32_t    channels = 0, max_rank = 0, rank = 0;
     float       phase = 0.0f;
     bool        update = true;              // bUpdate: settings not applied yet
+    bool        eager = false;              // transform when the frame fills (Multi...) / when the next sample comes
     uint32_t    offset = 0;                 // nOffset
     int         op = MI_SPECTRAL_OP_NONE;
     mi_spectral_func_t func = nullptr;
@@ -435,10 +450,26 @@ namespace
         return MI_OK;
     }
 
-    int spectral_hop(mi_spectral_bank *b, hipStream_t st)
+    int spectral_hop(mi_spectral_bank *b, hipStream_t st, bool analyze_only = false)
     {
         const int lh = int(b->rank) - 1;
         const dim3 grid(b->channels);
+        if (analyze_only)
+        {
+            if (b->op == MI_SPECTRAL_OP_CALLBACK && b->func != nullptr)
+            {
+                #define MI_CALL(LH) hipLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, \
+                    b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+                MI_HIP_CHECK(hipGetLastError());
+                b->func(b->object, b->subject, reinterpret_cast<float *>(b->d_spec), b->rank, b->channels, st);
+            }
+            const uint32_t frame = 1u << (b->rank - 1);
+            hipLaunchKernelGGL(stft_shift_kernel, dim3((frame + 255) / 256, b->channels), dim3(256), 0, st, b->d_in, b->d_out, frame);
+            MI_HIP_CHECK(hipGetLastError());
+            return MI_OK;
+        }
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
@@ -653,18 +684,31 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             return r;
     }
     const size_t N = size_t(1) << b->rank, frame = N >> 1;
+    const bool analyze_only = (out == nullptr) && !b->eager;       // process(src, count), SpectralProcessor.cpp:201-249
     size_t done = 0;
-    while (done < count)                                    // SpectralProcessor.cpp:156-198
+    while (done < count)                                    // SpectralProcessor.cpp:156-198, MultiSpectralProcessor.cpp:297-392
     {
+        // SpectralProcessor transforms a complete frame when the NEXT sample arrives (:159), MultiSpectralProcessor as
+        // soon as the frame is complete (:324): the samples are the same, the moment the function is called is not
+        if (!b->eager && b->offset >= frame)
+        {
+            const int r = spectral_hop(b, st, analyze_only);
+            if (r != MI_OK)
+                return r;
+            b->offset = 0;
+        }
         const size_t n = (count - done < frame - b->offset) ? count - done : frame - b->offset;
-        MI_HIP_CHECK(hipMemcpy2DAsync(b->d_in + frame + b->offset, N * sizeof(float), in + done, in_stride * sizeof(float),
-                                      n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
-        if (out != nullptr)
-            MI_HIP_CHECK(hipMemcpy2DAsync(out + done, out_stride * sizeof(float), b->d_out + b->offset, N * sizeof(float),
+        if (n > 0)
+        {
+            MI_HIP_CHECK(hipMemcpy2DAsync(b->d_in + frame + b->offset, N * sizeof(float), in + done, in_stride * sizeof(float),
                                           n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+            if (out != nullptr)
+                MI_HIP_CHECK(hipMemcpy2DAsync(out + done, out_stride * sizeof(float), b->d_out + b->offset, N * sizeof(float),
+                                              n * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+        }
         b->offset += uint32_t(n);
         done += n;
-        if (b->offset >= frame)                             // the frame is complete: transform it now, as the reference does
+        if (b->eager && b->offset >= frame)
         {
             const int r = spectral_hop(b, st);
             if (r != MI_OK)
@@ -672,6 +716,13 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             b->offset = 0;
         }
     }
+    return MI_OK;
+}
+
+int mi_spectral_bank_set_timing(mi_spectral_bank_t *b, int eager)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_set_timing: NULL bank");
+    b->eager = (eager != 0);
     return MI_OK;
 }
 

@@ -229,6 +229,10 @@ class SpectralBank:
     def set_phase(self, phase):
         check(lib.mi_spectral_bank_set_phase(self.handle, phase))
 
+    def set_timing(self, eager):
+        """False: SpectralProcessor (a full frame is transformed when the next sample arrives); True: Multi..."""
+        check(lib.mi_spectral_bank_set_timing(self.handle, 1 if eager else 0))
+
     def get(self):
         v = [c_uint32() for _ in range(3)]
         check(lib.mi_spectral_bank_get(self.handle, *[byref(x) for x in v]))

@@ -160,6 +160,31 @@ class SpectralProcessor:
             self.offset += todo; pos += todo; count -= todo
         return dst
 
+    def remaining(self):
+        return (1 << (self.rank - 1)) - self.offset
+
+    def analyze(self, src):
+        """process(src, count), SpectralProcessor.cpp:201-249: the function sees every frame, nothing comes back."""
+        src = np.asarray(src, np.float32)
+        if self.update:
+            self._apply()
+        n = 1 << self.rank
+        frame = n >> 1
+        pos, count = 0, src.size
+        while count > 0:
+            if self.offset >= frame:
+                if self.func is not None:
+                    re = (self.in_buf * self.wnd).astype(np.float32)
+                    c = np.zeros(2 * n, np.float32); c[0::2] = re
+                    self.func(B.packed_direct_fft(c, self.rank), self.rank)
+                self.out_buf[:frame] = self.out_buf[frame:]
+                self.out_buf[frame:] = 0.0
+                self.in_buf[:frame] = self.in_buf[frame:]
+                self.offset = 0
+            todo = min(frame - self.offset, count)
+            self.in_buf[frame + self.offset: frame + self.offset + todo] = src[pos:pos + todo]
+            self.offset += todo; pos += todo; count -= todo
+
 
 # ---- Analyzer -----------------------------------------------------------------------------------------------------
 class Analyzer:

@@ -219,3 +219,52 @@ def test_analyzer_rejects_zero_step(gpu):
     with pytest.raises(gpu.MiError):
         bank.process(d, 16)
     bank.close()
+
+
+def test_lazy_transform_timing_and_analysis_only_calls(gpu):
+    """SpectralProcessor transforms a complete frame when the NEXT sample arrives (SpectralProcessor.cpp:159): after a
+    call that ends on a frame boundary remaining() is 0 and the function has not seen that frame yet.  process(src, count)
+    without a destination (:201-249) calls the function on every frame but adds nothing to the output buffer, it only
+    shifts it and zeroes its tail -- visible when normal processing resumes."""
+    rank, n = 8, 2048
+    N, frame = 1 << rank, 1 << (rank - 1)
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((1, n)).astype(np.float32)
+    calls = []
+
+    def cb(spec_ptr, r, channels, stream):
+        calls.append(r)
+    bank = gpu.SpectralBank(1, rank)
+    bank.bind(cb)
+    ref = sp.SpectralProcessor(rank)
+    rcalls = []
+
+    def rfunc(spec, r):
+        rcalls.append(r); return spec
+    ref.bind(rfunc)
+    got, want = [], []
+    pos = 0
+    plan = [("p", frame), ("p", frame), ("a", 3 * frame), ("a", 50), ("p", frame), ("p", 300), ("a", frame - 94), ("p", 4 * frame)]
+    for kind, k in plan:
+        blk = x[:, pos:pos + k]; pos += k
+        if kind == "p":
+            out = gpu.DeviceBuffer((1, k))
+            bank.process(out, gpu.DeviceBuffer.from_host(blk), k)
+            got.append(out.download()[0]); want.append(ref.process(blk[0]))
+        else:
+            bank.process(None, gpu.DeviceBuffer.from_host(blk), k)
+            ref.analyze(blk[0])
+        assert len(calls) == len(rcalls), (kind, k, len(calls), len(rcalls))
+        assert bank.get()["remaining"] == ref.remaining()
+    assert pos <= n and len(calls) >= 8
+    got = np.concatenate(got); want = np.concatenate(want)
+    assert np.abs(got - want).max() <= TOL * float(np.abs(want).max())
+    # the first call ended on a frame boundary: nothing had been transformed yet
+    bank2 = gpu.SpectralBank(1, rank); seen = []
+    bank2.bind(lambda p, r, c, s: seen.append(r))
+    bank2.process(gpu.DeviceBuffer((1, frame)), gpu.DeviceBuffer.from_host(x[:, :frame]), frame)
+    assert seen == [] and bank2.get()["remaining"] == 0
+    bank2.set_timing(True)                                  # MultiSpectralProcessor.cpp:324: as soon as it is complete
+    bank2.process(gpu.DeviceBuffer((1, frame)), gpu.DeviceBuffer.from_host(x[:, :frame]), frame)
+    assert len(seen) == 2 and bank2.get()["remaining"] == frame
+    bank.close(); bank2.close()
