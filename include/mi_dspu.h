@@ -332,7 +332,9 @@ enum mi_envelope
 };
 /* windows::window(dst, n, type), src/main/misc/windows.cpp:62-98 (host memory). */
 int mi_window(float *dst, size_t n, int type);
-/* envelope::reverse_noise_lin(dst, first, last, center, n, type), src/main/misc/envelope.cpp:95-123 (host memory). */
+/* envelope::noise_lin / reverse_noise_lin(dst, first, last, center, n, type), src/main/misc/envelope.cpp:63-123 (host
+ * memory): the colour's spectral envelope (f / center)^k on n linearly spaced frequencies, or the opposite colour's. */
+int mi_envelope_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
 int mi_envelope_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
 
 /* ---- spectral processor bank -------------------------------------------------------------- */

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "mi_convolver_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_window": (c_int, [c_void_p, c_size_t, c_int]),
     "mi_envelope_reverse_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
+    "mi_envelope_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
     "mi_spectral_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_spectral_bank_destroy": (c_int, [c_void_p]),
     "mi_spectral_bank_set_rank": (c_int, [c_void_p, c_uint32]),

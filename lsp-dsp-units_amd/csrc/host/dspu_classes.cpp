@@ -12,6 +12,7 @@
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
+#include <lsp-plug.in/dsp-units/misc/envelope.h>
 #include <lsp-plug.in/dsp-units/misc/fft_crossover.h>
 #include <lsp-plug.in/dsp-units/util/FFTCrossover.h>
 #include <lsp-plug.in/dsp-units/util/SpectralSplitter.h>
@@ -1203,6 +1204,18 @@ void Crossover::dump(IStateDumper *v) const
 {
     v->write("nSplits", num_splits());
     v->write("nBufSize", max_buffer_size());
+}
+
+// ---- envelope::* -----------------------------------------------------------------------------------------------
+namespace envelope
+{
+    void noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t type)         { mi_envelope_noise_lin(dst, first, last, center, n, int(type)); }
+    void reverse_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t type) { mi_envelope_reverse_noise_lin(dst, first, last, center, n, int(type)); }
+    void white_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)        { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_WHITE_NOISE); }
+    void pink_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)         { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_PINK_NOISE); }
+    void brown_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)        { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_BROWN_NOISE); }
+    void blue_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)         { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_BLUE_NOISE); }
+    void violet_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)       { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_VIOLET_NOISE); }
 }
 
 // ---- crossover::* / SpectralSplitter / FFTCrossover ------------------------------------------------------------
@@ -2528,7 +2541,7 @@ struct Analyzer::impl_t
 {
     mi_analyzer_bank_t *bank = nullptr;
     size_t  channels = 0, rank = 0, max_rank = 0, sample_rate = 0, max_sample_rate = 0, max_delay = 0;
-    size_t  window = windows::HANN, envelope = 2 /* envelope::PINK_NOISE */;
+    size_t  window = windows::HANN, envelope = envelope::PINK_NOISE;
     float   shift = 1.0f, rate = 1.0f, min_rate = 1.0f, reactivity = 0.0f;
     bool    active = true, dirty = true;
     struct chan_t { bool active = true; size_t delay = 0; };
@@ -2648,7 +2661,7 @@ void Analyzer::set_activity(bool active)
 size_t Analyzer::get_rank() const               { return pImpl ? pImpl->rank : 0; }
 size_t Analyzer::get_channels() const           { return pImpl ? pImpl->channels : 0; }
 size_t Analyzer::get_window() const             { return pImpl ? pImpl->window : size_t(windows::HANN); }
-size_t Analyzer::get_envelope() const           { return pImpl ? pImpl->envelope : 2; }
+size_t Analyzer::get_envelope() const           { return pImpl ? pImpl->envelope : size_t(envelope::PINK_NOISE); }
 float  Analyzer::get_shift() const              { return pImpl ? pImpl->shift : 1.0f; }
 size_t Analyzer::get_sample_rate() const        { return pImpl ? pImpl->sample_rate : 0; }
 size_t Analyzer::get_max_sample_rate() const    { return pImpl ? pImpl->max_sample_rate : 0; }

@@ -225,26 +225,42 @@ void make_window(float *dst, size_t n, int type)
     }
 }
 
-// envelope::reverse_noise_lin (envelope.cpp:95-123): the inverse colour of `type` on a linear frequency grid
-void make_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type)
+// envelope::noise_lin / reverse_noise_lin (envelope.cpp:40-123): (f / center)^k on a linear frequency grid, k the
+// spectral slope of the colour (reverse: of the opposite colour)
+namespace
 {
-    constexpr float LOG10_2 = 0.30102999566398119521f;      // M_LOG10_2
-    constexpr float PLUS_4_5 = 4.5f / (20.0f * LOG10_2), MINUS_4_5 = -4.5f / (20.0f * LOG10_2);
-    float k;
-    switch (type)
+    bool colour_exponent(int type, bool reverse, float *k)
     {
-        case MI_ENVELOPE_WHITE_NOISE:
-            for (size_t i = 0; i < n; ++i)
-                dst[i] = 1.0f;
-            return;
-        case MI_ENVELOPE_PINK_NOISE:    k = 0.5f;  break;   // reverse of pink is blue
-        case MI_ENVELOPE_BROWN_NOISE:   k = 1.0f;  break;
-        case MI_ENVELOPE_BLUE_NOISE:    k = -0.5f; break;
-        case MI_ENVELOPE_VIOLET_NOISE:  k = -1.0f; break;
-        case MI_ENVELOPE_PLUS_4_5_DB:   k = MINUS_4_5; break;
-        case MI_ENVELOPE_MINUS_4_5_DB:  k = PLUS_4_5; break;
-        default:
-            return;
+        constexpr float LOG10_2 = 0.30102999566398119521f;  // M_LOG10_2
+        constexpr float PLUS_4_5 = 4.5f / (20.0f * LOG10_2), MINUS_4_5 = -4.5f / (20.0f * LOG10_2);
+        float v;
+        switch (type)
+        {
+            case MI_ENVELOPE_WHITE_NOISE:   v = 0.0f;  break;
+            case MI_ENVELOPE_PINK_NOISE:    v = -0.5f; break;
+            case MI_ENVELOPE_BROWN_NOISE:   v = -1.0f; break;
+            case MI_ENVELOPE_BLUE_NOISE:    v = 0.5f;  break;
+            case MI_ENVELOPE_VIOLET_NOISE:  v = 1.0f;  break;
+            case MI_ENVELOPE_PLUS_4_5_DB:   v = PLUS_4_5;  break;
+            case MI_ENVELOPE_MINUS_4_5_DB:  v = MINUS_4_5; break;
+            default:
+                return false;
+        }
+        *k = reverse ? -v : v;
+        return true;
+    }
+}
+
+void make_noise_lin(float *dst, float first, float last, float center, size_t n, int type, bool reverse)
+{
+    float k;
+    if (!colour_exponent(type, reverse, &k))
+        return;
+    if (type == MI_ENVELOPE_WHITE_NOISE)                    // fill_one, whatever n is
+    {
+        for (size_t i = 0; i < n; ++i)
+            dst[i] = 1.0f;
+        return;
     }
     if (n <= 1)                                             // envelope.cpp:42-47
     {
@@ -264,6 +280,11 @@ void make_reverse_noise_lin(float *dst, float first, float last, float center, s
         dst[i] = powf(dst[i], k);
 }
 
+void make_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type)
+{
+    make_noise_lin(dst, first, last, center, n, type, true);
+}
+
 } // namespace mi
 
 extern "C" {
@@ -273,6 +294,14 @@ int mi_window(float *dst, size_t n, int type)
     MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_window: NULL destination");
     MI_REQUIRE(type >= 0 && type < MI_WINDOW_TOTAL, MI_EINVAL, "mi_window: unknown window %d", type);
     mi::make_window(dst, n, type);
+    return MI_OK;
+}
+
+int mi_envelope_noise_lin(float *dst, float first, float last, float center, size_t n, int type)
+{
+    MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_envelope_noise_lin: NULL destination");
+    MI_REQUIRE(type >= 0 && type < MI_ENVELOPE_TOTAL, MI_EINVAL, "mi_envelope_noise_lin: unknown envelope %d", type);
+    mi::make_noise_lin(dst, first, last, center, n, type, false);
     return MI_OK;
 }
 

@@ -15,6 +15,7 @@
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
 #include <lsp-plug.in/dsp-units/meters/ILUFSMeter.h>
 #include <lsp-plug.in/dsp-units/meters/LoudnessMeter.h>
+#include <lsp-plug.in/dsp-units/misc/envelope.h>
 #include <lsp-plug.in/dsp-units/misc/fft_crossover.h>
 #include <lsp-plug.in/dsp-units/util/FFTCrossover.h>
 #include <lsp-plug.in/dsp-units/util/SpectralSplitter.h>
@@ -474,7 +475,7 @@ static void accessors()
     dspu::Analyzer a;
     CHECK(a.init(2, 10, 96000, 5.5f, 100), "analyzer init");
     CHECK(a.get_channels() == 2 && a.get_rank() == 10 && a.get_max_sample_rate() == 96000 && a.get_min_rate() == 5.0f, "init values");
-    CHECK(a.get_window() == size_t(dspu::windows::HANN) && a.get_shift() == 1.0f && a.get_reactivity() == 0.0f && a.activity(), "defaults");
+    CHECK(a.get_window() == size_t(dspu::windows::HANN) && a.get_envelope() == size_t(dspu::envelope::PINK_NOISE) && a.get_shift() == 1.0f && a.get_reactivity() == 0.0f && a.activity(), "defaults");
     CHECK(a.needs_reconfiguration(), "dirty after init");
     a.set_sample_rate(192000);
     CHECK(a.get_sample_rate() == 96000, "sample rate clamp %zu", a.get_sample_rate());
@@ -494,6 +495,12 @@ static void accessors()
     CHECK(a.read_frequencies(f, 10.0f, 50.0f, 5, dspu::FRQA_SCALE_LINEAR) && f[1] == 20.0f && f[4] == 50.0f, "linear frequencies");
     CHECK(!a.read_frequencies(f, 10.0f, 50.0f, 5, 7) && !a.read_frequencies(f, 10.0f, 50.0f, 0), "bad frequency requests");
     a.destroy();
+
+    float env[5];
+    dspu::envelope::reverse_noise_lin(env, 0.0f, 400.0f, 100.0f, 5, dspu::envelope::PINK_NOISE);      // blue: sqrt(f / centre)
+    CHECK(env[0] == env[1] && env[1] == 1.0f && fabsf(env[4] - 2.0f) < 1e-6f, "reverse pink envelope %g %g", env[1], env[4]);
+    dspu::envelope::brown_noise_lin(env, 100.0f, 500.0f, 100.0f, 5, dspu::envelope::WHITE_NOISE);
+    CHECK(env[0] == 1.0f && fabsf(env[4] - 0.2f) < 1e-6f, "brown envelope %g", env[4]);
 
     dspu::Equalizer eq;
     CHECK(eq.init(2, 8), "equalizer init");
