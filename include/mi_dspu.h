@@ -354,7 +354,7 @@ enum { MI_SPECTRAL_OP_NONE = 0, MI_SPECTRAL_OP_MASK = 1, MI_SPECTRAL_OP_CALLBACK
  */
 typedef void (*mi_spectral_func_t)(void *object, void *subject, float *spectrum, size_t rank, size_t channels, void *stream);
 
-/* SpectralProcessor::init(max_rank), SpectralProcessor.cpp:59-75 (ranks 5..12 supported). */
+/* SpectralProcessor::init(max_rank), SpectralProcessor.cpp:59-75 (ranks 5..14 supported). */
 int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32_t max_rank);
 int mi_spectral_bank_destroy(mi_spectral_bank_t *bank);
 /* set_rank / set_phase, SpectralProcessor.cpp:127-145 (a rank above max_rank is ignored, phase is clamped to 0..1). */
@@ -400,7 +400,7 @@ enum { MI_ANALYZER_SAMPLE_RATE, MI_ANALYZER_RATE, MI_ANALYZER_WINDOW, MI_ANALYZE
        MI_ANALYZER_REACTIVITY, MI_ANALYZER_RANK, MI_ANALYZER_ACTIVE };
 enum { MI_ANALYZER_CH_FREEZE, MI_ANALYZER_CH_ENABLE, MI_ANALYZER_CH_DELAY };
 
-/* Analyzer::init(channels, max_rank, max_sr, min_rate, max_delay), Analyzer.cpp:83-152 (ranks 5..13 supported). */
+/* Analyzer::init(channels, max_rank, max_sr, min_rate, max_delay), Analyzer.cpp:83-152 (ranks 5..14 supported). */
 int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t max_sample_rate,
                             float min_rate, uint32_t max_delay);
 int mi_analyzer_bank_destroy(mi_analyzer_bank_t *bank);
@@ -567,7 +567,7 @@ typedef struct mi_splitter_bank mi_splitter_bank_t;
 /* spectral_splitter_func_t on the device (util/SpectralSplitter.h:41-46): in/out are DEVICE pointers to
  * [channels][2 * 2^rank] floats (packed complex); the function runs on the host and may enqueue work on `stream`. */
 typedef void (*mi_splitter_func_t)(void *object, void *subject, float *out, const float *in, size_t rank, size_t channels, void *stream);
-/* init(max_rank, handlers), SpectralSplitter.cpp:62-127 (max_rank 5..13) */
+/* init(max_rank, handlers), SpectralSplitter.cpp:62-127 (max_rank 5..14) */
 int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t handlers);
 int mi_splitter_bank_destroy(mi_splitter_bank_t *bank);
 /* set_rank / set_chunk_rank / set_phase, SpectralSplitter.cpp:260-282 */

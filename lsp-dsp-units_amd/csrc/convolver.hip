@@ -35,7 +35,6 @@ namespace
 {
     using namespace mi_fft;
 
-    constexpr int TWN = 8192;               // twiddle table length: exp(-2 pi i j / TWN)
     constexpr int LOGM_MIN = 7, LOGM_MAX = 12;
 
 #ifdef MI_CONV_PROBE

@@ -28,7 +28,6 @@ namespace mi
 namespace
 {
     using namespace mi_fft;
-    constexpr int TWN = 8192;
 
     // mag[k] = | FFT( ir[n] * wnd[n] ) |, k < N            (Equalizer.cpp:283-288)
     template <int LOGN>

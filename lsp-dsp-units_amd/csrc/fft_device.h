@@ -19,6 +19,9 @@
 
 namespace mi_fft
 {
+    // length of the shared twiddle table exp(-2 pi i j / TWN) (mi::fft_twiddles): the largest real transform is 2^14 points
+    constexpr int TWN = 16384;
+
     __device__ __forceinline__ float2 cmul(float2 a, float2 b)
     {
         return make_float2(fmaf(a.x, b.x, -a.y * b.y), fmaf(a.x, b.y, a.y * b.x));

@@ -25,7 +25,6 @@
 namespace
 {
     using namespace mi_fft;
-    constexpr int TWN = 8192;           // must match convolver.hip (mi::fft_twiddles)
 
     // ---- hop transform of the spectral processor ----------------------------------------------------------
     // in_buf/out_buf: [channels][N] state of the reference object (pInBuf/pOutBuf); wnd: N window samples.
@@ -136,46 +135,66 @@ namespace
         }
     }
 
-    // CALLBACK path, second half: full complex N-point inverse, real part, window, overlap-add, input shift
-    template <int LOGN>
-    __global__ __launch_bounds__(plan<LOGN>::T)
+    // CALLBACK path, second half.  The function may have broken the Hermitian symmetry of the spectrum and only the real
+    // part of the inverse is kept (SpectralProcessor.cpp:168-169): Re ifft(S) = ifft of S's Hermitian part
+    // (S[k] + conj S[N-k]) / 2, so the way back is the same half-size real transform as the way there.
+    // Then window, overlap-add, input shift.
+    template <int LOGH>
+    __global__ __launch_bounds__(plan<LOGH>::T)
     void stft_inverse_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_out,
                              const float2 *__restrict__ spec, const uint8_t *__restrict__ active,
                              const uint8_t *__restrict__ has_out, const float2 *__restrict__ tw)
     {
-        using PL = plan<LOGN>;
-        constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N], scr[N];
+        using PL = plan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H;
+        __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
         const bool on = ((active == nullptr) || (active[ch] != 0)) && ((has_out == nullptr) || (has_out[ch] != 0));
-        fft_tw<LOGN> ft;
-        load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
-        finish_fft_tw<LOGN>(ft);
         const float2 *sp = spec + size_t(ch) * N;
-        float *ob = out_buf + size_t(ch) * N;
-        float *ib = in_buf + size_t(ch) * N;
+        float2 *o2 = reinterpret_cast<float2 *>(out_buf + size_t(ch) * N);
+        float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * N);
+        const float2 *wo = reinterpret_cast<const float2 *>(wnd_out);
         if (on)
         {
-            for (int k = tid; k < N; k += T)
-                buf[k] = sp[k];
+            real_fft<LOGH> rf;
+            rf.load(tw, TWN, tid);
+            rf.prepare();
+            for (int k = tid; k < H; k += T)
+            {
+                if (k == 0)
+                    buf[0] = make_float2(sp[0].x, sp[H].x);
+                else
+                {
+                    const float2 a = sp[k], c = sp[N - k];
+                    buf[k] = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+                }
+            }
             __syncthreads();
-            fft_lds<LOGN, true>(buf, scr, ft, tid);
+            rf.inverse(buf, scr, tid);
         }
         const float scale = 1.0f / float(N);
-        const float *sr = reinterpret_cast<const float *>(sp);
-        for (int n = tid; n < N / 2; n += T)
+        for (int m = tid; m < H / 2; m += T)
         {
-            // bound channels: real part of the inverse; others: whatever real data sits in the buffer
-            const float y0 = on ? buf[n].x * scale : sr[n];
-            const float y1 = on ? buf[n + N / 2].x * scale : sr[n + N / 2];
-            const float prev = ob[n + N / 2];
-            ob[n]         = fmaf(y0, wnd_out[n], prev);
-            ob[n + N / 2] = y1 * wnd_out[n + N / 2];
+            // bound channels: the inverse; others: the windowed frame the forward kernel left in the spectrum buffer
+            float2 y0, y1;
+            if (on)
+            {
+                y0 = make_float2(buf[m].x * scale, buf[m].y * scale);
+                y1 = make_float2(buf[m + H / 2].x * scale, buf[m + H / 2].y * scale);
+            }
+            else
+            {
+                y0 = sp[m];
+                y1 = sp[m + H / 2];
+            }
+            const float2 w0 = wo[m], w1 = wo[m + H / 2], prev = o2[m + H / 2];
+            o2[m]         = make_float2(fmaf(y0.x, w0.x, prev.x), fmaf(y0.y, w0.y, prev.y));
+            o2[m + H / 2] = make_float2(y1.x * w1.x, y1.y * w1.y);
         }
-        for (int n = tid; n < N / 2; n += T)
+        for (int m = tid; m < H / 2; m += T)
         {
-            const float v = ib[n + N / 2];
-            ib[n] = v;
+            const float2 v = x2[m + H / 2];
+            x2[m] = v;
         }
     }
 
@@ -408,20 +427,6 @@ namespace
             case 9:  { CALL(9);  break; }               \
             case 10: { CALL(10); break; }               \
             case 11: { CALL(11); break; }               \
-            default: { CALL(12); break; }               \
-        }
-
-    // full complex transforms of N = 2^rank points (callback path): ranks 5..13
-    #define MI_LOGN_SWITCH(ln, CALL)                    \
-        switch (ln)                                     \
-        {                                               \
-            case 5:  { CALL(5);  break; }               \
-            case 6:  { CALL(6);  break; }               \
-            case 7:  { CALL(7);  break; }               \
-            case 8:  { CALL(8);  break; }               \
-            case 9:  { CALL(9);  break; }               \
-            case 10: { CALL(10); break; }               \
-            case 11: { CALL(11); break; }               \
             case 12: { CALL(12); break; }               \
             default: { CALL(13); break; }               \
         }
@@ -497,9 +502,9 @@ namespace
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
             b->func(b->object, b->subject, reinterpret_cast<float *>(b->d_spec), b->rank, b->channels, st);
-            #define MI_CALL(LN) hipLaunchKernelGGL((stft_inverse_kernel<LN>), grid, dim3(plan<LN>::T), 0, st, \
+            #define MI_CALL(LH) hipLaunchKernelGGL((stft_inverse_kernel<LH>), grid, dim3(plan<LH>::T), 0, st, \
                 b->d_in, b->d_out, b->d_wnd_out, b->d_spec, b->d_active, b->d_has_out, b->d_tw)
-            MI_LOGN_SWITCH(int(b->rank), MI_CALL)
+            MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
         }
         MI_HIP_CHECK(hipGetLastError());
@@ -514,8 +519,8 @@ int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_spectral_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0, MI_EINVAL, "mi_spectral_bank_create: channels must be > 0");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 13, MI_EINVAL,
-               "mi_spectral_bank_create: max_rank %u outside the supported 5..13 (frames of 32..8192 samples)", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 14, MI_EINVAL,
+               "mi_spectral_bank_create: max_rank %u outside the supported 5..14 (frames of 32..16384 samples)", max_rank);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_spectral_bank *b = new (std::nothrow) mi_spectral_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_spectral_bank_create: out of host memory");
@@ -849,8 +854,8 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_analyzer_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0 && max_sample_rate > 0 && min_rate > 0.0f, MI_EINVAL, "mi_analyzer_bank_create: bad argument");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 13, MI_EINVAL,
-               "mi_analyzer_bank_create: max_rank %u outside the supported 5..13", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 14, MI_EINVAL,
+               "mi_analyzer_bank_create: max_rank %u outside the supported 5..14", max_rank);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_analyzer_bank *b = new (std::nothrow) mi_analyzer_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_analyzer_bank_create: out of host memory");

@@ -32,7 +32,6 @@ namespace mi
 namespace
 {
     using namespace mi_fft;
-    constexpr int TWN = 8192;           // must match convolver.hip (mi::fft_twiddles)
 
     enum { H_OFF = 0, H_COPY = 1, H_MASK = 2, H_CALLBACK = 3 };
 
@@ -170,34 +169,38 @@ namespace
         }
     }
 
-    // CALLBACK handlers: complex N-point inverse of what the function left in `spec`, real part of the last 2*frame samples
-    template <int LOGN>
-    __global__ __launch_bounds__(plan<LOGN>::T)
+    // CALLBACK handlers: only the real part of the inverse of what the function left in `spec` is kept (pcomplex_c2r),
+    // and Re ifft(S) is the inverse of S's Hermitian part (S[k] + conj S[N-k]) / 2 -- the same half-size real transform
+    // as on the way there.  The last 2*frame samples are windowed into the handler's line.
+    template <int LOGH>
+    __global__ __launch_bounds__(plan<LOGH>::T)
     void splitter_inverse_kernel(float *line0, size_t line_pitch, const float2 *__restrict__ spec,
                                  const float *__restrict__ wnd, uint32_t frame, const float2 *__restrict__ tw)
     {
-        using PL = plan<LOGN>;
-        constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N], scr[N];
+        using PL = plan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H;
+        __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
-        fft_tw<LOGN> ft;
-        load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
-        finish_fft_tw<LOGN>(ft);
+        real_fft<LOGH> rf;
+        rf.load(tw, TWN, tid);
+        rf.prepare();
         const float2 *sp = spec + size_t(ch) * N;
-        for (int k = tid; k < N; k += T)
-            buf[k] = sp[k];
-        __syncthreads();
-        fft_lds<LOGN, true>(buf, scr, ft, tid);
-        float *line = line0 + size_t(ch) * line_pitch;
-        const float scale = 1.0f / float(N);
-        const uint32_t first = uint32_t(N) - 2 * frame;
-        for (uint32_t n = tid; n < frame; n += T)
+        for (int k = tid; k < H; k += T)
         {
-            const float y0 = buf[first + n].x * scale, y1 = buf[first + n + frame].x * scale;
-            const float prev = line[n + frame];
-            line[n]         = fmaf(y0, wnd[n], prev);
-            line[n + frame] = y1 * wnd[n + frame];
+            if (k == 0)
+                buf[0] = make_float2(sp[0].x, sp[H].x);
+            else
+            {
+                const float2 a = sp[k], c = sp[N - k];
+                buf[k] = make_float2(0.5f * (a.x + c.x), 0.5f * (a.y - c.y));
+            }
         }
+        __syncthreads();
+        rf.inverse(buf, scr, tid);
+        float2 *line = reinterpret_cast<float2 *>(line0 + size_t(ch) * line_pitch);
+        const uint32_t first = uint32_t(H) - frame;                    // the last 2*frame samples, in pairs
+        overlap_add(line, reinterpret_cast<const float2 *>(wnd), frame, tid, T, 1.0f / float(N),
+                    [&](uint32_t m) { return buf[first + m]; });
     }
 
     // the streaming side of process(): new samples into the analysis buffers, finished samples out of the lines
@@ -310,7 +313,8 @@ namespace
             case 9:  { CALL(9);  break; }               \
             case 10: { CALL(10); break; }               \
             case 11: { CALL(11); break; }               \
-            default: { CALL(12); break; }               \
+            case 12: { CALL(12); break; }               \
+            default: { CALL(13); break; }               \
         }
 
     int splitter_hop(mi_splitter_bank *b, hipStream_t st)
@@ -347,20 +351,9 @@ namespace
             if (!b->has_sink[i])
                 continue;
             float *line0 = b->d_lines + size_t(i) * b->channels * b->pitch;
-            #define MI_CALL(LN) hipLaunchKernelGGL((splitter_inverse_kernel<LN>), grid, dim3(plan<LN>::T), 0, st, \
+            #define MI_CALL(LH) hipLaunchKernelGGL((splitter_inverse_kernel<LH>), grid, dim3(plan<LH>::T), 0, st, \
                 line0, b->pitch, b->d_tmp, b->d_wnd, frame, b->d_tw)
-            switch (b->rank)
-            {
-                case 5:  { MI_CALL(5);  break; }
-                case 6:  { MI_CALL(6);  break; }
-                case 7:  { MI_CALL(7);  break; }
-                case 8:  { MI_CALL(8);  break; }
-                case 9:  { MI_CALL(9);  break; }
-                case 10: { MI_CALL(10); break; }
-                case 11: { MI_CALL(11); break; }
-                case 12: { MI_CALL(12); break; }
-                default: { MI_CALL(13); break; }
-            }
+            MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
         }
@@ -388,7 +381,7 @@ int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_splitter_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0 && handlers > 0, MI_EINVAL, "mi_splitter_bank_create: no channels or handlers");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 13, MI_EINVAL, "mi_splitter_bank_create: max_rank %u outside 5..13", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 14, MI_EINVAL, "mi_splitter_bank_create: max_rank %u outside 5..14", max_rank);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_splitter_bank *b = new (std::nothrow) mi_splitter_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_splitter_bank_create: out of host memory");

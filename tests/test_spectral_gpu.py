@@ -47,7 +47,7 @@ def test_reference_utest_spectral_proc(gpu):
     assert np.abs(y[0, lat:] - src[0, :n - lat]).max() <= 1e-5
 
 
-@pytest.mark.parametrize("rank", [5, 6, 8, 9, 11, 12])
+@pytest.mark.parametrize("rank", [5, 6, 8, 9, 11, 12, 13, 14])
 @pytest.mark.parametrize("step", [97, 4096])
 def test_mask_operation_matches_oracle_callback(gpu, rank, step):
     """Fused gain mask == the reference with a callback that multiplies every bin k and N-k by mask[k]."""
@@ -57,13 +57,13 @@ def test_mask_operation_matches_oracle_callback(gpu, rank, step):
     x = rng.standard_normal((C, n)).astype(np.float32)
     masks = rng.uniform(0.0, 2.0, (C, H + 1)).astype(np.float32)
 
-    y, _ = run_spectral(gpu, x, 12, rank, split(n, step), setup=lambda b: b.bind_mask(masks), phase=0.3)
+    y, _ = run_spectral(gpu, x, max(12, rank), rank, split(n, step), setup=lambda b: b.bind_mask(masks), phase=0.3)
     for c in range(C):
         full = np.concatenate([masks[c], masks[c][H - 1:0:-1]]).astype(np.float32)      # N gains, Hermitian
         def cb(spec, r, full=full):
             out = spec.copy(); out[0::2] *= full; out[1::2] *= full
             return out
-        p = sp.SpectralProcessor(12); p.set_phase(0.3); p.set_rank(rank); p.bind(cb)
+        p = sp.SpectralProcessor(max(12, rank)); p.set_phase(0.3); p.set_rank(rank); p.bind(cb)
         ref = p.process(x[c])
         peak = max(np.abs(ref).max(), 1e-30)
         assert np.abs(y[c] - ref).max() <= TOL * peak, (rank, c, np.abs(y[c] - ref).max() / peak)
@@ -268,3 +268,51 @@ def test_lazy_transform_timing_and_analysis_only_calls(gpu):
     bank2.process(gpu.DeviceBuffer((1, frame)), gpu.DeviceBuffer.from_host(x[:, :frame]), frame)
     assert len(seen) == 2 and bank2.get()["remaining"] == frame
     bank.close(); bank2.close()
+
+
+@pytest.mark.parametrize("rank", [13, 14])
+def test_largest_frames_through_the_callback_path(gpu, rank):
+    """8192- and 16384-sample frames: 64 / 128 KiB of LDS per workgroup; the way back from the callback is a real
+    transform of the spectrum's Hermitian part."""
+    n = 3 * (1 << rank) + 100
+    rng = np.random.default_rng(13)
+    x = rng.standard_normal((2, n)).astype(np.float32)
+    calls = []
+    bank = gpu.SpectralBank(2, rank)
+    bank.bind(lambda p, r, c, s: calls.append((r, c)))        # identity: the spectrum goes back as it came
+    out = gpu.DeviceBuffer((2, n))
+    bank.process(out, gpu.DeviceBuffer.from_host(x), n)
+    y = out.download()
+    assert calls and calls[0] == (rank, 2)
+    for c in range(2):
+        p = sp.SpectralProcessor(rank); p.bind(lambda s, r: s)
+        ref = p.process(x[c])
+        assert np.abs(y[c] - ref).max() <= TOL * float(np.abs(ref).max())
+    bank.close()
+
+
+def test_analyzer_rank_14(gpu):
+    """16384-point spectra (the largest frame: 128 KiB of LDS per workgroup) against the oracle."""
+    sr, rank, C = 48000, 14, 2
+    rng = np.random.default_rng(14)
+    n = 40000
+    t = np.arange(n)
+    x = (0.2 * rng.standard_normal((C, n)) + np.sin(2 * np.pi * 997.0 * t / sr)[None, :]).astype(np.float32)
+    o = sp.Analyzer(C, rank, sr, 1.0, 0)
+    o.configure(sample_rate=sr, rate=4.0, rank=rank, window_name="hann", reactivity=0.1, shift=1.0)
+    bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+    for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, 4.0), (bank.RANK, rank), (bank.WINDOW, 0),
+                    (bank.REACTIVITY, 0.1), (bank.SHIFT, 1.0)):
+        bank.configure(what, v)
+    idx = np.arange(0, 8193, dtype=np.uint32)
+    pos = 0
+    for c in (12000, 12000, 16000):
+        o.process(x[:, pos:pos + c])
+        bank.process(gpu.DeviceBuffer.from_host(x[:, pos:pos + c]), c)
+        pos += c
+    got = bank.get_spectrum(idx); ref = o.get_spectrum(idx)
+    assert bank.info()["bins"] == 8193
+    peak = float(np.abs(ref).max())
+    assert np.abs(got - ref).max() <= TOL * peak
+    assert abs(int(np.argmax(ref[0])) - round(997.0 * (1 << rank) / sr)) <= 1
+    bank.close()

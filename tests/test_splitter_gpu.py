@@ -68,7 +68,7 @@ def _gpu_run(gpu, rank, chunk, phase, handlers, x, calls, max_rank=None):
 
 @pytest.mark.parametrize("rank,chunk,phase,calls", [
     (5, 0, 0.0, (300,)), (8, 0, 0.0, (1000, 24)), (9, 7, 0.0, (100, 3, 700, 197)), (10, 8, 0.5, (333, 1667)),
-    (12, 10, 0.0, (8192, 5000)), (13, 0, 0.25, (20000,)), (12, 5, 1.0, (6000,)),
+    (12, 10, 0.0, (8192, 5000)), (13, 0, 0.25, (20000,)), (12, 5, 1.0, (6000,)), (14, 12, 0.0, (40000,)),
 ])
 def test_masks_and_copy_handlers_match_oracle(gpu, rank, chunk, phase, calls):
     """Several bands in one pass: a shared symmetric mask, per-channel masks, an ASYMMETRIC real mask (only the real part
@@ -191,7 +191,7 @@ def test_argument_errors(gpu):
     with pytest.raises(gpu.MiError):
         gpu.SplitterBank(1, 4, 1)
     with pytest.raises(gpu.MiError):
-        gpu.SplitterBank(1, 14, 1)
+        gpu.SplitterBank(1, 15, 1)
     bank = gpu.SplitterBank(1, 8, 2)
     with pytest.raises(gpu.MiError):
         bank.bind_copy(2)
