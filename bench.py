@@ -313,7 +313,8 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                                "per-bin sum over all channels (all-reduce of %d x %d floats per %d frames)"
                                % (C, batch, bins, batch), "channels_per_gpu": C},
         "roofline": {"bound": "hbm", "achieved": round(frame_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(frame_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                     "unit": "GB/s", "frac": round(frame_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                     "traffic": _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None,
                      "kernel": "analyzer_kernel<11>", "kernel_avg_us": round(avg_ms * 1e3, 3),
                      "algorithmic_bytes_per_launch": frame_bytes},
         "whole_step": {"algorithmic_bytes": frame_bytes,

@@ -334,42 +334,46 @@ namespace
         }
     }
 
-    // Per-bin reduction over channels (the C5 callback), deterministic: a workgroup owns 64 bins; its 16 waves sum
-    // channels w, w+16, w+32, ... (256-B coalesced rows), then the 16 partial sums are added in wave order.
-    constexpr uint32_t REDUCE_BINS = 64, REDUCE_WAVES = 16;
+    // Per-bin reduction over channels (the C5 callback), deterministic and in one launch.  A workgroup owns 16 bins (one
+    // 64-byte segment of every channel row): a wave reads that segment of four channels at once, the 16 waves cover 64
+    // channels per pass with sixteen passes in flight; then the 64 partial sums of a bin are added in a fixed order.
+    // Narrow workgroups instead of 64-bin ones because 2049 bins would otherwise be 33 workgroups on 256 CUs.
+    constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16;
 
-    __global__ __launch_bounds__(REDUCE_BINS * REDUCE_WAVES)
+    __global__ __launch_bounds__(64 * REDUCE_WAVES)
     void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins,
                            const float *__restrict__ env)
     {
-        __shared__ float part[REDUCE_WAVES][REDUCE_BINS];
-        const uint32_t lane = threadIdx.x & (REDUCE_BINS - 1), w = threadIdx.x / REDUCE_BINS;
-        const uint32_t k = blockIdx.x * REDUCE_BINS + lane;
+        __shared__ float part[REDUCE_WAVES * REDUCE_ROWS][REDUCE_BINS];
+        const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint32_t b = lane & (REDUCE_BINS - 1), r = lane / REDUCE_BINS;
+        const uint32_t k = blockIdx.x * REDUCE_BINS + b;
+        constexpr uint32_t STEP = REDUCE_WAVES * REDUCE_ROWS;                   // channels per pass
         float s = 0.0f;
         if (k < bins)
         {
-            uint32_t c = w;
-            for (; c + 7 * REDUCE_WAVES < channels; c += 8 * REDUCE_WAVES)      // eight rows in flight
+            uint32_t c = w * REDUCE_ROWS + r;
+            for (; c + 15 * STEP < channels; c += 16 * STEP)                    // sixteen passes in flight
             {
-                float v[8];
+                float v[16];
                 #pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    v[j] = src[size_t(c + j * REDUCE_WAVES) * stride + k];
+                for (int j = 0; j < 16; ++j)
+                    v[j] = src[size_t(c + j * STEP) * stride + k];
                 #pragma unroll
-                for (int j = 0; j < 8; ++j)
+                for (int j = 0; j < 16; ++j)
                     s += v[j];
             }
-            for (; c < channels; c += REDUCE_WAVES)
+            for (; c < channels; c += STEP)
                 s += src[size_t(c) * stride + k];
         }
-        part[w][lane] = s;
+        part[w * REDUCE_ROWS + r][b] = s;
         __syncthreads();
-        if (w == 0 && k < bins)
+        if (threadIdx.x < REDUCE_BINS && k < bins)
         {
             float t = 0.0f;
             #pragma unroll
-            for (uint32_t g = 0; g < REDUCE_WAVES; ++g)
-                t += part[g][lane];
+            for (uint32_t g = 0; g < STEP; ++g)
+                t += part[g][b];
             out[k] = (env != nullptr) ? t * env[k] : t;
         }
     }
@@ -1053,7 +1057,7 @@ int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *b, float *out, int with_env
     MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_reduce_bins: bad argument");
     hipStream_t st = mi::as_stream(stream);
     const uint32_t bins = (1u << (b->rank - 1)) + 1;
-    hipLaunchKernelGGL(bin_reduce_kernel, dim3((bins + REDUCE_BINS - 1) / REDUCE_BINS), dim3(REDUCE_BINS * REDUCE_WAVES), 0, st,
+    hipLaunchKernelGGL(bin_reduce_kernel, dim3((bins + REDUCE_BINS - 1) / REDUCE_BINS), dim3(64 * REDUCE_WAVES), 0, st,
                        out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;

@@ -316,3 +316,33 @@ def test_analyzer_rank_14(gpu):
     assert np.abs(got - ref).max() <= TOL * peak
     assert abs(int(np.argmax(ref[0])) - round(997.0 * (1 << rank) / sr)) <= 1
     bank.close()
+
+
+def test_reduce_bins_many_channels(gpu):
+    """The per-bin reduction with more channels than one pass of a workgroup covers, and a channel count that is not a
+    multiple of it.  Every channel carries the same stationary signal (sines on bin centres: the magnitude spectrum does
+    not depend on where the window sits) at its own gain, so the sum over channels is known from a small bank."""
+    sr, rank, n = 48000, 8, 1500
+    N = 1 << rank
+    t = np.arange(n)
+    base = sum(a * np.sin(2 * np.pi * k * t / N + ph) for a, k, ph in ((0.5, 5, 0.1), (0.25, 33, 1.0), (0.125, 90, 2.0))).astype(np.float32)
+    outs = {}
+    for C in (16, 645):
+        gains = (1.0 + (np.arange(C) % 7)).astype(np.float32)
+        x = (base[None, :] * gains[:, None]).astype(np.float32)
+        bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+        for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, 50.0), (bank.RANK, rank), (bank.WINDOW, 0),
+                        (bank.REACTIVITY, 0.0), (bank.SHIFT, 1.0)):
+            bank.configure(what, v)
+        bank.process(gpu.DeviceBuffer.from_host(x), n)
+        res = []
+        for rep in range(3):
+            out = gpu.DeviceBuffer((129,))
+            bank.reduce_bins(out, with_envelope=(rep == 2))
+            res.append(out.download())
+        np.testing.assert_array_equal(res[0], res[1])        # same order of additions every time
+        outs[C] = (res[0] / gains.sum(), res[2] / gains.sum())
+        bank.close()
+    for a, b in zip(outs[16], outs[645]):
+        assert float(a.max()) > 0
+        assert np.abs(a - b).max() <= 1e-4 * float(a.max())     # the Hann window of windows.cpp is not exactly periodic
