@@ -750,7 +750,7 @@ struct mi_analyzer_bank
     uint32_t    reconfigure = 0x1f;
     std::vector<uint32_t> user_delay, delay;
     std::vector<uint8_t>  ch_active, ch_freeze;
-    float      *d_ring = nullptr, *d_amp = nullptr, *d_data = nullptr, *d_wnd = nullptr, *d_env = nullptr, *d_part = nullptr;
+    float      *d_ring = nullptr, *d_amp = nullptr, *d_data = nullptr, *d_wnd = nullptr, *d_env = nullptr;
     uint32_t   *d_delay = nullptr;
     uint8_t    *d_flags = nullptr;
     const float2 *d_tw = nullptr;
@@ -910,7 +910,7 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
     if (b == nullptr)
         return MI_OK;
     (void)hipFree(b->d_ring); (void)hipFree(b->d_amp); (void)hipFree(b->d_data); (void)hipFree(b->d_wnd);
-    (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags); (void)hipFree(b->d_part);
+    (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
     delete b;
     return MI_OK;
 }
