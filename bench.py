@@ -86,6 +86,22 @@ def _pmc_traffic(name):
         return None
 
 
+def _profile_avg_us(workload, kernel):
+    """Average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary (profiles/), or None.
+    rocprofv3 stamps a dispatch from the moment its packet is picked up, so with back-to-back launches its figure is the
+    step period (kernel + dispatch gap); the live HIP events bracket the execution only."""
+    import csv
+    import glob
+    try:
+        fn = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_kernel_stats.csv" % workload)))[-1]
+        for row in csv.DictReader(open(fn)):
+            if kernel in row["Name"]:
+                return round(float(row["AverageNs"]) / 1e3, 3)
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline_convolver(irs, frame, budget_s=4.0):
     """Oracle Convolver (restated reference algorithm: non-uniform partitions, scalar C) on this host's cores:
     one object per channel, whole 4096-sample frames, as many channels as fit in ~budget_s."""
@@ -161,7 +177,8 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("pmc_convolver_latest.json") if C == 256 else None,
                      "kernel": "conv_mac_kernel",
                      "kernel_avg_us": round(avg_ms * 1e3, 3), "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3),
-                     "algorithmic_bytes_per_launch": mac_bytes},
+                     "algorithmic_bytes_per_launch": mac_bytes,
+                     "rocprofv3_avg_us": _profile_avg_us("convolver", "conv_mac_kernel") if C == 256 else None},
         "whole_step": {"algorithmic_bytes": step_bytes,
                        "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / steps) / 1e9, 1),
                        "frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -421,6 +438,7 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "kernel": "biquad_bank_kernel<16,2>", "kernel_avg_us": round(avg_kernel_ms * 1e3, 3),
                 "kernel_median_us": round(med_kernel_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes,
+                "rocprofv3_avg_us": _profile_avg_us("biquad", "biquad_bank_kernel<16, 2") if (C, n) == (1024, 4096) else None,
             },
         }
         if not args.no_cpu_baseline:
