@@ -95,6 +95,10 @@ class BiquadBank:
         arr, n = _chains(coefs)
         check(lib.mi_biquad_bank_set_chains(self.handle, channel, arr, n, int(clear)))
 
+    def set_row_enabled(self, channel, enabled=True):
+        """A channel that is switched off is skipped by process(): state kept, output row not written."""
+        check(lib.mi_biquad_bank_set_row_enabled(self.handle, channel, 1 if enabled else 0))
+
     def set_all_chains(self, coefs, clear=False):
         c = np.ascontiguousarray(coefs, dtype=np.float32)
         assert c.ndim == 3 and c.shape[0] == self.channels and c.shape[2] == 5

@@ -173,6 +173,38 @@ def test_clear_and_reset_semantics(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("n", [4096, 1000, 37])
+def test_rows_switched_off_keep_state_and_output(gpu, n):
+    """mi_biquad_bank_set_row_enabled: what a caller of the reference gets by not calling FilterBank::process() for an
+    object -- every launch variant (L = 16 / 8, the tail kernel) leaves the row's delay memory and its output alone."""
+    C = 5
+    rng = np.random.default_rng(n)
+    x = rng.standard_normal((C, 2 * n)).astype(np.float32)
+    bank = gpu.BiquadBank(C, 8)
+    coef = wl.design(fd.FLT_BT_LRX_LOPASS, 4, 1500.0, 0, 1.0, 0.7)
+    for c in range(C):
+        bank.set_chains(c, coef)
+    out = gpu.DeviceBuffer((C, n))
+    bank.process(out, gpu.DeviceBuffer.from_host(x[:, :n]), n)
+    st = bank.get_state()
+    bank.set_row_enabled(1, False); bank.set_row_enabled(3, False)
+    marked = np.full((C, n), -5.0, np.float32)
+    out2 = gpu.DeviceBuffer.from_host(marked)
+    bank.process(out2, gpu.DeviceBuffer.from_host(x[:, n:]), n)
+    y2 = out2.download(); st2 = bank.get_state()
+    for c in (1, 3):
+        assert np.all(y2[c] == -5.0)
+        np.testing.assert_array_equal(st2[c], st[c])
+    for c in (0, 2, 4):
+        r, _ = oracle.biquad_cascade(x[c], coef)
+        assert_iir_parity(y2[c], r[n:], oracle.biquad_cascade_f64(x[c], coef)[n:])
+    bank.set_row_enabled(1, True)                             # back on: continues from the memory it kept
+    bank.process(out2, gpu.DeviceBuffer.from_host(x[:, n:]), n)
+    r, _ = oracle.biquad_cascade(x[1], coef)
+    assert_iir_parity(out2.download()[1], r[n:], oracle.biquad_cascade_f64(x[1], coef)[n:])
+    bank.close()
+
+
 def test_impulse_response_restores_state(gpu):
     """FilterBank::impulse_response (FilterBank.cpp:293-330)."""
     bq = wl.design(fd.FLT_BT_LRX_LOPASS, 2, 2000.0, 0, 1.0, 0.0)
