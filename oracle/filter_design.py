@@ -138,7 +138,8 @@ class _Designer:
 
     def _bilinear_relative(self, f1, f2):
         nf = F(C_PI / F(self.sr))
-        return F(tanf(F(f1 * nf)) / tanf(F(f2 * nf)))
+        with np.errstate(divide="ignore", invalid="ignore"):       # f2 == 0 divides by zero exactly as the C++ does
+            return F(tanf(F(f1 * nf)) / tanf(F(f2 * nf)))
 
     # -- dispatch (Filter.cpp:208-403) --------------------------------------
     def run(self):

@@ -75,8 +75,9 @@ def window(n, name):
         c = F((n - 1) * 0.5)
         return np.array([F(F(1.0) - abs(F(F(F(i) - c) * l))) for i in range(n)], np.float32)
     if name == "welch":
-        c = F(F(n - 1) * F(0.5)); mc = F(F(1.0) / c)
-        t = [F(F(F(i) - c) * mc) for i in range(n)]
+        with np.errstate(divide="ignore", invalid="ignore"):       # n == 1: 1 / 0 and 0 * inf, as in the C++
+            c = F(F(n - 1) * F(0.5)); mc = F(F(1.0) / c)
+            t = [F(F(F(i) - c) * mc) for i in range(n)]
         return np.array([F(F(1.0) - F(x * x)) for x in t], np.float32)
     raise KeyError(name)
 
