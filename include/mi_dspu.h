@@ -288,18 +288,25 @@ typedef struct mi_convolver_bank mi_convolver_bank_t;
  */
 int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, const float *irs, size_t ir_stride,
                              const uint32_t *counts, uint32_t count, uint32_t rank, float phase, void *stream);
-/* Replace every channel's impulse response by `count` taps read from DEVICE memory [channels][ir_stride]
- * (count within the capacity the bank was created with); input history is kept.  Used by the equalizer bank
- * when it retunes (the reference re-parses its FIR the same way, Equalizer.cpp:342-345). Synchronises `stream`. */
-int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count, void *stream);
+/* Replace the impulse response of the named channels (`channels`: HOST flags, NULL = every channel) by `count` taps read
+ * from DEVICE memory [channels][ir_stride] (count within the capacity the bank was created with); input history is kept.
+ * Used by the equalizer bank when it retunes (the reference re-parses its FIR the same way, Equalizer.cpp:342-345).
+ * Single-partition banks (taps <= frame) take the new response at the next frame boundary: the frame being received keeps
+ * the one it began with.  Synchronises `stream`. */
+int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count,
+                                     const uint8_t *channels, void *stream);
 /*
- * Single-partition banks (taps <= frame): the new responses wait for the next frame boundary and are cross-faded in
- * over that frame -- weight of the new response 0 up to B/2, a linear ramp over the next B output positions of the
- * frame's 2B-long result, 1 after that (what Equalizer::process does for a "smooth" retune, Equalizer.cpp:486-501).
- * A second call before the boundary replaces the waiting responses.  mi_convolver_bank_set_irs_device() in the middle
- * of a frame likewise takes effect at the boundary (without a fade).
+ * Single-partition banks: the new responses of the named channels wait for the next frame boundary and are cross-faded in
+ * over that frame -- weight of the new response 0 up to B/2, a linear ramp over the next B output positions of the frame's
+ * 2B-long result, 1 after that (what Equalizer::process does for a "smooth" retune, Equalizer.cpp:486-501).  Every
+ * channel behaves like one reference Equalizer object with its vConv, vNewConv and EF_XFADE: a later call for a channel
+ * that is still waiting replaces its target; a channel that is not named takes no part (the reference's cross-fade is not a
+ * no-op for an unchanged response -- it also scales the overlap tail of the previous blocks, Equalizer.cpp:496,499);
+ * mi_convolver_bank_set_irs_device() for a waiting channel changes the response the fade starts from, not its target
+ * (after the fade the target, i.e. the older request, is in force -- Equalizer.cpp:491).
  */
-int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count, void *stream);
+int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count,
+                                           const uint8_t *channels, void *stream);
 /* Convolver::destroy(), Convolver.cpp:71-75. */
 int mi_convolver_bank_destroy(mi_convolver_bank_t *bank);
 /* Forget all input history (state right after init). */

@@ -102,8 +102,8 @@ PROTOTYPES = {
     "mi_analyzer_bank_get_spectrum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32, c_void_p]),
     "mi_analyzer_bank_reduce_bins": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "mi_analyzer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
-    "mi_convolver_bank_set_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
-    "mi_convolver_bank_crossfade_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p]),
+    "mi_convolver_bank_set_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p]),
+    "mi_convolver_bank_crossfade_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p]),
     "mi_spectral_bank_set_windows": (c_int, [c_void_p, c_int, c_int]),
     "mi_equalizer_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32]),
     "mi_equalizer_bank_destroy": (c_int, [c_void_p]),

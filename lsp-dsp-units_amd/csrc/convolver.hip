@@ -76,11 +76,13 @@ namespace
     template <int LOGM>
     __global__ __launch_bounds__(plan<LOGM>::T)
     void conv_parse_kernel(float2 *H, const float *ir, size_t ir_stride, const uint32_t *__restrict__ counts,
-                           int P, const float2 *__restrict__ tw)
+                           int P, const float2 *__restrict__ tw, const uint8_t *__restrict__ only /* or NULL: every channel */)
     {
         constexpr int M = plan<LOGM>::N;
         __shared__ float2 buf[M], scr[M];
         const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+        if (only != nullptr && only[ch] == 0)
+            return;
         real_fft<LOGM> rf;
         rf.load(tw, TWN, tid);
         rf.prepare();
@@ -325,6 +327,16 @@ namespace
         }
     }
 
+    // rows of the named channels (all when `only` is NULL) from one [channels][n] array to another
+    __global__ __launch_bounds__(256)
+    void conv_copy_rows_kernel(float *dst, const float *src, size_t dst_pitch, size_t src_pitch, uint32_t n,
+                               const uint8_t *__restrict__ only)
+    {
+        const uint32_t ch = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+        if (i < n && (only == nullptr || only[ch] != 0))
+            dst[size_t(ch) * dst_pitch + i] = src[size_t(ch) * src_pitch + i];
+    }
+
     // ---- one-frame cross-fade between two impulse responses (Equalizer "smooth" retune, Equalizer.cpp:486-501) ----------
     // Weight of the NEW response at position n of the frame's 2B-long result: 0 before B/2, a linear ramp i/B over the
     // next B positions (dsp::lramp1 / lramp_add2 with delta = 1/B), 1 from 3B/2 on; the old response gets 1 - that.
@@ -339,7 +351,7 @@ namespace
     __global__ __launch_bounds__(plan<LOGM>::T)
     void conv_xfade_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                                  const float2 *__restrict__ Hold, const float2 *__restrict__ Hnew, float *acc,
-                                 const float2 *__restrict__ tw)
+                                 const float2 *__restrict__ tw, const uint8_t *__restrict__ xmask)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T;
@@ -382,7 +394,9 @@ namespace
         {
             const int m = tid + i * T;                          // samples 2m, 2m+1 of the 2B-long result
             const float2 yn = buf[m];
-            const float w0 = xfade_new_weight(2 * m, B), w1 = xfade_new_weight(2 * m + 1, B);
+            // a channel that takes no part in this cross-fade (its response did not change) keeps the old weights
+            const bool fades = xmask[ch] != 0;
+            const float w0 = fades ? xfade_new_weight(2 * m, B) : 0.0f, w1 = fades ? xfade_new_weight(2 * m + 1, B) : 0.0f;
             if (m < M / 2)                                      // first half: out = acc + y, acc <- next half
             {
                 // the reference ramps its output buffer down, i.e. the old result TOGETHER WITH the overlap tail of the
@@ -406,17 +420,18 @@ namespace
     // start of a cross-fade frame that arrives in pieces: the overlap tail already in acc fades with the old response
     // (see conv_xfade_frame_kernel), once
     __global__ __launch_bounds__(256)
-    void conv_xfade_prescale_kernel(float *acc, int B)
+    void conv_xfade_prescale_kernel(float *acc, int B, const uint8_t *__restrict__ xmask)
     {
         const int ch = blockIdx.y, n = B / 2 + blockIdx.x * 256 + threadIdx.x;
-        if (n < B)
+        if (n < B && xmask[ch] != 0)
             acc[size_t(ch) * 2 * B + n] *= 1.0f - xfade_new_weight(n, B);
     }
 
     // partial call inside the cross-fade frame: both head responses in the time domain, mixed by output position
     __global__ __launch_bounds__(256)
     void conv_direct_xfade_kernel(float *out, size_t out_stride, float *acc, const float *frame,
-                                  const float *__restrict__ h0_old, const float *__restrict__ h0_new, int B, int off, int cnt)
+                                  const float *__restrict__ h0_old, const float *__restrict__ h0_new, int B, int off, int cnt,
+                                  const uint8_t *__restrict__ xmask)
     {
         extern __shared__ float sxin[];                         // cnt samples of this call
         const int ch = blockIdx.y, tid = threadIdx.x;
@@ -436,7 +451,7 @@ namespace
             so = fmaf(sxin[j], ho[i - j], so);
             sn = fmaf(sxin[j], hn[i - j], sn);
         }
-        const float w = xfade_new_weight(off + i, B);
+        const float w = (xmask[ch] != 0) ? xfade_new_weight(off + i, B) : 0.0f;
         float *a = acc + size_t(ch) * 2 * B + off + i;
         const float v = *a + (so * (1.0f - w) + sn * w);
         *a = v;
@@ -493,14 +508,26 @@ struct mi_convolver_bank
     bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
-    // A response that takes over at the next frame boundary: plainly (a replacement that arrived in the middle of a
-    // frame) or cross-faded over that frame (mi_convolver_bank_crossfade_irs_device).  Single-partition banks only.
-    float2     *d_Hx = nullptr, *d_Hy = nullptr;   // x: target of the active cross-fade or the waiting response;
-    float      *d_h0x = nullptr, *d_h0y = nullptr; // y: a response that arrived while x was busy cross-fading
-    bool        pending_in_y = false;
-    enum { PEND_NONE = 0, PEND_REPLACE = 1, PEND_XFADE = 2 };
-    int         pending = PEND_NONE;
-    bool        xfade_active = false;   // the frame being received is the cross-fade frame
+    // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
+    // way a reference Equalizer object does (Equalizer.cpp:339-345,481-501): every object has a response in force (vConv),
+    // a cross-fade target (vNewConv) and a flag that the target waits for the block that completes next (EF_XFADE).
+    //   set_irs      -> vConv of the named channels            crossfade_irs -> vNewConv of the named channels + flag
+    //   a block completes: it is convolved with vConv; flagged channels fade to vNewConv, which becomes their vConv.
+    // A frame of this convolver is the reference's block on its way through, so it uses what was in force when it began:
+    // responses live in a pool of four buffers, `cv` / `nv` are the ones standing for vConv / vNewConv, and the frame being
+    // received keeps d_H / d_h0 (old) and d_Hx / d_h0x (new, cross-fade frames only) whatever arrives meanwhile.
+    struct response { float2 *H = nullptr; float *h0 = nullptr; };
+    response    pool[4];
+    int         cv = 0, nv = 0;             // pool index of vConv / vNewConv
+    int         fr_old = 0, fr_new = -1;    // pool indices the open frame uses
+    bool        frame_open = false;         // the frame's first samples have been taken (or its whole)
+    std::vector<uint8_t> xf_wait;           // EF_XFADE per channel
+    bool        xf_any = false;
+    float2     *d_Hx = nullptr;             // = pool[fr_new] in a cross-fade frame
+    float      *d_h0x = nullptr;
+    bool        xfade_active = false;       // the frame being received is a cross-fade frame
+    uint8_t    *d_xmask = nullptr;          // ... for these channels
+    uint8_t    *d_only = nullptr;           // scratch: channel selection of a parse
     const float2 *d_tw = nullptr;
     std::vector<uint32_t> counts;
 };
@@ -552,14 +579,30 @@ namespace mi
 {
     bool convolver_takes_delayed_frame(const mi_convolver_bank_t *b, size_t samples)
     {
-        return b != nullptr && b->live && b->off == 0 && samples == size_t(b->B) && !b->xfade_active &&
-               b->pending == mi_convolver_bank::PEND_NONE;
+        return b != nullptr && b->live && b->off == 0 && samples == size_t(b->B) && !b->xfade_active && !b->xf_any;
+    }
+
+    // EF_XFADE is dropped without having happened (Equalizer.cpp:250,264,356: the equalizer left its FIR modes)
+    void convolver_cancel_crossfade(mi_convolver_bank_t *b, const uint8_t *channels)
+    {
+        if (b == nullptr || !b->xf_any)
+            return;
+        bool left = false;
+        for (uint32_t c = 0; c < b->channels; ++c)
+        {
+            if (channels == nullptr || channels[c] != 0)
+                b->xf_wait[c] = 0;
+            left = left || (b->xf_wait[c] != 0);
+        }
+        b->xf_any = left;
     }
 
     int convolver_process_delayed_frame(mi_convolver_bank_t *b, float *out, const float *in, size_t out_stride,
                                         size_t in_stride, const delay_view &dl, hipStream_t st)
     {
         MI_REQUIRE(convolver_takes_delayed_frame(b, size_t(b->B)), MI_ESTATE, "convolver_process_delayed_frame: not at a plain frame boundary");
+        b->d_H = b->pool[b->cv].H;                                      // the response in force as the frame begins
+        b->d_h0 = b->pool[b->cv].h0;
         const uint32_t tail = (dl.head + dl.size - dl.delay) % dl.size;
         MI_REQUIRE((dl.size % 2 == 0) && (tail % 2 == 0) && (dl.head % 2 == 0) && dl.delay >= uint32_t(b->B) &&
                    size_t(dl.size - dl.delay) >= size_t(b->B), MI_EINVAL, "convolver_process_delayed_frame: delay line geometry");
@@ -596,6 +639,7 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     b->rank     = (rank < 8) ? 8 : (rank > 16) ? 16 : rank;             // CONVOLVER_RANK_MIN/MAX
     b->phase    = phase;
     b->counts.assign(channels, count);
+    b->xf_wait.assign(channels, 0);
     uint32_t longest = 0;
     for (uint32_t c = 0; c < channels; ++c)
     {
@@ -649,7 +693,7 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     if (e == hipSuccess)
     {
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, channels), dim3(plan<LM>::T), 0, st, \
-                                               b->d_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw)
+                                               b->d_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw, (const uint8_t *)nullptr)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         e = hipGetLastError();
@@ -657,6 +701,8 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_ir);
     (void)hipFree(d_counts);
+    b->pool[0].H = b->d_H;
+    b->pool[0].h0 = b->d_h0;
     if (e != hipSuccess)
     {
         mi_convolver_bank_destroy(b);
@@ -666,11 +712,21 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     return mi_convolver_bank_reset(b, stream);
 }
 
-// parse `count` taps per channel (device rows) into partition images at dst_H and the head taps at dst_h0
+// parse `count` taps per channel (device rows) into partition images at dst_H and the head taps at dst_h0; `only`
+// (HOST flags, NULL = every channel) limits the update to the named channels, the others keep their rows
 static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count, float2 *dst_H,
-                     float *dst_h0, hipStream_t st)
+                     float *dst_h0, const uint8_t *only, hipStream_t st)
 {
     const size_t M = size_t(b->B);
+    const uint8_t *d_only = nullptr;
+    if (only != nullptr)
+    {
+        if (b->d_only == nullptr)
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_only), b->channels));
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_only, only, b->channels, hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        d_only = b->d_only;
+    }
     // zero-padded staging rows [channels][P*B], then the same parse kernel as init
     float *d_ir = nullptr;
     uint32_t *d_counts = nullptr;
@@ -681,12 +737,16 @@ static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_strid
     if (e == hipSuccess) e = hipMemcpy2DAsync(d_ir, size_t(b->P) * M * sizeof(float), d_irs, ir_stride * sizeof(float),
                                               size_t(count) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_counts, cnt.data(), cnt.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemcpy2DAsync(dst_h0, M * sizeof(float), d_ir, size_t(b->P) * M * sizeof(float),
-                                              M * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st);
+    if (e == hipSuccess)
+    {
+        hipLaunchKernelGGL(conv_copy_rows_kernel, dim3(unsigned((M + 255) / 256), b->channels), dim3(256), 0, st,
+                           dst_h0, d_ir, M, size_t(b->P) * M, uint32_t(M), d_only);
+        e = hipGetLastError();
+    }
     if (e == hipSuccess)
     {
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, b->channels), dim3(plan<LM>::T), 0, st, \
-                                               dst_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw)
+                                               dst_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw, d_only)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         e = hipGetLastError();
@@ -694,69 +754,116 @@ static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_strid
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_ir);
     (void)hipFree(d_counts);
-    MI_HIP_CHECK(e);
+    if (e != hipSuccess)
+        return mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "convolver: parsing impulse responses: %s", hipGetErrorString(e));
     return MI_OK;
 }
 
-static int ensure_pending_buffers(mi_convolver_bank_t *b)
+namespace
 {
-    const size_t M = size_t(b->B);
-    if (b->d_Hx == nullptr)
-        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_Hx), size_t(b->channels) * b->P * M * sizeof(float2)));
-    if (b->d_h0x == nullptr)
-        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_h0x), size_t(b->channels) * M * sizeof(float)));
-    if (b->d_Hy == nullptr)
-        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_Hy), size_t(b->channels) * b->P * M * sizeof(float2)));
-    if (b->d_h0y == nullptr)
-        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_h0y), size_t(b->channels) * M * sizeof(float)));
-    return MI_OK;
+    bool used_by_frame(const mi_convolver_bank *b, int idx)
+    {
+        return b->frame_open && (idx == b->fr_old || (b->xfade_active && idx == b->fr_new));
+    }
+
+    // A pool buffer that vConv (which == 0) or vNewConv (which == 1) may be written into: its own one when nobody else
+    // holds it, otherwise a free one that starts as a copy of `base` (so that the channels a call does not name keep
+    // their rows).  Four buffers always leave one free: the open frame holds at most two, the other slot one.
+    int writable_response(mi_convolver_bank *b, int which, int base, hipStream_t st, int *out)
+    {
+        const int own = which ? b->nv : b->cv, other = which ? b->cv : b->nv;
+        int idx = own;
+        if (own == other || used_by_frame(b, own))
+        {
+            idx = -1;
+            for (int i = 0; i < 4 && idx < 0; ++i)
+                if (i != own && i != other && !used_by_frame(b, i))
+                    idx = i;
+            MI_REQUIRE(idx >= 0, MI_ESTATE, "convolver: no free response buffer");
+        }
+        const size_t M = size_t(b->B), nH = size_t(b->channels) * b->P * M, nh = size_t(b->channels) * M;
+        if (b->pool[idx].H == nullptr)
+        {
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->pool[idx].H), nH * sizeof(float2)));
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->pool[idx].h0), nh * sizeof(float)));
+        }
+        if (idx != base)
+        {
+            MI_HIP_CHECK(hipMemcpyAsync(b->pool[idx].H, b->pool[base].H, nH * sizeof(float2), hipMemcpyDeviceToDevice, st));
+            MI_HIP_CHECK(hipMemcpyAsync(b->pool[idx].h0, b->pool[base].h0, nh * sizeof(float), hipMemcpyDeviceToDevice, st));
+        }
+        *out = idx;
+        return MI_OK;
+    }
 }
 
-int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count, void *stream)
+int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count,
+                                     const uint8_t *channels, void *stream)
 {
     MI_REQUIRE(b != nullptr && b->live, MI_ESTATE, "mi_convolver_bank_set_irs_device: bank is not initialised");
     MI_REQUIRE(d_irs != nullptr && count > 0 && ir_stride >= count, MI_EINVAL, "mi_convolver_bank_set_irs_device: bad argument");
     MI_REQUIRE(count <= uint32_t(b->P) * uint32_t(b->B), MI_EINVAL,
                "mi_convolver_bank_set_irs_device: %u taps exceed the %d x %d the bank was created for", count, b->P, b->B);
     hipStream_t st = mi::as_stream(stream);
-    b->counts.assign(b->channels, count);
-    b->taps = count;
-    if (b->P == 1 && (b->off != 0 || b->xfade_active))
+    for (uint32_t c = 0; c < b->channels; ++c)
+        if (channels == nullptr || channels[c] != 0)
+            b->counts[c] = count;
+    b->taps = std::max(b->taps, count);
+    if (b->P > 1)                                                       // partitioned banks: in place, input history kept
+        return parse_irs(b, d_irs, ir_stride, count, b->d_H, b->d_h0, channels, st);
+    // vConv of the named channels.  The frame being received keeps the response it started with (the reference convolves a
+    // block as a whole with the response in force when the block completes, i.e. when this frame began).
+    int idx = 0;
+    int r = writable_response(b, 0, b->cv, st, &idx);
+    if (r == MI_OK)
+        r = parse_irs(b, d_irs, ir_stride, count, b->pool[idx].H, b->pool[idx].h0, channels, st);
+    if (r != MI_OK)
+        return r;
+    b->cv = idx;
+    if (b->xf_any)
     {
-        // in the middle of a frame: the frame keeps the response it started with, the new one takes over at the boundary
-        // (the reference's Equalizer convolves a block as a whole with the response in force when the block completes)
-        int r = ensure_pending_buffers(b);
-        if (r == MI_OK)
-            r = parse_irs(b, d_irs, ir_stride, count, b->xfade_active ? b->d_Hy : b->d_Hx,
-                          b->xfade_active ? b->d_h0y : b->d_h0x, st);
-        if (r != MI_OK)
-            return r;
-        b->pending_in_y = b->xfade_active;
-        b->pending = mi_convolver_bank::PEND_REPLACE;
-        return MI_OK;
+        // A cross-fade is waiting.  For the channels it is waiting for, vNewConv stays what it is -- after the fade that
+        // OLDER response is back in force (Equalizer.cpp:491: vConv <- vNewConv); the other channels have no fade ahead,
+        // their row of the fade target has to follow vConv
+        std::vector<uint8_t> follow(b->channels, 0);
+        bool any = false;
+        for (uint32_t c = 0; c < b->channels; ++c)
+            if ((channels == nullptr || channels[c] != 0) && !b->xf_wait[c])
+                any = follow[c] = 1;
+        if (any)
+            r = parse_irs(b, d_irs, ir_stride, count, b->pool[b->nv].H, b->pool[b->nv].h0, follow.data(), st);
     }
-    b->pending = mi_convolver_bank::PEND_NONE;
-    return parse_irs(b, d_irs, ir_stride, count, b->d_H, b->d_h0, st);
+    else
+        b->nv = b->cv;
+    return r;
 }
 
 int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *b, const float *d_irs, size_t ir_stride, uint32_t count,
-                                           void *stream)
+                                           const uint8_t *channels, void *stream)
 {
     MI_REQUIRE(b != nullptr && b->live, MI_ESTATE, "mi_convolver_bank_crossfade_irs_device: bank is not initialised");
     MI_REQUIRE(d_irs != nullptr && count > 0 && ir_stride >= count, MI_EINVAL, "mi_convolver_bank_crossfade_irs_device: bad argument");
     MI_REQUIRE(b->P == 1, MI_EINVAL, "mi_convolver_bank_crossfade_irs_device: only for single-partition banks (taps <= frame)");
     MI_REQUIRE(count <= uint32_t(b->B), MI_EINVAL, "mi_convolver_bank_crossfade_irs_device: %u taps exceed the frame of %d", count, b->B);
     hipStream_t st = mi::as_stream(stream);
-    int r = ensure_pending_buffers(b);
-    if (r == MI_OK)                                                             // a later call before the boundary wins
-        r = parse_irs(b, d_irs, ir_stride, count, b->xfade_active ? b->d_Hy : b->d_Hx,
-                      b->xfade_active ? b->d_h0y : b->d_h0x, st);
+    // vNewConv of the named channels; with no fade waiting yet the target starts as a copy of what is in force
+    int idx = 0;
+    int r = writable_response(b, 1, b->xf_any ? b->nv : b->cv, st, &idx);
+    if (r == MI_OK)
+        r = parse_irs(b, d_irs, ir_stride, count, b->pool[idx].H, b->pool[idx].h0, channels, st);
     if (r != MI_OK)
         return r;
-    b->counts.assign(b->channels, count);
-    b->taps = count;
-    b->pending_in_y = b->xfade_active;
-    b->pending = mi_convolver_bank::PEND_XFADE;
+    b->nv = idx;
+    for (uint32_t c = 0; c < b->channels; ++c)
+        if (channels == nullptr || channels[c] != 0)
+        {
+            b->counts[c] = count;
+            b->xf_wait[c] = 1;
+        }
+    b->taps = std::max(b->taps, count);
+    b->xf_any = true;
+    if (b->d_xmask == nullptr)
+        MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_xmask), b->channels));
     return MI_OK;
 }
 
@@ -764,9 +871,18 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
 {
     if (b == nullptr)
         return MI_OK;
-    (void)hipFree(b->d_H); (void)hipFree(b->d_ring); (void)hipFree(b->d_yt);
-    (void)hipFree(b->d_acc); (void)hipFree(b->d_frame); (void)hipFree(b->d_h0);
-    (void)hipFree(b->d_Hx); (void)hipFree(b->d_h0x); (void)hipFree(b->d_Hy); (void)hipFree(b->d_h0y);
+    if (b->pool[0].H == nullptr)                                        // creation failed before the pool took them over
+    {
+        (void)hipFree(b->d_H);
+        (void)hipFree(b->d_h0);
+    }
+    for (mi_convolver_bank::response &r : b->pool)
+    {
+        (void)hipFree(r.H);
+        (void)hipFree(r.h0);
+    }
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
+    (void)hipFree(b->d_xmask); (void)hipFree(b->d_only);
     delete b;
     return MI_OK;
 }
@@ -785,12 +901,12 @@ int mi_convolver_bank_reset(mi_convolver_bank_t *b, void *stream)
     b->slot = 0;
     b->off  = 0;
     b->yt_pending = false;
-    if (b->xfade_active)                                        // reset inside the cross-fade frame: the new response stays
-    {
-        std::swap(b->d_H, b->d_Hx);
-        std::swap(b->d_h0, b->d_h0x);
-        b->xfade_active = false;
-    }
+    // the frame being received is dropped; what is in force (and a fade that is still waiting) stays as it is: a fade that
+    // had begun was taken at the reference's block boundary, its target is the response in force already
+    b->frame_open = false;
+    b->xfade_active = false;
+    b->d_H = b->pool[b->cv].H;
+    b->d_h0 = b->pool[b->cv].h0;
     return MI_OK;
 }
 
@@ -826,35 +942,36 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
         const size_t left = samples - done;
         float *o = out + done;
         const float *x = in + done;
-        if (b->off == 0 && b->pending != mi_convolver_bank::PEND_NONE)      // frame boundary: a waiting response takes over
+        if (b->P == 1 && b->off == 0 && !b->frame_open)                     // a frame begins: the reference's block completes
         {
-            if (b->pending_in_y)                                            // (the cross-fade that kept x busy is over)
-            {
-                std::swap(b->d_Hx, b->d_Hy);
-                std::swap(b->d_h0x, b->d_h0y);
-                b->pending_in_y = false;
+            b->fr_old = b->cv;
+            b->d_H = b->pool[b->cv].H;
+            b->d_h0 = b->pool[b->cv].h0;
+            if (b->xf_any)                                                  // flagged channels fade to vNewConv across this frame,
+            {                                                               // which is their vConv from now on
+                b->fr_new = b->nv;
+                b->d_Hx = b->pool[b->nv].H;
+                b->d_h0x = b->pool[b->nv].h0;
+                MI_HIP_CHECK(hipMemcpyAsync(b->d_xmask, b->xf_wait.data(), b->channels, hipMemcpyHostToDevice, st));
+                MI_HIP_CHECK(hipStreamSynchronize(st));
+                b->xfade_active = true;
+                b->cv = b->nv;
+                std::fill(b->xf_wait.begin(), b->xf_wait.end(), uint8_t(0));
+                b->xf_any = false;
             }
-            if (b->pending == mi_convolver_bank::PEND_XFADE)
-                b->xfade_active = true;                                     // ... across this frame
-            else
-            {
-                std::swap(b->d_H, b->d_Hx);
-                std::swap(b->d_h0, b->d_h0x);
-            }
-            b->pending = mi_convolver_bank::PEND_NONE;
+            b->frame_open = true;
         }
         if (b->off == 0 && left >= size_t(B) && b->xfade_active)
         {
             const bool aligned = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) % 8 == 0) &&
                                  (out_stride % 2 == 0) && (in_stride % 2 == 0);
             #define MI_CALL(LM) hipLaunchKernelGGL((conv_xfade_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
-                                                   o, x, out_stride, in_stride, aligned, b->d_H, b->d_Hx, b->d_acc, b->d_tw)
+                                                   o, x, out_stride, in_stride, aligned, b->d_H, b->d_Hx, b->d_acc, b->d_tw, b->d_xmask)
             MI_LOGM_SWITCH(b->logm, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
-            std::swap(b->d_H, b->d_Hx);
-            std::swap(b->d_h0, b->d_h0x);
             b->xfade_active = false;
+            b->frame_open = false;
             done += size_t(B);
         }
         else if (b->off == 0 && left >= size_t(B))
@@ -874,6 +991,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             const int r = launch_mac(b, st);
             if (r != MI_OK)
                 return r;
+            b->frame_open = false;
             done += size_t(B);
         }
         else
@@ -886,10 +1004,10 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
                                           size_t(cnt) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
             if (b->xfade_active && b->off == 0)
-                hipLaunchKernelGGL(conv_xfade_prescale_kernel, dim3((B / 2 + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, B);
+                hipLaunchKernelGGL(conv_xfade_prescale_kernel, dim3((B / 2 + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, B, b->d_xmask);
             if (b->xfade_active)
                 hipLaunchKernelGGL(conv_direct_xfade_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
-                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, b->d_h0x, B, b->off, cnt);
+                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, b->d_h0x, B, b->off, cnt, b->d_xmask);
             else
                 hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
                                    o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
@@ -909,12 +1027,8 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 if (r != MI_OK)
                     return r;
                 b->off = 0;
-                if (b->xfade_active)                                        // the cross-fade frame is over
-                {
-                    std::swap(b->d_H, b->d_Hx);
-                    std::swap(b->d_h0, b->d_h0x);
-                    b->xfade_active = false;
-                }
+                b->xfade_active = false;
+                b->frame_open = false;
             }
         }
     }

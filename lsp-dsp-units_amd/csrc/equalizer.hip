@@ -165,23 +165,30 @@ namespace
         if (!(b->flags & (EF_REBUILD | EF_CLEAR)))
             return MI_OK;
         void *stream = st;
+        const bool clear = (b->flags & EF_CLEAR) != 0;
         if (b->mode == MI_EQM_BYPASS)
         {
+            // an object that reconfigures outside the FIR modes drops a cross-fade that was still waiting (:250)
+            std::vector<uint8_t> touched(b->channels, 0);
+            for (uint32_t ch = 0; ch < b->channels; ++ch)
+                touched[ch] = (b->dirty[ch] || clear) ? 1 : 0;
+            mi::convolver_cancel_crossfade(b->conv, touched.data());
             b->flags = 0;
             b->latency = 0;
             return MI_OK;
         }
-        const bool clear = (b->flags & EF_CLEAR) != 0;
         const size_t N = b->fir_size;
         std::vector<mi_biquad_x1_t> sections;
         std::vector<mi::design> designs;
         const bool need_mag = (b->mode == MI_EQM_FFT || b->mode == MI_EQM_SPM);
         bool any = false;
+        std::vector<uint8_t> rebuilt(b->channels, 0);                   // the objects whose reconfigure() does something
         for (uint32_t ch = 0; ch < b->channels; ++ch)
         {
             if (!b->dirty[ch] && !clear)
                 continue;
             any = true;
+            rebuilt[ch] = 1;
             channel_sections(b, ch, &sections, &designs);
             int r = mi_biquad_bank_set_chains(b->biquads, ch, sections.data(), uint32_t(sections.size()), clear ? 1 : 0);
             if (r != MI_OK)
@@ -193,6 +200,8 @@ namespace
         int r = mi_biquad_bank_commit(b->biquads, stream);
         if (r != MI_OK)
             return r;
+        if (b->mode == MI_EQM_IIR || b->mode == MI_EQM_SPM)
+            mi::convolver_cancel_crossfade(b->conv, rebuilt.data());       // Equalizer.cpp:264,356
         if (b->mode == MI_EQM_IIR)
         {
             b->flags = 0;
@@ -232,8 +241,9 @@ namespace
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
                 // EF_SMOOTH: the new response waits for the next block boundary and is cross-faded in over that block
-                r = b->smooth ? mi_convolver_bank_crossfade_irs_device(b->conv, b->d_taps, N, uint32_t(N), stream)
-                              : mi_convolver_bank_set_irs_device(b->conv, b->d_taps, N, uint32_t(N), stream);
+                // only the objects that reconfigure touch their responses: the others may have a cross-fade waiting
+                r = b->smooth ? mi_convolver_bank_crossfade_irs_device(b->conv, b->d_taps, N, uint32_t(N), rebuilt.data(), stream)
+                              : mi_convolver_bank_set_irs_device(b->conv, b->d_taps, N, uint32_t(N), rebuilt.data(), stream);
                 if (r != MI_OK) return r;
             }
             else
@@ -363,6 +373,9 @@ int mi_equalizer_bank_set_mode(mi_equalizer_bank_t *b, int mode)        // Equal
         return MI_OK;
     b->mode = mode;
     b->flags |= EF_REBUILD | EF_CLEAR;
+    // every channel's response has to be rebuilt for the new mode, also when a reset() takes EF_CLEAR away again before
+    // the next reconfigure (Equalizer.cpp:575)
+    std::fill(b->dirty.begin(), b->dirty.end(), uint8_t(1));
     b->streaming_ready = false;
     return MI_OK;
 }
@@ -425,7 +438,9 @@ int mi_equalizer_bank_reset(mi_equalizer_bank_t *b, void *stream)       // Equal
             b->primed = 0;
             break;
         case MI_EQM_SPM:
-            r = mi_spectral_bank_reset(b->spm, stream);
+            // vInBuffer, vOutBuffer AND nBufSize go back to zero (:590-592); SpectralProcessor::reset() keeps its frame
+            // position, so the STFT settings are re-applied instead: that clears both buffers and the position
+            r = mi_spectral_bank_set_phase(b->spm, 0.0f);
             break;
         default:
             break;

@@ -37,6 +37,7 @@ namespace mi
     int         delay_bank_view(mi_delay_bank_t *bank, delay_view *view);
     void        delay_bank_advance(mi_delay_bank_t *bank, size_t samples);
     // true if the next `samples` of the bank are exactly one whole frame handled by the plain frame kernel
+    void        convolver_cancel_crossfade(mi_convolver_bank_t *bank, const uint8_t *channels /* host flags or NULL */);
     bool        convolver_takes_delayed_frame(const mi_convolver_bank_t *bank, size_t samples);
     int         convolver_process_delayed_frame(mi_convolver_bank_t *bank, float *out, const float *in, size_t out_stride,
                                                 size_t in_stride, const delay_view &dl, hipStream_t st);

@@ -65,6 +65,16 @@ class Equalizer:
         self._reconfigure()
         return self.latency
 
+    def reset(self):                                            # Equalizer.cpp:573-597
+        self.clear = False
+        if self.mode == BYPASS:
+            return
+        if self.mode == IIR:
+            if getattr(self, "state", None) is not None:
+                self.state[:] = 0
+            return
+        self.inb[:] = 0; self.outb[:] = 0; self.bufsize = 0
+
     def _reconfigure(self):
         if not (self.rebuild or self.clear):
             return
@@ -74,7 +84,7 @@ class Equalizer:
             return
         designs = [fd.design(p, self.sr) for p in self.params]
         coef = np.concatenate([d[2] for d in designs]) if designs else np.zeros((0, 5), np.float32)
-        if self.clear or getattr(self, "coef", np.zeros((0, 5))).shape[0] != coef.shape[0]:
+        if self.clear or getattr(self, "state", None) is None or getattr(self, "coef", np.zeros((0, 5))).shape[0] != coef.shape[0]:
             self.state = np.zeros((max(coef.shape[0], 1), 2), np.float32)       # FilterBank::end(clear) / count change
         self.coef = coef.astype(np.float32)
         if self.mode == IIR:

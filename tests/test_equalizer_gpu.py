@@ -165,3 +165,60 @@ def test_smooth_retune_cross_fades_over_one_block(gpu, mode, calls):
     first = np.abs(y[0, N:N + N // 2]).max()
     assert first < 1e-6 * max(1.0, float(np.abs(y[0]).max())), "before N/2 into the first block's result only the old (zero) response may sound"
     eq.close()
+
+
+@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808, 909, 1010])
+def test_random_operation_sequences_match_oracle(gpu, seed):
+    """Differential stress: random sequences of retunes, mode switches, resets and ragged process() calls on a
+    two-channel bank against one oracle object per channel (well-conditioned filters: the strict tolerance applies)."""
+    rng = np.random.default_rng(seed)
+    C, nfilt, rank, sr = 2, 3, 7, 48000
+    N = 1 << rank
+    types = [fd.FLT_BT_RLC_BELL, fd.FLT_BT_RLC_HISHELF, fd.FLT_BT_RLC_LOSHELF, fd.FLT_MT_RLC_BELL, fd.FLT_BT_BWC_HIPASS,
+             fd.FLT_BT_LRX_LOPASS, fd.FLT_DR_APO_PEAKING, fd.FLT_NONE]
+    modes = [oe.IIR, oe.FIR, oe.FFT, oe.SPM, oe.BYPASS]
+    eq = gpu.EqualizerBank(C, nfilt, rank)
+    eq.set_sample_rate(sr)
+    refs = [oe.Equalizer(nfilt, rank) for _ in range(C)]
+    for o in refs:
+        o.set_sample_rate(sr)
+    log = []
+    for step in range(60):
+        op = rng.choice(["process", "process", "process", "retune", "mode", "reset", "smooth", "latency"])
+        if op == "process":
+            k = int(rng.choice([1, 7, N // 2 - 1, N // 2, N, N + 3, 3 * N, int(rng.integers(1, 4 * N))]))
+            x = (rng.standard_normal((C, k)) * 0.25).astype(np.float32)
+            dout = gpu.DeviceBuffer((C, k))
+            eq.process(dout, gpu.DeviceBuffer.from_host(x), k)
+            y = dout.download()
+            for c in range(C):
+                ref = refs[c].process(x[c])
+                scale = max(float(np.abs(ref).max()), 0.25)
+                err = float(np.abs(y[c] - ref).max())
+                assert err <= 2 * TOL * scale, (seed, step, c, err / scale, [str(l) for l in log])
+        elif op == "retune":
+            c = int(rng.integers(0, C)); i = int(rng.integers(0, nfilt))
+            p = (int(rng.choice(types)), int(rng.integers(1, 3)), float(rng.uniform(800.0, 12000.0)),
+                 float(rng.uniform(800.0, 12000.0)), float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.0, 2.0)))
+            eq.set_params(i, *p, channel=c)
+            refs[c].set_params(i, fd.Params(*p))
+        elif op == "mode":
+            m = int(rng.choice(modes))
+            eq.set_mode(m)
+            for o in refs:
+                o.set_mode(m)
+        elif op == "reset":
+            eq.reset()
+            for o in refs:
+                o.reset()
+        elif op == "smooth":
+            s = bool(rng.integers(0, 2))
+            eq.set_smooth(s)
+            for o in refs:
+                o.set_smooth(s)
+        else:
+            lat = eq.get_latency()
+            assert all(lat == o.get_latency() for o in refs), (seed, step, log[-8:])
+        log.append({"process": "process(%d)" % k if op == "process" else "", "mode": "mode(%d)" % m if op == "mode" else "",
+                    "smooth": "smooth(%d)" % s if op == "smooth" else ""}.get(op) or str(op))
+    eq.close()
