@@ -316,6 +316,16 @@ int mi_delay_bank_append(mi_delay_bank_t *b, const float *in, size_t count, size
     MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "mi_delay_bank_append: bad argument");
     if (count == 0)
         return MI_OK;
+    if (count >= b->size)
+    {
+        // a whole buffer or more: the reference keeps the last nSize samples from cell 0 on and restarts the write position
+        // there (Delay.cpp:95-99).  The absolute position matters: process_ramping's read index wraps modulo 2^64 before
+        // it is reduced modulo nSize (Delay.cpp:434), which depends on where the tail sits when the delay grows quickly.
+        b->head = 0;
+        const int r = append(b, in + (count - b->size), in_stride, b->size, mi::as_stream(stream));
+        b->head = 0;
+        return r;
+    }
     return append(b, in, in_stride, count, mi::as_stream(stream));
 }
 

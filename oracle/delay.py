@@ -83,7 +83,8 @@ class Delay:
             n = min(count - offset, gap)
             self._push(src[offset:offset + n])
             for i in range(n):
-                t = (old_tail + int(F(delta * F(offset)))) % self.size
+                # size_t + ssize_t is an unsigned 64-bit sum (Delay.cpp:434): a negative step wraps modulo 2^64 first
+                t = ((old_tail + int(F(delta * F(offset)))) % (1 << 64)) % self.size
                 v = self.buf[t]
                 if gain is not None:
                     v = F(v * (gain[offset] if np.ndim(gain) else F(gain)))

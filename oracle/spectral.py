@@ -164,6 +164,12 @@ class SpectralProcessor:
     def remaining(self):
         return (1 << (self.rank - 1)) - self.offset
 
+    def reset(self):                                        # SpectralProcessor.cpp:257-266: pOutBuf and pInBuf, not nOffset
+        if self.update:
+            return
+        self.out_buf[:] = 0
+        self.in_buf[:] = 0
+
     def analyze(self, src):
         """process(src, count), SpectralProcessor.cpp:201-249: the function sees every frame, nothing comes back."""
         src = np.asarray(src, np.float32)

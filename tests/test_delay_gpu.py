@@ -146,3 +146,71 @@ def test_delay_append_and_clear(gpu):
     bank.process(dout, din, 50, out_stride=300, in_stride=300)
     np.testing.assert_array_equal(dout.download()[:, :50], np.zeros((2, 50), np.float32))
     bank.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_delay_random_operation_sequences_bit_exact(gpu, seed):
+    """Differential stress, bit for bit: set_delay, clear, append and every process form (plain / gain / add / ramping,
+    in place or not) with random lengths around the sizes where the write and read positions wrap."""
+    rng = np.random.default_rng(7000 + seed)
+    C, maxd = 3, int(rng.choice([100, 511, 513, 1000]))
+    bank = gpu.DelayBank(C, maxd)
+    refs = [od.Delay(maxd) for _ in range(C)]
+    size = refs[0].size
+    log = []
+    for step in range(60):
+        op = rng.choice(["plain", "scalar", "vector", "add", "add_vector", "ramp", "ramp_gain", "set", "clear", "append"])
+        n = int(rng.choice([1, 2, 63, size - 1, size, size + 1, 2 * size + 5, int(rng.integers(1, 3 * size))]))
+        if op == "set":
+            d = int(rng.integers(0, maxd + 1))
+            c = int(rng.integers(-1, C))
+            if c < 0:
+                bank.set_delay(d)
+                for r in refs:
+                    r.set_delay(d)
+            else:
+                bank.set_delay(d, c); refs[c].set_delay(d)
+        elif op == "clear":
+            bank.clear()
+            for r in refs:
+                r.buf[:] = 0                                  # Delay::clear(): the buffer only (Delay.cpp:574-579)
+        elif op == "append":
+            x = rng.standard_normal((C, n)).astype(np.float32)
+            bank.append(gpu.DeviceBuffer.from_host(x), n)
+            for c, r in enumerate(refs):
+                r.append(x[c])
+        else:
+            x = rng.standard_normal((C, n)).astype(np.float32)
+            g = rng.uniform(0.5, 2.0, (C, n)).astype(np.float32)
+            base = rng.standard_normal((C, n)).astype(np.float32)
+            in_place = bool(rng.integers(0, 2)) and not op.startswith("add")
+            din = gpu.DeviceBuffer.from_host(x)
+            dout = din if in_place else gpu.DeviceBuffer.from_host(base)
+            dg = gpu.DeviceBuffer.from_host(g)
+            if op == "plain":
+                bank.process(dout, din, n); ref = [r.process(x[c]) for c, r in enumerate(refs)]
+            elif op == "scalar":
+                bank.process(dout, din, n, gain=0.37); ref = [r.process(x[c], gain=0.37) for c, r in enumerate(refs)]
+            elif op == "vector":
+                bank.process(dout, din, n, gain_vec=dg); ref = [r.process(x[c], gain=g[c]) for c, r in enumerate(refs)]
+            elif op == "add":
+                bank.process(dout, din, n, add=True); ref = [r.process(x[c], add_to=base[c]) for c, r in enumerate(refs)]
+            elif op == "add_vector":
+                bank.process(dout, din, n, add=True, gain_vec=dg); ref = [r.process(x[c], gain=g[c], add_to=base[c]) for c, r in enumerate(refs)]
+            else:
+                targets = [int(rng.integers(0, maxd + 1)) for _ in range(C)]
+                if rng.integers(0, 4) == 0:
+                    targets[0] = refs[0].delay                # no change on one channel: plain process (Delay.cpp:404)
+                if op == "ramp":
+                    bank.process_ramping(dout, din, targets, n)
+                    ref = [r.process_ramping(x[c], targets[c]) for c, r in enumerate(refs)]
+                else:
+                    bank.process_ramping(dout, din, targets, n, gain_vec=dg)
+                    ref = [r.process_ramping(x[c], targets[c], gain=g[c]) for c, r in enumerate(refs)]
+            np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=str((seed, step, op, n, log[-6:])))
+        for c, r in enumerate(refs):
+            st = bank.get(c)
+            # the absolute positions matter too: a fast-growing delay makes process_ramping's read index wrap modulo 2^64
+            assert (st["delay"], st["head"], st["tail"], st["size"]) == (r.delay, r.head, r.tail, r.size), (seed, step, c, log[-6:])
+        log.append((str(op), n))
+    bank.close()

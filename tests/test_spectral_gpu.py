@@ -346,3 +346,69 @@ def test_reduce_bins_many_channels(gpu):
     for a, b in zip(outs[16], outs[645]):
         assert float(a.max()) > 0
         assert np.abs(a - b).max() <= 1e-4 * float(a.max())     # the Hann window of windows.cpp is not exactly periodic
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_spectral_random_operation_sequences(gpu, seed):
+    """Differential stress of the spectral bank against the oracle SpectralProcessor: rank and phase changes, masks bound
+    and unbound, resets, analysis-only calls and ragged process() calls in random order."""
+    rng = np.random.default_rng(1000 + seed)
+    C, max_rank = 2, 9
+    bank = gpu.SpectralBank(C, max_rank)
+    refs = [sp.SpectralProcessor(max_rank) for _ in range(C)]
+    rank = max_rank
+    log = []
+    for step in range(50):
+        op = rng.choice(["process", "process", "process", "analyze", "rank", "phase", "mask", "unbind", "reset"])
+        if op in ("process", "analyze"):
+            frame = 1 << (rank - 1)
+            k = int(rng.choice([1, 5, frame - 1, frame, frame + 1, 2 * frame, int(rng.integers(1, 5 * frame))]))
+            x = rng.standard_normal((C, k)).astype(np.float32)
+            if op == "process":
+                out = gpu.DeviceBuffer((C, k))
+                bank.process(out, gpu.DeviceBuffer.from_host(x), k)
+                y = out.download()
+                for c in range(C):
+                    ref = refs[c].process(x[c])
+                    err = float(np.abs(y[c] - ref).max())
+                    assert err <= TOL * max(float(np.abs(ref).max()), 1.0), (seed, step, c, err, log)
+            else:
+                bank.process(None, gpu.DeviceBuffer.from_host(x), k)
+                for c in range(C):
+                    refs[c].analyze(x[c])
+            assert bank.get()["remaining"] == refs[0].remaining(), (seed, step, log)
+        elif op == "rank":
+            rank = int(rng.integers(5, max_rank + 2))           # max_rank + 1 is ignored
+            bank.set_rank(rank)
+            for r in refs:
+                r.set_rank(rank)
+            rank = refs[0].rank
+            bank.bind(None)                                     # a mask belongs to one rank
+            for r in refs:
+                r.bind(None)
+        elif op == "phase":
+            ph = float(rng.uniform(-0.2, 1.2))
+            bank.set_phase(ph)
+            for r in refs:
+                r.set_phase(ph)
+        elif op == "mask":
+            H = 1 << (rank - 1)
+            masks = rng.uniform(0.0, 2.0, (C, H + 1)).astype(np.float32)
+            bank.bind_mask(masks)
+            for c in range(C):
+                full = np.concatenate([masks[c], masks[c][H - 1:0:-1]]).astype(np.float32)
+
+                def cb(spec, r, full=full):
+                    out = spec.copy(); out[0::2] *= full; out[1::2] *= full
+                    return out
+                refs[c].bind(cb)
+        elif op == "unbind":
+            bank.bind(None)
+            for r in refs:
+                r.bind(None)
+        else:
+            bank.reset()
+            for r in refs:
+                r.reset()
+        log.append(str(op) + ("(%d)" % k if op in ("process", "analyze") else ""))
+    bank.close()

@@ -200,3 +200,104 @@ def test_argument_errors(gpu):
     bank.set_chunk_rank(3)
     assert bank.chunk_rank() == 5 and bank.latency() == 32
     bank.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_operation_sequences_match_oracle(gpu, seed):
+    """Differential stress against one oracle SpectralSplitter per channel: rank / chunk rank / phase changes, handlers
+    bound (gains or plain copy), re-bound and unbound, clear(), silence and ragged process() calls in random order."""
+    rng = np.random.default_rng(5000 + seed)
+    C, max_rank, H = 2, 8, 3
+    bank = gpu.SplitterBank(C, max_rank, H)
+    refs = [osp.SpectralSplitter(max_rank, H) for _ in range(C)]
+    col = {}
+
+    def sink_for(c, h):
+        def sink(s, first, count):
+            col[(c, h)].append(s.copy())
+        return sink
+
+    def mk(m):
+        def func(spec, r):
+            spec[0::2] *= m; spec[1::2] *= m
+            return spec
+        return func
+    bound = [None] * H                                       # None | "copy" | "mask"
+    log = []
+    for step in range(45):
+        op = rng.choice(["process", "process", "process", "silence", "rank", "chunk", "phase", "mask", "copy", "unbind", "clear"])
+        rank = refs[0].rank
+        if op in ("process", "silence"):
+            k = int(rng.choice([1, 15, 16, 17, 100, 256, int(rng.integers(1, 700))]))
+            x = rng.standard_normal((C, k)).astype(np.float32) if op == "process" else None
+            bufs = [gpu.DeviceBuffer.from_host(np.full((C, k), -3.0, np.float32)) if bound[h] is not None else None for h in range(H)]
+            bank.process(bufs, gpu.DeviceBuffer.from_host(x) if x is not None else None, k)
+            for key in col:
+                col[key].clear()
+            for c in range(C):
+                refs[c].process(x[c] if x is not None else None, k)
+            for h in range(H):
+                if bound[h] is None:
+                    continue
+                y = bufs[h].download()
+                for c in range(C):
+                    ref = np.concatenate(col[(c, h)]) if col[(c, h)] else np.zeros(0, np.float32)
+                    assert ref.size == k, (seed, step, h, c, ref.size, k, log)
+                    err = float(np.abs(y[c] - ref).max())
+                    assert err <= TOL * max(float(np.abs(ref).max()), 1.0), (seed, step, h, c, err, log)
+            assert bank.latency() == refs[0].latency()
+        elif op == "rank":
+            r = int(rng.integers(5, max_rank + 2))
+            bank.set_rank(r)
+            for s in refs:
+                s.set_rank(r)
+            if refs[0].rank != rank:                            # gains belong to one rank: start over with the handlers
+                for h in range(H):
+                    if bound[h] is not None:
+                        bank.unbind(h)
+                        for s in refs:
+                            s.unbind(h)
+                        bound[h] = None
+        elif op == "chunk":
+            cr = int(rng.choice([0, 3, 5, 6, 7, 8, 12]))
+            bank.set_chunk_rank(cr)
+            for s in refs:
+                s.set_chunk_rank(cr)
+        elif op == "phase":
+            ph = float(rng.uniform(-0.2, 1.2))
+            bank.set_phase(ph)
+            for s in refs:
+                s.set_phase(ph)
+        elif op in ("mask", "copy"):
+            h = int(rng.integers(0, H))
+            if op == "mask":
+                masks = rng.uniform(0.0, 1.5, (C, 1 << rank)).astype(np.float32)
+                if bound[h] == "mask":                          # new gains for a bound handler: the line lives on
+                    bank.bind_mask(h, masks)
+                    for c in range(C):
+                        refs[c].h[h]["func"] = mk(masks[c])
+                else:
+                    bank.bind_mask(h, masks)
+                    for c in range(C):
+                        col.setdefault((c, h), [])
+                        refs[c].bind(h, mk(masks[c]), sink_for(c, h))
+                bound[h] = "mask"
+            else:
+                bank.bind_copy(h)
+                for c in range(C):
+                    col.setdefault((c, h), [])
+                    refs[c].bind(h, None, sink_for(c, h))
+                bound[h] = "copy"
+        elif op == "unbind":
+            h = int(rng.integers(0, H))
+            if bound[h] is not None:
+                bank.unbind(h)
+                for s in refs:
+                    s.unbind(h)
+                bound[h] = None
+        else:
+            bank.clear()
+            for s in refs:
+                s.clear()
+        log.append(str(op))
+    bank.close()
