@@ -46,7 +46,10 @@ class Crossover:
                            lpf_coef=None, lpf_state=None, lpf_params=None, hpf_coef=None, hpf_state=None, hpf_params=None,
                            hpf_key=None)
                       for i in range(self.nsplits)]
-        self.band = [dict(gain=F(1.0), start=F(0), end=F(0), enabled=False, p_start=None, p_end=None) for _ in range(bands)]
+        # bands start out on the default split frequencies (Crossover.cpp:142-150); a band that is never enabled keeps them
+        self.band = [dict(gain=F(1.0), start=(SPEC_FREQ_MIN if i == 0 else self.split[i - 1]["freq"]),
+                          end=(self.split[i]["freq"] if i < self.nsplits else F(self.sr >> 1)),
+                          enabled=False, p_start=None, p_end=None) for i in range(bands)]
         self.plan = []
         self.dirty = self.clear = True
 
@@ -54,6 +57,7 @@ class Crossover:
     def set_sample_rate(self, sr):
         if sr != self.sr:
             self.sr = sr
+            self.band[self.nsplits]["end"] = F(sr >> 1)        # Crossover.cpp:323
             self.dirty = self.clear = True
 
     def set_slope(self, sp, slope):

@@ -259,3 +259,79 @@ def test_linearity_and_determinism_full_size(gpu):
     np.testing.assert_array_equal(y1, y2)
     y3, _ = run_bank(gpu, x * np.float32(2.0), list(coef))
     np.testing.assert_array_equal(y3, y1 * np.float32(2.0))     # power-of-two scaling commutes with rounding
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_operation_sequences(gpu, seed):
+    """Differential stress: per-channel cascades of different lengths re-designed at random (same count: memory kept,
+    other count or clear: memory cleared, FilterBank.cpp:233-235), resets, rows switched off, in-place calls and lengths
+    that exercise every launch variant and the tail kernel -- against the oracle run over the whole history of a channel."""
+    rng = np.random.default_rng(11000 + seed)
+    C = 4
+    bank = gpu.BiquadBank(C, 8)
+    types = [fd.FLT_BT_RLC_BELL, fd.FLT_BT_RLC_HISHELF, fd.FLT_BT_LRX_LOPASS, fd.FLT_MT_RLC_BELL, fd.FLT_BT_BWC_HIPASS]
+    coef = [None] * C
+    hist = [np.zeros(0, np.float32) for _ in range(C)]       # input since the channel's memory was last cleared ...
+    state0 = [None] * C                                      # ... under the current coefficients: oracle state at its start
+    enabled = [True] * C
+
+    def redesign(c, clear):
+        t = int(rng.choice(types))
+        slope = int(rng.integers(1, 3))
+        q = wl.design(t, slope, float(rng.uniform(700.0, 15000.0)), 0, float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.1, 2.0)))[:8]
+        old = coef[c]
+        # memory carried over when the section count is unchanged and no clear was asked for
+        keep = (old is not None) and (len(old) == len(q)) and not clear
+        if keep and hist[c].size:
+            _, st = oracle.biquad_cascade(hist[c], old, state0[c])
+            state0[c] = st
+        else:
+            state0[c] = None
+        hist[c] = np.zeros(0, np.float32)
+        coef[c] = q
+        bank.set_chains(c, q, clear=clear)
+    for c in range(C):
+        redesign(c, True)
+    for step in range(40):
+        op = rng.choice(["process", "process", "process", "redesign", "reset", "toggle", "ir"])
+        if op == "process":
+            n = int(rng.choice([1, 7, 15, 16, 17, 1000, 1024, 1031, 2048, 2049, 4096, int(rng.integers(1, 6000))]))
+            x = rng.standard_normal((C, n)).astype(np.float32)
+            din = gpu.DeviceBuffer.from_host(x)
+            in_place = bool(rng.integers(0, 2))
+            dout = din if in_place else gpu.DeviceBuffer.from_host(np.full((C, n), 9.0, np.float32))
+            bank.process(dout, din, n)
+            y = dout.download()
+            for c in range(C):
+                if not enabled[c]:
+                    assert np.array_equal(y[c], x[c] if in_place else np.full(n, 9.0, np.float32)), (seed, step, c)
+                    continue
+                hist[c] = np.concatenate([hist[c], x[c]])
+                ref, _ = oracle.biquad_cascade(hist[c], coef[c], state0[c])
+                if state0[c] is None:
+                    exact = oracle.biquad_cascade_f64(hist[c], coef[c])[-n:]
+                    assert_iir_parity(y[c], ref[-n:], exact, what=str((seed, step, c, n)))
+                else:                                        # carried memory: no zero-state float64 run to compare with
+                    peak = max(float(np.abs(ref).max()), 1.0)
+                    assert float(np.abs(y[c] - ref[-n:]).max()) <= 5e-5 * peak, (seed, step, c, n)
+        elif op == "redesign":
+            redesign(int(rng.integers(0, C)), bool(rng.integers(0, 2)))
+        elif op == "reset":
+            c = int(rng.integers(-1, C))
+            bank.reset(None if c < 0 else c)
+            for k in (range(C) if c < 0 else [c]):
+                hist[k] = np.zeros(0, np.float32); state0[k] = None
+        elif op == "toggle":
+            c = int(rng.integers(0, C))
+            enabled[c] = not enabled[c]
+            bank.set_row_enabled(c, enabled[c])
+        else:
+            out = gpu.DeviceBuffer((C, 300))
+            bank.impulse_response(out, 300)                  # must leave every channel's memory as it was
+            h = out.download()
+            imp = np.zeros(300, np.float32); imp[0] = 1.0
+            for c in range(C):
+                if enabled[c]:
+                    ref, _ = oracle.biquad_cascade(imp, coef[c])
+                    assert float(np.abs(h[c] - ref).max()) <= 2e-5 * max(float(np.abs(ref).max()), 1.0), (seed, step, c)
+    bank.close()

@@ -175,3 +175,36 @@ def test_c3_full_size(gpu):
         r = check(y[c], refs[c], exact_conv(x[c], irs[c]), "C3 ch %d" % c)
         worst = max(worst, r["gpu_vs_ref32"])
     print("C3 full size: worst |gpu - oracle| / peak = %.2e" % worst)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_geometry_and_call_sizes(gpu, seed):
+    """Differential stress against the exact (float64) linear convolution: random ranks, tap counts around the partition
+    size, per-channel counts, in-place or not, resets, and call sizes from one sample to several frames in random order."""
+    rng = np.random.default_rng(9000 + seed)
+    C = 3
+    rank = int(rng.choice([8, 9, 10]))
+    frame = 1 << (rank - 1)
+    taps = int(rng.choice([1, 31, frame - 1, frame, frame + 1, 2 * frame, 3 * frame + 17]))
+    counts = np.array([taps] + [int(rng.integers(1, taps + 1)) for _ in range(C - 1)], np.uint32)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / (0.3 * taps + 1))).astype(np.float32)
+    bank = gpu.ConvolverBank(irs, rank, counts=counts)
+    hist = [np.zeros(0, np.float32) for _ in range(C)]
+    for step in range(40):
+        if rng.integers(0, 12) == 0:
+            bank.reset()
+            hist = [np.zeros(0, np.float32) for _ in range(C)]
+            continue
+        k = int(rng.choice([1, 2, 127, 128, 129, frame - 1, frame, frame + 1, 2 * frame, int(rng.integers(1, 4 * frame))]))
+        x = rng.standard_normal((C, k)).astype(np.float32)
+        din = gpu.DeviceBuffer.from_host(x)
+        dout = din if rng.integers(0, 2) else gpu.DeviceBuffer((C, k))
+        bank.process(dout, din, k)
+        y = dout.download()
+        for c in range(C):
+            hist[c] = np.concatenate([hist[c], x[c]])[-(4 * frame + taps + k):]       # enough history for the tail
+            ref = exact_conv(hist[c], irs[c, :counts[c]])[-k:]
+            peak = max(float(np.abs(ref).max()), 1.0)
+            err = float(np.abs(y[c] - ref).max())
+            assert err <= 2 * TOL * peak, (seed, step, c, k, rank, taps, int(counts[c]), err / peak)
+    bank.close()

@@ -134,3 +134,36 @@ def test_freq_charts_match_oracle(gpu):
         g, r = bank.freq_chart(b, f), ref.freq_chart(b, f)
         assert np.abs(g - r).max() <= 2e-5 * max(1.0, np.abs(r).max()), b
     bank.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_retune_scripts(gpu, seed):
+    """Differential stress: random scripts of slope / frequency / mode / gain changes between blocks of random length,
+    random sets of bands with a handler.  Frequencies stay above 500 Hz so that the chained float32 recursions stay
+    comparable at a fixed tolerance."""
+    rng = np.random.default_rng(13000 + seed)
+    bands = int(rng.integers(2, 6))
+    C = 2
+    n_blocks = 8
+    block = int(rng.choice([16, 333, 1024, 2500]))
+    script = {0: [("set_sample_rate", int(rng.choice([44100, 48000, 96000])))]}
+    for i in range(bands - 1):                                # away from the default split points (70 Hz ...)
+        script[0].append(("set_frequency", i, float(rng.uniform(500.0, 15000.0))))
+    for k in range(n_blocks):
+        ops = script.setdefault(k, [])
+        for _ in range(int(rng.integers(0, 4)) + (3 if k == 0 else 0)):
+            kind = rng.choice(["set_slope", "set_frequency", "set_mode", "set_gain"])
+            if kind == "set_slope":
+                ops.append(("set_slope", int(rng.integers(0, bands - 1)), int(rng.integers(0, 6))))
+            elif kind == "set_frequency":
+                ops.append(("set_frequency", int(rng.integers(0, bands - 1)), float(rng.uniform(500.0, 15000.0))))
+            elif kind == "set_mode":
+                ops.append(("set_mode", int(rng.integers(0, bands - 1)), int(rng.integers(0, 2))))
+            else:
+                ops.append(("set_gain", int(rng.integers(0, bands)), float(rng.uniform(0.25, 2.0))))
+    handlers = sorted(set(int(b) for b in rng.integers(0, bands, bands + 1)))
+    bank, refs, x, got, ref, wrote = run_both(gpu, C, bands, script, n_blocks, block, handlers=handlers, seed=seed)
+    check_bands(x, got, ref, refs, wrote, "seed %d %s" % (seed, script), tol=5e-5)
+    for b in range(bands):
+        assert bank.get_band(b) == pytest.approx(refs[0].band_info(b))
+    bank.close()
