@@ -803,7 +803,14 @@ int mi_ilufs_bank_set_integration_period(mi_ilufs_bank_t *b, float period, void 
     hipStream_t st = mi::as_stream(stream);
     if (b->int_time <= 0)
     {
-        MI_HIP_CHECK(hipMemsetAsync(b->d_state, 0, b->meters * sizeof(ilufs_state), st));     // nMSCount = 0 (loudness too: next gate rewrites it)
+        // nMSCount = 0 (ILUFSMeter.cpp:276); the history position and the loudness being held stay as they are
+        std::vector<ilufs_state> h(b->meters);
+        MI_HIP_CHECK(hipMemcpyAsync(h.data(), b->d_state, h.size() * sizeof(ilufs_state), hipMemcpyDeviceToHost, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        for (ilufs_state &v : h)
+            v.count = 0;
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_state, h.data(), h.size() * sizeof(ilufs_state), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
         const int r = ilufs_clear_blocks(b, st);
         if (r != MI_OK)
             return r;

@@ -142,3 +142,50 @@ def test_disabled_channel_filter_freezes_until_reenabled(gpu):
     assert np.abs(got - want).max() <= 3e-5 * float(want.max())
     np.testing.assert_allclose(bank.loudness(), [float(ref.loud)], rtol=3e-5)
     bank.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_operation_sequences(gpu, seed):
+    """Differential stress of the integrated meter bank: integration period, weighting, designation and activity changes,
+    clear() and ragged process() calls (every call starts with the block-full flag cleared, as in the reference)."""
+    rng = np.random.default_rng(17000 + seed)
+    M, K, sr = 2, 2, 48000
+    max_int = float(rng.choice([0.0, 2.0]))
+    bank = gpu.ILUFSBank(M, K, max_int, 100.0)
+    refs = [oi.ILUFSMeter(K, max_int, 100.0) for _ in range(M)]
+    for obj in [bank] + refs:
+        obj.set_sample_rate(sr)
+    blk = refs[0].block_size
+    weight = ol.WEIGHT_K
+    log = []
+    for step in range(40):
+        op = rng.choice(["process", "process", "process", "period", "weighting", "designation", "active", "clear"])
+        if op == "process":
+            n = int(rng.choice([1, blk - 1, blk, blk + 1, 4 * blk, 4 * blk + 1, 9 * blk + 7, int(rng.integers(1, 12 * blk))]))
+            x = (rng.standard_normal((M * K, n)) * float(rng.choice([0.2, 1e-5]))).astype(np.float32)
+            got, want = _run(gpu, bank, refs, x, (n,), K, gain=float(rng.choice([1.0, 0.9235])))
+            tol = TOL if weight in (ol.WEIGHT_NONE, ol.WEIGHT_K) else 5e-5
+            peak = max(float(want.max()), 1e-4)
+            assert float(np.abs(got - want).max()) <= tol * peak, (seed, step, log[-8:])
+            np.testing.assert_allclose(bank.loudness(), [float(r.loud) for r in refs], rtol=5e-5, atol=1e-9)
+        elif op == "period":
+            p = float(rng.choice([0.05, 0.4, 1.0, 2.0, 5.0]))
+            for obj in [bank] + refs:
+                obj.set_integration_period(p)
+        elif op == "weighting":
+            weight = int(rng.choice([ol.WEIGHT_NONE, ol.WEIGHT_K, ol.WEIGHT_K, ol.WEIGHT_A]))
+            for obj in [bank] + refs:
+                obj.set_weighting(weight)
+        elif op == "designation":
+            k, d = int(rng.integers(0, K)), int(rng.choice([ol.CHANNEL_LEFT, ol.CHANNEL_CENTER, 7, ol.CHANNEL_LFE1]))
+            for obj in [bank] + refs:
+                obj.set_designation(k, d)
+        elif op == "active":
+            k, a = int(rng.integers(0, K)), bool(rng.integers(0, 2))
+            for obj in [bank] + refs:
+                obj.set_active(k, a)
+        else:
+            for obj in [bank] + refs:
+                obj.clear()
+        log.append(str(op))
+    bank.close()
