@@ -194,6 +194,14 @@ class SpectralProcessor:
 
 
 # ---- Analyzer -----------------------------------------------------------------------------------------------------
+R_ALL = frozenset(("envelope", "window", "analysis", "tau", "counters"))
+ENV_VIOLET_NOISE, ENV_BLUE_NOISE, ENV_WHITE_NOISE, ENV_PINK_NOISE, ENV_BROWN_NOISE, ENV_MINUS_4_5_DB, ENV_PLUS_4_5_DB = range(7)
+_P45 = float(np.float32(4.5 / (20.0 * float(np.float32(math.log10(2.0))))))
+# exponent of envelope::reverse_noise_lin (envelope.cpp:95-123): the opposite colour's slope; white is all ones
+ENV_REVERSE_SLOPE = {ENV_VIOLET_NOISE: -1.0, ENV_BLUE_NOISE: -0.5, ENV_WHITE_NOISE: None, ENV_PINK_NOISE: 0.5, ENV_BROWN_NOISE: 1.0,
+                     ENV_MINUS_4_5_DB: _P45, ENV_PLUS_4_5_DB: -_P45}
+
+
 class Analyzer:
     """Restated with the reference's staggered schedule (one channel analysed every nStep samples)."""
 
@@ -209,37 +217,67 @@ class Analyzer:
         self.delay = [0] * channels
         self.user_delay = [0] * channels
         self.sample_rate = 0; self.rate = F(1.0); self.reactivity = F(0.0); self.tau = F(1.0)
-        self.window_name = "hann"; self.env_k = 0.5; self.shift = F(1.0)       # PINK_NOISE -> reversed = blue (0.5)
+        self.max_sr = max_sr; self.min_rate = F(int(min_rate))          # fMinRate = uint32_t(min_rate), Analyzer.cpp:120
+        self.window_name = "hann"; self.envelope_type = ENV_PINK_NOISE; self.shift = F(1.0)
         self.counter = 0; self.head = 0
-        self.reconf = True
+        self.flags = set(R_ALL)                         # nReconfigure
         self.active = True                              # Analyzer::set_activity (Analyzer.h)
         self.ch_active = [True] * channels              # enable_channel  (Analyzer.cpp:213-249)
         self.ch_freeze = [False] * channels             # freeze_channel
+        self.step = self.period = 0
+        self.envelope = np.zeros(csize, np.float32)
+        self.wnd = None
 
-    def configure(self, sample_rate=None, rate=None, rank=None, window_name=None, reactivity=None, shift=None):
-        if sample_rate is not None: self.sample_rate = sample_rate
-        if rate is not None: self.rate = F(rate)
-        if rank is not None: self.rank = rank
-        if window_name is not None: self.window_name = window_name
-        if reactivity is not None: self.reactivity = F(reactivity)
-        if shift is not None: self.shift = F(shift)
-        self.reconf = True
+    # the setters raise the reference's reconfiguration flags, with its no-change tests (Analyzer.cpp:154-250)
+    def configure(self, sample_rate=None, rate=None, rank=None, window_name=None, reactivity=None, shift=None, envelope=None):
+        if sample_rate is not None:
+            sr = min(int(sample_rate), self.max_sr)
+            if sr != self.sample_rate:
+                self.sample_rate = sr; self.flags |= R_ALL
+        if rate is not None:
+            r = F(max(float(self.min_rate), float(F(rate))))
+            if r != self.rate:
+                self.rate = r; self.flags.add("counters")
+        if rank is not None and 2 <= rank <= self.max_rank and rank != self.rank:
+            self.rank = rank; self.flags |= R_ALL
+        if window_name is not None and window_name != self.window_name:
+            self.window_name = window_name; self.flags.add("window")
+        if reactivity is not None and F(reactivity) != self.reactivity:
+            self.reactivity = F(reactivity); self.flags.add("tau")
+        if shift is not None and F(shift) != self.shift:
+            self.shift = F(shift); self.flags.add("envelope")
+        if envelope is not None and envelope != self.envelope_type:
+            self.envelope_type = envelope; self.flags.add("envelope")
 
-    def _reconfigure(self):
-        if not self.reconf:
+    def enable_channel(self, ch, enable):
+        if self.ch_active[ch] == bool(enable):
+            return False
+        self.ch_active[ch] = bool(enable); self.flags.add("counters")
+        return True
+
+    def _reconfigure(self):                             # Analyzer.cpp:251-297
+        if not self.flags:
             return
         fft_size = 1 << self.rank
         self.csize = (fft_size >> 1) + 1
         period = int(F(self.sample_rate) / self.rate)
         self.step = period // self.channels
         self.period = self.step * self.channels
-        env = reverse_noise_lin(0.0, F(self.sample_rate) * F(0.5), 100.0, self.csize, self.env_k)
-        self.envelope = (env * F(self.shift / F(fft_size))).astype(np.float32)
-        self.amp[:] = 0; self.data[:] = 0
-        self.wnd = window(fft_size, self.window_name)
-        self.tau = F(F(1.0) - expf(F(logf(F(F(1.0) - F(math.sqrt(0.5)))) / F(self.reactivity * self.rate))))
-        self.delay = [i * self.step for i in range(self.channels)]
-        self.reconf = False
+        if "envelope" in self.flags:
+            k = ENV_REVERSE_SLOPE[self.envelope_type]
+            env = np.ones(self.csize, np.float32) if k is None else reverse_noise_lin(0.0, F(F(self.sample_rate) * F(0.5)), 100.0, self.csize, k)
+            self.envelope = np.zeros(self.amp.shape[1], np.float32)
+            self.envelope[:self.csize] = (env * F(self.shift / F(fft_size))).astype(np.float32)
+        if "analysis" in self.flags:
+            self.amp[:, :self.csize] = 0; self.data[:, :self.csize] = 0
+        if "window" in self.flags:
+            self.wnd = window(fft_size, self.window_name)
+        if "tau" in self.flags:
+            with np.errstate(divide="ignore", invalid="ignore"):
+                self.tau = F(F(1.0) - expf(F(logf(F(F(1.0) - F(math.sqrt(0.5)))) / F(self.reactivity * self.rate))))
+        if "counters" in self.flags:
+            self.delay = [i * self.step for i in range(self.channels)]
+        self.flags = set()
 
     def process(self, x):
         """x: [channels][n]."""

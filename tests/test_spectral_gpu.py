@@ -412,3 +412,75 @@ def test_spectral_random_operation_sequences(gpu, seed):
                 r.reset()
         log.append(str(op) + ("(%d)" % k if op in ("process", "analyze") else ""))
     bank.close()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_analyzer_random_settings_between_periods(gpu, seed):
+    """Differential stress of the analyzer bank: window, envelope, shift, reactivity, rank, rate, activity, channel freeze /
+    enable / delay changes and ragged process() calls.  Settings are changed at a strobe: the bank analyses every channel
+    at the strobe, the reference one channel every nStep samples, so a change in the middle of a
+    period reaches the channels whose turn is still to come one period earlier there (and a rate change in the middle of
+    a period lets the reference's channel index run past its array, Analyzer.cpp:314)."""
+    rng = np.random.default_rng(19000 + seed)
+    C, max_rank, sr = 4, 9, 48000
+    o = sp.Analyzer(C, max_rank, sr, 1.0, 300)
+    bank = gpu.AnalyzerBank(C, max_rank, sr, 1.0, 300)
+    names = {0: "hann", 1: "hamming", 2: "blackman", 9: "nuttall", 16: "rectangular"}
+    rank = max_rank
+    o.configure(sample_rate=sr, rate=60.0, rank=rank, window_name="hann", reactivity=0.1, shift=1.0)
+    for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, 60.0), (bank.RANK, rank), (bank.WINDOW, 0), (bank.REACTIVITY, 0.1), (bank.SHIFT, 1.0)):
+        bank.configure(what, v)
+    fed = 0                                                  # samples since the last strobe
+    log = []
+
+    def feed(n):
+        nonlocal fed
+        x = (rng.standard_normal((C, n)) * 0.3).astype(np.float32)
+        o.process(x)
+        bank.process(gpu.DeviceBuffer.from_host(x), n)
+        fed = (fed + n) % o.period
+        bins = (1 << (o.rank - 1)) + 1
+        idx = np.arange(bins, dtype=np.uint32)
+        got, ref = bank.get_spectrum(idx), o.get_spectrum(idx)
+        peak = max(float(np.abs(ref).max()), 1e-6)
+        assert float(np.abs(got - ref).max()) <= TOL * peak, (seed, log)
+    feed(3 * 800)
+    for step in range(30):
+        op = rng.choice(["feed", "feed", "window", "envelope", "shift", "reactivity", "rank", "activity", "freeze", "enable", "delay", "rate"])
+        if op != "feed" and fed:
+            feed(o.period - fed)                              # up to the strobe first
+        if op == "feed":
+            feed(int(rng.choice([1, 37, o.step, o.period, o.period + 1, int(rng.integers(1, 3 * o.period))])))
+        elif op == "window":
+            w = int(rng.choice(list(names)))
+            o.configure(window_name=names[w]); bank.configure(bank.WINDOW, w)
+        elif op == "envelope":
+            e = int(rng.integers(0, 7))
+            o.configure(envelope=e); bank.configure(bank.ENVELOPE, e)
+        elif op == "shift":
+            v = float(rng.choice([0.5, 1.0, 2.0]))
+            o.configure(shift=v); bank.configure(bank.SHIFT, v)
+        elif op == "reactivity":
+            v = float(rng.choice([0.05, 0.1, 0.3]))
+            o.configure(reactivity=v); bank.configure(bank.REACTIVITY, v)
+        elif op == "rank":
+            rank = int(rng.integers(6, max_rank + 1))
+            o.configure(rank=rank); bank.configure(bank.RANK, rank)
+        elif op == "activity":
+            a = bool(rng.integers(0, 2))
+            o.active = a; bank.configure(bank.ACTIVE, 1.0 if a else 0.0)
+        elif op == "freeze":
+            c, f = int(rng.integers(0, C)), bool(rng.integers(0, 2))
+            o.ch_freeze[c] = f; bank.channel(c, bank.CH_FREEZE, int(f))
+        elif op == "enable":
+            c, e = int(rng.integers(0, C)), bool(rng.integers(0, 2))
+            if o.enable_channel(c, e):
+                bank.channel(c, bank.CH_ENABLE, int(e))
+        elif op == "delay":
+            c, d = int(rng.integers(0, C)), int(rng.integers(0, 301))
+            o.user_delay[c] = d; bank.channel(c, bank.CH_DELAY, d)
+        else:
+            r = float(rng.choice([30.0, 60.0, 100.0]))
+            o.configure(rate=r); bank.configure(bank.RATE, r)
+        log.append(str(op))
+    bank.close()
