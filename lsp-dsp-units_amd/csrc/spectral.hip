@@ -755,6 +755,7 @@ struct mi_analyzer_bank
     uint8_t    *d_flags = nullptr;
     const float2 *d_tw = nullptr;
     bool        meta_dirty = true;
+    bool        analysed = false;           // a strobe pass has run: vAmp / vData hold a period's results
 
     uint32_t max_user_delay() const
     {
@@ -843,6 +844,38 @@ namespace
         #define MI_CALL(LH) hipExtLaunchKernelGGL((analyzer_kernel<LH>), dim3(b->channels), dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
             b->d_ring, b->buf_size, b->head, b->d_delay, b->d_flags, b->d_wnd, b->d_data, b->d_amp, b->bins_stride, b->tau, \
             b->d_tw, in, in_stride, n, zero ? 1 : 0)
+        MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        b->analysed = true;
+        return MI_OK;
+    }
+
+    // Settings changed in the middle of a period.  The reference analyses channel i when the period counter reaches
+    // i * nStep, with the settings of that moment, looking back to the strobe (Analyzer.cpp:314-366); the strobe pass
+    // above has already analysed every channel with the settings of the strobe.  The channels whose turn is still to
+    // come are analysed again with the settings now in force: same window of samples (it ends at the strobe), same
+    // previous spectrum (the published copy, vData), result over the strobe pass's.
+    int analyzer_redo(mi_analyzer_bank *b, hipStream_t st)
+    {
+        const uint32_t first = (b->counter + b->step - 1) / b->step;
+        if (first >= b->channels)
+            return MI_OK;
+        std::vector<uint32_t> d(b->channels);
+        std::vector<uint8_t> f(b->channels);
+        for (uint32_t i = 0; i < b->channels; ++i)
+        {
+            d[i] = b->counter + b->user_delay[i];               // back to the strobe, then the user delay
+            f[i] = uint8_t(((b->active && b->ch_active[i]) ? 1 : 0) | (b->ch_freeze[i] ? 2 : 0));
+        }
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_delay, d.data(), d.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_flags, f.data(), f.size(), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        b->meta_dirty = true;                                   // the next strobe wants its own delays back
+        const size_t row = size_t(first) * b->bins_stride;
+        #define MI_CALL(LH) hipLaunchKernelGGL((analyzer_kernel<LH>), dim3(b->channels - first), dim3(plan<LH>::T), 0, st, \
+            b->d_ring + size_t(first) * b->buf_size, b->buf_size, b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, \
+            b->d_data + row, b->d_amp + row, b->bins_stride, b->tau, b->d_tw, (const float *)nullptr, size_t(0), 0u, 0)
         MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
@@ -988,9 +1021,16 @@ int mi_analyzer_bank_process(mi_analyzer_bank_t *b, const float *in, size_t samp
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_process: NULL bank");
     hipStream_t st = mi::as_stream(stream);
+    const bool changed = (b->reconfigure != 0) || b->meta_dirty;
     int r = analyzer_reconfigure(b, st);
     if (r != MI_OK)
         return r;
+    if (changed && b->counter > 0 && b->analysed)
+    {
+        r = analyzer_redo(b, st);
+        if (r != MI_OK)
+            return r;
+    }
     size_t offset = 0;
     while (offset < samples)                                // Analyzer.cpp:309-408
     {
@@ -1043,9 +1083,14 @@ int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *b, float *out, size_t out_
 {
     MI_REQUIRE(b != nullptr && out != nullptr && idx != nullptr, MI_EINVAL, "mi_analyzer_bank_get_spectrum: bad argument");
     hipStream_t st = mi::as_stream(stream);
-    const int r = analyzer_reconfigure(b, st);
-    if (r != MI_OK)
-        return r;
+    // the reference reads vData and vEnvelope as they are (Analyzer.cpp:443-456): pending settings wait for process();
+    // only a bank that has never been configured builds its envelope here
+    if (b->period == 0)
+    {
+        const int r = analyzer_reconfigure(b, st);
+        if (r != MI_OK)
+            return r;
+    }
     hipLaunchKernelGGL(spectrum_gather_kernel, dim3((count + 255) / 256, b->channels), dim3(256), 0, st,
                        out, out_stride, b->d_data, b->bins_stride, b->d_env, idx, count);
     MI_HIP_CHECK(hipGetLastError());

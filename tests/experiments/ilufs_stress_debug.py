@@ -16,12 +16,13 @@ for step in range(40):
     op = rng.choice(["process", "process", "process", "period", "weighting", "designation", "active", "clear"])
     if op == "process":
         n = int(rng.choice([1, blk - 1, blk, blk + 1, 4 * blk, 4 * blk + 1, 9 * blk + 7, int(rng.integers(1, 12 * blk))]))
-        x = (rng.standard_normal((M * K, n)) * float(rng.choice([0.2, 1e-5]))).astype(np.float32)
+        x0 = rng.standard_normal((M * K, n)); amp = float(rng.choice([0.2, 1e-6]))
+        x = (x0 * amp).astype(np.float32)
         g = float(rng.choice([1.0, 0.9235]))
         out = gpu.DeviceBuffer((M, n)); bank.process(out, gpu.DeviceBuffer.from_host(x), n, gain=g); got = out.download()
         want = np.stack([refs[m].process(x[m * K:(m + 1) * K], gain=g) for m in range(M)])
         print(step, "process", n, "err", float(np.abs(got - want).max()), "want max", float(want.max()), "loud", bank.loudness(), [float(r.loud) for r in refs],
-              "ms_int", refs[0].ms_int, "count", refs[0].ms_count, "head", refs[0].ms_head, "int_time", float(refs[0].int_time))
+              "ms_int", refs[0].ms_int, "count", refs[0].ms_count, "head", refs[0].ms_head, "int_time", float(refs[0].int_time), "amp", amp, "hist", refs[0].hist[:4], "blocks", [c["block"].tolist() for c in refs[0].ch], "part", refs[0].block_part, "off", refs[0].block_offset)
     elif op == "period":
         p = float(rng.choice([0.05, 0.4, 1.0, 2.0, 5.0])); [obj.set_integration_period(p) for obj in [bank] + refs]; print(step, "period", p, "->", float(refs[0].int_time))
     elif op == "weighting":

@@ -158,16 +158,21 @@ def test_random_operation_sequences(gpu, seed):
     blk = refs[0].block_size
     weight = ol.WEIGHT_K
     log = []
+    level = 1e-4                                             # loudest input since the filters were last cleared
     for step in range(40):
         op = rng.choice(["process", "process", "process", "period", "weighting", "designation", "active", "clear"])
         if op == "process":
             n = int(rng.choice([1, blk - 1, blk, blk + 1, 4 * blk, 4 * blk + 1, 9 * blk + 7, int(rng.integers(1, 12 * blk))]))
-            x = (rng.standard_normal((M * K, n)) * float(rng.choice([0.2, 1e-5]))).astype(np.float32)
+            # loud, or far below the absolute gate (-70 LKFS is an amplitude of 3e-4): a block AT the gate would be kept or
+            # dropped by the last bit of its sum
+            x = (rng.standard_normal((M * K, n)) * float(rng.choice([0.2, 1e-6]))).astype(np.float32)
             got, want = _run(gpu, bank, refs, x, (n,), K, gain=float(rng.choice([1.0, 0.9235])))
             tol = TOL if weight in (ol.WEIGHT_NONE, ol.WEIGHT_K) else 5e-5
-            peak = max(float(want.max()), 1e-4)
-            assert float(np.abs(got - want).max()) <= tol * peak, (seed, step, log[-8:])
-            np.testing.assert_allclose(bank.loudness(), [float(r.loud) for r in refs], rtol=5e-5, atol=1e-9)
+            # relative to the level the weighting filters have seen: after loud material their decaying memory is what a
+            # quiet stretch measures, and that tail is reproducible to the float32 round-off of the loud part only
+            level = max(level, float(np.abs(x).max()))
+            assert float(np.abs(got - want).max()) <= 3 * tol * level, (seed, step, log[-8:])
+            np.testing.assert_allclose(bank.loudness(), [float(r.loud) for r in refs], rtol=0, atol=3 * tol * level)
         elif op == "period":
             p = float(rng.choice([0.05, 0.4, 1.0, 2.0, 5.0]))
             for obj in [bank] + refs:
@@ -187,5 +192,6 @@ def test_random_operation_sequences(gpu, seed):
         else:
             for obj in [bank] + refs:
                 obj.clear()
+            level = 1e-4
         log.append(str(op))
     bank.close()
