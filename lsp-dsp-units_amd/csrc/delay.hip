@@ -482,7 +482,8 @@ int mi_ring_bank_append(mi_ring_bank_t *b, const float *in, size_t count, size_t
         *appended = (count > b->capacity) ? b->capacity : count;        // RingBuffer.cpp:78-83,105
     if (count == 0)
         return MI_OK;
-    if (count > b->capacity)                                            // keeps the newest `capacity`, head = 0
+    const bool whole = count > b->capacity;                             // keeps the newest `capacity` from cell 0 on,
+    if (whole)                                                          // and the head stays there (RingBuffer.cpp:78-83)
     {
         in += count - b->capacity;
         count = b->capacity;
@@ -491,7 +492,10 @@ int mi_ring_bank_append(mi_ring_bank_t *b, const float *in, size_t count, size_t
     hipLaunchKernelGGL(ring_append_kernel, grid_for(count, b->channels), dim3(256), 0, mi::as_stream(stream),
                        b->d_ring, b->capacity, b->head, in, in_stride, count);
     MI_HIP_CHECK(hipGetLastError());
-    b->head = uint32_t((size_t(b->head) + count) % b->capacity);
+    // RingBuffer.cpp:85-103: the head wraps only when the block runs PAST the end; a block that ends exactly at the end
+    // leaves nHead == nCapacity (head_position() reports it; every position is taken modulo the capacity afterwards)
+    const size_t end = size_t(b->head) + count;
+    b->head = whole ? 0 : uint32_t((end > b->capacity) ? end - b->capacity : end);
     return MI_OK;
 }
 

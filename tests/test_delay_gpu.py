@@ -214,3 +214,46 @@ def test_delay_random_operation_sequences_bit_exact(gpu, seed):
             assert (st["delay"], st["head"], st["tail"], st["size"]) == (r.delay, r.head, r.tail, r.size), (seed, step, c, log[-6:])
         log.append((str(op), n))
     bank.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_ring_random_operation_sequences_bit_exact(gpu, seed):
+    """RingBuffer: append (also more than a whole buffer: the reference restarts at cell 0), block get with every kind of
+    zero fill, fill(), head and tail positions -- bit for bit against the oracle."""
+    rng = np.random.default_rng(21000 + seed)
+    C = 2
+    size = int(rng.choice([8, 100, 1000]))
+    fill0 = float(rng.choice([0.0, 0.5]))
+    rb = gpu.RingBank(C, size, fill0)
+    refs = [od.RingBuffer(size, fill0) for _ in range(C)]
+    cap = refs[0].cap
+    assert rb.info()["capacity"] == cap
+    for step in range(60):
+        op = rng.choice(["append", "append", "get", "get", "fill", "info"])
+        if op == "append":
+            n = int(rng.choice([1, 2, cap - 1, cap, cap + 1, 3 * cap, int(rng.integers(1, 2 * cap + 2))]))
+            x = rng.standard_normal((C, n)).astype(np.float32)
+            got = rb.append(gpu.DeviceBuffer.from_host(x), n)
+            want = [r.append(x[c]) for c, r in enumerate(refs)]
+            assert got == want[0], (seed, step, n)
+        elif op == "get":
+            off = int(rng.integers(0, 2 * cap + 2)); n = int(rng.integers(1, 2 * cap + 3))
+            out = gpu.DeviceBuffer.from_host(np.full((C, n), 77.0, np.float32))
+            got = rb.get(out, off, n)
+            y = out.download()
+            for c, r in enumerate(refs):
+                dst, to_read = r.get(off, n)
+                assert got == to_read, (seed, step, off, n)
+                keep = ~np.isnan(dst)                          # cells the reference leaves untouched stay as they were
+                np.testing.assert_array_equal(y[c][keep], dst[keep], err_msg=str((seed, step, off, n)))
+                assert np.all(y[c][~keep] == 77.0)
+        elif op == "fill":
+            v = float(rng.standard_normal())
+            rb.fill(v)
+            for r in refs:
+                r.data[:] = np.float32(v); r.head = 0         # RingBuffer.cpp:115-120
+        else:
+            off = int(rng.integers(0, cap + 3))
+            i = rb.info(off)
+            assert (i["head"], i["tail_position"]) == (refs[0].head, refs[0].tail_position(off)), (seed, step, off)
+    rb.close()
