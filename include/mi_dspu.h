@@ -527,14 +527,17 @@ int mi_loudness_bank_set_active(mi_loudness_bank_t *bank, uint32_t channel, int 
 int mi_loudness_bank_clear(mi_loudness_bank_t *bank, void *stream);
 int mi_loudness_bank_latency(const mi_loudness_bank_t *bank, uint32_t *samples);
 /*
- * process(out, count) / process(out, count, gain), LoudnessMeter.cpp:427-560.  in: [meters*channels][in_stride];
+ * process(out, count) / process(out, count, gain), LoudnessMeter.cpp:462-564.  in: [meters*channels][in_stride];
  * out: [meters][out_stride] or NULL; ch_out: [meters*channels][out_stride] or NULL (the reference's per-channel vOut with
- * linking: link 0 = the channel's own RMS, 1 = the mixed loudness).  gain multiplies every output (pass 1 for the
- * first form).  Channels without an input in the reference = set_active(channel, 0) here.
+ * linking: link 0 = the channel's own RMS, 1 = the mixed loudness).  The second form multiplies every output by gain and,
+ * like the reference's, leaves loudness() alone (only the first form records fLoudness, LoudnessMeter.cpp:485).
+ * Channels without an input in the reference = set_active(channel, 0) here.
  */
 int mi_loudness_bank_process(mi_loudness_bank_t *bank, float *out, float *ch_out, const float *in, size_t count,
-                             size_t out_stride, size_t in_stride, float gain, void *stream);
-/* loudness(): the last value of the mixed loudness of every meter (HOST array of `meters` floats; synchronises) */
+                             size_t out_stride, size_t in_stride, void *stream);
+int mi_loudness_bank_process_gain(mi_loudness_bank_t *bank, float *out, float *ch_out, const float *in, size_t count,
+                                  size_t out_stride, size_t in_stride, float gain, void *stream);
+/* loudness(): the last value of the mixed loudness recorded by process() (HOST array of `meters` floats; synchronises) */
 int mi_loudness_bank_loudness(mi_loudness_bank_t *bank, float *loudness, void *stream);
 
 /*

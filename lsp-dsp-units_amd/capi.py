@@ -124,7 +124,8 @@ PROTOTYPES = {
     "mi_loudness_bank_set_active": (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
     "mi_loudness_bank_clear": (c_int, [c_void_p, c_void_p]),
     "mi_loudness_bank_latency": (c_int, [c_void_p, POINTER(c_uint32)]),
-    "mi_loudness_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float, c_void_p]),
+    "mi_loudness_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_loudness_bank_process_gain": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float, c_void_p]),
     "mi_loudness_bank_loudness": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
     "mi_ilufs_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_float, c_float]),
     "mi_ilufs_bank_destroy": (c_int, [c_void_p]),

@@ -2048,9 +2048,11 @@ size_t LoudnessMeter::latency() const
     return v;
 }
 
-void LoudnessMeter::process(float *out, size_t count) { process(out, count, 1.0f); }
+void LoudnessMeter::process(float *out, size_t count)             { run(out, count, 1.0f, false); }
+void LoudnessMeter::process(float *out, size_t count, float gain) { run(out, count, gain, true); }
 
-void LoudnessMeter::process(float *out, size_t count, float gain)
+// with_gain: the reference's second form, which does not record fLoudness (LoudnessMeter.cpp:518-564)
+void LoudnessMeter::run(float *out, size_t count, float gain, bool with_gain)
 {
     impl_t *p = pImpl;
     if (p == nullptr || count == 0 || !p->reserve(count))
@@ -2065,7 +2067,8 @@ void LoudnessMeter::process(float *out, size_t count, float gain)
         want_ch = want_ch || (p->ch[c].out != nullptr);
     }
     bool ok = mi_dspu_copy_h2d(p->d_in, p->host.data(), K * count * sizeof(float), nullptr) == MI_OK &&
-              mi_loudness_bank_process(p->bank, p->d_out, want_ch ? p->d_ch : nullptr, p->d_in, count, count, count, gain, nullptr) == MI_OK;
+              (with_gain ? mi_loudness_bank_process_gain(p->bank, p->d_out, want_ch ? p->d_ch : nullptr, p->d_in, count, count, count, gain, nullptr)
+                         : mi_loudness_bank_process(p->bank, p->d_out, want_ch ? p->d_ch : nullptr, p->d_in, count, count, count, nullptr)) == MI_OK;
     if (ok && out != nullptr)
         ok = mi_dspu_copy_d2h(out, p->d_out, count * sizeof(float), nullptr) == MI_OK;
     if (ok && want_ch)
@@ -2078,7 +2081,7 @@ void LoudnessMeter::process(float *out, size_t count, float gain)
         if (p->ch[c].active)
             p->ch[c].offset += count;                       // LoudnessMeter.cpp:499
     }
-    if (ok)
+    if (ok && !with_gain)
         mi_loudness_bank_loudness(p->bank, &p->loudness, nullptr);
 }
 

@@ -138,7 +138,7 @@ namespace
             if (out != nullptr)
                 out[size_t(meter) * out_stride + j] = l * gain;
         }
-        if (tid == 0 && n > 0)
+        if (tid == 0 && n > 0 && loud != nullptr)
             loud[meter] = (mix[n - 1] > 0.0f) ? mix[n - 1] : 0.0f;
         __syncthreads();
         if (ch_out == nullptr)
@@ -396,8 +396,8 @@ int mi_loudness_bank_latency(const mi_loudness_bank_t *b, uint32_t *samples)
     return MI_OK;
 }
 
-int mi_loudness_bank_process(mi_loudness_bank_t *b, float *out, float *ch_out, const float *in, size_t count,
-                             size_t out_stride, size_t in_stride, float gain, void *stream)
+static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, const float *in, size_t count,
+                            size_t out_stride, size_t in_stride, float gain, bool remember, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_process: NULL bank");
     if (count == 0)
@@ -441,13 +441,28 @@ int mi_loudness_bank_process(mi_loudness_bank_t *b, float *out, float *ch_out, c
         hipLaunchKernelGGL(loudness_block_kernel, dim3(b->meters), dim3(LT), 0, st,
                            out ? out + offset : nullptr, ch_out ? ch_out + offset : nullptr, out_stride, b->d_flt, b->cap,
                            b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, b->d_msbuf, b->cap, b->d_cfg,
-                           b->channels, uint32_t(n), gain, b->d_loud);
+                           b->channels, uint32_t(n), gain, remember ? b->d_loud : static_cast<float *>(nullptr));
         MI_HIP_CHECK(hipGetLastError());
         b->head = (b->head + uint32_t(n)) & (b->data_size - 1);
         b->ms_refresh -= uint32_t(n);
         offset += n;
     }
     return MI_OK;
+}
+
+// process(out, count): also remembers the last loudness value for loudness() (LoudnessMeter.cpp:485)
+int mi_loudness_bank_process(mi_loudness_bank_t *b, float *out, float *ch_out, const float *in, size_t count,
+                             size_t out_stride, size_t in_stride, void *stream)
+{
+    return loudness_process(b, out, ch_out, in, count, out_stride, in_stride, 1.0f, true, stream);
+}
+
+// process(out, count, gain): every output times gain; loudness() keeps the value of the last call WITHOUT gain -- the
+// reference's second form does not touch fLoudness (LoudnessMeter.cpp:518-564)
+int mi_loudness_bank_process_gain(mi_loudness_bank_t *b, float *out, float *ch_out, const float *in, size_t count,
+                                  size_t out_stride, size_t in_stride, float gain, void *stream)
+{
+    return loudness_process(b, out, ch_out, in, count, out_stride, in_stride, gain, false, stream);
 }
 
 int mi_loudness_bank_loudness(mi_loudness_bank_t *b, float *loudness, void *stream)

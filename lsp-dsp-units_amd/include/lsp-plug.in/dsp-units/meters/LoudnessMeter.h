@@ -17,6 +17,7 @@ namespace lsp
             private:
                 struct impl_t;
                 impl_t     *pImpl;
+                void            run(float *out, size_t count, float gain, bool with_gain);
 
             public:
                 explicit LoudnessMeter();

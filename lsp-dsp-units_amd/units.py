@@ -459,11 +459,14 @@ class LoudnessBank:
         check(lib.mi_loudness_bank_latency(self.handle, byref(v)))
         return v.value
 
-    def process(self, out, ch_out, inp, count, out_stride=None, in_stride=None, gain=1.0, stream=None):
-        check(lib.mi_loudness_bank_process(self.handle, _ptr(out) if out is not None else None,
-                                           _ptr(ch_out) if ch_out is not None else None, _ptr(inp), count,
-                                           count if out_stride is None else out_stride,
-                                           count if in_stride is None else in_stride, float(gain), _stream(stream)))
+    def process(self, out, ch_out, inp, count, out_stride=None, in_stride=None, gain=None, stream=None):
+        """gain=None: process(out, count), which also records loudness(); a number: process(out, count, gain)."""
+        args = (self.handle, _ptr(out) if out is not None else None, _ptr(ch_out) if ch_out is not None else None, _ptr(inp),
+                count, count if out_stride is None else out_stride, count if in_stride is None else in_stride)
+        if gain is None:
+            check(lib.mi_loudness_bank_process(*args, _stream(stream)))
+        else:
+            check(lib.mi_loudness_bank_process_gain(*args, float(gain), _stream(stream)))
 
     def loudness(self, stream=None):
         v = (c_float * self.meters)()

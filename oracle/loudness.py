@@ -164,7 +164,8 @@ class LoudnessMeter:
                 mixed += 1
             buf = np.sqrt(np.maximum(buf, F(0.0))).astype(np.float32)
             out[off:off + todo] = (buf * g).astype(np.float32) if gain is not None else buf
-            self.loud = buf[-1]
+            if gain is None:                                    # only process(out, count) records fLoudness (:485)
+                self.loud = buf[-1]
             for i, c in enumerate(self.ch):
                 if not c["enabled"]:
                     continue

@@ -145,7 +145,7 @@ def test_random_operation_sequences(gpu, seed):
         if op == "process":
             n = int(rng.choice([1, 100, 1023, 1024, 1025, 4096, 4097, int(rng.integers(1, 9000))]))
             x = (rng.standard_normal((M * K, n)) * 0.2).astype(np.float32)
-            g = float(rng.choice([1.0, 0.5]))
+            g = [None, 1.0, 0.5][int(rng.integers(0, 3))]      # None: process(out, count), the form that records loudness()
             out = gpu.DeviceBuffer((M, n)); ch = gpu.DeviceBuffer.from_host(np.full((M * K, n), -1.0, np.float32))
             bank.process(out, ch, gpu.DeviceBuffer.from_host(x), n, gain=g)
             y, yc = out.download(), ch.download()
@@ -160,6 +160,7 @@ def test_random_operation_sequences(gpu, seed):
                         assert float(np.abs(yc[m * K + k] - c[k]).max()) <= tol * peak, (seed, step, m, k, log[-8:])
                     else:
                         assert np.all(yc[m * K + k] == -1.0)
+            np.testing.assert_allclose(bank.loudness(), [float(r.loud) for r in refs], rtol=0, atol=tol * 2.0)
         elif op == "period":
             # (not shorter: the running sum `ms += new - old` cancels catastrophically over a few samples and the square
             # root that follows magnifies its float32 round-off near zero -- two correct evaluations differ visibly)
