@@ -525,13 +525,16 @@ int mi_loudness_bank_set_link(mi_loudness_bank_t *bank, uint32_t channel, float 
 int mi_loudness_bank_set_active(mi_loudness_bank_t *bank, uint32_t channel, int active, void *stream);
 /* clear(), LoudnessMeter.cpp:280-295; latency() in samples, :323-326 */
 int mi_loudness_bank_clear(mi_loudness_bank_t *bank, void *stream);
+/* bind(id, out, in) with / without an input: an enabled channel without an input is left out of the blocks (its filter does
+ * not run, its squares line is not written, it is not mixed: LoudnessMeter.cpp:421-422) but keeps taking part in
+ * refresh_rms() and clear(); binding it again continues where it stopped (unlike set_active(1), which clears). */
+int mi_loudness_bank_set_bound(mi_loudness_bank_t *bank, uint32_t channel, int bound);
 int mi_loudness_bank_latency(const mi_loudness_bank_t *bank, uint32_t *samples);
 /*
  * process(out, count) / process(out, count, gain), LoudnessMeter.cpp:462-564.  in: [meters*channels][in_stride];
  * out: [meters][out_stride] or NULL; ch_out: [meters*channels][out_stride] or NULL (the reference's per-channel vOut with
  * linking: link 0 = the channel's own RMS, 1 = the mixed loudness).  The second form multiplies every output by gain and,
  * like the reference's, leaves loudness() alone (only the first form records fLoudness, LoudnessMeter.cpp:485).
- * Channels without an input in the reference = set_active(channel, 0) here.
  */
 int mi_loudness_bank_process(mi_loudness_bank_t *bank, float *out, float *ch_out, const float *in, size_t count,
                              size_t out_stride, size_t in_stride, void *stream);

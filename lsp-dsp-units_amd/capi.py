@@ -123,6 +123,7 @@ PROTOTYPES = {
     "mi_loudness_bank_set_link": (c_int, [c_void_p, c_uint32, c_float]),
     "mi_loudness_bank_set_active": (c_int, [c_void_p, c_uint32, c_int, c_void_p]),
     "mi_loudness_bank_clear": (c_int, [c_void_p, c_void_p]),
+    "mi_loudness_bank_set_bound": (c_int, [c_void_p, c_uint32, c_int]),
     "mi_loudness_bank_latency": (c_int, [c_void_p, POINTER(c_uint32)]),
     "mi_loudness_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_loudness_bank_process_gain": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float, c_void_p]),

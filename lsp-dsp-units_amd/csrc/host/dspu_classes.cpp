@@ -2058,10 +2058,12 @@ void LoudnessMeter::run(float *out, size_t count, float gain, bool with_gain)
     if (p == nullptr || count == 0 || !p->reserve(count))
         return;
     const size_t K = p->channels;
-    p->host.assign(K * count, 0.0f);                        // a channel without an input is measured as silence
+    p->host.assign(K * count, 0.0f);
     bool want_ch = false;
     for (size_t c = 0; c < K; ++c)
     {
+        // a channel without an input is left out of the block (LoudnessMeter.cpp:421-422)
+        mi_loudness_bank_set_bound(p->bank, uint32_t(c), p->ch[c].in != nullptr);
         if (p->ch[c].in != nullptr)
             std::memcpy(&p->host[c * count], p->ch[c].in, count * sizeof(float));      // vIn is read from its start every call (:424)
         want_ch = want_ch || (p->ch[c].out != nullptr);
@@ -2076,7 +2078,7 @@ void LoudnessMeter::run(float *out, size_t count, float gain, bool with_gain)
     ok = ok && mi_dspu_stream_synchronize(nullptr) == MI_OK;
     for (size_t c = 0; c < K; ++c)
     {
-        if (ok && p->ch[c].out != nullptr && p->ch[c].active)
+        if (ok && p->ch[c].out != nullptr && p->ch[c].active && p->ch[c].in != nullptr)
             std::memcpy(p->ch[c].out + p->ch[c].offset, &p->host[c * count], count * sizeof(float));
         if (p->ch[c].active)
             p->ch[c].offset += count;                       // LoudnessMeter.cpp:499

@@ -37,8 +37,8 @@ namespace
         float   weight;
         float   link;
         int     enabled;
-        int     pad;
-    };
+        int     unbound;        // LoudnessMeter: no input bound -- the channel is left out of the block (:421-422) but stays
+    };                          // enabled for refresh_rms() and clear(); always 0 for the integrated meter
 
     // exact window sums (refresh_rms): ms[row] = sum of the last `period` cells behind head
     __global__ __launch_bounds__(LT)
@@ -86,7 +86,7 @@ namespace
         for (uint32_t c = 0; c < channels; ++c)
         {
             const chan_cfg cc = cfg[c];
-            if (!cc.enabled)
+            if (!cc.enabled || cc.unbound)
                 continue;
             const uint32_t row = meter * channels + c;
             float *line = data + size_t(row) * size;
@@ -146,7 +146,7 @@ namespace
         for (uint32_t c = 0; c < channels; ++c)
         {
             const chan_cfg cc = cfg[c];
-            if (!cc.enabled)
+            if (!cc.enabled || cc.unbound)                  // (the reference hands an unbound channel's stale buffer on: nothing here)
                 continue;
             const uint32_t row = meter * channels + c;
             const float *mb = msbuf + size_t(row) * msbuf_stride;
@@ -375,7 +375,7 @@ int mi_loudness_bank_set_active(mi_loudness_bank_t *b, uint32_t channel, int act
     b->cfg_dirty = true;
     for (uint32_t m = 0; m < b->meters; ++m)                // a disabled channel's filter is not run: its memory freezes (:420-422)
     {
-        const int r = mi_biquad_bank_set_row_enabled(b->filters, m * b->channels + channel, active);
+        const int r = mi_biquad_bank_set_row_enabled(b->filters, m * b->channels + channel, active && !b->cfg[channel].unbound);
         if (r != MI_OK)
             return r;
     }
@@ -385,6 +385,25 @@ int mi_loudness_bank_set_active(mi_loudness_bank_t *b, uint32_t channel, int act
         MI_HIP_CHECK(hipMemset2DAsync(b->d_data + size_t(channel) * b->data_size, size_t(b->channels) * b->data_size * sizeof(float), 0,
                                       size_t(b->data_size) * sizeof(float), b->meters, st));
         MI_HIP_CHECK(hipMemset2DAsync(b->d_ms + channel, b->channels * sizeof(float), 0, sizeof(float), b->meters, st));
+    }
+    return MI_OK;
+}
+
+int mi_loudness_bank_set_bound(mi_loudness_bank_t *b, uint32_t channel, int bound)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_set_bound: NULL bank");
+    MI_REQUIRE(channel < b->channels, MI_EINVAL, "mi_loudness_bank_set_bound: channel %u out of range", channel);
+    const int unbound = bound ? 0 : 1;
+    if (b->cfg[channel].unbound == unbound)
+        return MI_OK;
+    b->cfg[channel].unbound = unbound;
+    b->cfg_dirty = true;
+    const int run = (b->cfg[channel].enabled && !unbound) ? 1 : 0;
+    for (uint32_t m = 0; m < b->meters; ++m)
+    {
+        const int r = mi_biquad_bank_set_row_enabled(b->filters, m * b->channels + channel, run);
+        if (r != MI_OK)
+            return r;
     }
     return MI_OK;
 }

@@ -1,5 +1,5 @@
 // lsp::dspu::LoudnessMeter on the GPU library (one meter, bound host pointers; the device-resident form for many
-// meters is mi_loudness_bank_*).  A channel bound without an input is measured as silence.
+// meters is mi_loudness_bank_*).
 #ifndef MI_LSP_PLUG_IN_DSP_UNITS_METERS_LOUDNESSMETER_H_
 #define MI_LSP_PLUG_IN_DSP_UNITS_METERS_LOUDNESSMETER_H_
 

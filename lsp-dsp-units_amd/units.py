@@ -451,6 +451,9 @@ class LoudnessBank:
     def set_active(self, channel, active=True, stream=None):
         check(lib.mi_loudness_bank_set_active(self.handle, channel, 1 if active else 0, _stream(stream)))
 
+    def set_bound(self, channel, bound=True):
+        check(lib.mi_loudness_bank_set_bound(self.handle, channel, 1 if bound else 0))
+
     def clear(self, stream=None):
         check(lib.mi_loudness_bank_clear(self.handle, _stream(stream)))
 

@@ -40,7 +40,7 @@ def _hsum(v):
 class LoudnessMeter:
     def __init__(self, channels, max_period=400.0):
         self.nch = channels
-        self.ch = [dict(weight=F(0.0), link=F(1.0), desig=CHANNEL_NONE, enabled=True, ms=F(0.0), data=None,
+        self.ch = [dict(weight=F(0.0), link=F(1.0), desig=CHANNEL_NONE, enabled=True, bound=True, ms=F(0.0), data=None,
                         coef=None, state=None) for _ in range(channels)]
         if channels == 1:
             self.ch[0]["desig"] = CHANNEL_CENTER
@@ -69,6 +69,9 @@ class LoudnessMeter:
         c["enabled"] = bool(active)
         if active and c["data"] is not None:
             c["data"][:] = 0; c["ms"] = F(0.0)
+
+    def set_bound(self, i, bound=True):                       # bind(id, out, in) with in == NULL or not
+        self.ch[i]["bound"] = bool(bound)
 
     def set_weighting(self, w):
         if w != self.weighting:
@@ -146,7 +149,7 @@ class LoudnessMeter:
             vms = {}
             mixed = 0
             for i, c in enumerate(self.ch):
-                if not c["enabled"]:
+                if not c["enabled"] or not c["bound"]:           # vIn == NULL: left out of the block (:421-422)
                     continue
                 y, c["state"] = B.biquad_cascade(x[i, off:off + todo], c["coef"], c["state"])
                 idx = (self.head + np.arange(todo)) & mask
@@ -167,7 +170,7 @@ class LoudnessMeter:
             if gain is None:                                    # only process(out, count) records fLoudness (:485)
                 self.loud = buf[-1]
             for i, c in enumerate(self.ch):
-                if not c["enabled"]:
+                if not c["enabled"] or not c["bound"]:           # (an unbound channel's output is a stale buffer in the reference)
                     continue
                 r = np.sqrt(np.maximum(vms[i], F(0.0))).astype(np.float32)
                 if c["link"] <= 0:

@@ -141,7 +141,7 @@ def test_random_operation_sequences(gpu, seed):
     weight = ol.WEIGHT_K
     log = []
     for step in range(40):
-        op = rng.choice(["process", "process", "process", "period", "weighting", "designation", "link", "active", "clear"])
+        op = rng.choice(["process", "process", "process", "period", "weighting", "designation", "link", "active", "bound", "clear"])
         if op == "process":
             n = int(rng.choice([1, 100, 1023, 1024, 1025, 4096, 4097, int(rng.integers(1, 9000))]))
             x = (rng.standard_normal((M * K, n)) * 0.2).astype(np.float32)
@@ -156,7 +156,7 @@ def test_random_operation_sequences(gpu, seed):
                 peak = max(float(np.abs(o).max()), float(np.abs(c).max()), 1e-3)
                 assert float(np.abs(y[m] - o).max()) <= tol * peak, (seed, step, m, log[-8:])
                 for k in range(K):
-                    if refs[m].ch[k]["enabled"]:
+                    if refs[m].ch[k]["enabled"] and refs[m].ch[k]["bound"]:
                         assert float(np.abs(yc[m * K + k] - c[k]).max()) <= tol * peak, (seed, step, m, k, log[-8:])
                     else:
                         assert np.all(yc[m * K + k] == -1.0)
