@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral"],
+    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral", "crossover", "splitter", "loudness"],
                     help="all = headline biquad line with the convolver result attached under \"convolver\"")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
@@ -340,6 +340,99 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     }
 
 
+def _step_result(name, workload, C, n, steps, elapsed, world, bytes_per_sample, extra=None):
+    """Sub-result of a SURVEY 8f row: whole-step throughput against the algorithmic bytes (several launches per step)."""
+    step_bytes = float(bytes_per_sample) * C * n
+    res = {"value": round(C * n * world * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+           "ms_per_step": round(elapsed / steps * 1e3, 5),
+           "config": {"workload": workload, "channels_per_gpu": C, "block": n},
+           "whole_step": {"algorithmic_bytes": step_bytes, "bytes_per_channel_sample": bytes_per_sample,
+                          "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / steps) / 1e9, 1),
+                          "frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
+    if extra:
+        res.update(extra)
+    return res
+
+
+def run_crossover(args, mi, torch, dist, rank, world, dev):
+    """IIR Crossover, 4 bands LR4 (3 split points), 1024 channels x 4096 samples per step.
+    Algorithmic bytes: 4 B in + 4 bands x 4 B out = 20 B per channel-sample."""
+    C, bands, n = 1024, 4, 4096
+    xo = mi.CrossoverBank(C, bands)
+    xo.set_sample_rate(48000)
+    for i, f in enumerate((200.0, 1500.0, 7000.0)):
+        xo.set_slope(i, 2); xo.set_frequency(i, f)
+    ring = 4
+    gen = torch.Generator(device="cpu"); gen.manual_seed(70 + rank)
+    xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    outs = [[torch.empty((C, n), dtype=torch.float32, device=dev) for _ in range(bands)] for _ in range(ring)]
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        xo.process(outs[i % ring], xin[i % ring], n, stream=stream)
+    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    assert all(bool(torch.isfinite(o).all()) for o in outs[0])
+    xo.close()
+    if rank != 0:
+        return None
+    return _step_result("crossover", "Crossover (IIR), 4 bands LR4, %d channels per GPU, 4096-sample blocks" % C,
+                        C, n, args.conv_steps, elapsed, world, 20.0)
+
+
+def run_splitter(args, mi, torch, dist, rank, world, dev):
+    """FFTCrossover / SpectralSplitter, rank 12 (frames of 2048 new samples), 4 bands of real gains,
+    256 channels x 4096 samples per step.  Algorithmic bytes: 4 B in + 4 x 4 B out = 20 B per channel-sample."""
+    C, bands, rank_fft, n = 256, 4, 12, 4096
+    sp = mi.SplitterBank(C, rank_fft, bands)
+    edges = [(None, (300.0, -32.0)), ((300.0, -32.0), (2000.0, -32.0)), ((2000.0, -32.0), (8000.0, -32.0)), ((8000.0, -32.0), None)]
+    for b, (hp, lp) in enumerate(edges):
+        sp.bind_mask(b, mi.crossover_fft_mask(hp, lp, 1.0, 1.0, 48000, rank_fft))
+    ring = 4
+    gen = torch.Generator(device="cpu"); gen.manual_seed(80 + rank)
+    xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    outs = [[torch.empty((C, n), dtype=torch.float32, device=dev) for _ in range(bands)] for _ in range(ring)]
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        sp.process(outs[i % ring], xin[i % ring], n, stream=stream)
+    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    assert all(bool(torch.isfinite(o).all()) for o in outs[0])
+    sp.close()
+    if rank != 0:
+        return None
+    return _step_result("splitter", "FFTCrossover / SpectralSplitter, rank 12, 4 bands, %d channels per GPU, 4096-sample "
+                        "blocks (two transforms of 4096 points forward and eight back per channel and step)" % C,
+                        C, n, args.conv_steps, elapsed, world, 20.0)
+
+
+def run_loudness(args, mi, torch, dist, rank, world, dev):
+    """512 stereo LoudnessMeter (K weighting, 400 ms) + 512 stereo ILUFSMeter on the same 1024 channel
+    rows, 4096 samples per step.  Algorithmic bytes per channel-sample: 4 B in + 2 B of the meter's output row (one row
+    per two channels) for each of the two meters = 8 B."""
+    M, K, n = 512, 2, 4096
+    lm = mi.LoudnessBank(M, K, 400.0)
+    lm.set_sample_rate(48000)
+    im = mi.ILUFSBank(M, K, 10.0, 400.0)
+    im.set_sample_rate(48000)
+    ring = 4
+    gen = torch.Generator(device="cpu"); gen.manual_seed(90 + rank)
+    xin = (torch.randn((ring, M * K, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    o1 = torch.empty((M, n), dtype=torch.float32, device=dev)
+    o2 = torch.empty((M, n), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        lm.process(o1, None, xin[i % ring], n, stream=stream)
+        im.process(o2, xin[i % ring], n, stream=stream)
+    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    assert bool(torch.isfinite(o1).all()) and bool(torch.isfinite(o2).all())
+    lm.close(); im.close()
+    if rank != 0:
+        return None
+    return _step_result("loudness", "LoudnessMeter + ILUFSMeter (K weighting), %d stereo meters each per GPU, 4096-sample "
+                        "blocks" % M, M * K, n, args.conv_steps, elapsed, world, 8.0)
+
+
 def main():
     args = parse()
     import numpy as np
@@ -360,8 +453,9 @@ def main():
     mi.check(mi.lib.mi_dspu_set_device(local_rank))
     import workloads as wl
 
-    if args.workload in ("convolver", "equalizer", "spectral"):
-        runner = {"convolver": run_convolver, "equalizer": run_equalizer, "spectral": run_spectral}[args.workload]
+    if args.workload in ("convolver", "equalizer", "spectral", "crossover", "splitter", "loudness"):
+        runner = {"convolver": run_convolver, "equalizer": run_equalizer, "spectral": run_spectral,
+                  "crossover": run_crossover, "splitter": run_splitter, "loudness": run_loudness}[args.workload]
         res = runner(args, mi, torch, dist, rank, world, dev)
         if rank == 0:
             line = {"metric": "Msamples/sec per GPU (biquad-x8 1024ch; Convolver 65536-tap) + HBM roofline %",
@@ -451,10 +545,13 @@ def main():
         conv = run_convolver(args, mi, torch, dist, rank, world, dev)
         eqr = run_equalizer(args, mi, torch, dist, rank, world, dev)
         spr = run_spectral(args, mi, torch, dist, rank, world, dev)
+        nxt = {name: fn(args, mi, torch, dist, rank, world, dev)
+               for name, fn in (("crossover", run_crossover), ("splitter", run_splitter), ("loudness", run_loudness))}
         if rank == 0:
             line["convolver"] = conv
             line["equalizer"] = eqr
             line["spectral"] = spr
+            line["next_rows"] = nxt
     if rank == 0:
         print(json.dumps(line), flush=True)
 

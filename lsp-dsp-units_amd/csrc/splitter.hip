@@ -35,6 +35,16 @@ namespace
 
     enum { H_OFF = 0, H_COPY = 1, H_MASK = 2, H_CALLBACK = 3 };
 
+    // the caller's output rows travel by value with the launch (no device copy of a pointer table to keep in step with the
+    // stream); banks with more handlers fall back to the table
+    constexpr uint32_t OUTS_BY_VALUE = 16;
+    struct out_table
+    {
+        float *p[OUTS_BY_VALUE];
+        float *const *more;             // handlers > OUTS_BY_VALUE: device array
+        __device__ __forceinline__ float *at(uint32_t h) const { return (more != nullptr) ? more[h] : p[h]; }
+    };
+
     struct handler_desc
     {
         const float *mask;              // H_MASK: [channels or 1][mask_stride] real gains, N per row
@@ -43,10 +53,11 @@ namespace
         uint32_t     has_sink;          // overlap-add only where somebody listens (SpectralSplitter.cpp:333)
     };
 
-    // overlap-add of 2*frame windowed samples y (as pairs) into a handler's line: the line moves on by one frame
+    // overlap-add of 2*frame windowed samples y (as pairs) into a handler's line: the line moves on by one frame.
+    // emit (or NULL): where the frame that is finished now -- the first half of the line -- goes in the caller's buffer.
     template <typename GET>
     __device__ __forceinline__ void overlap_add(float2 *line, const float2 *__restrict__ wnd, uint32_t frame, int tid, int T,
-                                                float scale, GET y)
+                                                float scale, float *emit, GET y)
     {
         const uint32_t hp = frame >> 1;                                 // a frame of samples is frame/2 pairs
         for (uint32_t m = tid; m < hp; m += T)
@@ -54,33 +65,60 @@ namespace
             // a thread owns pair m of both frames of the line: the old second frame is read before it is overwritten
             const float2 y0 = y(m), y1 = y(m + hp), w0 = wnd[m], w1 = wnd[m + hp];
             const float2 prev = line[m + hp];
-            line[m]      = make_float2(fmaf(y0.x * scale, w0.x, prev.x), fmaf(y0.y * scale, w0.y, prev.y));
+            const float2 done = make_float2(fmaf(y0.x * scale, w0.x, prev.x), fmaf(y0.y * scale, w0.y, prev.y));
+            line[m]      = done;
             line[m + hp] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+            if (emit != nullptr)
+            {
+                emit[2 * m]     = done.x;
+                emit[2 * m + 1] = done.y;
+            }
         }
     }
 
-    // One hop of one channel.  in_buf: [channels][in_pitch], the analysis buffer in its first N floats; lines:
+    // One hop of one channel.  in_cur / in_next: [channels][in_pitch], the analysis buffer in the first N floats -- read
+    // from one, written (moved on by one frame) into the other, so that several workgroups may work on a channel; lines:
     // [handlers][channels][line_pitch]; spec (only when WRITE_SPEC): [channels][N] complex.
-    template <int LOGH, bool WRITE_SPEC>
+    // gridDim.y == 1: the workgroup serves every handler of its channel (the input is read and transformed once);
+    // gridDim.y == handlers: one handler each (few channels: more workgroups than CUs matter more than the repeated
+    // forward transform); workgroup y == 0 moves the analysis buffer on.
+    // Fused streaming (ingest_n > 0): the `frame` samples that follow the hop are taken from `src` (NULL: silence) into the
+    // new analysis buffer, and the frame every handler finishes goes straight to the caller's buffers.
+    template <int LOGH, bool WRITE_SPEC, bool PER_BAND>
     __global__ __launch_bounds__(plan<LOGH>::T)
-    void splitter_hop_kernel(float *in_buf, size_t in_pitch, float *lines, size_t line_pitch, uint32_t channels,
-                             const handler_desc *__restrict__ hd, uint32_t handlers, const float *__restrict__ wnd,
-                             uint32_t frame, float2 *spec, const float2 *__restrict__ tw)
+    void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
+                             uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
+                             const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
+                             const float *src, size_t src_stride, uint32_t ingest_n, const out_table outs,
+                             size_t out_stride, size_t out_pos)
     {
         using PL = plan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, PER = (H + T - 1) / T;
         __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
+        constexpr bool all = !PER_BAND;
+        const uint32_t h0 = all ? 0 : blockIdx.y, h1 = all ? handlers : blockIdx.y + 1;
+        const bool owner = all || (blockIdx.y == 0);
+        bool masks = WRITE_SPEC && owner;
+        for (uint32_t h = h0; h < h1; ++h)
+            masks = masks || (hd[h].mode == H_MASK && hd[h].has_sink);
+        bool copies = false;
+        for (uint32_t h = h0; h < h1; ++h)
+            copies = copies || (hd[h].mode == H_COPY && hd[h].has_sink);
+        if (!owner && !masks && !copies)
+            return;
         real_fft<LOGH> rf;
-        rf.load(tw, TWN, tid);
-        float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * in_pitch);
+        if (masks)
+            rf.load(tw, TWN, tid);
+        const float2 *x2 = reinterpret_cast<const float2 *>(in_cur + size_t(ch) * in_pitch);
         const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
 
         float2 xr[PER];
         #pragma unroll
         for (int i = 0; i < PER; ++i)
             xr[i] = (tid + i * T < H) ? x2[tid + i * T] : make_float2(0.0f, 0.0f);
-        rf.prepare();
+        if (masks)
+            rf.prepare();
         #pragma unroll
         for (int i = 0; i < PER; ++i)
             if (tid + i * T < H)
@@ -88,30 +126,50 @@ namespace
         __syncthreads();
 
         // handlers without a spectral function see the head of the analysis buffer as it is
-        for (uint32_t h = 0; h < handlers; ++h)
+        for (uint32_t h = h0; h < h1; ++h)
         {
             if (hd[h].mode != H_COPY || !hd[h].has_sink)
                 continue;
             float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
-            overlap_add(line, w2, frame, tid, T, 1.0f, [&](uint32_t m) { return buf[m]; });
+            float *emit = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+            overlap_add(line, w2, frame, tid, T, 1.0f, emit, [&](uint32_t m) { return buf[m]; });
         }
-        // the analysis buffer moves on by one frame (every read of it above has completed: the values went through LDS)
-        #pragma unroll
-        for (int i = 0; i < PER; ++i)
+        if (owner)
         {
-            const int m = tid + i * T;
-            if (m >= int(frame >> 1) && m < H)
-                x2[m - (frame >> 1)] = xr[i];
+            // the analysis buffer moves on by one frame, then takes the samples of the frame that follows
+            float *nx = in_next + size_t(ch) * in_pitch;
+            float2 *n2 = reinterpret_cast<float2 *>(nx);
+            #pragma unroll
+            for (int i = 0; i < PER; ++i)
+            {
+                const int m = tid + i * T;
+                if (m >= int(frame >> 1) && m < H)
+                    n2[m - (frame >> 1)] = xr[i];
+            }
+            if (ingest_n > 0)
+            {
+                const float *sx = (src != nullptr) ? src + size_t(ch) * src_stride : nullptr;
+                for (uint32_t i = tid; i < ingest_n; i += T)
+                    nx[N - frame + i] = (sx != nullptr) ? sx[i] : 0.0f;
+            }
         }
+        if (!masks)
+            return;
         __syncthreads();
 
         rf.forward(buf, scr, tid);
-        float2 sp[PER];
-        #pragma unroll
-        for (int i = 0; i < PER; ++i)
-            sp[i] = (tid + i * T < H) ? buf[tid + i * T] : make_float2(0.0f, 0.0f);
+        // several handlers per workgroup: the spectrum waits in registers while they take turns in LDS; one handler per
+        // workgroup shapes it where it is
+        constexpr int KEEP = PER_BAND ? 1 : PER;
+        float2 sp[KEEP];
+        if (!PER_BAND || WRITE_SPEC)
+        {
+            #pragma unroll
+            for (int i = 0; i < KEEP; ++i)
+                sp[i] = (tid + i * T < H) ? buf[tid + i * T] : make_float2(0.0f, 0.0f);
+        }
 
-        if (WRITE_SPEC)
+        if (WRITE_SPEC && owner)
         {
             float2 *so = spec + size_t(ch) * N;
             #pragma unroll
@@ -134,19 +192,20 @@ namespace
         }
 
         const float scale = 1.0f / float(N);
-        for (uint32_t h = 0; h < handlers; ++h)
+        for (uint32_t h = h0; h < h1; ++h)
         {
             if (hd[h].mode != H_MASK || !hd[h].has_sink)
                 continue;
             const float *g = hd[h].mask + size_t(ch) * hd[h].mask_stride;
-            __syncthreads();                                            // the previous handler is done with buf
+            if (!PER_BAND)
+                __syncthreads();                                        // the previous handler is done with buf
             #pragma unroll
             for (int i = 0; i < PER; ++i)
             {
                 const int k = tid + i * T;
                 if (k >= H)
                     continue;
-                float2 v = sp[i];
+                float2 v = PER_BAND ? buf[k] : sp[PER_BAND ? 0 : i];
                 if (k == 0)
                 {
                     v.x *= g[0];
@@ -164,8 +223,9 @@ namespace
             __syncthreads();
             rf.inverse(buf, scr, tid);
             float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
+            float *emit = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
             const uint32_t first = uint32_t(H) - frame;                // the last 2*frame samples, in pairs
-            overlap_add(line, w2, frame, tid, T, scale, [&](uint32_t m) { return buf[first + m]; });
+            overlap_add(line, w2, frame, tid, T, scale, emit, [&](uint32_t m) { return buf[first + m]; });
         }
     }
 
@@ -199,7 +259,7 @@ namespace
         rf.inverse(buf, scr, tid);
         float2 *line = reinterpret_cast<float2 *>(line0 + size_t(ch) * line_pitch);
         const uint32_t first = uint32_t(H) - frame;                    // the last 2*frame samples, in pairs
-        overlap_add(line, reinterpret_cast<const float2 *>(wnd), frame, tid, T, 1.0f / float(N),
+        overlap_add(line, reinterpret_cast<const float2 *>(wnd), frame, tid, T, 1.0f / float(N), nullptr,
                     [&](uint32_t m) { return buf[first + m]; });
     }
 
@@ -207,7 +267,7 @@ namespace
     // grid (pieces of 256, channels, handlers + 1): z == 0 is the input, z - 1 the handler
     __global__ __launch_bounds__(256)
     void splitter_io_kernel(float *in_buf, size_t in_pitch, uint32_t in_pos, const float *__restrict__ src, size_t src_stride,
-                            const float *__restrict__ lines, size_t line_pitch, uint32_t line_pos, float *const *__restrict__ outs,
+                            const float *__restrict__ lines, size_t line_pitch, uint32_t line_pos, const out_table outs,
                             size_t out_stride, size_t out_pos, uint32_t channels, uint32_t n)
     {
         const uint32_t i = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y, z = blockIdx.z;
@@ -217,7 +277,7 @@ namespace
             in_buf[size_t(ch) * in_pitch + in_pos + i] = (src != nullptr) ? src[size_t(ch) * src_stride + i] : 0.0f;
         else
         {
-            float *o = outs[z - 1];
+            float *o = outs.at(z - 1);
             if (o != nullptr)
                 o[size_t(ch) * out_stride + out_pos + i] = lines[(size_t(z - 1) * channels + ch) * line_pitch + line_pos + i];
         }
@@ -242,7 +302,7 @@ struct mi_splitter_bank
     uint32_t    bindings = 0;
     std::vector<handler_t> h;
     std::vector<uint8_t> has_sink;
-    float      *d_in = nullptr, *d_lines = nullptr, *d_wnd = nullptr;
+    float      *d_in = nullptr, *d_in2 = nullptr, *d_lines = nullptr, *d_wnd = nullptr;    // d_in: current analysis buffers, d_in2: the other half of the pair
     float2     *d_spec = nullptr, *d_tmp = nullptr;
     handler_desc *d_desc = nullptr;
     float     **d_outs = nullptr;
@@ -264,6 +324,7 @@ namespace
     int splitter_clear(mi_splitter_bank *b, hipStream_t st)                              // SpectralSplitter.cpp:246-258
     {
         MI_HIP_CHECK(hipMemsetAsync(b->d_in, 0, size_t(b->channels) * b->pitch * sizeof(float), st));
+        MI_HIP_CHECK(hipMemsetAsync(b->d_in2, 0, size_t(b->channels) * b->pitch * sizeof(float), st));
         // every line: a handler nobody listens to never adds to its line, and bind() clears it anyway
         MI_HIP_CHECK(hipMemsetAsync(b->d_lines, 0, size_t(b->handlers) * b->channels * b->pitch * sizeof(float), st));
         return MI_OK;
@@ -317,30 +378,62 @@ namespace
             default: { CALL(13); break; }               \
         }
 
-    int splitter_hop(mi_splitter_bank *b, hipStream_t st)
+    out_table splitter_outs(const mi_splitter_bank *b)
+    {
+        out_table t;
+        for (uint32_t i = 0; i < OUTS_BY_VALUE; ++i)
+            t.p[i] = (i < b->handlers) ? b->outs_shadow[i] : nullptr;
+        t.more = (b->handlers > OUTS_BY_VALUE) ? b->d_outs : nullptr;
+        return t;
+    }
+
+    bool splitter_has_callbacks(const mi_splitter_bank *b)
+    {
+        for (uint32_t i = 0; i < b->handlers; ++i)
+            if (b->h[i].mode == H_CALLBACK)
+                return true;
+        return false;
+    }
+
+    // src / src_stride / ingest_n / out_stride / out_pos: the fused streaming of splitter_hop_kernel (ingest_n == 0: none)
+    int splitter_hop(mi_splitter_bank *b, hipStream_t st, const float *src, size_t src_stride, uint32_t ingest_n,
+                     size_t out_stride, size_t out_pos)
     {
         const int lh = int(b->rank) - 1;
         const uint32_t frame = 1u << (b->chunk_rank - 1);
-        const dim3 grid(b->channels);
-        bool callbacks = false;
-        for (uint32_t i = 0; i < b->handlers; ++i)
-            callbacks = callbacks || (b->h[i].mode == H_CALLBACK);
+        const bool callbacks = splitter_has_callbacks(b);
+        // few channels: one workgroup per handler (the forward transform is repeated, the device is filled)
+        const dim3 grid(b->channels, (!callbacks && b->handlers > 1 && b->channels * 2 <= 1024) ? b->handlers : 1);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         if (!callbacks)
         {
-            #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
-                b->d_in, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, (float2 *)nullptr, b->d_tw)
-            MI_LOGH_SWITCH(lh, MI_CALL)
-            #undef MI_CALL
+            #define MI_ARGS b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, \
+                (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos
+            if (grid.y > 1)
+            {
+                #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, false, true>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, MI_ARGS)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+            }
+            else
+            {
+                #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, false, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, MI_ARGS)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+            }
+            #undef MI_ARGS
             MI_HIP_CHECK(hipGetLastError());
+            std::swap(b->d_in, b->d_in2);
             return MI_OK;
         }
-        #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, true>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
-            b->d_in, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, b->d_spec, b->d_tw)
+        #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, true, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+            b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, b->d_spec, \
+            b->d_tw, (const float *)nullptr, size_t(0), 0u, splitter_outs(b), size_t(0), size_t(0))
         MI_LOGH_SWITCH(lh, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
+        std::swap(b->d_in, b->d_in2);
         for (uint32_t i = 0; i < b->handlers; ++i)
         {
             mi_splitter_bank::handler_t &h = b->h[i];
@@ -399,11 +492,13 @@ int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32
     {
         const size_t row = size_t(channels) * b->pitch;
         e = hipMalloc(reinterpret_cast<void **>(&b->d_in), row * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_in2), row * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_lines), row * handlers * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), b->pitch * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_desc), handlers * sizeof(handler_desc));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_outs), handlers * sizeof(float *));
         if (e == hipSuccess) e = hipMemset(b->d_in, 0, row * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_in2, 0, row * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_lines, 0, row * handlers * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_outs, 0, handlers * sizeof(float *));
     }
@@ -422,7 +517,7 @@ int mi_splitter_bank_destroy(mi_splitter_bank_t *b)
         return MI_OK;
     for (mi_splitter_bank::handler_t &h : b->h)
         (void)hipFree(h.d_mask);
-    (void)hipFree(b->d_in); (void)hipFree(b->d_lines); (void)hipFree(b->d_wnd); (void)hipFree(b->d_desc);
+    (void)hipFree(b->d_in); (void)hipFree(b->d_in2); (void)hipFree(b->d_lines); (void)hipFree(b->d_wnd); (void)hipFree(b->d_desc);
     (void)hipFree(b->d_outs); (void)hipFree(b->d_spec); (void)hipFree(b->d_tmp);
     delete b;
     return MI_OK;
@@ -588,7 +683,7 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
             outs_changed = true;
         }
     }
-    if (outs_changed)
+    if (outs_changed && b->handlers > OUTS_BY_VALUE)
     {
         MI_HIP_CHECK(hipMemcpyAsync(b->d_outs, b->outs_shadow.data(), b->handlers * sizeof(float *), hipMemcpyHostToDevice, st));
         MI_HIP_CHECK(hipStreamSynchronize(st));
@@ -601,20 +696,30 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
     }
     const uint32_t N = 1u << b->rank, frame = 1u << (b->chunk_rank - 1), gap = N - frame;
     size_t done = 0;
+    const bool callbacks = splitter_has_callbacks(b);
     while (done < count)
     {
         if (b->fill >= frame)                                           // a frame is complete: transform (:311-356)
         {
-            const int r = splitter_hop(b, st);
+            // a whole frame follows in this call: the transform kernel takes it in and hands the finished frame out itself
+            const bool fused = !callbacks && (count - done >= frame);
+            const int r = fused ? splitter_hop(b, st, (in != nullptr) ? in + done : nullptr, in_stride, frame, out_stride, done)
+                                : splitter_hop(b, st, nullptr, 0, 0, 0, 0);
             if (r != MI_OK)
                 return r;
             b->fill = 0;
+            if (fused)
+            {
+                b->fill = frame;
+                done += frame;
+                continue;
+            }
         }
         const uint32_t n = uint32_t(std::min<size_t>(frame - b->fill, count - done));
         const dim3 grid((n + 255) / 256, b->channels, b->handlers + 1);
         hipLaunchKernelGGL(splitter_io_kernel, grid, dim3(256), 0, st, b->d_in, b->pitch, gap + b->fill,
                            (in != nullptr) ? in + done : (const float *)nullptr, in_stride, b->d_lines, b->pitch, b->fill,
-                           b->d_outs, out_stride, done, b->channels, n);
+                           splitter_outs(b), out_stride, done, b->channels, n);
         MI_HIP_CHECK(hipGetLastError());
         b->fill += n;
         done += n;
