@@ -50,7 +50,7 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_biquad(coef, samples, budget_s=3.0):
+def cpu_baseline_biquad(coef, samples, budget_s=6.0):
     """CPU oracle ("port" of the reference algorithm) on this host's cores: repeat 1024ch x 4096 blocks
     until ~budget_s of wall time (x cores of CPU work) has been spent."""
     import numpy as np
@@ -102,7 +102,7 @@ def _profile_avg_us(workload, kernel):
     return None
 
 
-def cpu_baseline_convolver(irs, frame, budget_s=4.0):
+def cpu_baseline_convolver(irs, frame, budget_s=6.0):
     """Oracle Convolver (restated reference algorithm: non-uniform partitions, scalar C) on this host's cores:
     one object per channel, whole 4096-sample frames, as many channels as fit in ~budget_s."""
     import numpy as np
