@@ -20,7 +20,7 @@ namespace
 {
     constexpr uint32_t BUFFER_SIZE = 0x400;                 // LoudnessMeter.cpp:32
     constexpr int      LT = 256;                            // threads per meter
-    constexpr uint32_t MAX_BLOCK = 8192;                    // samples per launch (LDS: two float arrays of this size)
+    constexpr uint32_t MAX_BLOCK = 4096;                    // samples per launch: 16 register-resident passes of LT samples
 
     // bs::channel_weighting (src/main/misc/broadcast.cpp:32-55)
     float channel_weighting(int designation)
@@ -51,9 +51,29 @@ namespace
             return;
         const float *d = data + size_t(row) * size;
         const uint32_t tail = (head + size - period) & (size - 1);
-        float s = 0.0f;
-        for (uint32_t i = tid; i < period; i += LT)
-            s += d[(tail + i) & (size - 1)];
+        // 16-byte cells of the ring that cover [tail, tail + period); the cells at both ends are cut to the window
+        const uint32_t lead = tail & 3u, first = tail - lead, cells = (lead + period + 3u) >> 2;
+        float s0 = 0.0f, s1 = 0.0f;
+        for (uint32_t q = tid; q < cells; q += LT)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(d + ((first + 4u * q) & (size - 1)));
+            const uint32_t at = 4u * q;                     // position of the cell's first float, counted from `first`
+            const bool inner = at >= lead && at + 4u <= lead + period;
+            if (inner)
+            {
+                s0 += v.x + v.z;
+                s1 += v.y + v.w;
+            }
+            else
+            {
+                const float e[4] = { v.x, v.y, v.z, v.w };
+                #pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (at + k >= lead && at + k < lead + period)
+                        s0 += e[k];
+            }
+        }
+        const float s = s0 + s1;
         part[tid] = s;
         __syncthreads();
         for (int w = LT / 2; w > 0; w >>= 1)
@@ -66,22 +86,42 @@ namespace
             ms[row] = part[0];
     }
 
-    // one block of `n` samples of one meter
+    // inclusive sum scan over the 64 lanes with DPP: shifts inside the rows of 16 lanes, then the sums of rows 0 and 2 to
+    // rows 1 and 3 (row_bcast:15) and of the lower half to the upper half (row_bcast:31)
+    template <int CTRL, int ROW_MASK, bool ZERO_FILL>
+    __device__ __forceinline__ float dpp_term(float v)
+    {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, ZERO_FILL));
+    }
+
+    __device__ __forceinline__ float wave_scan(float v)
+    {
+        v += dpp_term<0x111, 0xf, true>(v);                 // row_shr:1
+        v += dpp_term<0x112, 0xf, true>(v);                 // row_shr:2
+        v += dpp_term<0x114, 0xf, true>(v);                 // row_shr:4
+        v += dpp_term<0x118, 0xf, true>(v);                 // row_shr:8
+        v += dpp_term<0x142, 0xa, false>(v);                // row_bcast:15 into rows 1 and 3
+        v += dpp_term<0x143, 0xc, false>(v);                // row_bcast:31 into rows 2 and 3
+        return v;
+    }
+
+    // one block of `n` <= E * LT samples of one meter
+    template <uint32_t E>                                   // passes: sample j = i * LT + tid lives in register i of thread tid
     __global__ __launch_bounds__(LT)
     void loudness_block_kernel(float *out, float *ch_out, size_t out_stride, const float *__restrict__ flt, size_t flt_stride,
                                float *data, uint32_t size, uint32_t head, uint32_t period, float avg, float *ms,
                                float *msbuf, size_t msbuf_stride, const chan_cfg *__restrict__ cfg, uint32_t channels,
                                uint32_t n, float gain, float *loud)
     {
-        __shared__ float sq[MAX_BLOCK];                     // this channel's squares (new values)
-        __shared__ float mix[MAX_BLOCK];                    // weighted sum of the channels' mean squares
-        __shared__ float tot[LT];
+        __shared__ float sq[E * LT];                        // this channel's squares (new values)
+        __shared__ __align__(16) float wtot[E][LT / 64];    // sums of the waves of every pass
         const uint32_t meter = blockIdx.x, tid = threadIdx.x, mask = size - 1;
-        const uint32_t E = (n + LT - 1) / LT;               // elements per thread (a contiguous run)
-        const uint32_t j0 = tid * E, j1 = (j0 + E < n) ? j0 + E : n;
+        const uint32_t lane = tid & 63, wave = tid >> 6;
         const uint32_t tail = (head + size - period) & mask;
-        for (uint32_t j = tid; j < n; j += LT)
-            mix[j] = 0.0f;
+        float mix[E];                                       // weighted sum of the channels' mean squares
+        #pragma unroll
+        for (uint32_t i = 0; i < E; ++i)
+            mix[i] = 0.0f;
         uint32_t mixed = 0;
         for (uint32_t c = 0; c < channels; ++c)
         {
@@ -91,56 +131,74 @@ namespace
             const uint32_t row = meter * channels + c;
             float *line = data + size_t(row) * size;
             const float *x = flt + size_t(row) * flt_stride;
-            __syncthreads();
-            for (uint32_t j = tid; j < n; j += LT)          // dsp::sqr2 into the line (LoudnessMeter.cpp:428-436)
+            float d[E], old[E];
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)                // every load of the block is issued before anything waits
             {
-                const float v = x[j] * x[j];
-                sq[j] = v;
-                line[(head + j) & mask] = v;
+                const uint32_t j = i * LT + tid;
+                d[i] = (j < n) ? x[j] : 0.0f;
+                old[i] = (j < n && j < period) ? line[(tail + j) & mask] : 0.0f;
+            }
+            const float start = ms[row];
+            __syncthreads();                                // the previous channel is through with sq[] and wtot[]
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)                // dsp::sqr2 into the line (LoudnessMeter.cpp:428-436)
+            {
+                const uint32_t j = i * LT + tid;
+                d[i] *= d[i];
+                if (j < n)
+                {
+                    sq[j] = d[i];
+                    line[(head + j) & mask] = d[i];
+                }
             }
             __syncthreads();
-            // ms_j = ms_(j-1) + (new_j - old_j): local prefix over the thread's run, then the runs are chained
-            float run = 0.0f;
-            for (uint32_t j = j0; j < j1; ++j)
+            // ms_j = ms_(j-1) + (new_j - old_j): an inclusive scan of every pass inside the wave, the sums of the waves
+            // through LDS, then the running sum carried from pass to pass
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
             {
-                const float old = (j >= period) ? sq[j - period] : line[(tail + j) & mask];
-                run += sq[j] - old;
+                const uint32_t j = i * LT + tid;
+                if (j < n)
+                    d[i] -= (j >= period) ? sq[j - period] : old[i];
+                d[i] = wave_scan(d[i]);
+                if (lane == 63)
+                    wtot[i][wave] = d[i];
             }
-            tot[tid] = run;
             __syncthreads();
-            float base = ms[row];
-            for (uint32_t k = 0; k < tid; ++k)              // 256 adds per thread: cheap next to the block, exact order
-                base += tot[k];
-            float acc = base;
+            float carry = start;
             float *mb = msbuf + size_t(row) * msbuf_stride;
-            for (uint32_t j = j0; j < j1; ++j)
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
             {
-                const float old = (j >= period) ? sq[j - period] : line[(tail + j) & mask];
-                acc += sq[j] - old;
-                const float m = avg * acc;                  // vMS[j] = fAvgCoeff * ms
-                mb[j] = m;
-                mix[j] = (mixed > 0) ? fmaf(m, cc.weight, mix[j]) : m * cc.weight;         // fmadd_k3 / mul_k3
+                const uint32_t j = i * LT + tid;
+                const float4 t = *reinterpret_cast<const float4 *>(wtot[i]);
+                static_assert(LT / 64 == 4, "one float4 of wave sums per pass");
+                float before = carry;
+                if (wave > 0) before += t.x;
+                if (wave > 1) before += t.y;
+                if (wave > 2) before += t.z;
+                const float m = avg * (before + d[i]);      // vMS[j] = fAvgCoeff * ms
+                if (j < n && ch_out != nullptr)
+                    mb[j] = m;
+                mix[i] = (mixed > 0) ? fmaf(m, cc.weight, mix[i]) : m * cc.weight;     // fmadd_k3 / mul_k3
+                carry += ((t.x + t.y) + t.z) + t.w;
             }
-            __syncthreads();
-            if (tid == LT - 1 || j1 == n)
-            {
-                if (j0 < n && j1 == n)
-                    ms[row] = acc;                          // the thread that owns the last sample carries the sum on
-            }
+            if (tid == 0)
+                ms[row] = carry;                            // the running sum goes on with the next block
             ++mixed;
         }
-        __syncthreads();
         // ssqrt1: sqrt of the non-negative part; then the outputs
-        for (uint32_t j = tid; j < n; j += LT)
+        #pragma unroll
+        for (uint32_t i = 0; i < E; ++i)
         {
-            const float l = (mix[j] > 0.0f) ? sqrtf(mix[j]) : 0.0f;
-            mix[j] = l;
-            if (out != nullptr)
-                out[size_t(meter) * out_stride + j] = l * gain;
+            const uint32_t j = i * LT + tid;
+            mix[i] = (mix[i] > 0.0f) ? sqrtf(mix[i]) : 0.0f;
+            if (out != nullptr && j < n)
+                out[size_t(meter) * out_stride + j] = mix[i] * gain;
+            if (loud != nullptr && j + 1 == n)
+                loud[meter] = mix[i];
         }
-        if (tid == 0 && n > 0 && loud != nullptr)
-            loud[meter] = (mix[n - 1] > 0.0f) ? mix[n - 1] : 0.0f;
-        __syncthreads();
         if (ch_out == nullptr)
             return;
         for (uint32_t c = 0; c < channels; ++c)
@@ -151,13 +209,17 @@ namespace
             const uint32_t row = meter * channels + c;
             const float *mb = msbuf + size_t(row) * msbuf_stride;
             float *o = ch_out + size_t(row) * out_stride;
-            for (uint32_t j = tid; j < n; j += LT)
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
             {
-                const float r = (mb[j] > 0.0f) ? sqrtf(mb[j]) : 0.0f;
+                const uint32_t j = i * LT + tid;
+                if (j >= n)
+                    continue;
+                const float r = (mb[j] > 0.0f) ? sqrtf(mb[j]) : 0.0f;   // written by this same thread above
                 float v;
                 if (cc.link <= 0.0f)       v = r * gain;
-                else if (cc.link >= 1.0f)  v = mix[j] * gain;
-                else                       v = mix[j] * (cc.link * gain) + r * ((1.0f - cc.link) * gain);     // mix_copy2
+                else if (cc.link >= 1.0f)  v = mix[i] * gain;
+                else                       v = mix[i] * (cc.link * gain) + r * ((1.0f - cc.link) * gain);     // mix_copy2
                 o[j] = v;
             }
         }
@@ -457,7 +519,9 @@ static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, co
         r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
         if (r != MI_OK)
             return r;
-        hipLaunchKernelGGL(loudness_block_kernel, dim3(b->meters), dim3(LT), 0, st,
+        auto kernel = (n <= 2 * LT) ? loudness_block_kernel<2> : (n <= 4 * LT) ? loudness_block_kernel<4> :
+                      (n <= 8 * LT) ? loudness_block_kernel<8> : loudness_block_kernel<MAX_BLOCK / LT>;
+        hipLaunchKernelGGL(kernel, dim3(b->meters), dim3(LT), 0, st,
                            out ? out + offset : nullptr, ch_out ? ch_out + offset : nullptr, out_stride, b->d_flt, b->cap,
                            b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, b->d_msbuf, b->cap, b->d_cfg,
                            b->channels, uint32_t(n), gain, remember ? b->d_loud : static_cast<float *>(nullptr));
