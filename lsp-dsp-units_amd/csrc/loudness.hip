@@ -572,41 +572,6 @@ namespace
 
     struct ilufs_state { uint32_t head, count; float loudness; uint32_t pad; };
 
-    // vBlock[row][part] += sum of squares of the row's filtered samples
-    __global__ __launch_bounds__(LT)
-    void ilufs_sqsum_kernel(float *block, uint32_t part, const float *__restrict__ flt, size_t flt_stride, uint32_t n,
-                            const chan_cfg *__restrict__ cfg, uint32_t channels)
-    {
-        __shared__ float partial[LT];
-        const uint32_t row = blockIdx.x, tid = threadIdx.x;
-        if (!cfg[row % channels].enabled)
-            return;
-        const float *x = flt + size_t(row) * flt_stride;
-        float s = 0.0f;
-        for (uint32_t i = tid; i < n; i += LT)
-            s = fmaf(x[i], x[i], s);
-        partial[tid] = s;
-        __syncthreads();
-        for (int w = LT / 2; w > 0; w >>= 1)
-        {
-            if (int(tid) < w)
-                partial[tid] += partial[tid + w];
-            __syncthreads();
-        }
-        if (tid == 0)
-            block[row * 4 + part] += partial[0];
-    }
-
-    // out[meter][i] = loudness[meter] * gain (the value is held between block boundaries, ILUFSMeter.cpp:386-387)
-    __global__ __launch_bounds__(256)
-    void ilufs_fill_kernel(float *out, size_t out_stride, const ilufs_state *__restrict__ st, float gain, uint32_t n)
-    {
-        const uint32_t meter = blockIdx.y;
-        const float v = st[meter].loudness * gain;
-        for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256)
-            out[size_t(meter) * out_stride + i] = v;
-    }
-
     // mean of the last `count` history entries above the ABSOLUTE gate (compute_gated_loudness, ILUFSMeter.cpp:324-341:
     // its `threshold` argument is not used by the reference -- both gating stages compare with GATING_ABS_THRESH, so the
     // relative stage returns what the absolute stage returned; one pass gives the reference's result for both)
@@ -642,15 +607,12 @@ namespace
         return r;
     }
 
-    // a gating block is complete (ILUFSMeter.cpp:402-458); one workgroup per meter
-    __global__ __launch_bounds__(LT)
-    void ilufs_gate_kernel(ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *__restrict__ block,
-                           const chan_cfg *__restrict__ cfg, uint32_t channels, float avg)
+    // a gating block is complete (ILUFSMeter.cpp:402-458); the workgroup of the meter
+    __device__ void ilufs_gate(uint32_t meter, ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *block,
+                               const chan_cfg *__restrict__ cfg, uint32_t channels, float avg,
+                               float *s_sum, uint32_t *s_cnt, float &s_val)
     {
-        __shared__ float s_sum[LT];
-        __shared__ uint32_t s_cnt[LT];
-        __shared__ float s_val;
-        const uint32_t meter = blockIdx.x, tid = threadIdx.x;
+        const uint32_t tid = threadIdx.x;
         float *h = hist + size_t(meter) * size;
         ilufs_state me = st[meter];
         if (tid == 0)
@@ -718,11 +680,55 @@ namespace
         }
     }
 
-    __global__ void ilufs_zero_part_kernel(float *block, uint32_t rows, uint32_t part)
+    // One piece of a block quarter, one workgroup per meter: the held loudness value into the output row
+    // (ILUFSMeter.cpp:386-387), vBlock[row][part] += the sum of squares of every enabled row's filtered samples
+    // (:372-384), then -- when the piece ends the quarter -- the gating arithmetic of a complete block and the reset of
+    // the quarter that is filled next (:402-466).
+    __global__ __launch_bounds__(LT)
+    void ilufs_piece_kernel(float *block, uint32_t part, const float *__restrict__ flt, size_t flt_stride, uint32_t n,
+                            const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
+                            ilufs_state *st, float gain, int gate, int zero_part, float *hist, uint32_t size, uint32_t ms_int,
+                            float avg)
     {
-        const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-        if (r < rows)
-            block[r * 4 + part] = 0.0f;
+        __shared__ float s_sum[LT];
+        __shared__ uint32_t s_cnt[LT];
+        __shared__ float s_val;
+        const uint32_t meter = blockIdx.x, tid = threadIdx.x;
+        if (out != nullptr)
+        {
+            const float v = st[meter].loudness * gain;
+            for (uint32_t i = tid; i < n; i += LT)
+                out[size_t(meter) * out_stride + i] = v;
+        }
+        for (uint32_t c = 0; c < channels && n > 0; ++c)
+        {
+            if (!cfg[c].enabled)
+                continue;
+            const uint32_t row = meter * channels + c;
+            const float *x = flt + size_t(row) * flt_stride;
+            float s = 0.0f;
+            for (uint32_t i = tid; i < n; i += LT)
+                s = fmaf(x[i], x[i], s);
+            s_sum[tid] = s;
+            __syncthreads();
+            for (int w = LT / 2; w > 0; w >>= 1)
+            {
+                if (int(tid) < w)
+                    s_sum[tid] += s_sum[tid + w];
+                __syncthreads();
+            }
+            if (tid == 0)
+                block[row * 4 + part] += s_sum[0];
+            __syncthreads();
+        }
+        if (gate)
+            ilufs_gate(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);   // thread 0 reads its own sums
+        if (zero_part >= 0)
+        {
+            __syncthreads();
+            for (uint32_t c = tid; c < channels; c += LT)
+                block[(meter * channels + c) * 4 + uint32_t(zero_part)] = 0.0f;
+        }
     }
 } // namespace
 
@@ -994,18 +1000,10 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_
             r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
             if (r != MI_OK)
                 return r;
-            hipLaunchKernelGGL(ilufs_sqsum_kernel, dim3(b->rows), dim3(LT), 0, st, b->d_block, b->block_part, b->d_flt, b->cap,
-                               uint32_t(n), b->d_cfg, b->channels);
-            MI_HIP_CHECK(hipGetLastError());
             b->block_offset += uint32_t(n);
-            if (out != nullptr)
-            {
-                const unsigned gx = unsigned(std::min<size_t>((n + 255) / 256, 64));
-                hipLaunchKernelGGL(ilufs_fill_kernel, dim3(gx, b->meters), dim3(256), 0, st, out + offset, out_stride, b->d_state,
-                                   gain, uint32_t(n));
-                MI_HIP_CHECK(hipGetLastError());
-            }
         }
+        int gate = 0, zero_part = -1;
+        const uint32_t part = b->block_part;
         if (b->block_offset >= b->block_size)               // a quarter of a gating block is complete
         {
             b->block_offset = 0;
@@ -1014,13 +1012,14 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_
                 b->block_part = 0;
                 b->blk_full = true;
             }
-            if (b->blk_full)
-            {
-                hipLaunchKernelGGL(ilufs_gate_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_state, b->d_hist, b->ms_size, b->ms_int,
-                                   b->d_block, b->d_cfg, b->channels, b->avg);
-                MI_HIP_CHECK(hipGetLastError());
-            }
-            hipLaunchKernelGGL(ilufs_zero_part_kernel, dim3((b->rows + 255) / 256), dim3(256), 0, st, b->d_block, b->rows, b->block_part);
+            gate = b->blk_full ? 1 : 0;
+            zero_part = int(b->block_part);
+        }
+        if (n > 0 || zero_part >= 0)
+        {
+            hipLaunchKernelGGL(ilufs_piece_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_block, part, b->d_flt, b->cap, uint32_t(n),
+                               b->d_cfg, b->channels, out ? out + offset : nullptr, out_stride, b->d_state, gain, gate, zero_part,
+                               b->d_hist, b->ms_size, b->ms_int, b->avg);
             MI_HIP_CHECK(hipGetLastError());
         }
         offset += n;
