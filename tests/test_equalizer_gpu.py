@@ -222,3 +222,55 @@ def test_random_operation_sequences_match_oracle(gpu, seed):
         log.append({"process": "process(%d)" % k if op == "process" else "", "mode": "mode(%d)" % m if op == "mode" else "",
                     "smooth": "smooth(%d)" % s if op == "smooth" else ""}.get(op) or str(op))
     eq.close()
+
+
+def test_c4_full_size(gpu):
+    """BASELINE config 3 at the per-GPU size: 256 channels, 32 RLC bells each with its own gains (seed 6), fir_rank 12,
+    EQM_FIR, blocks of 4096.  Sampled channels against the oracle; over all channels the size-independent properties:
+    a second bank fed the same input gives the same bits, and an input scaled by 2 gives exactly twice the output."""
+    rng = np.random.default_rng(6)
+    C, rank, nfilt, n, blocks = 256, 12, 32, 4096, 3
+    x = (rng.standard_normal((C, n * blocks)) * 0.25).astype(np.float32)
+    sampled = (0, 100, 255)
+    curves = [c4_filters(rng) for _ in range(C)]
+
+    def run(scale):
+        eq = gpu.EqualizerBank(C, nfilt, rank)
+        eq.set_mode(oe.FIR)
+        eq.set_sample_rate(48000)
+        for c in range(C):
+            for i, p in enumerate(curves[c]):
+                eq.set_params(i, *p, channel=c)
+        y = np.empty_like(x)
+        for b in range(blocks):
+            din = gpu.DeviceBuffer.from_host(x[:, b * n:(b + 1) * n] * np.float32(scale)); dout = gpu.DeviceBuffer((C, n))
+            eq.process(dout, din, n)
+            y[:, b * n:(b + 1) * n] = dout.download()
+        eq.close()
+        return y
+
+    y1, y1b, y2 = run(1.0), run(1.0), run(2.0)
+    assert np.isfinite(y1).all() and float(np.abs(y1).max()) > 0.0
+    np.testing.assert_array_equal(y1, y1b)
+    np.testing.assert_array_equal(y2, 2.0 * y1)
+    import oracle
+
+    def exact_ir(n_, coef, state):
+        imp = np.zeros(n_); imp[0] = 1.0
+        return oracle.biquad_cascade_f64(imp, coef).astype(np.float32)
+    for c in sampled:
+        refs = []
+        for ir_func in (None, exact_ir):
+            o = oe.Equalizer(nfilt, rank); o.set_mode(oe.FIR); o.set_sample_rate(48000)
+            for i, p in enumerate(curves[c]):
+                o.set_params(i, fd.Params(*p))
+            if ir_func is not None:
+                o.ir_func = ir_func
+            refs.append(o.process(x[c]))
+        ref, peak = refs[0], np.abs(refs[0]).max()
+        # the FIR is synthesised from the float32 impulse response of 32 sections: allow what that response's own
+        # round-off moves the output (same rule as test_c4_shape_32_band_eq)
+        noise = float(np.abs(refs[1] - ref).max() / peak)
+        err = float(np.abs(y1[c] - ref).max() / peak)
+        print("C4 full size ch %d: |gpu - oracle| / peak = %.2e (impulse-response round-off %.2e)" % (c, err, noise))
+        assert err <= max(2 * TOL, 4.0 * noise), (c, err, noise)

@@ -484,3 +484,43 @@ def test_analyzer_random_settings(gpu, seed):
             o.configure(rate=r); bank.configure(bank.RATE, r)
         log.append(str(op))
     bank.close()
+
+
+def test_c5_full_size(gpu):
+    """BASELINE config 4 at the per-GPU size: 1024 channels, 4096-point Hann spectra every 2048 samples, reactivity 0.2.
+    Every channel against the oracle after each period; the per-bin sum over the channels against the sum of the rows
+    (a checksum of checksums), bit-identical when asked twice."""
+    sr, rank, C, hop = 48000, 12, 1024, 2048
+    bins = (1 << (rank - 1)) + 1
+    rng = np.random.default_rng(7)
+    x = (rng.standard_normal((C, 4 * hop)) * 0.25).astype(np.float32)
+    o = sp.Analyzer(C, rank, sr, 1.0, 0)
+    o.configure(sample_rate=sr, rate=sr / float(hop), rank=rank, window_name="hann", reactivity=0.2, shift=1.0)
+    bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+    for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, sr / float(hop)), (bank.RANK, rank), (bank.WINDOW, 0),
+                    (bank.REACTIVITY, 0.2), (bank.SHIFT, 1.0)):
+        bank.configure(what, v)
+    idx = np.arange(0, bins, dtype=np.uint32)
+    worst = 0.0
+    for f in range(4):
+        blk = x[:, f * hop:(f + 1) * hop]
+        o.process(blk)
+        bank.process(gpu.DeviceBuffer.from_host(blk), hop)
+        got, ref = bank.get_spectrum(idx), o.get_spectrum(idx)
+        peak = np.abs(ref).max(axis=1, keepdims=True)
+        worst = max(worst, float((np.abs(got - ref) / np.maximum(peak, 1e-30)).max()))
+    assert (peak > 0).all()
+    assert bank.info()["period"] == hop
+    print("C5 full size: worst |gpu - oracle| / channel peak = %.2e" % worst)
+    assert worst <= TOL
+    # finish the period (the reference reaches its last channel just before the next strobe), then the reduction
+    tail = (rng.standard_normal((C, hop - 1)) * 0.25).astype(np.float32)
+    o.process(tail)
+    bank.process(gpu.DeviceBuffer.from_host(tail), hop - 1)
+    out1, out2 = gpu.DeviceBuffer((bins,)), gpu.DeviceBuffer((bins,))
+    bank.reduce_bins(out1)
+    bank.reduce_bins(out2)
+    np.testing.assert_array_equal(out1.download(), out2.download())
+    ref = o.amp[:, :bins].astype(np.float64).sum(axis=0)
+    assert np.abs(out1.download() - ref).max() <= TOL * np.abs(ref).max()
+    bank.close()
