@@ -20,13 +20,14 @@ def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     os.makedirs(dst, exist_ok=True)
     raw = {}
-    for wl, kname in KERNELS.items():
+    for wl in list(KERNELS) + ["crossover", "splitter", "loudness"]:
         stats = glob.glob(os.path.join(src, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True)
         if stats:
             with open(stats[0]) as f:
                 rows = f.readlines()[:12]
             with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)), "w") as f:
                 f.writelines(rows)
+    for wl, kname in KERNELS.items():
         per = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             files = glob.glob(os.path.join(src, "pmc_%s_%s" % (wl, ctr), "**", "*counter_collection.csv"), recursive=True)
