@@ -150,7 +150,8 @@ class _Designer:
             matched = name.startswith("FLT_MT_")
             base = t - 1 if matched else t
             if matched:
-                fp.fFreq2 = F(fp.fFreq / fp.fFreq2)
+                with np.errstate(divide="ignore", invalid="ignore"):    # fFreq2 == 0: inf, as the float division in C
+                    fp.fFreq2 = F(fp.fFreq / fp.fFreq2)
             else:
                 fp.fFreq2 = self._bilinear_relative(fp.fFreq, fp.fFreq2)
             bname = FILTER_TYPES[base]

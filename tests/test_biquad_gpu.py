@@ -282,9 +282,10 @@ def test_random_operation_sequences(gpu, seed):
         old = coef[c]
         # memory carried over when the section count is unchanged and no clear was asked for
         keep = (old is not None) and (len(old) == len(q)) and not clear
-        if keep and hist[c].size:
-            _, st = oracle.biquad_cascade(hist[c], old, state0[c])
-            state0[c] = st
+        if keep:
+            if hist[c].size:                                 # (nothing processed since the last re-design: state0 stands)
+                _, st = oracle.biquad_cascade(hist[c], old, state0[c])
+                state0[c] = st
         else:
             state0[c] = None
         hist[c] = np.zeros(0, np.float32)
@@ -309,8 +310,11 @@ def test_random_operation_sequences(gpu, seed):
                 hist[c] = np.concatenate([hist[c], x[c]])
                 ref, _ = oracle.biquad_cascade(hist[c], coef[c], state0[c])
                 if state0[c] is None:
-                    exact = oracle.biquad_cascade_f64(hist[c], coef[c])[-n:]
-                    assert_iir_parity(y[c], ref[-n:], exact, what=str((seed, step, c, n)))
+                    exact = oracle.biquad_cascade_f64(hist[c], coef[c])
+                    # errors relative to the peak of the channel's last 1024 samples: a call of a few samples has no
+                    # meaningful peak of its own
+                    assert_iir_parity(y[c], ref[-n:], exact[-n:], what=str((seed, step, c, n)),
+                                      peak=np.abs(exact[-max(n, 1024):]).max())
                 else:                                        # carried memory: no zero-state float64 run to compare with
                     peak = max(float(np.abs(ref).max()), 1.0)
                     assert float(np.abs(y[c] - ref[-n:]).max()) <= 5e-5 * peak, (seed, step, c, n)
