@@ -1,0 +1,98 @@
+"""Every bank on a caller's own non-blocking stream: same bits as on the default stream.  A non-blocking stream does not
+wait for the null stream and is not waited for by it, so an internal launch or copy that went to the wrong stream races
+with the rest of the call and shows up as a difference."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from oracle import filter_design as fd
+import workloads as wl
+
+pytestmark = pytest.mark.gpu
+C, N, CALLS = 64, 4096, 3
+
+
+@pytest.fixture(scope="module")
+def side_stream(gpu):
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0          # hipStreamNonBlocking
+    yield s.value
+    hip.hipStreamDestroy(s)
+
+
+def _run(gpu, kind, st):
+    rng = np.random.default_rng(33)
+    calls = 6 if kind == "ilufs" else CALLS              # the integrated meter reads 0 until its first 400 ms block is full
+    xs = [(rng.standard_normal((C, N)) * 0.25).astype(np.float32) for _ in range(calls)]
+    outs = []
+    buf = lambda shape=(C, N): gpu.DeviceBuffer(shape)                    # noqa: E731
+    if kind == "biquad":
+        b = gpu.BiquadBank(C, 8)
+        q = wl.design(fd.FLT_BT_LRX_LOPASS, 4, 3000.0, 0, 1.0, 0.75)
+        for c in range(C):
+            b.set_chains(c, q)
+        step = lambda d: (lambda y: (b.process(y, d, N, stream=st), [y])[1])(buf())          # noqa: E731
+    elif kind == "convolver":
+        b = gpu.ConvolverBank(rng.standard_normal((C, 9000)).astype(np.float32), 11, stream=st)
+        step = lambda d: (lambda y: (b.process(y, d, N, stream=st), [y])[1])(buf())          # noqa: E731
+    elif kind == "equalizer":
+        b = gpu.EqualizerBank(C, 4, 11); b.set_mode(2); b.set_sample_rate(48000)
+        for c in range(C):
+            b.set_params(0, fd.FLT_BT_RLC_BELL, 1, 500.0 + 100.0 * c, 1000.0, 2.0, 1.0, channel=c)
+        step = lambda d: (lambda y: (b.process(y, d, N, stream=st), [y])[1])(buf())          # noqa: E731
+    elif kind == "spectral":
+        b = gpu.SpectralBank(C, 12); b.set_rank(11)
+        b.bind_mask(np.linspace(0.0, 1.0, 2 << 11).astype(np.float32), stream=st)
+        step = lambda d: (lambda y: (b.process(y, d, N, stream=st), [y])[1])(buf())          # noqa: E731
+    elif kind == "analyzer":
+        b = gpu.AnalyzerBank(C, 12, 48000, 1.0, 0)
+        for what, v in ((b.SAMPLE_RATE, 48000), (b.RATE, 48000 / 2048.0), (b.RANK, 12), (b.WINDOW, 0), (b.REACTIVITY, 0.2), (b.SHIFT, 1.0)):
+            b.configure(what, v)
+
+        def step(d):
+            b.process(d, N, stream=st)
+            r = buf((2049,))
+            b.reduce_bins(r, stream=st)
+            return [r]
+    elif kind == "delay":
+        b = gpu.DelayBank(C, 6000)
+        for c in range(C):
+            b.set_delay(50 * c, channel=c)
+        step = lambda d: (lambda y: (b.process(y, d, N, stream=st), [y])[1])(buf())          # noqa: E731
+    elif kind == "loudness":
+        b = gpu.LoudnessBank(C // 2, 2, 400.0); b.set_sample_rate(48000)
+        step = lambda d: (lambda y, c: (b.process(y, c, d, N, stream=st), [y, c])[1])(buf((C // 2, N)), buf())   # noqa: E731
+    elif kind == "ilufs":
+        b = gpu.ILUFSBank(C // 2, 2, 10.0, 400.0); b.set_sample_rate(48000)
+        step = lambda d: (lambda y: (b.process(y, d, N, stream=st), [y])[1])(buf((C // 2, N)))                    # noqa: E731
+    elif kind == "splitter":
+        b = gpu.SplitterBank(C, 12, 3); b.set_rank(11); b.set_chunk_rank(9)
+        b.bind_copy(0, stream=st)
+        b.bind_mask(1, np.linspace(1.0, 0.0, 1 << 11).astype(np.float32), stream=st)
+        b.bind_mask(2, np.linspace(0.0, 1.0, 1 << 11).astype(np.float32), stream=st)
+        step = lambda d: (lambda ys: (b.process(ys, d, N, stream=st), ys)[1])([buf(), buf(), buf()])             # noqa: E731
+    else:
+        b = gpu.CrossoverBank(C, 3); b.set_sample_rate(48000)
+        for i, f in enumerate((500.0, 4000.0)):
+            b.set_slope(i, 2); b.set_frequency(i, f)
+        step = lambda d: (lambda ys: (b.process(ys, d, N, stream=st), ys)[1])([buf(), buf(), buf()])             # noqa: E731
+    for x in xs:
+        d = gpu.DeviceBuffer.from_host(x, stream=st)
+        outs.extend(o.download(stream=st) for o in step(d))
+    b.close()
+    return outs
+
+
+@pytest.mark.parametrize("kind", ["biquad", "convolver", "equalizer", "spectral", "analyzer", "delay", "loudness", "ilufs",
+                                  "splitter", "crossover"])
+def test_side_stream_gives_the_same_bits(gpu, side_stream, kind):
+    ref = _run(gpu, kind, None)
+    for _ in range(2):
+        got = _run(gpu, kind, side_stream)
+        assert len(got) == len(ref)
+        assert max(float(np.abs(r).max()) for r in ref) > 0.0
+        for a, r in zip(got, ref):
+            assert np.isfinite(r).all()
+            np.testing.assert_array_equal(a, r)
