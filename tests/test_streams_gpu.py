@@ -96,3 +96,49 @@ def test_side_stream_gives_the_same_bits(gpu, side_stream, kind):
         for a, r in zip(got, ref):
             assert np.isfinite(r).all()
             np.testing.assert_array_equal(a, r)
+
+
+def test_two_banks_on_two_streams_do_not_disturb_each_other(gpu):
+    """Two convolver banks and two spectral banks fed alternately on two non-blocking streams, nothing waited for until the
+    end: each gives what it gives alone (the banks share only read-only tables)."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    streams = []
+    for _ in range(2):
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+        streams.append(s.value)
+    rng = np.random.default_rng(44)
+    irs = [rng.standard_normal((C, 20000)).astype(np.float32) for _ in range(2)]
+    xs = [[(rng.standard_normal((C, N)) * 0.25).astype(np.float32) for _ in range(4)] for _ in range(2)]
+    masks = [np.linspace(0.0, 1.0, 2 << 11).astype(np.float32), np.linspace(1.0, 0.0, 2 << 11).astype(np.float32)]
+
+    def make(i, st):
+        cv = gpu.ConvolverBank(irs[i], 11, stream=st)
+        sp = gpu.SpectralBank(C, 12); sp.set_rank(11); sp.bind_mask(masks[i], stream=st)
+        return cv, sp
+
+    alone = []
+    for i in range(2):
+        cv, sp = make(i, None)
+        res = []
+        for x in xs[i]:
+            d, y, z = gpu.DeviceBuffer.from_host(x), gpu.DeviceBuffer((C, N)), gpu.DeviceBuffer((C, N))
+            cv.process(y, d, N); sp.process(z, y, N)
+            res.append(z.download())
+        alone.append(res)
+        cv.close(); sp.close()
+
+    banks = [make(i, streams[i]) for i in range(2)]
+    ins = [[gpu.DeviceBuffer.from_host(x, stream=streams[i]) for x in xs[i]] for i in range(2)]
+    mids = [[gpu.DeviceBuffer((C, N)) for _ in range(4)] for _ in range(2)]
+    outs = [[gpu.DeviceBuffer((C, N)) for _ in range(4)] for _ in range(2)]
+    for k in range(4):
+        for i in range(2):
+            banks[i][0].process(mids[i][k], ins[i][k], N, stream=streams[i])
+            banks[i][1].process(outs[i][k], mids[i][k], N, stream=streams[i])
+    for i in range(2):
+        for k in range(4):
+            np.testing.assert_array_equal(outs[i][k].download(stream=streams[i]), alone[i][k])
+        banks[i][0].close(); banks[i][1].close()
+    for s in streams:
+        hip.hipStreamDestroy(ctypes.c_void_p(s))
