@@ -531,10 +531,10 @@ namespace
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         if (aligned)
-            hipExtLaunchKernelGGL((biquad_bank_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, 0, out, in,
+            MI_LAUNCH((biquad_bank_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, out, in,
                                   out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
         else
-            hipExtLaunchKernelGGL((biquad_bank_kernel<L, NW, false>), grid, block, 0, st, ev0, ev1, 0, out, in,
+            MI_LAUNCH((biquad_bank_kernel<L, NW, false>), grid, block, 0, st, ev0, ev1, out, in,
                                   out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
         return hipGetLastError();
     }

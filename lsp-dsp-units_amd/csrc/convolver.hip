@@ -553,7 +553,7 @@ namespace
         const int M = b->B;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
-        hipExtLaunchKernelGGL(conv_mac_kernel, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1, 0,
+        MI_LAUNCH(conv_mac_kernel, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1,
                               b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = true;

@@ -22,6 +22,17 @@ namespace mi
     // consumes them (hipExtLaunchKernelGGL records them at the kernel's own begin/end).
     void        take_profile_events(hipEvent_t *start, hipEvent_t *stop);
 
+    // Launch of a hot-path kernel: the extended launch (which records the armed events at the kernel's own begin and end)
+    // only when events are armed -- it is not allowed on a capturing stream; the plain launch is, so a steady-state
+    // process() call can be captured into a hipGraph.
+    #define MI_LAUNCH(kernel, grid, block, lds, st, ev0, ev1, ...) \
+        do { \
+            if ((ev0) != nullptr || (ev1) != nullptr) \
+                hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__); \
+            else \
+                hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__); \
+        } while (0)
+
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);
 

@@ -484,7 +484,7 @@ namespace
         const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
         if (b->op == MI_SPECTRAL_OP_NONE || !bound)
         {
-            #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 0>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 0>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), (float2 *)nullptr, \
                 (const uint8_t *)nullptr, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
@@ -492,7 +492,7 @@ namespace
         }
         else if (b->op == MI_SPECTRAL_OP_MASK)
         {
-            #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 1>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 1>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, b->d_mask, b->mask_stride, (float2 *)nullptr, \
                 (const uint8_t *)nullptr, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
@@ -500,7 +500,7 @@ namespace
         }
         else
         {
-            #define MI_CALL(LH) hipExtLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
@@ -841,7 +841,7 @@ namespace
         std::swap(b->d_amp, b->d_data);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
-        #define MI_CALL(LH) hipExtLaunchKernelGGL((analyzer_kernel<LH>), dim3(b->channels), dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+        #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(b->channels), dim3(plan<LH>::T), 0, st, ev0, ev1, \
             b->d_ring, b->buf_size, b->head, b->d_delay, b->d_flags, b->d_wnd, b->d_data, b->d_amp, b->bins_stride, b->tau, \
             b->d_tw, in, in_stride, n, zero ? 1 : 0)
         MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)

@@ -412,13 +412,13 @@ namespace
                 (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos
             if (grid.y > 1)
             {
-                #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, false, true>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, MI_ARGS)
+                #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, true>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
             }
             else
             {
-                #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, false, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, MI_ARGS)
+                #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
             }
@@ -427,7 +427,7 @@ namespace
             std::swap(b->d_in, b->d_in2);
             return MI_OK;
         }
-        #define MI_CALL(LH) hipExtLaunchKernelGGL((splitter_hop_kernel<LH, true, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, 0, \
+        #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, true, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
             b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, b->d_spec, \
             b->d_tw, (const float *)nullptr, size_t(0), 0u, splitter_outs(b), size_t(0), size_t(0))
         MI_LOGH_SWITCH(lh, MI_CALL)

@@ -142,3 +142,52 @@ def test_two_banks_on_two_streams_do_not_disturb_each_other(gpu):
         banks[i][0].close(); banks[i][1].close()
     for s in streams:
         hip.hipStreamDestroy(ctypes.c_void_p(s))
+
+
+def test_biquad_bank_inside_a_hip_graph(gpu):
+    """The biquad bank keeps everything that changes from call to call (filter memory) on the device and takes no host
+    decision in a steady-state process(): a run of calls can be captured once into a hipGraph and replayed.  Three replays
+    of a four-call graph equal twelve eager calls, bit for bit."""
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+    st = s.value
+    rng = np.random.default_rng(55)
+    q = wl.design(fd.FLT_BT_LRX_LOPASS, 4, 3000.0, 0, 1.0, 0.75)
+    xs = [(rng.standard_normal((C, N)) * 0.25).astype(np.float32) for _ in range(4)]
+
+    def bank():
+        b = gpu.BiquadBank(C, 8)
+        for c in range(C):
+            b.set_chains(c, q)
+        b.commit(st)
+        return b
+
+    eager = bank()
+    ref = []
+    for rep in range(3):
+        for x in xs:
+            d, y = gpu.DeviceBuffer.from_host(x, stream=st), gpu.DeviceBuffer((C, N))
+            eager.process(y, d, N, stream=st)
+            ref.append(y.download(stream=st))
+    eager.close()
+
+    b = bank()
+    ins = [gpu.DeviceBuffer.from_host(x, stream=st) for x in xs]
+    outs = [gpu.DeviceBuffer((C, N)) for _ in xs]
+    graph, exe = ctypes.c_void_p(), ctypes.c_void_p()
+    del d, y                                    # (a buffer released while the stream captures would end the capture)
+    import gc
+    gc.collect()
+    assert hip.hipStreamBeginCapture(s, 0) == 0
+    for k in range(4):
+        b.process(outs[k], ins[k], N, stream=st)
+    assert hip.hipStreamEndCapture(s, ctypes.byref(graph)) == 0
+    assert hip.hipGraphInstantiate(ctypes.byref(exe), graph, None, None, ctypes.c_size_t(0)) == 0
+    for rep in range(3):
+        assert hip.hipGraphLaunch(exe, s) == 0
+        for k, y in enumerate(outs):
+            np.testing.assert_array_equal(y.download(stream=st), ref[rep * 4 + k])
+    hip.hipGraphExecDestroy(exe); hip.hipGraphDestroy(graph)
+    b.close()
+    hip.hipStreamDestroy(s)
