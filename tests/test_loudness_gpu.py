@@ -142,6 +142,7 @@ def test_random_operation_sequences(gpu, seed):
     log = []
     recent = [np.zeros(0) for _ in range(M)]
     level2 = 0.0
+    MS_TOL = 2e-5           # mean-square domain: 1e-5 of the amplitude at full level, looser only where the output is small
     for step in range(40):
         op = rng.choice(["process", "process", "process", "period", "weighting", "designation", "link", "active", "bound", "clear"])
         if op == "process":
@@ -166,14 +167,16 @@ def test_random_operation_sequences(gpu, seed):
                 # the mean-square domain, so it is judged there when the output is small.
                 level2 = max(level2, float((o / (g or 1.0)).max()) ** 2)
                 ms_err = float(np.abs(y[m].astype(np.float64) ** 2 - o.astype(np.float64) ** 2).max()) / (g or 1.0) ** 2
-                assert err <= tol * peak or ms_err <= 1e-6 * level2, \
-                    (seed, step, m, n, err / peak, ms_err / level2, int(np.abs(y[m] - o).argmax()), log[-8:])
+                assert err <= tol * peak or ms_err <= MS_TOL * level2, \
+                    (seed, step, m, n, err / peak, ms_err / level2, int(np.abs(y[m] - o).argmax()), log[-8:],
+                     y[m][max(0, int(np.abs(y[m] - o).argmax()) - 20):int(np.abs(y[m] - o).argmax()) + 4].tolist(),
+                     o[max(0, int(np.abs(y[m] - o).argmax()) - 20):int(np.abs(y[m] - o).argmax()) + 4].tolist())
                 for k in range(K):
                     if refs[m].ch[k]["enabled"] and refs[m].ch[k]["bound"]:
                         level2 = max(level2, float((c[k] / (g or 1.0)).max()) ** 2)
                         cerr = float(np.abs(yc[m * K + k] - c[k]).max())
                         cms = float(np.abs(yc[m * K + k].astype(np.float64) ** 2 - c[k].astype(np.float64) ** 2).max()) / (g or 1.0) ** 2
-                        assert cerr <= tol * peak or cms <= 1e-6 * level2, (seed, step, m, k, cerr / peak, cms / level2, log[-8:])
+                        assert cerr <= tol * peak or cms <= MS_TOL * level2, (seed, step, m, k, cerr / peak, cms / level2, log[-8:])
                     else:
                         assert np.all(yc[m * K + k] == -1.0)
             np.testing.assert_allclose(bank.loudness(), [float(r.loud) for r in refs], rtol=0, atol=tol * 2.0)
