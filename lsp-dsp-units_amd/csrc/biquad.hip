@@ -147,6 +147,12 @@ namespace
         const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
             out + size_t(ch) * out_stride, 0, n * 4, BUFFER_DWORD3);
         MI_PROBE(0);
+        // The two waves that share a SIMD belong to workgroups 256 apart in dispatch order (census of a 1024 x 128-thread
+        // launch on this part, tests/experiments/census.hip).  The earlier one gets issue priority: it reaches its stores
+        // while its partner is still in the sections, so the write-back of one overlaps the arithmetic of the other
+        // (about 0.8 us of a 13.9 us launch at 1024 channels; placement is never relied on for correctness).
+        if (((blockIdx.x >> 8) & 1) == 0)
+            __builtin_amdgcn_s_setprio(1);
 
         // ---- helpers ---------------------------------------------------------------------------
         float4 ld[LPT];
@@ -793,6 +799,10 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
             e = launch<8, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
         else if (force_nw == 1)
             e = launch<16, 1>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
+        else if (force_nw == 84)
+            e = launch<8, 4>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+        else if (force_nw == 82)
+            e = launch<8, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
         else
             e = launch<16, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
         MI_HIP_CHECK(e);
