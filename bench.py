@@ -10,10 +10,14 @@ A "step" is one pass of the hot path over one batch of synthetic input that is a
 With N > 1 (launched by torch.distributed.run, one process per GPU) the channels are sharded: every rank
 owns its own 1024 channels (weak scaling, no data-path collective: channels are independent).
 
-Prints ONE JSON line on rank 0.  `value` is whole-job Msamples/s over the timed region (barrier +
-synchronize on both sides, max over ranks); `roofline` is priced from the kernel's average launch
-duration measured with HIP events on the launch stream; `cpu_baseline` is the CPU oracle (a scalar C port
-of the reference algorithm, OpenMP over channels) timed on this host on a bounded sample.
+Prints ONE JSON line on rank 0.  After the W warm-up steps the K-step region (barrier + synchronize on both sides,
+max over ranks) is timed `--regions` times back to back and `value` is whole-job Msamples/s of the MEDIAN region, so
+a short region (the driver's K = 20 is a quarter of a millisecond) does not rest on one sample; every region's time is
+in `region_ms`.  The K steady-state calls of a region are captured once into a hipGraph and replayed (the calls take
+no host decision; `launch` says which mode ran).  `roofline` is priced from the dominant kernel's average duration
+over >= 16 launches that carry their own HIP event pair (hipExtLaunchKernelGGL on the launch stream), taken in an
+untimed pass after the regions.  `cpu_baseline` is the reference's x8 structure built -O3 -march=native for this
+host (oracle/cpu_baseline), on one core and on all cores, on a bounded sample.
 """
 import argparse
 import importlib
@@ -29,7 +33,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-SETUP_LAUNCHES = 32        # untimed launches during set-up, before the caller's warm-up steps (see main)
+KERNEL_PROBES = 16         # launches with their own event pair, after the timed regions
+FLT_BT_LRX_LOPASS = 47     # filter_type_t, include/lsp-plug.in/dsp-units/filters/common.h:95
 
 
 def parse():
@@ -43,6 +48,8 @@ def parse():
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
     ap.add_argument("--ring", type=int, default=16, help="distinct resident blocks cycled through "
                     "(16 x 32 MiB in+out > the 256 MiB Infinity Cache, so steps stream from HBM)")
+    ap.add_argument("--regions", type=int, default=0, help="timed repetitions of the K-step region (0 = 25, or 5 when K >= 500)")
+    ap.add_argument("--launch", default="graph", choices=["graph", "eager"], help="how the K steps of a region are issued")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sections", type=int, default=8, help="experiment knob: keep only the first N sections")
     ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
@@ -53,31 +60,60 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline_biquad(coef, samples, budget_s=6.0):
-    """CPU oracle ("port" of the reference algorithm) on this host's cores: repeat 1024ch x 4096 blocks
-    until ~budget_s of wall time (x cores of CPU work) has been spent."""
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline_biquad(coef, samples, budget_s=5.0):
+    """The reference's structure on this host (oracle/cpu_baseline/biquad_x8_host.c): one x8 software-pipelined pass per
+    channel and block (FilterBank.cpp:267-273), SIMD across the eight sections, four channels interleaved per thread,
+    persistent threads over fixed channel ranges, all blocks of a run inside one parallel region.  Rebuilt here with
+    -O3 -march=native for the machine the bench runs on; timed on one core and on all cores."""
+    import ctypes
+    import subprocess
     import numpy as np
-    import oracle
     import workloads as wl
-    C = coef.shape[0]
-    x = wl.c2_input(C, samples, blocks=2, seed=12)
-    state = np.zeros((C, coef.shape[1], 2), np.float32)
-    nsec = np.full(C, coef.shape[1], np.uint32)
-    oracle.biquad_bank(x[0], coef, nsec, state)          # warm up threads / pages
-    t0 = time.perf_counter()
-    blocks = 0
-    while time.perf_counter() - t0 < budget_s:
-        oracle.biquad_bank(x[blocks & 1], coef, nsec, state)
-        blocks += 1
-    dt = time.perf_counter() - t0
+    base = os.path.join(ROOT, "oracle", "cpu_baseline")
+    subprocess.check_call(["make", "-s", "-B", "-C", base])
+    lib = ctypes.CDLL(os.path.join(base, "libcpubase.so"))
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.cpu_biquad_x8_run.argtypes = [fp, fp] + [ctypes.c_size_t] * 4 + [fp, fp, ctypes.c_int]
+    C, ring = coef.shape[0], 2
+    x = wl.c2_input(C, samples, blocks=ring, seed=12)
+    y = np.empty_like(x)
+    coef = np.ascontiguousarray(coef, np.float32)
+    f = lambda a: a.ctypes.data_as(fp)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+
+    def timed(threads, blocks):
+        st = np.zeros((C, 8, 2), np.float32)
+        t0 = time.perf_counter()
+        used = lib.cpu_biquad_x8_run(f(y), f(x), C, samples, blocks, ring, f(coef), f(st), threads)
+        return used, time.perf_counter() - t0
+
+    res = {}
+    for name, threads in (("one_core", 1), ("all_cores", cores)):
+        used, dt = timed(threads, 64)                               # >= 64 blocks per parallel region; sizes the run
+        blocks = int(min(max(64, 64 * budget_s / max(dt, 1e-6)), 1 << 16))
+        used, dt = timed(threads, blocks)
+        res[name] = {"value": round(blocks * C * samples / dt / 1e6, 1), "threads": used, "blocks": blocks,
+                     "seconds": round(dt, 2)}
+    allc = res["all_cores"]
     return {
-        "value": round(blocks * C * samples / dt / 1e6, 2),
-        "unit": "Msamples/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": "%d blocks of %d ch x %d samples, 8-section cascade, scalar C oracle with OpenMP over channels "
-                  "(reference SIMD library lsp-dsp-lib is not available offline)" % (blocks, C, samples),
+        "value": allc["value"], "unit": "Msamples/s", "cores": allc["threads"], "kind": "port",
+        "per_core": round(allc["value"] / max(1, allc["threads"]), 1),
+        "one_core": {"value": res["one_core"]["value"], "unit": "Msamples/s", "cores": 1},
+        "cpu_model": _cpu_model(), "build": "gcc -O3 -march=native -ffp-contract=fast -fopenmp (rebuilt on this host)",
+        "sample": "%d blocks (all cores) / %d blocks (one core) of %d ch x %d samples in one parallel region each, 8-section "
+                  "cascade as one x8 software-pipelined pass per channel and block (FilterBank.cpp:267-273), SIMD across "
+                  "the sections, persistent threads; lsp-dsp-lib's hand-written kernels are not available offline"
+                  % (allc["blocks"], res["one_core"]["blocks"], C, samples),
     }
 
 
@@ -85,6 +121,13 @@ def _pmc_traffic(name):
     """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None."""
     try:
         return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def _committed_json(name):
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name)))
     except Exception:
         return None
 
@@ -156,7 +199,7 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
         k = i % ring
         bank.process(yout[k], xin[k], frame, stream=stream)
 
-    elapsed, kernel_ms = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup)
+    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup)
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     chk = yout[(warmup + steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
@@ -191,63 +234,90 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
     return res
 
 
-def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True):
-    """warm up, then time `steps` calls of step(i): returns (elapsed_s_max_over_ranks, sorted kernel ms list)."""
+def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True, regions=5, stream=None, graph=False):
+    """W untimed warm-up calls of step(i), then `regions` timed repetitions of the K-step region, each bracketed by
+    barrier + synchronize on both sides and reduced with MAX over the ranks.
+    Returns (median region seconds, sorted kernel ms list of the probe pass, info)."""
     import ctypes
+    import gc
     for i in range(warmup):
         step(i)
     torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
 
-    def new_event():
-        e = ctypes.c_void_p()
-        mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
-        return e
-    # The dominant kernel of the last `burst` steps of the timed region carries a start/stop event pair
-    # (hipExtLaunchKernelGGL).  An event pair serialises its launch against its neighbours, so a contiguous burst measures
-    # what rocprofv3 measures (one launch at a time) while the steps before it run back to back; the first launch of the
-    # burst still overlaps the un-instrumented launch before it and is dropped from the average.  An instrumented launch
-    # costs about two un-instrumented steps of the biquad workload, so the burst is kept short: it is part of the timed
-    # region and of `value`.
-    burst = min(16, max(2, steps // 8)) if profile else 0
-    probes = list(range(steps - burst, steps))
-    starts = {i: new_event() for i in probes}
-    stops = {i: new_event() for i in probes}
-    trace = [] if os.environ.get("MI_BENCH_TRACE") else None
-    # no interpreter housekeeping inside the timed region (a generation-2 collection after the set-up's many small
-    # ctypes objects costs more than a thousand of these steps' launch calls)
-    import gc
+    # The K steps of a region, captured once: steady-state process() calls take no host decision.
+    exe, mode = None, "eager"
+    if graph and stream is not None:
+        gc.collect()
+        gc.disable()
+        try:
+            mi.check(mi.lib.mi_dspu_graph_begin_capture(ctypes.c_void_p(stream.cuda_stream)))
+            try:
+                for i in range(steps):
+                    step(warmup + i)
+            finally:
+                h = ctypes.c_void_p()
+                rc = mi.lib.mi_dspu_graph_end_capture(ctypes.c_void_p(stream.cuda_stream), ctypes.byref(h))
+            mi.check(rc)
+            exe, mode = h, "hipGraph of %d process() calls, one graph launch per region" % steps
+        except mi.MiError as e:
+            print("bench: graph capture refused (%s), eager launches" % e, file=sys.stderr)
+        finally:
+            gc.enable()
+        torch.cuda.synchronize()
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    times = []
     gc.collect()
-    gc.disable()
-    t0 = time.perf_counter()
-    for i in range(steps):
-        if i in starts:
-            mi.check(mi.lib.mi_dspu_profile_next_launch(starts[i], stops[i]))
-        step(warmup + i)
-        if trace is not None:
-            trace.append(time.perf_counter() - t0)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    gc.disable()            # no interpreter housekeeping inside a timed region
+    for r in range(regions):
+        fence()
+        t0 = time.perf_counter()
+        if exe is not None:
+            mi.check(mi.lib.mi_dspu_graph_launch(exe, ctypes.c_void_p(stream.cuda_stream)))
+        else:
+            for i in range(steps):
+                step(warmup + i)
+        fence()
+        times.append(time.perf_counter() - t0)
     gc.enable()
-    if trace is not None:
-        print("host return times (us):", [round(t * 1e6) for t in trace[:16]], "end", round(elapsed * 1e6), file=sys.stderr)
+    if exe is not None:
+        mi.lib.mi_dspu_graph_destroy(exe)
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor(times, dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        times = [float(v) for v in tt.tolist()]
+
+    # Untimed probe pass: the dominant kernel of each call carries its own start/stop event pair (hipExtLaunchKernelGGL).
+    # An event pair serialises its launch against its neighbours, which is what rocprofv3 measures too; the first probe
+    # still overlaps the launch before it and is dropped.
     kernel_ms = []
-    for i in (probes[1:] if len(probes) > 1 else probes):
-        ms = ctypes.c_float()
-        mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), starts[i], stops[i]))
-        kernel_ms.append(float(ms.value))
-    for e in list(starts.values()) + list(stops.values()):
-        mi.lib.mi_dspu_event_destroy(e)
-    return elapsed, sorted(kernel_ms)
+    if profile:
+        def new_event():
+            e = ctypes.c_void_p()
+            mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
+            return e
+        n = KERNEL_PROBES + 1
+        starts, stops = [new_event() for _ in range(n)], [new_event() for _ in range(n)]
+        for j in range(n):
+            mi.check(mi.lib.mi_dspu_profile_next_launch(starts[j], stops[j]))
+            step(warmup + j)
+        torch.cuda.synchronize()
+        for j in range(1, n):
+            ms = ctypes.c_float()
+            mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), starts[j], stops[j]))
+            kernel_ms.append(float(ms.value))
+        for e in starts + stops:
+            mi.lib.mi_dspu_event_destroy(e)
+    st = sorted(times)
+    info = {"launch": mode, "regions": regions,
+            "region_ms": {"min": round(st[0] * 1e3, 5), "median": round(st[len(st) // 2] * 1e3, 5),
+                          "max": round(st[-1] * 1e3, 5), "first": round(times[0] * 1e3, 5)}}
+    return st[len(st) // 2], sorted(kernel_ms), info
 
 
 def run_equalizer(args, mi, torch, dist, rank, world, dev):
@@ -274,7 +344,7 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         eq.process(yout[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
     assert bool(torch.isfinite(yout[0]).all())
     eq.close()
     if rank != 0:
@@ -318,7 +388,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         if (i % batch) == batch - 1:
             sharding.allreduce_bins(sums)                   # one collective per `batch` frames (RCCL over xGMI)
     steps = args.conv_steps - (args.conv_steps % batch) or batch
-    elapsed, kernel_ms = _timed_steps(mi, torch, dist, world, dev, step, steps, batch)
+    elapsed, kernel_ms, _ = _timed_steps(mi, torch, dist, world, dev, step, steps, batch)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
     an.close()
     if rank != 0:
@@ -373,7 +443,7 @@ def run_crossover(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         xo.process(outs[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
     assert all(bool(torch.isfinite(o).all()) for o in outs[0])
     xo.close()
     if rank != 0:
@@ -398,7 +468,7 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         sp.process(outs[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
     assert all(bool(torch.isfinite(o).all()) for o in outs[0])
     sp.close()
     if rank != 0:
@@ -427,7 +497,7 @@ def run_loudness(args, mi, torch, dist, rank, world, dev):
     def step(i):
         lm.process(o1, None, xin[i % ring], n, stream=stream)
         im.process(o2, xin[i % ring], n, stream=stream)
-    elapsed, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
     assert bool(torch.isfinite(o1).all()) and bool(torch.isfinite(o2).all())
     lm.close(); im.close()
     if rank != 0:
@@ -480,9 +550,16 @@ def main():
         return
 
     C, n, ring = args.channels, args.samples, args.ring
-    # per-rank channel shard: rank r owns global channels [r*C, (r+1)*C)
-    coef_all, _ = wl.c2_coefficients(C * world)
-    coef = np.ascontiguousarray(coef_all[rank * C:(rank + 1) * C, :args.sections])
+    # per-rank channel shard: rank r owns global channels [r*C, (r+1)*C).  BASELINE config C2: FLT_BT_LRX_LOPASS slope 4
+    # (8 biquads), Q 0.75, cutoff log-uniform 200 Hz .. 18 kHz per channel (seed 3), designed by the PRODUCT's designer.
+    fc_all = np.exp(np.random.default_rng(3).uniform(np.log(200.0), np.log(18000.0), size=C * world))
+    coef = np.zeros((C, 8, 5), np.float32)
+    for c in range(C):
+        f = float(fc_all[rank * C + c])
+        _, _, sec = mi.design_filter(FLT_BT_LRX_LOPASS, 4, f, f, 1.0, 0.75, 48000)
+        assert sec.shape == (8, 5), sec.shape
+        coef[c] = sec
+    coef = np.ascontiguousarray(coef[:, :args.sections])
     bank = mi.BiquadBank(C, max(1, coef.shape[1]))
     bank.set_all_chains(coef)
 
@@ -490,21 +567,17 @@ def main():
     gen.manual_seed(2 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
     yout = torch.empty_like(xin)
-    stream = torch.cuda.current_stream()
+    stream = torch.cuda.Stream(device=dev)                  # a created stream: the region is captured into a hipGraph
     bank.commit(stream)
+    torch.cuda.synchronize()
 
     def step(i):
         k = i % ring
         bank.process(yout[k], xin[k], n, stream=stream)
 
-    # part of the set-up, like the table upload above: the code object is loaded and the clocks are up before the W
-    # warm-up steps the caller asked for (matters only when W is a handful)
-    for i in range(SETUP_LAUNCHES):
-        step(i)
-    torch.cuda.synchronize()
-
-    # live kernel durations: HIP event pairs recorded by the launch itself (hipExtLaunchKernelGGL on the launch stream)
-    elapsed, kernel_ms = _timed_steps(mi, torch, dist, world, dev, step, args.steps, args.warmup)
+    regions = args.regions or (5 if args.steps >= 500 else 25)
+    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, args.steps, args.warmup, regions=regions,
+                                             stream=stream, graph=(args.launch == "graph"))
     avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
     med_kernel_ms = kernel_ms[len(kernel_ms) // 2]
 
@@ -517,13 +590,11 @@ def main():
         samples_per_step = C * n * world
         alg_bytes = 8.0 * C * n                     # 4 B in + 4 B out per channel-sample
         achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_biquad_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        committed = {"note": "read from files committed under profiles/ (collected by tests/prof_round.sh in an earlier "
+                             "run of the same command), not measured by this run",
+                     "traffic": _pmc_traffic("pmc_biquad_latest.json"),
+                     "rocprofv3_avg_us": _profile_avg_us("biquad", "biquad_bank_kernel<16, 2") if (C, n) == (1024, 4096) else None,
+                     "parity": _committed_json("c2_parity_latest.json")}
         line = {
             "metric": "Msamples/sec per GPU (biquad-x8 1024ch; Convolver 65536-tap) + HBM roofline %",
             "value": round(samples_per_step * args.steps / elapsed / 1e6, 1),
@@ -537,7 +608,6 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "setup_launches": SETUP_LAUNCHES,
             "config": {
                 "workload": "biquad-x8 cascade (FilterBank::process), %d channels x %d-sample blocks per GPU, "
                             "FLT_BT_LRX_LOPASS slope 4 per-channel cutoffs, state carried across blocks" % (C, n),
@@ -545,13 +615,16 @@ def main():
                 "resident_ring_blocks": ring, "parallelism": "channel-shard x%d, no collective" % world,
             },
             "per_gpu_msamples_s": round(C * n * args.steps / elapsed / 1e6, 1),
+            "timing": tinfo,
             "roofline": {
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": committed["traffic"],
                 "kernel": "biquad_bank_kernel<16,2>", "kernel_avg_us": round(avg_kernel_ms * 1e3, 3),
-                "kernel_median_us": round(med_kernel_ms * 1e3, 3), "algorithmic_bytes_per_launch": alg_bytes,
-                "rocprofv3_avg_us": _profile_avg_us("biquad", "biquad_bank_kernel<16, 2") if (C, n) == (1024, 4096) else None,
+                "kernel_median_us": round(med_kernel_ms * 1e3, 3), "kernel_samples": len(kernel_ms),
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "whole_step_frac": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
             },
+            "committed_profile": committed,
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_biquad(coef, n)

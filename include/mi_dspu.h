@@ -72,6 +72,16 @@ int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
  * kernel's launch duration as a profiler reports it.  One-shot.
  */
 int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
+/*
+ * hipGraph helpers for launch-bound inner loops: every steady-state *_process() call of the banks takes no host
+ * decision and keeps what changes from call to call on the device, so a run of calls on `stream` can be captured
+ * once and replayed (hipStreamBeginCapture / hipStreamEndCapture + hipGraphInstantiate / hipGraphLaunch).
+ * begin: `stream` must be a created (non-NULL) stream.  end: returns an executable graph handle.
+ */
+int         mi_dspu_graph_begin_capture(void *stream);
+int         mi_dspu_graph_end_capture(void *stream, void **graph_exec);
+int         mi_dspu_graph_launch(void *graph_exec, void *stream);
+int         mi_dspu_graph_destroy(void *graph_exec);
 
 /* ---- biquad cascade bank -------------------------------------------------------------- */
 /*

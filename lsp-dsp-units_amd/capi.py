@@ -56,6 +56,10 @@ PROTOTYPES = {
     "mi_dspu_event_synchronize": (c_int, [c_void_p]),
     "mi_dspu_event_elapsed_ms": (c_int, [POINTER(c_float), c_void_p, c_void_p]),
     "mi_dspu_profile_next_launch": (c_int, [c_void_p, c_void_p]),
+    "mi_dspu_graph_begin_capture": (c_int, [c_void_p]),
+    "mi_dspu_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "mi_dspu_graph_launch": (c_int, [c_void_p, c_void_p]),
+    "mi_dspu_graph_destroy": (c_int, [c_void_p]),
     "mi_biquad_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_biquad_bank_destroy": (c_int, [c_void_p]),
     "mi_biquad_bank_set_chains": (c_int, [c_void_p, c_uint32, POINTER(BiquadX1), c_uint32, c_int]),

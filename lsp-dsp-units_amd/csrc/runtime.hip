@@ -164,4 +164,39 @@ int mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop)
     return MI_OK;
 }
 
+int mi_dspu_graph_begin_capture(void *stream)
+{
+    MI_REQUIRE(stream != nullptr, MI_EINVAL, "mi_dspu_graph_begin_capture: the NULL stream cannot be captured");
+    MI_HIP_CHECK(hipStreamBeginCapture(mi::as_stream(stream), hipStreamCaptureModeThreadLocal));
+    return MI_OK;
+}
+
+int mi_dspu_graph_end_capture(void *stream, void **graph_exec)
+{
+    MI_REQUIRE(graph_exec != nullptr, MI_EINVAL, "mi_dspu_graph_end_capture: NULL result pointer");
+    *graph_exec = nullptr;
+    hipGraph_t graph = nullptr;
+    MI_HIP_CHECK(hipStreamEndCapture(mi::as_stream(stream), &graph));
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    MI_HIP_CHECK(e);
+    *graph_exec = exec;
+    return MI_OK;
+}
+
+int mi_dspu_graph_launch(void *graph_exec, void *stream)
+{
+    MI_REQUIRE(graph_exec != nullptr, MI_EINVAL, "mi_dspu_graph_launch: NULL graph");
+    MI_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), mi::as_stream(stream)));
+    return MI_OK;
+}
+
+int mi_dspu_graph_destroy(void *graph_exec)
+{
+    if (graph_exec != nullptr)
+        MI_HIP_CHECK(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
+    return MI_OK;
+}
+
 } // extern "C"

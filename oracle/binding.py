@@ -74,6 +74,19 @@ def biquad_cascade_f64(x, coef):
     return y
 
 
+def biquad_cascade_f64_state(x, coef, state=None):
+    """The recurrence in float64 with a carried state: returns (y, state[ns][2]).  scipy's lfilter is the same
+    transposed direct form II (zi = {d0, d1}), so the state of the reference's sections maps onto it one to one;
+    this is what lets a test follow exact arithmetic across re-designs that keep the filter memory."""
+    from scipy.signal import lfilter
+    coef = np.asarray(coef, dtype=np.float64).reshape(-1, 5)
+    st = np.zeros((coef.shape[0], 2)) if state is None else np.array(state, dtype=np.float64, copy=True)
+    y = np.asarray(x, dtype=np.float64)
+    for j, (b0, b1, b2, a1, a2) in enumerate(coef):
+        y, st[j] = lfilter([b0, b1, b2], [1.0, -a1, -a2], y, zi=st[j])
+    return y, st
+
+
 # ---- FFT / fast convolution primitives (fft_oracle.c) ---------------------------------------------------
 _lib.orc_packed_direct_fft.argtypes = [_fp, _fp, c_size_t]
 _lib.orc_packed_reverse_fft.argtypes = [_fp, _fp, c_size_t]

@@ -20,10 +20,17 @@
  * stream (software-pipelined over SIMD lanes upstream); the arithmetic seen by
  * each section is the one above, so the oracle runs sections one after another.
  *
- * Parity pin: no reference test asserts IIR output.  The pins
- * are (1) the sign convention + the BS.1770 table in Filter.cpp:2103-2111
- * checked through the designer oracle, (2) frequency-response identity of the
- * impulse response (tests/test_oracle_filters.py).
+ * Parity pin: no reference test asserts IIR output, so the
+ * streaming arithmetic is pinned through what the reference documents about it:
+ *  (1) the sign convention + the BS.1770 table in Filter.cpp:2103-2111
+ *      (tests/test_filter_design.py::test_anchor_k_weighting_table);
+ *  (2) tests/test_oracle_filters.py: for every filter type the spectrum of THIS
+ *      file's impulse response equals the transfer function Filter::freq_chart
+ *      evaluates from the analog prototype (Filter.cpp:500-696) -- a wrong sign,
+ *      section order, state update or delay in the recurrence below breaks it;
+ *  (3) the impulse response head of the README filter recorded from the
+ *      reference's own objects by the survey probe (SURVEY.md Appendix C,
+ *      tests/golden/filter_anchors.json), same file.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off so the rounding is the
  * same on every host).

@@ -56,6 +56,11 @@ def parity_report(gpu_out, ref32, ref64, peak=None):
 TOL = 1e-5
 # a recursion whose float32 round-off noise is below this is "well conditioned": strict tolerance applies
 NOISE_FLOOR = 2e-6      # = TOL / 5: the noise rule below turns into the strict one exactly here (no jump in the bound)
+# Factors of the noise rule, set from the distribution measured on all 1024 channels of C2 on the MI355X
+# (tests/test_biquad_gpu.py::test_c2_full_size_all_channels writes it to gpurun_out/c2_parity.json; the committed copy
+# is profiles/c2_parity_latest.json): twice the worst ratios seen there.
+IIR_EXACT_FACTOR = 4.0  # |gpu - exact|  <= IIR_EXACT_FACTOR * noise
+IIR_REF_FACTOR = 5.0    # |gpu - oracle| <= IIR_REF_FACTOR * noise
 
 
 def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None):
@@ -71,6 +76,6 @@ def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None):
     if r["noise"] <= NOISE_FLOOR:
         assert r["gpu_vs_ref32"] <= TOL, msg
     else:
-        assert r["gpu_vs_exact"] <= max(TOL, 4.0 * r["noise"]), msg
-        assert r["gpu_vs_ref32"] <= max(TOL, 5.0 * r["noise"]), msg
+        assert r["gpu_vs_exact"] <= max(TOL, IIR_EXACT_FACTOR * r["noise"]), msg
+        assert r["gpu_vs_ref32"] <= max(TOL, IIR_REF_FACTOR * r["noise"]), msg
     return r

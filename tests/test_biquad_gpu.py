@@ -228,7 +228,15 @@ def test_impulse_response_restores_state(gpu):
 
 def test_c2_full_size_all_channels(gpu):
     """BASELINE config 1 at full size: 1024 ch x 4096, 8 sections, 4 consecutive blocks, every channel
-    checked against the oracle (OpenMP over channels keeps it to seconds)."""
+    checked against the oracle (OpenMP over channels keeps it to seconds).
+
+    The per-channel figures behind the IIR parity rule are written to gpurun_out/c2_parity.json (copied to
+    profiles/c2_parity_latest.json, which bench.py quotes) and summarised in the assertion messages, so the
+    distribution the rule's factors rest on is on record: how many channels fall under the strict 1e-5, the worst
+    distance from the oracle, and the worst distances in units of the float32 recursion's own noise."""
+    import json
+    import os
+    from conftest import IIR_EXACT_FACTOR, IIR_REF_FACTOR, NOISE_FLOOR, ROOT, TOL
     C, n, nb = 1024, 4096, 4
     coef, fc = wl.c2_coefficients(C)
     x = wl.c2_input(C, n, blocks=nb)
@@ -236,17 +244,49 @@ def test_c2_full_size_all_channels(gpu):
     state = np.zeros((C, 8, 2), np.float32)
     nsec = np.full(C, 8, np.uint32)
     y32 = np.stack([oracle.biquad_bank(x[b], coef, nsec, state) for b in range(nb)])
-    worst_strict, worst_any, n_strict = 0.0, 0.0, 0
+    rows = np.zeros((C, 4))
     for c in range(C):
         y64 = oracle.biquad_cascade_f64(x[:, c, :].reshape(-1), coef[c]).reshape(nb, n)
-        r = assert_iir_parity(y[:, c], y32[:, c], y64, "C2 ch%d fc=%.0f" % (c, fc[c]))
-        worst_any = max(worst_any, r["gpu_vs_ref32"])
-        if r["noise"] <= 3e-6:
-            n_strict += 1
-            worst_strict = max(worst_strict, r["gpu_vs_ref32"])
-    print("C2 full: %d/%d channels under the strict 1e-5 rule (worst %.2e); worst overall %.2e"
-          % (n_strict, C, worst_strict, worst_any))
-    assert n_strict > C // 4
+        r = parity_report(y[:, c], y32[:, c], y64)
+        rows[c] = (fc[c], r["noise"], r["gpu_vs_exact"], r["gpu_vs_ref32"])
+    noise, exact, ref32 = rows[:, 1], rows[:, 2], rows[:, 3]
+    strict = noise <= NOISE_FLOOR
+    rx, rr = exact / noise, ref32 / noise
+    loose = ~strict
+
+    def worst(metric, mask):
+        i = int(np.flatnonzero(mask)[np.argmax(metric[mask])])
+        return {"value": float(metric[i]), "channel": i, "cutoff_hz": round(float(fc[i]), 1), "noise": float(noise[i])}
+    summary = {
+        "config": "C2: 1024 ch x 4096 x 4 blocks, FLT_BT_LRX_LOPASS slope 4, cutoffs 200 Hz .. 18 kHz",
+        "rule": {"TOL": TOL, "NOISE_FLOOR": NOISE_FLOOR, "exact_factor": IIR_EXACT_FACTOR, "ref_factor": IIR_REF_FACTOR},
+        "n_channels": C, "n_strict": int(strict.sum()),
+        "worst_gpu_vs_ref32": worst(ref32, np.ones(C, bool)),
+        "worst_gpu_vs_ref32_strict_channels": worst(ref32, strict),
+        "worst_gpu_vs_exact_over_noise": worst(rx, loose) if loose.any() else None,
+        "worst_gpu_vs_ref32_over_noise": worst(rr, loose) if loose.any() else None,
+        "percentiles_noisy_channels": {
+            "gpu_vs_exact_over_noise": {str(q): float(np.percentile(rx[loose], q)) for q in (50, 90, 99, 100)},
+            "gpu_vs_ref32_over_noise": {str(q): float(np.percentile(rr[loose], q)) for q in (50, 90, 99, 100)},
+        } if loose.any() else None,
+        "by_cutoff": [{"band_hz": [lo, hi], "channels": int(m.sum()), "noise_max": float(noise[m].max()),
+                       "gpu_vs_exact_max": float(exact[m].max()), "gpu_vs_ref32_max": float(ref32[m].max())}
+                      for lo, hi in ((200, 400), (400, 800), (800, 1600), (1600, 3200), (3200, 6400), (6400, 18000))
+                      for m in [(fc >= lo) & (fc < hi)] if m.any()],
+    }
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "c2_parity.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    brief = "C2 parity: %s" % json.dumps({k: summary[k] for k in ("n_strict", "worst_gpu_vs_ref32",
+                                          "worst_gpu_vs_exact_over_noise", "worst_gpu_vs_ref32_over_noise")})
+    print(brief)
+    assert np.all(np.isfinite(y)), brief
+    assert np.all(ref32[strict] <= TOL), brief
+    if loose.any():
+        assert np.all(exact[loose] <= np.maximum(TOL, IIR_EXACT_FACTOR * noise[loose])), brief
+        assert np.all(ref32[loose] <= np.maximum(TOL, IIR_REF_FACTOR * noise[loose])), brief
+    assert strict.sum() > C // 4, brief
 
 
 def test_linearity_and_determinism_full_size(gpu):
