@@ -58,7 +58,12 @@ TOL = 1e-5
 NOISE_FLOOR = 2e-6      # = TOL / 5: the noise rule below turns into the strict one exactly here (no jump in the bound)
 # Factors of the noise rule, set from the distribution measured on all 1024 channels of C2 on the MI355X
 # (tests/test_biquad_gpu.py::test_c2_full_size_all_channels writes it to gpurun_out/c2_parity.json; the committed copy
-# is profiles/c2_parity_latest.json): twice the worst ratios seen there.
+# is profiles/c2_parity_latest.json).  Round 2, 652 channels above the noise floor:
+#   |gpu - exact| / noise   median 0.55, 90 % 1.10, 99 % 1.71, worst 2.61  (the GPU result is usually CLOSER to exact
+#                           arithmetic than the reference's own float32 recursion is)
+#   |gpu - oracle| / noise  median 1.15, 90 % 1.58, 99 % 2.11, worst 2.75  (two independent round-off walks)
+# `noise` is itself the maximum of ONE round-off walk, so single-run ratios scatter by about a factor of two; the
+# factors are 1.5x / 1.8x the worst ratio seen, i.e. a channel fails before it reaches twice the measured worst case.
 IIR_EXACT_FACTOR = 4.0  # |gpu - exact|  <= IIR_EXACT_FACTOR * noise
 IIR_REF_FACTOR = 5.0    # |gpu - oracle| <= IIR_REF_FACTOR * noise
 
