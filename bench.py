@@ -381,15 +381,31 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     an.process(xin[0], hop, stream=stream)
     info = an.info()
     assert info["period"] == hop, info
+    # the exchange step runs inside the library: its own RCCL communicator (ncclAllReduce from the C++ host side);
+    # the rehearsal mode (several ranks on one device, gloo) keeps the torch collective
+    state = {"comm": None, "collective": "none (one rank)"}
+    if world > 1:
+        state["collective"] = "torch.distributed all_reduce (%s)" % dist.get_backend()
+        if dist.get_backend() == "nccl":
+            try:
+                state["comm"] = sharding.library_comm(mi)
+                state["collective"] = "mi_analyzer_bank_allreduce_bins: ncclAllReduce from the library's host side (RCCL over xGMI)"
+            except Exception as e:                          # the measurement goes on with torch's communicator
+                print("bench: library communicator refused (%s); torch.distributed all_reduce instead" % e, file=sys.stderr)
 
     def step(i):
         an.process(xin[i % ring], hop, stream=stream)       # one frame: ingest + strobe analysis of every channel
         an.reduce_bins(sums[i % batch], stream=stream)      # local per-bin sum over this GPU's channels
-        if (i % batch) == batch - 1:
-            sharding.allreduce_bins(sums)                   # one collective per `batch` frames (RCCL over xGMI)
+        if (i % batch) == batch - 1:                        # one collective per `batch` frames (RCCL over xGMI)
+            if state["comm"] is not None:
+                an.allreduce_bins(sums, batch, state["comm"], stream=stream)
+            else:
+                sharding.allreduce_bins(sums)
     steps = args.conv_steps - (args.conv_steps % batch) or batch
     elapsed, kernel_ms, _ = _timed_steps(mi, torch, dist, world, dev, step, steps, batch)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
+    if state["comm"] is not None:
+        state["comm"].close()
     an.close()
     if rank != 0:
         return None
@@ -401,7 +417,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         "ms_per_step": round(elapsed / steps * 1e3, 5),
         "config": {"workload": "Analyzer: 4096-point Hann spectrum per channel every 2048 samples, %d channels per GPU, "
                                "per-bin sum over all channels (all-reduce of %d x %d floats per %d frames)"
-                               % (C, batch, bins, batch), "channels_per_gpu": C},
+                               % (C, batch, bins, batch), "channels_per_gpu": C, "collective": state["collective"]},
         "roofline": {"bound": "hbm", "achieved": round(frame_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(frame_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None,

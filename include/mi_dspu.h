@@ -440,6 +440,26 @@ int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *bank, float *out, size_t o
 int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_envelope, void *stream);
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *bank, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step);
 
+/*
+ * Multi-GPU: the one exchange step of the path.  Channels are sharded over the GPUs of a node, one process per GPU;
+ * the per-bin sum over ALL channels (the MultiSpectralProcessor-style callback stage, util/MultiSpectralProcessor.h:41,
+ * BASELINE config 5) is each rank's mi_analyzer_bank_reduce_bins followed by one RCCL all-reduce over xGMI, issued
+ * from the library's C++ host side on the caller's stream.  A communicator is created like an ncclComm_t: one rank
+ * makes the 128-byte id and hands it to the others by whatever means the host has (a file, MPI, torch.distributed).
+ * mi_dspu_comm_adopt wraps an ncclComm_t the host already owns (not destroyed with the wrapper).
+ * reduce_bins adds the channels in a shard-composable order (blocks of 16 channels, then a binary tree aligned to
+ * powers of two), so the halves of a channel set reduce to partial sums whose sum is the reduction of the whole set.
+ */
+#define MI_DSPU_COMM_ID_BYTES 128
+typedef struct mi_dspu_comm mi_dspu_comm_t;
+int mi_dspu_comm_unique_id(void *id128);
+int mi_dspu_comm_create(mi_dspu_comm_t **comm, const void *id128, int nranks, int rank);
+int mi_dspu_comm_adopt(mi_dspu_comm_t **comm, void *nccl_comm);
+int mi_dspu_comm_destroy(mi_dspu_comm_t *comm);
+int mi_dspu_comm_info(const mi_dspu_comm_t *comm, int *nranks, int *rank);
+/* bins: DEVICE [frames][2^(rank-1)+1], summed in place over the ranks of `comm` (float32, ncclSum). */
+int mi_analyzer_bank_allreduce_bins(mi_analyzer_bank_t *bank, float *bins, size_t frames, mi_dspu_comm_t *comm, void *stream);
+
 /* ---- equalizer bank --------------------------------------------------------------------------- */
 /*
  * mi_equalizer_bank: `channels` x lsp::dspu::Equalizer(filters, fir_rank)

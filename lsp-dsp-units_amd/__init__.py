@@ -12,7 +12,7 @@ Import with ``importlib.import_module("lsp-dsp-units_amd")`` (the directory
 name carries the reference's name and is not a Python identifier).
 """
 from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
-from .units import (AnalyzerBank, BiquadBank, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, EqualizerBank,  # noqa: F401
+from .units import (AnalyzerBank, BiquadBank, Comm, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, EqualizerBank,  # noqa: F401
                     ILUFSBank, LoudnessBank,
                     RingBank,
                     SpectralBank, SplitterBank, crossover_fft_mask,

@@ -60,6 +60,12 @@ PROTOTYPES = {
     "mi_dspu_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi_dspu_graph_launch": (c_int, [c_void_p, c_void_p]),
     "mi_dspu_graph_destroy": (c_int, [c_void_p]),
+    "mi_dspu_comm_unique_id": (c_int, [c_void_p]),
+    "mi_dspu_comm_create": (c_int, [POINTER(c_void_p), c_void_p, c_int, c_int]),
+    "mi_dspu_comm_adopt": (c_int, [POINTER(c_void_p), c_void_p]),
+    "mi_dspu_comm_destroy": (c_int, [c_void_p]),
+    "mi_dspu_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
+    "mi_analyzer_bank_allreduce_bins": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
     "mi_biquad_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_biquad_bank_destroy": (c_int, [c_void_p]),
     "mi_biquad_bank_set_chains": (c_int, [c_void_p, c_uint32, POINTER(BiquadX1), c_uint32, c_int]),

@@ -1,0 +1,170 @@
+// The one exchange step of the hot path: the cross-channel per-bin sum of the spectral path (BASELINE config 5, the
+// MultiSpectralProcessor-style callback, util/MultiSpectralProcessor.h:41) when the channels are sharded over the
+// GPUs of a node.  Every rank reduces its own channels on the device (mi_analyzer_bank_reduce_bins) and the partial
+// sums are all-reduced with RCCL over xGMI, from this library's C++ host side -- one ncclAllReduce of
+// frames x (2^(rank-1)+1) floats on the caller's stream, no torch involved.
+//
+// RCCL is bound at run time (dlopen of librccl.so.1 on the first communicator call): single-GPU users of the library
+// do not need it, and a process that already carries a copy (PyTorch's torch.distributed) shares that copy.
+#include "mi_common.h"
+
+#include <dlfcn.h>
+#include <mutex>
+#include <rccl/rccl.h>
+
+namespace
+{
+    struct rccl_api
+    {
+        void *handle = nullptr;
+        decltype(&ncclGetUniqueId)   get_unique_id = nullptr;
+        decltype(&ncclCommInitRank)  comm_init_rank = nullptr;
+        decltype(&ncclCommDestroy)   comm_destroy = nullptr;
+        decltype(&ncclAllReduce)     all_reduce = nullptr;
+        decltype(&ncclGetErrorString) error_string = nullptr;
+        decltype(&ncclCommCount)     comm_count = nullptr;
+        decltype(&ncclCommUserRank)  comm_user_rank = nullptr;
+    };
+
+    rccl_api *rccl()
+    {
+        static rccl_api api;
+        static std::once_flag once;
+        std::call_once(once, []
+        {
+            for (const char *name : { "librccl.so.1", "librccl.so" })
+                if ((api.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL)) != nullptr)
+                    break;
+            if (api.handle == nullptr)
+                return;
+            api.get_unique_id  = reinterpret_cast<decltype(api.get_unique_id)>(dlsym(api.handle, "ncclGetUniqueId"));
+            api.comm_init_rank = reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(api.handle, "ncclCommInitRank"));
+            api.comm_destroy   = reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.handle, "ncclCommDestroy"));
+            api.all_reduce     = reinterpret_cast<decltype(api.all_reduce)>(dlsym(api.handle, "ncclAllReduce"));
+            api.error_string   = reinterpret_cast<decltype(api.error_string)>(dlsym(api.handle, "ncclGetErrorString"));
+            api.comm_count     = reinterpret_cast<decltype(api.comm_count)>(dlsym(api.handle, "ncclCommCount"));
+            api.comm_user_rank = reinterpret_cast<decltype(api.comm_user_rank)>(dlsym(api.handle, "ncclCommUserRank"));
+        });
+        const bool ok = api.handle && api.get_unique_id && api.comm_init_rank && api.comm_destroy && api.all_reduce &&
+                        api.error_string && api.comm_count && api.comm_user_rank;
+        return ok ? &api : nullptr;
+    }
+
+    int nccl_fail(const rccl_api *a, const char *what, ncclResult_t r)
+    {
+        return mi::fail(MI_EHIP, "%s failed: %s", what, a->error_string(r));
+    }
+} // namespace
+
+struct mi_dspu_comm
+{
+    ncclComm_t  comm = nullptr;
+    bool        owned = false;
+    int         nranks = 1, rank = 0;
+};
+
+extern "C" {
+
+int mi_dspu_comm_unique_id(void *id128)
+{
+    MI_REQUIRE(id128 != nullptr, MI_EINVAL, "mi_dspu_comm_unique_id: NULL buffer");
+    static_assert(sizeof(ncclUniqueId) == MI_DSPU_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
+    rccl_api *a = rccl();
+    MI_REQUIRE(a != nullptr, MI_ENODEV, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    ncclUniqueId id;
+    const ncclResult_t r = a->get_unique_id(&id);
+    if (r != ncclSuccess)
+        return nccl_fail(a, "ncclGetUniqueId", r);
+    memcpy(id128, &id, sizeof(id));
+    return MI_OK;
+}
+
+int mi_dspu_comm_create(mi_dspu_comm_t **comm, const void *id128, int nranks, int rank)
+{
+    MI_REQUIRE(comm != nullptr, MI_EINVAL, "mi_dspu_comm_create: NULL result pointer");
+    *comm = nullptr;
+    MI_REQUIRE(id128 != nullptr && nranks >= 1 && rank >= 0 && rank < nranks, MI_EINVAL,
+               "mi_dspu_comm_create: bad id / rank %d of %d", rank, nranks);
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    rccl_api *a = rccl();
+    MI_REQUIRE(a != nullptr, MI_ENODEV, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    mi_dspu_comm *c = new (std::nothrow) mi_dspu_comm();
+    MI_REQUIRE(c != nullptr, MI_ENOMEM, "mi_dspu_comm_create: out of host memory");
+    ncclUniqueId id;
+    memcpy(&id, id128, sizeof(id));
+    const ncclResult_t r = a->comm_init_rank(&c->comm, nranks, id, rank);     // one process per GPU: the current device
+    if (r != ncclSuccess)
+    {
+        delete c;
+        return nccl_fail(a, "ncclCommInitRank", r);
+    }
+    c->owned = true;
+    c->nranks = nranks;
+    c->rank = rank;
+    *comm = c;
+    return MI_OK;
+}
+
+int mi_dspu_comm_adopt(mi_dspu_comm_t **comm, void *nccl_comm)
+{
+    MI_REQUIRE(comm != nullptr, MI_EINVAL, "mi_dspu_comm_adopt: NULL result pointer");
+    *comm = nullptr;
+    MI_REQUIRE(nccl_comm != nullptr, MI_EINVAL, "mi_dspu_comm_adopt: NULL ncclComm_t");
+    rccl_api *a = rccl();
+    MI_REQUIRE(a != nullptr, MI_ENODEV, "RCCL (librccl.so.1) could not be loaded: %s", dlerror());
+    mi_dspu_comm *c = new (std::nothrow) mi_dspu_comm();
+    MI_REQUIRE(c != nullptr, MI_ENOMEM, "mi_dspu_comm_adopt: out of host memory");
+    c->comm = reinterpret_cast<ncclComm_t>(nccl_comm);
+    c->owned = false;
+    ncclResult_t r = a->comm_count(c->comm, &c->nranks);
+    if (r == ncclSuccess)
+        r = a->comm_user_rank(c->comm, &c->rank);
+    if (r != ncclSuccess)
+    {
+        delete c;
+        return nccl_fail(a, "ncclCommCount", r);
+    }
+    *comm = c;
+    return MI_OK;
+}
+
+int mi_dspu_comm_destroy(mi_dspu_comm_t *c)
+{
+    if (c == nullptr)
+        return MI_OK;
+    rccl_api *a = rccl();
+    if (c->owned && c->comm != nullptr && a != nullptr)
+        (void)a->comm_destroy(c->comm);
+    delete c;
+    return MI_OK;
+}
+
+int mi_dspu_comm_info(const mi_dspu_comm_t *c, int *nranks, int *rank)
+{
+    MI_REQUIRE(c != nullptr, MI_ESTATE, "mi_dspu_comm_info: NULL communicator");
+    if (nranks) *nranks = c->nranks;
+    if (rank)   *rank = c->rank;
+    return MI_OK;
+}
+
+int mi_analyzer_bank_allreduce_bins(mi_analyzer_bank_t *bank, float *bins, size_t frames, mi_dspu_comm_t *c, void *stream)
+{
+    MI_REQUIRE(bank != nullptr, MI_ESTATE, "mi_analyzer_bank_allreduce_bins: NULL bank");
+    MI_REQUIRE(c != nullptr, MI_ESTATE, "mi_analyzer_bank_allreduce_bins: NULL communicator");
+    if (frames == 0)
+        return MI_OK;
+    MI_REQUIRE(bins != nullptr, MI_EINVAL, "mi_analyzer_bank_allreduce_bins: NULL buffer");
+    uint32_t nb = 0;
+    const int q = mi_analyzer_bank_info(bank, nullptr, &nb, nullptr, nullptr);
+    if (q != MI_OK)
+        return q;
+    rccl_api *a = rccl();
+    MI_REQUIRE(a != nullptr, MI_ENODEV, "RCCL (librccl.so.1) could not be loaded");
+    // in place, float32 sum, on the caller's stream: ordered behind the reduce_bins launches that filled `bins`
+    const ncclResult_t r = a->all_reduce(bins, bins, frames * size_t(nb), ncclFloat, ncclSum, c->comm, mi::as_stream(stream));
+    if (r != ncclSuccess)
+        return nccl_fail(a, "ncclAllReduce", r);
+    return MI_OK;
+}
+
+} // extern "C"

@@ -334,46 +334,65 @@ namespace
         }
     }
 
-    // Per-bin reduction over channels (the C5 callback), deterministic and in one launch.  A workgroup owns 16 bins (one
-    // 64-byte segment of every channel row): a wave reads that segment of four channels at once, the 16 waves cover 64
-    // channels per pass with sixteen passes in flight; then the 64 partial sums of a bin are added in a fixed order.
+    // Per-bin reduction over channels (the C5 callback), in one launch and in an order that does not depend on the launch
+    // geometry AND composes across channel shards: blocks of REDUCE_BLOCK consecutive channels are summed in channel
+    // order, the block sums are then added along a binary tree aligned to powers of two (element j takes in element
+    // j + s for s = 1, 2, 4, ...).  The sum over channels [0, 2^k * REDUCE_BLOCK) is a node of that tree, so the
+    // reductions of two banks that hold the halves of a channel set add up to the reduction of the whole set bit for
+    // bit -- which is what lets the per-bin sum be sharded over GPUs and all-reduced (tests/test_spectral_gpu.py).
+    // A workgroup owns 16 bins (one 64-byte segment of every channel row): a wave reads that segment of four channels at
+    // once, 64 groups of 16 lanes work on 64 blocks at a time with the sixteen loads of a block in flight.
     // Narrow workgroups instead of 64-bin ones because 2049 bins would otherwise be 33 workgroups on 256 CUs.
-    constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16;
+    constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16, REDUCE_BLOCK = 16, REDUCE_MAX_BLOCKS = 1024;
 
     __global__ __launch_bounds__(64 * REDUCE_WAVES)
     void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins,
-                           const float *__restrict__ env)
+                           const float *__restrict__ env, uint32_t block /* channels per block, multiple of 16 */)
     {
-        __shared__ float part[REDUCE_WAVES * REDUCE_ROWS][REDUCE_BINS];
+        __shared__ float part[REDUCE_MAX_BLOCKS][REDUCE_BINS];
         const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const uint32_t b = lane & (REDUCE_BINS - 1), r = lane / REDUCE_BINS;
         const uint32_t k = blockIdx.x * REDUCE_BINS + b;
-        constexpr uint32_t STEP = REDUCE_WAVES * REDUCE_ROWS;                   // channels per pass
-        float s = 0.0f;
-        if (k < bins)
+        constexpr uint32_t GROUPS = REDUCE_WAVES * REDUCE_ROWS;                 // blocks in flight
+        const uint32_t nblocks = (channels + block - 1) / block;
+        for (uint32_t j = w * REDUCE_ROWS + r; j < nblocks; j += GROUPS)
         {
-            uint32_t c = w * REDUCE_ROWS + r;
-            for (; c + 15 * STEP < channels; c += 16 * STEP)                    // sixteen passes in flight
+            float s = 0.0f;
+            if (k < bins)
             {
-                float v[16];
-                #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    v[j] = src[size_t(c + j * STEP) * stride + k];
-                #pragma unroll
-                for (int j = 0; j < 16; ++j)
-                    s += v[j];
+                const uint32_t c0 = j * block, c1 = (c0 + block < channels) ? c0 + block : channels;
+                uint32_t c = c0;
+                for (; c + 16 <= c1; c += 16)
+                {
+                    float v[16];
+                    #pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        v[i] = src[size_t(c + i) * stride + k];
+                    #pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s += v[i];
+                }
+                for (; c < c1; ++c)
+                    s += src[size_t(c) * stride + k];
             }
-            for (; c < channels; c += STEP)
-                s += src[size_t(c) * stride + k];
+            part[j][b] = s;
         }
-        part[w * REDUCE_ROWS + r][b] = s;
         __syncthreads();
+        for (uint32_t s = 1; s < nblocks; s <<= 1)
+        {
+            // element j (a multiple of 2s) takes in element j + s
+            const uint32_t pairs = (nblocks + 2 * s - 1) / (2 * s);
+            for (uint32_t i = threadIdx.x; i < pairs * REDUCE_BINS; i += 64 * REDUCE_WAVES)
+            {
+                const uint32_t j = (i / REDUCE_BINS) * 2 * s, bb = i & (REDUCE_BINS - 1);
+                if (j + s < nblocks)
+                    part[j][bb] += part[j + s][bb];
+            }
+            __syncthreads();
+        }
         if (threadIdx.x < REDUCE_BINS && k < bins)
         {
-            float t = 0.0f;
-            #pragma unroll
-            for (uint32_t g = 0; g < STEP; ++g)
-                t += part[g][b];
+            const float t = part[0][b];
             out[k] = (env != nullptr) ? t * env[k] : t;
         }
     }
@@ -1102,8 +1121,12 @@ int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *b, float *out, int with_env
     MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_reduce_bins: bad argument");
     hipStream_t st = mi::as_stream(stream);
     const uint32_t bins = (1u << (b->rank - 1)) + 1;
+    // blocks of 16 channels up to 16 384 channels; beyond that the block grows so that the block sums still fit the LDS
+    uint32_t block = REDUCE_BLOCK;
+    while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
+        block *= 2;
     hipLaunchKernelGGL(bin_reduce_kernel, dim3((bins + REDUCE_BINS - 1) / REDUCE_BINS), dim3(64 * REDUCE_WAVES), 0, st,
-                       out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr);
+                       out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }

@@ -3,9 +3,12 @@
 Channels of every unit are independent, so rank r of W simply owns a contiguous channel range and runs its own
 banks: no data-path collective.  The one exchange step of the hot path is the cross-channel per-bin reduction of
 the spectral path (the MultiSpectralProcessor-style callback of BASELINE config 5): every rank reduces its own
-channels on the device (mi_analyzer_bank_reduce_bins) and the partial sums are all-reduced -- RCCL over xGMI when
-the tensors live on GPUs (torch.distributed backend "nccl"), gloo in the CPU tests.  The message is tiny
-(2^(rank-1)+1 floats per frame), so frames are batched into one collective."""
+channels on the device (mi_analyzer_bank_reduce_bins, a shard-composable summation order) and the partial sums are
+all-reduced by the LIBRARY: mi_analyzer_bank_allreduce_bins issues one ncclAllReduce (RCCL over xGMI) from its C++
+host side on the caller's stream, through a communicator made with mi_dspu_comm_create.  `library_comm` below only
+carries the 128-byte communicator id from rank 0 to the others over whatever process group the launcher set up.
+The message is tiny (2^(rank-1)+1 floats per frame), so frames are batched into one collective.
+`allreduce_bins` is the same sum through torch.distributed, for process groups without GPUs (the gloo tests)."""
 
 
 def shard_range(total, rank, world):
@@ -23,3 +26,16 @@ def allreduce_bins(partial, group=None):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(partial, op=dist.ReduceOp.SUM, group=group)
     return partial
+
+
+def library_comm(mi, group=None):
+    """The library's own RCCL communicator over the ranks of the (initialised) torch.distributed group: rank 0 draws the
+    id (mi_dspu_comm_unique_id), the group broadcasts its 128 bytes, every rank joins (mi_dspu_comm_create).
+    Returns None for a single rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
+        return None
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [mi.Comm.unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0, group=group)
+    return mi.Comm(box[0], world, rank)

@@ -319,12 +319,50 @@ class AnalyzerBank:
         lib.mi_dspu_free(didx)
         return res
 
+    def allreduce_bins(self, bins, frames, comm, stream=None):
+        """Sum `bins` (device [frames][bins]) over the ranks of `comm` in place: RCCL from the library's host side."""
+        check(lib.mi_analyzer_bank_allreduce_bins(self.handle, _ptr(bins), int(frames), comm.handle, _stream(stream)))
+
     def reduce_bins(self, out, with_envelope=False, stream=None):
         check(lib.mi_analyzer_bank_reduce_bins(self.handle, _ptr(out), int(with_envelope), _stream(stream)))
 
     def close(self):
         if self.handle:
             lib.mi_analyzer_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Comm:
+    """mi_dspu_comm_t: an RCCL communicator owned by the library (one process per GPU)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(Comm.ID_BYTES)
+        check(lib.mi_dspu_comm_unique_id(buf))
+        return bytes(buf.raw)
+
+    def __init__(self, unique_id, nranks, rank):
+        assert len(unique_id) == Comm.ID_BYTES
+        h = c_void_p()
+        check(lib.mi_dspu_comm_create(byref(h), ctypes.c_char_p(unique_id), int(nranks), int(rank)))
+        self.handle = h
+
+    def info(self):
+        n, r = c_int(), c_int()
+        check(lib.mi_dspu_comm_info(self.handle, byref(n), byref(r)))
+        return n.value, r.value
+
+    def close(self):
+        if self.handle is not None:
+            lib.mi_dspu_comm_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

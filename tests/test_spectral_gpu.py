@@ -524,3 +524,66 @@ def test_c5_full_size(gpu):
     ref = o.amp[:, :bins].astype(np.float64).sum(axis=0)
     assert np.abs(out1.download() - ref).max() <= TOL * np.abs(ref).max()
     bank.close()
+
+
+def _analyzer(gpu, channels, rank, hop, sr=48000):
+    bank = gpu.AnalyzerBank(channels, rank, sr, 1.0, 0)
+    for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, sr / float(hop)), (bank.RANK, rank), (bank.WINDOW, 0),
+                    (bank.REACTIVITY, 0.2), (bank.SHIFT, 1.0)):
+        bank.configure(what, v)
+    return bank
+
+
+@pytest.mark.parametrize("channels,cut", [(1024, 512), (256, 128), (96, 64), (80, 64), (40, 32)])
+def test_bin_reduction_composes_across_channel_shards(gpu, channels, cut):
+    """Sharding the per-bin sum: two banks that hold the channels [0, cut) and [cut, channels) of a channel set reduce to
+    partial sums whose float32 sum IS the reduction of one bank over the whole set, bit for bit (the order is blocks
+    of 16 channels, then a binary tree aligned to powers of two: `cut` is a node of that tree).  This is the property the
+    multi-GPU per-bin all-reduce rests on; the spectra themselves do not depend on the bank a channel sits in.
+    (`cut` = the largest power-of-two multiple of 16 below the channel count: the root of the tree.)"""
+    rank, hop = 10, 512
+    bins = (1 << (rank - 1)) + 1
+    rng = np.random.default_rng(21)
+    x = (rng.standard_normal((channels, 3 * hop)) * 0.25).astype(np.float32)
+    whole, lo, hi = _analyzer(gpu, channels, rank, hop), _analyzer(gpu, cut, rank, hop), _analyzer(gpu, channels - cut, rank, hop)
+    for f in range(3):
+        blk = x[:, f * hop:(f + 1) * hop]
+        whole.process(gpu.DeviceBuffer.from_host(blk), hop)
+        lo.process(gpu.DeviceBuffer.from_host(blk[:cut]), hop)
+        hi.process(gpu.DeviceBuffer.from_host(blk[cut:]), hop)
+    idx = np.arange(0, bins, dtype=np.uint32)
+    np.testing.assert_array_equal(whole.get_spectrum(idx)[:cut], lo.get_spectrum(idx))       # same spectra in any bank
+    np.testing.assert_array_equal(whole.get_spectrum(idx)[cut:], hi.get_spectrum(idx))
+    a, b, t = gpu.DeviceBuffer((bins,)), gpu.DeviceBuffer((bins,)), gpu.DeviceBuffer((bins,))
+    lo.reduce_bins(a); hi.reduce_bins(b); whole.reduce_bins(t)
+    total = t.download()
+    assert np.abs(total).max() > 0
+    np.testing.assert_array_equal(a.download() + b.download(), total)
+    ref = whole.get_spectrum(idx).astype(np.float64).sum(axis=0)                              # and it is the sum of the rows
+    assert np.abs(total - ref).max() <= 1e-6 * np.abs(ref).max()
+    for bk in (whole, lo, hi):
+        bk.close()
+
+
+def test_library_communicator_single_rank(gpu):
+    """mi_dspu_comm_* / mi_analyzer_bank_allreduce_bins on the one GPU of the box: RCCL is found and bound at run time,
+    a one-rank communicator comes up, and the in-place all-reduce of the reduced bins returns them unchanged (the sum
+    over one rank).  The N > 1 arithmetic is covered by the composition test above and the gloo test on the CPU."""
+    rank, hop, C = 10, 512, 64
+    bins = (1 << (rank - 1)) + 1
+    bank = _analyzer(gpu, C, rank, hop)
+    x = (np.random.default_rng(3).standard_normal((C, hop)) * 0.25).astype(np.float32)
+    bank.process(gpu.DeviceBuffer.from_host(x), hop)
+    frames = 4
+    sums = gpu.DeviceBuffer((frames, bins))
+    one = gpu.DeviceBuffer((bins,))
+    bank.reduce_bins(one)
+    row = one.download()
+    sums.upload(np.tile(row, (frames, 1)))
+    comm = gpu.Comm(gpu.Comm.unique_id(), 1, 0)
+    assert comm.info() == (1, 0)
+    bank.allreduce_bins(sums, frames, comm)
+    gpu.check(gpu.lib.mi_dspu_stream_synchronize(None))
+    np.testing.assert_array_equal(sums.download(), np.tile(row, (frames, 1)))
+    comm.close()
+    bank.close()
