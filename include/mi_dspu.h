@@ -349,6 +349,13 @@ enum mi_envelope
 };
 /* windows::window(dst, n, type), src/main/misc/windows.cpp:62-98 (host memory). */
 int mi_window(float *dst, size_t n, int type);
+/*
+ * The parameterised families, windows::*_general of misc/windows.h:71,86,95,101,113,128,134,143,146,155:
+ *   TRIANGULAR {dn}   HAMMING {a, b}   BLACKMAN {a}   NUTTALL {a0..a3}   FLAT_TOP {a0..a4}   GAUSSIAN {s}
+ *   POISSON {t}   BARTLETT_HANN {a0, a1, a2}   HANN_POISSON {a}   TUKEY {a}
+ * (HANN, BLACKMAN_NUTTALL, BLACKMAN_HARRIS and BARTLETT_FEJER are members of those families and take the same lists).
+ */
+int mi_window_general(float *dst, size_t n, int type, const float *params, uint32_t count);
 /* envelope::noise_lin / reverse_noise_lin(dst, first, last, center, n, type), src/main/misc/envelope.cpp:63-123 (host
  * memory): the colour's spectral envelope (f / center)^k on n linearly spaced frequencies, or the opposite colour's. */
 int mi_envelope_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
@@ -687,6 +694,9 @@ int mi_delay_bank_process_ramping(mi_delay_bank_t *bank, float *out, const float
 typedef struct mi_ring_bank mi_ring_bank_t;
 /* RingBuffer::init(size, fill), RingBuffer.cpp:48-63. */
 int mi_ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill);
+/* The same with the storage in pinned host memory mapped into the device: *host_view ([channels][size]) is the raw
+ * storage as RingBuffer::data() exposes it (util/RingBuffer.h:130); valid after the stream of a call has been synchronised. */
+int mi_ring_bank_create_shared(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill, float **host_view);
 int mi_ring_bank_destroy(mi_ring_bank_t *bank);
 /* clear() / fill(value), RingBuffer.cpp:108-120 (head returns to 0). */
 int mi_ring_bank_fill(mi_ring_bank_t *bank, float value, void *stream);

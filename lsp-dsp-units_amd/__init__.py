@@ -16,4 +16,4 @@ from .units import (AnalyzerBank, BiquadBank, Comm, ConvolverBank, CrossoverBank
                     ILUFSBank, LoudnessBank,
                     RingBank,
                     SpectralBank, SplitterBank, crossover_fft_mask,
-                    design_filter, device_count, filter_freq_chart, make_window)
+                    design_filter, device_count, filter_freq_chart, make_window, make_window_general)

@@ -90,6 +90,7 @@ PROTOTYPES = {
                                        POINTER(c_uint32)]),
     "mi_convolver_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_window": (c_int, [c_void_p, c_size_t, c_int]),
+    "mi_window_general": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_uint32]),
     "mi_envelope_reverse_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
     "mi_envelope_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
     "mi_spectral_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
@@ -195,6 +196,7 @@ PROTOTYPES = {
     "mi_delay_bank_process_ramping": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int,
                                               c_float, c_void_p, c_size_t, c_void_p]),
     "mi_ring_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t, c_float]),
+    "mi_ring_bank_create_shared": (c_int, [POINTER(c_void_p), c_uint32, c_size_t, c_float, POINTER(c_void_p)]),
     "mi_ring_bank_destroy": (c_int, [c_void_p]),
     "mi_ring_bank_fill": (c_int, [c_void_p, c_float, c_void_p]),
     "mi_ring_bank_append": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, POINTER(c_size_t), c_void_p]),

@@ -431,11 +431,26 @@ struct mi_ring_bank
 {
     uint32_t    channels = 0, capacity = 0, head = 0;
     float      *d_ring = nullptr;
+    bool        host_shared = false;        // storage is pinned host memory mapped into the device
 };
 
 extern "C" {
 
+static int ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill, float **host_view);
+
 int mi_ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill)
+{
+    return ring_bank_create(bank, channels, size, fill, nullptr);
+}
+
+int mi_ring_bank_create_shared(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill, float **host_view)
+{
+    MI_REQUIRE(host_view != nullptr, MI_EINVAL, "mi_ring_bank_create_shared: NULL view pointer");
+    *host_view = nullptr;
+    return ring_bank_create(bank, channels, size, fill, host_view);
+}
+
+static int ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, float fill, float **host_view)
 {
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_ring_bank_create: NULL result pointer");
     *bank = nullptr;
@@ -445,21 +460,35 @@ int mi_ring_bank_create(mi_ring_bank_t **bank, uint32_t channels, size_t size, f
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_ring_bank_create: out of host memory");
     b->channels = channels;
     b->capacity = uint32_t(size);
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_ring), size_t(channels) * size * sizeof(float));
+    const size_t bytes = size_t(channels) * size * sizeof(float);
+    b->host_shared = (host_view != nullptr);
+    // shared: pinned host memory that the device addresses through the same pointer (coherent), so a host that reads or
+    // writes the raw storage (RingBuffer::data(), util/RingBuffer.h:130) and the kernels see the same cells
+    hipError_t e = b->host_shared ? hipHostMalloc(reinterpret_cast<void **>(&b->d_ring), bytes, hipHostMallocMapped)
+                                  : hipMalloc(reinterpret_cast<void **>(&b->d_ring), bytes);
     if (e != hipSuccess)
     {
         delete b;
         return mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_ring_bank_create: %s", hipGetErrorString(e));
     }
     *bank = b;
-    return mi_ring_bank_fill(b, fill, nullptr);                         // RingBuffer::init fills (RingBuffer.cpp:48-63)
+    const int r = mi_ring_bank_fill(b, fill, nullptr);                  // RingBuffer::init fills (RingBuffer.cpp:48-63)
+    if (r == MI_OK && host_view != nullptr)
+    {
+        MI_HIP_CHECK(hipStreamSynchronize(nullptr));
+        *host_view = b->d_ring;
+    }
+    return r;
 }
 
 int mi_ring_bank_destroy(mi_ring_bank_t *b)
 {
     if (b == nullptr)
         return MI_OK;
-    (void)hipFree(b->d_ring);
+    if (b->host_shared)
+        (void)hipHostFree(b->d_ring);
+    else
+        (void)hipFree(b->d_ring);
     delete b;
     return MI_OK;
 }

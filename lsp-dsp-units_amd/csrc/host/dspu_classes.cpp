@@ -24,7 +24,11 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
+#include <new>
+#include <unordered_map>
 #include <vector>
 
 #include "filter_design.h"
@@ -33,6 +37,22 @@ namespace lsp
 {
 namespace dspu
 {
+// The class API has no error channel (process() is void, as in the reference), so the last status of a C-ABI call made
+// on behalf of an object of this thread is kept and can be asked for: lsp::dspu::last_status() (mi_dspu_last_error()
+// holds the text).  A failed call leaves the output as documented per class (a copy, or zeros) -- never silently "ok".
+namespace
+{
+    thread_local int tl_last_status = MI_OK;
+    inline int last_status(int r)
+    {
+        if (r != MI_OK)
+            tl_last_status = r;
+        return r;
+    }
+}
+int last_status()           { return tl_last_status; }
+void clear_last_status()    { tl_last_status = MI_OK; }
+
 namespace
 {
     // a pair of device rows that grows on demand
@@ -73,82 +93,142 @@ namespace windows
     {
         mi_window(dst, n, int(type));
     }
+
+    void triangular_general(float *dst, size_t n, int dn)
+    {
+        const float q[] = { float(dn) };
+        mi_window_general(dst, n, MI_WINDOW_TRIANGULAR, q, 1);
+    }
+    void hamming_general(float *dst, size_t n, float a, float b)
+    {
+        const float q[] = { a, b };
+        mi_window_general(dst, n, MI_WINDOW_HAMMING, q, 2);
+    }
+    void blackman_general(float *dst, size_t n, float a)
+    {
+        mi_window_general(dst, n, MI_WINDOW_BLACKMAN, &a, 1);
+    }
+    void nuttall_general(float *dst, size_t n, float a0, float a1, float a2, float a3)
+    {
+        const float q[] = { a0, a1, a2, a3 };
+        mi_window_general(dst, n, MI_WINDOW_NUTTALL, q, 4);
+    }
+    void nutall_general(float *dst, size_t n, float a0, float a1, float a2, float a3) { nuttall_general(dst, n, a0, a1, a2, a3); }
+    void flat_top_general(float *dst, size_t n, float a0, float a1, float a2, float a3, float a4)
+    {
+        const float q[] = { a0, a1, a2, a3, a4 };
+        mi_window_general(dst, n, MI_WINDOW_FLAT_TOP, q, 5);
+    }
+    void gaussian_general(float *dst, size_t n, float s)        { mi_window_general(dst, n, MI_WINDOW_GAUSSIAN, &s, 1); }
+    void poisson_general(float *dst, size_t n, float t)         { mi_window_general(dst, n, MI_WINDOW_POISSON, &t, 1); }
+    void bartlett_hann_general(float *dst, size_t n, float a0, float a1, float a2)
+    {
+        const float q[] = { a0, a1, a2 };
+        mi_window_general(dst, n, MI_WINDOW_BARTLETT_HANN, q, 3);
+    }
+    void hann_poisson_general(float *dst, size_t n, float a)    { mi_window_general(dst, n, MI_WINDOW_HANN_POISSON, &a, 1); }
+    void tukey_general(float *dst, size_t n, float a)           { mi_window_general(dst, n, MI_WINDOW_TUKEY, &a, 1); }
 }
 
 // ---- FilterBank -------------------------------------------------------------------------------------------------
-struct FilterBank::impl_t
+// Reference members (filters/FilterBank.h:39-46): nItems / nMaxItems / nLastItems / vChains are live, vFilters carries
+// the device bank's handle, vBackup the staging rows, vData the host allocation.
+namespace
 {
-    mi_biquad_bank_t               *bank = nullptr;
-    std::vector<dsp::biquad_x1_t>   chains;
-    size_t                          items = 0, max_items = 0;
-    staging                         st;
-};
+    struct bank_ext                                     // lives at the start of FilterBank::vData
+    {
+        staging st;
+    };
+    inline mi_biquad_bank_t *dev_bank(dsp::biquad_t *p) { return reinterpret_cast<mi_biquad_bank_t *>(p); }
+}
+static_assert(sizeof(FilterBank) == 56, "FilterBank keeps the reference's layout (SURVEY.md 0.4)");
 
-FilterBank::FilterBank() : pImpl(nullptr) { construct(); }
+FilterBank::FilterBank() { construct(); }
 FilterBank::~FilterBank() { destroy(); }
-void FilterBank::construct() { pImpl = nullptr; }
+
+void FilterBank::construct()
+{
+    vFilters    = nullptr;
+    vChains     = nullptr;
+    nItems      = 0;
+    nMaxItems   = 0;
+    nLastItems  = size_t(-1);                           // FilterBank.cpp:45: the first end() clears
+    vBackup     = nullptr;
+    vData       = nullptr;
+}
 
 bool FilterBank::init(size_t filters)
 {
     destroy();
-    impl_t *p = new (std::nothrow) impl_t();
-    if (p == nullptr)
+    const size_t cap = (filters > 0) ? filters : 1;
+    const size_t head = (sizeof(bank_ext) + 63) & ~size_t(63);
+    uint8_t *raw = static_cast<uint8_t *>(std::calloc(1, head + cap * sizeof(dsp::biquad_x1_t)));
+    if (raw == nullptr)
         return false;
-    if (mi_biquad_bank_create(&p->bank, 1, uint32_t(filters)) != MI_OK)
+    mi_biquad_bank_t *bank = nullptr;
+    if (mi_biquad_bank_create(&bank, 1, uint32_t(filters)) != MI_OK)
     {
-        delete p;
+        std::free(raw);
         return false;
     }
-    p->max_items = (filters > 0) ? filters : 1;
-    p->chains.assign(p->max_items, dsp::biquad_x1_t());
-    pImpl = p;
+    new (raw) bank_ext();
+    vData       = raw;
+    vChains     = reinterpret_cast<dsp::biquad_x1_t *>(raw + head);
+    vFilters    = reinterpret_cast<dsp::biquad_t *>(bank);
+    nItems      = 0;
+    nMaxItems   = cap;
+    nLastItems  = size_t(-1);
     return true;
 }
 
 void FilterBank::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_biquad_bank_destroy(pImpl->bank);
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (vData != nullptr)
+    {
+        bank_ext *x = reinterpret_cast<bank_ext *>(vData);
+        x->st.release();
+        x->~bank_ext();
+        std::free(vData);
+    }
+    if (vFilters != nullptr)
+        mi_biquad_bank_destroy(dev_bank(vFilters));
+    construct();
 }
-
-void FilterBank::begin()                { if (pImpl) pImpl->items = 0; }
-size_t FilterBank::max_chains() const   { return pImpl ? pImpl->max_items : 0; }
-size_t FilterBank::size() const         { return pImpl ? pImpl->items : 0; }
 
 dsp::biquad_x1_t *FilterBank::add_chain()
 {
-    if (pImpl == nullptr)
+    if (vChains == nullptr)
         return nullptr;
-    if (pImpl->items >= pImpl->max_items)
-        return (pImpl->items == 0) ? nullptr : &pImpl->chains[pImpl->items - 1];
-    return &pImpl->chains[pImpl->items++];
+    if (nItems >= nMaxItems)                            // FilterBank.cpp:94-99: the last slot again
+        return (nItems == 0) ? nullptr : &vChains[nItems - 1];
+    return &vChains[nItems++];
 }
 
 dsp::biquad_x1_t *FilterBank::chain(size_t id)
 {
-    return (pImpl != nullptr && id < pImpl->items) ? &pImpl->chains[id] : nullptr;
+    return (vChains != nullptr && id < nItems) ? &vChains[id] : nullptr;
 }
 
 void FilterBank::end(bool clear)
 {
-    if (pImpl == nullptr)
+    if (vFilters == nullptr)
         return;
     static_assert(sizeof(dsp::biquad_x1_t) == sizeof(mi_biquad_x1_t), "section layout");
-    mi_biquad_bank_set_chains(pImpl->bank, 0, reinterpret_cast<const mi_biquad_x1_t *>(pImpl->chains.data()),
-                              uint32_t(pImpl->items), clear ? 1 : 0);
+    // FilterBank.cpp:233-235: the delays are cleared on request or when the section count changed since begin()
+    const bool wipe = clear || (nItems != nLastItems);
+    last_status(mi_biquad_bank_set_chains(dev_bank(vFilters), 0, reinterpret_cast<const mi_biquad_x1_t *>(vChains),
+                                          uint32_t(nItems), wipe ? 1 : 0));
+    nLastItems = nItems;
 }
 
 void FilterBank::process(float *out, const float *in, size_t samples)
 {
     if (samples == 0)
         return;
-    if (pImpl == nullptr || !pImpl->st.reserve(samples) || !pImpl->st.up(in, samples) ||
-        mi_biquad_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, samples, samples, samples, nullptr) != MI_OK ||
-        !pImpl->st.down(out, samples))
+    bank_ext *x = reinterpret_cast<bank_ext *>(vData);
+    if (x == nullptr || !x->st.reserve(samples) || !x->st.up(in, samples) ||
+        last_status(mi_biquad_bank_process(dev_bank(vFilters), x->st.d_out, x->st.d_in, samples, samples, samples, nullptr)) != MI_OK ||
+        !x->st.down(out, samples))
     {
         if (out != in)
             std::memmove(out, in, samples * sizeof(float));
@@ -159,160 +239,178 @@ void FilterBank::impulse_response(float *out, size_t samples)
 {
     if (samples == 0)
         return;
-    if (pImpl == nullptr || !pImpl->st.reserve(samples) ||
-        mi_biquad_bank_impulse_response(pImpl->bank, pImpl->st.d_out, samples, samples, nullptr) != MI_OK ||
-        !pImpl->st.down(out, samples))
+    bank_ext *x = reinterpret_cast<bank_ext *>(vData);
+    if (x == nullptr || !x->st.reserve(samples) ||
+        last_status(mi_biquad_bank_impulse_response(dev_bank(vFilters), x->st.d_out, samples, samples, nullptr)) != MI_OK ||
+        !x->st.down(out, samples))
         std::memset(out, 0, samples * sizeof(float));
 }
 
-void FilterBank::reset()                { if (pImpl) mi_biquad_bank_reset(pImpl->bank, 0, nullptr); }
+void FilterBank::reset()                { if (vFilters) last_status(mi_biquad_bank_reset(dev_bank(vFilters), 0, nullptr)); }
 
 void FilterBank::dump(IStateDumper *v) const
 {
-    v->write("nItems", size());
-    v->write("nMaxItems", max_chains());
+    v->write("nItems", nItems);
+    v->write("nMaxItems", nMaxItems);
+    v->write("nLastItems", nLastItems);
 }
 
 // ---- Filter ------------------------------------------------------------------------------------------------------
-struct Filter::impl_t
+// Reference members (filters/Filter.h:57-65), all live.  vData holds the designer's result (cascades + sections);
+// vItems / nItems view its cascades the way the reference's own array does.
+namespace
 {
-    FilterBank         *bank = nullptr;
-    bool                own_bank = false;
-    bool                need_rebuild = true, need_clear = true;
-    filter_params_t     params;
-    size_t              sample_rate = 48000;
-    mi::design          d;
-};
+    inline mi::design *design_of(uint8_t *p) { return reinterpret_cast<mi::design *>(p); }
+}
+static_assert(sizeof(Filter) == 88, "Filter keeps the reference's layout (SURVEY.md 0.4)");
+static_assert(sizeof(dsp::f_cascade_t) == sizeof(mi::cascade), "cascade layout");
 
-Filter::Filter() : pImpl(nullptr) { construct(); }
+Filter::Filter() { construct(); }
 Filter::~Filter() { destroy(); }
-void Filter::construct() { pImpl = nullptr; }
+
+void Filter::construct()                                    // Filter.cpp:43-58
+{
+    pBank           = nullptr;
+    sParams.nType   = FLT_NONE;
+    sParams.nSlope  = 1;
+    sParams.fFreq   = 0.0f;
+    sParams.fFreq2  = 0.0f;
+    sParams.fGain   = 0.0f;
+    sParams.fQuality= 0.0f;
+    nSampleRate     = 0;
+    nMode           = FM_BYPASS;
+    nItems          = 0;
+    vItems          = nullptr;
+    vData           = nullptr;
+    nFlags          = 0;
+    nLatency        = 0;
+}
 
 bool Filter::init(FilterBank *fb)
 {
     destroy();
-    impl_t *p = new (std::nothrow) impl_t();
-    if (p == nullptr)
+    mi::design *d = new (std::nothrow) mi::design();
+    if (d == nullptr)
         return false;
+    vData = reinterpret_cast<uint8_t *>(d);
     if (fb != nullptr)
-        p->bank = fb;
+        pBank = fb;
     else
     {
-        p->bank = new (std::nothrow) FilterBank();
-        p->own_bank = true;
-        if (p->bank == nullptr || !p->bank->init(FILTER_CHAINS_MAX))
+        pBank = new (std::nothrow) FilterBank();
+        if (pBank == nullptr || !pBank->init(FILTER_CHAINS_MAX))
         {
-            delete p->bank;
-            delete p;
+            delete pBank;
+            pBank = nullptr;
+            delete d;
+            vData = nullptr;
             return false;
         }
+        nFlags |= FF_OWN_BANK;
     }
-    pImpl = p;
     filter_params_t fp = { FLT_NONE, 1, 1000.0f, 1000.0f, 1.0f, 0.0f };
-    pImpl->params = fp;
+    sParams = fp;
     update(48000, &fp);
-    pImpl->need_rebuild = pImpl->need_clear = true;
+    nFlags |= FF_REBUILD | FF_CLEAR;                        // Filter.cpp:111-112
     return true;
 }
 
 void Filter::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    if (pImpl->own_bank)
+    if ((nFlags & FF_OWN_BANK) && pBank != nullptr)
     {
-        pImpl->bank->destroy();
-        delete pImpl->bank;
+        pBank->destroy();
+        delete pBank;
     }
-    delete pImpl;
-    pImpl = nullptr;
+    delete design_of(vData);
+    construct();
 }
 
-void Filter::update(size_t sr, const filter_params_t *params)
+void Filter::update(size_t sr, const filter_params_t *params)   // Filter.cpp:141-159
 {
-    if (pImpl == nullptr)
-        return;
-    const uint32_t type = pImpl->params.nType, slope = pImpl->params.nSlope;
-    pImpl->sample_rate = sr;
-    pImpl->params = *params;
-    mi::limit_params(&pImpl->params, uint32_t(sr));
-    pImpl->need_rebuild = true;
-    if (type != pImpl->params.nType || slope != pImpl->params.nSlope)
-        pImpl->need_clear = true;
+    const uint32_t type = sParams.nType, slope = sParams.nSlope;
+    nSampleRate = sr;
+    nMode       = FM_BYPASS;                                // Filter.cpp:150: inactive until the next rebuild()
+    nLatency    = 0;
+    sParams     = *params;
+    mi::limit_params(&sParams, uint32_t(sr));
+    nFlags     |= FF_REBUILD;
+    if (type != sParams.nType || slope != sParams.nSlope)
+        nFlags |= FF_CLEAR;
 }
 
 void Filter::limit(size_t, filter_params_t *fp)
 {
-    if (pImpl != nullptr)                                   // the reference ignores its sr argument too (Filter.cpp:161-163)
-        mi::limit_params(fp, uint32_t(pImpl->sample_rate));
+    mi::limit_params(fp, uint32_t(nSampleRate));           // the reference ignores its sr argument too (Filter.cpp:161-163)
 }
 
-void Filter::set_sample_rate(size_t sr)     { if (pImpl) { filter_params_t p = pImpl->params; update(sr, &p); } }
-void Filter::get_params(filter_params_t *params) { if (pImpl && params) *params = pImpl->params; }
-void Filter::clear()                        { if (pImpl) pImpl->need_clear = true; }
-size_t Filter::latency() const              { return 0; }
-bool Filter::inactive() const               { return pImpl == nullptr || pImpl->d.mode == mi::FM_BYPASS; }
-bool Filter::active() const                 { return !inactive(); }
+void Filter::set_sample_rate(size_t sr)     { filter_params_t p = sParams; update(sr, &p); }
+void Filter::get_params(filter_params_t *params) { if (params) *params = sParams; }
 
 void Filter::rebuild()
 {
-    if (pImpl == nullptr)
+    mi::design *d = design_of(vData);
+    if (d == nullptr || pBank == nullptr)
         return;
-    if (pImpl->own_bank)
-        pImpl->bank->begin();
-    pImpl->d.cascades.reserve(mi::CHAINS_MAX + 1);
-    mi::design_filter(&pImpl->d, &pImpl->params, uint32_t(pImpl->sample_rate));
-    for (const mi_biquad_x1_t &s : pImpl->d.sections)
+    if (nFlags & FF_OWN_BANK)
+        pBank->begin();
+    d->cascades.reserve(mi::CHAINS_MAX + 1);
+    mi::design_filter(d, &sParams, uint32_t(nSampleRate));
+    nMode   = filter_mode_t(d->mode);
+    nItems  = d->cascades.size();
+    vItems  = reinterpret_cast<dsp::f_cascade_t *>(d->cascades.data());
+    for (const mi_biquad_x1_t &s : d->sections)
     {
-        dsp::biquad_x1_t *c = pImpl->bank->add_chain();
+        dsp::biquad_x1_t *c = pBank->add_chain();
         if (c == nullptr)
             break;
         std::memcpy(c, &s, sizeof(s));
     }
-    if (pImpl->own_bank)
-        pImpl->bank->end(pImpl->need_clear);
-    pImpl->need_rebuild = pImpl->need_clear = false;
+    if (nFlags & FF_OWN_BANK)
+        pBank->end((nFlags & FF_CLEAR) != 0);
+    nFlags &= ~size_t(FF_REBUILD | FF_CLEAR);
 }
 
 void Filter::process(float *out, const float *in, size_t samples)
 {
-    if (pImpl == nullptr)
+    if (vData == nullptr)
     {
         if (out != in)
             std::memmove(out, in, samples * sizeof(float));
         return;
     }
-    if (pImpl->need_rebuild || pImpl->need_clear)
+    if (nFlags & (FF_REBUILD | FF_CLEAR))
         rebuild();
-    if (pImpl->d.mode == mi::FM_BYPASS)
+    if (nMode == FM_BYPASS)
     {
         if (out != in)
             std::memmove(out, in, samples * sizeof(float));
         return;
     }
-    pImpl->bank->process(out, in, samples);
+    pBank->process(out, in, samples);
 }
 
 bool Filter::impulse_response(float *out, size_t length)
 {
-    if (pImpl == nullptr || !pImpl->own_bank)
+    if (vData == nullptr || !(nFlags & FF_OWN_BANK))
         return false;
-    if (pImpl->need_rebuild || pImpl->need_clear)
+    if (nFlags & (FF_REBUILD | FF_CLEAR))
         rebuild();
-    pImpl->bank->impulse_response(out, length);
+    pBank->impulse_response(out, length);
     return true;
 }
 
 void Filter::freq_chart(float *c, const float *f, size_t count)
 {
-    if (pImpl == nullptr)
+    mi::design *d = design_of(vData);
+    if (d == nullptr)
         return;
-    if (pImpl->need_rebuild)
+    if (nFlags & FF_REBUILD)
     {
-        pImpl->d.cascades.reserve(mi::CHAINS_MAX + 1);
-        mi::design_filter(&pImpl->d, &pImpl->params, uint32_t(pImpl->sample_rate));
+        d->cascades.reserve(mi::CHAINS_MAX + 1);
+        mi::design_filter(d, &sParams, uint32_t(nSampleRate));
     }
-    mi::freq_chart(pImpl->d, c, f, count);
+    mi::freq_chart(*d, c, f, count);
 }
 
 void Filter::freq_chart(float *re, float *im, const float *f, size_t count)
@@ -328,34 +426,50 @@ void Filter::freq_chart(float *re, float *im, const float *f, size_t count)
 
 void Filter::dump(IStateDumper *v) const
 {
-    if (pImpl == nullptr)
-        return;
-    v->write("nSampleRate", pImpl->sample_rate);
-    v->write("nMode", size_t(pImpl->d.mode));
+    v->write("nSampleRate", size_t(nSampleRate));
+    v->write("nMode", size_t(nMode));
+    v->write("nItems", nItems);
+    v->write("nFlags", nFlags);
+    v->write("nLatency", size_t(nLatency));
 }
 
 // ---- Equalizer ---------------------------------------------------------------------------------------------------
+// Reference members (filters/Equalizer.h:59-78).  The Filter objects of vFilters hold the parameters and the mode of
+// each filter; the sections themselves run in the device bank behind pData.
 struct Equalizer::impl_t
 {
     mi_equalizer_bank_t *bank = nullptr;
-    size_t  filters = 0, fir_rank = 0, sample_rate = 0;
-    bool    smooth = false, changed = true;
-    equalizer_mode_t mode = EQM_BYPASS;
-    size_t  actual_sample_rate = 0;
-    std::vector<uint8_t> stale;             // filter updated since the last reconfigure(): Filter::update() leaves it in
-                                            // FM_BYPASS until rebuild() (Filter.cpp:150), so it reads as inactive
     staging st;
-
-    void rebuilt() { std::fill(stale.begin(), stale.end(), uint8_t(0)); changed = false; }
 };
+static_assert(sizeof(Equalizer) == 160, "Equalizer keeps the reference's layout (SURVEY.md 0.4)");
 
-Equalizer::Equalizer() : pImpl(nullptr) { construct(); }
+Equalizer::Equalizer() { construct(); }
 Equalizer::~Equalizer() { destroy(); }
-void Equalizer::construct() { pImpl = nullptr; }
+
+void Equalizer::construct()                                 // Equalizer.cpp:43-65
+{
+    sBank.construct();
+    vFilters = nullptr;
+    nFilters = nSampleRate = nActualSampleRate = nFirSize = nFirRank = nLatency = nBufSize = 0;
+    nMode = EQM_BYPASS;
+    vInBuffer = vOutBuffer = vNewConv = vConv = vFft = vTemp = nullptr;
+    pData = nullptr;
+    nFlags = EF_REBUILD | EF_CLEAR;
+}
+
+// The device bank has reconfigured: every filter is rebuilt, i.e. its mode is that of its current design again
+// (Equalizer.cpp:256-259: sBank.begin(); vFilters[i].rebuild(); sBank.end()).  The embedded bank has no storage, so
+// rebuild() designs, records nMode / nItems and hands out no section.
+void Equalizer::rebuilt()
+{
+    for (uint32_t i = 0; i < nFilters; ++i)
+        vFilters[i].rebuild();
+    nFlags &= ~size_t(EF_REBUILD | EF_CLEAR);
+}
 
 bool Equalizer::init(size_t filters, size_t fir_rank)
 {
-    if (pImpl != nullptr && pImpl->filters == filters && pImpl->fir_rank == fir_rank)
+    if (impl() != nullptr && nFilters == filters && nFirRank == fir_rank)
     {
         reset();
         return true;
@@ -364,124 +478,126 @@ bool Equalizer::init(size_t filters, size_t fir_rank)
     impl_t *p = new (std::nothrow) impl_t();
     if (p == nullptr)
         return false;
-    if (mi_equalizer_bank_create(&p->bank, 1, uint32_t(filters), uint32_t(fir_rank)) != MI_OK)
+    if (last_status(mi_equalizer_bank_create(&p->bank, 1, uint32_t(filters), uint32_t(fir_rank))) != MI_OK)
     {
         delete p;
         return false;
     }
-    p->filters = filters;
-    p->fir_rank = fir_rank;
-    p->stale.assign(filters, 0);
-    pImpl = p;
+    pData = reinterpret_cast<uint8_t *>(p);
+    vFilters = new (std::nothrow) Filter[filters];
+    if (vFilters == nullptr)
+    {
+        destroy();
+        return false;
+    }
+    nFilters = uint32_t(filters);
+    nFirRank = uint32_t(fir_rank);
+    nFirSize = (fir_rank > 0) ? (1u << fir_rank) : 0;
+    for (size_t i = 0; i < filters; ++i)
+        if (!vFilters[i].init(&sBank))
+        {
+            destroy();
+            return false;
+        }
+    nFlags |= EF_REBUILD | EF_CLEAR;
+    nLatency = 0;
+    nBufSize = 0;
     return true;
 }
 
 void Equalizer::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_equalizer_bank_destroy(pImpl->bank);
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (vFilters != nullptr)
+    {
+        for (uint32_t i = 0; i < nFilters; ++i)
+            vFilters[i].destroy();
+        delete [] vFilters;
+    }
+    if (impl_t *p = impl())
+    {
+        mi_equalizer_bank_destroy(p->bank);
+        p->st.release();
+        delete p;
+    }
+    sBank.destroy();
+    const size_t smooth = nFlags & EF_SMOOTH;
+    construct();
+    nFlags |= smooth;
 }
 
-bool Equalizer::configuration_changed() const { return pImpl != nullptr && pImpl->changed; }
+bool Equalizer::configuration_changed() const { return (nFlags & EF_REBUILD) != 0; }
 
 bool Equalizer::set_params(size_t id, const filter_params_t *params)
 {
-    if (pImpl == nullptr || id >= pImpl->filters)
+    if (impl() == nullptr || id >= nFilters)
         return false;
-    pImpl->changed = true;
-    pImpl->stale[id] = 1;
-    return mi_equalizer_bank_set_params(pImpl->bank, 0, uint32_t(id), params) == MI_OK;
+    vFilters[id].update(nSampleRate, params);               // mode reads FM_BYPASS until the next reconfigure
+    nFlags |= EF_REBUILD;
+    return last_status(mi_equalizer_bank_set_params(impl()->bank, 0, uint32_t(id), params)) == MI_OK;
 }
 
 bool Equalizer::limit_params(size_t id, filter_params_t *fp)
 {
-    if (pImpl == nullptr || id >= pImpl->filters)
+    if (id >= nFilters)
         return false;
-    return mi_filter_limit(fp, uint32_t(pImpl->sample_rate)) == MI_OK;
+    vFilters[id].limit(nSampleRate, fp);
+    return true;
 }
 
 bool Equalizer::get_params(size_t id, filter_params_t *params)
 {
-    if (pImpl == nullptr || id >= pImpl->filters)
+    if (id >= nFilters)
         return false;
-    return mi_equalizer_bank_get_params(pImpl->bank, 0, uint32_t(id), params) == MI_OK;
+    vFilters[id].get_params(params);
+    return true;
 }
 
 void Equalizer::set_mode(equalizer_mode_t mode)
 {
-    if (pImpl == nullptr)
+    if (impl() == nullptr || nMode == mode)                 // Equalizer.cpp:212-218
         return;
-    pImpl->mode = mode;
-    pImpl->changed = true;
-    mi_equalizer_bank_set_mode(pImpl->bank, int(mode));
+    nMode = mode;
+    nFlags |= EF_REBUILD | EF_CLEAR;
+    mi_equalizer_bank_set_mode(impl()->bank, int(mode));
 }
 
 void Equalizer::set_actual_sample_rate(size_t sr)
 {
-    if (pImpl == nullptr)
+    if (nActualSampleRate == sr)                            // Equalizer.cpp:368-375
         return;
-    pImpl->actual_sample_rate = sr;
-    mi_equalizer_bank_set_actual_sample_rate(pImpl->bank, uint32_t(sr));
-}
-
-size_t Equalizer::actual_sample_rate() const
-{
-    return (pImpl == nullptr) ? 0 : (pImpl->actual_sample_rate != 0) ? pImpl->actual_sample_rate : pImpl->sample_rate;
-}
-
-size_t Equalizer::fir_ir_size() const { return pImpl ? (size_t(1) << pImpl->fir_rank) << 1 : 0; }      // nFirSize << 1
-
-bool Equalizer::filter_inactive(size_t id) const
-{
-    if (pImpl == nullptr || id >= pImpl->filters)
-        return false;                                       // both forms answer false for a bad id (Equalizer.h:143-150)
-    if (pImpl->stale[id])
-        return true;
-    filter_params_t fp;
-    if (mi_equalizer_bank_get_params(pImpl->bank, 0, uint32_t(id), &fp) != MI_OK)
-        return true;
-    mi::design d;
-    mi::design_filter(&d, &fp, uint32_t(pImpl->sample_rate));
-    return d.mode == mi::FM_BYPASS;
-}
-
-bool Equalizer::filter_active(size_t id) const
-{
-    return pImpl != nullptr && id < pImpl->filters && !filter_inactive(id);
+    nActualSampleRate = uint32_t(sr);
+    if (nMode == EQM_IIR || nMode == EQM_SPM)
+        nFlags |= EF_REBUILD;
+    if (impl() != nullptr)
+        mi_equalizer_bank_set_actual_sample_rate(impl()->bank, uint32_t(sr));
 }
 
 void Equalizer::set_sample_rate(size_t sr)
 {
-    if (pImpl == nullptr || pImpl->sample_rate == sr)       // Equalizer.cpp:190-191
+    if (nSampleRate == sr)                                  // Equalizer.cpp:190-191
         return;
-    pImpl->sample_rate = sr;
-    pImpl->changed = true;
-    std::fill(pImpl->stale.begin(), pImpl->stale.end(), uint8_t(1));       // every filter is update()d (:196-200)
-    mi_equalizer_bank_set_sample_rate(pImpl->bank, uint32_t(sr));
+    nSampleRate = uint32_t(sr);
+    filter_params_t fp;
+    for (uint32_t i = 0; i < nFilters; ++i)                 // every filter is update()d (:196-200)
+    {
+        vFilters[i].get_params(&fp);
+        vFilters[i].update(nSampleRate, &fp);
+    }
+    nFlags |= EF_REBUILD | EF_CLEAR;
+    if (impl() != nullptr)
+        mi_equalizer_bank_set_sample_rate(impl()->bank, uint32_t(sr));
 }
-
-equalizer_mode_t Equalizer::get_mode() const { return pImpl ? pImpl->mode : EQM_BYPASS; }
-equalizer_mode_t Equalizer::mode() const     { return get_mode(); }
 
 size_t Equalizer::get_latency()
 {
     uint32_t lat = 0;
-    if (pImpl != nullptr)
+    if (impl() != nullptr)
     {
-        mi_equalizer_bank_get_latency(pImpl->bank, &lat, nullptr);
-        pImpl->rebuilt();
+        last_status(mi_equalizer_bank_get_latency(impl()->bank, &lat, nullptr));
+        rebuilt();
     }
+    nLatency = lat;
     return lat;
-}
-
-size_t Equalizer::max_latency() const
-{
-    const size_t n = (pImpl && pImpl->fir_rank) ? (size_t(1) << pImpl->fir_rank) : 0;
-    return n + (n >> 1);
 }
 
 bool Equalizer::freq_chart(size_t id, float *c, const float *f, size_t count)
@@ -489,7 +605,20 @@ bool Equalizer::freq_chart(size_t id, float *c, const float *f, size_t count)
     filter_params_t fp;
     if (!get_params(id, &fp))
         return false;
-    return mi_filter_freq_chart(&fp, uint32_t(pImpl->sample_rate), c, f, count) == MI_OK;
+    return mi_filter_freq_chart(&fp, nSampleRate, c, f, count) == MI_OK;
+}
+
+bool Equalizer::freq_chart(size_t id, float *re, float *im, const float *f, size_t count)
+{
+    std::vector<float> c(2 * count);
+    if (!freq_chart(id, c.data(), f, count))
+        return false;
+    for (size_t i = 0; i < count; ++i)
+    {
+        re[i] = c[2 * i];
+        im[i] = c[2 * i + 1];
+    }
+    return true;
 }
 
 void Equalizer::freq_chart(float *c, const float *f, size_t count)
@@ -499,15 +628,13 @@ void Equalizer::freq_chart(float *c, const float *f, size_t count)
         c[2 * i] = 1.0f;
         c[2 * i + 1] = 0.0f;
     }
-    if (pImpl == nullptr)
-        return;
     std::vector<float> t(2 * count);
-    for (size_t id = 0; id < pImpl->filters; ++id)
+    for (size_t id = 0; id < nFilters; ++id)
     {
         filter_params_t fp;
         if (!get_params(id, &fp) || fp.nType == FLT_NONE)
             continue;
-        if (mi_filter_freq_chart(&fp, uint32_t(pImpl->sample_rate), t.data(), f, count) != MI_OK)
+        if (mi_filter_freq_chart(&fp, nSampleRate, t.data(), f, count) != MI_OK)
             continue;
         for (size_t i = 0; i < count; ++i)
         {
@@ -519,67 +646,99 @@ void Equalizer::freq_chart(float *c, const float *f, size_t count)
     }
 }
 
+void Equalizer::freq_chart(float *re, float *im, const float *f, size_t count)
+{
+    std::vector<float> c(2 * count);
+    freq_chart(c.data(), f, count);
+    for (size_t i = 0; i < count; ++i)
+    {
+        re[i] = c[2 * i];
+        im[i] = c[2 * i + 1];
+    }
+}
+
 void Equalizer::process(float *out, const float *in, size_t samples)
 {
     if (samples == 0)
         return;
-    if (pImpl == nullptr || !pImpl->st.reserve(samples) || !pImpl->st.up(in, samples) ||
-        mi_equalizer_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, samples, samples, samples, nullptr) != MI_OK ||
-        !pImpl->st.down(out, samples))
+    impl_t *p = impl();
+    if (p == nullptr || !p->st.reserve(samples) || !p->st.up(in, samples) ||
+        last_status(mi_equalizer_bank_process(p->bank, p->st.d_out, p->st.d_in, samples, samples, samples, nullptr)) != MI_OK ||
+        !p->st.down(out, samples))
     {
         if (out != in)
             std::memmove(out, in, samples * sizeof(float));
         return;
     }
-    pImpl->rebuilt();
+    if (nFlags & (EF_REBUILD | EF_CLEAR))
+    {
+        uint32_t lat = 0;
+        mi_equalizer_bank_get_latency(p->bank, &lat, nullptr);
+        nLatency = lat;
+        rebuilt();
+    }
 }
 
-void Equalizer::reset()                     { if (pImpl) mi_equalizer_bank_reset(pImpl->bank, nullptr); }
-size_t Equalizer::fir_rank() const          { return pImpl ? pImpl->fir_rank : 0; }
-bool Equalizer::smooth() const              { return pImpl && pImpl->smooth; }
+void Equalizer::reset()                     { if (impl()) mi_equalizer_bank_reset(impl()->bank, nullptr); }
+bool Equalizer::smooth() const              { return (nFlags & EF_SMOOTH) != 0; }
+
 void Equalizer::set_smooth(bool smooth)
 {
-    if (pImpl == nullptr)
-        return;
-    pImpl->smooth = smooth;
-    mi_equalizer_bank_set_smooth(pImpl->bank, smooth ? 1 : 0);
+    nFlags = smooth ? (nFlags | EF_SMOOTH) : (nFlags & ~size_t(EF_SMOOTH));
+    if (impl() != nullptr)
+        mi_equalizer_bank_set_smooth(impl()->bank, smooth ? 1 : 0);
 }
 
 size_t Equalizer::ir_size() const
 {
     uint32_t n = 0;
-    if (pImpl != nullptr)
-        mi_equalizer_bank_info(pImpl->bank, nullptr, nullptr, nullptr, &n);
+    if (impl() != nullptr)
+        mi_equalizer_bank_info(impl()->bank, nullptr, nullptr, nullptr, &n);
     return n;
 }
 
 void Equalizer::dump(IStateDumper *v) const
 {
-    if (pImpl == nullptr)
-        return;
-    v->write("nFilters", pImpl->filters);
-    v->write("nFirRank", pImpl->fir_rank);
+    v->write("nFilters", size_t(nFilters));
+    v->write("nSampleRate", size_t(nSampleRate));
+    v->write("nFirSize", size_t(nFirSize));
+    v->write("nFirRank", size_t(nFirRank));
+    v->write("nLatency", size_t(nLatency));
+    v->write("nMode", size_t(nMode));
+    v->write("nFlags", nFlags);
 }
 
 // ---- Convolver ---------------------------------------------------------------------------------------------------
+// Reference members (util/Convolver.h:38-56).  The counters describe the response as Convolver::init computes them
+// (Convolver.cpp:87-142); the device-side state hangs off vData.
 struct Convolver::impl_t
 {
     mi_convolver_bank_t *bank = nullptr;
     staging st;
 };
+static_assert(sizeof(Convolver) == 144, "Convolver keeps the reference's layout (SURVEY.md 0.4)");
 
-Convolver::Convolver() : pImpl(nullptr) { construct(); }
+Convolver::Convolver() { construct(); }
 Convolver::~Convolver() { destroy(); }
-void Convolver::construct() { pImpl = nullptr; }
+
+void Convolver::construct()
+{
+    vDataBuffer = vFrame = vConvBuffer = vTaskData = vConvData = vDirectData = nullptr;
+    nDataBufferSize = nDirectSize = nFrameSize = nFrameOff = nConvSize = 0;
+    nLevels = nBlocks = nBlocksDone = nRank = nBlkInit = 0;
+    fBlkCoef = 0.0f;
+    vData = nullptr;
+}
 
 void Convolver::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_convolver_bank_destroy(pImpl->bank);
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_convolver_bank_destroy(p->bank);
+        p->st.release();
+        delete p;
+    }
+    construct();
 }
 
 bool Convolver::init(const float *data, size_t count, size_t rank, float phase)
@@ -590,12 +749,43 @@ bool Convolver::init(const float *data, size_t count, size_t rank, float phase)
     impl_t *p = new (std::nothrow) impl_t();
     if (p == nullptr)
         return false;
-    if (mi_convolver_bank_create(&p->bank, 1, data, count, nullptr, uint32_t(count), uint32_t(rank), phase, nullptr) != MI_OK)
+    if (last_status(mi_convolver_bank_create(&p->bank, 1, data, count, nullptr, uint32_t(count), uint32_t(rank), phase, nullptr)) != MI_OK)
     {
         delete p;
         return false;
     }
-    pImpl = p;
+    vData = reinterpret_cast<uint8_t *>(p);
+    // the reference's bookkeeping for this response (Convolver.cpp:87,90-93,137-142,166-210): same numbers, no buffers
+    const size_t r          = std::min<size_t>(std::max<size_t>(rank, CONVOLVER_RANK_MIN), CONVOLVER_RANK_MAX);
+    const size_t frame      = size_t(1) << (r - 1);
+    const size_t bins       = (count + frame - 1) >> (r - 1);
+    const size_t head       = size_t(1) << (CONVOLVER_RANK_MIN - 1);
+    nRank                   = r;
+    nConvSize               = count;
+    nDataBufferSize         = (bins + 1) * frame;
+    nFrameSize              = frame;
+    nFrameOff               = size_t(phase * float(frame)) % frame;
+    nDirectSize             = std::min(count, head);
+    size_t left             = count - nDirectSize;
+    nLevels                 = 0;
+    for (size_t brank = CONVOLVER_RANK_MIN; left > 0 && brank < r; ++brank)     // raising levels
+    {
+        left               -= std::min(left, size_t(1) << (brank - 1));
+        ++nLevels;
+    }
+    nBlocks                 = (left + frame - 1) / frame;                       // constant-size blocks
+    nBlocksDone             = nBlocks;
+    const size_t steps      = frame >> (CONVOLVER_RANK_MIN - 1);
+    if (steps <= 1)
+    {
+        nBlkInit            = nBlocks;
+        fBlkCoef            = 0.0f;
+    }
+    else
+    {
+        nBlkInit            = 1;
+        fBlkCoef            = (float(nBlocks) + 1e-3f) / (float(steps) - 1.0f);
+    }
     return true;
 }
 
@@ -603,43 +793,33 @@ void Convolver::process(float *dst, const float *src, size_t count)
 {
     if (count == 0)
         return;
-    if (pImpl == nullptr || !pImpl->st.reserve(count) || !pImpl->st.up(src, count) ||
-        mi_convolver_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, count, count, count, nullptr) != MI_OK ||
-        !pImpl->st.down(dst, count))
+    impl_t *p = impl();
+    if (p == nullptr || !p->st.reserve(count) || !p->st.up(src, count) ||
+        last_status(mi_convolver_bank_process(p->bank, p->st.d_out, p->st.d_in, count, count, count, nullptr)) != MI_OK ||
+        !p->st.down(dst, count))
+    {
         std::memset(dst, 0, count * sizeof(float));
-}
-
-size_t Convolver::data_size() const
-{
-    uint32_t n = 0;
-    if (pImpl != nullptr)
-        mi_convolver_bank_info(pImpl->bank, nullptr, nullptr, nullptr, &n);
-    return n;
-}
-
-size_t Convolver::rank() const
-{
-    uint32_t r = 0;
-    if (pImpl != nullptr)
-        mi_convolver_bank_info(pImpl->bank, &r, nullptr, nullptr, nullptr);
-    return r;
+        return;
+    }
+    nFrameOff = (nFrameOff + count) & (nFrameSize - 1);     // Convolver.cpp:299-305
 }
 
 void Convolver::dump(IStateDumper *v) const
 {
-    v->write("nConvSize", data_size());
-    v->write("nRank", rank());
+    v->write("nConvSize", nConvSize);
+    v->write("nRank", nRank);
+    v->write("nFrameSize", nFrameSize);
+    v->write("nLevels", nLevels);
+    v->write("nBlocks", nBlocks);
 }
 
 // ---- SpectralProcessor ------------------------------------------------------------------------------------------
+// Reference members (util/SpectralProcessor.h:47-62): rank, phase, update flag and the binding are the members
+// themselves; the device-side state hangs off pData.
 struct SpectralProcessor::impl_t
 {
     mi_spectral_bank_t *bank = nullptr;
-    size_t  max_rank = 0, rank = 0;
-    float   phase = 0.0f;
-    bool    update = true;
-    spectral_processor_func_t func = nullptr;
-    void   *object = nullptr, *subject = nullptr;
+    SpectralProcessor  *owner = nullptr;
     std::vector<float> host_spec;
     staging st;
 
@@ -652,15 +832,28 @@ struct SpectralProcessor::impl_t
         if (mi_dspu_copy_d2h(p->host_spec.data(), spectrum, floats * sizeof(float), stream) != MI_OK ||
             mi_dspu_stream_synchronize(stream) != MI_OK)
             return;
-        p->func(p->object, p->subject, p->host_spec.data(), rank);
+        p->owner->pFunc(p->owner->pObject, p->owner->pSubject, p->host_spec.data(), rank);
         mi_dspu_copy_h2d(spectrum, p->host_spec.data(), floats * sizeof(float), stream);
         mi_dspu_stream_synchronize(stream);
     }
 };
 
-SpectralProcessor::SpectralProcessor() : pImpl(nullptr) { construct(); }
+static_assert(sizeof(SpectralProcessor) == 104, "SpectralProcessor keeps the reference's layout");
+
+SpectralProcessor::SpectralProcessor() { construct(); }
 SpectralProcessor::~SpectralProcessor() { destroy(); }
-void SpectralProcessor::construct() { pImpl = nullptr; }
+
+void SpectralProcessor::construct()                         // SpectralProcessor.cpp:33-50
+{
+    nRank = nMaxRank = 0;
+    fPhase = 0.0f;
+    pWnd = pOutBuf = pInBuf = pFftBuf = nullptr;
+    nOffset = 0;
+    pData = nullptr;
+    bUpdate = true;
+    pFunc = nullptr;
+    pObject = pSubject = nullptr;
+}
 
 bool SpectralProcessor::init(size_t max_rank)
 {
@@ -675,96 +868,103 @@ bool SpectralProcessor::init(size_t max_rank)
         delete p;
         return false;
     }
-    p->max_rank = max_rank;
-    p->rank = max_rank;
-    pImpl = p;
+    p->owner = this;
+    pData = reinterpret_cast<uint8_t *>(p);
+    nMaxRank = nRank = max_rank;
+    fPhase = 0.0f;
+    nOffset = 0;
+    bUpdate = true;
     return true;
 }
 
 void SpectralProcessor::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_spectral_bank_destroy(pImpl->bank);
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_spectral_bank_destroy(p->bank);
+        p->st.release();
+        delete p;
+    }
+    construct();
 }
 
 void SpectralProcessor::bind(spectral_processor_func_t func, void *object, void *subject)
 {
-    if (pImpl == nullptr)
+    pFunc = func;
+    pObject = object;
+    pSubject = subject;
+    if (impl() == nullptr)
         return;
-    pImpl->func = func;
-    pImpl->object = object;
-    pImpl->subject = subject;
     if (func != nullptr)
-        mi_spectral_bank_bind(pImpl->bank, &impl_t::trampoline, pImpl, nullptr);
+        mi_spectral_bank_bind(impl()->bank, &impl_t::trampoline, impl(), nullptr);
     else
-        mi_spectral_bank_unbind(pImpl->bank);
+        mi_spectral_bank_unbind(impl()->bank);
 }
 
 void SpectralProcessor::unbind()            { bind(nullptr, nullptr, nullptr); }
-bool SpectralProcessor::needs_update() const { return pImpl && pImpl->update; }
-void SpectralProcessor::update_settings()   { if (pImpl) pImpl->update = false; }
-size_t SpectralProcessor::get_rank() const  { return pImpl ? pImpl->rank : 0; }
-float SpectralProcessor::phase() const      { return pImpl ? pImpl->phase : 0.0f; }
-size_t SpectralProcessor::latency() const   { return pImpl ? (size_t(1) << pImpl->rank) : 0; }
+void SpectralProcessor::update_settings()   { bUpdate = false; }
 
 void SpectralProcessor::set_phase(float phase)
 {
-    if (pImpl == nullptr)
-        return;
-    pImpl->phase = std::min(std::max(phase, 0.0f), 1.0f);
-    pImpl->update = true;
-    mi_spectral_bank_set_phase(pImpl->bank, pImpl->phase);
+    fPhase = std::min(std::max(phase, 0.0f), 1.0f);
+    bUpdate = true;
+    if (impl() != nullptr)
+        mi_spectral_bank_set_phase(impl()->bank, fPhase);
 }
 
 void SpectralProcessor::set_rank(size_t rank)
 {
-    if (pImpl == nullptr || rank == pImpl->rank || rank > pImpl->max_rank)
+    if (rank == nRank || rank > nMaxRank)
         return;
-    pImpl->rank = rank;
-    pImpl->update = true;
-    mi_spectral_bank_set_rank(pImpl->bank, uint32_t(rank));
+    nRank = rank;
+    bUpdate = true;
+    if (impl() != nullptr)
+        mi_spectral_bank_set_rank(impl()->bank, uint32_t(rank));
 }
 
 void SpectralProcessor::process(float *dst, const float *src, size_t count)
 {
     if (count == 0)
         return;
-    if (pImpl == nullptr || !pImpl->st.reserve(count) || !pImpl->st.up(src, count) ||
-        mi_spectral_bank_process(pImpl->bank, pImpl->st.d_out, pImpl->st.d_in, count, count, count, nullptr) != MI_OK ||
-        !pImpl->st.down(dst, count))
+    impl_t *p = impl();
+    if (p == nullptr || !p->st.reserve(count) || !p->st.up(src, count) ||
+        last_status(mi_spectral_bank_process(p->bank, p->st.d_out, p->st.d_in, count, count, count, nullptr)) != MI_OK ||
+        !p->st.down(dst, count))
     {
         std::memset(dst, 0, count * sizeof(float));
         return;
     }
-    pImpl->update = false;
+    bUpdate = false;
+    nOffset = (size_t(1) << (nRank - 1)) - remaining();
 }
 
 void SpectralProcessor::process(const float *src, size_t count)
 {
-    if (count == 0 || pImpl == nullptr || !pImpl->st.reserve(count) || !pImpl->st.up(src, count))
+    impl_t *p = impl();
+    if (count == 0 || p == nullptr || !p->st.reserve(count) || !p->st.up(src, count))
         return;
-    mi_spectral_bank_process(pImpl->bank, nullptr, pImpl->st.d_in, count, count, count, nullptr);
+    last_status(mi_spectral_bank_process(p->bank, nullptr, p->st.d_in, count, count, count, nullptr));
     mi_dspu_stream_synchronize(nullptr);
-    pImpl->update = false;
+    bUpdate = false;
+    nOffset = (size_t(1) << (nRank - 1)) - remaining();
 }
 
-void SpectralProcessor::reset()             { if (pImpl) mi_spectral_bank_reset(pImpl->bank, nullptr); }
+void SpectralProcessor::reset()             { if (impl()) mi_spectral_bank_reset(impl()->bank, nullptr); nOffset = 0; }
 
 size_t SpectralProcessor::remaining() const
 {
     uint32_t r = 0;
-    if (pImpl != nullptr)
-        mi_spectral_bank_get(pImpl->bank, nullptr, nullptr, &r);
+    if (impl() != nullptr)
+        mi_spectral_bank_get(impl()->bank, nullptr, nullptr, &r);
     return r;
 }
 
 void SpectralProcessor::dump(IStateDumper *v) const
 {
-    v->write("nRank", get_rank());
+    v->write("nRank", nRank);
+    v->write("nMaxRank", nMaxRank);
+    v->write("fPhase", fPhase);
+    v->write("bUpdate", bUpdate);
 }
 
 // ---- MultiSpectralProcessor -------------------------------------------------------------------------------------
@@ -2328,19 +2528,34 @@ struct Delay::impl_t
     }
 };
 
-Delay::Delay() : pImpl(nullptr) { construct(); }
+static_assert(sizeof(Delay) == 24, "Delay keeps the reference's layout");
+
+Delay::Delay() { construct(); }
 Delay::~Delay() { destroy(); }
-void Delay::construct() { pImpl = nullptr; }
+
+void Delay::construct()                                     // Delay.cpp:42-49
+{
+    pBuffer = nullptr;
+    nHead = nTail = nDelay = nSize = 0;
+}
 
 void Delay::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_delay_bank_destroy(pImpl->bank);
-    mi_dspu_free(pImpl->d_gain);
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_delay_bank_destroy(p->bank);
+        mi_dspu_free(p->d_gain);
+        p->st.release();
+        delete p;
+    }
+    construct();
+}
+
+// nHead / nTail / nDelay / nSize as the device line has them now (the reference's own absolute positions)
+void Delay::sync_positions()
+{
+    if (impl() != nullptr)
+        mi_delay_bank_get(impl()->bank, 0, &nDelay, &nSize, &nHead, &nTail);
 }
 
 bool Delay::init(size_t max_size)
@@ -2354,28 +2569,31 @@ bool Delay::init(size_t max_size)
         delete p;
         return false;
     }
-    pImpl = p;
+    pBuffer = reinterpret_cast<float *>(p);
+    sync_positions();
     return true;
 }
 
 void Delay::append(const float *src, size_t count)
 {
-    if (pImpl && count && pImpl->st.reserve(count) && pImpl->st.up(src, count))
+    impl_t *p = impl();
+    if (p && count && p->st.reserve(count) && p->st.up(src, count))
     {
-        mi_delay_bank_append(pImpl->bank, pImpl->st.d_in, count, count, nullptr);
+        last_status(mi_delay_bank_append(p->bank, p->st.d_in, count, count, nullptr));
         mi_dspu_stream_synchronize(nullptr);
+        sync_positions();
     }
 }
 
-void Delay::process(float *dst, const float *src, size_t count)                     { if (pImpl) pImpl->run(dst, src, count, 0, MI_GAIN_NONE, 0.0f, nullptr); }
-void Delay::process(float *dst, const float *src, float gain, size_t count)         { if (pImpl) pImpl->run(dst, src, count, 0, MI_GAIN_SCALAR, gain, nullptr); }
-void Delay::process(float *dst, const float *src, const float *gain, size_t count)  { if (pImpl) pImpl->run(dst, src, count, 0, MI_GAIN_VECTOR, 0.0f, gain); }
-void Delay::process_add(float *dst, const float *src, size_t count)                 { if (pImpl) pImpl->run(dst, src, count, 1, MI_GAIN_NONE, 0.0f, nullptr); }
-void Delay::process_add(float *dst, const float *src, float gain, size_t count)     { if (pImpl) pImpl->run(dst, src, count, 1, MI_GAIN_SCALAR, gain, nullptr); }
-void Delay::process_add(float *dst, const float *src, const float *gain, size_t count) { if (pImpl) pImpl->run(dst, src, count, 1, MI_GAIN_VECTOR, 0.0f, gain); }
-void Delay::process_ramping(float *dst, const float *src, size_t delay, size_t count) { if (pImpl) pImpl->ramp(dst, src, delay, count, MI_GAIN_NONE, 0.0f, nullptr); }
-void Delay::process_ramping(float *dst, const float *src, float gain, size_t delay, size_t count) { if (pImpl) pImpl->ramp(dst, src, delay, count, MI_GAIN_SCALAR, gain, nullptr); }
-void Delay::process_ramping(float *dst, const float *src, const float *gain, size_t delay, size_t count) { if (pImpl) pImpl->ramp(dst, src, delay, count, MI_GAIN_VECTOR, 0.0f, gain); }
+void Delay::process(float *dst, const float *src, size_t count)                     { if (impl()) { impl()->run(dst, src, count, 0, MI_GAIN_NONE, 0.0f, nullptr); sync_positions(); } }
+void Delay::process(float *dst, const float *src, float gain, size_t count)         { if (impl()) { impl()->run(dst, src, count, 0, MI_GAIN_SCALAR, gain, nullptr); sync_positions(); } }
+void Delay::process(float *dst, const float *src, const float *gain, size_t count)  { if (impl()) { impl()->run(dst, src, count, 0, MI_GAIN_VECTOR, 0.0f, gain); sync_positions(); } }
+void Delay::process_add(float *dst, const float *src, size_t count)                 { if (impl()) { impl()->run(dst, src, count, 1, MI_GAIN_NONE, 0.0f, nullptr); sync_positions(); } }
+void Delay::process_add(float *dst, const float *src, float gain, size_t count)     { if (impl()) { impl()->run(dst, src, count, 1, MI_GAIN_SCALAR, gain, nullptr); sync_positions(); } }
+void Delay::process_add(float *dst, const float *src, const float *gain, size_t count) { if (impl()) { impl()->run(dst, src, count, 1, MI_GAIN_VECTOR, 0.0f, gain); sync_positions(); } }
+void Delay::process_ramping(float *dst, const float *src, size_t delay, size_t count) { if (impl()) { impl()->ramp(dst, src, delay, count, MI_GAIN_NONE, 0.0f, nullptr); sync_positions(); } }
+void Delay::process_ramping(float *dst, const float *src, float gain, size_t delay, size_t count) { if (impl()) { impl()->ramp(dst, src, delay, count, MI_GAIN_SCALAR, gain, nullptr); sync_positions(); } }
+void Delay::process_ramping(float *dst, const float *src, const float *gain, size_t delay, size_t count) { if (impl()) { impl()->ramp(dst, src, delay, count, MI_GAIN_VECTOR, 0.0f, gain); sync_positions(); } }
 
 float Delay::process(float src)
 {
@@ -2391,21 +2609,21 @@ float Delay::process(float src, float gain)
     return out;
 }
 
-void Delay::set_delay(size_t delay)         { if (pImpl) mi_delay_bank_set_delay(pImpl->bank, 0, delay); }
+void Delay::set_delay(size_t delay)         { if (impl()) { mi_delay_bank_set_delay(impl()->bank, 0, delay); sync_positions(); } }
+void Delay::clear()                         { if (impl()) { mi_delay_bank_clear(impl()->bank, nullptr); sync_positions(); } }
 
-size_t Delay::get_delay() const
+void Delay::dump(IStateDumper *v) const
 {
-    uint32_t d = 0;
-    if (pImpl != nullptr)
-        mi_delay_bank_get(pImpl->bank, 0, &d, nullptr, nullptr, nullptr);
-    return d;
+    v->write("nHead", size_t(nHead));
+    v->write("nTail", size_t(nTail));
+    v->write("nDelay", size_t(nDelay));
+    v->write("nSize", size_t(nSize));
 }
 
-size_t Delay::delay() const                 { return get_delay(); }
-void Delay::clear()                         { if (pImpl) mi_delay_bank_clear(pImpl->bank, nullptr); }
-void Delay::dump(IStateDumper *v) const     { v->write("nDelay", get_delay()); }
-
 // ---- RingBuffer --------------------------------------------------------------------------------------------------
+// Reference members (util/RingBuffer.h:38-40): pData IS the raw storage (pinned host memory the device addresses
+// through the same pointer), so there is no room for a handle in the object: the device bank that owns a storage block
+// is looked up by that block's address.
 struct RingBuffer::impl_t
 {
     mi_ring_bank_t *bank = nullptr;
@@ -2413,63 +2631,119 @@ struct RingBuffer::impl_t
     staging st;
 };
 
-RingBuffer::RingBuffer() : pImpl(nullptr) { construct(); }
+namespace
+{
+    std::mutex                                   g_ring_lock;
+    std::unordered_map<const float *, void *>    g_ring_owner;      // storage address -> RingBuffer::impl_t
+}
+static_assert(sizeof(RingBuffer) == 16, "RingBuffer keeps the reference's layout");
+
+RingBuffer::impl_t *RingBuffer::impl() const
+{
+    if (pData == nullptr)
+        return nullptr;
+    std::lock_guard<std::mutex> g(g_ring_lock);
+    auto it = g_ring_owner.find(pData);
+    return (it != g_ring_owner.end()) ? static_cast<impl_t *>(it->second) : nullptr;
+}
+
+void RingBuffer::sync_head()
+{
+    uint32_t h = 0;
+    if (impl_t *p = impl())
+        mi_ring_bank_info(p->bank, 0, nullptr, &h, nullptr);
+    nHead = h;
+}
+
+RingBuffer::RingBuffer() { construct(); }
 RingBuffer::~RingBuffer() { destroy(); }
-void RingBuffer::construct() { pImpl = nullptr; }
+
+void RingBuffer::construct()                                // RingBuffer.cpp:41-46
+{
+    pData = nullptr;
+    nCapacity = 0;
+    nHead = 0;
+}
 
 bool RingBuffer::init(size_t size, float fill)
 {
-    if (pImpl != nullptr && pImpl->capacity == size)
-    {
-        mi_ring_bank_fill(pImpl->bank, fill, nullptr);      // note: the reference keeps nHead here; fill() resets it
-        return true;
-    }
+    if (impl_t *q = impl())
+        if (q->capacity == size)
+        {
+            mi_ring_bank_fill(q->bank, fill, nullptr);      // note: the reference keeps nHead here; fill() resets it
+            mi_dspu_stream_synchronize(nullptr);
+            sync_head();
+            return true;
+        }
     destroy();
     impl_t *p = new (std::nothrow) impl_t();
     if (p == nullptr)
         return false;
-    if (mi_ring_bank_create(&p->bank, 1, size, fill) != MI_OK)
+    float *view = nullptr;
+    if (last_status(mi_ring_bank_create_shared(&p->bank, 1, size, fill, &view)) != MI_OK)
     {
         delete p;
         return false;
     }
     p->capacity = size;
-    pImpl = p;
+    {
+        std::lock_guard<std::mutex> g(g_ring_lock);
+        g_ring_owner[view] = p;
+    }
+    pData = view;
+    nCapacity = uint32_t(size);
+    nHead = 0;
     return true;
 }
 
 void RingBuffer::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_ring_bank_destroy(pImpl->bank);
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        {
+            std::lock_guard<std::mutex> g(g_ring_lock);
+            g_ring_owner.erase(pData);
+        }
+        mi_ring_bank_destroy(p->bank);
+        p->st.release();
+        delete p;
+    }
+    construct();
 }
 
 size_t RingBuffer::append(const float *data, size_t count)
 {
     size_t n = 0;
-    if (pImpl && count && pImpl->st.reserve(count) && pImpl->st.up(data, count))
+    impl_t *p = impl();
+    if (p && count && p->st.reserve(count) && p->st.up(data, count))
     {
-        mi_ring_bank_append(pImpl->bank, pImpl->st.d_in, count, count, &n, nullptr);
+        last_status(mi_ring_bank_append(p->bank, p->st.d_in, count, count, &n, nullptr));
         mi_dspu_stream_synchronize(nullptr);
+        sync_head();
     }
     return n;
 }
 
 void RingBuffer::append(float data)         { append(&data, 1); }
-void RingBuffer::clear()                    { if (pImpl) mi_ring_bank_fill(pImpl->bank, 0.0f, nullptr); }
-void RingBuffer::fill(float value)          { if (pImpl) mi_ring_bank_fill(pImpl->bank, value, nullptr); }
-size_t RingBuffer::size() const             { return pImpl ? pImpl->capacity : 0; }
+void RingBuffer::fill(float value)
+{
+    if (impl_t *p = impl())
+    {
+        mi_ring_bank_fill(p->bank, value, nullptr);
+        mi_dspu_stream_synchronize(nullptr);                // the host may look at data() right away
+        sync_head();
+    }
+}
+
+void RingBuffer::clear()                    { fill(0.0f); }
 
 size_t RingBuffer::get(float *dst, size_t offset, size_t count) const
 {
     size_t n = 0;
-    if (pImpl == nullptr || count == 0 || !pImpl->st.reserve(count))
+    impl_t *p = impl();
+    if (p == nullptr || count == 0 || !p->st.reserve(count))
         return 0;
-    if (mi_ring_bank_get(pImpl->bank, pImpl->st.d_out, offset, count, count, &n, nullptr) != MI_OK || !pImpl->st.down(dst, count))
+    if (last_status(mi_ring_bank_get(p->bank, p->st.d_out, offset, count, count, &n, nullptr)) != MI_OK || !p->st.down(dst, count))
         return 0;
     return n;
 }
@@ -2523,23 +2797,19 @@ size_t RingBuffer::read(float *dst, size_t position, size_t count) const
     return count;
 }
 
-size_t RingBuffer::head_position() const
-{
-    uint32_t h = 0;
-    if (pImpl != nullptr)
-        mi_ring_bank_info(pImpl->bank, 0, nullptr, &h, nullptr);
-    return h;
-}
-
 size_t RingBuffer::tail_position(size_t offset) const
 {
     uint32_t t = 0;
-    if (pImpl != nullptr)
-        mi_ring_bank_info(pImpl->bank, offset, nullptr, nullptr, &t);
+    if (impl_t *p = impl())
+        mi_ring_bank_info(p->bank, offset, nullptr, nullptr, &t);
     return t;
 }
 
-void RingBuffer::dump(IStateDumper *v) const { v->write("nCapacity", size()); }
+void RingBuffer::dump(IStateDumper *v) const
+{
+    v->write("nCapacity", size_t(nCapacity));
+    v->write("nHead", size_t(nHead));
+}
 
 // ---- Analyzer ----------------------------------------------------------------------------------------------------
 struct Analyzer::impl_t

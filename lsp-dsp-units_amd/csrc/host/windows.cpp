@@ -60,29 +60,63 @@ namespace
     }
 } // namespace
 
-void make_window(float *dst, size_t n, int type)
+// Parameters of the window families (the reference's *_general forms, misc/windows.h:71-155); the named windows
+// are these with the reference's constants (windows.cpp:91-99,152-160,179-181,199-213,232-234,300-302,315-317,
+// 332-334,351-353,398-400).  Returns how many parameters the family takes, 0 for the parameter-free windows.
+int window_defaults(int type, size_t n, float *q)
 {
     switch (type)
     {
-        case MI_WINDOW_HANN:            { const float a[] = { 0.5f, 0.5f };   cosine_sum(dst, n, a, 2); break; }
-        case MI_WINDOW_HAMMING:         { const float a[] = { 0.54f, 0.46f }; cosine_sum(dst, n, a, 2); break; }
+        case MI_WINDOW_HANN:             q[0] = 0.5f;  q[1] = 0.5f;  return 2;
+        case MI_WINDOW_HAMMING:          q[0] = 0.54f; q[1] = 0.46f; return 2;
+        case MI_WINDOW_BLACKMAN:         q[0] = 0.16f; return 1;
+        case MI_WINDOW_NUTTALL:          q[0] = 0.355768f;  q[1] = 0.487396f;  q[2] = 0.144232f;  q[3] = 0.012604f;  return 4;
+        case MI_WINDOW_BLACKMAN_NUTTALL: q[0] = 0.3635819f; q[1] = 0.4891775f; q[2] = 0.1365995f; q[3] = 0.0106411f; return 4;
+        case MI_WINDOW_BLACKMAN_HARRIS:  q[0] = 0.35875f;   q[1] = 0.48829f;   q[2] = 0.14128f;   q[3] = 0.01168f;   return 4;
+        case MI_WINDOW_FLAT_TOP:         q[0] = 1.0f; q[1] = 1.93f; q[2] = 1.29f; q[3] = 0.388f; q[4] = 0.028f; return 5;
+        case MI_WINDOW_TRIANGULAR:       q[0] = 0.0f;  return 1;
+        case MI_WINDOW_BARTLETT_FEJER:   q[0] = -1.0f; return 1;
+        case MI_WINDOW_GAUSSIAN:         q[0] = 0.4f;  return 1;
+        case MI_WINDOW_POISSON:          q[0] = n * 0.5f; return 1;
+        case MI_WINDOW_BARTLETT_HANN:    q[0] = 0.62f; q[1] = 0.48f; q[2] = 0.38f; return 3;
+        case MI_WINDOW_HANN_POISSON:     q[0] = 2.0f;  return 1;
+        case MI_WINDOW_TUKEY:            q[0] = 0.5f;  return 1;
+        default:                         return 0;
+    }
+}
+
+void make_window_params(float *dst, size_t n, int type, const float *q);
+
+void make_window(float *dst, size_t n, int type)
+{
+    float q[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    window_defaults(type, n, q);
+    make_window_params(dst, n, type, q);
+}
+
+void make_window_params(float *dst, size_t n, int type, const float *q)
+{
+    switch (type)
+    {
+        case MI_WINDOW_HANN:
+        case MI_WINDOW_HAMMING:         { const float a[] = { q[0], q[1] }; cosine_sum(dst, n, a, 2); break; }
         case MI_WINDOW_BLACKMAN:
         {
-            const float alpha = 0.16f, a2 = alpha * 0.5f;
+            const float alpha = q[0], a2 = alpha * 0.5f;
             const float a[] = { 0.5f - a2, 0.5f, a2 };
             cosine_sum(dst, n, a, 3);
             break;
         }
-        case MI_WINDOW_NUTTALL:          { const float a[] = { 0.355768f, 0.487396f, 0.144232f, 0.012604f };   cosine_sum(dst, n, a, 4); break; }
-        case MI_WINDOW_BLACKMAN_NUTTALL: { const float a[] = { 0.3635819f, 0.4891775f, 0.1365995f, 0.0106411f }; cosine_sum(dst, n, a, 4); break; }
-        case MI_WINDOW_BLACKMAN_HARRIS:  { const float a[] = { 0.35875f, 0.48829f, 0.14128f, 0.01168f };       cosine_sum(dst, n, a, 4); break; }
-        case MI_WINDOW_FLAT_TOP:         { const float a[] = { 1.0f, 1.93f, 1.29f, 0.388f, 0.028f };           cosine_sum(dst, n, a, 5); break; }
+        case MI_WINDOW_NUTTALL:
+        case MI_WINDOW_BLACKMAN_NUTTALL:
+        case MI_WINDOW_BLACKMAN_HARRIS:  cosine_sum(dst, n, q, 4); break;
+        case MI_WINDOW_FLAT_TOP:         cosine_sum(dst, n, q, 5); break;
         case MI_WINDOW_RECTANGULAR:
             for (size_t i = 0; i < n; ++i)
                 dst[i] = 1.0f;
             break;
-        case MI_WINDOW_TRIANGULAR:      triangle(dst, n, 0); break;
-        case MI_WINDOW_BARTLETT_FEJER:  triangle(dst, n, -1); break;
+        case MI_WINDOW_TRIANGULAR:
+        case MI_WINDOW_BARTLETT_FEJER:  triangle(dst, n, int(q[0])); break;
         case MI_WINDOW_PARZEN:                              // windows.cpp:139-...: piecewise cubic
         {
             if (n == 0)
@@ -151,7 +185,7 @@ void make_window(float *dst, size_t n, int type)
         }
         case MI_WINDOW_GAUSSIAN:
         {
-            const float s = 0.4;
+            const float s = q[0];
             if (n == 0 || s > 0.5)
                 break;
             const float c = (n - 1) * 0.5f, sc = 1.0f / (c * s);
@@ -165,7 +199,7 @@ void make_window(float *dst, size_t n, int type)
         case MI_WINDOW_POISSON:
         {
             const float c = (n - 1) * 0.5f;
-            const float t = -1.0f / (n * 0.5f);
+            const float t = -1.0f / q[0];
             for (size_t i = 0; i < n; ++i)
                 dst[i] = expf(t * fabs(i - c));
             break;
@@ -174,7 +208,7 @@ void make_window(float *dst, size_t n, int type)
         {
             if (n == 0)
                 break;
-            const float a0 = 0.62f, a1 = 0.48f, a2 = 0.38f;
+            const float a0 = q[0], a1 = q[1], a2 = q[2];
             const float k1 = 1.0f / (n - 1), k2 = 2.0f * M_PI * k1;
             for (size_t i = 0; i < n; ++i)
                 dst[i] = a0 - a1 * fabs(i * k1 - 0.5f) - a2 * cosf(i * k2);
@@ -184,7 +218,7 @@ void make_window(float *dst, size_t n, int type)
         {
             if (n == 0)
                 break;
-            const float a = 2.0f;
+            const float a = q[0];
             const float f = 2.0f * M_PI / (n - 1);
             const float k1 = (n - 1) * 0.5, k2 = -a / k1;
             for (size_t i = 0; i < n; ++i)
@@ -207,7 +241,13 @@ void make_window(float *dst, size_t n, int type)
         {
             if (n == 0)
                 break;
-            const float a = 0.5f;
+            const float a = q[0];
+            if (a == 0.0f)                                  // windows.cpp:375-379
+            {
+                for (size_t i = 0; i < n; ++i)
+                    dst[i] = 1.0f;
+                break;
+            }
             const size_t last = n - 1;
             const size_t b1 = 0.5 * a * last, b2 = last - b1;
             const float k = M_PI * 2.0f / (a * last);
@@ -294,6 +334,20 @@ int mi_window(float *dst, size_t n, int type)
     MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_window: NULL destination");
     MI_REQUIRE(type >= 0 && type < MI_WINDOW_TOTAL, MI_EINVAL, "mi_window: unknown window %d", type);
     mi::make_window(dst, n, type);
+    return MI_OK;
+}
+
+int mi_window_general(float *dst, size_t n, int type, const float *params, uint32_t count)
+{
+    MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_window_general: NULL destination");
+    MI_REQUIRE(type >= 0 && type < MI_WINDOW_TOTAL, MI_EINVAL, "mi_window_general: unknown window %d", type);
+    float q[5] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+    const int want = mi::window_defaults(type, n, q);
+    MI_REQUIRE(want > 0, MI_EINVAL, "mi_window_general: window %d has no parameters", type);
+    MI_REQUIRE(params != nullptr && int(count) == want, MI_EINVAL, "mi_window_general: window %d takes %d parameters", type, want);
+    for (int i = 0; i < want; ++i)
+        q[i] = params[i];
+    mi::make_window_params(dst, n, type, q);
     return MI_OK;
 }
 

@@ -31,6 +31,20 @@ namespace lsp
             MI_WND(rectangular, RECTANGULAR) MI_WND(flat_top, FLAT_TOP) MI_WND(cosine, COSINE)
             MI_WND(sqr_cosine, SQR_COSINE) MI_WND(cubic, CUBIC)
             #undef MI_WND
+
+            // the parameterised families (misc/windows.h:71,86,95,101,113,128,134,143,146,155 of the reference)
+            LSP_DSP_UNITS_PUBLIC void triangular_general(float *dst, size_t n, int dn);
+            LSP_DSP_UNITS_PUBLIC void hamming_general(float *dst, size_t n, float a, float b);
+            LSP_DSP_UNITS_PUBLIC void blackman_general(float *dst, size_t n, float a);
+            LSP_DSP_UNITS_PUBLIC void nuttall_general(float *dst, size_t n, float a0, float a1, float a2, float a3);
+            // (the reference's header spells this one nutall_general, its source nuttall_general: both are provided)
+            LSP_DSP_UNITS_PUBLIC void nutall_general(float *dst, size_t n, float a0, float a1, float a2, float a3);
+            LSP_DSP_UNITS_PUBLIC void flat_top_general(float *dst, size_t n, float a0, float a1, float a2, float a3, float a4);
+            LSP_DSP_UNITS_PUBLIC void gaussian_general(float *dst, size_t n, float s);
+            LSP_DSP_UNITS_PUBLIC void poisson_general(float *dst, size_t n, float t);
+            LSP_DSP_UNITS_PUBLIC void bartlett_hann_general(float *dst, size_t n, float a0, float a1, float a2);
+            LSP_DSP_UNITS_PUBLIC void hann_poisson_general(float *dst, size_t n, float a);
+            LSP_DSP_UNITS_PUBLIC void tukey_general(float *dst, size_t n, float a);
         }
     }
 }

@@ -26,6 +26,26 @@ namespace lsp
             float p0, p1, p2;
         };
 
+        // lsp-dsp-lib's packed banks, kept for layout only (FilterBank holds a pointer of this type; field use as in
+        // src/main/filters/FilterBank.cpp:112-230 of the reference): 16 delay values, then the coefficients of one
+        // x1 / x2 / x4 / x8 group, 256 bytes, 64-byte aligned.  Nothing in this library computes with it.
+        struct biquad_x2_t { float b0[2], b1[2], b2[2], a1[2], a2[2], p[2]; };
+        struct biquad_x4_t { float b0[4], b1[4], b2[4], a1[4], a2[4]; };
+        struct biquad_x8_t { float b0[8], b1[8], b2[8], a1[8], a2[8]; };
+        struct alignas(64) biquad_t
+        {
+            float d[16];
+            union
+            {
+                biquad_x1_t x1;
+                biquad_x2_t x2;
+                biquad_x4_t x4;
+                biquad_x8_t x8;
+            };
+            float __pad[8];
+        };
+        static_assert(sizeof(biquad_x1_t) == 32 && sizeof(biquad_x8_t) == 160 && sizeof(biquad_t) == 256, "lsp-dsp-lib layouts");
+
         // numerator t[] / denominator b[] of an analog second-order cascade
         struct f_cascade_t
         {

@@ -217,6 +217,14 @@ def make_window(n, wtype):
     return out
 
 
+def make_window_general(n, wtype, params):
+    """windows::*_general (misc/windows.h:71-155): the window family `wtype` with its parameter list."""
+    out = np.empty(n, np.float32)
+    q = np.ascontiguousarray(params, dtype=np.float32)
+    check(lib.mi_window_general(out.ctypes.data_as(c_void_p), n, int(wtype), q.ctypes.data_as(c_void_p), q.size))
+    return out
+
+
 class SpectralBank:
     """`channels` x lsp::dspu::SpectralProcessor (one MultiSpectralProcessor) on the device."""
     OP_NONE, OP_MASK, OP_CALLBACK = 0, 1, 2

@@ -545,11 +545,192 @@ static void readme_filter()
     CHECK(y[479] == 0.0f && y[480] == c[0] && y[1999] == c[1519], "delay");
 }
 
+// ---- binary layout of the drop-in classes ---------------------------------------------------------------------------
+// Object sizes and member offsets of the reference headers (lsp-dsp-units 1.0.36, LP64; sizes of SURVEY.md 0.4 plus the
+// member lists of filters/FilterBank.h:39-46, filters/Filter.h:57-65, filters/Equalizer.h:59-78, util/Convolver.h:38-56,
+// util/Delay.h:38-42, util/RingBuffer.h:38-40, util/SpectralProcessor.h:47-62): a caller compiled against the
+// reference's headers embeds these objects by value and runs the reference's inline members on them.
+#pragma GCC diagnostic push
+#pragma GCC diagnostic ignored "-Winvalid-offsetof"
+namespace layout
+{
+    struct FilterBankP : dspu::FilterBank { static void check(); };
+    struct FilterP : dspu::Filter { static void check(); };
+    struct EqualizerP : dspu::Equalizer { static void check(); };
+    struct DelayP : dspu::Delay { static void check(); };
+    struct RingBufferP : dspu::RingBuffer { static void check(); };
+    struct SpectralProcessorP : dspu::SpectralProcessor { static void check(); };
+
+    static_assert(sizeof(dspu::FilterBank) == 56 && sizeof(dspu::Filter) == 88 && sizeof(dspu::Equalizer) == 160 &&
+                  sizeof(dspu::Convolver) == 144, "object sizes of SURVEY.md 0.4");
+    static_assert(sizeof(dspu::Delay) == 24 && sizeof(dspu::RingBuffer) == 16 && sizeof(dspu::SpectralProcessor) == 104,
+                  "object sizes of the reference headers");
+    static_assert(sizeof(dspu::filter_params_t) == 24 && sizeof(dsp::biquad_x1_t) == 32 && sizeof(dsp::f_cascade_t) == 32 &&
+                  sizeof(dsp::biquad_t) == 256, "plain structs of the API");
+
+    void FilterBankP::check()
+    {
+        static_assert(offsetof(FilterBankP, vFilters) == 0 && offsetof(FilterBankP, vChains) == 8 && offsetof(FilterBankP, nItems) == 16 &&
+                      offsetof(FilterBankP, nMaxItems) == 24 && offsetof(FilterBankP, nLastItems) == 32 &&
+                      offsetof(FilterBankP, vBackup) == 40 && offsetof(FilterBankP, vData) == 48, "FilterBank members");
+    }
+    void FilterP::check()
+    {
+        static_assert(offsetof(FilterP, pBank) == 0 && offsetof(FilterP, sParams) == 8 && offsetof(FilterP, nSampleRate) == 32 &&
+                      offsetof(FilterP, nMode) == 40 && offsetof(FilterP, nItems) == 48 && offsetof(FilterP, vItems) == 56 &&
+                      offsetof(FilterP, vData) == 64 && offsetof(FilterP, nFlags) == 72 && offsetof(FilterP, nLatency) == 80, "Filter members");
+    }
+    void EqualizerP::check()
+    {
+        static_assert(offsetof(EqualizerP, sBank) == 0 && offsetof(EqualizerP, vFilters) == 56 && offsetof(EqualizerP, nFilters) == 64 &&
+                      offsetof(EqualizerP, nSampleRate) == 68 && offsetof(EqualizerP, nActualSampleRate) == 72 &&
+                      offsetof(EqualizerP, nFirSize) == 76 && offsetof(EqualizerP, nFirRank) == 80 && offsetof(EqualizerP, nLatency) == 84 &&
+                      offsetof(EqualizerP, nBufSize) == 88 && offsetof(EqualizerP, nMode) == 92 && offsetof(EqualizerP, vInBuffer) == 96 &&
+                      offsetof(EqualizerP, vTemp) == 136 && offsetof(EqualizerP, nFlags) == 144 && offsetof(EqualizerP, pData) == 152,
+                      "Equalizer members");
+    }
+    void DelayP::check()
+    {
+        static_assert(offsetof(DelayP, pBuffer) == 0 && offsetof(DelayP, nHead) == 8 && offsetof(DelayP, nTail) == 12 &&
+                      offsetof(DelayP, nDelay) == 16 && offsetof(DelayP, nSize) == 20, "Delay members");
+    }
+    void RingBufferP::check()
+    {
+        static_assert(offsetof(RingBufferP, pData) == 0 && offsetof(RingBufferP, nCapacity) == 8 && offsetof(RingBufferP, nHead) == 12,
+                      "RingBuffer members");
+    }
+    void SpectralProcessorP::check()
+    {
+        static_assert(offsetof(SpectralProcessorP, nRank) == 0 && offsetof(SpectralProcessorP, nMaxRank) == 8 &&
+                      offsetof(SpectralProcessorP, fPhase) == 16 && offsetof(SpectralProcessorP, pWnd) == 24 &&
+                      offsetof(SpectralProcessorP, nOffset) == 56 && offsetof(SpectralProcessorP, pData) == 64 &&
+                      offsetof(SpectralProcessorP, bUpdate) == 72 && offsetof(SpectralProcessorP, pFunc) == 80 &&
+                      offsetof(SpectralProcessorP, pSubject) == 96, "SpectralProcessor members");
+    }
+}
+#pragma GCC diagnostic pop
+
+template <class T> static T *raw_object()                   // zeroed raw memory, as a host that embeds the object would hold it
+{
+    void *p = calloc(1, sizeof(T));
+    return static_cast<T *>(p);
+}
+
+// construct() on calloc()ed memory (no constructor has run), the object used through the reference's inline members,
+// destroy(), memory released with free(): what `construct()` is there for (filters/Filter.h:97-100).
+static void raw_memory_objects()
+{
+    printf("construct() on raw memory + inline members\n");
+    dspu::clear_last_status();
+
+    dspu::FilterBank *fb = raw_object<dspu::FilterBank>();
+    fb->construct();
+    CHECK(fb->size() == 0 && fb->max_chains() == 0, "constructed bank is empty");
+    CHECK(fb->init(4), "bank init");
+    fb->begin();
+    dsp::biquad_x1_t *c = fb->add_chain();
+    CHECK(c != NULL && fb->size() == 1 && fb->max_chains() == 4, "add_chain / size / max_chains");
+    c->b0 = 0.5f; c->b1 = 0.0f; c->b2 = 0.0f; c->a1 = 0.0f; c->a2 = 0.0f; c->p0 = c->p1 = c->p2 = 0.0f;
+    fb->end(true);
+    float x[8] = { 1, 2, 3, 4, 5, 6, 7, 8 }, y[8];
+    fb->process(y, x, 8);
+    CHECK(y[0] == 0.5f && y[7] == 4.0f, "one-section bank scales by b0");
+    fb->begin();
+    CHECK(fb->size() == 0, "begin() forgets the chains");
+    fb->destroy();
+    free(fb);
+
+    dspu::Filter *f = raw_object<dspu::Filter>();
+    f->construct();
+    CHECK(f->inactive() && f->latency() == 0, "constructed filter is inactive");
+    CHECK(f->init(NULL), "filter init");
+    dspu::filter_params_t fp;
+    fp.nType = dspu::FLT_BT_RLC_BELL; fp.fFreq = 1000.0f; fp.fFreq2 = 1000.0f; fp.fGain = 2.0f; fp.nSlope = 1; fp.fQuality = 1.0f;
+    f->update(48000, &fp);
+    CHECK(f->inactive(), "update() parks the filter in FM_BYPASS (Filter.cpp:150)");
+    f->rebuild();
+    CHECK(f->active() && !f->inactive(), "active after rebuild");
+    f->clear();                                             // inline: nFlags |= FF_CLEAR, picked up by the next process()
+    std::vector<float> ir(64, 0.0f);
+    ir[0] = 1.0f;
+    f->process(ir.data(), ir.data(), ir.size());
+    CHECK(ir[0] > 1.0f && ir[0] < 2.0f, "bell +6 dB impulse head %g", ir[0]);
+    f->destroy();
+    free(f);
+
+    dspu::Delay *d = raw_object<dspu::Delay>();
+    d->construct();
+    CHECK(d->get_delay() == 0, "constructed delay");
+    CHECK(d->init(100), "delay init");
+    d->set_delay(7);
+    CHECK(d->get_delay() == 7 && d->delay() == 7, "inline get_delay()");
+    float z[16];
+    d->process(z, x, 8);
+    d->process(&z[8], x, 8);
+    CHECK(z[6] == 0.0f && z[7] == 1.0f && z[14] == 8.0f && z[15] == 1.0f, "delayed by 7");
+    d->destroy();
+    free(d);
+
+    dspu::RingBuffer *rb = raw_object<dspu::RingBuffer>();
+    rb->construct();
+    CHECK(rb->size() == 0 && rb->data() == NULL, "constructed ring");
+    CHECK(rb->init(8, 0.25f), "ring init");
+    CHECK(rb->size() == 8 && rb->data() != NULL && rb->data()[0] == 0.25f && rb->data()[7] == 0.25f, "data() shows the fill value");
+    rb->append(x, 3);
+    CHECK(rb->head_position() == 3 && rb->data()[0] == 1.0f && rb->data()[2] == 3.0f && rb->data()[3] == 0.25f, "data() shows appended samples");
+    rb->data()[2] = 9.0f;                                   // a host write into the raw storage is what get() returns
+    CHECK(rb->get(0) == 9.0f && rb->get(1) == 2.0f, "host write through data()");
+    rb->destroy();
+    free(rb);
+
+    dspu::Convolver *cv = raw_object<dspu::Convolver>();
+    cv->construct();
+    CHECK(cv->data_size() == 0 && cv->rank() == 0, "constructed convolver");
+    std::vector<float> taps(300, 0.0f);
+    taps[0] = 1.0f; taps[299] = 0.5f;
+    CHECK(cv->init(taps.data(), taps.size(), 9, 0.0f), "convolver init");
+    CHECK(cv->data_size() == 300 && cv->rank() == 9, "inline data_size() / rank()");
+    std::vector<float> in(600, 0.0f), out(600, 0.0f);
+    in[0] = 1.0f;
+    cv->process(out.data(), in.data(), 600);
+    CHECK(fabsf(out[0] - 1.0f) < 1e-5f && fabsf(out[299] - 0.5f) < 1e-5f && fabsf(out[300]) < 1e-5f, "convolver output");
+    cv->destroy();
+    free(cv);
+
+    dspu::SpectralProcessor *sp = raw_object<dspu::SpectralProcessor>();
+    sp->construct();
+    CHECK(sp->needs_update() && sp->get_rank() == 0, "constructed spectral processor");
+    CHECK(sp->init(8), "spectral init");
+    CHECK(sp->get_rank() == 8 && sp->latency() == 256 && sp->phase() == 0.0f, "inline rank / latency / phase");
+    sp->set_rank(7);
+    sp->set_phase(0.5f);
+    CHECK(sp->get_rank() == 7 && sp->latency() == 128 && sp->phase() == 0.5f && sp->needs_update(), "setters reach the inline getters");
+    sp->update_settings();
+    CHECK(!sp->needs_update(), "update_settings()");
+    sp->destroy();
+    free(sp);
+
+    dspu::Equalizer *eq = raw_object<dspu::Equalizer>();
+    eq->construct();
+    CHECK(eq->get_mode() == dspu::EQM_BYPASS && eq->fir_rank() == 0 && !eq->filter_active(0), "constructed equalizer");
+    CHECK(eq->init(3, 9), "equalizer init");
+    eq->set_sample_rate(44100);
+    CHECK(eq->fir_rank() == 9 && eq->fir_ir_size() == 1024 && eq->max_latency() == 768 && eq->actual_sample_rate() == 44100, "inline sizes");
+    eq->set_params(1, &fp);
+    eq->set_mode(dspu::EQM_FIR);
+    CHECK(eq->mode() == dspu::EQM_FIR && eq->filter_inactive(1), "mode / stale filter");
+    CHECK(eq->get_latency() == 768 && eq->filter_active(1) && eq->filter_inactive(0), "latency 1.5 N and filter modes after reconfigure");
+    eq->destroy();
+    free(eq);
+
+    CHECK(dspu::last_status() == MI_OK, "a device call failed on the way: %d (%s)", dspu::last_status(), mi_dspu_last_error());
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -573,6 +754,8 @@ int main(int argc, char **argv)
     ringbuffer();
     accessors();
     readme_filter();
+    raw_memory_objects();
+    CHECK(dspu::last_status() == MI_OK, "device status after the whole replay: %d (%s)", dspu::last_status(), mi_dspu_last_error());
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
 }

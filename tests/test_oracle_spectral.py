@@ -64,3 +64,34 @@ def test_all_window_types_are_finite_and_bounded(mi):
     for t in range(21):
         w = mi.make_window(512, t)
         assert np.all(np.isfinite(w)) and w.max() <= 1.0 + 1e-5 and w.min() >= -0.1, t
+
+
+def test_general_window_families(mi):
+    """windows::*_general (misc/windows.h:71-155): with the reference's constants each family reproduces its named window
+    bit for bit (windows.cpp:91-99,152-160,179-181,199-213,232-234,300-302,315-317,332-334,351-353,398-400); with other
+    parameters the closed forms of windows.cpp:70-89,141-150,164-177,185-197,217-230,286-298,306-313,321-330,338-349,
+    371-396 hold; wrong parameter counts and parameter-free windows are refused."""
+    n = 257
+    # windows::window_t (misc/windows.h:36-62)
+    ids = {k: i for i, k in enumerate(["hann", "hamming", "blackman", "lanczos", "gaussian", "poisson", "parzen", "tukey", "welch",
+                                       "nuttall", "blackman_nuttall", "blackman_harris", "hann_poisson", "bartlett_hann",
+                                       "bartlett_fejer", "triangular", "rectangular", "flat_top", "cosine", "sqr_cosine", "cubic"])}
+    assert all(ids[k] == v for k, v in sp.WINDOW_IDS.items())
+    named = {"hann": [0.5, 0.5], "hamming": [0.54, 0.46], "blackman": [0.16],
+             "nuttall": [0.355768, 0.487396, 0.144232, 0.012604], "blackman_nuttall": [0.3635819, 0.4891775, 0.1365995, 0.0106411],
+             "blackman_harris": [0.35875, 0.48829, 0.14128, 0.01168], "flat_top": [1.0, 1.93, 1.29, 0.388, 0.028],
+             "triangular": [0], "bartlett_fejer": [-1], "gaussian": [0.4], "poisson": [n * 0.5],
+             "bartlett_hann": [0.62, 0.48, 0.38], "hann_poisson": [2.0], "tukey": [0.5]}
+    for name, q in named.items():
+        np.testing.assert_array_equal(mi.make_window_general(n, ids[name], q), mi.make_window(n, ids[name]), err_msg=name)
+    i = np.arange(n, dtype=np.float64)
+    c = (n - 1) * 0.5
+    np.testing.assert_allclose(mi.make_window_general(n, ids["hamming"], [0.6, 0.4]), 0.6 - 0.4 * np.cos(2 * np.pi * i / (n - 1)), atol=2e-6)
+    np.testing.assert_allclose(mi.make_window_general(n, ids["gaussian"], [0.25]), np.exp(-0.5 * ((i - c) / (c * 0.25)) ** 2), atol=2e-6)
+    np.testing.assert_allclose(mi.make_window_general(n, ids["poisson"], [40.0]), np.exp(-np.abs(i - c) / 40.0), atol=2e-6)
+    np.testing.assert_allclose(mi.make_window_general(n, ids["triangular"], [1]), 1.0 - np.abs((i - c) * 2.0 / (n + 1)), atol=2e-6)
+    np.testing.assert_array_equal(mi.make_window_general(n, ids["tukey"], [0.0]), np.ones(n, np.float32))      # a == 0: rectangular
+    assert np.all(mi.make_window_general(n, ids["gaussian"], [0.4]) == mi.make_window(n, ids["gaussian"]))
+    for bad in (("hann", [0.5]), ("cosine", [1.0]), ("tukey", [0.5, 0.5])):
+        with pytest.raises(mi.MiError):
+            mi.make_window_general(n, ids[bad[0]], bad[1])

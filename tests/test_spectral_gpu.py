@@ -541,7 +541,7 @@ def test_bin_reduction_composes_across_channel_shards(gpu, channels, cut):
     of 16 channels, then a binary tree aligned to powers of two: `cut` is a node of that tree).  This is the property the
     multi-GPU per-bin all-reduce rests on; the spectra themselves do not depend on the bank a channel sits in.
     (`cut` = the largest power-of-two multiple of 16 below the channel count: the root of the tree.)"""
-    rank, hop = 10, 512
+    rank, hop = 10, 2048                                    # (the refresh period must cover one sample per channel)
     bins = (1 << (rank - 1)) + 1
     rng = np.random.default_rng(21)
     x = (rng.standard_normal((channels, 3 * hop)) * 0.25).astype(np.float32)
