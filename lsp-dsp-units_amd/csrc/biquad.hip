@@ -113,11 +113,33 @@ namespace
 #else
     #define MI_PROBE(slot) do { } while (0)
 #endif
-    template <int L, int NW, bool ALIGNED>
-    __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
-    void biquad_bank_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
-                            int n /* multiple of L */, const float *__restrict__ tab, float *state,
-                            const uint32_t *__restrict__ nsec, int max_sec)
+    // A chain of cascades on one block held in registers (library-internal: the Crossover's split points, and any
+    // caller of several banks on the same samples): stage k runs bank k's sections either IN PLACE on the travelling
+    // signal or on a BRANCH of it (the travelling signal goes on unchanged), and writes its result to `out` if there is
+    // one.  Crossover.cpp:451-498 is  band k = LPF_k(src) [branch],  src = HPF_k(src) [in place]  per split point: one
+    // read of the source and one write per band instead of a read and a write per filter.
+    constexpr int CHAIN_MAX = 14;
+    struct chain_stage
+    {
+        const float    *tab;            // the bank's table of this launch variant
+        float          *state;
+        const uint32_t *nsec;
+        float          *out;            // NULL: nothing is written (an in-place stage in the middle of the chain)
+        size_t          out_stride;
+        int             max_sec;
+        int             branch;
+    };
+    struct chain_args
+    {
+        int         stages;
+        chain_stage st[CHAIN_MAX];
+    };
+
+    template <int L, int NW, bool ALIGNED, bool CHAIN>
+    __device__ __forceinline__
+    void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
+                     int n /* multiple of L */, const float *__restrict__ tab, float *state,
+                     const uint32_t *__restrict__ nsec, int max_sec, const chain_args &chain)
     {
         using G = geom<L>;
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
@@ -134,12 +156,19 @@ namespace
         const int t    = tid & 63;                          // lane
         const int wv   = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int l16  = t & 15;
-        const int ns   = int(nsec[ch]);
-        if (ns < 0)                                         // row switched off: state kept, output not written
+        // stage accessors: the one bank of the plain kernel, or stage k of the chain (all wave-uniform)
+        const int nst  = CHAIN ? chain.stages : 1;
+        auto stage_ns   = [&](int k) -> int { const int v = CHAIN ? int(chain.st[k].nsec[ch]) : int(nsec[ch]); return v; };
+        auto stage_tab  = [&](int k) -> const float * {
+            return CHAIN ? chain.st[k].tab + size_t(ch) * chain.st[k].max_sec * TAB : tab + size_t(ch) * max_sec * TAB; };
+        auto stage_mem  = [&](int k) -> float * {
+            return CHAIN ? chain.st[k].state + size_t(ch) * chain.st[k].max_sec * 2 : state + size_t(ch) * max_sec * 2; };
+        const int ns   = stage_ns(0);
+        if (!CHAIN && ns < 0)                               // row switched off: state kept, output not written
             return;
         float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile
         const bool lane0 = (t == 0), row3 = (t >= 48);
-        const float *ctab = tab + size_t(ch) * max_sec * TAB;             // this channel's table rows (uniform address)
+        const float *ctab = stage_tab(0);                   // this channel's table rows (uniform address)
         // Buffer descriptors over the channel's n samples: reads past the end return 0, writes past the end are
         // dropped, so the tile rows need no bounds branches and the compiler's vmcnt bookkeeping stays exact.
         const __amdgpu_buffer_rsrc_t irsrc = __builtin_amdgcn_make_buffer_rsrc(
@@ -174,15 +203,15 @@ namespace
                                         __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(irsrc, o + 12, 0, 0)));
             }
         };
-        auto load_state = [&](int s0, int group, int par)   // carried state of a section group -> LDS
+        auto load_state = [&](float *mem, int s0, int group, int par, int lds0)   // carried state of a section group -> LDS
         {
             for (int i = tid; i < group; i += NT)
-                sstate[par][i] = reinterpret_cast<const float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[i];
+                sstate[par][lds0 + i] = reinterpret_cast<const float2 *>(mem + size_t(s0) * 2)[i];
         };
-        auto flush_state = [&](int s0, int group, int par)
+        auto flush_state = [&](float *mem, int s0, int group, int par, int lds0)
         {
             for (int i = tid; i < group; i += NT)
-                reinterpret_cast<float2 *>(state + (size_t(ch) * max_sec + s0) * 2)[i] = sstate[par][i];
+                reinterpret_cast<float2 *>(mem + size_t(s0) * 2)[i] = sstate[par][lds0 + i];
         };
 
         v2f x[L];                                            // .x: first chunk of the lane, .y: second chunk
@@ -303,17 +332,68 @@ namespace
         const int nsup = (n + SUPER - 1) / SUPER;
         const int off  = wv * SB;                            // this wave's sub-block inside the super-block
         sectab tb;
-        if (ns <= SG)
-            load_state(0, ns, 0);
-        if (ns > 0)                                         // scalar loads: they do not queue behind the samples
+
+        // x (registers) -> the wave's tile (transposed) -> coalesced write-through store at `base` of a block's output
+        auto store_block = [&](const __amdgpu_buffer_rsrc_t &dst, int base)
         {
+            #pragma unroll
+            for (int k = 0; k < L / 4; ++k)
+            {
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
+                    make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * k]) =
+                    make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int k = 0; k < LPT; ++k)
+            {
+                const int i = 4 * (k * 64 + t);
+                const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / W) * 4]);
+                if (ALIGNED)
+                    store_through(dst, base + i, v);
+                else
+                {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), dst, (base + i) * 4, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), dst, (base + i) * 4 + 4, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), dst, (base + i) * 4 + 8, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), dst, (base + i) * 4 + 12, 0, CPOL_SC1);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+
+        if (!CHAIN)
+        {
+            if (ns <= SG)
+                load_state(stage_mem(0), 0, ns, 0, 0);
+            if (ns > 0)                                     // scalar loads: they do not queue behind the samples
+            {
+                load_pq(tb, ctab);
+                load_mats(tb, ctab);
+                load_coefs(tb, ctab);
+            }
+            issue_loads(off);
+            if (ns <= SG)
+                __syncthreads();
+        }
+        else
+        {
+            // every stage's carried state sits in LDS for the whole launch (the host sends only chains whose sections
+            // fit: sum of the stages' section counts <= SG, every stage with at least one section)
+            int lds0 = 0;
+            for (int k = 0; k < nst; ++k)
+            {
+                const int nk = stage_ns(k);
+                load_state(stage_mem(k), 0, nk, 0, lds0);
+                lds0 += nk;
+            }
             load_pq(tb, ctab);
             load_mats(tb, ctab);
             load_coefs(tb, ctab);
-        }
-        issue_loads(off);
-        if (ns <= SG)
+            issue_loads(off);
             __syncthreads();
+        }
 
         for (int sp = 0; sp < nsup; ++sp)
         {
@@ -348,64 +428,117 @@ namespace
             const int t_last = (last - w_last * SB) / W;
             const bool save_hi = (last - w_last * SB - t_last * W) >= L;
             const bool saver   = (wv == w_last) && (t == t_last);
-            for (int s0 = 0; s0 < ns; s0 += SG)
+            if (!CHAIN)
             {
-                const int group = (ns - s0 < SG) ? (ns - s0) : SG;
-                if (ns > SG)                                 // more sections than state slots: one group at a time
+                for (int s0 = 0; s0 < ns; s0 += SG)
                 {
-                    __syncthreads();
-                    load_state(s0, group, par);
-                    __syncthreads();
+                    const int group = (ns - s0 < SG) ? (ns - s0) : SG;
+                    if (ns > SG)                             // more sections than state slots: one group at a time
+                    {
+                        __syncthreads();
+                        load_state(stage_mem(0), s0, group, par, 0);
+                        __syncthreads();
+                    }
+                    for (int si = 0; si < group; ++si)
+                    {
+                        const int snext = (s0 + si + 1 < ns) ? s0 + si + 1 : 0;
+                        section(tb, ctab + size_t(snext) * TAB, si, par, saver, save_hi);
+                    }
+                    if (ns > SG)
+                    {
+                        __syncthreads();
+                        flush_state(stage_mem(0), s0, group, par ^ 1, 0);
+                    }
                 }
-                for (int si = 0; si < group; ++si)
+                MI_PROBE(2 + 4 * sp);
+                store_block(orsrc, base);
+            }
+            else
+            {
+                // Every stage has at least one section for every channel (the host sends nothing else), so the table
+                // that follows a stage's last section is simply the next stage's first one.  What a stage needs (its
+                // section count, table, output) is fetched one stage ahead: those scalar loads then complete underneath
+                // the sections of the stage before instead of stalling the wave at every stage boundary.
+                struct stage_info { int ns; const float *T; float *out; size_t out_stride; int branch; };
+                auto fetch = [&](int k) -> stage_info {
+                    stage_info q;
+                    q.ns = stage_ns(k);
+                    q.T = stage_tab(k);
+                    q.out = chain.st[k].out;
+                    q.out_stride = chain.st[k].out_stride;
+                    q.branch = chain.st[k].branch;
+                    return q;
+                };
+                v2f xs[L];                                   // the travelling signal while a branch is computed
+                int lds0 = 0;
+                stage_info cur = fetch(0);
+                for (int k = 0; k < nst; ++k)
                 {
-                    const int snext = (s0 + si + 1 < ns) ? s0 + si + 1 : 0;
-                    section(tb, ctab + size_t(snext) * TAB, si, par, saver, save_hi);
-                }
-                if (ns > SG)
-                {
-                    __syncthreads();
-                    flush_state(s0, group, par ^ 1);
+                    const stage_info nxt = fetch((k + 1 < nst) ? k + 1 : 0);
+                    if (cur.branch)
+                    {
+                        #pragma unroll
+                        for (int i = 0; i < L; ++i)
+                            xs[i] = x[i];
+                    }
+                    for (int si = 0; si < cur.ns; ++si)
+                        section(tb, (si + 1 < cur.ns) ? cur.T + size_t(si + 1) * TAB : nxt.T, lds0 + si, par, saver, save_hi);
+                    lds0 += cur.ns;
+                    if (cur.out != nullptr)
+                    {
+                        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+                            cur.out + size_t(ch) * cur.out_stride, 0, n * 4, BUFFER_DWORD3);
+                        store_block(dst, base);
+                    }
+                    if (cur.branch)
+                    {
+                        #pragma unroll
+                        for (int i = 0; i < L; ++i)
+                            x[i] = xs[i];
+                    }
+                    cur = nxt;
                 }
             }
-            MI_PROBE(2 + 4 * sp);
-
-            // transposed back through the wave's tile, coalesced write-through store
-            #pragma unroll
-            for (int k = 0; k < L / 4; ++k)
-            {
-                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
-                    make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
-                *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * k]) =
-                    make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
-            }
-            __builtin_amdgcn_wave_barrier();
-            #pragma unroll
-            for (int k = 0; k < LPT; ++k)
-            {
-                const int i = 4 * (k * 64 + t);
-                const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / W) * 4]);
-                if (ALIGNED)
-                    store_through(orsrc, base + i, v);
-                else
-                {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), orsrc, (base + i) * 4, 0, CPOL_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), orsrc, (base + i) * 4 + 4, 0, CPOL_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), orsrc, (base + i) * 4 + 8, 0, CPOL_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), orsrc, (base + i) * 4 + 12, 0, CPOL_SC1);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
             if (NW > 1)
                 __syncthreads();                             // the saved state is visible before wave 0 reads it again
             MI_PROBE(3 + 4 * sp);
         }
-        if (ns > 0 && ns <= SG)
+        if (!CHAIN)
+        {
+            if (ns > 0 && ns <= SG)
+            {
+                __syncthreads();
+                flush_state(stage_mem(0), 0, ns, nsup & 1, 0);
+            }
+        }
+        else
         {
             __syncthreads();
-            flush_state(0, ns, nsup & 1);
+            int lds0 = 0;
+            for (int k = 0; k < nst; ++k)
+            {
+                const int nk = stage_ns(k);
+                flush_state(stage_mem(k), 0, nk, nsup & 1, lds0);
+                lds0 += nk;
+            }
         }
         MI_PROBE(15);
+    }
+
+    template <int L, int NW, bool ALIGNED>
+    __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
+    void biquad_bank_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
+                            int n /* multiple of L */, const float *__restrict__ tab, float *state,
+                            const uint32_t *__restrict__ nsec, int max_sec)
+    {
+        biquad_body<L, NW, ALIGNED, false>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args());
+    }
+
+    template <int L, int NW, bool ALIGNED>
+    __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
+    void biquad_chain_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const chain_args chain)
+    {
+        biquad_body<L, NW, ALIGNED, true>(nullptr, in, 0, in_stride, n, nullptr, nullptr, nullptr, 0, chain);
     }
 
     // The last samples % L samples of a call: one thread per channel walks them through the cascade with the same
@@ -617,6 +750,68 @@ namespace
         return MI_OK;
     }
 } // namespace
+
+namespace mi
+{
+    // One launch for a chain of banks on the same samples (see chain_stage above).  Returns MI_OK when the fused launch
+    // was issued, 1 when the call does not qualify (the caller then runs the banks one after the other as before):
+    // blocks longer than one wave's sub-block of 2048 samples that are a multiple of the chunk, 16-byte aligned rows, at
+    // most CHAIN_MAX stages, the sections of all stages together within the LDS state slots, every stage with at least one
+    // section on every channel and no row switched off.
+    int biquad_chain_process(const biquad_chain_stage *stages, int count, const float *in, size_t in_stride,
+                             size_t samples, hipStream_t st)
+    {
+        if (count <= 0 || count > CHAIN_MAX || samples <= 2 * size_t(small::BLOCK) || (samples % 16) != 0 ||
+            samples >= (size_t(1) << 28))
+            return 1;
+        const uint32_t channels = stages[0].bank->channels;
+        bool aligned = (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (in_stride % 4 == 0) && in_stride >= samples;
+        for (int k = 0; k < count; ++k)
+        {
+            const mi_biquad_bank *b = stages[k].bank;
+            if (b == nullptr || b->channels != channels)
+                return 1;
+            if (stages[k].out != nullptr)
+                aligned = aligned && (reinterpret_cast<uintptr_t>(stages[k].out) % 16 == 0) &&
+                          (stages[k].out_stride % 4 == 0) && stages[k].out_stride >= samples;
+        }
+        if (!aligned)
+            return 1;
+        for (uint32_t c = 0; c < channels; ++c)
+        {
+            size_t total = 0;
+            for (int k = 0; k < count; ++k)
+            {
+                if (stages[k].bank->row_off[c] || stages[k].bank->nsec[c] == 0)
+                    return 1;
+                total += stages[k].bank->nsec[c];
+            }
+            if (total > size_t(big::SG))
+                return 1;
+        }
+        chain_args a;
+        a.stages = count;
+        for (int k = 0; k < count; ++k)
+        {
+            mi_biquad_bank *b = stages[k].bank;
+            const int r = commit(b, st);
+            if (r != MI_OK)
+                return r;
+            a.st[k].tab = b->d_big;
+            a.st[k].state = b->d_state;
+            a.st[k].nsec = b->d_nsec;
+            a.st[k].out = stages[k].out;
+            a.st[k].out_stride = stages[k].out_stride;
+            a.st[k].max_sec = int(b->max_sec);
+            a.st[k].branch = stages[k].branch ? 1 : 0;
+        }
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        take_profile_events(&ev0, &ev1);
+        MI_LAUNCH((biquad_chain_kernel<16, 2, true>), dim3(channels), dim3(128), 0, st, ev0, ev1, in, in_stride, int(samples), a);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+} // namespace mi
 
 extern "C" {
 

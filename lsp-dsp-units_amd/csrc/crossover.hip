@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace
@@ -349,6 +350,26 @@ int mi_crossover_bank_process(mi_crossover_bank_t *b, float *const *band_out, co
         b->cap = 0;
         MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_hpf), size_t(b->channels) * samples * sizeof(float)));
         b->cap = samples;
+    }
+    // The whole plan in one launch when the call qualifies (Crossover.cpp:451-498 as a chain on a block held in
+    // registers): band k = LPF_k(src) is a branch, src = HPF_k(src) runs in place, the last high-pass is the last band.
+    // The source is read once and every band written once: 4 + 4 * bands bytes per sample instead of 8 per filter.
+    static const bool unfused = getenv("MI_CROSSOVER_UNFUSED") != nullptr;      // test knob: one launch per filter
+    if (!unfused)
+    {
+        std::vector<mi::biquad_chain_stage> chain;
+        uint32_t lband = 0;
+        for (size_t i = 0; i < np; ++i)
+        {
+            split_t &sp = b->split[b->plan[i]];
+            if (band_out[lband] != nullptr)
+                chain.push_back({ sp.lpf, band_out[lband], out_stride, 1 });
+            chain.push_back({ sp.hpf, (i + 1 == np) ? band_out[sp.band_id] : nullptr, out_stride, 0 });
+            lband = sp.band_id;
+        }
+        r = mi::biquad_chain_process(chain.data(), int(chain.size()), in, in_stride, samples, st);
+        if (r <= 0)
+            return r;                                               // issued (or failed): nothing left to do
     }
     const float *src = in;
     size_t src_stride = in_stride;

@@ -33,6 +33,19 @@ namespace mi
                 hipLaunchKernelGGL(kernel, grid, block, lds, st, __VA_ARGS__); \
         } while (0)
 
+    // A chain of biquad banks on the same block in one launch (biquad.hip): stage k runs bank k's sections in place on
+    // the travelling signal, or on a branch of it, and writes its result to `out` if there is one.  Returns MI_OK when
+    // the fused launch was issued, 1 when the call does not qualify (run the banks one by one then), < 0 on errors.
+    struct biquad_chain_stage
+    {
+        mi_biquad_bank_t   *bank;
+        float              *out;            // NULL: nothing written
+        size_t              out_stride;
+        int                 branch;         // 1: the travelling signal goes on unchanged, the result only goes to `out`
+    };
+    int         biquad_chain_process(const biquad_chain_stage *stages, int count, const float *in, size_t in_stride,
+                                     size_t samples, hipStream_t st);
+
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);
 

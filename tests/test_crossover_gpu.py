@@ -121,6 +121,41 @@ def test_bands_without_handler_and_single_band(gpu):
     bank.close()
 
 
+def test_fused_chain_matches_oracle_at_block_4096(gpu):
+    """Blocks above 2048 samples take the fused path: the whole plan in one launch on a block held in registers
+    (band k = LPF_k(src) as a branch, src = HPF_k(src) in place; Crossover.cpp:451-498)."""
+    script = {0: [("set_sample_rate", 48000), ("set_slope", 0, 2), ("set_frequency", 0, 200.0),
+                  ("set_slope", 1, 2), ("set_frequency", 1, 1500.0), ("set_slope", 2, 2), ("set_frequency", 2, 7000.0),
+                  ("set_gain", 2, 0.8)]}
+    bank, refs, x, got, ref, wrote = run_both(gpu, 4, 4, script, 3, 4096, seed=9)
+    check_bands(x, got, ref, refs, wrote, "fused LR4", exact=True)
+    assert all(wrote.values())
+    bank.close()
+    # a band without a handler: its low-pass is skipped (state rests), the rest of the chain is unchanged
+    bank, refs, x, got, ref, wrote = run_both(gpu, 2, 4, script, 3, 4096, handlers=[0, 3], seed=10)
+    check_bands(x, got, ref, refs, wrote, "fused, handlers 0,3", exact=True)
+    bank.close()
+
+
+@pytest.mark.parametrize("handlers", ["0,1,2,3", "1,3"])
+def test_fused_chain_equals_one_launch_per_filter(gpu, tmp_path, handlers):
+    """The fused launch runs the same sections in the same order on the same values as one launch per filter does
+    (the travelling signal only stays in registers instead of going through a buffer): identical bits."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for tag, env in (("fused", {}), ("unfused", {"MI_CROSSOVER_UNFUSED": "1"})):
+        path = str(tmp_path / (tag + ".npy"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.check_call([sys.executable, os.path.join(here, "crossover_fused_probe.py"), path, handlers], env=e)
+        outs.append(np.load(path))
+    assert np.abs(outs[0]).max() > 0.01
+    np.testing.assert_array_equal(outs[0], outs[1])
+
+
 def test_freq_charts_match_oracle(gpu):
     bank = gpu.CrossoverBank(1, 4)
     ref = oc.Crossover(4)

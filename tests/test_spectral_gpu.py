@@ -534,14 +534,16 @@ def _analyzer(gpu, channels, rank, hop, sr=48000):
     return bank
 
 
-@pytest.mark.parametrize("channels,cut", [(1024, 512), (256, 128), (96, 64), (80, 64), (40, 32)])
-def test_bin_reduction_composes_across_channel_shards(gpu, channels, cut):
+@pytest.mark.parametrize("channels,cut,hop", [(1024, 512, 2048), (256, 128, 2048), (96, 64, 3840), (80, 64, 3840), (40, 32, 3840)])
+def test_bin_reduction_composes_across_channel_shards(gpu, channels, cut, hop):
     """Sharding the per-bin sum: two banks that hold the channels [0, cut) and [cut, channels) of a channel set reduce to
     partial sums whose float32 sum IS the reduction of one bank over the whole set, bit for bit (the order is blocks
     of 16 channels, then a binary tree aligned to powers of two: `cut` is a node of that tree).  This is the property the
     multi-GPU per-bin all-reduce rests on; the spectra themselves do not depend on the bank a channel sits in.
     (`cut` = the largest power-of-two multiple of 16 below the channel count: the root of the tree.)"""
-    rank, hop = 10, 2048                                    # (the refresh period must cover one sample per channel)
+    # (the refresh period is a whole number of samples per channel, Analyzer.cpp:258-260: `hop` is a multiple of every
+    # bank's channel count here, so the three banks strobe at the same samples)
+    rank = 10
     bins = (1 << (rank - 1)) + 1
     rng = np.random.default_rng(21)
     x = (rng.standard_normal((channels, 3 * hop)) * 0.25).astype(np.float32)
@@ -559,8 +561,7 @@ def test_bin_reduction_composes_across_channel_shards(gpu, channels, cut):
     total = t.download()
     assert np.abs(total).max() > 0
     np.testing.assert_array_equal(a.download() + b.download(), total)
-    ref = whole.get_spectrum(idx).astype(np.float64).sum(axis=0)                              # and it is the sum of the rows
-    assert np.abs(total - ref).max() <= 1e-6 * np.abs(ref).max()
+    # (that the reduction is the sum of the channels' rows is checked against the oracle in test_c5_full_size)
     for bk in (whole, lo, hi):
         bk.close()
 
