@@ -28,6 +28,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <utility>
 #include <vector>
 
@@ -208,6 +209,7 @@ namespace
 
     // ---- tail of the next frame: Yt = sum_{p=1..P-1} H_p * X_(newest - (p-1)) ------------------------------
     // One thread owns two neighbouring bins (16-B loads); grid = (M / 512, channels).
+    template <bool NT>
     __global__ __launch_bounds__(256)
     void conv_mac_kernel(float2 *Yt, const float2 *__restrict__ ring, int R, int newest,
                          const float2 *__restrict__ H, int P, int M)
@@ -225,8 +227,22 @@ namespace
         #pragma unroll 4
         for (int p = 1; p < P; ++p)
         {
-            const float4 h = Hc[size_t(p) * M4 + idx];
-            const float4 x = Xc[size_t(r) * M4 + idx];
+            // NT: a working set beyond the Infinity Cache is read exactly once per frame -- non-temporal loads keep the
+            // stream from displacing itself on the way (MI355X_MICROARCH.md, "nt-weights")
+            typedef float f4 __attribute__((ext_vector_type(4)));
+            float4 h, x;
+            if (NT)
+            {
+                const f4 hv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(&Hc[size_t(p) * M4 + idx]));
+                const f4 xv = __builtin_nontemporal_load(reinterpret_cast<const f4 *>(&Xc[size_t(r) * M4 + idx]));
+                h = make_float4(hv.x, hv.y, hv.z, hv.w);
+                x = make_float4(xv.x, xv.y, xv.z, xv.w);
+            }
+            else
+            {
+                h = Hc[size_t(p) * M4 + idx];
+                x = Xc[size_t(r) * M4 + idx];
+            }
             r = (r == 0) ? R - 1 : r - 1;
             // second bin of the pair is always an ordinary complex bin
             s.z = fmaf(x.z, h.z, fmaf(-x.w, h.w, s.z));
@@ -553,8 +569,16 @@ namespace
         const int M = b->B;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
-        MI_LAUNCH(conv_mac_kernel, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1,
-                              b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
+        // the images this launch reads: (P - 1) partitions of H and of the ring, M complex each, per channel
+        const size_t working_set = size_t(b->channels) * size_t(b->P - 1) * size_t(M) * sizeof(float2) * 2;
+        static const int force_nt = getenv("MI_CONV_NT") ? atoi(getenv("MI_CONV_NT")) : -1;    // experiment knob: 0 / 1
+        const bool nt = (force_nt >= 0) ? (force_nt != 0) : (working_set > (size_t(256) << 20));
+        if (nt)
+            MI_LAUNCH(conv_mac_kernel<true>, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1,
+                                  b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
+        else
+            MI_LAUNCH(conv_mac_kernel<false>, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1,
+                                  b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = true;
         return MI_OK;
