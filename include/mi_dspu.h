@@ -467,6 +467,35 @@ int mi_dspu_comm_info(const mi_dspu_comm_t *comm, int *nranks, int *rank);
 /* bins: DEVICE [frames][2^(rank-1)+1], summed in place over the ranks of `comm` (float32, ncclSum). */
 int mi_analyzer_bank_allreduce_bins(mi_analyzer_bank_t *bank, float *bins, size_t frames, mi_dspu_comm_t *comm, void *stream);
 
+/* ---- dynamic filter bank --------------------------------------------------- */
+/*
+ * mi_dynfilter_bank: `channels` x lsp::dspu::DynamicFilters(filters) that share their filter settings
+ * (filters/DynamicFilters.h:41-189, src/main/filters/DynamicFilters.cpp): filters whose gain follows a per-sample
+ * gain vector.  set_params / set_filter_active / process / freq_chart have the reference's meaning (:127-181, .h:147-153,
+ * :204-318, :1774-1970); process() takes DEVICE rows [channels][stride] for the samples AND the gains (every channel its
+ * own gain curve) and is a copy for an inactive / FLT_NONE / slope-0 filter (:207-212).  A change of a filter's type clears
+ * the memory of every filter at the next process() (:132-133,214-219).  FLT_*_RLC_ENVELOPE has no dynamic form here (the
+ * reference's builder reads unset fields, :1022-1085) and is refused with MI_EINVAL, as are the static-only types.
+ */
+typedef struct mi_dynfilter_bank mi_dynfilter_bank_t;
+int mi_dynfilter_bank_create(mi_dynfilter_bank_t **bank, uint32_t channels, uint32_t filters);
+int mi_dynfilter_bank_destroy(mi_dynfilter_bank_t *bank);
+int mi_dynfilter_bank_set_sample_rate(mi_dynfilter_bank_t *bank, uint32_t sample_rate);
+int mi_dynfilter_bank_set_params(mi_dynfilter_bank_t *bank, uint32_t id, const mi_filter_params_t *params);
+/* the parameters as set_params left them (fFreq2 transformed, DynamicFilters.cpp:170-178) */
+int mi_dynfilter_bank_get_params(const mi_dynfilter_bank_t *bank, uint32_t id, mi_filter_params_t *params, int *active);
+int mi_dynfilter_bank_set_filter_active(mi_dynfilter_bank_t *bank, uint32_t id, int active);
+int mi_dynfilter_bank_process(mi_dynfilter_bank_t *bank, uint32_t id, float *out, const float *in, const float *gain,
+                              size_t samples, size_t out_stride, size_t in_stride, size_t gain_stride, void *stream);
+/*
+ * Host-only (no device needed, like mi_filter_design): `params` are what set_params() receives.
+ * sections: the digital sections the filter has at a fixed gain -- what every sample of a constant gain vector is
+ * filtered with.  freq_chart: DynamicFilters::freq_chart(id, c, f, gain, count), packed complex.
+ */
+int mi_dynfilter_sections(const mi_filter_params_t *params, uint32_t sample_rate, float gain, mi_biquad_x1_t *sections,
+                          uint32_t max_sections, uint32_t *count);
+int mi_dynfilter_freq_chart(const mi_filter_params_t *params, uint32_t sample_rate, float *c, const float *f, float gain, size_t count);
+
 /* ---- equalizer bank --------------------------------------------------------------------------- */
 /*
  * mi_equalizer_bank: `channels` x lsp::dspu::Equalizer(filters, fir_rank)

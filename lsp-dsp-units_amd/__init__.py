@@ -12,8 +12,8 @@ Import with ``importlib.import_module("lsp-dsp-units_amd")`` (the directory
 name carries the reference's name and is not a Python identifier).
 """
 from .capi import LIB_PATH, MiError, check, lib          # noqa: F401
-from .units import (AnalyzerBank, BiquadBank, Comm, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, EqualizerBank,  # noqa: F401
+from .units import (AnalyzerBank, BiquadBank, Comm, ConvolverBank, CrossoverBank, DelayBank, DeviceBuffer, DynFilterBank, EqualizerBank,  # noqa: F401
                     ILUFSBank, LoudnessBank,
                     RingBank,
                     SpectralBank, SplitterBank, crossover_fft_mask,
-                    design_filter, device_count, filter_freq_chart, make_window, make_window_general)
+                    design_filter, device_count, dynfilter_freq_chart, dynfilter_sections, filter_freq_chart, make_window, make_window_general)

@@ -66,6 +66,15 @@ PROTOTYPES = {
     "mi_dspu_comm_destroy": (c_int, [c_void_p]),
     "mi_dspu_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "mi_analyzer_bank_allreduce_bins": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mi_dynfilter_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
+    "mi_dynfilter_bank_destroy": (c_int, [c_void_p]),
+    "mi_dynfilter_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),
+    "mi_dynfilter_bank_set_params": (c_int, [c_void_p, c_uint32, POINTER(FilterParams)]),
+    "mi_dynfilter_bank_get_params": (c_int, [c_void_p, c_uint32, POINTER(FilterParams), POINTER(c_int)]),
+    "mi_dynfilter_bank_set_filter_active": (c_int, [c_void_p, c_uint32, c_int]),
+    "mi_dynfilter_bank_process": (c_int, [c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_dynfilter_sections": (c_int, [POINTER(FilterParams), c_uint32, c_float, POINTER(BiquadX1), c_uint32, POINTER(c_uint32)]),
+    "mi_dynfilter_freq_chart": (c_int, [POINTER(FilterParams), c_uint32, c_void_p, c_void_p, c_float, c_size_t]),
     "mi_biquad_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_biquad_bank_destroy": (c_int, [c_void_p]),
     "mi_biquad_bank_set_chains": (c_int, [c_void_p, c_uint32, POINTER(BiquadX1), c_uint32, c_int]),

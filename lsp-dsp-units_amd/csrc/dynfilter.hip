@@ -1,0 +1,796 @@
+// Dynamic filter bank for gfx950: the GPU side of lsp::dspu::DynamicFilters (reference:
+// src/main/filters/DynamicFilters.cpp:127-181 set_params, :204-318 process, :320-1738 the cascade builders,
+// :1774-1970 freq_chart, include/lsp-plug.in/dsp-units/filters/DynamicFilters.h).
+//
+// A dynamic filter is a filter whose GAIN changes from sample to sample (dynamic equalisers, de-essers): for every sample
+// the reference rebuilds the analog cascades from the gain value, transforms them to digital sections
+// (dsp::bilinear_transform_x* / matched_transform_x*) and applies them to that sample (dsp::dyn_biquad_process_x*).
+// Those three primitives belong to the un-vendored lsp-dsp-lib; they are restated from their published algorithm:
+// the transforms are Filter::bilinear_transform / matched_transform (Filter.cpp:2225-2267, 2291-2416) evaluated per
+// sample in float, the processing is the transposed direct form II recurrence with one coefficient set per sample.
+// The reference lays its cascades out diagonally for lsp-dsp-lib's section-pipelined x8/x4/x2 kernels (:320-369 and
+// the `dst[(nc+1)*j]` walks); which numbers cascade J of sample n holds does not depend on that layout, and
+// dyn_cascade() below returns exactly those numbers.
+//
+// Kernel: one wave per channel walks the call in blocks of 64 lanes x 16 samples.  Per cascade every lane builds the 16
+// coefficient sets of its chunk from the gains (gain-independent parts are hoisted), composes the chunk's affine state
+// map s -> M s + v (time-varying, so the maps are per lane, not per section as in biquad.hip), an inclusive scan of the
+// maps over the wave gives every chunk its start state, and the exact recurrence then runs over the chunk with the
+// per-sample coefficients.  Samples stay in registers from cascade to cascade.
+#include "mi_common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <new>
+#include <vector>
+
+namespace
+{
+    constexpr float kPi = 3.14159265358979323846f, kPi2 = 1.57079632679489661923f, kTwoPi = 6.28318530717958647692f;
+    constexpr int CHAINS_MAX = 0x80;            // FILTER_CHAINS_MAX (filters/common.h:28)
+
+    // bilinear prototypes sit on odd enumerators, their matched-Z twins right after them (filters/common.h:38-135)
+    __host__ __device__ inline uint32_t base_type(uint32_t t) { return (t & 1) ? t : t - 1; }
+
+    // Number of cascades of a filter: the sum of build_filter_bank's pack sizes (DynamicFilters.cpp:625-1738)
+    __host__ __device__ inline uint32_t cascade_count(uint32_t type, uint32_t slope)
+    {
+        uint32_t n;
+        switch (base_type(type))
+        {
+            case MI_FLT_BT_AMPLIFIER: case MI_FLT_BT_RLC_NOTCH:                         n = 1; break;
+            case MI_FLT_BT_RLC_LOPASS: case MI_FLT_BT_RLC_HIPASS:
+            case MI_FLT_BT_BWC_LOPASS: case MI_FLT_BT_BWC_HIPASS:                       n = (slope >> 1) + (slope & 1); break;
+            case MI_FLT_BT_RLC_LOSHELF: case MI_FLT_BT_RLC_HISHELF: case MI_FLT_BT_RLC_BANDPASS:
+            case MI_FLT_BT_RLC_BELL: case MI_FLT_BT_RLC_RESONANCE:
+            case MI_FLT_BT_BWC_LOSHELF: case MI_FLT_BT_BWC_HISHELF:                     n = slope; break;
+            case MI_FLT_BT_RLC_LADDERPASS: case MI_FLT_BT_RLC_LADDERREJ:
+            case MI_FLT_BT_BWC_LADDERPASS: case MI_FLT_BT_BWC_LADDERREJ:
+            case MI_FLT_BT_BWC_BELL: case MI_FLT_BT_BWC_BANDPASS:
+            case MI_FLT_BT_LRX_LOPASS: case MI_FLT_BT_LRX_HIPASS:
+            case MI_FLT_BT_LRX_LOSHELF: case MI_FLT_BT_LRX_HISHELF:                     n = 2 * slope; break;
+            case MI_FLT_BT_LRX_LADDERPASS: case MI_FLT_BT_LRX_LADDERREJ:
+            case MI_FLT_BT_LRX_BELL: case MI_FLT_BT_LRX_BANDPASS:                       n = 4 * slope; break;
+            default:                                                                    n = 0; break;   // incl. RLC_ENVELOPE, see header
+        }
+        return (n < uint32_t(CHAINS_MAX)) ? n : uint32_t(CHAINS_MAX);
+    }
+
+    struct dyn_params            // what a builder needs besides the gain (set_params result, DynamicFilters.cpp:127-181)
+    {
+        uint32_t base, slope;
+        float    xf;             // fFreq2 AFTER the transformation of set_params (:170-178)
+        float    Q;
+    };
+
+    __host__ __device__ inline void set3(float *d, float a, float b, float c) { d[0] = a; d[1] = b; d[2] = c; }
+    __host__ __device__ inline void scale3(float *d, float g) { d[0] *= g; d[1] *= g; d[2] *= g; }
+    __host__ __device__ inline float iroot(float x, float n) { return expf(logf(x) / n); }      // dsp::irootf
+
+    // Analog cascade J (global index) of a filter at gain g: numerator t[3], denominator b[3].
+    __host__ __device__ inline void dyn_cascade(const dyn_params &p, uint32_t J, float g, float *t, float *b)
+    {
+        const float Q = p.Q, xf = p.xf;
+        const uint32_t slope = p.slope;
+        switch (p.base)
+        {
+            case MI_FLT_BT_AMPLIFIER:                                                   // :633-657
+                set3(t, g, 0.0f, 0.0f); set3(b, 1.0f, 0.0f, 0.0f);
+                break;
+
+            case MI_FLT_BT_RLC_LOPASS: case MI_FLT_BT_RLC_HIPASS:                       // :660-732
+            {
+                const bool lo = p.base == MI_FLT_BT_RLC_LOPASS;
+                if (J == 0 && (slope & 1))
+                {
+                    set3(b, 1.0f, 1.0f, 0.0f);
+                    set3(t, lo ? g : 0.0f, lo ? 0.0f : g, 0.0f);
+                    break;
+                }
+                set3(b, 1.0f, 2.0f / (1.0f + Q), 1.0f);
+                set3(t, lo ? 1.0f : 0.0f, 0.0f, lo ? 0.0f : 1.0f);
+                if (J == 0)
+                    scale3(t, g);                                                       // "Patch volume"
+                break;
+            }
+            case MI_FLT_BT_RLC_LOSHELF: case MI_FLT_BT_RLC_HISHELF:                     // :734-785
+            {
+                const float gs = sqrtf(g), fg = expf(logf(gs) / float(slope * 2)), k = 2.0f / (1.0f + Q);
+                float *tt = (p.base == MI_FLT_BT_RLC_LOSHELF) ? t : b, *bb = (p.base == MI_FLT_BT_RLC_LOSHELF) ? b : t;
+                set3(tt, fg, k, 1.0f / fg);
+                set3(bb, tt[2], tt[1], tt[0]);
+                if (J == 0)
+                    scale3(t, gs);
+                break;
+            }
+            case MI_FLT_BT_RLC_LADDERPASS: case MI_FLT_BT_RLC_LADDERREJ:                // :790-876
+            {
+                const bool rej = p.base == MI_FLT_BT_RLC_LADDERREJ;
+                const float s2 = float(slope * 2), sq = sqrtf(g), isq = sqrtf(1.0f / g);
+                float gain;
+                if (J & 1)                                                              // second shelf, always a hi-shelf
+                {
+                    gain = rej ? sq : isq;
+                    const float fg = expf(logf(gain) / s2), k = 2.0f * xf / (1.0f + Q);
+                    set3(b, fg, k, xf * xf / fg);
+                    set3(t, 1.0f / fg, k, fg * xf * xf);
+                }
+                else
+                {
+                    const float gain1 = rej ? isq : sq, gain2 = rej ? sq : isq;
+                    const float fg = expf(logf(rej ? gain2 : gain1) / s2), k = 2.0f / (1.0f + Q);
+                    gain = rej ? gain2 : gain1;
+                    float *tt = rej ? t : b, *bb = rej ? b : t;
+                    set3(tt, fg, k, 1.0f / fg);
+                    set3(bb, tt[2], tt[1], tt[0]);
+                }
+                if ((J >> 1) == 0)
+                    scale3(t, gain);
+                break;
+            }
+            case MI_FLT_BT_RLC_BANDPASS:                                                // :878-911
+            {
+                const float f2 = 1.0f / xf, k = (1.0f + f2) / (1.0f + Q);
+                set3(t, 0.0f, (J == 0) ? expf(float(slope) * logf(k)) * g : 1.0f, 0.0f);
+                set3(b, f2, k, 1.0f);
+                break;
+            }
+            case MI_FLT_BT_RLC_BELL: case MI_FLT_BT_RLC_RESONANCE:                      // :913-991
+            {
+                const float fg = expf(logf(g) / float(slope));
+                const float tsin = sinf(atanf(fg)), tcos = sqrtf(1.0f - tsin * tsin);
+                const float k = (p.base == MI_FLT_BT_RLC_BELL) ? 2.0f * (1.0f / fg + fg) / (1.0f + (2.0f * Q) / float(slope))
+                                                               : 2.0f / (1.0f + Q);
+                set3(t, 1.0f, k * tsin, 1.0f);
+                set3(b, 1.0f, k * tcos, 1.0f);
+                break;
+            }
+            case MI_FLT_BT_RLC_NOTCH:                                                   // :993-1020
+                set3(t, g, 0.0f, g);
+                set3(b, 1.0f, 2.0f / (1.0f + Q), 1.0f);
+                break;
+
+            case MI_FLT_BT_BWC_LOPASS: case MI_FLT_BT_BWC_HIPASS:                       // :1090-1170
+            case MI_FLT_BT_LRX_LOPASS: case MI_FLT_BT_LRX_HIPASS:                       // :1509-1563
+            {
+                const bool lrx = p.base == MI_FLT_BT_LRX_LOPASS || p.base == MI_FLT_BT_LRX_HIPASS;
+                const bool hi = p.base == MI_FLT_BT_BWC_HIPASS || p.base == MI_FLT_BT_LRX_HIPASS;
+                if (!lrx && J == 0 && (slope & 1))
+                {
+                    set3(b, 1.0f, 1.0f, 0.0f);
+                    set3(t, hi ? 0.0f : g, hi ? g : 0.0f, 0.0f);
+                    break;
+                }
+                const float k = 1.0f / (1.0f + Q);
+                const float theta = lrx ? (float((J & ~1u) + 1) * kPi2) / float(slope * 2)
+                                        : (float(2 * (J - (slope & 1)) + 1) * kPi2) / float(slope);
+                const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
+                const float kf1 = 1.0f / (tsin * tsin + k * k * tcos * tcos);
+                const float lead = (J == 0) ? g : 1.0f;
+                if (hi)
+                {
+                    set3(t, 0.0f, 0.0f, lead);
+                    set3(b, kf1, 2.0f * k * tcos * kf1, 1.0f);
+                }
+                else
+                {
+                    set3(t, lead, 0.0f, 0.0f);
+                    set3(b, 1.0f, 2.0f * k * tcos * kf1, kf1);
+                }
+                break;
+            }
+            case MI_FLT_BT_BWC_HISHELF: case MI_FLT_BT_BWC_LOSHELF:                     // :1172-1233
+            {
+                const float theta = (float(2 * J + 1) * kPi2) / float(2 * slope);
+                const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
+                const float gain = sqrtf(g), fg = expf(logf(gain) / (2.0f * float(slope)));
+                const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                const float kf = tsin * tsin + k * k * tcos * tcos;
+                float *tt = (p.base == MI_FLT_BT_BWC_HISHELF) ? t : b, *bb = (p.base == MI_FLT_BT_BWC_HISHELF) ? b : t;
+                set3(tt, kf / fg, 2.0f * k * tcos, fg);
+                set3(bb, tt[2], tt[1], tt[0]);
+                if (J == 0)
+                    scale3(t, gain);
+                break;
+            }
+            case MI_FLT_BT_BWC_LADDERPASS: case MI_FLT_BT_BWC_LADDERREJ:                // :1235-1347
+            {
+                const bool passing = p.base == MI_FLT_BT_BWC_LADDERPASS;
+                const float rc = 1.0f / float(slope * 2);
+                const float theta = (float((J & ~1u) + 1) * kPi2) * rc;
+                const float tcos = cosf(theta), tcos2 = tcos * tcos, tsin2 = 1.0f - tcos2;
+                if (J & 1)                                                              // second shelf, always a hi-shelf
+                {
+                    const float xf2 = xf * xf, xtcos = 2.0f * tcos * xf;
+                    const float gain = passing ? sqrtf(g) : sqrtf(1.0f / g);
+                    const float fg = expf(logf(gain) * rc);
+                    const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                    const float kf = tsin2 + k * k * tcos2;
+                    set3(b, kf / fg, k * xtcos, fg * xf2);
+                    set3(t, fg, b[1], b[0] * xf2);
+                    if (!(J & ~1u))
+                        scale3(t, 1.0f / gain);
+                }
+                else
+                {
+                    const float xtcos = 2.0f * tcos, gain = sqrtf(g);
+                    const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                    const float fg = expf(logf(gain) * rc), kf = tsin2 + k * k * tcos2;
+                    float *tt = passing ? t : b, *bb = passing ? b : t;
+                    set3(tt, kf / fg, k * xtcos, fg);
+                    set3(bb, tt[2], tt[1], tt[0]);
+                    if (!(J & ~1u))
+                        scale3(t, gain);
+                }
+                break;
+            }
+            case MI_FLT_BT_BWC_BELL: case MI_FLT_BT_LRX_BELL:                           // :1349-1442, :1573-1666
+            {
+                const bool lrx = p.base == MI_FLT_BT_LRX_BELL;
+                const float sl = float(slope * (lrx ? 4 : 2));
+                const float theta = (float(lrx ? ((J & ~3u) + 2) : ((J & ~1u) + 1)) * kPi2) / sl;
+                const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
+                const float k = 1.0f / (1.0f + Q), kf = tsin * tsin + k * k * tcos * tcos;
+                const float fg = expf(logf(g) / sl), c2 = 2.0f * k * tcos;
+                if (J & 1)
+                {
+                    if (g >= 1.0f) { set3(t, 1.0f, c2 / fg, kf / (fg * fg));       set3(b, 1.0f, c2, kf); }
+                    else           { set3(t, 1.0f, c2, kf);                        set3(b, 1.0f, c2 * fg, kf * fg * fg); }
+                }
+                else
+                {
+                    if (g >= 1.0f) { set3(t, 1.0f, c2 * fg / kf, 1.0f * fg * fg / kf);    set3(b, 1.0f, c2 / kf, 1.0f / kf); }
+                    else           { set3(t, 1.0f, c2 / kf, 1.0f / kf);            set3(b, 1.0f, c2 / (fg * kf), 1.0f / (fg * fg * kf)); }
+                }
+                break;
+            }
+            case MI_FLT_BT_BWC_BANDPASS: case MI_FLT_BT_LRX_BANDPASS:                   // :1444-1505, :1668-1730
+            {
+                const bool lrx = p.base == MI_FLT_BT_LRX_BANDPASS;
+                const float sl = float(slope * (lrx ? 4 : 2));
+                const float theta = (float(lrx ? ((J & ~3u) + 2) : ((J & ~1u) + 1)) * kPi2) / sl;
+                const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
+                const float k = 1.0f / (1.0f + Q), kf1 = 1.0f / (tsin * tsin + k * k * tcos * tcos);
+                if (J & 1)                                                              // hi-pass cascade
+                {
+                    set3(t, 1.0f, 0.0f, 0.0f);
+                    set3(b, 1.0f, 2.0f * k * tcos * xf * kf1, xf * xf * kf1);
+                }
+                else
+                {
+                    set3(t, 0.0f, 0.0f, (J == 0) ? g : 1.0f);
+                    set3(b, kf1, 2.0f * k * tcos * kf1, 1.0f);
+                }
+                break;
+            }
+            case MI_FLT_BT_LRX_HISHELF: case MI_FLT_BT_LRX_LOSHELF:                     // build_lrx_shelf_filter_bank, :509-623
+            {
+                const float b3 = sqrtf(g), gain = sqrtf(b3), fg = iroot(sqrtf(gain), float(slope));
+                const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                const float theta = (float((J & ~1u) + 1) * kPi2) / float(2 * slope);
+                const float tcos = cosf(theta), tcos2 = tcos * tcos, tsin2 = 1.0f - tcos2;
+                const float kf = tsin2 + k * k * tcos2;
+                float *tt = (p.base == MI_FLT_BT_LRX_HISHELF) ? t : b, *bb = (p.base == MI_FLT_BT_LRX_HISHELF) ? b : t;
+                set3(tt, kf * (1.0f / fg), k * (2.0f * tcos), fg);
+                set3(bb, tt[2], tt[1], tt[0]);
+                if (J == 0)
+                    scale3(t, b3);
+                break;
+            }
+            case MI_FLT_BT_LRX_LADDERPASS: case MI_FLT_BT_LRX_LADDERREJ:                // :320-507
+            {
+                const bool passing = p.base == MI_FLT_BT_LRX_LADDERPASS;
+                const float sl = float(slope * 4);
+                const float gain = sqrtf(g), igain = 1.0f / gain, fg = iroot(gain, sl), ifg = 1.0f / fg;
+                const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - igain)));
+                const float xf2 = xf * xf;
+                const float theta = (float((J & ~3u) + 2) * kPi2) / sl;
+                const float tcos = cosf(theta), tcos2 = tcos * tcos, tsin2 = 1.0f - tcos2;
+                const float xtcos = 2.0f * tcos, xtcos_xf = 2.0f * tcos * xf;
+                const float kf = tsin2 + k * k * tcos2;
+                float gn = gain;
+                if (passing)
+                {
+                    if (J & 1)
+                    {
+                        gn = igain;
+                        const float b0 = kf * ifg, b1 = k * xtcos_xf;
+                        set3(t, fg, b1, b0 * xf2);
+                        set3(b, b0, b1, fg * xf2);
+                    }
+                    else
+                    {
+                        const float t0 = kf * ifg, t1 = k * xtcos;
+                        set3(t, t0, t1, fg);
+                        set3(b, fg, t1, t0);
+                    }
+                }
+                else if (J & 1)
+                {
+                    const float b0 = kf * fg, b1 = k * xtcos_xf;
+                    set3(t, ifg, b1, b0 * xf2);
+                    set3(b, b0, b1, ifg * xf2);
+                }
+                else
+                {
+                    const float b0 = kf * ifg, b1 = k * xtcos;
+                    set3(t, fg, b1, b0);
+                    set3(b, b0, b1, fg);
+                }
+                if (!(J & ~1u))
+                    scale3(t, gn);
+                break;
+            }
+            default:
+                set3(t, 1.0f, 0.0f, 0.0f); set3(b, 1.0f, 0.0f, 0.0f);
+                break;
+        }
+    }
+
+    struct section5 { float b0, b1, b2, a1, a2; };
+
+    // dsp::bilinear_transform_x1 of one cascade: the formulas of Filter::bilinear_transform (Filter.cpp:2225-2262)
+    __host__ __device__ inline section5 bilinear(const float *t, const float *b, float kf)
+    {
+        const float kf2 = kf * kf;
+        const float T0 = t[0], T1 = t[1] * kf, T2 = t[2] * kf2;
+        const float B0 = b[0], B1 = b[1] * kf, B2 = b[2] * kf2;
+        const float N = 1.0f / (B0 + B1 + B2);
+        return section5{ (T0 + T1 + T2) * N, 2.0f * (T0 - T2) * N, (T0 - T1 + T2) * N,
+                         2.0f * (B2 - B0) * N, (B1 - B2 - B0) * N };                     // denominator signs negated
+    }
+
+    // dsp::matched_transform_x1 of one cascade: Filter::matched_transform (Filter.cpp:2291-2416), td = 2 pi / sample rate;
+    // the amplitude is matched at w = 0.1 f td (digital) against the prototype at 0.1 (normalised)
+    __host__ __device__ inline void matched_poly(const float *p, float f, float td, float *Qo)
+    {
+        Qo[0] = Qo[1] = Qo[2] = 0.0f;
+        if (p[2] == 0.0f)
+        {
+            if (p[1] == 0.0f)
+                Qo[0] = p[0];
+            else
+            {
+                const float k = p[1] / f, R = -p[0] / k;
+                Qo[0] = k;
+                Qo[1] = -k * expf(R * td);
+            }
+            return;
+        }
+        const float k = p[2], qa = 1.0f / (f * f), qb = p[1] / (f * p[2]), qc = p[0] / p[2];
+        float D = qb * qb - 4.0f * qa * qc;
+        if (D >= 0)
+        {
+            D = sqrtf(D);
+            const float R0 = (-qb - D) / (2.0f * qa), R1 = (-qb + D) / (2.0f * qa);
+            Qo[0] = k;
+            Qo[1] = -k * (expf(R0 * td) + expf(R1 * td));
+            Qo[2] = k * expf((R0 + R1) * td);
+        }
+        else
+        {
+            D = sqrtf(-D);
+            const float R = -qb / (2.0f * qa), K = D / (2.0f * qa);
+            Qo[0] = k;
+            Qo[1] = -2.0f * k * expf(R * td) * cosf(K * td);
+            Qo[2] = k * expf(2.0f * R * td);
+        }
+    }
+
+    __host__ __device__ inline section5 matched(const float *t, const float *b, float f, float td)
+    {
+        float P[2][3];
+        double A[2], I[2];
+        const double w = 0.1 * double(f) * double(td);
+        for (int side = 0; side < 2; ++side)
+        {
+            const float *p = side ? b : t;
+            matched_poly(p, f, td, P[side]);
+            double re = P[side][0] * cos(2.0 * w) + P[side][1] * cos(w) + P[side][2];
+            double im = P[side][0] * sin(2.0 * w) + P[side][1] * sin(w);
+            A[side] = sqrt(re * re + im * im);
+            re = p[0] - p[2] * 0.01;
+            im = p[1] * 0.1;
+            I[side] = sqrt(re * re + im * im);
+        }
+        const double AN = (A[1] * I[0]) / (A[0] * I[1]), N = 1.0 / P[1][0];
+        return section5{ float(P[0][0] * N * AN), float(P[0][1] * N * AN), float(P[0][2] * N * AN),
+                         float(-P[1][1] * N), float(-P[1][2] * N) };
+    }
+
+    struct dyn_filter            // one filter of the bank, kernel view
+    {
+        dyn_params  p;
+        uint32_t    nc;          // cascades
+        int         bilinear;    // nType & 1
+        float       kf;          // DynamicFilters.cpp:223-228: 0.95 | 1 / tan(pi f / sr) | 2 pi / sr
+        float       f0;          // fFreq (matched transform)
+    };
+
+    __host__ __device__ inline section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
+    {
+        float t[3], b[3];
+        dyn_cascade(f.p, J, g, t, b);
+        return f.bilinear ? bilinear(t, b, f.kf) : matched(t, b, f.f0, f.kf);
+    }
+
+    // ---- kernel -----------------------------------------------------------------------------------------------
+    constexpr int LC = 16;                       // samples per lane and block
+    constexpr int BLK = 64 * LC;                 // samples per block of a wave (= the reference's BUF_SIZE, 0x400)
+
+    struct aff { float m00, m01, m10, m11, v0, v1; };      // s -> M s + v
+
+    // the map of `first` followed by `then`
+    __device__ __forceinline__ aff then_(const aff &first, const aff &then)
+    {
+        aff r;
+        r.m00 = then.m00 * first.m00 + then.m01 * first.m10;
+        r.m01 = then.m00 * first.m01 + then.m01 * first.m11;
+        r.m10 = then.m10 * first.m00 + then.m11 * first.m10;
+        r.m11 = then.m10 * first.m01 + then.m11 * first.m11;
+        r.v0  = then.m00 * first.v0 + then.m01 * first.v1 + then.v0;
+        r.v1  = then.m10 * first.v0 + then.m11 * first.v1 + then.v1;
+        return r;
+    }
+
+    __global__ __launch_bounds__(64)
+    void dynfilter_kernel(float *out, const float *in, const float *gain, size_t out_stride, size_t in_stride,
+                          size_t gain_stride, uint32_t samples, dyn_filter f, float *state /* [channels][CHAINS_MAX][2] */)
+    {
+        const uint32_t ch = blockIdx.x, lane = threadIdx.x;
+        const float *x_in = in + size_t(ch) * in_stride;
+        const float *g_in = gain + size_t(ch) * gain_stride;
+        float *y_out = out + size_t(ch) * out_stride;
+        float2 *gmem = reinterpret_cast<float2 *>(state + size_t(ch) * CHAINS_MAX * 2);
+        // the cascades' carried state lives in LDS for the launch (a wave's LDS accesses complete in program order)
+        __shared__ float2 mem[CHAINS_MAX];
+        for (uint32_t J = lane; J < f.nc; J += 64)
+            mem[J] = gmem[J];
+        __builtin_amdgcn_wave_barrier();
+
+        for (uint32_t pos = 0; pos < samples; pos += BLK)
+        {
+            const uint32_t left = samples - pos;
+            const uint32_t valid = (left >= uint32_t(BLK)) ? uint32_t(BLK) : left;      // samples of this block
+            const uint32_t c0 = lane * LC;                                              // the lane's chunk in the block
+            float x[LC], g[LC];
+            #pragma unroll
+            for (int k = 0; k < LC; ++k)
+            {
+                const bool ok = c0 + k < valid;
+                x[k] = ok ? x_in[pos + c0 + k] : 0.0f;
+                g[k] = ok ? g_in[pos + c0 + k] : 1.0f;
+            }
+            const int nk = (c0 >= valid) ? 0 : ((valid - c0 >= uint32_t(LC)) ? LC : int(valid - c0));   // lane's samples
+            const uint32_t last_lane = (valid - 1) / LC;                                // holds the block's last sample
+
+            for (uint32_t J = 0; J < f.nc; ++J)
+            {
+                section5 q[LC];
+                #pragma unroll
+                for (int k = 0; k < LC; ++k)
+                    q[k] = dyn_section(f, J, g[k]);
+                // the chunk's state map: d0' = a1 d0 + d1 + (b1 + a1 b0) x,  d1' = a2 d0 + (b2 + a2 b0) x
+                aff m = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f };
+                #pragma unroll
+                for (int k = 0; k < LC; ++k)
+                {
+                    if (k < nk)
+                    {
+                        const float a1 = q[k].a1, a2 = q[k].a2;
+                        const float u0 = (q[k].b1 + a1 * q[k].b0) * x[k], u1 = (q[k].b2 + a2 * q[k].b0) * x[k];
+                        aff r;
+                        r.m00 = a1 * m.m00 + m.m10;  r.m01 = a1 * m.m01 + m.m11;
+                        r.m10 = a2 * m.m00;          r.m11 = a2 * m.m01;
+                        r.v0  = a1 * m.v0 + m.v1 + u0;
+                        r.v1  = a2 * m.v0 + u1;
+                        m = r;
+                    }
+                }
+                // inclusive scan over the lanes: afterwards m maps the block's start state to the state after this chunk
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1)
+                {
+                    aff o;
+                    o.m00 = __shfl_up(m.m00, d); o.m01 = __shfl_up(m.m01, d); o.m10 = __shfl_up(m.m10, d);
+                    o.m11 = __shfl_up(m.m11, d); o.v0 = __shfl_up(m.v0, d);   o.v1 = __shfl_up(m.v1, d);
+                    if (int(lane) >= d)
+                        m = then_(o, m);
+                }
+                // start state of the lane's chunk: the map of everything before it, applied to the carried state
+                const float2 cs = mem[J];
+                const float s0 = cs.x, s1 = cs.y;
+                aff e;
+                e.m00 = __shfl_up(m.m00, 1); e.m01 = __shfl_up(m.m01, 1); e.m10 = __shfl_up(m.m10, 1);
+                e.m11 = __shfl_up(m.m11, 1); e.v0 = __shfl_up(m.v0, 1);   e.v1 = __shfl_up(m.v1, 1);
+                float d0 = (lane == 0) ? s0 : e.m00 * s0 + e.m01 * s1 + e.v0;
+                float d1 = (lane == 0) ? s1 : e.m10 * s0 + e.m11 * s1 + e.v1;
+                // the exact recurrence with the sample's own coefficients (dsp::dyn_biquad_process_x1)
+                #pragma unroll
+                for (int k = 0; k < LC; ++k)
+                {
+                    if (k < nk)
+                    {
+                        const float xx = x[k];                  // same operation order as biquad.hip's sections
+                        const float tq = fmaf(q[k].b1, xx, d1);
+                        const float u  = q[k].b2 * xx;
+                        const float y  = fmaf(q[k].b0, xx, d0);
+                        d0 = fmaf(q[k].a1, y, tq);
+                        d1 = fmaf(q[k].a2, y, u);
+                        x[k] = y;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (lane == last_lane)                          // carried to the next block / call
+                    mem[J] = make_float2(d0, d1);
+                __builtin_amdgcn_wave_barrier();
+            }
+            #pragma unroll
+            for (int k = 0; k < LC; ++k)
+                if (c0 + k < valid)
+                    y_out[pos + c0 + k] = x[k];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t J = lane; J < f.nc; J += 64)
+            gmem[J] = mem[J];
+    }
+
+    __global__ __launch_bounds__(256)
+    void dyn_copy_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, size_t count)
+    {
+        const uint32_t ch = blockIdx.y;
+        for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
+            out[size_t(ch) * out_stride + i] = in[size_t(ch) * in_stride + i];
+    }
+} // namespace
+
+struct mi_dynfilter_bank
+{
+    uint32_t channels = 0, filters = 0, sample_rate = 0;
+    struct filter_t
+    {
+        mi_filter_params_t  params;      // as set_params leaves them: fFreq2 transformed (DynamicFilters.cpp:170-178)
+        bool                active = false;
+    };
+    std::vector<filter_t>   filter;
+    bool                    clear_mem = false;
+    float                  *d_state = nullptr;      // [filters][channels][CHAINS_MAX][2]
+};
+
+namespace
+{
+    // DynamicFilters::set_params' treatment of the parameters (DynamicFilters.cpp:135-178): band filters get f2 >= f, then
+    // fFreq2 becomes the ratio the builders use (pre-warped for the bilinear types)
+    void transform_params(mi_filter_params_t *fp, uint32_t sample_rate)
+    {
+        switch (base_type(fp->nType))
+        {
+            case MI_FLT_BT_RLC_LADDERPASS: case MI_FLT_BT_RLC_LADDERREJ: case MI_FLT_BT_RLC_BANDPASS:
+            case MI_FLT_BT_BWC_LADDERPASS: case MI_FLT_BT_BWC_LADDERREJ: case MI_FLT_BT_BWC_BANDPASS:
+            case MI_FLT_BT_LRX_LADDERPASS: case MI_FLT_BT_LRX_LADDERREJ: case MI_FLT_BT_LRX_BANDPASS:
+                if (fp->nType != MI_FLT_NONE && fp->fFreq2 < fp->fFreq)
+                {
+                    const float f = fp->fFreq;
+                    fp->fFreq = fp->fFreq2;
+                    fp->fFreq2 = f;
+                }
+                break;
+            default:
+                break;
+        }
+        if (fp->nType & 1)
+        {
+            const float nf = kPi / float(sample_rate);
+            fp->fFreq2 = tanf(fp->fFreq * nf) / tanf(fp->fFreq2 * nf);
+        }
+        else
+            fp->fFreq2 = fp->fFreq / fp->fFreq2;
+    }
+
+    bool make_filter_from(const mi_filter_params_t &p, uint32_t sample_rate, dyn_filter *f)
+    {
+        f->p.base = base_type(p.nType);
+        f->p.slope = p.nSlope;
+        f->p.xf = p.fFreq2;
+        f->p.Q = p.fQuality;
+        f->nc = cascade_count(p.nType, p.nSlope);
+        f->bilinear = int(p.nType & 1);
+        f->f0 = p.fFreq;
+        // DynamicFilters.cpp:223-228
+        f->kf = (p.nType <= MI_FLT_MT_AMPLIFIER) ? 0.95f
+              : (p.nType & 1) ? 1.0f / tanf(p.fFreq * kPi / float(sample_rate))
+              : kTwoPi / float(sample_rate);
+        return f->nc > 0;
+    }
+
+    bool make_filter(const mi_dynfilter_bank *b, uint32_t id, dyn_filter *f)
+    {
+        return make_filter_from(b->filter[id].params, b->sample_rate, f);
+    }
+
+    bool bypassed(const mi_dynfilter_bank *b, uint32_t id)     // DynamicFilters.cpp:207-212
+    {
+        if (id >= b->filters)
+            return true;
+        const mi_dynfilter_bank::filter_t &f = b->filter[id];
+        return !f.active || f.params.nType == MI_FLT_NONE || f.params.nSlope == 0 || b->sample_rate == 0;
+    }
+} // namespace
+
+extern "C" {
+
+int mi_dynfilter_bank_create(mi_dynfilter_bank_t **bank, uint32_t channels, uint32_t filters)
+{
+    MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_dynfilter_bank_create: NULL result pointer");
+    *bank = nullptr;
+    MI_REQUIRE(channels > 0 && filters > 0, MI_EINVAL, "mi_dynfilter_bank_create: channels and filters must be > 0");
+    MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
+    mi_dynfilter_bank *b = new (std::nothrow) mi_dynfilter_bank();
+    MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_dynfilter_bank_create: out of host memory");
+    b->channels = channels;
+    b->filters = filters;
+    b->filter.resize(filters);
+    for (mi_dynfilter_bank::filter_t &f : b->filter)           // DynamicFilters.cpp:95-108
+    {
+        f.params.nType = MI_FLT_NONE; f.params.nSlope = 0;
+        f.params.fFreq = f.params.fFreq2 = f.params.fGain = f.params.fQuality = 0.0f;
+        f.active = false;
+    }
+    const size_t bytes = size_t(filters) * channels * CHAINS_MAX * 2 * sizeof(float);
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&b->d_state), bytes);
+    if (e == hipSuccess) e = hipMemset(b->d_state, 0, bytes);
+    if (e != hipSuccess)
+    {
+        mi_dynfilter_bank_destroy(b);
+        return mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_dynfilter_bank_create: %s", hipGetErrorString(e));
+    }
+    *bank = b;
+    return MI_OK;
+}
+
+int mi_dynfilter_bank_destroy(mi_dynfilter_bank_t *b)
+{
+    if (b == nullptr)
+        return MI_OK;
+    (void)hipFree(b->d_state);
+    delete b;
+    return MI_OK;
+}
+
+int mi_dynfilter_bank_set_sample_rate(mi_dynfilter_bank_t *b, uint32_t sample_rate)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_dynfilter_bank_set_sample_rate: NULL bank");
+    b->sample_rate = sample_rate;
+    return MI_OK;
+}
+
+int mi_dynfilter_bank_set_params(mi_dynfilter_bank_t *b, uint32_t id, const mi_filter_params_t *params)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_dynfilter_bank_set_params: NULL bank");
+    MI_REQUIRE(params != nullptr, MI_EINVAL, "mi_dynfilter_bank_set_params: NULL params");
+    MI_REQUIRE(id < b->filters, MI_EINVAL, "mi_dynfilter_bank_set_params: filter %u out of range", id);     // the class returns false
+    MI_REQUIRE(params->nType == MI_FLT_NONE || cascade_count(params->nType, params->nSlope ? params->nSlope : 1) > 0, MI_EINVAL,
+               "mi_dynfilter_bank_set_params: filter type %u has no dynamic form here (FLT_*_RLC_ENVELOPE and the "
+               "static-only types of DynamicFilters.cpp:625-1738's default branch)", params->nType);
+    mi_filter_params_t *fp = &b->filter[id].params;
+    if (fp->nType != params->nType)                             // DynamicFilters.cpp:132-133
+        b->clear_mem = true;
+    *fp = *params;
+    transform_params(fp, b->sample_rate);
+    return MI_OK;
+}
+
+int mi_dynfilter_bank_get_params(const mi_dynfilter_bank_t *b, uint32_t id, mi_filter_params_t *params, int *active)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_dynfilter_bank_get_params: NULL bank");
+    MI_REQUIRE(id < b->filters, MI_EINVAL, "mi_dynfilter_bank_get_params: filter %u out of range", id);
+    if (params) *params = b->filter[id].params;
+    if (active) *active = b->filter[id].active ? 1 : 0;
+    return MI_OK;
+}
+
+int mi_dynfilter_bank_set_filter_active(mi_dynfilter_bank_t *b, uint32_t id, int active)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_dynfilter_bank_set_filter_active: NULL bank");
+    MI_REQUIRE(id < b->filters, MI_EINVAL, "mi_dynfilter_bank_set_filter_active: filter %u out of range", id);
+    (void)active;
+    b->filter[id].active = true;                                // the reference sets true whatever is asked (DynamicFilters.h:147-153)
+    return MI_OK;
+}
+
+int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, const float *in, const float *gain,
+                              size_t samples, size_t out_stride, size_t in_stride, size_t gain_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_dynfilter_bank_process: NULL bank");
+    if (samples == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_dynfilter_bank_process: NULL buffer");
+    MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL, "mi_dynfilter_bank_process: stride shorter than the block");
+    MI_REQUIRE(samples < (size_t(1) << 31), MI_EINVAL, "mi_dynfilter_bank_process: call too long");
+    hipStream_t st = mi::as_stream(stream);
+    dyn_filter f;
+    if (bypassed(b, id) || !make_filter(b, id, &f))             // DynamicFilters.cpp:207-212: copy
+    {
+        if (out != in)
+        {
+            const unsigned gx = unsigned(std::min<size_t>((samples + 255) / 256, 64));
+            hipLaunchKernelGGL(dyn_copy_kernel, dim3(gx, b->channels), dim3(256), 0, st, out, in, out_stride, in_stride, samples);
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        return MI_OK;
+    }
+    MI_REQUIRE(gain != nullptr && gain_stride >= samples, MI_EINVAL, "mi_dynfilter_bank_process: bad gain buffer");
+    if (b->clear_mem)                                           // :214-219: every filter's memory
+    {
+        MI_HIP_CHECK(hipMemsetAsync(b->d_state, 0, size_t(b->filters) * b->channels * CHAINS_MAX * 2 * sizeof(float), st));
+        b->clear_mem = false;
+    }
+    float *state = b->d_state + size_t(id) * b->channels * CHAINS_MAX * 2;
+    hipLaunchKernelGGL(dynfilter_kernel, dim3(b->channels), dim3(64), 0, st, out, in, gain, out_stride, in_stride,
+                       gain_stride, uint32_t(samples), f, state);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
+int mi_dynfilter_sections(const mi_filter_params_t *params, uint32_t sample_rate, float gain, mi_biquad_x1_t *sections,
+                          uint32_t max_sections, uint32_t *count)
+{
+    MI_REQUIRE(params != nullptr && count != nullptr && sample_rate > 0, MI_EINVAL, "mi_dynfilter_sections: bad argument");
+    *count = 0;
+    mi_filter_params_t fp = *params;
+    transform_params(&fp, sample_rate);
+    dyn_filter f;
+    if (fp.nType == MI_FLT_NONE || fp.nSlope == 0 || !make_filter_from(fp, sample_rate, &f))
+        return MI_OK;
+    *count = f.nc;
+    for (uint32_t J = 0; J < f.nc && J < max_sections && sections != nullptr; ++J)
+    {
+        const section5 q = dyn_section(f, J, gain);
+        sections[J] = mi_biquad_x1_t{ q.b0, q.b1, q.b2, q.a1, q.a2, 0.0f, 0.0f, 0.0f };
+    }
+    return MI_OK;
+}
+
+int mi_dynfilter_freq_chart(const mi_filter_params_t *params, uint32_t sample_rate, float *c, const float *f, float gain, size_t count)
+{
+    MI_REQUIRE(params != nullptr && sample_rate > 0, MI_EINVAL, "mi_dynfilter_freq_chart: bad argument");
+    MI_REQUIRE(c != nullptr && (f != nullptr || count == 0), MI_EINVAL, "mi_dynfilter_freq_chart: NULL buffer");
+    mi_filter_params_t p = *params;
+    transform_params(&p, sample_rate);
+    if (p.nType == MI_FLT_NONE || p.nType == MI_FLT_BT_AMPLIFIER || p.nType == MI_FLT_MT_AMPLIFIER)    // DynamicFilters.cpp:1882-1895
+    {
+        for (size_t i = 0; i < count; ++i)
+        {
+            c[2 * i] = (p.nType == MI_FLT_NONE) ? 1.0f : gain;
+            c[2 * i + 1] = 0.0f;
+        }
+        return MI_OK;
+    }
+    dyn_filter df;
+    make_filter_from(p, sample_rate, &df);
+    const float nf = kPi / float(sample_rate), kf = 1.0f / tanf(p.fFreq * nf), lf = float(sample_rate) * 0.499f;
+    for (size_t i = 0; i < count; ++i)
+    {
+        // the normalised frequency of the prototype (:1905-1912, :1938)
+        const float w = (p.nType & 1) ? tanf((f[i] > lf ? lf : f[i]) * nf) * kf : f[i] * (1.0f / p.fFreq);
+        const float w2 = w * w;
+        float re = 1.0f, im = 0.0f;
+        for (uint32_t J = 0; J < df.nc; ++J)                    // dsp::filter_transfer_calc_pc / apply_pc
+        {
+            float t[3], bb[3];
+            dyn_cascade(df.p, J, gain, t, bb);
+            const float t_re = t[0] - t[2] * w2, t_im = t[1] * w, b_re = bb[0] - bb[2] * w2, b_im = bb[1] * w;
+            const float n = 1.0f / (b_re * b_re + b_im * b_im);
+            const float hr = (t_re * b_re + t_im * b_im) * n, hi = (t_im * b_re - t_re * b_im) * n;
+            const float r2 = re * hr - im * hi, i2 = re * hi + im * hr;
+            re = r2;
+            im = i2;
+        }
+        c[2 * i] = re;
+        c[2 * i + 1] = im;
+    }
+    return MI_OK;
+}
+
+} // extern "C"

@@ -346,6 +346,65 @@ class AnalyzerBank:
             pass
 
 
+def dynfilter_sections(ftype, slope, freq, freq2, quality, gain, sample_rate=48000):
+    """Host: the digital sections of a dynamic filter at a fixed gain, (n, 5) float32."""
+    fp = FilterParams(int(ftype), int(slope), float(freq), float(freq2), 1.0, float(quality))
+    n = c_uint32()
+    arr = (BiquadX1 * 128)()
+    check(lib.mi_dynfilter_sections(byref(fp), int(sample_rate), float(gain), arr, 128, byref(n)))
+    return np.array([[c.b0, c.b1, c.b2, c.a1, c.a2] for c in arr[:n.value]], dtype=np.float32).reshape(-1, 5)
+
+
+def dynfilter_freq_chart(freqs, ftype, slope, freq, freq2, quality, gain, sample_rate=48000):
+    fp = FilterParams(int(ftype), int(slope), float(freq), float(freq2), 1.0, float(quality))
+    f = np.ascontiguousarray(freqs, dtype=np.float32)
+    c = np.empty(2 * f.size, np.float32)
+    check(lib.mi_dynfilter_freq_chart(byref(fp), int(sample_rate), c.ctypes.data_as(c_void_p), f.ctypes.data_as(c_void_p),
+                                      float(gain), f.size))
+    return c[0::2] + 1j * c[1::2]
+
+
+class DynFilterBank:
+    """`channels` x lsp::dspu::DynamicFilters(filters) on the device (shared settings, per-channel gain curves)."""
+
+    def __init__(self, channels, filters):
+        self.channels, self.filters = int(channels), int(filters)
+        h = c_void_p()
+        check(lib.mi_dynfilter_bank_create(byref(h), self.channels, self.filters))
+        self.handle = h
+
+    def set_sample_rate(self, sr):
+        check(lib.mi_dynfilter_bank_set_sample_rate(self.handle, int(sr)))
+
+    def set_params(self, fid, ftype, slope, freq, freq2, gain, quality):
+        fp = FilterParams(int(ftype), int(slope), float(freq), float(freq2), float(gain), float(quality))
+        check(lib.mi_dynfilter_bank_set_params(self.handle, int(fid), byref(fp)))
+
+    def get_params(self, fid):
+        fp, act = FilterParams(), c_int()
+        check(lib.mi_dynfilter_bank_get_params(self.handle, int(fid), byref(fp), byref(act)))
+        return dict(nType=fp.nType, nSlope=fp.nSlope, fFreq=fp.fFreq, fFreq2=fp.fFreq2, fGain=fp.fGain, fQuality=fp.fQuality), bool(act.value)
+
+    def set_filter_active(self, fid, active=True):
+        check(lib.mi_dynfilter_bank_set_filter_active(self.handle, int(fid), 1 if active else 0))
+
+    def process(self, fid, out, inp, gain, samples, out_stride=None, in_stride=None, gain_stride=None, stream=None):
+        check(lib.mi_dynfilter_bank_process(self.handle, int(fid), _ptr(out), _ptr(inp), _ptr(gain) if gain is not None else c_void_p(0),
+                                            int(samples), int(out_stride or samples), int(in_stride or samples),
+                                            int(gain_stride or samples), _stream(stream)))
+
+    def close(self):
+        if self.handle is not None:
+            lib.mi_dynfilter_bank_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Comm:
     """mi_dspu_comm_t: an RCCL communicator owned by the library (one process per GPU)."""
 

@@ -74,6 +74,34 @@ def biquad_cascade_f64(x, coef):
     return y
 
 
+_lib.orc_dyn_biquad_cascade.argtypes = [_fp, _fp, c_size_t, _fp, _fp, c_size_t]
+_lib.orc_dyn_biquad_cascade_f64.argtypes = [POINTER(ctypes.c_double), _fp, c_size_t, _fp, POINTER(ctypes.c_double), c_size_t]
+
+
+def dyn_biquad_cascade(x, coef, state=None):
+    """Time-varying sections: coef [ns][n][5], one coefficient set per section and sample; returns (y, state)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    coef = np.ascontiguousarray(coef, dtype=np.float32)
+    ns = coef.shape[0] if coef.size else 0
+    assert ns == 0 or coef.shape[1:] == (x.size, 5)
+    st = np.zeros((max(ns, 1), 2), np.float32) if state is None else np.array(state, dtype=np.float32, copy=True)
+    y = np.empty_like(x)
+    _lib.orc_dyn_biquad_cascade(_f(y), _f(x), x.size, _f(coef) if ns else None, _f(st), ns)
+    return y, st
+
+
+def dyn_biquad_cascade_f64(x, coef, state=None):
+    """The same recurrence in double arithmetic on the float32 coefficients; returns (y, state)."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    coef = np.ascontiguousarray(coef, dtype=np.float32)
+    ns = coef.shape[0] if coef.size else 0
+    st = np.zeros((max(ns, 1), 2), np.float64) if state is None else np.array(state, dtype=np.float64, copy=True)
+    y = np.empty(x.size, np.float64)
+    dp = POINTER(ctypes.c_double)
+    _lib.orc_dyn_biquad_cascade_f64(y.ctypes.data_as(dp), _f(x), x.size, _f(coef) if ns else None, st.ctypes.data_as(dp), ns)
+    return y, st
+
+
 def biquad_cascade_f64_state(x, coef, state=None):
     """The recurrence in float64 with a carried state: returns (y, state[ns][2]).  scipy's lfilter is the same
     transposed direct form II (zi = {d0, d1}), so the state of the reference's sections maps onto it one to one;

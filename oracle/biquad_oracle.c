@@ -96,3 +96,65 @@ void orc_biquad_impulse_response(float *out, size_t n, const float *coef, float 
     orc_biquad_cascade(out, out, n, coef, state, ns);
     memcpy(state, backup, 2*ns*sizeof(float));
 }
+
+/*
+ * Time-varying sections: lsp-dsp-lib's dsp::dyn_biquad_process_x1/x2/x4/x8 as DynamicFilters::process calls them
+ * (/root/reference/src/main/filters/DynamicFilters.cpp:255-305): the same transposed direct form II recurrence with
+ * one coefficient set per SAMPLE and section.  Upstream pipelines the sections over SIMD lanes (sample n reaches
+ * section j at step n + j, with its own coefficients travelling along: the diagonal cascade layout of
+ * DynamicFilters.cpp:320-369); what each section computes for sample n is what is written here.
+ * coef: [ns][n][5] = {b0, b1, b2, a1, a2} per section and sample, state: ns x {d0, d1}.
+ * Pin: with the same coefficients for every sample this IS orc_biquad_cascade, bit for bit
+ * (tests/test_oracle_dynamic_filters.py); no reference test or vector exists for the unit.
+ */
+void orc_dyn_biquad_cascade(float *dst, const float *src, size_t n, const float *coef, float *state, size_t ns)
+{
+    if (ns == 0)
+    {
+        if (dst != src)
+            memmove(dst, src, n * sizeof(float));
+        return;
+    }
+    for (size_t s = 0; s < ns; ++s)
+    {
+        const float *q = coef + s * n * 5;
+        float d0 = state[2*s+0], d1 = state[2*s+1];
+        const float *in = (s == 0) ? src : dst;
+        for (size_t i = 0; i < n; ++i, q += 5)
+        {
+            const float x  = in[i];
+            const float y  = q[0]*x + d0;
+            const float p1 = q[1]*x + q[3]*y;
+            const float p2 = q[2]*x + q[4]*y;
+            d0      = d1 + p1;
+            d1      = p2;
+            dst[i]  = y;
+        }
+        state[2*s+0] = d0;
+        state[2*s+1] = d1;
+    }
+}
+
+/* The same in double arithmetic on the float coefficients: the round-off yardstick of the parity tests. */
+void orc_dyn_biquad_cascade_f64(double *dst, const float *src, size_t n, const float *coef, double *state, size_t ns)
+{
+    for (size_t i = 0; i < n; ++i)
+        dst[i] = src[i];
+    for (size_t s = 0; s < ns; ++s)
+    {
+        const float *q = coef + s * n * 5;
+        double d0 = state[2*s+0], d1 = state[2*s+1];
+        for (size_t i = 0; i < n; ++i, q += 5)
+        {
+            const double x  = dst[i];
+            const double y  = (double)q[0]*x + d0;
+            const double p1 = (double)q[1]*x + (double)q[3]*y;
+            const double p2 = (double)q[2]*x + (double)q[4]*y;
+            d0      = d1 + p1;
+            d1      = p2;
+            dst[i]  = y;
+        }
+        state[2*s+0] = d0;
+        state[2*s+1] = d1;
+    }
+}
