@@ -7,6 +7,7 @@
 #include <lsp-plug.in/dsp-units/filters/Filter.h>
 #include <lsp-plug.in/dsp-units/filters/FilterBank.h>
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
+#include <lsp-plug.in/dsp-units/filters/DynamicFilters.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
@@ -706,6 +707,162 @@ void Equalizer::dump(IStateDumper *v) const
     v->write("nLatency", size_t(nLatency));
     v->write("nMode", size_t(nMode));
     v->write("nFlags", nFlags);
+}
+
+// ---- DynamicFilters ----------------------------------------------------------------------------------------------
+// Reference members (filters/DynamicFilters.h:43-75).  vFilters is the host array the inline members read and write;
+// the raw parameters of set_params() are kept next to the device bank, which needs them untransformed.
+struct DynamicFilters::impl_t
+{
+    mi_dynfilter_bank_t            *bank = nullptr;
+    std::vector<filter_params_t>    raw;            // as handed to set_params()
+    std::vector<uint8_t>            sent;           // the bank has this filter's parameters
+    staging                         st;
+    float                          *d_gain = nullptr;
+    size_t                          gain_cap = 0;
+};
+static_assert(sizeof(DynamicFilters) == 64, "DynamicFilters keeps the reference's layout");
+
+DynamicFilters::DynamicFilters() { construct(); }
+DynamicFilters::~DynamicFilters() { destroy(); }
+
+void DynamicFilters::construct()                            // DynamicFilters.cpp:56-66
+{
+    vFilters = nullptr;
+    vCascades = nullptr;
+    vMemory = nullptr;
+    vBiquads.ptr = nullptr;
+    nFilters = 0;
+    nSampleRate = 0;
+    pData = nullptr;
+    bClearMem = false;
+}
+
+status_t DynamicFilters::init(size_t filters)
+{
+    destroy();
+    impl_t *p = new (std::nothrow) impl_t();
+    filter_t *fl = static_cast<filter_t *>(std::calloc(filters ? filters : 1, sizeof(filter_t)));
+    if (p == nullptr || fl == nullptr ||
+        last_status(mi_dynfilter_bank_create(&p->bank, 1, uint32_t(filters))) != MI_OK)
+    {
+        delete p;
+        std::free(fl);
+        return STATUS_NO_MEM;
+    }
+    for (size_t i = 0; i < filters; ++i)                    // DynamicFilters.cpp:95-108
+    {
+        fl[i].sParams.nType = FLT_NONE;
+        fl[i].sParams.nSlope = 0;
+        fl[i].bActive = false;
+    }
+    p->raw.assign(filters, fl[0].sParams);
+    p->sent.assign(filters, 1);
+    pData = p;
+    vFilters = fl;
+    nFilters = filters;
+    return STATUS_OK;
+}
+
+void DynamicFilters::destroy()
+{
+    if (impl_t *p = impl())
+    {
+        mi_dynfilter_bank_destroy(p->bank);
+        mi_dspu_free(p->d_gain);
+        p->st.release();
+        delete p;
+    }
+    std::free(vFilters);
+    construct();
+}
+
+void DynamicFilters::set_sample_rate(size_t sr)
+{
+    nSampleRate = sr;
+    if (impl() != nullptr)
+        mi_dynfilter_bank_set_sample_rate(impl()->bank, uint32_t(sr));
+}
+
+bool DynamicFilters::set_params(size_t id, const filter_params_t *params)
+{
+    impl_t *p = impl();
+    if (p == nullptr || id >= nFilters)
+        return false;
+    if (vFilters[id].sParams.nType != params->nType)        // DynamicFilters.cpp:132-133
+        bClearMem = true;
+    p->raw[id] = *params;
+    if (last_status(mi_dynfilter_bank_set_params(p->bank, uint32_t(id), params)) == MI_OK)
+        mi_dynfilter_bank_get_params(p->bank, uint32_t(id), &vFilters[id].sParams, nullptr);     // transformed (:170-178)
+    else
+        vFilters[id].sParams = *params;                     // a type without a dynamic form: process() copies
+    return true;
+}
+
+bool DynamicFilters::get_params(size_t id, filter_params_t *params)
+{
+    if (id >= nFilters)
+        return false;
+    *params = vFilters[id].sParams;
+    return true;
+}
+
+void DynamicFilters::process(size_t id, float *out, const float *in, const float *gain, size_t samples)
+{
+    if (samples == 0)
+        return;
+    impl_t *p = impl();
+    const filter_t *f = (id < nFilters) ? &vFilters[id] : nullptr;
+    bool done = false;
+    if (p != nullptr && f != nullptr && f->bActive && f->sParams.nType != FLT_NONE && f->sParams.nSlope != 0 && nSampleRate != 0)
+    {
+        // the inline set_filter_active() only touches the host array: tell the bank now
+        mi_dynfilter_bank_set_filter_active(p->bank, uint32_t(id), 1);
+        if (samples > p->gain_cap)
+        {
+            mi_dspu_free(p->d_gain);
+            p->d_gain = nullptr;
+            p->gain_cap = 0;
+            if (mi_dspu_malloc(reinterpret_cast<void **>(&p->d_gain), samples * sizeof(float)) == MI_OK)
+                p->gain_cap = samples;
+        }
+        done = p->gain_cap >= samples && p->st.reserve(samples) && p->st.up(in, samples) &&
+               mi_dspu_copy_h2d(p->d_gain, gain, samples * sizeof(float), nullptr) == MI_OK &&
+               last_status(mi_dynfilter_bank_process(p->bank, uint32_t(id), p->st.d_out, p->st.d_in, p->d_gain, samples,
+                                                     samples, samples, samples, nullptr)) == MI_OK &&
+               p->st.down(out, samples);
+        bClearMem = false;
+    }
+    if (!done && out != in)                                 // DynamicFilters.cpp:207-212
+        std::memmove(out, in, samples * sizeof(float));
+}
+
+bool DynamicFilters::freq_chart(size_t id, float *dst, const float *f, float gain, size_t count)
+{
+    impl_t *p = impl();
+    if (p == nullptr || id >= nFilters)
+        return false;
+    return mi_dynfilter_freq_chart(&p->raw[id], uint32_t(nSampleRate ? nSampleRate : 48000), dst, f, gain, count) == MI_OK;
+}
+
+bool DynamicFilters::freq_chart(size_t id, float *re, float *im, const float *f, float gain, size_t count)
+{
+    std::vector<float> c(2 * count);
+    if (!freq_chart(id, c.data(), f, gain, count))
+        return false;
+    for (size_t i = 0; i < count; ++i)
+    {
+        re[i] = c[2 * i];
+        im[i] = c[2 * i + 1];
+    }
+    return true;
+}
+
+void DynamicFilters::dump(IStateDumper *v) const
+{
+    v->write("nFilters", nFilters);
+    v->write("nSampleRate", nSampleRate);
+    v->write("bClearMem", bClearMem);
 }
 
 // ---- Convolver ---------------------------------------------------------------------------------------------------

@@ -8,6 +8,7 @@
 // Plain C++11, no test framework: exit code 0 == all passed.  Needs a GPU (the classes have no CPU fallback).
 #include <lsp-plug.in/dsp-units/filters/Filter.h>
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
+#include <lsp-plug.in/dsp-units/filters/DynamicFilters.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
 #include <lsp-plug.in/dsp-units/util/SpectralProcessor.h>
 #include <lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h>
@@ -722,6 +723,31 @@ static void raw_memory_objects()
     CHECK(eq->get_latency() == 768 && eq->filter_active(1) && eq->filter_inactive(0), "latency 1.5 N and filter modes after reconfigure");
     eq->destroy();
     free(eq);
+
+    // DynamicFilters: a bell whose gain follows a per-sample vector; gain 1 is transparent, a constant gain is the static bell
+    static_assert(sizeof(dspu::DynamicFilters) == 64, "DynamicFilters object size of the reference header");
+    dspu::DynamicFilters *df = raw_object<dspu::DynamicFilters>();
+    df->construct();
+    CHECK(df->filter_inactive(0) && !df->filter_active(0), "constructed dynamic filters");
+    CHECK(df->init(2) == STATUS_OK, "dynamic filters init");
+    df->set_sample_rate(48000);
+    dspu::filter_params_t dp;
+    dp.nType = dspu::FLT_BT_RLC_BELL; dp.fFreq = 1000.0f; dp.fFreq2 = 1000.0f; dp.fGain = 1.0f; dp.nSlope = 2; dp.fQuality = 0.5f;
+    CHECK(df->set_params(1, &dp) && !df->set_params(2, &dp), "set_params range");
+    CHECK(df->filter_inactive(1) && df->set_filter_active(1, false) && df->filter_active(1), "inline activity (activates whatever is asked)");
+    std::vector<float> sx(3000), sg(3000, 1.0f), sy(3000);
+    for (size_t i = 0; i < sx.size(); ++i) sx[i] = sinf(0.13f * float(i)) + 0.3f * sinf(1.7f * float(i));
+    df->process(1, sy.data(), sx.data(), sg.data(), sx.size());
+    float worst = 0.0f;
+    for (size_t i = 0; i < sx.size(); ++i) worst = std::max(worst, fabsf(sy[i] - sx[i]));
+    CHECK(worst < 2e-5f, "gain 1: the bell is transparent (%g)", worst);
+    df->process(0, sy.data(), sx.data(), sg.data(), sx.size());
+    CHECK(memcmp(sy.data(), sx.data(), sx.size() * sizeof(float)) == 0, "an inactive filter copies");
+    float fr[3] = { 100.0f, 1000.0f, 10000.0f }, cre[3], cim[3];
+    CHECK(df->freq_chart(1, cre, cim, fr, 2.0f, 3) && fabsf(hypotf(cre[1], cim[1]) - 2.0f) < 0.02f && fabsf(hypotf(cre[0], cim[0]) - 1.0f) < 0.05f,
+          "freq_chart: +6 dB at the centre (%g)", hypotf(cre[1], cim[1]));
+    df->destroy();
+    free(df);
 
     CHECK(dspu::last_status() == MI_OK, "a device call failed on the way: %d (%s)", dspu::last_status(), mi_dspu_last_error());
 }
