@@ -633,6 +633,9 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *bank, float *out, const float *in, si
                           size_t in_stride, float gain, void *stream);
 /* loudness() of every meter (HOST array of `meters` floats; synchronises) */
 int mi_ilufs_bank_loudness(mi_ilufs_bank_t *bank, float *loudness, void *stream);
+/* The gating-block history as the meters hold it (vLoudness / nMSHead / nMSCount of ILUFSMeter.h): hist is HOST memory
+ * [meters][*size] (NULL: only the size is wanted), head / count HOST [meters] or NULL. */
+int mi_ilufs_bank_history(mi_ilufs_bank_t *bank, float *hist, uint32_t *size, uint32_t *head, uint32_t *count, void *stream);
 
 /*
  * mi_splitter_bank: lsp::dspu::SpectralSplitter for `channels` channels sharing the settings

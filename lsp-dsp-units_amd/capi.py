@@ -158,6 +158,7 @@ PROTOTYPES = {
     "mi_ilufs_bank_clear": (c_int, [c_void_p, c_void_p]),
     "mi_ilufs_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_float, c_void_p]),
     "mi_ilufs_bank_loudness": (c_int, [c_void_p, POINTER(c_float), c_void_p]),
+    "mi_ilufs_bank_history": (c_int, [c_void_p, c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), c_void_p]),
     "mi_splitter_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32]),
     "mi_splitter_bank_destroy": (c_int, [c_void_p]),
     "mi_splitter_bank_set_rank": (c_int, [c_void_p, c_uint32]),

@@ -135,6 +135,9 @@ namespace
         chain_stage st[CHAIN_MAX];
     };
 
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "biquad.hip relies on gfx950 (CDNA4) behaviour: wave64 DPP row/bank semantics and arrival-counting s_barrier"
+#endif
     template <int L, int NW, bool ALIGNED, bool CHAIN>
     __device__ __forceinline__
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
@@ -268,7 +271,14 @@ namespace
             const v2f Pc0 = v2f{tb.m0[0], tb.m0[1]}, Pc1 = v2f{tb.m0[2], tb.m0[3]};
             v2f e = mat_fma(Pc0, Pc1, zwA, zwB);
 
-            // state entering this wave's sub-block: carried over for wave 0, else the end state of the wave before
+            // state entering this wave's sub-block: carried over for wave 0, else the end state of the wave before.
+            // Hand-off by counted barriers: wave w passes w barriers before it reads its predecessor's end state and
+            // NW - 1 - w after it has published its own, i.e. every wave executes exactly NW - 1 s_barrier instructions
+            // per section, but at different program points.  That is legal on gfx9 / CDNA (gfx950 is the only target of
+            // this file, see the guard above the kernel): s_barrier counts ARRIVALS of the workgroup's waves, whatever
+            // their program counter is, and the compiler is told nothing else (no convergent-region assumption is made
+            // across the loop: the trip counts are wave-uniform).  On an architecture with split or named barriers this
+            // hand-off has to be rewritten (NW - 1 uniform barrier sites with predicated work).
             if (NW > 1)
                 for (int v = 0; v < wv; ++v)
                     __syncthreads();

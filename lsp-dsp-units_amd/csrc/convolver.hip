@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -477,12 +478,14 @@ namespace
 
     // ---- twiddle table, one per device -------------------------------------------------------------------
     float2 *g_tw[64] = { nullptr };
+    std::mutex g_tw_lock;               // banks may be created from several host threads
 
     int twiddle_table(const float2 **out)
     {
         int dev = 0;
         MI_HIP_CHECK(hipGetDevice(&dev));
         MI_REQUIRE(dev >= 0 && dev < 64, MI_EINVAL, "device index %d out of range", dev);
+        std::lock_guard<std::mutex> guard(g_tw_lock);
         if (g_tw[dev] == nullptr)
         {
             std::vector<float2> h(TWN);

@@ -202,6 +202,19 @@ namespace
         return MI_OK;
     }
 
+    // Delay::append(): a whole buffer or more keeps the last nSize samples from cell 0 on and restarts the write position
+    // there (Delay.cpp:95-99).  The absolute position matters: process_ramping's read index wraps modulo 2^64 before
+    // it is reduced modulo nSize (Delay.cpp:434), which depends on where the tail sits when the delay grows quickly.
+    int append_block(mi_delay_bank *b, const float *src, size_t stride, size_t count, hipStream_t st)
+    {
+        if (count < b->size)
+            return append(b, src, stride, count, st);
+        b->head = 0;
+        const int r = append(b, src + (count - b->size), stride, b->size, st);
+        b->head = 0;
+        return r;
+    }
+
     // a private copy of the caller's input when dst aliases src
     int stage_input(mi_delay_bank *b, const float **src, size_t *stride, size_t count, hipStream_t st)
     {
@@ -316,17 +329,7 @@ int mi_delay_bank_append(mi_delay_bank_t *b, const float *in, size_t count, size
     MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "mi_delay_bank_append: bad argument");
     if (count == 0)
         return MI_OK;
-    if (count >= b->size)
-    {
-        // a whole buffer or more: the reference keeps the last nSize samples from cell 0 on and restarts the write position
-        // there (Delay.cpp:95-99).  The absolute position matters: process_ramping's read index wraps modulo 2^64 before
-        // it is reduced modulo nSize (Delay.cpp:434), which depends on where the tail sits when the delay grows quickly.
-        b->head = 0;
-        const int r = append(b, in + (count - b->size), in_stride, b->size, mi::as_stream(stream));
-        b->head = 0;
-        return r;
-    }
-    return append(b, in, in_stride, count, mi::as_stream(stream));
+    return append_block(b, in, in_stride, count, mi::as_stream(stream));
 }
 
 int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_t count, size_t out_stride,
@@ -367,6 +370,23 @@ int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_
                            gain, gain_vec, gain_stride);
         MI_HIP_CHECK(hipGetLastError());
         return append(b, in, in_stride, count, st);
+    }
+    if (dmax == 0)
+    {
+        // In place without a delay the reference appends the block as a whole and then scales it (Delay.cpp:107-111,
+        // 155-160, 204-209, 254-259, 303-308, 352-357): a block of at least the line's length restarts the line at cell 0
+        // (:95-99), and the absolute position matters to a later process_ramping() (:434).
+        r = append_block(b, in, in_stride, count, st);
+        if (r != MI_OK)
+            return r;
+        if (add || gain_mode != G_NONE)
+        {
+            hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+                               out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
+                               gain, gain_vec, gain_stride);
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        return MI_OK;
     }
     const size_t gap = b->size - dmax;
     size_t done = 0;

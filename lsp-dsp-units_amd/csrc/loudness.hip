@@ -1039,5 +1039,26 @@ int mi_ilufs_bank_loudness(mi_ilufs_bank_t *b, float *loudness, void *stream)
     return MI_OK;
 }
 
+int mi_ilufs_bank_history(mi_ilufs_bank_t *b, float *hist, uint32_t *size, uint32_t *head, uint32_t *count, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_history: NULL bank");
+    if (size)
+        *size = b->ms_size;
+    if (hist == nullptr && head == nullptr && count == nullptr)
+        return MI_OK;
+    hipStream_t st = mi::as_stream(stream);
+    std::vector<ilufs_state> h(b->meters);
+    MI_HIP_CHECK(hipMemcpyAsync(h.data(), b->d_state, h.size() * sizeof(ilufs_state), hipMemcpyDeviceToHost, st));
+    if (hist != nullptr && b->d_hist != nullptr && b->ms_size > 0)
+        MI_HIP_CHECK(hipMemcpyAsync(hist, b->d_hist, size_t(b->meters) * b->ms_size * sizeof(float), hipMemcpyDeviceToHost, st));
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    for (uint32_t m = 0; m < b->meters; ++m)
+    {
+        if (head)  head[m] = h[m].head;
+        if (count) count[m] = h[m].count;
+    }
+    return MI_OK;
+}
+
 } // extern "C"
 

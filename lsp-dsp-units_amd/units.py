@@ -630,6 +630,17 @@ class ILUFSBank:
         check(lib.mi_ilufs_bank_loudness(self.handle, v, _stream(stream)))
         return np.array(list(v), np.float32)
 
+    def history(self, stream=None):
+        """(hist [meters][size], head [meters], count [meters]) as the meters hold them."""
+        size = c_uint32()
+        check(lib.mi_ilufs_bank_history(self.handle, None, byref(size), None, None, _stream(stream)))
+        hist = np.zeros((self.meters, size.value), np.float32)
+        head = (c_uint32 * self.meters)()
+        count = (c_uint32 * self.meters)()
+        check(lib.mi_ilufs_bank_history(self.handle, hist.ctypes.data_as(c_void_p) if size.value else None, byref(size), head, count,
+                                        _stream(stream)))
+        return hist, np.array(head[:], np.int64), np.array(count[:], np.int64)
+
     def close(self):
         if self.handle:
             lib.mi_ilufs_bank_destroy(self.handle)

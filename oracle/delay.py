@@ -43,9 +43,16 @@ class Delay:
             self.head = 0
         self.tail = (self.head + self.size - self.delay) % self.size
 
-    def process(self, src, gain=None, add_to=None):
-        """Delay::process / process_add with optional scalar or vector gain (Delay.cpp:104-397)."""
+    def process(self, src, gain=None, add_to=None, in_place=False):
+        """Delay::process / process_add with optional scalar or vector gain (Delay.cpp:104-397).
+        in_place: dst == src.  Without a delay the reference then appends the block as a whole and scales it
+        (:107-111, 155-160, 204-209, 254-259, 303-308, 352-357), which restarts the line at cell 0 for a block of at least
+        the line's length (:95-99)."""
         src = np.asarray(src, np.float32)
+        if in_place and self.delay == 0:
+            self.append(src)
+            v = src if gain is None else (src * (gain if np.ndim(gain) else F(gain))).astype(np.float32)
+            return v.copy() if add_to is None else (src + v).astype(np.float32)
         dst = np.empty_like(src) if add_to is None else np.array(add_to, np.float32, copy=True)
         gap = self.size - self.delay
         pos, count = 0, len(src)

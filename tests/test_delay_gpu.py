@@ -183,20 +183,30 @@ def test_delay_random_operation_sequences_bit_exact(gpu, seed):
             x = rng.standard_normal((C, n)).astype(np.float32)
             g = rng.uniform(0.5, 2.0, (C, n)).astype(np.float32)
             base = rng.standard_normal((C, n)).astype(np.float32)
-            in_place = bool(rng.integers(0, 2)) and not op.startswith("add")
+            in_place = bool(rng.integers(0, 2))
+            delays = [r.delay for r in refs]
+            # In place WITHOUT a delay the reference appends the block as a whole (a block of at least the line's length
+            # restarts the line at cell 0); the bank keeps one write position for all its channels, so it follows that path
+            # when no channel has a delay.  Channels with and without a delay in one in-place call of such a length would
+            # need a write position each: that one combination is left to separate banks.
+            if in_place and n >= size and min(delays) == 0 and max(delays) > 0:
+                in_place = False
+            if op.startswith("add") and in_place:
+                base = x                                      # dst == src: the accumulator IS the input
+            ip = in_place and max(delays) == 0                # the reference's shortcut (Delay.cpp:107-111 and its siblings)
             din = gpu.DeviceBuffer.from_host(x)
             dout = din if in_place else gpu.DeviceBuffer.from_host(base)
             dg = gpu.DeviceBuffer.from_host(g)
             if op == "plain":
-                bank.process(dout, din, n); ref = [r.process(x[c]) for c, r in enumerate(refs)]
+                bank.process(dout, din, n); ref = [r.process(x[c], in_place=ip) for c, r in enumerate(refs)]
             elif op == "scalar":
-                bank.process(dout, din, n, gain=0.37); ref = [r.process(x[c], gain=0.37) for c, r in enumerate(refs)]
+                bank.process(dout, din, n, gain=0.37); ref = [r.process(x[c], gain=0.37, in_place=ip) for c, r in enumerate(refs)]
             elif op == "vector":
-                bank.process(dout, din, n, gain_vec=dg); ref = [r.process(x[c], gain=g[c]) for c, r in enumerate(refs)]
+                bank.process(dout, din, n, gain_vec=dg); ref = [r.process(x[c], gain=g[c], in_place=ip) for c, r in enumerate(refs)]
             elif op == "add":
-                bank.process(dout, din, n, add=True); ref = [r.process(x[c], add_to=base[c]) for c, r in enumerate(refs)]
+                bank.process(dout, din, n, add=True); ref = [r.process(x[c], add_to=base[c], in_place=ip) for c, r in enumerate(refs)]
             elif op == "add_vector":
-                bank.process(dout, din, n, add=True, gain_vec=dg); ref = [r.process(x[c], gain=g[c], add_to=base[c]) for c, r in enumerate(refs)]
+                bank.process(dout, din, n, add=True, gain_vec=dg); ref = [r.process(x[c], gain=g[c], add_to=base[c], in_place=ip) for c, r in enumerate(refs)]
             else:
                 targets = [int(rng.integers(0, maxd + 1)) for _ in range(C)]
                 if rng.integers(0, 4) == 0:

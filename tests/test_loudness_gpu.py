@@ -166,11 +166,17 @@ def test_random_operation_sequences(gpu, seed):
                 # (about 1e-7 of them, different in any two evaluation orders) is all there is.  The error is linear in
                 # the mean-square domain, so it is judged there when the output is small.
                 level2 = max(level2, float((o / (g or 1.0)).max()) ** 2)
-                ms_err = float(np.abs(y[m].astype(np.float64) ** 2 - o.astype(np.float64) ** 2).max()) / (g or 1.0) ** 2
-                assert err <= tol * peak or ms_err <= MS_TOL * level2, \
-                    (seed, step, m, n, err / peak, ms_err / level2, int(np.abs(y[m] - o).argmax()), log[-8:],
-                     y[m][max(0, int(np.abs(y[m] - o).argmax()) - 20):int(np.abs(y[m] - o).argmax()) + 4].tolist(),
-                     o[max(0, int(np.abs(y[m] - o).argmax()) - 20):int(np.abs(y[m] - o).argmax()) + 4].tolist())
+                d_amp = np.abs(y[m].astype(np.float64) - o.astype(np.float64))
+                d_ms = np.abs(y[m].astype(np.float64) ** 2 - o.astype(np.float64) ** 2) / (g or 1.0) ** 2
+                # the mean-square criterion only where it belongs: samples whose output is below 3 % of the loudest level
+                # seen (1e-3 in the mean-square domain) -- the nearly empty window; everywhere else the amplitude rule
+                # holds, or the strict 1e-6 of the mean square
+                small = (o.astype(np.float64) / (g or 1.0)) ** 2 < 1e-3 * level2
+                bad = ~((d_amp <= tol * peak) | (d_ms <= 1e-6 * level2) | (small & (d_ms <= MS_TOL * level2)))
+                i_bad = int(np.argmax(bad)) if bad.any() else 0
+                assert not bad.any(), \
+                    (seed, step, m, n, int(bad.sum()), d_amp[i_bad] / peak, d_ms[i_bad] / level2, i_bad, log[-8:],
+                     y[m][max(0, i_bad - 20):i_bad + 4].tolist(), o[max(0, i_bad - 20):i_bad + 4].tolist())
                 for k in range(K):
                     if refs[m].ch[k]["enabled"] and refs[m].ch[k]["bound"]:
                         level2 = max(level2, float((c[k] / (g or 1.0)).max()) ** 2)
