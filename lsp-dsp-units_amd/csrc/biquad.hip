@@ -39,6 +39,7 @@
 // dwords, an odd number of 16-B slots: conflict-free ds_read_b128).
 #include "mi_common.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -135,14 +136,24 @@ namespace
         chain_stage st[CHAIN_MAX];
     };
 
+    // Epilogue of the meters (library-internal): the filtered samples are not stored; the sum of their squares is added
+    // to sums[channel * 4 + s] for the up to four consecutive segments [0, e0), [e0, e1), [e1, e2), [e2, n) of the call
+    // (ILUFSMeter.cpp:372-384 accumulates the squares of the weighted signal per quarter of a gating block).
+    struct sumsq_args
+    {
+        float      *sums;
+        int         e0, e1, e2;         // segment ends, e0 <= e1 <= e2 <= n; unused ones = n
+    };
+
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "biquad.hip relies on gfx950 (CDNA4) behaviour: wave64 DPP row/bank semantics and arrival-counting s_barrier"
 #endif
-    template <int L, int NW, bool ALIGNED, bool CHAIN>
+    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false>
     __device__ __forceinline__
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
-                     const uint32_t *__restrict__ nsec, int max_sec, const chain_args &chain)
+                     const uint32_t *__restrict__ nsec, int max_sec, const chain_args &chain,
+                     const sumsq_args &sq = sumsq_args())
     {
         using G = geom<L>;
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
@@ -373,6 +384,42 @@ namespace
             __builtin_amdgcn_wave_barrier();
         };
 
+        // SUMSQ: x (registers) -> the segments' sums of squares.  A chunk lies inside one segment unless one of the (at most
+        // three) segment ends of the call falls into it: only those lanes walk their chunk sample by sample.
+        float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+        auto seg_of = [&](int i) -> int { return int(i >= sq.e0) + int(i >= sq.e1) + int(i >= sq.e2); };
+        auto add_chunk = [&](float q, int c0, bool hi)
+        {
+            if (c0 >= n)                                    // a chunk past the end of the call (its loads returned zeros)
+                return;
+            const int sa = seg_of(c0), sb = seg_of(c0 + L - 1);
+            if (sa == sb)
+            {
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] += (sa == j) ? q : 0.0f;
+                return;
+            }
+            #pragma unroll
+            for (int k = 0; k < L; ++k)
+            {
+                const float y = hi ? x[k].y : x[k].x;
+                const int sk = seg_of(c0 + k);
+                #pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = (sk == j) ? fmaf(y, y, acc[j]) : acc[j];
+            }
+        };
+        auto add_squares = [&](int base)
+        {
+            v2f q = splat(0.0f);
+            #pragma unroll
+            for (int k = 0; k < L; ++k)
+                q = pk_fma(x[k], x[k], q);
+            add_chunk(q.x, base + t * W, false);
+            add_chunk(q.y, base + t * W + L, true);
+        };
+
         if (!CHAIN)
         {
             if (ns <= SG)
@@ -461,7 +508,10 @@ namespace
                     }
                 }
                 MI_PROBE(2 + 4 * sp);
-                store_block(orsrc, base);
+                if (SUMSQ)
+                    add_squares(base);
+                else
+                    store_block(orsrc, base);
             }
             else
             {
@@ -532,6 +582,28 @@ namespace
                 lds0 += nk;
             }
         }
+        if (SUMSQ)
+        {
+            __shared__ float red[NW][4];
+            #pragma unroll
+            for (int j = 0; j < 4; ++j)
+            {
+                float v = acc[j];
+                #pragma unroll
+                for (int d = 32; d > 0; d >>= 1)
+                    v += __shfl_xor(v, d);
+                if (lane0)
+                    red[wv][j] = v;
+            }
+            __syncthreads();
+            if (tid < 4)
+            {
+                float v = red[0][tid];
+                for (int w = 1; w < NW; ++w)
+                    v += red[w][tid];
+                sq.sums[size_t(ch) * 4 + tid] += v;
+            }
+        }
         MI_PROBE(15);
     }
 
@@ -546,6 +618,14 @@ namespace
 
     template <int L, int NW, bool ALIGNED>
     __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
+    void biquad_sumsq_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const float *__restrict__ tab,
+                             float *state, const uint32_t *__restrict__ nsec, int max_sec, const sumsq_args sq)
+    {
+        biquad_body<L, NW, ALIGNED, false, true>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), sq);
+    }
+
+    template <int L, int NW, bool ALIGNED>
+    __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
     void biquad_chain_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const chain_args chain)
     {
         biquad_body<L, NW, ALIGNED, true>(nullptr, in, 0, in_stride, n, nullptr, nullptr, nullptr, 0, chain);
@@ -555,7 +635,8 @@ namespace
     // recurrence (FilterBank.cpp:256-291 semantics for block sizes that are not a multiple of the chunk length).
     __global__ void biquad_tail_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
                                        size_t start, int count /* < 16 */, const float *__restrict__ tab, int tab_row,
-                                       float *state, const uint32_t *__restrict__ nsec, int max_sec, uint32_t channels)
+                                       float *state, const uint32_t *__restrict__ nsec, int max_sec, uint32_t channels,
+                                       const sumsq_args sq)
     {
         const uint32_t ch = blockIdx.x * blockDim.x + threadIdx.x;
         if (ch >= channels)
@@ -584,6 +665,19 @@ namespace
             }
             st[0] = d0;
             st[1] = d1;
+        }
+        if (sq.sums != nullptr)                             // the meters' epilogue: squares into the segments' sums
+        {
+            float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            for (int k = 0; k < count; ++k)
+            {
+                const int i = int(start) + k, sk = int(i >= sq.e0) + int(i >= sq.e1) + int(i >= sq.e2);
+                for (int j = 0; j < 4; ++j)
+                    acc[j] = (sk == j) ? fmaf(xs[k], xs[k], acc[j]) : acc[j];
+            }
+            for (int j = 0; j < 4; ++j)
+                sq.sums[size_t(ch) * 4 + j] += acc[j];
+            return;
         }
         for (int k = 0; k < count; ++k)
             out[size_t(ch) * out_stride + start + k] = xs[k];
@@ -674,12 +768,21 @@ namespace
 {
     template <int L, int NW>
     hipError_t launch(mi_biquad_bank *b, float *out, const float *in, size_t out_stride,
-                      size_t in_stride, int n, bool aligned, const float *tab, hipStream_t st)
+                      size_t in_stride, int n, bool aligned, const float *tab, hipStream_t st, const sumsq_args *sq = nullptr)
     {
         const dim3 grid(b->channels), block(64 * NW);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
-        if (aligned)
+        if (sq != nullptr)
+        {
+            if (aligned)
+                MI_LAUNCH((biquad_sumsq_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, in, in_stride, n, tab,
+                          b->d_state, b->d_nsec, int(b->max_sec), *sq);
+            else
+                MI_LAUNCH((biquad_sumsq_kernel<L, NW, false>), grid, block, 0, st, ev0, ev1, in, in_stride, n, tab,
+                          b->d_state, b->d_nsec, int(b->max_sec), *sq);
+        }
+        else if (aligned)
             MI_LAUNCH((biquad_bank_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, out, in,
                                   out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
         else
@@ -820,6 +923,29 @@ namespace mi
         MI_LAUNCH((biquad_chain_kernel<16, 2, true>), dim3(channels), dim3(128), 0, st, ev0, ev1, in, in_stride, int(samples), a);
         MI_HIP_CHECK(hipGetLastError());
         return MI_OK;
+    }
+} // namespace mi
+
+static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t samples, size_t out_stride, size_t in_stride,
+                    hipStream_t st, const sumsq_args *sq);
+
+namespace mi
+{
+    // The bank over `samples` samples without an output: sums[channel * 4 + s] += the sum of the squares of the filtered
+    // samples [seg_end[s - 1], seg_end[s]) (seg_end[3] = samples).  A channel switched off adds nothing.
+    int biquad_bank_sumsq(mi_biquad_bank *b, const float *in, size_t in_stride, size_t samples, const uint32_t seg_end[3],
+                          float *sums, hipStream_t st)
+    {
+        if (samples == 0)
+            return MI_OK;
+        MI_REQUIRE(b != nullptr && in != nullptr && sums != nullptr && in_stride >= samples && samples < (size_t(1) << 31),
+                   MI_EINVAL, "biquad_bank_sumsq: bad argument");
+        sumsq_args sq;
+        sq.sums = sums;
+        sq.e0 = int(std::min<size_t>(seg_end[0], samples));
+        sq.e1 = int(std::min<size_t>(seg_end[1], samples));
+        sq.e2 = int(std::min<size_t>(seg_end[2], samples));
+        return bank_run(b, nullptr, in, samples, 0, in_stride, st, &sq);
     }
 } // namespace mi
 
@@ -968,16 +1094,10 @@ int mi_biquad_bank_reset(mi_biquad_bank_t *b, uint32_t channel, void *stream)
     return commit(b, mi::as_stream(stream));
 }
 
-int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, size_t samples,
-                           size_t out_stride, size_t in_stride, void *stream)
+// One call of the bank over `samples` samples of every channel; sq != NULL: the meters' epilogue instead of the output
+static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t samples, size_t out_stride, size_t in_stride,
+                    hipStream_t st, const sumsq_args *sq)
 {
-    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_process: NULL bank");
-    if (samples == 0)
-        return MI_OK;
-    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_biquad_bank_process: NULL buffer");
-    MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL,
-               "mi_biquad_bank_process: stride shorter than the block");
-    hipStream_t st = mi::as_stream(stream);
     int r = commit(b, st);
     if (r != MI_OK)
         return r;
@@ -997,19 +1117,27 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
     {
         const size_t left = body - done;
         const size_t step = (left < (size_t(1) << 28)) ? left : (size_t(1) << 28);      // multiple of 16
+        sumsq_args part, *pq = nullptr;
+        if (sq != nullptr)                                  // segment ends counted from this launch's first sample
+        {
+            auto rel = [&](int e) -> int { return (size_t(e) <= done) ? 0 : (size_t(e) - done >= step) ? int(step) : int(size_t(e) - done); };
+            part.sums = sq->sums; part.e0 = rel(sq->e0); part.e1 = rel(sq->e1); part.e2 = rel(sq->e2);
+            pq = &part;
+        }
+        float *o = (out != nullptr) ? out + done : nullptr;
         hipError_t e;
         if (samples <= size_t(small::BLOCK))
-            e = launch<8, 1>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+            e = launch<8, 1>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st, pq);
         else if (use_small)
-            e = launch<8, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
-        else if (force_nw == 1)
-            e = launch<16, 1>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
-        else if (force_nw == 84)
-            e = launch<8, 4>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
-        else if (force_nw == 82)
-            e = launch<8, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+            e = launch<8, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st, pq);
+        else if (force_nw == 1 && pq == nullptr)
+            e = launch<16, 1>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
+        else if (force_nw == 84 && pq == nullptr)
+            e = launch<8, 4>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+        else if (force_nw == 82 && pq == nullptr)
+            e = launch<8, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
         else
-            e = launch<16, 2>(b, out + done, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
+            e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq);
         MI_HIP_CHECK(e);
         done += step;
     }
@@ -1017,10 +1145,22 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
     {
         hipLaunchKernelGGL(biquad_tail_kernel, dim3((b->channels + 63) / 64), dim3(64), 0, st, out, in, out_stride,
                            in_stride, body, int(tail), b->d_small, int(small::TAB), b->d_state, b->d_nsec,
-                           int(b->max_sec), b->channels);
+                           int(b->max_sec), b->channels, sq ? *sq : sumsq_args{ nullptr, 0, 0, 0 });
         MI_HIP_CHECK(hipGetLastError());
     }
     return MI_OK;
+}
+
+int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, size_t samples,
+                           size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_process: NULL bank");
+    if (samples == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_biquad_bank_process: NULL buffer");
+    MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL,
+               "mi_biquad_bank_process: stride shorter than the block");
+    return bank_run(b, out, in, samples, out_stride, in_stride, mi::as_stream(stream), nullptr);
 }
 
 int mi_biquad_bank_impulse_response(mi_biquad_bank_t *b, float *out, size_t samples, size_t out_stride, void *stream)

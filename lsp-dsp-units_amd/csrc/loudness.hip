@@ -14,13 +14,15 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 namespace
 {
     constexpr uint32_t BUFFER_SIZE = 0x400;                 // LoudnessMeter.cpp:32
     constexpr int      LT = 256;                            // threads per meter
-    constexpr uint32_t MAX_BLOCK = 4096;                    // samples per launch: 16 register-resident passes of LT samples
+    constexpr uint32_t MAX_BLOCK = 4096;                    // samples per launch: register-resident passes of the workgroup
+    constexpr uint32_t SEG = 256;                           // cells per segment of a line whose sum is kept beside the line
 
     // bs::channel_weighting (src/main/misc/broadcast.cpp:32-55)
     float channel_weighting(int designation)
@@ -39,52 +41,6 @@ namespace
         int     enabled;
         int     unbound;        // LoudnessMeter: no input bound -- the channel is left out of the block (:421-422) but stays
     };                          // enabled for refresh_rms() and clear(); always 0 for the integrated meter
-
-    // exact window sums (refresh_rms): ms[row] = sum of the last `period` cells behind head
-    __global__ __launch_bounds__(LT)
-    void loudness_refresh_kernel(float *ms, const float *__restrict__ data, uint32_t size, uint32_t head, uint32_t period,
-                                 const chan_cfg *__restrict__ cfg, uint32_t channels)
-    {
-        __shared__ float part[LT];
-        const uint32_t row = blockIdx.x, tid = threadIdx.x;
-        if (!cfg[row % channels].enabled)
-            return;
-        const float *d = data + size_t(row) * size;
-        const uint32_t tail = (head + size - period) & (size - 1);
-        // 16-byte cells of the ring that cover [tail, tail + period); the cells at both ends are cut to the window
-        const uint32_t lead = tail & 3u, first = tail - lead, cells = (lead + period + 3u) >> 2;
-        float s0 = 0.0f, s1 = 0.0f;
-        for (uint32_t q = tid; q < cells; q += LT)
-        {
-            const float4 v = *reinterpret_cast<const float4 *>(d + ((first + 4u * q) & (size - 1)));
-            const uint32_t at = 4u * q;                     // position of the cell's first float, counted from `first`
-            const bool inner = at >= lead && at + 4u <= lead + period;
-            if (inner)
-            {
-                s0 += v.x + v.z;
-                s1 += v.y + v.w;
-            }
-            else
-            {
-                const float e[4] = { v.x, v.y, v.z, v.w };
-                #pragma unroll
-                for (uint32_t k = 0; k < 4; ++k)
-                    if (at + k >= lead && at + k < lead + period)
-                        s0 += e[k];
-            }
-        }
-        const float s = s0 + s1;
-        part[tid] = s;
-        __syncthreads();
-        for (int w = LT / 2; w > 0; w >>= 1)
-        {
-            if (int(tid) < w)
-                part[tid] += part[tid + w];
-            __syncthreads();
-        }
-        if (tid == 0)
-            ms[row] = part[0];
-    }
 
     // inclusive sum scan over the 64 lanes with DPP: shifts inside the rows of 16 lanes, then the sums of rows 0 and 2 to
     // rows 1 and 3 (row_bcast:15) and of the lower half to the upper half (row_bcast:31)
@@ -105,24 +61,86 @@ namespace
         return v;
     }
 
-    // one block of `n` <= E * LT samples of one meter
-    template <uint32_t E>                                   // passes: sample j = i * LT + tid lives in register i of thread tid
-    __global__ __launch_bounds__(LT)
+    // sum of `cnt` cells of a ring line from cell `start` on, by the whole workgroup of T threads (every thread gets it)
+    template <uint32_t T>
+    __device__ float window_sum(const float *d, uint32_t size, uint32_t start, uint32_t cnt, float *part /* [T / 64] */)
+    {
+        const uint32_t tid = threadIdx.x, mask = size - 1;
+        // 16-byte cells of the ring that cover [start, start + cnt); the cells at both ends are cut to the window
+        const uint32_t lead = start & 3u, first = start - lead, cells = (cnt > 0) ? (lead + cnt + 3u) >> 2 : 0u;
+        float s0 = 0.0f, s1 = 0.0f;
+        for (uint32_t q = tid; q < cells; q += T)
+        {
+            const float4 v = *reinterpret_cast<const float4 *>(d + ((first + 4u * q) & mask));
+            const uint32_t at = 4u * q;                     // position of the cell's first float, counted from `first`
+            if (at >= lead && at + 4u <= lead + cnt)
+            {
+                s0 += v.x + v.z;
+                s1 += v.y + v.w;
+            }
+            else
+            {
+                const float e[4] = { v.x, v.y, v.z, v.w };
+                #pragma unroll
+                for (uint32_t k = 0; k < 4; ++k)
+                    if (at + k >= lead && at + k < lead + cnt)
+                        s0 += e[k];
+            }
+        }
+        float s = s0 + s1;
+        #pragma unroll
+        for (int w = 32; w > 0; w >>= 1)
+            s += __shfl_xor(s, w);
+        __syncthreads();                                    // part[] is free
+        if ((tid & 63) == 0)
+            part[tid >> 6] = s;
+        __syncthreads();
+        float r = 0.0f;
+        #pragma unroll
+        for (uint32_t w = 0; w < T / 64; ++w)
+            r += part[w];
+        return r;
+    }
+
+    // One block of `n` <= E * T samples of one meter: T threads, sample j = i * T + tid lives in register i of thread tid.
+    // refresh_at < n: the reference re-sums the window exactly before that sample of the block (refresh_rms(),
+    // LoudnessMeter.cpp:381-407 on its schedule :496-503); it is done here, inside the block, so that a block never has to
+    // be cut at the refresh point.
+    template <uint32_t T, uint32_t E>
+    __global__ __launch_bounds__(T)
     void loudness_block_kernel(float *out, float *ch_out, size_t out_stride, const float *__restrict__ flt, size_t flt_stride,
                                float *data, uint32_t size, uint32_t head, uint32_t period, float avg, float *ms,
                                float *msbuf, size_t msbuf_stride, const chan_cfg *__restrict__ cfg, uint32_t channels,
-                               uint32_t n, float gain, float *loud)
+                               uint32_t n, float gain, float *loud, uint32_t refresh_at, float *segsum, int use_seg)
     {
-        __shared__ float sq[E * LT];                        // this channel's squares (new values)
-        __shared__ __align__(16) float wtot[E][LT / 64];    // sums of the waves of every pass
+        constexpr uint32_t NWV = T / 64, MAXSEG = E * T / SEG + 1;
+        __shared__ float segnew[MAXSEG];                    // sums of the line's segments this block writes to
+        __shared__ float sq[E * T];                         // this channel's squares (new values)
+        __shared__ __align__(16) float wtot[E][NWV];        // sums of the waves of every pass
+        __shared__ float part[NWV];
+        __shared__ float s_before;                          // prefix sum just before the refresh point
         const uint32_t meter = blockIdx.x, tid = threadIdx.x, mask = size - 1;
         const uint32_t lane = tid & 63, wave = tid >> 6;
         const uint32_t tail = (head + size - period) & mask;
+        const bool refresh = refresh_at < n;
         float mix[E];                                       // weighted sum of the channels' mean squares
         #pragma unroll
         for (uint32_t i = 0; i < E; ++i)
             mix[i] = 0.0f;
         uint32_t mixed = 0;
+        // enabled channels without an input: the line stands still, but refresh_rms() re-sums every enabled channel's window
+        if (refresh)
+            for (uint32_t c = 0; c < channels; ++c)
+            {
+                const chan_cfg cc = cfg[c];
+                if (!cc.enabled || !cc.unbound)
+                    continue;
+                const uint32_t row = meter * channels + c;
+                const float r = window_sum<T>(data + size_t(row) * size, size, (head + refresh_at + size - period) & mask, period, part);
+                if (tid == 0)
+                    ms[row] = r;
+            }
+        // the channels with an input, one after the other
         for (uint32_t c = 0; c < channels; ++c)
         {
             const chan_cfg cc = cfg[c];
@@ -135,7 +153,7 @@ namespace
             #pragma unroll
             for (uint32_t i = 0; i < E; ++i)                // every load of the block is issued before anything waits
             {
-                const uint32_t j = i * LT + tid;
+                const uint32_t j = i * T + tid;
                 d[i] = (j < n) ? x[j] : 0.0f;
                 old[i] = (j < n && j < period) ? line[(tail + j) & mask] : 0.0f;
             }
@@ -144,7 +162,7 @@ namespace
             #pragma unroll
             for (uint32_t i = 0; i < E; ++i)                // dsp::sqr2 into the line (LoudnessMeter.cpp:428-436)
             {
-                const uint32_t j = i * LT + tid;
+                const uint32_t j = i * T + tid;
                 d[i] *= d[i];
                 if (j < n)
                 {
@@ -153,12 +171,89 @@ namespace
                 }
             }
             __syncthreads();
+            // Sums of the segments of SEG cells the block writes to, kept beside the line: a segment is always filled from
+            // its first cell on, block after block, so the block that holds the first cell restarts the sum and the
+            // others add to it.  (The sums stand for the cells themselves only where the line was written without a
+            // break; the host says when that holds -- use_seg.)
+            const uint32_t segs = size / SEG, q0 = head / SEG, nseg = (head + n - 1) / SEG - q0 + 1;
+            float *gseg = segsum + size_t(row) * segs;
+            for (uint32_t sgi = wave; sgi < nseg; sgi += NWV)
+            {
+                const uint32_t lo = ((q0 + sgi) * SEG > head) ? (q0 + sgi) * SEG - head : 0u;
+                const uint32_t hi = ((q0 + sgi + 1) * SEG - head < n) ? (q0 + sgi + 1) * SEG - head : n;
+                float v = 0.0f;
+                for (uint32_t j = lo + lane; j < hi; j += 64)
+                    v += sq[j];
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    v += __shfl_xor(v, w);
+                if (lane == 0)
+                {
+                    const uint32_t phys = (q0 + sgi) & (segs - 1);
+                    const float total = ((q0 + sgi) * SEG >= head) ? v : gseg[phys] + v;
+                    segnew[sgi] = total;
+                    gseg[phys] = total;
+                }
+            }
+            // the exact window sum at the refresh point
+            float exact = 0.0f;
+            if (refresh && use_seg)
+            {
+                // whole segments from their sums, the cut segments at both ends cell by cell (the block's own squares
+                // from LDS); positions are counted with one lap added so that the window's start stays positive
+                __syncthreads();                            // segnew[]
+                const uint32_t H = head + size, we = H + refresh_at, ws = we - period;
+                const uint32_t bl = ((ws + SEG - 1) / SEG) * SEG, br = (we / SEG) * SEG;
+                auto cell = [&](uint32_t u) -> float { return (u >= H) ? sq[u - H] : line[u & mask]; };
+                float s = 0.0f;
+                if (bl > br)
+                    for (uint32_t u = ws + tid; u < we; u += T)
+                        s += cell(u);
+                else
+                {
+                    for (uint32_t u = ws + tid; u < bl; u += T)
+                        s += cell(u);
+                    for (uint32_t u = br + tid; u < we; u += T)
+                        s += cell(u);
+                    for (uint32_t q = bl / SEG + tid; q < br / SEG; q += T)
+                        s += (q >= H / SEG) ? segnew[q - H / SEG] : gseg[q & (segs - 1)];
+                }
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    s += __shfl_xor(s, w);
+                __syncthreads();
+                if (lane == 0)
+                    part[wave] = s;
+                __syncthreads();
+                #pragma unroll
+                for (uint32_t w = 0; w < NWV; ++w)
+                    exact += part[w];
+            }
+            else if (refresh)
+            {
+                // cell by cell: the cells behind the block from the line, the block's own squares before the point from LDS
+                const uint32_t from_line = (refresh_at < period) ? period - refresh_at : 0u;
+                exact = window_sum<T>(line, size, (head + refresh_at + size - period) & mask, from_line, part);
+                float s = 0.0f;
+                for (uint32_t j = refresh_at - (period - from_line) + tid; j < refresh_at; j += T)
+                    s += sq[j];
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    s += __shfl_xor(s, w);
+                __syncthreads();
+                if (lane == 0)
+                    part[wave] = s;
+                __syncthreads();
+                #pragma unroll
+                for (uint32_t w = 0; w < NWV; ++w)
+                    exact += part[w];
+            }
             // ms_j = ms_(j-1) + (new_j - old_j): an inclusive scan of every pass inside the wave, the sums of the waves
             // through LDS, then the running sum carried from pass to pass
             #pragma unroll
             for (uint32_t i = 0; i < E; ++i)
             {
-                const uint32_t j = i * LT + tid;
+                const uint32_t j = i * T + tid;
                 if (j < n)
                     d[i] -= (j >= period) ? sq[j - period] : old[i];
                 d[i] = wave_scan(d[i]);
@@ -166,33 +261,47 @@ namespace
                     wtot[i][wave] = d[i];
             }
             __syncthreads();
-            float carry = start;
+            float carry = 0.0f;                             // prefix sums counted from the start of the block
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
+            {
+                float before = carry, total = 0.0f;
+                #pragma unroll
+                for (uint32_t w = 0; w < NWV; w += 4)
+                {
+                    const float4 t = *reinterpret_cast<const float4 *>(&wtot[i][w]);
+                    before += ((w + 0 < wave) ? t.x : 0.0f) + ((w + 1 < wave) ? t.y : 0.0f) +
+                              ((w + 2 < wave) ? t.z : 0.0f) + ((w + 3 < wave) ? t.w : 0.0f);
+                    total += (t.x + t.y) + (t.z + t.w);
+                }
+                d[i] += before;                             // P_j
+                carry += total;
+                if (refresh && refresh_at > 0 && i * T + tid + 1 == refresh_at)
+                    s_before = d[i];
+            }
+            if (refresh)
+                __syncthreads();
+            const float rebase = refresh ? exact - ((refresh_at > 0) ? s_before : 0.0f) : 0.0f;
             float *mb = msbuf + size_t(row) * msbuf_stride;
             #pragma unroll
             for (uint32_t i = 0; i < E; ++i)
             {
-                const uint32_t j = i * LT + tid;
-                const float4 t = *reinterpret_cast<const float4 *>(wtot[i]);
-                static_assert(LT / 64 == 4, "one float4 of wave sums per pass");
-                float before = carry;
-                if (wave > 0) before += t.x;
-                if (wave > 1) before += t.y;
-                if (wave > 2) before += t.z;
-                const float m = avg * (before + d[i]);      // vMS[j] = fAvgCoeff * ms
+                const uint32_t j = i * T + tid;
+                const float base = (refresh && j >= refresh_at) ? rebase : start;
+                const float m = avg * (base + d[i]);        // vMS[j] = fAvgCoeff * ms
                 if (j < n && ch_out != nullptr)
                     mb[j] = m;
                 mix[i] = (mixed > 0) ? fmaf(m, cc.weight, mix[i]) : m * cc.weight;     // fmadd_k3 / mul_k3
-                carry += ((t.x + t.y) + t.z) + t.w;
             }
             if (tid == 0)
-                ms[row] = carry;                            // the running sum goes on with the next block
+                ms[row] = (refresh ? rebase : start) + carry;    // the running sum goes on with the next block
             ++mixed;
         }
         // ssqrt1: sqrt of the non-negative part; then the outputs
         #pragma unroll
         for (uint32_t i = 0; i < E; ++i)
         {
-            const uint32_t j = i * LT + tid;
+            const uint32_t j = i * T + tid;
             mix[i] = (mix[i] > 0.0f) ? sqrtf(mix[i]) : 0.0f;
             if (out != nullptr && j < n)
                 out[size_t(meter) * out_stride + j] = mix[i] * gain;
@@ -212,7 +321,7 @@ namespace
             #pragma unroll
             for (uint32_t i = 0; i < E; ++i)
             {
-                const uint32_t j = i * LT + tid;
+                const uint32_t j = i * T + tid;
                 if (j >= n)
                     continue;
                 const float r = (mb[j] > 0.0f) ? sqrtf(mb[j]) : 0.0f;   // written by this same thread above
@@ -237,6 +346,8 @@ struct mi_loudness_bank
     std::vector<int>      designation;
     mi_biquad_bank_t *filters = nullptr;
     float      *d_data = nullptr, *d_ms = nullptr, *d_flt = nullptr, *d_msbuf = nullptr, *d_loud = nullptr;
+    float      *d_segsum = nullptr;         // [rows][data_size / SEG] sums of the lines' segments
+    uint64_t    raw_left = 0;               // samples for which the window is still re-summed cell by cell
     chan_cfg   *d_cfg = nullptr;
     size_t      cap = 0;
 };
@@ -343,7 +454,7 @@ int mi_loudness_bank_destroy(mi_loudness_bank_t *b)
         return MI_OK;
     mi_biquad_bank_destroy(b->filters);
     (void)hipFree(b->d_data); (void)hipFree(b->d_ms); (void)hipFree(b->d_flt); (void)hipFree(b->d_msbuf);
-    (void)hipFree(b->d_loud); (void)hipFree(b->d_cfg);
+    (void)hipFree(b->d_loud); (void)hipFree(b->d_cfg); (void)hipFree(b->d_segsum);
     delete b;
     return MI_OK;
 }
@@ -364,6 +475,9 @@ int mi_loudness_bank_clear(mi_loudness_bank_t *b, void *stream)                /
         MI_HIP_CHECK(hipMemset2DAsync(b->d_data + size_t(c) * b->data_size, size_t(b->channels) * b->data_size * sizeof(float), 0,
                                       size_t(b->data_size) * sizeof(float), b->meters, st));
         MI_HIP_CHECK(hipMemset2DAsync(b->d_ms + c, b->channels * sizeof(float), 0, sizeof(float), b->meters, st));
+        const size_t segs = b->data_size / SEG;
+        MI_HIP_CHECK(hipMemset2DAsync(b->d_segsum + size_t(c) * segs, size_t(b->channels) * segs * sizeof(float), 0,
+                                      segs * sizeof(float), b->meters, st));
     }
     return MI_OK;
 }
@@ -379,9 +493,14 @@ int mi_loudness_bank_set_sample_rate(mi_loudness_bank_t *b, uint32_t sample_rate
     MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_data), size_t(b->rows) * len * sizeof(float)));
     MI_HIP_CHECK(hipMemsetAsync(b->d_data, 0, size_t(b->rows) * len * sizeof(float), mi::as_stream(stream)));
     MI_HIP_CHECK(hipMemsetAsync(b->d_ms, 0, b->rows * sizeof(float), mi::as_stream(stream)));
+    (void)hipFree(b->d_segsum);
+    b->d_segsum = nullptr;
+    MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_segsum), size_t(b->rows) * (len / SEG) * sizeof(float)));
+    MI_HIP_CHECK(hipMemsetAsync(b->d_segsum, 0, size_t(b->rows) * (len / SEG) * sizeof(float), mi::as_stream(stream)));
     b->sample_rate = sample_rate;
     b->data_size = len;
     b->head = 0;
+    b->raw_left = 0;
     b->upd_filters = b->upd_time = true;
     return mi_loudness_bank_clear(b, stream);
 }
@@ -447,6 +566,9 @@ int mi_loudness_bank_set_active(mi_loudness_bank_t *b, uint32_t channel, int act
         MI_HIP_CHECK(hipMemset2DAsync(b->d_data + size_t(channel) * b->data_size, size_t(b->channels) * b->data_size * sizeof(float), 0,
                                       size_t(b->data_size) * sizeof(float), b->meters, st));
         MI_HIP_CHECK(hipMemset2DAsync(b->d_ms + channel, b->channels * sizeof(float), 0, sizeof(float), b->meters, st));
+        const size_t segs = b->data_size / SEG;
+        MI_HIP_CHECK(hipMemset2DAsync(b->d_segsum + size_t(channel) * segs, size_t(b->channels) * segs * sizeof(float), 0,
+                                      segs * sizeof(float), b->meters, st));
     }
     return MI_OK;
 }
@@ -460,6 +582,8 @@ int mi_loudness_bank_set_bound(mi_loudness_bank_t *b, uint32_t channel, int boun
         return MI_OK;
     b->cfg[channel].unbound = unbound;
     b->cfg_dirty = true;
+    if (!unbound)                                           // its line was not written for a while: the segment sums of the
+        b->raw_left = uint64_t(b->data_size) + SEG;         // bank are trusted again once the line has been written all round
     const int run = (b->cfg[channel].enabled && !unbound) ? 1 : 0;
     for (uint32_t m = 0; m < b->meters; ++m)
     {
@@ -490,21 +614,14 @@ static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, co
     if (r != MI_OK)
         return r;
     const uint32_t room = b->data_size - b->period;         // cells that may be written before the window's tail is reached
+    const uint32_t interval = std::max<uint32_t>(BUFFER_SIZE << 2, b->period >> 2);     // between exact re-summations (:496-503)
     size_t offset = 0;
     while (offset < count)
     {
-        if (b->ms_refresh == 0)                             // refresh_rms(), LoudnessMeter.cpp:381-407
-        {
-            hipLaunchKernelGGL(loudness_refresh_kernel, dim3(b->rows), dim3(LT), 0, st, b->d_ms, b->d_data, b->data_size, b->head,
-                               b->period, b->d_cfg, b->channels);
-            MI_HIP_CHECK(hipGetLastError());
-            const uint32_t a = BUFFER_SIZE << 2, q = b->period >> 2;
-            b->ms_refresh = (a > q) ? a : q;
-        }
         size_t n = count - offset;
-        n = std::min<size_t>(n, b->ms_refresh);
-        n = std::min<size_t>(n, MAX_BLOCK);
+        n = std::min<size_t>(n, MAX_BLOCK);                 // <= interval: at most one re-summation falls into a block
         n = std::min<size_t>(n, (room > BUFFER_SIZE) ? room : BUFFER_SIZE);
+        const uint32_t refresh_at = (b->ms_refresh < n) ? b->ms_refresh : UINT32_MAX;
         if (n > b->cap)
         {
             (void)hipFree(b->d_flt); (void)hipFree(b->d_msbuf);
@@ -519,15 +636,18 @@ static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, co
         r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
         if (r != MI_OK)
             return r;
-        auto kernel = (n <= 2 * LT) ? loudness_block_kernel<2> : (n <= 4 * LT) ? loudness_block_kernel<4> :
-                      (n <= 8 * LT) ? loudness_block_kernel<8> : loudness_block_kernel<MAX_BLOCK / LT>;
-        hipLaunchKernelGGL(kernel, dim3(b->meters), dim3(LT), 0, st,
+        // 512 threads x 8 passes for the long blocks: 120 VGPRs, two workgroups on a CU (1024 x 4 fits only one and is slower)
+        auto kernel = (n <= 512) ? loudness_block_kernel<256, 2> : (n <= 1024) ? loudness_block_kernel<256, 4> :
+                      (n <= 2048) ? loudness_block_kernel<512, 4> : loudness_block_kernel<512, MAX_BLOCK / 512>;
+        hipLaunchKernelGGL(kernel, dim3(b->meters), dim3((n <= 1024) ? 256 : 512), 0, st,
                            out ? out + offset : nullptr, ch_out ? ch_out + offset : nullptr, out_stride, b->d_flt, b->cap,
                            b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, b->d_msbuf, b->cap, b->d_cfg,
-                           b->channels, uint32_t(n), gain, remember ? b->d_loud : static_cast<float *>(nullptr));
+                           b->channels, uint32_t(n), gain, remember ? b->d_loud : static_cast<float *>(nullptr), refresh_at,
+                           b->d_segsum, (b->raw_left == 0) ? 1 : 0);
         MI_HIP_CHECK(hipGetLastError());
+        b->raw_left = (b->raw_left > n) ? b->raw_left - n : 0;
         b->head = (b->head + uint32_t(n)) & (b->data_size - 1);
-        b->ms_refresh -= uint32_t(n);
+        b->ms_refresh = (refresh_at != UINT32_MAX) ? interval - (uint32_t(n) - refresh_at) : b->ms_refresh - uint32_t(n);
         offset += n;
     }
     return MI_OK;
@@ -680,55 +800,59 @@ namespace
         }
     }
 
-    // One piece of a block quarter, one workgroup per meter: the held loudness value into the output row
-    // (ILUFSMeter.cpp:386-387), vBlock[row][part] += the sum of squares of every enabled row's filtered samples
-    // (:372-384), then -- when the piece ends the quarter -- the gating arithmetic of a complete block and the reset of
-    // the quarter that is filled next (:402-466).
+    // The pieces of one process() call, one workgroup per meter.  A piece is a run of samples inside one quarter of a
+    // gating block; the weighting filter's launch (biquad_bank_sumsq) has left the sum of squares of every row and piece
+    // in seg[row][piece].  Piece by piece: the held loudness value into the output row (ILUFSMeter.cpp:386-387),
+    // vBlock[row][part] += the piece's sum for every enabled row (:372-384), then -- when the piece ends the quarter --
+    // the gating arithmetic of a complete block and the reset of the quarter that is filled next (:402-466).
+    struct ilufs_piece { uint32_t offset, n, part; int gate, zero_part; };
+    struct ilufs_pieces { uint32_t count; ilufs_piece p[4]; };
+
     __global__ __launch_bounds__(LT)
-    void ilufs_piece_kernel(float *block, uint32_t part, const float *__restrict__ flt, size_t flt_stride, uint32_t n,
-                            const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
-                            ilufs_state *st, float gain, int gate, int zero_part, float *hist, uint32_t size, uint32_t ms_int,
-                            float avg)
+    void ilufs_call_kernel(float *block, float *seg, const ilufs_pieces pieces,
+                           const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
+                           ilufs_state *st, float gain, float *hist, uint32_t size, uint32_t ms_int, float avg)
     {
         __shared__ float s_sum[LT];
         __shared__ uint32_t s_cnt[LT];
         __shared__ float s_val;
         const uint32_t meter = blockIdx.x, tid = threadIdx.x;
-        if (out != nullptr)
+        for (uint32_t k = 0; k < pieces.count; ++k)
         {
-            const float v = st[meter].loudness * gain;
-            for (uint32_t i = tid; i < n; i += LT)
-                out[size_t(meter) * out_stride + i] = v;
-        }
-        for (uint32_t c = 0; c < channels && n > 0; ++c)
-        {
-            if (!cfg[c].enabled)
-                continue;
-            const uint32_t row = meter * channels + c;
-            const float *x = flt + size_t(row) * flt_stride;
-            float s = 0.0f;
-            for (uint32_t i = tid; i < n; i += LT)
-                s = fmaf(x[i], x[i], s);
-            s_sum[tid] = s;
-            __syncthreads();
-            for (int w = LT / 2; w > 0; w >>= 1)
+            const ilufs_piece pc = pieces.p[k];
+            if (out != nullptr && pc.n > 0)
             {
-                if (int(tid) < w)
-                    s_sum[tid] += s_sum[tid + w];
-                __syncthreads();
+                const float v = st[meter].loudness * gain;
+                float *o = out + size_t(meter) * out_stride + pc.offset;
+                // 16-byte stores over the aligned middle of the run
+                const uint32_t lead = uint32_t((4u - (uint32_t(reinterpret_cast<uintptr_t>(o) >> 2) & 3u)) & 3u);
+                const uint32_t head = (lead < pc.n) ? lead : pc.n, quads = (pc.n - head) >> 2;
+                if (tid < head)
+                    o[tid] = v;
+                float4 *o4 = reinterpret_cast<float4 *>(o + head);
+                for (uint32_t i = tid; i < quads; i += LT)
+                    o4[i] = make_float4(v, v, v, v);
+                for (uint32_t i = head + 4u * quads + tid; i < pc.n; i += LT)
+                    o[i] = v;
             }
-            if (tid == 0)
-                block[row * 4 + part] += s_sum[0];
+            if (pc.n > 0)
+                for (uint32_t c = tid; c < channels; c += LT)
+                    if (cfg[c].enabled)
+                    {
+                        const uint32_t row = meter * channels + c;
+                        block[row * 4 + pc.part] += seg[row * 4 + k];
+                    }
+            __syncthreads();
+            if (pc.gate)
+                ilufs_gate(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);
+            __syncthreads();
+            if (pc.zero_part >= 0)
+                for (uint32_t c = tid; c < channels; c += LT)
+                    block[(meter * channels + c) * 4 + uint32_t(pc.zero_part)] = 0.0f;
             __syncthreads();
         }
-        if (gate)
-            ilufs_gate(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);   // thread 0 reads its own sums
-        if (zero_part >= 0)
-        {
-            __syncthreads();
-            for (uint32_t c = tid; c < channels; c += LT)
-                block[(meter * channels + c) * 4 + uint32_t(zero_part)] = 0.0f;
-        }
+        for (uint32_t i = tid; i < channels * 4; i += LT)   // consumed: the next call's filter launch adds to zeros
+            seg[size_t(meter) * channels * 4 + i] = 0.0f;
     }
 } // namespace
 
@@ -741,10 +865,9 @@ struct mi_ilufs_bank
     bool        upd_filters = true, upd_time = true, cfg_dirty = true, blk_full = false;
     std::vector<chan_cfg> cfg;
     mi_biquad_bank_t *filters = nullptr;
-    float      *d_block = nullptr, *d_hist = nullptr, *d_flt = nullptr;
+    float      *d_block = nullptr, *d_hist = nullptr, *d_seg = nullptr;
     ilufs_state *d_state = nullptr;
     chan_cfg   *d_cfg = nullptr;
-    size_t      cap = 0;
 };
 
 namespace
@@ -752,6 +875,7 @@ namespace
     int ilufs_clear_blocks(mi_ilufs_bank *b, hipStream_t st)           // clear_block_buffers(), ILUFSMeter.cpp:515-526
     {
         MI_HIP_CHECK(hipMemsetAsync(b->d_block, 0, size_t(b->rows) * 4 * sizeof(float), st));
+        MI_HIP_CHECK(hipMemsetAsync(b->d_seg, 0, size_t(b->rows) * 4 * sizeof(float), st));
         if (b->d_hist != nullptr)
             MI_HIP_CHECK(hipMemsetAsync(b->d_hist, 0, size_t(b->meters) * b->ms_size * sizeof(float), st));
         b->blk_full = false;
@@ -837,6 +961,8 @@ int mi_ilufs_bank_create(mi_ilufs_bank_t **bank, uint32_t meters, uint32_t chann
     if (r == MI_OK)
     {
         e = hipMalloc(reinterpret_cast<void **>(&b->d_block), size_t(b->rows) * 4 * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_seg), size_t(b->rows) * 4 * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(b->d_seg, 0, size_t(b->rows) * 4 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_state), meters * sizeof(ilufs_state));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_cfg), channels * sizeof(chan_cfg));
         if (e == hipSuccess) e = hipMemset(b->d_block, 0, size_t(b->rows) * 4 * sizeof(float));
@@ -856,7 +982,7 @@ int mi_ilufs_bank_destroy(mi_ilufs_bank_t *b)
     if (b == nullptr)
         return MI_OK;
     mi_biquad_bank_destroy(b->filters);
-    (void)hipFree(b->d_block); (void)hipFree(b->d_hist); (void)hipFree(b->d_flt); (void)hipFree(b->d_state); (void)hipFree(b->d_cfg);
+    (void)hipFree(b->d_block); (void)hipFree(b->d_hist); (void)hipFree(b->d_seg); (void)hipFree(b->d_state); (void)hipFree(b->d_cfg);
     delete b;
     return MI_OK;
 }
@@ -981,48 +1107,51 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_
     // call starts with the flag cleared, and gating blocks are evaluated only from the point where the quarter counter
     // wraps inside the same call.  Reproduced so that a host that switches banks sees the same meter readings.
     b->blk_full = false;
+    // Up to four pieces (runs inside one quarter of a gating block) per pair of launches: the weighting filter walks
+    // them as one block and leaves the pieces' sums of squares, the meters' kernel does the bookkeeping piece by piece.
     size_t offset = 0;
     while (offset < count)
     {
-        size_t n = std::min<size_t>(count - offset, b->block_size - b->block_offset);
-        n = std::min<size_t>(n, 16384);
-        if (n > 0)
+        ilufs_pieces pcs;
+        pcs.count = 0;
+        uint32_t ends[3] = { 0, 0, 0 };
+        size_t taken = 0;
+        while (pcs.count < 4 && offset + taken < count && taken < (size_t(1) << 30))
         {
-            if (n > b->cap)
-            {
-                (void)hipFree(b->d_flt);
-                b->d_flt = nullptr;
-                b->cap = 0;
-                const size_t cap = std::min<size_t>(std::max<size_t>(n, 4096), 16384);
-                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_flt), size_t(b->rows) * cap * sizeof(float)));
-                b->cap = cap;
-            }
-            r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
-            if (r != MI_OK)
-                return r;
+            const size_t n = std::min<size_t>(std::min<size_t>(count - offset - taken, b->block_size - b->block_offset),
+                                              (size_t(1) << 30) - taken);
+            ilufs_piece &pc = pcs.p[pcs.count];
+            pc.offset = uint32_t(taken);
+            pc.n = uint32_t(n);
+            pc.part = b->block_part;
+            pc.gate = 0;
+            pc.zero_part = -1;
             b->block_offset += uint32_t(n);
-        }
-        int gate = 0, zero_part = -1;
-        const uint32_t part = b->block_part;
-        if (b->block_offset >= b->block_size)               // a quarter of a gating block is complete
-        {
-            b->block_offset = 0;
-            if (++b->block_part >= 4)
+            taken += n;
+            if (b->block_offset >= b->block_size)           // a quarter of a gating block is complete
             {
-                b->block_part = 0;
-                b->blk_full = true;
+                b->block_offset = 0;
+                if (++b->block_part >= 4)
+                {
+                    b->block_part = 0;
+                    b->blk_full = true;
+                }
+                pc.gate = b->blk_full ? 1 : 0;
+                pc.zero_part = int(b->block_part);
             }
-            gate = b->blk_full ? 1 : 0;
-            zero_part = int(b->block_part);
+            if (pcs.count < 3)
+                ends[pcs.count] = uint32_t(taken);
+            ++pcs.count;
         }
-        if (n > 0 || zero_part >= 0)
-        {
-            hipLaunchKernelGGL(ilufs_piece_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_block, part, b->d_flt, b->cap, uint32_t(n),
-                               b->d_cfg, b->channels, out ? out + offset : nullptr, out_stride, b->d_state, gain, gate, zero_part,
-                               b->d_hist, b->ms_size, b->ms_int, b->avg);
-            MI_HIP_CHECK(hipGetLastError());
-        }
-        offset += n;
+        for (uint32_t k = pcs.count; k < 3; ++k)
+            ends[k] = uint32_t(taken);
+        r = mi::biquad_bank_sumsq(b->filters, in + offset, in_stride, taken, ends, b->d_seg, st);
+        if (r != MI_OK)
+            return r;
+        hipLaunchKernelGGL(ilufs_call_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_block, b->d_seg, pcs, b->d_cfg, b->channels,
+                           out ? out + offset : nullptr, out_stride, b->d_state, gain, b->d_hist, b->ms_size, b->ms_int, b->avg);
+        MI_HIP_CHECK(hipGetLastError());
+        offset += taken;
     }
     return MI_OK;
 }

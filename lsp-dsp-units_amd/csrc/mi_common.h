@@ -46,6 +46,11 @@ namespace mi
     int         biquad_chain_process(const biquad_chain_stage *stages, int count, const float *in, size_t in_stride,
                                      size_t samples, hipStream_t st);
 
+    // A biquad bank over a block without an output (biquad.hip): sums[channel * 4 + s] += the sum of the squares of the
+    // filtered samples of segment s = [seg_end[s - 1], seg_end[s]), seg_end[3] = samples.  The meters' weighting filter.
+    int         biquad_bank_sumsq(mi_biquad_bank_t *bank, const float *in, size_t in_stride, size_t samples,
+                                  const uint32_t seg_end[3], float *sums, hipStream_t st);
+
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);
 

@@ -128,6 +128,44 @@ def test_disabled_channel_filter_freezes_until_reenabled(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("blocks", [(4096,) * 24, (4096, 1000, 4096, 3333, 4096, 4095, 2049, 4096, 777) * 3])
+def test_exact_resummation_inside_long_runs(gpu, blocks):
+    """The exact re-summation of the window (refresh_rms(), LoudnessMeter.cpp:381-407) falls INSIDE the blocks here and
+    is served from the segment sums kept beside the lines: several laps of the 16384-cell lines, block starts on and off
+    the segment grid, against the oracle that re-sums cell by cell on the reference's schedule.  The third channel loses
+    its input for a while (its line stands still, its window is still re-summed) and gets it back (the segment sums of
+    its line are stale for one lap: the bank re-sums cell by cell until the line has been written all round)."""
+    sr, M, K = 48000, 2, 3
+    rng = np.random.default_rng(16)
+    bank = gpu.LoudnessBank(M, K, 200.0)
+    refs = [ol.LoudnessMeter(K, 200.0) for _ in range(M)]
+    for obj in [bank] + refs:
+        obj.set_sample_rate(sr); obj.set_period(200.0)
+        obj.set_designation(0, ol.CHANNEL_LEFT); obj.set_designation(1, ol.CHANNEL_RIGHT); obj.set_designation(2, ol.CHANNEL_CENTER)
+        obj.set_link(0, 0.0); obj.set_link(2, 0.5)
+    level = 0.0
+    for step, n in enumerate(blocks):
+        if step == 5 or step == 17:
+            for obj in [bank] + refs:
+                obj.set_bound(2, False)
+        if step == 9 or step == 19:
+            for obj in [bank] + refs:
+                obj.set_bound(2, True)
+        amp = 0.3 if (step // 4) % 2 == 0 else 0.02             # level steps: a drifting running sum would show
+        x = (rng.standard_normal((M * K, n)) * amp).astype(np.float32)
+        out = gpu.DeviceBuffer((M, n)); ch = gpu.DeviceBuffer.from_host(np.full((M * K, n), -1.0, np.float32))
+        bank.process(out, ch, gpu.DeviceBuffer.from_host(x), n)
+        y, yc = out.download(), ch.download()
+        for m in range(M):
+            o, c = refs[m].process(x[m * K:(m + 1) * K])
+            level = max(level, float(o.max()))
+            assert np.abs(y[m] - o).max() <= TOL * level, (step, m, np.abs(y[m] - o).max() / level)
+            for k in range(K):
+                if refs[m].ch[k]["bound"]:
+                    assert np.abs(yc[m * K + k] - c[k]).max() <= TOL * level, (step, m, k)
+    bank.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_operation_sequences(gpu, seed):
     """Differential stress of the momentary / short-term meter bank: period, weighting, designation, link and activity
@@ -208,6 +246,10 @@ def test_random_operation_sequences(gpu, seed):
             k, a = int(rng.integers(0, K)), bool(rng.integers(0, 2))
             for obj in [bank] + refs:
                 obj.set_active(k, a)
+        elif op == "bound":
+            k, a = int(rng.integers(0, K)), bool(rng.integers(0, 2))
+            for obj in [bank] + refs:
+                obj.set_bound(k, a)
         else:
             for obj in [bank] + refs:
                 obj.clear()
