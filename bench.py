@@ -320,7 +320,10 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
             return e
         n = KERNEL_PROBES + 1
         starts, stops = [new_event() for _ in range(n)], [new_event() for _ in range(n)]
+        sync_probes = os.environ.get("MI_BENCH_PROBE_SYNC", "0") == "1"
         for j in range(n):
+            if sync_probes:
+                torch.cuda.synchronize()
             mi.check(mi.lib.mi_dspu_profile_next_launch(starts[j], stops[j]))
             step(warmup + j)
         torch.cuda.synchronize()
