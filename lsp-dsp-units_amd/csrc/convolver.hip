@@ -624,6 +624,18 @@ namespace mi
         b->xf_any = left;
     }
 
+    // what the launches of a call take by value from the host: ring slot, fill of the open frame, the responses in force
+    uint64_t convolver_bank_positions(const void *bank)
+    {
+        const mi_convolver_bank *b = static_cast<const mi_convolver_bank *>(bank);
+        uint64_t h = position_mix(uint64_t(b->slot), uint64_t(b->off));
+        h = position_mix(h, (uint64_t(b->live) << 0) | (uint64_t(b->yt_pending) << 1) | (uint64_t(b->frame_open) << 2) |
+                            (uint64_t(b->xf_any) << 3) | (uint64_t(b->xfade_active) << 4));
+        h = position_mix(h, (uint64_t(uint32_t(b->cv)) << 0) | (uint64_t(uint32_t(b->nv)) << 8) | (uint64_t(uint32_t(b->fr_old)) << 16) |
+                            (uint64_t(uint32_t(b->fr_new) & 0xff) << 24));
+        return h;
+    }
+
     int convolver_process_delayed_frame(mi_convolver_bank_t *b, float *out, const float *in, size_t out_stride,
                                         size_t in_stride, const delay_view &dl, hipStream_t st)
     {
@@ -957,6 +969,11 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
     MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_convolver_bank_process: NULL buffer");
     MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL, "mi_convolver_bank_process: stride shorter than the block");
     hipStream_t st = mi::as_stream(stream);
+    {
+        const int rc = mi::capture_touch(st, b, "convolver", mi::convolver_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     if (!b->live)                                                // Convolver.cpp:219-223
     {
         MI_HIP_CHECK(hipMemset2DAsync(out, out_stride * sizeof(float), 0, samples * sizeof(float), b->channels, st));

@@ -254,6 +254,16 @@ namespace mi
     {
         b->head = uint32_t((size_t(b->head) + samples) % b->size);
     }
+
+    // what the launches of a call take by value from the host: the head and the delays
+    uint64_t delay_bank_positions(const void *bank)
+    {
+        const mi_delay_bank *b = static_cast<const mi_delay_bank *>(bank);
+        uint64_t h = b->head;
+        for (uint32_t d : b->delay)
+            h = position_mix(h, d);
+        return h;
+    }
 } // namespace mi
 
 extern "C" {
@@ -329,6 +339,9 @@ int mi_delay_bank_append(mi_delay_bank_t *b, const float *in, size_t count, size
     MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "mi_delay_bank_append: bad argument");
     if (count == 0)
         return MI_OK;
+    const int r = mi::capture_touch(mi::as_stream(stream), b, "delay", mi::delay_bank_positions);
+    if (r != MI_OK)
+        return r;
     return append_block(b, in, in_stride, count, mi::as_stream(stream));
 }
 
@@ -342,7 +355,10 @@ int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_
     MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_delay_bank_process: NULL buffer");
     MI_REQUIRE(gain_mode != G_VECTOR || gain_vec != nullptr, MI_EINVAL, "mi_delay_bank_process: NULL gain vector");
     hipStream_t st = mi::as_stream(stream);
-    int r = sync_delays(b, st);
+    int r = mi::capture_touch(st, b, "delay", mi::delay_bank_positions);
+    if (r != MI_OK)
+        return r;
+    r = sync_delays(b, st);
     if (r != MI_OK)
         return r;
     // The reference alternates "push to_do samples / pull to_do samples" in pieces of at most size - delay
@@ -416,7 +432,10 @@ int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *i
         return MI_OK;
     MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_delay_bank_process_ramping: NULL buffer");
     hipStream_t st = mi::as_stream(stream);
-    int r = sync_delays(b, st);
+    int r = mi::capture_touch(st, b, "delay", mi::delay_bank_positions);
+    if (r != MI_OK)
+        return r;
+    r = sync_delays(b, st);
     if (r != MI_OK)
         return r;
     std::vector<uint32_t> nd(new_delays, new_delays + b->channels);
@@ -453,6 +472,8 @@ struct mi_ring_bank
     float      *d_ring = nullptr;
     bool        host_shared = false;        // storage is pinned host memory mapped into the device
 };
+
+static uint64_t ring_bank_positions(const void *bank) { return static_cast<const mi_ring_bank *>(bank)->head; }
 
 extern "C" {
 
@@ -516,6 +537,11 @@ int mi_ring_bank_destroy(mi_ring_bank_t *b)
 int mi_ring_bank_fill(mi_ring_bank_t *b, float value, void *stream)    // clear() / fill(), RingBuffer.cpp:108-120
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ring_bank_fill: NULL bank");
+    {
+        const int r = mi::capture_touch(mi::as_stream(stream), b, "ring buffer", ring_bank_positions);
+        if (r != MI_OK)
+            return r;
+    }
     b->head = 0;
     const size_t n = size_t(b->channels) * b->capacity;
     hipLaunchKernelGGL(fill_kernel, dim3(uint32_t((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256)), dim3(256), 0,
@@ -531,6 +557,11 @@ int mi_ring_bank_append(mi_ring_bank_t *b, const float *in, size_t count, size_t
         *appended = (count > b->capacity) ? b->capacity : count;        // RingBuffer.cpp:78-83,105
     if (count == 0)
         return MI_OK;
+    {
+        const int r = mi::capture_touch(mi::as_stream(stream), b, "ring buffer", ring_bank_positions);
+        if (r != MI_OK)
+            return r;
+    }
     const bool whole = count > b->capacity;                             // keeps the newest `capacity` from cell 0 on,
     if (whole)                                                          // and the head stays there (RingBuffer.cpp:78-83)
     {
@@ -565,6 +596,11 @@ int mi_ring_bank_get(mi_ring_bank_t *b, float *out, size_t offset, size_t count,
         *read = got;
     if (count == 0)
         return MI_OK;
+    {
+        const int r = mi::capture_touch(mi::as_stream(stream), b, "ring buffer", ring_bank_positions);
+        if (r != MI_OK)
+            return r;
+    }
     hipLaunchKernelGGL(ring_get_kernel, grid_for(count, b->channels), dim3(256), 0, mi::as_stream(stream),
                        out, out_stride, b->d_ring, b->capacity, b->head, offset, count);
     MI_HIP_CHECK(hipGetLastError());

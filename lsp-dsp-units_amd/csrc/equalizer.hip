@@ -448,6 +448,19 @@ int mi_equalizer_bank_reset(mi_equalizer_bank_t *b, void *stream)       // Equal
     return r;
 }
 
+// what the launches of a call take by value from the host: the positions of the delay line, the convolver and the
+// spectral processor behind the current mode, and how far the cleared line has been primed
+static uint64_t equalizer_bank_positions(const void *bank)
+{
+    const mi_equalizer_bank *b = static_cast<const mi_equalizer_bank *>(bank);
+    uint64_t h = mi::position_mix(uint64_t(b->mode), b->primed);
+    h = mi::position_mix(h, b->flags);
+    if (b->delay != nullptr) h = mi::position_mix(h, mi::delay_bank_positions(b->delay));
+    if (b->conv != nullptr)  h = mi::position_mix(h, mi::convolver_bank_positions(b->conv));
+    if (b->spm != nullptr)   h = mi::position_mix(h, mi::spectral_bank_positions(b->spm));
+    return h;
+}
+
 int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream)
 {
@@ -456,6 +469,11 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
         return MI_OK;
     MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_equalizer_bank_process: NULL buffer");
     hipStream_t st = mi::as_stream(stream);
+    {
+        const int rc = mi::capture_touch(st, b, "equalizer", equalizer_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     int r = reconfigure(b, st);
     if (r != MI_OK)
         return r;

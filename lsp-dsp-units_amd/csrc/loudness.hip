@@ -601,12 +601,25 @@ int mi_loudness_bank_latency(const mi_loudness_bank_t *b, uint32_t *samples)
     return MI_OK;
 }
 
+// what the launches of a call take by value from the host: head of the lines, distance to the next exact re-summation
+static uint64_t loudness_bank_positions(const void *bank)
+{
+    const mi_loudness_bank *b = static_cast<const mi_loudness_bank *>(bank);
+    uint64_t h = mi::position_mix(b->head, b->ms_refresh);
+    return mi::position_mix(h, (uint64_t(b->raw_left != 0) << 2) | (uint64_t(b->upd_time || b->upd_filters) << 1) | uint64_t(b->cfg_dirty));
+}
+
 static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, const float *in, size_t count,
                             size_t out_stride, size_t in_stride, float gain, bool remember, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_process: NULL bank");
     if (count == 0)
         return MI_OK;
+    {
+        const int rc = mi::capture_touch(mi::as_stream(stream), b, "loudness meter", loudness_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_loudness_bank_process: NULL input");
     MI_REQUIRE(b->sample_rate != 0 && b->d_data != nullptr, MI_ESTATE, "mi_loudness_bank_process: set_sample_rate() first");
     hipStream_t st = mi::as_stream(stream);
@@ -1091,12 +1104,25 @@ int mi_ilufs_bank_set_active(mi_ilufs_bank_t *b, uint32_t channel, int active)
     return MI_OK;
 }
 
+// what the launches of a call take by value from the host: the position inside the gating block
+static uint64_t ilufs_bank_positions(const void *bank)
+{
+    const mi_ilufs_bank *b = static_cast<const mi_ilufs_bank *>(bank);
+    uint64_t h = mi::position_mix(b->block_offset, b->block_part);
+    return mi::position_mix(h, (uint64_t(b->upd_time || b->upd_filters) << 1) | uint64_t(b->cfg_dirty));
+}
+
 int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_t count, size_t out_stride,
                           size_t in_stride, float gain, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_process: NULL bank");
     if (count == 0)
         return MI_OK;
+    {
+        const int rc = mi::capture_touch(mi::as_stream(stream), b, "integrated loudness meter", ilufs_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_ilufs_bank_process: NULL input");
     MI_REQUIRE(b->sample_rate != 0 && b->d_hist != nullptr, MI_ESTATE, "mi_ilufs_bank_process: set_sample_rate() first");
     hipStream_t st = mi::as_stream(stream);

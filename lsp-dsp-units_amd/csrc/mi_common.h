@@ -22,6 +22,17 @@ namespace mi
     // consumes them (hipExtLaunchKernelGGL records them at the kernel's own begin/end).
     void        take_profile_events(hipEvent_t *start, hipEvent_t *stop);
 
+    // hipGraph capture of a bank that keeps ring positions on the host (runtime.hip): called at the top of
+    // its process() with a function that packs those positions; on a stream that is being captured the positions are
+    // noted at the bank's first call and compared again at mi_dspu_graph_end_capture.  MI_OK when the stream is not
+    // capturing; MI_ESTATE when it is captured behind the library's back.
+    typedef uint64_t (*position_fn)(const void *bank);
+    int         capture_touch(hipStream_t st, const void *bank, const char *what, position_fn fn);
+    uint64_t    delay_bank_positions(const void *bank);         // delay.hip
+    uint64_t    convolver_bank_positions(const void *bank);     // convolver.hip
+    uint64_t    spectral_bank_positions(const void *bank);      // spectral.hip
+    inline uint64_t position_mix(uint64_t h, uint64_t v) { return (h ^ v) * 0x100000001b3ull + 0x9e3779b97f4a7c15ull; }
+
     // Launch of a hot-path kernel: the extended launch (which records the armed events at the kernel's own begin and end)
     // only when events are armed -- it is not allowed on a capturing stream; the plain launch is, so a steady-state
     // process() call can be captured into a hipGraph.

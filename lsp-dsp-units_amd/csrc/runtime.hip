@@ -1,5 +1,8 @@
 // Device/stream/memory plumbing of the C-ABI (include/mi_dspu.h).
 #include "mi_common.h"
+#include <vector>
+#include <mutex>
+#include <map>
 
 namespace mi
 {
@@ -27,6 +30,35 @@ namespace mi
         tl_stop  = nullptr;
     }
 } // namespace mi
+
+namespace
+{
+    struct capture_note { const void *bank; const char *what; mi::position_fn fn; uint64_t sig; };
+    std::mutex g_capture_lock;
+    std::map<hipStream_t, std::vector<capture_note>> g_captures;       // streams being captured through mi_dspu_graph_begin_capture
+}
+
+namespace mi
+{
+    int capture_touch(hipStream_t st, const void *bank, const char *what, position_fn fn)
+    {
+        if (st == nullptr)
+            return MI_OK;
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &status) != hipSuccess || status != hipStreamCaptureStatusActive)
+            return MI_OK;
+        std::lock_guard<std::mutex> lock(g_capture_lock);
+        auto it = g_captures.find(st);
+        if (it == g_captures.end())
+            return fail(MI_ESTATE, "the %s bank keeps ring positions on the host: capture it through mi_dspu_graph_begin_capture / "
+                        "end_capture, which check that the captured calls bring it back to its starting positions", what);
+        for (const capture_note &n : it->second)
+            if (n.bank == bank)
+                return MI_OK;
+        it->second.push_back(capture_note{ bank, what, fn, fn(bank) });
+        return MI_OK;
+    }
+}
 
 extern "C" {
 
@@ -168,6 +200,8 @@ int mi_dspu_graph_begin_capture(void *stream)
 {
     MI_REQUIRE(stream != nullptr, MI_EINVAL, "mi_dspu_graph_begin_capture: the NULL stream cannot be captured");
     MI_HIP_CHECK(hipStreamBeginCapture(mi::as_stream(stream), hipStreamCaptureModeThreadLocal));
+    std::lock_guard<std::mutex> lock(g_capture_lock);
+    g_captures[mi::as_stream(stream)].clear();
     return MI_OK;
 }
 
@@ -176,7 +210,26 @@ int mi_dspu_graph_end_capture(void *stream, void **graph_exec)
     MI_REQUIRE(graph_exec != nullptr, MI_EINVAL, "mi_dspu_graph_end_capture: NULL result pointer");
     *graph_exec = nullptr;
     hipGraph_t graph = nullptr;
+    std::vector<capture_note> notes;
+    {
+        std::lock_guard<std::mutex> lock(g_capture_lock);
+        auto it = g_captures.find(mi::as_stream(stream));
+        if (it != g_captures.end())
+        {
+            notes.swap(it->second);
+            g_captures.erase(it);
+        }
+    }
     MI_HIP_CHECK(hipStreamEndCapture(mi::as_stream(stream), &graph));
+    // A bank that keeps ring positions on the host passes them to its kernels by value: the captured launches are right
+    // for every replay only if the sequence brings each such bank back to the positions it started from.
+    for (const capture_note &n : notes)
+        if (n.fn(n.bank) != n.sig)
+        {
+            (void)hipGraphDestroy(graph);
+            return mi::fail(MI_ESTATE, "mi_dspu_graph_end_capture: the %s bank does not return to its starting positions over the "
+                            "captured calls -- capture a whole number of its position periods (DESIGN.md 3.9)", n.what);
+        }
     hipGraphExec_t exec = nullptr;
     const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);

@@ -437,6 +437,16 @@ struct mi_spectral_bank
     const float2 *d_tw = nullptr;
 };
 
+namespace mi
+{
+    // what the launches of a call take by value from the host: the fill of the frame being received
+    uint64_t spectral_bank_positions(const void *bank)
+    {
+        const mi_spectral_bank *b = static_cast<const mi_spectral_bank *>(bank);
+        return position_mix(b->offset, uint64_t(b->update));
+    }
+}
+
 namespace
 {
     #define MI_LOGH_SWITCH(lh, CALL)                    \
@@ -705,6 +715,11 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
         return MI_OK;
     MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_spectral_bank_process: NULL input");
     hipStream_t st = mi::as_stream(stream);
+    {
+        const int rc = mi::capture_touch(st, b, "spectral processor", mi::spectral_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     if (b->update)
     {
         const int r = spectral_apply_settings(b, st);
@@ -1036,10 +1051,25 @@ int mi_analyzer_bank_channel(mi_analyzer_bank_t *b, uint32_t channel, int what, 
     return MI_OK;
 }
 
+// what the launches of a call take by value from the host: ring head, position in the period, which of the two spectrum
+// buffers is vAmp
+static uint64_t analyzer_bank_positions(const void *bank)
+{
+    const mi_analyzer_bank *b = static_cast<const mi_analyzer_bank *>(bank);
+    uint64_t h = mi::position_mix(b->head, b->counter);
+    h = mi::position_mix(h, uint64_t(reinterpret_cast<uintptr_t>(b->d_amp)));
+    return mi::position_mix(h, (uint64_t(b->analysed) << 1) | uint64_t(b->reconfigure != 0 || b->meta_dirty));
+}
+
 int mi_analyzer_bank_process(mi_analyzer_bank_t *b, const float *in, size_t samples, size_t in_stride, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_process: NULL bank");
     hipStream_t st = mi::as_stream(stream);
+    {
+        const int rc = mi::capture_touch(st, b, "analyzer", analyzer_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     const bool changed = (b->reconfigure != 0) || b->meta_dirty;
     int r = analyzer_reconfigure(b, st);
     if (r != MI_OK)

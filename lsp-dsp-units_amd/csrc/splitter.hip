@@ -651,11 +651,24 @@ int mi_splitter_bank_clear(mi_splitter_bank_t *b, void *stream)
     return splitter_clear(b, mi::as_stream(stream));
 }
 
+// what the launches of a call take by value from the host: the fill of the frame, which analysis buffer of the pair is current
+static uint64_t splitter_bank_positions(const void *bank)
+{
+    const mi_splitter_bank *b = static_cast<const mi_splitter_bank *>(bank);
+    uint64_t h = mi::position_mix(b->fill, uint64_t(reinterpret_cast<uintptr_t>(b->d_in)));
+    return mi::position_mix(h, (uint64_t(b->update) << 1) | uint64_t(b->desc_dirty));
+}
+
 int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const float *in, size_t count, size_t out_stride,
                              size_t in_stride, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_process: NULL bank");
     hipStream_t st = mi::as_stream(stream);
+    {
+        const int rc = mi::capture_touch(st, b, "spectral splitter", splitter_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+    }
     if (b->update)
     {
         const int r = splitter_apply_settings(b, st);

@@ -4,7 +4,7 @@ W=$1; TAG=${2:-one}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
-cd /tmp && export TMPDIR=/tmp
+rm -rf $O/stats_$W; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats -d $O/stats_$W --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline > $O/stats_$W.log 2>&1
 python3 - <<PY
 import csv, glob

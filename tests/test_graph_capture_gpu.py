@@ -1,0 +1,246 @@
+"""hipGraph capture of every bank's process().
+
+Banks without positions (biquad, crossover, dynamic filters) replay any captured run of calls.  Banks that keep ring
+positions on the host hand them to their kernels by value, so a captured run is right for every replay exactly when it
+brings the bank back to the positions it started from: mi_dspu_graph_end_capture() checks that and refuses anything else,
+and a capture started behind the library's back is refused by process() itself.  Every case below captures the shortest
+accepted run (a position period), replays it three times and compares every output bit for bit with a twin bank driven
+by eager calls; shorter runs must have been refused where the bank has a period longer than one call."""
+import ctypes
+import gc
+
+import numpy as np
+import pytest
+
+import workloads as wl
+from oracle import filter_design as fd
+
+pytestmark = pytest.mark.gpu
+
+
+class Case:
+    """make() -> bank; call(bank, d_in, d_outs, n, stream); in_shape / out_shapes for one call."""
+    def __init__(self, name, make, call, in_shape, out_shapes, min_period=1):
+        self.name, self.make, self.call = name, make, call
+        self.in_shape, self.out_shapes, self.min_period = in_shape, out_shapes, min_period
+
+
+def _stream():
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+    return hip, s
+
+
+def _run(gpu, case, max_k=12, replays=3, seed=77):
+    hip, s = _stream()
+    st = s.value
+    rng = np.random.default_rng(seed)
+    xs = [(rng.standard_normal(case.in_shape) * 0.25).astype(np.float32) for _ in range(max_k)]
+    refused = []
+    accepted = None
+    for K in range(1, max_k + 1):
+        bank = case.make(st)
+        ins = [gpu.DeviceBuffer.from_host(xs[k], stream=st) for k in range(K)]
+        outs = [[gpu.DeviceBuffer(shape) for shape in case.out_shapes] for _ in range(K)]
+        for k in range(K):                                   # one eager run first: settings applied, scratch allocated
+            case.call(bank, ins[k], outs[k], st)
+        gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+        gc.collect()
+        gc.disable()
+        try:
+            gpu.check(gpu.lib.mi_dspu_graph_begin_capture(ctypes.c_void_p(st)))
+            for k in range(K):
+                case.call(bank, ins[k], outs[k], st)
+            exe = ctypes.c_void_p()
+            rc = gpu.lib.mi_dspu_graph_end_capture(ctypes.c_void_p(st), ctypes.byref(exe))
+        finally:
+            gc.enable()
+        if rc != 0:
+            msg = gpu.lib.mi_dspu_last_error().decode()
+            assert "starting positions" in msg, msg
+            refused.append(K)
+            bank.close()
+            continue
+        accepted = (K, bank, ins, outs, exe)
+        break
+    assert accepted is not None, (case.name, "no run of up to %d calls was accepted" % max_k, refused)
+    K, bank, ins, outs, exe = accepted
+    assert K >= case.min_period, (case.name, K, refused)
+    assert refused == list(range(1, K)), (case.name, K, refused)
+
+    # the twin: the same calls, eagerly
+    twin = case.make(st)
+    ref = []
+    for rep in range(1 + replays):
+        for k in range(K):
+            o = [gpu.DeviceBuffer(shape) for shape in case.out_shapes]
+            case.call(twin, ins[k], o, st)
+            ref.append([b.download(stream=st) for b in o])
+    for rep in range(replays):
+        gpu.check(gpu.lib.mi_dspu_graph_launch(exe, ctypes.c_void_p(st)))
+        for k in range(K):
+            for j, b in enumerate(outs[k]):
+                np.testing.assert_array_equal(b.download(stream=st), ref[(1 + rep) * K + k][j],
+                                              err_msg="%s: replay %d call %d output %d" % (case.name, rep, k, j))
+    gpu.lib.mi_dspu_graph_destroy(exe)
+    twin.close()
+    bank.close()
+    hip.hipStreamDestroy(s)
+    return K
+
+
+def test_delay_bank_replays_over_a_lap_of_the_line(gpu):
+    C, n = 6, 512
+
+    def make(st):
+        b = gpu.DelayBank(C, 1500)                           # size = align(1500 + 512, 512) = 2048: four calls per lap
+        for c in range(C):
+            b.set_delay(100 + 200 * c, channel=c)
+        return b
+
+    K = _run(gpu, Case("delay", make, lambda b, x, o, st: b.process(o[0], x, n, gain=0.5, stream=st), (C, n), [(C, n)], 4))
+    assert K == 4
+
+
+def test_ring_bank_replays_over_a_lap(gpu):
+    C, n = 4, 256
+
+    def call(b, x, o, st):
+        b.append(x, n, stream=st)
+        b.get(o[0], 300, n, stream=st)
+
+    K = _run(gpu, Case("ring", lambda st: gpu.RingBank(C, 1024), call, (C, n), [(C, n)], 4))
+    assert K == 4
+
+
+def test_convolver_bank_replays_over_its_ring_of_frames(gpu):
+    C, rank, taps = 4, 8, 1024
+    irs = (np.random.default_rng(3).standard_normal((C, taps)) * 0.1).astype(np.float32)
+    frame = 1 << (rank - 1)
+    K = _run(gpu, Case("convolver", lambda st: gpu.ConvolverBank(irs, rank, stream=st),
+                       lambda b, x, o, st: b.process(o[0], x, frame, stream=st), (C, frame), [(C, frame)], 2))
+    assert K > 1
+
+
+def test_equalizer_fir_replays(gpu):
+    C, n = 4, 512
+
+    def make(st):
+        eq = gpu.EqualizerBank(C, 2, 9)
+        eq.set_mode(gpu.EqualizerBank.FIR)
+        eq.set_sample_rate(48000)
+        eq.set_params(0, fd.FLT_BT_RLC_BELL, 1, 1000.0, 1000.0, 2.0, 2.0)
+        eq.set_params(1, fd.FLT_BT_RLC_HISHELF, 1, 6000.0, 6000.0, 0.5, 0.0)
+        return eq
+
+    # the delay line in front of the convolver is 9216 cells long: 18 calls of 512 samples per lap
+    K = _run(gpu, Case("equalizer", make, lambda b, x, o, st: b.process(o[0], x, n, stream=st), (C, n), [(C, n)]), max_k=20)
+    assert K == 18
+
+
+def test_analyzer_bank_replays_over_an_even_number_of_strobes(gpu):
+    C, rank = 8, 8
+
+    def make(st):
+        an = gpu.AnalyzerBank(C, rank, 48000, 100.0)
+        an.configure(an.SAMPLE_RATE, 48000); an.configure(an.RANK, rank); an.configure(an.RATE, 187.5)
+        an.configure(an.REACTIVITY, 0.2)
+        return an
+    period = 256                                             # 48000 / 187.5
+
+    def call(b, x, o, st):
+        b.process(x, period, stream=st)
+        b.reduce_bins(o[0], stream=st)
+
+    bins = (1 << (rank - 1)) + 1
+    K = _run(gpu, Case("analyzer", make, call, (C, period), [(bins,)], 2), max_k=16)
+    assert K % 2 == 0                                        # the two spectrum buffers swap roles at every strobe
+
+
+def test_spectral_bank_replays_every_call(gpu):
+    C, rank = 4, 8
+
+    def make(st):
+        b = gpu.SpectralBank(C, rank)
+        b.set_rank(rank)
+        return b
+    n = 1 << rank
+    K = _run(gpu, Case("spectral", make, lambda b, x, o, st: b.process(o[0], x, n, stream=st), (C, n), [(C, n)]))
+    assert K == 1
+
+
+def test_splitter_bank_replays(gpu):
+    C, rank, H = 4, 8, 2
+    n = 1 << (rank - 1)                                      # one hop per call: the analysis buffers swap every hop
+
+    def make(st):
+        sp = gpu.SplitterBank(C, rank, H)
+        sp.set_rank(rank)
+        sp.bind_mask(0, np.linspace(1.0, 0.0, 1 << rank).astype(np.float32), stream=st)
+        sp.bind_mask(1, np.linspace(0.0, 1.0, 1 << rank).astype(np.float32), stream=st)
+        return sp
+
+    K = _run(gpu, Case("splitter", make, lambda b, x, o, st: b.process(o, x, n, stream=st), (C, n), [(C, n), (C, n)], 2))
+    assert K == 2
+
+
+def test_loudness_and_ilufs_banks_replay(gpu):
+    M, Kc, n = 2, 2, 4096
+
+    def make_lm(st):
+        lm = gpu.LoudnessBank(M, Kc, 100.0)                  # 100 ms: lines of 8192 cells, re-summation every 4096 samples
+        lm.set_sample_rate(48000, stream=st)
+        return lm
+
+    K = _run(gpu, Case("loudness", make_lm, lambda b, x, o, st: b.process(o[0], None, x, n, stream=st),
+                       (M * Kc, n), [(M, n)], 2))
+    assert K == 2
+
+    def make_im(st):
+        im = gpu.ILUFSBank(M, Kc, 5.0, 400.0)                # gating blocks of four quarters of 4800 samples
+        im.set_sample_rate(48000, stream=st)
+        return im
+
+    K = _run(gpu, Case("ilufs", make_im, lambda b, x, o, st: b.process(o[0], x, 4800, stream=st), (M * Kc, 4800), [(M, 4800)], 4))
+    assert K == 4
+
+
+def test_banks_without_positions_replay_any_run(gpu):
+    C, n = 8, 4096
+
+    def make_xo(st):
+        xo = gpu.CrossoverBank(C, 3)
+        xo.set_sample_rate(48000)
+        for i, f in enumerate((300.0, 3000.0)):
+            xo.set_slope(i, 2); xo.set_frequency(i, f)
+        return xo
+
+    K = _run(gpu, Case("crossover", make_xo, lambda b, x, o, st: b.process(o, x, n, stream=st), (C, n), [(C, n)] * 3))
+    assert K == 1
+
+
+def test_capture_behind_the_librarys_back_is_refused(gpu):
+    """A positional bank on a stream captured with hipStreamBeginCapture directly: process() refuses (nothing could check
+    the positions at the end); a biquad bank is fine there (tests/test_streams_gpu.py)."""
+    hip, s = _stream()
+    st = s.value
+    C, n = 4, 256
+    b = gpu.DelayBank(C, 1000)
+    b.set_delay(300)
+    x, y = gpu.DeviceBuffer.from_host(np.ones((C, n), np.float32), stream=st), gpu.DeviceBuffer((C, n))
+    b.process(y, x, n, stream=st)
+    gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+    graph = ctypes.c_void_p()
+    assert hip.hipStreamBeginCapture(s, 0) == 0
+    with pytest.raises(gpu.MiError) as e:
+        b.process(y, x, n, stream=st)
+    assert "mi_dspu_graph_begin_capture" in str(e.value)
+    hip.hipStreamEndCapture(s, ctypes.byref(graph))
+    if graph.value:
+        hip.hipGraphDestroy(graph)
+    head = b.get()["head"]
+    b.process(y, x, n, stream=st)                            # the refused call changed nothing
+    assert b.get()["head"] == (head + n) % b.get()["size"]
+    b.close()
+    hip.hipStreamDestroy(s)
