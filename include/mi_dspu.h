@@ -73,10 +73,15 @@ int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
  */
 int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
 /*
- * hipGraph helpers for launch-bound inner loops: every steady-state *_process() call of the banks takes no host
- * decision and keeps what changes from call to call on the device, so a run of calls on `stream` can be captured
- * once and replayed (hipStreamBeginCapture / hipStreamEndCapture + hipGraphInstantiate / hipGraphLaunch).
+ * hipGraph helpers for launch-bound inner loops: a run of steady-state *_process() calls on `stream` is captured once
+ * and replayed (hipStreamBeginCapture / hipStreamEndCapture + hipGraphInstantiate / hipGraphLaunch).
  * begin: `stream` must be a created (non-NULL) stream.  end: returns an executable graph handle.
+ * Banks without ring positions (biquad, crossover, dynamic filters) replay any run.  The others (delay, ring buffer,
+ * convolver, equalizer, spectral processor, analyzer, splitter, loudness meters) hand ring positions kept on the host to
+ * their kernels by value: end_capture() checks that the captured calls bring every such bank back to the positions it
+ * started from and returns MI_ESTATE otherwise (capture a whole number of position periods: one lap of a delay line,
+ * an even number of analyzer strobes, ...).  On a stream captured with hipStreamBeginCapture directly those banks'
+ * process() returns MI_ESTATE and changes nothing.
  */
 int         mi_dspu_graph_begin_capture(void *stream);
 int         mi_dspu_graph_end_capture(void *stream, void **graph_exec);
