@@ -333,6 +333,8 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
             kernel_ms.append(float(ms.value))
         for e in starts + stops:
             mi.lib.mi_dspu_event_destroy(e)
+        if os.environ.get("MI_BENCH_DUMP_PROBES"):
+            print("probes us: " + " ".join("%.2f" % (v * 1e3) for v in kernel_ms), file=sys.stderr)
     st = sorted(times)
     info = {"launch": mode, "regions": regions,
             "region_ms": {"min": round(st[0] * 1e3, 5), "median": round(st[len(st) // 2] * 1e3, 5),
@@ -442,6 +444,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                      "unit": "GB/s", "frac": round(frame_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                      "traffic": _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None,
                      "kernel": "analyzer_kernel<11>", "kernel_avg_us": round(avg_ms * 1e3, 3),
+                     "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3), "kernel_samples": len(kernel_ms),
                      "algorithmic_bytes_per_launch": frame_bytes},
         "whole_step": {"algorithmic_bytes": frame_bytes,
                        "achieved_GBps_incl_launch_gaps": round(frame_bytes / (elapsed / steps) / 1e9, 1),
