@@ -601,7 +601,9 @@ namespace
                 float v = red[0][tid];
                 for (int w = 1; w < NW; ++w)
                     v += red[w][tid];
-                sq.sums[size_t(ch) * 4 + tid] += v;
+                // one addition per cell and launch (the order of the launches is the stream's): an atomic without a
+                // return value does not hold the workgroup up for the round trip a read-modify-write would
+                atomicAdd(&sq.sums[size_t(ch) * 4 + tid], v);
             }
         }
         MI_PROBE(15);

@@ -106,14 +106,23 @@ namespace
     // refresh_at < n: the reference re-sums the window exactly before that sample of the block (refresh_rms(),
     // LoudnessMeter.cpp:381-407 on its schedule :496-503); it is done here, inside the block, so that a block never has to
     // be cut at the refresh point.
+    // The kernel is a chain of dependent phases per channel (one workgroup round: its duration is the chain's latency, not
+    // the bytes moved -- with every global access of the block switched off it still takes 17 of its 20 us), so whatever can
+    // be asked for early is: the channel settings travel by value with the launch (up to CFG_BY_VALUE channels), the
+    // cells and segment sums of the exact re-summation are requested together with the block's samples.
+    constexpr uint32_t CFG_BY_VALUE = 8;
+    struct cfg_pack { chan_cfg c[CFG_BY_VALUE]; };
+
     template <uint32_t T, uint32_t E>
-    __global__ __launch_bounds__(T)
+    __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(4)))     // <= 128 VGPRs: two workgroups of 512 on a CU
     void loudness_block_kernel(float *out, float *ch_out, size_t out_stride, const float *__restrict__ flt, size_t flt_stride,
                                float *data, uint32_t size, uint32_t head, uint32_t period, float avg, float *ms,
-                               float *msbuf, size_t msbuf_stride, const chan_cfg *__restrict__ cfg, uint32_t channels,
-                               uint32_t n, float gain, float *loud, uint32_t refresh_at, float *segsum, int use_seg)
+                               float *msbuf, size_t msbuf_stride, const chan_cfg *__restrict__ cfg_mem, const cfg_pack pack,
+                               uint32_t channels, uint32_t n, float gain, float *loud, uint32_t refresh_at, float *segsum,
+                               int use_seg)
     {
         constexpr uint32_t NWV = T / 64, MAXSEG = E * T / SEG + 1;
+        auto cfg_of = [&](uint32_t c) -> chan_cfg { return (channels <= CFG_BY_VALUE) ? pack.c[c] : cfg_mem[c]; };
         __shared__ float segnew[MAXSEG];                    // sums of the line's segments this block writes to
         __shared__ float sq[E * T];                         // this channel's squares (new values)
         __shared__ __align__(16) float wtot[E][NWV];        // sums of the waves of every pass
@@ -132,7 +141,7 @@ namespace
         if (refresh)
             for (uint32_t c = 0; c < channels; ++c)
             {
-                const chan_cfg cc = cfg[c];
+                const chan_cfg cc = cfg_of(c);
                 if (!cc.enabled || !cc.unbound)
                     continue;
                 const uint32_t row = meter * channels + c;
@@ -143,7 +152,7 @@ namespace
         // the channels with an input, one after the other
         for (uint32_t c = 0; c < channels; ++c)
         {
-            const chan_cfg cc = cfg[c];
+            const chan_cfg cc = cfg_of(c);
             if (!cc.enabled || cc.unbound)
                 continue;
             const uint32_t row = meter * channels + c;
@@ -158,6 +167,30 @@ namespace
                 old[i] = (j < n && j < period) ? line[(tail + j) & mask] : 0.0f;
             }
             const float start = ms[row];
+            // what the exact re-summation needs from memory, asked for now: whole segments from their sums, the cut
+            // segments at both ends of the window cell by cell (positions are counted with one lap added so that the
+            // window's start stays positive; the block's own squares and segments come from LDS further down)
+            const uint32_t segs = size / SEG, q0 = head / SEG, nseg = (head + n - 1) / SEG - q0 + 1;
+            float *gseg = segsum + size_t(row) * segs;
+            const uint32_t H = head + size, we = H + refresh_at, ws = we - period;
+            const uint32_t bl = ((ws + SEG - 1) / SEG) * SEG, br = (we / SEG) * SEG;
+            float pre = 0.0f;
+            if (refresh && use_seg)
+            {
+                if (bl > br)
+                    for (uint32_t u = ws + tid; u < we && u < H; u += T)
+                        pre += line[u & mask];
+                else
+                {
+                    for (uint32_t u = ws + tid; u < bl && u < H; u += T)
+                        pre += line[u & mask];
+                    for (uint32_t u = br + tid; u < we && u < H; u += T)
+                        pre += line[u & mask];
+                    for (uint32_t q = bl / SEG + tid; q < br / SEG && q < H / SEG; q += T)
+                        pre += gseg[q & (segs - 1)];
+                }
+            }
+            const float gfirst = (head % SEG != 0) ? gseg[q0 & (segs - 1)] : 0.0f;     // the segment the block starts inside
             __syncthreads();                                // the previous channel is through with sq[] and wtot[]
             #pragma unroll
             for (uint32_t i = 0; i < E; ++i)                // dsp::sqr2 into the line (LoudnessMeter.cpp:428-436)
@@ -175,8 +208,6 @@ namespace
             // its first cell on, block after block, so the block that holds the first cell restarts the sum and the
             // others add to it.  (The sums stand for the cells themselves only where the line was written without a
             // break; the host says when that holds -- use_seg.)
-            const uint32_t segs = size / SEG, q0 = head / SEG, nseg = (head + n - 1) / SEG - q0 + 1;
-            float *gseg = segsum + size_t(row) * segs;
             for (uint32_t sgi = wave; sgi < nseg; sgi += NWV)
             {
                 const uint32_t lo = ((q0 + sgi) * SEG > head) ? (q0 + sgi) * SEG - head : 0u;
@@ -190,7 +221,7 @@ namespace
                 if (lane == 0)
                 {
                     const uint32_t phys = (q0 + sgi) & (segs - 1);
-                    const float total = ((q0 + sgi) * SEG >= head) ? v : gseg[phys] + v;
+                    const float total = ((q0 + sgi) * SEG >= head) ? v : gfirst + v;
                     segnew[sgi] = total;
                     gseg[phys] = total;
                 }
@@ -199,24 +230,20 @@ namespace
             float exact = 0.0f;
             if (refresh && use_seg)
             {
-                // whole segments from their sums, the cut segments at both ends cell by cell (the block's own squares
-                // from LDS); positions are counted with one lap added so that the window's start stays positive
+                // the part of the window that this block wrote: its squares and its segments' sums, from LDS
                 __syncthreads();                            // segnew[]
-                const uint32_t H = head + size, we = H + refresh_at, ws = we - period;
-                const uint32_t bl = ((ws + SEG - 1) / SEG) * SEG, br = (we / SEG) * SEG;
-                auto cell = [&](uint32_t u) -> float { return (u >= H) ? sq[u - H] : line[u & mask]; };
-                float s = 0.0f;
+                float s = pre;
                 if (bl > br)
-                    for (uint32_t u = ws + tid; u < we; u += T)
-                        s += cell(u);
+                    for (uint32_t u = ((ws > H) ? ws : H) + tid; u < we; u += T)
+                        s += sq[u - H];
                 else
                 {
-                    for (uint32_t u = ws + tid; u < bl; u += T)
-                        s += cell(u);
-                    for (uint32_t u = br + tid; u < we; u += T)
-                        s += cell(u);
-                    for (uint32_t q = bl / SEG + tid; q < br / SEG; q += T)
-                        s += (q >= H / SEG) ? segnew[q - H / SEG] : gseg[q & (segs - 1)];
+                    for (uint32_t u = ((ws > H) ? ws : H) + tid; u < bl; u += T)
+                        s += sq[u - H];
+                    for (uint32_t u = ((br > H) ? br : H) + tid; u < we; u += T)
+                        s += sq[u - H];
+                    for (uint32_t q = ((bl / SEG > H / SEG) ? bl / SEG : H / SEG) + tid; q < br / SEG; q += T)
+                        s += segnew[q - H / SEG];
                 }
                 #pragma unroll
                 for (int w = 32; w > 0; w >>= 1)
@@ -312,7 +339,7 @@ namespace
             return;
         for (uint32_t c = 0; c < channels; ++c)
         {
-            const chan_cfg cc = cfg[c];
+            const chan_cfg cc = cfg_of(c);
             if (!cc.enabled || cc.unbound)                  // (the reference hands an unbound channel's stale buffer on: nothing here)
                 continue;
             const uint32_t row = meter * channels + c;
@@ -330,6 +357,274 @@ namespace
                 else if (cc.link >= 1.0f)  v = mix[i] * gain;
                 else                       v = mix[i] * (cc.link * gain) + r * ((1.0f - cc.link) * gain);     // mix_copy2
                 o[j] = v;
+            }
+        }
+    }
+    // The same block with FOUR consecutive samples per lane (16-byte accesses): sample j = 4 (i T + tid) + k.  The scalar
+    // kernel above spends its time issuing instructions, not moving bytes (SQ counters: 1900 VALU instructions per wave,
+    // most of them address arithmetic and per-pass scan bookkeeping; with every global access switched off it still takes
+    // 17 of its 20 us) -- a quarter of the passes means a quarter of that.  Needs n, head and period to be multiples of 4
+    // (then no 16-byte cell straddles the window's tail, the end of the line or the end of the block); anything else
+    // takes the scalar kernel.
+    template <uint32_t T, uint32_t E>
+    __global__ __launch_bounds__(T)
+    void loudness_block4_kernel(float *out, float *ch_out, size_t out_stride, const float *__restrict__ flt, size_t flt_stride,
+                                float *data, uint32_t size, uint32_t head, uint32_t period, float avg, float *ms,
+                                float *msbuf, size_t msbuf_stride, const chan_cfg *__restrict__ cfg_mem, const cfg_pack pack,
+                                uint32_t channels, uint32_t n, float gain, float *loud, uint32_t refresh_at, float *segsum,
+                                int use_seg)
+    {
+        constexpr uint32_t NWV = T / 64, MAXSEG = E * T * 4 / SEG + 1;
+        auto cfg_of = [&](uint32_t c) -> chan_cfg { return (channels <= CFG_BY_VALUE) ? pack.c[c] : cfg_mem[c]; };
+        __shared__ float segnew[MAXSEG];
+        __shared__ __align__(16) float sq[E * T * 4];
+        __shared__ __align__(16) float wtot[E][NWV];
+        __shared__ float part[NWV];
+        __shared__ float s_before;
+        const uint32_t meter = blockIdx.x, tid = threadIdx.x, mask = size - 1;
+        const uint32_t lane = tid & 63, wave = tid >> 6;
+        const uint32_t tail = (head + size - period) & mask;
+        const bool refresh = refresh_at < n;
+        float4 mix[E];
+        #pragma unroll
+        for (uint32_t i = 0; i < E; ++i)
+            mix[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        uint32_t mixed = 0;
+        if (refresh)
+            for (uint32_t c = 0; c < channels; ++c)
+            {
+                const chan_cfg cc = cfg_of(c);
+                if (!cc.enabled || !cc.unbound)
+                    continue;
+                const uint32_t row = meter * channels + c;
+                const float r = window_sum<T>(data + size_t(row) * size, size, (head + refresh_at + size - period) & mask, period, part);
+                if (tid == 0)
+                    ms[row] = r;
+            }
+        for (uint32_t c = 0; c < channels; ++c)
+        {
+            const chan_cfg cc = cfg_of(c);
+            if (!cc.enabled || cc.unbound)
+                continue;
+            const uint32_t row = meter * channels + c;
+            float *line = data + size_t(row) * size;
+            const float *x = flt + size_t(row) * flt_stride;
+            float4 q[E], old[E];
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
+            {
+                const uint32_t j = (i * T + tid) * 4;
+                q[i] = (j < n) ? *reinterpret_cast<const float4 *>(x + j) : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                old[i] = (j < n && j < period) ? *reinterpret_cast<const float4 *>(line + ((tail + j) & mask))
+                                               : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+            const float start = ms[row];
+            const uint32_t segs = size / SEG, q0 = head / SEG, nseg = (head + n - 1) / SEG - q0 + 1;
+            float *gseg = segsum + size_t(row) * segs;
+            const uint32_t H = head + size, we = H + refresh_at, ws = we - period;
+            const uint32_t bl = ((ws + SEG - 1) / SEG) * SEG, br = (we / SEG) * SEG;
+            float pre = 0.0f;
+            if (refresh && use_seg)
+            {
+                if (bl > br)
+                    for (uint32_t u = ws + tid; u < we && u < H; u += T)
+                        pre += line[u & mask];
+                else
+                {
+                    for (uint32_t u = ws + tid; u < bl && u < H; u += T)
+                        pre += line[u & mask];
+                    for (uint32_t u = br + tid; u < we && u < H; u += T)
+                        pre += line[u & mask];
+                    for (uint32_t s2 = bl / SEG + tid; s2 < br / SEG && s2 < H / SEG; s2 += T)
+                        pre += gseg[s2 & (segs - 1)];
+                }
+            }
+            const float gfirst = (head % SEG != 0) ? gseg[q0 & (segs - 1)] : 0.0f;
+            __syncthreads();                                // the previous channel is through with sq[] and wtot[]
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)                // dsp::sqr2 into the line (LoudnessMeter.cpp:428-436)
+            {
+                const uint32_t j = (i * T + tid) * 4;
+                q[i] = make_float4(q[i].x * q[i].x, q[i].y * q[i].y, q[i].z * q[i].z, q[i].w * q[i].w);
+                if (j < n)
+                {
+                    *reinterpret_cast<float4 *>(sq + j) = q[i];
+                    *reinterpret_cast<float4 *>(line + ((head + j) & mask)) = q[i];
+                }
+            }
+            __syncthreads();
+            // sums of the segments the block writes to (see the scalar kernel)
+            static_assert(SEG == 256, "one 16-byte cell per lane covers a segment");
+            for (uint32_t sgi = wave; sgi < nseg; sgi += NWV)
+            {
+                const uint32_t lo = ((q0 + sgi) * SEG > head) ? (q0 + sgi) * SEG - head : 0u;
+                const uint32_t hi = ((q0 + sgi + 1) * SEG - head < n) ? (q0 + sgi + 1) * SEG - head : n;
+                float v = 0.0f;
+                const uint32_t j = lo + 4 * lane;           // SEG = 4 x 64: one 16-byte cell per lane
+                if (j < hi)
+                {
+                    const float4 t = *reinterpret_cast<const float4 *>(sq + j);
+                    v = (t.x + t.y) + (t.z + t.w);
+                }
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    v += __shfl_xor(v, w);
+                if (lane == 0)
+                {
+                    const uint32_t phys = (q0 + sgi) & (segs - 1);
+                    const float total = ((q0 + sgi) * SEG >= head) ? v : gfirst + v;
+                    segnew[sgi] = total;
+                    gseg[phys] = total;
+                }
+            }
+            float exact = 0.0f;
+            if (refresh && use_seg)
+            {
+                __syncthreads();                            // segnew[]
+                float s = pre;
+                if (bl > br)
+                    for (uint32_t u = ((ws > H) ? ws : H) + tid; u < we; u += T)
+                        s += sq[u - H];
+                else
+                {
+                    for (uint32_t u = ((ws > H) ? ws : H) + tid; u < bl; u += T)
+                        s += sq[u - H];
+                    for (uint32_t u = ((br > H) ? br : H) + tid; u < we; u += T)
+                        s += sq[u - H];
+                    for (uint32_t s2 = ((bl / SEG > H / SEG) ? bl / SEG : H / SEG) + tid; s2 < br / SEG; s2 += T)
+                        s += segnew[s2 - H / SEG];
+                }
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    s += __shfl_xor(s, w);
+                __syncthreads();
+                if (lane == 0)
+                    part[wave] = s;
+                __syncthreads();
+                #pragma unroll
+                for (uint32_t w = 0; w < NWV; ++w)
+                    exact += part[w];
+            }
+            else if (refresh)
+            {
+                const uint32_t from_line = (refresh_at < period) ? period - refresh_at : 0u;
+                exact = window_sum<T>(line, size, (head + refresh_at + size - period) & mask, from_line, part);
+                float s = 0.0f;
+                for (uint32_t j = refresh_at - (period - from_line) + tid; j < refresh_at; j += T)
+                    s += sq[j];
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    s += __shfl_xor(s, w);
+                __syncthreads();
+                if (lane == 0)
+                    part[wave] = s;
+                __syncthreads();
+                #pragma unroll
+                for (uint32_t w = 0; w < NWV; ++w)
+                    exact += part[w];
+            }
+            // ms_j = ms_(j-1) + (new_j - old_j): the four samples of a lane in sequence, an inclusive scan of the lanes'
+            // sums inside the wave, the sums of the waves through LDS, then the running sum carried from pass to pass
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
+            {
+                const uint32_t j = (i * T + tid) * 4;
+                float4 d = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (j < n)
+                {
+                    const float4 o = (j >= period) ? *reinterpret_cast<const float4 *>(sq + (j - period)) : old[i];
+                    d = make_float4(q[i].x - o.x, q[i].y - o.y, q[i].z - o.z, q[i].w - o.w);
+                }
+                d.y += d.x; d.z += d.y; d.w += d.z;
+                const float incl = wave_scan(d.w);
+                const float excl = incl - d.w;
+                q[i] = make_float4(d.x + excl, d.y + excl, d.z + excl, d.w + excl);
+                if (lane == 63)
+                    wtot[i][wave] = incl;
+            }
+            __syncthreads();
+            float carry = 0.0f;
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
+            {
+                const uint32_t j = (i * T + tid) * 4;
+                float before = carry, total = 0.0f;
+                #pragma unroll
+                for (uint32_t w = 0; w < NWV; w += 4)
+                {
+                    const float4 t = *reinterpret_cast<const float4 *>(&wtot[i][w]);
+                    before += ((w + 0 < wave) ? t.x : 0.0f) + ((w + 1 < wave) ? t.y : 0.0f) +
+                              ((w + 2 < wave) ? t.z : 0.0f) + ((w + 3 < wave) ? t.w : 0.0f);
+                    total += (t.x + t.y) + (t.z + t.w);
+                }
+                q[i] = make_float4(q[i].x + before, q[i].y + before, q[i].z + before, q[i].w + before);     // P_j
+                carry += total;
+                if (refresh && refresh_at > 0 && refresh_at - 1 >= j && refresh_at - 1 < j + 4)
+                {
+                    const uint32_t k = refresh_at - 1 - j;
+                    s_before = (k == 0) ? q[i].x : (k == 1) ? q[i].y : (k == 2) ? q[i].z : q[i].w;
+                }
+            }
+            if (refresh)
+                __syncthreads();
+            const float rebase = refresh ? exact - ((refresh_at > 0) ? s_before : 0.0f) : 0.0f;
+            float *mb = msbuf + size_t(row) * msbuf_stride;
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
+            {
+                const uint32_t j = (i * T + tid) * 4;
+                auto at = [&](uint32_t k, float p) -> float { return avg * (((refresh && j + k >= refresh_at) ? rebase : start) + p); };
+                const float4 m = make_float4(at(0, q[i].x), at(1, q[i].y), at(2, q[i].z), at(3, q[i].w));   // vMS[j] = fAvgCoeff * ms
+                if (j < n && ch_out != nullptr)
+                    *reinterpret_cast<float4 *>(mb + j) = m;
+                if (mixed > 0)
+                    mix[i] = make_float4(fmaf(m.x, cc.weight, mix[i].x), fmaf(m.y, cc.weight, mix[i].y),
+                                         fmaf(m.z, cc.weight, mix[i].z), fmaf(m.w, cc.weight, mix[i].w));  // fmadd_k3
+                else
+                    mix[i] = make_float4(m.x * cc.weight, m.y * cc.weight, m.z * cc.weight, m.w * cc.weight);   // mul_k3
+            }
+            if (tid == 0)
+                ms[row] = (refresh ? rebase : start) + carry;
+            ++mixed;
+        }
+        // ssqrt1: sqrt of the non-negative part; then the outputs
+        auto root = [](float v) -> float { return (v > 0.0f) ? sqrtf(v) : 0.0f; };
+        #pragma unroll
+        for (uint32_t i = 0; i < E; ++i)
+        {
+            const uint32_t j = (i * T + tid) * 4;
+            mix[i] = make_float4(root(mix[i].x), root(mix[i].y), root(mix[i].z), root(mix[i].w));
+            if (out != nullptr && j < n)
+                *reinterpret_cast<float4 *>(out + size_t(meter) * out_stride + j) =
+                    make_float4(mix[i].x * gain, mix[i].y * gain, mix[i].z * gain, mix[i].w * gain);
+            if (loud != nullptr && j + 4 == n)
+                loud[meter] = mix[i].w;
+        }
+        if (ch_out == nullptr)
+            return;
+        for (uint32_t c = 0; c < channels; ++c)
+        {
+            const chan_cfg cc = cfg_of(c);
+            if (!cc.enabled || cc.unbound)
+                continue;
+            const uint32_t row = meter * channels + c;
+            const float *mb = msbuf + size_t(row) * msbuf_stride;
+            float *o = ch_out + size_t(row) * out_stride;
+            #pragma unroll
+            for (uint32_t i = 0; i < E; ++i)
+            {
+                const uint32_t j = (i * T + tid) * 4;
+                if (j >= n)
+                    continue;
+                const float4 m = *reinterpret_cast<const float4 *>(mb + j);   // written by this same thread above
+                auto one = [&](float mv, float mx) -> float
+                {
+                    const float r = root(mv);
+                    if (cc.link <= 0.0f)       return r * gain;
+                    else if (cc.link >= 1.0f)  return mx * gain;
+                    return mx * (cc.link * gain) + r * ((1.0f - cc.link) * gain);     // mix_copy2
+                };
+                *reinterpret_cast<float4 *>(o + j) = make_float4(one(m.x, mix[i].x), one(m.y, mix[i].y), one(m.z, mix[i].z), one(m.w, mix[i].w));
             }
         }
     }
@@ -627,6 +922,9 @@ static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, co
     if (r != MI_OK)
         return r;
     const uint32_t room = b->data_size - b->period;         // cells that may be written before the window's tail is reached
+    cfg_pack pack;
+    for (uint32_t c = 0; c < CFG_BY_VALUE; ++c)
+        pack.c[c] = (c < b->channels) ? b->cfg[c] : chan_cfg{ 0.0f, 0.0f, 0, 0 };
     const uint32_t interval = std::max<uint32_t>(BUFFER_SIZE << 2, b->period >> 2);     // between exact re-summations (:496-503)
     size_t offset = 0;
     while (offset < count)
@@ -649,14 +947,29 @@ static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, co
         r = mi_biquad_bank_process(b->filters, b->d_flt, in + offset, n, b->cap, in_stride, stream);
         if (r != MI_OK)
             return r;
-        // 512 threads x 8 passes for the long blocks: 120 VGPRs, two workgroups on a CU (1024 x 4 fits only one and is slower)
-        auto kernel = (n <= 512) ? loudness_block_kernel<256, 2> : (n <= 1024) ? loudness_block_kernel<256, 4> :
-                      (n <= 2048) ? loudness_block_kernel<512, 4> : loudness_block_kernel<512, MAX_BLOCK / 512>;
-        hipLaunchKernelGGL(kernel, dim3(b->meters), dim3((n <= 1024) ? 256 : 512), 0, st,
-                           out ? out + offset : nullptr, ch_out ? ch_out + offset : nullptr, out_stride, b->d_flt, b->cap,
-                           b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, b->d_msbuf, b->cap, b->d_cfg,
-                           b->channels, uint32_t(n), gain, remember ? b->d_loud : static_cast<float *>(nullptr), refresh_at,
-                           b->d_segsum, (b->raw_left == 0) ? 1 : 0);
+        // four samples per lane when nothing straddles a 16-byte cell; else one per lane, 512 threads x 8 passes for the
+        // long blocks (<= 128 VGPRs: two workgroups on a CU)
+        float *o_main = out ? out + offset : nullptr, *o_ch = ch_out ? ch_out + offset : nullptr;
+        const bool vec4 = (n % 4 == 0) && (b->head % 4 == 0) && (b->period % 4 == 0) && (out_stride % 4 == 0) &&
+                          ((reinterpret_cast<uintptr_t>(o_main) | reinterpret_cast<uintptr_t>(o_ch)) % 16 == 0) &&
+                          getenv("MI_LOUDNESS_SCALAR") == nullptr;
+        float *loud_dst = remember ? b->d_loud : static_cast<float *>(nullptr);
+        #define MI_LARGS o_main, o_ch, out_stride, b->d_flt, b->cap, b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, \
+                         b->d_msbuf, b->cap, b->d_cfg, pack, b->channels, uint32_t(n), gain, loud_dst, refresh_at, \
+                         b->d_segsum, (b->raw_left == 0) ? 1 : 0
+        if (vec4)
+        {
+            if (n <= 1024)      hipLaunchKernelGGL((loudness_block4_kernel<256, 1>), dim3(b->meters), dim3(256), 0, st, MI_LARGS);
+            else if (n <= 2048) hipLaunchKernelGGL((loudness_block4_kernel<512, 1>), dim3(b->meters), dim3(512), 0, st, MI_LARGS);
+            else                hipLaunchKernelGGL((loudness_block4_kernel<512, MAX_BLOCK / 2048>), dim3(b->meters), dim3(512), 0, st, MI_LARGS);
+        }
+        else
+        {
+            auto kernel = (n <= 512) ? loudness_block_kernel<256, 2> : (n <= 1024) ? loudness_block_kernel<256, 4> :
+                          (n <= 2048) ? loudness_block_kernel<512, 4> : loudness_block_kernel<512, MAX_BLOCK / 512>;
+            hipLaunchKernelGGL(kernel, dim3(b->meters), dim3((n <= 1024) ? 256 : 512), 0, st, MI_LARGS);
+        }
+        #undef MI_LARGS
         MI_HIP_CHECK(hipGetLastError());
         b->raw_left = (b->raw_left > n) ? b->raw_left - n : 0;
         b->head = (b->head + uint32_t(n)) & (b->data_size - 1);
@@ -723,25 +1036,33 @@ namespace
                 ++c;
             }
         }
-        s_sum[tid] = s;
-        s_cnt[tid] = c;
-        __syncthreads();
-        for (int w = LT / 2; w > 0; w >>= 1)
+        // the waves' sums by shuffles, the four of them through LDS
+        #pragma unroll
+        for (int w = 32; w > 0; w >>= 1)
         {
-            if (int(tid) < w)
-            {
-                s_sum[tid] += s_sum[tid + w];
-                s_cnt[tid] += s_cnt[tid + w];
-            }
-            __syncthreads();
+            s += __shfl_xor(s, w);
+            c += __shfl_xor(c, w);
         }
+        if ((tid & 63) == 0)
+        {
+            s_sum[tid >> 6] = s;
+            s_cnt[tid >> 6] = c;
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            static_assert(LT == 256, "four waves");
+            s_sum[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+            s_cnt[0] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        }
+        __syncthreads();
         const float r = (s_cnt[0] > 0) ? s_sum[0] / float(s_cnt[0]) : 0.0f;
         __syncthreads();
         return r;
     }
 
     // a gating block is complete (ILUFSMeter.cpp:402-458); the workgroup of the meter
-    __device__ void ilufs_gate(uint32_t meter, ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *block,
+    __device__ float ilufs_gate(uint32_t meter, ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *block,
                                const chan_cfg *__restrict__ cfg, uint32_t channels, float avg,
                                float *s_sum, uint32_t *s_cnt, float &s_val)
     {
@@ -793,24 +1114,24 @@ namespace
                 float s = 0.0f;
                 for (uint32_t j = tid; j < size; j += LT)
                     s += mult * h[j];
-                s_sum[tid] = s;
+                #pragma unroll
+                for (int w = 32; w > 0; w >>= 1)
+                    s += __shfl_xor(s, w);
+                if ((tid & 63) == 0)
+                    s_sum[tid >> 6] = s;
                 __syncthreads();
-                for (int w = LT / 2; w > 0; w >>= 1)
-                {
-                    if (int(tid) < w)
-                        s_sum[tid] += s_sum[tid + w];
-                    __syncthreads();
-                }
+                if (tid == 0)
+                    s_sum[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+                __syncthreads();
                 loudness = s_sum[0];
             }
             else
                 loudness = 0.0f;
         }
+        me.loudness = sqrtf(loudness);
         if (tid == 0)
-        {
-            me.loudness = sqrtf(loudness);
             st[meter] = me;
-        }
+        return me.loudness;                                 // every thread has it: the next piece's output starts at once
     }
 
     // The pieces of one process() call, one workgroup per meter.  A piece is a run of samples inside one quarter of a
@@ -830,12 +1151,24 @@ namespace
         __shared__ uint32_t s_cnt[LT];
         __shared__ float s_val;
         const uint32_t meter = blockIdx.x, tid = threadIdx.x;
+        // everything the pieces need from memory is asked for at once: the value being held, and for the thread of
+        // channel c the pieces' sums of squares, its quarters and whether it counts
+        float held = st[meter].loudness;
+        const uint32_t myrow = meter * channels + tid;
+        float4 myseg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), myblk = myseg;
+        bool counts = false;
+        if (tid < channels)
+        {
+            myseg = *reinterpret_cast<const float4 *>(seg + size_t(myrow) * 4);
+            myblk = *reinterpret_cast<const float4 *>(block + size_t(myrow) * 4);
+            counts = cfg[tid].enabled != 0;
+        }
         for (uint32_t k = 0; k < pieces.count; ++k)
         {
             const ilufs_piece pc = pieces.p[k];
             if (out != nullptr && pc.n > 0)
             {
-                const float v = st[meter].loudness * gain;
+                const float v = held * gain;
                 float *o = out + size_t(meter) * out_stride + pc.offset;
                 // 16-byte stores over the aligned middle of the run
                 const uint32_t lead = uint32_t((4u - (uint32_t(reinterpret_cast<uintptr_t>(o) >> 2) & 3u)) & 3u);
@@ -849,19 +1182,35 @@ namespace
                     o[i] = v;
             }
             if (pc.n > 0)
-                for (uint32_t c = tid; c < channels; c += LT)
+            {
+                if (tid < channels && counts)
+                {
+                    const float add = (k == 0) ? myseg.x : (k == 1) ? myseg.y : (k == 2) ? myseg.z : myseg.w;
+                    float *q = (pc.part == 0) ? &myblk.x : (pc.part == 1) ? &myblk.y : (pc.part == 2) ? &myblk.z : &myblk.w;
+                    *q += add;
+                    block[size_t(myrow) * 4 + pc.part] = *q;
+                }
+                for (uint32_t c = tid + LT; c < channels; c += LT)         // meters of more than LT channels
                     if (cfg[c].enabled)
                     {
                         const uint32_t row = meter * channels + c;
                         block[row * 4 + pc.part] += seg[row * 4 + k];
                     }
+            }
             __syncthreads();
             if (pc.gate)
-                ilufs_gate(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);
+                held = ilufs_gate(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);
             __syncthreads();
             if (pc.zero_part >= 0)
+            {
+                if (tid < channels)
+                {
+                    float *q = (pc.zero_part == 0) ? &myblk.x : (pc.zero_part == 1) ? &myblk.y : (pc.zero_part == 2) ? &myblk.z : &myblk.w;
+                    *q = 0.0f;
+                }
                 for (uint32_t c = tid; c < channels; c += LT)
                     block[(meter * channels + c) * 4 + uint32_t(pc.zero_part)] = 0.0f;
+            }
             __syncthreads();
         }
         for (uint32_t i = tid; i < channels * 4; i += LT)   // consumed: the next call's filter launch adds to zeros
