@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral", "crossover", "splitter", "loudness"],
+    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral", "crossover", "splitter", "loudness", "dynfilter"],
                     help="all = headline biquad line with the convolver result attached under \"convolver\"")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
@@ -545,6 +545,34 @@ def run_loudness(args, mi, torch, dist, rank, world, dev):
                         "blocks" % M, M * K, n, args.conv_steps, elapsed, world, 8.0)
 
 
+def run_dynfilter(args, mi, torch, dist, rank, world, dev):
+    """DynamicFilters, one FLT_BT_RLC_BELL filter (slope 2: two sections) per channel whose gain follows a
+    per-sample curve (what a dynamic equalizer feeds it), 1024 channels x 4096 samples per step.  Algorithmic bytes:
+    4 B in + 4 B gain + 4 B out = 12 B per channel-sample."""
+    C, n = 1024, 4096
+    FLT_BT_RLC_BELL = 11
+    df = mi.DynFilterBank(C, 1)
+    df.set_sample_rate(48000)
+    df.set_params(0, FLT_BT_RLC_BELL, 2, 1000.0, 1000.0, 1.0, 2.0)
+    ring = 4
+    gen = torch.Generator(device="cpu"); gen.manual_seed(95 + rank)
+    xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    t = torch.arange(n, dtype=torch.float32) / n
+    curve = (1.0 + 0.8 * torch.sin(2.0 * 3.14159265 * (3.0 * t[None, :] + torch.rand((C, 1), generator=gen)))).contiguous().to(dev)
+    out = torch.empty((C, n), dtype=torch.float32, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        df.process(0, out, xin[i % ring], curve, n, stream=stream)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
+    df.close()
+    if rank != 0:
+        return None
+    return _step_result("dynfilter", "DynamicFilters, FLT_BT_RLC_BELL slope 2 with a per-sample gain curve, %d channels per GPU, "
+                        "4096-sample blocks" % C, C, n, args.conv_steps, elapsed, world, 12.0)
+
+
 def main():
     args = parse()
     import numpy as np
@@ -571,9 +599,10 @@ def main():
     mi.check(mi.lib.mi_dspu_set_device(local_rank))
     import workloads as wl
 
-    if args.workload in ("convolver", "equalizer", "spectral", "crossover", "splitter", "loudness"):
+    if args.workload in ("convolver", "equalizer", "spectral", "crossover", "splitter", "loudness", "dynfilter"):
         runner = {"convolver": run_convolver, "equalizer": run_equalizer, "spectral": run_spectral,
-                  "crossover": run_crossover, "splitter": run_splitter, "loudness": run_loudness}[args.workload]
+                  "crossover": run_crossover, "splitter": run_splitter, "loudness": run_loudness,
+                  "dynfilter": run_dynfilter}[args.workload]
         res = runner(args, mi, torch, dist, rank, world, dev)
         if rank == 0:
             line = {"metric": "Msamples/sec per GPU (biquad-x8 1024ch; Convolver 65536-tap) + HBM roofline %",
@@ -676,7 +705,8 @@ def main():
         eqr = run_equalizer(args, mi, torch, dist, rank, world, dev)
         spr = run_spectral(args, mi, torch, dist, rank, world, dev)
         nxt = {name: fn(args, mi, torch, dist, rank, world, dev)
-               for name, fn in (("crossover", run_crossover), ("splitter", run_splitter), ("loudness", run_loudness))}
+               for name, fn in (("dynfilter", run_dynfilter), ("crossover", run_crossover), ("splitter", run_splitter),
+                                ("loudness", run_loudness))}
         if rank == 0:
             line["convolver"] = conv
             line["equalizer"] = eqr
