@@ -35,6 +35,37 @@ def gpu(mi):
     return mi
 
 
+# ---- parity ledger --------------------------------------------------------------------------------------------
+# Every floating-point comparison of a GPU result with the oracle leaves its worst figure here; a GPU session writes the
+# ledger to gpurun_out/parity_report.json (a copy per round is committed under profiles/), so the margins of the
+# rules that are looser than 1e-5 can be read instead of being trusted.
+_LEDGER = {}
+
+
+def record_parity(rule, value, bound, **extra):
+    """rule: name of the tolerance rule; value / bound: the error and what it was allowed to be (same units)."""
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    e = _LEDGER.setdefault(rule, {"checks": 0, "worst_value": 0.0, "worst_ratio_to_bound": 0.0, "worst_test": "", "tests": set()})
+    e["checks"] += 1
+    e["tests"].add(test.split("::")[0])
+    ratio = float(value) / float(bound) if bound > 0 else (0.0 if value == 0 else float("inf"))
+    if ratio >= e["worst_ratio_to_bound"]:
+        e.update(worst_ratio_to_bound=ratio, worst_value=float(value), worst_bound=float(bound), worst_test=test,
+                 **{"worst_" + k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in extra.items()})
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not _LEDGER:
+        return
+    import json
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    doc = {k: dict(v, tests=sorted(v["tests"])) for k, v in sorted(_LEDGER.items())}
+    with open(os.path.join(out, "parity_report.json"), "w") as f:
+        json.dump({"note": "worst error / allowed error per tolerance rule over this pytest session (tests/conftest.py)",
+                   "exit_status": int(exitstatus), "rules": doc}, f, indent=1)
+
+
 def parity_report(gpu_out, ref32, ref64, peak=None):
     """Relative-to-block-peak errors used by every floating-point parity test.
 
@@ -79,8 +110,13 @@ def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None):
     msg = "%s: %s" % (what, r)
     assert np.all(np.isfinite(gpu_out)), msg
     if r["noise"] <= NOISE_FLOOR:
+        record_parity("iir strict: |gpu - oracle| <= 1e-5 peak (oracle noise <= 2e-6)", r["gpu_vs_ref32"], TOL, noise=r["noise"])
         assert r["gpu_vs_ref32"] <= TOL, msg
     else:
+        record_parity("iir noisy: |gpu - exact| <= max(1e-5, 4 noise)", r["gpu_vs_exact"], max(TOL, IIR_EXACT_FACTOR * r["noise"]),
+                      noise=r["noise"], over_noise=r["gpu_vs_exact"] / r["noise"])
+        record_parity("iir noisy: |gpu - oracle| <= max(1e-5, 5 noise)", r["gpu_vs_ref32"], max(TOL, IIR_REF_FACTOR * r["noise"]),
+                      noise=r["noise"], over_noise=r["gpu_vs_ref32"] / r["noise"])
         assert r["gpu_vs_exact"] <= max(TOL, IIR_EXACT_FACTOR * r["noise"]), msg
         assert r["gpu_vs_ref32"] <= max(TOL, IIR_REF_FACTOR * r["noise"]), msg
     return r

@@ -267,10 +267,10 @@ def meters_gpu(mi):
 CASES = {
     "biquad": (biquad_oracle, biquad_gpu, 1e-5),
     "convolver": (convolver_oracle, convolver_gpu, 1e-5),
-    "equalizer": (equalizer_oracle, equalizer_gpu, 2e-5),
+    "equalizer": (equalizer_oracle, equalizer_gpu, 1e-5),
     "spectral": (spectral_oracle, spectral_gpu, 1e-5),
     "splitter": (splitter_oracle, splitter_gpu, 1e-5),
     "delay": (delay_oracle, delay_gpu, 0.0),
-    "crossover": (crossover_oracle, crossover_gpu, 2e-5),
+    "crossover": (crossover_oracle, crossover_gpu, 1e-5),
     "meters": (meters_oracle, meters_gpu, 1e-5),
 }

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import TOL, parity_report
+from conftest import TOL, parity_report, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -49,6 +49,8 @@ def chunks_of(n, step):
 def check(gpu_y, ref32, ref64, what, tol=TOL):
     r = parity_report(gpu_y, ref32, ref64)
     assert np.all(np.isfinite(gpu_y)), what
+    record_parity("convolver: |gpu - oracle| <= max(tol, 3 noise)", r["gpu_vs_ref32"], max(tol, 3.0 * r["noise"]), noise=r["noise"], tol=tol)
+    record_parity("convolver: |gpu - exact| <= max(tol, 3 noise)", r["gpu_vs_exact"], max(tol, 3.0 * r["noise"]), noise=r["noise"], tol=tol)
     assert r["gpu_vs_ref32"] <= max(tol, 3.0 * r["noise"]), "%s: %s" % (what, r)
     assert r["gpu_vs_exact"] <= max(tol, 3.0 * r["noise"]), "%s: %s" % (what, r)
     return r

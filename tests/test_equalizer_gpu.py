@@ -1,5 +1,6 @@
 """GPU parity of mi_equalizer_bank_* (lsp::dspu::Equalizer) against the CPU oracle, through the C-ABI."""
 import numpy as np
+from conftest import record_parity
 import pytest
 
 from oracle import equalizer as oe
@@ -273,4 +274,6 @@ def test_c4_full_size(gpu):
         noise = float(np.abs(refs[1] - ref).max() / peak)
         err = float(np.abs(y1[c] - ref).max() / peak)
         print("C4 full size ch %d: |gpu - oracle| / peak = %.2e (impulse-response round-off %.2e)" % (c, err, noise))
+        record_parity("equalizer FIR full size: |gpu - oracle| <= max(2e-5, 4 x impulse-response round-off)", err,
+                      max(2 * TOL, 4.0 * noise), noise=noise)
         assert err <= max(2 * TOL, 4.0 * noise), (c, err, noise)
