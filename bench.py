@@ -554,6 +554,7 @@ def run_dynfilter(args, mi, torch, dist, rank, world, dev):
     df = mi.DynFilterBank(C, 1)
     df.set_sample_rate(48000)
     df.set_params(0, FLT_BT_RLC_BELL, 2, 1000.0, 1000.0, 1.0, 2.0)
+    df.set_filter_active(0, True)                  # (filters start inactive, DynamicFilters.cpp:108-120: process() copies)
     ring = 4
     gen = torch.Generator(device="cpu"); gen.manual_seed(95 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
@@ -566,6 +567,7 @@ def run_dynfilter(args, mi, torch, dist, rank, world, dev):
         df.process(0, out, xin[i % ring], curve, n, stream=stream)
     elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
     assert bool(torch.isfinite(out).all()) and float(out.abs().max()) > 0.0
+    assert float((out - xin[(args.conv_steps - 1) % ring]).abs().max()) > 1e-3, "the filter did not act on the signal"
     df.close()
     if rank != 0:
         return None

@@ -139,7 +139,14 @@ namespace
             case MI_FLT_BT_RLC_BELL: case MI_FLT_BT_RLC_RESONANCE:                      // :913-991
             {
                 const float fg = expf(logf(g) / float(slope));
+#ifdef __HIP_DEVICE_COMPILE__
+                // sin(atan(x)) = x / sqrt(1 + x^2), cos(atan(x)) = 1 / sqrt(1 + x^2): the same numbers to the last bits of
+                // float32 without the two transcendental calls per sample (the host keeps the reference's expression)
+                const float rs = 1.0f / sqrtf(fmaf(fg, fg, 1.0f));
+                const float tsin = fg * rs, tcos = rs;
+#else
                 const float tsin = sinf(atanf(fg)), tcos = sqrtf(1.0f - tsin * tsin);
+#endif
                 const float k = (p.base == MI_FLT_BT_RLC_BELL) ? 2.0f * (1.0f / fg + fg) / (1.0f + (2.0f * Q) / float(slope))
                                                                : 2.0f / (1.0f + Q);
                 set3(t, 1.0f, k * tsin, 1.0f);
@@ -408,7 +415,9 @@ namespace
         float       f0;          // fFreq (matched transform)
     };
 
-    __host__ __device__ inline section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
+    // (not inlined on the device: the kernel calls it once per sample of a lane, and eight or sixteen inlined copies of the
+    // builders' switch need more registers than a wave has)
+    __host__ __device__ __attribute__((noinline)) section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
     {
         float t[3], b[3];
         dyn_cascade(f.p, J, g, t, b);
@@ -416,15 +425,27 @@ namespace
     }
 
     // ---- kernel -----------------------------------------------------------------------------------------------
-    constexpr int LC = 16;                       // samples per lane and block
-    constexpr int BLK = 64 * LC;                 // samples per block of a wave (= the reference's BUF_SIZE, 0x400)
+    // One workgroup of NW waves per channel; a lane owns LC consecutive samples, the workgroup a super-block of
+    // NW x 64 x LC samples (longer calls walk super-block after super-block).  Per section: every lane builds the
+    // coefficients of its samples from the gain curve, folds its chunk into the affine map of the section state
+    // s -> M s + v, an inclusive shuffle scan composes the maps inside the wave, the waves' total maps meet in LDS, and
+    // the exact per-sample recurrence runs from each chunk's true start state.  What dominates is the coefficient
+    // arithmetic (transcendental functions per sample and section): hence as many waves as the block has work for
+    // (four per SIMD at 1024 channels x 4096 samples instead of one), and the sections of one sample are built once
+    // for the filter types whose cascades do not depend on the cascade index.
+    constexpr int LC = 8;                        // samples per lane and super-block
 
-    struct aff { float m00, m01, m10, m11, v0, v1; };      // s -> M s + v
+    struct aff { float m00, m01, m10, m11, v0, v1; };      // s -> M s + v  (a lane's own chunk)
+    // The chunk maps are composed across lanes and waves in double: a product of several hundred 2 x 2 matrices with
+    // eigenvalues next to the unit circle collects more float32 round-off than the recurrence it stands for (LRX low-pass:
+    // 3e-5 of the peak against the recurrence's own 6e-6, also when only the 64 maps of a wave are composed in float32),
+    // and the scan is a small part of the section's arithmetic.
+    struct affd { double m00, m01, m10, m11, v0, v1; };
 
     // the map of `first` followed by `then`
-    __device__ __forceinline__ aff then_(const aff &first, const aff &then)
+    __device__ __forceinline__ affd then_(const affd &first, const affd &then)
     {
-        aff r;
+        affd r;
         r.m00 = then.m00 * first.m00 + then.m01 * first.m10;
         r.m01 = then.m00 * first.m01 + then.m01 * first.m11;
         r.m10 = then.m10 * first.m00 + then.m11 * first.m10;
@@ -434,43 +455,71 @@ namespace
         return r;
     }
 
-    __global__ __launch_bounds__(64)
-    void dynfilter_kernel(float *out, const float *in, const float *gain, size_t out_stride, size_t in_stride,
-                          size_t gain_stride, uint32_t samples, dyn_filter f, float *state /* [channels][CHAINS_MAX][2] */)
+    // filter types whose analog cascade is the same for every cascade index J (dyn_cascade above)
+    __host__ __device__ inline bool uniform_cascades(uint32_t base)
     {
-        const uint32_t ch = blockIdx.x, lane = threadIdx.x;
+        return base == MI_FLT_BT_RLC_BELL || base == MI_FLT_BT_RLC_RESONANCE || base == MI_FLT_BT_RLC_NOTCH ||
+               base == MI_FLT_BT_AMPLIFIER;
+    }
+
+    template <int NW>
+    __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 VGPRs: two workgroups of 512 per CU
+    void dynfilter_kernel(float *out, const float *in, const float *gain, size_t out_stride, size_t in_stride,
+                          size_t gain_stride, uint32_t samples, dyn_filter f, float *state /* [channels][CHAINS_MAX][2] */,
+                          int aligned)
+    {
+        constexpr uint32_t SUPER = uint32_t(NW) * 64u * uint32_t(LC);
+        const uint32_t ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const float *x_in = in + size_t(ch) * in_stride;
         const float *g_in = gain + size_t(ch) * gain_stride;
         float *y_out = out + size_t(ch) * out_stride;
         float2 *gmem = reinterpret_cast<float2 *>(state + size_t(ch) * CHAINS_MAX * 2);
-        // the cascades' carried state lives in LDS for the launch (a wave's LDS accesses complete in program order)
-        __shared__ float2 mem[CHAINS_MAX];
-        for (uint32_t J = lane; J < f.nc; J += 64)
+        __shared__ float2 mem[CHAINS_MAX];                  // the cascades' carried state, in LDS for the launch
+        __shared__ affd wmap[NW];                           // each wave's map of the section in hand
+        for (uint32_t J = tid; J < f.nc; J += 64 * NW)
             mem[J] = gmem[J];
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();
+        const bool uniform = uniform_cascades(f.p.base);
 
-        for (uint32_t pos = 0; pos < samples; pos += BLK)
+        for (uint32_t pos = 0; pos < samples; pos += SUPER)
         {
             const uint32_t left = samples - pos;
-            const uint32_t valid = (left >= uint32_t(BLK)) ? uint32_t(BLK) : left;      // samples of this block
-            const uint32_t c0 = lane * LC;                                              // the lane's chunk in the block
+            const uint32_t valid = (left >= SUPER) ? SUPER : left;                      // samples of this super-block
+            const uint32_t c0 = tid * LC;                                               // the lane's chunk in it
             float x[LC], g[LC];
-            #pragma unroll
-            for (int k = 0; k < LC; ++k)
+            if (aligned && c0 + LC <= valid)
             {
-                const bool ok = c0 + k < valid;
-                x[k] = ok ? x_in[pos + c0 + k] : 0.0f;
-                g[k] = ok ? g_in[pos + c0 + k] : 1.0f;
+                #pragma unroll
+                for (int k = 0; k < LC; k += 4)
+                {
+                    const float4 xv = *reinterpret_cast<const float4 *>(x_in + pos + c0 + k);
+                    const float4 gv = *reinterpret_cast<const float4 *>(g_in + pos + c0 + k);
+                    x[k] = xv.x; x[k + 1] = xv.y; x[k + 2] = xv.z; x[k + 3] = xv.w;
+                    g[k] = gv.x; g[k + 1] = gv.y; g[k + 2] = gv.z; g[k + 3] = gv.w;
+                }
             }
-            const int nk = (c0 >= valid) ? 0 : ((valid - c0 >= uint32_t(LC)) ? LC : int(valid - c0));   // lane's samples
-            const uint32_t last_lane = (valid - 1) / LC;                                // holds the block's last sample
-
-            for (uint32_t J = 0; J < f.nc; ++J)
+            else
             {
-                section5 q[LC];
                 #pragma unroll
                 for (int k = 0; k < LC; ++k)
-                    q[k] = dyn_section(f, J, g[k]);
+                {
+                    const bool ok = c0 + k < valid;
+                    x[k] = ok ? x_in[pos + c0 + k] : 0.0f;
+                    g[k] = ok ? g_in[pos + c0 + k] : 1.0f;
+                }
+            }
+            const int nk = (c0 >= valid) ? 0 : ((valid - c0 >= uint32_t(LC)) ? LC : int(valid - c0));   // lane's samples
+            const uint32_t last_tid = (valid - 1) / LC;                                 // holds the super-block's last sample
+
+            section5 q[LC];
+            for (uint32_t J = 0; J < f.nc; ++J)
+            {
+                if (J == 0 || !uniform)
+                {
+                    #pragma unroll
+                    for (int k = 0; k < LC; ++k)
+                        q[k] = dyn_section(f, J, g[k]);
+                }
                 // the chunk's state map: d0' = a1 d0 + d1 + (b1 + a1 b0) x,  d1' = a2 d0 + (b2 + a2 b0) x
                 aff m = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f };
                 #pragma unroll
@@ -488,24 +537,39 @@ namespace
                         m = r;
                     }
                 }
-                // inclusive scan over the lanes: afterwards m maps the block's start state to the state after this chunk
+                // inclusive scan over the lanes: afterwards md maps the wave's start state to the state after this chunk
+                affd md = { double(m.m00), double(m.m01), double(m.m10), double(m.m11), double(m.v0), double(m.v1) };
                 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1)
                 {
-                    aff o;
-                    o.m00 = __shfl_up(m.m00, d); o.m01 = __shfl_up(m.m01, d); o.m10 = __shfl_up(m.m10, d);
-                    o.m11 = __shfl_up(m.m11, d); o.v0 = __shfl_up(m.v0, d);   o.v1 = __shfl_up(m.v1, d);
+                    affd o;
+                    o.m00 = __shfl_up(md.m00, d); o.m01 = __shfl_up(md.m01, d); o.m10 = __shfl_up(md.m10, d);
+                    o.m11 = __shfl_up(md.m11, d); o.v0 = __shfl_up(md.v0, d);   o.v1 = __shfl_up(md.v1, d);
                     if (int(lane) >= d)
-                        m = then_(o, m);
+                        md = then_(o, md);
                 }
-                // start state of the lane's chunk: the map of everything before it, applied to the carried state
+                // the state entering this wave: the carried state through the maps of the waves before it
                 const float2 cs = mem[J];
-                const float s0 = cs.x, s1 = cs.y;
-                aff e;
-                e.m00 = __shfl_up(m.m00, 1); e.m01 = __shfl_up(m.m01, 1); e.m10 = __shfl_up(m.m10, 1);
-                e.m11 = __shfl_up(m.m11, 1); e.v0 = __shfl_up(m.v0, 1);   e.v1 = __shfl_up(m.v1, 1);
-                float d0 = (lane == 0) ? s0 : e.m00 * s0 + e.m01 * s1 + e.v0;
-                float d1 = (lane == 0) ? s1 : e.m10 * s0 + e.m11 * s1 + e.v1;
+                double w0 = cs.x, w1 = cs.y;
+                if (NW > 1)
+                {
+                    if (lane == 63)
+                        wmap[wave] = md;
+                    __syncthreads();
+                    for (uint32_t v = 0; v < wave; ++v)
+                    {
+                        const affd p = wmap[v];
+                        const double n0 = p.m00 * w0 + p.m01 * w1 + p.v0, n1 = p.m10 * w0 + p.m11 * w1 + p.v1;
+                        w0 = n0;
+                        w1 = n1;
+                    }
+                }
+                // start state of the lane's chunk: the map of everything before it in the wave, applied to that state
+                affd e;
+                e.m00 = __shfl_up(md.m00, 1); e.m01 = __shfl_up(md.m01, 1); e.m10 = __shfl_up(md.m10, 1);
+                e.m11 = __shfl_up(md.m11, 1); e.v0 = __shfl_up(md.v0, 1);   e.v1 = __shfl_up(md.v1, 1);
+                float d0 = float((lane == 0) ? w0 : e.m00 * w0 + e.m01 * w1 + e.v0);
+                float d1 = float((lane == 0) ? w1 : e.m10 * w0 + e.m11 * w1 + e.v1);
                 // the exact recurrence with the sample's own coefficients (dsp::dyn_biquad_process_x1)
                 #pragma unroll
                 for (int k = 0; k < LC; ++k)
@@ -521,18 +585,26 @@ namespace
                         x[k] = y;
                     }
                 }
-                __builtin_amdgcn_wave_barrier();
-                if (lane == last_lane)                          // carried to the next block / call
+                __syncthreads();                                // every wave has read mem[J] and wmap[]
+                if (tid == last_tid)                            // carried to the next super-block / call
                     mem[J] = make_float2(d0, d1);
-                __builtin_amdgcn_wave_barrier();
             }
-            #pragma unroll
-            for (int k = 0; k < LC; ++k)
-                if (c0 + k < valid)
-                    y_out[pos + c0 + k] = x[k];
+            if (aligned && c0 + LC <= valid)
+            {
+                #pragma unroll
+                for (int k = 0; k < LC; k += 4)
+                    *reinterpret_cast<float4 *>(y_out + pos + c0 + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
+            }
+            else
+            {
+                #pragma unroll
+                for (int k = 0; k < LC; ++k)
+                    if (c0 + k < valid)
+                        y_out[pos + c0 + k] = x[k];
+            }
+            __syncthreads();                                    // mem[] of the last section before the next super-block reads it
         }
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t J = lane; J < f.nc; J += 64)
+        for (uint32_t J = tid; J < f.nc; J += 64 * NW)
             gmem[J] = mem[J];
     }
 
@@ -727,8 +799,17 @@ int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, c
         b->clear_mem = false;
     }
     float *state = b->d_state + size_t(id) * b->channels * CHAINS_MAX * 2;
-    hipLaunchKernelGGL(dynfilter_kernel, dim3(b->channels), dim3(64), 0, st, out, in, gain, out_stride, in_stride,
-                       gain_stride, uint32_t(samples), f, state);
+    const int aligned = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(gain)) % 16 == 0 &&
+                         out_stride % 4 == 0 && in_stride % 4 == 0 && gain_stride % 4 == 0) ? 1 : 0;
+    // as many waves per channel as the call has chunks for (a wave covers 64 x LC = 512 samples), up to eight
+    const size_t chunks = (samples + 64 * LC - 1) / (64 * LC);
+    #define MI_DYN_LAUNCH(NW) hipLaunchKernelGGL((dynfilter_kernel<NW>), dim3(b->channels), dim3(64 * NW), 0, st, out, in, gain, \
+                                                 out_stride, in_stride, gain_stride, uint32_t(samples), f, state, aligned)
+    if (chunks <= 1)      MI_DYN_LAUNCH(1);
+    else if (chunks <= 2) MI_DYN_LAUNCH(2);
+    else if (chunks <= 4) MI_DYN_LAUNCH(4);
+    else                  MI_DYN_LAUNCH(8);
+    #undef MI_DYN_LAUNCH
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
