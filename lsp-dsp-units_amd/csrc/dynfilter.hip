@@ -415,9 +415,7 @@ namespace
         float       f0;          // fFreq (matched transform)
     };
 
-    // (not inlined on the device: the kernel calls it once per sample of a lane, and eight or sixteen inlined copies of the
-    // builders' switch need more registers than a wave has)
-    __host__ __device__ __attribute__((noinline)) section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
+    __host__ __device__ inline section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
     {
         float t[3], b[3];
         dyn_cascade(f.p, J, g, t, b);
@@ -463,7 +461,7 @@ namespace
     }
 
     template <int NW>
-    __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(4)))      // <= 128 VGPRs: two workgroups of 512 per CU
+    __global__ __launch_bounds__(64 * NW)
     void dynfilter_kernel(float *out, const float *in, const float *gain, size_t out_stride, size_t in_stride,
                           size_t gain_stride, uint32_t samples, dyn_filter f, float *state /* [channels][CHAINS_MAX][2] */,
                           int aligned)
@@ -476,6 +474,11 @@ namespace
         float2 *gmem = reinterpret_cast<float2 *>(state + size_t(ch) * CHAINS_MAX * 2);
         __shared__ float2 mem[CHAINS_MAX];                  // the cascades' carried state, in LDS for the launch
         __shared__ affd wmap[NW];                           // each wave's map of the section in hand
+        // The sections of the lane's samples, [sample][coefficient][thread]: they are built in ONE rolled loop (a single
+        // inlined copy of the builders' switch, whose gain-independent parts -- the sines and cosines of angles that depend
+        // on the cascade index and the slope only -- the compiler hoists out of the loop) and read back where needed.
+        __shared__ float qs[LC][5][64 * NW];
+        __shared__ float gs[LC][64 * NW];
         for (uint32_t J = tid; J < f.nc; J += 64 * NW)
             mem[J] = gmem[J];
         __syncthreads();
@@ -511,15 +514,24 @@ namespace
             const int nk = (c0 >= valid) ? 0 : ((valid - c0 >= uint32_t(LC)) ? LC : int(valid - c0));   // lane's samples
             const uint32_t last_tid = (valid - 1) / LC;                                 // holds the super-block's last sample
 
-            section5 q[LC];
+            #pragma unroll
+            for (int k = 0; k < LC; ++k)
+                gs[k][tid] = g[k];
             for (uint32_t J = 0; J < f.nc; ++J)
             {
                 if (J == 0 || !uniform)
                 {
-                    #pragma unroll
+                    #pragma unroll 1
                     for (int k = 0; k < LC; ++k)
-                        q[k] = dyn_section(f, J, g[k]);
+                    {
+                        const section5 c = dyn_section(f, J, gs[k][tid]);
+                        qs[k][0][tid] = c.b0; qs[k][1][tid] = c.b1; qs[k][2][tid] = c.b2; qs[k][3][tid] = c.a1; qs[k][4][tid] = c.a2;
+                    }
                 }
+                section5 q[LC];
+                #pragma unroll
+                for (int k = 0; k < LC; ++k)
+                    q[k] = section5{ qs[k][0][tid], qs[k][1][tid], qs[k][2][tid], qs[k][3][tid], qs[k][4][tid] };
                 // the chunk's state map: d0' = a1 d0 + d1 + (b1 + a1 b0) x,  d1' = a2 d0 + (b2 + a2 b0) x
                 aff m = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f };
                 #pragma unroll
@@ -801,14 +813,14 @@ int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, c
     float *state = b->d_state + size_t(id) * b->channels * CHAINS_MAX * 2;
     const int aligned = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(gain)) % 16 == 0 &&
                          out_stride % 4 == 0 && in_stride % 4 == 0 && gain_stride % 4 == 0) ? 1 : 0;
-    // as many waves per channel as the call has chunks for (a wave covers 64 x LC = 512 samples), up to eight
+    // as many waves per channel as the call has chunks for (a wave covers 64 x LC = 512 samples), up to four (48 KiB of
+    // LDS per workgroup: three workgroups per CU)
     const size_t chunks = (samples + 64 * LC - 1) / (64 * LC);
     #define MI_DYN_LAUNCH(NW) hipLaunchKernelGGL((dynfilter_kernel<NW>), dim3(b->channels), dim3(64 * NW), 0, st, out, in, gain, \
                                                  out_stride, in_stride, gain_stride, uint32_t(samples), f, state, aligned)
     if (chunks <= 1)      MI_DYN_LAUNCH(1);
     else if (chunks <= 2) MI_DYN_LAUNCH(2);
-    else if (chunks <= 4) MI_DYN_LAUNCH(4);
-    else                  MI_DYN_LAUNCH(8);
+    else                  MI_DYN_LAUNCH(4);
     #undef MI_DYN_LAUNCH
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
