@@ -528,10 +528,7 @@ namespace
                         qs[k][0][tid] = c.b0; qs[k][1][tid] = c.b1; qs[k][2][tid] = c.b2; qs[k][3][tid] = c.a1; qs[k][4][tid] = c.a2;
                     }
                 }
-                section5 q[LC];
-                #pragma unroll
-                for (int k = 0; k < LC; ++k)
-                    q[k] = section5{ qs[k][0][tid], qs[k][1][tid], qs[k][2][tid], qs[k][3][tid], qs[k][4][tid] };
+                auto q_of = [&](int k) -> section5 { return section5{ qs[k][0][tid], qs[k][1][tid], qs[k][2][tid], qs[k][3][tid], qs[k][4][tid] }; };
                 // the chunk's state map: d0' = a1 d0 + d1 + (b1 + a1 b0) x,  d1' = a2 d0 + (b2 + a2 b0) x
                 aff m = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f };
                 #pragma unroll
@@ -539,8 +536,9 @@ namespace
                 {
                     if (k < nk)
                     {
-                        const float a1 = q[k].a1, a2 = q[k].a2;
-                        const float u0 = (q[k].b1 + a1 * q[k].b0) * x[k], u1 = (q[k].b2 + a2 * q[k].b0) * x[k];
+                        const section5 c = q_of(k);
+                        const float a1 = c.a1, a2 = c.a2;
+                        const float u0 = (c.b1 + a1 * c.b0) * x[k], u1 = (c.b2 + a2 * c.b0) * x[k];
                         aff r;
                         r.m00 = a1 * m.m00 + m.m10;  r.m01 = a1 * m.m01 + m.m11;
                         r.m10 = a2 * m.m00;          r.m11 = a2 * m.m01;
@@ -588,12 +586,13 @@ namespace
                 {
                     if (k < nk)
                     {
+                        const section5 c = q_of(k);
                         const float xx = x[k];                  // same operation order as biquad.hip's sections
-                        const float tq = fmaf(q[k].b1, xx, d1);
-                        const float u  = q[k].b2 * xx;
-                        const float y  = fmaf(q[k].b0, xx, d0);
-                        d0 = fmaf(q[k].a1, y, tq);
-                        d1 = fmaf(q[k].a2, y, u);
+                        const float tq = fmaf(c.b1, xx, d1);
+                        const float u  = c.b2 * xx;
+                        const float y  = fmaf(c.b0, xx, d0);
+                        d0 = fmaf(c.a1, y, tq);
+                        d1 = fmaf(c.a2, y, u);
                         x[k] = y;
                     }
                 }
