@@ -166,6 +166,34 @@ def test_exact_resummation_inside_long_runs(gpu, blocks):
     bank.close()
 
 
+def test_vector_and_scalar_block_kernels_agree(gpu, monkeypatch):
+    """Blocks whose length, line position and period are multiples of four take the kernel with four samples per lane,
+    anything else the one-sample kernel (MI_LOUDNESS_SCALAR forces it): the same stream through both, several laps of the
+    lines with the exact re-summation inside the blocks, must agree to float32 round-off of the scan order (and both with
+    the oracle through the other tests)."""
+    sr, M, K, n = 48000, 3, 2, 4096
+    rng = np.random.default_rng(17)
+    xs = [(rng.standard_normal((M * K, n)) * (0.3 if i % 3 else 0.03)).astype(np.float32) for i in range(12)]
+    runs = []
+    for scalar in (False, True):
+        if scalar:
+            monkeypatch.setenv("MI_LOUDNESS_SCALAR", "1")
+        else:
+            monkeypatch.delenv("MI_LOUDNESS_SCALAR", raising=False)
+        bank = gpu.LoudnessBank(M, K, 400.0)
+        bank.set_sample_rate(sr); bank.set_link(1, 0.4)
+        outs = []
+        for x in xs:
+            out = gpu.DeviceBuffer((M, n)); ch = gpu.DeviceBuffer((M * K, n))
+            bank.process(out, ch, gpu.DeviceBuffer.from_host(x), n)
+            outs.append((out.download(), ch.download()))
+        runs.append(outs)
+        bank.close()
+    peak = max(float(o.max()) for o, _ in runs[0])
+    for (a, ac), (b, bc) in zip(*runs):
+        assert np.abs(a - b).max() <= 2e-6 * peak and np.abs(ac - bc).max() <= 2e-6 * peak
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_random_operation_sequences(gpu, seed):
     """Differential stress of the momentary / short-term meter bank: period, weighting, designation, link and activity
