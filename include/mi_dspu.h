@@ -383,7 +383,8 @@ enum { MI_SPECTRAL_OP_NONE = 0, MI_SPECTRAL_OP_MASK = 1, MI_SPECTRAL_OP_CALLBACK
  */
 typedef void (*mi_spectral_func_t)(void *object, void *subject, float *spectrum, size_t rank, size_t channels, void *stream);
 
-/* SpectralProcessor::init(max_rank), SpectralProcessor.cpp:59-75 (ranks 5..14 supported). */
+/* SpectralProcessor::init(max_rank), SpectralProcessor.cpp:59-75 (ranks 5..18: frames up to 2^14 samples are transformed
+ * in LDS in one launch per hop, longer ones through global memory in several). */
 int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32_t max_rank);
 int mi_spectral_bank_destroy(mi_spectral_bank_t *bank);
 /* set_rank / set_phase, SpectralProcessor.cpp:127-145 (a rank above max_rank is ignored, phase is clamped to 0..1). */

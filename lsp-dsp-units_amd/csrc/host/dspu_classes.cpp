@@ -1019,7 +1019,7 @@ bool SpectralProcessor::init(size_t max_rank)
     if (p == nullptr)
         return false;
     // the library holds frames up to 2^13; larger max_rank values are accepted as long as the rank in use fits
-    const uint32_t cap = uint32_t(std::min<size_t>(std::max<size_t>(max_rank, 5), 14));
+    const uint32_t cap = uint32_t(std::min<size_t>(std::max<size_t>(max_rank, 5), 18));
     if (mi_spectral_bank_create(&p->bank, 1, cap) != MI_OK)
     {
         delete p;
@@ -1183,7 +1183,7 @@ bool MultiSpectralProcessor::init(size_t channels, size_t max_rank)
     impl_t *p = new (std::nothrow) impl_t();
     if (p == nullptr)
         return false;
-    const uint32_t cap = uint32_t(std::min<size_t>(std::max<size_t>(max_rank, 5), 14));
+    const uint32_t cap = uint32_t(std::min<size_t>(std::max<size_t>(max_rank, 5), 18));
     if (mi_spectral_bank_create(&p->bank, uint32_t(channels), cap) != MI_OK)
     {
         delete p;

@@ -198,6 +198,132 @@ namespace
         }
     }
 
+    // ---- frames above 2^14 samples (ranks 15 .. BIG_MAX_RANK) ------------------------------------------------------
+    // Such a frame does not fit the LDS of a workgroup.  Its transform goes through global memory as a four-step complex
+    // transform N = N1 x N2: N2 = N / 8192 interleaved sub-sequences of N1 = 8192 points are transformed in LDS with the
+    // core above and multiplied by W_N^(n2 k1); N1 columns of N2 <= 32 points are then summed directly.  With
+    // n = n1 N2 + n2 and k = k1 + N1 k2:  X[k] = sum_n2 W_N2^(n2 k2) [ W_N^(n2 k1) sum_n1 x[n1 N2 + n2] W_N1^(n1 k1) ].
+    // The frame is treated as complex with a zero imaginary part and only the real part of the way back is kept, which is
+    // what the reference does (pcomplex_r2c ... pcomplex_c2r, SpectralProcessor.cpp:164-169).  These frames are rare and
+    // long: the path is several plain launches per hop, not a fused kernel.
+    constexpr int BIG_LOG1 = 13, BIG_N1 = 1 << BIG_LOG1, BIG_MAX_RANK = 18;
+
+    // work[n] = (in[n] * w[n], 0)
+    __global__ __launch_bounds__(256)
+    void big_window_kernel(float2 *work, const float *__restrict__ in_buf, const float *__restrict__ wnd, uint32_t N)
+    {
+        const uint32_t n = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (n < N)
+        {
+            const float v = in_buf[size_t(ch) * N + n];
+            work[size_t(ch) * N + n] = make_float2((wnd != nullptr) ? v * wnd[n] : v, 0.0f);
+        }
+    }
+
+    template <bool INVERSE>
+    __global__ __launch_bounds__(plan<BIG_LOG1>::T)
+    void big_rows_kernel(float2 *dst /* [ch][N2][N1] */, const float2 *__restrict__ src /* [ch][N] */, uint32_t N2, uint32_t N,
+                         const float2 *__restrict__ tw)
+    {
+        constexpr int T = plan<BIG_LOG1>::T;
+        __shared__ float2 buf[BIG_N1], scr[BIG_N1];
+        const uint32_t n2 = blockIdx.x, ch = blockIdx.y;
+        const int tid = threadIdx.x;
+        fft_tw<BIG_LOG1> ft;
+        load_fft_tw<BIG_LOG1>(ft, tw, TWN / BIG_N1, tid);
+        finish_fft_tw<BIG_LOG1>(ft);
+        const float2 *x = src + size_t(ch) * N;
+        for (int n1 = tid; n1 < BIG_N1; n1 += T)
+            buf[n1] = x[size_t(n1) * N2 + n2];
+        __syncthreads();
+        fft_lds<BIG_LOG1, INVERSE>(buf, scr, ft, tid);
+        float2 *y = dst + size_t(ch) * N + size_t(n2) * BIG_N1;
+        const float unit = (INVERSE ? 2.0f : -2.0f) / float(N);     // n2 k1 < N <= 2^18: exact in float32
+        for (int k1 = tid; k1 < BIG_N1; k1 += T)
+        {
+            float sn, cs;
+            sincospif(unit * float(n2 * uint32_t(k1)), &sn, &cs);
+            y[k1] = cmul(buf[k1], make_float2(cs, sn));
+        }
+    }
+
+    template <int LOG2, bool INVERSE>
+    __global__ __launch_bounds__(256)
+    void big_cols_kernel(float2 *dst /* [ch][N] natural order */, const float2 *__restrict__ src /* [ch][N2][N1] */, uint32_t N)
+    {
+        constexpr int N2 = 1 << LOG2;
+        const uint32_t k1 = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        float2 y[N2];
+        #pragma unroll
+        for (int n2 = 0; n2 < N2; ++n2)
+            y[n2] = src[size_t(ch) * N + size_t(n2) * BIG_N1 + k1];
+        #pragma unroll
+        for (int k2 = 0; k2 < N2; ++k2)
+        {
+            float2 acc = y[0];
+            #pragma unroll
+            for (int n2 = 1; n2 < N2; ++n2)
+            {
+                const int j = (n2 * k2) & (N2 - 1);                    // W_N2^(n2 k2): folded at compile time
+                const double a = (INVERSE ? 2.0 : -2.0) * 3.14159265358979323846 * double(j) / double(N2);
+                const float2 w = make_float2(float(__builtin_cos(a)), float(__builtin_sin(a)));
+                acc = cadd(acc, cmul(y[n2], w));
+            }
+            dst[size_t(ch) * N + k1 + size_t(BIG_N1) * k2] = acc;
+        }
+    }
+
+    // S[k] *= mask[min(k, N - k)]  (the N/2 + 1 real gains of bind_mask act on k and N - k alike)
+    __global__ __launch_bounds__(256)
+    void big_mask_kernel(float2 *spec, const float *__restrict__ mask, size_t mask_stride, uint32_t N)
+    {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (k < N)
+        {
+            const float g = mask[size_t(ch) * mask_stride + ((k <= N / 2) ? k : N - k)];
+            float2 &v = spec[size_t(ch) * N + k];
+            v = make_float2(v.x * g, v.y * g);
+        }
+    }
+
+    // channels without a bound input: their windowed frame travels on in the spectrum buffer (MultiSpectralProcessor.cpp:346-350)
+    __global__ __launch_bounds__(256)
+    void big_unbound_kernel(float2 *spec, const float2 *__restrict__ work, const uint8_t *__restrict__ active, uint32_t N)
+    {
+        const uint32_t n = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (n < N && active[ch] == 0)
+            reinterpret_cast<float *>(spec + size_t(ch) * N)[n] = work[size_t(ch) * N + n].x;
+    }
+
+    // overlap-add with the output window (out shifted by half a frame), then the input buffer moves on by half a frame
+    __global__ __launch_bounds__(256)
+    void big_ola_kernel(float *in_buf, float *out_buf, const float2 *__restrict__ work, const float2 *__restrict__ spec,
+                        const float *__restrict__ wnd_out, float scale, uint32_t N, const uint8_t *__restrict__ active,
+                        const uint8_t *__restrict__ has_out)
+    {
+        const uint32_t m = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y, half = N >> 1;
+        if (m >= half)
+            return;
+        const bool on = (spec == nullptr) || (((active == nullptr) || active[ch] != 0) && ((has_out == nullptr) || has_out[ch] != 0));
+        float y0, y1;
+        if (on)
+        {
+            y0 = work[size_t(ch) * N + m].x * scale;
+            y1 = work[size_t(ch) * N + m + half].x * scale;
+        }
+        else
+        {
+            const float *f = reinterpret_cast<const float *>(spec + size_t(ch) * N);
+            y0 = f[m];
+            y1 = f[m + half];
+        }
+        float *o = out_buf + size_t(ch) * N, *x = in_buf + size_t(ch) * N;
+        const float prev = o[m + half];
+        o[m]        = fmaf(y0, wnd_out[m], prev);
+        o[m + half] = y1 * wnd_out[m + half];
+        x[m] = x[m + half];
+    }
+
     // process(src, count) of the reference -- analysis only (SpectralProcessor.cpp:201-249): no inverse transform and
     // nothing is added to the output buffer; it is shifted by half a frame and its tail zeroed, the input buffer shifted.
     __global__ __launch_bounds__(256)
@@ -435,6 +561,7 @@ struct mi_spectral_bank
     uint8_t    *d_active = nullptr, *d_has_out = nullptr;   // MultiSpectralProcessor bindings (NULL: all bound)
     size_t      mask_stride = 0;
     const float2 *d_tw = nullptr;
+    float2     *d_big_work = nullptr, *d_big_tmp = nullptr;    // frames above 2^14 samples: the transform's scratch
 };
 
 namespace mi
@@ -488,8 +615,80 @@ namespace
         return MI_OK;
     }
 
+    template <bool INVERSE>
+    int big_fft(mi_spectral_bank *b, float2 *dst, const float2 *src, hipStream_t st)
+    {
+        const uint32_t N = 1u << b->rank, N2 = N / uint32_t(BIG_N1);
+        hipLaunchKernelGGL((big_rows_kernel<INVERSE>), dim3(N2, b->channels), dim3(plan<BIG_LOG1>::T), 0, st, b->d_big_tmp, src, N2, N, b->d_tw);
+        MI_HIP_CHECK(hipGetLastError());
+        const dim3 grid(BIG_N1 / 256, b->channels);
+        switch (b->rank - BIG_LOG1)
+        {
+            case 2:  hipLaunchKernelGGL((big_cols_kernel<2, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
+            case 3:  hipLaunchKernelGGL((big_cols_kernel<3, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
+            case 4:  hipLaunchKernelGGL((big_cols_kernel<4, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
+            default: hipLaunchKernelGGL((big_cols_kernel<5, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
+        }
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+
+    // a hop of a frame above 2^14 samples: the same steps as stft_hop_kernel / stft_inverse_kernel, one launch each
+    int spectral_hop_big(mi_spectral_bank *b, hipStream_t st, bool analyze_only)
+    {
+        const uint32_t N = 1u << b->rank, frame = N >> 1;
+        const dim3 gN((N + 255) / 256, b->channels), gH((frame + 255) / 256, b->channels);
+        const bool callback = (b->op == MI_SPECTRAL_OP_CALLBACK) && (b->func != nullptr);
+        const bool transform = callback || (b->op == MI_SPECTRAL_OP_MASK);
+        if (analyze_only && !callback)
+        {
+            hipLaunchKernelGGL(stft_shift_kernel, gH, dim3(256), 0, st, b->d_in, b->d_out, frame);
+            MI_HIP_CHECK(hipGetLastError());
+            return MI_OK;
+        }
+        hipLaunchKernelGGL(big_window_kernel, gN, dim3(256), 0, st, b->d_big_work, b->d_in,
+                           (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, N);
+        MI_HIP_CHECK(hipGetLastError());
+        if (transform)
+        {
+            int r = big_fft<false>(b, b->d_spec, b->d_big_work, st);
+            if (r != MI_OK)
+                return r;
+            if (callback)
+            {
+                if (b->d_active != nullptr)
+                {
+                    hipLaunchKernelGGL(big_unbound_kernel, gN, dim3(256), 0, st, b->d_spec, b->d_big_work, b->d_active, N);
+                    MI_HIP_CHECK(hipGetLastError());
+                }
+                b->func(b->object, b->subject, reinterpret_cast<float *>(b->d_spec), b->rank, b->channels, st);
+            }
+            else
+            {
+                hipLaunchKernelGGL(big_mask_kernel, gN, dim3(256), 0, st, b->d_spec, b->d_mask, b->mask_stride, N);
+                MI_HIP_CHECK(hipGetLastError());
+            }
+            if (analyze_only)
+            {
+                hipLaunchKernelGGL(stft_shift_kernel, gH, dim3(256), 0, st, b->d_in, b->d_out, frame);
+                MI_HIP_CHECK(hipGetLastError());
+                return MI_OK;
+            }
+            r = big_fft<true>(b, b->d_big_work, b->d_spec, st);
+            if (r != MI_OK)
+                return r;
+        }
+        hipLaunchKernelGGL(big_ola_kernel, gH, dim3(256), 0, st, b->d_in, b->d_out, b->d_big_work,
+                           callback ? b->d_spec : (const float2 *)nullptr, b->d_wnd_out, transform ? 1.0f / float(N) : 1.0f, N,
+                           callback ? b->d_active : (const uint8_t *)nullptr, callback ? b->d_has_out : (const uint8_t *)nullptr);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+
     int spectral_hop(mi_spectral_bank *b, hipStream_t st, bool analyze_only = false)
     {
+        if (b->rank > 14)
+            return spectral_hop_big(b, st, analyze_only);
         const int lh = int(b->rank) - 1;
         const dim3 grid(b->channels);
         if (analyze_only)
@@ -552,8 +751,9 @@ int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_spectral_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0, MI_EINVAL, "mi_spectral_bank_create: channels must be > 0");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 14, MI_EINVAL,
-               "mi_spectral_bank_create: max_rank %u outside the supported 5..14 (frames of 32..16384 samples)", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= uint32_t(BIG_MAX_RANK), MI_EINVAL,
+               "mi_spectral_bank_create: max_rank %u outside the supported 5..%d (frames of 32..%d samples)", max_rank,
+               BIG_MAX_RANK, 1 << BIG_MAX_RANK);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_spectral_bank *b = new (std::nothrow) mi_spectral_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_spectral_bank_create: out of host memory");
@@ -569,6 +769,12 @@ int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_out), size_t(channels) * N * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), N * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd_out), N * sizeof(float));
+        if (max_rank > 14)                                  // frames that go through global memory: two complex scratch frames
+        {                                                   // and the spectrum buffer per channel
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_big_work), size_t(channels) * N * sizeof(float2));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_big_tmp), size_t(channels) * N * sizeof(float2));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_spec), size_t(channels) * N * sizeof(float2));
+        }
         if (e != hipSuccess)
             r = mi::fail(e == hipErrorOutOfMemory ? MI_ENOMEM : MI_EHIP, "mi_spectral_bank_create: %s", hipGetErrorString(e));
     }
@@ -587,6 +793,7 @@ int mi_spectral_bank_destroy(mi_spectral_bank_t *b)
         return MI_OK;
     (void)hipFree(b->d_in); (void)hipFree(b->d_out); (void)hipFree(b->d_wnd); (void)hipFree(b->d_wnd_out); (void)hipFree(b->d_mask);
     (void)hipFree(b->d_spec); (void)hipFree(b->d_active); (void)hipFree(b->d_has_out);
+    (void)hipFree(b->d_big_work); (void)hipFree(b->d_big_tmp);
     delete b;
     return MI_OK;
 }

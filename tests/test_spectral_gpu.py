@@ -291,6 +291,58 @@ def test_largest_frames_through_the_callback_path(gpu, rank):
     bank.close()
 
 
+@pytest.mark.parametrize("rank", [15, 16, 18])
+def test_frames_above_the_lds_limit(gpu, rank):
+    """Frames of 2^15 and 2^16 samples (SpectralProcessor::init has no upper bound on max_rank): the four-step transform
+    through global memory.  Three operations against the oracle: the unbound processor (the input delayed by the latency,
+    the reference's own utest at a larger rank), a gain mask (== the reference with a callback multiplying bins k and
+    N - k) and a callback that breaks the Hermitian symmetry (only the real part of the way back is kept), on ragged calls."""
+    N, H = 1 << rank, 1 << (rank - 1)
+    C, n = 2, 2 * N + H + 77
+    rng = np.random.default_rng(100 + rank)
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    calls = split(n, 30011)
+
+    # 1. nothing bound: identity after the latency
+    y, info = run_spectral(gpu, x, rank, rank, calls)
+    assert info["latency"] == N
+    for c in range(C):
+        p = sp.SpectralProcessor(rank)
+        ref = p.process(x[c])
+        assert np.abs(y[c] - ref).max() <= TOL * float(np.abs(ref).max()), ("identity", rank, c)
+    assert np.abs(y[:, N:] - x[:, :n - N]).max() <= 1e-5 * float(np.abs(x).max())
+
+    # 2. gain mask, with a phase offset
+    masks = rng.uniform(0.0, 2.0, (C, H + 1)).astype(np.float32)
+    y, _ = run_spectral(gpu, x, rank, rank, calls, setup=lambda b: b.bind_mask(masks), phase=0.25)
+    for c in range(C):
+        full = np.concatenate([masks[c], masks[c][H - 1:0:-1]]).astype(np.float32)
+        def cb(spec, r, full=full):
+            out = spec.copy(); out[0::2] *= full; out[1::2] *= full
+            return out
+        p = sp.SpectralProcessor(rank); p.set_phase(0.25); p.bind(cb)
+        ref = p.process(x[c])
+        assert np.abs(y[c] - ref).max() <= TOL * float(np.abs(ref).max()), ("mask", rank, c, np.abs(y[c] - ref).max() / np.abs(ref).max())
+
+    # 3. callback on the device spectra: channel 0 halved, channel 1 conjugated
+    def dev_cb(spec_ptr, r, channels, stream):
+        host = np.empty((channels, 2 * N), np.float32)
+        gpu.check(gpu.lib.mi_dspu_copy_d2h(host.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(spec_ptr), host.nbytes, ctypes.c_void_p(stream)))
+        gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(stream)))
+        host[0] *= np.float32(0.5)
+        host[1, 1::2] *= np.float32(-1.0)
+        gpu.check(gpu.lib.mi_dspu_copy_h2d(ctypes.c_void_p(spec_ptr), host.ctypes.data_as(ctypes.c_void_p), host.nbytes, ctypes.c_void_p(stream)))
+        gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(stream)))
+    y, _ = run_spectral(gpu, x, rank, rank, calls, setup=lambda b: b.bind(dev_cb))
+
+    def conj(spec, r):
+        out = spec.copy(); out[1::2] *= np.float32(-1.0); return out
+    for c, f in enumerate([lambda s_, r: s_ * np.float32(0.5), conj]):
+        p = sp.SpectralProcessor(rank); p.bind(f)
+        ref = p.process(x[c])
+        assert np.abs(y[c] - ref).max() <= TOL * float(np.abs(ref).max()), ("callback", rank, c)
+
+
 def test_analyzer_rank_14(gpu):
     """16384-point spectra (the largest frame: 128 KiB of LDS per workgroup) against the oracle."""
     sr, rank, C = 48000, 14, 2
