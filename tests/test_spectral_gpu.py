@@ -221,13 +221,14 @@ def test_analyzer_rejects_zero_step(gpu):
     bank.close()
 
 
-def test_lazy_transform_timing_and_analysis_only_calls(gpu):
+@pytest.mark.parametrize("rank", [8, 15])
+def test_lazy_transform_timing_and_analysis_only_calls(gpu, rank):
     """SpectralProcessor transforms a complete frame when the NEXT sample arrives (SpectralProcessor.cpp:159): after a
     call that ends on a frame boundary remaining() is 0 and the function has not seen that frame yet.  process(src, count)
     without a destination (:201-249) calls the function on every frame but adds nothing to the output buffer, it only
     shifts it and zeroes its tail -- visible when normal processing resumes."""
-    rank, n = 8, 2048
     N, frame = 1 << rank, 1 << (rank - 1)
+    n = 16 * frame
     rng = np.random.default_rng(9)
     x = rng.standard_normal((1, n)).astype(np.float32)
     calls = []
