@@ -430,7 +430,7 @@ enum { MI_ANALYZER_SAMPLE_RATE, MI_ANALYZER_RATE, MI_ANALYZER_WINDOW, MI_ANALYZE
        MI_ANALYZER_REACTIVITY, MI_ANALYZER_RANK, MI_ANALYZER_ACTIVE };
 enum { MI_ANALYZER_CH_FREEZE, MI_ANALYZER_CH_ENABLE, MI_ANALYZER_CH_DELAY };
 
-/* Analyzer::init(channels, max_rank, max_sr, min_rate, max_delay), Analyzer.cpp:83-152 (ranks 5..14 supported). */
+/* Analyzer::init(channels, max_rank, max_sr, min_rate, max_delay), Analyzer.cpp:83-152 (ranks 5..18; above 14 through global memory). */
 int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t max_sample_rate,
                             float min_rate, uint32_t max_delay);
 int mi_analyzer_bank_destroy(mi_analyzer_bank_t *bank);

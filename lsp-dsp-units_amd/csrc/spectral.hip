@@ -460,6 +460,59 @@ namespace
         }
     }
 
+    // ---- analyzer frames above 2^14 samples: the steps of analyzer_kernel as plain launches around the four-step transform
+    // work[n] = (ring[(head - N - delay + n) mod size] * w[n], 0) for the channels that are analysed
+    __global__ __launch_bounds__(256)
+    void big_an_gather_kernel(float2 *work, const float *__restrict__ ring, uint32_t buf_size, uint32_t head,
+                              const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
+                              const float *__restrict__ wnd, uint32_t N)
+    {
+        const uint32_t n = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (n >= N || flags[ch] != 1)                       // frozen or inactive: nothing is transformed
+            return;
+        int64_t doff = int64_t(head) - int64_t(N) - int64_t(delay[ch]);     // Analyzer.cpp:339-353
+        while (doff < 0)
+            doff += buf_size;
+        uint32_t i = uint32_t((uint64_t(doff) + n) % buf_size);
+        work[size_t(ch) * N + n] = make_float2(ring[size_t(ch) * buf_size + i] * wnd[n], 0.0f);
+    }
+
+    // vAmp = mix2(vAmp, |X|, 1 - tau, tau) over N/2 + 1 bins (Analyzer.cpp:359-361); frozen: kept (:334); inactive: 0 (:363-364)
+    __global__ __launch_bounds__(256)
+    void big_an_mag_kernel(const float2 *__restrict__ spec, const float *__restrict__ amp_old, float *amp_new, uint32_t amp_stride,
+                           float tau, const uint8_t *__restrict__ flags, uint32_t N)
+    {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (k > N / 2)
+            return;
+        const uint8_t fl = flags[ch];
+        const float a = amp_old[size_t(ch) * amp_stride + k];
+        float r;
+        if (fl & 2)
+            r = a;
+        else if (!(fl & 1))
+            r = 0.0f;
+        else
+        {
+            const float2 v = spec[size_t(ch) * N + k];
+            r = a * (1.0f - tau) + sqrtf(v.x * v.x + v.y * v.y) * tau;
+        }
+        amp_new[size_t(ch) * amp_stride + k] = r;
+    }
+
+    // the samples that follow the strobe go into the ring behind head (Analyzer.cpp:371-398)
+    __global__ __launch_bounds__(256)
+    void an_ingest_kernel(float *ring, uint32_t buf_size, uint32_t head, const float *__restrict__ in, size_t in_stride,
+                          uint32_t n, int zero)
+    {
+        const uint32_t i = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (i >= n)
+            return;
+        uint32_t w = head + i;
+        if (w >= buf_size) w -= buf_size;
+        ring[size_t(ch) * buf_size + w] = zero ? 0.0f : in[size_t(ch) * in_stride + i];
+    }
+
     // Per-bin reduction over channels (the C5 callback), in one launch and in an order that does not depend on the launch
     // geometry AND composes across channel shards: blocks of REDUCE_BLOCK consecutive channels are summed in channel
     // order, the block sums are then added along a binary tree aligned to powers of two (element j takes in element
@@ -616,21 +669,27 @@ namespace
     }
 
     template <bool INVERSE>
-    int big_fft(mi_spectral_bank *b, float2 *dst, const float2 *src, hipStream_t st)
+    int big_fft_run(float2 *dst, const float2 *src, float2 *tmp, uint32_t rank, uint32_t channels, const float2 *tw, hipStream_t st)
     {
-        const uint32_t N = 1u << b->rank, N2 = N / uint32_t(BIG_N1);
-        hipLaunchKernelGGL((big_rows_kernel<INVERSE>), dim3(N2, b->channels), dim3(plan<BIG_LOG1>::T), 0, st, b->d_big_tmp, src, N2, N, b->d_tw);
+        const uint32_t N = 1u << rank, N2 = N / uint32_t(BIG_N1);
+        hipLaunchKernelGGL((big_rows_kernel<INVERSE>), dim3(N2, channels), dim3(plan<BIG_LOG1>::T), 0, st, tmp, src, N2, N, tw);
         MI_HIP_CHECK(hipGetLastError());
-        const dim3 grid(BIG_N1 / 256, b->channels);
-        switch (b->rank - BIG_LOG1)
+        const dim3 grid(BIG_N1 / 256, channels);
+        switch (rank - BIG_LOG1)
         {
-            case 2:  hipLaunchKernelGGL((big_cols_kernel<2, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
-            case 3:  hipLaunchKernelGGL((big_cols_kernel<3, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
-            case 4:  hipLaunchKernelGGL((big_cols_kernel<4, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
-            default: hipLaunchKernelGGL((big_cols_kernel<5, INVERSE>), grid, dim3(256), 0, st, dst, b->d_big_tmp, N); break;
+            case 2:  hipLaunchKernelGGL((big_cols_kernel<2, INVERSE>), grid, dim3(256), 0, st, dst, tmp, N); break;
+            case 3:  hipLaunchKernelGGL((big_cols_kernel<3, INVERSE>), grid, dim3(256), 0, st, dst, tmp, N); break;
+            case 4:  hipLaunchKernelGGL((big_cols_kernel<4, INVERSE>), grid, dim3(256), 0, st, dst, tmp, N); break;
+            default: hipLaunchKernelGGL((big_cols_kernel<5, INVERSE>), grid, dim3(256), 0, st, dst, tmp, N); break;
         }
         MI_HIP_CHECK(hipGetLastError());
         return MI_OK;
+    }
+
+    template <bool INVERSE>
+    int big_fft(mi_spectral_bank *b, float2 *dst, const float2 *src, hipStream_t st)
+    {
+        return big_fft_run<INVERSE>(dst, src, b->d_big_tmp, b->rank, b->channels, b->d_tw, st);
     }
 
     // a hop of a frame above 2^14 samples: the same steps as stft_hop_kernel / stft_inverse_kernel, one launch each
@@ -992,6 +1051,7 @@ struct mi_analyzer_bank
     std::vector<uint32_t> user_delay, delay;
     std::vector<uint8_t>  ch_active, ch_freeze;
     float      *d_ring = nullptr, *d_amp = nullptr, *d_data = nullptr, *d_wnd = nullptr, *d_env = nullptr;
+    float2     *d_big_work = nullptr, *d_big_tmp = nullptr, *d_big_spec = nullptr;    // frames above 2^14 samples
     uint32_t   *d_delay = nullptr;
     uint8_t    *d_flags = nullptr;
     const float2 *d_tw = nullptr;
@@ -1059,6 +1119,43 @@ namespace
     // One analysis pass for all channels at the strobe instant (the reference staggers the
     // channels over the period but every channel reads the window that ends at the strobe).
     // One launch per strobe: the analysis of every channel plus the ingest of the `n` samples that follow the strobe.
+    // the analysis of channels [first, channels) with the delays and flags on the device, then the ingest of `n` samples
+    // (strobe pass only): one fused launch for frames up to 2^14 samples, the four-step path above that
+    int analyzer_launch(mi_analyzer_bank *b, hipStream_t st, uint32_t first, const float *in, size_t in_stride, uint32_t n,
+                        bool zero, hipEvent_t ev0, hipEvent_t ev1)
+    {
+        const uint32_t count = b->channels - first;
+        float *ring = b->d_ring + size_t(first) * b->buf_size;
+        const size_t row = size_t(first) * b->bins_stride;
+        if (b->rank <= 14)
+        {
+            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(count), dim3(plan<LH>::T), 0, st, ev0, ev1, \
+                ring, b->buf_size, b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, b->d_data + row, b->d_amp + row, \
+                b->bins_stride, b->tau, b->d_tw, in, in_stride, n, zero ? 1 : 0)
+            MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            return MI_OK;
+        }
+        const uint32_t N = 1u << b->rank;
+        hipLaunchKernelGGL(big_an_gather_kernel, dim3((N + 255) / 256, count), dim3(256), 0, st, b->d_big_work, ring, b->buf_size,
+                           b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, N);
+        MI_HIP_CHECK(hipGetLastError());
+        const int r = big_fft_run<false>(b->d_big_spec, b->d_big_work, b->d_big_tmp, b->rank, count, b->d_tw, st);
+        if (r != MI_OK)
+            return r;
+        hipLaunchKernelGGL(big_an_mag_kernel, dim3((N / 2 + 1 + 255) / 256, count), dim3(256), 0, st, b->d_big_spec, b->d_data + row,
+                           b->d_amp + row, b->bins_stride, b->tau, b->d_flags + first, N);
+        MI_HIP_CHECK(hipGetLastError());
+        if (n > 0)
+        {
+            hipLaunchKernelGGL(an_ingest_kernel, dim3((n + 255) / 256, count), dim3(256), 0, st, ring, b->buf_size, b->head, in,
+                               in_stride, n, zero ? 1 : 0);
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        return MI_OK;
+    }
+
     int analyzer_strobe(mi_analyzer_bank *b, hipStream_t st, const float *in, size_t in_stride, uint32_t n, bool zero)
     {
         if (b->meta_dirty)
@@ -1082,12 +1179,9 @@ namespace
         std::swap(b->d_amp, b->d_data);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
-        #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(b->channels), dim3(plan<LH>::T), 0, st, ev0, ev1, \
-            b->d_ring, b->buf_size, b->head, b->d_delay, b->d_flags, b->d_wnd, b->d_data, b->d_amp, b->bins_stride, b->tau, \
-            b->d_tw, in, in_stride, n, zero ? 1 : 0)
-        MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
-        #undef MI_CALL
-        MI_HIP_CHECK(hipGetLastError());
+        const int rl = analyzer_launch(b, st, 0, in, in_stride, n, zero, ev0, ev1);
+        if (rl != MI_OK)
+            return rl;
         b->analysed = true;
         return MI_OK;
     }
@@ -1113,12 +1207,9 @@ namespace
         MI_HIP_CHECK(hipMemcpyAsync(b->d_flags, f.data(), f.size(), hipMemcpyHostToDevice, st));
         MI_HIP_CHECK(hipStreamSynchronize(st));
         b->meta_dirty = true;                                   // the next strobe wants its own delays back
-        const size_t row = size_t(first) * b->bins_stride;
-        #define MI_CALL(LH) hipLaunchKernelGGL((analyzer_kernel<LH>), dim3(b->channels - first), dim3(plan<LH>::T), 0, st, \
-            b->d_ring + size_t(first) * b->buf_size, b->buf_size, b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, \
-            b->d_data + row, b->d_amp + row, b->bins_stride, b->tau, b->d_tw, (const float *)nullptr, size_t(0), 0u, 0)
-        MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
-        #undef MI_CALL
+        const int rl = analyzer_launch(b, st, first, nullptr, 0, 0, false, nullptr, nullptr);
+        if (rl != MI_OK)
+            return rl;
         MI_HIP_CHECK(hipGetLastError());
         return MI_OK;
     }
@@ -1132,8 +1223,8 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_analyzer_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0 && max_sample_rate > 0 && min_rate > 0.0f, MI_EINVAL, "mi_analyzer_bank_create: bad argument");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 14, MI_EINVAL,
-               "mi_analyzer_bank_create: max_rank %u outside the supported 5..14", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= uint32_t(BIG_MAX_RANK), MI_EINVAL,
+               "mi_analyzer_bank_create: max_rank %u outside the supported 5..%d", max_rank, BIG_MAX_RANK);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_analyzer_bank *b = new (std::nothrow) mi_analyzer_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_analyzer_bank_create: out of host memory");
@@ -1164,6 +1255,12 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_env), b->bins_stride * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_delay), channels * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_flags), channels);
+        if (max_rank > 14)                                  // frames that go through global memory: three complex frames per channel
+        {
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_big_work), size_t(channels) * fft_items * sizeof(float2));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_big_tmp), size_t(channels) * fft_items * sizeof(float2));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_big_spec), size_t(channels) * fft_items * sizeof(float2));
+        }
         if (e == hipSuccess) e = hipMemset(b->d_ring, 0, size_t(channels) * bs * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_amp, 0, size_t(channels) * b->bins_stride * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_data, 0, size_t(channels) * b->bins_stride * sizeof(float));
@@ -1185,6 +1282,7 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
         return MI_OK;
     (void)hipFree(b->d_ring); (void)hipFree(b->d_amp); (void)hipFree(b->d_data); (void)hipFree(b->d_wnd);
     (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
+    (void)hipFree(b->d_big_work); (void)hipFree(b->d_big_tmp); (void)hipFree(b->d_big_spec);
     delete b;
     return MI_OK;
 }

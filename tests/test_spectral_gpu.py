@@ -344,29 +344,35 @@ def test_frames_above_the_lds_limit(gpu, rank):
         assert np.abs(y[c] - ref).max() <= TOL * float(np.abs(ref).max()), ("callback", rank, c)
 
 
-def test_analyzer_rank_14(gpu):
-    """16384-point spectra (the largest frame: 128 KiB of LDS per workgroup) against the oracle."""
-    sr, rank, C = 48000, 14, 2
+@pytest.mark.parametrize("rank", [14, 15, 16])
+def test_analyzer_largest_frames(gpu, rank):
+    """16384-point spectra (the largest frame in LDS: 128 KiB per workgroup) and the 32768- / 65536-point ones that go
+    through the four-step transform in global memory, against the oracle (one channel frozen half way, one delayed)."""
+    sr, C = 48000, 3
     rng = np.random.default_rng(14)
-    n = 40000
+    n = 40000 if rank == 14 else 5 * (1 << rank) // 2
     t = np.arange(n)
     x = (0.2 * rng.standard_normal((C, n)) + np.sin(2 * np.pi * 997.0 * t / sr)[None, :]).astype(np.float32)
-    o = sp.Analyzer(C, rank, sr, 1.0, 0)
+    o = sp.Analyzer(C, rank, sr, 1.0, 500)
     o.configure(sample_rate=sr, rate=4.0, rank=rank, window_name="hann", reactivity=0.1, shift=1.0)
-    bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+    bank = gpu.AnalyzerBank(C, rank, sr, 1.0, 500)
     for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, 4.0), (bank.RANK, rank), (bank.WINDOW, 0),
                     (bank.REACTIVITY, 0.1), (bank.SHIFT, 1.0)):
         bank.configure(what, v)
-    idx = np.arange(0, 8193, dtype=np.uint32)
+    o.user_delay[2] = 333; bank.channel(2, bank.CH_DELAY, 333)
+    bins = (1 << (rank - 1)) + 1
+    idx = np.arange(0, bins, dtype=np.uint32)
     pos = 0
-    for c in (12000, 12000, 16000):
+    for i, c in enumerate((3 * n // 10, 3 * n // 10, n - 2 * (3 * n // 10))):
+        if i == 2:
+            o.ch_freeze[1] = True; bank.channel(1, bank.CH_FREEZE, 1)
         o.process(x[:, pos:pos + c])
         bank.process(gpu.DeviceBuffer.from_host(x[:, pos:pos + c]), c)
         pos += c
     got = bank.get_spectrum(idx); ref = o.get_spectrum(idx)
-    assert bank.info()["bins"] == 8193
+    assert bank.info()["bins"] == bins
     peak = float(np.abs(ref).max())
-    assert np.abs(got - ref).max() <= TOL * peak
+    assert np.abs(got - ref).max() <= TOL * peak, np.abs(got - ref).max() / peak
     assert abs(int(np.argmax(ref[0])) - round(997.0 * (1 << rank) / sr)) <= 1
     bank.close()
 
