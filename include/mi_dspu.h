@@ -365,6 +365,10 @@ int mi_window_general(float *dst, size_t n, int type, const float *params, uint3
  * memory): the colour's spectral envelope (f / center)^k on n linearly spaced frequencies, or the opposite colour's. */
 int mi_envelope_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
 int mi_envelope_reverse_noise_lin(float *dst, float first, float last, float center, size_t n, int type);
+/* envelope::noise_log / reverse_noise_log (envelope.cpp:170-268: logarithmic frequency grid) and noise_list /
+ * reverse_noise_list (:272-344: an explicit list of frequencies); reverse != 0 selects the compensating colour. */
+int mi_envelope_noise_log(float *dst, float first, float last, float center, size_t n, int type, int reverse);
+int mi_envelope_noise_list(float *dst, const float *freqs, float center, size_t n, int type, int reverse);
 
 /* ---- spectral processor bank -------------------------------------------------------------- */
 /*
@@ -557,6 +561,8 @@ int mi_crossover_bank_set_mode(mi_crossover_bank_t *bank, uint32_t split, int mo
 int mi_crossover_bank_set_gain(mi_crossover_bank_t *bank, uint32_t band, float gain);
 /* get_slope / get_frequency / get_mode (any pointer may be NULL) */
 int mi_crossover_bank_get_split(const mi_crossover_bank_t *bank, uint32_t split, uint32_t *slope, float *freq, int *mode);
+/* Crossover::needs_reconfiguration(), util/Crossover.h:352 */
+int mi_crossover_bank_needs_reconfiguration(const mi_crossover_bank_t *bank, int *pending);
 /* get_gain / get_band_start / get_band_end / band_active after reconfigure(), Crossover.cpp:256-325 */
 int mi_crossover_bank_get_band(mi_crossover_bank_t *bank, uint32_t band, float *gain, float *start, float *end, int *active,
                                void *stream);
@@ -601,6 +607,9 @@ int mi_loudness_bank_clear(mi_loudness_bank_t *bank, void *stream);
  * not run, its squares line is not written, it is not mixed: LoudnessMeter.cpp:421-422) but keeps taking part in
  * refresh_rms() and clear(); binding it again continues where it stopped (unlike set_active(1), which clears). */
 int mi_loudness_bank_set_bound(mi_loudness_bank_t *bank, uint32_t channel, int bound);
+/* LoudnessMeter::needs_update() / update_settings(), meters/LoudnessMeter.h:264-269 */
+int mi_loudness_bank_needs_update(const mi_loudness_bank_t *bank, int *pending);
+int mi_loudness_bank_update_settings(mi_loudness_bank_t *bank, void *stream);
 int mi_loudness_bank_latency(const mi_loudness_bank_t *bank, uint32_t *samples);
 /*
  * process(out, count) / process(out, count, gain), LoudnessMeter.cpp:462-564.  in: [meters*channels][in_stride];
@@ -638,6 +647,9 @@ int mi_ilufs_bank_clear(mi_ilufs_bank_t *bank, void *stream);                   
 int mi_ilufs_bank_process(mi_ilufs_bank_t *bank, float *out, const float *in, size_t count, size_t out_stride,
                           size_t in_stride, float gain, void *stream);
 /* loudness() of every meter (HOST array of `meters` floats; synchronises) */
+/* ILUFSMeter::needs_update() / update_settings(), meters/ILUFSMeter.h:244-249 */
+int mi_ilufs_bank_needs_update(const mi_ilufs_bank_t *bank, int *pending);
+int mi_ilufs_bank_update_settings(mi_ilufs_bank_t *bank, void *stream);
 int mi_ilufs_bank_loudness(mi_ilufs_bank_t *bank, float *loudness, void *stream);
 /* The gating-block history as the meters hold it (vLoudness / nMSHead / nMSCount of ILUFSMeter.h): hist is HOST memory
  * [meters][*size] (NULL: only the size is wanted), head / count HOST [meters] or NULL. */

@@ -102,6 +102,13 @@ PROTOTYPES = {
     "mi_window_general": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_uint32]),
     "mi_envelope_reverse_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
     "mi_envelope_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),
+    "mi_crossover_bank_needs_reconfiguration": (c_int, [c_void_p, POINTER(c_int)]),
+    "mi_loudness_bank_needs_update": (c_int, [c_void_p, POINTER(c_int)]),
+    "mi_loudness_bank_update_settings": (c_int, [c_void_p, c_void_p]),
+    "mi_ilufs_bank_needs_update": (c_int, [c_void_p, POINTER(c_int)]),
+    "mi_ilufs_bank_update_settings": (c_int, [c_void_p, c_void_p]),
+    "mi_envelope_noise_log": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int, c_int]),
+    "mi_envelope_noise_list": (c_int, [c_void_p, c_void_p, c_float, c_size_t, c_int, c_int]),
     "mi_spectral_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_spectral_bank_destroy": (c_int, [c_void_p]),
     "mi_spectral_bank_set_rank": (c_int, [c_void_p, c_uint32]),

@@ -295,6 +295,13 @@ int mi_crossover_bank_set_gain(mi_crossover_bank_t *b, uint32_t band, float gain
     return MI_OK;
 }
 
+int mi_crossover_bank_needs_reconfiguration(const mi_crossover_bank_t *b, int *pending)     // Crossover.h:352
+{
+    MI_REQUIRE(b != nullptr && pending != nullptr, MI_EINVAL, "mi_crossover_bank_needs_reconfiguration: bad argument");
+    *pending = b->dirty ? 1 : 0;
+    return MI_OK;
+}
+
 int mi_crossover_bank_get_split(const mi_crossover_bank_t *b, uint32_t split, uint32_t *slope, float *freq, int *mode)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_crossover_bank_get_split: NULL bank");

@@ -1496,6 +1496,12 @@ void Crossover::set_sample_rate(size_t sr)
 
 size_t Crossover::get_sample_rate()            { return pImpl ? pImpl->sample_rate : 48000; }
 
+bool Crossover::needs_reconfiguration() const
+{
+    int pending = 0;
+    return pImpl != nullptr && mi_crossover_bank_needs_reconfiguration(pImpl->bank, &pending) == MI_OK && pending != 0;
+}
+
 void Crossover::reconfigure()
 {
     if (pImpl) mi_crossover_bank_get_band(pImpl->bank, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
@@ -1573,6 +1579,20 @@ namespace envelope
     void brown_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)        { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_BROWN_NOISE); }
     void blue_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)         { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_BLUE_NOISE); }
     void violet_noise_lin(float *dst, float first, float last, float center, size_t n, envelope_t)       { mi_envelope_noise_lin(dst, first, last, center, n, MI_ENVELOPE_VIOLET_NOISE); }
+    void noise_log(float *dst, float first, float last, float center, size_t n, envelope_t type)         { mi_envelope_noise_log(dst, first, last, center, n, int(type), 0); }
+    void reverse_noise_log(float *dst, float first, float last, float center, size_t n, envelope_t type) { mi_envelope_noise_log(dst, first, last, center, n, int(type), 1); }
+    void white_noise_log(float *dst, float first, float last, float center, size_t n, envelope_t)        { mi_envelope_noise_log(dst, first, last, center, n, MI_ENVELOPE_WHITE_NOISE, 0); }
+    void pink_noise_log(float *dst, float first, float last, float center, size_t n, envelope_t)         { mi_envelope_noise_log(dst, first, last, center, n, MI_ENVELOPE_PINK_NOISE, 0); }
+    void brown_noise_log(float *dst, float first, float last, float center, size_t n, envelope_t)        { mi_envelope_noise_log(dst, first, last, center, n, MI_ENVELOPE_BROWN_NOISE, 0); }
+    void blue_noise_log(float *dst, float first, float last, float center, size_t n, envelope_t)         { mi_envelope_noise_log(dst, first, last, center, n, MI_ENVELOPE_BLUE_NOISE, 0); }
+    void violet_noise_log(float *dst, float first, float last, float center, size_t n, envelope_t)       { mi_envelope_noise_log(dst, first, last, center, n, MI_ENVELOPE_VIOLET_NOISE, 0); }
+    void noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t type)             { mi_envelope_noise_list(dst, freqs, center, n, int(type), 0); }
+    void reverse_noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t type)     { mi_envelope_noise_list(dst, freqs, center, n, int(type), 1); }
+    void white_noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t)            { mi_envelope_noise_list(dst, freqs, center, n, MI_ENVELOPE_WHITE_NOISE, 0); }
+    void pink_noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t)             { mi_envelope_noise_list(dst, freqs, center, n, MI_ENVELOPE_PINK_NOISE, 0); }
+    void brown_noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t)            { mi_envelope_noise_list(dst, freqs, center, n, MI_ENVELOPE_BROWN_NOISE, 0); }
+    void blue_noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t)             { mi_envelope_noise_list(dst, freqs, center, n, MI_ENVELOPE_BLUE_NOISE, 0); }
+    void violet_noise_list(float *dst, const float *freqs, float center, size_t n, envelope_t)           { mi_envelope_noise_list(dst, freqs, center, n, MI_ENVELOPE_VIOLET_NOISE, 0); }
 }
 
 // ---- crossover::* / SpectralSplitter / FFTCrossover ------------------------------------------------------------
@@ -2385,6 +2405,18 @@ void LoudnessMeter::set_period(float period)
 
 float LoudnessMeter::period() const { return pImpl ? pImpl->period : 0.0f; }
 
+bool LoudnessMeter::needs_update() const
+{
+    int pending = 0;
+    return pImpl != nullptr && mi_loudness_bank_needs_update(pImpl->bank, &pending) == MI_OK && pending != 0;
+}
+
+void LoudnessMeter::update_settings()
+{
+    if (pImpl != nullptr)
+        mi_loudness_bank_update_settings(pImpl->bank, nullptr);
+}
+
 status_t LoudnessMeter::set_sample_rate(size_t sample_rate)
 {
     if (pImpl == nullptr)
@@ -2568,6 +2600,18 @@ void ILUFSMeter::set_weighting(bs::weighting_t weighting)
 }
 
 bs::weighting_t ILUFSMeter::weighting() const { return pImpl ? pImpl->weighting : bs::WEIGHT_K; }
+
+bool ILUFSMeter::needs_update() const
+{
+    int pending = 0;
+    return pImpl != nullptr && mi_ilufs_bank_needs_update(pImpl->bank, &pending) == MI_OK && pending != 0;
+}
+
+void ILUFSMeter::update_settings()
+{
+    if (pImpl != nullptr)
+        mi_ilufs_bank_update_settings(pImpl->bank, nullptr);
+}
 
 void ILUFSMeter::set_integration_period(float period)
 {

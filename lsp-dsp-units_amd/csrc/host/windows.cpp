@@ -325,6 +325,50 @@ void make_reverse_noise_lin(float *dst, float first, float last, float center, s
     make_noise_lin(dst, first, last, center, n, type, true);
 }
 
+// envelope::noise_log / reverse_noise_log (envelope.cpp:170-268): the same power law on a logarithmic frequency grid,
+// f_i = first exp(i ln(last / first) / (n - 1)) in units of the centre frequency
+void make_noise_log(float *dst, float first, float last, float center, size_t n, int type, bool reverse)
+{
+    float k;
+    if (!colour_exponent(type, reverse, &k))
+        return;
+    if (type == MI_ENVELOPE_WHITE_NOISE)
+    {
+        for (size_t i = 0; i < n; ++i)
+            dst[i] = 1.0f;
+        return;
+    }
+    if (n <= 1)                                             // envelope.cpp:172-177
+    {
+        if (n > 0)
+            dst[0] = 1.0f;
+        return;
+    }
+    const float kf = 1.0f / center;
+    first *= kf;
+    last  *= kf;
+    const float df = logf(last / first) / (n - 1);
+    for (size_t i = 0; i < n; ++i)                          // dsp::exp1, mul_k2, powvc1
+        dst[i] = powf(expf(df * i) * first, k);
+}
+
+// envelope::noise_list / reverse_noise_list (envelope.cpp:272-344): (freqs[i] / center)^k
+void make_noise_list(float *dst, const float *freqs, float center, size_t n, int type, bool reverse)
+{
+    float k;
+    if (!colour_exponent(type, reverse, &k))
+        return;
+    if (type == MI_ENVELOPE_WHITE_NOISE)
+    {
+        for (size_t i = 0; i < n; ++i)
+            dst[i] = 1.0f;
+        return;
+    }
+    const float kf = 1.0f / center;
+    for (size_t i = 0; i < n; ++i)                          // dsp::mul_k3, powvc1
+        dst[i] = powf(freqs[i] * kf, k);
+}
+
 } // namespace mi
 
 extern "C" {
@@ -356,6 +400,22 @@ int mi_envelope_noise_lin(float *dst, float first, float last, float center, siz
     MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_envelope_noise_lin: NULL destination");
     MI_REQUIRE(type >= 0 && type < MI_ENVELOPE_TOTAL, MI_EINVAL, "mi_envelope_noise_lin: unknown envelope %d", type);
     mi::make_noise_lin(dst, first, last, center, n, type, false);
+    return MI_OK;
+}
+
+int mi_envelope_noise_log(float *dst, float first, float last, float center, size_t n, int type, int reverse)
+{
+    MI_REQUIRE(n == 0 || dst != nullptr, MI_EINVAL, "mi_envelope_noise_log: NULL destination");
+    MI_REQUIRE(type >= 0 && type < MI_ENVELOPE_TOTAL, MI_EINVAL, "mi_envelope_noise_log: unknown envelope %d", type);
+    mi::make_noise_log(dst, first, last, center, n, type, reverse != 0);
+    return MI_OK;
+}
+
+int mi_envelope_noise_list(float *dst, const float *freqs, float center, size_t n, int type, int reverse)
+{
+    MI_REQUIRE(n == 0 || (dst != nullptr && freqs != nullptr), MI_EINVAL, "mi_envelope_noise_list: NULL buffer");
+    MI_REQUIRE(type >= 0 && type < MI_ENVELOPE_TOTAL, MI_EINVAL, "mi_envelope_noise_list: unknown envelope %d", type);
+    mi::make_noise_list(dst, freqs, center, n, type, reverse != 0);
     return MI_OK;
 }
 

@@ -889,6 +889,20 @@ int mi_loudness_bank_set_bound(mi_loudness_bank_t *b, uint32_t channel, int boun
     return MI_OK;
 }
 
+int mi_loudness_bank_needs_update(const mi_loudness_bank_t *b, int *pending)                  // LoudnessMeter.h:264
+{
+    MI_REQUIRE(b != nullptr && pending != nullptr, MI_EINVAL, "mi_loudness_bank_needs_update: bad argument");
+    *pending = (b->upd_filters || b->upd_time) ? 1 : 0;
+    return MI_OK;
+}
+
+int mi_loudness_bank_update_settings(mi_loudness_bank_t *b, void *stream)                     // LoudnessMeter.cpp:328-379
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_loudness_bank_update_settings: NULL bank");
+    MI_REQUIRE(b->sample_rate != 0, MI_ESTATE, "mi_loudness_bank_update_settings: set_sample_rate() first");
+    return update_settings(b, mi::as_stream(stream));
+}
+
 int mi_loudness_bank_latency(const mi_loudness_bank_t *b, uint32_t *samples)
 {
     MI_REQUIRE(b != nullptr && samples != nullptr, MI_EINVAL, "mi_loudness_bank_latency: bad argument");
@@ -1529,6 +1543,20 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_
         offset += taken;
     }
     return MI_OK;
+}
+
+int mi_ilufs_bank_needs_update(const mi_ilufs_bank_t *b, int *pending)                        // ILUFSMeter.h:244
+{
+    MI_REQUIRE(b != nullptr && pending != nullptr, MI_EINVAL, "mi_ilufs_bank_needs_update: bad argument");
+    *pending = (b->upd_filters || b->upd_time) ? 1 : 0;
+    return MI_OK;
+}
+
+int mi_ilufs_bank_update_settings(mi_ilufs_bank_t *b, void *stream)                           // ILUFSMeter.cpp:472-513
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_ilufs_bank_update_settings: NULL bank");
+    MI_REQUIRE(b->sample_rate != 0, MI_ESTATE, "mi_ilufs_bank_update_settings: set_sample_rate() first");
+    return ilufs_update(b, mi::as_stream(stream));
 }
 
 int mi_ilufs_bank_loudness(mi_ilufs_bank_t *b, float *loudness, void *stream)

@@ -37,6 +37,8 @@ namespace lsp
                 bool            active(size_t id) const;
                 void            set_weighting(bs::weighting_t weighting);
                 bs::weighting_t weighting() const;
+                bool            needs_update() const;           // settings changed since the last process() / update_settings()
+                void            update_settings();
                 void            set_integration_period(float period);
                 float           integration_period() const;
                 status_t        set_sample_rate(size_t sample_rate);

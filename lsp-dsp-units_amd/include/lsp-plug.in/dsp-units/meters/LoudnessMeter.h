@@ -42,6 +42,8 @@ namespace lsp
                 bs::weighting_t weighting() const;
                 void            set_period(float period);
                 float           period() const;
+                bool            needs_update() const;           // settings changed since the last process() / update_settings()
+                void            update_settings();
                 status_t        set_sample_rate(size_t sample_rate);
                 size_t          sample_rate() const;
                 size_t          latency() const;

@@ -74,6 +74,7 @@ namespace lsp
                 bool            freq_chart(size_t band, float *re, float *im, const float *f, size_t count);
                 bool            freq_chart(size_t band, float *c, const float *f, size_t count);
                 void            reconfigure();
+                bool            needs_reconfiguration() const;
                 void            process(const float *in, size_t samples);
                 void            dump(IStateDumper *v) const;
         };

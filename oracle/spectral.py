@@ -87,6 +87,23 @@ WINDOW_IDS = {"hann": 0, "hamming": 1, "blackman": 2, "welch": 8, "nuttall": 9, 
               "sqr_cosine": 19}
 
 
+def noise_log(first, last, center, n, k):
+    """basic_noise_log with colour exponent k (envelope.cpp:152-169): the grid first * exp(i ln(last / first) / (n - 1))."""
+    if n <= 1:
+        return np.ones(n, np.float32)
+    kf = F(F(1.0) / F(center))
+    first = F(F(first) * kf); last = F(F(last) * kf)
+    df = F(np.log(F(last / first), dtype=np.float32) / F(n - 1))
+    d = np.array([F(np.exp(F(df * F(i)), dtype=np.float32) * first) for i in range(n)], np.float32)
+    return np.power(d, F(k)).astype(np.float32)
+
+
+def noise_list(freqs, center, k):
+    """basic_noise_list (envelope.cpp:272-280): (freqs / center)^k."""
+    d = (np.asarray(freqs, np.float32) * F(F(1.0) / F(center))).astype(np.float32)
+    return np.power(d, F(k)).astype(np.float32)
+
+
 def reverse_noise_lin(first, last, center, n, k):
     """basic_noise_lin with the reversed colour exponent k (envelope.cpp:40-62,95-123)."""
     if n <= 1:

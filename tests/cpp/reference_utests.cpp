@@ -502,6 +502,39 @@ static void accessors()
     CHECK(env[0] == env[1] && env[1] == 1.0f && fabsf(env[4] - 2.0f) < 1e-6f, "reverse pink envelope %g %g", env[1], env[4]);
     dspu::envelope::brown_noise_lin(env, 100.0f, 500.0f, 100.0f, 5, dspu::envelope::WHITE_NOISE);
     CHECK(env[0] == 1.0f && fabsf(env[4] - 0.2f) < 1e-6f, "brown envelope %g", env[4]);
+    dspu::envelope::noise_log(env, 100.0f, 1600.0f, 100.0f, 5, dspu::envelope::VIOLET_NOISE);         // octaves: 1 2 4 8 16
+    CHECK(fabsf(env[0] - 1.0f) < 1e-5f && fabsf(env[2] - 4.0f) < 1e-4f && fabsf(env[4] - 16.0f) < 1e-3f, "violet on a log grid %g %g", env[2], env[4]);
+    const float fl[3] = { 50.0f, 100.0f, 400.0f };
+    dspu::envelope::reverse_noise_list(env, fl, 100.0f, 3, dspu::envelope::BROWN_NOISE);               // violet: f / centre
+    CHECK(fabsf(env[0] - 0.5f) < 1e-6f && env[1] == 1.0f && fabsf(env[2] - 4.0f) < 1e-6f, "reverse brown on a list %g", env[2]);
+    dspu::envelope::pink_noise_list(env, fl, 100.0f, 3, dspu::envelope::WHITE_NOISE);
+    CHECK(fabsf(env[2] - 0.5f) < 1e-6f, "pink on a list %g", env[2]);
+
+    {   // needs_update() / update_settings() of the meters, needs_reconfiguration() of the crossover
+        dspu::LoudnessMeter lm;
+        CHECK(lm.init(1, 400.0f) == STATUS_OK && lm.set_sample_rate(48000) == STATUS_OK, "loudness meter init");
+        CHECK(lm.needs_update(), "settings pending after set_sample_rate");
+        lm.update_settings();
+        CHECK(!lm.needs_update(), "clean after update_settings");
+        lm.set_period(200.0f);
+        CHECK(lm.needs_update(), "a new period is pending");
+        lm.destroy();
+        dspu::ILUFSMeter im;
+        CHECK(im.init(1, 5.0f, 400.0f) == STATUS_OK && im.set_sample_rate(48000) == STATUS_OK, "ilufs meter init");
+        CHECK(im.needs_update(), "settings pending after set_sample_rate");
+        im.update_settings();
+        CHECK(!im.needs_update(), "clean after update_settings");
+        im.destroy();
+        dspu::Crossover xo;
+        CHECK(xo.init(3, 256), "crossover init");
+        xo.set_sample_rate(48000);
+        CHECK(xo.needs_reconfiguration(), "dirty after init");
+        xo.reconfigure();
+        CHECK(!xo.needs_reconfiguration(), "clean after reconfigure");
+        xo.set_frequency(0, 1234.0f);
+        CHECK(xo.needs_reconfiguration(), "a moved split point is pending");
+        xo.destroy();
+    }
 
     dspu::Equalizer eq;
     CHECK(eq.init(2, 8), "equalizer init");

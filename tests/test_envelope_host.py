@@ -42,9 +42,34 @@ def test_linear_grid_envelopes(mi, kind, n):
         assert abs(g[i] - (f[i] / center) ** -0.5) < 1e-5
 
 
+@pytest.mark.parametrize("kind", range(7))
+@pytest.mark.parametrize("n", [1, 2, 300])
+def test_logarithmic_grid_and_list_envelopes(mi, kind, n):
+    """envelope::noise_log / reverse_noise_log (envelope.cpp:152-268) and noise_list / reverse_noise_list (:272-344)
+    against the oracle's restatement, plus the definition itself: (f / center)^k on the grid."""
+    first, last, center = 20.0, 20000.0, 1000.0
+    freqs = np.geomspace(first, last, n).astype(np.float32) if n > 1 else np.array([440.0], np.float32)
+    for reverse, sign in ((0, 1.0), (1, -1.0)):
+        got = np.full(n, -1.0, np.float32)
+        mi.check(mi.lib.mi_envelope_noise_log(got.ctypes.data_as(FP), first, last, center, n, kind, reverse))
+        want = np.ones(n, np.float32) if kind == WHITE else osp.noise_log(first, last, center, n, sign * SLOPE[kind])
+        np.testing.assert_allclose(got, want, rtol=1e-6, atol=0)    # expf and powf of two libms
+        if n > 2 and kind != WHITE:
+            grid = first * (last / first) ** (np.arange(n) / (n - 1))
+            np.testing.assert_allclose(got, (grid / center) ** (sign * SLOPE[kind]), rtol=2e-5)
+        got = np.full(n, -1.0, np.float32)
+        mi.check(mi.lib.mi_envelope_noise_list(got.ctypes.data_as(FP), freqs.ctypes.data_as(FP), center, n, kind, reverse))
+        want = np.ones(n, np.float32) if kind == WHITE else osp.noise_list(freqs, center, sign * SLOPE[kind])
+        np.testing.assert_allclose(got, want, rtol=4e-7, atol=0)
+
+
 def test_bad_arguments(mi):
     g = np.empty(4, np.float32)
     with pytest.raises(mi.MiError):
         mi.check(mi.lib.mi_envelope_noise_lin(g.ctypes.data_as(FP), 0.0, 1.0, 1.0, 4, 9))
     with pytest.raises(mi.MiError):
         mi.check(mi.lib.mi_envelope_reverse_noise_lin(None, 0.0, 1.0, 1.0, 4, PINK))
+    with pytest.raises(mi.MiError):
+        mi.check(mi.lib.mi_envelope_noise_log(g.ctypes.data_as(FP), 1.0, 2.0, 1.0, 4, 9, 0))
+    with pytest.raises(mi.MiError):
+        mi.check(mi.lib.mi_envelope_noise_list(g.ctypes.data_as(FP), None, 1.0, 4, PINK, 0))
