@@ -34,6 +34,11 @@
 
 #include "filter_design.h"
 
+// lsp::dspu::filter_params_t is the reference's own type (so that the mangled names match); the C-ABI's record has the same
+// fields in the same order (static_assert in filters/common.h)
+static inline mi_filter_params_t *cfp(lsp::dspu::filter_params_t *p)             { return reinterpret_cast<mi_filter_params_t *>(p); }
+static inline const mi_filter_params_t *cfp(const lsp::dspu::filter_params_t *p) { return reinterpret_cast<const mi_filter_params_t *>(p); }
+
 namespace lsp
 {
 namespace dspu
@@ -94,6 +99,16 @@ namespace windows
     {
         mi_window(dst, n, int(type));
     }
+
+    #define MI_WND(fn, id) void fn(float *dst, size_t n) { mi_window(dst, n, int(id)); }
+    MI_WND(hann, HANN) MI_WND(hamming, HAMMING) MI_WND(blackman, BLACKMAN) MI_WND(lanczos, LANCZOS)
+    MI_WND(gaussian, GAUSSIAN) MI_WND(poisson, POISSON) MI_WND(parzen, PARZEN) MI_WND(tukey, TUKEY)
+    MI_WND(welch, WELCH) MI_WND(nuttall, NUTTALL) MI_WND(blackman_nuttall, BLACKMAN_NUTTALL)
+    MI_WND(blackman_harris, BLACKMAN_HARRIS) MI_WND(hann_poisson, HANN_POISSON)
+    MI_WND(bartlett_hann, BARTLETT_HANN) MI_WND(bartlett_fejer, BARTLETT_FEJER) MI_WND(triangular, TRIANGULAR)
+    MI_WND(rectangular, RECTANGULAR) MI_WND(flat_top, FLAT_TOP) MI_WND(cosine, COSINE)
+    MI_WND(sqr_cosine, SQR_COSINE) MI_WND(cubic, CUBIC)
+    #undef MI_WND
 
     void triangular_general(float *dst, size_t n, int dn)
     {
@@ -334,7 +349,7 @@ void Filter::update(size_t sr, const filter_params_t *params)   // Filter.cpp:14
     nMode       = FM_BYPASS;                                // Filter.cpp:150: inactive until the next rebuild()
     nLatency    = 0;
     sParams     = *params;
-    mi::limit_params(&sParams, uint32_t(sr));
+    mi::limit_params(cfp(&sParams), uint32_t(sr));
     nFlags     |= FF_REBUILD;
     if (type != sParams.nType || slope != sParams.nSlope)
         nFlags |= FF_CLEAR;
@@ -342,7 +357,7 @@ void Filter::update(size_t sr, const filter_params_t *params)   // Filter.cpp:14
 
 void Filter::limit(size_t, filter_params_t *fp)
 {
-    mi::limit_params(fp, uint32_t(nSampleRate));           // the reference ignores its sr argument too (Filter.cpp:161-163)
+    mi::limit_params(cfp(fp), uint32_t(nSampleRate));           // the reference ignores its sr argument too (Filter.cpp:161-163)
 }
 
 void Filter::set_sample_rate(size_t sr)     { filter_params_t p = sParams; update(sr, &p); }
@@ -356,7 +371,7 @@ void Filter::rebuild()
     if (nFlags & FF_OWN_BANK)
         pBank->begin();
     d->cascades.reserve(mi::CHAINS_MAX + 1);
-    mi::design_filter(d, &sParams, uint32_t(nSampleRate));
+    mi::design_filter(d, cfp(&sParams), uint32_t(nSampleRate));
     nMode   = filter_mode_t(d->mode);
     nItems  = d->cascades.size();
     vItems  = reinterpret_cast<dsp::f_cascade_t *>(d->cascades.data());
@@ -409,7 +424,7 @@ void Filter::freq_chart(float *c, const float *f, size_t count)
     if (nFlags & FF_REBUILD)
     {
         d->cascades.reserve(mi::CHAINS_MAX + 1);
-        mi::design_filter(d, &sParams, uint32_t(nSampleRate));
+        mi::design_filter(d, cfp(&sParams), uint32_t(nSampleRate));
     }
     mi::freq_chart(*d, c, f, count);
 }
@@ -534,7 +549,7 @@ bool Equalizer::set_params(size_t id, const filter_params_t *params)
         return false;
     vFilters[id].update(nSampleRate, params);               // mode reads FM_BYPASS until the next reconfigure
     nFlags |= EF_REBUILD;
-    return last_status(mi_equalizer_bank_set_params(impl()->bank, 0, uint32_t(id), params)) == MI_OK;
+    return last_status(mi_equalizer_bank_set_params(impl()->bank, 0, uint32_t(id), cfp(params))) == MI_OK;
 }
 
 bool Equalizer::limit_params(size_t id, filter_params_t *fp)
@@ -606,7 +621,7 @@ bool Equalizer::freq_chart(size_t id, float *c, const float *f, size_t count)
     filter_params_t fp;
     if (!get_params(id, &fp))
         return false;
-    return mi_filter_freq_chart(&fp, nSampleRate, c, f, count) == MI_OK;
+    return mi_filter_freq_chart(cfp(&fp), nSampleRate, c, f, count) == MI_OK;
 }
 
 bool Equalizer::freq_chart(size_t id, float *re, float *im, const float *f, size_t count)
@@ -635,7 +650,7 @@ void Equalizer::freq_chart(float *c, const float *f, size_t count)
         filter_params_t fp;
         if (!get_params(id, &fp) || fp.nType == FLT_NONE)
             continue;
-        if (mi_filter_freq_chart(&fp, nSampleRate, t.data(), f, count) != MI_OK)
+        if (mi_filter_freq_chart(cfp(&fp), nSampleRate, t.data(), f, count) != MI_OK)
             continue;
         for (size_t i = 0; i < count; ++i)
         {
@@ -792,8 +807,8 @@ bool DynamicFilters::set_params(size_t id, const filter_params_t *params)
     if (vFilters[id].sParams.nType != params->nType)        // DynamicFilters.cpp:132-133
         bClearMem = true;
     p->raw[id] = *params;
-    if (last_status(mi_dynfilter_bank_set_params(p->bank, uint32_t(id), params)) == MI_OK)
-        mi_dynfilter_bank_get_params(p->bank, uint32_t(id), &vFilters[id].sParams, nullptr);     // transformed (:170-178)
+    if (last_status(mi_dynfilter_bank_set_params(p->bank, uint32_t(id), cfp(params))) == MI_OK)
+        mi_dynfilter_bank_get_params(p->bank, uint32_t(id), cfp(&vFilters[id].sParams), nullptr);     // transformed (:170-178)
     else
         vFilters[id].sParams = *params;                     // a type without a dynamic form: process() copies
     return true;
@@ -842,7 +857,7 @@ bool DynamicFilters::freq_chart(size_t id, float *dst, const float *f, float gai
     impl_t *p = impl();
     if (p == nullptr || id >= nFilters)
         return false;
-    return mi_dynfilter_freq_chart(&p->raw[id], uint32_t(nSampleRate ? nSampleRate : 48000), dst, f, gain, count) == MI_OK;
+    return mi_dynfilter_freq_chart(cfp(&p->raw[id]), uint32_t(nSampleRate ? nSampleRate : 48000), dst, f, gain, count) == MI_OK;
 }
 
 bool DynamicFilters::freq_chart(size_t id, float *re, float *im, const float *f, float gain, size_t count)

@@ -45,8 +45,19 @@ namespace lsp
             #undef MI_FLT
         };
 
-        // field-for-field the record the C-ABI uses (mi_filter_params_t)
-        typedef mi_filter_params_t filter_params_t;
+        // The reference's own record (filters/common.h:137-145), a type of this namespace so that the member functions that
+        // take it come out of the library under the reference's mangled names; field for field the record of the C-ABI.
+        typedef struct filter_params_t
+        {
+            uint32_t    nType;      // Filter class
+            uint32_t    nSlope;     // Filter slope
+            float       fFreq;      // Frequency
+            float       fFreq2;     // Second frequency (for bandpass/allpass2 filter)
+            float       fGain;      // Gain
+            float       fQuality;   // Quality factor
+        } filter_params_t;
+        static_assert(sizeof(filter_params_t) == sizeof(mi_filter_params_t) && sizeof(filter_params_t) == 24,
+                      "filter_params_t and mi_filter_params_t are the same record");
     }
 }
 

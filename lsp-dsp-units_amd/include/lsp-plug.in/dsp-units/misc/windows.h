@@ -22,14 +22,12 @@ namespace lsp
 
             LSP_DSP_UNITS_PUBLIC void window(float *dst, size_t n, window_t type);
 
-            #define MI_WND(fn, id) inline void fn(float *dst, size_t n) { window(dst, n, id); }
-            MI_WND(hann, HANN) MI_WND(hamming, HAMMING) MI_WND(blackman, BLACKMAN) MI_WND(lanczos, LANCZOS)
-            MI_WND(gaussian, GAUSSIAN) MI_WND(poisson, POISSON) MI_WND(parzen, PARZEN) MI_WND(tukey, TUKEY)
-            MI_WND(welch, WELCH) MI_WND(nuttall, NUTTALL) MI_WND(blackman_nuttall, BLACKMAN_NUTTALL)
-            MI_WND(blackman_harris, BLACKMAN_HARRIS) MI_WND(hann_poisson, HANN_POISSON)
-            MI_WND(bartlett_hann, BARTLETT_HANN) MI_WND(bartlett_fejer, BARTLETT_FEJER) MI_WND(triangular, TRIANGULAR)
-            MI_WND(rectangular, RECTANGULAR) MI_WND(flat_top, FLAT_TOP) MI_WND(cosine, COSINE)
-            MI_WND(sqr_cosine, SQR_COSINE) MI_WND(cubic, CUBIC)
+            // the named windows (misc/windows.h:64-160 of the reference): exported, like there
+            #define MI_WND(fn) LSP_DSP_UNITS_PUBLIC void fn(float *dst, size_t n);
+            MI_WND(hann) MI_WND(hamming) MI_WND(blackman) MI_WND(lanczos) MI_WND(gaussian) MI_WND(poisson) MI_WND(parzen)
+            MI_WND(tukey) MI_WND(welch) MI_WND(nuttall) MI_WND(blackman_nuttall) MI_WND(blackman_harris) MI_WND(hann_poisson)
+            MI_WND(bartlett_hann) MI_WND(bartlett_fejer) MI_WND(triangular) MI_WND(rectangular) MI_WND(flat_top) MI_WND(cosine)
+            MI_WND(sqr_cosine) MI_WND(cubic)
             #undef MI_WND
 
             // the parameterised families (misc/windows.h:71,86,95,101,113,128,134,143,146,155 of the reference)
