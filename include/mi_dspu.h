@@ -439,6 +439,8 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
                             float min_rate, uint32_t max_delay);
 int mi_analyzer_bank_destroy(mi_analyzer_bank_t *bank);
 /* set_sample_rate/set_rate/set_window/set_envelope/set_shift/set_reactivity/set_rank/set_activity, Analyzer.cpp:154-211. */
+/* Analyzer::reset(): the smoothed and the published spectra are cleared at the next reconfigure (Analyzer.cpp:274-281) */
+int mi_analyzer_bank_reset(mi_analyzer_bank_t *bank);
 int mi_analyzer_bank_configure(mi_analyzer_bank_t *bank, int what, double value);
 /* freeze_channel/enable_channel/set_channel_delay, Analyzer.cpp:213-249. */
 int mi_analyzer_bank_channel(mi_analyzer_bank_t *bank, uint32_t channel, int what, uint32_t value);

@@ -107,6 +107,7 @@ PROTOTYPES = {
     "mi_loudness_bank_update_settings": (c_int, [c_void_p, c_void_p]),
     "mi_ilufs_bank_needs_update": (c_int, [c_void_p, POINTER(c_int)]),
     "mi_ilufs_bank_update_settings": (c_int, [c_void_p, c_void_p]),
+    "mi_analyzer_bank_reset": (c_int, [c_void_p]),
     "mi_envelope_noise_log": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int, c_int]),
     "mi_envelope_noise_list": (c_int, [c_void_p, c_void_p, c_float, c_size_t, c_int, c_int]),
     "mi_spectral_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),

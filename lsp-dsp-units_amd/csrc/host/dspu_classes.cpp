@@ -1143,20 +1143,15 @@ void SpectralProcessor::dump(IStateDumper *v) const
 struct MultiSpectralProcessor::impl_t
 {
     mi_spectral_bank_t *bank = nullptr;
-    size_t  channels = 0, max_rank = 0, rank = 0;
-    float   phase = 0.0f;
-    bool    update = true;
-    multi_spectral_processor_func_t func = nullptr;
-    void   *object = nullptr, *subject = nullptr;
-    std::vector<const float *> in;          // bound pointers, advanced by process() (MultiSpectralProcessor.cpp:310-320)
-    std::vector<float *>       out;
+    MultiSpectralProcessor *owner = nullptr;
+    std::vector<channel_t>     ch;          // storage behind vChannels
     std::vector<uint8_t>       has_in, has_out;
     std::vector<float>         host_io, host_spec;
     std::vector<float *>       spec_ptr;
     float  *d_in = nullptr, *d_out = nullptr;
     size_t  cap = 0;
 
-    bool reserve(size_t count)
+    bool reserve(size_t channels, size_t count)
     {
         if (count <= cap)
             return true;
@@ -1173,23 +1168,37 @@ struct MultiSpectralProcessor::impl_t
     static void trampoline(void *object, void *, float *spectrum, size_t rank, size_t channels, void *stream)
     {
         impl_t *p = static_cast<impl_t *>(object);
+        MultiSpectralProcessor *o = p->owner;
         const size_t floats = size_t(2) << rank;
         p->host_spec.resize(floats * channels);
-        if (mi_dspu_copy_d2h(p->host_spec.data(), spectrum, floats * channels * sizeof(float), stream) != MI_OK ||
+        if (o->pFunc == nullptr ||
+            mi_dspu_copy_d2h(p->host_spec.data(), spectrum, floats * channels * sizeof(float), stream) != MI_OK ||
             mi_dspu_stream_synchronize(stream) != MI_OK)
             return;
         p->spec_ptr.resize(channels);
         for (size_t i = 0; i < channels; ++i)
             p->spec_ptr[i] = p->has_in[i] ? &p->host_spec[i * floats] : nullptr;    // MultiSpectralProcessor.cpp:338-350
-        p->func(p->object, p->subject, p->spec_ptr.data(), rank);
+        o->pFunc(o->pObject, o->pSubject, p->spec_ptr.data(), rank);
         mi_dspu_copy_h2d(spectrum, p->host_spec.data(), floats * channels * sizeof(float), stream);
         mi_dspu_stream_synchronize(stream);
     }
 };
 
-MultiSpectralProcessor::MultiSpectralProcessor() : pImpl(nullptr) { construct(); }
+MultiSpectralProcessor::MultiSpectralProcessor() { construct(); }
 MultiSpectralProcessor::~MultiSpectralProcessor() { destroy(); }
-void MultiSpectralProcessor::construct() { pImpl = nullptr; }
+
+void MultiSpectralProcessor::construct()                    // MultiSpectralProcessor.cpp:33-58
+{
+    nChannels = nRank = nMaxRank = nOffset = 0;
+    vChannels = nullptr;
+    vFftBuf = nullptr;
+    pWnd = nullptr;
+    fPhase = 0.0f;
+    bUpdate = true;
+    pFunc = nullptr;
+    pObject = pSubject = nullptr;
+    pData = nullptr;
+}
 
 bool MultiSpectralProcessor::init(size_t channels, size_t max_rank)
 {
@@ -1206,71 +1215,79 @@ bool MultiSpectralProcessor::init(size_t channels, size_t max_rank)
     }
     mi_spectral_bank_set_timing(p->bank, 1);                // transform as soon as the frame is complete (:324)
     destroy();
-    p->channels = channels;
-    p->max_rank = max_rank;
-    p->rank = max_rank;
-    p->in.assign(channels, nullptr);
-    p->out.assign(channels, nullptr);
+    p->owner = this;
+    p->ch.assign(channels, channel_t{ nullptr, nullptr, nullptr, nullptr, nullptr });
     p->has_in.assign(channels, 0);
     p->has_out.assign(channels, 0);
-    pImpl = p;
+    pData = reinterpret_cast<uint8_t *>(p);
+    vChannels = p->ch.data();
+    nChannels = uint32_t(channels);
+    nMaxRank = nRank = uint32_t(max_rank);
+    nOffset = 0;
+    fPhase = 0.0f;
+    bUpdate = true;
+    pFunc = nullptr;
+    pObject = pSubject = nullptr;
     return true;
 }
 
 void MultiSpectralProcessor::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_spectral_bank_destroy(pImpl->bank);
-    mi_dspu_free(pImpl->d_in);
-    mi_dspu_free(pImpl->d_out);
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_spectral_bank_destroy(p->bank);
+        mi_dspu_free(p->d_in);
+        mi_dspu_free(p->d_out);
+        delete p;
+    }
+    pData = nullptr;
+    vChannels = nullptr;
 }
 
 void MultiSpectralProcessor::bind_handler(multi_spectral_processor_func_t func, void *object, void *subject)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    pImpl->func = func;
-    pImpl->object = object;
-    pImpl->subject = subject;
+    pFunc = func;
+    pObject = object;
+    pSubject = subject;
     if (func != nullptr)
-        mi_spectral_bank_bind(pImpl->bank, &impl_t::trampoline, pImpl, nullptr);
+        mi_spectral_bank_bind(p->bank, &impl_t::trampoline, p, nullptr);
     else
-        mi_spectral_bank_unbind(pImpl->bank);
+        mi_spectral_bank_unbind(p->bank);
 }
 
 void MultiSpectralProcessor::unbind_handler() { bind_handler(nullptr, nullptr, nullptr); }
 
 status_t MultiSpectralProcessor::bind(size_t index, float *out, const float *in)
 {
-    if (pImpl == nullptr)
+    if (impl() == nullptr)
         return STATUS_BAD_STATE;
-    if (index >= pImpl->channels)
+    if (index >= nChannels)
         return STATUS_INVALID_VALUE;
-    pImpl->in[index] = in;
-    pImpl->out[index] = out;
+    vChannels[index].pIn = in;
+    vChannels[index].pOut = out;
     return STATUS_OK;
 }
 
 status_t MultiSpectralProcessor::bind_in(size_t index, const float *in)
 {
-    if (pImpl == nullptr)
+    if (impl() == nullptr)
         return STATUS_BAD_STATE;
-    if (index >= pImpl->channels)
+    if (index >= nChannels)
         return STATUS_INVALID_VALUE;
-    pImpl->in[index] = in;
+    vChannels[index].pIn = in;
     return STATUS_OK;
 }
 
 status_t MultiSpectralProcessor::bind_out(size_t index, float *out)
 {
-    if (pImpl == nullptr)
+    if (impl() == nullptr)
         return STATUS_BAD_STATE;
-    if (index >= pImpl->channels)
+    if (index >= nChannels)
         return STATUS_INVALID_VALUE;
-    pImpl->out[index] = out;
+    vChannels[index].pOut = out;
     return STATUS_OK;
 }
 
@@ -1280,92 +1297,97 @@ status_t MultiSpectralProcessor::unbind_out(size_t index) { return bind_out(inde
 
 void MultiSpectralProcessor::unbind_all()
 {
-    if (pImpl == nullptr)
-        return;
-    std::fill(pImpl->in.begin(), pImpl->in.end(), nullptr);
-    std::fill(pImpl->out.begin(), pImpl->out.end(), nullptr);
+    for (uint32_t i = 0; impl() != nullptr && i < nChannels; ++i)
+    {
+        vChannels[i].pIn = nullptr;
+        vChannels[i].pOut = nullptr;
+    }
 }
 
-bool MultiSpectralProcessor::needs_update() const  { return pImpl && pImpl->update; }
-void MultiSpectralProcessor::update_settings()     { if (pImpl) pImpl->update = false; }
-size_t MultiSpectralProcessor::get_rank() const    { return pImpl ? pImpl->rank : 0; }
-float MultiSpectralProcessor::phase() const        { return pImpl ? pImpl->phase : 0.0f; }
-size_t MultiSpectralProcessor::latency() const     { return pImpl ? (size_t(1) << pImpl->rank) : 0; }
-size_t MultiSpectralProcessor::frame_size() const  { return pImpl ? (size_t(1) << (pImpl->rank - 1)) : 0; }
+void MultiSpectralProcessor::update_settings()     { if (impl() != nullptr) bUpdate = false; }
 
 void MultiSpectralProcessor::set_phase(float phase)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    pImpl->phase = std::min(std::max(phase, 0.0f), 1.0f);
-    pImpl->update = true;
-    mi_spectral_bank_set_phase(pImpl->bank, pImpl->phase);
+    fPhase = std::min(std::max(phase, 0.0f), 1.0f);
+    bUpdate = true;
+    mi_spectral_bank_set_phase(p->bank, fPhase);
 }
 
 void MultiSpectralProcessor::set_rank(size_t rank)
 {
-    if (pImpl == nullptr || rank == pImpl->rank || rank > pImpl->max_rank)
+    impl_t *p = impl();
+    if (p == nullptr || rank == nRank || rank > nMaxRank)
         return;
-    pImpl->rank = rank;
-    pImpl->update = true;
-    mi_spectral_bank_set_rank(pImpl->bank, uint32_t(rank));
+    nRank = uint32_t(rank);
+    bUpdate = true;
+    mi_spectral_bank_set_rank(p->bank, uint32_t(rank));
 }
 
 void MultiSpectralProcessor::process(size_t count)
 {
-    impl_t *p = pImpl;
+    impl_t *p = impl();
     if (p == nullptr || count == 0)
         return;
-    const size_t C = p->channels;
+    const size_t C = nChannels;
     for (size_t i = 0; i < C; ++i)
     {
-        p->has_in[i]  = (p->in[i] != nullptr) ? 1 : 0;
-        p->has_out[i] = (p->out[i] != nullptr) ? 1 : 0;
+        p->has_in[i]  = (vChannels[i].pIn != nullptr) ? 1 : 0;
+        p->has_out[i] = (vChannels[i].pOut != nullptr) ? 1 : 0;
     }
-    bool ok = p->reserve(count) &&
+    bool ok = p->reserve(C, count) &&
               mi_spectral_bank_bind_channels(p->bank, p->has_in.data(), p->has_out.data(), nullptr) == MI_OK;
     if (ok)
     {
         // channels without an input take zeros (MultiSpectralProcessor.cpp:316-317)
         p->host_io.assign(C * count, 0.0f);
         for (size_t i = 0; i < C; ++i)
-            if (p->in[i] != nullptr)
-                std::memcpy(&p->host_io[i * count], p->in[i], count * sizeof(float));
+            if (vChannels[i].pIn != nullptr)
+                std::memcpy(&p->host_io[i * count], vChannels[i].pIn, count * sizeof(float));
         ok = mi_dspu_copy_h2d(p->d_in, p->host_io.data(), C * count * sizeof(float), nullptr) == MI_OK &&
              mi_spectral_bank_process(p->bank, p->d_out, p->d_in, count, count, count, nullptr) == MI_OK &&
              mi_dspu_copy_d2h(p->host_io.data(), p->d_out, C * count * sizeof(float), nullptr) == MI_OK &&
              mi_dspu_stream_synchronize(nullptr) == MI_OK;
     }
-    for (size_t i = 0; i < C; ++i)
+    for (size_t i = 0; i < C; ++i)                           // the bound pointers move on (:310-320)
     {
-        if (p->out[i] != nullptr)
+        if (vChannels[i].pOut != nullptr)
         {
             if (ok)
-                std::memcpy(p->out[i], &p->host_io[i * count], count * sizeof(float));
+                std::memcpy(vChannels[i].pOut, &p->host_io[i * count], count * sizeof(float));
             else
-                std::memset(p->out[i], 0, count * sizeof(float));
-            p->out[i] += count;
+                std::memset(vChannels[i].pOut, 0, count * sizeof(float));
+            vChannels[i].pOut += count;
         }
-        if (p->in[i] != nullptr)
-            p->in[i] += count;
+        if (vChannels[i].pIn != nullptr)
+            vChannels[i].pIn += count;
     }
-    p->update = false;
+    uint32_t r = 0;
+    mi_spectral_bank_get(p->bank, nullptr, nullptr, &r);
+    nOffset = uint32_t((size_t(1) << (nRank - 1)) - r);
+    bUpdate = false;
 }
 
-void MultiSpectralProcessor::reset()             { if (pImpl) mi_spectral_bank_reset(pImpl->bank, nullptr); }
+void MultiSpectralProcessor::reset()             { if (impl_t *p = impl()) mi_spectral_bank_reset(p->bank, nullptr); }
 
 size_t MultiSpectralProcessor::remaining() const
 {
     uint32_t r = 0;
-    if (pImpl != nullptr)
-        mi_spectral_bank_get(pImpl->bank, nullptr, nullptr, &r);
+    if (impl_t *p = impl())
+        mi_spectral_bank_get(p->bank, nullptr, nullptr, &r);
     return r;
 }
 
 void MultiSpectralProcessor::dump(IStateDumper *v) const
 {
-    v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
-    v->write("nRank", get_rank());
+    v->write("nChannels", size_t(nChannels));
+    v->write("nRank", size_t(nRank));
+    v->write("nMaxRank", size_t(nMaxRank));
+    v->write("nOffset", size_t(nOffset));
+    v->write("fPhase", fPhase);
+    v->write("bUpdate", bUpdate);
 }
 
 // ---- Crossover --------------------------------------------------------------------------------------------------
@@ -3031,12 +3053,8 @@ void RingBuffer::dump(IStateDumper *v) const
 struct Analyzer::impl_t
 {
     mi_analyzer_bank_t *bank = nullptr;
-    size_t  channels = 0, rank = 0, max_rank = 0, sample_rate = 0, max_sample_rate = 0, max_delay = 0;
-    size_t  window = windows::HANN, envelope = envelope::PINK_NOISE;
-    float   shift = 1.0f, rate = 1.0f, min_rate = 1.0f, reactivity = 0.0f;
-    bool    active = true, dirty = true;
-    struct chan_t { bool active = true; size_t delay = 0; };
-    std::vector<chan_t> ch;
+    std::vector<channel_t> ch;              // storage behind vChannels
+    bool    pushed_active = true;           // bActive as the bank last saw it (set_activity() is inline: it only writes the member)
     float  *d_in = nullptr;
     size_t  in_cap = 0;
     float  *d_out = nullptr;
@@ -3044,18 +3062,37 @@ struct Analyzer::impl_t
     size_t  q_cap = 0;
 };
 
-Analyzer::Analyzer() : pImpl(nullptr) { construct(); }
+Analyzer::Analyzer() { construct(); }
 Analyzer::~Analyzer() { destroy(); }
-void Analyzer::construct() { pImpl = nullptr; }
+
+void Analyzer::construct()                                  // Analyzer.cpp:33-66
+{
+    nChannels = nMaxRank = nRank = nSampleRate = nMaxSampleRate = nBufSize = nCounter = nPeriod = nStep = nHead = 0;
+    nReconfigure = 0;
+    nEnvelope = envelope::PINK_NOISE;
+    nWindow = windows::HANN;
+    nMaxUserDelay = 0;
+    fReactivity = 0.0f;
+    fTau = 1.0f;
+    fRate = 1.0f;
+    fMinRate = 1.0f;
+    fShift = 1.0f;
+    bActive = true;
+    vChannels = nullptr;
+    vData = nullptr;
+    vSigRe = vFftReIm = vWindow = vEnvelope = nullptr;
+}
 
 void Analyzer::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_analyzer_bank_destroy(pImpl->bank);
-    mi_dspu_free(pImpl->d_in); mi_dspu_free(pImpl->d_out); mi_dspu_free(pImpl->d_idx);
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_analyzer_bank_destroy(p->bank);
+        mi_dspu_free(p->d_in); mi_dspu_free(p->d_out); mi_dspu_free(p->d_idx);
+        delete p;
+    }
+    vData = nullptr;
+    vChannels = nullptr;
 }
 
 bool Analyzer::init(size_t channels, size_t max_rank, size_t max_sr, float min_rate, size_t max_delay)
@@ -3069,149 +3106,178 @@ bool Analyzer::init(size_t channels, size_t max_rank, size_t max_sr, float min_r
         delete p;
         return false;
     }
-    p->channels = channels;
-    p->rank = p->max_rank = max_rank;
-    p->max_sample_rate = max_sr;
-    p->max_delay = max_delay;
-    p->min_rate = float(uint32_t(min_rate));                // fMinRate = uint32_t(min_rate), Analyzer.cpp:120
-    p->ch.resize(channels);
-    pImpl = p;
+    p->ch.assign(channels, channel_t{ nullptr, nullptr, nullptr, 0, 0, false, true });
+    vData = p;
+    vChannels = p->ch.data();
+    nChannels = uint32_t(channels);                         // Analyzer.cpp:113-131
+    nMaxRank = nRank = uint32_t(max_rank);
+    nSampleRate = 0;
+    nMaxSampleRate = uint32_t(max_sr);
+    nMaxUserDelay = uint32_t(max_delay);
+    fMinRate = float(uint32_t(min_rate));                   // fMinRate = uint32_t(min_rate), :120
+    const size_t fft = size_t(1) << max_rank;
+    nBufSize = uint32_t((fft + size_t(float(max_sr * 2) / min_rate) + max_delay + 0x40 + 0x3f) & ~size_t(0x3f));
+    nCounter = nPeriod = nStep = nHead = 0;
+    nEnvelope = envelope::PINK_NOISE;
+    nWindow = windows::HANN;
+    fReactivity = 0.0f;
+    fTau = 1.0f;
+    fRate = 1.0f;
+    fShift = 1.0f;
+    bActive = true;
+    nReconfigure = R_ALL;
     return true;
 }
 
-// The setters keep the values the getters report and the "something changed" flag of needs_reconfiguration(), with the
-// reference's own no-change tests (Analyzer.cpp:154-250); the bank applies them at the next process() / reconfigure().
+// The setters keep the members the inline getters report and the flags of needs_reconfiguration(), with the reference's
+// own no-change tests (Analyzer.cpp:154-250); the bank applies them at the next process() / reconfigure().
 void Analyzer::set_sample_rate(size_t sr)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    sr = std::min(sr, pImpl->max_sample_rate);
-    if (pImpl->sample_rate == sr)
+    sr = std::min(sr, size_t(nMaxSampleRate));
+    if (nSampleRate == sr)
         return;
-    pImpl->sample_rate = sr;
-    pImpl->dirty = true;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SAMPLE_RATE, double(sr));
+    nSampleRate = uint32_t(sr);
+    nReconfigure |= R_ALL;
+    mi_analyzer_bank_configure(p->bank, MI_ANALYZER_SAMPLE_RATE, double(sr));
 }
 
 void Analyzer::set_rate(float rate)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    rate = std::max(pImpl->min_rate, rate);
-    if (pImpl->rate == rate)
+    rate = std::max(fMinRate, rate);
+    if (fRate == rate)
         return;
-    pImpl->rate = rate;
-    pImpl->dirty = true;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RATE, rate);
+    fRate = rate;
+    nReconfigure |= R_COUNTERS;
+    mi_analyzer_bank_configure(p->bank, MI_ANALYZER_RATE, rate);
 }
 
 void Analyzer::set_window(size_t window)
 {
-    if (pImpl == nullptr || pImpl->window == window)
+    impl_t *p = impl();
+    if (p == nullptr || nWindow == window)
         return;
-    pImpl->window = window;
-    pImpl->dirty = true;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_WINDOW, double(window));
+    nWindow = uint32_t(window);
+    nReconfigure |= R_WINDOW;
+    mi_analyzer_bank_configure(p->bank, MI_ANALYZER_WINDOW, double(window));
 }
 
 void Analyzer::set_envelope(size_t env)
 {
-    if (pImpl == nullptr || pImpl->envelope == env)
+    impl_t *p = impl();
+    if (p == nullptr || nEnvelope == env)
         return;
-    pImpl->envelope = env;
-    pImpl->dirty = true;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ENVELOPE, double(env));
+    nEnvelope = uint32_t(env);
+    nReconfigure |= R_ENVELOPE;
+    mi_analyzer_bank_configure(p->bank, MI_ANALYZER_ENVELOPE, double(env));
 }
 
 void Analyzer::set_shift(float shift)
 {
-    if (pImpl == nullptr || pImpl->shift == shift)
+    impl_t *p = impl();
+    if (p == nullptr || fShift == shift)
         return;
-    pImpl->shift = shift;
-    pImpl->dirty = true;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_SHIFT, shift);
+    fShift = shift;
+    nReconfigure |= R_ENVELOPE;
+    mi_analyzer_bank_configure(p->bank, MI_ANALYZER_SHIFT, shift);
 }
 
 void Analyzer::set_reactivity(float r)
 {
-    if (pImpl == nullptr || pImpl->reactivity == r)
+    impl_t *p = impl();
+    if (p == nullptr || fReactivity == r)
         return;
-    pImpl->reactivity = r;
-    pImpl->dirty = true;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_REACTIVITY, r);
+    fReactivity = r;
+    nReconfigure |= R_TAU;
+    mi_analyzer_bank_configure(p->bank, MI_ANALYZER_REACTIVITY, r);
 }
 
-void Analyzer::set_activity(bool active)
+// set_activity() and reset() are inline in the reference header: a caller compiled against it only writes bActive /
+// nReconfigure.  Whatever changed that way reaches the bank here, before it is used.
+void Analyzer::sync_inline_state()
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    pImpl->active = active;
-    mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_ACTIVE, active ? 1.0 : 0.0);
+    if (p->pushed_active != bActive)
+    {
+        mi_analyzer_bank_configure(p->bank, MI_ANALYZER_ACTIVE, bActive ? 1.0 : 0.0);
+        p->pushed_active = bActive;
+    }
+    if (nReconfigure & R_ANALYSIS)
+        mi_analyzer_bank_reset(p->bank);                    // (R_ALL from the setters includes it: the bank has it set already)
 }
-
-size_t Analyzer::get_rank() const               { return pImpl ? pImpl->rank : 0; }
-size_t Analyzer::get_channels() const           { return pImpl ? pImpl->channels : 0; }
-size_t Analyzer::get_window() const             { return pImpl ? pImpl->window : size_t(windows::HANN); }
-size_t Analyzer::get_envelope() const           { return pImpl ? pImpl->envelope : size_t(envelope::PINK_NOISE); }
-float  Analyzer::get_shift() const              { return pImpl ? pImpl->shift : 1.0f; }
-size_t Analyzer::get_sample_rate() const        { return pImpl ? pImpl->sample_rate : 0; }
-size_t Analyzer::get_max_sample_rate() const    { return pImpl ? pImpl->max_sample_rate : 0; }
-float  Analyzer::get_rate() const               { return pImpl ? pImpl->rate : 1.0f; }
-float  Analyzer::get_min_rate() const           { return pImpl ? pImpl->min_rate : 1.0f; }
-float  Analyzer::get_reactivity() const         { return pImpl ? pImpl->reactivity : 0.0f; }
-bool   Analyzer::activity() const               { return pImpl ? pImpl->active : true; }
-bool   Analyzer::channel_active(size_t c) const { return pImpl != nullptr && c < pImpl->channels && pImpl->ch[c].active; }
-size_t Analyzer::channel_delay(size_t c) const  { return (pImpl != nullptr && c < pImpl->channels) ? pImpl->ch[c].delay : 0; }
-bool   Analyzer::needs_reconfiguration() const  { return pImpl != nullptr && pImpl->dirty; }
-void   Analyzer::reset()                        { if (pImpl) pImpl->dirty = true; }    // nReconfigure |= R_ANALYSIS: nothing to redo here
 
 void Analyzer::reconfigure()
 {
-    if (pImpl == nullptr || !pImpl->dirty)
+    impl_t *p = impl();
+    if (p == nullptr || !nReconfigure)
         return;
-    mi_analyzer_bank_process(pImpl->bank, nullptr, 0, 0, nullptr);      // applies the pending settings, consumes no samples
-    pImpl->dirty = false;
+    sync_inline_state();
+    mi_analyzer_bank_process(p->bank, nullptr, 0, 0, nullptr);      // applies the pending settings, consumes no samples
+    uint32_t period = 0, step = 0;
+    mi_analyzer_bank_info(p->bank, nullptr, nullptr, &period, &step);
+    nPeriod = period;
+    nStep = step;
+    for (uint32_t i = 0; i < nChannels; ++i)
+        vChannels[i].nDelay = i * nStep;                    // Analyzer.cpp:289-293
+    nReconfigure = 0;
 }
 
 bool Analyzer::set_rank(size_t rank)
 {
-    if (pImpl == nullptr || rank < 2 || rank > pImpl->max_rank)
+    impl_t *p = impl();
+    if (p == nullptr || rank < 2 || rank > nMaxRank)
         return false;
-    if (pImpl->rank == rank)
+    if (nRank == rank)
         return true;
-    if (mi_analyzer_bank_configure(pImpl->bank, MI_ANALYZER_RANK, double(rank)) != MI_OK)
+    if (mi_analyzer_bank_configure(p->bank, MI_ANALYZER_RANK, double(rank)) != MI_OK)
         return false;
-    pImpl->rank = rank;
-    pImpl->dirty = true;
+    nRank = uint32_t(rank);
+    nReconfigure |= R_ALL;
     return true;
 }
 
-bool Analyzer::freeze_channel(size_t ch, bool freeze)   { return pImpl && mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_FREEZE, freeze) == MI_OK; }
+bool Analyzer::freeze_channel(size_t ch, bool freeze)
+{
+    impl_t *p = impl();
+    if (p == nullptr || ch >= nChannels || mi_analyzer_bank_channel(p->bank, uint32_t(ch), MI_ANALYZER_CH_FREEZE, freeze) != MI_OK)
+        return false;
+    vChannels[ch].bFreeze = freeze;
+    return true;
+}
 
 bool Analyzer::enable_channel(size_t ch, bool enable)
 {
-    if (pImpl == nullptr || ch >= pImpl->channels || pImpl->ch[ch].active == enable)     // no change answers false (:232-235)
+    impl_t *p = impl();
+    if (p == nullptr || ch >= nChannels || vChannels[ch].bActive == enable)      // no change answers false (:232-235)
         return false;
-    if (mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_ENABLE, enable) != MI_OK)
+    if (mi_analyzer_bank_channel(p->bank, uint32_t(ch), MI_ANALYZER_CH_ENABLE, enable) != MI_OK)
         return false;
-    pImpl->ch[ch].active = enable;
-    pImpl->dirty = true;
+    vChannels[ch].bActive = enable;
+    nReconfigure |= R_COUNTERS;
     return true;
 }
 
 bool Analyzer::set_channel_delay(size_t ch, size_t d)
 {
-    if (pImpl == nullptr || ch >= pImpl->channels || d > pImpl->max_delay)
+    impl_t *p = impl();
+    if (p == nullptr || ch >= nChannels || d > nMaxUserDelay)
         return false;
-    if (mi_analyzer_bank_channel(pImpl->bank, uint32_t(ch), MI_ANALYZER_CH_DELAY, uint32_t(d)) != MI_OK)
+    if (mi_analyzer_bank_channel(p->bank, uint32_t(ch), MI_ANALYZER_CH_DELAY, uint32_t(d)) != MI_OK)
         return false;
-    pImpl->ch[ch].delay = d;
+    vChannels[ch].nUserDelay = uint32_t(d);
     return true;
 }
 
 bool Analyzer::read_frequencies(float *frq, float start, float stop, size_t count, size_t flags)     // Analyzer.cpp:411-441
 {
-    if (pImpl == nullptr || count == 0)
+    if (impl() == nullptr || count == 0)
         return false;
     if (count == 1)
     {
@@ -3238,9 +3304,11 @@ bool Analyzer::read_frequencies(float *frq, float start, float stop, size_t coun
 
 void Analyzer::process(const float * const *in, size_t samples)
 {
+    impl_t *pImpl = impl();
     if (pImpl == nullptr || samples == 0)
         return;
-    const size_t need = pImpl->channels * samples;
+    sync_inline_state();
+    const size_t need = size_t(nChannels) * samples;
     if (need > pImpl->in_cap)
     {
         mi_dspu_free(pImpl->d_in);
@@ -3250,7 +3318,7 @@ void Analyzer::process(const float * const *in, size_t samples)
             return;
         pImpl->in_cap = need;
     }
-    for (size_t c = 0; c < pImpl->channels; ++c)
+    for (size_t c = 0; c < nChannels; ++c)
     {
         if (in != nullptr && in[c] != nullptr)
             mi_dspu_copy_h2d(pImpl->d_in + c * samples, in[c], samples * sizeof(float), nullptr);
@@ -3259,18 +3327,28 @@ void Analyzer::process(const float * const *in, size_t samples)
     }
     mi_analyzer_bank_process(pImpl->bank, pImpl->d_in, samples, samples, nullptr);
     mi_dspu_stream_synchronize(nullptr);
-    pImpl->dirty = false;
+    if (nReconfigure)                                       // process() reconfigures first (Analyzer.cpp:303)
+    {
+        uint32_t period = 0, step = 0;
+        mi_analyzer_bank_info(pImpl->bank, nullptr, nullptr, &period, &step);
+        nPeriod = period;
+        nStep = step;
+        for (uint32_t i = 0; i < nChannels; ++i)
+            vChannels[i].nDelay = i * nStep;
+        nReconfigure = 0;
+    }
 }
 
 bool Analyzer::get_spectrum(size_t channel, float *out, const uint32_t *idx, size_t count)
 {
-    if (pImpl == nullptr || channel >= pImpl->channels || count == 0)
+    impl_t *pImpl = impl();
+    if (pImpl == nullptr || channel >= nChannels || count == 0)
         return false;
     if (count > pImpl->q_cap)
     {
         mi_dspu_free(pImpl->d_out); mi_dspu_free(pImpl->d_idx);
         pImpl->d_out = nullptr; pImpl->d_idx = nullptr; pImpl->q_cap = 0;
-        if (mi_dspu_malloc(reinterpret_cast<void **>(&pImpl->d_out), pImpl->channels * count * sizeof(float)) != MI_OK ||
+        if (mi_dspu_malloc(reinterpret_cast<void **>(&pImpl->d_out), size_t(nChannels) * count * sizeof(float)) != MI_OK ||
             mi_dspu_malloc(reinterpret_cast<void **>(&pImpl->d_idx), count * sizeof(uint32_t)) != MI_OK)
             return false;
         pImpl->q_cap = count;
@@ -3290,10 +3368,10 @@ float Analyzer::get_level(size_t channel, const uint32_t idx)
 
 void Analyzer::get_frequencies(float *frq, uint32_t *idx, float start, float stop, size_t count, bool linear)
 {
-    if (pImpl == nullptr)
+    if (impl() == nullptr)
         return;
-    const size_t fft_size = size_t(1) << pImpl->rank, fft_width = fft_size >> 1;
-    const float scale = float(fft_size) / float(pImpl->sample_rate);
+    const size_t fft_size = size_t(1) << nRank, fft_width = fft_size >> 1;
+    const float scale = float(fft_size) / float(nSampleRate);
     const float norm = linear ? (stop - start) / (count - 1) : logf(stop / start) / (count - 1);
     for (size_t i = 0; i < count; ++i)
     {
@@ -3304,7 +3382,15 @@ void Analyzer::get_frequencies(float *frq, uint32_t *idx, float start, float sto
     }
 }
 
-void Analyzer::dump(IStateDumper *v) const  { v->write("nRank", get_rank()); }
+void Analyzer::dump(IStateDumper *v) const
+{
+    v->write("nChannels", size_t(nChannels));
+    v->write("nMaxRank", size_t(nMaxRank));
+    v->write("nRank", size_t(nRank));
+    v->write("nSampleRate", size_t(nSampleRate));
+    v->write("nReconfigure", size_t(nReconfigure));
+    v->write("bActive", bActive);
+}
 
 } // namespace dspu
 } // namespace lsp

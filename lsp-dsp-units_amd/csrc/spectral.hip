@@ -1287,6 +1287,13 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
     return MI_OK;
 }
 
+int mi_analyzer_bank_reset(mi_analyzer_bank_t *b)                         // Analyzer::reset(), util/Analyzer.h:296
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_reset: NULL bank");
+    b->reconfigure |= R_ANALYSIS;                           // the spectra are cleared at the next reconfigure (Analyzer.cpp:274-281)
+    return MI_OK;
+}
+
 int mi_analyzer_bank_configure(mi_analyzer_bank_t *b, int what, double value)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_configure: NULL bank");

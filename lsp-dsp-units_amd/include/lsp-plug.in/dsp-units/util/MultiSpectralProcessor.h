@@ -17,17 +17,49 @@ namespace lsp
 
         class LSP_DSP_UNITS_PUBLIC MultiSpectralProcessor
         {
-            private:
+            // Binary layout: data members, order and inline members of the reference class
+            // (include/lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h:50-80,178-218 of lsp-dsp-units 1.0.36).  vChannels
+            // holds the bound pointers exactly as there (advanced by process()); pData owns them and the GPU bank.
+            protected:
+                typedef struct channel_t
+                {
+                    const float            *pIn;        // bound input, NULL: none
+                    float                  *pOut;       // bound output, NULL: none
+                    float                  *pInBuf;     // (device side: the bank's buffers)
+                    float                  *pOutBuf;
+                    float                  *pFftBuf;
+                } channel_t;
+
+            protected:
+                uint32_t                    nChannels;
+                uint32_t                    nRank;
+                uint32_t                    nMaxRank;
+                uint32_t                    nOffset;
+                channel_t                  *vChannels;
+                float                     **vFftBuf;
+                float                      *pWnd;
+                float                       fPhase;
+                bool                        bUpdate;
+
+                multi_spectral_processor_func_t pFunc;
+                void                       *pObject;
+                void                       *pSubject;
+
+                uint8_t                    *pData;      // the channel records and the GPU state
+
+            protected:
                 struct impl_t;
-                impl_t     *pImpl;
+                impl_t                     *impl() const    { return reinterpret_cast<impl_t *>(pData); }
 
             public:
                 explicit MultiSpectralProcessor();
                 MultiSpectralProcessor(const MultiSpectralProcessor &) = delete;
+                MultiSpectralProcessor(MultiSpectralProcessor &&) = delete;
                 MultiSpectralProcessor & operator = (const MultiSpectralProcessor &) = delete;
+                MultiSpectralProcessor & operator = (MultiSpectralProcessor &&) = delete;
                 ~MultiSpectralProcessor();
 
-                void            construct();
+                void            construct();                // valid on raw (e.g. zeroed) memory
                 bool            init(size_t channels, size_t max_rank);
                 void            destroy();
 
@@ -41,14 +73,14 @@ namespace lsp
                 status_t        unbind_in(size_t index);
                 status_t        unbind_out(size_t index);
                 void            unbind_all();
-                bool            needs_update() const;
+                inline bool     needs_update() const        { return bUpdate;           }
                 void            update_settings();
-                size_t          get_rank() const;
-                float           phase() const;
+                inline size_t   get_rank() const            { return nRank;             }
+                inline float    phase() const               { return fPhase;            }
                 void            set_phase(float phase);
                 void            set_rank(size_t rank);
-                size_t          latency() const;
-                size_t          frame_size() const;
+                inline size_t   latency() const             { return 1 << nRank;        }
+                inline size_t   frame_size() const          { return 1 << (nRank - 1);  }
                 void            process(size_t count);
                 void            reset();
                 size_t          remaining() const;

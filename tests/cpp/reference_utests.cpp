@@ -674,6 +674,62 @@ static void raw_memory_objects()
     fb->destroy();
     free(fb);
 
+    {   // MultiSpectralProcessor on raw memory: inline getters read the members
+        dspu::MultiSpectralProcessor *mp = raw_object<dspu::MultiSpectralProcessor>();
+        mp->construct();
+        CHECK(mp->get_rank() == 0 && mp->needs_update() && mp->phase() == 0.0f, "constructed multi-processor");
+        CHECK(mp->init(2, 9), "multi-processor init");
+        CHECK(mp->get_rank() == 9 && mp->latency() == 512 && mp->frame_size() == 256, "rank / latency / frame_size");
+        mp->set_rank(8);
+        CHECK(mp->get_rank() == 8 && mp->latency() == 256 && mp->needs_update(), "set_rank");
+        std::vector<float> in0(2048), out0(2048, -1.0f);
+        for (size_t i = 0; i < in0.size(); ++i)
+            in0[i] = sinf(0.05f * float(i));
+        CHECK(mp->bind(0, out0.data(), in0.data()) == STATUS_OK && mp->bind(5, NULL, NULL) == STATUS_INVALID_VALUE, "bind");
+        mp->process(2048);
+        CHECK(!mp->needs_update(), "process() applies the settings");
+        float worst = 0.0f;
+        for (size_t i = 256; i < 2048; ++i)
+            worst = fmaxf(worst, fabsf(out0[i] - in0[i - 256]));
+        CHECK(worst <= 1e-5f, "unbound handler: the input delayed by the latency (%g)", worst);
+        mp->destroy();
+        free(mp);
+    }
+
+    {   // Analyzer: inline setters only write members; the object follows them at its next process()
+        dspu::Analyzer *an = raw_object<dspu::Analyzer>();
+        an->construct();
+        CHECK(an->get_channels() == 0 && an->get_rank() == 0 && !an->needs_reconfiguration() && an->activity(), "constructed analyzer");
+        CHECK(an->init(2, 9, 48000, 10.0f, 64), "analyzer init");
+        CHECK(an->get_channels() == 2 && an->get_rank() == 9 && an->needs_reconfiguration(), "init members");
+        an->set_sample_rate(48000); an->set_rate(93.75f); an->set_reactivity(0.0001f);
+        std::vector<float> a0(512), a1(512, 0.0f);
+        for (int i = 0; i < 512; ++i)
+            a0[i] = sinf(2.0f * float(M_PI) * 32.0f * i / 512.0f);
+        const float *ins[2] = { a0.data(), a1.data() };
+        for (int k = 0; k < 4; ++k)
+            an->process(ins, 512);
+        CHECK(!an->needs_reconfiguration(), "process() reconfigures");
+        const uint32_t bin = 32;
+        const float lit = an->get_level(0, bin);
+        CHECK(lit > 0.0f, "a sine lights its bin: %g", lit);
+        an->set_activity(false);                            // inline: bActive = false
+        for (int k = 0; k < 3; ++k)
+            an->process(ins, 512);
+        CHECK(an->get_level(0, bin) == 0.0f, "an inactive analyzer publishes zeros: %g", an->get_level(0, bin));
+        an->set_activity(true);
+        for (int k = 0; k < 3; ++k)
+            an->process(ins, 512);
+        CHECK(an->get_level(0, bin) > 0.0f, "active again");
+        an->reset();                                        // inline: nReconfigure |= R_ANALYSIS
+        CHECK(an->needs_reconfiguration(), "reset() asks for a reconfigure");
+        an->reconfigure();
+        CHECK(an->get_level(0, bin) == 0.0f, "reset() clears the spectra: %g", an->get_level(0, bin));
+        CHECK(an->channel_active(1) && an->enable_channel(1, false) && !an->channel_active(1) && an->channel_delay(1) == 0, "channel records");
+        an->destroy();
+        free(an);
+    }
+
     dspu::Filter *f = raw_object<dspu::Filter>();
     f->construct();
     CHECK(f->inactive() && f->latency() == 0, "constructed filter is inactive");
@@ -759,6 +815,8 @@ static void raw_memory_objects()
 
     // DynamicFilters: a bell whose gain follows a per-sample vector; gain 1 is transparent, a constant gain is the static bell
     static_assert(sizeof(dspu::DynamicFilters) == 64, "DynamicFilters object size of the reference header");
+    static_assert(sizeof(dspu::MultiSpectralProcessor) == 80, "MultiSpectralProcessor object size of the reference header");
+    static_assert(sizeof(dspu::Analyzer) == 128, "Analyzer object size of the reference header (14 x u32, 5 x f32, bool, 6 pointers)");
     dspu::DynamicFilters *df = raw_object<dspu::DynamicFilters>();
     df->construct();
     CHECK(df->filter_inactive(0) && !df->filter_active(0), "constructed dynamic filters");
