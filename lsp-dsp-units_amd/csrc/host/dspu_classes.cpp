@@ -2309,9 +2309,6 @@ namespace bs
 struct LoudnessMeter::impl_t
 {
     mi_loudness_bank_t *bank = nullptr;
-    size_t  channels = 0, sample_rate = 0;
-    float   period = 400.0f, max_period = 400.0f, loudness = 0.0f;
-    bs::weighting_t weighting = bs::WEIGHT_K;
     struct chan_t { const float *in = nullptr; float *out = nullptr; size_t offset = 0; float link = 1.0f;
                     bs::channel_t designation = bs::CHANNEL_NONE; bool active = true; };
     std::vector<chan_t> ch;
@@ -2319,7 +2316,7 @@ struct LoudnessMeter::impl_t
     float  *d_in = nullptr, *d_out = nullptr, *d_ch = nullptr;
     size_t  cap = 0;
 
-    bool reserve(size_t n)
+    bool reserve(size_t channels, size_t n)
     {
         if (n <= cap)
             return true;
@@ -2334,18 +2331,38 @@ struct LoudnessMeter::impl_t
     }
 };
 
-LoudnessMeter::LoudnessMeter() : pImpl(nullptr) { construct(); }
+LoudnessMeter::LoudnessMeter() { construct(); }
 LoudnessMeter::~LoudnessMeter() { destroy(); }
-void LoudnessMeter::construct() { pImpl = nullptr; }
+
+void LoudnessMeter::construct()                             // LoudnessMeter.cpp:37-63
+{
+    vChannels = nullptr;
+    vBuffer = nullptr;
+    fPeriod = 0.0f;
+    fMaxPeriod = 0.0f;
+    fAvgCoeff = 1.0f;
+    fLoudness = 0.0f;
+    nSampleRate = 0;
+    nPeriod = 0;
+    nMSRefresh = 0;
+    nChannels = 0;
+    nFlags = F_UPD_ALL;
+    nDataHead = 0;
+    nDataSize = 0;
+    enWeight = bs::WEIGHT_K;
+    pData = nullptr;
+    pVarData = nullptr;
+}
 
 void LoudnessMeter::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_loudness_bank_destroy(pImpl->bank);
-    mi_dspu_free(pImpl->d_in); mi_dspu_free(pImpl->d_out); mi_dspu_free(pImpl->d_ch);
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_loudness_bank_destroy(p->bank);
+        mi_dspu_free(p->d_in); mi_dspu_free(p->d_out); mi_dspu_free(p->d_ch);
+        delete p;
+    }
+    pData = nullptr;
 }
 
 status_t LoudnessMeter::init(size_t channels, float max_period)
@@ -2359,9 +2376,6 @@ status_t LoudnessMeter::init(size_t channels, float max_period)
         delete p;
         return STATUS_NO_MEM;
     }
-    p->channels = channels;
-    p->max_period = max_period;
-    p->period = std::min(max_period, bs::LUFS_MEASURE_PERIOD_MS);
     p->ch.resize(channels);
     if (channels == 1)
         p->ch[0].designation = bs::CHANNEL_CENTER;
@@ -2370,107 +2384,132 @@ status_t LoudnessMeter::init(size_t channels, float max_period)
         p->ch[0].designation = bs::CHANNEL_LEFT;
         p->ch[1].designation = bs::CHANNEL_RIGHT;
     }
-    pImpl = p;
+    pData = reinterpret_cast<uint8_t *>(p);
+    nChannels = channels;                                   // LoudnessMeter.cpp:160-177
+    fMaxPeriod = max_period;
+    fPeriod = std::min(max_period, bs::LUFS_MEASURE_PERIOD_MS);
+    fAvgCoeff = 1.0f;
+    fLoudness = 0.0f;
+    nSampleRate = 0;
+    nPeriod = 0;
+    nMSRefresh = 0;
+    enWeight = bs::WEIGHT_K;
+    nFlags = F_UPD_ALL;
+    nDataHead = 0;
+    nDataSize = 0;
     return STATUS_OK;
 }
 
 status_t LoudnessMeter::bind(size_t id, float *out, const float *in, size_t pos)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].in = in;
-    pImpl->ch[id].out = out;
-    pImpl->ch[id].offset = pos;
+    p->ch[id].in = in;
+    p->ch[id].out = out;
+    p->ch[id].offset = pos;
     return STATUS_OK;
 }
 
-status_t LoudnessMeter::unbind(size_t id) { return bind(id, nullptr, nullptr, 0); }
-
 status_t LoudnessMeter::set_designation(size_t id, bs::channel_t designation)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].designation = designation;
-    mi_loudness_bank_set_designation(pImpl->bank, uint32_t(id), int(designation));
+    p->ch[id].designation = designation;
+    mi_loudness_bank_set_designation(p->bank, uint32_t(id), int(designation));
     return STATUS_OK;
 }
 
 bs::channel_t LoudnessMeter::designation(size_t id) const
 {
-    return (pImpl && id < pImpl->channels) ? pImpl->ch[id].designation : bs::CHANNEL_NONE;
+    impl_t *p = impl();
+    return (p && id < nChannels) ? p->ch[id].designation : bs::CHANNEL_NONE;
 }
 
 status_t LoudnessMeter::set_link(size_t id, float link)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].link = std::min(std::max(link, 0.0f), 1.0f);
-    mi_loudness_bank_set_link(pImpl->bank, uint32_t(id), link);
+    p->ch[id].link = std::min(std::max(link, 0.0f), 1.0f);
+    mi_loudness_bank_set_link(p->bank, uint32_t(id), link);
     return STATUS_OK;
 }
 
-float LoudnessMeter::link(size_t id) const { return (pImpl && id < pImpl->channels) ? pImpl->ch[id].link : 0.0f; }
+float LoudnessMeter::link(size_t id) const
+{
+    impl_t *p = impl();
+    return (p && id < nChannels) ? p->ch[id].link : 0.0f;
+}
 
 status_t LoudnessMeter::set_active(size_t id, bool active)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].active = active;
-    mi_loudness_bank_set_active(pImpl->bank, uint32_t(id), active ? 1 : 0, nullptr);
+    p->ch[id].active = active;
+    mi_loudness_bank_set_active(p->bank, uint32_t(id), active ? 1 : 0, nullptr);
     return STATUS_OK;
 }
 
-bool LoudnessMeter::active(size_t id) const { return (pImpl && id < pImpl->channels) ? pImpl->ch[id].active : false; }
-
-void LoudnessMeter::set_weighting(bs::weighting_t weighting)
+bool LoudnessMeter::active(size_t id) const
 {
-    if (pImpl == nullptr)
-        return;
-    pImpl->weighting = weighting;
-    mi_loudness_bank_set_weighting(pImpl->bank, int(weighting));
+    impl_t *p = impl();
+    return (p && id < nChannels) ? p->ch[id].active : false;
 }
 
-bs::weighting_t LoudnessMeter::weighting() const { return pImpl ? pImpl->weighting : bs::WEIGHT_K; }
-
-void LoudnessMeter::set_period(float period)
+void LoudnessMeter::set_weighting(bs::weighting_t weighting)     // LoudnessMeter.cpp:199-206
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr || enWeight == weighting)
         return;
-    pImpl->period = std::min(std::max(period, 0.0f), pImpl->max_period);
-    mi_loudness_bank_set_period(pImpl->bank, period);
+    enWeight = weighting;
+    nFlags |= F_UPD_FILTERS;
+    mi_loudness_bank_set_weighting(p->bank, int(weighting));
 }
 
-float LoudnessMeter::period() const { return pImpl ? pImpl->period : 0.0f; }
-
-bool LoudnessMeter::needs_update() const
+void LoudnessMeter::set_period(float period)                     // :208-216
 {
-    int pending = 0;
-    return pImpl != nullptr && mi_loudness_bank_needs_update(pImpl->bank, &pending) == MI_OK && pending != 0;
+    impl_t *p = impl();
+    if (p == nullptr)
+        return;
+    period = std::min(std::max(period, 0.0f), fMaxPeriod);
+    if (fPeriod == period)
+        return;
+    fPeriod = period;
+    nFlags |= F_UPD_TIME;
+    mi_loudness_bank_set_period(p->bank, period);
 }
 
 void LoudnessMeter::update_settings()
 {
-    if (pImpl != nullptr)
-        mi_loudness_bank_update_settings(pImpl->bank, nullptr);
+    impl_t *p = impl();
+    if (p == nullptr || nFlags == 0)
+        return;
+    mi_loudness_bank_update_settings(p->bank, nullptr);
+    nFlags = 0;
 }
 
 status_t LoudnessMeter::set_sample_rate(size_t sample_rate)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return STATUS_BAD_STATE;
-    if (mi_loudness_bank_set_sample_rate(pImpl->bank, uint32_t(sample_rate), nullptr) != MI_OK)
+    if (nSampleRate == sample_rate)
+        return STATUS_OK;
+    if (mi_loudness_bank_set_sample_rate(p->bank, uint32_t(sample_rate), nullptr) != MI_OK)
         return STATUS_NO_MEM;
-    pImpl->sample_rate = sample_rate;
+    nSampleRate = sample_rate;
+    nFlags |= F_UPD_ALL;
     return STATUS_OK;
 }
-
-size_t LoudnessMeter::sample_rate() const { return pImpl ? pImpl->sample_rate : 0; }
 
 size_t LoudnessMeter::latency() const
 {
     uint32_t v = 0;
-    if (pImpl != nullptr)
-        mi_loudness_bank_latency(pImpl->bank, &v);
+    if (impl_t *p = impl())
+        mi_loudness_bank_latency(p->bank, &v);
     return v;
 }
 
@@ -2480,10 +2519,10 @@ void LoudnessMeter::process(float *out, size_t count, float gain) { run(out, cou
 // with_gain: the reference's second form, which does not record fLoudness (LoudnessMeter.cpp:518-564)
 void LoudnessMeter::run(float *out, size_t count, float gain, bool with_gain)
 {
-    impl_t *p = pImpl;
-    if (p == nullptr || count == 0 || !p->reserve(count))
+    impl_t *p = impl();
+    const size_t K = nChannels;
+    if (p == nullptr || count == 0 || !p->reserve(K, count))
         return;
-    const size_t K = p->channels;
     p->host.assign(K * count, 0.0f);
     bool want_ch = false;
     for (size_t c = 0; c < K; ++c)
@@ -2510,39 +2549,40 @@ void LoudnessMeter::run(float *out, size_t count, float gain, bool with_gain)
             p->ch[c].offset += count;                       // LoudnessMeter.cpp:499
     }
     if (ok && !with_gain)
-        mi_loudness_bank_loudness(p->bank, &p->loudness, nullptr);
+        mi_loudness_bank_loudness(p->bank, &fLoudness, nullptr);
+    nFlags = 0;                                             // process() starts with update_settings() (:471-472)
 }
-
-float LoudnessMeter::loudness() const { return pImpl ? pImpl->loudness : 0.0f; }
 
 void LoudnessMeter::clear()
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    pImpl->loudness = 0.0f;
-    mi_loudness_bank_clear(pImpl->bank, nullptr);
+    fLoudness = 0.0f;
+    mi_loudness_bank_clear(p->bank, nullptr);
 }
 
 void LoudnessMeter::dump(IStateDumper *v) const
 {
-    v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
-    v->write("fPeriod", period());
+    v->write("nChannels", nChannels);
+    v->write("fPeriod", fPeriod);
+    v->write("fMaxPeriod", fMaxPeriod);
+    v->write("fLoudness", fLoudness);
+    v->write("nSampleRate", nSampleRate);
+    v->write("nFlags", nFlags);
 }
 
 // ---- ILUFSMeter ------------------------------------------------------------------------------------------------
 struct ILUFSMeter::impl_t
 {
     mi_ilufs_bank_t *bank = nullptr;
-    size_t  channels = 0, sample_rate = 0;
-    float   int_time = 60.0f, max_int_time = 60.0f, block_period = 400.0f, loudness = 0.0f;
-    bs::weighting_t weighting = bs::WEIGHT_K;
     struct chan_t { const float *in = nullptr; bs::channel_t designation = bs::CHANNEL_NONE; bool active = true, bound = true; };
     std::vector<chan_t> ch;
     std::vector<float>  host;
     float  *d_in = nullptr, *d_out = nullptr;
     size_t  cap = 0;
 
-    bool reserve(size_t n)
+    bool reserve(size_t channels, size_t n)
     {
         if (n <= cap)
             return true;
@@ -2556,18 +2596,37 @@ struct ILUFSMeter::impl_t
     }
 };
 
-ILUFSMeter::ILUFSMeter() : pImpl(nullptr) { construct(); }
+ILUFSMeter::ILUFSMeter() { construct(); }
 ILUFSMeter::~ILUFSMeter() { destroy(); }
-void ILUFSMeter::construct() { pImpl = nullptr; }
+
+void ILUFSMeter::construct()                                // ILUFSMeter.cpp:57-85
+{
+    vChannels = nullptr;
+    vBuffer = vLoudness = nullptr;
+    fBlockPeriod = 0.0f;
+    fIntTime = 0.0f;
+    fMaxIntTime = 0.0f;
+    fAvgCoeff = 1.0f;
+    fLoudness = 0.0f;
+    nBlockSize = nBlockOffset = nBlockPart = 0;
+    nMSSize = nMSHead = nMSInt = nMSCount = 0;
+    nSampleRate = 0;
+    nChannels = 0;
+    nFlags = F_UPD_ALL;
+    enWeight = bs::WEIGHT_K;
+    pData = nullptr;
+    pVarData = nullptr;
+}
 
 void ILUFSMeter::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_ilufs_bank_destroy(pImpl->bank);
-    mi_dspu_free(pImpl->d_in); mi_dspu_free(pImpl->d_out);
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        mi_ilufs_bank_destroy(p->bank);
+        mi_dspu_free(p->d_in); mi_dspu_free(p->d_out);
+        delete p;
+    }
+    pData = nullptr;
 }
 
 status_t ILUFSMeter::init(size_t channels, float max_int_time, float block_period)
@@ -2581,9 +2640,6 @@ status_t ILUFSMeter::init(size_t channels, float max_int_time, float block_perio
         delete p;
         return STATUS_NO_MEM;
     }
-    p->channels = channels;
-    p->int_time = p->max_int_time = max_int_time;
-    p->block_period = block_period;
     p->ch.resize(channels);
     if (channels == 1)
         p->ch[0].designation = bs::CHANNEL_CENTER;
@@ -2592,95 +2648,114 @@ status_t ILUFSMeter::init(size_t channels, float max_int_time, float block_perio
         p->ch[0].designation = bs::CHANNEL_LEFT;
         p->ch[1].designation = bs::CHANNEL_RIGHT;
     }
-    pImpl = p;
+    pData = reinterpret_cast<uint8_t *>(p);
+    nChannels = uint32_t(channels);                         // ILUFSMeter.cpp:183-205
+    fBlockPeriod = block_period;
+    fIntTime = fMaxIntTime = max_int_time;
+    fAvgCoeff = 1.0f;
+    fLoudness = 0.0f;
+    nBlockSize = nBlockOffset = nBlockPart = 0;
+    nMSSize = nMSHead = nMSInt = nMSCount = 0;
+    nSampleRate = 0;
+    enWeight = bs::WEIGHT_K;
+    nFlags = F_UPD_ALL;
     return STATUS_OK;
 }
 
 status_t ILUFSMeter::bind(size_t id, const float *in)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].in = in;
+    p->ch[id].in = in;
     return STATUS_OK;
 }
 
 status_t ILUFSMeter::set_designation(size_t id, bs::channel_t designation)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].designation = designation;
-    mi_ilufs_bank_set_designation(pImpl->bank, uint32_t(id), int(designation));
+    p->ch[id].designation = designation;
+    mi_ilufs_bank_set_designation(p->bank, uint32_t(id), int(designation));
     return STATUS_OK;
 }
 
 bs::channel_t ILUFSMeter::designation(size_t id) const
 {
-    return (pImpl && id < pImpl->channels) ? pImpl->ch[id].designation : bs::CHANNEL_NONE;
+    impl_t *p = impl();
+    return (p && id < nChannels) ? p->ch[id].designation : bs::CHANNEL_NONE;
 }
 
 status_t ILUFSMeter::set_active(size_t id, bool active)
 {
-    if (pImpl == nullptr || id >= pImpl->channels)
+    impl_t *p = impl();
+    if (p == nullptr || id >= nChannels)
         return STATUS_OVERFLOW;
-    pImpl->ch[id].active = active;
+    p->ch[id].active = active;
     return STATUS_OK;
 }
 
-bool ILUFSMeter::active(size_t id) const { return (pImpl && id < pImpl->channels) ? pImpl->ch[id].active : false; }
-
-void ILUFSMeter::set_weighting(bs::weighting_t weighting)
+bool ILUFSMeter::active(size_t id) const
 {
-    if (pImpl == nullptr)
-        return;
-    pImpl->weighting = weighting;
-    mi_ilufs_bank_set_weighting(pImpl->bank, int(weighting));
+    impl_t *p = impl();
+    return (p && id < nChannels) ? p->ch[id].active : false;
 }
 
-bs::weighting_t ILUFSMeter::weighting() const { return pImpl ? pImpl->weighting : bs::WEIGHT_K; }
-
-bool ILUFSMeter::needs_update() const
+void ILUFSMeter::set_weighting(bs::weighting_t weighting)       // ILUFSMeter.cpp:255-262
 {
-    int pending = 0;
-    return pImpl != nullptr && mi_ilufs_bank_needs_update(pImpl->bank, &pending) == MI_OK && pending != 0;
+    impl_t *p = impl();
+    if (p == nullptr || enWeight == weighting)
+        return;
+    enWeight = weighting;
+    nFlags |= F_UPD_FILTERS;
+    mi_ilufs_bank_set_weighting(p->bank, int(weighting));
 }
 
 void ILUFSMeter::update_settings()
 {
-    if (pImpl != nullptr)
-        mi_ilufs_bank_update_settings(pImpl->bank, nullptr);
-}
-
-void ILUFSMeter::set_integration_period(float period)
-{
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr || nFlags == 0)
         return;
-    const float lo = pImpl->block_period * 0.001f;
-    pImpl->int_time = (period < lo) ? lo : (period > pImpl->max_int_time) ? pImpl->max_int_time : period;      // lsp_limit, :266
-    mi_ilufs_bank_set_integration_period(pImpl->bank, period, nullptr);
+    mi_ilufs_bank_update_settings(p->bank, nullptr);
+    nFlags = 0;
 }
 
-float ILUFSMeter::integration_period() const { return pImpl ? pImpl->int_time : 0.0f; }
+void ILUFSMeter::set_integration_period(float period)           // :264-289
+{
+    impl_t *p = impl();
+    if (p == nullptr)
+        return;
+    const float lo = fBlockPeriod * 0.001f;
+    period = (period < lo) ? lo : (period > fMaxIntTime) ? fMaxIntTime : period;       // lsp_limit, :266
+    if (fIntTime == period)
+        return;
+    fIntTime = period;
+    nFlags |= F_UPD_TIME;
+    mi_ilufs_bank_set_integration_period(p->bank, period, nullptr);
+}
 
 status_t ILUFSMeter::set_sample_rate(size_t sample_rate)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return STATUS_BAD_STATE;
-    if (mi_ilufs_bank_set_sample_rate(pImpl->bank, uint32_t(sample_rate), nullptr) != MI_OK)
+    if (nSampleRate == sample_rate)
+        return STATUS_OK;
+    if (mi_ilufs_bank_set_sample_rate(p->bank, uint32_t(sample_rate), nullptr) != MI_OK)
         return STATUS_NO_MEM;
-    if (pImpl->sample_rate != sample_rate)
-        pImpl->loudness = 0.0f;
-    pImpl->sample_rate = sample_rate;
+    fLoudness = 0.0f;
+    nSampleRate = uint32_t(sample_rate);
+    nFlags |= F_UPD_ALL;
     return STATUS_OK;
 }
 
-size_t ILUFSMeter::sample_rate() const { return pImpl ? pImpl->sample_rate : 0; }
-
 void ILUFSMeter::process(float *out, size_t count, float gain)
 {
-    impl_t *p = pImpl;
-    if (p == nullptr || count == 0 || !p->reserve(count))
+    impl_t *p = impl();
+    const size_t K = nChannels;
+    if (p == nullptr || count == 0 || !p->reserve(K, count))
         return;
-    const size_t K = p->channels;
     p->host.assign(K * count, 0.0f);
     for (size_t c = 0; c < K; ++c)
     {
@@ -2700,23 +2775,28 @@ void ILUFSMeter::process(float *out, size_t count, float gain)
         ok = mi_dspu_copy_d2h(out, p->d_out, count * sizeof(float), nullptr) == MI_OK;
     ok = ok && mi_dspu_stream_synchronize(nullptr) == MI_OK;
     if (ok)
-        mi_ilufs_bank_loudness(p->bank, &p->loudness, nullptr);
+        mi_ilufs_bank_loudness(p->bank, &fLoudness, nullptr);
+    nFlags = 0;                                             // process() starts with update_settings() (:357-358)
 }
-
-float ILUFSMeter::loudness() const { return pImpl ? pImpl->loudness : 0.0f; }
 
 void ILUFSMeter::clear()
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    pImpl->loudness = 0.0f;
-    mi_ilufs_bank_clear(pImpl->bank, nullptr);
+    fLoudness = 0.0f;
+    mi_ilufs_bank_clear(p->bank, nullptr);
 }
 
 void ILUFSMeter::dump(IStateDumper *v) const
 {
-    v->write("nChannels", pImpl ? pImpl->channels : size_t(0));
-    v->write("fIntTime", integration_period());
+    v->write("nChannels", size_t(nChannels));
+    v->write("fIntTime", fIntTime);
+    v->write("fMaxIntTime", fMaxIntTime);
+    v->write("fBlockPeriod", fBlockPeriod);
+    v->write("fLoudness", fLoudness);
+    v->write("nSampleRate", size_t(nSampleRate));
+    v->write("nFlags", size_t(nFlags));
 }
 
 // ---- Delay -----------------------------------------------------------------------------------------------------

@@ -815,6 +815,7 @@ static void raw_memory_objects()
 
     // DynamicFilters: a bell whose gain follows a per-sample vector; gain 1 is transparent, a constant gain is the static bell
     static_assert(sizeof(dspu::DynamicFilters) == 64, "DynamicFilters object size of the reference header");
+    static_assert(sizeof(dspu::LoudnessMeter) == 112 && sizeof(dspu::ILUFSMeter) == 104, "meter object sizes of the reference headers");
     static_assert(sizeof(dspu::MultiSpectralProcessor) == 80, "MultiSpectralProcessor object size of the reference header");
     static_assert(sizeof(dspu::Analyzer) == 128, "Analyzer object size of the reference header (14 x u32, 5 x f32, bool, 6 pointers)");
     dspu::DynamicFilters *df = raw_object<dspu::DynamicFilters>();
