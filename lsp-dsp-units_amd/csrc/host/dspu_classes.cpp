@@ -1716,44 +1716,63 @@ namespace
 struct SpectralSplitter::impl_t
 {
     splitter_stream st;
-    size_t  max_rank = 0, bindings = 0;
-    ssize_t user_chunk_rank = 0;
-    float   phase = 0.0f;
-    bool    update = true;
-    struct handler_t
-    {
-        void *object = nullptr, *subject = nullptr;
-        spectral_splitter_func_t func = nullptr;
-        spectral_splitter_sink_t sink = nullptr;
-        std::vector<float> *spec_in = nullptr, *spec_out = nullptr;
-    };
-    std::vector<handler_t> h;
+    std::vector<handler_t> h;               // storage behind vHandlers
     std::vector<float> spec_in, spec_out;
+    struct hook_t { SpectralSplitter *owner; size_t id; };
+    std::vector<hook_t> hooks;
+    std::vector<uint8_t> gains;             // handler shaped by device-side gains (bind_gains)
 
     // mi_splitter_func_t: the device spectrum comes down, the user's function runs on host memory, its result goes up
     static void trampoline(void *object, void *, float *out, const float *in, size_t rank, size_t channels, void *stream)
     {
-        handler_t *h = static_cast<handler_t *>(object);
+        hook_t *k = static_cast<hook_t *>(object);
+        impl_t *p = k->owner->impl();
+        const handler_t &h = p->h[k->id];
         const size_t bytes = channels * (size_t(2) << rank) * sizeof(float);
-        if (mi_dspu_copy_d2h(h->spec_in->data(), in, bytes, stream) != MI_OK || mi_dspu_stream_synchronize(stream) != MI_OK)
+        if (h.pFunc == nullptr || mi_dspu_copy_d2h(p->spec_in.data(), in, bytes, stream) != MI_OK || mi_dspu_stream_synchronize(stream) != MI_OK)
             return;
-        h->func(h->object, h->subject, h->spec_out->data(), h->spec_in->data(), rank);
-        if (mi_dspu_copy_h2d(out, h->spec_out->data(), bytes, stream) == MI_OK)
+        h.pFunc(h.pObject, h.pSubject, p->spec_out.data(), p->spec_in.data(), rank);
+        if (mi_dspu_copy_h2d(out, p->spec_out.data(), bytes, stream) == MI_OK)
             mi_dspu_stream_synchronize(stream);
     }
 };
 
-SpectralSplitter::SpectralSplitter() : pImpl(nullptr) { construct(); }
+SpectralSplitter::SpectralSplitter() { construct(); }
 SpectralSplitter::~SpectralSplitter() { destroy(); }
-void SpectralSplitter::construct() { pImpl = nullptr; }
+
+void SpectralSplitter::construct()                          // SpectralSplitter.cpp:33-55
+{
+    nRank = nMaxRank = 0;
+    nUserChunkRank = 0;
+    nChunkRank = 0;
+    fPhase = 0.0f;
+    vWnd = vInBuf = vFftBuf = vFftTmp = nullptr;
+    nFrameSize = nInOffset = 0;
+    bUpdate = true;
+    vHandlers = nullptr;
+    nHandlers = nBindings = 0;
+    pData = nullptr;
+}
 
 void SpectralSplitter::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    if (impl_t *p = impl())
+    {
+        p->st.release();
+        delete p;
+    }
+    pData = nullptr;
+    vHandlers = nullptr;
+    nHandlers = nBindings = 0;
+}
+
+void SpectralSplitter::sync_ranks()
+{
+    uint32_t r = 0, c = 0;
+    if (impl_t *p = impl())
+        mi_splitter_bank_get(p->st.bank, &r, &c, nullptr, nullptr);
+    nRank = r;
+    nChunkRank = c;
 }
 
 status_t SpectralSplitter::init(size_t max_rank, size_t handlers)
@@ -1770,410 +1789,448 @@ status_t SpectralSplitter::init(size_t max_rank, size_t handlers)
         delete p;
         return STATUS_NO_MEM;
     }
-    p->max_rank = max_rank;
-    p->h.resize(handlers);
+    p->h.assign(handlers, handler_t{ nullptr, nullptr, nullptr, nullptr, nullptr });
+    p->hooks.resize(handlers);
+    p->gains.assign(handlers, 0);
+    for (size_t i = 0; i < handlers; ++i)
+        p->hooks[i] = impl_t::hook_t{ this, i };
     p->spec_in.resize(size_t(2) << max_rank);
     p->spec_out.resize(size_t(2) << max_rank);
-    for (impl_t::handler_t &h : p->h)
-    {
-        h.spec_in = &p->spec_in;
-        h.spec_out = &p->spec_out;
-    }
-    pImpl = p;
+    pData = reinterpret_cast<uint8_t *>(p);
+    vHandlers = p->h.data();
+    nHandlers = handlers;
+    nBindings = 0;
+    nMaxRank = max_rank;
+    nUserChunkRank = 0;
+    fPhase = 0.0f;
+    nFrameSize = nInOffset = 0;
+    bUpdate = true;
+    sync_ranks();
     return STATUS_OK;
 }
 
 status_t SpectralSplitter::bind(size_t id, void *object, void *subject, spectral_splitter_func_t func, spectral_splitter_sink_t sink)
 {
-    if (pImpl == nullptr || id >= pImpl->h.size())
+    impl_t *p = impl();
+    if (p == nullptr || id >= nHandlers)
         return STATUS_OVERFLOW;
     if (func == nullptr && sink == nullptr)
         return STATUS_INVALID_VALUE;
-    impl_t::handler_t &h = pImpl->h[id];
-    if (h.func == nullptr && h.sink == nullptr)
-        ++pImpl->bindings;
-    h.object = object;
-    h.subject = subject;
-    h.func = func;
-    h.sink = sink;
+    handler_t &h = vHandlers[id];
+    if (h.pFunc == nullptr && h.pSink == nullptr)
+        ++nBindings;
+    h.pObject = object;
+    h.pSubject = subject;
+    h.pFunc = func;
+    h.pSink = sink;
+    p->gains[id] = 0;
     const int r = (func != nullptr) ?
-        mi_splitter_bank_bind_callback(pImpl->st.bank, uint32_t(id), impl_t::trampoline, &h, nullptr, nullptr) :
-        mi_splitter_bank_bind_copy(pImpl->st.bank, uint32_t(id), nullptr);
+        mi_splitter_bank_bind_callback(p->st.bank, uint32_t(id), impl_t::trampoline, &p->hooks[id], nullptr, nullptr) :
+        mi_splitter_bank_bind_copy(p->st.bank, uint32_t(id), nullptr);
     return (r == MI_OK) ? STATUS_OK : STATUS_NO_MEM;
 }
 
 status_t SpectralSplitter::unbind(size_t id)
 {
-    if (pImpl == nullptr || id >= pImpl->h.size())
+    impl_t *p = impl();
+    if (p == nullptr || id >= nHandlers)
         return STATUS_OVERFLOW;
-    impl_t::handler_t &h = pImpl->h[id];
-    if (h.func == nullptr && h.sink == nullptr)
+    handler_t &h = vHandlers[id];
+    if (h.pFunc == nullptr && h.pSink == nullptr)
         return STATUS_NOT_BOUND;
-    h = impl_t::handler_t();
-    h.spec_in = &pImpl->spec_in;
-    h.spec_out = &pImpl->spec_out;
-    --pImpl->bindings;
-    mi_splitter_bank_unbind(pImpl->st.bank, uint32_t(id));
+    h = handler_t{ nullptr, nullptr, nullptr, nullptr, nullptr };
+    --nBindings;
+    p->gains[id] = 0;
+    mi_splitter_bank_unbind(p->st.bank, uint32_t(id));
     return STATUS_OK;
+}
+
+status_t SpectralSplitter::bind_gains(size_t id, void *object, void *subject, const float *gains, spectral_splitter_sink_t sink)
+{
+    impl_t *p = impl();
+    if (p == nullptr || id >= nHandlers)
+        return STATUS_OVERFLOW;
+    if (gains == nullptr || sink == nullptr)
+        return STATUS_INVALID_VALUE;
+    handler_t &h = vHandlers[id];
+    if (h.pFunc == nullptr && h.pSink == nullptr)
+        ++nBindings;
+    h.pObject = object;
+    h.pSubject = subject;
+    h.pFunc = nullptr;
+    h.pSink = sink;
+    p->gains[id] = 1;
+    return (mi_splitter_bank_bind_mask(p->st.bank, uint32_t(id), gains, 0, nullptr) == MI_OK) ? STATUS_OK : STATUS_NO_MEM;
+}
+
+void SpectralSplitter::set_gains(size_t id, const float *gains)
+{
+    impl_t *p = impl();
+    if (p != nullptr && id < nHandlers && p->gains[id])
+        mi_splitter_bank_bind_mask(p->st.bank, uint32_t(id), gains, 0, nullptr);
 }
 
 void SpectralSplitter::unbind_all()
 {
-    if (pImpl == nullptr)
-        return;
-    for (size_t i = 0; i < pImpl->h.size(); ++i)
+    for (size_t i = 0; impl() != nullptr && i < nHandlers; ++i)
         unbind(i);
 }
 
 bool SpectralSplitter::bound(size_t id) const
 {
-    return pImpl != nullptr && id < pImpl->h.size() && (pImpl->h[id].func != nullptr || pImpl->h[id].sink != nullptr);
+    return impl() != nullptr && id < nHandlers && (vHandlers[id].pFunc != nullptr || vHandlers[id].pSink != nullptr);
 }
-
-size_t SpectralSplitter::handlers() const { return pImpl ? pImpl->h.size() : 0; }
-size_t SpectralSplitter::bindings() const { return pImpl ? pImpl->bindings : 0; }
-bool SpectralSplitter::needs_update() const { return pImpl ? pImpl->update : false; }
 
 void SpectralSplitter::update_settings()
 {
-    if (pImpl == nullptr || !pImpl->update)
+    impl_t *p = impl();
+    if (p == nullptr || !bUpdate)
         return;
-    mi_splitter_bank_process(pImpl->st.bank, nullptr, nullptr, 0, 0, 0, nullptr);      // applies the pending settings
-    pImpl->update = false;
+    mi_splitter_bank_process(p->st.bank, nullptr, nullptr, 0, 0, 0, nullptr);          // applies the pending settings
+    sync_ranks();
+    bUpdate = false;
 }
-
-size_t SpectralSplitter::rank() const
-{
-    uint32_t v = 0;
-    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, &v, nullptr, nullptr, nullptr);
-    return v;
-}
-
-size_t SpectralSplitter::max_rank() const { return pImpl ? pImpl->max_rank : 0; }
-
-ssize_t SpectralSplitter::chunk_rank() const
-{
-    uint32_t v = 0;
-    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, nullptr, &v, nullptr, nullptr);
-    return ssize_t(v);
-}
-
-float SpectralSplitter::phase() const { return pImpl ? pImpl->phase : 0.0f; }
 
 void SpectralSplitter::set_phase(float phase)
 {
-    if (pImpl == nullptr)
+    impl_t *p = impl();
+    if (p == nullptr)
         return;
-    pImpl->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
-    pImpl->update = true;
-    mi_splitter_bank_set_phase(pImpl->st.bank, phase);
+    fPhase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
+    bUpdate = true;
+    mi_splitter_bank_set_phase(p->st.bank, phase);
 }
 
 void SpectralSplitter::set_rank(size_t rank)
 {
-    if (pImpl == nullptr || rank == this->rank() || rank > pImpl->max_rank)
+    impl_t *p = impl();
+    if (p == nullptr || rank == nRank || rank > nMaxRank)
         return;
-    if (mi_splitter_bank_set_rank(pImpl->st.bank, uint32_t(rank)) == MI_OK)
-        pImpl->update = true;
+    if (mi_splitter_bank_set_rank(p->st.bank, uint32_t(rank)) == MI_OK)
+    {
+        nRank = rank;
+        bUpdate = true;
+    }
 }
 
 void SpectralSplitter::set_chunk_rank(ssize_t rank)
 {
-    if (pImpl == nullptr || rank == pImpl->user_chunk_rank)
+    impl_t *p = impl();
+    if (p == nullptr || rank == nUserChunkRank)
         return;
-    pImpl->user_chunk_rank = rank;
-    pImpl->update = true;
-    mi_splitter_bank_set_chunk_rank(pImpl->st.bank, int32_t(rank));
+    nUserChunkRank = rank;
+    bUpdate = true;
+    mi_splitter_bank_set_chunk_rank(p->st.bank, int32_t(rank));
 }
 
 size_t SpectralSplitter::latency() const
 {
     uint32_t v = 0;
-    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, nullptr, nullptr, &v, nullptr);
+    if (impl_t *p = impl())
+        mi_splitter_bank_get(p->st.bank, nullptr, nullptr, &v, nullptr);
     return v;
 }
 
 void SpectralSplitter::process(const float *src, size_t count)
 {
-    impl_t *p = pImpl;
+    impl_t *p = impl();
     if (p == nullptr)
         return;
     update_settings();
-    if (p->bindings == 0)
+    if (nBindings == 0)
         return;
+    SpectralSplitter *self = this;
     p->st.process(src, count,
-        [p](size_t i) { return p->h[i].sink != nullptr; },
-        [p](size_t i, const float *data, size_t first, size_t n) { p->h[i].sink(p->h[i].object, p->h[i].subject, data, first, n); });
+        [self](size_t i) { return self->vHandlers[i].pSink != nullptr; },
+        [self](size_t i, const float *data, size_t first, size_t n)
+        { const handler_t &h = self->vHandlers[i]; h.pSink(h.pObject, h.pSubject, data, first, n); });
 }
 
 void SpectralSplitter::clear()
 {
-    if (pImpl)
-        mi_splitter_bank_clear(pImpl->st.bank, nullptr);
+    if (impl_t *p = impl())
+        mi_splitter_bank_clear(p->st.bank, nullptr);
 }
 
 void SpectralSplitter::dump(IStateDumper *v) const
 {
-    v->write("nRank", rank());
-    v->write("nMaxRank", max_rank());
-    v->write("nChunkRank", size_t(chunk_rank()));
-    v->write("fPhase", phase());
+    v->write("nRank", nRank);
+    v->write("nMaxRank", nMaxRank);
+    v->write("nChunkRank", nChunkRank);
+    v->write("fPhase", fPhase);
+    v->write("nHandlers", nHandlers);
+    v->write("nBindings", nBindings);
+    v->write("bUpdate", bUpdate);
 }
 
-struct FFTCrossover::impl_t
-{
-    splitter_stream st;
-    size_t  max_rank = 0, sample_rate = 0;
-    float   phase = 0.0f;
-    struct band_t
-    {
-        float   hpf_freq = 100.0f, lpf_freq = 1000.0f, hpf_slope = -24.0f, lpf_slope = -24.0f, gain = 1.0f, flatten = 1.0f;
-        bool    lpf = false, hpf = false, enabled = false, update = true, bound = false;
-        crossover_func_t func = nullptr;
-        void   *object = nullptr, *subject = nullptr;
-    };
-    std::vector<band_t> b;
-    std::vector<float>  mask;
-
-    size_t rank() const
-    {
-        uint32_t v = 0;
-        mi_splitter_bank_get(st.bank, &v, nullptr, nullptr, nullptr);
-        return v;
-    }
-
-    // FFTCrossover::update_band (FFTCrossover.cpp:459-486); the gains go to the band's handler when it is bound
-    void update_band(size_t i)
-    {
-        band_t &x = b[i];
-        if (!x.update)
-            return;
-        const size_t rk = rank(), bins = size_t(1) << rk;
-        mask.resize(bins);
-        if (x.hpf || x.lpf)
-        {
-            if (x.hpf)
-            {
-                mi_crossover_hipass_fft_set(mask.data(), x.hpf_freq, x.hpf_slope, float(sample_rate), rk);
-                if (x.lpf)
-                    mi_crossover_lopass_fft_apply(mask.data(), x.lpf_freq, x.lpf_slope, float(sample_rate), rk);
-            }
-            else
-                mi_crossover_lopass_fft_set(mask.data(), x.lpf_freq, x.lpf_slope, float(sample_rate), rk);
-            for (float &g : mask)                            // limit1(0, fFlatten), mul_k2(fGain)
-                g = ((g < 0.0f) ? 0.0f : (g > x.flatten) ? x.flatten : g) * x.gain;
-        }
-        else
-            std::fill(mask.begin(), mask.end(), x.flatten * x.gain);
-        if (x.bound)
-            mi_splitter_bank_bind_mask(st.bank, uint32_t(i), mask.data(), 0, nullptr);
-        x.update = false;
-    }
-
-    void sync_binding(size_t i)                              // :355-364
-    {
-        band_t &x = b[i];
-        if (x.enabled && x.func != nullptr)
-        {
-            if (!x.bound)
-            {
-                x.bound = true;
-                x.update = true;                             // the handler needs its gains: same values the reference's
-                update_band(i);                              // spectral_func would find or rebuild at the next transform
-            }
-        }
-        else if (x.bound)
-        {
-            mi_splitter_bank_unbind(st.bank, uint32_t(i));
-            x.bound = false;
-        }
-    }
-};
-
-FFTCrossover::FFTCrossover() : pImpl(nullptr) { construct(); }
+// The reference object: an embedded SpectralSplitter whose handlers are the bands, the band records and their gains in
+// one block behind pData (FFTCrossover.cpp:40-121).  Here the bands' gains act on the device (SpectralSplitter::bind_gains).
+FFTCrossover::FFTCrossover() { construct(); }
 FFTCrossover::~FFTCrossover() { destroy(); }
-void FFTCrossover::construct() { pImpl = nullptr; }
+
+void FFTCrossover::construct()
+{
+    sSplitter.construct();
+    vBands = nullptr;
+    nSampleRate = 0;
+    pData = nullptr;
+}
 
 void FFTCrossover::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    pImpl->st.release();
-    delete pImpl;
-    pImpl = nullptr;
+    sSplitter.destroy();
+    free(pData);
+    pData = nullptr;
+    vBands = nullptr;
+    nSampleRate = 0;
 }
 
 status_t FFTCrossover::init(size_t max_rank, size_t bands)
 {
-    if (max_rank < 5)
-        return STATUS_INVALID_VALUE;
-    destroy();
-    impl_t *p = new (std::nothrow) impl_t();
-    if (p == nullptr)
-        return STATUS_NO_MEM;
-    if (bands == 0 || !p->st.init(max_rank, bands))
+    const status_t res = sSplitter.init(max_rank, bands);
+    if (res != STATUS_OK)
+        return res;
+    free(pData);
+    pData = nullptr;
+    vBands = nullptr;
+
+    const size_t bins = size_t(1) << max_rank;
+    const size_t szof_bands = (sizeof(band_t) * bands + 63) & ~size_t(63);
+    uint8_t *ptr = static_cast<uint8_t *>(calloc(1, szof_bands + bands * bins * sizeof(float)));
+    if (ptr == nullptr)
     {
-        p->st.release();
-        delete p;
+        sSplitter.destroy();
         return STATUS_NO_MEM;
     }
-    p->max_rank = max_rank;
-    p->b.resize(bands);
-    pImpl = p;
+    pData = ptr;
+    vBands = reinterpret_cast<band_t *>(ptr);
+    ptr += szof_bands;
+    for (size_t i = 0; i < bands; ++i, ptr += bins * sizeof(float))
+    {
+        band_t *b = &vBands[i];
+        b->fHpfFreq = 100.0f;
+        b->fLpfFreq = 1000.0f;
+        b->fHpfSlope = -24.0f;
+        b->fLpfSlope = -24.0f;
+        b->fGain = 1.0f;
+        b->fFlatten = 1.0f;
+        b->bLpf = b->bHpf = b->bEnabled = false;
+        b->bUpdate = true;
+        b->pObject = b->pSubject = nullptr;
+        b->pFunc = nullptr;
+        b->vFFT = reinterpret_cast<float *>(ptr);
+    }
     return STATUS_OK;
 }
 
-size_t FFTCrossover::bands() const { return pImpl ? pImpl->b.size() : 0; }
+void FFTCrossover::spectral_sink(void *object, void *subject, const float *samples, size_t first, size_t count)     // :142-153
+{
+    band_t *b = static_cast<band_t *>(subject);
+    if (b->pFunc == nullptr)
+        return;
+    FFTCrossover *self = static_cast<FFTCrossover *>(object);
+    b->pFunc(b->pObject, b->pSubject, b - self->vBands, samples, first, count);
+}
+
+// FFTCrossover::update_band (FFTCrossover.cpp:459-486); the gains go to the band's handler when it is bound
+void FFTCrossover::update_band(band_t *b)
+{
+    if (!b->bUpdate)
+        return;
+    const size_t rk = sSplitter.rank(), bins = size_t(1) << rk;
+    if (b->bHpf || b->bLpf)
+    {
+        if (b->bHpf)
+        {
+            mi_crossover_hipass_fft_set(b->vFFT, b->fHpfFreq, b->fHpfSlope, float(nSampleRate), rk);
+            if (b->bLpf)
+                mi_crossover_lopass_fft_apply(b->vFFT, b->fLpfFreq, b->fLpfSlope, float(nSampleRate), rk);
+        }
+        else
+            mi_crossover_lopass_fft_set(b->vFFT, b->fLpfFreq, b->fLpfSlope, float(nSampleRate), rk);
+        for (size_t i = 0; i < bins; ++i)                    // limit1(0, fFlatten), mul_k2(fGain)
+        {
+            const float g = b->vFFT[i];
+            b->vFFT[i] = ((g < 0.0f) ? 0.0f : (g > b->fFlatten) ? b->fFlatten : g) * b->fGain;
+        }
+    }
+    else
+        std::fill(b->vFFT, b->vFFT + bins, b->fFlatten * b->fGain);
+    sSplitter.set_gains(b - vBands, b->vFFT);                // no-op while the band is not bound
+    b->bUpdate = false;
+}
+
+void FFTCrossover::sync_binding(size_t band, band_t *b)     // :355-364
+{
+    const bool bound = sSplitter.bound(band);
+    if (b->bEnabled && b->pFunc != nullptr)
+    {
+        if (!bound)
+        {
+            b->bUpdate = true;                               // the handler needs its gains: the values the reference's
+            update_band(b);                                  // spectral_func would find or rebuild at the next transform
+            sSplitter.bind_gains(band, this, b, b->vFFT, spectral_sink);
+        }
+    }
+    else if (bound)
+        sSplitter.unbind(band);
+}
+
+void FFTCrossover::mark_bands_for_update()
+{
+    for (size_t i = 0, n = sSplitter.handlers(); i < n; ++i)
+        vBands[i].bUpdate = true;
+}
 
 #define MI_BAND_OR(ret)                                         \
-    if (pImpl == nullptr || band >= pImpl->b.size())            \
+    if (band >= sSplitter.handlers())                           \
         return ret;                                             \
-    impl_t::band_t &x = pImpl->b[band];
+    band_t &x = vBands[band];
 
 // the update-flag rules are the reference's, including the asymmetric ones (FFTCrossover.cpp:155-345)
 void FFTCrossover::set_slope(size_t band, float lpf, float hpf)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = (x.lpf && x.lpf_slope != lpf) || (x.hpf && x.hpf_slope != hpf);
-    x.lpf_slope = lpf;
-    x.hpf_slope = hpf;
+    if (!x.bUpdate)
+        x.bUpdate = (x.bLpf && x.fLpfSlope != lpf) || (x.bHpf && x.fHpfSlope != hpf);
+    x.fLpfSlope = lpf;
+    x.fHpfSlope = hpf;
 }
 
 void FFTCrossover::set_lpf_slope(size_t band, float slope)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = x.lpf && x.lpf_slope != slope;
-    x.lpf_slope = slope;
+    if (!x.bUpdate)
+        x.bUpdate = x.bLpf && x.fLpfSlope != slope;
+    x.fLpfSlope = slope;
 }
 
 void FFTCrossover::set_hpf_slope(size_t band, float slope)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = x.hpf && x.hpf_slope != slope;
-    x.hpf_slope = slope;
+    if (!x.bUpdate)
+        x.bUpdate = x.bHpf && x.fHpfSlope != slope;
+    x.fHpfSlope = slope;
 }
 
 void FFTCrossover::set_frequency(size_t band, float lpf, float hpf)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = (x.lpf && x.lpf_freq != lpf) || (x.hpf && x.hpf_freq != hpf);
-    x.lpf_freq = lpf;
-    x.hpf_freq = hpf;
+    if (!x.bUpdate)
+        x.bUpdate = (x.bLpf && x.fLpfFreq != lpf) || (x.bHpf && x.fHpfFreq != hpf);
+    x.fLpfFreq = lpf;
+    x.fHpfFreq = hpf;
 }
 
 void FFTCrossover::set_lpf_frequency(size_t band, float freq)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = x.lpf && x.lpf_freq != freq;
-    x.lpf_freq = freq;
+    if (!x.bUpdate)
+        x.bUpdate = x.bLpf && x.fLpfFreq != freq;
+    x.fLpfFreq = freq;
 }
 
 void FFTCrossover::set_hpf_frequency(size_t band, float freq)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = x.hpf && x.hpf_freq != freq;
-    x.hpf_freq = freq;
+    if (!x.bUpdate)
+        x.bUpdate = x.bHpf && x.fHpfFreq != freq;
+    x.fHpfFreq = freq;
 }
 
 void FFTCrossover::enable_filters(size_t band, bool lpf, bool hpf)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = (x.lpf != lpf) || (x.hpf != hpf);
-    x.lpf = lpf;
-    x.hpf = hpf;
+    if (!x.bUpdate)
+        x.bUpdate = (x.bLpf != lpf) || (x.bHpf != hpf);
+    x.bLpf = lpf;
+    x.bHpf = hpf;
 }
 
 void FFTCrossover::enable_lpf(size_t band, bool enable)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = x.lpf != enable;
-    x.lpf = enable;
+    if (!x.bUpdate)
+        x.bUpdate = x.bLpf != enable;
+    x.bLpf = enable;
 }
 
 void FFTCrossover::enable_hpf(size_t band, bool enable)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = x.hpf != enable;
-    x.hpf = enable;
+    if (!x.bUpdate)
+        x.bUpdate = x.bHpf != enable;
+    x.bHpf = enable;
 }
 
 void FFTCrossover::set_lpf(size_t band, float freq, float slope, bool enabled)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = enabled && (x.lpf_freq != freq || x.lpf_slope != slope || x.lpf != enabled);
-    x.lpf_freq = freq;
-    x.lpf_slope = slope;
-    x.lpf = enabled;
+    if (!x.bUpdate)
+        x.bUpdate = enabled && (x.fLpfFreq != freq || x.fLpfSlope != slope || x.bLpf != enabled);
+    x.fLpfFreq = freq;
+    x.fLpfSlope = slope;
+    x.bLpf = enabled;
 }
 
 void FFTCrossover::set_hpf(size_t band, float freq, float slope, bool enabled)
 {
     MI_BAND_OR()
-    if (!x.update)
-        x.update = enabled && (x.hpf_freq != freq || x.hpf_slope != slope || x.hpf != enabled);
-    x.hpf_freq = freq;
-    x.hpf_slope = slope;
-    x.hpf = enabled;
+    if (!x.bUpdate)
+        x.bUpdate = enabled && (x.fHpfFreq != freq || x.fHpfSlope != slope || x.bHpf != enabled);
+    x.fHpfFreq = freq;
+    x.fHpfSlope = slope;
+    x.bHpf = enabled;
 }
 
 void FFTCrossover::set_gain(size_t band, float gain)
 {
     MI_BAND_OR()
-    if (x.gain == gain)
+    if (x.fGain == gain)
         return;
-    x.update = true;
-    x.gain = gain;
+    x.bUpdate = true;
+    x.fGain = gain;
 }
 
 void FFTCrossover::set_flatten(size_t band, float amount)
 {
     MI_BAND_OR()
-    if (x.flatten == amount)
+    if (x.fFlatten == amount)
         return;
-    x.update = true;
-    x.flatten = amount;
+    x.bUpdate = true;
+    x.fFlatten = amount;
 }
 
 #undef MI_BAND_OR
-#define MI_BAND_GET(field, fallback) ((pImpl != nullptr && band < pImpl->b.size()) ? pImpl->b[band].field : (fallback))
-float FFTCrossover::lpf_slope(size_t band) const     { return MI_BAND_GET(lpf_slope, -1.0f); }
-float FFTCrossover::hpf_slope(size_t band) const     { return MI_BAND_GET(hpf_slope, -1.0f); }
-float FFTCrossover::lpf_frequency(size_t band) const { return MI_BAND_GET(lpf_freq, -1.0f); }
-float FFTCrossover::hpf_frequency(size_t band) const { return MI_BAND_GET(hpf_freq, -1.0f); }
-bool  FFTCrossover::lpf_enabled(size_t band) const   { return MI_BAND_GET(lpf, false); }
-bool  FFTCrossover::hpf_enabled(size_t band) const   { return MI_BAND_GET(hpf, false); }
-float FFTCrossover::gain(size_t band) const          { return MI_BAND_GET(gain, -1.0f); }
-float FFTCrossover::flatten(size_t band) const       { return MI_BAND_GET(flatten, -1.0f); }
-bool  FFTCrossover::band_enabled(size_t band) const  { return MI_BAND_GET(enabled, false); }
+#define MI_BAND_GET(field, fallback) ((band < sSplitter.handlers()) ? vBands[band].field : (fallback))
+float FFTCrossover::lpf_slope(size_t band) const     { return MI_BAND_GET(fLpfSlope, -1.0f); }
+float FFTCrossover::hpf_slope(size_t band) const     { return MI_BAND_GET(fHpfSlope, -1.0f); }
+float FFTCrossover::lpf_frequency(size_t band) const { return MI_BAND_GET(fLpfFreq, -1.0f); }
+float FFTCrossover::hpf_frequency(size_t band) const { return MI_BAND_GET(fHpfFreq, -1.0f); }
+bool  FFTCrossover::lpf_enabled(size_t band) const   { return MI_BAND_GET(bLpf, false); }
+bool  FFTCrossover::hpf_enabled(size_t band) const   { return MI_BAND_GET(bHpf, false); }
+float FFTCrossover::gain(size_t band) const          { return MI_BAND_GET(fGain, -1.0f); }
+float FFTCrossover::flatten(size_t band) const       { return MI_BAND_GET(fFlatten, -1.0f); }
+bool  FFTCrossover::band_enabled(size_t band) const  { return MI_BAND_GET(bEnabled, false); }
 #undef MI_BAND_GET
 
 void FFTCrossover::enable_band(size_t band, bool enable)
 {
-    if (pImpl == nullptr || band >= pImpl->b.size() || pImpl->b[band].enabled == enable)
+    if (band >= sSplitter.handlers() || vBands[band].bEnabled == enable)
         return;
-    pImpl->b[band].enabled = enable;
-    pImpl->sync_binding(band);
+    vBands[band].bEnabled = enable;
+    sync_binding(band, &vBands[band]);
 }
 
 bool FFTCrossover::set_handler(size_t band, crossover_func_t func, void *object, void *subject)
 {
-    if (pImpl == nullptr || band >= pImpl->b.size())
+    if (band >= sSplitter.handlers())
         return false;
-    impl_t::band_t &x = pImpl->b[band];
-    x.func = func;
-    x.object = object;
-    x.subject = subject;
-    pImpl->sync_binding(band);
+    band_t *b = &vBands[band];
+    b->pFunc = func;
+    b->pObject = object;
+    b->pSubject = subject;
+    sync_binding(band, b);
     return true;
 }
 
@@ -2181,115 +2238,75 @@ bool FFTCrossover::unset_handler(size_t band) { return set_handler(band, nullptr
 
 void FFTCrossover::set_sample_rate(size_t sr)
 {
-    if (pImpl == nullptr || pImpl->sample_rate == sr)
+    if (nSampleRate == sr)
         return;
-    pImpl->sample_rate = sr;
-    for (impl_t::band_t &x : pImpl->b)
-        x.update = true;
+    nSampleRate = sr;
+    mark_bands_for_update();
 }
-
-size_t FFTCrossover::sample_rate() const { return pImpl ? pImpl->sample_rate : 0; }
 
 void FFTCrossover::set_rank(size_t rank)
 {
-    if (pImpl == nullptr)
+    rank = std::min(rank, sSplitter.max_rank());
+    if (sSplitter.rank() == rank)
         return;
-    rank = std::min(rank, pImpl->max_rank);
-    if (pImpl->rank() == rank || mi_splitter_bank_set_rank(pImpl->st.bank, uint32_t(rank)) != MI_OK)
-        return;
-    for (impl_t::band_t &x : pImpl->b)
-        x.update = true;
+    sSplitter.set_rank(rank);
+    mark_bands_for_update();
 }
 
-void FFTCrossover::set_phase(float phase)
-{
-    if (pImpl == nullptr)
-        return;
-    pImpl->phase = (phase < 0.0f) ? 0.0f : (phase > 1.0f) ? 1.0f : phase;
-    mi_splitter_bank_set_phase(pImpl->st.bank, phase);
-}
-
-float  FFTCrossover::phase() const { return pImpl ? pImpl->phase : 0.0f; }
-size_t FFTCrossover::rank() const  { return pImpl ? pImpl->rank() : 0; }
-
-size_t FFTCrossover::latency() const
-{
-    uint32_t v = 0;
-    if (pImpl) mi_splitter_bank_get(pImpl->st.bank, nullptr, nullptr, &v, nullptr);
-    return v;
-}
+void FFTCrossover::set_phase(float phase) { sSplitter.set_phase(phase); }
 
 bool FFTCrossover::needs_update() const
 {
-    if (pImpl == nullptr)
-        return false;
-    for (const impl_t::band_t &x : pImpl->b)
-        if (x.enabled && x.update)
+    for (size_t i = 0, n = sSplitter.handlers(); i < n; ++i)
+        if (vBands[i].bEnabled && vBands[i].bUpdate)
             return true;
     return false;
 }
 
 void FFTCrossover::update_settings()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_splitter_bank_process(pImpl->st.bank, nullptr, nullptr, 0, 0, 0, nullptr);
-    for (size_t i = 0; i < pImpl->b.size(); ++i)
-        if (pImpl->b[i].enabled)
-            pImpl->update_band(i);
+    sSplitter.update_settings();
+    for (size_t i = 0, n = sSplitter.handlers(); i < n; ++i)
+        if (vBands[i].bEnabled)
+            update_band(&vBands[i]);
 }
 
 void FFTCrossover::process(const float *in, size_t samples)
 {
-    impl_t *p = pImpl;
-    if (p == nullptr)
-        return;
     // the reference refreshes a band's gains inside its spectral function, i.e. before the next transform uses them
-    for (size_t i = 0; i < p->b.size(); ++i)
-        if (p->b[i].bound)
-            p->update_band(i);
-    p->st.process(in, samples,
-        [p](size_t i) { return p->b[i].bound; },
-        [p](size_t i, const float *data, size_t first, size_t n)
-        {
-            if (p->b[i].func != nullptr)
-                p->b[i].func(p->b[i].object, p->b[i].subject, i, data, first, n);
-        });
-}
-
-void FFTCrossover::clear()
-{
-    if (pImpl)
-        mi_splitter_bank_clear(pImpl->st.bank, nullptr);
+    for (size_t i = 0, n = sSplitter.handlers(); i < n; ++i)
+        if (sSplitter.bound(i))
+            update_band(&vBands[i]);
+    sSplitter.process(in, samples);
 }
 
 bool FFTCrossover::freq_chart(size_t band, float *m, const float *f, size_t count)      // :497-521
 {
-    if (pImpl == nullptr || band >= pImpl->b.size())
+    if (band >= sSplitter.handlers())
         return false;
-    const impl_t::band_t &x = pImpl->b[band];
-    if (x.hpf || x.lpf)
+    const band_t &x = vBands[band];
+    if (x.bHpf || x.bLpf)
     {
-        if (x.hpf)
+        if (x.bHpf)
         {
-            mi_crossover_hipass_set(m, f, x.hpf_freq, x.hpf_slope, count);
-            if (x.lpf)
-                mi_crossover_lopass_apply(m, f, x.lpf_freq, x.lpf_slope, count);
+            mi_crossover_hipass_set(m, f, x.fHpfFreq, x.fHpfSlope, count);
+            if (x.bLpf)
+                mi_crossover_lopass_apply(m, f, x.fLpfFreq, x.fLpfSlope, count);
         }
         else
-            mi_crossover_lopass_set(m, f, x.lpf_freq, x.lpf_slope, count);
+            mi_crossover_lopass_set(m, f, x.fLpfFreq, x.fLpfSlope, count);
         for (size_t i = 0; i < count; ++i)
-            m[i] = ((m[i] < 0.0f) ? 0.0f : (m[i] > x.flatten) ? x.flatten : m[i]) * x.gain;
+            m[i] = ((m[i] < 0.0f) ? 0.0f : (m[i] > x.fFlatten) ? x.fFlatten : m[i]) * x.fGain;
     }
     else
-        std::fill(m, m + count, x.flatten * x.gain);
+        std::fill(m, m + count, x.fFlatten * x.fGain);
     return true;
 }
 
 void FFTCrossover::dump(IStateDumper *v) const
 {
     v->write("nBands", bands());
-    v->write("nSampleRate", sample_rate());
+    v->write("nSampleRate", nSampleRate);
     v->write("nRank", rank());
 }
 

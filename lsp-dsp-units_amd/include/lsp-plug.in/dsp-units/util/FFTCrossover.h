@@ -6,6 +6,7 @@
 #include <lsp-plug.in/dsp-units/version.h>
 #include <lsp-plug.in/dsp-units/iface/IStateDumper.h>
 #include <lsp-plug.in/dsp-units/util/Crossover.h>
+#include <lsp-plug.in/dsp-units/util/SpectralSplitter.h>
 #include <lsp-plug.in/dsp/dsp.h>
 
 namespace lsp
@@ -14,9 +15,39 @@ namespace lsp
     {
         class LSP_DSP_UNITS_PUBLIC FFTCrossover
         {
-            private:
-                struct impl_t;
-                impl_t     *pImpl;
+            // Binary layout: data members, order and inline members of the reference class
+            // (include/lsp-plug.in/dsp-units/util/FFTCrossover.h:46-73,130,352-417 of lsp-dsp-units 1.0.36).
+            protected:
+                typedef struct band_t
+                {
+                    float               fHpfFreq;
+                    float               fLpfFreq;
+                    float               fHpfSlope;
+                    float               fLpfSlope;
+                    float               fGain;
+                    float               fFlatten;
+                    bool                bLpf;
+                    bool                bHpf;
+                    bool                bEnabled;
+                    bool                bUpdate;
+
+                    void               *pObject;
+                    void               *pSubject;
+                    crossover_func_t    pFunc;
+                    float              *vFFT;           // the band's gains, host copy (the device holds what the transforms use)
+                } split_t;
+
+            protected:
+                dspu::SpectralSplitter  sSplitter;
+                band_t                 *vBands;
+                size_t                  nSampleRate;
+                uint8_t                *pData;
+
+            protected:
+                static void spectral_sink(void *object, void *subject, const float *samples, size_t first, size_t count);
+                void            update_band(band_t *b);
+                void            sync_binding(size_t band, band_t *b);
+                void            mark_bands_for_update();
 
             public:
                 explicit FFTCrossover();
@@ -29,7 +60,7 @@ namespace lsp
                 status_t        init(size_t max_rank, size_t bands);
 
             public:
-                size_t          bands() const;
+                inline size_t   bands() const                   { return sSplitter.handlers(); }
                 void            set_slope(size_t band, float lpf, float hpf);
                 void            set_lpf_slope(size_t band, float slope);
                 void            set_hpf_slope(size_t band, float slope);
@@ -60,17 +91,17 @@ namespace lsp
                 bool            set_handler(size_t band, crossover_func_t func, void *object, void *subject);
                 bool            unset_handler(size_t band);
                 void            set_sample_rate(size_t sr);
-                size_t          sample_rate() const;
+                inline size_t   sample_rate() const             { return nSampleRate; }
                 void            set_rank(size_t rank);
                 void            set_phase(float phase);
-                float           phase() const;
-                size_t          rank() const;
-                size_t          latency() const;
+                inline float    phase() const                   { return sSplitter.phase(); }
+                inline size_t   rank() const                    { return sSplitter.rank(); }
+                inline size_t   latency() const                 { return sSplitter.latency(); }
                 bool            freq_chart(size_t band, float *m, const float *f, size_t count);
                 bool            needs_update() const;
                 void            update_settings();
                 void            process(const float *in, size_t samples);
-                void            clear();
+                inline void     clear()                         { sSplitter.clear(); }
                 void            dump(IStateDumper *v) const;
         };
     }

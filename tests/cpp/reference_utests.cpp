@@ -696,6 +696,76 @@ static void raw_memory_objects()
         free(mp);
     }
 
+    {   // SpectralSplitter on raw memory: the inline getters read the members the out-of-line calls keep current
+        dspu::SpectralSplitter *ss = raw_object<dspu::SpectralSplitter>();
+        ss->construct();
+        CHECK(ss->handlers() == 0 && ss->bindings() == 0 && ss->needs_update() && ss->rank() == 0 && ss->phase() == 0.0f, "constructed splitter");
+        CHECK(ss->init(4, 2) == STATUS_INVALID_VALUE && ss->init(10, 2) == STATUS_OK, "splitter init");
+        CHECK(ss->handlers() == 2 && ss->max_rank() == 10 && ss->rank() == 10 && ss->bindings() == 0, "init members");
+        ss->set_rank(8); ss->set_chunk_rank(6); ss->set_phase(0.25f);
+        CHECK(ss->rank() == 8 && ss->phase() == 0.25f && ss->needs_update(), "setters mark the settings dirty");
+        ss->update_settings();
+        CHECK(!ss->needs_update() && ss->chunk_rank() == 6 && ss->latency() == 64, "update_settings(): chunk rank %d latency %d",
+              int(ss->chunk_rank()), int(ss->latency()));
+        struct sink_t { std::vector<float> out; } sink;
+        sink.out.assign(1024, -1.0f);
+        auto fn = [](void *, void *, float *out, const float *in, size_t rank) { memcpy(out, in, sizeof(float) * (size_t(2) << rank)); };
+        auto snk = [](void *obj, void *, const float *samples, size_t first, size_t count)
+        { memcpy(static_cast<sink_t *>(obj)->out.data() + first, samples, count * sizeof(float)); };
+        CHECK(ss->bind(1, &sink, NULL, fn, snk) == STATUS_OK && ss->bindings() == 1 && ss->bound(1) && !ss->bound(0), "bind");
+        CHECK(ss->bind(2, &sink, NULL, fn, snk) == STATUS_OVERFLOW && ss->bind(0, NULL, NULL, NULL, NULL) == STATUS_INVALID_VALUE, "bind errors");
+        std::vector<float> x(1024);
+        for (size_t i = 0; i < x.size(); ++i)
+            x[i] = sinf(0.03f * float(i));
+        ss->process(x.data(), x.size());
+        float worst = 0.0f;
+        for (size_t i = 64; i < 1024; ++i)
+            worst = fmaxf(worst, fabsf(sink.out[i] - x[i - 64]));
+        CHECK(worst <= 1e-5f, "identity handler: the input delayed by the latency (%g)", worst);
+        CHECK(ss->unbind(1) == STATUS_OK && ss->unbind(1) == STATUS_NOT_BOUND && ss->bindings() == 0, "unbind");
+        ss->destroy();
+        CHECK(ss->handlers() == 0, "destroyed splitter");
+        free(ss);
+    }
+
+    {   // FFTCrossover on raw memory: the embedded splitter answers the inline members
+        dspu::FFTCrossover *fx = raw_object<dspu::FFTCrossover>();
+        fx->construct();
+        CHECK(fx->bands() == 0 && fx->sample_rate() == 0 && fx->rank() == 0 && !fx->needs_update(), "constructed FFT crossover");
+        CHECK(fx->init(10, 2) == STATUS_OK && fx->bands() == 2 && fx->rank() == 10, "FFT crossover init");
+        fx->set_sample_rate(48000); fx->set_rank(9); fx->set_phase(0.5f);
+        CHECK(fx->sample_rate() == 48000 && fx->rank() == 9 && fx->phase() == 0.5f, "inline getters follow the setters");
+        struct got_t { std::vector<float> y[2]; } got;
+        got.y[0].assign(4096, 0.0f); got.y[1].assign(4096, 0.0f);
+        auto take = [](void *obj, void *, size_t band, const float *data, size_t first, size_t count)
+        { memcpy(static_cast<got_t *>(obj)->y[band].data() + first, data, count * sizeof(float)); };
+        fx->set_lpf(0, 1000.0f, -48.0f, true);
+        fx->set_hpf(1, 1000.0f, -48.0f, true);
+        CHECK(fx->set_handler(0, take, &got, NULL) && fx->set_handler(1, take, &got, NULL) && !fx->set_handler(2, take, &got, NULL), "handlers");
+        fx->enable_band(0); fx->enable_band(1);
+        CHECK(fx->band_enabled(0) && fx->lpf_enabled(0) && !fx->hpf_enabled(0) && fx->lpf_frequency(0) == 1000.0f && fx->gain(5) == -1.0f, "band records");
+        fx->update_settings();
+        CHECK(!fx->needs_update() && fx->latency() == 512, "update_settings(): latency %d", int(fx->latency()));
+        std::vector<float> x(4096);
+        uint32_t seed = 12345;
+        for (float &v : x)
+        {
+            seed = seed * 1664525u + 1013904223u;
+            v = float(int32_t(seed >> 8) - (1 << 23)) / float(1 << 23);
+        }
+        fx->process(x.data(), x.size());
+        float worst = 0.0f;
+        for (size_t i = 512; i < 4096; ++i)
+            worst = fmaxf(worst, fabsf(got.y[0][i] + got.y[1][i] - x[i - 512]));
+        CHECK(worst <= 1e-4f, "complementary bands add up to the delayed input (%g)", worst);
+        fx->disable_band(1);
+        CHECK(!fx->band_enabled(1), "disable_band");
+        fx->clear();
+        fx->destroy();
+        CHECK(fx->bands() == 0, "destroyed FFT crossover");
+        free(fx);
+    }
+
     {   // Analyzer: inline setters only write members; the object follows them at its next process()
         dspu::Analyzer *an = raw_object<dspu::Analyzer>();
         an->construct();
@@ -816,6 +886,8 @@ static void raw_memory_objects()
     // DynamicFilters: a bell whose gain follows a per-sample vector; gain 1 is transparent, a constant gain is the static bell
     static_assert(sizeof(dspu::DynamicFilters) == 64, "DynamicFilters object size of the reference header");
     static_assert(sizeof(dspu::LoudnessMeter) == 112 && sizeof(dspu::ILUFSMeter) == 104, "meter object sizes of the reference headers");
+    static_assert(sizeof(dspu::SpectralSplitter) == 128, "SpectralSplitter object size of the reference header");
+    static_assert(sizeof(dspu::FFTCrossover) == 152, "FFTCrossover object size of the reference header (splitter by value + 3 words)");
     static_assert(sizeof(dspu::MultiSpectralProcessor) == 80, "MultiSpectralProcessor object size of the reference header");
     static_assert(sizeof(dspu::Analyzer) == 128, "Analyzer object size of the reference header (14 x u32, 5 x f32, bool, 6 pointers)");
     dspu::DynamicFilters *df = raw_object<dspu::DynamicFilters>();
