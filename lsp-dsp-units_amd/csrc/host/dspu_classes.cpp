@@ -1394,28 +1394,50 @@ void MultiSpectralProcessor::dump(IStateDumper *v) const
 struct Crossover::impl_t
 {
     mi_crossover_bank_t *bank = nullptr;
-    size_t  bands = 0, buf_size = 0, sample_rate = 48000;
+    size_t  bands = 0;
     struct handler_t { crossover_func_t func = nullptr; void *object = nullptr, *subject = nullptr; };
     std::vector<handler_t> handlers;
     std::vector<float *>   d_band;          // one device buffer of buf_size samples per band
     std::vector<float>     host;
     float  *d_in = nullptr;
+
+    ~impl_t()
+    {
+        mi_crossover_bank_destroy(bank);
+        for (float *p : d_band)
+            mi_dspu_free(p);
+        mi_dspu_free(d_in);
+    }
 };
 
-Crossover::Crossover() : pImpl(nullptr) { construct(); }
+Crossover::Crossover() { construct(); }
 Crossover::~Crossover() { destroy(); }
-void Crossover::construct() { pImpl = nullptr; }
+
+void Crossover::construct()                                 // Crossover.cpp:41-56
+{
+    nReconfigure = R_ALL;
+    nSplits = 0;
+    nBufSize = 0;
+    nSampleRate = 48000;                                    // LSP_DSP_UNITS_DEFAULT_SAMPLE_RATE
+    nPlanSize = 0;
+    vBands = nullptr;
+    vSplit = nullptr;
+    vPlan = nullptr;
+    vLpfBuf = vHpfBuf = nullptr;
+    pData = nullptr;
+}
 
 void Crossover::destroy()
 {
-    if (pImpl == nullptr)
-        return;
-    mi_crossover_bank_destroy(pImpl->bank);
-    for (float *p : pImpl->d_band)
-        mi_dspu_free(p);
-    mi_dspu_free(pImpl->d_in);
-    delete pImpl;
-    pImpl = nullptr;
+    delete impl();
+    construct();
+}
+
+void Crossover::sync_flags()
+{
+    int pending = 0;
+    impl_t *p = impl();
+    nReconfigure = (p != nullptr && mi_crossover_bank_needs_reconfiguration(p->bank, &pending) == MI_OK && pending != 0) ? uint32_t(R_ALL) : 0u;
 }
 
 bool Crossover::init(size_t bands, size_t buf_size)
@@ -1425,69 +1447,77 @@ bool Crossover::init(size_t bands, size_t buf_size)
     impl_t *p = new (std::nothrow) impl_t();
     if (p == nullptr)
         return false;
+    const size_t cap = (buf_size > 0) ? buf_size : 1;
     bool ok = mi_crossover_bank_create(&p->bank, 1, uint32_t(bands)) == MI_OK;
     p->bands = bands;
-    p->buf_size = (buf_size > 0) ? buf_size : 1;
     p->handlers.resize(bands);
     p->d_band.assign(bands, nullptr);
     for (size_t i = 0; ok && i < bands; ++i)
-        ok = mi_dspu_malloc(reinterpret_cast<void **>(&p->d_band[i]), p->buf_size * sizeof(float)) == MI_OK;
-    ok = ok && mi_dspu_malloc(reinterpret_cast<void **>(&p->d_in), p->buf_size * sizeof(float)) == MI_OK;
+        ok = mi_dspu_malloc(reinterpret_cast<void **>(&p->d_band[i]), cap * sizeof(float)) == MI_OK;
+    ok = ok && mi_dspu_malloc(reinterpret_cast<void **>(&p->d_in), cap * sizeof(float)) == MI_OK;
     if (!ok)
     {
-        mi_crossover_bank_destroy(p->bank);
-        for (float *q : p->d_band)
-            mi_dspu_free(q);
-        mi_dspu_free(p->d_in);
         delete p;
         return false;
     }
     destroy();
-    p->buf_size = buf_size;
-    pImpl = p;
+    pData = reinterpret_cast<uint8_t *>(p);
+    nSplits = uint32_t(bands - 1);
+    nBufSize = uint32_t(buf_size);
+    vLpfBuf = p->d_in;
+    mi_crossover_bank_set_sample_rate(p->bank, nSampleRate);
+    sync_flags();
     return true;
 }
 
-size_t Crossover::num_bands() const        { return pImpl ? pImpl->bands : 1; }
-size_t Crossover::num_splits() const       { return pImpl ? pImpl->bands - 1 : 0; }
-size_t Crossover::max_buffer_size() const  { return pImpl ? pImpl->buf_size : 0; }
-
 void Crossover::set_slope(size_t sp, size_t slope)
 {
-    if (pImpl) mi_crossover_bank_set_slope(pImpl->bank, uint32_t(sp), uint32_t(slope));
+    if (impl() == nullptr)
+        return;
+    mi_crossover_bank_set_slope(impl()->bank, uint32_t(sp), uint32_t(slope));
+    sync_flags();
 }
 
 ssize_t Crossover::get_slope(size_t sp) const
 {
     uint32_t v = 0;
-    return (pImpl && sp + 1 < pImpl->bands && mi_crossover_bank_get_split(pImpl->bank, uint32_t(sp), &v, nullptr, nullptr) == MI_OK) ? ssize_t(v) : -1;
+    return (impl() && sp < nSplits && mi_crossover_bank_get_split(impl()->bank, uint32_t(sp), &v, nullptr, nullptr) == MI_OK) ? ssize_t(v) : -1;
 }
 
 void Crossover::set_frequency(size_t sp, float freq)
 {
-    if (pImpl) mi_crossover_bank_set_frequency(pImpl->bank, uint32_t(sp), freq);
+    if (impl() == nullptr)
+        return;
+    mi_crossover_bank_set_frequency(impl()->bank, uint32_t(sp), freq);
+    sync_flags();
 }
 
 float Crossover::get_frequency(size_t sp) const
 {
     float v = -1.0f;
-    return (pImpl && sp + 1 < pImpl->bands && mi_crossover_bank_get_split(pImpl->bank, uint32_t(sp), nullptr, &v, nullptr) == MI_OK) ? v : -1.0f;
+    return (impl() && sp < nSplits && mi_crossover_bank_get_split(impl()->bank, uint32_t(sp), nullptr, &v, nullptr) == MI_OK) ? v : -1.0f;
 }
 
 void Crossover::set_mode(size_t sp, crossover_mode_t mode)
 {
-    if (pImpl) mi_crossover_bank_set_mode(pImpl->bank, uint32_t(sp), int(mode));
+    if (impl() == nullptr)
+        return;
+    mi_crossover_bank_set_mode(impl()->bank, uint32_t(sp), int(mode));
+    sync_flags();
 }
 
 ssize_t Crossover::get_mode(size_t sp) const
 {
     int v = -1;
-    return (pImpl && sp + 1 < pImpl->bands && mi_crossover_bank_get_split(pImpl->bank, uint32_t(sp), nullptr, nullptr, &v) == MI_OK) ? ssize_t(v) : -1;
+    return (impl() && sp < nSplits && mi_crossover_bank_get_split(impl()->bank, uint32_t(sp), nullptr, nullptr, &v) == MI_OK) ? ssize_t(v) : -1;
 }
 
 void Crossover::set_gain(size_t band, float gain)
 {
-    if (pImpl) mi_crossover_bank_set_gain(pImpl->bank, uint32_t(band), gain);
+    if (impl() == nullptr)
+        return;
+    mi_crossover_bank_set_gain(impl()->bank, uint32_t(band), gain);
+    sync_flags();
 }
 
 namespace
@@ -1503,21 +1533,41 @@ namespace
     }
 }
 
+// the getters below reconfigure first, as the reference's do (Crossover.cpp:262-325)
 float Crossover::get_gain(size_t band) const
 {
-    return pImpl ? crossover_band_field(pImpl->bank, pImpl->bands, band, 0, -1.0f) : -1.0f;
+    return impl() ? crossover_band_field(impl()->bank, impl()->bands, band, 0, -1.0f) : -1.0f;
 }
-float Crossover::get_band_start(size_t band)   { return pImpl ? crossover_band_field(pImpl->bank, pImpl->bands, band, 1, -1.0f) : -1.0f; }
-float Crossover::get_band_end(size_t band)     { return pImpl ? crossover_band_field(pImpl->bank, pImpl->bands, band, 2, -1.0f) : -1.0f; }
-bool Crossover::band_active(size_t band)       { return pImpl && crossover_band_field(pImpl->bank, pImpl->bands, band, 3, 0.0f) != 0.0f; }
+
+float Crossover::get_band_start(size_t band)
+{
+    const float v = impl() ? crossover_band_field(impl()->bank, impl()->bands, band, 1, -1.0f) : -1.0f;
+    sync_flags();
+    return v;
+}
+
+float Crossover::get_band_end(size_t band)
+{
+    const float v = impl() ? crossover_band_field(impl()->bank, impl()->bands, band, 2, -1.0f) : -1.0f;
+    sync_flags();
+    return v;
+}
+
+bool Crossover::band_active(size_t band)
+{
+    const bool v = impl() && crossover_band_field(impl()->bank, impl()->bands, band, 3, 0.0f) != 0.0f;
+    sync_flags();
+    return v;
+}
 
 bool Crossover::set_handler(size_t band, crossover_func_t func, void *object, void *subject)
 {
-    if (pImpl == nullptr || band >= pImpl->bands)
+    impl_t *p = impl();
+    if (p == nullptr || band >= p->bands)
         return false;
-    pImpl->handlers[band].func = func;
-    pImpl->handlers[band].object = object;
-    pImpl->handlers[band].subject = subject;
+    p->handlers[band].func = func;
+    p->handlers[band].object = object;
+    p->handlers[band].subject = subject;
     return true;
 }
 
@@ -1525,38 +1575,42 @@ bool Crossover::unset_handler(size_t band)     { return set_handler(band, nullpt
 
 void Crossover::set_sample_rate(size_t sr)
 {
-    if (pImpl == nullptr)
+    if (nSampleRate == sr)                                  // Crossover.cpp:327-345
         return;
-    pImpl->sample_rate = sr;
-    mi_crossover_bank_set_sample_rate(pImpl->bank, uint32_t(sr));
-}
-
-size_t Crossover::get_sample_rate()            { return pImpl ? pImpl->sample_rate : 48000; }
-
-bool Crossover::needs_reconfiguration() const
-{
-    int pending = 0;
-    return pImpl != nullptr && mi_crossover_bank_needs_reconfiguration(pImpl->bank, &pending) == MI_OK && pending != 0;
+    nSampleRate = uint32_t(sr);
+    if (impl() != nullptr)
+    {
+        mi_crossover_bank_set_sample_rate(impl()->bank, uint32_t(sr));
+        sync_flags();
+    }
 }
 
 void Crossover::reconfigure()
 {
-    if (pImpl) mi_crossover_bank_get_band(pImpl->bank, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (impl() != nullptr)
+        mi_crossover_bank_get_band(impl()->bank, 0, nullptr, nullptr, nullptr, nullptr, nullptr);
+    sync_flags();
 }
 
 bool Crossover::freq_chart(size_t band, float *c, const float *f, size_t count)
 {
-    if (pImpl == nullptr || band >= pImpl->bands)
+    impl_t *p = impl();
+    if (p == nullptr || band >= p->bands)
         return false;
-    return mi_crossover_bank_freq_chart(pImpl->bank, uint32_t(band), c, f, count, nullptr) == MI_OK;
+    const bool ok = mi_crossover_bank_freq_chart(p->bank, uint32_t(band), c, f, count, nullptr) == MI_OK;
+    sync_flags();
+    return ok;
 }
 
 bool Crossover::freq_chart(size_t band, float *re, float *im, const float *f, size_t count)
 {
-    if (pImpl == nullptr || band >= pImpl->bands)
+    impl_t *p = impl();
+    if (p == nullptr || band >= p->bands)
         return false;
     std::vector<float> c(2 * count);
-    if (mi_crossover_bank_freq_chart(pImpl->bank, uint32_t(band), c.data(), f, count, nullptr) != MI_OK)
+    const bool ok = mi_crossover_bank_freq_chart(p->bank, uint32_t(band), c.data(), f, count, nullptr) == MI_OK;
+    sync_flags();
+    if (!ok)
         return false;
     for (size_t i = 0; i < count; ++i)
     {
@@ -1568,18 +1622,20 @@ bool Crossover::freq_chart(size_t band, float *re, float *im, const float *f, si
 
 void Crossover::process(const float *in, size_t samples)   // Crossover.cpp:451-498: chunks of buf_size, handlers per chunk
 {
-    impl_t *p = pImpl;
+    impl_t *p = impl();
     if (p == nullptr)
         return;
     std::vector<float *> outs(p->bands);
     for (size_t sample = 0; sample < samples; )
     {
-        const size_t to_do = std::min(samples - sample, p->buf_size);
+        const size_t to_do = std::min<size_t>(samples - sample, nBufSize);
+        if (to_do == 0)
+            break;
         for (size_t b = 0; b < p->bands; ++b)
             outs[b] = (p->handlers[b].func != nullptr) ? p->d_band[b] : nullptr;
         if (mi_dspu_copy_h2d(p->d_in, in, to_do * sizeof(float), nullptr) != MI_OK ||
             mi_crossover_bank_process(p->bank, outs.data(), p->d_in, to_do, to_do, to_do, nullptr) != MI_OK)
-            return;
+            break;
         p->host.resize(to_do);
         // handlers fire from the lowest band upwards, the order the reference walks its plan in
         std::vector<std::pair<float, size_t> > order;
@@ -1598,12 +1654,15 @@ void Crossover::process(const float *in, size_t samples)   // Crossover.cpp:451-
         in += to_do;
         sample += to_do;
     }
+    sync_flags();
 }
 
 void Crossover::dump(IStateDumper *v) const
 {
-    v->write("nSplits", num_splits());
-    v->write("nBufSize", max_buffer_size());
+    v->write("nReconfigure", size_t(nReconfigure));
+    v->write("nSplits", size_t(nSplits));
+    v->write("nBufSize", size_t(nBufSize));
+    v->write("nSampleRate", size_t(nSampleRate));
 }
 
 // ---- envelope::* -----------------------------------------------------------------------------------------------
@@ -2306,7 +2365,7 @@ bool FFTCrossover::freq_chart(size_t band, float *m, const float *f, size_t coun
 void FFTCrossover::dump(IStateDumper *v) const
 {
     v->write("nBands", bands());
-    v->write("nSampleRate", nSampleRate);
+    v->write("nSampleRate", size_t(nSampleRate));
     v->write("nRank", rank());
 }
 
@@ -2585,7 +2644,7 @@ void LoudnessMeter::dump(IStateDumper *v) const
     v->write("fPeriod", fPeriod);
     v->write("fMaxPeriod", fMaxPeriod);
     v->write("fLoudness", fLoudness);
-    v->write("nSampleRate", nSampleRate);
+    v->write("nSampleRate", size_t(nSampleRate));
     v->write("nFlags", nFlags);
 }
 

@@ -38,9 +38,39 @@ namespace lsp
 
         class LSP_DSP_UNITS_PUBLIC Crossover
         {
-            private:
+            // Binary layout: data members, order and inline members of the reference class
+            // (include/lsp-plug.in/dsp-units/util/Crossover.h:149-163,201-216,323,352 of lsp-dsp-units 1.0.36).  The band and split
+            // records of the reference hold Equalizer / Filter objects; here the filters live in the GPU bank behind pData
+            // and the three list pointers stay NULL.
+            protected:
+                enum reconfigure_t
+                {
+                    R_GAIN          = 1 << 0,
+                    R_SPLIT         = 1 << 1,
+                    R_ALL           = R_GAIN | R_SPLIT
+                };
+                struct split_t;
+                struct band_t;
+
+            protected:
+                uint32_t        nReconfigure;
+                uint32_t        nSplits;
+                uint32_t        nBufSize;
+                uint32_t        nSampleRate;
+                uint32_t        nPlanSize;
+
+                band_t         *vBands;
+                split_t        *vSplit;
+                split_t       **vPlan;
+
+                float          *vLpfBuf;        // (device: staging of the caller's block)
+                float          *vHpfBuf;
+                uint8_t        *pData;
+
+            protected:
                 struct impl_t;
-                impl_t     *pImpl;
+                impl_t         *impl() const    { return reinterpret_cast<impl_t *>(pData); }
+                void            sync_flags();   // nReconfigure as the bank sees it
 
             public:
                 explicit Crossover();
@@ -53,9 +83,9 @@ namespace lsp
                 bool            init(size_t bands, size_t buf_size);
 
             public:
-                size_t          num_bands() const;
-                size_t          num_splits() const;
-                size_t          max_buffer_size() const;
+                inline size_t   num_bands() const                       { return nSplits+1;     }
+                inline size_t   num_splits() const                      { return nSplits;       }
+                inline size_t   max_buffer_size() const                 { return nBufSize;      }
                 void            set_slope(size_t sp, size_t slope);
                 ssize_t         get_slope(size_t sp) const;
                 void            set_frequency(size_t sp, float freq);
@@ -70,11 +100,11 @@ namespace lsp
                 bool            set_handler(size_t band, crossover_func_t func, void *object, void *subject);
                 bool            unset_handler(size_t band);
                 void            set_sample_rate(size_t sr);
-                size_t          get_sample_rate();
+                inline size_t   get_sample_rate()                       { return nSampleRate;   }
                 bool            freq_chart(size_t band, float *re, float *im, const float *f, size_t count);
                 bool            freq_chart(size_t band, float *c, const float *f, size_t count);
                 void            reconfigure();
-                bool            needs_reconfiguration() const;
+                inline bool     needs_reconfiguration() const           { return nReconfigure != 0; }
                 void            process(const float *in, size_t samples);
                 void            dump(IStateDumper *v) const;
         };

@@ -728,6 +728,46 @@ static void raw_memory_objects()
         free(ss);
     }
 
+    {   // Crossover on raw memory: counts, sample rate and the reconfiguration flag are members the inline getters read
+        dspu::Crossover *xo = raw_object<dspu::Crossover>();
+        xo->construct();
+        CHECK(xo->num_bands() == 1 && xo->num_splits() == 0 && xo->max_buffer_size() == 0 && xo->get_sample_rate() == 48000 &&
+              xo->needs_reconfiguration(), "constructed crossover");
+        CHECK(!xo->init(0, 256) && xo->init(3, 256), "crossover init");
+        CHECK(xo->num_bands() == 3 && xo->num_splits() == 2 && xo->max_buffer_size() == 256 && xo->needs_reconfiguration(), "init members");
+        xo->set_sample_rate(44100);
+        xo->set_slope(0, dspu::CROSS_SLOPE_LR4); xo->set_frequency(0, 500.0f);
+        xo->set_slope(1, dspu::CROSS_SLOPE_LR4); xo->set_frequency(1, 4000.0f);
+        CHECK(xo->get_sample_rate() == 44100 && xo->get_slope(1) == dspu::CROSS_SLOPE_LR4 && xo->get_frequency(0) == 500.0f &&
+              xo->get_slope(2) == -1, "split records");
+        xo->reconfigure();
+        CHECK(!xo->needs_reconfiguration() && xo->band_active(1) && xo->get_band_start(1) == 500.0f && xo->get_band_end(1) == 4000.0f, "reconfigure()");
+        xo->set_gain(1, 0.5f);
+        CHECK(xo->needs_reconfiguration() && xo->get_gain(1) == 0.5f, "set_gain marks the crossover dirty");
+        xo->set_gain(1, 1.0f);
+        struct got_t { std::vector<float> y[3]; } got;
+        for (auto &v : got.y) v.assign(2000, 0.0f);
+        auto take = [](void *obj, void *, size_t band, const float *data, size_t first, size_t count)
+        { memcpy(static_cast<got_t *>(obj)->y[band].data() + first, data, count * sizeof(float)); };
+        for (size_t b = 0; b < 3; ++b)
+            CHECK(xo->set_handler(b, take, &got, NULL), "set_handler");
+        std::vector<float> x(2000, 0.0f);
+        x[0] = 1.0f;
+        xo->process(x.data(), x.size());
+        CHECK(!xo->needs_reconfiguration(), "process() reconfigures");
+        // Linkwitz-Riley bands add up to an all-pass: the energy of the sum of the bands' impulse responses is 1
+        double energy = 0.0;
+        for (size_t i = 0; i < 2000; ++i)
+        {
+            const double v = double(got.y[0][i]) + got.y[1][i] + got.y[2][i];
+            energy += v * v;
+        }
+        CHECK(fabs(energy - 1.0) < 1e-3, "bands add up to an all-pass (energy %g)", energy);
+        xo->destroy();
+        CHECK(xo->num_bands() == 1 && xo->needs_reconfiguration(), "destroyed crossover");
+        free(xo);
+    }
+
     {   // FFTCrossover on raw memory: the embedded splitter answers the inline members
         dspu::FFTCrossover *fx = raw_object<dspu::FFTCrossover>();
         fx->construct();
@@ -887,6 +927,7 @@ static void raw_memory_objects()
     static_assert(sizeof(dspu::DynamicFilters) == 64, "DynamicFilters object size of the reference header");
     static_assert(sizeof(dspu::LoudnessMeter) == 112 && sizeof(dspu::ILUFSMeter) == 104, "meter object sizes of the reference headers");
     static_assert(sizeof(dspu::SpectralSplitter) == 128, "SpectralSplitter object size of the reference header");
+    static_assert(sizeof(dspu::Crossover) == 72, "Crossover object size of the reference header (5 x u32, 6 pointers)");
     static_assert(sizeof(dspu::FFTCrossover) == 152, "FFTCrossover object size of the reference header (splitter by value + 3 words)");
     static_assert(sizeof(dspu::MultiSpectralProcessor) == 80, "MultiSpectralProcessor object size of the reference header");
     static_assert(sizeof(dspu::Analyzer) == 128, "Analyzer object size of the reference header (14 x u32, 5 x f32, bool, 6 pointers)");
