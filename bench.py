@@ -246,7 +246,7 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
         return None
     if big is not None:
         res["beyond_infinity_cache"] = {k: big[k] for k in ("value", "ms_per_step", "config", "roofline", "whole_step")}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_convolver(irs, 4096)
     return res
 
@@ -696,7 +696,7 @@ def main():
             },
             "committed_profile": committed,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # the CPU figure is a 1-process measurement (rank 0 at N = 1 only)
             line["cpu_baseline"] = cpu_baseline_biquad(coef, n)
 
     bank.close()
