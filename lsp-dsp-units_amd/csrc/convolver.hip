@@ -104,7 +104,8 @@ namespace
                            float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                            float *acc, const float2 *__restrict__ Yt /* pending tail or NULL */,
                            const float2 *__restrict__ tw,
-                           float *dl_ring /* or NULL */, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head)
+                           float *dl_ring /* or NULL */, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head,
+                           bool upper_zero /* acc[B:2B] is known to hold zeros: neither read nor re-zeroed */)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
@@ -158,7 +159,7 @@ namespace
         for (int i = 0; i < NPT; ++i)
         {
             a0[i] = *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T));
-            a1[i] = *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
+            a1[i] = upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
         }
         MI_CPROBE(1);
         rf.prepare();
@@ -203,7 +204,8 @@ namespace
                 mi::wt_store(rout, 8 * n + 4, r.y);
             }
             mi::wt_store(racc, 8 * n, make_float2(fmaf(y1.x, scale, a1[i].x), fmaf(y1.y, scale, a1[i].y)));
-            mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
+            if (!upper_zero)
+                mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
         }
         MI_CPROBE(5);
     }
@@ -525,6 +527,7 @@ struct mi_convolver_bank
     int         off = 0;            // samples already received of the current frame
     bool        live = false;       // false: count == 0, process() emits zeros (Convolver.cpp:219-223)
     bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
+    bool        upper_zero = false; // acc[B:2B] holds zeros (true between whole frames: the frame kernel skips that half)
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
@@ -598,6 +601,7 @@ namespace
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = false;
+        b->upper_zero = false;
         return MI_OK;
     }
 } // namespace
@@ -630,7 +634,7 @@ namespace mi
         const mi_convolver_bank *b = static_cast<const mi_convolver_bank *>(bank);
         uint64_t h = position_mix(uint64_t(b->slot), uint64_t(b->off));
         h = position_mix(h, (uint64_t(b->live) << 0) | (uint64_t(b->yt_pending) << 1) | (uint64_t(b->frame_open) << 2) |
-                            (uint64_t(b->xf_any) << 3) | (uint64_t(b->xfade_active) << 4));
+                            (uint64_t(b->xf_any) << 3) | (uint64_t(b->xfade_active) << 4) | (uint64_t(b->upper_zero) << 5));
         h = position_mix(h, (uint64_t(uint32_t(b->cv)) << 0) | (uint64_t(uint32_t(b->nv)) << 8) | (uint64_t(uint32_t(b->fr_old)) << 16) |
                             (uint64_t(uint32_t(b->fr_new) & 0xff) << 24));
         return h;
@@ -652,11 +656,12 @@ namespace mi
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
                                                out, in, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
                                                b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
-                                               dl.ring, dl.size, tail, dl.head)
+                                               dl.ring, dl.size, tail, dl.head, b->upper_zero)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = false;
+        b->upper_zero = true;
         return launch_mac(b, st);
     }
 } // namespace mi
@@ -936,6 +941,7 @@ int mi_convolver_bank_reset(mi_convolver_bank_t *b, void *stream)
     if (b->R > 0)
         MI_HIP_CHECK(hipMemsetAsync(b->d_ring, 0, size_t(b->channels) * b->R * M * sizeof(float2), st));
     MI_HIP_CHECK(hipMemsetAsync(b->d_acc, 0, size_t(b->channels) * 2 * M * sizeof(float), st));
+    b->upper_zero = true;
     MI_HIP_CHECK(hipMemsetAsync(b->d_frame, 0, size_t(b->channels) * M * sizeof(float), st));
     b->slot = 0;
     b->off  = 0;
@@ -1014,6 +1020,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             MI_LOGM_SWITCH(b->logm, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
+            b->upper_zero = true;
             b->xfade_active = false;
             b->frame_open = false;
             done += size_t(B);
@@ -1027,11 +1034,12 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
                                                    o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
                                                    b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
-                                                   static_cast<float *>(nullptr), 0u, 0u, 0u)
+                                                   static_cast<float *>(nullptr), 0u, 0u, 0u, b->upper_zero)
             MI_LOGM_SWITCH(b->logm, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
             b->yt_pending = false;
+            b->upper_zero = true;
             const int r = launch_mac(b, st);
             if (r != MI_OK)
                 return r;
@@ -1056,6 +1064,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
                                    o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
             MI_HIP_CHECK(hipGetLastError());
+            b->upper_zero = false;
             b->off += cnt;
             done += size_t(cnt);
             if (b->off == B)
@@ -1067,6 +1076,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
+                b->upper_zero = true;
                 const int r = launch_mac(b, st);
                 if (r != MI_OK)
                     return r;
