@@ -174,16 +174,20 @@ def test_freq_charts_match_oracle(gpu):
 @pytest.mark.parametrize("seed", range(8))
 def test_random_retune_scripts(gpu, seed):
     """Differential stress: random scripts of slope / frequency / mode / gain changes between blocks of random length,
-    random sets of bands with a handler.  Frequencies stay above 500 Hz so that the chained float32 recursions stay
-    comparable at a fixed tolerance."""
+    random sets of bands with a handler.  Frequencies stay above 500 Hz at 48 kHz -- the same fraction of the sample rate
+    at the others -- so that the chained float32 recursions stay comparable at a fixed tolerance (a
+    Linkwitz-Riley low-pass at 250 Hz / 48 kHz, i.e. 500 Hz / 96 kHz, is only reproducible to 1e-4 of the peak; seeds 10624
+    and 10996 of the round-2 sweep drew 514 and 573 Hz at 96 kHz and differed from the oracle by 6e-5 and 7e-5)."""
     rng = np.random.default_rng(13000 + seed)
     bands = int(rng.integers(2, 6))
     C = 2
     n_blocks = 8
     block = int(rng.choice([16, 333, 1024, 2500]))
-    script = {0: [("set_sample_rate", int(rng.choice([44100, 48000, 96000])))]}
+    sr = int(rng.choice([44100, 48000, 96000]))
+    floor = 500.0 * max(sr, 48000) / 48000.0
+    script = {0: [("set_sample_rate", sr)]}
     for i in range(bands - 1):                                # away from the default split points (70 Hz ...)
-        script[0].append(("set_frequency", i, float(rng.uniform(500.0, 15000.0))))
+        script[0].append(("set_frequency", i, max(float(rng.uniform(500.0, 15000.0)), floor)))
     for k in range(n_blocks):
         ops = script.setdefault(k, [])
         for _ in range(int(rng.integers(0, 4)) + (3 if k == 0 else 0)):
@@ -191,7 +195,7 @@ def test_random_retune_scripts(gpu, seed):
             if kind == "set_slope":
                 ops.append(("set_slope", int(rng.integers(0, bands - 1)), int(rng.integers(0, 6))))
             elif kind == "set_frequency":
-                ops.append(("set_frequency", int(rng.integers(0, bands - 1)), float(rng.uniform(500.0, 15000.0))))
+                ops.append(("set_frequency", int(rng.integers(0, bands - 1)), max(float(rng.uniform(500.0, 15000.0)), floor)))
             elif kind == "set_mode":
                 ops.append(("set_mode", int(rng.integers(0, bands - 1)), int(rng.integers(0, 2))))
             else:
