@@ -669,7 +669,8 @@ typedef struct mi_splitter_bank mi_splitter_bank_t;
 /* spectral_splitter_func_t on the device (util/SpectralSplitter.h:41-46): in/out are DEVICE pointers to
  * [channels][2 * 2^rank] floats (packed complex); the function runs on the host and may enqueue work on `stream`. */
 typedef void (*mi_splitter_func_t)(void *object, void *subject, float *out, const float *in, size_t rank, size_t channels, void *stream);
-/* init(max_rank, handlers), SpectralSplitter.cpp:62-127 (max_rank 5..14) */
+/* init(max_rank, handlers), SpectralSplitter.cpp:62-127 (max_rank 5..18; frames above 2^14 samples go through global memory,
+ * one plain launch per step of the hop instead of the fused kernel) */
 int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32_t max_rank, uint32_t handlers);
 int mi_splitter_bank_destroy(mi_splitter_bank_t *bank);
 /* set_rank / set_chunk_rank / set_phase, SpectralSplitter.cpp:260-282 */

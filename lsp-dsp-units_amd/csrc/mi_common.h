@@ -64,6 +64,10 @@ namespace mi
 
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);
+    // Complex transform of `channels` sequences of 2^rank points (rank 15 .. 18) through global memory (spectral.hip, the
+    // four-step form N = 8192 x N2): src -> tmp -> dst, unnormalised either way; dst may be src.
+    int         big_fft_run(bool inverse, float2 *dst, const float2 *src, float2 *tmp, uint32_t rank, uint32_t channels,
+                            const float2 *tw, hipStream_t st);
 
     // Library-internal coupling of a delay line bank and a convolver bank (the Equalizer's FIR path): the convolver's
     // frame kernel pulls its frame straight out of the delay line and pushes the new samples into it, one launch

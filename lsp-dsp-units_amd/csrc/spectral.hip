@@ -803,6 +803,18 @@ namespace
     }
 } // namespace
 
+namespace mi
+{
+    int big_fft_run(bool inverse, float2 *dst, const float2 *src, float2 *tmp, uint32_t rank, uint32_t channels, const float2 *tw,
+                    hipStream_t st)
+    {
+        if (rank <= uint32_t(BIG_LOG1) + 1 || rank > uint32_t(BIG_MAX_RANK))
+            return fail(MI_EINVAL, "big_fft_run: rank %u outside 15..%d", rank, BIG_MAX_RANK);
+        return inverse ? ::big_fft_run<true>(dst, src, tmp, rank, channels, tw, st)
+                       : ::big_fft_run<false>(dst, src, tmp, rank, channels, tw, st);
+    }
+}
+
 extern "C" {
 
 int mi_spectral_bank_create(mi_spectral_bank_t **bank, uint32_t channels, uint32_t max_rank)

@@ -303,7 +303,7 @@ struct mi_splitter_bank
     std::vector<handler_t> h;
     std::vector<uint8_t> has_sink;
     float      *d_in = nullptr, *d_in2 = nullptr, *d_lines = nullptr, *d_wnd = nullptr;    // d_in: current analysis buffers, d_in2: the other half of the pair
-    float2     *d_spec = nullptr, *d_tmp = nullptr;
+    float2     *d_spec = nullptr, *d_tmp = nullptr, *d_big = nullptr;     // d_big: scratch of the four-step transform (ranks >= 15)
     handler_desc *d_desc = nullptr;
     float     **d_outs = nullptr;
     std::vector<float *> outs_shadow;
@@ -465,6 +465,102 @@ namespace
                                     size_t(b->channels) * b->pitch * sizeof(float), st));
         return MI_OK;
     }
+
+    // ---- frames above 2^14 samples (ranks 15 .. 18): the hop as plain launches around the four-step transform of spectral.hip
+    // (mi::big_fft_run), complex all the way as in the reference (pcomplex_r2c ... packed_reverse_fft, real part kept)
+
+    // spec[n] = (in[n], 0): the analysis buffer as a complex sequence
+    __global__ __launch_bounds__(256)
+    void splitter_big_load_kernel(float2 *spec, const float *__restrict__ in_buf, size_t in_pitch, uint32_t N)
+    {
+        const uint32_t n = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (n < N)
+            spec[size_t(ch) * N + n] = make_float2(in_buf[size_t(ch) * in_pitch + n], 0.0f);
+    }
+
+    // prod[k] = spec[k] * g[k], the N real gains in FFT order (FFTCrossover::spectral_func, FFTCrossover.cpp:137-139)
+    __global__ __launch_bounds__(256)
+    void splitter_big_mask_kernel(float2 *prod, const float2 *__restrict__ spec, const float *__restrict__ mask, size_t mask_stride,
+                                  uint32_t N)
+    {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (k < N)
+        {
+            const float g = mask[size_t(ch) * mask_stride + k];
+            const float2 v = spec[size_t(ch) * N + k];
+            prod[size_t(ch) * N + k] = make_float2(v.x * g, v.y * g);
+        }
+    }
+
+    // the handler's line moves on by one frame and takes the windowed last 2*frame samples of the way back (res != NULL:
+    // real parts, scaled) or the first 2*frame samples of the analysis buffer (a handler without a spectral function, :330)
+    __global__ __launch_bounds__(256)
+    void splitter_big_ola_kernel(float *line0, size_t line_pitch, const float2 *__restrict__ res, const float *__restrict__ in_buf,
+                                 size_t in_pitch, const float *__restrict__ wnd, uint32_t frame, uint32_t N, float scale)
+    {
+        const uint32_t m = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y;
+        if (m >= frame)
+            return;
+        float y0, y1;
+        if (res != nullptr)
+        {
+            const float2 *r = res + size_t(ch) * N + (N - 2 * frame);
+            y0 = r[m].x * scale;
+            y1 = r[m + frame].x * scale;
+        }
+        else
+        {
+            y0 = in_buf[size_t(ch) * in_pitch + m];
+            y1 = in_buf[size_t(ch) * in_pitch + m + frame];
+        }
+        float *line = line0 + size_t(ch) * line_pitch;
+        const float prev = line[m + frame];
+        line[m]         = fmaf(y0, wnd[m], prev);
+        line[m + frame] = y1 * wnd[m + frame];
+    }
+
+    int splitter_hop_big(mi_splitter_bank *b, hipStream_t st)
+    {
+        const uint32_t N = 1u << b->rank, frame = 1u << (b->chunk_rank - 1);
+        const dim3 gN((N + 255) / 256, b->channels), gF((frame + 255) / 256, b->channels);
+        hipLaunchKernelGGL(splitter_big_load_kernel, gN, dim3(256), 0, st, b->d_spec, b->d_in, b->pitch, N);
+        MI_HIP_CHECK(hipGetLastError());
+        int r = mi::big_fft_run(false, b->d_spec, b->d_spec, b->d_big, b->rank, b->channels, b->d_tw, st);
+        if (r != MI_OK)
+            return r;
+        for (uint32_t i = 0; i < b->handlers; ++i)
+        {
+            mi_splitter_bank::handler_t &h = b->h[i];
+            if (h.mode == H_OFF)
+                continue;
+            const float2 *res = nullptr;
+            if (h.mode == H_CALLBACK)                       // the function runs whether or not somebody listens (:316-327)
+                h.func(h.object, h.subject, reinterpret_cast<float *>(b->d_tmp), reinterpret_cast<const float *>(b->d_spec), b->rank,
+                       b->channels, st);
+            if (!b->has_sink[i])
+                continue;
+            if (h.mode == H_MASK)
+            {
+                hipLaunchKernelGGL(splitter_big_mask_kernel, gN, dim3(256), 0, st, b->d_tmp, b->d_spec, h.d_mask, h.mask_stride, N);
+                MI_HIP_CHECK(hipGetLastError());
+            }
+            if (h.mode != H_COPY)
+            {
+                r = mi::big_fft_run(true, b->d_tmp, b->d_tmp, b->d_big, b->rank, b->channels, b->d_tw, st);
+                if (r != MI_OK)
+                    return r;
+                res = b->d_tmp;
+            }
+            hipLaunchKernelGGL(splitter_big_ola_kernel, gF, dim3(256), 0, st, b->d_lines + size_t(i) * b->channels * b->pitch, b->pitch,
+                               res, b->d_in, b->pitch, b->d_wnd, frame, N, 1.0f / float(N));
+            MI_HIP_CHECK(hipGetLastError());
+        }
+        // the analysis buffer moves on by one frame, into the other buffer of the pair
+        MI_HIP_CHECK(hipMemcpy2DAsync(b->d_in2, b->pitch * sizeof(float), b->d_in + frame, b->pitch * sizeof(float),
+                                      size_t(N - frame) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+        std::swap(b->d_in, b->d_in2);
+        return MI_OK;
+    }
 } // namespace
 
 extern "C" {
@@ -474,7 +570,7 @@ int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_splitter_bank_create: NULL result pointer");
     *bank = nullptr;
     MI_REQUIRE(channels > 0 && handlers > 0, MI_EINVAL, "mi_splitter_bank_create: no channels or handlers");
-    MI_REQUIRE(max_rank >= 5 && max_rank <= 14, MI_EINVAL, "mi_splitter_bank_create: max_rank %u outside 5..14", max_rank);
+    MI_REQUIRE(max_rank >= 5 && max_rank <= 18, MI_EINVAL, "mi_splitter_bank_create: max_rank %u outside 5..18", max_rank);
     MI_REQUIRE(mi_dspu_device_count() > 0, MI_ENODEV, "no HIP device available (there is no CPU fallback)");
     mi_splitter_bank *b = new (std::nothrow) mi_splitter_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_splitter_bank_create: out of host memory");
@@ -501,6 +597,13 @@ int mi_splitter_bank_create(mi_splitter_bank_t **bank, uint32_t channels, uint32
         if (e == hipSuccess) e = hipMemset(b->d_in2, 0, row * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_lines, 0, row * handlers * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_outs, 0, handlers * sizeof(float *));
+        if (e == hipSuccess && max_rank > 14)               // frames above 2^14: spectrum, product / result, transform scratch
+        {
+            const size_t n = size_t(channels) << max_rank;
+            e = hipMalloc(reinterpret_cast<void **>(&b->d_spec), n * sizeof(float2));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_tmp), n * sizeof(float2));
+            if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_big), n * sizeof(float2));
+        }
     }
     if (r != MI_OK || e != hipSuccess)
     {
@@ -518,7 +621,7 @@ int mi_splitter_bank_destroy(mi_splitter_bank_t *b)
     for (mi_splitter_bank::handler_t &h : b->h)
         (void)hipFree(h.d_mask);
     (void)hipFree(b->d_in); (void)hipFree(b->d_in2); (void)hipFree(b->d_lines); (void)hipFree(b->d_wnd); (void)hipFree(b->d_desc);
-    (void)hipFree(b->d_outs); (void)hipFree(b->d_spec); (void)hipFree(b->d_tmp);
+    (void)hipFree(b->d_outs); (void)hipFree(b->d_spec); (void)hipFree(b->d_tmp); (void)hipFree(b->d_big);
     delete b;
     return MI_OK;
 }
@@ -715,8 +818,10 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
         if (b->fill >= frame)                                           // a frame is complete: transform (:311-356)
         {
             // a whole frame follows in this call: the transform kernel takes it in and hands the finished frame out itself
-            const bool fused = !callbacks && (count - done >= frame);
-            const int r = fused ? splitter_hop(b, st, (in != nullptr) ? in + done : nullptr, in_stride, frame, out_stride, done)
+            const bool big = b->rank > 14;
+            const bool fused = !big && !callbacks && (count - done >= frame);
+            const int r = big   ? splitter_hop_big(b, st)
+                        : fused ? splitter_hop(b, st, (in != nullptr) ? in + done : nullptr, in_stride, frame, out_stride, done)
                                 : splitter_hop(b, st, nullptr, 0, 0, 0, 0);
             if (r != MI_OK)
                 return r;

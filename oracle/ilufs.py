@@ -52,6 +52,9 @@ class ILUFSMeter:
         self.upd_filters = self.upd_time = True; self.blk_full = False
         self.weighting = WEIGHT_K
         self.hist = None
+        # diagnostic for the tests, not part of the restated state: how close (relative) any gating block evaluated since
+        # the last clear() came to the absolute gate -- a block the gate DROPS leaves no other trace when the mean runs on
+        self.gate_margin = float("inf")
 
     def set_designation(self, i, d):
         self.ch[i]["weight"] = channel_weighting(d)
@@ -91,6 +94,7 @@ class ILUFSMeter:
         self.loud = F(0.0)
         self.block_offset = self.block_part = 0
         self.ms_head = self.ms_count = 0
+        self.gate_margin = float("inf")
 
     def _blk(self):
         return int(F(F(F(self.block_period * F(0.25)) * F(0.001)) * F(self.sr)))
@@ -178,6 +182,7 @@ class ILUFSMeter:
                         b = c["block"]
                         s = F(F(F(F(b[0] + b[1]) + b[2]) + b[3]) * self.avg)
                         loud = F(loud + F(c["weight"] * s))
+                    self.gate_margin = min(self.gate_margin, abs(float(loud) - float(GATING_ABS_THRESH)) / float(GATING_ABS_THRESH))
                     if self.ms_int > 0:
                         self.ms_count = min(self.ms_count + 1, self.ms_int)
                         self.hist[self.ms_head] = loud

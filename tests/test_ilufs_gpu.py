@@ -186,7 +186,9 @@ def test_random_operation_sequences(gpu, seed):
                 r = refs[m]
                 h = np.asarray(r.hist, np.float64).ravel()
                 if max_int == 0.0:
-                    if h.size and float(np.min(np.abs(h - GATE) / GATE)) < 0.05:
+                    # (the running mean keeps no record of a block the gate dropped: the oracle notes how close any
+                    # evaluated block came -- seed 12445 of the round-2 sweep had one the GPU kept and the oracle dropped)
+                    if r.gate_margin < 0.05:
                         at_gate[m] = True
                     continue
                 live = [(r.ms_head + r.ms_size - 1 - k) % r.ms_size for k in range(r.ms_count)]

@@ -268,7 +268,7 @@ def test_random_operation_sequences(gpu, seed):
                 # |out_a - out_b| <= sqrt(sum_k w_k sum_window e_k^2 / N) (triangle inequality of the l2 norm) with
                 # e_k <= the IIR rule of DESIGN.md section 4 applied to the line's peak -- that bound, sample by sample.
                 N = refs[m].period
-                live = [k for k in range(K) if refs[m].ch[k]["enabled"] and refs[m].ch[k]["bound"]]
+                live = [k for k in range(K) if refs[m].ch[k]["enabled"] and refs[m].ch[k]["bound"] and float(refs[m].ch[k]["weight"]) != 0.0]
                 filling = len(live) > 0 and all(held[k] + n <= N // 16 for k in live)
                 if filling:
                     e_rel = max(TOL, IIR_REF_FACTOR * _weighting_noise(weight, sr))

@@ -69,6 +69,7 @@ def _gpu_run(gpu, rank, chunk, phase, handlers, x, calls, max_rank=None):
 @pytest.mark.parametrize("rank,chunk,phase,calls", [
     (5, 0, 0.0, (300,)), (8, 0, 0.0, (1000, 24)), (9, 7, 0.0, (100, 3, 700, 197)), (10, 8, 0.5, (333, 1667)),
     (12, 10, 0.0, (8192, 5000)), (13, 0, 0.25, (20000,)), (12, 5, 1.0, (6000,)), (14, 12, 0.0, (40000,)),
+    (15, 0, 0.0, (70000, 1234)), (16, 13, 0.5, (70000, 5000)), (15, 14, 0.25, (40000,)),     # frames above the LDS limit
 ])
 def test_masks_and_copy_handlers_match_oracle(gpu, rank, chunk, phase, calls):
     """Several bands in one pass: a shared symmetric mask, per-channel masks, an ASYMMETRIC real mask (only the real part
@@ -187,11 +188,49 @@ def test_callback_handler_gets_the_full_spectrum(gpu):
     bank.close()
 
 
+def test_largest_frames_callback_copy_and_rank_switch(gpu):
+    """Ranks 15 .. 18 (frames that do not fit the LDS): a CALLBACK handler sees the complex spectrum and hands it back, so it
+    reproduces the input delayed by the latency; switching the same bank down to rank 12 and back up works like a fresh one."""
+    C, n = 2, 50000
+    rng = np.random.default_rng(15)
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    bank = gpu.SplitterBank(C, 17, 2)
+    bank.set_rank(15); bank.set_chunk_rank(13)
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    seen = []
+
+    def func(out, inp, r, ch, st):
+        seen.append((r, ch))
+        assert hip.hipMemcpyAsync(out, inp, ch * (2 << r) * 4, 3, st) == 0
+    bank.bind_callback(0, func)
+    bank.bind_mask(1, np.ones(1 << 15, np.float32))
+    o0 = gpu.DeviceBuffer((C, n)); o1 = gpu.DeviceBuffer((C, n))
+    bank.process([o0, o1], gpu.DeviceBuffer.from_host(x), n)
+    y0, y1 = o0.download(), o1.download()
+    lat = bank.latency()
+    assert lat == 1 << 13 and seen and seen[0] == (15, C) and len(seen) == (n - 1) // (lat // 2)
+    assert np.abs(y0[:, 2 * lat:] - x[:, lat:n - lat]).max() < 2e-5 * np.abs(x).max()
+    assert np.abs(y0 - y1).max() < 2e-5 * np.abs(x).max()
+    # down to a frame that fits the LDS, then up again: each switch restarts the unit (update_settings clears it)
+    for rank in (12, 16):
+        bank.set_rank(rank); bank.set_chunk_rank(11)
+        bank.bind_mask(1, np.ones(1 << rank, np.float32))
+        o0 = gpu.DeviceBuffer((C, n)); o1 = gpu.DeviceBuffer((C, n))
+        bank.process([o0, o1], gpu.DeviceBuffer.from_host(x), n)
+        y0, y1 = o0.download(), o1.download()
+        lat = bank.latency()
+        assert lat == 1 << 11
+        assert np.abs(y1[:, lat:] - x[:, :n - lat]).max() < 2e-5 * np.abs(x).max(), rank
+        assert np.abs(y0 - y1).max() < 2e-5 * np.abs(x).max(), rank
+    bank.close()
+
+
 def test_argument_errors(gpu):
     with pytest.raises(gpu.MiError):
         gpu.SplitterBank(1, 4, 1)
     with pytest.raises(gpu.MiError):
-        gpu.SplitterBank(1, 15, 1)
+        gpu.SplitterBank(1, 19, 1)
     bank = gpu.SplitterBank(1, 8, 2)
     with pytest.raises(gpu.MiError):
         bank.bind_copy(2)
