@@ -800,6 +800,31 @@ static void raw_memory_objects()
         CHECK(worst <= 1e-4f, "complementary bands add up to the delayed input (%g)", worst);
         fx->disable_band(1);
         CHECK(!fx->band_enabled(1), "disable_band");
+        // frames above 2^14 samples (the reference's init() has no upper limit): rank 15, the same complementary pair
+        fx->enable_band(1);
+        fx->set_rank(15);
+        CHECK(fx->rank() == 10, "set_rank above max_rank is clamped to it (FFTCrossover.cpp:433)");
+        fx->destroy();
+        CHECK(fx->init(15, 2) == STATUS_OK && fx->rank() == 15, "FFT crossover init at rank 15");
+        fx->set_sample_rate(48000);
+        fx->set_lpf(0, 1000.0f, -48.0f, true);
+        fx->set_hpf(1, 1000.0f, -48.0f, true);
+        const size_t big_n = 3 * 32768 + 1000;
+        got.y[0].assign(big_n, 0.0f); got.y[1].assign(big_n, 0.0f);
+        CHECK(fx->set_handler(0, take, &got, NULL) && fx->set_handler(1, take, &got, NULL), "handlers at rank 15");
+        fx->enable_band(0); fx->enable_band(1);
+        std::vector<float> xb(big_n);
+        for (float &v : xb)
+        {
+            seed = seed * 1664525u + 1013904223u;
+            v = float(int32_t(seed >> 8) - (1 << 23)) / float(1 << 23);
+        }
+        fx->process(xb.data(), xb.size());
+        CHECK(fx->latency() == 32768, "latency at rank 15: %d", int(fx->latency()));
+        worst = 0.0f;
+        for (size_t i = 32768; i < big_n; ++i)
+            worst = fmaxf(worst, fabsf(got.y[0][i] + got.y[1][i] - xb[i - 32768]));
+        CHECK(worst <= 1e-4f, "rank 15: complementary bands add up to the delayed input (%g)", worst);
         fx->clear();
         fx->destroy();
         CHECK(fx->bands() == 0, "destroyed FFT crossover");
