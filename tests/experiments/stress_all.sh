@@ -7,6 +7,6 @@ for T in "test_biquad_gpu test_random_operation_sequences" "test_convolver_gpu t
          "test_delay_gpu test_ring_random_operation_sequences_bit_exact" "test_equalizer_gpu test_random_operation_sequences_match_oracle" \
          "test_ilufs_gpu test_random_operation_sequences" "test_loudness_gpu test_random_operation_sequences" \
          "test_spectral_gpu test_spectral_random_operation_sequences" "test_spectral_gpu test_analyzer_random_settings" \
-         "test_splitter_gpu test_random_operation_sequences_match_oracle"; do
+         "test_splitter_gpu test_random_operation_sequences_match_oracle" "test_dynfilter_gpu test_random_operation_sequences"; do
     timeout 1500 python tests/experiments/stress_sweep.py $T $A $B 2>&1 | tail -4 | cut -c1-400
 done
