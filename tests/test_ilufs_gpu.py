@@ -200,9 +200,13 @@ def test_random_operation_sequences(gpu, seed):
                 gh = hist[m].astype(np.float64)
                 for i in live:                               # every block of the window, the borderline ones included
                     assert abs(gh[i] - h[i]) <= 3 * tol * level * level, (seed, step, m, i, gh[i], h[i])
-                kept = [gh[i] for i in live if gh[i] > GATE]
-                own = float(np.sqrt(np.mean(kept))) if kept else 0.0
-                assert abs(float(bank.loudness()[m]) - own) <= 3 * tol * max(level, own), (seed, step, m, own)
+                # the held value is the gated mean of the window AS OF THE LAST EVALUATION: only a call in which a block was
+                # evaluated leaves it equal to the mean of the window as it is now (seed 13582 of the round-2 sweep: the
+                # integration period shrank the window, then a call of one quarter evaluated nothing)
+                if r.blk_full:
+                    kept = [gh[i] for i in live if gh[i] > GATE]
+                    own = float(np.sqrt(np.mean(kept))) if kept else 0.0
+                    assert abs(float(bank.loudness()[m]) - own) <= 3 * tol * max(level, own), (seed, step, m, own)
             ok = [m for m in range(M) if not at_gate[m]]
             if ok:
                 err = float(np.abs(got[ok] - want[ok]).max())
