@@ -286,7 +286,7 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     times = []
     gc.collect()

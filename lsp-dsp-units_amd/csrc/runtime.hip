@@ -234,6 +234,10 @@ int mi_dspu_graph_end_capture(void *stream, void **graph_exec)
     const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     MI_HIP_CHECK(e);
+    // the executable graph's device-side image goes up now instead of inside the first launch (best effort: a runtime that
+    // cannot upload simply does it at that launch)
+    if (hipGraphUpload(exec, mi::as_stream(stream)) != hipSuccess)
+        (void)hipGetLastError();
     *graph_exec = exec;
     return MI_OK;
 }

@@ -35,3 +35,24 @@ def region_graph():
     torch.cuda.synchronize(); return time.perf_counter() - t0
 ts = sorted(region_graph() for _ in range(R))
 print("one graph launch:   median region %.1f us = %.2f us per call (min %.1f)" % (ts[R // 2] * 1e6, ts[R // 2] * 1e6 / K, ts[0] * 1e6))
+
+# ---- what the fence around a 20-call region costs: plain synchronize, a polling wait, and an uploaded graph -------------------
+hip = ctypes.CDLL("libamdhip64.so")
+S = ctypes.c_void_p(st.cuda_stream)
+def region_poll():
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    mi.lib.mi_dspu_graph_launch(exe, S)
+    while hip.hipStreamQuery(S) != 0:
+        pass
+    return time.perf_counter() - t0
+ts = sorted(region_poll() for _ in range(R))
+print("graph + polling wait: median region %.1f us = %.2f us per call (min %.1f)" % (ts[R // 2] * 1e6, ts[R // 2] * 1e6 / K, ts[0] * 1e6))
+try:
+    rc = hip.hipGraphUpload(exe, S)
+    torch.cuda.synchronize()
+    ts = sorted(region_graph() for _ in range(R))
+    print("uploaded graph (rc %d): median region %.1f us = %.2f us per call (min %.1f)" % (rc, ts[R // 2] * 1e6, ts[R // 2] * 1e6 / K, ts[0] * 1e6))
+    ts = sorted(region_poll() for _ in range(R))
+    print("uploaded + polling:   median region %.1f us = %.2f us per call (min %.1f)" % (ts[R // 2] * 1e6, ts[R // 2] * 1e6 / K, ts[0] * 1e6))
+except Exception as e:
+    print("hipGraphUpload:", e)
