@@ -201,18 +201,20 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
     avg_ms = sum(kernel_ms) / len(kernel_ms)
     chk = yout[(warmup + steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
+    bank_faults = bank.faults(stream=stream)
     bank.close()
     del xin, yout
     torch.cuda.empty_cache()
     if rank != 0:
         return None, irs
-    # dominant kernel conv_mac_kernel: per channel-frame it reads (P-1) IR images and (P-1) ring images of
-    # 32 KiB each and writes one 32 KiB image
+    # dominant kernel conv_step_kernel = the whole step in one launch (frame role + tail role): per
+    # channel-frame the tail role reads (P-1) IR images and (P-1) ring images of 32 KiB each and writes one, the frame role
+    # moves the rest of SURVEY.md 8d's 272 B per channel-sample at P = 16
     img = 8 * frame
-    mac_bytes = float(C) * (2 * (P - 1) + 1) * img
-    # whole step: 272 B per channel-sample at P = 16
     step_bytes = float(C) * frame * 16.0 * (P + 1)
+    mac_bytes = step_bytes
     achieved = mac_bytes / (avg_ms * 1e-3) / 1e9
+    assert bank_faults == 0, "the roles of conv_step_kernel gave up waiting for each other %d times" % bank_faults
     res = {
         "value": round(C * frame * world * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
         "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
@@ -222,7 +224,7 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
                    "images_read_per_step_MiB": round(float(C) * 2 * (P - 1) * img / 2 ** 20, 1)},
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("pmc_convolver_latest.json") if C == 256 else None,
-                     "kernel": "conv_mac_kernel",
+                     "kernel": "conv_step_kernel<12>",
                      "kernel_avg_us": round(avg_ms * 1e3, 3), "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3),
                      "kernel_samples": len(kernel_ms), "algorithmic_bytes_per_launch": mac_bytes},
         "whole_step": {"algorithmic_bytes": step_bytes,

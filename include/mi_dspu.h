@@ -324,6 +324,9 @@ int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *bank, const floa
                                            const uint8_t *channels, void *stream);
 /* Convolver::destroy(), Convolver.cpp:71-75. */
 int mi_convolver_bank_destroy(mi_convolver_bank_t *bank);
+/* Diagnostic (synchronises the stream): how often the two roles of the one-launch frame step gave up waiting for each other
+ * (about a second each; 0 on a healthy device -- DESIGN.md 3.2). */
+int mi_convolver_bank_faults(mi_convolver_bank_t *bank, uint32_t *count, void *stream);
 /* Forget all input history (state right after init). */
 int mi_convolver_bank_reset(mi_convolver_bank_t *bank, void *stream);
 /* Convolver::rank() / data_size() (Convolver.h:100-106) plus the partition geometry in use. */

@@ -94,6 +94,7 @@ PROTOTYPES = {
     "mi_convolver_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_void_p, c_size_t, c_void_p, c_uint32, c_uint32,
                                          c_float, c_void_p]),
     "mi_convolver_bank_destroy": (c_int, [c_void_p]),
+    "mi_convolver_bank_faults": (c_int, [c_void_p, POINTER(c_uint32), c_void_p]),
     "mi_convolver_bank_reset": (c_int, [c_void_p, c_void_p]),
     "mi_convolver_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                        POINTER(c_uint32)]),

@@ -98,19 +98,24 @@ namespace
     }
 
     // ---- whole frame --------------------------------------------------------------------------------------
-    template <int LOGM>
-    __global__ __launch_bounds__(plan<LOGM>::T)
-    void conv_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
-                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
-                           float *acc, const float2 *__restrict__ Yt /* pending tail or NULL */,
-                           const float2 *__restrict__ tw,
-                           float *dl_ring /* or NULL */, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head,
-                           bool upper_zero /* acc[B:2B] is known to hold zeros: neither read nor re-zeroed */)
+    // One workgroup, one channel.  `done` (or NULL): a per-channel counter the workgroup bumps once the frame's image is in
+    // the ring and the pending tail has been consumed -- the tail role of conv_step_kernel waits for it.
+    // LEAN: operands of the later phases are loaded where they are used instead of up front -- for conv_step_kernel, whose
+    // frame role is not on the critical path but must leave half of the register file to the tail role's waves.
+    template <int LOGM, bool LEAN>
+    __device__ __forceinline__
+    void frame_role(float2 *buf, float2 *scr, const int ch,
+                    float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
+                    float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
+                    float *acc, const float2 *__restrict__ Yt /* pending tail or NULL */,
+                    const float2 *__restrict__ tw,
+                    float *dl_ring /* or NULL */, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head,
+                    bool upper_zero /* acc[B:2B] is known to hold zeros: neither read nor re-zeroed */,
+                    uint32_t *done)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
-        __shared__ float2 buf[M], scr[M];
-        const int ch = blockIdx.x, tid = threadIdx.x;
+        const int tid = threadIdx.x;
         MI_CPROBE(0);
         // Request order = order of use (vmcnt counts in order): twiddles, the frame, then the operands of the later
         // phases -- the head partition's image, the pending tail and the overlap-add accumulator wait in registers.
@@ -148,18 +153,21 @@ namespace
         const float2 *h0 = H + size_t(ch) * P * M;
         const float2 *yt = (Yt != nullptr) ? Yt + size_t(ch) * M : nullptr;
         float *a = acc + size_t(ch) * 2 * B;
-        float2 hreg[KPT], yreg[KPT], a0[NPT], a1[NPT];
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
+        float2 hreg[LEAN ? 1 : KPT], yreg[LEAN ? 1 : KPT], a0[LEAN ? 1 : NPT], a1[LEAN ? 1 : NPT];
+        if (!LEAN)
         {
-            hreg[i] = h0[tid + i * T];
-            yreg[i] = (yt != nullptr) ? yt[tid + i * T] : make_float2(0.0f, 0.0f);
-        }
-        #pragma unroll
-        for (int i = 0; i < NPT; ++i)
-        {
-            a0[i] = *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T));
-            a1[i] = upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                hreg[i] = h0[tid + i * T];
+                yreg[i] = (yt != nullptr) ? yt[tid + i * T] : make_float2(0.0f, 0.0f);
+            }
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+            {
+                a0[i] = *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T));
+                a1[i] = upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
+            }
         }
         MI_CPROBE(1);
         rf.prepare();
@@ -179,9 +187,17 @@ namespace
             const int k = tid + i * T;
             const float2 xk = buf[k];
             mi::wt_store(rring, k * int(sizeof(float2)), xk);        // dropped by the bounds check when there is no ring
-            buf[k] = cadd(image_mul(xk, hreg[i], k), yreg[i]);
+            const float2 hk = LEAN ? h0[k] : hreg[i];
+            const float2 yk = LEAN ? ((yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f)) : yreg[i];
+            buf[k] = cadd(image_mul(xk, hk, k), yk);
         }
+        // The image went to the ring with write-through stores; they are complete (vmcnt 0: the workgroup-scope fence)
+        // before the counter moves.  NOT a device-scope release fence: that writes back the whole L2 of the XCD.
+        if (done != nullptr)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __syncthreads();
+        if (done != nullptr && tid == 0)
+            __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MI_CPROBE(3);
         rf.inverse(buf, scr, tid);
         MI_CPROBE(4);
@@ -195,7 +211,9 @@ namespace
         {
             const int n = tid + i * T;
             const float2 y0 = buf[n], y1 = buf[n + M / 2];
-            const float2 r = make_float2(fmaf(y0.x, scale, a0[i].x), fmaf(y0.y, scale, a0[i].y));
+            const float2 p0 = LEAN ? *reinterpret_cast<const float2 *>(a + 2 * n) : a0[i];
+            const float2 p1 = !LEAN ? a1[i] : upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * n);
+            const float2 r = make_float2(fmaf(y0.x, scale, p0.x), fmaf(y0.y, scale, p0.y));
             if (aligned)
                 mi::wt_store(rout, 8 * n, r);
             else
@@ -203,11 +221,147 @@ namespace
                 mi::wt_store(rout, 8 * n, r.x);
                 mi::wt_store(rout, 8 * n + 4, r.y);
             }
-            mi::wt_store(racc, 8 * n, make_float2(fmaf(y1.x, scale, a1[i].x), fmaf(y1.y, scale, a1[i].y)));
+            mi::wt_store(racc, 8 * n, make_float2(fmaf(y1.x, scale, p1.x), fmaf(y1.y, scale, p1.y)));
             if (!upper_zero)
                 mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
         }
         MI_CPROBE(5);
+    }
+
+    template <int LOGM>
+    __global__ __launch_bounds__(plan<LOGM>::T)
+    void conv_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
+                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
+                           float *acc, const float2 *__restrict__ Yt, const float2 *__restrict__ tw,
+                           float *dl_ring, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head, bool upper_zero)
+    {
+        constexpr int M = plan<LOGM>::N;
+        __shared__ float2 buf[M], scr[M];
+        frame_role<LOGM, false>(buf, scr, blockIdx.x, out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc, Yt, tw,
+                                dl_ring, dl_size, dl_tail, dl_head, upper_zero, nullptr);
+    }
+
+    // ---- whole frame AND the tail owed to the next one, in one launch (P >= 2) ------------------------------------------
+    // Workgroups 0 .. C-1 are the frame role above (latency bound: load, two transforms, store); workgroups C .. 2C-1
+    // stream the channel's tail  Yt' = sum_{p>=1} H_p X_(k+1-p)  (bandwidth bound: H and the ring once) at the same
+    // time -- one of each fits a CU (8 + 8 waves at <= 128 VGPRs, 2 x 64 KiB of LDS), so the frame role's 12 us disappear
+    // under the stream instead of preceding it: 43.7 us per step at C3 against 50.4 us as two launches.
+    // Partitions p >= 2 only need frames that were in the ring before the launch; the p = 1 term needs THIS frame's image:
+    // the tail role takes it last, after the frame workgroup of its channel has bumped `done` (which also says that the
+    // pending Yt has been consumed, so Yt can be overwritten).  The hand-over uses device-scope ATOMIC accesses only
+    // (relaxed counter, write-through stores of the image, device-scope loads of it) -- a device-scope release / acquire
+    // fence writes back / invalidates the whole L2 of the XCD, once per workgroup and once per poll: the first version of
+    // this kernel took 118 us per step for that reason alone.
+    // Frame workgroups have the lower indices and the dispatcher hands workgroups out in index order, so whatever a tail
+    // workgroup waits for has already been started; a wait that does not end (about a second) bumps `fault`
+    // (mi_convolver_bank_faults) and gives up instead of hanging the device.  `seen` is the tail role's private count of
+    // the frames it has taken.
+    template <int LOGM, bool NT>
+    __global__ __launch_bounds__(plan<LOGM>::T, 2)
+    void conv_step_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
+                          float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
+                          float *acc, float2 *Yt, bool yt_pending, const float2 *__restrict__ tw, bool upper_zero,
+                          int channels, uint32_t *done, uint32_t *seen, uint32_t *fault)
+    {
+        using PL = plan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
+        __shared__ float2 buf[M], scr[M];
+        if (int(blockIdx.x) < channels)
+        {
+            frame_role<LOGM, true>(buf, scr, blockIdx.x, out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc,
+                                   yt_pending ? Yt : nullptr, tw, nullptr, 0u, 0u, 0u, upper_zero, done);
+            return;
+        }
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int ch = int(blockIdx.x) - channels, tid = threadIdx.x;
+        const f4 *Hc = reinterpret_cast<const f4 *>(H + size_t(ch) * P * M);
+        const f4 *Xc = reinterpret_cast<const f4 *>(ring + size_t(ch) * R * M);
+        f4 s[J];
+        float dc = 0.0f, ny = 0.0f;                             // bin 0 packs (DC, Nyquist): thread 0, j = 0
+        #pragma unroll
+        for (int j = 0; j < J; ++j)
+            s[j] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+        auto mac = [&](const f4 h, const f4 x, int j)
+        {
+            s[j].z = fmaf(x.z, h.z, fmaf(-x.w, h.w, s[j].z));
+            s[j].w = fmaf(x.z, h.w, fmaf(x.w, h.z, s[j].w));
+            s[j].x = fmaf(x.x, h.x, fmaf(-x.y, h.y, s[j].x));
+            s[j].y = fmaf(x.x, h.y, fmaf(x.y, h.x, s[j].y));
+            if (j == 0)
+            {
+                dc = fmaf(x.x, h.x, dc);
+                ny = fmaf(x.y, h.y, ny);
+            }
+        };
+        int r = (slot == 0) ? R - 1 : slot - 1;                 // the frame before this one
+        #pragma unroll 2
+        for (int p = 2; p < P; ++p)
+        {
+            f4 h[J], x[J];
+            #pragma unroll
+            for (int j = 0; j < J; ++j)
+            {
+                const int idx = tid + j * T;
+                if (idx < M4)
+                {
+                    h[j] = NT ? __builtin_nontemporal_load(&Hc[size_t(p) * M4 + idx]) : Hc[size_t(p) * M4 + idx];
+                    x[j] = NT ? __builtin_nontemporal_load(&Xc[size_t(r) * M4 + idx]) : Xc[size_t(r) * M4 + idx];
+                }
+            }
+            r = (r == 0) ? R - 1 : r - 1;
+            #pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (tid + j * T < M4)
+                    mac(h[j], x[j], j);
+        }
+        // this frame's image
+        f4 h1[J];
+        #pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (tid + j * T < M4)
+                h1[j] = NT ? __builtin_nontemporal_load(&Hc[size_t(1) * M4 + tid + j * T]) : Hc[size_t(1) * M4 + tid + j * T];
+        if (tid == 0)
+        {
+            const uint32_t target = seen[ch] + 1u;
+            uint32_t spins = 0;
+            while (int32_t(__hip_atomic_load(done + ch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0)
+            {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > (1u << 22))
+                {
+                    atomicAdd(fault, 1u);
+                    break;
+                }
+            }
+            seen[ch] = target;
+        }
+        __syncthreads();
+        // this frame's image: device-scope loads (past the L2 of this XCD, which never held these lines in this launch anyway)
+        #pragma unroll
+        for (int j = 0; j < J; ++j)
+        {
+            const int idx = tid + j * T;
+            if (idx < M4)
+            {
+                const unsigned long long *q = reinterpret_cast<const unsigned long long *>(&Xc[size_t(slot) * M4 + idx]);
+                const unsigned long long lo = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned long long hi = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                f4 xk;
+                xk.x = __uint_as_float(unsigned(lo)); xk.y = __uint_as_float(unsigned(lo >> 32));
+                xk.z = __uint_as_float(unsigned(hi)); xk.w = __uint_as_float(unsigned(hi >> 32));
+                mac(h1[j], xk, j);
+            }
+        }
+        if (tid == 0)
+        {
+            s[0].x = dc;
+            s[0].y = ny;
+        }
+        f4 *dst = reinterpret_cast<f4 *>(Yt + size_t(ch) * M);
+        #pragma unroll
+        for (int j = 0; j < J; ++j)
+            if (tid + j * T < M4)
+                dst[tid + j * T] = s[j];
     }
 
     // ---- tail of the next frame: Yt = sum_{p=1..P-1} H_p * X_(newest - (p-1)) ------------------------------
@@ -528,6 +682,7 @@ struct mi_convolver_bank
     bool        live = false;       // false: count == 0, process() emits zeros (Convolver.cpp:219-223)
     bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
     bool        upper_zero = false; // acc[B:2B] holds zeros (true between whole frames: the frame kernel skips that half)
+    uint32_t   *d_sync = nullptr;   // [done[channels] | seen[channels] | fault]: hand-over between the roles of conv_step_kernel
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
@@ -587,6 +742,45 @@ namespace
                                   b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = true;
+        return MI_OK;
+    }
+
+    // A whole frame from the caller's block: frame and tail roles in one launch when there is a tail (P >= 2)
+    int launch_frame(mi_convolver_bank *b, float *o, const float *x, size_t out_stride, size_t in_stride, bool aligned, hipStream_t st)
+    {
+        if (b->R > 0)
+            b->slot = (b->slot + 1) % b->R;
+        if (b->P >= 2)
+        {
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            mi::take_profile_events(&ev0, &ev1);
+            const size_t working_set = size_t(b->channels) * size_t(b->P - 1) * size_t(b->B) * sizeof(float2) * 2;
+            static const int force_nt = getenv("MI_CONV_NT") ? atoi(getenv("MI_CONV_NT")) : -1;    // experiment knob: 0 / 1
+            const bool nt = (force_nt >= 0) ? (force_nt != 0) : (working_set > (size_t(256) << 20));
+            uint32_t *done = b->d_sync, *seen = b->d_sync + b->channels, *fault = b->d_sync + 2 * size_t(b->channels);
+            #define MI_CALL(LM) \
+                if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(2 * b->channels), dim3(plan<LM>::T), 0, st, ev0, ev1, \
+                                  o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
+                                  b->yt_pending, b->d_tw, b->upper_zero, int(b->channels), done, seen, fault); \
+                else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(2 * b->channels), dim3(plan<LM>::T), 0, st, ev0, ev1, \
+                                  o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
+                                  b->yt_pending, b->d_tw, b->upper_zero, int(b->channels), done, seen, fault)
+            MI_LOGM_SWITCH(b->logm, MI_CALL)
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            b->yt_pending = true;
+            b->upper_zero = true;
+            return MI_OK;
+        }
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                                               o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
+                                               b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
+                                               static_cast<float *>(nullptr), 0u, 0u, 0u, b->upper_zero)
+        MI_LOGM_SWITCH(b->logm, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        b->yt_pending = false;
+        b->upper_zero = true;
         return MI_OK;
     }
 
@@ -720,6 +914,8 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_yt), size_t(channels) * M * sizeof(float2));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_acc), size_t(channels) * 2 * M * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_frame), size_t(channels) * M * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_sync), (2 * size_t(channels) + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMemsetAsync(b->d_sync, 0, (2 * size_t(channels) + 1) * sizeof(uint32_t), st);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_h0), size_t(channels) * M * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_ir), size_t(channels) * b->P * M * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_counts), channels * sizeof(uint32_t));
@@ -911,6 +1107,18 @@ int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *b, const float *
     return MI_OK;
 }
 
+int mi_convolver_bank_faults(mi_convolver_bank_t *b, uint32_t *count, void *stream)
+{
+    MI_REQUIRE(b != nullptr && count != nullptr, MI_EINVAL, "mi_convolver_bank_faults: bad argument");
+    *count = 0;
+    if (b->d_sync == nullptr)
+        return MI_OK;
+    hipStream_t st = mi::as_stream(stream);
+    MI_HIP_CHECK(hipMemcpyAsync(count, b->d_sync + 2 * size_t(b->channels), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    MI_HIP_CHECK(hipStreamSynchronize(st));
+    return MI_OK;
+}
+
 int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
 {
     if (b == nullptr)
@@ -926,7 +1134,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
         (void)hipFree(r.h0);
     }
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
-    (void)hipFree(b->d_xmask); (void)hipFree(b->d_only);
+    (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     delete b;
     return MI_OK;
 }
@@ -1029,18 +1237,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
         {
             const bool aligned = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) % 8 == 0) &&
                                  (out_stride % 2 == 0) && (in_stride % 2 == 0);
-            if (b->R > 0)
-                b->slot = (b->slot + 1) % b->R;
-            #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
-                                                   o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
-                                                   b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
-                                                   static_cast<float *>(nullptr), 0u, 0u, 0u, b->upper_zero)
-            MI_LOGM_SWITCH(b->logm, MI_CALL)
-            #undef MI_CALL
-            MI_HIP_CHECK(hipGetLastError());
-            b->yt_pending = false;
-            b->upper_zero = true;
-            const int r = launch_mac(b, st);
+            const int r = launch_frame(b, o, x, out_stride, in_stride, aligned, st);
             if (r != MI_OK)
                 return r;
             b->frame_open = false;

@@ -171,6 +171,12 @@ class ConvolverBank:
         check(lib.mi_convolver_bank_info(self.handle, *[byref(x) for x in v]))
         return dict(zip(("rank", "frame", "partitions", "data_size"), [x.value for x in v]))
 
+    def faults(self, stream=None):
+        """How often the two roles of the one-launch frame step gave up waiting for each other (0 on a healthy device)."""
+        n = c_uint32(0)
+        check(lib.mi_convolver_bank_faults(self.handle, byref(n), _stream(stream)))
+        return int(n.value)
+
     def reset(self, stream=None):
         check(lib.mi_convolver_bank_reset(self.handle, _stream(stream)))
 

@@ -35,6 +35,7 @@ def run_gpu(gpu, irs, rank, x, chunks, counts=None, in_place=False):
         pos += c
     assert pos == n
     info = bank.info()
+    assert bank.faults() == 0                                # the one-launch frame step never gave up a hand-over
     bank.close()
     return y, info
 
@@ -135,6 +136,7 @@ def test_uninitialised_bank_outputs_zero(gpu):
     bank.process(dout, din, 100)
     np.testing.assert_array_equal(dout.download(), np.zeros((2, 100), np.float32))
     assert bank.info()["rank"] == 0
+    assert bank.faults() == 0                                # the one-launch frame step never gave up a hand-over
     bank.close()
 
 
@@ -154,6 +156,7 @@ def test_reset_and_linearity(gpu):
     din.upload(x * np.float32(4.0))
     bank.process(dout, din, 2048)
     np.testing.assert_array_equal(dout.download(), y1 * np.float32(4.0))   # power-of-two scaling is exact
+    assert bank.faults() == 0                                # the one-launch frame step never gave up a hand-over
     bank.close()
 
 
@@ -209,4 +212,5 @@ def test_random_geometry_and_call_sizes(gpu, seed):
             peak = max(float(np.abs(ref).max()), 1.0)
             err = float(np.abs(y[c] - ref).max())
             assert err <= 2 * TOL * peak, (seed, step, c, k, rank, taps, int(counts[c]), err / peak)
+    assert bank.faults() == 0                                # the one-launch frame step never gave up a hand-over
     bank.close()
