@@ -261,19 +261,20 @@ namespace
     void conv_step_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                           float *acc, float2 *Yt, bool yt_pending, const float2 *__restrict__ tw, bool upper_zero,
-                          int channels, uint32_t *done, uint32_t *seen, uint32_t *fault)
+                          int channels /* of this launch */, int first /* its first channel */,
+                          uint32_t *done, uint32_t *seen, uint32_t *fault)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
         __shared__ float2 buf[M], scr[M];
         if (int(blockIdx.x) < channels)
         {
-            frame_role<LOGM, true>(buf, scr, blockIdx.x, out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc,
+            frame_role<LOGM, true>(buf, scr, first + int(blockIdx.x), out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc,
                                    yt_pending ? Yt : nullptr, tw, nullptr, 0u, 0u, 0u, upper_zero, done);
             return;
         }
         typedef float f4 __attribute__((ext_vector_type(4)));
-        const int ch = int(blockIdx.x) - channels, tid = threadIdx.x;
+        const int ch = first + int(blockIdx.x) - channels, tid = threadIdx.x;
         const f4 *Hc = reinterpret_cast<const f4 *>(H + size_t(ch) * P * M);
         const f4 *Xc = reinterpret_cast<const f4 *>(ring + size_t(ch) * R * M);
         f4 s[J];
@@ -758,16 +759,26 @@ namespace
             static const int force_nt = getenv("MI_CONV_NT") ? atoi(getenv("MI_CONV_NT")) : -1;    // experiment knob: 0 / 1
             const bool nt = (force_nt >= 0) ? (force_nt != 0) : (working_set > (size_t(256) << 20));
             uint32_t *done = b->d_sync, *seen = b->d_sync + b->channels, *fault = b->d_sync + 2 * size_t(b->channels);
-            #define MI_CALL(LM) \
-                if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(2 * b->channels), dim3(plan<LM>::T), 0, st, ev0, ev1, \
-                                  o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
-                                  b->yt_pending, b->d_tw, b->upper_zero, int(b->channels), done, seen, fault); \
-                else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(2 * b->channels), dim3(plan<LM>::T), 0, st, ev0, ev1, \
-                                  o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
-                                  b->yt_pending, b->d_tw, b->upper_zero, int(b->channels), done, seen, fault)
-            MI_LOGM_SWITCH(b->logm, MI_CALL)
-            #undef MI_CALL
-            MI_HIP_CHECK(hipGetLastError());
+            // One frame and one tail workgroup per CU run side by side; with more channels than CUs the frame workgroups
+            // (lower indices, dispatched first) would take both places of every CU and the tail role would follow them
+            // instead of overlapping: such banks go in launches of one CU-count of channels each.
+            static const int cus = []{ int n = 0, dev = 0; (void)hipGetDevice(&dev); return (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
+            const int per_launch = (b->logm >= 12) ? cus : int(b->channels);      // (smaller transforms: several workgroups fit a CU anyway)
+            for (int first = 0; first < int(b->channels); first += per_launch)
+            {
+                const int cnt = std::min(per_launch, int(b->channels) - first);
+                hipEvent_t e0 = (first == 0) ? ev0 : nullptr, e1 = (first + cnt >= int(b->channels)) ? ev1 : nullptr;
+                #define MI_CALL(LM) \
+                    if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(2 * cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
+                                      o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
+                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault); \
+                    else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(2 * cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
+                                      o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
+                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault)
+                MI_LOGM_SWITCH(b->logm, MI_CALL)
+                #undef MI_CALL
+                MI_HIP_CHECK(hipGetLastError());
+            }
             b->yt_pending = true;
             b->upper_zero = true;
             return MI_OK;

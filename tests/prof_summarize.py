@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-KERNELS = {"biquad": "biquad_bank_kernel", "convolver": "conv_mac_kernel", "equalizer": "conv_frame_kernel",
+KERNELS = {"biquad": "biquad_bank_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frame_kernel",
            "spectral": "analyzer_kernel"}
 
 

@@ -214,3 +214,22 @@ def test_random_geometry_and_call_sizes(gpu, seed):
             assert err <= 2 * TOL * peak, (seed, step, c, k, rank, taps, int(counts[c]), err / peak)
     assert bank.faults() == 0                                # the one-launch frame step never gave up a hand-over
     bank.close()
+
+
+def test_more_channels_than_compute_units(gpu):
+    """The one-launch frame step pairs a frame and a tail workgroup per CU; a bank with more channels than the device has
+    CUs goes in several such launches per frame.  300 channels at rank 13 (distinct three-partition responses), whole frames
+    and a ragged tail; channels on both sides of the launch boundary against exact float64 convolution and, a few, the oracle."""
+    rng = np.random.default_rng(31)
+    C, taps, n = 300, 9000, 3 * 4096 + 777
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 3000.0)).astype(np.float32)
+    x = (rng.standard_normal((C, n)) * 0.3).astype(np.float32)
+    y, info = run_gpu(gpu, irs, 13, x, [4096, 4096, 4096, 777])
+    assert info["frame"] == 4096 and info["partitions"] == 3
+    for c in (0, 1, 128, 254, 255, 256, 257, 299):
+        ex = exact_conv(x[c], irs[c])
+        err = float(np.abs(y[c] - ex).max()) / float(np.abs(ex).max())
+        assert err <= TOL, (c, err)
+    for c in (255, 256):
+        ref = oracle.Convolver(irs[c], 13).process_chunked(x[c], 4096)
+        check(y[c], ref, exact_conv(x[c], irs[c]), "channel %d" % c)
