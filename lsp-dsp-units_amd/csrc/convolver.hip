@@ -252,9 +252,10 @@ namespace
     // (relaxed counter, write-through stores of the image, device-scope loads of it) -- a device-scope release / acquire
     // fence writes back / invalidates the whole L2 of the XCD, once per workgroup and once per poll: the first version of
     // this kernel took 118 us per step for that reason alone.
-    // Frame workgroups have the lower indices and the dispatcher hands workgroups out in index order, so whatever a tail
-    // workgroup waits for has already been started; a wait that does not end (about a second) bumps `fault`
-    // (mi_convolver_bank_faults) and gives up instead of hanging the device.  `seen` is the tail role's private count of
+    // Frame workgroups have the lower indices and every XCD's dispatcher hands out its share of the grid in index order: a
+    // tail workgroup is only placed after every frame workgroup of its XCD has been placed, frame workgroups never wait for
+    // anything, so no cycle of waiting workgroups can form whatever the channel count; a wait that does not end (about a
+    // second) bumps `fault` (mi_convolver_bank_faults) and gives up instead of hanging the device.  `seen` is the tail role's private count of
     // the frames it has taken.
     template <int LOGM, bool NT>
     __global__ __launch_bounds__(plan<LOGM>::T, 2)
@@ -267,14 +268,19 @@ namespace
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
         __shared__ float2 buf[M], scr[M];
-        if (int(blockIdx.x) < channels)
+        // (the role boundary is `channels` rounded up to the 8 XCDs the workgroups are dealt to in turn: both workgroups of a
+        // channel then sit on the same XCD, whose dispatcher hands out its share of the grid in index order -- frame before tail)
+        const int boundary = (channels + 7) & ~7;
+        if (int(blockIdx.x) < boundary)
         {
+            if (int(blockIdx.x) >= channels)
+                return;
             frame_role<LOGM, true>(buf, scr, first + int(blockIdx.x), out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc,
                                    yt_pending ? Yt : nullptr, tw, nullptr, 0u, 0u, 0u, upper_zero, done);
             return;
         }
         typedef float f4 __attribute__((ext_vector_type(4)));
-        const int ch = first + int(blockIdx.x) - channels, tid = threadIdx.x;
+        const int ch = first + int(blockIdx.x) - boundary, tid = threadIdx.x;
         const f4 *Hc = reinterpret_cast<const f4 *>(H + size_t(ch) * P * M);
         const f4 *Xc = reinterpret_cast<const f4 *>(ring + size_t(ch) * R * M);
         f4 s[J];
@@ -769,10 +775,10 @@ namespace
                 const int cnt = std::min(per_launch, int(b->channels) - first);
                 hipEvent_t e0 = (first == 0) ? ev0 : nullptr, e1 = (first + cnt >= int(b->channels)) ? ev1 : nullptr;
                 #define MI_CALL(LM) \
-                    if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(2 * cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
+                    if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(((cnt + 7) & ~7) + cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
                                       b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault); \
-                    else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(2 * cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
+                    else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(((cnt + 7) & ~7) + cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
                                       b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault)
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
