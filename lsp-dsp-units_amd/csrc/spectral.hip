@@ -338,6 +338,15 @@ namespace
         ib[i] = ib[i + frame];
     }
 
+#ifdef MI_AN_PROBE
+    // phase timestamps of thread 0 of every workgroup (tests/experiments/analyzer_probe.hip)
+    __device__ unsigned long long g_an_probe[4096 * 8];
+    #define MI_APROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) \
+        g_an_probe[blockIdx.x * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+    #define MI_APROBE(slot) do { } while (0)
+#endif
+
     // ---- analyzer -------------------------------------------------------------------------------------------
     // ring: [channels][buf_size]; the frame of channel c ends `delay[c]` samples before `head`.
     // amp_old: vAmp as of the strobe (what get_spectrum() shows until the next strobe: the reference copies vAmp to vData
@@ -356,7 +365,16 @@ namespace
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
         __shared__ float2 buf[H], scr[H];
         const int ch = blockIdx.x, tid = threadIdx.x;
+        MI_APROBE(0);
+        // Everything the launch needs is requested before anything is waited for (in-kernel timeline,
+        // tests/experiments/analyzer_probe.hip: the two dependent little loads -- the channel's flags, then its delay for the
+        // frame's address -- used to cost two exposed latencies before the frame was even asked for, and the new samples were
+        // only asked for when the spectrum had been stored): twiddles, flags AND delay, then the frame, the spectrum being
+        // smoothed and the samples to ingest.
+        real_fft<LOGH> rf;
+        rf.load(tw, TWN, tid);
         const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
+        const uint32_t dly = delay[ch];
         const float *a = amp_old + size_t(ch) * amp_stride;
         float *an = amp_new + size_t(ch) * amp_stride;
         float *rbw = ring + size_t(ch) * buf_size;
@@ -383,12 +401,9 @@ namespace
                 an[k] = 0.0f;
             return;
         }
-        // request order = order of use: twiddles, the frame, then the spectrum being smoothed (one exposed HBM latency)
-        real_fft<LOGH> rf;
-        rf.load(tw, TWN, tid);
         constexpr int KPT = (H + T - 1) / T;
         // Analyzer.cpp:339-353: doff = head - (fft_size + delay), wrapped into the ring
-        int64_t doff = int64_t(head) - int64_t(N) - int64_t(delay[ch]);
+        int64_t doff = int64_t(head) - int64_t(N) - int64_t(dly);
         while (doff < 0)
             doff += buf_size;
         const float *rb = rbw;
@@ -412,13 +427,26 @@ namespace
             aold[i] = (tid + i * T < H) ? a[tid + i * T] : 0.0f;
         if (tid == 0)
             aold_h = a[H];
+        // the first IPF * T samples to ingest wait in registers
+        constexpr int IPF = 8;
+        float ing[IPF];
+        #pragma unroll
+        for (int j = 0; j < IPF; ++j)
+        {
+            const uint32_t i = tid + j * T;
+            ing[j] = (i < ingest_n && !ingest_zero) ? ingest[size_t(ch) * ingest_stride + i] : 0.0f;
+        }
+        MI_APROBE(1);
         rf.prepare();
+        MI_APROBE(2);
         #pragma unroll
         for (int i = 0; i < KPT; ++i)
             if (tid + i * T < H)
                 buf[tid + i * T] = make_float2(xin[i].x * win[i].x, xin[i].y * win[i].y);
         __syncthreads();
+        MI_APROBE(3);
         rf.forward(buf, scr, tid);
+        MI_APROBE(4);
         // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
         const float keep = 1.0f - tau;
         const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(an, unsigned((H + 1) * sizeof(float)));
@@ -434,11 +462,21 @@ namespace
         }
         if (tid == 0)
             mi::wt_store(ramp, 4 * H, aold_h * keep + fabsf(buf[0].y) * tau);
+        MI_APROBE(5);
         // ring ingest: cells head .. head + ingest_n - 1 (mod size), none of them inside a window read above
         if (ingest_n > 0)
         {
             const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
-            for (uint32_t i0 = 0; i0 < ingest_n; i0 += IPT * T)
+            #pragma unroll
+            for (int j = 0; j < IPF; ++j)
+            {
+                const uint32_t i = tid + j * T;
+                uint32_t w = head + i;
+                if (w >= buf_size) w -= buf_size;
+                if (i < ingest_n)
+                    mi::wt_store(rring, int(w * sizeof(float)), ing[j]);
+            }
+            for (uint32_t i0 = IPF * T; i0 < ingest_n; i0 += IPT * T)
             {
                 float v[IPT];
                 #pragma unroll
@@ -458,6 +496,7 @@ namespace
                 }
             }
         }
+        MI_APROBE(6);
     }
 
     // ---- analyzer frames above 2^14 samples: the steps of analyzer_kernel as plain launches around the four-step transform

@@ -99,6 +99,13 @@ namespace
         constexpr bool all = !PER_BAND;
         const uint32_t h0 = all ? 0 : blockIdx.y, h1 = all ? handlers : blockIdx.y + 1;
         const bool owner = all || (blockIdx.y == 0);
+        // the frame is asked for before the handler descriptors are looked at (their little dependent loads would otherwise
+        // cost an exposed latency before the frame's own: tests/experiments/analyzer_probe.hip found that pattern)
+        const float2 *x2 = reinterpret_cast<const float2 *>(in_cur + size_t(ch) * in_pitch);
+        float2 xr[PER];
+        #pragma unroll
+        for (int i = 0; i < PER; ++i)
+            xr[i] = (tid + i * T < H) ? x2[tid + i * T] : make_float2(0.0f, 0.0f);
         bool masks = WRITE_SPEC && owner;
         for (uint32_t h = h0; h < h1; ++h)
             masks = masks || (hd[h].mode == H_MASK && hd[h].has_sink);
@@ -110,13 +117,7 @@ namespace
         real_fft<LOGH> rf;
         if (masks)
             rf.load(tw, TWN, tid);
-        const float2 *x2 = reinterpret_cast<const float2 *>(in_cur + size_t(ch) * in_pitch);
         const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
-
-        float2 xr[PER];
-        #pragma unroll
-        for (int i = 0; i < PER; ++i)
-            xr[i] = (tid + i * T < H) ? x2[tid + i * T] : make_float2(0.0f, 0.0f);
         if (masks)
             rf.prepare();
         #pragma unroll
