@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=50)
-    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral", "crossover", "splitter", "loudness", "dynfilter"],
+    ap.add_argument("--workload", default="all", choices=["all", "biquad", "convolver", "equalizer", "spectral", "stft", "crossover", "splitter", "loudness", "dynfilter"],
                     help="all = headline biquad line with the convolver result attached under \"convolver\"")
     ap.add_argument("--channels", type=int, default=1024, help="channels per GPU")
     ap.add_argument("--samples", type=int, default=4096, help="samples per block")
@@ -454,6 +454,32 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     }
 
 
+def run_spectral_processor(args, mi, torch, dist, rank, world, dev):
+    """Row a10: SpectralProcessor with a fused gain mask, rank 12 (frames of 4096 samples, hops of 2048), 1024 channels x
+    4096 samples per step = two hops per channel.  Algorithmic bytes: 4 B in + 4 B out per channel-sample."""
+    import numpy as np
+    C, rank_fft, n = 1024, 12, 4096
+    sp = mi.SpectralBank(C, rank_fft)
+    sp.set_rank(rank_fft)
+    sp.bind_mask(np.linspace(1.0, 0.25, (1 << (rank_fft - 1)) + 1).astype(np.float32))
+    ring = 4
+    gen = torch.Generator(device="cpu"); gen.manual_seed(90 + rank)
+    xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
+    yout = torch.empty_like(xin)
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        sp.process(yout[i % ring], xin[i % ring], n, stream=stream)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    assert bool(torch.isfinite(yout).all()) and float(yout.abs().max()) > 0.0
+    sp.close()
+    if rank != 0:
+        return None
+    return _step_result("spectral_processor", "SpectralProcessor with a gain mask, rank 12, %d channels per GPU, 4096-sample blocks "
+                        "(two hops: one launch each -- transform, gains, inverse, overlap-add, emission and intake fused)" % C,
+                        C, n, args.conv_steps, elapsed, world, 8.0)
+
+
 def _step_result(name, workload, C, n, steps, elapsed, world, bytes_per_sample, extra=None):
     """Sub-result of a SURVEY 8f row: whole-step throughput against the algorithmic bytes (several launches per step)."""
     step_bytes = float(bytes_per_sample) * C * n
@@ -603,8 +629,8 @@ def main():
     mi.check(mi.lib.mi_dspu_set_device(local_rank))
     import workloads as wl
 
-    if args.workload in ("convolver", "equalizer", "spectral", "crossover", "splitter", "loudness", "dynfilter"):
-        runner = {"convolver": run_convolver, "equalizer": run_equalizer, "spectral": run_spectral,
+    if args.workload in ("convolver", "equalizer", "spectral", "stft", "crossover", "splitter", "loudness", "dynfilter"):
+        runner = {"convolver": run_convolver, "equalizer": run_equalizer, "spectral": run_spectral, "stft": run_spectral_processor,
                   "crossover": run_crossover, "splitter": run_splitter, "loudness": run_loudness,
                   "dynfilter": run_dynfilter}[args.workload]
         res = runner(args, mi, torch, dist, rank, world, dev)
@@ -708,6 +734,9 @@ def main():
         conv = run_convolver(args, mi, torch, dist, rank, world, dev)
         eqr = run_equalizer(args, mi, torch, dist, rank, world, dev)
         spr = run_spectral(args, mi, torch, dist, rank, world, dev)
+        spp = run_spectral_processor(args, mi, torch, dist, rank, world, dev)
+        if spr is not None:
+            spr["spectral_processor"] = spp
         nxt = {name: fn(args, mi, torch, dist, rank, world, dev)
                for name, fn in (("dynfilter", run_dynfilter), ("crossover", run_crossover), ("splitter", run_splitter),
                                 ("loudness", run_loudness))}

@@ -135,6 +135,91 @@ namespace
         }
     }
 
+    // A whole hop of a streaming call in ONE launch (operations NONE and MASK, SpectralProcessor's timing): the hop of
+    // stft_hop_kernel, then what process() would do with two more launches -- the frame that the overlap-add has just
+    // finished goes to the caller's `dst`, and the caller's next `frame` samples enter the input buffer behind the shift.
+    // Every global operand is requested up front (twiddles, frame, window, the output buffer's second half, the new
+    // samples, the gains); the second half of the frame stays in registers for the shift instead of being read again.
+    // Pairs: a frame of N = 2H samples is H float2 pairs, a hop is H/2 pairs; thread t owns pairs t + i T, so pair m and
+    // pair m + H/2 belong to the same thread (KPT = H / T is even: LOGH >= 7).
+    template <int LOGH, bool MASKED>
+    __global__ __launch_bounds__(plan<LOGH>::T, (plan<LOGH>::T <= 256) ? 4 : (plan<LOGH>::T <= 512) ? 2 : 1)   // <= 128 VGPRs: four waves per SIMD
+    void stft_stream_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in, const float *__restrict__ wnd_out,
+                            const float *__restrict__ mask, size_t mask_stride, const float2 *__restrict__ tw,
+                            const float *__restrict__ src, size_t src_stride, float *dst, size_t dst_stride)
+    {
+        using PL = plan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H, KPT = H / T, HPT = KPT / 2;
+        static_assert(KPT >= 2 && (KPT & 1) == 0 && KPT * T == H, "stft_stream_kernel needs an even number of pairs per thread");
+        __shared__ float2 buf[H], scr[H];
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        real_fft<LOGH> rf;
+        if (MASKED)
+            rf.load(tw, TWN, tid);
+        float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * N);
+        float2 *o2 = reinterpret_cast<float2 *>(out_buf + size_t(ch) * N);
+        const float2 *wi = reinterpret_cast<const float2 *>(wnd_in);
+        const float2 *wo = reinterpret_cast<const float2 *>(wnd_out);
+        const float2 *s2 = reinterpret_cast<const float2 *>(src + size_t(ch) * src_stride);
+        float2 *d2 = reinterpret_cast<float2 *>(dst + size_t(ch) * dst_stride);
+        float2 xr[KPT], wr[KPT], prev[HPT], fresh[HPT];
+        float gk[MASKED ? KPT : 1];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            xr[i] = x2[tid + i * T];
+            wr[i] = (wi != nullptr) ? wi[tid + i * T] : make_float2(1.0f, 1.0f);
+        }
+        #pragma unroll
+        for (int i = 0; i < HPT; ++i)
+        {
+            prev[i]  = o2[tid + i * T + H / 2];
+            fresh[i] = s2[tid + i * T];
+        }
+        float g_nyquist = 0.0f;
+        if (MASKED)
+        {
+            const float *mk = mask + size_t(ch) * mask_stride;          // H + 1 real gains
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                gk[i] = mk[tid + i * T];
+            g_nyquist = mk[H];
+            rf.prepare();
+        }
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            buf[tid + i * T] = make_float2(xr[i].x * wr[i].x, xr[i].y * wr[i].y);
+        __syncthreads();
+        if (MASKED)
+        {
+            rf.forward(buf, scr, tid);
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = tid + i * T;
+                float2 v = buf[k];
+                if (k == 0) { v.x *= gk[i]; v.y *= g_nyquist; }
+                else        { v.x *= gk[i]; v.y *= gk[i]; }
+                buf[k] = v;
+            }
+            __syncthreads();
+            rf.inverse(buf, scr, tid);
+        }
+        const float scale = MASKED ? 1.0f / float(N) : 1.0f;
+        #pragma unroll
+        for (int i = 0; i < HPT; ++i)
+        {
+            const int m = tid + i * T;
+            const float2 y0 = buf[m], w0 = wo[m], y1 = buf[m + H / 2], w1 = wo[m + H / 2];
+            const float2 done = make_float2(fmaf(y0.x * scale, w0.x, prev[i].x), fmaf(y0.y * scale, w0.y, prev[i].y));
+            o2[m]         = done;
+            o2[m + H / 2] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+            d2[m]         = done;                                       // the finished frame, straight to the caller
+            x2[m]         = xr[i + HPT];                                // the input buffer moves on by half a frame ...
+            x2[m + H / 2] = fresh[i];                                   // ... and takes the caller's next frame
+        }
+    }
+
     // CALLBACK path, second half.  The function may have broken the Hermitian symmetry of the spectrum and only the real
     // part of the inverse is kept (SpectralProcessor.cpp:168-169): Re ifft(S) = ifft of S's Hermitian part
     // (S[k] + conj S[N-k]) / 2, so the way back is the same half-size real transform as the way there.
@@ -1052,6 +1137,32 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
         // soon as the frame is complete (:324): the samples are the same, the moment the function is called is not
         if (!b->eager && b->offset >= frame)
         {
+            // a whole frame follows in this call: the hop, the emission of the frame it finishes and the intake of the next
+            // one in a single launch (stft_stream_kernel) instead of a hop and two strided copies
+            static const bool no_stream = getenv("MI_SPECTRAL_NO_STREAM") != nullptr;          // experiment knob
+            const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
+            const bool plain = (b->op == MI_SPECTRAL_OP_NONE) || !bound, masked = bound && (b->op == MI_SPECTRAL_OP_MASK);
+            const bool aligned = ((reinterpret_cast<uintptr_t>(in + done) | reinterpret_cast<uintptr_t>(out + done)) % 8 == 0) &&
+                                 (in_stride % 2 == 0) && (out_stride % 2 == 0);
+            if (!no_stream && out != nullptr && (plain || masked) && b->rank >= 8 && b->rank <= 13 && count - done >= frame && aligned &&
+                b->d_active == nullptr)
+            {
+                const int lh = int(b->rank) - 1;
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                mi::take_profile_events(&ev0, &ev1);
+                const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
+                #define MI_CALL(LH) \
+                    if (masked) MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), true>), dim3(b->channels), dim3(plan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
+                                          b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->mask_stride, b->d_tw, in + done, in_stride, out + done, out_stride); \
+                    else        MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), false>), dim3(b->channels), dim3(plan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
+                                          b->d_in, b->d_out, wi, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_tw, in + done, in_stride, out + done, out_stride)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+                MI_HIP_CHECK(hipGetLastError());
+                b->offset = uint32_t(frame);
+                done += frame;
+                continue;
+            }
             const int r = spectral_hop(b, st, analyze_only);
             if (r != MI_OK)
                 return r;
