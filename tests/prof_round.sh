@@ -15,7 +15,7 @@ for W in biquad convolver equalizer spectral; do
         rocprofv3 --pmc $C --kernel-trace -d $O/pmc_${W}_$C --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --steps 50 --conv-steps 50 > $O/pmc_${W}_$C.log 2>&1
     done
 done
-for W in dynfilter crossover splitter loudness; do       # kernel summary only
+for W in stft dynfilter crossover splitter loudness; do       # row a10's streaming hop and the SURVEY 8f rows: kernel summary only
     rocprofv3 --kernel-trace --stats -d $O/stats_$W --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline > $O/stats_$W.log 2>&1
 done
 python3 $R/tests/prof_summarize.py $O $R/gpurun_out/profiles_$TAG $TAG

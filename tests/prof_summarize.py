@@ -20,7 +20,7 @@ def main():
     src, dst, tag = sys.argv[1], sys.argv[2], sys.argv[3]
     os.makedirs(dst, exist_ok=True)
     raw = {}
-    for wl in list(KERNELS) + ["dynfilter", "crossover", "splitter", "loudness"]:
+    for wl in list(KERNELS) + ["stft", "dynfilter", "crossover", "splitter", "loudness"]:
         stats = glob.glob(os.path.join(src, "stats_" + wl, "**", "*kernel_stats.csv"), recursive=True)
         if stats:
             with open(stats[0]) as f:
