@@ -5,7 +5,7 @@
 #include <cstdio>
 #include <vector>
 using namespace mi_fft;
-constexpr int TWN = 8192;
+
 
 template <int LOGM>
 __global__ __launch_bounds__(plan<LOGM>::T)
