@@ -55,6 +55,7 @@ class ILUFSMeter:
         # diagnostic for the tests, not part of the restated state: how close (relative) any gating block evaluated since
         # the last clear() came to the absolute gate -- a block the gate DROPS leaves no other trace when the mean runs on
         self.gate_margin = float("inf")
+        self.call_gate_margin = float("inf")                 # the same over the blocks evaluated by the last process() call
 
     def set_designation(self, i, d):
         self.ch[i]["weight"] = channel_weighting(d)
@@ -155,6 +156,7 @@ class ILUFSMeter:
         """x: [channels][n] -> integrated loudness per sample [n] (as a gain)."""
         # update_settings() returns early when no flag is set; F_BLK_FULL counts as a flag and is wiped with the rest
         self._update()
+        self.call_gate_margin = float("inf")
         x = np.asarray(x, np.float32)
         n = x.shape[1]
         out = np.zeros(n, np.float32)
@@ -182,7 +184,9 @@ class ILUFSMeter:
                         b = c["block"]
                         s = F(F(F(F(b[0] + b[1]) + b[2]) + b[3]) * self.avg)
                         loud = F(loud + F(c["weight"] * s))
-                    self.gate_margin = min(self.gate_margin, abs(float(loud) - float(GATING_ABS_THRESH)) / float(GATING_ABS_THRESH))
+                    margin = abs(float(loud) - float(GATING_ABS_THRESH)) / float(GATING_ABS_THRESH)
+                    self.gate_margin = min(self.gate_margin, margin)
+                    self.call_gate_margin = min(self.call_gate_margin, margin)
                     if self.ms_int > 0:
                         self.ms_count = min(self.ms_count + 1, self.ms_int)
                         self.hist[self.ms_head] = loud

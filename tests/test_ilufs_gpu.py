@@ -193,8 +193,10 @@ def test_random_operation_sequences(gpu, seed):
                     continue
                 live = [(r.ms_head + r.ms_size - 1 - k) % r.ms_size for k in range(r.ms_count)]
                 near = [i for i in live if abs(float(h[i]) - GATE) < 0.05 * GATE]
-                at_gate[m] = bool(near)
-                if not near:
+                # (a borderline block may also have come AND gone inside this call when the window is short: the oracle notes
+                # how close any block evaluated by the call came -- seed 23821 of the round-2 sweep, a window of one block)
+                at_gate[m] = bool(near) or r.call_gate_margin < 0.05
+                if not at_gate[m]:
                     continue
                 assert int(head[m]) == r.ms_head and int(count[m]) == r.ms_count, (seed, step, m)
                 gh = hist[m].astype(np.float64)
