@@ -33,7 +33,8 @@ namespace
     __global__ __launch_bounds__(plan<LOGH>::T)
     void stft_hop_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in,
                          const float *__restrict__ wnd_out, const float *__restrict__ mask, size_t mask_stride,
-                         float2 *spec, const uint8_t *__restrict__ active, const float2 *__restrict__ tw)
+                         float2 *spec, const uint8_t *__restrict__ active, const float2 *__restrict__ tw,
+                         const float *io_src, size_t io_src_stride, float *io_dst, size_t io_dst_stride)
     {
         using PL = plan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
@@ -51,6 +52,20 @@ namespace
         const float2 *wo = reinterpret_cast<const float2 *>(wnd_out);
         const bool on = (active == nullptr) || (active[ch] != 0);
 
+        if (MODE == 2 && io_src != nullptr)
+        {
+            // MultiSpectralProcessor's timing with a whole frame in one call (process() would do this with two strided
+            // copies before the hop): the frame the last overlap-add finished goes to the caller, the caller's frame
+            // becomes the second half of the input buffer.  Pair-aligned rows.
+            const float2 *s2 = reinterpret_cast<const float2 *>(io_src + size_t(ch) * io_src_stride);
+            float2 *d2 = reinterpret_cast<float2 *>(io_dst + size_t(ch) * io_dst_stride);
+            for (int m = tid; m < H / 2; m += T)
+            {
+                d2[m] = o2[m];
+                x2[m + H / 2] = s2[m];
+            }
+            __syncthreads();                                // other threads of the workgroup read these cells below
+        }
         if (MODE != 3)
         {
             // frame * input window, packed as z[m] = x[2m] + i x[2m+1]
@@ -868,7 +883,10 @@ namespace
         return MI_OK;
     }
 
-    int spectral_hop(mi_spectral_bank *b, hipStream_t st, bool analyze_only = false)
+    // io_src / io_dst (callback operation only): the whole frame the hop transforms is taken from the caller and the frame
+    // finished by the previous hop handed out inside the hop's first launch (see stft_hop_kernel)
+    int spectral_hop(mi_spectral_bank *b, hipStream_t st, bool analyze_only = false, const float *io_src = nullptr,
+                     size_t io_src_stride = 0, float *io_dst = nullptr, size_t io_dst_stride = 0)
     {
         if (b->rank > 14)
             return spectral_hop_big(b, st, analyze_only);
@@ -879,7 +897,7 @@ namespace
             if (b->op == MI_SPECTRAL_OP_CALLBACK && b->func != nullptr)
             {
                 #define MI_CALL(LH) hipLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, \
-                    b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
+                    b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw, (const float *)nullptr, size_t(0), (float *)nullptr, size_t(0))
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
@@ -897,7 +915,7 @@ namespace
         {
             #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 0>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), (float2 *)nullptr, \
-                (const uint8_t *)nullptr, b->d_tw)
+                (const uint8_t *)nullptr, b->d_tw, (const float *)nullptr, size_t(0), (float *)nullptr, size_t(0))
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
         }
@@ -905,14 +923,14 @@ namespace
         {
             #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 1>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, b->d_mask, b->mask_stride, (float2 *)nullptr, \
-                (const uint8_t *)nullptr, b->d_tw)
+                (const uint8_t *)nullptr, b->d_tw, (const float *)nullptr, size_t(0), (float *)nullptr, size_t(0))
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
         }
         else
         {
             #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
-                b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw)
+                b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw, io_src, io_src_stride, io_dst, io_dst_stride)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
@@ -1169,6 +1187,22 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             b->offset = 0;
         }
         const size_t n = (count - done < frame - b->offset) ? count - done : frame - b->offset;
+        // MultiSpectralProcessor's timing, a bound function and a whole frame in this piece: the hand-out of the finished frame
+        // and the intake of the new one ride on the hop's first launch instead of two strided copies
+        if (b->eager && b->offset == 0 && n == frame && out != nullptr && b->op == MI_SPECTRAL_OP_CALLBACK && b->func != nullptr &&
+            b->rank <= 14 && (reinterpret_cast<uintptr_t>(in + done) | reinterpret_cast<uintptr_t>(out + done)) % 8 == 0 &&
+            in_stride % 2 == 0 && out_stride % 2 == 0)
+        {
+            static const bool no_stream = getenv("MI_SPECTRAL_NO_STREAM") != nullptr;
+            if (!no_stream)
+            {
+                const int r = spectral_hop(b, st, false, in + done, in_stride, out + done, out_stride);
+                if (r != MI_OK)
+                    return r;
+                done += frame;                                  // offset stays 0: the frame was complete and is transformed
+                continue;
+            }
+        }
         if (n > 0)
         {
             MI_HIP_CHECK(hipMemcpy2DAsync(b->d_in + frame + b->offset, N * sizeof(float), in + done, in_stride * sizeof(float),
