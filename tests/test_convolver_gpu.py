@@ -233,3 +233,21 @@ def test_more_channels_than_compute_units(gpu):
     for c in (255, 256):
         ref = oracle.Convolver(irs[c], 13).process_chunked(x[c], 4096)
         check(y[c], ref, exact_conv(x[c], irs[c]), "channel %d" % c)
+
+
+def test_more_workgroups_than_the_device_holds(gpu):
+    """6000 channels at rank 9: the one-launch frame step is a grid of 12 000 single-wave workgroups, more than can be resident
+    at once, so tail workgroups are dispatched while frame workgroups are still queued behind others -- the hand-over must not
+    depend on everybody being resident (frame workgroups come first in every XCD's share of the grid).  Whole frames and a
+    ragged tail; channels spread over the grid against exact float64 convolution; no hand-over may have timed out."""
+    rng = np.random.default_rng(33)
+    C, rank, frame = 6000, 9, 256
+    taps = 3 * frame + 5
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 300.0)).astype(np.float32)
+    x = (rng.standard_normal((C, 5 * frame + 100)) * 0.3).astype(np.float32)
+    y, info = run_gpu(gpu, irs, rank, x, [frame, 2 * frame, frame, frame, 100])
+    assert info["frame"] == frame and info["partitions"] == 4
+    for c in list(range(0, C, 509)) + [C - 1]:
+        ex = exact_conv(x[c], irs[c])
+        err = float(np.abs(y[c] - ex).max()) / float(np.abs(ex).max())
+        assert err <= TOL, (c, err)
