@@ -616,6 +616,11 @@ def main():
     # and talk over gloo -- RCCL refuses two ranks on one device.  It exercises the N > 1 control flow (sharding,
     # barriers, max over ranks, the bin all-reduce); its numbers mean nothing and the JSON line says so.
     rehearsal = world > 1 and os.environ.get("MI_BENCH_REHEARSAL", "0") == "1"
+    if world > 1 and os.environ.get("MASTER_ADDR", "127.0.0.1") in ("127.0.0.1", "localhost"):
+        # one node: the collectives' bootstrap goes over loopback (the data over xGMI); without this RCCL probes every
+        # interface of the box first, which takes minutes where there is no network
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     if world > 1:
         dist.init_process_group(backend="gloo" if rehearsal or not torch.cuda.is_available() else "nccl")
     if not torch.cuda.is_available():

@@ -629,6 +629,10 @@ def test_library_communicator_single_rank(gpu):
     """mi_dspu_comm_* / mi_analyzer_bank_allreduce_bins on the one GPU of the box: RCCL is found and bound at run time,
     a one-rank communicator comes up, and the in-place all-reduce of the reduced bins returns them unchanged (the sum
     over one rank).  The N > 1 arithmetic is covered by the composition test above and the gloo test on the CPU."""
+    import os
+    # one node, no network on the test boxes: RCCL's bootstrap otherwise probes interfaces that time out (minutes on some boxes)
+    os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+    os.environ.setdefault("NCCL_IB_DISABLE", "1")
     rank, hop, C = 10, 512, 64
     bins = (1 << (rank - 1)) + 1
     bank = _analyzer(gpu, C, rank, hop)
