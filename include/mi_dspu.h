@@ -419,7 +419,10 @@ int mi_spectral_bank_bind_channels(mi_spectral_bank_t *bank, const uint8_t *has_
 int mi_spectral_bank_reset(mi_spectral_bank_t *bank, void *stream);
 /* process(dst, src, count), SpectralProcessor.cpp:147-199.  With out == NULL: process(src, count), :201-249 -- analysis
  * only: the function is called on every frame, nothing is transformed back and the output buffer is shifted and its
- * tail zeroed instead of overlap-added (MultiSpectralProcessor timing: out == NULL just skips the copy-out). */
+ * tail zeroed instead of overlap-added (MultiSpectralProcessor timing: out == NULL just skips the copy-out).
+ * Throughput note: a call that hands over whole frames from rows whose pointers are 8-byte aligned and whose strides are
+ * even is one launch per hop for the operations NONE and MASK at ranks 8..13 (two around the function for CALLBACK with
+ * MultiSpectralProcessor's timing); anything else adds two strided copies per piece. */
 int mi_spectral_bank_process(mi_spectral_bank_t *bank, float *out, const float *in, size_t count,
                              size_t out_stride, size_t in_stride, void *stream);
 /* When a complete frame is transformed: eager == 0 (default) when the next sample arrives, as SpectralProcessor does
