@@ -322,12 +322,16 @@ int mi_convolver_bank_set_irs_device(mi_convolver_bank_t *bank, const float *irs
  */
 int mi_convolver_bank_crossfade_irs_device(mi_convolver_bank_t *bank, const float *irs, size_t ir_stride, uint32_t count,
                                            const uint8_t *channels, void *stream);
-/* Convolver::destroy(), Convolver.cpp:71-75. */
+/* Convolver::destroy(), Convolver.cpp:71-75.  MI_EHIP (the bank is freed all the same) if a hand-over had timed out, see
+ * mi_convolver_bank_faults. */
 int mi_convolver_bank_destroy(mi_convolver_bank_t *bank);
 /* Diagnostic (synchronises the stream): how often the two roles of the one-launch frame step gave up waiting for each other
- * (about a second each; 0 on a healthy device -- DESIGN.md 3.2). */
+ * (about a second each; 0 on a healthy device -- DESIGN.md 3.2).  A fault is not silent: it raises a host-visible flag, and
+ * from then on mi_convolver_bank_process (without synchronising), this call and mi_convolver_bank_destroy return MI_EHIP
+ * until mi_convolver_bank_reset -- the frame in which it happened and everything after it is invalid.  The one-launch step
+ * is used on gfx950 only; MI_CONV_TWO_LAUNCH=1 in the environment selects the two-launch form (no in-launch waiting). */
 int mi_convolver_bank_faults(mi_convolver_bank_t *bank, uint32_t *count, void *stream);
-/* Forget all input history (state right after init). */
+/* Forget all input history (state right after init); clears a recorded fault. */
 int mi_convolver_bank_reset(mi_convolver_bank_t *bank, void *stream);
 /* Convolver::rank() / data_size() (Convolver.h:100-106) plus the partition geometry in use. */
 int mi_convolver_bank_info(const mi_convolver_bank_t *bank, uint32_t *rank, uint32_t *frame,

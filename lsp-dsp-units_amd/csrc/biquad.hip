@@ -148,7 +148,7 @@ namespace
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "biquad.hip relies on gfx950 (CDNA4) behaviour: wave64 DPP row/bank semantics and arrival-counting s_barrier"
 #endif
-    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false>
+    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, bool ROLES = false>
     __device__ __forceinline__
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
@@ -159,11 +159,13 @@ namespace
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
         constexpr int LPT = W / 4;                          // float4 per lane and sub-block
         constexpr int NT = 64 * NW;
+        constexpr int XW = ROLES ? 1 : NW;                  // waves that share one section of one super-block
+        static_assert(!ROLES || (NW == 2 && !CHAIN && !SUMSQ), "the two-role form is the plain kernel with two waves");
         constexpr int TAB_QL = TAB_PQ + 2 * L;
 
         __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
         __shared__ float2 sstate[2][SG];                    // state carried between super-blocks, by parity
-        __shared__ float2 xchg[2][SG][NW];                  // end state of every wave's sub-block
+        __shared__ float2 xchg[2][ROLES ? 1 : SG][NW];      // end state of every wave's sub-block
 
         const int ch   = blockIdx.x;
         const int tid  = threadIdx.x;
@@ -180,7 +182,7 @@ namespace
         const int ns   = stage_ns(0);
         if (!CHAIN && ns < 0)                               // row switched off: state kept, output not written
             return;
-        float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile
+        float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile (ROLES: the tile in hand)
         const bool lane0 = (t == 0), row3 = (t >= 48);
         const float *ctab = stage_tab(0);                   // this channel's table rows (uniform address)
         // Buffer descriptors over the channel's n samples: reads past the end return 0, writes past the end are
@@ -290,10 +292,10 @@ namespace
             // their program counter is, and the compiler is told nothing else (no convergent-region assumption is made
             // across the loop: the trip counts are wave-uniform).  On an architecture with split or named barriers this
             // hand-off has to be rewritten (NW - 1 uniform barrier sites with predicated work).
-            if (NW > 1)
+            if (XW > 1)
                 for (int v = 0; v < wv; ++v)
                     __syncthreads();
-            const float2 cs = (NW > 1 && wv > 0) ? xchg[par][si][wv - 1] : sstate[par][si];
+            const float2 cs = (XW > 1 && wv > 0) ? xchg[par][si][wv - 1] : sstate[par][si];
             const v2f cvec = lane0 ? v2f{cs.x, cs.y} : splat(0.0f);
             e = mat_fma(v2f{tb.m0[4], tb.m0[5]}, v2f{tb.m0[6], tb.m0[7]}, cvec, e);
 
@@ -312,11 +314,11 @@ namespace
                 const v2f s2 = mat_fma(v2f{tb.m1[12], tb.m1[13]}, v2f{tb.m1[14], tb.m1[15]}, s, zero);
                 e = mat_fma(QLc0, QLc1, row3 ? s2 : s, e);
             }
-            if (NW > 1)
+            if (XW > 1)
             {
                 if (t == 63)
                     xchg[par][si][wv] = make_float2(e.x, e.y);
-                for (int v = wv; v < NW - 1; ++v)
+                for (int v = wv; v < XW - 1; ++v)
                     __syncthreads();
             }
 
@@ -419,6 +421,96 @@ namespace
             add_chunk(q.x, base + t * W, false);
             add_chunk(q.y, base + t * W + L, true);
         };
+
+
+        // ---- two roles (ROLES): the sections split between the two waves, the tiles pipelined ---------------------
+        // The plain two-wave form above gives each wave one sub-block and runs all sections on it: every wave of the chip
+        // loads, computes and stores at the same time, so the memory phases and the arithmetic add.  Here wave A runs the
+        // first half of the sections on tile after tile (2048 samples each) and hands every finished tile to wave B through
+        // LDS, in the chunk layout both use (no transposition in between); B runs the other half and stores.  A's loads of
+        // tile i + 1 fly under its sections on tile i, B's stores of tile i drain under its sections on tile i + 1, and
+        // between the tiles the state of a section stays inside ONE wave (no per-section hand-off, no per-section barrier).
+        // Two tile buffers: A fills buffer i & 1 (first with the rows as loaded, then with its result), B empties it and
+        // uses it once more to transpose its own result for the store.  Barrier i: A arrives once tile i is handed over,
+        // B once it is done with tile i - 1 -- so A never touches a buffer B still needs, and both waves execute exactly
+        // `tiles` barriers (s_barrier counts arrivals, see the note in `section`).
+        if constexpr (ROLES)
+        {
+            const int hA    = (ns + 1) >> 1;
+            const int s_lo  = wv ? hA : 0, s_hi = wv ? ns : hA; // this wave's sections
+            const int tiles = (n + SB - 1) / SB;
+            float *mem = stage_mem(0);
+            for (int i = s_lo + t; i < s_hi; i += 64)           // carried state of this wave's sections (wave-private cells;
+                sstate[0][i] = reinterpret_cast<const float2 *>(mem)[i];     // a wave's LDS accesses complete in order)
+            if (s_hi > s_lo)
+            {
+                load_pq(tb, ctab + size_t(s_lo) * TAB);
+                load_mats(tb, ctab + size_t(s_lo) * TAB);
+                load_coefs(tb, ctab + size_t(s_lo) * TAB);
+            }
+            if (wv == 0)
+                issue_loads(0);
+            else
+                __builtin_amdgcn_s_setprio(1);                  // B holds the finished half of the work: its stores go first
+            for (int i = 0; i < tiles; ++i)
+            {
+                const int par  = i & 1;
+                const int left = n - i * SB;
+                const int last = ((left < SB) ? left : SB) - 1;
+                const int t_last = last / W;
+                const bool save_hi = (last - t_last * W) >= L;
+                const bool saver   = (t == t_last);
+                sx = sx_all + par * 64 * PITCH;
+                if (wv == 0)
+                {
+                    #pragma unroll
+                    for (int k = 0; k < LPT; ++k)
+                    {
+                        const int j = 4 * (k * 64 + t);
+                        *reinterpret_cast<float4 *>(&sx[j + (j / W) * 4]) = ld[k];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    MI_PROBE(1 + 4 * i);
+                    if (i + 1 < tiles)
+                        issue_loads((i + 1) * SB);
+                }
+                else
+                {
+                    __syncthreads();                            // barrier i: tile i is in the buffer
+                    MI_PROBE(1 + 4 * i);
+                }
+                #pragma unroll
+                for (int k = 0; k < L / 4; ++k)
+                {
+                    const float4 a = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * k]);
+                    const float4 b = *reinterpret_cast<const float4 *>(&sx[t * PITCH + L + 4 * k]);
+                    x[4 * k + 0] = v2f{a.x, b.x}; x[4 * k + 1] = v2f{a.y, b.y};
+                    x[4 * k + 2] = v2f{a.z, b.z}; x[4 * k + 3] = v2f{a.w, b.w};
+                }
+                for (int si = s_lo; si < s_hi; ++si)
+                    section(tb, ctab + size_t((si + 1 < s_hi) ? si + 1 : s_lo) * TAB, si, par, saver, save_hi);
+                MI_PROBE(2 + 4 * i);
+                if (wv == 0)
+                {
+                    #pragma unroll
+                    for (int k = 0; k < L / 4; ++k)
+                    {
+                        *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
+                            make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
+                        *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * k]) =
+                            make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
+                    }
+                    __syncthreads();                            // barrier i: handed over
+                }
+                else
+                    store_block(orsrc, i * SB);
+                MI_PROBE(3 + 4 * i);
+            }
+            for (int i = s_lo + t; i < s_hi; i += 64)
+                reinterpret_cast<float2 *>(mem)[i] = sstate[tiles & 1][i];
+            MI_PROBE(15);
+            return;
+        }
 
         if (!CHAIN)
         {
@@ -616,6 +708,16 @@ namespace
                             const uint32_t *__restrict__ nsec, int max_sec)
     {
         biquad_body<L, NW, ALIGNED, false>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args());
+    }
+
+    // FilterBank::process for calls longer than one tile: two waves per channel in two roles (see ROLES in biquad_body)
+    template <bool ALIGNED>
+    __global__ __launch_bounds__(128, 2)
+    void biquad_roles_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
+                             int n /* multiple of 16 */, const float *__restrict__ tab, float *state,
+                             const uint32_t *__restrict__ nsec, int max_sec)
+    {
+        biquad_body<16, 2, ALIGNED, false, false, true>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args());
     }
 
     template <int L, int NW, bool ALIGNED>
@@ -1138,6 +1240,23 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
             e = launch<8, 4>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
         else if (force_nw == 82 && pq == nullptr)
             e = launch<8, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
+        else if (pq == nullptr && force_nw == 22 && b->max_sec <= uint32_t(big::SG))
+        {
+            // Experiment kept for reproducibility (profiles/r03_experiments/biquad_two_roles.txt: 15.3 us against 12.7 us --
+            // a wave that is alone on its SIMD runs the section code at 7 - 9.5 cycles per instruction, so the fill and the
+            // drain of the two-stage pipeline cost more than the overlapped memory phases save): two roles per channel,
+            // sections split between the waves, tiles pipelined
+            const dim3 grid(b->channels), block(128);
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            mi::take_profile_events(&ev0, &ev1);
+            if (aligned)
+                MI_LAUNCH((biquad_roles_kernel<true>), grid, block, 0, st, ev0, ev1, o, in + done, out_stride, in_stride,
+                          int(step), b->d_big, b->d_state, b->d_nsec, int(b->max_sec));
+            else
+                MI_LAUNCH((biquad_roles_kernel<false>), grid, block, 0, st, ev0, ev1, o, in + done, out_stride, in_stride,
+                          int(step), b->d_big, b->d_state, b->d_nsec, int(b->max_sec));
+            e = hipGetLastError();
+        }
         else
             e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq);
         MI_HIP_CHECK(e);

@@ -191,10 +191,14 @@ namespace
             const float2 yk = LEAN ? ((yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f)) : yreg[i];
             buf[k] = cadd(image_mul(xk, hk, k), yk);
         }
-        // The image went to the ring with write-through stores; they are complete (vmcnt 0: the workgroup-scope fence)
-        // before the counter moves.  NOT a device-scope release fence: that writes back the whole L2 of the XCD.
+        // The image went to the ring with write-through (sc1) stores; EVERY storing wave drains them (vmcnt 0) before it
+        // arrives at the barrier behind which thread 0 moves the counter.  The wait is written out: a workgroup-scope
+        // release only lowers to lgkmcnt(0) on gfx950 and s_barrier adds no vmcnt wait of its own, so without it the
+        // counter could overtake another wave's image stores (MI355X_MICROARCH.md, valid hand-off forms, condition 3).
+        // Inline asm: the waitcnt-insertion pass cannot drop it (build check: tests/test_abi.py greps the ISA for it).
+        // NOT a device-scope release fence: that writes back the whole L2 of the XCD.
         if (done != nullptr)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (done != nullptr && tid == 0)
             __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -254,16 +258,22 @@ namespace
     // this kernel took 118 us per step for that reason alone.
     // Frame workgroups have the lower indices and every XCD's dispatcher hands out its share of the grid in index order: a
     // tail workgroup is only placed after every frame workgroup of its XCD has been placed, frame workgroups never wait for
-    // anything, so no cycle of waiting workgroups can form whatever the channel count; a wait that does not end (about a
-    // second) bumps `fault` (mi_convolver_bank_faults) and gives up instead of hanging the device.  `seen` is the tail role's private count of
-    // the frames it has taken.
+    // anything, so no cycle of waiting workgroups can form whatever the channel count.  That index-ordered dispatch is OBSERVED
+    // behaviour of gfx950 (MI355X_MICROARCH.md, "Workgroup dispatch": blocks are dealt round-robin over the 8 XCDs, each XCD
+    // places its share in index order), not a HIP guarantee; the rounding to 8 below only keeps both roles of a channel on
+    // one XCD (speed).  Hence three safeguards: (1) the one-launch step is only used on gfx950 and can be switched off
+    // (MI_CONV_TWO_LAUNCH=1: conv_frame_kernel + conv_mac_kernel, no in-launch waiting at all); (2) a wait that does not end
+    // (about a second) bumps `fault` and raises the host-mapped `fault_host` and gives up instead of hanging the device;
+    // (3) the NEXT mi_convolver_bank_process / _faults / _destroy of the bank reports MI_EHIP once that flag is up (the frame
+    // in which it happened and everything after it is invalid until mi_convolver_bank_reset).  `seen` is the tail role's
+    // private count of the frames it has taken.
     template <int LOGM, bool NT>
     __global__ __launch_bounds__(plan<LOGM>::T, 2)
     void conv_step_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                           float *acc, float2 *Yt, bool yt_pending, const float2 *__restrict__ tw, bool upper_zero,
                           int channels /* of this launch */, int first /* its first channel */,
-                          uint32_t *done, uint32_t *seen, uint32_t *fault)
+                          uint32_t *done, uint32_t *seen, uint32_t *fault, uint32_t *fault_host)
     {
         using PL = plan<LOGM>;
         constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
@@ -337,6 +347,8 @@ namespace
                 if (++spins > (1u << 22))
                 {
                     atomicAdd(fault, 1u);
+                    // host-mapped word: the next process() call of the bank sees it without a synchronisation
+                    __hip_atomic_store(fault_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                     break;
                 }
             }
@@ -690,6 +702,10 @@ struct mi_convolver_bank
     bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
     bool        upper_zero = false; // acc[B:2B] holds zeros (true between whole frames: the frame kernel skips that half)
     uint32_t   *d_sync = nullptr;   // [done[channels] | seen[channels] | fault]: hand-over between the roles of conv_step_kernel
+    uint32_t   *h_fault = nullptr;  // host-mapped flag raised by a hand-over that timed out (read by process() without a sync)
+    uint32_t   *d_fault_host = nullptr;     // its device address
+    int         cus = 256;          // compute units of the device the bank lives on
+    bool        one_launch = true;  // whole-frame steps as conv_step_kernel (gfx950, not switched off) or as two launches
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
@@ -757,7 +773,7 @@ namespace
     {
         if (b->R > 0)
             b->slot = (b->slot + 1) % b->R;
-        if (b->P >= 2)
+        if (b->P >= 2 && b->one_launch)
         {
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             mi::take_profile_events(&ev0, &ev1);
@@ -768,8 +784,7 @@ namespace
             // One frame and one tail workgroup per CU run side by side; with more channels than CUs the frame workgroups
             // (lower indices, dispatched first) would take both places of every CU and the tail role would follow them
             // instead of overlapping: such banks go in launches of one CU-count of channels each.
-            static const int cus = []{ int n = 0, dev = 0; (void)hipGetDevice(&dev); return (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256; }();
-            const int per_launch = (b->logm >= 12) ? cus : int(b->channels);      // (smaller transforms: several workgroups fit a CU anyway)
+            const int per_launch = (b->logm >= 12) ? b->cus : int(b->channels);   // (smaller transforms: several workgroups fit a CU anyway)
             for (int first = 0; first < int(b->channels); first += per_launch)
             {
                 const int cnt = std::min(per_launch, int(b->channels) - first);
@@ -777,10 +792,10 @@ namespace
                 #define MI_CALL(LM) \
                     if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(((cnt + 7) & ~7) + cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
-                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault); \
+                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host); \
                     else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(((cnt + 7) & ~7) + cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
-                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault)
+                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host)
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
@@ -798,7 +813,7 @@ namespace
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = false;
         b->upper_zero = true;
-        return MI_OK;
+        return launch_mac(b, st);                                   // (nothing to do for P == 1)
     }
 
     // acc += IFFT(Yt): only the partial-call path needs the tail in the time domain
@@ -933,6 +948,28 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_frame), size_t(channels) * M * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_sync), (2 * size_t(channels) + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(b->d_sync, 0, (2 * size_t(channels) + 1) * sizeof(uint32_t), st);
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b->h_fault), sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess)
+    {
+        *b->h_fault = 0u;
+        e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_fault_host), b->h_fault, 0);
+    }
+    if (e == hipSuccess)
+    {
+        // The one-launch step leans on gfx950's index-ordered dispatch (see conv_step_kernel): other parts, and anyone who
+        // asks (MI_CONV_TWO_LAUNCH=1), get the frame kernel followed by the tail kernel.
+        int dev = 0, n = 0;
+        hipDeviceProp_t prop;
+        e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipGetDeviceProperties(&prop, dev);
+        if (e == hipSuccess)
+        {
+            if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+                b->cus = n;
+            const char *knob = getenv("MI_CONV_TWO_LAUNCH");
+            b->one_launch = (std::strncmp(prop.gcnArchName, "gfx950", 6) == 0) && !(knob != nullptr && atoi(knob) != 0);
+        }
+    }
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_h0), size_t(channels) * M * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_ir), size_t(channels) * b->P * M * sizeof(float));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_counts), channels * sizeof(uint32_t));
@@ -1133,6 +1170,9 @@ int mi_convolver_bank_faults(mi_convolver_bank_t *b, uint32_t *count, void *stre
     hipStream_t st = mi::as_stream(stream);
     MI_HIP_CHECK(hipMemcpyAsync(count, b->d_sync + 2 * size_t(b->channels), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     MI_HIP_CHECK(hipStreamSynchronize(st));
+    if (*count != 0)
+        return mi::fail(MI_EHIP, "mi_convolver_bank_faults: %u hand-over(s) between the roles of a frame step timed out; "
+                                 "the bank's output is invalid from that frame on until mi_convolver_bank_reset", *count);
     return MI_OK;
 }
 
@@ -1152,7 +1192,12 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     }
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
+    const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
+    (void)hipHostFree(b->h_fault);
     delete b;
+    if (faulted)
+        return mi::fail(MI_EHIP, "mi_convolver_bank_destroy: a hand-over between the roles of a frame step had timed out; "
+                                 "output of the bank after that frame was invalid");
     return MI_OK;
 }
 
@@ -1171,6 +1216,15 @@ int mi_convolver_bank_reset(mi_convolver_bank_t *b, void *stream)
     b->slot = 0;
     b->off  = 0;
     b->yt_pending = false;
+    if (b->d_sync != nullptr)                                           // hand-over counters and fault records start over
+        MI_HIP_CHECK(hipMemsetAsync(b->d_sync, 0, (2 * size_t(b->channels) + 1) * sizeof(uint32_t), st));
+    if (b->h_fault != nullptr)
+    {
+        // a launch that is still waiting could raise the flag after this point: let the stream drain first (only when it is up)
+        if (*static_cast<volatile uint32_t *>(b->h_fault) != 0u)
+            MI_HIP_CHECK(hipStreamSynchronize(st));
+        *static_cast<volatile uint32_t *>(b->h_fault) = 0u;
+    }
     // the frame being received is dropped; what is in force (and a fade that is still waiting) stays as it is: a fade that
     // had begun was taken at the reference's block boundary, its target is the response in force already
     b->frame_open = false;
@@ -1210,6 +1264,10 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
         MI_HIP_CHECK(hipMemset2DAsync(out, out_stride * sizeof(float), 0, samples * sizeof(float), b->channels, st));
         return MI_OK;
     }
+    // a hand-over inside an earlier frame step gave up (conv_step_kernel): what the bank has produced since is invalid
+    MI_REQUIRE(b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u, MI_EHIP,
+               "mi_convolver_bank_process: a hand-over between the roles of an earlier frame step timed out "
+               "(mi_convolver_bank_faults); the bank's output is invalid from that frame on until mi_convolver_bank_reset");
     const int B = b->B;
     size_t done = 0;
     while (done < samples)
