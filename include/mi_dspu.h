@@ -80,8 +80,11 @@ int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
  * convolver, equalizer, spectral processor, analyzer, splitter, loudness meters) hand ring positions kept on the host to
  * their kernels by value: end_capture() checks that the captured calls bring every such bank back to the positions it
  * started from and returns MI_ESTATE otherwise (capture a whole number of position periods: one lap of a delay line,
- * an even number of analyzer strobes, ...).  On a stream captured with hipStreamBeginCapture directly those banks'
- * process() returns MI_ESTATE and changes nothing.
+ * an even number of analyzer strobes, ...).  A refused capture is not lost work and leaves no inconsistent state: the
+ * captured calls are executed ONCE inside end_capture() (synchronising the stream), so device rings and host positions
+ * agree as after eager calls; no graph is returned.  Dynamic filters refuse capture (MI_ESTATE) while a clear of their
+ * filter memory is pending (right after init / set_sample_rate): make one eager call first.  On a stream captured with
+ * hipStreamBeginCapture directly those banks' process() returns MI_ESTATE and changes nothing.
  */
 int         mi_dspu_graph_begin_capture(void *stream);
 int         mi_dspu_graph_end_capture(void *stream, void **graph_exec);

@@ -806,6 +806,11 @@ int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, c
     MI_REQUIRE(gain != nullptr && gain_stride >= samples, MI_EINVAL, "mi_dynfilter_bank_process: bad gain buffer");
     if (b->clear_mem)                                           // :214-219: every filter's memory
     {
+        // a captured memset would zero the filter memory again on EVERY replay of the graph
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+            return mi::fail(MI_ESTATE, "mi_dynfilter_bank_process: a clear of the filter memory is pending (init / set_sample_rate): "
+                                       "make one eager call before capturing");
         MI_HIP_CHECK(hipMemsetAsync(b->d_state, 0, size_t(b->filters) * b->channels * CHAINS_MAX * 2 * sizeof(float), st));
         b->clear_mem = false;
     }

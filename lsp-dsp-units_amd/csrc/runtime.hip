@@ -226,9 +226,23 @@ int mi_dspu_graph_end_capture(void *stream, void **graph_exec)
     for (const capture_note &n : notes)
         if (n.fn(n.bank) != n.sig)
         {
+            // The banks' host-side positions have already moved on over the captured calls although no kernel ran.  Only a
+            // signature of the starting positions was kept, so they cannot be rolled back: instead the captured work is
+            // EXECUTED once here -- device rings and host positions agree again, exactly as if the calls had been made
+            // eagerly -- and the graph is dropped.  The caller goes on with eager calls (bench.py does).
+            hipGraphExec_t once = nullptr;
+            hipError_t e = hipGraphInstantiate(&once, graph, nullptr, nullptr, 0);
+            if (e == hipSuccess) e = hipGraphLaunch(once, mi::as_stream(stream));
+            if (e == hipSuccess) e = hipStreamSynchronize(mi::as_stream(stream));
+            if (once != nullptr) (void)hipGraphExecDestroy(once);
             (void)hipGraphDestroy(graph);
+            if (e != hipSuccess)
+                return mi::fail(MI_EHIP, "mi_dspu_graph_end_capture: the %s bank does not return to its starting positions over the "
+                                "captured calls, and running them once instead failed (%s): reset every bank the capture touched",
+                                n.what, hipGetErrorString(e));
             return mi::fail(MI_ESTATE, "mi_dspu_graph_end_capture: the %s bank does not return to its starting positions over the "
-                            "captured calls -- capture a whole number of its position periods (DESIGN.md 3.9)", n.what);
+                            "captured calls -- capture a whole number of its position periods (DESIGN.md 3.9).  The captured calls "
+                            "have been executed ONCE (device state and host positions agree); no graph was made", n.what);
         }
     hipGraphExec_t exec = nullptr;
     const hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);

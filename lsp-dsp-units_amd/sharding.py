@@ -36,6 +36,8 @@ def library_comm(mi, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) <= 1:
         return None
     rank, world = dist.get_rank(group), dist.get_world_size(group)
+    # broadcast_object_list takes the GLOBAL rank of the source: the group's rank 0 draws the id and sends it
+    src = dist.get_global_rank(group, 0) if group is not None else 0
     box = [mi.Comm.unique_id() if rank == 0 else None]
-    dist.broadcast_object_list(box, src=0, group=group)
+    dist.broadcast_object_list(box, src=src, group=group)
     return mi.Comm(box[0], world, rank)

@@ -244,3 +244,41 @@ def test_capture_behind_the_librarys_back_is_refused(gpu):
     assert b.get()["head"] == (head + n) % b.get()["size"]
     b.close()
     hip.hipStreamDestroy(s)
+
+
+def test_refused_capture_leaves_the_bank_consistent(gpu):
+    """end_capture() refuses a run that does not close a position period -- and by then the bank's host-side positions have
+    moved although no kernel ran.  The library executes the captured calls once in that case, so the eager calls that follow
+    (bench.py's fallback) continue the stream exactly as if every call had been eager."""
+    hip, s = _stream()
+    st = s.value
+    C, n = 5, 512
+    rng = np.random.default_rng(5)
+    xs = [(rng.standard_normal((C, n)) * 0.25).astype(np.float32) for _ in range(6)]
+
+    def make():
+        b = gpu.DelayBank(C, 1500)                           # a lap is four calls of 512
+        for c in range(C):
+            b.set_delay(90 + 170 * c, channel=c)
+        return b
+
+    bank, twin = make(), make()
+    ins = [gpu.DeviceBuffer.from_host(x, stream=st) for x in xs]
+    outs = [gpu.DeviceBuffer((C, n)) for _ in xs]
+    bank.process(outs[0], ins[0], n, gain=0.5, stream=st)                  # eager
+    gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+    gpu.check(gpu.lib.mi_dspu_graph_begin_capture(ctypes.c_void_p(st)))
+    for k in (1, 2):                                                       # two calls: half a lap, refused
+        bank.process(outs[k], ins[k], n, gain=0.5, stream=st)
+    exe = ctypes.c_void_p()
+    rc = gpu.lib.mi_dspu_graph_end_capture(ctypes.c_void_p(st), ctypes.byref(exe))
+    assert rc == -5 and not exe.value, (rc, gpu.lib.mi_dspu_last_error())
+    assert b"executed ONCE" in gpu.lib.mi_dspu_last_error()
+    for k in (3, 4, 5):                                                    # eager again
+        bank.process(outs[k], ins[k], n, gain=0.5, stream=st)
+    for k in range(6):
+        o = gpu.DeviceBuffer((C, n))
+        twin.process(o, ins[k], n, gain=0.5, stream=st)
+        np.testing.assert_array_equal(outs[k].download(stream=st), o.download(stream=st), err_msg="call %d" % k)
+    bank.close(); twin.close()
+    hip.hipStreamDestroy(s)

@@ -28,8 +28,9 @@ def _kernel_bodies(lines, name_part):
     i = 0
     while i < len(lines):
         l = lines[i]
-        if l.endswith(":") and name_part in l and l.startswith("_Z") and "@" not in l.split(":")[0]:
-            name = l.split(":")[0]
+        m = re.match(r"^(_Z\w+):", l)                       # "<mangled name>:  ; @<mangled name>"
+        if m and name_part in m.group(1):
+            name = m.group(1)
             j = i + 1
             while j < len(lines) and ".amdhsa_kernel" not in lines[j] and not lines[j].startswith(".Lfunc_end"):
                 j += 1
@@ -46,20 +47,25 @@ def test_conv_step_frame_role_drains_image_stores_before_the_counter(tmp_path):
     bodies = _kernel_bodies(lines, "conv_step_kernel")
     assert len(bodies) >= 12, sorted(bodies)               # 6 transform sizes x {plain, non-temporal}
     for name, body in bodies.items():
-        text = [l.strip() for l in body]
-        # the counter: the only returning-free atomic add behind a barrier in the frame role is the LAST atomic add of the body
-        adds = [i for i, l in enumerate(text) if l.startswith("global_atomic_add")]
-        assert adds, name
-        done_add = adds[-1]
-        barrier = max(i for i in range(done_add) if text[i].startswith("s_barrier"))
-        # last write-through store of the image before that barrier
-        stores = [i for i in range(barrier) if text[i].startswith("buffer_store") and " sc1" in text[i]]
-        assert stores, name
-        last_store = stores[-1]
-        window = text[last_store:barrier]
-        # the hand-written wait (inline asm is bracketed by ;;#ASMSTART / ;;#ASMEND) sits between the two
-        k = [i for i, l in enumerate(window) if l == ";;#ASMSTART"]
-        assert k and any(window[i + 1].replace(" ", "") == "s_waitcntvmcnt(0)" for i in k), (name, window[-12:])
-        # and nothing stores to memory between the wait and the barrier
-        w = max(i for i in k if window[i + 1].replace(" ", "") == "s_waitcntvmcnt(0)")
-        assert not [l for l in window[w:] if re.match(r"(buffer|global|flat)_store", l)], name
+        text = [l.strip() for l in body if l.strip() and not l.strip().startswith(";") or l.strip().startswith(";;#ASM")]
+        # the hand-written wait (inline asm is bracketed by ;;#ASMSTART / ;;#ASMEND)
+        waits = [i for i, l in enumerate(text) if l == ";;#ASMSTART" and text[i + 1].replace(" ", "") == "s_waitcntvmcnt(0)"]
+        assert len(waits) == 1, (name, len(waits))
+        w = waits[0]
+        # behind it: the workgroup barrier, reached without another store to memory, and then the counter's atomic add
+        labels = {l[:-1]: i for i, l in enumerate(text) if l.endswith(":")}
+        path, i = [], w
+        # (a one-wave workgroup, plan<7>, has no s_barrier at all: the wave's own wait orders its stores before its add)
+        while not text[i].startswith("s_barrier") and not text[i].startswith("global_atomic_add"):
+            path.append(text[i])                            # straight-line walk; an unconditional branch is followed
+            i = labels[text[i].split()[1]] if text[i].startswith("s_branch") else i + 1
+            assert i < len(text) and len(path) < 200, (name, path[-10:])
+        nxt = i
+        assert not [l for l in path if re.match(r"(buffer|global|flat)_store", l)], (name, path)
+        after = text[nxt:nxt + 40]
+        assert any(l.startswith("global_atomic_add") for l in after), (name, after)
+        assert not any(l.startswith("s_barrier") for l in after[1:next(i for i, l in enumerate(after) if l.startswith("global_atomic_add"))]), name
+        # in front of it: the write-through stores of the image, with no barrier between the last of them and the wait
+        prev = max([i for i in range(w) if text[i].startswith("s_barrier")] or [0])
+        stores = [l for l in text[prev:w] if l.startswith("buffer_store") and " sc1" in l]
+        assert stores, (name, "no sc1 image store between the previous barrier and the wait")
