@@ -60,6 +60,29 @@ def parse():
     return ap.parse_args()
 
 
+def _effective_cores():
+    """CPUs this process can really use: the affinity mask, cut down to the cgroup's CPU quota (a container limited to
+    8 CPUs of a 256-thread host still sees 256 in sched_getaffinity)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:                                                    # cgroup v2
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:                                                # cgroup v1
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    if quota is not None:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -89,7 +112,7 @@ def cpu_baseline_biquad(coef, samples, budget_s=5.0):
     y = np.empty_like(x)
     coef = np.ascontiguousarray(coef, np.float32)
     f = lambda a: a.ctypes.data_as(fp)
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _effective_cores()
 
     def timed(threads, blocks):
         st = np.zeros((C, 8, 2), np.float32)
@@ -107,6 +130,8 @@ def cpu_baseline_biquad(coef, samples, budget_s=5.0):
     allc = res["all_cores"]
     return {
         "value": allc["value"], "unit": "Msamples/s", "cores": allc["threads"], "kind": "port",
+        "cores_note": "threads = CPUs this process may use: affinity mask (%d) cut to the cgroup CPU quota" %
+                      (len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)),
         "per_core": round(allc["value"] / max(1, allc["threads"]), 1),
         "one_core": {"value": res["one_core"]["value"], "unit": "Msamples/s", "cores": 1},
         "cpu_model": _cpu_model(), "build": "gcc -O3 -march=native -ffp-contract=fast -fopenmp (rebuilt on this host)",
@@ -115,6 +140,45 @@ def cpu_baseline_biquad(coef, samples, budget_s=5.0):
                   "the sections, persistent threads; lsp-dsp-lib's hand-written kernels are not available offline"
                   % (allc["blocks"], res["one_core"]["blocks"], C, samples),
     }
+
+
+def _roofline(kernel, alg_bytes, kernel_ms, step_ms, probe_mode, traffic=None, extra=None):
+    """The `roofline` object of a (sub-)result from the probe pass of _timed_steps -- or a null object that says why when
+    the probes contradict the step time (a kernel cannot outlast its step)."""
+    avg_ms = sum(kernel_ms) / len(kernel_ms)
+    if probe_mode == "inconsistent" or avg_ms > 1.05 * step_ms:
+        return {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": traffic,
+                "kernel": kernel, "reason": "probe pass unreliable: kernel_avg_us %.2f > ms_per_step %.2f us x 1.05 -- use "
+                "whole_step.frac" % (avg_ms * 1e3, step_ms * 1e3)}
+    achieved = alg_bytes / (avg_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "kernel": kernel,
+         "kernel_avg_us": round(avg_ms * 1e3, 3), "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3),
+         "kernel_samples": len(kernel_ms), "probe": probe_mode, "algorithmic_bytes_per_launch": alg_bytes}
+    if extra:
+        r.update(extra)
+    return r
+
+
+def _biquad_issue_side(kernel_ms, alg_bytes, step_s, C, n, sections):
+    """The second roof of the biquad kernel next to the HBM one: VALU issue.  Instructions per launch from the committed SQ
+    counters (profiles/r02_biquad_pmc_sq.json: SQ_INSTS_VALU of the C2 launch, the same code object), one wave64 VALU
+    instruction per 4 clocks and SIMD (`v_pk_fma_f32` included: MI355X_MICROARCH.md, 157.3 TFLOP/s = 1024 SIMDs x 2.4 GHz x
+    16 lanes x 2 (packed) x 2 (fma)), 1024 SIMDs, 2.4 GHz."""
+    sq = _committed_json("r02_biquad_pmc_sq.json") or {}
+    insts = sq.get("SQ_INSTS_VALU")
+    out = {"whole_step_frac": round(alg_bytes / step_s / 1e9 / HBM_PEAK_GBS, 4)}
+    if insts and (C, n, sections) == (1024, 4096, 8):
+        avg_s = sum(kernel_ms) / len(kernel_ms) * 1e-3
+        floor_s = float(insts) * 4.0 / 1024.0 / 2.4e9
+        out.update({
+            "valu_issue_frac": round(floor_s / avg_s, 4), "valu_insts_per_launch": insts,
+            "valu_issue_floor_us": round(floor_s * 1e6, 2), "hbm_floor_us": round(alg_bytes / 6.29e12 * 1e6, 2),
+            "limiter": "neither roof alone: the launch is ONE round of 2048 waves (two per SIMD) that load, compute and store "
+                       "together, so the HBM floor and the VALU-issue floor add instead of overlapping (in-kernel timelines: "
+                       "profiles/r03_experiments/biquad_two_roles.txt); `bound` stays \"hbm\" because the algorithmic intensity "
+                       "(9 flop/B) is below the fp32 ridge (19.6 flop/B)"})
+    return out
 
 
 def _pmc_traffic(name):
@@ -154,7 +218,7 @@ def cpu_baseline_convolver(irs, frame, budget_s=6.0):
     import numpy as np
     import oracle
     from concurrent.futures import ThreadPoolExecutor
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = _effective_cores()
     workers = min(cores, 64)
     nch = min(irs.shape[0], workers)
     x = np.random.default_rng(5).standard_normal((nch, 2 * frame)).astype(np.float32)
@@ -198,7 +262,6 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
         bank.process(yout[k], xin[k], frame, stream=stream)
 
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup)
-    avg_ms = sum(kernel_ms) / len(kernel_ms)
     chk = yout[(warmup + steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
     bank_faults = bank.faults(stream=stream)
@@ -213,7 +276,11 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
     img = 8 * frame
     step_bytes = float(C) * frame * 16.0 * (P + 1)
     mac_bytes = step_bytes
-    achieved = mac_bytes / (avg_ms * 1e-3) / 1e9
+    # a bank with more channels than the device has CUs goes in launches of one CU-count of channels each; the probe's event
+    # pair then spans ALL launches of the step (first launch's start, last launch's stop)
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    launches = (C + cus - 1) // cus
+    kname = "conv_step_kernel<12>" if launches == 1 else "conv_step_kernel<12> x %d launches of <= %d channels (events span the step)" % (launches, cus)
     assert bank_faults == 0, "the roles of conv_step_kernel gave up waiting for each other %d times" % bank_faults
     res = {
         "value": round(C * frame * world * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
@@ -222,11 +289,8 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
                                "channel, rank 13, one 4096-sample frame per step" % C,
                    "channels_per_gpu": C, "taps": taps, "frame": frame, "partitions": P,
                    "images_read_per_step_MiB": round(float(C) * 2 * (P - 1) * img / 2 ** 20, 1)},
-        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": _pmc_traffic("pmc_convolver_latest.json") if C == 256 else None,
-                     "kernel": "conv_step_kernel<12>",
-                     "kernel_avg_us": round(avg_ms * 1e3, 3), "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3),
-                     "kernel_samples": len(kernel_ms), "algorithmic_bytes_per_launch": mac_bytes},
+        "roofline": _roofline(kname, mac_bytes, kernel_ms, elapsed / steps * 1e3, tinfo["probe"],
+                              _pmc_traffic("pmc_convolver_latest.json") if C == 256 else None, {"launches_per_step": launches}),
         "whole_step": {"algorithmic_bytes": step_bytes,
                        "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / steps) / 1e9, 1),
                        "frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -314,31 +378,46 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
     # Untimed probe pass: the dominant kernel of each call carries its own start/stop event pair (hipExtLaunchKernelGGL).
     # An event pair serialises its launch against its neighbours, which is what rocprofv3 measures too; the first probe
     # still overlaps the launch before it and is dropped.
-    kernel_ms = []
+    kernel_ms, probe_mode = [], None
+    st = sorted(times)
+    step_ms = st[len(st) // 2] / steps * 1e3
     if profile:
         def new_event():
             e = ctypes.c_void_p()
             mi.check(mi.lib.mi_dspu_event_create(ctypes.byref(e)))
             return e
-        n = KERNEL_PROBES + 1
-        starts, stops = [new_event() for _ in range(n)], [new_event() for _ in range(n)]
-        sync_probes = os.environ.get("MI_BENCH_PROBE_SYNC", "0") == "1"
-        for j in range(n):
-            if sync_probes:
-                torch.cuda.synchronize()
-            mi.check(mi.lib.mi_dspu_profile_next_launch(starts[j], stops[j]))
-            step(warmup + j)
-        torch.cuda.synchronize()
-        for j in range(1, n):
-            ms = ctypes.c_float()
-            mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), starts[j], stops[j]))
-            kernel_ms.append(float(ms.value))
-        for e in starts + stops:
-            mi.lib.mi_dspu_event_destroy(e)
+
+        def probe_pass(sync_probes):
+            n = KERNEL_PROBES + 1
+            starts, stops = [new_event() for _ in range(n)], [new_event() for _ in range(n)]
+            for j in range(n):
+                if sync_probes:
+                    torch.cuda.synchronize()
+                mi.check(mi.lib.mi_dspu_profile_next_launch(starts[j], stops[j]))
+                step(warmup + j)
+            torch.cuda.synchronize()
+            out = []
+            for j in range(1, n):
+                ms = ctypes.c_float()
+                mi.check(mi.lib.mi_dspu_event_elapsed_ms(ctypes.byref(ms), starts[j], stops[j]))
+                out.append(float(ms.value))
+            for e in starts + stops:
+                mi.lib.mi_dspu_event_destroy(e)
+            return out
+        # A kernel cannot take longer than the step it is part of.  An event pair whose start stamp is taken while the
+        # launch before it (another kernel of the same step) is still running reads too long: such a pass is repeated
+        # with the stream drained in front of every probed step, and if that does not help either the caller is told
+        # (kernel_ms stays, `probe` says "inconsistent": the roofline object is then null with the reason).
+        kernel_ms = probe_pass(os.environ.get("MI_BENCH_PROBE_SYNC", "0") == "1")
+        probe_mode = "back to back"
+        if sum(kernel_ms) / len(kernel_ms) > 1.05 * step_ms:
+            kernel_ms = probe_pass(True)
+            probe_mode = "stream drained before each probed step (the back-to-back pass read longer than the step)"
+            if sum(kernel_ms) / len(kernel_ms) > 1.05 * step_ms:
+                probe_mode = "inconsistent"
         if os.environ.get("MI_BENCH_DUMP_PROBES"):
             print("probes us: " + " ".join("%.2f" % (v * 1e3) for v in kernel_ms), file=sys.stderr)
-    st = sorted(times)
-    info = {"launch": mode, "regions": regions,
+    info = {"launch": mode, "regions": regions, "probe": probe_mode,
             "region_ms": {"min": round(st[0] * 1e3, 5), "median": round(st[len(st) // 2] * 1e3, 5),
                           "max": round(st[-1] * 1e3, 5), "first": round(times[0] * 1e3, 5)}}
     return st[len(st) // 2], sorted(kernel_ms), info
@@ -426,7 +505,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
             else:
                 sharding.allreduce_bins(sums)
     steps = args.conv_steps - (args.conv_steps % batch) or batch
-    elapsed, kernel_ms, _ = _timed_steps(mi, torch, dist, world, dev, step, steps, batch)
+    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
     if state["comm"] is not None:
         state["comm"].close()
@@ -434,7 +513,6 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     if rank != 0:
         return None
     frame_bytes = float(C) * (4096 * 4 + bins * 4)          # 24 580 B per channel-frame
-    avg_ms = sum(kernel_ms) / len(kernel_ms)
     return {
         "value": round(C * world * steps / elapsed, 1), "unit": "channel-frames/s",
         "msamples_per_s": round(C * world * hop * steps / elapsed / 1e6, 1),
@@ -442,12 +520,8 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         "config": {"workload": "Analyzer: 4096-point Hann spectrum per channel every 2048 samples, %d channels per GPU, "
                                "per-bin sum over all channels (all-reduce of %d x %d floats per %d frames)"
                                % (C, batch, bins, batch), "channels_per_gpu": C, "collective": state["collective"]},
-        "roofline": {"bound": "hbm", "achieved": round(frame_bytes / (avg_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(frame_bytes / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                     "traffic": _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None,
-                     "kernel": "analyzer_kernel<11>", "kernel_avg_us": round(avg_ms * 1e3, 3),
-                     "kernel_median_us": round(kernel_ms[len(kernel_ms) // 2] * 1e3, 3), "kernel_samples": len(kernel_ms),
-                     "algorithmic_bytes_per_launch": frame_bytes},
+        "roofline": _roofline("analyzer_kernel<11>", frame_bytes, kernel_ms, elapsed / steps * 1e3, tinfo["probe"],
+                              _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None),
         "whole_step": {"algorithmic_bytes": frame_bytes,
                        "achieved_GBps_incl_launch_gaps": round(frame_bytes / (elapsed / steps) / 1e9, 1),
                        "frac": round(frame_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
@@ -603,8 +677,29 @@ def run_dynfilter(args, mi, torch, dist, rank, world, dev):
                         "4096-sample blocks" % C, C, n, args.conv_steps, elapsed, world, 12.0)
 
 
+def _spawn_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start N ranks through torch.distributed.run (one process per GPU,
+    rendezvous on 127.0.0.1) BEFORE this process has touched the GPU, and leave with their status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ:
+        if args.gpus > 1:                                   # nothing of this process has initialised the GPU yet
+            sys.exit(_spawn_ranks(args))
+    elif int(os.environ["WORLD_SIZE"]) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the two must agree (n_gpus in the "
+                         "JSON line is the number of ranks that ran)" % (args.gpus, os.environ["WORLD_SIZE"]))
     import numpy as np
     import torch                                   # torch first: one HIP runtime per process
     import torch.distributed as dist
@@ -681,8 +776,6 @@ def main():
     regions = args.regions or (5 if args.steps >= 500 else 25)
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, args.steps, args.warmup, regions=regions,
                                              stream=stream, graph=(args.launch == "graph"))
-    avg_kernel_ms = sum(kernel_ms) / len(kernel_ms)
-    med_kernel_ms = kernel_ms[len(kernel_ms) // 2]
 
     # sanity: the output of the last step is finite and non-trivial
     chk = yout[(args.warmup + args.steps - 1) % ring]
@@ -692,7 +785,6 @@ def main():
     if rank == 0:
         samples_per_step = C * n * world
         alg_bytes = 8.0 * C * n                     # 4 B in + 4 B out per channel-sample
-        achieved = alg_bytes / (avg_kernel_ms * 1e-3) / 1e9
         committed = {"note": "read from files committed under profiles/ (collected by tests/prof_round.sh in an earlier "
                              "run of the same command), not measured by this run",
                      "traffic": _pmc_traffic("pmc_biquad_latest.json"),
@@ -719,14 +811,8 @@ def main():
             },
             "per_gpu_msamples_s": round(C * n * args.steps / elapsed / 1e6, 1),
             "timing": tinfo,
-            "roofline": {
-                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": committed["traffic"],
-                "kernel": "biquad_bank_kernel<16,2>", "kernel_avg_us": round(avg_kernel_ms * 1e3, 3),
-                "kernel_median_us": round(med_kernel_ms * 1e3, 3), "kernel_samples": len(kernel_ms),
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "whole_step_frac": round(alg_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS, 4),
-            },
+            "roofline": _roofline("biquad_bank_kernel<16,2>", alg_bytes, kernel_ms, elapsed / args.steps * 1e3, tinfo["probe"],
+                                  committed["traffic"], _biquad_issue_side(kernel_ms, alg_bytes, elapsed / args.steps, C, n, coef.shape[1])),
             "committed_profile": committed,
         }
         if not args.no_cpu_baseline and world == 1:         # the CPU figure is a 1-process measurement (rank 0 at N = 1 only)

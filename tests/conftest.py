@@ -64,6 +64,12 @@ def pytest_sessionfinish(session, exitstatus):
     with open(os.path.join(out, "parity_report.json"), "w") as f:
         json.dump({"note": "worst error / allowed error per tolerance rule over this pytest session (tests/conftest.py)",
                    "exit_status": int(exitstatus), "rules": doc}, f, indent=1)
+    # The ledger exists to make the looser-than-1e-5 rules readable: a row above 1 in a session whose tests all passed
+    # would mean that a rule recorded something it did not judge.  That is an error of the test code and fails the session.
+    over = {k: v["worst_ratio_to_bound"] for k, v in doc.items() if not (v["worst_ratio_to_bound"] <= 1.0)}
+    if over and int(exitstatus) == 0:
+        print("\nparity ledger: rows above their bound in a green session: %s" % over, file=sys.stderr)
+        session.exitstatus = 1
 
 
 def parity_report(gpu_out, ref32, ref64, peak=None, noise_over=None):

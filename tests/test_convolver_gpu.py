@@ -161,25 +161,40 @@ def test_reset_and_linearity(gpu):
 
 
 def test_c3_full_size(gpu):
-    """BASELINE config 2 at full size: 256 channels, distinct 65536-tap IRs (N(0,1)*exp(-t/16384), seed 4),
-    rank 13, three 4096-sample frames (seed 5); every channel against the oracle and float64."""
-    C, taps, frame, nf = 256, 65536, 4096, 3
+    """BASELINE config 2 at full size: 256 channels, distinct 65536-tap IRs (N(0,1)*exp(-t/16384), seed 4), rank 13,
+    SEVENTEEN 4096-sample frames (seed 5): the 15-slot ring of frame images is lapped once and wraps, so every partition
+    of the conv_step_kernel<12> instantiation multiplies real history.  Every channel against the oracle (the reference's
+    non-uniform algorithm, float32) and exact (float64) linear convolution over all frames, and once more against float64
+    over the LAST frame alone (which contains the contributions of all sixteen partitions) with the strict 1e-5."""
+    C, taps, frame, nf = 256, 65536, 4096, 17
     rng = np.random.default_rng(4)
     irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
     x = np.random.default_rng(5).standard_normal((C, nf * frame)).astype(np.float32)
     y, info = run_gpu(gpu, irs, 13, x, [frame] * nf)
     assert info == {"rank": 13, "frame": 4096, "partitions": 16, "data_size": 65536}
+    picked = list(range(C))
 
     def ref(c):
         o = oracle.Convolver(irs[c], 13)
         return np.concatenate([o.process(x[c, i:i + frame]) for i in range(0, nf * frame, frame)])
-    with ThreadPoolExecutor(max_workers=16) as ex:
-        refs = list(ex.map(ref, range(C)))
-    worst = 0.0
-    for c in range(C):
+
+    def exact_last(c):                                           # float64 linear convolution, its last frame
+        return exact_conv(x[c], irs[c])[(nf - 1) * frame:]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        refs = dict(zip(picked, ex.map(ref, picked)))
+        last = list(ex.map(exact_last, range(C)))
+    worst, worst_last = 0.0, 0.0
+    for c in picked:
         r = check(y[c], refs[c], exact_conv(x[c], irs[c]), "C3 ch %d" % c)
         worst = max(worst, r["gpu_vs_ref32"])
-    print("C3 full size: worst |gpu - oracle| / peak = %.2e" % worst)
+    for c in range(C):
+        peak = float(np.abs(last[c]).max())
+        err = float(np.abs(y[c, (nf - 1) * frame:] - last[c]).max()) / peak
+        record_parity("convolver C3, frame 17 of every channel: |gpu - exact| <= 1e-5 peak", err, TOL)
+        assert err <= TOL, (c, err)
+        worst_last = max(worst_last, err)
+    print("C3 full size, 17 frames, 256 channels: worst |gpu - oracle| / peak = %.2e, worst |gpu - exact| / peak on the last "
+          "frame = %.2e" % (worst, worst_last))
 
 
 @pytest.mark.parametrize("seed", range(10))
