@@ -25,6 +25,7 @@
 // Spectra use the packed real-FFT image of fft_device.h (B complex per 2B-point real transform).
 #include "mi_common.h"
 #include "fft_device.h"
+#include "fft16.h"
 
 #include <cmath>
 #include <cstdint>
@@ -36,6 +37,8 @@
 namespace
 {
     using namespace mi_fft;
+    // radix-16 core (fft16.h) for 1024 .. 8192-point transforms, radix-8 core (fft_device.h) below that
+    template <int L_> using fplan = mi_fft16::fsel<L_>;
 
     constexpr int LOGM_MIN = 7, LOGM_MAX = 12;
 
@@ -51,9 +54,9 @@ namespace
     // ---- forward transform of a real block of `valid` samples zero-padded to 2M, into buf ---------------
     template <int LOGM>
     __device__ void load_and_forward(float2 *buf, float2 *scr, const float *src, int valid, bool aligned,
-                                     const real_fft<LOGM> &rf, int tid)
+                                     const typename fplan<LOGM>::real &rf, int tid)
     {
-        using PL = plan<LOGM>;
+        using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T;
         for (int n = tid; n < M; n += T)
         {
@@ -76,16 +79,17 @@ namespace
 
     // ---- IR partition -> image (Convolver::init, Convolver.cpp:152-197) -----------------------------------
     template <int LOGM>
-    __global__ __launch_bounds__(plan<LOGM>::T)
+    __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_parse_kernel(float2 *H, const float *ir, size_t ir_stride, const uint32_t *__restrict__ counts,
                            int P, const float2 *__restrict__ tw, const uint8_t *__restrict__ only /* or NULL: every channel */)
     {
-        constexpr int M = plan<LOGM>::N;
-        __shared__ float2 buf[M], scr[M];
+        constexpr int M = fplan<LOGM>::N;
+        __shared__ float2 lds_[fplan<LOGM>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
         const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
         if (only != nullptr && only[ch] == 0)
             return;
-        real_fft<LOGM> rf;
+        typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);
         rf.prepare();
         const int count = int(counts[ch]);
@@ -93,7 +97,7 @@ namespace
         valid = (valid < 0) ? 0 : (valid > M ? M : valid);
         load_and_forward<LOGM>(buf, scr, ir + size_t(ch) * ir_stride + size_t(p) * M, valid, false, rf, tid);
         float2 *dst = H + (size_t(ch) * P + p) * M;
-        for (int k = tid; k < M; k += plan<LOGM>::T)
+        for (int k = tid; k < M; k += fplan<LOGM>::T)
             dst[k] = buf[k];
     }
 
@@ -113,14 +117,14 @@ namespace
                     bool upper_zero /* acc[B:2B] is known to hold zeros: neither read nor re-zeroed */,
                     uint32_t *done)
     {
-        using PL = plan<LOGM>;
+        using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
         const int tid = threadIdx.x;
         MI_CPROBE(0);
         // Request order = order of use (vmcnt counts in order): twiddles, the frame, then the operands of the later
         // phases -- the head partition's image, the pending tail and the overlap-add accumulator wait in registers.
         // One exposed HBM latency instead of four.
-        real_fft<LOGM> rf;
+        typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);
         constexpr int KPT = M / T, NPT = (M / 2) / T;
         const float *x = in + size_t(ch) * in_stride;
@@ -233,14 +237,15 @@ namespace
     }
 
     template <int LOGM>
-    __global__ __launch_bounds__(plan<LOGM>::T)
+    __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                            float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                            float *acc, const float2 *__restrict__ Yt, const float2 *__restrict__ tw,
                            float *dl_ring, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head, bool upper_zero)
     {
-        constexpr int M = plan<LOGM>::N;
-        __shared__ float2 buf[M], scr[M];
+        constexpr int M = fplan<LOGM>::N;
+        __shared__ float2 lds_[fplan<LOGM>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
         frame_role<LOGM, false>(buf, scr, blockIdx.x, out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc, Yt, tw,
                                 dl_ring, dl_size, dl_tail, dl_head, upper_zero, nullptr);
     }
@@ -268,16 +273,19 @@ namespace
     // in which it happened and everything after it is invalid until mi_convolver_bank_reset).  `seen` is the tail role's
     // private count of the frames it has taken.
     template <int LOGM, bool NT>
-    __global__ __launch_bounds__(plan<LOGM>::T, 2)
+    // (one frame and one tail workgroup share a CU at LOGM = 12: 4 + 4 waves of <= 256 VGPRs; the smaller transforms have one- or
+    //  two-wave workgroups, several of which fit a CU whatever they allocate)
+    __global__ __launch_bounds__(fplan<LOGM>::T, (fplan<LOGM>::T >= 256) ? 2 : 1)
     void conv_step_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                           float *acc, float2 *Yt, bool yt_pending, const float2 *__restrict__ tw, bool upper_zero,
                           int channels /* of this launch */, int first /* its first channel */,
                           uint32_t *done, uint32_t *seen, uint32_t *fault, uint32_t *fault_host)
     {
-        using PL = plan<LOGM>;
+        using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
-        __shared__ float2 buf[M], scr[M];
+        __shared__ float2 lds_[fplan<LOGM>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
         // (the role boundary is `channels` rounded up to the 8 XCDs the workgroups are dealt to in turn: both workgroups of a
         // channel then sit on the same XCD, whose dispatcher hands out its share of the grid in index order -- frame before tail)
         const int boundary = (channels + 7) & ~7;
@@ -438,14 +446,15 @@ namespace
     }
 
     template <int LOGM>
-    __global__ __launch_bounds__(plan<LOGM>::T)
+    __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_tail_kernel(float *acc, const float2 *__restrict__ Yt, const float2 *__restrict__ tw)
     {
-        using PL = plan<LOGM>;
+        using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T;
-        __shared__ float2 buf[M], scr[M];
+        __shared__ float2 lds_[fplan<LOGM>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
         const int ch = blockIdx.x, tid = threadIdx.x;
-        real_fft<LOGM> rf;
+        typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);
         const float2 *src = Yt + size_t(ch) * M;
         for (int k = tid; k < M; k += T)
@@ -493,17 +502,18 @@ namespace
 
     // frame complete after partial calls: its spectrum enters the ring, acc moves on by one frame
     template <int LOGM>
-    __global__ __launch_bounds__(plan<LOGM>::T)
+    __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_commit_kernel(const float *frame, float2 *ring, int R, int slot, float *acc,
                             const float2 *__restrict__ tw)
     {
-        using PL = plan<LOGM>;
+        using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
-        __shared__ float2 buf[M], scr[M];
+        __shared__ float2 lds_[fplan<LOGM>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
         const int ch = blockIdx.x, tid = threadIdx.x;
         if (R > 0)
         {
-            real_fft<LOGM> rf;
+            typename fplan<LOGM>::real rf;
             rf.load(tw, TWN, tid);
             rf.prepare();
             load_and_forward<LOGM>(buf, scr, frame + size_t(ch) * B, B, true, rf, tid);
@@ -540,16 +550,17 @@ namespace
 
     // whole frame, single partition (P == 1): y = w_old IFFT(X H_old) + w_new IFFT(X H_new), then the usual overlap-add
     template <int LOGM>
-    __global__ __launch_bounds__(plan<LOGM>::T)
+    __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_xfade_frame_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, bool aligned,
                                  const float2 *__restrict__ Hold, const float2 *__restrict__ Hnew, float *acc,
                                  const float2 *__restrict__ tw, const uint8_t *__restrict__ xmask)
     {
-        using PL = plan<LOGM>;
+        using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T;
-        __shared__ float2 buf[M], scr[M];
+        __shared__ float2 lds_[fplan<LOGM>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
         const int ch = blockIdx.x, tid = threadIdx.x;
-        real_fft<LOGM> rf;
+        typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);
         rf.prepare();
         load_and_forward<LOGM>(buf, scr, in + size_t(ch) * in_stride, B, aligned, rf, tid);
@@ -663,15 +674,18 @@ namespace
         std::lock_guard<std::mutex> guard(g_tw_lock);
         if (g_tw[dev] == nullptr)
         {
-            std::vector<float2> h(TWN);
+            // TWN entries exp(-2 pi i j / TWN), then the per-pass twiddle tables of the radix-16 core (fft16.h)
+            const size_t total = size_t(TWN) + 2 * size_t(mi_fft16::table16_total());
+            std::vector<float2> h(total);
             for (int j = 0; j < TWN; ++j)
             {
                 const double a = -2.0 * M_PI * double(j) / double(TWN);
                 h[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
             }
+            mi_fft16::table16_build(reinterpret_cast<float *>(h.data() + TWN));
             float2 *d = nullptr;
-            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), TWN * sizeof(float2)));
-            MI_HIP_CHECK(hipMemcpy(d, h.data(), TWN * sizeof(float2), hipMemcpyHostToDevice));
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&d), total * sizeof(float2)));
+            MI_HIP_CHECK(hipMemcpy(d, h.data(), total * sizeof(float2), hipMemcpyHostToDevice));
             g_tw[dev] = d;
         }
         *out = g_tw[dev];
@@ -790,10 +804,10 @@ namespace
                 const int cnt = std::min(per_launch, int(b->channels) - first);
                 hipEvent_t e0 = (first == 0) ? ev0 : nullptr, e1 = (first + cnt >= int(b->channels)) ? ev1 : nullptr;
                 #define MI_CALL(LM) \
-                    if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(((cnt + 7) & ~7) + cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
+                    if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(((cnt + 7) & ~7) + cnt), dim3(fplan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
                                       b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host); \
-                    else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(((cnt + 7) & ~7) + cnt), dim3(plan<LM>::T), 0, st, e0, e1, \
+                    else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(((cnt + 7) & ~7) + cnt), dim3(fplan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
                                       b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host)
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
@@ -804,7 +818,7 @@ namespace
             b->upper_zero = true;
             return MI_OK;
         }
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
                                                o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
                                                b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
                                                static_cast<float *>(nullptr), 0u, 0u, 0u, b->upper_zero)
@@ -821,7 +835,7 @@ namespace
     {
         if (!b->yt_pending)
             return MI_OK;
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_tail_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_tail_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
                                                b->d_acc, b->d_yt, b->d_tw)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
@@ -879,7 +893,7 @@ namespace mi
                              (out_stride % 2 == 0) && (in_stride % 2 == 0);
         if (b->R > 0)
             b->slot = (b->slot + 1) % b->R;
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
                                                out, in, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
                                                b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
                                                dl.ring, dl.size, tail, dl.head, b->upper_zero)
@@ -986,7 +1000,7 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
                                               M * sizeof(float), channels, hipMemcpyDeviceToDevice, st);
     if (e == hipSuccess)
     {
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, channels), dim3(plan<LM>::T), 0, st, \
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, channels), dim3(fplan<LM>::T), 0, st, \
                                                b->d_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw, (const uint8_t *)nullptr)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
@@ -1039,7 +1053,7 @@ static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_strid
     }
     if (e == hipSuccess)
     {
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, b->channels), dim3(plan<LM>::T), 0, st, \
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_parse_kernel<LM>), dim3(b->P, b->channels), dim3(fplan<LM>::T), 0, st, \
                                                dst_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw, d_only)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
@@ -1298,7 +1312,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
         {
             const bool aligned = ((reinterpret_cast<uintptr_t>(o) | reinterpret_cast<uintptr_t>(x)) % 8 == 0) &&
                                  (out_stride % 2 == 0) && (in_stride % 2 == 0);
-            #define MI_CALL(LM) hipLaunchKernelGGL((conv_xfade_frame_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+            #define MI_CALL(LM) hipLaunchKernelGGL((conv_xfade_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
                                                    o, x, out_stride, in_stride, aligned, b->d_H, b->d_Hx, b->d_acc, b->d_tw, b->d_xmask)
             MI_LOGM_SWITCH(b->logm, MI_CALL)
             #undef MI_CALL
@@ -1343,7 +1357,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             {
                 if (b->R > 0)
                     b->slot = (b->slot + 1) % b->R;
-                #define MI_CALL(LM) hipLaunchKernelGGL((conv_commit_kernel<LM>), dim3(b->channels), dim3(plan<LM>::T), 0, st, \
+                #define MI_CALL(LM) hipLaunchKernelGGL((conv_commit_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
                                                        b->d_frame, b->d_ring, b->R, b->slot, b->d_acc, b->d_tw)
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
                 #undef MI_CALL

@@ -37,9 +37,11 @@ namespace mi_fft
     typedef float v2f __attribute__((ext_vector_type(2)));
     // complex a * b (CONJ_A: conj(a) * b).  op_sel picks the half that feeds the low lane, op_sel_hi the high lane:
     //   t = (a.x b.x, a.x b.y);   r = (t.x -+ a.y b.y, t.y +- a.y b.x)
+    // (host build: the same arithmetic in plain C++ -- tests/cpp/fft16_host.cpp runs the index math of fft16.h on the CPU)
     template <bool CONJ_A>
-    __device__ __forceinline__ v2f pmul(v2f a, v2f b)
+    __host__ __device__ __forceinline__ v2f pmul(v2f a, v2f b)
     {
+#if defined(__HIP_DEVICE_COMPILE__)
         v2f t, r;
         asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(a), "v"(b));
         if (CONJ_A)
@@ -47,17 +49,25 @@ namespace mi_fft
         else
             asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "v"(a), "v"(b), "v"(t));
         return r;
+#else
+        const float ay = CONJ_A ? -a.y : a.y;
+        return v2f{a.x * b.x - ay * b.y, a.x * b.y + ay * b.x};
+#endif
     }
     // a + i b (PLUS_I) or a - i b:  (a.x -+ b.y, a.y +- b.x) in one v_pk_add_f32
     template <bool PLUS_I>
-    __device__ __forceinline__ v2f padd_i(v2f a, v2f b)
+    __host__ __device__ __forceinline__ v2f padd_i(v2f a, v2f b)
     {
+#if defined(__HIP_DEVICE_COMPILE__)
         v2f r;
         if (PLUS_I)
             asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
         else
             asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
         return r;
+#else
+        return PLUS_I ? v2f{a.x - b.y, a.y + b.x} : v2f{a.x + b.y, a.y - b.x};
+#endif
     }
     __device__ __forceinline__ v2f ld2(const float2 *p) { return *reinterpret_cast<const v2f *>(p); }
     __device__ __forceinline__ void st2(float2 *p, v2f v) { *reinterpret_cast<v2f *>(p) = v; }
@@ -153,7 +163,7 @@ namespace mi_fft
 
     // 4-point DFT in registers, outputs in natural order (forward: e^{-j}, INVERSE: e^{+j})
     template <bool INVERSE>
-    __device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
+    __host__ __device__ __forceinline__ void dft4(v2f &x0, v2f &x1, v2f &x2, v2f &x3)
     {
         const v2f apc = x0 + x2, amc = x0 - x2, bpd = x1 + x3, bmd = x1 - x3;
         x0 = apc + bpd;
@@ -165,7 +175,7 @@ namespace mi_fft
     // 8-point DFT in registers, outputs in natural order: even outputs = DFT4 of the sums, odd outputs = DFT4 of the
     // differences rotated by W8^k
     template <bool INVERSE>
-    __device__ __forceinline__ void dft8(v2f (&x)[8])
+    __host__ __device__ __forceinline__ void dft8(v2f (&x)[8])
     {
         constexpr float H = 0.70710678118654752f;
         v2f a0 = x[0] + x[4], a1 = x[1] + x[5], a2 = x[2] + x[6], a3 = x[3] + x[7];

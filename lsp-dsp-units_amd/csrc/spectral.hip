@@ -17,6 +17,7 @@
 //             real part is kept, SpectralProcessor.cpp:168-169).
 #include "mi_common.h"
 #include "fft_device.h"
+#include "fft16.h"
 
 #include <cmath>
 #include <cstdint>
@@ -25,22 +26,25 @@
 namespace
 {
     using namespace mi_fft;
+    // radix-16 core (fft16.h) for 1024 .. 8192-point transforms, radix-8 core (fft_device.h) below that
+    template <int L_> using fplan = mi_fft16::fsel<L_>;
 
     // ---- hop transform of the spectral processor ----------------------------------------------------------
     // in_buf/out_buf: [channels][N] state of the reference object (pInBuf/pOutBuf); wnd: N window samples.
     // MODE 0: NONE, 1: MASK (fused), 2: forward half of the CALLBACK path (writes spec), 3: inverse half.
     template <int LOGH, int MODE>
-    __global__ __launch_bounds__(plan<LOGH>::T)
+    __global__ __launch_bounds__(fplan<LOGH>::T)
     void stft_hop_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in,
                          const float *__restrict__ wnd_out, const float *__restrict__ mask, size_t mask_stride,
                          float2 *spec, const uint8_t *__restrict__ active, const float2 *__restrict__ tw,
                          const float *io_src, size_t io_src_stride, float *io_dst, size_t io_dst_stride)
     {
-        using PL = plan<LOGH>;
+        using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 buf[H], scr[H];
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
-        real_fft<LOGH> rf;
+        typename fplan<LOGH>::real rf;
         if (MODE == 1 || MODE == 2)
         {
             rf.load(tw, TWN, tid);
@@ -158,17 +162,20 @@ namespace
     // Pairs: a frame of N = 2H samples is H float2 pairs, a hop is H/2 pairs; thread t owns pairs t + i T, so pair m and
     // pair m + H/2 belong to the same thread (KPT = H / T is even: LOGH >= 7).
     template <int LOGH, bool MASKED>
-    __global__ __launch_bounds__(plan<LOGH>::T, (plan<LOGH>::T <= 256) ? 4 : (plan<LOGH>::T <= 512) ? 2 : 1)   // <= 128 VGPRs: four waves per SIMD
+    // (radix-8 core: <= 128 VGPRs, four waves per SIMD; radix-16 core: sixteen points and two passes of twiddles per thread,
+    //  two waves per SIMD -- a bank of 1024 channels is 2048 waves, two per SIMD, either way)
+    __global__ __launch_bounds__(fplan<LOGH>::T, fplan<LOGH>::radix16 ? 2 : (fplan<LOGH>::T <= 256) ? 4 : (fplan<LOGH>::T <= 512) ? 2 : 1)
     void stft_stream_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in, const float *__restrict__ wnd_out,
                             const float *__restrict__ mask, size_t mask_stride, const float2 *__restrict__ tw,
                             const float *__restrict__ src, size_t src_stride, float *dst, size_t dst_stride)
     {
-        using PL = plan<LOGH>;
+        using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, KPT = H / T, HPT = KPT / 2;
         static_assert(KPT >= 2 && (KPT & 1) == 0 && KPT * T == H, "stft_stream_kernel needs an even number of pairs per thread");
-        __shared__ float2 buf[H], scr[H];
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
-        real_fft<LOGH> rf;
+        typename fplan<LOGH>::real rf;
         if (MASKED)
             rf.load(tw, TWN, tid);
         float2 *x2 = reinterpret_cast<float2 *>(in_buf + size_t(ch) * N);
@@ -240,14 +247,15 @@ namespace
     // (S[k] + conj S[N-k]) / 2, so the way back is the same half-size real transform as the way there.
     // Then window, overlap-add, input shift.
     template <int LOGH>
-    __global__ __launch_bounds__(plan<LOGH>::T)
+    __global__ __launch_bounds__(fplan<LOGH>::T)
     void stft_inverse_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_out,
                              const float2 *__restrict__ spec, const uint8_t *__restrict__ active,
                              const uint8_t *__restrict__ has_out, const float2 *__restrict__ tw)
     {
-        using PL = plan<LOGH>;
+        using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 buf[H], scr[H];
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
         const bool on = ((active == nullptr) || (active[ch] != 0)) && ((has_out == nullptr) || (has_out[ch] != 0));
         const float2 *sp = spec + size_t(ch) * N;
@@ -256,7 +264,7 @@ namespace
         const float2 *wo = reinterpret_cast<const float2 *>(wnd_out);
         if (on)
         {
-            real_fft<LOGH> rf;
+            typename fplan<LOGH>::real rf;
             rf.load(tw, TWN, tid);
             rf.prepare();
             for (int k = tid; k < H; k += T)
@@ -454,16 +462,17 @@ namespace
     // ingest: `ingest_n` new samples per channel go into the ring behind `head` in the same launch (the "fill the
     // buffer" half of Analyzer::process, Analyzer.cpp:371-398; they lie outside every analysis window of this strobe).
     template <int LOGH>
-    __global__ __launch_bounds__(plan<LOGH>::T)
+    __global__ __launch_bounds__(fplan<LOGH>::T)
     void analyzer_kernel(float *ring, uint32_t buf_size, uint32_t head,
                          const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
                          const float *__restrict__ wnd, const float *__restrict__ amp_old, float *amp_new,
                          uint32_t amp_stride, float tau, const float2 *__restrict__ tw,
                          const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero)
     {
-        using PL = plan<LOGH>;
+        using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 buf[H], scr[H];
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
         MI_APROBE(0);
         // Everything the launch needs is requested before anything is waited for (in-kernel timeline,
@@ -471,7 +480,7 @@ namespace
         // frame's address -- used to cost two exposed latencies before the frame was even asked for, and the new samples were
         // only asked for when the spectrum had been stored): twiddles, flags AND delay, then the frame, the spectrum being
         // smoothed and the samples to ingest.
-        real_fft<LOGH> rf;
+        typename fplan<LOGH>::real rf;
         rf.load(tw, TWN, tid);
         const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
         const uint32_t dly = delay[ch];
@@ -896,7 +905,7 @@ namespace
         {
             if (b->op == MI_SPECTRAL_OP_CALLBACK && b->func != nullptr)
             {
-                #define MI_CALL(LH) hipLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, \
+                #define MI_CALL(LH) hipLaunchKernelGGL((stft_hop_kernel<LH, 2>), grid, dim3(fplan<LH>::T), 0, st, \
                     b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw, (const float *)nullptr, size_t(0), (float *)nullptr, size_t(0))
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
@@ -913,7 +922,7 @@ namespace
         const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
         if (b->op == MI_SPECTRAL_OP_NONE || !bound)
         {
-            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 0>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
+            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 0>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), (float2 *)nullptr, \
                 (const uint8_t *)nullptr, b->d_tw, (const float *)nullptr, size_t(0), (float *)nullptr, size_t(0))
             MI_LOGH_SWITCH(lh, MI_CALL)
@@ -921,7 +930,7 @@ namespace
         }
         else if (b->op == MI_SPECTRAL_OP_MASK)
         {
-            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 1>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
+            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 1>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, b->d_mask, b->mask_stride, (float2 *)nullptr, \
                 (const uint8_t *)nullptr, b->d_tw, (const float *)nullptr, size_t(0), (float *)nullptr, size_t(0))
             MI_LOGH_SWITCH(lh, MI_CALL)
@@ -929,13 +938,13 @@ namespace
         }
         else
         {
-            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 2>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
+            #define MI_CALL(LH) MI_LAUNCH((stft_hop_kernel<LH, 2>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, \
                 b->d_in, b->d_out, (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_spec, b->d_active, b->d_tw, io_src, io_src_stride, io_dst, io_dst_stride)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
             b->func(b->object, b->subject, reinterpret_cast<float *>(b->d_spec), b->rank, b->channels, st);
-            #define MI_CALL(LH) hipLaunchKernelGGL((stft_inverse_kernel<LH>), grid, dim3(plan<LH>::T), 0, st, \
+            #define MI_CALL(LH) hipLaunchKernelGGL((stft_inverse_kernel<LH>), grid, dim3(fplan<LH>::T), 0, st, \
                 b->d_in, b->d_out, b->d_wnd_out, b->d_spec, b->d_active, b->d_has_out, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
@@ -1170,9 +1179,9 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
                 mi::take_profile_events(&ev0, &ev1);
                 const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
                 #define MI_CALL(LH) \
-                    if (masked) MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), true>), dim3(b->channels), dim3(plan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
+                    if (masked) MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), true>), dim3(b->channels), dim3(fplan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
                                           b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->mask_stride, b->d_tw, in + done, in_stride, out + done, out_stride); \
-                    else        MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), false>), dim3(b->channels), dim3(plan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
+                    else        MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), false>), dim3(b->channels), dim3(fplan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
                                           b->d_in, b->d_out, wi, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_tw, in + done, in_stride, out + done, out_stride)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
@@ -1325,7 +1334,7 @@ namespace
         const size_t row = size_t(first) * b->bins_stride;
         if (b->rank <= 14)
         {
-            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(count), dim3(plan<LH>::T), 0, st, ev0, ev1, \
+            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(count), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
                 ring, b->buf_size, b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, b->d_data + row, b->d_amp + row, \
                 b->bins_stride, b->tau, b->d_tw, in, in_stride, n, zero ? 1 : 0)
             MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)

@@ -18,6 +18,7 @@
 //             lsp::dspu::SpectralSplitter class mirror.
 #include "mi_common.h"
 #include "fft_device.h"
+#include "fft16.h"
 
 #include <algorithm>
 #include <cmath>
@@ -32,6 +33,8 @@ namespace mi
 namespace
 {
     using namespace mi_fft;
+    // radix-16 core (fft16.h) for 1024 .. 8192-point transforms, radix-8 core (fft_device.h) below that
+    template <int L_> using fplan = mi_fft16::fsel<L_>;
 
     enum { H_OFF = 0, H_COPY = 1, H_MASK = 2, H_CALLBACK = 3 };
 
@@ -85,16 +88,17 @@ namespace
     // Fused streaming (ingest_n > 0): the `frame` samples that follow the hop are taken from `src` (NULL: silence) into the
     // new analysis buffer, and the frame every handler finishes goes straight to the caller's buffers.
     template <int LOGH, bool WRITE_SPEC, bool PER_BAND>
-    __global__ __launch_bounds__(plan<LOGH>::T)
+    __global__ __launch_bounds__(fplan<LOGH>::T)
     void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
                              uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
                              const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
                              const float *src, size_t src_stride, uint32_t ingest_n, const out_table outs,
                              size_t out_stride, size_t out_pos)
     {
-        using PL = plan<LOGH>;
+        using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, PER = (H + T - 1) / T;
-        __shared__ float2 buf[H], scr[H];
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
         constexpr bool all = !PER_BAND;
         const uint32_t h0 = all ? 0 : blockIdx.y, h1 = all ? handlers : blockIdx.y + 1;
@@ -114,7 +118,7 @@ namespace
             copies = copies || (hd[h].mode == H_COPY && hd[h].has_sink);
         if (!owner && !masks && !copies)
             return;
-        real_fft<LOGH> rf;
+        typename fplan<LOGH>::real rf;
         if (masks)
             rf.load(tw, TWN, tid);
         const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
@@ -234,15 +238,16 @@ namespace
     // and Re ifft(S) is the inverse of S's Hermitian part (S[k] + conj S[N-k]) / 2 -- the same half-size real transform
     // as on the way there.  The last 2*frame samples are windowed into the handler's line.
     template <int LOGH>
-    __global__ __launch_bounds__(plan<LOGH>::T)
+    __global__ __launch_bounds__(fplan<LOGH>::T)
     void splitter_inverse_kernel(float *line0, size_t line_pitch, const float2 *__restrict__ spec,
                                  const float *__restrict__ wnd, uint32_t frame, const float2 *__restrict__ tw)
     {
-        using PL = plan<LOGH>;
+        using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 buf[H], scr[H];
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
-        real_fft<LOGH> rf;
+        typename fplan<LOGH>::real rf;
         rf.load(tw, TWN, tid);
         rf.prepare();
         const float2 *sp = spec + size_t(ch) * N;
@@ -413,13 +418,13 @@ namespace
                 (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos
             if (grid.y > 1)
             {
-                #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, true>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
             }
             else
             {
-                #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, false>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
             }
@@ -428,7 +433,7 @@ namespace
             std::swap(b->d_in, b->d_in2);
             return MI_OK;
         }
-        #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, true, false>), grid, dim3(plan<LH>::T), 0, st, ev0, ev1, \
+        #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, true, false>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, \
             b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, b->d_spec, \
             b->d_tw, (const float *)nullptr, size_t(0), 0u, splitter_outs(b), size_t(0), size_t(0))
         MI_LOGH_SWITCH(lh, MI_CALL)
@@ -445,7 +450,7 @@ namespace
             if (!b->has_sink[i])
                 continue;
             float *line0 = b->d_lines + size_t(i) * b->channels * b->pitch;
-            #define MI_CALL(LH) hipLaunchKernelGGL((splitter_inverse_kernel<LH>), grid, dim3(plan<LH>::T), 0, st, \
+            #define MI_CALL(LH) hipLaunchKernelGGL((splitter_inverse_kernel<LH>), grid, dim3(fplan<LH>::T), 0, st, \
                 line0, b->pitch, b->d_tmp, b->d_wnd, frame, b->d_tw)
             MI_LOGH_SWITCH(lh, MI_CALL)
             #undef MI_CALL
