@@ -69,3 +69,15 @@ def test_conv_step_frame_role_drains_image_stores_before_the_counter(tmp_path):
         prev = max([i for i in range(w) if text[i].startswith("s_barrier")] or [0])
         stores = [l for l in text[prev:w] if l.startswith("buffer_store") and " sc1" in l]
         assert stores, (name, "no sc1 image store between the previous barrier and the wait")
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_fft16_index_arithmetic_on_the_host(tmp_path):
+    """fft16.h's phases (butterflies, exchange image addressing, twiddle table) run for all threads of a workgroup in lock step
+    on the CPU, 1024 .. 8192 points, forward and inverse, against a double-precision DFT (tests/cpp/fft16_host.cpp)."""
+    exe = os.path.join(str(tmp_path), "fft16_host")
+    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "--offload-arch=gfx950", "-w", "-I" + CSRC,
+                           os.path.join(ROOT, "tests", "cpp", "fft16_host.cpp"), "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, timeout=300)
+    assert out.returncode == 0, out.stdout.decode()[-800:]
+    assert out.stdout.count(b"max error") == 8
