@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
     ap.add_argument("--eq-channels", type=int, default=256, help="equalizer channels per GPU (config 3: 2048 over 8 GPUs)")
     ap.add_argument("--spec-channels", type=int, default=1024, help="analyzer channels per GPU (config 4: 8192 over 8 GPUs)")
+    ap.add_argument("--call", type=int, default=0, help="convolver workload: also time a stream of calls of this many samples "
+                    "(e.g. 256: what a plugin host does; a step is still one 4096-sample frame = 4096 / call calls)")
     ap.add_argument("--conv-steps", type=int, default=200)
     ap.add_argument("--conv-warmup", type=int, default=10)
     return ap.parse_args()
@@ -298,6 +300,51 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
     return res, irs
 
 
+def _convolver_call_stream(args, mi, torch, dist, rank, world, dev, C, call, steps, warmup):
+    """The same bank fed with `call`-sample calls (sub-frame path: conv_small_kernel per aligned 256-sample block, the frame's
+    commit and tail every 4096 samples).  A step is one frame's worth of calls."""
+    import numpy as np
+    taps, frame = 65536, 4096
+    assert frame % call == 0
+    rng = np.random.default_rng(4 + rank)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
+    bank = mi.ConvolverBank(irs, 13)
+    info = bank.info()
+    period = max(1, info["partitions"] - 1)             # the frame ring's lap: a captured run must cover whole laps of it
+    ring = period
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(5 + rank)
+    xin = torch.randn((ring, C, frame), generator=gen, dtype=torch.float32).to(dev)
+    yout = torch.empty_like(xin)
+    stream = torch.cuda.Stream(device=dev)              # a created stream: the run is captured into a hipGraph
+    import ctypes
+    st = ctypes.c_void_p(stream.cuda_stream)
+    # raw pointers of every call, made once: the timed loop (or the capture) does nothing but the library calls
+    calls = [[(ctypes.c_void_p(yout[k].data_ptr() + 4 * o), ctypes.c_void_p(xin[k].data_ptr() + 4 * o))
+              for o in range(0, frame, call)] for k in range(ring)]
+    fn, h = mi.lib.mi_convolver_bank_process, bank.handle
+
+    def step(i):
+        for po, pi in calls[i % ring]:
+            mi.check(fn(h, po, pi, call, frame, frame, st))
+    steps = max(period, steps - steps % period)
+    torch.cuda.synchronize()
+    elapsed, _, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, period, profile=False, stream=stream, graph=True)
+    stream.synchronize()
+    assert bool(torch.isfinite(yout).all()) and float(yout.abs().max()) > 0.0
+    assert bank.faults(stream=stream) == 0
+    bank.close()
+    del xin, yout
+    torch.cuda.empty_cache()
+    if rank != 0:
+        return None
+    return {"call": call, "calls_per_step": frame // call, "steps": steps, "launch": tinfo["launch"],
+            "value": round(C * frame * world * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
+            "ms_per_step": round(elapsed / steps * 1e3, 5), "us_per_call": round(elapsed / steps / (frame // call) * 1e6, 2),
+            "config": {"workload": "Convolver, %d channels per GPU, 65536-tap IR per channel, rank 13, fed in %d-sample calls "
+                                   "(one kernel per aligned 256-sample block; commit + tail of the frame every 4096 samples)" % (C, call), "channels_per_gpu": C}}
+
+
 def run_convolver(args, mi, torch, dist, rank, world, dev):
     """BASELINE.json configs[2]: 256 channels per GPU, 65536-tap IR per channel, rank 13 -> 4096-sample frames.
     At that size the images a step reads (248 MiB) just fit the 256 MiB Infinity Cache, so part of the figure is cache
@@ -310,8 +357,16 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
         big, _ = _convolver_pass(args, mi, torch, dist, rank, world, dev, 512, max(40, args.conv_steps // 2), args.conv_warmup)
     if rank != 0:
         return None
+    stream_res = None
+    if args.call > 0:
+        stream_res = _convolver_call_stream(args, mi, torch, dist, rank, world, dev, C, args.call, max(20, args.conv_steps // 4), 3)
+    if rank != 0:
+        return None
     if big is not None:
         res["beyond_infinity_cache"] = {k: big[k] for k in ("value", "ms_per_step", "config", "roofline", "whole_step")}
+    if stream_res is not None:
+        stream_res["fraction_of_whole_frame_rate"] = round(stream_res["value"] / res["value"], 3)
+        res["call_stream"] = stream_res
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_convolver(irs, 4096)
     return res

@@ -92,7 +92,7 @@ namespace
         typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);
         rf.prepare();
-        const int count = int(counts[ch]);
+        const int count = (counts != nullptr) ? int(counts[ch]) : P * M;
         int valid = count - p * M;
         valid = (valid < 0) ? 0 : (valid > M ? M : valid);
         load_and_forward<LOGM>(buf, scr, ir + size_t(ch) * ir_stride + size_t(p) * M, valid, false, rf, tid);
@@ -476,7 +476,8 @@ namespace
     // input: several workgroups of one channel read all of them).
     __global__ __launch_bounds__(256)
     void conv_direct_kernel(float *out, size_t out_stride, float *acc, const float *frame,
-                            const float *__restrict__ h0, int B, int off, int cnt)
+                            const float *__restrict__ h0, int B, int off, int cnt, int taps /* <= B: h0[0 .. taps) only */,
+                            int limit /* results at off + i >= limit are not produced (2 B: all of them) */)
     {
         extern __shared__ float sxin[];                         // cnt samples of this call
         const int ch = blockIdx.y, tid = threadIdx.x;
@@ -485,10 +486,10 @@ namespace
             sxin[j] = x[j];
         __syncthreads();
         const int i = blockIdx.x * 256 + tid;                   // output position relative to `off`
-        if (i >= cnt + B - 1)
+        if (i >= cnt + taps - 1 || off + i >= limit)
             return;
         const float *h = h0 + size_t(ch) * B;
-        const int jlo = (i - (B - 1) > 0) ? i - (B - 1) : 0;
+        const int jlo = (i - (taps - 1) > 0) ? i - (taps - 1) : 0;
         const int jhi = (i < cnt - 1) ? i : cnt - 1;
         float s = 0.0f;
         for (int j = jlo; j <= jhi; ++j)
@@ -500,31 +501,223 @@ namespace
             out[size_t(ch) * out_stride + i] = v;
     }
 
+
+    // ---- sub-frame calls of partitioned banks: the head partition as a delay line of SMALL blocks -------------------------
+    // (round 3; the reference bounds the work of every call with its 128-tap head and doubling levels, Convolver.cpp:144-210,
+    // 230-296.)  A call that is not a whole frame used to convolve its samples with all B taps of the head partition in
+    // the time domain (conv_direct_kernel): O(n B) per call, 4096 multiply-adds per output sample at rank 13.  For banks
+    // with a frame of 1024 samples or more the head partition is itself partitioned, uniformly, into blocks of SB = 256,
+    // INSIDE the frame that is being received:
+    //     taps [0, SB)       in the time domain, as the samples arrive (zero latency for any chunking)    [conv_direct_kernel]
+    //     taps [SB, B)       a frequency-domain delay line over the frame's own blocks: when block k of the frame is
+    //                        complete its image enters the small ring (slot k) and what the frame's blocks owe block
+    //                        k + 1, sum_{p = 1 .. k+1} Hs_p Xs_(k+1-p), goes into acc                        [conv_small_kernel]
+    //     across the frame boundary nothing is paid piecewise: every result that would land beyond the frame's end is
+    //     dropped, and when the frame completes its whole spill through the head partition, IFFT(H_0 X_F)[B, 2B), is
+    //     added at once by the commit kernel, which has the frame's image X_F in its hands anyway  [conv_commit_kernel<.., true>]
+    //     taps [B, ...)      the frame-sized delay line, as before
+    // So a frame received in pieces settles with the next frame exactly like a frame received whole, the small ring starts
+    // empty with every frame, and whole-frame calls and sub-frame calls mix freely.  A piece that is exactly one aligned
+    // small block takes all of its work in ONE launch (FULL: its own partition-0 term through the transform as well).
+    // Work per sample is bounded by B / SB complex multiply-adds and three 512-point transforms per 256 samples.
+    constexpr int LOGS = 8, SB = 1 << LOGS;
+
+    // Block k of the frame (`off` = k SB its first sample).
+    //   FULL:      the block arrives whole in this call: in -> frame, image -> ring, out = acc + (Hs_0 x)[0:SB]
+    //   otherwise: the block has been received piecewise (frame holds it, its partition-0 term went through the direct
+    //              kernel): image -> ring
+    // then acc[off + SB, off + 3 SB) += IFFT(sum_{p = 1 .. k+1} Hs_p Xs_(k+1-p)), as far as that lies inside the frame.
+    template <bool FULL>
+    __global__ __launch_bounds__(fplan<LOGS>::T)
+    void conv_small_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, float *frame, int B,
+                           int off, float2 *sring, int Ps, const float2 *__restrict__ Hs,
+                           float *acc, const float2 *__restrict__ tw)
+    {
+        constexpr int M = fplan<LOGS>::N, T = fplan<LOGS>::T, KPT = M / T;
+        static_assert(KPT * T == M && (KPT % 2) == 0, "small blocks: whole pairs per thread");
+        __shared__ float2 lds_[fplan<LOGS>::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + M;
+        const int ch = blockIdx.x, tid = threadIdx.x, kblk = off / SB;
+        typename fplan<LOGS>::real rf;
+        rf.load(tw, TWN, tid);
+        rf.prepare();
+        float *fr = frame + size_t(ch) * B + off;
+        float *a  = acc + size_t(ch) * 2 * B + off;
+        const float2 *hs = Hs + size_t(ch) * Ps * M;
+        float2 *rg = sring + size_t(ch) * Ps * M;
+        const bool next1 = (off + SB < B), next2 = (off + 2 * SB < B);     // the two blocks after this one, if the frame has them
+        float2 xk[KPT];
+        // Everything the ring's debt needs that does not depend on this block is asked for NOW: the small partitions' images
+        // and the images of the frame's earlier blocks (one wave per channel, 512 registers to itself: up to 2 x 15 x 4
+        // values in flight under the transforms instead of fifteen dependent round trips to L2 behind them).
+        constexpr int PMAX = 15;                                            // B / SB - 1 at the largest frame
+        const int pmax = !next1 ? 0 : (kblk + 1 < Ps - 1) ? kblk + 1 : Ps - 1;
+        float2 hreg[PMAX][KPT], xreg[PMAX][KPT];
+        #pragma unroll
+        for (int p = 1; p <= PMAX; ++p)
+            if (p <= pmax)
+            {
+                #pragma unroll
+                for (int i = 0; i < KPT; ++i)
+                {
+                    hreg[p - 1][i] = hs[size_t(p) * M + tid + i * T];
+                    if (p >= 2)
+                        xreg[p - 1][i] = rg[size_t(kblk + 1 - p) * M + tid + i * T];
+                }
+            }
+        // SB real samples = SB / 2 pairs, zero-padded to 2 SB
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int n = tid + i * T;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (n < SB / 2)
+            {
+                if (FULL)
+                {
+                    const float *x = in + size_t(ch) * in_stride;
+                    v = make_float2(x[2 * n], x[2 * n + 1]);
+                    *reinterpret_cast<float2 *>(fr + 2 * n) = v;            // the frame keeps its samples for the commit
+                }
+                else
+                    v = *reinterpret_cast<const float2 *>(fr + 2 * n);
+            }
+            buf[n] = v;
+        }
+        __syncthreads();
+        rf.forward(buf, scr, tid);
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            xk[i] = buf[tid + i * T];
+            if (next2)                                                      // (nobody reads the last two blocks' images)
+                rg[size_t(kblk) * M + tid + i * T] = xk[i];
+        }
+        const float scale = 1.0f / float(2 * M);
+        float2 yhi[KPT / 2];                                                // (Hs_0 x)[SB, 2 SB): owed to the next block
+        #pragma unroll
+        for (int i = 0; i < KPT / 2; ++i)
+            yhi[i] = make_float2(0.0f, 0.0f);
+        if (FULL)
+        {
+            __syncthreads();
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = tid + i * T;
+                buf[k] = image_mul(xk[i], hs[k], k);
+            }
+            __syncthreads();
+            rf.inverse(buf, scr, tid);
+            float *o = out + size_t(ch) * out_stride;
+            #pragma unroll
+            for (int i = 0; i < KPT / 2; ++i)
+            {
+                const int n = tid + i * T;                                  // pair n of the first half, pair n + M/2 of the second
+                const float2 y0 = buf[n], p0 = *reinterpret_cast<const float2 *>(a + 2 * n);
+                o[2 * n]     = fmaf(y0.x, scale, p0.x);
+                o[2 * n + 1] = fmaf(y0.y, scale, p0.y);
+                yhi[i] = buf[n + M / 2];
+            }
+        }
+        if (!next1)
+            return;                                                         // the frame's last block: the commit settles the rest
+        // what the frame's blocks owe block k + 1: p = 1 is this block's own image
+        float2 t[KPT];
+        float dc = 0.0f, ny = 0.0f;
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            t[i] = make_float2(0.0f, 0.0f);
+        #pragma unroll
+        for (int p = 1; p <= PMAX; ++p)
+            if (p <= pmax)
+            {
+                #pragma unroll
+                for (int i = 0; i < KPT; ++i)
+                {
+                    const int k = tid + i * T;
+                    const float2 h = hreg[p - 1][i];
+                    const float2 x = (p == 1) ? xk[i] : xreg[p - 1][i];
+                    t[i].x = fmaf(x.x, h.x, fmaf(-x.y, h.y, t[i].x));
+                    t[i].y = fmaf(x.x, h.y, fmaf(x.y, h.x, t[i].y));
+                    if (k == 0)
+                    {
+                        dc = fmaf(x.x, h.x, dc);
+                        ny = fmaf(x.y, h.y, ny);
+                    }
+                }
+            }
+        __syncthreads();
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int k = tid + i * T;
+            buf[k] = (k == 0) ? make_float2(dc, ny) : t[i];
+        }
+        __syncthreads();
+        rf.inverse(buf, scr, tid);
+        #pragma unroll
+        for (int i = 0; i < KPT / 2; ++i)
+        {
+            const int n = tid + i * T;
+            const float2 t0 = buf[n], t1 = buf[n + M / 2];
+            float2 *a1 = reinterpret_cast<float2 *>(a + SB + 2 * n), *a2 = reinterpret_cast<float2 *>(a + 2 * SB + 2 * n);
+            const float2 v1 = *a1;
+            *a1 = make_float2(fmaf(t0.x + yhi[i].x, scale, v1.x), fmaf(t0.y + yhi[i].y, scale, v1.y));
+            if (next2)
+            {
+                const float2 v2 = *a2;
+                *a2 = make_float2(fmaf(t1.x, scale, v2.x), fmaf(t1.y, scale, v2.y));
+            }
+        }
+    }
+
     // frame complete after partial calls: its spectrum enters the ring, acc moves on by one frame
-    template <int LOGM>
+    // SETTLE (banks whose sub-frame calls go through conv_small_kernel): nothing of this frame has been added beyond its end
+    // yet -- its whole spill through the head partition, IFFT(H_0 X_F)[B, 2B), is added here.
+    template <int LOGM, bool SETTLE>
     __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_commit_kernel(const float *frame, float2 *ring, int R, int slot, float *acc,
-                            const float2 *__restrict__ tw)
+                            const float2 *__restrict__ tw, const float2 *__restrict__ H, int P)
     {
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
         float2 *const buf = lds_, *const scr = lds_ + M;
         const int ch = blockIdx.x, tid = threadIdx.x;
-        if (R > 0)
+        if (R > 0 || SETTLE)
         {
             typename fplan<LOGM>::real rf;
             rf.load(tw, TWN, tid);
             rf.prepare();
             load_and_forward<LOGM>(buf, scr, frame + size_t(ch) * B, B, true, rf, tid);
             float2 *rdst = ring + (size_t(ch) * R + slot) * M;
+            const float2 *h0 = H + size_t(ch) * P * M;
             for (int k = tid; k < M; k += T)
-                rdst[k] = buf[k];
+            {
+                const float2 xk = buf[k];
+                if (R > 0)
+                    rdst[k] = xk;
+                if (SETTLE)
+                    buf[k] = image_mul(xk, h0[k], k);
+            }
+            if (SETTLE)
+            {
+                __syncthreads();
+                rf.inverse(buf, scr, tid);
+            }
         }
+        const float scale = 1.0f / float(2 * M);
         float2 *a = reinterpret_cast<float2 *>(acc + size_t(ch) * 2 * B);
         for (int n = tid; n < M / 2; n += T)
         {
-            a[n] = a[n + M / 2];
+            float2 v = a[n + M / 2];
+            if (SETTLE)
+            {
+                const float2 y1 = buf[n + M / 2];
+                v = make_float2(fmaf(y1.x, scale, v.x), fmaf(y1.y, scale, v.y));
+            }
+            a[n] = v;
             a[n + M / 2] = make_float2(0.0f, 0.0f);
         }
     }
@@ -716,6 +909,10 @@ struct mi_convolver_bank
     bool        yt_pending = false; // d_yt holds a tail spectrum that has not been folded into acc yet
     bool        upper_zero = false; // acc[B:2B] holds zeros (true between whole frames: the frame kernel skips that half)
     uint32_t   *d_sync = nullptr;   // [done[channels] | seen[channels] | fault]: hand-over between the roles of conv_step_kernel
+    // sub-frame calls of partitioned banks (conv_small_kernel): the head partition as a delay line of SB-sample blocks
+    bool        small = false;      // P >= 2 and B >= 1024
+    int         Ps = 0;             // small partitions of the head: B / SB
+    float2     *d_Hs = nullptr, *d_sring = nullptr;     // [channels][Ps][SB]: images of the small partitions / of the frame's blocks
     uint32_t   *h_fault = nullptr;  // host-mapped flag raised by a hand-over that timed out (read by process() without a sync)
     uint32_t   *d_fault_host = nullptr;     // its device address
     int         cus = 256;          // compute units of the device the bank lives on
@@ -1006,6 +1203,22 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
         #undef MI_CALL
         e = hipGetLastError();
     }
+    static const bool no_small = getenv("MI_CONV_NO_SMALL") != nullptr;         // experiment knob: the round-2 path
+    if (e == hipSuccess && b->P >= 2 && b->B >= 4 * SB && !no_small)
+    {
+        b->small = true;
+        b->Ps = b->B / SB;
+        const size_t cells = size_t(channels) * b->Ps * SB;
+        e = hipMalloc(reinterpret_cast<void **>(&b->d_Hs), cells * sizeof(float2));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_sring), cells * sizeof(float2));
+        if (e == hipSuccess)
+        {
+            // the head partition's taps (zero padded rows of d_h0) as Ps small partitions
+            hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, channels), dim3(fplan<LOGS>::T), 0, st,
+                               b->d_Hs, b->d_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, (const uint8_t *)nullptr);
+            e = hipGetLastError();
+        }
+    }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     (void)hipFree(d_ir);
     (void)hipFree(d_counts);
@@ -1057,6 +1270,12 @@ static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_strid
                                                dst_H, d_ir, size_t(b->P) * M, d_counts, b->P, b->d_tw, d_only)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && b->small && dst_h0 == b->d_h0)
+    {
+        hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, b->channels), dim3(fplan<LOGS>::T), 0, st,
+                           b->d_Hs, dst_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, d_only);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -1206,6 +1425,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     }
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
+    (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
     const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
     (void)hipHostFree(b->h_fault);
     delete b;
@@ -1337,6 +1557,41 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             const int rf = fold_pending(b, st);
             if (rf != MI_OK)
                 return rf;
+            if (b->small)
+            {
+                // the head partition as a delay line of SB-sample blocks inside the frame (conv_small_kernel): bounded work
+                int cnt;
+                if ((b->off % SB) == 0 && left >= size_t(SB))
+                {
+                    cnt = SB;                                               // an aligned whole block: one launch
+                    hipLaunchKernelGGL((conv_small_kernel<true>), dim3(b->channels), dim3(fplan<LOGS>::T), 0, st,
+                                       o, x, out_stride, in_stride, b->d_frame, B, b->off, b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
+                    MI_HIP_CHECK(hipGetLastError());
+                    b->off += cnt;
+                }
+                else
+                {
+                    const size_t room = size_t(SB - (b->off % SB));
+                    cnt = int((left < room) ? left : room);
+                    MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
+                                                  size_t(cnt) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+                    hipLaunchKernelGGL(conv_direct_kernel, dim3((cnt + SB - 1 + 255) / 256, b->channels), dim3(256),
+                                       size_t(cnt) * sizeof(float), st, o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, SB, B);
+                    MI_HIP_CHECK(hipGetLastError());
+                    b->off += cnt;
+                    if ((b->off % SB) == 0)                                 // the block is complete: its image, and what the frame owes the next
+                    {
+                        hipLaunchKernelGGL((conv_small_kernel<false>), dim3(b->channels), dim3(fplan<LOGS>::T), 0, st,
+                                           (float *)nullptr, (const float *)nullptr, size_t(0), size_t(0), b->d_frame, B, b->off - SB,
+                                           b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
+                        MI_HIP_CHECK(hipGetLastError());
+                    }
+                }
+                b->upper_zero = false;
+                done += size_t(cnt);
+            }
+            else
+            {
             const int cnt = int((left < size_t(B - b->off)) ? left : size_t(B - b->off));
             const dim3 grid((cnt + B - 1 + 255) / 256, b->channels);
             MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
@@ -1348,17 +1603,21 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                                    o, out_stride, b->d_acc, b->d_frame, b->d_h0, b->d_h0x, B, b->off, cnt, b->d_xmask);
             else
                 hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
-                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt);
+                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, B, 2 * B);
             MI_HIP_CHECK(hipGetLastError());
             b->upper_zero = false;
             b->off += cnt;
             done += size_t(cnt);
+            }
             if (b->off == B)
             {
                 if (b->R > 0)
                     b->slot = (b->slot + 1) % b->R;
-                #define MI_CALL(LM) hipLaunchKernelGGL((conv_commit_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
-                                                       b->d_frame, b->d_ring, b->R, b->slot, b->d_acc, b->d_tw)
+                #define MI_CALL(LM) \
+                    if (b->small) hipLaunchKernelGGL((conv_commit_kernel<LM, true>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
+                                                     b->d_frame, b->d_ring, b->R, b->slot, b->d_acc, b->d_tw, b->d_H, b->P); \
+                    else          hipLaunchKernelGGL((conv_commit_kernel<LM, false>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
+                                                     b->d_frame, b->d_ring, b->R, b->slot, b->d_acc, b->d_tw, b->d_H, b->P)
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());

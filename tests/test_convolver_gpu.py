@@ -231,6 +231,62 @@ def test_random_geometry_and_call_sizes(gpu, seed):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_subframe_calls_on_large_frames(gpu, seed):
+    """Sub-frame calls of partitioned banks with frames of 1024 samples and more go through the small-block delay line
+    (conv_small_kernel: 256-sample blocks inside the frame, the frame's spill settled at its completion), whole frames through
+    the frame step; both mixed at random -- aligned blocks, ragged pieces, pieces across block and frame boundaries, whole
+    frames in between, resets -- against the exact (float64) linear convolution of the channel's history."""
+    rng = np.random.default_rng(9100 + seed)
+    C = 3
+    rank = int(rng.choice([11, 12, 13]))
+    frame = 1 << (rank - 1)
+    taps = int(rng.choice([frame + 1, 2 * frame, 3 * frame + 17, 5 * frame]))
+    counts = np.array([taps] + [int(rng.integers(frame + 1, taps + 1)) for _ in range(C - 1)], np.uint32)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / (0.3 * taps + 1))).astype(np.float32)
+    bank = gpu.ConvolverBank(irs, rank, counts=counts)
+    hist = [np.zeros(0, np.float32) for _ in range(C)]
+    sizes = [1, 2, 100, 255, 256, 257, 511, 512, 768, 1000, frame - 256, frame - 1, frame, frame + 1, frame + 256, 2 * frame]
+    for step in range(36):
+        if rng.integers(0, 15) == 0:
+            bank.reset()
+            hist = [np.zeros(0, np.float32) for _ in range(C)]
+            continue
+        k = int(rng.choice(sizes + [int(rng.integers(1, 3 * frame))]))
+        x = rng.standard_normal((C, k)).astype(np.float32)
+        din = gpu.DeviceBuffer.from_host(x)
+        dout = din if rng.integers(0, 2) else gpu.DeviceBuffer((C, k))
+        bank.process(dout, din, k)
+        y = dout.download()
+        for c in range(C):
+            hist[c] = np.concatenate([hist[c], x[c]])[-(taps + 4 * frame + k):]
+            ref = exact_conv(hist[c], irs[c, :counts[c]])[-k:]
+            peak = max(float(np.abs(ref).max()), 1.0)
+            err = float(np.abs(y[c] - ref).max())
+            record_parity("convolver sub-frame calls: |gpu - exact| <= 2e-5 peak", err, 2 * TOL * peak)
+            assert err <= 2 * TOL * peak, (seed, step, c, k, rank, taps, int(counts[c]), err / peak)
+    assert bank.faults() == 0
+    bank.close()
+
+
+def test_stream_of_256_sample_calls_c3_shape(gpu):
+    """What a plugin host does: 256-sample calls, for ever.  16 channels of the C3 shape (65536 taps, rank 13), five frames'
+    worth of calls: every call is one aligned small block (one launch), every sixteenth completes a frame."""
+    rng = np.random.default_rng(77)
+    C, taps, frame, nf = 16, 65536, 4096, 5
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
+    x = rng.standard_normal((C, nf * frame)).astype(np.float32)
+    y, info = run_gpu(gpu, irs, 13, x, [256] * (nf * frame // 256))
+    assert info["frame"] == 4096 and info["partitions"] == 16
+    for c in range(C):
+        ex = exact_conv(x[c], irs[c])
+        err = float(np.abs(y[c] - ex).max()) / float(np.abs(ex).max())
+        record_parity("convolver, stream of 256-sample calls: |gpu - exact| <= 1e-5 peak", err, TOL)
+        assert err <= TOL, (c, err)
+    ref = oracle.Convolver(irs[0], 13).process_chunked(x[0], 256)
+    check(y[0], ref, exact_conv(x[0], irs[0]), "channel 0, 256-sample calls")
+
+
 def test_more_channels_than_compute_units(gpu):
     """The one-launch frame step pairs a frame and a tail workgroup per CU; a bank with more channels than the device has
     CUs goes in several such launches per frame.  300 channels at rank 13 (distinct three-partition responses), whole frames
