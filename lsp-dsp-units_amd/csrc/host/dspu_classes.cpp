@@ -6,6 +6,7 @@
 // unusable object, leaves the output as the reference would (zeros or a copy).
 #include <lsp-plug.in/dsp-units/filters/Filter.h>
 #include <lsp-plug.in/dsp-units/filters/FilterBank.h>
+#include <lsp-plug.in/dsp-units/filters/FilterArray.h>
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
 #include <lsp-plug.in/dsp-units/filters/DynamicFilters.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
@@ -3546,6 +3547,160 @@ void Analyzer::dump(IStateDumper *v) const
     v->write("nSampleRate", size_t(nSampleRate));
     v->write("nReconfigure", size_t(nReconfigure));
     v->write("bActive", bActive);
+}
+
+// ---- FilterArray (extension: the batched mode under the class API) ------------------------------------------------------
+// One device bank with one channel per Filter object; the objects' designs are kept on the host and sent to the bank
+// lazily, as Filter::process() rebuilds lazily (Filter.cpp:698-720).
+namespace
+{
+    struct filter_array
+    {
+        mi_biquad_bank_t               *bank = nullptr;
+        size_t                          max_chains = 0;
+        std::vector<filter_params_t>    params;
+        std::vector<uint32_t>           rate;
+        std::vector<uint8_t>            rebuild, wipe;
+        bool                            pending = false;
+        staging                         st;
+    };
+    inline filter_array *fa_of(void *p) { return static_cast<filter_array *>(p); }
+}
+
+FilterArray::FilterArray() { construct(); }
+FilterArray::~FilterArray() { destroy(); }
+void FilterArray::construct() { pImpl = nullptr; }
+
+bool FilterArray::init(size_t filters, size_t max_chains)
+{
+    destroy();
+    if (filters == 0 || max_chains == 0 || max_chains > size_t(mi::CHAINS_MAX))
+        return false;
+    filter_array *a = new (std::nothrow) filter_array();
+    if (a == nullptr)
+        return false;
+    if (last_status(mi_biquad_bank_create(&a->bank, uint32_t(filters), uint32_t(max_chains))) != MI_OK)
+    {
+        delete a;
+        return false;
+    }
+    a->max_chains = max_chains;
+    filter_params_t none;
+    none.nType = FLT_NONE; none.nSlope = 1; none.fFreq = none.fFreq2 = none.fGain = none.fQuality = 0.0f;
+    a->params.assign(filters, none);
+    a->rate.assign(filters, 0);
+    a->rebuild.assign(filters, 0);
+    a->wipe.assign(filters, 0);
+    pImpl = a;
+    return true;
+}
+
+void FilterArray::destroy()
+{
+    filter_array *a = fa_of(pImpl);
+    if (a != nullptr)
+    {
+        a->st.release();
+        mi_biquad_bank_destroy(a->bank);
+        delete a;
+    }
+    pImpl = nullptr;
+}
+
+size_t FilterArray::size() const { return (pImpl != nullptr) ? fa_of(pImpl)->params.size() : 0; }
+
+bool FilterArray::update(size_t id, size_t sr, const filter_params_t *params)
+{
+    filter_array *a = fa_of(pImpl);
+    if (a == nullptr || id >= a->params.size() || params == nullptr || sr == 0)
+        return false;
+    // the design is checked now (so that an over-long one can be refused) and sent with the next process()
+    uint32_t n = 0;
+    if (last_status(mi_filter_design(cfp(params), uint32_t(sr), nullptr, 0, &n, nullptr, 0, nullptr, nullptr)) != MI_OK || n > a->max_chains)
+        return false;
+    a->params[id]  = *params;
+    mi_filter_limit(cfp(&a->params[id]), uint32_t(sr));         // Filter::update stores the limited parameters (Filter.cpp:147-150)
+    a->rate[id]    = uint32_t(sr);
+    a->rebuild[id] = 1;
+    a->pending     = true;
+    return true;
+}
+
+bool FilterArray::get_params(size_t id, filter_params_t *params) const
+{
+    const filter_array *a = fa_of(pImpl);
+    if (a == nullptr || id >= a->params.size() || params == nullptr)
+        return false;
+    *params = a->params[id];
+    return true;
+}
+
+void FilterArray::clear(size_t id)
+{
+    filter_array *a = fa_of(pImpl);
+    if (a == nullptr)
+        return;
+    for (size_t i = 0; i < a->params.size(); ++i)
+        if (id == size_t(-1) || id == i)
+            a->wipe[i] = 1;
+    a->pending = true;
+}
+
+namespace
+{
+    bool fa_commit(filter_array *a, void *stream)
+    {
+        if (!a->pending)
+            return true;
+        std::vector<mi_biquad_x1_t> sec(a->max_chains);
+        for (size_t i = 0; i < a->params.size(); ++i)
+        {
+            if (a->rebuild[i])
+            {
+                uint32_t n = 0;
+                int mode = MI_FM_BYPASS;
+                if (last_status(mi_filter_design(cfp(&a->params[i]), a->rate[i], sec.data(), uint32_t(sec.size()), &n, nullptr, 0,
+                                                 nullptr, &mode)) != MI_OK)
+                    return false;
+                if (mode == MI_FM_BYPASS)
+                    n = 0;                                      // Filter::process copies (Filter.cpp:712-717): a bank row without sections
+                // FilterBank::end(clear): the memory goes when asked for or when the section count changed (FilterBank.cpp:233-235)
+                if (last_status(mi_biquad_bank_set_chains(a->bank, uint32_t(i), sec.data(), n, a->wipe[i] ? 1 : 0)) != MI_OK)
+                    return false;
+                a->rebuild[i] = a->wipe[i] = 0;
+            }
+            else if (a->wipe[i])
+            {
+                if (last_status(mi_biquad_bank_reset(a->bank, uint32_t(i), stream)) != MI_OK)
+                    return false;
+                a->wipe[i] = 0;
+            }
+        }
+        a->pending = false;
+        return last_status(mi_biquad_bank_commit(a->bank, stream)) == MI_OK;
+    }
+}
+
+bool FilterArray::process(float *dev_out, const float *dev_in, size_t samples, size_t stride, void *stream)
+{
+    filter_array *a = fa_of(pImpl);
+    if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
+        return false;
+    if (samples == 0)
+        return true;
+    return fa_commit(a, stream) &&
+           last_status(mi_biquad_bank_process(a->bank, dev_out, dev_in, samples, stride, stride, stream)) == MI_OK;
+}
+
+bool FilterArray::process_host(float *out, const float *in, size_t samples, size_t stride)
+{
+    filter_array *a = fa_of(pImpl);
+    if (a == nullptr || out == nullptr || in == nullptr || stride < samples)
+        return false;
+    if (samples == 0)
+        return true;
+    const size_t n = a->params.size() * stride;
+    return a->st.reserve(n) && a->st.up(in, n) && process(a->st.d_out, a->st.d_in, samples, stride, nullptr) && a->st.down(out, n);
 }
 
 } // namespace dspu

@@ -7,6 +7,7 @@
 //   README.md:145-230                      the Filter demo (C1)
 // Plain C++11, no test framework: exit code 0 == all passed.  Needs a GPU (the classes have no CPU fallback).
 #include <lsp-plug.in/dsp-units/filters/Filter.h>
+#include <lsp-plug.in/dsp-units/filters/FilterArray.h>
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
 #include <lsp-plug.in/dsp-units/filters/DynamicFilters.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
@@ -579,6 +580,67 @@ static void readme_filter()
     CHECK(y[479] == 0.0f && y[480] == c[0] && y[1999] == c[1519], "delay");
 }
 
+// ---- FilterArray: N Filter objects behind one bank (this library's extension) ------------------------------------------
+// Every object of the array must behave like the dspu::Filter it stands for: same designer, same lazy rebuild, the filter
+// memory cleared when the section count changes and kept otherwise, bypass for FLT_NONE -- checked block by block against
+// N separate Filter objects, over retunes in the middle of the stream, on host rows and on device rows.
+static void filter_array_equals_n_filters()
+{
+    printf("FilterArray against separate Filter objects\n");
+    const size_t N = 9, n = 3000, blocks = 4;
+    const int types[N] = { dspu::FLT_BT_RLC_BELL, dspu::FLT_BT_BWC_HISHELF, dspu::FLT_BT_LRX_LOPASS, dspu::FLT_MT_RLC_BELL,
+                           dspu::FLT_NONE, dspu::FLT_BT_RLC_LOPASS, dspu::FLT_BT_BWC_HIPASS, dspu::FLT_BT_RLC_NOTCH, dspu::FLT_BT_LRX_HISHELF };
+    dspu::FilterArray fa;
+    CHECK(fa.init(N, 16), "FilterArray::init");
+    CHECK(fa.size() == N, "size");
+    std::vector<dspu::Filter> fl(N);
+    std::vector<dspu::filter_params_t> fp(N);
+    for (size_t i = 0; i < N; ++i)
+    {
+        fp[i].nType = types[i]; fp[i].nSlope = 1 + (i % 3); fp[i].fFreq = 300.0f * float(i + 1); fp[i].fFreq2 = fp[i].fFreq * 2.0f;
+        fp[i].fGain = (i & 1) ? 2.0f : 0.5f; fp[i].fQuality = 0.3f * float(i % 4);
+        CHECK(fl[i].init(NULL), "Filter::init");
+        fl[i].update(48000, &fp[i]);
+        CHECK(fa.update(i, 48000, &fp[i]), "FilterArray::update %zu", i);
+    }
+    dspu::filter_params_t big = fp[2];
+    big.nSlope = 20;                                                 // LRX slope 20 = 40 sections: more than the array's 16
+    CHECK(!fa.update(2, 48000, &big), "an over-long design must be refused");
+    std::vector<float> x(N * n), ya(N * n), yf(N * n);
+    float *din = NULL, *dout = NULL;
+    CHECK(mi_dspu_malloc(reinterpret_cast<void **>(&din), x.size() * sizeof(float)) == MI_OK &&
+          mi_dspu_malloc(reinterpret_cast<void **>(&dout), x.size() * sizeof(float)) == MI_OK, "device rows");
+    unsigned seed = 12345;
+    for (size_t b = 0; b < blocks; ++b)
+    {
+        for (size_t i = 0; i < x.size(); ++i) { seed = seed * 1664525u + 1013904223u; x[i] = (float(seed >> 8) / 8388608.0f - 1.0f) * 0.25f; }
+        if (b == 2)                                                  // retune in mid-stream: object 0 keeps its section count (memory kept),
+        {                                                            // object 1 changes it (memory cleared), object 4 comes alive
+            fp[0].fGain = 1.5f;                 fl[0].update(48000, &fp[0]); CHECK(fa.update(0, 48000, &fp[0]), "retune 0");
+            fp[1].nSlope = 3;                   fl[1].update(48000, &fp[1]); CHECK(fa.update(1, 48000, &fp[1]), "retune 1");
+            fp[4].nType = dspu::FLT_BT_RLC_BELL; fl[4].update(48000, &fp[4]); CHECK(fa.update(4, 48000, &fp[4]), "retune 4");
+        }
+        for (size_t i = 0; i < N; ++i)
+            fl[i].process(&yf[i * n], &x[i * n], n);
+        if (b & 1)                                                   // device rows
+        {
+            CHECK(mi_dspu_copy_h2d(din, x.data(), x.size() * sizeof(float), NULL) == MI_OK, "h2d");
+            CHECK(fa.process(dout, din, n, n), "FilterArray::process");
+            CHECK(mi_dspu_copy_d2h(ya.data(), dout, ya.size() * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+        }
+        else
+            CHECK(fa.process_host(ya.data(), x.data(), n, n), "FilterArray::process_host");
+        // the same kernels run either way (one row of a nine-row bank against nine one-row banks): bit for bit
+        size_t bad = 0;
+        for (size_t i = 0; i < x.size(); ++i)
+            bad += (ya[i] != yf[i]);
+        CHECK(bad == 0, "block %zu: %zu samples differ from the separate Filter objects", b, bad);
+    }
+    dspu::filter_params_t back;
+    CHECK(fa.get_params(0, &back) && back.fGain == 1.5f, "get_params");
+    mi_dspu_free(din); mi_dspu_free(dout);
+}
+
 // ---- binary layout of the drop-in classes ---------------------------------------------------------------------------
 // Object sizes and member offsets of the reference headers (lsp-dsp-units 1.0.36, LP64; sizes of SURVEY.md 0.4 plus the
 // member lists of filters/FilterBank.h:39-46, filters/Filter.h:57-65, filters/Equalizer.h:59-78, util/Convolver.h:38-56,
@@ -986,7 +1048,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects filter_array");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -1011,6 +1073,7 @@ int main(int argc, char **argv)
     accessors();
     readme_filter();
     raw_memory_objects();
+    filter_array_equals_n_filters();
     CHECK(dspu::last_status() == MI_OK, "device status after the whole replay: %d (%s)", dspu::last_status(), mi_dspu_last_error());
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
