@@ -195,11 +195,20 @@ namespace mi_fft
     // synchronises).  On entry the caller must have synchronised after filling buf; on exit the transform is in buf,
     // natural order, synchronised.  One barrier per pass: the passes ping-pong between the two buffers (an odd number of
     // passes starts with one in-place pass).
-    template <int LOGN, bool INVERSE>
-    __device__ void fft_lds(float2 *buf, float2 *scr, const fft_tw<LOGN> &tws, int tid)
+    // REG_IN:  the first pass takes its inputs from `io` instead of buf: io[i] = x[tid + i T], i < N / T -- the natural
+    //          distribution of a sequence over the workgroup, which is exactly what thread tid's butterflies of the first
+    //          pass read (j + k Q with Q a multiple of T), so a kernel that has just loaded (and windowed) its frame hands it
+    //          over in registers and saves the LDS write, the barrier and the first pass's LDS reads;
+    // REG_OUT: the last pass leaves its outputs in `io` (same distribution: output m of butterfly j is X[j + m Q]) instead
+    //          of writing them to buf -- for a consumer that works element-wise (window, overlap-add, store).
+    // On entry with REG_IN nobody may still be using buf or scr (a barrier of the caller covers that); on exit with REG_OUT
+    // buf and scr are free again after the caller's next barrier.
+    template <int LOGN, bool INVERSE, bool REG_IN = false, bool REG_OUT = false>
+    __device__ void fft_lds(float2 *buf, float2 *scr, const fft_tw<LOGN> &tws, int tid, v2f *io = nullptr)
     {
         using P = plan<LOGN>;
         constexpr int N = P::N, T = P::T, NP = P::NP;
+        static_assert(!(REG_IN || REG_OUT) || (T == P::TB), "register hand-over needs a whole butterfly of the widest pass per thread (512 .. 8192 points)");
 
         float2 *src = buf;
         float2 *dst = (NP & 1) ? buf : scr;
@@ -220,10 +229,11 @@ namespace mi_fft
                     {
                         #pragma unroll
                         for (int k = 0; k < 8; ++k)
-                            v[b][k] = ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
+                            v[b][k] = (first && REG_IN) ? io[b + k * (Q / T)]          // x[j + k Q] = x[tid + (b + k Q/T) T]
+                                                        : ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
                     }
                 }
-                if (dst == src)
+                if (dst == src && !(first && REG_IN))
                     __syncthreads();
                 #pragma unroll
                 for (int b = 0; b < BPT; ++b)
@@ -240,7 +250,10 @@ namespace mi_fft
                             v2f r = v[b][m];
                             if (m > 0 && s < Q)                          // s == Q: p = 0, all twiddles are 1
                                 r = pmul<INVERSE>(tws.w[pass][b][m - 1], r);
-                            st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
+                            if (last && REG_OUT)
+                                io[b + m * (Q / T)] = r;                 // X[j + m Q] (last pass: s = Q, o = j)
+                            else
+                                st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
                         }
                     }
                 }
@@ -257,10 +270,11 @@ namespace mi_fft
                     {
                         #pragma unroll
                         for (int k = 0; k < 4; ++k)
-                            v[b][k] = ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
+                            v[b][k] = (first && REG_IN) ? io[b + k * (Q / T)]
+                                                        : ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
                     }
                 }
-                if (dst == src)
+                if (dst == src && !(first && REG_IN))
                     __syncthreads();
                 #pragma unroll
                 for (int b = 0; b < BPT; ++b)
@@ -277,12 +291,16 @@ namespace mi_fft
                             v2f r = v[b][m];
                             if (m > 0 && s < Q)
                                 r = pmul<INVERSE>(tws.w[pass][b][m - 1], r);
-                            st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
+                            if (last && REG_OUT)
+                                io[b + m * (Q / T)] = r;
+                            else
+                                st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
                         }
                     }
                 }
             }
-            __syncthreads();
+            if (!(last && REG_OUT))
+                __syncthreads();
             src = dst;
             dst = (src == buf) ? scr : buf;
         }
@@ -405,6 +423,62 @@ namespace mi_fft
         {
             real_merge<LOGM>(buf, rt, tid);
             fft_lds<LOGM, true>(buf, scr, ft, tid);
+        }
+
+        // The same with the samples handed over in registers (512 .. 8192-point transforms: fft_lds REG_IN / REG_OUT):
+        // io[i] = pair tid + i T of the packed sequence, i < M / T.
+        static constexpr bool REGS = (plan<LOGM>::T == plan<LOGM>::TB);
+        static constexpr int  KPT  = plan<LOGM>::N / plan<LOGM>::T;
+        __device__ __forceinline__ void forward_regs(v2f *io, float2 *buf, float2 *scr, int tid) const
+        {
+            fft_lds<LOGM, false, true, false>(buf, scr, ft, tid, io);
+            real_split<LOGM>(buf, rt, tid);
+        }
+        __device__ __forceinline__ void inverse_regs(v2f *io, float2 *buf, float2 *scr, int tid) const
+        {
+            real_merge<LOGM>(buf, rt, tid);
+            fft_lds<LOGM, true, false, true>(buf, scr, ft, tid, io);
+        }
+        // Z (the M-point transform of the packed sequence, in buf) -> image, times REAL gains per bin (g[k], k = 0 .. M: a
+        // Hermitian-symmetric mask), -> the Z' whose unnormalised inverse is 2M times the masked sequence: real_split, the
+        // multiplication and real_merge in ONE pass over the pairs (k, M - k) -- one LDS round trip and one barrier instead
+        // of three of each.  With A = e - i w o (= X_k) and Bc = e + i w o (= conj X_(M-k)) of real_split:
+        //     e' = g_k A + g_m Bc,  o' = g_k A - g_m Bc,  Z'_k = e' + i conj(w) o',  Z'_(M-k) = conj(e' - i conj(w) o')
+        __device__ __forceinline__ void mask_pairs(float2 *buf, const float *__restrict__ g, int tid) const
+        {
+            constexpr int M = plan<LOGM>::N, T = plan<LOGM>::T;
+            #pragma unroll
+            for (int i = 0; i < real_tw<LOGM>::ITER; ++i)
+            {
+                const int k = tid + i * T;
+                if (k >= M / 2)
+                    continue;
+                if (k == 0)
+                {
+                    const float2 z0 = buf[0];
+                    const float x0 = (z0.x + z0.y) * g[0], xm = (z0.x - z0.y) * g[M];
+                    buf[0] = make_float2(x0 + xm, x0 - xm);
+                    const float2 zh = buf[M / 2];
+                    const float gh = 2.0f * g[M / 2];
+                    buf[M / 2] = make_float2(gh * zh.x, gh * zh.y);
+                }
+                else
+                {
+                    const float2 zk = buf[k], zm = buf[M - k];
+                    const float2 w  = rt.w[i];
+                    const float gk = g[k], gm = g[M - k];
+                    const float2 e  = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                    const float2 o  = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
+                    const float2 wo = cmul(w, o);
+                    const float2 A  = make_float2((e.x + wo.y) * gk, (e.y - wo.x) * gk);     // g_k X_k
+                    const float2 Bc = make_float2((e.x - wo.y) * gm, (e.y + wo.x) * gm);     // g_m conj X_(M-k)
+                    const float2 e2 = cadd(A, Bc), o2 = csub(A, Bc);
+                    const float2 wq = cmul(cconj(w), o2);
+                    buf[k]     = make_float2(e2.x - wq.y, e2.y + wq.x);
+                    buf[M - k] = make_float2(e2.x + wq.y, -(e2.y - wq.x));
+                }
+            }
+            __syncthreads();
         }
     };
 } // namespace mi_fft

@@ -219,18 +219,35 @@ namespace
                 for (int i = 0; i < HPT; ++i)
                     hi[i] = s2[(h - 1) * (H / 2) + tix + i * T];
             }
+            // 512 .. 8192-point transforms take the windowed frame in registers and hand the result back in registers (fft_lds
+            // REG_IN / REG_OUT: pair tix + i T is exactly what thread tix's first butterfly reads and its last one writes),
+            // and the split into the half spectrum, the gains and the merge are ONE pass over LDS (real_fft::mask_pairs)
+            constexpr bool REGS = MASKED && !fplan<LOGH>::radix16 && (mi_fft::plan<LOGH>::T == mi_fft::plan<LOGH>::TB);
+            v2f io[KPT];
             #pragma unroll
             for (int i = 0; i < HPT; ++i)
             {
                 const int m = tix + i * T;
                 const float2 w0 = (wi != nullptr) ? wi[m] : make_float2(1.0f, 1.0f);
                 const float2 w1 = (wi != nullptr) ? wi[m + H / 2] : make_float2(1.0f, 1.0f);
-                buf[m]         = make_float2(lo[i].x * w0.x, lo[i].y * w0.y);
-                buf[m + H / 2] = make_float2(hi[i].x * w1.x, hi[i].y * w1.y);
+                io[i]       = v2f{lo[i].x * w0.x, lo[i].y * w0.y};
+                io[i + HPT] = v2f{hi[i].x * w1.x, hi[i].y * w1.y};
+                if (!REGS)
+                {
+                    buf[m]         = make_float2(io[i].x, io[i].y);
+                    buf[m + H / 2] = make_float2(io[i + HPT].x, io[i + HPT].y);
+                }
                 lo[i] = hi[i];                                              // the frame moves on by half
             }
-            __syncthreads();
-            if (MASKED)
+            if (!REGS)
+                __syncthreads();
+            if constexpr (REGS)
+            {
+                mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tix, io);
+                rf.mask_pairs(buf, mk, tix);
+                mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tix, io);
+            }
+            else if (MASKED)
             {
                 rf.forward(buf, scr, tix);
                 #pragma unroll
@@ -246,12 +263,23 @@ namespace
                 __syncthreads();
                 rf.inverse(buf, scr, tix);
             }
+            if (!REGS)
+            {
+                #pragma unroll
+                for (int i = 0; i < HPT; ++i)
+                {
+                    const float2 a = buf[tix + i * T], c = buf[tix + i * T + H / 2];
+                    io[i] = v2f{a.x, a.y};
+                    io[i + HPT] = v2f{c.x, c.y};
+                }
+            }
             const bool last = (h + 1 == hops);
             #pragma unroll
             for (int i = 0; i < HPT; ++i)
             {
                 const int m = tix + i * T;
-                const float2 y0 = buf[m], w0 = wo[m], y1 = buf[m + H / 2], w1 = wo[m + H / 2];
+                const float2 w0 = wo[m], w1 = wo[m + H / 2];
+                const v2f y0 = io[i], y1 = io[i + HPT];
                 const float2 done = make_float2(fmaf(y0.x * scale, w0.x, prev[i].x), fmaf(y0.y * scale, w0.y, prev[i].y));
                 prev[i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);     // the tail the next hop adds to
                 d2[h * (H / 2) + m] = done;                                 // the finished frame, straight to the caller
