@@ -175,11 +175,26 @@ namespace
         }
         MI_CPROBE(1);
         rf.prepare();
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            buf[tid + i * T] = xin[i];
-        __syncthreads();
-        rf.forward(buf, scr, tid);
+        // 512-point transforms and up: the frame goes into the forward transform in registers and comes out of the inverse in
+        // registers (fft_lds REG_IN / REG_OUT): two LDS round trips and two barriers less per frame
+        constexpr bool REGS = !fplan<LOGM>::radix16 && (mi_fft::plan<LOGM>::T == mi_fft::plan<LOGM>::TB);
+        v2f io[KPT];
+        if constexpr (REGS)
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                io[i] = v2f{xin[i].x, xin[i].y};
+            mi_fft::fft_lds<LOGM, false, true, false>(buf, scr, rf.ft, tid, io);
+            mi_fft::real_split<LOGM>(buf, rf.rt, tid);
+        }
+        else
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                buf[tid + i * T] = xin[i];
+            __syncthreads();
+            rf.forward(buf, scr, tid);
+        }
         MI_CPROBE(2);
 
         // the frame's image enters the ring; its product with the head partition plus the pending tail goes back
@@ -207,7 +222,13 @@ namespace
         if (done != nullptr && tid == 0)
             __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MI_CPROBE(3);
-        rf.inverse(buf, scr, tid);
+        if constexpr (REGS)
+        {
+            mi_fft::real_merge<LOGM>(buf, rf.rt, tid);
+            mi_fft::fft_lds<LOGM, true, false, true>(buf, scr, rf.ft, tid, io);
+        }
+        else
+            rf.inverse(buf, scr, tid);
         MI_CPROBE(4);
 
         const float scale = 1.0f / float(2 * M);
@@ -218,7 +239,8 @@ namespace
         for (int i = 0; i < NPT; ++i)
         {
             const int n = tid + i * T;
-            const float2 y0 = buf[n], y1 = buf[n + M / 2];
+            const float2 y0 = REGS ? make_float2(io[i].x, io[i].y) : buf[n];
+            const float2 y1 = REGS ? make_float2(io[i + NPT].x, io[i + NPT].y) : buf[n + M / 2];
             const float2 p0 = LEAN ? *reinterpret_cast<const float2 *>(a + 2 * n) : a0[i];
             const float2 p1 = !LEAN ? a1[i] : upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * n);
             const float2 r = make_float2(fmaf(y0.x, scale, p0.x), fmaf(y0.y, scale, p0.y));

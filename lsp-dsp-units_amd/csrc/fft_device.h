@@ -444,6 +444,55 @@ namespace mi_fft
         // multiplication and real_merge in ONE pass over the pairs (k, M - k) -- one LDS round trip and one barrier instead
         // of three of each.  With A = e - i w o (= X_k) and Bc = e + i w o (= conj X_(M-k)) of real_split:
         //     e' = g_k A + g_m Bc,  o' = g_k A - g_m Bc,  Z'_k = e' + i conj(w) o',  Z'_(M-k) = conj(e' - i conj(w) o')
+        // The same in two steps, for several masks on one spectrum: the thread's pairs are read once into registers
+        // (zk[i] = Z_k, zm[i] = Z_(M-k), k = tid + i T < M/2; the thread of k = 0 holds Z_0 and Z_(M/2)) ...
+        static constexpr int PAIRS = real_tw<LOGM>::ITER;
+        __device__ __forceinline__ void pairs_load(const float2 *buf, float2 (&zk)[PAIRS], float2 (&zm)[PAIRS], int tid) const
+        {
+            constexpr int M = plan<LOGM>::N, T = plan<LOGM>::T;
+            #pragma unroll
+            for (int i = 0; i < PAIRS; ++i)
+            {
+                const int k = tid + i * T;
+                zk[i] = (k < M / 2) ? buf[k] : make_float2(0.0f, 0.0f);
+                zm[i] = (k < M / 2) ? buf[(k == 0) ? M / 2 : M - k] : make_float2(0.0f, 0.0f);
+            }
+        }
+        // ... and every mask writes its Z' (see mask_pairs) from them; gain(k), k = 0 .. M.  Synchronises behind the stores.
+        template <typename G>
+        __device__ __forceinline__ void pairs_mask_store(float2 *buf, const float2 (&zk)[PAIRS], const float2 (&zm)[PAIRS], G gain, int tid) const
+        {
+            constexpr int M = plan<LOGM>::N, T = plan<LOGM>::T;
+            #pragma unroll
+            for (int i = 0; i < PAIRS; ++i)
+            {
+                const int k = tid + i * T;
+                if (k >= M / 2)
+                    continue;
+                if (k == 0)
+                {
+                    const float x0 = (zk[i].x + zk[i].y) * gain(0), xm = (zk[i].x - zk[i].y) * gain(M);
+                    buf[0] = make_float2(x0 + xm, x0 - xm);
+                    const float gh = 2.0f * gain(M / 2);
+                    buf[M / 2] = make_float2(gh * zm[i].x, gh * zm[i].y);
+                }
+                else
+                {
+                    const float2 w  = rt.w[i];
+                    const float gk = gain(k), gm = gain(M - k);
+                    const float2 e  = make_float2(0.5f * (zk[i].x + zm[i].x), 0.5f * (zk[i].y - zm[i].y));
+                    const float2 o  = make_float2(0.5f * (zk[i].x - zm[i].x), 0.5f * (zk[i].y + zm[i].y));
+                    const float2 wo = cmul(w, o);
+                    const float2 A  = make_float2((e.x + wo.y) * gk, (e.y - wo.x) * gk);
+                    const float2 Bc = make_float2((e.x - wo.y) * gm, (e.y + wo.x) * gm);
+                    const float2 e2 = cadd(A, Bc), o2 = csub(A, Bc);
+                    const float2 wq = cmul(cconj(w), o2);
+                    buf[k]     = make_float2(e2.x - wq.y, e2.y + wq.x);
+                    buf[M - k] = make_float2(e2.x + wq.y, -(e2.y - wq.x));
+                }
+            }
+            __syncthreads();
+        }
         __device__ __forceinline__ void mask_pairs(float2 *buf, const float *__restrict__ g, int tid) const
         {
             constexpr int M = plan<LOGM>::N, T = plan<LOGM>::T;

@@ -602,13 +602,28 @@ namespace
         MI_APROBE(1);
         rf.prepare();
         MI_APROBE(2);
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            if (tid + i * T < H)
-                buf[tid + i * T] = make_float2(xin[i].x * win[i].x, xin[i].y * win[i].y);
-        __syncthreads();
-        MI_APROBE(3);
-        rf.forward(buf, scr, tid);
+        constexpr bool REGS = !fplan<LOGH>::radix16 && (mi_fft::plan<LOGH>::T == mi_fft::plan<LOGH>::TB);
+        if constexpr (REGS)
+        {
+            // the windowed frame goes into the transform in registers (fft_lds REG_IN): one LDS round trip and a barrier less
+            v2f io[KPT];
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                io[i] = v2f{xin[i].x * win[i].x, xin[i].y * win[i].y};
+            MI_APROBE(3);
+            mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tid, io);
+            mi_fft::real_split<LOGH>(buf, rf.rt, tid);
+        }
+        else
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                if (tid + i * T < H)
+                    buf[tid + i * T] = make_float2(xin[i].x * win[i].x, xin[i].y * win[i].y);
+            __syncthreads();
+            MI_APROBE(3);
+            rf.forward(buf, scr, tid);
+        }
         MI_APROBE(4);
         // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
         const float keep = 1.0f - tau;

@@ -162,6 +162,57 @@ namespace
             return;
         __syncthreads();
 
+        // 512 .. 8192-point transforms whose hop is the whole half frame (frame == H: the line's 2 * frame samples are the
+        // transform's output as it stands): the frame goes into the forward transform in registers, the thread's pairs
+        // (Z_k, Z_(H-k)) wait in registers while the handlers take turns, each handler's split + gains + merge is ONE pass
+        // (real_fft::pairs_mask_store) and its inverse hands the samples back in registers for the overlap-add
+        // (round 3: 104 + 96 h LDS instructions per thread and hop -> 72 + 64 h).
+        if constexpr (!WRITE_SPEC && LOGH <= 12 && !fplan<LOGH>::radix16 && (mi_fft::plan<LOGH>::T == mi_fft::plan<LOGH>::TB))
+        {
+            if (frame == uint32_t(H))
+            {
+                static_assert(PER * T == H && (PER % 2) == 0, "whole pairs per thread");
+                constexpr int IT = mi_fft::real_fft<LOGH>::PAIRS;
+                v2f io[PER];
+                #pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    io[i] = v2f{xr[i].x, xr[i].y};
+                mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tid, io);
+                float2 zk[IT], zm[IT];
+                rf.pairs_load(buf, zk, zm, tid);
+                const float scale = 1.0f / float(N);
+                const uint32_t hp = frame >> 1;
+                for (uint32_t h = h0; h < h1; ++h)
+                {
+                    if (hd[h].mode != H_MASK || !hd[h].has_sink)
+                        continue;
+                    const float *g = hd[h].mask + size_t(ch) * hd[h].mask_stride;
+                    __syncthreads();                                    // everybody holds its pairs / is done with the handler before
+                    // only the real part of the inverse is kept (pcomplex_c2r): a real gain acts through its even part
+                    rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tid);
+                    mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tid, io);
+                    float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
+                    float *emit = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+                    #pragma unroll
+                    for (int i = 0; i < PER / 2; ++i)
+                    {
+                        const uint32_t m = tid + i * T;                 // pair m of the first frame, pair m + hp of the second
+                        const v2f y0 = io[i], y1 = io[i + PER / 2];
+                        const float2 w0 = w2[m], w1 = w2[m + hp], prev = line[m + hp];
+                        const float2 done = make_float2(fmaf(y0.x * scale, w0.x, prev.x), fmaf(y0.y * scale, w0.y, prev.y));
+                        line[m]      = done;
+                        line[m + hp] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+                        if (emit != nullptr)
+                        {
+                            emit[2 * m]     = done.x;
+                            emit[2 * m + 1] = done.y;
+                        }
+                    }
+                }
+                return;
+            }
+        }
+
         rf.forward(buf, scr, tid);
         // several handlers per workgroup: the spectrum waits in registers while they take turns in LDS; one handler per
         // workgroup shapes it where it is

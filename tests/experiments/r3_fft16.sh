@@ -5,7 +5,7 @@ O=$R/gpurun_out/r3c
 mkdir -p $O
 cd $R
 timeout 1500 python3 -m pytest tests/test_spectral_gpu.py tests/test_convolver_gpu.py tests/test_equalizer_gpu.py tests/test_splitter_gpu.py tests/test_golden_vectors.py -x -q -m gpu > $O/pytest_fft.txt 2>&1
-tail -15 $O/pytest_fft.txt
+grep -E "passed|failed" $O/pytest_fft.txt | tail -2
 for W in spectral stft equalizer splitter convolver; do
   python3 bench.py --workload $W --no-cpu-baseline > $O/bench_$W.json 2> $O/bench_$W.err
   python3 - <<PY
