@@ -49,7 +49,9 @@ def parse():
     ap.add_argument("--ring", type=int, default=16, help="distinct resident blocks cycled through "
                     "(16 x 32 MiB in+out > the 256 MiB Infinity Cache, so steps stream from HBM)")
     ap.add_argument("--regions", type=int, default=0, help="timed repetitions of the K-step region (0 = 25, or 5 when K >= 500)")
-    ap.add_argument("--launch", default="graph", choices=["graph", "eager"], help="how the K steps of a region are issued")
+    ap.add_argument("--launch", default="graph", choices=["blocks", "graph", "eager"],
+                    help="how the K steps of a region are issued: blocks = one mi_biquad_bank_process_blocks call (K launches back "
+                         "to back from C), graph = one hipGraph of K process() calls, eager = K process() calls from Python")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sections", type=int, default=8, help="experiment knob: keep only the first N sections")
     ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
@@ -372,7 +374,7 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
     return res
 
 
-def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True, regions=5, stream=None, graph=False):
+def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True, regions=5, stream=None, graph=False, region=None):
     """W untimed warm-up calls of step(i), then `regions` timed repetitions of the K-step region, each bracketed by
     barrier + synchronize on both sides and reduced with MAX over the ranks.
     Returns (median region seconds, sorted kernel ms list of the probe pass, info)."""
@@ -383,7 +385,7 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
     torch.cuda.synchronize()
 
     # The K steps of a region, captured once: steady-state process() calls take no host decision.
-    exe, mode = None, "eager"
+    exe, mode = None, ("eager" if region is None else "one mi_biquad_bank_process_blocks call per region (K launches back to back from C)")
     if graph and stream is not None:
         gc.collect()
         gc.disable()
@@ -417,6 +419,8 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
         t0 = time.perf_counter()
         if exe is not None:
             mi.check(mi.lib.mi_dspu_graph_launch(exe, ctypes.c_void_p(stream.cuda_stream)))
+        elif region is not None:
+            region()                                        # the K steps as one library call
         else:
             for i in range(steps):
                 step(warmup + i)
@@ -829,8 +833,18 @@ def main():
         bank.process(yout[k], xin[k], n, stream=stream)
 
     regions = args.regions or (5 if args.steps >= 500 else 25)
+    region = None
+    if args.launch == "blocks":
+        seq = [(args.warmup + i) % ring for i in range(args.steps)]
+        import ctypes
+        po = (ctypes.c_void_p * args.steps)(*[yout[k].data_ptr() for k in seq])
+        pi = (ctypes.c_void_p * args.steps)(*[xin[k].data_ptr() for k in seq])
+        st_ptr = ctypes.c_void_p(stream.cuda_stream)
+
+        def region():
+            mi.check(mi.lib.mi_biquad_bank_process_blocks(bank.handle, po, pi, args.steps, n, n, n, st_ptr))
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, args.steps, args.warmup, regions=regions,
-                                             stream=stream, graph=(args.launch == "graph"))
+                                             stream=stream, graph=(args.launch == "graph"), region=region)
 
     # sanity: the output of the last step is finite and non-trivial
     chk = yout[(args.warmup + args.steps - 1) % ring]

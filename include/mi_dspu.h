@@ -148,6 +148,14 @@ int mi_biquad_bank_reset(mi_biquad_bank_t *bank, uint32_t channel, void *stream)
 int mi_biquad_bank_process(mi_biquad_bank_t *bank, float *out, const float *in,
                            size_t samples, size_t out_stride, size_t in_stride, void *stream);
 /*
+ * `blocks` consecutive FilterBank::process() calls in one C call: block k reads in[k] and writes out[k] (HOST arrays of
+ * `blocks` DEVICE pointers, each [channels][*_stride]); the filter memory is carried from block to block exactly as by
+ * `blocks` separate calls -- it IS `blocks` launches, issued back to back without returning to the caller in between
+ * (a host language whose call overhead is of the order of the 12 us a 1024 x 4096 block takes keeps the GPU busy this way).
+ */
+int mi_biquad_bank_process_blocks(mi_biquad_bank_t *bank, float *const *out, const float *const *in, size_t blocks,
+                                  size_t samples, size_t out_stride, size_t in_stride, void *stream);
+/*
  * FilterBank::impulse_response(out, samples), FilterBank.cpp:293-330: delay
  * memory is saved, zeroed, a unit impulse is run and the memory restored.
  */

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "mi_biquad_bank_commit": (c_int, [c_void_p, c_void_p]),
     "mi_biquad_bank_reset": (c_int, [c_void_p, c_uint32, c_void_p]),
     "mi_biquad_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_biquad_bank_process_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_biquad_bank_impulse_response": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mi_biquad_bank_get_state": (c_int, [c_void_p, c_void_p, c_void_p]),
     "mi_biquad_bank_set_state": (c_int, [c_void_p, c_void_p, c_void_p]),

@@ -1284,6 +1284,25 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
     return bank_run(b, out, in, samples, out_stride, in_stride, mi::as_stream(stream), nullptr);
 }
 
+int mi_biquad_bank_process_blocks(mi_biquad_bank_t *b, float *const *out, const float *const *in, size_t blocks,
+                                  size_t samples, size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_process_blocks: NULL bank");
+    if (samples == 0 || blocks == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_biquad_bank_process_blocks: NULL pointer table");
+    MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL,
+               "mi_biquad_bank_process_blocks: stride shorter than the block");
+    for (size_t k = 0; k < blocks; ++k)
+    {
+        MI_REQUIRE(out[k] != nullptr && in[k] != nullptr, MI_EINVAL, "mi_biquad_bank_process_blocks: NULL buffer of block %zu", k);
+        const int r = bank_run(b, out[k], in[k], samples, out_stride, in_stride, mi::as_stream(stream), nullptr);
+        if (r != MI_OK)
+            return r;
+    }
+    return MI_OK;
+}
+
 int mi_biquad_bank_impulse_response(mi_biquad_bank_t *b, float *out, size_t samples, size_t out_stride, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_impulse_response: NULL bank");
