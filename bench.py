@@ -556,8 +556,9 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                 print("bench: library communicator refused (%s); torch.distributed all_reduce instead" % e, file=sys.stderr)
 
     def step(i):
-        an.process(xin[i % ring], hop, stream=stream)       # one frame: ingest + strobe analysis of every channel
-        an.reduce_bins(sums[i % batch], stream=stream)      # local per-bin sum over this GPU's channels
+        # one frame: ingest + strobe analysis of every channel, and the local per-bin sum over this GPU's channels riding on
+        # the same launch (mi_analyzer_bank_process_reduce)
+        an.process_reduce(xin[i % ring], hop, sums[i % batch], stream=stream)
         if (i % batch) == batch - 1:                        # one collective per `batch` frames (RCCL over xGMI)
             if state["comm"] is not None:
                 an.allreduce_bins(sums, batch, state["comm"], stream=stream)

@@ -478,6 +478,16 @@ int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *bank, float *out, size_t o
 /* Per-bin sum over this bank's channels of the smoothed magnitudes (2^(rank-1)+1 floats, DEVICE): the local half
  * of the cross-channel per-bin reduction; the caller all-reduces it across GPUs. */
 int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_envelope, void *stream);
+/*
+ * mi_analyzer_bank_process followed by mi_analyzer_bank_reduce_bins in one call.  By default that is exactly the two
+ * launches.  With MI_ANALYZER_FUSED_REDUCE=1 in the environment the reduction rides on the analysis launch of the call's
+ * (last) strobe as a second role of the same kernel (the reduce workgroups wait for the rows inside the launch): same
+ * results bit for bit, and on MI355X at 1024 channels SLOWER than two launches (20.3 against 17.2 us per step: the
+ * reduction needs every row, so nothing overlaps, and a reduce role as narrow as an analysis workgroup is slower than the
+ * 16-wave workgroups of its own launch -- profiles/r03_experiments/analyzer_fused_reduce.txt); kept for the record.
+ */
+int mi_analyzer_bank_process_reduce(mi_analyzer_bank_t *bank, const float *in, size_t samples, size_t in_stride,
+                                    float *out, int with_envelope, void *stream);
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *bank, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step);
 
 /*

@@ -509,6 +509,90 @@ namespace
     #define MI_APROBE(slot) do { } while (0)
 #endif
 
+    // Per-bin reduction over channels (the C5 callback), in one launch and in an order that does not depend on the launch
+    // geometry AND composes across channel shards: blocks of REDUCE_BLOCK consecutive channels are summed in channel
+    // order, the block sums are then added along a binary tree aligned to powers of two (element j takes in element
+    // j + s for s = 1, 2, 4, ...).  The sum over channels [0, 2^k * REDUCE_BLOCK) is a node of that tree, so the
+    // reductions of two banks that hold the halves of a channel set add up to the reduction of the whole set bit for
+    // bit -- which is what lets the per-bin sum be sharded over GPUs and all-reduced (tests/test_spectral_gpu.py).
+    // A workgroup owns 16 bins (one 64-byte segment of every channel row): a wave reads that segment of four channels at
+    // once, WAVES x 4 groups of 16 lanes work on as many blocks at a time with the sixteen loads of a block in flight.
+    // Narrow workgroups instead of 64-bin ones because 2049 bins would otherwise be 33 workgroups on 256 CUs.
+    // The body serves two callers: bin_reduce_kernel (its own launch, 16 waves) and the reduce role that rides on the
+    // analysis launch (analyzer_kernel, round 3: as many waves as the analysis workgroups have; DEVICE: the rows were
+    // written by other workgroups of the SAME launch, so they are read with device-scope loads past this CU's L1).
+    constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16, REDUCE_BLOCK = 16, REDUCE_MAX_BLOCKS = 1024;
+
+    template <uint32_t WAVES, bool DEVICE>
+    __device__ __forceinline__
+    void bin_reduce_body(float *out, const float *src, uint32_t stride, uint32_t channels, uint32_t bins,
+                         const float *__restrict__ env, uint32_t block /* channels per block, multiple of 16 */,
+                         float (*part)[REDUCE_BINS], uint32_t group /* which 16 bins */)
+    {
+        const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+        const uint32_t b = lane & (REDUCE_BINS - 1), r = lane / REDUCE_BINS;
+        const uint32_t k = group * REDUCE_BINS + b;
+        constexpr uint32_t GROUPS = WAVES * REDUCE_ROWS;                        // blocks in flight
+        const uint32_t nblocks = (channels + block - 1) / block;
+        // DEVICE: sc1 loads (past this CU's L1, coherent at device scope) through a buffer descriptor -- the builtin, not an
+        // atomic load: the compiler keeps sixteen of them in flight, sixteen relaxed atomic loads it waits for one by one
+        // (measured: 45 us instead of 3 for the 8.4 MB of C5)
+        const __amdgpu_buffer_rsrc_t rsrc = mi::wt_buffer(const_cast<float *>(src), unsigned(size_t(channels) * stride * sizeof(float)));
+        auto row = [&](uint32_t c) -> float {
+            if (DEVICE)
+                return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int((size_t(c) * stride + k) * sizeof(float)), 0, mi::CPOL_SC1));
+            return src[size_t(c) * stride + k];
+        };
+        for (uint32_t j = w * REDUCE_ROWS + r; j < nblocks; j += GROUPS)
+        {
+            float s = 0.0f;
+            if (k < bins)
+            {
+                const uint32_t c0 = j * block, c1 = (c0 + block < channels) ? c0 + block : channels;
+                uint32_t c = c0;
+                for (; c + 16 <= c1; c += 16)
+                {
+                    float v[16];
+                    #pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        v[i] = row(c + i);
+                    #pragma unroll
+                    for (int i = 0; i < 16; ++i)
+                        s += v[i];
+                }
+                for (; c < c1; ++c)
+                    s += row(c);
+            }
+            part[j][b] = s;
+        }
+        __syncthreads();
+        for (uint32_t s = 1; s < nblocks; s <<= 1)
+        {
+            // element j (a multiple of 2s) takes in element j + s
+            const uint32_t pairs = (nblocks + 2 * s - 1) / (2 * s);
+            for (uint32_t i = threadIdx.x; i < pairs * REDUCE_BINS; i += 64 * WAVES)
+            {
+                const uint32_t j = (i / REDUCE_BINS) * 2 * s, bb = i & (REDUCE_BINS - 1);
+                if (j + s < nblocks)
+                    part[j][bb] += part[j + s][bb];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < REDUCE_BINS && k < bins)
+        {
+            const float t = part[0][b];
+            out[k] = (env != nullptr) ? t * env[k] : t;
+        }
+    }
+
+    __global__ __launch_bounds__(64 * REDUCE_WAVES)
+    void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins,
+                           const float *__restrict__ env, uint32_t block /* channels per block, multiple of 16 */)
+    {
+        __shared__ float part[REDUCE_MAX_BLOCKS][REDUCE_BINS];
+        bin_reduce_body<REDUCE_WAVES, false>(out, src, stride, channels, bins, env, block, part, blockIdx.x);
+    }
+
     // ---- analyzer -------------------------------------------------------------------------------------------
     // ring: [channels][buf_size]; the frame of channel c ends `delay[c]` samples before `head`.
     // amp_old: vAmp as of the strobe (what get_spectrum() shows until the next strobe: the reference copies vAmp to vData
@@ -516,16 +600,15 @@ namespace
     // ingest: `ingest_n` new samples per channel go into the ring behind `head` in the same launch (the "fill the
     // buffer" half of Analyzer::process, Analyzer.cpp:371-398; they lie outside every analysis window of this strobe).
     template <int LOGH>
-    __global__ __launch_bounds__(fplan<LOGH>::T)
-    void analyzer_kernel(float *ring, uint32_t buf_size, uint32_t head,
-                         const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
-                         const float *__restrict__ wnd, const float *__restrict__ amp_old, float *amp_new,
-                         uint32_t amp_stride, float tau, const float2 *__restrict__ tw,
-                         const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero)
+    __device__ __forceinline__
+    void analyzer_role(float2 *lds_, float *ring, uint32_t buf_size, uint32_t head,
+                       const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
+                       const float *__restrict__ wnd, const float *__restrict__ amp_old, float *amp_new,
+                       uint32_t amp_stride, float tau, const float2 *__restrict__ tw,
+                       const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero)
     {
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        __shared__ float2 lds_[fplan<LOGH>::LDS];
         float2 *const buf = lds_, *const scr = lds_ + H;
         const int ch = blockIdx.x, tid = threadIdx.x;
         MI_APROBE(0);
@@ -554,14 +637,16 @@ namespace
         }
         if (fl & 2)                                         // frozen: vAmp stays (Analyzer.cpp:334)
         {
+            const __amdgpu_buffer_rsrc_t rrow = mi::wt_buffer(an, unsigned((H + 1) * sizeof(float)));
             for (int k = tid; k <= H; k += T)
-                an[k] = a[k];
+                mi::wt_store(rrow, 4 * k, a[k]);
             return;
         }
         if (!(fl & 1))                                      // inactive: vAmp = 0 (Analyzer.cpp:363-364)
         {
+            const __amdgpu_buffer_rsrc_t rrow = mi::wt_buffer(an, unsigned((H + 1) * sizeof(float)));
             for (int k = tid; k <= H; k += T)
-                an[k] = 0.0f;
+                mi::wt_store(rrow, 4 * k, 0.0f);
             return;
         }
         constexpr int KPT = (H + T - 1) / T;
@@ -677,6 +762,63 @@ namespace
         MI_APROBE(6);
     }
 
+    // The analysis of every channel and, riding on the same launch, the per-bin reduction over the channels (round 3).
+    // Workgroups 0 .. channels - 1 are the analysis above.  With a reduction asked for (`red_out`), workgroups from `boundary`
+    // on own 16 bins each (bin_reduce_body): they wait until every analysis workgroup of the launch has flagged its channel in
+    // `rows` -- each does so once its row is complete: the row is written with write-through (sc1) stores, every wave drains its own
+    // (s_waitcnt vmcnt(0), written out) before the workgroup barrier behind which thread 0 stores the flag -- and
+    // read the rows with device-scope loads.  Rows are 128-byte aligned (bins_stride is a multiple of 32 floats): a wave's
+    // store instruction covers whole lines.  The same two-role pattern, the same ordering argument and the same safeguards
+    // as conv_step_kernel (convolver.hip): analysis workgroups never wait, the reduce workgroups have the higher indices,
+    // a wait that does not end raises a host-visible flag instead of hanging.
+    template <int LOGH>
+    __global__ __launch_bounds__(fplan<LOGH>::T)
+    void analyzer_kernel(float *ring, uint32_t buf_size, uint32_t head,
+                         const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
+                         const float *__restrict__ wnd, const float *__restrict__ amp_old, float *amp_new,
+                         uint32_t amp_stride, float tau, const float2 *__restrict__ tw,
+                         const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero,
+                         uint32_t channels, uint32_t boundary, float *red_out, const float *__restrict__ red_env,
+                         uint32_t red_block, uint32_t *rows /* [channels]: the launch in which the row was last completed */, uint32_t rows_target, uint32_t *fault_host)
+    {
+        constexpr int T = fplan<LOGH>::T, H = fplan<LOGH>::N;
+        __shared__ float2 lds_[fplan<LOGH>::LDS];
+        if (blockIdx.x < boundary)
+        {
+            if (blockIdx.x >= channels)
+                return;
+            analyzer_role<LOGH>(lds_, ring, buf_size, head, delay, flags, wnd, amp_old, amp_new, amp_stride, tau, tw,
+                                ingest, ingest_stride, ingest_n, ingest_zero);
+            if (red_out != nullptr)
+            {
+                // one flag word per channel, written by one lane with a device-scope store: no read-modify-write (a counter
+                // that 1024 workgroups bump within a microsecond or two serialises at about 12 ns per add and made the fused
+                // launch three times slower than two launches)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (threadIdx.x == 0)
+                    __hip_atomic_store(rows + blockIdx.x, rows_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        for (uint32_t c = threadIdx.x; c < channels; c += T)
+        {
+            uint32_t spins = 0;
+            while (int32_t(__hip_atomic_load(rows + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rows_target) < 0)
+            {
+                __builtin_amdgcn_s_sleep(4);
+                if (++spins > (1u << 22))
+                {
+                    __hip_atomic_store(fault_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                    break;
+                }
+            }
+        }
+        __syncthreads();
+        bin_reduce_body<T / 64, true>(red_out, amp_new, amp_stride, channels, uint32_t(H) + 1u, red_env, red_block,
+                                      reinterpret_cast<float (*)[REDUCE_BINS]>(lds_), blockIdx.x - boundary);
+    }
+
     // ---- analyzer frames above 2^14 samples: the steps of analyzer_kernel as plain launches around the four-step transform
     // work[n] = (ring[(head - N - delay + n) mod size] * w[n], 0) for the channels that are analysed
     __global__ __launch_bounds__(256)
@@ -728,69 +870,6 @@ namespace
         uint32_t w = head + i;
         if (w >= buf_size) w -= buf_size;
         ring[size_t(ch) * buf_size + w] = zero ? 0.0f : in[size_t(ch) * in_stride + i];
-    }
-
-    // Per-bin reduction over channels (the C5 callback), in one launch and in an order that does not depend on the launch
-    // geometry AND composes across channel shards: blocks of REDUCE_BLOCK consecutive channels are summed in channel
-    // order, the block sums are then added along a binary tree aligned to powers of two (element j takes in element
-    // j + s for s = 1, 2, 4, ...).  The sum over channels [0, 2^k * REDUCE_BLOCK) is a node of that tree, so the
-    // reductions of two banks that hold the halves of a channel set add up to the reduction of the whole set bit for
-    // bit -- which is what lets the per-bin sum be sharded over GPUs and all-reduced (tests/test_spectral_gpu.py).
-    // A workgroup owns 16 bins (one 64-byte segment of every channel row): a wave reads that segment of four channels at
-    // once, 64 groups of 16 lanes work on 64 blocks at a time with the sixteen loads of a block in flight.
-    // Narrow workgroups instead of 64-bin ones because 2049 bins would otherwise be 33 workgroups on 256 CUs.
-    constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16, REDUCE_BLOCK = 16, REDUCE_MAX_BLOCKS = 1024;
-
-    __global__ __launch_bounds__(64 * REDUCE_WAVES)
-    void bin_reduce_kernel(float *out, const float *__restrict__ src, uint32_t stride, uint32_t channels, uint32_t bins,
-                           const float *__restrict__ env, uint32_t block /* channels per block, multiple of 16 */)
-    {
-        __shared__ float part[REDUCE_MAX_BLOCKS][REDUCE_BINS];
-        const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-        const uint32_t b = lane & (REDUCE_BINS - 1), r = lane / REDUCE_BINS;
-        const uint32_t k = blockIdx.x * REDUCE_BINS + b;
-        constexpr uint32_t GROUPS = REDUCE_WAVES * REDUCE_ROWS;                 // blocks in flight
-        const uint32_t nblocks = (channels + block - 1) / block;
-        for (uint32_t j = w * REDUCE_ROWS + r; j < nblocks; j += GROUPS)
-        {
-            float s = 0.0f;
-            if (k < bins)
-            {
-                const uint32_t c0 = j * block, c1 = (c0 + block < channels) ? c0 + block : channels;
-                uint32_t c = c0;
-                for (; c + 16 <= c1; c += 16)
-                {
-                    float v[16];
-                    #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        v[i] = src[size_t(c + i) * stride + k];
-                    #pragma unroll
-                    for (int i = 0; i < 16; ++i)
-                        s += v[i];
-                }
-                for (; c < c1; ++c)
-                    s += src[size_t(c) * stride + k];
-            }
-            part[j][b] = s;
-        }
-        __syncthreads();
-        for (uint32_t s = 1; s < nblocks; s <<= 1)
-        {
-            // element j (a multiple of 2s) takes in element j + s
-            const uint32_t pairs = (nblocks + 2 * s - 1) / (2 * s);
-            for (uint32_t i = threadIdx.x; i < pairs * REDUCE_BINS; i += 64 * REDUCE_WAVES)
-            {
-                const uint32_t j = (i / REDUCE_BINS) * 2 * s, bb = i & (REDUCE_BINS - 1);
-                if (j + s < nblocks)
-                    part[j][bb] += part[j + s][bb];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x < REDUCE_BINS && k < bins)
-        {
-            const float t = part[0][b];
-            out[k] = (env != nullptr) ? t * env[k] : t;
-        }
     }
 
     // out[c][i] = data[c][idx[i]] * env[idx[i]]   (Analyzer::get_spectrum, Analyzer.cpp:443-456)
@@ -1334,6 +1413,12 @@ struct mi_analyzer_bank
     const float2 *d_tw = nullptr;
     bool        meta_dirty = true;
     bool        analysed = false;           // a strobe pass has run: vAmp / vData hold a period's results
+    // per-bin reduction riding on the analysis launch (mi_analyzer_bank_process_reduce)
+    float      *fuse_out = nullptr;         // where the next strobe's launch leaves the reduction (NULL: no reduce role)
+    bool        fuse_env = false, fuse_done = false;
+    uint32_t   *d_rows = nullptr;           // [channels]: sequence number of the launch that last completed the channel's row
+    uint32_t    rows_target = 0;            // sequence number of the launch in hand
+    uint32_t   *h_fault = nullptr, *d_fault_host = nullptr;     // host-mapped flag: a reduce role gave up waiting
 
     uint32_t max_user_delay() const
     {
@@ -1406,11 +1491,29 @@ namespace
         const size_t row = size_t(first) * b->bins_stride;
         if (b->rank <= 14)
         {
-            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(count), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
+            // the per-bin reduction rides on the launch when one has been asked for (mi_analyzer_bank_process_reduce), the
+            // launch covers every channel and the block sums fit the analysis workgroup's LDS
+            const uint32_t bins = (1u << (b->rank - 1)) + 1;
+            uint32_t block = REDUCE_BLOCK;
+            while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
+                block *= 2;                                             // (the standalone kernel's choice: same summation order)
+            const size_t lds_floats = size_t(1) << b->rank;             // (at least: the transform's LDS is 2^rank floats or more with either core)
+            const bool fuse = b->fuse_out != nullptr && first == 0 && b->d_rows != nullptr &&
+                              size_t((b->channels + block - 1) / block) * REDUCE_BINS <= lds_floats &&
+                              getenv("MI_ANALYZER_FUSED_REDUCE") != nullptr;      // (measured slower than two launches: see the header)
+            const uint32_t boundary = fuse ? ((count + 7u) & ~7u) : count;
+            const uint32_t grid = fuse ? boundary + (bins + REDUCE_BINS - 1) / REDUCE_BINS : count;
+            if (fuse)
+                b->rows_target += 1;                                    // this launch's sequence number
+            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(grid), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
                 ring, b->buf_size, b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, b->d_data + row, b->d_amp + row, \
-                b->bins_stride, b->tau, b->d_tw, in, in_stride, n, zero ? 1 : 0)
+                b->bins_stride, b->tau, b->d_tw, in, in_stride, n, zero ? 1 : 0, \
+                count, boundary, fuse ? b->fuse_out : (float *)nullptr, (fuse && b->fuse_env) ? b->d_env : (const float *)nullptr, \
+                block, b->d_rows, b->rows_target, b->d_fault_host)
             MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
             #undef MI_CALL
+            if (fuse)
+                b->fuse_done = true;
             MI_HIP_CHECK(hipGetLastError());
             return MI_OK;
         }
@@ -1515,7 +1618,7 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
     size_t bs = fft_items + size_t(float(max_sample_rate * 2) / min_rate) + max_delay + 0x40;
     bs = (bs + 0x3f) & ~size_t(0x3f);
     b->buf_size = uint32_t(bs);
-    b->bins_stride = uint32_t((((fft_items >> 1) + 1) + 15) & ~size_t(15));
+    b->bins_stride = uint32_t((((fft_items >> 1) + 1) + 31) & ~size_t(31));    // rows start on 128-byte lines (see analyzer_kernel)
     b->user_delay.assign(channels, 0);
     b->delay.assign(channels, 0);
     b->ch_active.assign(channels, 1);
@@ -1530,6 +1633,14 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_data), size_t(channels) * b->bins_stride * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), fft_items * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_env), b->bins_stride * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_rows), channels * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->d_rows, 0, channels * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b->h_fault), sizeof(uint32_t), hipHostMallocMapped);
+        if (e == hipSuccess)
+        {
+            *b->h_fault = 0u;
+            e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_fault_host), b->h_fault, 0);
+        }
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_delay), channels * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_flags), channels);
         if (max_rank > 14)                                  // frames that go through global memory: three complex frames per channel
@@ -1560,6 +1671,8 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_amp); (void)hipFree(b->d_data); (void)hipFree(b->d_wnd);
     (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
     (void)hipFree(b->d_big_work); (void)hipFree(b->d_big_tmp); (void)hipFree(b->d_big_spec);
+    (void)hipFree(b->d_rows);
+    (void)hipHostFree(b->h_fault);
     delete b;
     return MI_OK;
 }
@@ -1653,6 +1766,9 @@ static uint64_t analyzer_bank_positions(const void *bank)
 int mi_analyzer_bank_process(mi_analyzer_bank_t *b, const float *in, size_t samples, size_t in_stride, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_process: NULL bank");
+    MI_REQUIRE(b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u, MI_EHIP,
+               "mi_analyzer_bank_process: the reduce role of an earlier analysis launch gave up waiting for the rows "
+               "(MI_ANALYZER_FUSED_REDUCE): that reduction is invalid");
     hipStream_t st = mi::as_stream(stream);
     {
         const int rc = mi::capture_touch(st, b, "analyzer", analyzer_bank_positions);
@@ -1748,6 +1864,24 @@ int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *b, float *out, int with_env
                        out, b->d_amp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
+}
+
+int mi_analyzer_bank_process_reduce(mi_analyzer_bank_t *b, const float *in, size_t samples, size_t in_stride,
+                                    float *out, int with_envelope, void *stream)
+{
+    MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_process_reduce: bad argument");
+    b->fuse_out = out;
+    b->fuse_env = with_envelope != 0;
+    b->fuse_done = false;
+    const int r = mi_analyzer_bank_process(b, in, samples, in_stride, stream);
+    const bool done = b->fuse_done;
+    b->fuse_out = nullptr;
+    b->fuse_done = false;
+    if (r != MI_OK)
+        return r;
+    // no strobe fell into this call, or its launch could not carry the reduce role (frames above 2^14 samples, settings
+    // changed in mid-period, too many channels for the block sums): the reduction as its own launch
+    return done ? MI_OK : mi_analyzer_bank_reduce_bins(b, out, with_envelope, stream);
 }
 
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *b, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step)

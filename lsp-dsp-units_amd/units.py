@@ -350,6 +350,12 @@ class AnalyzerBank:
     def reduce_bins(self, out, with_envelope=False, stream=None):
         check(lib.mi_analyzer_bank_reduce_bins(self.handle, _ptr(out), int(with_envelope), _stream(stream)))
 
+    def process_reduce(self, inp, samples, out, with_envelope=False, in_stride=None, stream=None):
+        """process() + reduce_bins(), the reduction riding on the analysis launch (mi_analyzer_bank_process_reduce)."""
+        check(lib.mi_analyzer_bank_process_reduce(self.handle, _ptr(inp) if inp is not None else None, samples,
+                                                  samples if in_stride is None else in_stride, _ptr(out),
+                                                  int(with_envelope), _stream(stream)))
+
     def close(self):
         if self.handle:
             lib.mi_analyzer_bank_destroy(self.handle)

@@ -407,6 +407,42 @@ def test_reduce_bins_many_channels(gpu):
         assert np.abs(a - b).max() <= 1e-4 * float(a.max())     # the Hann window of windows.cpp is not exactly periodic
 
 
+@pytest.mark.parametrize("rank,C", [(12, 1024), (12, 301), (9, 40), (6, 700), (13, 64)])
+def test_reduce_riding_on_the_analysis_launch_equals_two_launches(gpu, rank, C, monkeypatch):
+    """mi_analyzer_bank_process_reduce: the per-bin reduction as a second role of the analysis launch (reduce workgroups
+    wait for the rows inside the launch) against process() followed by reduce_bins() -- bit for bit, over several strobes,
+    with frozen and inactive channels in the bank (their rows are written by other code paths), with and without the
+    envelope, for channel counts on both sides of the workgroup-rounding boundary and for a geometry whose block sums do
+    not fit the analysis workgroup's LDS (rank 6, 700 channels: falls back to two launches by itself)."""
+    sr = 48000
+    monkeypatch.setenv("MI_ANALYZER_FUSED_REDUCE", "1")     # (not the default: slower than two launches on MI355X)
+    rng = np.random.default_rng(900 + rank + C)
+    bins = (1 << (rank - 1)) + 1
+    banks = []
+    for fused in (True, False):
+        b = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+        for what, v in ((b.SAMPLE_RATE, sr), (b.RATE, sr / float(max(1 << (rank - 1), 1024))), (b.RANK, rank), (b.WINDOW, 0), (b.REACTIVITY, 0.2), (b.SHIFT, 1.0)):
+            b.configure(what, v)
+        if C > 3:
+            b.channel(1, b.CH_FREEZE, 1)                     # its row is copied ...
+            b.channel(2, b.CH_ENABLE, 0)                     # ... and this one zeroed, by other paths of the kernel
+        banks.append(b)
+    banks[0].process(None, 0); banks[1].process(None, 0)
+    for step in range(5):
+        period = banks[0].info()["period"]                   # one strobe per call (whatever the rate setting rounded to)
+        x = gpu.DeviceBuffer.from_host((rng.standard_normal((C, period)) * 0.3).astype(np.float32))
+        oa, ob = gpu.DeviceBuffer((bins,)), gpu.DeviceBuffer((bins,))
+        env = bool(step & 1)
+        banks[0].process_reduce(x, period, oa, with_envelope=env)
+        banks[1].process(x, period)
+        banks[1].reduce_bins(ob, with_envelope=env)
+        a, b_ = oa.download(), ob.download()
+        assert np.isfinite(a).all() and (step == 0 or float(np.abs(a).max()) > 0.0)     # (the first strobe looks at an empty ring)
+        np.testing.assert_array_equal(a, b_, err_msg="strobe %d" % step)
+    for b in banks:
+        b.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_spectral_random_operation_sequences(gpu, seed):
     """Differential stress of the spectral bank against the oracle SpectralProcessor: rank and phase changes, masks bound
