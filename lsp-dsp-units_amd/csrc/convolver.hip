@@ -85,7 +85,7 @@ namespace
     {
         constexpr int M = fplan<LOGM>::N;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         const int p = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
         if (only != nullptr && only[ch] == 0)
             return;
@@ -267,7 +267,7 @@ namespace
     {
         constexpr int M = fplan<LOGM>::N;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         frame_role<LOGM, false>(buf, scr, blockIdx.x, out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc, Yt, tw,
                                 dl_ring, dl_size, dl_tail, dl_head, upper_zero, nullptr);
     }
@@ -307,7 +307,7 @@ namespace
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         // (the role boundary is `channels` rounded up to the 8 XCDs the workgroups are dealt to in turn: both workgroups of a
         // channel then sit on the same XCD, whose dispatcher hands out its share of the grid in index order -- frame before tail)
         const int boundary = (channels + 7) & ~7;
@@ -474,7 +474,7 @@ namespace
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);
@@ -558,7 +558,7 @@ namespace
         constexpr int M = fplan<LOGS>::N, T = fplan<LOGS>::T, KPT = M / T;
         static_assert(KPT * T == M && (KPT % 2) == 0, "small blocks: whole pairs per thread");
         __shared__ float2 lds_[fplan<LOGS>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGS>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x, kblk = off / SB;
         typename fplan<LOGS>::real rf;
         rf.load(tw, TWN, tid);
@@ -705,7 +705,7 @@ namespace
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         if (R > 0 || SETTLE)
         {
@@ -773,7 +773,7 @@ namespace
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + M;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         typename fplan<LOGM>::real rf;
         rf.load(tw, TWN, tid);

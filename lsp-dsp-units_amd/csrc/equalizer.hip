@@ -37,7 +37,7 @@ namespace
     {
         using PL = plan<LOGN>;
         constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N], scr[N];
+        __shared__ float2 buf[plan<LOGN>::BUF], scr[plan<LOGN>::BUF];    // sequence + the padding of the intermediate layouts
         const int ch = blockIdx.x, tid = threadIdx.x;
         fft_tw<LOGN> ft;
         load_fft_tw<LOGN>(ft, tw, TWN / N, tid);
@@ -58,7 +58,7 @@ namespace
     {
         using PL = plan<LOGN>;
         constexpr int N = PL::N, T = PL::T;
-        __shared__ float2 buf[N], scr[N];
+        __shared__ float2 buf[plan<LOGN>::BUF], scr[plan<LOGN>::BUF];    // sequence + the padding of the intermediate layouts
         const int ch = blockIdx.x, tid = threadIdx.x;
         fft_tw<LOGN> ft;
         load_fft_tw<LOGN>(ft, tw, TWN / N, tid);

@@ -438,7 +438,7 @@ namespace mi_fft16
     };
 
     // ---- which core a kernel gets for a 2^LOGM-point complex transform -------------------------------------------------------
-    // fsel<LOGM>::T threads, fsel<LOGM>::LDS complex cells of LDS (buf = lds, scr = lds + N for the radix-8 core; the
+    // fsel<LOGM>::T threads, fsel<LOGM>::LDS complex cells of LDS (buf = lds, scr = lds + fsel::SCR for the radix-8 core; the
     // radix-16 core only uses buf, N + N/16 cells of it), fsel<LOGM>::real with the common interface
     //   load(tw, twn, tid); prepare(); forward(buf, scr, tid); inverse(buf, scr, tid)
     // Round 3 measured the radix-16 core as a drop-in (same kernels, half the threads): analyzer 12.1 -> 18.2 us, stft hop
@@ -456,14 +456,15 @@ namespace mi_fft16
     template <int LOGM>
     struct fsel<LOGM, true>
     {
-        static constexpr int N = plan16<LOGM>::N, T = plan16<LOGM>::T, LDS = plan16<LOGM>::LDS;
+        static constexpr int N = plan16<LOGM>::N, T = plan16<LOGM>::T, LDS = plan16<LOGM>::LDS, SCR = N;
         static constexpr bool radix16 = true;
         typedef real_fft16<LOGM> real;
     };
     template <int LOGM>
     struct fsel<LOGM, false>
     {
-        static constexpr int N = mi_fft::plan<LOGM>::N, T = mi_fft::plan<LOGM>::T, LDS = 2 * N;
+        // buf and scr of the radix-8 core: N cells of sequence plus the padding of its intermediate layouts each
+        static constexpr int N = mi_fft::plan<LOGM>::N, T = mi_fft::plan<LOGM>::T, SCR = mi_fft::plan<LOGM>::BUF, LDS = 2 * SCR;
         static constexpr bool radix16 = false;
         typedef mi_fft::real_fft<LOGM> real;
     };

@@ -89,15 +89,31 @@ namespace mi_fft
         // radix of pass i and the stride (product of the radices before it)
         static constexpr int radix(int i)  { return (i < N8) ? 8 : 4; }
         static constexpr int stride(int i) { return (i <= N8) ? (1 << (3 * i)) : (1 << (3 * N8 + 2 * (i - N8))); }
+        // Layout of the buffer a pass WRITES (see fft_lds): a pass that is not the last and whose stride is below 64 leaves s
+        // cells of padding behind every R s cells; everything else is in natural order.  Cells a buffer needs:
+        static constexpr bool padded(int i) { return i < NP - 1 && stride(i) < 64; }
+        static constexpr int pad_cells()
+        {
+            int worst = 0;
+            for (int i = 0; i < NP; ++i)
+                if (padded(i) && N / radix(i) > worst)
+                    worst = N / radix(i);
+            return worst;
+        }
+        static constexpr int BUF = N + pad_cells();             // cells of buf and of scr
     };
 
-    // Bank swizzle of the intermediate passes: the autosort write index q + s*(R p + k) has a stride of R (s = 1) or
-    // R^2 complex values between neighbouring lanes -- a many-way LDS bank conflict in the first passes.
-    // XOR-ing the low four index bits with the next four spreads those writes over all banks; reads of 16 consecutive
-    // values stay a permutation of the same 16 slots.  First read and last write of a transform use natural order.
-    template <int N>
-    __device__ __forceinline__ int swz(int i) { return (N >= 256) ? (i ^ ((i >> 4) & 15)) : i; }
-
+    // Bank layout of the intermediate buffers (round 3; the XOR swizzle of rounds 1-2 cost three to four VALU instructions
+    // per LDS access -- more address arithmetic than butterfly arithmetic in every pass).  The autosort write index of a
+    // radix-R pass with stride s is q + R s p + s m for lane j = q + s p: runs of s consecutive lanes R s cells apart -- for
+    // s < 64 a many-way bank conflict.  The buffer such a pass writes gets s cells of padding behind every R s cells:
+    //     cell(pos) = pos + s (pos div R s)
+    // so that the runs of a 16-lane write group tile the banks (pitch (R + 1) s cells: 18 dwords at R = 8, s = 1; 144 = 16
+    // mod 32 at s = 8), and BOTH sides stay base(lane) + constant(slot):
+    //     writer:  cell(q + R s p + s m)  = q + (R + 1) s p + s m                     (q + s m < R s)
+    //     reader:  cell(j + k Q')         = j + s (j div R s) + k (Q' + Q' / R)       (Q' a multiple of R s)
+    // The reader's 32-lane groups stay inside one R s block for s >= 32 and cross at most three pads for s = 1 (a 2-way
+    // conflict on six banks of one pass's reads).  Passes with s >= 64 write 64 consecutive lanes: natural order.
     // Twiddles of every pass for the butterflies this thread owns: W^(m p s), m = 1 .. radix-1, fetched (m = 1) once
     // per kernel -- ideally long before the transform: the table lives in global memory -- and reused by the forward and
     // the inverse transform.
@@ -217,6 +233,11 @@ namespace mi_fft
         {
             const bool first = (pass == 0), last = (pass == NP - 1);
             const int R = P::radix(pass), s = P::stride(pass), Q = N / R;
+            // layout of the buffer this pass reads (written by the pass before) and of the one it writes
+            const bool rd_pad = !first && P::padded(pass - 1), wr_pad = P::padded(pass);
+            const int ps = first ? 1 : P::stride(pass - 1), pR = first ? 8 : P::radix(pass - 1);
+            const int rd_step = rd_pad ? Q + Q / pR : Q;
+            auto rd_base = [&](int j) -> int { return rd_pad ? j + ps * (j / (pR * ps)) : j; };
             if (R == 8)
             {
                 constexpr int BPT = P::BPT8;
@@ -227,10 +248,11 @@ namespace mi_fft
                     const int j = tid + b * T;
                     if (j < Q)
                     {
+                        const int rb = rd_base(j);                       // cell(j + k Q) = rb + k rd_step
                         #pragma unroll
                         for (int k = 0; k < 8; ++k)
                             v[b][k] = (first && REG_IN) ? io[b + k * (Q / T)]          // x[j + k Q] = x[tid + (b + k Q/T) T]
-                                                        : ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
+                                                        : ld2(src + rb + k * rd_step);
                     }
                 }
                 if (dst == src && !(first && REG_IN))
@@ -253,7 +275,7 @@ namespace mi_fft
                             if (last && REG_OUT)
                                 io[b + m * (Q / T)] = r;                 // X[j + m Q] (last pass: s = Q, o = j)
                             else
-                                st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
+                                st2(dst + (wr_pad ? q + 9 * (j - q) : o) + m * s, r);   // padded: q + (R + 1) s p + s m
                         }
                     }
                 }
@@ -268,10 +290,11 @@ namespace mi_fft
                     const int j = tid + b * T;
                     if (j < Q)
                     {
+                        const int rb = rd_base(j);
                         #pragma unroll
                         for (int k = 0; k < 4; ++k)
                             v[b][k] = (first && REG_IN) ? io[b + k * (Q / T)]
-                                                        : ld2(src + (first ? (j + k * Q) : swz<N>(j + k * Q)));
+                                                        : ld2(src + rb + k * rd_step);
                     }
                 }
                 if (dst == src && !(first && REG_IN))
@@ -294,7 +317,7 @@ namespace mi_fft
                             if (last && REG_OUT)
                                 io[b + m * (Q / T)] = r;
                             else
-                                st2(dst + (last ? o + m * s : swz<N>(o + m * s)), r);
+                                st2(dst + (wr_pad ? q + 5 * (j - q) : o) + m * s, r);
                         }
                     }
                 }

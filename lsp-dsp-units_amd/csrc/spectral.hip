@@ -43,7 +43,7 @@ namespace
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
         __shared__ float2 lds_[fplan<LOGH>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + H;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         typename fplan<LOGH>::real rf;
         if (MODE == 1 || MODE == 2)
@@ -178,7 +178,7 @@ namespace
         constexpr int H = PL::N, T = PL::T, N = 2 * H, KPT = H / T, HPT = KPT / 2;
         static_assert(KPT >= 2 && (KPT & 1) == 0 && KPT * T == H, "stft_stream_kernel needs an even number of pairs per thread");
         __shared__ float2 lds_[fplan<LOGH>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + H;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         typename fplan<LOGH>::real rf;
         if (MASKED)
@@ -309,7 +309,7 @@ namespace
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
         __shared__ float2 lds_[fplan<LOGH>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + H;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         const bool on = ((active == nullptr) || (active[ch] != 0)) && ((has_out == nullptr) || (has_out[ch] != 0));
         const float2 *sp = spec + size_t(ch) * N;
@@ -388,7 +388,7 @@ namespace
                          const float2 *__restrict__ tw)
     {
         constexpr int T = plan<BIG_LOG1>::T;
-        __shared__ float2 buf[BIG_N1], scr[BIG_N1];
+        __shared__ float2 buf[plan<BIG_LOG1>::BUF], scr[plan<BIG_LOG1>::BUF];
         const uint32_t n2 = blockIdx.x, ch = blockIdx.y;
         const int tid = threadIdx.x;
         fft_tw<BIG_LOG1> ft;
@@ -609,7 +609,7 @@ namespace
     {
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
-        float2 *const buf = lds_, *const scr = lds_ + H;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         MI_APROBE(0);
         // Everything the launch needs is requested before anything is waited for (in-kernel timeline,

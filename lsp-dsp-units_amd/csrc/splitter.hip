@@ -98,7 +98,7 @@ namespace
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, PER = (H + T - 1) / T;
         __shared__ float2 lds_[fplan<LOGH>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + H;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         constexpr bool all = !PER_BAND;
         const uint32_t h0 = all ? 0 : blockIdx.y, h1 = all ? handlers : blockIdx.y + 1;
@@ -296,7 +296,7 @@ namespace
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H;
         __shared__ float2 lds_[fplan<LOGH>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + H;
+        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         typename fplan<LOGH>::real rf;
         rf.load(tw, TWN, tid);
