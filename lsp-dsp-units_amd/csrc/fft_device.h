@@ -69,6 +69,42 @@ namespace mi_fft
         return PLUS_I ? v2f{a.x - b.y, a.y + b.x} : v2f{a.x + b.y, a.y - b.x};
 #endif
     }
+    // a + conj(b), a - conj(b), and the two conjugated +-i forms of the real split / merge, one v_pk_add_f32 each
+    __host__ __device__ __forceinline__ v2f padd_cj(v2f a, v2f b)           // (a.x + b.x, a.y - b.y)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        v2f r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+#else
+        return v2f{a.x + b.x, a.y - b.y};
+#endif
+    }
+    __host__ __device__ __forceinline__ v2f psub_cj(v2f a, v2f b)           // (a.x - b.x, a.y + b.y)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        v2f r;
+        asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+#else
+        return v2f{a.x - b.x, a.y + b.y};
+#endif
+    }
+    // conj(a + i b) (PLUS_I) or conj(a - i b):  (a.x -+ b.y, -(a.y +- b.x))
+    template <bool PLUS_I>
+    __host__ __device__ __forceinline__ v2f pconj_add_i(v2f a, v2f b)
+    {
+#if defined(__HIP_DEVICE_COMPILE__)
+        v2f r;
+        if (PLUS_I)
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(r) : "v"(a), "v"(b));
+        else
+            asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[1,0]" : "=v"(r) : "v"(a), "v"(b));
+        return r;
+#else
+        return PLUS_I ? v2f{a.x - b.y, -(a.y + b.x)} : v2f{a.x + b.y, -(a.y - b.x)};
+#endif
+    }
     __device__ __forceinline__ v2f ld2(const float2 *p) { return *reinterpret_cast<const v2f *>(p); }
     __device__ __forceinline__ void st2(float2 *p, v2f v) { *reinterpret_cast<v2f *>(p) = v; }
 
@@ -373,13 +409,13 @@ namespace mi_fft
             }
             else
             {
-                const float2 zk = buf[k], zm = buf[M - k];
-                const float2 w  = rt.w[i];                                // e^{-i pi k / M}
-                const float2 e  = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));   // (Zk + conj Zm)/2
-                const float2 o  = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));   // (Zk - conj Zm)/2
-                const float2 wo = cmul(w, o);
-                buf[k]     = make_float2(e.x + wo.y, e.y - wo.x);         // e - i*wo
-                buf[M - k] = make_float2(e.x - wo.y, -(e.y + wo.x));      // conj(e + i*wo)
+                // packed: e2 = Zk + conj Zm, o2 = Zk - conj Zm, wo = (w / 2) o2;  X_k = e2 / 2 - i wo,  X_(M-k) = conj(e2 / 2 + i wo)
+                const v2f zk = ld2(buf + k), zm = ld2(buf + M - k);
+                const v2f wh = v2f{0.5f * rt.w[i].x, 0.5f * rt.w[i].y};   // e^{-i pi k / M} / 2
+                const v2f eh = padd_cj(zk, zm) * v2f{0.5f, 0.5f};
+                const v2f wo = pmul<false>(wh, psub_cj(zk, zm));
+                st2(buf + k, padd_i<false>(eh, wo));
+                st2(buf + M - k, pconj_add_i<true>(eh, wo));
             }
         }
         __syncthreads();
@@ -408,13 +444,13 @@ namespace mi_fft
             }
             else
             {
-                const float2 xk = buf[k], xm = buf[M - k];
-                const float2 w  = cconj(rt.w[i]);                         // e^{+i pi k / M}
-                const float2 e  = make_float2(xk.x + xm.x, xk.y - xm.y);  // Xk + conj Xm
-                const float2 o  = make_float2(xk.x - xm.x, xk.y + xm.y);  // Xk - conj Xm
-                const float2 wo = cmul(w, o);
-                buf[k]     = make_float2(e.x - wo.y, e.y + wo.x);         // e + i*wo
-                buf[M - k] = make_float2(e.x + wo.y, -(e.y - wo.x));      // conj(e - i*wo)
+                // packed: e = Xk + conj Xm, o = Xk - conj Xm, wo = conj(w) o;  Z_k = e + i wo,  Z_(M-k) = conj(e - i wo)
+                const v2f xk = ld2(buf + k), xm = ld2(buf + M - k);
+                const v2f w  = v2f{rt.w[i].x, rt.w[i].y};
+                const v2f e  = padd_cj(xk, xm);
+                const v2f wo = pmul<true>(w, psub_cj(xk, xm));
+                st2(buf + k, padd_i<true>(e, wo));
+                st2(buf + M - k, pconj_add_i<false>(e, wo));
             }
         }
         __syncthreads();
@@ -501,17 +537,18 @@ namespace mi_fft
                 }
                 else
                 {
-                    const float2 w  = rt.w[i];
-                    const float gk = gain(k), gm = gain(M - k);
-                    const float2 e  = make_float2(0.5f * (zk[i].x + zm[i].x), 0.5f * (zk[i].y - zm[i].y));
-                    const float2 o  = make_float2(0.5f * (zk[i].x - zm[i].x), 0.5f * (zk[i].y + zm[i].y));
-                    const float2 wo = cmul(w, o);
-                    const float2 A  = make_float2((e.x + wo.y) * gk, (e.y - wo.x) * gk);
-                    const float2 Bc = make_float2((e.x - wo.y) * gm, (e.y + wo.x) * gm);
-                    const float2 e2 = cadd(A, Bc), o2 = csub(A, Bc);
-                    const float2 wq = cmul(cconj(w), o2);
-                    buf[k]     = make_float2(e2.x - wq.y, e2.y + wq.x);
-                    buf[M - k] = make_float2(e2.x + wq.y, -(e2.y - wq.x));
+                    // packed (the halves of real_split go into the gains): A = g_k X_k, Bc = g_m conj X_(M-k)
+                    const v2f w  = v2f{rt.w[i].x, rt.w[i].y};
+                    const float gk = 0.5f * gain(k), gm = 0.5f * gain(M - k);
+                    const v2f Zk = v2f{zk[i].x, zk[i].y}, Zm = v2f{zm[i].x, zm[i].y};
+                    const v2f e  = padd_cj(Zk, Zm);
+                    const v2f wo = pmul<false>(w, psub_cj(Zk, Zm));
+                    const v2f A  = padd_i<false>(e, wo) * v2f{gk, gk};
+                    const v2f Bc = padd_i<true>(e, wo) * v2f{gm, gm};
+                    const v2f e2 = A + Bc;
+                    const v2f wq = pmul<true>(w, A - Bc);
+                    st2(buf + k, padd_i<true>(e2, wq));
+                    st2(buf + M - k, pconj_add_i<false>(e2, wq));
                 }
             }
             __syncthreads();
@@ -536,18 +573,17 @@ namespace mi_fft
                 }
                 else
                 {
-                    const float2 zk = buf[k], zm = buf[M - k];
-                    const float2 w  = rt.w[i];
-                    const float gk = g[k], gm = g[M - k];
-                    const float2 e  = make_float2(0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
-                    const float2 o  = make_float2(0.5f * (zk.x - zm.x), 0.5f * (zk.y + zm.y));
-                    const float2 wo = cmul(w, o);
-                    const float2 A  = make_float2((e.x + wo.y) * gk, (e.y - wo.x) * gk);     // g_k X_k
-                    const float2 Bc = make_float2((e.x - wo.y) * gm, (e.y + wo.x) * gm);     // g_m conj X_(M-k)
-                    const float2 e2 = cadd(A, Bc), o2 = csub(A, Bc);
-                    const float2 wq = cmul(cconj(w), o2);
-                    buf[k]     = make_float2(e2.x - wq.y, e2.y + wq.x);
-                    buf[M - k] = make_float2(e2.x + wq.y, -(e2.y - wq.x));
+                    const v2f Zk = ld2(buf + k), Zm = ld2(buf + M - k);
+                    const v2f w  = v2f{rt.w[i].x, rt.w[i].y};
+                    const float gk = 0.5f * g[k], gm = 0.5f * g[M - k];
+                    const v2f e  = padd_cj(Zk, Zm);
+                    const v2f wo = pmul<false>(w, psub_cj(Zk, Zm));
+                    const v2f A  = padd_i<false>(e, wo) * v2f{gk, gk};
+                    const v2f Bc = padd_i<true>(e, wo) * v2f{gm, gm};
+                    const v2f e2 = A + Bc;
+                    const v2f wq = pmul<true>(w, A - Bc);
+                    st2(buf + k, padd_i<true>(e2, wq));
+                    st2(buf + M - k, pconj_add_i<false>(e2, wq));
                 }
             }
             __syncthreads();
