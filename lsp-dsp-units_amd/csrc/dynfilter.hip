@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdint>
 #include <new>
+#include <type_traits>
 #include <vector>
 
 namespace
@@ -66,11 +67,43 @@ namespace
 
     __host__ __device__ inline void set3(float *d, float a, float b, float c) { d[0] = a; d[1] = b; d[2] = c; }
     __host__ __device__ inline void scale3(float *d, float g) { d[0] *= g; d[1] *= g; d[2] *= g; }
-    __host__ __device__ inline float iroot(float x, float n) { return expf(logf(x) / n); }      // dsp::irootf
+    // a / b.  Host: the division.  Device: reciprocal, one Newton step and one correction of the quotient -- six
+    // instructions instead of the ten (and two mode switches) of the compiler's IEEE sequence, whose scaling steps serve
+    // operands next to the ends of the exponent range; gains, their roots and the prototype's polynomials are nowhere near.
+    // The same quotient bit for bit on 2^24 random pairs from [1e-4, 1e4]^2, half of them reciprocals
+    // (tests/experiments/dyn_div_probe.hip, profiles/r03_experiments/dynfilter_per_type.txt).
+    __host__ __device__ __attribute__((always_inline)) inline float dv(float a, float b)
+    {
+#ifdef __HIP_DEVICE_COMPILE__
+        float r = __builtin_amdgcn_rcpf(b);
+        r = fmaf(fmaf(-b, r, 1.0f), r, r);
+        const float q = a * r;
+        return fmaf(fmaf(-b, q, a), r, q);
+#else
+        return a / b;
+#endif
+    }
+
+    __host__ __device__ inline float iroot(float x, float n) { return expf(dv(logf(x), n)); }      // dsp::irootf
+    // a polynomial on one side and its mirror image on the other (the shelving builders); the VALUES are selected, not
+    // the destination: a selected pointer (also one the optimiser makes out of two mirrored branches) keeps t[] and b[]
+    // in scratch memory on the device
+    __host__ __device__ inline void set_mirrored(bool t_first, float *t, float *b, float a0, float a1, float a2)
+    {
+        const float lo = t_first ? a0 : a2, hi = t_first ? a2 : a0;
+        set3(t, lo, a1, hi);
+        set3(b, hi, a1, lo);
+    }
 
     // Analog cascade J (global index) of a filter at gain g: numerator t[3], denominator b[3].
-    __host__ __device__ inline void dyn_cascade(const dyn_params &p, uint32_t J, float g, float *t, float *b)
+    // Returned BY VALUE from local arrays: with caller-owned arrays the optimiser sinks the branches' stores through
+    // phi'd pointers before the arrays are split into registers, and t[] / b[] then live in scratch memory on the device.
+    struct cascade { float t[3], b[3]; };
+
+    __host__ __device__ __attribute__((always_inline)) inline cascade dyn_cascade(const dyn_params &p, uint32_t J, float g)
     {
+        cascade cs_;
+        float *const t = cs_.t, *const b = cs_.b;
         const float Q = p.Q, xf = p.xf;
         const uint32_t slope = p.slope;
         switch (p.base)
@@ -88,7 +121,7 @@ namespace
                     set3(t, lo ? g : 0.0f, lo ? 0.0f : g, 0.0f);
                     break;
                 }
-                set3(b, 1.0f, 2.0f / (1.0f + Q), 1.0f);
+                set3(b, 1.0f, dv(2.0f, 1.0f + Q), 1.0f);
                 set3(t, lo ? 1.0f : 0.0f, 0.0f, lo ? 0.0f : 1.0f);
                 if (J == 0)
                     scale3(t, g);                                                       // "Patch volume"
@@ -96,10 +129,8 @@ namespace
             }
             case MI_FLT_BT_RLC_LOSHELF: case MI_FLT_BT_RLC_HISHELF:                     // :734-785
             {
-                const float gs = sqrtf(g), fg = expf(logf(gs) / float(slope * 2)), k = 2.0f / (1.0f + Q);
-                float *tt = (p.base == MI_FLT_BT_RLC_LOSHELF) ? t : b, *bb = (p.base == MI_FLT_BT_RLC_LOSHELF) ? b : t;
-                set3(tt, fg, k, 1.0f / fg);
-                set3(bb, tt[2], tt[1], tt[0]);
+                const float gs = sqrtf(g), fg = expf(dv(logf(gs), float(slope * 2))), k = dv(2.0f, 1.0f + Q);
+                set_mirrored(p.base == MI_FLT_BT_RLC_LOSHELF, t, b, fg, k, dv(1.0f, fg));
                 if (J == 0)
                     scale3(t, gs);
                 break;
@@ -107,23 +138,21 @@ namespace
             case MI_FLT_BT_RLC_LADDERPASS: case MI_FLT_BT_RLC_LADDERREJ:                // :790-876
             {
                 const bool rej = p.base == MI_FLT_BT_RLC_LADDERREJ;
-                const float s2 = float(slope * 2), sq = sqrtf(g), isq = sqrtf(1.0f / g);
+                const float s2 = float(slope * 2), sq = sqrtf(g), isq = sqrtf(dv(1.0f, g));
                 float gain;
                 if (J & 1)                                                              // second shelf, always a hi-shelf
                 {
                     gain = rej ? sq : isq;
-                    const float fg = expf(logf(gain) / s2), k = 2.0f * xf / (1.0f + Q);
-                    set3(b, fg, k, xf * xf / fg);
-                    set3(t, 1.0f / fg, k, fg * xf * xf);
+                    const float fg = expf(dv(logf(gain), s2)), k = dv(2.0f * xf, 1.0f + Q);
+                    set3(b, fg, k, dv(xf * xf, fg));
+                    set3(t, dv(1.0f, fg), k, fg * xf * xf);
                 }
                 else
                 {
                     const float gain1 = rej ? isq : sq, gain2 = rej ? sq : isq;
-                    const float fg = expf(logf(rej ? gain2 : gain1) / s2), k = 2.0f / (1.0f + Q);
+                    const float fg = expf(dv(logf(rej ? gain2 : gain1), s2)), k = dv(2.0f, 1.0f + Q);
                     gain = rej ? gain2 : gain1;
-                    float *tt = rej ? t : b, *bb = rej ? b : t;
-                    set3(tt, fg, k, 1.0f / fg);
-                    set3(bb, tt[2], tt[1], tt[0]);
+                    set_mirrored(rej, t, b, fg, k, dv(1.0f, fg));
                 }
                 if ((J >> 1) == 0)
                     scale3(t, gain);
@@ -131,31 +160,31 @@ namespace
             }
             case MI_FLT_BT_RLC_BANDPASS:                                                // :878-911
             {
-                const float f2 = 1.0f / xf, k = (1.0f + f2) / (1.0f + Q);
+                const float f2 = dv(1.0f, xf), k = dv(1.0f + f2, 1.0f + Q);
                 set3(t, 0.0f, (J == 0) ? expf(float(slope) * logf(k)) * g : 1.0f, 0.0f);
                 set3(b, f2, k, 1.0f);
                 break;
             }
             case MI_FLT_BT_RLC_BELL: case MI_FLT_BT_RLC_RESONANCE:                      // :913-991
             {
-                const float fg = expf(logf(g) / float(slope));
+                const float fg = expf(dv(logf(g), float(slope)));
 #ifdef __HIP_DEVICE_COMPILE__
                 // sin(atan(x)) = x / sqrt(1 + x^2), cos(atan(x)) = 1 / sqrt(1 + x^2): the same numbers to the last bits of
                 // float32 without the two transcendental calls per sample (the host keeps the reference's expression)
-                const float rs = 1.0f / sqrtf(fmaf(fg, fg, 1.0f));
+                const float rs = dv(1.0f, sqrtf(fmaf(fg, fg, 1.0f)));
                 const float tsin = fg * rs, tcos = rs;
 #else
                 const float tsin = sinf(atanf(fg)), tcos = sqrtf(1.0f - tsin * tsin);
 #endif
-                const float k = (p.base == MI_FLT_BT_RLC_BELL) ? 2.0f * (1.0f / fg + fg) / (1.0f + (2.0f * Q) / float(slope))
-                                                               : 2.0f / (1.0f + Q);
+                const float k = (p.base == MI_FLT_BT_RLC_BELL) ? dv(2.0f * (dv(1.0f, fg) + fg), 1.0f + dv(2.0f * Q, float(slope)))
+                                                               : dv(2.0f, 1.0f + Q);
                 set3(t, 1.0f, k * tsin, 1.0f);
                 set3(b, 1.0f, k * tcos, 1.0f);
                 break;
             }
             case MI_FLT_BT_RLC_NOTCH:                                                   // :993-1020
                 set3(t, g, 0.0f, g);
-                set3(b, 1.0f, 2.0f / (1.0f + Q), 1.0f);
+                set3(b, 1.0f, dv(2.0f, 1.0f + Q), 1.0f);
                 break;
 
             case MI_FLT_BT_BWC_LOPASS: case MI_FLT_BT_BWC_HIPASS:                       // :1090-1170
@@ -169,11 +198,11 @@ namespace
                     set3(t, hi ? 0.0f : g, hi ? g : 0.0f, 0.0f);
                     break;
                 }
-                const float k = 1.0f / (1.0f + Q);
-                const float theta = lrx ? (float((J & ~1u) + 1) * kPi2) / float(slope * 2)
-                                        : (float(2 * (J - (slope & 1)) + 1) * kPi2) / float(slope);
+                const float k = dv(1.0f, 1.0f + Q);
+                const float theta = lrx ? dv(float((J & ~1u) + 1) * kPi2, float(slope * 2))
+                                        : dv(float(2 * (J - (slope & 1)) + 1) * kPi2, float(slope));
                 const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
-                const float kf1 = 1.0f / (tsin * tsin + k * k * tcos * tcos);
+                const float kf1 = dv(1.0f, tsin * tsin + k * k * tcos * tcos);
                 const float lead = (J == 0) ? g : 1.0f;
                 if (hi)
                 {
@@ -189,14 +218,12 @@ namespace
             }
             case MI_FLT_BT_BWC_HISHELF: case MI_FLT_BT_BWC_LOSHELF:                     // :1172-1233
             {
-                const float theta = (float(2 * J + 1) * kPi2) / float(2 * slope);
+                const float theta = dv(float(2 * J + 1) * kPi2, float(2 * slope));
                 const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
-                const float gain = sqrtf(g), fg = expf(logf(gain) / (2.0f * float(slope)));
-                const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                const float gain = sqrtf(g), fg = expf(dv(logf(gain), 2.0f * float(slope)));
+                const float k = dv(1.0f, 1.0f + Q * (1.0f - expf(2.0f - gain - dv(1.0f, gain))));
                 const float kf = tsin * tsin + k * k * tcos * tcos;
-                float *tt = (p.base == MI_FLT_BT_BWC_HISHELF) ? t : b, *bb = (p.base == MI_FLT_BT_BWC_HISHELF) ? b : t;
-                set3(tt, kf / fg, 2.0f * k * tcos, fg);
-                set3(bb, tt[2], tt[1], tt[0]);
+                set_mirrored(p.base == MI_FLT_BT_BWC_HISHELF, t, b, dv(kf, fg), 2.0f * k * tcos, fg);
                 if (J == 0)
                     scale3(t, gain);
                 break;
@@ -204,29 +231,27 @@ namespace
             case MI_FLT_BT_BWC_LADDERPASS: case MI_FLT_BT_BWC_LADDERREJ:                // :1235-1347
             {
                 const bool passing = p.base == MI_FLT_BT_BWC_LADDERPASS;
-                const float rc = 1.0f / float(slope * 2);
+                const float rc = dv(1.0f, float(slope * 2));
                 const float theta = (float((J & ~1u) + 1) * kPi2) * rc;
                 const float tcos = cosf(theta), tcos2 = tcos * tcos, tsin2 = 1.0f - tcos2;
                 if (J & 1)                                                              // second shelf, always a hi-shelf
                 {
                     const float xf2 = xf * xf, xtcos = 2.0f * tcos * xf;
-                    const float gain = passing ? sqrtf(g) : sqrtf(1.0f / g);
+                    const float gain = passing ? sqrtf(g) : sqrtf(dv(1.0f, g));
                     const float fg = expf(logf(gain) * rc);
-                    const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                    const float k = dv(1.0f, 1.0f + Q * (1.0f - expf(2.0f - gain - dv(1.0f, gain))));
                     const float kf = tsin2 + k * k * tcos2;
-                    set3(b, kf / fg, k * xtcos, fg * xf2);
+                    set3(b, dv(kf, fg), k * xtcos, fg * xf2);
                     set3(t, fg, b[1], b[0] * xf2);
                     if (!(J & ~1u))
-                        scale3(t, 1.0f / gain);
+                        scale3(t, dv(1.0f, gain));
                 }
                 else
                 {
                     const float xtcos = 2.0f * tcos, gain = sqrtf(g);
-                    const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
+                    const float k = dv(1.0f, 1.0f + Q * (1.0f - expf(2.0f - gain - dv(1.0f, gain))));
                     const float fg = expf(logf(gain) * rc), kf = tsin2 + k * k * tcos2;
-                    float *tt = passing ? t : b, *bb = passing ? b : t;
-                    set3(tt, kf / fg, k * xtcos, fg);
-                    set3(bb, tt[2], tt[1], tt[0]);
+                    set_mirrored(passing, t, b, dv(kf, fg), k * xtcos, fg);
                     if (!(J & ~1u))
                         scale3(t, gain);
                 }
@@ -236,19 +261,19 @@ namespace
             {
                 const bool lrx = p.base == MI_FLT_BT_LRX_BELL;
                 const float sl = float(slope * (lrx ? 4 : 2));
-                const float theta = (float(lrx ? ((J & ~3u) + 2) : ((J & ~1u) + 1)) * kPi2) / sl;
+                const float theta = dv(float(lrx ? ((J & ~3u) + 2) : ((J & ~1u) + 1)) * kPi2, sl);
                 const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
-                const float k = 1.0f / (1.0f + Q), kf = tsin * tsin + k * k * tcos * tcos;
-                const float fg = expf(logf(g) / sl), c2 = 2.0f * k * tcos;
+                const float k = dv(1.0f, 1.0f + Q), kf = tsin * tsin + k * k * tcos * tcos;
+                const float fg = expf(dv(logf(g), sl)), c2 = 2.0f * k * tcos;
                 if (J & 1)
                 {
-                    if (g >= 1.0f) { set3(t, 1.0f, c2 / fg, kf / (fg * fg));       set3(b, 1.0f, c2, kf); }
+                    if (g >= 1.0f) { set3(t, 1.0f, dv(c2, fg), dv(kf, fg * fg));   set3(b, 1.0f, c2, kf); }
                     else           { set3(t, 1.0f, c2, kf);                        set3(b, 1.0f, c2 * fg, kf * fg * fg); }
                 }
                 else
                 {
-                    if (g >= 1.0f) { set3(t, 1.0f, c2 * fg / kf, 1.0f * fg * fg / kf);    set3(b, 1.0f, c2 / kf, 1.0f / kf); }
-                    else           { set3(t, 1.0f, c2 / kf, 1.0f / kf);            set3(b, 1.0f, c2 / (fg * kf), 1.0f / (fg * fg * kf)); }
+                    if (g >= 1.0f) { set3(t, 1.0f, dv(c2 * fg, kf), dv(1.0f * fg * fg, kf));    set3(b, 1.0f, dv(c2, kf), dv(1.0f, kf)); }
+                    else           { set3(t, 1.0f, dv(c2, kf), dv(1.0f, kf));      set3(b, 1.0f, dv(c2, fg * kf), dv(1.0f, fg * fg * kf)); }
                 }
                 break;
             }
@@ -256,9 +281,9 @@ namespace
             {
                 const bool lrx = p.base == MI_FLT_BT_LRX_BANDPASS;
                 const float sl = float(slope * (lrx ? 4 : 2));
-                const float theta = (float(lrx ? ((J & ~3u) + 2) : ((J & ~1u) + 1)) * kPi2) / sl;
+                const float theta = dv(float(lrx ? ((J & ~3u) + 2) : ((J & ~1u) + 1)) * kPi2, sl);
                 const float tsin = sinf(theta), tcos = sqrtf(1.0f - tsin * tsin);
-                const float k = 1.0f / (1.0f + Q), kf1 = 1.0f / (tsin * tsin + k * k * tcos * tcos);
+                const float k = dv(1.0f, 1.0f + Q), kf1 = dv(1.0f, tsin * tsin + k * k * tcos * tcos);
                 if (J & 1)                                                              // hi-pass cascade
                 {
                     set3(t, 1.0f, 0.0f, 0.0f);
@@ -274,13 +299,11 @@ namespace
             case MI_FLT_BT_LRX_HISHELF: case MI_FLT_BT_LRX_LOSHELF:                     // build_lrx_shelf_filter_bank, :509-623
             {
                 const float b3 = sqrtf(g), gain = sqrtf(b3), fg = iroot(sqrtf(gain), float(slope));
-                const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - 1.0f / gain)));
-                const float theta = (float((J & ~1u) + 1) * kPi2) / float(2 * slope);
+                const float k = dv(1.0f, 1.0f + Q * (1.0f - expf(2.0f - gain - dv(1.0f, gain))));
+                const float theta = dv(float((J & ~1u) + 1) * kPi2, float(2 * slope));
                 const float tcos = cosf(theta), tcos2 = tcos * tcos, tsin2 = 1.0f - tcos2;
                 const float kf = tsin2 + k * k * tcos2;
-                float *tt = (p.base == MI_FLT_BT_LRX_HISHELF) ? t : b, *bb = (p.base == MI_FLT_BT_LRX_HISHELF) ? b : t;
-                set3(tt, kf * (1.0f / fg), k * (2.0f * tcos), fg);
-                set3(bb, tt[2], tt[1], tt[0]);
+                set_mirrored(p.base == MI_FLT_BT_LRX_HISHELF, t, b, kf * dv(1.0f, fg), k * (2.0f * tcos), fg);
                 if (J == 0)
                     scale3(t, b3);
                 break;
@@ -289,10 +312,10 @@ namespace
             {
                 const bool passing = p.base == MI_FLT_BT_LRX_LADDERPASS;
                 const float sl = float(slope * 4);
-                const float gain = sqrtf(g), igain = 1.0f / gain, fg = iroot(gain, sl), ifg = 1.0f / fg;
-                const float k = 1.0f / (1.0f + Q * (1.0f - expf(2.0f - gain - igain)));
+                const float gain = sqrtf(g), igain = dv(1.0f, gain), fg = iroot(gain, sl), ifg = dv(1.0f, fg);
+                const float k = dv(1.0f, 1.0f + Q * (1.0f - expf(2.0f - gain - igain)));
                 const float xf2 = xf * xf;
-                const float theta = (float((J & ~3u) + 2) * kPi2) / sl;
+                const float theta = dv(float((J & ~3u) + 2) * kPi2, sl);
                 const float tcos = cosf(theta), tcos2 = tcos * tcos, tsin2 = 1.0f - tcos2;
                 const float xtcos = 2.0f * tcos, xtcos_xf = 2.0f * tcos * xf;
                 const float kf = tsin2 + k * k * tcos2;
@@ -333,6 +356,7 @@ namespace
                 set3(t, 1.0f, 0.0f, 0.0f); set3(b, 1.0f, 0.0f, 0.0f);
                 break;
         }
+        return cs_;
     }
 
     struct section5 { float b0, b1, b2, a1, a2; };
@@ -343,7 +367,7 @@ namespace
         const float kf2 = kf * kf;
         const float T0 = t[0], T1 = t[1] * kf, T2 = t[2] * kf2;
         const float B0 = b[0], B1 = b[1] * kf, B2 = b[2] * kf2;
-        const float N = 1.0f / (B0 + B1 + B2);
+        const float N = dv(1.0f, B0 + B1 + B2);
         return section5{ (T0 + T1 + T2) * N, 2.0f * (T0 - T2) * N, (T0 - T1 + T2) * N,
                          2.0f * (B2 - B0) * N, (B1 - B2 - B0) * N };                     // denominator signs negated
     }
@@ -385,25 +409,30 @@ namespace
         }
     }
 
+    struct matched_side { float P[3]; double A, I; };      // one polynomial: its digital image, |digital| and |analog| at the match point
+
+    __host__ __device__ inline matched_side matched_one(const float *p, float f, float td, double w)
+    {
+        matched_side r;
+        matched_poly(p, f, td, r.P);
+        double re = r.P[0] * cos(2.0 * w) + r.P[1] * cos(w) + r.P[2];
+        double im = r.P[0] * sin(2.0 * w) + r.P[1] * sin(w);
+        r.A = sqrt(re * re + im * im);
+        re = p[0] - p[2] * 0.01;
+        im = p[1] * 0.1;
+        r.I = sqrt(re * re + im * im);
+        return r;
+    }
+
+    // numerator and denominator go through the same function one after the other (not a loop over a selected pointer:
+    // that keeps t[] and b[] in scratch memory on the device)
     __host__ __device__ inline section5 matched(const float *t, const float *b, float f, float td)
     {
-        float P[2][3];
-        double A[2], I[2];
         const double w = 0.1 * double(f) * double(td);
-        for (int side = 0; side < 2; ++side)
-        {
-            const float *p = side ? b : t;
-            matched_poly(p, f, td, P[side]);
-            double re = P[side][0] * cos(2.0 * w) + P[side][1] * cos(w) + P[side][2];
-            double im = P[side][0] * sin(2.0 * w) + P[side][1] * sin(w);
-            A[side] = sqrt(re * re + im * im);
-            re = p[0] - p[2] * 0.01;
-            im = p[1] * 0.1;
-            I[side] = sqrt(re * re + im * im);
-        }
-        const double AN = (A[1] * I[0]) / (A[0] * I[1]), N = 1.0 / P[1][0];
-        return section5{ float(P[0][0] * N * AN), float(P[0][1] * N * AN), float(P[0][2] * N * AN),
-                         float(-P[1][1] * N), float(-P[1][2] * N) };
+        const matched_side n = matched_one(t, f, td, w), d = matched_one(b, f, td, w);
+        const double AN = (d.A * n.I) / (n.A * d.I), N = 1.0 / d.P[0];
+        return section5{ float(n.P[0] * N * AN), float(n.P[1] * N * AN), float(n.P[2] * N * AN),
+                         float(-d.P[1] * N), float(-d.P[2] * N) };
     }
 
     struct dyn_filter            // one filter of the bank, kernel view
@@ -415,11 +444,21 @@ namespace
         float       f0;          // fFreq (matched transform)
     };
 
-    __host__ __device__ inline section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
+    __host__ __device__ __attribute__((always_inline)) inline section5 dyn_section(const dyn_filter &f, uint32_t J, float g)
     {
-        float t[3], b[3];
-        dyn_cascade(f.p, J, g, t, b);
-        return f.bilinear ? bilinear(t, b, f.kf) : matched(t, b, f.f0, f.kf);
+        const cascade c = dyn_cascade(f.p, J, g);
+        return f.bilinear ? bilinear(c.t, c.b, f.kf) : matched(c.t, c.b, f.f0, f.kf);
+    }
+
+    // the bilinear section of a filter whose base type is known when the kernel is compiled: the builders' switch folds
+    // to the one family, whose gain-independent terms then leave the per-sample code
+    template <uint32_t BASE>
+    __device__ __forceinline__ section5 dyn_section_of(const dyn_filter &f, uint32_t J, float g)
+    {
+        dyn_params p = f.p;
+        p.base = BASE;
+        const cascade c = dyn_cascade(p, J, g);
+        return bilinear(c.t, c.b, f.kf);
     }
 
     // ---- kernel -----------------------------------------------------------------------------------------------
@@ -432,6 +471,18 @@ namespace
     // (four per SIMD at 1024 channels x 4096 samples instead of one), and the sections of one sample are built once
     // for the filter types whose cascades do not depend on the cascade index.
     constexpr int LC = 8;                        // samples per lane and super-block
+#ifndef MI_DYN_BUILDERS_IN_FLIGHT
+#define MI_DYN_BUILDERS_IN_FLIGHT 2
+#endif
+#ifndef MI_DYN_SAMPLES_PER_LANE
+#define MI_DYN_SAMPLES_PER_LANE 8               // per-type kernels: 16 spills at 256 VGPRs (33.6 us against 31.2), 12 leaves a ragged second super-block
+#endif
+#ifndef MI_DYN_SPEC_FROM
+#define MI_DYN_SPEC_FROM (64 * 4 * MI_DYN_SAMPLES_PER_LANE / 2) // calls longer than half a super-block of the per-type kernels
+#endif
+#ifndef MI_DYN_WAVES_PER_SIMD
+#define MI_DYN_WAVES_PER_SIMD 2                 // register budget of the per-type kernels: 256 VGPRs
+#endif
 
     struct aff { float m00, m01, m10, m11, v0, v1; };      // s -> M s + v  (a lane's own chunk)
     // The chunk maps are composed across lanes and waves in double: a product of several hundred 2 x 2 matrices with
@@ -460,13 +511,19 @@ namespace
                base == MI_FLT_BT_AMPLIFIER;
     }
 
-    template <int NW>
-    __global__ __launch_bounds__(64 * NW)
+    //
+    // BASE = 0: any filter (the type is a kernel argument; the sections of a lane's samples are built in ONE rolled
+    // loop and parked in LDS).  BASE != 0: a bilinear filter of that base type -- one kernel per type, the sections of
+    // the lane's eight samples are built side by side and stay in registers; without the 48 KiB of parked sections all
+    // 1024 workgroups of the bench shape are resident at once (four waves per SIMD) instead of 768 and then 256.
+    template <int NW, uint32_t BASE>
+    __global__ __launch_bounds__(64 * NW, BASE != 0 ? MI_DYN_WAVES_PER_SIMD : 1)
     void dynfilter_kernel(float *out, const float *in, const float *gain, size_t out_stride, size_t in_stride,
                           size_t gain_stride, uint32_t samples, dyn_filter f, float *state /* [channels][CHAINS_MAX][2] */,
                           int aligned)
     {
-        constexpr uint32_t SUPER = uint32_t(NW) * 64u * uint32_t(LC);
+        constexpr int LCK = (BASE != 0) ? MI_DYN_SAMPLES_PER_LANE : LC;     // the lane's chunk (LC_OF<BASE> on the host side)
+        constexpr uint32_t SUPER = uint32_t(NW) * 64u * uint32_t(LCK);
         const uint32_t ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
         const float *x_in = in + size_t(ch) * in_stride;
         const float *g_in = gain + size_t(ch) * gain_stride;
@@ -477,23 +534,25 @@ namespace
         // The sections of the lane's samples, [sample][coefficient][thread]: they are built in ONE rolled loop (a single
         // inlined copy of the builders' switch, whose gain-independent parts -- the sines and cosines of angles that depend
         // on the cascade index and the slope only -- the compiler hoists out of the loop) and read back where needed.
-        __shared__ float qs[LC][5][64 * NW];
-        __shared__ float gs[LC][64 * NW];
+        constexpr bool SPEC = BASE != 0;
+        __shared__ float qs[SPEC ? 1 : LCK][5][SPEC ? 1 : 64 * NW];
+        __shared__ float gs[SPEC ? 1 : LCK][SPEC ? 1 : 64 * NW];
+        section5 q[SPEC ? LCK : 1];
         for (uint32_t J = tid; J < f.nc; J += 64 * NW)
             mem[J] = gmem[J];
         __syncthreads();
-        const bool uniform = uniform_cascades(f.p.base);
+        const bool uniform = uniform_cascades(SPEC ? BASE : f.p.base);
 
         for (uint32_t pos = 0; pos < samples; pos += SUPER)
         {
             const uint32_t left = samples - pos;
             const uint32_t valid = (left >= SUPER) ? SUPER : left;                      // samples of this super-block
-            const uint32_t c0 = tid * LC;                                               // the lane's chunk in it
-            float x[LC], g[LC];
-            if (aligned && c0 + LC <= valid)
+            const uint32_t c0 = tid * LCK;                                               // the lane's chunk in it
+            float x[LCK], g[LCK];
+            if (aligned && c0 + LCK <= valid)
             {
                 #pragma unroll
-                for (int k = 0; k < LC; k += 4)
+                for (int k = 0; k < LCK; k += 4)
                 {
                     const float4 xv = *reinterpret_cast<const float4 *>(x_in + pos + c0 + k);
                     const float4 gv = *reinterpret_cast<const float4 *>(g_in + pos + c0 + k);
@@ -504,112 +563,147 @@ namespace
             else
             {
                 #pragma unroll
-                for (int k = 0; k < LC; ++k)
+                for (int k = 0; k < LCK; ++k)
                 {
                     const bool ok = c0 + k < valid;
                     x[k] = ok ? x_in[pos + c0 + k] : 0.0f;
                     g[k] = ok ? g_in[pos + c0 + k] : 1.0f;
                 }
             }
-            const int nk = (c0 >= valid) ? 0 : ((valid - c0 >= uint32_t(LC)) ? LC : int(valid - c0));   // lane's samples
-            const uint32_t last_tid = (valid - 1) / LC;                                 // holds the super-block's last sample
+            const int nk = (c0 >= valid) ? 0 : ((valid - c0 >= uint32_t(LCK)) ? LCK : int(valid - c0));   // lane's samples
+            const uint32_t last_tid = (valid - 1) / LCK;                                 // holds the super-block's last sample
 
-            #pragma unroll
-            for (int k = 0; k < LC; ++k)
-                gs[k][tid] = g[k];
-            for (uint32_t J = 0; J < f.nc; ++J)
+            if constexpr (!SPEC)
             {
-                if (J == 0 || !uniform)
-                {
-                    #pragma unroll 1
-                    for (int k = 0; k < LC; ++k)
-                    {
-                        const section5 c = dyn_section(f, J, gs[k][tid]);
-                        qs[k][0][tid] = c.b0; qs[k][1][tid] = c.b1; qs[k][2][tid] = c.b2; qs[k][3][tid] = c.a1; qs[k][4][tid] = c.a2;
-                    }
-                }
-                auto q_of = [&](int k) -> section5 { return section5{ qs[k][0][tid], qs[k][1][tid], qs[k][2][tid], qs[k][3][tid], qs[k][4][tid] }; };
-                // the chunk's state map: d0' = a1 d0 + d1 + (b1 + a1 b0) x,  d1' = a2 d0 + (b2 + a2 b0) x
-                aff m = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f };
                 #pragma unroll
-                for (int k = 0; k < LC; ++k)
-                {
-                    if (k < nk)
-                    {
-                        const section5 c = q_of(k);
-                        const float a1 = c.a1, a2 = c.a2;
-                        const float u0 = (c.b1 + a1 * c.b0) * x[k], u1 = (c.b2 + a2 * c.b0) * x[k];
-                        aff r;
-                        r.m00 = a1 * m.m00 + m.m10;  r.m01 = a1 * m.m01 + m.m11;
-                        r.m10 = a2 * m.m00;          r.m11 = a2 * m.m01;
-                        r.v0  = a1 * m.v0 + m.v1 + u0;
-                        r.v1  = a2 * m.v0 + u1;
-                        m = r;
-                    }
-                }
-                // inclusive scan over the lanes: afterwards md maps the wave's start state to the state after this chunk
-                affd md = { double(m.m00), double(m.m01), double(m.m10), double(m.m11), double(m.v0), double(m.v1) };
-                #pragma unroll
-                for (int d = 1; d < 64; d <<= 1)
-                {
-                    affd o;
-                    o.m00 = __shfl_up(md.m00, d); o.m01 = __shfl_up(md.m01, d); o.m10 = __shfl_up(md.m10, d);
-                    o.m11 = __shfl_up(md.m11, d); o.v0 = __shfl_up(md.v0, d);   o.v1 = __shfl_up(md.v1, d);
-                    if (int(lane) >= d)
-                        md = then_(o, md);
-                }
-                // the state entering this wave: the carried state through the maps of the waves before it
-                const float2 cs = mem[J];
-                double w0 = cs.x, w1 = cs.y;
-                if (NW > 1)
-                {
-                    if (lane == 63)
-                        wmap[wave] = md;
-                    __syncthreads();
-                    for (uint32_t v = 0; v < wave; ++v)
-                    {
-                        const affd p = wmap[v];
-                        const double n0 = p.m00 * w0 + p.m01 * w1 + p.v0, n1 = p.m10 * w0 + p.m11 * w1 + p.v1;
-                        w0 = n0;
-                        w1 = n1;
-                    }
-                }
-                // start state of the lane's chunk: the map of everything before it in the wave, applied to that state
-                affd e;
-                e.m00 = __shfl_up(md.m00, 1); e.m01 = __shfl_up(md.m01, 1); e.m10 = __shfl_up(md.m10, 1);
-                e.m11 = __shfl_up(md.m11, 1); e.v0 = __shfl_up(md.v0, 1);   e.v1 = __shfl_up(md.v1, 1);
-                float d0 = float((lane == 0) ? w0 : e.m00 * w0 + e.m01 * w1 + e.v0);
-                float d1 = float((lane == 0) ? w1 : e.m10 * w0 + e.m11 * w1 + e.v1);
-                // the exact recurrence with the sample's own coefficients (dsp::dyn_biquad_process_x1)
-                #pragma unroll
-                for (int k = 0; k < LC; ++k)
-                {
-                    if (k < nk)
-                    {
-                        const section5 c = q_of(k);
-                        const float xx = x[k];                  // same operation order as biquad.hip's sections
-                        const float tq = fmaf(c.b1, xx, d1);
-                        const float u  = c.b2 * xx;
-                        const float y  = fmaf(c.b0, xx, d0);
-                        d0 = fmaf(c.a1, y, tq);
-                        d1 = fmaf(c.a2, y, u);
-                        x[k] = y;
-                    }
-                }
-                __syncthreads();                                // every wave has read mem[J] and wmap[]
-                if (tid == last_tid)                            // carried to the next super-block / call
-                    mem[J] = make_float2(d0, d1);
+                for (int k = 0; k < LCK; ++k)
+                    gs[k][tid] = g[k];
             }
-            if (aligned && c0 + LC <= valid)
+            // the sections one after the other; FULL: every lane holds LCK samples of the super-block (no per-sample guards)
+            auto run_sections = [&](auto full_tag) __attribute__((always_inline))
+            {
+                constexpr bool FULL = decltype(full_tag)::value;
+                for (uint32_t J = 0; J < f.nc; ++J)
+                {
+                    if (J == 0 || !uniform)
+                    {
+                        if constexpr (SPEC)
+                        {
+                            #pragma unroll
+                            for (int k = 0; k < LCK; ++k)
+                            {
+                                q[k] = dyn_section_of<BASE>(f, J, g[k]);
+                                if ((k + 1) % MI_DYN_BUILDERS_IN_FLIGHT == 0)       // so many builders interleaved by the scheduler
+                                    __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                        else
+                        {
+                            #pragma unroll 1
+                            for (int k = 0; k < LCK; ++k)
+                            {
+                                const section5 c = dyn_section(f, J, gs[k][tid]);
+                                qs[k][0][tid] = c.b0; qs[k][1][tid] = c.b1; qs[k][2][tid] = c.b2; qs[k][3][tid] = c.a1; qs[k][4][tid] = c.a2;
+                            }
+                        }
+                    }
+                    auto q_of = [&](int k) -> section5 {
+                        if constexpr (SPEC)
+                            return q[k];
+                        else
+                            return section5{ qs[k][0][tid], qs[k][1][tid], qs[k][2][tid], qs[k][3][tid], qs[k][4][tid] };
+                    };
+                    // the chunk's state map: d0' = a1 d0 + d1 + (b1 + a1 b0) x,  d1' = a2 d0 + (b2 + a2 b0) x
+                    aff m = { 1.0f, 0.0f, 0.0f, 1.0f, 0.0f, 0.0f };
+                    #pragma unroll
+                    for (int k = 0; k < LCK; ++k)
+                    {
+                        if (FULL || k < nk)
+                        {
+                            const section5 c = q_of(k);
+                            const float a1 = c.a1, a2 = c.a2;
+                            const float u0 = (c.b1 + a1 * c.b0) * x[k], u1 = (c.b2 + a2 * c.b0) * x[k];
+                            aff r;
+                            r.m00 = a1 * m.m00 + m.m10;  r.m01 = a1 * m.m01 + m.m11;
+                            r.m10 = a2 * m.m00;          r.m11 = a2 * m.m01;
+                            r.v0  = a1 * m.v0 + m.v1 + u0;
+                            r.v1  = a2 * m.v0 + u1;
+                            m = r;
+                        }
+                    }
+                    // inclusive scan over the lanes: afterwards md maps the wave's start state to the state after this chunk
+                    affd md = { double(m.m00), double(m.m01), double(m.m10), double(m.m11), double(m.v0), double(m.v1) };
+                    #pragma unroll
+                    for (int d = 1; d < 64; d <<= 1)
+                    {
+                        affd o;
+                        o.m00 = __shfl_up(md.m00, d); o.m01 = __shfl_up(md.m01, d); o.m10 = __shfl_up(md.m10, d);
+                        o.m11 = __shfl_up(md.m11, d); o.v0 = __shfl_up(md.v0, d);   o.v1 = __shfl_up(md.v1, d);
+                        if (int(lane) >= d)
+                            md = then_(o, md);
+                    }
+                    // the state entering this wave: the carried state through the maps of the waves before it
+                    const float2 cs = mem[J];
+                    double w0 = cs.x, w1 = cs.y;
+                    if (NW > 1)
+                    {
+                        if (lane == 63)
+                            wmap[wave] = md;
+                        __syncthreads();
+                        for (uint32_t v = 0; v < wave; ++v)
+                        {
+                            const affd p = wmap[v];
+                            const double n0 = p.m00 * w0 + p.m01 * w1 + p.v0, n1 = p.m10 * w0 + p.m11 * w1 + p.v1;
+                            w0 = n0;
+                            w1 = n1;
+                        }
+                    }
+                    // start state of the lane's chunk: the map of everything before it in the wave, applied to that state
+                    affd e;
+                    e.m00 = __shfl_up(md.m00, 1); e.m01 = __shfl_up(md.m01, 1); e.m10 = __shfl_up(md.m10, 1);
+                    e.m11 = __shfl_up(md.m11, 1); e.v0 = __shfl_up(md.v0, 1);   e.v1 = __shfl_up(md.v1, 1);
+                    float d0 = float((lane == 0) ? w0 : e.m00 * w0 + e.m01 * w1 + e.v0);
+                    float d1 = float((lane == 0) ? w1 : e.m10 * w0 + e.m11 * w1 + e.v1);
+                    // the exact recurrence with the sample's own coefficients (dsp::dyn_biquad_process_x1)
+                    #pragma unroll
+                    for (int k = 0; k < LCK; ++k)
+                    {
+                        if (FULL || k < nk)
+                        {
+                            const section5 c = q_of(k);
+                            const float xx = x[k];                  // same operation order as biquad.hip's sections
+                            const float tq = fmaf(c.b1, xx, d1);
+                            const float u  = c.b2 * xx;
+                            const float y  = fmaf(c.b0, xx, d0);
+                            d0 = fmaf(c.a1, y, tq);
+                            d1 = fmaf(c.a2, y, u);
+                            x[k] = y;
+                        }
+                    }
+                    __syncthreads();                                // every wave has read mem[J] and wmap[]
+                    if (tid == last_tid)                            // carried to the next super-block / call
+                        mem[J] = make_float2(d0, d1);
+                }
+            };
+            if constexpr (SPEC)                                 // (one copy of the any-type kernel's builders is enough)
+            {
+                if (valid == SUPER)
+                    run_sections(std::true_type{});
+                else
+                    run_sections(std::false_type{});
+            }
+            else
+                run_sections(std::false_type{});
+            if (aligned && c0 + LCK <= valid)
             {
                 #pragma unroll
-                for (int k = 0; k < LC; k += 4)
+                for (int k = 0; k < LCK; k += 4)
                     *reinterpret_cast<float4 *>(y_out + pos + c0 + k) = make_float4(x[k], x[k + 1], x[k + 2], x[k + 3]);
             }
             else
             {
                 #pragma unroll
-                for (int k = 0; k < LC; ++k)
+                for (int k = 0; k < LCK; ++k)
                     if (c0 + k < valid)
                         y_out[pos + c0 + k] = x[k];
             }
@@ -820,11 +914,39 @@ int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, c
     // as many waves per channel as the call has chunks for (a wave covers 64 x LC = 512 samples), up to four (48 KiB of
     // LDS per workgroup: three workgroups per CU)
     const size_t chunks = (samples + 64 * LC - 1) / (64 * LC);
-    #define MI_DYN_LAUNCH(NW) hipLaunchKernelGGL((dynfilter_kernel<NW>), dim3(b->channels), dim3(64 * NW), 0, st, out, in, gain, \
-                                                 out_stride, in_stride, gain_stride, uint32_t(samples), f, state, aligned)
-    if (chunks <= 1)      MI_DYN_LAUNCH(1);
-    else if (chunks <= 2) MI_DYN_LAUNCH(2);
-    else                  MI_DYN_LAUNCH(4);
+    #define MI_DYN_LAUNCH(NW, BASE) hipLaunchKernelGGL((dynfilter_kernel<NW, BASE>), dim3(b->channels), dim3(64 * NW), 0, st, out, in, \
+                                                       gain, out_stride, in_stride, gain_stride, uint32_t(samples), f, state, aligned)
+    static const bool generic = getenv("MI_DYNFILTER_GENERIC") != nullptr;     // test knob: the any-type kernel for every call
+    bool issued = false;
+    if (samples > size_t(MI_DYN_SPEC_FROM) && f.bilinear && !generic)      // long calls of bilinear filters: the kernel of the base type
+    {
+        issued = true;
+        switch (f.p.base)
+        {
+            #define MI_DYN_CASE(B) case B: MI_DYN_LAUNCH(4, B); break;
+            MI_DYN_CASE(MI_FLT_BT_AMPLIFIER)
+            MI_DYN_CASE(MI_FLT_BT_RLC_LOPASS)     MI_DYN_CASE(MI_FLT_BT_RLC_HIPASS)
+            MI_DYN_CASE(MI_FLT_BT_RLC_LOSHELF)    MI_DYN_CASE(MI_FLT_BT_RLC_HISHELF)
+            MI_DYN_CASE(MI_FLT_BT_RLC_LADDERPASS) MI_DYN_CASE(MI_FLT_BT_RLC_LADDERREJ)
+            MI_DYN_CASE(MI_FLT_BT_RLC_BANDPASS)
+            MI_DYN_CASE(MI_FLT_BT_RLC_BELL)       MI_DYN_CASE(MI_FLT_BT_RLC_RESONANCE)
+            MI_DYN_CASE(MI_FLT_BT_RLC_NOTCH)
+            MI_DYN_CASE(MI_FLT_BT_BWC_LOPASS)     MI_DYN_CASE(MI_FLT_BT_BWC_HIPASS)
+            MI_DYN_CASE(MI_FLT_BT_LRX_LOPASS)     MI_DYN_CASE(MI_FLT_BT_LRX_HIPASS)
+            MI_DYN_CASE(MI_FLT_BT_BWC_LOSHELF)    MI_DYN_CASE(MI_FLT_BT_BWC_HISHELF)
+            MI_DYN_CASE(MI_FLT_BT_BWC_LADDERPASS) MI_DYN_CASE(MI_FLT_BT_BWC_LADDERREJ)
+            MI_DYN_CASE(MI_FLT_BT_BWC_BELL)       MI_DYN_CASE(MI_FLT_BT_LRX_BELL)
+            MI_DYN_CASE(MI_FLT_BT_BWC_BANDPASS)   MI_DYN_CASE(MI_FLT_BT_LRX_BANDPASS)
+            MI_DYN_CASE(MI_FLT_BT_LRX_LOSHELF)    MI_DYN_CASE(MI_FLT_BT_LRX_HISHELF)
+            MI_DYN_CASE(MI_FLT_BT_LRX_LADDERPASS) MI_DYN_CASE(MI_FLT_BT_LRX_LADDERREJ)
+            #undef MI_DYN_CASE
+            default: issued = false; break;
+        }
+    }
+    if (issued)                ;
+    else if (chunks <= 1)      MI_DYN_LAUNCH(1, 0);
+    else if (chunks <= 2)      MI_DYN_LAUNCH(2, 0);
+    else                       MI_DYN_LAUNCH(4, 0);
     #undef MI_DYN_LAUNCH
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -875,8 +997,8 @@ int mi_dynfilter_freq_chart(const mi_filter_params_t *params, uint32_t sample_ra
         float re = 1.0f, im = 0.0f;
         for (uint32_t J = 0; J < df.nc; ++J)                    // dsp::filter_transfer_calc_pc / apply_pc
         {
-            float t[3], bb[3];
-            dyn_cascade(df.p, J, gain, t, bb);
+            const cascade cs = dyn_cascade(df.p, J, gain);
+            const float *t = cs.t, *bb = cs.b;
             const float t_re = t[0] - t[2] * w2, t_im = t[1] * w, b_re = bb[0] - bb[2] * w2, b_im = bb[1] * w;
             const float n = 1.0f / (b_re * b_re + b_im * b_im);
             const float hr = (t_re * b_re + t_im * b_im) * n, hi = (t_im * b_re - t_re * b_im) * n;

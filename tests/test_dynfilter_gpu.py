@@ -77,6 +77,41 @@ def test_every_type_matches_the_oracle(gpu, t):
     bank.close()
 
 
+@pytest.mark.parametrize("t", [t for t in TYPES if t & 1])
+def test_bilinear_types_on_whole_super_blocks(gpu, t):
+    """A call of 4096 samples: two whole super-blocks of the kernel compiled for the base type, the path without the
+    per-sample guards (dynfilter.hip, run_sections<FULL>), followed by a ragged call of 2048 + 100 with carried memory."""
+    rng = np.random.default_rng(4100 + t)
+    C, calls = 2, (4096, 2148)
+    n = sum(calls)
+    slope = 2 if df.cascade_count(t, 2) <= 16 else 1
+    bank = gpu.DynFilterBank(C, 1)
+    bank.set_sample_rate(SR)
+    bank.set_params(0, t, slope, 900.0, 4000.0, 1.0, 0.8)
+    bank.set_filter_active(0)
+    refs = [df.DynamicFilters(1) for _ in range(C)]
+    for r in refs:
+        r.set_sample_rate(SR)
+        r.set_params(0, t, slope, 900.0, 4000.0, 1.0, 0.8)
+        r.set_filter_active(0, True)
+    x = (rng.standard_normal((C, n)) * 0.25).astype(np.float32)
+    g = gains(rng, C, n, "jumpy" if t % 4 == 1 else "sweep")
+    y = np.empty_like(x)
+    ref, exact = np.empty_like(x), np.empty(x.shape, np.float64)
+    pos = 0
+    for m in calls:
+        seg = slice(pos, pos + m)
+        din, dg, dout = gpu.DeviceBuffer.from_host(x[:, seg]), gpu.DeviceBuffer.from_host(g[:, seg]), gpu.DeviceBuffer((C, m))
+        bank.process(0, dout, din, dg, m)
+        y[:, seg] = dout.download()
+        for c in range(C):
+            ref[c, seg], exact[c, seg] = refs[c].process(0, x[c, seg], g[c, seg], exact=True)
+        pos += m
+    for c in range(C):
+        check(y[c], ref[c], exact[c], "%s ch %d, whole super-blocks" % (fd.FILTER_TYPES[t], c))
+    bank.close()
+
+
 @pytest.mark.parametrize("kind", ["constant", "sweep", "jumpy"])
 def test_gain_shapes_sizes_and_in_place(gpu, kind):
     """Constant, slowly varying and sample-to-sample gains; ragged call sizes around the 1024-sample block and the

@@ -81,3 +81,29 @@ def test_fft16_index_arithmetic_on_the_host(tmp_path):
     out = subprocess.run([exe], stdout=subprocess.PIPE, timeout=300)
     assert out.returncode == 0, out.stdout.decode()[-800:]
     assert out.stdout.count(b"max error") == 8
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_dynfilter_kernels_keep_the_cascades_in_registers(tmp_path):
+    """The analog cascades t[3] / b[3] of a sample must live in registers: a selected destination pointer (written in the
+    source, or made by the optimiser out of two mirrored branches) parks them in scratch memory, a round trip to memory per
+    sample.  Neither the any-type kernels nor the per-type ones may have a private segment, nor call a function."""
+    out = os.path.join(str(tmp_path), "dynfilter.s")
+    cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-fno-slp-vectorize", "-w",
+           "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + os.path.join(ROOT, "lsp-dsp-units_amd", "include"),
+           "-S", "--offload-device-only", os.path.join(CSRC, "dynfilter.hip"), "-o", out]
+    subprocess.check_call(cmd)
+    text = open(out).read()
+    meta = text[text.index("amdhsa.kernels:"):].split("  - .agpr_count:")[1:]
+    seen = 0
+    for block in meta:
+        name = re.search(r"\.name: *(\S+)", block).group(1)
+        if "dynfilter_kernel" not in name:
+            continue
+        seen += 1
+        assert int(re.search(r"\.private_segment_fixed_size: *(\d+)", block).group(1)) == 0, name
+    assert seen >= 3 + 27, seen                              # NW = 1, 2, 4 of the any-type kernel + one per bilinear base type
+    assert "s_swappc_b64" not in text
+    # the Makefile builds this file without the SLP vectorizer (see the note there); the flag above must stay in step
+    mk = open(os.path.join(ROOT, "lsp-dsp-units_amd", "Makefile")).read()
+    assert "dynfilter.hip.o: HIPFLAGS += -fno-slp-vectorize" in mk
