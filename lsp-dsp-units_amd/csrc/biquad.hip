@@ -38,6 +38,7 @@
 // rows, transposed through a padded LDS tile private to the wave (pitch 2L+4
 // dwords, an odd number of 16-B slots: conflict-free ds_read_b128).
 #include "mi_common.h"
+#include "ilufs_device.h"
 
 #include <algorithm>
 #include <cmath>
@@ -728,6 +729,40 @@ namespace
         biquad_body<L, NW, ALIGNED, false, true>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), sq);
     }
 
+    // The same with the integrated loudness meter's bookkeeping riding on the launch (ilufs_device.h): a workgroup that has
+    // left its row's sums of squares counts itself in at its meter; the one that finds all the other rows of the meter
+    // already counted does what ilufs_call_kernel would do in a launch of its own.  The sums and the count are agent-scope
+    // atomics, performed at the memory side; the adding threads wait for theirs (s_waitcnt vmcnt(0): an atomic without a
+    // return value completes like a store) before the barrier behind which thread 0 counts the row in, and the reader
+    // takes the sums with agent-scope loads.  No fence: an agent-scope release writes the XCD's L2 back, once per workgroup.
+    template <int L, int NW, bool ALIGNED>
+    __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
+    void biquad_sumsq_ilufs_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const float *__restrict__ tab,
+                                   float *state, const uint32_t *__restrict__ nsec, int max_sec, const sumsq_args sq,
+                                   const mi_meters::ilufs_epilogue ep)
+    {
+        biquad_body<L, NW, ALIGNED, false, true>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), sq);
+        __shared__ uint32_t s_last;
+        __shared__ float s_sum[4];
+        __shared__ uint32_t s_cnt[4];
+        __shared__ float s_val;
+        const uint32_t meter = blockIdx.x / ep.channels;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this row's additions are performed before it is counted in
+        __syncthreads();
+        if (threadIdx.x == 0)
+        {
+            const uint32_t before = __hip_atomic_fetch_add(&ep.arrived[meter], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = (before + 1 == ep.channels) ? 1u : 0u;
+            if (s_last)
+                __hip_atomic_store(&ep.arrived[meter], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+        }
+        __syncthreads();
+        if (!s_last)
+            return;
+        mi_meters::ilufs_call_body<64 * NW, true>(meter, ep.block, sq.sums, ep.pieces, ep.cfg, ep.channels, ep.out, ep.out_stride,
+                                            ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val);
+    }
+
     template <int L, int NW, bool ALIGNED>
     __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
     void biquad_chain_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const chain_args chain)
@@ -872,11 +907,25 @@ namespace
 {
     template <int L, int NW>
     hipError_t launch(mi_biquad_bank *b, float *out, const float *in, size_t out_stride,
-                      size_t in_stride, int n, bool aligned, const float *tab, hipStream_t st, const sumsq_args *sq = nullptr)
+                      size_t in_stride, int n, bool aligned, const float *tab, hipStream_t st, const sumsq_args *sq = nullptr,
+                      const mi_meters::ilufs_epilogue *ep = nullptr)
     {
         const dim3 grid(b->channels), block(64 * NW);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
+        if constexpr (L == 16 && NW == 2)
+        {
+            if (sq != nullptr && ep != nullptr)
+            {
+                if (aligned)
+                    MI_LAUNCH((biquad_sumsq_ilufs_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, in, in_stride, n, tab,
+                              b->d_state, b->d_nsec, int(b->max_sec), *sq, *ep);
+                else
+                    MI_LAUNCH((biquad_sumsq_ilufs_kernel<L, NW, false>), grid, block, 0, st, ev0, ev1, in, in_stride, n, tab,
+                              b->d_state, b->d_nsec, int(b->max_sec), *sq, *ep);
+                return hipGetLastError();
+            }
+        }
         if (sq != nullptr)
         {
             if (aligned)
@@ -1031,15 +1080,19 @@ namespace mi
 } // namespace mi
 
 static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t samples, size_t out_stride, size_t in_stride,
-                    hipStream_t st, const sumsq_args *sq);
+                    hipStream_t st, const sumsq_args *sq, const mi_meters::ilufs_epilogue *ep = nullptr, bool *rode = nullptr);
 
 namespace mi
 {
     // The bank over `samples` samples without an output: sums[channel * 4 + s] += the sum of the squares of the filtered
     // samples [seg_end[s - 1], seg_end[s]) (seg_end[3] = samples).  A channel switched off adds nothing.
+    // `ep` != NULL: the integrated meter's bookkeeping for this call; *rode tells whether it went with the launch (then
+    // the caller has nothing left to do) or the call did not qualify (the caller launches its own kernel behind this one).
     int biquad_bank_sumsq(mi_biquad_bank *b, const float *in, size_t in_stride, size_t samples, const uint32_t seg_end[3],
-                          float *sums, hipStream_t st)
+                          float *sums, hipStream_t st, const mi_meters::ilufs_epilogue *ep, bool *rode)
     {
+        if (rode != nullptr)
+            *rode = false;
         if (samples == 0)
             return MI_OK;
         MI_REQUIRE(b != nullptr && in != nullptr && sums != nullptr && in_stride >= samples && samples < (size_t(1) << 31),
@@ -1049,7 +1102,7 @@ namespace mi
         sq.e0 = int(std::min<size_t>(seg_end[0], samples));
         sq.e1 = int(std::min<size_t>(seg_end[1], samples));
         sq.e2 = int(std::min<size_t>(seg_end[2], samples));
-        return bank_run(b, nullptr, in, samples, 0, in_stride, st, &sq);
+        return bank_run(b, nullptr, in, samples, 0, in_stride, st, &sq, ep, rode);
     }
 } // namespace mi
 
@@ -1200,7 +1253,7 @@ int mi_biquad_bank_reset(mi_biquad_bank_t *b, uint32_t channel, void *stream)
 
 // One call of the bank over `samples` samples of every channel; sq != NULL: the meters' epilogue instead of the output
 static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t samples, size_t out_stride, size_t in_stride,
-                    hipStream_t st, const sumsq_args *sq)
+                    hipStream_t st, const sumsq_args *sq, const mi_meters::ilufs_epilogue *ep, bool *rode)
 {
     int r = commit(b, st);
     if (r != MI_OK)
@@ -1216,6 +1269,12 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
     const size_t chunk = use_small ? 8 : 16;
     const size_t tail  = samples % chunk;                   // < chunk samples, done by biquad_tail_kernel
     const size_t body  = samples - tail;
+    // the meter's bookkeeping rides on the launch when the launch is the whole call: the long-call variant, no tail kernel
+    // behind it (whose sums would come too late), one launch
+    const bool no_ride = ep != nullptr && getenv("MI_ILUFS_TWO_LAUNCHES") != nullptr;       // test knob, read per call
+    const bool ride = sq != nullptr && ep != nullptr && !use_small && tail == 0 && body < (size_t(1) << 28) && !no_ride;
+    if (rode != nullptr)
+        *rode = ride;
     size_t done = 0;
     while (done < body)
     {
@@ -1258,7 +1317,7 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
             e = hipGetLastError();
         }
         else
-            e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq);
+            e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq, ride ? ep : nullptr);
         MI_HIP_CHECK(e);
         done += step;
     }

@@ -1,0 +1,286 @@
+// Device side of the integrated loudness meter's bookkeeping (lsp::dspu::ILUFSMeter, reference:
+// src/main/meters/ILUFSMeter.cpp:324-353 gated / infinite loudness, :355-470 process), shared by two launches:
+//   * loudness.hip's ilufs_call_kernel: one workgroup of 256 threads per meter, behind the weighting filter's launch;
+//   * biquad.hip's biquad_sumsq_kernel<.., true>: the weighting filter's own launch, where the workgroup that is the
+//     LAST of a meter's rows to leave its sums of squares does the meter's bookkeeping (one launch per call instead of
+//     two); its 128 threads then stand in for the 256.  Hand-over without fences: the sums are agent-scope atomics
+//     (performed at the memory side, not in an XCD's L2), every adding thread waits for their completion before the
+//     workgroup counts itself in, and the reader takes them with agent-scope loads (an agent-scope release fence per
+//     workgroup -- an L2 write-back each -- took the step from 38 to 60 us).
+// Every sum below is laid out over VTH = 256 "virtual" threads in four virtual waves, whatever the number of real
+// threads: the two launches give the same floats bit for bit.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace mi_meters
+{
+    struct chan_cfg
+    {
+        float   weight;
+        float   link;
+        int     enabled;
+        int     unbound;        // LoudnessMeter: no input bound -- the channel is left out of the block (:421-422) but stays
+    };                          // enabled for refresh_rms() and clear(); always 0 for the integrated meter
+
+    constexpr float GATING_ABS_THRESH = 1.17246530458e-07f;         // ILUFSMeter.cpp:39
+    constexpr uint32_t MIN_GATING_BLOCKS = 64;                      // :55
+    constexpr int VTH = 256;                                        // virtual threads per meter (the order of the sums)
+
+    struct ilufs_state { uint32_t head, count; float loudness; uint32_t pad; };
+
+    // The pieces of one process() call.  A piece is a run of samples inside one quarter of a gating block; the weighting
+    // filter has left the sum of squares of every row and piece in seg[row][piece].  Piece by piece: the held loudness
+    // value into the output row (ILUFSMeter.cpp:386-387), vBlock[row][part] += the piece's sum for every enabled row
+    // (:372-384), then -- when the piece ends the quarter -- the gating arithmetic of a complete block and the reset of
+    // the quarter that is filled next (:402-466).
+    struct ilufs_piece { uint32_t offset, n, part; int gate, zero_part; };
+    struct ilufs_pieces { uint32_t count; ilufs_piece p[4]; };
+
+    // What the last-arriving workgroup of the weighting filter's launch needs for a meter's bookkeeping
+    struct ilufs_epilogue
+    {
+        uint32_t       *arrived;        // [meters] rows of the meter that have left their sums (back to 0 when the last one has)
+        float          *block;          // [rows][4] the quarters of the gating block in hand
+        const chan_cfg *cfg;
+        uint32_t        channels;
+        float          *out;
+        size_t          out_stride;
+        ilufs_state    *st;
+        float           gain;
+        float          *hist;
+        uint32_t        size, ms_int;
+        float           avg;
+        ilufs_pieces    pieces;
+    };
+
+#if defined(__HIPCC__)
+    // the four virtual waves' partial sums -> one number, in the order ((w0 + w1) + w2) + w3
+    template <int TT>
+    __device__ __forceinline__ void virtual_wave_sums(float (&s)[VTH / TT], float *s_sum)
+    {
+        const uint32_t tid = threadIdx.x;
+        #pragma unroll
+        for (int r = 0; r < VTH / TT; ++r)
+        {
+            float v = s[r];
+            #pragma unroll
+            for (int w = 32; w > 0; w >>= 1)
+                v += __shfl_xor(v, w);
+            if ((tid & 63) == 0)
+                s_sum[(tid >> 6) + r * (TT / 64)] = v;
+        }
+    }
+
+    // mean of the last `count` history entries above the ABSOLUTE gate (compute_gated_loudness, ILUFSMeter.cpp:324-341:
+    // its `threshold` argument is not used by the reference -- both gating stages compare with GATING_ABS_THRESH, so the
+    // relative stage returns what the absolute stage returned; one pass gives the reference's result for both)
+    template <int TT>
+    __device__ float gated_mean(const float *hist, uint32_t size, uint32_t head, uint32_t count, float *s_sum, uint32_t *s_cnt)
+    {
+        static_assert(TT == 128 || TT == 256, "two or four real waves");
+        constexpr int R = VTH / TT;
+        const uint32_t tid = threadIdx.x;
+        const uint32_t tail = (head + size - count) % size;
+        float s[R];
+        uint32_t c[R];
+        #pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            s[r] = 0.0f;
+            c[r] = 0;
+            for (uint32_t j = tid + r * TT; j < count; j += VTH)
+            {
+                const float l = hist[(tail + j) % size];
+                if (l > GATING_ABS_THRESH)
+                {
+                    s[r] += l;
+                    ++c[r];
+                }
+            }
+        }
+        // the waves' sums by shuffles, the four virtual ones through LDS
+        virtual_wave_sums<TT>(s, s_sum);
+        #pragma unroll
+        for (int r = 0; r < R; ++r)
+        {
+            uint32_t v = c[r];
+            #pragma unroll
+            for (int w = 32; w > 0; w >>= 1)
+                v += __shfl_xor(v, w);
+            if ((tid & 63) == 0)
+                s_cnt[(tid >> 6) + r * (TT / 64)] = v;
+        }
+        __syncthreads();
+        if (tid == 0)
+        {
+            s_sum[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+            s_cnt[0] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+        }
+        __syncthreads();
+        const float r = (s_cnt[0] > 0) ? s_sum[0] / float(s_cnt[0]) : 0.0f;
+        __syncthreads();
+        return r;
+    }
+
+    // a gating block is complete (ILUFSMeter.cpp:402-458); the workgroup of the meter
+    template <int TT>
+    __device__ float ilufs_gate(uint32_t meter, ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *block,
+                                const chan_cfg *__restrict__ cfg, uint32_t channels, float avg,
+                                float *s_sum, uint32_t *s_cnt, float &s_val)
+    {
+        constexpr int R = VTH / TT;
+        const uint32_t tid = threadIdx.x;
+        float *h = hist + size_t(meter) * size;
+        ilufs_state me = st[meter];
+        if (tid == 0)
+        {
+            float loudness = 0.0f;                          // every channel's block enters, enabled or not (:407-414)
+            for (uint32_t c = 0; c < channels; ++c)
+            {
+                const float *blk = block + (size_t(meter) * channels + c) * 4;
+                loudness += cfg[c].weight * ((blk[0] + blk[1] + blk[2] + blk[3]) * avg);
+            }
+            s_val = loudness;
+        }
+        __syncthreads();
+        float loudness = s_val;
+        __syncthreads();
+        if (ms_int > 0)                                     // finite integration period
+        {
+            me.count = (me.count + 1 < ms_int) ? me.count + 1 : ms_int;
+            if (tid == 0)
+                h[me.head] = loudness;
+            me.head = (me.head + 1) % size;
+            __syncthreads();
+            loudness = gated_mean<TT>(h, size, me.head, me.count, s_sum, s_cnt);
+        }
+        else                                                // since the last clear(): running mean of the gated blocks
+        {
+            if (loudness > GATING_ABS_THRESH)
+            {
+                if (me.count >= 0x100)                      // floating-point overflow protection (:440-444)
+                {
+                    for (uint32_t j = tid; j < size; j += TT)
+                        h[j] *= 0.5f;
+                    me.count >>= 1;
+                    __syncthreads();
+                }
+                ++me.count;
+                if (tid == 0)
+                    h[me.head] += loudness;
+                me.head = (me.head + 1) % size;
+                __syncthreads();
+            }
+            if (me.count > 0)                               // compute_infinite_loudness: sum of hist[j] / count
+            {
+                const float mult = 1.0f / float(me.count);
+                float s[R];
+                #pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+                    s[r] = 0.0f;
+                    for (uint32_t j = tid + r * TT; j < size; j += VTH)
+                        s[r] += mult * h[j];
+                }
+                virtual_wave_sums<TT>(s, s_sum);
+                __syncthreads();
+                if (tid == 0)
+                    s_sum[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
+                __syncthreads();
+                loudness = s_sum[0];
+            }
+            else
+                loudness = 0.0f;
+        }
+        me.loudness = sqrtf(loudness);
+        if (tid == 0)
+            st[meter] = me;
+        return me.loudness;                                 // every thread has it: the next piece's output starts at once
+    }
+
+    // seg[] cell; FRESH: read at the memory side (agent scope), for the launch in which other workgroups, possibly on
+    // another XCD with an L2 of its own, have only just added to it
+    template <bool FRESH>
+    __device__ __forceinline__ float seg_load(const float *p)
+    {
+        return FRESH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+    }
+
+    // The pieces of one call for one meter, by a workgroup of TT threads (s_sum, s_cnt: four cells of LDS each)
+    template <int TT, bool FRESH = false>
+    __device__ void ilufs_call_body(uint32_t meter, float *block, float *seg, const ilufs_pieces &pieces,
+                                    const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
+                                    ilufs_state *st, float gain, float *hist, uint32_t size, uint32_t ms_int, float avg,
+                                    float *s_sum, uint32_t *s_cnt, float &s_val)
+    {
+        const uint32_t tid = threadIdx.x;
+        // everything the pieces need from memory is asked for at once: the value being held, and for the thread of
+        // channel c the pieces' sums of squares, its quarters and whether it counts
+        float held = st[meter].loudness;
+        const uint32_t myrow = meter * channels + tid;
+        float4 myseg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), myblk = myseg;
+        bool counts = false;
+        if (tid < channels)
+        {
+            const float *ms = seg + size_t(myrow) * 4;
+            myseg = FRESH ? make_float4(seg_load<true>(ms), seg_load<true>(ms + 1), seg_load<true>(ms + 2), seg_load<true>(ms + 3))
+                          : *reinterpret_cast<const float4 *>(ms);
+            myblk = *reinterpret_cast<const float4 *>(block + size_t(myrow) * 4);
+            counts = cfg[tid].enabled != 0;
+        }
+        for (uint32_t k = 0; k < pieces.count; ++k)
+        {
+            const ilufs_piece pc = pieces.p[k];
+            if (out != nullptr && pc.n > 0)
+            {
+                const float v = held * gain;
+                float *o = out + size_t(meter) * out_stride + pc.offset;
+                // 16-byte stores over the aligned middle of the run
+                const uint32_t lead = uint32_t((4u - (uint32_t(reinterpret_cast<uintptr_t>(o) >> 2) & 3u)) & 3u);
+                const uint32_t head = (lead < pc.n) ? lead : pc.n, quads = (pc.n - head) >> 2;
+                if (tid < head)
+                    o[tid] = v;
+                float4 *o4 = reinterpret_cast<float4 *>(o + head);
+                for (uint32_t i = tid; i < quads; i += TT)
+                    o4[i] = make_float4(v, v, v, v);
+                for (uint32_t i = head + 4u * quads + tid; i < pc.n; i += TT)
+                    o[i] = v;
+            }
+            if (pc.n > 0)
+            {
+                if (tid < channels && counts)
+                {
+                    const float add = (k == 0) ? myseg.x : (k == 1) ? myseg.y : (k == 2) ? myseg.z : myseg.w;
+                    float *q = (pc.part == 0) ? &myblk.x : (pc.part == 1) ? &myblk.y : (pc.part == 2) ? &myblk.z : &myblk.w;
+                    *q += add;
+                    block[size_t(myrow) * 4 + pc.part] = *q;
+                }
+                for (uint32_t c = tid + TT; c < channels; c += TT)         // meters of more channels than threads
+                    if (cfg[c].enabled)
+                    {
+                        const uint32_t row = meter * channels + c;
+                        block[row * 4 + pc.part] += seg_load<FRESH>(seg + row * 4 + k);
+                    }
+            }
+            __syncthreads();
+            if (pc.gate)
+                held = ilufs_gate<TT>(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);
+            __syncthreads();
+            if (pc.zero_part >= 0)
+            {
+                if (tid < channels)
+                {
+                    float *q = (pc.zero_part == 0) ? &myblk.x : (pc.zero_part == 1) ? &myblk.y : (pc.zero_part == 2) ? &myblk.z : &myblk.w;
+                    *q = 0.0f;
+                }
+                for (uint32_t c = tid; c < channels; c += TT)
+                    block[(meter * channels + c) * 4 + uint32_t(pc.zero_part)] = 0.0f;
+            }
+            __syncthreads();
+        }
+        for (uint32_t i = tid; i < channels * 4; i += TT)   // consumed: the next call's filter launch adds to zeros
+            seg[size_t(meter) * channels * 4 + i] = 0.0f;
+    }
+#endif
+} // namespace mi_meters

@@ -9,6 +9,7 @@
 // One workgroup per meter: it walks the meter's channels, mixes the mean squares with the designation weights,
 // takes the square root and writes the mixed loudness and the (linked) per-channel values.
 #include "mi_common.h"
+#include "ilufs_device.h"
 #include "host/filter_design.h"
 
 #include <algorithm>
@@ -34,13 +35,7 @@ namespace
         return 1.0f;
     }
 
-    struct chan_cfg
-    {
-        float   weight;
-        float   link;
-        int     enabled;
-        int     unbound;        // LoudnessMeter: no input bound -- the channel is left out of the block (:421-422) but stays
-    };                          // enabled for refresh_rms() and clear(); always 0 for the integrated meter
+    using mi_meters::chan_cfg;          // ilufs_device.h (shared with the integrated meter's fused launch)
 
     // inclusive sum scan over the 64 lanes with DPP: shifts inside the rows of 16 lanes, then the sums of rows 0 and 2 to
     // rows 1 and 3 (row_bcast:15) and of the lower half to the upper half (row_bcast:31)
@@ -1027,208 +1022,24 @@ int mi_loudness_bank_loudness(mi_loudness_bank_t *b, float *loudness, void *stre
 // boundary one workgroup per meter does the reference's gating arithmetic over the meter's history of gating blocks.
 namespace
 {
-    constexpr float GATING_ABS_THRESH = 1.17246530458e-07f;         // ILUFSMeter.cpp:39
-    constexpr uint32_t MIN_GATING_BLOCKS = 64;                      // :55
+    using mi_meters::ilufs_state;
+    using mi_meters::ilufs_piece;
+    using mi_meters::ilufs_pieces;
+    using mi_meters::MIN_GATING_BLOCKS;
 
-    struct ilufs_state { uint32_t head, count; float loudness; uint32_t pad; };
-
-    // mean of the last `count` history entries above the ABSOLUTE gate (compute_gated_loudness, ILUFSMeter.cpp:324-341:
-    // its `threshold` argument is not used by the reference -- both gating stages compare with GATING_ABS_THRESH, so the
-    // relative stage returns what the absolute stage returned; one pass gives the reference's result for both)
-    __device__ float gated_mean(const float *hist, uint32_t size, uint32_t head, uint32_t count, float *s_sum, uint32_t *s_cnt)
-    {
-        const uint32_t tid = threadIdx.x;
-        const uint32_t tail = (head + size - count) % size;
-        float s = 0.0f;
-        uint32_t c = 0;
-        for (uint32_t j = tid; j < count; j += LT)
-        {
-            const float l = hist[(tail + j) % size];
-            if (l > GATING_ABS_THRESH)
-            {
-                s += l;
-                ++c;
-            }
-        }
-        // the waves' sums by shuffles, the four of them through LDS
-        #pragma unroll
-        for (int w = 32; w > 0; w >>= 1)
-        {
-            s += __shfl_xor(s, w);
-            c += __shfl_xor(c, w);
-        }
-        if ((tid & 63) == 0)
-        {
-            s_sum[tid >> 6] = s;
-            s_cnt[tid >> 6] = c;
-        }
-        __syncthreads();
-        if (tid == 0)
-        {
-            static_assert(LT == 256, "four waves");
-            s_sum[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
-            s_cnt[0] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
-        }
-        __syncthreads();
-        const float r = (s_cnt[0] > 0) ? s_sum[0] / float(s_cnt[0]) : 0.0f;
-        __syncthreads();
-        return r;
-    }
-
-    // a gating block is complete (ILUFSMeter.cpp:402-458); the workgroup of the meter
-    __device__ float ilufs_gate(uint32_t meter, ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *block,
-                               const chan_cfg *__restrict__ cfg, uint32_t channels, float avg,
-                               float *s_sum, uint32_t *s_cnt, float &s_val)
-    {
-        const uint32_t tid = threadIdx.x;
-        float *h = hist + size_t(meter) * size;
-        ilufs_state me = st[meter];
-        if (tid == 0)
-        {
-            float loudness = 0.0f;                          // every channel's block enters, enabled or not (:407-414)
-            for (uint32_t c = 0; c < channels; ++c)
-            {
-                const float *blk = block + (size_t(meter) * channels + c) * 4;
-                loudness += cfg[c].weight * ((blk[0] + blk[1] + blk[2] + blk[3]) * avg);
-            }
-            s_val = loudness;
-        }
-        __syncthreads();
-        float loudness = s_val;
-        __syncthreads();
-        if (ms_int > 0)                                     // finite integration period
-        {
-            me.count = (me.count + 1 < ms_int) ? me.count + 1 : ms_int;
-            if (tid == 0)
-                h[me.head] = loudness;
-            me.head = (me.head + 1) % size;
-            __syncthreads();
-            loudness = gated_mean(h, size, me.head, me.count, s_sum, s_cnt);
-        }
-        else                                                // since the last clear(): running mean of the gated blocks
-        {
-            if (loudness > GATING_ABS_THRESH)
-            {
-                if (me.count >= 0x100)                      // floating-point overflow protection (:440-444)
-                {
-                    for (uint32_t j = tid; j < size; j += LT)
-                        h[j] *= 0.5f;
-                    me.count >>= 1;
-                    __syncthreads();
-                }
-                ++me.count;
-                if (tid == 0)
-                    h[me.head] += loudness;
-                me.head = (me.head + 1) % size;
-                __syncthreads();
-            }
-            if (me.count > 0)                               // compute_infinite_loudness: sum of hist[j] / count
-            {
-                const float mult = 1.0f / float(me.count);
-                float s = 0.0f;
-                for (uint32_t j = tid; j < size; j += LT)
-                    s += mult * h[j];
-                #pragma unroll
-                for (int w = 32; w > 0; w >>= 1)
-                    s += __shfl_xor(s, w);
-                if ((tid & 63) == 0)
-                    s_sum[tid >> 6] = s;
-                __syncthreads();
-                if (tid == 0)
-                    s_sum[0] = ((s_sum[0] + s_sum[1]) + s_sum[2]) + s_sum[3];
-                __syncthreads();
-                loudness = s_sum[0];
-            }
-            else
-                loudness = 0.0f;
-        }
-        me.loudness = sqrtf(loudness);
-        if (tid == 0)
-            st[meter] = me;
-        return me.loudness;                                 // every thread has it: the next piece's output starts at once
-    }
-
-    // The pieces of one process() call, one workgroup per meter.  A piece is a run of samples inside one quarter of a
-    // gating block; the weighting filter's launch (biquad_bank_sumsq) has left the sum of squares of every row and piece
-    // in seg[row][piece].  Piece by piece: the held loudness value into the output row (ILUFSMeter.cpp:386-387),
-    // vBlock[row][part] += the piece's sum for every enabled row (:372-384), then -- when the piece ends the quarter --
-    // the gating arithmetic of a complete block and the reset of the quarter that is filled next (:402-466).
-    struct ilufs_piece { uint32_t offset, n, part; int gate, zero_part; };
-    struct ilufs_pieces { uint32_t count; ilufs_piece p[4]; };
-
+    // The pieces of one process() call behind the weighting filter's launch, one workgroup per meter
+    // (ilufs_device.h; calls that qualify do the same inside the filter's launch, mi::biquad_bank_sumsq)
     __global__ __launch_bounds__(LT)
     void ilufs_call_kernel(float *block, float *seg, const ilufs_pieces pieces,
                            const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
                            ilufs_state *st, float gain, float *hist, uint32_t size, uint32_t ms_int, float avg)
     {
-        __shared__ float s_sum[LT];
-        __shared__ uint32_t s_cnt[LT];
+        __shared__ float s_sum[4];
+        __shared__ uint32_t s_cnt[4];
         __shared__ float s_val;
-        const uint32_t meter = blockIdx.x, tid = threadIdx.x;
-        // everything the pieces need from memory is asked for at once: the value being held, and for the thread of
-        // channel c the pieces' sums of squares, its quarters and whether it counts
-        float held = st[meter].loudness;
-        const uint32_t myrow = meter * channels + tid;
-        float4 myseg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), myblk = myseg;
-        bool counts = false;
-        if (tid < channels)
-        {
-            myseg = *reinterpret_cast<const float4 *>(seg + size_t(myrow) * 4);
-            myblk = *reinterpret_cast<const float4 *>(block + size_t(myrow) * 4);
-            counts = cfg[tid].enabled != 0;
-        }
-        for (uint32_t k = 0; k < pieces.count; ++k)
-        {
-            const ilufs_piece pc = pieces.p[k];
-            if (out != nullptr && pc.n > 0)
-            {
-                const float v = held * gain;
-                float *o = out + size_t(meter) * out_stride + pc.offset;
-                // 16-byte stores over the aligned middle of the run
-                const uint32_t lead = uint32_t((4u - (uint32_t(reinterpret_cast<uintptr_t>(o) >> 2) & 3u)) & 3u);
-                const uint32_t head = (lead < pc.n) ? lead : pc.n, quads = (pc.n - head) >> 2;
-                if (tid < head)
-                    o[tid] = v;
-                float4 *o4 = reinterpret_cast<float4 *>(o + head);
-                for (uint32_t i = tid; i < quads; i += LT)
-                    o4[i] = make_float4(v, v, v, v);
-                for (uint32_t i = head + 4u * quads + tid; i < pc.n; i += LT)
-                    o[i] = v;
-            }
-            if (pc.n > 0)
-            {
-                if (tid < channels && counts)
-                {
-                    const float add = (k == 0) ? myseg.x : (k == 1) ? myseg.y : (k == 2) ? myseg.z : myseg.w;
-                    float *q = (pc.part == 0) ? &myblk.x : (pc.part == 1) ? &myblk.y : (pc.part == 2) ? &myblk.z : &myblk.w;
-                    *q += add;
-                    block[size_t(myrow) * 4 + pc.part] = *q;
-                }
-                for (uint32_t c = tid + LT; c < channels; c += LT)         // meters of more than LT channels
-                    if (cfg[c].enabled)
-                    {
-                        const uint32_t row = meter * channels + c;
-                        block[row * 4 + pc.part] += seg[row * 4 + k];
-                    }
-            }
-            __syncthreads();
-            if (pc.gate)
-                held = ilufs_gate(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);
-            __syncthreads();
-            if (pc.zero_part >= 0)
-            {
-                if (tid < channels)
-                {
-                    float *q = (pc.zero_part == 0) ? &myblk.x : (pc.zero_part == 1) ? &myblk.y : (pc.zero_part == 2) ? &myblk.z : &myblk.w;
-                    *q = 0.0f;
-                }
-                for (uint32_t c = tid; c < channels; c += LT)
-                    block[(meter * channels + c) * 4 + uint32_t(pc.zero_part)] = 0.0f;
-            }
-            __syncthreads();
-        }
-        for (uint32_t i = tid; i < channels * 4; i += LT)   // consumed: the next call's filter launch adds to zeros
-            seg[size_t(meter) * channels * 4 + i] = 0.0f;
+        static_assert(LT == mi_meters::VTH, "one real thread per virtual one");
+        mi_meters::ilufs_call_body<LT>(blockIdx.x, block, seg, pieces, cfg, channels, out, out_stride, st, gain, hist, size,
+                                       ms_int, avg, s_sum, s_cnt, s_val);
     }
 } // namespace
 
@@ -1242,6 +1053,7 @@ struct mi_ilufs_bank
     std::vector<chan_cfg> cfg;
     mi_biquad_bank_t *filters = nullptr;
     float      *d_block = nullptr, *d_hist = nullptr, *d_seg = nullptr;
+    uint32_t   *d_arrived = nullptr;        // [meters] rows counted in by the weighting filter's launch (ilufs_device.h)
     ilufs_state *d_state = nullptr;
     chan_cfg   *d_cfg = nullptr;
 };
@@ -1340,6 +1152,8 @@ int mi_ilufs_bank_create(mi_ilufs_bank_t **bank, uint32_t meters, uint32_t chann
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_seg), size_t(b->rows) * 4 * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_seg, 0, size_t(b->rows) * 4 * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_state), meters * sizeof(ilufs_state));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_arrived), meters * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemset(b->d_arrived, 0, meters * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_cfg), channels * sizeof(chan_cfg));
         if (e == hipSuccess) e = hipMemset(b->d_block, 0, size_t(b->rows) * 4 * sizeof(float));
         if (e == hipSuccess) e = hipMemset(b->d_state, 0, meters * sizeof(ilufs_state));
@@ -1358,7 +1172,7 @@ int mi_ilufs_bank_destroy(mi_ilufs_bank_t *b)
     if (b == nullptr)
         return MI_OK;
     mi_biquad_bank_destroy(b->filters);
-    (void)hipFree(b->d_block); (void)hipFree(b->d_hist); (void)hipFree(b->d_seg); (void)hipFree(b->d_state); (void)hipFree(b->d_cfg);
+    (void)hipFree(b->d_block); (void)hipFree(b->d_hist); (void)hipFree(b->d_seg); (void)hipFree(b->d_state); (void)hipFree(b->d_cfg); (void)hipFree(b->d_arrived);
     delete b;
     return MI_OK;
 }
@@ -1534,12 +1348,20 @@ int mi_ilufs_bank_process(mi_ilufs_bank_t *b, float *out, const float *in, size_
         }
         for (uint32_t k = pcs.count; k < 3; ++k)
             ends[k] = uint32_t(taken);
-        r = mi::biquad_bank_sumsq(b->filters, in + offset, in_stride, taken, ends, b->d_seg, st);
+        mi_meters::ilufs_epilogue ep;
+        ep.arrived = b->d_arrived; ep.block = b->d_block; ep.cfg = b->d_cfg; ep.channels = b->channels;
+        ep.out = out ? out + offset : nullptr; ep.out_stride = out_stride; ep.st = b->d_state; ep.gain = gain;
+        ep.hist = b->d_hist; ep.size = b->ms_size; ep.ms_int = b->ms_int; ep.avg = b->avg; ep.pieces = pcs;
+        bool rode = false;
+        r = mi::biquad_bank_sumsq(b->filters, in + offset, in_stride, taken, ends, b->d_seg, st, &ep, &rode);
         if (r != MI_OK)
             return r;
-        hipLaunchKernelGGL(ilufs_call_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_block, b->d_seg, pcs, b->d_cfg, b->channels,
-                           out ? out + offset : nullptr, out_stride, b->d_state, gain, b->d_hist, b->ms_size, b->ms_int, b->avg);
-        MI_HIP_CHECK(hipGetLastError());
+        if (!rode)                                          // short or ragged call: the bookkeeping in a launch of its own
+        {
+            hipLaunchKernelGGL(ilufs_call_kernel, dim3(b->meters), dim3(LT), 0, st, b->d_block, b->d_seg, pcs, b->d_cfg, b->channels,
+                               ep.out, out_stride, b->d_state, gain, b->d_hist, b->ms_size, b->ms_int, b->avg);
+            MI_HIP_CHECK(hipGetLastError());
+        }
         offset += taken;
     }
     return MI_OK;

@@ -10,6 +10,8 @@
 
 #include "mi_dspu.h"
 
+namespace mi_meters { struct ilufs_epilogue; }
+
 namespace mi
 {
     // Thread-local message behind mi_dspu_last_error().
@@ -59,8 +61,11 @@ namespace mi
 
     // A biquad bank over a block without an output (biquad.hip): sums[channel * 4 + s] += the sum of the squares of the
     // filtered samples of segment s = [seg_end[s - 1], seg_end[s]), seg_end[3] = samples.  The meters' weighting filter.
+    // ep != NULL: the integrated loudness meter's bookkeeping of this call (ilufs_device.h) goes with the launch when the
+    // call qualifies (*rode = true: the last workgroup of every meter does it), otherwise the caller's own kernel follows.
     int         biquad_bank_sumsq(mi_biquad_bank_t *bank, const float *in, size_t in_stride, size_t samples,
-                                  const uint32_t seg_end[3], float *sums, hipStream_t st);
+                                  const uint32_t seg_end[3], float *sums, hipStream_t st,
+                                  const mi_meters::ilufs_epilogue *ep = nullptr, bool *rode = nullptr);
 
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);

@@ -237,3 +237,43 @@ def test_random_operation_sequences(gpu, seed):
             at_gate = [False] * M
         log.append(str(op))
     bank.close()
+
+
+@pytest.mark.parametrize("mode", ["finite", "infinite"])
+def test_bookkeeping_riding_on_the_filter_launch_equals_two_launches(gpu, monkeypatch, mode):
+    """Calls that are a multiple of 16 samples and longer than 2048 do the meter's bookkeeping on the last workgroup of the
+    weighting filter's launch (biquad_sumsq_ilufs_kernel); MI_ILUFS_TWO_LAUNCHES keeps the separate kernel.  Both lay their
+    sums out over the same 256 virtual threads: the same floats bit for bit, output rows, loudness and history, over
+    ragged and whole calls, five channels per meter (more rows per meter than the two of a stereo pair)."""
+    sr, M, K = 48000, 6, 5
+    calls = (4096, 4800, 2064, 19200, 8192, 1024, 4096, 38400, 4112)
+    n = sum(calls)
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((M * K, n)) * 0.2).astype(np.float32)
+    x[:, 30000:42000] *= 1e-5
+    results = []
+    for two in (False, True):
+        if two:
+            monkeypatch.setenv("MI_ILUFS_TWO_LAUNCHES", "1")
+        else:
+            monkeypatch.delenv("MI_ILUFS_TWO_LAUNCHES", raising=False)
+        bank = gpu.ILUFSBank(M, K, 0.0 if mode == "infinite" else 1.2)
+        bank.set_sample_rate(sr)
+        for c, d in enumerate((ol.CHANNEL_LEFT, ol.CHANNEL_RIGHT, ol.CHANNEL_CENTER, 7, ol.CHANNEL_LFE1)):
+            bank.set_designation(c, d)
+        bank.set_active(3, False)
+        if mode == "infinite":
+            bank.set_integration_period(0.0)
+        ys, pos = [], 0
+        for k in calls:
+            out = gpu.DeviceBuffer((M, k))
+            bank.process(out, gpu.DeviceBuffer.from_host(x[:, pos:pos + k]), k, gain=0.7)
+            ys.append(out.download())
+            pos += k
+        results.append((np.concatenate(ys, axis=1), bank.loudness().copy(), [np.array(v) for v in bank.history()]))
+        bank.close()
+    (y0, l0, h0), (y1, l1, h1) = results
+    assert float(np.abs(y1).max()) > 0
+    assert np.array_equal(y0, y1) and np.array_equal(l0, l1)
+    for a, b in zip(h0, h1):
+        assert np.array_equal(a, b)
