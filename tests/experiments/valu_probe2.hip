@@ -24,7 +24,8 @@ __device__ __forceinline__ float dpp0(float v)
 #define FMAC_DPP(dst, src, m, ctrl) asm volatile("v_fmac_f32_dpp %0, %1, %2 " ctrl " row_mask:0xf bank_mask:0xf bound_ctrl:0" : "+v"(dst) : "v"(src), "v"(m))
 
 template <int KIND, int CH>
-__global__ void probe(float *out, unsigned long long *stamps, const float *coef, int iters)
+__global__ __launch_bounds__(256)      // (without it the 128-VGPR default spills the 4-chunk packed bodies: 25 and 53 registers)
+void probe(float *out, unsigned long long *stamps, const float *coef, int iters)
 {
     // coefficients: wave-uniform, kept in SGPRs
     float c[40];
