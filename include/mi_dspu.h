@@ -740,9 +740,11 @@ void  mi_crossover_lopass_fft_apply(float *mag, float f0, float slope, float sam
 
 /* ---- delay line and ring buffer banks ----------------------------------------------------- */
 /*
- * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  All
- * channels share one write position; the delay is per channel.  Index arithmetic is the reference's
- * (uint32 head/tail/size, src/main/util/Delay.cpp:76-102,434,569-574): outputs are bit-exact.
+ * mi_delay_bank: `channels` x lsp::dspu::Delay (include/lsp-plug.in/dsp-units/util/Delay.h:35-209).  The delay is
+ * per channel.  Calls on the whole bank move every line by the same amount; the *_rows calls move the listed lines
+ * only, each line then keeps a write position of its own (every reference object has its nHead, Delay.h:35).
+ * Index arithmetic is the reference's (uint32 head/tail/size, src/main/util/Delay.cpp:76-102,434,569-574):
+ * outputs are bit-exact.
  */
 typedef struct mi_delay_bank mi_delay_bank_t;
 enum { MI_GAIN_NONE = 0, MI_GAIN_SCALAR = 1, MI_GAIN_VECTOR = 2 };
@@ -773,6 +775,18 @@ int mi_delay_bank_process(mi_delay_bank_t *bank, float *out, const float *in, si
 int mi_delay_bank_process_ramping(mi_delay_bank_t *bank, float *out, const float *in, const uint32_t *new_delays,
                                   size_t count, size_t out_stride, size_t in_stride, int gain_mode, float gain,
                                   const float *gain_vec, size_t gain_stride, void *stream);
+/*
+ * The same calls for a SUBSET of the bank's lines -- Delay objects with different call histories in one bank:
+ * rows (HOST array of n_rows distinct channel indices) names the line behind every row of the call's buffers
+ * (row r of in / out / gain_vec belongs to channel rows[r]); only those lines are written and move on.  One launch
+ * however the lines' positions differ (they are read from a per-line table on the device).  The first *_rows call
+ * switches the bank's kernels to that table; whole-bank calls keep working and move every line.
+ */
+int mi_delay_bank_append_rows(mi_delay_bank_t *bank, const uint32_t *rows, uint32_t n_rows, const float *in, size_t count,
+                              size_t in_stride, void *stream);
+int mi_delay_bank_process_rows(mi_delay_bank_t *bank, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
+                               size_t count, size_t out_stride, size_t in_stride, int add, int gain_mode, float gain,
+                               const float *gain_vec, size_t gain_stride, void *stream);
 
 /* mi_ring_bank: `channels` x lsp::dspu::RingBuffer (util/RingBuffer.h:35-179, src/main/util/RingBuffer.cpp:48-209). */
 typedef struct mi_ring_bank mi_ring_bank_t;

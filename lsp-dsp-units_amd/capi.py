@@ -214,6 +214,9 @@ PROTOTYPES = {
     "mi_delay_bank_append": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p]),
     "mi_delay_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int, c_int, c_float,
                                       c_void_p, c_size_t, c_void_p]),
+    "mi_delay_bank_append_rows": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_size_t, c_size_t, c_void_p]),
+    "mi_delay_bank_process_rows": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int, c_int,
+                                   c_float, c_void_p, c_size_t, c_void_p]),
     "mi_delay_bank_process_ramping": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int,
                                               c_float, c_void_p, c_size_t, c_void_p]),
     "mi_ring_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t, c_float]),

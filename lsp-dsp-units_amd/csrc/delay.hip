@@ -3,7 +3,9 @@
 //   mi_ring_bank  -- `channels` x lsp::dspu::RingBuffer (reference: src/main/util/RingBuffer.cpp:48-209)
 // Pure data movement: every kernel is a gather/scatter whose index arithmetic is the reference's own
 // (unsigned 32-bit head/tail/size, same modulo expressions), so results are bit-exact by construction.
-// All channels of a bank advance together (one head), delays are per channel.
+// Delays are per channel.  The channels of a bank advance together (one head, passed by value) unless the caller uses the
+// *_rows calls, which move a subset only: every channel then carries an offset to the common head (util/Delay.h:35 -- each
+// reference object has its own nHead), kept on the device and touched only by calls that move a subset.
 #include "mi_common.h"
 
 #include <cstdint>
@@ -16,6 +18,15 @@ namespace
     // gain modes shared by the process variants (Delay.cpp:104-397)
     enum { G_NONE = 0, G_SCALAR = 1, G_VECTOR = 2 };
 
+    // Which line a row of the call's buffers belongs to, and where that line's write position is: rows == NULL: row r is
+    // channel r; off == NULL: every line sits at the common head.
+    struct row_map { const uint32_t *rows; const uint32_t *off; };
+    __device__ __forceinline__ uint32_t line_of(const row_map &m, uint32_t r) { return m.rows ? m.rows[r] : r; }
+    __device__ __forceinline__ uint32_t head_of(const row_map &m, uint32_t ch, uint32_t head, uint32_t size)
+    {
+        return m.off ? (head + m.off[ch]) % size : head;
+    }
+
     __device__ __forceinline__ float apply_gain(float v, int mode, float k, const float *gv, size_t i)
     {
         return (mode == G_SCALAR) ? v * k : (mode == G_VECTOR) ? v * gv[i] : v;
@@ -23,26 +34,27 @@ namespace
 
     // ring[(head + i) % size] = src[i] for the last min(count, size) samples (Delay::append, Delay.cpp:76-102)
     __global__ __launch_bounds__(256)
-    void ring_append_kernel(float *ring, uint32_t size, uint32_t head, const float *src, size_t src_stride, size_t count)
+    void ring_append_kernel(float *ring, uint32_t size, uint32_t head0, const float *src, size_t src_stride, size_t count,
+                            const row_map rm)
     {
-        const uint32_t ch = blockIdx.y;
+        const uint32_t r = blockIdx.y, ch = line_of(rm, r), head = head_of(rm, ch, head0, size);
         const size_t first = (count > size) ? count - size : 0;         // older samples would be overwritten anyway
         for (size_t i = first + size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
-            ring[size_t(ch) * size + (head + i) % size] = src[size_t(ch) * src_stride + i];
+            ring[size_t(ch) * size + (head + i) % size] = src[size_t(r) * src_stride + i];
     }
 
     // dst[i] (+)= gain * ring[(tail_c + i) % size] -- the "shift data from buffer" half of Delay::process
     __global__ __launch_bounds__(256)
-    void ring_read_kernel(float *dst, size_t dst_stride, const float *ring, uint32_t size, uint32_t head,
+    void ring_read_kernel(float *dst, size_t dst_stride, const float *ring, uint32_t size, uint32_t head0,
                           const uint32_t *__restrict__ delay, size_t count, int add, int gmode, float k,
-                          const float *gv, size_t gv_stride)
+                          const float *gv, size_t gv_stride, const row_map rm)
     {
-        const uint32_t ch = blockIdx.y;
+        const uint32_t r = blockIdx.y, ch = line_of(rm, r), head = head_of(rm, ch, head0, size);
         const uint32_t tail = (head + size - delay[ch]) % size;         // Delay.cpp:101
         for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
         {
-            const float v = apply_gain(ring[size_t(ch) * size + (tail + i) % size], gmode, k, gv + size_t(ch) * gv_stride, i);
-            float *d = dst + size_t(ch) * dst_stride + i;
+            const float v = apply_gain(ring[size_t(ch) * size + (tail + i) % size], gmode, k, gv + size_t(r) * gv_stride, i);
+            float *d = dst + size_t(r) * dst_stride + i;
             *d = add ? *d + v : v;
         }
     }
@@ -52,18 +64,18 @@ namespace
     // src[i - d] as soon as i >= d), without cutting the block into pieces.
     __global__ __launch_bounds__(256)
     void delay_direct_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, const float *ring,
-                             uint32_t size, uint32_t head, const uint32_t *__restrict__ delay, size_t count,
-                             int add, int gmode, float k, const float *gv, size_t gv_stride)
+                             uint32_t size, uint32_t head0, const uint32_t *__restrict__ delay, size_t count,
+                             int add, int gmode, float k, const float *gv, size_t gv_stride, const row_map rm)
     {
-        const uint32_t ch = blockIdx.y;
+        const uint32_t r = blockIdx.y, ch = line_of(rm, r), head = head_of(rm, ch, head0, size);
         const uint32_t d = delay[ch];
         const uint32_t tail = (head + size - d) % size;
-        const float *x = src + size_t(ch) * src_stride;
+        const float *x = src + size_t(r) * src_stride;
         for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
         {
             const float raw = (i >= d) ? x[i - d] : ring[size_t(ch) * size + (tail + i) % size];
-            const float v = apply_gain(raw, gmode, k, gv + size_t(ch) * gv_stride, i);
-            float *o = dst + size_t(ch) * dst_stride + i;
+            const float v = apply_gain(raw, gmode, k, gv + size_t(r) * gv_stride, i);
+            float *o = dst + size_t(r) * dst_stride + i;
             *o = add ? *o + v : v;
         }
     }
@@ -73,18 +85,18 @@ namespace
     //   v = ring[(tail + i) % size];  ring[(head + i) % size] = src[i];  dst[i] (+)= gain * v
     __global__ __launch_bounds__(256)
     void delay_exchange_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, float *ring,
-                               uint32_t size, uint32_t head, const uint32_t *__restrict__ delay, size_t count,
-                               int add, int gmode, float k, const float *gv, size_t gv_stride)
+                               uint32_t size, uint32_t head0, const uint32_t *__restrict__ delay, size_t count,
+                               int add, int gmode, float k, const float *gv, size_t gv_stride, const row_map rm)
     {
-        const uint32_t ch = blockIdx.y;
+        const uint32_t row = blockIdx.y, ch = line_of(rm, row), head = head_of(rm, ch, head0, size);
         const uint32_t tail = (head + size - delay[ch]) % size;
         float *r = ring + size_t(ch) * size;
         for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
         {
-            const float x = src[size_t(ch) * src_stride + i];
-            const float v = apply_gain(r[(tail + i) % size], gmode, k, gv + size_t(ch) * gv_stride, i);
+            const float x = src[size_t(row) * src_stride + i];
+            const float v = apply_gain(r[(tail + i) % size], gmode, k, gv + size_t(row) * gv_stride, i);
             r[(head + i) % size] = x;
-            float *o = dst + size_t(ch) * dst_stride + i;
+            float *o = dst + size_t(row) * dst_stride + i;
             *o = add ? *o + v : v;
         }
     }
@@ -94,11 +106,12 @@ namespace
     // is the newest input written to that ring cell by the end of o's chunk, else the cell's old content.
     __global__ __launch_bounds__(256)
     void delay_ramp_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, const float *ring,
-                           uint32_t size, uint32_t head, const uint32_t *__restrict__ old_delay,
+                           uint32_t size, uint32_t head0, const uint32_t *__restrict__ old_delay,
                            const uint32_t *__restrict__ new_delay, size_t count, int gmode, float k,
-                           const float *gv, size_t gv_stride)
+                           const float *gv, size_t gv_stride, const row_map rm)
     {
-        const uint32_t ch = blockIdx.y;
+        const uint32_t ch = blockIdx.y;                                 // (whole banks only: row = channel)
+        const uint32_t head = head_of(rm, ch, head0, size);
         const uint32_t od = old_delay[ch], nd = new_delay[ch];
         const uint32_t old_tail = (head + size - od) % size;
         const float *x = src + size_t(ch) * src_stride;
@@ -179,6 +192,20 @@ struct mi_delay_bank
     size_t      scratch_floats = 0;
     uint32_t   *d_delay = nullptr, *d_delay_new = nullptr;
     bool        delay_dirty = true;
+    // lines with positions of their own (the *_rows calls): offset of every line's write position to `head`; all zero --
+    // and the kernels told nothing about it -- until a call moves a subset
+    std::vector<uint32_t> off;
+    uint32_t   *d_off = nullptr, *d_rows = nullptr;
+    uint32_t    rows_cap = 0;
+    bool        off_any = false, off_dirty = false;
+};
+
+// the lines a call moves: all of them (rows == nullptr, n == channels) or the listed ones
+struct delay_rows
+{
+    const uint32_t *host = nullptr;     // channel of every row of the call's buffers
+    uint32_t        n = 0;
+    row_map         rm = { nullptr, nullptr };
 };
 
 namespace
@@ -193,10 +220,68 @@ namespace
         return MI_OK;
     }
 
-    int append(mi_delay_bank *b, const float *src, size_t stride, size_t count, hipStream_t st)
+    int sync_offsets(mi_delay_bank *b, hipStream_t st)
     {
-        hipLaunchKernelGGL(ring_append_kernel, grid_for(count, b->channels), dim3(256), 0, st,
-                           b->d_ring, b->size, b->head, src, stride, count);
+        if (!b->off_dirty)
+            return MI_OK;
+        if (b->d_off == nullptr)
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_off), b->channels * sizeof(uint32_t)));
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_off, b->off.data(), b->channels * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+        b->off_dirty = false;
+        return MI_OK;
+    }
+
+    // The lines of a call.  hrows == nullptr: the whole bank.  The kernels hear about offsets only when there are any.
+    int make_rows(mi_delay_bank *b, const uint32_t *hrows, uint32_t n_rows, delay_rows *dr, hipStream_t st)
+    {
+        dr->host = hrows;
+        dr->n = (hrows != nullptr) ? n_rows : b->channels;
+        if (hrows != nullptr)
+        {
+            if (b->off.empty())
+                b->off.assign(b->channels, 0);
+            if (n_rows > b->rows_cap)
+            {
+                (void)hipFree(b->d_rows);
+                b->d_rows = nullptr;
+                b->rows_cap = 0;
+                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_rows), n_rows * sizeof(uint32_t)));
+                b->rows_cap = n_rows;
+            }
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_rows, hrows, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipStreamSynchronize(st));        // (hrows is the caller's memory)
+            b->off_any = true;                              // from here on the lines no longer move as one
+            if (b->d_off == nullptr)
+                b->off_dirty = true;
+        }
+        const int r = sync_offsets(b, st);
+        if (r != MI_OK)
+            return r;
+        dr->rm.rows = (hrows != nullptr) ? b->d_rows : nullptr;
+        dr->rm.off = b->off_any ? b->d_off : nullptr;
+        return MI_OK;
+    }
+
+    // what a call did to the positions: a whole-bank call has moved `head`; a call on a subset leaves `head` where it was
+    // and moves the offsets of its lines by the same amount
+    void settle_rows(mi_delay_bank *b, const delay_rows &dr, uint32_t head_before)
+    {
+        if (dr.host == nullptr)
+            return;
+        const uint32_t delta = (b->head + b->size - head_before) % b->size;
+        b->head = head_before;
+        if (delta == 0)
+            return;
+        for (uint32_t r = 0; r < dr.n; ++r)
+            b->off[dr.host[r]] = (b->off[dr.host[r]] + delta) % b->size;
+        b->off_dirty = true;
+    }
+
+    int append(mi_delay_bank *b, const delay_rows &dr, const float *src, size_t stride, size_t count, hipStream_t st)
+    {
+        hipLaunchKernelGGL(ring_append_kernel, grid_for(count, dr.n), dim3(256), 0, st,
+                           b->d_ring, b->size, b->head, src, stride, count, dr.rm);
         MI_HIP_CHECK(hipGetLastError());
         b->head = uint32_t((size_t(b->head) + count) % b->size);
         return MI_OK;
@@ -205,20 +290,40 @@ namespace
     // Delay::append(): a whole buffer or more keeps the last nSize samples from cell 0 on and restarts the write position
     // there (Delay.cpp:95-99).  The absolute position matters: process_ramping's read index wraps modulo 2^64 before
     // it is reduced modulo nSize (Delay.cpp:434), which depends on where the tail sits when the delay grows quickly.
-    int append_block(mi_delay_bank *b, const float *src, size_t stride, size_t count, hipStream_t st)
+    int append_block(mi_delay_bank *b, delay_rows &dr, const float *src, size_t stride, size_t count, hipStream_t st)
     {
         if (count < b->size)
-            return append(b, src, stride, count, st);
-        b->head = 0;
-        const int r = append(b, src + (count - b->size), stride, b->size, st);
-        b->head = 0;
+            return append(b, dr, src, stride, count, st);
+        // every line of the call restarts at cell 0
+        if (dr.host == nullptr)
+        {
+            b->head = 0;
+            if (b->off_any)
+            {
+                std::fill(b->off.begin(), b->off.end(), 0u);
+                b->off_dirty = true;
+            }
+        }
+        else
+        {
+            for (uint32_t r = 0; r < dr.n; ++r)
+                b->off[dr.host[r]] = (b->size - b->head % b->size) % b->size;
+            b->off_dirty = true;
+        }
+        int r = sync_offsets(b, st);
+        if (r != MI_OK)
+            return r;
+        dr.rm.off = b->off_any ? b->d_off : nullptr;
+        const uint32_t h = b->head;
+        r = append(b, dr, src + (count - b->size), stride, b->size, st);
+        b->head = h;                                                    // a whole lap: the position is where it was
         return r;
     }
 
     // a private copy of the caller's input when dst aliases src
-    int stage_input(mi_delay_bank *b, const float **src, size_t *stride, size_t count, hipStream_t st)
+    int stage_input(mi_delay_bank *b, uint32_t rows, const float **src, size_t *stride, size_t count, hipStream_t st)
     {
-        const size_t need = size_t(b->channels) * count;
+        const size_t need = size_t(rows) * count;
         if (need > b->scratch_floats)
         {
             (void)hipFree(b->d_scratch);
@@ -228,7 +333,7 @@ namespace
             b->scratch_floats = need;
         }
         MI_HIP_CHECK(hipMemcpy2DAsync(b->d_scratch, count * sizeof(float), *src, *stride * sizeof(float),
-                                      count * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+                                      count * sizeof(float), rows, hipMemcpyDeviceToDevice, st));
         *src = b->d_scratch;
         *stride = count;
         return MI_OK;
@@ -247,6 +352,8 @@ namespace mi
         for (uint32_t d : b->delay)
             if (d != v->delay)
                 v->delay = UINT32_MAX;
+        if (b->off_any)                                     // lines at positions of their own: no common view
+            v->delay = UINT32_MAX;
         return MI_OK;
     }
 
@@ -262,6 +369,9 @@ namespace mi
         uint64_t h = b->head;
         for (uint32_t d : b->delay)
             h = position_mix(h, d);
+        if (b->off_any)
+            for (uint32_t o : b->off)
+                h = position_mix(h, o);
         return h;
     }
 } // namespace mi
@@ -298,6 +408,7 @@ int mi_delay_bank_destroy(mi_delay_bank_t *b)
     if (b == nullptr)
         return MI_OK;
     (void)hipFree(b->d_ring); (void)hipFree(b->d_scratch); (void)hipFree(b->d_delay); (void)hipFree(b->d_delay_new);
+    (void)hipFree(b->d_off); (void)hipFree(b->d_rows);
     delete b;
     return MI_OK;
 }
@@ -322,8 +433,9 @@ int mi_delay_bank_get(const mi_delay_bank_t *b, uint32_t channel, uint32_t *dela
     MI_REQUIRE(b != nullptr && channel < b->channels, MI_EINVAL, "mi_delay_bank_get: bad argument");
     if (delay) *delay = b->delay[channel];
     if (size)  *size = b->size;
-    if (head)  *head = b->head;
-    if (tail)  *tail = (b->head + b->size - b->delay[channel]) % b->size;
+    const uint32_t h = b->off_any ? (b->head + b->off[channel]) % b->size : b->head;
+    if (head)  *head = h;
+    if (tail)  *tail = (h + b->size - b->delay[channel]) % b->size;
     return MI_OK;
 }
 
@@ -334,26 +446,35 @@ int mi_delay_bank_clear(mi_delay_bank_t *b, void *stream)
     return MI_OK;
 }
 
-int mi_delay_bank_append(mi_delay_bank_t *b, const float *in, size_t count, size_t in_stride, void *stream)
+static int delay_append_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, const float *in, size_t count,
+                             size_t in_stride, void *stream, const char *who)
 {
-    MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "mi_delay_bank_append: bad argument");
-    if (count == 0)
+    MI_REQUIRE(b != nullptr && (count == 0 || in != nullptr), MI_EINVAL, "%s: bad argument", who);
+    if (count == 0 || (rows != nullptr && n_rows == 0))
         return MI_OK;
-    const int r = mi::capture_touch(mi::as_stream(stream), b, "delay", mi::delay_bank_positions);
+    hipStream_t st = mi::as_stream(stream);
+    int r = mi::capture_touch(st, b, "delay", mi::delay_bank_positions);
     if (r != MI_OK)
         return r;
-    return append_block(b, in, in_stride, count, mi::as_stream(stream));
+    delay_rows dr;
+    r = make_rows(b, rows, n_rows, &dr, st);
+    if (r != MI_OK)
+        return r;
+    const uint32_t head_before = b->head;
+    r = append_block(b, dr, in, in_stride, count, st);
+    settle_rows(b, dr, head_before);
+    return r;
 }
 
-int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_t count, size_t out_stride,
-                          size_t in_stride, int add, int gain_mode, float gain, const float *gain_vec,
-                          size_t gain_stride, void *stream)
+static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
+                              size_t count, size_t out_stride, size_t in_stride, int add, int gain_mode, float gain,
+                              const float *gain_vec, size_t gain_stride, void *stream, const char *who)
 {
-    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_delay_bank_process: NULL bank");
-    if (count == 0)
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "%s: NULL bank", who);
+    if (count == 0 || (rows != nullptr && n_rows == 0))
         return MI_OK;
-    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_delay_bank_process: NULL buffer");
-    MI_REQUIRE(gain_mode != G_VECTOR || gain_vec != nullptr, MI_EINVAL, "mi_delay_bank_process: NULL gain vector");
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "%s: NULL buffer", who);
+    MI_REQUIRE(gain_mode != G_VECTOR || gain_vec != nullptr, MI_EINVAL, "%s: NULL gain vector", who);
     hipStream_t st = mi::as_stream(stream);
     int r = mi::capture_touch(st, b, "delay", mi::delay_bank_positions);
     if (r != MI_OK)
@@ -361,65 +482,124 @@ int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_
     r = sync_delays(b, st);
     if (r != MI_OK)
         return r;
+    delay_rows dr;
+    r = make_rows(b, rows, n_rows, &dr, st);
+    if (r != MI_OK)
+        return r;
+    const uint32_t head_before = b->head;
     // The reference alternates "push to_do samples / pull to_do samples" in pieces of at most size - delay
     // (Delay.cpp:113-142) so that a pull never reads a cell a later push of the same call already overwrote.
-    // Same order here, with the piece bounded by the largest delay of the bank.
+    // Same order here, with the piece bounded by the largest delay among the lines of the call.
     uint32_t dmin = UINT32_MAX, dmax = 0;
-    for (uint32_t d : b->delay)
+    for (uint32_t k = 0; k < dr.n; ++k)
     {
+        const uint32_t d = b->delay[dr.host ? dr.host[k] : k];
         dmin = (d < dmin) ? d : dmin;
         dmax = (d > dmax) ? d : dmax;
     }
     if (count <= dmin && count <= size_t(b->size - dmax))
     {
-        hipLaunchKernelGGL(delay_exchange_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+        hipLaunchKernelGGL(delay_exchange_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                            out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
-                           gain, gain_vec, gain_stride);
+                           gain, gain_vec, gain_stride, dr.rm);
         MI_HIP_CHECK(hipGetLastError());
         b->head = uint32_t((size_t(b->head) + count) % b->size);
+        settle_rows(b, dr, head_before);
         return MI_OK;
     }
     if (static_cast<const void *>(out) != static_cast<const void *>(in))
     {
-        hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+        hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                            out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
-                           gain, gain_vec, gain_stride);
+                           gain, gain_vec, gain_stride, dr.rm);
         MI_HIP_CHECK(hipGetLastError());
-        return append(b, in, in_stride, count, st);
+        r = append(b, dr, in, in_stride, count, st);
+        settle_rows(b, dr, head_before);
+        return r;
     }
     if (dmax == 0)
     {
         // In place without a delay the reference appends the block as a whole and then scales it (Delay.cpp:107-111,
         // 155-160, 204-209, 254-259, 303-308, 352-357): a block of at least the line's length restarts the line at cell 0
         // (:95-99), and the absolute position matters to a later process_ramping() (:434).
-        r = append_block(b, in, in_stride, count, st);
-        if (r != MI_OK)
-            return r;
-        if (add || gain_mode != G_NONE)
+        r = append_block(b, dr, in, in_stride, count, st);
+        if (r == MI_OK && (add || gain_mode != G_NONE))
         {
-            hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+            hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                                out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
-                               gain, gain_vec, gain_stride);
-            MI_HIP_CHECK(hipGetLastError());
+                               gain, gain_vec, gain_stride, dr.rm);
+            if (hipGetLastError() != hipSuccess)
+                r = mi::fail(MI_EHIP, "%s: launch failed", who);
         }
-        return MI_OK;
+        settle_rows(b, dr, head_before);
+        return r;
     }
     const size_t gap = b->size - dmax;
     size_t done = 0;
-    while (done < count)
+    while (done < count && r == MI_OK)
     {
         const size_t n = (count - done < gap) ? count - done : gap;
-        const uint32_t head_before = b->head;
-        r = append(b, in + done, in_stride, n, st);
+        const uint32_t head_piece = b->head;
+        r = append(b, dr, in + done, in_stride, n, st);
         if (r != MI_OK)
-            return r;
-        hipLaunchKernelGGL(ring_read_kernel, grid_for(n, b->channels), dim3(256), 0, st,
-                           out + done, out_stride, b->d_ring, b->size, head_before, b->d_delay, n, add, gain_mode, gain,
-                           gain_vec ? gain_vec + done : nullptr, gain_stride);
-        MI_HIP_CHECK(hipGetLastError());
+            break;
+        hipLaunchKernelGGL(ring_read_kernel, grid_for(n, dr.n), dim3(256), 0, st,
+                           out + done, out_stride, b->d_ring, b->size, head_piece, b->d_delay, n, add, gain_mode, gain,
+                           gain_vec ? gain_vec + done : nullptr, gain_stride, dr.rm);
+        if (hipGetLastError() != hipSuccess)
+            r = mi::fail(MI_EHIP, "%s: launch failed", who);
         done += n;
     }
+    settle_rows(b, dr, head_before);
+    return r;
+}
+
+static int delay_check_rows(const mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, const char *who)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "%s: NULL bank", who);
+    MI_REQUIRE(rows != nullptr || n_rows == 0, MI_EINVAL, "%s: NULL row list", who);
+    MI_REQUIRE(n_rows <= b->channels, MI_EINVAL, "%s: more rows than the bank has lines", who);
+    std::vector<uint8_t> seen(b->channels, 0);
+    for (uint32_t r = 0; r < n_rows; ++r)
+    {
+        MI_REQUIRE(rows[r] < b->channels, MI_EINVAL, "%s: line %u out of range", who, rows[r]);
+        MI_REQUIRE(!seen[rows[r]], MI_EINVAL, "%s: line %u listed twice", who, rows[r]);
+        seen[rows[r]] = 1;
+    }
     return MI_OK;
+}
+
+int mi_delay_bank_append(mi_delay_bank_t *b, const float *in, size_t count, size_t in_stride, void *stream)
+{
+    return delay_append_impl(b, nullptr, 0, in, count, in_stride, stream, "mi_delay_bank_append");
+}
+
+int mi_delay_bank_append_rows(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, const float *in, size_t count,
+                              size_t in_stride, void *stream)
+{
+    const int r = delay_check_rows(b, rows, n_rows, "mi_delay_bank_append_rows");
+    if (r != MI_OK)
+        return r;
+    return delay_append_impl(b, rows, n_rows, in, count, in_stride, stream, "mi_delay_bank_append_rows");
+}
+
+int mi_delay_bank_process(mi_delay_bank_t *b, float *out, const float *in, size_t count, size_t out_stride,
+                          size_t in_stride, int add, int gain_mode, float gain, const float *gain_vec,
+                          size_t gain_stride, void *stream)
+{
+    return delay_process_impl(b, nullptr, 0, out, in, count, out_stride, in_stride, add, gain_mode, gain, gain_vec,
+                              gain_stride, stream, "mi_delay_bank_process");
+}
+
+int mi_delay_bank_process_rows(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
+                               size_t count, size_t out_stride, size_t in_stride, int add, int gain_mode, float gain,
+                               const float *gain_vec, size_t gain_stride, void *stream)
+{
+    const int r = delay_check_rows(b, rows, n_rows, "mi_delay_bank_process_rows");
+    if (r != MI_OK)
+        return r;
+    return delay_process_impl(b, rows, n_rows, out, in, count, out_stride, in_stride, add, gain_mode, gain, gain_vec,
+                              gain_stride, stream, "mi_delay_bank_process_rows");
 }
 
 int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *in, const uint32_t *new_delays,
@@ -447,15 +627,19 @@ int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *i
     size_t stride = in_stride;
     if (static_cast<const void *>(out) == static_cast<const void *>(in))
     {
-        r = stage_input(b, &src, &stride, count, st);
+        r = stage_input(b, b->channels, &src, &stride, count, st);
         if (r != MI_OK)
             return r;
     }
+    delay_rows dr;
+    r = make_rows(b, nullptr, 0, &dr, st);
+    if (r != MI_OK)
+        return r;
     hipLaunchKernelGGL(delay_ramp_kernel, grid_for(count, b->channels), dim3(256), 0, st,
                        out, out_stride, src, stride, b->d_ring, b->size, b->head, b->d_delay, b->d_delay_new,
-                       count, gain_mode, gain, gain_vec, gain_stride);
+                       count, gain_mode, gain, gain_vec, gain_stride, dr.rm);
     MI_HIP_CHECK(hipGetLastError());
-    r = append(b, src, stride, count, st);
+    r = append(b, dr, src, stride, count, st);
     if (r != MI_OK)
         return r;
     b->delay = nd;                                                      // Delay.cpp:444-445
@@ -570,7 +754,7 @@ int mi_ring_bank_append(mi_ring_bank_t *b, const float *in, size_t count, size_t
         b->head = 0;
     }
     hipLaunchKernelGGL(ring_append_kernel, grid_for(count, b->channels), dim3(256), 0, mi::as_stream(stream),
-                       b->d_ring, b->capacity, b->head, in, in_stride, count);
+                       b->d_ring, b->capacity, b->head, in, in_stride, count, row_map{ nullptr, nullptr });
     MI_HIP_CHECK(hipGetLastError());
     // RingBuffer.cpp:85-103: the head wraps only when the block runs PAST the end; a block that ends exactly at the end
     // leaves nHead == nCapacity (head_position() reports it; every position is taken modulo the capacity afterwards)

@@ -491,6 +491,22 @@ class DelayBank:
                                         0.0 if gain is None else float(gain),
                                         _ptr(gain_vec) if gain_vec is not None else None, count, _stream(stream)))
 
+    def append_rows(self, rows, inp, count, in_stride=None, stream=None):
+        """Delay::append for the listed lines only (row r of `inp` belongs to channel rows[r])."""
+        rw = np.ascontiguousarray(rows, dtype=np.uint32)
+        check(lib.mi_delay_bank_append_rows(self.handle, rw.ctypes.data_as(c_void_p), len(rw), _ptr(inp), count,
+                                            count if in_stride is None else in_stride, _stream(stream)))
+
+    def process_rows(self, rows, out, inp, count, add=False, gain=None, gain_vec=None, out_stride=None, in_stride=None, stream=None):
+        """Delay::process for the listed lines only: they alone are written and move on."""
+        rw = np.ascontiguousarray(rows, dtype=np.uint32)
+        mode = 2 if gain_vec is not None else (1 if gain is not None else 0)
+        check(lib.mi_delay_bank_process_rows(self.handle, rw.ctypes.data_as(c_void_p), len(rw), _ptr(out), _ptr(inp), count,
+                                             count if out_stride is None else out_stride,
+                                             count if in_stride is None else in_stride, int(add), mode,
+                                             0.0 if gain is None else float(gain),
+                                             _ptr(gain_vec) if gain_vec is not None else None, count, _stream(stream)))
+
     def process_ramping(self, out, inp, new_delays, count, gain=None, gain_vec=None, stream=None):
         nd = np.ascontiguousarray(new_delays, dtype=np.uint32)
         assert nd.shape == (self.channels,)

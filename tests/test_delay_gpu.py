@@ -226,6 +226,92 @@ def test_delay_random_operation_sequences_bit_exact(gpu, seed):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_delay_lines_with_positions_of_their_own(gpu, seed):
+    """Delay objects with DIFFERENT call histories in one bank (util/Delay.h:35: every object has its nHead): calls on random
+    subsets of the lines (mi_delay_bank_process_rows / append_rows, rows in random order) mixed with calls on the whole
+    bank, every process form, lengths around the wrap points, whole-line appends that restart a line at cell 0 -- outputs
+    and the absolute positions of every line bit for bit against one oracle object per line."""
+    rng = np.random.default_rng(9100 + seed)
+    C, maxd = 6, int(rng.choice([100, 511, 513, 1000]))
+    bank = gpu.DelayBank(C, maxd)
+    refs = [od.Delay(maxd) for _ in range(C)]
+    size = refs[0].size
+    log = []
+    for c in range(C):
+        d = int(rng.integers(0, maxd + 1))
+        bank.set_delay(d, c); refs[c].set_delay(d)
+    for step in range(70):
+        op = str(rng.choice(["plain", "scalar", "vector", "add", "add_vector", "append", "set", "ramp"]))
+        whole = bool(rng.integers(0, 3) == 0)
+        rows = list(range(C)) if whole else [int(v) for v in rng.permutation(C)[:int(rng.integers(1, C + 1))]]
+        n = int(rng.choice([1, 2, 63, size - 1, size, size + 1, 2 * size + 5, int(rng.integers(1, 3 * size))]))
+        R = len(rows)
+        if op == "set":
+            c = int(rng.integers(0, C)); d = int(rng.integers(0, maxd + 1))
+            bank.set_delay(d, c); refs[c].set_delay(d)
+        elif op == "ramp":                                    # whole bank only
+            x = rng.standard_normal((C, n)).astype(np.float32)
+            targets = [int(rng.integers(0, maxd + 1)) for _ in range(C)]
+            din = gpu.DeviceBuffer.from_host(x); dout = gpu.DeviceBuffer((C, n))
+            bank.process_ramping(dout, din, targets, n)
+            ref = [r.process_ramping(x[c], targets[c]) for c, r in enumerate(refs)]
+            np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=str((seed, step, op, n, log[-6:])))
+        elif op == "append":
+            x = rng.standard_normal((R, n)).astype(np.float32)
+            if whole:
+                bank.append(gpu.DeviceBuffer.from_host(x), n)
+            else:
+                bank.append_rows(rows, gpu.DeviceBuffer.from_host(x), n)
+            for k, c in enumerate(rows):
+                refs[c].append(x[k])
+        else:
+            x = rng.standard_normal((R, n)).astype(np.float32)
+            g = rng.uniform(0.5, 2.0, (R, n)).astype(np.float32)
+            base = rng.standard_normal((R, n)).astype(np.float32)
+            in_place = bool(rng.integers(0, 2))
+            delays = [refs[c].delay for c in rows]
+            if in_place and n >= size and min(delays) == 0 and max(delays) > 0:
+                in_place = False                              # (lines with and without a delay restart differently: two calls)
+            if op.startswith("add") and in_place:
+                base = x
+            ip = in_place and max(delays) == 0
+            din = gpu.DeviceBuffer.from_host(x)
+            dout = din if in_place else gpu.DeviceBuffer.from_host(base)
+            dg = gpu.DeviceBuffer.from_host(g)
+            kw = {"plain": {}, "scalar": {"gain": 0.37}, "vector": {"gain_vec": dg}, "add": {"add": True},
+                  "add_vector": {"add": True, "gain_vec": dg}}[op]
+            if whole:
+                bank.process(dout, din, n, **kw)
+            else:
+                bank.process_rows(rows, dout, din, n, **kw)
+            ref = []
+            for k, c in enumerate(rows):
+                rk = {}
+                if op == "scalar": rk["gain"] = 0.37
+                if op in ("vector", "add_vector"): rk["gain"] = g[k]
+                if op.startswith("add"): rk["add_to"] = base[k]
+                ref.append(refs[c].process(x[k], in_place=ip, **rk))
+            np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=str((seed, step, op, rows, n, log[-6:])))
+        for c, r in enumerate(refs):
+            st = bank.get(c)
+            assert (st["delay"], st["head"], st["tail"], st["size"]) == (r.delay, r.head, r.tail, r.size), (seed, step, c, op, rows, log[-6:])
+        log.append((op, "all" if whole else tuple(rows), n))
+    bank.close()
+
+
+def test_delay_rows_argument_errors(gpu):
+    bank = gpu.DelayBank(4, 100)
+    buf = gpu.DeviceBuffer((4, 16))
+    for rows in ([0, 0], [4], [0, 1, 2, 3, 1]):
+        with pytest.raises(gpu.MiError):
+            bank.process_rows(rows, buf, buf, 16)
+        with pytest.raises(gpu.MiError):
+            bank.append_rows(rows, buf, 16)
+    bank.process_rows([], buf, buf, 16)                       # nothing to do
+    bank.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_ring_random_operation_sequences_bit_exact(gpu, seed):
     """RingBuffer: append (also more than a whole buffer: the reference restarts at cell 0), block get with every kind of
