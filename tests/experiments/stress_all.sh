@@ -4,7 +4,7 @@
 A=${1:-1000}; B=${2:-1200}
 for T in "test_biquad_gpu test_random_operation_sequences" "test_convolver_gpu test_random_geometry_and_call_sizes" \
          "test_crossover_gpu test_random_retune_scripts" "test_delay_gpu test_delay_random_operation_sequences_bit_exact" \
-         "test_delay_gpu test_ring_random_operation_sequences_bit_exact" "test_equalizer_gpu test_random_operation_sequences_match_oracle" \
+         "test_delay_gpu test_ring_random_operation_sequences_bit_exact" "test_delay_gpu test_delay_lines_with_positions_of_their_own" "test_equalizer_gpu test_random_operation_sequences_match_oracle" \
          "test_ilufs_gpu test_random_operation_sequences" "test_loudness_gpu test_random_operation_sequences" \
          "test_spectral_gpu test_spectral_random_operation_sequences" "test_spectral_gpu test_analyzer_random_settings" \
          "test_splitter_gpu test_random_operation_sequences_match_oracle" "test_dynfilter_gpu test_random_operation_sequences"; do
