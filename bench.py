@@ -331,7 +331,8 @@ def _convolver_call_stream(args, mi, torch, dist, rank, world, dev, C, call, ste
             mi.check(fn(h, po, pi, call, frame, frame, st))
     steps = max(period, steps - steps % period)
     torch.cuda.synchronize()
-    elapsed, _, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, period, profile=False, stream=stream, graph=True)
+    elapsed, _, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, period, profile=False, stream=stream,
+                                     graph=(args.launch != "eager"))
     stream.synchronize()
     assert bool(torch.isfinite(yout).all()) and float(yout.abs().max()) > 0.0
     assert bank.faults(stream=stream) == 0
