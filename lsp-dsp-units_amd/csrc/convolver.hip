@@ -549,17 +549,29 @@ namespace
     //   otherwise: the block has been received piecewise (frame holds it, its partition-0 term went through the direct
     //              kernel): image -> ring
     // then acc[off + SB, off + 3 SB) += IFFT(sum_{p = 1 .. k+1} Hs_p Xs_(k+1-p)), as far as that lies inside the frame.
+    // FULL runs as TWO waves per channel (round 3): both transform the block (each into its own half of the LDS -- the
+    // forward transform is on either wave's path anyway), then wave 0 takes the output (Hs_0 x, inverse, out) and wave 1
+    // the debt (the sum over the small partitions, inverse, acc); wave 0 hands the upper half of its inverse, which the
+    // debt's store adds, over through LDS.  One wave did the three transforms one after the other: 8.2 us per call, most
+    // of it a lone wave's instruction latency.  Same arithmetic in the same order: the same floats.
     template <bool FULL>
-    __global__ __launch_bounds__(fplan<LOGS>::T)
+    __global__ __launch_bounds__(fplan<LOGS>::T * (FULL ? 2 : 1))
     void conv_small_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, float *frame, int B,
                            int off, float2 *sring, int Ps, const float2 *__restrict__ Hs,
                            float *acc, const float2 *__restrict__ tw)
     {
         constexpr int M = fplan<LOGS>::N, T = fplan<LOGS>::T, KPT = M / T;
         static_assert(KPT * T == M && (KPT % 2) == 0, "small blocks: whole pairs per thread");
-        __shared__ float2 lds_[fplan<LOGS>::LDS];
-        float2 *const buf = lds_, *const scr = lds_ + fplan<LOGS>::SCR;
-        const int ch = blockIdx.x, tid = threadIdx.x, kblk = off / SB;
+        static_assert(T == 64, "one wave per role");
+        __shared__ float2 lds_[FULL ? 2 : 1][fplan<LOGS>::LDS];
+        __shared__ float2 yx[FULL ? M / 2 : 1];                             // (Hs_0 x)[SB, 2 SB), from the output wave to the debt wave
+        const int role = FULL ? int(threadIdx.x >> 6) : 0;
+        const bool outs = FULL && role == 0, debt = !FULL || role == 1;
+        float2 *const buf = lds_[role], *const scr = lds_[role] + fplan<LOGS>::SCR;
+        const int ch = blockIdx.x, tid = threadIdx.x & (T - 1), kblk = off / SB;
+        const bool next1 = (off + SB < B), next2 = (off + 2 * SB < B);     // the two blocks after this one, if the frame has them
+        if (FULL && role == 1 && !next1)
+            return;                                                         // the frame's last block owes nothing inside the frame
         typename fplan<LOGS>::real rf;
         rf.load(tw, TWN, tid);
         rf.prepare();
@@ -567,13 +579,12 @@ namespace
         float *a  = acc + size_t(ch) * 2 * B + off;
         const float2 *hs = Hs + size_t(ch) * Ps * M;
         float2 *rg = sring + size_t(ch) * Ps * M;
-        const bool next1 = (off + SB < B), next2 = (off + 2 * SB < B);     // the two blocks after this one, if the frame has them
         float2 xk[KPT];
         // Everything the ring's debt needs that does not depend on this block is asked for NOW: the small partitions' images
-        // and the images of the frame's earlier blocks (one wave per channel, 512 registers to itself: up to 2 x 15 x 4
+        // and the images of the frame's earlier blocks (a wave has 512 registers to itself: up to 2 x 15 x 4
         // values in flight under the transforms instead of fifteen dependent round trips to L2 behind them).
         constexpr int PMAX = 15;                                            // B / SB - 1 at the largest frame
-        const int pmax = !next1 ? 0 : (kblk + 1 < Ps - 1) ? kblk + 1 : Ps - 1;
+        const int pmax = (!next1 || !debt) ? 0 : (kblk + 1 < Ps - 1) ? kblk + 1 : Ps - 1;
         float2 hreg[PMAX][KPT], xreg[PMAX][KPT];
         #pragma unroll
         for (int p = 1; p <= PMAX; ++p)
@@ -599,7 +610,8 @@ namespace
                 {
                     const float *x = in + size_t(ch) * in_stride;
                     v = make_float2(x[2 * n], x[2 * n + 1]);
-                    *reinterpret_cast<float2 *>(fr + 2 * n) = v;            // the frame keeps its samples for the commit
+                    if (outs)
+                        *reinterpret_cast<float2 *>(fr + 2 * n) = v;        // the frame keeps its samples for the commit
                 }
                 else
                     v = *reinterpret_cast<const float2 *>(fr + 2 * n);
@@ -612,25 +624,58 @@ namespace
         for (int i = 0; i < KPT; ++i)
         {
             xk[i] = buf[tid + i * T];
-            if (next2)                                                      // (nobody reads the last two blocks' images)
+            if (next2 && (outs || !FULL))                                   // (nobody reads the last two blocks' images)
                 rg[size_t(kblk) * M + tid + i * T] = xk[i];
         }
         const float scale = 1.0f / float(2 * M);
-        float2 yhi[KPT / 2];                                                // (Hs_0 x)[SB, 2 SB): owed to the next block
-        #pragma unroll
-        for (int i = 0; i < KPT / 2; ++i)
-            yhi[i] = make_float2(0.0f, 0.0f);
-        if (FULL)
+        if (!FULL && !next1)
+            return;                                                         // the frame's last block: the commit settles the rest
+        // what goes through the inverse transform: the output wave's Hs_0 x, or what the frame's blocks owe block k + 1
+        // (p = 1 is this block's own image)
+        float2 t[KPT];
+        float dc = 0.0f, ny = 0.0f;
+        if (outs)
         {
-            __syncthreads();
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
-            {
-                const int k = tid + i * T;
-                buf[k] = image_mul(xk[i], hs[k], k);
-            }
-            __syncthreads();
-            rf.inverse(buf, scr, tid);
+                t[i] = image_mul(xk[i], hs[tid + i * T], tid + i * T);
+        }
+        else
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                t[i] = make_float2(0.0f, 0.0f);
+            #pragma unroll
+            for (int p = 1; p <= PMAX; ++p)
+                if (p <= pmax)
+                {
+                    #pragma unroll
+                    for (int i = 0; i < KPT; ++i)
+                    {
+                        const int k = tid + i * T;
+                        const float2 h = hreg[p - 1][i];
+                        const float2 x = (p == 1) ? xk[i] : xreg[p - 1][i];
+                        t[i].x = fmaf(x.x, h.x, fmaf(-x.y, h.y, t[i].x));
+                        t[i].y = fmaf(x.x, h.y, fmaf(x.y, h.x, t[i].y));
+                        if (k == 0)
+                        {
+                            dc = fmaf(x.x, h.x, dc);
+                            ny = fmaf(x.y, h.y, ny);
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int k = tid + i * T;
+            buf[k] = (!outs && k == 0) ? make_float2(dc, ny) : t[i];
+        }
+        __syncthreads();
+        rf.inverse(buf, scr, tid);
+        if (outs)
+        {
             float *o = out + size_t(ch) * out_stride;
             #pragma unroll
             for (int i = 0; i < KPT / 2; ++i)
@@ -639,53 +684,22 @@ namespace
                 const float2 y0 = buf[n], p0 = *reinterpret_cast<const float2 *>(a + 2 * n);
                 o[2 * n]     = fmaf(y0.x, scale, p0.x);
                 o[2 * n + 1] = fmaf(y0.y, scale, p0.y);
-                yhi[i] = buf[n + M / 2];
+                yx[n] = buf[n + M / 2];
             }
         }
-        if (!next1)
-            return;                                                         // the frame's last block: the commit settles the rest
-        // what the frame's blocks owe block k + 1: p = 1 is this block's own image
-        float2 t[KPT];
-        float dc = 0.0f, ny = 0.0f;
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            t[i] = make_float2(0.0f, 0.0f);
-        #pragma unroll
-        for (int p = 1; p <= PMAX; ++p)
-            if (p <= pmax)
-            {
-                #pragma unroll
-                for (int i = 0; i < KPT; ++i)
-                {
-                    const int k = tid + i * T;
-                    const float2 h = hreg[p - 1][i];
-                    const float2 x = (p == 1) ? xk[i] : xreg[p - 1][i];
-                    t[i].x = fmaf(x.x, h.x, fmaf(-x.y, h.y, t[i].x));
-                    t[i].y = fmaf(x.x, h.y, fmaf(x.y, h.x, t[i].y));
-                    if (k == 0)
-                    {
-                        dc = fmaf(x.x, h.x, dc);
-                        ny = fmaf(x.y, h.y, ny);
-                    }
-                }
-            }
-        __syncthreads();
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-        {
-            const int k = tid + i * T;
-            buf[k] = (k == 0) ? make_float2(dc, ny) : t[i];
-        }
-        __syncthreads();
-        rf.inverse(buf, scr, tid);
+        if (FULL)
+            __syncthreads();                                                // yx is there (a lone output wave passes at once)
+        if (!debt)
+            return;
         #pragma unroll
         for (int i = 0; i < KPT / 2; ++i)
         {
             const int n = tid + i * T;
             const float2 t0 = buf[n], t1 = buf[n + M / 2];
+            const float2 yhi = FULL ? yx[n] : make_float2(0.0f, 0.0f);
             float2 *a1 = reinterpret_cast<float2 *>(a + SB + 2 * n), *a2 = reinterpret_cast<float2 *>(a + 2 * SB + 2 * n);
             const float2 v1 = *a1;
-            *a1 = make_float2(fmaf(t0.x + yhi[i].x, scale, v1.x), fmaf(t0.y + yhi[i].y, scale, v1.y));
+            *a1 = make_float2(fmaf(t0.x + yhi.x, scale, v1.x), fmaf(t0.y + yhi.y, scale, v1.y));
             if (next2)
             {
                 const float2 v2 = *a2;
@@ -1586,7 +1600,7 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 if ((b->off % SB) == 0 && left >= size_t(SB))
                 {
                     cnt = SB;                                               // an aligned whole block: one launch
-                    hipLaunchKernelGGL((conv_small_kernel<true>), dim3(b->channels), dim3(fplan<LOGS>::T), 0, st,
+                    hipLaunchKernelGGL((conv_small_kernel<true>), dim3(b->channels), dim3(2 * fplan<LOGS>::T), 0, st,
                                        o, x, out_stride, in_stride, b->d_frame, B, b->off, b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
                     MI_HIP_CHECK(hipGetLastError());
                     b->off += cnt;
