@@ -598,6 +598,22 @@ namespace
                         xreg[p - 1][i] = rg[size_t(kblk + 1 - p) * M + tid + i * T];
                 }
             }
+        // ... and so is what the results are added to (acc: written by earlier launches of the stream only)
+        float2 accv[KPT / 2], accw[KPT / 2];
+        #pragma unroll
+        for (int i = 0; i < KPT / 2; ++i)
+        {
+            const int n = tid + i * T;
+            accv[i] = accw[i] = make_float2(0.0f, 0.0f);
+            if (outs)
+                accv[i] = *reinterpret_cast<const float2 *>(a + 2 * n);
+            else if (next1)
+            {
+                accv[i] = *reinterpret_cast<const float2 *>(a + SB + 2 * n);
+                if (next2)
+                    accw[i] = *reinterpret_cast<const float2 *>(a + 2 * SB + 2 * n);
+            }
+        }
         // SB real samples = SB / 2 pairs, zero-padded to 2 SB
         #pragma unroll
         for (int i = 0; i < KPT; ++i)
@@ -681,7 +697,7 @@ namespace
             for (int i = 0; i < KPT / 2; ++i)
             {
                 const int n = tid + i * T;                                  // pair n of the first half, pair n + M/2 of the second
-                const float2 y0 = buf[n], p0 = *reinterpret_cast<const float2 *>(a + 2 * n);
+                const float2 y0 = buf[n], p0 = accv[i];
                 o[2 * n]     = fmaf(y0.x, scale, p0.x);
                 o[2 * n + 1] = fmaf(y0.y, scale, p0.y);
                 yx[n] = buf[n + M / 2];
@@ -698,11 +714,11 @@ namespace
             const float2 t0 = buf[n], t1 = buf[n + M / 2];
             const float2 yhi = FULL ? yx[n] : make_float2(0.0f, 0.0f);
             float2 *a1 = reinterpret_cast<float2 *>(a + SB + 2 * n), *a2 = reinterpret_cast<float2 *>(a + 2 * SB + 2 * n);
-            const float2 v1 = *a1;
+            const float2 v1 = accv[i];
             *a1 = make_float2(fmaf(t0.x + yhi.x, scale, v1.x), fmaf(t0.y + yhi.y, scale, v1.y));
             if (next2)
             {
-                const float2 v2 = *a2;
+                const float2 v2 = accw[i];
                 *a2 = make_float2(fmaf(t1.x, scale, v2.x), fmaf(t1.y, scale, v2.y));
             }
         }
