@@ -452,13 +452,18 @@ namespace
 
     // the bilinear section of a filter whose base type is known when the kernel is compiled: the builders' switch folds
     // to the one family, whose gain-independent terms then leave the per-sample code
+    // (BASE: the base type, + MATCHED_BIT for its matched-Z twin)
+    constexpr uint32_t MATCHED_BIT = 0x100;
     template <uint32_t BASE>
     __device__ __forceinline__ section5 dyn_section_of(const dyn_filter &f, uint32_t J, float g)
     {
         dyn_params p = f.p;
-        p.base = BASE;
+        p.base = BASE & (MATCHED_BIT - 1);
         const cascade c = dyn_cascade(p, J, g);
-        return bilinear(c.t, c.b, f.kf);
+        if constexpr ((BASE & MATCHED_BIT) != 0)
+            return matched(c.t, c.b, f.f0, f.kf);
+        else
+            return bilinear(c.t, c.b, f.kf);
     }
 
     // ---- kernel -----------------------------------------------------------------------------------------------
@@ -513,7 +518,7 @@ namespace
 
     //
     // BASE = 0: any filter (the type is a kernel argument; the sections of a lane's samples are built in ONE rolled
-    // loop and parked in LDS).  BASE != 0: a bilinear filter of that base type -- one kernel per type, the sections of
+    // loop and parked in LDS).  BASE != 0: a filter of that base type (+ MATCHED_BIT: its matched-Z twin) -- one kernel per type, the sections of
     // the lane's eight samples are built side by side and stay in registers; without the 48 KiB of parked sections all
     // 1024 workgroups of the bench shape are resident at once (four waves per SIMD) instead of 768 and then 256.
     template <int NW, uint32_t BASE>
@@ -541,7 +546,7 @@ namespace
         for (uint32_t J = tid; J < f.nc; J += 64 * NW)
             mem[J] = gmem[J];
         __syncthreads();
-        const bool uniform = uniform_cascades(SPEC ? BASE : f.p.base);
+        const bool uniform = uniform_cascades(SPEC ? (BASE & (MATCHED_BIT - 1)) : f.p.base);
 
         for (uint32_t pos = 0; pos < samples; pos += SUPER)
         {
@@ -593,7 +598,7 @@ namespace
                             for (int k = 0; k < LCK; ++k)
                             {
                                 q[k] = dyn_section_of<BASE>(f, J, g[k]);
-                                if ((k + 1) % MI_DYN_BUILDERS_IN_FLIGHT == 0)       // so many builders interleaved by the scheduler
+                                if ((k + 1) % (((BASE & MATCHED_BIT) != 0) ? 1 : MI_DYN_BUILDERS_IN_FLIGHT) == 0)       // so many builders interleaved (matched-Z: one, its double-precision part is register-hungry)
                                     __builtin_amdgcn_sched_barrier(0);
                             }
                         }
@@ -918,12 +923,15 @@ int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, c
                                                        gain, out_stride, in_stride, gain_stride, uint32_t(samples), f, state, aligned)
     static const bool generic = getenv("MI_DYNFILTER_GENERIC") != nullptr;     // test knob: the any-type kernel for every call
     bool issued = false;
-    if (samples > size_t(MI_DYN_SPEC_FROM) && f.bilinear && !generic)      // long calls of bilinear filters: the kernel of the base type
+    // long calls: the kernel of the filter's type.  (Matched-Z bell and resonance are the two of the 54 that the any-type
+    // kernel serves faster: 92 against 100 us per 1024 x 4096 call, profiles/r03_experiments/dynfilter_per_type.txt)
+    const bool slower = !f.bilinear && (f.p.base == MI_FLT_BT_RLC_BELL || f.p.base == MI_FLT_BT_RLC_RESONANCE);
+    if (samples > size_t(MI_DYN_SPEC_FROM) && !generic && !slower)
     {
         issued = true;
         switch (f.p.base)
         {
-            #define MI_DYN_CASE(B) case B: MI_DYN_LAUNCH(4, B); break;
+            #define MI_DYN_CASE(B) case B: if (f.bilinear) MI_DYN_LAUNCH(4, B); else MI_DYN_LAUNCH(4, (B | MATCHED_BIT)); break;
             MI_DYN_CASE(MI_FLT_BT_AMPLIFIER)
             MI_DYN_CASE(MI_FLT_BT_RLC_LOPASS)     MI_DYN_CASE(MI_FLT_BT_RLC_HIPASS)
             MI_DYN_CASE(MI_FLT_BT_RLC_LOSHELF)    MI_DYN_CASE(MI_FLT_BT_RLC_HISHELF)
