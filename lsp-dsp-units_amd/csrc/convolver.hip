@@ -232,9 +232,9 @@ namespace
         MI_CPROBE(4);
 
         const float scale = 1.0f / float(2 * M);
-        float *o = out + size_t(ch) * out_stride;
+        float *o = (out != nullptr) ? out + size_t(ch) * out_stride : nullptr;
         const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(a, unsigned(2 * B * sizeof(float)));
-        const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, unsigned(B * sizeof(float)));
+        const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, (out != nullptr) ? unsigned(B * sizeof(float)) : 0u);
         #pragma unroll
         for (int i = 0; i < NPT; ++i)
         {
@@ -244,7 +244,9 @@ namespace
             const float2 p0 = LEAN ? *reinterpret_cast<const float2 *>(a + 2 * n) : a0[i];
             const float2 p1 = !LEAN ? a1[i] : upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * n);
             const float2 r = make_float2(fmaf(y0.x, scale, p0.x), fmaf(y0.y, scale, p0.y));
-            if (aligned)
+            if (out == nullptr)
+                ;                                           // a frame received in blocks: its own half has gone out block by block
+            else if (aligned)
                 mi::wt_store(rout, 8 * n, r);
             else
             {
@@ -1661,7 +1663,21 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             b->off += cnt;
             done += size_t(cnt);
             }
-            if (b->off == B)
+            static const bool two_role_completion = getenv("MI_CONV_COMMIT_LAUNCHES") == nullptr;    // (knob: commit + tail as before)
+            if (b->off == B && b->small && b->P >= 2 && b->one_launch && !b->yt_pending && two_role_completion)
+            {
+                // A frame received in blocks completes like a whole frame minus its output (which went out block by
+                // block): the frame role of the one-launch step transforms d_frame, hands the image to the tail role and
+                // leaves IFFT(H_0 X)[B, 2B) + acc[B, 2B) as the new accumulator -- commit and tail side by side in one
+                // launch instead of one after the other (14.7 + 38.6 us as two launches at C3).
+                const int r = launch_frame(b, nullptr, b->d_frame, 0, size_t(B), true, st);
+                if (r != MI_OK)
+                    return r;
+                b->off = 0;
+                b->xfade_active = false;
+                b->frame_open = false;
+            }
+            else if (b->off == B)
             {
                 if (b->R > 0)
                     b->slot = (b->slot + 1) % b->R;
