@@ -115,7 +115,7 @@ namespace
                     const float2 *__restrict__ tw,
                     float *dl_ring /* or NULL */, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head,
                     bool upper_zero /* acc[B:2B] is known to hold zeros: neither read nor re-zeroed */,
-                    uint32_t *done)
+                    uint32_t *done, bool twice = false /* bump `done` once more when acc is written (the tail role folds into it) */)
     {
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M;
@@ -258,6 +258,15 @@ namespace
                 mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
         }
         MI_CPROBE(5);
+        if (done != nullptr && twice)
+        {
+            // the accumulator is in memory (write-through stores, drained by every wave before the barrier, as above): the
+            // tail role of this channel may add its inverse transform to it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0)
+                __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 
     template <int LOGM>
@@ -304,7 +313,8 @@ namespace
                           float2 *ring, int R, int slot, const float2 *__restrict__ H, int P,
                           float *acc, float2 *Yt, bool yt_pending, const float2 *__restrict__ tw, bool upper_zero,
                           int channels /* of this launch */, int first /* its first channel */,
-                          uint32_t *done, uint32_t *seen, uint32_t *fault, uint32_t *fault_host)
+                          uint32_t *done, uint32_t *seen, uint32_t *fault, uint32_t *fault_host,
+                          bool fold /* the tail goes straight into acc (time domain) instead of into Yt: a frame received in blocks */)
     {
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, M4 = M / 2, J = (M4 + T - 1) / T;
@@ -318,7 +328,7 @@ namespace
             if (int(blockIdx.x) >= channels)
                 return;
             frame_role<LOGM, true>(buf, scr, first + int(blockIdx.x), out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc,
-                                   yt_pending ? Yt : nullptr, tw, nullptr, 0u, 0u, 0u, upper_zero, done);
+                                   yt_pending ? Yt : nullptr, tw, nullptr, 0u, 0u, 0u, upper_zero, done, fold);
             return;
         }
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -369,7 +379,7 @@ namespace
         for (int j = 0; j < J; ++j)
             if (tid + j * T < M4)
                 h1[j] = NT ? __builtin_nontemporal_load(&Hc[size_t(1) * M4 + tid + j * T]) : Hc[size_t(1) * M4 + tid + j * T];
-        if (tid == 0)
+        auto await = [&]()                                     // thread 0: the frame workgroup's next bump of `done`
         {
             const uint32_t target = seen[ch] + 1u;
             uint32_t spins = 0;
@@ -385,7 +395,9 @@ namespace
                 }
             }
             seen[ch] = target;
-        }
+        };
+        if (tid == 0)
+            await();
         __syncthreads();
         // this frame's image: device-scope loads (past the L2 of this XCD, which never held these lines in this launch anyway)
         #pragma unroll
@@ -407,6 +419,35 @@ namespace
         {
             s[0].x = dc;
             s[0].y = ny;
+        }
+        if (fold)
+        {
+            // acc += IFFT(Yt) right here (conv_tail_kernel's work, one launch and 16 MB of Yt less): the tail's image goes
+            // through this workgroup's LDS, and the accumulator -- written by the frame workgroup of the channel, on
+            // another CU, in this same launch -- is read past the L1 once that workgroup has said it is there
+            typename fplan<LOGM>::real rf;
+            rf.load(tw, TWN, tid);
+            f4 *image = reinterpret_cast<f4 *>(buf);
+            #pragma unroll
+            for (int j = 0; j < J; ++j)
+                if (tid + j * T < M4)
+                    image[tid + j * T] = s[j];
+            rf.prepare();
+            __syncthreads();
+            rf.inverse(buf, scr, tid);
+            if (tid == 0)
+                await();
+            __syncthreads();
+            const float scale = 1.0f / float(2 * M);
+            const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(acc + size_t(ch) * 2 * M, unsigned(2 * M * sizeof(float)));
+            for (int n = tid; n < M; n += T)
+            {
+                typedef unsigned u2 __attribute__((ext_vector_type(2)));
+                const u2 raw = __builtin_amdgcn_raw_buffer_load_b64(racc, n * int(sizeof(float2)), 0, mi::CPOL_SC1);
+                const float2 y = buf[n], v = make_float2(__uint_as_float(raw.x), __uint_as_float(raw.y));
+                mi::wt_store(racc, n * int(sizeof(float2)), make_float2(fmaf(y.x, scale, v.x), fmaf(y.y, scale, v.y)));
+            }
+            return;
         }
         f4 *dst = reinterpret_cast<f4 *>(Yt + size_t(ch) * M);
         #pragma unroll
@@ -1034,7 +1075,8 @@ namespace
     }
 
     // A whole frame from the caller's block: frame and tail roles in one launch when there is a tail (P >= 2)
-    int launch_frame(mi_convolver_bank *b, float *o, const float *x, size_t out_stride, size_t in_stride, bool aligned, hipStream_t st)
+    int launch_frame(mi_convolver_bank *b, float *o, const float *x, size_t out_stride, size_t in_stride, bool aligned, hipStream_t st,
+                     bool fold = false)
     {
         if (b->R > 0)
             b->slot = (b->slot + 1) % b->R;
@@ -1057,16 +1099,16 @@ namespace
                 #define MI_CALL(LM) \
                     if (nt) MI_LAUNCH((conv_step_kernel<LM, true>), dim3(((cnt + 7) & ~7) + cnt), dim3(fplan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
-                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host); \
+                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host, fold); \
                     else    MI_LAUNCH((conv_step_kernel<LM, false>), dim3(((cnt + 7) & ~7) + cnt), dim3(fplan<LM>::T), 0, st, e0, e1, \
                                       o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_H, b->P, b->d_acc, b->d_yt, \
-                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host)
+                                      b->yt_pending, b->d_tw, b->upper_zero, cnt, first, done, seen, fault, b->d_fault_host, fold)
                 MI_LOGM_SWITCH(b->logm, MI_CALL)
                 #undef MI_CALL
                 MI_HIP_CHECK(hipGetLastError());
             }
-            b->yt_pending = true;
-            b->upper_zero = true;
+            b->yt_pending = !fold;
+            b->upper_zero = !fold;                                      // (folded: the tail's inverse fills both halves of acc)
             return MI_OK;
         }
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
@@ -1670,7 +1712,8 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 // block): the frame role of the one-launch step transforms d_frame, hands the image to the tail role and
                 // leaves IFFT(H_0 X)[B, 2B) + acc[B, 2B) as the new accumulator -- commit and tail side by side in one
                 // launch instead of one after the other (14.7 + 38.6 us as two launches at C3).
-                const int r = launch_frame(b, nullptr, b->d_frame, 0, size_t(B), true, st);
+                static const bool fold_in_launch = getenv("MI_CONV_FOLD_LAUNCH") == nullptr;          // (knob: the fold as its own launch)
+                const int r = launch_frame(b, nullptr, b->d_frame, 0, size_t(B), true, st, fold_in_launch);
                 if (r != MI_OK)
                     return r;
                 b->off = 0;

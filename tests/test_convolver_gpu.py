@@ -260,8 +260,12 @@ def test_subframe_calls_on_large_frames(gpu, seed):
         y = dout.download()
         for c in range(C):
             hist[c] = np.concatenate([hist[c], x[c]])[-(taps + 4 * frame + k):]
-            ref = exact_conv(hist[c], irs[c, :counts[c]])[-k:]
-            peak = max(float(np.abs(ref).max()), 1.0)
+            full = exact_conv(hist[c], irs[c, :counts[c]])
+            ref = full[-k:]
+            # the peak of the channel's recent output, not of this call alone: a call of one or two samples can land on a
+            # zero crossing of a signal whose float32 partition sums carry the rounding of its LEVEL (seeds 33045, 33204 of
+            # tests/experiments/stress_sweep.py: 2.0e-5 and 3.1e-5 of a single sample's own magnitude, with every path)
+            peak = max(float(np.abs(full[-max(k, 1024):]).max()), 1.0)
             err = float(np.abs(y[c] - ref).max())
             record_parity("convolver sub-frame calls: |gpu - exact| <= 2e-5 peak", err, 2 * TOL * peak)
             assert err <= 2 * TOL * peak, (seed, step, c, k, rank, taps, int(counts[c]), err / peak)

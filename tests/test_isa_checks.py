@@ -50,25 +50,26 @@ def test_conv_step_frame_role_drains_image_stores_before_the_counter(tmp_path):
         text = [l.strip() for l in body if l.strip() and not l.strip().startswith(";") or l.strip().startswith(";;#ASM")]
         # the hand-written wait (inline asm is bracketed by ;;#ASMSTART / ;;#ASMEND)
         waits = [i for i, l in enumerate(text) if l == ";;#ASMSTART" and text[i + 1].replace(" ", "") == "s_waitcntvmcnt(0)"]
-        assert len(waits) == 1, (name, len(waits))
-        w = waits[0]
-        # behind it: the workgroup barrier, reached without another store to memory, and then the counter's atomic add
-        labels = {l[:-1]: i for i, l in enumerate(text) if l.endswith(":")}
-        path, i = [], w
-        # (a one-wave workgroup, plan<7>, has no s_barrier at all: the wave's own wait orders its stores before its add)
-        while not text[i].startswith("s_barrier") and not text[i].startswith("global_atomic_add"):
-            path.append(text[i])                            # straight-line walk; an unconditional branch is followed
-            i = labels[text[i].split()[1]] if text[i].startswith("s_branch") else i + 1
-            assert i < len(text) and len(path) < 200, (name, path[-10:])
-        nxt = i
-        assert not [l for l in path if re.match(r"(buffer|global|flat)_store", l)], (name, path)
-        after = text[nxt:nxt + 40]
-        assert any(l.startswith("global_atomic_add") for l in after), (name, after)
-        assert not any(l.startswith("s_barrier") for l in after[1:next(i for i, l in enumerate(after) if l.startswith("global_atomic_add"))]), name
-        # in front of it: the write-through stores of the image, with no barrier between the last of them and the wait
-        prev = max([i for i in range(w) if text[i].startswith("s_barrier")] or [0])
-        stores = [l for l in text[prev:w] if l.startswith("buffer_store") and " sc1" in l]
-        assert stores, (name, "no sc1 image store between the previous barrier and the wait")
+        # two hand-overs: the image (always), and the accumulator when the tail role folds into it (a frame received in blocks)
+        assert len(waits) == 2, (name, len(waits))
+        for w in waits:
+            # behind it: the workgroup barrier, reached without another store to memory, and then the counter's atomic add
+            labels = {l[:-1]: i for i, l in enumerate(text) if l.endswith(":")}
+            path, i = [], w
+            # (a one-wave workgroup, plan<7>, has no s_barrier at all: the wave's own wait orders its stores before its add)
+            while not text[i].startswith("s_barrier") and not text[i].startswith("global_atomic_add"):
+                path.append(text[i])                            # straight-line walk; an unconditional branch is followed
+                i = labels[text[i].split()[1]] if text[i].startswith("s_branch") else i + 1
+                assert i < len(text) and len(path) < 200, (name, path[-10:])
+            nxt = i
+            assert not [l for l in path if re.match(r"(buffer|global|flat)_store", l)], (name, path)
+            after = text[nxt:nxt + 40]
+            assert any(l.startswith("global_atomic_add") for l in after), (name, after)
+            assert not any(l.startswith("s_barrier") for l in after[1:next(i for i, l in enumerate(after) if l.startswith("global_atomic_add"))]), name
+            # in front of it: the write-through stores of the image, with no barrier between the last of them and the wait
+            prev = max([i for i in range(w) if text[i].startswith("s_barrier")] or [0])
+            stores = [l for l in text[prev:w] if l.startswith("buffer_store") and " sc1" in l]
+            assert stores, (name, "no sc1 image store between the previous barrier and the wait")
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
