@@ -376,7 +376,7 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
 
 
 def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True, regions=5, stream=None, graph=False, region=None,
-                 probe_step=None):
+                 probe_step=None, probe_sync=False):
     """W untimed warm-up calls of step(i), then `regions` timed repetitions of the K-step region, each bracketed by
     barrier + synchronize on both sides and reduced with MAX over the ranks.
     Returns (median region seconds, sorted kernel ms list of the probe pass, info).
@@ -471,8 +471,9 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
         # launch before it (another kernel of the same step) is still running reads too long: such a pass is repeated
         # with the stream drained in front of every probed step, and if that does not help either the caller is told
         # (kernel_ms stays, `probe` says "inconsistent": the roofline object is then null with the reason).
-        kernel_ms = probe_pass(os.environ.get("MI_BENCH_PROBE_SYNC", "0") == "1")
-        probe_mode = "back to back"
+        drained = probe_sync or os.environ.get("MI_BENCH_PROBE_SYNC", "0") == "1"
+        kernel_ms = probe_pass(drained)
+        probe_mode = "stream drained before each probed launch" if drained else "back to back"
         if sum(kernel_ms) / len(kernel_ms) > 1.05 * step_ms:
             kernel_ms = probe_pass(True)
             probe_mode = "stream drained before each probed step (the back-to-back pass read longer than the step)"
@@ -569,10 +570,11 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
             else:
                 sharding.allreduce_bins(sums)
     steps = args.conv_steps - (args.conv_steps % batch) or batch
-    # probes: the analysis launch alone, back to back (behind a step's own bin_reduce_kernel the start stamp of the event
-    # pair is taken while that kernel still runs, and the pair then reads analysis + reduction)
+    # probes: the analysis launch alone, the stream drained in front of each (behind a step's own bin_reduce_kernel -- or
+    # behind another analysis launch that is still draining -- the start stamp of the event pair is taken early and the pair
+    # reads more than the kernel: 16.4 us in one run, 11.0 in the next, against rocprofv3's 11.8)
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch,
-                                             probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream))
+                                             probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream), probe_sync=True)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
     if state["comm"] is not None:
         state["comm"].close()
