@@ -310,6 +310,25 @@ def test_more_channels_than_compute_units(gpu):
         check(y[c], ref, exact_conv(x[c], irs[c]), "channel %d" % c)
 
 
+def test_block_stream_with_more_channels_than_compute_units(gpu):
+    """The completion of a frame received in blocks is the one-launch step with the tail role folding into the accumulator:
+    300 channels at rank 13 go in two such launches per frame (one CU-count of channels each).  256-sample calls over
+    two and a half frames, then a ragged piece; channels on both sides of the launch boundary against float64."""
+    rng = np.random.default_rng(32)
+    C, taps = 300, 9000
+    calls = [256] * 40 + [100]
+    n = sum(calls)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 3000.0)).astype(np.float32)
+    x = (rng.standard_normal((C, n)) * 0.3).astype(np.float32)
+    y, info = run_gpu(gpu, irs, 13, x, calls)
+    assert info["frame"] == 4096 and info["partitions"] == 3
+    for c in (0, 1, 127, 254, 255, 256, 257, 299):
+        ex = exact_conv(x[c], irs[c])
+        err = float(np.abs(y[c] - ex).max()) / float(np.abs(ex).max())
+        record_parity("convolver, stream of 256-sample calls: |gpu - exact| <= 1e-5 peak", err, TOL)
+        assert err <= TOL, (c, err)
+
+
 def test_more_workgroups_than_the_device_holds(gpu):
     """6000 channels at rank 9: the one-launch frame step is a grid of 12 000 single-wave workgroups, more than can be resident
     at once, so tail workgroups are dispatched while frame workgroups are still queued behind others -- the hand-over must not
