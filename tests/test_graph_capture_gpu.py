@@ -123,6 +123,17 @@ def test_convolver_bank_replays_over_its_ring_of_frames(gpu):
     assert K > 1
 
 
+def test_convolver_block_stream_replays(gpu):
+    """A stream of 256-sample calls on a partitioned bank with frames of 1024 (rank 11: four block kernels and one folding
+    completion per frame): the captured run must cover whole laps of the frame ring -- two frames, eight calls -- and its
+    replays equal the same calls made eagerly, bit for bit."""
+    C, rank, taps = 5, 11, 3000                               # three partitions of 1024: a ring of two frames
+    irs = (np.random.default_rng(4).standard_normal((C, taps)) * 0.1).astype(np.float32)
+    K = _run(gpu, Case("convolver block stream", lambda st: gpu.ConvolverBank(irs, rank, stream=st),
+                       lambda b, x, o, st: b.process(o[0], x, 256, stream=st), (C, 256), [(C, 256)], 8), max_k=16)
+    assert K == 8
+
+
 def test_equalizer_fir_replays(gpu):
     C, n = 4, 512
 
