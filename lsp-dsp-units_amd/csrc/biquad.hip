@@ -245,22 +245,40 @@ namespace
             float  a2;                                       //  compiler would recycle them and stall on the load)
             float4 ql;
         };
+        // The wave-uniform parts are read through the CONSTANT address space from an address made uniform with
+        // readfirstlane: scalar loads into SGPRs.  The plain kernel got those anyway (its table is a __restrict__ kernel
+        // argument); the chain kernel, whose table pointers come out of the argument struct by a loop index, did not -- the
+        // compiler could neither prove the address uniform nor the rows unclobbered by the band stores, and fetched every
+        // row with vector loads into VGPRs: 29 vector-memory instructions and about 100 extra VALU per section (SQ
+        // counters: 388 VMEM and 3432 VALU per wave for 12 sections).
+        typedef const __attribute__((address_space(4))) float cfloat;
+        auto uniform_row = [&](const float *T) -> cfloat * {
+            const uint64_t v = reinterpret_cast<uint64_t>(T);
+            const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+            const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
+            return reinterpret_cast<cfloat *>((uint64_t(hi) << 32) | lo);
+        };
+        typedef const __attribute__((address_space(4))) v16f cv16f;
+        typedef const __attribute__((address_space(4))) v8f cv8f;
         auto load_pq = [&](sectab &r, const float *T)
         {
+            cfloat *U = uniform_row(T);
             #pragma unroll
             for (int j = 0; j < L / 8; ++j)
-                r.pq[j] = *reinterpret_cast<const v16f *>(T + TAB_PQ + 16 * j);
+                r.pq[j] = *reinterpret_cast<cv16f *>(U + TAB_PQ + 16 * j);
         };
         auto load_mats = [&](sectab &r, const float *T)
         {
-            r.m0 = *reinterpret_cast<const v8f *>(T + 8);
-            r.m1 = *reinterpret_cast<const v16f *>(T + 16);
+            cfloat *U = uniform_row(T);
+            r.m0 = *reinterpret_cast<cv8f *>(U + 8);
+            r.m1 = *reinterpret_cast<cv16f *>(U + 16);
             r.ql = *reinterpret_cast<const float4 *>(T + TAB_QL + 4 * l16);
         };
         auto load_coefs = [&](sectab &r, const float *T)
         {
-            r.cf = *reinterpret_cast<const float4 *>(T);
-            r.a2 = T[4];
+            cfloat *U = uniform_row(T);
+            r.cf = make_float4(U[0], U[1], U[2], U[3]);
+            r.a2 = U[4];
         };
 
         // One section over the lane's two chunks.  par: parity of the super-block.  `saver` marks the lane holding
