@@ -251,10 +251,14 @@ namespace mi_meters
             {
                 if (tid < channels && counts)
                 {
+                    // (components picked by value: a picked POINTER into myblk parks it in scratch memory)
                     const float add = (k == 0) ? myseg.x : (k == 1) ? myseg.y : (k == 2) ? myseg.z : myseg.w;
-                    float *q = (pc.part == 0) ? &myblk.x : (pc.part == 1) ? &myblk.y : (pc.part == 2) ? &myblk.z : &myblk.w;
-                    *q += add;
-                    block[size_t(myrow) * 4 + pc.part] = *q;
+                    const float now = ((pc.part == 0) ? myblk.x : (pc.part == 1) ? myblk.y : (pc.part == 2) ? myblk.z : myblk.w) + add;
+                    myblk.x = (pc.part == 0) ? now : myblk.x;
+                    myblk.y = (pc.part == 1) ? now : myblk.y;
+                    myblk.z = (pc.part == 2) ? now : myblk.z;
+                    myblk.w = (pc.part == 3) ? now : myblk.w;
+                    block[size_t(myrow) * 4 + pc.part] = now;
                 }
                 for (uint32_t c = tid + TT; c < channels; c += TT)         // meters of more channels than threads
                     if (cfg[c].enabled)
@@ -271,8 +275,10 @@ namespace mi_meters
             {
                 if (tid < channels)
                 {
-                    float *q = (pc.zero_part == 0) ? &myblk.x : (pc.zero_part == 1) ? &myblk.y : (pc.zero_part == 2) ? &myblk.z : &myblk.w;
-                    *q = 0.0f;
+                    myblk.x = (pc.zero_part == 0) ? 0.0f : myblk.x;
+                    myblk.y = (pc.zero_part == 1) ? 0.0f : myblk.y;
+                    myblk.z = (pc.zero_part == 2) ? 0.0f : myblk.z;
+                    myblk.w = (pc.zero_part == 3) ? 0.0f : myblk.w;
                 }
                 for (uint32_t c = tid; c < channels; c += TT)
                     block[(meter * channels + c) * 4 + uint32_t(pc.zero_part)] = 0.0f;

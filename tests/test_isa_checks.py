@@ -117,3 +117,31 @@ def test_dynfilter_kernels_keep_the_cascades_in_registers(tmp_path):
     # the Makefile builds this file without the SLP vectorizer (see the note there); the flag above must stay in step
     mk = open(os.path.join(ROOT, "lsp-dsp-units_amd", "Makefile")).read()
     assert "dynfilter.hip.o: HIPFLAGS += -fno-slp-vectorize" in mk
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_no_kernel_parks_data_in_scratch(tmp_path):
+    """A private segment means round trips to memory in the middle of a kernel.  Twice it was not a register spill but a
+    POINTER picked at run time into a small local (the cascades of dynfilter.hip; `&myblk.x / .y / .z / .w` in the integrated
+    meter's bookkeeping): values are picked instead.  Every kernel of the library is held to no private segment at all, but for
+    the known register spills: SpectralSplitter hops of 8192-point transforms (128-VGPR budget of their 1024 threads) and the
+    matched-Z per-type kernels of DynamicFilters (checked in detail above)."""
+    allowed = ("splitter_hop_kernelILi13E", "dynfilter_kernel")
+    offenders = []
+    for src in sorted(os.listdir(CSRC)):
+        if not src.endswith(".hip"):
+            continue
+        out = os.path.join(str(tmp_path), src + ".s")
+        extra = ["-fno-slp-vectorize"] if src == "dynfilter.hip" else []
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=on", "-w"] + extra +
+                              ["-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "-I" + os.path.join(ROOT, "lsp-dsp-units_amd", "include"),
+                               "-S", "--offload-device-only", os.path.join(CSRC, src), "-o", out])
+        text = open(out).read()
+        if "amdhsa.kernels:" not in text:
+            continue
+        for block in text[text.index("amdhsa.kernels:"):].split("  - .agpr_count:")[1:]:
+            name = re.search(r"\.name: *(\S+)", block).group(1)
+            scratch = int(re.search(r"\.private_segment_fixed_size: *(\d+)", block).group(1))
+            if scratch > 0 and not any(a in name for a in allowed):
+                offenders.append((src, name, scratch))
+    assert not offenders, offenders
