@@ -556,7 +556,8 @@ namespace mi_fft
             }
             __syncthreads();
         }
-        __device__ __forceinline__ void mask_pairs(float2 *buf, const float *__restrict__ g, int tid) const
+        template <class GAINS /* a pointer to the M + 1 gains, in whatever address space the caller knows them to be */>
+        __device__ __forceinline__ void mask_pairs(float2 *buf, GAINS g, int tid) const
         {
             constexpr int M = plan<LOGM>::N, T = plan<LOGM>::T;
             #pragma unroll

@@ -210,6 +210,13 @@ namespace
             // loads per thread out of this loop, keeps them in registers across the transforms and spills the twiddles to
             // scratch (measured: 35 -> 91 us per step).  The pointers are laundered once per hop instead.
             asm volatile("" : "+s"(wi), "+s"(wo), "+s"(mk));
+            // (a laundered pointer has lost its address space: read through it the windows and gains would be FLAT loads,
+            // which count against lgkmcnt as well and so tie every wait for LDS data to them -- back to global they go)
+            typedef const __attribute__((address_space(1))) v2f gv2f;
+            typedef const __attribute__((address_space(1))) float gfloat;
+            gv2f *const wig = reinterpret_cast<gv2f *>(reinterpret_cast<uint64_t>(wi));
+            gv2f *const wog = reinterpret_cast<gv2f *>(reinterpret_cast<uint64_t>(wo));
+            gfloat *const mkg = reinterpret_cast<gfloat *>(reinterpret_cast<uint64_t>(mk));
             // (the same goes for everything derived from the thread index: the swizzled LDS addresses of the eight passes)
             int tix = tid;
             asm volatile("" : "+v"(tix));
@@ -228,8 +235,8 @@ namespace
             for (int i = 0; i < HPT; ++i)
             {
                 const int m = tix + i * T;
-                const float2 w0 = (wi != nullptr) ? wi[m] : make_float2(1.0f, 1.0f);
-                const float2 w1 = (wi != nullptr) ? wi[m + H / 2] : make_float2(1.0f, 1.0f);
+                const v2f w0 = (wi != nullptr) ? wig[m] : v2f{1.0f, 1.0f};
+                const v2f w1 = (wi != nullptr) ? wig[m + H / 2] : v2f{1.0f, 1.0f};
                 io[i]       = v2f{lo[i].x * w0.x, lo[i].y * w0.y};
                 io[i + HPT] = v2f{hi[i].x * w1.x, hi[i].y * w1.y};
                 if (!REGS)
@@ -244,7 +251,7 @@ namespace
             if constexpr (REGS)
             {
                 mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tix, io);
-                rf.mask_pairs(buf, mk, tix);
+                rf.mask_pairs(buf, mkg, tix);
                 mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tix, io);
             }
             else if (MASKED)
@@ -254,9 +261,9 @@ namespace
                 for (int i = 0; i < KPT; ++i)
                 {
                     const int k = tix + i * T;
-                    const float g = mk[k];
+                    const float g = mkg[k];
                     float2 v = buf[k];
-                    if (k == 0) { v.x *= g; v.y *= mk[H]; }
+                    if (k == 0) { v.x *= g; v.y *= mkg[H]; }
                     else        { v.x *= g; v.y *= g; }
                     buf[k] = v;
                 }
@@ -278,7 +285,7 @@ namespace
             for (int i = 0; i < HPT; ++i)
             {
                 const int m = tix + i * T;
-                const float2 w0 = wo[m], w1 = wo[m + H / 2];
+                const v2f w0 = wog[m], w1 = wog[m + H / 2];
                 const v2f y0 = io[i], y1 = io[i + HPT];
                 const float2 done = make_float2(fmaf(y0.x * scale, w0.x, prev[i].x), fmaf(y0.y * scale, w0.y, prev[i].y));
                 prev[i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);     // the tail the next hop adds to

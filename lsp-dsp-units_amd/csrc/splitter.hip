@@ -73,8 +73,11 @@ namespace
             line[m + hp] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
             if (emit != nullptr)
             {
-                emit[2 * m]     = done.x;
-                emit[2 * m + 1] = done.y;
+                // (the caller's row: global memory, whatever the pointer's history -- see the note in splitter_hop_kernel)
+                typedef __attribute__((address_space(1))) float gwfloat;
+                gwfloat *const e = reinterpret_cast<gwfloat *>(reinterpret_cast<uint64_t>(emit));
+                e[2 * m]     = done.x;
+                e[2 * m + 1] = done.y;
             }
         }
     }
@@ -186,13 +189,19 @@ namespace
                 {
                     if (hd[h].mode != H_MASK || !hd[h].has_sink)
                         continue;
-                    const float *g = hd[h].mask + size_t(ch) * hd[h].mask_stride;
+                    // (pointers that come out of memory -- the handler's gains, the caller's output rows -- are generic to the
+                    // compiler: read or written through them every access is a FLAT instruction, which counts against
+                    // lgkmcnt too and ties the waits for LDS data to it.  They are global memory and are told so.)
+                    typedef const __attribute__((address_space(1))) float gfloat;
+                    typedef __attribute__((address_space(1))) float gwfloat;
+                    gfloat *const g = reinterpret_cast<gfloat *>(reinterpret_cast<uint64_t>(hd[h].mask + size_t(ch) * hd[h].mask_stride));
                     __syncthreads();                                    // everybody holds its pairs / is done with the handler before
                     // only the real part of the inverse is kept (pcomplex_c2r): a real gain acts through its even part
                     rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tid);
                     mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tid, io);
                     float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
-                    float *emit = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+                    float *emit_ = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+                    gwfloat *const emit = reinterpret_cast<gwfloat *>(reinterpret_cast<uint64_t>(emit_));
                     #pragma unroll
                     for (int i = 0; i < PER / 2; ++i)
                     {
@@ -252,7 +261,8 @@ namespace
         {
             if (hd[h].mode != H_MASK || !hd[h].has_sink)
                 continue;
-            const float *g = hd[h].mask + size_t(ch) * hd[h].mask_stride;
+            typedef const __attribute__((address_space(1))) float gfloat;
+            gfloat *const g = reinterpret_cast<gfloat *>(reinterpret_cast<uint64_t>(hd[h].mask + size_t(ch) * hd[h].mask_stride));
             if (!PER_BAND)
                 __syncthreads();                                        // the previous handler is done with buf
             #pragma unroll
