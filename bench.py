@@ -376,12 +376,16 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
 
 
 def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True, regions=5, stream=None, graph=False, region=None,
-                 probe_step=None, probe_sync=False):
+                 probe_step=None, probe_sync=True):
     """W untimed warm-up calls of step(i), then `regions` timed repetitions of the K-step region, each bracketed by
     barrier + synchronize on both sides and reduced with MAX over the ranks.
     Returns (median region seconds, sorted kernel ms list of the probe pass, info).
     probe_step: what the probe pass calls instead of step() when a step has more than one launch -- the dominant kernel's
-    launch alone, back to back, so that its event pair does not span the other kernels of the step."""
+    launch alone, so that its event pair does not span the other kernels of the step.
+    probe_sync: the stream is drained in front of every probed launch (what rocprofv3's serialised kernel durations measure
+    too); back to back the start stamp of a pair can be taken while the launch before still drains, or the launches
+    overlap their ramps, and the pair reads anything between 0.93 and 1.4 of the kernel (11.8 .. 12.6 us for the 12.8 us
+    biquad launch, 11.0 .. 16.4 us for the 11.8 us analysis launch, run to run)."""
     import ctypes
     import gc
     for i in range(warmup):
