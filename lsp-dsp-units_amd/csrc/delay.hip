@@ -43,6 +43,18 @@ namespace
             ring[size_t(ch) * size + (head + i) % size] = src[size_t(r) * src_stride + i];
     }
 
+    // the same with four samples per lane: count, the write position and first are multiples of four (16-byte cells)
+    __global__ __launch_bounds__(256)
+    void ring_append4_kernel(float *ring, uint32_t size, uint32_t head0, const float *src, size_t src_stride, size_t count,
+                             const row_map rm)
+    {
+        const uint32_t r = blockIdx.y, ch = line_of(rm, r), head = head_of(rm, ch, head0, size);
+        const size_t first = (count > size) ? count - size : 0;
+        for (size_t i = first + 4 * (size_t(blockIdx.x) * 256 + threadIdx.x); i < count; i += 4 * size_t(gridDim.x) * 256)
+            *reinterpret_cast<float4 *>(ring + size_t(ch) * size + (head + i) % size) =
+                *reinterpret_cast<const float4 *>(src + size_t(r) * src_stride + i);
+    }
+
     // dst[i] (+)= gain * ring[(tail_c + i) % size] -- the "shift data from buffer" half of Delay::process
     __global__ __launch_bounds__(256)
     void ring_read_kernel(float *dst, size_t dst_stride, const float *ring, uint32_t size, uint32_t head0,
@@ -98,6 +110,70 @@ namespace
             r[(head + i) % size] = x;
             float *o = dst + size_t(row) * dst_stride + i;
             *o = add ? *o + v : v;
+        }
+    }
+
+    // The two steady-state kernels above with FOUR consecutive samples per lane (16-byte accesses): when the block, the write
+    // position and every delay of the call are multiples of four (the line's length always is) no 16-byte cell straddles
+    // the end of the line or the border between "still in the line" and "already in this block".  Same cells, same values.
+    __device__ __forceinline__ float4 apply_gain4(float4 v, int mode, float k, const float *gv, size_t i)
+    {
+        if (mode == G_SCALAR)
+            return make_float4(v.x * k, v.y * k, v.z * k, v.w * k);
+        if (mode == G_VECTOR)
+        {
+            const float4 g = *reinterpret_cast<const float4 *>(gv + i);
+            return make_float4(v.x * g.x, v.y * g.y, v.z * g.z, v.w * g.w);
+        }
+        return v;
+    }
+
+    __global__ __launch_bounds__(256)
+    void delay_exchange4_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, float *ring,
+                                uint32_t size, uint32_t head0, const uint32_t *__restrict__ delay, size_t count,
+                                int add, int gmode, float k, const float *gv, size_t gv_stride, const row_map rm)
+    {
+        const uint32_t row = blockIdx.y, ch = line_of(rm, row), head = head_of(rm, ch, head0, size);
+        const uint32_t tail = (head + size - delay[ch]) % size;
+        float *r = ring + size_t(ch) * size;
+        for (size_t i = 4 * (size_t(blockIdx.x) * 256 + threadIdx.x); i < count; i += 4 * size_t(gridDim.x) * 256)
+        {
+            const float4 x = *reinterpret_cast<const float4 *>(src + size_t(row) * src_stride + i);
+            const float4 v = apply_gain4(*reinterpret_cast<const float4 *>(r + (tail + i) % size), gmode, k, gv + size_t(row) * gv_stride, i);
+            *reinterpret_cast<float4 *>(r + (head + i) % size) = x;
+            float4 *o = reinterpret_cast<float4 *>(dst + size_t(row) * dst_stride + i);
+            if (add)
+            {
+                const float4 p = *o;
+                *o = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+            }
+            else
+                *o = v;
+        }
+    }
+
+    __global__ __launch_bounds__(256)
+    void delay_direct4_kernel(float *dst, size_t dst_stride, const float *src, size_t src_stride, const float *ring,
+                              uint32_t size, uint32_t head0, const uint32_t *__restrict__ delay, size_t count,
+                              int add, int gmode, float k, const float *gv, size_t gv_stride, const row_map rm)
+    {
+        const uint32_t r = blockIdx.y, ch = line_of(rm, r), head = head_of(rm, ch, head0, size);
+        const uint32_t d = delay[ch];
+        const uint32_t tail = (head + size - d) % size;
+        const float *x = src + size_t(r) * src_stride;
+        for (size_t i = 4 * (size_t(blockIdx.x) * 256 + threadIdx.x); i < count; i += 4 * size_t(gridDim.x) * 256)
+        {
+            const float4 raw = (i >= d) ? *reinterpret_cast<const float4 *>(x + (i - d))
+                                        : *reinterpret_cast<const float4 *>(ring + size_t(ch) * size + (tail + i) % size);
+            const float4 v = apply_gain4(raw, gmode, k, gv + size_t(r) * gv_stride, i);
+            float4 *o = reinterpret_cast<float4 *>(dst + size_t(r) * dst_stride + i);
+            if (add)
+            {
+                const float4 p = *o;
+                *o = make_float4(p.x + v.x, p.y + v.y, p.z + v.z, p.w + v.w);
+            }
+            else
+                *o = v;
         }
     }
 
@@ -280,6 +356,13 @@ namespace
 
     int append(mi_delay_bank *b, const delay_rows &dr, const float *src, size_t stride, size_t count, hipStream_t st)
     {
+        bool quads = (count % 4 == 0) && (b->head % 4 == 0) && (stride % 4 == 0) && (reinterpret_cast<uintptr_t>(src) % 16 == 0);
+        for (uint32_t k = 0; quads && b->off_any && k < dr.n; ++k)
+            quads = b->off[dr.host ? dr.host[k] : k] % 4 == 0;
+        if (quads)
+            hipLaunchKernelGGL(ring_append4_kernel, grid_for(count / 4, dr.n), dim3(256), 0, st,
+                               b->d_ring, b->size, b->head, src, stride, count, dr.rm);
+        else
         hipLaunchKernelGGL(ring_append_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                            b->d_ring, b->size, b->head, src, stride, count, dr.rm);
         MI_HIP_CHECK(hipGetLastError());
@@ -497,8 +580,22 @@ static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t
         dmin = (d < dmin) ? d : dmin;
         dmax = (d > dmax) ? d : dmax;
     }
+    // four samples per lane when nothing of the call straddles a 16-byte cell
+    bool quads = (count % 4 == 0) && (b->head % 4 == 0) && (out_stride % 4 == 0) && (in_stride % 4 == 0) &&
+                 ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 16 == 0) &&
+                 (gain_mode != G_VECTOR || (gain_stride % 4 == 0 && reinterpret_cast<uintptr_t>(gain_vec) % 16 == 0));
+    for (uint32_t k = 0; quads && k < dr.n; ++k)
+    {
+        const uint32_t c = dr.host ? dr.host[k] : k;
+        quads = (b->delay[c] % 4 == 0) && (!b->off_any || b->off[c] % 4 == 0);
+    }
     if (count <= dmin && count <= size_t(b->size - dmax))
     {
+        if (quads)
+            hipLaunchKernelGGL(delay_exchange4_kernel, grid_for(count / 4, dr.n), dim3(256), 0, st,
+                               out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
+                               gain, gain_vec, gain_stride, dr.rm);
+        else
         hipLaunchKernelGGL(delay_exchange_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                            out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
                            gain, gain_vec, gain_stride, dr.rm);
@@ -509,6 +606,11 @@ static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t
     }
     if (static_cast<const void *>(out) != static_cast<const void *>(in))
     {
+        if (quads)
+            hipLaunchKernelGGL(delay_direct4_kernel, grid_for(count / 4, dr.n), dim3(256), 0, st,
+                               out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
+                               gain, gain_vec, gain_stride, dr.rm);
+        else
         hipLaunchKernelGGL(delay_direct_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                            out, out_stride, in, in_stride, b->d_ring, b->size, b->head, b->d_delay, count, add, gain_mode,
                            gain, gain_vec, gain_stride, dr.rm);

@@ -1,8 +1,8 @@
 # the delay bank's process() forms on resident buffers, 1024 channels x 4096 samples per call.  The loop below is bound by
 # the eager launches (about 10 us per call from Python); kernel durations come from running it under
 #   rocprofv3 --kernel-trace --stats -- python3 tests/experiments/delay_rate.py
-# Round 3, final tree: delay_exchange_kernel 15.4 us (16 B per sample: 4.4 TB/s), delay_direct_kernel 13.2, ring_append_kernel
-# 9.2.  Replacing the per-element `% size` by an incrementally wrapped position made them SLOWER (17.3 / 15.1 / 10.6 us): at
+# Round 3: delay_exchange_kernel 15.4 us (16 B per sample: 4.4 TB/s), delay_direct_kernel 13.2, ring_append_kernel 9.2 with one
+# sample per lane; with four (calls on the quad grid): 11.3 (5.9 TB/s) / 7.2 / 6.5 us.  Replacing the per-element `% size` by an incrementally wrapped position made them SLOWER (17.3 / 15.1 / 10.6 us): at
 # one element per thread the two 32-bit modulos cost less than setting the walk up.
 import importlib, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

@@ -105,6 +105,44 @@ def test_delay_short_blocks_single_pass_bit_exact(gpu, in_place):
 
 
 @pytest.mark.parametrize("in_place", [False, True])
+def test_delay_quad_paths_bit_exact(gpu, in_place):
+    """Blocks, write position and delays that are all multiples of four take the 16-byte kernels (delay_exchange4_kernel for
+    blocks no longer than the shortest delay, delay_direct4_kernel beyond): every process form against the oracle, across
+    the wrap of the line, then one odd call that knocks the line off the quad grid and back onto the scalar kernels."""
+    rng = np.random.default_rng(44)
+    C, maxd = 5, 3000
+    delays = [0, 4, 512, 1500, 3000] if not in_place else [1024, 2000, 512, 1500, 3000]
+    bank = gpu.DelayBank(C, maxd)
+    refs = [od.Delay(maxd) for _ in range(C)]
+    for c, d in enumerate(delays):
+        bank.set_delay(d, c); refs[c].set_delay(d)
+    for n, mode in ((256, "plain"), (512, "scalar"), (1024, "vector"), (2048, "add"), (512, "add_vector"), (3584, "plain"),
+                    (4096, "vector"), (7, "plain"), (512, "plain"), (1021, "scalar"), (256, "add")):
+        x = rng.standard_normal((C, n)).astype(np.float32)
+        g = rng.uniform(0.5, 2.0, (C, n)).astype(np.float32)
+        base = rng.standard_normal((C, n)).astype(np.float32)
+        ip = in_place and not mode.startswith("add")
+        din = gpu.DeviceBuffer.from_host(x)
+        dout = din if ip else gpu.DeviceBuffer.from_host(base)
+        dg = gpu.DeviceBuffer.from_host(g)
+        kw = {"plain": {}, "scalar": {"gain": 0.37}, "vector": {"gain_vec": dg}, "add": {"add": True},
+              "add_vector": {"add": True, "gain_vec": dg}}[mode]
+        bank.process(dout, din, n, **kw)
+        ref = []
+        for c, r in enumerate(refs):
+            rk = {}
+            if mode == "scalar": rk["gain"] = 0.37
+            if mode in ("vector", "add_vector"): rk["gain"] = g[c]
+            if mode.startswith("add"): rk["add_to"] = base[c]
+            ref.append(r.process(x[c], **rk))
+        np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=str((mode, n)))
+        for c, r in enumerate(refs):
+            st = bank.get(c)
+            assert (st["head"], st["tail"]) == (r.head, r.tail), (mode, n, c)
+    bank.close()
+
+
+@pytest.mark.parametrize("in_place", [False, True])
 def test_delay_ramping_bit_exact(gpu, in_place):
     """Delay::process_ramping index (old_tail + ssize_t(delta * offset)) % size, incl. pieces and wrap."""
     rng = np.random.default_rng(2)
