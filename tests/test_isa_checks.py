@@ -144,4 +144,12 @@ def test_no_kernel_parks_data_in_scratch(tmp_path):
             scratch = int(re.search(r"\.private_segment_fixed_size: *(\d+)", block).group(1))
             if scratch > 0 and not any(a in name for a in allowed):
                 offenders.append((src, name, scratch))
+        # the streaming hop kernels read windows, gains and the callers' rows as GLOBAL memory: pointers that were laundered
+        # against hoisting or came out of memory are generic to the compiler, and flat loads count against lgkmcnt as well
+        # (every wait for LDS data then waits for them too)
+        for part in ("stft_stream_kernel", "splitter_hop_kernel"):
+            for name, body in _kernel_bodies(text.split("\n"), part).items():
+                flat = sum(1 for l in body if l.strip().startswith("flat_"))
+                if flat > 4:
+                    offenders.append((src, name, "flat instructions", flat))
     assert not offenders, offenders
