@@ -96,7 +96,7 @@ namespace
                              uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
                              const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
                              const float *src, size_t src_stride, uint32_t ingest_n, const out_table outs,
-                             size_t out_stride, size_t out_pos)
+                             size_t out_stride, size_t out_pos, uint32_t hops /* > 1: that many hops of a streaming call at once */)
     {
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, PER = (H + T - 1) / T;
@@ -158,7 +158,10 @@ namespace
             {
                 const float *sx = (src != nullptr) ? src + size_t(ch) * src_stride : nullptr;
                 for (uint32_t i = tid; i < ingest_n; i += T)
-                    nx[N - frame + i] = (sx != nullptr) ? sx[i] : 0.0f;
+                    nx[N - frame + i] = (sx != nullptr) ? sx[size_t(hops - 1) * frame + i] : 0.0f;
+                if (hops > 1)                               // (frame == N / 2 then) the buffer after the last hop: the call's last two blocks
+                    for (uint32_t i = tid; i < frame; i += T)
+                        nx[i] = (sx != nullptr) ? sx[size_t(hops - 2) * frame + i] : 0.0f;
             }
         }
         if (!masks)
@@ -176,6 +179,92 @@ namespace
             {
                 static_assert(PER * T == H && (PER % 2) == 0, "whole pairs per thread");
                 constexpr int IT = mi_fft::real_fft<LOGH>::PAIRS;
+                const float scale = 1.0f / float(N);
+                const uint32_t hp = frame >> 1;
+                typedef const __attribute__((address_space(1))) float gfloat;
+                typedef __attribute__((address_space(1))) float gwfloat;
+                typedef const __attribute__((address_space(1))) v2f gv2f;
+                if (hops > 1)
+                {
+                    // Several hops of a streaming call in ONE launch (host: one handler per workgroup, every listening handler
+                    // a mask): between two hops nothing goes through memory -- the half of the frame the next hop starts with,
+                    // and the tail the overlap-add leaves in the handler's line, stay in registers; the caller's samples that
+                    // complete the next frame come straight from its block.
+                    const uint32_t h = h0;
+                    if (hd[h].mode != H_MASK || !hd[h].has_sink)
+                        return;
+                    float2 lo[PER / 2], hi[PER / 2], tail[PER / 2], last[PER / 2];
+                    float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
+                    #pragma unroll
+                    for (int i = 0; i < PER / 2; ++i)
+                    {
+                        lo[i] = xr[i];
+                        hi[i] = xr[i + PER / 2];
+                        tail[i] = line[tid + i * T + hp];
+                        last[i] = make_float2(0.0f, 0.0f);
+                    }
+                    // (the same for every lane, and told so: the addresses live in SGPRs)
+                    auto one = [](const void *q) -> uint64_t {
+                        const uint64_t v = reinterpret_cast<uint64_t>(q);
+                        return uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v)))))
+                             | (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))))) << 32);
+                    };
+                    uint64_t gp = one(hd[h].mask + size_t(ch) * hd[h].mask_stride);
+                    uint64_t sp = one((src != nullptr) ? src + size_t(ch) * src_stride : nullptr);
+                    uint64_t ep = one((outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr);
+                    uint64_t wp = one(wnd);
+                    for (uint32_t hop = 0; hop < hops; ++hop)
+                    {
+                        // (what does not change from hop to hop is laundered once per hop: hoisted out of the loop its loads
+                        // would be kept across the transforms and spill the twiddles, spectral.hip's stft_stream_kernel)
+                        asm volatile("" : "+s"(gp), "+s"(sp), "+s"(ep), "+s"(wp));
+                        int tix = tid;
+                        asm volatile("" : "+v"(tix));
+                        gfloat *const g = reinterpret_cast<gfloat *>(gp);
+                        gv2f *const s2 = reinterpret_cast<gv2f *>(sp);
+                        gv2f *const wg = reinterpret_cast<gv2f *>(wp);
+                        gwfloat *const emit = reinterpret_cast<gwfloat *>(ep);
+                        v2f io[PER];
+                        #pragma unroll
+                        for (int i = 0; i < PER / 2; ++i)
+                        {
+                            io[i] = v2f{lo[i].x, lo[i].y};
+                            io[i + PER / 2] = v2f{hi[i].x, hi[i].y};
+                            lo[i] = hi[i];                              // the frame moves on by half
+                            const v2f nx = (sp != 0) ? s2[size_t(hop) * hp + tix + i * T] : v2f{0.0f, 0.0f};
+                            hi[i] = make_float2(nx.x, nx.y);
+                        }
+                        mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tix, io);
+                        float2 zk[IT], zm[IT];
+                        rf.pairs_load(buf, zk, zm, tix);
+                        __syncthreads();
+                        rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tix);
+                        mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tix, io);
+                        #pragma unroll
+                        for (int i = 0; i < PER / 2; ++i)
+                        {
+                            const uint32_t m = tix + i * T;
+                            const v2f y0 = io[i], y1 = io[i + PER / 2], w0 = wg[m], w1 = wg[m + hp];
+                            const float2 done = make_float2(fmaf(y0.x * scale, w0.x, tail[i].x), fmaf(y0.y * scale, w0.y, tail[i].y));
+                            tail[i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+                            last[i] = done;
+                            if (ep != 0)
+                            {
+                                emit[size_t(hop) * frame + 2 * m]     = done.x;
+                                emit[size_t(hop) * frame + 2 * m + 1] = done.y;
+                            }
+                        }
+                        if (hop + 1 < hops)
+                            __syncthreads();                            // buf is refilled by the next hop
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < PER / 2; ++i)                   // the handler's line as the call leaves it
+                    {
+                        line[tid + i * T]      = last[i];
+                        line[tid + i * T + hp] = tail[i];
+                    }
+                    return;
+                }
                 v2f io[PER];
                 #pragma unroll
                 for (int i = 0; i < PER; ++i)
@@ -183,8 +272,6 @@ namespace
                 mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tid, io);
                 float2 zk[IT], zm[IT];
                 rf.pairs_load(buf, zk, zm, tid);
-                const float scale = 1.0f / float(N);
-                const uint32_t hp = frame >> 1;
                 for (uint32_t h = h0; h < h1; ++h)
                 {
                     if (hd[h].mode != H_MASK || !hd[h].has_sink)
@@ -192,8 +279,6 @@ namespace
                     // (pointers that come out of memory -- the handler's gains, the caller's output rows -- are generic to the
                     // compiler: read or written through them every access is a FLAT instruction, which counts against
                     // lgkmcnt too and ties the waits for LDS data to it.  They are global memory and are told so.)
-                    typedef const __attribute__((address_space(1))) float gfloat;
-                    typedef __attribute__((address_space(1))) float gwfloat;
                     gfloat *const g = reinterpret_cast<gfloat *>(reinterpret_cast<uint64_t>(hd[h].mask + size_t(ch) * hd[h].mask_stride));
                     __syncthreads();                                    // everybody holds its pairs / is done with the handler before
                     // only the real part of the inverse is kept (pcomplex_c2r): a real gain acts through its even part
@@ -454,6 +539,27 @@ namespace
         return t;
     }
 
+    template <int LH> constexpr bool hop_in_registers = (LH <= 12) && !fplan<LH>::radix16 && (mi_fft::plan<LH>::T == mi_fft::plan<LH>::TB);
+
+    // May the hops of one streaming call share a launch (splitter_hop_kernel, hops > 1)?  The register path must exist for
+    // the size, the hop must be the whole half frame, and every handler that is listened to must be a mask.
+    bool splitter_hops_fuse(const mi_splitter_bank *b, const float *src, size_t src_stride)
+    {
+        if (b->chunk_rank != b->rank || getenv("MI_SPLITTER_HOP_LAUNCHES") != nullptr)
+            return false;
+        bool fast = false;
+        #define MI_CALL(LH) fast = hop_in_registers<LH>
+        MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
+        #undef MI_CALL
+        if (!fast || (b->handlers > 1 && b->channels * 2 > 1024))
+            return false;
+        for (uint32_t i = 0; i < b->handlers; ++i)
+            if (b->has_sink[i] && b->h[i].mode != H_MASK)
+                return false;
+        // the blocks that follow the first come in as pairs of samples
+        return src == nullptr || ((reinterpret_cast<uintptr_t>(src) % 8) == 0 && (src_stride % 2) == 0);
+    }
+
     bool splitter_has_callbacks(const mi_splitter_bank *b)
     {
         for (uint32_t i = 0; i < b->handlers; ++i)
@@ -464,7 +570,7 @@ namespace
 
     // src / src_stride / ingest_n / out_stride / out_pos: the fused streaming of splitter_hop_kernel (ingest_n == 0: none)
     int splitter_hop(mi_splitter_bank *b, hipStream_t st, const float *src, size_t src_stride, uint32_t ingest_n,
-                     size_t out_stride, size_t out_pos)
+                     size_t out_stride, size_t out_pos, uint32_t hops = 1)
     {
         const int lh = int(b->rank) - 1;
         const uint32_t frame = 1u << (b->chunk_rank - 1);
@@ -476,7 +582,7 @@ namespace
         if (!callbacks)
         {
             #define MI_ARGS b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, \
-                (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos
+                (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos, hops
             if (grid.y > 1)
             {
                 #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
@@ -496,7 +602,7 @@ namespace
         }
         #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, true, false>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, \
             b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, b->d_spec, \
-            b->d_tw, (const float *)nullptr, size_t(0), 0u, splitter_outs(b), size_t(0), size_t(0))
+            b->d_tw, (const float *)nullptr, size_t(0), 0u, splitter_outs(b), size_t(0), size_t(0), 1u)
         MI_LOGH_SWITCH(lh, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
@@ -887,8 +993,11 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
             // a whole frame follows in this call: the transform kernel takes it in and hands the finished frame out itself
             const bool big = b->rank > 14;
             const bool fused = !big && !callbacks && (count - done >= frame);
+            const float *src = (in != nullptr) ? in + done : nullptr;
+            const uint32_t hops = (fused && count - done >= 2 * size_t(frame) && splitter_hops_fuse(b, src, in_stride))
+                                ? uint32_t(std::min<size_t>((count - done) / frame, 1u << 20)) : 1;
             const int r = big   ? splitter_hop_big(b, st)
-                        : fused ? splitter_hop(b, st, (in != nullptr) ? in + done : nullptr, in_stride, frame, out_stride, done)
+                        : fused ? splitter_hop(b, st, src, in_stride, frame, out_stride, done, hops)
                                 : splitter_hop(b, st, nullptr, 0, 0, 0, 0);
             if (r != MI_OK)
                 return r;
@@ -896,7 +1005,7 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
             if (fused)
             {
                 b->fill = frame;
-                done += frame;
+                done += size_t(hops) * frame;
                 continue;
             }
         }

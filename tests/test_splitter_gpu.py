@@ -94,6 +94,54 @@ def test_masks_and_copy_handlers_match_oracle(gpu, rank, chunk, phase, calls):
         assert float(np.abs(want[i]).max()) > 0.01
 
 
+@pytest.mark.parametrize("rank", [6, 8, 9, 10, 11, 12, 13])
+def test_hops_of_a_call_sharing_one_launch(gpu, rank, monkeypatch):
+    """A call that brings several whole frames to a splitter whose listening handlers are all masks runs its hops in ONE
+    launch (splitter_hop_kernel, hops > 1): against the oracle, and bit for bit against one launch per hop
+    (MI_SPLITTER_HOP_LAUNCHES); calls whose blocks cannot be read as pairs (odd position / odd row stride), a call of
+    silence and the calls that follow see the same state either way."""
+    C, F = 3, 1 << (rank - 1)
+    rng = np.random.default_rng(900 + rank)
+    sym = osp.hipass_fft_set(2000.0, -24.0, 48000.0, rank)
+    per = np.stack([osp.lopass_fft_set(500.0 * (c + 1), -32.0, 48000.0, rank) for c in range(C)])
+    asym = rng.uniform(0.0, 1.5, 1 << rank).astype(np.float32)
+    handlers = [sym, None, per, asym]
+    calls = (4 * F, F // 2, F // 2 + 3 * F, 2 * F + 1, 3, 5 * F, F - 4, 2 * F)
+    x = (rng.standard_normal((C, sum(calls))) * 0.5).astype(np.float32)
+    want = _oracle_run(rank, 0, 0.0, handlers, x, calls)
+    got, _ = _gpu_run(gpu, rank, 0, 0.0, handlers, x, calls)
+    monkeypatch.setenv("MI_SPLITTER_HOP_LAUNCHES", "1")
+    one, _ = _gpu_run(gpu, rank, 0, 0.0, handlers, x, calls)
+    monkeypatch.delenv("MI_SPLITTER_HOP_LAUNCHES")
+    for i, h in enumerate(handlers):
+        if h is None:
+            continue
+        err = float(np.abs(got[i] - want[i]).max())
+        assert err <= TOL * max(float(np.abs(x).max()), float(np.abs(want[i]).max())), (i, err)
+        assert np.array_equal(got[i], one[i]), i
+    # silence through the same path, then signal again
+    bank = gpu.SplitterBank(C, rank, 1)
+    bank.set_rank(rank); bank.bind_mask(0, asym)
+    ref = [osp.SpectralSplitter(rank, 1) for _ in range(C)]
+    col = [[] for _ in range(C)]
+    for c in range(C):
+        def func(spec, r):
+            spec[0::2] *= asym; spec[1::2] *= asym
+            return spec
+        ref[c].bind(0, func, lambda s, first, count, c=c: col[c].append(s.copy()))
+    for k, quiet in ((3 * F, False), (4 * F, True), (2 * F, False)):
+        xs = None if quiet else (rng.standard_normal((C, k)) * 0.5).astype(np.float32)
+        buf = gpu.DeviceBuffer.from_host(np.full((C, k), -7.0, np.float32))
+        bank.process([buf], gpu.DeviceBuffer.from_host(xs) if xs is not None else None, k)
+        y = buf.download()
+        for c in range(C):
+            col[c].clear()
+            ref[c].process(xs[c] if xs is not None else None, k)
+            w = np.concatenate(col[c])
+            assert float(np.abs(y[c] - w).max()) <= TOL * max(1.0, float(np.abs(w).max())), (k, quiet, c)
+    bank.close()
+
+
 def test_rank_below_max_rank_rebind_unbind_clear_and_silence(gpu):
     C, rank, n = 2, 9, 2048
     rng = np.random.default_rng(77)
