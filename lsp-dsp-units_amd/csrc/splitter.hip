@@ -90,8 +90,8 @@ namespace
     // forward transform); workgroup y == 0 moves the analysis buffer on.
     // Fused streaming (ingest_n > 0): the `frame` samples that follow the hop are taken from `src` (NULL: silence) into the
     // new analysis buffer, and the frame every handler finishes goes straight to the caller's buffers.
-    template <int LOGH, bool WRITE_SPEC, bool PER_BAND>
-    __global__ __launch_bounds__(fplan<LOGH>::T)
+    template <int LOGH, bool WRITE_SPEC, bool PER_BAND, bool MULTI = false>
+    __global__ __launch_bounds__(fplan<LOGH>::T, (MULTI && PER_BAND) ? 4 : 1)    // (four waves per SIMD as the one-hop kernel has them)
     void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
                              uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
                              const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
@@ -184,7 +184,7 @@ namespace
                 typedef const __attribute__((address_space(1))) float gfloat;
                 typedef __attribute__((address_space(1))) float gwfloat;
                 typedef const __attribute__((address_space(1))) v2f gv2f;
-                if (hops > 1)
+                if constexpr (MULTI)
                 {
                     // Several hops of a streaming call in ONE launch (host: one handler per workgroup, every listening handler
                     // a mask): between two hops nothing goes through memory -- the half of the frame the next hop starts with,
@@ -193,7 +193,7 @@ namespace
                     const uint32_t h = h0;
                     if (hd[h].mode != H_MASK || !hd[h].has_sink)
                         return;
-                    float2 lo[PER / 2], hi[PER / 2], tail[PER / 2], last[PER / 2];
+                    float2 lo[PER / 2], hi[PER / 2], tail[PER / 2];
                     float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
                     #pragma unroll
                     for (int i = 0; i < PER / 2; ++i)
@@ -201,7 +201,6 @@ namespace
                         lo[i] = xr[i];
                         hi[i] = xr[i + PER / 2];
                         tail[i] = line[tid + i * T + hp];
-                        last[i] = make_float2(0.0f, 0.0f);
                     }
                     // (the same for every lane, and told so: the addresses live in SGPRs)
                     auto one = [](const void *q) -> uint64_t {
@@ -247,7 +246,8 @@ namespace
                             const v2f y0 = io[i], y1 = io[i + PER / 2], w0 = wg[m], w1 = wg[m + hp];
                             const float2 done = make_float2(fmaf(y0.x * scale, w0.x, tail[i].x), fmaf(y0.y * scale, w0.y, tail[i].y));
                             tail[i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
-                            last[i] = done;
+                            if (hop + 1 == hops)
+                                line[m] = done;                         // the handler's line as the call leaves it
                             if (ep != 0)
                             {
                                 emit[size_t(hop) * frame + 2 * m]     = done.x;
@@ -258,11 +258,8 @@ namespace
                             __syncthreads();                            // buf is refilled by the next hop
                     }
                     #pragma unroll
-                    for (int i = 0; i < PER / 2; ++i)                   // the handler's line as the call leaves it
-                    {
-                        line[tid + i * T]      = last[i];
+                    for (int i = 0; i < PER / 2; ++i)
                         line[tid + i * T + hp] = tail[i];
-                    }
                     return;
                 }
                 v2f io[PER];
@@ -583,7 +580,21 @@ namespace
         {
             #define MI_ARGS b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, \
                 (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos, hops
-            if (grid.y > 1)
+            if (hops > 1 && grid.y > 1)
+            {
+                #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
+                    MI_LAUNCH((splitter_hop_kernel<LH, false, true, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+            }
+            else if (hops > 1)
+            {
+                #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
+                    MI_LAUNCH((splitter_hop_kernel<LH, false, false, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+            }
+            else if (grid.y > 1)
             {
                 #define MI_CALL(LH) MI_LAUNCH((splitter_hop_kernel<LH, false, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
