@@ -90,8 +90,9 @@ namespace
     // forward transform); workgroup y == 0 moves the analysis buffer on.
     // Fused streaming (ingest_n > 0): the `frame` samples that follow the hop are taken from `src` (NULL: silence) into the
     // new analysis buffer, and the frame every handler finishes goes straight to the caller's buffers.
-    template <int LOGH, bool WRITE_SPEC, bool PER_BAND, bool MULTI = false>
-    __global__ __launch_bounds__(fplan<LOGH>::T, (MULTI && PER_BAND) ? 4 : 1)    // (four waves per SIMD as the one-hop kernel has them)
+    // MULTI > 0: the several-hops form, MULTI handlers per workgroup (1: four waves per SIMD as the one-hop kernel has them)
+    template <int LOGH, bool WRITE_SPEC, bool PER_BAND, int MULTI = 0>
+    __global__ __launch_bounds__(fplan<LOGH>::T, (MULTI == 1 && PER_BAND) ? 4 : (MULTI == 2) ? 2 : 1)
     void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
                              uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
                              const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
@@ -104,7 +105,8 @@ namespace
         float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
         constexpr bool all = !PER_BAND;
-        const uint32_t h0 = all ? 0 : blockIdx.y, h1 = all ? handlers : blockIdx.y + 1;
+        constexpr uint32_t BPW = (MULTI > 0) ? MULTI : 1;          // handlers per workgroup
+        const uint32_t h0 = all ? 0 : blockIdx.y * BPW, h1 = all ? handlers : (h0 + BPW < handlers ? h0 + BPW : handlers);
         const bool owner = all || (blockIdx.y == 0);
         // the frame is asked for before the handler descriptors are looked at (their little dependent loads would otherwise
         // cost an exposed latency before the frame's own: tests/experiments/analyzer_probe.hip found that pattern)
@@ -184,45 +186,51 @@ namespace
                 typedef const __attribute__((address_space(1))) float gfloat;
                 typedef __attribute__((address_space(1))) float gwfloat;
                 typedef const __attribute__((address_space(1))) v2f gv2f;
-                if constexpr (MULTI)
+                if constexpr (MULTI > 0)
                 {
-                    // Several hops of a streaming call in ONE launch (host: one handler per workgroup, every listening handler
-                    // a mask): between two hops nothing goes through memory -- the half of the frame the next hop starts with,
-                    // and the tail the overlap-add leaves in the handler's line, stay in registers; the caller's samples that
-                    // complete the next frame come straight from its block.
-                    const uint32_t h = h0;
-                    if (hd[h].mode != H_MASK || !hd[h].has_sink)
-                        return;
-                    float2 lo[PER / 2], hi[PER / 2], tail[PER / 2];
-                    float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
-                    #pragma unroll
-                    for (int i = 0; i < PER / 2; ++i)
-                    {
-                        lo[i] = xr[i];
-                        hi[i] = xr[i + PER / 2];
-                        tail[i] = line[tid + i * T + hp];
-                    }
+                    // Several hops of a streaming call in ONE launch (host: every listening handler a mask; MULTI handlers per
+                    // workgroup, which share the forward transform): between two hops nothing goes through memory -- the half
+                    // of the frame the next hop starts with, and the tail the overlap-add leaves in a handler's line, stay in
+                    // registers; the caller's samples that complete the next frame come straight from its block.
                     // (the same for every lane, and told so: the addresses live in SGPRs)
                     auto one = [](const void *q) -> uint64_t {
                         const uint64_t v = reinterpret_cast<uint64_t>(q);
                         return uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v)))))
                              | (uint64_t(uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))))) << 32);
                     };
-                    uint64_t gp = one(hd[h].mask + size_t(ch) * hd[h].mask_stride);
+                    float2 lo[PER / 2], hi[PER / 2], tail[MULTI][PER / 2];
+                    bool on[MULTI];
+                    uint64_t gp[MULTI], ep[MULTI], lp[MULTI];
+                    #pragma unroll
+                    for (int b = 0; b < MULTI; ++b)
+                    {
+                        const uint32_t h = h0 + b;
+                        on[b] = h < h1 && hd[h].mode == H_MASK && hd[h].has_sink;
+                        const uint32_t hh = on[b] ? h : h0;
+                        gp[b] = one(hd[hh].mask + size_t(ch) * hd[hh].mask_stride);
+                        ep[b] = one((outs.at(hh) != nullptr) ? outs.at(hh) + size_t(ch) * out_stride + out_pos : nullptr);
+                        lp[b] = one(lines + (size_t(hh) * channels + ch) * line_pitch);
+                        #pragma unroll
+                        for (int i = 0; i < PER / 2; ++i)
+                            tail[b][i] = on[b] ? reinterpret_cast<const float2 *>(lp[b])[tid + i * T + hp] : make_float2(0.0f, 0.0f);
+                    }
+                    #pragma unroll
+                    for (int i = 0; i < PER / 2; ++i)
+                    {
+                        lo[i] = xr[i];
+                        hi[i] = xr[i + PER / 2];
+                    }
                     uint64_t sp = one((src != nullptr) ? src + size_t(ch) * src_stride : nullptr);
-                    uint64_t ep = one((outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr);
                     uint64_t wp = one(wnd);
                     for (uint32_t hop = 0; hop < hops; ++hop)
                     {
                         // (what does not change from hop to hop is laundered once per hop: hoisted out of the loop its loads
                         // would be kept across the transforms and spill the twiddles, spectral.hip's stft_stream_kernel)
-                        asm volatile("" : "+s"(gp), "+s"(sp), "+s"(ep), "+s"(wp));
+                        asm volatile("" : "+s"(sp), "+s"(wp));
                         int tix = tid;
                         asm volatile("" : "+v"(tix));
-                        gfloat *const g = reinterpret_cast<gfloat *>(gp);
                         gv2f *const s2 = reinterpret_cast<gv2f *>(sp);
                         gv2f *const wg = reinterpret_cast<gv2f *>(wp);
-                        gwfloat *const emit = reinterpret_cast<gwfloat *>(ep);
                         v2f io[PER];
                         #pragma unroll
                         for (int i = 0; i < PER / 2; ++i)
@@ -236,30 +244,44 @@ namespace
                         mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tix, io);
                         float2 zk[IT], zm[IT];
                         rf.pairs_load(buf, zk, zm, tix);
-                        __syncthreads();
-                        rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tix);
-                        mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tix, io);
                         #pragma unroll
-                        for (int i = 0; i < PER / 2; ++i)
+                        for (int b = 0; b < MULTI; ++b)
                         {
-                            const uint32_t m = tix + i * T;
-                            const v2f y0 = io[i], y1 = io[i + PER / 2], w0 = wg[m], w1 = wg[m + hp];
-                            const float2 done = make_float2(fmaf(y0.x * scale, w0.x, tail[i].x), fmaf(y0.y * scale, w0.y, tail[i].y));
-                            tail[i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
-                            if (hop + 1 == hops)
-                                line[m] = done;                         // the handler's line as the call leaves it
-                            if (ep != 0)
+                            if (!on[b])
+                                continue;
+                            asm volatile("" : "+s"(gp[b]), "+s"(ep[b]), "+s"(lp[b]));
+                            gfloat *const g = reinterpret_cast<gfloat *>(gp[b]);
+                            gwfloat *const emit = reinterpret_cast<gwfloat *>(ep[b]);
+                            __syncthreads();                            // everybody holds its pairs / is done with the handler before
+                            rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tix);
+                            mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tix, io);
+                            #pragma unroll
+                            for (int i = 0; i < PER / 2; ++i)
                             {
-                                emit[size_t(hop) * frame + 2 * m]     = done.x;
-                                emit[size_t(hop) * frame + 2 * m + 1] = done.y;
+                                const uint32_t m = tix + i * T;
+                                const v2f y0 = io[i], y1 = io[i + PER / 2], w0 = wg[m], w1 = wg[m + hp];
+                                const float2 done = make_float2(fmaf(y0.x * scale, w0.x, tail[b][i].x), fmaf(y0.y * scale, w0.y, tail[b][i].y));
+                                tail[b][i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
+                                if (hop + 1 == hops)                    // the handler's line as the call leaves it
+                                    reinterpret_cast<float2 *>(lp[b])[m] = done;
+                                if (ep[b] != 0)
+                                {
+                                    emit[size_t(hop) * frame + 2 * m]     = done.x;
+                                    emit[size_t(hop) * frame + 2 * m + 1] = done.y;
+                                }
                             }
                         }
                         if (hop + 1 < hops)
                             __syncthreads();                            // buf is refilled by the next hop
                     }
                     #pragma unroll
-                    for (int i = 0; i < PER / 2; ++i)
-                        line[tid + i * T + hp] = tail[i];
+                    for (int b = 0; b < MULTI; ++b)
+                        if (on[b])
+                        {
+                            #pragma unroll
+                            for (int i = 0; i < PER / 2; ++i)
+                                reinterpret_cast<float2 *>(lp[b])[tid + i * T + hp] = tail[b][i];
+                        }
                     return;
                 }
                 v2f io[PER];
@@ -573,24 +595,38 @@ namespace
         const uint32_t frame = 1u << (b->chunk_rank - 1);
         const bool callbacks = splitter_has_callbacks(b);
         // few channels: one workgroup per handler (the forward transform is repeated, the device is filled)
-        const dim3 grid(b->channels, (!callbacks && b->handlers > 1 && b->channels * 2 <= 1024) ? b->handlers : 1);
+        dim3 grid(b->channels, (!callbacks && b->handlers > 1 && b->channels * 2 <= 1024) ? b->handlers : 1);
+        // several hops per launch with TWO handlers per workgroup sharing the forward transform: a quarter less arithmetic,
+        // half the waves per SIMD -- 27.7 against 24.4 us per block at 256 channels x 4 bands (rank 12), so only on request
+        // (profiles/r03_experiments/splitter_hops_per_launch.txt; the test runs it)
+        const char *const knob = getenv("MI_SPLITTER_BANDS_PER_WG");
+        const bool pairs = hops > 1 && grid.y > 1 && knob != nullptr && atoi(knob) == 2;
+        if (pairs)
+            grid.y = (b->handlers + 1) / 2;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         if (!callbacks)
         {
             #define MI_ARGS b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, \
                 (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos, hops
-            if (hops > 1 && grid.y > 1)
+            if (pairs)
             {
                 #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
-                    MI_LAUNCH((splitter_hop_kernel<LH, false, true, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                    MI_LAUNCH((splitter_hop_kernel<LH, false, true, 2>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                MI_LOGH_SWITCH(lh, MI_CALL)
+                #undef MI_CALL
+            }
+            else if (hops > 1 && grid.y > 1)
+            {
+                #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
+                    MI_LAUNCH((splitter_hop_kernel<LH, false, true, 1>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
             }
             else if (hops > 1)
             {
                 #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
-                    MI_LAUNCH((splitter_hop_kernel<LH, false, false, true>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
+                    MI_LAUNCH((splitter_hop_kernel<LH, false, false, 1>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
                 MI_LOGH_SWITCH(lh, MI_CALL)
                 #undef MI_CALL
             }

@@ -113,12 +113,19 @@ def test_hops_of_a_call_sharing_one_launch(gpu, rank, monkeypatch):
     monkeypatch.setenv("MI_SPLITTER_HOP_LAUNCHES", "1")
     one, _ = _gpu_run(gpu, rank, 0, 0.0, handlers, x, calls)
     monkeypatch.delenv("MI_SPLITTER_HOP_LAUNCHES")
+    # two handlers per workgroup sharing the forward transform (what banks that fill the device several times over get)
+    monkeypatch.setenv("MI_SPLITTER_BANDS_PER_WG", "2")
+    two, _ = _gpu_run(gpu, rank, 0, 0.0, handlers, x, calls)
+    odd, _ = _gpu_run(gpu, rank, 0, 0.0, handlers[:3] + [None, asym], x, calls)      # five slots: the last pair is half empty
+    monkeypatch.delenv("MI_SPLITTER_BANDS_PER_WG")
     for i, h in enumerate(handlers):
         if h is None:
             continue
         err = float(np.abs(got[i] - want[i]).max())
         assert err <= TOL * max(float(np.abs(x).max()), float(np.abs(want[i]).max())), (i, err)
         assert np.array_equal(got[i], one[i]), i
+        assert np.array_equal(got[i], two[i]), i
+        assert np.array_equal(got[i], odd[i if i < 3 else 4]), i
     # silence through the same path, then signal again
     bank = gpu.SplitterBank(C, rank, 1)
     bank.set_rank(rank); bank.bind_mask(0, asym)
