@@ -570,7 +570,7 @@ namespace
         #define MI_CALL(LH) fast = hop_in_registers<LH>
         MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
         #undef MI_CALL
-        if (!fast || (b->handlers > 1 && b->channels * 2 > 1024))
+        if (!fast)
             return false;
         for (uint32_t i = 0; i < b->handlers; ++i)
             if (b->has_sink[i] && b->h[i].mode != H_MASK)
@@ -595,7 +595,9 @@ namespace
         const uint32_t frame = 1u << (b->chunk_rank - 1);
         const bool callbacks = splitter_has_callbacks(b);
         // few channels: one workgroup per handler (the forward transform is repeated, the device is filled)
-        dim3 grid(b->channels, (!callbacks && b->handlers > 1 && b->channels * 2 <= 1024) ? b->handlers : 1);
+        // (the several-hops form at any channel count: 82 against 105 us per 4096-sample call at 1024 channels x 4 bands,
+        // tests/experiments/splitter_rate.py)
+        dim3 grid(b->channels, (!callbacks && b->handlers > 1 && (b->channels <= 512 || hops > 1)) ? b->handlers : 1);
         // several hops per launch with TWO handlers per workgroup sharing the forward transform: a quarter less arithmetic,
         // half the waves per SIMD -- 27.7 against 24.4 us per block at 256 channels x 4 bands (rank 12), so only on request
         // (profiles/r03_experiments/splitter_hops_per_launch.txt; the test runs it)
