@@ -149,6 +149,27 @@ def test_hops_of_a_call_sharing_one_launch(gpu, rank, monkeypatch):
     bank.close()
 
 
+def test_hops_sharing_one_launch_with_more_channels_than_the_one_hop_grid_takes(gpu, monkeypatch):
+    """Above 512 channels the one-hop launch runs one workgroup per channel (all handlers in turn); the several-hops launch
+    keeps one per (channel, handler).  Same floats either way, and the oracle's on the first and last channels."""
+    C, rank = 600, 9
+    F = 1 << (rank - 1)
+    rng = np.random.default_rng(4242)
+    lo = osp.lopass_fft_set(3000.0, -24.0, 48000.0, rank)
+    hi = osp.hipass_fft_set(3000.0, -24.0, 48000.0, rank)
+    calls = (3 * F, 5 * F)
+    x = (rng.standard_normal((C, sum(calls))) * 0.5).astype(np.float32)
+    got, _ = _gpu_run(gpu, rank, 0, 0.0, [lo, hi], x, calls)
+    monkeypatch.setenv("MI_SPLITTER_HOP_LAUNCHES", "1")
+    one, _ = _gpu_run(gpu, rank, 0, 0.0, [lo, hi], x, calls)
+    monkeypatch.delenv("MI_SPLITTER_HOP_LAUNCHES")
+    assert np.array_equal(got, one)
+    pick = [0, 1, C - 1]
+    want = _oracle_run(rank, 0, 0.0, [lo, hi], x[pick], calls)
+    for i in range(2):
+        assert float(np.abs(got[i][pick] - want[i]).max()) <= TOL * max(1.0, float(np.abs(want[i]).max()))
+
+
 def test_rank_below_max_rank_rebind_unbind_clear_and_silence(gpu):
     C, rank, n = 2, 9, 2048
     rng = np.random.default_rng(77)
