@@ -186,6 +186,7 @@ namespace
                 typedef const __attribute__((address_space(1))) float gfloat;
                 typedef __attribute__((address_space(1))) float gwfloat;
                 typedef const __attribute__((address_space(1))) v2f gv2f;
+                typedef __attribute__((address_space(1))) v2f gwv2f;
                 if constexpr (MULTI > 0)
                 {
                     // Several hops of a streaming call in ONE launch (host: every listening handler a mask; MULTI handlers per
@@ -212,7 +213,10 @@ namespace
                         lp[b] = one(lines + (size_t(hh) * channels + ch) * line_pitch);
                         #pragma unroll
                         for (int i = 0; i < PER / 2; ++i)
-                            tail[b][i] = on[b] ? reinterpret_cast<const float2 *>(lp[b])[tid + i * T + hp] : make_float2(0.0f, 0.0f);
+                        {
+                            const v2f t = on[b] ? reinterpret_cast<gv2f *>(lp[b])[tid + i * T + hp] : v2f{0.0f, 0.0f};
+                            tail[b][i] = make_float2(t.x, t.y);
+                        }
                     }
                     #pragma unroll
                     for (int i = 0; i < PER / 2; ++i)
@@ -263,7 +267,7 @@ namespace
                                 const float2 done = make_float2(fmaf(y0.x * scale, w0.x, tail[b][i].x), fmaf(y0.y * scale, w0.y, tail[b][i].y));
                                 tail[b][i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);
                                 if (hop + 1 == hops)                    // the handler's line as the call leaves it
-                                    reinterpret_cast<float2 *>(lp[b])[m] = done;
+                                    reinterpret_cast<gwv2f *>(lp[b])[m] = v2f{done.x, done.y};
                                 if (ep[b] != 0)
                                 {
                                     emit[size_t(hop) * frame + 2 * m]     = done.x;
@@ -280,7 +284,7 @@ namespace
                         {
                             #pragma unroll
                             for (int i = 0; i < PER / 2; ++i)
-                                reinterpret_cast<float2 *>(lp[b])[tid + i * T + hp] = tail[b][i];
+                                reinterpret_cast<gwv2f *>(lp[b])[tid + i * T + hp] = v2f{tail[b][i].x, tail[b][i].y};
                         }
                     return;
                 }
