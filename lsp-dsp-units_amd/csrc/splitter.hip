@@ -90,9 +90,12 @@ namespace
     // forward transform); workgroup y == 0 moves the analysis buffer on.
     // Fused streaming (ingest_n > 0): the `frame` samples that follow the hop are taken from `src` (NULL: silence) into the
     // new analysis buffer, and the frame every handler finishes goes straight to the caller's buffers.
-    // MULTI > 0: the several-hops form, MULTI handlers per workgroup (1: four waves per SIMD as the one-hop kernel has them)
+    // MULTI > 0: the several-hops form, MULTI handlers per workgroup.  One handler per workgroup: held to four waves per
+    // SIMD (128 VGPRs) -- 1024 workgroups of 256 threads are then ONE round on the device; left to itself the compiler
+    // lands on either side of that line from one change of the source to the next (102 / 135 / 146 VGPRs seen: 30 against
+    // 36 us per block).
     template <int LOGH, bool WRITE_SPEC, bool PER_BAND, int MULTI = 0>
-    __global__ __launch_bounds__(fplan<LOGH>::T, (MULTI == 1 && PER_BAND) ? 4 : (MULTI == 2) ? 2 : 1)
+    __global__ __launch_bounds__(fplan<LOGH>::T, (PER_BAND && MULTI <= 1) ? 4 : (MULTI == 2) ? 2 : 1)
     void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
                              uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
                              const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
@@ -106,7 +109,10 @@ namespace
         const int ch = blockIdx.x, tid = threadIdx.x;
         constexpr bool all = !PER_BAND;
         constexpr uint32_t BPW = (MULTI > 0) ? MULTI : 1;          // handlers per workgroup
-        const uint32_t h0 = all ? 0 : blockIdx.y * BPW, h1 = all ? handlers : (h0 + BPW < handlers ? h0 + BPW : handlers);
+        // (one handler per workgroup: the compiler must SEE that the handler loops run once -- as a min() with `handlers`
+        // the one-hop kernel took 152 registers instead of 102)
+        const uint32_t h0 = all ? 0 : blockIdx.y * BPW;
+        const uint32_t h1 = all ? handlers : (BPW == 1) ? h0 + 1 : (h0 + BPW < handlers ? h0 + BPW : handlers);
         const bool owner = all || (blockIdx.y == 0);
         // the frame is asked for before the handler descriptors are looked at (their little dependent loads would otherwise
         // cost an exposed latency before the frame's own: tests/experiments/analyzer_probe.hip found that pattern)
@@ -257,7 +263,7 @@ namespace
                             gfloat *const g = reinterpret_cast<gfloat *>(gp[b]);
                             gwfloat *const emit = reinterpret_cast<gwfloat *>(ep[b]);
                             __syncthreads();                            // everybody holds its pairs / is done with the handler before
-                            rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tix);
+                            rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return g[k]; /* the even part already, bind_mask */ }, tix);
                             mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tix, io);
                             #pragma unroll
                             for (int i = 0; i < PER / 2; ++i)
@@ -305,7 +311,11 @@ namespace
                     gfloat *const g = reinterpret_cast<gfloat *>(reinterpret_cast<uint64_t>(hd[h].mask + size_t(ch) * hd[h].mask_stride));
                     __syncthreads();                                    // everybody holds its pairs / is done with the handler before
                     // only the real part of the inverse is kept (pcomplex_c2r): a real gain acts through its even part
-                    rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return (k == 0 || k == H) ? g[k] : 0.5f * (g[k] + g[N - k]); }, tid);
+                    // (the gains are asked for here, not ahead of the forward transform: with their addresses known early the
+                    // compiler fetches them all at the top and the kernel needs 146 registers instead of 102)
+                    int tix = tid;
+                    asm volatile("" : "+v"(tix));
+                    rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return g[k]; /* the even part already, bind_mask */ }, tix);
                     mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tid, io);
                     float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
                     float *emit_ = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
@@ -927,8 +937,21 @@ int mi_splitter_bank_bind_mask(mi_splitter_bank_t *b, uint32_t handler, const fl
         h.mask_cap = need;
         b->desc_dirty = true;
     }
-    MI_HIP_CHECK(hipMemcpy2DAsync(h.d_mask, N * sizeof(float), mask, ((mask_stride == 0) ? N : mask_stride) * sizeof(float),
-                                  N * sizeof(float), rows, hipMemcpyHostToDevice, st));
+    // Only the real part of the inverse is kept (pcomplex_c2r), so a real gain acts through its even part
+    // (g[k] + g[N - k]) / 2: that is what goes to the device (the same float the kernels used to form per bin and hop; a
+    // table that is even already comes out as it went in, x + x and the halving are exact).
+    std::vector<float> even;
+    try { even.resize(need); } catch (...) { return MI_ENOMEM; }
+    for (size_t r = 0; r < rows; ++r)
+    {
+        const float *g = mask + r * ((mask_stride == 0) ? N : mask_stride);
+        float *e = even.data() + r * N;
+        e[0] = g[0];
+        e[N / 2] = g[N / 2];
+        for (size_t k = 1; k < N / 2; ++k)
+            e[k] = e[N - k] = 0.5f * (g[k] + g[N - k]);
+    }
+    MI_HIP_CHECK(hipMemcpyAsync(h.d_mask, even.data(), need * sizeof(float), hipMemcpyHostToDevice, st));
     MI_HIP_CHECK(hipStreamSynchronize(st));
     const size_t new_stride = (mask_stride == 0) ? 0 : N;
     if (h.mask_stride != new_stride)

@@ -120,6 +120,24 @@ def test_dynfilter_kernels_keep_the_cascades_in_registers(tmp_path):
 
 
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_splitter_hop_kernels_with_one_handler_per_workgroup_fit_four_waves_per_simd(tmp_path):
+    """1024 workgroups of 256 threads (256 channels x 4 bands, rank 12) are ONE round on the device only at four waves per
+    SIMD, i.e. with at most 128 VGPRs; twice in round 3 a harmless-looking change of the source took the one-hop kernel from
+    102 to 135 / 152 registers (30 -> 36 us per block).  No scratch either: the budget must be met without spilling."""
+    text = "\n".join(_isa(os.path.join(CSRC, "splitter.hip"), tmp_path))
+    seen = 0
+    for block in text[text.index("amdhsa.kernels:"):].split("  - .agpr_count:")[1:]:
+        name = re.search(r"\.name: *(\S+)", block).group(1)
+        m = re.search(r"splitter_hop_kernelILi(\d+)ELb0ELb1ELi([01])E", name)
+        if m is None or int(m.group(1)) > 12:
+            continue
+        seen += 1
+        vgprs = int(re.search(r"\.vgpr_count: *(\d+)", block).group(1))
+        scratch = int(re.search(r"\.private_segment_fixed_size: *(\d+)", block).group(1))
+        assert vgprs <= 128 and scratch == 0, (name, vgprs, scratch)
+    assert seen >= 14                                           # one-hop: 4 .. 12, several hops: the register path's sizes
+
+
 def test_no_kernel_parks_data_in_scratch(tmp_path):
     """A private segment means round trips to memory in the middle of a kernel.  Twice it was not a register spill but a
     POINTER picked at run time into a small local (the cascades of dynfilter.hip; `&myblk.x / .y / .z / .w` in the integrated
