@@ -699,7 +699,8 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
     if rank != 0:
         return None
     return _step_result("splitter", "FFTCrossover / SpectralSplitter, rank 12, 4 bands, %d channels per GPU, 4096-sample "
-                        "blocks (two transforms of 4096 points forward and eight back per channel and step)" % C,
+                        "blocks (algorithmically two transforms of 4096 points forward and eight back per channel and step; the "
+                        "launch runs one workgroup per channel and band, each with its own forward transform)" % C,
                         C, n, args.conv_steps, elapsed, world, 20.0)
 
 
