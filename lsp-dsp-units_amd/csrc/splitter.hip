@@ -87,7 +87,7 @@ namespace
     // [handlers][channels][line_pitch]; spec (only when WRITE_SPEC): [channels][N] complex.
     // gridDim.y == 1: the workgroup serves every handler of its channel (the input is read and transformed once);
     // gridDim.y == handlers: one handler each (few channels: more workgroups than CUs matter more than the repeated
-    // forward transform); workgroup y == 0 moves the analysis buffer on.
+    // forward transform; ceil(handlers / MULTI) in the several-hops form); workgroup y == 0 moves the analysis buffer on.
     // Fused streaming (ingest_n > 0): the `frame` samples that follow the hop are taken from `src` (NULL: silence) into the
     // new analysis buffer, and the frame every handler finishes goes straight to the caller's buffers.
     // MULTI > 0: the several-hops form, MULTI handlers per workgroup.  One handler per workgroup: held to four waves per
