@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--spec-channels", type=int, default=1024, help="analyzer channels per GPU (config 4: 8192 over 8 GPUs)")
     ap.add_argument("--call", type=int, default=0, help="convolver workload: also time a stream of calls of this many samples "
                     "(e.g. 256: what a plugin host does; a step is still one 4096-sample frame = 4096 / call calls)")
+    ap.add_argument("--no-stream-pair", action="store_true", help="meters row: skip the extra measurement with the two banks on "
+                    "a stream each (kernel profiles of the row then hold the one-stream launches only)")
     ap.add_argument("--conv-steps", type=int, default=200)
     ap.add_argument("--conv-warmup", type=int, default=10)
     return ap.parse_args()
@@ -729,7 +731,7 @@ def run_loudness(args, mi, torch, dist, rank, world, dev):
     # one-stream figure, never instead of it (events on the forking stream around 200 steps, best of five).
     s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
     best = None
-    for _ in range(5):
+    for _ in range(0 if args.no_stream_pair else 5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record(stream)
         s1.wait_event(e0); s2.wait_event(e0)
@@ -746,8 +748,8 @@ def run_loudness(args, mi, torch, dist, rank, world, dev):
         return None
     return _step_result("loudness", "LoudnessMeter + ILUFSMeter (K weighting), %d stereo meters each per GPU, 4096-sample "
                         "blocks" % M, M * K, n, args.conv_steps, elapsed, world, 8.0,
-                        extra={"banks_on_two_streams": {"ms_per_step": round(best, 5), "note": "each bank on a stream of its "
-                               "own; not the figure `value` is computed from"}})
+                        extra=None if best is None else {"banks_on_two_streams": {"ms_per_step": round(best, 5), "note": "each "
+                               "bank on a stream of its own; not the figure `value` is computed from"}})
 
 
 def run_dynfilter(args, mi, torch, dist, rank, world, dev):

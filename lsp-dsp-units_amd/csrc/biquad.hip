@@ -764,7 +764,25 @@ namespace
         __shared__ float s_sum[4];
         __shared__ uint32_t s_cnt[4];
         __shared__ float s_val;
+        __shared__ float s_chan[2 * 64 * NW];
         const uint32_t meter = blockIdx.x / ep.channels;
+        // what the meter's bookkeeping reads of EARLIER calls is asked for by every row's workgroup, underneath the wait for
+        // its own additions: the one that turns out to be the last has it in registers by then (ilufs_device.h)
+        const mi_meters::ilufs_early<64 * NW> early = mi_meters::ilufs_ask<64 * NW>(meter, ep.block, ep.cfg, ep.channels, ep.st, ep.hist,
+                                                                                   ep.size, ep.ms_int);
+        // The output run of the call's FIRST piece is the value held since the last call -- known now, to every row of the
+        // meter: each writes its share of the run here, in the shadow of the wait below, instead of the last one writing
+        // all of it on the tail of the launch (16 KB per meter and 4096-sample call).
+        const mi_meters::ilufs_piece first = ep.pieces.p[0];
+        const bool fill_early = ep.out != nullptr && ep.pieces.count > 0 && first.n > 0;
+        if (fill_early)
+        {
+            const uint32_t row = blockIdx.x - meter * ep.channels;
+            const uint32_t share = (((first.n + ep.channels - 1) / ep.channels) + 3u) & ~3u;
+            const uint32_t a = (row * share < first.n) ? row * share : first.n, b = (a + share < first.n) ? a + share : first.n;
+            if (b > a)
+                mi_meters::ilufs_fill<64 * NW>(ep.out + size_t(meter) * ep.out_stride + first.offset + a, b - a, early.me.loudness * ep.gain);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this row's additions are performed before it is counted in
         __syncthreads();
         if (threadIdx.x == 0)
@@ -778,7 +796,7 @@ namespace
         if (!s_last)
             return;
         mi_meters::ilufs_call_body<64 * NW, true>(meter, ep.block, sq.sums, ep.pieces, ep.cfg, ep.channels, ep.out, ep.out_stride,
-                                            ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val);
+                                            ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val, s_chan, early, fill_early);
     }
 
     template <int L, int NW, bool ALIGNED>

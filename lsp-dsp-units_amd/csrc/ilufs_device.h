@@ -72,11 +72,66 @@ namespace mi_meters
         }
     }
 
+    // What a meter's bookkeeping reads that the call in hand does NOT produce -- its state, the quarters of the block in
+    // hand, the channel settings, and the history as the call's first complete block will see it -- is asked for EARLY:
+    // by every workgroup of the filter's launch before it waits for its own sums to be performed (whichever turns out to
+    // be the meter's last has the answers by then), by ilufs_call_kernel at its start.  What is left behind the count is
+    // one round trip for the rows' sums; the bookkeeping itself then runs out of registers and LDS (it used to read its
+    // own stores back three times: the quarters, the state, the history entry it had just appended -- a microsecond each on
+    // the tail of the launch).
+    template <int TT>
+    struct ilufs_early
+    {
+        ilufs_state me;
+        float4      blk;                // tid < channels: the row's quarters
+        float       weight;
+        int         counts;
+        float       hv[VTH / TT];       // history entry j = tid + r TT of the first gate's window (the newest is not there yet)
+        int         hist_ok;            // ... valid: finite integration, at most one entry per virtual thread
+    };
+
+    template <int TT>
+    __device__ __forceinline__ ilufs_early<TT> ilufs_ask(uint32_t meter, const float *block, const chan_cfg *__restrict__ cfg,
+                                                         uint32_t channels, const ilufs_state *st, const float *hist,
+                                                         uint32_t size, uint32_t ms_int)
+    {
+        ilufs_early<TT> e;
+        const uint32_t tid = threadIdx.x;
+        e.me = st[meter];
+        e.blk = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        e.weight = 0.0f;
+        e.counts = 0;
+        if (tid < channels)
+        {
+            e.blk = *reinterpret_cast<const float4 *>(block + (size_t(meter) * channels + tid) * 4);
+            e.weight = cfg[tid].weight;
+            e.counts = cfg[tid].enabled != 0;
+        }
+        // the window of the gate that follows: count' = min(count + 1, ms_int) entries that end with the one the gate appends
+        const uint32_t count = (e.me.count + 1 < ms_int) ? e.me.count + 1 : ms_int;
+        uint32_t head = e.me.head + 1;
+        head = (head >= size) ? head - size : head;
+        uint32_t tail = head + size - count;
+        tail = (tail >= size) ? tail - size : tail;
+        e.hist_ok = (ms_int > 0 && count <= uint32_t(VTH) && count <= size && e.me.head < size) ? 1 : 0;
+        #pragma unroll
+        for (int r = 0; r < VTH / TT; ++r)
+        {
+            const uint32_t j = tid + r * TT;
+            uint32_t at = tail + j;
+            at = (at >= size) ? at - size : at;
+            e.hv[r] = (e.hist_ok && j + 1 < count) ? hist[size_t(meter) * size + at] : 0.0f;
+        }
+        return e;
+    }
+
     // mean of the last `count` history entries above the ABSOLUTE gate (compute_gated_loudness, ILUFSMeter.cpp:324-341:
     // its `threshold` argument is not used by the reference -- both gating stages compare with GATING_ABS_THRESH, so the
     // relative stage returns what the absolute stage returned; one pass gives the reference's result for both)
+    // early != nullptr: the window's entries are in registers (ilufs_ask), the newest of them is `newest`
     template <int TT>
-    __device__ float gated_mean(const float *hist, uint32_t size, uint32_t head, uint32_t count, float *s_sum, uint32_t *s_cnt)
+    __device__ float gated_mean(const float *hist, uint32_t size, uint32_t head, uint32_t count, float *s_sum, uint32_t *s_cnt,
+                                const float *early = nullptr, float newest = 0.0f)
     {
         static_assert(TT == 128 || TT == 256, "two or four real waves");
         constexpr int R = VTH / TT;
@@ -89,6 +144,17 @@ namespace mi_meters
         {
             s[r] = 0.0f;
             c[r] = 0;
+            if (early != nullptr)                           // (count <= VTH: one entry per virtual thread)
+            {
+                const uint32_t j = tid + r * TT;
+                const float l = (j + 1 == count) ? newest : early[r];
+                if (j < count && l > GATING_ABS_THRESH)
+                {
+                    s[r] += l;
+                    ++c[r];
+                }
+                continue;
+            }
             for (uint32_t j = tid + r * TT; j < count; j += VTH)
             {
                 const float l = hist[(tail + j) % size];
@@ -123,24 +189,39 @@ namespace mi_meters
         return r;
     }
 
-    // a gating block is complete (ILUFSMeter.cpp:402-458); the workgroup of the meter
+    // a gating block is complete (ILUFSMeter.cpp:402-458); the workgroup of the meter.  `me`: the meter's state, carried in
+    // registers from gate to gate of a call (every thread holds the same); blk / weight: the thread's row (tid < channels) as
+    // the pieces have left it; early: ilufs_ask's history window, for the first gate of a call.
     template <int TT>
-    __device__ float ilufs_gate(uint32_t meter, ilufs_state *st, float *hist, uint32_t size, uint32_t ms_int, const float *block,
+    __device__ float ilufs_gate(uint32_t meter, ilufs_state *st, ilufs_state &me, float *hist, uint32_t size, uint32_t ms_int,
+                                const float *block, const float4 blk, const float weight,
                                 const chan_cfg *__restrict__ cfg, uint32_t channels, float avg,
-                                float *s_sum, uint32_t *s_cnt, float &s_val)
+                                float *s_sum, uint32_t *s_cnt, float &s_val, float *s_chan /* [2 TT] */, const float *early)
     {
         constexpr int R = VTH / TT;
         const uint32_t tid = threadIdx.x;
         float *h = hist + size_t(meter) * size;
-        ilufs_state me = st[meter];
+        if (channels <= uint32_t(TT))                       // the rows' quarters are in their threads' registers
+        {
+            if (tid < channels)
+            {
+                s_chan[tid] = (blk.x + blk.y + blk.z + blk.w) * avg;
+                s_chan[TT + tid] = weight;
+            }
+            __syncthreads();
+        }
         if (tid == 0)
         {
             float loudness = 0.0f;                          // every channel's block enters, enabled or not (:407-414)
-            for (uint32_t c = 0; c < channels; ++c)
-            {
-                const float *blk = block + (size_t(meter) * channels + c) * 4;
-                loudness += cfg[c].weight * ((blk[0] + blk[1] + blk[2] + blk[3]) * avg);
-            }
+            if (channels <= uint32_t(TT))
+                for (uint32_t c = 0; c < channels; ++c)
+                    loudness += s_chan[TT + c] * s_chan[c];
+            else
+                for (uint32_t c = 0; c < channels; ++c)
+                {
+                    const float *blk4 = block + (size_t(meter) * channels + c) * 4;
+                    loudness += cfg[c].weight * ((blk4[0] + blk4[1] + blk4[2] + blk4[3]) * avg);
+                }
             s_val = loudness;
         }
         __syncthreads();
@@ -152,8 +233,9 @@ namespace mi_meters
             if (tid == 0)
                 h[me.head] = loudness;
             me.head = (me.head + 1) % size;
-            __syncthreads();
-            loudness = gated_mean<TT>(h, size, me.head, me.count, s_sum, s_cnt);
+            if (early == nullptr)
+                __syncthreads();                            // the new entry is read back with the others
+            loudness = gated_mean<TT>(h, size, me.head, me.count, s_sum, s_cnt, early, loudness);
         }
         else                                                // since the last clear(): running mean of the gated blocks
         {
@@ -207,46 +289,50 @@ namespace mi_meters
         return FRESH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
     }
 
+    // a run of the output row = the value being held (ILUFSMeter.cpp:386-387): 16-byte stores over its aligned middle
+    template <int TT>
+    __device__ __forceinline__ void ilufs_fill(float *o, uint32_t n, float v)
+    {
+        const uint32_t tid = threadIdx.x;
+        const uint32_t lead = uint32_t((4u - (uint32_t(reinterpret_cast<uintptr_t>(o) >> 2) & 3u)) & 3u);
+        const uint32_t head = (lead < n) ? lead : n, quads = (n - head) >> 2;
+        if (tid < head)
+            o[tid] = v;
+        float4 *o4 = reinterpret_cast<float4 *>(o + head);
+        for (uint32_t i = tid; i < quads; i += TT)
+            o4[i] = make_float4(v, v, v, v);
+        for (uint32_t i = head + 4u * quads + tid; i < n; i += TT)
+            o[i] = v;
+    }
+
     // The pieces of one call for one meter, by a workgroup of TT threads (s_sum, s_cnt: four cells of LDS each)
     template <int TT, bool FRESH = false>
     __device__ void ilufs_call_body(uint32_t meter, float *block, float *seg, const ilufs_pieces &pieces,
                                     const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
                                     ilufs_state *st, float gain, float *hist, uint32_t size, uint32_t ms_int, float avg,
-                                    float *s_sum, uint32_t *s_cnt, float &s_val)
+                                    float *s_sum, uint32_t *s_cnt, float &s_val, float *s_chan /* [2 TT] */,
+                                    const ilufs_early<TT> &early, bool first_filled = false /* the first piece's output run is written */)
     {
         const uint32_t tid = threadIdx.x;
-        // everything the pieces need from memory is asked for at once: the value being held, and for the thread of
-        // channel c the pieces' sums of squares, its quarters and whether it counts
-        float held = st[meter].loudness;
+        // the value being held, the row's quarters and whether it counts came early (ilufs_ask); what this call has
+        // produced -- the pieces' sums of squares of the thread's row -- is asked for now
+        ilufs_state me = early.me;
+        float held = me.loudness;
         const uint32_t myrow = meter * channels + tid;
-        float4 myseg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), myblk = myseg;
-        bool counts = false;
+        float4 myseg = make_float4(0.0f, 0.0f, 0.0f, 0.0f), myblk = early.blk;
+        const bool counts = early.counts != 0;
+        bool first_gate = true;
         if (tid < channels)
         {
             const float *ms = seg + size_t(myrow) * 4;
             myseg = FRESH ? make_float4(seg_load<true>(ms), seg_load<true>(ms + 1), seg_load<true>(ms + 2), seg_load<true>(ms + 3))
                           : *reinterpret_cast<const float4 *>(ms);
-            myblk = *reinterpret_cast<const float4 *>(block + size_t(myrow) * 4);
-            counts = cfg[tid].enabled != 0;
         }
         for (uint32_t k = 0; k < pieces.count; ++k)
         {
             const ilufs_piece pc = pieces.p[k];
-            if (out != nullptr && pc.n > 0)
-            {
-                const float v = held * gain;
-                float *o = out + size_t(meter) * out_stride + pc.offset;
-                // 16-byte stores over the aligned middle of the run
-                const uint32_t lead = uint32_t((4u - (uint32_t(reinterpret_cast<uintptr_t>(o) >> 2) & 3u)) & 3u);
-                const uint32_t head = (lead < pc.n) ? lead : pc.n, quads = (pc.n - head) >> 2;
-                if (tid < head)
-                    o[tid] = v;
-                float4 *o4 = reinterpret_cast<float4 *>(o + head);
-                for (uint32_t i = tid; i < quads; i += TT)
-                    o4[i] = make_float4(v, v, v, v);
-                for (uint32_t i = head + 4u * quads + tid; i < pc.n; i += TT)
-                    o[i] = v;
-            }
+            if (out != nullptr && pc.n > 0 && !(k == 0 && first_filled))
+                ilufs_fill<TT>(out + size_t(meter) * out_stride + pc.offset, pc.n, held * gain);
             if (pc.n > 0)
             {
                 if (tid < channels && counts)
@@ -269,7 +355,11 @@ namespace mi_meters
             }
             __syncthreads();
             if (pc.gate)
-                held = ilufs_gate<TT>(meter, st, hist, size, ms_int, block, cfg, channels, avg, s_sum, s_cnt, s_val);
+            {
+                held = ilufs_gate<TT>(meter, st, me, hist, size, ms_int, block, myblk, early.weight, cfg, channels, avg, s_sum, s_cnt,
+                                      s_val, s_chan, (first_gate && early.hist_ok) ? early.hv : nullptr);
+                first_gate = false;
+            }
             __syncthreads();
             if (pc.zero_part >= 0)
             {

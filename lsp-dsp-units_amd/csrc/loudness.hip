@@ -1037,9 +1037,11 @@ namespace
         __shared__ float s_sum[4];
         __shared__ uint32_t s_cnt[4];
         __shared__ float s_val;
+        __shared__ float s_chan[2 * LT];
         static_assert(LT == mi_meters::VTH, "one real thread per virtual one");
+        const mi_meters::ilufs_early<LT> early = mi_meters::ilufs_ask<LT>(blockIdx.x, block, cfg, channels, st, hist, size, ms_int);
         mi_meters::ilufs_call_body<LT>(blockIdx.x, block, seg, pieces, cfg, channels, out, out_stride, st, gain, hist, size,
-                                       ms_int, avg, s_sum, s_cnt, s_val);
+                                       ms_int, avg, s_sum, s_cnt, s_val, s_chan, early);
     }
 } // namespace
 

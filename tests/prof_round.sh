@@ -16,6 +16,6 @@ for W in biquad convolver equalizer spectral; do
     done
 done
 for W in stft dynfilter crossover splitter loudness; do       # row a10's streaming hop and the SURVEY 8f rows: kernel summary only
-    rocprofv3 --kernel-trace --stats -d $O/stats_$W --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline > $O/stats_$W.log 2>&1
+    rocprofv3 --kernel-trace --stats -d $O/stats_$W --output-format csv -- python3 $R/bench.py --workload $W --no-cpu-baseline --no-stream-pair > $O/stats_$W.log 2>&1
 done
 python3 $R/tests/prof_summarize.py $O $R/gpurun_out/profiles_$TAG $TAG
