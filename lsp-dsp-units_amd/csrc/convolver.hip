@@ -157,14 +157,26 @@ namespace
         const float2 *h0 = H + size_t(ch) * P * M;
         const float2 *yt = (Yt != nullptr) ? Yt + size_t(ch) * M : nullptr;
         float *a = acc + size_t(ch) * 2 * B;
+        // 512-point transforms and up: the frame goes into the forward transform in registers and comes out of the inverse in
+        // registers (fft_lds REG_IN / REG_OUT), and split + product + merge are ONE pass over LDS (real_split_filter_merge):
+        // four LDS round trips and four barriers less per frame
+        constexpr bool REGS = !fplan<LOGM>::radix16 && (mi_fft::plan<LOGM>::T == mi_fft::plan<LOGM>::TB);
+        // bin of register slot i: in order (REGS: by pairs -- slot i < NPT holds bin k = tid + i T, slot i + NPT its partner
+        // M - k, the partner of the packed bin 0 being M / 2)
+        auto bin_of = [&](int i) -> int {
+            if (!REGS)
+                return tid + i * T;
+            const int k = tid + (i % NPT) * T;
+            return (i < NPT) ? k : (k == 0) ? M / 2 : M - k;
+        };
         float2 hreg[LEAN ? 1 : KPT], yreg[LEAN ? 1 : KPT], a0[LEAN ? 1 : NPT], a1[LEAN ? 1 : NPT];
         if (!LEAN)
         {
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
             {
-                hreg[i] = h0[tid + i * T];
-                yreg[i] = (yt != nullptr) ? yt[tid + i * T] : make_float2(0.0f, 0.0f);
+                hreg[i] = h0[bin_of(i)];
+                yreg[i] = (yt != nullptr) ? yt[bin_of(i)] : make_float2(0.0f, 0.0f);
             }
             #pragma unroll
             for (int i = 0; i < NPT; ++i)
@@ -175,9 +187,6 @@ namespace
         }
         MI_CPROBE(1);
         rf.prepare();
-        // 512-point transforms and up: the frame goes into the forward transform in registers and comes out of the inverse in
-        // registers (fft_lds REG_IN / REG_OUT): two LDS round trips and two barriers less per frame
-        constexpr bool REGS = !fplan<LOGM>::radix16 && (mi_fft::plan<LOGM>::T == mi_fft::plan<LOGM>::TB);
         v2f io[KPT];
         if constexpr (REGS)
         {
@@ -185,7 +194,6 @@ namespace
             for (int i = 0; i < KPT; ++i)
                 io[i] = v2f{xin[i].x, xin[i].y};
             mi_fft::fft_lds<LOGM, false, true, false>(buf, scr, rf.ft, tid, io);
-            mi_fft::real_split<LOGM>(buf, rf.rt, tid);
         }
         else
         {
@@ -200,15 +208,21 @@ namespace
         // the frame's image enters the ring; its product with the head partition plus the pending tail goes back
         const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer((R > 0) ? ring + (size_t(ch) * R + slot) * M : nullptr,
                                                            (R > 0) ? unsigned(M * sizeof(float2)) : 0u);
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-        {
-            const int k = tid + i * T;
-            const float2 xk = buf[k];
+        // bin k of the image: into the ring, times the head partition's, plus the pending tail's
+        auto through = [&](int slot_i, int k, float2 xk) -> float2 {
             mi::wt_store(rring, k * int(sizeof(float2)), xk);        // dropped by the bounds check when there is no ring
-            const float2 hk = LEAN ? h0[k] : hreg[i];
-            const float2 yk = LEAN ? ((yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f)) : yreg[i];
-            buf[k] = cadd(image_mul(xk, hk, k), yk);
+            const float2 hk = LEAN ? h0[k] : hreg[slot_i];
+            const float2 yk = LEAN ? ((yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f)) : yreg[slot_i];
+            return cadd(image_mul(xk, hk, k), yk);
+        };
+        if constexpr (!REGS)
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = tid + i * T;
+                buf[k] = through(i, k, buf[k]);
+            }
         }
         // The image went to the ring with write-through (sc1) stores; EVERY storing wave drains them (vmcnt 0) before it
         // arrives at the barrier behind which thread 0 moves the counter.  The wait is written out: a workgroup-scope
@@ -216,17 +230,41 @@ namespace
         // counter could overtake another wave's image stores (MI355X_MICROARCH.md, valid hand-off forms, condition 3).
         // Inline asm: the waitcnt-insertion pass cannot drop it (build check: tests/test_abi.py greps the ISA for it).
         // NOT a device-scope release fence: that writes back the whole L2 of the XCD.
-        if (done != nullptr)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // Split, product and merge: ONE pass over LDS where the frame is the launch (conv_frame_kernel: equalizer FIR 9.8 ->
+        // 9.2 us per block), three passes in the frame ROLE of conv_step_kernel, whose operands are loaded where they are used
+        // (LEAN) -- fused there the step measured 44.6 against 44.1 us (profiles/r03_experiments/conv_frame_one_pass.txt)
+        if constexpr (REGS && LEAN)
+        {
+            mi_fft::real_split<LOGM>(buf, rf.rt, tid);
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = bin_of(i);
+                buf[k] = through(i, k, buf[k]);
+            }
+            if (done != nullptr)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            mi_fft::real_merge<LOGM>(buf, rf.rt, tid);
+        }
+        else if constexpr (REGS)
+        {
+            // (the pass ends with the barrier; the wait for the image stores stands in front of it)
+            mi_fft::real_split_filter_merge<LOGM>(buf, rf.rt, tid,
+                [&](int i, int k, float2 xk, bool partner) -> float2 { return through(partner ? i + NPT : i, k, xk); },
+                [&]() { if (done != nullptr) asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); });
+        }
+        else
+        {
+            if (done != nullptr)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
         if (done != nullptr && tid == 0)
             __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MI_CPROBE(3);
         if constexpr (REGS)
-        {
-            mi_fft::real_merge<LOGM>(buf, rf.rt, tid);
             mi_fft::fft_lds<LOGM, true, false, true>(buf, scr, rf.ft, tid, io);
-        }
         else
             rf.inverse(buf, scr, tid);
         MI_CPROBE(4);

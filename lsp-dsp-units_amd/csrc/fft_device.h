@@ -459,6 +459,50 @@ namespace mi_fft
         __syncthreads();
     }
 
+    // real_split, a function of the image's bins, real_merge -- in ONE pass over the buffer: thread by thread the pair
+    // (Z_k, Z_(M-k)) becomes the image's (X_k, X_(M-k)), filt(k, X_k) and filt(M - k, X_(M-k)) give the bins that go back
+    // (k = 0: the packed (DC, Nyquist) bin; k = M / 2 with it), and the merged pair is stored where the pair came from.  The
+    // same arithmetic as the three passes, two barriers and two trips through LDS less.  Synchronises behind the stores.
+    // (`arrive` runs in every thread in front of the closing barrier: what a caller must have waited for before the
+    // workgroup as a whole moves on)
+    template <int LOGM, class F, class A>
+    __device__ __forceinline__ void real_split_filter_merge(float2 *buf, const real_tw<LOGM> &rt, int tid, F filt, A arrive)
+    {
+        using P = plan<LOGM>;
+        constexpr int M = P::N, T = P::T;
+        #pragma unroll
+        for (int i = 0; i < real_tw<LOGM>::ITER; ++i)
+        {
+            const int k = tid + i * T;
+            if (k >= M / 2)
+                continue;
+            if (k == 0)
+            {
+                const float2 z0 = buf[0];
+                const float2 y0 = filt(i, 0, make_float2(z0.x + z0.y, z0.x - z0.y), false);
+                const float2 yh = filt(i, M / 2, cconj(buf[M / 2]), true);
+                buf[0] = make_float2(y0.x + y0.y, y0.x - y0.y);
+                buf[M / 2] = make_float2(2.0f * yh.x, -2.0f * yh.y);
+            }
+            else
+            {
+                const v2f zk = ld2(buf + k), zm = ld2(buf + M - k);
+                const v2f wh = v2f{0.5f * rt.w[i].x, 0.5f * rt.w[i].y};
+                const v2f eh = padd_cj(zk, zm) * v2f{0.5f, 0.5f};
+                const v2f ws = pmul<false>(wh, psub_cj(zk, zm));
+                const v2f xk = padd_i<false>(eh, ws), xm = pconj_add_i<true>(eh, ws);
+                const float2 yk = filt(i, k, make_float2(xk.x, xk.y), false), ym = filt(i, M - k, make_float2(xm.x, xm.y), true);
+                const v2f w  = v2f{rt.w[i].x, rt.w[i].y};
+                const v2f e  = padd_cj(v2f{yk.x, yk.y}, v2f{ym.x, ym.y});
+                const v2f wo = pmul<true>(w, psub_cj(v2f{yk.x, yk.y}, v2f{ym.x, ym.y}));
+                st2(buf + k, padd_i<true>(e, wo));
+                st2(buf + M - k, pconj_add_i<false>(e, wo));
+            }
+        }
+        arrive();
+        __syncthreads();
+    }
+
     // A 2M-point real transform pair through M-point complex transforms: twiddles in registers, two LDS buffers.
     template <int LOGM>
     struct real_fft
