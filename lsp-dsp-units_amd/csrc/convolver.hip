@@ -245,6 +245,8 @@ namespace
             if (done != nullptr)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
+            if (done != nullptr && tid == 0)                // (the tail role may go on while this one merges)
+                __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             mi_fft::real_merge<LOGM>(buf, rf.rt, tid);
         }
         else if constexpr (REGS)
@@ -260,7 +262,7 @@ namespace
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();
         }
-        if (done != nullptr && tid == 0)
+        if (!(REGS && LEAN) && done != nullptr && tid == 0)
             __hip_atomic_fetch_add(done + ch, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         MI_CPROBE(3);
         if constexpr (REGS)
