@@ -662,13 +662,22 @@ namespace
         float *a  = acc + size_t(ch) * 2 * B + off;
         const float2 *hs = Hs + size_t(ch) * Ps * M;
         float2 *rg = sring + size_t(ch) * Ps * M;
-        float2 xk[KPT];
+        // Register slots hold the image's bins by the PAIRS of the real transform's split (fft_device.h
+        // real_split_filter_merge): slot i < KPT / 2 is bin k = tid + i T, slot i + KPT / 2 its partner M - k (M / 2 for the
+        // packed bin 0) -- the thread that holds a pair splits it, takes it through the products and merges it again.
+        auto bin_of = [&](int slot) -> int {
+            const int k = tid + (slot % (KPT / 2)) * T;
+            return (slot < KPT / 2) ? k : (k == 0) ? M / 2 : M - k;
+        };
         // Everything the ring's debt needs that does not depend on this block is asked for NOW: the small partitions' images
         // and the images of the frame's earlier blocks (a wave has 512 registers to itself: up to 2 x 15 x 4
         // values in flight under the transforms instead of fifteen dependent round trips to L2 behind them).
         constexpr int PMAX = 15;                                            // B / SB - 1 at the largest frame
         const int pmax = (!next1 || !debt) ? 0 : (kblk + 1 < Ps - 1) ? kblk + 1 : Ps - 1;
-        float2 hreg[PMAX][KPT], xreg[PMAX][KPT];
+        float2 hreg[PMAX][KPT], xreg[PMAX][KPT], h0reg[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            h0reg[i] = outs ? hs[bin_of(i)] : make_float2(0.0f, 0.0f);
         #pragma unroll
         for (int p = 1; p <= PMAX; ++p)
             if (p <= pmax)
@@ -676,9 +685,9 @@ namespace
                 #pragma unroll
                 for (int i = 0; i < KPT; ++i)
                 {
-                    hreg[p - 1][i] = hs[size_t(p) * M + tid + i * T];
+                    hreg[p - 1][i] = hs[size_t(p) * M + bin_of(i)];
                     if (p >= 2)
-                        xreg[p - 1][i] = rg[size_t(kblk + 1 - p) * M + tid + i * T];
+                        xreg[p - 1][i] = rg[size_t(kblk + 1 - p) * M + bin_of(i)];
                 }
             }
         // ... and so is what the results are added to (acc: written by earlier launches of the stream only)
@@ -697,7 +706,8 @@ namespace
                     accw[i] = *reinterpret_cast<const float2 *>(a + 2 * SB + 2 * n);
             }
         }
-        // SB real samples = SB / 2 pairs, zero-padded to 2 SB
+        // SB real samples = SB / 2 pairs, zero-padded to 2 SB: straight into the transform's registers (fft_lds REG_IN)
+        v2f io[KPT];
         #pragma unroll
         for (int i = 0; i < KPT; ++i)
         {
@@ -715,75 +725,58 @@ namespace
                 else
                     v = *reinterpret_cast<const float2 *>(fr + 2 * n);
             }
-            buf[n] = v;
+            io[i] = v2f{v.x, v.y};
         }
-        __syncthreads();
-        rf.forward(buf, scr, tid);
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-        {
-            xk[i] = buf[tid + i * T];
-            if (next2 && (outs || !FULL))                                   // (nobody reads the last two blocks' images)
-                rg[size_t(kblk) * M + tid + i * T] = xk[i];
-        }
+        mi_fft::fft_lds<LOGS, false, true, false>(buf, scr, rf.ft, tid, io);
         const float scale = 1.0f / float(2 * M);
-        if (!FULL && !next1)
-            return;                                                         // the frame's last block: the commit settles the rest
-        // what goes through the inverse transform: the output wave's Hs_0 x, or what the frame's blocks owe block k + 1
-        // (p = 1 is this block's own image)
-        float2 t[KPT];
-        float dc = 0.0f, ny = 0.0f;
-        if (outs)
-        {
-            #pragma unroll
-            for (int i = 0; i < KPT; ++i)
-                t[i] = image_mul(xk[i], hs[tid + i * T], tid + i * T);
-        }
-        else
-        {
-            #pragma unroll
-            for (int i = 0; i < KPT; ++i)
-                t[i] = make_float2(0.0f, 0.0f);
-            #pragma unroll
-            for (int p = 1; p <= PMAX; ++p)
-                if (p <= pmax)
-                {
-                    #pragma unroll
-                    for (int i = 0; i < KPT; ++i)
+        const bool keep = next2 && (outs || !FULL);                         // (nobody reads the last two blocks' images)
+        // ONE pass over the transform's output: the pair is split into the image's bins, the image goes to the ring, and what
+        // goes through the inverse transform -- the output wave's Hs_0 x, or what the frame's blocks owe block k + 1 (p = 1
+        // is this block's own image) -- is formed and merged in place.  (Round 3, first form: forward with its split pass,
+        // the image read back, the products, a pass to put them into LDS, inverse with its merge pass -- five barriers and
+        // five trips through LDS more on a lone wave's path.)
+        mi_fft::real_split_filter_merge<LOGS>(buf, rf.rt, tid,
+            [&](int i, int k, float2 x0, bool partner) -> float2 {
+                const int slot = partner ? i + KPT / 2 : i;
+                if (keep)
+                    rg[size_t(kblk) * M + k] = x0;
+                if (outs)
+                    return image_mul(x0, h0reg[slot], k);
+                float2 t = make_float2(0.0f, 0.0f);
+                #pragma unroll
+                for (int p = 1; p <= PMAX; ++p)
+                    if (p <= pmax)
                     {
-                        const int k = tid + i * T;
-                        const float2 h = hreg[p - 1][i];
-                        const float2 x = (p == 1) ? xk[i] : xreg[p - 1][i];
-                        t[i].x = fmaf(x.x, h.x, fmaf(-x.y, h.y, t[i].x));
-                        t[i].y = fmaf(x.x, h.y, fmaf(x.y, h.x, t[i].y));
-                        if (k == 0)
+                        const float2 h = hreg[p - 1][slot];
+                        const float2 x = (p == 1) ? x0 : xreg[p - 1][slot];
+                        if (k == 0)                                         // bin 0 packs (DC, Nyquist)
                         {
-                            dc = fmaf(x.x, h.x, dc);
-                            ny = fmaf(x.y, h.y, ny);
+                            t.x = fmaf(x.x, h.x, t.x);
+                            t.y = fmaf(x.y, h.y, t.y);
+                        }
+                        else
+                        {
+                            t.x = fmaf(x.x, h.x, fmaf(-x.y, h.y, t.x));
+                            t.y = fmaf(x.x, h.y, fmaf(x.y, h.x, t.y));
                         }
                     }
-                }
-        }
-        __syncthreads();
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-        {
-            const int k = tid + i * T;
-            buf[k] = (!outs && k == 0) ? make_float2(dc, ny) : t[i];
-        }
-        __syncthreads();
-        rf.inverse(buf, scr, tid);
+                return t;
+            }, [] {});
+        if (!FULL && !next1)
+            return;                                                         // the frame's last block: the commit settles the rest
+        mi_fft::fft_lds<LOGS, true, false, true>(buf, scr, rf.ft, tid, io);
+        // (io[i]: pair n = tid + i T of the first half, io[i + KPT / 2]: pair n + M / 2 of the second)
         if (outs)
         {
             float *o = out + size_t(ch) * out_stride;
             #pragma unroll
             for (int i = 0; i < KPT / 2; ++i)
             {
-                const int n = tid + i * T;                                  // pair n of the first half, pair n + M/2 of the second
-                const float2 y0 = buf[n], p0 = accv[i];
-                o[2 * n]     = fmaf(y0.x, scale, p0.x);
-                o[2 * n + 1] = fmaf(y0.y, scale, p0.y);
-                yx[n] = buf[n + M / 2];
+                const int n = tid + i * T;
+                const float2 p0 = accv[i];
+                o[2 * n]     = fmaf(io[i].x, scale, p0.x);
+                o[2 * n + 1] = fmaf(io[i].y, scale, p0.y);
+                yx[n] = make_float2(io[i + KPT / 2].x, io[i + KPT / 2].y);
             }
         }
         if (FULL)
@@ -794,7 +787,7 @@ namespace
         for (int i = 0; i < KPT / 2; ++i)
         {
             const int n = tid + i * T;
-            const float2 t0 = buf[n], t1 = buf[n + M / 2];
+            const float2 t0 = make_float2(io[i].x, io[i].y), t1 = make_float2(io[i + KPT / 2].x, io[i + KPT / 2].y);
             const float2 yhi = FULL ? yx[n] : make_float2(0.0f, 0.0f);
             float2 *a1 = reinterpret_cast<float2 *>(a + SB + 2 * n), *a2 = reinterpret_cast<float2 *>(a + 2 * SB + 2 * n);
             const float2 v1 = accv[i];
