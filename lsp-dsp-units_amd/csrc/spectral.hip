@@ -573,6 +573,23 @@ namespace
             part[j][b] = s;
         }
         __syncthreads();
+        if (nblocks <= 64)
+        {
+            // Up to 64 block sums per bin (1024 channels): the same binary tree -- element j, a multiple of 2 s, takes in element
+            // j + s -- inside ONE wave per bin by xor shuffles (lane j holds block j; a block that is not there enters as + 0,
+            // which changes no sum of non-negative terms), instead of six rounds over LDS with a barrier behind each.
+            for (uint32_t bb = w; bb < REDUCE_BINS; bb += WAVES)
+            {
+                float v = (lane < nblocks) ? part[lane][bb] : 0.0f;
+                #pragma unroll
+                for (int s = 1; s < 64; s <<= 1)
+                    v += __shfl_xor(v, s);
+                const uint32_t kk = group * REDUCE_BINS + bb;
+                if (lane == 0 && kk < bins)
+                    out[kk] = (env != nullptr) ? v * env[kk] : v;
+            }
+            return;
+        }
         for (uint32_t s = 1; s < nblocks; s <<= 1)
         {
             // element j (a multiple of 2s) takes in element j + s
