@@ -149,7 +149,10 @@ namespace
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
 #error "biquad.hip relies on gfx950 (CDNA4) behaviour: wave64 DPP row/bank semantics and arrival-counting s_barrier"
 #endif
-    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, bool ROLES = false>
+    // ROWS > 1 (SUMSQ only): the workgroup runs ROWS consecutive rows side by side, NW waves each -- for the integrated meter,
+    // whose rows then leave their sums of squares in LDS (sq.sums points there) for the same workgroup's bookkeeping.  The
+    // barriers are the workgroup's: the rows must have the same number of sections and none of them may be switched off.
+    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, bool ROLES = false, int ROWS = 1>
     __device__ __forceinline__
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
@@ -164,12 +167,18 @@ namespace
         static_assert(!ROLES || (NW == 2 && !CHAIN && !SUMSQ), "the two-role form is the plain kernel with two waves");
         constexpr int TAB_QL = TAB_PQ + 2 * L;
 
-        __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
-        __shared__ float2 sstate[2][SG];                    // state carried between super-blocks, by parity
-        __shared__ float2 xchg[2][ROLES ? 1 : SG][NW];      // end state of every wave's sub-block
+        static_assert(ROWS == 1 || (SUMSQ && !CHAIN && !ROLES), "rows side by side: the meters' form only");
+        __shared__ __attribute__((aligned(16))) float sx_rows[ROWS][NW * 64 * PITCH];
+        __shared__ float2 sstate_rows[ROWS][2][SG];         // state carried between super-blocks, by parity
+        __shared__ float2 xchg_rows[ROWS][2][ROLES ? 1 : SG][NW];   // end state of every wave's sub-block
+        // (one row per workgroup: `slot` is the constant 0 and everything below is what it was)
+        const int slot = (ROWS > 1) ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) / NT) : 0;
+        float *const sx_all = sx_rows[slot];
+        float2 (*const sstate)[SG] = sstate_rows[slot];
+        float2 (*const xchg)[ROLES ? 1 : SG][NW] = xchg_rows[slot];
 
-        const int ch   = blockIdx.x;
-        const int tid  = threadIdx.x;
+        const int ch   = int(blockIdx.x) * ROWS + slot;
+        const int tid  = int(threadIdx.x) - slot * NT;
         const int t    = tid & 63;                          // lane
         const int wv   = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int l16  = t & 15;
@@ -695,7 +704,8 @@ namespace
         }
         if (SUMSQ)
         {
-            __shared__ float red[NW][4];
+            __shared__ float red_rows[ROWS][NW][4];
+            float (*const red)[4] = red_rows[slot];
             #pragma unroll
             for (int j = 0; j < 4; ++j)
             {
@@ -712,9 +722,12 @@ namespace
                 float v = red[0][tid];
                 for (int w = 1; w < NW; ++w)
                     v += red[w][tid];
-                // one addition per cell and launch (the order of the launches is the stream's): an atomic without a
-                // return value does not hold the workgroup up for the round trip a read-modify-write would
-                atomicAdd(&sq.sums[size_t(ch) * 4 + tid], v);
+                if constexpr (ROWS > 1)
+                    sq.sums[slot * 4 + tid] = v;            // LDS of this workgroup: its bookkeeping follows
+                else
+                    // one addition per cell and launch (the order of the launches is the stream's): an atomic without a
+                    // return value does not hold the workgroup up for the round trip a read-modify-write would
+                    atomicAdd(&sq.sums[size_t(ch) * 4 + tid], v);
             }
         }
         MI_PROBE(15);
@@ -797,6 +810,35 @@ namespace
             return;
         mi_meters::ilufs_call_body<64 * NW, true>(meter, ep.block, sq.sums, ep.pieces, ep.cfg, ep.channels, ep.out, ep.out_stride,
                                             ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val, s_chan, early, fill_early);
+    }
+
+    // The stereo meter in ONE workgroup: its two rows run the weighting filter side by side (biquad_body ROWS = 2), leave
+    // their sums of squares in LDS, and the workgroup -- 256 threads, one per virtual thread of the bookkeeping -- goes
+    // straight on with the meter's pieces.  No hand-over through memory at all: the riding form above pays three dependent
+    // trips to the memory side on the tail of its launch (additions performed, count fetched, the other row's sums fetched).
+    // Host: two channels per meter, every row enabled, the same number of sections in every row.
+    template <int L, int NW, bool ALIGNED>
+    __global__ __launch_bounds__(2 * 64 * NW, 1)
+    void biquad_sumsq_ilufs_pair_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const float *__restrict__ tab,
+                                        float *state, const uint32_t *__restrict__ nsec, int max_sec, const sumsq_args sq,
+                                        const mi_meters::ilufs_epilogue ep)
+    {
+        constexpr int TT = 2 * 64 * NW;
+        static_assert(TT == mi_meters::VTH, "one real thread per virtual one");
+        __shared__ float s_seg[2 * 4];
+        __shared__ float s_sum[4];
+        __shared__ uint32_t s_cnt[4];
+        __shared__ float s_val;
+        __shared__ float s_chan[2 * TT];
+        const uint32_t meter = blockIdx.x;
+        // what the bookkeeping reads of earlier calls is asked for now and arrives underneath the filter
+        const mi_meters::ilufs_early<TT> early = mi_meters::ilufs_ask<TT>(meter, ep.block, ep.cfg, 2u, ep.st, ep.hist, ep.size, ep.ms_int);
+        sumsq_args local = sq;
+        local.sums = s_seg;
+        biquad_body<L, NW, ALIGNED, false, true, false, 2>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), local);
+        __syncthreads();
+        mi_meters::ilufs_call_body<TT, false, true>(meter, ep.block, s_seg, ep.pieces, ep.cfg, 2u, ep.out, ep.out_stride,
+                                                    ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val, s_chan, early);
     }
 
     template <int L, int NW, bool ALIGNED>
@@ -944,13 +986,24 @@ namespace
     template <int L, int NW>
     hipError_t launch(mi_biquad_bank *b, float *out, const float *in, size_t out_stride,
                       size_t in_stride, int n, bool aligned, const float *tab, hipStream_t st, const sumsq_args *sq = nullptr,
-                      const mi_meters::ilufs_epilogue *ep = nullptr)
+                      const mi_meters::ilufs_epilogue *ep = nullptr, bool pair = false /* the stereo meter in one workgroup */)
     {
         const dim3 grid(b->channels), block(64 * NW);
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         if constexpr (L == 16 && NW == 2)
         {
+            if (sq != nullptr && ep != nullptr && pair)
+            {
+                const dim3 pgrid(b->channels / 2), pblock(2 * 64 * NW);
+                if (aligned)
+                    MI_LAUNCH((biquad_sumsq_ilufs_pair_kernel<L, NW, true>), pgrid, pblock, 0, st, ev0, ev1, in, in_stride, n, tab,
+                              b->d_state, b->d_nsec, int(b->max_sec), *sq, *ep);
+                else
+                    MI_LAUNCH((biquad_sumsq_ilufs_pair_kernel<L, NW, false>), pgrid, pblock, 0, st, ev0, ev1, in, in_stride, n, tab,
+                              b->d_state, b->d_nsec, int(b->max_sec), *sq, *ep);
+                return hipGetLastError();
+            }
             if (sq != nullptr && ep != nullptr)
             {
                 if (aligned)
@@ -1311,6 +1364,11 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
     const bool ride = sq != nullptr && ep != nullptr && !use_small && tail == 0 && body < (size_t(1) << 28) && !no_ride;
     if (rode != nullptr)
         *rode = ride;
+    // the stereo meter in one workgroup (biquad_sumsq_ilufs_pair_kernel): rows in pairs, all of them enabled and alike in
+    // their number of sections (the workgroup's barriers are shared by its two rows)
+    bool pair_ok = ride && ep->channels == 2 && (b->channels % 2) == 0 && getenv("MI_ILUFS_ROWS_APART") == nullptr;
+    for (uint32_t c = 0; pair_ok && c < b->channels; ++c)
+        pair_ok = !b->row_off[c] && b->nsec[c] == b->nsec[0];
     size_t done = 0;
     while (done < body)
     {
@@ -1353,7 +1411,8 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
             e = hipGetLastError();
         }
         else
-            e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq, ride ? ep : nullptr);
+            e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq, ride ? ep : nullptr,
+                              ride && pair_ok);
         MI_HIP_CHECK(e);
         done += step;
     }

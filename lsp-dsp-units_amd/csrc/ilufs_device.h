@@ -306,7 +306,9 @@ namespace mi_meters
     }
 
     // The pieces of one call for one meter, by a workgroup of TT threads (s_sum, s_cnt: four cells of LDS each)
-    template <int TT, bool FRESH = false>
+    // LOCAL: `seg` is this workgroup's own LDS, [channels][4], left there by the rows' filters a barrier ago (nothing to take
+    // from memory and nothing to clear behind)
+    template <int TT, bool FRESH = false, bool LOCAL = false>
     __device__ void ilufs_call_body(uint32_t meter, float *block, float *seg, const ilufs_pieces &pieces,
                                     const chan_cfg *__restrict__ cfg, uint32_t channels, float *out, size_t out_stride,
                                     ilufs_state *st, float gain, float *hist, uint32_t size, uint32_t ms_int, float avg,
@@ -324,8 +326,9 @@ namespace mi_meters
         bool first_gate = true;
         if (tid < channels)
         {
-            const float *ms = seg + size_t(myrow) * 4;
-            myseg = FRESH ? make_float4(seg_load<true>(ms), seg_load<true>(ms + 1), seg_load<true>(ms + 2), seg_load<true>(ms + 3))
+            const float *ms = LOCAL ? seg + size_t(tid) * 4 : seg + size_t(myrow) * 4;
+            myseg = LOCAL ? make_float4(ms[0], ms[1], ms[2], ms[3])
+                  : FRESH ? make_float4(seg_load<true>(ms), seg_load<true>(ms + 1), seg_load<true>(ms + 2), seg_load<true>(ms + 3))
                           : *reinterpret_cast<const float4 *>(ms);
         }
         for (uint32_t k = 0; k < pieces.count; ++k)
@@ -346,7 +349,7 @@ namespace mi_meters
                     myblk.w = (pc.part == 3) ? now : myblk.w;
                     block[size_t(myrow) * 4 + pc.part] = now;
                 }
-                for (uint32_t c = tid + TT; c < channels; c += TT)         // meters of more channels than threads
+                for (uint32_t c = tid + TT; !LOCAL && c < channels; c += TT)       // meters of more channels than threads
                     if (cfg[c].enabled)
                     {
                         const uint32_t row = meter * channels + c;
@@ -375,7 +378,7 @@ namespace mi_meters
             }
             __syncthreads();
         }
-        for (uint32_t i = tid; i < channels * 4; i += TT)   // consumed: the next call's filter launch adds to zeros
+        for (uint32_t i = tid; !LOCAL && i < channels * 4; i += TT)   // consumed: the next call's filter launch adds to zeros
             seg[size_t(meter) * channels * 4 + i] = 0.0f;
     }
 #endif

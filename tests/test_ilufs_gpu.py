@@ -281,3 +281,48 @@ def test_bookkeeping_riding_on_the_filter_launch_equals_two_launches(gpu, monkey
     assert np.array_equal(y0, y1) and np.array_equal(l0, l1)
     for a, b in zip(h0, h1):
         assert np.array_equal(a, b)
+
+
+@pytest.mark.parametrize("mode", ["finite", "infinite"])
+def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, mode):
+    """Two channels per meter, every channel enabled: the meter's two rows run the weighting filter side by side in ONE
+    workgroup, which goes straight on with the bookkeeping (biquad_sumsq_ilufs_pair_kernel; no hand-over through memory).
+    Same floats as the rows in workgroups of their own with the bookkeeping riding on the last (MI_ILUFS_ROWS_APART) and
+    as two launches (MI_ILUFS_TWO_LAUNCHES) -- output rows, loudness and history; and a bank with a channel switched off,
+    which cannot pair its rows, still agrees with its two-launch form."""
+    sr, M, K = 48000, 7, 2
+    calls = (4096, 4800, 2064, 19200, 8192, 1024, 4096, 38400, 4112)
+    rng = np.random.default_rng(78)
+    x = (rng.standard_normal((M * K, sum(calls))) * 0.2).astype(np.float32)
+    x[:, 30000:42000] *= 1e-5
+
+    def run(env, off=None):
+        for k in ("MI_ILUFS_ROWS_APART", "MI_ILUFS_TWO_LAUNCHES"):
+            monkeypatch.delenv(k, raising=False)
+        if env:
+            monkeypatch.setenv(env, "1")
+        bank = gpu.ILUFSBank(M, K, 0.0 if mode == "infinite" else 1.2)
+        bank.set_sample_rate(sr)
+        bank.set_designation(0, ol.CHANNEL_LEFT); bank.set_designation(1, ol.CHANNEL_RIGHT)
+        if off is not None:
+            bank.set_active(off, False)
+        if mode == "infinite":
+            bank.set_integration_period(0.0)
+        ys, pos = [], 0
+        for k in calls:
+            out = gpu.DeviceBuffer((M, k))
+            bank.process(out, gpu.DeviceBuffer.from_host(x[:, pos:pos + k]), k, gain=0.7)
+            ys.append(out.download())
+            pos += k
+        res = (np.concatenate(ys, axis=1), bank.loudness().copy(), [np.array(v) for v in bank.history()])
+        bank.close()
+        return res
+
+    def same(a, b):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for u, v in zip(a[2], b[2]):
+            assert np.array_equal(u, v)
+    pair, apart, two = run(None), run("MI_ILUFS_ROWS_APART"), run("MI_ILUFS_TWO_LAUNCHES")
+    assert float(np.abs(pair[0]).max()) > 0
+    same(pair, apart); same(pair, two)
+    same(run(None, off=1), run("MI_ILUFS_TWO_LAUNCHES", off=1))
