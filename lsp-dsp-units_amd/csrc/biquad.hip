@@ -157,7 +157,7 @@ namespace
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
                      const uint32_t *__restrict__ nsec, int max_sec, const chain_args &chain,
-                     const sumsq_args &sq = sumsq_args())
+                     const sumsq_args &sq = sumsq_args(), const bool sums_local = false /* sq.sums: [ROWS][4] in LDS */)
     {
         using G = geom<L>;
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
@@ -722,7 +722,7 @@ namespace
                 float v = red[0][tid];
                 for (int w = 1; w < NW; ++w)
                     v += red[w][tid];
-                if constexpr (ROWS > 1)
+                if (ROWS > 1 || sums_local)
                     sq.sums[slot * 4 + tid] = v;            // LDS of this workgroup: its bookkeeping follows
                 else
                     // one addition per cell and launch (the order of the launches is the stream's): an atomic without a
@@ -817,27 +817,28 @@ namespace
     // straight on with the meter's pieces.  No hand-over through memory at all: the riding form above pays three dependent
     // trips to the memory side on the tail of its launch (additions performed, count fetched, the other row's sums fetched).
     // Host: two channels per meter, every row enabled, the same number of sections in every row.
-    template <int L, int NW, bool ALIGNED>
-    __global__ __launch_bounds__(2 * 64 * NW, 1)
+    // (ROWS = 1: the mono meter, whose one row needs no hand-over either -- 128 threads stand in for the 256 virtual ones)
+    template <int L, int NW, bool ALIGNED, int ROWS = 2>
+    __global__ __launch_bounds__(ROWS * 64 * NW, 1)
     void biquad_sumsq_ilufs_pair_kernel(const float *in, size_t in_stride, int n /* multiple of L */, const float *__restrict__ tab,
                                         float *state, const uint32_t *__restrict__ nsec, int max_sec, const sumsq_args sq,
                                         const mi_meters::ilufs_epilogue ep)
     {
-        constexpr int TT = 2 * 64 * NW;
-        static_assert(TT == mi_meters::VTH, "one real thread per virtual one");
-        __shared__ float s_seg[2 * 4];
+        constexpr int TT = ROWS * 64 * NW;
+        static_assert(TT == 128 || TT == mi_meters::VTH, "two or four real waves for the 256 virtual threads");
+        __shared__ float s_seg[ROWS * 4];
         __shared__ float s_sum[4];
         __shared__ uint32_t s_cnt[4];
         __shared__ float s_val;
         __shared__ float s_chan[2 * TT];
         const uint32_t meter = blockIdx.x;
         // what the bookkeeping reads of earlier calls is asked for now and arrives underneath the filter
-        const mi_meters::ilufs_early<TT> early = mi_meters::ilufs_ask<TT>(meter, ep.block, ep.cfg, 2u, ep.st, ep.hist, ep.size, ep.ms_int);
+        const mi_meters::ilufs_early<TT> early = mi_meters::ilufs_ask<TT>(meter, ep.block, ep.cfg, uint32_t(ROWS), ep.st, ep.hist, ep.size, ep.ms_int);
         sumsq_args local = sq;
         local.sums = s_seg;
-        biquad_body<L, NW, ALIGNED, false, true, false, 2>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), local);
+        biquad_body<L, NW, ALIGNED, false, true, false, ROWS>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), local, true);
         __syncthreads();
-        mi_meters::ilufs_call_body<TT, false, true>(meter, ep.block, s_seg, ep.pieces, ep.cfg, 2u, ep.out, ep.out_stride,
+        mi_meters::ilufs_call_body<TT, false, true>(meter, ep.block, s_seg, ep.pieces, ep.cfg, uint32_t(ROWS), ep.out, ep.out_stride,
                                                     ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val, s_chan, early);
     }
 
@@ -993,6 +994,16 @@ namespace
         mi::take_profile_events(&ev0, &ev1);
         if constexpr (L == 16 && NW == 2)
         {
+            if (sq != nullptr && ep != nullptr && pair && ep->channels == 1)
+            {
+                if (aligned)
+                    MI_LAUNCH((biquad_sumsq_ilufs_pair_kernel<L, NW, true, 1>), grid, block, 0, st, ev0, ev1, in, in_stride, n, tab,
+                              b->d_state, b->d_nsec, int(b->max_sec), *sq, *ep);
+                else
+                    MI_LAUNCH((biquad_sumsq_ilufs_pair_kernel<L, NW, false, 1>), grid, block, 0, st, ev0, ev1, in, in_stride, n, tab,
+                              b->d_state, b->d_nsec, int(b->max_sec), *sq, *ep);
+                return hipGetLastError();
+            }
             if (sq != nullptr && ep != nullptr && pair)
             {
                 const dim3 pgrid(b->channels / 2), pblock(2 * 64 * NW);
@@ -1366,7 +1377,7 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
         *rode = ride;
     // the stereo meter in one workgroup (biquad_sumsq_ilufs_pair_kernel): rows in pairs, all of them enabled and alike in
     // their number of sections (the workgroup's barriers are shared by its two rows)
-    bool pair_ok = ride && ep->channels == 2 && (b->channels % 2) == 0 && getenv("MI_ILUFS_ROWS_APART") == nullptr;
+    bool pair_ok = ride && (ep->channels == 1 || (ep->channels == 2 && (b->channels % 2) == 0)) && getenv("MI_ILUFS_ROWS_APART") == nullptr;
     for (uint32_t c = 0; pair_ok && c < b->channels; ++c)
         pair_ok = !b->row_off[c] && b->nsec[c] == b->nsec[0];
     size_t done = 0;

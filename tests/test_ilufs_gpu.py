@@ -283,14 +283,16 @@ def test_bookkeeping_riding_on_the_filter_launch_equals_two_launches(gpu, monkey
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("K", [2, 1])
 @pytest.mark.parametrize("mode", ["finite", "infinite"])
-def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, mode):
+def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, mode, K):
     """Two channels per meter, every channel enabled: the meter's two rows run the weighting filter side by side in ONE
     workgroup, which goes straight on with the bookkeeping (biquad_sumsq_ilufs_pair_kernel; no hand-over through memory).
     Same floats as the rows in workgroups of their own with the bookkeeping riding on the last (MI_ILUFS_ROWS_APART) and
     as two launches (MI_ILUFS_TWO_LAUNCHES) -- output rows, loudness and history; and a bank with a channel switched off,
-    which cannot pair its rows, still agrees with its two-launch form."""
-    sr, M, K = 48000, 7, 2
+    which cannot pair its rows, still agrees with its two-launch form.  K = 1: the mono meter, whose single row needs no
+    hand-over either (the same kernel with one row per workgroup)."""
+    sr, M = 48000, 7
     calls = (4096, 4800, 2064, 19200, 8192, 1024, 4096, 38400, 4112)
     rng = np.random.default_rng(78)
     x = (rng.standard_normal((M * K, sum(calls))) * 0.2).astype(np.float32)
@@ -303,7 +305,9 @@ def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, 
             monkeypatch.setenv(env, "1")
         bank = gpu.ILUFSBank(M, K, 0.0 if mode == "infinite" else 1.2)
         bank.set_sample_rate(sr)
-        bank.set_designation(0, ol.CHANNEL_LEFT); bank.set_designation(1, ol.CHANNEL_RIGHT)
+        bank.set_designation(0, ol.CHANNEL_LEFT)
+        if K > 1:
+            bank.set_designation(1, ol.CHANNEL_RIGHT)
         if off is not None:
             bank.set_active(off, False)
         if mode == "infinite":
@@ -325,4 +329,4 @@ def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, 
     pair, apart, two = run(None), run("MI_ILUFS_ROWS_APART"), run("MI_ILUFS_TWO_LAUNCHES")
     assert float(np.abs(pair[0]).max()) > 0
     same(pair, apart); same(pair, two)
-    same(run(None, off=1), run("MI_ILUFS_TWO_LAUNCHES", off=1))
+    same(run(None, off=K - 1), run("MI_ILUFS_TWO_LAUNCHES", off=K - 1))
