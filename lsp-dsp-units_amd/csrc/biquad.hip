@@ -849,6 +849,289 @@ namespace
         biquad_body<L, NW, ALIGNED, true>(nullptr, in, 0, in_stride, n, nullptr, nullptr, nullptr, 0, chain);
     }
 
+    // ---- several consecutive blocks in ONE launch -------------------------------------------------------------------
+    // FilterBank::process is called block after block (FilterBank.cpp:256-291); a launch per block is one round of work on
+    // this chip -- every wave loads, computes and stores at the same time, and the memory phases add to the arithmetic.
+    // Here a channel's workgroup walks a STREAM of sub-blocks: the 2048-sample sub-blocks of block 0, then those of block
+    // 1, ... (each block a buffer of its own, the pointers in the kernel arguments).  Wave w takes sub-blocks w, w + NW,
+    // w + 2 NW, ...; the loads of its next sub-block fly underneath the sections of the current one and the stores drain
+    // behind them, so in the steady state some waves of a SIMD compute while others wait on memory.
+    //
+    // The state travels from sub-block g - 1 to sub-block g per section, through one LDS cell per (section, wave):
+    // {d0, d1, seq}.  The producer writes the state, then seq = g (a wave's LDS accesses are performed in program order);
+    // the consumer reads seq, then the state, and repeats both until seq == g.  No s_barrier: a wave never waits for
+    // anything but the one value it needs, so NW = 4 pipelines (with counted barriers every wave would wait for every
+    // other wave's scan).  A cell cannot be overwritten early: its producer publishes (section s, sub-block g + NW) only
+    // after the chain g+1 ... g+NW-1 of section s, whose first link is the consumer's own publication, made after its read.
+    //
+    // Bit for bit the same as `blocks` launches of biquad_bank_kernel<16, 2>: the same table, the same scan and recurrence
+    // per sub-block, and the same KIND of state at every hand-over -- the scan's end state of lane 63 from an even sub-block
+    // of a block to the odd one behind it (there: wave 0 to wave 1 of a super-block), the recurrence's own end state after
+    // an odd sub-block and at the end of a block (there: the state saved for the next super-block / the next call).
+    constexpr int STREAM_MAX_BLOCKS = 128;      // 2 KiB of pointers in the kernel arguments
+    constexpr int STREAM_SG         = 32;       // sections with a hand-over cell
+    struct stream_args
+    {
+        int             blocks;
+        float          *out[STREAM_MAX_BLOCKS];
+        const float    *in[STREAM_MAX_BLOCKS];
+    };
+    struct stream_cell { float d0, d1; uint32_t seq, pad; };
+    typedef volatile __attribute__((address_space(3))) stream_cell lds_cell;    // ds_read / ds_write, in program order
+
+    template <int NW>
+    __global__ __launch_bounds__(64 * NW, (NW >= 4) ? 4 : 2)
+    void biquad_stream_kernel(const stream_args a, size_t out_stride, size_t in_stride, int n /* multiple of 16 */,
+                              const float *__restrict__ tab, float *state, const uint32_t *__restrict__ nsec, int max_sec)
+    {
+        using G = geom<16>;
+        constexpr int L = 16, W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK;
+        constexpr int LPT = W / 4;
+        constexpr int TAB_QL = TAB_PQ + 2 * L;
+        __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
+        __shared__ stream_cell cell[STREAM_SG][NW];
+
+        const int ch  = int(blockIdx.x);
+        const int tid = int(threadIdx.x);
+        const int t   = tid & 63;
+        const int wv  = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int l16 = t & 15;
+        const int ns  = int(nsec[ch]);
+        if (ns < 0)                                          // row switched off
+            return;
+        float *const sx = sx_all + wv * 64 * PITCH;
+        const bool lane0 = (t == 0), row3 = (t >= 48);
+        const float *ctab = tab + size_t(ch) * max_sec * TAB;
+        float *const mem = state + size_t(ch) * max_sec * 2;
+
+        // the cells: nothing published yet (seq 0), and the memory the call starts from as "the state behind sub-block -1"
+        for (int i = tid; i < ns * NW; i += 64 * NW)
+        {
+            const int si = i / NW, w = i - si * NW;
+            stream_cell c = { 0.0f, 0.0f, 0u, 0u };
+            if (w == NW - 1)
+            {
+                const float2 s = reinterpret_cast<const float2 *>(mem)[si];
+                c.d0 = s.x;
+                c.d1 = s.y;
+            }
+            cell[si][w] = c;
+        }
+        __syncthreads();
+
+        const int spb   = (n + SB - 1) / SB;                 // sub-blocks of a block
+        const int total = a.blocks * spb;
+        const int pred  = (wv + NW - 1) % NW;
+
+        typedef const __attribute__((address_space(4))) float cfloat;
+        typedef const __attribute__((address_space(4))) v16f cv16f;
+        typedef const __attribute__((address_space(4))) v8f cv8f;
+        auto uniform_row = [&](const float *T) -> cfloat * {
+            const uint64_t v = reinterpret_cast<uint64_t>(T);
+            const uint32_t lo = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v))));
+            const uint32_t hi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(v >> 32))));
+            return reinterpret_cast<cfloat *>((uint64_t(hi) << 32) | lo);
+        };
+        struct sectab
+        {
+            v16f pq[L / 8];
+            v8f  m0;
+            v16f m1;
+            float4 cf;
+            float  a2;
+            float4 ql;
+        };
+        auto load_pq = [&](sectab &r, const float *T)
+        {
+            cfloat *U = uniform_row(T);
+            #pragma unroll
+            for (int j = 0; j < L / 8; ++j)
+                r.pq[j] = *reinterpret_cast<cv16f *>(U + TAB_PQ + 16 * j);
+        };
+        auto load_mats = [&](sectab &r, const float *T)
+        {
+            cfloat *U = uniform_row(T);
+            r.m0 = *reinterpret_cast<cv8f *>(U + 8);
+            r.m1 = *reinterpret_cast<cv16f *>(U + 16);
+            r.ql = *reinterpret_cast<const float4 *>(T + TAB_QL + 4 * l16);
+        };
+        auto load_coefs = [&](sectab &r, const float *T)
+        {
+            cfloat *U = uniform_row(T);
+            r.cf = make_float4(U[0], U[1], U[2], U[3]);
+            r.a2 = U[4];
+        };
+
+        float4 ld[LPT];
+        auto issue_loads = [&](int g)                        // coalesced rows of sub-block g -> registers
+        {
+            const int k = g / spb, j = g - k * spb;
+            const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float *>(a.in[k] + size_t(ch) * in_stride), 0, n * 4, BUFFER_DWORD3);
+            #pragma unroll
+            for (int q = 0; q < LPT; ++q)
+            {
+                const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(src, (j * SB + 4 * (q * 64 + t)) * 4, 0, 0);
+                ld[q] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+            }
+        };
+
+        v2f x[L];
+        sectab tb;
+        if (ns > 0)
+        {
+            load_pq(tb, ctab);
+            load_mats(tb, ctab);
+            load_coefs(tb, ctab);
+        }
+        if (wv < total)
+            issue_loads(wv);
+
+        for (int g = wv; g < total; g += NW)
+        {
+            const int k = g / spb, j = g - k * spb;
+            const int base  = j * SB;
+            const int valid = (n - base < SB) ? n - base : SB;       // multiple of L
+            const int last  = valid - 1;
+            const int t_last = last / W;
+            const bool save_hi = (last - t_last * W) >= L;
+            const bool saver   = (t == t_last);
+            const bool exact_out = (j & 1) || (j == spb - 1);        // how this sub-block hands its state on
+            const bool final_sb  = (g == total - 1);
+            const uint32_t want = uint32_t(g), mine = uint32_t(g + 1);
+
+            #pragma unroll
+            for (int q = 0; q < LPT; ++q)
+            {
+                const int i = 4 * (q * 64 + t);
+                *reinterpret_cast<float4 *>(&sx[i + (i / W) * 4]) = ld[q];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (g + NW < total)
+                issue_loads(g + NW);
+            #pragma unroll
+            for (int q = 0; q < L / 4; ++q)
+            {
+                const float4 lo = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * q]);
+                const float4 hi = *reinterpret_cast<const float4 *>(&sx[t * PITCH + L + 4 * q]);
+                x[4 * q + 0] = v2f{lo.x, hi.x}; x[4 * q + 1] = v2f{lo.y, hi.y};
+                x[4 * q + 2] = v2f{lo.z, hi.z}; x[4 * q + 3] = v2f{lo.w, hi.w};
+            }
+
+            for (int si = 0; si < ns; ++si)
+            {
+                const float *Tnext = ctab + size_t((si + 1 < ns) ? si + 1 : 0) * TAB;
+                lds_cell *const from = (lds_cell *)&cell[si][pred];
+                lds_cell *const to   = (lds_cell *)&cell[si][wv];
+                // asked for now, looked at after the dot products
+                uint32_t got = from->seq;
+                float c0 = from->d0, c1 = from->d1;
+
+                // 1. zero-state end states of both chunks
+                v2f a0 = splat(0.0f), a1_ = splat(0.0f), b0_ = splat(0.0f), b1_ = splat(0.0f);
+                #pragma unroll
+                for (int q = 0; q < L; q += 2)
+                {
+                    const v16f &r = tb.pq[q / 8];
+                    const v2f pq0 = v2f{r[(2 * q) % 16], r[(2 * q + 1) % 16]};
+                    const v2f pq1 = v2f{r[(2 * q + 2) % 16], r[(2 * q + 3) % 16]};
+                    a0  = pk_fma(pq0, splat(x[q].x), a0);      b0_ = pk_fma(pq0, splat(x[q].y), b0_);
+                    a1_ = pk_fma(pq1, splat(x[q + 1].x), a1_); b1_ = pk_fma(pq1, splat(x[q + 1].y), b1_);
+                }
+                const v2f zwA = a0 + a1_, zwB = b0_ + b1_;
+
+                // 2. end state of the pair for a zero start, the state entering the sub-block at lane 0
+                const v2f Pc0 = v2f{tb.m0[0], tb.m0[1]}, Pc1 = v2f{tb.m0[2], tb.m0[3]};
+                v2f e = mat_fma(Pc0, Pc1, zwA, zwB);
+                asm volatile("" : "+v"(e));                  // the dot products stay in front of the wait (no sinking behind the loop)
+                while (got != want)
+                {
+                    __builtin_amdgcn_s_sleep(1);
+                    got = from->seq;
+                    c0 = from->d0;
+                    c1 = from->d1;
+                }
+                const v2f cvec = lane0 ? v2f{c0, c1} : splat(0.0f);
+                e = mat_fma(v2f{tb.m0[4], tb.m0[5]}, v2f{tb.m0[6], tb.m0[7]}, cvec, e);
+
+                const v2f zero = splat(0.0f);
+                e = mat_fma(v2f{tb.m0[4], tb.m0[5]}, v2f{tb.m0[6], tb.m0[7]}, dpp_zero<DPP_ROW_SHR1>(e), e);
+                e = mat_fma(v2f{tb.m1[0], tb.m1[1]}, v2f{tb.m1[2], tb.m1[3]}, dpp_zero<DPP_ROW_SHR2>(e), e);
+                e = mat_fma(v2f{tb.m1[4], tb.m1[5]}, v2f{tb.m1[6], tb.m1[7]}, dpp_zero<DPP_ROW_SHR4>(e), e);
+                e = mat_fma(v2f{tb.m1[8], tb.m1[9]}, v2f{tb.m1[10], tb.m1[11]}, dpp_zero<DPP_ROW_SHR8>(e), e);
+                const v2f QLc0 = v2f{tb.ql.x, tb.ql.y}, QLc1 = v2f{tb.ql.z, tb.ql.w};
+                e = mat_fma(QLc0, QLc1, dpp_or<DPP_ROW_BCAST15, 0xa>(zero, e), e);
+                {
+                    const v2f s  = dpp_or<DPP_ROW_BCAST31, 0xc>(zero, e);
+                    const v2f s2 = mat_fma(v2f{tb.m1[12], tb.m1[13]}, v2f{tb.m1[14], tb.m1[15]}, s, zero);
+                    e = mat_fma(QLc0, QLc1, row3 ? s2 : s, e);
+                }
+                if (!exact_out && t == 63)                   // the scan's end state goes on (a full sub-block)
+                {
+                    to->d0 = e.x;
+                    to->d1 = e.y;
+                    to->seq = mine;
+                }
+
+                // 3. start states, the next section's table underneath the recurrence
+                const v2f S  = dpp_or<DPP_WAVE_SHR1, 0xf>(cvec, e);
+                const v2f SB2 = mat_fma(Pc0, Pc1, S, zwA);
+                v2f d0 = v2f{S.x, SB2.x}, d1 = v2f{S.y, SB2.y};
+                __builtin_amdgcn_sched_barrier(0);
+                load_pq(tb, Tnext);
+                load_mats(tb, Tnext);
+                __builtin_amdgcn_sched_barrier(0);
+
+                const v2f b0 = splat(tb.cf.x), b1 = splat(tb.cf.y), b2 = splat(tb.cf.z), a1 = splat(tb.cf.w), a2 = splat(tb.a2);
+                #pragma unroll
+                for (int q = 0; q < L; ++q)
+                {
+                    const v2f xx = x[q];
+                    const v2f tq = pk_fma(b1, xx, d1);
+                    const v2f u  = b2 * xx;
+                    const v2f y  = pk_fma(b0, xx, d0);
+                    d0   = pk_fma(a1, y, tq);
+                    d1   = pk_fma(a2, y, u);
+                    x[q] = y;
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                load_coefs(tb, Tnext);
+                if (saver && (exact_out || final_sb))
+                {
+                    const float s0 = save_hi ? d0.y : d0.x, s1 = save_hi ? d1.y : d1.x;
+                    if (exact_out)
+                    {
+                        to->d0 = s0;
+                        to->d1 = s1;
+                        to->seq = mine;
+                    }
+                    if (final_sb)                            // the memory the next call starts from
+                        reinterpret_cast<float2 *>(mem)[si] = make_float2(s0, s1);
+                }
+            }
+
+            // x (registers) -> the wave's tile (transposed) -> coalesced write-through store
+            const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
+                a.out[k] + size_t(ch) * out_stride, 0, n * 4, BUFFER_DWORD3);
+            #pragma unroll
+            for (int q = 0; q < L / 4; ++q)
+            {
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * q]) =
+                    make_float4(x[4 * q + 0].x, x[4 * q + 1].x, x[4 * q + 2].x, x[4 * q + 3].x);
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * q]) =
+                    make_float4(x[4 * q + 0].y, x[4 * q + 1].y, x[4 * q + 2].y, x[4 * q + 3].y);
+            }
+            __builtin_amdgcn_wave_barrier();
+            #pragma unroll
+            for (int q = 0; q < LPT; ++q)
+            {
+                const int i = 4 * (q * 64 + t);
+                store_through(dst, base + i, *reinterpret_cast<const float4 *>(&sx[i + (i / W) * 4]));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
     // The last samples % L samples of a call: one thread per channel walks them through the cascade with the same
     // recurrence (FilterBank.cpp:256-291 semantics for block sizes that are not a multiple of the chunk length).
     __global__ void biquad_tail_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
@@ -1449,6 +1732,36 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
     return bank_run(b, out, in, samples, out_stride, in_stride, mi::as_stream(stream), nullptr);
 }
 
+// Blocks [first, first + count) of a process_blocks call as ONE launch of biquad_stream_kernel
+static int stream_launch(mi_biquad_bank_t *b, float *const *out, const float *const *in, size_t first, size_t count,
+                         size_t samples, size_t out_stride, size_t in_stride, hipStream_t st)
+{
+    static const int force_nw = getenv("MI_BIQUAD_STREAM_WAVES") ? atoi(getenv("MI_BIQUAD_STREAM_WAVES")) : 0;  // profiling knob
+    stream_args a;
+    a.blocks = int(count);
+    for (size_t k = 0; k < count; ++k)
+    {
+        a.out[k] = out[first + k];
+        a.in[k]  = in[first + k];
+    }
+    const size_t subs = count * ((samples + big::BLOCK - 1) / big::BLOCK);
+    const int nw = (force_nw == 1 || force_nw == 2 || force_nw == 4) ? force_nw : (subs >= 4) ? 4 : 2;
+    const dim3 grid(b->channels);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    mi::take_profile_events(&ev0, &ev1);
+    if (nw == 4)
+        MI_LAUNCH((biquad_stream_kernel<4>), grid, dim3(256), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples), b->d_big,
+                  b->d_state, b->d_nsec, int(b->max_sec));
+    else if (nw == 2)
+        MI_LAUNCH((biquad_stream_kernel<2>), grid, dim3(128), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples), b->d_big,
+                  b->d_state, b->d_nsec, int(b->max_sec));
+    else
+        MI_LAUNCH((biquad_stream_kernel<1>), grid, dim3(64), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples), b->d_big,
+                  b->d_state, b->d_nsec, int(b->max_sec));
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
 int mi_biquad_bank_process_blocks(mi_biquad_bank_t *b, float *const *out, const float *const *in, size_t blocks,
                                   size_t samples, size_t out_stride, size_t in_stride, void *stream)
 {
@@ -1459,11 +1772,57 @@ int mi_biquad_bank_process_blocks(mi_biquad_bank_t *b, float *const *out, const 
     MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL,
                "mi_biquad_bank_process_blocks: stride shorter than the block");
     for (size_t k = 0; k < blocks; ++k)
-    {
         MI_REQUIRE(out[k] != nullptr && in[k] != nullptr, MI_EINVAL, "mi_biquad_bank_process_blocks: NULL buffer of block %zu", k);
-        const int r = bank_run(b, out[k], in[k], samples, out_stride, in_stride, mi::as_stream(stream), nullptr);
+    hipStream_t st = mi::as_stream(stream);
+    int r = commit(b, st);
+    if (r != MI_OK)
+        return r;
+
+    // One launch for a run of blocks (biquad_stream_kernel) where the blocks are what the long-call kernel takes -- more
+    // than 2048 samples, whole chunks of 16, 16-byte aligned rows -- and every channel's sections have a hand-over cell.
+    bool streamable = samples > 2 * size_t(small::BLOCK) && (samples % 16) == 0 && samples < (size_t(1) << 28) &&
+                      (out_stride % 4) == 0 && (in_stride % 4) == 0 && getenv("MI_BIQUAD_BLOCKS_LOOP") == nullptr;
+    for (uint32_t c = 0; streamable && c < b->channels; ++c)
+        streamable = b->nsec[c] <= uint32_t(STREAM_SG);
+    const size_t spb = (samples + big::BLOCK - 1) / big::BLOCK;
+    const size_t out_bytes = (size_t(b->channels - 1) * out_stride + samples) * sizeof(float);
+    const size_t in_bytes  = (size_t(b->channels - 1) * in_stride + samples) * sizeof(float);
+    auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+        return a0 < b0 + qn && b0 < a0 + pn;
+    };
+    // Inside a launch a block's loads are issued while blocks before it are still computing, and its stores are not
+    // ordered against another wave's: a block joins the run only if it neither reads nor overwrites what a block of the
+    // run writes (except the same rows through the same wave: an output buffer that comes round again a multiple of four
+    // sub-blocks later), and does not write what one of them reads.  A block may be processed in place.
+    auto joins = [&](size_t first, size_t k) -> bool {
+        if (!streamable || ((reinterpret_cast<uintptr_t>(out[k]) | reinterpret_cast<uintptr_t>(in[k])) % 16) != 0)
+            return false;
+        for (size_t i = first; i < k; ++i)
+        {
+            if (overlap(out[i], out_bytes, in[k], in_bytes) || overlap(in[i], in_bytes, out[k], out_bytes))
+                return false;
+            if (overlap(out[i], out_bytes, out[k], out_bytes) && (out[i] != out[k] || (((k - i) * spb) % 4) != 0))
+                return false;
+        }
+        return true;
+    };
+    size_t first = 0;
+    while (first < blocks)
+    {
+        size_t count = 0;
+        while (first + count < blocks && count < size_t(STREAM_MAX_BLOCKS) && joins(first, first + count))
+            ++count;
+        if (count >= 2)
+            r = stream_launch(b, out, in, first, count, samples, out_stride, in_stride, st);
+        else
+        {
+            count = 1;
+            r = bank_run(b, out[first], in[first], samples, out_stride, in_stride, st, nullptr);
+        }
         if (r != MI_OK)
             return r;
+        first += count;
     }
     return MI_OK;
 }

@@ -296,23 +296,78 @@ def test_c2_full_size_all_channels(gpu):
     assert strict.sum() > C // 4, brief
 
 
-def test_process_blocks_equals_separate_calls(gpu):
-    """mi_biquad_bank_process_blocks is `blocks` process() calls issued from C: same launches, same bits, same carried state."""
-    C, n, nb = 6, 4096 + 48, 5
-    rng = np.random.default_rng(321)
-    coef = [wl.design(fd.FLT_BT_LRX_LOPASS, 4, 500.0 * (c + 1), 0, 1.0, 0.75)[:8] for c in range(C)]
+@pytest.mark.parametrize("n,nb", [(4096 + 48, 5), (4096, 8), (4096, 2), (4096, 3), (2064, 5), (6144, 3), (8192 + 16, 4),
+                                  (4096, 131), (1024, 4), (4100, 3)])
+def test_process_blocks_equals_separate_calls(gpu, n, nb):
+    """mi_biquad_bank_process_blocks runs the blocks in ONE launch where they qualify (biquad_stream_kernel: more than 2048
+    samples, whole chunks of 16; more than 128 blocks: several launches) and otherwise as process() calls issued from C --
+    either way the same bits and the same carried state as `nb` separate process() calls.  Channels with different section
+    counts, one without sections (a copy), one switched off."""
+    C = 7
+    rng = np.random.default_rng(321 + n + nb)
+    coef = [wl.design(fd.FLT_BT_LRX_LOPASS, 4, 500.0 * (c + 1), 0, 1.0, 0.75)[:8 - c] for c in range(C - 1)]
+    coef.append(np.zeros((0, 5), np.float32))
     x = (rng.standard_normal((nb, C, n)) * 0.25).astype(np.float32)
-    y_ref, st_ref = run_bank(gpu, x, coef)
-    bank = gpu.BiquadBank(C, 8)
-    for c in range(C):
-        bank.set_chains(c, coef[c], False)
+
+    def make_bank():
+        bank = gpu.BiquadBank(C, 8)
+        for c in range(C):
+            bank.set_chains(c, coef[c], False)
+        bank.set_row_enabled(2, False)
+        return bank
+    ref = make_bank()
     ins = [gpu.DeviceBuffer.from_host(x[b]) for b in range(nb)]
-    outs = [gpu.DeviceBuffer((C, n)) for _ in range(nb)]
+    sentinel = np.full((C, n), 7.0, np.float32)
+    outs_ref = [gpu.DeviceBuffer.from_host(sentinel) for _ in range(nb)]
+    for b in range(nb):
+        ref.process(outs_ref[b], ins[b], n)
+    y_ref = [o.download() for o in outs_ref]
+    st_ref = ref.get_state()
+    ref.close()
+    assert np.all(y_ref[0][2] == 7.0) and np.array_equal(y_ref[0][6], x[0][6])        # switched off; no sections
+
+    bank = make_bank()
+    outs = [gpu.DeviceBuffer.from_host(sentinel) for _ in range(nb)]
     bank.process_blocks(outs, ins, n)
     for b in range(nb):
         np.testing.assert_array_equal(outs[b].download(), y_ref[b])
     np.testing.assert_array_equal(bank.get_state(), st_ref)
     bank.close()
+
+
+def test_process_blocks_aliasing(gpu):
+    """Blocks that depend on each other through memory keep the meaning of separate calls: a block processed in place, an
+    output buffer that comes round again (a ring of buffers), a block that reads what an earlier block of the same call
+    wrote (such a block starts a new launch)."""
+    C, n = 5, 4096
+    rng = np.random.default_rng(99)
+    coef = [wl.design(fd.FLT_BT_LRX_LOPASS, 4, 700.0 * (c + 1), 0, 1.0, 0.75)[:8] for c in range(C)]
+    x = (rng.standard_normal((6, C, n)) * 0.25).astype(np.float32)
+
+    def run(blocks_call):
+        bank = gpu.BiquadBank(C, 8)
+        for c in range(C):
+            bank.set_chains(c, coef[c], False)
+        bufs = [gpu.DeviceBuffer.from_host(x[b]) for b in range(6)]
+        ring = [gpu.DeviceBuffer((C, n)) for _ in range(2)]
+        scratch = gpu.DeviceBuffer((C, n))
+        # in place; a ring of two outputs (every block's output comes round again); a chain through `scratch`
+        ins = [bufs[0], bufs[1], bufs[2], bufs[3], bufs[4], scratch, bufs[5]]
+        outs = [bufs[0], ring[0], ring[1], ring[0], scratch, ring[1], ring[0]]
+        if blocks_call:
+            bank.process_blocks(outs, ins, n)
+        else:
+            for o, i in zip(outs, ins):
+                bank.process(o, i, n)
+        res = [b.download() for b in bufs + ring + [scratch]]
+        st = bank.get_state()
+        bank.close()
+        return res, st
+    a, sa = run(False)
+    b, sb = run(True)
+    for u, v in zip(a, b):
+        np.testing.assert_array_equal(u, v)
+    np.testing.assert_array_equal(sa, sb)
 
 
 def test_linearity_and_determinism_full_size(gpu):
