@@ -868,6 +868,31 @@ namespace
     // per sub-block, and the same KIND of state at every hand-over -- the scan's end state of lane 63 from an even sub-block
     // of a block to the odd one behind it (there: wave 0 to wave 1 of a super-block), the recurrence's own end state after
     // an odd sub-block and at the end of a block (there: the state saved for the next super-block / the next call).
+#ifdef MI_BIQUAD_PROBE
+    // per-wave account of the stream kernel (tests/experiments/biquad_stream_probe.hip): g_probe[wave][slot] =
+    //   0 entry (100 MHz wall clock)  1 exit  2 shader cycles in all  3 waiting for the tile (loads)  4 sections
+    //   5 transposition + store issue  6 turns of the hand-over wait loop  7 first tile ready (wall)  8 first store issued (wall)
+    #define MI_STREAM_PROBE_BEGIN() unsigned long long pc_[4] = {0, 0, 0, 0}, pt_ = __builtin_readcyclecounter(), pw0_ = wall_clock64(), \
+        pw1_ = 0, pw2_ = 0; const unsigned long long pc0_ = pt_; unsigned spins_ = 0
+    #define MI_STREAM_PROBE(slot) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = __builtin_readcyclecounter(); \
+        pc_[slot] += now_ - pt_; pt_ = now_; if ((slot) == 1 && pw1_ == 0) pw1_ = wall_clock64(); if ((slot) == 3 && pw2_ == 0) pw2_ = wall_clock64(); \
+        __builtin_amdgcn_sched_barrier(0); } while (0)
+    #define MI_STREAM_PROBE_SPIN() (++spins_)
+    #define MI_STREAM_PROBE_ITER(it) do { if (t == 0 && (it) < 20) g_probe[(size_t(blockIdx.x) * NW + wv) * 32 + 11 + (it)] = wall_clock64(); } while (0)
+    #define MI_STREAM_PROBE_END() do { if (t == 0) { unsigned long long *p_ = g_probe + (size_t(blockIdx.x) * NW + wv) * 32; \
+        p_[0] = pw0_; p_[1] = wall_clock64(); p_[2] = __builtin_readcyclecounter() - pc0_; p_[3] = pc_[1]; p_[4] = pc_[2]; p_[5] = pc_[3] + pc_[0]; \
+        p_[6] = spins_; p_[7] = pw1_; p_[8] = pw2_; \
+        p_[9] = __builtin_amdgcn_s_getreg((31 << 11) | 4); p_[10] = __builtin_amdgcn_s_getreg((31 << 11) | 20); } } while (0)
+#else
+    #define MI_STREAM_PROBE_BEGIN() do { } while (0)
+    #define MI_STREAM_PROBE(slot) do { } while (0)
+    #define MI_STREAM_PROBE_SPIN() do { } while (0)
+    #define MI_STREAM_PROBE_ITER(it) do { } while (0)
+    #define MI_STREAM_PROBE_END() do { } while (0)
+#endif
+#ifndef MI_STREAM_ROTATE
+#define MI_STREAM_ROTATE 1                      // 0: experiments only (the arbiter's oldest-first order decides)
+#endif
     constexpr int STREAM_MAX_BLOCKS = 128;      // 2 KiB of pointers in the kernel arguments
     constexpr int STREAM_SG         = 32;       // sections with a hand-over cell
     struct stream_args
@@ -986,9 +1011,11 @@ namespace
         }
         if (wv < total)
             issue_loads(wv);
+        MI_STREAM_PROBE_BEGIN();
 
         for (int g = wv; g < total; g += NW)
         {
+            MI_STREAM_PROBE(0);
             const int k = g / spb, j = g - k * spb;
             const int base  = j * SB;
             const int valid = (n - base < SB) ? n - base : SB;       // multiple of L
@@ -1000,27 +1027,50 @@ namespace
             const bool final_sb  = (g == total - 1);
             const uint32_t want = uint32_t(g), mine = uint32_t(g + 1);
 
+            // The tile holds a lane's two chunks INTERLEAVED (first, second, first, second, ...): a 16-byte read is two
+            // register pairs {first chunk's sample, second chunk's sample} as the packed arithmetic wants them, no moves.
+            // The row pieces go in (and come out) with a stride of two dwords instead.
             #pragma unroll
             for (int q = 0; q < LPT; ++q)
             {
-                const int i = 4 * (q * 64 + t);
-                *reinterpret_cast<float4 *>(&sx[i + (i / W) * 4]) = ld[q];
+                const int i = 4 * (q * 64 + t);              // the piece's first sample in the sub-block
+                float *d = &sx[(i / W) * PITCH + 2 * (i % L) + ((i % W) / L)];
+                d[0] = ld[q].x; d[2] = ld[q].y; d[4] = ld[q].z; d[6] = ld[q].w;
             }
             __builtin_amdgcn_wave_barrier();
+            MI_STREAM_PROBE(1);
             if (g + NW < total)
                 issue_loads(g + NW);
             #pragma unroll
-            for (int q = 0; q < L / 4; ++q)
+            for (int q = 0; q < L / 2; ++q)
             {
-                const float4 lo = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * q]);
-                const float4 hi = *reinterpret_cast<const float4 *>(&sx[t * PITCH + L + 4 * q]);
-                x[4 * q + 0] = v2f{lo.x, hi.x}; x[4 * q + 1] = v2f{lo.y, hi.y};
-                x[4 * q + 2] = v2f{lo.z, hi.z}; x[4 * q + 3] = v2f{lo.w, hi.w};
+                const float4 v = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * q]);
+                x[2 * q] = v2f{v.x, v.y};
+                x[2 * q + 1] = v2f{v.z, v.w};
             }
 
             for (int si = 0; si < ns; ++si)
             {
                 const float *Tnext = ctab + size_t((si + 1 < ns) ? si + 1 : 0) * TAB;
+#if MI_STREAM_ROTATE
+                // The instruction arbiter of a SIMD serves its OLDEST wave first: of the four workgroups that share a CU --
+                // on this part workgroups b, b + 256, b + 512, b + 768 of a 1024-channel launch, in the order of their
+                // entry (census in tests/experiments/biquad_stream_probe.hip) -- the first runs ahead and the last falls
+                // behind (exits 480 .. 850 us apart in a 125-block launch), and the launch ends with the stragglers alone
+                // on their SIMDs.  So the issue priority goes round with a wave's own progress, every four sections, each
+                // workgroup of a CU starting at a different level: exits 720 .. 750 us, the launch 3 - 6 % shorter.  (Keeping
+                // the pace through progress marks in global memory balances perfectly and costs a factor 1.8: the agent-scope
+                // marks alone do, profiles/r04_experiments/biquad_stream_pace.txt; priorities switched by the 100 MHz
+                // clock instead of the progress: the same balance, no shorter.)
+                if ((si & 3) == 0)
+                    switch (((si >> 2) + (g / NW) + int(blockIdx.x >> 8)) & 3)
+                    {
+                        case 0: __builtin_amdgcn_s_setprio(3); break;
+                        case 1: __builtin_amdgcn_s_setprio(2); break;
+                        case 2: __builtin_amdgcn_s_setprio(1); break;
+                        default: __builtin_amdgcn_s_setprio(0); break;
+                    }
+#endif
                 lds_cell *const from = (lds_cell *)&cell[si][pred];
                 lds_cell *const to   = (lds_cell *)&cell[si][wv];
                 // asked for now, looked at after the dot products
@@ -1046,6 +1096,7 @@ namespace
                 asm volatile("" : "+v"(e));                  // the dot products stay in front of the wait (no sinking behind the loop)
                 while (got != want)
                 {
+                    MI_STREAM_PROBE_SPIN();
                     __builtin_amdgcn_s_sleep(1);
                     got = from->seq;
                     c0 = from->d0;
@@ -1110,26 +1161,26 @@ namespace
                 }
             }
 
+            MI_STREAM_PROBE(2);
             // x (registers) -> the wave's tile (transposed) -> coalesced write-through store
             const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
                 a.out[k] + size_t(ch) * out_stride, 0, n * 4, BUFFER_DWORD3);
             #pragma unroll
-            for (int q = 0; q < L / 4; ++q)
-            {
-                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * q]) =
-                    make_float4(x[4 * q + 0].x, x[4 * q + 1].x, x[4 * q + 2].x, x[4 * q + 3].x);
-                *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * q]) =
-                    make_float4(x[4 * q + 0].y, x[4 * q + 1].y, x[4 * q + 2].y, x[4 * q + 3].y);
-            }
+            for (int q = 0; q < L / 2; ++q)
+                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * q]) = make_float4(x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y);
             __builtin_amdgcn_wave_barrier();
             #pragma unroll
             for (int q = 0; q < LPT; ++q)
             {
                 const int i = 4 * (q * 64 + t);
-                store_through(dst, base + i, *reinterpret_cast<const float4 *>(&sx[i + (i / W) * 4]));
+                const float *d = &sx[(i / W) * PITCH + 2 * (i % L) + ((i % W) / L)];
+                store_through(dst, base + i, make_float4(d[0], d[2], d[4], d[6]));
             }
             __builtin_amdgcn_wave_barrier();
+            MI_STREAM_PROBE(3);
+            MI_STREAM_PROBE_ITER(g / NW);
         }
+        MI_STREAM_PROBE_END();
     }
 
     // The last samples % L samples of a call: one thread per channel walks them through the cascade with the same

@@ -1,0 +1,116 @@
+// Account of biquad_stream_kernel from inside the waves (lane 0 of every wave): where the shader cycles of a K-block
+// launch go -- waiting for the tile's loads, the sections, the transposition and store issue -- and how often the
+// hand-over wait loop turns.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -DMI_BIQUAD_PROBE -I include -I lsp-dsp-units_amd/csrc \
+//        tests/experiments/biquad_stream_probe.hip lsp-dsp-units_amd/csrc/runtime.hip -o tests/experiments/biquad_stream_probe
+// Run:   biquad_stream_probe [sections = 8] [samples = 4096] [blocks = 20]
+#include "../../lsp-dsp-units_amd/csrc/biquad.hip"
+#include <algorithm>
+#include <cstdio>
+#include <map>
+
+int main(int argc, char **argv)
+{
+    const uint32_t C = 1024, NS = (argc > 1) ? atoi(argv[1]) : 8;
+    const size_t n = (argc > 2) ? atoi(argv[2]) : 4096;
+    const int K = (argc > 3) ? atoi(argv[3]) : 20;
+    const int NWV = getenv("MI_BIQUAD_STREAM_WAVES") ? atoi(getenv("MI_BIQUAD_STREAM_WAVES")) : 4;
+    mi_biquad_bank_t *bank = nullptr;
+    if (mi_biquad_bank_create(&bank, C, NS ? NS : 1) != MI_OK) { printf("create: %s\n", mi_dspu_last_error()); return 1; }
+    std::vector<mi_biquad_x1_t> ch(size_t(C) * (NS ? NS : 1));
+    for (auto &q : ch) { q.b0 = 0.2f; q.b1 = 0.4f; q.b2 = 0.2f; q.a1 = 0.5f; q.a2 = -0.3f; q.p0 = q.p1 = q.p2 = 0.0f; }
+    mi_biquad_bank_set_all_chains(bank, ch.data(), NS, 1);
+    float *in, *out;
+    const int ring = 16;
+    hipMalloc(&in, ring * C * n * sizeof(float)); hipMalloc(&out, ring * C * n * sizeof(float));
+    hipMemset(in, 0, ring * C * n * sizeof(float));
+    std::vector<float *> po(K);
+    std::vector<const float *> pi(K);
+    for (int k = 0; k < K; ++k) { po[k] = out + size_t(k % ring) * C * n; pi[k] = in + size_t(k % ring) * C * n; }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const int reps = 40;
+    for (int rep = 0; rep < reps + 5; ++rep)
+    {
+        if (rep == 5) hipEventRecord(e0, nullptr);
+        if (mi_biquad_bank_process_blocks(bank, po.data(), pi.data(), K, n, n, n, nullptr) != MI_OK) { printf("%s\n", mi_dspu_last_error()); return 1; }
+    }
+    hipEventRecord(e1, nullptr);
+    hipDeviceSynchronize();
+    float ms = 0; hipEventElapsedTime(&ms, e0, e1);
+    printf("%d blocks per launch, %d waves per channel: %.2f us per block (back-to-back launches)\n", K, NWV, ms * 1000.0f / reps / K);
+    const uint32_t WAVES = C * NWV;
+    std::vector<unsigned long long> h(4096 * 16 * 2);
+    hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(g_probe), h.size() * sizeof(h[0]));
+    unsigned long long t0 = ~0ull;
+    for (uint32_t b = 0; b < WAVES; ++b) t0 = std::min(t0, h[b * 32]);
+    auto stat = [&](const char *name, int slot, bool wall, double scale) {
+        std::vector<double> v;
+        for (uint32_t b = 0; b < WAVES; ++b) v.push_back(wall ? (h[b * 32 + slot] - t0) / 100.0 : double(h[b * 32 + slot]) * scale);
+        std::sort(v.begin(), v.end());
+        printf("  %-44s %9.2f %9.2f %9.2f\n", name, v.front(), v[v.size() / 2], v.back());
+    };
+    printf("last launch, min / median / max over %u waves\n", WAVES);
+    stat("entry (us since the first wave)", 0, true, 1);
+    stat("first tile ready (us)", 7, true, 1);
+    stat("first store issued (us)", 8, true, 1);
+    stat("exit (us)", 1, true, 1);
+    const double per = 1.0 / K;
+    stat("shader cycles per block, all", 2, false, per);
+    stat("  waiting for the tile's loads", 3, false, per);
+    stat("  sections", 4, false, per);
+    stat("  transposition, store issue, loop", 5, false, per);
+    stat("turns of the hand-over wait loop per block", 6, false, per);
+    // the stream's pace: when the waves left their i-th sub-block
+    printf("wave iteration i done (us): min / median / max over the waves, and the median's step\n");
+    double prev = 0;
+    for (int it = 0; it < 20 && it * NWV < K * int((n + 2047) / 2048); ++it)
+    {
+        std::vector<double> v;
+        for (uint32_t b = 0; b < WAVES; ++b) if (h[b * 32 + 11 + it]) v.push_back((h[b * 32 + 11 + it] - t0) / 100.0);
+        if (v.empty()) break;
+        std::sort(v.begin(), v.end());
+        printf("  %2d: %8.2f %8.2f %8.2f   +%.2f\n", it, v.front(), v[v.size() / 2], v.back(), v[v.size() / 2] - prev);
+        prev = v[v.size() / 2];
+    }
+    // age inside a CU: the workgroups of a CU in the order of their entry, and when each one left
+    std::map<unsigned, std::vector<std::pair<unsigned long long, double>>> cu;
+    std::map<unsigned, std::vector<uint32_t>> members;
+    for (uint32_t b = 0; b < C; ++b)
+    {
+        const unsigned hw = unsigned(h[b * NWV * 32 + 9]), xcc = unsigned(h[b * NWV * 32 + 10]) & 0xf;
+        const unsigned key = (xcc << 12) | (((hw >> 13) & 7) << 8) | (((hw >> 12) & 1) << 4) | ((hw >> 8) & 15);
+        double ex = 0;
+        for (int w = 0; w < NWV; ++w) ex = std::max(ex, (h[(b * NWV + w) * 32 + 1] - t0) / 100.0);
+        cu[key].push_back({h[b * NWV * 32], ex});
+        members[key].push_back(b);
+    }
+    int regular = 0;
+    for (auto &kv : members)
+    {
+        std::sort(kv.second.begin(), kv.second.end());
+        bool ok = kv.second.size() == 4;
+        for (size_t i = 0; ok && i < 4; ++i) ok = kv.second[i] == kv.second[0] + 256 * i;
+        regular += ok;
+    }
+    printf("CUs whose workgroups are b, b + 256, b + 512, b + 768: %d\n", regular);
+    std::map<size_t, int> hist;
+    std::vector<std::vector<double>> by_rank(8);
+    for (auto &kv : cu)
+    {
+        hist[kv.second.size()]++;
+        std::sort(kv.second.begin(), kv.second.end());
+        for (size_t r = 0; r < kv.second.size() && r < 8; ++r) by_rank[r].push_back(kv.second[r].second);
+    }
+    printf("CUs %zu;", cu.size());
+    for (auto &kv : hist) printf(" %d CUs with %zu workgroups;", kv.second, kv.first);
+    printf("\nexit time (us) of a CU's workgroups by order of entry: min / median / max over the CUs\n");
+    for (size_t r = 0; r < 8; ++r)
+    {
+        auto &v = by_rank[r];
+        if (v.empty()) continue;
+        std::sort(v.begin(), v.end());
+        printf("  entered %zu.: %9.2f %9.2f %9.2f\n", r + 1, v.front(), v[v.size() / 2], v.back());
+    }
+    return 0;
+}
