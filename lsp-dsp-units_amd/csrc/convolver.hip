@@ -1144,10 +1144,12 @@ namespace
             b->upper_zero = !fold;                                      // (folded: the tail's inverse fills both halves of acc)
             return MI_OK;
         }
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
-                                               o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
-                                               b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
-                                               static_cast<float *>(nullptr), 0u, 0u, 0u, b->upper_zero)
+        hipEvent_t fe0 = nullptr, fe1 = nullptr;
+        mi::take_profile_events(&fe0, &fe1);
+        #define MI_CALL(LM) MI_LAUNCH((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, fe0, fe1, \
+                                      o, x, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
+                                      b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
+                                      static_cast<float *>(nullptr), 0u, 0u, 0u, b->upper_zero)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
@@ -1219,10 +1221,12 @@ namespace mi
                              (out_stride % 2 == 0) && (in_stride % 2 == 0);
         if (b->R > 0)
             b->slot = (b->slot + 1) % b->R;
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
-                                               out, in, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
-                                               b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
-                                               dl.ring, dl.size, tail, dl.head, b->upper_zero)
+        hipEvent_t fe0 = nullptr, fe1 = nullptr;
+        mi::take_profile_events(&fe0, &fe1);
+        #define MI_CALL(LM) MI_LAUNCH((conv_frame_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, fe0, fe1, \
+                                      out, in, out_stride, in_stride, aligned, b->d_ring, b->R, b->slot, \
+                                      b->d_H, b->P, b->d_acc, b->yt_pending ? b->d_yt : nullptr, b->d_tw, \
+                                      dl.ring, dl.size, tail, dl.head, b->upper_zero)
         MI_LOGM_SWITCH(b->logm, MI_CALL)
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
