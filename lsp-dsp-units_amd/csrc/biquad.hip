@@ -878,7 +878,8 @@ namespace
         pc_[slot] += now_ - pt_; pt_ = now_; if ((slot) == 1 && pw1_ == 0) pw1_ = wall_clock64(); if ((slot) == 3 && pw2_ == 0) pw2_ = wall_clock64(); \
         __builtin_amdgcn_sched_barrier(0); } while (0)
     #define MI_STREAM_PROBE_SPIN() (++spins_)
-    #define MI_STREAM_PROBE_ITER(it) do { if (t == 0 && (it) < 20) g_probe[(size_t(blockIdx.x) * NW + wv) * 32 + 11 + (it)] = wall_clock64(); } while (0)
+    #define MI_STREAM_PROBE_ITER(it) do { if (t == 0 && (it) < 20) g_probe[(size_t(blockIdx.x) * NW + wv) * 32 + 11 + (it)] = \
+        (wall_clock64() & 0xffffffffull) | ((__builtin_readcyclecounter() & 0xffffffffull) << 32); } while (0)
     #define MI_STREAM_PROBE_END() do { if (t == 0) { unsigned long long *p_ = g_probe + (size_t(blockIdx.x) * NW + wv) * 32; \
         p_[0] = pw0_; p_[1] = wall_clock64(); p_[2] = __builtin_readcyclecounter() - pc0_; p_[3] = pc_[1]; p_[4] = pc_[2]; p_[5] = pc_[3] + pc_[0]; \
         p_[6] = spins_; p_[7] = pw1_; p_[8] = pw2_; \
@@ -1235,6 +1236,59 @@ namespace
             out[size_t(ch) * out_stride + start + k] = xs[k];
     }
 
+    // The impulse response of a channel's cascade in the REFERENCE's arithmetic, operation for operation: the generic
+    // transposed direct form II section of lsp-dsp-lib (y = b0 x + d0; p1 = b1 x + a1 y; p2 = b2 x + a2 y; d0 = d1 + p1;
+    // d1 = p2 -- every product and every sum rounded on its own, no fused multiply-add), sample after sample.  Design-time
+    // work: the Equalizer synthesises its FIR from this response (Equalizer.cpp:284-288), and the round-off of a float32
+    // recursion through 32 sections is worth 1e-4 of the taps -- taken in another order the taps are another filter of the
+    // same accuracy, taken in this order they are the reference's to the last bit.
+    // One wave per channel, lane j = section j, a systolic line: at step t lane j works on sample t - j, which lane j - 1
+    // finished one step earlier (wave_shr:1); what a section computes for a sample does not depend on when it does.  More
+    // than 64 sections: passes of 64, the later ones reading what the pass before left in `out`.
+    __global__ __launch_bounds__(64)
+    void biquad_reference_ir_kernel(float *out, size_t stride, int n, const float *__restrict__ tab, int tab_row,
+                                    const uint32_t *__restrict__ nsec, int max_sec)
+    {
+        const int ch = int(blockIdx.x), t = int(threadIdx.x);
+        const int ns = int(nsec[ch] & 0x7fffffffu);
+        float *o = out + size_t(ch) * stride;
+        const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(o, 0, n * 4, BUFFER_DWORD3);
+        if (ns == 0)                                         // FilterBank.cpp:261-265: an empty bank copies (the impulse)
+        {
+            for (int i = t; i < n; i += 64)
+                o[i] = (i == 0) ? 1.0f : 0.0f;
+            return;
+        }
+        for (int s0 = 0; s0 < ns; s0 += 64)
+        {
+            const int g = (ns - s0 < 64) ? ns - s0 : 64;    // sections of this pass
+            const float *q = tab + (size_t(ch) * max_sec + s0 + ((t < g) ? t : 0)) * tab_row;
+            const float b0 = q[0], b1 = q[1], b2 = q[2], a1 = q[3], a2 = q[4];
+            float d0 = 0.0f, d1 = 0.0f, y = 0.0f, chunk = 0.0f;
+            for (int s64 = 0; s64 < n + g - 1; s64 += 64)
+            {
+                // the next 64 input samples, one per lane (waited for once, in front of the 64 steps)
+                chunk = (s0 == 0) ? ((s64 + t == 0) ? 1.0f : 0.0f) : ((s64 + t < n) ? o[s64 + t] : 0.0f);
+                const int steps = (n + g - 1 - s64 < 64) ? n + g - 1 - s64 : 64;
+                for (int k = 0; k < steps; ++k)
+                {
+                    const float x0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(chunk), k));
+                    // lane 0 takes the input, lane j what lane j - 1 produced in the step before; lanes that have not
+                    // started yet pass zeros through a zero state, lanes past their last sample produce what nobody stores
+                    const float x = dpp_or<DPP_WAVE_SHR1, 0xf>(x0, y);
+                    y = __fadd_rn(__fmul_rn(b0, x), d0);
+                    const float p1 = __fadd_rn(__fmul_rn(b1, x), __fmul_rn(a1, y));
+                    const float p2 = __fadd_rn(__fmul_rn(b2, x), __fmul_rn(a2, y));
+                    d0 = __fadd_rn(d1, p1);
+                    d1 = p2;
+                    const int i = s64 + k - (g - 1);        // the last section of the pass emits sample i
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(y), dst, (t == g - 1 && i >= 0) ? i * 4 : -4, 0, 0);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next pass reads this pass's output
+        }
+    }
+
     __global__ void impulse_kernel(float *out, size_t stride, size_t samples, uint32_t channels)
     {
         // FilterBank.cpp:316-318: zero the buffer, out[0] = 1
@@ -1518,6 +1572,23 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
 
 namespace mi
 {
+    // FilterBank::impulse_response (FilterBank.cpp:293-330) in the reference's own operation order (see
+    // biquad_reference_ir_kernel): the filter memory is not touched (the response starts from a zeroed one by definition).
+    int biquad_bank_reference_impulse_response(mi_biquad_bank *b, float *out, size_t samples, size_t out_stride, hipStream_t st)
+    {
+        MI_REQUIRE(b != nullptr && out != nullptr && out_stride >= samples && samples < (size_t(1) << 29), MI_EINVAL,
+                   "biquad_bank_reference_impulse_response: bad argument");
+        if (samples == 0)
+            return MI_OK;
+        const int r = commit(b, st);
+        if (r != MI_OK)
+            return r;
+        hipLaunchKernelGGL(biquad_reference_ir_kernel, dim3(b->channels), dim3(64), 0, st, out, out_stride, int(samples),
+                           b->d_small, int(small::TAB), b->d_nsec, int(b->max_sec));
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+
     // The bank over `samples` samples without an output: sums[channel * 4 + s] += the sum of the squares of the filtered
     // samples [seg_end[s - 1], seg_end[s]) (seg_end[3] = samples).  A channel switched off adds nothing.
     // `ep` != NULL: the integrated meter's bookkeeping for this call; *rode tells whether it went with the launch (then

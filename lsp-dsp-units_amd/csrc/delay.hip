@@ -270,10 +270,18 @@ struct mi_delay_bank
     bool        delay_dirty = true;
     // lines with positions of their own (the *_rows calls): offset of every line's write position to `head`; all zero --
     // and the kernels told nothing about it -- until a call moves a subset
+    // The offsets live on the device and are moved there (offsets_update_kernel); `off` is the host's mirror of them, kept
+    // by the same arithmetic, never uploaded.  The row list of a call is the caller's memory: it goes through one of a few
+    // pinned staging slots (a slot is taken again only after the copy out of it has run), so a *_rows call blocks on nothing.
     std::vector<uint32_t> off;
     uint32_t   *d_off = nullptr, *d_rows = nullptr;
     uint32_t    rows_cap = 0;
-    bool        off_any = false, off_dirty = false;
+    bool        off_any = false;
+    static constexpr int ROW_SLOTS = 4;
+    uint32_t   *h_rows = nullptr;                   // pinned: [ROW_SLOTS][rows_cap]
+    hipEvent_t  row_ev[ROW_SLOTS] = { nullptr, nullptr, nullptr, nullptr };
+    bool        row_busy[ROW_SLOTS] = { false, false, false, false };
+    int         row_slot = 0;
 };
 
 // the lines a call moves: all of them (rows == nullptr, n == channels) or the listed ones
@@ -296,16 +304,27 @@ namespace
         return MI_OK;
     }
 
-    int sync_offsets(mi_delay_bank *b, hipStream_t st)
+    // off[line] = value (set) or (off[line] + value) % size, for the listed lines (rows == nullptr: lines 0 .. n - 1)
+    __global__ void offsets_update_kernel(uint32_t *off, const uint32_t *rows, uint32_t n, uint32_t size, uint32_t value, int set)
     {
-        if (!b->off_dirty)
-            return MI_OK;
-        if (b->d_off == nullptr)
-            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_off), b->channels * sizeof(uint32_t)));
-        MI_HIP_CHECK(hipMemcpyAsync(b->d_off, b->off.data(), b->channels * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        MI_HIP_CHECK(hipStreamSynchronize(st));
-        b->off_dirty = false;
+        const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+        if (k >= n)
+            return;
+        const uint32_t c = (rows != nullptr) ? rows[k] : k;
+        off[c] = set ? value : (off[c] + value) % size;
+    }
+
+    int update_offsets(mi_delay_bank *b, const delay_rows &dr, uint32_t value, int set, hipStream_t st)
+    {
+        hipLaunchKernelGGL(offsets_update_kernel, dim3((dr.n + 255) / 256), dim3(256), 0, st, b->d_off, dr.rm.rows, dr.n, b->size, value, set);
+        MI_HIP_CHECK(hipGetLastError());
         return MI_OK;
+    }
+
+    bool capturing(hipStream_t st)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        return st != nullptr && hipStreamIsCapturing(st, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
     }
 
     // The lines of a call.  hrows == nullptr: the whole bank.  The kernels hear about offsets only when there are any.
@@ -315,43 +334,63 @@ namespace
         dr->n = (hrows != nullptr) ? n_rows : b->channels;
         if (hrows != nullptr)
         {
+            // the row list is copied at call time: a replay of a captured call would move whatever the staging slot holds then
+            MI_REQUIRE(!capturing(st), MI_ESTATE, "a call on a subset of the lines (*_rows) cannot be captured into a graph: its row "
+                       "list is read from the caller's memory when the call is made");
             if (b->off.empty())
                 b->off.assign(b->channels, 0);
-            if (n_rows > b->rows_cap)
+            if (n_rows > b->rows_cap)                       // (rare: the staging grows; what is in flight has to land first)
             {
+                MI_HIP_CHECK(hipStreamSynchronize(st));
+                for (int k = 0; k < mi_delay_bank::ROW_SLOTS; ++k)
+                    b->row_busy[k] = false;
                 (void)hipFree(b->d_rows);
+                (void)hipHostFree(b->h_rows);
                 b->d_rows = nullptr;
+                b->h_rows = nullptr;
                 b->rows_cap = 0;
-                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_rows), n_rows * sizeof(uint32_t)));
-                b->rows_cap = n_rows;
+                const uint32_t cap = (n_rows > 64) ? n_rows : 64;
+                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_rows), cap * sizeof(uint32_t)));
+                MI_HIP_CHECK(hipHostMalloc(reinterpret_cast<void **>(&b->h_rows), size_t(mi_delay_bank::ROW_SLOTS) * cap * sizeof(uint32_t),
+                                           hipHostMallocDefault));
+                b->rows_cap = cap;
             }
-            MI_HIP_CHECK(hipMemcpyAsync(b->d_rows, hrows, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-            MI_HIP_CHECK(hipStreamSynchronize(st));        // (hrows is the caller's memory)
-            b->off_any = true;                              // from here on the lines no longer move as one
-            if (b->d_off == nullptr)
-                b->off_dirty = true;
+            const int slot = b->row_slot;
+            b->row_slot = (slot + 1) % mi_delay_bank::ROW_SLOTS;
+            if (b->row_ev[slot] == nullptr)
+                MI_HIP_CHECK(hipEventCreateWithFlags(&b->row_ev[slot], hipEventDisableTiming));
+            if (b->row_busy[slot])
+                MI_HIP_CHECK(hipEventSynchronize(b->row_ev[slot]));        // ROW_SLOTS calls ago: long done
+            uint32_t *stage = b->h_rows + size_t(slot) * b->rows_cap;
+            std::copy(hrows, hrows + n_rows, stage);
+            MI_HIP_CHECK(hipMemcpyAsync(b->d_rows, stage, n_rows * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            MI_HIP_CHECK(hipEventRecord(b->row_ev[slot], st));
+            b->row_busy[slot] = true;
+            if (b->d_off == nullptr)                        // from here on the lines no longer move as one
+            {
+                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_off), b->channels * sizeof(uint32_t)));
+                MI_HIP_CHECK(hipMemsetAsync(b->d_off, 0, b->channels * sizeof(uint32_t), st));
+            }
+            b->off_any = true;
         }
-        const int r = sync_offsets(b, st);
-        if (r != MI_OK)
-            return r;
         dr->rm.rows = (hrows != nullptr) ? b->d_rows : nullptr;
         dr->rm.off = b->off_any ? b->d_off : nullptr;
         return MI_OK;
     }
 
     // what a call did to the positions: a whole-bank call has moved `head`; a call on a subset leaves `head` where it was
-    // and moves the offsets of its lines by the same amount
-    void settle_rows(mi_delay_bank *b, const delay_rows &dr, uint32_t head_before)
+    // and moves the offsets of its lines by the same amount, on the device (behind the call's kernels) and in the mirror
+    int settle_rows(mi_delay_bank *b, const delay_rows &dr, uint32_t head_before, hipStream_t st)
     {
         if (dr.host == nullptr)
-            return;
+            return MI_OK;
         const uint32_t delta = (b->head + b->size - head_before) % b->size;
         b->head = head_before;
         if (delta == 0)
-            return;
+            return MI_OK;
         for (uint32_t r = 0; r < dr.n; ++r)
             b->off[dr.host[r]] = (b->off[dr.host[r]] + delta) % b->size;
-        b->off_dirty = true;
+        return update_offsets(b, dr, delta, 0, st);
     }
 
     int append(mi_delay_bank *b, const delay_rows &dr, const float *src, size_t stride, size_t count, hipStream_t st)
@@ -378,25 +417,25 @@ namespace
         if (count < b->size)
             return append(b, dr, src, stride, count, st);
         // every line of the call restarts at cell 0
+        int r = MI_OK;
         if (dr.host == nullptr)
         {
             b->head = 0;
             if (b->off_any)
             {
                 std::fill(b->off.begin(), b->off.end(), 0u);
-                b->off_dirty = true;
+                MI_HIP_CHECK(hipMemsetAsync(b->d_off, 0, b->channels * sizeof(uint32_t), st));
             }
         }
         else
         {
-            for (uint32_t r = 0; r < dr.n; ++r)
-                b->off[dr.host[r]] = (b->size - b->head % b->size) % b->size;
-            b->off_dirty = true;
+            const uint32_t v = (b->size - b->head % b->size) % b->size;
+            for (uint32_t k = 0; k < dr.n; ++k)
+                b->off[dr.host[k]] = v;
+            r = update_offsets(b, dr, v, 1, st);
+            if (r != MI_OK)
+                return r;
         }
-        int r = sync_offsets(b, st);
-        if (r != MI_OK)
-            return r;
-        dr.rm.off = b->off_any ? b->d_off : nullptr;
         const uint32_t h = b->head;
         r = append(b, dr, src + (count - b->size), stride, b->size, st);
         b->head = h;                                                    // a whole lap: the position is where it was
@@ -492,6 +531,10 @@ int mi_delay_bank_destroy(mi_delay_bank_t *b)
         return MI_OK;
     (void)hipFree(b->d_ring); (void)hipFree(b->d_scratch); (void)hipFree(b->d_delay); (void)hipFree(b->d_delay_new);
     (void)hipFree(b->d_off); (void)hipFree(b->d_rows);
+    (void)hipHostFree(b->h_rows);
+    for (int k = 0; k < mi_delay_bank::ROW_SLOTS; ++k)
+        if (b->row_ev[k] != nullptr)
+            (void)hipEventDestroy(b->row_ev[k]);
     delete b;
     return MI_OK;
 }
@@ -545,8 +588,8 @@ static int delay_append_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t 
         return r;
     const uint32_t head_before = b->head;
     r = append_block(b, dr, in, in_stride, count, st);
-    settle_rows(b, dr, head_before);
-    return r;
+    const int rs = settle_rows(b, dr, head_before, st);
+    return (r != MI_OK) ? r : rs;
 }
 
 static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
@@ -601,8 +644,7 @@ static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t
                            gain, gain_vec, gain_stride, dr.rm);
         MI_HIP_CHECK(hipGetLastError());
         b->head = uint32_t((size_t(b->head) + count) % b->size);
-        settle_rows(b, dr, head_before);
-        return MI_OK;
+        return settle_rows(b, dr, head_before, st);
     }
     if (static_cast<const void *>(out) != static_cast<const void *>(in))
     {
@@ -616,8 +658,8 @@ static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t
                            gain, gain_vec, gain_stride, dr.rm);
         MI_HIP_CHECK(hipGetLastError());
         r = append(b, dr, in, in_stride, count, st);
-        settle_rows(b, dr, head_before);
-        return r;
+        const int rs = settle_rows(b, dr, head_before, st);
+        return (r != MI_OK) ? r : rs;
     }
     if (dmax == 0)
     {
@@ -633,8 +675,8 @@ static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t
             if (hipGetLastError() != hipSuccess)
                 r = mi::fail(MI_EHIP, "%s: launch failed", who);
         }
-        settle_rows(b, dr, head_before);
-        return r;
+        const int rs = settle_rows(b, dr, head_before, st);
+        return (r != MI_OK) ? r : rs;
     }
     const size_t gap = b->size - dmax;
     size_t done = 0;
@@ -652,8 +694,8 @@ static int delay_process_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t
             r = mi::fail(MI_EHIP, "%s: launch failed", who);
         done += n;
     }
-    settle_rows(b, dr, head_before);
-    return r;
+    const int rs = settle_rows(b, dr, head_before, st);
+    return (r != MI_OK) ? r : rs;
 }
 
 static int delay_check_rows(const mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, const char *who)

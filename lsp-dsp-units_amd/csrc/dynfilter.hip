@@ -71,14 +71,22 @@ namespace
     // instructions instead of the ten (and two mode switches) of the compiler's IEEE sequence, whose scaling steps serve
     // operands next to the ends of the exponent range; gains, their roots and the prototype's polynomials are nowhere near.
     // The same quotient bit for bit on 2^24 random pairs from [1e-4, 1e4]^2, half of them reciprocals
-    // (tests/experiments/dyn_div_probe.hip, profiles/r03_experiments/dynfilter_per_type.txt).
+    // (tests/experiments/dyn_div_probe.hip, profiles/r03_experiments/dynfilter_per_type.txt); non-finite results are
+    // redone with the IEEE division (tests/test_dynfilter_gpu.py::test_gain_samples_of_zero).
     __host__ __device__ __attribute__((always_inline)) inline float dv(float a, float b)
     {
 #ifdef __HIP_DEVICE_COMPILE__
         float r = __builtin_amdgcn_rcpf(b);
         r = fmaf(fmaf(-b, r, 1.0f), r, r);
         const float q = a * r;
-        return fmaf(fmaf(-b, q, a), r, q);
+        const float v = fmaf(fmaf(-b, q, a), r, q);
+        // Operands at the ends of the range -- a gain sample of exactly 0 makes logf(g) = -inf, 1 / g = inf -- turn the
+        // correction steps into inf - inf: whatever does not come out finite is divided again the IEEE way (one class
+        // test per division; the branch is not taken on ordinary gains).  The reference computes expf(-inf) = 0 there
+        // and goes on with a finite filter (DynamicFilters.cpp:964-980).
+        if (__builtin_expect(__builtin_amdgcn_classf(v, 0x207), 0))       // sNaN | qNaN | -inf | +inf
+            return a / b;
+        return v;
 #else
         return a / b;
 #endif

@@ -221,7 +221,8 @@ namespace
         {
             if (b->mode == MI_EQM_FIR)
             {
-                if ((r = mi_biquad_bank_impulse_response(b->biquads, b->d_ir, N, N, stream)) != MI_OK) return r;
+                // (the reference's arithmetic operation for operation: the taps are then the reference's, see biquad.hip)
+                if ((r = mi::biquad_bank_reference_impulse_response(b->biquads, b->d_ir, N, N, st)) != MI_OK) return r;
                 #define MI_CALL(LN) hipLaunchKernelGGL((eq_ir_to_magnitude_kernel<LN>), dim3(b->channels), dim3(plan<LN>::T), 0, st, \
                                                        b->d_mag, b->d_ir, N, b->d_wnd2n_tail, b->d_tw)
                 MI_LOGN_SWITCH(int(b->fir_rank), MI_CALL)

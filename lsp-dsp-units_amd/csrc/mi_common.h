@@ -67,6 +67,11 @@ namespace mi
                                   const uint32_t seg_end[3], float *sums, hipStream_t st,
                                   const mi_meters::ilufs_epilogue *ep = nullptr, bool *rode = nullptr);
 
+    // The impulse response of every channel's cascade in the reference's own operation order (unfused, sample after
+    // sample): what the Equalizer synthesises its FIR from.  biquad.hip.
+    int         biquad_bank_reference_impulse_response(mi_biquad_bank_t *bank, float *out, size_t samples, size_t out_stride,
+                                                       hipStream_t st);
+
     // Device twiddle table exp(-2 pi i j / twn), one per device, created on first use (convolver.hip).
     int         fft_twiddles(const float2 **tw, int *twn);
     // Complex transform of `channels` sequences of 2^rank points (rank 15 .. 18) through global memory (spectral.hip, the

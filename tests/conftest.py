@@ -54,6 +54,27 @@ def record_parity(rule, value, bound, **extra):
                  **{"worst_" + k: (float(v) if isinstance(v, (int, float, np.floating)) else v) for k, v in extra.items()})
 
 
+_NOTES = []
+
+
+def note(text):
+    """A line for the end-of-session summary (shown by -q as well, so it lands in the driver's pytest log): the full-size
+    parity tests leave their measured distributions here, not only in gpurun_out/."""
+    print(text)
+    _NOTES.append("%s: %s" % (os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], text))
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    if _NOTES:
+        terminalreporter.section("parity notes (measured in this session)")
+        for line in _NOTES:
+            terminalreporter.write_line(line)
+    if _LEDGER:
+        terminalreporter.section("parity ledger: worst error / allowed error per tolerance rule")
+        for k, v in sorted(_LEDGER.items()):
+            terminalreporter.write_line("%6.3f  (%d checks)  %s" % (v["worst_ratio_to_bound"], v["checks"], k))
+
+
 def pytest_sessionfinish(session, exitstatus):
     if not _LEDGER:
         return
@@ -97,16 +118,17 @@ def parity_report(gpu_out, ref32, ref64, peak=None, noise_over=None):
 TOL = 1e-5
 # a recursion whose float32 round-off noise is below this is "well conditioned": strict tolerance applies
 NOISE_FLOOR = 2e-6      # = TOL / 5: the noise rule below turns into the strict one exactly here (no jump in the bound)
-# Factors of the noise rule, set from the distribution measured on all 1024 channels of C2 on the MI355X
-# (tests/test_biquad_gpu.py::test_c2_full_size_all_channels writes it to gpurun_out/c2_parity.json; the committed copy
-# is profiles/c2_parity_latest.json).  Round 2, 652 channels above the noise floor:
-#   |gpu - exact| / noise   median 0.55, 90 % 1.10, 99 % 1.71, worst 2.61  (the GPU result is usually CLOSER to exact
-#                           arithmetic than the reference's own float32 recursion is)
-#   |gpu - oracle| / noise  median 1.15, 90 % 1.58, 99 % 2.11, worst 2.75  (two independent round-off walks)
-# `noise` is itself the maximum of ONE round-off walk, so single-run ratios scatter by about a factor of two; the
-# factors are 1.5x / 1.8x the worst ratio seen, i.e. a channel fails before it reaches twice the measured worst case.
-IIR_EXACT_FACTOR = 4.0  # |gpu - exact|  <= IIR_EXACT_FACTOR * noise
-IIR_REF_FACTOR = 5.0    # |gpu - oracle| <= IIR_REF_FACTOR * noise
+# Factors of the noise rule, set from the distribution measured on all 1024 channels of C2 on the MI355X over 64 blocks
+# with carried state (tests/test_biquad_gpu.py::test_c2_full_size_all_channels prints it and writes it to
+# gpurun_out/c2_parity.json; committed copies: profiles/r0N_c2_parity.json).  Round 3, 667 channels above the noise floor:
+#   |gpu - exact| / noise   median 0.51, worst 2.02  (the GPU result is usually CLOSER to exact arithmetic than the
+#                           reference's own float32 recursion is)
+#   |gpu - oracle| / noise  worst 2.54               (two independent round-off walks)
+# `noise` is itself the maximum of ONE round-off walk, so single-run ratios scatter; the factors are 1.5x the worst ratio
+# measured: a channel fails well before it reaches twice the measured worst case.  (Over every other IIR check of a GPU
+# session the worst ratio to these bounds was 0.29 in round 3: profiles/r03_parity_report.json.)
+IIR_EXACT_FACTOR = 3.0  # |gpu - exact|  <= IIR_EXACT_FACTOR * noise
+IIR_REF_FACTOR = 3.75   # |gpu - oracle| <= IIR_REF_FACTOR * noise
 
 
 def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None, noise_over=None):
@@ -114,8 +136,8 @@ def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None, noise_over=None
 
     * well-conditioned filter (reference's own float32 noise <= NOISE_FLOOR): |gpu - ref32| <= 1e-5 * peak;
     * otherwise the float32 recursion itself is only reproducible to `noise`; the GPU result must then be
-      of the same accuracy class: within 4x the reference's own distance from exact arithmetic (the
-      single-run maximum of a round-off random walk varies by that much between equally good orderings)."""
+      of the same accuracy class: within IIR_EXACT_FACTOR x the reference's own distance from exact arithmetic and within
+      IIR_REF_FACTOR x of the oracle (1.5 x the worst ratios measured over all channels of C2)."""
     r = parity_report(gpu_out, ref32, ref64, peak, noise_over)
     msg = "%s: %s" % (what, r)
     assert np.all(np.isfinite(gpu_out)), msg
@@ -123,9 +145,9 @@ def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None, noise_over=None
         record_parity("iir strict: |gpu - oracle| <= 1e-5 peak (oracle noise <= 2e-6)", r["gpu_vs_ref32"], TOL, noise=r["noise"])
         assert r["gpu_vs_ref32"] <= TOL, msg
     else:
-        record_parity("iir noisy: |gpu - exact| <= max(1e-5, 4 noise)", r["gpu_vs_exact"], max(TOL, IIR_EXACT_FACTOR * r["noise"]),
+        record_parity("iir noisy: |gpu - exact| <= max(1e-5, %g noise)" % IIR_EXACT_FACTOR, r["gpu_vs_exact"], max(TOL, IIR_EXACT_FACTOR * r["noise"]),
                       noise=r["noise"], over_noise=r["gpu_vs_exact"] / r["noise"])
-        record_parity("iir noisy: |gpu - oracle| <= max(1e-5, 5 noise)", r["gpu_vs_ref32"], max(TOL, IIR_REF_FACTOR * r["noise"]),
+        record_parity("iir noisy: |gpu - oracle| <= max(1e-5, %g noise)" % IIR_REF_FACTOR, r["gpu_vs_ref32"], max(TOL, IIR_REF_FACTOR * r["noise"]),
                       noise=r["noise"], over_noise=r["gpu_vs_ref32"] / r["noise"])
         assert r["gpu_vs_exact"] <= max(TOL, IIR_EXACT_FACTOR * r["noise"]), msg
         assert r["gpu_vs_ref32"] <= max(TOL, IIR_REF_FACTOR * r["noise"]), msg

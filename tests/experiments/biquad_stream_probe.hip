@@ -7,6 +7,7 @@
 #include "../../lsp-dsp-units_amd/csrc/biquad.hip"
 #include <algorithm>
 #include <cstdio>
+#include <cmath>
 #include <map>
 
 int main(int argc, char **argv)
@@ -18,12 +19,29 @@ int main(int argc, char **argv)
     mi_biquad_bank_t *bank = nullptr;
     if (mi_biquad_bank_create(&bank, C, NS ? NS : 1) != MI_OK) { printf("create: %s\n", mi_dspu_last_error()); return 1; }
     std::vector<mi_biquad_x1_t> ch(size_t(C) * (NS ? NS : 1));
-    for (auto &q : ch) { q.b0 = 0.2f; q.b1 = 0.4f; q.b2 = 0.2f; q.a1 = 0.5f; q.a2 = -0.3f; q.p0 = q.p1 = q.p2 = 0.0f; }
+    // per-channel low-passes with cut-offs log-uniform in 200 Hz .. 18 kHz (RBJ form, Q 0.75; a1, a2 with the reference's
+    // sign convention: already negated) and noise as input, so that the arithmetic draws the power of the real workload
+    for (uint32_t c = 0; c < C; ++c)
+    {
+        const double fc = 200.0 * std::pow(90.0, double((c * 2654435761u) % 1024) / 1024.0), w = 2.0 * M_PI * fc / 48000.0;
+        const double al = std::sin(w) / 1.5, a0 = 1.0 + al, cs = std::cos(w);
+        for (uint32_t k = 0; k < (NS ? NS : 1); ++k)
+        {
+            mi_biquad_x1_t &q = ch[size_t(c) * (NS ? NS : 1) + k];
+            q.b0 = float((1.0 - cs) / 2.0 / a0); q.b1 = float((1.0 - cs) / a0); q.b2 = q.b0;
+            q.a1 = float(2.0 * cs / a0); q.a2 = float(-(1.0 - al) / a0); q.p0 = q.p1 = q.p2 = 0.0f;
+        }
+    }
     mi_biquad_bank_set_all_chains(bank, ch.data(), NS, 1);
     float *in, *out;
     const int ring = 16;
     hipMalloc(&in, ring * C * n * sizeof(float)); hipMalloc(&out, ring * C * n * sizeof(float));
-    hipMemset(in, 0, ring * C * n * sizeof(float));
+    {
+        std::vector<float> hx(size_t(ring) * C * n);
+        uint32_t r = 12345u;
+        for (auto &v : hx) { r = r * 1664525u + 1013904223u; v = (float(r >> 8) / 8388608.0f - 1.0f) * 0.5f; }
+        hipMemcpy(in, hx.data(), hx.size() * sizeof(float), hipMemcpyHostToDevice);
+    }
     std::vector<float *> po(K);
     std::vector<const float *> pi(K);
     for (int k = 0; k < K; ++k) { po[k] = out + size_t(k % ring) * C * n; pi[k] = in + size_t(k % ring) * C * n; }
@@ -61,16 +79,34 @@ int main(int argc, char **argv)
     stat("  sections", 4, false, per);
     stat("  transposition, store issue, loop", 5, false, per);
     stat("turns of the hand-over wait loop per block", 6, false, per);
-    // the stream's pace: when the waves left their i-th sub-block
-    printf("wave iteration i done (us): min / median / max over the waves, and the median's step\n");
+    {
+        std::vector<double> v;
+        for (uint32_t b = 0; b < WAVES; ++b) v.push_back(double(h[b * 32 + 2]) / ((h[b * 32 + 1] - h[b * 32 + 0]) / 100.0) / 1000.0);
+        std::sort(v.begin(), v.end());
+        printf("  %-44s %9.3f %9.3f %9.3f\n", "shader clock (GHz: cycles / wall time)", v.front(), v[v.size() / 2], v.back());
+    }
+    // the stream's pace: when the waves left their i-th sub-block, and the shader clock over that sub-block
+    printf("wave iteration i done (us): min / median / max over the waves, the median's step, median clock (GHz) over the iteration\n");
     double prev = 0;
     for (int it = 0; it < 20 && it * NWV < K * int((n + 2047) / 2048); ++it)
     {
-        std::vector<double> v;
-        for (uint32_t b = 0; b < WAVES; ++b) if (h[b * 32 + 11 + it]) v.push_back((h[b * 32 + 11 + it] - t0) / 100.0);
+        std::vector<double> v, ck;
+        for (uint32_t b = 0; b < WAVES; ++b)
+        {
+            const unsigned long long cur = h[b * 32 + 11 + it];
+            if (!cur) continue;
+            v.push_back(double(uint32_t(cur) - uint32_t(t0)) / 100.0);
+            if (it > 0 && h[b * 32 + 10 + it])
+            {
+                const unsigned long long pr = h[b * 32 + 10 + it];
+                const double dw = double(uint32_t(cur) - uint32_t(pr)) / 100.0, dc = double(uint32_t(cur >> 32) - uint32_t(pr >> 32));
+                if (dw > 0) ck.push_back(dc / dw / 1000.0);
+            }
+        }
         if (v.empty()) break;
         std::sort(v.begin(), v.end());
-        printf("  %2d: %8.2f %8.2f %8.2f   +%.2f\n", it, v.front(), v[v.size() / 2], v.back(), v[v.size() / 2] - prev);
+        std::sort(ck.begin(), ck.end());
+        printf("  %2d: %8.2f %8.2f %8.2f   +%.2f   %.3f\n", it, v.front(), v[v.size() / 2], v.back(), v[v.size() / 2] - prev, ck.empty() ? 0.0 : ck[ck.size() / 2]);
         prev = v[v.size() / 2];
     }
     // age inside a CU: the workgroups of a CU in the order of their entry, and when each one left

@@ -350,6 +350,49 @@ def test_delay_rows_argument_errors(gpu):
     bank.close()
 
 
+def test_delay_rows_calls_are_refused_while_the_stream_captures(gpu):
+    """A call on a subset of the lines reads its row list from the caller's memory when it is made: inside a graph capture it
+    is refused (MI_ESTATE) before anything is copied or synchronised, the capture stays valid, and whole-bank calls of a bank
+    whose lines already stand at positions of their own are still captured (the offsets live on the device)."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    s = ctypes.c_void_p()
+    assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+    st = s.value
+    C, n = 4, 64
+    rng = np.random.default_rng(5)
+    refs = [od.Delay(300) for _ in range(C)]
+    K = refs[0].size // n                                    # a graph of the bank covers whole laps of the write position
+    x = rng.standard_normal((1 + K, C, n)).astype(np.float32)
+    bank = gpu.DelayBank(C, 300)
+    for c in range(C):
+        bank.set_delay(40 + 8 * c, channel=c)
+        refs[c].set_delay(40 + 8 * c)
+    # lines 1 and 3 move ahead of the others
+    d0 = gpu.DeviceBuffer.from_host(x[0][[1, 3]], stream=st)
+    o0 = gpu.DeviceBuffer((2, n))
+    bank.process_rows([1, 3], o0, d0, n, stream=st)
+    for k, c in enumerate((1, 3)):
+        np.testing.assert_array_equal(o0.download(stream=st)[k], refs[c].process(x[0][c]))
+    din = [gpu.DeviceBuffer.from_host(x[1 + b], stream=st) for b in range(K)]
+    dout = [gpu.DeviceBuffer((C, n)) for _ in range(K)]
+    gpu.check(gpu.lib.mi_dspu_graph_begin_capture(ctypes.c_void_p(st)))
+    with pytest.raises(gpu.MiError):
+        bank.process_rows([0, 2], o0, d0, n, stream=st)
+    for b in range(K):
+        bank.process(dout[b], din[b], n, stream=st)
+    h = ctypes.c_void_p()
+    gpu.check(gpu.lib.mi_dspu_graph_end_capture(ctypes.c_void_p(st), ctypes.byref(h)))
+    gpu.check(gpu.lib.mi_dspu_graph_launch(h, ctypes.c_void_p(st)))
+    for b in range(K):
+        y = dout[b].download(stream=st)
+        for c in range(C):
+            np.testing.assert_array_equal(y[c], refs[c].process(x[1 + b][c]))
+    gpu.lib.mi_dspu_graph_destroy(h)
+    bank.close()
+    hip.hipStreamDestroy(s)
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_ring_random_operation_sequences_bit_exact(gpu, seed):
     """RingBuffer: append (also more than a whole buffer: the reference restarts at cell 0), block get with every kind of

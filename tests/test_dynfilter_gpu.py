@@ -113,6 +113,47 @@ def test_every_type_on_whole_super_blocks(gpu, t):
     bank.close()
 
 
+@pytest.mark.parametrize("t", [fd.FLT_BT_RLC_RESONANCE, fd.FLT_MT_RLC_RESONANCE, fd.FLT_BT_RLC_BELL, fd.FLT_BT_RLC_LOSHELF,
+                               fd.FLT_BT_RLC_HISHELF, fd.FLT_BT_BWC_BELL, fd.FLT_BT_LRX_LOSHELF, fd.FLT_BT_AMPLIFIER])
+def test_gain_samples_of_zero(gpu, t):
+    """Gain samples of exactly 0 (and next to the ends of the float range) among ordinary ones: logf(g) = -inf and 1 / g =
+    inf reach the builders' divisions.  Where the reference's arithmetic stays finite (RLC_RESONANCE: t = {1, 0, 1},
+    DynamicFilters.cpp:964-980) the device must follow it and the memory must stay usable for the block behind; where the
+    reference itself leaves the finite numbers (a division by the gain) only the blocks before are compared."""
+    rng = np.random.default_rng(700 + t)
+    C, n = 2, 1024
+    bank = gpu.DynFilterBank(C, 1)
+    bank.set_sample_rate(SR)
+    bank.set_params(0, t, 1, 1200.0, 5000.0, 1.0, 0.6)
+    bank.set_filter_active(0)
+    refs = [df.DynamicFilters(1) for _ in range(C)]
+    for r in refs:
+        r.set_sample_rate(SR)
+        r.set_params(0, t, 1, 1200.0, 5000.0, 1.0, 0.6)
+        r.set_filter_active(0, True)
+    x = (rng.standard_normal((3, C, n)) * 0.25).astype(np.float32)
+    g = gains(rng, C, 3 * n, "sweep").reshape(C, 3, n).transpose(1, 0, 2).copy()
+    g[1, 0, 100:140] = 0.0                                    # a stretch of zeros, single zeros, tiny and large gains
+    g[1, 0, 500] = 0.0
+    g[1, 1, 300:310] = np.float32(1e-30)
+    g[1, 1, 700:705] = np.float32(50.0)
+    finite = True
+    for b in range(3):
+        din, dg, dout = gpu.DeviceBuffer.from_host(x[b]), gpu.DeviceBuffer.from_host(g[b]), gpu.DeviceBuffer((C, n))
+        bank.process(0, dout, din, dg, n)
+        y = dout.download()
+        for c in range(C):
+            with np.errstate(all="ignore"):
+                ref, exact = refs[c].process(0, x[b, c], g[b, c], exact=True)
+            if not (np.all(np.isfinite(ref)) and np.all(np.isfinite(exact))):
+                finite = False                                # the reference left the finite numbers: nothing to hold on to
+            if finite:
+                check(y[c], ref, exact, "%s block %d ch %d" % (fd.FILTER_TYPES[t], b, c), coef_tol=0.0 if (t & 1) else 1e-3)
+    if t in (fd.FLT_BT_RLC_RESONANCE, fd.FLT_BT_AMPLIFIER):
+        assert finite, "the reference's arithmetic is finite at gain 0 for this type"
+    bank.close()
+
+
 @pytest.mark.parametrize("kind", ["constant", "sweep", "jumpy"])
 def test_gain_shapes_sizes_and_in_place(gpu, kind):
     """Constant, slowly varying and sample-to-sample gains; ragged call sizes around the 1024-sample block and the

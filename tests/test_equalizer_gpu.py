@@ -1,6 +1,8 @@
 """GPU parity of mi_equalizer_bank_* (lsp::dspu::Equalizer) against the CPU oracle, through the C-ABI."""
 import numpy as np
-from conftest import record_parity
+import os
+
+from conftest import note, record_parity
 import pytest
 
 from oracle import equalizer as oe
@@ -72,19 +74,9 @@ def test_c4_shape_32_band_eq(gpu, mode):
             # the IIR rule of conftest.assert_iir_parity applies (DESIGN.md "Parity for recursive filters")
             assert_iir_parity(y[c], ref, oracle.biquad_cascade_f64(x[c], refs[c].coef), "EQ IIR ch%d" % c)
             continue
-        tol = 2 * TOL
-        if mode == oe.FIR:
-            # the FIR is synthesised from that same recursion's impulse response: measure how far the
-            # reference's float32 impulse response moves the output, and allow that much
-            ex = oe.Equalizer(nfilt, rank); ex.set_mode(mode); ex.set_sample_rate(48000)
-            ex.params = [p.copy() for p in refs[c].params]
-
-            def exact_ir(n_, coef, state):
-                imp = np.zeros(n_); imp[0] = 1.0
-                return oracle.biquad_cascade_f64(imp, coef).astype(np.float32)
-            ex.ir_func = exact_ir
-            noise = np.abs(ex.process(x[c]) - ref).max() / np.abs(ref).max()
-            tol = max(tol, 4.0 * noise)
+        # FIR: the taps come from the impulse response taken in the reference's operation order (biquad_reference_ir_kernel):
+        # no allowance for the recursion's round-off any more; FFT / SPM: the transforms' round-off on a few-tap response
+        tol = TOL if mode == oe.FIR else 2 * TOL
         peak = np.abs(ref).max()
         err = np.abs(y[c] - ref).max() / peak
         assert err <= tol, (mode, c, err, tol)
@@ -227,12 +219,11 @@ def test_random_operation_sequences_match_oracle(gpu, seed):
 
 def test_c4_full_size(gpu):
     """BASELINE config 3 at the per-GPU size: 256 channels, 32 RLC bells each with its own gains (seed 6), fir_rank 12,
-    EQM_FIR, blocks of 4096.  Sampled channels against the oracle; over all channels the size-independent properties:
-    a second bank fed the same input gives the same bits, and an input scaled by 2 gives exactly twice the output."""
+    EQM_FIR, blocks of 4096.  Every channel against the oracle, and the size-independent properties: a second bank fed the
+    same input gives the same bits, and an input scaled by 2 gives exactly twice the output."""
     rng = np.random.default_rng(6)
     C, rank, nfilt, n, blocks = 256, 12, 32, 4096, 3
     x = (rng.standard_normal((C, n * blocks)) * 0.25).astype(np.float32)
-    sampled = (0, 100, 255)
     curves = [c4_filters(rng) for _ in range(C)]
 
     def run(scale):
@@ -254,26 +245,31 @@ def test_c4_full_size(gpu):
     assert np.isfinite(y1).all() and float(np.abs(y1).max()) > 0.0
     np.testing.assert_array_equal(y1, y1b)
     np.testing.assert_array_equal(y2, 2.0 * y1)
-    import oracle
-
-    def exact_ir(n_, coef, state):
-        imp = np.zeros(n_); imp[0] = 1.0
-        return oracle.biquad_cascade_f64(imp, coef).astype(np.float32)
-    for c in sampled:
-        refs = []
-        for ir_func in (None, exact_ir):
-            o = oe.Equalizer(nfilt, rank); o.set_mode(oe.FIR); o.set_sample_rate(48000)
-            for i, p in enumerate(curves[c]):
-                o.set_params(i, fd.Params(*p))
-            if ir_func is not None:
-                o.ir_func = ir_func
-            refs.append(o.process(x[c]))
-        ref, peak = refs[0], np.abs(refs[0]).max()
-        # the FIR is synthesised from the float32 impulse response of 32 sections: allow what that response's own
-        # round-off moves the output (same rule as test_c4_shape_32_band_eq)
-        noise = float(np.abs(refs[1] - ref).max() / peak)
-        err = float(np.abs(y1[c] - ref).max() / peak)
-        print("C4 full size ch %d: |gpu - oracle| / peak = %.2e (impulse-response round-off %.2e)" % (c, err, noise))
-        record_parity("equalizer FIR full size: |gpu - oracle| <= max(2e-5, 4 x impulse-response round-off)", err,
-                      max(2 * TOL, 4.0 * noise), noise=noise)
-        assert err <= max(2 * TOL, 4.0 * noise), (c, err, noise)
+    # EVERY channel against the oracle (worker processes: 0.3 s of oracle per channel)
+    import oracle_workers as ow
+    refs = ow.run_pool(ow.c4_channel, [(curves[c], x[c], nfilt, rank) for c in range(C)])
+    errs, exacts, noises = np.empty(C), np.empty(C), np.empty(C)
+    for c in range(C):
+        ref, ref_exact = refs[c]
+        peak = np.abs(ref).max()
+        # The FIR is synthesised from the float32 impulse response of 32 sections (Equalizer.cpp:284-345): that recursion's
+        # own round-off moves the output by `noise` (the oracle run again with the impulse response taken in float64).
+        noises[c] = float(np.abs(ref_exact - ref).max() / peak)
+        errs[c] = float(np.abs(y1[c] - ref).max() / peak)
+        exacts[c] = float(np.abs(y1[c] - ref_exact).max() / peak)
+    pct = lambda v: [round(float(np.percentile(v, q)), 2) for q in (50, 90, 99, 100)]
+    note("C4 full size, all %d channels against the oracle: |gpu - oracle| / peak median %.2e, max %.2e; channels within 1e-5: %d; "
+         "the FIR synthesis' own float32 noise: median %.2e, max %.2e; |gpu - float64-response output| / noise percentiles "
+         "50/90/99/100 = %s, |gpu - oracle| / noise = %s"
+         % (C, float(np.median(errs)), float(errs.max()), int((errs <= TOL).sum()), float(np.median(noises)), float(noises.max()),
+            pct(exacts / noises), pct(errs / noises)))
+    if os.environ.get("MI_DUMP_C4"):
+        np.savez(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "c4_parity.npz"),
+                 errs=errs, exacts=exacts, noises=noises)
+    # The north-star tolerance, every channel: the FIR is synthesised from the impulse response taken in the reference's own
+    # operation order (biquad_reference_ir_kernel), so the taps are the oracle's and what is left is the round-off of the
+    # transforms.  (The float32 synthesis itself sits 8e-5 .. 2.5e-3 of the peak from a float64 one: `noises` -- an
+    # impulse response taken in any other order would be that far from the oracle as well.)
+    for c in range(C):
+        record_parity("equalizer FIR full size: |gpu - oracle| <= 1e-5 peak (every channel)", errs[c], TOL, noise=noises[c])
+    assert np.all(errs <= TOL), (int(np.argmax(errs)), float(errs.max()))
