@@ -922,29 +922,10 @@ namespace
         const int t   = tid & 63;
         const int wv  = __builtin_amdgcn_readfirstlane(tid >> 6);
         const int l16 = t & 15;
-        const int ns  = int(nsec[ch]);
-        if (ns < 0)                                          // row switched off
-            return;
         float *const sx = sx_all + wv * 64 * PITCH;
         const bool lane0 = (t == 0), row3 = (t >= 48);
         const float *ctab = tab + size_t(ch) * max_sec * TAB;
         float *const mem = state + size_t(ch) * max_sec * 2;
-
-        // the cells: nothing published yet (seq 0), and the memory the call starts from as "the state behind sub-block -1"
-        for (int i = tid; i < ns * NW; i += 64 * NW)
-        {
-            const int si = i / NW, w = i - si * NW;
-            stream_cell c = { 0.0f, 0.0f, 0u, 0u };
-            if (w == NW - 1)
-            {
-                const float2 s = reinterpret_cast<const float2 *>(mem)[si];
-                c.d0 = s.x;
-                c.d1 = s.y;
-            }
-            cell[si][w] = c;
-        }
-        __syncthreads();
-
         const int spb   = (n + SB - 1) / SB;                 // sub-blocks of a block
         const int total = a.blocks * spb;
         const int pred  = (wv + NW - 1) % NW;
@@ -1002,6 +983,28 @@ namespace
             }
         };
 
+        // the first tile's loads go out before anything else is asked of memory (section count, filter memory, tables):
+        // those arrive underneath them
+        if (wv < total)
+            issue_loads(wv);
+        const int ns  = int(nsec[ch]);
+        if (ns < 0)                                          // row switched off
+            return;
+        // the cells: nothing published yet (seq 0), and the memory the call starts from as "the state behind sub-block -1"
+        for (int i = tid; i < ns * NW; i += 64 * NW)
+        {
+            const int si = i / NW, w = i - si * NW;
+            stream_cell c = { 0.0f, 0.0f, 0u, 0u };
+            if (w == NW - 1)
+            {
+                const float2 s = reinterpret_cast<const float2 *>(mem)[si];
+                c.d0 = s.x;
+                c.d1 = s.y;
+            }
+            cell[si][w] = c;
+        }
+        __syncthreads();
+
         v2f x[L];
         sectab tb;
         if (ns > 0)
@@ -1010,8 +1013,6 @@ namespace
             load_mats(tb, ctab);
             load_coefs(tb, ctab);
         }
-        if (wv < total)
-            issue_loads(wv);
         MI_STREAM_PROBE_BEGIN();
 
         for (int g = wv; g < total; g += NW)

@@ -28,9 +28,11 @@
  *      file's impulse response equals the transfer function Filter::freq_chart
  *      evaluates from the analog prototype (Filter.cpp:500-696) -- a wrong sign,
  *      section order, state update or delay in the recurrence below breaks it;
- *  (3) the impulse response head of the README filter recorded from the
- *      reference's own objects by the survey probe (SURVEY.md Appendix C,
- *      tests/golden/filter_anchors.json), same file.
+ *  (3) on the device, tests/hip/serial_biquad.hip runs this recurrence operation for operation and equals this
+ *      file bit for bit (tests/test_biquad_gpu.py::test_device_twin_equals_the_oracle): the GPU's float32
+ *      arithmetic is the one written here.
+ * The README filter values in tests/golden/filter_anchors.json were recorded by the survey probe with stand-in
+ * headers and a scalar shim: a regression check of the designer, not a pin of this arithmetic.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off so the rounding is the
  * same on every host).
