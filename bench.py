@@ -204,10 +204,15 @@ def _biquad_issue_side(kernel_ms, C, n, sections, launch_steps, counters):
             "counters_from": "profiles/" + counters}
 
 
-def _pmc_traffic(name):
-    """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None."""
+def _pmc_traffic(name, kernel=None, units=1):
+    """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None.  kernel: the summary must be
+    of that kernel; units: what this run's launch carries (blocks of a biquad_stream_kernel launch) -- the summary holds the
+    bytes per unit of the launch it was taken from."""
     try:
-        return json.load(open(os.path.join(ROOT, "profiles", name))).get("hbm_bytes_per_launch")
+        d = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if kernel is not None and kernel not in d.get("kernel", ""):
+            return None
+        return d["hbm_bytes_per_unit"] * units if "hbm_bytes_per_unit" in d else d.get("hbm_bytes_per_launch")
     except Exception:
         return None
 
@@ -1025,7 +1030,7 @@ def main():
         kname = "biquad_stream_kernel<4> (%d blocks per launch)" % launch_steps if streamed else "biquad_bank_kernel<16,2>"
         committed = {"note": "read from files committed under profiles/ (collected by tests/prof_round.sh in an earlier "
                              "run of the same command), not measured by this run",
-                     "traffic": _pmc_traffic("pmc_biquad_latest.json"),
+                     "traffic": _pmc_traffic("pmc_biquad_latest.json", "biquad_stream_kernel" if streamed else "biquad_bank_kernel", launch_steps),
                      "rocprofv3_avg_us": _profile_avg_us("biquad", "biquad_stream_kernel" if streamed else "biquad_bank_kernel<16, 2")
                                          if (C, n) == (1024, 4096) else None,
                      "parity": _committed_json("c2_parity_latest.json")}

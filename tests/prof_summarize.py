@@ -12,8 +12,10 @@ import json
 import os
 import sys
 
-KERNELS = {"biquad": "biquad_bank_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frame_kernel",
+KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frame_kernel",
            "spectral": "analyzer_kernel"}
+# the PMC passes run `bench.py --steps 50`: the headline's launch (biquad_stream_kernel) then carries 50 blocks
+UNITS_PER_LAUNCH = {"biquad": 50}
 
 
 def main():
@@ -43,7 +45,8 @@ def main():
         if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
             hbm = (per["FETCH_SIZE"]["avg_KB"] * 2.0 + per["WRITE_SIZE"]["avg_KB"]) * 1024.0
             with open(os.path.join(dst, "pmc_%s_latest.json" % wl), "w") as f:
-                json.dump({"hbm_bytes_per_launch": hbm, "kernel": kname,
+                units = UNITS_PER_LAUNCH.get(wl, 1)
+                json.dump({"hbm_bytes_per_launch": hbm, "kernel": kname, "units_per_launch": units, "hbm_bytes_per_unit": hbm / units,
                            "note": "rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes (%s_pmc_hbm_raw.json); "
                                    "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports half of wide coalesced "
                                    "reads); KB -> bytes" % tag}, f, indent=1)
