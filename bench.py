@@ -631,7 +631,22 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         eq.process(yout[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup)
+    # the K steps of a region as ONE mi_equalizer_bank_process_blocks call: runs of up to 128 blocks ride one launch of
+    # conv_frames_kernel (the response's image and the overlap-add tail stay in registers from block to block)
+    import ctypes
+    K = args.conv_steps
+    seq = [(args.conv_warmup + i) % ring for i in range(K)]
+    po = (ctypes.c_void_p * K)(*[yout[k].data_ptr() for k in seq])
+    pi = (ctypes.c_void_p * K)(*[xin[k].data_ptr() for k in seq])
+    st_ptr = ctypes.c_void_p(stream.cuda_stream)
+    launch_steps = min(K, 128)
+
+    def region():
+        mi.check(mi.lib.mi_equalizer_bank_process_blocks(eq.handle, po, pi, K, n, n, n, st_ptr))
+    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, region=region,
+                                             probe_step=lambda j: region(), probe_steps=launch_steps)
+    tinfo["launch"] = "one mi_equalizer_bank_process_blocks call per region: runs of up to 128 blocks ride ONE launch (conv_frames_kernel)"
+    pc_elapsed, pc_kernel_ms, pc_info = _timed_steps(mi, torch, dist, world, dev, step, K, 0)
     assert bool(torch.isfinite(yout[0]).all())
     eq.close()
     if rank != 0:
@@ -647,11 +662,20 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
                                "4096-sample blocks" % C, "channels_per_gpu": C},
         # the step is ONE launch: conv_frame_kernel<12> pulls the frame out of the delay line, transforms, multiplies with
         # the channel's FIR image, transforms back, overlap-adds and emits
-        "roofline": _roofline("conv_frame_kernel<12>", step_bytes, kernel_ms, elapsed / args.conv_steps * 1e3, tinfo["probe"],
-                              _pmc_traffic("pmc_equalizer_latest.json") if C == 256 else None),
+        "timing": tinfo,
+        # the region is ONE launch per 128 blocks: conv_frames_kernel walks the blocks of a channel -- frame out of the delay
+        # line once, transforms, product with the channel's FIR image (in registers), inverse, overlap-add, emission
+        "roofline": _roofline("conv_frames_kernel<12> (%d blocks per launch)" % launch_steps, step_bytes * launch_steps, kernel_ms,
+                              elapsed / args.conv_steps * 1e3, tinfo["probe"],
+                              _pmc_traffic("pmc_equalizer_latest.json", "conv_frames_kernel", launch_steps) if C == 256 else None,
+                              launch_steps=launch_steps),
         "whole_step": {"algorithmic_bytes": step_bytes,
                        "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / args.conv_steps) / 1e9, 1),
                        "frac": round(step_bytes / (elapsed / args.conv_steps) / 1e9 / HBM_PEAK_GBS, 4)},
+        "per_call": {"what": "the same blocks as separate mi_equalizer_bank_process calls (one launch of conv_frame_kernel per block)",
+                     "value": round(C * n * world * args.conv_steps / pc_elapsed / 1e6, 1), "unit": "Msamples/s",
+                     "ms_per_step": round(pc_elapsed / args.conv_steps * 1e3, 5),
+                     "roofline": _roofline("conv_frame_kernel<12>", step_bytes, pc_kernel_ms, pc_elapsed / args.conv_steps * 1e3, pc_info["probe"])},
     }
     if cpu is not None:
         res["cpu_baseline"] = cpu

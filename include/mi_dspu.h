@@ -568,6 +568,14 @@ int mi_equalizer_bank_set_smooth(mi_equalizer_bank_t *bank, int smooth);
 /* process(out, in, samples), Equalizer.cpp:460-571. */
 int mi_equalizer_bank_process(mi_equalizer_bank_t *bank, float *out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream);
+/*
+ * `blocks` consecutive Equalizer::process() calls in one C call: block k reads in[k] and writes out[k] (HOST arrays of
+ * DEVICE pointers, each [channels][*_stride]).  In the FIR and FFT modes runs of blocks of exactly 2^fir_rank samples go
+ * as ONE launch (the response's image and the overlap-add tail stay on chip from block to block); results and carried
+ * state are those of `blocks` separate calls, bit for bit (Equalizer.cpp:460-571 called block after block).
+ */
+int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *bank, float *const *out, const float *const *in, size_t blocks,
+                                     size_t samples, size_t out_stride, size_t in_stride, void *stream);
 /* filter count, fir_rank(), mode(), ir_size() (Equalizer.cpp:599-616). */
 int mi_equalizer_bank_info(const mi_equalizer_bank_t *bank, uint32_t *filters, uint32_t *fir_rank, int *mode, uint32_t *ir_size);
 

@@ -205,6 +205,7 @@ PROTOTYPES = {
     "mi_crossover_bank_freq_chart": (c_int, [c_void_p, c_uint32, POINTER(c_float), POINTER(c_float), c_size_t, c_void_p]),
     "mi_equalizer_bank_reset": (c_int, [c_void_p, c_void_p]),
     "mi_equalizer_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_equalizer_bank_process_blocks": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_equalizer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_int), POINTER(c_uint32)]),
     "mi_delay_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t]),
     "mi_delay_bank_destroy": (c_int, [c_void_p]),

@@ -323,6 +323,130 @@ namespace
                                 dl_ring, dl_size, dl_tail, dl_head, upper_zero, nullptr);
     }
 
+
+    // ---- several whole frames of a single-partition bank in ONE launch (the Equalizer's FIR path, block after block) ------
+    // A launch per block (conv_frame_kernel) fetches, per channel and block, the response's image (8 B per sample), the
+    // overlap-add tail (4 + 4 B) and the frame out of the delay line (4 B) next to the 4 + 4 B of samples in and out, and does
+    // nothing else while they arrive.  Here a channel's workgroup walks K consecutive blocks: the image and the tail stay in
+    // registers from block to block, the delay line is read once (block f's frame IS block f - 1 of the call: the line is a
+    // delay of exactly one block) and written once, and block f + 1's samples are asked for before block f's transforms.
+    // Same transforms, same products, same sums as K launches of conv_frame_kernel: bit-identical results.
+    constexpr int FRAMES_MAX_BLOCKS = 128;
+    struct frames_args
+    {
+        int             blocks;
+        float          *out[FRAMES_MAX_BLOCKS];
+        const float    *in[FRAMES_MAX_BLOCKS];
+    };
+
+    template <int LOGM>
+    __global__ __launch_bounds__(fplan<LOGM>::T)
+    void conv_frames_kernel(const frames_args fa, size_t out_stride, size_t in_stride, bool aligned,
+                            const float2 *__restrict__ H /* [channels][M]: one partition */, float *acc,
+                            const float2 *__restrict__ Yt /* always NULL (a single partition owes no tail): see `through` */,
+                            const float2 *__restrict__ tw,
+                            float *dl_ring, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head, bool upper_zero)
+    {
+        using PL = fplan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T, NPT = KPT / 2;
+        static_assert(!PL::radix16 && mi_fft::plan<LOGM>::T == mi_fft::plan<LOGM>::TB, "register hand-over of the transforms (512 .. 8192 points)");
+        __shared__ float2 lds_[PL::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + PL::SCR;
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        typename PL::real rf;
+        rf.load(tw, TWN, tid);
+        float *const line = dl_ring + size_t(ch) * dl_size;
+        float *const a = acc + size_t(ch) * 2 * B;
+        const float2 *const h0 = H + size_t(ch) * M;
+        // the first frame: what the delay line gives back (cells dl_tail ..., even offsets: a pair never straddles the end)
+        float2 xin[NPT];
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            uint32_t r = dl_tail + 2 * (tid + i * T);
+            if (r >= dl_size) r -= dl_size;
+            xin[i] = *reinterpret_cast<const float2 *>(line + r);
+        }
+        // the image by pairs of bins (slot i: bin k = tid + i T, slot i + NPT its partner M - k; bin 0 packs DC and Nyquist,
+        // its partner slot holds bin M / 2) and the overlap-add tail: in registers for the whole launch
+        // (yreg: the pending tail frame_role adds to the product -- zeros here, but kept as the same run-time operand so that
+        // the compiler contracts product and sum into the same fused multiply-adds as in conv_frame_kernel: same bits)
+        float2 hreg[KPT], yreg[KPT], a0[NPT], a1[NPT];
+        const float2 *const yt = (Yt != nullptr) ? Yt + size_t(ch) * M : nullptr;
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            const int k = tid + i * T, km = (k == 0) ? M / 2 : M - k;
+            hreg[i] = h0[k];
+            hreg[i + NPT] = h0[km];
+            yreg[i] = (yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f);
+            yreg[i + NPT] = (yt != nullptr) ? yt[km] : make_float2(0.0f, 0.0f);
+            a0[i] = *reinterpret_cast<const float2 *>(a + 2 * k);
+            a1[i] = upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * k);
+        }
+        rf.prepare();
+        const float scale = 1.0f / float(2 * M);
+        for (int f = 0; f < fa.blocks; ++f)
+        {
+            // the call's block f: the frame of block f + 1 (or what the delay line holds after the call)
+            const float *x = fa.in[f] + size_t(ch) * in_stride;
+            float2 xnext[NPT];
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+            {
+                const int n = tid + i * T;
+                xnext[i] = aligned ? *reinterpret_cast<const float2 *>(x + 2 * n) : make_float2(x[2 * n], x[2 * n + 1]);
+            }
+            v2f io[KPT];
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+            {
+                io[i] = v2f{xin[i].x, xin[i].y};
+                io[i + NPT] = v2f{0.0f, 0.0f};              // B samples zero-padded to 2 B
+            }
+            mi_fft::fft_lds<LOGM, false, true, false>(buf, scr, rf.ft, tid, io);
+            mi_fft::real_split_filter_merge<LOGM>(buf, rf.rt, tid,
+                [&](int i, int k, float2 xk, bool partner) -> float2 {
+                    const int slot_i = partner ? i + NPT : i;
+                    return cadd(image_mul(xk, hreg[slot_i], k), yreg[slot_i]);
+                },
+                []() { });
+            mi_fft::fft_lds<LOGM, true, false, true>(buf, scr, rf.ft, tid, io);
+            float *o = fa.out[f] + size_t(ch) * out_stride;
+            const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, unsigned(B * sizeof(float)));
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+            {
+                const int n = tid + i * T;
+                const float2 r = make_float2(fmaf(io[i].x, scale, a0[i].x), fmaf(io[i].y, scale, a0[i].y));
+                if (aligned)
+                    mi::wt_store(rout, 8 * n, r);
+                else
+                {
+                    mi::wt_store(rout, 8 * n, r.x);
+                    mi::wt_store(rout, 8 * n + 4, r.y);
+                }
+                a0[i] = make_float2(fmaf(io[i + NPT].x, scale, a1[i].x), fmaf(io[i + NPT].y, scale, a1[i].y));
+                a1[i] = make_float2(0.0f, 0.0f);
+                xin[i] = xnext[i];
+            }
+            __syncthreads();                                // the transforms' buffers are free for the next frame
+        }
+        // what the next call starts from: the last block in the delay line (where K single-block calls would have left it),
+        // the tail in the accumulator, its upper half zero
+        const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(a, unsigned(2 * B * sizeof(float)));
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            const int n = tid + i * T;
+            uint32_t w = uint32_t((uint64_t(dl_head) + uint64_t(fa.blocks - 1) * B + 2 * n) % dl_size);
+            *reinterpret_cast<float2 *>(line + w) = xin[i];
+            mi::wt_store(racc, 8 * n, a0[i]);
+            if (!upper_zero)
+                mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
+        }
+    }
+
     // ---- whole frame AND the tail owed to the next one, in one launch (P >= 2) ------------------------------------------
     // Workgroups 0 .. C-1 are the frame role above (latency bound: load, two transforms, store); workgroups C .. 2C-1
     // stream the channel's tail  Yt' = sum_{p>=1} H_p X_(k+1-p)  (bandwidth bound: H and the ring once) at the same
@@ -1233,6 +1357,51 @@ namespace mi
         b->yt_pending = false;
         b->upper_zero = true;
         return launch_mac(b, st);
+    }
+
+    // true if `blocks` blocks of `samples` samples each can go as one launch of conv_frames_kernel: a single-partition bank at a
+    // plain frame boundary, blocks of exactly one frame, transforms of 512 .. 8192 points, no cross-fade waiting
+    bool convolver_takes_delayed_frames(const mi_convolver_bank_t *b, size_t samples)
+    {
+        return convolver_takes_delayed_frame(b, samples) && b->P == 1 && b->R == 0 && !b->yt_pending && b->logm >= 9 && b->logm <= 12;
+    }
+
+    int convolver_process_delayed_frames(mi_convolver_bank_t *b, float *const *out, const float *const *in, size_t blocks,
+                                         size_t out_stride, size_t in_stride, const delay_view &dl, hipStream_t st)
+    {
+        MI_REQUIRE(convolver_takes_delayed_frames(b, size_t(b->B)) && blocks >= 1 && blocks <= size_t(FRAMES_MAX_BLOCKS), MI_ESTATE,
+                   "convolver_process_delayed_frames: not at a plain frame boundary of a single-partition bank");
+        b->d_H = b->pool[b->cv].H;                                      // the response in force as the frames begin
+        b->d_h0 = b->pool[b->cv].h0;
+        const uint32_t tail = (dl.head + dl.size - dl.delay) % dl.size;
+        MI_REQUIRE((dl.size % 2 == 0) && (tail % 2 == 0) && (dl.head % 2 == 0) && (b->B % 2 == 0) && dl.delay == uint32_t(b->B) &&
+                   size_t(dl.size) >= 2 * size_t(b->B), MI_EINVAL, "convolver_process_delayed_frames: delay line geometry");
+        frames_args fa;
+        fa.blocks = int(blocks);
+        bool aligned = (out_stride % 2 == 0) && (in_stride % 2 == 0);
+        for (size_t k = 0; k < blocks; ++k)
+        {
+            fa.out[k] = out[k];
+            fa.in[k] = in[k];
+            aligned = aligned && ((reinterpret_cast<uintptr_t>(out[k]) | reinterpret_cast<uintptr_t>(in[k])) % 8 == 0);
+        }
+        hipEvent_t fe0 = nullptr, fe1 = nullptr;
+        mi::take_profile_events(&fe0, &fe1);
+        #define MI_CALL(LM) MI_LAUNCH((conv_frames_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, fe0, fe1, \
+                                      fa, out_stride, in_stride, aligned, b->d_H, b->d_acc, static_cast<const float2 *>(nullptr), \
+                                      b->d_tw, dl.ring, dl.size, tail, dl.head, \
+                                      b->upper_zero)
+        switch (b->logm)
+        {
+            case 9:  { MI_CALL(9);  break; }
+            case 10: { MI_CALL(10); break; }
+            case 11: { MI_CALL(11); break; }
+            default: { MI_CALL(12); break; }
+        }
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        b->upper_zero = true;
+        return MI_OK;
     }
 } // namespace mi
 

@@ -500,9 +500,34 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
                         return MI_OK;
                 }
                 const size_t rest = samples - done;
+                mi::delay_view dl;
+                // several whole blocks at a plain frame boundary: ONE launch walks them (conv_frames_kernel: the response's
+                // image and the overlap-add tail stay in registers, the delay line is touched once at either end)
+                if (rest >= 2 * size_t(b->fir_size) && rest % b->fir_size == 0 && getenv("MI_EQ_FRAME_PER_LAUNCH") == nullptr &&
+                    mi::convolver_takes_delayed_frames(b->conv, b->fir_size) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
+                    dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && dl.size >= 2 * b->fir_size)
+                {
+                    const size_t N = b->fir_size, blocks = rest / N;
+                    float *po[mi::CONV_FRAMES_MAX];
+                    const float *pi[mi::CONV_FRAMES_MAX];
+                    for (size_t k0 = 0; k0 < blocks; k0 += mi::CONV_FRAMES_MAX)
+                    {
+                        const size_t cnt = (blocks - k0 < mi::CONV_FRAMES_MAX) ? blocks - k0 : mi::CONV_FRAMES_MAX;
+                        for (size_t k = 0; k < cnt; ++k)
+                        {
+                            po[k] = out + done + (k0 + k) * N;
+                            pi[k] = in + done + (k0 + k) * N;
+                        }
+                        if (mi::delay_bank_view(b->delay, &dl) != MI_OK)
+                            return MI_ESTATE;
+                        if ((r = mi::convolver_process_delayed_frames(b->conv, po, pi, cnt, out_stride, in_stride, dl, st)) != MI_OK)
+                            return r;
+                        mi::delay_bank_advance(b->delay, cnt * N);
+                    }
+                    return MI_OK;
+                }
                 // a whole block at a plain frame boundary: the frame kernel reads its frame out of the delay line and
                 // pushes the new samples into it itself (one launch)
-                mi::delay_view dl;
                 if (mi::convolver_takes_delayed_frame(b->conv, rest) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
                     dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && (dl.delay % 2 == 0) &&
                     size_t(dl.size - dl.delay) >= rest)
@@ -524,6 +549,74 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
                                               samples * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
             return MI_OK;
     }
+}
+
+// `blocks` consecutive process() calls in one C call; runs of whole FIR blocks go as ONE launch (conv_frames_kernel)
+int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *b, float *const *out, const float *const *in, size_t blocks, size_t samples,
+                                     size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_equalizer_bank_process_blocks: NULL bank");
+    if (samples == 0 || blocks == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_equalizer_bank_process_blocks: NULL pointer table");
+    for (size_t k = 0; k < blocks; ++k)
+        MI_REQUIRE(out[k] != nullptr && in[k] != nullptr, MI_EINVAL, "mi_equalizer_bank_process_blocks: NULL buffer of block %zu", k);
+    hipStream_t st = mi::as_stream(stream);
+    const size_t ob = (size_t(b->channels - 1) * out_stride + samples) * sizeof(float), ib = (size_t(b->channels - 1) * in_stride + samples) * sizeof(float);
+    auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+        return a0 < b0 + qn && b0 < a0 + pn;
+    };
+    size_t k = 0;
+    while (k < blocks)
+    {
+        // a run of blocks for one launch: FIR / FFT mode in its steady state, blocks of exactly the FIR size, and no block that
+        // partly overlaps another block's buffers
+        size_t cnt = 0;
+        if (b->mode == MI_EQM_FIR || b->mode == MI_EQM_FFT)
+        {
+            const int rc = mi::capture_touch(st, b, "equalizer", equalizer_bank_positions);
+            if (rc != MI_OK)
+                return rc;
+            const int r = reconfigure(b, st);
+            if (r != MI_OK)
+                return r;
+            mi::delay_view dl;
+            if (samples == size_t(b->fir_size) && b->primed >= b->fir_size && getenv("MI_EQ_FRAME_PER_LAUNCH") == nullptr &&
+                mi::convolver_takes_delayed_frames(b->conv, samples) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
+                dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && dl.size >= 2 * b->fir_size)
+            {
+                while (k + cnt < blocks && cnt < mi::CONV_FRAMES_MAX)
+                {
+                    bool ok = true;
+                    // (the same buffer again is fine -- a ring of buffers, a block in place: a thread of the kernel touches
+                    // the same sample positions of every block, in the blocks' order; buffers that overlap otherwise are not)
+                    const float *oj = out[k + cnt], *ij = in[k + cnt];
+                    for (size_t i = k; ok && i < k + cnt; ++i)
+                        ok = (out[i] == ij || !overlap(out[i], ob, ij, ib)) && (in[i] == oj || !overlap(in[i], ib, oj, ob)) &&
+                             (out[i] == oj || !overlap(out[i], ob, oj, ob));
+                    ok = ok && (oj == ij || !overlap(oj, ob, ij, ib));
+                    if (!ok)
+                        break;
+                    ++cnt;
+                }
+                if (cnt >= 2)
+                {
+                    const int rr = mi::convolver_process_delayed_frames(b->conv, out + k, in + k, cnt, out_stride, in_stride, dl, st);
+                    if (rr != MI_OK)
+                        return rr;
+                    mi::delay_bank_advance(b->delay, cnt * samples);
+                    k += cnt;
+                    continue;
+                }
+            }
+        }
+        const int r = mi_equalizer_bank_process(b, out[k], in[k], samples, out_stride, in_stride, stream);
+        if (r != MI_OK)
+            return r;
+        ++k;
+    }
+    return MI_OK;
 }
 
 int mi_equalizer_bank_info(const mi_equalizer_bank_t *b, uint32_t *filters, uint32_t *fir_rank, int *mode, uint32_t *ir_size)

@@ -95,6 +95,12 @@ namespace mi
     bool        convolver_takes_delayed_frame(const mi_convolver_bank_t *bank, size_t samples);
     int         convolver_process_delayed_frame(mi_convolver_bank_t *bank, float *out, const float *in, size_t out_stride,
                                                 size_t in_stride, const delay_view &dl, hipStream_t st);
+    // the same for a run of blocks of one frame each in ONE launch (single-partition banks: the Equalizer's FIR); the delay
+    // line is advanced by the caller by blocks x frame samples
+    bool        convolver_takes_delayed_frames(const mi_convolver_bank_t *bank, size_t samples);
+    int         convolver_process_delayed_frames(mi_convolver_bank_t *bank, float *const *out, const float *const *in, size_t blocks,
+                                                 size_t out_stride, size_t in_stride, const delay_view &dl, hipStream_t st);
+    constexpr size_t CONV_FRAMES_MAX = 128;         // blocks per launch
 } // namespace mi
 
 #if defined(__HIPCC__)

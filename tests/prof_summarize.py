@@ -12,10 +12,10 @@ import json
 import os
 import sys
 
-KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frame_kernel",
+KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frames_kernel",
            "spectral": "analyzer_kernel"}
 # the PMC passes run `bench.py --steps 50`: the headline's launch (biquad_stream_kernel) then carries 50 blocks
-UNITS_PER_LAUNCH = {"biquad": 50}
+UNITS_PER_LAUNCH = {"biquad": 50, "equalizer": 50}
 
 
 def main():

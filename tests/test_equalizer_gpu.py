@@ -217,6 +217,70 @@ def test_random_operation_sequences_match_oracle(gpu, seed):
     eq.close()
 
 
+@pytest.mark.parametrize("rank,mode", [(12, oe.FIR), (9, oe.FIR), (10, oe.FFT), (8, oe.FIR)])
+def test_runs_of_blocks_in_one_launch_equal_block_by_block(gpu, rank, mode):
+    """FIR / FFT mode: a call of several whole blocks and mi_equalizer_bank_process_blocks walk the blocks in ONE launch
+    (conv_frames_kernel, transforms of 512 .. 8192 points: the response's image and the overlap-add tail stay in registers,
+    the delay line is touched at the ends) -- the same bits and the same carried state as block-by-block calls, also in place,
+    also behind an odd-sized call, and the state left behind serves whatever call comes next (rank 8: the per-block path)."""
+    rng = np.random.default_rng(40 + rank)
+    C, nfilt, N = 5, 6, 1 << rank
+    blocks = 7
+    x = (rng.standard_normal((C, N * (blocks + 4) + 300)) * 0.25).astype(np.float32)
+    curves = [[(fd.FLT_BT_RLC_BELL, 1, float(f), float(f), float(g), 2.0)
+               for f, g in zip(np.exp(rng.uniform(np.log(100), np.log(15000), nfilt)), 10 ** (rng.uniform(-9, 9, nfilt) / 20))] for _ in range(C)]
+
+    def make():
+        eq = gpu.EqualizerBank(C, nfilt, rank)
+        eq.set_mode(mode)
+        eq.set_sample_rate(48000)
+        for c in range(C):
+            for i, p in enumerate(curves[c]):
+                eq.set_params(i, *p, channel=c)
+        return eq
+
+    def feed(eq, plan):
+        """plan: list of (kind, samples) over consecutive stretches of x; returns the concatenated output"""
+        y, pos = [], 0
+        for kind, n in plan:
+            seg = x[:, pos:pos + n]
+            if kind == "blocks":                            # n = k N: k blocks through process_blocks
+                k = n // N
+                ins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(seg[:, j * N:(j + 1) * N])) for j in range(k)]
+                outs = [gpu.DeviceBuffer((C, N)) for _ in range(k)]
+                eq.process_blocks(outs, ins, N)
+                y.extend(o.download() for o in outs)
+            elif kind == "inplace":
+                d = gpu.DeviceBuffer.from_host(np.ascontiguousarray(seg))
+                eq.process(d, d, n)
+                y.append(d.download())
+            elif kind == "each":                            # block by block
+                for j in range(0, n, N):
+                    d, o = gpu.DeviceBuffer.from_host(np.ascontiguousarray(seg[:, j:j + N])), gpu.DeviceBuffer((C, min(N, n - j)))
+                    eq.process(o, d, min(N, n - j))
+                    y.append(o.download())
+            else:                                           # one call
+                d, o = gpu.DeviceBuffer.from_host(np.ascontiguousarray(seg)), gpu.DeviceBuffer((C, n))
+                eq.process(o, d, n)
+                y.append(o.download())
+            pos += n
+        return np.concatenate(y, axis=1)
+    ref_eq = make()
+    ref = feed(ref_eq, [("each", N), ("each", N * blocks), ("each", 2 * N), ("each", 300), ("each", N)])
+    a = make()
+    ya = feed(a, [("each", N), ("call", N * blocks), ("inplace", 2 * N), ("call", 300), ("call", N)])
+    b = make()
+    yb = feed(b, [("each", N), ("blocks", N * blocks), ("blocks", 2 * N), ("each", 300), ("each", N)])
+    aligned = N * (blocks + 3)
+    np.testing.assert_array_equal(ya[:, :aligned], ref[:, :aligned])
+    np.testing.assert_array_equal(yb[:, :aligned], ref[:, :aligned])
+    # behind the run: the delay line and the overlap-add tail it left serve an odd-sized call and the block after it
+    np.testing.assert_array_equal(ya[:, aligned:], ref[:, aligned:])
+    np.testing.assert_array_equal(yb[:, aligned:], ref[:, aligned:])
+    for eq in (ref_eq, a, b):
+        eq.close()
+
+
 def test_c4_full_size(gpu):
     """BASELINE config 3 at the per-GPU size: 256 channels, 32 RLC bells each with its own gains (seed 6), fir_rank 12,
     EQM_FIR, blocks of 4096.  Every channel against the oracle, and the size-independent properties: a second bank fed the
