@@ -715,20 +715,33 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                 print("bench: library communicator refused (%s); torch.distributed all_reduce instead" % e, file=sys.stderr)
 
     def step(i):
-        # one frame: ingest + strobe analysis of every channel, and the local per-bin sum over this GPU's channels riding on
-        # the same launch (mi_analyzer_bank_process_reduce)
+        # one frame: ingest + strobe analysis of every channel, then the local per-bin sum over this GPU's channels
         an.process_reduce(xin[i % ring], hop, sums[i % batch], stream=stream)
         if (i % batch) == batch - 1:                        # one collective per `batch` frames (RCCL over xGMI)
             if state["comm"] is not None:
                 an.allreduce_bins(sums, batch, state["comm"], stream=stream)
             else:
                 sharding.allreduce_bins(sums)
+
+    def batch_step(i):
+        # the same `batch` frames as ONE mi_analyzer_bank_process_reduce_frames call: eight analyses, their reductions as one
+        # launch, then the collective
+        an.process_reduce_frames([xin[(i + j) % ring] for j in range(batch)], hop, sums, stream=stream)
+        if state["comm"] is not None:
+            an.allreduce_bins(sums, batch, state["comm"], stream=stream)
+        else:
+            sharding.allreduce_bins(sums)
     steps = args.conv_steps - (args.conv_steps % batch) or batch
     # probes: the analysis launch alone, the stream drained in front of each (behind a step's own bin_reduce_kernel -- or
     # behind another analysis launch that is still draining -- the start stamp of the event pair is taken early and the pair
     # reads more than the kernel: 16.4 us in one run, 11.0 in the next, against rocprofv3's 11.8)
-    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch,
+    def region():
+        for i in range(0, steps, batch):
+            batch_step(i)
+    elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch, region=region,
                                              probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream), probe_sync=True)
+    tinfo["launch"] = "%d mi_analyzer_bank_process_reduce_frames calls of %d frames each per region (analysis launch per frame, the %d reductions as one launch)" % (steps // batch, batch, batch)
+    pc_elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, steps, batch, profile=False)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
     if state["comm"] is not None:
         state["comm"].close()
@@ -744,6 +757,9 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         "config": {"workload": "Analyzer: 4096-point Hann spectrum per channel every 2048 samples, %d channels per GPU, "
                                "per-bin sum over all channels (all-reduce of %d x %d floats per %d frames)"
                                % (C, batch, bins, batch), "channels_per_gpu": C, "collective": state["collective"]},
+        "timing": tinfo,
+        "per_call": {"what": "a mi_analyzer_bank_process_reduce call per frame (analysis launch + reduction launch)",
+                     "ms_per_step": round(pc_elapsed / steps * 1e3, 5), "value": round(C * world * steps / pc_elapsed, 1), "unit": "channel-frames/s"},
         "roofline": _roofline("analyzer_kernel<11>", frame_bytes, kernel_ms, elapsed / steps * 1e3, tinfo["probe"],
                               _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None),
         "whole_step": {"algorithmic_bytes": frame_bytes,

@@ -488,6 +488,14 @@ int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_
  */
 int mi_analyzer_bank_process_reduce(mi_analyzer_bank_t *bank, const float *in, size_t samples, size_t in_stride,
                                     float *out, int with_envelope, void *stream);
+/*
+ * `frames` consecutive mi_analyzer_bank_process_reduce calls in one C call: frame k takes in[k] (HOST array of DEVICE
+ * pointers, each [channels][in_stride]) and leaves its per-bin sums in out + k * out_stride.  Where every call is exactly
+ * one strobe (samples == period) the spectra of up to 16 frames are kept and their reductions run as ONE launch; the
+ * sums and the state left behind are those of `frames` separate calls, bit for bit.
+ */
+int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *bank, const float *const *in, size_t frames, size_t samples,
+                                           size_t in_stride, float *out, size_t out_stride, int with_envelope, void *stream);
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *bank, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step);
 
 /*

@@ -132,6 +132,7 @@ PROTOTYPES = {
     "mi_analyzer_bank_get_spectrum": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_uint32, c_void_p]),
     "mi_analyzer_bank_reduce_bins": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "mi_analyzer_bank_process_reduce": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_void_p, c_int, c_void_p]),
+    "mi_analyzer_bank_process_reduce_frames": (c_int, [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p, c_size_t, c_int, c_void_p]),
     "mi_analyzer_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "mi_convolver_bank_set_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p]),
     "mi_convolver_bank_crossfade_irs_device": (c_int, [c_void_p, c_void_p, c_size_t, c_uint32, c_void_p, c_void_p]),

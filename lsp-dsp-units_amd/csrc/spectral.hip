@@ -617,6 +617,20 @@ namespace
         bin_reduce_body<REDUCE_WAVES, false>(out, src, stride, channels, bins, env, block, part, blockIdx.x);
     }
 
+    // The reductions of several analyses in ONE launch: blockIdx.y picks the frame, whose rows stand in a plane of their own
+    // (mi_analyzer_bank_process_reduce_frames).  A reduction alone is 129 workgroups of one per CU on a 256-CU part and mostly
+    // latency; eight frames' worth fill the chip.  Same body, same order of summation, same bits per frame.
+    constexpr uint32_t REDUCE_FRAMES_MAX = 16;
+    struct reduce_planes { const float *rows[REDUCE_FRAMES_MAX]; };
+    __global__ __launch_bounds__(64 * REDUCE_WAVES)
+    void bin_reduce_frames_kernel(float *out, size_t out_stride, const reduce_planes planes, uint32_t stride, uint32_t channels,
+                                  uint32_t bins, const float *__restrict__ env, uint32_t block)
+    {
+        __shared__ float part[REDUCE_MAX_BLOCKS][REDUCE_BINS];
+        bin_reduce_body<REDUCE_WAVES, false>(out + size_t(blockIdx.y) * out_stride, planes.rows[blockIdx.y], stride, channels, bins, env,
+                                             block, part, blockIdx.x);
+    }
+
     // ---- analyzer -------------------------------------------------------------------------------------------
     // ring: [channels][buf_size]; the frame of channel c ends `delay[c]` samples before `head`.
     // amp_old: vAmp as of the strobe (what get_spectrum() shows until the next strobe: the reference copies vAmp to vData
@@ -1438,6 +1452,9 @@ struct mi_analyzer_bank
     bool        meta_dirty = true;
     bool        analysed = false;           // a strobe pass has run: vAmp / vData hold a period's results
     // per-bin reduction riding on the analysis launch (mi_analyzer_bank_process_reduce)
+    // mi_analyzer_bank_process_reduce_frames: planes that keep the spectra of the frames of a call until their reductions
+    // run as one launch; d_amp and d_data are always two of the planes the bank owns (these and the two it was made with)
+    std::vector<float *> planes;
     float      *fuse_out = nullptr;         // where the next strobe's launch leaves the reduction (NULL: no reduce role)
     bool        fuse_env = false, fuse_done = false;
     uint32_t   *d_rows = nullptr;           // [channels]: sequence number of the launch that last completed the channel's row
@@ -1692,7 +1709,14 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
 {
     if (b == nullptr)
         return MI_OK;
-    (void)hipFree(b->d_ring); (void)hipFree(b->d_amp); (void)hipFree(b->d_data); (void)hipFree(b->d_wnd);
+    if (b->planes.empty())
+    {
+        (void)hipFree(b->d_amp);
+        (void)hipFree(b->d_data);
+    }
+    for (float *p : b->planes)                              // (d_amp and d_data are among them)
+        (void)hipFree(p);
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_wnd);
     (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
     (void)hipFree(b->d_big_work); (void)hipFree(b->d_big_tmp); (void)hipFree(b->d_big_spec);
     (void)hipFree(b->d_rows);
@@ -1906,6 +1930,72 @@ int mi_analyzer_bank_process_reduce(mi_analyzer_bank_t *b, const float *in, size
     // no strobe fell into this call, or its launch could not carry the reduce role (frames above 2^14 samples, settings
     // changed in mid-period, too many channels for the block sums): the reduction as its own launch
     return done ? MI_OK : mi_analyzer_bank_reduce_bins(b, out, with_envelope, stream);
+}
+
+int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *const *in, size_t frames, size_t samples, size_t in_stride,
+                                           float *out, size_t out_stride, int with_envelope, void *stream)
+{
+    MI_REQUIRE(b != nullptr && out != nullptr && in != nullptr, MI_EINVAL, "mi_analyzer_bank_process_reduce_frames: bad argument");
+    const uint32_t bins = (1u << (b->rank - 1)) + 1;
+    MI_REQUIRE(out_stride >= bins, MI_EINVAL, "mi_analyzer_bank_process_reduce_frames: out_stride shorter than a row of bins");
+    hipStream_t st = mi::as_stream(stream);
+    size_t f = 0;
+    while (f < frames)
+    {
+        // pending settings take effect at the first call as always; the batched form needs every call to be exactly one
+        // strobe: a period per call, starting at a strobe, transforms of up to 2^14 points
+        int r = analyzer_reconfigure(b, st);
+        if (r != MI_OK)
+            return r;
+        const bool batch = b->rank <= 14 && samples == size_t(b->period) && b->counter == 0 && !b->meta_dirty && frames - f >= 2 &&
+                           size_t(b->buf_size) >= (size_t(1) << b->rank) + b->max_user_delay() + samples &&
+                           getenv("MI_ANALYZER_REDUCE_PER_FRAME") == nullptr;
+        if (!batch)
+        {
+            r = mi_analyzer_bank_process_reduce(b, in[f], samples, in_stride, out + f * out_stride, with_envelope, stream);
+            if (r != MI_OK)
+                return r;
+            ++f;
+            continue;
+        }
+        const size_t plane_bytes = size_t(b->channels) * b->bins_stride * sizeof(float);
+        if (b->planes.empty())
+        {
+            b->planes.push_back(b->d_amp);
+            b->planes.push_back(b->d_data);
+            for (uint32_t k = 0; k + 1 < REDUCE_FRAMES_MAX; ++k)
+            {
+                float *p = nullptr;
+                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), plane_bytes));
+                b->planes.push_back(p);
+            }
+        }
+        const size_t cnt = (frames - f < size_t(REDUCE_FRAMES_MAX)) ? frames - f : size_t(REDUCE_FRAMES_MAX);
+        // frame k's analysis reads the spectrum of the frame before (vAmp) and leaves its own in a plane that nothing reads
+        // any more: the published copy's (vData: the strobe replaces it, Analyzer.cpp:321-326) first, then the spare ones
+        std::vector<float *> spare;
+        spare.push_back(b->d_data);
+        for (float *p : b->planes)
+            if (p != b->d_amp && p != b->d_data)
+                spare.push_back(p);
+        reduce_planes rp;
+        for (size_t k = 0; k < cnt; ++k)
+        {
+            b->d_data = spare[k];                           // analyzer_strobe swaps: d_amp <- this plane, d_data <- the spectrum so far
+            r = mi_analyzer_bank_process(b, in[f + k], samples, in_stride, stream);
+            if (r != MI_OK)
+                return r;
+            rp.rows[k] = b->d_amp;
+        }
+        uint32_t block = REDUCE_BLOCK;
+        while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
+            block *= 2;
+        hipLaunchKernelGGL(bin_reduce_frames_kernel, dim3((bins + REDUCE_BINS - 1) / REDUCE_BINS, uint32_t(cnt)), dim3(64 * REDUCE_WAVES), 0, st,
+                           out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
+        MI_HIP_CHECK(hipGetLastError());
+        f += cnt;
+    }
+    return MI_OK;
 }
 
 int mi_analyzer_bank_info(const mi_analyzer_bank_t *b, uint32_t *rank, uint32_t *bins, uint32_t *period, uint32_t *step)

@@ -356,6 +356,15 @@ class AnalyzerBank:
                                                   samples if in_stride is None else in_stride, _ptr(out),
                                                   int(with_envelope), _stream(stream)))
 
+    def process_reduce_frames(self, inps, samples, out, with_envelope=False, in_stride=None, out_stride=None, stream=None):
+        """len(inps) consecutive process_reduce() calls in one C call; frame k's sums go to row k of `out`."""
+        n = len(inps)
+        pi = (c_void_p * n)(*[_ptr(b) for b in inps])
+        bins = self.info()["bins"]
+        check(lib.mi_analyzer_bank_process_reduce_frames(self.handle, pi, n, samples, samples if in_stride is None else in_stride,
+                                                         _ptr(out), bins if out_stride is None else out_stride, int(with_envelope),
+                                                         _stream(stream)))
+
     def close(self):
         if self.handle:
             lib.mi_analyzer_bank_destroy(self.handle)

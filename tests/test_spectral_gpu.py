@@ -443,6 +443,50 @@ def test_reduce_riding_on_the_analysis_launch_equals_two_launches(gpu, rank, C, 
         b.close()
 
 
+@pytest.mark.parametrize("rank,C,frames", [(12, 1024, 8), (12, 301, 19), (9, 40, 3), (13, 64, 2), (12, 64, 1)])
+def test_reductions_of_several_frames_in_one_launch(gpu, rank, C, frames):
+    """mi_analyzer_bank_process_reduce_frames: the analyses of a run of frames keep their spectra in planes of their own and
+    the per-bin reductions of up to 16 of them run as ONE launch -- against frame-by-frame process_reduce(): the same sums
+    bit for bit, the same published spectrum afterwards (get_spectrum), and the same behaviour of whatever call follows; with a
+    frozen and a disabled channel, with and without the envelope, more frames than one batch holds."""
+    sr = 48000
+    rng = np.random.default_rng(1900 + rank + C)
+    bins = (1 << (rank - 1)) + 1
+    banks = []
+    for _ in range(2):
+        b = gpu.AnalyzerBank(C, rank, sr, 1.0, 0)
+        for what, v in ((b.SAMPLE_RATE, sr), (b.RATE, sr / float(max(1 << (rank - 1), 1024))), (b.RANK, rank), (b.WINDOW, 0), (b.REACTIVITY, 0.2), (b.SHIFT, 1.0)):
+            b.configure(what, v)
+        if C > 3:
+            b.channel(1, b.CH_FREEZE, 1)
+            b.channel(2, b.CH_ENABLE, 0)
+        banks.append(b)
+    banks[0].process(None, 0); banks[1].process(None, 0)
+    period = banks[0].info()["period"]
+    idx = np.arange(0, bins, dtype=np.uint32)
+    for rnd in range(2):
+        env = bool(rnd & 1)
+        xs = [(rng.standard_normal((C, period)) * 0.3).astype(np.float32) for _ in range(frames)]
+        dx = [gpu.DeviceBuffer.from_host(x) for x in xs]
+        oa = gpu.DeviceBuffer((frames, bins))
+        banks[0].process_reduce_frames(dx, period, oa, with_envelope=env)
+        a = oa.download()
+        for f in range(frames):
+            ob = gpu.DeviceBuffer((bins,))
+            banks[1].process_reduce(dx[f], period, ob, with_envelope=env)
+            np.testing.assert_array_equal(a[f], ob.download(), err_msg="round %d frame %d" % (rnd, f))
+        assert frames == 1 or float(np.abs(a[-1]).max()) > 0.0     # (the very first strobe looks at an empty ring)
+        np.testing.assert_array_equal(banks[0].get_spectrum(idx), banks[1].get_spectrum(idx))
+        # an odd-sized call in between (half a period, then the other half): the batch left positions and spectra in order
+        half = period // 2
+        for part in (xs[0][:, :half], xs[0][:, half:]):
+            d = gpu.DeviceBuffer.from_host(np.ascontiguousarray(part))
+            banks[0].process(d, part.shape[1]); banks[1].process(d, part.shape[1])
+        np.testing.assert_array_equal(banks[0].get_spectrum(idx), banks[1].get_spectrum(idx))
+    for b in banks:
+        b.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_spectral_random_operation_sequences(gpu, seed):
     """Differential stress of the spectral bank against the oracle SpectralProcessor: rank and phase changes, masks bound
