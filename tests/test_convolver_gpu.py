@@ -197,6 +197,58 @@ def test_c3_full_size(gpu):
           "frame = %.2e" % (worst, worst_last))
 
 
+def test_one_launch_step_while_another_stream_keeps_every_cu_busy(gpu):
+    """The whole-frame step is ONE launch of two roles that wait for each other inside the launch (conv_step_kernel: the tail
+    role of a channel waits for its frame role's image).  That is safe as long as the frame workgroups are placed -- they
+    never wait -- which index-ordered dispatch gives on an idle device.  Here a second stream keeps every CU occupied with
+    long calls of a 1024-channel biquad bank (four waves per SIMD each, launched ahead and in between) while 256-channel,
+    16-partition frames are stepped: the hand-over must neither give up (faults() == 0) nor change a bit of the result
+    against the same frames stepped on an idle device, and the result is the oracle's."""
+    import ctypes
+    import workloads as wl
+    hip = ctypes.CDLL("libamdhip64.so")
+    streams = []
+    for _ in range(2):
+        s = ctypes.c_void_p()
+        assert hip.hipStreamCreateWithFlags(ctypes.byref(s), 1) == 0
+        streams.append(s)
+    sa, sb = streams[0].value, streams[1].value
+    C, taps, rank, frame, nf = 256, 16 * 1024, 11, 1024, 20
+    rng = np.random.default_rng(77)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 4096.0)).astype(np.float32)
+    x = rng.standard_normal((C, nf * frame)).astype(np.float32)
+    quiet, info = run_gpu(gpu, irs, rank, x, [frame] * nf)
+    assert info["partitions"] == 16
+    # the load: 1024 channels x 131072 samples per call, about a quarter of a millisecond of every SIMD each
+    BC, bn = 1024, 131072
+    coef, _ = wl.c2_coefficients(BC)
+    noise = gpu.BiquadBank(BC, 8)
+    noise.set_all_chains(coef)
+    nin = gpu.DeviceBuffer.from_host((rng.standard_normal((BC, bn)) * 0.1).astype(np.float32), stream=sb)
+    nout = gpu.DeviceBuffer((BC, bn))
+    noise.commit(sb)
+    bank = gpu.ConvolverBank(irs, rank)
+    dins = [gpu.DeviceBuffer.from_host(x[:, f * frame:(f + 1) * frame], stream=sa) for f in range(nf)]
+    douts = [gpu.DeviceBuffer((C, frame)) for _ in range(nf)]
+    assert hip.hipStreamSynchronize(streams[0]) == 0 and hip.hipStreamSynchronize(streams[1]) == 0
+    for f in range(nf):
+        for _ in range(2):                                   # keep the other stream's queue full
+            noise.process(nout, nin, bn, stream=sb)
+        bank.process(douts[f], dins[f], frame, stream=sa)
+    assert hip.hipStreamSynchronize(streams[0]) == 0 and hip.hipStreamSynchronize(streams[1]) == 0
+    assert bank.faults(stream=sa) == 0
+    busy = np.concatenate([d.download(stream=sa) for d in douts], axis=1)
+    np.testing.assert_array_equal(busy, quiet)
+    for c in (0, 97, 255):
+        o = oracle.Convolver(irs[c], rank)
+        ref = np.concatenate([o.process(x[c, i:i + frame]) for i in range(0, nf * frame, frame)])
+        check(busy[c], ref, exact_conv(x[c], irs[c]), "contended step ch %d" % c)
+    bank.close()
+    noise.close()
+    for s in streams:
+        hip.hipStreamDestroy(s)
+
+
 @pytest.mark.parametrize("seed", range(10))
 def test_random_geometry_and_call_sizes(gpu, seed):
     """Differential stress against the exact (float64) linear convolution: random ranks, tap counts around the partition
