@@ -1189,6 +1189,9 @@ int mi_ilufs_bank_clear(mi_ilufs_bank_t *b, void *stream)                      /
     if (r != MI_OK)
         return r;
     MI_HIP_CHECK(hipMemsetAsync(b->d_state, 0, b->meters * sizeof(ilufs_state), st));
+    // the rows counted in by a weighting-filter launch (biquad_sumsq_ilufs_kernel): a launch that ended on an error would
+    // leave its meter's count short of a full round and no later launch could elect a last workgroup
+    MI_HIP_CHECK(hipMemsetAsync(b->d_arrived, 0, b->meters * sizeof(uint32_t), st));
     b->block_offset = 0;
     b->block_part = 0;
     return MI_OK;

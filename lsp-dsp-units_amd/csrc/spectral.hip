@@ -1539,7 +1539,12 @@ namespace
             while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
                 block *= 2;                                             // (the standalone kernel's choice: same summation order)
             const size_t lds_floats = size_t(1) << b->rank;             // (at least: the transform's LDS is 2^rank floats or more with either core)
-            const bool fuse = b->fuse_out != nullptr && first == 0 && b->d_rows != nullptr &&
+            // ... and the stream is not capturing: the reduce role waits for a sequence number the HOST counts up per launch
+            // (rows_target, by value); a replay of the captured launch would find that number already reached by the
+            // replay before and sum rows that are still being written
+            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+            const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+            const bool fuse = b->fuse_out != nullptr && first == 0 && count == b->channels && b->d_rows != nullptr && !capturing &&
                               size_t((b->channels + block - 1) / block) * REDUCE_BINS <= lds_floats &&
                               getenv("MI_ANALYZER_FUSED_REDUCE") != nullptr;      // (measured slower than two launches: see the header)
             const uint32_t boundary = fuse ? ((count + 7u) & ~7u) : count;

@@ -171,3 +171,42 @@ def test_no_kernel_parks_data_in_scratch(tmp_path):
                 if flat > 4:
                     offenders.append((src, name, "flat instructions", flat))
     assert not offenders, offenders
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_biquad_kernels_in_the_compilers_output(tmp_path):
+    """Three properties of biquad.hip that only the generated code shows:
+    * biquad_stream_kernel<4> (the headline launch) fits four waves per SIMD (at most 128 VGPRs), touches its hand-over cells
+      with DS instructions (not flat ones: the cells are addressed through an LDS-qualified pointer) and forms its register
+      pairs without the 64 moves per sub-block the padded tile cost (the interleaved tile: a 16-byte LDS read IS two pairs);
+    * biquad_reference_ir_kernel (the impulse response the Equalizer's FIR is synthesised from) contains no fused
+      multiply-add: every product and every sum of the reference's recurrence is rounded on its own;
+    * biquad_sumsq_ilufs_kernel (the meter's bookkeeping riding on the filter launch) drains its additions -- the written-out
+      s_waitcnt vmcnt(0) -- before the barrier behind which the row is counted in."""
+    lines = _isa(os.path.join(CSRC, "biquad.hip"), tmp_path)
+    text = "\n".join(lines)
+    meta = {re.search(r"\.name: *(\S+)", b).group(1): b for b in text[text.index("amdhsa.kernels:"):].split("  - .agpr_count:")[1:]}
+    stream4 = [n for n in meta if "biquad_stream_kernelILi4E" in n]
+    assert len(stream4) == 1, sorted(meta)
+    assert int(re.search(r"\.vgpr_count: *(\d+)", meta[stream4[0]]).group(1)) <= 128
+    body = _kernel_bodies(lines, "biquad_stream_kernelILi4E")[stream4[0]]
+    ops = [l.split()[0] for l in body if l.strip() and not l.strip().startswith((";", "."))]
+    assert not any(o.startswith(("flat_", "scratch_")) for o in ops)
+    assert sum(1 for o in ops if o == "ds_read_b32") >= 3 and sum(1 for o in ops if o == "ds_read2_b32") >= 8
+    assert sum(1 for o in ops if o == "v_mov_b32_e32") <= 48, sum(1 for o in ops if o == "v_mov_b32_e32")
+    for name, b in _kernel_bodies(lines, "biquad_reference_ir_kernel").items():
+        o2 = [l.split()[0] for l in b if l.strip() and not l.strip().startswith((";", "."))]
+        assert not any(o.startswith(("v_fma", "v_fmac", "v_mac_f", "v_pk_fma", "v_mad_f", "v_mad_legacy", "v_mad_mix")) for o in o2), name
+        assert sum(1 for o in o2 if o.startswith("v_mul_f32")) >= 5
+    riding = _kernel_bodies(lines, "biquad_sumsq_ilufs_kernel")
+    assert riding
+    for name, b in riding.items():
+        t = [l.strip() for l in b if l.strip() and (not l.strip().startswith(";") or l.strip().startswith(";;#ASM"))]
+        waits = [i for i, l in enumerate(t) if l == ";;#ASMSTART" and t[i + 1].replace(" ", "") == "s_waitcntvmcnt(0)"]
+        assert waits, name
+        w = waits[-1]
+        adds = [i for i, l in enumerate(t) if l.startswith("global_atomic_add_u32") or l.startswith("global_atomic_add ")]
+        assert adds and min(a for a in adds if a > w) > w, name
+        between = t[w:min(a for a in adds if a > w)]
+        assert any(l.startswith("s_barrier") for l in between), name
+        assert not any(l.startswith(("global_atomic_add_f32", "buffer_store", "global_store")) for l in between), name
