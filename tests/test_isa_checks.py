@@ -197,7 +197,7 @@ def test_biquad_kernels_in_the_compilers_output(tmp_path):
     for name, b in _kernel_bodies(lines, "biquad_reference_ir_kernel").items():
         o2 = [l.split()[0] for l in b if l.strip() and not l.strip().startswith((";", "."))]
         assert not any(o.startswith(("v_fma", "v_fmac", "v_mac_f", "v_pk_fma", "v_mad_f", "v_mad_legacy", "v_mad_mix")) for o in o2), name
-        assert sum(1 for o in o2 if o.startswith("v_mul_f32")) >= 5
+        assert sum(1 for o in o2 if o.startswith("v_mul_f32")) + 2 * sum(1 for o in o2 if o.startswith("v_pk_mul_f32")) >= 5
     riding = _kernel_bodies(lines, "biquad_sumsq_ilufs_kernel")
     assert riding
     for name, b in riding.items():
