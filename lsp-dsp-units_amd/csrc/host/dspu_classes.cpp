@@ -7,6 +7,8 @@
 #include <lsp-plug.in/dsp-units/filters/Filter.h>
 #include <lsp-plug.in/dsp-units/filters/FilterBank.h>
 #include <lsp-plug.in/dsp-units/filters/FilterArray.h>
+#include <lsp-plug.in/dsp-units/filters/EqualizerArray.h>
+#include <lsp-plug.in/dsp-units/util/ConvolverArray.h>
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
 #include <lsp-plug.in/dsp-units/filters/DynamicFilters.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
@@ -3700,6 +3702,187 @@ bool FilterArray::process_host(float *out, const float *in, size_t samples, size
     if (samples == 0)
         return true;
     const size_t n = a->params.size() * stride;
+    return a->st.reserve(n) && a->st.up(in, n) && process(a->st.d_out, a->st.d_in, samples, stride, nullptr) && a->st.down(out, n);
+}
+
+// ---- EqualizerArray / ConvolverArray (extensions: the batched mode under the class API, like FilterArray) -----------------
+// Thin: the device banks (mi_equalizer_bank_*, mi_convolver_bank_*) already hold one object per channel and do the lazy
+// reconfiguration of the reference inside process(); the arrays only give them the classes' vocabulary.
+namespace
+{
+    struct equalizer_array { mi_equalizer_bank_t *bank = nullptr; size_t count = 0; staging st; };
+    struct convolver_array { mi_convolver_bank_t *bank = nullptr; size_t count = 0; staging st; };
+    inline equalizer_array *ea_of(void *p) { return static_cast<equalizer_array *>(p); }
+    inline convolver_array *ca_of(void *p) { return static_cast<convolver_array *>(p); }
+}
+
+EqualizerArray::EqualizerArray() { construct(); }
+EqualizerArray::~EqualizerArray() { destroy(); }
+void EqualizerArray::construct() { pImpl = nullptr; }
+
+bool EqualizerArray::init(size_t equalizers, size_t filters, size_t fir_rank)
+{
+    destroy();
+    if (equalizers == 0)
+        return false;
+    equalizer_array *a = new (std::nothrow) equalizer_array();
+    if (a == nullptr)
+        return false;
+    if (last_status(mi_equalizer_bank_create(&a->bank, uint32_t(equalizers), uint32_t(filters), uint32_t(fir_rank))) != MI_OK)
+    {
+        delete a;
+        return false;
+    }
+    a->count = equalizers;
+    pImpl = a;
+    return true;
+}
+
+void EqualizerArray::destroy()
+{
+    equalizer_array *a = ea_of(pImpl);
+    if (a != nullptr)
+    {
+        a->st.release();
+        mi_equalizer_bank_destroy(a->bank);
+        delete a;
+    }
+    pImpl = nullptr;
+}
+
+size_t EqualizerArray::size() const { return (pImpl != nullptr) ? ea_of(pImpl)->count : 0; }
+
+bool EqualizerArray::set_params(size_t eq, size_t id, const filter_params_t *params)
+{
+    equalizer_array *a = ea_of(pImpl);
+    if (a == nullptr || params == nullptr || (eq != size_t(-1) && eq >= a->count))
+        return false;
+    return last_status(mi_equalizer_bank_set_params(a->bank, (eq == size_t(-1)) ? UINT32_MAX : uint32_t(eq), uint32_t(id), cfp(params))) == MI_OK;
+}
+
+bool EqualizerArray::get_params(size_t eq, size_t id, filter_params_t *params) const
+{
+    const equalizer_array *a = ea_of(pImpl);
+    if (a == nullptr || params == nullptr || eq >= a->count)
+        return false;
+    return last_status(mi_equalizer_bank_get_params(a->bank, uint32_t(eq), uint32_t(id), cfp(params))) == MI_OK;
+}
+
+void EqualizerArray::set_mode(equalizer_mode_t mode)    { if (pImpl != nullptr) last_status(mi_equalizer_bank_set_mode(ea_of(pImpl)->bank, int(mode))); }
+void EqualizerArray::set_sample_rate(size_t sr)         { if (pImpl != nullptr) last_status(mi_equalizer_bank_set_sample_rate(ea_of(pImpl)->bank, uint32_t(sr))); }
+void EqualizerArray::set_smooth(bool smooth)            { if (pImpl != nullptr) last_status(mi_equalizer_bank_set_smooth(ea_of(pImpl)->bank, smooth ? 1 : 0)); }
+void EqualizerArray::reset(void *stream)                { if (pImpl != nullptr) last_status(mi_equalizer_bank_reset(ea_of(pImpl)->bank, stream)); }
+
+size_t EqualizerArray::get_latency(void *stream)
+{
+    uint32_t lat = 0;
+    if (pImpl == nullptr || last_status(mi_equalizer_bank_get_latency(ea_of(pImpl)->bank, &lat, stream)) != MI_OK)
+        return 0;
+    return lat;
+}
+
+bool EqualizerArray::process(float *dev_out, const float *dev_in, size_t samples, size_t stride, void *stream)
+{
+    equalizer_array *a = ea_of(pImpl);
+    if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
+        return false;
+    return samples == 0 || last_status(mi_equalizer_bank_process(a->bank, dev_out, dev_in, samples, stride, stride, stream)) == MI_OK;
+}
+
+bool EqualizerArray::process_blocks(float *const *dev_out, const float *const *dev_in, size_t blocks, size_t samples, size_t stride, void *stream)
+{
+    equalizer_array *a = ea_of(pImpl);
+    if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
+        return false;
+    return samples == 0 || blocks == 0 ||
+           last_status(mi_equalizer_bank_process_blocks(a->bank, dev_out, dev_in, blocks, samples, stride, stride, stream)) == MI_OK;
+}
+
+bool EqualizerArray::process_host(float *out, const float *in, size_t samples, size_t stride)
+{
+    equalizer_array *a = ea_of(pImpl);
+    if (a == nullptr || out == nullptr || in == nullptr || stride < samples)
+        return false;
+    if (samples == 0)
+        return true;
+    const size_t n = a->count * stride;
+    return a->st.reserve(n) && a->st.up(in, n) && process(a->st.d_out, a->st.d_in, samples, stride, nullptr) && a->st.down(out, n);
+}
+
+ConvolverArray::ConvolverArray() { construct(); }
+ConvolverArray::~ConvolverArray() { destroy(); }
+void ConvolverArray::construct() { pImpl = nullptr; }
+
+bool ConvolverArray::init(size_t convolvers, const float *irs, size_t ir_stride, size_t count, size_t rank, float phase, const size_t *counts)
+{
+    destroy();
+    if (convolvers == 0 || irs == nullptr || count == 0 || ir_stride < count)          // Convolver::init: no data, no object (Convolver.cpp:79-84)
+        return false;
+    convolver_array *a = new (std::nothrow) convolver_array();
+    if (a == nullptr)
+        return false;
+    std::vector<uint32_t> cn;
+    if (counts != nullptr)
+    {
+        cn.resize(convolvers);
+        for (size_t c = 0; c < convolvers; ++c)
+            cn[c] = uint32_t((counts[c] < count) ? counts[c] : count);
+    }
+    if (last_status(mi_convolver_bank_create(&a->bank, uint32_t(convolvers), irs, ir_stride, counts ? cn.data() : nullptr, uint32_t(count),
+                                             uint32_t(rank), phase, nullptr)) != MI_OK)
+    {
+        delete a;
+        return false;
+    }
+    a->count = convolvers;
+    pImpl = a;
+    return true;
+}
+
+void ConvolverArray::destroy()
+{
+    convolver_array *a = ca_of(pImpl);
+    if (a != nullptr)
+    {
+        a->st.release();
+        mi_convolver_bank_destroy(a->bank);
+        delete a;
+    }
+    pImpl = nullptr;
+}
+
+size_t ConvolverArray::size() const { return (pImpl != nullptr) ? ca_of(pImpl)->count : 0; }
+
+size_t ConvolverArray::rank() const
+{
+    uint32_t r = 0;
+    return (pImpl != nullptr && mi_convolver_bank_info(ca_of(pImpl)->bank, &r, nullptr, nullptr, nullptr) == MI_OK) ? r : 0;
+}
+
+size_t ConvolverArray::data_size() const
+{
+    uint32_t n = 0;
+    return (pImpl != nullptr && mi_convolver_bank_info(ca_of(pImpl)->bank, nullptr, nullptr, nullptr, &n) == MI_OK) ? n : 0;
+}
+
+void ConvolverArray::reset(void *stream) { if (pImpl != nullptr) last_status(mi_convolver_bank_reset(ca_of(pImpl)->bank, stream)); }
+
+bool ConvolverArray::process(float *dev_out, const float *dev_in, size_t samples, size_t stride, void *stream)
+{
+    convolver_array *a = ca_of(pImpl);
+    if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
+        return false;
+    return samples == 0 || last_status(mi_convolver_bank_process(a->bank, dev_out, dev_in, samples, stride, stride, stream)) == MI_OK;
+}
+
+bool ConvolverArray::process_host(float *out, const float *in, size_t samples, size_t stride)
+{
+    convolver_array *a = ca_of(pImpl);
+    if (a == nullptr || out == nullptr || in == nullptr || stride < samples)
+        return false;
+    if (samples == 0)
+        return true;
+    const size_t n = a->count * stride;
     return a->st.reserve(n) && a->st.up(in, n) && process(a->st.d_out, a->st.d_in, samples, stride, nullptr) && a->st.down(out, n);
 }
 

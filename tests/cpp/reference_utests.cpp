@@ -8,6 +8,8 @@
 // Plain C++11, no test framework: exit code 0 == all passed.  Needs a GPU (the classes have no CPU fallback).
 #include <lsp-plug.in/dsp-units/filters/Filter.h>
 #include <lsp-plug.in/dsp-units/filters/FilterArray.h>
+#include <lsp-plug.in/dsp-units/filters/EqualizerArray.h>
+#include <lsp-plug.in/dsp-units/util/ConvolverArray.h>
 #include <lsp-plug.in/dsp-units/filters/Equalizer.h>
 #include <lsp-plug.in/dsp-units/filters/DynamicFilters.h>
 #include <lsp-plug.in/dsp-units/util/Convolver.h>
@@ -641,6 +643,98 @@ static void filter_array_equals_n_filters()
     mi_dspu_free(din); mi_dspu_free(dout);
 }
 
+// ---- EqualizerArray / ConvolverArray: N objects behind one bank (this library's extensions) ---------------------------------
+// Object c of an array must behave like the dspu::Equalizer / dspu::Convolver it stands for: checked block by block against N
+// separate objects (the same kernels on one row of an N-row bank and on N one-row banks: bit for bit), on device rows, on host
+// rows, and -- the equalizer -- over a run of blocks in one call.
+static void equalizer_array_equals_n_equalizers()
+{
+    printf("EqualizerArray against separate Equalizer objects\n");
+    const size_t N = 5, NF = 4, RANK = 9, n = 512, blocks = 6;
+    dspu::EqualizerArray ea;
+    CHECK(ea.init(N, NF, RANK) && ea.size() == N, "EqualizerArray::init");
+    ea.set_mode(dspu::EQM_FIR);
+    ea.set_sample_rate(48000);
+    std::vector<dspu::Equalizer> eq(N);
+    for (size_t c = 0; c < N; ++c)
+    {
+        CHECK(eq[c].init(NF, RANK), "Equalizer::init");
+        eq[c].set_mode(dspu::EQM_FIR);
+        eq[c].set_sample_rate(48000);
+        for (size_t i = 0; i < NF; ++i)
+        {
+            dspu::filter_params_t fp;
+            fp.nType = dspu::FLT_BT_RLC_BELL; fp.nSlope = 1; fp.fFreq = fp.fFreq2 = 200.0f * float(1 + i) * float(1 + c);
+            fp.fGain = (i + c) & 1 ? 2.0f : 0.5f; fp.fQuality = 1.0f;
+            eq[c].set_params(i, &fp);
+            CHECK(ea.set_params(c, i, &fp), "EqualizerArray::set_params");
+        }
+    }
+    CHECK(ea.get_latency() == eq[0].get_latency(), "latency %zu != %zu", ea.get_latency(), size_t(eq[0].get_latency()));
+    std::vector<float> x(blocks * N * n), ya(blocks * N * n), ye(blocks * N * n);
+    unsigned seed = 777;
+    for (size_t i = 0; i < x.size(); ++i) { seed = seed * 1664525u + 1013904223u; x[i] = (float(seed >> 8) / 8388608.0f - 1.0f) * 0.25f; }
+    for (size_t b = 0; b < blocks; ++b)
+        for (size_t c = 0; c < N; ++c)
+            eq[c].process(&ye[(b * N + c) * n], &x[(b * N + c) * n], n);
+    float *din = NULL, *dout = NULL;
+    CHECK(mi_dspu_malloc(reinterpret_cast<void **>(&din), x.size() * sizeof(float)) == MI_OK &&
+          mi_dspu_malloc(reinterpret_cast<void **>(&dout), x.size() * sizeof(float)) == MI_OK, "device rows");
+    CHECK(mi_dspu_copy_h2d(din, x.data(), x.size() * sizeof(float), NULL) == MI_OK, "h2d");
+    // block 0 on host rows, block 1 on device rows, blocks 2.. as one run
+    CHECK(ea.process_host(&ya[0], &x[0], n, n), "process_host");
+    CHECK(ea.process(dout + N * n, din + N * n, n, n), "process");
+    float *po[blocks]; const float *pi[blocks];
+    for (size_t b = 2; b < blocks; ++b) { po[b - 2] = dout + b * N * n; pi[b - 2] = din + b * N * n; }
+    CHECK(ea.process_blocks(po, pi, blocks - 2, n, n), "process_blocks");
+    CHECK(mi_dspu_copy_d2h(&ya[N * n], dout + N * n, (blocks - 1) * N * n * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+    size_t bad = 0;
+    for (size_t i = 0; i < x.size(); ++i)
+        bad += (ya[i] != ye[i]);
+    CHECK(bad == 0, "%zu samples differ from the separate Equalizer objects", bad);
+    mi_dspu_free(din); mi_dspu_free(dout);
+}
+
+static void convolver_array_equals_n_convolvers()
+{
+    printf("ConvolverArray against separate Convolver objects\n");
+    const size_t N = 4, TAPS = 3000, RANK = 10, n = 512, blocks = 5;
+    std::vector<float> irs(N * TAPS), x(blocks * N * n), ya(blocks * N * n), yc(blocks * N * n);
+    unsigned seed = 4242;
+    for (size_t i = 0; i < irs.size(); ++i) { seed = seed * 1664525u + 1013904223u; irs[i] = (float(seed >> 8) / 8388608.0f - 1.0f) * 0.1f; }
+    for (size_t i = 0; i < x.size(); ++i) { seed = seed * 1664525u + 1013904223u; x[i] = (float(seed >> 8) / 8388608.0f - 1.0f) * 0.25f; }
+    const size_t counts[N] = { TAPS, 700, TAPS - 1, 1 };
+    dspu::ConvolverArray ca;
+    CHECK(ca.init(N, irs.data(), TAPS, TAPS, RANK, 0.0f, counts) && ca.size() == N, "ConvolverArray::init");
+    std::vector<dspu::Convolver> cv(N);
+    for (size_t c = 0; c < N; ++c)
+        CHECK(cv[c].init(&irs[c * TAPS], counts[c], RANK, 0.0f), "Convolver::init");
+    CHECK(ca.rank() == cv[0].rank() && ca.data_size() == TAPS, "rank / data_size");
+    for (size_t b = 0; b < blocks; ++b)
+        for (size_t c = 0; c < N; ++c)
+            cv[c].process(&yc[(b * N + c) * n], &x[(b * N + c) * n], n);
+    float *din = NULL, *dout = NULL;
+    CHECK(mi_dspu_malloc(reinterpret_cast<void **>(&din), N * n * sizeof(float)) == MI_OK &&
+          mi_dspu_malloc(reinterpret_cast<void **>(&dout), N * n * sizeof(float)) == MI_OK, "device rows");
+    for (size_t b = 0; b < blocks; ++b)
+    {
+        if (b & 1)
+        {
+            CHECK(mi_dspu_copy_h2d(din, &x[b * N * n], N * n * sizeof(float), NULL) == MI_OK, "h2d");
+            CHECK(ca.process(dout, din, n, n), "process");
+            CHECK(mi_dspu_copy_d2h(&ya[b * N * n], dout, N * n * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+        }
+        else
+            CHECK(ca.process_host(&ya[b * N * n], &x[b * N * n], n, n), "process_host");
+    }
+    // (a one-row bank and a row of a four-row bank take the same kernels except where the launch geometry depends on the
+    // channel count: compared to the last few bits)
+    double worst = 0.0, peak = 0.0;
+    for (size_t i = 0; i < x.size(); ++i) { worst = std::max(worst, double(std::fabs(ya[i] - yc[i]))); peak = std::max(peak, double(std::fabs(yc[i]))); }
+    CHECK(worst <= 1e-6 * peak, "ConvolverArray differs from the separate objects by %.3g of the peak", worst / peak);
+    mi_dspu_free(din); mi_dspu_free(dout);
+}
+
 // ---- binary layout of the drop-in classes ---------------------------------------------------------------------------
 // Object sizes and member offsets of the reference headers (lsp-dsp-units 1.0.36, LP64; sizes of SURVEY.md 0.4 plus the
 // member lists of filters/FilterBank.h:39-46, filters/Filter.h:57-65, filters/Equalizer.h:59-78, util/Convolver.h:38-56,
@@ -1048,7 +1142,7 @@ int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects filter_array");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects filter_array equalizer_array convolver_array");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -1074,6 +1168,8 @@ int main(int argc, char **argv)
     readme_filter();
     raw_memory_objects();
     filter_array_equals_n_filters();
+    equalizer_array_equals_n_equalizers();
+    convolver_array_equals_n_convolvers();
     CHECK(dspu::last_status() == MI_OK, "device status after the whole replay: %d (%s)", dspu::last_status(), mi_dspu_last_error());
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
