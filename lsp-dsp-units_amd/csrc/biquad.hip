@@ -922,12 +922,6 @@ namespace
         constexpr int TAB_QL = TAB_PQ + 2 * L;
         __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
         __shared__ stream_cell cell[STREAM_SG][NW];
-#ifdef MI_STREAM_EXTRA_LDS
-        // experiment (profiles/r04_experiments/biquad_stream_lds_dma.txt): the LDS a landing tile for LDS-DMA loads would take
-        __shared__ float landing[NW * MI_STREAM_EXTRA_LDS / 4];
-        if (threadIdx.x == 0 && out_stride == 1)
-            landing[n & 1023] = 0.0f;
-#endif
 
         const int ch  = int(blockIdx.x);
         const int tid = int(threadIdx.x);
