@@ -803,6 +803,10 @@ int mi_delay_bank_append_rows(mi_delay_bank_t *bank, const uint32_t *rows, uint3
 int mi_delay_bank_process_rows(mi_delay_bank_t *bank, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
                                size_t count, size_t out_stride, size_t in_stride, int add, int gain_mode, float gain,
                                const float *gain_vec, size_t gain_stride, void *stream);
+/* Delay::process_ramping for the listed lines only: new_delays[r] is the delay line rows[r] slides to (HOST array of n_rows). */
+int mi_delay_bank_process_ramping_rows(mi_delay_bank_t *bank, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
+                                       const uint32_t *new_delays, size_t count, size_t out_stride, size_t in_stride, int gain_mode,
+                                       float gain, const float *gain_vec, size_t gain_stride, void *stream);
 
 /* mi_ring_bank: `channels` x lsp::dspu::RingBuffer (util/RingBuffer.h:35-179, src/main/util/RingBuffer.cpp:48-209). */
 typedef struct mi_ring_bank mi_ring_bank_t;

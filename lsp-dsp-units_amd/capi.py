@@ -221,6 +221,8 @@ PROTOTYPES = {
                                    c_float, c_void_p, c_size_t, c_void_p]),
     "mi_delay_bank_process_ramping": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int,
                                               c_float, c_void_p, c_size_t, c_void_p]),
+    "mi_delay_bank_process_ramping_rows": (c_int, [c_void_p, c_void_p, c_uint32, c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_int,
+                                              c_float, c_void_p, c_size_t, c_void_p]),
     "mi_ring_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_size_t, c_float]),
     "mi_ring_bank_create_shared": (c_int, [POINTER(c_void_p), c_uint32, c_size_t, c_float, POINTER(c_void_p)]),
     "mi_ring_bank_destroy": (c_int, [c_void_p]),

@@ -186,18 +186,18 @@ namespace
                            const uint32_t *__restrict__ new_delay, size_t count, int gmode, float k,
                            const float *gv, size_t gv_stride, const row_map rm)
     {
-        const uint32_t ch = blockIdx.y;                                 // (whole banks only: row = channel)
+        const uint32_t row = blockIdx.y, ch = line_of(rm, row);         // row of the call's buffers, line of the bank
         const uint32_t head = head_of(rm, ch, head0, size);
         const uint32_t od = old_delay[ch], nd = new_delay[ch];
         const uint32_t old_tail = (head + size - od) % size;
-        const float *x = src + size_t(ch) * src_stride;
+        const float *x = src + size_t(row) * src_stride;
         const float *rb = ring + size_t(ch) * size;
         if (od == nd)                                                   // Delay.cpp:402-406: plain process
         {
             for (size_t i = size_t(blockIdx.x) * 256 + threadIdx.x; i < count; i += size_t(gridDim.x) * 256)
             {
                 const float v = (i >= od) ? x[i - od] : rb[(old_tail + i) % size];
-                dst[size_t(ch) * dst_stride + i] = apply_gain(v, gmode, k, gv + size_t(ch) * gv_stride, i);
+                dst[size_t(row) * dst_stride + i] = apply_gain(v, gmode, k, gv + size_t(row) * gv_stride, i);
             }
             return;
         }
@@ -213,7 +213,7 @@ namespace
                 v = x[i0 + ((chunk_end - 1 - i0) / size) * size];       // newest write so far
             else
                 v = rb[tail];
-            dst[size_t(ch) * dst_stride + o] = apply_gain(v, gmode, k, gv + size_t(ch) * gv_stride, o);
+            dst[size_t(row) * dst_stride + o] = apply_gain(v, gmode, k, gv + size_t(row) * gv_stride, o);
         }
     }
 
@@ -746,15 +746,15 @@ int mi_delay_bank_process_rows(mi_delay_bank_t *b, const uint32_t *rows, uint32_
                               gain_stride, stream, "mi_delay_bank_process_rows");
 }
 
-int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *in, const uint32_t *new_delays,
-                                  size_t count, size_t out_stride, size_t in_stride, int gain_mode, float gain,
-                                  const float *gain_vec, size_t gain_stride, void *stream)
+static int delay_ramping_impl(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
+                              const uint32_t *new_delays, size_t count, size_t out_stride, size_t in_stride, int gain_mode, float gain,
+                              const float *gain_vec, size_t gain_stride, void *stream, const char *who)
 {
-    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_delay_bank_process_ramping: NULL bank");
-    MI_REQUIRE(new_delays != nullptr, MI_EINVAL, "mi_delay_bank_process_ramping: NULL delays");
-    if (count == 0)                                                     // Delay.cpp:407-408
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "%s: NULL bank", who);
+    MI_REQUIRE(new_delays != nullptr, MI_EINVAL, "%s: NULL delays", who);
+    if (count == 0 || (rows != nullptr && n_rows == 0))                 // Delay.cpp:407-408
         return MI_OK;
-    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_delay_bank_process_ramping: NULL buffer");
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "%s: NULL buffer", who);
     hipStream_t st = mi::as_stream(stream);
     int r = mi::capture_touch(st, b, "delay", mi::delay_bank_positions);
     if (r != MI_OK)
@@ -762,33 +762,59 @@ int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *i
     r = sync_delays(b, st);
     if (r != MI_OK)
         return r;
-    std::vector<uint32_t> nd(new_delays, new_delays + b->channels);
-    for (uint32_t c = 0; c < b->channels; ++c)
-        MI_REQUIRE(nd[c] < b->size, MI_EINVAL, "mi_delay_bank_process_ramping: delay %u does not fit the line", nd[c]);
+    // the delays the lines of the call slide to; the other lines keep theirs (row r of new_delays belongs to line rows[r])
+    const uint32_t n = (rows != nullptr) ? n_rows : b->channels;
+    std::vector<uint32_t> nd(b->delay);
+    for (uint32_t k = 0; k < n; ++k)
+    {
+        MI_REQUIRE(new_delays[k] < b->size, MI_EINVAL, "%s: delay %u does not fit the line", who, new_delays[k]);
+        nd[rows ? rows[k] : k] = new_delays[k];
+    }
     MI_HIP_CHECK(hipMemcpyAsync(b->d_delay_new, nd.data(), nd.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     MI_HIP_CHECK(hipStreamSynchronize(st));
     const float *src = in;
     size_t stride = in_stride;
     if (static_cast<const void *>(out) == static_cast<const void *>(in))
     {
-        r = stage_input(b, b->channels, &src, &stride, count, st);
+        r = stage_input(b, n, &src, &stride, count, st);
         if (r != MI_OK)
             return r;
     }
     delay_rows dr;
-    r = make_rows(b, nullptr, 0, &dr, st);
+    r = make_rows(b, rows, n_rows, &dr, st);
     if (r != MI_OK)
         return r;
-    hipLaunchKernelGGL(delay_ramp_kernel, grid_for(count, b->channels), dim3(256), 0, st,
+    const uint32_t head_before = b->head;
+    hipLaunchKernelGGL(delay_ramp_kernel, grid_for(count, dr.n), dim3(256), 0, st,
                        out, out_stride, src, stride, b->d_ring, b->size, b->head, b->d_delay, b->d_delay_new,
                        count, gain_mode, gain, gain_vec, gain_stride, dr.rm);
     MI_HIP_CHECK(hipGetLastError());
     r = append(b, dr, src, stride, count, st);
-    if (r != MI_OK)
-        return r;
+    const int rs = settle_rows(b, dr, head_before, st);
+    if (r != MI_OK || rs != MI_OK)
+        return (r != MI_OK) ? r : rs;
     b->delay = nd;                                                      // Delay.cpp:444-445
     b->delay_dirty = true;
     return MI_OK;
+}
+
+int mi_delay_bank_process_ramping(mi_delay_bank_t *b, float *out, const float *in, const uint32_t *new_delays,
+                                  size_t count, size_t out_stride, size_t in_stride, int gain_mode, float gain,
+                                  const float *gain_vec, size_t gain_stride, void *stream)
+{
+    return delay_ramping_impl(b, nullptr, 0, out, in, new_delays, count, out_stride, in_stride, gain_mode, gain, gain_vec, gain_stride,
+                              stream, "mi_delay_bank_process_ramping");
+}
+
+int mi_delay_bank_process_ramping_rows(mi_delay_bank_t *b, const uint32_t *rows, uint32_t n_rows, float *out, const float *in,
+                                       const uint32_t *new_delays, size_t count, size_t out_stride, size_t in_stride, int gain_mode,
+                                       float gain, const float *gain_vec, size_t gain_stride, void *stream)
+{
+    const int r = delay_check_rows(b, rows, n_rows, "mi_delay_bank_process_ramping_rows");
+    if (r != MI_OK)
+        return r;
+    return delay_ramping_impl(b, rows, n_rows, out, in, new_delays, count, out_stride, in_stride, gain_mode, gain, gain_vec, gain_stride,
+                              stream, "mi_delay_bank_process_ramping_rows");
 }
 
 } // extern "C"

@@ -524,6 +524,17 @@ class DelayBank:
                                                 count, count, mode, 0.0 if gain is None else float(gain),
                                                 _ptr(gain_vec) if gain_vec is not None else None, count, _stream(stream)))
 
+    def process_ramping_rows(self, rows, out, inp, new_delays, count, gain=None, gain_vec=None, stream=None):
+        """Delay::process_ramping for the listed lines only (row r of the buffers and new_delays[r] belong to line rows[r])."""
+        rw = np.ascontiguousarray(rows, dtype=np.uint32)
+        nd = np.ascontiguousarray(new_delays, dtype=np.uint32)
+        assert nd.shape == rw.shape
+        mode = 2 if gain_vec is not None else (1 if gain is not None else 0)
+        check(lib.mi_delay_bank_process_ramping_rows(self.handle, rw.ctypes.data_as(c_void_p), len(rw), _ptr(out), _ptr(inp),
+                                                     nd.ctypes.data_as(c_void_p), count, count, count, mode,
+                                                     0.0 if gain is None else float(gain),
+                                                     _ptr(gain_vec) if gain_vec is not None else None, count, _stream(stream)))
+
     def close(self):
         if self.handle:
             lib.mi_delay_bank_destroy(self.handle)

@@ -288,13 +288,16 @@ def test_delay_lines_with_positions_of_their_own(gpu, seed):
         if op == "set":
             c = int(rng.integers(0, C)); d = int(rng.integers(0, maxd + 1))
             bank.set_delay(d, c); refs[c].set_delay(d)
-        elif op == "ramp":                                    # whole bank only
-            x = rng.standard_normal((C, n)).astype(np.float32)
-            targets = [int(rng.integers(0, maxd + 1)) for _ in range(C)]
-            din = gpu.DeviceBuffer.from_host(x); dout = gpu.DeviceBuffer((C, n))
-            bank.process_ramping(dout, din, targets, n)
-            ref = [r.process_ramping(x[c], targets[c]) for c, r in enumerate(refs)]
-            np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=str((seed, step, op, n, log[-6:])))
+        elif op == "ramp":                                    # the whole bank or a subset (mi_delay_bank_process_ramping_rows)
+            x = rng.standard_normal((R, n)).astype(np.float32)
+            targets = [int(rng.integers(0, maxd + 1)) for _ in range(R)]
+            din = gpu.DeviceBuffer.from_host(x); dout = gpu.DeviceBuffer((R, n))
+            if whole:
+                bank.process_ramping(dout, din, targets, n)
+            else:
+                bank.process_ramping_rows(rows, dout, din, targets, n)
+            ref = [refs[c].process_ramping(x[k], targets[k]) for k, c in enumerate(rows)]
+            np.testing.assert_array_equal(dout.download(), np.stack(ref), err_msg=str((seed, step, op, rows, n, log[-6:])))
         elif op == "append":
             x = rng.standard_normal((R, n)).astype(np.float32)
             if whole:
