@@ -857,6 +857,140 @@ namespace
                                       reinterpret_cast<float (*)[REDUCE_BINS]>(lds_), blockIdx.x - boundary);
     }
 
+
+    // ---- several strobes of the analyzer in ONE launch (mi_analyzer_bank_process_reduce_frames) --------------------------------
+    // The C5 shape: a strobe per call, the hop half a frame (period = N / 2), no user delays.  The frame of strobe f is then
+    // the two hops BEFORE the call's block f -- hops the launch has just had in its hands -- so a channel's workgroup walks the
+    // frames with the window's halves in registers (the second half of frame f is the first half of frame f + 1), the spectrum
+    // being smoothed in registers (no read of vAmp per strobe), the next block's samples asked for before the transform; what
+    // it leaves behind is what `frames` launches of analyzer_kernel leave: every hop in the ring at its place, every strobe's
+    // spectrum in the plane it would have been written to (rows[f]: the per-bin reductions read them).  Same window products,
+    // same transform, same magnitude and mix2 per strobe: bit-identical.
+    constexpr int AN_FRAMES_MAX = 16;
+    struct an_frames_args
+    {
+        int             frames;
+        const float    *in[AN_FRAMES_MAX];      // block f of the call: ingested at strobe f
+        float          *rows[AN_FRAMES_MAX];    // plane that takes vAmp after strobe f
+    };
+
+    template <int LOGH>
+    __global__ __launch_bounds__(fplan<LOGH>::T)
+    void analyzer_frames_kernel(const an_frames_args fa, size_t in_stride, bool aligned, float *ring, uint32_t buf_size, uint32_t head,
+                                const uint8_t *__restrict__ flags, const float *__restrict__ wnd, const float *__restrict__ amp_old,
+                                uint32_t amp_stride, float tau, const float2 *__restrict__ tw)
+    {
+        using PL = fplan<LOGH>;
+        constexpr int H = PL::N, T = PL::T, N = 2 * H, KPT = H / T, HALF = KPT / 2, HOP = H;      // HOP samples = HOP / 2 pairs
+        static_assert(!PL::radix16 && mi_fft::plan<LOGH>::T == mi_fft::plan<LOGH>::TB && (KPT % 2) == 0, "register hand-over of the transform");
+        __shared__ float2 lds_[PL::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + PL::SCR;
+        const int ch = blockIdx.x, tid = threadIdx.x;
+        typename PL::real rf;
+        rf.load(tw, TWN, tid);
+        const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
+        const float *a = amp_old + size_t(ch) * amp_stride;
+        float *rbw = ring + size_t(ch) * buf_size;
+        const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+        // block f's samples of this thread: pairs p = tid + j T of the hop
+        auto load_hop = [&](int f, float2 (&v)[HALF]) {
+            const float *x = fa.in[f] + size_t(ch) * in_stride;
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                const int p = tid + j * T;
+                v[j] = aligned ? *reinterpret_cast<const float2 *>(x + 2 * p) : make_float2(x[2 * p], x[2 * p + 1]);
+            }
+        };
+        // ... into the ring behind the head of strobe f (Analyzer.cpp:371-398)
+        auto ingest_hop = [&](int f, const float2 (&v)[HALF]) {
+            const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(f) * HOP) % buf_size);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                uint32_t w0 = h0 + 2 * (tid + j * T);
+                if (w0 >= buf_size) w0 -= buf_size;
+                uint32_t w1 = w0 + 1;
+                if (w1 >= buf_size) w1 -= buf_size;
+                mi::wt_store(rring, int(w0 * sizeof(float)), v[j].x);
+                mi::wt_store(rring, int(w1 * sizeof(float)), v[j].y);
+            }
+        };
+        if ((fl & 2) || !(fl & 1))
+        {
+            // frozen: vAmp stays (Analyzer.cpp:334); inactive: vAmp = 0 (:363-364) -- strobe after strobe; the samples go in all the same
+            for (int f = 0; f < fa.frames; ++f)
+            {
+                float2 v[HALF];
+                load_hop(f, v);
+                const __amdgpu_buffer_rsrc_t rrow = mi::wt_buffer(fa.rows[f] + size_t(ch) * amp_stride, unsigned((H + 1) * sizeof(float)));
+                for (int k = tid; k <= H; k += T)
+                    mi::wt_store(rrow, 4 * k, (fl & 2) ? a[k] : 0.0f);
+                ingest_hop(f, v);
+            }
+            return;
+        }
+        // the frame of the first strobe: the N samples in front of the head (Analyzer.cpp:339-353 with no delay)
+        int64_t doff = int64_t(head) - int64_t(N);
+        while (doff < 0)
+            doff += buf_size;
+        const float2 *w2 = reinterpret_cast<const float2 *>(wnd);
+        float2 xin[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int m = tid + i * T;
+            uint32_t i0 = uint32_t(doff) + 2 * m;
+            if (i0 >= buf_size) i0 -= buf_size;
+            if (i0 + 1 < buf_size)
+                xin[i] = *reinterpret_cast<const float2 *>(rbw + i0);
+            else
+                xin[i] = make_float2(rbw[i0], rbw[0]);
+        }
+        rf.prepare();
+        const float keep = 1.0f - tau;
+        const float *prev = a;                              // vAmp before the strobe in hand: the plane the strobe before wrote
+        for (int f = 0; f < fa.frames; ++f)
+        {
+            // (the window and the spectrum being smoothed come out of the L2 at every strobe -- the latter was written a strobe
+            // ago by the very threads that read it now -- instead of occupying 24 registers: four workgroups fit a CU)
+            v2f io[KPT];
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const float2 w = w2[tid + i * T];
+                io[i] = v2f{xin[i].x * w.x, xin[i].y * w.y};
+            }
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+                xin[j] = xin[j + HALF];
+            mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tid, io);
+            mi_fft::real_split<LOGH>(buf, rf.rt, tid);
+            // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
+            float *const row = fa.rows[f] + size_t(ch) * amp_stride;
+            const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(row, unsigned((H + 1) * sizeof(float)));
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = tid + i * T;
+                const float2 v = buf[k];
+                const float mag = (k == 0) ? fabsf(v.x) : sqrtf(v.x * v.x + v.y * v.y);
+                mi::wt_store(ramp, 4 * k, prev[k] * keep + mag * tau);
+            }
+            if (tid == 0)
+                mi::wt_store(ramp, 4 * H, prev[H] * keep + fabsf(buf[0].y) * tau);
+            prev = row;
+            // this strobe's block: into the ring, and the second half of the next strobe's frame
+            float2 blk[HALF];
+            load_hop(f, blk);
+            ingest_hop(f, blk);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+                xin[j + HALF] = blk[j];
+            __syncthreads();                                // the transform's buffers are free for the next strobe
+        }
+    }
+
     // ---- analyzer frames above 2^14 samples: the steps of analyzer_kernel as plain launches around the four-step transform
     // work[n] = (ring[(head - N - delay + n) mod size] * w[n], 0) for the channels that are analysed
     __global__ __launch_bounds__(256)
@@ -1984,7 +2118,51 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
             if (p != b->d_amp && p != b->d_data)
                 spare.push_back(p);
         reduce_planes rp;
-        for (size_t k = 0; k < cnt; ++k)
+        // the strobes themselves as ONE launch (analyzer_frames_kernel) where the hop is half a frame, nothing is delayed and
+        // every block is there; otherwise a launch per strobe
+        const int lh = int(b->rank) - 1;
+        bool one_launch = lh >= 9 && lh <= 12 && 2 * size_t(b->period) == (size_t(1) << b->rank) && b->max_user_delay() == 0 &&
+                          getenv("MI_ANALYZER_STROBE_PER_LAUNCH") == nullptr;
+        for (size_t k = 0; one_launch && k < cnt; ++k)
+            one_launch = in[f + k] != nullptr;
+        if (one_launch)
+        {
+            MI_REQUIRE(b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u, MI_EHIP,
+                       "mi_analyzer_bank_process_reduce_frames: the reduce role of an earlier analysis launch gave up waiting");
+            const int rc = mi::capture_touch(st, b, "analyzer", analyzer_bank_positions);
+            if (rc != MI_OK)
+                return rc;
+            an_frames_args fa;
+            fa.frames = int(cnt);
+            bool aligned = (in_stride % 2) == 0;
+            for (size_t k = 0; k < cnt; ++k)
+            {
+                fa.in[k] = in[f + k];
+                fa.rows[k] = spare[k];
+                rp.rows[k] = spare[k];
+                aligned = aligned && (reinterpret_cast<uintptr_t>(in[f + k]) % 8) == 0;
+            }
+            hipEvent_t ev0 = nullptr, ev1 = nullptr;
+            mi::take_profile_events(&ev0, &ev1);
+            #define MI_CALL(LH) MI_LAUNCH((analyzer_frames_kernel<LH>), dim3(b->channels), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
+                fa, in_stride, aligned, b->d_ring, b->buf_size, b->head, b->d_flags, b->d_wnd, b->d_amp, b->bins_stride, b->tau, b->d_tw)
+            switch (lh)
+            {
+                case 9:  { MI_CALL(9);  break; }
+                case 10: { MI_CALL(10); break; }
+                case 11: { MI_CALL(11); break; }
+                default: { MI_CALL(12); break; }
+            }
+            #undef MI_CALL
+            MI_HIP_CHECK(hipGetLastError());
+            // where `cnt` strobes leave the bank (analyzer_strobe: the planes swap roles at every strobe; Analyzer.cpp:321-326)
+            float *const before = b->d_amp;
+            b->d_amp = spare[cnt - 1];
+            b->d_data = (cnt >= 2) ? spare[cnt - 2] : before;
+            b->head = uint32_t((uint64_t(b->head) + uint64_t(cnt) * samples) % b->buf_size);
+            b->analysed = true;
+        }
+        for (size_t k = 0; !one_launch && k < cnt; ++k)
         {
             b->d_data = spare[k];                           // analyzer_strobe swaps: d_amp <- this plane, d_data <- the spectrum so far
             r = mi_analyzer_bank_process(b, in[f + k], samples, in_stride, stream);
