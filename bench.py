@@ -1092,6 +1092,10 @@ def main():
                             "FLT_BT_LRX_LOPASS slope 4 per-channel cutoffs, state carried across blocks" % (C, n),
                 "channels_per_gpu": C, "block": n, "sections": int(coef.shape[1]),
                 "resident_ring_blocks": ring, "parallelism": "channel-shard x%d, no collective" % world,
+                "blocks_per_call": args.steps if args.launch == "blocks" else 1,
+                "call": ("mi_biquad_bank_process_blocks: the %d blocks of a timed region in one call (one launch per run of <= 128 blocks), "
+                         "bit-identical to %d mi_biquad_bank_process calls -- those are timed beside it under \"per_call\"" % (args.steps, args.steps))
+                        if args.launch == "blocks" else "mi_biquad_bank_process: one call and one launch per block",
             },
             "per_gpu_msamples_s": round(C * n * args.steps / elapsed / 1e6, 1),
             "timing": tinfo,
