@@ -138,6 +138,26 @@ int main(int argc, char **argv)
         std::sort(kv.second.begin(), kv.second.end());
         for (size_t r = 0; r < kv.second.size() && r < 8; ++r) by_rank[r].push_back(kv.second[r].second);
     }
+    // where the slow workgroups sit: exit of the LAST workgroup of every CU, by XCD and by shader engine
+    {
+        std::map<unsigned, std::vector<double>> by_xcc, by_se;
+        for (auto &kv : cu)
+        {
+            double last = 0;
+            for (auto &e : kv.second) last = std::max(last, e.second);
+            by_xcc[kv.first >> 12].push_back(last);
+            by_se[kv.first >> 8].push_back(last);
+        }
+        printf("exit of a CU's last workgroup (us), min / median / max over the CUs of an XCD:\n");
+        for (auto &kv : by_xcc)
+        {
+            auto &v = kv.second; std::sort(v.begin(), v.end());
+            printf("  xcd %u (%zu CUs): %8.2f %8.2f %8.2f\n", kv.first, v.size(), v.front(), v[v.size() / 2], v.back());
+        }
+        printf("  ... by shader engine (median):");
+        for (auto &kv : by_se) { auto &v = kv.second; std::sort(v.begin(), v.end()); printf(" %.0f", v[v.size() / 2]); }
+        printf("\n");
+    }
     printf("CUs %zu;", cu.size());
     for (auto &kv : hist) printf(" %d CUs with %zu workgroups;", kv.second, kv.first);
     printf("\nexit time (us) of a CU's workgroups by order of entry: min / median / max over the CUs\n");

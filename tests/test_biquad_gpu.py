@@ -341,6 +341,36 @@ def test_process_blocks_equals_separate_calls(gpu, n, nb):
     bank.close()
 
 
+def test_process_blocks_falls_back_where_the_stream_kernel_does_not_apply(gpu):
+    """More sections than the stream kernel has hand-over cells for (40 > 32), and rows that are not 16-byte aligned: the call
+    runs the blocks as separate launches -- same bits either way."""
+    C, n, nb = 3, 4096, 4
+    rng = np.random.default_rng(11)
+    x = (rng.standard_normal((nb, C, n + 4)) * 0.25).astype(np.float32)
+    for sections, shift in ((40, 0), (8, 1)):
+        coef = [np.concatenate([wl.design(fd.FLT_BT_LRX_LOPASS, 4, 900.0 * (c + 1) + 37.0 * k, 0, 1.0, 0.75)[:8] for k in range(sections // 8)])
+                for c in range(C)]
+        res = []
+        for blocks_call in (False, True):
+            bank = gpu.BiquadBank(C, sections)
+            for c in range(C):
+                bank.set_chains(c, coef[c], False)
+            ins = [gpu.DeviceBuffer.from_host(x[b]) for b in range(nb)]
+            outs = [gpu.DeviceBuffer((C, n + 4)) for _ in range(nb)]
+            vi = [b.ptr + 4 * shift for b in ins]             # raw device addresses: one float off the 16-byte grid
+            vo = [b.ptr + 4 * shift for b in outs]
+            if blocks_call:
+                bank.process_blocks(vo, vi, n, out_stride=n + 4, in_stride=n + 4)
+            else:
+                for o, i in zip(vo, vi):
+                    bank.process(o, i, n, out_stride=n + 4, in_stride=n + 4)
+            res.append(([o.download() for o in outs], bank.get_state()))
+            bank.close()
+        for u, v in zip(res[0][0], res[1][0]):
+            np.testing.assert_array_equal(u[:, shift:shift + n], v[:, shift:shift + n])
+        np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
 def test_process_blocks_aliasing(gpu):
     """Blocks that depend on each other through memory keep the meaning of separate calls: a block processed in place, an
     output buffer that comes round again (a ring of buffers), a block that reads what an earlier block of the same call
