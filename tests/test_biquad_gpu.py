@@ -341,6 +341,32 @@ def test_process_blocks_equals_separate_calls(gpu, n, nb):
     bank.close()
 
 
+def test_c2_full_size_blocks_call_equals_block_by_block(gpu):
+    """C2 at full size through the one-launch path: 1024 channels x 4096 x 20 blocks (the driver's bench shape) as ONE
+    mi_biquad_bank_process_blocks call against 20 process() calls -- every bit of every block and of the filter memory.  (The
+    block-by-block results are what test_c2_full_size_all_channels holds against the oracle.)"""
+    C, n, nb = 1024, 4096, 20
+    coef, _ = wl.c2_coefficients(C)
+    x = wl.c2_input(C, n, blocks=nb)
+    res = []
+    for blocks_call in (False, True):
+        bank = gpu.BiquadBank(C, 8)
+        bank.set_all_chains(coef)
+        ins = [gpu.DeviceBuffer.from_host(x[b]) for b in range(nb)]
+        outs = [gpu.DeviceBuffer((C, n)) for _ in range(nb)]
+        if blocks_call:
+            bank.process_blocks(outs, ins, n)
+        else:
+            for o, i in zip(outs, ins):
+                bank.process(o, i, n)
+        res.append(([o.download() for o in outs], bank.get_state()))
+        bank.close()
+        del ins, outs
+    for b in range(nb):
+        np.testing.assert_array_equal(res[0][0][b], res[1][0][b], err_msg="block %d" % b)
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
 def test_process_blocks_falls_back_where_the_stream_kernel_does_not_apply(gpu):
     """More sections than the stream kernel has hand-over cells for (40 > 32), and rows that are not 16-byte aligned: the call
     runs the blocks as separate launches -- same bits either way."""
