@@ -875,7 +875,7 @@ namespace
     };
 
     template <int LOGH>
-    __global__ __launch_bounds__(fplan<LOGH>::T)
+    __global__ __launch_bounds__(fplan<LOGH>::T, (fplan<LOGH>::T <= 256) ? 4 : 2)   // four workgroups of 256 threads per CU: 1024 channels in one round
     void analyzer_frames_kernel(const an_frames_args fa, size_t in_stride, bool aligned, float *ring, uint32_t buf_size, uint32_t head,
                                 const uint8_t *__restrict__ flags, const float *__restrict__ wnd, const float *__restrict__ amp_old,
                                 uint32_t amp_stride, float tau, const float2 *__restrict__ tw)
@@ -886,6 +886,7 @@ namespace
         __shared__ float2 lds_[PL::LDS];
         float2 *const buf = lds_, *const scr = lds_ + PL::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
+        MI_APROBE(0);
         typename PL::real rf;
         rf.load(tw, TWN, tid);
         const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
@@ -947,13 +948,18 @@ namespace
             else
                 xin[i] = make_float2(rbw[i0], rbw[0]);
         }
+        MI_APROBE(1);
         rf.prepare();
         const float keep = 1.0f - tau;
-        const float *prev = a;                              // vAmp before the strobe in hand: the plane the strobe before wrote
+        float amp[KPT], amp_h = 0.0f;                       // vAmp: in registers from strobe to strobe
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            amp[i] = a[tid + i * T];
+        if (tid == 0)
+            amp_h = a[H];
         for (int f = 0; f < fa.frames; ++f)
         {
-            // (the window and the spectrum being smoothed come out of the L2 at every strobe -- the latter was written a strobe
-            // ago by the very threads that read it now -- instead of occupying 24 registers: four workgroups fit a CU)
+            // (the window comes out of the L2 at every strobe instead of occupying 16 registers: four workgroups fit a CU)
             v2f io[KPT];
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
@@ -964,8 +970,10 @@ namespace
             #pragma unroll
             for (int j = 0; j < HALF; ++j)
                 xin[j] = xin[j + HALF];
+            if (f == 3) MI_APROBE(2);
             mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tid, io);
             mi_fft::real_split<LOGH>(buf, rf.rt, tid);
+            if (f == 3) MI_APROBE(3);
             // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
             float *const row = fa.rows[f] + size_t(ch) * amp_stride;
             const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(row, unsigned((H + 1) * sizeof(float)));
@@ -975,11 +983,15 @@ namespace
                 const int k = tid + i * T;
                 const float2 v = buf[k];
                 const float mag = (k == 0) ? fabsf(v.x) : sqrtf(v.x * v.x + v.y * v.y);
-                mi::wt_store(ramp, 4 * k, prev[k] * keep + mag * tau);
+                amp[i] = amp[i] * keep + mag * tau;
+                mi::wt_store(ramp, 4 * k, amp[i]);
             }
             if (tid == 0)
-                mi::wt_store(ramp, 4 * H, prev[H] * keep + fabsf(buf[0].y) * tau);
-            prev = row;
+            {
+                amp_h = amp_h * keep + fabsf(buf[0].y) * tau;
+                mi::wt_store(ramp, 4 * H, amp_h);
+            }
+            if (f == 3) MI_APROBE(4);
             // this strobe's block: into the ring, and the second half of the next strobe's frame
             float2 blk[HALF];
             load_hop(f, blk);
@@ -988,7 +1000,10 @@ namespace
             for (int j = 0; j < HALF; ++j)
                 xin[j + HALF] = blk[j];
             __syncthreads();                                // the transform's buffers are free for the next strobe
+            if (f == 3) MI_APROBE(5);
+            if (f == 2) MI_APROBE(7);
         }
+        MI_APROBE(6);
     }
 
     // ---- analyzer frames above 2^14 samples: the steps of analyzer_kernel as plain launches around the four-step transform
