@@ -341,6 +341,63 @@ def test_process_blocks_equals_separate_calls(gpu, n, nb):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", range(24))
+def test_process_blocks_random_geometries(gpu, seed):
+    """Differential stress of the one-launch path against separate process() calls, bit for bit: random channel counts, section
+    counts per channel (empty and switched-off channels among them), block lengths (whole chunks of 16 above 2048 samples, and now
+    and then one the stream kernel does not take), strides, numbers of blocks, blocks in place, output buffers that come round
+    again, blocks that read an earlier block's output, and a second call on the state the first one left."""
+    rng = np.random.default_rng(77000 + seed)
+    C = int(rng.integers(1, 41))
+    max_sec = int(rng.choice([1, 3, 8, 16, 32]))
+    coef = []
+    for c in range(C):
+        k = int(rng.integers(0, max_sec + 1))
+        q = [wl.design(fd.FLT_BT_RLC_BELL, 1, float(rng.uniform(60.0, 16000.0)), 0, float(rng.uniform(0.5, 2.0)), float(rng.uniform(0.3, 3.0)))[:1]
+             for _ in range(k)]
+        coef.append(np.concatenate(q) if q else np.zeros((0, 5), np.float32))
+    off = [c for c in range(C) if rng.integers(0, 9) == 0]
+    n = int(rng.choice([2064, 4096, 4096 + 16 * int(rng.integers(1, 200)), 8192, 3 * 4096 + 32, 6000 - 6000 % 16, 1000, 4100]))
+    stride = n + int(rng.choice([0, 4, 8, 64]))
+    results = []
+    for blocks_call in (False, True):
+        r2 = np.random.default_rng(88000 + seed)            # the same plan for both runs
+        bank = gpu.BiquadBank(C, max_sec)
+        for c in range(C):
+            bank.set_chains(c, coef[c], False)
+        for c in off:
+            bank.set_row_enabled(c, False)
+        outputs = []
+        for call in range(2):
+            nb = int(r2.integers(2, 13))
+            pool = [gpu.DeviceBuffer.from_host((r2.standard_normal((C, stride)) * 0.25).astype(np.float32)) for _ in range(nb + 2)]
+            ins, outs = [], []
+            for b in range(nb):
+                kind = int(r2.integers(0, 6))
+                i = pool[b]
+                if kind == 0:
+                    o = i                                    # in place
+                elif kind == 1 and outs:
+                    o = outs[int(r2.integers(0, len(outs)))] # an output buffer again
+                else:
+                    o = pool[nb + int(r2.integers(0, 2))] if kind == 2 else gpu.DeviceBuffer.from_host(np.full((C, stride), 3.0, np.float32))
+                if kind == 3 and outs:
+                    i = outs[int(r2.integers(0, len(outs)))] # reads what an earlier block wrote
+                ins.append(i); outs.append(o)
+            if blocks_call:
+                bank.process_blocks(outs, ins, n, out_stride=stride, in_stride=stride)
+            else:
+                for o, i in zip(outs, ins):
+                    bank.process(o, i, n, out_stride=stride, in_stride=stride)
+            outputs.append([b.download() for b in pool] + [o.download() for o in outs])
+        results.append((outputs, bank.get_state()))
+        bank.close()
+    for ca, cb in zip(results[0][0], results[1][0]):
+        for u, v in zip(ca, cb):
+            np.testing.assert_array_equal(u, v, err_msg=str((seed, C, max_sec, n, stride)))
+    np.testing.assert_array_equal(results[0][1], results[1][1])
+
+
 def test_c2_full_size_blocks_call_equals_block_by_block(gpu):
     """C2 at full size through the one-launch path: 1024 channels x 4096 x 20 blocks (the driver's bench shape) as ONE
     mi_biquad_bank_process_blocks call against 20 process() calls -- every bit of every block and of the filter memory.  (The

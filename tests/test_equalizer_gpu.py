@@ -160,12 +160,15 @@ def test_smooth_retune_cross_fades_over_one_block(gpu, mode, calls):
     eq.close()
 
 
+@pytest.mark.parametrize("rank", [7, 9])
 @pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808, 909, 1010])
-def test_random_operation_sequences_match_oracle(gpu, seed):
+def test_random_operation_sequences_match_oracle(gpu, seed, rank):
     """Differential stress: random sequences of retunes, mode switches, resets and ragged process() calls on a
-    two-channel bank against one oracle object per channel (well-conditioned filters: the strict tolerance applies)."""
-    rng = np.random.default_rng(seed)
-    C, nfilt, rank, sr = 2, 3, 7, 48000
+    two-channel bank against one oracle object per channel (well-conditioned filters: the strict tolerance applies).
+    rank 9: calls of several whole blocks walk them in one launch (conv_frames_kernel) -- between retunes, cross-fades that wait
+    for a block boundary, resets and mode switches."""
+    rng = np.random.default_rng(seed + rank)
+    C, nfilt, sr = 2, 3, 48000
     N = 1 << rank
     types = [fd.FLT_BT_RLC_BELL, fd.FLT_BT_RLC_HISHELF, fd.FLT_BT_RLC_LOSHELF, fd.FLT_MT_RLC_BELL, fd.FLT_BT_BWC_HIPASS,
              fd.FLT_BT_LRX_LOPASS, fd.FLT_DR_APO_PEAKING, fd.FLT_NONE]
@@ -179,7 +182,7 @@ def test_random_operation_sequences_match_oracle(gpu, seed):
     for step in range(60):
         op = rng.choice(["process", "process", "process", "retune", "mode", "reset", "smooth", "latency"])
         if op == "process":
-            k = int(rng.choice([1, 7, N // 2 - 1, N // 2, N, N + 3, 3 * N, int(rng.integers(1, 4 * N))]))
+            k = int(rng.choice([1, 7, N // 2 - 1, N // 2, N, N + 3, 2 * N, 3 * N, int(rng.integers(1, 4 * N))]))
             x = (rng.standard_normal((C, k)) * 0.25).astype(np.float32)
             dout = gpu.DeviceBuffer((C, k))
             eq.process(dout, gpu.DeviceBuffer.from_host(x), k)
