@@ -341,6 +341,34 @@ def test_process_blocks_equals_separate_calls(gpu, n, nb):
     bank.close()
 
 
+@pytest.mark.parametrize("n", [8192, 8192 + 16, 65536, 48000, 3 * 4096 + 2048 + 32])
+def test_long_calls_through_the_stream_kernel_same_bits(gpu, n, monkeypatch):
+    """A process() call of four sub-blocks and more is walked by the stream kernel (four waves per channel) instead of the
+    super-block loop of the one-block kernel: the same bits and the same carried state (MI_BIQUAD_BLOCKS_LOOP=1 selects the old
+    path), over two consecutive calls, in place as well."""
+    C = 9
+    rng = np.random.default_rng(4000 + n)
+    coef = [wl.design(fd.FLT_BT_LRX_LOPASS, 4, 300.0 * (c + 1), 0, 1.0, 0.75)[:8 - (c % 3)] for c in range(C)]
+    x = (rng.standard_normal((2, C, n)) * 0.25).astype(np.float32)
+    res = []
+    for old in (True, False):
+        if old:
+            monkeypatch.setenv("MI_BIQUAD_BLOCKS_LOOP", "1")
+        else:
+            monkeypatch.delenv("MI_BIQUAD_BLOCKS_LOOP", raising=False)
+        bank = gpu.BiquadBank(C, 8)
+        for c in range(C):
+            bank.set_chains(c, coef[c], False)
+        d0, o0 = gpu.DeviceBuffer.from_host(x[0]), gpu.DeviceBuffer((C, n))
+        bank.process(o0, d0, n)
+        d1 = gpu.DeviceBuffer.from_host(x[1])
+        bank.process(d1, d1, n)                               # in place
+        res.append((o0.download(), d1.download(), bank.get_state()))
+        bank.close()
+    for u, v in zip(res[0], res[1]):
+        np.testing.assert_array_equal(u, v)
+
+
 @pytest.mark.parametrize("seed", range(24))
 def test_process_blocks_random_geometries(gpu, seed):
     """Differential stress of the one-launch path against separate process() calls, bit for bit: random channel counts, section
