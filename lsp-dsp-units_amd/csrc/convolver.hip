@@ -47,8 +47,13 @@ namespace
     __device__ unsigned long long g_conv_probe[1024 * 8];
     #define MI_CPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) \
         g_conv_probe[blockIdx.x * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // conv_small_kernel: lane 0 of each of a workgroup's two waves (tests/experiments/conv_small_probe.hip)
+    __device__ unsigned long long g_small_probe[1024 * 2 * 8];
+    #define MI_SPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) \
+        g_small_probe[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
     #define MI_CPROBE(slot) do { } while (0)
+    #define MI_SPROBE(slot) do { } while (0)
 #endif
 
     // ---- forward transform of a real block of `valid` samples zero-padded to 2M, into buf ---------------
@@ -700,29 +705,59 @@ namespace
         }
     }
 
+    // a call's samples into the frame (hipMemcpy2DAsync does the same behind 10 us and more of host work per call)
+    __global__ __launch_bounds__(256)
+    void conv_file_kernel(float *frame, int B, int off, const float *in, size_t in_stride, int cnt)
+    {
+        const int j = blockIdx.x * 256 + threadIdx.x;
+        if (j < cnt)
+            frame[size_t(blockIdx.y) * B + off + j] = in[size_t(blockIdx.y) * in_stride + j];
+    }
+
     // ---- partial call: time-domain head (Convolver.cpp:292-296 does the same with dsp::convolve) ---------
     // The call's samples have already been copied into frame[off..off+cnt) (so `out` may alias the caller's
     // input: several workgroups of one channel read all of them).
+    // `in` != NULL: the samples have NOT been copied -- they are read from the caller's rows and the first workgroup of a
+    // channel files them in the frame (the host passes `in` only when `out` does not overlap it: one launch per call
+    // instead of a copy and a launch).
     __global__ __launch_bounds__(256)
-    void conv_direct_kernel(float *out, size_t out_stride, float *acc, const float *frame,
+    void conv_direct_kernel(float *out, size_t out_stride, float *acc, float *frame,
                             const float *__restrict__ h0, int B, int off, int cnt, int taps /* <= B: h0[0 .. taps) only */,
-                            int limit /* results at off + i >= limit are not produced (2 B: all of them) */)
+                            int limit /* results at off + i >= limit are not produced (2 B: all of them) */,
+                            const float *in = nullptr, size_t in_stride = 0)
     {
         extern __shared__ float sxin[];                         // cnt samples of this call
         const int ch = blockIdx.y, tid = threadIdx.x;
-        const float *x = frame + size_t(ch) * B + off;
+        float *fr = frame + size_t(ch) * B + off;
+        const float *x = (in != nullptr) ? in + size_t(ch) * in_stride : fr;
         for (int j = tid; j < cnt; j += 256)
-            sxin[j] = x[j];
+        {
+            const float v = x[j];
+            sxin[j] = v;
+            if (in != nullptr && blockIdx.x == 0)
+                fr[j] = v;
+        }
+        // the taps this workgroup's 256 results meet, h[i - j] for j in [0, cnt): a window of at most cnt + 255, in LDS as well
+        // (read from memory inside the loop every multiply-add waited for its own load: 22 us for 256 samples against 512
+        // taps, 1 us of arithmetic)
+        float *const sh = sxin + cnt;
+        const float *h = h0 + size_t(ch) * B;
+        const int i0 = blockIdx.x * 256;
+        const int wlo = (i0 - (cnt - 1) > 0) ? i0 - (cnt - 1) : 0;
+        const int whi = (i0 + 255 < taps - 1) ? i0 + 255 : taps - 1;
+        for (int k = tid; k <= whi - wlo; k += 256)
+            sh[k] = h[wlo + k];
         __syncthreads();
-        const int i = blockIdx.x * 256 + tid;                   // output position relative to `off`
+        const int i = i0 + tid;                                 // output position relative to `off`
         if (i >= cnt + taps - 1 || off + i >= limit)
             return;
-        const float *h = h0 + size_t(ch) * B;
         const int jlo = (i - (taps - 1) > 0) ? i - (taps - 1) : 0;
         const int jhi = (i < cnt - 1) ? i : cnt - 1;
         float s = 0.0f;
+        const float *hw = sh + (i - wlo);
+        #pragma unroll 8
         for (int j = jlo; j <= jhi; ++j)
-            s = fmaf(sxin[j], h[i - j], s);
+            s = fmaf(sxin[j], hw[-j], s);
         float *a = acc + size_t(ch) * 2 * B + off + i;
         const float v = *a + s;
         *a = v;
@@ -777,12 +812,35 @@ namespace
         float2 *const buf = lds_[role], *const scr = lds_[role] + fplan<LOGS>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x & (T - 1), kblk = off / SB;
         const bool next1 = (off + SB < B), next2 = (off + 2 * SB < B);     // the two blocks after this one, if the frame has them
+        MI_SPROBE(0);
         if (FULL && role == 1 && !next1)
             return;                                                         // the frame's last block owes nothing inside the frame
+        // Memory first, in the order of need: the block's samples, the twiddles, then everything else (a wave's loads return in
+        // the order of their issue: what the forward transform waits for must not stand behind the 130 loads of the debt --
+        // with the twiddles prepared first and the samples asked for last the kernel paid the latency of memory twice, 2.0 of
+        // its 5.1 us before the first butterfly, profiles/r04_experiments/conv_small_timeline.txt)
+        float *fr = frame + size_t(ch) * B + off;
+        // SB real samples = SB / 2 pairs, zero-padded to 2 SB: straight into the transform's registers (fft_lds REG_IN)
+        v2f io[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int n = tid + i * T;
+            float2 v = make_float2(0.0f, 0.0f);
+            if (n < SB / 2)
+            {
+                if (FULL)
+                {
+                    const float *x = in + size_t(ch) * in_stride;
+                    v = make_float2(x[2 * n], x[2 * n + 1]);
+                }
+                else
+                    v = *reinterpret_cast<const float2 *>(fr + 2 * n);
+            }
+            io[i] = v2f{v.x, v.y};
+        }
         typename fplan<LOGS>::real rf;
         rf.load(tw, TWN, tid);
-        rf.prepare();
-        float *fr = frame + size_t(ch) * B + off;
         float *a  = acc + size_t(ch) * 2 * B + off;
         const float2 *hs = Hs + size_t(ch) * Ps * M;
         float2 *rg = sring + size_t(ch) * Ps * M;
@@ -830,28 +888,17 @@ namespace
                     accw[i] = *reinterpret_cast<const float2 *>(a + 2 * SB + 2 * n);
             }
         }
-        // SB real samples = SB / 2 pairs, zero-padded to 2 SB: straight into the transform's registers (fft_lds REG_IN)
-        v2f io[KPT];
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
+        MI_SPROBE(1);
+        rf.prepare();
+        if (outs)                                                           // the frame keeps its samples for the commit
         {
-            const int n = tid + i * T;
-            float2 v = make_float2(0.0f, 0.0f);
-            if (n < SB / 2)
-            {
-                if (FULL)
-                {
-                    const float *x = in + size_t(ch) * in_stride;
-                    v = make_float2(x[2 * n], x[2 * n + 1]);
-                    if (outs)
-                        *reinterpret_cast<float2 *>(fr + 2 * n) = v;        // the frame keeps its samples for the commit
-                }
-                else
-                    v = *reinterpret_cast<const float2 *>(fr + 2 * n);
-            }
-            io[i] = v2f{v.x, v.y};
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                if (tid + i * T < SB / 2)
+                    *reinterpret_cast<float2 *>(fr + 2 * (tid + i * T)) = make_float2(io[i].x, io[i].y);
         }
         mi_fft::fft_lds<LOGS, false, true, false>(buf, scr, rf.ft, tid, io);
+        MI_SPROBE(2);
         const float scale = 1.0f / float(2 * M);
         const bool keep = next2 && (outs || !FULL);                         // (nobody reads the last two blocks' images)
         // ONE pass over the transform's output: the pair is split into the image's bins, the image goes to the ring, and what
@@ -886,9 +933,11 @@ namespace
                     }
                 return t;
             }, [] {});
+        MI_SPROBE(3);
         if (!FULL && !next1)
             return;                                                         // the frame's last block: the commit settles the rest
         mi_fft::fft_lds<LOGS, true, false, true>(buf, scr, rf.ft, tid, io);
+        MI_SPROBE(4);
         // (io[i]: pair n = tid + i T of the first half, io[i + KPT / 2]: pair n + M / 2 of the second)
         if (outs)
         {
@@ -905,6 +954,7 @@ namespace
         }
         if (FULL)
             __syncthreads();                                                // yx is there (a lone output wave passes at once)
+        MI_SPROBE(5);
         if (!debt)
             return;
         #pragma unroll
@@ -922,6 +972,7 @@ namespace
                 *a2 = make_float2(fmaf(t1.x, scale, v2.x), fmaf(t1.y, scale, v2.y));
             }
         }
+        MI_SPROBE(6);
     }
 
     // frame complete after partial calls: its spectrum enters the ring, acc moves on by one frame
@@ -1781,6 +1832,14 @@ int mi_convolver_bank_info(const mi_convolver_bank_t *b, uint32_t *rank, uint32_
     return MI_OK;
 }
 
+// whether the rows a call writes lie apart from the rows it reads (as whole address ranges)
+static bool rows_apart(const float *o, size_t out_stride, const float *x, size_t in_stride, size_t cnt, uint32_t channels)
+{
+    const uintptr_t o0 = reinterpret_cast<uintptr_t>(o), x0 = reinterpret_cast<uintptr_t>(x);
+    const uintptr_t on = (size_t(channels - 1) * out_stride + cnt) * sizeof(float), xn = (size_t(channels - 1) * in_stride + cnt) * sizeof(float);
+    return o0 + on <= x0 || x0 + xn <= o0;
+}
+
 int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream)
 {
@@ -1875,10 +1934,13 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 {
                     const size_t room = size_t(SB - (b->off % SB));
                     cnt = int((left < room) ? left : room);
-                    MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
-                                                  size_t(cnt) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+                    const bool apart = rows_apart(o, out_stride, x, in_stride, size_t(cnt), b->channels);
+                    if (!apart)
+                        hipLaunchKernelGGL(conv_file_kernel, dim3((cnt + 255) / 256, b->channels), dim3(256), 0, st, b->d_frame, B, b->off,
+                                           x, in_stride, cnt);
                     hipLaunchKernelGGL(conv_direct_kernel, dim3((cnt + SB - 1 + 255) / 256, b->channels), dim3(256),
-                                       size_t(cnt) * sizeof(float), st, o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, SB, B);
+                                       size_t(2 * cnt + 256) * sizeof(float), st, o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, SB, B,
+                                       apart ? x : nullptr, in_stride);
                     MI_HIP_CHECK(hipGetLastError());
                     b->off += cnt;
                     if ((b->off % SB) == 0)                                 // the block is complete: its image, and what the frame owes the next
@@ -1896,16 +1958,18 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             {
             const int cnt = int((left < size_t(B - b->off)) ? left : size_t(B - b->off));
             const dim3 grid((cnt + B - 1 + 255) / 256, b->channels);
-            MI_HIP_CHECK(hipMemcpy2DAsync(b->d_frame + b->off, size_t(B) * sizeof(float), x, in_stride * sizeof(float),
-                                          size_t(cnt) * sizeof(float), b->channels, hipMemcpyDeviceToDevice, st));
+            const bool apart = !b->xfade_active && rows_apart(o, out_stride, x, in_stride, size_t(cnt), b->channels);
+            if (!apart)
+                hipLaunchKernelGGL(conv_file_kernel, dim3((cnt + 255) / 256, b->channels), dim3(256), 0, st, b->d_frame, B, b->off,
+                                   x, in_stride, cnt);
             if (b->xfade_active && b->off == 0)
                 hipLaunchKernelGGL(conv_xfade_prescale_kernel, dim3((B / 2 + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, B, b->d_xmask);
             if (b->xfade_active)
                 hipLaunchKernelGGL(conv_direct_xfade_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
                                    o, out_stride, b->d_acc, b->d_frame, b->d_h0, b->d_h0x, B, b->off, cnt, b->d_xmask);
             else
-                hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
-                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, B, 2 * B);
+                hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(2 * cnt + 256) * sizeof(float), st,
+                                   o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, B, 2 * B, apart ? x : nullptr, in_stride);
             MI_HIP_CHECK(hipGetLastError());
             b->upper_zero = false;
             b->off += cnt;
