@@ -397,3 +397,47 @@ def test_more_workgroups_than_the_device_holds(gpu):
         ex = exact_conv(x[c], irs[c])
         err = float(np.abs(y[c] - ex).max()) / float(np.abs(ex).max())
         assert err <= TOL, (c, err)
+
+
+@pytest.mark.parametrize("rank,taps", [(10, 2500), (12, 9000)])
+def test_sub_frame_calls_whose_rows_overlap_or_lie_apart(gpu, rank, taps):
+    """A sub-frame call reads the caller's rows itself when its output lies apart from them (one launch) and through a copy
+    in the frame otherwise: the output rows shifted DOWN against the input rows by one row and by a few samples (what a
+    block-by-block walk like Convolver.cpp:217-313 survives: nothing is written that is still to be read), in place, and
+    apart -- the same samples every time."""
+    rng = np.random.default_rng(77 + rank)
+    C, n, stride = 6, 3000, 3400
+    irs = rng.standard_normal((C, taps)).astype(np.float32) * 0.05
+    x = rng.standard_normal((C, n)).astype(np.float32)
+    chunks, left = [], n
+    while left:
+        c = int(min(left, rng.choice([1, 40, 64, 128, 200, 256, 300])))
+        chunks.append(c); left -= c
+    want = None
+    for mode in ("apart", "in place", "one row down", "five samples down"):
+        bank = gpu.ConvolverBank(irs, rank)
+        arena = gpu.DeviceBuffer((2 * C + 2, stride))
+        y = np.empty_like(x)
+        pos = 0
+        for c in chunks:
+            host = np.zeros((2 * C + 2, stride), np.float32)
+            host[1:C + 1, :c] = x[:, pos:pos + c]
+            arena.upload(host)
+            src = arena.ptr + 4 * stride
+            dst = {"apart": arena.ptr + 4 * stride * (C + 1), "in place": src, "one row down": arena.ptr,
+                   "five samples down": src - 20}[mode]
+            bank.process(dst, src, c, stride, stride)
+            got = arena.download().reshape(-1)
+            o0 = (dst - arena.ptr) // 4
+            y[:, pos:pos + c] = np.stack([got[o0 + r * stride:o0 + r * stride + c] for r in range(C)])
+            pos += c
+        assert bank.faults() == 0
+        bank.close()
+        arena.free()
+        if want is None:
+            want = y
+            for ch in (0, C - 1):
+                ref32 = oracle.Convolver(irs[ch], rank).process_chunked(x[ch], 1 << (rank - 1))
+                check(y[ch], ref32, exact_conv(x[ch], irs[ch]), "rank %d ch %d" % (rank, ch))
+        else:
+            assert np.array_equal(y, want), mode
