@@ -2117,7 +2117,7 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
         {
             b->planes.push_back(b->d_amp);
             b->planes.push_back(b->d_data);
-            for (uint32_t k = 0; k + 1 < REDUCE_FRAMES_MAX; ++k)
+            for (uint32_t k = 0; k + 2 < REDUCE_FRAMES_MAX; ++k)
             {
                 float *p = nullptr;
                 MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), plane_bytes));
@@ -2125,13 +2125,21 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
             }
         }
         const size_t cnt = (frames - f < size_t(REDUCE_FRAMES_MAX)) ? frames - f : size_t(REDUCE_FRAMES_MAX);
-        // frame k's analysis reads the spectrum of the frame before (vAmp) and leaves its own in a plane that nothing reads
-        // any more: the published copy's (vData: the strobe replaces it, Analyzer.cpp:321-326) first, then the spare ones
-        std::vector<float *> spare;
-        spare.push_back(b->d_data);
-        for (float *p : b->planes)
-            if (p != b->d_amp && p != b->d_data)
-                spare.push_back(p);
+        // Frame k's analysis reads the spectrum of the frame before (vAmp) and leaves its own in a plane that nothing reads
+        // any more.  The last two frames of the batch take the planes the bank came in with -- the last one the plane that was
+        // vAmp (only the batch's first frame reads it), the one before it the published copy's (vData: the strobe replaces it,
+        // Analyzer.cpp:321-326) -- so that a batch leaves vAmp and vData where it found them (a captured run of batches then
+        // repeats with the ring alone); the frames before those two go through the spare planes.
+        float *const amp0 = b->d_amp, *const data0 = b->d_data;
+        std::vector<float *> spare(cnt);
+        {
+            size_t k = 0;
+            for (float *p : b->planes)
+                if (p != amp0 && p != data0 && k + 2 < cnt)
+                    spare[k++] = p;
+            spare[cnt - 2] = data0;
+            spare[cnt - 1] = amp0;
+        }
         reduce_planes rp;
         // the strobes themselves as ONE launch (analyzer_frames_kernel) where the hop is half a frame, nothing is delayed and
         // every block is there; otherwise a launch per strobe
@@ -2170,10 +2178,8 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
             }
             #undef MI_CALL
             MI_HIP_CHECK(hipGetLastError());
-            // where `cnt` strobes leave the bank (analyzer_strobe: the planes swap roles at every strobe; Analyzer.cpp:321-326)
-            float *const before = b->d_amp;
-            b->d_amp = spare[cnt - 1];
-            b->d_data = (cnt >= 2) ? spare[cnt - 2] : before;
+            // where `cnt` strobes leave the bank (analyzer_strobe: the planes swap roles at every strobe; Analyzer.cpp:321-326):
+            // vAmp = the last frame's plane = amp0, vData = the one before = data0
             b->head = uint32_t((uint64_t(b->head) + uint64_t(cnt) * samples) % b->buf_size);
             b->analysed = true;
         }

@@ -293,3 +293,57 @@ def test_refused_capture_leaves_the_bank_consistent(gpu):
         np.testing.assert_array_equal(outs[k].download(stream=st), o.download(stream=st), err_msg="call %d" % k)
     bank.close(); twin.close()
     hip.hipStreamDestroy(s)
+
+
+def _blocks(buf, k, cells):
+    """Device addresses of the k blocks of `cells` floats a DeviceBuffer holds one behind the other."""
+    return [buf.ptr + 4 * cells * i for i in range(k)]
+
+
+def test_runs_of_blocks_in_one_launch_replay(gpu):
+    """The calls that carry several blocks (frames) per launch under capture: the biquad bank's process_blocks (no positions:
+    any run), the equalizer's (one lap of its delay line in ONE call, half a lap in two) and the analyzer's
+    process_reduce_frames (strobes in pairs: every call brings the spectrum buffers back)."""
+    C, n, Kb = 8, 4096, 6
+    coefs, _ = wl.c2_coefficients(C)
+
+    def make_bq(st):
+        b = gpu.BiquadBank(C, 8)
+        b.set_all_chains(coefs, clear=True)
+        return b
+
+    K = _run(gpu, Case("biquad blocks", make_bq,
+                       lambda b, x, o, st: b.process_blocks(_blocks(o[0], Kb, C * n), _blocks(x, Kb, C * n), n, stream=st),
+                       (Kb, C, n), [(Kb, C, n)]), max_k=2)
+    assert K == 1
+
+    Ce, ne = 4, 512
+
+    def make_eq(st):
+        eq = gpu.EqualizerBank(Ce, 2, 9)
+        eq.set_mode(gpu.EqualizerBank.FIR)
+        eq.set_sample_rate(48000)
+        eq.set_params(0, fd.FLT_BT_RLC_BELL, 1, 1000.0, 1000.0, 2.0, 2.0)
+        eq.set_params(1, fd.FLT_BT_RLC_HISHELF, 1, 6000.0, 6000.0, 0.5, 0.0)
+        return eq
+
+    for kb, want in ((18, 1), (9, 2)):                       # the delay line in front of the convolver: 18 blocks of 512 per lap
+        K = _run(gpu, Case("equalizer blocks", make_eq,
+                           lambda b, x, o, st: b.process_blocks(_blocks(o[0], kb, Ce * ne), _blocks(x, kb, Ce * ne), ne, stream=st),
+                           (kb, Ce, ne), [(kb, Ce, ne)], want), max_k=4)
+        assert K == want
+
+    Ca, rank, F = 8, 10, 6
+    period = 512                                             # half a frame: the strobes of a run go out in one launch
+    bins = (1 << (rank - 1)) + 1
+
+    def make_an(st):
+        an = gpu.AnalyzerBank(Ca, rank, 49600, 50.0)         # ring of 1024 + 2 * 992 + 64 = 3072 cells: a call of six hops is a lap
+        an.configure(an.SAMPLE_RATE, 49600); an.configure(an.RANK, rank); an.configure(an.RATE, 96.875)
+        an.configure(an.REACTIVITY, 0.2)
+        return an
+
+    K = _run(gpu, Case("analyzer frames", make_an,
+                       lambda b, x, o, st: b.process_reduce_frames(_blocks(x, F, Ca * period), period, o[0], stream=st),
+                       (F, Ca, period), [(F, bins)]), max_k=3)
+    assert K == 1
