@@ -827,13 +827,24 @@ def run_crossover(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         xo.process(outs[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    K = args.conv_steps
+
+    def region():                                           # the K blocks of a region as ONE library call (runs of 64 per launch)
+        xo.process_blocks([outs[(args.conv_warmup + i) % ring] for i in range(K)],
+                          [xin[(args.conv_warmup + i) % ring] for i in range(K)], n, stream=stream)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, profile=False, region=region)
+    pc_elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, profile=False)
     assert all(bool(torch.isfinite(o).all()) for o in outs[0])
     xo.close()
     if rank != 0:
         return None
     return _step_result("crossover", "Crossover (IIR), 4 bands LR4, %d channels per GPU, 4096-sample blocks" % C,
-                        C, n, args.conv_steps, elapsed, world, 20.0)
+                        C, n, K, elapsed, world, 20.0,
+                        {"call": "one mi_crossover_bank_process_blocks call per region: the %d blocks ride biquad_stream_chain_kernel "
+                                 "(runs of 64 blocks per launch), bit-identical to %d process() calls" % (K, K),
+                         "per_call": {"what": "the same blocks as separate mi_crossover_bank_process calls (one launch of biquad_chain_kernel per block)",
+                                      "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),
+                                      "whole_step_frac": round(20.0 * C * n / (pc_elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)}})
 
 
 def run_splitter(args, mi, torch, dist, rank, world, dev):

@@ -622,6 +622,13 @@ int mi_crossover_bank_get_band(mi_crossover_bank_t *bank, uint32_t band, float *
  */
 int mi_crossover_bank_process(mi_crossover_bank_t *bank, float *const *band_out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream);
+/*
+ * `blocks` consecutive process() calls in one C call (Crossover.cpp:451-498 per block): block i reads in[i] and writes band k
+ * to band_out[i * bands + k] (HOST tables of DEVICE pointers; a band is NULL in every block or in none).  Runs of blocks
+ * whose buffers do not overlap each other go out as ONE launch; the results are bit for bit those of the calls one by one.
+ */
+int mi_crossover_bank_process_blocks(mi_crossover_bank_t *bank, float *const *band_out, const float *const *in, size_t blocks,
+                                     size_t samples, size_t out_stride, size_t in_stride, void *stream);
 /* freq_chart(band, c, f, count), packed complex (re, im interleaved), HOST memory, Crossover.cpp:500-590 */
 int mi_crossover_bank_freq_chart(mi_crossover_bank_t *bank, uint32_t band, float *c, const float *f, size_t count, void *stream);
 

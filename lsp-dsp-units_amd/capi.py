@@ -203,6 +203,7 @@ PROTOTYPES = {
     "mi_crossover_bank_get_split": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_float), POINTER(c_int)]),
     "mi_crossover_bank_get_band": (c_int, [c_void_p, c_uint32, POINTER(c_float), POINTER(c_float), POINTER(c_float), POINTER(c_int), c_void_p]),
     "mi_crossover_bank_process": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_crossover_bank_process_blocks": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_crossover_bank_freq_chart": (c_int, [c_void_p, c_uint32, POINTER(c_float), POINTER(c_float), c_size_t, c_void_p]),
     "mi_equalizer_bank_reset": (c_int, [c_void_p, c_void_p]),
     "mi_equalizer_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),

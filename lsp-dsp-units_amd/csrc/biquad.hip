@@ -908,13 +908,34 @@ namespace
         float          *out[STREAM_MAX_BLOCKS];
         const float    *in[STREAM_MAX_BLOCKS];
     };
+    // ... and a CHAIN of banks on the blocks of such a run (chain_stage above; the Crossover's plan): stage k's output of block
+    // i, if it has one, is out[i * outs + slot_k].  All outputs share one row stride.
+    constexpr int STREAM_CHAIN_BLOCKS = 64;     // 0.5 KiB of input pointers
+    constexpr int STREAM_CHAIN_PTRS   = 320;    // 2.5 KiB of output pointers: blocks * outs at most
+    struct stream_chain_stage
+    {
+        const float    *tab;
+        float          *state;
+        const uint32_t *nsec;
+        int             max_sec;
+        int             slot;           // -1: nothing is written
+        int             branch;
+    };
+    struct stream_chain_args
+    {
+        int                 blocks, stages, outs;
+        stream_chain_stage  st[CHAIN_MAX];
+        const float        *in[STREAM_CHAIN_BLOCKS];
+        float              *out[STREAM_CHAIN_PTRS];
+    };
     struct stream_cell { float d0, d1; uint32_t seq, pad; };
     typedef volatile __attribute__((address_space(3))) stream_cell lds_cell;    // ds_read / ds_write, in program order
 
-    template <int NW>
-    __global__ __launch_bounds__(64 * NW, (NW >= 4) ? 4 : 2)
-    void biquad_stream_kernel(const stream_args a, size_t out_stride, size_t in_stride, int n /* multiple of 16 */,
-                              const float *__restrict__ tab, float *state, const uint32_t *__restrict__ nsec, int max_sec)
+    template <int NW, bool CHAIN>
+    __device__ __forceinline__
+    void biquad_stream_body(const stream_args *pa, const stream_chain_args *pc, size_t out_stride, size_t in_stride,
+                            int n /* multiple of 16 */, const float *__restrict__ tab, float *state,
+                            const uint32_t *__restrict__ nsec, int max_sec)
     {
         using G = geom<16>;
         constexpr int L = 16, W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK;
@@ -930,10 +951,17 @@ namespace
         const int l16 = t & 15;
         float *const sx = sx_all + wv * 64 * PITCH;
         const bool lane0 = (t == 0), row3 = (t >= 48);
-        const float *ctab = tab + size_t(ch) * max_sec * TAB;
-        float *const mem = state + size_t(ch) * max_sec * 2;
+        // stage accessors: the one bank of the plain kernel, or stage k of the chain (all wave-uniform)
+        const int nst = CHAIN ? pc->stages : 1;
+        auto stage_ns  = [&](int k) -> int { return CHAIN ? int(pc->st[k].nsec[ch]) : int(nsec[ch]); };
+        auto stage_tab = [&](int k) -> const float * {
+            return CHAIN ? pc->st[k].tab + size_t(ch) * pc->st[k].max_sec * TAB : tab + size_t(ch) * max_sec * TAB; };
+        auto stage_mem = [&](int k) -> float * {
+            return CHAIN ? pc->st[k].state + size_t(ch) * pc->st[k].max_sec * 2 : state + size_t(ch) * max_sec * 2; };
+        const float *ctab = stage_tab(0);
+        float2 *const mem0 = reinterpret_cast<float2 *>(stage_mem(0));
         const int spb   = (n + SB - 1) / SB;                 // sub-blocks of a block
-        const int total = a.blocks * spb;
+        const int total = (CHAIN ? pc->blocks : pa->blocks) * spb;
         const int pred  = (wv + NW - 1) % NW;
 
         typedef const __attribute__((address_space(4))) float cfloat;
@@ -976,11 +1004,12 @@ namespace
         };
 
         float4 ld[LPT];
-        auto issue_loads = [&](int g)                        // coalesced rows of sub-block g -> registers
+        auto issue_loads = [&](int g, bool there = true)     // coalesced rows of sub-block g -> registers (!there: zeros, no traffic)
         {
             const int k = g / spb, j = g - k * spb;
+            const float *blk = CHAIN ? pc->in[k] : pa->in[k];
             const __amdgpu_buffer_rsrc_t src = __builtin_amdgcn_make_buffer_rsrc(
-                const_cast<float *>(a.in[k] + size_t(ch) * in_stride), 0, n * 4, BUFFER_DWORD3);
+                const_cast<float *>(blk + size_t(ch) * in_stride), 0, there ? n * 4 : 0, BUFFER_DWORD3);
             #pragma unroll
             for (int q = 0; q < LPT; ++q)
             {
@@ -993,27 +1022,37 @@ namespace
         // those arrive underneath them
         if (wv < total)
             issue_loads(wv);
-        const int ns  = int(nsec[ch]);
-        if (ns < 0)                                          // row switched off
+        const int ns  = stage_ns(0);
+        if (!CHAIN && ns < 0)                                // row switched off (the chain's rows never are: the host sees to it)
             return;
         // the cells: nothing published yet (seq 0), and the memory the call starts from as "the state behind sub-block -1"
-        for (int i = tid; i < ns * NW; i += 64 * NW)
+        // (the chain: the stages' sections one behind the other -- the host sends only chains whose sections have a cell each)
         {
-            const int si = i / NW, w = i - si * NW;
-            stream_cell c = { 0.0f, 0.0f, 0u, 0u };
-            if (w == NW - 1)
+            int lds0 = 0;
+            for (int k = 0; k < nst; ++k)
             {
-                const float2 s = reinterpret_cast<const float2 *>(mem)[si];
-                c.d0 = s.x;
-                c.d1 = s.y;
+                const int nk = (k == 0) ? ns : stage_ns(k);
+                const float *mk = stage_mem(k);
+                for (int i = tid; i < nk * NW; i += 64 * NW)
+                {
+                    const int si = i / NW, w = i - si * NW;
+                    stream_cell c = { 0.0f, 0.0f, 0u, 0u };
+                    if (w == NW - 1)
+                    {
+                        const float2 s = reinterpret_cast<const float2 *>(mk)[si];
+                        c.d0 = s.x;
+                        c.d1 = s.y;
+                    }
+                    cell[lds0 + si][w] = c;
+                }
+                lds0 += nk;
             }
-            cell[si][w] = c;
         }
         __syncthreads();
 
         v2f x[L];
         sectab tb;
-        if (ns > 0)
+        if (CHAIN || ns > 0)
         {
             load_pq(tb, ctab);
             load_mats(tb, ctab);
@@ -1047,7 +1086,7 @@ namespace
             }
             __builtin_amdgcn_wave_barrier();
             MI_STREAM_PROBE(1);
-            if (g + NW < total)
+            if (!CHAIN && g + NW < total)                    // (the chain asks later: see below)
                 issue_loads(g + NW);
             #pragma unroll
             for (int q = 0; q < L / 2; ++q)
@@ -1057,9 +1096,10 @@ namespace
                 x[2 * q + 1] = v2f{v.z, v.w};
             }
 
-            for (int si = 0; si < ns; ++si)
+            // One section over the sub-block: `tb` holds its table on entry and the table at Tnext on exit; ci: its hand-over
+            // cell; mem2: where its state goes at the end of the launch; turn: what the issue priority goes round with.
+            auto section = [&](const float *Tnext, int ci, float2 *mem2, int turn)
             {
-                const float *Tnext = ctab + size_t((si + 1 < ns) ? si + 1 : 0) * TAB;
 #if MI_STREAM_ROTATE
                 // The instruction arbiter of a SIMD serves its OLDEST wave first: of the four workgroups that share a CU --
                 // on this part workgroups b, b + 256, b + 512, b + 768 of a 1024-channel launch, in the order of their
@@ -1070,8 +1110,8 @@ namespace
                 // the pace through progress marks in global memory balances perfectly and costs a factor 1.8: the agent-scope
                 // marks alone do, profiles/r04_experiments/biquad_stream_pace.txt; priorities switched by the 100 MHz
                 // clock instead of the progress: the same balance, no shorter.)
-                if ((si & 3) == 0)
-                    switch (((si >> 2) + (g / NW) + int(blockIdx.x >> 8)) & 3)
+                if ((turn & 3) == 0)
+                    switch (((turn >> 2) + (g / NW) + int(blockIdx.x >> 8)) & 3)
                     {
                         case 0: __builtin_amdgcn_s_setprio(3); break;
                         case 1: __builtin_amdgcn_s_setprio(2); break;
@@ -1079,8 +1119,8 @@ namespace
                         default: __builtin_amdgcn_s_setprio(0); break;
                     }
 #endif
-                lds_cell *const from = (lds_cell *)&cell[si][pred];
-                lds_cell *const to   = (lds_cell *)&cell[si][wv];
+                lds_cell *const from = (lds_cell *)&cell[ci][pred];
+                lds_cell *const to   = (lds_cell *)&cell[ci][wv];
                 // asked for now, looked at after the dot products
                 uint32_t got = from->seq;
                 float c0 = from->d0, c1 = from->d1;
@@ -1165,30 +1205,112 @@ namespace
                         to->seq = mine;
                     }
                     if (final_sb)                            // the memory the next call starts from
-                        reinterpret_cast<float2 *>(mem)[si] = make_float2(s0, s1);
+                        *mem2 = make_float2(s0, s1);
                 }
-            }
-
-            MI_STREAM_PROBE(2);
+            };
             // x (registers) -> the wave's tile (transposed) -> coalesced write-through store
-            const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(
-                a.out[k] + size_t(ch) * out_stride, 0, n * 4, BUFFER_DWORD3);
-            #pragma unroll
-            for (int q = 0; q < L / 2; ++q)
-                *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * q]) = make_float4(x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y);
-            __builtin_amdgcn_wave_barrier();
-            #pragma unroll
-            for (int q = 0; q < LPT; ++q)
+            auto store_tile = [&](float *rows)
             {
-                const int i = 4 * (q * 64 + t);
-                const float *d = &sx[(i / W) * PITCH + 2 * (i % L) + ((i % W) / L)];
-                store_through(dst, base + i, make_float4(d[0], d[2], d[4], d[6]));
+                const __amdgpu_buffer_rsrc_t dst = __builtin_amdgcn_make_buffer_rsrc(rows + size_t(ch) * out_stride, 0, n * 4, BUFFER_DWORD3);
+                #pragma unroll
+                for (int q = 0; q < L / 2; ++q)
+                    *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * q]) = make_float4(x[2 * q].x, x[2 * q].y, x[2 * q + 1].x, x[2 * q + 1].y);
+                __builtin_amdgcn_wave_barrier();
+                #pragma unroll
+                for (int q = 0; q < LPT; ++q)
+                {
+                    const int i = 4 * (q * 64 + t);
+                    const float *d = &sx[(i / W) * PITCH + 2 * (i % L) + ((i % W) / L)];
+                    store_through(dst, base + i, make_float4(d[0], d[2], d[4], d[6]));
+                }
+                __builtin_amdgcn_wave_barrier();
+            };
+
+            if constexpr (!CHAIN)
+            {
+                for (int si = 0; si < ns; ++si)
+                    section(ctab + size_t((si + 1 < ns) ? si + 1 : 0) * TAB, si, mem0 + si, si);
+                MI_STREAM_PROBE(2);
+                store_tile(pa->out[k]);
             }
-            __builtin_amdgcn_wave_barrier();
+            else
+            {
+                // Every stage has at least one section on every channel (the host sends nothing else): the table that follows
+                // a stage's last section is the next stage's first one.  What a stage needs is fetched one stage ahead, so that
+                // the scalar loads complete underneath the sections of the stage before.
+                struct stage_info { int ns; const float *T; float2 *mem2; int slot, branch; };
+                auto fetch = [&](int q) -> stage_info {
+                    stage_info v;
+                    v.ns = stage_ns(q);
+                    v.T = stage_tab(q);
+                    v.mem2 = reinterpret_cast<float2 *>(stage_mem(q));
+                    v.slot = pc->st[q].slot;
+                    v.branch = pc->st[q].branch;
+                    return v;
+                };
+                // A branch keeps a copy of the travelling signal (32 registers) and the next sub-block's rows wait in 32 more:
+                // the two never at the same time -- the rows are asked for in front of the LAST stage (which the host sends
+                // as an in-place one: the Crossover's last high-pass), whose sections cover the latency of memory, so the
+                // kernel stays within the 128 registers of four waves per SIMD.
+                auto run_stage = [&](auto may_branch, const stage_info &cur, const float *Tn, int lds0)
+                {
+                    constexpr bool BR = decltype(may_branch)::value;
+                    v2f xs[L];                               // the travelling signal while a branch is computed
+                    if (BR && cur.branch)
+                    {
+                        #pragma unroll
+                        for (int i = 0; i < L; ++i)
+                            xs[i] = x[i];
+                    }
+                    for (int si = 0; si < cur.ns; ++si)
+                        section((si + 1 < cur.ns) ? cur.T + size_t(si + 1) * TAB : Tn, lds0 + si, cur.mem2 + si, lds0 + si);
+                    if (cur.slot >= 0)
+                        store_tile(pc->out[k * pc->outs + cur.slot]);
+                    if (BR && cur.branch)
+                    {
+                        #pragma unroll
+                        for (int i = 0; i < L; ++i)
+                            x[i] = xs[i];
+                    }
+                };
+                int lds0 = 0;
+                stage_info cur = fetch(0);
+                for (int q = 0; q + 1 < nst; ++q)
+                {
+                    const stage_info nxt = fetch(q + 1);
+                    run_stage(std::true_type(), cur, nxt.T, lds0);
+                    lds0 += cur.ns;
+                    cur = nxt;
+                }
+                // (asked for unconditionally -- behind the last sub-block from a window of no bytes: a conditional request would
+                // keep the registers of the rows alive across the whole iteration for the case that it is not made)
+                {
+                    const bool more = g + NW < total;
+                    issue_loads(more ? g + NW : g, more);
+                }
+                run_stage(std::false_type(), cur, ctab, lds0);
+                MI_STREAM_PROBE(2);
+            }
             MI_STREAM_PROBE(3);
             MI_STREAM_PROBE_ITER(g / NW);
         }
         MI_STREAM_PROBE_END();
+    }
+
+    template <int NW>
+    __global__ __launch_bounds__(64 * NW, (NW >= 4) ? 4 : 2)
+    void biquad_stream_kernel(const stream_args a, size_t out_stride, size_t in_stride, int n /* multiple of 16 */,
+                              const float *__restrict__ tab, float *state, const uint32_t *__restrict__ nsec, int max_sec)
+    {
+        biquad_stream_body<NW, false>(&a, nullptr, out_stride, in_stride, n, tab, state, nsec, max_sec);
+    }
+
+    // the chain on a run of blocks
+    template <int NW>
+    __global__ __launch_bounds__(64 * NW, 4)
+    void biquad_stream_chain_kernel(const stream_chain_args c, size_t out_stride, size_t in_stride, int n /* multiple of 16 */)
+    {
+        biquad_stream_body<NW, true>(nullptr, &c, out_stride, in_stride, n, nullptr, nullptr, nullptr, 0);
     }
 
     // The last samples % L samples of a call: one thread per channel walks them through the cascade with the same
@@ -1570,6 +1692,133 @@ namespace mi
         take_profile_events(&ev0, &ev1);
         MI_LAUNCH((biquad_chain_kernel<16, 2, true>), dim3(channels), dim3(128), 0, st, ev0, ev1, in, in_stride, int(samples), a);
         MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+
+    // The chain over a run of blocks (see mi_common.h).  A block joins the run under the rules of
+    // mi_biquad_bank_process_blocks: nothing a block of the run writes is read or written by another one (except the very
+    // same rows through the same wave: an output that comes round again a multiple of the waves' stride later), nothing one
+    // of them reads is written by another; a block's output may be its own input.
+    int biquad_chain_process_blocks(const biquad_chain_stage *stages, const int *slot, int count, int outs,
+                                    float *const *out, const float *const *in, size_t blocks, size_t samples,
+                                    size_t out_stride, size_t in_stride, hipStream_t st)
+    {
+        constexpr int NW = 4;                               // (two for the shortest runs; the rules below hold for both)
+        if (count <= 0 || count > CHAIN_MAX || outs <= 0 || stages[count - 1].branch || samples <= 2 * size_t(small::BLOCK) || (samples % 16) != 0 ||
+            samples >= (size_t(1) << 28) || (out_stride % 4) != 0 || (in_stride % 4) != 0 || out_stride < samples || in_stride < samples)
+            return 1;
+        const uint32_t channels = stages[0].bank->channels;
+        for (int k = 0; k < count; ++k)
+            if (stages[k].bank == nullptr || stages[k].bank->channels != channels || slot[k] >= outs)
+                return 1;
+        for (uint32_t c = 0; c < channels; ++c)
+        {
+            size_t total = 0;
+            for (int k = 0; k < count; ++k)
+            {
+                if (stages[k].bank->row_off[c] || stages[k].bank->nsec[c] == 0)
+                    return 1;
+                total += stages[k].bank->nsec[c];
+            }
+            if (total > size_t(STREAM_SG))
+                return 1;
+        }
+        for (size_t i = 0; i < blocks; ++i)
+        {
+            if (in[i] == nullptr || (reinterpret_cast<uintptr_t>(in[i]) % 16) != 0)
+                return 1;
+            for (int s = 0; s < outs; ++s)
+                if (out[i * outs + s] == nullptr || (reinterpret_cast<uintptr_t>(out[i * outs + s]) % 16) != 0)
+                    return 1;
+        }
+        stream_chain_args a;
+        a.stages = count;
+        a.outs = outs;
+        for (int k = 0; k < count; ++k)
+        {
+            mi_biquad_bank *b = stages[k].bank;
+            const int r = commit(b, st);
+            if (r != MI_OK)
+                return r;
+            a.st[k].tab = b->d_big;
+            a.st[k].state = b->d_state;
+            a.st[k].nsec = b->d_nsec;
+            a.st[k].max_sec = int(b->max_sec);
+            a.st[k].slot = slot[k];
+            a.st[k].branch = stages[k].branch ? 1 : 0;
+        }
+        static const bool loop = getenv("MI_BIQUAD_BLOCKS_LOOP") != nullptr;    // test knob: a launch per block
+        const size_t spb = (samples + big::BLOCK - 1) / big::BLOCK;
+        const size_t out_bytes = (size_t(channels - 1) * out_stride + samples) * sizeof(float);
+        const size_t in_bytes  = (size_t(channels - 1) * in_stride + samples) * sizeof(float);
+        auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
+            const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+            return a0 < b0 + qn && b0 < a0 + pn;
+        };
+        auto joins = [&](size_t first, size_t k) -> bool {
+            if (loop)
+                return false;
+            for (int s = 0; s < outs; ++s)                  // a block's own outputs: apart from each other, and from its input unless equal
+            {
+                const float *o = out[k * outs + s];
+                if (o != in[k] && overlap(o, out_bytes, in[k], in_bytes))
+                    return false;
+                for (int q = 0; q < s; ++q)
+                    if (overlap(o, out_bytes, out[k * outs + q], out_bytes))
+                        return false;
+            }
+            for (size_t i = first; i < k; ++i)
+                for (int s = 0; s < outs; ++s)
+                {
+                    if (overlap(out[i * outs + s], out_bytes, in[k], in_bytes) || overlap(in[i], in_bytes, out[k * outs + s], out_bytes))
+                        return false;
+                    for (int q = 0; q < outs; ++q)
+                        if (overlap(out[i * outs + s], out_bytes, out[k * outs + q], out_bytes) &&
+                            (out[i * outs + s] != out[k * outs + q] || (((k - i) * spb) % NW) != 0))
+                            return false;
+                }
+            return true;
+        };
+        const size_t cap = std::min<size_t>(size_t(STREAM_CHAIN_BLOCKS), size_t(STREAM_CHAIN_PTRS) / size_t(outs));
+        size_t first = 0;
+        while (first < blocks)
+        {
+            size_t n = 0;
+            while (first + n < blocks && n < cap && joins(first, first + n))
+                ++n;
+            if (n >= 2)
+            {
+                a.blocks = int(n);
+                for (size_t i = 0; i < n; ++i)
+                {
+                    a.in[i] = in[first + i];
+                    for (int s = 0; s < outs; ++s)
+                        a.out[i * outs + s] = out[(first + i) * outs + s];
+                }
+                hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                take_profile_events(&ev0, &ev1);
+                if (n * spb >= 4)
+                    MI_LAUNCH((biquad_stream_chain_kernel<4>), dim3(channels), dim3(256), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples));
+                else
+                    MI_LAUNCH((biquad_stream_chain_kernel<2>), dim3(channels), dim3(128), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples));
+                MI_HIP_CHECK(hipGetLastError());
+            }
+            else
+            {
+                n = 1;
+                biquad_chain_stage one[CHAIN_MAX];
+                for (int k = 0; k < count; ++k)
+                {
+                    one[k] = stages[k];
+                    one[k].out = (slot[k] >= 0) ? out[first * outs + slot[k]] : nullptr;
+                    one[k].out_stride = out_stride;
+                }
+                const int r = biquad_chain_process(one, count, in[first], in_stride, samples, st);
+                if (r != MI_OK)
+                    return (r == 1) ? fail(MI_ESTATE, "biquad_chain_process_blocks: a block of a qualified run was turned down") : r;
+            }
+            first += n;
+        }
         return MI_OK;
     }
 } // namespace mi

@@ -404,6 +404,75 @@ int mi_crossover_bank_process(mi_crossover_bank_t *b, float *const *band_out, co
     return MI_OK;
 }
 
+// `blocks` consecutive process() calls in one C call: block i reads in[i] and writes its bands to band_out[i * (splits + 1) +
+// band].  Runs of blocks go out as ONE launch (biquad_stream_chain_kernel: the plan's chain on a stream of sub-blocks, the
+// loads of a sub-block and the stores of the bands underneath the sections of its neighbours) -- the same bits as the calls
+// one by one.  Crossover.cpp:451-498 per block.
+int mi_crossover_bank_process_blocks(mi_crossover_bank_t *b, float *const *band_out, const float *const *in, size_t blocks,
+                                     size_t samples, size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_crossover_bank_process_blocks: NULL bank");
+    if (samples == 0 || blocks == 0)
+        return MI_OK;
+    MI_REQUIRE(band_out != nullptr && in != nullptr, MI_EINVAL, "mi_crossover_bank_process_blocks: NULL pointer table");
+    for (size_t i = 0; i < blocks; ++i)
+        MI_REQUIRE(in[i] != nullptr, MI_EINVAL, "mi_crossover_bank_process_blocks: NULL input of block %zu", i);
+    hipStream_t st = mi::as_stream(stream);
+    int r = reconfigure(b, stream);
+    if (r != MI_OK)
+        return r;
+    const size_t nb = size_t(b->splits) + 1, np = b->plan.size();
+    auto one_by_one = [&]() -> int {
+        for (size_t i = 0; i < blocks; ++i)
+        {
+            const int rc = mi_crossover_bank_process(b, band_out + i * nb, in[i], samples, out_stride, in_stride, stream);
+            if (rc != MI_OK)
+                return rc;
+        }
+        return MI_OK;
+    };
+    static const bool unfused = getenv("MI_CROSSOVER_UNFUSED") != nullptr;
+    if (np == 0 || blocks < 2 || unfused)
+        return one_by_one();
+    // the same bands have a handler in every block (a band without one is skipped, its low-pass rests: Crossover.cpp:462-466)
+    for (size_t i = 1; i < blocks; ++i)
+        for (size_t k = 0; k < nb; ++k)
+            if ((band_out[i * nb + k] == nullptr) != (band_out[k] == nullptr))
+                return one_by_one();
+    std::vector<mi::biquad_chain_stage> chain;
+    std::vector<int> slot;
+    std::vector<uint32_t> band_of_slot;
+    auto slot_of = [&](uint32_t band) -> int {
+        if (band_out[band] == nullptr)
+            return -1;
+        band_of_slot.push_back(band);
+        return int(band_of_slot.size()) - 1;
+    };
+    uint32_t lband = 0;
+    for (size_t i = 0; i < np; ++i)
+    {
+        split_t &sp = b->split[b->plan[i]];
+        if (band_out[lband] != nullptr)
+        {
+            chain.push_back({ sp.lpf, nullptr, out_stride, 1 });
+            slot.push_back(slot_of(lband));
+        }
+        chain.push_back({ sp.hpf, nullptr, out_stride, 0 });
+        slot.push_back((i + 1 == np) ? slot_of(sp.band_id) : -1);
+        lband = sp.band_id;
+    }
+    const int outs = int(band_of_slot.size());
+    if (outs == 0)
+        return one_by_one();
+    std::vector<float *> po(blocks * size_t(outs));
+    for (size_t i = 0; i < blocks; ++i)
+        for (int s = 0; s < outs; ++s)
+            po[i * outs + s] = band_out[i * nb + band_of_slot[s]];
+    r = mi::biquad_chain_process_blocks(chain.data(), slot.data(), int(chain.size()), outs, po.data(), in, blocks, samples,
+                                        out_stride, in_stride, st);
+    return (r == 1) ? one_by_one() : r;
+}
+
 int mi_crossover_bank_freq_chart(mi_crossover_bank_t *b, uint32_t band, float *c, const float *f, size_t count, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_crossover_bank_freq_chart: NULL bank");

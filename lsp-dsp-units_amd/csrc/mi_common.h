@@ -58,6 +58,14 @@ namespace mi
     };
     int         biquad_chain_process(const biquad_chain_stage *stages, int count, const float *in, size_t in_stride,
                                      size_t samples, hipStream_t st);
+    // The same chain over `blocks` consecutive blocks (buffers of their own): runs of blocks go out as ONE launch
+    // (biquad_stream_chain_kernel) where the blocks allow it, single blocks as biquad_chain_process.  slot[k]: which of a
+    // block's `outs` outputs stage k writes (-1: none; stages[k].out is not looked at); block i's output s is
+    // out[i * outs + s], all outputs with the row stride out_stride.  Returns like biquad_chain_process -- 1 before
+    // anything has been issued.
+    int         biquad_chain_process_blocks(const biquad_chain_stage *stages, const int *slot, int count, int outs,
+                                            float *const *out, const float *const *in, size_t blocks, size_t samples,
+                                            size_t out_stride, size_t in_stride, hipStream_t st);
 
     // A biquad bank over a block without an output (biquad.hip): sums[channel * 4 + s] += the sum of the squares of the
     // filtered samples of segment s = [seg_end[s - 1], seg_end[s]), seg_end[3] = samples.  The meters' weighting filter.

@@ -849,6 +849,18 @@ class CrossoverBank:
                                             samples if out_stride is None else out_stride,
                                             samples if in_stride is None else in_stride, _stream(stream)))
 
+    def process_blocks(self, band_outs, inps, samples, out_stride=None, in_stride=None, stream=None):
+        """len(inps) consecutive process() calls in one C call; band_outs[i]: block i's list of `bands` buffers (or None)."""
+        n = len(inps)
+        assert n == len(band_outs)
+        flat = [(_ptr(b) if b is not None else None) for outs in band_outs for b in outs]
+        assert len(flat) == n * self.bands
+        po = (c_void_p * len(flat))(*flat)
+        pi = (c_void_p * n)(*[_ptr(b) for b in inps])
+        check(lib.mi_crossover_bank_process_blocks(self.handle, po, pi, n, samples,
+                                                   samples if out_stride is None else out_stride,
+                                                   samples if in_stride is None else in_stride, _stream(stream)))
+
     def freq_chart(self, band, freqs, stream=None):
         import numpy as np
         f = np.ascontiguousarray(freqs, dtype=np.float32)

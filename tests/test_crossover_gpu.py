@@ -206,3 +206,99 @@ def test_random_retune_scripts(gpu, seed):
     for b in range(bands):
         assert bank.get_band(b) == pytest.approx(refs[0].band_info(b))
     bank.close()
+
+
+def _xo(gpu, C, bands, freqs, slope=2):
+    bank = gpu.CrossoverBank(C, bands)
+    bank.set_sample_rate(48000)
+    for i, f in enumerate(freqs):
+        bank.set_slope(i, slope); bank.set_frequency(i, f)
+    return bank
+
+
+@pytest.mark.parametrize("n,K,handlers", [(4096, 5, None), (4096, 2, None), (6144, 4, None), (2064, 7, None), (4096, 6, [0, 3]),
+                                          (4096, 3, [1]), (8192, 3, [0, 1, 2, 3]), (4096, 70, None)])
+def test_process_blocks_is_bit_identical_to_block_by_block(gpu, n, K, handlers):
+    """mi_crossover_bank_process_blocks: K consecutive blocks in ONE launch (biquad_stream_chain_kernel) against K calls of
+    process() on a twin bank -- every band of every block bit for bit, and the filter memories left behind (a further block
+    through both).  Bands without a handler are skipped in both; 70 blocks: more than one launch carries."""
+    C, bands = 5, 4
+    handlers = list(range(bands)) if handlers is None else handlers
+    rng = np.random.default_rng(n + K)
+    x = (rng.standard_normal((K + 1, C, n)) * 0.25).astype(np.float32)
+    a = _xo(gpu, C, bands, (200.0, 1500.0, 7000.0))
+    b = _xo(gpu, C, bands, (200.0, 1500.0, 7000.0))
+    dins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K + 1)]
+    mk = lambda: [gpu.DeviceBuffer.from_host(np.full((C, n), 7.0, np.float32)) if q in handlers else None for q in range(bands)]
+    oa = [mk() for _ in range(K + 1)]
+    ob = [mk() for _ in range(K + 1)]
+    a.process_blocks(oa[:K], dins[:K], n)
+    a.process(oa[K], dins[K], n)
+    for k in range(K + 1):
+        b.process(ob[k], dins[k], n)
+    for k in range(K + 1):
+        for q in handlers:
+            ya, yb = oa[k][q].download(), ob[k][q].download()
+            assert np.abs(yb).max() > 1e-3 and not np.any(yb == 7.0)
+            np.testing.assert_array_equal(ya, yb, err_msg="block %d band %d" % (k, q))
+    a.close(); b.close()
+
+
+def test_process_blocks_with_buffers_that_come_round_and_overlap(gpu):
+    """Output buffers reused inside the call (a ring of two sets of bands), a block processed in place (one band written over
+    its own input) and a block that reads what an earlier block of the call wrote: the call splits into the runs that may
+    share a launch and gives what block-by-block calls give."""
+    C, bands, n, K = 3, 3, 4096, 6
+    rng = np.random.default_rng(5)
+    x = (rng.standard_normal((K, C, n)) * 0.25).astype(np.float32)
+    res = []
+    for blocks_call in (True, False):
+        bank = _xo(gpu, C, bands, (400.0, 4000.0))
+        dins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K)]
+        ring = [[gpu.DeviceBuffer((C, n)) for _ in range(bands)] for _ in range(2)]
+        outs = [ring[k % 2] for k in range(K)]
+        outs[2] = [dins[2], ring[0][1], ring[0][2]]          # band 0 of block 2 in place
+        dins[4] = ring[1][0]                                 # block 4 reads band 0 of block 3 (and 1)
+        got = []
+        if blocks_call:
+            # the ring would be overwritten before it is looked at: take the call in two halves and look in between
+            for lo, hi in ((0, 2), (2, 4), (4, 6)):
+                bank.process_blocks(outs[lo:hi], dins[lo:hi], n)
+                got += [[b.download() for b in outs[k]] for k in range(lo, hi)][-1:]
+        else:
+            for k in range(K):
+                bank.process(outs[k], dins[k], n)
+                if k % 2 == 1:
+                    got.append([b.download() for b in outs[k]])
+        res.append(got)
+        bank.close()
+    for ga, gb in zip(*res):
+        for ya, yb in zip(ga, gb):
+            np.testing.assert_array_equal(ya, yb)
+
+
+def test_process_blocks_falls_back_where_the_chain_does_not_apply(gpu):
+    """Short blocks, a bank without split points and a retune between two calls: process_blocks is K process() calls."""
+    C, bands, K = 2, 3, 4
+    rng = np.random.default_rng(8)
+    for n, freqs in ((1000, (400.0, 4000.0)), (4096, ())):
+        x = (rng.standard_normal((K, C, n)) * 0.25).astype(np.float32)
+        a, b = _xo(gpu, C, bands, freqs), _xo(gpu, C, bands, freqs)
+        if not freqs:
+            for bank in (a, b):
+                for i in range(bands - 1):
+                    bank.set_slope(i, 0)
+        dins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K)]
+        oa = [[gpu.DeviceBuffer.from_host(np.full((C, n), 7.0, np.float32)) for _ in range(bands)] for _ in range(K)]
+        ob = [[gpu.DeviceBuffer.from_host(np.full((C, n), 7.0, np.float32)) for _ in range(bands)] for _ in range(K)]
+        a.process_blocks(oa[:2], dins[:2], n)
+        a.set_gain(0, 0.5)
+        a.process_blocks(oa[2:], dins[2:], n)
+        for k in range(K):
+            if k == 2:
+                b.set_gain(0, 0.5)
+            b.process(ob[k], dins[k], n)
+        for k in range(K):
+            for q in range(bands):
+                np.testing.assert_array_equal(oa[k][q].download(), ob[k][q].download(), err_msg="n %d block %d band %d" % (n, k, q))
+        a.close(); b.close()
