@@ -1636,17 +1636,46 @@ namespace
 
 namespace mi
 {
+    int biquad_chain_process_blocks(const biquad_chain_stage *stages, const int *slot, int count, int outs,
+                                    float *const *out, const float *const *in, size_t blocks, size_t samples,
+                                    size_t out_stride, size_t in_stride, hipStream_t st);
+
     // One launch for a chain of banks on the same samples (see chain_stage above).  Returns MI_OK when the fused launch
     // was issued, 1 when the call does not qualify (the caller then runs the banks one after the other as before):
     // blocks longer than one wave's sub-block of 2048 samples that are a multiple of the chunk, 16-byte aligned rows, at
     // most CHAIN_MAX stages, the sections of all stages together within the LDS state slots, every stage with at least one
     // section on every channel and no row switched off.
     int biquad_chain_process(const biquad_chain_stage *stages, int count, const float *in, size_t in_stride,
-                             size_t samples, hipStream_t st)
+                             size_t samples, hipStream_t st, bool long_calls_as_streams)
     {
         if (count <= 0 || count > CHAIN_MAX || samples <= 2 * size_t(small::BLOCK) || (samples % 16) != 0 ||
             samples >= (size_t(1) << 28))
             return 1;
+        // A long call (four sub-blocks of 2048 samples and more) is a stream of sub-blocks like a run of blocks: the stream
+        // kernel walks it with four waves per channel, hand-over for hand-over what the super-block loop below does.
+        if (long_calls_as_streams && samples >= 4 * size_t(big::BLOCK))
+        {
+            int slot[CHAIN_MAX], outs = 0;
+            float *po[CHAIN_MAX];
+            size_t stride = 0;
+            bool same = true;
+            for (int k = 0; k < count; ++k)
+            {
+                slot[k] = -1;
+                if (stages[k].out == nullptr)
+                    continue;
+                same = same && (outs == 0 || stages[k].out_stride == stride);
+                stride = stages[k].out_stride;
+                po[outs] = stages[k].out;
+                slot[k] = outs++;
+            }
+            if (same && outs > 0)
+            {
+                const int r = biquad_chain_process_blocks(stages, slot, count, outs, po, &in, 1, samples, stride, in_stride, st);
+                if (r != 1)
+                    return r;
+            }
+        }
         const uint32_t channels = stages[0].bank->channels;
         bool aligned = (reinterpret_cast<uintptr_t>(in) % 16 == 0) && (in_stride % 4 == 0) && in_stride >= samples;
         for (int k = 0; k < count; ++k)
@@ -1786,7 +1815,7 @@ namespace mi
             size_t n = 0;
             while (first + n < blocks && n < cap && joins(first, first + n))
                 ++n;
-            if (n >= 2)
+            if (n >= 2 || (n == 1 && spb >= 4 && !loop))
             {
                 a.blocks = int(n);
                 for (size_t i = 0; i < n; ++i)
@@ -1805,7 +1834,7 @@ namespace mi
             }
             else
             {
-                n = 1;
+                n = 1;                                      // (also a block whose own buffers overlap: joins() turned it down)
                 biquad_chain_stage one[CHAIN_MAX];
                 for (int k = 0; k < count; ++k)
                 {
@@ -1813,7 +1842,7 @@ namespace mi
                     one[k].out = (slot[k] >= 0) ? out[first * outs + slot[k]] : nullptr;
                     one[k].out_stride = out_stride;
                 }
-                const int r = biquad_chain_process(one, count, in[first], in_stride, samples, st);
+                const int r = biquad_chain_process(one, count, in[first], in_stride, samples, st, false);
                 if (r != MI_OK)
                     return (r == 1) ? fail(MI_ESTATE, "biquad_chain_process_blocks: a block of a qualified run was turned down") : r;
             }

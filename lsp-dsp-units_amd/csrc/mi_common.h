@@ -57,7 +57,7 @@ namespace mi
         int                 branch;         // 1: the travelling signal goes on unchanged, the result only goes to `out`
     };
     int         biquad_chain_process(const biquad_chain_stage *stages, int count, const float *in, size_t in_stride,
-                                     size_t samples, hipStream_t st);
+                                     size_t samples, hipStream_t st, bool long_calls_as_streams = true);
     // The same chain over `blocks` consecutive blocks (buffers of their own): runs of blocks go out as ONE launch
     // (biquad_stream_chain_kernel) where the blocks allow it, single blocks as biquad_chain_process.  slot[k]: which of a
     // block's `outs` outputs stage k writes (-1: none; stages[k].out is not looked at); block i's output s is

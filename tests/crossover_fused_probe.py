@@ -1,5 +1,6 @@
 """Helper of tests/test_crossover_gpu.py::test_fused_chain_equals_one_launch_per_filter: runs a 4-band crossover over
-three 4096-sample blocks and saves the bands.  With MI_CROSSOVER_UNFUSED set the bank runs one launch per filter."""
+three blocks (4096 samples unless given) and saves the bands.  With MI_CROSSOVER_UNFUSED set the bank runs one launch per
+filter, with MI_BIQUAD_BLOCKS_LOOP long calls stay with the super-block loop of biquad_chain_kernel."""
 import importlib
 import os
 import sys
@@ -10,9 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def run(out_path, handlers):
+def run(out_path, handlers, block=4096):
     mi = importlib.import_module("lsp-dsp-units_amd")
-    C, bands, block, blocks = 6, 4, 4096, 3
+    C, bands, blocks = 6, 4, 3
     x = (np.random.default_rng(11).standard_normal((C, blocks * block)) * 0.25).astype(np.float32)
     bank = mi.CrossoverBank(C, bands)
     bank.set_sample_rate(48000)
@@ -33,4 +34,4 @@ def run(out_path, handlers):
 
 
 if __name__ == "__main__":
-    run(sys.argv[1], [int(v) for v in sys.argv[2].split(",")])
+    run(sys.argv[1], [int(v) for v in sys.argv[2].split(",")], int(sys.argv[3]) if len(sys.argv) > 3 else 4096)

@@ -156,6 +156,26 @@ def test_fused_chain_equals_one_launch_per_filter(gpu, tmp_path, handlers):
     np.testing.assert_array_equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("block", [8192, 10000 - 10000 % 16, 16384])
+def test_long_calls_through_the_stream_kernel_same_bits(gpu, tmp_path, block):
+    """process() calls of four sub-blocks and more walk through biquad_stream_chain_kernel: the same bits as the
+    super-block loop of biquad_chain_kernel (MI_BIQUAD_BLOCKS_LOOP) and as one launch per filter."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    outs = []
+    for tag, env in (("stream", {}), ("loop", {"MI_BIQUAD_BLOCKS_LOOP": "1"}), ("unfused", {"MI_CROSSOVER_UNFUSED": "1", "MI_BIQUAD_BLOCKS_LOOP": "1"})):
+        path = str(tmp_path / (tag + ".npy"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.check_call([sys.executable, os.path.join(here, "crossover_fused_probe.py"), path, "0,1,2,3", str(block)], env=e)
+        outs.append(np.load(path))
+    assert np.abs(outs[0]).max() > 0.01
+    np.testing.assert_array_equal(outs[0], outs[1])
+    np.testing.assert_array_equal(outs[0], outs[2])
+
+
 def test_freq_charts_match_oracle(gpu):
     bank = gpu.CrossoverBank(1, 4)
     ref = oc.Crossover(4)
