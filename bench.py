@@ -686,7 +686,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     """BASELINE.json configs[4]: 4096-point Hann spectrum of 1024 channels per GPU every 2048 samples, per-bin sum
     over ALL channels of the job: local reduction on the device + one RCCL all-reduce per batch of frames."""
     sharding = importlib.import_module("lsp-dsp-units_amd.sharding")
-    C, rank_fft, hop, batch = args.spec_channels, 12, 2048, 8
+    C, rank_fft, hop, batch = args.spec_channels, 12, 2048, int(os.environ.get("MI_BENCH_SPEC_BATCH", "16"))
     sr = 48000
     an = mi.AnalyzerBank(C, rank_fft, sr, 1.0, 0)
     for what, v in ((an.SAMPLE_RATE, sr), (an.RATE, sr / float(hop)), (an.RANK, rank_fft), (an.WINDOW, 0),
@@ -724,7 +724,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                 sharding.allreduce_bins(sums)
 
     def batch_step(i):
-        # the same `batch` frames as ONE mi_analyzer_bank_process_reduce_frames call: eight analyses, their reductions as one
+        # the same `batch` frames as ONE mi_analyzer_bank_process_reduce_frames call: the strobes as one launch, their reductions as one
         # launch, then the collective
         an.process_reduce_frames([xin[(i + j) % ring] for j in range(batch)], hop, sums, stream=stream)
         if state["comm"] is not None:
@@ -738,10 +738,14 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     def region():
         for i in range(0, steps, batch):
             batch_step(i)
+    # probes: the analysis launch of a batch alone (analyzer_frames_kernel takes the event pair, the reduction and the
+    # collective behind it do not), the stream drained in front of each
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch, region=region,
-                                             probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream), probe_sync=True)
-    tinfo["launch"] = "%d mi_analyzer_bank_process_reduce_frames calls of %d frames each per region (analysis launch per frame, the %d reductions as one launch)" % (steps // batch, batch, batch)
-    pc_elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, steps, batch, profile=False)
+                                             probe_step=lambda i: batch_step(i * batch), probe_sync=True, probe_steps=batch)
+    tinfo["launch"] = ("%d mi_analyzer_bank_process_reduce_frames calls of %d frames each per region (the %d strobes as ONE launch of "
+                       "analyzer_frames_kernel, their reductions as one launch of bin_reduce_frames_kernel)" % (steps // batch, batch, batch))
+    pc_elapsed, pc_kernel_ms, pc_info = _timed_steps(mi, torch, dist, world, dev, step, steps, batch,
+                                                     probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream), probe_sync=True)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
     if state["comm"] is not None:
         state["comm"].close()
@@ -759,9 +763,12 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                                % (C, batch, bins, batch), "channels_per_gpu": C, "collective": state["collective"]},
         "timing": tinfo,
         "per_call": {"what": "a mi_analyzer_bank_process_reduce call per frame (analysis launch + reduction launch)",
-                     "ms_per_step": round(pc_elapsed / steps * 1e3, 5), "value": round(C * world * steps / pc_elapsed, 1), "unit": "channel-frames/s"},
-        "roofline": _roofline("analyzer_kernel<11>", frame_bytes, kernel_ms, elapsed / steps * 1e3, tinfo["probe"],
-                              _pmc_traffic("pmc_spectral_latest.json") if C == 1024 else None),
+                     "ms_per_step": round(pc_elapsed / steps * 1e3, 5), "value": round(C * world * steps / pc_elapsed, 1), "unit": "channel-frames/s",
+                     "roofline": _roofline("analyzer_kernel<11>", frame_bytes, pc_kernel_ms, pc_elapsed / steps * 1e3, pc_info["probe"])},
+        "roofline": _roofline("analyzer_frames_kernel<11> (%d frames per launch)" % batch, frame_bytes * batch, kernel_ms,
+                              elapsed / steps * 1e3, tinfo["probe"],
+                              _pmc_traffic("pmc_spectral_latest.json", "analyzer_frames_kernel", batch) if C == 1024 else None,
+                              launch_steps=batch),
         "whole_step": {"algorithmic_bytes": frame_bytes,
                        "achieved_GBps_incl_launch_gaps": round(frame_bytes / (elapsed / steps) / 1e9, 1),
                        "frac": round(frame_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},

@@ -13,9 +13,9 @@ import os
 import sys
 
 KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frames_kernel",
-           "spectral": "analyzer_kernel"}
+           "spectral": "analyzer_frames_kernel"}
 # the PMC passes run `bench.py --steps 50`: the headline's launch (biquad_stream_kernel) then carries 50 blocks
-UNITS_PER_LAUNCH = {"biquad": 50, "equalizer": 50}
+UNITS_PER_LAUNCH = {"biquad": 50, "equalizer": 50, "spectral": 16}
 
 
 def main():
