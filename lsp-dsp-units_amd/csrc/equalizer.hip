@@ -567,6 +567,17 @@ int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *b, float *const *out, 
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
         return a0 < b0 + qn && b0 < a0 + pn;
     };
+    if (b->mode == MI_EQM_IIR)                              // the cascade of all filters' sections: the biquad bank's runs of blocks
+    {
+        const int rc = mi::capture_touch(st, b, "equalizer", equalizer_bank_positions);
+        if (rc != MI_OK)
+            return rc;
+        const int r = reconfigure(b, st);
+        if (r != MI_OK)
+            return r;
+        if (b->mode == MI_EQM_IIR)                          // (reconfigure settles a pending change of mode)
+            return mi_biquad_bank_process_blocks(b->biquads, out, in, blocks, samples, out_stride, in_stride, stream);
+    }
     size_t k = 0;
     while (k < blocks)
     {

@@ -340,3 +340,35 @@ def test_c4_full_size(gpu):
     for c in range(C):
         record_parity("equalizer FIR full size: |gpu - oracle| <= 1e-5 peak (every channel)", errs[c], TOL, noise=noises[c])
     assert np.all(errs <= TOL), (int(np.argmax(errs)), float(errs.max()))
+
+
+def test_runs_of_blocks_in_iir_mode_ride_the_biquad_stream(gpu):
+    """EQM_IIR: mi_equalizer_bank_process_blocks hands the run to the cascade's bank (mi_biquad_bank_process_blocks: one launch
+    for the blocks) -- the bits of block-by-block calls, the state left behind serves the next call."""
+    rng = np.random.default_rng(314)
+    C, nfilt, n, K = 6, 5, 4096, 5
+    x = (rng.standard_normal((K + 1, C, n)) * 0.25).astype(np.float32)
+    curves = [[(fd.FLT_BT_RLC_BELL, 1, float(f), float(f), float(g), 2.0)
+               for f, g in zip(np.exp(rng.uniform(np.log(100), np.log(15000), nfilt)), 10 ** (rng.uniform(-9, 9, nfilt) / 20))] for _ in range(C)]
+
+    def make():
+        eq = gpu.EqualizerBank(C, nfilt, 10)
+        eq.set_mode(gpu.EqualizerBank.IIR)
+        eq.set_sample_rate(48000)
+        for c in range(C):
+            for i, p in enumerate(curves[c]):
+                eq.set_params(i, *p, channel=c)
+        return eq
+    a, b = make(), make()
+    ins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K + 1)]
+    oa = [gpu.DeviceBuffer((C, n)) for _ in range(K + 1)]
+    ob = [gpu.DeviceBuffer((C, n)) for _ in range(K + 1)]
+    a.process_blocks(oa[:K], ins[:K], n)
+    a.process(oa[K], ins[K], n)
+    for k in range(K + 1):
+        b.process(ob[k], ins[k], n)
+    for k in range(K + 1):
+        ya, yb = oa[k].download(), ob[k].download()
+        assert np.abs(yb).max() > 1e-3
+        np.testing.assert_array_equal(ya, yb, err_msg="block %d" % k)
+    a.close(); b.close()
