@@ -528,8 +528,11 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
     times = []
     gc.collect()
     gc.disable()            # no interpreter housekeeping inside a timed region
+    gap_s = float(os.environ.get("MI_BENCH_REGION_GAP_MS", "0")) * 1e-3      # experiment knob: idle time between regions
     for r in range(regions):
         fence()
+        if gap_s > 0.0:
+            time.sleep(gap_s)
         t0 = time.perf_counter()
         if exe is not None:
             mi.check(mi.lib.mi_dspu_graph_launch(exe, ctypes.c_void_p(stream.cuda_stream)))
@@ -601,9 +604,16 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
                 probe_mode = "inconsistent"
         if os.environ.get("MI_BENCH_DUMP_PROBES"):
             print("probes us: " + " ".join("%.2f" % (v * 1e3) for v in kernel_ms), file=sys.stderr)
+    def _med(v):
+        v = sorted(v)
+        return round(v[len(v) // 2] * 1e3, 5)
     info = {"launch": mode, "regions": regions, "probe": probe_mode,
             "region_ms": {"min": round(st[0] * 1e3, 5), "median": round(st[len(st) // 2] * 1e3, 5),
-                          "max": round(st[-1] * 1e3, 5), "first": round(times[0] * 1e3, 5)}}
+                          "max": round(st[-1] * 1e3, 5), "first": round(times[0] * 1e3, 5),
+                          "in_order": [round(v * 1e3, 4) for v in times]}}
+    if len(times) >= 50:                                    # the onset transient of the power controller, and the settled state
+        info["region_ms"]["median_of_first_25"] = _med(times[:25])
+        info["region_ms"]["median_of_last_25"] = _med(times[-25:])
     return st[len(st) // 2], sorted(kernel_ms), info
 
 
@@ -1053,7 +1063,11 @@ def main():
         k = i % ring
         bank.process(yout[k], xin[k], n, stream=stream)
 
-    regions = args.regions or (5 if args.steps >= 500 else 25)
+    # Short regions (K = 20: 0.16 - 0.2 ms each) are timed 101 times: the chip's power controller answers the onset of the
+    # load with a dip of the shader clock that lasts 20 - 30 regions (160 -> 215 us per region) and settles after 60 - 80
+    # (165 - 175 us; timing.region_ms.in_order shows the walk, profiles/r04_experiments/bench_k20_regions.txt) -- 25 regions
+    # measured that transient, not the state a stream of blocks runs in.  `value` is the median region.
+    regions = args.regions or (5 if args.steps >= 500 else 101)
     region, launch_steps = None, 1
     if args.launch == "blocks":
         seq = [(args.warmup + i) % ring for i in range(args.steps)]
