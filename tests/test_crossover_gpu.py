@@ -322,3 +322,54 @@ def test_process_blocks_falls_back_where_the_chain_does_not_apply(gpu):
             for q in range(bands):
                 np.testing.assert_array_equal(oa[k][q].download(), ob[k][q].download(), err_msg="n %d block %d band %d" % (n, k, q))
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_process_blocks_random_geometries(gpu, seed):
+    """Differential stress of the crossover's runs of blocks against block-by-block calls, bit for bit: random channel and band
+    counts, slopes (chains of 2 .. 28 sections; longer ones than the stream kernel has cells for fall back), bands without a
+    handler, block lengths (whole chunks of 16 above 2048 samples, now and then one the chain does not take), strides, numbers
+    of blocks (beyond one launch's share too), bands written over the block's own input, output sets that come round again,
+    blocks that read a band an earlier block wrote, and a second call on the filter memories the first one left."""
+    rng = np.random.default_rng(91000 + seed)
+    C = int(rng.integers(1, 13))
+    bands = int(rng.integers(2, 6))
+    slopes = [int(rng.choice([1, 2, 2, 3, 4])) for _ in range(bands - 1)]
+    freqs = sorted(float(f) for f in np.exp(rng.uniform(np.log(80.0), np.log(15000.0), bands - 1)))
+    handlers = [q for q in range(bands) if rng.integers(0, 5) != 0] or [0]
+    n = int(rng.choice([2064, 4096, 4096, 4096 + 16 * int(rng.integers(1, 200)), 8192, 3 * 4096 + 32, 1000, 4100]))
+    stride = n + int(rng.choice([0, 4, 8, 64]))
+    results = []
+    for blocks_call in (False, True):
+        r2 = np.random.default_rng(92000 + seed)            # the same plan for both runs
+        bank = gpu.CrossoverBank(C, bands)
+        bank.set_sample_rate(48000)
+        for i in range(bands - 1):
+            bank.set_slope(i, slopes[i]); bank.set_frequency(i, freqs[i])
+        outputs = []
+        for call in range(2):
+            nb = int(r2.choice([2, 3, 5, 9, 70])) if call == 0 else int(r2.integers(2, 6))
+            pool = [gpu.DeviceBuffer.from_host((r2.standard_normal((C, stride)) * 0.25).astype(np.float32)) for _ in range(min(nb, 6))]
+            sets = [[gpu.DeviceBuffer.from_host(np.full((C, stride), 3.0, np.float32)) if q in handlers else None for q in range(bands)]
+                    for _ in range(3)]
+            ins, outs = [], []
+            for b in range(nb):
+                kind = int(r2.integers(0, 6))
+                i = pool[b % len(pool)]
+                o = list(sets[b % 3]) if kind != 1 else list(sets[int(r2.integers(0, 3))])
+                if kind == 0 and b < len(pool):
+                    o[handlers[0]] = i                       # a band over the block's own input
+                if kind == 3 and outs:
+                    i = outs[int(r2.integers(0, len(outs)))][handlers[-1]]      # reads a band an earlier block wrote
+                ins.append(i); outs.append(o)
+            if blocks_call:
+                bank.process_blocks(outs, ins, n, out_stride=stride, in_stride=stride)
+            else:
+                for o, i in zip(outs, ins):
+                    bank.process(o, i, n, out_stride=stride, in_stride=stride)
+            outputs.append([b.download() for b in pool] + [s[q].download() for s in sets for q in handlers])
+        results.append(outputs)
+        bank.close()
+    for ca, cb in zip(results[0], results[1]):
+        for u, v in zip(ca, cb):
+            np.testing.assert_array_equal(u, v, err_msg=str((seed, C, bands, slopes, handlers, n, stride)))
