@@ -931,18 +931,26 @@ namespace
     struct stream_cell { float d0, d1; uint32_t seq, pad; };
     typedef volatile __attribute__((address_space(3))) stream_cell lds_cell;    // ds_read / ds_write, in program order
 
-    template <int NW, bool CHAIN>
+    // QLDS: the per-lane operand of the scan ((P^2)^(lane % 16 + 1), 16 bytes per lane and section) waits in LDS for the whole
+    // launch instead of being fetched from the table section by section.  As a vector load it shared the wave's in-order
+    // counter with the prefetched rows of the next sub-block and the stores of the last one: the wait in front of the first
+    // section's scan was a wait for all of those (s_waitcnt vmcnt(0): the loop over the sections is one piece of code and
+    // cannot count differently for its first turn) -- a memory latency per sub-block in the middle of the arithmetic.
+    // `cap`: sections the dynamic LDS has room for (cells, and 256 bytes per section for QLDS).
+    template <int NW, bool CHAIN, bool QLDS>
     __device__ __forceinline__
     void biquad_stream_body(const stream_args *pa, const stream_chain_args *pc, size_t out_stride, size_t in_stride,
                             int n /* multiple of 16 */, const float *__restrict__ tab, float *state,
-                            const uint32_t *__restrict__ nsec, int max_sec)
+                            const uint32_t *__restrict__ nsec, int max_sec, int cap)
     {
         using G = geom<16>;
         constexpr int L = 16, W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK;
         constexpr int LPT = W / 4;
         constexpr int TAB_QL = TAB_PQ + 2 * L;
         __shared__ __attribute__((aligned(16))) float sx_all[NW * 64 * PITCH];
-        __shared__ stream_cell cell[STREAM_SG][NW];
+        extern __shared__ float4 stream_dyn[];              // cells [cap][NW], then (QLDS) the scan operands [cap][16]
+        stream_cell *const cell = reinterpret_cast<stream_cell *>(stream_dyn);
+        const float4 *const sql = stream_dyn + cap * NW;
 
         const int ch  = int(blockIdx.x);
         const int tid = int(threadIdx.x);
@@ -989,12 +997,12 @@ namespace
             for (int j = 0; j < L / 8; ++j)
                 r.pq[j] = *reinterpret_cast<cv16f *>(U + TAB_PQ + 16 * j);
         };
-        auto load_mats = [&](sectab &r, const float *T)
+        auto load_mats = [&](sectab &r, const float *T, int qi /* the section's place among the launch's sections */)
         {
             cfloat *U = uniform_row(T);
             r.m0 = *reinterpret_cast<cv8f *>(U + 8);
             r.m1 = *reinterpret_cast<cv16f *>(U + 16);
-            r.ql = *reinterpret_cast<const float4 *>(T + TAB_QL + 4 * l16);
+            r.ql = QLDS ? sql[qi * 16 + l16] : *reinterpret_cast<const float4 *>(T + TAB_QL + 4 * l16);
         };
         auto load_coefs = [&](sectab &r, const float *T)
         {
@@ -1022,6 +1030,18 @@ namespace
         // those arrive underneath them
         if (wv < total)
             issue_loads(wv);
+        // The rows are waited for at the top of every sub-block, with the stores of the sub-block before issued in between: the
+        // wait may leave those eight stores in flight -- if the compiler's count of what follows the loads is the same on the way
+        // INTO the loop as round it (it settles for the smaller of the two, and on the way in nothing followed the loads: the
+        // wave then waited for its own stores to be acknowledged at the top of every sub-block).  Eight stores into a window of
+        // no bytes behind the first request: dropped by the address check, counted by the compiler.
+        if (QLDS)
+        {
+            const __amdgpu_buffer_rsrc_t none = __builtin_amdgcn_make_buffer_rsrc(state, 0, 0, BUFFER_DWORD3);
+            #pragma unroll
+            for (int q = 0; q < LPT; ++q)
+                store_through(none, 4 * (q * 64 + t), make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+        }
         const int ns  = stage_ns(0);
         if (!CHAIN && ns < 0)                                // row switched off (the chain's rows never are: the host sees to it)
             return;
@@ -1043,7 +1063,13 @@ namespace
                         c.d0 = s.x;
                         c.d1 = s.y;
                     }
-                    cell[lds0 + si][w] = c;
+                    cell[(lds0 + si) * NW + w] = c;
+                }
+                if (QLDS)
+                {
+                    const float *tk = stage_tab(k);
+                    for (int i = tid; i < nk * 16; i += 64 * NW)
+                        stream_dyn[cap * NW + lds0 * 16 + i] = *reinterpret_cast<const float4 *>(tk + size_t(i >> 4) * TAB + TAB_QL + 4 * (i & 15));
                 }
                 lds0 += nk;
             }
@@ -1055,7 +1081,7 @@ namespace
         if (CHAIN || ns > 0)
         {
             load_pq(tb, ctab);
-            load_mats(tb, ctab);
+            load_mats(tb, ctab, 0);
             load_coefs(tb, ctab);
         }
         MI_STREAM_PROBE_BEGIN();
@@ -1098,7 +1124,7 @@ namespace
 
             // One section over the sub-block: `tb` holds its table on entry and the table at Tnext on exit; ci: its hand-over
             // cell; mem2: where its state goes at the end of the launch; turn: what the issue priority goes round with.
-            auto section = [&](const float *Tnext, int ci, float2 *mem2, int turn)
+            auto section = [&](const float *Tnext, int qnext, int ci, float2 *mem2, int turn)
             {
 #if MI_STREAM_ROTATE
                 // The instruction arbiter of a SIMD serves its OLDEST wave first: of the four workgroups that share a CU --
@@ -1119,8 +1145,8 @@ namespace
                         default: __builtin_amdgcn_s_setprio(0); break;
                     }
 #endif
-                lds_cell *const from = (lds_cell *)&cell[ci][pred];
-                lds_cell *const to   = (lds_cell *)&cell[ci][wv];
+                lds_cell *const from = (lds_cell *)&cell[ci * NW + pred];
+                lds_cell *const to   = (lds_cell *)&cell[ci * NW + wv];
                 // asked for now, looked at after the dot products
                 uint32_t got = from->seq;
                 float c0 = from->d0, c1 = from->d1;
@@ -1178,7 +1204,7 @@ namespace
                 v2f d0 = v2f{S.x, SB2.x}, d1 = v2f{S.y, SB2.y};
                 __builtin_amdgcn_sched_barrier(0);
                 load_pq(tb, Tnext);
-                load_mats(tb, Tnext);
+                load_mats(tb, Tnext, qnext);
                 __builtin_amdgcn_sched_barrier(0);
 
                 const v2f b0 = splat(tb.cf.x), b1 = splat(tb.cf.y), b2 = splat(tb.cf.z), a1 = splat(tb.cf.w), a2 = splat(tb.a2);
@@ -1229,7 +1255,10 @@ namespace
             if constexpr (!CHAIN)
             {
                 for (int si = 0; si < ns; ++si)
-                    section(ctab + size_t((si + 1 < ns) ? si + 1 : 0) * TAB, si, mem0 + si, si);
+                {
+                    const int snext = (si + 1 < ns) ? si + 1 : 0;
+                    section(ctab + size_t(snext) * TAB, snext, si, mem0 + si, si);
+                }
                 MI_STREAM_PROBE(2);
                 store_tile(pa->out[k]);
             }
@@ -1252,7 +1281,7 @@ namespace
                 // the two never at the same time -- the rows are asked for in front of the LAST stage (which the host sends
                 // as an in-place one: the Crossover's last high-pass), whose sections cover the latency of memory, so the
                 // kernel stays within the 128 registers of four waves per SIMD.
-                auto run_stage = [&](auto may_branch, const stage_info &cur, const float *Tn, int lds0)
+                auto run_stage = [&](auto may_branch, const stage_info &cur, const float *Tn, int lds0, int qn /* Tn's place */)
                 {
                     constexpr bool BR = decltype(may_branch)::value;
                     v2f xs[L];                               // the travelling signal while a branch is computed
@@ -1263,7 +1292,8 @@ namespace
                             xs[i] = x[i];
                     }
                     for (int si = 0; si < cur.ns; ++si)
-                        section((si + 1 < cur.ns) ? cur.T + size_t(si + 1) * TAB : Tn, lds0 + si, cur.mem2 + si, lds0 + si);
+                        section((si + 1 < cur.ns) ? cur.T + size_t(si + 1) * TAB : Tn, (si + 1 < cur.ns) ? lds0 + si + 1 : qn,
+                                lds0 + si, cur.mem2 + si, lds0 + si);
                     if (cur.slot >= 0)
                         store_tile(pc->out[k * pc->outs + cur.slot]);
                     if (BR && cur.branch)
@@ -1278,7 +1308,7 @@ namespace
                 for (int q = 0; q + 1 < nst; ++q)
                 {
                     const stage_info nxt = fetch(q + 1);
-                    run_stage(std::true_type(), cur, nxt.T, lds0);
+                    run_stage(std::true_type(), cur, nxt.T, lds0, lds0 + cur.ns);
                     lds0 += cur.ns;
                     cur = nxt;
                 }
@@ -1288,7 +1318,7 @@ namespace
                     const bool more = g + NW < total;
                     issue_loads(more ? g + NW : g, more);
                 }
-                run_stage(std::false_type(), cur, ctab, lds0);
+                run_stage(std::false_type(), cur, ctab, lds0, 0);
                 MI_STREAM_PROBE(2);
             }
             MI_STREAM_PROBE(3);
@@ -1297,21 +1327,27 @@ namespace
         MI_STREAM_PROBE_END();
     }
 
-    template <int NW>
+    template <int NW, bool QLDS>
     __global__ __launch_bounds__(64 * NW, (NW >= 4) ? 4 : 2)
     void biquad_stream_kernel(const stream_args a, size_t out_stride, size_t in_stride, int n /* multiple of 16 */,
-                              const float *__restrict__ tab, float *state, const uint32_t *__restrict__ nsec, int max_sec)
+                              const float *__restrict__ tab, float *state, const uint32_t *__restrict__ nsec, int max_sec, int cap)
     {
-        biquad_stream_body<NW, false>(&a, nullptr, out_stride, in_stride, n, tab, state, nsec, max_sec);
+        biquad_stream_body<NW, false, QLDS>(&a, nullptr, out_stride, in_stride, n, tab, state, nsec, max_sec, cap);
     }
 
     // the chain on a run of blocks
-    template <int NW>
+    template <int NW, bool QLDS>
     __global__ __launch_bounds__(64 * NW, 4)
-    void biquad_stream_chain_kernel(const stream_chain_args c, size_t out_stride, size_t in_stride, int n /* multiple of 16 */)
+    void biquad_stream_chain_kernel(const stream_chain_args c, size_t out_stride, size_t in_stride, int n /* multiple of 16 */, int cap)
     {
-        biquad_stream_body<NW, true>(nullptr, &c, out_stride, in_stride, n, nullptr, nullptr, nullptr, 0);
+        biquad_stream_body<NW, true, QLDS>(nullptr, &c, out_stride, in_stride, n, nullptr, nullptr, nullptr, 0, cap);
     }
+
+    // Dynamic LDS of a stream launch: a cell per (section, wave), and with the scan operands in LDS 256 bytes per section more.
+    // The operands go to LDS as long as four workgroups of four waves still share a CU's 160 KiB with them (the tiles take
+    // 36 KiB per workgroup): up to twelve sections.
+    inline bool stream_qlds(int nw, int cap) { return size_t(nw) * 64 * geom<16>::PITCH * 4 + size_t(cap) * (nw + 16) * 16 <= 40960; }
+    inline size_t stream_lds(int nw, int cap, bool qlds) { return size_t(cap) * (nw + (qlds ? 16 : 0)) * 16; }
 
     // The last samples % L samples of a call: one thread per channel walks them through the cascade with the same
     // recurrence (FilterBank.cpp:256-291 semantics for block sizes that are not a multiple of the chunk length).
@@ -1740,6 +1776,7 @@ namespace mi
         for (int k = 0; k < count; ++k)
             if (stages[k].bank == nullptr || stages[k].bank->channels != channels || slot[k] >= outs)
                 return 1;
+        int sec_cap = 1;
         for (uint32_t c = 0; c < channels; ++c)
         {
             size_t total = 0;
@@ -1751,6 +1788,7 @@ namespace mi
             }
             if (total > size_t(STREAM_SG))
                 return 1;
+            sec_cap = std::max(sec_cap, int(total));
         }
         for (size_t i = 0; i < blocks; ++i)
         {
@@ -1826,10 +1864,15 @@ namespace mi
                 }
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 take_profile_events(&ev0, &ev1);
-                if (n * spb >= 4)
-                    MI_LAUNCH((biquad_stream_chain_kernel<4>), dim3(channels), dim3(256), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples));
-                else
-                    MI_LAUNCH((biquad_stream_chain_kernel<2>), dim3(channels), dim3(128), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples));
+                const int nw = (n * spb >= 4) ? 4 : 2;
+                static const bool ql_global = getenv("MI_BIQUAD_QL_GLOBAL") != nullptr;
+                const bool qlds = !ql_global && stream_qlds(nw, sec_cap);
+                const size_t lds = stream_lds(nw, sec_cap, qlds);
+                #define MI_STREAM(NWV, Q) MI_LAUNCH((biquad_stream_chain_kernel<NWV, Q>), dim3(channels), dim3(64 * NWV), lds, st, ev0, ev1, a, \
+                                                    out_stride, in_stride, int(samples), sec_cap)
+                if (nw == 4) { if (qlds) MI_STREAM(4, true); else MI_STREAM(4, false); }
+                else         { if (qlds) MI_STREAM(2, true); else MI_STREAM(2, false); }
+                #undef MI_STREAM
                 MI_HIP_CHECK(hipGetLastError());
             }
             else
@@ -2179,15 +2222,18 @@ static int stream_launch(mi_biquad_bank_t *b, float *const *out, const float *co
     const dim3 grid(b->channels);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mi::take_profile_events(&ev0, &ev1);
-    if (nw == 4)
-        MI_LAUNCH((biquad_stream_kernel<4>), grid, dim3(256), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples), b->d_big,
-                  b->d_state, b->d_nsec, int(b->max_sec));
-    else if (nw == 2)
-        MI_LAUNCH((biquad_stream_kernel<2>), grid, dim3(128), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples), b->d_big,
-                  b->d_state, b->d_nsec, int(b->max_sec));
-    else
-        MI_LAUNCH((biquad_stream_kernel<1>), grid, dim3(64), 0, st, ev0, ev1, a, out_stride, in_stride, int(samples), b->d_big,
-                  b->d_state, b->d_nsec, int(b->max_sec));
+    int cap = 1;                                            // sections the launch's cells (and scan operands) must hold
+    for (uint32_t c = 0; c < b->channels; ++c)
+        cap = std::max(cap, int(b->nsec[c]));
+    static const bool ql_global = getenv("MI_BIQUAD_QL_GLOBAL") != nullptr;     // experiment knob: the scan operand from the table
+    const bool qlds = !ql_global && stream_qlds(nw, cap);
+    const size_t lds = stream_lds(nw, cap, qlds);
+    #define MI_STREAM(NWV, Q) MI_LAUNCH((biquad_stream_kernel<NWV, Q>), grid, dim3(64 * NWV), lds, st, ev0, ev1, a, out_stride, in_stride, \
+                                        int(samples), b->d_big, b->d_state, b->d_nsec, int(b->max_sec), cap)
+    if (nw == 4)      { if (qlds) MI_STREAM(4, true); else MI_STREAM(4, false); }
+    else if (nw == 2) { if (qlds) MI_STREAM(2, true); else MI_STREAM(2, false); }
+    else              { if (qlds) MI_STREAM(1, true); else MI_STREAM(1, false); }
+    #undef MI_STREAM
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
