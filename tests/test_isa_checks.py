@@ -176,7 +176,7 @@ def test_no_kernel_parks_data_in_scratch(tmp_path):
 @pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
 def test_biquad_kernels_in_the_compilers_output(tmp_path):
     """Three properties of biquad.hip that only the generated code shows:
-    * biquad_stream_kernel<4> (the headline launch) fits four waves per SIMD (at most 128 VGPRs), touches its hand-over cells
+    * biquad_stream_kernel<4, true> (the headline launch) fits four waves per SIMD (at most 128 VGPRs), touches its hand-over cells
       with DS instructions (not flat ones: the cells are addressed through an LDS-qualified pointer) and forms its register
       pairs without the 64 moves per sub-block the padded tile cost (the interleaved tile: a 16-byte LDS read IS two pairs);
     * biquad_reference_ir_kernel (the impulse response the Equalizer's FIR is synthesised from) contains no fused
@@ -186,14 +186,28 @@ def test_biquad_kernels_in_the_compilers_output(tmp_path):
     lines = _isa(os.path.join(CSRC, "biquad.hip"), tmp_path)
     text = "\n".join(lines)
     meta = {re.search(r"\.name: *(\S+)", b).group(1): b for b in text[text.index("amdhsa.kernels:"):].split("  - .agpr_count:")[1:]}
-    stream4 = [n for n in meta if "biquad_stream_kernelILi4E" in n]
+    # <4, true>: four waves per channel, the scan's per-lane operand in LDS (the form the C2 launch takes)
+    stream4 = [n for n in meta if "biquad_stream_kernelILi4ELb1E" in n]
     assert len(stream4) == 1, sorted(meta)
     assert int(re.search(r"\.vgpr_count: *(\d+)", meta[stream4[0]]).group(1)) <= 128
-    body = _kernel_bodies(lines, "biquad_stream_kernelILi4E")[stream4[0]]
+    body = _kernel_bodies(lines, "biquad_stream_kernelILi4ELb1E")[stream4[0]]
     ops = [l.split()[0] for l in body if l.strip() and not l.strip().startswith((";", "."))]
     assert not any(o.startswith(("flat_", "scratch_")) for o in ops)
     assert sum(1 for o in ops if o == "ds_read_b32") >= 3 and sum(1 for o in ops if o == "ds_read2_b32") >= 8
     assert sum(1 for o in ops if o == "v_mov_b32_e32") <= 48, sum(1 for o in ops if o == "v_mov_b32_e32")
+    # no vector-memory wait inside the sections (behind the hand-over's s_sleep), and the wait for the rows at the top of a
+    # sub-block leaves the eight stores behind them in flight: vmcnt(15) .. vmcnt(8)
+    stripped = [l.strip() for l in body]
+    sleep_at = stripped.index("s_sleep 1")
+    waits = [(i, int(re.search(r"vmcnt\((\d+)\)", l).group(1))) for i, l in enumerate(stripped) if l.startswith("s_waitcnt") and "vmcnt" in l]
+    assert not [w for w in waits if w[0] > sleep_at], waits
+    assert [w[1] for w in waits][-8:] == list(range(15, 7, -1)), waits
+    # the chain on a run of blocks: four waves per SIMD as well (the branch's copy and the prefetched rows never alive together)
+    chain4 = [n for n in meta if "biquad_stream_chain_kernelILi4E" in n]
+    assert len(chain4) == 2, sorted(meta)
+    for n in chain4:
+        assert int(re.search(r"\.vgpr_count: *(\d+)", meta[n]).group(1)) <= 128, n
+        assert int(re.search(r"\.private_segment_fixed_size: *(\d+)", meta[n]).group(1)) == 0, n
     for name, b in _kernel_bodies(lines, "biquad_reference_ir_kernel").items():
         o2 = [l.split()[0] for l in b if l.strip() and not l.strip().startswith((";", "."))]
         assert not any(o.startswith(("v_fma", "v_fmac", "v_mac_f", "v_pk_fma", "v_mad_f", "v_mad_legacy", "v_mad_mix")) for o in o2), name
