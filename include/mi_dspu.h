@@ -353,6 +353,13 @@ int mi_convolver_bank_info(const mi_convolver_bank_t *bank, uint32_t *rank, uint
  */
 int mi_convolver_bank_process(mi_convolver_bank_t *bank, float *out, const float *in, size_t samples,
                               size_t out_stride, size_t in_stride, void *stream);
+/*
+ * `blocks` consecutive mi_convolver_bank_process calls in one C call (Convolver.cpp:217-313 per block): block k reads in[k]
+ * and writes out[k] (HOST tables of DEVICE pointers).  Whole frames of a partitioned bank go in batches of up to 16 frames
+ * whose tails come out of ONE pass over the partitions' images; samples and state are those of the calls one by one.
+ */
+int mi_convolver_bank_process_blocks(mi_convolver_bank_t *bank, float *const *out, const float *const *in, size_t blocks,
+                                     size_t samples, size_t out_stride, size_t in_stride, void *stream);
 
 /* ---- windows and spectral envelopes (host side) ---------------------------------------- */
 /* windows::window_t with the same enumerator values (include/lsp-plug.in/dsp-units/misc/windows.h:34-62). */

@@ -100,6 +100,7 @@ PROTOTYPES = {
     "mi_convolver_bank_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32),
                                        POINTER(c_uint32)]),
     "mi_convolver_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_convolver_bank_process_blocks": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_window": (c_int, [c_void_p, c_size_t, c_int]),
     "mi_window_general": (c_int, [c_void_p, c_size_t, c_int, c_void_p, c_uint32]),
     "mi_envelope_reverse_noise_lin": (c_int, [c_void_p, c_float, c_float, c_float, c_size_t, c_int]),

@@ -452,6 +452,239 @@ namespace
         }
     }
 
+    // ---- K whole frames of a partitioned bank in ONE call (mi_convolver_bank_process_blocks) ------------------------------------
+    // A frame per launch streams, frame after frame, all partitions' images and the whole ring (272 B per channel-sample at
+    // C3): every H_p is read once per frame.  With K frames in hand the tails of all of them come out of ONE pass over the
+    // partitions -- a thread owns a pair of bins, keeps the K sums and a window of K frames' values of that pair in registers
+    // and takes the partitions in the order the tail role of conv_step_kernel takes them (p = 2 .. P - 1, then p = 1), so every
+    // sum goes through the same additions in the same order: the same floats as K one-launch steps.  Three launches:
+    //   conv_batch_forward_kernel   the K frames' images (forward transform + split, as frame_role does it) -> staging
+    //   conv_batch_tail_kernel<K>   Yt_f = sum_{p >= 1} H_p X_(f + 1 - p) for the K frames: H once, the ring's and the staged
+    //                               images once (2 K + 2 P loads of 16 bytes per thread instead of 2 K (P - 1))
+    //   conv_batch_frames_kernel    per channel, frame after frame: image times H_0 plus the tail owed to it, merge, inverse,
+    //                               overlap-add, emission; the image enters the ring; the accumulator stays in registers
+    constexpr int BATCH_MAX = 16;
+    struct batch_args
+    {
+        int             frames;
+        float          *out[BATCH_MAX];
+        const float    *in[BATCH_MAX];
+    };
+
+    template <int LOGM>
+    __global__ __launch_bounds__(fplan<LOGM>::T)
+    void conv_batch_forward_kernel(const batch_args ba, size_t in_stride, bool aligned, float2 *xs /* [channels][frames][M] */,
+                                   const float2 *__restrict__ tw)
+    {
+        using PL = fplan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T, NPT = KPT / 2;
+        static_assert(!PL::radix16 && mi_fft::plan<LOGM>::T == mi_fft::plan<LOGM>::TB, "register hand-over of the transforms (512 .. 8192 points)");
+        __shared__ float2 lds_[PL::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + PL::SCR;
+        const int ch = blockIdx.x, f = blockIdx.y, tid = threadIdx.x;
+        typename PL::real rf;
+        rf.load(tw, TWN, tid);
+        const float *x = ba.in[f] + size_t(ch) * in_stride;
+        v2f io[KPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+        {
+            const int n = tid + i * T;                      // B samples, zero-padded to 2 B
+            const float2 v = (n >= B / 2) ? make_float2(0.0f, 0.0f)
+                           : aligned ? *reinterpret_cast<const float2 *>(x + 2 * n) : make_float2(x[2 * n], x[2 * n + 1]);
+            io[i] = v2f{v.x, v.y};
+        }
+        rf.prepare();
+        mi_fft::fft_lds<LOGM, false, true, false>(buf, scr, rf.ft, tid, io);
+        mi_fft::real_split<LOGM>(buf, rf.rt, tid);
+        float2 *dst = xs + (size_t(ch) * ba.frames + f) * M;
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)                       // (the pairs this thread split itself)
+        {
+            const int k0 = tid + (i % NPT) * T;
+            const int k = (i < NPT) ? k0 : (k0 == 0) ? M / 2 : M - k0;
+            dst[k] = buf[k];
+        }
+    }
+
+    template <int K>
+    __global__ __launch_bounds__(256)
+    void conv_batch_tail_kernel(float2 *yts /* [channels][K][M] */,
+                                const float2 *__restrict__ xs /* [channels][K][M] */, const float2 *__restrict__ ring, int R, int slot0,
+                                const float2 *__restrict__ H, int P, int M)
+    {
+        typedef float f4 __attribute__((ext_vector_type(4)));
+        const int ch = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x, M4 = M / 2;      // (M4 is a multiple of 256: M >= 512)
+        const f4 *Hc = reinterpret_cast<const f4 *>(H + size_t(ch) * P * M);
+        const f4 *Xr = reinterpret_cast<const f4 *>(ring + size_t(ch) * R * M);
+        const f4 *Xs = reinterpret_cast<const f4 *>(xs + size_t(ch) * K * M);
+        // frame m of the call (m >= 0: staged) or before it (m < 0: frame -1 sits in ring slot slot0, -2 in the one before, ...)
+        auto image = [&](int m) -> const f4 * {
+            if (m >= 0)
+                return Xs + size_t(m) * M4;
+            int r = (slot0 + 1 + m) % R;
+            r = (r < 0) ? r + R : r;
+            return Xr + size_t(r) * M4;
+        };
+        auto mac = [](f4 &s, const f4 h, const f4 x)        // the tail role's sums, term for term
+        {
+            s.z = fmaf(x.z, h.z, fmaf(-x.w, h.w, s.z));
+            s.w = fmaf(x.z, h.w, fmaf(x.w, h.z, s.w));
+            s.x = fmaf(x.x, h.x, fmaf(-x.y, h.y, s.x));
+            s.y = fmaf(x.x, h.y, fmaf(x.y, h.x, s.y));
+        };
+        f4 s[K], xw[K];
+        // the window for p = 2: frames f - 1, f = 0 .. K - 1; frame m lives in register m mod K throughout
+        #pragma unroll
+        for (int f = 0; f < K; ++f)
+        {
+            s[f] = f4{0.0f, 0.0f, 0.0f, 0.0f};
+            xw[(f - 1 + K) % K] = image(f - 1)[idx];
+        }
+        int p = 2;
+        while (p < P)
+        {
+            #pragma unroll
+            for (int u = 0; u < K; ++u)                     // p = 2 + c K + u: frame f + 1 - p sits in register (f - 1 - u) mod K
+            {
+                if (p < P)
+                {
+                    const f4 h = Hc[size_t(p) * M4 + idx];
+                    f4 xn = f4{0.0f, 0.0f, 0.0f, 0.0f};
+                    if (p + 1 < P)
+                        xn = image(-p)[idx];                // what the window takes in for p + 1 (frame -p), in place of frame K - p
+                    #pragma unroll
+                    for (int f = 0; f < K; ++f)
+                        mac(s[f], h, xw[(f - 1 - u + 2 * K) % K]);
+                    xw[(2 * K - 2 - u) % K] = xn;
+                    ++p;
+                }
+            }
+        }
+        // p = 1 last: the frames' own images
+        {
+            const f4 h1 = Hc[size_t(1) * M4 + idx];
+            #pragma unroll
+            for (int f = 0; f < K; ++f)
+                mac(s[f], h1, Xs[size_t(f) * M4 + idx]);
+        }
+        #pragma unroll
+        for (int f = 0; f < K; ++f)
+        {
+            f4 *dst = reinterpret_cast<f4 *>(yts + (size_t(ch) * K + f) * M);
+            dst[idx] = s[f];
+        }
+        // bin 0 packs (DC, Nyquist): two real products instead of a complex one -- lane f of the first workgroup redoes the
+        // first pair's first bin of frame f (the same chain of multiply-adds as the tail role's dc / ny)
+        if (blockIdx.x != 0)
+            return;
+        __syncthreads();
+        if (threadIdx.x < K)
+        {
+            const int f = threadIdx.x;
+            float dc = 0.0f, ny = 0.0f;
+            for (int q = 2; q < P; ++q)
+            {
+                const f4 h = Hc[size_t(q) * M4], x = image(f + 1 - q)[0];
+                dc = fmaf(x.x, h.x, dc);
+                ny = fmaf(x.y, h.y, ny);
+            }
+            const f4 h = Hc[size_t(1) * M4], x = Xs[size_t(f) * M4];
+            dc = fmaf(x.x, h.x, dc);
+            ny = fmaf(x.y, h.y, ny);
+            float2 *dst = yts + (size_t(ch) * K + f) * M;
+            dst[0] = make_float2(dc, ny);
+        }
+    }
+
+    template <int LOGM>
+    __global__ __launch_bounds__(fplan<LOGM>::T)
+    void conv_batch_frames_kernel(const batch_args ba, size_t out_stride, bool aligned, const float2 *__restrict__ xs,
+                                  const float2 *__restrict__ yts, const float2 *yt0 /* the tail pending before the call, or NULL */,
+                                  float2 *yt_out /* the tail pending after it: Yt of the last frame (may be the buffer yt0 points into) */,
+                                  float2 *ring, int R, int slot0, const float2 *__restrict__ H, int P, float *acc,
+                                  const float2 *__restrict__ tw, bool upper_zero)
+    {
+        using PL = fplan<LOGM>;
+        constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T, NPT = KPT / 2;
+        static_assert(!PL::radix16 && mi_fft::plan<LOGM>::T == mi_fft::plan<LOGM>::TB, "register hand-over of the transforms (512 .. 8192 points)");
+        __shared__ float2 lds_[PL::LDS];
+        float2 *const buf = lds_, *const scr = lds_ + PL::SCR;
+        const int ch = blockIdx.x, tid = threadIdx.x, K = ba.frames;
+        typename PL::real rf;
+        rf.load(tw, TWN, tid);
+        float *const a = acc + size_t(ch) * 2 * B;
+        const float2 *const h0 = H + size_t(ch) * P * M;
+        auto bin_of = [&](int i) -> int {
+            const int k = tid + (i % NPT) * T;
+            return (i < NPT) ? k : (k == 0) ? M / 2 : M - k;
+        };
+        float2 hreg[KPT], a0[NPT], a1[NPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            hreg[i] = h0[bin_of(i)];
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            a0[i] = *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T));
+            a1[i] = upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
+        }
+        rf.prepare();
+        const float scale = 1.0f / float(2 * M);
+        for (int f = 0; f < K; ++f)
+        {
+            const float2 *X = xs + (size_t(ch) * K + f) * M;
+            const float2 *yt = (f == 0) ? ((yt0 != nullptr) ? yt0 + size_t(ch) * M : nullptr) : yts + (size_t(ch) * K + f - 1) * M;
+            float2 *rdst = ring + (size_t(ch) * R + (slot0 + 1 + f) % R) * M;
+            // bin k of the image: into the ring, times the head partition's, plus the tail owed to this frame (frame_role's `through`)
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = bin_of(i);
+                const float2 xk = X[k];
+                const float2 yk = (yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f);
+                rdst[k] = xk;
+                buf[k] = cadd(image_mul(xk, hreg[i], k), yk);
+            }
+            __syncthreads();
+            mi_fft::real_merge<LOGM>(buf, rf.rt, tid);
+            v2f io[KPT];
+            mi_fft::fft_lds<LOGM, true, false, true>(buf, scr, rf.ft, tid, io);
+            float *o = ba.out[f] + size_t(ch) * out_stride;
+            const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, unsigned(B * sizeof(float)));
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+            {
+                const int n = tid + i * T;
+                const float2 r = make_float2(fmaf(io[i].x, scale, a0[i].x), fmaf(io[i].y, scale, a0[i].y));
+                if (aligned)
+                    mi::wt_store(rout, 8 * n, r);
+                else
+                {
+                    mi::wt_store(rout, 8 * n, r.x);
+                    mi::wt_store(rout, 8 * n + 4, r.y);
+                }
+                a0[i] = make_float2(fmaf(io[i + NPT].x, scale, a1[i].x), fmaf(io[i + NPT].y, scale, a1[i].y));
+                a1[i] = make_float2(0.0f, 0.0f);
+            }
+            __syncthreads();                                // the transforms' buffers are free for the next frame
+        }
+        const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(a, unsigned(2 * B * sizeof(float)));
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            const int n = tid + i * T;
+            mi::wt_store(racc, 8 * n, a0[i]);
+            if (!upper_zero)
+                mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
+        }
+        // the tail the last frame owes the next call (this workgroup was the only reader of the channel's pending one)
+        const float2 *last = yts + (size_t(ch) * K + K - 1) * M;
+        float2 *ytl = yt_out + size_t(ch) * M;
+        for (int k = tid; k < M; k += T)
+            ytl[k] = last[k];
+    }
+
     // ---- whole frame AND the tail owed to the next one, in one launch (P >= 2) ------------------------------------------
     // Workgroups 0 .. C-1 are the frame role above (latency bound: load, two transforms, store); workgroups C .. 2C-1
     // stream the channel's tail  Yt' = sum_{p>=1} H_p X_(k+1-p)  (bandwidth bound: H and the ring once) at the same
@@ -1222,6 +1455,7 @@ struct mi_convolver_bank
     bool        one_launch = true;  // whole-frame steps as conv_step_kernel (gfx950, not switched off) or as two launches
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
+    float2     *d_xs = nullptr, *d_yts = nullptr;       // [channels][BATCH_MAX][B]: images and tails of a batch of frames (process_blocks)
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
     // way a reference Equalizer object does (Equalizer.cpp:339-345,481-501): every object has a response in force (vConv),
     // a cross-fade target (vNewConv) and a flag that the target waits for the block that completes next (EF_XFADE).
@@ -1345,6 +1579,51 @@ namespace
         MI_HIP_CHECK(hipGetLastError());
         b->yt_pending = false;
         b->upper_zero = false;
+        return MI_OK;
+    }
+
+    // K whole frames (2 <= K <= BATCH_MAX, a power of two) of a partitioned bank at a frame boundary: three launches
+    int launch_batch(mi_convolver_bank *b, float *const *out, const float *const *in, int K, size_t out_stride, size_t in_stride,
+                     hipStream_t st)
+    {
+        const size_t cells = size_t(b->channels) * BATCH_MAX * size_t(b->B);
+        if (b->d_xs == nullptr)
+        {
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_xs), cells * sizeof(float2)));
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_yts), cells * sizeof(float2)));
+        }
+        batch_args ba;
+        ba.frames = K;
+        bool aligned = (out_stride % 2 == 0) && (in_stride % 2 == 0);
+        for (int k = 0; k < K; ++k)
+        {
+            ba.out[k] = out[k];
+            ba.in[k] = in[k];
+            aligned = aligned && ((reinterpret_cast<uintptr_t>(out[k]) | reinterpret_cast<uintptr_t>(in[k])) % 8 == 0);
+        }
+        const int M = b->B;
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_forward_kernel<LM>), dim3(b->channels, K), dim3(fplan<LM>::T), 0, st, \
+                                               ba, in_stride, aligned, b->d_xs, b->d_tw)
+        switch (b->logm) { case 9: { MI_CALL(9); break; } case 10: { MI_CALL(10); break; } case 11: { MI_CALL(11); break; } default: { MI_CALL(12); break; } }
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);                // the pass over the partitions is what the batch is about
+        const dim3 tgrid(M / 2 / 256, b->channels);
+        #define MI_TAIL(KK) MI_LAUNCH((conv_batch_tail_kernel<KK>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_xs, b->d_ring, \
+                                      b->R, b->slot, b->d_H, b->P, M)
+        switch (K) { case 2: { MI_TAIL(2); break; } case 4: { MI_TAIL(4); break; } case 8: { MI_TAIL(8); break; } default: { MI_TAIL(16); break; } }
+        #undef MI_TAIL
+        MI_HIP_CHECK(hipGetLastError());
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_frames_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
+                                               ba, out_stride, aligned, b->d_xs, b->d_yts, b->yt_pending ? b->d_yt : nullptr, b->d_yt, b->d_ring, b->R, \
+                                               b->slot, b->d_H, b->P, b->d_acc, b->d_tw, b->upper_zero)
+        switch (b->logm) { case 9: { MI_CALL(9); break; } case 10: { MI_CALL(10); break; } case 11: { MI_CALL(11); break; } default: { MI_CALL(12); break; } }
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        b->slot = (b->slot + K) % b->R;
+        b->yt_pending = true;
+        b->upper_zero = true;
         return MI_OK;
     }
 } // namespace
@@ -1779,6 +2058,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
+    (void)hipFree(b->d_xs); (void)hipFree(b->d_yts);
     const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
     (void)hipHostFree(b->h_fault);
     delete b;
@@ -2011,6 +2291,72 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 b->frame_open = false;
             }
         }
+    }
+    return MI_OK;
+}
+
+// `blocks` consecutive process() calls in one C call.  Whole frames of a partitioned bank at a frame boundary go in batches of
+// 16 / 8 / 4 / 2 frames (launch_batch: every partition's image is read once per batch instead of once per frame) -- the samples
+// and the state left behind are those of the calls one by one (the one-launch frame step's, sum for sum).  Anything else
+// (other block sizes, single-partition banks, a cross-fade under way, a block that reads what an earlier block of the call
+// writes, captures) is what it says: a loop of process() calls.
+int mi_convolver_bank_process_blocks(mi_convolver_bank_t *b, float *const *out, const float *const *in, size_t blocks, size_t samples,
+                                     size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_convolver_bank_process_blocks: NULL bank");
+    if (samples == 0 || blocks == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_convolver_bank_process_blocks: NULL pointer table");
+    for (size_t k = 0; k < blocks; ++k)
+        MI_REQUIRE(out[k] != nullptr && in[k] != nullptr, MI_EINVAL, "mi_convolver_bank_process_blocks: NULL buffer of block %zu", k);
+    MI_REQUIRE(out_stride >= samples && in_stride >= samples, MI_EINVAL, "mi_convolver_bank_process_blocks: stride shorter than the block");
+    hipStream_t st = mi::as_stream(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+    static const bool per_frame = getenv("MI_CONV_FRAME_PER_LAUNCH") != nullptr;        // test knob: the loop of calls
+    const size_t ob = (size_t(b->channels - 1) * out_stride + samples) * sizeof(float), ib = (size_t(b->channels - 1) * in_stride + samples) * sizeof(float);
+    auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
+        const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+        return a0 < b0 + qn && b0 < a0 + pn;
+    };
+    size_t k = 0;
+    while (k < blocks)
+    {
+        size_t run = 0;
+        const bool batchable = b->live && b->P >= 2 && b->R >= 1 && samples == size_t(b->B) && b->off == 0 && !b->frame_open &&
+                               !b->xfade_active && !b->xf_any && b->logm >= 9 && b->logm <= 12 && !capturing && !per_frame &&
+                               (b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u);
+        if (batchable)
+        {
+            // the frames of a batch are all read before any of them is written: a block joins unless it reads what an earlier
+            // block of the batch writes (its own output may be its input)
+            run = 1;
+            while (k + run < blocks && run < size_t(BATCH_MAX))
+            {
+                bool ok = true;
+                for (size_t i = k; ok && i < k + run; ++i)
+                    ok = !overlap(out[i], ob, in[k + run], ib);
+                if (!ok)
+                    break;
+                ++run;
+            }
+            size_t K = 1;
+            while (2 * K <= run)
+                K *= 2;
+            run = K;
+        }
+        if (run >= 2)
+        {
+            const int r = launch_batch(b, out + k, in + k, int(run), out_stride, in_stride, st);
+            if (r != MI_OK)
+                return r;
+            k += run;
+            continue;
+        }
+        const int r = mi_convolver_bank_process(b, out[k], in[k], samples, out_stride, in_stride, stream);
+        if (r != MI_OK)
+            return r;
+        ++k;
     }
     return MI_OK;
 }

@@ -195,6 +195,16 @@ class ConvolverBank:
                                             samples if out_stride is None else out_stride,
                                             samples if in_stride is None else in_stride, _stream(stream)))
 
+    def process_blocks(self, outs, inps, samples, out_stride=None, in_stride=None, stream=None):
+        """len(outs) consecutive process() calls issued by one C call (mi_convolver_bank_process_blocks)."""
+        n = len(outs)
+        assert n == len(inps)
+        po = (c_void_p * n)(*[_ptr(b) for b in outs])
+        pi = (c_void_p * n)(*[_ptr(b) for b in inps])
+        check(lib.mi_convolver_bank_process_blocks(self.handle, po, pi, n, samples,
+                                                   samples if out_stride is None else out_stride,
+                                                   samples if in_stride is None else in_stride, _stream(stream)))
+
     def close(self):
         if self.handle:
             lib.mi_convolver_bank_destroy(self.handle)

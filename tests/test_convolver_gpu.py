@@ -441,3 +441,91 @@ def test_sub_frame_calls_whose_rows_overlap_or_lie_apart(gpu, rank, taps):
                 check(y[ch], ref32, exact_conv(x[ch], irs[ch]), "rank %d ch %d" % (rank, ch))
         else:
             assert np.array_equal(y, want), mode
+
+
+@pytest.mark.parametrize("rank,taps,K", [(10, 2500, 16), (10, 2500, 7), (11, 5000, 37), (12, 9000, 4), (13, 20000, 6), (10, 1024, 5), (10, 3 * 512 + 1, 21)])
+def test_process_blocks_batches_of_frames_equal_frame_by_frame(gpu, rank, taps, K):
+    """mi_convolver_bank_process_blocks: whole frames of a partitioned bank in batches of 16 / 8 / 4 / 2 (three launches per
+    batch: the frames' images, ALL their tails in one pass over the partitions, the frames' outputs) against K process() calls on
+    a twin bank -- bit for bit the one-launch frame step's samples, and the ring, the pending tail and the accumulator left behind
+    (further frames through both, one of them in pieces).  Oracle parity of the first and last channel."""
+    rng = np.random.default_rng(1000 * rank + K)
+    C, frame = 5, 1 << (rank - 1)
+    counts = np.array([taps, taps - 7, max(1, taps // 2), taps, frame + 1], np.uint32)
+    irs = (rng.standard_normal((C, taps)) * 0.05).astype(np.float32)
+    x = (rng.standard_normal((K + 4, C, frame)) * 0.25).astype(np.float32)
+    a = gpu.ConvolverBank(irs, rank, counts=counts)
+    b = gpu.ConvolverBank(irs, rank, counts=counts)
+    ins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K + 4)]
+    oa = [gpu.DeviceBuffer((C, frame)) for _ in range(K + 4)]
+    ob = [gpu.DeviceBuffer((C, frame)) for _ in range(K + 4)]
+    a.process(oa[0], ins[0], frame)                          # a frame in front: the ring, the tail and the accumulator are not empty
+    a.process_blocks(oa[1:K + 1], ins[1:K + 1], frame)
+    a.process(oa[K + 1], ins[K + 1], frame)
+    a.process(oa[K + 2], ins[K + 2], 100, frame, frame)      # a frame in pieces on what the batch left
+    half = gpu.DeviceBuffer((C, frame))
+    a.process(half.ptr, ins[K + 2].ptr + 400, frame - 100, frame, frame)
+    a.process(oa[K + 3], ins[K + 3], frame)
+    for k in range(K + 2):
+        b.process(ob[k], ins[k], frame)
+    b.process(ob[K + 2], ins[K + 2], 100, frame, frame)
+    half_b = gpu.DeviceBuffer((C, frame))
+    b.process(half_b.ptr, ins[K + 2].ptr + 400, frame - 100, frame, frame)
+    b.process(ob[K + 3], ins[K + 3], frame)
+    assert a.faults() == 0 and b.faults() == 0
+    for k in list(range(K + 2)) + [K + 3]:
+        np.testing.assert_array_equal(oa[k].download(), ob[k].download(), err_msg="block %d" % k)
+    np.testing.assert_array_equal(oa[K + 2].download()[:, :100], ob[K + 2].download()[:, :100])
+    np.testing.assert_array_equal(half.download()[:, :frame - 100], half_b.download()[:, :frame - 100])
+    y = np.concatenate([oa[k].download() for k in range(K + 2)], axis=1)
+    xs = np.concatenate([x[k] for k in range(K + 2)], axis=1)
+    for ch in (0, C - 1):
+        ir = irs[ch, :counts[ch]]
+        ref32 = oracle.Convolver(ir, rank).process_chunked(xs[ch], frame)
+        check(y[ch], ref32, exact_conv(xs[ch], ir), "rank %d ch %d" % (rank, ch))
+    a.close(); b.close()
+
+
+def test_process_blocks_splits_where_blocks_depend_on_each_other(gpu):
+    """A block that reads what an earlier block of the call writes starts a new batch; blocks in place and output buffers that
+    come round again stay in one; other block sizes and single-partition banks are plain loops of calls."""
+    rng = np.random.default_rng(99)
+    C, rank, taps, K = 3, 10, 2000, 9
+    frame = 1 << (rank - 1)
+    irs = (rng.standard_normal((C, taps)) * 0.05).astype(np.float32)
+    x = (rng.standard_normal((K, C, frame)) * 0.25).astype(np.float32)
+    res = []
+    for blocks_call in (True, False):
+        bank = gpu.ConvolverBank(irs, rank)
+        ins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K)]
+        ring = [gpu.DeviceBuffer((C, frame)) for _ in range(2)]
+        outs = [ring[k % 2] for k in range(K)]
+        outs[2] = ins[2]                                     # in place
+        ins[5] = ring[0]                                     # reads block 4's output
+        outs[7] = gpu.DeviceBuffer((C, frame))
+        got = []
+        if blocks_call:
+            for lo, hi in ((0, 3), (3, 9)):
+                bank.process_blocks(outs[lo:hi], ins[lo:hi], frame)
+                got += [outs[hi - 1].download(), outs[hi - 2].download()]
+            got.append(outs[7].download())
+        else:
+            for k in range(K):
+                bank.process(outs[k], ins[k], frame)
+                if k in (2, 8):
+                    got += [outs[k].download(), outs[k - 1].download()]
+            got.append(outs[7].download())
+        res.append(got)
+        bank.close()
+    for ya, yb in zip(*res):
+        np.testing.assert_array_equal(ya, yb)
+    for rank2, taps2, n in ((10, 300, 512), (10, 2000, 300)):   # one partition; blocks that are not frames
+        a, b = gpu.ConvolverBank(irs[:, :taps2], rank2), gpu.ConvolverBank(irs[:, :taps2], rank2)
+        ins = [gpu.DeviceBuffer.from_host(x[k][:, :n]) for k in range(4)]
+        oa, ob = [gpu.DeviceBuffer((C, n)) for _ in range(4)], [gpu.DeviceBuffer((C, n)) for _ in range(4)]
+        a.process_blocks(oa, ins, n)
+        for k in range(4):
+            b.process(ob[k], ins[k], n)
+        for k in range(4):
+            np.testing.assert_array_equal(oa[k].download(), ob[k].download())
+        a.close(); b.close()
