@@ -597,13 +597,20 @@ namespace
         }
     }
 
+    // The frames' outputs: a channel's K frames are shared out among G workgroups, each walking `per` consecutive frames with the
+    // accumulator in registers and the next frame's operands asked for before the current frame's transforms.  The overlap-add
+    // couples a frame to the one before it only through the upper half of that frame's inverse transform (acc = fma(y1, scale,
+    // 0) once the upper half of the accumulator is zero), so a workgroup whose run starts inside the batch runs the inverse of
+    // the frame before its first one as well and needs no other workgroup.  (One workgroup per channel: 9.6 us per frame, a
+    // chain of memory latencies on 256 workgroups; one per frame: 11.5 us, every image and every tail read twice.)  Nothing
+    // the launch reads is written by it: the accumulator the last frame leaves goes to acc_new, its tail stays in yts, and
+    // conv_batch_finish_kernel files both where the bank keeps them.
     template <int LOGM>
     __global__ __launch_bounds__(fplan<LOGM>::T)
-    void conv_batch_frames_kernel(const batch_args ba, size_t out_stride, bool aligned, const float2 *__restrict__ xs,
-                                  const float2 *__restrict__ yts, const float2 *yt0 /* the tail pending before the call, or NULL */,
-                                  float2 *yt_out /* the tail pending after it: Yt of the last frame (may be the buffer yt0 points into) */,
-                                  float2 *ring, int R, int slot0, const float2 *__restrict__ H, int P, float *acc,
-                                  const float2 *__restrict__ tw, bool upper_zero)
+    void conv_batch_frames_kernel(const batch_args ba, int per, size_t out_stride, bool aligned, const float2 *__restrict__ xs,
+                                  const float2 *__restrict__ yts, const float2 *__restrict__ yt0 /* the tail pending before the call, or NULL */,
+                                  float2 *ring, int R, int slot0, const float2 *__restrict__ H, int P, const float *__restrict__ acc,
+                                  float *acc_new, const float2 *__restrict__ tw, bool upper_zero)
     {
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T, NPT = KPT / 2;
@@ -611,45 +618,77 @@ namespace
         __shared__ float2 lds_[PL::LDS];
         float2 *const buf = lds_, *const scr = lds_ + PL::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x, K = ba.frames;
+        const int f0 = int(blockIdx.y) * per, f1 = (f0 + per < K) ? f0 + per : K;
         typename PL::real rf;
         rf.load(tw, TWN, tid);
-        float *const a = acc + size_t(ch) * 2 * B;
+        const float *const a = acc + size_t(ch) * 2 * B;
         const float2 *const h0 = H + size_t(ch) * P * M;
         auto bin_of = [&](int i) -> int {
             const int k = tid + (i % NPT) * T;
             return (i < NPT) ? k : (k == 0) ? M / 2 : M - k;
         };
-        float2 hreg[KPT], a0[NPT], a1[NPT];
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            hreg[i] = h0[bin_of(i)];
-        #pragma unroll
-        for (int i = 0; i < NPT; ++i)
+        // frame g's image and the tail owed to it, by this thread's bins
+        float2 xr[KPT], yr[KPT];
+        auto fetch = [&](int g)
         {
-            a0[i] = *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T));
-            a1[i] = upper_zero ? make_float2(0.0f, 0.0f) : *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T));
-        }
-        rf.prepare();
-        const float scale = 1.0f / float(2 * M);
-        for (int f = 0; f < K; ++f)
-        {
-            const float2 *X = xs + (size_t(ch) * K + f) * M;
-            const float2 *yt = (f == 0) ? ((yt0 != nullptr) ? yt0 + size_t(ch) * M : nullptr) : yts + (size_t(ch) * K + f - 1) * M;
-            float2 *rdst = ring + (size_t(ch) * R + (slot0 + 1 + f) % R) * M;
-            // bin k of the image: into the ring, times the head partition's, plus the tail owed to this frame (frame_role's `through`)
+            const float2 *X = xs + (size_t(ch) * K + g) * M;
+            const float2 *yt = (g == 0) ? ((yt0 != nullptr) ? yt0 + size_t(ch) * M : nullptr) : yts + (size_t(ch) * K + g - 1) * M;
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
             {
                 const int k = bin_of(i);
-                const float2 xk = X[k];
-                const float2 yk = (yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f);
-                rdst[k] = xk;
-                buf[k] = cadd(image_mul(xk, hreg[i], k), yk);
+                xr[i] = X[k];
+                yr[i] = (yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f);
             }
+        };
+        fetch((f0 > 0) ? f0 - 1 : 0);
+        float2 hreg[KPT], a0[NPT], a1[NPT];
+        #pragma unroll
+        for (int i = 0; i < KPT; ++i)
+            hreg[i] = h0[bin_of(i)];
+        // what the accumulator held before the call concerns frames 0 (both halves) and 1 (the upper half under frame 0's spill)
+        #pragma unroll
+        for (int i = 0; i < NPT; ++i)
+        {
+            a0[i] = (f0 == 0) ? *reinterpret_cast<const float2 *>(a + 2 * (tid + i * T)) : make_float2(0.0f, 0.0f);
+            a1[i] = (f0 <= 1 && !upper_zero) ? *reinterpret_cast<const float2 *>(a + B + 2 * (tid + i * T)) : make_float2(0.0f, 0.0f);
+        }
+        rf.prepare();
+        const float scale = 1.0f / float(2 * M);
+        v2f io[KPT];
+        // the fetched frame: bin k of its image times the head partition's, plus the tail owed to it (frame_role's `through`), merged
+        // and through the inverse transform: io = the frame's 2 B samples (times 2 M).  `next`: the frame to fetch meanwhile.
+        auto inverse = [&](float2 *file /* the frame's ring slot, or NULL */, int next)
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+            {
+                const int k = bin_of(i);
+                if (file != nullptr)
+                    file[k] = xr[i];                        // the frame's image enters the ring
+                buf[k] = cadd(image_mul(xr[i], hreg[i], k), yr[i]);
+            }
+            if (next >= 0)
+                fetch(next);
             __syncthreads();
             mi_fft::real_merge<LOGM>(buf, rf.rt, tid);
-            v2f io[KPT];
             mi_fft::fft_lds<LOGM, true, false, true>(buf, scr, rf.ft, tid, io);
+        };
+        if (f0 > 0)
+        {
+            inverse(nullptr, f0);                           // the frame before the run: its upper half is what the run's first output starts from
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+            {
+                a0[i] = make_float2(fmaf(io[i + NPT].x, scale, a1[i].x), fmaf(io[i + NPT].y, scale, a1[i].y));
+                a1[i] = make_float2(0.0f, 0.0f);
+            }
+            __syncthreads();                                // the transforms' buffers are free again
+        }
+        for (int f = f0; f < f1; ++f)
+        {
+            // (the ring keeps the last R frames: an earlier one's slot belongs to a later one)
+            inverse((f + R >= K) ? ring + (size_t(ch) * R + (slot0 + 1 + f) % R) * M : nullptr, (f + 1 < f1) ? f + 1 : -1);
             float *o = ba.out[f] + size_t(ch) * out_stride;
             const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, unsigned(B * sizeof(float)));
             #pragma unroll
@@ -669,20 +708,29 @@ namespace
             }
             __syncthreads();                                // the transforms' buffers are free for the next frame
         }
-        const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(a, unsigned(2 * B * sizeof(float)));
-        #pragma unroll
-        for (int i = 0; i < NPT; ++i)
+        if (f1 == K)                                        // the last frame's spill: the accumulator after the call
         {
-            const int n = tid + i * T;
-            mi::wt_store(racc, 8 * n, a0[i]);
-            if (!upper_zero)
-                mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
+            const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(acc_new + size_t(ch) * B, unsigned(B * sizeof(float)));
+            #pragma unroll
+            for (int i = 0; i < NPT; ++i)
+                mi::wt_store(racc, 8 * (tid + i * T), a0[i]);
         }
-        // the tail the last frame owes the next call (this workgroup was the only reader of the channel's pending one)
-        const float2 *last = yts + (size_t(ch) * K + K - 1) * M;
-        float2 *ytl = yt_out + size_t(ch) * M;
-        for (int k = tid; k < M; k += T)
-            ytl[k] = last[k];
+    }
+
+    // what a batch leaves where the bank keeps it: acc[0, B) = the last frame's spill, acc[B, 2 B) = 0, the pending tail = Yt of
+    // the last frame
+    __global__ __launch_bounds__(256)
+    void conv_batch_finish_kernel(float *acc, const float *__restrict__ acc_new, float *yt /* [channels][2 B] floats */,
+                                  const float *__restrict__ yts /* [channels][K][2 B] floats */, int K, int B, bool upper_zero)
+    {
+        const int ch = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;      // n < 2 B
+        if (n >= 2 * B)
+            return;
+        yt[size_t(ch) * 2 * B + n] = yts[(size_t(ch) * K + K - 1) * 2 * B + n];
+        if (n < B)
+            acc[size_t(ch) * 2 * B + n] = acc_new[size_t(ch) * B + n];
+        else if (!upper_zero)
+            acc[size_t(ch) * 2 * B + n] = 0.0f;
     }
 
     // ---- whole frame AND the tail owed to the next one, in one launch (P >= 2) ------------------------------------------
@@ -1456,6 +1504,7 @@ struct mi_convolver_bank
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     float2     *d_xs = nullptr, *d_yts = nullptr;       // [channels][BATCH_MAX][B]: images and tails of a batch of frames (process_blocks)
+    float      *d_acc_new = nullptr;                    // [channels][B]: the accumulator a batch leaves, on its way into d_acc
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
     // way a reference Equalizer object does (Equalizer.cpp:339-345,481-501): every object has a response in force (vConv),
     // a cross-fade target (vNewConv) and a flag that the target waits for the block that completes next (EF_XFADE).
@@ -1591,6 +1640,7 @@ namespace
         {
             MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_xs), cells * sizeof(float2)));
             MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_yts), cells * sizeof(float2)));
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_acc_new), size_t(b->channels) * size_t(b->B) * sizeof(float)));
         }
         batch_args ba;
         ba.frames = K;
@@ -1615,11 +1665,18 @@ namespace
         switch (K) { case 2: { MI_TAIL(2); break; } case 4: { MI_TAIL(4); break; } case 8: { MI_TAIL(8); break; } default: { MI_TAIL(16); break; } }
         #undef MI_TAIL
         MI_HIP_CHECK(hipGetLastError());
-        #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_frames_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, \
-                                               ba, out_stride, aligned, b->d_xs, b->d_yts, b->yt_pending ? b->d_yt : nullptr, b->d_yt, b->d_ring, b->R, \
-                                               b->slot, b->d_H, b->P, b->d_acc, b->d_tw, b->upper_zero)
+        static const int force_groups = getenv("MI_CONV_BATCH_GROUPS") ? atoi(getenv("MI_CONV_BATCH_GROUPS")) : 0;     // experiment knob
+        // (enough workgroups to fill the chip: one per channel where there are 512 channels and more, up to four per channel)
+        const int want = (force_groups > 0) ? force_groups : std::max(1, std::min(4, int((512 + b->channels - 1) / b->channels)));
+        const int groups = std::min(K, want), per = (K + groups - 1) / groups;
+        #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_frames_kernel<LM>), dim3(b->channels, (K + per - 1) / per), dim3(fplan<LM>::T), 0, st, \
+                                               ba, per, out_stride, aligned, b->d_xs, b->d_yts, b->yt_pending ? b->d_yt : nullptr, b->d_ring, b->R, \
+                                               b->slot, b->d_H, b->P, b->d_acc, b->d_acc_new, b->d_tw, b->upper_zero)
         switch (b->logm) { case 9: { MI_CALL(9); break; } case 10: { MI_CALL(10); break; } case 11: { MI_CALL(11); break; } default: { MI_CALL(12); break; } }
         #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(conv_batch_finish_kernel, dim3((2 * M + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, b->d_acc_new,
+                           reinterpret_cast<float *>(b->d_yt), reinterpret_cast<const float *>(b->d_yts), K, M, b->upper_zero);
         MI_HIP_CHECK(hipGetLastError());
         b->slot = (b->slot + K) % b->R;
         b->yt_pending = true;
@@ -2058,7 +2115,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
-    (void)hipFree(b->d_xs); (void)hipFree(b->d_yts);
+    (void)hipFree(b->d_xs); (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new);
     const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
     (void)hipHostFree(b->h_fault);
     delete b;
@@ -2328,14 +2385,14 @@ int mi_convolver_bank_process_blocks(mi_convolver_bank_t *b, float *const *out, 
                                (b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u);
         if (batchable)
         {
-            // the frames of a batch are all read before any of them is written: a block joins unless it reads what an earlier
-            // block of the batch writes (its own output may be its input)
+            // the frames of a batch are all read before any of them is written, and written side by side: a block joins unless
+            // it reads or writes what an earlier block of the batch writes (its own output may be its input)
             run = 1;
             while (k + run < blocks && run < size_t(BATCH_MAX))
             {
                 bool ok = true;
                 for (size_t i = k; ok && i < k + run; ++i)
-                    ok = !overlap(out[i], ob, in[k + run], ib);
+                    ok = !overlap(out[i], ob, in[k + run], ib) && !overlap(out[i], ob, out[k + run], ob);
                 if (!ok)
                     break;
                 ++run;

@@ -487,8 +487,9 @@ def test_process_blocks_batches_of_frames_equal_frame_by_frame(gpu, rank, taps, 
 
 
 def test_process_blocks_splits_where_blocks_depend_on_each_other(gpu):
-    """A block that reads what an earlier block of the call writes starts a new batch; blocks in place and output buffers that
-    come round again stay in one; other block sizes and single-partition banks are plain loops of calls."""
+    """A block that reads or writes what an earlier block of the call writes starts a new batch (here: a ring of two output
+    buffers, a block fed from it); a block in place stays in its batch; other block sizes and single-partition banks are plain
+    loops of calls."""
     rng = np.random.default_rng(99)
     C, rank, taps, K = 3, 10, 2000, 9
     frame = 1 << (rank - 1)
