@@ -359,7 +359,7 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
     bank = mi.ConvolverBank(irs, 13)
     info = bank.info()
     P = info["partitions"]
-    ring = 8
+    ring = 16                                               # (a batch of frames needs outputs that lie apart)
     gen = torch.Generator(device="cpu")
     gen.manual_seed(5 + rank)
     xin = torch.randn((ring, C, frame), generator=gen, dtype=torch.float32).to(dev)
@@ -370,6 +370,23 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
         k = i % ring
         bank.process(yout[k], xin[k], frame, stream=stream)
 
+    # the K frames of a region as ONE mi_convolver_bank_process_blocks call: batches of 16 frames whose tails come out of one pass
+    # over the partitions' images (conv_batch_tail_kernel<16>: the probed launch), bit for bit the frame-by-frame samples
+    import ctypes
+    BATCH = 16
+    seq = [(warmup + i) % ring for i in range(steps)]
+    po = (ctypes.c_void_p * steps)(*[yout[k].data_ptr() for k in seq])
+    pi = (ctypes.c_void_p * steps)(*[xin[k].data_ptr() for k in seq])
+    st_ptr = ctypes.c_void_p(stream.cuda_stream)
+
+    def region():
+        mi.check(mi.lib.mi_convolver_bank_process_blocks(bank.handle, po, pi, steps, frame, frame, frame, st_ptr))
+    batched = steps >= BATCH and ring >= BATCH
+    if batched:
+        b_elapsed, b_kernel_ms, b_info = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, region=region,
+                                                      probe_step=lambda j: region(), probe_steps=BATCH)
+        b_info["launch"] = ("one mi_convolver_bank_process_blocks call per region: batches of %d frames, four launches each "
+                            "(conv_batch_forward / _tail<%d> / _frames / _finish)" % (BATCH, BATCH))
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup)
     chk = yout[(warmup + steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
@@ -399,11 +416,38 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
                    "channels_per_gpu": C, "taps": taps, "frame": frame, "partitions": P,
                    "images_read_per_step_MiB": round(float(C) * 2 * (P - 1) * img / 2 ** 20, 1)},
         "roofline": _roofline(kname, mac_bytes, kernel_ms, elapsed / steps * 1e3, tinfo["probe"],
-                              _pmc_traffic("pmc_convolver_latest.json") if C == 256 else None, {"launches_per_step": launches}),
+                              _pmc_traffic("pmc_convolver_step_latest.json", "conv_step_kernel") if C == 256 else None, {"launches_per_step": launches}),
         "whole_step": {"algorithmic_bytes": step_bytes,
                        "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / steps) / 1e9, 1),
                        "frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
     }
+    if batched:
+        # The batch's own traffic model: per channel and batch of K frames the partitions' images once
+        # ((P - 1) x 32 KiB), the ring's once ((P - 2) x 32 KiB), the K new images once and the K tails out (32 KiB each) for the
+        # probed kernel; for the whole batch in + out 16 K KiB each, the overlap-add tail, H and the ring once, the ring's update.
+        tail_bytes = float(C) * img * ((P - 1) + (P - 2) + 2 * BATCH)
+        batch_bytes = float(C) * (2 * 4 * frame * BATCH + 2 * 8 * frame + img * (P + (P - 1) + min(BATCH, P - 1)))
+        per_call = dict(res)
+        per_call["what"] = "the same frames as separate mi_convolver_bank_process calls: one launch of conv_step_kernel per frame (SURVEY 8d's streaming model, 272 B per channel-sample)"
+        per_call.pop("config", None)
+        res = {
+            "value": round(C * frame * world * steps / b_elapsed / 1e6, 1), "unit": "Msamples/s",
+            "ms_per_step": round(b_elapsed / steps * 1e3, 5), "steps": steps, "warmup": warmup,
+            "config": dict(res["config"], call="one mi_convolver_bank_process_blocks call per region (batches of %d frames; "
+                                               "bit-identical to %d process() calls -- those are timed under \"per_call\")" % (BATCH, steps)),
+            "timing": b_info,
+            "roofline": _roofline("conv_batch_tail_kernel<%d> (%d frames per launch; the batch is four launches)" % (BATCH, BATCH),
+                                  tail_bytes, b_kernel_ms, b_elapsed / steps * 1e3, b_info["probe"],
+                                  _pmc_traffic("pmc_convolver_latest.json", "conv_batch_tail_kernel", BATCH) if C == 256 else None,
+                                  {"bytes_model": "this kernel per channel and batch: (P - 1) + (P - 2) + 2 K images of 32 KiB",
+                                   "streaming_model_frac": round(step_bytes / (b_elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                                  launch_steps=BATCH),
+            "whole_step": {"algorithmic_bytes": batch_bytes / BATCH, "bytes_model": "a batch of K frames per channel: in + out 16 K KiB each, "
+                           "overlap-add tail 32 KiB, H P x 32 KiB, ring (P - 1) x 32 KiB read and min(K, P - 1) x 32 KiB written",
+                           "achieved_GBps_incl_launch_gaps": round(batch_bytes / BATCH / (b_elapsed / steps) / 1e9, 1),
+                           "frac": round(batch_bytes / BATCH / (b_elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+            "per_call": per_call,
+        }
     return res, irs
 
 
@@ -473,7 +517,7 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
     if big is not None:
         res["beyond_infinity_cache"] = {k: big[k] for k in ("value", "ms_per_step", "config", "roofline", "whole_step")}
     if stream_res is not None:
-        stream_res["fraction_of_whole_frame_rate"] = round(stream_res["value"] / res["value"], 3)
+        stream_res["fraction_of_whole_frame_rate"] = round(stream_res["value"] / res.get("per_call", res)["value"], 3)   # (a launch per frame)
         res["call_stream"] = stream_res
     if not args.no_cpu_baseline and world == 1:
         res["cpu_baseline"] = cpu_baseline_convolver(irs, 4096)

@@ -12,10 +12,12 @@ import json
 import os
 import sys
 
-KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_step_kernel<12, false>", "equalizer": "conv_frames_kernel",
+KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_batch_tail_kernel<16>", "equalizer": "conv_frames_kernel",
            "spectral": "analyzer_frames_kernel"}
+# second kernels of a workload's PMC passes (bench.py's per_call legs): summary name -> (workload, kernel)
+EXTRA = {"convolver_step": ("convolver", "conv_step_kernel<12, false>")}
 # the PMC passes run `bench.py --steps 50`: the headline's launch (biquad_stream_kernel) then carries 50 blocks
-UNITS_PER_LAUNCH = {"biquad": 50, "equalizer": 50, "spectral": 16}
+UNITS_PER_LAUNCH = {"biquad": 50, "equalizer": 50, "spectral": 16, "convolver": 16}
 
 
 def main():
@@ -29,10 +31,12 @@ def main():
                 rows = f.readlines()[:12]
             with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)), "w") as f:
                 f.writelines(rows)
-    for wl, kname in KERNELS.items():
+    jobs = [(wl, wl, k) for wl, k in KERNELS.items()] + [(name, wl, k) for name, (wl, k) in EXTRA.items()]
+    for name, wl_dir, kname in jobs:
+        wl = name
         per = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            files = glob.glob(os.path.join(src, "pmc_%s_%s" % (wl, ctr), "**", "*counter_collection.csv"), recursive=True)
+            files = glob.glob(os.path.join(src, "pmc_%s_%s" % (wl_dir, ctr), "**", "*counter_collection.csv"), recursive=True)
             vals = []
             for fn in files:
                 with open(fn) as f:
