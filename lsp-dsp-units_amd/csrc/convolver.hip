@@ -507,7 +507,7 @@ namespace
         }
     }
 
-    template <int K>
+    template <int K, bool KEEP>
     __global__ __launch_bounds__(256)
     void conv_batch_tail_kernel(float2 *yts /* [channels][K][M] */,
                                 const float2 *__restrict__ xs /* [channels][K][M] */, const float2 *__restrict__ ring, int R, int slot0,
@@ -534,12 +534,17 @@ namespace
             s.y = fmaf(x.x, h.y, fmaf(x.y, h.x, s.y));
         };
         f4 s[K], xw[K];
-        // the window for p = 2: frames f - 1, f = 0 .. K - 1; frame m lives in register m mod K throughout
+        // the window for p = 2: frames f - 1, f = 0 .. K - 1; frame m lives in register m mod K throughout.  The staged frames
+        // among them (0 .. K - 2) are needed once more, by the p = 1 term at the end: they wait in LDS instead of being read twice
+        __shared__ f4 own[KEEP ? K - 1 : 1][KEEP ? 256 : 1];
         #pragma unroll
         for (int f = 0; f < K; ++f)
         {
             s[f] = f4{0.0f, 0.0f, 0.0f, 0.0f};
-            xw[(f - 1 + K) % K] = image(f - 1)[idx];
+            const f4 v = image(f - 1)[idx];
+            xw[(f - 1 + K) % K] = v;
+            if (KEEP && f >= 1)
+                own[f - 1][threadIdx.x] = v;
         }
         int p = 2;
         while (p < P)
@@ -566,7 +571,7 @@ namespace
             const f4 h1 = Hc[size_t(1) * M4 + idx];
             #pragma unroll
             for (int f = 0; f < K; ++f)
-                mac(s[f], h1, Xs[size_t(f) * M4 + idx]);
+                mac(s[f], h1, (KEEP && f < K - 1) ? own[f][threadIdx.x] : Xs[size_t(f) * M4 + idx]);
         }
         #pragma unroll
         for (int f = 0; f < K; ++f)
@@ -1660,8 +1665,11 @@ namespace
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);                // the pass over the partitions is what the batch is about
         const dim3 tgrid(M / 2 / 256, b->channels);
-        #define MI_TAIL(KK) MI_LAUNCH((conv_batch_tail_kernel<KK>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_xs, b->d_ring, \
-                                      b->R, b->slot, b->d_H, b->P, M)
+        static const bool keep = getenv("MI_CONV_BATCH_REREAD") == nullptr;     // experiment knob: the staged frames read twice
+        #define MI_TAIL(KK) do { if (keep) MI_LAUNCH((conv_batch_tail_kernel<KK, true>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_xs, \
+                                                     b->d_ring, b->R, b->slot, b->d_H, b->P, M); \
+                                 else      MI_LAUNCH((conv_batch_tail_kernel<KK, false>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_xs, \
+                                                     b->d_ring, b->R, b->slot, b->d_H, b->P, M); } while (0)
         switch (K) { case 2: { MI_TAIL(2); break; } case 4: { MI_TAIL(4); break; } case 8: { MI_TAIL(8); break; } default: { MI_TAIL(16); break; } }
         #undef MI_TAIL
         MI_HIP_CHECK(hipGetLastError());
