@@ -530,3 +530,66 @@ def test_process_blocks_splits_where_blocks_depend_on_each_other(gpu):
         for k in range(4):
             np.testing.assert_array_equal(oa[k].download(), ob[k].download())
         a.close(); b.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_process_blocks_random_scripts(gpu, seed):
+    """Differential stress of the batched frames against frame-by-frame calls, bit for bit: random ranks (10 .. 13), tap counts
+    per channel, channel counts, and a random script of process_blocks calls (1 .. 40 frames, some in place, some with outputs
+    that come round again or feed a later block), whole-frame calls and calls of odd sizes in between."""
+    rng = np.random.default_rng(5100 + seed)
+    rank = int(rng.choice([10, 10, 11, 12, 13]))
+    frame = 1 << (rank - 1)
+    C = int(rng.integers(1, 7))
+    taps = int(rng.integers(frame + 1, 9 * frame))
+    counts = np.array([int(rng.integers(1, taps + 1)) for _ in range(C)], np.uint32)
+    counts[int(rng.integers(0, C))] = taps
+    irs = (rng.standard_normal((C, taps)) * 0.05).astype(np.float32)
+    script = []
+    for _ in range(int(rng.integers(3, 7))):
+        kind = int(rng.integers(0, 4))
+        if kind <= 1:
+            script.append(("blocks", int(rng.choice([2, 3, 5, 8, 16, 17, 40]))))
+        elif kind == 2:
+            script.append(("frame", 1))
+        else:
+            n = int(rng.integers(1, frame))
+            script.append(("odd", n))
+            script.append(("odd", frame - n))
+    results = []
+    for blocks_call in (False, True):
+        r2 = np.random.default_rng(6100 + seed)
+        bank = gpu.ConvolverBank(irs, rank, counts=counts)
+        got = []
+        for kind, n in script:
+            if kind == "odd":
+                d = gpu.DeviceBuffer.from_host((r2.standard_normal((C, n)) * 0.25).astype(np.float32))
+                o = gpu.DeviceBuffer((C, n))
+                bank.process(o, d, n)
+                got.append(o.download())
+                continue
+            pool = [gpu.DeviceBuffer.from_host((r2.standard_normal((C, frame)) * 0.25).astype(np.float32)) for _ in range(n)]
+            ins, outs = [], []
+            for k in range(n):
+                mode = int(r2.integers(0, 8))
+                i = pool[k]
+                if mode == 0:
+                    o = i                                    # in place
+                elif mode == 1 and outs:
+                    o = outs[int(r2.integers(0, len(outs)))] # an output buffer again
+                else:
+                    o = gpu.DeviceBuffer((C, frame))
+                if mode == 2 and outs:
+                    i = outs[int(r2.integers(0, len(outs)))] # reads what an earlier block wrote
+                ins.append(i); outs.append(o)
+            if blocks_call and kind == "blocks":
+                bank.process_blocks(outs, ins, frame)
+            else:
+                for o, i in zip(outs, ins):
+                    bank.process(o, i, frame)
+            got += [b.download() for b in pool] + [o.download() for o in outs]
+        assert bank.faults() == 0
+        results.append(got)
+        bank.close()
+    for u, v in zip(*results):
+        np.testing.assert_array_equal(u, v, err_msg=str((seed, rank, C, taps, script)))
