@@ -3694,6 +3694,17 @@ bool FilterArray::process(float *dev_out, const float *dev_in, size_t samples, s
            last_status(mi_biquad_bank_process(a->bank, dev_out, dev_in, samples, stride, stride, stream)) == MI_OK;
 }
 
+bool FilterArray::process_blocks(float *const *dev_out, const float *const *dev_in, size_t blocks, size_t samples, size_t stride, void *stream)
+{
+    filter_array *a = fa_of(pImpl);
+    if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
+        return false;
+    if (samples == 0 || blocks == 0)
+        return true;
+    return fa_commit(a, stream) &&
+           last_status(mi_biquad_bank_process_blocks(a->bank, dev_out, dev_in, blocks, samples, stride, stride, stream)) == MI_OK;
+}
+
 bool FilterArray::process_host(float *out, const float *in, size_t samples, size_t stride)
 {
     filter_array *a = fa_of(pImpl);
@@ -3873,6 +3884,15 @@ bool ConvolverArray::process(float *dev_out, const float *dev_in, size_t samples
     if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
         return false;
     return samples == 0 || last_status(mi_convolver_bank_process(a->bank, dev_out, dev_in, samples, stride, stride, stream)) == MI_OK;
+}
+
+bool ConvolverArray::process_blocks(float *const *dev_out, const float *const *dev_in, size_t blocks, size_t samples, size_t stride, void *stream)
+{
+    convolver_array *a = ca_of(pImpl);
+    if (a == nullptr || dev_out == nullptr || dev_in == nullptr || stride < samples)
+        return false;
+    return samples == 0 || blocks == 0 ||
+           last_status(mi_convolver_bank_process_blocks(a->bank, dev_out, dev_in, blocks, samples, stride, stride, stream)) == MI_OK;
 }
 
 bool ConvolverArray::process_host(float *out, const float *in, size_t samples, size_t stride)

@@ -52,6 +52,11 @@ namespace lsp
                 /** Filter::process(out, in, samples) of EVERY object: row `id` of the DEVICE arrays [filters][stride] float32;
                  *  out may be in.  One launch on `stream` (a hipStream_t, NULL = default stream), nothing is synchronised. */
                 bool                process(float *dev_out, const float *dev_in, size_t samples, size_t stride, void *stream = NULL);
+                /** `blocks` consecutive process() calls: dev_out[k] / dev_in[k] are the DEVICE arrays of block k (the pointer
+                 *  tables themselves in host memory).  Blocks of more than 2048 samples in whole chunks of 16 ride ONE launch; the
+                 *  samples and the filter memory are those of the calls one by one, bit for bit. */
+                bool                process_blocks(float *const *dev_out, const float *const *dev_in, size_t blocks, size_t samples,
+                                                   size_t stride, void *stream = NULL);
                 /** the same on HOST rows: one upload, one launch, one download (synchronises the default stream) */
                 bool                process_host(float *out, const float *in, size_t samples, size_t stride);
         };

@@ -43,6 +43,11 @@ namespace lsp
                 /** Convolver::process(dst, src, count) of EVERY object: row c of the DEVICE arrays [convolvers][stride];
                  *  out may be in.  Launches on `stream` (a hipStream_t, NULL = default stream), nothing is synchronised. */
                 bool                process(float *dev_out, const float *dev_in, size_t samples, size_t stride, void *stream = NULL);
+                /** `blocks` consecutive process() calls: dev_out[k] / dev_in[k] are the DEVICE arrays of block k (the pointer
+                 *  tables themselves in host memory).  Whole frames go in batches of up to 16 whose tails come out of one pass
+                 *  over the partitions' images; the samples are those of the calls one by one, bit for bit. */
+                bool                process_blocks(float *const *dev_out, const float *const *dev_in, size_t blocks, size_t samples,
+                                                   size_t stride, void *stream = NULL);
                 /** the same on HOST rows: one upload, the launch, one download (synchronises the default stream) */
                 bool                process_host(float *out, const float *in, size_t samples, size_t stride);
         };

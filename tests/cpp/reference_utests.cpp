@@ -641,6 +641,36 @@ static void filter_array_equals_n_filters()
     dspu::filter_params_t back;
     CHECK(fa.get_params(0, &back) && back.fGain == 1.5f, "get_params");
     mi_dspu_free(din); mi_dspu_free(dout);
+    // a run of blocks in one call (ONE launch for blocks of more than 2048 samples): the samples of the calls one by one
+    {
+        const size_t nb = 4096, K = 5;
+        std::vector<float> xb(K * N * nb), y1(K * N * nb), y2(K * N * nb);
+        for (size_t i = 0; i < xb.size(); ++i) { seed = seed * 1664525u + 1013904223u; xb[i] = (float(seed >> 8) / 8388608.0f - 1.0f) * 0.25f; }
+        float *bi = NULL, *bo = NULL;
+        CHECK(mi_dspu_malloc(reinterpret_cast<void **>(&bi), xb.size() * sizeof(float)) == MI_OK &&
+              mi_dspu_malloc(reinterpret_cast<void **>(&bo), xb.size() * sizeof(float)) == MI_OK, "device rows");
+        CHECK(mi_dspu_copy_h2d(bi, xb.data(), xb.size() * sizeof(float), NULL) == MI_OK, "h2d");
+        dspu::FilterArray fb;
+        CHECK(fb.init(N, 16), "FilterArray::init");
+        for (size_t i = 0; i < N; ++i)
+            CHECK(fb.update(i, 48000, &fp[i]), "update");
+        float *po[K]; const float *pi[K];
+        for (size_t k = 0; k < K; ++k) { po[k] = bo + k * N * nb; pi[k] = bi + k * N * nb; }
+        CHECK(fb.process_blocks(po, pi, K, nb, nb), "FilterArray::process_blocks");
+        CHECK(mi_dspu_copy_d2h(y1.data(), bo, y1.size() * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+        dspu::FilterArray fc;
+        CHECK(fc.init(N, 16), "FilterArray::init");
+        for (size_t i = 0; i < N; ++i)
+            CHECK(fc.update(i, 48000, &fp[i]), "update");
+        for (size_t k = 0; k < K; ++k)
+            CHECK(fc.process(bo + k * N * nb, bi + k * N * nb, nb, nb), "process");
+        CHECK(mi_dspu_copy_d2h(y2.data(), bo, y2.size() * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+        size_t bad = 0;
+        for (size_t i = 0; i < y1.size(); ++i)
+            bad += (y1[i] != y2[i]);
+        CHECK(bad == 0, "process_blocks: %zu samples differ from block-by-block calls", bad);
+        mi_dspu_free(bi); mi_dspu_free(bo);
+    }
 }
 
 // ---- EqualizerArray / ConvolverArray: N objects behind one bank (this library's extensions) ---------------------------------
@@ -733,6 +763,30 @@ static void convolver_array_equals_n_convolvers()
     for (size_t i = 0; i < x.size(); ++i) { worst = std::max(worst, double(std::fabs(ya[i] - yc[i]))); peak = std::max(peak, double(std::fabs(yc[i]))); }
     CHECK(worst <= 1e-6 * peak, "ConvolverArray differs from the separate objects by %.3g of the peak", worst / peak);
     mi_dspu_free(din); mi_dspu_free(dout);
+    // a run of whole frames in one call (batches of frames): the samples of the calls one by one, bit for bit
+    {
+        const size_t K = 7;
+        std::vector<float> xb(K * N * n), y1(K * N * n), y2(K * N * n);
+        for (size_t i = 0; i < xb.size(); ++i) { seed = seed * 1664525u + 1013904223u; xb[i] = (float(seed >> 8) / 8388608.0f - 1.0f) * 0.25f; }
+        float *bi = NULL, *bo = NULL;
+        CHECK(mi_dspu_malloc(reinterpret_cast<void **>(&bi), xb.size() * sizeof(float)) == MI_OK &&
+              mi_dspu_malloc(reinterpret_cast<void **>(&bo), xb.size() * sizeof(float)) == MI_OK, "device rows");
+        CHECK(mi_dspu_copy_h2d(bi, xb.data(), xb.size() * sizeof(float), NULL) == MI_OK, "h2d");
+        dspu::ConvolverArray cb, cc;
+        CHECK(cb.init(N, irs.data(), TAPS, TAPS, RANK, 0.0f, counts) && cc.init(N, irs.data(), TAPS, TAPS, RANK, 0.0f, counts), "ConvolverArray::init");
+        float *po[K]; const float *pi[K];
+        for (size_t k = 0; k < K; ++k) { po[k] = bo + k * N * n; pi[k] = bi + k * N * n; }
+        CHECK(cb.process_blocks(po, pi, K, n, n), "ConvolverArray::process_blocks");
+        CHECK(mi_dspu_copy_d2h(y1.data(), bo, y1.size() * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+        for (size_t k = 0; k < K; ++k)
+            CHECK(cc.process(bo + k * N * n, bi + k * N * n, n, n), "process");
+        CHECK(mi_dspu_copy_d2h(y2.data(), bo, y2.size() * sizeof(float), NULL) == MI_OK && mi_dspu_stream_synchronize(NULL) == MI_OK, "d2h");
+        size_t bad = 0;
+        for (size_t i = 0; i < y1.size(); ++i)
+            bad += (y1[i] != y2[i]);
+        CHECK(bad == 0, "process_blocks: %zu samples differ from frame-by-frame calls", bad);
+        mi_dspu_free(bi); mi_dspu_free(bo);
+    }
 }
 
 // ---- binary layout of the drop-in classes ---------------------------------------------------------------------------
