@@ -509,8 +509,9 @@ namespace
 
     template <int K, bool KEEP>
     __global__ __launch_bounds__(256)
-    void conv_batch_tail_kernel(float2 *yts /* [channels][K][M] */,
-                                const float2 *__restrict__ xs /* [channels][K][M] */, const float2 *__restrict__ ring, int R, int slot0,
+    void conv_batch_tail_kernel(float2 *yps /* [channels][K][M]: H_0 X_f + Yt_(f-1), what frame f's inverse transform takes */,
+                                float2 *yt /* [channels][M]: in, the tail pending before the call (if `pending`); out, Yt_(K-1) */,
+                                bool pending, const float2 *__restrict__ xs /* [channels][K][M] */, float2 *ring, int R, int slot0,
                                 const float2 *__restrict__ H, int P, int M)
     {
         typedef float f4 __attribute__((ext_vector_type(4)));
@@ -533,6 +534,36 @@ namespace
             s.x = fmaf(x.x, h.x, fmaf(-x.y, h.y, s.x));
             s.y = fmaf(x.x, h.y, fmaf(x.y, h.x, s.y));
         };
+        // bin 0 packs (DC, Nyquist): two real products instead of a complex one -- lane f of the first workgroup forms the first
+        // pair's first bin of frame f's tail (the same chain of multiply-adds as the tail role's dc / ny) and of what frame f's
+        // inverse transform takes, NOW (the ring still holds the frames before the call), and files them at the end
+        float2 fix_y = make_float2(0.0f, 0.0f), fix_t = make_float2(0.0f, 0.0f);
+        if (blockIdx.x == 0 && threadIdx.x < 64)
+        {
+            const int f = (threadIdx.x < K) ? int(threadIdx.x) : K - 1;
+            float dc = 0.0f, ny = 0.0f;
+            for (int q = 2; q < P; ++q)
+            {
+                const f4 h = Hc[size_t(q) * M4], x = image(f + 1 - q)[0];
+                dc = fmaf(x.x, h.x, dc);
+                ny = fmaf(x.y, h.y, ny);
+            }
+            const f4 h = Hc[size_t(1) * M4], x = Xs[size_t(f) * M4];
+            dc = fmaf(x.x, h.x, dc);
+            ny = fmaf(x.y, h.y, ny);
+            // the tail owed to frame f: lane f - 1's (lane 0: the pending one from before the call)
+            float pdc = __shfl_up(dc, 1), pny = __shfl_up(ny, 1);
+            if (threadIdx.x == 0)
+            {
+                const float2 before = pending ? (yt + size_t(ch) * M)[0] : make_float2(0.0f, 0.0f);
+                pdc = before.x;
+                pny = before.y;
+            }
+            const f4 h0 = Hc[0];
+            const int k0 = 2 * idx;                         // 0 in lane 0 only; lanes 1 .. K - 1 pass 0 as a run-time value as well
+            fix_y = cadd(image_mul(make_float2(x.x, x.y), make_float2(h0.x, h0.y), k0 - 2 * int(threadIdx.x)), make_float2(pdc, pny));
+            fix_t = make_float2(dc, ny);
+        }
         f4 s[K], xw[K];
         // the window for p = 2: frames f - 1, f = 0 .. K - 1; frame m lives in register m mod K throughout.  The staged frames
         // among them (0 .. K - 2) are needed once more, by the p = 1 term at the end: they wait in LDS instead of being read twice
@@ -566,56 +597,52 @@ namespace
                 }
             }
         }
-        // p = 1 last: the frames' own images
+        // p = 1 last: the frames' own images.  With frame f's image in hand and the tail of frame f - 1 complete, what frame f's
+        // inverse transform takes is formed right here (frame_role's `through`: image times H_0 plus the tail owed to the frame)
+        // and the image enters the ring -- this thread alone touches this pair of bins in any slot, and is done reading them
         {
-            const f4 h1 = Hc[size_t(1) * M4 + idx];
+            const f4 h1 = Hc[size_t(1) * M4 + idx], h0 = Hc[idx];
+            f4 *const ytc = reinterpret_cast<f4 *>(yt + size_t(ch) * M);
+            f4 prev = pending ? ytc[idx] : f4{0.0f, 0.0f, 0.0f, 0.0f};
+            f4 *const Rw = reinterpret_cast<f4 *>(ring + size_t(ch) * R * M);
             #pragma unroll
             for (int f = 0; f < K; ++f)
-                mac(s[f], h1, (KEEP && f < K - 1) ? own[f][threadIdx.x] : Xs[size_t(f) * M4 + idx]);
+            {
+                const f4 x = (KEEP && f < K - 1) ? own[f][threadIdx.x] : Xs[size_t(f) * M4 + idx];
+                mac(s[f], h1, x);
+                const float2 y0 = cadd(image_mul(make_float2(x.x, x.y), make_float2(h0.x, h0.y), 2 * idx), make_float2(prev.x, prev.y));
+                const float2 y1 = cadd(image_mul(make_float2(x.z, x.w), make_float2(h0.z, h0.w), 2 * idx + 1), make_float2(prev.z, prev.w));
+                reinterpret_cast<f4 *>(yps + (size_t(ch) * K + f) * M)[idx] = f4{y0.x, y0.y, y1.x, y1.y};
+                if (f + R >= K)                             // (the ring keeps the last R frames)
+                    Rw[size_t((slot0 + 1 + f) % R) * M4 + idx] = x;
+                prev = s[f];
+            }
+            ytc[idx] = s[K - 1];
         }
-        #pragma unroll
-        for (int f = 0; f < K; ++f)
-        {
-            f4 *dst = reinterpret_cast<f4 *>(yts + (size_t(ch) * K + f) * M);
-            dst[idx] = s[f];
-        }
-        // bin 0 packs (DC, Nyquist): two real products instead of a complex one -- lane f of the first workgroup redoes the
-        // first pair's first bin of frame f (the same chain of multiply-adds as the tail role's dc / ny)
+        // (the first workgroup: the packed first bins, formed before anything was written)
         if (blockIdx.x != 0)
             return;
         __syncthreads();
         if (threadIdx.x < K)
         {
             const int f = threadIdx.x;
-            float dc = 0.0f, ny = 0.0f;
-            for (int q = 2; q < P; ++q)
-            {
-                const f4 h = Hc[size_t(q) * M4], x = image(f + 1 - q)[0];
-                dc = fmaf(x.x, h.x, dc);
-                ny = fmaf(x.y, h.y, ny);
-            }
-            const f4 h = Hc[size_t(1) * M4], x = Xs[size_t(f) * M4];
-            dc = fmaf(x.x, h.x, dc);
-            ny = fmaf(x.y, h.y, ny);
-            float2 *dst = yts + (size_t(ch) * K + f) * M;
-            dst[0] = make_float2(dc, ny);
+            (yps + (size_t(ch) * K + f) * M)[0] = fix_y;
+            if (f == K - 1)
+                (yt + size_t(ch) * M)[0] = fix_t;
         }
     }
 
     // The frames' outputs: a channel's K frames are shared out among G workgroups, each walking `per` consecutive frames with the
-    // accumulator in registers and the next frame's operands asked for before the current frame's transforms.  The overlap-add
+    // accumulator in registers and the next frame's spectrum asked for before the current frame's transforms.  The overlap-add
     // couples a frame to the one before it only through the upper half of that frame's inverse transform (acc = fma(y1, scale,
     // 0) once the upper half of the accumulator is zero), so a workgroup whose run starts inside the batch runs the inverse of
-    // the frame before its first one as well and needs no other workgroup.  (One workgroup per channel: 9.6 us per frame, a
-    // chain of memory latencies on 256 workgroups; one per frame: 11.5 us, every image and every tail read twice.)  Nothing
-    // the launch reads is written by it: the accumulator the last frame leaves goes to acc_new, its tail stays in yts, and
-    // conv_batch_finish_kernel files both where the bank keeps them.
+    // the frame before its first one as well and needs no other workgroup.  (One workgroup per channel: a chain of memory
+    // latencies on 256 workgroups; one per frame: every spectrum read twice.)  Nothing the launch reads is written by it: the
+    // accumulator the last frame leaves goes to acc_new and conv_batch_finish_kernel files it where the bank keeps it.
     template <int LOGM>
     __global__ __launch_bounds__(fplan<LOGM>::T)
-    void conv_batch_frames_kernel(const batch_args ba, int per, size_t out_stride, bool aligned, const float2 *__restrict__ xs,
-                                  const float2 *__restrict__ yts, const float2 *__restrict__ yt0 /* the tail pending before the call, or NULL */,
-                                  float2 *ring, int R, int slot0, const float2 *__restrict__ H, int P, const float *__restrict__ acc,
-                                  float *acc_new, const float2 *__restrict__ tw, bool upper_zero)
+    void conv_batch_frames_kernel(const batch_args ba, int per, size_t out_stride, bool aligned, const float2 *__restrict__ yps,
+                                  const float *__restrict__ acc, float *acc_new, const float2 *__restrict__ tw, bool upper_zero)
     {
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T, NPT = KPT / 2;
@@ -627,30 +654,20 @@ namespace
         typename PL::real rf;
         rf.load(tw, TWN, tid);
         const float *const a = acc + size_t(ch) * 2 * B;
-        const float2 *const h0 = H + size_t(ch) * P * M;
         auto bin_of = [&](int i) -> int {
             const int k = tid + (i % NPT) * T;
             return (i < NPT) ? k : (k == 0) ? M / 2 : M - k;
         };
-        // frame g's image and the tail owed to it, by this thread's bins
-        float2 xr[KPT], yr[KPT];
+        float2 yr[KPT];                                      // frame g's spectrum (H_0 X_g + Yt_(g-1)) by this thread's bins
         auto fetch = [&](int g)
         {
-            const float2 *X = xs + (size_t(ch) * K + g) * M;
-            const float2 *yt = (g == 0) ? ((yt0 != nullptr) ? yt0 + size_t(ch) * M : nullptr) : yts + (size_t(ch) * K + g - 1) * M;
+            const float2 *Y = yps + (size_t(ch) * K + g) * M;
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
-            {
-                const int k = bin_of(i);
-                xr[i] = X[k];
-                yr[i] = (yt != nullptr) ? yt[k] : make_float2(0.0f, 0.0f);
-            }
+                yr[i] = Y[bin_of(i)];
         };
         fetch((f0 > 0) ? f0 - 1 : 0);
-        float2 hreg[KPT], a0[NPT], a1[NPT];
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            hreg[i] = h0[bin_of(i)];
+        float2 a0[NPT], a1[NPT];
         // what the accumulator held before the call concerns frames 0 (both halves) and 1 (the upper half under frame 0's spill)
         #pragma unroll
         for (int i = 0; i < NPT; ++i)
@@ -661,18 +678,13 @@ namespace
         rf.prepare();
         const float scale = 1.0f / float(2 * M);
         v2f io[KPT];
-        // the fetched frame: bin k of its image times the head partition's, plus the tail owed to it (frame_role's `through`), merged
-        // and through the inverse transform: io = the frame's 2 B samples (times 2 M).  `next`: the frame to fetch meanwhile.
-        auto inverse = [&](float2 *file /* the frame's ring slot, or NULL */, int next)
+        // the fetched spectrum, merged and through the inverse transform: io = the frame's 2 B samples (times 2 M); `next`: the
+        // frame to fetch meanwhile
+        auto inverse = [&](int next)
         {
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
-            {
-                const int k = bin_of(i);
-                if (file != nullptr)
-                    file[k] = xr[i];                        // the frame's image enters the ring
-                buf[k] = cadd(image_mul(xr[i], hreg[i], k), yr[i]);
-            }
+                buf[bin_of(i)] = yr[i];
             if (next >= 0)
                 fetch(next);
             __syncthreads();
@@ -681,7 +693,7 @@ namespace
         };
         if (f0 > 0)
         {
-            inverse(nullptr, f0);                           // the frame before the run: its upper half is what the run's first output starts from
+            inverse(f0);                                    // the frame before the run: its upper half is what the run's first output starts from
             #pragma unroll
             for (int i = 0; i < NPT; ++i)
             {
@@ -692,8 +704,7 @@ namespace
         }
         for (int f = f0; f < f1; ++f)
         {
-            // (the ring keeps the last R frames: an earlier one's slot belongs to a later one)
-            inverse((f + R >= K) ? ring + (size_t(ch) * R + (slot0 + 1 + f) % R) * M : nullptr, (f + 1 < f1) ? f + 1 : -1);
+            inverse((f + 1 < f1) ? f + 1 : -1);
             float *o = ba.out[f] + size_t(ch) * out_stride;
             const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(o, unsigned(B * sizeof(float)));
             #pragma unroll
@@ -722,19 +733,14 @@ namespace
         }
     }
 
-    // what a batch leaves where the bank keeps it: acc[0, B) = the last frame's spill, acc[B, 2 B) = 0, the pending tail = Yt of
-    // the last frame
+    // the accumulator a batch leaves, where the bank keeps it: acc[0, B) = the last frame's spill, acc[B, 2 B) = 0
     __global__ __launch_bounds__(256)
-    void conv_batch_finish_kernel(float *acc, const float *__restrict__ acc_new, float *yt /* [channels][2 B] floats */,
-                                  const float *__restrict__ yts /* [channels][K][2 B] floats */, int K, int B, bool upper_zero)
+    void conv_batch_finish_kernel(float *acc, const float *__restrict__ acc_new, int B, bool upper_zero)
     {
         const int ch = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;      // n < 2 B
-        if (n >= 2 * B)
-            return;
-        yt[size_t(ch) * 2 * B + n] = yts[(size_t(ch) * K + K - 1) * 2 * B + n];
         if (n < B)
             acc[size_t(ch) * 2 * B + n] = acc_new[size_t(ch) * B + n];
-        else if (!upper_zero)
+        else if (n < 2 * B && !upper_zero)
             acc[size_t(ch) * 2 * B + n] = 0.0f;
     }
 
@@ -1666,25 +1672,25 @@ namespace
         mi::take_profile_events(&ev0, &ev1);                // the pass over the partitions is what the batch is about
         const dim3 tgrid(M / 2 / 256, b->channels);
         static const bool keep = getenv("MI_CONV_BATCH_REREAD") == nullptr;     // experiment knob: the staged frames read twice
-        #define MI_TAIL(KK) do { if (keep) MI_LAUNCH((conv_batch_tail_kernel<KK, true>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_xs, \
-                                                     b->d_ring, b->R, b->slot, b->d_H, b->P, M); \
-                                 else      MI_LAUNCH((conv_batch_tail_kernel<KK, false>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_xs, \
-                                                     b->d_ring, b->R, b->slot, b->d_H, b->P, M); } while (0)
+        #define MI_TAIL(KK) do { if (keep) MI_LAUNCH((conv_batch_tail_kernel<KK, true>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
+                                                     b->yt_pending, b->d_xs, b->d_ring, b->R, b->slot, b->d_H, b->P, M); \
+                                 else      MI_LAUNCH((conv_batch_tail_kernel<KK, false>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
+                                                     b->yt_pending, b->d_xs, b->d_ring, b->R, b->slot, b->d_H, b->P, M); } while (0)
         switch (K) { case 2: { MI_TAIL(2); break; } case 4: { MI_TAIL(4); break; } case 8: { MI_TAIL(8); break; } default: { MI_TAIL(16); break; } }
         #undef MI_TAIL
         MI_HIP_CHECK(hipGetLastError());
         static const int force_groups = getenv("MI_CONV_BATCH_GROUPS") ? atoi(getenv("MI_CONV_BATCH_GROUPS")) : 0;     // experiment knob
-        // (enough workgroups to fill the chip: one per channel where there are 512 channels and more, up to four per channel)
-        const int want = (force_groups > 0) ? force_groups : std::max(1, std::min(4, int((512 + b->channels - 1) / b->channels)));
+        // (a workgroup per CU is enough for these: one run per channel from 256 channels on -- 16.9 against 17.2 / 17.5 / 18.2 us per
+        // frame with 2 / 4 / 8 runs at C3 --, up to four per channel below that)
+        const int want = (force_groups > 0) ? force_groups : std::max(1, std::min(4, int(256 / b->channels)));
         const int groups = std::min(K, want), per = (K + groups - 1) / groups;
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_frames_kernel<LM>), dim3(b->channels, (K + per - 1) / per), dim3(fplan<LM>::T), 0, st, \
-                                               ba, per, out_stride, aligned, b->d_xs, b->d_yts, b->yt_pending ? b->d_yt : nullptr, b->d_ring, b->R, \
-                                               b->slot, b->d_H, b->P, b->d_acc, b->d_acc_new, b->d_tw, b->upper_zero)
+                                               ba, per, out_stride, aligned, b->d_yts, b->d_acc, b->d_acc_new, b->d_tw, b->upper_zero)
         switch (b->logm) { case 9: { MI_CALL(9); break; } case 10: { MI_CALL(10); break; } case 11: { MI_CALL(11); break; } default: { MI_CALL(12); break; } }
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(conv_batch_finish_kernel, dim3((2 * M + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, b->d_acc_new,
-                           reinterpret_cast<float *>(b->d_yt), reinterpret_cast<const float *>(b->d_yts), K, M, b->upper_zero);
+        hipLaunchKernelGGL(conv_batch_finish_kernel, dim3((2 * M + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, b->d_acc_new, M,
+                           b->upper_zero);
         MI_HIP_CHECK(hipGetLastError());
         b->slot = (b->slot + K) % b->R;
         b->yt_pending = true;
