@@ -423,10 +423,10 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
     }
     if batched:
         # The batch's own traffic model: per channel and batch of K frames the probed kernel reads the P partitions'
-        # images, P - 2 of the ring's, the K new ones and the pending tail, and writes K spectra, the ring's update (min(K, P - 1))
-        # and the new pending tail (32 KiB each); for the whole batch in + out 16 K KiB each, the overlap-add tail, H and the
-        # ring once, the ring's update.
-        tail_bytes = float(C) * img * (P + (P - 2) + BATCH + 1 + BATCH + min(BATCH, P - 1) + 1)
+        # images, P - 2 of the ring's older ones, the K new ones and the pending tail, and writes K spectra and the new pending
+        # tail (32 KiB each); for the whole batch in + out 16 K KiB each, the overlap-add tail, H and the ring once, the ring's
+        # update.
+        tail_bytes = float(C) * img * (P + (P - 2) + BATCH + 1 + BATCH + 1)
         batch_bytes = float(C) * (2 * 4 * frame * BATCH + 2 * 8 * frame + img * (P + (P - 1) + min(BATCH, P - 1)))
         per_call = dict(res)
         per_call["what"] = "the same frames as separate mi_convolver_bank_process calls: one launch of conv_step_kernel per frame (SURVEY 8d's streaming model, 272 B per channel-sample)"
@@ -440,7 +440,7 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
             "roofline": _roofline("conv_batch_tail_kernel<%d> (%d frames per launch; the batch is four launches)" % (BATCH, BATCH),
                                   tail_bytes, b_kernel_ms, b_elapsed / steps * 1e3, b_info["probe"],
                                   _pmc_traffic("pmc_convolver_latest.json", "conv_batch_tail_kernel", BATCH) if C == 256 else None,
-                                  {"bytes_model": "this kernel per channel and batch: P + (P - 2) + K + 1 images of 32 KiB read, K + min(K, P - 1) + 1 written",
+                                  {"bytes_model": "this kernel per channel and batch: P + (P - 2) + K + 1 images of 32 KiB read, K + 1 written",
                                    "streaming_model_frac": round(step_bytes / (b_elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
                                   launch_steps=BATCH),
             "whole_step": {"algorithmic_bytes": batch_bytes / BATCH, "bytes_model": "a batch of K frames per channel: in + out 16 K KiB each, "

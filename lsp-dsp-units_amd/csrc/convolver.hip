@@ -473,7 +473,7 @@ namespace
 
     template <int LOGM>
     __global__ __launch_bounds__(fplan<LOGM>::T)
-    void conv_batch_forward_kernel(const batch_args ba, size_t in_stride, bool aligned, float2 *xs /* [channels][frames][M] */,
+    void conv_batch_forward_kernel(const batch_args ba, size_t in_stride, bool aligned, float2 *ring, int R, int slot0,
                                    const float2 *__restrict__ tw)
     {
         using PL = fplan<LOGM>;
@@ -497,7 +497,8 @@ namespace
         rf.prepare();
         mi_fft::fft_lds<LOGM, false, true, false>(buf, scr, rf.ft, tid, io);
         mi_fft::real_split<LOGM>(buf, rf.rt, tid);
-        float2 *dst = xs + (size_t(ch) * ba.frames + f) * M;
+        // (the ring has room for a batch next to the P - 2 frames the batch's tails still need: see launch_batch)
+        float2 *dst = ring + (size_t(ch) * R + (slot0 + 1 + f) % R) * M;
         #pragma unroll
         for (int i = 0; i < KPT; ++i)                       // (the pairs this thread split itself)
         {
@@ -511,18 +512,15 @@ namespace
     __global__ __launch_bounds__(256)
     void conv_batch_tail_kernel(float2 *yps /* [channels][K][M]: H_0 X_f + Yt_(f-1), what frame f's inverse transform takes */,
                                 float2 *yt /* [channels][M]: in, the tail pending before the call (if `pending`); out, Yt_(K-1) */,
-                                bool pending, const float2 *__restrict__ xs /* [channels][K][M] */, float2 *ring, int R, int slot0,
+                                bool pending, const float2 *__restrict__ ring, int R, int slot0,
                                 const float2 *__restrict__ H, int P, int M)
     {
         typedef float f4 __attribute__((ext_vector_type(4)));
         const int ch = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x, M4 = M / 2;      // (M4 is a multiple of 256: M >= 512)
         const f4 *Hc = reinterpret_cast<const f4 *>(H + size_t(ch) * P * M);
         const f4 *Xr = reinterpret_cast<const f4 *>(ring + size_t(ch) * R * M);
-        const f4 *Xs = reinterpret_cast<const f4 *>(xs + size_t(ch) * K * M);
-        // frame m of the call (m >= 0: staged) or before it (m < 0: frame -1 sits in ring slot slot0, -2 in the one before, ...)
+        // frame m of the call (m >= 0) or before it (m < 0): frame -1 sits in ring slot slot0, frame 0 in the one behind it, ...
         auto image = [&](int m) -> const f4 * {
-            if (m >= 0)
-                return Xs + size_t(m) * M4;
             int r = (slot0 + 1 + m) % R;
             r = (r < 0) ? r + R : r;
             return Xr + size_t(r) * M4;
@@ -548,7 +546,7 @@ namespace
                 dc = fmaf(x.x, h.x, dc);
                 ny = fmaf(x.y, h.y, ny);
             }
-            const f4 h = Hc[size_t(1) * M4], x = Xs[size_t(f) * M4];
+            const f4 h = Hc[size_t(1) * M4], x = image(f)[0];
             dc = fmaf(x.x, h.x, dc);
             ny = fmaf(x.y, h.y, ny);
             // the tail owed to frame f: lane f - 1's (lane 0: the pending one from before the call)
@@ -599,22 +597,18 @@ namespace
         }
         // p = 1 last: the frames' own images.  With frame f's image in hand and the tail of frame f - 1 complete, what frame f's
         // inverse transform takes is formed right here (frame_role's `through`: image times H_0 plus the tail owed to the frame)
-        // and the image enters the ring -- this thread alone touches this pair of bins in any slot, and is done reading them
         {
             const f4 h1 = Hc[size_t(1) * M4 + idx], h0 = Hc[idx];
             f4 *const ytc = reinterpret_cast<f4 *>(yt + size_t(ch) * M);
             f4 prev = pending ? ytc[idx] : f4{0.0f, 0.0f, 0.0f, 0.0f};
-            f4 *const Rw = reinterpret_cast<f4 *>(ring + size_t(ch) * R * M);
             #pragma unroll
             for (int f = 0; f < K; ++f)
             {
-                const f4 x = (KEEP && f < K - 1) ? own[f][threadIdx.x] : Xs[size_t(f) * M4 + idx];
+                const f4 x = (KEEP && f < K - 1) ? own[f][threadIdx.x] : image(f)[idx];
                 mac(s[f], h1, x);
                 const float2 y0 = cadd(image_mul(make_float2(x.x, x.y), make_float2(h0.x, h0.y), 2 * idx), make_float2(prev.x, prev.y));
                 const float2 y1 = cadd(image_mul(make_float2(x.z, x.w), make_float2(h0.z, h0.w), 2 * idx + 1), make_float2(prev.z, prev.w));
                 reinterpret_cast<f4 *>(yps + (size_t(ch) * K + f) * M)[idx] = f4{y0.x, y0.y, y1.x, y1.y};
-                if (f + R >= K)                             // (the ring keeps the last R frames)
-                    Rw[size_t((slot0 + 1 + f) % R) * M4 + idx] = x;
                 prev = s[f];
             }
             ytc[idx] = s[K - 1];
@@ -1514,7 +1508,7 @@ struct mi_convolver_bank
     bool        one_launch = true;  // whole-frame steps as conv_step_kernel (gfx950, not switched off) or as two launches
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
-    float2     *d_xs = nullptr, *d_yts = nullptr;       // [channels][BATCH_MAX][B]: images and tails of a batch of frames (process_blocks)
+    float2     *d_yts = nullptr;                        // [channels][BATCH_MAX][B]: what the inverse transforms of a batch of frames take (process_blocks)
     float      *d_acc_new = nullptr;                    // [channels][B]: the accumulator a batch leaves, on its way into d_acc
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
     // way a reference Equalizer object does (Equalizer.cpp:339-345,481-501): every object has a response in force (vConv),
@@ -1647,11 +1641,35 @@ namespace
                      hipStream_t st)
     {
         const size_t cells = size_t(b->channels) * BATCH_MAX * size_t(b->B);
-        if (b->d_xs == nullptr)
+        if (b->d_yts == nullptr)
         {
-            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_xs), cells * sizeof(float2)));
             MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_yts), cells * sizeof(float2)));
             MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&b->d_acc_new), size_t(b->channels) * size_t(b->B) * sizeof(float)));
+        }
+        // The frames of a batch enter the ring BEFORE their tails are formed: the ring needs room for them next to the P - 2
+        // frames those tails still take.  Grown once, at the first batch: the frames it holds move to the end of the new one.
+        if (b->R < b->P - 1 + BATCH_MAX)
+        {
+            const int newR = b->P - 1 + BATCH_MAX;
+            const size_t img = size_t(b->B) * sizeof(float2);
+            float2 *grown = nullptr;
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&grown), size_t(b->channels) * newR * img));
+            hipError_t e = hipMemsetAsync(grown, 0, size_t(b->channels) * newR * img, st);
+            for (int j = 0; e == hipSuccess && j < b->R; ++j)              // frame -1 - j: slot (slot - j) mod R -> slot newR - 1 - j
+                e = hipMemcpy2DAsync(grown + size_t(newR - 1 - j) * b->B, size_t(newR) * img,
+                                     b->d_ring + size_t(((b->slot - j) % b->R + b->R) % b->R) * b->B, size_t(b->R) * img,
+                                     img, b->channels, hipMemcpyDeviceToDevice, st);
+            if (e == hipSuccess)
+                e = hipStreamSynchronize(st);
+            if (e != hipSuccess)
+            {
+                (void)hipFree(grown);
+                MI_HIP_CHECK(e);
+            }
+            (void)hipFree(b->d_ring);
+            b->d_ring = grown;
+            b->R = newR;
+            b->slot = newR - 1;
         }
         batch_args ba;
         ba.frames = K;
@@ -1664,7 +1682,7 @@ namespace
         }
         const int M = b->B;
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_forward_kernel<LM>), dim3(b->channels, K), dim3(fplan<LM>::T), 0, st, \
-                                               ba, in_stride, aligned, b->d_xs, b->d_tw)
+                                               ba, in_stride, aligned, b->d_ring, b->R, b->slot, b->d_tw)
         switch (b->logm) { case 9: { MI_CALL(9); break; } case 10: { MI_CALL(10); break; } case 11: { MI_CALL(11); break; } default: { MI_CALL(12); break; } }
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
@@ -1673,9 +1691,9 @@ namespace
         const dim3 tgrid(M / 2 / 256, b->channels);
         static const bool keep = getenv("MI_CONV_BATCH_REREAD") == nullptr;     // experiment knob: the staged frames read twice
         #define MI_TAIL(KK) do { if (keep) MI_LAUNCH((conv_batch_tail_kernel<KK, true>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
-                                                     b->yt_pending, b->d_xs, b->d_ring, b->R, b->slot, b->d_H, b->P, M); \
+                                                     b->yt_pending, b->d_ring, b->R, b->slot, b->d_H, b->P, M); \
                                  else      MI_LAUNCH((conv_batch_tail_kernel<KK, false>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
-                                                     b->yt_pending, b->d_xs, b->d_ring, b->R, b->slot, b->d_H, b->P, M); } while (0)
+                                                     b->yt_pending, b->d_ring, b->R, b->slot, b->d_H, b->P, M); } while (0)
         switch (K) { case 2: { MI_TAIL(2); break; } case 4: { MI_TAIL(4); break; } case 8: { MI_TAIL(8); break; } default: { MI_TAIL(16); break; } }
         #undef MI_TAIL
         MI_HIP_CHECK(hipGetLastError());
@@ -2129,7 +2147,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
-    (void)hipFree(b->d_xs); (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new);
+    (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new);
     const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
     (void)hipHostFree(b->h_fault);
     delete b;
