@@ -504,10 +504,11 @@ def run_convolver(args, mi, torch, dist, rank, world, dev):
     bandwidth; the same pass over 512 channels (496 MiB, streamed from HBM with non-temporal loads) is reported next to it
     under "beyond_infinity_cache" so that the BASELINE-size fraction is not read as an HBM figure."""
     C = args.conv_channels
-    res, irs = _convolver_pass(args, mi, torch, dist, rank, world, dev, C, args.conv_steps, args.conv_warmup)
+    whole = lambda k: (k // 16) * 16 if k >= 16 else k      # (whole batches of 16 frames in a region)
+    res, irs = _convolver_pass(args, mi, torch, dist, rank, world, dev, C, whole(args.conv_steps), args.conv_warmup)
     big = None
     if C == 256:
-        big, _ = _convolver_pass(args, mi, torch, dist, rank, world, dev, 512, max(40, args.conv_steps // 2), args.conv_warmup)
+        big, _ = _convolver_pass(args, mi, torch, dist, rank, world, dev, 512, whole(max(48, args.conv_steps // 2)), args.conv_warmup)
     if rank != 0:
         return None
     stream_res = None
