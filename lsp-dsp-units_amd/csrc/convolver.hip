@@ -1510,6 +1510,7 @@ struct mi_convolver_bank
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     float2     *d_yts = nullptr;                        // [channels][BATCH_MAX][B]: what the inverse transforms of a batch of frames take (process_blocks)
     float      *d_acc_new = nullptr;                    // [channels][B]: the accumulator a batch leaves, on its way into d_acc
+    float2     *d_ring_first = nullptr;                 // the ring the bank was made with, once a batch has grown it (kept, unused)
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
     // way a reference Equalizer object does (Equalizer.cpp:339-345,481-501): every object has a response in force (vConv),
     // a cross-fade target (vNewConv) and a flag that the target waits for the block that completes next (EF_XFADE).
@@ -1666,7 +1667,8 @@ namespace
                 (void)hipFree(grown);
                 MI_HIP_CHECK(e);
             }
-            (void)hipFree(b->d_ring);
+            // (the ring of before stays allocated until the bank goes: a graph captured on it earlier must not run into freed memory)
+            b->d_ring_first = b->d_ring;
             b->d_ring = grown;
             b->R = newR;
             b->slot = newR - 1;
@@ -2147,7 +2149,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
-    (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new);
+    (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new); (void)hipFree(b->d_ring_first);
     const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
     (void)hipHostFree(b->h_fault);
     delete b;
