@@ -347,3 +347,24 @@ def test_runs_of_blocks_in_one_launch_replay(gpu):
                        lambda b, x, o, st: b.process_reduce_frames(_blocks(x, F, Ca * period), period, o[0], stream=st),
                        (F, Ca, period), [(F, bins)]), max_k=3)
     assert K == 1
+
+
+def test_convolver_bank_replays_after_a_batch_has_grown_its_ring(gpu):
+    """mi_convolver_bank_process_blocks grows the ring of frames once (room for a batch of sixteen next to the frames its tails
+    take): frame-by-frame calls captured afterwards repeat over a lap of the grown ring, bit for bit the eager calls."""
+    C, rank, taps = 3, 10, 2000                              # four partitions of 512: a ring of 3, grown to 19
+    frame = 1 << (rank - 1)
+    irs = (np.random.default_rng(8).standard_normal((C, taps)) * 0.1).astype(np.float32)
+    x0 = (np.random.default_rng(9).standard_normal((2, C, frame)) * 0.25).astype(np.float32)
+
+    def make(st):
+        b = gpu.ConvolverBank(irs, rank, stream=st)
+        ins = [gpu.DeviceBuffer.from_host(x0[k], stream=st) for k in range(2)]
+        outs = [gpu.DeviceBuffer((C, frame)) for _ in range(2)]
+        b.process_blocks(outs, ins, frame, stream=st)
+        gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+        return b
+
+    K = _run(gpu, Case("convolver after a batch", make, lambda b, x, o, st: b.process(o[0], x, frame, stream=st),
+                       (C, frame), [(C, frame)], 19), max_k=20)
+    assert K == 19
