@@ -765,8 +765,9 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         state["collective"] = "torch.distributed all_reduce (%s)" % dist.get_backend()
         if dist.get_backend() == "nccl":
             try:
-                state["comm"] = sharding.library_comm(mi)
-                state["collective"] = "mi_analyzer_bank_allreduce_bins: ncclAllReduce from the library's host side (RCCL over xGMI)"
+                state["comm"] = sharding.library_comm(mi)   # (a communicator on every rank or on none: the ranks agree inside)
+                if state["comm"] is not None:
+                    state["collective"] = "mi_analyzer_bank_allreduce_bins: ncclAllReduce from the library's host side (RCCL over xGMI)"
             except Exception as e:                          # the measurement goes on with torch's communicator
                 print("bench: library communicator refused (%s); torch.distributed all_reduce instead" % e, file=sys.stderr)
 

@@ -38,6 +38,30 @@ def library_comm(mi, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     # broadcast_object_list takes the GLOBAL rank of the source: the group's rank 0 draws the id and sends it
     src = dist.get_global_rank(group, 0) if group is not None else 0
-    box = [mi.Comm.unique_id() if rank == 0 else None]
+    # Every rank must come out of this with the same answer (a communicator on all of them or on none): a rank that went on
+    # with torch's collective while the others wait inside the library's would hang the job.
+    box = [None]
+    if rank == 0:
+        try:
+            box[0] = mi.Comm.unique_id()
+        except Exception as e:                               # the others are told: nobody joins
+            box[0] = None
+            print("library_comm: no unique id (%s)" % e)
     dist.broadcast_object_list(box, src=src, group=group)
-    return mi.Comm(box[0], world, rank)
+    if box[0] is None:
+        return None
+    comm, ok = None, 1
+    try:
+        comm = mi.Comm(box[0], world, rank)
+    except Exception as e:
+        ok = 0
+        print("library_comm: rank %d could not join (%s)" % (rank, e))
+    import torch
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    if int(flag.item()) == 0:
+        if comm is not None:
+            comm.close()
+        return None
+    return comm

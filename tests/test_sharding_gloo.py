@@ -90,3 +90,30 @@ def test_library_comm_is_none_for_one_rank():
     sharding = importlib.import_module("lsp-dsp-units_amd.sharding")
     mi = importlib.import_module("lsp-dsp-units_amd")
     assert sharding.library_comm(mi) is None
+
+
+def _comm_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    sharding = importlib.import_module("lsp-dsp-units_amd.sharding")
+    mi = importlib.import_module("lsp-dsp-units_amd")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    comm = sharding.library_comm(mi)                        # no device here: nobody can join -- and everybody must say so
+    with open(os.path.join(out_dir, "rank%d.txt" % rank), "w") as f:
+        f.write("none" if comm is None else "comm")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_library_comm_agrees_across_ranks_when_it_cannot_be_built(tmp_path):
+    """Two ranks on a box without a device: the library's communicator cannot be created -- every rank must come out of
+    sharding.library_comm with None (and out of it at all: a rank that went on alone would hang the job at its first collective)."""
+    mi = importlib.import_module("lsp-dsp-units_amd")
+    if mi.device_count() > 0:
+        pytest.skip("a device is present: the communicator would be built")
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_comm_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert [open(os.path.join(str(tmp_path), "rank%d.txt" % r)).read() for r in range(world)] == ["none", "none"]
