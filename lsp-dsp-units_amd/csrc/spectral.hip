@@ -167,13 +167,22 @@ namespace
     // samples, the gains); the second half of the frame stays in registers for the shift instead of being read again.
     // Pairs: a frame of N = 2H samples is H float2 pairs, a hop is H/2 pairs; thread t owns pairs t + i T, so pair m and
     // pair m + H/2 belong to the same thread (KPT = H / T is even: LOGH >= 7).
-    template <int LOGH, bool MASKED>
-    // (radix-8 core: <= 128 VGPRs, four waves per SIMD; radix-16 core: sixteen points and two passes of twiddles per thread,
-    //  two waves per SIMD -- a bank of 1024 channels is 2048 waves, two per SIMD, either way)
-    __global__ __launch_bounds__(fplan<LOGH>::T, fplan<LOGH>::radix16 ? 2 : (fplan<LOGH>::T <= 256) ? 4 : (fplan<LOGH>::T <= 512) ? 2 : 1)
-    void stft_stream_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in, const float *__restrict__ wnd_out,
-                            const float *__restrict__ mask, size_t mask_stride, const float2 *__restrict__ tw,
-                            const float *__restrict__ src, size_t src_stride, float *dst, size_t dst_stride, int hops)
+    // Runs of blocks (mi_spectral_bank_process_blocks): the hops of SEVERAL calls in one launch -- every block a buffer of its
+    // own, `per` hops each, the addresses in the kernel arguments.
+    constexpr int STFT_BLOCKS_MAX = 64;
+    struct stft_blocks
+    {
+        int             per;            // hops per block
+        const float    *src[STFT_BLOCKS_MAX];
+        float          *dst[STFT_BLOCKS_MAX];
+    };
+
+    template <int LOGH, bool MASKED, bool TAB>
+    __device__ __forceinline__
+    void stft_stream_body(float *in_buf, float *out_buf, const float *__restrict__ wnd_in, const float *__restrict__ wnd_out,
+                          const float *__restrict__ mask, size_t mask_stride, const float2 *__restrict__ tw,
+                          const float *__restrict__ src, size_t src_stride, float *dst, size_t dst_stride, int hops,
+                          const stft_blocks *tab)
     {
         // `hops` consecutive hops of the call in ONE launch (round 3): between two hops nothing goes through memory -- the second
         // half of the frame and the caller's samples that complete the next frame are in registers already, and so is the tail
@@ -192,8 +201,21 @@ namespace
         float2 *o2 = reinterpret_cast<float2 *>(out_buf + size_t(ch) * N);
         const float2 *wi = reinterpret_cast<const float2 *>(wnd_in);
         const float2 *wo = reinterpret_cast<const float2 *>(wnd_out);
-        const float2 *s2 = reinterpret_cast<const float2 *>(src + size_t(ch) * src_stride);
-        float2 *d2 = reinterpret_cast<float2 *>(dst + size_t(ch) * dst_stride);
+        const float2 *s2 = TAB ? nullptr : reinterpret_cast<const float2 *>(src + size_t(ch) * src_stride);
+        float2 *d2 = TAB ? nullptr : reinterpret_cast<float2 *>(dst + size_t(ch) * dst_stride);
+        // the caller's samples of hop q / where hop q's finished frame goes (TAB: block q / per of the run, hop q % per inside it)
+        auto src_hop = [&](int q) -> const float2 * {
+            if (!TAB)
+                return s2 + q * (H / 2);
+            const int k = q / tab->per;
+            return reinterpret_cast<const float2 *>(tab->src[k] + size_t(ch) * src_stride) + (q - k * tab->per) * (H / 2);
+        };
+        auto dst_hop = [&](int q) -> float2 * {
+            if (!TAB)
+                return d2 + q * (H / 2);
+            const int k = q / tab->per;
+            return reinterpret_cast<float2 *>(tab->dst[k] + size_t(ch) * dst_stride) + (q - k * tab->per) * (H / 2);
+        };
         // live across the transforms: the half of the frame that the next hop starts with and the pending tail (the twiddles take
         // most of the rest of the 128 registers: a spill to scratch costs this kernel a factor of three); everything else is
         // read where it is used -- the frame's new half from the caller's block, windows and gains from L2
@@ -227,9 +249,10 @@ namespace
             asm volatile("" : "+v"(tix));
             if (h > 0)                                                      // frame h = [second half of frame h - 1 | caller's samples h - 1]
             {
+                const float2 *sh = src_hop(h - 1);
                 #pragma unroll
                 for (int i = 0; i < HPT; ++i)
-                    hi[i] = s2[(h - 1) * (H / 2) + tix + i * T];
+                    hi[i] = sh[tix + i * T];
             }
             // 512 .. 8192-point transforms take the windowed frame in registers and hand the result back in registers (fft_lds
             // REG_IN / REG_OUT: pair tix + i T is exactly what thread tix's first butterfly reads and its last one writes),
@@ -286,6 +309,8 @@ namespace
                 }
             }
             const bool last = (h + 1 == hops);
+            float2 *const dh = dst_hop(h);
+            const float2 *const sl = last ? src_hop(h) : nullptr;
             #pragma unroll
             for (int i = 0; i < HPT; ++i)
             {
@@ -294,18 +319,38 @@ namespace
                 const v2f y0 = io[i], y1 = io[i + HPT];
                 const float2 done = make_float2(fmaf(y0.x * scale, w0.x, prev[i].x), fmaf(y0.y * scale, w0.y, prev[i].y));
                 prev[i] = make_float2(y1.x * scale * w1.x, y1.y * scale * w1.y);     // the tail the next hop adds to
-                d2[h * (H / 2) + m] = done;                                 // the finished frame, straight to the caller
+                dh[m] = done;                                               // the finished frame, straight to the caller
                 if (last)                                                   // the object's state as the call leaves it
                 {
                     o2[m]         = done;
                     o2[m + H / 2] = prev[i];
                     x2[m]         = lo[i];
-                    x2[m + H / 2] = s2[h * (H / 2) + m];
+                    x2[m + H / 2] = sl[m];
                 }
             }
             if (!last)
                 __syncthreads();                                            // buf is refilled by the next hop
         }
+    }
+
+    template <int LOGH, bool MASKED>
+    // (radix-8 core: <= 128 VGPRs, four waves per SIMD; radix-16 core: sixteen points and two passes of twiddles per thread,
+    //  two waves per SIMD -- a bank of 1024 channels is 2048 waves, two per SIMD, either way)
+    __global__ __launch_bounds__(fplan<LOGH>::T, fplan<LOGH>::radix16 ? 2 : (fplan<LOGH>::T <= 256) ? 4 : (fplan<LOGH>::T <= 512) ? 2 : 1)
+    void stft_stream_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in, const float *__restrict__ wnd_out,
+                            const float *__restrict__ mask, size_t mask_stride, const float2 *__restrict__ tw,
+                            const float *__restrict__ src, size_t src_stride, float *dst, size_t dst_stride, int hops)
+    {
+        stft_stream_body<LOGH, MASKED, false>(in_buf, out_buf, wnd_in, wnd_out, mask, mask_stride, tw, src, src_stride, dst, dst_stride, hops, nullptr);
+    }
+
+    template <int LOGH, bool MASKED>
+    __global__ __launch_bounds__(fplan<LOGH>::T, fplan<LOGH>::radix16 ? 2 : (fplan<LOGH>::T <= 256) ? 4 : (fplan<LOGH>::T <= 512) ? 2 : 1)
+    void stft_stream_blocks_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in, const float *__restrict__ wnd_out,
+                                   const float *__restrict__ mask, size_t mask_stride, const float2 *__restrict__ tw,
+                                   const stft_blocks tab, size_t src_stride, size_t dst_stride, int hops)
+    {
+        stft_stream_body<LOGH, MASKED, true>(in_buf, out_buf, wnd_in, wnd_out, mask, mask_stride, tw, nullptr, src_stride, nullptr, dst_stride, hops, &tab);
     }
 
     // CALLBACK path, second half.  The function may have broken the Hermitian symmetry of the spectrum and only the real
@@ -1511,8 +1556,14 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             const bool plain = (b->op == MI_SPECTRAL_OP_NONE) || !bound, masked = bound && (b->op == MI_SPECTRAL_OP_MASK);
             const bool aligned = ((reinterpret_cast<uintptr_t>(in + done) | reinterpret_cast<uintptr_t>(out + done)) % 8 == 0) &&
                                  (in_stride % 2 == 0) && (out_stride % 2 == 0);
+            // (the stream launch hands a finished frame to the caller BEFORE it takes the caller's samples at the same place:
+            // a call whose output rows overlap its input rows -- in place, SpectralProcessor.cpp:188-189 copies in before it
+            // copies out -- keeps the hop and the two copies)
+            const uintptr_t o0 = reinterpret_cast<uintptr_t>(out), i0 = reinterpret_cast<uintptr_t>(in);
+            const bool apart = out == nullptr || o0 + ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float) <= i0 ||
+                               i0 + ((size_t(b->channels) - 1) * in_stride + count) * sizeof(float) <= o0;
             if (!no_stream && out != nullptr && (plain || masked) && b->rank >= 8 && b->rank <= 13 && count - done >= frame && aligned &&
-                b->d_active == nullptr)
+                b->d_active == nullptr && apart)
             {
                 const int lh = int(b->rank) - 1;
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1541,9 +1592,13 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
         const size_t n = (count - done < frame - b->offset) ? count - done : frame - b->offset;
         // MultiSpectralProcessor's timing, a bound function and a whole frame in this piece: the hand-out of the finished frame
         // and the intake of the new one ride on the hop's first launch instead of two strided copies
+        // (rows that lie apart only: see above)
+        const uintptr_t eo0 = reinterpret_cast<uintptr_t>(out), ei0 = reinterpret_cast<uintptr_t>(in);
+        const bool rows_apart = out == nullptr || eo0 + ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float) <= ei0 ||
+                                ei0 + ((size_t(b->channels) - 1) * in_stride + count) * sizeof(float) <= eo0;
         if (b->eager && b->offset == 0 && n == frame && out != nullptr && b->op == MI_SPECTRAL_OP_CALLBACK && b->func != nullptr &&
             b->rank <= 14 && (reinterpret_cast<uintptr_t>(in + done) | reinterpret_cast<uintptr_t>(out + done)) % 8 == 0 &&
-            in_stride % 2 == 0 && out_stride % 2 == 0)
+            in_stride % 2 == 0 && out_stride % 2 == 0 && rows_apart)
         {
             static const bool no_stream = getenv("MI_SPECTRAL_NO_STREAM") != nullptr;
             if (!no_stream)

@@ -731,3 +731,30 @@ def test_library_communicator_single_rank(gpu):
     np.testing.assert_array_equal(sums.download(), np.tile(row, (frames, 1)))
     comm.close()
     bank.close()
+
+
+@pytest.mark.parametrize("rank,masked", [(8, True), (9, False), (11, True), (12, True)])
+def test_spectral_bank_in_place_equals_out_of_place(gpu, rank, masked):
+    """SpectralProcessor::process(dst, src, count) takes the caller's samples before it hands out the finished ones at the same
+    place (SpectralProcessor.cpp:188-189: copy in, then copy out): dst may be src.  Calls of several hops, of one hop and of odd
+    sizes, in place, give the samples of the same calls with separate buffers."""
+    rng = np.random.default_rng(300 + rank)
+    C, frame = 3, 1 << (rank - 1)
+    sizes = [4 * frame, frame, 3 * frame + 17, frame - 17, 2 * frame, 5, 2 * frame - 5]
+    x = [(rng.standard_normal((C, n)) * 0.25).astype(np.float32) for n in sizes]
+    res = []
+    for in_place in (False, True):
+        sp = gpu.SpectralBank(C, rank)
+        sp.set_rank(rank)
+        if masked:
+            sp.bind_mask(np.linspace(1.0, 0.25, frame + 1).astype(np.float32))
+        ys = []
+        for xi in x:
+            d = gpu.DeviceBuffer.from_host(xi)
+            o = d if in_place else gpu.DeviceBuffer(xi.shape)
+            sp.process(o, d, xi.shape[1])
+            ys.append(o.download())
+        res.append(np.concatenate(ys, axis=1))
+        sp.close()
+    assert np.abs(res[0]).max() > 1e-3
+    np.testing.assert_array_equal(res[1], res[0])
