@@ -749,7 +749,8 @@ int mi_splitter_bank_bind_callback(mi_splitter_bank_t *bank, uint32_t handler, m
 int mi_splitter_bank_unbind(mi_splitter_bank_t *bank, uint32_t handler);
 int mi_splitter_bank_clear(mi_splitter_bank_t *bank, void *stream);                /* SpectralSplitter.cpp:246-258 */
 /* process(src, count), :295-361.  in: [channels][in_stride] or NULL (silence); outs: HOST array of `handlers` device
- * pointers, each [channels][out_stride] or NULL (no sink). */
+ * pointers, each [channels][out_stride] or NULL (no sink).  An output buffer must not overlap the input rows (MI_EINVAL): the
+ * reference hands bands to sink functions, never back into the block being read. */
 int mi_splitter_bank_process(mi_splitter_bank_t *bank, float *const *outs, const float *in, size_t count, size_t out_stride,
                              size_t in_stride, void *stream);
 

@@ -1029,6 +1029,20 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
     }
     if (b->bindings == 0 || count == 0)                                // SpectralSplitter.cpp:299-300
         return MI_OK;
+    // The reference hands its bands to sink functions (SpectralSplitter.cpp:344-356): a band cannot be the block it reads.  Here
+    // the bands are buffers, and the kernels write a band's finished samples before they take the caller's samples of the
+    // same place: an output row that overlaps the input rows is refused rather than filled with something else.
+    if (in != nullptr && outs != nullptr)
+    {
+        const uintptr_t i0 = reinterpret_cast<uintptr_t>(in), in_bytes = ((size_t(b->channels) - 1) * in_stride + count) * sizeof(float);
+        const uintptr_t out_bytes = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float);
+        for (uint32_t i = 0; i < b->handlers; ++i)
+        {
+            const uintptr_t o0 = reinterpret_cast<uintptr_t>(outs[i]);
+            MI_REQUIRE(outs[i] == nullptr || o0 + out_bytes <= i0 || i0 + in_bytes <= o0, MI_EINVAL,
+                       "mi_splitter_bank_process: the output rows of handler %u overlap the input rows", i);
+        }
+    }
     // who listens: a handler whose output pointer is NULL has no sink
     bool outs_changed = false;
     for (uint32_t i = 0; i < b->handlers; ++i)

@@ -416,3 +416,23 @@ def test_random_operation_sequences_match_oracle(gpu, seed):
                 s.clear()
         log.append(str(op))
     bank.close()
+
+
+def test_an_output_that_overlaps_the_input_is_refused(gpu):
+    """The bands are buffers here (sink functions in the reference, SpectralSplitter.cpp:344-356): an output row that overlaps the
+    input rows is refused (MI_EINVAL) instead of being filled with something else; the bank goes on with the next proper call."""
+    C, rank, n = 2, 9, 1024
+    sp = gpu.SplitterBank(C, rank, 2)
+    sp.bind_copy(0)
+    sp.bind_copy(1)
+    x = (np.random.default_rng(4).standard_normal((C, n)) * 0.25).astype(np.float32)
+    din = gpu.DeviceBuffer.from_host(x)
+    other = gpu.DeviceBuffer((C, n))
+    with pytest.raises(gpu.MiError):
+        sp.process([din, other], din, n)
+    with pytest.raises(gpu.MiError):
+        sp.process([other, din.ptr + 64], din, n - 16, out_stride=n, in_stride=n)
+    a, b2 = gpu.DeviceBuffer((C, n)), gpu.DeviceBuffer((C, n))
+    sp.process([a, b2], din, n)
+    assert np.isfinite(a.download()).all()
+    sp.close()
