@@ -851,14 +851,25 @@ def run_spectral_processor(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         sp.process(yout[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    K = args.conv_steps
+
+    def region():                                           # the K blocks of a region as ONE library call (runs of 64 per launch)
+        sp.process_blocks([yout[(args.conv_warmup + i) % ring] for i in range(K)],
+                          [xin[(args.conv_warmup + i) % ring] for i in range(K)], n, stream=stream)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, profile=False, region=region)
+    pc_elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, profile=False)
     assert bool(torch.isfinite(yout).all()) and float(yout.abs().max()) > 0.0
     sp.close()
     if rank != 0:
         return None
     return _step_result("spectral_processor", "SpectralProcessor with a gain mask, rank 12, %d channels per GPU, 4096-sample blocks "
-                        "(two hops: one launch each -- transform, gains, inverse, overlap-add, emission and intake fused)" % C,
-                        C, n, args.conv_steps, elapsed, world, 8.0)
+                        "(two hops each: transform, gains, inverse, overlap-add, emission and intake fused)" % C,
+                        C, n, K, elapsed, world, 8.0,
+                        {"call": "one mi_spectral_bank_process_blocks call per region: runs of 64 blocks ride stft_stream_blocks_kernel, "
+                                 "bit-identical to %d process() calls" % K,
+                         "per_call": {"what": "the same blocks as separate mi_spectral_bank_process calls (one launch of stft_stream_kernel per block)",
+                                      "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),
+                                      "whole_step_frac": round(8.0 * C * n / (pc_elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)}})
 
 
 def _step_result(name, workload, C, n, steps, elapsed, world, bytes_per_sample, extra=None):

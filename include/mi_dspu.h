@@ -447,6 +447,13 @@ int mi_spectral_bank_reset(mi_spectral_bank_t *bank, void *stream);
  * MultiSpectralProcessor's timing); anything else adds two strided copies per piece. */
 int mi_spectral_bank_process(mi_spectral_bank_t *bank, float *out, const float *in, size_t count,
                              size_t out_stride, size_t in_stride, void *stream);
+/*
+ * `blocks` consecutive mi_spectral_bank_process calls in one C call (SpectralProcessor.cpp:143-199 per block): block k reads
+ * in[k] and writes out[k] (HOST tables of DEVICE pointers).  Runs of blocks of whole frames whose buffers lie apart go out as
+ * one launch; the samples and the state are those of the calls one by one.
+ */
+int mi_spectral_bank_process_blocks(mi_spectral_bank_t *bank, float *const *out, const float *const *in, size_t blocks,
+                                    size_t count, size_t out_stride, size_t in_stride, void *stream);
 /* When a complete frame is transformed: eager == 0 (default) when the next sample arrives, as SpectralProcessor does
  * (SpectralProcessor.cpp:159: remaining() can read 0, the function runs at the start of the following call); eager != 0
  * as soon as the frame is complete, as MultiSpectralProcessor does (MultiSpectralProcessor.cpp:324). */

@@ -124,6 +124,7 @@ PROTOTYPES = {
     "mi_spectral_bank_bind_channels": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
     "mi_spectral_bank_reset": (c_int, [c_void_p, c_void_p]),
     "mi_spectral_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_spectral_bank_process_blocks": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_spectral_bank_set_timing": (c_int, [c_void_p, c_int]),
     "mi_analyzer_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32, c_uint32, c_float, c_uint32]),
     "mi_analyzer_bank_destroy": (c_int, [c_void_p]),

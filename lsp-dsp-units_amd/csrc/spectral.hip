@@ -1631,6 +1631,100 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
     return MI_OK;
 }
 
+// `blocks` consecutive process() calls in one C call (SpectralProcessor.cpp:143-199 per block).  Runs of blocks of whole frames
+// whose buffers lie apart go out as ONE launch (stft_stream_blocks_kernel: between two hops nothing goes through memory, whichever
+// block they belong to) -- the samples and the state of the calls one by one.
+int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, const float *const *in, size_t blocks, size_t count,
+                                    size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_process_blocks: NULL bank");
+    if (count == 0 || blocks == 0)
+        return MI_OK;
+    MI_REQUIRE(out != nullptr && in != nullptr, MI_EINVAL, "mi_spectral_bank_process_blocks: NULL pointer table");
+    for (size_t k = 0; k < blocks; ++k)
+        MI_REQUIRE(in[k] != nullptr, MI_EINVAL, "mi_spectral_bank_process_blocks: NULL input of block %zu", k);
+    hipStream_t st = mi::as_stream(stream);
+    auto one_by_one = [&](size_t first, size_t n) -> int {
+        for (size_t k = first; k < first + n; ++k)
+        {
+            const int r = mi_spectral_bank_process(b, out[k], in[k], count, out_stride, in_stride, stream);
+            if (r != MI_OK)
+                return r;
+        }
+        return MI_OK;
+    };
+    static const bool per_block = getenv("MI_SPECTRAL_NO_STREAM") != nullptr || getenv("MI_SPECTRAL_ONE_HOP") != nullptr;
+    size_t k = 0;
+    while (k < blocks)
+    {
+        {
+            const int rc = mi::capture_touch(st, b, "spectral processor", mi::spectral_bank_positions);
+            if (rc != MI_OK)
+                return rc;
+        }
+        if (b->update)
+        {
+            const int r = spectral_apply_settings(b, st);
+            if (r != MI_OK)
+                return r;
+        }
+        const size_t N = size_t(1) << b->rank, frame = N >> 1;
+        const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
+        const bool plain = (b->op == MI_SPECTRAL_OP_NONE) || !bound, masked = bound && (b->op == MI_SPECTRAL_OP_MASK);
+        const bool steady = !per_block && !b->eager && b->offset == frame && (plain || masked) && b->rank >= 8 && b->rank <= 13 &&
+                            (count % frame) == 0 && (in_stride % 2) == 0 && (out_stride % 2) == 0 && b->d_active == nullptr;
+        size_t run = 0;
+        if (steady)
+        {
+            const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float), ib = ((size_t(b->channels) - 1) * in_stride + count) * sizeof(float);
+            auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
+                const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+                return a0 < b0 + qn && b0 < a0 + pn;
+            };
+            while (k + run < blocks && run < size_t(STFT_BLOCKS_MAX))
+            {
+                const size_t j = k + run;
+                bool ok = out[j] != nullptr && ((reinterpret_cast<uintptr_t>(out[j]) | reinterpret_cast<uintptr_t>(in[j])) % 8) == 0;
+                for (size_t i = k; ok && i <= j; ++i)       // nothing the run writes is read by it (its own rows included)
+                    ok = !overlap(out[i], ob, in[j], ib) && !overlap(out[j], ob, in[i], ib);
+                if (!ok)
+                    break;
+                ++run;
+            }
+        }
+        if (run < 2)
+        {
+            const int r = one_by_one(k, 1);
+            if (r != MI_OK)
+                return r;
+            ++k;
+            continue;
+        }
+        stft_blocks tab;
+        tab.per = int(count / frame);
+        for (size_t i = 0; i < run; ++i)
+        {
+            tab.src[i] = in[k + i];
+            tab.dst[i] = out[k + i];
+        }
+        const int hops = int(run) * tab.per, lh = int(b->rank) - 1;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
+        #define MI_CALL(LH) \
+            if (masked) MI_LAUNCH((stft_stream_blocks_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), true>), dim3(b->channels), dim3(fplan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
+                                  b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->mask_stride, b->d_tw, tab, in_stride, out_stride, hops); \
+            else        MI_LAUNCH((stft_stream_blocks_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), false>), dim3(b->channels), dim3(fplan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
+                                  b->d_in, b->d_out, wi, b->d_wnd_out, (const float *)nullptr, size_t(0), b->d_tw, tab, in_stride, out_stride, hops)
+        MI_LOGH_SWITCH(lh, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        b->offset = uint32_t(frame);
+        k += run;
+    }
+    return MI_OK;
+}
+
 int mi_spectral_bank_set_timing(mi_spectral_bank_t *b, int eager)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_spectral_bank_set_timing: NULL bank");

@@ -305,6 +305,16 @@ class SpectralBank:
                                            count if out_stride is None else out_stride,
                                            count if in_stride is None else in_stride, _stream(stream)))
 
+    def process_blocks(self, outs, inps, count, out_stride=None, in_stride=None, stream=None):
+        """len(outs) consecutive process() calls issued by one C call (mi_spectral_bank_process_blocks)."""
+        n = len(outs)
+        assert n == len(inps)
+        po = (c_void_p * n)(*[(_ptr(b) if b is not None else None) for b in outs])
+        pi = (c_void_p * n)(*[_ptr(b) for b in inps])
+        check(lib.mi_spectral_bank_process_blocks(self.handle, po, pi, n, count,
+                                                  count if out_stride is None else out_stride,
+                                                  count if in_stride is None else in_stride, _stream(stream)))
+
     def close(self):
         if self.handle:
             lib.mi_spectral_bank_destroy(self.handle)

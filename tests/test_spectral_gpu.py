@@ -758,3 +758,49 @@ def test_spectral_bank_in_place_equals_out_of_place(gpu, rank, masked):
         sp.close()
     assert np.abs(res[0]).max() > 1e-3
     np.testing.assert_array_equal(res[1], res[0])
+
+
+@pytest.mark.parametrize("rank,masked,n_frames,K", [(12, True, 2, 5), (9, True, 1, 7), (10, False, 3, 4), (11, True, 2, 70), (8, True, 4, 3)])
+def test_spectral_process_blocks_equal_block_by_block(gpu, rank, masked, n_frames, K):
+    """mi_spectral_bank_process_blocks: K blocks of whole frames as ONE launch (stft_stream_blocks_kernel; 70 blocks: two) against
+    K process() calls on a twin bank -- bit for bit, and the state left behind (a further odd-sized call and a block through
+    both).  Blocks that are not whole frames, or that overlap, are plain loops of calls."""
+    rng = np.random.default_rng(700 + rank + K)
+    C, frame = 3, 1 << (rank - 1)
+    n = n_frames * frame
+    x = (rng.standard_normal((K + 2, C, n)) * 0.25).astype(np.float32)
+
+    def make():
+        sp = gpu.SpectralBank(C, rank)
+        sp.set_rank(rank)
+        if masked:
+            sp.bind_mask(np.linspace(1.0, 0.25, frame + 1).astype(np.float32))
+        return sp
+    a, b = make(), make()
+    ins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K + 2)]
+    oa = [gpu.DeviceBuffer((C, n)) for _ in range(K + 2)]
+    ob = [gpu.DeviceBuffer((C, n)) for _ in range(K + 2)]
+    a.process(oa[0], ins[0], n)                              # the steady state: a frame is in hand
+    a.process_blocks(oa[1:K + 1], ins[1:K + 1], n)
+    a.process(oa[K + 1], ins[K + 1], n - 37, n, n)
+    for k in range(K + 1):
+        b.process(ob[k], ins[k], n)
+    b.process(ob[K + 1], ins[K + 1], n - 37, n, n)
+    for k in range(K + 1):
+        ya, yb = oa[k].download(), ob[k].download()
+        assert k == 0 or np.abs(yb).max() > 1e-3
+        np.testing.assert_array_equal(ya, yb, err_msg="block %d" % k)
+    np.testing.assert_array_equal(oa[K + 1].download()[:, :n - 37], ob[K + 1].download()[:, :n - 37])
+    # from a fresh bank (no frame in hand yet), with odd block sizes, in place: the loop of calls
+    c, d = make(), make()
+    m = frame + 5
+    xs = [(rng.standard_normal((C, m)) * 0.25).astype(np.float32) for _ in range(3)]
+    bc = [gpu.DeviceBuffer.from_host(v) for v in xs]
+    bd = [gpu.DeviceBuffer.from_host(v) for v in xs]
+    c.process_blocks(bc, bc, m)
+    for v in bd:
+        d.process(v, v, m)
+    for u, v in zip(bc, bd):
+        np.testing.assert_array_equal(u.download(), v.download())
+    for bank in (a, b, c, d):
+        bank.close()
