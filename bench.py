@@ -938,7 +938,13 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
 
     def step(i):
         sp.process(outs[i % ring], xin[i % ring], n, stream=stream)
-    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, args.conv_steps, args.conv_warmup, profile=False)
+    K = args.conv_steps
+
+    def region():                                           # the K blocks of a region as ONE library call (runs of 64 per launch)
+        sp.process_blocks([outs[(args.conv_warmup + i) % ring] for i in range(K)],
+                          [xin[(args.conv_warmup + i) % ring] for i in range(K)], n, stream=stream)
+    elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, profile=False, region=region)
+    pc_elapsed, _, _ = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, profile=False)
     assert all(bool(torch.isfinite(o).all()) for o in outs[0])
     sp.close()
     if rank != 0:
@@ -946,7 +952,12 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
     return _step_result("splitter", "FFTCrossover / SpectralSplitter, rank 12, 4 bands, %d channels per GPU, 4096-sample "
                         "blocks (algorithmically two transforms of 4096 points forward and eight back per channel and step; the "
                         "launch runs one workgroup per channel and band, each with its own forward transform)" % C,
-                        C, n, args.conv_steps, elapsed, world, 20.0)
+                        C, n, K, elapsed, world, 20.0,
+                        {"call": "one mi_splitter_bank_process_blocks call per region: runs of 64 blocks ride splitter_hops_blocks_kernel, "
+                                 "bit-identical to %d process() calls" % K,
+                         "per_call": {"what": "the same blocks as separate mi_splitter_bank_process calls (one launch of splitter_hop_kernel per block)",
+                                      "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),
+                                      "whole_step_frac": round(20.0 * C * n / (pc_elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)}})
 
 
 def run_loudness(args, mi, torch, dist, rank, world, dev):

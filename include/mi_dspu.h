@@ -760,6 +760,14 @@ int mi_splitter_bank_clear(mi_splitter_bank_t *bank, void *stream);             
  * reference hands bands to sink functions, never back into the block being read. */
 int mi_splitter_bank_process(mi_splitter_bank_t *bank, float *const *outs, const float *in, size_t count, size_t out_stride,
                              size_t in_stride, void *stream);
+/*
+ * `blocks` consecutive mi_splitter_bank_process calls in one C call (SpectralSplitter.cpp:295-361 per block): block k reads
+ * in[k] and hands band i to outs[k * handlers + i] (HOST tables of DEVICE pointers; a band is NULL in every block of a run
+ * or in none).  Runs of blocks of whole frames go out as one launch where the several-hops kernel applies; the samples and
+ * the state are those of the calls one by one.
+ */
+int mi_splitter_bank_process_blocks(mi_splitter_bank_t *bank, float *const *outs, const float *const *in, size_t blocks,
+                                    size_t count, size_t out_stride, size_t in_stride, void *stream);
 
 /*
  * crossover::* of misc/fft_crossover.h:47-154 (src/main/misc/fft_crossover.cpp): magnitude of the FFT crossover's high-

@@ -185,6 +185,7 @@ PROTOTYPES = {
     "mi_splitter_bank_unbind": (c_int, [c_void_p, c_uint32]),
     "mi_splitter_bank_clear": (c_int, [c_void_p, c_void_p]),
     "mi_splitter_bank_process": (c_int, [c_void_p, POINTER(c_void_p), c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),
+    "mi_splitter_bank_process_blocks": (c_int, [c_void_p, POINTER(c_void_p), POINTER(c_void_p), c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]),
     "mi_crossover_hipass": (c_float, [c_float, c_float, c_float]),
     "mi_crossover_lopass": (c_float, [c_float, c_float, c_float]),
     "mi_crossover_hipass_set": (None, [POINTER(c_float), POINTER(c_float), c_float, c_float, c_size_t]),

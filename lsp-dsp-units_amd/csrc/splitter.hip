@@ -94,14 +94,26 @@ namespace
     // SIMD (128 VGPRs) -- 1024 workgroups of 256 threads are then ONE round on the device; left to itself the compiler
     // lands on either side of that line from one change of the source to the next (102 / 135 / 146 VGPRs seen: 30 against
     // 36 us per block).
-    template <int LOGH, bool WRITE_SPEC, bool PER_BAND, int MULTI = 0>
-    __global__ __launch_bounds__(fplan<LOGH>::T, (PER_BAND && MULTI <= 1) ? 4 : (MULTI == 2) ? 2 : 1)
-    void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
-                             uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
-                             const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
-                             const float *src, size_t src_stride, uint32_t ingest_n, const out_table outs,
-                             size_t out_stride, size_t out_pos, uint32_t hops /* > 1: that many hops of a streaming call at once */)
+    // Runs of blocks (mi_splitter_bank_process_blocks): the hops of SEVERAL calls in one launch -- every block a buffer of its
+    // own (and a set of output buffers of its own), `per` hops each, the addresses in the kernel arguments.
+    constexpr uint32_t SPLIT_BLOCKS_MAX = 64, SPLIT_PTRS_MAX = 256;
+    struct split_blocks
     {
+        uint32_t        per;                    // hops per block
+        const float    *src[SPLIT_BLOCKS_MAX];
+        float          *out[SPLIT_PTRS_MAX];    // [block * handlers + handler]
+    };
+
+    template <int LOGH, bool WRITE_SPEC, bool PER_BAND, int MULTI, bool TAB>
+    __device__ __forceinline__
+    void splitter_hop_body(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
+                           uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
+                           const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
+                           const float *src, size_t src_stride, uint32_t ingest_n, const out_table &outs,
+                           size_t out_stride, size_t out_pos, uint32_t hops /* > 1: that many hops of a streaming call at once */,
+                           const split_blocks *tab)
+    {
+        static_assert(!TAB || MULTI > 0, "runs of blocks: the several-hops form");
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, PER = (H + T - 1) / T;
         __shared__ float2 lds_[fplan<LOGH>::LDS];
@@ -164,12 +176,24 @@ namespace
             }
             if (ingest_n > 0)
             {
-                const float *sx = (src != nullptr) ? src + size_t(ch) * src_stride : nullptr;
+                // the caller's `frame` samples behind hop q (TAB: block q / per of the run, hop q % per inside it)
+                auto hop_src = [&](uint32_t q) -> const float * {
+                    if (TAB)
+                    {
+                        const uint32_t k = q / tab->per;
+                        return tab->src[k] + size_t(ch) * src_stride + size_t(q - k * tab->per) * frame;
+                    }
+                    return (src != nullptr) ? src + size_t(ch) * src_stride + size_t(q) * frame : nullptr;
+                };
+                const float *s1 = hop_src(hops - 1);
                 for (uint32_t i = tid; i < ingest_n; i += T)
-                    nx[N - frame + i] = (sx != nullptr) ? sx[size_t(hops - 1) * frame + i] : 0.0f;
+                    nx[N - frame + i] = (s1 != nullptr) ? s1[i] : 0.0f;
                 if (hops > 1)                               // (frame == N / 2 then) the buffer after the last hop: the call's last two blocks
+                {
+                    const float *s0 = hop_src(hops - 2);
                     for (uint32_t i = tid; i < frame; i += T)
-                        nx[i] = (sx != nullptr) ? sx[size_t(hops - 2) * frame + i] : 0.0f;
+                        nx[i] = (s0 != nullptr) ? s0[i] : 0.0f;
+                }
             }
         }
         if (!masks)
@@ -234,6 +258,25 @@ namespace
                     uint64_t wp = one(wnd);
                     for (uint32_t hop = 0; hop < hops; ++hop)
                     {
+                        // TAB: hop `hop` of the run is hop `jh` of block `blk`; at a block's first hop the addresses of its
+                        // input rows and of the handlers' output rows are taken from the table
+                        uint32_t jh = hop;
+                        if (TAB)
+                        {
+                            const uint32_t blk = hop / tab->per;
+                            jh = hop - blk * tab->per;
+                            if (jh == 0)
+                            {
+                                sp = one(tab->src[blk] + size_t(ch) * src_stride);
+                                #pragma unroll
+                                for (int b = 0; b < MULTI; ++b)
+                                {
+                                    const uint32_t hh = on[b] ? h0 + b : h0;
+                                    float *o = tab->out[blk * handlers + hh];
+                                    ep[b] = one((o != nullptr) ? o + size_t(ch) * out_stride : nullptr);
+                                }
+                            }
+                        }
                         // (what does not change from hop to hop is laundered once per hop: hoisted out of the loop its loads
                         // would be kept across the transforms and spill the twiddles, spectral.hip's stft_stream_kernel)
                         asm volatile("" : "+s"(sp), "+s"(wp));
@@ -248,7 +291,7 @@ namespace
                             io[i] = v2f{lo[i].x, lo[i].y};
                             io[i + PER / 2] = v2f{hi[i].x, hi[i].y};
                             lo[i] = hi[i];                              // the frame moves on by half
-                            const v2f nx = (sp != 0) ? s2[size_t(hop) * hp + tix + i * T] : v2f{0.0f, 0.0f};
+                            const v2f nx = (sp != 0) ? s2[size_t(jh) * hp + tix + i * T] : v2f{0.0f, 0.0f};
                             hi[i] = make_float2(nx.x, nx.y);
                         }
                         mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tix, io);
@@ -276,8 +319,8 @@ namespace
                                     reinterpret_cast<gwv2f *>(lp[b])[m] = v2f{done.x, done.y};
                                 if (ep[b] != 0)
                                 {
-                                    emit[size_t(hop) * frame + 2 * m]     = done.x;
-                                    emit[size_t(hop) * frame + 2 * m + 1] = done.y;
+                                    emit[size_t(jh) * frame + 2 * m]     = done.x;
+                                    emit[size_t(jh) * frame + 2 * m + 1] = done.y;
                                 }
                             }
                         }
@@ -411,6 +454,34 @@ namespace
             const uint32_t first = uint32_t(H) - frame;                // the last 2*frame samples, in pairs
             overlap_add(line, w2, frame, tid, T, scale, emit, [&](uint32_t m) { return buf[first + m]; });
         }
+    }
+
+    template <int LOGH, bool WRITE_SPEC, bool PER_BAND, int MULTI = 0>
+    __global__ __launch_bounds__(fplan<LOGH>::T, (PER_BAND && MULTI <= 1) ? 4 : (MULTI == 2) ? 2 : 1)
+    void splitter_hop_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
+                             uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
+                             const float *__restrict__ wnd, uint32_t frame, float2 *spec, const float2 *__restrict__ tw,
+                             const float *src, size_t src_stride, uint32_t ingest_n, const out_table outs,
+                             size_t out_stride, size_t out_pos, uint32_t hops /* > 1: that many hops of a streaming call at once */)
+    {
+        splitter_hop_body<LOGH, WRITE_SPEC, PER_BAND, MULTI, false>(in_cur, in_next, in_pitch, lines, line_pitch, channels, hd, handlers, wnd,
+                                                                   frame, spec, tw, src, src_stride, ingest_n, outs, out_stride, out_pos, hops, nullptr);
+    }
+
+    // the several-hops form over a run of blocks, one handler per workgroup
+    template <int LOGH>
+    __global__ __launch_bounds__(fplan<LOGH>::T, 4)
+    void splitter_hops_blocks_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
+                                     uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
+                                     const float *__restrict__ wnd, uint32_t frame, const float2 *__restrict__ tw,
+                                     size_t src_stride, size_t out_stride, uint32_t hops, const split_blocks tab)
+    {
+        out_table none;
+        for (uint32_t i = 0; i < OUTS_BY_VALUE; ++i)
+            none.p[i] = tab.out[i < handlers ? i : 0];      // (the first block's rows: what tells "somebody listens" from "nobody")
+        none.more = nullptr;
+        splitter_hop_body<LOGH, false, true, 1, true>(in_cur, in_next, in_pitch, lines, line_pitch, channels, hd, handlers, wnd, frame,
+                                                      nullptr, tw, tab.src[0], src_stride, frame, none, out_stride, 0, hops, &tab);
     }
 
     // CALLBACK handlers: only the real part of the inverse of what the function left in `spec` is kept (pcomplex_c2r),
@@ -1011,6 +1082,41 @@ static uint64_t splitter_bank_positions(const void *bank)
     return mi::position_mix(h, (uint64_t(b->update) << 1) | uint64_t(b->desc_dirty));
 }
 
+// who listens: a handler whose output pointer is NULL has no sink (the descriptors on the device follow)
+static int splitter_listeners(mi_splitter_bank_t *b, float *const *outs, hipStream_t st)
+{
+    bool outs_changed = false;
+    for (uint32_t i = 0; i < b->handlers; ++i)
+    {
+        float *o = (outs != nullptr) ? outs[i] : nullptr;
+        const uint8_t sink = (o != nullptr && b->h[i].mode != H_OFF) ? 1 : 0;
+        if (sink != b->has_sink[i])
+        {
+            b->has_sink[i] = sink;
+            b->desc_dirty = true;
+        }
+        if (b->h[i].mode == H_OFF)
+            o = nullptr;
+        if (o != b->outs_shadow[i])
+        {
+            b->outs_shadow[i] = o;
+            outs_changed = true;
+        }
+    }
+    if (outs_changed && b->handlers > OUTS_BY_VALUE)
+    {
+        MI_HIP_CHECK(hipMemcpyAsync(b->d_outs, b->outs_shadow.data(), b->handlers * sizeof(float *), hipMemcpyHostToDevice, st));
+        MI_HIP_CHECK(hipStreamSynchronize(st));
+    }
+    if (b->desc_dirty)
+    {
+        const int r = splitter_upload_desc(b, st);
+        if (r != MI_OK)
+            return r;
+    }
+    return MI_OK;
+}
+
 int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const float *in, size_t count, size_t out_stride,
                              size_t in_stride, void *stream)
 {
@@ -1043,33 +1149,8 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
                        "mi_splitter_bank_process: the output rows of handler %u overlap the input rows", i);
         }
     }
-    // who listens: a handler whose output pointer is NULL has no sink
-    bool outs_changed = false;
-    for (uint32_t i = 0; i < b->handlers; ++i)
     {
-        float *o = (outs != nullptr) ? outs[i] : nullptr;
-        const uint8_t sink = (o != nullptr && b->h[i].mode != H_OFF) ? 1 : 0;
-        if (sink != b->has_sink[i])
-        {
-            b->has_sink[i] = sink;
-            b->desc_dirty = true;
-        }
-        if (b->h[i].mode == H_OFF)
-            o = nullptr;
-        if (o != b->outs_shadow[i])
-        {
-            b->outs_shadow[i] = o;
-            outs_changed = true;
-        }
-    }
-    if (outs_changed && b->handlers > OUTS_BY_VALUE)
-    {
-        MI_HIP_CHECK(hipMemcpyAsync(b->d_outs, b->outs_shadow.data(), b->handlers * sizeof(float *), hipMemcpyHostToDevice, st));
-        MI_HIP_CHECK(hipStreamSynchronize(st));
-    }
-    if (b->desc_dirty)
-    {
-        const int r = splitter_upload_desc(b, st);
+        const int r = splitter_listeners(b, outs, st);
         if (r != MI_OK)
             return r;
     }
@@ -1107,6 +1188,102 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
         MI_HIP_CHECK(hipGetLastError());
         b->fill += n;
         done += n;
+    }
+    return MI_OK;
+}
+
+// `blocks` consecutive process() calls in one C call (SpectralSplitter.cpp:295-361 per block): block k reads in[k] and hands
+// band i to outs[k * handlers + i].  Runs of blocks of whole frames go out as ONE launch of the several-hops kernel
+// (splitter_hops_blocks_kernel: between two hops nothing goes through memory, whichever block they belong to) where that kernel
+// applies -- every listening handler a mask, the chunk the whole half frame, more than one handler -- with the samples and the
+// state of the calls one by one.
+int mi_splitter_bank_process_blocks(mi_splitter_bank_t *b, float *const *outs, const float *const *in, size_t blocks, size_t count,
+                                    size_t out_stride, size_t in_stride, void *stream)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_splitter_bank_process_blocks: NULL bank");
+    if (count == 0 || blocks == 0)
+        return MI_OK;
+    MI_REQUIRE(in != nullptr, MI_EINVAL, "mi_splitter_bank_process_blocks: NULL pointer table");
+    hipStream_t st = mi::as_stream(stream);
+    const uint32_t nh = b->handlers;
+    auto one_block = [&](size_t k) -> int {
+        return mi_splitter_bank_process(b, (outs != nullptr) ? outs + k * nh : nullptr, in[k], count, out_stride, in_stride, stream);
+    };
+    size_t k = 0;
+    while (k < blocks)
+    {
+        {
+            const int rc = mi::capture_touch(st, b, "spectral splitter", splitter_bank_positions);
+            if (rc != MI_OK)
+                return rc;
+        }
+        if (b->update)
+        {
+            const int r = splitter_apply_settings(b, st);
+            if (r != MI_OK)
+                return r;
+        }
+        const uint32_t frame = 1u << (b->chunk_rank - 1);
+        size_t run = 0;
+        const bool steady = b->bindings != 0 && outs != nullptr && b->fill >= frame && b->rank <= 14 && !splitter_has_callbacks(b) && nh > 1 &&
+                            nh <= OUTS_BY_VALUE && (count % frame) == 0 && in[k] != nullptr && (out_stride % 2) == 0;
+        if (steady)
+        {
+            const int r = splitter_listeners(b, outs + k * nh, st);
+            if (r != MI_OK)
+                return r;
+        }
+        if (steady && splitter_hops_fuse(b, in[k], in_stride))
+        {
+            const size_t cap = std::min<size_t>(SPLIT_BLOCKS_MAX, SPLIT_PTRS_MAX / nh);
+            const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float), ib = ((size_t(b->channels) - 1) * in_stride + count) * sizeof(float);
+            auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
+                const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
+                return p != nullptr && q != nullptr && a0 < b0 + qn && b0 < a0 + pn;
+            };
+            while (k + run < blocks && run < cap)
+            {
+                const size_t j = k + run;
+                bool ok = in[j] != nullptr && (reinterpret_cast<uintptr_t>(in[j]) % 8) == 0;
+                for (uint32_t i = 0; ok && i < nh; ++i)    // the same handlers listen in every block of the run; rows of pairs
+                    ok = ((outs[j * nh + i] != nullptr) == (outs[k * nh + i] != nullptr)) && (reinterpret_cast<uintptr_t>(outs[j * nh + i]) % 8) == 0;
+                for (size_t q = k; ok && q <= j; ++q)       // nothing the run writes is read by it
+                    for (uint32_t i = 0; ok && i < nh; ++i)
+                        ok = !overlap(outs[q * nh + i], ob, in[j], ib) && !overlap(outs[j * nh + i], ob, in[q], ib);
+                if (!ok)
+                    break;
+                ++run;
+            }
+        }
+        if (run < 2)
+        {
+            const int r = one_block(k);
+            if (r != MI_OK)
+                return r;
+            ++k;
+            continue;
+        }
+        split_blocks tab;
+        tab.per = uint32_t(count / frame);
+        for (size_t q = 0; q < run; ++q)
+        {
+            tab.src[q] = in[k + q];
+            for (uint32_t i = 0; i < nh; ++i)
+                tab.out[q * nh + i] = (b->h[i].mode == H_OFF) ? nullptr : outs[(k + q) * nh + i];
+        }
+        const uint32_t hops = uint32_t(run) * tab.per;
+        const int lh = int(b->rank) - 1;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
+            MI_LAUNCH((splitter_hops_blocks_kernel<LH>), dim3(b->channels, nh), dim3(fplan<LH>::T), 0, st, ev0, ev1, b->d_in, b->d_in2, b->pitch, \
+                      b->d_lines, b->pitch, b->channels, b->d_desc, nh, b->d_wnd, frame, b->d_tw, in_stride, out_stride, hops, tab)
+        MI_LOGH_SWITCH(lh, MI_CALL)
+        #undef MI_CALL
+        MI_HIP_CHECK(hipGetLastError());
+        std::swap(b->d_in, b->d_in2);
+        b->fill = frame;
+        k += run;
     }
     return MI_OK;
 }

@@ -798,6 +798,18 @@ class SplitterBank:
                                            count if out_stride is None else out_stride,
                                            count if in_stride is None else in_stride, _stream(stream)))
 
+    def process_blocks(self, outs, inps, count, out_stride=None, in_stride=None, stream=None):
+        """len(inps) consecutive process() calls in one C call; outs[k]: block k's list of `handlers` buffers (or None)."""
+        n = len(inps)
+        assert n == len(outs)
+        flat = [(_ptr(b) if b is not None else None) for o in outs for b in o]
+        assert len(flat) == n * self.handlers
+        po = (c_void_p * len(flat))(*flat)
+        pi = (c_void_p * n)(*[_ptr(b) for b in inps])
+        check(lib.mi_splitter_bank_process_blocks(self.handle, po, pi, n, count,
+                                                  count if out_stride is None else out_stride,
+                                                  count if in_stride is None else in_stride, _stream(stream)))
+
     def close(self):
         if self.handle:
             lib.mi_splitter_bank_destroy(self.handle)

@@ -436,3 +436,43 @@ def test_an_output_that_overlaps_the_input_is_refused(gpu):
     sp.process([a, b2], din, n)
     assert np.isfinite(a.download()).all()
     sp.close()
+
+
+@pytest.mark.parametrize("rank,bands,n_frames,K,listen", [(12, 4, 2, 5, None), (9, 3, 1, 7, None), (10, 2, 3, 4, None), (11, 4, 2, 70, None),
+                                                           (10, 4, 2, 6, [0, 2])])
+def test_process_blocks_equal_block_by_block(gpu, rank, bands, n_frames, K, listen):
+    """mi_splitter_bank_process_blocks: K blocks of whole frames as ONE launch of the several-hops kernel (70 blocks: two) against
+    K process() calls on a twin bank -- every band bit for bit, and the state left behind (an odd-sized call and a block through
+    both); handlers nobody listens to are skipped in both."""
+    rng = np.random.default_rng(900 + rank + K)
+    C, frame = 3, 1 << (rank - 1)
+    n = n_frames * frame
+    listen = list(range(bands)) if listen is None else listen
+    x = (rng.standard_normal((K + 2, C, n)) * 0.25).astype(np.float32)
+    masks = [np.clip(rng.uniform(0.0, 1.2, 1 << rank), 0.0, 1.0).astype(np.float32) for _ in range(bands)]
+
+    def make():
+        sp = gpu.SplitterBank(C, rank, bands)
+        for i in range(bands):
+            sp.bind_mask(i, masks[i])
+        return sp
+
+    def outs_of():
+        return [gpu.DeviceBuffer.from_host(np.full((C, n), 7.0, np.float32)) if i in listen else None for i in range(bands)]
+    a, b = make(), make()
+    ins = [gpu.DeviceBuffer.from_host(x[k]) for k in range(K + 2)]
+    oa = [outs_of() for _ in range(K + 2)]
+    ob = [outs_of() for _ in range(K + 2)]
+    a.process(oa[0], ins[0], n)                              # the steady state: a frame is in hand
+    a.process_blocks(oa[1:K + 1], ins[1:K + 1], n)
+    a.process(oa[K + 1], ins[K + 1], n - 37, n, n)
+    for k in range(K + 1):
+        b.process(ob[k], ins[k], n)
+    b.process(ob[K + 1], ins[K + 1], n - 37, n, n)
+    for k in range(K + 2):
+        m = n if k <= K else n - 37
+        for i in listen:
+            ya, yb = oa[k][i].download()[:, :m], ob[k][i].download()[:, :m]
+            assert k == 0 or np.abs(yb).max() > 1e-4
+            np.testing.assert_array_equal(ya, yb, err_msg="block %d band %d" % (k, i))
+    a.close(); b.close()
