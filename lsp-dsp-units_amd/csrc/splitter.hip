@@ -119,6 +119,8 @@ namespace
         __shared__ float2 lds_[fplan<LOGH>::LDS];
         float2 *const buf = lds_, *const scr = lds_ + fplan<LOGH>::SCR;
         const int ch = blockIdx.x, tid = threadIdx.x;
+        // a handler's output rows (runs of blocks: out of the table at every block's first hop -- every listening handler is a mask there)
+        auto out_row = [&](uint32_t h) -> float * { return TAB ? nullptr : outs.at(h); };
         constexpr bool all = !PER_BAND;
         constexpr uint32_t BPW = (MULTI > 0) ? MULTI : 1;          // handlers per workgroup
         // (one handler per workgroup: the compiler must SEE that the handler loops run once -- as a min() with `handlers`
@@ -159,7 +161,8 @@ namespace
             if (hd[h].mode != H_COPY || !hd[h].has_sink)
                 continue;
             float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
-            float *emit = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+            float *const orow = out_row(h);
+            float *emit = (ingest_n > 0 && orow != nullptr) ? orow + size_t(ch) * out_stride + out_pos : nullptr;
             overlap_add(line, w2, frame, tid, T, 1.0f, emit, [&](uint32_t m) { return buf[m]; });
         }
         if (owner)
@@ -239,7 +242,8 @@ namespace
                         on[b] = h < h1 && hd[h].mode == H_MASK && hd[h].has_sink;
                         const uint32_t hh = on[b] ? h : h0;
                         gp[b] = one(hd[hh].mask + size_t(ch) * hd[hh].mask_stride);
-                        ep[b] = one((outs.at(hh) != nullptr) ? outs.at(hh) + size_t(ch) * out_stride + out_pos : nullptr);
+                        float *const orow = out_row(hh);
+                        ep[b] = one((orow != nullptr) ? orow + size_t(ch) * out_stride + out_pos : nullptr);
                         lp[b] = one(lines + (size_t(hh) * channels + ch) * line_pitch);
                         #pragma unroll
                         for (int i = 0; i < PER / 2; ++i)
@@ -361,7 +365,7 @@ namespace
                     rf.pairs_mask_store(buf, zk, zm, [&](int k) -> float { return g[k]; /* the even part already, bind_mask */ }, tix);
                     mi_fft::fft_lds<LOGH, true, false, true>(buf, scr, rf.ft, tid, io);
                     float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
-                    float *emit_ = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+                    float *emit_ = (ingest_n > 0 && out_row(h) != nullptr) ? out_row(h) + size_t(ch) * out_stride + out_pos : nullptr;
                     gwfloat *const emit = reinterpret_cast<gwfloat *>(reinterpret_cast<uint64_t>(emit_));
                     #pragma unroll
                     for (int i = 0; i < PER / 2; ++i)
@@ -450,7 +454,7 @@ namespace
             __syncthreads();
             rf.inverse(buf, scr, tid);
             float2 *line = reinterpret_cast<float2 *>(lines + (size_t(h) * channels + ch) * line_pitch);
-            float *emit = (ingest_n > 0 && outs.at(h) != nullptr) ? outs.at(h) + size_t(ch) * out_stride + out_pos : nullptr;
+            float *emit = (ingest_n > 0 && out_row(h) != nullptr) ? out_row(h) + size_t(ch) * out_stride + out_pos : nullptr;
             const uint32_t first = uint32_t(H) - frame;                // the last 2*frame samples, in pairs
             overlap_add(line, w2, frame, tid, T, scale, emit, [&](uint32_t m) { return buf[first + m]; });
         }
@@ -470,16 +474,13 @@ namespace
 
     // the several-hops form over a run of blocks, one handler per workgroup
     template <int LOGH>
-    __global__ __launch_bounds__(fplan<LOGH>::T, 4)
+    __global__ __launch_bounds__(fplan<LOGH>::T, (fplan<LOGH>::T <= 64) ? 2 : 4)     // (one-wave workgroups: no need to squeeze into 128 registers)
     void splitter_hops_blocks_kernel(const float *in_cur, float *in_next, size_t in_pitch, float *lines, size_t line_pitch,
                                      uint32_t channels, const handler_desc *__restrict__ hd, uint32_t handlers,
                                      const float *__restrict__ wnd, uint32_t frame, const float2 *__restrict__ tw,
                                      size_t src_stride, size_t out_stride, uint32_t hops, const split_blocks tab)
     {
-        out_table none;
-        for (uint32_t i = 0; i < OUTS_BY_VALUE; ++i)
-            none.p[i] = tab.out[i < handlers ? i : 0];      // (the first block's rows: what tells "somebody listens" from "nobody")
-        none.more = nullptr;
+        const out_table none = {};                          // (the rows come out of the table, block by block)
         splitter_hop_body<LOGH, false, true, 1, true>(in_cur, in_next, in_pitch, lines, line_pitch, channels, hd, handlers, wnd, frame,
                                                       nullptr, tw, tab.src[0], src_stride, frame, none, out_stride, 0, hops, &tab);
     }

@@ -333,6 +333,33 @@ def test_runs_of_blocks_in_one_launch_replay(gpu):
                            (kb, Ce, ne), [(kb, Ce, ne)], want), max_k=4)
         assert K == want
 
+    # the spectral bank's and the splitter's runs of blocks: the positions (a frame in hand) are where they were after every call
+    Cs, rs, ns, Ks = 4, 9, 512, 3
+
+    def make_sp(st):
+        b = gpu.SpectralBank(Cs, rs)
+        b.set_rank(rs)
+        b.bind_mask(np.linspace(1.0, 0.3, (1 << (rs - 1)) + 1).astype(np.float32))
+        return b
+
+    K = _run(gpu, Case("spectral blocks", make_sp,
+                       lambda b, x, o, st: b.process_blocks(_blocks(o[0], Ks, Cs * ns), _blocks(x, Ks, Cs * ns), ns, stream=st),
+                       (Ks, Cs, ns), [(Ks, Cs, ns)]), max_k=2)
+    assert K == 1
+
+    def make_spl(st):
+        b = gpu.SplitterBank(Cs, rs, 2)
+        b.bind_mask(0, np.linspace(1.0, 0.0, 1 << rs).astype(np.float32))
+        b.bind_mask(1, np.linspace(0.0, 1.0, 1 << rs).astype(np.float32))
+        return b
+
+    def call_spl(b, x, o, st):
+        outs = [[o[0].ptr + 4 * Cs * ns * k, o[1].ptr + 4 * Cs * ns * k] for k in range(Ks)]
+        b.process_blocks(outs, _blocks(x, Ks, Cs * ns), ns, stream=st)
+
+    K = _run(gpu, Case("splitter blocks", make_spl, call_spl, (Ks, Cs, ns), [(Ks, Cs, ns), (Ks, Cs, ns)], 2), max_k=2)
+    assert K == 2                                            # (a launch swaps the roles of the two analysis buffers)
+
     Ca, rank, F = 8, 10, 6
     period = 512                                             # half a frame: the strobes of a run go out in one launch
     bins = (1 << (rank - 1)) + 1
