@@ -71,8 +71,8 @@ namespace
     // instructions instead of the ten (and two mode switches) of the compiler's IEEE sequence, whose scaling steps serve
     // operands next to the ends of the exponent range; gains, their roots and the prototype's polynomials are nowhere near.
     // The same quotient bit for bit on 2^24 random pairs from [1e-4, 1e4]^2, half of them reciprocals
-    // (tests/experiments/dyn_div_probe.hip, profiles/r03_experiments/dynfilter_per_type.txt); non-finite results are
-    // redone with the IEEE division (tests/test_dynfilter_gpu.py::test_gain_samples_of_zero).
+    // (tests/experiments/dyn_div_probe.hip, profiles/r03_experiments/dynfilter_per_type.txt); zero, infinite and NaN operands
+    // get the IEEE result (tests/test_dynfilter_gpu.py::test_gain_samples_of_zero).
     __host__ __device__ __attribute__((always_inline)) inline float dv(float a, float b)
     {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -81,12 +81,12 @@ namespace
         const float q = a * r;
         const float v = fmaf(fmaf(-b, q, a), r, q);
         // Operands at the ends of the range -- a gain sample of exactly 0 makes logf(g) = -inf, 1 / g = inf -- turn the
-        // correction steps into inf - inf: whatever does not come out finite is divided again the IEEE way (one class
-        // test per division; the branch is not taken on ordinary gains).  The reference computes expf(-inf) = 0 there
-        // and goes on with a finite filter (DynamicFilters.cpp:964-980).
-        if (__builtin_expect(__builtin_amdgcn_classf(v, 0x207), 0))       // sNaN | qNaN | -inf | +inf
-            return a / b;
-        return v;
+        // correction steps into inf - inf.  The reference computes expf(-inf) = 0 there and goes on with a finite filter
+        // (DynamicFilters.cpp:964-980): the IEEE result for zero, infinite and NaN operands is put in place by the
+        // instruction the compiler's own division ends with (v_div_fixup_f32: the quotient as it is for ordinary operands)
+        // -- one instruction instead of a class test and a branch around a second division per call (81 of them in the
+        // bell's kernel).
+        return __builtin_amdgcn_div_fixupf(v, b, a);
 #else
         return a / b;
 #endif
