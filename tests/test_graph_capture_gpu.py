@@ -395,3 +395,18 @@ def test_convolver_bank_replays_after_a_batch_has_grown_its_ring(gpu):
     K = _run(gpu, Case("convolver after a batch", make, lambda b, x, o, st: b.process(o[0], x, frame, stream=st),
                        (C, frame), [(C, frame)], 19), max_k=20)
     assert K == 19
+
+
+def test_convolver_process_blocks_under_capture_is_the_loop_of_calls(gpu):
+    """Under capture mi_convolver_bank_process_blocks does not batch (a batch may have to allocate and to grow the ring): the
+    frames go one by one, and a captured lap of the ring replays bit for bit."""
+    C, rank, taps = 3, 10, 2000                              # four partitions of 512: a ring of three frames, nineteen once the
+    frame = 1 << (rank - 1)                                  # eager call in front of the capture has been through as batches
+    irs = (np.random.default_rng(12).standard_normal((C, taps)) * 0.1).astype(np.float32)
+    Kb = 19
+
+    def call(b, x, o, st):
+        b.process_blocks(_blocks(o[0], Kb, C * frame), _blocks(x, Kb, C * frame), frame, stream=st)
+
+    K = _run(gpu, Case("convolver blocks", lambda st: gpu.ConvolverBank(irs, rank, stream=st), call, (Kb, C, frame), [(Kb, C, frame)]), max_k=3)
+    assert K == 1
