@@ -51,9 +51,14 @@ namespace
     __device__ unsigned long long g_small_probe[1024 * 2 * 8];
     #define MI_SPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0) \
         g_small_probe[(blockIdx.x * 2 + (threadIdx.x >> 6)) * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // conv_batch_tail_kernel: thread 0 of every workgroup (tests/experiments/conv_tail_probe.hip)
+    __device__ unsigned long long g_tail_probe[4096 * 8];
+    #define MI_TPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) \
+        g_tail_probe[((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
     #define MI_CPROBE(slot) do { } while (0)
     #define MI_SPROBE(slot) do { } while (0)
+    #define MI_TPROBE(slot) do { } while (0)
 #endif
 
     // ---- forward transform of a real block of `valid` samples zero-padded to 2M, into buf ---------------
@@ -508,15 +513,21 @@ namespace
         }
     }
 
+    #ifndef MI_TAIL_DEPTH
+    #define MI_TAIL_DEPTH 2
+    #endif
     template <int K, bool KEEP>
-    __global__ __launch_bounds__(256)
+    __global__ __launch_bounds__(256, 2)                    // two workgroups per CU (the staged frames in LDS allow no more at K = 16)
     void conv_batch_tail_kernel(float2 *yps /* [channels][K][M]: H_0 X_f + Yt_(f-1), what frame f's inverse transform takes */,
                                 float2 *yt /* [channels][M]: in, the tail pending before the call (if `pending`); out, Yt_(K-1) */,
                                 bool pending, const float2 *__restrict__ ring, int R, int slot0,
                                 const float2 *__restrict__ H, int P, int M)
     {
         typedef float f4 __attribute__((ext_vector_type(4)));
-        const int ch = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x, M4 = M / 2;      // (M4 is a multiple of 256: M >= 512)
+        // (a channel's first piece, which also forms the packed first bins, moves from XCD to XCD with the channel: a launch's
+        // workgroups go to the XCDs in turn, and with piece = blockIdx.x all first pieces met on one of them)
+        const int ch = blockIdx.y, piece = (blockIdx.x + blockIdx.y) % gridDim.x;
+        const int idx = piece * 256 + threadIdx.x, M4 = M / 2;                            // (M4 is a multiple of 256: M >= 512)
         const f4 *Hc = reinterpret_cast<const f4 *>(H + size_t(ch) * P * M);
         const f4 *Xr = reinterpret_cast<const f4 *>(ring + size_t(ch) * R * M);
         // frame m of the call (m >= 0) or before it (m < 0): frame -1 sits in ring slot slot0, frame 0 in the one behind it, ...
@@ -525,26 +536,49 @@ namespace
             r = (r < 0) ? r + R : r;
             return Xr + size_t(r) * M4;
         };
-        auto mac = [](f4 &s, const f4 h, const f4 x)        // the tail role's sums, term for term
+        // the tail role's sums, term for term: per bin  t = (fma(-x.y, h.y, s.x), fma(x.y, h.x, s.y)),  s = (fma(x.x, h.x, t.x),
+        // fma(x.x, h.y, t.y)).  The first pair is ONE v_pk_fma_f32 whose operand selectors take x's and h's halves crosswise
+        // (written out: the compiler copies x.y into a register of its own first, a move per multiply-add pair -- a quarter
+        // of the walk's instructions)
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        auto cmac = [](const f2 s, const f2 h, const f2 x) __attribute__((always_inline)) -> f2 {
+            f2 t;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "=v"(t) : "v"(x), "v"(h), "v"(s));
+            return f2{fmaf(x.x, h.x, t.x), fmaf(x.x, h.y, t.y)};
+        };
+        auto mac = [&](f4 &s, const f4 h, const f4 x) __attribute__((always_inline))
         {
-            s.z = fmaf(x.z, h.z, fmaf(-x.w, h.w, s.z));
-            s.w = fmaf(x.z, h.w, fmaf(x.w, h.z, s.w));
-            s.x = fmaf(x.x, h.x, fmaf(-x.y, h.y, s.x));
-            s.y = fmaf(x.x, h.y, fmaf(x.y, h.x, s.y));
+            s.hi = cmac(s.hi, h.hi, x.hi);
+            s.lo = cmac(s.lo, h.lo, x.lo);
         };
         // bin 0 packs (DC, Nyquist): two real products instead of a complex one -- lane f of the first workgroup forms the first
         // pair's first bin of frame f's tail (the same chain of multiply-adds as the tail role's dc / ny) and of what frame f's
         // inverse transform takes, NOW (the ring still holds the frames before the call), and files them at the end
         float2 fix_y = make_float2(0.0f, 0.0f), fix_t = make_float2(0.0f, 0.0f);
-        if (blockIdx.x == 0 && threadIdx.x < 64)
+        MI_TPROBE(7);
+        if (piece == 0 && threadIdx.x < 64)
         {
             const int f = (threadIdx.x < K) ? int(threadIdx.x) : K - 1;
             float dc = 0.0f, ny = 0.0f;
-            for (int q = 2; q < P; ++q)
+            // (sixteen partitions' operands asked for at once, then the chain: one at a time it was P - 2 memory round trips, 19 us
+            // in front of everything else this workgroup does)
+            for (int q0 = 2; q0 < P; q0 += 16)
             {
-                const f4 h = Hc[size_t(q) * M4], x = image(f + 1 - q)[0];
-                dc = fmaf(x.x, h.x, dc);
-                ny = fmaf(x.y, h.y, ny);
+                float2 hh[16], xx[16];
+                #pragma unroll
+                for (int j = 0; j < 16; ++j)
+                {
+                    const int q = (q0 + j < P) ? q0 + j : P - 1;
+                    hh[j] = *reinterpret_cast<const float2 *>(Hc + size_t(q) * M4);
+                    xx[j] = *reinterpret_cast<const float2 *>(image(f + 1 - q));
+                }
+                #pragma unroll
+                for (int j = 0; j < 16; ++j)
+                    if (q0 + j < P)
+                    {
+                        dc = fmaf(xx[j].x, hh[j].x, dc);
+                        ny = fmaf(xx[j].y, hh[j].y, ny);
+                    }
             }
             const f4 h = Hc[size_t(1) * M4], x = image(f)[0];
             dc = fmaf(x.x, h.x, dc);
@@ -562,10 +596,14 @@ namespace
             fix_y = cadd(image_mul(make_float2(x.x, x.y), make_float2(h0.x, h0.y), k0 - 2 * int(threadIdx.x)), make_float2(pdc, pny));
             fix_t = make_float2(dc, ny);
         }
+        MI_TPROBE(0);
         f4 s[K], xw[K];
         // the window for p = 2: frames f - 1, f = 0 .. K - 1; frame m lives in register m mod K throughout.  The staged frames
         // among them (0 .. K - 2) are needed once more, by the p = 1 term at the end: they wait in LDS instead of being read twice
-        __shared__ f4 own[KEEP ? K - 1 : 1][KEEP ? 256 : 1];
+        // (one block of LDS, the request queue of the walk over the partitions first: its addresses go through M0)
+        constexpr int D = (K >= MI_TAIL_DEPTH) ? MI_TAIL_DEPTH : K;
+        __shared__ f4 lds_[(2 * D + (KEEP ? K - 1 : 0)) * 256];
+        f4 (*const qh)[256] = reinterpret_cast<f4 (*)[256]>(lds_), (*const qx)[256] = qh + D, (*const own)[256] = qx + D;
         #pragma unroll
         for (int f = 0; f < K; ++f)
         {
@@ -575,32 +613,81 @@ namespace
             if (KEEP && f >= 1)
                 own[f - 1][threadIdx.x] = v;
         }
-        int p = 2;
-        while (p < P)
+        // The partitions' images and the frames the window takes in are asked for D steps ahead of the sums that take them (a
+        // step's 16 K multiply-adds are a quarter of a memory round trip) and land in LDS by themselves (LDS-DMA: a wave's 64
+        // lanes write 1 KiB in lane order, each lane reads back its own 16 bytes -- no barrier, the issuing wave's counted
+        // vmcnt covers it): a queue in registers went from step to step through copies of registers whose loads had just
+        // been issued, i.e. waited for them at every step.  Every step issues its two requests, past the last partition a
+        // repeat of it, so that the count the wait rests on never changes.
+        static_assert(K % D == 0, "the queue's phase survives the loop's back edge");
+        if (P > 2)
         {
-            #pragma unroll
-            for (int u = 0; u < K; ++u)                     // p = 2 + c K + u: frame f + 1 - p sits in register (f - 1 - u) mod K
-            {
-                if (p < P)
+            const f4 *hp = Hc + size_t(2) * M4 + idx;       // H_q, this thread's pair of bins
+            const f4 *const xl = Xr + idx;
+            int q = 2, rq = (slot0 + 1 - 2) % R;            // the next partition asked for and the ring slot of frame -q
+            rq = __builtin_amdgcn_readfirstlane((rq < 0) ? rq + R : rq);
+            const int w0 = threadIdx.x & ~63;
+            // (written out: the compiler puts a vmcnt(0) in front of every LDS read that follows an LDS-DMA builtin of its own)
+            auto dma = [](const f4 *src, const f4 *dst) __attribute__((always_inline)) {
+                unsigned keep;
+                const unsigned at = __builtin_amdgcn_readfirstlane(unsigned(uintptr_t(dst)));
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(at) : "memory");
+            };
+            auto ask = [&](int slot) __attribute__((always_inline)) {
+                dma(hp, &qh[slot][w0]);
+                dma(xl + uint32_t(rq) * uint32_t(M4), &qx[slot][w0]);    // what the window takes in for q + 1 (frame -q), in place of frame K - q
+                if (q < P - 1)
                 {
-                    const f4 h = Hc[size_t(p) * M4 + idx];
-                    f4 xn = f4{0.0f, 0.0f, 0.0f, 0.0f};
-                    if (p + 1 < P)
-                        xn = image(-p)[idx];                // what the window takes in for p + 1 (frame -p), in place of frame K - p
-                    #pragma unroll
-                    for (int f = 0; f < K; ++f)
-                        mac(s[f], h, xw[(f - 1 - u + 2 * K) % K]);
-                    xw[(2 * K - 2 - u) % K] = xn;
-                    ++p;
+                    ++q;
+                    hp += M4;
+                    rq = (rq == 0) ? R - 1 : rq - 1;
+                }
+            };
+            // (the window is in its registers before the first request goes out: the compiler's own wait for it would otherwise
+            // sit inside the loop, a vmcnt(0) at every step)
+            #pragma unroll
+            for (int f = 0; f < K; ++f)
+                asm volatile("" :: "v"(xw[f]));
+            MI_TPROBE(1);
+            #pragma unroll
+            for (int d = 0; d < D; ++d)
+                ask(d);
+            int p = 2;
+            while (p < P)
+            {
+                #pragma unroll
+                for (int u = 0; u < K; ++u)                 // p = 2 + c K + u: frame f + 1 - p sits in register (f - 1 - u) mod K
+                {
+                    if (p < P)
+                    {
+                        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * (D - 1)) : "memory");     // this step's pair has landed
+                        const f4 h = qh[(K * 4 + u) % D][threadIdx.x], xn = qx[(K * 4 + u) % D][threadIdx.x];
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                    // ... and is in registers: the slot is free
+                        ask((K * 4 + u) % D);
+                        #pragma unroll
+                        for (int f = 0; f < K; ++f)
+                            mac(s[f], h, xw[(f - 1 - u + 2 * K) % K]);
+                        xw[(2 * K - 2 - u) % K] = xn;       // (behind the last partition: a value no sum takes)
+                        if (u == 0) MI_TPROBE(2);
+                        if (u == 7 % K) MI_TPROBE(3);
+                        ++p;
+                    }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                  // (the repeats still on their way)
         }
+        MI_TPROBE(4);
         // p = 1 last: the frames' own images.  With frame f's image in hand and the tail of frame f - 1 complete, what frame f's
         // inverse transform takes is formed right here (frame_role's `through`: image times H_0 plus the tail owed to the frame)
         {
             const f4 h1 = Hc[size_t(1) * M4 + idx], h0 = Hc[idx];
             f4 *const ytc = reinterpret_cast<f4 *>(yt + size_t(ch) * M);
             f4 prev = pending ? ytc[idx] : f4{0.0f, 0.0f, 0.0f, 0.0f};
+            #ifdef MI_CONV_PROBE
+            asm volatile("" :: "v"(h1), "v"(h0), "v"(prev));
+            MI_TPROBE(5);
+            #endif
             #pragma unroll
             for (int f = 0; f < K; ++f)
             {
@@ -613,8 +700,9 @@ namespace
             }
             ytc[idx] = s[K - 1];
         }
+        MI_TPROBE(6);
         // (the first workgroup: the packed first bins, formed before anything was written)
-        if (blockIdx.x != 0)
+        if (piece != 0)
             return;
         __syncthreads();
         if (threadIdx.x < K)
