@@ -383,7 +383,8 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
         mi.check(mi.lib.mi_convolver_bank_process_blocks(bank.handle, po, pi, steps, frame, frame, frame, st_ptr))
     batched = steps >= BATCH and ring >= BATCH
     if batched:
-        b_elapsed, b_kernel_ms, b_info = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, region=region,
+        # (15 regions: the first few of a fresh leg run 10 - 15 % longer than the ones behind them, timing.region_ms.in_order)
+        b_elapsed, b_kernel_ms, b_info = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, region=region, regions=15,
                                                       probe_step=lambda j: region(), probe_steps=BATCH)
         b_info["launch"] = ("one mi_convolver_bank_process_blocks call per region: batches of %d frames, four launches each "
                             "(conv_batch_forward / _tail<%d> / _frames / _finish)" % (BATCH, BATCH))
