@@ -580,16 +580,16 @@ namespace
     // written by other workgroups of the SAME launch, so they are read with device-scope loads past this CU's L1).
     constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16, REDUCE_BLOCK = 16, REDUCE_MAX_BLOCKS = 1024;
 
-    template <uint32_t WAVES, bool DEVICE>
+    template <uint32_t WAVES, bool DEVICE, uint32_t REDUCE_BINS = 16>
     __device__ __forceinline__
     void bin_reduce_body(float *out, const float *src, uint32_t stride, uint32_t channels, uint32_t bins,
                          const float *__restrict__ env, uint32_t block /* channels per block, multiple of 16 */,
-                         float (*part)[REDUCE_BINS], uint32_t group /* which 16 bins */)
+                         float (*part)[REDUCE_BINS], uint32_t group /* which REDUCE_BINS bins */)
     {
         const uint32_t lane = threadIdx.x & 63, w = threadIdx.x >> 6;
         const uint32_t b = lane & (REDUCE_BINS - 1), r = lane / REDUCE_BINS;
         const uint32_t k = group * REDUCE_BINS + b;
-        constexpr uint32_t GROUPS = WAVES * REDUCE_ROWS;                        // blocks in flight
+        constexpr uint32_t GROUPS = WAVES * (64 / REDUCE_BINS);                 // blocks in flight
         const uint32_t nblocks = (channels + block - 1) / block;
         // DEVICE: sc1 loads (past this CU's L1, coherent at device scope) through a buffer descriptor -- the builtin, not an
         // atomic load: the compiler keeps sixteen of them in flight, sixteen relaxed atomic loads it waits for one by one
@@ -600,7 +600,7 @@ namespace
                 return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, int((size_t(c) * stride + k) * sizeof(float)), 0, mi::CPOL_SC1));
             return src[size_t(c) * stride + k];
         };
-        for (uint32_t j = w * REDUCE_ROWS + r; j < nblocks; j += GROUPS)
+        for (uint32_t j = w * (64 / REDUCE_BINS) + r; j < nblocks; j += GROUPS)
         {
             float s = 0.0f;
             if (k < bins)
@@ -670,15 +670,19 @@ namespace
     // The reductions of several analyses in ONE launch: blockIdx.y picks the frame, whose rows stand in a plane of their own
     // (mi_analyzer_bank_process_reduce_frames).  A reduction alone is 129 workgroups of one per CU on a 256-CU part and mostly
     // latency; eight frames' worth fill the chip.  Same body, same order of summation, same bits per frame.
-    constexpr uint32_t REDUCE_FRAMES_MAX = 16;
+    // With several frames to fill the chip a workgroup owns BINS = 32 bins, a whole 128-byte line of every channel row (16 bins
+    // are half a line: the other half went to the neighbouring workgroup, i.e. to another XCD's L2 -- every line fetched twice);
+    // the 16-bin form serves banks of more than BINS_32_BLOCKS blocks (its LDS holds twice the block sums).
+    constexpr uint32_t REDUCE_FRAMES_MAX = 16, BINS_32_BLOCKS = 512;
     struct reduce_planes { const float *rows[REDUCE_FRAMES_MAX]; };
+    template <uint32_t BINS>
     __global__ __launch_bounds__(64 * REDUCE_WAVES)
     void bin_reduce_frames_kernel(float *out, size_t out_stride, const reduce_planes planes, uint32_t stride, uint32_t channels,
                                   uint32_t bins, const float *__restrict__ env, uint32_t block)
     {
-        __shared__ float part[REDUCE_MAX_BLOCKS][REDUCE_BINS];
-        bin_reduce_body<REDUCE_WAVES, false>(out + size_t(blockIdx.y) * out_stride, planes.rows[blockIdx.y], stride, channels, bins, env,
-                                             block, part, blockIdx.x);
+        __shared__ float part[REDUCE_MAX_BLOCKS * 16 / BINS][BINS];
+        bin_reduce_body<REDUCE_WAVES, false, BINS>(out + size_t(blockIdx.y) * out_stride, planes.rows[blockIdx.y], stride, channels, bins,
+                                                   env, block, part, blockIdx.x);
     }
 
     // ---- analyzer -------------------------------------------------------------------------------------------
@@ -2348,8 +2352,13 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
         uint32_t block = REDUCE_BLOCK;
         while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
             block *= 2;
-        hipLaunchKernelGGL(bin_reduce_frames_kernel, dim3((bins + REDUCE_BINS - 1) / REDUCE_BINS, uint32_t(cnt)), dim3(64 * REDUCE_WAVES), 0, st,
-                           out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
+        static const bool narrow = getenv("MI_REDUCE_16_BINS") != nullptr;                  // experiment knob: half a line per workgroup
+        if ((b->channels + block - 1) / block <= BINS_32_BLOCKS && !narrow)
+            hipLaunchKernelGGL((bin_reduce_frames_kernel<32>), dim3((bins + 31) / 32, uint32_t(cnt)), dim3(64 * REDUCE_WAVES), 0, st,
+                               out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
+        else
+            hipLaunchKernelGGL((bin_reduce_frames_kernel<16>), dim3((bins + 15) / 16, uint32_t(cnt)), dim3(64 * REDUCE_WAVES), 0, st,
+                               out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
         MI_HIP_CHECK(hipGetLastError());
         f += cnt;
     }
