@@ -31,20 +31,43 @@ def main():
                 rows = f.readlines()[:12]
             with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (tag, wl)), "w") as f:
                 f.writelines(rows)
+        # the same kernel at several grid sizes (the convolver row also runs a 512-channel pass beside BASELINE's 256): the
+        # --stats summary averages them together, so the trace is summed up per (kernel, grid) as well
+        traces = glob.glob(os.path.join(src, "stats_" + wl, "**", "*kernel_trace.csv"), recursive=True)
+        if traces:
+            per = {}
+            with open(traces[0]) as f:
+                for r in csv.DictReader(f):
+                    key = (r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0],
+                           int(r["Grid_Size_X"]) * int(r["Grid_Size_Y"]) * int(r["Grid_Size_Z"]))
+                    per.setdefault(key, []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            grids = {}
+            for (name, grid) in per:
+                grids.setdefault(name, set()).add(grid)
+            rows = [(name, grid, v) for (name, grid), v in per.items() if len(grids[name]) > 1 and sum(v) > 1e6]
+            if rows:
+                with open(os.path.join(dst, "%s_%s_kernel_by_grid.csv" % (tag, wl)), "w") as f:
+                    f.write('"Name","GridThreads","Calls","AverageNs","MinNs","MaxNs"\n')
+                    for name, grid, v in sorted(rows):
+                        f.write('"%s",%d,%d,%.1f,%d,%d\n' % (name, grid, len(v), sum(v) / len(v), min(v), max(v)))
     jobs = [(wl, wl, k) for wl, k in KERNELS.items()] + [(name, wl, k) for name, (wl, k) in EXTRA.items()]
     for name, wl_dir, kname in jobs:
         wl = name
         per = {}
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             files = glob.glob(os.path.join(src, "pmc_%s_%s" % (wl_dir, ctr), "**", "*counter_collection.csv"), recursive=True)
-            vals = []
+            by_grid = {}
             for fn in files:
                 with open(fn) as f:
                     for r in csv.DictReader(f):
                         if kname in r["Kernel_Name"] and r["Counter_Name"] == ctr:
-                            vals.append(float(r["Counter_Value"]))
-            if vals:
-                per[ctr] = {"dispatches": len(vals), "avg_KB": sum(vals) / len(vals)}
+                            by_grid.setdefault(int(r["Grid_Size"]), []).append(float(r["Counter_Value"]))
+            if by_grid:
+                # (several grid sizes: BASELINE's configuration is the smallest -- the row's extra pass doubles the channels)
+                grid = min(by_grid)
+                vals = by_grid[grid]
+                per[ctr] = {"dispatches": len(vals), "avg_KB": sum(vals) / len(vals), "grid_threads": grid,
+                            "other_grids": {str(g): {"dispatches": len(v), "avg_KB": sum(v) / len(v)} for g, v in by_grid.items() if g != grid}}
         raw[wl] = per
         if "FETCH_SIZE" in per and "WRITE_SIZE" in per:
             hbm = (per["FETCH_SIZE"]["avg_KB"] * 2.0 + per["WRITE_SIZE"]["avg_KB"]) * 1024.0
