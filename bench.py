@@ -386,8 +386,8 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
         # (15 regions: the first few of a fresh leg run 10 - 15 % longer than the ones behind them, timing.region_ms.in_order)
         b_elapsed, b_kernel_ms, b_info = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, region=region, regions=15,
                                                       probe_step=lambda j: region(), probe_steps=BATCH)
-        b_info["launch"] = ("one mi_convolver_bank_process_blocks call per region: batches of %d frames, four launches each "
-                            "(conv_batch_forward / _tail<%d> / _frames / _finish)" % (BATCH, BATCH))
+        b_info["launch"] = ("one mi_convolver_bank_process_blocks call per region: batches of %d frames, three launches each "
+                            "(conv_batch_forward / _tail<%d> / _frames; below 256 channels a fourth, _finish)" % (BATCH, BATCH))
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, warmup)
     chk = yout[(warmup + steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
@@ -438,7 +438,7 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
             "config": dict(res["config"], call="one mi_convolver_bank_process_blocks call per region (batches of %d frames; "
                                                "bit-identical to %d process() calls -- those are timed under \"per_call\")" % (BATCH, steps)),
             "timing": b_info,
-            "roofline": _roofline("conv_batch_tail_kernel<%d> (%d frames per launch; the batch is four launches)" % (BATCH, BATCH),
+            "roofline": _roofline("conv_batch_tail_kernel<%d> (%d frames per launch; the batch is three launches)" % (BATCH, BATCH),
                                   tail_bytes, b_kernel_ms, b_elapsed / steps * 1e3, b_info["probe"],
                                   _pmc_traffic("pmc_convolver_latest.json", "conv_batch_tail_kernel", BATCH) if C == 256 else None,
                                   {"bytes_model": "this kernel per channel and batch: P + (P - 2) + K + 1 images of 32 KiB read, K + 1 written",

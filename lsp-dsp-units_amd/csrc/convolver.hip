@@ -720,11 +720,13 @@ namespace
     // 0) once the upper half of the accumulator is zero), so a workgroup whose run starts inside the batch runs the inverse of
     // the frame before its first one as well and needs no other workgroup.  (One workgroup per channel: a chain of memory
     // latencies on 256 workgroups; one per frame: every spectrum read twice.)  Nothing the launch reads is written by it: the
-    // accumulator the last frame leaves goes to acc_new and conv_batch_finish_kernel files it where the bank keeps it.
+    // accumulator the last frame leaves goes to acc_new and conv_batch_finish_kernel files it where the bank keeps it (one run per
+    // channel: acc_new IS the accumulator, see the end of the kernel).
     template <int LOGM>
     __global__ __launch_bounds__(fplan<LOGM>::T)
     void conv_batch_frames_kernel(const batch_args ba, int per, size_t out_stride, bool aligned, const float2 *__restrict__ yps,
-                                  const float *__restrict__ acc, float *acc_new, const float2 *__restrict__ tw, bool upper_zero)
+                                  const float *acc, float *acc_new, int acc_new_stride, bool zero_upper, const float2 *__restrict__ tw,
+                                  bool upper_zero)
     {
         using PL = fplan<LOGM>;
         constexpr int M = PL::N, T = PL::T, B = M, KPT = M / T, NPT = KPT / 2;
@@ -808,10 +810,16 @@ namespace
         }
         if (f1 == K)                                        // the last frame's spill: the accumulator after the call
         {
-            const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(acc_new + size_t(ch) * B, unsigned(B * sizeof(float)));
+            // (one run per channel: this workgroup is the accumulator's only reader in the launch, so acc_new is the accumulator
+            // itself -- rows of 2 B, the upper half zeroed here if it was not -- and there is no finish launch)
+            const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(acc_new + size_t(ch) * acc_new_stride, unsigned((zero_upper ? 2 * B : B) * sizeof(float)));
             #pragma unroll
             for (int i = 0; i < NPT; ++i)
+            {
                 mi::wt_store(racc, 8 * (tid + i * T), a0[i]);
+                if (zero_upper)
+                    mi::wt_store(racc, int(B * sizeof(float)) + 8 * (tid + i * T), make_float2(0.0f, 0.0f));
+            }
         }
     }
 
@@ -1792,14 +1800,24 @@ namespace
         // frame with 2 / 4 / 8 runs at C3 --, up to four per channel below that)
         const int want = (force_groups > 0) ? force_groups : std::max(1, std::min(4, int(256 / b->channels)));
         const int groups = std::min(K, want), per = (K + groups - 1) / groups;
+        // one run per channel: the workgroup that takes the accumulator is the one that leaves it -- straight into d_acc, no finish launch
+        static const bool always_finish = getenv("MI_CONV_BATCH_FINISH") != nullptr;       // experiment knob: the launch as before
+        const bool direct = per >= K && !always_finish;
+        float *const acc_out = direct ? b->d_acc : b->d_acc_new;
+        const int acc_out_stride = direct ? 2 * M : M;
+        const bool zero_upper = direct && !b->upper_zero;
         #define MI_CALL(LM) hipLaunchKernelGGL((conv_batch_frames_kernel<LM>), dim3(b->channels, (K + per - 1) / per), dim3(fplan<LM>::T), 0, st, \
-                                               ba, per, out_stride, aligned, b->d_yts, b->d_acc, b->d_acc_new, b->d_tw, b->upper_zero)
+                                               ba, per, out_stride, aligned, b->d_yts, b->d_acc, acc_out, acc_out_stride, zero_upper, b->d_tw, \
+                                               b->upper_zero)
         switch (b->logm) { case 9: { MI_CALL(9); break; } case 10: { MI_CALL(10); break; } case 11: { MI_CALL(11); break; } default: { MI_CALL(12); break; } }
         #undef MI_CALL
         MI_HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(conv_batch_finish_kernel, dim3((2 * M + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, b->d_acc_new, M,
-                           b->upper_zero);
-        MI_HIP_CHECK(hipGetLastError());
+        if (!direct)
+        {
+            hipLaunchKernelGGL(conv_batch_finish_kernel, dim3((2 * M + 255) / 256, b->channels), dim3(256), 0, st, b->d_acc, b->d_acc_new, M,
+                               b->upper_zero);
+            MI_HIP_CHECK(hipGetLastError());
+        }
         b->slot = (b->slot + K) % b->R;
         b->yt_pending = true;
         b->upper_zero = true;
