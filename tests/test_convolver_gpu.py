@@ -443,7 +443,7 @@ def test_sub_frame_calls_whose_rows_overlap_or_lie_apart(gpu, rank, taps):
             assert np.array_equal(y, want), mode
 
 
-@pytest.mark.parametrize("rank,taps,K", [(10, 2500, 16), (10, 2500, 7), (11, 5000, 37), (12, 9000, 4), (13, 20000, 6), (10, 1024, 5), (10, 3 * 512 + 1, 21)])
+@pytest.mark.parametrize("rank,taps,K", [(10, 2500, 16), (10, 2500, 7), (11, 5000, 37), (12, 9000, 4), (13, 20000, 6), (10, 1024, 5), (10, 3 * 512 + 1, 21), (12, 9000, 48)])
 def test_process_blocks_batches_of_frames_equal_frame_by_frame(gpu, rank, taps, K):
     """mi_convolver_bank_process_blocks: whole frames of a partitioned bank in batches of 16 / 8 / 4 / 2 (three launches per
     batch: the frames' images, ALL their tails in one pass over the partitions, the frames' outputs) against K process() calls on
