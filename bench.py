@@ -180,6 +180,9 @@ def _roofline(kernel, alg_bytes, kernel_ms, step_ms, probe_mode, traffic=None, e
         r.update({"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "source": "kernel_events",
                   "kernel_avg_us": round(avg_ms * 1e3, 3), "kernel_median_us": round(ks[len(ks) // 2] * 1e3, 3),
                   "kernel_us_per_step": round(avg_ms * 1e3 / launch_steps, 3), "kernel_samples": len(kernel_ms),
+                  # (all probes, untrimmed: a rocprofv3 --stats average of the same command also covers the launches of the
+                  # timed regions, the first of which run in the power controller's onset dip -- timing.region_ms.in_order)
+                  "kernel_min_mean_max_us": [round(ks[0] * 1e3, 3), round(sum(ks) / len(ks) * 1e3, 3), round(ks[-1] * 1e3, 3)],
                   "kernel_avg_of": "probes %d..%d of %d in order of duration" %
                                    (3 if len(ks) >= 8 else 1, len(ks) - 2 if len(ks) >= 8 else len(ks), len(ks)),
                   "probe": probe_mode})
