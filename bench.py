@@ -1079,14 +1079,14 @@ def main():
         # interface of the box first, which takes minutes where there is no network
         os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
         os.environ.setdefault("NCCL_IB_DISABLE", "1")
-    if world > 1:
-        dist.init_process_group(backend="gloo" if rehearsal or not torch.cuda.is_available() else "nccl")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU fallback)")
     if rehearsal:
         local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
+    torch.cuda.set_device(local_rank)                       # (before the process group: its collectives run on the current device)
     dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="gloo" if rehearsal else "nccl")
 
     mi = importlib.import_module("lsp-dsp-units_amd")
     mi.check(mi.lib.mi_dspu_set_device(local_rank))
