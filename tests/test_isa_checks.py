@@ -224,3 +224,31 @@ def test_biquad_kernels_in_the_compilers_output(tmp_path):
         between = t[w:min(a for a in adds if a > w)]
         assert any(l.startswith("s_barrier") for l in between), name
         assert not any(l.startswith(("global_atomic_add_f32", "buffer_store", "global_store")) for l in between), name
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_conv_batch_tail_queue_waits_for_its_own_requests_and_nothing_else(tmp_path):
+    """conv_batch_tail_kernel asks for a partition's image and the frame the window takes in two steps ahead by LDS-DMA
+    (global_load_lds_dwordx4, written as asm) and reads each lane's 16 bytes back from LDS.  Nothing orders that read behind
+    the DMA except the issuing wave's counted vmcnt (MI355X_MICROARCH.md): every step must open with the hand-written
+    `s_waitcnt vmcnt(2)` (the pair of two steps ago has landed, the pair of the step before may still be on its way), and the
+    compiler must not have put a vmcnt wait of its own between the requests (the window's loads are waited for in front of
+    the loop: a `vmcnt(0)` inside it is a memory round trip per step)."""
+    lines = _isa(os.path.join(CSRC, "convolver.hip"), tmp_path)
+    bodies = _kernel_bodies(lines, "conv_batch_tail_kernel")
+    assert len(bodies) == 8, sorted(bodies)                 # K = 2, 4, 8, 16 x {staged frames kept, re-read}
+    for name, body in bodies.items():
+        text = [l.strip() for l in body if l.strip() and (not l.strip().startswith(";") or l.strip().startswith(";;#ASM"))]
+        dma = [i for i, l in enumerate(text) if l.startswith("global_load_lds_dwordx4")]
+        assert len(dma) >= 4, (name, len(dma))
+        region = text[dma[0]:dma[-1] + 1]
+        waits = [l for l in region if l.startswith("s_waitcnt") and "vmcnt" in l]
+        assert waits and all(w == "s_waitcnt vmcnt(2)" for w in waits), (name, sorted(set(waits)))
+        # each step: the counted wait, then the two reads of the queue, then lgkmcnt(0) in front of the refill of the slot
+        for i, l in enumerate(region):
+            if l == "s_waitcnt vmcnt(2)":
+                after = [x for x in region[i + 1:i + 24] if not x.startswith(";;#ASM")]
+                refill = next(k for k, x in enumerate(after) if x.startswith("global_load_lds_dwordx4"))
+                reads = [k for k, x in enumerate(after[:refill]) if x.startswith("ds_read_b128")]
+                assert len(reads) >= 2 and "s_waitcnt lgkmcnt(0)" in after[reads[1]:refill], (name, after)
+        # the asm's own vmcnt(0) behind the loop (the repeats past the last partition) sits outside the region by construction
