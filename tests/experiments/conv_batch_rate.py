@@ -8,7 +8,7 @@ import torch
 
 mi = importlib.import_module("lsp-dsp-units_amd")
 C = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-taps, frame = 65536, 4096
+taps, frame = int(os.environ.get("MI_RATE_TAPS", "65536")), 4096   # (MI_RATE_TAPS: another partition count)
 rng = np.random.default_rng(4)
 irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
 dev = torch.device("cuda:0")
