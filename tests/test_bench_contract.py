@@ -49,3 +49,57 @@ def test_gpus_n_spawns_n_ranks_without_a_launcher():
     r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "biquad", "--no-cpu-baseline"], {})
     assert r.returncode != 0                                # the ranks' status, not the parent's own
     assert r.stderr.count(b"bench.py needs a HIP device") >= 2, r.stderr[-800:]
+
+
+def _canned_full_result():
+    """A full (detail) result as bench.py builds it: round 4's 20 KB line, committed under profiles/."""
+    import json
+    return json.load(open(os.path.join(ROOT, "profiles", "r04_driver_cmd_bench_line.json")))
+
+
+def test_final_line_fits_the_drivers_tail(tmp_path, capsys, monkeypatch):
+    """the driver keeps the last ~8 KB of stdout + stderr and parses the final line; round 4's line had grown to
+    20 KB and BENCH_r04 was `parsed: null`.  The line must stay under 4 KB, parse from the last 4096 bytes of stdout, and carry
+    the contract's keys with `roofline` and `cpu_baseline`."""
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    full = _canned_full_result()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))       # (the detail file goes to <ROOT>/gpurun_out)
+    print("x" * 20000)                                      # whatever was on stdout before the line
+    bench.emit(full)
+    out = capsys.readouterr()
+    assert out.err == ""                                    # nothing on stderr: the driver's tail is one buffer for both
+    tail = out.out.encode()[-4096:].decode()
+    last = tail.rstrip("\n").split("\n")[-1]
+    assert len(last) < 4096
+    line = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["value"] == full["value"] and line["ms_per_step"] == full["ms_per_step"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in line["roofline"], k
+    assert line["roofline"]["frac"] == full["roofline"]["frac"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in line["cpu_baseline"], k
+    assert "workload" in line["config"] and "model" not in line["config"]
+    for sub in ("convolver", "equalizer", "spectral"):
+        assert line[sub]["value"] == full[sub]["value"] and "frac" in line[sub]["roofline"]
+    detail = json.load(open(os.path.join(str(tmp_path), line["detail"])))
+    assert detail["timing"]["region_ms"]["in_order"] == full["timing"]["region_ms"]["in_order"]     # nothing is lost, only moved
+
+
+def test_final_line_sheds_parts_rather_than_grow():
+    import importlib
+    import json
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    full = _canned_full_result()
+    full["next_rows"] = {"row%d" % i: {"value": 1.0, "ms_per_step": 0.1, "whole_step": {"frac": 0.5}} for i in range(200)}
+    full["config"]["workload"] = "w" * 5000
+    line = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    text = json.dumps(line)
+    assert len(text) <= bench.LINE_LIMIT
+    assert "roofline" in line and "cpu_baseline" in line and "value" in line
