@@ -85,6 +85,9 @@ int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
  * agree as after eager calls; no graph is returned.  Dynamic filters refuse capture (MI_ESTATE) while a clear of their
  * filter memory is pending (right after init / set_sample_rate): make one eager call first.  On a stream captured with
  * hipStreamBeginCapture directly those banks' process() returns MI_ESTATE and changes nothing.
+ * launch: a bank that has re-made device buffers since the capture (the convolver's ring of frames is grown once, by
+ * the bank's first mi_convolver_bank_process_blocks batch) makes the graph stale: MI_ESTATE, nothing is launched --
+ * capture again.
  */
 int         mi_dspu_graph_begin_capture(void *stream);
 int         mi_dspu_graph_end_capture(void *stream, void **graph_exec);

@@ -1606,7 +1606,6 @@ struct mi_convolver_bank
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     float2     *d_yts = nullptr;                        // [channels][BATCH_MAX][B]: what the inverse transforms of a batch of frames take (process_blocks)
     float      *d_acc_new = nullptr;                    // [channels][B]: the accumulator a batch leaves, on its way into d_acc
-    float2     *d_ring_first = nullptr;                 // the ring the bank was made with, once a batch has grown it (kept, unused)
     // Single-partition banks (the equalizer's FIR) can change their responses while streaming, channel by channel, the
     // way a reference Equalizer object does (Equalizer.cpp:339-345,481-501): every object has a response in force (vConv),
     // a cross-fade target (vNewConv) and a flag that the target waits for the block that completes next (EF_XFADE).
@@ -1763,8 +1762,10 @@ namespace
                 (void)hipFree(grown);
                 MI_HIP_CHECK(e);
             }
-            // (the ring of before stays allocated until the bank goes: a graph captured on it earlier must not run into freed memory)
-            b->d_ring_first = b->d_ring;
+            // A graph captured on this bank earlier holds the old ring, its size and slot in its launches: the epoch tells
+            // mi_dspu_graph_launch to refuse it (MI_ESTATE) -- so the old ring can go (the stream has just been drained).
+            mi::bank_epoch_bump(b);
+            (void)hipFree(b->d_ring);
             b->d_ring = grown;
             b->R = newR;
             b->slot = newR - 1;
@@ -2255,7 +2256,8 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
-    (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new); (void)hipFree(b->d_ring_first);
+    (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new);
+    mi::bank_epoch_forget(b);
     const bool faulted = (b->h_fault != nullptr) && (*static_cast<volatile uint32_t *>(b->h_fault) != 0u);
     (void)hipHostFree(b->h_fault);
     delete b;
@@ -2520,7 +2522,8 @@ int mi_convolver_bank_process_blocks(mi_convolver_bank_t *b, float *const *out, 
     while (k < blocks)
     {
         size_t run = 0;
-        const bool batchable = b->live && b->P >= 2 && b->R >= 1 && samples == size_t(b->B) && b->off == 0 && !b->frame_open &&
+        // (one_launch: the batch is bit for bit the ONE-LAUNCH frame step's sums; the two-launch fall-back stays frame by frame)
+        const bool batchable = b->live && b->one_launch && b->P >= 2 && b->R >= 1 && samples == size_t(b->B) && b->off == 0 && !b->frame_open &&
                                !b->xfade_active && !b->xf_any && b->logm >= 9 && b->logm <= 12 && !capturing && !per_frame &&
                                (b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u);
         if (batchable)

@@ -30,6 +30,10 @@ namespace mi
     // capturing; MI_ESTATE when it is captured behind the library's back.
     typedef uint64_t (*position_fn)(const void *bank);
     int         capture_touch(hipStream_t st, const void *bank, const char *what, position_fn fn);
+    // A bank that re-makes device buffers its launches take by value (the convolver's ring at its first batch of frames) bumps
+    // its epoch: graphs captured on it before are refused at mi_dspu_graph_launch (MI_ESTATE) instead of replaying stale addresses.
+    void        bank_epoch_bump(const void *bank);
+    void        bank_epoch_forget(const void *bank);        // at the bank's destruction
     uint64_t    delay_bank_positions(const void *bank);         // delay.hip
     uint64_t    convolver_bank_positions(const void *bank);     // convolver.hip
     uint64_t    spectral_bank_positions(const void *bank);      // spectral.hip

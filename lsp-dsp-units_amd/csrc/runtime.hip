@@ -33,9 +33,23 @@ namespace mi
 
 namespace
 {
-    struct capture_note { const void *bank; const char *what; mi::position_fn fn; uint64_t sig; };
+    struct capture_note { const void *bank; const char *what; mi::position_fn fn; uint64_t sig; uint64_t epoch; };
     std::mutex g_capture_lock;
     std::map<hipStream_t, std::vector<capture_note>> g_captures;       // streams being captured through mi_dspu_graph_begin_capture
+    // Banks whose device buffers have been re-made since they were created (the convolver's ring, grown by its first batch
+    // of frames): a graph captured before that has the old addresses and sizes baked into its launches.  Every captured
+    // bank's epoch is kept with the executable graph and compared again at every launch.
+    std::map<const void *, uint64_t> g_epochs;
+    uint64_t epoch_of(const void *bank)                                // (g_capture_lock held)
+    {
+        auto it = g_epochs.find(bank);
+        return it == g_epochs.end() ? 0 : it->second;
+    }
+    struct graph_handle
+    {
+        hipGraphExec_t exec = nullptr;
+        std::vector<capture_note> banks;
+    };
 }
 
 namespace mi
@@ -55,8 +69,20 @@ namespace mi
         for (const capture_note &n : it->second)
             if (n.bank == bank)
                 return MI_OK;
-        it->second.push_back(capture_note{ bank, what, fn, fn(bank) });
+        it->second.push_back(capture_note{ bank, what, fn, fn(bank), epoch_of(bank) });
         return MI_OK;
+    }
+
+    void bank_epoch_bump(const void *bank)
+    {
+        std::lock_guard<std::mutex> lock(g_capture_lock);
+        ++g_epochs[bank];
+    }
+
+    void bank_epoch_forget(const void *bank)
+    {
+        std::lock_guard<std::mutex> lock(g_capture_lock);
+        g_epochs.erase(bank);
     }
 }
 
@@ -252,21 +278,38 @@ int mi_dspu_graph_end_capture(void *stream, void **graph_exec)
     // cannot upload simply does it at that launch)
     if (hipGraphUpload(exec, mi::as_stream(stream)) != hipSuccess)
         (void)hipGetLastError();
-    *graph_exec = exec;
+    graph_handle *h = new graph_handle;
+    h->exec = exec;
+    h->banks.swap(notes);
+    *graph_exec = h;
     return MI_OK;
 }
 
 int mi_dspu_graph_launch(void *graph_exec, void *stream)
 {
     MI_REQUIRE(graph_exec != nullptr, MI_EINVAL, "mi_dspu_graph_launch: NULL graph");
-    MI_HIP_CHECK(hipGraphLaunch(reinterpret_cast<hipGraphExec_t>(graph_exec), mi::as_stream(stream)));
+    graph_handle *h = static_cast<graph_handle *>(graph_exec);
+    {
+        std::lock_guard<std::mutex> lock(g_capture_lock);
+        for (const capture_note &n : h->banks)
+            if (epoch_of(n.bank) != n.epoch)
+                return mi::fail(MI_ESTATE, "mi_dspu_graph_launch: the %s bank has re-made its device buffers since this graph was "
+                                "captured (a first batch of frames grows the convolver's ring): the graph's launches hold the old "
+                                "ones -- capture again", n.what);
+    }
+    MI_HIP_CHECK(hipGraphLaunch(h->exec, mi::as_stream(stream)));
     return MI_OK;
 }
 
 int mi_dspu_graph_destroy(void *graph_exec)
 {
     if (graph_exec != nullptr)
-        MI_HIP_CHECK(hipGraphExecDestroy(reinterpret_cast<hipGraphExec_t>(graph_exec)));
+    {
+        graph_handle *h = static_cast<graph_handle *>(graph_exec);
+        const hipError_t e = hipGraphExecDestroy(h->exec);
+        delete h;
+        MI_HIP_CHECK(e);
+    }
     return MI_OK;
 }
 

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
-from conftest import TOL, parity_report, record_parity
+from conftest import TOL, note, parity_report, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -94,7 +94,7 @@ def test_collisions_subset(gpu):
         assert np.abs(y[0] - ref).max() <= 1e-5, gap
 
 
-@pytest.mark.parametrize("rank", [8, 9, 10, 11, 12, 13, 14, 16])
+@pytest.mark.parametrize("rank", [8, 9, 10, 11, 12, 13, 14, 15, 16])        # every rank of util/Convolver.h:28-29
 def test_whole_frames_every_rank(gpu, rank):
     rng = np.random.default_rng(rank)
     frame = 1 << (rank - 1)
@@ -195,6 +195,108 @@ def test_c3_full_size(gpu):
         worst_last = max(worst_last, err)
     print("C3 full size, 17 frames, 256 channels: worst |gpu - oracle| / peak = %.2e, worst |gpu - exact| / peak on the last "
           "frame = %.2e" % (worst, worst_last))
+
+
+
+def test_c3_full_size_process_blocks(gpu):
+    """BASELINE config 2 at full size through the call bench.py's C3 `value` is measured on: 256 channels, distinct 65536-tap
+    IRs, rank 13, THIRTY-THREE 4096-sample frames as ONE mi_convolver_bank_process_blocks call = two batches of sixteen
+    frames and a single one.  With 256 channels a batch takes the `direct` branch of launch_batch (one run per channel: the
+    frames kernel leaves the accumulator in place and zeroes its upper half itself, no finish launch) that no smaller test
+    reaches.  Every channel against the oracle (the reference's non-uniform algorithm, float32) and exact (float64) linear
+    convolution over all frames; frame 33 of every channel -- all sixteen partitions' contributions, three laps of batches
+    behind it -- against float64 with the strict 1e-5; and, bit for bit, against a twin bank stepped frame by frame
+    (conv_step_kernel: what test_c3_full_size holds against the oracle)."""
+    C, taps, frame, nf = 256, 65536, 4096, 33
+    rng = np.random.default_rng(4)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / 16384.0)).astype(np.float32)
+    x = np.random.default_rng(55).standard_normal((C, nf * frame)).astype(np.float32)
+    bank, twin = gpu.ConvolverBank(irs, 13), gpu.ConvolverBank(irs, 13)
+    ins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, f * frame:(f + 1) * frame])) for f in range(nf)]
+    outs = [gpu.DeviceBuffer((C, frame)) for _ in range(nf)]
+    touts = [gpu.DeviceBuffer((C, frame)) for _ in range(nf)]
+    bank.process_blocks(outs, ins, frame)
+    for f in range(nf):
+        twin.process(touts[f], ins[f], frame)
+    assert bank.faults() == 0 and twin.faults() == 0
+    y = np.concatenate([o.download() for o in outs], axis=1)
+    yt = np.concatenate([o.download() for o in touts], axis=1)
+    bank.close(); twin.close()
+    np.testing.assert_array_equal(y, yt)                       # the batches' sums are the frame step's, at BASELINE size
+
+    def ref(c):
+        o = oracle.Convolver(irs[c], 13)
+        return np.concatenate([o.process(x[c, i:i + frame]) for i in range(0, nf * frame, frame)])
+
+    def exact(c):
+        return exact_conv(x[c], irs[c])
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        refs = list(ex.map(ref, range(C)))
+        exacts = list(ex.map(exact, range(C)))
+    worst, worst_last = 0.0, 0.0
+    for c in range(C):
+        r = check(y[c], refs[c], exacts[c], "C3 batches ch %d" % c)
+        worst = max(worst, r["gpu_vs_ref32"])
+        last = exacts[c][(nf - 1) * frame:]
+        err = float(np.abs(y[c, (nf - 1) * frame:] - last).max()) / float(np.abs(last).max())
+        record_parity("convolver C3 batches, frame 33 of every channel: |gpu - exact| <= 1e-5 peak", err, TOL)
+        assert err <= TOL, (c, err)
+        worst_last = max(worst_last, err)
+    note("C3 full size as ONE process_blocks call (16 + 16 + 1 frames, 256 channels, direct branch): worst |gpu - oracle| / peak = "
+         "%.2e, worst |gpu - exact| / peak on frame 33 = %.2e; bit-identical to 33 process() calls" % (worst, worst_last))
+
+
+_DIRECT_VS_FINISH = r"""
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+mi = importlib.import_module("lsp-dsp-units_amd")
+C, rank, taps, nf = 130, 10, 2000, 21
+frame = 1 << (rank - 1)
+rng = np.random.default_rng(130)
+irs = (rng.standard_normal((C, taps)) * 0.05).astype(np.float32)
+x = (rng.standard_normal((nf + 2, C, frame)) * 0.25).astype(np.float32)
+bank = mi.ConvolverBank(irs, rank)
+ins = [mi.DeviceBuffer.from_host(x[k]) for k in range(nf + 2)]
+outs = [mi.DeviceBuffer((C, frame)) for _ in range(nf + 2)]
+bank.process(outs[0], ins[0], 100, frame, frame)            # a frame in pieces in front: the accumulator's upper half is in use
+bank.process(outs[0].ptr + 400, ins[0].ptr + 400, frame - 100, frame, frame)
+bank.process_blocks(outs[1:nf + 1], ins[1:nf + 1], frame)   # 16 + 4 + 1
+bank.process(outs[nf + 1], ins[nf + 1], frame)              # a frame on what the batches left
+assert bank.faults() == 0
+np.save(sys.argv[2], np.stack([o.download() for o in outs]))
+bank.close()
+"""
+
+
+def test_process_blocks_direct_branch_equals_the_finish_launch(gpu, tmp_path):
+    """launch_batch with one run per channel (more than 128 channels) writes the accumulator a batch leaves straight into the
+    bank's (`direct`), with fewer channels a finish launch does (conv_batch_finish_kernel; MI_CONV_BATCH_FINISH forces it).  130
+    channels at rank 10, a frame in pieces in front (the accumulator's upper half is live when the first batch starts), 21 frames
+    as batches of 16 + 4 + 1, a frame behind: both branches bit for bit, and against frame-by-frame calls and the oracle.  (The
+    knob is read once per process: each variant runs in a process of its own.)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for name, env in (("direct", {}), ("finish", {"MI_CONV_BATCH_FINISH": "1"}), ("calls", {"MI_CONV_FRAME_PER_LAUNCH": "1"})):
+        out = str(tmp_path / (name + ".npy"))
+        e = dict(os.environ)
+        e.update(env)
+        subprocess.run([sys.executable, "-c", _DIRECT_VS_FINISH, root, out], check=True, env=e, timeout=600)
+        got[name] = np.load(out)
+    np.testing.assert_array_equal(got["direct"], got["finish"])
+    np.testing.assert_array_equal(got["direct"], got["calls"])
+    C, rank, taps, nf = 130, 10, 2000, 21
+    frame = 1 << (rank - 1)
+    rng = np.random.default_rng(130)
+    irs = (rng.standard_normal((C, taps)) * 0.05).astype(np.float32)
+    x = (rng.standard_normal((nf + 2, C, frame)) * 0.25).astype(np.float32)
+    for ch in (0, 64, 129):
+        xs = x[:, ch, :].reshape(-1)
+        ref32 = oracle.Convolver(irs[ch], rank).process_chunked(xs, frame)
+        check(got["direct"][:, ch, :].reshape(-1), ref32, exact_conv(xs, irs[ch]), "direct branch ch %d" % ch)
 
 
 def test_one_launch_step_while_another_stream_keeps_every_cu_busy(gpu):

@@ -286,33 +286,42 @@ def test_runs_of_blocks_in_one_launch_equal_block_by_block(gpu, rank, mode):
 
 def test_c4_full_size(gpu):
     """BASELINE config 3 at the per-GPU size: 256 channels, 32 RLC bells each with its own gains (seed 6), fir_rank 12,
-    EQM_FIR, blocks of 4096.  Every channel against the oracle, and the size-independent properties: a second bank fed the
-    same input gives the same bits, and an input scaled by 2 gives exactly twice the output."""
+    EQM_FIR, NINE blocks of 4096: the first through mi_equalizer_bank_process, the other eight as ONE
+    mi_equalizer_bank_process_blocks call (conv_frames_kernel<12> at 256 channels: the launch bench.py's C4 `value` is measured
+    on).  Every channel against the oracle, bit for bit against nine process() calls (conv_frame_kernel<12>), and the
+    size-independent properties: a second bank fed the same input gives the same bits, and an input scaled by 2 gives exactly
+    twice the output."""
     rng = np.random.default_rng(6)
-    C, rank, nfilt, n, blocks = 256, 12, 32, 4096, 3
+    C, rank, nfilt, n, blocks = 256, 12, 32, 4096, 9
     x = (rng.standard_normal((C, n * blocks)) * 0.25).astype(np.float32)
     curves = [c4_filters(rng) for _ in range(C)]
 
-    def run(scale):
+    def run(scale, blocks_call=True):
         eq = gpu.EqualizerBank(C, nfilt, rank)
         eq.set_mode(oe.FIR)
         eq.set_sample_rate(48000)
         for c in range(C):
             for i, p in enumerate(curves[c]):
                 eq.set_params(i, *p, channel=c)
-        y = np.empty_like(x)
-        for b in range(blocks):
-            din = gpu.DeviceBuffer.from_host(x[:, b * n:(b + 1) * n] * np.float32(scale)); dout = gpu.DeviceBuffer((C, n))
-            eq.process(dout, din, n)
-            y[:, b * n:(b + 1) * n] = dout.download()
+        ins = [gpu.DeviceBuffer.from_host(x[:, b * n:(b + 1) * n] * np.float32(scale)) for b in range(blocks)]
+        outs = [gpu.DeviceBuffer((C, n)) for _ in range(blocks)]
+        eq.process(outs[0], ins[0], n)
+        if blocks_call:
+            eq.process_blocks(outs[1:], ins[1:], n)
+        else:
+            for b in range(1, blocks):
+                eq.process(outs[b], ins[b], n)
+        y = np.concatenate([o.download() for o in outs], axis=1)
         eq.close()
         return y
 
+    y_calls = run(1.0, blocks_call=False)
     y1, y1b, y2 = run(1.0), run(1.0), run(2.0)
     assert np.isfinite(y1).all() and float(np.abs(y1).max()) > 0.0
     np.testing.assert_array_equal(y1, y1b)
     np.testing.assert_array_equal(y2, 2.0 * y1)
-    # EVERY channel against the oracle (worker processes: 0.3 s of oracle per channel)
+    np.testing.assert_array_equal(y1, y_calls)              # the run of blocks in one launch: the bits of the calls one by one
+    # EVERY channel against the oracle (worker processes: about a second of oracle per channel)
     import oracle_workers as ow
     refs = ow.run_pool(ow.c4_channel, [(curves[c], x[c], nfilt, rank) for c in range(C)])
     errs, exacts, noises = np.empty(C), np.empty(C), np.empty(C)
@@ -325,7 +334,7 @@ def test_c4_full_size(gpu):
         errs[c] = float(np.abs(y1[c] - ref).max() / peak)
         exacts[c] = float(np.abs(y1[c] - ref_exact).max() / peak)
     pct = lambda v: [round(float(np.percentile(v, q)), 2) for q in (50, 90, 99, 100)]
-    note("C4 full size, all %d channels against the oracle: |gpu - oracle| / peak median %.2e, max %.2e; channels within 1e-5: %d; "
+    note("C4 full size (9 blocks, 8 of them as ONE mi_equalizer_bank_process_blocks call), all %d channels against the oracle: |gpu - oracle| / peak median %.2e, max %.2e; channels within 1e-5: %d; "
          "the FIR synthesis' own float32 noise: median %.2e, max %.2e; |gpu - float64-response output| / noise percentiles "
          "50/90/99/100 = %s, |gpu - oracle| / noise = %s"
          % (C, float(np.median(errs)), float(errs.max()), int((errs <= TOL).sum()), float(np.median(noises)), float(noises.max()),

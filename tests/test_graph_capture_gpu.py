@@ -410,3 +410,41 @@ def test_convolver_process_blocks_under_capture_is_the_loop_of_calls(gpu):
 
     K = _run(gpu, Case("convolver blocks", lambda st: gpu.ConvolverBank(irs, rank, stream=st), call, (Kb, C, frame), [(Kb, C, frame)]), max_k=3)
     assert K == 1
+
+
+def test_graph_captured_before_the_ring_grew_is_refused(gpu):
+    """a graph captured on a convolver bank holds the ring's address, size and slot in its launches; the bank's first
+    batch of frames re-makes the ring.  The library keeps every captured bank's epoch with the executable graph: the stale
+    graph is refused at mi_dspu_graph_launch (MI_ESTATE, nothing launched), a graph captured afterwards replays bit for bit."""
+    hip, s = _stream()
+    st = s.value
+    C, rank, taps = 3, 10, 2000                              # four partitions of 512: a ring of 3 frames, 19 after a batch
+    frame = 1 << (rank - 1)
+    rng = np.random.default_rng(31)
+    irs = (rng.standard_normal((C, taps)) * 0.1).astype(np.float32)
+    xs = [(rng.standard_normal((C, frame)) * 0.25).astype(np.float32) for _ in range(3)]
+    bank = gpu.ConvolverBank(irs, rank, stream=st)
+    ins = [gpu.DeviceBuffer.from_host(x, stream=st) for x in xs]
+    outs = [gpu.DeviceBuffer((C, frame)) for _ in range(3)]
+    for k in range(3):
+        bank.process(outs[k], ins[k], frame, stream=st)
+    gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+    gpu.check(gpu.lib.mi_dspu_graph_begin_capture(ctypes.c_void_p(st)))
+    for k in range(3):                                       # a lap of the ring of three
+        bank.process(outs[k], ins[k], frame, stream=st)
+    exe = ctypes.c_void_p()
+    gpu.check(gpu.lib.mi_dspu_graph_end_capture(ctypes.c_void_p(st), ctypes.byref(exe)))
+    gpu.check(gpu.lib.mi_dspu_graph_launch(exe, ctypes.c_void_p(st)))          # fine so far
+    bank.process_blocks(outs[:2], ins[:2], frame, stream=st)                    # the first batch: the ring is re-made
+    gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+    before = [o.download(stream=st) for o in outs]
+    rc = gpu.lib.mi_dspu_graph_launch(exe, ctypes.c_void_p(st))
+    assert rc == -5, rc                                      # MI_ESTATE (include/mi_dspu.h:40)
+    assert "capture again" in gpu.lib.mi_dspu_last_error().decode()
+    gpu.check(gpu.lib.mi_dspu_stream_synchronize(ctypes.c_void_p(st)))
+    for o, w in zip(outs, before):
+        np.testing.assert_array_equal(o.download(stream=st), w)                 # nothing ran
+    gpu.lib.mi_dspu_graph_destroy(exe)
+    assert bank.faults(stream=st) == 0
+    bank.close()
+    hip.hipStreamDestroy(s)
