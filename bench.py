@@ -58,6 +58,7 @@ def parse():
     ap.add_argument("--conv-channels", type=int, default=256, help="convolver channels per GPU")
     ap.add_argument("--eq-channels", type=int, default=256, help="equalizer channels per GPU (config 3: 2048 over 8 GPUs)")
     ap.add_argument("--spec-channels", type=int, default=1024, help="analyzer channels per GPU (config 4: 8192 over 8 GPUs)")
+    ap.add_argument("--split-channels", type=int, default=256, help="splitter row: channels per GPU")
     ap.add_argument("--call", type=int, default=0, help="convolver workload: also time a stream of calls of this many samples "
                     "(e.g. 256: what a plugin host does; a step is still one 4096-sample frame = 4096 / call calls)")
     ap.add_argument("--no-stream-pair", action="store_true", help="meters row: skip the extra measurement with the two banks on "
@@ -967,7 +968,7 @@ def run_crossover(args, mi, torch, dist, rank, world, dev):
 def run_splitter(args, mi, torch, dist, rank, world, dev):
     """FFTCrossover / SpectralSplitter, rank 12 (frames of 2048 new samples), 4 bands of real gains,
     256 channels x 4096 samples per step.  Algorithmic bytes: 4 B in + 4 x 4 B out = 20 B per channel-sample."""
-    C, bands, rank_fft, n = 256, 4, 12, 4096
+    C, bands, rank_fft, n = args.split_channels, 4, 12, 4096
     sp = mi.SplitterBank(C, rank_fft, bands)
     edges = [(None, (300.0, -32.0)), ((300.0, -32.0), (2000.0, -32.0)), ((2000.0, -32.0), (8000.0, -32.0)), ((8000.0, -32.0), None)]
     for b, (hp, lp) in enumerate(edges):

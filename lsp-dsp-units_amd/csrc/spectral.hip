@@ -958,13 +958,23 @@ namespace
             }
         };
         // ... into the ring behind the head of strobe f (Analyzer.cpp:371-398)
+        // (an even head in a ring of even size: a pair never straddles the wrap and goes out as ONE 8-byte store -- 512 contiguous
+        // bytes per wave instruction.  As two 4-byte stores every instruction wrote every other word of four cache lines and the
+        // write-through traffic of the ingest counted twice: round 4's 1.40 x of the launch's algorithmic bytes,
+        // profiles/r04_pmc_hbm_raw.json WRITE_SIZE 403 MB against 279 MB of rows and samples)
         auto ingest_hop = [&](int f, const float2 (&v)[HALF]) {
             const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(f) * HOP) % buf_size);
+            const bool pairs = ((h0 | buf_size) & 1u) == 0u;
             #pragma unroll
             for (int j = 0; j < HALF; ++j)
             {
                 uint32_t w0 = h0 + 2 * (tid + j * T);
                 if (w0 >= buf_size) w0 -= buf_size;
+                if (pairs)
+                {
+                    mi::wt_store(rring, int(w0 * sizeof(float)), v[j]);
+                    continue;
+                }
                 uint32_t w1 = w0 + 1;
                 if (w1 >= buf_size) w1 -= buf_size;
                 mi::wt_store(rring, int(w0 * sizeof(float)), v[j].x);
