@@ -143,6 +143,7 @@ def cpu_baseline_biquad(coef, samples, budget_s=5.0):
         "per_core": round(allc["value"] / max(1, allc["threads"]), 1),
         "one_core": {"value": res["one_core"]["value"], "unit": "Msamples/s", "cores": 1},
         "cpu_model": _cpu_model(), "build": "gcc -O3 -march=native -ffp-contract=fast -fopenmp (rebuilt on this host)",
+        "simd": "x8: eight sections side by side in vector registers",
         "sample": "%d blocks (all cores) / %d blocks (one core) of %d ch x %d samples in one parallel region each, 8-section "
                   "cascade as one x8 software-pipelined pass per channel and block (FilterBank.cpp:267-273), SIMD across "
                   "the sections, persistent threads; lsp-dsp-lib's hand-written kernels are not available offline"
@@ -241,36 +242,45 @@ def _profile_avg_us(workload, kernel):
 
 
 def cpu_baseline_convolver(irs, frame, budget_s=6.0):
-    """Oracle Convolver (restated reference algorithm: non-uniform partitions, scalar C) on this host's cores:
-    one object per channel, whole 4096-sample frames, as many channels as fit in ~budget_s."""
+    """The reference's Convolver::process on this host (oracle/cpu_baseline/fft_units_host.c: cpu_convolver_bank_* -- the oracle's
+    restatement of the non-uniform partitioned algorithm, Convolver.cpp:217-313, one object per channel, on the vectorised
+    dsp:: primitives of fft_simd_host.c, OpenMP over the channels; -O3 -march=native, rebuilt here)."""
+    import ctypes
     import numpy as np
-    import oracle
-    from concurrent.futures import ThreadPoolExecutor
+    lib = _cpubase()
+    fp = ctypes.POINTER(ctypes.c_float)
+    lib.cpu_convolver_bank_create.restype = ctypes.c_void_p
+    lib.cpu_convolver_bank_create.argtypes = [fp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    lib.cpu_convolver_bank_run.argtypes = [ctypes.c_void_p, fp, fp, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_size_t, ctypes.c_int]
+    lib.cpu_convolver_bank_destroy.argtypes = [ctypes.c_void_p]
+    f = lambda a: a.ctypes.data_as(fp)
     cores = _effective_cores()
-    workers = min(cores, 64)
-    nch = min(irs.shape[0], workers)
-    x = np.random.default_rng(5).standard_normal((nch, 2 * frame)).astype(np.float32)
-    objs = [oracle.Convolver(irs[c], 13) for c in range(nch)]
+    C, taps, ring = irs.shape[0], irs.shape[1], 2
+    irs = np.ascontiguousarray(irs, np.float32)
+    x = np.random.default_rng(5).standard_normal((ring, C, frame)).astype(np.float32)
+    y = np.empty_like(x)
+    bank = lib.cpu_convolver_bank_create(f(irs), taps, C, 13, cores)
+    used = [1]
 
-    def run(c):
-        objs[c].process(x[c, :frame])
-        objs[c].process(x[c, frame:])
-        return 2 * frame
-    t0 = time.perf_counter()
-    done = 0
-    with ThreadPoolExecutor(max_workers=workers) as ex:
-        while time.perf_counter() - t0 < budget_s:
-            done += sum(ex.map(run, range(nch)))
-    dt = time.perf_counter() - t0
+    def timed(frames):
+        t0 = time.perf_counter()
+        used[0] = lib.cpu_convolver_bank_run(bank, f(y), f(x), frame, frames, ring, cores)
+        return time.perf_counter() - t0
+    timed(2)                                                # (the ring of frame images fills)
+    rate, frames = _cpu_sized_run(timed, C * frame, budget_s, first=2)
+    lib.cpu_convolver_bank_destroy(bank)
+    assert np.isfinite(y).all() and float(np.abs(y).max()) > 0.0
     return {
-        "value": round(done / dt / 1e6, 3), "unit": "Msamples/s", "cores": workers, "kind": "port",
-        "sample": "%d channel-frames of 4096 samples, 65536-tap IR, rank 13, scalar C oracle of the reference's "
-                  "non-uniform partitioned algorithm, one thread per channel" % (done // frame),
+        "value": round(rate / 1e6, 2), "unit": "Msamples/s", "cores": used[0], "kind": "port", "simd": "gcc -O3 -march=native vector code",
+        "cpu_model": _cpu_model(),
+        "sample": "%d frames of %d channels x 4096 samples, 65536-tap IR per channel, rank 13: the reference's non-uniform partitioned "
+                  "algorithm (Convolver.cpp:217-313, C restatement) on vectorised four-step FFT primitives, OpenMP over the channels" % (frames, C),
     }
 
 
 def _cpubase():
-    """oracle/cpu_baseline rebuilt -O3 -march=native for this host (measurement infrastructure)."""
+    """oracle/cpu_baseline rebuilt -O3 -march=native for this host (measurement infrastructure): the reference's block logic on
+    vectorised restatements of the dsp:: primitives -- lsp-dsp-lib's own SIMD kernels are un-vendored (modules.mk:29-33)."""
     import ctypes
     import subprocess
     base = os.path.join(ROOT, "oracle", "cpu_baseline")
@@ -316,8 +326,9 @@ def cpu_baseline_equalizer(C, n, budget_s=5.0):
     rate, blocks = _cpu_sized_run(timed, C * n, budget_s)
     assert np.isfinite(y).all() and float(np.abs(y).max()) > 0.0
     return {"value": round(rate / 1e6, 2), "unit": "Msamples/s", "cores": used[0], "kind": "port", "cpu_model": _cpu_model(),
+            "simd": "gcc -O3 -march=native vector code",
             "sample": "%d blocks of %d ch x %d samples, Equalizer EQM_FIR fir_rank 12 (Equalizer.cpp:460-571: one 8192-point "
-                      "fastconv_parse_apply per block and channel), scalar C primitives, OpenMP over the channels" % (blocks, C, n)}
+                      "fastconv_parse_apply per block and channel), vectorised four-step FFT primitives, OpenMP over the channels" % (blocks, C, n)}
 
 
 def cpu_baseline_analyzer(C, rank_fft, hop, budget_s=5.0):
@@ -346,8 +357,9 @@ def cpu_baseline_analyzer(C, rank_fft, hop, budget_s=5.0):
     rate, frames = _cpu_sized_run(timed, C, budget_s)
     assert np.isfinite(amp).all() and float(amp.max()) > 0.0
     return {"value": round(rate, 1), "unit": "channel-frames/s", "cores": used[0], "kind": "port", "cpu_model": _cpu_model(),
+            "simd": "gcc -O3 -march=native vector code",
             "sample": "%d frames of %d channels (2048 new samples, one Hann-windowed 4096-point spectrum, magnitude, smoothing: "
-                      "Analyzer.cpp:299-409), scalar C primitives, OpenMP over the channels" % (frames, C)}
+                      "Analyzer.cpp:299-409), vectorised four-step FFT primitives, OpenMP over the channels" % (frames, C)}
 
 
 def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
