@@ -205,6 +205,23 @@ def _biquad_issue_side(kernel_ms, C, n, sections, launch_steps, counters):
             "counters_from": "profiles/" + counters}
 
 
+
+def _issue_side(kernel, kernel_ms, launch_units, counters="r05_kernels_pmc_sq.json"):
+    """The second roof of a launch next to the HBM one: vector issue.  VALU instructions per unit (block / frame) of `kernel`
+    from the committed rocprofv3 --pmc counts (profiles/<counters>, tests/prof_valu.sh), one wave64 VALU instruction per 4 clocks
+    and SIMD, 1024 SIMDs, 2.4 GHz: valu_issue_frac = that floor / the launch's measured time per unit.  A launch far below BOTH
+    roofs (the transforms: 0.3 - 0.4 of the issue rate at a fraction of the HBM rate) is bound by neither -- by its passes
+    through LDS and the barriers between them (profiles/r05_experiments/fft_kernels_issue_and_occupancy.txt)."""
+    doc = _committed_json(counters) or {}
+    for name, d in (doc.get("kernels") or {}).items():
+        if kernel in name and kernel_ms:
+            per_unit_s = _probe_mean(kernel_ms) * 1e-3 / launch_units
+            floor_s = float(d["valu_per_unit"]) * 4.0 / 1024.0 / 2.4e9
+            return {"valu_issue_frac": round(floor_s / per_unit_s, 4), "valu_insts_per_unit": round(float(d["valu_per_unit"])),
+                    "valu_issue_floor_us_per_unit": round(floor_s * 1e6, 3), "counters_from": "profiles/" + counters}
+    return {}
+
+
 def _pmc_traffic(name, kernel=None, units=1):
     """HBM bytes per launch measured with rocprofv3 --pmc (committed under profiles/), or None.  kernel: the summary must be
     of that kernel; units: what this run's launch carries (blocks of a biquad_stream_kernel launch) -- the summary holds the
@@ -453,8 +470,9 @@ def _convolver_pass(args, mi, torch, dist, rank, world, dev, C, steps, warmup):
             "roofline": _roofline("conv_batch_tail_kernel<%d> (%d frames per launch; the batch is three launches)" % (BATCH, BATCH),
                                   tail_bytes, b_kernel_ms, b_elapsed / steps * 1e3, b_info["probe"],
                                   _pmc_traffic("pmc_convolver_latest.json", "conv_batch_tail_kernel", BATCH) if C == 256 else None,
-                                  {"bytes_model": "this kernel per channel and batch: P + (P - 2) + K + 1 images of 32 KiB read, K + 1 written",
-                                   "streaming_model_frac": round(step_bytes / (b_elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                                  dict({"bytes_model": "this kernel per channel and batch: P + (P - 2) + K + 1 images of 32 KiB read, K + 1 written",
+                                        "streaming_model_frac": round(step_bytes / (b_elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)},
+                                       **(_issue_side("conv_batch_tail_kernel<16", b_kernel_ms, BATCH) if C == 256 else {})),
                                   launch_steps=BATCH),
             "whole_step": {"algorithmic_bytes": batch_bytes / BATCH, "bytes_model": "a batch of K frames per channel: in + out 16 K KiB each, "
                            "overlap-add tail 32 KiB, H P x 32 KiB, ring (P - 1) x 32 KiB read and min(K, P - 1) x 32 KiB written",
@@ -768,7 +786,7 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
         cpu = cpu_baseline_equalizer(C, n)
     res = {
         "value": round(C * n * world * args.conv_steps / elapsed / 1e6, 1), "unit": "Msamples/s",
-        "ms_per_step": round(elapsed / args.conv_steps * 1e3, 5),
+        "ms_per_step": round(elapsed / args.conv_steps * 1e3, 5), "steps": args.conv_steps, "warmup": args.conv_warmup,
         "config": {"workload": "Equalizer EQM_FIR, 32 x FLT_BT_RLC_BELL per channel, fir_rank 12, %d channels per GPU, "
                                "4096-sample blocks" % C, "channels_per_gpu": C},
         # the step is ONE launch: conv_frame_kernel<12> pulls the frame out of the delay line, transforms, multiplies with
@@ -779,6 +797,7 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
         "roofline": _roofline("conv_frames_kernel<12> (%d blocks per launch)" % launch_steps, step_bytes * launch_steps, kernel_ms,
                               elapsed / args.conv_steps * 1e3, tinfo["probe"],
                               _pmc_traffic("pmc_equalizer_latest.json", "conv_frames_kernel", launch_steps) if C == 256 else None,
+                              _issue_side("conv_frames_kernel<12>", kernel_ms, launch_steps) if C == 256 else None,
                               launch_steps=launch_steps),
         "whole_step": {"algorithmic_bytes": step_bytes,
                        "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / args.conv_steps) / 1e9, 1),
@@ -869,7 +888,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     res = {
         "value": round(C * world * steps / elapsed, 1), "unit": "channel-frames/s",
         "msamples_per_s": round(C * world * hop * steps / elapsed / 1e6, 1),
-        "ms_per_step": round(elapsed / steps * 1e3, 5),
+        "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps, "warmup": batch,
         "config": {"workload": "Analyzer: 4096-point Hann spectrum per channel every 2048 samples, %d channels per GPU, "
                                "per-bin sum over all channels (all-reduce of %d x %d floats per %d frames)"
                                % (C, batch, bins, batch), "channels_per_gpu": C, "collective": state["collective"]},
@@ -880,6 +899,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         "roofline": _roofline("analyzer_frames_kernel<11> (%d frames per launch)" % batch, frame_bytes * batch, kernel_ms,
                               elapsed / steps * 1e3, tinfo["probe"],
                               _pmc_traffic("pmc_spectral_latest.json", "analyzer_frames_kernel", batch) if C == 1024 else None,
+                              _issue_side("analyzer_frames_kernel<11>", kernel_ms, batch) if C == 1024 else None,
                               launch_steps=batch),
         "whole_step": {"algorithmic_bytes": frame_bytes,
                        "achieved_GBps_incl_launch_gaps": round(frame_bytes / (elapsed / steps) / 1e9, 1),
@@ -931,13 +951,19 @@ def _step_result(name, workload, C, n, steps, elapsed, world, bytes_per_sample, 
     """Sub-result of a SURVEY 8f row: whole-step throughput against the algorithmic bytes (several launches per step)."""
     step_bytes = float(bytes_per_sample) * C * n
     res = {"value": round(C * n * world * steps / elapsed / 1e6, 1), "unit": "Msamples/s",
-           "ms_per_step": round(elapsed / steps * 1e3, 5),
+           "ms_per_step": round(elapsed / steps * 1e3, 5), "steps": steps,
            "config": {"workload": workload, "channels_per_gpu": C, "block": n},
            "whole_step": {"algorithmic_bytes": step_bytes, "bytes_per_channel_sample": bytes_per_sample,
                           "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / steps) / 1e9, 1),
                           "frac": round(step_bytes / (elapsed / steps) / 1e9 / HBM_PEAK_GBS, 4)}}
     if extra:
         res.update(extra)
+    # (the row's dominant launch against the vector unit's issue rate, priced from the whole step: the rows carry no kernel probes)
+    kern = {"crossover": "biquad_stream_chain_kernel", "splitter": "splitter_hops_blocks_kernel", "spectral_processor": "stft_stream_blocks_kernel",
+            "dynfilter": "dynfilter_kernel"}.get(name)
+    side = _issue_side(kern, [elapsed / steps * 1e3], 1) if kern else {}
+    if side and (C, n) == {"splitter": (256, 4096)}.get(name, (1024, 4096)):
+        res["whole_step"]["valu_issue_frac"] = side["valu_issue_frac"]
     return res
 
 
@@ -1111,7 +1137,7 @@ def _short_roofline(rf):
         out["algorithmic"] = _r(alg, 0)
         if rf.get("traffic"):
             out["traffic_ratio"] = _r(rf["traffic"] / alg, 3)
-    for k in ("kernel_avg_us", "kernel_samples", "steps_per_launch", "whole_step_frac", "valu_issue_frac", "second_roof"):
+    for k in ("kernel_avg_us", "kernel_samples", "steps_per_launch", "whole_step_frac", "valu_issue_frac"):
         if rf.get(k) is not None:
             out[k] = rf[k]
     return out
@@ -1185,8 +1211,10 @@ def compact_line(full, detail_path=None):
     if sp:
         nxt["spectral_processor"] = sp
     if nxt:
-        line["next_rows"] = {k: {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"),
-                                 "whole_step_frac": (v.get("whole_step") or {}).get("frac")} for k, v in nxt.items() if v}
+        line["next_rows"] = {k: {kk: vv for kk, vv in {"value": v.get("value"), "ms_per_step": v.get("ms_per_step"),
+                                                       "whole_step_frac": (v.get("whole_step") or {}).get("frac"),
+                                                       "valu_issue_frac": (v.get("whole_step") or {}).get("valu_issue_frac")}.items()
+                                 if vv is not None} for k, v in nxt.items() if v}
     if detail_path:
         line["detail"] = detail_path
     # never over the limit: shed the optional parts in order of (un)importance

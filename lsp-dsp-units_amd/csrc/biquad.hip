@@ -1814,7 +1814,9 @@ namespace mi
             a.st[k].slot = slot[k];
             a.st[k].branch = stages[k].branch ? 1 : 0;
         }
-        static const bool loop = getenv("MI_BIQUAD_BLOCKS_LOOP") != nullptr;    // test knob: a launch per block
+        // (test knob: a launch per block.  Read per call like mi_biquad_bank_process / _process_blocks read it, so that a test
+        // that flips it in-process switches the bank path and the chain path together: ADVICE r04)
+        const bool loop = getenv("MI_BIQUAD_BLOCKS_LOOP") != nullptr;
         const size_t spb = (samples + big::BLOCK - 1) / big::BLOCK;
         const size_t out_bytes = (size_t(channels - 1) * out_stride + samples) * sizeof(float);
         const size_t in_bytes  = (size_t(channels - 1) * in_stride + samples) * sizeof(float);

@@ -2261,6 +2261,9 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
     const uint32_t bins = (1u << (b->rank - 1)) + 1;
     MI_REQUIRE(out_stride >= bins, MI_EINVAL, "mi_analyzer_bank_process_reduce_frames: out_stride shorter than a row of bins");
     hipStream_t st = mi::as_stream(stream);
+    // (test knobs, read once per call -- not once per turn of the loop: ADVICE r04)
+    const bool knob_per_frame = getenv("MI_ANALYZER_REDUCE_PER_FRAME") != nullptr;
+    const bool knob_strobe_per_launch = getenv("MI_ANALYZER_STROBE_PER_LAUNCH") != nullptr;
     size_t f = 0;
     while (f < frames)
     {
@@ -2271,7 +2274,7 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
             return r;
         const bool batch = b->rank <= 14 && samples == size_t(b->period) && b->counter == 0 && !b->meta_dirty && frames - f >= 2 &&
                            size_t(b->buf_size) >= (size_t(1) << b->rank) + b->max_user_delay() + samples &&
-                           getenv("MI_ANALYZER_REDUCE_PER_FRAME") == nullptr;
+                           !knob_per_frame;
         if (!batch)
         {
             r = mi_analyzer_bank_process_reduce(b, in[f], samples, in_stride, out + f * out_stride, with_envelope, stream);
@@ -2283,14 +2286,24 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
         const size_t plane_bytes = size_t(b->channels) * b->bins_stride * sizeof(float);
         if (b->planes.empty())
         {
-            b->planes.push_back(b->d_amp);
-            b->planes.push_back(b->d_data);
+            // (all the spare planes or none: a list that is short would leave NULL rows for a later call to write through --
+            // ADVICE r04)
+            std::vector<float *> made;
+            made.push_back(b->d_amp);
+            made.push_back(b->d_data);
             for (uint32_t k = 0; k + 2 < REDUCE_FRAMES_MAX; ++k)
             {
                 float *p = nullptr;
-                MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&p), plane_bytes));
-                b->planes.push_back(p);
+                const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), plane_bytes);
+                if (e != hipSuccess)
+                {
+                    for (size_t j = 2; j < made.size(); ++j)
+                        (void)hipFree(made[j]);
+                    MI_HIP_CHECK(e);
+                }
+                made.push_back(p);
             }
+            b->planes.swap(made);
         }
         const size_t cnt = (frames - f < size_t(REDUCE_FRAMES_MAX)) ? frames - f : size_t(REDUCE_FRAMES_MAX);
         // Frame k's analysis reads the spectrum of the frame before (vAmp) and leaves its own in a plane that nothing reads
@@ -2313,7 +2326,7 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
         // every block is there; otherwise a launch per strobe
         const int lh = int(b->rank) - 1;
         bool one_launch = lh >= 9 && lh <= 12 && 2 * size_t(b->period) == (size_t(1) << b->rank) && b->max_user_delay() == 0 &&
-                          getenv("MI_ANALYZER_STROBE_PER_LAUNCH") == nullptr;
+                          !knob_strobe_per_launch;
         for (size_t k = 0; one_launch && k < cnt; ++k)
             one_launch = in[f + k] != nullptr;
         if (one_launch)

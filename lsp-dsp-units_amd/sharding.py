@@ -50,17 +50,54 @@ def library_comm(mi, group=None):
     dist.broadcast_object_list(box, src=src, group=group)
     if box[0] is None:
         return None
-    comm, ok = None, 1
-    try:
-        comm = mi.Comm(box[0], world, rank)
-    except Exception as e:
-        ok = 0
-        print("library_comm: rank %d could not join (%s)" % (rank, e))
     import torch
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
-    flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
-    if int(flag.item()) == 0:
+
+    def flag_device():
+        # (a group made with the default, multi-backend setting reports "cuda:nccl,cpu:gloo": anything with nccl in it carries
+        # device tensors)
+        backend = str(dist.get_backend(group)).lower()
+        return torch.device("cuda", torch.cuda.current_device()) if ("nccl" in backend and torch.cuda.is_available()) else torch.device("cpu")
+
+    def all_agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=flag_device())
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return int(flag.item()) != 0
+
+    # 1. Everything a rank can find out WITHOUT joining -- the id arrived whole, the library has the entry points, a device is
+    #    there -- is agreed on first: joining is a rendezvous (ncclCommInitRank), and a rank that raised before it would leave
+    #    the others blocked inside it, never reaching the vote below.
+    ready = True
+    try:
+        ready = isinstance(box[0], (bytes, bytearray)) and len(box[0]) == mi.Comm.ID_BYTES and mi.device_count() > 0 \
+                and hasattr(mi.lib, "mi_dspu_comm_create")
+    except Exception as e:
+        ready = False
+        print("library_comm: rank %d is not ready to join (%s)" % (rank, e))
+    if not all_agree(ready):
+        return None
+    # 2. The rendezvous itself, with a deadline: a peer that died on the way leaves ncclCommInitRank waiting for ever, and a job
+    #    that hangs is worse than one that ends -- the rank gives up with a non-zero status (MI_COMM_INIT_TIMEOUT seconds, 180).
+    import os
+    import threading
+    result = {}
+
+    def join():
+        try:
+            result["comm"] = mi.Comm(box[0], world, rank)
+        except Exception as e:
+            result["error"] = e
+    th = threading.Thread(target=join, daemon=True)
+    th.start()
+    th.join(float(os.environ.get("MI_COMM_INIT_TIMEOUT", "180")))
+    if th.is_alive():
+        print("library_comm: rank %d: the communicator's rendezvous did not complete in time; giving up" % rank, flush=True)
+        os._exit(3)
+    comm, ok = result.get("comm"), 1
+    if comm is None:
+        ok = 0
+        print("library_comm: rank %d could not join (%s)" % (rank, result.get("error")))
+    # 3. A communicator on every rank or on none
+    if not all_agree(ok):
         if comm is not None:
             comm.close()
         return None
