@@ -1,13 +1,15 @@
 #!/bin/bash
-# Everything the round's profiles/ directory is made from, in one gpurun call (from the repo root): tests/final_evidence.sh r04
-TAG=${1:-r04}
+# Everything the round's profiles/ directory is made from, in one gpurun call (from the repo root): tests/final_evidence.sh r05
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out/profiles_$TAG
 python3 -m pytest tests -q -m gpu 2>&1 | tail -45 > gpurun_out/profiles_$TAG/${TAG}_pytest_gpu_tail.log
 cp gpurun_out/parity_report.json gpurun_out/profiles_$TAG/${TAG}_parity_report.json 2>/dev/null
 cp gpurun_out/c2_parity.json gpurun_out/profiles_$TAG/${TAG}_c2_parity.json 2>/dev/null
+for f in gpurun_out/c2_parity_blocks_*.json; do cp $f gpurun_out/profiles_$TAG/${TAG}_$(basename $f) 2>/dev/null; done
 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/profiles_$TAG/${TAG}_bench_k20.json 2> gpurun_out/bench_k20.err
+cp gpurun_out/bench_detail.json gpurun_out/profiles_$TAG/${TAG}_bench_k20_detail.json 2>/dev/null
 python3 bench.py --workload biquad --steps 1000 --warmup 50 > gpurun_out/profiles_$TAG/${TAG}_bench_k1000.json 2> gpurun_out/bench_k1000.err
 for W in crossover stft dynfilter splitter loudness; do
     python3 bench.py --workload $W --no-cpu-baseline 2>/dev/null | tail -1 > gpurun_out/profiles_$TAG/${TAG}_bench_$W.json
@@ -17,5 +19,6 @@ MI_BENCH_REHEARSAL=1 HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python3 -m torch.d
 bash tests/prof_round.sh $TAG < /dev/null > gpurun_out/prof_round.log 2>&1
 bash tests/prof_sq.sh $TAG < /dev/null > gpurun_out/prof_sq.log 2>&1
 bash tests/prof_driver_cmd.sh $TAG < /dev/null > gpurun_out/prof_driver_cmd.log 2>&1
+bash tests/prof_valu.sh $TAG < /dev/null > gpurun_out/prof_valu.log 2>&1
 ls gpurun_out/profiles_$TAG
 tail -3 gpurun_out/profiles_$TAG/${TAG}_pytest_gpu_tail.log

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 --kernel-trace --stats of the DRIVER's bench command (python3 bench.py --gpus 1 --steps 20 --warmup 5), through gpurun:
 #   tests/prof_driver_cmd.sh r04   -> gpurun_out/profiles_r04/r04_driver_cmd_kernel_stats.csv (+ the bench line of the profiled run)
-TAG=${1:-r04}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/driver_cmd_$TAG
 rm -rf $O; mkdir -p $O $R/gpurun_out/profiles_$TAG
