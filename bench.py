@@ -1417,7 +1417,7 @@ def main():
             "roofline": _roofline(kname, alg_bytes * launch_steps, kernel_ms, elapsed / args.steps * 1e3, tinfo["probe"],
                                   committed["traffic"],
                                   _biquad_issue_side(kernel_ms, C, n, coef.shape[1], launch_steps,
-                                                     "r04_biquad_stream_pmc_sq.json" if streamed else "r04_biquad_pmc_sq.json"),
+                                                     "r05_biquad_stream_pmc_sq.json" if streamed else "r05_biquad_pmc_sq.json"),
                                   launch_steps=launch_steps),
             "committed_profile": committed,
         }
@@ -1430,7 +1430,7 @@ def main():
                 "value": round(samples_per_step * args.steps / pe / 1e6, 1), "unit": "Msamples/s",
                 "ms_per_step": round(pe / args.steps * 1e3, 5), "timing": pinfo,
                 "roofline": _roofline("biquad_bank_kernel<16,2>", alg_bytes, pk, pe / args.steps * 1e3, pinfo["probe"], None,
-                                      _biquad_issue_side(pk, C, n, coef.shape[1], 1, "r04_biquad_pmc_sq.json")),
+                                      _biquad_issue_side(pk, C, n, coef.shape[1], 1, "r05_biquad_pmc_sq.json")),
             }
         if not args.no_cpu_baseline and world == 1:         # the CPU figure is a 1-process measurement (rank 0 at N = 1 only)
             line["cpu_baseline"] = cpu_baseline_biquad(coef, n)
