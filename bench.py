@@ -652,8 +652,13 @@ def _timed_steps(mi, torch, dist, world, dev, step, steps, warmup, profile=True,
             mi.check(mi.lib.mi_dspu_profile_next_launch(pairs[-1][0], pairs[-1][1]))
         t0 = time.perf_counter()
         one_region()
-        fence()
+        # the closing bracket: this rank's work is done (synchronize) -> its clock stops -> the ranks meet (barrier).  The
+        # region's time is the MAX over the ranks of start-together-to-own-completion (below); with the barrier inside every
+        # rank's span each of them would add a collective's latency (tens of microseconds, the size of a K = 20 region) to all.
+        torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
+        if world > 1:
+            dist.barrier()
     gc.enable()
     in_region_ms = []
     for e0, e1 in pairs:
