@@ -137,6 +137,36 @@ def test_fused_chain_matches_oracle_at_block_4096(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("block,K,handlers", [(4096, 6, None), (4096, 9, [0, 3]), (6144, 4, None)])
+def test_runs_of_blocks_match_the_oracle(gpu, block, K, handlers):
+    """mi_crossover_bank_process_blocks -- the K blocks as ONE launch of biquad_stream_chain_kernel (what bench.py's crossover row
+    times) -- directly against the oracle's Crossover objects (one per channel, state carried over the blocks) and the float64
+    chain, by the IIR parity rule: not only bit for bit against the per-block launches."""
+    C, bands = 6, 4
+    listen = list(range(bands)) if handlers is None else handlers
+    rng = np.random.default_rng(500 + block + K)
+    x = (rng.standard_normal((C, K * block)) * 0.25).astype(np.float32)
+    bank = gpu.CrossoverBank(C, bands)
+    refs = [oc.Crossover(bands) for _ in range(C)]
+    for obj in [bank] + refs:
+        obj.set_sample_rate(48000)
+        for i, f in enumerate((200.0, 1500.0, 7000.0)):
+            obj.set_slope(i, 2)
+            obj.set_frequency(i, f)
+    dins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, k * block:(k + 1) * block])) for k in range(K)]
+    outs = [[gpu.DeviceBuffer((C, block)) if b in listen else None for b in range(bands)] for _ in range(K)]
+    bank.process_blocks(outs, dins, block)
+    got = {b: np.concatenate([outs[k][b].download() for k in range(K)], axis=1) for b in listen}
+    ref = {b: np.zeros_like(x) for b in listen}
+    for c, r in enumerate(refs):
+        for k in range(K):
+            res = r.process(x[c, k * block:(k + 1) * block], listen)
+            for b in listen:
+                ref[b][c, k * block:(k + 1) * block] = res[b]
+    check_bands(x, got, ref, refs, {b: True for b in listen}, "runs of %d blocks of %d" % (K, block), exact=True)
+    bank.close()
+
+
 @pytest.mark.parametrize("handlers", ["0,1,2,3", "1,3"])
 def test_fused_chain_equals_one_launch_per_filter(gpu, tmp_path, handlers):
     """The fused launch runs the same sections in the same order on the same values as one launch per filter does

@@ -665,6 +665,44 @@ def test_c5_full_size(gpu):
     bank.close()
 
 
+def test_c5_full_size_frames_call(gpu):
+    """BASELINE config 4 through the call bench.py's C5 `value` is measured on: 1024 channels, 4096-point Hann spectra every 2048
+    samples, SEVENTEEN frames as ONE mi_analyzer_bank_process_reduce_frames call (a run of sixteen strobes in one launch of
+    analyzer_frames_kernel -- the even-head ring ingest as 8-byte stores -- and their reductions in one launch, then a single
+    frame) directly against the oracle: every frame's per-bin sum over all channels against the oracle's rows summed in float64,
+    and every channel's smoothed spectrum after the run."""
+    sr, rank, C, hop, frames = 48000, 12, 1024, 2048, 17
+    bins = (1 << (rank - 1)) + 1
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal((frames + 1, C, hop)) * 0.25).astype(np.float32)
+    o = sp.Analyzer(C, rank, sr, 1.0, 0)
+    o.configure(sample_rate=sr, rate=sr / float(hop), rank=rank, window_name="hann", reactivity=0.2, shift=1.0)
+    bank = _analyzer(gpu, C, rank, hop)
+    o.process(x[0])                                          # a first period in front: the ring holds a frame's worth
+    bank.process(gpu.DeviceBuffer.from_host(x[0]), hop)
+    assert bank.info()["period"] == hop
+    ins = [gpu.DeviceBuffer.from_host(x[1 + f]) for f in range(frames)]
+    sums = gpu.DeviceBuffer((frames, bins))
+    bank.process_reduce_frames(ins, hop, sums)
+    got = sums.download()
+    idx = np.arange(0, bins, dtype=np.uint32)
+    worst_sum = 0.0
+    for f in range(frames):
+        # (the oracle analyses channel c two samples after channel c - 1, each over the frame as it stood at the strobe: once the
+        # period is through, every row is the strobe's)
+        o.process(x[1 + f])
+        ref = o.amp[:, :bins].astype(np.float64).sum(axis=0)
+        err = float(np.abs(got[f] - ref).max() / np.abs(ref).max())
+        worst_sum = max(worst_sum, err)
+    spec, ref_spec = bank.get_spectrum(idx), o.get_spectrum(idx)
+    peak = np.abs(ref_spec).max(axis=1, keepdims=True)
+    worst = float((np.abs(spec - ref_spec) / np.maximum(peak, 1e-30)).max())
+    print("C5 full size as ONE process_reduce_frames call (16 + 1 strobes): worst per-bin sum error %.2e of the sums' peak, worst "
+          "|gpu - oracle| / channel peak of the spectra left behind %.2e" % (worst_sum, worst))
+    assert worst <= TOL and worst_sum <= TOL, (worst, worst_sum)
+    bank.close()
+
+
 def _analyzer(gpu, channels, rank, hop, sr=48000):
     bank = gpu.AnalyzerBank(channels, rank, sr, 1.0, 0)
     for what, v in ((bank.SAMPLE_RATE, sr), (bank.RATE, sr / float(hop)), (bank.RANK, rank), (bank.WINDOW, 0),
@@ -804,3 +842,34 @@ def test_spectral_process_blocks_equal_block_by_block(gpu, rank, masked, n_frame
         np.testing.assert_array_equal(u.download(), v.download())
     for bank in (a, b, c, d):
         bank.close()
+
+
+@pytest.mark.parametrize("rank,n_frames,K", [(12, 2, 6), (9, 3, 8)])
+def test_spectral_runs_of_blocks_match_the_oracle(gpu, rank, n_frames, K):
+    """mi_spectral_bank_process_blocks -- K blocks of whole frames as ONE launch of stft_stream_blocks_kernel (what bench.py's
+    SpectralProcessor row times: rank 12, a gain mask, 4096-sample blocks) -- directly against the oracle's SpectralProcessor
+    with a callback that applies the mask, not only bit for bit against the per-block launches."""
+    rng = np.random.default_rng(1300 + rank + K)
+    N, H = 1 << rank, 1 << (rank - 1)
+    C, n = 3, n_frames * (1 << (rank - 1))
+    x = (rng.standard_normal((C, (K + 1) * n)) * 0.25).astype(np.float32)
+    masks = rng.uniform(0.0, 2.0, (C, H + 1)).astype(np.float32)
+    bank = gpu.SpectralBank(C, rank)
+    bank.set_rank(rank)
+    bank.bind_mask(masks)
+    ins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, k * n:(k + 1) * n])) for k in range(K + 1)]
+    outs = [gpu.DeviceBuffer((C, n)) for _ in range(K + 1)]
+    bank.process(outs[0], ins[0], n)                         # the steady state: a frame is in hand
+    bank.process_blocks(outs[1:], ins[1:], n)
+    y = np.concatenate([o.download() for o in outs], axis=1)
+    bank.close()
+    for c in range(C):
+        full = np.concatenate([masks[c], masks[c][H - 1:0:-1]]).astype(np.float32)      # N gains, Hermitian
+
+        def cb(spec, r, full=full):
+            out = spec.copy(); out[0::2] *= full; out[1::2] *= full
+            return out
+        p = sp.SpectralProcessor(rank); p.set_rank(rank); p.bind(cb)
+        ref = p.process(x[c])
+        peak = max(np.abs(ref).max(), 1e-30)
+        assert np.abs(y[c] - ref).max() <= TOL * peak, (rank, c, np.abs(y[c] - ref).max() / peak)

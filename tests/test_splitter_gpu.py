@@ -476,3 +476,31 @@ def test_process_blocks_equal_block_by_block(gpu, rank, bands, n_frames, K, list
             assert k == 0 or np.abs(yb).max() > 1e-4
             np.testing.assert_array_equal(ya, yb, err_msg="block %d band %d" % (k, i))
     a.close(); b.close()
+
+
+@pytest.mark.parametrize("rank,bands,n_frames,K", [(12, 4, 2, 6), (10, 3, 1, 9)])
+def test_runs_of_blocks_match_the_oracle(gpu, rank, bands, n_frames, K):
+    """mi_splitter_bank_process_blocks -- K blocks of whole frames as ONE launch of splitter_hops_blocks_kernel (what bench.py's
+    splitter row times: rank 12, four masks, 4096-sample blocks) -- directly against the oracle's SpectralSplitter fed the same
+    blocks, every band, not only bit for bit against the per-block launches."""
+    rng = np.random.default_rng(1200 + rank + K)
+    C, frame = 3, 1 << (rank - 1)
+    n = n_frames * frame
+    x = (rng.standard_normal((C, (K + 1) * n)) * 0.25).astype(np.float32)
+    masks = [np.clip(rng.uniform(0.0, 1.2, 1 << rank), 0.0, 1.0).astype(np.float32) for _ in range(bands)]
+    want = _oracle_run(rank, rank, 0.0, masks, x, [n] * (K + 1))
+    bank = gpu.SplitterBank(C, rank, bands)
+    bank.set_rank(rank); bank.set_chunk_rank(rank); bank.set_phase(0.0)
+    for i in range(bands):
+        bank.bind_mask(i, masks[i])
+    ins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, k * n:(k + 1) * n])) for k in range(K + 1)]
+    outs = [[gpu.DeviceBuffer((C, n)) for _ in range(bands)] for _ in range(K + 1)]
+    bank.process(outs[0], ins[0], n)                         # the steady state: a frame is in hand
+    bank.process_blocks(outs[1:], ins[1:], n)
+    peak = float(np.abs(x).max())
+    for i in range(bands):
+        got = np.concatenate([outs[k][i].download() for k in range(K + 1)], axis=1)
+        err = float(np.abs(got - want[i]).max())
+        assert float(np.abs(want[i]).max()) > 0.01
+        assert err <= TOL * max(peak, float(np.abs(want[i]).max())), (i, err)
+    bank.close()
