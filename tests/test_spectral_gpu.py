@@ -692,8 +692,7 @@ def test_c5_full_size_frames_call(gpu):
         # period is through, every row is the strobe's)
         o.process(x[1 + f])
         ref = o.amp[:, :bins].astype(np.float64).sum(axis=0)
-        err = float(np.abs(got[f] - ref).max() / np.abs(ref).max())
-        worst_sum = max(worst_sum, err)
+        worst_sum = max(worst_sum, float(np.abs(got[f] - ref).max() / np.abs(ref).max()))
     spec, ref_spec = bank.get_spectrum(idx), o.get_spectrum(idx)
     peak = np.abs(ref_spec).max(axis=1, keepdims=True)
     worst = float((np.abs(spec - ref_spec) / np.maximum(peak, 1e-30)).max())
