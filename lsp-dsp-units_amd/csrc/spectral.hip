@@ -1023,7 +1023,9 @@ namespace
             amp_h = a[H];
         for (int f = 0; f < fa.frames; ++f)
         {
-            // (the window comes out of the L2 at every strobe instead of occupying 16 registers: four workgroups fit a CU)
+            // (the window comes out of the L2 at every strobe instead of occupying 16 registers: four workgroups fit a CU.  Asked
+            // for one strobe ahead -- behind the transform, next to the block's request below -- it costs four spilled registers
+            // and 8 % of the launch: measured, round 5)
             v2f io[KPT];
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
@@ -1038,6 +1040,11 @@ namespace
             mi_fft::fft_lds<LOGH, false, true, false>(buf, scr, rf.ft, tid, io);
             mi_fft::real_split<LOGH>(buf, rf.rt, tid);
             if (f == 3) MI_APROBE(3);
+            // this strobe's block is asked for NOW -- the transform's registers are free again, and the request is in flight
+            // underneath the magnitudes and the row's stores instead of behind them (the stores to the rows and the loads of the
+            // caller's block cannot be told apart by the compiler, which keeps them in program order)
+            float2 blk[HALF];
+            load_hop(f, blk);
             // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
             float *const row = fa.rows[f] + size_t(ch) * amp_stride;
             const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(row, unsigned((H + 1) * sizeof(float)));
@@ -1057,8 +1064,6 @@ namespace
             }
             if (f == 3) MI_APROBE(4);
             // this strobe's block: into the ring, and the second half of the next strobe's frame
-            float2 blk[HALF];
-            load_hop(f, blk);
             ingest_hop(f, blk);
             #pragma unroll
             for (int j = 0; j < HALF; ++j)
