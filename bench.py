@@ -144,9 +144,8 @@ def cpu_baseline_biquad(coef, samples, budget_s=5.0):
         "one_core": {"value": res["one_core"]["value"], "unit": "Msamples/s", "cores": 1},
         "cpu_model": _cpu_model(), "build": "gcc -O3 -march=native -ffp-contract=fast -fopenmp (rebuilt on this host)",
         "simd": "x8: eight sections side by side in vector registers",
-        "sample": "%d blocks (all cores) / %d blocks (one core) of %d ch x %d samples in one parallel region each, 8-section "
-                  "cascade as one x8 software-pipelined pass per channel and block (FilterBank.cpp:267-273), SIMD across "
-                  "the sections, persistent threads; lsp-dsp-lib's hand-written kernels are not available offline"
+        "sample": "%d blocks (all cores) / %d (one core) of %d ch x %d samples, x8 pipelined pass per channel and block (FilterBank.cpp:267-273), "
+                  "SIMD across the sections; lsp-dsp-lib's own kernels are not available offline"
                   % (allc["blocks"], res["one_core"]["blocks"], C, samples),
     }
 
