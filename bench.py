@@ -1175,7 +1175,7 @@ def _short_cpu(cb, full=False):
         if cb.get("one_core"):
             out["one_core"] = cb["one_core"].get("value")
         out["cpu_model"] = cb.get("cpu_model")
-        out["sample"] = str(cb.get("sample", ""))[:160]
+        out["sample"] = str(cb.get("sample", ""))[:220]
     else:
         out["simd"] = cb.get("simd")
     return {k: v for k, v in out.items() if v is not None}
