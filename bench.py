@@ -1295,6 +1295,9 @@ def main():
     elif int(os.environ["WORLD_SIZE"]) != args.gpus:
         raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%s ranks: the two must agree (n_gpus in the "
                          "JSON line is the number of ranks that ran)" % (args.gpus, os.environ["WORLD_SIZE"]))
+    # (the driver's tail of the run is one buffer for stdout and stderr: the c10d socket warnings of a one-node rendezvous --
+    # a dozen lines per rank -- stay out of it)
+    os.environ.setdefault("TORCH_CPP_LOG_LEVEL", "ERROR")
     import numpy as np
     import torch                                   # torch first: one HIP runtime per process
     import torch.distributed as dist
