@@ -26,7 +26,9 @@
 #include "mi_common.h"
 #include "fft_device.h"
 #include "fft16.h"
+#include "fft_wave.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -455,6 +457,148 @@ namespace
             if (!upper_zero)
                 mi::wt_store(racc, 4 * B + 8 * n, make_float2(0.0f, 0.0f));
         }
+    }
+
+    // ---- the same run of blocks at B = 4096 on the wave-resident transform (fft_wave.h) ------------------------------------------
+    // conv_frames_kernel<12> runs AT the rate of its transforms (1.9 us per 4096-point transform and CU: their passes through LDS
+    // and their butterflies add up, profiles/r05_experiments/fft_cores_probe.txt).  Here a WAVE owns a block: 64 registers per lane
+    // of samples, forward transform, split-product-merge as one step per bin (table (alpha, beta) of the response,
+    // conv_wave_table_kernel), inverse -- no workgroup-wide pass and no barrier.
+    // Overlap-SAVE, so that the waves owe each other nothing: with u_g the frame of block g (block g - 1 of the call: the delay line
+    // is a delay of exactly one block; u_0 is what the line holds), unit g transforms the 2 B samples [u_(g-1) | u_g] and the upper
+    // half of the circular convolution IS block g's output (the response has at most B taps).  u_(-1) := 0 makes unit 0's upper half
+    // the lower half of u_0 * h, to which the accumulator the call found is added; u_K := 0 makes unit K's upper half the tail the
+    // call leaves in the accumulator: K + 1 units for K blocks, each input block read by two waves (the second time out of the L2),
+    // no sums between the waves, no LDS besides the waves' own exchange areas.  (The first version handed overlap-add tails from
+    // wave to wave through LDS behind two barriers per eight blocks: 441 us per 128 blocks at 256 channels, a quarter of it the
+    // exposed latency of loads and stores that the lockstep of the barriers put in the same place for all eight waves.)
+    // The host sends a run this way only if no output buffer of the call overlaps an input buffer and everything is 8-byte aligned.
+    // The same convolution in another order of roundings: within 1e-6 of conv_frames_kernel<12>, not bit-identical.
+    constexpr int WAVE_FRAMES = 8;                          // waves of a workgroup
+    __global__ __launch_bounds__(64 * WAVE_FRAMES, 2)
+    void conv_frames_wave_kernel(const frames_args fa, size_t out_stride, size_t in_stride,
+                                 const float4 *__restrict__ tabs /* [channels][4096]: (alpha, beta) per bin */, float *acc,
+                                 const float2 *__restrict__ tw,
+                                 float *dl_ring, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head, bool upper_zero)
+    {
+        using namespace mi_fftw;
+        constexpr int B = N, HALF = R / 2;                  // samples of a block; registers of a half frame
+        __shared__ float areas[WAVE_FRAMES][AREA];
+        __shared__ float2 pl[8 * R];
+        const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);           // (a scalar: the buffers of a wave's unit are uniform)
+        fill_table(pl, tw, tid);
+        v2f Q[8];
+        load_lane_twiddles(Q, tw, lane);
+        __syncthreads();
+        const __amdgpu_buffer_rsrc_t tab = table_of(tabs + size_t(ch) * N);
+        float *const line = dl_ring + size_t(ch) * dl_size;
+        float *const a = acc + size_t(ch) * 2 * B;
+        const __amdgpu_buffer_rsrc_t racc = mi::wt_buffer(a, unsigned(2 * B * sizeof(float)));
+        // two floats at byte `lane_off` (a VGPR) + `row_off` (a scalar): one base per buffer, not a 64-bit pointer per row
+        auto pair_at = [](__amdgpu_buffer_rsrc_t r, int lane_off, int row_off) -> v2f {
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            const u2 d = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, row_off, 0);
+            return v2f{__uint_as_float(d.x), __uint_as_float(d.y)};
+        };
+        v2f x[R];
+        for (int g = wv; g <= fa.blocks; g += WAVE_FRAMES)
+        {
+            // [u_(g-1) | u_g]: sample pair n = lane + 64 j of the first half in register j, of the second in register HALF + j
+            #pragma unroll
+            for (int half = 0; half < 2; ++half)
+            {
+                const int u = g - 1 + half;                 // frame u: block u - 1 of the call
+                if (u < 0 || u >= fa.blocks)
+                {
+                    #pragma unroll
+                    for (int j = 0; j < HALF; ++j)
+                        x[half * HALF + j] = v2f{0.0f, 0.0f};
+                }
+                else if (u == 0)
+                {
+                    const __amdgpu_buffer_rsrc_t rline = mi::wt_buffer(line, unsigned(dl_size * sizeof(float)));
+                    #pragma unroll
+                    for (int j = 0; j < HALF; ++j)
+                    {
+                        uint32_t r = dl_tail + 2 * (lane + 64 * j);     // even offsets: a pair never straddles the end
+                        if (r >= dl_size) r -= dl_size;
+                        x[half * HALF + j] = pair_at(rline, int(r * sizeof(float)), 0);
+                    }
+                }
+                else
+                {
+                    const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[u - 1]) + size_t(ch) * in_stride,
+                                                                     unsigned(B * sizeof(float)));
+                    #pragma unroll
+                    for (int j = 0; j < HALF; ++j)
+                        x[half * HALF + j] = pair_at(rin, lane * 8, j * 512);
+                }
+            }
+            float4 q[2 * AHEAD];
+            fft4096<false>(x, pl, Q, areas[wv], lane, [&]() { table_ahead(q, tab, lane); });
+            split_filter_merge(x, q, tab, lane);
+            fft4096<true>(x, pl, Q, areas[wv], lane);
+            // register HALF + i: samples 2 n, 2 n + 1 of block g (n = lane + 64 i); the lower half is the circular wrap: not used
+            if (g == 0)
+            {
+                #pragma unroll
+                for (int i = 0; i < HALF; ++i)
+                    x[HALF + i] += pair_at(racc, lane * 8, i * 512);
+            }
+            else if (g == 1 && !upper_zero)
+            {
+                #pragma unroll
+                for (int i = 0; i < HALF; ++i)
+                    x[HALF + i] += pair_at(racc, lane * 8, 4 * B + i * 512);
+            }
+            if (g < fa.blocks)
+            {
+                const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(fa.out[g] + size_t(ch) * out_stride, unsigned(B * sizeof(float)));
+                #pragma unroll
+                for (int i = 0; i < HALF; ++i)
+                    mi::wt_store(rout, 8 * (lane + 64 * i), make_float2(x[HALF + i].x, x[HALF + i].y));
+            }
+        }
+        // What the next call starts from: the tail (unit K's result: the last one of its wave, still in its registers) in the
+        // accumulator, its upper half zero -- behind a barrier: units 0 and 1 have read the accumulator the call found.
+        __syncthreads();
+        if (wv == fa.blocks % WAVE_FRAMES)
+        {
+            #pragma unroll
+            for (int i = 0; i < HALF; ++i)
+            {
+                mi::wt_store(racc, 8 * (lane + 64 * i), make_float2(x[HALF + i].x, x[HALF + i].y));
+                if (!upper_zero)
+                    mi::wt_store(racc, 4 * B + 8 * (lane + 64 * i), make_float2(0.0f, 0.0f));
+            }
+        }
+        // ... and the last block in the delay line (where as many single-block calls would have left it)
+        const float *last = fa.in[fa.blocks - 1] + size_t(ch) * in_stride;
+        #pragma unroll
+        for (int i = 0; i < B / 2 / (64 * WAVE_FRAMES); ++i)
+        {
+            const int n = tid + i * 64 * WAVE_FRAMES;
+            const uint32_t w = uint32_t((uint64_t(dl_head) + uint64_t(fa.blocks - 1) * B + 2 * n) % dl_size);
+            *reinterpret_cast<float2 *>(line + w) = *reinterpret_cast<const float2 *>(last + 2 * n);
+        }
+    }
+
+    // (alpha, beta) of fft_wave.h's split_filter_merge from a single-partition bank's images, bin by bin
+    __global__ __launch_bounds__(256)
+    void conv_wave_table_kernel(float4 *tabs, const float2 *__restrict__ H, const float2 *__restrict__ tw)
+    {
+        constexpr int M = mi_fftw::N;
+        const int ch = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+        const float2 *h = H + size_t(ch) * M;
+        const float2 h0 = h[0];                             // (DC, Nyquist)
+        const float2 hk = (k == 0) ? make_float2(h0.x, 0.0f) : h[k];
+        const float2 hp = (k == 0) ? make_float2(h0.y, 0.0f) : h[M - k];
+        const float sx = 0.5f * (hk.x + hp.x), sy = 0.5f * (hk.y - hp.y);      // S, D = (H[k] +- conj H[M - k]) / 2
+        const float dx = 0.5f * (hk.x - hp.x), dy = 0.5f * (hk.y + hp.y);
+        const float2 w = tw[k * (TWN / (2 * M))];           // e^{-i pi k / M}
+        const float sc = 1.0f / float(M);
+        tabs[size_t(ch) * M + k] = make_float4((sx + dx * w.y) * sc, (sy + dy * w.y) * sc, -dy * w.x * sc, dx * w.x * sc);
     }
 
     // ---- K whole frames of a partitioned bank in ONE call (mi_convolver_bank_process_blocks) ------------------------------------
@@ -1614,7 +1758,12 @@ struct mi_convolver_bank
     // A frame of this convolver is the reference's block on its way through, so it uses what was in force when it began:
     // responses live in a pool of four buffers, `cv` / `nv` are the ones standing for vConv / vNewConv, and the frame being
     // received keeps d_H / d_h0 (old) and d_Hx / d_h0x (new, cross-fade frames only) whatever arrives meanwhile.
-    struct response { float2 *H = nullptr; float *h0 = nullptr; };
+    struct response
+    {
+        float2 *H = nullptr; float *h0 = nullptr;
+        float4 *W = nullptr;        // single-partition banks of 4096-sample frames: the images as (alpha, beta) per bin (fft_wave.h);
+                                    // made wherever H is written (refresh_wave_table), so it is never older than H
+    };
     response    pool[4];
     int         cv = 0, nv = 0;             // pool index of vConv / vNewConv
     int         fr_old = 0, fr_new = -1;    // pool indices the open frame uses
@@ -1887,6 +2036,61 @@ namespace mi
         return launch_mac(b, st);
     }
 
+    // pool[idx].H has just been written (stream order): its (alpha, beta) table follows.  Every channel: rows a parse did not
+    // name were copied from the buffer it started from, and so is what is derived from them.
+    int refresh_wave_table(mi_convolver_bank_t *b, int idx, hipStream_t st)
+    {
+        if (b->P != 1 || b->logm != 12)
+            return MI_OK;
+        mi_convolver_bank::response &r = b->pool[idx];
+        if (r.W == nullptr)
+            MI_HIP_CHECK(hipMalloc(reinterpret_cast<void **>(&r.W), size_t(b->channels) * mi_fftw::N * sizeof(float4)));
+        hipLaunchKernelGGL(conv_wave_table_kernel, dim3(mi_fftw::N / 256, b->channels), dim3(256), 0, st, r.W, r.H, b->d_tw);
+        MI_HIP_CHECK(hipGetLastError());
+        return MI_OK;
+    }
+
+    // May a run of blocks ride conv_frames_wave_kernel?  Its waves take the blocks in no particular order, so: no output overlaps
+    // an input; two outputs either do not overlap or are the SAME buffer at a distance of a multiple of WAVE_FRAMES blocks (a ring
+    // of buffers: those blocks belong to one wave, which writes them in the blocks' order).
+    static bool wave_run_ok(float *const *out, const float *const *in, size_t blocks, size_t span_o, size_t span_i)
+    {
+        struct iv { uintptr_t a, e; int idx; bool is_out; };
+        std::vector<iv> v;
+        v.reserve(2 * blocks);
+        for (size_t k = 0; k < blocks; ++k)
+        {
+            v.push_back({reinterpret_cast<uintptr_t>(out[k]), reinterpret_cast<uintptr_t>(out[k] + span_o), int(k), true});
+            v.push_back({reinterpret_cast<uintptr_t>(in[k]), reinterpret_cast<uintptr_t>(in[k] + span_i), int(k), false});
+        }
+        std::sort(v.begin(), v.end(), [](const iv &x, const iv &y) { return x.a != y.a ? x.a < y.a : x.idx < y.idx; });
+        uintptr_t end_out = 0, end_in = 0, last_out = 0;
+        int last_idx = 0;
+        for (const iv &x : v)
+        {
+            if (x.is_out)
+            {
+                if (x.a < end_in)
+                    return false;
+                if (x.a < end_out && !(x.a == last_out && (x.idx - last_idx) % WAVE_FRAMES == 0))
+                    return false;
+                if (x.a != last_out || end_out == 0)
+                {
+                    last_out = x.a;
+                    last_idx = x.idx;
+                }
+                end_out = std::max(end_out, x.e);
+            }
+            else
+            {
+                if (x.a < end_out)
+                    return false;
+                end_in = std::max(end_in, x.e);
+            }
+        }
+        return true;
+    }
+
     // true if `blocks` blocks of `samples` samples each can go as one launch of conv_frames_kernel: a single-partition bank at a
     // plain frame boundary, blocks of exactly one frame, transforms of 512 .. 8192 points, no cross-fade waiting
     bool convolver_takes_delayed_frames(const mi_convolver_bank_t *b, size_t samples)
@@ -1895,7 +2099,7 @@ namespace mi
     }
 
     int convolver_process_delayed_frames(mi_convolver_bank_t *b, float *const *out, const float *const *in, size_t blocks,
-                                         size_t out_stride, size_t in_stride, const delay_view &dl, hipStream_t st)
+                                         size_t out_stride, size_t in_stride, const delay_view &dl, hipStream_t st, bool apart)
     {
         MI_REQUIRE(convolver_takes_delayed_frames(b, size_t(b->B)) && blocks >= 1 && blocks <= size_t(FRAMES_MAX_BLOCKS), MI_ESTATE,
                    "convolver_process_delayed_frames: not at a plain frame boundary of a single-partition bank");
@@ -1915,6 +2119,18 @@ namespace mi
         }
         hipEvent_t fe0 = nullptr, fe1 = nullptr;
         mi::take_profile_events(&fe0, &fe1);
+        // 4096-sample blocks: a wave per block on the wave-resident transform (conv_frames_wave_kernel) -- if the buffers of the run
+        // allow its blocks to be taken in any order (wave_run_ok: a run in place goes the workgroup's way)
+        bool waves = b->logm == 12 && aligned && blocks >= 2 && b->pool[b->cv].W != nullptr && getenv("MI_CONV_FRAMES_LDS") == nullptr;
+        const size_t span_o = (b->channels - 1) * out_stride + size_t(b->B), span_i = (b->channels - 1) * in_stride + size_t(b->B);
+        if (waves && (apart || wave_run_ok(out, in, blocks, span_o, span_i)))
+        {
+            MI_LAUNCH(conv_frames_wave_kernel, dim3(b->channels), dim3(64 * WAVE_FRAMES), 0, st, fe0, fe1,
+                      fa, out_stride, in_stride, b->pool[b->cv].W, b->d_acc, b->d_tw, dl.ring, dl.size, tail, dl.head, b->upper_zero);
+            MI_HIP_CHECK(hipGetLastError());
+            b->upper_zero = true;
+            return MI_OK;
+        }
         #define MI_CALL(LM) MI_LAUNCH((conv_frames_kernel<LM>), dim3(b->channels), dim3(fplan<LM>::T), 0, st, fe0, fe1, \
                                       fa, out_stride, in_stride, aligned, b->d_H, b->d_acc, static_cast<const float2 *>(nullptr), \
                                       b->d_tw, dl.ring, dl.size, tail, dl.head, \
@@ -2054,6 +2270,9 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
     (void)hipFree(d_counts);
     b->pool[0].H = b->d_H;
     b->pool[0].h0 = b->d_h0;
+    if (e == hipSuccess && mi::refresh_wave_table(b, 0, st) != MI_OK)
+        e = hipErrorOutOfMemory;
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess)
     {
         mi_convolver_bank_destroy(b);
@@ -2102,6 +2321,9 @@ static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_strid
         #undef MI_CALL
         e = hipGetLastError();
     }
+    for (int i = 0; i < 4 && e == hipSuccess; ++i)
+        if (b->pool[i].H == dst_H && mi::refresh_wave_table(b, i, st) != MI_OK)
+            e = hipErrorOutOfMemory;
     if (e == hipSuccess && b->small && dst_h0 == b->d_h0)
     {
         hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, b->channels), dim3(fplan<LOGS>::T), 0, st,
@@ -2252,6 +2474,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
     {
         (void)hipFree(r.H);
         (void)hipFree(r.h0);
+        (void)hipFree(r.W);
     }
     (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);

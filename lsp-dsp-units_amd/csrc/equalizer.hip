@@ -508,11 +508,15 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
                     dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && dl.size >= 2 * b->fir_size)
                 {
                     const size_t N = b->fir_size, blocks = rest / N;
+                    // column slices of the caller's two buffers: distinct outputs, and no output overlaps an input unless the
+                    // buffers themselves do (in place: the workgroup's kernel, block after block)
+                    const size_t fo = (b->channels - 1) * out_stride + samples, fi = (b->channels - 1) * in_stride + samples;
+                    const bool apart = (out + fo <= in) || (in + fi <= out);
                     float *po[mi::CONV_FRAMES_MAX];
                     const float *pi[mi::CONV_FRAMES_MAX];
-                    for (size_t k0 = 0; k0 < blocks; k0 += mi::CONV_FRAMES_MAX)
+                    for (size_t k0 = 0, cnt = 0; k0 < blocks; k0 += cnt)
                     {
-                        const size_t cnt = (blocks - k0 < mi::CONV_FRAMES_MAX) ? blocks - k0 : mi::CONV_FRAMES_MAX;
+                        cnt = mi::conv_frames_chunk(blocks - k0);
                         for (size_t k = 0; k < cnt; ++k)
                         {
                             po[k] = out + done + (k0 + k) * N;
@@ -520,7 +524,7 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
                         }
                         if (mi::delay_bank_view(b->delay, &dl) != MI_OK)
                             return MI_ESTATE;
-                        if ((r = mi::convolver_process_delayed_frames(b->conv, po, pi, cnt, out_stride, in_stride, dl, st)) != MI_OK)
+                        if ((r = mi::convolver_process_delayed_frames(b->conv, po, pi, cnt, out_stride, in_stride, dl, st, apart)) != MI_OK)
                             return r;
                         mi::delay_bank_advance(b->delay, cnt * N);
                     }
@@ -597,7 +601,8 @@ int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *b, float *const *out, 
                 mi::convolver_takes_delayed_frames(b->conv, samples) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
                 dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && dl.size >= 2 * b->fir_size)
             {
-                while (k + cnt < blocks && cnt < mi::CONV_FRAMES_MAX)
+                const size_t most = mi::conv_frames_chunk(blocks - k);
+                while (k + cnt < blocks && cnt < most)
                 {
                     bool ok = true;
                     // (the same buffer again is fine -- a ring of buffers, a block in place: a thread of the kernel touches

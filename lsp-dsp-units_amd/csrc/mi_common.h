@@ -111,8 +111,12 @@ namespace mi
     // line is advanced by the caller by blocks x frame samples
     bool        convolver_takes_delayed_frames(const mi_convolver_bank_t *bank, size_t samples);
     int         convolver_process_delayed_frames(mi_convolver_bank_t *bank, float *const *out, const float *const *in, size_t blocks,
-                                                 size_t out_stride, size_t in_stride, const delay_view &dl, hipStream_t st);
+                                                 size_t out_stride, size_t in_stride, const delay_view &dl, hipStream_t st,
+                                                 bool apart = false /* the caller vouches: the blocks' outputs are distinct and none overlaps an input */);
     constexpr size_t CONV_FRAMES_MAX = 128;         // blocks per launch
+    // blocks of the next launch when `left` are left: a run of K blocks is K + 1 units of work for the eight waves of
+    // conv_frames_wave_kernel's workgroups, so a full launch takes 127 (128 units: sixteen rounds and no seventeenth for one wave)
+    inline size_t conv_frames_chunk(size_t left) { return (left <= CONV_FRAMES_MAX) ? left : CONV_FRAMES_MAX - 1; }
 } // namespace mi
 
 #if defined(__HIPCC__)
