@@ -765,20 +765,20 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
     def step(i):
         eq.process(yout[i % ring], xin[i % ring], n, stream=stream)
     # the K steps of a region as ONE mi_equalizer_bank_process_blocks call: runs of up to 128 blocks ride one launch of
-    # conv_frames_kernel (the response's image and the overlap-add tail stay in registers from block to block)
+    # conv_frames_wave_kernel (a wave per block on the wave-resident 4096-point transform, overlap-save: DESIGN.md 3.4)
     import ctypes
     K = args.conv_steps
     seq = [(args.conv_warmup + i) % ring for i in range(K)]
     po = (ctypes.c_void_p * K)(*[yout[k].data_ptr() for k in seq])
     pi = (ctypes.c_void_p * K)(*[xin[k].data_ptr() for k in seq])
     st_ptr = ctypes.c_void_p(stream.cuda_stream)
-    launch_steps = min(K, 128)
+    launch_steps = K if K <= 128 else 127                   # (mi::conv_frames_chunk: a full launch is 127 blocks = 128 units of the waves' work)
 
     def region():
         mi.check(mi.lib.mi_equalizer_bank_process_blocks(eq.handle, po, pi, K, n, n, n, st_ptr))
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, K, args.conv_warmup, region=region,
                                              probe_step=lambda j: region(), probe_steps=launch_steps)
-    tinfo["launch"] = "one mi_equalizer_bank_process_blocks call per region: runs of up to 128 blocks ride ONE launch (conv_frames_kernel)"
+    tinfo["launch"] = "one mi_equalizer_bank_process_blocks call per region: runs of up to 128 blocks ride ONE launch (conv_frames_wave_kernel)"
     pc_elapsed, pc_kernel_ms, pc_info = _timed_steps(mi, torch, dist, world, dev, step, K, 0)
     assert bool(torch.isfinite(yout[0]).all())
     eq.close()
@@ -796,12 +796,13 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
         # the step is ONE launch: conv_frame_kernel<12> pulls the frame out of the delay line, transforms, multiplies with
         # the channel's FIR image, transforms back, overlap-adds and emits
         "timing": tinfo,
-        # the region is ONE launch per 128 blocks: conv_frames_kernel walks the blocks of a channel -- frame out of the delay
-        # line once, transforms, product with the channel's FIR image (in registers), inverse, overlap-add, emission
-        "roofline": _roofline("conv_frames_kernel<12> (%d blocks per launch)" % launch_steps, step_bytes * launch_steps, kernel_ms,
+        # the region is ONE launch per 127 blocks: a wave of conv_frames_wave_kernel per block -- two blocks of samples in 64
+        # registers per lane, forward transform, split-product-merge against the response's (alpha, beta) table, inverse, the upper
+        # half out (overlap-save)
+        "roofline": _roofline("conv_frames_wave_kernel (%d blocks per launch)" % launch_steps, step_bytes * launch_steps, kernel_ms,
                               elapsed / args.conv_steps * 1e3, tinfo["probe"],
-                              _pmc_traffic("pmc_equalizer_latest.json", "conv_frames_kernel", launch_steps) if C == 256 else None,
-                              _issue_side("conv_frames_kernel<12>", kernel_ms, launch_steps) if C == 256 else None,
+                              _pmc_traffic("pmc_equalizer_latest.json", "conv_frames_wave_kernel", launch_steps) if C == 256 else None,
+                              _issue_side("conv_frames_wave_kernel", kernel_ms, launch_steps) if C == 256 else None,
                               launch_steps=launch_steps),
         "whole_step": {"algorithmic_bytes": step_bytes,
                        "achieved_GBps_incl_launch_gaps": round(step_bytes / (elapsed / args.conv_steps) / 1e9, 1),

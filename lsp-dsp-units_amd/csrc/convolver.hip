@@ -518,10 +518,12 @@ namespace
                 else if (u == 0)
                 {
                     const __amdgpu_buffer_rsrc_t rline = mi::wt_buffer(line, unsigned(dl_size * sizeof(float)));
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));            // (the 32 wrapped offsets are made here, once per launch, not ahead of the loop)
                     #pragma unroll
                     for (int j = 0; j < HALF; ++j)
                     {
-                        uint32_t r = dl_tail + 2 * (lane + 64 * j);     // even offsets: a pair never straddles the end
+                        uint32_t r = dl_tail + 2 * (ln + 64 * j);       // even offsets: a pair never straddles the end
                         if (r >= dl_size) r -= dl_size;
                         x[half * HALF + j] = pair_at(rline, int(r * sizeof(float)), 0);
                     }

@@ -26,6 +26,10 @@
 #include "fft_device.h"
 #include "mi_common.h"
 
+#ifndef MI_FFTW_PAIRS_AHEAD
+#define MI_FFTW_PAIRS_AHEAD 4
+#endif
+
 namespace mi_fftw
 {
     using mi_fft::v2f;
@@ -150,6 +154,18 @@ namespace mi_fftw
             Q[b] = mi_fft::ld2(tw + lane * b * (mi_fft::TWN / N));
     }
 
+    // both sets in the workgroup's table (16 rows, 8 KiB: rows 0 .. 7 = P, rows 8 .. 15 = Q): fft4096_t reads the lane's Q at the
+    // twiddle step instead of holding sixteen registers through the transforms (kernels with other things to keep: stft_wave_*)
+    __device__ __forceinline__ void fill_table_pq(float2 *plq /* 16 R */, const float2 *__restrict__ tw, int tid, int threads)
+    {
+        for (int i = tid; i < 16 * R; i += threads)
+        {
+            const int l = i & 63, row = i >> 6;
+            const int m = (row < 8) ? ((8 * l * row) & (N - 1)) : l * (row - 8);
+            plq[i] = tw[m * (mi_fft::TWN / N)];
+        }
+    }
+
     struct no_hook { __device__ __forceinline__ void operator()() const { } };
 
     // a whole transform of the wave, natural order both sides: x[j] = in[lane + 64 j]  ->  x[k1] = out[lane + 64 k1], unnormalised.
@@ -162,6 +178,33 @@ namespace mi_fftw
         for (int a = 0; a < 8; ++a)
         {
             const v2f Pa = mi_fft::ld2(pl + a * R + lane);
+            #pragma unroll
+            for (int b = 0; b < 8; ++b)
+            {
+                if (a == 0 && b == 0)
+                    continue;
+                const v2f w = (a == 0) ? Q[b] : (b == 0) ? Pa : pmul<false>(Pa, Q[b]);
+                const int k2 = 8 * a + b;
+                x[rev4_6(k2)] = INV ? pmul<true>(w, x[rev4_6(k2)]) : pmul<false>(w, x[rev4_6(k2)]);
+            }
+        }
+        exchange(x, area, lane);
+        mid();
+        fft64_dit<INV>(x);
+    }
+
+    template <bool INV, class HOOK = no_hook>
+    __device__ __forceinline__ void fft4096_t(v2f (&x)[R], const float2 *plq, float *area, int lane, HOOK mid = HOOK())
+    {
+        fft64_dif<INV>(x);
+        v2f Q[8];
+        #pragma unroll
+        for (int b = 0; b < 8; ++b)
+            Q[b] = mi_fft::ld2(plq + (8 + b) * R + lane);
+        #pragma unroll
+        for (int a = 0; a < 8; ++a)
+        {
+            const v2f Pa = mi_fft::ld2(plq + a * R + lane);
             #pragma unroll
             for (int b = 0; b < 8; ++b)
             {
@@ -227,17 +270,32 @@ namespace mi_fftw
         const int paddr = ((64 - lane) & 63) * 4;
         const bool l0 = lane == 0;
         v2f saved = x[0];
+        // the partners' values are asked for PAIRS_AHEAD iterations early (registers r + 1 .. and .. 62 - r are still the old
+        // ones): with two waves on a SIMD the round trip of a ds_bpermute per iteration was what this step waited for
+        constexpr int PAIRS_AHEAD = MI_FFTW_PAIRS_AHEAD;
+        v2f n1[PAIRS_AHEAD], n2[PAIRS_AHEAD];
+        #pragma unroll
+        for (int r = 0; r < PAIRS_AHEAD; ++r)
+        {
+            n1[r] = from_partner(paddr, x[63 - r]);
+            n2[r] = from_partner(paddr, x[r]);
+        }
         #pragma unroll
         for (int r = 0; r < R / 2; ++r)
         {
-            const int r2 = 63 - r, s = r % AHEAD;
+            const int r2 = 63 - r, s = r % AHEAD, sp = r % PAIRS_AHEAD;
             const float4 ab1 = q[2 * s], ab2 = q[2 * s + 1];
             if (r + AHEAD < R / 2)
             {
                 q[2 * s] = table_row(tab, lane * 16, r + AHEAD);
                 q[2 * s + 1] = table_row(tab, lane * 16, r2 - AHEAD);
             }
-            const v2f t1 = from_partner(paddr, x[r2]), t2 = from_partner(paddr, x[r]);
+            const v2f t1 = n1[sp], t2 = n2[sp];
+            if (r + PAIRS_AHEAD < R / 2)
+            {
+                n1[sp] = from_partner(paddr, x[r2 - PAIRS_AHEAD]);
+                n2[sp] = from_partner(paddr, x[r + PAIRS_AHEAD]);
+            }
             const v2f own1 = (r == 0) ? x[0] : saved, own2 = x[r + 1];
             const v2f c1 = v2f{l0 ? own1.x : t1.x, l0 ? own1.y : t1.y}, c2 = v2f{l0 ? own2.x : t2.x, l0 ? own2.y : t2.y};
             saved = x[r2];

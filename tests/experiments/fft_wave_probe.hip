@@ -13,159 +13,25 @@
 // the same butterflies.  The probe runs pairs forward + inverse with the device full and checks one forward transform against a
 // double-precision DFT on the host.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -I lsp-dsp-units_amd/csrc -I include tests/experiments/fft_wave_probe.hip -o tests/experiments/fft_wave_probe
-#include "fft_device.h"
-#include "mi_common.h"
+#include "fft_wave.h"
 #include <cmath>
 #include <cstdio>
 #include <vector>
-using mi_fft::v2f;
-using mi_fft::padd_i;
-using mi_fft::pmul;
+using namespace mi_fftw;
 
 namespace
 {
-    constexpr int N = 4096, R = 64, WAVES = 8, PITCH = 65;                 // PITCH: floats per row of the exchange area
-
-    constexpr int rev4_6(int k)                             // base-4 digit reversal of a 6-bit index
-    {
-        return ((k & 3) << 4) | (k & 12) | ((k >> 4) & 3);
-    }
-
-    constexpr double PI = 3.14159265358979323846;
-
-    // (wx + i wy) b with the constant in a pair of SGPRs: mi_fft::pmul wants its operands in VGPRs, and 108 constants hoisted out
-    // of the loop as VGPR pairs are what spilled.  The empty volatile asm pins the s_mov's next to their use.
-    __device__ __forceinline__ v2f pmul_c(float wx, float wy, v2f b)
-    {
-        v2f w{wx, wy}, t, r;
-        asm volatile("" : "+s"(w));
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "s"(w), "v"(b));
-        asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "=v"(r) : "s"(w), "v"(b), "v"(t));
-        return r;
-    }
-
-    // 64-point transform over the registers, in place; out[k] = x[rev4_6(k)] afterwards.  INV: e^{+i}.
-    template <bool INV>
-    __device__ __forceinline__ void fft64(v2f (&x)[R])
-    {
-        #pragma unroll
-        for (int len = 64; len >= 4; len /= 4)
-        {
-            const int q = len / 4;
-            #pragma unroll
-            for (int g = 0; g < R; g += len)
-                #pragma unroll
-                for (int j = 0; j < q; ++j)
-                {
-                    const v2f a0 = x[g + j], a1 = x[g + j + q], a2 = x[g + j + 2 * q], a3 = x[g + j + 3 * q];
-                    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
-                    v2f y0 = t0 + t2, y2 = t0 - t2;
-                    v2f y1 = INV ? padd_i<true>(t1, d) : padd_i<false>(t1, d);      // t1 -+ i d
-                    v2f y3 = INV ? padd_i<false>(t1, d) : padd_i<true>(t1, d);
-                    if (j > 0)
-                    {
-                        const double a = (INV ? 2.0 : -2.0) * PI * double(j) / double(len);
-                        y1 = pmul_c(float(__builtin_cos(a)), float(__builtin_sin(a)), y1);
-                        y2 = pmul_c(float(__builtin_cos(2 * a)), float(__builtin_sin(2 * a)), y2);
-                        y3 = pmul_c(float(__builtin_cos(3 * a)), float(__builtin_sin(3 * a)), y3);
-                    }
-                    x[g + j] = y0; x[g + j + q] = y1; x[g + j + 2 * q] = y2; x[g + j + 3 * q] = y3;
-                }
-        }
-    }
-
-    // the same transform by decimation in time: in: x[rev4_6(n)] = in[n]; out: natural order.
-    template <bool INV>
-    __device__ __forceinline__ void fft64_dit(v2f (&x)[R])
-    {
-        #pragma unroll
-        for (int len = 4; len <= 64; len *= 4)
-        {
-            const int q = len / 4;
-            #pragma unroll
-            for (int g = 0; g < R; g += len)
-                #pragma unroll
-                for (int j = 0; j < q; ++j)
-                {
-                    v2f a0 = x[g + j], a1 = x[g + j + q], a2 = x[g + j + 2 * q], a3 = x[g + j + 3 * q];
-                    if (j > 0)
-                    {
-                        const double a = (INV ? 2.0 : -2.0) * PI * double(j) / double(len);
-                        a1 = pmul_c(float(__builtin_cos(a)), float(__builtin_sin(a)), a1);
-                        a2 = pmul_c(float(__builtin_cos(2 * a)), float(__builtin_sin(2 * a)), a2);
-                        a3 = pmul_c(float(__builtin_cos(3 * a)), float(__builtin_sin(3 * a)), a3);
-                    }
-                    const v2f t0 = a0 + a2, t1 = a0 - a2, t2 = a1 + a3, d = a1 - a3;
-                    x[g + j] = t0 + t2;
-                    x[g + j + q] = INV ? padd_i<true>(t1, d) : padd_i<false>(t1, d);
-                    x[g + j + 2 * q] = t0 - t2;
-                    x[g + j + 3 * q] = INV ? padd_i<false>(t1, d) : padd_i<true>(t1, d);
-                }
-        }
-    }
-
-    // the exchange: in: lane l holds x[rev4_6(k2)] = Y[l][k2]; out: lane k2 holds x[rev4_6(l)] = Y[l][k2] (the order the second
-    // transform wants: which register a value is read into is free).  area: 64 x PITCH floats of this wave.
-    __device__ __forceinline__ void exchange(v2f (&x)[R], float *area, int lane)
-    {
-        asm volatile("" : "+v"(lane));                      // (the sixteen bases the reads want are computed here, not kept across
-                                                            //  the loop in registers this kernel does not have)
-        float *row = area + lane * PITCH;                   // row = source lane, column = k2
-        #pragma unroll
-        for (int k2 = 0; k2 < R; ++k2)
-            row[k2] = x[rev4_6(k2)].x;
-        __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int l = 0; l < R; ++l)
-            x[rev4_6(l)].x = area[l * PITCH + lane];        // (same wave: the writes above are performed first)
-        __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int k2 = 0; k2 < R; ++k2)
-            row[k2] = x[rev4_6(k2)].y;
-        __builtin_amdgcn_wave_barrier();
-        #pragma unroll
-        for (int l = 0; l < R; ++l)
-            x[rev4_6(l)].y = area[l * PITCH + lane];
-        __builtin_amdgcn_wave_barrier();
-    }
-
-    // a whole transform of the wave, natural order both sides: x[j] = in[lane + 64 j]  ->  x[k1] = out[lane + 64 k1].
-    // Q[b] = W_4096^(l b) in registers, P[a] = W_4096^(8 l a) from the workgroup's table pl[a][l] (this lane's l), a, b < 8.
-    struct no_hook { __device__ __forceinline__ void operator()() const { } };
-    template <bool INV, class HOOK = no_hook>
-    __device__ __forceinline__ void fft4096(v2f (&x)[R], const float2 *pl, const v2f (&Q)[8], float *area, int lane, HOOK mid = HOOK())
-    {
-        fft64<INV>(x);
-        #pragma unroll
-        for (int a = 0; a < 8; ++a)
-        {
-            const v2f Pa = mi_fft::ld2(pl + a * R + lane);
-            #pragma unroll
-            for (int b = 0; b < 8; ++b)
-            {
-                if (a == 0 && b == 0)
-                    continue;
-                const v2f w = (a == 0) ? Q[b] : (b == 0) ? Pa : pmul<false>(Pa, Q[b]);
-                const int k2 = 8 * a + b;
-                x[rev4_6(k2)] = INV ? pmul<true>(w, x[rev4_6(k2)]) : pmul<false>(w, x[rev4_6(k2)]);
-            }
-        }
-        exchange(x, area, lane);
-        mid();                                              // (loads the step after this transform wants: in flight over its second half)
-        fft64_dit<INV>(x);
-    }
+    constexpr int WAVES = 8;
 
     __global__ __launch_bounds__(64 * WAVES, 2)
-    void probe(float2 *data, const float2 *__restrict__ tw /* W_4096^m, m < 4096 */, int reps, int check)
+    void probe(float2 *data, const float2 *__restrict__ tw, int reps, int check)
     {
-        __shared__ float areas[WAVES][R * PITCH];
+        __shared__ float areas[WAVES][AREA];
         __shared__ float2 pl[8 * R];
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        pl[tid] = tw[(8 * (tid & 63) * (tid >> 6)) & (N - 1)];
+        fill_table(pl, tw, tid);
         v2f Q[8];
-        #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            Q[b] = mi_fft::ld2(tw + lane * b);
+        load_lane_twiddles(Q, tw, lane);
         __syncthreads();
         float2 *seq = data + (size_t(blockIdx.x) * WAVES + wv) * N + lane;
         v2f x[R];
@@ -191,85 +57,18 @@ namespace
 
 namespace
 {
-    // alpha x + beta conj(c) in four packed instructions
-    __device__ __forceinline__ v2f fused_bin(float4 ab, v2f x, v2f c)
-    {
-        const v2f al{ab.x, ab.y}, be{ab.z, ab.w};
-        v2f t;
-        asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(al), "v"(x));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]" : "+v"(t) : "v"(al), "v"(x));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,0,0] op_sel_hi:[0,1,1] neg_hi:[0,1,0]" : "+v"(t) : "v"(be), "v"(c));
-        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "+v"(t) : "v"(be), "v"(c));
-        return t;
-    }
-
-    __device__ __forceinline__ v2f from_partner(int addr, v2f v)
-    {
-        return v2f{__int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v.x))),
-                   __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v.y)))};
-    }
-
-    // The packed spectrum of a real frame of 8192 (bin k = lane + 64 r in register r), times a real response's spectrum, packed
-    // again -- split, product and merge of the workgroup cores as ONE step per bin:
-    //     Zy[k] = alpha[k] Z[k] + beta[k] conj(Z[N - k]),
-    //     alpha = S + D Im W,  beta = i D Re W,  S, D = (H[k] +- conj H[N - k]) / 2,  W = e^{-i pi k / N}   (k = 0: H[0], H[N] real)
-    // (tables per response, made where the response is parsed).  The partner N - k sits in lane 64 - lane, register 63 - r; lane 0
-    // pairs with itself, register (64 - r) & 63 -- the one select per value.
-    constexpr int AHEAD = 4;                                // iterations of split_filter_merge whose table rows are in flight
-    // row r of the table for this lane: ONE lane offset in a VGPR, the row in the scalar offset (64-bit row pointers are what spilled)
-    __device__ __forceinline__ float4 table_row(__amdgpu_buffer_rsrc_t tab, int lane16, int r)
-    {
-        typedef unsigned u4 __attribute__((ext_vector_type(4)));
-        const u4 d = __builtin_amdgcn_raw_buffer_load_b128(tab, lane16, r * R * int(sizeof(float4)), 0);
-        return make_float4(__uint_as_float(d.x), __uint_as_float(d.y), __uint_as_float(d.z), __uint_as_float(d.w));
-    }
-    __device__ __forceinline__ void table_ahead(float4 (&q)[2 * AHEAD], __amdgpu_buffer_rsrc_t tab, int lane)
-    {
-        #pragma unroll
-        for (int r = 0; r < AHEAD; ++r)
-        {
-            q[2 * r] = table_row(tab, lane * 16, r);
-            q[2 * r + 1] = table_row(tab, lane * 16, 63 - r);
-        }
-    }
-    __device__ __forceinline__ void split_filter_merge(v2f (&x)[R], float4 (&q)[2 * AHEAD], __amdgpu_buffer_rsrc_t tab /* [r][lane] */, int lane)
-    {
-        const int paddr = ((64 - lane) & 63) * 4;
-        const bool l0 = lane == 0;
-        v2f saved = x[0];
-        #pragma unroll
-        for (int r = 0; r < R / 2; ++r)
-        {
-            const int r2 = 63 - r, s = r % AHEAD;
-            const float4 ab1 = q[2 * s], ab2 = q[2 * s + 1];
-            if (r + AHEAD < R / 2)
-            {
-                q[2 * s] = table_row(tab, lane * 16, r + AHEAD);
-                q[2 * s + 1] = table_row(tab, lane * 16, r2 - AHEAD);
-            }
-            const v2f t1 = from_partner(paddr, x[r2]), t2 = from_partner(paddr, x[r]);
-            const v2f own1 = (r == 0) ? x[0] : saved, own2 = x[r + 1];
-            const v2f c1 = v2f{l0 ? own1.x : t1.x, l0 ? own1.y : t1.y}, c2 = v2f{l0 ? own2.x : t2.x, l0 ? own2.y : t2.y};
-            saved = x[r2];
-            x[r] = fused_bin(ab1, x[r], c1);
-            x[r2] = fused_bin(ab2, x[r2], c2);
-        }
-    }
-
     // a real frame of 8192 per wave: forward, split-filter-merge, inverse (what a block of the FIR equalizer is)
     __global__ __launch_bounds__(64 * WAVES, 2)
     void probe_conv(float2 *data, const float4 *__restrict__ ab, const float2 *__restrict__ tw, int reps)
     {
-        __shared__ float areas[WAVES][R * PITCH];
+        __shared__ float areas[WAVES][AREA];
         __shared__ float2 pl[8 * R];
         const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-        pl[tid] = tw[(8 * (tid & 63) * (tid >> 6)) & (N - 1)];
+        fill_table(pl, tw, tid);
         v2f Q[8];
-        #pragma unroll
-        for (int b = 0; b < 8; ++b)
-            Q[b] = mi_fft::ld2(tw + lane * b);
+        load_lane_twiddles(Q, tw, lane);
         __syncthreads();
-        const __amdgpu_buffer_rsrc_t tab = __builtin_amdgcn_make_buffer_rsrc(const_cast<float4 *>(ab), 0, int(N * sizeof(float4)), mi::BUFFER_DWORD3);
+        const __amdgpu_buffer_rsrc_t tab = table_of(ab);
         float2 *seq = data + (size_t(blockIdx.x) * WAVES + wv) * N + lane;      // (x[2 n], x[2 n + 1]), n = lane + 64 j
         v2f x[R];
         #pragma unroll
@@ -290,9 +89,9 @@ namespace
 
 int main()
 {
-    std::vector<float2> tw(N);
-    for (int m = 0; m < N; ++m)
-        tw[m] = make_float2(float(cos(-2.0 * PI * m / N)), float(sin(-2.0 * PI * m / N)));
+    std::vector<float2> tw(mi_fft::TWN);                    // the device table of the library: exp(-2 pi i j / TWN)
+    for (int m = 0; m < mi_fft::TWN; ++m)
+        tw[m] = make_float2(float(cos(-2.0 * PI * m / mi_fft::TWN)), float(sin(-2.0 * PI * m / mi_fft::TWN)));
     float2 *dtw;
     (void)hipMalloc(&dtw, tw.size() * sizeof(float2));
     (void)hipMemcpy(dtw, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice);

@@ -12,7 +12,7 @@ import json
 import os
 import sys
 
-KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_batch_tail_kernel<16,", "equalizer": "conv_frames_kernel",
+KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_batch_tail_kernel<16,", "equalizer": "conv_frames_wave_kernel",
            "spectral": "analyzer_frames_kernel"}
 # second kernels of a workload's PMC passes (bench.py's per_call legs): summary name -> (workload, kernel)
 EXTRA = {"convolver_step": ("convolver", "conv_step_kernel<12, false>")}

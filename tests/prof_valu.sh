@@ -15,7 +15,7 @@ python3 - "$O" "$R/gpurun_out/profiles_$TAG/${TAG}_kernels_pmc_sq.json" <<'PY'
 import csv, glob, json, os, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 # units (blocks / frames) a launch of the kernel carries in these passes (--conv-steps 128)
-UNITS = {"conv_frames_kernel": 128, "conv_batch_tail_kernel": 16, "conv_batch_forward_kernel": 16, "conv_batch_frames_kernel": 16,
+UNITS = {"conv_frames_kernel": 128, "conv_frames_wave_kernel": 128, "conv_batch_tail_kernel": 16, "conv_batch_forward_kernel": 16, "conv_batch_frames_kernel": 16,
          "analyzer_frames_kernel": 16, "bin_reduce_frames_kernel": 16, "stft_stream_blocks_kernel": 64, "splitter_hops_blocks_kernel": 64,
          "biquad_stream_chain_kernel": 64}
 out = {"note": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR, one pass per bench workload "
