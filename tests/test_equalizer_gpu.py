@@ -160,8 +160,8 @@ def test_smooth_retune_cross_fades_over_one_block(gpu, mode, calls):
     eq.close()
 
 
-@pytest.mark.parametrize("rank", [7, 9])
-@pytest.mark.parametrize("seed", [101, 202, 303, 404, 505, 606, 707, 808, 909, 1010])
+@pytest.mark.parametrize("seed,rank", [(s, r) for r in (7, 9) for s in (101, 202, 303, 404, 505, 606, 707, 808, 909, 1010)] +
+                                      [(111, 12), (222, 12), (333, 12)])     # (rank 12: calls of several blocks ride conv_frames_wave_kernel)
 def test_random_operation_sequences_match_oracle(gpu, seed, rank):
     """Differential stress: random sequences of retunes, mode switches, resets and ragged process() calls on a
     two-channel bank against one oracle object per channel (well-conditioned filters: the strict tolerance applies).
