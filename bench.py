@@ -754,7 +754,7 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
         gains = 10.0 ** (rng.uniform(-12.0, 12.0, nfilt) / 20.0)
         for i in range(nfilt):
             eq.set_params(i, FLT_BT_RLC_BELL, 1, float(freqs[i]), float(freqs[i]), float(gains[i]), 2.0, channel=c)
-    ring = 8
+    ring = int(os.environ.get("MI_BENCH_EQ_RING", "8"))     # (experiment knob: 192 = a buffer of its own for every block of a region)
     gen = torch.Generator(device="cpu")
     gen.manual_seed(60 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
