@@ -484,12 +484,10 @@ namespace
         using namespace mi_fftw;
         constexpr int B = N, HALF = R / 2;                  // samples of a block; registers of a half frame
         __shared__ float areas[WAVE_FRAMES][AREA];
-        __shared__ float2 pl[8 * R];
+        __shared__ float2 pl[16 * R];
         const int ch = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);           // (a scalar: the buffers of a wave's unit are uniform)
-        fill_table(pl, tw, tid);
-        v2f Q[8];
-        load_lane_twiddles(Q, tw, lane);
+        fill_table_pq(pl, tw, tid, 64 * WAVE_FRAMES);
         __syncthreads();
         const __amdgpu_buffer_rsrc_t tab = table_of(tabs + size_t(ch) * N);
         float *const line = dl_ring + size_t(ch) * dl_size;
@@ -538,9 +536,9 @@ namespace
                 }
             }
             float4 q[2 * AHEAD];
-            fft4096<false>(x, pl, Q, areas[wv], lane, [&]() { table_ahead(q, tab, lane); });
+            fft4096_t<false>(x, pl, areas[wv], lane, [&]() { table_ahead(q, tab, lane); });
             split_filter_merge(x, q, tab, lane);
-            fft4096<true>(x, pl, Q, areas[wv], lane);
+            fft4096_t<true>(x, pl, areas[wv], lane);
             // register HALF + i: samples 2 n, 2 n + 1 of block g (n = lane + 64 i); the lower half is the circular wrap: not used
             if (g == 0)
             {
