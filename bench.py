@@ -972,7 +972,7 @@ def _step_result(name, workload, C, n, steps, elapsed, world, bytes_per_sample, 
     if extra:
         res.update(extra)
     # (the row's dominant launch against the vector unit's issue rate, priced from the whole step: the rows carry no kernel probes)
-    kern = {"crossover": "biquad_stream_chain_kernel", "splitter": "splitter_hops_blocks_kernel", "spectral_processor": "stft_stream_blocks_kernel",
+    kern = {"crossover": "biquad_stream_chain_kernel", "splitter": "splitter_wave_blocks_kernel", "spectral_processor": "stft_stream_blocks_kernel",
             "dynfilter": "dynfilter_kernel"}.get(name)
     side = _issue_side(kern, [elapsed / steps * 1e3], 1) if kern else {}
     if side and (C, n) == {"splitter": (256, 4096)}.get(name, (1024, 4096)):
@@ -1030,7 +1030,7 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
     edges = [(None, (300.0, -32.0)), ((300.0, -32.0), (2000.0, -32.0)), ((2000.0, -32.0), (8000.0, -32.0)), ((8000.0, -32.0), None)]
     for b, (hp, lp) in enumerate(edges):
         sp.bind_mask(b, mi.crossover_fft_mask(hp, lp, 1.0, 1.0, 48000, rank_fft))
-    ring = 4
+    ring = int(os.environ.get("MI_BENCH_SPLIT_RING", "64"))  # a buffer of its own for every block of a run of 64 (1.3 GB)
     gen = torch.Generator(device="cpu"); gen.manual_seed(80 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
     outs = [[torch.empty((C, n), dtype=torch.float32, device=dev) for _ in range(bands)] for _ in range(ring)]
@@ -1056,11 +1056,13 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
     if rank != 0:
         return None
     return _step_result("splitter", "FFTCrossover / SpectralSplitter, rank 12, 4 bands, %d channels per GPU, 4096-sample "
-                        "blocks (algorithmically two transforms of 4096 points forward and eight back per channel and step; the "
-                        "launch runs one workgroup per channel and band, each with its own forward transform)" % C,
+                        "blocks (a wave per channel and quarter of the run: the two frames of a block as ONE 4096-point complex "
+                        "transform, one forward and four inverse transforms per channel and step, the spectrum and the bands' "
+                        "overlap-add tails in registers; a buffer of its own for every block of a run)" % C,
                         C, n, K, elapsed, world, 20.0,
-                        {"call": "one mi_splitter_bank_process_blocks call per region: runs of 64 blocks ride splitter_hops_blocks_kernel, "
-                                 "bit-identical to %d process() calls" % K,
+                        {"call": "one mi_splitter_bank_process_blocks call per region: runs of 64 blocks ride splitter_wave_blocks_kernel "
+                                 "(fft_wave.h: within 1e-6 of %d process() calls; MI_SPLITTER_LDS=1: splitter_hops_blocks_kernel, one "
+                                 "workgroup per channel and band, their bits)" % K,
                          "per_call": {"what": "the same blocks as separate mi_splitter_bank_process calls (one launch of splitter_hop_kernel per block)",
                                       "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),
                                       "whole_step_frac": round(20.0 * C * n / (pc_elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)}})

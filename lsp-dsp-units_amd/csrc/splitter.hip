@@ -19,10 +19,12 @@
 #include "mi_common.h"
 #include "fft_device.h"
 #include "fft16.h"
+#include "fft_wave.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace mi
@@ -457,6 +459,153 @@ namespace
             float *emit = (ingest_n > 0 && out_row(h) != nullptr) ? out_row(h) + size_t(ch) * out_stride + out_pos : nullptr;
             const uint32_t first = uint32_t(H) - frame;                // the last 2*frame samples, in pairs
             overlap_add(line, w2, frame, tid, T, scale, emit, [&](uint32_t m) { return buf[first + m]; });
+        }
+    }
+
+    // ---- runs of 4096-sample blocks at rank 12, every listening handler a mask shared by the channels: on the wave-resident
+    // transform (fft_wave.h) ------------------------------------------------------------------------------------------------------
+    // splitter_hops_blocks_kernel runs at the rate of its transforms through LDS, and at 256 channels it is one workgroup per channel
+    // AND band, each redoing the forward transform.  Here a WAVE owns a channel's consecutive blocks and takes the two frames of a
+    // block -- frame 2u = block u - 1, frame 2u + 1 = [second half of block u - 1 | first half of block u] -- as ONE complex
+    // sequence z = A + i B: a real, even gain acts on the spectra of A and B alike, so g Z is the spectrum of the two shaped frames:
+    // ONE forward transform per block and one inverse per band (NB + 1 transforms of 4096 complex points for what was 2 + 2 NB real
+    // transforms of 4096 points, with their splits and merges), no barrier.  The spectrum waits in registers while the bands take
+    // turns, each band's overlap-add tail stays in 32 registers of the wave: 128 (work) + 128 (spectrum) + 32 NB registers -- the
+    // wave has its SIMD to itself (four waves per CU) and the whole register file with it.  Window and gains (their halves: bind_mask
+    // stores the even part) sit in LDS.  A channel's run is cut into 1, 2 or 4 segments, the waves of one workgroup; a segment that
+    // does not start the run first redoes the block in front of it (without storing) for the tails it starts from.
+    // The same sums through another transform and in another order of roundings: within 1e-6 of splitter_hops_blocks_kernel, not its
+    // bits.  The host sends a run this way only if no buffer of the run overlaps another (the segments run side by side).
+    constexpr int SPW = 4;                                  // waves of a workgroup: one per SIMD
+    struct wave_bands
+    {
+        const float    *gain[4];                            // the listening handlers' gains (N floats, even)
+        float          *line[4];                            // ... their lines [channels][pitch]
+        uint32_t        handler[4];                         // ... their numbers (columns of split_blocks::out)
+    };
+    template <int NB>
+    __global__ __launch_bounds__(64 * SPW, 1)
+    void splitter_wave_blocks_kernel(const float *in_cur, float *in_next, size_t in_pitch, size_t line_pitch, const wave_bands wb,
+                                     uint32_t handlers, const float *__restrict__ wnd, const float2 *__restrict__ tw,
+                                     const split_blocks tab, size_t src_stride, size_t out_stride, int blocks, int channels, int segs)
+    {
+        using namespace mi_fftw;
+        constexpr int HALF = R / 2, HOP = N / 2;
+        __shared__ float areas[SPW][AREA];
+        __shared__ float2 pl[16 * R];
+        __shared__ float wnd_l[N];
+        __shared__ float gain_h[NB][HOP + 1];
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        fill_table_pq(pl, tw, tid, 64 * SPW);
+        for (int i = tid; i < N; i += 64 * SPW)
+            wnd_l[i] = wnd[i] * (1.0f / float(N));          // (the transform pair's 1 / N rides on the window)
+        #pragma unroll
+        for (int b = 0; b < NB; ++b)
+            for (int i = tid; i <= HOP; i += 64 * SPW)
+                gain_h[b][i] = wb.gain[b][i];
+        __syncthreads();
+        const int gid = blockIdx.x * SPW + wv;              // wave of the launch: (channel, segment); segs divides SPW
+        const bool idle = gid >= channels * segs;
+        const int ch = idle ? 0 : gid / segs, seg = gid - ch * segs;
+        const int per = (blocks + segs - 1) / segs, u0 = seg * per, u1 = idle ? u0 : ((u0 + per < blocks) ? u0 + per : blocks);
+        auto at = [](__amdgpu_buffer_rsrc_t r, int lane_off, int row_off) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
+        };
+        // block u of the run as the caller gave it (u = -1: the N samples the object holds)
+        auto block_in = [&](int u) -> __amdgpu_buffer_rsrc_t {
+            return mi::wt_buffer((u < 0) ? const_cast<float *>(in_cur) + size_t(ch) * in_pitch
+                                         : const_cast<float *>(tab.src[u]) + size_t(ch) * src_stride, unsigned(N * sizeof(float)));
+        };
+        float tail[NB][HALF];                               // what the next frame adds to, band by band: sample lane + 64 j
+        #pragma unroll
+        for (int b = 0; b < NB; ++b)
+        {
+            const __amdgpu_buffer_rsrc_t rl = mi::wt_buffer(wb.line[b] + size_t(ch) * line_pitch, (u0 == 0 && u0 < u1) ? unsigned(N * sizeof(float)) : 0u);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+                tail[b][j] = at(rl, lane * 4, (HOP + 64 * j) * 4);      // (0 where the segment starts inside the run: out of range)
+        }
+        for (int u = (u0 == 0) ? 0 : u0 - 1; u < u1 && u0 < u1; ++u)
+        {
+            // z[n] = A[n] + i B[n], n = lane + 64 j: A = block u - 1, B = [its second half | first half of block u]
+            const __amdgpu_buffer_rsrc_t ra = block_in(u - 1), rb = block_in(u);
+            v2f x[R], z[R];
+            #pragma unroll
+            for (int j = 0; j < R; ++j)
+                x[j].x = at(ra, lane * 4, 256 * j);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                x[j].y = x[j + HALF].x;
+                x[j + HALF].y = at(rb, lane * 4, 256 * j);
+            }
+            fft4096_t<false>(x, pl, areas[wv], lane);
+            #pragma unroll
+            for (int r = 0; r < R; ++r)
+                z[r] = x[r];
+            const bool store = u >= u0;                      // (the block in front of the segment: only its tails are wanted)
+            // The bands take turns in ONE copy of the code (an inverse transform is 37 KB of it): the loop is kept rolled and the
+            // tails ROTATE through tail[0] -- indexed by the loop's counter they would live in scratch memory.
+            #pragma nounroll
+            for (int b = 0; b < NB; ++b)
+            {
+                // the gain of bin k = lane + 64 r: g[min(k, N - k)]
+                #pragma unroll
+                for (int r = 0; r < R; ++r)
+                {
+                    const float g = (r < HALF) ? gain_h[b][lane + 64 * r] : gain_h[b][64 * (R - r) - lane];
+                    x[r] = z[r] * v2f{g, g};
+                }
+                fft4096_t<true>(x, pl, areas[wv], lane);
+                #pragma unroll
+                for (int j = 0; j < R; ++j)
+                {
+                    const float w = wnd_l[lane + 64 * j];
+                    x[j] = x[j] * v2f{w, w};
+                }
+                float *const o = tab.out[size_t(u) * handlers + wb.handler[b]];
+                const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer((store && o != nullptr) ? o + size_t(ch) * out_stride : nullptr,
+                                                                  (store && o != nullptr) ? unsigned(N * sizeof(float)) : 0u);
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                {
+                    const float done_a = x[j].x + tail[0][j];
+                    const float done_b = x[j].y + x[j + HALF].x;
+                    const float mine = x[j + HALF].y;                       // this band's new tail: to the back of the queue
+                    #pragma unroll
+                    for (int q = 0; q + 1 < NB; ++q)
+                        tail[q][j] = tail[q + 1][j];
+                    tail[NB - 1][j] = mine;
+                    mi::wt_store(rout, lane * 4 + 256 * j, done_a);             // (dropped by the bounds check where nothing is stored)
+                    mi::wt_store(rout, lane * 4 + 256 * (j + HALF), done_b);
+                }
+            }
+        }
+        // The object's state as the call leaves it -- behind a barrier: the wave of the channel's first segment has read the state the
+        // call found.  Lines: [the frame finished last | the tail]; the analysis buffer (the other one of the pair): the last block.
+        __syncthreads();
+        if (u1 == blocks && u0 < u1)
+        {
+            const __amdgpu_buffer_rsrc_t rlast = block_in(blocks - 1);
+            const __amdgpu_buffer_rsrc_t rx = mi::wt_buffer(in_next + size_t(ch) * in_pitch, unsigned(N * sizeof(float)));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (this wave's own stores of the last block)
+            #pragma unroll
+            for (int j = 0; j < R; ++j)
+                mi::wt_store(rx, lane * 4 + 256 * j, at(rlast, lane * 4, 256 * j));
+            #pragma unroll
+            for (int b = 0; b < NB; ++b)
+            {
+                const __amdgpu_buffer_rsrc_t rl = mi::wt_buffer(wb.line[b] + size_t(ch) * line_pitch, unsigned(N * sizeof(float)));
+                float *const o = tab.out[size_t(blocks - 1) * handlers + wb.handler[b]];
+                const __amdgpu_buffer_rsrc_t rd = mi::wt_buffer(o + size_t(ch) * out_stride, unsigned(N * sizeof(float)));
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                {
+                    mi::wt_store(rl, lane * 4 + 256 * j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 256 * (j + HALF), mi::CPOL_SC1)));
+                    mi::wt_store(rl, lane * 4 + 256 * (j + HALF), tail[b][j]);
+                }
+            }
         }
     }
 
@@ -1276,6 +1425,65 @@ int mi_splitter_bank_process_blocks(mi_splitter_bank_t *b, float *const *outs, c
         const int lh = int(b->rank) - 1;
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
+        // rank 12, blocks of exactly one frame, up to four listening masks shared by the channels, every buffer of the run apart from
+        // every other: a wave per channel and segment of the run on the wave-resident transform (splitter_wave_blocks_kernel)
+        {
+            wave_bands wb{};
+            uint32_t nb = 0;
+            bool waves = b->rank == 12 && count == (size_t(1) << b->rank) && getenv("MI_SPLITTER_LDS") == nullptr;
+            for (uint32_t i = 0; i < nh && waves; ++i)
+            {
+                if (!b->has_sink[i])
+                    continue;
+                if (b->h[i].mode != H_MASK || b->h[i].mask_stride != 0 || nb == 4)
+                {
+                    waves = false;
+                    break;
+                }
+                wb.gain[nb] = b->h[i].d_mask;
+                wb.line[nb] = b->d_lines + size_t(i) * b->channels * b->pitch;
+                wb.handler[nb] = i;
+                ++nb;
+            }
+            waves = waves && nb >= 1;
+            if (waves)
+            {
+                std::vector<std::pair<uintptr_t, uintptr_t>> iv;
+                const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float);
+                for (size_t q = 0; q < run; ++q)
+                    for (uint32_t i = 0; i < nb; ++i)
+                    {
+                        const uintptr_t p = reinterpret_cast<uintptr_t>(outs[(k + q) * nh + wb.handler[i]]);
+                        iv.emplace_back(p, p + ob);
+                    }
+                std::sort(iv.begin(), iv.end());
+                for (size_t i = 1; i < iv.size() && waves; ++i)
+                    waves = iv[i].first >= iv[i - 1].second;    // (outputs against inputs: the run was formed that way)
+            }
+            if (waves)
+            {
+                const int want = int((1024 + b->channels - 1) / b->channels);
+                int segs = 1;
+                while (segs < SPW && 2 * segs <= want && 2 * segs <= int(run) / 4)
+                    segs *= 2;
+                const dim3 grid((b->channels * unsigned(segs) + SPW - 1) / SPW);
+                #define MI_WAVE(NB_) MI_LAUNCH((splitter_wave_blocks_kernel<NB_>), grid, dim3(64 * SPW), 0, st, ev0, ev1, b->d_in, b->d_in2, b->pitch, \
+                                               b->pitch, wb, nh, b->d_wnd, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs)
+                switch (nb)
+                {
+                    case 1:  { MI_WAVE(1); break; }
+                    case 2:  { MI_WAVE(2); break; }
+                    case 3:  { MI_WAVE(3); break; }
+                    default: { MI_WAVE(4); break; }
+                }
+                #undef MI_WAVE
+                MI_HIP_CHECK(hipGetLastError());
+                std::swap(b->d_in, b->d_in2);
+                b->fill = frame;
+                k += run;
+                continue;
+            }
+        }
         #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
             MI_LAUNCH((splitter_hops_blocks_kernel<LH>), dim3(b->channels, nh), dim3(fplan<LH>::T), 0, st, ev0, ev1, b->d_in, b->d_in2, b->pitch, \
                       b->d_lines, b->pitch, b->channels, b->d_desc, nh, b->d_wnd, frame, b->d_tw, in_stride, out_stride, hops, tab)
