@@ -493,17 +493,22 @@ namespace
         constexpr int HALF = R / 2, HOP = N / 2;
         __shared__ float areas[SPW][AREA];
         __shared__ float2 pl[16 * R];
-        __shared__ float wnd_l[N];
-        __shared__ float gain_h[NB][HOP + 1];
+        // window and gains the way a lane reads them: entry lane + 64 r of a table at float4 cell [r / 4][lane], component r % 4 --
+        // sixteen 16-byte LDS reads per table and use instead of sixty-four 4-byte ones (one wave per SIMD: every read's round trip
+        // is the wave's own time)
+        __shared__ float4 wnd_l[N / 4];
+        __shared__ float4 gain_l[NB][N / 4];
         const int tid = threadIdx.x, lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         fill_table_pq(pl, tw, tid, 64 * SPW);
         for (int i = tid; i < N; i += 64 * SPW)
-            wnd_l[i] = wnd[i] * (1.0f / float(N));          // (the transform pair's 1 / N rides on the window)
-        #pragma unroll
-        for (int b = 0; b < NB; ++b)
-            for (int i = tid; i <= HOP; i += 64 * SPW)
-                gain_h[b][i] = wb.gain[b][i];
+        {
+            const int l = i & 63, r = i >> 6;               // entry i = l + 64 r
+            reinterpret_cast<float *>(wnd_l)[((r >> 2) * 64 + l) * 4 + (r & 3)] = wnd[i] * (1.0f / float(N));   // (the pair's 1 / N rides on the window)
+            #pragma unroll
+            for (int b = 0; b < NB; ++b)
+                reinterpret_cast<float *>(gain_l[b])[((r >> 2) * 64 + l) * 4 + (r & 3)] = wb.gain[b][i];
+        }
         __syncthreads();
         const int gid = blockIdx.x * SPW + wv;              // wave of the launch: (channel, segment); segs divides SPW
         const bool idle = gid >= channels * segs;
@@ -550,19 +555,25 @@ namespace
             #pragma nounroll
             for (int b = 0; b < NB; ++b)
             {
-                // the gain of bin k = lane + 64 r: g[min(k, N - k)]
+                // the gain of bin k = lane + 64 r (the even part of the handler's gains: N of them)
                 #pragma unroll
-                for (int r = 0; r < R; ++r)
+                for (int r4 = 0; r4 < R / 4; ++r4)
                 {
-                    const float g = (r < HALF) ? gain_h[b][lane + 64 * r] : gain_h[b][64 * (R - r) - lane];
-                    x[r] = z[r] * v2f{g, g};
+                    const float4 g = gain_l[b][r4 * 64 + lane];
+                    x[4 * r4 + 0] = z[4 * r4 + 0] * v2f{g.x, g.x};
+                    x[4 * r4 + 1] = z[4 * r4 + 1] * v2f{g.y, g.y};
+                    x[4 * r4 + 2] = z[4 * r4 + 2] * v2f{g.z, g.z};
+                    x[4 * r4 + 3] = z[4 * r4 + 3] * v2f{g.w, g.w};
                 }
                 fft4096_t<true>(x, pl, areas[wv], lane);
                 #pragma unroll
-                for (int j = 0; j < R; ++j)
+                for (int j4 = 0; j4 < R / 4; ++j4)
                 {
-                    const float w = wnd_l[lane + 64 * j];
-                    x[j] = x[j] * v2f{w, w};
+                    const float4 w = wnd_l[j4 * 64 + lane];
+                    x[4 * j4 + 0] = x[4 * j4 + 0] * v2f{w.x, w.x};
+                    x[4 * j4 + 1] = x[4 * j4 + 1] * v2f{w.y, w.y};
+                    x[4 * j4 + 2] = x[4 * j4 + 2] * v2f{w.z, w.z};
+                    x[4 * j4 + 3] = x[4 * j4 + 3] * v2f{w.w, w.w};
                 }
                 float *const o = tab.out[size_t(u) * handlers + wb.handler[b]];
                 const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer((store && o != nullptr) ? o + size_t(ch) * out_stride : nullptr,
