@@ -923,7 +923,9 @@ def run_spectral_processor(args, mi, torch, dist, rank, world, dev):
     sp = mi.SpectralBank(C, rank_fft)
     sp.set_rank(rank_fft)
     sp.bind_mask(np.linspace(1.0, 0.25, (1 << (rank_fft - 1)) + 1).astype(np.float32))
-    ring = 4
+    # a buffer of its own for every block of a run of 64 (2 x 1 GiB: nothing comes back out of the 256 MiB last-level cache,
+    # and stft_wave_blocks_kernel -- whose waves take a channel's run in segments side by side -- wants the run's buffers apart)
+    ring = 64
     gen = torch.Generator(device="cpu"); gen.manual_seed(90 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
     yout = torch.empty_like(xin)

@@ -18,10 +18,12 @@
 #include "mi_common.h"
 #include "fft_device.h"
 #include "fft16.h"
+#include "fft_wave.h"
 
 #include <algorithm>
 #include <cmath>
 #include <cstdint>
+#include <utility>
 #include <vector>
 
 namespace
@@ -351,6 +353,154 @@ namespace
                                    const stft_blocks tab, size_t src_stride, size_t dst_stride, int hops)
     {
         stft_stream_body<LOGH, MASKED, true>(in_buf, out_buf, wnd_in, wnd_out, mask, mask_stride, tw, nullptr, src_stride, nullptr, dst_stride, hops, &tab);
+    }
+
+    // ---- runs of 4096-sample blocks at rank 12 with a fused mask shared by the channels, on the wave-resident transform (fft_wave.h) --
+    // stft_stream_blocks_kernel runs at the rate of its transforms through LDS (0.24 of the HBM roofline, 0.40 of the issue rate).
+    // Here a WAVE owns a channel's consecutive blocks and takes the two frames of a block -- frame 2u = block u - 1, frame 2u + 1
+    // = [second half of block u - 1 | first half of block u] -- as ONE complex sequence z = w (A + i B): a real, symmetric gain
+    // acts on the spectrum of A and on the spectrum of B alike, so G Z is the spectrum of the two shaped frames: one forward and one
+    // inverse 4096-point complex transform per BLOCK (two real frames), no split, no merge, no barrier.  The inverse's real part is
+    // frame A's result, its imaginary part frame B's; the output window and the overlap-add are the lane's own registers, and the
+    // tail the next block adds to stays in 32 registers of the wave.  The shape of splitter_wave_blocks_kernel (splitter.hip) with one
+    // band and a window in front: four waves per workgroup, one per SIMD; the windows and the gains sit in LDS the way a lane reads them
+    // (16-byte reads).  A first version with two waves per SIMD, 4-byte reads of half tables and a hundred spilled registers measured
+    // 21.8 - 26 us per block against the workgroup kernel's 19.4 (profiles/r05_experiments/stft_wave_blocks.txt).
+    // A channel's run is cut into 1, 2 or 4 segments, the waves of one workgroup; a segment that does not start the run first redoes
+    // the block in front of it (without storing) for the tail it starts from.
+    // The same sums through another transform: within 1e-6 of stft_stream_blocks_kernel, not its bits.  The host sends a run this way
+    // only if no buffer of the run overlaps another (the segments run side by side).
+    constexpr int STFT_WAVES = 4;
+    __global__ __launch_bounds__(64 * STFT_WAVES, 1)
+    void stft_wave_blocks_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in /* or NULL: none */,
+                                 const float *__restrict__ wnd_out, const float *__restrict__ mask /* one row of N / 2 + 1 gains */,
+                                 const float2 *__restrict__ tw, const stft_blocks tab, size_t src_stride, size_t dst_stride,
+                                 int blocks, int channels, int segs)
+    {
+        using namespace mi_fftw;
+        constexpr int HALF = R / 2, HOP = N / 2;            // registers of half a frame; samples of a hop
+        __shared__ float areas[STFT_WAVES][AREA];
+        __shared__ float2 pl[16 * R];
+        // entry lane + 64 r of a table at float4 cell [r / 4][lane], component r % 4
+        __shared__ float4 win_l[N / 4], wout_l[N / 4], gain_l[N / 4];
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        fill_table_pq(pl, tw, tid, 64 * STFT_WAVES);
+        for (int i = tid; i < N; i += 64 * STFT_WAVES)
+        {
+            const int l = i & 63, r = i >> 6, cell = ((r >> 2) * 64 + l) * 4 + (r & 3);
+            reinterpret_cast<float *>(win_l)[cell] = (wnd_in != nullptr) ? wnd_in[i] : 1.0f;
+            reinterpret_cast<float *>(wout_l)[cell] = wnd_out[i] * (1.0f / float(N));    // (the transform pair's 1 / N rides on the window)
+            reinterpret_cast<float *>(gain_l)[cell] = mask[(i <= HOP) ? i : N - i];       // the N / 2 + 1 gains act on k and N - k alike
+        }
+        __syncthreads();
+        const int gid = blockIdx.x * STFT_WAVES + wv;       // wave of the launch: (channel, segment); segs divides STFT_WAVES
+        const bool idle = gid >= channels * segs;
+        const int ch = idle ? 0 : gid / segs, seg = gid - ch * segs;
+        const int per = (blocks + segs - 1) / segs, u0 = seg * per, u1 = idle ? u0 : ((u0 + per < blocks) ? u0 + per : blocks);
+        float *const xs = in_buf + size_t(ch) * N, *const os = out_buf + size_t(ch) * N;
+        auto at = [](__amdgpu_buffer_rsrc_t r, int lane_off, int row_off) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
+        };
+        // block u of the run as the caller gave it (u = -1: the N samples the object holds)
+        auto block_in = [&](int u) -> __amdgpu_buffer_rsrc_t {
+            return mi::wt_buffer((u < 0) ? xs : const_cast<float *>(tab.src[u]) + size_t(ch) * src_stride, unsigned(N * sizeof(float)));
+        };
+        auto times = [&](v2f (&x)[R], const float4 *t) {
+            #pragma unroll
+            for (int r4 = 0; r4 < R / 4; ++r4)
+            {
+                const float4 g = t[r4 * 64 + lane];
+                x[4 * r4 + 0] = x[4 * r4 + 0] * v2f{g.x, g.x};
+                x[4 * r4 + 1] = x[4 * r4 + 1] * v2f{g.y, g.y};
+                x[4 * r4 + 2] = x[4 * r4 + 2] * v2f{g.z, g.z};
+                x[4 * r4 + 3] = x[4 * r4 + 3] * v2f{g.w, g.w};
+            }
+        };
+        float prev[HALF];                                   // the tail the next frame adds to: sample lane + 64 j
+        {
+            const __amdgpu_buffer_rsrc_t ro = mi::wt_buffer(os, (u0 == 0 && u0 < u1) ? unsigned(N * sizeof(float)) : 0u);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+                prev[j] = at(ro, lane * 4, (HOP + 64 * j) * 4);         // (0 where the segment starts inside the run: out of range)
+        }
+        // half blocks in hand: h0, h1 = block u - 1, h2 = first half of block u (sample lane + 64 j each); the two the next block
+        // needs are asked for before this block's transforms and arrive underneath them (one wave per SIMD: nothing else hides them;
+        // the wave has the registers for it)
+        const int ustart = (u0 == 0) ? 0 : u0 - 1;
+        float h0[HALF], h1[HALF], h2[HALF], n1[HALF], n2[HALF];
+        if (u0 < u1)
+        {
+            const __amdgpu_buffer_rsrc_t ra = block_in(ustart - 1), rb = block_in(ustart);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                h0[j] = at(ra, lane * 4, 256 * j);
+                h1[j] = at(ra, lane * 4, 256 * (j + HALF));
+                h2[j] = at(rb, lane * 4, 256 * j);
+            }
+        }
+        for (int u = ustart; u < u1 && u0 < u1; ++u)
+        {
+            // z[n] = w[n] (A[n] + i B[n]), n = lane + 64 j: A = block u - 1 = [h0 | h1], B = [h1 | h2]
+            v2f x[R];
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                x[j] = v2f{h0[j], h1[j]};
+                x[j + HALF] = v2f{h1[j], h2[j]};
+                h0[j] = h2[j];
+            }
+            {
+                const bool more = u + 1 < u1;
+                const __amdgpu_buffer_rsrc_t ra = mi::wt_buffer(const_cast<float *>(tab.src[more ? u : 0]) + size_t(ch) * src_stride, more ? unsigned(N * sizeof(float)) : 0u);
+                const __amdgpu_buffer_rsrc_t rb = mi::wt_buffer(const_cast<float *>(tab.src[more ? u + 1 : 0]) + size_t(ch) * src_stride, more ? unsigned(N * sizeof(float)) : 0u);
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                {
+                    n1[j] = at(ra, lane * 4, 256 * (j + HALF));
+                    n2[j] = at(rb, lane * 4, 256 * j);
+                }
+            }
+            times(x, win_l);
+            fft4096_t<false>(x, pl, areas[wv], lane);
+            times(x, gain_l);
+            fft4096_t<true>(x, pl, areas[wv], lane);
+            times(x, wout_l);
+            const bool store = u >= u0;                      // (the block in front of the segment: only its tail is wanted)
+            const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(store ? tab.dst[u] + size_t(ch) * dst_stride : nullptr,
+                                                              store ? unsigned(N * sizeof(float)) : 0u);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                const float done_a = x[j].x + prev[j];
+                const float done_b = x[j].y + x[j + HALF].x;
+                prev[j] = x[j + HALF].y;
+                mi::wt_store(rout, lane * 4 + 256 * j, done_a);                 // (dropped by the bounds check where nothing is stored)
+                mi::wt_store(rout, lane * 4 + 256 * (j + HALF), done_b);
+                h1[j] = n1[j];
+                h2[j] = n2[j];
+            }
+        }
+        // The object's state as the call leaves it -- behind a barrier: the wave of the channel's first segment has read the state
+        // the call found.  Output buffer: [the frame finished last | the tail]; input buffer: the last block.
+        __syncthreads();
+        if (u1 == blocks && u0 < u1)
+        {
+            const __amdgpu_buffer_rsrc_t rl = block_in(blocks - 1), rx = mi::wt_buffer(xs, unsigned(N * sizeof(float)));
+            const __amdgpu_buffer_rsrc_t ro = mi::wt_buffer(os, unsigned(N * sizeof(float)));
+            const __amdgpu_buffer_rsrc_t rd = mi::wt_buffer(tab.dst[blocks - 1] + size_t(ch) * dst_stride, unsigned(N * sizeof(float)));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (this wave's own stores of the last block)
+            #pragma unroll
+            for (int j = 0; j < R; ++j)
+                mi::wt_store(rx, lane * 4 + 256 * j, at(rl, lane * 4, 256 * j));
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                mi::wt_store(ro, lane * 4 + 256 * j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 256 * (j + HALF), mi::CPOL_SC1)));
+                mi::wt_store(ro, lane * 4 + 256 * (j + HALF), prev[j]);
+            }
+        }
     }
 
     // CALLBACK path, second half.  The function may have broken the Hermitian symmetry of the spectrum and only the real
@@ -1730,6 +1880,33 @@ int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, co
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
+        // rank 12, a fused mask, blocks of exactly one frame whose buffers all lie apart: a wave per channel and segment of the run
+        // on the wave-resident transform (stft_wave_blocks_kernel: two frames per complex transform)
+        bool waves = masked && b->rank == 12 && count == N && b->mask_stride == 0 && getenv("MI_STFT_LDS") == nullptr;
+        if (waves)
+        {
+            std::vector<std::pair<uintptr_t, uintptr_t>> iv;
+            const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float);
+            for (size_t i = 0; i < run; ++i)
+                iv.emplace_back(reinterpret_cast<uintptr_t>(out[k + i]), reinterpret_cast<uintptr_t>(out[k + i]) + ob);
+            std::sort(iv.begin(), iv.end());
+            for (size_t i = 1; i < run && waves; ++i)
+                waves = iv[i].first >= iv[i - 1].second;     // (outputs against inputs: the run was formed that way)
+        }
+        if (waves)
+        {
+            // segments per channel: a wave per SIMD on the device (1024 waves) if the run is long enough to be cut
+            int want = int((1024 + b->channels - 1) / b->channels), segs = 1;
+            while (segs < STFT_WAVES && 2 * segs <= want && 2 * segs <= int(run) / 4)
+                segs *= 2;
+            const unsigned total = b->channels * unsigned(segs);
+            MI_LAUNCH(stft_wave_blocks_kernel, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(64 * STFT_WAVES), 0, st, ev0, ev1,
+                      b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs);
+            MI_HIP_CHECK(hipGetLastError());
+            b->offset = uint32_t(frame);
+            k += run;
+            continue;
+        }
         #define MI_CALL(LH) \
             if (masked) MI_LAUNCH((stft_stream_blocks_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), true>), dim3(b->channels), dim3(fplan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
                                   b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->mask_stride, b->d_tw, tab, in_stride, out_stride, hops); \
