@@ -924,8 +924,8 @@ def run_spectral_processor(args, mi, torch, dist, rank, world, dev):
     sp.set_rank(rank_fft)
     sp.bind_mask(np.linspace(1.0, 0.25, (1 << (rank_fft - 1)) + 1).astype(np.float32))
     # a buffer of its own for every block of a run of 64 (2 x 1 GiB: nothing comes back out of the 256 MiB last-level cache,
-    # and stft_wave_blocks_kernel -- whose waves take a channel's run in segments side by side -- wants the run's buffers apart)
-    ring = 64
+    # and stft_wave_blocks_kernel -- whose waves may take a channel's run in segments side by side -- wants the run's buffers apart)
+    ring = int(os.environ.get("MI_BENCH_STFT_RING", "64"))
     gen = torch.Generator(device="cpu"); gen.manual_seed(90 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
     yout = torch.empty_like(xin)
@@ -953,10 +953,11 @@ def run_spectral_processor(args, mi, torch, dist, rank, world, dev):
     if rank != 0:
         return None
     return _step_result("spectral_processor", "SpectralProcessor with a gain mask, rank 12, %d channels per GPU, 4096-sample blocks "
-                        "(two hops each: transform, gains, inverse, overlap-add, emission and intake fused)" % C,
+                        "(two hops each: the two frames of a block as ONE 4096-point complex transform pair, a wave per channel; "
+                        "a buffer of its own for every block of a run)" % C,
                         C, n, K, elapsed, world, 8.0,
-                        {"call": "one mi_spectral_bank_process_blocks call per region: runs of 64 blocks ride stft_stream_blocks_kernel, "
-                                 "bit-identical to %d process() calls" % K,
+                        {"call": "one mi_spectral_bank_process_blocks call per region: runs of 64 blocks ride stft_wave_blocks_kernel "
+                                 "(fft_wave.h: within 1e-6 of %d process() calls; MI_STFT_LDS=1: stft_stream_blocks_kernel, their bits)" % K,
                          "per_call": {"what": "the same blocks as separate mi_spectral_bank_process calls (one launch of stft_stream_kernel per block)",
                                       "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),
                                       "whole_step_frac": round(8.0 * C * n / (pc_elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)}})
@@ -974,7 +975,7 @@ def _step_result(name, workload, C, n, steps, elapsed, world, bytes_per_sample, 
     if extra:
         res.update(extra)
     # (the row's dominant launch against the vector unit's issue rate, priced from the whole step: the rows carry no kernel probes)
-    kern = {"crossover": "biquad_stream_chain_kernel", "splitter": "splitter_wave_blocks_kernel", "spectral_processor": "stft_stream_blocks_kernel",
+    kern = {"crossover": "biquad_stream_chain_kernel", "splitter": "splitter_wave_blocks_kernel", "spectral_processor": "stft_wave_blocks_kernel",
             "dynfilter": "dynfilter_kernel"}.get(name)
     side = _issue_side(kern, [elapsed / steps * 1e3], 1) if kern else {}
     if side and (C, n) == {"splitter": (256, 4096)}.get(name, (1024, 4096)):
