@@ -574,13 +574,19 @@ namespace
             }
         }
         // ... and the last block in the delay line (where as many single-block calls would have left it)
+        // (the loads first, then the stores: alternating, every store waits for its load's round trip)
         const float *last = fa.in[fa.blocks - 1] + size_t(ch) * in_stride;
+        constexpr int COPIES = B / 2 / (64 * WAVE_FRAMES);
+        float2 v[COPIES];
         #pragma unroll
-        for (int i = 0; i < B / 2 / (64 * WAVE_FRAMES); ++i)
+        for (int i = 0; i < COPIES; ++i)
+            v[i] = *reinterpret_cast<const float2 *>(last + 2 * (tid + i * 64 * WAVE_FRAMES));
+        #pragma unroll
+        for (int i = 0; i < COPIES; ++i)
         {
             const int n = tid + i * 64 * WAVE_FRAMES;
             const uint32_t w = uint32_t((uint64_t(dl_head) + uint64_t(fa.blocks - 1) * B + 2 * n) % dl_size);
-            *reinterpret_cast<float2 *>(line + w) = *reinterpret_cast<const float2 *>(last + 2 * n);
+            *reinterpret_cast<float2 *>(line + w) = v[i];
         }
     }
 

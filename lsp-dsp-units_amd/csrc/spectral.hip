@@ -491,13 +491,22 @@ namespace
             const __amdgpu_buffer_rsrc_t ro = mi::wt_buffer(os, unsigned(N * sizeof(float)));
             const __amdgpu_buffer_rsrc_t rd = mi::wt_buffer(tab.dst[blocks - 1] + size_t(ch) * dst_stride, unsigned(N * sizeof(float)));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (this wave's own stores of the last block)
+            // (all the loads, then all the stores: alternating, every store waited for its load's round trip -- the compiler keeps
+            // them in program order -- and the 96 of them were 45 us of every launch, three quarters of a one-block call)
+            float t[R], d[HALF];
             #pragma unroll
             for (int j = 0; j < R; ++j)
-                mi::wt_store(rx, lane * 4 + 256 * j, at(rl, lane * 4, 256 * j));
+                t[j] = at(rl, lane * 4, 256 * j);
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+                d[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 256 * (j + HALF), mi::CPOL_SC1));
+            #pragma unroll
+            for (int j = 0; j < R; ++j)
+                mi::wt_store(rx, lane * 4 + 256 * j, t[j]);
             #pragma unroll
             for (int j = 0; j < HALF; ++j)
             {
-                mi::wt_store(ro, lane * 4 + 256 * j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 256 * (j + HALF), mi::CPOL_SC1)));
+                mi::wt_store(ro, lane * 4 + 256 * j, d[j]);
                 mi::wt_store(ro, lane * 4 + 256 * (j + HALF), prev[j]);
             }
         }
@@ -1690,6 +1699,22 @@ int mi_spectral_bank_reset(mi_spectral_bank_t *b, void *stream)
     return MI_OK;
 }
 
+// `run` blocks of N samples at rank 12 with a mask shared by the channels, every buffer apart from every other: stft_wave_blocks_kernel
+static int stft_wave_launch(mi_spectral_bank_t *b, const stft_blocks &tab, size_t run, size_t in_stride, size_t out_stride, hipStream_t st,
+                            hipEvent_t ev0, hipEvent_t ev1)
+{
+    const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
+    // segments per channel: a wave per SIMD on the device (1024 waves) if the run is long enough to be cut
+    int want = int((1024 + b->channels - 1) / b->channels), segs = 1;
+    while (segs < STFT_WAVES && 2 * segs <= want && 2 * segs <= int(run) / 4)
+        segs *= 2;
+    const unsigned total = b->channels * unsigned(segs);
+    MI_LAUNCH(stft_wave_blocks_kernel, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(64 * STFT_WAVES), 0, st, ev0, ev1,
+              b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs);
+    MI_HIP_CHECK(hipGetLastError());
+    return MI_OK;
+}
+
 int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in, size_t count,
                              size_t out_stride, size_t in_stride, void *stream)
 {
@@ -1734,6 +1759,9 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             if (!no_stream && out != nullptr && (plain || masked) && b->rank >= 8 && b->rank <= 13 && count - done >= frame && aligned &&
                 b->d_active == nullptr && apart)
             {
+                // (a call of whole blocks stays on the workgroup kernel: stft_wave_blocks_kernel has 20 us of its own per launch -- its
+                // tables into LDS, a first block with nothing in flight, the state written back -- and a one-block call measured 32.5
+                // against 25 - 30 us; runs of blocks are mi_spectral_bank_process_blocks' business)
                 const int lh = int(b->rank) - 1;
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 mi::take_profile_events(&ev0, &ev1);
@@ -1895,14 +1923,9 @@ int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, co
         }
         if (waves)
         {
-            // segments per channel: a wave per SIMD on the device (1024 waves) if the run is long enough to be cut
-            int want = int((1024 + b->channels - 1) / b->channels), segs = 1;
-            while (segs < STFT_WAVES && 2 * segs <= want && 2 * segs <= int(run) / 4)
-                segs *= 2;
-            const unsigned total = b->channels * unsigned(segs);
-            MI_LAUNCH(stft_wave_blocks_kernel, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(64 * STFT_WAVES), 0, st, ev0, ev1,
-                      b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs);
-            MI_HIP_CHECK(hipGetLastError());
+            const int rw = stft_wave_launch(b, tab, run, in_stride, out_stride, st, ev0, ev1);
+            if (rw != MI_OK)
+                return rw;
             b->offset = uint32_t(frame);
             k += run;
             continue;

@@ -601,19 +601,30 @@ namespace
             const __amdgpu_buffer_rsrc_t rlast = block_in(blocks - 1);
             const __amdgpu_buffer_rsrc_t rx = mi::wt_buffer(in_next + size_t(ch) * in_pitch, unsigned(N * sizeof(float)));
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // (this wave's own stores of the last block)
-            #pragma unroll
-            for (int j = 0; j < R; ++j)
-                mi::wt_store(rx, lane * 4 + 256 * j, at(rlast, lane * 4, 256 * j));
+            // (all the loads of a piece, then its stores: alternating, every store waits for its load's round trip)
+            {
+                float t[R];
+                #pragma unroll
+                for (int j = 0; j < R; ++j)
+                    t[j] = at(rlast, lane * 4, 256 * j);
+                #pragma unroll
+                for (int j = 0; j < R; ++j)
+                    mi::wt_store(rx, lane * 4 + 256 * j, t[j]);
+            }
             #pragma unroll
             for (int b = 0; b < NB; ++b)
             {
                 const __amdgpu_buffer_rsrc_t rl = mi::wt_buffer(wb.line[b] + size_t(ch) * line_pitch, unsigned(N * sizeof(float)));
                 float *const o = tab.out[size_t(blocks - 1) * handlers + wb.handler[b]];
                 const __amdgpu_buffer_rsrc_t rd = mi::wt_buffer(o + size_t(ch) * out_stride, unsigned(N * sizeof(float)));
+                float d[HALF];
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                    d[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 256 * (j + HALF), mi::CPOL_SC1));
                 #pragma unroll
                 for (int j = 0; j < HALF; ++j)
                 {
-                    mi::wt_store(rl, lane * 4 + 256 * j, __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rd, lane * 4, 256 * (j + HALF), mi::CPOL_SC1)));
+                    mi::wt_store(rl, lane * 4 + 256 * j, d[j]);
                     mi::wt_store(rl, lane * 4 + 256 * (j + HALF), tail[b][j]);
                 }
             }
