@@ -872,19 +872,23 @@ def test_spectral_runs_rank_12_on_the_workgroup_kernel_are_the_calls_bits():
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("rank,n_frames,K", [(12, 2, 6), (9, 3, 8), (12, 2, 40)])
-def test_spectral_runs_of_blocks_match_the_oracle(gpu, rank, n_frames, K):
-    """mi_spectral_bank_process_blocks -- K blocks of whole frames as ONE launch of stft_stream_blocks_kernel (what bench.py's
-    SpectralProcessor row times: rank 12, a gain mask, 4096-sample blocks) -- directly against the oracle's SpectralProcessor
-    with a callback that applies the mask, not only bit for bit against the per-block launches."""
+@pytest.mark.parametrize("rank,n_frames,K,shared", [(12, 2, 6, False), (9, 3, 8, False), (12, 2, 40, False),
+                                                     (12, 2, 6, True), (12, 2, 41, True), (12, 2, 64, True)])
+def test_spectral_runs_of_blocks_match_the_oracle(gpu, rank, n_frames, K, shared):
+    """mi_spectral_bank_process_blocks -- K blocks of whole frames as ONE launch (what bench.py's SpectralProcessor row times: rank
+    12, a gain mask, 4096-sample blocks) -- directly against the oracle's SpectralProcessor with a callback that applies the mask,
+    not only against the per-block launches.  shared: ONE row of gains for all channels, as in the bench -- at rank 12 the run rides
+    stft_wave_blocks_kernel (a mask per channel: stft_stream_blocks_kernel)."""
     rng = np.random.default_rng(1300 + rank + K)
     N, H = 1 << rank, 1 << (rank - 1)
     C, n = 3, n_frames * (1 << (rank - 1))
     x = (rng.standard_normal((C, (K + 1) * n)) * 0.25).astype(np.float32)
     masks = rng.uniform(0.0, 2.0, (C, H + 1)).astype(np.float32)
+    if shared:
+        masks[:] = masks[0]
     bank = gpu.SpectralBank(C, rank)
     bank.set_rank(rank)
-    bank.bind_mask(masks)
+    bank.bind_mask(masks[0] if shared else masks)
     ins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, k * n:(k + 1) * n])) for k in range(K + 1)]
     outs = [gpu.DeviceBuffer((C, n)) for _ in range(K + 1)]
     bank.process(outs[0], ins[0], n)                         # the steady state: a frame is in hand
