@@ -355,7 +355,7 @@ namespace
         stft_stream_body<LOGH, MASKED, true>(in_buf, out_buf, wnd_in, wnd_out, mask, mask_stride, tw, nullptr, src_stride, nullptr, dst_stride, hops, &tab);
     }
 
-    // ---- runs of 4096-sample blocks at rank 12 with a fused mask shared by the channels, on the wave-resident transform (fft_wave.h) --
+    // ---- runs of 4096-sample blocks at rank 12 with a fused mask, on the wave-resident transform (fft_wave.h) -------------------------
     // stft_stream_blocks_kernel runs at the rate of its transforms through LDS (0.24 of the HBM roofline, 0.40 of the issue rate).
     // Here a WAVE owns a channel's consecutive blocks and takes the two frames of a block -- frame 2u = block u - 1, frame 2u + 1
     // = [second half of block u - 1 | first half of block u] -- as ONE complex sequence z = w (A + i B): a real, symmetric gain
@@ -370,10 +370,14 @@ namespace
     // the block in front of it (without storing) for the tail it starts from.
     // The same sums through another transform: within 1e-6 of stft_stream_blocks_kernel, not its bits.  The host sends a run this way
     // only if no buffer of the run overlaps another (the segments run side by side).
+    // SHARED: one row of gains for every channel -- in LDS; otherwise a row per channel, which the wave asks for (64 loads of its
+    // own channel's row, the gain of bin k at min(k, N - k)) in front of the forward transform and finds in registers behind it.
     constexpr int STFT_WAVES = 4;
+    template <bool SHARED>
     __global__ __launch_bounds__(64 * STFT_WAVES, 1)
     void stft_wave_blocks_kernel(float *in_buf, float *out_buf, const float *__restrict__ wnd_in /* or NULL: none */,
-                                 const float *__restrict__ wnd_out, const float *__restrict__ mask /* one row of N / 2 + 1 gains */,
+                                 const float *__restrict__ wnd_out, const float *__restrict__ mask /* rows of N / 2 + 1 gains */,
+                                 size_t mask_stride /* 0 (SHARED) or the rows' pitch */,
                                  const float2 *__restrict__ tw, const stft_blocks tab, size_t src_stride, size_t dst_stride,
                                  int blocks, int channels, int segs)
     {
@@ -382,7 +386,7 @@ namespace
         __shared__ float areas[STFT_WAVES][AREA];
         __shared__ float2 pl[16 * R];
         // entry lane + 64 r of a table at float4 cell [r / 4][lane], component r % 4
-        __shared__ float4 win_l[N / 4], wout_l[N / 4], gain_l[N / 4];
+        __shared__ float4 win_l[N / 4], wout_l[N / 4], gain_l[SHARED ? N / 4 : 1];
         const int tid = threadIdx.x, lane = tid & 63;
         const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
         fill_table_pq(pl, tw, tid, 64 * STFT_WAVES);
@@ -391,7 +395,8 @@ namespace
             const int l = i & 63, r = i >> 6, cell = ((r >> 2) * 64 + l) * 4 + (r & 3);
             reinterpret_cast<float *>(win_l)[cell] = (wnd_in != nullptr) ? wnd_in[i] : 1.0f;
             reinterpret_cast<float *>(wout_l)[cell] = wnd_out[i] * (1.0f / float(N));    // (the transform pair's 1 / N rides on the window)
-            reinterpret_cast<float *>(gain_l)[cell] = mask[(i <= HOP) ? i : N - i];       // the N / 2 + 1 gains act on k and N - k alike
+            if (SHARED)
+                reinterpret_cast<float *>(gain_l)[cell] = mask[(i <= HOP) ? i : N - i];   // the N / 2 + 1 gains act on k and N - k alike
         }
         __syncthreads();
         const int gid = blockIdx.x * STFT_WAVES + wv;       // wave of the launch: (channel, segment); segs divides STFT_WAVES
@@ -463,8 +468,23 @@ namespace
                 }
             }
             times(x, win_l);
-            fft4096_t<false>(x, pl, areas[wv], lane);
-            times(x, gain_l);
+            if constexpr (SHARED)
+            {
+                fft4096_t<false>(x, pl, areas[wv], lane);
+                times(x, gain_l);
+            }
+            else
+            {
+                const __amdgpu_buffer_rsrc_t rmk = mi::wt_buffer(const_cast<float *>(mask) + size_t(ch) * mask_stride, unsigned((HOP + 1) * sizeof(float)));
+                float g[R];
+                #pragma unroll
+                for (int r = 0; r < R; ++r)                 // bin lane + 64 r: row entry lane + 64 r, or 64 (64 - r) - lane behind N / 2
+                    g[r] = (r < HALF) ? at(rmk, lane * 4, 256 * r) : at(rmk, (64 - lane) * 4, 256 * (R - 1 - r));
+                fft4096_t<false>(x, pl, areas[wv], lane);
+                #pragma unroll
+                for (int r = 0; r < R; ++r)
+                    x[r] = x[r] * v2f{g[r], g[r]};
+            }
             fft4096_t<true>(x, pl, areas[wv], lane);
             times(x, wout_l);
             const bool store = u >= u0;                      // (the block in front of the segment: only its tail is wanted)
@@ -1709,8 +1729,12 @@ static int stft_wave_launch(mi_spectral_bank_t *b, const stft_blocks &tab, size_
     while (segs < STFT_WAVES && 2 * segs <= want && 2 * segs <= int(run) / 4)
         segs *= 2;
     const unsigned total = b->channels * unsigned(segs);
-    MI_LAUNCH(stft_wave_blocks_kernel, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(64 * STFT_WAVES), 0, st, ev0, ev1,
-              b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs);
+    if (b->mask_stride == 0)
+        MI_LAUNCH(stft_wave_blocks_kernel<true>, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(64 * STFT_WAVES), 0, st, ev0, ev1,
+                  b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, size_t(0), b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs);
+    else
+        MI_LAUNCH(stft_wave_blocks_kernel<false>, dim3((total + STFT_WAVES - 1) / STFT_WAVES), dim3(64 * STFT_WAVES), 0, st, ev0, ev1,
+                  b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->mask_stride, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs);
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
 }
@@ -1910,7 +1934,7 @@ int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, co
         const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
         // rank 12, a fused mask, blocks of exactly one frame whose buffers all lie apart: a wave per channel and segment of the run
         // on the wave-resident transform (stft_wave_blocks_kernel: two frames per complex transform)
-        bool waves = masked && b->rank == 12 && count == N && b->mask_stride == 0 && getenv("MI_STFT_LDS") == nullptr;
+        bool waves = masked && b->rank == 12 && count == N && getenv("MI_STFT_LDS") == nullptr;
         if (waves)
         {
             std::vector<std::pair<uintptr_t, uintptr_t>> iv;
