@@ -1783,9 +1783,34 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             if (!no_stream && out != nullptr && (plain || masked) && b->rank >= 8 && b->rank <= 13 && count - done >= frame && aligned &&
                 b->d_active == nullptr && apart)
             {
-                // (a call of whole blocks stays on the workgroup kernel: stft_wave_blocks_kernel has 20 us of its own per launch -- its
-                // tables into LDS, a first block with nothing in flight, the state written back -- and a one-block call measured 32.5
-                // against 25 - 30 us; runs of blocks are mi_spectral_bank_process_blocks' business)
+                // A call of EIGHT or more whole blocks of N samples at rank 12 with a mask: a wave per channel (and segment) on the
+                // wave-resident transform, the blocks being column slices of the caller's two buffers, which lie apart
+                // (stft_wave_blocks_kernel: 14.6 us per block at eight blocks, 12 at 64, against the workgroup kernel's 17 - 19).
+                // Shorter calls stay where they are: the kernel has 20 us of its own per launch -- its tables into LDS, a first block
+                // with nothing in flight, the state written back -- and a one-block call measured 32.5 against 25 - 30 us.
+                if (masked && b->rank == 12 && (count - done) % N == 0 && (count - done) / N >= 8 && getenv("MI_STFT_LDS") == nullptr &&
+                    getenv("MI_SPECTRAL_ONE_HOP") == nullptr)
+                {
+                    while (done < count)
+                    {
+                        const size_t run = std::min<size_t>((count - done) / N, size_t(STFT_BLOCKS_MAX));
+                        stft_blocks tab;
+                        tab.per = 2;
+                        for (size_t q = 0; q < run; ++q)
+                        {
+                            tab.src[q] = in + done + q * N;
+                            tab.dst[q] = out + done + q * N;
+                        }
+                        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                        mi::take_profile_events(&ev0, &ev1);
+                        const int r = stft_wave_launch(b, tab, run, in_stride, out_stride, st, ev0, ev1);
+                        if (r != MI_OK)
+                            return r;
+                        done += run * N;
+                    }
+                    b->offset = uint32_t(frame);
+                    continue;
+                }
                 const int lh = int(b->rank) - 1;
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 mi::take_profile_events(&ev0, &ev1);

@@ -1289,6 +1289,9 @@ static int splitter_listeners(mi_splitter_bank_t *b, float *const *outs, hipStre
     return MI_OK;
 }
 
+static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, float *const *outs, size_t run, size_t count,
+                             size_t in_stride, size_t out_stride, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
+
 int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const float *in, size_t count, size_t out_stride,
                              size_t in_stride, void *stream)
 {
@@ -1337,6 +1340,43 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
             const bool big = b->rank > 14;
             const bool fused = !big && !callbacks && (count - done >= frame);
             const float *src = (in != nullptr) ? in + done : nullptr;
+            // EIGHT or more whole blocks of N samples follow in this call (rank 12, listening masks shared by the channels): a wave
+            // per channel and segment on the wave-resident transform, the blocks being column slices of the caller's buffers
+            // (splitter_wave_blocks_kernel; shorter calls stay on the workgroup kernels: the launch has 25 us of its own)
+            if (fused && src != nullptr && outs != nullptr && b->rank == 12 && (count - done) % N == 0 && (count - done) / N >= 8 &&
+                b->handlers <= OUTS_BY_VALUE && splitter_hops_fuse(b, src, in_stride) && (out_stride % 2) == 0)
+            {
+                bool went = true;
+                while (went && done < count)
+                {
+                    const size_t cap = std::min<size_t>(SPLIT_BLOCKS_MAX, SPLIT_PTRS_MAX / b->handlers);
+                    const size_t run = std::min<size_t>((count - done) / N, cap);
+                    split_blocks tab;
+                    tab.per = 2;
+                    for (size_t q = 0; q < run; ++q)
+                    {
+                        tab.src[q] = in + done + q * N;
+                        for (uint32_t i = 0; i < b->handlers; ++i)
+                            tab.out[q * b->handlers + i] = (b->h[i].mode == H_OFF || outs[i] == nullptr) ? nullptr : outs[i] + done + q * N;
+                    }
+                    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+                    mi::take_profile_events(&ev0, &ev1);
+                    const int rw = splitter_wave_try(b, tab, nullptr, run, N, in_stride, out_stride, st, ev0, ev1);
+                    if (rw < 0)
+                        return rw;
+                    went = rw == 1;
+                    if (went)
+                    {
+                        std::swap(b->d_in, b->d_in2);
+                        b->fill = frame;
+                        done += run * N;
+                    }
+                }
+                if (done >= count)
+                    return MI_OK;
+                if (went)
+                    continue;
+            }
             const uint32_t hops = (fused && count - done >= 2 * size_t(frame) && splitter_hops_fuse(b, src, in_stride))
                                 ? uint32_t(std::min<size_t>((count - done) / frame, 1u << 20)) : 1;
             const int r = big   ? splitter_hop_big(b, st)
@@ -1362,6 +1402,68 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
         done += n;
     }
     return MI_OK;
+}
+
+// A run of `run` blocks of `count` samples (tab: their input rows and the handlers' output rows, outs: the same output rows as
+// [block * handlers + handler]) on splitter_wave_blocks_kernel if it qualifies: rank 12, blocks of exactly one frame, one to four
+// listening masks shared by the channels, every output buffer of the run apart from every other (the segments of a channel's run
+// go side by side).  Returns 1 if the run went out this way (the caller swaps the analysis buffers), 0 if it does not qualify.
+static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, float *const *outs, size_t run, size_t count,
+                             size_t in_stride, size_t out_stride, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
+{
+    const uint32_t nh = b->handlers;
+    wave_bands wb{};
+    uint32_t nb = 0;
+    bool waves = b->rank == 12 && b->chunk_rank == b->rank && count == (size_t(1) << b->rank) && getenv("MI_SPLITTER_LDS") == nullptr;
+    for (uint32_t i = 0; i < nh && waves; ++i)
+    {
+        if (!b->has_sink[i])
+            continue;
+        if (b->h[i].mode != H_MASK || b->h[i].mask_stride != 0 || nb == 4)
+        {
+            waves = false;
+            break;
+        }
+        wb.gain[nb] = b->h[i].d_mask;
+        wb.line[nb] = b->d_lines + size_t(i) * b->channels * b->pitch;
+        wb.handler[nb] = i;
+        ++nb;
+    }
+    waves = waves && nb >= 1;
+    if (waves)
+    {
+        std::vector<std::pair<uintptr_t, uintptr_t>> iv;
+        const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float);
+        for (size_t q = 0; q < run; ++q)
+            for (uint32_t i = 0; i < nb; ++i)
+            {
+                const uintptr_t p = reinterpret_cast<uintptr_t>(tab.out[q * nh + wb.handler[i]]);
+                iv.emplace_back(p, p + ob);
+            }
+        std::sort(iv.begin(), iv.end());
+        for (size_t i = 1; i < iv.size() && waves; ++i)
+            waves = iv[i].first >= iv[i - 1].second;    // (outputs against inputs: the run was formed that way)
+    }
+    (void)outs;
+    if (!waves)
+        return 0;
+    const int want = int((1024 + b->channels - 1) / b->channels);
+    int segs = 1;
+    while (segs < SPW && 2 * segs <= want && 2 * segs <= int(run) / 4)
+        segs *= 2;
+    const dim3 grid((b->channels * unsigned(segs) + SPW - 1) / SPW);
+    #define MI_WAVE(NB_) MI_LAUNCH((splitter_wave_blocks_kernel<NB_>), grid, dim3(64 * SPW), 0, st, ev0, ev1, b->d_in, b->d_in2, b->pitch, \
+                                   b->pitch, wb, nh, b->d_wnd, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs)
+    switch (nb)
+    {
+        case 1:  { MI_WAVE(1); break; }
+        case 2:  { MI_WAVE(2); break; }
+        case 3:  { MI_WAVE(3); break; }
+        default: { MI_WAVE(4); break; }
+    }
+    #undef MI_WAVE
+    MI_HIP_CHECK(hipGetLastError());
+    return 1;
 }
 
 // `blocks` consecutive process() calls in one C call (SpectralSplitter.cpp:295-361 per block): block k reads in[k] and hands
@@ -1450,56 +1552,11 @@ int mi_splitter_bank_process_blocks(mi_splitter_bank_t *b, float *const *outs, c
         // rank 12, blocks of exactly one frame, up to four listening masks shared by the channels, every buffer of the run apart from
         // every other: a wave per channel and segment of the run on the wave-resident transform (splitter_wave_blocks_kernel)
         {
-            wave_bands wb{};
-            uint32_t nb = 0;
-            bool waves = b->rank == 12 && count == (size_t(1) << b->rank) && getenv("MI_SPLITTER_LDS") == nullptr;
-            for (uint32_t i = 0; i < nh && waves; ++i)
+            const int rw = splitter_wave_try(b, tab, outs + k * nh, run, count, in_stride, out_stride, st, ev0, ev1);
+            if (rw < 0)
+                return rw;
+            if (rw == 1)
             {
-                if (!b->has_sink[i])
-                    continue;
-                if (b->h[i].mode != H_MASK || b->h[i].mask_stride != 0 || nb == 4)
-                {
-                    waves = false;
-                    break;
-                }
-                wb.gain[nb] = b->h[i].d_mask;
-                wb.line[nb] = b->d_lines + size_t(i) * b->channels * b->pitch;
-                wb.handler[nb] = i;
-                ++nb;
-            }
-            waves = waves && nb >= 1;
-            if (waves)
-            {
-                std::vector<std::pair<uintptr_t, uintptr_t>> iv;
-                const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float);
-                for (size_t q = 0; q < run; ++q)
-                    for (uint32_t i = 0; i < nb; ++i)
-                    {
-                        const uintptr_t p = reinterpret_cast<uintptr_t>(outs[(k + q) * nh + wb.handler[i]]);
-                        iv.emplace_back(p, p + ob);
-                    }
-                std::sort(iv.begin(), iv.end());
-                for (size_t i = 1; i < iv.size() && waves; ++i)
-                    waves = iv[i].first >= iv[i - 1].second;    // (outputs against inputs: the run was formed that way)
-            }
-            if (waves)
-            {
-                const int want = int((1024 + b->channels - 1) / b->channels);
-                int segs = 1;
-                while (segs < SPW && 2 * segs <= want && 2 * segs <= int(run) / 4)
-                    segs *= 2;
-                const dim3 grid((b->channels * unsigned(segs) + SPW - 1) / SPW);
-                #define MI_WAVE(NB_) MI_LAUNCH((splitter_wave_blocks_kernel<NB_>), grid, dim3(64 * SPW), 0, st, ev0, ev1, b->d_in, b->d_in2, b->pitch, \
-                                               b->pitch, wb, nh, b->d_wnd, b->d_tw, tab, in_stride, out_stride, int(run), int(b->channels), segs)
-                switch (nb)
-                {
-                    case 1:  { MI_WAVE(1); break; }
-                    case 2:  { MI_WAVE(2); break; }
-                    case 3:  { MI_WAVE(3); break; }
-                    default: { MI_WAVE(4); break; }
-                }
-                #undef MI_WAVE
-                MI_HIP_CHECK(hipGetLastError());
                 std::swap(b->d_in, b->d_in2);
                 b->fill = frame;
                 k += run;

@@ -859,6 +859,39 @@ def test_spectral_process_blocks_equal_block_by_block(gpu, rank, masked, n_frame
         bank.close()
 
 
+def test_spectral_long_call_at_rank_12_rides_the_wave_kernel(gpu):
+    """A process() call of eight or more whole blocks at rank 12 with a mask and separate buffers goes out on stft_wave_blocks_kernel
+    (the blocks as column slices of the caller's buffers, a channel's run in segments): against the oracle, and the state it leaves
+    behind serves an odd-sized call; seven blocks stay on the workgroup kernel."""
+    rng = np.random.default_rng(777)
+    C, rank = 4, 12
+    N, H = 1 << rank, 1 << (rank - 1)
+    sizes = [N, 19 * N, 300, 7 * N, 8 * N]
+    x = (rng.standard_normal((C, sum(sizes))) * 0.25).astype(np.float32)
+    mask = rng.uniform(0.0, 2.0, H + 1).astype(np.float32)
+    full = np.concatenate([mask, mask[H - 1:0:-1]]).astype(np.float32)
+
+    def cb(spec, r):
+        out = spec.copy(); out[0::2] *= full; out[1::2] *= full
+        return out
+    bank = gpu.SpectralBank(C, rank)
+    bank.set_rank(rank)
+    bank.bind_mask(mask)
+    ys, pos = [], 0
+    for n in sizes:
+        d, o = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos:pos + n])), gpu.DeviceBuffer((C, n))
+        bank.process(o, d, n)
+        ys.append(o.download())
+        pos += n
+    y = np.concatenate(ys, axis=1)
+    bank.close()
+    for c in range(C):
+        p = sp.SpectralProcessor(rank); p.set_rank(rank); p.bind(cb)
+        ref = p.process(x[c])
+        peak = max(float(np.abs(ref).max()), 1e-30)
+        assert float(np.abs(y[c] - ref).max()) <= TOL * peak, (c, float(np.abs(y[c] - ref).max()) / peak)
+
+
 def test_spectral_runs_rank_12_on_the_workgroup_kernel_are_the_calls_bits():
     """MI_STFT_LDS=1: runs of 4096-sample blocks at rank 12 on stft_stream_blocks_kernel<11> (what runs whose buffers overlap take
     in any case) -- the bits of block-by-block calls."""

@@ -492,6 +492,38 @@ def test_process_blocks_equal_block_by_block(gpu, rank, bands, n_frames, K, list
     a.close(); b.close()
 
 
+def test_long_call_at_rank_12_rides_the_wave_kernel(gpu):
+    """A process() call of eight or more whole blocks at rank 12 (listening masks shared by the channels, the bands in buffers of
+    their own) goes out on splitter_wave_blocks_kernel -- the blocks as column slices of the caller's buffers, a channel's run in
+    segments -- against the oracle, every band; the state it leaves serves an odd-sized call and a shorter one (workgroup kernels)."""
+    rng = np.random.default_rng(4242)
+    C, rank, bands = 3, 12, 3
+    N = 1 << rank
+    sizes = [N, 17 * N, 300, 5 * N, 9 * N]
+    x = (rng.standard_normal((C, sum(sizes))) * 0.25).astype(np.float32)
+    masks = [np.clip(rng.uniform(0.0, 1.2, N), 0.0, 1.0).astype(np.float32) for _ in range(bands)]
+    want = _oracle_run(rank, rank, 0.0, masks, x, sizes)
+    bank = gpu.SplitterBank(C, rank, bands)
+    bank.set_rank(rank); bank.set_chunk_rank(rank); bank.set_phase(0.0)
+    for i in range(bands):
+        bank.bind_mask(i, masks[i])
+    got, pos = [[] for _ in range(bands)], 0
+    for n in sizes:
+        d = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos:pos + n]))
+        outs = [gpu.DeviceBuffer((C, n)) for _ in range(bands)]
+        bank.process(outs, d, n)
+        for i in range(bands):
+            got[i].append(outs[i].download())
+        pos += n
+    bank.close()
+    peak = float(np.abs(x).max())
+    for i in range(bands):
+        y = np.concatenate(got[i], axis=1)
+        err = float(np.abs(y - want[i]).max())
+        assert float(np.abs(want[i]).max()) > 0.01
+        assert err <= TOL * max(peak, float(np.abs(want[i]).max())), (i, err)
+
+
 def test_process_blocks_rank_12_on_the_workgroup_kernel_are_the_calls_bits():
     """MI_SPLITTER_LDS=1: runs of 4096-sample blocks at rank 12 on splitter_hops_blocks_kernel<11> -- the bits of block-by-block calls."""
     import subprocess
