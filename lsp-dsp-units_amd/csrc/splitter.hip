@@ -1289,7 +1289,7 @@ static int splitter_listeners(mi_splitter_bank_t *b, float *const *outs, hipStre
     return MI_OK;
 }
 
-static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, float *const *outs, size_t run, size_t count,
+static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, size_t run, size_t count,
                              size_t in_stride, size_t out_stride, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1);
 
 int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const float *in, size_t count, size_t out_stride,
@@ -1361,7 +1361,7 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
                     }
                     hipEvent_t ev0 = nullptr, ev1 = nullptr;
                     mi::take_profile_events(&ev0, &ev1);
-                    const int rw = splitter_wave_try(b, tab, nullptr, run, N, in_stride, out_stride, st, ev0, ev1);
+                    const int rw = splitter_wave_try(b, tab, run, N, in_stride, out_stride, st, ev0, ev1);
                     if (rw < 0)
                         return rw;
                     went = rw == 1;
@@ -1404,11 +1404,11 @@ int mi_splitter_bank_process(mi_splitter_bank_t *b, float *const *outs, const fl
     return MI_OK;
 }
 
-// A run of `run` blocks of `count` samples (tab: their input rows and the handlers' output rows, outs: the same output rows as
-// [block * handlers + handler]) on splitter_wave_blocks_kernel if it qualifies: rank 12, blocks of exactly one frame, one to four
+// A run of `run` blocks of `count` samples (tab: their input rows and the handlers' output rows) on splitter_wave_blocks_kernel if it
+// qualifies: rank 12, blocks of exactly one frame, one to four
 // listening masks shared by the channels, every output buffer of the run apart from every other (the segments of a channel's run
 // go side by side).  Returns 1 if the run went out this way (the caller swaps the analysis buffers), 0 if it does not qualify.
-static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, float *const *outs, size_t run, size_t count,
+static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, size_t run, size_t count,
                              size_t in_stride, size_t out_stride, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1)
 {
     const uint32_t nh = b->handlers;
@@ -1444,7 +1444,6 @@ static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, flo
         for (size_t i = 1; i < iv.size() && waves; ++i)
             waves = iv[i].first >= iv[i - 1].second;    // (outputs against inputs: the run was formed that way)
     }
-    (void)outs;
     if (!waves)
         return 0;
     const int want = int((1024 + b->channels - 1) / b->channels);
@@ -1552,7 +1551,7 @@ int mi_splitter_bank_process_blocks(mi_splitter_bank_t *b, float *const *outs, c
         // rank 12, blocks of exactly one frame, up to four listening masks shared by the channels, every buffer of the run apart from
         // every other: a wave per channel and segment of the run on the wave-resident transform (splitter_wave_blocks_kernel)
         {
-            const int rw = splitter_wave_try(b, tab, outs + k * nh, run, count, in_stride, out_stride, st, ev0, ev1);
+            const int rw = splitter_wave_try(b, tab, run, count, in_stride, out_stride, st, ev0, ev1);
             if (rw < 0)
                 return rw;
             if (rw == 1)
