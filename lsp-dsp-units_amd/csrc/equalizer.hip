@@ -581,6 +581,8 @@ int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *b, float *const *out, 
             return r;
         if (b->mode == MI_EQM_IIR)                          // (reconfigure settles a pending change of mode)
             return mi_biquad_bank_process_blocks(b->biquads, out, in, blocks, samples, out_stride, in_stride, stream);
+        if (b->mode == MI_EQM_SPM)                          // the spectral bank's own runs of blocks (spectral.hip)
+            return mi_spectral_bank_process_blocks(b->spm, out, in, blocks, samples, out_stride, in_stride, stream);
     }
     size_t k = 0;
     while (k < blocks)

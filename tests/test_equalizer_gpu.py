@@ -431,6 +431,47 @@ def test_c4_full_size(gpu):
     assert np.all(errs <= TOL), (int(np.argmax(errs)), float(errs.max()))
 
 
+@pytest.mark.parametrize("rank,K", [(12, 9), (10, 6)])
+def test_runs_of_blocks_in_spm_mode_ride_the_spectral_bank(gpu, rank, K):
+    """EQM_SPM: mi_equalizer_bank_process_blocks hands the run to the spectral bank (mi_spectral_bank_process_blocks: one launch for
+    the run; rank 12: stft_wave_blocks_kernel with a row of gains per channel) -- against the oracle, and the state it leaves
+    serves the call behind it."""
+    rng = np.random.default_rng(660 + rank)
+    C, nfilt = 3, 5
+    N = 1 << rank
+    x = (rng.standard_normal((C, N * (K + 2) + 300)) * 0.25).astype(np.float32)
+    curves = [[(fd.FLT_BT_RLC_BELL, 1, float(f), float(f), float(g), 2.0)
+               for f, g in zip(np.exp(rng.uniform(np.log(100), np.log(15000), nfilt)), 10 ** (rng.uniform(-9, 9, nfilt) / 20))] for _ in range(C)]
+    eq = gpu.EqualizerBank(C, nfilt, rank)
+    eq.set_mode(oe.SPM)
+    eq.set_sample_rate(48000)
+    refs = []
+    for c in range(C):
+        o = oe.Equalizer(nfilt, rank)
+        o.set_sample_rate(48000)
+        o.set_mode(oe.SPM)
+        for i, p in enumerate(curves[c]):
+            eq.set_params(i, *p, channel=c)
+            o.set_params(i, fd.Params(*p))
+        refs.append(o)
+    ys, pos = [], 0
+    d0, o0 = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, :N])), gpu.DeviceBuffer((C, N))
+    eq.process(o0, d0, N); ys.append(o0.download()); pos = N
+    ins = [gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos + k * N:pos + (k + 1) * N])) for k in range(K)]
+    outs = [gpu.DeviceBuffer((C, N)) for _ in range(K)]
+    eq.process_blocks(outs, ins, N)
+    ys.extend(o.download() for o in outs); pos += K * N
+    for n in (300, N):
+        d, o = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos:pos + n])), gpu.DeviceBuffer((C, n))
+        eq.process(o, d, n); ys.append(o.download()); pos += n
+    y = np.concatenate(ys, axis=1)
+    eq.close()
+    for c in range(C):
+        ref = refs[c].process(x[c, :pos])
+        peak = max(float(np.abs(ref).max()), 0.25)
+        assert float(np.abs(y[c] - ref).max()) <= TOL * peak, (rank, c, float(np.abs(y[c] - ref).max()) / peak)
+
+
 def test_runs_of_blocks_in_iir_mode_ride_the_biquad_stream(gpu):
     """EQM_IIR: mi_equalizer_bank_process_blocks hands the run to the cascade's bank (mi_biquad_bank_process_blocks: one launch
     for the blocks) -- the bits of block-by-block calls, the state left behind serves the next call."""
