@@ -32,6 +32,10 @@ namespace
     // rounded sqrtf the compiler builds around it (a dozen instructions more per value: a quarter of the analysis kernels'
     // arithmetic) -- 6e-8 of the value against the 1e-5 the results are held to.
     __device__ __forceinline__ float mag_root(float x) { return __builtin_amdgcn_sqrtf(x); }
+    // mix2(vAmp, |X|, 1 - tau, tau) (Analyzer.cpp:361): two products and their sum, each rounded -- the oracle's arithmetic, and
+    // ONE form for every kernel that smooths (a contraction chosen per kernel by the compiler would make the bits of a run of
+    // strobes depend on the launch that took them)
+    __device__ __forceinline__ float mix2(float a, float m, float keep, float tau) { return __fadd_rn(__fmul_rn(a, keep), __fmul_rn(m, tau)); }
 
     using namespace mi_fft;
     // radix-16 core (fft16.h) for 1024 .. 8192-point transforms, radix-8 core (fft_device.h) below that
@@ -741,8 +745,13 @@ namespace
     __device__ unsigned long long g_an_probe[4096 * 8];
     #define MI_APROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) \
         g_an_probe[blockIdx.x * 8 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+    // ... and of lane 0 of every wave of analyzer_frames_wave_kernel (tests/experiments/analyzer_wave_probe.hip)
+    __device__ unsigned long long g_anw_probe[256 * 8 * 32];
+    #define MI_WPROBE(slot) do { __builtin_amdgcn_sched_barrier(0); if ((threadIdx.x & 63) == 0 && blockIdx.x < 256 && (slot) < 32) \
+        g_anw_probe[(blockIdx.x * 8 + (threadIdx.x >> 6)) * 32 + (slot)] = wall_clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
     #define MI_APROBE(slot) do { } while (0)
+    #define MI_WPROBE(slot) do { } while (0)
 #endif
 
     // Per-bin reduction over channels (the C5 callback), in one launch and in an order that does not depend on the launch
@@ -992,10 +1001,10 @@ namespace
                 break;
             const float2 v = buf[k];
             const float mag = (k == 0) ? fabsf(v.x) : mag_root(v.x * v.x + v.y * v.y);
-            mi::wt_store(ramp, 4 * k, aold[i] * keep + mag * tau);
+            mi::wt_store(ramp, 4 * k, mix2(aold[i], mag, keep, tau));
         }
         if (tid == 0)
-            mi::wt_store(ramp, 4 * H, aold_h * keep + fabsf(buf[0].y) * tau);
+            mi::wt_store(ramp, 4 * H, mix2(aold_h, fabsf(buf[0].y), keep, tau));
         MI_APROBE(5);
         // ring ingest: cells head .. head + ingest_n - 1 (mod size), none of them inside a window read above
         if (ingest_n > 0)
@@ -1093,25 +1102,30 @@ namespace
 
     // ---- several strobes of the analyzer in ONE launch (mi_analyzer_bank_process_reduce_frames) --------------------------------
     // The C5 shape: a strobe per call, the hop half a frame (period = N / 2), no user delays.  The frame of strobe f is then
-    // the two hops BEFORE the call's block f -- hops the launch has just had in its hands -- so a channel's workgroup walks the
-    // frames with the window's halves in registers (the second half of frame f is the first half of frame f + 1), the spectrum
-    // being smoothed in registers (no read of vAmp per strobe), the next block's samples asked for before the transform; what
-    // it leaves behind is what `frames` launches of analyzer_kernel leave: every hop in the ring at its place, every strobe's
-    // spectrum in the plane it would have been written to (rows[f]: the per-bin reductions read them).  Same window products,
-    // same transform, same magnitude and mix2 per strobe: bit-identical.
+    // the two hops BEFORE the call's block f -- hops the launch has just had in its hands.  Round 6: the launch leaves the RAW
+    // magnitudes of strobe f in plane rows[f]; the smoothing vAmp = mix2(vAmp, |X|, 1 - tau, tau) (Analyzer.cpp:359-361) -- an
+    // elementwise first-order recurrence over the strobes -- is walked by the reduction launch that reads every plane anyway
+    // (bin_smooth_reduce_kernel), in the reference's order.  With that the strobes of a channel owe each other nothing:
+    // channels x frames independent units instead of `channels` sequential walks.  What the launch leaves in the ring is what
+    // `frames` launches of analyzer_kernel leave: every hop at its place.  Frozen and inactive channels only take their samples
+    // (their rows are the reduction's business: kept / zero, Analyzer.cpp:334,363-364).
     constexpr int AN_FRAMES_MAX = 16;
     struct an_frames_args
     {
         int             frames;
         const float    *in[AN_FRAMES_MAX];      // block f of the call: ingested at strobe f
-        float          *rows[AN_FRAMES_MAX];    // plane that takes vAmp after strobe f
+        float          *rows[AN_FRAMES_MAX];    // plane that takes |X| of strobe f (raw: not smoothed)
     };
 
+    // Workgroup form (transforms of 1024 .. 8192 points other than 4096: the wave form below takes rank 12): a channel's
+    // workgroup walks the frames with the window's halves in registers (the second half of frame f is the first half of
+    // frame f + 1), the next block's samples asked for before the transform.  Same window products, same transform, same
+    // magnitude per strobe as analyzer_kernel: with the reduction's mix2 the bits of frame-by-frame calls.
     template <int LOGH>
     __global__ __launch_bounds__(fplan<LOGH>::T, (fplan<LOGH>::T <= 256) ? 4 : 2)   // four workgroups of 256 threads per CU: 1024 channels in one round
     void analyzer_frames_kernel(const an_frames_args fa, size_t in_stride, bool aligned, float *ring, uint32_t buf_size, uint32_t head,
-                                const uint8_t *__restrict__ flags, const float *__restrict__ wnd, const float *__restrict__ amp_old,
-                                uint32_t amp_stride, float tau, const float2 *__restrict__ tw)
+                                const uint8_t *__restrict__ flags, const float *__restrict__ wnd, uint32_t amp_stride,
+                                const float2 *__restrict__ tw)
     {
         using PL = fplan<LOGH>;
         constexpr int H = PL::N, T = PL::T, N = 2 * H, KPT = H / T, HALF = KPT / 2, HOP = H;      // HOP samples = HOP / 2 pairs
@@ -1123,7 +1137,6 @@ namespace
         typename PL::real rf;
         rf.load(tw, TWN, tid);
         const uint8_t fl = flags[ch];                       // bit0: active, bit1: frozen
-        const float *a = amp_old + size_t(ch) * amp_stride;
         float *rbw = ring + size_t(ch) * buf_size;
         const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
         // block f's samples of this thread: pairs p = tid + j T of the hop
@@ -1162,14 +1175,12 @@ namespace
         };
         if ((fl & 2) || !(fl & 1))
         {
-            // frozen: vAmp stays (Analyzer.cpp:334); inactive: vAmp = 0 (:363-364) -- strobe after strobe; the samples go in all the same
+            // frozen: vAmp stays (Analyzer.cpp:334); inactive: vAmp = 0 (:363-364) -- the reduction launch sees to that; the
+            // samples go in all the same
             for (int f = 0; f < fa.frames; ++f)
             {
                 float2 v[HALF];
                 load_hop(f, v);
-                const __amdgpu_buffer_rsrc_t rrow = mi::wt_buffer(fa.rows[f] + size_t(ch) * amp_stride, unsigned((H + 1) * sizeof(float)));
-                for (int k = tid; k <= H; k += T)
-                    mi::wt_store(rrow, 4 * k, (fl & 2) ? a[k] : 0.0f);
                 ingest_hop(f, v);
             }
             return;
@@ -1193,13 +1204,6 @@ namespace
         }
         MI_APROBE(1);
         rf.prepare();
-        const float keep = 1.0f - tau;
-        float amp[KPT], amp_h = 0.0f;                       // vAmp: in registers from strobe to strobe
-        #pragma unroll
-        for (int i = 0; i < KPT; ++i)
-            amp[i] = a[tid + i * T];
-        if (tid == 0)
-            amp_h = a[H];
         for (int f = 0; f < fa.frames; ++f)
         {
             // (the window comes out of the L2 at every strobe instead of occupying 16 registers: four workgroups fit a CU.  Asked
@@ -1224,7 +1228,7 @@ namespace
             // caller's block cannot be told apart by the compiler, which keeps them in program order)
             float2 blk[HALF];
             load_hop(f, blk);
-            // pcomplex_mod over N/2+1 bins, then mix2(vAmp, mod, 1 - tau, tau) (Analyzer.cpp:359-361)
+            // pcomplex_mod over N/2+1 bins (Analyzer.cpp:359); mix2 follows in the reduction launch
             float *const row = fa.rows[f] + size_t(ch) * amp_stride;
             const __amdgpu_buffer_rsrc_t ramp = mi::wt_buffer(row, unsigned((H + 1) * sizeof(float)));
             #pragma unroll
@@ -1232,15 +1236,10 @@ namespace
             {
                 const int k = tid + i * T;
                 const float2 v = buf[k];
-                const float mag = (k == 0) ? fabsf(v.x) : mag_root(v.x * v.x + v.y * v.y);
-                amp[i] = amp[i] * keep + mag * tau;
-                mi::wt_store(ramp, 4 * k, amp[i]);
+                mi::wt_store(ramp, 4 * k, (k == 0) ? fabsf(v.x) : mag_root(v.x * v.x + v.y * v.y));
             }
             if (tid == 0)
-            {
-                amp_h = amp_h * keep + fabsf(buf[0].y) * tau;
-                mi::wt_store(ramp, 4 * H, amp_h);
-            }
+                mi::wt_store(ramp, 4 * H, fabsf(buf[0].y));
             if (f == 3) MI_APROBE(4);
             // this strobe's block: into the ring, and the second half of the next strobe's frame
             ingest_hop(f, blk);
@@ -1252,6 +1251,530 @@ namespace
             if (f == 2) MI_APROBE(7);
         }
         MI_APROBE(6);
+    }
+
+    // ---- the same run of strobes at rank 12 on the wave-resident transform (fft_wave.h; round 6) --------------------------------
+    // A WAVE owns a PAIR of consecutive strobes of a channel: the frames of strobes 2p and 2p + 1 -- hops [h(2p-2) | h(2p-1)] and
+    // [h(2p-1) | h(2p)], h(q) = block q of the call for q >= 0, what the ring holds in front of the head for q < 0 -- are the real
+    // and the imaginary part of ONE 4096-point complex sequence z = w (A + i B); the spectra come apart as
+    // X_A[k] = (Z[k] + conj Z[N-k]) / 2, X_B[k] = (Z[k] - conj Z[N-k]) / 2i, the partner bin by ds_bpermute (lane 64 - l, register
+    // 63 - r; lane 0: register (64 - r) & 63), and only the magnitudes of bins 0 .. N/2 are wanted: one forward transform per TWO
+    // strobes, no workgroup-wide LDS pass, no barrier behind the tables.  The magnitudes go out RAW (the smoothing walks the planes
+    // in the reduction launch), so the eight waves of a channel's workgroup -- sixteen strobes -- owe each other nothing, two waves
+    // per SIMD: round 5's form of this kernel kept vAmp in registers from strobe to strobe, i.e. ONE wave per channel and SIMD, and
+    // a lone wave issued at half the rate (profiles/r05_experiments/analyzer_frames_wave.txt).
+    // Ring ingest (Analyzer.cpp:371-398): wave p files hops 2p - 1 and 2p (it has them in registers); wave 0, which has no hop -1
+    // to file, takes the call's last block when the count of strobes is even.  The host sends a run this way only while the ring
+    // holds a frame AND the run's hops side by side (no wave overwrites what another still reads).
+    // Same products, another transform and another order of roundings: within 1e-6 of analyzer_kernel<11>, not its bits.
+    constexpr int ANW_WAVES = 8;
+#ifndef MI_ANW_KNOBS
+#define MI_ANW_KNOBS 0
+#endif
+#ifndef MI_ANW_CPOL
+#define MI_ANW_CPOL 2
+#endif
+#ifndef MI_ANW_LPOL
+#define MI_ANW_LPOL 0
+#endif
+#define MI_ANW_LNT ""
+    __global__ __launch_bounds__(64 * ANW_WAVES, 2)
+    void analyzer_frames_wave_kernel(const an_frames_args fa, size_t in_stride, float *ring, uint32_t buf_size, uint32_t head,
+                                     const uint8_t *__restrict__ flags, const float *__restrict__ wnd, uint32_t amp_stride,
+                                     const float2 *__restrict__ tw, int channels)
+    {
+        using namespace mi_fftw;
+        constexpr int HALF = R / 2, HOP = N / 2;            // registers of a hop (sample lane + 64 j); samples of a hop
+        __shared__ float areas[ANW_WAVES][AREA];
+        __shared__ float2 pl[16 * R];
+        __shared__ float wnd_l[N];
+        const int tid = threadIdx.x, lane = tid & 63;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+        MI_WPROBE(30);
+        fill_table_pq(pl, tw, tid, 64 * ANW_WAVES);
+        for (int i = tid; i < N; i += 64 * ANW_WAVES)
+            wnd_l[i] = wnd[i];
+        // the flags (bit0: active, bit1: frozen) of the channels this workgroup walks, one per lane: a v_readlane away
+        const int walk = (channels - int(blockIdx.x) + int(gridDim.x) - 1) / int(gridDim.x);      // channels blockIdx.x + i gridDim.x, i < walk
+        auto flags_of = [&](int i0) -> uint32_t {
+            const int c = int(blockIdx.x) + (i0 + lane) * int(gridDim.x);
+            return (c < channels) ? uint32_t(flags[c]) : 0u;
+        };
+        uint32_t flv = flags_of(0);
+        __syncthreads();
+        MI_WPROBE(31);
+        int unit_no = 0;
+        const int pairs = (fa.frames + 1) / 2;
+        auto at = [](__amdgpu_buffer_rsrc_t r, int lane_off, int row_off) -> float {
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, MI_ANW_LPOL));
+        };
+        // hop q of the call (q >= 0: the caller's block q; q < 0: what the ring holds in front of the head) of channel ch, sample
+        // lane + 64 j.  One lane offset in a VGPR, the row in the scalar offset -- also for the ring unless the hop straddles its
+        // end (once per turn of the ring: offsets per element there)
+        auto load_hop = [&](int ch, int q, float (&v)[HALF]) {
+            if (MI_ANW_KNOBS & 4) { for (int j = 0; j < HALF; ++j) v[j] = float(lane + j + q); return; }
+            if (q >= 0)
+            {
+                const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float)));
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                    v[j] = at(rin, lane * 4, 256 * j);
+                return;
+            }
+            float *rbw = ring + size_t(ch) * buf_size;
+            int64_t doff = int64_t(head) + int64_t(q) * HOP;                // Analyzer.cpp:339-353 with no delay
+            while (doff < 0)
+                doff += buf_size;
+            const uint32_t d0 = uint32_t(doff);
+            if (d0 + HOP <= buf_size)
+            {
+                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + d0, unsigned(HOP * sizeof(float)));
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                    v[j] = at(rhop, lane * 4, 256 * j);
+                return;
+            }
+            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+            int ln = lane;
+            asm volatile("" : "+v"(ln));                    // (the wrapped offsets are made here, not ahead of the loops and spilled)
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                uint32_t i0 = d0 + uint32_t(ln + 64 * j);
+                if (i0 >= buf_size) i0 -= buf_size;
+                v[j] = at(rring, int(i0 * sizeof(float)), 0);
+            }
+        };
+        // ... into the ring behind the head of strobe q (Analyzer.cpp:371-398): 256 contiguous bytes per wave instruction
+        auto ingest_hop = [&](int ch, int q, const float (&v)[HALF]) {
+            if ((MI_ANW_KNOBS & 8) && v[0] != 12345.f) return;
+            float *rbw = ring + size_t(ch) * buf_size;
+            const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(q) * HOP) % buf_size);
+            if (h0 + HOP <= buf_size)
+            {
+                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + h0, unsigned(HOP * sizeof(float)));
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), rhop, lane * 4, 256 * j, MI_ANW_CPOL);
+                return;
+            }
+            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
+            {
+                uint32_t w0 = h0 + uint32_t(ln + 64 * j);
+                if (w0 >= buf_size) w0 -= buf_size;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), rring, int(w0 * sizeof(float)), 0, MI_ANW_CPOL);
+            }
+        };
+        // A slice of a hop: rows j0 .. j0 + ROWS - 1 of the 32 (the call's last block when the count of strobes is even -- no pair's
+        // frame holds it -- is filed by all eight waves, four rows each)
+        constexpr int XROWS = HALF / ANW_WAVES;
+        auto load_rows = [&](int ch, int q, int j0, float (&e)[XROWS]) {
+            if (MI_ANW_KNOBS & 12) return;
+            const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float)));
+            #pragma unroll
+            for (int j = 0; j < XROWS; ++j)
+                e[j] = at(rin, lane * 4, 256 * (j0 + j));
+        };
+        auto file_rows = [&](int ch, int q, int j0, const float (&e)[XROWS]) {
+            if (MI_ANW_KNOBS & 12) return;
+            float *rbw = ring + size_t(ch) * buf_size;
+            const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(q) * HOP) % buf_size);
+            if (h0 + HOP <= buf_size)
+            {
+                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + h0, unsigned(HOP * sizeof(float)));
+                #pragma unroll
+                for (int j = 0; j < XROWS; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[j]), rhop, lane * 4, 256 * (j0 + j), MI_ANW_CPOL);
+                return;
+            }
+            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            #pragma unroll
+            for (int j = 0; j < XROWS; ++j)
+            {
+                uint32_t w0 = h0 + uint32_t(ln + 64 * (j0 + j));
+                if (w0 >= buf_size) w0 -= buf_size;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[j]), rring, int(w0 * sizeof(float)), 0, MI_ANW_CPOL);
+            }
+        };
+        auto flags_at = [&](int i) -> uint32_t {           // channel i of the walk (its flags in lane i & 63 of flv)
+            if ((i & 63) == 0 && i > 0)
+                flv = flags_of(i);
+            return uint32_t(__builtin_amdgcn_readlane(int(flv), i & 63));
+        };
+        // the frozen and inactive channels of the walk only take their samples (the reduction launch keeps / zeroes their rows):
+        // a pass of its own in front of the analyses, the hops shared out among the waves
+        for (int i = 0; i < walk; ++i)
+        {
+            if ((flags_at(i) & 3u) == 1u)
+                continue;
+            const int ch = int(blockIdx.x) + i * int(gridDim.x);
+            for (int q = wv; q < fa.frames; q += ANW_WAVES)
+            {
+                float v[HALF];
+                load_hop(ch, q, v);
+                ingest_hop(ch, q, v);
+            }
+        }
+        if (walk > 64)
+            flv = flags_of(0);
+        auto next_active = [&](int i) -> int {             // the first analysed channel of the walk at or behind position i (walk: none)
+            while (i < walk && (flags_at(i) & 3u) != 1u)
+                ++i;
+            return i;
+        };
+        // A wave takes pair p = wv of channel after channel.  Strobes 2p and 2p + 1: A = [h(2p-2) | h(2p-1)], B = [h(2p-1) | h(2p)].
+        // The hops of the NEXT channel's pair are asked for underneath this one's transform: h(2p) into 32 registers in front of
+        // it, h(2p-2) and h(2p-1) by LDS-DMA into the wave's exchange area (row j of a hop = 256 bytes at 256 j: lane order is
+        // sample order) as soon as the transform's one exchange has left it -- no registers, and a wave has its 24 KiB of
+        // requests in flight while it computes.  (Written in asm: the compiler knows nothing of these loads, the wait at the head
+        // of a unit is ours; vmcnt counts stores as well on this part, so the wait is for everything.)
+        const int p = wv;
+        if (p >= pairs)
+            return;
+        const bool second = 2 * p + 1 < fa.frames;
+        const bool even = (fa.frames & 1) == 0;
+        float *const area = areas[wv];
+        const unsigned area_at = unsigned(uintptr_t(area));                // LDS byte address (wave-uniform)
+        // sixteen rows (4 KiB) of a hop: memory rsrc + lane * 4 + soff + 256 j -> LDS m0v + lane * 4 + 256 j
+        auto dma16 = [&](__amdgpu_buffer_rsrc_t rsrc, int soff, unsigned m0v) __attribute__((always_inline)) {
+            unsigned keep;
+            const int voff = lane * 4;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                         "buffer_load_dword %1, %2, %3 offen lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:256 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:512 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:768 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1024 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1280 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1536 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1792 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2048 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2304 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2560 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2816 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3072 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3328 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3584 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3840 lds" MI_ANW_LNT "\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(m0v) : "memory");
+        };
+        // hop q of channel ch -> LDS at byte address `to` (8 KiB)
+        auto dma_hop = [&](int ch, int q, unsigned to) {
+            if (MI_ANW_KNOBS & 4) return;
+            if (q >= 0)
+            {
+                const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float)));
+                dma16(rin, 0, to);
+                dma16(rin, 4096, to + 4096);
+                return;
+            }
+            float *rbw = ring + size_t(ch) * buf_size;
+            int64_t doff = int64_t(head) + int64_t(q) * HOP;                // Analyzer.cpp:339-353 with no delay
+            while (doff < 0)
+                doff += buf_size;
+            const uint32_t d0 = uint32_t(doff);
+            if (d0 + HOP <= buf_size)
+            {
+                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + d0, unsigned(HOP * sizeof(float)));
+                dma16(rhop, 0, to);
+                dma16(rhop, 4096, to + 4096);
+                return;
+            }
+            // the hop straddles the ring's end (once per turn of the ring): a wrapped offset per row
+            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+            for (int j = 0; j < HALF; ++j)
+            {
+                uint32_t i0 = d0 + uint32_t(lane + 64 * j);
+                if (i0 >= buf_size) i0 -= buf_size;
+                const int voff = int(i0 * sizeof(float));
+                const unsigned m0v = to + 256u * unsigned(j);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" MI_ANW_LNT "\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(voff), "s"(rring), "s"(m0v) : "memory");
+            }
+        };
+        int i = next_active(0);
+        float h2[HALF], e[XROWS];
+        if (i < walk)
+        {
+            const int ch = int(blockIdx.x) + i * int(gridDim.x);
+            dma_hop(ch, 2 * p - 2, area_at);
+            dma_hop(ch, 2 * p - 1, area_at + unsigned(HOP * sizeof(float)));
+            load_hop(ch, 2 * p, h2);
+            if (even)
+                load_rows(ch, fa.frames - 1, XROWS * wv, e);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        while (i < walk)
+        {
+            const int ch = int(blockIdx.x) + i * int(gridDim.x);
+            v2f x[R];
+            // the unit's three hops are here: every load is older than the 66 stores of the rows that followed them (in-order
+            // completion: all but the newest 63 operations done = every load done)
+            asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+            MI_WPROBE(unit_no * 6 + 0);
+            {
+                // the window's products; hop 2p - 1 goes on into the ring from the registers it passes through
+                float *rbw = ring + size_t(ch) * buf_size;
+                const uint32_t g0 = uint32_t((uint64_t(head) + uint64_t(buf_size) + uint64_t(int64_t(2 * p - 1) * HOP)) % buf_size);
+                const bool file1 = p > 0 && !(MI_ANW_KNOBS & 8), straight = g0 + HOP <= buf_size;
+                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(straight ? rbw + g0 : rbw, (file1 && straight) ? unsigned(HOP * sizeof(float)) : 0u);
+                #pragma unroll
+                for (int j = 0; j < HALF; ++j)
+                {
+                    const float w0 = wnd_l[lane + 64 * j], w1 = wnd_l[lane + 64 * (j + HALF)];
+                    const float a = area[64 * j + lane], b = area[HOP + 64 * j + lane];
+                    x[j] = v2f{a * w0, b * w0};
+                    x[j + HALF] = v2f{b * w1, h2[j] * w1};
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b), rhop, lane * 4, 256 * j, MI_ANW_CPOL);
+                }
+                if (file1 && !straight)
+                {
+                    // (the hop straddles the ring's end: once more out of the area, offsets per element)
+                    const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
+                    for (int j = 0; j < HALF; ++j)
+                    {
+                        uint32_t w0 = g0 + uint32_t(lane + 64 * j);
+                        if (w0 >= buf_size) w0 -= buf_size;
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(area[HOP + 64 * j + lane]), rring, int(w0 * sizeof(float)), 0, MI_ANW_CPOL);
+                    }
+                }
+                ingest_hop(ch, 2 * p, h2);
+            }
+            MI_WPROBE(unit_no * 6 + 1);
+            if (even)
+                file_rows(ch, fa.frames - 1, XROWS * wv, e);
+            MI_WPROBE(unit_no * 6 + 2);
+            i = next_active(i + 1);
+            const int chn = int(blockIdx.x) + i * int(gridDim.x);
+            if (!(MI_ANW_KNOBS & 1))
+            fft4096_t<false>(x, pl, area, lane, [&]() {
+                // the exchange is through: its area takes the next unit's first two hops, 32 registers the third (the
+                // transform's first half has none to spare)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                MI_WPROBE(unit_no * 6 + 3);
+                if (i < walk)
+                {
+                    dma_hop(chn, 2 * p - 2, area_at);
+                    dma_hop(chn, 2 * p - 1, area_at + unsigned(HOP * sizeof(float)));
+                    load_hop(chn, 2 * p, h2);
+                    if (even)
+                        load_rows(chn, fa.frames - 1, XROWS * wv, e);
+                }
+            });
+            MI_WPROBE(unit_no * 6 + 4);
+            // pcomplex_mod over N/2 + 1 bins (Analyzer.cpp:359) of strobe 2p and of strobe 2p + 1
+            const unsigned row_bytes = unsigned((HOP + 1) * sizeof(float));
+            const __amdgpu_buffer_rsrc_t row_a = mi::wt_buffer(fa.rows[2 * p] + size_t(ch) * amp_stride, row_bytes);
+            const __amdgpu_buffer_rsrc_t row_b = mi::wt_buffer(fa.rows[second ? 2 * p + 1 : 2 * p] + size_t(ch) * amp_stride, second ? row_bytes : 0u);
+            const int paddr = ((64 - lane) & 63) * 4;
+            const bool l0 = lane == 0;
+            // 2 X_A = Z + conj P, 2i X_B = Z - conj P with P = Z[N - k]: lane 64 - l, register 63 - r (lane 0: register (64 - r) & 63)
+            auto mags = [&](v2f z, v2f pz, float &ma, float &mb) {
+                const float ex = z.x + pz.x, ey = z.y - pz.y, ox = z.x - pz.x, oy = z.y + pz.y;
+                ma = 0.5f * mag_root(ex * ex + ey * ey);
+                mb = 0.5f * mag_root(ox * ox + oy * oy);
+            };
+            constexpr int CH = 8;                           // partners asked for together (registers: the next channel's hops are waiting)
+            #pragma unroll
+            for (int r0 = 0; r0 < HALF; r0 += CH)
+            {
+                v2f part[CH];
+                #pragma unroll
+                for (int r = 0; r < CH; ++r)
+                    part[r] = from_partner(paddr, x[63 - (r0 + r)]);
+                #pragma unroll
+                for (int rr = 0; rr < CH; ++rr)
+                {
+                    const int r = r0 + rr;
+                    const v2f own = x[(64 - r) & 63];
+                    const v2f pz = v2f{l0 ? own.x : part[rr].x, l0 ? own.y : part[rr].y};
+                    float ma, mb;
+                    mags(x[r], pz, ma, mb);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma), row_a, lane * 4, 256 * r, MI_ANW_CPOL);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb), row_b, lane * 4, 256 * r, MI_ANW_CPOL);
+                }
+            }
+            if (l0)                                         // bin N / 2: lane 0's register HALF, its own partner
+            {
+                float ma, mb;
+                mags(x[HALF], x[HALF], ma, mb);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma), row_a, 4 * HOP, 0, MI_ANW_CPOL);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb), row_b, 4 * HOP, 0, MI_ANW_CPOL);
+            }
+            MI_WPROBE(unit_no * 6 + 5);
+            ++unit_no;
+        }
+        MI_WPROBE(29);
+    }
+
+    // ---- smoothing + per-bin reduction of a run of strobes (round 6) ----------------------------------------------------------------
+    // The planes hold the RAW magnitudes of strobes 0 .. frames - 1 (analyzer_frames_*_kernel).  A thread owns one bin of a block
+    // of `block` consecutive channels: channel after channel it walks vAmp = mix2(vAmp, |X_f|, 1 - tau, tau) over the strobes in
+    // the reference's order (Analyzer.cpp:355-361; frozen: vAmp stays, :334; inactive: 0, :363-364) starting from the bank's vAmp,
+    // adds every strobe's smoothed value to that strobe's block sum -- in channel order: the order of bin_reduce_body -- and leaves
+    // vAmp after the last strobe in `amp` and after the one before it in `data` (what the strobe publishes, Analyzer.cpp:321-326).
+    // A wave owns 64 bins (two 128-byte lines of every row) of ONE block, so the channel -- its flags, every plane's row -- is a
+    // scalar; a workgroup owns SMR_BLOCKS blocks, whose sums go through the first levels of bin_reduce_body's binary tree (element
+    // j, a multiple of 2 s, takes in element j + s) into `partial` [slice][frame][bins_stride]; bin_combine_kernel walks the
+    // tree's upper levels over the slices.  Same additions in the same order as frames x (analyzer_kernel, bin_reduce_kernel): the
+    // sums' bits depend on the magnitudes alone.  SMR_AHEAD channels' rows (17 loads each) are in flight together -- a thread's
+    // channels are a chain of round trips otherwise; nothing is loaded under a condition a load decides (a frozen or inactive
+    // channel's planes are read and not used).
+    #ifndef MI_SMR_AHEAD
+#define MI_SMR_AHEAD 4
+#endif
+    constexpr uint32_t SMR_BINS = 64, SMR_BLOCKS = 4, SMR_AHEAD = MI_SMR_AHEAD;
+    struct smooth_planes { const float *raw[AN_FRAMES_MAX]; };
+    template <bool FULL /* all AN_FRAMES_MAX strobes */>
+    __global__ __launch_bounds__(64 * SMR_BLOCKS)
+    void bin_smooth_reduce_kernel(float *__restrict__ partial, const smooth_planes sp, int frames_, float *__restrict__ amp,
+                                  float *__restrict__ data, uint32_t stride, uint32_t channels, uint32_t bins,
+                                  const uint8_t *__restrict__ flags, float tau, uint32_t block)
+    {
+        __shared__ float part[AN_FRAMES_MAX][SMR_BLOCKS][SMR_BINS];
+        const int frames = FULL ? AN_FRAMES_MAX : frames_;
+        const uint32_t lane = threadIdx.x & 63;
+        const uint32_t w = uint32_t(__builtin_amdgcn_readfirstlane(int(threadIdx.x >> 6)));
+        const uint32_t k = blockIdx.x * SMR_BINS + lane;
+        const uint32_t j = blockIdx.y * SMR_BLOCKS + w;                    // the block of channels
+        const float keep = 1.0f - tau;
+        float s[AN_FRAMES_MAX];
+        #pragma unroll
+        for (int f = 0; f < AN_FRAMES_MAX; ++f)
+            s[f] = 0.0f;
+        const uint32_t c0 = j * block;
+        if (c0 < channels)
+        {
+            const uint32_t c1 = (c0 + block < channels) ? c0 + block : channels;
+            const uint32_t kk = (k < bins) ? k : bins - 1;                  // (lanes past the last bin: its value again, not kept)
+            for (uint32_t cb = c0; cb < c1; cb += 64)
+            {
+                // the flags of up to 64 channels, one per lane: a channel's flags are then a v_readlane away, not a round trip
+                // in front of its rows' requests
+                const uint32_t flv = flags[(cb + lane < c1) ? cb + lane : c1 - 1];
+                const uint32_t ce = (cb + 64 < c1) ? cb + 64 : c1;
+                for (uint32_t cc = cb; cc < ce; cc += SMR_AHEAD)
+                {
+                    float m[SMR_AHEAD][AN_FRAMES_MAX], a0[SMR_AHEAD];
+                    #pragma unroll
+                    for (uint32_t u = 0; u < SMR_AHEAD; ++u)
+                    {
+                        const uint32_t c = (cc + u < ce) ? cc + u : ce - 1;    // (past the end: the last channel again, not used)
+                        const size_t at = size_t(c) * stride + kk;
+                        a0[u] = amp[at];
+                        #pragma unroll
+                        for (int f = 0; f < AN_FRAMES_MAX; ++f)
+                        {
+                            // (a run of fewer strobes: plane 0 again -- an unconditional request; its value is not used)
+                            const float *__restrict__ plane = sp.raw[(f < frames) ? f : 0];
+                            m[u][f] = plane[at];
+                        }
+                    }
+                    #pragma unroll
+                    for (uint32_t u = 0; u < SMR_AHEAD; ++u)
+                    {
+                        if (cc + u >= ce)
+                            break;
+                        const size_t at = size_t(cc + u) * stride + kk;
+                        const uint32_t fl = uint32_t(__builtin_amdgcn_readlane(int(flv), int(cc + u - cb)));
+                        const bool active = (fl & 3u) == 1u;
+                        float a = (fl == 0u) ? 0.0f : a0[u];                // inactive (and not frozen): vAmp = 0 from the first strobe on
+                        #pragma unroll
+                        for (int f = 0; f < AN_FRAMES_MAX; ++f)
+                        {
+                            if (f < frames)
+                            {
+                                a = active ? mix2(a, m[u][f], keep, tau) : a;
+                                s[f] += a;
+                                if (f == frames - 2 && k < bins)
+                                    data[at] = a;
+                            }
+                        }
+                        if (k < bins)
+                            amp[at] = a;
+                    }
+                }
+            }
+        }
+        #pragma unroll
+        for (int f = 0; f < AN_FRAMES_MAX; ++f)
+            part[f][w][lane] = s[f];
+        __syncthreads();
+        // tree levels s = 1, 2 over the four block sums of the slice
+        static_assert(SMR_BLOCKS == 4, "the tree below is written out for four block sums");
+        for (uint32_t i = threadIdx.x; i < uint32_t(frames) * SMR_BINS; i += 64 * SMR_BLOCKS)
+        {
+            const uint32_t f = i / SMR_BINS, bb = i & (SMR_BINS - 1);
+            const float v = (part[f][0][bb] + part[f][1][bb]) + (part[f][2][bb] + part[f][3][bb]);
+            if (blockIdx.x * SMR_BINS + bb < stride)
+                partial[(size_t(blockIdx.y) * AN_FRAMES_MAX + f) * stride + blockIdx.x * SMR_BINS + bb] = v;
+        }
+    }
+
+    // The upper levels of the tree: out[f][k] = tree over the slices' partial sums, times the envelope where one is asked for.  The
+    // slices come in order; st[b] holds the sum of a complete aligned run of 2^b slices waiting for its right-hand neighbour (a
+    // binary counter: slice i's carries are the set low bits of i, all scalars) -- element j, a multiple of 2 s, takes in element
+    // j + s, a slice that is not there enters as + 0: bin_reduce_body's tree.  (As the last-arriving workgroup's job inside the
+    // launch above it measured 10 us more than this launch's 4.8: a release, an add, an acquire and the reads at the end of
+    // every group of bins at once.)
+    constexpr uint32_t CMB_AHEAD = 16, CMB_LEVELS = 9;                      // up to 256 slices (REDUCE_MAX_BLOCKS / SMR_BLOCKS)
+    __global__ __launch_bounds__(256)
+    void bin_combine_kernel(float *out, size_t out_stride, const float *__restrict__ partial, uint32_t slices, uint32_t stride,
+                            uint32_t bins, const float *__restrict__ env)
+    {
+        const uint32_t k = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y;
+        if (k >= bins)
+            return;
+        float st[CMB_LEVELS];
+        #pragma unroll
+        for (uint32_t b = 0; b < CMB_LEVELS; ++b)
+            st[b] = 0.0f;
+        for (uint32_t i0 = 0; i0 < slices; i0 += CMB_AHEAD)
+        {
+            float v[CMB_AHEAD];
+            #pragma unroll
+            for (uint32_t u = 0; u < CMB_AHEAD; ++u)
+                v[u] = (i0 + u < slices) ? partial[(size_t(i0 + u) * AN_FRAMES_MAX + f) * stride + k] : 0.0f;
+            #pragma unroll
+            for (uint32_t u = 0; u < CMB_AHEAD; ++u)
+            {
+                const uint32_t i = i0 + u;
+                if (i >= slices)
+                    break;
+                float x = v[u];
+                bool carry = true;
+                #pragma unroll
+                for (uint32_t b = 0; b < CMB_LEVELS; ++b)
+                {
+                    if (carry && ((i >> b) & 1u))
+                        x = st[b] + x;
+                    else if (carry)
+                    {
+                        st[b] = x;
+                        carry = false;
+                    }
+                }
+            }
+        }
+        // the runs that are left are the set bits of `slices`; a run enters the level above with + 0 at its right until it meets one
+        float acc = 0.0f;
+        bool have = false;
+        #pragma unroll
+        for (uint32_t b = 0; b < CMB_LEVELS; ++b)
+            if ((slices >> b) & 1u)
+            {
+                acc = have ? st[b] + acc : st[b];
+                have = true;
+            }
+        out[size_t(f) * out_stride + k] = (env != nullptr) ? acc * env[k] : acc;
     }
 
     // ---- analyzer frames above 2^14 samples: the steps of analyzer_kernel as plain launches around the four-step transform
@@ -1289,7 +1812,7 @@ namespace
         else
         {
             const float2 v = spec[size_t(ch) * N + k];
-            r = a * (1.0f - tau) + mag_root(v.x * v.x + v.y * v.y) * tau;
+            r = mix2(a, mag_root(v.x * v.x + v.y * v.y), 1.0f - tau, tau);
         }
         amp_new[size_t(ch) * amp_stride + k] = r;
     }
@@ -2026,6 +2549,7 @@ struct mi_analyzer_bank
     // mi_analyzer_bank_process_reduce_frames: planes that keep the spectra of the frames of a call until their reductions
     // run as one launch; d_amp and d_data are always two of the planes the bank owns (these and the two it was made with)
     std::vector<float *> planes;
+    float      *d_partial = nullptr;        // [slices][REDUCE_FRAMES_MAX][bins_stride]: the slices' partial sums of bin_smooth_reduce_kernel
     float      *fuse_out = nullptr;         // where the next strobe's launch leaves the reduction (NULL: no reduce role)
     bool        fuse_env = false, fuse_done = false;
     uint32_t   *d_rows = nullptr;           // [channels]: sequence number of the launch that last completed the channel's row
@@ -2296,6 +2820,7 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
     (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
     (void)hipFree(b->d_big_work); (void)hipFree(b->d_big_tmp); (void)hipFree(b->d_big_spec);
     (void)hipFree(b->d_rows);
+    (void)hipFree(b->d_partial);
     (void)hipHostFree(b->h_fault);
     delete b;
     return MI_OK;
@@ -2538,45 +3063,44 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
             continue;
         }
         const size_t plane_bytes = size_t(b->channels) * b->bins_stride * sizeof(float);
+        uint32_t block = REDUCE_BLOCK;
+        while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
+            block *= 2;
+        const uint32_t nblocks = (b->channels + block - 1) / block, slices = (nblocks + SMR_BLOCKS - 1) / SMR_BLOCKS;
         if (b->planes.empty())
         {
             // (all the spare planes or none: a list that is short would leave NULL rows for a later call to write through --
-            // ADVICE r04)
+            // ADVICE r04)  REDUCE_FRAMES_MAX spare planes (a run's raw magnitudes) next to vAmp and vData, and the slices' partial
+            // sums of the smoothing reduction
             std::vector<float *> made;
             made.push_back(b->d_amp);
             made.push_back(b->d_data);
-            for (uint32_t k = 0; k + 2 < REDUCE_FRAMES_MAX; ++k)
+            hipError_t e = hipSuccess;
+            for (uint32_t k = 0; k < REDUCE_FRAMES_MAX && e == hipSuccess; ++k)
             {
                 float *p = nullptr;
-                const hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), plane_bytes);
-                if (e != hipSuccess)
-                {
-                    for (size_t j = 2; j < made.size(); ++j)
-                        (void)hipFree(made[j]);
-                    MI_HIP_CHECK(e);
-                }
-                made.push_back(p);
+                e = hipMalloc(reinterpret_cast<void **>(&p), plane_bytes);
+                if (e == hipSuccess)
+                    made.push_back(p);
             }
+            float *part = nullptr;
+            if (e == hipSuccess)
+                e = hipMalloc(reinterpret_cast<void **>(&part), size_t(slices) * REDUCE_FRAMES_MAX * b->bins_stride * sizeof(float));
+
+            if (e != hipSuccess)
+            {
+                for (size_t j = 2; j < made.size(); ++j)
+                    (void)hipFree(made[j]);
+                (void)hipFree(part);
+                MI_HIP_CHECK(e);
+            }
+            b->d_partial = part;
+
             b->planes.swap(made);
         }
-        const size_t cnt = (frames - f < size_t(REDUCE_FRAMES_MAX)) ? frames - f : size_t(REDUCE_FRAMES_MAX);
-        // Frame k's analysis reads the spectrum of the frame before (vAmp) and leaves its own in a plane that nothing reads
-        // any more.  The last two frames of the batch take the planes the bank came in with -- the last one the plane that was
-        // vAmp (only the batch's first frame reads it), the one before it the published copy's (vData: the strobe replaces it,
-        // Analyzer.cpp:321-326) -- so that a batch leaves vAmp and vData where it found them (a captured run of batches then
-        // repeats with the ring alone); the frames before those two go through the spare planes.
-        float *const amp0 = b->d_amp, *const data0 = b->d_data;
-        std::vector<float *> spare(cnt);
-        {
-            size_t k = 0;
-            for (float *p : b->planes)
-                if (p != amp0 && p != data0 && k + 2 < cnt)
-                    spare[k++] = p;
-            spare[cnt - 2] = data0;
-            spare[cnt - 1] = amp0;
-        }
-        reduce_planes rp;
-        // the strobes themselves as ONE launch (analyzer_frames_kernel) where the hop is half a frame, nothing is delayed and
+        size_t cnt = (frames - f < size_t(REDUCE_FRAMES_MAX)) ? frames - f : size_t(REDUCE_FRAMES_MAX);
+        const float *const env = with_envelope ? b->d_env : nullptr;
+        // the strobes themselves as ONE launch (analyzer_frames_*_kernel) where the hop is half a frame, nothing is delayed and
         // every block is there; otherwise a launch per strobe
         const int lh = int(b->rank) - 1;
         bool one_launch = lh >= 9 && lh <= 12 && 2 * size_t(b->period) == (size_t(1) << b->rank) && b->max_user_delay() == 0 &&
@@ -2585,40 +3109,91 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
             one_launch = in[f + k] != nullptr;
         if (one_launch)
         {
+            // the launch's units take the run's hops in no particular order: the ring must hold the first strobe's frame and all
+            // the run's hops side by side (a shorter ring: a shorter run)
+            const size_t room = (size_t(b->buf_size) - (size_t(1) << b->rank)) / samples;
+            cnt = (cnt < room) ? cnt : room;
+            one_launch = cnt >= 2;
+            if (!one_launch)
+                cnt = (frames - f < size_t(REDUCE_FRAMES_MAX)) ? frames - f : size_t(REDUCE_FRAMES_MAX);
+        }
+        if (one_launch)
+        {
             MI_REQUIRE(b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u, MI_EHIP,
                        "mi_analyzer_bank_process_reduce_frames: the reduce role of an earlier analysis launch gave up waiting");
             const int rc = mi::capture_touch(st, b, "analyzer", analyzer_bank_positions);
             if (rc != MI_OK)
                 return rc;
+            // The launch leaves strobe k's RAW magnitudes in spare plane k; bin_smooth_reduce_kernel walks the smoothing over
+            // them from vAmp (d_amp, in place: vAmp after the run) and leaves vAmp as of the last strobe but one -- the copy that
+            // strobe published (Analyzer.cpp:321-326) -- in d_data: the planes stay where the run found them (a captured run of
+            // batches repeats with the ring alone).
             an_frames_args fa;
+            smooth_planes sp;
             fa.frames = int(cnt);
             bool aligned = (in_stride % 2) == 0;
-            for (size_t k = 0; k < cnt; ++k)
+            for (size_t k = 0; k < size_t(AN_FRAMES_MAX); ++k)
             {
-                fa.in[k] = in[f + k];
-                fa.rows[k] = spare[k];
-                rp.rows[k] = spare[k];
-                aligned = aligned && (reinterpret_cast<uintptr_t>(in[f + k]) % 8) == 0;
+                fa.in[k] = (k < cnt) ? in[f + k] : nullptr;
+                sp.raw[k] = fa.rows[k] = b->planes[2 + k];
+                aligned = aligned && (k >= cnt || (reinterpret_cast<uintptr_t>(in[f + k]) % 8) == 0);
             }
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             mi::take_profile_events(&ev0, &ev1);
-            #define MI_CALL(LH) MI_LAUNCH((analyzer_frames_kernel<LH>), dim3(b->channels), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
-                fa, in_stride, aligned, b->d_ring, b->buf_size, b->head, b->d_flags, b->d_wnd, b->d_amp, b->bins_stride, b->tau, b->d_tw)
-            switch (lh)
+            if (lh == 11)
             {
-                case 9:  { MI_CALL(9);  break; }
-                case 10: { MI_CALL(10); break; }
-                case 11: { MI_CALL(11); break; }
-                default: { MI_CALL(12); break; }
+                // rank 12: a wave per pair of strobes on the wave-resident transform; one workgroup per CU walks the channels
+                // (its tables are filled once, a wave's next unit is in flight underneath its transform; any grid is a correct one)
+                static const uint32_t cus = []() {
+                    int dev = 0, n = 0;
+                    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+                        n = 256;
+                    return uint32_t(n);
+                }();
+                MI_LAUNCH(analyzer_frames_wave_kernel, dim3(b->channels < cus ? b->channels : cus), dim3(64 * ANW_WAVES), 0, st, ev0, ev1,
+                          fa, in_stride, b->d_ring, b->buf_size, b->head, b->d_flags, b->d_wnd, b->bins_stride, b->d_tw, int(b->channels));
             }
-            #undef MI_CALL
+            else
+            {
+                #define MI_CALL(LH) MI_LAUNCH((analyzer_frames_kernel<LH>), dim3(b->channels), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
+                    fa, in_stride, aligned, b->d_ring, b->buf_size, b->head, b->d_flags, b->d_wnd, b->bins_stride, b->d_tw)
+                switch (lh)
+                {
+                    case 9:  { MI_CALL(9);  break; }
+                    case 10: { MI_CALL(10); break; }
+                    default: { MI_CALL(12); break; }
+                }
+                #undef MI_CALL
+            }
             MI_HIP_CHECK(hipGetLastError());
-            // where `cnt` strobes leave the bank (analyzer_strobe: the planes swap roles at every strobe; Analyzer.cpp:321-326):
-            // vAmp = the last frame's plane = amp0, vData = the one before = data0
+            if (cnt == size_t(AN_FRAMES_MAX))
+                hipLaunchKernelGGL((bin_smooth_reduce_kernel<true>), dim3((bins + SMR_BINS - 1) / SMR_BINS, slices), dim3(64 * SMR_BLOCKS), 0, st,
+                                   b->d_partial, sp, int(cnt), b->d_amp, b->d_data, b->bins_stride, b->channels, bins, b->d_flags, b->tau, block);
+            else
+                hipLaunchKernelGGL((bin_smooth_reduce_kernel<false>), dim3((bins + SMR_BINS - 1) / SMR_BINS, slices), dim3(64 * SMR_BLOCKS), 0, st,
+                                   b->d_partial, sp, int(cnt), b->d_amp, b->d_data, b->bins_stride, b->channels, bins, b->d_flags, b->tau, block);
+            MI_HIP_CHECK(hipGetLastError());
+            hipLaunchKernelGGL(bin_combine_kernel, dim3((bins + 255) / 256, uint32_t(cnt)), dim3(256), 0, st,
+                               out + f * out_stride, out_stride, b->d_partial, slices, b->bins_stride, bins, env);
+            MI_HIP_CHECK(hipGetLastError());
             b->head = uint32_t((uint64_t(b->head) + uint64_t(cnt) * samples) % b->buf_size);
             b->analysed = true;
+            f += cnt;
+            continue;
         }
-        for (size_t k = 0; !one_launch && k < cnt; ++k)
+        // A launch per strobe: frame k's analysis reads the spectrum of the frame before (vAmp) and leaves its own in a plane that
+        // nothing reads any more.  The last two frames of the batch take the planes the bank came in with -- the last one the
+        // plane that was vAmp (only the batch's first frame reads it), the one before it the published copy's (vData: the strobe
+        // replaces it, Analyzer.cpp:321-326) -- so that a batch leaves vAmp and vData where it found them; the frames before
+        // those two go through the spare planes.  The reductions of the batch's strobes then run as ONE launch.
+        float *const amp0 = b->d_amp, *const data0 = b->d_data;
+        std::vector<float *> spare(cnt);
+        for (size_t k = 0; k + 2 < cnt; ++k)
+            spare[k] = b->planes[2 + k];
+        spare[cnt - 2] = data0;
+        spare[cnt - 1] = amp0;
+        reduce_planes rp;
+        for (size_t k = 0; k < cnt; ++k)
         {
             b->d_data = spare[k];                           // analyzer_strobe swaps: d_amp <- this plane, d_data <- the spectrum so far
             r = mi_analyzer_bank_process(b, in[f + k], samples, in_stride, stream);
@@ -2626,16 +3201,12 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
                 return r;
             rp.rows[k] = b->d_amp;
         }
-        uint32_t block = REDUCE_BLOCK;
-        while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
-            block *= 2;
-        static const bool narrow = getenv("MI_REDUCE_16_BINS") != nullptr;                  // experiment knob: half a line per workgroup
-        if ((b->channels + block - 1) / block <= BINS_32_BLOCKS && !narrow)
+        if (nblocks <= BINS_32_BLOCKS)
             hipLaunchKernelGGL((bin_reduce_frames_kernel<32>), dim3((bins + 31) / 32, uint32_t(cnt)), dim3(64 * REDUCE_WAVES), 0, st,
-                               out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
+                               out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, env, block);
         else
             hipLaunchKernelGGL((bin_reduce_frames_kernel<16>), dim3((bins + 15) / 16, uint32_t(cnt)), dim3(64 * REDUCE_WAVES), 0, st,
-                               out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, with_envelope ? b->d_env : nullptr, block);
+                               out + f * out_stride, out_stride, rp, b->bins_stride, b->channels, bins, env, block);
         MI_HIP_CHECK(hipGetLastError());
         f += cnt;
     }
