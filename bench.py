@@ -874,12 +874,13 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     def region():
         for i in range(0, steps, batch):
             batch_step(i)
-    # probes: the analysis launch of a batch alone (analyzer_frames_kernel takes the event pair, the reduction and the
+    # probes: the analysis launch of a batch alone (analyzer_frames_wave_kernel takes the event pair, the reduction and the
     # collective behind it do not), the stream drained in front of each
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch, region=region,
                                              probe_step=lambda i: batch_step(i * batch), probe_sync=True, probe_steps=batch)
     tinfo["launch"] = ("%d mi_analyzer_bank_process_reduce_frames calls of %d frames each per region (the %d strobes as ONE launch of "
-                       "analyzer_frames_kernel, their reductions as one launch of bin_reduce_frames_kernel)" % (steps // batch, batch, batch))
+                       "analyzer_frames_wave_kernel -- raw magnitudes -- then bin_smooth_reduce_kernel + bin_combine_kernel: the smoothing "
+                       "walked over the strobes where the per-bin sums are formed)" % (steps // batch, batch, batch))
     pc_elapsed, pc_kernel_ms, pc_info = _timed_steps(mi, torch, dist, world, dev, step, steps, batch,
                                                      probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream), probe_sync=True)
     assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
@@ -901,10 +902,10 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
         "per_call": {"what": "a mi_analyzer_bank_process_reduce call per frame (analysis launch + reduction launch)",
                      "ms_per_step": round(pc_elapsed / steps * 1e3, 5), "value": round(C * world * steps / pc_elapsed, 1), "unit": "channel-frames/s",
                      "roofline": _roofline("analyzer_kernel<11>", frame_bytes, pc_kernel_ms, pc_elapsed / steps * 1e3, pc_info["probe"])},
-        "roofline": _roofline("analyzer_frames_kernel<11> (%d frames per launch)" % batch, frame_bytes * batch, kernel_ms,
+        "roofline": _roofline("analyzer_frames_wave_kernel (%d frames per launch)" % batch, frame_bytes * batch, kernel_ms,
                               elapsed / steps * 1e3, tinfo["probe"],
-                              _pmc_traffic("pmc_spectral_latest.json", "analyzer_frames_kernel", batch) if C == 1024 else None,
-                              _issue_side("analyzer_frames_kernel<11>", kernel_ms, batch) if C == 1024 else None,
+                              _pmc_traffic("pmc_spectral_latest.json", "analyzer_frames_wave_kernel", batch) if C == 1024 else None,
+                              _issue_side("analyzer_frames_wave_kernel", kernel_ms, batch) if C == 1024 else None,
                               launch_steps=batch),
         "whole_step": {"algorithmic_bytes": frame_bytes,
                        "achieved_GBps_incl_launch_gaps": round(frame_bytes / (elapsed / steps) / 1e9, 1),

@@ -1260,28 +1260,26 @@ namespace
     // X_A[k] = (Z[k] + conj Z[N-k]) / 2, X_B[k] = (Z[k] - conj Z[N-k]) / 2i, the partner bin by ds_bpermute (lane 64 - l, register
     // 63 - r; lane 0: register (64 - r) & 63), and only the magnitudes of bins 0 .. N/2 are wanted: one forward transform per TWO
     // strobes, no workgroup-wide LDS pass, no barrier behind the tables.  The magnitudes go out RAW (the smoothing walks the planes
-    // in the reduction launch), so the eight waves of a channel's workgroup -- sixteen strobes -- owe each other nothing, two waves
-    // per SIMD: round 5's form of this kernel kept vAmp in registers from strobe to strobe, i.e. ONE wave per channel and SIMD, and
-    // a lone wave issued at half the rate (profiles/r05_experiments/analyzer_frames_wave.txt).
-    // Ring ingest (Analyzer.cpp:371-398): wave p files hops 2p - 1 and 2p (it has them in registers); wave 0, which has no hop -1
-    // to file, takes the call's last block when the count of strobes is even.  The host sends a run this way only while the ring
-    // holds a frame AND the run's hops side by side (no wave overwrites what another still reads).
-    // Same products, another transform and another order of roundings: within 1e-6 of analyzer_kernel<11>, not its bits.
-    constexpr int ANW_WAVES = 8;
-#ifndef MI_ANW_KNOBS
-#define MI_ANW_KNOBS 0
-#endif
-#ifndef MI_ANW_CPOL
-#define MI_ANW_CPOL 2
-#endif
-#ifndef MI_ANW_LPOL
-#define MI_ANW_LPOL 0
-#endif
-#define MI_ANW_LNT ""
+    // in the reduction launch), so the eight waves of a workgroup -- the sixteen strobes of a channel -- owe each other nothing, two
+    // waves per SIMD: round 5's form of this kernel kept vAmp in registers from strobe to strobe, i.e. ONE wave per channel and
+    // SIMD, and a lone wave issued at half the rate (profiles/r05_experiments/analyzer_frames_wave.txt).
+    // One workgroup per CU walks the channels blockIdx.x + i gridDim.x (tables filled once); wave p takes pair p of channel after
+    // channel with the NEXT channel's hops in flight underneath this one's transform: h(2p-2) and h(2p-1) by LDS-DMA into the
+    // wave's exchange area as soon as the transform's one exchange has left it (16-byte pieces: the area's image of a hop is its
+    // samples in order, 64 j + lane = the sample a lane wants in register j), h(2p) into 32 registers.  In-kernel timeline
+    // (tests/experiments/analyzer_wave_probe.hip): a unit never waits for its hops; what a wave spends is its own instructions, a
+    // third of them memory instructions that issue against the queue's back-pressure -- hence wide pieces wherever the layout
+    // allows: the DMA, and the ring ingest (Analyzer.cpp:371-398) of the two hops that lie in the area (wave p files hops 2p - 2
+    // and 2p - 1 from there, 16 bytes per lane; the run's last one or two hops, which no area holds, are shared out among the
+    // eight waves by rows).  Stores are non-temporal (nothing here is read again soon: 92 -> 80 us per launch).
+    // The host sends a run this way only while the ring holds a frame AND the run's hops side by side (no wave overwrites what
+    // another still reads).  Same products, another transform and another order of roundings: within 1e-6 of analyzer_kernel<11>,
+    // not its bits.
+    constexpr int ANW_WAVES = 8, ANW_NT = 2 /* cache policy: non-temporal */;
     __global__ __launch_bounds__(64 * ANW_WAVES, 2)
-    void analyzer_frames_wave_kernel(const an_frames_args fa, size_t in_stride, float *ring, uint32_t buf_size, uint32_t head,
-                                     const uint8_t *__restrict__ flags, const float *__restrict__ wnd, uint32_t amp_stride,
-                                     const float2 *__restrict__ tw, int channels)
+    void analyzer_frames_wave_kernel(const an_frames_args fa, size_t in_stride, int wide /* blocks and rows 16-byte aligned */, float *ring,
+                                     uint32_t buf_size, uint32_t head, const uint8_t *__restrict__ flags, const float *__restrict__ wnd,
+                                     uint32_t amp_stride, const float2 *__restrict__ tw, int channels)
     {
         using namespace mi_fftw;
         constexpr int HALF = R / 2, HOP = N / 2;            // registers of a hop (sample lane + 64 j); samples of a hop
@@ -1306,101 +1304,65 @@ namespace
         int unit_no = 0;
         const int pairs = (fa.frames + 1) / 2;
         auto at = [](__amdgpu_buffer_rsrc_t r, int lane_off, int row_off) -> float {
-            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, MI_ANW_LPOL));
+            return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));
         };
-        // hop q of the call (q >= 0: the caller's block q; q < 0: what the ring holds in front of the head) of channel ch, sample
-        // lane + 64 j.  One lane offset in a VGPR, the row in the scalar offset -- also for the ring unless the hop straddles its
-        // end (once per turn of the ring: offsets per element there)
-        auto load_hop = [&](int ch, int q, float (&v)[HALF]) {
-            if (MI_ANW_KNOBS & 4) { for (int j = 0; j < HALF; ++j) v[j] = float(lane + j + q); return; }
-            if (q >= 0)
-            {
-                const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float)));
-                #pragma unroll
-                for (int j = 0; j < HALF; ++j)
-                    v[j] = at(rin, lane * 4, 256 * j);
-                return;
-            }
+        auto put = [](float v, __amdgpu_buffer_rsrc_t r, int lane_off, int row_off) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, lane_off, row_off, ANW_NT);
+        };
+        // Where hop q of channel ch is read from (q >= 0: the caller's block q; q < 0: the ring in front of the head,
+        // Analyzer.cpp:339-353 with no delay) and where it is filed (the ring behind the head of strobe q, :371-398): a buffer of
+        // the hop's 8 KiB when it lies in one piece -- row j at 256 j, one lane offset in a VGPR and the row in the scalar offset --
+        // or the whole ring and a first cell (the hop straddles the ring's end: once per turn, offsets per element there)
+        struct place { __amdgpu_buffer_rsrc_t rsrc; uint32_t first; bool straight, quads; };
+        auto ring_place = [&](int ch, int64_t cell) -> place {
             float *rbw = ring + size_t(ch) * buf_size;
-            int64_t doff = int64_t(head) + int64_t(q) * HOP;                // Analyzer.cpp:339-353 with no delay
-            while (doff < 0)
-                doff += buf_size;
-            const uint32_t d0 = uint32_t(doff);
-            if (d0 + HOP <= buf_size)
+            while (cell < 0)
+                cell += buf_size;
+            const uint32_t c0 = uint32_t(uint64_t(cell) % buf_size);
+            if (c0 + HOP <= buf_size)
+                return place{mi::wt_buffer(rbw + c0, unsigned(HOP * sizeof(float))), 0u, true, (c0 & 3u) == 0u};      // (rows of the ring start on 16 bytes)
+            return place{mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float))), c0, false, false};
+        };
+        auto source = [&](int ch, int q) -> place {
+            if (q >= 0)
+                return place{mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float))), 0u, true, wide != 0};
+            return ring_place(ch, int64_t(head) + int64_t(q) * HOP);
+        };
+        auto wrapped = [&](uint32_t first, int cell) -> int {             // byte offset of cell first + `cell` of a ring
+            uint32_t c = first + uint32_t(cell);
+            if (c >= buf_size) c -= buf_size;
+            return int(c * sizeof(float));
+        };
+        // rows j0 .. j0 + ROWS - 1 of a hop into registers (sample lane + 64 j), and from registers into the ring
+        auto load_rows = [&](const place &s, int j0, auto &v) {
+            constexpr int ROWS = int(sizeof(v) / sizeof(v[0]));
+            if (s.straight)
             {
-                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + d0, unsigned(HOP * sizeof(float)));
                 #pragma unroll
-                for (int j = 0; j < HALF; ++j)
-                    v[j] = at(rhop, lane * 4, 256 * j);
+                for (int j = 0; j < ROWS; ++j)
+                    v[j] = at(s.rsrc, lane * 4, 256 * (j0 + j));
                 return;
             }
-            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
             int ln = lane;
             asm volatile("" : "+v"(ln));                    // (the wrapped offsets are made here, not ahead of the loops and spilled)
             #pragma unroll
-            for (int j = 0; j < HALF; ++j)
-            {
-                uint32_t i0 = d0 + uint32_t(ln + 64 * j);
-                if (i0 >= buf_size) i0 -= buf_size;
-                v[j] = at(rring, int(i0 * sizeof(float)), 0);
-            }
+            for (int j = 0; j < ROWS; ++j)
+                v[j] = at(s.rsrc, wrapped(s.first, ln + 64 * (j0 + j)), 0);
         };
-        // ... into the ring behind the head of strobe q (Analyzer.cpp:371-398): 256 contiguous bytes per wave instruction
-        auto ingest_hop = [&](int ch, int q, const float (&v)[HALF]) {
-            if ((MI_ANW_KNOBS & 8) && v[0] != 12345.f) return;
-            float *rbw = ring + size_t(ch) * buf_size;
-            const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(q) * HOP) % buf_size);
-            if (h0 + HOP <= buf_size)
+        auto file_rows = [&](const place &d, int j0, const auto &v) {
+            constexpr int ROWS = int(sizeof(v) / sizeof(v[0]));
+            if (d.straight)
             {
-                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + h0, unsigned(HOP * sizeof(float)));
                 #pragma unroll
-                for (int j = 0; j < HALF; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), rhop, lane * 4, 256 * j, MI_ANW_CPOL);
+                for (int j = 0; j < ROWS; ++j)
+                    put(v[j], d.rsrc, lane * 4, 256 * (j0 + j));
                 return;
             }
-            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
             int ln = lane;
             asm volatile("" : "+v"(ln));
             #pragma unroll
-            for (int j = 0; j < HALF; ++j)
-            {
-                uint32_t w0 = h0 + uint32_t(ln + 64 * j);
-                if (w0 >= buf_size) w0 -= buf_size;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v[j]), rring, int(w0 * sizeof(float)), 0, MI_ANW_CPOL);
-            }
-        };
-        // A slice of a hop: rows j0 .. j0 + ROWS - 1 of the 32 (the call's last block when the count of strobes is even -- no pair's
-        // frame holds it -- is filed by all eight waves, four rows each)
-        constexpr int XROWS = HALF / ANW_WAVES;
-        auto load_rows = [&](int ch, int q, int j0, float (&e)[XROWS]) {
-            if (MI_ANW_KNOBS & 12) return;
-            const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float)));
-            #pragma unroll
-            for (int j = 0; j < XROWS; ++j)
-                e[j] = at(rin, lane * 4, 256 * (j0 + j));
-        };
-        auto file_rows = [&](int ch, int q, int j0, const float (&e)[XROWS]) {
-            if (MI_ANW_KNOBS & 12) return;
-            float *rbw = ring + size_t(ch) * buf_size;
-            const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(q) * HOP) % buf_size);
-            if (h0 + HOP <= buf_size)
-            {
-                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + h0, unsigned(HOP * sizeof(float)));
-                #pragma unroll
-                for (int j = 0; j < XROWS; ++j)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[j]), rhop, lane * 4, 256 * (j0 + j), MI_ANW_CPOL);
-                return;
-            }
-            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
-            int ln = lane;
-            asm volatile("" : "+v"(ln));
-            #pragma unroll
-            for (int j = 0; j < XROWS; ++j)
-            {
-                uint32_t w0 = h0 + uint32_t(ln + 64 * (j0 + j));
-                if (w0 >= buf_size) w0 -= buf_size;
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e[j]), rring, int(w0 * sizeof(float)), 0, MI_ANW_CPOL);
-            }
+            for (int j = 0; j < ROWS; ++j)
+                put(v[j], d.rsrc, wrapped(d.first, ln + 64 * (j0 + j)), 0);
         };
         auto flags_at = [&](int i) -> uint32_t {           // channel i of the walk (its flags in lane i & 63 of flv)
             if ((i & 63) == 0 && i > 0)
@@ -1417,8 +1379,8 @@ namespace
             for (int q = wv; q < fa.frames; q += ANW_WAVES)
             {
                 float v[HALF];
-                load_hop(ch, q, v);
-                ingest_hop(ch, q, v);
+                load_rows(source(ch, q), 0, v);
+                file_rows(ring_place(ch, int64_t(head) + int64_t(q) * HOP), 0, v);
             }
         }
         if (walk > 64)
@@ -1428,76 +1390,123 @@ namespace
                 ++i;
             return i;
         };
-        // A wave takes pair p = wv of channel after channel.  Strobes 2p and 2p + 1: A = [h(2p-2) | h(2p-1)], B = [h(2p-1) | h(2p)].
-        // The hops of the NEXT channel's pair are asked for underneath this one's transform: h(2p) into 32 registers in front of
-        // it, h(2p-2) and h(2p-1) by LDS-DMA into the wave's exchange area (row j of a hop = 256 bytes at 256 j: lane order is
-        // sample order) as soon as the transform's one exchange has left it -- no registers, and a wave has its 24 KiB of
-        // requests in flight while it computes.  (Written in asm: the compiler knows nothing of these loads, the wait at the head
-        // of a unit is ours; vmcnt counts stores as well on this part, so the wait is for everything.)
+        // The run's last hops -- 2 (pairs - 1) and, with an even count of strobes, the one behind it -- lie in no wave's area: their
+        // 32 or 64 rows are filed by the eight waves, XROWS each (asked for with a unit's third hop, filed by the unit behind it)
+        const int first_loose = 2 * (pairs - 1), loose_rows = (fa.frames - first_loose) * HALF / ANW_WAVES;          // 4 or 8
+        constexpr int XROWS = 2 * HALF / ANW_WAVES;
+        const int loose_q = first_loose + (wv * loose_rows) / HALF, loose_j0 = (wv * loose_rows) % HALF;
+        auto load_loose = [&](int ch, float (&e)[XROWS]) {
+            const place s = source(ch, loose_q);
+            float (&lo)[XROWS / 2] = reinterpret_cast<float (&)[XROWS / 2]>(e[0]);
+            float (&hi)[XROWS / 2] = reinterpret_cast<float (&)[XROWS / 2]>(e[XROWS / 2]);
+            load_rows(s, loose_j0, lo);
+            if (loose_rows == XROWS)
+                load_rows(s, loose_j0 + XROWS / 2, hi);
+        };
+        auto file_loose = [&](int ch, const float (&e)[XROWS]) {
+            const place d = ring_place(ch, int64_t(head) + int64_t(loose_q) * HOP);
+            const float (&lo)[XROWS / 2] = reinterpret_cast<const float (&)[XROWS / 2]>(e[0]);
+            const float (&hi)[XROWS / 2] = reinterpret_cast<const float (&)[XROWS / 2]>(e[XROWS / 2]);
+            file_rows(d, loose_j0, lo);
+            if (loose_rows == XROWS)
+                file_rows(d, loose_j0 + XROWS / 2, hi);
+        };
         const int p = wv;
         if (p >= pairs)
+        {
+            // (a run of fewer than fifteen strobes: a wave without a pair still files its share of the last hops)
+            for (int i = next_active(0); i < walk; i = next_active(i + 1))
+            {
+                const int ch = int(blockIdx.x) + i * int(gridDim.x);
+                float e[XROWS];
+                load_loose(ch, e);
+                file_loose(ch, e);
+            }
             return;
+        }
         const bool second = 2 * p + 1 < fa.frames;
-        const bool even = (fa.frames & 1) == 0;
         float *const area = areas[wv];
         const unsigned area_at = unsigned(uintptr_t(area));                // LDS byte address (wave-uniform)
-        // sixteen rows (4 KiB) of a hop: memory rsrc + lane * 4 + soff + 256 j -> LDS m0v + lane * 4 + 256 j
-        auto dma16 = [&](__amdgpu_buffer_rsrc_t rsrc, int soff, unsigned m0v) __attribute__((always_inline)) {
+        // LDS-DMA, written in asm: the compiler knows nothing of these loads (the wait at the head of a unit is ours).  A piece:
+        // memory rsrc + voff + soff + offset -> LDS m0 + lane x (4 | 16) + offset; 4 KiB per statement.
+        auto dma_quads = [&](__amdgpu_buffer_rsrc_t rsrc, int soff, unsigned m0v) __attribute__((always_inline)) {
             unsigned keep;
-            const int voff = lane * 4;
+            const int voff = lane * 16;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
-                         "buffer_load_dword %1, %2, %3 offen lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:256 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:512 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:768 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:1024 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:1280 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:1536 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:1792 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:2048 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:2304 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:2560 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:2816 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:3072 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:3328 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:3584 lds" MI_ANW_LNT "\n\t"
-                         "buffer_load_dword %1, %2, %3 offen offset:3840 lds" MI_ANW_LNT "\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen offset:1024 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen offset:2048 lds\n\t"
+                         "buffer_load_dwordx4 %1, %2, %3 offen offset:3072 lds\n\t"
                          "s_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(m0v) : "memory");
         };
-        // hop q of channel ch -> LDS at byte address `to` (8 KiB)
+        auto dma_words = [&](__amdgpu_buffer_rsrc_t rsrc, int soff, unsigned m0v) __attribute__((always_inline)) {
+            unsigned keep;
+            const int voff = lane * 4;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\t"
+                         "buffer_load_dword %1, %2, %3 offen lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:256 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:512 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:768 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1024 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1280 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1536 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:1792 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2048 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2304 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2560 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:2816 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3072 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3328 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3584 lds\n\t"
+                         "buffer_load_dword %1, %2, %3 offen offset:3840 lds\n\t"
+                         "s_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(voff), "s"(rsrc), "s"(soff), "s"(m0v) : "memory");
+        };
+        // hop q of channel ch -> the 8 KiB of LDS at byte address `to`, its samples in order
         auto dma_hop = [&](int ch, int q, unsigned to) {
-            if (MI_ANW_KNOBS & 4) return;
-            if (q >= 0)
+            const place s = source(ch, q);
+            if (s.straight && s.quads)
             {
-                const __amdgpu_buffer_rsrc_t rin = mi::wt_buffer(const_cast<float *>(fa.in[q]) + size_t(ch) * in_stride, unsigned(HOP * sizeof(float)));
-                dma16(rin, 0, to);
-                dma16(rin, 4096, to + 4096);
+                dma_quads(s.rsrc, 0, to);
+                dma_quads(s.rsrc, 4096, to + 4096);
+            }
+            else if (s.straight)
+            {
+                dma_words(s.rsrc, 0, to);
+                dma_words(s.rsrc, 4096, to + 4096);
+            }
+            else
+                for (int j = 0; j < HALF; ++j)
+                {
+                    const int voff = wrapped(s.first, lane + 64 * j);
+                    const unsigned m0v = to + 256u * unsigned(j);
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(voff), "s"(s.rsrc), "s"(m0v) : "memory");
+                }
+        };
+        // ... and from the area into the ring: hop q (its image at word `from` of the area), 16 bytes per lane where its place allows
+        auto file_area = [&](int ch, int q, int from) {
+            const place d = ring_place(ch, int64_t(head) + int64_t(q) * HOP);
+            if (d.straight && d.quads)
+            {
+                #pragma unroll
+                for (int k = 0; k < HOP / 256; ++k)
+                {
+                    const float4 v = *reinterpret_cast<const float4 *>(area + from + 256 * k + 4 * lane);
+                    const mi::u32x4 u = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
+                    __builtin_amdgcn_raw_buffer_store_b128(u, d.rsrc, lane * 16, 1024 * k, ANW_NT);
+                }
                 return;
             }
-            float *rbw = ring + size_t(ch) * buf_size;
-            int64_t doff = int64_t(head) + int64_t(q) * HOP;                // Analyzer.cpp:339-353 with no delay
-            while (doff < 0)
-                doff += buf_size;
-            const uint32_t d0 = uint32_t(doff);
-            if (d0 + HOP <= buf_size)
-            {
-                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(rbw + d0, unsigned(HOP * sizeof(float)));
-                dma16(rhop, 0, to);
-                dma16(rhop, 4096, to + 4096);
-                return;
-            }
-            // the hop straddles the ring's end (once per turn of the ring): a wrapped offset per row
-            const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
             for (int j = 0; j < HALF; ++j)
             {
-                uint32_t i0 = d0 + uint32_t(lane + 64 * j);
-                if (i0 >= buf_size) i0 -= buf_size;
-                const int voff = int(i0 * sizeof(float));
-                const unsigned m0v = to + 256u * unsigned(j);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds" MI_ANW_LNT "\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(voff), "s"(rring), "s"(m0v) : "memory");
+                const float v = area[from + 64 * j + lane];
+                if (d.straight)
+                    put(v, d.rsrc, lane * 4, 256 * j);
+                else
+                    put(v, d.rsrc, wrapped(d.first, lane + 64 * j), 0);
             }
         };
         int i = next_active(0);
@@ -1507,66 +1516,48 @@ namespace
             const int ch = int(blockIdx.x) + i * int(gridDim.x);
             dma_hop(ch, 2 * p - 2, area_at);
             dma_hop(ch, 2 * p - 1, area_at + unsigned(HOP * sizeof(float)));
-            load_hop(ch, 2 * p, h2);
-            if (even)
-                load_rows(ch, fa.frames - 1, XROWS * wv, e);
+            load_rows(source(ch, 2 * p), 0, h2);
+            load_loose(ch, e);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         while (i < walk)
         {
             const int ch = int(blockIdx.x) + i * int(gridDim.x);
             v2f x[R];
-            // the unit's three hops are here: every load is older than the 66 stores of the rows that followed them (in-order
-            // completion: all but the newest 63 operations done = every load done)
+            // The unit's hops are here: every load is older than the 66 stores of the rows that followed them (completion in
+            // order: all but the newest 63 operations done = every load done)
             asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
             MI_WPROBE(unit_no * 6 + 0);
+            // strobes 2p and 2p + 1: A = [h(2p-2) | h(2p-1)], B = [h(2p-1) | h(2p)], times the window
+            #pragma unroll
+            for (int j = 0; j < HALF; ++j)
             {
-                // the window's products; hop 2p - 1 goes on into the ring from the registers it passes through
-                float *rbw = ring + size_t(ch) * buf_size;
-                const uint32_t g0 = uint32_t((uint64_t(head) + uint64_t(buf_size) + uint64_t(int64_t(2 * p - 1) * HOP)) % buf_size);
-                const bool file1 = p > 0 && !(MI_ANW_KNOBS & 8), straight = g0 + HOP <= buf_size;
-                const __amdgpu_buffer_rsrc_t rhop = mi::wt_buffer(straight ? rbw + g0 : rbw, (file1 && straight) ? unsigned(HOP * sizeof(float)) : 0u);
-                #pragma unroll
-                for (int j = 0; j < HALF; ++j)
-                {
-                    const float w0 = wnd_l[lane + 64 * j], w1 = wnd_l[lane + 64 * (j + HALF)];
-                    const float a = area[64 * j + lane], b = area[HOP + 64 * j + lane];
-                    x[j] = v2f{a * w0, b * w0};
-                    x[j + HALF] = v2f{b * w1, h2[j] * w1};
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(b), rhop, lane * 4, 256 * j, MI_ANW_CPOL);
-                }
-                if (file1 && !straight)
-                {
-                    // (the hop straddles the ring's end: once more out of the area, offsets per element)
-                    const __amdgpu_buffer_rsrc_t rring = mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float)));
-                    for (int j = 0; j < HALF; ++j)
-                    {
-                        uint32_t w0 = g0 + uint32_t(lane + 64 * j);
-                        if (w0 >= buf_size) w0 -= buf_size;
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(area[HOP + 64 * j + lane]), rring, int(w0 * sizeof(float)), 0, MI_ANW_CPOL);
-                    }
-                }
-                ingest_hop(ch, 2 * p, h2);
+                const float w0 = wnd_l[lane + 64 * j], w1 = wnd_l[lane + 64 * (j + HALF)];
+                const float a = area[64 * j + lane], b = area[HOP + 64 * j + lane];
+                x[j] = v2f{a * w0, b * w0};
+                x[j + HALF] = v2f{b * w1, h2[j] * w1};
+            }
+            if (p > 0)
+            {
+                file_area(ch, 2 * p - 2, 0);
+                file_area(ch, 2 * p - 1, HOP);
             }
             MI_WPROBE(unit_no * 6 + 1);
-            if (even)
-                file_rows(ch, fa.frames - 1, XROWS * wv, e);
+            file_loose(ch, e);
             MI_WPROBE(unit_no * 6 + 2);
             i = next_active(i + 1);
             const int chn = int(blockIdx.x) + i * int(gridDim.x);
-            if (!(MI_ANW_KNOBS & 1))
             fft4096_t<false>(x, pl, area, lane, [&]() {
-                // the exchange is through: its area takes the next unit's first two hops, 32 registers the third (the
-                // transform's first half has none to spare)
+                // the exchange is through (and the area's hops filed: the LDS pipe takes a wave's accesses in order): the area takes
+                // the next unit's first two hops, 32 registers the third (the transform's first half has none to spare)
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 MI_WPROBE(unit_no * 6 + 3);
                 if (i < walk)
                 {
                     dma_hop(chn, 2 * p - 2, area_at);
                     dma_hop(chn, 2 * p - 1, area_at + unsigned(HOP * sizeof(float)));
-                    load_hop(chn, 2 * p, h2);
-                    if (even)
-                        load_rows(chn, fa.frames - 1, XROWS * wv, e);
+                    load_rows(source(chn, 2 * p), 0, h2);
+                    load_loose(chn, e);
                 }
             });
             MI_WPROBE(unit_no * 6 + 4);
@@ -1582,7 +1573,7 @@ namespace
                 ma = 0.5f * mag_root(ex * ex + ey * ey);
                 mb = 0.5f * mag_root(ox * ox + oy * oy);
             };
-            constexpr int CH = 8;                           // partners asked for together (registers: the next channel's hops are waiting)
+            constexpr int CH = 8;                           // partners asked for together (registers: the next channel's hop is waiting)
             #pragma unroll
             for (int r0 = 0; r0 < HALF; r0 += CH)
             {
@@ -1598,16 +1589,16 @@ namespace
                     const v2f pz = v2f{l0 ? own.x : part[rr].x, l0 ? own.y : part[rr].y};
                     float ma, mb;
                     mags(x[r], pz, ma, mb);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma), row_a, lane * 4, 256 * r, MI_ANW_CPOL);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb), row_b, lane * 4, 256 * r, MI_ANW_CPOL);
+                    put(ma, row_a, lane * 4, 256 * r);
+                    put(mb, row_b, lane * 4, 256 * r);
                 }
             }
             if (l0)                                         // bin N / 2: lane 0's register HALF, its own partner
             {
                 float ma, mb;
                 mags(x[HALF], x[HALF], ma, mb);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ma), row_a, 4 * HOP, 0, MI_ANW_CPOL);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(mb), row_b, 4 * HOP, 0, MI_ANW_CPOL);
+                put(ma, row_a, 4 * HOP, 0);
+                put(mb, row_b, 4 * HOP, 0);
             }
             MI_WPROBE(unit_no * 6 + 5);
             ++unit_no;
@@ -1628,10 +1619,7 @@ namespace
     // sums' bits depend on the magnitudes alone.  SMR_AHEAD channels' rows (17 loads each) are in flight together -- a thread's
     // channels are a chain of round trips otherwise; nothing is loaded under a condition a load decides (a frozen or inactive
     // channel's planes are read and not used).
-    #ifndef MI_SMR_AHEAD
-#define MI_SMR_AHEAD 4
-#endif
-    constexpr uint32_t SMR_BINS = 64, SMR_BLOCKS = 4, SMR_AHEAD = MI_SMR_AHEAD;
+        constexpr uint32_t SMR_BINS = 64, SMR_BLOCKS = 4, SMR_AHEAD = 4;      // (2, 4, 8 channels ahead measure 39, 38, 43 us at C5)
     struct smooth_planes { const float *raw[AN_FRAMES_MAX]; };
     template <bool FULL /* all AN_FRAMES_MAX strobes */>
     __global__ __launch_bounds__(64 * SMR_BLOCKS)
@@ -3150,8 +3138,11 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
                         n = 256;
                     return uint32_t(n);
                 }();
+                bool wide = (in_stride % 4) == 0;
+                for (size_t k = 0; k < cnt; ++k)
+                    wide = wide && (reinterpret_cast<uintptr_t>(in[f + k]) % 16) == 0;
                 MI_LAUNCH(analyzer_frames_wave_kernel, dim3(b->channels < cus ? b->channels : cus), dim3(64 * ANW_WAVES), 0, st, ev0, ev1,
-                          fa, in_stride, b->d_ring, b->buf_size, b->head, b->d_flags, b->d_wnd, b->bins_stride, b->d_tw, int(b->channels));
+                          fa, in_stride, wide ? 1 : 0, b->d_ring, b->buf_size, b->head, b->d_flags, b->d_wnd, b->bins_stride, b->d_tw, int(b->channels));
             }
             else
             {

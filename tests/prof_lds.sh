@@ -17,7 +17,7 @@ done
 python3 - "$O" "$R/gpurun_out/profiles_$TAG/${TAG}_fft_lds_pmc_sq.json" <<'PY'
 import csv, glob, json, os, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
-KEEP = ("conv_frames_kernel", "conv_frames_wave_kernel", "analyzer_frames_kernel", "stft_stream_blocks_kernel", "stft_wave_blocks_kernel", "splitter_hops_blocks_kernel", "splitter_wave_blocks_kernel")
+KEEP = ("conv_frames_kernel", "conv_frames_wave_kernel", "analyzer_frames_wave_kernel", "bin_smooth_reduce_kernel", "stft_stream_blocks_kernel", "stft_wave_blocks_kernel", "splitter_hops_blocks_kernel", "splitter_wave_blocks_kernel")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True):
     for r in csv.DictReader(open(fn)):

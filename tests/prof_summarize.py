@@ -13,7 +13,7 @@ import os
 import sys
 
 KERNELS = {"biquad": "biquad_stream_kernel", "convolver": "conv_batch_tail_kernel<16,", "equalizer": "conv_frames_wave_kernel",
-           "spectral": "analyzer_frames_kernel"}
+           "spectral": "analyzer_frames_wave_kernel"}
 # second kernels of a workload's PMC passes (bench.py's per_call legs): summary name -> (workload, kernel)
 EXTRA = {"convolver_step": ("convolver", "conv_step_kernel<12, false>")}
 # the PMC passes run `bench.py --steps 50`: the headline's launch (biquad_stream_kernel) then carries 50 blocks

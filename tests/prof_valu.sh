@@ -16,7 +16,7 @@ import csv, glob, json, os, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
 # units (blocks / frames) a launch of the kernel carries in these passes (--conv-steps 128)
 UNITS = {"conv_frames_kernel": 128, "conv_frames_wave_kernel": 128, "conv_batch_tail_kernel": 16, "conv_batch_forward_kernel": 16, "conv_batch_frames_kernel": 16,
-         "analyzer_frames_kernel": 16, "bin_reduce_frames_kernel": 16, "stft_stream_blocks_kernel": 64, "stft_wave_blocks_kernel": 64, "splitter_hops_blocks_kernel": 64, "splitter_wave_blocks_kernel": 64,
+         "analyzer_frames_wave_kernel": 16, "bin_smooth_reduce_kernel": 16, "bin_reduce_frames_kernel": 16, "stft_stream_blocks_kernel": 64, "stft_wave_blocks_kernel": 64, "splitter_hops_blocks_kernel": 64, "splitter_wave_blocks_kernel": 64,
          "biquad_stream_chain_kernel": 64}
 out = {"note": "rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR, one pass per bench workload "
                "(tests/prof_valu.sh: bench.py --workload W --conv-steps 128), averages per dispatch of the smallest grid a kernel ran with "
