@@ -73,6 +73,12 @@ int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
  */
 int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
 /*
+ * The hot-path kernel the calling thread launched last (its name as the library spells it, template arguments included;
+ * "" before the first one).  For tests and profiles that must know WHICH launch a call took -- a run of blocks riding its
+ * one-launch kernel or the block-by-block fallback -- not only that the result is right.  No reference counterpart.
+ */
+const char *mi_dspu_last_launch(void);
+/*
  * hipGraph helpers for launch-bound inner loops: a run of steady-state *_process() calls on `stream` is captured once
  * and replayed (hipStreamBeginCapture / hipStreamEndCapture + hipGraphInstantiate / hipGraphLaunch).
  * begin: `stream` must be a created (non-NULL) stream.  end: returns an executable graph handle.

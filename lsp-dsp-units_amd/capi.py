@@ -56,6 +56,7 @@ PROTOTYPES = {
     "mi_dspu_event_synchronize": (c_int, [c_void_p]),
     "mi_dspu_event_elapsed_ms": (c_int, [POINTER(c_float), c_void_p, c_void_p]),
     "mi_dspu_profile_next_launch": (c_int, [c_void_p, c_void_p]),
+    "mi_dspu_last_launch": (c_char_p, []),
     "mi_dspu_graph_begin_capture": (c_int, [c_void_p]),
     "mi_dspu_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi_dspu_graph_launch": (c_int, [c_void_p, c_void_p]),

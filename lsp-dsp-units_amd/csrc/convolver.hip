@@ -1753,6 +1753,7 @@ struct mi_convolver_bank
     int         cus = 256;          // compute units of the device the bank lives on
     bool        one_launch = true;  // whole-frame steps as conv_step_kernel (gfx950, not switched off) or as two launches
     float2     *d_H = nullptr, *d_ring = nullptr, *d_yt = nullptr;
+    float2     *d_ring_before = nullptr;    // the ring the bank was made with, once its first batch of frames has grown it (kept: see there)
     float      *d_acc = nullptr, *d_frame = nullptr, *d_h0 = nullptr;
     float2     *d_yts = nullptr;                        // [channels][BATCH_MAX][B]: what the inverse transforms of a batch of frames take (process_blocks)
     float      *d_acc_new = nullptr;                    // [channels][B]: the accumulator a batch leaves, on its way into d_acc
@@ -1918,9 +1919,11 @@ namespace
                 MI_HIP_CHECK(e);
             }
             // A graph captured on this bank earlier holds the old ring, its size and slot in its launches: the epoch tells
-            // mi_dspu_graph_launch to refuse it (MI_ESTATE) -- so the old ring can go (the stream has just been drained).
+            // mi_dspu_graph_launch to refuse it (MI_ESTATE).  The old ring itself stays allocated until the bank goes (one
+            // allocation, once per bank): a graph launched some other way, or one still in flight on another stream, then
+            // reads and writes memory that is still the bank's instead of freed addresses.
             mi::bank_epoch_bump(b);
-            (void)hipFree(b->d_ring);
+            b->d_ring_before = b->d_ring;
             b->d_ring = grown;
             b->R = newR;
             b->slot = newR - 1;
@@ -2482,7 +2485,7 @@ int mi_convolver_bank_destroy(mi_convolver_bank_t *b)
         (void)hipFree(r.h0);
         (void)hipFree(r.W);
     }
-    (void)hipFree(b->d_ring); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
+    (void)hipFree(b->d_ring); (void)hipFree(b->d_ring_before); (void)hipFree(b->d_yt); (void)hipFree(b->d_acc); (void)hipFree(b->d_frame);
     (void)hipFree(b->d_xmask); (void)hipFree(b->d_only); (void)hipFree(b->d_sync);
     (void)hipFree(b->d_Hs); (void)hipFree(b->d_sring);
     (void)hipFree(b->d_yts); (void)hipFree(b->d_acc_new);

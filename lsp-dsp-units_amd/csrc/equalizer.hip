@@ -571,7 +571,7 @@ int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *b, float *const *out, 
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);
         return a0 < b0 + qn && b0 < a0 + pn;
     };
-    if (b->mode == MI_EQM_IIR)                              // the cascade of all filters' sections: the biquad bank's runs of blocks
+    if (b->mode == MI_EQM_IIR || b->mode == MI_EQM_SPM)     // the banks with runs of blocks of their own (SPM was shut out)
     {
         const int rc = mi::capture_touch(st, b, "equalizer", equalizer_bank_positions);
         if (rc != MI_OK)

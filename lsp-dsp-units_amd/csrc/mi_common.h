@@ -23,6 +23,9 @@ namespace mi
     // Events armed by mi_dspu_profile_next_launch(); the next hot-path kernel launch of this thread
     // consumes them (hipExtLaunchKernelGGL records them at the kernel's own begin/end).
     void        take_profile_events(hipEvent_t *start, hipEvent_t *stop);
+    // the hot-path kernel the calling thread launched last (MI_LAUNCH notes its name): mi_dspu_last_launch(), so that a test can
+    // tell WHICH launch a call took, not only that its result is right
+    void        note_launch(const char *kernel);
 
     // hipGraph capture of a bank that keeps ring positions on the host (runtime.hip): called at the top of
     // its process() with a function that packs those positions; on a stream that is being captured the positions are
@@ -44,6 +47,7 @@ namespace mi
     // process() call can be captured into a hipGraph.
     #define MI_LAUNCH(kernel, grid, block, lds, st, ev0, ev1, ...) \
         do { \
+            ::mi::note_launch(#kernel); \
             if ((ev0) != nullptr || (ev1) != nullptr) \
                 hipExtLaunchKernelGGL(kernel, grid, block, lds, st, ev0, ev1, 0, __VA_ARGS__); \
             else \

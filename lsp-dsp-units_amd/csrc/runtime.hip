@@ -22,6 +22,9 @@ namespace mi
     }
     static thread_local hipEvent_t tl_start = nullptr, tl_stop = nullptr;
 
+    static thread_local const char *tl_last_launch = "";
+    void note_launch(const char *kernel) { tl_last_launch = kernel; }
+
     void take_profile_events(hipEvent_t *start, hipEvent_t *stop)
     {
         *start = tl_start;
@@ -95,6 +98,8 @@ int mi_dspu_profile_next_launch(void *start_event, void *stop_event)
     return MI_OK;
 }
 
+
+const char *mi_dspu_last_launch(void) { return mi::tl_last_launch; }
 
 int mi_dspu_abi_version(void) { return MI_DSPU_ABI_VERSION; }
 

@@ -1432,17 +1432,33 @@ static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, siz
     waves = waves && nb >= 1;
     if (waves)
     {
-        std::vector<std::pair<uintptr_t, uintptr_t>> iv;
-        const size_t ob = ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float);
+        // Every output of the run apart from every other, ROW BY ROW: an output is `channels` rows of `count` samples, out_stride
+        // apart -- the column slices of one [channels][blocks x count] buffer (what a long process() call hands over) interleave
+        // without touching, although their whole spans overlap (the span test sent every such call to the workgroup
+        // kernels).  Rows a + c S and b + c' S meet iff |(b - a) + k S| < L for a k with |k| < channels.
+        std::vector<uintptr_t> outs_;
         for (size_t q = 0; q < run; ++q)
             for (uint32_t i = 0; i < nb; ++i)
-            {
-                const uintptr_t p = reinterpret_cast<uintptr_t>(tab.out[q * nh + wb.handler[i]]);
-                iv.emplace_back(p, p + ob);
-            }
-        std::sort(iv.begin(), iv.end());
-        for (size_t i = 1; i < iv.size() && waves; ++i)
-            waves = iv[i].first >= iv[i - 1].second;    // (outputs against inputs: the run was formed that way)
+                outs_.push_back(reinterpret_cast<uintptr_t>(tab.out[q * nh + wb.handler[i]]));
+        const int64_t S = int64_t(out_stride * sizeof(float)), L = int64_t(count * sizeof(float)), C1 = int64_t(b->channels) - 1;
+        auto meet = [&](uintptr_t a, uintptr_t c) -> bool {
+            const int64_t d = int64_t(c) - int64_t(a);
+            if (S <= 0 || C1 == 0)
+                return d < L && -d < L;
+            int64_t k0 = d / S;
+            if (d - k0 * S < 0)
+                --k0;                                       // floor
+            const int64_t m = d - k0 * S;                   // 0 <= m < S: row c' of one lies m bytes behind row c' + k0 of the other
+            return (m < L && k0 <= C1 && -k0 <= C1) || (S - m < L && k0 + 1 <= C1 && -(k0 + 1) <= C1);
+        };
+        std::sort(outs_.begin(), outs_.end());
+        for (size_t i = 1; i < outs_.size() && waves; ++i)
+            waves = outs_[i] != outs_[i - 1];
+        // (sorted: an output can only meet the ones that start within its own span)
+        const uintptr_t span = uintptr_t(C1 * S + L);
+        for (size_t i = 0; i < outs_.size() && waves; ++i)
+            for (size_t j = i + 1; j < outs_.size() && waves && outs_[j] < outs_[i] + span; ++j)
+                waves = !meet(outs_[i], outs_[j]);          // (outputs against inputs: the run was formed that way)
     }
     if (!waves)
         return 0;

@@ -81,9 +81,17 @@ def library_comm(mi, group=None):
     import threading
     result = {}
 
+    # (HIP's current device is per thread and a new thread starts on device 0: the device the main thread works on is taken
+    # here and selected again inside the thread -- ncclCommInitRank binds to the calling thread's device)
+    dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+
     def join():
         try:
+            if torch.cuda.is_available():
+                torch.cuda.set_device(dev)
+            mi.check(mi.lib.mi_dspu_set_device(dev))
             result["comm"] = mi.Comm(box[0], world, rank)
+            result["device"] = dev
         except Exception as e:
             result["error"] = e
     th = threading.Thread(target=join, daemon=True)

@@ -11,6 +11,11 @@ def device_count():
     return int(lib.mi_dspu_device_count())
 
 
+def last_launch():
+    """The hot-path kernel this thread launched last (mi_dspu_last_launch): which launch a call took."""
+    return (lib.mi_dspu_last_launch() or b"").decode()
+
+
 def _ptr(x):
     """Device address of a DeviceBuffer, a torch tensor or a raw int."""
     if isinstance(x, DeviceBuffer):

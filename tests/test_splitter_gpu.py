@@ -512,6 +512,12 @@ def test_long_call_at_rank_12_rides_the_wave_kernel(gpu):
         d = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos:pos + n]))
         outs = [gpu.DeviceBuffer((C, n)) for _ in range(bands)]
         bank.process(outs, d, n)
+        # (which launch the call took: the column slices of a call's buffers interleave row by row -- ADVICE r05 found them
+        # refused as overlapping and this test green on the workgroup kernels)
+        # (the 17-block call finds the bank on a frame boundary; the 9-block one behind the 300-sample call does not and stays
+        # on the workgroup kernels, as does every call when MI_SPLITTER_LDS is set)
+        if n == 17 * N and os.environ.get("MI_SPLITTER_LDS") is None:
+            assert gpu.last_launch().startswith("(splitter_wave_blocks_kernel"), (n, gpu.last_launch())
         for i in range(bands):
             got[i].append(outs[i].download())
         pos += n
