@@ -1234,6 +1234,11 @@ def compact_line(full, detail_path=None):
     if pc:
         line["per_call"] = {"value": pc.get("value"), "ms_per_step": pc.get("ms_per_step"),
                             "frac": (pc.get("roofline") or {}).get("frac", pc.get("whole_step_frac"))}
+    em = full.get("exact_mode")
+    if em:
+        line["exact_mode"] = {"value": em.get("value"), "ms_per_step": em.get("ms_per_step"), "frac": em.get("frac")}
+    if full.get("headline_definition_changed_in"):
+        line["headline_definition_changed_in"] = full["headline_definition_changed_in"]
     for name in ("convolver", "equalizer", "spectral"):
         if full.get(name):
             line[name] = _short_sub(full[name])
@@ -1249,7 +1254,7 @@ def compact_line(full, detail_path=None):
     if detail_path:
         line["detail"] = detail_path
     # never over the limit: shed the optional parts in order of (un)importance
-    for drop in (("next_rows",), ("timing",), ("per_call",), ("equalizer", "cpu_baseline"), ("spectral", "cpu_baseline"),
+    for drop in (("next_rows",), ("timing",), ("per_call",), ("exact_mode",), ("equalizer", "cpu_baseline"), ("spectral", "cpu_baseline"),
                  ("convolver", "cpu_baseline"), ("spectral",), ("equalizer",), ("convolver",), ("cpu_baseline", "sample")):
         if len(json.dumps(line)) <= LINE_LIMIT:
             break
@@ -1407,6 +1412,22 @@ def main():
                                                          regions=max(3, min(regions, 101) // 5), stream=stream, graph=True)
         per_call = (pc_elapsed, pc_kernel_ms, pc_info)
 
+    # the bank's exact mode (mi_biquad_bank_set_exact: the reference's serial recurrence, bit for bit) on the same blocks, one
+    # launch per block -- reported beside `value`, never part of it
+    exact_mode = None
+    if args.launch == "blocks" and hasattr(mi.lib, "mi_biquad_bank_set_exact"):
+        bank.set_exact(True)
+        reps = 16
+        for i in range(3):
+            step(i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(reps):
+            step(i)
+        stream.synchronize()
+        exact_mode = (time.perf_counter() - t0) / reps
+        bank.set_exact(False)
+
     # sanity: the output of the last step is finite and non-trivial
     chk = yout[(args.warmup + args.steps - 1) % ring]
     assert bool(torch.isfinite(chk).all()) and float(chk.abs().max()) > 0.0
@@ -1466,6 +1487,15 @@ def main():
                 "roofline": _roofline("biquad_bank_kernel<16,2>", alg_bytes, pk, pe / args.steps * 1e3, pinfo["probe"], None,
                                       _biquad_issue_side(pk, C, n, coef.shape[1], 1, "r05_biquad_pmc_sq.json")),
             }
+        if exact_mode is not None:
+            line["exact_mode"] = {
+                "what": "mi_biquad_bank_set_exact(1): FilterBank::process's serial recurrence, a section per lane -- the reference's bits "
+                        "(tests/test_biquad_gpu.py::test_c2_full_size_all_channels_exact_mode: 0 of 65 536 channel-blocks differ); one launch per block",
+                "value": round(samples_per_step / exact_mode / 1e6, 1), "unit": "Msamples/s", "ms_per_step": round(exact_mode * 1e3, 5),
+                "frac": round(alg_bytes / exact_mode / 1e9 / HBM_PEAK_GBS, 4)}
+        # `value` counts the K blocks of a region as ONE call since round 4 (288 K -> 528 K Msamples/s between rounds 3 and 5 is
+        # that change of what is measured; the launch per block -- per_call -- has been 285 K since round 2)
+        line["headline_definition_changed_in"] = "r04"
         if not args.no_cpu_baseline and world == 1:         # the CPU figure is a 1-process measurement (rank 0 at N = 1 only)
             line["cpu_baseline"] = cpu_baseline_biquad(coef, n)
 

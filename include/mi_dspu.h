@@ -145,6 +145,20 @@ int mi_biquad_bank_size(const mi_biquad_bank_t *bank, uint32_t channel, uint32_t
  * written -- what a caller gets by not calling FilterBank::process() for that object (the meters do this for disabled
  * channels, LoudnessMeter.cpp:420-422, ILUFSMeter.cpp:370). */
 int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *bank, uint32_t channel, int enabled);
+/*
+ * The bank's arithmetic.  0 (default): the time-parallel kernels -- the reference's recurrence inside chunks of 16 samples,
+ * the chunks joined by a scan: the same filter in another order of roundings, within the recursion's own float32 noise of the
+ * reference's output (DESIGN.md section 4 states the bound), 550 000 Msamples/s at 1024 channels x 8 sections.
+ * 1: FilterBank::process's serial recurrence (/root/reference/src/main/filters/FilterBank.cpp:256-291; lsp-dsp-lib's
+ * biquad_process_x1 form, every product and sum rounded on its own) sample after sample, a section per lane: the reference's
+ * output and filter memory BIT FOR BIT, at the price of the recursion's latency chain (19 000 Msamples/s at that size).
+ * The filter memory is the same in both modes: calls may alternate.  process(), process_blocks() and impulse_response()
+ * follow the mode; the meters' fused sums (LoudnessMeter / ILUFSMeter) keep the fast kernels.
+ * mi_dspu_set_exact_iir_default: the mode banks created from now on start in (process-wide; how the class layer's
+ * dspu::Filter / FilterBank / Equalizer objects are put into the exact mode: set it before constructing them).
+ */
+int mi_biquad_bank_set_exact(mi_biquad_bank_t *bank, int on);
+int mi_dspu_set_exact_iir_default(int on);
 /* Push pending coefficient tables / state clears to the device (async on stream). */
 int mi_biquad_bank_commit(mi_biquad_bank_t *bank, void *stream);
 /* FilterBank::reset(), FilterBank.cpp:238-254; channel = UINT32_MAX for all. */

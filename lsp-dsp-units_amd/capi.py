@@ -82,6 +82,8 @@ PROTOTYPES = {
     "mi_biquad_bank_set_all_chains": (c_int, [c_void_p, POINTER(BiquadX1), c_uint32, c_int]),
     "mi_biquad_bank_size": (c_int, [c_void_p, c_uint32, POINTER(c_uint32)]),
     "mi_biquad_bank_set_row_enabled": (c_int, [c_void_p, c_uint32, c_int]),
+    "mi_biquad_bank_set_exact": (c_int, [c_void_p, c_int]),
+    "mi_dspu_set_exact_iir_default": (c_int, [c_int]),
     "mi_biquad_bank_commit": (c_int, [c_void_p, c_void_p]),
     "mi_biquad_bank_reset": (c_int, [c_void_p, c_uint32, c_void_p]),
     "mi_biquad_bank_process": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]),

@@ -41,6 +41,7 @@
 #include "ilufs_device.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -1454,6 +1455,121 @@ namespace
         }
     }
 
+    // ---- FilterBank::process in the REFERENCE's arithmetic, operation for operation (the bank's opt-in exact mode, round 6) --------
+    // The kernels above split time into chunks and re-join them with a scan: the same filter in another order of roundings
+    // (only the chunks' start states differ from the serial recursion's, by round-off -- but a recursive filter near the unit
+    // circle remembers that for thousands of samples: |gpu - oracle| reaches 3e-4 of the peak at C2's 200 Hz low-passes, and
+    // tests/conftest.py holds the fast kernels to a noise rule there instead of north_star's 1e-5).  This kernel runs the
+    // recurrence of FilterBank.cpp:256-291 as lsp-dsp-lib's generic biquad_process_x1 writes it -- y = b0 x + d0;
+    // p1 = b1 x + a1 y; p2 = b2 x + a2 y; d0 = d1 + p1; d1 = p2, every product and every sum rounded on its own -- sample after
+    // sample: what the CPU's x8 form does with its eight SIMD lanes.  G lanes per channel (the power of two that holds the
+    // bank's longest cascade), lane j = section j, a systolic line: at step s lane j works on sample s - j, which lane j - 1
+    // finished one step earlier (wave_shr:1); what a section computes for a sample does not depend on when it does.  The filter
+    // memory is the bank's own {d0, d1} per section, read at the start and left as the recursion leaves it: calls in this mode
+    // and in the fast one can follow each other.  The result is the oracle's BIT FOR BIT (tests/test_biquad_gpu.py); the price
+    // is the recursion's latency chain, n steps of some eighteen instructions one behind the other per call (220 us per 4096
+    // samples whatever the channel count up to a wave per SIMD's worth: 19 000 Msamples/s at C2 against the fast kernels'
+    // 280 000 - 550 000; a 16-core host runs the vectorised x8 form at 17 700).
+    // 64 input samples per lane sit in registers one chunk ahead (every lane of a channel loads the same addresses); more than
+    // 64 sections: passes of 64, the later ones in place on `out`.
+    template <int G>
+    __global__ __launch_bounds__(64)
+    void biquad_exact_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, int n,
+                             const float *__restrict__ tab, int tab_row, float *state, const uint32_t *__restrict__ nsec,
+                             int max_sec, int channels, int cap /* the longest cascade of the bank */)
+    {
+        constexpr int CPW = 64 / G;                         // channels of a wave
+        const int t = int(threadIdx.x), j = t % G;
+        const int ch = int(blockIdx.x) * CPW + t / G;
+        const uint32_t nv = (ch < channels) ? nsec[ch] : 0x80000000u;       // (sign bit: the row is switched off -- nothing read, nothing written)
+        const bool on = (nv & 0x80000000u) == 0u;
+        const int ns = int(nv & 0x7fffffffu);
+        const int chc = (ch < channels) ? ch : 0;
+        float *const o = out + size_t(chc) * out_stride;
+        const float *const x_in = in + size_t(chc) * in_stride;
+        if (on && ns == 0 && o != x_in)                     // FilterBank.cpp:261-265: an empty bank copies
+            for (int i = j; i < n; i += G)
+                o[i] = x_in[i];
+        for (int s0 = 0; s0 < cap; s0 += 64)
+        {
+            const bool mine = on && s0 + j < ns;            // this lane's section exists
+            const int cnt = on ? ((ns - s0 < G) ? ns - s0 : G) : 0;        // sections of the channel in this pass (<= 0: it is through)
+            const bool emit = cnt >= 1 && j == cnt - 1;     // the pass's last section of the channel hands the samples out
+            const float *q = tab + (size_t(chc) * max_sec + (mine ? s0 + j : 0)) * tab_row;
+            const float b0 = mine ? q[0] : 0.0f, b1 = mine ? q[1] : 0.0f, b2 = mine ? q[2] : 0.0f, a1 = mine ? q[3] : 0.0f, a2 = mine ? q[4] : 0.0f;
+            float *const st = state + (size_t(chc) * max_sec + (mine ? s0 + j : 0)) * 2;
+            float d0 = mine ? st[0] : 0.0f, d1 = mine ? st[1] : 0.0f, y = 0.0f;
+            const float *const src = (s0 == 0) ? x_in : o;  // later passes run in place (FilterBank.cpp:270)
+            // (unconditional loads: a load under a condition per element compiles to a cascade of 64 x 64 register copies.  A chunk
+            // that reaches past the call's end reads its last sample again -- a value no active lane takes)
+            auto fetch = [&](int s64, float (&v)[64]) {
+                if (s64 + 64 <= n)
+                {
+                    const float *p = src + s64;
+                    #pragma unroll
+                    for (int i = 0; i < 64; ++i)
+                        v[i] = p[i];
+                    return;
+                }
+                #pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    v[i] = src[(s64 + i < n) ? s64 + i : n - 1];
+            };
+            const int steps = n + G - 1;
+            float xs[64], xn[64];
+            fetch(0, xs);
+            for (int s64 = 0; s64 < steps; s64 += 64)
+            {
+                fetch(s64 + 64, xn);                        // the next chunk's samples, in flight over this chunk's steps (zeros behind the call's end)
+                const bool edge = s64 < G - 1 || s64 + 64 > n;      // lanes start one step after another and stop one after another
+                if (!edge)
+                {
+                    #pragma unroll
+                    for (int k = 0; k < 64; ++k)
+                    {
+                        const float up = dpp_or<DPP_WAVE_SHR1, 0xf>(0.0f, y);
+                        const float x = (j == 0) ? xs[k] : up;
+                        y = __fadd_rn(__fmul_rn(b0, x), d0);
+                        const float p1 = __fadd_rn(__fmul_rn(b1, x), __fmul_rn(a1, y));
+                        const float p2 = __fadd_rn(__fmul_rn(b2, x), __fmul_rn(a2, y));
+                        d0 = __fadd_rn(d1, p1);
+                        d1 = p2;
+                        if (emit)
+                            o[s64 + k - j] = y;
+                    }
+                }
+                else
+                {
+                    #pragma unroll
+                    for (int k = 0; k < 64; ++k)
+                    {
+                        const int i = s64 + k - j;          // the sample this lane's section meets at this step
+                        const bool act = mine && i >= 0 && i < n;
+                        const float up = dpp_or<DPP_WAVE_SHR1, 0xf>(0.0f, y);
+                        const float x = (j == 0) ? xs[k] : up;
+                        const float yn = __fadd_rn(__fmul_rn(b0, x), d0);
+                        const float p1 = __fadd_rn(__fmul_rn(b1, x), __fmul_rn(a1, yn));
+                        const float p2 = __fadd_rn(__fmul_rn(b2, x), __fmul_rn(a2, yn));
+                        y = yn;
+                        d0 = act ? __fadd_rn(d1, p1) : d0;
+                        d1 = act ? p2 : d1;
+                        if (emit && act)
+                            o[i] = yn;
+                    }
+                }
+                #pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    xs[i] = xn[i];
+            }
+            if (mine)
+            {
+                st[0] = d0;
+                st[1] = d1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");      // the next pass reads this pass's output
+        }
+    }
+
     __global__ void impulse_kernel(float *out, size_t stride, size_t samples, uint32_t channels)
     {
         // FilterBank.cpp:316-318: zero the buffer, out[0] = 1
@@ -1527,6 +1643,7 @@ struct mi_biquad_bank
     std::vector<uint8_t>    row_off;        // channel switched off: process() leaves its state and its output alone
     bool                    nsec_dirty  = false;
     bool                    pending     = false;
+    bool                    exact       = false;   // process() on biquad_exact_kernel: the reference's serial recurrence, bit for bit
     std::vector<float>      h_big, h_small; // host images of the device tables
     float                  *d_big       = nullptr;
     float                  *d_small     = nullptr;
@@ -1943,6 +2060,8 @@ namespace mi
 
 extern "C" {
 
+static std::atomic<int> g_exact_default{0};     // mi_dspu_set_exact_iir_default: what banks made from now on start with
+
 int mi_biquad_bank_create(mi_biquad_bank_t **bank, uint32_t channels, uint32_t max_sections)
 {
     MI_REQUIRE(bank != nullptr, MI_EINVAL, "mi_biquad_bank_create: NULL result pointer");
@@ -1955,6 +2074,7 @@ int mi_biquad_bank_create(mi_biquad_bank_t **bank, uint32_t channels, uint32_t m
     mi_biquad_bank *b = new (std::nothrow) mi_biquad_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_biquad_bank_create: out of host memory");
     b->channels = channels;
+    b->exact = g_exact_default.load() != 0;
     b->max_sec  = max_sections;
     const size_t cs = size_t(channels) * max_sections;
     try
@@ -2066,6 +2186,19 @@ int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *b, uint32_t channel, int en
     return MI_OK;
 }
 
+int mi_dspu_set_exact_iir_default(int on)
+{
+    g_exact_default.store(on ? 1 : 0);
+    return MI_OK;
+}
+
+int mi_biquad_bank_set_exact(mi_biquad_bank_t *b, int on)
+{
+    MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_set_exact: NULL bank");
+    b->exact = on != 0;
+    return MI_OK;
+}
+
 int mi_biquad_bank_commit(mi_biquad_bank_t *b, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_biquad_bank_commit: NULL bank");
@@ -2089,6 +2222,41 @@ int mi_biquad_bank_reset(mi_biquad_bank_t *b, uint32_t channel, void *stream)
 static int stream_launch(mi_biquad_bank_t *b, float *const *out, const float *const *in, size_t first, size_t count,
                          size_t samples, size_t out_stride, size_t in_stride, hipStream_t st);
 
+// The call on biquad_exact_kernel (mi_biquad_bank_set_exact): G lanes per channel, the power of two that holds the longest cascade
+static int exact_run(mi_biquad_bank_t *b, float *out, const float *in, size_t samples, size_t out_stride, size_t in_stride, hipStream_t st)
+{
+    int cap = 0;
+    for (uint32_t c = 0; c < b->channels; ++c)
+        cap = std::max(cap, int(b->nsec[c]));
+    int g = 1;
+    while (g < cap && g < 64)
+        g *= 2;
+    size_t done = 0;
+    while (done < samples)
+    {
+        const size_t step = std::min<size_t>(samples - done, size_t(1) << 28);
+        const dim3 grid((b->channels * unsigned(g) + 63) / 64);
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        mi::take_profile_events(&ev0, &ev1);
+        #define MI_EXACT(G_) MI_LAUNCH((biquad_exact_kernel<G_>), grid, dim3(64), 0, st, ev0, ev1, out + done, in + done, out_stride, in_stride, \
+                                       int(step), b->d_small, int(small::TAB), b->d_state, b->d_nsec, int(b->max_sec), int(b->channels), std::max(cap, 1))
+        switch (g)
+        {
+            case 1:  { MI_EXACT(1);  break; }
+            case 2:  { MI_EXACT(2);  break; }
+            case 4:  { MI_EXACT(4);  break; }
+            case 8:  { MI_EXACT(8);  break; }
+            case 16: { MI_EXACT(16); break; }
+            case 32: { MI_EXACT(32); break; }
+            default: { MI_EXACT(64); break; }
+        }
+        #undef MI_EXACT
+        MI_HIP_CHECK(hipGetLastError());
+        done += step;
+    }
+    return MI_OK;
+}
+
 // One call of the bank over `samples` samples of every channel; sq != NULL: the meters' epilogue instead of the output
 static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t samples, size_t out_stride, size_t in_stride,
                     hipStream_t st, const sumsq_args *sq, const mi_meters::ilufs_epilogue *ep, bool *rode)
@@ -2096,6 +2264,8 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
     int r = commit(b, st);
     if (r != MI_OK)
         return r;
+    if (b->exact && sq == nullptr)
+        return exact_run(b, out, in, samples, out_stride, in_stride, st);
 
     const bool aligned = ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 16 == 0) &&
                          (out_stride % 4 == 0) && (in_stride % 4 == 0);
@@ -2188,7 +2358,7 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
     // walks it with four waves per channel (7.7 instead of 9.2 us per 4096 samples at 65536-sample calls) -- the same bits as
     // the super-block loop of biquad_bank_kernel, whose hand-overs it reproduces kind for kind.
     if (samples >= 4 * size_t(big::BLOCK) && (samples % 16) == 0 && samples < (size_t(1) << 28) && (out_stride % 4) == 0 &&
-        (in_stride % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 16) == 0 &&
+        (in_stride % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 16) == 0 && !b->exact &&
         getenv("MI_BIQUAD_BLOCKS_LOOP") == nullptr)
     {
         bool fits = true;
@@ -2258,7 +2428,7 @@ int mi_biquad_bank_process_blocks(mi_biquad_bank_t *b, float *const *out, const 
 
     // One launch for a run of blocks (biquad_stream_kernel) where the blocks are what the long-call kernel takes -- more
     // than 2048 samples, whole chunks of 16, 16-byte aligned rows -- and every channel's sections have a hand-over cell.
-    bool streamable = samples > 2 * size_t(small::BLOCK) && (samples % 16) == 0 && samples < (size_t(1) << 28) &&
+    bool streamable = samples > 2 * size_t(small::BLOCK) && (samples % 16) == 0 && samples < (size_t(1) << 28) && !b->exact &&
                       (out_stride % 4) == 0 && (in_stride % 4) == 0 && getenv("MI_BIQUAD_BLOCKS_LOOP") == nullptr;
     for (uint32_t c = 0; streamable && c < b->channels; ++c)
         streamable = b->nsec[c] <= uint32_t(STREAM_SG);

@@ -104,6 +104,10 @@ class BiquadBank:
         """A channel that is switched off is skipped by process(): state kept, output row not written."""
         check(lib.mi_biquad_bank_set_row_enabled(self.handle, channel, 1 if enabled else 0))
 
+    def set_exact(self, on=True):
+        """The reference's serial recurrence, bit for bit (mi_biquad_bank_set_exact), instead of the time-parallel kernels."""
+        check(lib.mi_biquad_bank_set_exact(self.handle, 1 if on else 0))
+
     def set_all_chains(self, coefs, clear=False):
         c = np.ascontiguousarray(coefs, dtype=np.float32)
         assert c.ndim == 3 and c.shape[0] == self.channels and c.shape[2] == 5

@@ -118,21 +118,32 @@ def parity_report(gpu_out, ref32, ref64, peak=None, noise_over=None):
 TOL = 1e-5
 # a recursion whose float32 round-off noise is below this is "well conditioned": strict tolerance applies
 NOISE_FLOOR = 2e-6      # = TOL / 5: the noise rule below turns into the strict one exactly here (no jump in the bound)
-# Factors of the noise rule, set from the distribution measured on all 1024 channels of C2 on the MI355X over 64 blocks
-# with carried state (tests/test_biquad_gpu.py::test_c2_full_size_all_channels prints it and writes it to
-# gpurun_out/c2_parity.json; committed copies: profiles/r0N_c2_parity.json).  Round 3, 667 channels above the noise floor:
-#   |gpu - exact| / noise   median 0.51, worst 2.02  (the GPU result is usually CLOSER to exact arithmetic than the
-#                           reference's own float32 recursion is)
-#   |gpu - oracle| / noise  worst 2.54               (two independent round-off walks)
-# `noise` is itself the maximum of ONE round-off walk, so single-run ratios scatter; the factors are 1.5x the worst ratio
-# measured: a channel fails well before it reaches twice the measured worst case.  (Over every other IIR check of a GPU
-# session the worst ratio to these bounds was 0.29 in round 3: profiles/r03_parity_report.json.)
-# FROZEN since round 3 (not refitted): round 5 holds the same two factors against the block-by-block kernel and against ONE
-# 64-block mi_biquad_bank_process_blocks call over five draws of cutoffs and input at C2 size (test_c2_full_size_all_channels,
-# profiles/r05_c2_parity*.json): worst |gpu - exact| / noise 2.02, 1.69, 1.91, 1.72, 1.76; worst |gpu - oracle| / noise 2.54, 2.14,
-# 2.00, 2.07, 2.34.
-IIR_EXACT_FACTOR = 3.0  # |gpu - exact|  <= IIR_EXACT_FACTOR * noise
-IIR_REF_FACTOR = 3.75   # |gpu - oracle| <= IIR_REF_FACTOR * noise
+# The noise rule's factors, DERIVED (round 6) and no longer "1.5 x the worst ratio seen":
+#   The fast kernels run the reference's recurrence inside chunks of 16 samples from start states a scan supplies; to first order
+#   in eps = 2^-24 a float32 evaluation of the cascade is  y + sum_i G_i * rho_i  (rho_i: the local roundings, G_i: the exact
+#   transfer from where they enter to the output).  The serial recursion (the oracle) has the roundings of its nine operations per
+#   sample and section; the fast kernels have the same ones (same operations on the same kind of values -- fewer, where they fuse)
+#   plus what the scan's dot products and 2 x 2 products put into the start states every 16 samples, through the SAME
+#   state-to-output transfer as the recursion's own d0/d1 roundings and from fewer operations per sample (2.4 against 9): a
+#   second round-off walk of at most the first one's variance.  Once the two evaluations differ at all their roundings are
+#   independent.  With sigma the serial recursion's noise (rms):
+#       rms(gpu - exact)  <= sqrt(1 + 1) sigma,      rms(gpu - oracle) <= sqrt(2 + 1) sigma.
+#   `noise` below is the MAXIMUM of one realisation of the serial walk, so a ratio of maxima of different realisations scatters;
+#   IIR_MAX_SCATTER is the allowance for that (the worst of 6 x 1024 channel runs at C2 is 1.45 x its typical value):
+IIR_MAX_SCATTER = 3.0 / 2.0 ** 0.5                      # 2.12
+IIR_EXACT_FACTOR = 2.0 ** 0.5 * IIR_MAX_SCATTER         # |gpu - exact|  <= 3.00 noise   (round 3's fitted 3.0: the same number)
+IIR_REF_FACTOR = 3.0 ** 0.5 * IIR_MAX_SCATTER           # |gpu - oracle| <= 3.67 noise   (round 3's fitted 3.75 dominates it)
+# ... and the derivation's own statement, on root-mean-squares over a whole run (which scatter far less than maxima; held at C2's
+# full size, every channel, by test_c2_full_size_all_channels): the allowance covers the estimate of sigma from one run of a
+# narrow-band walk AND the channels where the scan's share is the larger one: where the powers of a section's transition matrix
+# grow before they decay (the lowest cut-offs) the start states carry more than the recursion's own roundings -- measured over
+# 6 x 1024 channel runs: rms(gpu - exact) / sigma median 0.59 (the fused recurrence is the quieter one), 99th percentile 1.5,
+# worst 2.15; rms(gpu - oracle) / sigma median 1.15 = sqrt(1 + 0.59^2): the two walks ARE independent; worst 2.36
+IIR_RMS_MARGIN = 2.0
+# Measured against these (profiles/r0N_c2_parity*.json; six cases x 1024 channels): worst |gpu - exact| / noise 2.02, 1.69, 1.91,
+# 1.72, 1.76 (median 0.51: the GPU result is usually CLOSER to exact arithmetic than the oracle's own recursion -- its recurrence
+# fuses); worst |gpu - oracle| / noise 2.54, 2.14, 2.00, 2.07, 2.34.  A caller that needs the reference's bits rather than its
+# accuracy class has them: mi_biquad_bank_set_exact (tests: test_exact_mode_*, test_c2_full_size_all_channels_exact_mode).
 
 
 def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None, noise_over=None):
@@ -141,7 +152,7 @@ def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None, noise_over=None
     * well-conditioned filter (reference's own float32 noise <= NOISE_FLOOR): |gpu - ref32| <= 1e-5 * peak;
     * otherwise the float32 recursion itself is only reproducible to `noise`; the GPU result must then be
       of the same accuracy class: within IIR_EXACT_FACTOR x the reference's own distance from exact arithmetic and within
-      IIR_REF_FACTOR x of the oracle (1.5 x the worst ratios measured over all channels of C2)."""
+      IIR_REF_FACTOR x of the oracle (sqrt 2 and sqrt 3 x the allowance for comparing maxima: derived above)."""
     r = parity_report(gpu_out, ref32, ref64, peak, noise_over)
     msg = "%s: %s" % (what, r)
     assert np.all(np.isfinite(gpu_out)), msg
@@ -149,9 +160,9 @@ def assert_iir_parity(gpu_out, ref32, ref64, what="", peak=None, noise_over=None
         record_parity("iir strict: |gpu - oracle| <= 1e-5 peak (oracle noise <= 2e-6)", r["gpu_vs_ref32"], TOL, noise=r["noise"])
         assert r["gpu_vs_ref32"] <= TOL, msg
     else:
-        record_parity("iir noisy: |gpu - exact| <= max(1e-5, %g noise)" % IIR_EXACT_FACTOR, r["gpu_vs_exact"], max(TOL, IIR_EXACT_FACTOR * r["noise"]),
+        record_parity("iir noisy: |gpu - exact| <= max(1e-5, %.3g noise)" % IIR_EXACT_FACTOR, r["gpu_vs_exact"], max(TOL, IIR_EXACT_FACTOR * r["noise"]),
                       noise=r["noise"], over_noise=r["gpu_vs_exact"] / r["noise"])
-        record_parity("iir noisy: |gpu - oracle| <= max(1e-5, %g noise)" % IIR_REF_FACTOR, r["gpu_vs_ref32"], max(TOL, IIR_REF_FACTOR * r["noise"]),
+        record_parity("iir noisy: |gpu - oracle| <= max(1e-5, %.3g noise)" % IIR_REF_FACTOR, r["gpu_vs_ref32"], max(TOL, IIR_REF_FACTOR * r["noise"]),
                       noise=r["noise"], over_noise=r["gpu_vs_ref32"] / r["noise"])
         assert r["gpu_vs_exact"] <= max(TOL, IIR_EXACT_FACTOR * r["noise"]), msg
         assert r["gpu_vs_ref32"] <= max(TOL, IIR_REF_FACTOR * r["noise"]), msg
