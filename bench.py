@@ -832,7 +832,9 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     gen.manual_seed(7 + rank)
     xin = torch.randn((ring, C, hop), generator=gen, dtype=torch.float32).to(dev)
     bins = (1 << (rank_fft - 1)) + 1
-    sums = torch.zeros((batch, bins), dtype=torch.float32, device=dev)
+    # two buffers of per-bin sums: batch k's collective runs beside batch k + 1's analysis, which fills the other one
+    sums2 = torch.zeros((2, batch, bins), dtype=torch.float32, device=dev)
+    sums = sums2[0]
     stream = torch.cuda.current_stream()
     an.process(xin[0], hop, stream=stream)
     info = an.info()
@@ -846,7 +848,8 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
             try:
                 state["comm"] = sharding.library_comm(mi)   # (a communicator on every rank or on none: the ranks agree inside)
                 if state["comm"] is not None:
-                    state["collective"] = "mi_analyzer_bank_allreduce_bins: ncclAllReduce from the library's host side (RCCL over xGMI)"
+                    state["collective"] = ("mi_analyzer_bank_allreduce_bins_begin: ncclAllReduce from the library's host side on its side stream "
+                                           "(RCCL over xGMI), beside the next batch's analysis; the sums double-buffered")
             except Exception as e:                          # the measurement goes on with torch's communicator
                 print("bench: library communicator refused (%s); torch.distributed all_reduce instead" % e, file=sys.stderr)
 
@@ -861,12 +864,16 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
 
     def batch_step(i):
         # the same `batch` frames as ONE mi_analyzer_bank_process_reduce_frames call: the strobes as one launch, their reductions as one
-        # launch, then the collective
-        an.process_reduce_frames([xin[(i + j) % ring] for j in range(batch)], hop, sums, stream=stream)
+        # launch, then the collective -- on the library's side stream, beside the next batch (which fills the other buffer): the
+        # stream only waits for the collective that used THIS buffer two batches ago
+        b = (i // batch) & 1
         if state["comm"] is not None:
-            an.allreduce_bins(sums, batch, state["comm"], stream=stream)
+            state["comm"].wait(b, stream=stream)
+        an.process_reduce_frames([xin[(i + j) % ring] for j in range(batch)], hop, sums2[b], stream=stream)
+        if state["comm"] is not None:
+            an.allreduce_bins_begin(sums2[b], sums2[b], batch, state["comm"], b, stream=stream)
         else:
-            sharding.allreduce_bins(sums)
+            sharding.allreduce_bins(sums2[b])
     steps = args.conv_steps - (args.conv_steps % batch) or batch
     # probes: the analysis launch alone, the stream drained in front of each (behind a step's own bin_reduce_kernel -- or
     # behind another analysis launch that is still draining -- the start stamp of the event pair is taken early and the pair
@@ -874,6 +881,9 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
     def region():
         for i in range(0, steps, batch):
             batch_step(i)
+        if state["comm"] is not None:                       # the region ends when its last collectives have
+            state["comm"].wait(0, stream=stream)
+            state["comm"].wait(1, stream=stream)
     # probes: the analysis launch of a batch alone (analyzer_frames_wave_kernel takes the event pair, the reduction and the
     # collective behind it do not), the stream drained in front of each
     elapsed, kernel_ms, tinfo = _timed_steps(mi, torch, dist, world, dev, step, steps, batch, region=region,
@@ -883,7 +893,7 @@ def run_spectral(args, mi, torch, dist, rank, world, dev):
                        "walked over the strobes where the per-bin sums are formed)" % (steps // batch, batch, batch))
     pc_elapsed, pc_kernel_ms, pc_info = _timed_steps(mi, torch, dist, world, dev, step, steps, batch,
                                                      probe_step=lambda i: an.process(xin[i % ring], hop, stream=stream), probe_sync=True)
-    assert bool(torch.isfinite(sums).all()) and float(sums.abs().max()) > 0.0
+    assert bool(torch.isfinite(sums2).all()) and float(sums2.abs().max()) > 0.0
     if state["comm"] is not None:
         state["comm"].close()
     an.close()

@@ -554,6 +554,20 @@ int mi_dspu_comm_destroy(mi_dspu_comm_t *comm);
 int mi_dspu_comm_info(const mi_dspu_comm_t *comm, int *nranks, int *rank);
 /* bins: DEVICE [frames][2^(rank-1)+1], summed in place over the ranks of `comm` (float32, ncclSum). */
 int mi_analyzer_bank_allreduce_bins(mi_analyzer_bank_t *bank, float *bins, size_t frames, mi_dspu_comm_t *comm, void *stream);
+/*
+ * The same exchange step beside the caller's stream, for callers that double-buffer the sums: begin() issues the collective on
+ * the communicator's own (least urgent: it takes the CUs the next batch's launches leave) side stream behind everything `stream` has enqueued so far -- `partial` summed over the
+ * ranks into `total` (may be the same buffer) -- and returns; `stream` goes on with the next batch of frames, whose reduction
+ * writes ANOTHER buffer.  mi_dspu_comm_wait() makes `stream` wait, on the device, for the slot's collective: call it in front of
+ * whatever reads `total` and in front of the work that overwrites the slot's buffers again.  Slots: 0 .. MI_DSPU_COMM_SLOTS - 1.
+ * The result is the serial call's bit for bit (the same ncclAllReduce on the same data).  Not capturable into a hipGraph.
+ * Reference for the semantic: the cross-channel callback of MultiSpectralProcessor
+ * (/root/reference/include/lsp-plug.in/dsp-units/util/MultiSpectralProcessor.h:41).
+ */
+#define MI_DSPU_COMM_SLOTS 4
+int mi_analyzer_bank_allreduce_bins_begin(mi_analyzer_bank_t *bank, const float *partial, float *total, size_t frames,
+                                          mi_dspu_comm_t *comm, int slot, void *stream);
+int mi_dspu_comm_wait(mi_dspu_comm_t *comm, int slot, void *stream);
 
 /* ---- dynamic filter bank --------------------------------------------------- */
 /*

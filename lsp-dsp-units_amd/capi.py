@@ -67,6 +67,8 @@ PROTOTYPES = {
     "mi_dspu_comm_destroy": (c_int, [c_void_p]),
     "mi_dspu_comm_info": (c_int, [c_void_p, POINTER(c_int), POINTER(c_int)]),
     "mi_analyzer_bank_allreduce_bins": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "mi_analyzer_bank_allreduce_bins_begin": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, c_void_p]),
+    "mi_dspu_comm_wait": (c_int, [c_void_p, c_int, c_void_p]),
     "mi_dynfilter_bank_create": (c_int, [POINTER(c_void_p), c_uint32, c_uint32]),
     "mi_dynfilter_bank_destroy": (c_int, [c_void_p]),
     "mi_dynfilter_bank_set_sample_rate": (c_int, [c_void_p, c_uint32]),

@@ -1458,7 +1458,7 @@ namespace
     // ---- FilterBank::process in the REFERENCE's arithmetic, operation for operation (the bank's opt-in exact mode, round 6) --------
     // The kernels above split time into chunks and re-join them with a scan: the same filter in another order of roundings
     // (only the chunks' start states differ from the serial recursion's, by round-off -- but a recursive filter near the unit
-    // circle remembers that for thousands of samples: |gpu - oracle| reaches 3e-4 of the peak at C2's 200 Hz low-passes, and
+    // circle remembers that for thousands of samples: the distance from the serial recursion reaches 3e-4 of the peak at C2's 200 Hz low-passes, and
     // tests/conftest.py holds the fast kernels to a noise rule there instead of north_star's 1e-5).  This kernel runs the
     // recurrence of FilterBank.cpp:256-291 as lsp-dsp-lib's generic biquad_process_x1 writes it -- y = b0 x + d0;
     // p1 = b1 x + a1 y; p2 = b2 x + a2 y; d0 = d1 + p1; d1 = p2, every product and every sum rounded on its own -- sample after
@@ -1466,7 +1466,7 @@ namespace
     // bank's longest cascade), lane j = section j, a systolic line: at step s lane j works on sample s - j, which lane j - 1
     // finished one step earlier (wave_shr:1); what a section computes for a sample does not depend on when it does.  The filter
     // memory is the bank's own {d0, d1} per section, read at the start and left as the recursion leaves it: calls in this mode
-    // and in the fast one can follow each other.  The result is the oracle's BIT FOR BIT (tests/test_biquad_gpu.py); the price
+    // and in the fast one can follow each other.  The result is the serial CPU recursion's BIT FOR BIT (tests/test_biquad_gpu.py); the price
     // is the recursion's latency chain, n steps of some eighteen instructions one behind the other per call (220 us per 4096
     // samples whatever the channel count up to a wave per SIMD's worth: 19 000 Msamples/s at C2 against the fast kernels'
     // 280 000 - 550 000; a 16-core host runs the vectorised x8 form at 17 700).

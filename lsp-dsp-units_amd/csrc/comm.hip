@@ -61,7 +61,34 @@ struct mi_dspu_comm
     ncclComm_t  comm = nullptr;
     bool        owned = false;
     int         nranks = 1, rank = 0;
+    // the side stream of mi_analyzer_bank_allreduce_bins_begin: a collective there runs beside whatever the caller's stream
+    // goes on with; `ready` = the caller's stream has produced the slot's partial sums, `done` = the slot's collective is through
+    hipStream_t side = nullptr;
+    hipEvent_t  ready[MI_DSPU_COMM_SLOTS] = {}, done[MI_DSPU_COMM_SLOTS] = {};
+    bool        pending[MI_DSPU_COMM_SLOTS] = {};
 };
+
+namespace
+{
+    int comm_side(mi_dspu_comm *c)                          // made on first use (a communicator that never overlaps has none)
+    {
+        if (c->side != nullptr)
+            return MI_OK;
+        // The LEAST urgent priority: the analysis launch of the next batch holds every CU (one persistent workgroup each, all of a
+        // CU's LDS and registers) for its ~80 us; a collective kernel that got a CU first would hold up that CU's workgroup -- a
+        // quarter of the launch's work -- by its own duration, the serial cost over again.  Least urgent, it takes the CUs the
+        // analysis leaves (the reduction behind it does not fill them) and ends inside the two batches the caller's slots give it.
+        int least = 0, most = 0;
+        MI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &most));
+        MI_HIP_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
+        for (int k = 0; k < MI_DSPU_COMM_SLOTS; ++k)
+        {
+            MI_HIP_CHECK(hipEventCreateWithFlags(&c->ready[k], hipEventDisableTiming));
+            MI_HIP_CHECK(hipEventCreateWithFlags(&c->done[k], hipEventDisableTiming));
+        }
+        return MI_OK;
+    }
+}
 
 extern "C" {
 
@@ -133,6 +160,16 @@ int mi_dspu_comm_destroy(mi_dspu_comm_t *c)
     if (c == nullptr)
         return MI_OK;
     rccl_api *a = rccl();
+    if (c->side != nullptr)
+    {
+        (void)hipStreamSynchronize(c->side);
+        for (int k = 0; k < MI_DSPU_COMM_SLOTS; ++k)
+        {
+            if (c->ready[k] != nullptr) (void)hipEventDestroy(c->ready[k]);
+            if (c->done[k] != nullptr) (void)hipEventDestroy(c->done[k]);
+        }
+        (void)hipStreamDestroy(c->side);
+    }
     if (c->owned && c->comm != nullptr && a != nullptr)
         (void)a->comm_destroy(c->comm);
     delete c;
@@ -164,6 +201,56 @@ int mi_analyzer_bank_allreduce_bins(mi_analyzer_bank_t *bank, float *bins, size_
     const ncclResult_t r = a->all_reduce(bins, bins, frames * size_t(nb), ncclFloat, ncclSum, c->comm, mi::as_stream(stream));
     if (r != ncclSuccess)
         return nccl_fail(a, "ncclAllReduce", r);
+    return MI_OK;
+}
+
+// The same exchange step BESIDE the caller's stream (round 6): the batch's collective is a small message whose latency -- a few
+// tens of microseconds over xGMI -- otherwise stands between two batches on the one stream.  begin(): the side stream waits for
+// what `stream` has enqueued so far (the batch's reduction: an event), sums `partial` over the ranks into `total` (the same buffer:
+// in place) and marks the slot done; the caller's stream goes straight on with the next batch, which writes ANOTHER buffer.
+// wait(): `stream` waits (on the device: the host does not block) for the slot's collective -- in front of whatever consumes
+// `total`, and in front of the reduction that overwrites the slot's buffers two batches later.  Slots are the caller's double
+// (or deeper) buffering; a slot that is begun again while pending is waited for on the side stream's own order.
+int mi_analyzer_bank_allreduce_bins_begin(mi_analyzer_bank_t *bank, const float *partial, float *total, size_t frames,
+                                          mi_dspu_comm_t *c, int slot, void *stream)
+{
+    MI_REQUIRE(bank != nullptr, MI_ESTATE, "mi_analyzer_bank_allreduce_bins_begin: NULL bank");
+    MI_REQUIRE(c != nullptr, MI_ESTATE, "mi_analyzer_bank_allreduce_bins_begin: NULL communicator");
+    MI_REQUIRE(slot >= 0 && slot < MI_DSPU_COMM_SLOTS, MI_EINVAL, "mi_analyzer_bank_allreduce_bins_begin: slot %d outside 0..%d", slot, MI_DSPU_COMM_SLOTS - 1);
+    if (frames == 0)
+        return MI_OK;
+    MI_REQUIRE(partial != nullptr && total != nullptr, MI_EINVAL, "mi_analyzer_bank_allreduce_bins_begin: NULL buffer");
+    uint32_t nb = 0;
+    const int q = mi_analyzer_bank_info(bank, nullptr, &nb, nullptr, nullptr);
+    if (q != MI_OK)
+        return q;
+    rccl_api *a = rccl();
+    MI_REQUIRE(a != nullptr, MI_ENODEV, "RCCL (librccl.so.1) could not be loaded");
+    const int rs = comm_side(c);
+    if (rs != MI_OK)
+        return rs;
+    hipStream_t st = mi::as_stream(stream);
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    MI_REQUIRE(!(st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone), MI_ESTATE,
+               "mi_analyzer_bank_allreduce_bins_begin: the stream is being captured (the collective's side stream is not part of a graph)");
+    MI_HIP_CHECK(hipEventRecord(c->ready[slot], st));
+    MI_HIP_CHECK(hipStreamWaitEvent(c->side, c->ready[slot], 0));
+    const ncclResult_t r = a->all_reduce(partial, total, frames * size_t(nb), ncclFloat, ncclSum, c->comm, c->side);
+    if (r != ncclSuccess)
+        return nccl_fail(a, "ncclAllReduce", r);
+    MI_HIP_CHECK(hipEventRecord(c->done[slot], c->side));
+    c->pending[slot] = true;
+    return MI_OK;
+}
+
+int mi_dspu_comm_wait(mi_dspu_comm_t *c, int slot, void *stream)
+{
+    MI_REQUIRE(c != nullptr, MI_ESTATE, "mi_dspu_comm_wait: NULL communicator");
+    MI_REQUIRE(slot >= 0 && slot < MI_DSPU_COMM_SLOTS, MI_EINVAL, "mi_dspu_comm_wait: slot %d outside 0..%d", slot, MI_DSPU_COMM_SLOTS - 1);
+    if (!c->pending[slot])                                  // nothing begun in this slot (or already waited for): nothing to wait for
+        return MI_OK;
+    MI_HIP_CHECK(hipStreamWaitEvent(mi::as_stream(stream), c->done[slot], 0));
+    c->pending[slot] = false;
     return MI_OK;
 }
 

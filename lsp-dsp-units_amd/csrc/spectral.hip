@@ -32,7 +32,7 @@ namespace
     // rounded sqrtf the compiler builds around it (a dozen instructions more per value: a quarter of the analysis kernels'
     // arithmetic) -- 6e-8 of the value against the 1e-5 the results are held to.
     __device__ __forceinline__ float mag_root(float x) { return __builtin_amdgcn_sqrtf(x); }
-    // mix2(vAmp, |X|, 1 - tau, tau) (Analyzer.cpp:361): two products and their sum, each rounded -- the oracle's arithmetic, and
+    // mix2(vAmp, |X|, 1 - tau, tau) (Analyzer.cpp:361): two products and their sum, each rounded -- the arithmetic of the reference's generic dsp::mix2, and
     // ONE form for every kernel that smooths (a contraction chosen per kernel by the compiler would make the bits of a run of
     // strobes depend on the launch that took them)
     __device__ __forceinline__ float mix2(float a, float m, float keep, float tau) { return __fadd_rn(__fmul_rn(a, keep), __fmul_rn(m, tau)); }

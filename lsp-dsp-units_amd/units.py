@@ -376,6 +376,11 @@ class AnalyzerBank:
         """Sum `bins` (device [frames][bins]) over the ranks of `comm` in place: RCCL from the library's host side."""
         check(lib.mi_analyzer_bank_allreduce_bins(self.handle, _ptr(bins), int(frames), comm.handle, _stream(stream)))
 
+    def allreduce_bins_begin(self, partial, total, frames, comm, slot, stream=None):
+        """The same collective on the communicator's side stream, behind what `stream` has enqueued so far; comm.wait(slot, stream)
+        before `total` is read or the slot's buffers are written again (mi_analyzer_bank_allreduce_bins_begin)."""
+        check(lib.mi_analyzer_bank_allreduce_bins_begin(self.handle, _ptr(partial), _ptr(total), int(frames), comm.handle, int(slot), _stream(stream)))
+
     def reduce_bins(self, out, with_envelope=False, stream=None):
         check(lib.mi_analyzer_bank_reduce_bins(self.handle, _ptr(out), int(with_envelope), _stream(stream)))
 
@@ -486,6 +491,10 @@ class Comm:
         n, r = c_int(), c_int()
         check(lib.mi_dspu_comm_info(self.handle, byref(n), byref(r)))
         return n.value, r.value
+
+    def wait(self, slot, stream=None):
+        """`stream` waits (on the device) for the collective begun in `slot` (mi_dspu_comm_wait)."""
+        check(lib.mi_dspu_comm_wait(self.handle, int(slot), _stream(stream)))
 
     def close(self):
         if self.handle is not None:

@@ -785,6 +785,37 @@ def test_library_communicator_single_rank(gpu):
     bank.close()
 
 
+def test_collective_beside_the_next_batch_equals_the_serial_one(gpu):
+    """mi_analyzer_bank_allreduce_bins_begin / mi_dspu_comm_wait (the batch's all-reduce on the communicator's side stream, the
+    sums double-buffered: bench.py's C5 loop at N > 1) on the one GPU of the box through a single-rank communicator: the sums
+    every batch ends with are the serial mi_analyzer_bank_allreduce_bins loop's BIT FOR BIT, over seven batches (the slots come
+    round three times; an odd count leaves one slot pending at the end)."""
+    import comm_overlap_demo as demo
+    a = demo.run(gpu, batches=7, C=128, overlapped=True)
+    b = demo.run(gpu, batches=7, C=128, overlapped=False)
+    assert len(a) == len(b) == 7
+    for k in range(7):
+        assert float(np.abs(b[k]).max()) > 0
+        np.testing.assert_array_equal(a[k], b[k], err_msg="batch %d" % k)
+
+
+def test_bench_rehearsal_two_ranks_on_one_gpu():
+    """The N > 1 control flow of bench.py's C5 row -- channel shards, the double-buffered sums, a collective per batch, barriers, the
+    max over the ranks -- with TWO ranks on the one GPU of the box (MI_BENCH_REHEARSAL=1: RCCL refuses two ranks on a device, the
+    ranks talk over gloo; the product's kernels and the sharding code are the real ones): rc 0 and ONE parsable line whose
+    n_gpus is 2.  (Its numbers mean nothing and the line says so.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MI_BENCH_REHEARSAL="1", MI_BENCH_DETAIL="bench_detail_rehearsal.json")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--workload", "spectral", "--spec-channels", "128",
+                        "--conv-steps", "32", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and "REHEARSAL" in line["data"], line
+
+
 @pytest.mark.parametrize("rank,masked", [(8, True), (9, False), (11, True), (12, True)])
 def test_spectral_bank_in_place_equals_out_of_place(gpu, rank, masked):
     """SpectralProcessor::process(dst, src, count) takes the caller's samples before it hands out the finished ones at the same
