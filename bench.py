@@ -188,7 +188,7 @@ def _roofline(kernel, alg_bytes, kernel_ms, step_ms, probe_mode, traffic=None, e
     return r
 
 
-def _biquad_issue_side(kernel_ms, C, n, sections, launch_steps, counters):
+def _biquad_issue_side(kernel_ms, C, n, sections, launch_steps, counters, clock_ghz=None):
     """The second roof of the biquad kernels next to the HBM one: VALU issue.  Instructions per launch from the committed SQ
     counters of the SAME kernel (`counters`: a file under profiles/ holding SQ_INSTS_VALU per launch and the blocks that
     launch carried), one wave64 VALU instruction per 4 clocks and SIMD (`v_pk_fma_f32` included: MI355X_MICROARCH.md,
@@ -197,15 +197,23 @@ def _biquad_issue_side(kernel_ms, C, n, sections, launch_steps, counters):
     insts, per = sq.get("SQ_INSTS_VALU"), sq.get("blocks_per_launch", 1)
     if not insts or not kernel_ms or (C, n, sections) != (1024, 4096, 8):
         return {}
+    if not _sources_current(sq.get("sources"), counters):
+        return {}
     avg_s = _probe_mean(kernel_ms) * 1e-3 / launch_steps
     floor_s = float(insts) / per * 4.0 / 1024.0 / 2.4e9
-    return {"valu_issue_frac": round(floor_s / avg_s, 4), "valu_insts_per_block": round(float(insts) / per),
-            "valu_issue_floor_us_per_block": round(floor_s * 1e6, 2), "hbm_floor_us_per_block": round(8.0 * C * n / 6.29e12 * 1e6, 2),
-            "counters_from": "profiles/" + counters}
+    r = {"valu_issue_frac": round(floor_s / avg_s, 4), "valu_insts_per_block": round(float(insts) / per),
+         "valu_issue_floor_us_per_block": round(floor_s * 1e6, 2), "hbm_floor_us_per_block": round(8.0 * C * n / 6.29e12 * 1e6, 2),
+         "counters_from": "profiles/" + counters}
+    if clock_ghz:
+        # the same count at the shader clock the launch HELD (mi_dspu_last_stream_clock: the part lowers its clock under dense packed
+        # arithmetic), not the nominal 2.4 GHz
+        r["shader_clock_ghz"] = round(clock_ghz, 3)
+        r["valu_issue_frac_at_clock"] = round(floor_s * 2.4 / clock_ghz / avg_s, 4)
+    return r
 
 
 
-def _issue_side(kernel, kernel_ms, launch_units, counters="r05_kernels_pmc_sq.json"):
+def _issue_side(kernel, kernel_ms, launch_units, counters="r06_kernels_pmc_sq.json"):
     """The second roof of a launch next to the HBM one: vector issue.  VALU instructions per unit (block / frame) of `kernel`
     from the committed rocprofv3 --pmc counts (profiles/<counters>, tests/prof_valu.sh), one wave64 VALU instruction per 4 clocks
     and SIMD, 1024 SIMDs, 2.4 GHz: valu_issue_frac = that floor / the launch's measured time per unit.  A launch far below BOTH
@@ -214,6 +222,8 @@ def _issue_side(kernel, kernel_ms, launch_units, counters="r05_kernels_pmc_sq.js
     doc = _committed_json(counters) or {}
     for name, d in (doc.get("kernels") or {}).items():
         if kernel in name and kernel_ms:
+            if not _sources_current(d.get("sources"), "%s: %s" % (counters, kernel)):
+                return {}
             per_unit_s = _probe_mean(kernel_ms) * 1e-3 / launch_units
             floor_s = float(d["valu_per_unit"]) * 4.0 / 1024.0 / 2.4e9
             return {"valu_issue_frac": round(floor_s / per_unit_s, 4), "valu_insts_per_unit": round(float(d["valu_per_unit"])),
@@ -229,9 +239,28 @@ def _pmc_traffic(name, kernel=None, units=1):
         d = json.load(open(os.path.join(ROOT, "profiles", name)))
         if kernel is not None and kernel not in d.get("kernel", ""):
             return None
+        if not _sources_current(d.get("sources"), name):
+            return None
         return d["hbm_bytes_per_unit"] * units if "hbm_bytes_per_unit" in d else d.get("hbm_bytes_per_launch")
     except Exception:
         return None
+
+
+_STALE = set()
+
+
+def _sources_current(recorded, what):
+    """A committed counter summary is quoted only while the library this run loaded was built from the sources the summary was
+    measured on (the summary's "sources": file -> sha, tests/prof_sources.py; the library's: mi_dspu_source_sha).  A summary
+    without hashes, or with other ones, is stale: its figure stays out of the line and the line says so ("stale_counters")."""
+    try:
+        mi = importlib.import_module("lsp-dsp-units_amd")
+        ok = bool(recorded) and all(mi.source_sha(f) == sha for f, sha in recorded.items())
+    except Exception:
+        ok = False
+    if not ok:
+        _STALE.add(what)
+    return ok
 
 
 def _committed_json(name):
@@ -1178,9 +1207,12 @@ def _short_roofline(rf):
         out["algorithmic"] = _r(alg, 0)
         if rf.get("traffic"):
             out["traffic_ratio"] = _r(rf["traffic"] / alg, 3)
-    for k in ("kernel_avg_us", "kernel_samples", "steps_per_launch", "whole_step_frac", "valu_issue_frac"):
+    for k in ("kernel_avg_us", "kernel_samples", "steps_per_launch", "whole_step_frac", "valu_issue_frac", "shader_clock_ghz",
+              "valu_issue_frac_at_clock"):
         if rf.get(k) is not None:
             out[k] = rf[k]
+    if rf.get("traffic") is None and rf.get("stale"):
+        out["stale"] = True
     return out
 
 
@@ -1249,6 +1281,10 @@ def compact_line(full, detail_path=None):
         line["exact_mode"] = {"value": em.get("value"), "ms_per_step": em.get("ms_per_step"), "frac": em.get("frac")}
     if full.get("headline_definition_changed_in"):
         line["headline_definition_changed_in"] = full["headline_definition_changed_in"]
+    if full.get("stale_counters"):
+        line["stale_counters"] = len(full["stale_counters"])        # (which ones: the detail file)
+        if line.get("roofline") and line["roofline"].get("traffic") is None:
+            line["roofline"]["stale"] = True
     for name in ("convolver", "equalizer", "spectral"):
         if full.get(name):
             line[name] = _short_sub(full[name])
@@ -1276,6 +1312,12 @@ def compact_line(full, detail_path=None):
 
 
 def emit(full):
+    if _STALE:
+        full["stale_counters"] = sorted(_STALE)
+    _emit(full)
+
+
+def _emit(full):
     """Writes the full result to gpurun_out/bench_detail.json (nothing of it goes to stdout or stderr: the driver's tail is
     one buffer for both) and prints the compact line as the last thing on stdout."""
     detail = None
@@ -1415,6 +1457,16 @@ def main():
                                              probe_steps=launch_steps,
                                              fill_seconds=(0.0 if args.regions else 1.0),
                                              sample_every=(-1 if region is not None else 0))
+    # the shader clock the headline's launches hold: one more region, then the stamps its first workgroup left
+    stream_clock = None
+    if region is not None and hasattr(mi.lib, "mi_dspu_last_stream_clock"):
+        try:
+            for _ in range(3):
+                region()
+            stream.synchronize()
+            stream_clock = mi.last_stream_clock()[0]
+        except Exception:
+            stream_clock = None
     # the same steps as separate process() calls (one launch per block, a hipGraph of the K calls): reported beside `value`
     per_call = None
     if args.launch == "blocks":
@@ -1482,7 +1534,7 @@ def main():
             "roofline": _roofline(kname, alg_bytes * launch_steps, kernel_ms, elapsed / args.steps * 1e3, tinfo["probe"],
                                   committed["traffic"],
                                   _biquad_issue_side(kernel_ms, C, n, coef.shape[1], launch_steps,
-                                                     "r05_biquad_stream_pmc_sq.json" if streamed else "r05_biquad_pmc_sq.json"),
+                                                     "r06_biquad_stream_pmc_sq.json" if streamed else "r06_biquad_pmc_sq.json", clock_ghz=stream_clock),
                                   launch_steps=launch_steps),
             "committed_profile": committed,
         }
@@ -1495,7 +1547,7 @@ def main():
                 "value": round(samples_per_step * args.steps / pe / 1e6, 1), "unit": "Msamples/s",
                 "ms_per_step": round(pe / args.steps * 1e3, 5), "timing": pinfo,
                 "roofline": _roofline("biquad_bank_kernel<16,2>", alg_bytes, pk, pe / args.steps * 1e3, pinfo["probe"], None,
-                                      _biquad_issue_side(pk, C, n, coef.shape[1], 1, "r05_biquad_pmc_sq.json")),
+                                      _biquad_issue_side(pk, C, n, coef.shape[1], 1, "r06_biquad_pmc_sq.json")),
             }
         if exact_mode is not None:
             line["exact_mode"] = {
@@ -1506,6 +1558,8 @@ def main():
         # `value` counts the K blocks of a region as ONE call since round 4 (288 K -> 528 K Msamples/s between rounds 3 and 5 is
         # that change of what is measured; the launch per block -- per_call -- has been 285 K since round 2)
         line["headline_definition_changed_in"] = "r04"
+        if stream_clock:
+            line["roofline"]["shader_clock_ghz"] = round(stream_clock, 3)
         if not args.no_cpu_baseline and world == 1:         # the CPU figure is a 1-process measurement (rank 0 at N = 1 only)
             line["cpu_baseline"] = cpu_baseline_biquad(coef, n)
 

@@ -79,6 +79,12 @@ int         mi_dspu_profile_next_launch(void *start_event, void *stop_event);
  */
 const char *mi_dspu_last_launch(void);
 /*
+ * The first 16 hex digits of the SHA-256 of a source file of csrc/ (e.g. "biquad.hip") as it was when THIS library was built,
+ * or NULL for a name the build did not see.  Counter summaries under profiles/ carry the hashes of the sources they were
+ * measured on; bench.py quotes a committed counter only while the library it loaded was built from the same source.
+ */
+const char *mi_dspu_source_sha(const char *file);
+/*
  * hipGraph helpers for launch-bound inner loops: a run of steady-state *_process() calls on `stream` is captured once
  * and replayed (hipStreamBeginCapture / hipStreamEndCapture + hipGraphInstantiate / hipGraphLaunch).
  * begin: `stream` must be a created (non-NULL) stream.  end: returns an executable graph handle.
@@ -159,6 +165,13 @@ int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *bank, uint32_t channel, int
  */
 int mi_biquad_bank_set_exact(mi_biquad_bank_t *bank, int on);
 int mi_dspu_set_exact_iir_default(int on);
+/*
+ * Measurement aid: the shader clock (GHz) the last run-of-blocks launch of the biquad bank (mi_biquad_bank_process_blocks)
+ * held, from the cycle counter and the 100 MHz wall clock its first workgroup stamps at entry and exit, and that workgroup's
+ * life in microseconds.  The part lowers its clock under dense packed arithmetic: an issue-rate roof priced at the nominal
+ * 2.4 GHz is not the one the launch met (bench.py prices valu_issue_frac at this clock).  Synchronises with the device.
+ */
+int mi_dspu_last_stream_clock(double *ghz, double *microseconds);
 /* Push pending coefficient tables / state clears to the device (async on stream). */
 int mi_biquad_bank_commit(mi_biquad_bank_t *bank, void *stream);
 /* FilterBank::reset(), FilterBank.cpp:238-254; channel = UINT32_MAX for all. */

@@ -16,4 +16,4 @@ from .units import (AnalyzerBank, BiquadBank, Comm, ConvolverBank, CrossoverBank
                     ILUFSBank, LoudnessBank,
                     RingBank,
                     SpectralBank, SplitterBank, crossover_fft_mask,
-                    design_filter, device_count, last_launch, dynfilter_freq_chart, dynfilter_sections, filter_freq_chart, make_window, make_window_general)
+                    design_filter, device_count, last_launch, last_stream_clock, source_sha, dynfilter_freq_chart, dynfilter_sections, filter_freq_chart, make_window, make_window_general)

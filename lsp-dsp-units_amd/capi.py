@@ -1,7 +1,7 @@
 """ctypes declarations for include/mi_dspu.h (one line per exported symbol)."""
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_size_t, c_uint32, c_void_p
+from ctypes import POINTER, c_char_p, c_double, c_float, c_int, c_size_t, c_uint32, c_void_p
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmi_dspu.so")
 
@@ -57,6 +57,8 @@ PROTOTYPES = {
     "mi_dspu_event_elapsed_ms": (c_int, [POINTER(c_float), c_void_p, c_void_p]),
     "mi_dspu_profile_next_launch": (c_int, [c_void_p, c_void_p]),
     "mi_dspu_last_launch": (c_char_p, []),
+    "mi_dspu_source_sha": (c_char_p, [c_char_p]),
+    "mi_dspu_last_stream_clock": (c_int, [POINTER(c_double), POINTER(c_double)]),
     "mi_dspu_graph_begin_capture": (c_int, [c_void_p]),
     "mi_dspu_graph_end_capture": (c_int, [c_void_p, POINTER(c_void_p)]),
     "mi_dspu_graph_launch": (c_int, [c_void_p, c_void_p]),

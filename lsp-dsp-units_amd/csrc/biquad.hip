@@ -1328,12 +1328,27 @@ namespace
         MI_STREAM_PROBE_END();
     }
 
+    __device__ unsigned long long g_stream_clock[4];        // {cycles, wall} at entry, {cycles, wall} at exit of workgroup 0
+
     template <int NW, bool QLDS>
     __global__ __launch_bounds__(64 * NW, (NW >= 4) ? 4 : 2)
     void biquad_stream_kernel(const stream_args a, size_t out_stride, size_t in_stride, int n /* multiple of 16 */,
                               const float *__restrict__ tab, float *state, const uint32_t *__restrict__ nsec, int max_sec, int cap)
     {
+        // (the shader clock the launch ran at: workgroup 0 stamps the shader's cycle counter and the 100 MHz wall clock at its
+        // entry and exit -- mi_dspu_last_stream_clock; a workgroup's life is the launch's for a channel's run of blocks)
+        const bool stamp = blockIdx.x == 0 && threadIdx.x == 0;
+        if (stamp)
+        {
+            g_stream_clock[0] = __builtin_readcyclecounter();
+            g_stream_clock[1] = wall_clock64();
+        }
         biquad_stream_body<NW, false, QLDS>(&a, nullptr, out_stride, in_stride, n, tab, state, nsec, max_sec, cap);
+        if (stamp)
+        {
+            g_stream_clock[2] = __builtin_readcyclecounter();
+            g_stream_clock[3] = wall_clock64();
+        }
     }
 
     // the chain on a run of blocks
@@ -2183,6 +2198,19 @@ int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *b, uint32_t channel, int en
     b->row_off[channel] = off;
     b->nsec_dirty = true;
     b->pending = true;
+    return MI_OK;
+}
+
+int mi_dspu_last_stream_clock(double *ghz, double *microseconds)
+{
+    MI_REQUIRE(ghz != nullptr, MI_EINVAL, "mi_dspu_last_stream_clock: NULL result pointer");
+    unsigned long long h[4] = { 0, 0, 0, 0 };
+    MI_HIP_CHECK(hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stream_clock), sizeof(h)));      // (synchronises with the device)
+    MI_REQUIRE(h[3] > h[1] && h[2] > h[0], MI_ESTATE, "mi_dspu_last_stream_clock: no mi_biquad_bank_process_blocks launch has run yet");
+    const double us = double(h[3] - h[1]) / 100.0;          // wall_clock64: 100 MHz
+    *ghz = double(h[2] - h[0]) / us / 1e3;
+    if (microseconds != nullptr)
+        *microseconds = us;
     return MI_OK;
 }
 

@@ -1,5 +1,6 @@
 // Device/stream/memory plumbing of the C-ABI (include/mi_dspu.h).
 #include "mi_common.h"
+#include <cstring>
 #include <vector>
 #include <mutex>
 #include <map>
@@ -100,6 +101,18 @@ int mi_dspu_profile_next_launch(void *start_event, void *stop_event)
 
 
 const char *mi_dspu_last_launch(void) { return mi::tl_last_launch; }
+
+const char *mi_dspu_source_sha(const char *file)
+{
+    // build/src_sha.h: { "biquad.hip", "0123..." }, ... written by the Makefile from the sources of this build
+    static const struct { const char *file, *sha; } table[] = {
+#include "src_sha.h"
+        { nullptr, nullptr } };
+    for (int i = 0; file != nullptr && table[i].file != nullptr; ++i)
+        if (strcmp(table[i].file, file) == 0)
+            return table[i].sha;
+    return nullptr;
+}
 
 int mi_dspu_abi_version(void) { return MI_DSPU_ABI_VERSION; }
 

@@ -16,6 +16,19 @@ def last_launch():
     return (lib.mi_dspu_last_launch() or b"").decode()
 
 
+def source_sha(name):
+    """SHA-256 (16 hex digits) of csrc/<name> as the loaded library was built from it (mi_dspu_source_sha), or None."""
+    v = lib.mi_dspu_source_sha(name.encode())
+    return v.decode() if v else None
+
+
+def last_stream_clock():
+    """(GHz, microseconds) of the last mi_biquad_bank_process_blocks launch (mi_dspu_last_stream_clock)."""
+    g, us = ctypes.c_double(), ctypes.c_double()
+    check(lib.mi_dspu_last_stream_clock(byref(g), byref(us)))
+    return g.value, us.value
+
+
 def _ptr(x):
     """Device address of a DeviceBuffer, a torch tensor or a raw int."""
     if isinstance(x, DeviceBuffer):

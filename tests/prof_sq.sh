@@ -14,7 +14,9 @@ for CTRS in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_
     rocprofv3 --pmc $CTRS --kernel-trace -d $O/pass$P --output-format csv -- python3 $R/bench.py --workload biquad --no-cpu-baseline --steps 50 > $O/pass$P.log 2>&1
 done
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, os, sys
+sys.path.insert(0, "$R/tests")
+import prof_sources
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for fn in glob.glob("$O/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
@@ -22,7 +24,7 @@ for fn in glob.glob("$O/**/*counter_collection.csv", recursive=True):
             if key in r["Kernel_Name"]:
                 acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for key, name, per in (("biquad_stream_kernel", "${TAG}_biquad_stream_pmc_sq.json", 50), ("biquad_bank_kernel", "${TAG}_biquad_pmc_sq.json", 1)):
-    d = {"kernel": key, "config": "C2: 1024 channels x 4096 samples, 8 sections", "blocks_per_launch": per,
+    d = {"kernel": key, "config": "C2: 1024 channels x 4096 samples, 8 sections", "blocks_per_launch": per, "sources": prof_sources.sources_for(key),
          "note": "rocprofv3 --pmc in three passes (tests/prof_sq.sh), averages per dispatch of bench.py --workload biquad --steps 50; "
                  "cycle counters are in units of four clocks on gfx950"}
     for c, v in acc[key].items():

@@ -14,6 +14,8 @@ done
 python3 - "$O" "$R/gpurun_out/profiles_$TAG/${TAG}_kernels_pmc_sq.json" <<'PY'
 import csv, glob, json, os, sys, collections
 src, dst = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
+import prof_sources
 # units (blocks / frames) a launch of the kernel carries in these passes (--conv-steps 128)
 UNITS = {"conv_frames_kernel": 128, "conv_frames_wave_kernel": 128, "conv_batch_tail_kernel": 16, "conv_batch_forward_kernel": 16, "conv_batch_frames_kernel": 16,
          "analyzer_frames_wave_kernel": 16, "bin_smooth_reduce_kernel": 16, "bin_reduce_frames_kernel": 16, "stft_stream_blocks_kernel": 64, "stft_wave_blocks_kernel": 64, "splitter_hops_blocks_kernel": 64, "splitter_wave_blocks_kernel": 64,
@@ -38,6 +40,7 @@ for wl in sorted(os.listdir(src)):
         d["grid_threads"] = grid
         short = name.split("<")[0]
         d["units_per_launch"] = UNITS.get(short, 1)
+        d["sources"] = prof_sources.sources_for(name)
         d["valu_per_unit"] = d["SQ_INSTS_VALU"] / d["units_per_launch"]
         d["issue_floor_us_per_unit_at_2.4GHz"] = round(d["valu_per_unit"] * 4.0 / 1024.0 / 2400.0, 3)
         out["kernels"]["%s: %s" % (wl, name)] = d
