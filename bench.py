@@ -997,7 +997,7 @@ def run_spectral_processor(args, mi, torch, dist, rank, world, dev):
                         "a buffer of its own for every block of a run)" % C,
                         C, n, K, elapsed, world, 8.0,
                         {"call": "one mi_spectral_bank_process_blocks call per region: runs of 64 blocks ride stft_wave_blocks_kernel "
-                                 "(fft_wave.h: within 1e-6 of %d process() calls; MI_STFT_LDS=1: stft_stream_blocks_kernel, their bits)" % K,
+                                 "(fft_wave.h: within 1e-6 of %d process() calls; MI_DSPU_COMPAT_BITS=1: stft_stream_blocks_kernel, their bits)" % K,
                          "per_call": {"what": "the same blocks as separate mi_spectral_bank_process calls (one launch of stft_stream_kernel per block)",
                                       "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),
                                       "whole_step_frac": round(8.0 * C * n / (pc_elapsed / K) / 1e9 / HBM_PEAK_GBS, 4)}})
@@ -1104,7 +1104,7 @@ def run_splitter(args, mi, torch, dist, rank, world, dev):
                         "overlap-add tails in registers; a buffer of its own for every block of a run)" % C,
                         C, n, K, elapsed, world, 20.0,
                         {"call": "one mi_splitter_bank_process_blocks call per region: runs of 64 blocks ride splitter_wave_blocks_kernel "
-                                 "(fft_wave.h: within 1e-6 of %d process() calls; MI_SPLITTER_LDS=1: splitter_hops_blocks_kernel, one "
+                                 "(fft_wave.h: within 1e-6 of %d process() calls; MI_DSPU_COMPAT_BITS=1: splitter_hops_blocks_kernel, one "
                                  "workgroup per channel and band, their bits)" % K,
                          "per_call": {"what": "the same blocks as separate mi_splitter_bank_process calls (one launch of splitter_hop_kernel per block)",
                                       "value": round(C * n * world * K / pc_elapsed / 1e6, 1), "ms_per_step": round(pc_elapsed / K * 1e3, 5),

@@ -66,6 +66,19 @@ int         mi_dspu_event_record(void *event, void *stream);
 int         mi_dspu_event_synchronize(void *event);
 int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
 /*
+ * Environment switches -- the library reads exactly these four, at every call:
+ *   MI_DSPU_COMPAT_BITS=1     runs of 4096-point blocks (Equalizer FIR/FFT, SpectralProcessor with a mask, SpectralSplitter at
+ *                             rank 12) stay on the workgroup kernels, whose results are the block-by-block calls' BIT FOR BIT,
+ *                             instead of the wave-resident transform kernels (1.3 - 1.7 x faster, within 1e-6 of the calls)
+ *   MI_CONV_TWO_LAUNCH=1      Convolver: frame launch + tail launch instead of the one-launch step   } fall-backs behind two
+ *   MI_ILUFS_TWO_LAUNCHES=1   ILUFSMeter: bookkeeping in a launch of its own                         } in-launch hand-overs that
+ *                             rest on gfx950's dispatch order / memory-side atomics (a wait that does not end raises a fault)
+ *   MI_DSPU_TEST_PATH=a,b,..  TEST HOOK, not a tuning knob: sends calls down another LIVE path of the library -- one that other
+ *                             inputs take anyway -- so that differential tests can hold two paths against each other:
+ *                             blocks_loop, conv_batch_finish, conv_frame_per_launch, crossover_unfused, ilufs_rows_apart,
+ *                             loudness_scalar, splitter_hop_launches, analyzer_strobe_per_launch
+ */
+/*
  * Arm a pair of events for the calling thread: the next hot-path kernel this
  * thread launches (the dominant kernel of the next process() call) records them
  * at its own begin and end (hipExtLaunchKernelGGL), so their elapsed time is the
@@ -529,12 +542,8 @@ int mi_analyzer_bank_get_spectrum(mi_analyzer_bank_t *bank, float *out, size_t o
  * of the cross-channel per-bin reduction; the caller all-reduces it across GPUs. */
 int mi_analyzer_bank_reduce_bins(mi_analyzer_bank_t *bank, float *out, int with_envelope, void *stream);
 /*
- * mi_analyzer_bank_process followed by mi_analyzer_bank_reduce_bins in one call.  By default that is exactly the two
- * launches.  With MI_ANALYZER_FUSED_REDUCE=1 in the environment the reduction rides on the analysis launch of the call's
- * (last) strobe as a second role of the same kernel (the reduce workgroups wait for the rows inside the launch): same
- * results bit for bit, and on MI355X at 1024 channels SLOWER than two launches (20.3 against 17.2 us per step: the
- * reduction needs every row, so nothing overlaps, and a reduce role as narrow as an analysis workgroup is slower than the
- * 16-wave workgroups of its own launch -- profiles/r03_experiments/analyzer_fused_reduce.txt); kept for the record.
+ * mi_analyzer_bank_process followed by mi_analyzer_bank_reduce_bins in one call: the two launches.  (The reduction as a second
+ * role of the analysis launch -- round 3, 20.3 against 17.2 us per step -- was removed in round 6.)
  */
 int mi_analyzer_bank_process_reduce(mi_analyzer_bank_t *bank, const float *in, size_t samples, size_t in_stride,
                                     float *out, int with_envelope, void *stream);

@@ -153,7 +153,7 @@ namespace
     // ROWS > 1 (SUMSQ only): the workgroup runs ROWS consecutive rows side by side, NW waves each -- for the integrated meter,
     // whose rows then leave their sums of squares in LDS (sq.sums points there) for the same workgroup's bookkeeping.  The
     // barriers are the workgroup's: the rows must have the same number of sections and none of them may be switched off.
-    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, bool ROLES = false, int ROWS = 1>
+    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, bool ROLES = false /* (retired: always false) */, int ROWS = 1>
     __device__ __forceinline__
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
@@ -452,94 +452,9 @@ namespace
         };
 
 
-        // ---- two roles (ROLES): the sections split between the two waves, the tiles pipelined ---------------------
-        // The plain two-wave form above gives each wave one sub-block and runs all sections on it: every wave of the chip
-        // loads, computes and stores at the same time, so the memory phases and the arithmetic add.  Here wave A runs the
-        // first half of the sections on tile after tile (2048 samples each) and hands every finished tile to wave B through
-        // LDS, in the chunk layout both use (no transposition in between); B runs the other half and stores.  A's loads of
-        // tile i + 1 fly under its sections on tile i, B's stores of tile i drain under its sections on tile i + 1, and
-        // between the tiles the state of a section stays inside ONE wave (no per-section hand-off, no per-section barrier).
-        // Two tile buffers: A fills buffer i & 1 (first with the rows as loaded, then with its result), B empties it and
-        // uses it once more to transpose its own result for the store.  Barrier i: A arrives once tile i is handed over,
-        // B once it is done with tile i - 1 -- so A never touches a buffer B still needs, and both waves execute exactly
-        // `tiles` barriers (s_barrier counts arrivals, see the note in `section`).
-        if constexpr (ROLES)
-        {
-            const int hA    = (ns + 1) >> 1;
-            const int s_lo  = wv ? hA : 0, s_hi = wv ? ns : hA; // this wave's sections
-            const int tiles = (n + SB - 1) / SB;
-            float *mem = stage_mem(0);
-            for (int i = s_lo + t; i < s_hi; i += 64)           // carried state of this wave's sections (wave-private cells;
-                sstate[0][i] = reinterpret_cast<const float2 *>(mem)[i];     // a wave's LDS accesses complete in order)
-            if (s_hi > s_lo)
-            {
-                load_pq(tb, ctab + size_t(s_lo) * TAB);
-                load_mats(tb, ctab + size_t(s_lo) * TAB);
-                load_coefs(tb, ctab + size_t(s_lo) * TAB);
-            }
-            if (wv == 0)
-                issue_loads(0);
-            else
-                __builtin_amdgcn_s_setprio(1);                  // B holds the finished half of the work: its stores go first
-            for (int i = 0; i < tiles; ++i)
-            {
-                const int par  = i & 1;
-                const int left = n - i * SB;
-                const int last = ((left < SB) ? left : SB) - 1;
-                const int t_last = last / W;
-                const bool save_hi = (last - t_last * W) >= L;
-                const bool saver   = (t == t_last);
-                sx = sx_all + par * 64 * PITCH;
-                if (wv == 0)
-                {
-                    #pragma unroll
-                    for (int k = 0; k < LPT; ++k)
-                    {
-                        const int j = 4 * (k * 64 + t);
-                        *reinterpret_cast<float4 *>(&sx[j + (j / W) * 4]) = ld[k];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    MI_PROBE(1 + 4 * i);
-                    if (i + 1 < tiles)
-                        issue_loads((i + 1) * SB);
-                }
-                else
-                {
-                    __syncthreads();                            // barrier i: tile i is in the buffer
-                    MI_PROBE(1 + 4 * i);
-                }
-                #pragma unroll
-                for (int k = 0; k < L / 4; ++k)
-                {
-                    const float4 a = *reinterpret_cast<const float4 *>(&sx[t * PITCH + 4 * k]);
-                    const float4 b = *reinterpret_cast<const float4 *>(&sx[t * PITCH + L + 4 * k]);
-                    x[4 * k + 0] = v2f{a.x, b.x}; x[4 * k + 1] = v2f{a.y, b.y};
-                    x[4 * k + 2] = v2f{a.z, b.z}; x[4 * k + 3] = v2f{a.w, b.w};
-                }
-                for (int si = s_lo; si < s_hi; ++si)
-                    section(tb, ctab + size_t((si + 1 < s_hi) ? si + 1 : s_lo) * TAB, si, par, saver, save_hi);
-                MI_PROBE(2 + 4 * i);
-                if (wv == 0)
-                {
-                    #pragma unroll
-                    for (int k = 0; k < L / 4; ++k)
-                    {
-                        *reinterpret_cast<float4 *>(&sx[t * PITCH + 4 * k]) =
-                            make_float4(x[4 * k + 0].x, x[4 * k + 1].x, x[4 * k + 2].x, x[4 * k + 3].x);
-                        *reinterpret_cast<float4 *>(&sx[t * PITCH + L + 4 * k]) =
-                            make_float4(x[4 * k + 0].y, x[4 * k + 1].y, x[4 * k + 2].y, x[4 * k + 3].y);
-                    }
-                    __syncthreads();                            // barrier i: handed over
-                }
-                else
-                    store_block(orsrc, i * SB);
-                MI_PROBE(3 + 4 * i);
-            }
-            for (int i = s_lo + t; i < s_hi; i += 64)
-                reinterpret_cast<float2 *>(mem)[i] = sstate[tiles & 1][i];
-            MI_PROBE(15);
-            return;
-        }
+        // (a two-role form -- the sections split between the two waves, the tiles pipelined -- was built and measured in round 3:
+        // 15.3 against 12.7 us, profiles/r03_experiments/biquad_two_roles.txt; removed in round 6)
+
 
         if (!CHAIN)
         {
@@ -741,16 +656,6 @@ namespace
                             const uint32_t *__restrict__ nsec, int max_sec)
     {
         biquad_body<L, NW, ALIGNED, false>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args());
-    }
-
-    // FilterBank::process for calls longer than one tile: two waves per channel in two roles (see ROLES in biquad_body)
-    template <bool ALIGNED>
-    __global__ __launch_bounds__(128, 2)
-    void biquad_roles_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
-                             int n /* multiple of 16 */, const float *__restrict__ tab, float *state,
-                             const uint32_t *__restrict__ nsec, int max_sec)
-    {
-        biquad_body<16, 2, ALIGNED, false, false, true>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args());
     }
 
     template <int L, int NW, bool ALIGNED>
@@ -1948,7 +1853,7 @@ namespace mi
         }
         // (test knob: a launch per block.  Read per call like mi_biquad_bank_process / _process_blocks read it, so that a test
         // that flips it in-process switches the bank path and the chain path together: ADVICE r04)
-        const bool loop = getenv("MI_BIQUAD_BLOCKS_LOOP") != nullptr;
+        const bool loop = mi::test_path("blocks_loop");
         const size_t spb = (samples + big::BLOCK - 1) / big::BLOCK;
         const size_t out_bytes = (size_t(channels - 1) * out_stride + samples) * sizeof(float);
         const size_t in_bytes  = (size_t(channels - 1) * in_stride + samples) * sizeof(float);
@@ -1999,8 +1904,7 @@ namespace mi
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 take_profile_events(&ev0, &ev1);
                 const int nw = (n * spb >= 4) ? 4 : 2;
-                static const bool ql_global = getenv("MI_BIQUAD_QL_GLOBAL") != nullptr;
-                const bool qlds = !ql_global && stream_qlds(nw, sec_cap);
+                const bool qlds = stream_qlds(nw, sec_cap);
                 const size_t lds = stream_lds(nw, sec_cap, qlds);
                 #define MI_STREAM(NWV, Q) MI_LAUNCH((biquad_stream_chain_kernel<NWV, Q>), dim3(channels), dim3(64 * NWV), lds, st, ev0, ev1, a, \
                                                     out_stride, in_stride, int(samples), sec_cap)
@@ -2300,20 +2204,19 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
     // One launch walks the whole call.  The variant sets the chunk length and how many waves share a channel:
     // a wave owns a sub-block of 64 x 2L samples, NW waves cover NW consecutive sub-blocks at once.
     //   <= 1024 samples: L = 8, one wave;  <= 2048: L = 8, two waves;  longer: L = 16, two waves.
-    static const int force_nw = getenv("MI_BIQUAD_WAVES") ? atoi(getenv("MI_BIQUAD_WAVES")) : 0;    // profiling knob
     const bool use_small = samples <= 2 * size_t(small::BLOCK);
     const size_t chunk = use_small ? 8 : 16;
     const size_t tail  = samples % chunk;                   // < chunk samples, done by biquad_tail_kernel
     const size_t body  = samples - tail;
     // the meter's bookkeeping rides on the launch when the launch is the whole call: the long-call variant, no tail kernel
     // behind it (whose sums would come too late), one launch
-    const bool no_ride = ep != nullptr && getenv("MI_ILUFS_TWO_LAUNCHES") != nullptr;       // test knob, read per call
+    const bool no_ride = ep != nullptr && getenv("MI_ILUFS_TWO_LAUNCHES") != nullptr;       // (fall-back: the hand-over inside the launch rests on gfx950 behaviour)
     const bool ride = sq != nullptr && ep != nullptr && !use_small && tail == 0 && body < (size_t(1) << 28) && !no_ride;
     if (rode != nullptr)
         *rode = ride;
     // the stereo meter in one workgroup (biquad_sumsq_ilufs_pair_kernel): rows in pairs, all of them enabled and alike in
     // their number of sections (the workgroup's barriers are shared by its two rows)
-    bool pair_ok = ride && (ep->channels == 1 || (ep->channels == 2 && (b->channels % 2) == 0)) && getenv("MI_ILUFS_ROWS_APART") == nullptr;
+    bool pair_ok = ride && (ep->channels == 1 || (ep->channels == 2 && (b->channels % 2) == 0)) && !mi::test_path("ilufs_rows_apart");
     for (uint32_t c = 0; pair_ok && c < b->channels; ++c)
         pair_ok = !b->row_off[c] && b->nsec[c] == b->nsec[0];
     size_t done = 0;
@@ -2334,29 +2237,6 @@ static int bank_run(mi_biquad_bank_t *b, float *out, const float *in, size_t sam
             e = launch<8, 1>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st, pq);
         else if (use_small)
             e = launch<8, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st, pq);
-        else if (force_nw == 1 && pq == nullptr)
-            e = launch<16, 1>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st);
-        else if (force_nw == 84 && pq == nullptr)
-            e = launch<8, 4>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
-        else if (force_nw == 82 && pq == nullptr)
-            e = launch<8, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_small, st);
-        else if (pq == nullptr && force_nw == 22 && b->max_sec <= uint32_t(big::SG))
-        {
-            // Experiment kept for reproducibility (profiles/r03_experiments/biquad_two_roles.txt: 15.3 us against 12.7 us --
-            // a wave that is alone on its SIMD runs the section code at 7 - 9.5 cycles per instruction, so the fill and the
-            // drain of the two-stage pipeline cost more than the overlapped memory phases save): two roles per channel,
-            // sections split between the waves, tiles pipelined
-            const dim3 grid(b->channels), block(128);
-            hipEvent_t ev0 = nullptr, ev1 = nullptr;
-            mi::take_profile_events(&ev0, &ev1);
-            if (aligned)
-                MI_LAUNCH((biquad_roles_kernel<true>), grid, block, 0, st, ev0, ev1, o, in + done, out_stride, in_stride,
-                          int(step), b->d_big, b->d_state, b->d_nsec, int(b->max_sec));
-            else
-                MI_LAUNCH((biquad_roles_kernel<false>), grid, block, 0, st, ev0, ev1, o, in + done, out_stride, in_stride,
-                          int(step), b->d_big, b->d_state, b->d_nsec, int(b->max_sec));
-            e = hipGetLastError();
-        }
         else
             e = launch<16, 2>(b, o, in + done, out_stride, in_stride, int(step), aligned, b->d_big, st, pq, ride ? ep : nullptr,
                               ride && pair_ok);
@@ -2387,7 +2267,7 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
     // the super-block loop of biquad_bank_kernel, whose hand-overs it reproduces kind for kind.
     if (samples >= 4 * size_t(big::BLOCK) && (samples % 16) == 0 && samples < (size_t(1) << 28) && (out_stride % 4) == 0 &&
         (in_stride % 4) == 0 && ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(in)) % 16) == 0 && !b->exact &&
-        getenv("MI_BIQUAD_BLOCKS_LOOP") == nullptr)
+        !mi::test_path("blocks_loop"))
     {
         bool fits = true;
         for (uint32_t c = 0; fits && c < b->channels; ++c)
@@ -2409,7 +2289,6 @@ int mi_biquad_bank_process(mi_biquad_bank_t *b, float *out, const float *in, siz
 static int stream_launch(mi_biquad_bank_t *b, float *const *out, const float *const *in, size_t first, size_t count,
                          size_t samples, size_t out_stride, size_t in_stride, hipStream_t st)
 {
-    static const int force_nw = getenv("MI_BIQUAD_STREAM_WAVES") ? atoi(getenv("MI_BIQUAD_STREAM_WAVES")) : 0;  // profiling knob
     stream_args a;
     a.blocks = int(count);
     for (size_t k = 0; k < count; ++k)
@@ -2418,21 +2297,20 @@ static int stream_launch(mi_biquad_bank_t *b, float *const *out, const float *co
         a.in[k]  = in[first + k];
     }
     const size_t subs = count * ((samples + big::BLOCK - 1) / big::BLOCK);
-    const int nw = (force_nw == 1 || force_nw == 2 || force_nw == 4) ? force_nw : (subs >= 4) ? 4 : 2;
+    const int nw = (subs >= 4) ? 4 : 2;
     const dim3 grid(b->channels);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     mi::take_profile_events(&ev0, &ev1);
     int cap = 1;                                            // sections the launch's cells (and scan operands) must hold
     for (uint32_t c = 0; c < b->channels; ++c)
         cap = std::max(cap, int(b->nsec[c]));
-    static const bool ql_global = getenv("MI_BIQUAD_QL_GLOBAL") != nullptr;     // experiment knob: the scan operand from the table
-    const bool qlds = !ql_global && stream_qlds(nw, cap);
+    const bool qlds = stream_qlds(nw, cap);
     const size_t lds = stream_lds(nw, cap, qlds);
     #define MI_STREAM(NWV, Q) MI_LAUNCH((biquad_stream_kernel<NWV, Q>), grid, dim3(64 * NWV), lds, st, ev0, ev1, a, out_stride, in_stride, \
                                         int(samples), b->d_big, b->d_state, b->d_nsec, int(b->max_sec), cap)
     if (nw == 4)      { if (qlds) MI_STREAM(4, true); else MI_STREAM(4, false); }
     else if (nw == 2) { if (qlds) MI_STREAM(2, true); else MI_STREAM(2, false); }
-    else              { if (qlds) MI_STREAM(1, true); else MI_STREAM(1, false); }
+    else              { if (qlds) MI_STREAM(2, true); else MI_STREAM(2, false); }
     #undef MI_STREAM
     MI_HIP_CHECK(hipGetLastError());
     return MI_OK;
@@ -2457,7 +2335,7 @@ int mi_biquad_bank_process_blocks(mi_biquad_bank_t *b, float *const *out, const 
     // One launch for a run of blocks (biquad_stream_kernel) where the blocks are what the long-call kernel takes -- more
     // than 2048 samples, whole chunks of 16, 16-byte aligned rows -- and every channel's sections have a hand-over cell.
     bool streamable = samples > 2 * size_t(small::BLOCK) && (samples % 16) == 0 && samples < (size_t(1) << 28) && !b->exact &&
-                      (out_stride % 4) == 0 && (in_stride % 4) == 0 && getenv("MI_BIQUAD_BLOCKS_LOOP") == nullptr;
+                      (out_stride % 4) == 0 && (in_stride % 4) == 0 && !mi::test_path("blocks_loop");
     for (uint32_t c = 0; streamable && c < b->channels; ++c)
         streamable = b->nsec[c] <= uint32_t(STREAM_SG);
     const size_t spb = (samples + big::BLOCK - 1) / big::BLOCK;

@@ -1809,8 +1809,7 @@ namespace
         mi::take_profile_events(&ev0, &ev1);
         // the images this launch reads: (P - 1) partitions of H and of the ring, M complex each, per channel
         const size_t working_set = size_t(b->channels) * size_t(b->P - 1) * size_t(M) * sizeof(float2) * 2;
-        static const int force_nt = getenv("MI_CONV_NT") ? atoi(getenv("MI_CONV_NT")) : -1;    // experiment knob: 0 / 1
-        const bool nt = (force_nt >= 0) ? (force_nt != 0) : (working_set > (size_t(256) << 20));
+        const bool nt = working_set > (size_t(256) << 20);
         if (nt)
             MI_LAUNCH(conv_mac_kernel<true>, dim3((M / 2 + 255) / 256, b->channels), dim3(256), 0, st, ev0, ev1,
                                   b->d_yt, b->d_ring, b->R, b->slot, b->d_H, b->P, M);
@@ -1833,8 +1832,7 @@ namespace
             hipEvent_t ev0 = nullptr, ev1 = nullptr;
             mi::take_profile_events(&ev0, &ev1);
             const size_t working_set = size_t(b->channels) * size_t(b->P - 1) * size_t(b->B) * sizeof(float2) * 2;
-            static const int force_nt = getenv("MI_CONV_NT") ? atoi(getenv("MI_CONV_NT")) : -1;    // experiment knob: 0 / 1
-            const bool nt = (force_nt >= 0) ? (force_nt != 0) : (working_set > (size_t(256) << 20));
+            const bool nt = working_set > (size_t(256) << 20);
             uint32_t *done = b->d_sync, *seen = b->d_sync + b->channels, *fault = b->d_sync + 2 * size_t(b->channels);
             // One frame and one tail workgroup per CU run side by side; with more channels than CUs the frame workgroups
             // (lower indices, dispatched first) would take both places of every CU and the tail role would follow them
@@ -1946,21 +1944,17 @@ namespace
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);                // the pass over the partitions is what the batch is about
         const dim3 tgrid(M / 2 / 256, b->channels);
-        static const bool keep = getenv("MI_CONV_BATCH_REREAD") == nullptr;     // experiment knob: the staged frames read twice
-        #define MI_TAIL(KK) do { if (keep) MI_LAUNCH((conv_batch_tail_kernel<KK, true>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
-                                                     b->yt_pending, b->d_ring, b->R, b->slot, b->d_H, b->P, M); \
-                                 else      MI_LAUNCH((conv_batch_tail_kernel<KK, false>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
-                                                     b->yt_pending, b->d_ring, b->R, b->slot, b->d_H, b->P, M); } while (0)
+        #define MI_TAIL(KK) MI_LAUNCH((conv_batch_tail_kernel<KK, true>), tgrid, dim3(256), 0, st, ev0, ev1, b->d_yts, b->d_yt, \
+                                      b->yt_pending, b->d_ring, b->R, b->slot, b->d_H, b->P, M)
         switch (K) { case 2: { MI_TAIL(2); break; } case 4: { MI_TAIL(4); break; } case 8: { MI_TAIL(8); break; } default: { MI_TAIL(16); break; } }
         #undef MI_TAIL
         MI_HIP_CHECK(hipGetLastError());
-        static const int force_groups = getenv("MI_CONV_BATCH_GROUPS") ? atoi(getenv("MI_CONV_BATCH_GROUPS")) : 0;     // experiment knob
         // (a workgroup per CU is enough for these: one run per channel from 256 channels on -- 16.9 against 17.2 / 17.5 / 18.2 us per
         // frame with 2 / 4 / 8 runs at C3 --, up to four per channel below that)
-        const int want = (force_groups > 0) ? force_groups : std::max(1, std::min(4, int(256 / b->channels)));
+        const int want = std::max(1, std::min(4, int(256 / b->channels)));
         const int groups = std::min(K, want), per = (K + groups - 1) / groups;
         // one run per channel: the workgroup that takes the accumulator is the one that leaves it -- straight into d_acc, no finish launch
-        static const bool always_finish = getenv("MI_CONV_BATCH_FINISH") != nullptr;       // experiment knob: the launch as before
+        const bool always_finish = mi::test_path("conv_batch_finish");      // (the finish launch banks of fewer than 256 channels take anyway)
         const bool direct = per >= K && !always_finish;
         float *const acc_out = direct ? b->d_acc : b->d_acc_new;
         const int acc_out_stride = direct ? 2 * M : M;
@@ -2130,7 +2124,7 @@ namespace mi
         mi::take_profile_events(&fe0, &fe1);
         // 4096-sample blocks: a wave per block on the wave-resident transform (conv_frames_wave_kernel) -- if the buffers of the run
         // allow its blocks to be taken in any order (wave_run_ok: a run in place goes the workgroup's way)
-        bool waves = b->logm == 12 && aligned && blocks >= 2 && b->pool[b->cv].W != nullptr && getenv("MI_CONV_FRAMES_LDS") == nullptr;
+        bool waves = b->logm == 12 && aligned && blocks >= 2 && b->pool[b->cv].W != nullptr && !mi::compat_bits();
         const size_t span_o = (b->channels - 1) * out_stride + size_t(b->B), span_i = (b->channels - 1) * in_stride + size_t(b->B);
         if (waves && (apart || wave_run_ok(out, in, blocks, span_o, span_i)))
         {
@@ -2258,8 +2252,7 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
         #undef MI_CALL
         e = hipGetLastError();
     }
-    static const bool no_small = getenv("MI_CONV_NO_SMALL") != nullptr;         // experiment knob: the round-2 path
-    if (e == hipSuccess && b->P >= 2 && b->B >= 4 * SB && !no_small)
+    if (e == hipSuccess && b->P >= 2 && b->B >= 4 * SB)
     {
         b->small = true;
         b->Ps = b->B / SB;
@@ -2686,15 +2679,13 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
             b->off += cnt;
             done += size_t(cnt);
             }
-            static const bool two_role_completion = getenv("MI_CONV_COMMIT_LAUNCHES") == nullptr;    // (knob: commit + tail as before)
-            if (b->off == B && b->small && b->P >= 2 && b->one_launch && !b->yt_pending && two_role_completion)
+            if (b->off == B && b->small && b->P >= 2 && b->one_launch && !b->yt_pending)
             {
                 // A frame received in blocks completes like a whole frame minus its output (which went out block by
                 // block): the frame role of the one-launch step transforms d_frame, hands the image to the tail role and
                 // leaves IFFT(H_0 X)[B, 2B) + acc[B, 2B) as the new accumulator -- commit and tail side by side in one
                 // launch instead of one after the other (14.7 + 38.6 us as two launches at C3).
-                static const bool fold_in_launch = getenv("MI_CONV_FOLD_LAUNCH") == nullptr;          // (knob: the fold as its own launch)
-                const int r = launch_frame(b, nullptr, b->d_frame, 0, size_t(B), true, st, fold_in_launch);
+                const int r = launch_frame(b, nullptr, b->d_frame, 0, size_t(B), true, st, true);
                 if (r != MI_OK)
                     return r;
                 b->off = 0;
@@ -2744,7 +2735,7 @@ int mi_convolver_bank_process_blocks(mi_convolver_bank_t *b, float *const *out, 
     hipStream_t st = mi::as_stream(stream);
     hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
     const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-    static const bool per_frame = getenv("MI_CONV_FRAME_PER_LAUNCH") != nullptr;        // test knob: the loop of calls
+    const bool per_frame = mi::test_path("conv_frame_per_launch");      // (the loop of calls that blocks which are not whole frames take anyway)
     const size_t ob = (size_t(b->channels - 1) * out_stride + samples) * sizeof(float), ib = (size_t(b->channels - 1) * in_stride + samples) * sizeof(float);
     auto overlap = [](const void *p, size_t pn, const void *q, size_t qn) -> bool {
         const uintptr_t a0 = reinterpret_cast<uintptr_t>(p), b0 = reinterpret_cast<uintptr_t>(q);

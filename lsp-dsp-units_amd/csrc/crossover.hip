@@ -361,7 +361,7 @@ int mi_crossover_bank_process(mi_crossover_bank_t *b, float *const *band_out, co
     // The whole plan in one launch when the call qualifies (Crossover.cpp:451-498 as a chain on a block held in
     // registers): band k = LPF_k(src) is a branch, src = HPF_k(src) runs in place, the last high-pass is the last band.
     // The source is read once and every band written once: 4 + 4 * bands bytes per sample instead of 8 per filter.
-    static const bool unfused = getenv("MI_CROSSOVER_UNFUSED") != nullptr;      // test knob: one launch per filter
+    const bool unfused = mi::test_path("crossover_unfused");          // (one launch per filter: what calls that do not qualify take anyway)
     if (!unfused)
     {
         std::vector<mi::biquad_chain_stage> chain;
@@ -431,7 +431,7 @@ int mi_crossover_bank_process_blocks(mi_crossover_bank_t *b, float *const *band_
         }
         return MI_OK;
     };
-    static const bool unfused = getenv("MI_CROSSOVER_UNFUSED") != nullptr;
+    const bool unfused = mi::test_path("crossover_unfused");
     if (np == 0 || blocks < 2 || unfused)
         return one_by_one();
     // the same bands have a handler in every block (a band without one is skipped, its low-pass rests: Crossover.cpp:462-466)

@@ -929,12 +929,11 @@ int mi_dynfilter_bank_process(mi_dynfilter_bank_t *b, uint32_t id, float *out, c
     const size_t chunks = (samples + 64 * LC - 1) / (64 * LC);
     #define MI_DYN_LAUNCH(NW, BASE) hipLaunchKernelGGL((dynfilter_kernel<NW, BASE>), dim3(b->channels), dim3(64 * NW), 0, st, out, in, \
                                                        gain, out_stride, in_stride, gain_stride, uint32_t(samples), f, state, aligned)
-    static const bool generic = getenv("MI_DYNFILTER_GENERIC") != nullptr;     // test knob: the any-type kernel for every call
     bool issued = false;
     // long calls: the kernel of the filter's type.  (Matched-Z bell and resonance are the two of the 54 that the any-type
     // kernel serves faster: 92 against 100 us per 1024 x 4096 call, profiles/r03_experiments/dynfilter_per_type.txt)
     const bool slower = !f.bilinear && (f.p.base == MI_FLT_BT_RLC_BELL || f.p.base == MI_FLT_BT_RLC_RESONANCE);
-    if (samples > size_t(MI_DYN_SPEC_FROM) && !generic && !slower)
+    if (samples > size_t(MI_DYN_SPEC_FROM) && !slower)
     {
         issued = true;
         switch (f.p.base)

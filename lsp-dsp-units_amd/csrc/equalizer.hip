@@ -503,7 +503,7 @@ int mi_equalizer_bank_process(mi_equalizer_bank_t *b, float *out, const float *i
                 mi::delay_view dl;
                 // several whole blocks at a plain frame boundary: ONE launch walks them (conv_frames_kernel: the response's
                 // image and the overlap-add tail stay in registers, the delay line is touched once at either end)
-                if (rest >= 2 * size_t(b->fir_size) && rest % b->fir_size == 0 && getenv("MI_EQ_FRAME_PER_LAUNCH") == nullptr &&
+                if (rest >= 2 * size_t(b->fir_size) && rest % b->fir_size == 0 &&
                     mi::convolver_takes_delayed_frames(b->conv, b->fir_size) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
                     dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && dl.size >= 2 * b->fir_size)
                 {
@@ -599,7 +599,7 @@ int mi_equalizer_bank_process_blocks(mi_equalizer_bank_t *b, float *const *out, 
             if (r != MI_OK)
                 return r;
             mi::delay_view dl;
-            if (samples == size_t(b->fir_size) && b->primed >= b->fir_size && getenv("MI_EQ_FRAME_PER_LAUNCH") == nullptr &&
+            if (samples == size_t(b->fir_size) && b->primed >= b->fir_size &&
                 mi::convolver_takes_delayed_frames(b->conv, samples) && mi::delay_bank_view(b->delay, &dl) == MI_OK &&
                 dl.delay == b->fir_size && (dl.size % 2 == 0) && (dl.head % 2 == 0) && dl.size >= 2 * b->fir_size)
             {

@@ -961,7 +961,7 @@ static int loudness_process(mi_loudness_bank_t *b, float *out, float *ch_out, co
         float *o_main = out ? out + offset : nullptr, *o_ch = ch_out ? ch_out + offset : nullptr;
         const bool vec4 = (n % 4 == 0) && (b->head % 4 == 0) && (b->period % 4 == 0) && (out_stride % 4 == 0) &&
                           ((reinterpret_cast<uintptr_t>(o_main) | reinterpret_cast<uintptr_t>(o_ch)) % 16 == 0) &&
-                          getenv("MI_LOUDNESS_SCALAR") == nullptr;
+                          !mi::test_path("loudness_scalar");          // (the one-sample kernel that unaligned calls take anyway)
         float *loud_dst = remember ? b->d_loud : static_cast<float *>(nullptr);
         #define MI_LARGS o_main, o_ch, out_stride, b->d_flt, b->cap, b->d_data, b->data_size, b->head, b->period, b->avg, b->d_ms, \
                          b->d_msbuf, b->cap, b->d_cfg, pack, b->channels, uint32_t(n), gain, loud_dst, refresh_at, \

@@ -26,6 +26,14 @@ namespace mi
     // the hot-path kernel the calling thread launched last (MI_LAUNCH notes its name): mi_dspu_last_launch(), so that a test can
     // tell WHICH launch a call took, not only that its result is right
     void        note_launch(const char *kernel);
+    // The library's environment switches, ALL of them (read at every call; documented in include/mi_dspu.h):
+    //   MI_DSPU_COMPAT_BITS=1     runs of 4096-point blocks stay on the workgroup kernels -- the bits of block-by-block calls --
+    //                             instead of the wave-resident transform kernels (within 1e-6 of them): compat_bits()
+    //   MI_CONV_TWO_LAUNCH=1, MI_ILUFS_TWO_LAUNCHES=1   fall-backs behind two in-launch hand-overs that rest on gfx950 behaviour
+    //   MI_DSPU_TEST_PATH=a,b,..  test hook: sends a call down ANOTHER LIVE path of the library (one that other inputs take anyway)
+    //                             so that a differential test can hold the two against each other: test_path("a")
+    bool        compat_bits();
+    bool        test_path(const char *name);
 
     // hipGraph capture of a bank that keeps ring positions on the host (runtime.hip): called at the top of
     // its process() with a function that packs those positions; on a stream that is being captured the positions are

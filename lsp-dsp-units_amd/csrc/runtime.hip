@@ -1,5 +1,6 @@
 // Device/stream/memory plumbing of the C-ABI (include/mi_dspu.h).
 #include "mi_common.h"
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include <mutex>
@@ -22,6 +23,24 @@ namespace mi
         return code;
     }
     static thread_local hipEvent_t tl_start = nullptr, tl_stop = nullptr;
+
+    bool compat_bits()
+    {
+        const char *v = getenv("MI_DSPU_COMPAT_BITS");
+        return v != nullptr && v[0] != '\0' && v[0] != '0';
+    }
+
+    bool test_path(const char *name)
+    {
+        const char *v = getenv("MI_DSPU_TEST_PATH");
+        if (v == nullptr || name == nullptr)
+            return false;
+        const size_t n = strlen(name);
+        for (const char *p = v; (p = strstr(p, name)) != nullptr; p += n)
+            if ((p == v || p[-1] == ',') && (p[n] == '\0' || p[n] == ','))
+                return true;
+        return false;
+    }
 
     static thread_local const char *tl_last_launch = "";
     void note_launch(const char *kernel) { tl_last_launch = kernel; }
@@ -106,7 +125,9 @@ const char *mi_dspu_source_sha(const char *file)
 {
     // build/src_sha.h: { "biquad.hip", "0123..." }, ... written by the Makefile from the sources of this build
     static const struct { const char *file, *sha; } table[] = {
+#if __has_include("src_sha.h")
 #include "src_sha.h"
+#endif
         { nullptr, nullptr } };
     for (int i = 0; file != nullptr && table[i].file != nullptr; ++i)
         if (strcmp(table[i].file, file) == 0)

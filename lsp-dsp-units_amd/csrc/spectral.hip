@@ -1042,61 +1042,20 @@ namespace
         MI_APROBE(6);
     }
 
-    // The analysis of every channel and, riding on the same launch, the per-bin reduction over the channels (round 3).
-    // Workgroups 0 .. channels - 1 are the analysis above.  With a reduction asked for (`red_out`), workgroups from `boundary`
-    // on own 16 bins each (bin_reduce_body): they wait until every analysis workgroup of the launch has flagged its channel in
-    // `rows` -- each does so once its row is complete: the row is written with write-through (sc1) stores, every wave drains its own
-    // (s_waitcnt vmcnt(0), written out) before the workgroup barrier behind which thread 0 stores the flag -- and
-    // read the rows with device-scope loads.  Rows are 128-byte aligned (bins_stride is a multiple of 32 floats): a wave's
-    // store instruction covers whole lines.  The same two-role pattern, the same ordering argument and the same safeguards
-    // as conv_step_kernel (convolver.hip): analysis workgroups never wait, the reduce workgroups have the higher indices,
-    // a wait that does not end raises a host-visible flag instead of hanging.
+    // The analysis of every channel at a strobe (one workgroup per channel).  (Round 3 also let the per-bin reduction ride on this
+    // launch as a second role -- reduce workgroups waiting inside the launch for the rows; measured slower than two launches,
+    // profiles/HISTORY.md, and removed in round 6.)
     template <int LOGH>
     __global__ __launch_bounds__(fplan<LOGH>::T)
     void analyzer_kernel(float *ring, uint32_t buf_size, uint32_t head,
                          const uint32_t *__restrict__ delay, const uint8_t *__restrict__ flags,
                          const float *__restrict__ wnd, const float *__restrict__ amp_old, float *amp_new,
                          uint32_t amp_stride, float tau, const float2 *__restrict__ tw,
-                         const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero,
-                         uint32_t channels, uint32_t boundary, float *red_out, const float *__restrict__ red_env,
-                         uint32_t red_block, uint32_t *rows /* [channels]: the launch in which the row was last completed */, uint32_t rows_target, uint32_t *fault_host)
+                         const float *ingest, size_t ingest_stride, uint32_t ingest_n, int ingest_zero)
     {
-        constexpr int T = fplan<LOGH>::T, H = fplan<LOGH>::N;
         __shared__ float2 lds_[fplan<LOGH>::LDS];
-        if (blockIdx.x < boundary)
-        {
-            if (blockIdx.x >= channels)
-                return;
-            analyzer_role<LOGH>(lds_, ring, buf_size, head, delay, flags, wnd, amp_old, amp_new, amp_stride, tau, tw,
-                                ingest, ingest_stride, ingest_n, ingest_zero);
-            if (red_out != nullptr)
-            {
-                // one flag word per channel, written by one lane with a device-scope store: no read-modify-write (a counter
-                // that 1024 workgroups bump within a microsecond or two serialises at about 12 ns per add and made the fused
-                // launch three times slower than two launches)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (threadIdx.x == 0)
-                    __hip_atomic_store(rows + blockIdx.x, rows_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            return;
-        }
-        for (uint32_t c = threadIdx.x; c < channels; c += T)
-        {
-            uint32_t spins = 0;
-            while (int32_t(__hip_atomic_load(rows + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - rows_target) < 0)
-            {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > (1u << 22))
-                {
-                    __hip_atomic_store(fault_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                    break;
-                }
-            }
-        }
-        __syncthreads();
-        bin_reduce_body<T / 64, true>(red_out, amp_new, amp_stride, channels, uint32_t(H) + 1u, red_env, red_block,
-                                      reinterpret_cast<float (*)[REDUCE_BINS]>(lds_), blockIdx.x - boundary);
+        analyzer_role<LOGH>(lds_, ring, buf_size, head, delay, flags, wnd, amp_old, amp_new, amp_stride, tau, tw,
+                            ingest, ingest_stride, ingest_n, ingest_zero);
     }
 
 
@@ -1500,14 +1459,13 @@ namespace
                 }
                 return;
             }
+            // (its place is not 16-byte aligned, or it straddles the ring's end: a word per lane; the cell's offset is formed per
+            // row -- nothing of this rare path is kept in registers across the transform)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            #pragma unroll 1
             for (int j = 0; j < HALF; ++j)
-            {
-                const float v = area[from + 64 * j + lane];
-                if (d.straight)
-                    put(v, d.rsrc, lane * 4, 256 * j);
-                else
-                    put(v, d.rsrc, wrapped(d.first, lane + 64 * j), 0);
-            }
+                put(area[from + 64 * j + ln], d.rsrc, d.straight ? 4 * (ln + 64 * j) : wrapped(d.first, ln + 64 * j), 0);
         };
         int i = next_active(0);
         float h2[HALF], e[XROWS];
@@ -2280,7 +2238,6 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
         {
             // a whole frame follows in this call: the hop, the emission of the frame it finishes and the intake of the next
             // one in a single launch (stft_stream_kernel) instead of a hop and two strided copies
-            static const bool no_stream = getenv("MI_SPECTRAL_NO_STREAM") != nullptr;          // experiment knob
             const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
             const bool plain = (b->op == MI_SPECTRAL_OP_NONE) || !bound, masked = bound && (b->op == MI_SPECTRAL_OP_MASK);
             const bool aligned = ((reinterpret_cast<uintptr_t>(in + done) | reinterpret_cast<uintptr_t>(out + done)) % 8 == 0) &&
@@ -2291,7 +2248,7 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             const uintptr_t o0 = reinterpret_cast<uintptr_t>(out), i0 = reinterpret_cast<uintptr_t>(in);
             const bool apart = out == nullptr || o0 + ((size_t(b->channels) - 1) * out_stride + count) * sizeof(float) <= i0 ||
                                i0 + ((size_t(b->channels) - 1) * in_stride + count) * sizeof(float) <= o0;
-            if (!no_stream && out != nullptr && (plain || masked) && b->rank >= 8 && b->rank <= 13 && count - done >= frame && aligned &&
+            if (out != nullptr && (plain || masked) && b->rank >= 8 && b->rank <= 13 && count - done >= frame && aligned &&
                 b->d_active == nullptr && apart)
             {
                 // A call of EIGHT or more whole blocks of N samples at rank 12 with a mask: a wave per channel (and segment) on the
@@ -2299,8 +2256,7 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
                 // (stft_wave_blocks_kernel: 14.6 us per block at eight blocks, 12 at 64, against the workgroup kernel's 17 - 19).
                 // Shorter calls stay where they are: the kernel has 20 us of its own per launch -- its tables into LDS, a first block
                 // with nothing in flight, the state written back -- and a one-block call measured 32.5 against 25 - 30 us.
-                if (masked && b->rank == 12 && (count - done) % N == 0 && (count - done) / N >= 8 && getenv("MI_STFT_LDS") == nullptr &&
-                    getenv("MI_SPECTRAL_ONE_HOP") == nullptr)
+                if (masked && b->rank == 12 && (count - done) % N == 0 && (count - done) / N >= 8 && !mi::compat_bits())
                 {
                     while (done < count)
                     {
@@ -2326,9 +2282,8 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
                 hipEvent_t ev0 = nullptr, ev1 = nullptr;
                 mi::take_profile_events(&ev0, &ev1);
                 const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
-                // every whole frame that follows in this call rides on the same launch (MI_SPECTRAL_ONE_HOP=1: one launch per hop)
-                static const bool one_hop = getenv("MI_SPECTRAL_ONE_HOP") != nullptr;
-                const int hops = one_hop ? 1 : int(std::min<size_t>((count - done) / frame, size_t(1) << 20));
+                // every whole frame that follows in this call rides on the same launch
+                const int hops = int(std::min<size_t>((count - done) / frame, size_t(1) << 20));
                 #define MI_CALL(LH) \
                     if (masked) MI_LAUNCH((stft_stream_kernel<(LH < 7 ? 7 : LH > 12 ? 12 : LH), true>), dim3(b->channels), dim3(fplan<(LH < 7 ? 7 : LH > 12 ? 12 : LH)>::T), 0, st, ev0, ev1, \
                                           b->d_in, b->d_out, wi, b->d_wnd_out, b->d_mask, b->mask_stride, b->d_tw, in + done, in_stride, out + done, out_stride, hops); \
@@ -2357,15 +2312,11 @@ int mi_spectral_bank_process(mi_spectral_bank_t *b, float *out, const float *in,
             b->rank <= 14 && (reinterpret_cast<uintptr_t>(in + done) | reinterpret_cast<uintptr_t>(out + done)) % 8 == 0 &&
             in_stride % 2 == 0 && out_stride % 2 == 0 && rows_apart)
         {
-            static const bool no_stream = getenv("MI_SPECTRAL_NO_STREAM") != nullptr;
-            if (!no_stream)
-            {
-                const int r = spectral_hop(b, st, false, in + done, in_stride, out + done, out_stride);
-                if (r != MI_OK)
-                    return r;
-                done += frame;                                  // offset stays 0: the frame was complete and is transformed
-                continue;
-            }
+            const int r = spectral_hop(b, st, false, in + done, in_stride, out + done, out_stride);
+            if (r != MI_OK)
+                return r;
+            done += frame;                                      // offset stays 0: the frame was complete and is transformed
+            continue;
         }
         if (n > 0)
         {
@@ -2410,7 +2361,6 @@ int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, co
         }
         return MI_OK;
     };
-    static const bool per_block = getenv("MI_SPECTRAL_NO_STREAM") != nullptr || getenv("MI_SPECTRAL_ONE_HOP") != nullptr;
     size_t k = 0;
     while (k < blocks)
     {
@@ -2428,7 +2378,7 @@ int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, co
         const size_t N = size_t(1) << b->rank, frame = N >> 1;
         const bool bound = (b->op == MI_SPECTRAL_OP_CALLBACK) ? (b->func != nullptr) : true;
         const bool plain = (b->op == MI_SPECTRAL_OP_NONE) || !bound, masked = bound && (b->op == MI_SPECTRAL_OP_MASK);
-        const bool steady = !per_block && !b->eager && b->offset == frame && (plain || masked) && b->rank >= 8 && b->rank <= 13 &&
+        const bool steady = !b->eager && b->offset == frame && (plain || masked) && b->rank >= 8 && b->rank <= 13 &&
                             (count % frame) == 0 && (in_stride % 2) == 0 && (out_stride % 2) == 0 && b->d_active == nullptr;
         size_t run = 0;
         if (steady)
@@ -2470,7 +2420,7 @@ int mi_spectral_bank_process_blocks(mi_spectral_bank_t *b, float *const *out, co
         const float *wi = (b->wnd_in >= 0) ? b->d_wnd : (const float *)nullptr;
         // rank 12, a fused mask, blocks of exactly one frame whose buffers all lie apart: a wave per channel and segment of the run
         // on the wave-resident transform (stft_wave_blocks_kernel: two frames per complex transform)
-        bool waves = masked && b->rank == 12 && count == N && getenv("MI_STFT_LDS") == nullptr;
+        bool waves = masked && b->rank == 12 && count == N && !mi::compat_bits();
         if (waves)
         {
             std::vector<std::pair<uintptr_t, uintptr_t>> iv;
@@ -2538,11 +2488,6 @@ struct mi_analyzer_bank
     // run as one launch; d_amp and d_data are always two of the planes the bank owns (these and the two it was made with)
     std::vector<float *> planes;
     float      *d_partial = nullptr;        // [slices][REDUCE_FRAMES_MAX][bins_stride]: the slices' partial sums of bin_smooth_reduce_kernel
-    float      *fuse_out = nullptr;         // where the next strobe's launch leaves the reduction (NULL: no reduce role)
-    bool        fuse_env = false, fuse_done = false;
-    uint32_t   *d_rows = nullptr;           // [channels]: sequence number of the launch that last completed the channel's row
-    uint32_t    rows_target = 0;            // sequence number of the launch in hand
-    uint32_t   *h_fault = nullptr, *d_fault_host = nullptr;     // host-mapped flag: a reduce role gave up waiting
 
     uint32_t max_user_delay() const
     {
@@ -2615,34 +2560,11 @@ namespace
         const size_t row = size_t(first) * b->bins_stride;
         if (b->rank <= 14)
         {
-            // the per-bin reduction rides on the launch when one has been asked for (mi_analyzer_bank_process_reduce), the
-            // launch covers every channel and the block sums fit the analysis workgroup's LDS
-            const uint32_t bins = (1u << (b->rank - 1)) + 1;
-            uint32_t block = REDUCE_BLOCK;
-            while ((b->channels + block - 1) / block > REDUCE_MAX_BLOCKS)
-                block *= 2;                                             // (the standalone kernel's choice: same summation order)
-            const size_t lds_floats = size_t(1) << b->rank;             // (at least: the transform's LDS is 2^rank floats or more with either core)
-            // ... and the stream is not capturing: the reduce role waits for a sequence number the HOST counts up per launch
-            // (rows_target, by value); a replay of the captured launch would find that number already reached by the
-            // replay before and sum rows that are still being written
-            hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-            const bool capturing = st != nullptr && hipStreamIsCapturing(st, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
-            const bool fuse = b->fuse_out != nullptr && first == 0 && count == b->channels && b->d_rows != nullptr && !capturing &&
-                              size_t((b->channels + block - 1) / block) * REDUCE_BINS <= lds_floats &&
-                              getenv("MI_ANALYZER_FUSED_REDUCE") != nullptr;      // (measured slower than two launches: see the header)
-            const uint32_t boundary = fuse ? ((count + 7u) & ~7u) : count;
-            const uint32_t grid = fuse ? boundary + (bins + REDUCE_BINS - 1) / REDUCE_BINS : count;
-            if (fuse)
-                b->rows_target += 1;                                    // this launch's sequence number
-            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(grid), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
+            #define MI_CALL(LH) MI_LAUNCH((analyzer_kernel<LH>), dim3(count), dim3(fplan<LH>::T), 0, st, ev0, ev1, \
                 ring, b->buf_size, b->head, b->d_delay + first, b->d_flags + first, b->d_wnd, b->d_data + row, b->d_amp + row, \
-                b->bins_stride, b->tau, b->d_tw, in, in_stride, n, zero ? 1 : 0, \
-                count, boundary, fuse ? b->fuse_out : (float *)nullptr, (fuse && b->fuse_env) ? b->d_env : (const float *)nullptr, \
-                block, b->d_rows, b->rows_target, b->d_fault_host)
+                b->bins_stride, b->tau, b->d_tw, in, in_stride, n, zero ? 1 : 0)
             MI_LOGH_SWITCH(int(b->rank) - 1, MI_CALL)
             #undef MI_CALL
-            if (fuse)
-                b->fuse_done = true;
             MI_HIP_CHECK(hipGetLastError());
             return MI_OK;
         }
@@ -2762,14 +2684,6 @@ int mi_analyzer_bank_create(mi_analyzer_bank_t **bank, uint32_t channels, uint32
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_data), size_t(channels) * b->bins_stride * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_wnd), fft_items * sizeof(float));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_env), b->bins_stride * sizeof(float));
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_rows), channels * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipMemset(b->d_rows, 0, channels * sizeof(uint32_t));
-        if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&b->h_fault), sizeof(uint32_t), hipHostMallocMapped);
-        if (e == hipSuccess)
-        {
-            *b->h_fault = 0u;
-            e = hipHostGetDevicePointer(reinterpret_cast<void **>(&b->d_fault_host), b->h_fault, 0);
-        }
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_delay), channels * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_flags), channels);
         if (max_rank > 14)                                  // frames that go through global memory: three complex frames per channel
@@ -2807,9 +2721,7 @@ int mi_analyzer_bank_destroy(mi_analyzer_bank_t *b)
     (void)hipFree(b->d_ring); (void)hipFree(b->d_wnd);
     (void)hipFree(b->d_env); (void)hipFree(b->d_delay); (void)hipFree(b->d_flags);
     (void)hipFree(b->d_big_work); (void)hipFree(b->d_big_tmp); (void)hipFree(b->d_big_spec);
-    (void)hipFree(b->d_rows);
     (void)hipFree(b->d_partial);
-    (void)hipHostFree(b->h_fault);
     delete b;
     return MI_OK;
 }
@@ -2903,9 +2815,6 @@ static uint64_t analyzer_bank_positions(const void *bank)
 int mi_analyzer_bank_process(mi_analyzer_bank_t *b, const float *in, size_t samples, size_t in_stride, void *stream)
 {
     MI_REQUIRE(b != nullptr, MI_ESTATE, "mi_analyzer_bank_process: NULL bank");
-    MI_REQUIRE(b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u, MI_EHIP,
-               "mi_analyzer_bank_process: the reduce role of an earlier analysis launch gave up waiting for the rows "
-               "(MI_ANALYZER_FUSED_REDUCE): that reduction is invalid");
     hipStream_t st = mi::as_stream(stream);
     {
         const int rc = mi::capture_touch(st, b, "analyzer", analyzer_bank_positions);
@@ -3007,18 +2916,10 @@ int mi_analyzer_bank_process_reduce(mi_analyzer_bank_t *b, const float *in, size
                                     float *out, int with_envelope, void *stream)
 {
     MI_REQUIRE(b != nullptr && out != nullptr, MI_EINVAL, "mi_analyzer_bank_process_reduce: bad argument");
-    b->fuse_out = out;
-    b->fuse_env = with_envelope != 0;
-    b->fuse_done = false;
     const int r = mi_analyzer_bank_process(b, in, samples, in_stride, stream);
-    const bool done = b->fuse_done;
-    b->fuse_out = nullptr;
-    b->fuse_done = false;
     if (r != MI_OK)
         return r;
-    // no strobe fell into this call, or its launch could not carry the reduce role (frames above 2^14 samples, settings
-    // changed in mid-period, too many channels for the block sums): the reduction as its own launch
-    return done ? MI_OK : mi_analyzer_bank_reduce_bins(b, out, with_envelope, stream);
+    return mi_analyzer_bank_reduce_bins(b, out, with_envelope, stream);
 }
 
 int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *const *in, size_t frames, size_t samples, size_t in_stride,
@@ -3029,8 +2930,9 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
     MI_REQUIRE(out_stride >= bins, MI_EINVAL, "mi_analyzer_bank_process_reduce_frames: out_stride shorter than a row of bins");
     hipStream_t st = mi::as_stream(stream);
     // (test knobs, read once per call -- not once per turn of the loop: ADVICE r04)
-    const bool knob_per_frame = getenv("MI_ANALYZER_REDUCE_PER_FRAME") != nullptr;
-    const bool knob_strobe_per_launch = getenv("MI_ANALYZER_STROBE_PER_LAUNCH") != nullptr;
+    // (test hook: the run as a launch per strobe + the planes' reductions in one launch -- what runs with user delays or another
+    // hop take anyway)
+    const bool knob_strobe_per_launch = mi::test_path("analyzer_strobe_per_launch");
     size_t f = 0;
     while (f < frames)
     {
@@ -3040,8 +2942,7 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
         if (r != MI_OK)
             return r;
         const bool batch = b->rank <= 14 && samples == size_t(b->period) && b->counter == 0 && !b->meta_dirty && frames - f >= 2 &&
-                           size_t(b->buf_size) >= (size_t(1) << b->rank) + b->max_user_delay() + samples &&
-                           !knob_per_frame;
+                           size_t(b->buf_size) >= (size_t(1) << b->rank) + b->max_user_delay() + samples;
         if (!batch)
         {
             r = mi_analyzer_bank_process_reduce(b, in[f], samples, in_stride, out + f * out_stride, with_envelope, stream);
@@ -3107,8 +3008,6 @@ int mi_analyzer_bank_process_reduce_frames(mi_analyzer_bank_t *b, const float *c
         }
         if (one_launch)
         {
-            MI_REQUIRE(b->h_fault == nullptr || *static_cast<volatile uint32_t *>(b->h_fault) == 0u, MI_EHIP,
-                       "mi_analyzer_bank_process_reduce_frames: the reduce role of an earlier analysis launch gave up waiting");
             const int rc = mi::capture_touch(st, b, "analyzer", analyzer_bank_positions);
             if (rc != MI_OK)
                 return rc;

@@ -821,7 +821,7 @@ namespace
     // the size, the hop must be the whole half frame, and every handler that is listened to must be a mask.
     bool splitter_hops_fuse(const mi_splitter_bank *b, const float *src, size_t src_stride)
     {
-        if (b->chunk_rank != b->rank || getenv("MI_SPLITTER_HOP_LAUNCHES") != nullptr)
+        if (b->chunk_rank != b->rank || mi::test_path("splitter_hop_launches"))     // (a launch per hop: what chunked frames take anyway)
             return false;
         bool fast = false;
         #define MI_CALL(LH) fast = hop_in_registers<LH>
@@ -855,27 +855,16 @@ namespace
         // (the several-hops form at any channel count: 82 against 105 us per 4096-sample call at 1024 channels x 4 bands,
         // tests/experiments/splitter_rate.py)
         dim3 grid(b->channels, (!callbacks && b->handlers > 1 && (b->channels <= 512 || hops > 1)) ? b->handlers : 1);
-        // several hops per launch with TWO handlers per workgroup sharing the forward transform: a quarter less arithmetic,
-        // half the waves per SIMD -- 27.7 against 24.4 us per block at 256 channels x 4 bands (rank 12), so only on request
-        // (profiles/r03_experiments/splitter_hops_per_launch.txt; the test runs it)
-        const char *const knob = getenv("MI_SPLITTER_BANDS_PER_WG");
-        const bool pairs = hops > 1 && grid.y > 1 && knob != nullptr && atoi(knob) == 2;
-        if (pairs)
-            grid.y = (b->handlers + 1) / 2;
+        // (several hops per launch with TWO handlers per workgroup sharing the forward transform -- a quarter less arithmetic, half the
+        // waves per SIMD -- measured 27.7 against 24.4 us per block at 256 channels x 4 bands, rank 12:
+        // profiles/r03_experiments/splitter_hops_per_launch.txt; removed in round 6)
         hipEvent_t ev0 = nullptr, ev1 = nullptr;
         mi::take_profile_events(&ev0, &ev1);
         if (!callbacks)
         {
             #define MI_ARGS b->d_in, b->d_in2, b->pitch, b->d_lines, b->pitch, b->channels, b->d_desc, b->handlers, b->d_wnd, frame, \
                 (float2 *)nullptr, b->d_tw, src, src_stride, ingest_n, splitter_outs(b), out_stride, out_pos, hops
-            if (pairs)
-            {
-                #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
-                    MI_LAUNCH((splitter_hop_kernel<LH, false, true, 2>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
-                MI_LOGH_SWITCH(lh, MI_CALL)
-                #undef MI_CALL
-            }
-            else if (hops > 1 && grid.y > 1)
+            if (hops > 1 && grid.y > 1)
             {
                 #define MI_CALL(LH) if constexpr (hop_in_registers<LH>) \
                     MI_LAUNCH((splitter_hop_kernel<LH, false, true, 1>), grid, dim3(fplan<LH>::T), 0, st, ev0, ev1, MI_ARGS)
@@ -1414,7 +1403,7 @@ static int splitter_wave_try(mi_splitter_bank_t *b, const split_blocks &tab, siz
     const uint32_t nh = b->handlers;
     wave_bands wb{};
     uint32_t nb = 0;
-    bool waves = b->rank == 12 && b->chunk_rank == b->rank && count == (size_t(1) << b->rank) && getenv("MI_SPLITTER_LDS") == nullptr;
+    bool waves = b->rank == 12 && b->chunk_rank == b->rank && count == (size_t(1) << b->rank) && !mi::compat_bits();
     for (uint32_t i = 0; i < nh && waves; ++i)
     {
         if (!b->has_sink[i])

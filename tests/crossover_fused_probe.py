@@ -1,6 +1,6 @@
 """Helper of tests/test_crossover_gpu.py::test_fused_chain_equals_one_launch_per_filter: runs a 4-band crossover over
-three blocks (4096 samples unless given) and saves the bands.  With MI_CROSSOVER_UNFUSED set the bank runs one launch per
-filter, with MI_BIQUAD_BLOCKS_LOOP long calls stay with the super-block loop of biquad_chain_kernel."""
+three blocks (4096 samples unless given) and saves the bands.  With MI_DSPU_TEST_PATH=crossover_unfused the bank runs one launch per
+filter, with MI_DSPU_TEST_PATH=blocks_loop long calls stay with the super-block loop of biquad_chain_kernel."""
 import importlib
 import os
 import sys

@@ -390,7 +390,7 @@ def test_process_blocks_equals_separate_calls(gpu, n, nb):
 @pytest.mark.parametrize("n", [8192, 8192 + 16, 65536, 48000, 3 * 4096 + 2048 + 32])
 def test_long_calls_through_the_stream_kernel_same_bits(gpu, n, monkeypatch):
     """A process() call of four sub-blocks and more is walked by the stream kernel (four waves per channel) instead of the
-    super-block loop of the one-block kernel: the same bits and the same carried state (MI_BIQUAD_BLOCKS_LOOP=1 selects the old
+    super-block loop of the one-block kernel: the same bits and the same carried state (MI_DSPU_TEST_PATH=blocks_loop selects the old
     path), over two consecutive calls, in place as well."""
     C = 9
     rng = np.random.default_rng(4000 + n)
@@ -399,9 +399,9 @@ def test_long_calls_through_the_stream_kernel_same_bits(gpu, n, monkeypatch):
     res = []
     for old in (True, False):
         if old:
-            monkeypatch.setenv("MI_BIQUAD_BLOCKS_LOOP", "1")
+            monkeypatch.setenv("MI_DSPU_TEST_PATH", "blocks_loop")
         else:
-            monkeypatch.delenv("MI_BIQUAD_BLOCKS_LOOP", raising=False)
+            monkeypatch.delenv("MI_DSPU_TEST_PATH", raising=False)
         bank = gpu.BiquadBank(C, 8)
         for c in range(C):
             bank.set_chains(c, coef[c], False)

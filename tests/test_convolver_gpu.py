@@ -271,7 +271,7 @@ bank.close()
 
 def test_process_blocks_direct_branch_equals_the_finish_launch(gpu, tmp_path):
     """launch_batch with one run per channel (more than 128 channels) writes the accumulator a batch leaves straight into the
-    bank's (`direct`), with fewer channels a finish launch does (conv_batch_finish_kernel; MI_CONV_BATCH_FINISH forces it).  130
+    bank's (`direct`), with fewer channels a finish launch does (conv_batch_finish_kernel; MI_DSPU_TEST_PATH=conv_batch_finish forces it).  130
     channels at rank 10, a frame in pieces in front (the accumulator's upper half is live when the first batch starts), 21 frames
     as batches of 16 + 4 + 1, a frame behind: both branches bit for bit, and against frame-by-frame calls and the oracle.  (The
     knob is read once per process: each variant runs in a process of its own.)"""
@@ -280,7 +280,7 @@ def test_process_blocks_direct_branch_equals_the_finish_launch(gpu, tmp_path):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for name, env in (("direct", {}), ("finish", {"MI_CONV_BATCH_FINISH": "1"}), ("calls", {"MI_CONV_FRAME_PER_LAUNCH": "1"})):
+    for name, env in (("direct", {}), ("finish", {"MI_DSPU_TEST_PATH": "conv_batch_finish"}), ("calls", {"MI_DSPU_TEST_PATH": "conv_frame_per_launch"})):
         out = str(tmp_path / (name + ".npy"))
         e = dict(os.environ)
         e.update(env)

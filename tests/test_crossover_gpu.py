@@ -176,7 +176,7 @@ def test_fused_chain_equals_one_launch_per_filter(gpu, tmp_path, handlers):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = []
-    for tag, env in (("fused", {}), ("unfused", {"MI_CROSSOVER_UNFUSED": "1"})):
+    for tag, env in (("fused", {}), ("unfused", {"MI_DSPU_TEST_PATH": "crossover_unfused"})):
         path = str(tmp_path / (tag + ".npy"))
         e = dict(os.environ)
         e.update(env)
@@ -189,13 +189,13 @@ def test_fused_chain_equals_one_launch_per_filter(gpu, tmp_path, handlers):
 @pytest.mark.parametrize("block", [8192, 10000 - 10000 % 16, 16384])
 def test_long_calls_through_the_stream_kernel_same_bits(gpu, tmp_path, block):
     """process() calls of four sub-blocks and more walk through biquad_stream_chain_kernel: the same bits as the
-    super-block loop of biquad_chain_kernel (MI_BIQUAD_BLOCKS_LOOP) and as one launch per filter."""
+    super-block loop of biquad_chain_kernel (MI_DSPU_TEST_PATH=blocks_loop) and as one launch per filter."""
     import os
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     outs = []
-    for tag, env in (("stream", {}), ("loop", {"MI_BIQUAD_BLOCKS_LOOP": "1"}), ("unfused", {"MI_CROSSOVER_UNFUSED": "1", "MI_BIQUAD_BLOCKS_LOOP": "1"})):
+    for tag, env in (("stream", {}), ("loop", {"MI_DSPU_TEST_PATH": "blocks_loop"}), ("unfused", {"MI_DSPU_TEST_PATH": "crossover_unfused,blocks_loop"})):
         path = str(tmp_path / (tag + ".npy"))
         e = dict(os.environ)
         e.update(env)

@@ -228,7 +228,7 @@ def test_runs_of_blocks_in_one_launch_equal_block_by_block(gpu, rank, mode):
     also behind an odd-sized call, and the state left behind serves whatever call comes next (rank 8: the per-block path).
     Rank 12 with inputs and outputs apart rides conv_frames_wave_kernel (a wave per block on the wave-resident transform):
     the same sums in another order of roundings -- within 1e-6 of the peak of the block-by-block calls instead of their bits
-    (in place it is the workgroup kernel: bits; MI_CONV_FRAMES_LDS=1 keeps that kernel everywhere:
+    (in place it is the workgroup kernel: bits; MI_DSPU_COMPAT_BITS=1 keeps that kernel everywhere:
     test_runs_of_blocks_rank_12_on_the_workgroup_kernel_are_the_calls_bits)."""
     rng = np.random.default_rng(40 + rank)
     C, nfilt, N = 5, 6, 1 << rank
@@ -279,7 +279,7 @@ def test_runs_of_blocks_in_one_launch_equal_block_by_block(gpu, rank, mode):
     b = make()
     yb = feed(b, [("each", N), ("blocks", N * blocks), ("blocks", 2 * N), ("each", 300), ("each", N)])
     aligned = N * (blocks + 3)
-    waves = rank == 12 and os.environ.get("MI_CONV_FRAMES_LDS") is None
+    waves = rank == 12 and os.environ.get("MI_DSPU_COMPAT_BITS") is None
 
     def same(got, want):
         if waves:
@@ -298,11 +298,11 @@ def test_runs_of_blocks_in_one_launch_equal_block_by_block(gpu, rank, mode):
 
 
 def test_runs_of_blocks_rank_12_on_the_workgroup_kernel_are_the_calls_bits():
-    """MI_CONV_FRAMES_LDS=1: runs of 4096-sample blocks on conv_frames_kernel<12> (what in-place runs and rings of buffers shorter
+    """MI_DSPU_COMPAT_BITS=1: runs of 4096-sample blocks on conv_frames_kernel<12> (what in-place runs and rings of buffers shorter
     than the run take in any case) -- the bits of block-by-block calls, as rounds 4 and 5 measured it."""
     import subprocess
     import sys
-    env = dict(os.environ, MI_CONV_FRAMES_LDS="1")
+    env = dict(os.environ, MI_DSPU_COMPAT_BITS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.abspath(__file__) + "::test_runs_of_blocks_in_one_launch_equal_block_by_block"],
                        env=env, capture_output=True, text=True, timeout=900,

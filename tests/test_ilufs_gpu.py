@@ -288,7 +288,7 @@ def test_bookkeeping_riding_on_the_filter_launch_equals_two_launches(gpu, monkey
 def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, mode, K):
     """Two channels per meter, every channel enabled: the meter's two rows run the weighting filter side by side in ONE
     workgroup, which goes straight on with the bookkeeping (biquad_sumsq_ilufs_pair_kernel; no hand-over through memory).
-    Same floats as the rows in workgroups of their own with the bookkeeping riding on the last (MI_ILUFS_ROWS_APART) and
+    Same floats as the rows in workgroups of their own with the bookkeeping riding on the last (MI_DSPU_TEST_PATH=ilufs_rows_apart) and
     as two launches (MI_ILUFS_TWO_LAUNCHES) -- output rows, loudness and history; and a bank with a channel switched off,
     which cannot pair its rows, still agrees with its two-launch form.  K = 1: the mono meter, whose single row needs no
     hand-over either (the same kernel with one row per workgroup)."""
@@ -299,9 +299,11 @@ def test_stereo_meter_in_one_workgroup_equals_the_other_forms(gpu, monkeypatch, 
     x[:, 30000:42000] *= 1e-5
 
     def run(env, off=None):
-        for k in ("MI_ILUFS_ROWS_APART", "MI_ILUFS_TWO_LAUNCHES"):
+        for k in ("MI_DSPU_TEST_PATH", "MI_ILUFS_TWO_LAUNCHES"):
             monkeypatch.delenv(k, raising=False)
-        if env:
+        if env == "MI_ILUFS_ROWS_APART":
+            monkeypatch.setenv("MI_DSPU_TEST_PATH", "ilufs_rows_apart")
+        elif env:
             monkeypatch.setenv(env, "1")
         bank = gpu.ILUFSBank(M, K, 0.0 if mode == "infinite" else 1.2)
         bank.set_sample_rate(sr)

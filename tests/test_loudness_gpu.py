@@ -191,7 +191,7 @@ def test_exact_resummation_inside_long_runs(gpu, blocks):
 
 def test_vector_and_scalar_block_kernels_agree(gpu, monkeypatch):
     """Blocks whose length, line position and period are multiples of four take the kernel with four samples per lane,
-    anything else the one-sample kernel (MI_LOUDNESS_SCALAR forces it): the same stream through both, several laps of the
+    anything else the one-sample kernel (MI_DSPU_TEST_PATH=loudness_scalar forces it): the same stream through both, several laps of the
     lines with the exact re-summation inside the blocks, must agree to float32 round-off of the scan order (and both with
     the oracle through the other tests)."""
     sr, M, K, n = 48000, 3, 2, 4096
@@ -200,9 +200,9 @@ def test_vector_and_scalar_block_kernels_agree(gpu, monkeypatch):
     runs = []
     for scalar in (False, True):
         if scalar:
-            monkeypatch.setenv("MI_LOUDNESS_SCALAR", "1")
+            monkeypatch.setenv("MI_DSPU_TEST_PATH", "loudness_scalar")
         else:
-            monkeypatch.delenv("MI_LOUDNESS_SCALAR", raising=False)
+            monkeypatch.delenv("MI_DSPU_TEST_PATH", raising=False)
         bank = gpu.LoudnessBank(M, K, 400.0)
         bank.set_sample_rate(sr); bank.set_link(1, 0.4)
         outs = []

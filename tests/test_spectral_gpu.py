@@ -409,14 +409,12 @@ def test_reduce_bins_many_channels(gpu):
 
 
 @pytest.mark.parametrize("rank,C", [(12, 1024), (12, 301), (9, 40), (6, 700), (13, 64)])
-def test_reduce_riding_on_the_analysis_launch_equals_two_launches(gpu, rank, C, monkeypatch):
-    """mi_analyzer_bank_process_reduce: the per-bin reduction as a second role of the analysis launch (reduce workgroups
-    wait for the rows inside the launch) against process() followed by reduce_bins() -- bit for bit, over several strobes,
-    with frozen and inactive channels in the bank (their rows are written by other code paths), with and without the
-    envelope, for channel counts on both sides of the workgroup-rounding boundary and for a geometry whose block sums do
-    not fit the analysis workgroup's LDS (rank 6, 700 channels: falls back to two launches by itself)."""
+def test_process_reduce_equals_process_and_reduce_bins(gpu, rank, C):
+    """mi_analyzer_bank_process_reduce against process() followed by reduce_bins() -- bit for bit, over several strobes, with
+    frozen and inactive channels in the bank (their rows are written by other code paths), with and without the envelope.
+    (Round 3's form of the call -- the reduction as a second role of the analysis launch -- measured slower than the two
+    launches it is now and was removed in round 6.)"""
     sr = 48000
-    monkeypatch.setenv("MI_ANALYZER_FUSED_REDUCE", "1")     # (not the default: slower than two launches on MI355X)
     rng = np.random.default_rng(900 + rank + C)
     bins = (1 << (rank - 1)) + 1
     banks = []
@@ -851,7 +849,7 @@ def test_spectral_process_blocks_equal_block_by_block(gpu, rank, masked, n_frame
     both).  Blocks that are not whole frames, or that overlap, are plain loops of calls.
     Rank 12 with a mask and blocks of exactly one frame ride stft_wave_blocks_kernel (a wave per channel and segment of the run, two
     frames per complex transform on the wave-resident core; 37 blocks of 3 channels: segments of 5): the same sums in another order
-    of roundings -- within 1e-6 of the peak of the calls, the state it leaves included (MI_STFT_LDS=1 keeps the workgroup kernel:
+    of roundings -- within 1e-6 of the peak of the calls, the state it leaves included (MI_DSPU_COMPAT_BITS=1 keeps the workgroup kernel:
     test_spectral_runs_rank_12_on_the_workgroup_kernel_are_the_calls_bits)."""
     rng = np.random.default_rng(700 + rank + K)
     C, frame = 3, 1 << (rank - 1)
@@ -874,7 +872,7 @@ def test_spectral_process_blocks_equal_block_by_block(gpu, rank, masked, n_frame
     for k in range(K + 1):
         b.process(ob[k], ins[k], n)
     b.process(ob[K + 1], ins[K + 1], n - 37, n, n)
-    waves = rank == 12 and masked and n_frames == 2 and os.environ.get("MI_STFT_LDS") is None
+    waves = rank == 12 and masked and n_frames == 2 and os.environ.get("MI_DSPU_COMPAT_BITS") is None
     peak = max(float(np.abs(o.download()).max()) for o in ob[:K + 1])
 
     def same(got, want, msg=""):
@@ -926,7 +924,7 @@ def test_spectral_long_call_at_rank_12_rides_the_wave_kernel(gpu):
     for n in sizes:
         d, o = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos:pos + n])), gpu.DeviceBuffer((C, n))
         bank.process(o, d, n)
-        if n == 19 * N and os.environ.get("MI_STFT_LDS") is None:      # which launch the call took (the bank on a frame boundary)
+        if n == 19 * N and os.environ.get("MI_DSPU_COMPAT_BITS") is None:      # which launch the call took (the bank on a frame boundary)
             assert gpu.last_launch().startswith("stft_wave_blocks_kernel"), (n, gpu.last_launch())
         ys.append(o.download())
         pos += n
@@ -940,11 +938,11 @@ def test_spectral_long_call_at_rank_12_rides_the_wave_kernel(gpu):
 
 
 def test_spectral_runs_rank_12_on_the_workgroup_kernel_are_the_calls_bits():
-    """MI_STFT_LDS=1: runs of 4096-sample blocks at rank 12 on stft_stream_blocks_kernel<11> (what runs whose buffers overlap take
+    """MI_DSPU_COMPAT_BITS=1: runs of 4096-sample blocks at rank 12 on stft_stream_blocks_kernel<11> (what runs whose buffers overlap take
     in any case) -- the bits of block-by-block calls."""
     import subprocess
     import sys
-    env = dict(os.environ, MI_STFT_LDS="1")
+    env = dict(os.environ, MI_DSPU_COMPAT_BITS="1")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
                         os.path.abspath(__file__) + "::test_spectral_process_blocks_equal_block_by_block"],
                        env=env, capture_output=True, text=True, timeout=900,
