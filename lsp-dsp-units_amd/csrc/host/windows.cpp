@@ -43,20 +43,29 @@ namespace
         }
     }
 
-    void triangle(float *dst, size_t n, int dn)         // windows.cpp:100-137
+    // The triangular family (misc/windows.cpp:70-99: triangular_general and, with the zeros one step outside / on the ends,
+    // Bartlett-Fejer and the plain triangle): a tent 1 - |i - middle| * slope over `feet`, the distance between its zeros.
+    // Filled from both ends towards the middle: i - middle and (count - 1 - i) - middle are exact negatives of each other
+    // (half-integers far below 2^24), so both flanks get the value the reference computes for them.
+    void tent(float *w, size_t count, int ends /* > 0: zeros one step outside, < 0: on the first and last sample, 0: half a step outside */)
     {
-        if (n == 0)
+        if (count == 0)
             return;
-        float l = (dn > 0) ? n + 1 : (dn < 0) ? n - 1 : n;
-        if (l == 0.0f)
+        const size_t feet = (ends > 0) ? count + 1 : (ends < 0) ? count - 1 : count;
+        if (feet == 0)
         {
-            dst[0] = 0.0f;
+            w[0] = 0.0f;
             return;
         }
-        l = 2.0f / l;
-        const float c = (n - 1) * 0.5;
-        for (size_t i = 0; i < n; ++i)
-            dst[i] = 1.0f - fabs((i - c) * l);
+        const float slope = 2.0f / float(feet), middle = (count - 1) * 0.5;
+        for (size_t lo = 0, hi = count - 1; lo <= hi; ++lo, --hi)
+        {
+            const float v = 1.0f - fabs((lo - middle) * slope);
+            w[lo] = v;
+            w[hi] = v;
+            if (hi == 0)
+                break;
+        }
     }
 } // namespace
 
@@ -116,7 +125,7 @@ void make_window_params(float *dst, size_t n, int type, const float *q)
                 dst[i] = 1.0f;
             break;
         case MI_WINDOW_TRIANGULAR:
-        case MI_WINDOW_BARTLETT_FEJER:  triangle(dst, n, int(q[0])); break;
+        case MI_WINDOW_BARTLETT_FEJER:  tent(dst, n, int(q[0])); break;
         case MI_WINDOW_PARZEN:                              // windows.cpp:139-...: piecewise cubic
         {
             if (n == 0)
