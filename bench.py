@@ -783,7 +783,9 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
         gains = 10.0 ** (rng.uniform(-12.0, 12.0, nfilt) / 20.0)
         for i in range(nfilt):
             eq.set_params(i, FLT_BT_RLC_BELL, 1, float(freqs[i]), float(freqs[i]), float(gains[i]), 2.0, channel=c)
-    ring = int(os.environ.get("MI_BENCH_EQ_RING", "8"))     # (experiment knob: 192 = a buffer of its own for every block of a region)
+    # a buffer of its own for every block of a region (192): nothing comes back out of the 256 MB last-level cache -- an HBM figure --
+    # and the waves take a run's units in a row (MI_BENCH_EQ_RING=8: round 5's ring of eight, which sat in that cache)
+    ring = int(os.environ.get("MI_BENCH_EQ_RING", "192"))
     gen = torch.Generator(device="cpu")
     gen.manual_seed(60 + rank)
     xin = (torch.randn((ring, C, n), generator=gen, dtype=torch.float32) * 0.25).to(dev)
