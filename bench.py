@@ -796,7 +796,7 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
     def step(i):
         eq.process(yout[i % ring], xin[i % ring], n, stream=stream)
     # the K steps of a region as ONE mi_equalizer_bank_process_blocks call: runs of up to 128 blocks ride one launch of
-    # conv_frames_wave_kernel (a wave per block on the wave-resident 4096-point transform, overlap-save: DESIGN.md 3.4)
+    # conv_frames_wave_kernel (a wave per block on the wave-resident 4096-point transform, overlap-save: DESIGN.md 3.3)
     import ctypes
     K = args.conv_steps
     seq = [(args.conv_warmup + i) % ring for i in range(K)]
@@ -825,11 +825,11 @@ def run_equalizer(args, mi, torch, dist, rank, world, dev):
         "config": {"workload": "Equalizer EQM_FIR, 32 x FLT_BT_RLC_BELL per channel, fir_rank 12, %d channels per GPU, "
                                "4096-sample blocks" % C, "channels_per_gpu": C},
         # the step is ONE launch: conv_frame_kernel<12> pulls the frame out of the delay line, transforms, multiplies with
-        # the channel's FIR image, transforms back, overlap-adds and emits (DESIGN.md 3.4)
+        # the channel's FIR image, transforms back, overlap-adds and emits (DESIGN.md 3.3)
         "timing": tinfo,
         # the region is ONE launch per 127 blocks: a wave of conv_frames_wave_kernel per block -- two blocks of samples in 64
         # registers per lane, forward transform, split-product-merge against the response's (alpha, beta) table, inverse, the upper
-        # half out (overlap-save; DESIGN.md 3.4)
+        # half out (overlap-save; DESIGN.md 3.3)
         "roofline": _roofline("conv_frames_wave_kernel (%d blocks per launch)" % launch_steps, step_bytes * launch_steps, kernel_ms,
                               elapsed / args.conv_steps * 1e3, tinfo["probe"],
                               _pmc_traffic("pmc_equalizer_latest.json", "conv_frames_wave_kernel", launch_steps) if C == 256 else None,

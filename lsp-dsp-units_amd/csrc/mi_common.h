@@ -35,7 +35,7 @@ namespace mi
     bool        compat_bits();
     bool        test_path(const char *name);
 
-    // hipGraph capture of a bank that keeps ring positions on the host (runtime.hip, DESIGN.md 3.9): called at the top of
+    // hipGraph capture of a bank that keeps ring positions on the host (runtime.hip, DESIGN.md 3.7): called at the top of
     // its process() with a function that packs those positions; on a stream that is being captured the positions are
     // noted at the bank's first call and compared again at mi_dspu_graph_end_capture.  MI_OK when the stream is not
     // capturing; MI_ESTATE when it is captured behind the library's back.

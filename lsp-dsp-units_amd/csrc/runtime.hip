@@ -306,7 +306,7 @@ int mi_dspu_graph_end_capture(void *stream, void **graph_exec)
                                 "captured calls, and running them once instead failed (%s): reset every bank the capture touched",
                                 n.what, hipGetErrorString(e));
             return mi::fail(MI_ESTATE, "mi_dspu_graph_end_capture: the %s bank does not return to its starting positions over the "
-                            "captured calls -- capture a whole number of its position periods (DESIGN.md 3.9).  The captured calls "
+                            "captured calls -- capture a whole number of its position periods (DESIGN.md 3.7).  The captured calls "
                             "have been executed ONCE (device state and host positions agree); no graph was made", n.what);
         }
     hipGraphExec_t exec = nullptr;

@@ -1,4 +1,4 @@
-"""hipGraph capture of every bank's process() (DESIGN.md 3.9).
+"""hipGraph capture of every bank's process() (DESIGN.md 3.7).
 
 Banks without positions (biquad, crossover, dynamic filters) replay any captured run of calls.  Banks that keep ring
 positions on the host hand them to their kernels by value, so a captured run is right for every replay exactly when it

@@ -571,7 +571,7 @@ def test_analyzer_random_settings(gpu, seed):
     """Differential stress of the analyzer bank: window, envelope, shift, reactivity, rank, rate, activity, channel freeze /
     enable / delay changes and ragged process() calls, at any point of the period: the bank analyses every channel at the
     strobe and, when settings change in the middle of a period, again the channels whose turn has not come yet in the
-    reference's one-channel-every-nStep schedule (DESIGN.md section 3.3).  Only the refresh rate is changed at a strobe:
+    reference's one-channel-every-nStep schedule (DESIGN.md section 3.4).  Only the refresh rate is changed at a strobe:
     in the middle of a period it lets the reference's channel index run past its array (Analyzer.cpp:314)."""
     rng = np.random.default_rng(19000 + seed)
     C, max_rank, sr = 4, 9, 48000
