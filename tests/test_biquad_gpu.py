@@ -844,3 +844,35 @@ def test_c2_full_size_all_channels_exact_mode(gpu):
     assert differing == 0, differing
     np.testing.assert_array_equal(bank.get_state(), state)
     bank.close()
+
+
+def test_c1_readme_filter_in_the_exact_mode_by_default_switch(gpu):
+    """BASELINE config 0 (1 ch x 48000, FLT_BT_BWC_HISHELF slope 2 @1 kHz +6 dB, README.md:176-191) with the process-wide switch
+    mi_dspu_set_exact_iir_default(1) -- how objects of the class layer are put into the exact mode: a bank created afterwards runs
+    biquad_exact_kernel and gives the oracle's output and filter memory bit for bit, in place, in three uneven calls; a bank
+    created after the switch is cleared is a fast one again."""
+    gain = float(np.float32(np.exp(np.float32(6.0) * np.float32(np.log(10.0)) * np.float32(0.05))))
+    bq = wl.design(fd.FLT_BT_BWC_HISHELF, 2, 1000.0, 1000.0, gain, 0.0)
+    x = (np.random.default_rng(1).standard_normal((1, 48000)) * 0.25).astype(np.float32)
+    ref, st = oracle.biquad_cascade(x[0], bq, None)
+    gpu.check(gpu.lib.mi_dspu_set_exact_iir_default(1))
+    try:
+        bank = gpu.BiquadBank(1, 2)
+    finally:
+        gpu.check(gpu.lib.mi_dspu_set_exact_iir_default(0))
+    bank.set_chains(0, bq)
+    buf = gpu.DeviceBuffer.from_host(x)
+    pos = 0
+    for n in (4096, 40000, 3904):
+        seg = gpu.DeviceBuffer.from_host(np.ascontiguousarray(x[:, pos:pos + n]))
+        bank.process(seg, seg, n)                               # in place
+        assert gpu.last_launch().startswith("(biquad_exact_kernel"), gpu.last_launch()
+        np.testing.assert_array_equal(seg.download()[0], ref[pos:pos + n])
+        pos += n
+    np.testing.assert_array_equal(bank.get_state()[0], np.asarray(st, np.float32).reshape(2, 2))
+    bank.close()
+    fast = gpu.BiquadBank(1, 2)
+    fast.set_chains(0, bq)
+    fast.process(buf, buf, 48000)
+    assert not gpu.last_launch().startswith("(biquad_exact_kernel")
+    fast.close()
