@@ -98,9 +98,11 @@ namespace
     using mi::BUFFER_DWORD3;
     using mi::CPOL_SC1;
     using mi::u32x4;
+    using mi::CPOL_NT_SC1;
+    template <int POL = CPOL_NT_SC1>
     __device__ __forceinline__ void store_through(__amdgpu_buffer_rsrc_t rsrc, int dword_index, float4 v)
     {
-        mi::wt_store(rsrc, dword_index * 4, v);
+        mi::wt_store<POL>(rsrc, dword_index * 4, v);
     }
 
 #ifndef MI_ABLATE
@@ -158,7 +160,8 @@ namespace
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
                      const uint32_t *__restrict__ nsec, int max_sec, const chain_args &chain,
-                     const sumsq_args &sq = sumsq_args(), const bool sums_local = false /* sq.sums: [ROWS][4] in LDS */)
+                     const sumsq_args &sq = sumsq_args(), const bool sums_local = false /* sq.sums: [ROWS][4] in LDS */,
+                     const bool out_reread = false /* the next launch reads `out`: plain write-through, not non-temporal */)
     {
         using G = geom<L>;
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
@@ -402,14 +405,17 @@ namespace
             {
                 const int i = 4 * (k * 64 + t);
                 const float4 v = *reinterpret_cast<const float4 *>(&sx[i + (i / W) * 4]);
-                if (ALIGNED)
-                    store_through(dst, base + i, v);
+                constexpr int POL = SUMSQ ? CPOL_SC1 : CPOL_NT_SC1;
+                if (ALIGNED && out_reread)
+                    store_through<CPOL_SC1>(dst, base + i, v);
+                else if (ALIGNED)
+                    store_through<POL>(dst, base + i, v);
                 else
                 {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), dst, (base + i) * 4, 0, CPOL_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), dst, (base + i) * 4 + 4, 0, CPOL_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), dst, (base + i) * 4 + 8, 0, CPOL_SC1);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), dst, (base + i) * 4 + 12, 0, CPOL_SC1);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.x), dst, (base + i) * 4, 0, POL);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.y), dst, (base + i) * 4 + 4, 0, POL);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.z), dst, (base + i) * 4 + 8, 0, POL);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v.w), dst, (base + i) * 4 + 12, 0, POL);
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -653,9 +659,10 @@ namespace
     __global__ __launch_bounds__(64 * NW, (NW > 1) ? 2 : 1)
     void biquad_bank_kernel(float *out, const float *in, size_t out_stride, size_t in_stride,
                             int n /* multiple of L */, const float *__restrict__ tab, float *state,
-                            const uint32_t *__restrict__ nsec, int max_sec)
+                            const uint32_t *__restrict__ nsec, int max_sec, int out_reread)
     {
-        biquad_body<L, NW, ALIGNED, false>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args());
+        biquad_body<L, NW, ALIGNED, false>(out, in, out_stride, in_stride, n, tab, state, nsec, max_sec, chain_args(), sumsq_args(), false,
+                                           out_reread != 0);
     }
 
     template <int L, int NW, bool ALIGNED>
@@ -1563,6 +1570,7 @@ struct mi_biquad_bank
     std::vector<uint8_t>    row_off;        // channel switched off: process() leaves its state and its output alone
     bool                    nsec_dirty  = false;
     bool                    pending     = false;
+    bool                    out_reread  = false;   // the owner's next launch reads process()'s output (LoudnessMeter): keep it in L2
     bool                    exact       = false;   // process() on biquad_exact_kernel: the reference's serial recurrence, bit for bit
     std::vector<float>      h_big, h_small; // host images of the device tables
     float                  *d_big       = nullptr;
@@ -1627,10 +1635,10 @@ namespace
         }
         else if (aligned)
             MI_LAUNCH((biquad_bank_kernel<L, NW, true>), grid, block, 0, st, ev0, ev1, out, in,
-                                  out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
+                                  out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec), int(b->out_reread));
         else
             MI_LAUNCH((biquad_bank_kernel<L, NW, false>), grid, block, 0, st, ev0, ev1, out, in,
-                                  out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec));
+                                  out_stride, in_stride, n, tab, b->d_state, b->d_nsec, int(b->max_sec), int(b->out_reread));
         return hipGetLastError();
     }
 
@@ -1959,6 +1967,8 @@ namespace mi
     // samples [seg_end[s - 1], seg_end[s]) (seg_end[3] = samples).  A channel switched off adds nothing.
     // `ep` != NULL: the integrated meter's bookkeeping for this call; *rode tells whether it went with the launch (then
     // the caller has nothing left to do) or the call did not qualify (the caller launches its own kernel behind this one).
+    void biquad_bank_output_reread(mi_biquad_bank *b, bool yes) { if (b != nullptr) b->out_reread = yes; }
+
     int biquad_bank_sumsq(mi_biquad_bank *b, const float *in, size_t in_stride, size_t samples, const uint32_t seg_end[3],
                           float *sums, hipStream_t st, const mi_meters::ilufs_epilogue *ep, bool *rode)
     {

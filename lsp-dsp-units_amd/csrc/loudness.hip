@@ -720,6 +720,8 @@ int mi_loudness_bank_create(mi_loudness_bank_t **bank, uint32_t meters, uint32_t
         if (b->designation[c] != MI_BS_CHANNEL_NONE)
             b->cfg[c].weight = channel_weighting(b->designation[c]);
     int r = mi_biquad_bank_create(&b->filters, b->rows, 4);                     // sBank.init(4)
+    if (r == MI_OK)
+        mi::biquad_bank_output_reread(b->filters, true);                        // d_flt is the meter kernel's input
     hipError_t e = hipSuccess;
     if (r == MI_OK)
     {

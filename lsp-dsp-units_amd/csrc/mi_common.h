@@ -87,6 +87,7 @@ namespace mi
     // filtered samples of segment s = [seg_end[s - 1], seg_end[s]), seg_end[3] = samples.  The meters' weighting filter.
     // ep != NULL: the integrated loudness meter's bookkeeping of this call (ilufs_device.h) goes with the launch when the
     // call qualifies (*rode = true: the last workgroup of every meter does it), otherwise the caller's own kernel follows.
+    void        biquad_bank_output_reread(mi_biquad_bank_t *bank, bool yes);   // process()'s output feeds the owner's next launch
     int         biquad_bank_sumsq(mi_biquad_bank_t *bank, const float *in, size_t in_stride, size_t samples,
                                   const uint32_t seg_end[3], float *sums, hipStream_t st,
                                   const mi_meters::ilufs_epilogue *ep = nullptr, bool *rode = nullptr);
@@ -139,6 +140,11 @@ namespace mi
     // (MI355X_MICROARCH.md, "publish-large").  Builtins, not inline asm: the compiler's vmcnt bookkeeping sees them.
     constexpr int BUFFER_DWORD3 = 0x00020000;               // raw buffer, 32-bit data format (gfx9 family)
     constexpr int CPOL_SC1 = 16;
+    // ... and non-temporal on top (nt|sc1) for output that nobody on the DEVICE reads again at all (the caller's output
+    // planes): the lines do not displace the state and tables the next launch wants from L2 / MALL.  Measured both ways
+    // (profiles/r06_experiments/store_policy.txt): it pays for the biquad and splitter outputs; planes that the next
+    // launch re-reads (C5's amp/data, the meters' sums) stay sc1.
+    constexpr int CPOL_NT_SC1 = 18;
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -146,19 +152,22 @@ namespace mi
     {
         return __builtin_amdgcn_make_buffer_rsrc(base, 0, int(bytes), BUFFER_DWORD3);
     }
+    template <int POL = CPOL_SC1>
     __device__ __forceinline__ void wt_store(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, float v)
     {
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, byte_offset, 0, CPOL_SC1);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rsrc, byte_offset, 0, POL);
     }
+    template <int POL = CPOL_SC1>
     __device__ __forceinline__ void wt_store(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, float2 v)
     {
         const u32x2 d = { __float_as_uint(v.x), __float_as_uint(v.y) };
-        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, byte_offset, 0, CPOL_SC1);
+        __builtin_amdgcn_raw_buffer_store_b64(d, rsrc, byte_offset, 0, POL);
     }
+    template <int POL = CPOL_SC1>
     __device__ __forceinline__ void wt_store(__amdgpu_buffer_rsrc_t rsrc, int byte_offset, float4 v)
     {
         const u32x4 d = { __float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w) };
-        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, byte_offset, 0, CPOL_SC1);
+        __builtin_amdgcn_raw_buffer_store_b128(d, rsrc, byte_offset, 0, POL);
     }
 } // namespace mi
 #endif
