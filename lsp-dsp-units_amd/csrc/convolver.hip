@@ -299,11 +299,11 @@ namespace
             if (out == nullptr)
                 ;                                           // a frame received in blocks: its own half has gone out block by block
             else if (aligned)
-                mi::wt_store(rout, 8 * n, r);
+                mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n, r);
             else
             {
-                mi::wt_store(rout, 8 * n, r.x);
-                mi::wt_store(rout, 8 * n + 4, r.y);
+                mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n, r.x);
+                mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n + 4, r.y);
             }
             mi::wt_store(racc, 8 * n, make_float2(fmaf(y1.x, scale, p1.x), fmaf(y1.y, scale, p1.y)));
             if (!upper_zero)
@@ -432,11 +432,11 @@ namespace
                 const int n = tid + i * T;
                 const float2 r = make_float2(fmaf(io[i].x, scale, a0[i].x), fmaf(io[i].y, scale, a0[i].y));
                 if (aligned)
-                    mi::wt_store(rout, 8 * n, r);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n, r);
                 else
                 {
-                    mi::wt_store(rout, 8 * n, r.x);
-                    mi::wt_store(rout, 8 * n + 4, r.y);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n, r.x);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n + 4, r.y);
                 }
                 a0[i] = make_float2(fmaf(io[i + NPT].x, scale, a1[i].x), fmaf(io[i + NPT].y, scale, a1[i].y));
                 a1[i] = make_float2(0.0f, 0.0f);
@@ -557,7 +557,7 @@ namespace
                 const __amdgpu_buffer_rsrc_t rout = mi::wt_buffer(fa.out[g] + size_t(ch) * out_stride, unsigned(B * sizeof(float)));
                 #pragma unroll
                 for (int i = 0; i < HALF; ++i)
-                    mi::wt_store(rout, 8 * (lane + 64 * i), make_float2(x[HALF + i].x, x[HALF + i].y));
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * (lane + 64 * i), make_float2(x[HALF + i].x, x[HALF + i].y));
             }
         }
         // What the next call starts from: the tail (unit K's result: the last one of its wave, still in its registers) in the
@@ -947,11 +947,11 @@ namespace
                 const int n = tid + i * T;
                 const float2 r = make_float2(fmaf(io[i].x, scale, a0[i].x), fmaf(io[i].y, scale, a0[i].y));
                 if (aligned)
-                    mi::wt_store(rout, 8 * n, r);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n, r);
                 else
                 {
-                    mi::wt_store(rout, 8 * n, r.x);
-                    mi::wt_store(rout, 8 * n + 4, r.y);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n, r.x);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, 8 * n + 4, r.y);
                 }
                 a0[i] = make_float2(fmaf(io[i + NPT].x, scale, a1[i].x), fmaf(io[i + NPT].y, scale, a1[i].y));
                 a1[i] = make_float2(0.0f, 0.0f);
