@@ -1328,22 +1328,22 @@ namespace
     // the debt (the sum over the small partitions, inverse, acc); wave 0 hands the upper half of its inverse, which the
     // debt's store adds, over through LDS.  One wave did the three transforms one after the other: 8.2 us per call, most
     // of it a lone wave's instruction latency.  Same arithmetic in the same order: the same floats.
-    template <bool FULL>
-    __global__ __launch_bounds__(fplan<LOGS>::T * (FULL ? 2 : 1))
+    template <bool FULL, int LS = LOGS, int PMAX = (1 << (LOGM_MAX - LOGS)) - 1 /* B / SBK - 1 at the largest frame */>
+    __global__ __launch_bounds__(fplan<LS>::T * (FULL ? 2 : 1))
     void conv_small_kernel(float *out, const float *in, size_t out_stride, size_t in_stride, float *frame, int B,
                            int off, float2 *sring, int Ps, const float2 *__restrict__ Hs,
                            float *acc, const float2 *__restrict__ tw)
     {
-        constexpr int M = fplan<LOGS>::N, T = fplan<LOGS>::T, KPT = M / T;
+        constexpr int M = fplan<LS>::N, T = fplan<LS>::T, KPT = M / T, SBK = 1 << LS;   // SBK: samples of a block
         static_assert(KPT * T == M && (KPT % 2) == 0, "small blocks: whole pairs per thread");
         static_assert(T == 64, "one wave per role");
-        __shared__ float2 lds_[FULL ? 2 : 1][fplan<LOGS>::LDS];
-        __shared__ float2 yx[FULL ? M / 2 : 1];                             // (Hs_0 x)[SB, 2 SB), from the output wave to the debt wave
+        __shared__ float2 lds_[FULL ? 2 : 1][fplan<LS>::LDS];
+        __shared__ float2 yx[FULL ? M / 2 : 1];                             // (Hs_0 x)[SBK, 2 SBK), from the output wave to the debt wave
         const int role = FULL ? int(threadIdx.x >> 6) : 0;
         const bool outs = FULL && role == 0, debt = !FULL || role == 1;
-        float2 *const buf = lds_[role], *const scr = lds_[role] + fplan<LOGS>::SCR;
-        const int ch = blockIdx.x, tid = threadIdx.x & (T - 1), kblk = off / SB;
-        const bool next1 = (off + SB < B), next2 = (off + 2 * SB < B);     // the two blocks after this one, if the frame has them
+        float2 *const buf = lds_[role], *const scr = lds_[role] + fplan<LS>::SCR;
+        const int ch = blockIdx.x, tid = threadIdx.x & (T - 1), kblk = off / SBK;
+        const bool next1 = (off + SBK < B), next2 = (off + 2 * SBK < B);     // the two blocks after this one, if the frame has them
         MI_SPROBE(0);
         if (FULL && role == 1 && !next1)
             return;                                                         // the frame's last block owes nothing inside the frame
@@ -1352,14 +1352,14 @@ namespace
         // with the twiddles prepared first and the samples asked for last the kernel paid the latency of memory twice, 2.0 of
         // its 5.1 us before the first butterfly, profiles/r04_experiments/conv_small_timeline.txt)
         float *fr = frame + size_t(ch) * B + off;
-        // SB real samples = SB / 2 pairs, zero-padded to 2 SB: straight into the transform's registers (fft_lds REG_IN)
+        // SBK real samples = SBK / 2 pairs, zero-padded to 2 SBK: straight into the transform's registers (fft_lds REG_IN)
         v2f io[KPT];
         #pragma unroll
         for (int i = 0; i < KPT; ++i)
         {
             const int n = tid + i * T;
             float2 v = make_float2(0.0f, 0.0f);
-            if (n < SB / 2)
+            if (n < SBK / 2)
             {
                 if (FULL)
                 {
@@ -1371,7 +1371,7 @@ namespace
             }
             io[i] = v2f{v.x, v.y};
         }
-        typename fplan<LOGS>::real rf;
+        typename fplan<LS>::real rf;
         rf.load(tw, TWN, tid);
         float *a  = acc + size_t(ch) * 2 * B + off;
         const float2 *hs = Hs + size_t(ch) * Ps * M;
@@ -1386,7 +1386,6 @@ namespace
         // Everything the ring's debt needs that does not depend on this block is asked for NOW: the small partitions' images
         // and the images of the frame's earlier blocks (a wave has 512 registers to itself: up to 2 x 15 x 4
         // values in flight under the transforms instead of fifteen dependent round trips to L2 behind them).
-        constexpr int PMAX = 15;                                            // B / SB - 1 at the largest frame
         const int pmax = (!next1 || !debt) ? 0 : (kblk + 1 < Ps - 1) ? kblk + 1 : Ps - 1;
         float2 hreg[PMAX][KPT], xreg[PMAX][KPT], h0reg[KPT];
         #pragma unroll
@@ -1415,9 +1414,9 @@ namespace
                 accv[i] = *reinterpret_cast<const float2 *>(a + 2 * n);
             else if (next1)
             {
-                accv[i] = *reinterpret_cast<const float2 *>(a + SB + 2 * n);
+                accv[i] = *reinterpret_cast<const float2 *>(a + SBK + 2 * n);
                 if (next2)
-                    accw[i] = *reinterpret_cast<const float2 *>(a + 2 * SB + 2 * n);
+                    accw[i] = *reinterpret_cast<const float2 *>(a + 2 * SBK + 2 * n);
             }
         }
         MI_SPROBE(1);
@@ -1426,10 +1425,21 @@ namespace
         {
             #pragma unroll
             for (int i = 0; i < KPT; ++i)
-                if (tid + i * T < SB / 2)
+                if (tid + i * T < SBK / 2)
                     *reinterpret_cast<float2 *>(fr + 2 * (tid + i * T)) = make_float2(io[i].x, io[i].y);
         }
-        mi_fft::fft_lds<LOGS, false, true, false>(buf, scr, rf.ft, tid, io);
+        // (128-point transforms: their widest pass has fewer butterflies than the wave has lanes, no register hand-over)
+        constexpr bool REG = (T == mi_fft::plan<LS>::TB);
+        if constexpr (REG)
+            mi_fft::fft_lds<LS, false, true, false>(buf, scr, rf.ft, tid, io);
+        else
+        {
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                buf[tid + i * T] = make_float2(io[i].x, io[i].y);
+            __syncthreads();
+            mi_fft::fft_lds<LS, false>(buf, scr, rf.ft, tid);
+        }
         MI_SPROBE(2);
         const float scale = 1.0f / float(2 * M);
         const bool keep = next2 && (outs || !FULL);                         // (nobody reads the last two blocks' images)
@@ -1438,7 +1448,7 @@ namespace
         // is this block's own image) -- is formed and merged in place.  (Round 3, first form: forward with its split pass,
         // the image read back, the products, a pass to put them into LDS, inverse with its merge pass -- five barriers and
         // five trips through LDS more on a lone wave's path.)
-        mi_fft::real_split_filter_merge<LOGS>(buf, rf.rt, tid,
+        mi_fft::real_split_filter_merge<LS>(buf, rf.rt, tid,
             [&](int i, int k, float2 x0, bool partner) -> float2 {
                 const int slot = partner ? i + KPT / 2 : i;
                 if (keep)
@@ -1468,7 +1478,15 @@ namespace
         MI_SPROBE(3);
         if (!FULL && !next1)
             return;                                                         // the frame's last block: the commit settles the rest
-        mi_fft::fft_lds<LOGS, true, false, true>(buf, scr, rf.ft, tid, io);
+        if constexpr (REG)
+            mi_fft::fft_lds<LS, true, false, true>(buf, scr, rf.ft, tid, io);
+        else
+        {
+            mi_fft::fft_lds<LS, true>(buf, scr, rf.ft, tid);
+            #pragma unroll
+            for (int i = 0; i < KPT; ++i)
+                io[i] = v2f{buf[tid + i * T].x, buf[tid + i * T].y};
+        }
         MI_SPROBE(4);
         // (io[i]: pair n = tid + i T of the first half, io[i + KPT / 2]: pair n + M / 2 of the second)
         if (outs)
@@ -1495,7 +1513,7 @@ namespace
             const int n = tid + i * T;
             const float2 t0 = make_float2(io[i].x, io[i].y), t1 = make_float2(io[i + KPT / 2].x, io[i + KPT / 2].y);
             const float2 yhi = FULL ? yx[n] : make_float2(0.0f, 0.0f);
-            float2 *a1 = reinterpret_cast<float2 *>(a + SB + 2 * n), *a2 = reinterpret_cast<float2 *>(a + 2 * SB + 2 * n);
+            float2 *a1 = reinterpret_cast<float2 *>(a + SBK + 2 * n), *a2 = reinterpret_cast<float2 *>(a + 2 * SBK + 2 * n);
             const float2 v1 = accv[i];
             *a1 = make_float2(fmaf(t0.x + yhi.x, scale, v1.x), fmaf(t0.y + yhi.y, scale, v1.y));
             if (next2)
@@ -1747,6 +1765,7 @@ struct mi_convolver_bank
     // sub-frame calls of partitioned banks (conv_small_kernel): the head partition as a delay line of SB-sample blocks
     bool        small = false;      // P >= 2 and B >= 1024
     int         Ps = 0;             // small partitions of the head: B / SB
+    int         logs = LOGS;        // log2 SB: 256-sample blocks; a frame of 256 (rank 9) takes two blocks of 128
     float2     *d_Hs = nullptr, *d_sring = nullptr;     // [channels][Ps][SB]: images of the small partitions / of the frame's blocks
     uint32_t   *h_fault = nullptr;  // host-mapped flag raised by a hand-over that timed out (read by process() without a sync)
     uint32_t   *d_fault_host = nullptr;     // its device address
@@ -2252,18 +2271,25 @@ int mi_convolver_bank_create(mi_convolver_bank_t **bank, uint32_t channels, cons
         #undef MI_CALL
         e = hipGetLastError();
     }
-    if (e == hipSuccess && b->P >= 2 && b->B >= 4 * SB)
+    if (e == hipSuccess && b->P >= 2 && b->B >= SB)
     {
+        // (round 6: frames of 512 and 256 samples too -- ranks 10 and 9, Convolver.cpp:251-262 runs its doubling levels there:
+        // two blocks of half a frame, so that a host that calls with half frames pays one launch per call)
         b->small = true;
-        b->Ps = b->B / SB;
-        const size_t cells = size_t(channels) * b->Ps * SB;
+        b->logs = (b->B >= 2 * SB) ? LOGS : LOGS - 1;
+        b->Ps = b->B >> b->logs;
+        const size_t cells = size_t(channels) * b->B;                       // Ps blocks of SB cells
         e = hipMalloc(reinterpret_cast<void **>(&b->d_Hs), cells * sizeof(float2));
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&b->d_sring), cells * sizeof(float2));
         if (e == hipSuccess)
         {
             // the head partition's taps (zero padded rows of d_h0) as Ps small partitions
-            hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, channels), dim3(fplan<LOGS>::T), 0, st,
-                               b->d_Hs, b->d_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, (const uint8_t *)nullptr);
+            if (b->logs == LOGS)
+                hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, channels), dim3(fplan<LOGS>::T), 0, st,
+                                   b->d_Hs, b->d_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, (const uint8_t *)nullptr);
+            else
+                hipLaunchKernelGGL((conv_parse_kernel<LOGS - 1>), dim3(b->Ps, channels), dim3(fplan<LOGS - 1>::T), 0, st,
+                                   b->d_Hs, b->d_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, (const uint8_t *)nullptr);
             e = hipGetLastError();
         }
     }
@@ -2328,8 +2354,12 @@ static int parse_irs(mi_convolver_bank_t *b, const float *d_irs, size_t ir_strid
             e = hipErrorOutOfMemory;
     if (e == hipSuccess && b->small && dst_h0 == b->d_h0)
     {
-        hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, b->channels), dim3(fplan<LOGS>::T), 0, st,
-                           b->d_Hs, dst_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, d_only);
+        if (b->logs == LOGS)
+            hipLaunchKernelGGL((conv_parse_kernel<LOGS>), dim3(b->Ps, b->channels), dim3(fplan<LOGS>::T), 0, st,
+                               b->d_Hs, dst_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, d_only);
+        else
+            hipLaunchKernelGGL((conv_parse_kernel<LOGS - 1>), dim3(b->Ps, b->channels), dim3(fplan<LOGS - 1>::T), 0, st,
+                               b->d_Hs, dst_h0, M, (const uint32_t *)nullptr, b->Ps, b->d_tw, d_only);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(st);
@@ -2624,34 +2654,46 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 return rf;
             if (b->small)
             {
-                // the head partition as a delay line of SB-sample blocks inside the frame (conv_small_kernel): bounded work
+                // the head partition as a delay line of sb-sample blocks inside the frame (conv_small_kernel): bounded work
+                const int sb = 1 << b->logs;
                 int cnt;
-                if ((b->off % SB) == 0 && left >= size_t(SB))
+                if ((b->off % sb) == 0 && left >= size_t(sb))
                 {
-                    cnt = SB;                                               // an aligned whole block: one launch
-                    hipLaunchKernelGGL((conv_small_kernel<true>), dim3(b->channels), dim3(2 * fplan<LOGS>::T), 0, st,
-                                       o, x, out_stride, in_stride, b->d_frame, B, b->off, b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
+                    cnt = sb;                                               // an aligned whole block: one launch
+                    mi::note_launch("conv_small_kernel<true>");
+                    if (b->logs == LOGS)
+                        hipLaunchKernelGGL((conv_small_kernel<true>), dim3(b->channels), dim3(2 * fplan<LOGS>::T), 0, st,
+                                           o, x, out_stride, in_stride, b->d_frame, B, b->off, b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
+                    else
+                        hipLaunchKernelGGL((conv_small_kernel<true, LOGS - 1, 1>), dim3(b->channels), dim3(2 * fplan<LOGS - 1>::T), 0, st,
+                                           o, x, out_stride, in_stride, b->d_frame, B, b->off, b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
                     MI_HIP_CHECK(hipGetLastError());
                     b->off += cnt;
                 }
                 else
                 {
-                    const size_t room = size_t(SB - (b->off % SB));
+                    const size_t room = size_t(sb - (b->off % sb));
                     cnt = int((left < room) ? left : room);
                     const bool apart = rows_apart(o, out_stride, x, in_stride, size_t(cnt), b->channels);
                     if (!apart)
                         hipLaunchKernelGGL(conv_file_kernel, dim3((cnt + 255) / 256, b->channels), dim3(256), 0, st, b->d_frame, B, b->off,
                                            x, in_stride, cnt);
-                    hipLaunchKernelGGL(conv_direct_kernel, dim3((cnt + SB - 1 + 255) / 256, b->channels), dim3(256),
-                                       size_t(2 * cnt + 256) * sizeof(float), st, o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, SB, B,
+                    mi::note_launch("conv_direct_kernel");
+                    hipLaunchKernelGGL(conv_direct_kernel, dim3((cnt + sb - 1 + 255) / 256, b->channels), dim3(256),
+                                       size_t(2 * cnt + 256) * sizeof(float), st, o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, sb, B,
                                        apart ? x : nullptr, in_stride);
                     MI_HIP_CHECK(hipGetLastError());
                     b->off += cnt;
-                    if ((b->off % SB) == 0)                                 // the block is complete: its image, and what the frame owes the next
+                    if ((b->off % sb) == 0)                                 // the block is complete: its image, and what the frame owes the next
                     {
-                        hipLaunchKernelGGL((conv_small_kernel<false>), dim3(b->channels), dim3(fplan<LOGS>::T), 0, st,
-                                           (float *)nullptr, (const float *)nullptr, size_t(0), size_t(0), b->d_frame, B, b->off - SB,
-                                           b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
+                        if (b->logs == LOGS)
+                            hipLaunchKernelGGL((conv_small_kernel<false>), dim3(b->channels), dim3(fplan<LOGS>::T), 0, st,
+                                               (float *)nullptr, (const float *)nullptr, size_t(0), size_t(0), b->d_frame, B, b->off - sb,
+                                               b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
+                        else
+                            hipLaunchKernelGGL((conv_small_kernel<false, LOGS - 1, 1>), dim3(b->channels), dim3(fplan<LOGS - 1>::T), 0, st,
+                                               (float *)nullptr, (const float *)nullptr, size_t(0), size_t(0), b->d_frame, B, b->off - sb,
+                                               b->d_sring, b->Ps, b->d_Hs, b->d_acc, b->d_tw);
                         MI_HIP_CHECK(hipGetLastError());
                     }
                 }
@@ -2672,8 +2714,11 @@ int mi_convolver_bank_process(mi_convolver_bank_t *b, float *out, const float *i
                 hipLaunchKernelGGL(conv_direct_xfade_kernel, grid, dim3(256), size_t(cnt) * sizeof(float), st,
                                    o, out_stride, b->d_acc, b->d_frame, b->d_h0, b->d_h0x, B, b->off, cnt, b->d_xmask);
             else
+            {
+                mi::note_launch("conv_direct_kernel");
                 hipLaunchKernelGGL(conv_direct_kernel, grid, dim3(256), size_t(2 * cnt + 256) * sizeof(float), st,
                                    o, out_stride, b->d_acc, b->d_frame, b->d_h0, B, b->off, cnt, B, 2 * B, apart ? x : nullptr, in_stride);
+            }
             MI_HIP_CHECK(hipGetLastError());
             b->upper_zero = false;
             b->off += cnt;

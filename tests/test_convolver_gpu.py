@@ -427,6 +427,81 @@ def test_subframe_calls_on_large_frames(gpu, seed):
     bank.close()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_subframe_calls_on_small_frames(gpu, seed):
+    """Ranks 9 and 10 (frames of 256 / 512 samples; the reference runs its doubling levels there, Convolver.cpp:251-262):
+    sub-frame calls of partitioned banks go through the small-block delay line with blocks of HALF a frame (128 / 256
+    samples) -- aligned blocks, ragged pieces, pieces across block and frame boundaries, whole frames in between, resets --
+    against the exact (float64) linear convolution of the channel's history."""
+    rng = np.random.default_rng(9300 + seed)
+    C = 3
+    rank = 9 + seed % 2
+    frame = 1 << (rank - 1)
+    half = frame // 2
+    taps = int(rng.choice([frame + 1, 2 * frame, 3 * frame + 17, 9 * frame - 5]))
+    counts = np.array([taps] + [int(rng.integers(frame + 1, taps + 1)) for _ in range(C - 1)], np.uint32)
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / (0.3 * taps + 1))).astype(np.float32)
+    bank = gpu.ConvolverBank(irs, rank, counts=counts)
+    hist = [np.zeros(0, np.float32) for _ in range(C)]
+    sizes = [1, 2, 31, half - 1, half, half, half, half + 1, frame - 1, frame, frame + 1, frame + half, 2 * frame]
+    for step in range(48):
+        if rng.integers(0, 16) == 0:
+            bank.reset()
+            hist = [np.zeros(0, np.float32) for _ in range(C)]
+            continue
+        k = int(rng.choice(sizes + [int(rng.integers(1, 3 * frame))]))
+        x = rng.standard_normal((C, k)).astype(np.float32)
+        din = gpu.DeviceBuffer.from_host(x)
+        dout = din if rng.integers(0, 2) else gpu.DeviceBuffer((C, k))
+        bank.process(dout, din, k)
+        y = dout.download()
+        for c in range(C):
+            hist[c] = np.concatenate([hist[c], x[c]])[-(taps + 4 * frame + k):]
+            full = exact_conv(hist[c], irs[c, :counts[c]])
+            ref = full[-k:]
+            peak = max(float(np.abs(full[-max(k, 1024):]).max()), 1.0)
+            err = float(np.abs(y[c] - ref).max())
+            record_parity("convolver sub-frame calls: |gpu - exact| <= 2e-5 peak", err, 2 * TOL * peak)
+            assert err <= 2 * TOL * peak, (seed, step, c, k, rank, taps, int(counts[c]), err / peak)
+    assert bank.faults() == 0
+    bank.close()
+
+
+@pytest.mark.parametrize("rank", [9, 10])
+def test_stream_of_half_frame_calls_small_ranks(gpu, rank):
+    """A host that calls with half frames at ranks 9 / 10: every call is one aligned small block in the
+    frequency domain (conv_small_kernel, one launch), every second one completes the frame (the one-launch frame step takes
+    its image and the tail); against the oracle's non-uniform partitioning and the exact convolution, and against the same
+    input given as whole frames."""
+    rng = np.random.default_rng(780 + rank)
+    frame = 1 << (rank - 1)
+    C, taps, nf = 8, 6 * frame + 11, 12
+    irs = (rng.standard_normal((C, taps)) * np.exp(-np.arange(taps) / (2.0 * frame))).astype(np.float32)
+    x = rng.standard_normal((C, nf * frame)).astype(np.float32)
+    bank = gpu.ConvolverBank(irs, rank)
+    y = np.empty_like(x)
+    seen = set()
+    for i in range(2 * nf):
+        din = gpu.DeviceBuffer.from_host(x[:, i * frame // 2:(i + 1) * frame // 2])
+        dout = gpu.DeviceBuffer((C, frame // 2))
+        bank.process(dout, din, frame // 2)
+        seen.add(gpu.last_launch().split("<")[0].strip("("))          # (the last launch of the call)
+        y[:, i * frame // 2:(i + 1) * frame // 2] = dout.download()
+    assert bank.faults() == 0
+    bank.close()
+    assert seen <= {"conv_small_kernel", "conv_step_kernel"}, seen          # (launches that note themselves: no time-domain head)
+    whole, _ = run_gpu(gpu, irs, rank, x, [frame] * nf)
+    for c in range(C):
+        ex = exact_conv(x[c], irs[c])
+        peak = float(np.abs(ex).max())
+        err = float(np.abs(y[c] - ex).max()) / peak
+        record_parity("convolver, half-frame calls at ranks 9-10: |gpu - exact| <= 1e-5 peak", err, TOL)
+        assert err <= TOL, (c, err)
+        assert float(np.abs(y[c] - whole[c]).max()) / peak <= TOL
+    ref = oracle.Convolver(irs[0], rank).process_chunked(x[0], frame // 2)
+    check(y[0], ref, exact_conv(x[0], irs[0]), "channel 0, half-frame calls at rank %d" % rank)
+
+
 def test_stream_of_256_sample_calls_c3_shape(gpu):
     """What a plugin host does: 256-sample calls, for ever.  16 channels of the C3 shape (65536 taps, rank 13), five frames'
     worth of calls: every call is one aligned small block (one launch), every sixteenth completes a frame."""
