@@ -1,6 +1,6 @@
 #!/bin/bash
-# Everything the round's profiles/ directory is made from, in one gpurun call (from the repo root): tests/final_evidence.sh r05
-TAG=${1:-r05}
+# Everything the round's profiles/ directory is made from, in one gpurun call (from the repo root): tests/final_evidence.sh r06
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 cd $R
 mkdir -p gpurun_out/profiles_$TAG
@@ -20,5 +20,8 @@ bash tests/prof_round.sh $TAG < /dev/null > gpurun_out/prof_round.log 2>&1
 bash tests/prof_sq.sh $TAG < /dev/null > gpurun_out/prof_sq.log 2>&1
 bash tests/prof_driver_cmd.sh $TAG < /dev/null > gpurun_out/prof_driver_cmd.log 2>&1
 bash tests/prof_valu.sh $TAG < /dev/null > gpurun_out/prof_valu.log 2>&1
+bash tests/prof_comm_overlap.sh $TAG < /dev/null > gpurun_out/prof_comm_overlap.log 2>&1
+bash tests/prof_sq_spectral.sh < /dev/null > gpurun_out/profiles_$TAG/${TAG}_analyzer_wave_pmc_sq.txt 2>&1
+python3 tests/experiments/conv_small_rank_rate.py 2>/dev/null | grep "^rank" > gpurun_out/profiles_$TAG/${TAG}_conv_small_rank_rate.txt
 ls gpurun_out/profiles_$TAG
 tail -3 gpurun_out/profiles_$TAG/${TAG}_pytest_gpu_tail.log
