@@ -269,9 +269,60 @@ void FilterBank::reset()                { if (vFilters) last_status(mi_biquad_ba
 
 void FilterBank::dump(IStateDumper *v) const
 {
+    // FilterBank.cpp:332-424: the sections as end() packs them -- groups of 8, then 4, 2, 1 chains, every coefficient of a group
+    // side by side -- then the chains themselves.  The packed copy lives on the device here; its groups are gathered from
+    // vChains, which is what end() sent (the delay memory is not part of the reference's dump either).
+    const size_t groups = (nItems >> 3) + ((nItems >> 2) & 1) + ((nItems >> 1) & 1) + (nItems & 1);
+    const dsp::biquad_x1_t *c = vChains;
+    auto gather = [&](size_t lanes, bool with_p)
+    {
+        float col[5][8];
+        for (size_t i = 0; i < lanes; ++i)
+        {
+            col[0][i] = c[i].b0; col[1][i] = c[i].b1; col[2][i] = c[i].b2; col[3][i] = c[i].a1; col[4][i] = c[i].a2;
+        }
+        static const char *const names[5] = { "b0", "b1", "b2", "a1", "a2" };
+        v->begin_object(c, sizeof(dsp::biquad_t));
+        for (int k = 0; k < 5; ++k)
+            v->writev(names[k], col[k], lanes);
+        if (with_p)
+        {
+            const float p[2] = { 0.0f, 0.0f };
+            v->writev("p", p, 2);
+        }
+        v->end_object();
+        c += lanes;
+    };
+    auto single = [&](const dsp::biquad_x1_t *q)
+    {
+        v->begin_object(q, sizeof(dsp::biquad_x1_t));
+        v->write("b0", q->b0); v->write("b1", q->b1); v->write("b2", q->b2);
+        v->write("a1", q->a1); v->write("a2", q->a2);
+        v->write("p0", q->p0); v->write("p1", q->p1); v->write("p2", q->p2);
+        v->end_object();
+    };
+    v->begin_array("vFilters", vFilters, groups);
+    if (c != nullptr)
+    {
+        for (size_t g = 0; g < (nItems >> 3); ++g)
+            gather(8, false);
+        if (nItems & 4)
+            gather(4, false);
+        if (nItems & 2)
+            gather(2, true);
+        if (nItems & 1)
+            single(c);
+    }
+    v->end_array();
+    v->begin_array("vChains", vChains, nItems);
+    for (size_t i = 0; vChains != nullptr && i < nItems; ++i)
+        single(&vChains[i]);
+    v->end_array();
     v->write("nItems", nItems);
     v->write("nMaxItems", nMaxItems);
     v->write("nLastItems", nLastItems);
+    v->write("vBackup", vBackup);
+    v->write("vData", vData);
 }
 
 // ---- Filter ------------------------------------------------------------------------------------------------------
@@ -445,11 +496,34 @@ void Filter::freq_chart(float *re, float *im, const float *f, size_t count)
 
 void Filter::dump(IStateDumper *v) const
 {
-    v->write("nSampleRate", size_t(nSampleRate));
-    v->write("nMode", size_t(nMode));
+    // Filter.cpp:2430-2466
+    if (nFlags & FF_OWN_BANK)
+        v->write_object("pBank", pBank);
+    else
+        v->write("pBank", pBank);
+    v->begin_object("sParams", &sParams, sizeof(filter_params_t));
+    v->write("nType", sParams.nType);
+    v->write("fFreq", sParams.fFreq);
+    v->write("fFreq2", sParams.fFreq2);
+    v->write("fGain", sParams.fGain);
+    v->write("nSlope", sParams.nSlope);
+    v->write("fQuality", sParams.fQuality);
+    v->end_object();
+    v->write("nSampleRate", nSampleRate);
+    v->write("nMode", int(nMode));
     v->write("nItems", nItems);
+    v->begin_array("vItems", vItems, nItems);
+    for (size_t i = 0; vItems != nullptr && i < nItems; ++i)
+    {
+        v->begin_object(&vItems[i], sizeof(dsp::f_cascade_t));
+        v->writev("t", vItems[i].t, 4);
+        v->writev("b", vItems[i].b, 4);
+        v->end_object();
+    }
+    v->end_array();
+    v->write("vData", vData);
     v->write("nFlags", nFlags);
-    v->write("nLatency", size_t(nLatency));
+    v->write("nLatency", nLatency);
 }
 
 // ---- Equalizer ---------------------------------------------------------------------------------------------------
@@ -718,13 +792,27 @@ size_t Equalizer::ir_size() const
 
 void Equalizer::dump(IStateDumper *v) const
 {
-    v->write("nFilters", size_t(nFilters));
-    v->write("nSampleRate", size_t(nSampleRate));
-    v->write("nFirSize", size_t(nFirSize));
-    v->write("nFirRank", size_t(nFirRank));
-    v->write("nLatency", size_t(nLatency));
-    v->write("nMode", size_t(nMode));
+    // Equalizer.cpp:628-652
+    v->write_object("sBank", &sBank);
+    v->begin_array("vFilters", vFilters, nFilters);
+    for (size_t i = 0; vFilters != nullptr && i < nFilters; ++i)
+        v->write_object(&vFilters[i]);
+    v->end_array();
+    v->write("nFilters", nFilters);
+    v->write("nSampleRate", nSampleRate);
+    v->write("nFirSize", nFirSize);
+    v->write("nFirRank", nFirRank);
+    v->write("nLatency", nLatency);
+    v->write("nBufSize", nBufSize);
+    v->write("nMode", int(nMode));
+    v->write("vInBuffer", vInBuffer);
+    v->write("vOutBuffer", vOutBuffer);
+    v->write("vConv", vConv);
+    v->write("vNewConv", vNewConv);
+    v->write("vFft", vFft);
+    v->write("vTemp", vTemp);
     v->write("nFlags", nFlags);
+    v->write("pData", pData);
 }
 
 // ---- DynamicFilters ----------------------------------------------------------------------------------------------
@@ -878,8 +966,27 @@ bool DynamicFilters::freq_chart(size_t id, float *re, float *im, const float *f,
 
 void DynamicFilters::dump(IStateDumper *v) const
 {
+    // DynamicFilters.cpp:1973-1998
+    v->begin_array("vFilters", vFilters, nFilters);
+    for (size_t i = 0; vFilters != nullptr && i < nFilters; ++i)
+    {
+        const filter_t *f = &vFilters[i];
+        v->begin_object(f, sizeof(filter_t));
+        v->write("nType", f->sParams.nType);
+        v->write("fFreq", f->sParams.fFreq);
+        v->write("fFreq2", f->sParams.fFreq2);
+        v->write("fGain", f->sParams.fGain);
+        v->write("nSlope", f->sParams.nSlope);
+        v->write("fQuality", f->sParams.fQuality);
+        v->write("bActive", f->bActive);
+        v->end_object();
+    }
+    v->end_array();
+    v->write("vCascades", vCascades);
+    v->write("vBiquads", vBiquads.ptr);
     v->write("nFilters", nFilters);
     v->write("nSampleRate", nSampleRate);
+    v->write("pData", pData);
     v->write("bClearMem", bClearMem);
 }
 
@@ -981,11 +1088,25 @@ void Convolver::process(float *dst, const float *src, size_t count)
 
 void Convolver::dump(IStateDumper *v) const
 {
-    v->write("nConvSize", nConvSize);
-    v->write("nRank", nRank);
+    // Convolver.cpp:315-337 (the first key is spelt "pDataBuffer" there)
+    v->write("pDataBuffer", vDataBuffer);
+    v->write("vFrame", vFrame);
+    v->write("vConvBuffer", vConvBuffer);
+    v->write("vTaskData", vTaskData);
+    v->write("vConvData", vConvData);
+    v->write("vDirectData", vDirectData);
+    v->write("nDataBufferSize", nDataBufferSize);
+    v->write("nDirectSize", nDirectSize);
     v->write("nFrameSize", nFrameSize);
+    v->write("nFrameOff", nFrameOff);
+    v->write("nConvSize", nConvSize);
     v->write("nLevels", nLevels);
     v->write("nBlocks", nBlocks);
+    v->write("nBlocksDone", nBlocksDone);
+    v->write("nRank", nRank);
+    v->write("nBlkInit", nBlkInit);
+    v->write("fBlkCoef", fBlkCoef);
+    v->write("vData", vData);
 }
 
 // ---- SpectralProcessor ------------------------------------------------------------------------------------------
@@ -1136,10 +1257,20 @@ size_t SpectralProcessor::remaining() const
 
 void SpectralProcessor::dump(IStateDumper *v) const
 {
+    // SpectralProcessor.cpp:265-281
     v->write("nRank", nRank);
     v->write("nMaxRank", nMaxRank);
     v->write("fPhase", fPhase);
+    v->write("pWnd", pWnd);
+    v->write("pOutBuf", pOutBuf);
+    v->write("pInBuf", pInBuf);
+    v->write("pFftBuf", pFftBuf);
+    v->write("nOffset", nOffset);
+    v->write("pData", pData);
     v->write("bUpdate", bUpdate);
+    v->write("pFunc", reinterpret_cast<const void *>(pFunc));
+    v->write("pObject", pObject);
+    v->write("pSubject", pSubject);
 }
 
 // ---- MultiSpectralProcessor -------------------------------------------------------------------------------------
@@ -1385,12 +1516,30 @@ size_t MultiSpectralProcessor::remaining() const
 
 void MultiSpectralProcessor::dump(IStateDumper *v) const
 {
-    v->write("nChannels", size_t(nChannels));
-    v->write("nRank", size_t(nRank));
-    v->write("nMaxRank", size_t(nMaxRank));
-    v->write("nOffset", size_t(nOffset));
+    // MultiSpectralProcessor.cpp:411-443 (the channel records go out as bare runs of five keys, without objects, there too)
+    v->write("nChannels", nChannels);
+    v->write("nRank", nRank);
+    v->write("nMaxRank", nMaxRank);
+    v->write("nOffset", nOffset);
+    v->begin_array("vChannels", vChannels, nChannels);
+    for (size_t i = 0; vChannels != nullptr && i < nChannels; ++i)
+    {
+        const channel_t *c = &vChannels[i];
+        v->write("pIn", c->pIn);
+        v->write("pOut", c->pOut);
+        v->write("pInBuf", c->pInBuf);
+        v->write("pOutBuf", c->pOutBuf);
+        v->write("pFftBuf", c->pFftBuf);
+    }
+    v->end_array();
+    v->writev("vFftBuf", vFftBuf, (vFftBuf != nullptr) ? size_t(nChannels) : 0);
+    v->write("pWnd", pWnd);
     v->write("fPhase", fPhase);
     v->write("bUpdate", bUpdate);
+    v->write("pFunc", reinterpret_cast<const void *>(pFunc));
+    v->write("pObject", pObject);
+    v->write("pSubject", pSubject);
+    v->write("pData", pData);
 }
 
 // ---- Crossover --------------------------------------------------------------------------------------------------
@@ -1662,10 +1811,57 @@ void Crossover::process(const float *in, size_t samples)   // Crossover.cpp:451-
 
 void Crossover::dump(IStateDumper *v) const
 {
-    v->write("nReconfigure", size_t(nReconfigure));
-    v->write("nSplits", size_t(nSplits));
-    v->write("nBufSize", size_t(nBufSize));
-    v->write("nSampleRate", size_t(nSampleRate));
+    // Crossover.cpp:588-641.  The band and split records live in the device bank: their fields come from its getters, the
+    // per-split Filter objects (sLPF / sHPF) do not exist on this side and go out as null.  Key spellings as in the
+    // reference ("pOpbject", "nSlopw").
+    impl_t *p = impl();
+    const size_t bands = (p != nullptr) ? p->bands : 0, splits = (bands > 0) ? bands - 1 : 0;
+    v->write("nReconfigure", nReconfigure);
+    v->write("nSplits", nSplits);
+    v->write("nBufSize", nBufSize);
+    v->write("nSampleRate", nSampleRate);
+    v->write("nPlanSize", nPlanSize);
+    v->begin_array("vBands", vBands, bands);
+    for (size_t i = 0; i < bands; ++i)
+    {
+        float gain = 0.0f, start = 0.0f, end = 0.0f;
+        int active = 0;
+        mi_crossover_bank_get_band(p->bank, uint32_t(i), &gain, &start, &end, &active, nullptr);
+        v->begin_object(&p->handlers[i], sizeof(impl_t::handler_t));
+        v->write("fGain", gain);
+        v->write("fStart", start);
+        v->write("fEnd", end);
+        v->write("bEnabled", active != 0);
+        v->write("pStart", static_cast<const void *>(nullptr));
+        v->write("pEnd", static_cast<const void *>(nullptr));
+        v->write("pFunc", reinterpret_cast<const void *>(p->handlers[i].func));
+        v->write("pOpbject", p->handlers[i].object);
+        v->write("pSubject", p->handlers[i].subject);
+        v->write("nId", i);
+        v->end_object();
+    }
+    v->end_array();
+    v->begin_array("vSplit", vSplit, splits);
+    for (size_t i = 0; i < splits; ++i)
+    {
+        uint32_t slope = 0;
+        float freq = 0.0f;
+        int mode = 0;
+        mi_crossover_bank_get_split(p->bank, uint32_t(i), &slope, &freq, &mode);
+        v->begin_object(p->bank, 0);
+        v->write("sLPF", static_cast<const void *>(nullptr));
+        v->write("sHPF", static_cast<const void *>(nullptr));
+        v->write("nBandId", i + 1);
+        v->write("nSlopw", size_t(slope));
+        v->write("fFreq", freq);
+        v->write("nMode", mode);
+        v->end_object();
+    }
+    v->end_array();
+    v->writev("vPlan", reinterpret_cast<const void * const *>(vPlan), (vPlan != nullptr) ? size_t(nPlanSize) : 0);
+    v->write("vLpfBuf", vLpfBuf);
+    v->write("vHpfBuf", vHpfBuf);
+    v->write("pData", pData);
 }
 
 // ---- envelope::* -----------------------------------------------------------------------------------------------
@@ -2016,13 +2212,34 @@ void SpectralSplitter::clear()
 
 void SpectralSplitter::dump(IStateDumper *v) const
 {
+    // SpectralSplitter.cpp:388-424
     v->write("nRank", nRank);
     v->write("nMaxRank", nMaxRank);
+    v->write("nUserChunkRank", nUserChunkRank);
     v->write("nChunkRank", nChunkRank);
     v->write("fPhase", fPhase);
+    v->write("vWnd", vWnd);
+    v->write("vInBuf", vInBuf);
+    v->write("vFftBuf", vFftBuf);
+    v->write("vFftTmp", vFftTmp);
+    v->write("nFrameSize", nFrameSize);
+    v->write("nInOffset", nInOffset);
+    v->begin_array("vHandlers", vHandlers, nHandlers);
+    for (size_t i = 0; vHandlers != nullptr && i < nHandlers; ++i)
+    {
+        const handler_t *h = &vHandlers[i];
+        v->begin_object(h, sizeof(handler_t));
+        v->write("pObject", h->pObject);
+        v->write("pSubject", h->pSubject);
+        v->write("pFunc", reinterpret_cast<const void *>(h->pFunc));
+        v->write("pSink", reinterpret_cast<const void *>(h->pSink));
+        v->write("vOutBuf", h->vOutBuf);
+        v->end_object();
+    }
+    v->end_array();
     v->write("nHandlers", nHandlers);
     v->write("nBindings", nBindings);
-    v->write("bUpdate", bUpdate);
+    v->write("pData", pData);
 }
 
 // The reference object: an embedded SpectralSplitter whose handlers are the bands, the band records and their gains in
@@ -2367,9 +2584,33 @@ bool FFTCrossover::freq_chart(size_t band, float *m, const float *f, size_t coun
 
 void FFTCrossover::dump(IStateDumper *v) const
 {
-    v->write("nBands", bands());
-    v->write("nSampleRate", size_t(nSampleRate));
-    v->write("nRank", rank());
+    // FFTCrossover.cpp:524-559
+    v->write_object("sSplitter", &sSplitter);
+    const size_t n = sSplitter.handlers();
+    v->begin_array("vBands", vBands, n);
+    for (size_t i = 0; vBands != nullptr && i < n; ++i)
+    {
+        const band_t *b = &vBands[i];
+        v->begin_object(b, sizeof(band_t));
+        v->write("fHpfFreq", b->fHpfFreq);
+        v->write("fLpfFreq", b->fLpfFreq);
+        v->write("fHpfSlope", b->fHpfSlope);
+        v->write("fLpfSlope", b->fLpfSlope);
+        v->write("fGain", b->fGain);
+        v->write("fFlatten", b->fFlatten);
+        v->write("bLpf", b->bLpf);
+        v->write("bHpf", b->bHpf);
+        v->write("bEnabled", b->bEnabled);
+        v->write("bUpdate", b->bUpdate);
+        v->write("pObject", b->pObject);
+        v->write("pSubject", b->pSubject);
+        v->write("pFunc", reinterpret_cast<const void *>(b->pFunc));
+        v->write("vFFT", b->vFFT);
+        v->end_object();
+    }
+    v->end_array();
+    v->write("nSampleRate", nSampleRate);
+    v->write("pData", pData);
 }
 
 // ---- bs::channel_weighting / LoudnessMeter ---------------------------------------------------------------------
@@ -2643,12 +2884,46 @@ void LoudnessMeter::clear()
 
 void LoudnessMeter::dump(IStateDumper *v) const
 {
-    v->write("nChannels", nChannels);
+    // LoudnessMeter.cpp:566-615.  The channel records (weighting filter, square line, running sum) live in the device bank:
+    // the bindings and settings this object keeps go out under the reference's keys, the per-channel FilterBank / Filter
+    // objects and lines, which do not exist on this side, as null.
+    impl_t *p = impl();
+    const size_t n = (p != nullptr) ? p->ch.size() : 0;
+    v->begin_array("vChannels", vChannels, n);
+    for (size_t i = 0; i < n; ++i)
+    {
+        const impl_t::chan_t &c = p->ch[i];
+        v->begin_object(&c, sizeof(c));
+        v->write("sBank", static_cast<const void *>(nullptr));
+        v->write("sFilter", static_cast<const void *>(nullptr));
+        v->write("vIn", c.in);
+        v->write("vOut", c.out);
+        v->write("vData", static_cast<const void *>(nullptr));
+        v->write("vMS", static_cast<const void *>(nullptr));
+        v->write("fMS", 0.0f);
+        v->write("fWeight", bs::channel_weighting(c.designation));
+        v->write("fLink", c.link);
+        v->write("enDesignation", int(c.designation));
+        v->write("nFlags", size_t(c.active ? 1 : 0));         // C_ENABLED
+        v->write("nOffset", c.offset);
+        v->end_object();
+    }
+    v->end_array();
+    v->write("vBuffer", vBuffer);
     v->write("fPeriod", fPeriod);
     v->write("fMaxPeriod", fMaxPeriod);
+    v->write("fAvgCoeff", fAvgCoeff);
     v->write("fLoudness", fLoudness);
-    v->write("nSampleRate", size_t(nSampleRate));
+    v->write("nSampleRate", nSampleRate);
+    v->write("nPeriod", nPeriod);
+    v->write("nMSRefresh", nMSRefresh);
+    v->write("nChannels", nChannels);
     v->write("nFlags", nFlags);
+    v->write("nDataHead", nDataHead);
+    v->write("nDataSize", nDataSize);
+    v->write("enWeight", int(enWeight));
+    v->write("pData", pData);
+    v->write("pVarData", pVarData);
 }
 
 // ---- ILUFSMeter ------------------------------------------------------------------------------------------------
@@ -2869,13 +3144,45 @@ void ILUFSMeter::clear()
 
 void ILUFSMeter::dump(IStateDumper *v) const
 {
-    v->write("nChannels", size_t(nChannels));
+    // ILUFSMeter.cpp:552-602 (channel records: see LoudnessMeter::dump)
+    impl_t *p = impl();
+    const size_t n = (p != nullptr) ? p->ch.size() : 0;
+    v->begin_array("vChannels", vChannels, n);
+    for (size_t i = 0; i < n; ++i)
+    {
+        const impl_t::chan_t &c = p->ch[i];
+        const float block[4] = { 0.0f, 0.0f, 0.0f, 0.0f };     // (the quarter sums of the open block stay on the device)
+        v->begin_object(&c, sizeof(c));
+        v->write("sBank", static_cast<const void *>(nullptr));
+        v->write("sFilter", static_cast<const void *>(nullptr));
+        v->write("vIn", c.in);
+        v->writev("vBlock", block, 4);
+        v->write("fWeight", bs::channel_weighting(c.designation));
+        v->write("enDesignation", int(c.designation));
+        v->write("nFlags", size_t(c.active ? 1 : 0));         // C_ENABLED
+        v->end_object();
+    }
+    v->end_array();
+    v->write("vBuffer", vBuffer);
+    v->write("vLoudness", vLoudness);
+    v->write("fBlockPeriod", fBlockPeriod);
     v->write("fIntTime", fIntTime);
     v->write("fMaxIntTime", fMaxIntTime);
-    v->write("fBlockPeriod", fBlockPeriod);
+    v->write("fAvgCoeff", fAvgCoeff);
     v->write("fLoudness", fLoudness);
-    v->write("nSampleRate", size_t(nSampleRate));
-    v->write("nFlags", size_t(nFlags));
+    v->write("nBlockSize", nBlockSize);
+    v->write("nBlockOffset", nBlockOffset);
+    v->write("nBlockPart", nBlockPart);
+    v->write("nMSSize", nMSSize);
+    v->write("nMSHead", nMSHead);
+    v->write("nMSInt", nMSInt);
+    v->write("nMSCount", nMSCount);
+    v->write("nSampleRate", nSampleRate);
+    v->write("nChannels", nChannels);
+    v->write("nFlags", nFlags);
+    v->write("enWeight", int(enWeight));
+    v->write("pData", pData);
+    v->write("pVarData", pVarData);
 }
 
 // ---- Delay -----------------------------------------------------------------------------------------------------
@@ -3011,10 +3318,12 @@ void Delay::clear()                         { if (impl()) { mi_delay_bank_clear(
 
 void Delay::dump(IStateDumper *v) const
 {
-    v->write("nHead", size_t(nHead));
-    v->write("nTail", size_t(nTail));
-    v->write("nDelay", size_t(nDelay));
-    v->write("nSize", size_t(nSize));
+    // Delay.cpp:581-588
+    v->write("pBuffer", pBuffer);
+    v->write("nHead", nHead);
+    v->write("nTail", nTail);
+    v->write("nDelay", nDelay);
+    v->write("nSize", nSize);
 }
 
 // ---- RingBuffer --------------------------------------------------------------------------------------------------
@@ -3204,8 +3513,10 @@ size_t RingBuffer::tail_position(size_t offset) const
 
 void RingBuffer::dump(IStateDumper *v) const
 {
-    v->write("nCapacity", size_t(nCapacity));
-    v->write("nHead", size_t(nHead));
+    // RingBuffer.cpp:211-216
+    v->write("pData", pData);
+    v->write("nCapacity", nCapacity);
+    v->write("nHead", nHead);
 }
 
 // ---- Analyzer ----------------------------------------------------------------------------------------------------
@@ -3543,12 +3854,47 @@ void Analyzer::get_frequencies(float *frq, uint32_t *idx, float start, float sto
 
 void Analyzer::dump(IStateDumper *v) const
 {
-    v->write("nChannels", size_t(nChannels));
-    v->write("nMaxRank", size_t(nMaxRank));
-    v->write("nRank", size_t(nRank));
-    v->write("nSampleRate", size_t(nSampleRate));
-    v->write("nReconfigure", size_t(nReconfigure));
+    // Analyzer.cpp:496-544
+    v->write("nChannels", nChannels);
+    v->write("nMaxRank", nMaxRank);
+    v->write("nRank", nRank);
+    v->write("nSampleRate", nSampleRate);
+    v->write("nMaxSampleRate", nMaxSampleRate);
+    v->write("nBufSize", nBufSize);
+    v->write("nCounter", nCounter);
+    v->write("nPeriod", nPeriod);
+    v->write("nStep", nStep);
+    v->write("nHead", nHead);
+    v->write("nReconfigure", nReconfigure);
+    v->write("nEnvelope", nEnvelope);
+    v->write("nWindow", nWindow);
+    v->write("nMaxUserDelay", nMaxUserDelay);
+    v->write("fReactivity", fReactivity);
+    v->write("fTau", fTau);
+    v->write("fRate", fRate);
+    v->write("fMinRate", fMinRate);
+    v->write("fShift", fShift);
     v->write("bActive", bActive);
+    v->begin_array("vChannels", vChannels, nChannels);
+    for (size_t i = 0; vChannels != nullptr && i < nChannels; ++i)
+    {
+        const channel_t *c = &vChannels[i];
+        v->begin_object(c, sizeof(channel_t));
+        v->write("vBuffer", c->vBuffer);
+        v->write("vAmp", c->vAmp);
+        v->write("vData", c->vData);
+        v->write("nDelay", c->nDelay);
+        v->write("nUserDelay", c->nUserDelay);
+        v->write("bFreeze", c->bFreeze);
+        v->write("bActive", c->bActive);
+        v->end_object();
+    }
+    v->end_array();
+    v->write("vData", vData);
+    v->write("vSigRe", vSigRe);
+    v->write("vFftReIm", vFftReIm);
+    v->write("vWindow", vWindow);
+    v->write("vEnvelope", vEnvelope);
 }
 
 // ---- FilterArray (extension: the batched mode under the class API) ------------------------------------------------------

@@ -32,6 +32,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <utility>
 #include <vector>
 
 using namespace lsp;
@@ -1204,11 +1206,153 @@ static void raw_memory_objects()
     CHECK(dspu::last_status() == MI_OK, "a device call failed on the way: %d (%s)", dspu::last_status(), mi_dspu_last_error());
 }
 
+// dump(): every unit writes the reference's keys (tests/golden/dump_keys.json is checked statically by
+// tests/test_cpp_classes.py); here the objects are live and the visitor checks what a dump is at run time -- balanced
+// objects and arrays, the names in order, the FilterBank's packed groups equal to the chains they were gathered from.
+namespace
+{
+    struct recorder: public dspu::IStateDumper
+    {
+        std::vector<std::string> names;
+        std::vector<std::pair<std::string, std::vector<float> > > vectors;
+        int depth = 0, worst = 0, objects = 0, arrays = 0;
+        void enter(const char *n)                   { if (n) names.push_back(n); ++depth; }
+        void leave()                                { --depth; worst = std::min(worst, depth); }
+        void begin_object(const char *n, const void *, size_t) override  { ++objects; enter(n); }
+        void begin_object(const void *, size_t) override                 { ++objects; enter(nullptr); }
+        void end_object() override                                        { leave(); }
+        void begin_array(const char *n, const void *, size_t) override   { ++arrays; enter(n); }
+        void begin_array(const void *, size_t) override                  { ++arrays; enter(nullptr); }
+        void end_array() override                                         { leave(); }
+        void write(const char *n, const void *) override        { names.push_back(n); }
+        void write(const char *n, const char *) override        { names.push_back(n); }
+        #define REC(T) void write(const char *n, T) override { names.push_back(n); }
+        MI_DUMPER_TYPES(REC)
+        #undef REC
+        void writev(const char *n, const void * const *, size_t) override { names.push_back(n); }
+        void writev(const char *n, const float *p, size_t c) override     { names.push_back(n); vectors.push_back(std::make_pair(std::string(n), std::vector<float>(p, p + c))); }
+        bool has(const char *n) const               { return std::find(names.begin(), names.end(), n) != names.end(); }
+    };
+
+    template <class T>
+    void dumped(const char *what, const T &unit, const char *first, const char *last, size_t at_least)
+    {
+        recorder r;
+        unit.dump(&r);
+        CHECK(r.depth == 0 && r.worst == 0, "%s: objects / arrays not balanced (%d, %d)", what, r.depth, r.worst);
+        CHECK(r.names.size() >= at_least, "%s: %zu names, expected at least %zu", what, r.names.size(), at_least);
+        CHECK(!r.names.empty() && r.names.front() == first && r.names.back() == last, "%s: runs from %s to %s",
+              what, r.names.empty() ? "-" : r.names.front().c_str(), r.names.empty() ? "-" : r.names.back().c_str());
+    }
+}
+
+static void state_dumps()
+{
+    printf("state dumps\n");
+    {   // FilterBank.cpp:332-424: 11 chains = one group of 8, one of 2, one single
+        dspu::FilterBank fb;
+        CHECK(fb.init(16), "bank init");
+        fb.begin();
+        for (int i = 0; i < 11; ++i)
+        {
+            dsp::biquad_x1_t *c = fb.add_chain();
+            c->b0 = 1.0f + i; c->b1 = 0.1f * i; c->b2 = 0.01f * i; c->a1 = -0.001f * i; c->a2 = 0.0001f * i;
+            c->p0 = c->p1 = c->p2 = 0.0f;
+        }
+        fb.end(true);
+        recorder r;
+        fb.dump(&r);
+        CHECK(r.depth == 0 && r.arrays == 2 && r.objects == 3 + 11, "bank: %d arrays, %d objects", r.arrays, r.objects);
+        CHECK(r.vectors.size() == 5 + 6 && r.vectors[0].first == "b0" && r.vectors[0].second.size() == 8 && r.vectors[5].second.size() == 2 &&
+              r.vectors[10].first == "p", "bank: packed groups");
+        if (r.vectors.size() == 11)
+        {
+            for (int i = 0; i < 8; ++i)
+                CHECK(r.vectors[0].second[i] == 1.0f + i && r.vectors[3].second[i] == -0.001f * i, "group of 8, chain %d", i);
+            CHECK(r.vectors[5].second[0] == 9.0f && r.vectors[5].second[1] == 10.0f, "group of 2");
+        }
+        CHECK(r.names.front() == "vFilters" && r.names.back() == "vData" && r.has("vChains") && r.has("nLastItems"), "bank: names");
+        fb.destroy();
+    }
+    {
+        dspu::Filter f;
+        CHECK(f.init(NULL), "filter init");
+        dspu::filter_params_t fp;
+        fp.nType = dspu::FLT_BT_RLC_BELL; fp.fFreq = 1000.0f; fp.fFreq2 = 1000.0f; fp.fGain = 2.0f; fp.nSlope = 2; fp.fQuality = 0.5f;
+        f.update(48000, &fp);
+        float y[8] = { 1, 0, 0, 0, 0, 0, 0, 0 };
+        f.process(y, y, 8);
+        recorder r;
+        f.dump(&r);
+        CHECK(r.depth == 0 && r.names.front() == "pBank" && r.names.back() == "nLatency" && r.has("vItems") && r.has("t") && r.has("vChains"),
+              "filter: an own bank goes out as an object, the cascades with their polynomials");
+        f.destroy();
+    }
+    {
+        dspu::Equalizer eq;
+        CHECK(eq.init(2, 9), "equalizer init");
+        eq.set_sample_rate(48000);
+        dumped("equalizer", eq, "sBank", "pData", 17 + 2 * 10);
+        eq.destroy();
+        dspu::DynamicFilters df;
+        CHECK(df.init(2) == STATUS_OK, "dynamic filters init");
+        dumped("dynamic filters", df, "vFilters", "bClearMem", 6 + 2 * 7);
+        df.destroy();
+        dspu::Convolver cv;
+        const float taps[4] = { 1.0f, 0.5f, 0.25f, 0.125f };
+        CHECK(cv.init(taps, 4, 9, 0.0f), "convolver init");
+        dumped("convolver", cv, "pDataBuffer", "vData", 18);
+        cv.destroy();
+        dspu::SpectralProcessor sp;
+        CHECK(sp.init(10), "spectral processor init");
+        dumped("spectral processor", sp, "nRank", "pSubject", 13);
+        sp.destroy();
+        dspu::MultiSpectralProcessor mp;
+        CHECK(mp.init(2, 10), "multi spectral processor init");
+        dumped("multi spectral processor", mp, "nChannels", "pData", 13 + 2 * 5);
+        mp.destroy();
+        dspu::Crossover xo;
+        CHECK(xo.init(3, 256), "crossover init");
+        xo.set_sample_rate(48000);
+        xo.reconfigure();
+        dumped("crossover", xo, "nReconfigure", "pData", 11 + 3 * 10 + 2 * 6);
+        xo.destroy();
+        dspu::SpectralSplitter ss;
+        CHECK(ss.init(10, 2) == STATUS_OK, "spectral splitter init");
+        dumped("spectral splitter", ss, "nRank", "pData", 15 + 2 * 5);
+        ss.destroy();
+        dspu::FFTCrossover fx;
+        CHECK(fx.init(10, 2) == STATUS_OK, "fft crossover init");
+        dumped("fft crossover", fx, "sSplitter", "pData", 4 + 2 * 14 + 15);
+        fx.destroy();
+        dspu::LoudnessMeter lm;
+        CHECK(lm.init(2, 400.0f) == STATUS_OK, "loudness meter init");
+        dumped("loudness meter", lm, "vChannels", "pVarData", 16 + 2 * 12);
+        lm.destroy();
+        dspu::ILUFSMeter im;
+        CHECK(im.init(2, 5.0f, 400.0f) == STATUS_OK, "ilufs meter init");
+        dumped("ilufs meter", im, "vChannels", "pVarData", 21 + 2 * 7);
+        im.destroy();
+        dspu::Delay dl;
+        CHECK(dl.init(100), "delay init");
+        dumped("delay", dl, "pBuffer", "nSize", 5);
+        dl.destroy();
+        dspu::RingBuffer rb;
+        CHECK(rb.init(16), "ring buffer init");
+        dumped("ring buffer", rb, "pData", "nHead", 3);
+        rb.destroy();
+        dspu::Analyzer an;
+        CHECK(an.init(2, 10, 48000, 10.0f), "analyzer init");
+        dumped("analyzer", an, "nChannels", "vEnvelope", 26 + 2 * 7);
+        an.destroy();
+    }
+}
+
 int main(int argc, char **argv)
 {
     if (argc > 1 && strcmp(argv[1], "--list") == 0)
     {
-        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects filter_array equalizer_array convolver_array");
+        puts("convolver.test_small convolver.test_large equalizer.FIR equalizer.FFT equalizer.SPM spectral_proc multi_spectral_proc crossover loudness_meter ilufs_meter spectral_splitter fft_crossover ringbuffer accessors readme_filter raw_memory_objects filter_array equalizer_array convolver_array state_dumps");
         return 0;
     }
     if (mi_dspu_device_count() <= 0)
@@ -1236,6 +1380,7 @@ int main(int argc, char **argv)
     filter_array_equals_n_filters();
     equalizer_array_equals_n_equalizers();
     convolver_array_equals_n_convolvers();
+    state_dumps();
     CHECK(dspu::last_status() == MI_OK, "device status after the whole replay: %d (%s)", dspu::last_status(), mi_dspu_last_error());
     printf("%s (%d failure%s)\n", failures ? "FAILED" : "ALL PASSED", failures, failures == 1 ? "" : "s");
     return failures ? 1 : 0;
