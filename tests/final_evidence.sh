@@ -23,5 +23,10 @@ bash tests/prof_valu.sh $TAG < /dev/null > gpurun_out/prof_valu.log 2>&1
 bash tests/prof_comm_overlap.sh $TAG < /dev/null > gpurun_out/prof_comm_overlap.log 2>&1
 bash tests/prof_sq_spectral.sh < /dev/null > gpurun_out/profiles_$TAG/${TAG}_analyzer_wave_pmc_sq.txt 2>&1
 python3 tests/experiments/conv_small_rank_rate.py 2>/dev/null | grep "^rank" > gpurun_out/profiles_$TAG/${TAG}_conv_small_rank_rate.txt
+# what comes back is capped at 64 MiB: the raw rocprofv3 output stays on the box
+du -sh gpurun_out/* 2>/dev/null | sort -h | tail -8
+rm -rf gpurun_out/prof_$TAG gpurun_out/sq_$TAG gpurun_out/valu_$TAG gpurun_out/comm_overlap gpurun_out/sq_spectral gpurun_out/driver_cmd_$TAG gpurun_out/prof_driver_$TAG
+for d in gpurun_out/*/; do [ "$d" != "gpurun_out/profiles_$TAG/" ] && [ $(du -sm "$d" | cut -f1) -gt 8 ] && rm -rf "$d"; done
 ls gpurun_out/profiles_$TAG
+grep -E "passed|failed|error" gpurun_out/profiles_$TAG/${TAG}_pytest_gpu_tail.log | tail -3
 tail -3 gpurun_out/profiles_$TAG/${TAG}_pytest_gpu_tail.log
