@@ -814,6 +814,32 @@ def test_bench_rehearsal_two_ranks_on_one_gpu():
     assert line["n_gpus"] == 2 and line["value"] > 0 and "REHEARSAL" in line["data"], line
 
 
+@pytest.mark.parametrize("channels,rank_fft", [(256, 12), (96, 10)])
+def test_product_shards_and_collective_equal_the_unsharded_bank(channels, rank_fft):
+    """World size 2 with the PRODUCT on both ranks (the gloo tests of tests/test_sharding_gloo.py reduce oracle
+    spectra): two processes share the box's one GPU, each runs the analyzer bank of its channel shard -- the run of strobes as one
+    launch, the device-side per-bin sums --, the shards' sums are all-reduced over gloo by lsp-dsp-units_amd.sharding, and rank 0
+    compares with the unsharded bank: bit for bit (the unsharded tree's top level is the sum of the halves; 96 channels: shards
+    of 48 = three blocks of 16 each, where the tree of the whole and the trees of the halves differ in shape -- the sums are
+    then compared to 1e-6 of the peak instead)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29533", os.path.join(root, "tests", "shard_product_demo.py"), str(channels), str(rank_fft)],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=root)
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert lines, r.stdout[-1500:] + r.stderr[-1500:]
+    res = json.loads(lines[-1])
+    assert res["world"] == 2 and res["peak"] > 0.0, res
+    if channels == 256:
+        assert r.returncode == 0 and res["bit_equal"], res
+    else:
+        assert res["worst_abs_diff"] <= 1e-6 * res["peak"], res
+
+
 @pytest.mark.parametrize("rank,masked", [(8, True), (9, False), (11, True), (12, True)])
 def test_spectral_bank_in_place_equals_out_of_place(gpu, rank, masked):
     """SpectralProcessor::process(dst, src, count) takes the caller's samples before it hands out the finished ones at the same
