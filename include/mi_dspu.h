@@ -172,7 +172,8 @@ int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *bank, uint32_t channel, int
  * biquad_process_x1 form, every product and sum rounded on its own) sample after sample, a section per lane: the reference's
  * output and filter memory BIT FOR BIT, at the price of the recursion's latency chain (19 000 Msamples/s at that size).
  * The filter memory is the same in both modes: calls may alternate.  process(), process_blocks() and impulse_response()
- * follow the mode; the meters' fused sums (LoudnessMeter / ILUFSMeter) keep the fast kernels.
+ * follow the mode, and chains of banks (Crossover, the Equalizer's IIR mode) then run bank by bank instead of through their
+ * fused launch; the meters' fused sums (LoudnessMeter / ILUFSMeter) keep the fast kernels.
  * mi_dspu_set_exact_iir_default: the mode banks created from now on start in (process-wide; how the class layer's
  * dspu::Filter / FilterBank / Equalizer objects are put into the exact mode: set it before constructing them).
  */

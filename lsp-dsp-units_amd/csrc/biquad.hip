@@ -1732,6 +1732,9 @@ namespace mi
         if (count <= 0 || count > CHAIN_MAX || samples <= 2 * size_t(small::BLOCK) || (samples % 16) != 0 ||
             samples >= (size_t(1) << 28))
             return 1;
+        for (int k = 0; k < count; ++k)                     // a bank in the exact mode runs its own launch (biquad_exact_kernel)
+            if (stages[k].bank != nullptr && stages[k].bank->exact)
+                return 1;
         // A long call (four sub-blocks of 2048 samples and more) is a stream of sub-blocks like a run of blocks: the stream
         // kernel walks it with four waves per channel, hand-over for hand-over what the super-block loop below does.
         if (long_calls_as_streams && samples >= 4 * size_t(big::BLOCK))
@@ -1819,7 +1822,7 @@ namespace mi
             return 1;
         const uint32_t channels = stages[0].bank->channels;
         for (int k = 0; k < count; ++k)
-            if (stages[k].bank == nullptr || stages[k].bank->channels != channels || slot[k] >= outs)
+            if (stages[k].bank == nullptr || stages[k].bank->channels != channels || slot[k] >= outs || stages[k].bank->exact)
                 return 1;
         int sec_cap = 1;
         for (uint32_t c = 0; c < channels; ++c)

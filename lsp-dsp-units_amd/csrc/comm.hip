@@ -80,12 +80,27 @@ namespace
         // analysis leaves (the reduction behind it does not fill them) and ends inside the two batches the caller's slots give it.
         int least = 0, most = 0;
         MI_HIP_CHECK(hipDeviceGetStreamPriorityRange(&least, &most));
-        MI_HIP_CHECK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
+        // (all of it or none: a stream without its events would be taken for a complete set by the next call)
+        hipStream_t side = nullptr;
+        hipEvent_t ev[2 * MI_DSPU_COMM_SLOTS] = {};
+        hipError_t e = hipStreamCreateWithPriority(&side, hipStreamNonBlocking, least);
+        for (int k = 0; k < 2 * MI_DSPU_COMM_SLOTS && e == hipSuccess; ++k)
+            e = hipEventCreateWithFlags(&ev[k], hipEventDisableTiming);
+        if (e != hipSuccess)
+        {
+            for (hipEvent_t v : ev)
+                if (v != nullptr)
+                    (void)hipEventDestroy(v);
+            if (side != nullptr)
+                (void)hipStreamDestroy(side);
+            MI_HIP_CHECK(e);
+        }
         for (int k = 0; k < MI_DSPU_COMM_SLOTS; ++k)
         {
-            MI_HIP_CHECK(hipEventCreateWithFlags(&c->ready[k], hipEventDisableTiming));
-            MI_HIP_CHECK(hipEventCreateWithFlags(&c->done[k], hipEventDisableTiming));
+            c->ready[k] = ev[2 * k];
+            c->done[k] = ev[2 * k + 1];
         }
+        c->side = side;
         return MI_OK;
     }
 }

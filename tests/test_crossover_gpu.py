@@ -92,6 +92,27 @@ def test_four_band_lr4_matches_oracle_with_state_carry(gpu):
     bank.close()
 
 
+@pytest.mark.parametrize("block", [2048, 4096])
+def test_exact_iir_default_reaches_the_crossovers_banks(gpu, block):
+    """mi_dspu_set_exact_iir_default(1): the banks a Crossover makes from then on run the reference's serial recurrence -- its
+    chains of banks go bank by bank (biquad_exact_kernel) instead of through the fused chain launch -- and every band is the
+    oracle's output BIT FOR BIT (the oracle restates lsp-dsp-lib's biquad_process_x1 rounding for rounding; the band gain is
+    one multiplication).  Block sizes on both sides of the fused chain's threshold."""
+    script = {0: [("set_sample_rate", 48000), ("set_slope", 0, 2), ("set_frequency", 0, 120.0),
+                  ("set_slope", 1, 2), ("set_frequency", 1, 1000.0), ("set_slope", 2, 2), ("set_frequency", 2, 8000.0),
+                  ("set_gain", 1, 1.5), ("set_gain", 3, 0.5)]}
+    gpu.check(gpu.lib.mi_dspu_set_exact_iir_default(1))
+    try:
+        bank, refs, x, got, ref, wrote = run_both(gpu, 3, 4, script, 3, block)
+    finally:
+        gpu.check(gpu.lib.mi_dspu_set_exact_iir_default(0))
+    assert "exact" in gpu.last_launch(), gpu.last_launch()
+    for b in got:
+        assert wrote[b]
+        np.testing.assert_array_equal(got[b], ref[b])
+    bank.close()
+
+
 def test_retunes_slopes_modes_and_unsorted_split_points(gpu):
     """slopes LR2..LR16, matched-transform mode, a split point switched off and on, frequencies out of order,
     gain changes: the plan is rebuilt, filter states survive or clear exactly as in the reference."""
