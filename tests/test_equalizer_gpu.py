@@ -83,6 +83,39 @@ def test_c4_shape_32_band_eq(gpu, mode):
     eq.close()
 
 
+def test_iir_mode_under_the_exact_default_is_the_oracle_bit_for_bit(gpu):
+    """mi_dspu_set_exact_iir_default(1): the equalizer's cascade bank runs the reference's serial recurrence -- 32 bells down to
+    20 Hz, where the fast kernels need conftest's noise rule, come out as the oracle's floats, ragged call sizes and all."""
+    rng = np.random.default_rng(6)
+    C, rank, nfilt, n = 3, 12, 32, 4096 * 3 + 100
+    x = (rng.standard_normal((C, n)) * 0.25).astype(np.float32)
+    gpu.check(gpu.lib.mi_dspu_set_exact_iir_default(1))
+    try:
+        eq = gpu.EqualizerBank(C, nfilt, rank)
+    finally:
+        gpu.check(gpu.lib.mi_dspu_set_exact_iir_default(0))
+    eq.set_mode(oe.IIR)
+    eq.set_sample_rate(48000)
+    refs = []
+    for c in range(C):
+        o = oe.Equalizer(nfilt, rank); o.set_mode(oe.IIR); o.set_sample_rate(48000)
+        for i, p in enumerate(c4_filters(rng)):
+            eq.set_params(i, *p, channel=c)
+            o.set_params(i, fd.Params(*p))
+        refs.append(o)
+    y = np.empty_like(x)
+    pos = 0
+    for k in (4096, 1000, 4096, n - 9192):
+        din = gpu.DeviceBuffer.from_host(x[:, pos:pos + k]); dout = gpu.DeviceBuffer((C, k))
+        eq.process(dout, din, k)
+        y[:, pos:pos + k] = dout.download()
+        pos += k
+    assert "exact" in gpu.last_launch(), gpu.last_launch()
+    for c in range(C):
+        np.testing.assert_array_equal(y[c], refs[c].process(x[c]), err_msg="channel %d" % c)
+    eq.close()
+
+
 def test_retune_mode_switch_and_reset(gpu):
     rng = np.random.default_rng(1)
     x = rng.standard_normal((1, 6000)).astype(np.float32)
