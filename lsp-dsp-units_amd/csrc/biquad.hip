@@ -155,7 +155,7 @@ namespace
     // ROWS > 1 (SUMSQ only): the workgroup runs ROWS consecutive rows side by side, NW waves each -- for the integrated meter,
     // whose rows then leave their sums of squares in LDS (sq.sums points there) for the same workgroup's bookkeeping.  The
     // barriers are the workgroup's: the rows must have the same number of sections and none of them may be switched off.
-    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, bool ROLES = false /* (retired: always false) */, int ROWS = 1>
+    template <int L, int NW, bool ALIGNED, bool CHAIN, bool SUMSQ = false, int ROWS = 1>
     __device__ __forceinline__
     void biquad_body(float *out, const float *in, size_t out_stride, size_t in_stride,
                      int n /* multiple of L */, const float *__restrict__ tab, float *state,
@@ -167,19 +167,18 @@ namespace
         constexpr int W = G::W, TAB = G::TAB, PITCH = G::PITCH, SB = G::BLOCK, SG = G::SG;
         constexpr int LPT = W / 4;                          // float4 per lane and sub-block
         constexpr int NT = 64 * NW;
-        constexpr int XW = ROLES ? 1 : NW;                  // waves that share one section of one super-block
-        static_assert(!ROLES || (NW == 2 && !CHAIN && !SUMSQ), "the two-role form is the plain kernel with two waves");
+        constexpr int XW = NW;                              // waves that share one section of one super-block
         constexpr int TAB_QL = TAB_PQ + 2 * L;
 
-        static_assert(ROWS == 1 || (SUMSQ && !CHAIN && !ROLES), "rows side by side: the meters' form only");
+        static_assert(ROWS == 1 || (SUMSQ && !CHAIN), "rows side by side: the meters' form only");
         __shared__ __attribute__((aligned(16))) float sx_rows[ROWS][NW * 64 * PITCH];
         __shared__ float2 sstate_rows[ROWS][2][SG];         // state carried between super-blocks, by parity
-        __shared__ float2 xchg_rows[ROWS][2][ROLES ? 1 : SG][NW];   // end state of every wave's sub-block
+        __shared__ float2 xchg_rows[ROWS][2][SG][NW];   // end state of every wave's sub-block
         // (one row per workgroup: `slot` is the constant 0 and everything below is what it was)
         const int slot = (ROWS > 1) ? __builtin_amdgcn_readfirstlane(int(threadIdx.x) / NT) : 0;
         float *const sx_all = sx_rows[slot];
         float2 (*const sstate)[SG] = sstate_rows[slot];
-        float2 (*const xchg)[ROLES ? 1 : SG][NW] = xchg_rows[slot];
+        float2 (*const xchg)[SG][NW] = xchg_rows[slot];
 
         const int ch   = int(blockIdx.x) * ROWS + slot;
         const int tid  = int(threadIdx.x) - slot * NT;
@@ -196,7 +195,7 @@ namespace
         const int ns   = stage_ns(0);
         if (!CHAIN && ns < 0)                               // row switched off: state kept, output not written
             return;
-        float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile (ROLES: the tile in hand)
+        float *sx = sx_all + wv * 64 * PITCH;               // this wave's private transpose tile
         const bool lane0 = (t == 0), row3 = (t >= 48);
         const float *ctab = stage_tab(0);                   // this channel's table rows (uniform address)
         // Buffer descriptors over the channel's n samples: reads past the end return 0, writes past the end are
@@ -755,7 +754,7 @@ namespace
         const mi_meters::ilufs_early<TT> early = mi_meters::ilufs_ask<TT>(meter, ep.block, ep.cfg, uint32_t(ROWS), ep.st, ep.hist, ep.size, ep.ms_int);
         sumsq_args local = sq;
         local.sums = s_seg;
-        biquad_body<L, NW, ALIGNED, false, true, false, ROWS>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), local, true);
+        biquad_body<L, NW, ALIGNED, false, true, ROWS>(nullptr, in, 0, in_stride, n, tab, state, nsec, max_sec, chain_args(), local, true);
         __syncthreads();
         mi_meters::ilufs_call_body<TT, false, true>(meter, ep.block, s_seg, ep.pieces, ep.cfg, uint32_t(ROWS), ep.out, ep.out_stride,
                                                     ep.st, ep.gain, ep.hist, ep.size, ep.ms_int, ep.avg, s_sum, s_cnt, s_val, s_chan, early);
