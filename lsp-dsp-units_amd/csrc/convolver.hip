@@ -328,7 +328,6 @@ namespace
                            float *acc, const float2 *__restrict__ Yt, const float2 *__restrict__ tw,
                            float *dl_ring, uint32_t dl_size, uint32_t dl_tail, uint32_t dl_head, bool upper_zero)
     {
-        constexpr int M = fplan<LOGM>::N;
         __shared__ float2 lds_[fplan<LOGM>::LDS];
         float2 *const buf = lds_, *const scr = lds_ + fplan<LOGM>::SCR;
         frame_role<LOGM, false>(buf, scr, blockIdx.x, out, in, out_stride, in_stride, aligned, ring, R, slot, H, P, acc, Yt, tw,

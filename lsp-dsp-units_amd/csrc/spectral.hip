@@ -766,7 +766,7 @@ namespace
     // The body serves two callers: bin_reduce_kernel (its own launch, 16 waves) and the reduce role that rides on the
     // analysis launch (analyzer_kernel, round 3: as many waves as the analysis workgroups have; DEVICE: the rows were
     // written by other workgroups of the SAME launch, so they are read with device-scope loads past this CU's L1).
-    constexpr uint32_t REDUCE_BINS = 16, REDUCE_ROWS = 4, REDUCE_WAVES = 16, REDUCE_BLOCK = 16, REDUCE_MAX_BLOCKS = 1024;
+    constexpr uint32_t REDUCE_BINS = 16, REDUCE_WAVES = 16, REDUCE_BLOCK = 16, REDUCE_MAX_BLOCKS = 1024;
 
     template <uint32_t WAVES, bool DEVICE, uint32_t REDUCE_BINS = 16>
     __device__ __forceinline__
@@ -1260,7 +1260,7 @@ namespace
         uint32_t flv = flags_of(0);
         __syncthreads();
         MI_WPROBE(31);
-        int unit_no = 0;
+        [[maybe_unused]] int unit_no = 0;                   // (the probe's stamps are numbered by it)
         const int pairs = (fa.frames + 1) / 2;
         auto at = [](__amdgpu_buffer_rsrc_t r, int lane_off, int row_off) -> float {
             return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, lane_off, row_off, 0));

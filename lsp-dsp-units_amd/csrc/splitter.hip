@@ -588,8 +588,8 @@ namespace
                     for (int q = 0; q + 1 < NB; ++q)
                         tail[q][j] = tail[q + 1][j];
                     tail[NB - 1][j] = mine;
-                    mi::wt_store(rout, lane * 4 + 256 * j, done_a);             // (dropped by the bounds check where nothing is stored)
-                    mi::wt_store(rout, lane * 4 + 256 * (j + HALF), done_b);
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, lane * 4 + 256 * j, done_a);             // (dropped by the bounds check where nothing is stored)
+                    mi::wt_store<mi::CPOL_NT_SC1>(rout, lane * 4 + 256 * (j + HALF), done_b);
                 }
             }
         }
