@@ -1450,18 +1450,29 @@ namespace
                 const bool edge = s64 < G - 1 || s64 + 64 > n;      // lanes start one step after another and stop one after another
                 if (!edge)
                 {
+                    // (the chunk's 64 results stay in registers and leave as sixteen 16-byte stores behind the chunk: a store per
+                    // step was five instructions of a step's twenty -- exec mask, branch, address, store, exec mask; the shift
+                    // fills lane 0 with a zero it never takes instead of copying one in)
+                    float ys[64];
                     #pragma unroll
                     for (int k = 0; k < 64; ++k)
                     {
-                        const float up = dpp_or<DPP_WAVE_SHR1, 0xf>(0.0f, y);
+                        const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), DPP_WAVE_SHR1, 0xf, 0xf, true));
                         const float x = (j == 0) ? xs[k] : up;
                         y = __fadd_rn(__fmul_rn(b0, x), d0);
                         const float p1 = __fadd_rn(__fmul_rn(b1, x), __fmul_rn(a1, y));
                         const float p2 = __fadd_rn(__fmul_rn(b2, x), __fmul_rn(a2, y));
                         d0 = __fadd_rn(d1, p1);
                         d1 = p2;
-                        if (emit)
-                            o[s64 + k - j] = y;
+                        ys[k] = y;
+                    }
+                    if (emit)
+                    {
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));      // (rows and the lane's skew: 4-byte aligned)
+                        float *const p = o + (s64 - j);
+                        #pragma unroll
+                        for (int k = 0; k < 64; k += 4)
+                            *reinterpret_cast<f4u *>(p + k) = f4u{ys[k], ys[k + 1], ys[k + 2], ys[k + 3]};
                     }
                 }
                 else
