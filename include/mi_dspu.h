@@ -170,7 +170,7 @@ int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *bank, uint32_t channel, int
  * reference's output (DESIGN.md section 4 states the bound), 550 000 Msamples/s at 1024 channels x 8 sections.
  * 1: FilterBank::process's serial recurrence (/root/reference/src/main/filters/FilterBank.cpp:256-291; lsp-dsp-lib's
  * biquad_process_x1 form, every product and sum rounded on its own) sample after sample, a section per lane: the reference's
- * output and filter memory BIT FOR BIT, at the price of the recursion's latency chain (30 000 Msamples/s at that size).
+ * output and filter memory BIT FOR BIT, at the price of the recursion's latency chain (32 000 Msamples/s at that size).
  * The filter memory is the same in both modes: calls may alternate.  process(), process_blocks() and impulse_response()
  * follow the mode, and chains of banks (Crossover, the Equalizer's IIR mode) then run bank by bank instead of through their
  * fused launch; the meters' fused sums (LoudnessMeter / ILUFSMeter) keep the fast kernels.

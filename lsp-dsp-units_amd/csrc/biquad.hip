@@ -1444,9 +1444,11 @@ namespace
             const int steps = n + G - 1;
             float xs[64], xn[64];
             fetch(0, xs);
-            for (int s64 = 0; s64 < steps; s64 += 64)
+            // one chunk of 64 steps on `cur` while `nxt` takes the chunk behind it; two chunks per trip of the loop, the two sets
+            // of registers changing places by name (copying one into the other was 64 of a chunk's 770 vector instructions)
+            auto chunk = [&](const int s64, const float (&cur)[64], float (&nxt)[64]) __attribute__((always_inline))
             {
-                fetch(s64 + 64, xn);                        // the next chunk's samples, in flight over this chunk's steps (zeros behind the call's end)
+                fetch(s64 + 64, nxt);                        // the next chunk's samples, in flight over this chunk's steps (zeros behind the call's end)
                 const bool edge = s64 < G - 1 || s64 + 64 > n;      // lanes start one step after another and stop one after another
                 if (!edge)
                 {
@@ -1458,7 +1460,7 @@ namespace
                     for (int k = 0; k < 64; ++k)
                     {
                         const float up = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(y), DPP_WAVE_SHR1, 0xf, 0xf, true));
-                        const float x = (j == 0) ? xs[k] : up;
+                        const float x = (j == 0) ? cur[k] : up;
                         y = __fadd_rn(__fmul_rn(b0, x), d0);
                         const float p1 = __fadd_rn(__fmul_rn(b1, x), __fmul_rn(a1, y));
                         const float p2 = __fadd_rn(__fmul_rn(b2, x), __fmul_rn(a2, y));
@@ -1483,7 +1485,7 @@ namespace
                         const int i = s64 + k - j;          // the sample this lane's section meets at this step
                         const bool act = mine && i >= 0 && i < n;
                         const float up = dpp_or<DPP_WAVE_SHR1, 0xf>(0.0f, y);
-                        const float x = (j == 0) ? xs[k] : up;
+                        const float x = (j == 0) ? cur[k] : up;
                         const float yn = __fadd_rn(__fmul_rn(b0, x), d0);
                         const float p1 = __fadd_rn(__fmul_rn(b1, x), __fmul_rn(a1, yn));
                         const float p2 = __fadd_rn(__fmul_rn(b2, x), __fmul_rn(a2, yn));
@@ -1494,9 +1496,12 @@ namespace
                             o[i] = yn;
                     }
                 }
-                #pragma unroll
-                for (int i = 0; i < 64; ++i)
-                    xs[i] = xn[i];
+            };
+            for (int s64 = 0; s64 < steps; s64 += 128)
+            {
+                chunk(s64, xs, xn);
+                if (s64 + 64 < steps)
+                    chunk(s64 + 64, xn, xs);
             }
             if (mine)
             {
