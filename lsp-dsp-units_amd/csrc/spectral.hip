@@ -1114,7 +1114,10 @@ namespace
         // write-through traffic of the ingest counted twice: round 4's 1.40 x of the launch's algorithmic bytes,
         // profiles/r04_pmc_hbm_raw.json WRITE_SIZE 403 MB against 279 MB of rows and samples)
         auto ingest_hop = [&](int f, const float2 (&v)[HALF]) {
-            const uint32_t h0 = uint32_t((uint64_t(head) + uint64_t(f) * HOP) % buf_size);
+            uint64_t hc = uint64_t(head) + uint64_t(f) * HOP;           // (inside one turn of the ring: see ring_place)
+            while (hc >= buf_size)
+                hc -= buf_size;
+            const uint32_t h0 = uint32_t(hc);
             const bool pairs = ((h0 | buf_size) & 1u) == 0u;
             #pragma unroll
             for (int j = 0; j < HALF; ++j)
@@ -1275,9 +1278,11 @@ namespace
         struct place { __amdgpu_buffer_rsrc_t rsrc; uint32_t first; bool straight, quads; };
         auto ring_place = [&](int ch, int64_t cell) -> place {
             float *rbw = ring + size_t(ch) * buf_size;
-            while (cell < 0)
-                cell += buf_size;
-            const uint32_t c0 = uint32_t(uint64_t(cell) % buf_size);
+            // (the host keeps a run inside one turn of the ring -- frame + run <= buf_size --: a step either way at most.  As
+            // `cell % buf_size` every place cost a 64-bit division in scalar code: 500 of a unit's 650 scalar instructions)
+            cell += (cell < 0) ? int64_t(buf_size) : 0;
+            cell -= (cell >= int64_t(buf_size)) ? int64_t(buf_size) : 0;
+            const uint32_t c0 = uint32_t(cell);
             if (c0 + HOP <= buf_size)
                 return place{mi::wt_buffer(rbw + c0, unsigned(HOP * sizeof(float))), 0u, true, (c0 & 3u) == 0u};      // (rows of the ring start on 16 bytes)
             return place{mi::wt_buffer(rbw, unsigned(buf_size * sizeof(float))), c0, false, false};
