@@ -66,10 +66,12 @@ int         mi_dspu_event_record(void *event, void *stream);
 int         mi_dspu_event_synchronize(void *event);
 int         mi_dspu_event_elapsed_ms(float *ms, void *start, void *stop);
 /*
- * Environment switches -- the library reads exactly these four, at every call:
+ * Environment switches -- the library reads exactly these five, at every call:
  *   MI_DSPU_COMPAT_BITS=1     runs of 4096-point blocks (Equalizer FIR/FFT, SpectralProcessor with a mask, SpectralSplitter at
  *                             rank 12) stay on the workgroup kernels, whose results are the block-by-block calls' BIT FOR BIT,
  *                             instead of the wave-resident transform kernels (1.3 - 1.7 x faster, within 1e-6 of the calls)
+ *   MI_DSPU_EXACT_IIR=1       biquad banks START in the exact mode (mi_biquad_bank_set_exact below): the reference's serial recurrence,
+ *                             its output bit for bit, for hosts that cannot be changed to call mi_dspu_set_exact_iir_default
  *   MI_CONV_TWO_LAUNCH=1      Convolver: frame launch + tail launch instead of the one-launch step   } fall-backs behind two
  *   MI_ILUFS_TWO_LAUNCHES=1   ILUFSMeter: bookkeeping in a launch of its own                         } in-launch hand-overs that
  *                             rest on gfx950's dispatch order / memory-side atomics (a wait that does not end raises a fault)
@@ -174,7 +176,7 @@ int mi_biquad_bank_set_row_enabled(mi_biquad_bank_t *bank, uint32_t channel, int
  * The filter memory is the same in both modes: calls may alternate.  process(), process_blocks() and impulse_response()
  * follow the mode, and chains of banks (Crossover, the Equalizer's IIR mode) then run bank by bank instead of through their
  * fused launch; the meters' fused sums (LoudnessMeter / ILUFSMeter) keep the fast kernels.
- * mi_dspu_set_exact_iir_default: the mode banks created from now on start in (process-wide; how the class layer's
+ * mi_dspu_set_exact_iir_default (or MI_DSPU_EXACT_IIR=1 in the environment): the mode banks created from now on start in (process-wide; how the class layer's
  * dspu::Filter / FilterBank / Equalizer objects are put into the exact mode: set it before constructing them).
  */
 int mi_biquad_bank_set_exact(mi_biquad_bank_t *bank, int on);

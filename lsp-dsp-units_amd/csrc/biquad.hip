@@ -2021,7 +2021,9 @@ int mi_biquad_bank_create(mi_biquad_bank_t **bank, uint32_t channels, uint32_t m
     mi_biquad_bank *b = new (std::nothrow) mi_biquad_bank();
     MI_REQUIRE(b != nullptr, MI_ENOMEM, "mi_biquad_bank_create: out of host memory");
     b->channels = channels;
-    b->exact = g_exact_default.load() != 0;
+    // (MI_DSPU_EXACT_IIR=1: the same default for hosts that cannot be changed to call mi_dspu_set_exact_iir_default)
+    const char *const exact_env = getenv("MI_DSPU_EXACT_IIR");
+    b->exact = g_exact_default.load() != 0 || (exact_env != nullptr && atoi(exact_env) != 0);
     b->max_sec  = max_sections;
     const size_t cs = size_t(channels) * max_sections;
     try

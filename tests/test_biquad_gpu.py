@@ -876,3 +876,25 @@ def test_c1_readme_filter_in_the_exact_mode_by_default_switch(gpu):
     fast.process(buf, buf, 48000)
     assert not gpu.last_launch().startswith("(biquad_exact_kernel")
     fast.close()
+
+
+def test_exact_mode_by_the_environment_switch(gpu, monkeypatch):
+    """MI_DSPU_EXACT_IIR=1, read when a bank is created: a host that cannot be changed to call mi_dspu_set_exact_iir_default gets the
+    reference's bits; without the variable (or with 0) a bank is a fast one."""
+    gain = float(np.float32(np.exp(np.float32(6.0) * np.float32(np.log(10.0)) * np.float32(0.05))))
+    bq = wl.design(fd.FLT_BT_BWC_HISHELF, 2, 1000.0, 1000.0, gain, 0.0)
+    x = (np.random.default_rng(11).standard_normal((1, 8192)) * 0.25).astype(np.float32)
+    ref, _ = oracle.biquad_cascade(x[0], bq, None)
+    for value, exact in (("1", True), ("0", False), (None, False)):
+        if value is None:
+            monkeypatch.delenv("MI_DSPU_EXACT_IIR", raising=False)
+        else:
+            monkeypatch.setenv("MI_DSPU_EXACT_IIR", value)
+        bank = gpu.BiquadBank(1, 2)
+        bank.set_chains(0, bq)
+        out = gpu.DeviceBuffer((1, 8192))
+        bank.process(out, gpu.DeviceBuffer.from_host(x), 8192)
+        assert gpu.last_launch().startswith("(biquad_exact_kernel") == exact, (value, gpu.last_launch())
+        if exact:
+            np.testing.assert_array_equal(out.download()[0], ref)
+        bank.close()
