@@ -442,8 +442,9 @@ def test_process_reduce_equals_process_and_reduce_bins(gpu, rank, C):
         b.close()
 
 
-@pytest.mark.parametrize("rank,C,frames", [(12, 1024, 8), (12, 301, 19), (9, 40, 3), (13, 64, 2), (12, 64, 1)])
-def test_reductions_of_several_frames_in_one_launch(gpu, rank, C, frames):
+@pytest.mark.parametrize("rank,C,frames,pad", [(12, 1024, 8, 0), (12, 301, 19, 0), (9, 40, 3, 0), (13, 64, 2, 0), (12, 64, 1, 0),
+                                               (12, 70, 2, 0), (12, 33, 15, 1), (12, 20, 16, 0), (12, 18, 17, 3), (12, 24, 37, 0), (12, 260, 16, 1)])
+def test_reductions_of_several_frames_in_one_launch(gpu, rank, C, frames, pad):
     """mi_analyzer_bank_process_reduce_frames: the analyses of a run of frames keep their spectra in planes of their own and
     the per-bin reductions of up to 16 of them run as ONE launch -- against frame-by-frame process_reduce(): the same sums
     bit for bit, the same published spectrum afterwards (get_spectrum), and the same behaviour of whatever call follows; with a
@@ -479,11 +480,15 @@ def test_reductions_of_several_frames_in_one_launch(gpu, rank, C, frames):
             np.testing.assert_array_equal(got, want, err_msg=msg)
     for rnd in range(2):
         env = bool(rnd & 1)
-        xs = [(rng.standard_normal((C, period)) * 0.3).astype(np.float32) for _ in range(frames)]
+        # (pad: the blocks' rows `pad` floats apart from a multiple of four -- rows that are not 16-byte aligned take the launch's
+        # word-by-word requests)
+        xs = [(rng.standard_normal((C, period + pad)) * 0.3).astype(np.float32) for _ in range(frames)]
         dx = [gpu.DeviceBuffer.from_host(x) for x in xs]
         oa = gpu.DeviceBuffer((frames, bins))
-        banks[0].process_reduce_frames(dx, period, oa, with_envelope=env)
+        banks[0].process_reduce_frames(dx, period, oa, with_envelope=env, in_stride=period + pad)
         a = oa.download()
+        xs = [np.ascontiguousarray(x[:, :period]) for x in xs]
+        dx = [gpu.DeviceBuffer.from_host(x) for x in xs]
         for f in range(frames):
             ob = gpu.DeviceBuffer((bins,))
             banks[1].process_reduce(dx[f], period, ob, with_envelope=env)
